@@ -1,0 +1,198 @@
+#!/usr/bin/env python3
+"""bench.py -- classified queries/s of the raxtax hot path on N MI355X of one node.
+
+A "step" is one pass of the whole device path (kmer_extract -> hit_count -> prob_table ->
+taxon_prefix -> lineage_walk -> result rows on the host) over one batch of synthetic queries
+per GPU, with the queries and the index already resident in HBM when the timed region starts
+(BASELINE.json configs[1]: 100k COI-length queries vs a 50k-sequence reference database,
+replicated per GPU; queries are sharded, so scaling is weak: every rank classifies its own
+--queries).  With N > 1 the per-rank result records are gathered to rank 0 over RCCL inside the
+timed region (the only collective on the path).
+
+One JSON line on rank 0: metric/value (whole-job queries/s), ms_per_step, `roofline` of the
+dominant kernel (hit_count: algorithmic bytes 4*H_q + L_q per query, SURVEY.md 8d, over the
+kernel time measured with HIP events on the library's stream) and `cpu_baseline` (the CPU oracle,
+a C port of the reference algorithm, timed on this host's cores on a bounded sample).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6290 measured for a copy
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--refs", type=int, default=50_000, help="reference sequences (replicated per GPU)")
+    ap.add_argument("--queries", type=int, default=100_000, help="queries per GPU per step")
+    ap.add_argument("--sub-batch", type=int, default=0, help="queries per kernel wave (0 = auto)")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--skip-exact-matches", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(db, qs, target_s: float):
+    """Times the oracle (oracle/, kind "port") on this host's cores on a prefix of the queries."""
+    from oracle.oracle_py import Oracle
+
+    cores = os.cpu_count() or 1
+    orc = Oracle(native=True)
+    otree = orc.tree_new_flat(db.lineages, db.seq_bytes, db.seq_off)
+    L = db.length
+
+    def run(n):
+        t0 = time.perf_counter()
+        bad, _, _ = otree.classify_batch(qs.bases[: n * L], qs.base_off[: n + 1], threads=cores)
+        return time.perf_counter() - t0, bad
+
+    probe = min(qs.n, 4 * cores)
+    dt, _ = run(probe)
+    rate = probe / dt
+    n = int(min(qs.n, max(probe, rate * target_s)))
+    dt, bad = run(n)
+    return {"value": n / dt, "unit": "queries/s", "cores": cores, "kind": "port",
+            "sample": f"first {n} queries of the same workload, {cores} threads, {dt:.1f} s, "
+                      f"chunking as src/main.rs:119-124, no string formatting"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    import torch
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback for the device path)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+
+        dist = dist_mod
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import raxtax_amd as rx
+    from raxtax_amd import synth
+
+    # ---- inputs (untimed): identical database on every rank, rank-specific queries
+    db = synth.make_db(args.refs)
+    qs = synth.make_queries(db, args.queries, seed=3 + rank, first_label=rank * args.queries)
+    tree = rx.Tree.new_flat(db.lineages, db.seq_bytes, db.seq_off)
+    index = rx.Index(tree, device=local_rank, sub_batch=args.sub_batch)
+    ex_ids, ex_off = index.exact_matches(qs.bases, qs.base_off)   # Tree.sequences.get, raxtax.rs:42 (host)
+    index.upload(qs.bases, qs.base_off, ex_ids, ex_off)            # inputs resident in HBM from here on
+    flags = rx.RTX_SKIP_EXACT_MATCHES if args.skip_exact_matches else 0
+
+    def step():
+        index.run(flags)
+        view = index.download(copy=False)       # sync + D2H of the result records + host finalisation
+        if dist is not None:
+            # the only collective: gather the per-rank result records on rank 0 (RCCL over xGMI)
+            n_rows = int(view.n_rows)
+            conf = np.ctypeslib.as_array(view.row_conf, shape=(max(n_rows, 1), 32))[:, :8]
+            lin = np.ctypeslib.as_array(view.row_lineage, shape=(max(n_rows, 1),))
+            rec = np.concatenate([lin.astype(np.float64)[:, None], conf], axis=1)
+            sizes = torch.tensor([n_rows], device="cuda", dtype=torch.int64)
+            all_sizes = [torch.zeros_like(sizes) for _ in range(world)]
+            dist.all_gather(all_sizes, sizes)
+            cap = int(max(int(s.item()) for s in all_sizes))
+            buf = torch.zeros((cap, rec.shape[1]), device="cuda", dtype=torch.float64)
+            buf[:n_rows] = torch.from_numpy(rec[:n_rows]).cuda()
+            gathered = [torch.zeros_like(buf) for _ in range(world)] if rank == 0 else None
+            dist.gather(buf, gathered, dst=0)
+        return view
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    stage_ms = {s: 0.0 for s in rx._lib.STAGES}
+    stage_n = {s: 0 for s in rx._lib.STAGES}
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        for s, (ms, n) in index.stage_times().items():   # reads already-recorded HIP events
+            stage_ms[s] += ms
+            stage_n[s] += n
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    work = index.work()
+    view = index.download(copy=False)
+    ok = int((np.ctypeslib.as_array(view.status, shape=(args.queries,)) == 0).sum())
+    if rank == 0:
+        total_q = args.queries * world * args.steps
+        # roofline of the dominant kernel: algorithmic bytes (4 B per posting the reference would
+        # touch + the query bytes) per launch / mean launch duration (HIP events, library stream)
+        bytes_alg = 4 * work["sum_hits"] + work["sum_query_bytes"]     # one step, this rank
+        n_launch = max(stage_n["hit_count"], 1)
+        hit_ms = stage_ms["hit_count"] / n_launch
+        launches_per_step = n_launch / args.steps
+        achieved = (bytes_alg / launches_per_step) / (hit_ms * 1e-3) / 1e9
+        line = {
+            "metric": "classified queries/sec (whole node)",
+            "value": total_q / elapsed,
+            "unit": "queries/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u32 bit-planes + f64",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{args.queries} synthetic COI-length (658 bp) queries per GPU vs {args.refs}-seq "
+                            f"reference DB replicated in HBM (BASELINE.json configs[1])",
+                "refs": args.refs, "queries_per_gpu": args.queries, "query_len": db.length,
+                "model": "phylo (SURVEY.md 8d)", "parallelism": f"queries sharded x{world}, index replicated",
+                "classified_ok": ok, "skip_exact_matches": bool(args.skip_exact_matches),
+            },
+            "roofline": {
+                "bound": "hbm", "kernel": "hit_count_kernel",
+                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "algorithmic_bytes_per_query": bytes_alg / args.queries,
+                "bitmap_bytes_per_query": work["bitmap_bytes_read"] / args.queries,
+                "launch_ms": hit_ms, "launches_per_step": launches_per_step,
+            },
+            "stage_ms_per_step": {s: stage_ms[s] / args.steps for s in stage_ms},
+        }
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(db, qs, args.cpu_seconds)
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

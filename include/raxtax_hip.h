@@ -1,0 +1,236 @@
+/*
+ * raxtax_hip.h -- C ABI of libraxtax_hip.so, the MI355X (gfx950) drop-in for the
+ * per-query k-mer classification hot path of noahares/raxtax v1.5.0.
+ *
+ * The reference has no FFI or plugin interface: its seam is the Rust function
+ *     raxtax(queries, tree, skip_exact_matches, raw_confidence, chunk_size, sender, tsv)
+ * (src/raxtax.rs:14-22, called once from src/main.rs:137-145).  The entry points
+ * below are what a Rust `extern "C"` block for that seam binds (INTEGRATION.md
+ * shows the binding).  Plain pointers and sizes only; every function returns an
+ * int status (RTX_OK or a negative RTX_ERR_*); `rtx_last_error()` returns a
+ * message for the calling thread.  The caller owns every host buffer it passes
+ * in; the library owns all device memory and every buffer it hands out through
+ * a view (valid until the next call on the same handle, or its destruction).
+ * One handle per GPU; calls on one handle must be serialised by the caller;
+ * distinct handles may be driven from distinct host threads.
+ *
+ * There is NO CPU fallback: every rtx_index_* / rtx_batch_* / rtx_classify_*
+ * call fails with RTX_ERR_NO_DEVICE when no gfx950 device is usable.
+ *
+ * Sequences are passed as the reference stores them: one byte per base, 4-bit
+ * one-hot codes A=1 C=2 G=4 T=8, ambiguity codes = unions (src/parser.rs:11-34).
+ * Reference ids are indices into the lineage-sorted order of Tree::new
+ * (src/tree.rs:53-54), i.e. indices into `tree.lineages`.
+ */
+#ifndef RAXTAX_HIP_H
+#define RAXTAX_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RTX_ABI_VERSION 1
+#define RTX_NUM_KMERS 65536u /* 2 << 15 posting lists, src/tree.rs:52 */
+#define RTX_MAX_DEPTH 32u    /* deepest lineage (comma-separated levels) the device walk carries */
+
+/* status codes */
+#define RTX_OK 0
+#define RTX_ERR_INVALID (-1)    /* bad argument / malformed input arrays            */
+#define RTX_ERR_HIP (-2)        /* HIP runtime error (see rtx_last_error)           */
+#define RTX_ERR_NO_DEVICE (-3)  /* no usable gfx950 device                          */
+#define RTX_ERR_OOM (-4)        /* host or device allocation failed                 */
+#define RTX_ERR_PARSE (-5)      /* FASTA / lineage annotation error (parser.rs)     */
+#define RTX_ERR_DEPTH (-6)      /* lineage deeper than RTX_MAX_DEPTH                */
+#define RTX_ERR_STATE (-7)      /* call sequence violated (e.g. run before upload)  */
+#define RTX_ERR_TOO_LONG (-8)   /* a query has more than 65535 distinct k-mers (assert at raxtax.rs:56) */
+#define RTX_ERR_SENDER (-9)     /* the result sink refused a message (closed channel, raxtax.rs:87)    */
+
+/* flags of rtx_classify_batch / rtx_batch_run (src/io.rs:119-121,131-133) */
+#define RTX_SKIP_EXACT_MATCHES 1u /* zero the hit counts of exact matches, raxtax.rs:65-68 */
+#define RTX_RAW_CONFIDENCE 2u     /* host mirror only: suppress the single-exact-match override, raxtax.rs:73-84 */
+
+/* per-query status in rtx_result_view.status */
+#define RTX_Q_OK 0
+#define RTX_Q_NO_KMERS 1 /* t == 0, or t == 1 without a full-overlap reference: the reference
+                            panics here (prob.rs:21 u64 underflow / prob.rs:162 zip_eq); the
+                            library reports the query instead of aborting -- deliberate divergence */
+
+typedef struct rtx_tree rtx_tree;   /* host mirror of `Tree` (src/tree.rs:36-43)          */
+typedef struct rtx_index rtx_index; /* device-resident index + per-GPU batch workspace    */
+
+/* ------------------------------------------------------------------------- */
+/* diagnostics                                                                */
+/* ------------------------------------------------------------------------- */
+int rtx_abi_version(void);
+const char *rtx_last_error(void);
+int rtx_device_count(void); /* number of visible HIP devices, 0 if none / no driver */
+
+/* ------------------------------------------------------------------------- */
+/* Host mirror of the index build (plumbing around the hot path)             */
+/* ------------------------------------------------------------------------- */
+/* Tree::new(lineages, sequences), src/tree.rs:46-140.  Lineage i is the byte
+ * range lineage_bytes[lineage_off[i] .. lineage_off[i+1]) (no terminator);
+ * sequence i is seq_bytes[seq_off[i] .. seq_off[i+1]). */
+int rtx_tree_build(uint64_t n, const char *lineage_bytes, const uint64_t *lineage_off,
+                   const uint8_t *seq_bytes, const uint64_t *seq_off, rtx_tree **out);
+/* parse_reference_fasta_str, src/parser.rs:46-105 */
+int rtx_tree_parse_reference_fasta(const char *text, uint64_t len, rtx_tree **out);
+void rtx_tree_destroy(rtx_tree *tree);
+uint64_t rtx_tree_num_tips(const rtx_tree *tree);                  /* Tree.num_tips      */
+const char *rtx_tree_lineage(const rtx_tree *tree, uint64_t i);    /* Tree.lineages[i]   */
+uint64_t rtx_tree_original_index(const rtx_tree *tree, uint64_t i);/* sorted -> input idx */
+/* Tree.k_mer_map as CSR: offsets[65537], postings sorted-unique per list (tree.rs:134-137) */
+int rtx_tree_kmer_csr(const rtx_tree *tree, const uint64_t **offsets, const uint32_t **postings);
+/* Tree.sequences.get(seq), src/raxtax.rs:42.  Returns the number of ids. */
+uint64_t rtx_tree_exact_matches(const rtx_tree *tree, const uint8_t *seq, uint64_t len,
+                                const uint32_t **ids);
+/* The same lookup for a batch: fills exact_off[n_queries+1] and up to ids_cap ids; returns the
+ * total number of ids (call again with a larger buffer if it exceeds ids_cap). */
+uint64_t rtx_tree_exact_matches_batch(const rtx_tree *tree, uint64_t n_queries, const uint8_t *bases,
+                                      const uint64_t *base_off, uint64_t *exact_off, uint32_t *exact_ids,
+                                      uint64_t ids_cap);
+/* Flattened taxonomy: nodes in breadth-first order (root = node 0, the children of a node
+ * are consecutive), childless Sequence nodes (tree.rs:102-107) dropped -- they never
+ * influence Lineage::evaluate.  node_begin/end = Node.confidence_range (tree.rs:190). */
+typedef struct {
+    uint32_t n_nodes;
+    const uint32_t *node_begin;
+    const uint32_t *node_end;
+    const uint32_t *node_first_child;
+    const uint32_t *node_n_children;
+    const uint32_t *node_parent; /* 0xFFFFFFFF for the root */
+    const uint8_t *node_type;    /* 0 Inner, 1 Taxon, 2 Sequence (tree.rs:181-186) */
+} rtx_nodes_view;
+int rtx_tree_nodes(const rtx_tree *tree, rtx_nodes_view *out);
+
+/* parse_query_fasta_str, src/parser.rs:117-154.  Returns a handle holding labels and
+ * encoded sequences; `skip` labels (already-processed queries, parser.rs:150-153) are dropped. */
+typedef struct rtx_queries rtx_queries;
+int rtx_queries_parse_fasta(const char *text, uint64_t len, const char *const *skip, uint64_t n_skip,
+                            rtx_queries **out);
+void rtx_queries_destroy(rtx_queries *q);
+uint64_t rtx_queries_len(const rtx_queries *q);
+const char *rtx_queries_label(const rtx_queries *q, uint64_t i);
+/* all sequences concatenated + n+1 offsets (the layout rtx_classify_batch takes) */
+int rtx_queries_data(const rtx_queries *q, const uint8_t **bases, const uint64_t **base_off);
+
+/* ------------------------------------------------------------------------- */
+/* Device index (replaces the read-only `&Tree` argument of raxtax())        */
+/* ------------------------------------------------------------------------- */
+/* Uploads Tree.k_mer_map (CSR, lists sorted-unique) and the flattened taxonomy
+ * (as rtx_nodes_view) to GPU `device`; the library re-encodes the postings into
+ * its own HBM layout (per-k-mer reference bitmaps).  n_refs = Tree.num_tips. */
+int rtx_index_create(int device, uint64_t n_refs, const uint64_t *offsets /*65537*/,
+                     const uint32_t *postings, uint32_t n_nodes, const uint32_t *node_begin,
+                     const uint32_t *node_end, const uint32_t *node_first_child,
+                     const uint32_t *node_n_children, const uint8_t *node_type, rtx_index **out);
+/* Convenience: the same from a host tree. */
+int rtx_index_create_from_tree(int device, const rtx_tree *tree, rtx_index **out);
+void rtx_index_destroy(rtx_index *index);
+uint64_t rtx_index_num_refs(const rtx_index *index);
+uint64_t rtx_index_device_bytes(const rtx_index *index); /* HBM held by the index itself */
+/* queries processed per kernel wave (sub-batch); 0 = choose from free HBM */
+int rtx_index_set_batch(rtx_index *index, uint32_t sub_batch);
+
+/* ------------------------------------------------------------------------- */
+/* Classification: the body of raxtax(), src/raxtax.rs:39-84, minus string    */
+/* formatting (host mirror) and the exact-match lookup (caller passes ids).   */
+/* ------------------------------------------------------------------------- */
+/* One result row = one EvaluationResult (src/lineage.rs:8-14) before the
+ * single-exact-match override of raxtax.rs:73-84 (applied by the caller /
+ * host mirror, since it needs `raw_confidence` and the lineage strings). */
+typedef struct {
+    uint32_t n_queries;
+    uint64_t n_rows;
+    const uint32_t *t;             /* [n_queries] distinct valid 8-mers (k_mers.len(), raxtax.rs:55) */
+    const uint8_t *status;         /* [n_queries] RTX_Q_*                                            */
+    const double *global_signal;   /* [n_queries] lineage.rs:86-90                                   */
+    const uint64_t *row_off;       /* [n_queries+1] rows of query q = row_off[q] .. row_off[q+1]     */
+    const uint32_t *row_lineage;   /* [n_rows] index into tree.lineages (lineage.rs:105)             */
+    const uint32_t *row_node;      /* [n_rows] node id (rtx_nodes_view numbering)                    */
+    const uint32_t *row_depth;     /* [n_rows] number of confidence values                           */
+    const double *row_conf;        /* [n_rows][RTX_MAX_DEPTH] confidence_values, rounded to 2 decimals */
+    const double *row_local_signal;/* [n_rows] lineage.rs:95-102                                     */
+} rtx_result_view;
+
+/* Whole path for one batch of queries: H2D, kernels, D2H, host finalisation (sort
+ * lineage.rs:91-93 + local signal).  exact_ids/exact_off: the ids Tree.sequences.get()
+ * returned per query (raxtax.rs:42); may be NULL when no query has an exact match. */
+int rtx_classify_batch(rtx_index *index, uint64_t n_queries, const uint8_t *bases,
+                       const uint64_t *base_off, const uint32_t *exact_ids,
+                       const uint64_t *exact_off, uint32_t flags, rtx_result_view *out);
+
+/* The same in stages, so that a caller (bench.py) can keep inputs resident in HBM and
+ * time the device part alone, or overlap stages of different batches. */
+int rtx_batch_upload(rtx_index *index, uint64_t n_queries, const uint8_t *bases,
+                     const uint64_t *base_off, const uint32_t *exact_ids,
+                     const uint64_t *exact_off);
+int rtx_batch_run(rtx_index *index, uint32_t flags); /* enqueue all kernels (async)        */
+int rtx_batch_sync(rtx_index *index);                /* wait for the handle's stream        */
+int rtx_batch_download(rtx_index *index, rtx_result_view *out);
+
+/* Per-kernel device time of the last rtx_batch_run, from HIP events on the library's
+ * stream (ms, summed over sub-batches), and launch counts.  Stage order: */
+#define RTX_STAGE_KMER_EXTRACT 0
+#define RTX_STAGE_HIT_COUNT 1
+#define RTX_STAGE_PROB_TABLE 2
+#define RTX_STAGE_TAXON_PREFIX 3
+#define RTX_STAGE_LINEAGE_WALK 4
+#define RTX_NUM_STAGES 5
+int rtx_batch_stage_times(rtx_index *index, float ms[RTX_NUM_STAGES], uint32_t launches[RTX_NUM_STAGES]);
+/* Algorithmic work of the last rtx_batch_run: sum over queries of
+ * H_q = sum_r count_q[r] (postings touched) and of L_q (query bytes), and the bitmap
+ * bytes the hit_count kernel actually requested. */
+int rtx_batch_work(rtx_index *index, uint64_t *sum_hits, uint64_t *sum_query_bytes,
+                   uint64_t *bitmap_bytes_read);
+
+/* ------------------------------------------------------------------------- */
+/* Parity / debug taps (full vectors; not used on the fast path)              */
+/* ------------------------------------------------------------------------- */
+/* Valid after rtx_batch_run + rtx_batch_sync for queries of the LAST sub-batch only when
+ * the batch spans several sub-batches; tests keep n_queries <= sub-batch.  */
+int rtx_debug_kmers(rtx_index *index, uint64_t query, uint16_t *kmers /*cap 65535*/, uint32_t *t);
+int rtx_debug_hit_counts(rtx_index *index, uint64_t query, uint16_t *counts /*n_refs*/);
+int rtx_debug_prob_table(rtx_index *index, uint64_t query, double *table_over_z /*t+1*/, double *z);
+int rtx_debug_probs(rtx_index *index, uint64_t query, double *probs /*n_refs*/);
+/* Lineage::new(label, tree, probs).evaluate() (src/lineage.rs:61-112) on a caller-supplied
+ * probability vector: runs taxon_prefix + lineage_walk + the host finalisation for one
+ * pseudo-query.  Lets the reference's lineage KATs pin the device walk.  Small trees only
+ * (n_refs up to a few thousand: the workspace is sized as for a query with n_refs k-mers). */
+int rtx_debug_evaluate(rtx_index *index, const double *probs /*n_refs*/, rtx_result_view *out);
+
+/* ------------------------------------------------------------------------- */
+/* Host mirror of the output formatting (src/lineage.rs:17-48, utils.rs:62-89) */
+/* ------------------------------------------------------------------------- */
+/* Applies the single-exact-match override (raxtax.rs:73-84, unless RTX_RAW_CONFIDENCE or
+ * RTX_SKIP_EXACT_MATCHES is set in flags) and formats the `.out` (and, if tsv_buf != NULL,
+ * `.tsv`) lines of query q of a result view.  Returns bytes written (excluding NUL) or a
+ * negative RTX_ERR_*; lines of one query are '\n'-joined without a trailing newline. */
+int64_t rtx_format_query(const rtx_tree *tree, const rtx_result_view *res, uint64_t q,
+                         const char *label, const uint8_t *seq, uint64_t seq_len,
+                         const uint32_t *exact_ids, uint64_t n_exact, uint32_t flags, char *out_buf,
+                         uint64_t out_cap, char *tsv_buf, uint64_t tsv_cap, int64_t *tsv_len);
+
+/* ------------------------------------------------------------------------- */
+/* Host mirror of raxtax() itself (src/raxtax.rs:14-97)                       */
+/* ------------------------------------------------------------------------- */
+/* Receives one message per query, in input order: the `(label, out_lines, tsv_lines?)`
+ * triple the reference sends on its crossbeam channel (raxtax.rs:85-87).  A non-zero
+ * return plays the role of a closed channel: rtx_raxtax stops with RTX_ERR_SENDER. */
+typedef int (*rtx_sender_fn)(void *ctx, const char *label, const char *out_lines, const char *tsv_lines);
+/* Same arguments, in the same order and with the same meaning as the reference function,
+ * plus the device index that replaces the CPU traversal of `tree`.  chunk_size = queries
+ * per device batch (0 = all at once; the reference's rayon chunking has no other effect).
+ * Exact-match lookups (raxtax.rs:42), the lineage-consistency warning (raxtax.rs:43-53,
+ * written to stderr) and the override (raxtax.rs:73-84) run on the host. */
+int rtx_raxtax(rtx_index *index, const rtx_tree *tree, uint64_t n_queries, const char *const *labels,
+               const uint8_t *bases, const uint64_t *base_off, int skip_exact_matches, int raw_confidence,
+               uint64_t chunk_size, rtx_sender_fn sender, void *sender_ctx, int tsv);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RAXTAX_HIP_H */

@@ -1,0 +1,64 @@
+"""Builds raxtax_amd/libraxtax_hip.so in-tree with hipcc for gfx950 (MI355X).
+
+hipcc cross-compiles without a GPU; the built .so is git-ignored but travels with the
+repository snapshot to the GPU box.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+from pathlib import Path
+
+PKG = Path(__file__).resolve().parent
+ROOT = PKG.parent
+CSRC = PKG / "csrc"
+LIB = PKG / "libraxtax_hip.so"
+SOURCES = ["rtx_kernels.hip", "rtx_api.hip", "host_tree.cpp", "host_format.cpp", "host_raxtax.cpp"]
+HEADERS = ["rtx_kernels.hpp", "rtx_internal.hpp", "rtx_math.hpp", "host_raxtax.hpp"]
+CLI = PKG / "raxtax-hip"
+
+
+def _hipcc() -> str:
+    for c in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if c and Path(c).exists():
+            return c
+    raise RuntimeError("hipcc not found (ROCm toolchain required to build libraxtax_hip.so)")
+
+
+def _stale(target: Path, deps) -> bool:
+    if not target.exists():
+        return True
+    t = target.stat().st_mtime
+    return any(Path(d).stat().st_mtime > t for d in deps if Path(d).exists())
+
+
+def build_lib(force: bool = False, verbose: bool = False) -> Path:
+    srcs = [CSRC / s for s in SOURCES if (CSRC / s).exists()]
+    deps = srcs + [CSRC / h for h in HEADERS] + [ROOT / "include" / "raxtax_hip.h"]
+    if not force and not _stale(LIB, deps):
+        return LIB
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+           f"-I{ROOT / 'include'}", f"-I{CSRC}", "-o", str(LIB)] + [str(s) for s in srcs] + ["-lpthread"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB
+
+
+def build_cli(force: bool = False) -> Path | None:
+    main = CSRC / "cli_main.cpp"
+    if not main.exists():
+        return None
+    build_lib(force=force)
+    if not force and not _stale(CLI, [main, LIB]):
+        return CLI
+    cmd = [_hipcc(), "-O2", "-std=c++17", f"-I{ROOT / 'include'}", f"-I{CSRC}", "-o", str(CLI), str(main),
+           f"-L{PKG}", "-lraxtax_hip", f"-Wl,-rpath,{PKG}", "-Wl,-rpath,$ORIGIN", "-lpthread"]
+    subprocess.check_call(cmd)
+    return CLI
+
+
+if __name__ == "__main__":
+    print(build_lib(force=True, verbose=True))
+    print(build_cli(force=True))

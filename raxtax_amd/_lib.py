@@ -1,0 +1,124 @@
+"""ctypes binding of include/raxtax_hip.h.  Fails loudly when libraxtax_hip.so is missing:
+there is no Python or CPU fallback for the device path."""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+import numpy as np
+
+PKG = Path(__file__).resolve().parent
+LIB_PATH = PKG / "libraxtax_hip.so"
+
+RTX_MAX_DEPTH = 32
+RTX_NUM_KMERS = 65536
+RTX_OK = 0
+RTX_ERR_INVALID, RTX_ERR_HIP, RTX_ERR_NO_DEVICE, RTX_ERR_OOM = -1, -2, -3, -4
+RTX_ERR_PARSE, RTX_ERR_DEPTH, RTX_ERR_STATE, RTX_ERR_TOO_LONG = -5, -6, -7, -8
+RTX_SKIP_EXACT_MATCHES = 1
+RTX_RAW_CONFIDENCE = 2
+RTX_Q_OK, RTX_Q_NO_KMERS = 0, 1
+STAGES = ("kmer_extract", "hit_count", "prob_table", "taxon_prefix", "lineage_walk")
+
+u8p = C.POINTER(C.c_uint8)
+u16p = C.POINTER(C.c_uint16)
+u32p = C.POINTER(C.c_uint32)
+u64p = C.POINTER(C.c_uint64)
+f64p = C.POINTER(C.c_double)
+f32p = C.POINTER(C.c_float)
+
+
+class NodesView(C.Structure):
+    _fields_ = [("n_nodes", C.c_uint32), ("node_begin", u32p), ("node_end", u32p), ("node_first_child", u32p),
+                ("node_n_children", u32p), ("node_parent", u32p), ("node_type", u8p)]
+
+
+class ResultView(C.Structure):
+    _fields_ = [("n_queries", C.c_uint32), ("n_rows", C.c_uint64), ("t", u32p), ("status", u8p),
+                ("global_signal", f64p), ("row_off", u64p), ("row_lineage", u32p), ("row_node", u32p),
+                ("row_depth", u32p), ("row_conf", f64p), ("row_local_signal", f64p)]
+
+
+class RtxError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"libraxtax_hip error {code}: {msg}")
+        self.code = code
+
+
+# every symbol include/raxtax_hip.h declares (tests/test_abi_symbols.py checks the export list)
+_SIGNATURES = {
+    "rtx_abi_version": (C.c_int, []),
+    "rtx_last_error": (C.c_char_p, []),
+    "rtx_device_count": (C.c_int, []),
+    "rtx_tree_build": (C.c_int, [C.c_uint64, C.c_char_p, u64p, u8p, u64p, C.POINTER(C.c_void_p)]),
+    "rtx_tree_parse_reference_fasta": (C.c_int, [C.c_char_p, C.c_uint64, C.POINTER(C.c_void_p)]),
+    "rtx_tree_destroy": (None, [C.c_void_p]),
+    "rtx_tree_num_tips": (C.c_uint64, [C.c_void_p]),
+    "rtx_tree_lineage": (C.c_char_p, [C.c_void_p, C.c_uint64]),
+    "rtx_tree_original_index": (C.c_uint64, [C.c_void_p, C.c_uint64]),
+    "rtx_tree_kmer_csr": (C.c_int, [C.c_void_p, C.POINTER(u64p), C.POINTER(u32p)]),
+    "rtx_tree_exact_matches": (C.c_uint64, [C.c_void_p, u8p, C.c_uint64, C.POINTER(u32p)]),
+    "rtx_tree_exact_matches_batch": (C.c_uint64, [C.c_void_p, C.c_uint64, u8p, u64p, u64p, u32p, C.c_uint64]),
+    "rtx_tree_nodes": (C.c_int, [C.c_void_p, C.POINTER(NodesView)]),
+    "rtx_queries_parse_fasta": (C.c_int, [C.c_char_p, C.c_uint64, C.POINTER(C.c_char_p), C.c_uint64,
+                                          C.POINTER(C.c_void_p)]),
+    "rtx_queries_destroy": (None, [C.c_void_p]),
+    "rtx_queries_len": (C.c_uint64, [C.c_void_p]),
+    "rtx_queries_label": (C.c_char_p, [C.c_void_p, C.c_uint64]),
+    "rtx_queries_data": (C.c_int, [C.c_void_p, C.POINTER(u8p), C.POINTER(u64p)]),
+    "rtx_index_create": (C.c_int, [C.c_int, C.c_uint64, u64p, u32p, C.c_uint32, u32p, u32p, u32p, u32p, u8p,
+                                   C.POINTER(C.c_void_p)]),
+    "rtx_index_create_from_tree": (C.c_int, [C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "rtx_index_destroy": (None, [C.c_void_p]),
+    "rtx_index_num_refs": (C.c_uint64, [C.c_void_p]),
+    "rtx_index_device_bytes": (C.c_uint64, [C.c_void_p]),
+    "rtx_index_set_batch": (C.c_int, [C.c_void_p, C.c_uint32]),
+    "rtx_classify_batch": (C.c_int, [C.c_void_p, C.c_uint64, u8p, u64p, u32p, u64p, C.c_uint32,
+                                     C.POINTER(ResultView)]),
+    "rtx_batch_upload": (C.c_int, [C.c_void_p, C.c_uint64, u8p, u64p, u32p, u64p]),
+    "rtx_batch_run": (C.c_int, [C.c_void_p, C.c_uint32]),
+    "rtx_batch_sync": (C.c_int, [C.c_void_p]),
+    "rtx_batch_download": (C.c_int, [C.c_void_p, C.POINTER(ResultView)]),
+    "rtx_batch_stage_times": (C.c_int, [C.c_void_p, f32p, u32p]),
+    "rtx_batch_work": (C.c_int, [C.c_void_p, u64p, u64p, u64p]),
+    "rtx_debug_kmers": (C.c_int, [C.c_void_p, C.c_uint64, u16p, u32p]),
+    "rtx_debug_hit_counts": (C.c_int, [C.c_void_p, C.c_uint64, u16p]),
+    "rtx_debug_prob_table": (C.c_int, [C.c_void_p, C.c_uint64, f64p, f64p]),
+    "rtx_debug_probs": (C.c_int, [C.c_void_p, C.c_uint64, f64p]),
+    "rtx_debug_evaluate": (C.c_int, [C.c_void_p, f64p, C.POINTER(ResultView)]),
+    "rtx_format_query": (C.c_int64, [C.c_void_p, C.POINTER(ResultView), C.c_uint64, C.c_char_p, u8p, C.c_uint64,
+                                     u32p, C.c_uint64, C.c_uint32, C.c_char_p, C.c_uint64, C.c_char_p, C.c_uint64,
+                                     C.POINTER(C.c_int64)]),
+    "rtx_raxtax": (C.c_int, None),  # argtypes set in api.py (callback type)
+}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Loads libraxtax_hip.so (built by raxtax_amd._build.build_lib / __graft_entry__.build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -m raxtax_amd._build` (hipcc, gfx950). "
+            "raxtax_amd has no CPU fallback.")
+    lib = C.CDLL(str(LIB_PATH))
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the ABI is incomplete
+        fn.restype = res
+        if args is not None:
+            fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(code: int):
+    if code < 0:
+        raise RtxError(code, load().rtx_last_error().decode(errors="replace"))
+    return code
+
+
+def ptr(a: np.ndarray, typ):
+    return a.ctypes.data_as(typ)

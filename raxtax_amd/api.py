@@ -1,0 +1,338 @@
+"""Python face of libraxtax_hip.so, mirroring the reference's interface for the hot path
+(same names, argument meaning and error behaviour):
+
+    Tree.new(lineages, sequences)            src/tree.rs:46-140   (host mirror)
+    parse_reference_fasta_str(text) -> Tree  src/parser.rs:46-105
+    parse_query_fasta_str(text, skip)        src/parser.rs:117-154
+    raxtax(queries, tree, skip_exact_matches, raw_confidence, chunk_size, sender, tsv)
+                                             src/raxtax.rs:14-97  (device path)
+    Index(tree).classify(...)                the body of raxtax() without string formatting
+
+Everything device-side goes through the C ABI (include/raxtax_hip.h).  No fallbacks.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Callable, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _lib
+from ._lib import (RTX_MAX_DEPTH, RTX_RAW_CONFIDENCE, RTX_SKIP_EXACT_MATCHES, NodesView, ResultView, RtxError, check,
+                   f32p, f64p, ptr, u8p, u16p, u32p, u64p)
+
+
+def _flatten(seqs: Sequence[np.ndarray]) -> Tuple[np.ndarray, np.ndarray]:
+    off = np.zeros(len(seqs) + 1, dtype=np.uint64)
+    if len(seqs):
+        off[1:] = np.cumsum([len(s) for s in seqs], dtype=np.uint64)
+    flat = np.zeros(max(int(off[-1]), 1), dtype=np.uint8)
+    for i, s in enumerate(seqs):
+        flat[int(off[i]):int(off[i + 1])] = np.asarray(s, dtype=np.uint8)
+    return flat, off
+
+
+class Tree:
+    """Host mirror of `Tree` (src/tree.rs:36-43)."""
+
+    def __init__(self, handle: int):
+        self._h = C.c_void_p(handle)
+        self._lib = _lib.load()
+
+    def __del__(self):
+        try:
+            if self._h:
+                self._lib.rtx_tree_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    @classmethod
+    def new(cls, lineages: Sequence[str], sequences: Sequence[np.ndarray]) -> "Tree":
+        flat, off = _flatten(sequences)
+        return cls.new_flat(lineages, flat, off)
+
+    @classmethod
+    def new_flat(cls, lineages: Sequence[str], seq_bytes: np.ndarray, seq_off: np.ndarray) -> "Tree":
+        lib = _lib.load()
+        enc = [l.encode() for l in lineages]
+        loff = np.zeros(len(enc) + 1, dtype=np.uint64)
+        if enc:
+            loff[1:] = np.cumsum([len(e) for e in enc], dtype=np.uint64)
+        lbytes = b"".join(enc)
+        seq_bytes = np.ascontiguousarray(seq_bytes, dtype=np.uint8)
+        seq_off = np.ascontiguousarray(seq_off, dtype=np.uint64)
+        h = C.c_void_p()
+        check(lib.rtx_tree_build(len(enc), lbytes, ptr(loff, u64p), ptr(seq_bytes, u8p), ptr(seq_off, u64p),
+                                 C.byref(h)))
+        return cls(h.value)
+
+    @property
+    def num_tips(self) -> int:
+        return self._lib.rtx_tree_num_tips(self._h)
+
+    def lineage(self, i: int) -> str:
+        return self._lib.rtx_tree_lineage(self._h, i).decode()
+
+    @property
+    def lineages(self) -> List[str]:
+        return [self.lineage(i) for i in range(self.num_tips)]
+
+    def original_index(self) -> np.ndarray:
+        return np.array([self._lib.rtx_tree_original_index(self._h, i) for i in range(self.num_tips)], np.uint64)
+
+    def csr(self) -> Tuple[np.ndarray, np.ndarray]:
+        """Tree.k_mer_map as (offsets[65537], postings) -- views copied out of the handle."""
+        po, pp = u64p(), u32p()
+        check(self._lib.rtx_tree_kmer_csr(self._h, C.byref(po), C.byref(pp)))
+        off = np.ctypeslib.as_array(po, shape=(65537,)).copy()
+        tot = int(off[-1])
+        post = np.ctypeslib.as_array(pp, shape=(tot,)).copy() if tot else np.zeros(0, np.uint32)
+        return off, post
+
+    def k_mer_map(self, kmer: int) -> np.ndarray:
+        off, post = self.csr()
+        return post[int(off[kmer]):int(off[kmer + 1])]
+
+    def exact_matches(self, seq: np.ndarray) -> np.ndarray:
+        seq = np.ascontiguousarray(seq, dtype=np.uint8)
+        p = u32p()
+        n = self._lib.rtx_tree_exact_matches(self._h, ptr(seq, u8p), len(seq), C.byref(p))
+        return np.ctypeslib.as_array(p, shape=(n,)).copy() if n else np.zeros(0, np.uint32)
+
+    def exact_matches_batch(self, bases: np.ndarray, base_off: np.ndarray):
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        base_off = np.ascontiguousarray(base_off, dtype=np.uint64)
+        n_q = len(base_off) - 1
+        off = np.zeros(n_q + 1, dtype=np.uint64)
+        ids = np.zeros(max(n_q, 16), dtype=np.uint32)
+        tot = self._lib.rtx_tree_exact_matches_batch(self._h, n_q, ptr(bases, u8p), ptr(base_off, u64p), ptr(off, u64p),
+                                                     ptr(ids, u32p), len(ids))
+        if tot > len(ids):
+            ids = np.zeros(tot, dtype=np.uint32)
+            self._lib.rtx_tree_exact_matches_batch(self._h, n_q, ptr(bases, u8p), ptr(base_off, u64p), ptr(off, u64p),
+                                                   ptr(ids, u32p), len(ids))
+        return ids[:tot].copy(), off
+
+    def nodes(self) -> dict:
+        v = NodesView()
+        check(self._lib.rtx_tree_nodes(self._h, C.byref(v)))
+        n = v.n_nodes
+        g = lambda p: np.ctypeslib.as_array(p, shape=(n,)).copy()
+        return dict(begin=g(v.node_begin), end=g(v.node_end), first_child=g(v.node_first_child),
+                    n_children=g(v.node_n_children), parent=g(v.node_parent), type=g(v.node_type))
+
+
+def parse_reference_fasta_str(text: str) -> Tree:
+    lib = _lib.load()
+    b = text.encode()
+    h = C.c_void_p()
+    check(lib.rtx_tree_parse_reference_fasta(b, len(b), C.byref(h)))
+    return Tree(h.value)
+
+
+def parse_query_fasta_str(text: str, queries_to_skip: Sequence[str] = ()) -> List[Tuple[str, np.ndarray]]:
+    lib = _lib.load()
+    b = text.encode()
+    skip = (C.c_char_p * max(len(queries_to_skip), 1))(*[s.encode() for s in queries_to_skip])
+    h = C.c_void_p()
+    check(lib.rtx_queries_parse_fasta(b, len(b), skip, len(queries_to_skip), C.byref(h)))
+    try:
+        n = lib.rtx_queries_len(h)
+        pb, po = u8p(), u64p()
+        check(lib.rtx_queries_data(h, C.byref(pb), C.byref(po)))
+        off = np.ctypeslib.as_array(po, shape=(n + 1,)).copy()
+        tot = int(off[-1])
+        bases = np.ctypeslib.as_array(pb, shape=(tot,)).copy() if tot else np.zeros(0, np.uint8)
+        return [(lib.rtx_queries_label(h, i).decode(), bases[int(off[i]):int(off[i + 1])].copy()) for i in range(n)]
+    finally:
+        lib.rtx_queries_destroy(h)
+
+
+@dataclass
+class EvaluationResult:
+    """src/lineage.rs:8-14 (lineage given as index into tree.lineages)."""
+    lineage: int
+    node: int
+    confidence_values: List[float]
+    local_signal: float
+    global_signal: float
+
+
+class Result:
+    """Arrays of one classified batch (copied out of the library-owned rtx_result_view)."""
+
+    def __init__(self, view: ResultView):
+        nq, nr = view.n_queries, view.n_rows
+        arr = lambda p, n: (np.ctypeslib.as_array(p, shape=(n,)).copy() if n else np.zeros(0))
+        self.n_queries = nq
+        self.t = arr(view.t, nq)
+        self.status = arr(view.status, nq)
+        self.global_signal = arr(view.global_signal, nq)
+        self.row_off = arr(view.row_off, nq + 1)
+        self.row_lineage = arr(view.row_lineage, nr)
+        self.row_node = arr(view.row_node, nr)
+        self.row_depth = arr(view.row_depth, nr)
+        self.row_conf = (np.ctypeslib.as_array(view.row_conf, shape=(nr, RTX_MAX_DEPTH)).copy() if nr
+                         else np.zeros((0, RTX_MAX_DEPTH)))
+        self.row_local_signal = arr(view.row_local_signal, nr)
+
+    def rows(self, q: int) -> List[EvaluationResult]:
+        out = []
+        for r in range(int(self.row_off[q]), int(self.row_off[q + 1])):
+            d = int(self.row_depth[r])
+            out.append(EvaluationResult(int(self.row_lineage[r]), int(self.row_node[r]),
+                                        [float(x) for x in self.row_conf[r, :d]],
+                                        float(self.row_local_signal[r]), float(self.global_signal[q])))
+        return out
+
+
+class Index:
+    """Device-resident index + batch workspace of one GPU (rtx_index)."""
+
+    def __init__(self, tree: Tree, device: int = 0, sub_batch: int = 0):
+        self._lib = _lib.load()
+        self.tree = tree
+        h = C.c_void_p()
+        check(self._lib.rtx_index_create_from_tree(device, tree._h, C.byref(h)))
+        self._h = h
+        self.n_refs = self._lib.rtx_index_num_refs(self._h)
+        if sub_batch:
+            check(self._lib.rtx_index_set_batch(self._h, sub_batch))
+        self._view = ResultView()
+        self._keep = None
+
+    def __del__(self):
+        try:
+            if self._h:
+                self._lib.rtx_index_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    @property
+    def device_bytes(self) -> int:
+        return self._lib.rtx_index_device_bytes(self._h)
+
+    # ---- staged interface -------------------------------------------------------------
+    def upload(self, bases: np.ndarray, base_off: np.ndarray, exact_ids: Optional[np.ndarray] = None,
+               exact_off: Optional[np.ndarray] = None):
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        base_off = np.ascontiguousarray(base_off, dtype=np.uint64)
+        n_q = len(base_off) - 1
+        if exact_off is not None:
+            exact_off = np.ascontiguousarray(exact_off, dtype=np.uint64)
+            exact_ids = np.ascontiguousarray(exact_ids if exact_ids is not None and len(exact_ids) else
+                                             np.zeros(1, np.uint32), dtype=np.uint32)
+            check(self._lib.rtx_batch_upload(self._h, n_q, ptr(bases, u8p), ptr(base_off, u64p), ptr(exact_ids, u32p),
+                                             ptr(exact_off, u64p)))
+        else:
+            check(self._lib.rtx_batch_upload(self._h, n_q, ptr(bases, u8p), ptr(base_off, u64p), None, None))
+        self._keep = (bases, base_off, exact_ids, exact_off)
+
+    def run(self, flags: int = 0):
+        check(self._lib.rtx_batch_run(self._h, flags))
+
+    def sync(self):
+        check(self._lib.rtx_batch_sync(self._h))
+
+    def download(self, copy: bool = True):
+        check(self._lib.rtx_batch_download(self._h, C.byref(self._view)))
+        return Result(self._view) if copy else self._view
+
+    def stage_times(self):
+        ms = (C.c_float * 5)()
+        n = (C.c_uint32 * 5)()
+        check(self._lib.rtx_batch_stage_times(self._h, ms, n))
+        return {s: (float(ms[i]), int(n[i])) for i, s in enumerate(_lib.STAGES)}
+
+    def work(self):
+        a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        check(self._lib.rtx_batch_work(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return dict(sum_hits=a.value, sum_query_bytes=b.value, bitmap_bytes_read=c.value)
+
+    # ---- one call -----------------------------------------------------------------------
+    def exact_matches(self, bases: np.ndarray, base_off: np.ndarray):
+        """Tree.sequences.get() for every query (raxtax.rs:42) -> (ids, offsets)."""
+        return self.tree.exact_matches_batch(bases, base_off)
+
+    def classify(self, bases: np.ndarray, base_off: np.ndarray, exact_ids=None, exact_off=None,
+                 skip_exact_matches: bool = False) -> Result:
+        self.upload(bases, base_off, exact_ids, exact_off)
+        self.run(RTX_SKIP_EXACT_MATCHES if skip_exact_matches else 0)
+        return self.download()
+
+    # ---- parity taps ----------------------------------------------------------------------
+    def debug_kmers(self, q: int) -> np.ndarray:
+        out = np.zeros(65536, dtype=np.uint16)
+        t = C.c_uint32()
+        check(self._lib.rtx_debug_kmers(self._h, q, ptr(out, u16p), C.byref(t)))
+        return out[:t.value].copy()
+
+    def debug_hit_counts(self, q: int) -> np.ndarray:
+        out = np.zeros(self.n_refs, dtype=np.uint16)
+        check(self._lib.rtx_debug_hit_counts(self._h, q, ptr(out, u16p)))
+        return out
+
+    def debug_prob_table(self, q: int, t: int):
+        out = np.zeros(t + 1, dtype=np.float64)
+        z = C.c_double()
+        check(self._lib.rtx_debug_prob_table(self._h, q, ptr(out, f64p), C.byref(z)))
+        return out, z.value
+
+    def debug_probs(self, q: int) -> np.ndarray:
+        out = np.zeros(self.n_refs, dtype=np.float64)
+        check(self._lib.rtx_debug_probs(self._h, q, ptr(out, f64p)))
+        return out
+
+    def debug_evaluate(self, probs) -> Result:
+        """Lineage::new(label, tree, probs).evaluate() on the device (lineage.rs:61-112)."""
+        probs = np.ascontiguousarray(probs, dtype=np.float64)
+        assert len(probs) == self.n_refs
+        check(self._lib.rtx_debug_evaluate(self._h, ptr(probs, f64p), C.byref(self._view)))
+        return Result(self._view)
+
+    def format_query(self, q: int, label: str, seq: np.ndarray, exact_ids: np.ndarray, flags: int = 0,
+                     tsv: bool = False):
+        """Lines of query q of the last download (after override raxtax.rs:73-84)."""
+        seq = np.ascontiguousarray(seq, dtype=np.uint8)
+        ex = np.ascontiguousarray(exact_ids if len(exact_ids) else np.zeros(1, np.uint32), dtype=np.uint32)
+        cap = 1 << 20
+        out = C.create_string_buffer(cap)
+        tbuf = C.create_string_buffer(cap) if tsv else None
+        tlen = C.c_int64()
+        n = self._lib.rtx_format_query(self.tree._h, C.byref(self._view), q, label.encode(), ptr(seq, u8p), len(seq),
+                                       ptr(ex, u32p), len(exact_ids), flags, out, cap, tbuf, cap, C.byref(tlen))
+        check(n)
+        return out.raw[:n].decode(), (tbuf.raw[:tlen.value].decode() if tsv else None)
+
+
+_SENDER = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_char_p, C.c_char_p, C.c_char_p)
+
+
+def raxtax(queries: Sequence[Tuple[str, np.ndarray]], tree: Index, skip_exact_matches: bool, raw_confidence: bool,
+           chunk_size: int, sender: Callable[[str, str, Optional[str]], None], tsv: bool) -> None:
+    """src/raxtax.rs:14-22 -- same arguments; `tree` is the device Index built from the Tree.
+    `sender(label, out_lines, tsv_lines_or_None)` is called once per query; raising from it
+    plays the role of a closed channel."""
+    lib = _lib.load()
+    lib.rtx_raxtax.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_char_p), u8p, u64p, C.c_int, C.c_int,
+                               C.c_uint64, _SENDER, C.c_void_p, C.c_int]
+    labels = (C.c_char_p * max(len(queries), 1))(*[q[0].encode() for q in queries])
+    flat, off = _flatten([q[1] for q in queries])
+    err: List[BaseException] = []
+
+    def cb(_ctx, label, out, tsv_lines):
+        try:
+            sender(label.decode(), out.decode(), tsv_lines.decode() if tsv_lines is not None else None)
+            return 0
+        except BaseException as e:  # noqa: BLE001 - forwarded below
+            err.append(e)
+            return 1
+
+    rc = lib.rtx_raxtax(tree._h, tree.tree._h, len(queries), labels, ptr(flat, u8p), ptr(off, u64p),
+                        int(skip_exact_matches), int(raw_confidence), chunk_size, _SENDER(cb), None, int(tsv))
+    if err:
+        raise err[0]
+    check(rc)

@@ -1,0 +1,131 @@
+// Host mirror of the result formatting and of the single-exact-match override:
+//   EvaluationResult::get_output_string  src/lineage.rs:17-29
+//   EvaluationResult::get_tsv_string     src/lineage.rs:31-48
+//   utils::get_results / get_results_tsv src/utils.rs:62-68,83-89
+//   utils::decompress_sequence           src/utils.rs:70-81
+//   exact-match override                 src/raxtax.rs:73-84
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+#include "rtx_internal.hpp"
+
+namespace {
+
+struct Out {
+    char *buf;
+    uint64_t cap, len = 0;
+    bool ok = true;
+    void put(const char *s, size_t n) {
+        if (!ok) return;
+        if (len + n + 1 > cap) { ok = false; return; }
+        memcpy(buf + len, s, n);
+        len += n;
+        buf[len] = 0;
+    }
+    void put(const std::string &s) { put(s.data(), s.size()); }
+    void putc(char c) { put(&c, 1); }
+    void putf(const char *fmt, double v) {
+        char tmp[64];
+        int n = snprintf(tmp, sizeof tmp, fmt, v);
+        put(tmp, (size_t)n);
+    }
+};
+
+}  // namespace
+
+extern "C" int64_t rtx_format_query(const rtx_tree *tree, const rtx_result_view *res, uint64_t q, const char *label,
+                                    const uint8_t *seq, uint64_t seq_len, const uint32_t *exact_ids, uint64_t n_exact,
+                                    uint32_t flags, char *out_buf, uint64_t out_cap, char *tsv_buf, uint64_t tsv_cap,
+                                    int64_t *tsv_len) {
+    if (!tree || !res || !label || !out_buf || q >= res->n_queries) {
+        rtx::set_error("rtx_format_query: invalid argument");
+        return RTX_ERR_INVALID;
+    }
+    uint64_t r0 = res->row_off[q], r1 = res->row_off[q + 1];
+    if (r1 == r0) {  // assert!(!eval_res.is_empty()), raxtax.rs:72
+        rtx::set_error("query %llu has no result rows (status %u)", (unsigned long long)q, res->status[q]);
+        return RTX_ERR_INVALID;
+    }
+    // raxtax.rs:73-84: exactly one exact match -> one row, confidence 1.0 on every level,
+    // signals of the former first row
+    const bool override_one =
+        !(flags & RTX_RAW_CONFIDENCE) && !(flags & RTX_SKIP_EXACT_MATCHES) && exact_ids && n_exact == 1;
+    std::string dec;
+    if (tsv_buf) {
+        dec.resize(seq_len);
+        for (uint64_t i = 0; i < seq_len; i++) {
+            switch (seq[i]) {
+                case 1: dec[i] = 'A'; break;
+                case 2: dec[i] = 'C'; break;
+                case 4: dec[i] = 'G'; break;
+                case 8: dec[i] = 'T'; break;
+                default: dec[i] = '-';
+            }
+        }
+    }
+    Out o{out_buf, out_cap}, tv{tsv_buf, tsv_buf ? tsv_cap : 0};
+    const uint64_t n_out = override_one ? 1 : r1 - r0;
+    for (uint64_t i = 0; i < n_out; i++) {
+        const uint64_t r = r0 + i;
+        uint32_t lin_idx = res->row_lineage[r];
+        uint32_t depth = res->row_depth[r];
+        const double *conf = res->row_conf + r * RTX_MAX_DEPTH;
+        double ones[RTX_MAX_DEPTH];
+        if (override_one) {
+            lin_idx = exact_ids[0];
+            const std::string &l = tree->lineages[lin_idx];
+            depth = 1;
+            for (char c : l) depth += c == ',';
+            if (depth > RTX_MAX_DEPTH) { rtx::set_error("lineage deeper than RTX_MAX_DEPTH"); return RTX_ERR_DEPTH; }
+            for (uint32_t d = 0; d < depth; d++) ones[d] = 1.0;
+            conf = ones;
+        }
+        const std::string &lineage = tree->lineages[lin_idx];
+        const double local = res->row_local_signal[r0 + (override_one ? 0 : i)];
+        const double global = res->global_signal[q];
+        if (i) o.putc('\n');
+        o.put(label, strlen(label));
+        o.putc('\t');
+        o.put(lineage);
+        o.putc('\t');
+        for (uint32_t d = 0; d < depth; d++) {
+            if (d) o.putc(',');
+            o.putf("%.2f", conf[d]);
+        }
+        o.putf("\t%.5f", local);
+        o.putf("\t%.5f", global);
+        if (tsv_buf) {
+            if (i) tv.putc('\n');
+            tv.put(label, strlen(label));
+            tv.putc('\t');
+            // levels interleaved with confidences; interleave() drains the longer side
+            size_t pos = 0;
+            uint32_t d = 0;
+            bool lin_done = false, first = true;
+            while (!lin_done || d < depth) {
+                if (!lin_done) {
+                    size_t c = lineage.find(',', pos);
+                    if (!first) tv.putc('\t');
+                    tv.put(lineage.data() + pos, (c == std::string::npos ? lineage.size() : c) - pos);
+                    first = false;
+                    if (c == std::string::npos) lin_done = true;
+                    else pos = c + 1;
+                }
+                if (d < depth) {
+                    if (!first) tv.putc('\t');
+                    tv.putf("%.2f", conf[d]);
+                    first = false;
+                    d++;
+                }
+            }
+            tv.putf("\t%.5f", local);
+            tv.putf("\t%.5f", global);
+            tv.putc('\t');
+            tv.put(dec);
+        }
+    }
+    if (!o.ok || (tsv_buf && !tv.ok)) { rtx::set_error("rtx_format_query: output buffer too small"); return RTX_ERR_INVALID; }
+    if (tsv_len) *tsv_len = tsv_buf ? (int64_t)tv.len : 0;
+    return (int64_t)o.len;
+}

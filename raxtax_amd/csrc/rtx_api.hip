@@ -1,0 +1,858 @@
+// C-ABI implementation of the device side of libraxtax_hip.so: index upload/re-encoding,
+// batch workspace, kernel sequencing on the handle's HIP stream, result download and the
+// host finalisation (sort lineage.rs:91-93, local signal lineage.rs:95-102).
+// There is deliberately no CPU fallback in this file: without a gfx950 device every entry
+// point returns RTX_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <thread>
+
+#include "rtx_internal.hpp"
+#include "rtx_kernels.hpp"
+
+using namespace rtx;
+
+namespace {
+
+constexpr uint32_t kEmptyRow = 0xFFFFFFFFu;
+constexpr uint32_t kLnFactLen = 98320;  // covers t + n - 1 for every t <= 65535
+
+#define RTX_HIP(call)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (call);                                                                \
+        if (e_ != hipSuccess) {                                                                \
+            set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return e_ == hipErrorOutOfMemory ? RTX_ERR_OOM : RTX_ERR_HIP;                      \
+        }                                                                                      \
+    } while (0)
+
+template <class T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    int alloc(size_t count) {
+        if (count <= n && p) return RTX_OK;
+        release();
+        if (count == 0) count = 1;
+        hipError_t e = hipMalloc((void **)&p, count * sizeof(T));
+        if (e != hipSuccess) {
+            p = nullptr;
+            set_error("hipMalloc(%zu bytes) failed: %s", count * sizeof(T), hipGetErrorString(e));
+            return RTX_ERR_OOM;
+        }
+        n = count;
+        return RTX_OK;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    ~DevBuf() { release(); }
+};
+
+// statrs 0.16 `ln_factorial` (the reference's ln_binomial, prob.rs:5,20,117,143): ln of a cached
+// f64 factorial up to 170, Lanczos ln_gamma (g = 10.900511, 11 terms) above.
+double statrs_ln_gamma(double x) {
+    static const double dk[11] = {2.48574089138753565546e-5, 1.05142378581721974210,  -3.45687097222016235469,
+                                  4.51227709466894823700,    -2.98285225323576655721, 1.05639711577126713077,
+                                  -1.95428773191645869583e-1, 1.70970543404441224307e-2,
+                                  -5.71926117404305781283e-4, 4.63399473359905636708e-6,
+                                  -2.71994908488607703910e-9};
+    const double r = 10.900511, ln_2_sqrt_e_over_pi = 0.6207822376352452223455184457816472122518527279025978;
+    double s = dk[0];
+    for (int i = 1; i < 11; i++) s += dk[i] / (x + (double)i - 1.0);
+    return std::log(s) + ln_2_sqrt_e_over_pi + (x - 0.5) * std::log((x - 0.5 + r) / M_E);
+}
+void fill_ln_factorial(std::vector<double> &lf) {
+    lf.resize(kLnFactLen);
+    double f = 1.0;
+    for (uint32_t x = 0; x < kLnFactLen; x++) {
+        if (x <= 170) {
+            if (x > 0) f *= (double)x;
+            lf[x] = std::log(f);
+        } else {
+            lf[x] = statrs_ln_gamma((double)x + 1.0);
+        }
+    }
+}
+
+inline uint64_t align_up(uint64_t v, uint64_t a) { return (v + a - 1) / a * a; }
+
+}  // namespace
+
+struct rtx_index {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    uint64_t n_refs = 0;
+    // ---- index proper
+    uint32_t n_rows = 0;        // non-empty posting lists
+    uint32_t stride_bytes = 0;  // bytes per bitmap row (multiple of 128)
+    uint64_t npad = 0;          // references per padded row (= stride_bytes * 8)
+    uint32_t ntiles = 0;        // 8192-reference tiles
+    DevBuf<uint32_t> d_bitmap, d_row_of, d_list_len;
+    DevBuf<double> d_lnfact;
+    std::vector<uint32_t> h_list_len;
+    // ---- taxonomy
+    FlatNodes nodes;
+    std::vector<uint32_t> bnd;  // sorted unique range endpoints
+    uint32_t n_bnd = 0;
+    DevBuf<uint32_t> d_blo, d_bhi, d_first, d_nch, d_bnd_rank;
+    DevBuf<uint8_t> d_type, d_bnd_bits;
+    // ---- batch inputs
+    uint64_t n_q = 0;
+    bool uploaded = false, ran = false, synced = false;
+    uint32_t last_flags = 0;
+    DevBuf<uint8_t> d_bases;
+    DevBuf<uint64_t> d_base_off, d_exact_off;
+    DevBuf<uint32_t> d_exact_ids;
+    uint64_t sum_query_bytes = 0;
+    uint32_t kstride = 0, rstride = 0, hstride = 0, tmax = 0;
+    int planes = 10;
+    // ---- sub-batch scratch
+    uint32_t sub_batch_req = 0, sub_batch = 0;
+    DevBuf<uint16_t> d_kmers, d_counts;
+    DevBuf<uint32_t> d_rows, d_t, d_nrows, d_hist;
+    DevBuf<double> d_table_z, d_prefix, d_probs_dbg;
+    // ---- per-query results
+    DevBuf<uint8_t> d_status;
+    DevBuf<uint32_t> d_t_all, d_nrows_all, d_n_rows, d_flags;
+    DevBuf<double> d_gs, d_z;
+    DevBuf<unsigned long long> d_hq, d_row_start, d_cursor;
+    DevBuf<DevRow> d_arena;
+    uint64_t arena_cap = 0;
+    // ---- timing
+    std::vector<hipEvent_t> events;  // 2 per (sub-batch, stage)
+    uint32_t n_sub_last = 0;
+    // ---- host results
+    std::vector<uint32_t> h_t, h_nrows_all, h_n_rows, v_row_lineage, v_row_node, v_row_depth;
+    std::vector<uint8_t> h_status;
+    std::vector<double> h_gs, h_z, v_row_conf, v_row_local;
+    std::vector<unsigned long long> h_hq, h_row_start;
+    std::vector<uint64_t> v_row_off;
+    std::vector<DevRow> h_arena;
+
+    ~rtx_index() {
+        for (auto e : events) (void)hipEventDestroy(e);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+};
+
+namespace {
+
+int bind(rtx_index *ix) {
+    if (!ix) { set_error("null index handle"); return RTX_ERR_INVALID; }
+    RTX_HIP(hipSetDevice(ix->device));
+    return RTX_OK;
+}
+
+int ensure_events(rtx_index *ix, size_t count) {
+    while (ix->events.size() < count) {
+        hipEvent_t e;
+        RTX_HIP(hipEventCreate(&e));
+        ix->events.push_back(e);
+    }
+    return RTX_OK;
+}
+
+// Enqueues every kernel of the uploaded batch on the handle's stream.
+int enqueue_batch(rtx_index *ix, uint32_t flags) {
+    hipStream_t s = ix->stream;
+    RTX_HIP(hipMemsetAsync(ix->d_cursor.p, 0, sizeof(unsigned long long), s));
+    RTX_HIP(hipMemsetAsync(ix->d_flags.p, 0, sizeof(uint32_t), s));
+    const uint32_t B = ix->sub_batch;
+    const uint32_t n_sub = (uint32_t)((ix->n_q + B - 1) / B);
+    const bool timed = n_sub <= 4096;
+    if (timed) {
+        int rc = ensure_events(ix, (size_t)n_sub * RTX_NUM_STAGES * 2);
+        if (rc) return rc;
+    }
+    ix->n_sub_last = timed ? n_sub : 0;
+    for (uint32_t sb = 0; sb < n_sub; sb++) {
+        const uint64_t q0 = (uint64_t)sb * B;
+        const uint32_t nq = (uint32_t)std::min<uint64_t>(B, ix->n_q - q0);
+        auto ev = [&](int stage, int which) -> hipEvent_t {
+            return ix->events[((size_t)sb * RTX_NUM_STAGES + stage) * 2 + which];
+        };
+        KmerParams kp{};
+        kp.bases = ix->d_bases.p;
+        kp.base_off = ix->d_base_off.p;
+        kp.q0 = q0;
+        kp.row_of = ix->d_row_of.p;
+        kp.list_len = ix->d_list_len.p;
+        kp.zero_row = ix->n_rows;
+        kp.kmers = ix->d_kmers.p;
+        kp.kstride = ix->kstride;
+        kp.rows = ix->d_rows.p;
+        kp.rstride = ix->rstride;
+        kp.t = ix->d_t.p;
+        kp.nrows = ix->d_nrows.p;
+        kp.hq = ix->d_hq.p;
+        kp.t_all = ix->d_t_all.p;
+        kp.nrows_all = ix->d_nrows_all.p;
+        if (timed) RTX_HIP(hipEventRecord(ev(RTX_STAGE_KMER_EXTRACT, 0), s));
+        launch_kmer_extract(s, kp, nq);
+        if (timed) RTX_HIP(hipEventRecord(ev(RTX_STAGE_KMER_EXTRACT, 1), s));
+
+        RTX_HIP(hipMemsetAsync(ix->d_hist.p, 0, (size_t)nq * ix->hstride * sizeof(uint32_t), s));
+        HitParams hp{};
+        hp.bitmap = ix->d_bitmap.p;
+        hp.stride_bytes = ix->stride_bytes;
+        hp.n_refs = ix->n_refs;
+        hp.rows = ix->d_rows.p;
+        hp.rstride = ix->rstride;
+        hp.nrows = ix->d_nrows.p;
+        hp.t = ix->d_t.p;
+        hp.counts = ix->d_counts.p;
+        hp.npad = ix->npad;
+        hp.hist = ix->d_hist.p;
+        hp.hstride = ix->hstride;
+        hp.flags = flags;
+        hp.q0 = q0;
+        hp.exact_ids = ix->d_exact_ids.p;
+        hp.exact_off = ix->d_exact_off.p;
+        if (timed) RTX_HIP(hipEventRecord(ev(RTX_STAGE_HIT_COUNT, 0), s));
+        launch_hit_count(s, hp, nq, ix->ntiles, ix->planes);
+        if (timed) RTX_HIP(hipEventRecord(ev(RTX_STAGE_HIT_COUNT, 1), s));
+
+        ProbParams pp{};
+        pp.t = ix->d_t.p;
+        pp.hist = ix->d_hist.p;
+        pp.hstride = ix->hstride;
+        pp.tmax = ix->tmax;
+        pp.n1max = ix->tmax / 2 + 1;
+        pp.lnfact = ix->d_lnfact.p;
+        pp.n_refs = ix->n_refs;
+        pp.q0 = q0;
+        pp.table_z = ix->d_table_z.p;
+        pp.z = ix->d_z.p;
+        pp.gs = ix->d_gs.p;
+        pp.status = ix->d_status.p;
+        if (timed) RTX_HIP(hipEventRecord(ev(RTX_STAGE_PROB_TABLE, 0), s));
+        launch_prob_table(s, pp, nq);
+        if (timed) RTX_HIP(hipEventRecord(ev(RTX_STAGE_PROB_TABLE, 1), s));
+
+        PrefixParams fp{};
+        fp.status = ix->d_status.p;
+        fp.q0 = q0;
+        fp.counts = ix->d_counts.p;
+        fp.npad = ix->npad;
+        fp.table_z = ix->d_table_z.p;
+        fp.hstride = ix->hstride;
+        fp.n_refs = ix->n_refs;
+        fp.bnd_bits = ix->d_bnd_bits.p;
+        fp.bnd_rank = ix->d_bnd_rank.p;
+        fp.prefix = ix->d_prefix.p;
+        fp.n_bnd = ix->n_bnd;
+        if (timed) RTX_HIP(hipEventRecord(ev(RTX_STAGE_TAXON_PREFIX, 0), s));
+        launch_taxon_prefix(s, fp, nq);
+        if (timed) RTX_HIP(hipEventRecord(ev(RTX_STAGE_TAXON_PREFIX, 1), s));
+
+        WalkParams wp{};
+        wp.status = ix->d_status.p;
+        wp.q0 = q0;
+        wp.prefix = ix->d_prefix.p;
+        wp.n_bnd = ix->n_bnd;
+        wp.blo = ix->d_blo.p;
+        wp.bhi = ix->d_bhi.p;
+        wp.first_child = ix->d_first.p;
+        wp.n_children = ix->d_nch.p;
+        wp.type = ix->d_type.p;
+        wp.arena = ix->d_arena.p;
+        wp.arena_cap = ix->arena_cap;
+        wp.arena_cursor = ix->d_cursor.p;
+        wp.n_rows = ix->d_n_rows.p;
+        wp.row_start = ix->d_row_start.p;
+        wp.flags_out = ix->d_flags.p;
+        if (timed) RTX_HIP(hipEventRecord(ev(RTX_STAGE_LINEAGE_WALK, 0), s));
+        launch_lineage_walk(s, wp, nq);
+        if (timed) RTX_HIP(hipEventRecord(ev(RTX_STAGE_LINEAGE_WALK, 1), s));
+    }
+    RTX_HIP(hipGetLastError());
+    return RTX_OK;
+}
+
+// Sizes and allocates the per-batch workspace for n_queries queries of at most tmax k-mers.
+int prepare_workspace(rtx_index *ix, uint64_t n_queries, uint64_t tmax, uint64_t max_len) {
+    int rc;
+    if (tmax > 65535) { set_error("query with up to %llu k-mers: raxtax.rs:56 asserts t fits u16", (unsigned long long)tmax); return RTX_ERR_TOO_LONG; }
+    if (prob_table_lds_bytes((uint32_t)tmax) > 160 * 1024 - 512) {
+        set_error("query of %llu bases needs %zu bytes of LDS in prob_table (limit 160 KiB)", (unsigned long long)max_len,
+                  prob_table_lds_bytes((uint32_t)tmax));
+        return RTX_ERR_TOO_LONG;
+    }
+    ix->tmax = (uint32_t)tmax;
+    ix->kstride = (uint32_t)align_up(tmax, 8);
+    ix->rstride = (uint32_t)align_up(tmax, 16) + 16;
+    ix->hstride = (uint32_t)align_up(tmax + 1, 8);
+    ix->planes = tmax <= 1023 ? 10 : (tmax <= 4095 ? 12 : 16);
+    ix->n_q = n_queries;
+    if ((rc = ix->d_exact_off.alloc(n_queries + 1))) return rc;
+    // ---- per-query results
+    if ((rc = ix->d_status.alloc(n_queries)) || (rc = ix->d_t_all.alloc(n_queries)) || (rc = ix->d_nrows_all.alloc(n_queries)) ||
+        (rc = ix->d_n_rows.alloc(n_queries)) || (rc = ix->d_gs.alloc(n_queries)) || (rc = ix->d_z.alloc(n_queries)) ||
+        (rc = ix->d_hq.alloc(n_queries)) || (rc = ix->d_row_start.alloc(n_queries)))
+        return rc;
+    const uint64_t want_arena = n_queries * 8 + 4096;
+    if (ix->arena_cap < want_arena) {
+        if ((rc = ix->d_arena.alloc(want_arena))) return rc;
+        ix->arena_cap = want_arena;
+    }
+    // ---- sub-batch scratch, sized against free HBM
+    const uint64_t per_q = (uint64_t)ix->kstride * 2 + (uint64_t)ix->rstride * 4 + ix->npad * 2 + (uint64_t)ix->hstride * 12 +
+                           (uint64_t)ix->n_bnd * 8 + 64;
+    uint32_t B = ix->sub_batch_req;
+    if (B == 0) {
+        size_t free_b = 0, total_b = 0;
+        RTX_HIP(hipMemGetInfo(&free_b, &total_b));
+        // scratch already held by this handle is reusable
+        const uint64_t held = ix->d_counts.n * 2 + ix->d_prefix.n * 8;
+        const uint64_t budget = (uint64_t)((free_b + held) * 0.6);
+        B = (uint32_t)std::min<uint64_t>(4096, std::max<uint64_t>(64, budget / per_q));
+    }
+    B = (uint32_t)std::min<uint64_t>(B, n_queries);
+    ix->sub_batch = B;
+    if ((rc = ix->d_kmers.alloc((size_t)B * ix->kstride)) || (rc = ix->d_rows.alloc((size_t)B * ix->rstride)) ||
+        (rc = ix->d_t.alloc(B)) || (rc = ix->d_nrows.alloc(B)) || (rc = ix->d_counts.alloc((size_t)B * ix->npad)) ||
+        (rc = ix->d_hist.alloc((size_t)B * ix->hstride)) || (rc = ix->d_table_z.alloc((size_t)B * ix->hstride)) ||
+        (rc = ix->d_prefix.alloc((size_t)B * ix->n_bnd)))
+        return rc;
+    return RTX_OK;
+}
+
+// lineage.rs:91-110 for the rows of one query: expected vectors, stable descending sort by
+// confidence vector, local signal (utils.rs:91-105).
+struct HostRow {
+    uint32_t node, depth;
+    double conf[RTX_MAX_DEPTH], expd[RTX_MAX_DEPTH];
+};
+
+bool conf_less(const HostRow &a, const HostRow &b) {  // a < b, lexicographic, shorter prefix smaller
+    const uint32_t n = std::min(a.depth, b.depth);
+    for (uint32_t i = 0; i < n; i++) {
+        if (a.conf[i] < b.conf[i]) return true;
+        if (a.conf[i] > b.conf[i]) return false;
+    }
+    return a.depth < b.depth;
+}
+
+double euclidean_distance_l1(const double *a, const double *b, uint32_t n) {  // utils.rs:91-105
+    if (n == 0) return 0.0;
+    double a_sum = 0.0, b_sum = 0.0;
+    for (uint32_t i = 0; i < n; i++) a_sum += a[i];
+    for (uint32_t i = 0; i < n; i++) b_sum += b[i];
+    double s = 0.0;
+    for (uint32_t i = 0; i < n; i++) {
+        const double d = a[i] / a_sum - b[i] / b_sum;
+        s += d * d;
+    }
+    return std::sqrt(s);
+}
+
+void finalise_range(rtx_index *ix, uint64_t qa, uint64_t qb) {
+    const FlatNodes &f = ix->nodes;
+    const double N = (double)ix->n_refs;
+    std::vector<HostRow> rows;
+    for (uint64_t q = qa; q < qb; q++) {
+        const uint32_t nr = ix->h_n_rows[q];
+        rows.resize(nr);
+        const DevRow *src = ix->h_arena.data() + ix->h_row_start[q];
+        for (uint32_t r = 0; r < nr; r++) {
+            HostRow &h = rows[r];
+            h.node = src[r].node;
+            h.depth = f.depth[h.node];
+            uint32_t anc = h.node;
+            for (int d = (int)h.depth - 1; d >= 0; d--) {
+                h.conf[d] = (double)src[r].k[d] / 100.0;  // == round(x*100)/100, lineage.rs:128-129
+                h.expd[d] = (double)(f.end[anc] - f.begin[anc]) / N;  // lineage.rs:137-139
+                anc = f.parent[anc];
+            }
+        }
+        // stable, descending (lineage.rs:91-93)
+        std::stable_sort(rows.begin(), rows.end(), [](const HostRow &a, const HostRow &b) { return conf_less(b, a); });
+        uint64_t o = ix->v_row_off[q];
+        for (uint32_t r = 0; r < nr; r++, o++) {
+            const HostRow &h = rows[r];
+            ix->v_row_lineage[o] = f.begin[h.node];
+            ix->v_row_node[o] = h.node;
+            ix->v_row_depth[o] = h.depth;
+            double *c = ix->v_row_conf.data() + o * RTX_MAX_DEPTH;
+            for (uint32_t d = 0; d < RTX_MAX_DEPTH; d++) c[d] = d < h.depth ? h.conf[d] : 0.0;
+            uint32_t s = h.depth ? h.depth - 1 : 0;  // lineage.rs:95-98
+            for (uint32_t d = 0; d < h.depth; d++)
+                if (1.0 > h.expd[d]) { s = d; break; }
+            ix->v_row_local[o] = h.depth ? euclidean_distance_l1(h.conf + s, h.expd + s, h.depth - s) : 0.0;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int rtx_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int rtx_index_create(int device, uint64_t n_refs, const uint64_t *offsets, const uint32_t *postings,
+                     uint32_t n_nodes, const uint32_t *node_begin, const uint32_t *node_end,
+                     const uint32_t *node_first_child, const uint32_t *node_n_children, const uint8_t *node_type,
+                     rtx_index **out) {
+    if (!out || !offsets || !node_begin || !node_end || !node_first_child || !node_n_children || !node_type ||
+        n_refs == 0 || n_refs > 0xFFFFFFFFull) {
+        set_error("rtx_index_create: invalid argument");
+        return RTX_ERR_INVALID;
+    }
+    if (offsets[RTX_NUM_KMERS] && !postings) { set_error("rtx_index_create: postings is null"); return RTX_ERR_INVALID; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) {
+        set_error("no usable HIP device (requested %d of %d); libraxtax_hip has no CPU fallback", device, ndev);
+        return RTX_ERR_NO_DEVICE;
+    }
+    RTX_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    RTX_HIP(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        set_error("device %d is %s; this library carries gfx950 (MI355X) code objects only", device, prop.gcnArchName);
+        return RTX_ERR_NO_DEVICE;
+    }
+    auto ix = new rtx_index();
+    ix->device = device;
+    ix->n_refs = n_refs;
+    int rc = RTX_OK;
+    auto fail = [&](int code) { delete ix; return code; };
+    if (!derive_flat_nodes(n_refs, n_nodes, node_begin, node_end, node_first_child, node_n_children, node_type, ix->nodes))
+        return fail(RTX_ERR_INVALID);
+    if (ix->nodes.max_depth > RTX_MAX_DEPTH) {
+        set_error("lineage depth %u exceeds RTX_MAX_DEPTH=%u", ix->nodes.max_depth, RTX_MAX_DEPTH);
+        return fail(RTX_ERR_DEPTH);
+    }
+    if (hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking) != hipSuccess) {
+        set_error("hipStreamCreate failed");
+        return fail(RTX_ERR_HIP);
+    }
+    // ---- taxonomy boundaries
+    {
+        std::vector<uint32_t> b;
+        b.reserve(2 * (size_t)n_nodes + 2);
+        b.push_back(0);
+        b.push_back((uint32_t)n_refs);
+        for (uint32_t v = 0; v < n_nodes; v++) { b.push_back(ix->nodes.begin[v]); b.push_back(ix->nodes.end[v]); }
+        std::sort(b.begin(), b.end());
+        b.erase(std::unique(b.begin(), b.end()), b.end());
+        ix->bnd = std::move(b);
+        ix->n_bnd = (uint32_t)ix->bnd.size();
+        std::vector<uint32_t> blo(n_nodes), bhi(n_nodes);
+        for (uint32_t v = 0; v < n_nodes; v++) {
+            blo[v] = (uint32_t)(std::lower_bound(ix->bnd.begin(), ix->bnd.end(), ix->nodes.begin[v]) - ix->bnd.begin());
+            bhi[v] = (uint32_t)(std::lower_bound(ix->bnd.begin(), ix->bnd.end(), ix->nodes.end[v]) - ix->bnd.begin());
+        }
+        const size_t nchunk = (size_t)((n_refs + 7) / 8);
+        std::vector<uint8_t> bits(nchunk, 0);
+        std::vector<uint32_t> rank(nchunk, 0);
+        for (uint32_t j = 1; j < ix->n_bnd; j++) {  // boundary position p >= 1 belongs to reference p-1
+            const uint32_t r = ix->bnd[j] - 1;
+            bits[r >> 3] |= (uint8_t)(1u << (r & 7u));
+        }
+        uint32_t run = 1;
+        for (size_t c = 0; c < nchunk; c++) {
+            rank[c] = run;
+            run += (uint32_t)__builtin_popcount(bits[c]);
+        }
+        if ((rc = ix->d_blo.alloc(n_nodes)) || (rc = ix->d_bhi.alloc(n_nodes)) || (rc = ix->d_first.alloc(n_nodes)) ||
+            (rc = ix->d_nch.alloc(n_nodes)) || (rc = ix->d_type.alloc(n_nodes)) || (rc = ix->d_bnd_bits.alloc(nchunk)) ||
+            (rc = ix->d_bnd_rank.alloc(nchunk)))
+            return fail(rc);
+        hipError_t e = hipSuccess;
+        auto up = [&](void *d, const void *h, size_t bytes) { if (e == hipSuccess) e = hipMemcpy(d, h, bytes, hipMemcpyHostToDevice); };
+        up(ix->d_blo.p, blo.data(), n_nodes * 4);
+        up(ix->d_bhi.p, bhi.data(), n_nodes * 4);
+        up(ix->d_first.p, ix->nodes.first_child.data(), n_nodes * 4);
+        up(ix->d_nch.p, ix->nodes.n_children.data(), n_nodes * 4);
+        up(ix->d_type.p, ix->nodes.type.data(), n_nodes);
+        up(ix->d_bnd_bits.p, bits.data(), nchunk);
+        up(ix->d_bnd_rank.p, rank.data(), nchunk * 4);
+        if (e != hipSuccess) { set_error("taxonomy upload failed: %s", hipGetErrorString(e)); return fail(RTX_ERR_HIP); }
+    }
+    // ---- ln-factorial table
+    {
+        std::vector<double> lf;
+        fill_ln_factorial(lf);
+        if ((rc = ix->d_lnfact.alloc(lf.size()))) return fail(rc);
+        if (hipMemcpy(ix->d_lnfact.p, lf.data(), lf.size() * 8, hipMemcpyHostToDevice) != hipSuccess) {
+            set_error("lnfact upload failed");
+            return fail(RTX_ERR_HIP);
+        }
+    }
+    // ---- bitmap index: one row of n_refs bits per non-empty posting list (+ one zero row)
+    {
+        std::vector<uint32_t> row_of(RTX_NUM_KMERS, kEmptyRow);
+        ix->h_list_len.assign(RTX_NUM_KMERS, 0);
+        uint32_t nr = 0;
+        for (uint32_t k = 0; k < RTX_NUM_KMERS; k++) {
+            if (offsets[k + 1] < offsets[k]) { set_error("offsets not monotone at k-mer %u", k); return fail(RTX_ERR_INVALID); }
+            const uint64_t l = offsets[k + 1] - offsets[k];
+            if (l > n_refs) { set_error("posting list %u longer than n_refs", k); return fail(RTX_ERR_INVALID); }
+            ix->h_list_len[k] = (uint32_t)l;
+            if (l) row_of[k] = nr++;
+        }
+        ix->n_rows = nr;
+        ix->stride_bytes = (uint32_t)align_up((n_refs + 7) / 8, 128);
+        ix->npad = (uint64_t)ix->stride_bytes * 8;
+        ix->ntiles = (ix->stride_bytes + 1023) / 1024;
+        const size_t words = (size_t)(nr + 1) * (ix->stride_bytes / 4);
+        const uint64_t total = offsets[RTX_NUM_KMERS];
+        DevBuf<uint64_t> d_off;
+        DevBuf<uint32_t> d_post;
+        if ((rc = ix->d_bitmap.alloc(words)) || (rc = ix->d_row_of.alloc(RTX_NUM_KMERS)) ||
+            (rc = ix->d_list_len.alloc(RTX_NUM_KMERS)) || (rc = d_off.alloc(RTX_NUM_KMERS + 1)) ||
+            (rc = d_post.alloc(total)))
+            return fail(rc);
+        hipError_t e = hipMemset(ix->d_bitmap.p, 0, words * 4);
+        if (e == hipSuccess) e = hipMemcpy(ix->d_row_of.p, row_of.data(), RTX_NUM_KMERS * 4, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(ix->d_list_len.p, ix->h_list_len.data(), RTX_NUM_KMERS * 4, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(d_off.p, offsets, (RTX_NUM_KMERS + 1) * 8, hipMemcpyHostToDevice);
+        if (e == hipSuccess && total) e = hipMemcpy(d_post.p, postings, total * 4, hipMemcpyHostToDevice);
+        if (e == hipSuccess) {
+            launch_bitmap_build(ix->stream, d_off.p, d_post.p, ix->d_row_of.p, ix->d_bitmap.p, ix->stride_bytes / 4);
+            e = hipStreamSynchronize(ix->stream);
+        }
+        if (e != hipSuccess) { set_error("bitmap build failed: %s", hipGetErrorString(e)); return fail(RTX_ERR_HIP); }
+    }
+    if ((rc = ix->d_cursor.alloc(1)) || (rc = ix->d_flags.alloc(1))) return fail(rc);
+    *out = ix;
+    return RTX_OK;
+}
+
+int rtx_index_create_from_tree(int device, const rtx_tree *tree, rtx_index **out) {
+    if (!tree || !out) { set_error("null argument"); return RTX_ERR_INVALID; }
+    const FlatNodes &f = tree->flat;
+    return rtx_index_create(device, tree->num_tips, tree->csr_off.data(), tree->postings.data(), f.size(), f.begin.data(),
+                            f.end.data(), f.first_child.data(), f.n_children.data(), f.type.data(), out);
+}
+
+void rtx_index_destroy(rtx_index *index) {
+    if (!index) return;
+    (void)hipSetDevice(index->device);
+    delete index;
+}
+
+uint64_t rtx_index_num_refs(const rtx_index *index) { return index ? index->n_refs : 0; }
+uint64_t rtx_index_device_bytes(const rtx_index *index) {
+    if (!index) return 0;
+    return index->d_bitmap.n * 4 + index->d_row_of.n * 4 + index->d_list_len.n * 4 + index->d_lnfact.n * 8 +
+           index->d_blo.n * 4 * 4 + index->d_type.n + index->d_bnd_bits.n + index->d_bnd_rank.n * 4;
+}
+int rtx_index_set_batch(rtx_index *index, uint32_t sub_batch) {
+    if (!index) { set_error("null index handle"); return RTX_ERR_INVALID; }
+    index->sub_batch_req = sub_batch;
+    return RTX_OK;
+}
+
+int rtx_batch_upload(rtx_index *ix, uint64_t n_queries, const uint8_t *bases, const uint64_t *base_off,
+                     const uint32_t *exact_ids, const uint64_t *exact_off) {
+    int rc = bind(ix);
+    if (rc) return rc;
+    if (n_queries == 0 || !base_off || (!bases && base_off[n_queries])) {
+        set_error("rtx_batch_upload: invalid argument");
+        return RTX_ERR_INVALID;
+    }
+    ix->uploaded = ix->ran = ix->synced = false;
+    uint64_t max_len = 0;
+    for (uint64_t q = 0; q < n_queries; q++) {
+        if (base_off[q + 1] < base_off[q]) { set_error("base_off not monotone at query %llu", (unsigned long long)q); return RTX_ERR_INVALID; }
+        max_len = std::max(max_len, base_off[q + 1] - base_off[q]);
+    }
+    const uint64_t total = base_off[n_queries] - base_off[0];
+    // t <= min(len - 7, 65536); t == 65536 would trip the u16 assert of raxtax.rs:56
+    const uint64_t tmax = max_len >= 8 ? max_len - 7 : 1;
+    if ((rc = prepare_workspace(ix, n_queries, tmax, max_len))) return rc;
+    ix->sum_query_bytes = total;
+
+    // ---- inputs
+    if ((rc = ix->d_bases.alloc(total + 16)) || (rc = ix->d_base_off.alloc(n_queries + 1)))
+        return rc;
+    std::vector<uint64_t> off0(n_queries + 1);
+    for (uint64_t q = 0; q <= n_queries; q++) off0[q] = base_off[q] - base_off[0];
+    RTX_HIP(hipMemcpy(ix->d_bases.p, bases + base_off[0], total, hipMemcpyHostToDevice));
+    RTX_HIP(hipMemcpy(ix->d_base_off.p, off0.data(), (n_queries + 1) * 8, hipMemcpyHostToDevice));
+    uint64_t n_exact = 0;
+    if (exact_off) {
+        if (exact_off[0] != 0) { set_error("exact_off[0] must be 0"); return RTX_ERR_INVALID; }
+        n_exact = exact_off[n_queries];
+        for (uint64_t q = 0; q < n_queries; q++)
+            if (exact_off[q + 1] < exact_off[q]) { set_error("exact_off not monotone"); return RTX_ERR_INVALID; }
+        if (n_exact && !exact_ids) { set_error("exact_ids is null"); return RTX_ERR_INVALID; }
+        for (uint64_t i = 0; i < n_exact; i++)
+            if (exact_ids[i] >= ix->n_refs) { set_error("exact id %u out of range", exact_ids[i]); return RTX_ERR_INVALID; }
+        RTX_HIP(hipMemcpy(ix->d_exact_off.p, exact_off, (n_queries + 1) * 8, hipMemcpyHostToDevice));
+    } else {
+        RTX_HIP(hipMemset(ix->d_exact_off.p, 0, (n_queries + 1) * 8));
+    }
+    if ((rc = ix->d_exact_ids.alloc(n_exact + 1))) return rc;
+    if (n_exact) RTX_HIP(hipMemcpy(ix->d_exact_ids.p, exact_ids, n_exact * 4, hipMemcpyHostToDevice));
+    ix->uploaded = true;
+    return RTX_OK;
+}
+
+int rtx_batch_run(rtx_index *ix, uint32_t flags) {
+    int rc = bind(ix);
+    if (rc) return rc;
+    if (!ix->uploaded) { set_error("rtx_batch_run before rtx_batch_upload"); return RTX_ERR_STATE; }
+    ix->last_flags = flags;
+    ix->synced = false;
+    rc = enqueue_batch(ix, flags);
+    ix->ran = rc == RTX_OK;
+    return rc;
+}
+
+int rtx_batch_sync(rtx_index *ix) {
+    int rc = bind(ix);
+    if (rc) return rc;
+    if (!ix->ran) { set_error("rtx_batch_sync before rtx_batch_run"); return RTX_ERR_STATE; }
+    RTX_HIP(hipStreamSynchronize(ix->stream));
+    ix->synced = true;
+    return RTX_OK;
+}
+
+int rtx_batch_download(rtx_index *ix, rtx_result_view *out) {
+    int rc = bind(ix);
+    if (rc) return rc;
+    if (!ix->ran || !out) { set_error("rtx_batch_download before rtx_batch_run"); return RTX_ERR_STATE; }
+    const uint64_t nq = ix->n_q;
+    unsigned long long cursor = 0;
+    for (int attempt = 0;; attempt++) {
+        RTX_HIP(hipStreamSynchronize(ix->stream));
+        ix->synced = true;
+        uint32_t flags = 0;
+        RTX_HIP(hipMemcpy(&flags, ix->d_flags.p, 4, hipMemcpyDeviceToHost));
+        RTX_HIP(hipMemcpy(&cursor, ix->d_cursor.p, 8, hipMemcpyDeviceToHost));
+        if (flags & 2u) { set_error("lineage walk exceeded its row/depth bounds (internal error)"); return RTX_ERR_HIP; }
+        if (!(flags & 1u)) break;
+        if (attempt >= 2) { set_error("result arena overflow persists"); return RTX_ERR_HIP; }
+        // arena too small: grow to what this run asked for and repeat the (deterministic) run
+        const uint64_t want = cursor + 4096;
+        if ((rc = ix->d_arena.alloc(want))) return rc;
+        ix->arena_cap = want;
+        if ((rc = enqueue_batch(ix, ix->last_flags))) return rc;
+    }
+    ix->h_status.resize(nq);
+    ix->h_t.resize(nq);
+    ix->h_nrows_all.resize(nq);
+    ix->h_n_rows.resize(nq);
+    ix->h_gs.resize(nq);
+    ix->h_z.resize(nq);
+    ix->h_hq.resize(nq);
+    ix->h_row_start.resize(nq);
+    ix->h_arena.resize(cursor ? cursor : 1);
+    RTX_HIP(hipMemcpy(ix->h_status.data(), ix->d_status.p, nq, hipMemcpyDeviceToHost));
+    RTX_HIP(hipMemcpy(ix->h_t.data(), ix->d_t_all.p, nq * 4, hipMemcpyDeviceToHost));
+    RTX_HIP(hipMemcpy(ix->h_nrows_all.data(), ix->d_nrows_all.p, nq * 4, hipMemcpyDeviceToHost));
+    RTX_HIP(hipMemcpy(ix->h_n_rows.data(), ix->d_n_rows.p, nq * 4, hipMemcpyDeviceToHost));
+    RTX_HIP(hipMemcpy(ix->h_gs.data(), ix->d_gs.p, nq * 8, hipMemcpyDeviceToHost));
+    RTX_HIP(hipMemcpy(ix->h_z.data(), ix->d_z.p, nq * 8, hipMemcpyDeviceToHost));
+    RTX_HIP(hipMemcpy(ix->h_hq.data(), ix->d_hq.p, nq * 8, hipMemcpyDeviceToHost));
+    RTX_HIP(hipMemcpy(ix->h_row_start.data(), ix->d_row_start.p, nq * 8, hipMemcpyDeviceToHost));
+    if (cursor) RTX_HIP(hipMemcpy(ix->h_arena.data(), ix->d_arena.p, cursor * sizeof(DevRow), hipMemcpyDeviceToHost));
+
+    ix->v_row_off.resize(nq + 1);
+    ix->v_row_off[0] = 0;
+    for (uint64_t q = 0; q < nq; q++) ix->v_row_off[q + 1] = ix->v_row_off[q] + ix->h_n_rows[q];
+    const uint64_t nrows = ix->v_row_off[nq];
+    ix->v_row_lineage.resize(nrows);
+    ix->v_row_node.resize(nrows);
+    ix->v_row_depth.resize(nrows);
+    ix->v_row_local.resize(nrows);
+    ix->v_row_conf.resize(nrows * RTX_MAX_DEPTH);
+    unsigned nt = std::min<unsigned>(8, std::max(1u, std::thread::hardware_concurrency()));
+    if (nq < 4096) nt = 1;
+    if (nt == 1) {
+        finalise_range(ix, 0, nq);
+    } else {
+        std::vector<std::thread> th;
+        for (unsigned i = 0; i < nt; i++)
+            th.emplace_back(finalise_range, ix, nq * i / nt, nq * (i + 1) / nt);
+        for (auto &t : th) t.join();
+    }
+    out->n_queries = (uint32_t)nq;
+    out->n_rows = nrows;
+    out->t = ix->h_t.data();
+    out->status = ix->h_status.data();
+    out->global_signal = ix->h_gs.data();
+    out->row_off = ix->v_row_off.data();
+    out->row_lineage = ix->v_row_lineage.data();
+    out->row_node = ix->v_row_node.data();
+    out->row_depth = ix->v_row_depth.data();
+    out->row_conf = ix->v_row_conf.data();
+    out->row_local_signal = ix->v_row_local.data();
+    return RTX_OK;
+}
+
+int rtx_classify_batch(rtx_index *index, uint64_t n_queries, const uint8_t *bases, const uint64_t *base_off,
+                       const uint32_t *exact_ids, const uint64_t *exact_off, uint32_t flags, rtx_result_view *out) {
+    int rc = rtx_batch_upload(index, n_queries, bases, base_off, exact_ids, exact_off);
+    if (rc) return rc;
+    if ((rc = rtx_batch_run(index, flags))) return rc;
+    return rtx_batch_download(index, out);
+}
+
+int rtx_batch_stage_times(rtx_index *ix, float ms[RTX_NUM_STAGES], uint32_t launches[RTX_NUM_STAGES]) {
+    int rc = bind(ix);
+    if (rc) return rc;
+    if (!ix->synced) { set_error("rtx_batch_stage_times: batch not synchronised"); return RTX_ERR_STATE; }
+    for (int s = 0; s < RTX_NUM_STAGES; s++) { ms[s] = 0.f; launches[s] = 0; }
+    for (uint32_t sb = 0; sb < ix->n_sub_last; sb++)
+        for (int s = 0; s < RTX_NUM_STAGES; s++) {
+            float t = 0.f;
+            RTX_HIP(hipEventElapsedTime(&t, ix->events[((size_t)sb * RTX_NUM_STAGES + s) * 2],
+                                        ix->events[((size_t)sb * RTX_NUM_STAGES + s) * 2 + 1]));
+            ms[s] += t;
+            launches[s]++;
+        }
+    return RTX_OK;
+}
+
+int rtx_batch_work(rtx_index *ix, uint64_t *sum_hits, uint64_t *sum_query_bytes, uint64_t *bitmap_bytes_read) {
+    if (!ix) { set_error("null index handle"); return RTX_ERR_INVALID; }
+    if (ix->h_hq.size() != ix->n_q) { set_error("rtx_batch_work: call rtx_batch_download first"); return RTX_ERR_STATE; }
+    uint64_t h = 0, b = 0;
+    const uint64_t row_bytes = (ix->n_refs + 7) / 8;
+    for (uint64_t q = 0; q < ix->n_q; q++) {
+        h += ix->h_hq[q];
+        b += (uint64_t)ix->h_nrows_all[q] * row_bytes;
+    }
+    if (sum_hits) *sum_hits = h;
+    if (sum_query_bytes) *sum_query_bytes = ix->sum_query_bytes;
+    if (bitmap_bytes_read) *bitmap_bytes_read = b;
+    return RTX_OK;
+}
+
+// ---- debug taps -------------------------------------------------------------------------
+static int debug_slot(rtx_index *ix, uint64_t query, uint32_t *slot) {
+    int rc = bind(ix);
+    if (rc) return rc;
+    if (!ix->synced) { set_error("debug tap: batch not synchronised"); return RTX_ERR_STATE; }
+    const uint64_t last0 = (ix->n_q - 1) / ix->sub_batch * ix->sub_batch;
+    if (query >= ix->n_q || query < last0) { set_error("debug tap: query %llu not in the last sub-batch", (unsigned long long)query); return RTX_ERR_INVALID; }
+    *slot = (uint32_t)(query - last0);
+    return RTX_OK;
+}
+
+int rtx_debug_kmers(rtx_index *ix, uint64_t query, uint16_t *kmers, uint32_t *t) {
+    uint32_t slot;
+    int rc = debug_slot(ix, query, &slot);
+    if (rc) return rc;
+    uint32_t tt = 0;
+    RTX_HIP(hipMemcpy(&tt, ix->d_t.p + slot, 4, hipMemcpyDeviceToHost));
+    if (t) *t = tt;
+    if (kmers && tt) RTX_HIP(hipMemcpy(kmers, ix->d_kmers.p + (size_t)slot * ix->kstride, std::min(tt, ix->kstride) * 2, hipMemcpyDeviceToHost));
+    return RTX_OK;
+}
+
+int rtx_debug_hit_counts(rtx_index *ix, uint64_t query, uint16_t *counts) {
+    uint32_t slot;
+    int rc = debug_slot(ix, query, &slot);
+    if (rc) return rc;
+    RTX_HIP(hipMemcpy(counts, ix->d_counts.p + (size_t)slot * ix->npad, ix->n_refs * 2, hipMemcpyDeviceToHost));
+    return RTX_OK;
+}
+
+int rtx_debug_prob_table(rtx_index *ix, uint64_t query, double *table_over_z, double *z) {
+    uint32_t slot;
+    int rc = debug_slot(ix, query, &slot);
+    if (rc) return rc;
+    uint32_t tt = 0;
+    RTX_HIP(hipMemcpy(&tt, ix->d_t.p + slot, 4, hipMemcpyDeviceToHost));
+    std::vector<uint32_t> hist(tt + 1);
+    RTX_HIP(hipMemcpy(hist.data(), ix->d_hist.p + (size_t)slot * ix->hstride, (tt + 1) * 4, hipMemcpyDeviceToHost));
+    RTX_HIP(hipMemcpy(table_over_z, ix->d_table_z.p + (size_t)slot * ix->hstride, (tt + 1) * 8, hipMemcpyDeviceToHost));
+    for (uint32_t m = 0; m <= tt; m++)
+        if (!hist[m]) table_over_z[m] = 0.0;  // entries of absent counts are never written
+    if (z) RTX_HIP(hipMemcpy(z, ix->d_z.p + query, 8, hipMemcpyDeviceToHost));
+    return RTX_OK;
+}
+
+int rtx_debug_probs(rtx_index *ix, uint64_t query, double *probs) {
+    uint32_t slot;
+    int rc = debug_slot(ix, query, &slot);
+    if (rc) return rc;
+    if ((rc = ix->d_probs_dbg.alloc(ix->n_refs))) return rc;
+    launch_probs_expand(ix->stream, ix->d_counts.p + (size_t)slot * ix->npad, ix->d_table_z.p + (size_t)slot * ix->hstride,
+                        ix->n_refs, ix->d_probs_dbg.p);
+    RTX_HIP(hipStreamSynchronize(ix->stream));
+    RTX_HIP(hipMemcpy(probs, ix->d_probs_dbg.p, ix->n_refs * 8, hipMemcpyDeviceToHost));
+    return RTX_OK;
+}
+
+// Runs taxon_prefix + lineage_walk + host finalisation on a caller-supplied probability vector
+// (Lineage::new(label, tree, probs).evaluate(), lineage.rs:61-112), so that the reference's
+// lineage KATs (lineage.rs:192-334) pin the device walk directly.  n_refs <= 65535.
+int rtx_debug_evaluate(rtx_index *ix, const double *probs, rtx_result_view *out) {
+    int rc = bind(ix);
+    if (rc) return rc;
+    if (!probs || !out) { set_error("null argument"); return RTX_ERR_INVALID; }
+    const uint64_t N = ix->n_refs;
+    if (N > 65535) { set_error("rtx_debug_evaluate supports at most 65535 references"); return RTX_ERR_INVALID; }
+    ix->uploaded = ix->ran = ix->synced = false;
+    if ((rc = prepare_workspace(ix, 1, std::max<uint64_t>(N, 8), 0))) return rc;
+    ix->sum_query_bytes = 0;
+    std::vector<uint16_t> counts(ix->npad, 0);
+    for (uint64_t r = 0; r < N; r++) counts[r] = (uint16_t)r;  // count_r = r, table[r] = probs[r]
+    double gs = 0.0;
+    for (uint64_t r = 0; r < N; r++) { const double d = probs[r] - 1.0 / (double)N; gs += d * d; }
+    gs = std::sqrt(gs);
+    const uint8_t ok = RTX_Q_OK;
+    hipStream_t s = ix->stream;
+    RTX_HIP(hipMemcpy(ix->d_counts.p, counts.data(), ix->npad * 2, hipMemcpyHostToDevice));
+    RTX_HIP(hipMemcpy(ix->d_table_z.p, probs, N * 8, hipMemcpyHostToDevice));
+    RTX_HIP(hipMemcpy(ix->d_status.p, &ok, 1, hipMemcpyHostToDevice));
+    RTX_HIP(hipMemcpy(ix->d_gs.p, &gs, 8, hipMemcpyHostToDevice));
+    RTX_HIP(hipMemset(ix->d_t_all.p, 0, 4));
+    RTX_HIP(hipMemset(ix->d_nrows_all.p, 0, 4));
+    RTX_HIP(hipMemset(ix->d_hq.p, 0, 8));
+    RTX_HIP(hipMemset(ix->d_z.p, 0, 8));
+    RTX_HIP(hipMemset(ix->d_cursor.p, 0, 8));
+    RTX_HIP(hipMemset(ix->d_flags.p, 0, 4));
+    PrefixParams fp{};
+    fp.status = ix->d_status.p;
+    fp.q0 = 0;
+    fp.counts = ix->d_counts.p;
+    fp.npad = ix->npad;
+    fp.table_z = ix->d_table_z.p;
+    fp.hstride = ix->hstride;
+    fp.n_refs = N;
+    fp.bnd_bits = ix->d_bnd_bits.p;
+    fp.bnd_rank = ix->d_bnd_rank.p;
+    fp.prefix = ix->d_prefix.p;
+    fp.n_bnd = ix->n_bnd;
+    launch_taxon_prefix(s, fp, 1);
+    WalkParams wp{};
+    wp.status = ix->d_status.p;
+    wp.q0 = 0;
+    wp.prefix = ix->d_prefix.p;
+    wp.n_bnd = ix->n_bnd;
+    wp.blo = ix->d_blo.p;
+    wp.bhi = ix->d_bhi.p;
+    wp.first_child = ix->d_first.p;
+    wp.n_children = ix->d_nch.p;
+    wp.type = ix->d_type.p;
+    wp.arena = ix->d_arena.p;
+    wp.arena_cap = ix->arena_cap;
+    wp.arena_cursor = ix->d_cursor.p;
+    wp.n_rows = ix->d_n_rows.p;
+    wp.row_start = ix->d_row_start.p;
+    wp.flags_out = ix->d_flags.p;
+    launch_lineage_walk(s, wp, 1);
+    RTX_HIP(hipGetLastError());
+    ix->n_sub_last = 0;
+    ix->ran = true;
+    ix->last_flags = 0;
+    return rtx_batch_download(ix, out);
+}
+
+}  // extern "C"

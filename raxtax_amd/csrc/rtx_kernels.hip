@@ -1,0 +1,658 @@
+// Hand-written gfx950 (CDNA4, wave64) kernels of the raxtax classification hot path.
+//
+//   bitmap_build      Tree.k_mer_map (CSR)  -> per-k-mer reference bitmaps   (index build, once)
+//   kmer_extract      src/utils.rs:17-40    -> sorted distinct 8-mers, t, bitmap-row list
+//   hit_count         src/raxtax.rs:41,58-68 + prob.rs:13-19 -> count[r] (u16), histogram
+//   prob_table        src/prob.rs:20-103    -> table[m]/Z, Z, global signal
+//   taxon_prefix      src/lineage.rs:61-66  -> prefix sums of p_r at taxonomy boundaries
+//   lineage_walk      src/lineage.rs:114-179 -> result rows (node, rounded confidences)
+//
+// No MFMA: the path is integer bit-slicing + f64 VALU, bounded by HBM/L2 bandwidth
+// (DESIGN.md has the roofline of every kernel).  Wave = 64 lanes everywhere.
+#include <hip/hip_runtime.h>
+
+#include "rtx_kernels.hpp"
+#include "rtx_math.hpp"
+
+namespace rtx {
+
+static constexpr uint32_t kEmptyRow = 0xFFFFFFFFu;
+
+// ---------------------------------------------------------------------------
+// wave helpers (wave64)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
+
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t o = __shfl_up(v, d, 64);
+        if ((int)lane_id() >= d) v += o;
+    }
+    return v;
+}
+
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;  // every lane holds the total (fixed butterfly order: deterministic)
+}
+
+__device__ __forceinline__ double wave_incl_scan_f64(double v) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        double o = __shfl_up(v, d, 64);
+        if ((int)lane_id() >= d) v += o;
+    }
+    return v;
+}
+
+// ---------------------------------------------------------------------------
+// bitmap_build: one workgroup per k-mer; sets bit r of row row_of[k] for every posting r.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bitmap_build_kernel(const uint64_t *__restrict__ off,
+                                                           const uint32_t *__restrict__ post,
+                                                           const uint32_t *__restrict__ row_of,
+                                                           uint32_t *__restrict__ bitmap, uint32_t stride_words) {
+    const uint32_t k = blockIdx.x;
+    const uint32_t row = row_of[k];
+    if (row == kEmptyRow) return;
+    const uint64_t b = off[k], e = off[k + 1];
+    uint32_t *dst = bitmap + (size_t)row * stride_words;
+    for (uint64_t i = b + threadIdx.x; i < e; i += blockDim.x) {
+        const uint32_t r = post[i];
+        atomicOr(&dst[r >> 5], 1u << (r & 31u));
+    }
+}
+
+// ---------------------------------------------------------------------------
+// kmer_extract (src/utils.rs:17-40): one wave per query.
+// A 65536-bit set in LDS gives HashSet semantics; reading it out word by word in
+// ascending order gives `.sorted()`.  Also emits, for hit_count, the list of bitmap rows
+// of the k-mers that occur in the index (padded with the all-zero row to a multiple of
+// 16 plus one look-ahead group) and H_q = sum of posting-list lengths.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void kmer_extract_kernel(KmerParams p) {
+    __shared__ uint32_t bm[2048];
+    const uint32_t q = blockIdx.x;
+    const uint32_t lane = threadIdx.x;
+    const uint64_t gq = p.q0 + q;
+    const uint64_t b0 = p.base_off[gq];
+    const uint64_t len = p.base_off[gq + 1] - b0;
+    const uint8_t *seq = p.bases + b0;
+
+    for (uint32_t i = lane; i < 2048; i += 64) bm[i] = 0;
+    __syncthreads();
+
+    for (uint64_t w = lane; w + 8 <= len; w += 64) {
+        uint32_t k = 0;
+        bool ok = true;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const uint32_t c = seq[w + j];
+            // one-hot nibble {1,2,4,8} -> {0,1,2,3}; everything else invalidates the window
+            ok = ok && (c == 1u || c == 2u || c == 4u || c == 8u);
+            k |= ((uint32_t)__ffs((int)c) - 1u) << (14 - 2 * j);
+        }
+        if (ok) atomicOr(&bm[(k & 0xFFFFu) >> 5], 1u << (k & 31u));
+    }
+    __syncthreads();
+
+    // ascending read-out: round r covers words r*64 .. r*64+63 (conflict-free LDS reads)
+    uint16_t *kout = p.kmers + (size_t)q * p.kstride;
+    uint32_t base = 0;
+    for (uint32_t r = 0; r < 32; r++) {
+        uint32_t word = bm[r * 64 + lane];
+        const uint32_t cnt = __popc(word);
+        const uint32_t incl = wave_incl_scan_u32(cnt);
+        uint32_t pos = base + incl - cnt;
+        const uint32_t kbase = (r * 64 + lane) * 32;
+        while (word) {
+            const uint32_t bit = __ffs((int)word) - 1;
+            word &= word - 1;
+            if (pos < p.kstride) kout[pos] = (uint16_t)(kbase + bit);
+            pos++;
+        }
+        base += __shfl(incl, 63, 64);
+    }
+    const uint32_t t = base;
+    __syncthreads();  // kout visible to the whole wave
+
+    // rows of k-mers present in the index, in ascending k-mer order
+    uint32_t *rout = p.rows + (size_t)q * p.rstride;
+    uint32_t nrows = 0;
+    unsigned long long hq = 0;
+    const uint32_t tt = t < p.kstride ? t : p.kstride;
+    for (uint32_t i0 = 0; i0 < tt; i0 += 64) {
+        const uint32_t i = i0 + lane;
+        uint32_t row = kEmptyRow;
+        if (i < tt) {
+            const uint32_t k = kout[i];
+            row = p.row_of[k];
+            hq += p.list_len[k];
+        }
+        const unsigned long long m = __ballot(row != kEmptyRow);
+        if (row != kEmptyRow) rout[nrows + __popcll(m & ((1ull << lane) - 1ull))] = row;
+        nrows += (uint32_t)__popcll(m);
+    }
+    const uint32_t padded = ((nrows + 15u) & ~15u) + 8u;
+    for (uint32_t i = nrows + lane; i < padded; i += 64) rout[i] = p.zero_row;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) hq += __shfl_xor(hq, d, 64);
+    if (lane == 0) {
+        p.t[q] = t;
+        p.nrows[q] = nrows;
+        p.hq[gq] = hq;
+        p.t_all[gq] = t;
+        p.nrows_all[gq] = nrows;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// hit_count (src/raxtax.rs:41,58-68): one wave per (query, 8192-reference tile).
+// Lane l owns references [tile*8192 + l*128, +128): 16 bytes of every bitmap row, so a
+// wave reads 1 KiB contiguous per row (one global_load_dwordx4 per lane, row base in
+// SGPRs).  Rows are folded eight at a time into NP bit planes per 32-reference word
+// (rtx_math.hpp).  The epilogue zeroes exact matches (raxtax.rs:65-68), unpacks the planes
+// to u16 counts, stores them, and builds the hit-count histogram of prob.rs:13-19 with
+// LDS atomics, flushed with one global atomic per non-empty bin.
+// blockIdx.x = query (fast) so that concurrently resident waves work on the same
+// reference tile and popular rows are served from L2.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void load8(uint4 (&buf)[8], const char *__restrict__ bm, size_t stride,
+                                      const uint32_t *__restrict__ rows) {
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const uint32_t row = rows[j];  // wave-uniform -> scalar load
+        buf[j] = *reinterpret_cast<const uint4 *>(bm + (size_t)row * stride);
+    }
+}
+
+template <int NP>
+__device__ __forceinline__ void add8(uint32_t (&pl)[4][NP], const uint4 (&a)[8]) {
+    planes_add8<NP>(pl[0], a[0].x, a[1].x, a[2].x, a[3].x, a[4].x, a[5].x, a[6].x, a[7].x);
+    planes_add8<NP>(pl[1], a[0].y, a[1].y, a[2].y, a[3].y, a[4].y, a[5].y, a[6].y, a[7].y);
+    planes_add8<NP>(pl[2], a[0].z, a[1].z, a[2].z, a[3].z, a[4].z, a[5].z, a[6].z, a[7].z);
+    planes_add8<NP>(pl[3], a[0].w, a[1].w, a[2].w, a[3].w, a[4].w, a[5].w, a[6].w, a[7].w);
+}
+
+template <int NP>
+__global__ __launch_bounds__(64) void hit_count_kernel(HitParams p) {
+    extern __shared__ uint32_t hist_lds[];
+    const uint32_t q = blockIdx.x, tile = blockIdx.y, lane = threadIdx.x;
+    const uint32_t t = p.t[q];
+    for (uint32_t i = lane; i <= t; i += 64) hist_lds[i] = 0;
+
+    const uint32_t col = tile * 1024u + lane * 16u;
+    const bool active = col < p.stride_bytes;
+    uint32_t pl[4][NP];
+#pragma unroll
+    for (int w = 0; w < 4; w++)
+#pragma unroll
+        for (int b = 0; b < NP; b++) pl[w][b] = 0;
+
+    if (active) {
+        const uint32_t *rows = p.rows + (size_t)q * p.rstride;
+        const uint32_t npairs = (p.nrows[q] + 15u) >> 4;
+        const char *bm = reinterpret_cast<const char *>(p.bitmap) + col;
+        const size_t stride = p.stride_bytes;
+        uint4 A[8], B[8];
+        load8(A, bm, stride, rows);
+        for (uint32_t g = 0; g < npairs; g++) {
+            load8(B, bm, stride, rows + g * 16 + 8);
+            add8<NP>(pl, A);
+            load8(A, bm, stride, rows + g * 16 + 16);  // look-ahead group (zero rows past the end)
+            add8<NP>(pl, B);
+        }
+    }
+    __syncthreads();
+    if (!active) return;  // single-wave workgroup: no further barriers below need these lanes
+
+    const uint32_t ref0 = tile * 8192u + lane * 128u;
+    if (p.flags & RTX_SKIP_EXACT_MATCHES) {  // raxtax.rs:65-68
+        const uint64_t e0 = p.exact_off[p.q0 + q], e1 = p.exact_off[p.q0 + q + 1];
+        for (uint64_t e = e0; e < e1; e++) {
+            const uint32_t id = p.exact_ids[e];
+            if (id >= ref0 && id < ref0 + 128u) {
+                const uint32_t w = (id - ref0) >> 5, msk = ~(1u << (id & 31u));
+#pragma unroll
+                for (int ww = 0; ww < 4; ww++)
+                    if ((uint32_t)ww == w) {
+#pragma unroll
+                        for (int b = 0; b < NP; b++) pl[ww][b] &= msk;
+                    }
+            }
+        }
+    }
+    const uint32_t nvalid = ref0 >= p.n_refs ? 0u : ((p.n_refs - ref0) < 128u ? (uint32_t)(p.n_refs - ref0) : 128u);
+    uint16_t *out = p.counts + (size_t)q * p.npad + ref0;
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+#pragma unroll
+        for (int g2 = 0; g2 < 4; g2++) {  // 8 references per 16-byte store
+            uint32_t lo0, hi0, lo1, hi1;
+            planes_unpack4<NP>(pl[w], 2 * g2, lo0, hi0);
+            planes_unpack4<NP>(pl[w], 2 * g2 + 1, lo1, hi1);
+            uint4 st;
+            // bytes (lo.b0, hi.b0, lo.b1, hi.b1) -> two u16 counts
+            st.x = __builtin_amdgcn_perm(hi0, lo0, 0x05010400u);
+            st.y = __builtin_amdgcn_perm(hi0, lo0, 0x07030602u);
+            st.z = __builtin_amdgcn_perm(hi1, lo1, 0x05010400u);
+            st.w = __builtin_amdgcn_perm(hi1, lo1, 0x07030602u);
+            *reinterpret_cast<uint4 *>(out + w * 32 + g2 * 8) = st;
+            const uint32_t rbase = w * 32 + g2 * 8;
+            const uint32_t cw[4] = {st.x, st.y, st.z, st.w};
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const uint32_t c = (cw[j >> 1] >> ((j & 1) * 16)) & 0xFFFFu;
+                if (rbase + j < nvalid) atomicAdd(&hist_lds[c], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    uint32_t *hist = p.hist + (size_t)q * p.hstride;
+    for (uint32_t m = lane; m <= t; m += 64) {
+        const uint32_t v = hist_lds[m];
+        if (v) atomicAdd(&hist[m], v);
+    }
+}
+
+template __global__ void hit_count_kernel<10>(HitParams);
+template __global__ void hit_count_kernel<12>(HitParams);
+template __global__ void hit_count_kernel<16>(HitParams);
+
+// ---------------------------------------------------------------------------
+// prob_table (src/prob.rs:8-103): one 256-thread workgroup per query.
+// Lanes <-> distinct hit counts m (ascending), sequential over i = 0..n.
+//   pass 1: ln cmf_m(i) for every (m, i); prod(i) = sum_m hist[m] ln cmf_m(i)  (prob.rs:62-73)
+//           reduced over lanes by a fixed butterfly, over waves through per-wave LDS slots
+//           (deterministic, unlike the reference's ahash iteration order).
+//   pass 2: table[m] = sum_i pmf_m(i) * exp(prod(i)) / cmf_m(i)                (prob.rs:74-90)
+// then Z = sum_m hist[m] table[m] (= probs_sum, prob.rs:97), table/Z (prob.rs:99-102) and the
+// global signal ||p - 1/N||_2 (lineage.rs:86-90) from the histogram.
+// LDS (dynamic): slots[4][n1] | P[n1] | inv[t+n1+1] | red[16] | ms[t+1] (u16)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void prob_table_kernel(ProbParams p) {
+    extern __shared__ double smem[];
+    __shared__ uint32_t s_D;
+    const uint32_t q = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint64_t gq = p.q0 + q;
+    const uint32_t t = p.t[q];
+    const uint32_t n = t >> 1;  // num_trials = k_mers.len() / 2, raxtax.rs:57
+    const uint32_t n1 = n + 1;
+    const uint32_t n1max = p.n1max;
+    double *slots = smem;
+    double *Pi = slots + 4 * (size_t)n1max;
+    double *inv = Pi + n1max;
+    double *red = inv + (p.tmax + n1max + 1);
+    uint16_t *ms = reinterpret_cast<uint16_t *>(red + 16);
+    const uint32_t *hist = p.hist + (size_t)q * p.hstride;
+    double *tz = p.table_z + (size_t)q * p.hstride;
+    const double *lf = p.lnfact;
+
+    if (t == 0) {  // reference: u64 underflow at prob.rs:21
+        if (tid == 0) { p.status[gq] = RTX_Q_NO_KMERS; p.z[gq] = 0.0; p.gs[gq] = 0.0; }
+        return;
+    }
+    // distinct counts, ascending (wave 0 compacts)
+    if (wave == 0) {
+        uint32_t D = 0;
+        for (uint32_t m0 = 0; m0 <= t; m0 += 64) {
+            const uint32_t m = m0 + lane;
+            const bool has = m <= t && hist[m] != 0;
+            const unsigned long long bal = __ballot(has);
+            if (has) ms[D + __popcll(bal & ((1ull << lane) - 1ull))] = (uint16_t)m;
+            D += (uint32_t)__popcll(bal);
+        }
+        if (lane == 0) s_D = D;
+    }
+    for (uint32_t x = tid + 1; x <= t + n; x += 256) inv[x] = 1.0 / (double)x;
+    for (uint32_t i = tid; i < 4 * n1; i += 256) slots[i] = 0.0;
+    __syncthreads();
+    const uint32_t D = s_D;
+    const double ln_total = ln_binom_tab(lf, t + n - 1, n);  // prob.rs:20-23
+    const bool any_full = ms[D - 1] == t;                    // prob.rs:24-26
+
+    if (any_full) {  // prob.rs:27-41
+        for (uint32_t j = tid; j < D; j += 256) {
+            const uint32_t m = ms[j];
+            tz[m] = only_last_pmf_tab(lf, t, n, m, ln_total);
+        }
+    } else {
+        if (n == 0) {  // reference: zip_eq length mismatch at prob.rs:162
+            if (tid == 0) { p.status[gq] = RTX_Q_NO_KMERS; p.z[gq] = 0.0; p.gs[gq] = 0.0; }
+            return;
+        }
+        const uint32_t nslab = (D + 255u) >> 8;
+        // ---- pass 1
+        for (uint32_t s = 0; s < nslab; s++) {
+            const uint32_t j = s * 256 + tid;
+            const uint32_t m = j < D ? ms[j] : 0u;
+            const bool act = m != 0;
+            if (!__any(act)) continue;  // whole wave idle in this slab
+            const double h = act ? (double)hist[m] : 0.0;
+            PmfState st{0.0, 0.0, 0};
+            if (act) st = pmf_start(lf, t, n, m, ln_total);
+            double L = act ? pmf_ln_cmf(st) : 0.0;
+            for (uint32_t i = 0; i <= n; i++) {
+                if (i > 0 && act) {
+                    const double c_old = st.c;
+                    const int k_old = st.k;
+                    pmf_step(st, inv, t, n, m, i);
+                    // ln cmf only changes when the sum does
+                    if (st.k > 0) L = neg_inf();
+                    else if (st.c != c_old || k_old != 0) L = log(st.c);
+                }
+                const double contrib = wave_sum_f64(act ? h * L : 0.0);
+                if (lane == 0) slots[wave * n1 + i] += contrib;
+            }
+        }
+        __syncthreads();
+        for (uint32_t i = tid; i <= n; i += 256) {
+            const double prod = ((slots[i] + slots[n1 + i]) + slots[2 * n1 + i]) + slots[3 * n1 + i];
+            Pi[i] = exp(prod);  // exp(-inf) = 0
+        }
+        __syncthreads();
+        // ---- pass 2
+        for (uint32_t s = 0; s < nslab; s++) {
+            const uint32_t j = s * 256 + tid;
+            if (j >= D) continue;
+            const uint32_t m = ms[j];
+            if (m == 0) {  // pmf = [1,0,...], cmf = 1: table[0] = exp(prod(0))
+                tz[0] = Pi[0];
+                continue;
+            }
+            PmfState st = pmf_start(lf, t, n, m, ln_total);
+            double acc = 0.0;
+            for (uint32_t i = 0; i <= n; i++) {
+                if (i > 0) pmf_step(st, inv, t, n, m, i);
+                const double P = Pi[i];
+                if (P > 0.0 && st.k == 0 && st.c > 0.0) acc += st.v * P / st.c;
+            }
+            tz[m] = acc;
+        }
+    }
+    __syncthreads();
+    // Z = probs_sum (prob.rs:97) grouped by count value; fixed reduction order
+    double part = 0.0;
+    for (uint32_t j = tid; j < D; j += 256) {
+        const uint32_t m = ms[j];
+        part += (double)hist[m] * tz[m];
+    }
+    part = wave_sum_f64(part);
+    if (lane == 0) red[wave] = part;
+    __syncthreads();
+    const double Z = (red[0] + red[1]) + (red[2] + red[3]);
+    __syncthreads();
+    const double inv_n = 1.0 / (double)p.n_refs;
+    double g = 0.0;
+    for (uint32_t j = tid; j < D; j += 256) {
+        const uint32_t m = ms[j];
+        const double v = tz[m] / Z;  // prob.rs:99-102
+        tz[m] = v;
+        const double d = v - inv_n;
+        g += (double)hist[m] * d * d;
+    }
+    g = wave_sum_f64(g);
+    if (lane == 0) red[8 + wave] = g;
+    __syncthreads();
+    if (tid == 0) {
+        p.z[gq] = Z;
+        p.gs[gq] = sqrt((red[8] + red[9]) + (red[10] + red[11]));
+        p.status[gq] = RTX_Q_OK;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// taxon_prefix (src/lineage.rs:61-66): P[j] = sum_{r < bnd[j]} p_r, p_r = table[count_r]/Z,
+// sampled at the taxonomy boundaries only (every node range is [bnd[a], bnd[b])).
+// One 256-thread workgroup per query, 8 references per thread per sweep.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void taxon_prefix_kernel(PrefixParams p) {
+    __shared__ double wsum[4];
+    const uint32_t q = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint64_t gq = p.q0 + q;
+    double *P = p.prefix + (size_t)q * p.n_bnd;
+    if (p.status[gq] != RTX_Q_OK) return;
+    const double *tz = p.table_z + (size_t)q * p.hstride;
+    const uint16_t *cnt = p.counts + (size_t)q * p.npad;
+    if (tid == 0) P[0] = 0.0;
+    double carry = 0.0;
+    const uint64_t n = p.n_refs;
+    for (uint64_t base = 0; base < n; base += 2048) {
+        const uint64_t r0 = base + (uint64_t)tid * 8;
+        double s[8];
+        double run = 0.0;
+        if (r0 < n) {
+            const uint4 cv = *reinterpret_cast<const uint4 *>(cnt + r0);
+            const uint32_t cw[4] = {cv.x, cv.y, cv.z, cv.w};
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const uint32_t c = (cw[j >> 1] >> ((j & 1) * 16)) & 0xFFFFu;
+                const double v = (r0 + j < n) ? tz[c] : 0.0;
+                run += v;
+                s[j] = run;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; j++) s[j] = 0.0;
+        }
+        const double incl = wave_incl_scan_f64(run);
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        double off = carry + (incl - run);
+        double tot = 0.0;
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            const double ws = wsum[w];
+            if ((uint32_t)w < wave) off += ws;
+            tot += ws;
+        }
+        carry += tot;
+        if (r0 < n) {
+            const uint32_t chunk = (uint32_t)(r0 >> 3);
+            uint32_t bits = p.bnd_bits[chunk];
+            if (bits) {
+                uint32_t rank = p.bnd_rank[chunk];
+                while (bits) {
+                    const int j = __ffs((int)bits) - 1;
+                    bits &= bits - 1;
+                    P[rank++] = off + s[j];
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------
+// lineage_walk (src/lineage.rs:114-179): one wave per query, explicit DFS stack; the 64
+// lanes evaluate 64 children of the current node at once (confidence = P[hi]-P[lo],
+// lineage.rs:114-117; rounding lineage.rs:128-129).  Rows (node id + per-level rounded
+// confidences in hundredths) are staged in LDS and appended to a global arena with one
+// atomic per query.  Sorting (lineage.rs:91-93) and the local signal happen on the host.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ double node_conf(const double *__restrict__ P, const uint32_t *__restrict__ blo,
+                                            const uint32_t *__restrict__ bhi, uint32_t node) {
+    return P[bhi[node]] - P[blo[node]];
+}
+
+__global__ __launch_bounds__(64) void lineage_walk_kernel(WalkParams p) {
+    __shared__ uint32_t st_node[RTX_MAX_DEPTH + 1];
+    __shared__ uint32_t st_cursor[RTX_MAX_DEPTH + 1];
+    __shared__ uint8_t st_nosig[RTX_MAX_DEPTH + 1];
+    __shared__ uint8_t st_pushed[RTX_MAX_DEPTH + 1];
+    __shared__ uint8_t kpath[RTX_MAX_DEPTH + 1];
+    __shared__ DevRow rows[kWalkMaxRows];
+    const uint32_t q = blockIdx.x, lane = threadIdx.x;
+    const uint64_t gq = p.q0 + q;
+    if (p.status[gq] != RTX_Q_OK) {
+        if (lane == 0) { p.n_rows[gq] = 0; p.row_start[gq] = 0; }
+        return;
+    }
+    const double *P = p.prefix + (size_t)q * p.n_bnd;
+    uint32_t nrows = 0;
+    bool overflow = false;
+
+    auto emit = [&](uint32_t node, uint32_t depth) {
+        if (nrows < kWalkMaxRows) {
+            if (lane == 0) rows[nrows].node = node;
+            if (lane < RTX_MAX_DEPTH) rows[nrows].k[lane] = lane < depth ? kpath[lane] : 0;
+        } else {
+            overflow = true;
+        }
+        nrows++;
+    };
+
+    int depth = 0;
+    if (lane == 0) { st_node[0] = 0; st_cursor[0] = 0; st_nosig[0] = 1; st_pushed[0] = 0; }
+    __syncthreads();
+    while (depth >= 0) {
+        const uint32_t node = st_node[depth];
+        uint32_t cur = st_cursor[depth];
+        const uint32_t nch = p.n_children[node], fc = p.first_child[node];
+        int found = -1;
+        uint32_t kval = 0;
+        while (cur < nch) {
+            const uint32_t idx = cur + lane;
+            int kk = 0;
+            if (idx < nch) {
+                const double conf = node_conf(P, p.blo, p.bhi, fc + idx);
+                const double r = round(conf * 100.0);  // f64::round: half away from zero
+                kk = r > 255.0 ? 255 : (r < -255.0 ? -255 : (int)r);
+            }
+            const unsigned long long bal = __ballot(kk != 0);
+            if (bal) {
+                const int first = __ffsll((long long)bal) - 1;
+                found = (int)cur + first;
+                const int kf = __shfl(kk, first, 64);
+                kval = (uint32_t)(kf < 0 ? 255 : kf);
+                if (kf < 0 || kf > 200) overflow = true;  // cannot happen for probabilities
+                break;
+            }
+            cur += 64;
+        }
+        __syncthreads();
+        if (found >= 0) {
+            if (depth + 1 > (int)RTX_MAX_DEPTH) {  // guarded at index creation
+                overflow = true;
+                break;
+            }
+            if (lane == 0) {
+                st_cursor[depth] = (uint32_t)found + 1;
+                st_nosig[depth] = 0;
+                kpath[depth] = (uint8_t)kval;
+                st_node[depth + 1] = fc + (uint32_t)found;
+                st_cursor[depth + 1] = 0;
+                st_nosig[depth + 1] = 1;
+                st_pushed[depth + 1] = 0;
+            }
+            depth++;
+            __syncthreads();
+            continue;
+        }
+        // children exhausted
+        bool pushed = st_pushed[depth] != 0;
+        if (st_nosig[depth] && p.type[node] == kInner) {  // lineage.rs:151-177
+            uint32_t cn = node;
+            uint32_t d = (uint32_t)depth;
+            while (p.type[cn] == kInner && p.n_children[cn] > 0) {
+                const uint32_t cnch = p.n_children[cn], cfc = p.first_child[cn];
+                // Iterator::max_by keeps the LAST maximum
+                double best = -INFINITY;
+                uint32_t besti = 0;
+                bool have = false;
+                for (uint32_t idx = lane; idx < cnch; idx += 64) {
+                    const double v = node_conf(P, p.blo, p.bhi, cfc + idx);
+                    if (!have || !(v < best)) { best = v; besti = idx; have = true; }
+                }
+#pragma unroll
+                for (int s = 32; s >= 1; s >>= 1) {
+                    const double ov = __shfl_xor(best, s, 64);
+                    const uint32_t oi = __shfl_xor(besti, s, 64);
+                    const int oh = __shfl_xor((int)have, s, 64);
+                    if (oh && (!have || ov > best || (ov == best && oi > besti))) { best = ov; besti = oi; have = true; }
+                }
+                cn = cfc + besti;
+                if (d >= RTX_MAX_DEPTH) { overflow = true; break; }
+                if (lane == 0) kpath[d] = 1;  // 1.0 / rounding_factor
+                d++;
+            }
+            __syncthreads();
+            emit(cn, d);
+            pushed = true;
+        }
+        depth--;
+        if (depth >= 0) {
+            // back in the parent: lineage.rs:141-149
+            if (!pushed && p.type[node] == kTaxon) {
+                emit(node, (uint32_t)depth + 1);
+                pushed = true;
+            }
+            if (pushed && lane == 0) st_pushed[depth] = 1;
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    const uint32_t keep = nrows < kWalkMaxRows ? nrows : kWalkMaxRows;
+    unsigned long long start = 0;
+    if (lane == 0) start = atomicAdd(p.arena_cursor, (unsigned long long)keep);
+    start = __shfl(start, 0, 64);
+    if (start + keep <= p.arena_cap) {
+        // DevRow = 9 dwords
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(rows);
+        uint32_t *dst = reinterpret_cast<uint32_t *>(p.arena + start);
+        for (uint32_t i = lane; i < keep * (uint32_t)(sizeof(DevRow) / 4); i += 64) dst[i] = src[i];
+    } else if (lane == 0) {
+        atomicOr(p.flags_out, 1u);  // arena overflow: host re-runs with a larger arena
+    }
+    if (lane == 0) {
+        p.n_rows[gq] = keep;
+        p.row_start[gq] = start;
+        if (overflow) atomicOr(p.flags_out, 2u);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// debug tap: p_r = table[count_r]/Z for one query (rtx_debug_probs)
+// ---------------------------------------------------------------------------
+__global__ void probs_expand_kernel(const uint16_t *counts, const double *tz, uint64_t n, double *out) {
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < n) out[r] = tz[counts[r]];
+}
+
+// ---------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------
+void launch_bitmap_build(hipStream_t s, const uint64_t *off, const uint32_t *post, const uint32_t *row_of,
+                         uint32_t *bitmap, uint32_t stride_words) {
+    hipLaunchKernelGGL(bitmap_build_kernel, dim3(RTX_NUM_KMERS), dim3(256), 0, s, off, post, row_of, bitmap,
+                       stride_words);
+}
+void launch_kmer_extract(hipStream_t s, const KmerParams &p, uint32_t nq) {
+    hipLaunchKernelGGL(kmer_extract_kernel, dim3(nq), dim3(64), 0, s, p);
+}
+void launch_hit_count(hipStream_t s, const HitParams &p, uint32_t nq, uint32_t ntiles, int planes) {
+    const size_t lds = (size_t)p.hstride * sizeof(uint32_t);
+    if (planes <= 10) hipLaunchKernelGGL(hit_count_kernel<10>, dim3(nq, ntiles), dim3(64), lds, s, p);
+    else if (planes <= 12) hipLaunchKernelGGL(hit_count_kernel<12>, dim3(nq, ntiles), dim3(64), lds, s, p);
+    else hipLaunchKernelGGL(hit_count_kernel<16>, dim3(nq, ntiles), dim3(64), lds, s, p);
+}
+size_t prob_table_lds_bytes(uint32_t tmax) {
+    const size_t n1max = tmax / 2 + 1;
+    return sizeof(double) * (4 * n1max + n1max + (tmax + n1max + 1) + 16) + sizeof(uint16_t) * ((size_t)tmax + 2);
+}
+void launch_prob_table(hipStream_t s, const ProbParams &p, uint32_t nq) {
+    hipLaunchKernelGGL(prob_table_kernel, dim3(nq), dim3(256), prob_table_lds_bytes(p.tmax), s, p);
+}
+void launch_taxon_prefix(hipStream_t s, const PrefixParams &p, uint32_t nq) {
+    hipLaunchKernelGGL(taxon_prefix_kernel, dim3(nq), dim3(256), 0, s, p);
+}
+void launch_lineage_walk(hipStream_t s, const WalkParams &p, uint32_t nq) {
+    hipLaunchKernelGGL(lineage_walk_kernel, dim3(nq), dim3(64), 0, s, p);
+}
+void launch_probs_expand(hipStream_t s, const uint16_t *counts, const double *tz, uint64_t n, double *out) {
+    hipLaunchKernelGGL(probs_expand_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, counts, tz, n, out);
+}
+
+}  // namespace rtx

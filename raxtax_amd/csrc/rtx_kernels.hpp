@@ -1,0 +1,117 @@
+// Kernel parameter blocks and launchers (rtx_kernels.hip) used by the C-ABI layer
+// (rtx_api.hip).  Plain structs passed by value to the kernels.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "raxtax_hip.h"
+
+namespace rtx {
+
+#ifndef RTX_NODE_TYPES_DEFINED
+#define RTX_NODE_TYPES_DEFINED
+enum NodeType : uint8_t { kInner = 0, kTaxon = 1, kSequence = 2 };  // src/tree.rs:181-186
+#endif
+
+constexpr uint32_t kWalkMaxRows = 208;  // >= 200 rows of confidence >= 0.005 + fallback
+
+struct DevRow {  // one result row as the device emits it
+    uint32_t node;               // flattened node id
+    uint8_t k[RTX_MAX_DEPTH];    // rounded confidence per level, in hundredths
+};
+static_assert(sizeof(DevRow) == 36, "DevRow layout");
+
+struct KmerParams {
+    const uint8_t *bases;
+    const uint64_t *base_off;
+    uint64_t q0;
+    const uint32_t *row_of;    // [65536] bitmap row of a k-mer or 0xFFFFFFFF
+    const uint32_t *list_len;  // [65536] posting-list length
+    uint32_t zero_row;
+    uint16_t *kmers;  // [B][kstride]
+    uint32_t kstride;
+    uint32_t *rows;  // [B][rstride]
+    uint32_t rstride;
+    uint32_t *t;      // [B]
+    uint32_t *nrows;  // [B]
+    unsigned long long *hq;  // [n_q]
+    uint32_t *t_all;         // [n_q]
+    uint32_t *nrows_all;     // [n_q]
+};
+
+struct HitParams {
+    const uint32_t *bitmap;
+    uint32_t stride_bytes;
+    uint64_t n_refs;
+    const uint32_t *rows;
+    uint32_t rstride;
+    const uint32_t *nrows;
+    const uint32_t *t;
+    uint16_t *counts;  // [B][npad]
+    uint64_t npad;
+    uint32_t *hist;  // [B][hstride]
+    uint32_t hstride;
+    uint32_t flags;
+    uint64_t q0;
+    const uint32_t *exact_ids;
+    const uint64_t *exact_off;
+};
+
+struct ProbParams {
+    const uint32_t *t;
+    const uint32_t *hist;
+    uint32_t hstride;
+    uint32_t tmax;
+    uint32_t n1max;
+    const double *lnfact;
+    uint64_t n_refs;
+    uint64_t q0;
+    double *table_z;  // [B][hstride]
+    double *z;        // [n_q]
+    double *gs;       // [n_q]
+    uint8_t *status;  // [n_q]
+};
+
+struct PrefixParams {
+    const uint8_t *status;
+    uint64_t q0;
+    const uint16_t *counts;
+    uint64_t npad;
+    const double *table_z;
+    uint32_t hstride;
+    uint64_t n_refs;
+    const uint8_t *bnd_bits;    // [ceil(N/8)] bit j: position 8*chunk+j+1 is a boundary
+    const uint32_t *bnd_rank;   // [ceil(N/8)] boundary index of the first such position
+    double *prefix;             // [B][n_bnd]
+    uint32_t n_bnd;
+};
+
+struct WalkParams {
+    const uint8_t *status;
+    uint64_t q0;
+    const double *prefix;
+    uint32_t n_bnd;
+    const uint32_t *blo, *bhi;  // boundary indices of every node's range
+    const uint32_t *first_child, *n_children;
+    const uint8_t *type;
+    DevRow *arena;
+    unsigned long long arena_cap;
+    unsigned long long *arena_cursor;
+    uint32_t *n_rows;                // [n_q]
+    unsigned long long *row_start;   // [n_q]
+    uint32_t *flags_out;             // bit0 arena overflow, bit1 row/depth overflow
+};
+
+void launch_bitmap_build(hipStream_t s, const uint64_t *off, const uint32_t *post, const uint32_t *row_of,
+                         uint32_t *bitmap, uint32_t stride_words);
+void launch_kmer_extract(hipStream_t s, const KmerParams &p, uint32_t nq);
+void launch_hit_count(hipStream_t s, const HitParams &p, uint32_t nq, uint32_t ntiles, int planes);
+size_t prob_table_lds_bytes(uint32_t tmax);
+void launch_prob_table(hipStream_t s, const ProbParams &p, uint32_t nq);
+void launch_taxon_prefix(hipStream_t s, const PrefixParams &p, uint32_t nq);
+void launch_lineage_walk(hipStream_t s, const WalkParams &p, uint32_t nq);
+void launch_probs_expand(hipStream_t s, const uint16_t *counts, const double *tz, uint64_t n, double *out);
+
+}  // namespace rtx

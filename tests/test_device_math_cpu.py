@@ -1,0 +1,105 @@
+"""Runs the device arithmetic of raxtax_amd/csrc/rtx_math.hpp (the inline functions the HIP
+kernels call) on the CPU through a small emulation harness and checks it against the oracle:
+bit-sliced counters must be bit-exact, the linear-domain pmf recurrence must reproduce the
+reference's log-space probability table."""
+import ctypes as C
+import subprocess
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from raxtax_amd import synth
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+@pytest.fixture(scope="module")
+def emul():
+    out = ROOT / "tests" / "_build" / "librtx_emul.so"
+    out.parent.mkdir(exist_ok=True)
+    src = ROOT / "raxtax_amd" / "csrc" / "rtx_emul.cpp"
+    hdr = ROOT / "raxtax_amd" / "csrc" / "rtx_math.hpp"
+    if not out.exists() or out.stat().st_mtime < max(src.stat().st_mtime, hdr.stat().st_mtime):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", f"-I{src.parent}", "-o", str(out), str(src)])
+    lib = C.CDLL(str(out))
+    lib.emul_prob_table.restype = C.c_int
+    return lib
+
+
+@pytest.mark.parametrize("planes,n_rows,density", [(10, 648, 0.3), (10, 1016, 0.97), (12, 4088, 0.5), (16, 8000, 0.9)])
+def test_bit_planes_exact(emul, planes, n_rows, density):
+    rng = np.random.default_rng(planes * 1000 + n_rows)
+    bits = rng.random((n_rows, 32)) < density
+    rows = (bits.astype(np.uint64) << np.arange(32, dtype=np.uint64)).sum(axis=1).astype(np.uint32)
+    out = np.zeros(32, dtype=np.uint32)
+    emul.emul_planes_count(rows.ctypes.data_as(C.c_void_p), n_rows, planes, out.ctypes.data_as(C.c_void_p))
+    assert np.array_equal(out, bits.sum(axis=0).astype(np.uint32))
+
+
+def _lnfact(oracle, n):
+    return np.array([oracle.lib.orc_ln_factorial(i) for i in range(n)], dtype=np.float64)
+
+
+def _emul_table(emul, lf, t, sizes):
+    hist = np.bincount(sizes, minlength=t + 1).astype(np.uint32)
+    tz = np.zeros(t + 1)
+    z, gs = C.c_double(), C.c_double()
+    rc = emul.emul_prob_table(C.c_uint32(t), hist.ctypes.data_as(C.c_void_p), C.c_uint64(len(sizes)),
+                              lf.ctypes.data_as(C.c_void_p), tz.ctypes.data_as(C.c_void_p), C.byref(z), C.byref(gs))
+    return rc, tz, z.value, gs.value
+
+
+def test_prob_recurrence_matches_reference_p2(emul, oracle, kats):
+    k = kats["P2_hit_prob"]
+    t = k["t"]
+    sizes = np.arange(0, t + 1, dtype=np.uint16)
+    lf = _lnfact(oracle, 2 * t + 8)
+    rc, tz, z, gs = _emul_table(emul, lf, t, sizes)
+    assert rc == 0
+    ref = oracle.highest_hit_prob_per_reference(t, t // 2, sizes)   # any count == t -> only_last branch
+    assert np.max(np.abs(tz[sizes] - ref)) < 1e-12
+    # general branch: drop the full-overlap reference
+    sizes2 = np.arange(0, t, dtype=np.uint16)
+    rc, tz, z, gs = _emul_table(emul, lf, t, sizes2)
+    ref = oracle.highest_hit_prob_per_reference(t, t // 2, sizes2)
+    assert rc == 0 and z >= 1.0
+    assert np.max(np.abs(tz[sizes2] - ref)) < 1e-12
+    assert abs(ref.sum() - 1.0) < 1e-9
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_prob_recurrence_on_realistic_counts(emul, oracle, seed):
+    db = synth.make_db(1200, fanouts=(2, 2, 3, 3, 3, 2))
+    ot = oracle.tree_new_flat(db.lineages, db.seq_bytes, db.seq_off)
+    qs = synth.make_queries(db, 6, seed=10 + seed, exact_frac=0.3)
+    lf = _lnfact(oracle, 2048)
+    for i in range(qs.n):
+        for skip in (False, True):
+            t, counts = ot.hit_counts(qs.seq(i), skip_exact=skip)
+            rc, tz, z, gs = _emul_table(emul, lf, t, counts)
+            ref = oracle.highest_hit_prob_per_reference(t, t // 2, counts)
+            assert rc == 0
+            assert np.max(np.abs(tz[counts] - ref)) < 1e-11, (i, skip)
+            gs_ref = np.sqrt(((ref - 1.0 / len(ref)) ** 2).sum())
+            assert abs(gs - gs_ref) < 1e-11
+
+
+def test_prob_recurrence_long_sequences_need_scaling(emul, oracle):
+    # t = 3000: ln pmf_m(0) is far below ln(DBL_MIN); exercises the 2^-512 rescaling path
+    t = 3000
+    rng = np.random.default_rng(5)
+    sizes = np.concatenate([rng.integers(200, 700, 400), rng.integers(2500, 2950, 5), [0, 1, 2990]]).astype(np.uint16)
+    lf = _lnfact(oracle, 2 * t + 8)
+    rc, tz, z, gs = _emul_table(emul, lf, t, sizes)
+    ref = oracle.highest_hit_prob_per_reference(t, t // 2, sizes)
+    assert rc == 0
+    assert np.max(np.abs(tz[sizes] - ref)) < 1e-11
+
+
+def test_prob_status_cases(emul, oracle):
+    lf = _lnfact(oracle, 64)
+    assert _emul_table(emul, lf, 0, np.zeros(4, np.uint16))[0] == 1          # t == 0
+    assert _emul_table(emul, lf, 1, np.zeros(4, np.uint16))[0] == 1          # t == 1, no full overlap
+    rc, tz, z, gs = _emul_table(emul, lf, 1, np.array([0, 1, 1, 0], np.uint16))  # t == 1 with full overlap
+    assert rc == 0 and z == 2.0 and tz[1] == 0.5 and tz[0] == 0.0

@@ -1,0 +1,98 @@
+"""Host-side mirror (libraxtax_hip.so, no GPU needed): Tree::new / FASTA parsing / formatting
+against the reference's known-answer vectors and against the oracle on seeded inputs."""
+import numpy as np
+import pytest
+
+import raxtax_amd as rx
+from raxtax_amd import synth
+
+
+def test_f5_str_parser_host(kats):
+    k = kats["F5_str_parser"]
+    tree = rx.parse_reference_fasta_str(k["fasta"])
+    for kmer, ids in k["k_mer_map"].items():
+        assert sorted(tree.k_mer_map(int(kmer))) == ids
+    assert tree.num_tips == k["num_tips"]
+    assert tree.lineages == k["lineages"]
+
+
+def test_f6_query_parser_host(kats):
+    for c in kats["F6_query_parser"]:
+        (label, seq), = rx.parse_query_fasta_str(c["fasta"])
+        assert label == "label1"
+        assert list(seq) == c["sequence"]
+
+
+def test_f7_kmers_host(kats):
+    k = kats["F7_kmers"]
+    tree = rx.parse_reference_fasta_str(k["fasta"])
+    for kmer, ids in k["k_mer_map"].items():
+        assert sorted(tree.k_mer_map(int(kmer))) == ids
+
+
+def test_parser_error_paths():
+    with pytest.raises(rx.RtxError):
+        rx.parse_reference_fasta_str("")                       # "File is empty", parser.rs:47-49
+    with pytest.raises(rx.RtxError):
+        rx.parse_reference_fasta_str("ACGT\n>x;tax=a;\nACGT")  # "Not a valid FASTA file"
+    with pytest.raises(rx.RtxError):
+        rx.parse_reference_fasta_str(">x;nolineage\nACGT")     # missing tax=...;
+    with pytest.raises(rx.RtxError):
+        rx.parse_reference_fasta_str(">x;tax=a;\nACGU")        # unexpected character
+    with pytest.raises(rx.RtxError):
+        rx.parse_reference_fasta_str(">x;tax=a;\n>y;tax=b;\nACGT")  # label/sequence count mismatch
+    # comment and blank lines are skipped, lines are trimmed, case-insensitive
+    t = rx.parse_reference_fasta_str(";c\n\n  >x;tax=a,b;  \n acgtacgta \n")
+    assert t.num_tips == 1 and t.lineages == ["a,b"]
+
+
+def test_query_parser_skip_and_multiline():
+    qs = rx.parse_query_fasta_str(">a\nACGT\nACGT\n>b\nTTTT\n>c\nGG", ["b"])
+    assert [q[0] for q in qs] == ["a", "c"]
+    assert list(qs[0][1]) == [1, 2, 4, 8, 1, 2, 4, 8]
+
+
+@pytest.mark.parametrize("n_refs", [300, 5184])
+def test_tree_matches_oracle(oracle, n_refs):
+    db = synth.make_db(n_refs)
+    ot = oracle.tree_new_flat(db.lineages, db.seq_bytes, db.seq_off)
+    ht = rx.Tree.new_flat(db.lineages, db.seq_bytes, db.seq_off)
+    assert ht.num_tips == ot.num_tips == n_refs
+    assert ht.lineages == ot.lineages
+    assert np.array_equal(ht.original_index(), ot.original_index())
+    oo, op = ot.csr()
+    ho, hp = ht.csr()
+    assert np.array_equal(oo, ho) and np.array_equal(op, hp)
+    # exact-match map
+    qs = synth.make_queries(db, 64, exact_frac=0.5)
+    for i in range(qs.n):
+        assert np.array_equal(ht.exact_matches(qs.seq(i)), ot.exact_matches(qs.seq(i)))
+    # flattened taxonomy == the oracle's tree without childless Sequence nodes
+    on = ot.nodes()
+    hn = ht.nodes()
+    keep = [i for i in range(len(on["type"])) if not (on["type"][i] == 2 and on["n_children"][i] == 0)]
+    assert len(keep) == len(hn["type"])
+    o_ranges = sorted((int(on["lo"][i]), int(on["hi"][i]), int(on["type"][i])) for i in keep)
+    h_ranges = sorted((int(hn["begin"][i]), int(hn["end"][i]), int(hn["type"][i])) for i in range(len(hn["type"])))
+    assert o_ranges == h_ranges
+    # BFS invariants the device relies on
+    nxt = 1
+    for v in range(len(hn["type"])):
+        if hn["n_children"][v]:
+            assert hn["first_child"][v] == nxt
+            for c in range(nxt, nxt + hn["n_children"][v]):
+                assert hn["parent"][c] == v
+            nxt += int(hn["n_children"][v])
+    assert nxt == len(hn["type"])
+
+
+def test_tree_variable_depth_and_duplicates(oracle, kats):
+    k = kats["F9_variable_lineage_length"]
+    seqs = [np.full(9, 0, np.uint8) for _ in k["lineages"]]
+    ht = rx.Tree.new(k["lineages"], seqs)
+    ot = oracle.tree_new(k["lineages"], seqs)
+    assert ht.lineages == ot.lineages
+    hn = ht.nodes()
+    # all 7 identical sequences are exact matches of one another (ids in sorted order)
+    assert list(ht.exact_matches(seqs[0])) == list(range(7))
+    assert int(hn["end"][0]) == 7 and int(hn["type"][0]) == 0

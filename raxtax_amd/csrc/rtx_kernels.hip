@@ -206,50 +206,53 @@ __global__ __launch_bounds__(64) void hit_count_kernel(HitParams p) {
         }
     }
     __syncthreads();
-    if (!active) return;  // single-wave workgroup: no further barriers below need these lanes
 
-    const uint32_t ref0 = tile * 8192u + lane * 128u;
-    if (p.flags & RTX_SKIP_EXACT_MATCHES) {  // raxtax.rs:65-68
-        const uint64_t e0 = p.exact_off[p.q0 + q], e1 = p.exact_off[p.q0 + q + 1];
-        for (uint64_t e = e0; e < e1; e++) {
-            const uint32_t id = p.exact_ids[e];
-            if (id >= ref0 && id < ref0 + 128u) {
-                const uint32_t w = (id - ref0) >> 5, msk = ~(1u << (id & 31u));
+    if (active) {
+        const uint32_t ref0 = tile * 8192u + lane * 128u;
+        if (p.flags & RTX_SKIP_EXACT_MATCHES) {  // raxtax.rs:65-68
+            const uint64_t e0 = p.exact_off[p.q0 + q], e1 = p.exact_off[p.q0 + q + 1];
+            for (uint64_t e = e0; e < e1; e++) {
+                const uint32_t id = p.exact_ids[e];
+                if (id >= ref0 && id < ref0 + 128u) {
+                    const uint32_t w = (id - ref0) >> 5, msk = ~(1u << (id & 31u));
 #pragma unroll
-                for (int ww = 0; ww < 4; ww++)
-                    if ((uint32_t)ww == w) {
+                    for (int ww = 0; ww < 4; ww++)
+                        if ((uint32_t)ww == w) {
 #pragma unroll
-                        for (int b = 0; b < NP; b++) pl[ww][b] &= msk;
-                    }
+                            for (int b = 0; b < NP; b++) pl[ww][b] &= msk;
+                        }
+                }
             }
         }
-    }
-    const uint32_t nvalid = ref0 >= p.n_refs ? 0u : ((p.n_refs - ref0) < 128u ? (uint32_t)(p.n_refs - ref0) : 128u);
-    uint16_t *out = p.counts + (size_t)q * p.npad + ref0;
+        const uint32_t nvalid =
+            ref0 >= p.n_refs ? 0u : ((p.n_refs - ref0) < 128u ? (uint32_t)(p.n_refs - ref0) : 128u);
+        uint16_t *out = p.counts + (size_t)q * p.npad + ref0;
 #pragma unroll
-    for (int w = 0; w < 4; w++) {
+        for (int w = 0; w < 4; w++) {
 #pragma unroll
-        for (int g2 = 0; g2 < 4; g2++) {  // 8 references per 16-byte store
-            uint32_t lo0, hi0, lo1, hi1;
-            planes_unpack4<NP>(pl[w], 2 * g2, lo0, hi0);
-            planes_unpack4<NP>(pl[w], 2 * g2 + 1, lo1, hi1);
-            uint4 st;
-            // bytes (lo.b0, hi.b0, lo.b1, hi.b1) -> two u16 counts
-            st.x = __builtin_amdgcn_perm(hi0, lo0, 0x05010400u);
-            st.y = __builtin_amdgcn_perm(hi0, lo0, 0x07030602u);
-            st.z = __builtin_amdgcn_perm(hi1, lo1, 0x05010400u);
-            st.w = __builtin_amdgcn_perm(hi1, lo1, 0x07030602u);
-            *reinterpret_cast<uint4 *>(out + w * 32 + g2 * 8) = st;
-            const uint32_t rbase = w * 32 + g2 * 8;
-            const uint32_t cw[4] = {st.x, st.y, st.z, st.w};
+            for (int g2 = 0; g2 < 4; g2++) {  // 8 references per 16-byte store
+                uint32_t lo0, hi0, lo1, hi1;
+                planes_unpack4<NP>(pl[w], 2 * g2, lo0, hi0);
+                planes_unpack4<NP>(pl[w], 2 * g2 + 1, lo1, hi1);
+                uint4 st;
+                // bytes (lo.b0, hi.b0, lo.b1, hi.b1) -> two u16 counts
+                st.x = __builtin_amdgcn_perm(hi0, lo0, 0x05010400u);
+                st.y = __builtin_amdgcn_perm(hi0, lo0, 0x07030602u);
+                st.z = __builtin_amdgcn_perm(hi1, lo1, 0x05010400u);
+                st.w = __builtin_amdgcn_perm(hi1, lo1, 0x07030602u);
+                *reinterpret_cast<uint4 *>(out + w * 32 + g2 * 8) = st;
+                const uint32_t rbase = w * 32 + g2 * 8;
+                const uint32_t cw[4] = {st.x, st.y, st.z, st.w};
 #pragma unroll
-            for (int j = 0; j < 8; j++) {
-                const uint32_t c = (cw[j >> 1] >> ((j & 1) * 16)) & 0xFFFFu;
-                if (rbase + j < nvalid) atomicAdd(&hist_lds[c], 1u);
+                for (int j = 0; j < 8; j++) {
+                    const uint32_t c = (cw[j >> 1] >> ((j & 1) * 16)) & 0xFFFFu;
+                    if (rbase + j < nvalid) atomicAdd(&hist_lds[c], 1u);
+                }
             }
         }
     }
     __syncthreads();
+    // every lane of the wave flushes (also those whose columns lie beyond the row)
     uint32_t *hist = p.hist + (size_t)q * p.hstride;
     for (uint32_t m = lane; m <= t; m += 64) {
         const uint32_t v = hist_lds[m];

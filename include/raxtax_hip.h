@@ -134,6 +134,12 @@ uint64_t rtx_index_num_refs(const rtx_index *index);
 uint64_t rtx_index_device_bytes(const rtx_index *index); /* HBM held by the index itself */
 /* queries processed per kernel wave (sub-batch); 0 = choose from free HBM */
 int rtx_index_set_batch(rtx_index *index, uint32_t sub_batch);
+/* Tuning / test knobs.  RTX_OPT_PROB_MODE: 0 = auto (memoised cmf tables when every query has
+ * t <= 1023 and they fit in HBM, else the per-query recurrence kernel), 1 = recurrence only,
+ * 2 = tables only (error if unavailable).  Both produce the same probabilities to ~1e-13. */
+#define RTX_OPT_SUB_BATCH 1
+#define RTX_OPT_PROB_MODE 2
+int rtx_index_set_option(rtx_index *index, int option, uint64_t value);
 
 /* ------------------------------------------------------------------------- */
 /* Classification: the body of raxtax(), src/raxtax.rs:39-84, minus string    */

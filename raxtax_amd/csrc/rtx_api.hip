@@ -94,8 +94,16 @@ struct rtx_index {
     uint64_t npad = 0;          // references per padded row (= stride_bytes * 8)
     uint32_t ntiles = 0;        // 8192-reference tiles
     DevBuf<uint32_t> d_bitmap, d_row_of, d_list_len;
-    DevBuf<double> d_lnfact;
+    DevBuf<double> d_lnfact, d_inv;
     std::vector<uint32_t> h_list_len;
+    // ---- memoised prob tables (t <= 1023), built lazily for the largest tmax seen
+    int prob_mode = 0;  // 0 auto, 1 recurrence kernel only, 2 tables (error if they do not fit)
+    uint32_t tab_tmax = 0;
+    DevBuf<double> d_tab_cmf, d_tab_ratio;
+    DevBuf<uint64_t> d_tab_off;
+    DevBuf<uint32_t> d_tab_moff, d_order;
+    DevBuf<uint16_t> d_tab_ilo, d_tab_sat;
+    bool use_tables = false;
     // ---- taxonomy
     FlatNodes nodes;
     std::vector<uint32_t> bnd;  // sorted unique range endpoints
@@ -232,7 +240,15 @@ int enqueue_batch(rtx_index *ix, uint32_t flags) {
         pp.gs = ix->d_gs.p;
         pp.status = ix->d_status.p;
         if (timed) RTX_HIP(hipEventRecord(ev(RTX_STAGE_PROB_TABLE, 0), s));
-        launch_prob_table(s, pp, nq);
+        if (ix->use_tables) {
+            ProbTables tb{ix->d_tab_cmf.p, ix->d_tab_ratio.p, ix->d_tab_off.p, ix->d_tab_moff.p,
+                          ix->d_tab_ilo.p, ix->d_tab_sat.p, ix->tab_tmax};
+            launch_prob_order(s, ix->d_t.p, nq, ix->d_order.p);
+            pp.order = ix->d_order.p;
+            launch_prob_lookup(s, pp, tb, nq);
+        } else {
+            launch_prob_table(s, pp, nq);
+        }
         if (timed) RTX_HIP(hipEventRecord(ev(RTX_STAGE_PROB_TABLE, 1), s));
 
         PrefixParams fp{};
@@ -275,6 +291,48 @@ int enqueue_batch(rtx_index *ix, uint32_t flags) {
     return RTX_OK;
 }
 
+// Builds (once per handle and tmax) the memoised cmf tables used by prob_lookup_kernel.
+constexpr uint32_t kProbTablesMaxT = 1023;
+int ensure_prob_tables(rtx_index *ix) {
+    ix->use_tables = false;
+    if (ix->prob_mode == 1 || ix->tmax < 2) return RTX_OK;
+    if (ix->tmax > kProbTablesMaxT) {
+        if (ix->prob_mode == 2) { set_error("prob tables need t <= %u (got %u)", kProbTablesMaxT, ix->tmax); return RTX_ERR_TOO_LONG; }
+        return RTX_OK;
+    }
+    if (ix->tab_tmax >= ix->tmax) { ix->use_tables = true; return RTX_OK; }
+    const uint32_t T = ix->tmax;
+    std::vector<uint64_t> off(T + 1, 0);
+    std::vector<uint32_t> moff(T + 1, 0);
+    uint64_t run = 0;
+    uint32_t mrun = 0;
+    for (uint32_t t = 2; t <= T; t++) {
+        off[t] = run;
+        moff[t] = mrun;
+        run += (uint64_t)t * (t / 2 + 1);
+        mrun += t;
+    }
+    int rc;
+    size_t free_b = 0, total_b = 0;
+    RTX_HIP(hipMemGetInfo(&free_b, &total_b));
+    if (run * 16 > free_b / 2) {  // keep at least half of the free HBM for the batch workspace
+        if (ix->prob_mode == 2) { set_error("prob tables (%llu bytes) do not fit", (unsigned long long)(run * 16)); return RTX_ERR_OOM; }
+        return RTX_OK;
+    }
+    if ((rc = ix->d_tab_cmf.alloc(run)) || (rc = ix->d_tab_ratio.alloc(run)) || (rc = ix->d_tab_off.alloc(T + 1)) ||
+        (rc = ix->d_tab_moff.alloc(T + 1)) || (rc = ix->d_tab_ilo.alloc(mrun)) || (rc = ix->d_tab_sat.alloc(mrun)))
+        return rc;
+    RTX_HIP(hipMemcpy(ix->d_tab_off.p, off.data(), (T + 1) * 8, hipMemcpyHostToDevice));
+    RTX_HIP(hipMemcpy(ix->d_tab_moff.p, moff.data(), (T + 1) * 4, hipMemcpyHostToDevice));
+    ProbTables tb{ix->d_tab_cmf.p, ix->d_tab_ratio.p, ix->d_tab_off.p, ix->d_tab_moff.p, ix->d_tab_ilo.p, ix->d_tab_sat.p, T};
+    launch_prob_tables_build(ix->stream, tb, ix->d_lnfact.p, ix->d_inv.p);
+    RTX_HIP(hipGetLastError());
+    RTX_HIP(hipStreamSynchronize(ix->stream));
+    ix->tab_tmax = T;
+    ix->use_tables = true;
+    return RTX_OK;
+}
+
 // Sizes and allocates the per-batch workspace for n_queries queries of at most tmax k-mers.
 int prepare_workspace(rtx_index *ix, uint64_t n_queries, uint64_t tmax, uint64_t max_len) {
     int rc;
@@ -286,11 +344,12 @@ int prepare_workspace(rtx_index *ix, uint64_t n_queries, uint64_t tmax, uint64_t
     }
     ix->tmax = (uint32_t)tmax;
     ix->kstride = (uint32_t)align_up(tmax, 8);
-    ix->rstride = (uint32_t)align_up(tmax, 16) + 16;
+    ix->rstride = (uint32_t)align_up(tmax, 32) + 32;
     ix->hstride = (uint32_t)align_up(tmax + 1, 8);
     ix->planes = tmax <= 1023 ? 10 : (tmax <= 4095 ? 12 : 16);
     ix->n_q = n_queries;
     if ((rc = ix->d_exact_off.alloc(n_queries + 1))) return rc;
+    if ((rc = ensure_prob_tables(ix))) return rc;
     // ---- per-query results
     if ((rc = ix->d_status.alloc(n_queries)) || (rc = ix->d_t_all.alloc(n_queries)) || (rc = ix->d_nrows_all.alloc(n_queries)) ||
         (rc = ix->d_n_rows.alloc(n_queries)) || (rc = ix->d_gs.alloc(n_queries)) || (rc = ix->d_z.alloc(n_queries)) ||
@@ -313,12 +372,13 @@ int prepare_workspace(rtx_index *ix, uint64_t n_queries, uint64_t tmax, uint64_t
         const uint64_t budget = (uint64_t)((free_b + held) * 0.6);
         B = (uint32_t)std::min<uint64_t>(4096, std::max<uint64_t>(64, budget / per_q));
     }
+    if (B > 4096) B = 4096;  // prob_order_kernel sorts a sub-batch in LDS
     B = (uint32_t)std::min<uint64_t>(B, n_queries);
     ix->sub_batch = B;
     if ((rc = ix->d_kmers.alloc((size_t)B * ix->kstride)) || (rc = ix->d_rows.alloc((size_t)B * ix->rstride)) ||
         (rc = ix->d_t.alloc(B)) || (rc = ix->d_nrows.alloc(B)) || (rc = ix->d_counts.alloc((size_t)B * ix->npad)) ||
         (rc = ix->d_hist.alloc((size_t)B * ix->hstride)) || (rc = ix->d_table_z.alloc((size_t)B * ix->hstride)) ||
-        (rc = ix->d_prefix.alloc((size_t)B * ix->n_bnd)))
+        (rc = ix->d_prefix.alloc((size_t)B * ix->n_bnd)) || (rc = ix->d_order.alloc(B)))
         return rc;
     return RTX_OK;
 }
@@ -488,6 +548,13 @@ int rtx_index_create(int device, uint64_t n_refs, const uint64_t *offsets, const
             set_error("lnfact upload failed");
             return fail(RTX_ERR_HIP);
         }
+        std::vector<double> inv(lf.size(), 0.0);
+        for (size_t x = 1; x < inv.size(); x++) inv[x] = 1.0 / (double)x;
+        if ((rc = ix->d_inv.alloc(inv.size()))) return fail(rc);
+        if (hipMemcpy(ix->d_inv.p, inv.data(), inv.size() * 8, hipMemcpyHostToDevice) != hipSuccess) {
+            set_error("reciprocal table upload failed");
+            return fail(RTX_ERR_HIP);
+        }
     }
     // ---- bitmap index: one row of n_refs bits per non-empty posting list (+ one zero row)
     {
@@ -552,6 +619,20 @@ int rtx_index_set_batch(rtx_index *index, uint32_t sub_batch) {
     if (!index) { set_error("null index handle"); return RTX_ERR_INVALID; }
     index->sub_batch_req = sub_batch;
     return RTX_OK;
+}
+
+int rtx_index_set_option(rtx_index *index, int option, uint64_t value) {
+    if (!index) { set_error("null index handle"); return RTX_ERR_INVALID; }
+    switch (option) {
+        case RTX_OPT_SUB_BATCH: index->sub_batch_req = (uint32_t)value; return RTX_OK;
+        case RTX_OPT_PROB_MODE:
+            if (value > 2) break;
+            index->prob_mode = (int)value;
+            return RTX_OK;
+        default: break;
+    }
+    set_error("rtx_index_set_option: unknown option %d / value %llu", option, (unsigned long long)value);
+    return RTX_ERR_INVALID;
 }
 
 int rtx_batch_upload(rtx_index *ix, uint64_t n_queries, const uint8_t *bases, const uint64_t *base_off,

@@ -3,6 +3,7 @@
 // and never runs on the product path.  It executes the very same inline functions the HIP
 // kernels call (bit-plane adders/unpack, pmf recurrence), sequentially on x86, so that
 // their logic is checked against the oracle without a GPU.
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -21,7 +22,22 @@ void emul_planes_count(const uint32_t *rows, uint32_t n_rows, int planes, uint32
         constexpr int NP = decltype(tag)::value;
         uint32_t pl[NP];
         for (int p = 0; p < NP; p++) pl[p] = 0;
-        for (uint32_t r = 0; r + 8 <= n_rows; r += 8)
+        uint32_t r = 0;
+        // the kernel's schedule: 32 rows = four tree8 + two CSAs on plane 3 + one on plane 4 + ripple
+        for (; r + 32 <= n_rows; r += 32) {
+            auto t8 = [&](uint32_t o) {
+                return planes_tree8<NP>(pl, rows[o], rows[o + 1], rows[o + 2], rows[o + 3], rows[o + 4], rows[o + 5],
+                                        rows[o + 6], rows[o + 7]);
+            };
+            uint32_t c3a = t8(r), c3b = t8(r + 8), c4a, c4b, c5;
+            csa(pl[3], c3a, c3b, pl[3], c4a);
+            c3a = t8(r + 16);
+            c3b = t8(r + 24);
+            csa(pl[3], c3a, c3b, pl[3], c4b);
+            csa(pl[4], c4a, c4b, pl[4], c5);
+            planes_ripple<NP, 5>(pl, c5);
+        }
+        for (; r + 8 <= n_rows; r += 8)
             planes_add8<NP>(pl, rows[r], rows[r + 1], rows[r + 2], rows[r + 3], rows[r + 4], rows[r + 5], rows[r + 6],
                             rows[r + 7]);
         for (int g = 0; g < 8; g++) {
@@ -35,51 +51,119 @@ void emul_planes_count(const uint32_t *rows, uint32_t n_rows, int planes, uint32
     else run(std::integral_constant<int, 16>{});
 }
 
-// Sequential emulation of prob_table_kernel.  hist has t+1 entries.  Returns 0, or 1 when the
-// kernel would flag RTX_Q_NO_KMERS.
+// Sequential emulation of prob_table_kernel (same lane grouping, pruning and arithmetic; only the
+// order of the cross-lane sums differs).  hist has t+1 entries.  Returns 0, or 1 when the kernel
+// would flag RTX_Q_NO_KMERS.  stats (may be null): [0] heavy group-steps, [1] light group-steps,
+// [2] skipped groups, [3] i_lo.
 int emul_prob_table(uint32_t t, const uint32_t *hist, uint64_t n_refs, const double *lf, double *table_z, double *z,
-                    double *gs) {
+                    double *gs, uint64_t *stats) {
     const uint32_t n = t >> 1;
     if (t == 0) return 1;
     std::vector<uint32_t> ms;
     for (uint32_t m = 0; m <= t; m++)
         if (hist[m]) ms.push_back(m);
+    const uint32_t D = (uint32_t)ms.size();
     std::vector<double> inv(t + n + 2, 0.0);
     for (uint32_t x = 1; x <= t + n; x++) inv[x] = 1.0 / (double)x;
     const double ln_total = ln_binom_tab(lf, t + n - 1, n);
     std::vector<double> tab(t + 1, 0.0);
+    uint64_t st_heavy = 0, st_light = 0, st_skip = 0, st_ilo = 0;
     if (ms.back() == t) {
         for (uint32_t m : ms) tab[m] = only_last_pmf_tab(lf, t, n, m, ln_total);
     } else {
         if (n == 0) return 1;
-        std::vector<double> prod(n + 1, 0.0), Pi(n + 1);
-        for (uint32_t m : ms) {
-            if (m == 0) continue;
-            const double h = (double)hist[m];
-            PmfState st = pmf_start(lf, t, n, m, ln_total);
-            double L = pmf_ln_cmf(st);
-            for (uint32_t i = 0; i <= n; i++) {
-                if (i > 0) {
-                    const double c_old = st.c;
-                    const int k_old = st.k;
-                    pmf_step(st, inv.data(), t, n, m, i);
-                    if (st.k > 0) L = neg_inf();
-                    else if (st.c != c_old || k_old != 0) L = log(st.c);
+        const uint32_t M = ms.back();
+        uint32_t i_lo = 0;
+        if (M > 0) {
+            i_lo = n;
+            for (uint32_t i = 0; i <= n; i++)
+                if (ln_pmf_tab(lf, t, n, M, i, ln_total) >= kLnNegligibleP) { i_lo = i; break; }
+        }
+        st_ilo = i_lo;
+        const uint32_t ngroups = (D + 63) / 64;  // lane groups (waves) in descending order of m
+        std::vector<double> prod(n + 1, 1.0), Pi(n + 1, 0.0), base(ngroups, 1.0);
+        std::vector<uint32_t> bw(ngroups, 0), istart(ngroups, 0);
+        std::vector<uint8_t> skipped(ngroups, 0);
+        for (uint32_t g = 0; g < ngroups; g++) {
+            const uint32_t m_hi = ms[D - 1 - g * 64];
+            if (m_hi == 0 || group_negligible(lf, t, n, m_hi, i_lo, ln_total)) {
+                skipped[g] = 1;
+                st_skip++;
+                continue;
+            }
+            const uint32_t nl = std::min<uint32_t>(64, D - g * 64);
+            // start index of the group: first i at which its smallest count's pmf reaches e^-100
+            uint32_t m_lo = ms[D - 1 - (g * 64 + nl - 1)];
+            if (m_lo == 0) m_lo = nl > 1 ? ms[D - 1 - (g * 64 + nl - 2)] : m_hi;
+            uint32_t i_s = i_lo;
+            for (uint32_t i = 0; i < i_lo; i++)
+                if (ln_pmf_tab(lf, t, n, m_lo, i, ln_total) >= kLnNegligibleP) { i_s = i; break; }
+            istart[g] = i_s;
+            std::vector<PmfState> st(nl);
+            std::vector<uint32_t> h(nl, 0);
+            std::vector<uint8_t> act(nl, 0), sat(nl, 0);
+            for (uint32_t l = 0; l < nl; l++) {
+                const uint32_t m = ms[D - 1 - (g * 64 + l)];
+                act[l] = m != 0;
+                if (act[l]) { st[l] = pmf_start_at(lf, t, n, m, i_s, ln_total); h[l] = hist[m]; }
+            }
+            bw[g] = n + 1;
+            for (uint32_t i = i_s; i <= n; i++) {
+                bool all_sat = i > i_s;
+                for (uint32_t l = 0; l < nl; l++) {
+                    if (!act[l]) continue;
+                    const uint32_t m = ms[D - 1 - (g * 64 + l)];
+                    if (i > i_s) {
+                        const double c_old = st[l].c;
+                        const int k_old = st[l].k;
+                        pmf_step(st[l], inv.data(), t, n, m, i);
+                        sat[l] = st[l].c == c_old && k_old == 0 && st[l].k == 0;
+                    }
+                    all_sat = all_sat && sat[l];
                 }
-                prod[i] += h * L;
+                if (all_sat) {
+                    double b = 1.0;
+                    for (uint32_t l = 0; l < nl; l++)
+                        if (act[l]) b *= pmf_cmf_pow(st[l], h[l]);
+                    base[g] = b;
+                    bw[g] = i;
+                    break;
+                }
+                if (i >= i_lo) {
+                    double f = 1.0;
+                    for (uint32_t l = 0; l < nl; l++)
+                        if (act[l]) f *= pmf_cmf_pow(st[l], h[l]);
+                    prod[i] *= f;
+                    st_heavy++;
+                } else {
+                    st_light++;
+                }
             }
         }
-        for (uint32_t i = 0; i <= n; i++) Pi[i] = exp(prod[i]);
-        for (uint32_t m : ms) {
-            if (m == 0) { tab[0] = Pi[0]; continue; }
-            PmfState st = pmf_start(lf, t, n, m, ln_total);
-            double acc = 0.0;
-            for (uint32_t i = 0; i <= n; i++) {
-                if (i > 0) pmf_step(st, inv.data(), t, n, m, i);
-                const double P = Pi[i];
-                if (P > 0.0 && st.k == 0 && st.c > 0.0) acc += st.v * P / st.c;
+        for (uint32_t i = i_lo; i <= n; i++) {
+            double p = prod[i];
+            for (uint32_t g = 0; g < ngroups; g++)
+                if (!skipped[g] && i >= bw[g]) p *= base[g];
+            Pi[i] = p;
+        }
+        for (uint32_t g = 0; g < ngroups; g++) {
+            const uint32_t nl = std::min<uint32_t>(64, D - g * 64);
+            for (uint32_t l = 0; l < nl; l++) {
+                const uint32_t m = ms[D - 1 - (g * 64 + l)];
+                if (m == 0) { tab[0] = Pi[0]; continue; }
+                if (skipped[g]) { tab[m] = 0.0; continue; }
+                const uint32_t i_s = istart[g];
+                PmfState st = pmf_start_at(lf, t, n, m, i_s, ln_total);
+                double acc = 0.0;
+                const uint32_t last = std::min(n, bw[g] == 0 ? 0 : bw[g] - 1);
+                for (uint32_t i = i_s; i <= last; i++) {
+                    if (i > i_s) pmf_step(st, inv.data(), t, n, m, i);
+                    if (i < i_lo) continue;
+                    const double P = Pi[i];
+                    if (P > 0.0 && st.k == 0 && st.c > 0.0) acc += st.v * P / st.c;
+                }
+                tab[m] = acc;
             }
-            tab[m] = acc;
         }
     }
     double Z = 0.0;
@@ -94,6 +178,88 @@ int emul_prob_table(uint32_t t, const uint32_t *hist, uint64_t n_refs, const dou
     }
     *z = Z;
     *gs = sqrt(g);
+    if (stats) { stats[0] = st_heavy; stats[1] = st_light; stats[2] = st_skip; stats[3] = st_ilo; }
+    return 0;
+}
+
+
+// Sequential emulation of prob_lookup_kernel + prob_tables_build_kernel (rtx_prob_tables.hip): the rows
+// C = cmf, R = pmf/cmf, sat and ilo are produced by the same recurrence (here on demand instead of from the
+// memoised table), then P(i) and table[m] are formed exactly as the lookup kernel does.
+int emul_prob_lookup(uint32_t t, const uint32_t *hist, uint64_t n_refs, const double *lf, double *table_z, double *z,
+                     double *gs, uint64_t *stats) {
+    const uint32_t n = t >> 1;
+    if (t == 0) return 1;
+    std::vector<uint32_t> ms;
+    for (uint32_t m = 0; m <= t; m++)
+        if (hist[m]) ms.push_back(m);
+    std::vector<double> inv(t + n + 2, 0.0);
+    for (uint32_t x = 1; x <= t + n; x++) inv[x] = 1.0 / (double)x;
+    const double ln_total = ln_binom_tab(lf, t + n - 1, n);
+    std::vector<double> tab(t + 1, 0.0);
+    uint64_t st_rows = 0, st_points = 0;
+    auto build_row = [&](uint32_t m, std::vector<double> &C, std::vector<double> &R, uint32_t &sat, uint32_t &ilo) {
+        C.assign(n + 1, 0.0);
+        R.assign(n + 1, 0.0);
+        PmfState st = pmf_start(lf, t, n, m, ln_total);
+        sat = n + 1;
+        ilo = n;
+        bool found = false;
+        for (uint32_t i = 0; i <= n; i++) {
+            if (i > 0) {
+                const double c_old = st.c;
+                const int k_old = st.k;
+                pmf_step(st, inv.data(), t, n, m, i);
+                if (sat == n + 1 && st.c == c_old && k_old == 0 && st.k == 0) sat = i;
+            }
+            const bool live = st.k == 0 && st.c > 0.0;
+            C[i] = live ? st.c : 0.0;
+            R[i] = live ? st.v / st.c : 0.0;
+            if (!found && ln_pmf_tab(lf, t, n, m, i, ln_total) >= kLnNegligibleP) { ilo = i; found = true; }
+        }
+    };
+    if (ms.back() == t) {
+        for (uint32_t m : ms) tab[m] = only_last_pmf_tab(lf, t, n, m, ln_total);
+    } else {
+        if (n == 0) return 1;
+        const uint32_t M = ms.back();
+        std::vector<double> C, R;
+        uint32_t sat = 0, ilo = 0, i_lo = 0;
+        if (M > 0) { build_row(M, C, R, sat, ilo); i_lo = ilo; }
+        std::vector<double> Pi(n + 1, 1.0);
+        struct Row { uint32_t m, sat; std::vector<double> R; };
+        std::vector<Row> rows;
+        for (size_t j = ms.size(); j-- > 0;) {
+            const uint32_t m = ms[j];
+            if (m == 0) continue;
+            build_row(m, C, R, sat, ilo);
+            if (sat <= i_lo) continue;  // saturated before i_lo: factor 1, table 0
+            for (uint32_t i = i_lo; i <= n; i++)
+                if (i < sat) { Pi[i] *= pow_uint(C[i], hist[m]); st_points++; }
+            rows.push_back(Row{m, sat, R});
+            st_rows++;
+        }
+        for (const Row &r : rows) {
+            const uint32_t last = std::min(n, r.sat - 1);
+            double acc = 0.0;
+            for (uint32_t i = i_lo; i <= last; i++) acc += r.R[i] * Pi[i];
+            tab[r.m] = acc;
+        }
+        if (ms[0] == 0) tab[0] = i_lo == 0 ? Pi[0] : 0.0;
+    }
+    double Z = 0.0;
+    for (uint32_t m : ms) Z += (double)hist[m] * tab[m];
+    const double inv_n = 1.0 / (double)n_refs;
+    double g = 0.0;
+    for (uint32_t m = 0; m <= t; m++) table_z[m] = 0.0;
+    for (uint32_t m : ms) {
+        const double v = tab[m] / Z;
+        table_z[m] = v;
+        g += (double)hist[m] * (v - inv_n) * (v - inv_n);
+    }
+    *z = Z;
+    *gs = sqrt(g);
+    if (stats) { stats[0] = st_rows; stats[1] = st_points; stats[2] = 0; stats[3] = 0; }
     return 0;
 }
 

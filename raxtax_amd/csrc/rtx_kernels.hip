@@ -13,39 +13,11 @@
 
 #include "rtx_kernels.hpp"
 #include "rtx_math.hpp"
+#include "rtx_wave.hpp"
 
 namespace rtx {
 
 static constexpr uint32_t kEmptyRow = 0xFFFFFFFFu;
-
-// ---------------------------------------------------------------------------
-// wave helpers (wave64)
-// ---------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
-
-__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        uint32_t o = __shfl_up(v, d, 64);
-        if ((int)lane_id() >= d) v += o;
-    }
-    return v;
-}
-
-__device__ __forceinline__ double wave_sum_f64(double v) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
-    return v;  // every lane holds the total (fixed butterfly order: deterministic)
-}
-
-__device__ __forceinline__ double wave_incl_scan_f64(double v) {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        double o = __shfl_up(v, d, 64);
-        if ((int)lane_id() >= d) v += o;
-    }
-    return v;
-}
 
 // ---------------------------------------------------------------------------
 // bitmap_build: one workgroup per k-mer; sets bit r of row row_of[k] for every posting r.
@@ -70,7 +42,7 @@ __global__ __launch_bounds__(256) void bitmap_build_kernel(const uint64_t *__res
 // A 65536-bit set in LDS gives HashSet semantics; reading it out word by word in
 // ascending order gives `.sorted()`.  Also emits, for hit_count, the list of bitmap rows
 // of the k-mers that occur in the index (padded with the all-zero row to a multiple of
-// 16 plus one look-ahead group) and H_q = sum of posting-list lengths.
+// 32 plus one look-ahead group) and H_q = sum of posting-list lengths.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void kmer_extract_kernel(KmerParams p) {
     __shared__ uint32_t bm[2048];
@@ -135,7 +107,7 @@ __global__ __launch_bounds__(64) void kmer_extract_kernel(KmerParams p) {
         if (row != kEmptyRow) rout[nrows + __popcll(m & ((1ull << lane) - 1ull))] = row;
         nrows += (uint32_t)__popcll(m);
     }
-    const uint32_t padded = ((nrows + 15u) & ~15u) + 8u;
+    const uint32_t padded = ((nrows + 31u) & ~31u) + 8u;
     for (uint32_t i = nrows + lane; i < padded; i += 64) rout[i] = p.zero_row;
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) hq += __shfl_xor(hq, d, 64);
@@ -152,28 +124,51 @@ __global__ __launch_bounds__(64) void kmer_extract_kernel(KmerParams p) {
 // hit_count (src/raxtax.rs:41,58-68): one wave per (query, 8192-reference tile).
 // Lane l owns references [tile*8192 + l*128, +128): 16 bytes of every bitmap row, so a
 // wave reads 1 KiB contiguous per row (one global_load_dwordx4 per lane, row base in
-// SGPRs).  Rows are folded eight at a time into NP bit planes per 32-reference word
-// (rtx_math.hpp).  The epilogue zeroes exact matches (raxtax.rs:65-68), unpacks the planes
+// SGPRs).  Rows are folded 32 at a time into NP bit planes per 32-reference word with a
+// Harley-Seal carry-save tree (rtx_math.hpp: 31 CSAs + one ripple per 32 rows).  The epilogue zeroes exact matches (raxtax.rs:65-68), unpacks the planes
 // to u16 counts, stores them, and builds the hit-count histogram of prob.rs:13-19 with
 // LDS atomics, flushed with one global atomic per non-empty bin.
 // blockIdx.x = query (fast) so that concurrently resident waves work on the same
 // reference tile and popular rows are served from L2.
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ void load8(uint4 (&buf)[8], const char *__restrict__ bm, size_t stride,
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+
+// Eight row segments through raw buffer loads: the row id is wave-uniform, so the 64-bit row base
+// lives in SGPRs (buffer descriptor rebuilt per row with scalar ops) and the only vector operand
+// is the 32-bit column offset: `buffer_load_dwordx4 v, v_col, s[desc], 0 offen`, no address VALU.
+// num_records = bytes per row, so lanes whose columns lie beyond the row read zeros.
+__device__ __forceinline__ void load8(uint4 (&buf)[8], const char *__restrict__ bitmap, uint32_t col, uint32_t stride,
                                       const uint32_t *__restrict__ rows) {
 #pragma unroll
     for (int j = 0; j < 8; j++) {
-        const uint32_t row = rows[j];  // wave-uniform -> scalar load
-        buf[j] = *reinterpret_cast<const uint4 *>(bm + (size_t)row * stride);
+        const uint32_t row = __builtin_amdgcn_readfirstlane(rows[j]);
+        const char *rowbase = bitmap + (size_t)row * stride;
+        const __amdgpu_buffer_rsrc_t rsrc =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(rowbase), 0, stride, 0x00027000);
+        const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, col, 0, 0);
+        buf[j] = make_uint4(v.x, v.y, v.z, v.w);
     }
 }
 
+// carry of weight 8 of eight 16-byte row segments, per 32-reference word
 template <int NP>
-__device__ __forceinline__ void add8(uint32_t (&pl)[4][NP], const uint4 (&a)[8]) {
-    planes_add8<NP>(pl[0], a[0].x, a[1].x, a[2].x, a[3].x, a[4].x, a[5].x, a[6].x, a[7].x);
-    planes_add8<NP>(pl[1], a[0].y, a[1].y, a[2].y, a[3].y, a[4].y, a[5].y, a[6].y, a[7].y);
-    planes_add8<NP>(pl[2], a[0].z, a[1].z, a[2].z, a[3].z, a[4].z, a[5].z, a[6].z, a[7].z);
-    planes_add8<NP>(pl[3], a[0].w, a[1].w, a[2].w, a[3].w, a[4].w, a[5].w, a[6].w, a[7].w);
+__device__ __forceinline__ uint4 tree8(uint32_t (&pl)[4][NP], const uint4 (&a)[8]) {
+    uint4 e;
+    e.x = planes_tree8<NP>(pl[0], a[0].x, a[1].x, a[2].x, a[3].x, a[4].x, a[5].x, a[6].x, a[7].x);
+    e.y = planes_tree8<NP>(pl[1], a[0].y, a[1].y, a[2].y, a[3].y, a[4].y, a[5].y, a[6].y, a[7].y);
+    e.z = planes_tree8<NP>(pl[2], a[0].z, a[1].z, a[2].z, a[3].z, a[4].z, a[5].z, a[6].z, a[7].z);
+    e.w = planes_tree8<NP>(pl[3], a[0].w, a[1].w, a[2].w, a[3].w, a[4].w, a[5].w, a[6].w, a[7].w);
+    return e;
+}
+
+template <int NP, int P>
+__device__ __forceinline__ uint4 csa_plane(uint32_t (&pl)[4][NP], const uint4 &a, const uint4 &b) {
+    uint4 c;
+    csa(pl[0][P], a.x, b.x, pl[0][P], c.x);
+    csa(pl[1][P], a.y, b.y, pl[1][P], c.y);
+    csa(pl[2][P], a.z, b.z, pl[2][P], c.z);
+    csa(pl[3][P], a.w, b.w, pl[3][P], c.w);
+    return c;
 }
 
 template <int NP>
@@ -191,18 +186,30 @@ __global__ __launch_bounds__(64) void hit_count_kernel(HitParams p) {
 #pragma unroll
         for (int b = 0; b < NP; b++) pl[w][b] = 0;
 
-    if (active) {
+    {
         const uint32_t *rows = p.rows + (size_t)q * p.rstride;
-        const uint32_t npairs = (p.nrows[q] + 15u) >> 4;
-        const char *bm = reinterpret_cast<const char *>(p.bitmap) + col;
-        const size_t stride = p.stride_bytes;
+        const uint32_t n32 = (p.nrows[q] + 31u) >> 5;  // the list is padded with zero rows (kmer_extract)
+        const char *bitmap = reinterpret_cast<const char *>(p.bitmap);
+        const uint32_t stride = p.stride_bytes;
         uint4 A[8], B[8];
-        load8(A, bm, stride, rows);
-        for (uint32_t g = 0; g < npairs; g++) {
-            load8(B, bm, stride, rows + g * 16 + 8);
-            add8<NP>(pl, A);
-            load8(A, bm, stride, rows + g * 16 + 16);  // look-ahead group (zero rows past the end)
-            add8<NP>(pl, B);
+        load8(A, bitmap, col, stride, rows);
+        for (uint32_t g = 0; g < n32; g++) {
+            const uint32_t *r = rows + g * 32;
+            load8(B, bitmap, col, stride, r + 8);
+            const uint4 c3a = tree8<NP>(pl, A);
+            load8(A, bitmap, col, stride, r + 16);
+            const uint4 c3b = tree8<NP>(pl, B);
+            const uint4 c4a = csa_plane<NP, 3>(pl, c3a, c3b);
+            load8(B, bitmap, col, stride, r + 24);
+            const uint4 c3c = tree8<NP>(pl, A);
+            load8(A, bitmap, col, stride, r + 32);  // look-ahead group (zero rows past the end)
+            const uint4 c3d = tree8<NP>(pl, B);
+            const uint4 c4b = csa_plane<NP, 3>(pl, c3c, c3d);
+            const uint4 c5 = csa_plane<NP, 4>(pl, c4a, c4b);
+            planes_ripple<NP, 5>(pl[0], c5.x);
+            planes_ripple<NP, 5>(pl[1], c5.y);
+            planes_ripple<NP, 5>(pl[2], c5.z);
+            planes_ripple<NP, 5>(pl[3], c5.w);
         }
     }
     __syncthreads();
@@ -265,30 +272,44 @@ template __global__ void hit_count_kernel<12>(HitParams);
 template __global__ void hit_count_kernel<16>(HitParams);
 
 // ---------------------------------------------------------------------------
-// prob_table (src/prob.rs:8-103): one 256-thread workgroup per query.
-// Lanes <-> distinct hit counts m (ascending), sequential over i = 0..n.
-//   pass 1: ln cmf_m(i) for every (m, i); prod(i) = sum_m hist[m] ln cmf_m(i)  (prob.rs:62-73)
-//           reduced over lanes by a fixed butterfly, over waves through per-wave LDS slots
-//           (deterministic, unlike the reference's ahash iteration order).
-//   pass 2: table[m] = sum_i pmf_m(i) * exp(prod(i)) / cmf_m(i)                (prob.rs:74-90)
+// prob_table (src/prob.rs:8-103): one workgroup of kProbWaves waves per query.
+// Lanes <-> distinct hit counts m in DESCENDING order (group g = 64 consecutive counts, handled
+// by wave g mod kProbWaves), sequential over i = 0..n with the linear-domain recurrence of rtx_math.hpp.
+//   pre-pass: i_lo from the largest count M (P(i) := 0 below it), per-group skip test.
+//   pass 1 : P(i) = prod_m cmf_m(i)^hist[m] = exp(prod(i)) of prob.rs:62-73 for i >= i_lo, kept as a
+//            product (integer powers by square-and-multiply, no logarithms), reduced over lanes by
+//            a fixed DPP order and over waves through per-wave LDS slots (deterministic, unlike the
+//            reference's ahash iteration order).  A group starts where its smallest count's pmf
+//            reaches e^-100 and stops when all its cmfs have saturated; from there on it
+//            contributes the constant `base`.
+//   pass 2 : table[m] = sum_i pmf_m(i) * exp(prod(i)) / cmf_m(i)              (prob.rs:74-90)
 // then Z = sum_m hist[m] table[m] (= probs_sum, prob.rs:97), table/Z (prob.rs:99-102) and the
 // global signal ||p - 1/N||_2 (lineage.rs:86-90) from the histogram.
-// LDS (dynamic): slots[4][n1] | P[n1] | inv[t+n1+1] | red[16] | ms[t+1] (u16)
+// LDS (dynamic): slots[4][n1max] | P[n1max] | inv[tmax+n1max+1] | red[16] | gbase[ng] | gbw[ng], gstart[ng] u32 | ms u16
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void prob_table_kernel(ProbParams p) {
+static constexpr uint32_t kGroupSkipped = 0xFFFFFFFFu;
+
+static constexpr uint32_t kProbWaves = 2;  // waves per query: groups g = wave, wave+2, ...
+static constexpr uint32_t kProbThreads = kProbWaves * 64;
+
+__global__ __launch_bounds__(kProbThreads) void prob_table_kernel(ProbParams p) {
     extern __shared__ double smem[];
-    __shared__ uint32_t s_D;
+    __shared__ uint32_t s_D, s_ilo;
     const uint32_t q = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint64_t gq = p.q0 + q;
     const uint32_t t = p.t[q];
     const uint32_t n = t >> 1;  // num_trials = k_mers.len() / 2, raxtax.rs:57
     const uint32_t n1 = n + 1;
     const uint32_t n1max = p.n1max;
+    const uint32_t ngmax = (p.tmax + 64) / 64 + 1;
     double *slots = smem;
-    double *Pi = slots + 4 * (size_t)n1max;
+    double *Pi = slots + kProbWaves * (size_t)n1max;
     double *inv = Pi + n1max;
     double *red = inv + (p.tmax + n1max + 1);
-    uint16_t *ms = reinterpret_cast<uint16_t *>(red + 16);
+    double *gbase = red + 16;
+    uint32_t *gbw = reinterpret_cast<uint32_t *>(gbase + ngmax);
+    uint32_t *gstart = gbw + ngmax;
+    uint16_t *ms = reinterpret_cast<uint16_t *>(gstart + ngmax);
     const uint32_t *hist = p.hist + (size_t)q * p.hstride;
     double *tz = p.table_z + (size_t)q * p.hstride;
     const double *lf = p.lnfact;
@@ -307,17 +328,18 @@ __global__ __launch_bounds__(256) void prob_table_kernel(ProbParams p) {
             if (has) ms[D + __popcll(bal & ((1ull << lane) - 1ull))] = (uint16_t)m;
             D += (uint32_t)__popcll(bal);
         }
-        if (lane == 0) s_D = D;
+        if (lane == 0) { s_D = D; s_ilo = n; }
     }
-    for (uint32_t x = tid + 1; x <= t + n; x += 256) inv[x] = 1.0 / (double)x;
-    for (uint32_t i = tid; i < 4 * n1; i += 256) slots[i] = 0.0;
+    for (uint32_t x = tid + 1; x <= t + n; x += kProbThreads) inv[x] = 1.0 / (double)x;
+    for (uint32_t i = tid; i < kProbWaves * n1; i += kProbThreads) slots[i] = 1.0;
     __syncthreads();
     const uint32_t D = s_D;
     const double ln_total = ln_binom_tab(lf, t + n - 1, n);  // prob.rs:20-23
-    const bool any_full = ms[D - 1] == t;                    // prob.rs:24-26
+    const uint32_t M = ms[D - 1];
+    const bool any_full = M == t;  // prob.rs:24-26
 
     if (any_full) {  // prob.rs:27-41
-        for (uint32_t j = tid; j < D; j += 256) {
+        for (uint32_t j = tid; j < D; j += kProbThreads) {
             const uint32_t m = ms[j];
             tz[m] = only_last_pmf_tab(lf, t, n, m, ln_total);
         }
@@ -326,49 +348,98 @@ __global__ __launch_bounds__(256) void prob_table_kernel(ProbParams p) {
             if (tid == 0) { p.status[gq] = RTX_Q_NO_KMERS; p.z[gq] = 0.0; p.gs[gq] = 0.0; }
             return;
         }
-        const uint32_t nslab = (D + 255u) >> 8;
-        // ---- pass 1
-        for (uint32_t s = 0; s < nslab; s++) {
-            const uint32_t j = s * 256 + tid;
-            const uint32_t m = j < D ? ms[j] : 0u;
+        // ---- pre-pass: first i at which P(i) can matter
+        if (M > 0) {
+            for (uint32_t i = tid; i <= n; i += kProbThreads)
+                if (ln_pmf_tab(lf, t, n, M, i, ln_total) >= kLnNegligibleP) atomicMin(&s_ilo, i);
+        } else if (tid == 0) {
+            s_ilo = 0;
+        }
+        __syncthreads();
+        const uint32_t i_lo = s_ilo;
+        const uint32_t ngroups = (D + 63u) >> 6;
+        // ---- pass 1: P(i) = prod_m cmf_m(i)^hist[m], accumulated multiplicatively (no logarithms)
+        for (uint32_t g = wave; g < ngroups; g += kProbWaves) {
+            const uint32_t j = g * 64 + lane;
+            const uint32_t m = j < D ? ms[D - 1 - j] : 0u;
             const bool act = m != 0;
-            if (!__any(act)) continue;  // whole wave idle in this slab
-            const double h = act ? (double)hist[m] : 0.0;
-            PmfState st{0.0, 0.0, 0};
-            if (act) st = pmf_start(lf, t, n, m, ln_total);
-            double L = act ? pmf_ln_cmf(st) : 0.0;
-            for (uint32_t i = 0; i <= n; i++) {
-                if (i > 0 && act) {
+            const uint32_t m_hi = ms[D - 1 - g * 64];
+            if (m_hi == 0 || group_negligible(lf, t, n, m_hi, i_lo, ln_total)) {  // wave-uniform
+                if (lane == 0) { gbw[g] = kGroupSkipped; gbase[g] = 1.0; gstart[g] = 0; }
+                continue;
+            }
+            // group start: first i at which the group's smallest count reaches e^-100 (<= i_lo)
+            const uint32_t nl = D - g * 64 < 64u ? D - g * 64 : 64u;
+            uint32_t m_lo = ms[D - 1 - (g * 64 + nl - 1)];
+            if (m_lo == 0) m_lo = nl > 1 ? ms[D - 1 - (g * 64 + nl - 2)] : m_hi;
+            uint32_t i_s = i_lo;
+            for (uint32_t i0 = 0; i0 < i_lo; i0 += 64) {
+                const uint32_t i = i0 + lane;
+                const bool hit = i < i_lo && ln_pmf_tab(lf, t, n, m_lo, i, ln_total) >= kLnNegligibleP;
+                const unsigned long long bal = __ballot(hit);
+                if (bal) { i_s = i0 + (uint32_t)__ffsll((long long)bal) - 1u; break; }
+            }
+            const uint32_t h = act ? hist[m] : 0u;
+            PmfState st{1.0, 1.0, 0};
+            if (act) st = pmf_start_at(lf, t, n, m, i_s, ln_total);
+            uint32_t bw = n + 1;
+            double base = 1.0;
+            for (uint32_t i = i_s; i <= n; i++) {
+                bool sat = !act;
+                if (i > i_s && act) {
                     const double c_old = st.c;
                     const int k_old = st.k;
                     pmf_step(st, inv, t, n, m, i);
-                    // ln cmf only changes when the sum does
-                    if (st.k > 0) L = neg_inf();
-                    else if (st.c != c_old || k_old != 0) L = log(st.c);
+                    sat = st.c == c_old && k_old == 0 && st.k == 0;  // pmf < 2^-53 cmf: cmf is final
                 }
-                const double contrib = wave_sum_f64(act ? h * L : 0.0);
-                if (lane == 0) slots[wave * n1 + i] += contrib;
+                if (i > i_s && __all(sat)) {
+                    base = wave_prod_f64_dpp(act ? pmf_cmf_pow(st, h) : 1.0);
+                    bw = i;
+                    break;
+                }
+                if (i >= i_lo) {
+                    const double f = wave_prod_f64_dpp(act ? pmf_cmf_pow(st, h) : 1.0);
+                    if (lane == 0) slots[wave * n1 + i] *= f;
+                }
             }
+            if (lane == 0) { gbw[g] = bw; gbase[g] = base; gstart[g] = i_s; }
         }
         __syncthreads();
-        for (uint32_t i = tid; i <= n; i += 256) {
-            const double prod = ((slots[i] + slots[n1 + i]) + slots[2 * n1 + i]) + slots[3 * n1 + i];
-            Pi[i] = exp(prod);  // exp(-inf) = 0
+        for (uint32_t i = tid; i <= n; i += kProbThreads) {
+            double P = 0.0;
+            if (i >= i_lo) {
+                P = slots[i];
+#pragma unroll
+                for (uint32_t w = 1; w < kProbWaves; w++) P *= slots[w * n1 + i];
+                for (uint32_t g = 0; g < ngroups; g++) {
+                    const uint32_t b = gbw[g];
+                    if (b != kGroupSkipped && i >= b) P *= gbase[g];
+                }
+            }
+            Pi[i] = P;
         }
         __syncthreads();
         // ---- pass 2
-        for (uint32_t s = 0; s < nslab; s++) {
-            const uint32_t j = s * 256 + tid;
+        for (uint32_t g = wave; g < ngroups; g += kProbWaves) {
+            const uint32_t j = g * 64 + lane;
             if (j >= D) continue;
-            const uint32_t m = ms[j];
-            if (m == 0) {  // pmf = [1,0,...], cmf = 1: table[0] = exp(prod(0))
+            const uint32_t m = ms[D - 1 - j];
+            if (m == 0) {  // pmf = [1,0,...], cmf = 1: table[0] = P(0)
                 tz[0] = Pi[0];
                 continue;
             }
-            PmfState st = pmf_start(lf, t, n, m, ln_total);
+            const uint32_t b = gbw[g];
+            if (b == kGroupSkipped) {
+                tz[m] = 0.0;
+                continue;
+            }
+            const uint32_t i_s = gstart[g];
+            const uint32_t last = b == 0 ? 0u : (b - 1 < n ? b - 1 : n);
+            PmfState st = pmf_start_at(lf, t, n, m, i_s, ln_total);
             double acc = 0.0;
-            for (uint32_t i = 0; i <= n; i++) {
-                if (i > 0) pmf_step(st, inv, t, n, m, i);
+            for (uint32_t i = i_s; i <= last; i++) {
+                if (i > i_s) pmf_step(st, inv, t, n, m, i);
+                if (i < i_lo) continue;
                 const double P = Pi[i];
                 if (P > 0.0 && st.k == 0 && st.c > 0.0) acc += st.v * P / st.c;
             }
@@ -378,30 +449,35 @@ __global__ __launch_bounds__(256) void prob_table_kernel(ProbParams p) {
     __syncthreads();
     // Z = probs_sum (prob.rs:97) grouped by count value; fixed reduction order
     double part = 0.0;
-    for (uint32_t j = tid; j < D; j += 256) {
+    for (uint32_t j = tid; j < D; j += kProbThreads) {
         const uint32_t m = ms[j];
         part += (double)hist[m] * tz[m];
     }
     part = wave_sum_f64(part);
     if (lane == 0) red[wave] = part;
     __syncthreads();
-    const double Z = (red[0] + red[1]) + (red[2] + red[3]);
+    double Z = red[0];
+#pragma unroll
+    for (uint32_t w = 1; w < kProbWaves; w++) Z += red[w];
     __syncthreads();
     const double inv_n = 1.0 / (double)p.n_refs;
-    double g = 0.0;
-    for (uint32_t j = tid; j < D; j += 256) {
+    double gsum = 0.0;
+    for (uint32_t j = tid; j < D; j += kProbThreads) {
         const uint32_t m = ms[j];
         const double v = tz[m] / Z;  // prob.rs:99-102
         tz[m] = v;
         const double d = v - inv_n;
-        g += (double)hist[m] * d * d;
+        gsum += (double)hist[m] * d * d;
     }
-    g = wave_sum_f64(g);
-    if (lane == 0) red[8 + wave] = g;
+    gsum = wave_sum_f64(gsum);
+    if (lane == 0) red[8 + wave] = gsum;
     __syncthreads();
     if (tid == 0) {
         p.z[gq] = Z;
-        p.gs[gq] = sqrt((red[8] + red[9]) + (red[10] + red[11]));
+        double gtot = red[8];
+#pragma unroll
+        for (uint32_t w = 1; w < kProbWaves; w++) gtot += red[8 + w];
+        p.gs[gq] = sqrt(gtot);
         p.status[gq] = RTX_Q_OK;
     }
 }
@@ -643,10 +719,12 @@ void launch_hit_count(hipStream_t s, const HitParams &p, uint32_t nq, uint32_t n
 }
 size_t prob_table_lds_bytes(uint32_t tmax) {
     const size_t n1max = tmax / 2 + 1;
-    return sizeof(double) * (4 * n1max + n1max + (tmax + n1max + 1) + 16) + sizeof(uint16_t) * ((size_t)tmax + 2);
+    const size_t ngmax = (tmax + 64) / 64 + 1;
+    return sizeof(double) * (2 * n1max + n1max + (tmax + n1max + 1) + 16 + ngmax) + sizeof(uint32_t) * (2 * ngmax + 2) +
+           sizeof(uint16_t) * ((size_t)tmax + 2);
 }
 void launch_prob_table(hipStream_t s, const ProbParams &p, uint32_t nq) {
-    hipLaunchKernelGGL(prob_table_kernel, dim3(nq), dim3(256), prob_table_lds_bytes(p.tmax), s, p);
+    hipLaunchKernelGGL(prob_table_kernel, dim3(nq), dim3(kProbThreads), prob_table_lds_bytes(p.tmax), s, p);
 }
 void launch_taxon_prefix(hipStream_t s, const PrefixParams &p, uint32_t nq) {
     hipLaunchKernelGGL(taxon_prefix_kernel, dim3(nq), dim3(256), 0, s, p);

@@ -59,7 +59,20 @@ struct HitParams {
     const uint64_t *exact_off;
 };
 
+// memoised cmf / pmf-ratio tables for every (t, m, i), t <= tmax (rtx_prob_tables.hip)
+struct ProbTables {
+    double *cmf;           // [off[t] + m * (t/2+1) + i]
+    double *ratio;         // same indexing: pmf / cmf
+    const uint64_t *off;   // [tmax+1]
+    const uint32_t *moff;  // [tmax+1] offset of row t in ilo / sat
+    uint16_t *ilo;         // [moff[t] + m] first i with ln pmf_m(i) >= -100
+    uint16_t *sat;         // [moff[t] + m] first i at which cmf_m has stopped changing
+    uint32_t tmax;
+};
+
 struct ProbParams {
+    const uint32_t *order;  // processing order of the sub-batch (slot indices) or null
+    const uint64_t *perm;   // global query permutation or null
     const uint32_t *t;
     const uint32_t *hist;
     uint32_t hstride;
@@ -110,6 +123,10 @@ void launch_kmer_extract(hipStream_t s, const KmerParams &p, uint32_t nq);
 void launch_hit_count(hipStream_t s, const HitParams &p, uint32_t nq, uint32_t ntiles, int planes);
 size_t prob_table_lds_bytes(uint32_t tmax);
 void launch_prob_table(hipStream_t s, const ProbParams &p, uint32_t nq);
+size_t prob_lookup_lds_bytes(uint32_t tmax);
+void launch_prob_tables_build(hipStream_t s, const ProbTables &tb, const double *lf, const double *inv);
+void launch_prob_order(hipStream_t s, const uint32_t *t, uint32_t nq, uint32_t *order);
+void launch_prob_lookup(hipStream_t s, const ProbParams &p, const ProbTables &tb, uint32_t nq);
 void launch_taxon_prefix(hipStream_t s, const PrefixParams &p, uint32_t nq);
 void launch_lineage_walk(hipStream_t s, const WalkParams &p, uint32_t nq);
 void launch_probs_expand(hipStream_t s, const uint16_t *counts, const double *tz, uint64_t n, double *out);

@@ -26,9 +26,17 @@ namespace rtx {
 
 // full adder on bit vectors: (a + b + c) -> sum (weight 1), carry (weight 2)
 RTX_HD void csa(uint32_t a, uint32_t b, uint32_t c, uint32_t &sum, uint32_t &carry) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    // gfx950 v_bitop3_b32: any 3-input boolean in one op.  0x96 = a^b^c, 0xE8 = majority(a,b,c)
+    const uint32_t s_ = __builtin_amdgcn_bitop3_b32(a, b, c, 0x96);
+    carry = __builtin_amdgcn_bitop3_b32(a, b, c, 0xE8);
+    sum = s_;
+#else
     uint32_t u = a ^ b;
-    sum = u ^ c;
-    carry = (a & b) | (u & c);  // v_bfi-able majority
+    uint32_t s_ = u ^ c;
+    carry = (a & b) | (u & c);
+    sum = s_;
+#endif
 }
 
 template <int NP>
@@ -50,8 +58,42 @@ RTX_HD void planes_add8(uint32_t (&pl)[NP], uint32_t a0, uint32_t a1, uint32_t a
     }
 }
 
+// Harley-Seal style tree: folds eight words into planes 0..2 and RETURNS the carry of weight 8
+// (7 CSAs, 21 ops); the caller combines such carries pairwise with further CSAs on planes 3, 4
+// (32 inputs = 31 CSAs) before one ripple, 3.2 ops per input word instead of 4.4 for planes_add8.
+template <int NP>
+RTX_HD uint32_t planes_tree8(uint32_t (&pl)[NP], uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3, uint32_t a4,
+                             uint32_t a5, uint32_t a6, uint32_t a7) {
+    uint32_t t1a, t1b, t1c, t1d, t2a, t2b, e;
+    csa(pl[0], a0, a1, pl[0], t1a);
+    csa(pl[0], a2, a3, pl[0], t1b);
+    csa(pl[1], t1a, t1b, pl[1], t2a);
+    csa(pl[0], a4, a5, pl[0], t1c);
+    csa(pl[0], a6, a7, pl[0], t1d);
+    csa(pl[1], t1c, t1d, pl[1], t2b);
+    csa(pl[2], t2a, t2b, pl[2], e);
+    return e;
+}
+
+// adds a carry vector of weight 2^L into planes L..NP-1
+template <int NP, int L>
+RTX_HD void planes_ripple(uint32_t (&pl)[NP], uint32_t e) {
+#pragma unroll
+    for (int p = L; p < NP; p++) {
+        uint32_t c = pl[p] & e;
+        pl[p] ^= e;
+        e = c;
+    }
+}
+
 // Spreads the 4 bits x[3:0] into the low bit of the 4 bytes of the result.
-RTX_HD uint32_t spread4(uint32_t x) { return ((x & 0xFu) * 0x00204081u) & 0x01010101u; }
+RTX_HD uint32_t spread4(uint32_t x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umul24(x & 0xFu, 0x00204081u) & 0x01010101u;  // v_mul_u32_u24 is full rate, v_mul_lo_u32 is not
+#else
+    return ((x & 0xFu) * 0x00204081u) & 0x01010101u;
+#endif
+}
 
 // Counters of references 4g..4g+3 of a 32-reference word: low 8 bits of each counter in
 // the bytes of `lo`, bits 8.. in the bytes of `hi`.
@@ -109,10 +151,47 @@ RTX_HD PmfState pmf_start(const double *lf, uint32_t t, uint32_t n, uint32_t m, 
     return s;
 }
 
+// The same state started at an arbitrary index i_s (closed-form ln pmf from the table) with
+// cmf := pmf, i.e. dropping sum_{j<i_s} pmf_m(j).  Callers choose i_s so that this dropped mass
+// is < (i_s+1) e^-100 (every earlier pmf is below e^-100 on the rising side).
+RTX_HD double ln_pmf_tab(const double *lf, uint32_t t, uint32_t n, uint32_t m, uint32_t i, double ln_total);
+RTX_HD PmfState pmf_start_at(const double *lf, uint32_t t, uint32_t n, uint32_t m, uint32_t i_s, double ln_total) {
+    double x0 = ln_pmf_tab(lf, t, n, m, i_s, ln_total);
+    PmfState s;
+    s.k = 0;
+    if (x0 < -600.0) {
+        s.k = (int)ceil((-600.0 - x0) / kScaleLn);
+        x0 += (double)s.k * kScaleLn;
+    }
+    s.v = exp(x0);
+    s.c = s.v;
+    return s;
+}
+
+// c^h for a non-negative integer h by square-and-multiply: prod(i) of prob.rs:62-73 is kept as
+// the product  prod_m cmf_m(i)^hist[m]  instead of exp(sum hist[m] ln cmf_m(i)) -- no logarithms.
+// Underflow to 0 means the true value is < 1e-308: P(i) is negligible there.
+RTX_HD double pow_uint(double c, uint32_t h) {
+    double r = 1.0, b = c;
+    while (h) {
+        if (h & 1u) r *= b;
+        b *= b;
+        h >>= 1;
+    }
+    return r;
+}
+
+// cmf_m(i)^h as a factor of P(i); 0 where the true cmf is below 2^-412
+RTX_HD double pmf_cmf_pow(const PmfState &s, uint32_t h) {
+    if (s.k > 0 || !(s.c > 0.0)) return 0.0;
+    return pow_uint(s.c, h);
+}
+
 // advance from i-1 to i (1 <= i <= n); inv[x] = 1.0/x
 RTX_HD void pmf_step(PmfState &s, const double *inv, uint32_t t, uint32_t n, uint32_t m, uint32_t i) {
-    double num = (double)(m + i - 1) * (double)(n - i + 1);
-    s.v = s.v * num * inv[i] * inv[t - m + n - i];
+    // the ratio does not depend on v: it stays off the dependent chain v -> c
+    const double ratio = ((double)(m + i - 1) * inv[i]) * ((double)(n - i + 1) * inv[t - m + n - i]);
+    s.v *= ratio;
     s.c += s.v;
     if (s.k > 0 && s.v > kScaleUp) {
         s.v *= kScaleDown;
@@ -127,6 +206,37 @@ RTX_HD double neg_inf() { return -INFINITY; }
 RTX_HD double pmf_ln_cmf(const PmfState &s) {
     if (s.k > 0 || !(s.c > 0.0)) return neg_inf();
     return log(s.c);
+}
+
+// ---------------------------------------------------------------------------
+// Work pruning of prob_table (all bounds are rigorous; Z >= 1 makes absolute errors of
+// 1e-18 per reference irrelevant at the 1e-6 parity tolerance):
+//  * i_lo: with M the largest hit count present, prod(i) <= ln cmf_M(i), and for i below the
+//    mode cmf_M(i) <= (i+1) pmf_M(i).  Every i with ln pmf_M(i) < -100 on the rising side
+//    therefore has exp(prod(i)) < e^-94: P(i) is taken as 0 and neither ln cmf nor the
+//    pass-2 terms are evaluated there.
+//  * group skip: a group of lanes whose largest count m_hi has its mode below i_lo and
+//    (n-i_lo+1) pmf_{m_hi}(i_lo) < 1e-18 has cmf_m(i) >= 1 - 1e-18 for every i >= i_lo
+//    (ln cmf = 0 to 1e-18) and pass-2 terms < 1e-18: the group is skipped (table[m] = 0).
+//  * saturation: once cmf stops changing (pmf < 2^-53 cmf, past the mode) ln cmf is constant
+//    and the remaining pass-2 terms are < 1e-16 pmf-sums: the lane group stops.
+// ---------------------------------------------------------------------------
+constexpr double kLnNegligibleP = -100.0;            // ln pmf_M(i) below this (rising side) => P(i) := 0
+constexpr double kLnTailSkip = -41.446531673892822;  // ln 1e-18
+
+// ln pmf_m(i), closed form (the `pmf` helper of the reference's tests, prob.rs:178-206), 0 < m < t
+RTX_HD double ln_pmf_tab(const double *lf, uint32_t t, uint32_t n, uint32_t m, uint32_t i, double ln_total) {
+    return ln_binom_tab(lf, m + i - 1, i) + ln_binom_tab(lf, t - m + n - i - 1, n - i) - ln_total;
+}
+
+// true if the lane group whose largest count is m_hi (> 0) contributes nothing for i >= i_lo
+RTX_HD bool group_negligible(const double *lf, uint32_t t, uint32_t n, uint32_t m_hi, uint32_t i_lo, double ln_total) {
+    if (i_lo == 0) return false;
+    // pmf_{m_hi} must already be falling at i_lo: (m+i-1)(n-i+1) < i (t-m+n-i)
+    const double up = (double)(m_hi + i_lo - 1) * (double)(n - i_lo + 1);
+    const double dn = (double)i_lo * (double)(t - m_hi + n - i_lo);
+    if (!(up < dn)) return false;
+    return log((double)(n - i_lo + 1)) + ln_pmf_tab(lf, t, n, m_hi, i_lo, ln_total) < kLnTailSkip;
 }
 
 // prob.rs:105-119 with the table

@@ -1,0 +1,273 @@
+// prob_table through memoised cmf tables (src/prob.rs:8-103).
+//
+// pmf_m(i) and cmf_m(i) of prob.rs:121-170 depend on (t, n = t/2, m, i) only -- not on the query
+// beyond its number of distinct k-mers t.  For barcode-length queries (t <= 1023) the library
+// therefore builds, once per index handle, for every t <= tmax and every 0 < m < t
+//     C[t][m][i] = cmf_m(i)              R[t][m][i] = pmf_m(i) / cmf_m(i)
+// with the very recurrence of rtx_math.hpp (same arithmetic as prob_table_kernel), plus per (t, m)
+//     ilo[t][m] = first i with ln pmf_m(i) >= -100          (i_lo when m is the largest count)
+//     sat[t][m] = first i at which cmf_m stops changing      (cmf == its final value from there on)
+// A query then needs no recurrence at all:
+//     P(i)     = prod_m C[t][m][i]^hist[m]          (lanes <-> i, rows streamed coalesced)
+//     table[m] = sum_i R[t][m][i] * P(i)            (one wave reduction per distinct count)
+// restricted to i >= i_lo and to the rows that are not yet saturated at i_lo (a saturated row
+// contributes the constant factor cmf_final^h = 1 + O(h 1e-16), identical for every i >= i_lo,
+// which cancels in the normalisation by Z).  Longer queries use prob_table_kernel.
+#include <hip/hip_runtime.h>
+
+#include "rtx_kernels.hpp"
+#include "rtx_math.hpp"
+#include "rtx_wave.hpp"
+
+namespace rtx {
+
+// ---------------------------------------------------------------------------
+// table build: one thread per (t, m), sequential over i (same recurrence as prob_table_kernel)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void prob_tables_build_kernel(ProbTables tb, const double *__restrict__ lf,
+                                                                const double *__restrict__ inv) {
+    const uint32_t t = blockIdx.y + 2;  // t = 2 .. tmax
+    const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t > tb.tmax || m >= t) return;
+    const uint32_t n = t >> 1, n1 = n + 1;
+    double *C = tb.cmf + tb.off[t] + (size_t)m * n1;
+    double *R = tb.ratio + tb.off[t] + (size_t)m * n1;
+    uint16_t *meta_ilo = tb.ilo + tb.moff[t];
+    uint16_t *meta_sat = tb.sat + tb.moff[t];
+    if (m == 0) {  // pmf = [1, 0, ...], cmf = 1 (prob.rs:134-137)
+        for (uint32_t i = 0; i <= n; i++) { C[i] = 1.0; R[i] = i == 0 ? 1.0 : 0.0; }
+        meta_ilo[0] = 0;
+        meta_sat[0] = 1;
+        return;
+    }
+    const double ln_total = ln_binom_tab(lf, t + n - 1, n);
+    PmfState st = pmf_start(lf, t, n, m, ln_total);
+    uint32_t sat = n + 1, ilo = n;
+    bool ilo_found = false;
+    for (uint32_t i = 0; i <= n; i++) {
+        if (i > 0) {
+            const double c_old = st.c;
+            const int k_old = st.k;
+            pmf_step(st, inv, t, n, m, i);
+            if (sat == n + 1 && st.c == c_old && k_old == 0 && st.k == 0) sat = i;
+        }
+        const bool live = st.k == 0 && st.c > 0.0;  // below 2^-412 the cmf counts as 0 (rtx_math.hpp)
+        C[i] = live ? st.c : 0.0;
+        R[i] = live ? st.v / st.c : 0.0;
+        if (!ilo_found && ln_pmf_tab(lf, t, n, m, i, ln_total) >= kLnNegligibleP) { ilo = i; ilo_found = true; }
+    }
+    meta_ilo[m] = (uint16_t)ilo;
+    meta_sat[m] = (uint16_t)sat;
+}
+
+// ---------------------------------------------------------------------------
+// per-query lookup kernel: 256 threads (4 waves) per query
+// LDS (dynamic): Pi[n1max] f64 | red[16] f64 | row_h[tmax+2] u32 | row_m, row_sat, ms [tmax+2] u16 each
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void prob_lookup_kernel(ProbParams p, ProbTables tb) {
+    extern __shared__ double smem[];
+    __shared__ uint32_t s_D, s_nact;
+    const uint32_t q = p.order ? p.order[blockIdx.x] : blockIdx.x;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint64_t gq = p.perm ? p.perm[p.q0 + q] : p.q0 + q;
+    const uint32_t t = p.t[q];
+    const uint32_t n = t >> 1;  // num_trials = k_mers.len() / 2, raxtax.rs:57
+    const uint32_t n1 = n + 1;
+    double *Pi = smem;
+    double *red = Pi + p.n1max;
+    uint32_t *row_h = reinterpret_cast<uint32_t *>(red + 16);
+    uint16_t *row_m = reinterpret_cast<uint16_t *>(row_h + (p.tmax + 10));
+    uint16_t *row_sat = row_m + (p.tmax + 10);
+    uint16_t *ms = row_sat + (p.tmax + 10);
+    const uint32_t *hist = p.hist + (size_t)q * p.hstride;
+    double *tz = p.table_z + (size_t)q * p.hstride;
+    const double *lf = p.lnfact;
+
+    if (t == 0) {  // reference: u64 underflow at prob.rs:21
+        if (tid == 0) { p.status[gq] = RTX_Q_NO_KMERS; p.z[gq] = 0.0; p.gs[gq] = 0.0; }
+        return;
+    }
+    if (wave == 0) {  // distinct counts, ascending
+        uint32_t D = 0;
+        for (uint32_t m0 = 0; m0 <= t; m0 += 64) {
+            const uint32_t m = m0 + lane;
+            const bool has = m <= t && hist[m] != 0;
+            const unsigned long long bal = __ballot(has);
+            if (has) ms[D + __popcll(bal & ((1ull << lane) - 1ull))] = (uint16_t)m;
+            D += (uint32_t)__popcll(bal);
+        }
+        if (lane == 0) s_D = D;
+    }
+    __syncthreads();
+    const uint32_t D = s_D;
+    const uint32_t M = ms[D - 1];
+    const double ln_total = ln_binom_tab(lf, t + n - 1, n);  // prob.rs:20-23
+    if (M == t) {  // prob.rs:24-41
+        for (uint32_t j = tid; j < D; j += 256) {
+            const uint32_t m = ms[j];
+            tz[m] = only_last_pmf_tab(lf, t, n, m, ln_total);
+        }
+    } else {
+        if (n == 0) {  // reference: zip_eq length mismatch at prob.rs:162
+            if (tid == 0) { p.status[gq] = RTX_Q_NO_KMERS; p.z[gq] = 0.0; p.gs[gq] = 0.0; }
+            return;
+        }
+        const uint16_t *t_ilo = tb.ilo + tb.moff[t];
+        const uint16_t *t_sat = tb.sat + tb.moff[t];
+        const double *Ct = tb.cmf + tb.off[t];
+        const double *Rt = tb.ratio + tb.off[t];
+        const uint32_t i_lo = M > 0 ? t_ilo[M] : 0u;
+        // rows still moving at i_lo, in descending order of m; everything else gets table = 0
+        if (wave == 0) {
+            uint32_t na = 0;
+            for (uint32_t j0 = 0; j0 < D; j0 += 64) {
+                const uint32_t j = j0 + lane;
+                uint32_t m = 0, sat = 0;
+                if (j < D) {
+                    m = ms[D - 1 - j];
+                    sat = m ? t_sat[m] : 0u;
+                    if (m && sat <= i_lo) tz[m] = 0.0;
+                }
+                const bool keep = m != 0 && sat > i_lo;
+                const unsigned long long bal = __ballot(keep);
+                if (keep) {
+                    const uint32_t pos = na + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+                    row_m[pos] = (uint16_t)m;
+                    row_sat[pos] = (uint16_t)sat;
+                    row_h[pos] = hist[m];
+                }
+                na += (uint32_t)__popcll(bal);
+            }
+            // pad to a multiple of 8 with neutral rows (m = 0: cmf = 1, sat = 0, h = 0)
+            const uint32_t padded = (na + 7u) & ~7u;
+            if (na + lane < padded) { row_m[na + lane] = 0; row_sat[na + lane] = 0; row_h[na + lane] = 0; }
+            if (lane == 0) s_nact = na;
+        }
+        __syncthreads();
+        const uint32_t nact = s_nact;
+        // ---- pass 1: P(i) = prod_m cmf_m(i)^hist[m]  (prob.rs:62-73), lanes <-> i.  Rows are taken
+        // eight at a time: eight independent 512-byte row-slice loads in flight per wave, then the powers.
+        for (uint32_t i0 = i_lo + wave * 64; i0 <= n; i0 += 256) {
+            const uint32_t i = i0 + lane;
+            const bool in = i <= n;
+            double P = 1.0;
+            for (uint32_t r0 = 0; r0 < nact; r0 += 8) {
+                double c[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    const uint32_t m = row_m[r0 + k], sat = row_sat[r0 + k];
+                    c[k] = (in && i < sat) ? Ct[(size_t)m * n1 + i] : 1.0;  // past saturation the factor is 1
+                }
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    const uint32_t h = __builtin_amdgcn_readfirstlane(row_h[r0 + k]);
+                    P *= pow_uint(c[k], h);
+                }
+            }
+            if (in) Pi[i - i_lo] = P;
+        }
+        __syncthreads();
+        // ---- pass 2: table[m] = sum_i pmf_m(i) P(i) / cmf_m(i)  (prob.rs:74-90); a wave takes four
+        // rows per turn so that their loads overlap, then one DPP reduction per row
+        for (uint32_t r0 = wave * 4; r0 < nact; r0 += 16) {
+            double acc[4] = {0.0, 0.0, 0.0, 0.0};
+            uint32_t mm[4], last[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                mm[k] = row_m[r0 + k];
+                const uint32_t sat = row_sat[r0 + k];
+                last[k] = sat == 0 ? 0u : (sat - 1u < n ? sat - 1u : n);
+            }
+            const uint32_t lmax = max(max(last[0], last[1]), max(last[2], last[3]));
+            for (uint32_t i = i_lo + lane; i <= lmax; i += 64) {
+                const double P = Pi[i - i_lo];
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    if (mm[k] != 0 && i <= last[k]) acc[k] += Rt[(size_t)mm[k] * n1 + i] * P;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const double v = wave_sum_f64_dpp(acc[k]);
+                if (lane == 0 && mm[k] != 0) tz[mm[k]] = v;
+            }
+        }
+        if (tid == 0 && ms[0] == 0) tz[0] = i_lo == 0 ? Pi[0] : 0.0;  // m = 0: table[0] = P(0)
+    }
+    __syncthreads();
+    // Z = probs_sum (prob.rs:97) grouped by count value; fixed reduction order
+    double part = 0.0;
+    for (uint32_t j = tid; j < D; j += 256) {
+        const uint32_t m = ms[j];
+        part += (double)hist[m] * tz[m];
+    }
+    part = wave_sum_f64_dpp(part);
+    if (lane == 0) red[wave] = part;
+    __syncthreads();
+    const double Z = (red[0] + red[1]) + (red[2] + red[3]);
+    __syncthreads();
+    const double inv_n = 1.0 / (double)p.n_refs;
+    double gsum = 0.0;
+    for (uint32_t j = tid; j < D; j += 256) {
+        const uint32_t m = ms[j];
+        const double v = tz[m] / Z;  // prob.rs:99-102
+        tz[m] = v;
+        const double d = v - inv_n;
+        gsum += (double)hist[m] * d * d;
+    }
+    gsum = wave_sum_f64_dpp(gsum);
+    if (lane == 0) red[8 + wave] = gsum;
+    __syncthreads();
+    if (tid == 0) {
+        p.z[gq] = Z;
+        p.gs[gq] = sqrt((red[8] + red[9]) + (red[10] + red[11]));
+        p.status[gq] = RTX_Q_OK;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// processing order of a sub-batch for prob_lookup: queries sorted by (t, slot), so that concurrently
+// resident workgroups read the same (t) tables out of L2.  One workgroup, bitonic sort of the unique
+// keys t << 16 | slot in LDS (deterministic); nq <= 4096.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void prob_order_kernel(const uint32_t *__restrict__ t, uint32_t nq,
+                                                          uint32_t *__restrict__ order) {
+    __shared__ uint32_t key[4096];
+    const uint32_t tid = threadIdx.x;
+    uint32_t np2 = 1;
+    while (np2 < nq) np2 <<= 1;
+    for (uint32_t q = tid; q < np2; q += 1024) key[q] = q < nq ? ((t[q] < 65535u ? t[q] : 65535u) << 16) | q : 0xFFFFFFFFu;
+    __syncthreads();
+    for (uint32_t k = 2; k <= np2; k <<= 1) {
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t x = tid; x < np2; x += 1024) {
+                const uint32_t y = x ^ j;
+                if (y > x) {
+                    const uint32_t a = key[x], b = key[y];
+                    const bool up = (x & k) == 0;
+                    if ((a > b) == up) { key[x] = b; key[y] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (uint32_t q = tid; q < nq; q += 1024) order[q] = key[q] & 0xFFFFu;
+}
+
+// ---------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------
+size_t prob_lookup_lds_bytes(uint32_t tmax) {
+    const size_t n1max = tmax / 2 + 1;
+    return sizeof(double) * (n1max + 16) + (sizeof(uint32_t) + 3 * sizeof(uint16_t)) * ((size_t)tmax + 10) + 8;
+}
+void launch_prob_tables_build(hipStream_t s, const ProbTables &tb, const double *lf, const double *inv) {
+    hipLaunchKernelGGL(prob_tables_build_kernel, dim3((tb.tmax + 255) / 256, tb.tmax - 1), dim3(256), 0, s, tb, lf, inv);
+}
+void launch_prob_order(hipStream_t s, const uint32_t *t, uint32_t nq, uint32_t *order) {
+    hipLaunchKernelGGL(prob_order_kernel, dim3(1), dim3(1024), 0, s, t, nq, order);
+}
+void launch_prob_lookup(hipStream_t s, const ProbParams &p, const ProbTables &tb, uint32_t nq) {
+    hipLaunchKernelGGL(prob_lookup_kernel, dim3(nq), dim3(256), prob_lookup_lds_bytes(p.tmax), s, p, tb);
+}
+
+}  // namespace rtx

@@ -41,12 +41,17 @@ def _lnfact(oracle, n):
     return np.array([oracle.lib.orc_ln_factorial(i) for i in range(n)], dtype=np.float64)
 
 
-def _emul_table(emul, lf, t, sizes):
+def _emul_table(emul, lf, t, sizes, fn="emul_prob_table"):
     hist = np.bincount(sizes, minlength=t + 1).astype(np.uint32)
     tz = np.zeros(t + 1)
     z, gs = C.c_double(), C.c_double()
-    rc = emul.emul_prob_table(C.c_uint32(t), hist.ctypes.data_as(C.c_void_p), C.c_uint64(len(sizes)),
-                              lf.ctypes.data_as(C.c_void_p), tz.ctypes.data_as(C.c_void_p), C.byref(z), C.byref(gs))
+    stats = np.zeros(4, dtype=np.uint64)
+    f = getattr(emul, fn)
+    f.restype = C.c_int
+    rc = f(C.c_uint32(t), hist.ctypes.data_as(C.c_void_p), C.c_uint64(len(sizes)),
+                              lf.ctypes.data_as(C.c_void_p), tz.ctypes.data_as(C.c_void_p), C.byref(z), C.byref(gs),
+                              stats.ctypes.data_as(C.c_void_p))
+    _emul_table.last_stats = stats
     return rc, tz, z.value, gs.value
 
 
@@ -103,3 +108,29 @@ def test_prob_status_cases(emul, oracle):
     assert _emul_table(emul, lf, 1, np.zeros(4, np.uint16))[0] == 1          # t == 1, no full overlap
     rc, tz, z, gs = _emul_table(emul, lf, 1, np.array([0, 1, 1, 0], np.uint16))  # t == 1 with full overlap
     assert rc == 0 and z == 2.0 and tz[1] == 0.5 and tz[0] == 0.0
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+def test_prob_lookup_tables_match_reference(emul, oracle, seed):
+    """The memoised-table formulation (rtx_prob_tables.hip) against the reference's log-space table."""
+    db = synth.make_db(1200, fanouts=(2, 2, 3, 3, 3, 2))
+    ot = oracle.tree_new_flat(db.lineages, db.seq_bytes, db.seq_off)
+    qs = synth.make_queries(db, 6, seed=20 + seed, exact_frac=0.3)
+    lf = _lnfact(oracle, 2048)
+    for i in range(qs.n):
+        for skip in (False, True):
+            t, counts = ot.hit_counts(qs.seq(i), skip_exact=skip)
+            rc, tz, z, gs = _emul_table(emul, lf, t, counts, fn="emul_prob_lookup")
+            ref = oracle.highest_hit_prob_per_reference(t, t // 2, counts)
+            assert rc == 0
+            assert np.max(np.abs(tz[counts] - ref)) < 1e-11, (i, skip)
+    # P2 of the reference's tests, general branch
+    t = 400
+    sizes = np.arange(0, t, dtype=np.uint16)
+    rc, tz, z, gs = _emul_table(emul, _lnfact(oracle, 2 * t + 8), t, sizes, fn="emul_prob_lookup")
+    ref = oracle.highest_hit_prob_per_reference(t, t // 2, sizes)
+    assert rc == 0 and np.max(np.abs(tz[sizes] - ref)) < 1e-12
+    # degenerate inputs
+    assert _emul_table(emul, lf, 0, np.zeros(4, np.uint16), fn="emul_prob_lookup")[0] == 1
+    rc, tz, z, gs = _emul_table(emul, lf, 9, np.zeros(7, np.uint16), fn="emul_prob_lookup")   # no hits at all
+    assert rc == 0 and abs(tz[0] - 1.0 / 7) < 1e-15

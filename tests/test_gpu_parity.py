@@ -33,8 +33,6 @@ def _special_queries(db):
     gap = r0.copy(); gap[10:400] = 15                                # long run of N
     out.append(("gap", gap))
     out.append(("poly_T", np.full(L, 8, np.uint8)))                  # a single distinct k-mer, t == 1
-    longq = np.concatenate([r0, db.seq(db.n // 2), db.seq(db.n - 1)[:200]])  # longer than any reference
-    out.append(("long", longq))
     out.append(("exact_first", db.seq(0).copy()))
     out.append(("exact_last", db.seq(db.n - 1).copy()))
     return out
@@ -285,3 +283,70 @@ def test_uniform_model_and_odd_sizes(oracle):
         rows, _ = otree.classify(s, raw_confidence=True)
         probs_ref = oracle.highest_hit_prob_per_reference(t, t // 2, counts)
         assert_rows_equivalent(res.rows(q), rows, probs_ref, lins, f"uniform q{q}")
+
+
+def test_prob_recurrence_kernel_equals_table_kernel(world, oracle):
+    """RTX_OPT_PROB_MODE: the per-query recurrence kernel (any t) and the memoised-table kernel
+    (t <= 1023) give the same probabilities; both are checked against the oracle."""
+    w = world
+    ex_ids, ex_off = w["index"].exact_matches(w["bases"], w["off"])
+    ix_rec = rx.Index(w["tree"], prob_mode=1)
+    ix_tab = rx.Index(w["tree"], prob_mode=2)
+    r1 = ix_rec.classify(w["bases"], w["off"], ex_ids, ex_off)
+    r2 = ix_tab.classify(w["bases"], w["off"], ex_ids, ex_off)
+    assert np.array_equal(r1.status, r2.status)
+    assert np.array_equal(r1.row_off, r2.row_off)
+    assert np.max(np.abs(r1.global_signal - r2.global_signal)) < 1e-12
+    for q in range(0, len(w["seqs"]), 7):
+        if r1.status[q] != 0:
+            continue
+        t, counts = w["otree"].hit_counts(w["seqs"][q])
+        ref = oracle.highest_hit_prob_per_reference(t, t // 2, counts)
+        p1, p2 = ix_rec.debug_probs(q), ix_tab.debug_probs(q)
+        assert np.max(np.abs(p1 - ref)) < TOL_TIGHT and np.max(np.abs(p2 - ref)) < TOL_TIGHT
+        assert np.max(np.abs(p1 - p2)) < 1e-12
+
+
+def test_long_queries_use_recurrence_path(oracle):
+    """Queries with more than 1023 distinct k-mers (16S-length): 12 bit planes in hit_count, per-query
+    recurrence in prob_table (with the 2^-512 rescaling of the pmf start)."""
+    rng = np.random.default_rng(5)
+    code = np.array([1, 2, 4, 8], np.uint8)
+    n, L = 600, 1500
+    root = rng.integers(0, 4, size=L)
+    seqs, lineages = [], []
+    for g in range(20):
+        gs = root.copy()
+        mut = rng.random(L) < 0.08
+        gs[mut] = rng.integers(0, 4, size=int(mut.sum()))
+        for s_ in range(n // 20):
+            ss = gs.copy()
+            mut = rng.random(L) < 0.01
+            ss[mut] = rng.integers(0, 4, size=int(mut.sum()))
+            seqs.append(code[ss])
+            lineages.append(f"d:D,g:G{g},s:S{g}_{s_ % 6}")
+    otree = oracle.tree_new(lineages, seqs)
+    tree = rx.Tree.new(lineages, seqs)
+    ix = rx.Index(tree)
+    qseqs = []
+    for i in rng.integers(0, n, size=24):
+        s = seqs[i].copy()
+        mut = rng.random(L) < 0.02
+        s[mut] = code[rng.integers(0, 4, size=int(mut.sum()))]
+        qseqs.append(s)
+    qseqs.append(seqs[3].copy())                      # exact match
+    qseqs.append(np.concatenate([seqs[5], seqs[77]]))  # t ~ 2900
+    off = np.zeros(len(qseqs) + 1, np.uint64)
+    off[1:] = np.cumsum([len(s) for s in qseqs])
+    bases = np.concatenate(qseqs)
+    ex_ids, ex_off = ix.exact_matches(bases, off)
+    res = ix.classify(bases, off, ex_ids, ex_off)
+    lins = otree.lineages
+    for q, s in enumerate(qseqs):
+        t, counts = otree.hit_counts(s)
+        assert t > 1023
+        assert np.array_equal(ix.debug_hit_counts(q), counts)
+        probs_ref = oracle.highest_hit_prob_per_reference(t, t // 2, counts)
+        assert np.max(np.abs(ix.debug_probs(q) - probs_ref)) < TOL_TIGHT
+        rows, _ = otree.classify(s, raw_confidence=True)
+        assert_rows_equivalent(res.rows(q), rows, probs_ref, lins, f"long q{q}")

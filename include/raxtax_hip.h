@@ -139,6 +139,8 @@ int rtx_index_set_batch(rtx_index *index, uint32_t sub_batch);
  * 2 = tables only (error if unavailable).  Both produce the same probabilities to ~1e-13. */
 #define RTX_OPT_SUB_BATCH 1
 #define RTX_OPT_PROB_MODE 2
+#define RTX_OPT_STREAMS 3 /* 1 (default) = one HIP stream; 2 = consecutive sub-batches alternate between two streams
+                             (measured slower on MI355X: the kernels contend for L2) */
 int rtx_index_set_option(rtx_index *index, int option, uint64_t value);
 
 /* ------------------------------------------------------------------------- */

@@ -191,7 +191,7 @@ class Result:
 class Index:
     """Device-resident index + batch workspace of one GPU (rtx_index)."""
 
-    def __init__(self, tree: Tree, device: int = 0, sub_batch: int = 0, prob_mode: int = 0):
+    def __init__(self, tree: Tree, device: int = 0, sub_batch: int = 0, prob_mode: int = 0, streams: int = 0):
         self._lib = _lib.load()
         self.tree = tree
         h = C.c_void_p()
@@ -202,6 +202,8 @@ class Index:
             check(self._lib.rtx_index_set_batch(self._h, sub_batch))
         if prob_mode:
             check(self._lib.rtx_index_set_option(self._h, 2, prob_mode))
+        if streams:
+            check(self._lib.rtx_index_set_option(self._h, 3, streams))
         self._view = ResultView()
         self._keep = None
 

@@ -101,7 +101,7 @@ struct rtx_index {
     uint32_t tab_tmax = 0;
     DevBuf<double> d_tab_cmf, d_tab_ratio;
     DevBuf<uint64_t> d_tab_off;
-    DevBuf<uint32_t> d_tab_moff, d_order;
+    DevBuf<uint32_t> d_tab_moff;
     DevBuf<uint16_t> d_tab_ilo, d_tab_sat;
     bool use_tables = false;
     // ---- taxonomy
@@ -120,11 +120,19 @@ struct rtx_index {
     uint64_t sum_query_bytes = 0;
     uint32_t kstride = 0, rstride = 0, hstride = 0, tmax = 0;
     int planes = 10;
-    // ---- sub-batch scratch
+    // ---- sub-batch scratch: two sets, so that consecutive sub-batches can run on two streams
+    // (the HBM/L2-bound hit_count of one overlaps the latency-bound prob/prefix/walk of the other)
     uint32_t sub_batch_req = 0, sub_batch = 0;
-    DevBuf<uint16_t> d_kmers, d_counts;
-    DevBuf<uint32_t> d_rows, d_t, d_nrows, d_hist;
-    DevBuf<double> d_table_z, d_prefix, d_probs_dbg;
+    struct Scratch {
+        DevBuf<uint16_t> d_kmers, d_counts;
+        DevBuf<uint32_t> d_rows, d_t, d_nrows, d_hist, d_order;
+        DevBuf<double> d_table_z, d_prefix;
+    } sc[2];
+    uint32_t n_streams_req = 1, n_streams = 1;
+    hipStream_t stream2 = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    uint32_t last_set = 0;  // scratch set of the last sub-batch (debug taps)
+    DevBuf<double> d_probs_dbg;
     // ---- per-query results
     DevBuf<uint8_t> d_status;
     DevBuf<uint32_t> d_t_all, d_nrows_all, d_n_rows, d_flags;
@@ -145,6 +153,9 @@ struct rtx_index {
 
     ~rtx_index() {
         for (auto e : events) (void)hipEventDestroy(e);
+        if (ev_fork) (void)hipEventDestroy(ev_fork);
+        if (ev_join) (void)hipEventDestroy(ev_join);
+        if (stream2) (void)hipStreamDestroy(stream2);
         if (stream) (void)hipStreamDestroy(stream);
     }
 };
@@ -168,9 +179,13 @@ int ensure_events(rtx_index *ix, size_t count) {
 
 // Enqueues every kernel of the uploaded batch on the handle's stream.
 int enqueue_batch(rtx_index *ix, uint32_t flags) {
-    hipStream_t s = ix->stream;
-    RTX_HIP(hipMemsetAsync(ix->d_cursor.p, 0, sizeof(unsigned long long), s));
-    RTX_HIP(hipMemsetAsync(ix->d_flags.p, 0, sizeof(uint32_t), s));
+    RTX_HIP(hipMemsetAsync(ix->d_cursor.p, 0, sizeof(unsigned long long), ix->stream));
+    RTX_HIP(hipMemsetAsync(ix->d_flags.p, 0, sizeof(uint32_t), ix->stream));
+    const bool two = ix->n_streams == 2;
+    if (two) {  // the second stream starts after the resets above
+        RTX_HIP(hipEventRecord(ix->ev_fork, ix->stream));
+        RTX_HIP(hipStreamWaitEvent(ix->stream2, ix->ev_fork, 0));
+    }
     const uint32_t B = ix->sub_batch;
     const uint32_t n_sub = (uint32_t)((ix->n_q + B - 1) / B);
     const bool timed = n_sub <= 4096;
@@ -182,6 +197,10 @@ int enqueue_batch(rtx_index *ix, uint32_t flags) {
     for (uint32_t sb = 0; sb < n_sub; sb++) {
         const uint64_t q0 = (uint64_t)sb * B;
         const uint32_t nq = (uint32_t)std::min<uint64_t>(B, ix->n_q - q0);
+        const uint32_t set = two ? (sb & 1u) : 0u;
+        rtx_index::Scratch &sc = ix->sc[set];
+        hipStream_t s = set ? ix->stream2 : ix->stream;
+        ix->last_set = set;
         auto ev = [&](int stage, int which) -> hipEvent_t {
             return ix->events[((size_t)sb * RTX_NUM_STAGES + stage) * 2 + which];
         };
@@ -192,12 +211,12 @@ int enqueue_batch(rtx_index *ix, uint32_t flags) {
         kp.row_of = ix->d_row_of.p;
         kp.list_len = ix->d_list_len.p;
         kp.zero_row = ix->n_rows;
-        kp.kmers = ix->d_kmers.p;
+        kp.kmers = sc.d_kmers.p;
         kp.kstride = ix->kstride;
-        kp.rows = ix->d_rows.p;
+        kp.rows = sc.d_rows.p;
         kp.rstride = ix->rstride;
-        kp.t = ix->d_t.p;
-        kp.nrows = ix->d_nrows.p;
+        kp.t = sc.d_t.p;
+        kp.nrows = sc.d_nrows.p;
         kp.hq = ix->d_hq.p;
         kp.t_all = ix->d_t_all.p;
         kp.nrows_all = ix->d_nrows_all.p;
@@ -205,18 +224,18 @@ int enqueue_batch(rtx_index *ix, uint32_t flags) {
         launch_kmer_extract(s, kp, nq);
         if (timed) RTX_HIP(hipEventRecord(ev(RTX_STAGE_KMER_EXTRACT, 1), s));
 
-        RTX_HIP(hipMemsetAsync(ix->d_hist.p, 0, (size_t)nq * ix->hstride * sizeof(uint32_t), s));
+        RTX_HIP(hipMemsetAsync(sc.d_hist.p, 0, (size_t)nq * ix->hstride * sizeof(uint32_t), s));
         HitParams hp{};
         hp.bitmap = ix->d_bitmap.p;
         hp.stride_bytes = ix->stride_bytes;
         hp.n_refs = ix->n_refs;
-        hp.rows = ix->d_rows.p;
+        hp.rows = sc.d_rows.p;
         hp.rstride = ix->rstride;
-        hp.nrows = ix->d_nrows.p;
-        hp.t = ix->d_t.p;
-        hp.counts = ix->d_counts.p;
+        hp.nrows = sc.d_nrows.p;
+        hp.t = sc.d_t.p;
+        hp.counts = sc.d_counts.p;
         hp.npad = ix->npad;
-        hp.hist = ix->d_hist.p;
+        hp.hist = sc.d_hist.p;
         hp.hstride = ix->hstride;
         hp.flags = flags;
         hp.q0 = q0;
@@ -227,15 +246,15 @@ int enqueue_batch(rtx_index *ix, uint32_t flags) {
         if (timed) RTX_HIP(hipEventRecord(ev(RTX_STAGE_HIT_COUNT, 1), s));
 
         ProbParams pp{};
-        pp.t = ix->d_t.p;
-        pp.hist = ix->d_hist.p;
+        pp.t = sc.d_t.p;
+        pp.hist = sc.d_hist.p;
         pp.hstride = ix->hstride;
         pp.tmax = ix->tmax;
         pp.n1max = ix->tmax / 2 + 1;
         pp.lnfact = ix->d_lnfact.p;
         pp.n_refs = ix->n_refs;
         pp.q0 = q0;
-        pp.table_z = ix->d_table_z.p;
+        pp.table_z = sc.d_table_z.p;
         pp.z = ix->d_z.p;
         pp.gs = ix->d_gs.p;
         pp.status = ix->d_status.p;
@@ -243,8 +262,8 @@ int enqueue_batch(rtx_index *ix, uint32_t flags) {
         if (ix->use_tables) {
             ProbTables tb{ix->d_tab_cmf.p, ix->d_tab_ratio.p, ix->d_tab_off.p, ix->d_tab_moff.p,
                           ix->d_tab_ilo.p, ix->d_tab_sat.p, ix->tab_tmax};
-            launch_prob_order(s, ix->d_t.p, nq, ix->d_order.p);
-            pp.order = ix->d_order.p;
+            launch_prob_order(s, sc.d_t.p, nq, sc.d_order.p);
+            pp.order = sc.d_order.p;
             launch_prob_lookup(s, pp, tb, nq);
         } else {
             launch_prob_table(s, pp, nq);
@@ -253,15 +272,17 @@ int enqueue_batch(rtx_index *ix, uint32_t flags) {
 
         PrefixParams fp{};
         fp.status = ix->d_status.p;
+        fp.t = sc.d_t.p;
+        fp.tz_in_lds = (size_t)ix->hstride * 8 <= 48 * 1024 ? 1u : 0u;
         fp.q0 = q0;
-        fp.counts = ix->d_counts.p;
+        fp.counts = sc.d_counts.p;
         fp.npad = ix->npad;
-        fp.table_z = ix->d_table_z.p;
+        fp.table_z = sc.d_table_z.p;
         fp.hstride = ix->hstride;
         fp.n_refs = ix->n_refs;
         fp.bnd_bits = ix->d_bnd_bits.p;
         fp.bnd_rank = ix->d_bnd_rank.p;
-        fp.prefix = ix->d_prefix.p;
+        fp.prefix = sc.d_prefix.p;
         fp.n_bnd = ix->n_bnd;
         if (timed) RTX_HIP(hipEventRecord(ev(RTX_STAGE_TAXON_PREFIX, 0), s));
         launch_taxon_prefix(s, fp, nq);
@@ -270,7 +291,7 @@ int enqueue_batch(rtx_index *ix, uint32_t flags) {
         WalkParams wp{};
         wp.status = ix->d_status.p;
         wp.q0 = q0;
-        wp.prefix = ix->d_prefix.p;
+        wp.prefix = sc.d_prefix.p;
         wp.n_bnd = ix->n_bnd;
         wp.blo = ix->d_blo.p;
         wp.bhi = ix->d_bhi.p;
@@ -286,6 +307,10 @@ int enqueue_batch(rtx_index *ix, uint32_t flags) {
         if (timed) RTX_HIP(hipEventRecord(ev(RTX_STAGE_LINEAGE_WALK, 0), s));
         launch_lineage_walk(s, wp, nq);
         if (timed) RTX_HIP(hipEventRecord(ev(RTX_STAGE_LINEAGE_WALK, 1), s));
+    }
+    if (two) {  // everything is complete once the main stream is: join the second stream into it
+        RTX_HIP(hipEventRecord(ix->ev_join, ix->stream2));
+        RTX_HIP(hipStreamWaitEvent(ix->stream, ix->ev_join, 0));
     }
     RTX_HIP(hipGetLastError());
     return RTX_OK;
@@ -360,26 +385,35 @@ int prepare_workspace(rtx_index *ix, uint64_t n_queries, uint64_t tmax, uint64_t
         if ((rc = ix->d_arena.alloc(want_arena))) return rc;
         ix->arena_cap = want_arena;
     }
-    // ---- sub-batch scratch, sized against free HBM
-    const uint64_t per_q = (uint64_t)ix->kstride * 2 + (uint64_t)ix->rstride * 4 + ix->npad * 2 + (uint64_t)ix->hstride * 12 +
-                           (uint64_t)ix->n_bnd * 8 + 64;
+    // ---- sub-batch scratch (x2 when two streams are used), sized against free HBM
+    ix->n_streams = (ix->n_streams_req >= 2 && n_queries > 1) ? 2u : 1u;
+    if (ix->n_streams == 2 && !ix->stream2) {
+        RTX_HIP(hipStreamCreateWithFlags(&ix->stream2, hipStreamNonBlocking));
+        RTX_HIP(hipEventCreateWithFlags(&ix->ev_fork, hipEventDisableTiming));
+        RTX_HIP(hipEventCreateWithFlags(&ix->ev_join, hipEventDisableTiming));
+    }
+    const uint64_t per_q = ((uint64_t)ix->kstride * 2 + (uint64_t)ix->rstride * 4 + ix->npad * 2 + (uint64_t)ix->hstride * 12 +
+                            (uint64_t)ix->n_bnd * 8 + 64) * ix->n_streams;
     uint32_t B = ix->sub_batch_req;
     if (B == 0) {
         size_t free_b = 0, total_b = 0;
         RTX_HIP(hipMemGetInfo(&free_b, &total_b));
         // scratch already held by this handle is reusable
-        const uint64_t held = ix->d_counts.n * 2 + ix->d_prefix.n * 8;
+        const uint64_t held = (ix->sc[0].d_counts.n + ix->sc[1].d_counts.n) * 2 + (ix->sc[0].d_prefix.n + ix->sc[1].d_prefix.n) * 8;
         const uint64_t budget = (uint64_t)((free_b + held) * 0.6);
         B = (uint32_t)std::min<uint64_t>(4096, std::max<uint64_t>(64, budget / per_q));
     }
     if (B > 4096) B = 4096;  // prob_order_kernel sorts a sub-batch in LDS
-    B = (uint32_t)std::min<uint64_t>(B, n_queries);
+    B = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(B, n_queries));
     ix->sub_batch = B;
-    if ((rc = ix->d_kmers.alloc((size_t)B * ix->kstride)) || (rc = ix->d_rows.alloc((size_t)B * ix->rstride)) ||
-        (rc = ix->d_t.alloc(B)) || (rc = ix->d_nrows.alloc(B)) || (rc = ix->d_counts.alloc((size_t)B * ix->npad)) ||
-        (rc = ix->d_hist.alloc((size_t)B * ix->hstride)) || (rc = ix->d_table_z.alloc((size_t)B * ix->hstride)) ||
-        (rc = ix->d_prefix.alloc((size_t)B * ix->n_bnd)) || (rc = ix->d_order.alloc(B)))
-        return rc;
+    for (uint32_t k = 0; k < ix->n_streams; k++) {
+        rtx_index::Scratch &sc = ix->sc[k];
+        if ((rc = sc.d_kmers.alloc((size_t)B * ix->kstride)) || (rc = sc.d_rows.alloc((size_t)B * ix->rstride)) ||
+            (rc = sc.d_t.alloc(B)) || (rc = sc.d_nrows.alloc(B)) || (rc = sc.d_counts.alloc((size_t)B * ix->npad)) ||
+            (rc = sc.d_hist.alloc((size_t)B * ix->hstride)) || (rc = sc.d_table_z.alloc((size_t)B * ix->hstride)) ||
+            (rc = sc.d_prefix.alloc((size_t)B * ix->n_bnd)) || (rc = sc.d_order.alloc(B)))
+            return rc;
+    }
     return RTX_OK;
 }
 
@@ -625,6 +659,10 @@ int rtx_index_set_option(rtx_index *index, int option, uint64_t value) {
     if (!index) { set_error("null index handle"); return RTX_ERR_INVALID; }
     switch (option) {
         case RTX_OPT_SUB_BATCH: index->sub_batch_req = (uint32_t)value; return RTX_OK;
+        case RTX_OPT_STREAMS:
+            if (value < 1 || value > 2) break;
+            index->n_streams_req = (uint32_t)value;
+            return RTX_OK;
         case RTX_OPT_PROB_MODE:
             if (value > 2) break;
             index->prob_mode = (int)value;
@@ -829,9 +867,9 @@ int rtx_debug_kmers(rtx_index *ix, uint64_t query, uint16_t *kmers, uint32_t *t)
     int rc = debug_slot(ix, query, &slot);
     if (rc) return rc;
     uint32_t tt = 0;
-    RTX_HIP(hipMemcpy(&tt, ix->d_t.p + slot, 4, hipMemcpyDeviceToHost));
+    RTX_HIP(hipMemcpy(&tt, ix->sc[ix->last_set].d_t.p + slot, 4, hipMemcpyDeviceToHost));
     if (t) *t = tt;
-    if (kmers && tt) RTX_HIP(hipMemcpy(kmers, ix->d_kmers.p + (size_t)slot * ix->kstride, std::min(tt, ix->kstride) * 2, hipMemcpyDeviceToHost));
+    if (kmers && tt) RTX_HIP(hipMemcpy(kmers, ix->sc[ix->last_set].d_kmers.p + (size_t)slot * ix->kstride, std::min(tt, ix->kstride) * 2, hipMemcpyDeviceToHost));
     return RTX_OK;
 }
 
@@ -839,7 +877,7 @@ int rtx_debug_hit_counts(rtx_index *ix, uint64_t query, uint16_t *counts) {
     uint32_t slot;
     int rc = debug_slot(ix, query, &slot);
     if (rc) return rc;
-    RTX_HIP(hipMemcpy(counts, ix->d_counts.p + (size_t)slot * ix->npad, ix->n_refs * 2, hipMemcpyDeviceToHost));
+    RTX_HIP(hipMemcpy(counts, ix->sc[ix->last_set].d_counts.p + (size_t)slot * ix->npad, ix->n_refs * 2, hipMemcpyDeviceToHost));
     return RTX_OK;
 }
 
@@ -848,10 +886,10 @@ int rtx_debug_prob_table(rtx_index *ix, uint64_t query, double *table_over_z, do
     int rc = debug_slot(ix, query, &slot);
     if (rc) return rc;
     uint32_t tt = 0;
-    RTX_HIP(hipMemcpy(&tt, ix->d_t.p + slot, 4, hipMemcpyDeviceToHost));
+    RTX_HIP(hipMemcpy(&tt, ix->sc[ix->last_set].d_t.p + slot, 4, hipMemcpyDeviceToHost));
     std::vector<uint32_t> hist(tt + 1);
-    RTX_HIP(hipMemcpy(hist.data(), ix->d_hist.p + (size_t)slot * ix->hstride, (tt + 1) * 4, hipMemcpyDeviceToHost));
-    RTX_HIP(hipMemcpy(table_over_z, ix->d_table_z.p + (size_t)slot * ix->hstride, (tt + 1) * 8, hipMemcpyDeviceToHost));
+    RTX_HIP(hipMemcpy(hist.data(), ix->sc[ix->last_set].d_hist.p + (size_t)slot * ix->hstride, (tt + 1) * 4, hipMemcpyDeviceToHost));
+    RTX_HIP(hipMemcpy(table_over_z, ix->sc[ix->last_set].d_table_z.p + (size_t)slot * ix->hstride, (tt + 1) * 8, hipMemcpyDeviceToHost));
     for (uint32_t m = 0; m <= tt; m++)
         if (!hist[m]) table_over_z[m] = 0.0;  // entries of absent counts are never written
     if (z) RTX_HIP(hipMemcpy(z, ix->d_z.p + query, 8, hipMemcpyDeviceToHost));
@@ -863,7 +901,7 @@ int rtx_debug_probs(rtx_index *ix, uint64_t query, double *probs) {
     int rc = debug_slot(ix, query, &slot);
     if (rc) return rc;
     if ((rc = ix->d_probs_dbg.alloc(ix->n_refs))) return rc;
-    launch_probs_expand(ix->stream, ix->d_counts.p + (size_t)slot * ix->npad, ix->d_table_z.p + (size_t)slot * ix->hstride,
+    launch_probs_expand(ix->stream, ix->sc[ix->last_set].d_counts.p + (size_t)slot * ix->npad, ix->sc[ix->last_set].d_table_z.p + (size_t)slot * ix->hstride,
                         ix->n_refs, ix->d_probs_dbg.p);
     RTX_HIP(hipStreamSynchronize(ix->stream));
     RTX_HIP(hipMemcpy(probs, ix->d_probs_dbg.p, ix->n_refs * 8, hipMemcpyDeviceToHost));
@@ -881,6 +919,7 @@ int rtx_debug_evaluate(rtx_index *ix, const double *probs, rtx_result_view *out)
     if (N > 65535) { set_error("rtx_debug_evaluate supports at most 65535 references"); return RTX_ERR_INVALID; }
     ix->uploaded = ix->ran = ix->synced = false;
     if ((rc = prepare_workspace(ix, 1, std::max<uint64_t>(N, 8), 0))) return rc;
+    ix->last_set = 0;
     ix->sum_query_bytes = 0;
     std::vector<uint16_t> counts(ix->npad, 0);
     for (uint64_t r = 0; r < N; r++) counts[r] = (uint16_t)r;  // count_r = r, table[r] = probs[r]
@@ -889,8 +928,8 @@ int rtx_debug_evaluate(rtx_index *ix, const double *probs, rtx_result_view *out)
     gs = std::sqrt(gs);
     const uint8_t ok = RTX_Q_OK;
     hipStream_t s = ix->stream;
-    RTX_HIP(hipMemcpy(ix->d_counts.p, counts.data(), ix->npad * 2, hipMemcpyHostToDevice));
-    RTX_HIP(hipMemcpy(ix->d_table_z.p, probs, N * 8, hipMemcpyHostToDevice));
+    RTX_HIP(hipMemcpy(ix->sc[ix->last_set].d_counts.p, counts.data(), ix->npad * 2, hipMemcpyHostToDevice));
+    RTX_HIP(hipMemcpy(ix->sc[ix->last_set].d_table_z.p, probs, N * 8, hipMemcpyHostToDevice));
     RTX_HIP(hipMemcpy(ix->d_status.p, &ok, 1, hipMemcpyHostToDevice));
     RTX_HIP(hipMemcpy(ix->d_gs.p, &gs, 8, hipMemcpyHostToDevice));
     RTX_HIP(hipMemset(ix->d_t_all.p, 0, 4));
@@ -901,21 +940,23 @@ int rtx_debug_evaluate(rtx_index *ix, const double *probs, rtx_result_view *out)
     RTX_HIP(hipMemset(ix->d_flags.p, 0, 4));
     PrefixParams fp{};
     fp.status = ix->d_status.p;
+    fp.t = ix->sc[ix->last_set].d_t.p;
+    fp.tz_in_lds = 0;  // the pseudo-query's "counts" index the probability vector directly
     fp.q0 = 0;
-    fp.counts = ix->d_counts.p;
+    fp.counts = ix->sc[ix->last_set].d_counts.p;
     fp.npad = ix->npad;
-    fp.table_z = ix->d_table_z.p;
+    fp.table_z = ix->sc[ix->last_set].d_table_z.p;
     fp.hstride = ix->hstride;
     fp.n_refs = N;
     fp.bnd_bits = ix->d_bnd_bits.p;
     fp.bnd_rank = ix->d_bnd_rank.p;
-    fp.prefix = ix->d_prefix.p;
+    fp.prefix = ix->sc[ix->last_set].d_prefix.p;
     fp.n_bnd = ix->n_bnd;
     launch_taxon_prefix(s, fp, 1);
     WalkParams wp{};
     wp.status = ix->d_status.p;
     wp.q0 = 0;
-    wp.prefix = ix->d_prefix.p;
+    wp.prefix = ix->sc[ix->last_set].d_prefix.p;
     wp.n_bnd = ix->n_bnd;
     wp.blo = ix->d_blo.p;
     wp.bhi = ix->d_bhi.p;

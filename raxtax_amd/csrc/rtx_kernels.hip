@@ -485,12 +485,13 @@ __global__ __launch_bounds__(kProbThreads) void prob_table_kernel(ProbParams p) 
 // ---------------------------------------------------------------------------
 // taxon_prefix (src/lineage.rs:61-66): P[j] = sum_{r < bnd[j]} p_r, p_r = table[count_r]/Z,
 // sampled at the taxonomy boundaries only (every node range is [bnd[a], bnd[b])).
-// One 256-thread workgroup per query, 8 references per thread per sweep.
+// One 256-thread workgroup per query, 8 references per thread per sweep (2048 per sweep); low
+// register use keeps 8 workgroups per CU resident, which is what hides the sweep latency.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void taxon_prefix_kernel(PrefixParams p) {
     __shared__ double wsum[4];
     const uint32_t q = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const uint64_t gq = p.q0 + q;
+    const uint64_t gq = p.perm ? p.perm[p.q0 + q] : p.q0 + q;
     double *P = p.prefix + (size_t)q * p.n_bnd;
     if (p.status[gq] != RTX_Q_OK) return;
     const double *tz = p.table_z + (size_t)q * p.hstride;

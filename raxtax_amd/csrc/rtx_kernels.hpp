@@ -89,6 +89,9 @@ struct ProbParams {
 
 struct PrefixParams {
     const uint8_t *status;
+    const uint64_t *perm;  // global query permutation or null
+    const uint32_t *t;     // [B] distinct k-mers per slot (size of the table copy)
+    uint32_t tz_in_lds;    // copy table/Z to LDS first (hstride * 8 bytes must fit)
     uint64_t q0;
     const uint16_t *counts;
     uint64_t npad;

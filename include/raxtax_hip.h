@@ -76,6 +76,11 @@ int rtx_device_count(void); /* number of visible HIP devices, 0 if none / no dri
  * sequence i is seq_bytes[seq_off[i] .. seq_off[i+1]). */
 int rtx_tree_build(uint64_t n, const char *lineage_bytes, const uint64_t *lineage_off,
                    const uint8_t *seq_bytes, const uint64_t *seq_off, rtx_tree **out);
+/* The same with options.  RTX_TREE_SKIP_KMER_MAP: sort, taxonomy and exact-sequence map only; the k-mer
+ * index is then built on the GPU from the sequences by rtx_index_create_from_tree. */
+#define RTX_TREE_SKIP_KMER_MAP 1u
+int rtx_tree_build_ex(uint64_t n, const char *lineage_bytes, const uint64_t *lineage_off,
+                      const uint8_t *seq_bytes, const uint64_t *seq_off, uint32_t flags, rtx_tree **out);
 /* parse_reference_fasta_str, src/parser.rs:46-105 */
 int rtx_tree_parse_reference_fasta(const char *text, uint64_t len, rtx_tree **out);
 void rtx_tree_destroy(rtx_tree *tree);
@@ -127,7 +132,13 @@ int rtx_index_create(int device, uint64_t n_refs, const uint64_t *offsets /*6553
                      const uint32_t *postings, uint32_t n_nodes, const uint32_t *node_begin,
                      const uint32_t *node_end, const uint32_t *node_first_child,
                      const uint32_t *node_n_children, const uint8_t *node_type, rtx_index **out);
-/* Convenience: the same from a host tree. */
+/* Index build on the GPU (the k-mer part of Tree::new, src/tree.rs:114-123,134-137): the encoded
+ * reference sequences in lineage-sorted order (sequence i = reference id i) instead of posting lists. */
+int rtx_index_create_from_sequences(int device, uint64_t n_refs, const uint8_t *seq_bytes, const uint64_t *seq_off,
+                                    uint32_t n_nodes, const uint32_t *node_begin, const uint32_t *node_end,
+                                    const uint32_t *node_first_child, const uint32_t *node_n_children,
+                                    const uint8_t *node_type, rtx_index **out);
+/* Convenience: the same from a host tree (GPU build if the tree has no k-mer map). */
 int rtx_index_create_from_tree(int device, const rtx_tree *tree, rtx_index **out);
 void rtx_index_destroy(rtx_index *index);
 uint64_t rtx_index_num_refs(const rtx_index *index);

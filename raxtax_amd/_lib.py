@@ -51,6 +51,7 @@ _SIGNATURES = {
     "rtx_last_error": (C.c_char_p, []),
     "rtx_device_count": (C.c_int, []),
     "rtx_tree_build": (C.c_int, [C.c_uint64, C.c_char_p, u64p, u8p, u64p, C.POINTER(C.c_void_p)]),
+    "rtx_tree_build_ex": (C.c_int, [C.c_uint64, C.c_char_p, u64p, u8p, u64p, C.c_uint32, C.POINTER(C.c_void_p)]),
     "rtx_tree_parse_reference_fasta": (C.c_int, [C.c_char_p, C.c_uint64, C.POINTER(C.c_void_p)]),
     "rtx_tree_destroy": (None, [C.c_void_p]),
     "rtx_tree_num_tips": (C.c_uint64, [C.c_void_p]),
@@ -68,6 +69,8 @@ _SIGNATURES = {
     "rtx_queries_data": (C.c_int, [C.c_void_p, C.POINTER(u8p), C.POINTER(u64p)]),
     "rtx_index_create": (C.c_int, [C.c_int, C.c_uint64, u64p, u32p, C.c_uint32, u32p, u32p, u32p, u32p, u8p,
                                    C.POINTER(C.c_void_p)]),
+    "rtx_index_create_from_sequences": (C.c_int, [C.c_int, C.c_uint64, u8p, u64p, C.c_uint32, u32p, u32p, u32p, u32p, u8p,
+                                                 C.POINTER(C.c_void_p)]),
     "rtx_index_create_from_tree": (C.c_int, [C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]),
     "rtx_index_destroy": (None, [C.c_void_p]),
     "rtx_index_num_refs": (C.c_uint64, [C.c_void_p]),

@@ -54,7 +54,9 @@ class Tree:
         return cls.new_flat(lineages, flat, off)
 
     @classmethod
-    def new_flat(cls, lineages: Sequence[str], seq_bytes: np.ndarray, seq_off: np.ndarray) -> "Tree":
+    def new_flat(cls, lineages: Sequence[str], seq_bytes: np.ndarray, seq_off: np.ndarray,
+                 kmer_map: bool = True) -> "Tree":
+        """kmer_map=False skips the host k-mer map; Index(tree) then builds the bitmaps on the GPU."""
         lib = _lib.load()
         enc = [l.encode() for l in lineages]
         loff = np.zeros(len(enc) + 1, dtype=np.uint64)
@@ -64,8 +66,8 @@ class Tree:
         seq_bytes = np.ascontiguousarray(seq_bytes, dtype=np.uint8)
         seq_off = np.ascontiguousarray(seq_off, dtype=np.uint64)
         h = C.c_void_p()
-        check(lib.rtx_tree_build(len(enc), lbytes, ptr(loff, u64p), ptr(seq_bytes, u8p), ptr(seq_off, u64p),
-                                 C.byref(h)))
+        check(lib.rtx_tree_build_ex(len(enc), lbytes, ptr(loff, u64p), ptr(seq_bytes, u8p), ptr(seq_off, u64p),
+                                    0 if kmer_map else 1, C.byref(h)))
         return cls(h.value)
 
     @property

@@ -198,7 +198,7 @@ static void flatten(rtx_tree &t) {
 }
 
 static int build_tree(std::vector<std::string> &&lineages_in, const uint8_t *seq_bytes, const uint64_t *seq_off,
-                      rtx_tree **out) {
+                      rtx_tree **out, bool with_kmer_map = true) {
     const uint64_t n = lineages_in.size();
     if (n > 0xFFFFFFFFull) {  // check_lineage_size, tree.rs:24-31 (IndexType = u32)
         set_error("too many database sequences for 32-bit indices");
@@ -265,6 +265,11 @@ static int build_tree(std::vector<std::string> &&lineages_in, const uint8_t *seq
         t->sequences[key].push_back((uint32_t)idx);
     }
 
+    if (!with_kmer_map) {  // the bitmaps are then built on the GPU from the sequences (rtx_index_create_from_tree)
+        flatten(*t);
+        *out = t;
+        return RTX_OK;
+    }
     // Tree.k_mer_map (tree.rs:114-123,134-137) as CSR by counting sort: pass 1 counts the
     // distinct k-mers of every reference, pass 2 scatters reference ids in ascending order,
     // which leaves every list sorted and unique.
@@ -304,6 +309,11 @@ const char *rtx_last_error(void) { return rtx::g_err.c_str(); }
 
 int rtx_tree_build(uint64_t n, const char *lineage_bytes, const uint64_t *lineage_off,
                    const uint8_t *seq_bytes, const uint64_t *seq_off, rtx_tree **out) {
+    return rtx_tree_build_ex(n, lineage_bytes, lineage_off, seq_bytes, seq_off, 0, out);
+}
+
+int rtx_tree_build_ex(uint64_t n, const char *lineage_bytes, const uint64_t *lineage_off, const uint8_t *seq_bytes,
+                      const uint64_t *seq_off, uint32_t flags, rtx_tree **out) {
     if (!out || (n && (!lineage_bytes || !lineage_off || !seq_off))) {
         set_error("rtx_tree_build: null argument");
         return RTX_ERR_INVALID;
@@ -311,7 +321,7 @@ int rtx_tree_build(uint64_t n, const char *lineage_bytes, const uint64_t *lineag
     try {
         std::vector<std::string> lin(n);
         for (uint64_t i = 0; i < n; i++) lin[i].assign(lineage_bytes + lineage_off[i], lineage_off[i + 1] - lineage_off[i]);
-        return build_tree(std::move(lin), seq_bytes, seq_off, out);
+        return build_tree(std::move(lin), seq_bytes, seq_off, out, !(flags & RTX_TREE_SKIP_KMER_MAP));
     } catch (const std::bad_alloc &) {
         set_error("rtx_tree_build: out of host memory");
         return RTX_ERR_OOM;
@@ -371,6 +381,7 @@ uint64_t rtx_tree_original_index(const rtx_tree *tree, uint64_t i) {
 }
 int rtx_tree_kmer_csr(const rtx_tree *tree, const uint64_t **offsets, const uint32_t **postings) {
     if (!tree || !offsets || !postings) { set_error("null argument"); return RTX_ERR_INVALID; }
+    if (tree->csr_off.empty()) { set_error("tree was built with RTX_TREE_SKIP_KMER_MAP"); return RTX_ERR_STATE; }
     *offsets = tree->csr_off.data();
     *postings = tree->postings.data();
     return RTX_OK;

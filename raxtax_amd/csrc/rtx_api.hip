@@ -95,7 +95,6 @@ struct rtx_index {
     uint32_t ntiles = 0;        // 8192-reference tiles
     DevBuf<uint32_t> d_bitmap, d_row_of, d_list_len;
     DevBuf<double> d_lnfact, d_inv;
-    std::vector<uint32_t> h_list_len;
     // ---- memoised prob tables (t <= 1023), built lazily for the largest tmax seen
     int prob_mode = 0;  // 0 auto, 1 recurrence kernel only, 2 tables (error if they do not fit)
     uint32_t tab_tmax = 0;
@@ -493,16 +492,15 @@ int rtx_device_count(void) {
     return n;
 }
 
-int rtx_index_create(int device, uint64_t n_refs, const uint64_t *offsets, const uint32_t *postings,
-                     uint32_t n_nodes, const uint32_t *node_begin, const uint32_t *node_end,
-                     const uint32_t *node_first_child, const uint32_t *node_n_children, const uint8_t *node_type,
-                     rtx_index **out) {
-    if (!out || !offsets || !node_begin || !node_end || !node_first_child || !node_n_children || !node_type ||
-        n_refs == 0 || n_refs > 0xFFFFFFFFull) {
+// Everything of index creation except the bitmap: device checks, stream, taxonomy, tables.
+static int create_common(int device, uint64_t n_refs, uint32_t n_nodes, const uint32_t *node_begin,
+                         const uint32_t *node_end, const uint32_t *node_first_child, const uint32_t *node_n_children,
+                         const uint8_t *node_type, rtx_index **out) {
+    if (!out || !node_begin || !node_end || !node_first_child || !node_n_children || !node_type || n_refs == 0 ||
+        n_refs > 0xFFFFFFFFull) {
         set_error("rtx_index_create: invalid argument");
         return RTX_ERR_INVALID;
     }
-    if (offsets[RTX_NUM_KMERS] && !postings) { set_error("rtx_index_create: postings is null"); return RTX_ERR_INVALID; }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) {
         set_error("no usable HIP device (requested %d of %d); libraxtax_hip has no CPU fallback", device, ndev);
@@ -590,22 +588,37 @@ int rtx_index_create(int device, uint64_t n_refs, const uint64_t *offsets, const
             return fail(RTX_ERR_HIP);
         }
     }
+    ix->stride_bytes = (uint32_t)align_up((n_refs + 7) / 8, 128);
+    ix->npad = (uint64_t)ix->stride_bytes * 8;
+    ix->ntiles = (ix->stride_bytes + 1023) / 1024;
+    if ((rc = ix->d_cursor.alloc(1)) || (rc = ix->d_flags.alloc(1))) return fail(rc);
+    *out = ix;
+    return RTX_OK;
+}
+
+int rtx_index_create(int device, uint64_t n_refs, const uint64_t *offsets, const uint32_t *postings,
+                     uint32_t n_nodes, const uint32_t *node_begin, const uint32_t *node_end,
+                     const uint32_t *node_first_child, const uint32_t *node_n_children, const uint8_t *node_type,
+                     rtx_index **out) {
+    if (!offsets) { set_error("rtx_index_create: offsets is null"); return RTX_ERR_INVALID; }
+    if (offsets[RTX_NUM_KMERS] && !postings) { set_error("rtx_index_create: postings is null"); return RTX_ERR_INVALID; }
+    rtx_index *ix = nullptr;
+    int rc = create_common(device, n_refs, n_nodes, node_begin, node_end, node_first_child, node_n_children, node_type, &ix);
+    if (rc) return rc;
+    auto fail = [&](int code) { delete ix; return code; };
     // ---- bitmap index: one row of n_refs bits per non-empty posting list (+ one zero row)
     {
         std::vector<uint32_t> row_of(RTX_NUM_KMERS, kEmptyRow);
-        ix->h_list_len.assign(RTX_NUM_KMERS, 0);
+        std::vector<uint32_t> list_len(RTX_NUM_KMERS, 0);
         uint32_t nr = 0;
         for (uint32_t k = 0; k < RTX_NUM_KMERS; k++) {
             if (offsets[k + 1] < offsets[k]) { set_error("offsets not monotone at k-mer %u", k); return fail(RTX_ERR_INVALID); }
             const uint64_t l = offsets[k + 1] - offsets[k];
             if (l > n_refs) { set_error("posting list %u longer than n_refs", k); return fail(RTX_ERR_INVALID); }
-            ix->h_list_len[k] = (uint32_t)l;
+            list_len[k] = (uint32_t)l;
             if (l) row_of[k] = nr++;
         }
         ix->n_rows = nr;
-        ix->stride_bytes = (uint32_t)align_up((n_refs + 7) / 8, 128);
-        ix->npad = (uint64_t)ix->stride_bytes * 8;
-        ix->ntiles = (ix->stride_bytes + 1023) / 1024;
         const size_t words = (size_t)(nr + 1) * (ix->stride_bytes / 4);
         const uint64_t total = offsets[RTX_NUM_KMERS];
         DevBuf<uint64_t> d_off;
@@ -616,7 +629,7 @@ int rtx_index_create(int device, uint64_t n_refs, const uint64_t *offsets, const
             return fail(rc);
         hipError_t e = hipMemset(ix->d_bitmap.p, 0, words * 4);
         if (e == hipSuccess) e = hipMemcpy(ix->d_row_of.p, row_of.data(), RTX_NUM_KMERS * 4, hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = hipMemcpy(ix->d_list_len.p, ix->h_list_len.data(), RTX_NUM_KMERS * 4, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(ix->d_list_len.p, list_len.data(), RTX_NUM_KMERS * 4, hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMemcpy(d_off.p, offsets, (RTX_NUM_KMERS + 1) * 8, hipMemcpyHostToDevice);
         if (e == hipSuccess && total) e = hipMemcpy(d_post.p, postings, total * 4, hipMemcpyHostToDevice);
         if (e == hipSuccess) {
@@ -625,7 +638,54 @@ int rtx_index_create(int device, uint64_t n_refs, const uint64_t *offsets, const
         }
         if (e != hipSuccess) { set_error("bitmap build failed: %s", hipGetErrorString(e)); return fail(RTX_ERR_HIP); }
     }
-    if ((rc = ix->d_cursor.alloc(1)) || (rc = ix->d_flags.alloc(1))) return fail(rc);
+    *out = ix;
+    return RTX_OK;
+}
+
+// Index build on the GPU from the encoded reference sequences in lineage-sorted order
+// (the k-mer map of Tree::new, tree.rs:114-123,134-137, without ever materialising posting lists).
+int rtx_index_create_from_sequences(int device, uint64_t n_refs, const uint8_t *seq_bytes, const uint64_t *seq_off,
+                                    uint32_t n_nodes, const uint32_t *node_begin, const uint32_t *node_end,
+                                    const uint32_t *node_first_child, const uint32_t *node_n_children,
+                                    const uint8_t *node_type, rtx_index **out) {
+    if (!seq_off || (!seq_bytes && n_refs && seq_off[n_refs])) { set_error("rtx_index_create_from_sequences: null sequences"); return RTX_ERR_INVALID; }
+    rtx_index *ix = nullptr;
+    int rc = create_common(device, n_refs, n_nodes, node_begin, node_end, node_first_child, node_n_children, node_type, &ix);
+    if (rc) return rc;
+    auto fail = [&](int code) { delete ix; return code; };
+    const uint64_t total = seq_off[n_refs] - seq_off[0];
+    DevBuf<uint8_t> d_seq;
+    DevBuf<uint64_t> d_off;
+    DevBuf<uint32_t> d_present;
+    if ((rc = d_seq.alloc(total + 16)) || (rc = d_off.alloc(n_refs + 1)) || (rc = d_present.alloc(2048)) ||
+        (rc = ix->d_row_of.alloc(RTX_NUM_KMERS)) || (rc = ix->d_list_len.alloc(RTX_NUM_KMERS)))
+        return fail(rc);
+    std::vector<uint64_t> off0(n_refs + 1);
+    for (uint64_t i = 0; i <= n_refs; i++) off0[i] = seq_off[i] - seq_off[0];
+    hipError_t e = hipMemcpy(d_seq.p, seq_bytes + seq_off[0], total, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_off.p, off0.data(), (n_refs + 1) * 8, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemset(d_present.p, 0, 2048 * 4);
+    if (e == hipSuccess) {
+        launch_ref_kmer_mark(ix->stream, d_seq.p, d_off.p, n_refs, d_present.p);
+        e = hipStreamSynchronize(ix->stream);
+    }
+    std::vector<uint32_t> present(2048, 0), row_of(RTX_NUM_KMERS, kEmptyRow);
+    if (e == hipSuccess) e = hipMemcpy(present.data(), d_present.p, 2048 * 4, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) { set_error("k-mer marking failed: %s", hipGetErrorString(e)); return fail(RTX_ERR_HIP); }
+    uint32_t nr = 0;
+    for (uint32_t k = 0; k < RTX_NUM_KMERS; k++)
+        if (present[k >> 5] & (1u << (k & 31u))) row_of[k] = nr++;
+    ix->n_rows = nr;
+    const size_t words = (size_t)(nr + 1) * (ix->stride_bytes / 4);
+    if ((rc = ix->d_bitmap.alloc(words))) return fail(rc);
+    e = hipMemset(ix->d_bitmap.p, 0, words * 4);
+    if (e == hipSuccess) e = hipMemcpy(ix->d_row_of.p, row_of.data(), RTX_NUM_KMERS * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        launch_ref_bitmap_set(ix->stream, d_seq.p, d_off.p, n_refs, ix->d_row_of.p, ix->d_bitmap.p, ix->stride_bytes / 4);
+        launch_row_popcount(ix->stream, ix->d_row_of.p, ix->d_bitmap.p, ix->stride_bytes / 4, ix->d_list_len.p);
+        e = hipStreamSynchronize(ix->stream);
+    }
+    if (e != hipSuccess) { set_error("bitmap build from sequences failed: %s", hipGetErrorString(e)); return fail(RTX_ERR_HIP); }
     *out = ix;
     return RTX_OK;
 }
@@ -633,6 +693,10 @@ int rtx_index_create(int device, uint64_t n_refs, const uint64_t *offsets, const
 int rtx_index_create_from_tree(int device, const rtx_tree *tree, rtx_index **out) {
     if (!tree || !out) { set_error("null argument"); return RTX_ERR_INVALID; }
     const FlatNodes &f = tree->flat;
+    if (tree->csr_off.empty())  // tree built without the host k-mer map: build the bitmaps on the GPU
+        return rtx_index_create_from_sequences(device, tree->num_tips, tree->seq_bytes.data(), tree->seq_off.data(), f.size(),
+                                               f.begin.data(), f.end.data(), f.first_child.data(), f.n_children.data(),
+                                               f.type.data(), out);
     return rtx_index_create(device, tree->num_tips, tree->csr_off.data(), tree->postings.data(), f.size(), f.begin.data(),
                             f.end.data(), f.first_child.data(), f.n_children.data(), f.type.data(), out);
 }

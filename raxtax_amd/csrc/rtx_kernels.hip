@@ -38,6 +38,81 @@ __global__ __launch_bounds__(256) void bitmap_build_kernel(const uint64_t *__res
 }
 
 // ---------------------------------------------------------------------------
+// Index build straight from the encoded reference sequences (the k-mer part of Tree::new,
+// src/tree.rs:114-123,134-137).  With one bitmap row per k-mer no sort or
+// dedup pass is needed: setting bit `ref` of row `k` is idempotent.
+//   ref_kmer_mark : which of the 65536 k-mers occur at all (-> row_of on the host)
+//   ref_bitmap_set: bit (row_of[k], ref) for every valid window of every reference
+//   row_popcount  : posting-list lengths (= set bits per row), for the work accounting
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ bool window_kmer(const uint8_t *__restrict__ seq, uint64_t w, uint32_t &k) {
+    k = 0;
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const uint32_t c = seq[w + j];
+        ok = ok && (c == 1u || c == 2u || c == 4u || c == 8u);
+        k |= ((uint32_t)__ffs((int)c) - 1u) << (14 - 2 * j);
+    }
+    k &= 0xFFFFu;
+    return ok;
+}
+
+__global__ __launch_bounds__(64) void ref_kmer_mark_kernel(const uint8_t *__restrict__ bases,
+                                                           const uint64_t *__restrict__ off, uint64_t n_refs,
+                                                           uint32_t *__restrict__ present /*2048 words*/) {
+    __shared__ uint32_t bm[2048];
+    const uint32_t lane = threadIdx.x;
+    for (uint32_t i = lane; i < 2048; i += 64) bm[i] = 0;
+    __syncthreads();
+    for (uint64_t r = blockIdx.x; r < n_refs; r += gridDim.x) {
+        const uint64_t b0 = off[r], len = off[r + 1] - b0;
+        for (uint64_t w = lane; w + 8 <= len; w += 64) {
+            uint32_t k;
+            if (window_kmer(bases + b0, w, k)) atomicOr(&bm[k >> 5], 1u << (k & 31u));
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = lane; i < 2048; i += 64)
+        if (bm[i]) atomicOr(&present[i], bm[i]);
+}
+
+__global__ __launch_bounds__(64) void ref_bitmap_set_kernel(const uint8_t *__restrict__ bases,
+                                                            const uint64_t *__restrict__ off, uint64_t n_refs,
+                                                            const uint32_t *__restrict__ row_of,
+                                                            uint32_t *__restrict__ bitmap, uint32_t stride_words) {
+    const uint64_t r = blockIdx.x;
+    if (r >= n_refs) return;
+    const uint32_t lane = threadIdx.x;
+    const uint64_t b0 = off[r], len = off[r + 1] - b0;
+    const uint32_t word = (uint32_t)(r >> 5), bit = 1u << (r & 31u);
+    for (uint64_t w = lane; w + 8 <= len; w += 64) {
+        uint32_t k;
+        if (window_kmer(bases + b0, w, k)) atomicOr(&bitmap[(size_t)row_of[k] * stride_words + word], bit);
+    }
+}
+
+__global__ __launch_bounds__(256) void row_popcount_kernel(const uint32_t *__restrict__ row_of,
+                                                           const uint32_t *__restrict__ bitmap, uint32_t stride_words,
+                                                           uint32_t *__restrict__ list_len) {
+    __shared__ uint32_t part[4];
+    const uint32_t k = blockIdx.x;
+    const uint32_t row = row_of[k];
+    if (row == kEmptyRow) {
+        if (threadIdx.x == 0) list_len[k] = 0;
+        return;
+    }
+    const uint32_t *src = bitmap + (size_t)row * stride_words;
+    uint32_t c = 0;
+    for (uint32_t i = threadIdx.x; i < stride_words; i += 256) c += __popc(src[i]);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d, 64);
+    if ((threadIdx.x & 63u) == 0) part[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) list_len[k] = part[0] + part[1] + part[2] + part[3];
+}
+
+// ---------------------------------------------------------------------------
 // kmer_extract (src/utils.rs:17-40): one wave per query.
 // A 65536-bit set in LDS gives HashSet semantics; reading it out word by word in
 // ascending order gives `.sorted()`.  Also emits, for hit_count, the list of bitmap rows
@@ -708,6 +783,18 @@ void launch_bitmap_build(hipStream_t s, const uint64_t *off, const uint32_t *pos
                          uint32_t *bitmap, uint32_t stride_words) {
     hipLaunchKernelGGL(bitmap_build_kernel, dim3(RTX_NUM_KMERS), dim3(256), 0, s, off, post, row_of, bitmap,
                        stride_words);
+}
+void launch_ref_kmer_mark(hipStream_t s, const uint8_t *bases, const uint64_t *off, uint64_t n_refs, uint32_t *present) {
+    hipLaunchKernelGGL(ref_kmer_mark_kernel, dim3(4096), dim3(64), 0, s, bases, off, n_refs, present);
+}
+void launch_ref_bitmap_set(hipStream_t s, const uint8_t *bases, const uint64_t *off, uint64_t n_refs,
+                           const uint32_t *row_of, uint32_t *bitmap, uint32_t stride_words) {
+    hipLaunchKernelGGL(ref_bitmap_set_kernel, dim3((unsigned)n_refs), dim3(64), 0, s, bases, off, n_refs, row_of, bitmap,
+                       stride_words);
+}
+void launch_row_popcount(hipStream_t s, const uint32_t *row_of, const uint32_t *bitmap, uint32_t stride_words,
+                         uint32_t *list_len) {
+    hipLaunchKernelGGL(row_popcount_kernel, dim3(RTX_NUM_KMERS), dim3(256), 0, s, row_of, bitmap, stride_words, list_len);
 }
 void launch_kmer_extract(hipStream_t s, const KmerParams &p, uint32_t nq) {
     hipLaunchKernelGGL(kmer_extract_kernel, dim3(nq), dim3(64), 0, s, p);

@@ -350,3 +350,24 @@ def test_long_queries_use_recurrence_path(oracle):
         assert np.max(np.abs(ix.debug_probs(q) - probs_ref)) < TOL_TIGHT
         rows, _ = otree.classify(s, raw_confidence=True)
         assert_rows_equivalent(res.rows(q), rows, probs_ref, lins, f"long q{q}")
+
+
+def test_gpu_index_build_from_sequences(world):
+    """the bitmaps built on the GPU straight from the reference sequences (no host k-mer map)
+    give the same hit counts, work accounting and results as the index uploaded from Tree.k_mer_map."""
+    w = world
+    db = w["db"]
+    tree2 = rx.Tree.new_flat(db.lineages, db.seq_bytes, db.seq_off, kmer_map=False)
+    assert tree2.lineages == w["tree"].lineages
+    with pytest.raises(rx.RtxError):
+        tree2.csr()
+    ix2 = rx.Index(tree2)
+    ex_ids, ex_off = w["index"].exact_matches(w["bases"], w["off"])
+    ref = w["index"].classify(w["bases"], w["off"], ex_ids, ex_off)
+    work_ref = w["index"].work()
+    got = ix2.classify(w["bases"], w["off"], ex_ids, ex_off)
+    assert ix2.work() == work_ref
+    for q in range(0, len(w["seqs"]), 5):
+        assert np.array_equal(ix2.debug_hit_counts(q), w["index"].debug_hit_counts(q))
+    assert np.array_equal(got.row_off, ref.row_off) and np.array_equal(got.row_lineage, ref.row_lineage)
+    assert np.array_equal(got.row_conf, ref.row_conf) and np.array_equal(got.global_signal, ref.global_signal)

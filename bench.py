@@ -43,6 +43,9 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--skip-exact-matches", action="store_true")
+    ap.add_argument("--shard-db", action="store_true",
+                    help="BASELINE configs[4]: shard the REFERENCES over the GPUs (every rank classifies the same "
+                         "queries; RCCL all-reduce of histograms + all-gather of prefix sums per sub-batch)")
     return ap.parse_args()
 
 
@@ -87,6 +90,59 @@ def measured_traffic(args, launches_per_step):
     return None
 
 
+def bench_sharded_db(args, rx, synth, db, tree, dist, rank, local_rank, world, flags):
+    """Reference-sharded database: rank r holds references [cuts[r], cuts[r+1]); all ranks classify the same
+    --queries; strong scaling (total work fixed)."""
+    import torch
+
+    from raxtax_amd import sharded
+
+    qs = synth.make_queries(db, args.queries, seed=3)              # identical on every rank
+    cuts = sharded.shard_cuts(tree.num_tips, world)
+    shard = sharded.ShardIndex(tree, rank, cuts, device=local_rank, sub_batch=args.sub_batch or 2048)
+    if dist is not None:
+        w = torch.tensor([shard.n_bnd_local], device="cuda", dtype=torch.int64)
+        ws = [torch.zeros_like(w) for _ in range(world)]
+        dist.all_gather(ws, w)
+        comm = sharded.TorchComm(dist, world, [int(x.item()) for x in ws])
+    else:
+        comm = sharded.LocalComm()
+    clf = sharded.ShardedClassifier([shard], comm)
+    ex_ids, ex_off = shard.exact_matches(qs.bases, qs.base_off)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        clf.classify(qs.bases, qs.base_off, ex_ids, ex_off, skip_exact_matches=bool(flags))
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = clf.classify(qs.bases, qs.base_off, ex_ids, ex_off, skip_exact_matches=bool(flags))
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    if rank == 0:
+        print(json.dumps({
+            "metric": "classified queries/sec (whole node)", "value": args.queries * args.steps / elapsed,
+            "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "u32 bit-planes + f64", "data": "synthetic",
+            "config": {"workload": f"{args.queries} synthetic 658-bp queries vs {args.refs}-seq DB sharded by reference id "
+                                   f"over {world} GPU(s) (BASELINE.json configs[4] shape; includes H2D of the queries)",
+                       "refs": args.refs, "queries": args.queries, "parallelism": f"references sharded x{world}",
+                       "classified_ok": int((res.status == 0).sum())},
+            "roofline": None, "cpu_baseline": None}), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -114,10 +170,12 @@ def main():
     db = synth.make_db(args.refs)
     qs = synth.make_queries(db, args.queries, seed=3 + rank, first_label=rank * args.queries)
     tree = rx.Tree.new_flat(db.lineages, db.seq_bytes, db.seq_off)
+    flags = rx.RTX_SKIP_EXACT_MATCHES if args.skip_exact_matches else 0
+    if args.shard_db:
+        return bench_sharded_db(args, rx, synth, db, tree, dist, rank, local_rank, world, flags)
     index = rx.Index(tree, device=local_rank, sub_batch=args.sub_batch)
     ex_ids, ex_off = index.exact_matches(qs.bases, qs.base_off)   # Tree.sequences.get, raxtax.rs:42 (host)
     index.upload(qs.bases, qs.base_off, ex_ids, ex_off)            # inputs resident in HBM from here on
-    flags = rx.RTX_SKIP_EXACT_MATCHES if args.skip_exact_matches else 0
 
     def step():
         index.run(flags)

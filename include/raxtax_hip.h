@@ -132,6 +132,16 @@ int rtx_index_create(int device, uint64_t n_refs, const uint64_t *offsets /*6553
                      const uint32_t *postings, uint32_t n_nodes, const uint32_t *node_begin,
                      const uint32_t *node_end, const uint32_t *node_first_child,
                      const uint32_t *node_n_children, const uint8_t *node_type, rtx_index **out);
+/* One shard of a reference-sharded database (BASELINE.json configs[4]): the handle holds the bitmaps of
+ * references [ref_lo, ref_hi) only; offsets/postings and the taxonomy are those of the WHOLE database
+ * (global ids).  shard_cuts lists the boundaries of all shards (every rank passes the same list) so that
+ * the taxonomy boundary numbering is identical on every rank.  Such a handle is driven with
+ * rtx_shard_begin / _count / _prob / _walk (below) instead of rtx_batch_run. */
+int rtx_index_create_shard(int device, uint64_t n_refs_total, uint64_t ref_lo, uint64_t ref_hi,
+                           const uint64_t *shard_cuts, uint32_t n_cuts, const uint64_t *offsets,
+                           const uint32_t *postings, uint32_t n_nodes, const uint32_t *node_begin,
+                           const uint32_t *node_end, const uint32_t *node_first_child,
+                           const uint32_t *node_n_children, const uint8_t *node_type, rtx_index **out);
 /* Index build on the GPU (the k-mer part of Tree::new, src/tree.rs:114-123,134-137): the encoded
  * reference sequences in lineage-sorted order (sequence i = reference id i) instead of posting lists. */
 int rtx_index_create_from_sequences(int device, uint64_t n_refs, const uint8_t *seq_bytes, const uint64_t *seq_off,
@@ -190,6 +200,23 @@ int rtx_batch_upload(rtx_index *index, uint64_t n_queries, const uint8_t *bases,
 int rtx_batch_run(rtx_index *index, uint32_t flags); /* enqueue all kernels (async)        */
 int rtx_batch_sync(rtx_index *index);                /* wait for the handle's stream        */
 int rtx_batch_download(rtx_index *index, rtx_result_view *out);
+
+/* ---- staged execution of a reference-sharded handle (one sub-batch at a time) --------------------
+ * Between the stages the caller exchanges two device buffers with the other shards (RCCL):
+ *   after rtx_shard_count: all-reduce(sum) RTX_BUF_HIST   ([n][row_stride] uint32, n = queries of the sub-batch)
+ *   after rtx_shard_prob : all-gather  RTX_BUF_PREFIX ([n][n_bnd_local] double); the global prefix row is the
+ *                          concatenation over shards of prefix_s[1..] + sum of the totals prefix_s'[last] of
+ *                          the shards s' < s, preceded by a 0 (n_bnd_global values) -> rtx_shard_walk.
+ * Stages are asynchronous on the handle's stream: rtx_batch_sync before touching a buffer. */
+#define RTX_BUF_HIST 1
+#define RTX_BUF_PREFIX 2
+int rtx_shard_begin(rtx_index *index, uint32_t *n_sub_batches, uint32_t *sub_batch);
+int rtx_shard_count(rtx_index *index, uint32_t sub_batch_idx, uint32_t flags);
+int rtx_shard_prob(rtx_index *index, uint32_t sub_batch_idx);
+int rtx_shard_walk(rtx_index *index, uint32_t sub_batch_idx, const double *prefix_global /* device */);
+int rtx_shard_info(const rtx_index *index, uint64_t *ref_lo, uint64_t *ref_hi, uint32_t *n_bnd_global,
+                   uint32_t *n_bnd_local, uint32_t *first_bnd);
+int rtx_device_buffer(rtx_index *index, int which, void **device_ptr, uint64_t *row_stride_elems);
 
 /* Per-kernel device time of the last rtx_batch_run, from HIP events on the library's
  * stream (ms, summed over sub-batches), and launch counts.  Stage order: */

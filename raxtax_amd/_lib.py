@@ -69,6 +69,14 @@ _SIGNATURES = {
     "rtx_queries_data": (C.c_int, [C.c_void_p, C.POINTER(u8p), C.POINTER(u64p)]),
     "rtx_index_create": (C.c_int, [C.c_int, C.c_uint64, u64p, u32p, C.c_uint32, u32p, u32p, u32p, u32p, u8p,
                                    C.POINTER(C.c_void_p)]),
+    "rtx_index_create_shard": (C.c_int, [C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, u64p, C.c_uint32, u64p, u32p, C.c_uint32,
+                                        u32p, u32p, u32p, u32p, u8p, C.POINTER(C.c_void_p)]),
+    "rtx_shard_begin": (C.c_int, [C.c_void_p, u32p, u32p]),
+    "rtx_shard_count": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32]),
+    "rtx_shard_prob": (C.c_int, [C.c_void_p, C.c_uint32]),
+    "rtx_shard_walk": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p]),
+    "rtx_shard_info": (C.c_int, [C.c_void_p, u64p, u64p, u32p, u32p, u32p]),
+    "rtx_device_buffer": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), u64p]),
     "rtx_index_create_from_sequences": (C.c_int, [C.c_int, C.c_uint64, u8p, u64p, C.c_uint32, u32p, u32p, u32p, u32p, u8p,
                                                  C.POINTER(C.c_void_p)]),
     "rtx_index_create_from_tree": (C.c_int, [C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]),
@@ -108,6 +116,13 @@ def load() -> C.CDLL:
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `python -m raxtax_amd._build` (hipcc, gfx950). "
             "raxtax_amd has no CPU fallback.")
+    # PyTorch-ROCm bundles its own libamdhip64; two HIP runtimes in one process do not both see the GPU.
+    # Importing torch first makes libraxtax_hip.so resolve to the runtime that is already loaded, so the
+    # library and torch.distributed (RCCL) share one (bench.py, raxtax_amd/sharded.py).  Optional.
+    try:
+        import torch  # noqa: F401
+    except Exception:  # pragma: no cover - torch is plumbing, not a requirement of the library
+        pass
     lib = C.CDLL(str(LIB_PATH))
     for name, (res, args) in _SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the ABI is incomplete

@@ -87,7 +87,11 @@ inline uint64_t align_up(uint64_t v, uint64_t a) { return (v + a - 1) / a * a; }
 struct rtx_index {
     int device = -1;
     hipStream_t stream = nullptr;
-    uint64_t n_refs = 0;
+    uint64_t n_refs = 0;    // references held by this handle (the whole database, or one shard of it)
+    uint64_t n_total = 0;   // references of the whole database (Tree.num_tips)
+    uint32_t ref_lo = 0;    // first global reference id of this shard
+    uint32_t n_bnd_local = 0, bnd_first = 0;  // boundaries in (ref_lo, ref_hi] + 1; global index of ref_lo
+    const double *ext_prefix = nullptr;       // sharded mode: assembled global prefix handed to the walk
     // ---- index proper
     uint32_t n_rows = 0;        // non-empty posting lists
     uint32_t stride_bytes = 0;  // bytes per bitmap row (multiple of 128)
@@ -176,136 +180,188 @@ int ensure_events(rtx_index *ix, size_t count) {
     return RTX_OK;
 }
 
-// Enqueues every kernel of the uploaded batch on the handle's stream.
-int enqueue_batch(rtx_index *ix, uint32_t flags) {
+// One sub-batch = three groups of kernels.  A whole-database handle runs them back to back; a
+// reference-sharded handle (config 5) stops after each group for the exchange with the other shards.
+struct SubBatch {
+    uint32_t sb, nq, set;
+    uint64_t q0;
+    hipStream_t s;
+    bool timed;
+};
+
+SubBatch sub_batch_of(rtx_index *ix, uint32_t sb, bool timed) {
+    SubBatch b;
+    b.sb = sb;
+    b.q0 = (uint64_t)sb * ix->sub_batch;
+    b.nq = (uint32_t)std::min<uint64_t>(ix->sub_batch, ix->n_q - b.q0);
+    b.set = ix->n_streams == 2 ? (sb & 1u) : 0u;
+    b.s = b.set ? ix->stream2 : ix->stream;
+    b.timed = timed;
+    return b;
+}
+
+hipEvent_t stage_event(rtx_index *ix, const SubBatch &b, int stage, int which) {
+    return ix->events[((size_t)b.sb * RTX_NUM_STAGES + stage) * 2 + which];
+}
+
+// group 1: kmer_extract + hit_count -> counts, per-shard histogram
+int enqueue_count(rtx_index *ix, const SubBatch &b, uint32_t flags) {
+    rtx_index::Scratch &sc = ix->sc[b.set];
+    hipStream_t s = b.s;
+    ix->last_set = b.set;
+    KmerParams kp{};
+    kp.bases = ix->d_bases.p;
+    kp.base_off = ix->d_base_off.p;
+    kp.q0 = b.q0;
+    kp.row_of = ix->d_row_of.p;
+    kp.list_len = ix->d_list_len.p;
+    kp.zero_row = ix->n_rows;
+    kp.kmers = sc.d_kmers.p;
+    kp.kstride = ix->kstride;
+    kp.rows = sc.d_rows.p;
+    kp.rstride = ix->rstride;
+    kp.t = sc.d_t.p;
+    kp.nrows = sc.d_nrows.p;
+    kp.hq = ix->d_hq.p;
+    kp.t_all = ix->d_t_all.p;
+    kp.nrows_all = ix->d_nrows_all.p;
+    if (b.timed) RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_KMER_EXTRACT, 0), s));
+    launch_kmer_extract(s, kp, b.nq);
+    if (b.timed) RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_KMER_EXTRACT, 1), s));
+
+    RTX_HIP(hipMemsetAsync(sc.d_hist.p, 0, (size_t)b.nq * ix->hstride * sizeof(uint32_t), s));
+    HitParams hp{};
+    hp.bitmap = ix->d_bitmap.p;
+    hp.stride_bytes = ix->stride_bytes;
+    hp.n_refs = ix->n_refs;
+    hp.ref_base = ix->ref_lo;
+    hp.rows = sc.d_rows.p;
+    hp.rstride = ix->rstride;
+    hp.nrows = sc.d_nrows.p;
+    hp.t = sc.d_t.p;
+    hp.counts = sc.d_counts.p;
+    hp.npad = ix->npad;
+    hp.hist = sc.d_hist.p;
+    hp.hstride = ix->hstride;
+    hp.flags = flags;
+    hp.q0 = b.q0;
+    hp.exact_ids = ix->d_exact_ids.p;
+    hp.exact_off = ix->d_exact_off.p;
+    if (b.timed) RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_HIT_COUNT, 0), s));
+    launch_hit_count(s, hp, b.nq, ix->ntiles, ix->planes);
+    if (b.timed) RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_HIT_COUNT, 1), s));
+    return RTX_OK;
+}
+
+// group 2: prob table from the (whole-database) histogram + prefix sums over this handle's references
+int enqueue_prob_prefix(rtx_index *ix, const SubBatch &b) {
+    rtx_index::Scratch &sc = ix->sc[b.set];
+    hipStream_t s = b.s;
+    ProbParams pp{};
+    pp.t = sc.d_t.p;
+    pp.hist = sc.d_hist.p;
+    pp.hstride = ix->hstride;
+    pp.tmax = ix->tmax;
+    pp.n1max = ix->tmax / 2 + 1;
+    pp.lnfact = ix->d_lnfact.p;
+    pp.n_refs = ix->n_total;
+    pp.q0 = b.q0;
+    pp.table_z = sc.d_table_z.p;
+    pp.z = ix->d_z.p;
+    pp.gs = ix->d_gs.p;
+    pp.status = ix->d_status.p;
+    if (b.timed) RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_PROB_TABLE, 0), s));
+    if (ix->use_tables) {
+        ProbTables tb{ix->d_tab_cmf.p, ix->d_tab_ratio.p, ix->d_tab_off.p, ix->d_tab_moff.p,
+                      ix->d_tab_ilo.p, ix->d_tab_sat.p, ix->tab_tmax};
+        launch_prob_order(s, sc.d_t.p, b.nq, sc.d_order.p);
+        pp.order = sc.d_order.p;
+        launch_prob_lookup(s, pp, tb, b.nq);
+    } else {
+        launch_prob_table(s, pp, b.nq);
+    }
+    if (b.timed) RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_PROB_TABLE, 1), s));
+
+    PrefixParams fp{};
+    fp.status = ix->d_status.p;
+    fp.t = sc.d_t.p;
+    fp.tz_in_lds = 0;
+    fp.q0 = b.q0;
+    fp.counts = sc.d_counts.p;
+    fp.npad = ix->npad;
+    fp.table_z = sc.d_table_z.p;
+    fp.hstride = ix->hstride;
+    fp.n_refs = ix->n_refs;
+    fp.bnd_bits = ix->d_bnd_bits.p;
+    fp.bnd_rank = ix->d_bnd_rank.p;
+    fp.prefix = sc.d_prefix.p;
+    fp.n_bnd = ix->n_bnd_local;
+    if (b.timed) RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_TAXON_PREFIX, 0), s));
+    launch_taxon_prefix(s, fp, b.nq);
+    if (b.timed) RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_TAXON_PREFIX, 1), s));
+    return RTX_OK;
+}
+
+// group 3: taxonomy walk over prefix sums covering the WHOLE database ([nq][n_bnd], device)
+int enqueue_walk(rtx_index *ix, const SubBatch &b, const double *prefix) {
+    hipStream_t s = b.s;
+    WalkParams wp{};
+    wp.status = ix->d_status.p;
+    wp.q0 = b.q0;
+    wp.prefix = prefix;
+    wp.n_bnd = ix->n_bnd;
+    wp.blo = ix->d_blo.p;
+    wp.bhi = ix->d_bhi.p;
+    wp.first_child = ix->d_first.p;
+    wp.n_children = ix->d_nch.p;
+    wp.type = ix->d_type.p;
+    wp.arena = ix->d_arena.p;
+    wp.arena_cap = ix->arena_cap;
+    wp.arena_cursor = ix->d_cursor.p;
+    wp.n_rows = ix->d_n_rows.p;
+    wp.row_start = ix->d_row_start.p;
+    wp.flags_out = ix->d_flags.p;
+    if (b.timed) RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_LINEAGE_WALK, 0), s));
+    launch_lineage_walk(s, wp, b.nq);
+    if (b.timed) RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_LINEAGE_WALK, 1), s));
+    return RTX_OK;
+}
+
+int begin_run(rtx_index *ix, uint32_t *n_sub_out, bool *timed_out) {
     RTX_HIP(hipMemsetAsync(ix->d_cursor.p, 0, sizeof(unsigned long long), ix->stream));
     RTX_HIP(hipMemsetAsync(ix->d_flags.p, 0, sizeof(uint32_t), ix->stream));
-    const bool two = ix->n_streams == 2;
-    if (two) {  // the second stream starts after the resets above
-        RTX_HIP(hipEventRecord(ix->ev_fork, ix->stream));
-        RTX_HIP(hipStreamWaitEvent(ix->stream2, ix->ev_fork, 0));
-    }
-    const uint32_t B = ix->sub_batch;
-    const uint32_t n_sub = (uint32_t)((ix->n_q + B - 1) / B);
+    const uint32_t n_sub = (uint32_t)((ix->n_q + ix->sub_batch - 1) / ix->sub_batch);
     const bool timed = n_sub <= 4096;
     if (timed) {
         int rc = ensure_events(ix, (size_t)n_sub * RTX_NUM_STAGES * 2);
         if (rc) return rc;
     }
     ix->n_sub_last = timed ? n_sub : 0;
+    *n_sub_out = n_sub;
+    *timed_out = timed;
+    return RTX_OK;
+}
+
+// Enqueues every kernel of the uploaded batch (whole-database handle).
+int enqueue_batch(rtx_index *ix, uint32_t flags) {
+    if (ix->n_refs != ix->n_total) {
+        set_error("this handle holds a reference shard: drive it with rtx_shard_count/_prob/_walk");
+        return RTX_ERR_STATE;
+    }
+    uint32_t n_sub = 0;
+    bool timed = false;
+    int rc = begin_run(ix, &n_sub, &timed);
+    if (rc) return rc;
+    const bool two = ix->n_streams == 2;
+    if (two) {  // the second stream starts after the resets above
+        RTX_HIP(hipEventRecord(ix->ev_fork, ix->stream));
+        RTX_HIP(hipStreamWaitEvent(ix->stream2, ix->ev_fork, 0));
+    }
     for (uint32_t sb = 0; sb < n_sub; sb++) {
-        const uint64_t q0 = (uint64_t)sb * B;
-        const uint32_t nq = (uint32_t)std::min<uint64_t>(B, ix->n_q - q0);
-        const uint32_t set = two ? (sb & 1u) : 0u;
-        rtx_index::Scratch &sc = ix->sc[set];
-        hipStream_t s = set ? ix->stream2 : ix->stream;
-        ix->last_set = set;
-        auto ev = [&](int stage, int which) -> hipEvent_t {
-            return ix->events[((size_t)sb * RTX_NUM_STAGES + stage) * 2 + which];
-        };
-        KmerParams kp{};
-        kp.bases = ix->d_bases.p;
-        kp.base_off = ix->d_base_off.p;
-        kp.q0 = q0;
-        kp.row_of = ix->d_row_of.p;
-        kp.list_len = ix->d_list_len.p;
-        kp.zero_row = ix->n_rows;
-        kp.kmers = sc.d_kmers.p;
-        kp.kstride = ix->kstride;
-        kp.rows = sc.d_rows.p;
-        kp.rstride = ix->rstride;
-        kp.t = sc.d_t.p;
-        kp.nrows = sc.d_nrows.p;
-        kp.hq = ix->d_hq.p;
-        kp.t_all = ix->d_t_all.p;
-        kp.nrows_all = ix->d_nrows_all.p;
-        if (timed) RTX_HIP(hipEventRecord(ev(RTX_STAGE_KMER_EXTRACT, 0), s));
-        launch_kmer_extract(s, kp, nq);
-        if (timed) RTX_HIP(hipEventRecord(ev(RTX_STAGE_KMER_EXTRACT, 1), s));
-
-        RTX_HIP(hipMemsetAsync(sc.d_hist.p, 0, (size_t)nq * ix->hstride * sizeof(uint32_t), s));
-        HitParams hp{};
-        hp.bitmap = ix->d_bitmap.p;
-        hp.stride_bytes = ix->stride_bytes;
-        hp.n_refs = ix->n_refs;
-        hp.rows = sc.d_rows.p;
-        hp.rstride = ix->rstride;
-        hp.nrows = sc.d_nrows.p;
-        hp.t = sc.d_t.p;
-        hp.counts = sc.d_counts.p;
-        hp.npad = ix->npad;
-        hp.hist = sc.d_hist.p;
-        hp.hstride = ix->hstride;
-        hp.flags = flags;
-        hp.q0 = q0;
-        hp.exact_ids = ix->d_exact_ids.p;
-        hp.exact_off = ix->d_exact_off.p;
-        if (timed) RTX_HIP(hipEventRecord(ev(RTX_STAGE_HIT_COUNT, 0), s));
-        launch_hit_count(s, hp, nq, ix->ntiles, ix->planes);
-        if (timed) RTX_HIP(hipEventRecord(ev(RTX_STAGE_HIT_COUNT, 1), s));
-
-        ProbParams pp{};
-        pp.t = sc.d_t.p;
-        pp.hist = sc.d_hist.p;
-        pp.hstride = ix->hstride;
-        pp.tmax = ix->tmax;
-        pp.n1max = ix->tmax / 2 + 1;
-        pp.lnfact = ix->d_lnfact.p;
-        pp.n_refs = ix->n_refs;
-        pp.q0 = q0;
-        pp.table_z = sc.d_table_z.p;
-        pp.z = ix->d_z.p;
-        pp.gs = ix->d_gs.p;
-        pp.status = ix->d_status.p;
-        if (timed) RTX_HIP(hipEventRecord(ev(RTX_STAGE_PROB_TABLE, 0), s));
-        if (ix->use_tables) {
-            ProbTables tb{ix->d_tab_cmf.p, ix->d_tab_ratio.p, ix->d_tab_off.p, ix->d_tab_moff.p,
-                          ix->d_tab_ilo.p, ix->d_tab_sat.p, ix->tab_tmax};
-            launch_prob_order(s, sc.d_t.p, nq, sc.d_order.p);
-            pp.order = sc.d_order.p;
-            launch_prob_lookup(s, pp, tb, nq);
-        } else {
-            launch_prob_table(s, pp, nq);
-        }
-        if (timed) RTX_HIP(hipEventRecord(ev(RTX_STAGE_PROB_TABLE, 1), s));
-
-        PrefixParams fp{};
-        fp.status = ix->d_status.p;
-        fp.t = sc.d_t.p;
-        fp.tz_in_lds = (size_t)ix->hstride * 8 <= 48 * 1024 ? 1u : 0u;
-        fp.q0 = q0;
-        fp.counts = sc.d_counts.p;
-        fp.npad = ix->npad;
-        fp.table_z = sc.d_table_z.p;
-        fp.hstride = ix->hstride;
-        fp.n_refs = ix->n_refs;
-        fp.bnd_bits = ix->d_bnd_bits.p;
-        fp.bnd_rank = ix->d_bnd_rank.p;
-        fp.prefix = sc.d_prefix.p;
-        fp.n_bnd = ix->n_bnd;
-        if (timed) RTX_HIP(hipEventRecord(ev(RTX_STAGE_TAXON_PREFIX, 0), s));
-        launch_taxon_prefix(s, fp, nq);
-        if (timed) RTX_HIP(hipEventRecord(ev(RTX_STAGE_TAXON_PREFIX, 1), s));
-
-        WalkParams wp{};
-        wp.status = ix->d_status.p;
-        wp.q0 = q0;
-        wp.prefix = sc.d_prefix.p;
-        wp.n_bnd = ix->n_bnd;
-        wp.blo = ix->d_blo.p;
-        wp.bhi = ix->d_bhi.p;
-        wp.first_child = ix->d_first.p;
-        wp.n_children = ix->d_nch.p;
-        wp.type = ix->d_type.p;
-        wp.arena = ix->d_arena.p;
-        wp.arena_cap = ix->arena_cap;
-        wp.arena_cursor = ix->d_cursor.p;
-        wp.n_rows = ix->d_n_rows.p;
-        wp.row_start = ix->d_row_start.p;
-        wp.flags_out = ix->d_flags.p;
-        if (timed) RTX_HIP(hipEventRecord(ev(RTX_STAGE_LINEAGE_WALK, 0), s));
-        launch_lineage_walk(s, wp, nq);
-        if (timed) RTX_HIP(hipEventRecord(ev(RTX_STAGE_LINEAGE_WALK, 1), s));
+        const SubBatch b = sub_batch_of(ix, sb, timed);
+        if ((rc = enqueue_count(ix, b, flags)) || (rc = enqueue_prob_prefix(ix, b)) ||
+            (rc = enqueue_walk(ix, b, ix->sc[b.set].d_prefix.p)))
+            return rc;
     }
     if (two) {  // everything is complete once the main stream is: join the second stream into it
         RTX_HIP(hipEventRecord(ix->ev_join, ix->stream2));
@@ -392,7 +448,7 @@ int prepare_workspace(rtx_index *ix, uint64_t n_queries, uint64_t tmax, uint64_t
         RTX_HIP(hipEventCreateWithFlags(&ix->ev_join, hipEventDisableTiming));
     }
     const uint64_t per_q = ((uint64_t)ix->kstride * 2 + (uint64_t)ix->rstride * 4 + ix->npad * 2 + (uint64_t)ix->hstride * 12 +
-                            (uint64_t)ix->n_bnd * 8 + 64) * ix->n_streams;
+                            (uint64_t)ix->n_bnd_local * 8 + 64) * ix->n_streams;
     uint32_t B = ix->sub_batch_req;
     if (B == 0) {
         size_t free_b = 0, total_b = 0;
@@ -410,7 +466,7 @@ int prepare_workspace(rtx_index *ix, uint64_t n_queries, uint64_t tmax, uint64_t
         if ((rc = sc.d_kmers.alloc((size_t)B * ix->kstride)) || (rc = sc.d_rows.alloc((size_t)B * ix->rstride)) ||
             (rc = sc.d_t.alloc(B)) || (rc = sc.d_nrows.alloc(B)) || (rc = sc.d_counts.alloc((size_t)B * ix->npad)) ||
             (rc = sc.d_hist.alloc((size_t)B * ix->hstride)) || (rc = sc.d_table_z.alloc((size_t)B * ix->hstride)) ||
-            (rc = sc.d_prefix.alloc((size_t)B * ix->n_bnd)) || (rc = sc.d_order.alloc(B)))
+            (rc = sc.d_prefix.alloc((size_t)B * ix->n_bnd_local)) || (rc = sc.d_order.alloc(B)))
             return rc;
     }
     return RTX_OK;
@@ -447,7 +503,7 @@ double euclidean_distance_l1(const double *a, const double *b, uint32_t n) {  //
 
 void finalise_range(rtx_index *ix, uint64_t qa, uint64_t qb) {
     const FlatNodes &f = ix->nodes;
-    const double N = (double)ix->n_refs;
+    const double N = (double)ix->n_total;
     std::vector<HostRow> rows;
     for (uint64_t q = qa; q < qb; q++) {
         const uint32_t nr = ix->h_n_rows[q];
@@ -493,14 +549,16 @@ int rtx_device_count(void) {
 }
 
 // Everything of index creation except the bitmap: device checks, stream, taxonomy, tables.
-static int create_common(int device, uint64_t n_refs, uint32_t n_nodes, const uint32_t *node_begin,
-                         const uint32_t *node_end, const uint32_t *node_first_child, const uint32_t *node_n_children,
-                         const uint8_t *node_type, rtx_index **out) {
-    if (!out || !node_begin || !node_end || !node_first_child || !node_n_children || !node_type || n_refs == 0 ||
-        n_refs > 0xFFFFFFFFull) {
+static int create_common(int device, uint64_t n_total, uint64_t ref_lo, uint64_t ref_hi, const uint64_t *cuts,
+                         uint32_t n_cuts, uint32_t n_nodes, const uint32_t *node_begin, const uint32_t *node_end,
+                         const uint32_t *node_first_child, const uint32_t *node_n_children, const uint8_t *node_type,
+                         rtx_index **out) {
+    if (!out || !node_begin || !node_end || !node_first_child || !node_n_children || !node_type || n_total == 0 ||
+        n_total > 0xFFFFFFFFull || ref_lo >= ref_hi || ref_hi > n_total) {
         set_error("rtx_index_create: invalid argument");
         return RTX_ERR_INVALID;
     }
+    const uint64_t n_refs = ref_hi - ref_lo;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) {
         set_error("no usable HIP device (requested %d of %d); libraxtax_hip has no CPU fallback", device, ndev);
@@ -516,9 +574,11 @@ static int create_common(int device, uint64_t n_refs, uint32_t n_nodes, const ui
     auto ix = new rtx_index();
     ix->device = device;
     ix->n_refs = n_refs;
+    ix->n_total = n_total;
+    ix->ref_lo = (uint32_t)ref_lo;
     int rc = RTX_OK;
     auto fail = [&](int code) { delete ix; return code; };
-    if (!derive_flat_nodes(n_refs, n_nodes, node_begin, node_end, node_first_child, node_n_children, node_type, ix->nodes))
+    if (!derive_flat_nodes(n_total, n_nodes, node_begin, node_end, node_first_child, node_n_children, node_type, ix->nodes))
         return fail(RTX_ERR_INVALID);
     if (ix->nodes.max_depth > RTX_MAX_DEPTH) {
         set_error("lineage depth %u exceeds RTX_MAX_DEPTH=%u", ix->nodes.max_depth, RTX_MAX_DEPTH);
@@ -533,7 +593,13 @@ static int create_common(int device, uint64_t n_refs, uint32_t n_nodes, const ui
         std::vector<uint32_t> b;
         b.reserve(2 * (size_t)n_nodes + 2);
         b.push_back(0);
-        b.push_back((uint32_t)n_refs);
+        b.push_back((uint32_t)n_total);
+        b.push_back((uint32_t)ref_lo);
+        b.push_back((uint32_t)ref_hi);
+        for (uint32_t c = 0; c < n_cuts; c++) {  // shard cut points: identical boundary lists on every rank
+            if (cuts[c] > n_total) { set_error("shard cut %llu beyond n_refs", (unsigned long long)cuts[c]); return fail(RTX_ERR_INVALID); }
+            b.push_back((uint32_t)cuts[c]);
+        }
         for (uint32_t v = 0; v < n_nodes; v++) { b.push_back(ix->nodes.begin[v]); b.push_back(ix->nodes.end[v]); }
         std::sort(b.begin(), b.end());
         b.erase(std::unique(b.begin(), b.end()), b.end());
@@ -544,12 +610,18 @@ static int create_common(int device, uint64_t n_refs, uint32_t n_nodes, const ui
             blo[v] = (uint32_t)(std::lower_bound(ix->bnd.begin(), ix->bnd.end(), ix->nodes.begin[v]) - ix->bnd.begin());
             bhi[v] = (uint32_t)(std::lower_bound(ix->bnd.begin(), ix->bnd.end(), ix->nodes.end[v]) - ix->bnd.begin());
         }
+        // flags / ranks over the LOCAL references: boundary position p in (ref_lo, ref_hi] belongs to
+        // local reference p - 1 - ref_lo; local boundary 0 is ref_lo itself
         const size_t nchunk = (size_t)((n_refs + 7) / 8);
         std::vector<uint8_t> bits(nchunk, 0);
         std::vector<uint32_t> rank(nchunk, 0);
-        for (uint32_t j = 1; j < ix->n_bnd; j++) {  // boundary position p >= 1 belongs to reference p-1
-            const uint32_t r = ix->bnd[j] - 1;
+        ix->bnd_first = (uint32_t)(std::lower_bound(ix->bnd.begin(), ix->bnd.end(), (uint32_t)ref_lo) - ix->bnd.begin());
+        ix->n_bnd_local = 1;
+        for (uint32_t j = 1; j < ix->n_bnd; j++) {
+            if (ix->bnd[j] <= ref_lo || ix->bnd[j] > ref_hi) continue;
+            const uint32_t r = ix->bnd[j] - 1 - (uint32_t)ref_lo;
             bits[r >> 3] |= (uint8_t)(1u << (r & 7u));
+            ix->n_bnd_local++;
         }
         uint32_t run = 1;
         for (size_t c = 0; c < nchunk; c++) {
@@ -596,25 +668,52 @@ static int create_common(int device, uint64_t n_refs, uint32_t n_nodes, const ui
     return RTX_OK;
 }
 
+static int create_from_csr(int device, uint64_t n_total, uint64_t ref_lo, uint64_t ref_hi, const uint64_t *cuts,
+                           uint32_t n_cuts, const uint64_t *offsets, const uint32_t *postings, uint32_t n_nodes,
+                           const uint32_t *node_begin, const uint32_t *node_end, const uint32_t *node_first_child,
+                           const uint32_t *node_n_children, const uint8_t *node_type, rtx_index **out);
+
 int rtx_index_create(int device, uint64_t n_refs, const uint64_t *offsets, const uint32_t *postings,
                      uint32_t n_nodes, const uint32_t *node_begin, const uint32_t *node_end,
                      const uint32_t *node_first_child, const uint32_t *node_n_children, const uint8_t *node_type,
                      rtx_index **out) {
     if (!offsets) { set_error("rtx_index_create: offsets is null"); return RTX_ERR_INVALID; }
     if (offsets[RTX_NUM_KMERS] && !postings) { set_error("rtx_index_create: postings is null"); return RTX_ERR_INVALID; }
+    return create_from_csr(device, n_refs, 0, n_refs, nullptr, 0, offsets, postings, n_nodes, node_begin, node_end,
+                           node_first_child, node_n_children, node_type, out);
+}
+
+int rtx_index_create_shard(int device, uint64_t n_refs_total, uint64_t ref_lo, uint64_t ref_hi, const uint64_t *shard_cuts,
+                           uint32_t n_cuts, const uint64_t *offsets, const uint32_t *postings, uint32_t n_nodes,
+                           const uint32_t *node_begin, const uint32_t *node_end, const uint32_t *node_first_child,
+                           const uint32_t *node_n_children, const uint8_t *node_type, rtx_index **out) {
+    if (!offsets) { set_error("rtx_index_create_shard: offsets is null"); return RTX_ERR_INVALID; }
+    if (offsets[RTX_NUM_KMERS] && !postings) { set_error("rtx_index_create_shard: postings is null"); return RTX_ERR_INVALID; }
+    return create_from_csr(device, n_refs_total, ref_lo, ref_hi, shard_cuts, n_cuts, offsets, postings, n_nodes, node_begin,
+                           node_end, node_first_child, node_n_children, node_type, out);
+}
+
+static int create_from_csr(int device, uint64_t n_total, uint64_t ref_lo, uint64_t ref_hi, const uint64_t *cuts,
+                           uint32_t n_cuts, const uint64_t *offsets, const uint32_t *postings, uint32_t n_nodes,
+                           const uint32_t *node_begin, const uint32_t *node_end, const uint32_t *node_first_child,
+                           const uint32_t *node_n_children, const uint8_t *node_type, rtx_index **out) {
     rtx_index *ix = nullptr;
-    int rc = create_common(device, n_refs, n_nodes, node_begin, node_end, node_first_child, node_n_children, node_type, &ix);
+    int rc = create_common(device, n_total, ref_lo, ref_hi, cuts, n_cuts, n_nodes, node_begin, node_end, node_first_child,
+                           node_n_children, node_type, &ix);
     if (rc) return rc;
     auto fail = [&](int code) { delete ix; return code; };
-    // ---- bitmap index: one row of n_refs bits per non-empty posting list (+ one zero row)
+    // ---- bitmap index: one row of (local) n_refs bits per posting list that is non-empty in this shard
     {
         std::vector<uint32_t> row_of(RTX_NUM_KMERS, kEmptyRow);
         std::vector<uint32_t> list_len(RTX_NUM_KMERS, 0);
         uint32_t nr = 0;
         for (uint32_t k = 0; k < RTX_NUM_KMERS; k++) {
             if (offsets[k + 1] < offsets[k]) { set_error("offsets not monotone at k-mer %u", k); return fail(RTX_ERR_INVALID); }
-            const uint64_t l = offsets[k + 1] - offsets[k];
-            if (l > n_refs) { set_error("posting list %u longer than n_refs", k); return fail(RTX_ERR_INVALID); }
+            const uint64_t l0 = offsets[k + 1] - offsets[k];
+            if (l0 > n_total) { set_error("posting list %u longer than n_refs", k); return fail(RTX_ERR_INVALID); }
+            // lists are sorted (tree.rs:134-137): the shard's part is a contiguous run
+            const uint32_t *b = postings + offsets[k], *e = postings + offsets[k + 1];
+            const uint64_t l = l0 ? (uint64_t)(std::lower_bound(b, e, (uint32_t)ref_hi) - std::lower_bound(b, e, (uint32_t)ref_lo)) : 0;
             list_len[k] = (uint32_t)l;
             if (l) row_of[k] = nr++;
         }
@@ -633,7 +732,8 @@ int rtx_index_create(int device, uint64_t n_refs, const uint64_t *offsets, const
         if (e == hipSuccess) e = hipMemcpy(d_off.p, offsets, (RTX_NUM_KMERS + 1) * 8, hipMemcpyHostToDevice);
         if (e == hipSuccess && total) e = hipMemcpy(d_post.p, postings, total * 4, hipMemcpyHostToDevice);
         if (e == hipSuccess) {
-            launch_bitmap_build(ix->stream, d_off.p, d_post.p, ix->d_row_of.p, ix->d_bitmap.p, ix->stride_bytes / 4);
+            launch_bitmap_build(ix->stream, d_off.p, d_post.p, ix->d_row_of.p, ix->d_bitmap.p, ix->stride_bytes / 4,
+                                (uint32_t)ref_lo, (uint32_t)ref_hi);
             e = hipStreamSynchronize(ix->stream);
         }
         if (e != hipSuccess) { set_error("bitmap build failed: %s", hipGetErrorString(e)); return fail(RTX_ERR_HIP); }
@@ -650,7 +750,8 @@ int rtx_index_create_from_sequences(int device, uint64_t n_refs, const uint8_t *
                                     const uint8_t *node_type, rtx_index **out) {
     if (!seq_off || (!seq_bytes && n_refs && seq_off[n_refs])) { set_error("rtx_index_create_from_sequences: null sequences"); return RTX_ERR_INVALID; }
     rtx_index *ix = nullptr;
-    int rc = create_common(device, n_refs, n_nodes, node_begin, node_end, node_first_child, node_n_children, node_type, &ix);
+    int rc = create_common(device, n_refs, 0, n_refs, nullptr, 0, n_nodes, node_begin, node_end, node_first_child,
+                           node_n_children, node_type, &ix);
     if (rc) return rc;
     auto fail = [&](int code) { delete ix; return code; };
     const uint64_t total = seq_off[n_refs] - seq_off[0];
@@ -707,7 +808,7 @@ void rtx_index_destroy(rtx_index *index) {
     delete index;
 }
 
-uint64_t rtx_index_num_refs(const rtx_index *index) { return index ? index->n_refs : 0; }
+uint64_t rtx_index_num_refs(const rtx_index *index) { return index ? index->n_total : 0; }
 uint64_t rtx_index_device_bytes(const rtx_index *index) {
     if (!index) return 0;
     return index->d_bitmap.n * 4 + index->d_row_of.n * 4 + index->d_list_len.n * 4 + index->d_lnfact.n * 8 +
@@ -772,7 +873,7 @@ int rtx_batch_upload(rtx_index *ix, uint64_t n_queries, const uint8_t *bases, co
             if (exact_off[q + 1] < exact_off[q]) { set_error("exact_off not monotone"); return RTX_ERR_INVALID; }
         if (n_exact && !exact_ids) { set_error("exact_ids is null"); return RTX_ERR_INVALID; }
         for (uint64_t i = 0; i < n_exact; i++)
-            if (exact_ids[i] >= ix->n_refs) { set_error("exact id %u out of range", exact_ids[i]); return RTX_ERR_INVALID; }
+            if (exact_ids[i] >= ix->n_total) { set_error("exact id %u out of range", exact_ids[i]); return RTX_ERR_INVALID; }
         RTX_HIP(hipMemcpy(ix->d_exact_off.p, exact_off, (n_queries + 1) * 8, hipMemcpyHostToDevice));
     } else {
         RTX_HIP(hipMemset(ix->d_exact_off.p, 0, (n_queries + 1) * 8));
@@ -822,6 +923,10 @@ int rtx_batch_download(rtx_index *ix, rtx_result_view *out) {
         const uint64_t want = cursor + 4096;
         if ((rc = ix->d_arena.alloc(want))) return rc;
         ix->arena_cap = want;
+        if (ix->n_refs != ix->n_total) {  // a sharded run is driven by the caller: ask it to repeat
+            set_error("result arena overflow: repeat the sharded run (the arena has been enlarged)");
+            return RTX_ERR_STATE;
+        }
         if ((rc = enqueue_batch(ix, ix->last_flags))) return rc;
     }
     ix->h_status.resize(nq);
@@ -882,6 +987,88 @@ int rtx_classify_batch(rtx_index *index, uint64_t n_queries, const uint8_t *base
     if (rc) return rc;
     if ((rc = rtx_batch_run(index, flags))) return rc;
     return rtx_batch_download(index, out);
+}
+
+// ---- reference-sharded database (BASELINE.json configs[4], SURVEY.md 8e mode B) ------------------
+// Every rank holds the bitmaps of a contiguous range of references and classifies the SAME queries.
+// Per sub-batch the caller alternates library stages with two exchanges (RCCL through
+// torch.distributed in raxtax_amd/sharded.py):
+//   rtx_shard_count  -> all-reduce(sum) of the histograms  (RTX_BUF_HIST,  [nq][hstride] u32)
+//   rtx_shard_prob   -> all-gather of the local prefix sums (RTX_BUF_PREFIX, [nq][n_bnd_local] f64), offset
+//                       by the running shard totals and concatenated into [nq][n_bnd]
+//   rtx_shard_walk(prefix_global)
+int rtx_shard_begin(rtx_index *ix, uint32_t *n_sub_batches, uint32_t *sub_batch) {
+    int rc = bind(ix);
+    if (rc) return rc;
+    if (!ix->uploaded) { set_error("rtx_shard_begin before rtx_batch_upload"); return RTX_ERR_STATE; }
+    if (ix->n_streams != 1) { set_error("sharded handles use one stream"); return RTX_ERR_STATE; }
+    uint32_t n_sub = 0;
+    bool timed = false;
+    if ((rc = begin_run(ix, &n_sub, &timed))) return rc;
+    ix->ran = true;
+    ix->synced = false;
+    ix->last_flags = 0;
+    if (n_sub_batches) *n_sub_batches = n_sub;
+    if (sub_batch) *sub_batch = ix->sub_batch;
+    return RTX_OK;
+}
+
+static int shard_sb(rtx_index *ix, uint32_t sb, SubBatch *b) {
+    int rc = bind(ix);
+    if (rc) return rc;
+    if (!ix->ran) { set_error("rtx_shard_* before rtx_shard_begin"); return RTX_ERR_STATE; }
+    const uint32_t n_sub = (uint32_t)((ix->n_q + ix->sub_batch - 1) / ix->sub_batch);
+    if (sb >= n_sub) { set_error("sub-batch %u out of range (%u)", sb, n_sub); return RTX_ERR_INVALID; }
+    *b = sub_batch_of(ix, sb, ix->n_sub_last != 0);
+    ix->synced = false;
+    return RTX_OK;
+}
+
+int rtx_shard_count(rtx_index *ix, uint32_t sb, uint32_t flags) {
+    SubBatch b;
+    int rc = shard_sb(ix, sb, &b);
+    if (rc) return rc;
+    ix->last_flags = flags;
+    return enqueue_count(ix, b, flags);
+}
+
+int rtx_shard_prob(rtx_index *ix, uint32_t sb) {
+    SubBatch b;
+    int rc = shard_sb(ix, sb, &b);
+    if (rc) return rc;
+    return enqueue_prob_prefix(ix, b);
+}
+
+int rtx_shard_walk(rtx_index *ix, uint32_t sb, const double *prefix_global) {
+    SubBatch b;
+    int rc = shard_sb(ix, sb, &b);
+    if (rc) return rc;
+    if (!prefix_global) { set_error("rtx_shard_walk: null prefix"); return RTX_ERR_INVALID; }
+    return enqueue_walk(ix, b, prefix_global);
+}
+
+int rtx_shard_info(const rtx_index *ix, uint64_t *ref_lo, uint64_t *ref_hi, uint32_t *n_bnd_global, uint32_t *n_bnd_local,
+                   uint32_t *first_bnd) {
+    if (!ix) { set_error("null index handle"); return RTX_ERR_INVALID; }
+    if (ref_lo) *ref_lo = ix->ref_lo;
+    if (ref_hi) *ref_hi = ix->ref_lo + ix->n_refs;
+    if (n_bnd_global) *n_bnd_global = ix->n_bnd;
+    if (n_bnd_local) *n_bnd_local = ix->n_bnd_local;
+    if (first_bnd) *first_bnd = ix->bnd_first;
+    return RTX_OK;
+}
+
+int rtx_device_buffer(rtx_index *ix, int which, void **ptr, uint64_t *row_stride_elems) {
+    if (!ix || !ptr) { set_error("null argument"); return RTX_ERR_INVALID; }
+    if (!ix->uploaded) { set_error("rtx_device_buffer before rtx_batch_upload"); return RTX_ERR_STATE; }
+    rtx_index::Scratch &sc = ix->sc[0];
+    switch (which) {
+        case RTX_BUF_HIST: *ptr = sc.d_hist.p; if (row_stride_elems) *row_stride_elems = ix->hstride; return RTX_OK;
+        case RTX_BUF_PREFIX: *ptr = sc.d_prefix.p; if (row_stride_elems) *row_stride_elems = ix->n_bnd_local; return RTX_OK;
+        default: break;
+    }
+    set_error("rtx_device_buffer: unknown buffer %d", which);
+    return RTX_ERR_INVALID;
 }
 
 int rtx_batch_stage_times(rtx_index *ix, float ms[RTX_NUM_STAGES], uint32_t launches[RTX_NUM_STAGES]) {
@@ -1015,7 +1202,7 @@ int rtx_debug_evaluate(rtx_index *ix, const double *probs, rtx_result_view *out)
     fp.bnd_bits = ix->d_bnd_bits.p;
     fp.bnd_rank = ix->d_bnd_rank.p;
     fp.prefix = ix->sc[ix->last_set].d_prefix.p;
-    fp.n_bnd = ix->n_bnd;
+    fp.n_bnd = ix->n_bnd_local;
     launch_taxon_prefix(s, fp, 1);
     WalkParams wp{};
     wp.status = ix->d_status.p;

@@ -25,14 +25,17 @@ static constexpr uint32_t kEmptyRow = 0xFFFFFFFFu;
 __global__ __launch_bounds__(256) void bitmap_build_kernel(const uint64_t *__restrict__ off,
                                                            const uint32_t *__restrict__ post,
                                                            const uint32_t *__restrict__ row_of,
-                                                           uint32_t *__restrict__ bitmap, uint32_t stride_words) {
+                                                           uint32_t *__restrict__ bitmap, uint32_t stride_words,
+                                                           uint32_t ref_lo, uint32_t ref_hi) {
     const uint32_t k = blockIdx.x;
     const uint32_t row = row_of[k];
     if (row == kEmptyRow) return;
     const uint64_t b = off[k], e = off[k + 1];
     uint32_t *dst = bitmap + (size_t)row * stride_words;
     for (uint64_t i = b + threadIdx.x; i < e; i += blockDim.x) {
-        const uint32_t r = post[i];
+        const uint32_t g = post[i];
+        if (g < ref_lo || g >= ref_hi) continue;  // reference held by another shard
+        const uint32_t r = g - ref_lo;
         atomicOr(&dst[r >> 5], 1u << (r & 31u));
     }
 }
@@ -294,7 +297,7 @@ __global__ __launch_bounds__(64) void hit_count_kernel(HitParams p) {
         if (p.flags & RTX_SKIP_EXACT_MATCHES) {  // raxtax.rs:65-68
             const uint64_t e0 = p.exact_off[p.q0 + q], e1 = p.exact_off[p.q0 + q + 1];
             for (uint64_t e = e0; e < e1; e++) {
-                const uint32_t id = p.exact_ids[e];
+                const uint32_t id = p.exact_ids[e] - p.ref_base;  // local id; other shards' ids wrap out of range
                 if (id >= ref0 && id < ref0 + 128u) {
                     const uint32_t w = (id - ref0) >> 5, msk = ~(1u << (id & 31u));
 #pragma unroll
@@ -780,9 +783,9 @@ __global__ void probs_expand_kernel(const uint16_t *counts, const double *tz, ui
 // launchers
 // ---------------------------------------------------------------------------
 void launch_bitmap_build(hipStream_t s, const uint64_t *off, const uint32_t *post, const uint32_t *row_of,
-                         uint32_t *bitmap, uint32_t stride_words) {
+                         uint32_t *bitmap, uint32_t stride_words, uint32_t ref_lo, uint32_t ref_hi) {
     hipLaunchKernelGGL(bitmap_build_kernel, dim3(RTX_NUM_KMERS), dim3(256), 0, s, off, post, row_of, bitmap,
-                       stride_words);
+                       stride_words, ref_lo, ref_hi);
 }
 void launch_ref_kmer_mark(hipStream_t s, const uint8_t *bases, const uint64_t *off, uint64_t n_refs, uint32_t *present) {
     hipLaunchKernelGGL(ref_kmer_mark_kernel, dim3(4096), dim3(64), 0, s, bases, off, n_refs, present);

@@ -45,6 +45,7 @@ struct HitParams {
     const uint32_t *bitmap;
     uint32_t stride_bytes;
     uint64_t n_refs;
+    uint32_t ref_base;  // global id of local reference 0 (reference-sharded index)
     const uint32_t *rows;
     uint32_t rstride;
     const uint32_t *nrows;
@@ -121,7 +122,7 @@ struct WalkParams {
 };
 
 void launch_bitmap_build(hipStream_t s, const uint64_t *off, const uint32_t *post, const uint32_t *row_of,
-                         uint32_t *bitmap, uint32_t stride_words);
+                         uint32_t *bitmap, uint32_t stride_words, uint32_t ref_lo, uint32_t ref_hi);
 void launch_ref_kmer_mark(hipStream_t s, const uint8_t *bases, const uint64_t *off, uint64_t n_refs, uint32_t *present);
 void launch_ref_bitmap_set(hipStream_t s, const uint8_t *bases, const uint64_t *off, uint64_t n_refs,
                            const uint32_t *row_of, uint32_t *bitmap, uint32_t stride_words);

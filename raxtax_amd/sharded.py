@@ -1,0 +1,192 @@
+"""Reference-sharded database (BASELINE.json configs[4], SURVEY.md 8e mode B).
+
+The lineage-sorted references are cut into contiguous ranges, one per GPU; every rank classifies the
+SAME queries against its range.  Per sub-batch two exchanges make the result identical to the
+unsharded one:
+
+  1. hit-count histograms      all-reduce(sum) of [n][t+1] uint32  -> every rank computes the same
+                               probability table (prob.rs:13-103 needs the histogram of ALL references)
+  2. boundary prefix sums      all-gather of [n][n_bnd_local] float64; rank s's prefix is offset by the
+                               totals of the ranks before it -> prefix sums over the whole database at
+                               the taxonomy boundaries (lineage.rs:61-66), then the walk (lineage.rs:119-179)
+
+Communication volume is independent of the number of references per k-mer: 2.6 KB + 8 n_bnd bytes per
+query.  The exchanges go through a small `Comm` interface: `TorchComm` (torch.distributed, backend
+"nccl" = RCCL over xGMI, one process per GPU) in production; `LocalComm` runs several shards inside one
+process (tests on a single GPU).  The library side is the staged C ABI rtx_shard_* (include/raxtax_hip.h).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+from ._lib import check, ptr, u8p, u32p, u64p
+from .api import Index, Result, Tree
+
+RTX_BUF_HIST, RTX_BUF_PREFIX = 1, 2
+
+
+class _DevArray:
+    """Zero-copy view of library-owned device memory for torch (via __cuda_array_interface__)."""
+
+    def __init__(self, addr: int, shape, typestr: str):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (addr, False),
+                                         "version": 2, "strides": None}
+
+
+def device_tensor(addr: int, shape, typestr: str, device: int):
+    import torch
+
+    return torch.as_tensor(_DevArray(addr, shape, typestr), device=f"cuda:{device}")
+
+
+def shard_cuts(n_refs: int, world: int) -> List[int]:
+    """Balanced contiguous cut points [0, ..., n_refs] (world + 1 values)."""
+    base, rem = divmod(n_refs, world)
+    cuts = [0]
+    for r in range(world):
+        cuts.append(cuts[-1] + base + (1 if r < rem else 0))
+    return cuts
+
+
+class ShardIndex(Index):
+    """Device index holding references [cuts[rank], cuts[rank+1]) of the tree."""
+
+    def __init__(self, tree: Tree, rank: int, cuts: Sequence[int], device: int = 0, sub_batch: int = 1024):
+        self._lib = _lib.load()
+        self.tree = tree
+        self.device = device
+        self.rank = rank
+        off, post = tree.csr()
+        nd = tree.nodes()
+        cuts_a = np.asarray(cuts, dtype=np.uint64)
+        post = post if len(post) else np.zeros(1, np.uint32)
+        h = C.c_void_p()
+        check(self._lib.rtx_index_create_shard(
+            device, tree.num_tips, int(cuts[rank]), int(cuts[rank + 1]), ptr(cuts_a, u64p), len(cuts_a),
+            ptr(off, u64p), ptr(post, u32p), len(nd["type"]), ptr(nd["begin"], u32p), ptr(nd["end"], u32p),
+            ptr(nd["first_child"], u32p), ptr(nd["n_children"], u32p), ptr(nd["type"], u8p), C.byref(h)))
+        self._h = h
+        self.n_refs = int(cuts[rank + 1]) - int(cuts[rank])      # local references (debug taps)
+        if sub_batch:
+            check(self._lib.rtx_index_set_batch(self._h, sub_batch))
+        from ._lib import ResultView
+
+        self._view = ResultView()
+        self._keep = None
+        lo, hi, ng, nl, fb = C.c_uint64(), C.c_uint64(), C.c_uint32(), C.c_uint32(), C.c_uint32()
+        check(self._lib.rtx_shard_info(self._h, C.byref(lo), C.byref(hi), C.byref(ng), C.byref(nl), C.byref(fb)))
+        self.ref_lo, self.ref_hi, self.n_bnd, self.n_bnd_local, self.first_bnd = lo.value, hi.value, ng.value, nl.value, fb.value
+
+    # ---- staged interface ----------------------------------------------------------------------
+    def begin(self):
+        n_sub, b = C.c_uint32(), C.c_uint32()
+        check(self._lib.rtx_shard_begin(self._h, C.byref(n_sub), C.byref(b)))
+        return n_sub.value, b.value
+
+    def count(self, sb: int, flags: int = 0):
+        check(self._lib.rtx_shard_count(self._h, sb, flags))
+
+    def prob(self, sb: int):
+        check(self._lib.rtx_shard_prob(self._h, sb))
+
+    def walk(self, sb: int, prefix_global):
+        assert prefix_global.is_contiguous() and prefix_global.shape[1] == self.n_bnd
+        check(self._lib.rtx_shard_walk(self._h, sb, C.c_void_p(prefix_global.data_ptr())))
+
+    def buffer(self, which: int, n_rows: int):
+        p, stride = C.c_void_p(), C.c_uint64()
+        check(self._lib.rtx_device_buffer(self._h, which, C.byref(p), C.byref(stride)))
+        return device_tensor(p.value, (n_rows, stride.value), "<i4" if which == RTX_BUF_HIST else "<f8", self.device)
+
+
+class LocalComm:
+    """All shards live in this process (single-GPU tests): the collectives are plain tensor ops."""
+
+    def allreduce_hist(self, hists):
+        total = hists[0].clone()
+        for h in hists[1:]:
+            total += h
+        for h in hists:
+            h.copy_(total)
+
+    def allgather_prefix(self, locals_):
+        return [p.clone() for p in locals_]
+
+
+class TorchComm:
+    """One shard per process; torch.distributed (backend nccl = RCCL on GPUs, gloo on CPU tensors)."""
+
+    def __init__(self, dist, world: int, widths: Sequence[int]):
+        self.dist, self.world, self.widths = dist, world, list(widths)
+
+    def allreduce_hist(self, hists):
+        (h,) = hists           # int32 view of the uint32 histogram (counts < 2^31)
+        self.dist.all_reduce(h)
+
+    def allgather_prefix(self, locals_):
+        import torch
+
+        (p,) = locals_
+        wmax = max(self.widths)
+        pad = torch.zeros((p.shape[0], wmax), dtype=p.dtype, device=p.device)
+        pad[:, : p.shape[1]] = p
+        out = [torch.zeros_like(pad) for _ in range(self.world)]
+        self.dist.all_gather(out, pad)
+        return [o[:, : self.widths[s]] for s, o in enumerate(out)]
+
+
+def assemble_prefix(parts):
+    """Concatenates per-shard prefix sums ([n][w_s], column 0 = 0, last column = shard total) into the prefix
+    over the whole database: [n][1 + sum_s (w_s - 1)]."""
+    import torch
+
+    n = parts[0].shape[0]
+    cols = [torch.zeros((n, 1), dtype=parts[0].dtype, device=parts[0].device)]
+    offset = torch.zeros((n,), dtype=parts[0].dtype, device=parts[0].device)
+    for p in parts:
+        cols.append(p[:, 1:] + offset[:, None])
+        offset = offset + p[:, -1]
+    return torch.cat(cols, dim=1).contiguous()
+
+
+class ShardedClassifier:
+    """Drives one (TorchComm) or several (LocalComm) ShardIndex handles through the staged path."""
+
+    def __init__(self, shards: Sequence[ShardIndex], comm):
+        self.shards, self.comm = list(shards), comm
+
+    def classify(self, bases: np.ndarray, base_off: np.ndarray, exact_ids=None, exact_off=None,
+                 skip_exact_matches: bool = False) -> Result:
+        import torch
+
+        flags = _lib.RTX_SKIP_EXACT_MATCHES if skip_exact_matches else 0
+        for s in self.shards:
+            s.upload(bases, base_off, exact_ids, exact_off)
+        n_sub, B = self.shards[0].begin()
+        for s in self.shards[1:]:
+            assert s.begin() == (n_sub, B), "all shards must use the same sub-batch size"
+        n_q = len(base_off) - 1
+        for sb in range(n_sub):
+            nq = min(B, n_q - sb * B)
+            for s in self.shards:
+                s.count(sb, flags)
+            for s in self.shards:
+                s.sync()
+            self.comm.allreduce_hist([s.buffer(RTX_BUF_HIST, nq) for s in self.shards])
+            torch.cuda.synchronize()
+            for s in self.shards:
+                s.prob(sb)
+            for s in self.shards:
+                s.sync()
+            parts = self.comm.allgather_prefix([s.buffer(RTX_BUF_PREFIX, nq) for s in self.shards])
+            pref = assemble_prefix(parts)
+            torch.cuda.synchronize()
+            for s in self.shards:
+                s.walk(sb, pref)
+            for s in self.shards:
+                s.sync()
+        return self.shards[0].download()

@@ -371,3 +371,39 @@ def test_gpu_index_build_from_sequences(world):
         assert np.array_equal(ix2.debug_hit_counts(q), w["index"].debug_hit_counts(q))
     assert np.array_equal(got.row_off, ref.row_off) and np.array_equal(got.row_lineage, ref.row_lineage)
     assert np.array_equal(got.row_conf, ref.row_conf) and np.array_equal(got.global_signal, ref.global_signal)
+
+
+@pytest.mark.parametrize("n_shards,cuts", [(2, None), (3, [0, 1001, 3333, 5184])])
+def test_reference_sharded_database_equals_unsharded(world, n_shards, cuts):
+    """BASELINE.json configs[4] / SURVEY.md 8e mode B, emulated on one GPU: the references are cut into
+    contiguous shards (cut points deliberately inside taxa), every shard counts against its range, the
+    histograms are summed, the boundary prefix sums concatenated -- the result rows equal the unsharded run."""
+    from raxtax_amd import sharded
+
+    w = world
+    tree = w["tree"]
+    cuts = cuts or sharded.shard_cuts(tree.num_tips, n_shards)
+    shards = [sharded.ShardIndex(tree, r, cuts, sub_batch=64) for r in range(n_shards)]
+    assert sum(s.n_bnd_local - 1 for s in shards) + 1 == shards[0].n_bnd
+    clf = sharded.ShardedClassifier(shards, sharded.LocalComm())
+    ex_ids, ex_off = w["index"].exact_matches(w["bases"], w["off"])
+    for skip in (False, True):
+        ref = w["index"].classify(w["bases"], w["off"], ex_ids, ex_off, skip_exact_matches=skip)
+        got = clf.classify(w["bases"], w["off"], ex_ids, ex_off, skip_exact_matches=skip)
+        assert np.array_equal(got.status, ref.status) and np.array_equal(got.t, ref.t)
+        assert np.array_equal(got.row_off, ref.row_off)
+        assert np.array_equal(got.row_conf, ref.row_conf)
+        # lineages identical for the full-length queries; the degenerate short ones contain exact ties between
+        # sibling taxa, which the offset-added prefix sums may break the other way (DESIGN.md section 4)
+        n_regular_rows = int(ref.row_off[160])
+        assert np.array_equal(got.row_lineage[:n_regular_rows], ref.row_lineage[:n_regular_rows])
+        assert np.mean(got.row_lineage != ref.row_lineage) < 0.1
+        assert np.max(np.abs(got.global_signal - ref.global_signal)) < 1e-12
+        assert np.max(np.abs(got.row_local_signal[:n_regular_rows] - ref.row_local_signal[:n_regular_rows])) < 1e-9
+    # the per-shard hit counts are the slices of the unsharded ones (last sub-batch is still resident)
+    w["index"].classify(w["bases"], w["off"], ex_ids, ex_off)
+    clf.classify(w["bases"], w["off"], ex_ids, ex_off)
+    q = len(w["seqs"]) - 1
+    full = w["index"].debug_hit_counts(q)
+    for s in shards:
+        assert np.array_equal(s.debug_hit_counts(q), full[s.ref_lo:s.ref_hi])

@@ -71,3 +71,50 @@ def test_two_rank_gloo_gather(tmp_path):
     mp.spawn(_worker, args=(2, _free_port(), str(out)), nprocs=2, join=True)
     ok, n_rows = np.load(out)
     assert ok == 1 and n_rows >= 41
+
+
+def _shard_worker(rank, world, port, out_path):
+    """Exchange logic of the reference-sharded database (raxtax_amd/sharded.py) on CPU tensors over gloo:
+    histogram all-reduce + prefix all-gather/assembly reproduce the unsharded histogram and prefix sums."""
+    sys.path.insert(0, str(ROOT))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch
+    import torch.distributed as dist
+
+    from raxtax_amd import sharded
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rng = np.random.default_rng(7)                      # same data on every rank
+    n_q, n_refs, t = 5, 1000, 40
+    counts = rng.integers(0, t + 1, size=(n_q, n_refs))
+    probs = rng.random((n_q, n_refs))
+    bnd = np.unique(np.concatenate([[0, n_refs], rng.integers(1, n_refs, 60)]))
+    cuts = sharded.shard_cuts(n_refs, world)
+    bnd = np.unique(np.concatenate([bnd, cuts]))        # cut points are boundaries on every rank
+    lo, hi = cuts[rank], cuts[rank + 1]
+    # what this rank's kernels would produce
+    hist = np.stack([np.bincount(counts[q, lo:hi], minlength=t + 1) for q in range(n_q)]).astype(np.int32)
+    local_b = bnd[(bnd >= lo) & (bnd <= hi)]
+    pref_local = np.stack([np.concatenate([[0.0], np.cumsum(probs[q, lo:hi])])[local_b - lo] for q in range(n_q)])
+    widths = [int(((bnd >= cuts[r]) & (bnd <= cuts[r + 1])).sum()) for r in range(world)]
+    comm = sharded.TorchComm(dist, world, widths)
+    h = torch.from_numpy(hist.copy())
+    comm.allreduce_hist([h])
+    parts = comm.allgather_prefix([torch.from_numpy(pref_local)])
+    pref = sharded.assemble_prefix(parts).numpy()
+    want_hist = np.stack([np.bincount(counts[q], minlength=t + 1) for q in range(n_q)])
+    want_pref = np.stack([np.concatenate([[0.0], np.cumsum(probs[q])])[bnd] for q in range(n_q)])
+    ok = np.array_equal(h.numpy(), want_hist) and pref.shape == want_pref.shape and np.max(np.abs(pref - want_pref)) < 1e-9
+    if rank == 0:
+        np.save(out_path, np.array([ok]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_two_rank_gloo_sharded_db_exchange(tmp_path):
+    import torch.multiprocessing as mp
+
+    out = tmp_path / "ok2.npy"
+    mp.spawn(_shard_worker, args=(2, _free_port(), str(out)), nprocs=2, join=True)
+    assert np.load(out)[0]

@@ -163,6 +163,13 @@ int rtx_index_set_batch(rtx_index *index, uint32_t sub_batch);
 #define RTX_OPT_STREAMS 3 /* 1 (default) = one HIP stream; 2 = consecutive sub-batches alternate between two streams
                              (measured slower on MI355X: the kernels contend for L2) */
 int rtx_index_set_option(rtx_index *index, int option, uint64_t value);
+/* Process-wide defaults for handles created afterwards.  RTX_OPT_HYBRID (default 0): move quarter-tile chunks
+ * (2048 references) of a bitmap row that hold at most RTX_OPT_SPARSE_MAX (default 12) references into sparse
+ * lists, so that hit_count reads only well-filled chunks.  Bit-exact, but measured slower on MI355X (hit_count
+ * is bound by the per-CU load rate, not by bytes: DESIGN.md section 3), hence off by default. */
+#define RTX_OPT_HYBRID 4
+#define RTX_OPT_SPARSE_MAX 5
+int rtx_set_default_option(int option, uint64_t value);
 
 /* ------------------------------------------------------------------------- */
 /* Classification: the body of raxtax(), src/raxtax.rs:39-84, minus string    */

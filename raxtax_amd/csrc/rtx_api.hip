@@ -98,6 +98,12 @@ struct rtx_index {
     uint64_t npad = 0;          // references per padded row (= stride_bytes * 8)
     uint32_t ntiles = 0;        // 8192-reference tiles
     DevBuf<uint32_t> d_bitmap, d_row_of, d_list_len;
+    // hybrid dense/sparse split of the bitmap (rtx_hybrid.hip)
+    bool hybrid = false;
+    DevBuf<uint8_t> d_qmask;
+    DevBuf<uint32_t> d_soff;
+    DevBuf<uint16_t> d_sent;
+    uint64_t n_sparse_entries = 0;
     DevBuf<double> d_lnfact, d_inv;
     // ---- memoised prob tables (t <= 1023), built lazily for the largest tmax seen
     int prob_mode = 0;  // 0 auto, 1 recurrence kernel only, 2 tables (error if they do not fit)
@@ -248,7 +254,12 @@ int enqueue_count(rtx_index *ix, const SubBatch &b, uint32_t flags) {
     hp.exact_ids = ix->d_exact_ids.p;
     hp.exact_off = ix->d_exact_off.p;
     if (b.timed) RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_HIT_COUNT, 0), s));
-    launch_hit_count(s, hp, b.nq, ix->ntiles, ix->planes);
+    if (ix->hybrid) {
+        HybridIndex hy{ix->d_qmask.p, ix->d_soff.p, ix->d_sent.p, ix->n_rows + 1, ix->n_rows, ix->rstride};
+        launch_hit_count_hybrid(s, hp, hy, b.nq, ix->ntiles, ix->planes);
+    } else {
+        launch_hit_count(s, hp, b.nq, ix->ntiles, ix->planes);
+    }
     if (b.timed) RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_HIT_COUNT, 1), s));
     return RTX_OK;
 }
@@ -548,6 +559,40 @@ int rtx_device_count(void) {
     return n;
 }
 
+// process-wide defaults applied to handles created afterwards (rtx_set_default_option)
+static uint64_t g_default_hybrid = 0, g_default_sparse_max = 12;
+
+// Moves nearly empty quarter-tile chunks of the bitmap into sparse lists (rtx_hybrid.hip).
+static int build_hybrid(rtx_index *ix) {
+    if (!g_default_hybrid) return RTX_OK;
+    const uint32_t n_rows1 = ix->n_rows + 1;
+    const size_t entries = (size_t)n_rows1 * ix->ntiles;
+    DevBuf<uint32_t> d_scount;
+    int rc;
+    if ((rc = ix->d_qmask.alloc(entries)) || (rc = d_scount.alloc(entries)) || (rc = ix->d_soff.alloc(entries + 1))) return rc;
+    launch_hybrid_classify(ix->stream, ix->d_bitmap.p, ix->stride_bytes, n_rows1, ix->ntiles, (uint32_t)g_default_sparse_max,
+                           ix->d_qmask.p, d_scount.p);
+    RTX_HIP(hipGetLastError());
+    RTX_HIP(hipStreamSynchronize(ix->stream));
+    std::vector<uint32_t> soff(entries + 1);
+    RTX_HIP(hipMemcpy(soff.data() + 1, d_scount.p, entries * 4, hipMemcpyDeviceToHost));
+    soff[0] = 0;
+    uint64_t run = 0;
+    for (size_t i = 0; i < entries; i++) {
+        run += soff[i + 1];
+        if (run > 0xFFFFFFFFull) { set_error("hybrid index: more than 2^32 sparse entries"); return RTX_ERR_INVALID; }
+        soff[i + 1] = (uint32_t)run;
+    }
+    ix->n_sparse_entries = run;
+    RTX_HIP(hipMemcpy(ix->d_soff.p, soff.data(), (entries + 1) * 4, hipMemcpyHostToDevice));
+    if ((rc = ix->d_sent.alloc(run + 1))) return rc;
+    launch_hybrid_emit(ix->stream, ix->d_bitmap.p, ix->stride_bytes, n_rows1, ix->ntiles, ix->d_qmask.p, ix->d_soff.p, ix->d_sent.p);
+    RTX_HIP(hipGetLastError());
+    RTX_HIP(hipStreamSynchronize(ix->stream));
+    ix->hybrid = true;
+    return RTX_OK;
+}
+
 // Everything of index creation except the bitmap: device checks, stream, taxonomy, tables.
 static int create_common(int device, uint64_t n_total, uint64_t ref_lo, uint64_t ref_hi, const uint64_t *cuts,
                          uint32_t n_cuts, uint32_t n_nodes, const uint32_t *node_begin, const uint32_t *node_end,
@@ -738,6 +783,7 @@ static int create_from_csr(int device, uint64_t n_total, uint64_t ref_lo, uint64
         }
         if (e != hipSuccess) { set_error("bitmap build failed: %s", hipGetErrorString(e)); return fail(RTX_ERR_HIP); }
     }
+    if ((rc = build_hybrid(ix))) return fail(rc);
     *out = ix;
     return RTX_OK;
 }
@@ -787,6 +833,7 @@ int rtx_index_create_from_sequences(int device, uint64_t n_refs, const uint8_t *
         e = hipStreamSynchronize(ix->stream);
     }
     if (e != hipSuccess) { set_error("bitmap build from sequences failed: %s", hipGetErrorString(e)); return fail(RTX_ERR_HIP); }
+    if ((rc = build_hybrid(ix))) return fail(rc);
     *out = ix;
     return RTX_OK;
 }
@@ -811,13 +858,26 @@ void rtx_index_destroy(rtx_index *index) {
 uint64_t rtx_index_num_refs(const rtx_index *index) { return index ? index->n_total : 0; }
 uint64_t rtx_index_device_bytes(const rtx_index *index) {
     if (!index) return 0;
-    return index->d_bitmap.n * 4 + index->d_row_of.n * 4 + index->d_list_len.n * 4 + index->d_lnfact.n * 8 +
+    return index->d_qmask.n + index->d_soff.n * 4 + index->d_sent.n * 2 + index->d_bitmap.n * 4 + index->d_row_of.n * 4 + index->d_list_len.n * 4 + index->d_lnfact.n * 8 +
            index->d_blo.n * 4 * 4 + index->d_type.n + index->d_bnd_bits.n + index->d_bnd_rank.n * 4;
 }
 int rtx_index_set_batch(rtx_index *index, uint32_t sub_batch) {
     if (!index) { set_error("null index handle"); return RTX_ERR_INVALID; }
     index->sub_batch_req = sub_batch;
     return RTX_OK;
+}
+
+int rtx_set_default_option(int option, uint64_t value) {
+    switch (option) {
+        case RTX_OPT_HYBRID: g_default_hybrid = value ? 1 : 0; return RTX_OK;
+        case RTX_OPT_SPARSE_MAX:
+            if (value > 64) break;
+            g_default_sparse_max = value;
+            return RTX_OK;
+        default: break;
+    }
+    set_error("rtx_set_default_option: unknown option %d / value %llu", option, (unsigned long long)value);
+    return RTX_ERR_INVALID;
 }
 
 int rtx_index_set_option(rtx_index *index, int option, uint64_t value) {

@@ -83,6 +83,10 @@ int rtx_tree_build_ex(uint64_t n, const char *lineage_bytes, const uint64_t *lin
                       const uint8_t *seq_bytes, const uint64_t *seq_off, uint32_t flags, rtx_tree **out);
 /* parse_reference_fasta_str, src/parser.rs:46-105 */
 int rtx_tree_parse_reference_fasta(const char *text, uint64_t len, rtx_tree **out);
+/* Tree::save_to_file / Tree::load_from_file (src/tree.rs:147-164): the reference's `.bin` database,
+ * bincode 1.3.3 default options.  Files written here are readable by upstream raxtax and vice versa. */
+int rtx_tree_save_bin(const rtx_tree *tree, const char *path);
+int rtx_tree_load_bin(const char *path, rtx_tree **out);
 void rtx_tree_destroy(rtx_tree *tree);
 uint64_t rtx_tree_num_tips(const rtx_tree *tree);                  /* Tree.num_tips      */
 const char *rtx_tree_lineage(const rtx_tree *tree, uint64_t i);    /* Tree.lineages[i]   */

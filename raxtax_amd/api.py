@@ -70,6 +70,18 @@ class Tree:
                                     0 if kmer_map else 1, C.byref(h)))
         return cls(h.value)
 
+    def save_to_file(self, path: str) -> None:
+        """Tree::save_to_file (tree.rs:147-153): the reference's bincode `.bin` database."""
+        check(self._lib.rtx_tree_save_bin(self._h, str(path).encode()))
+
+    @classmethod
+    def load_from_file(cls, path: str) -> "Tree":
+        """Tree::load_from_file (tree.rs:155-164)."""
+        lib = _lib.load()
+        h = C.c_void_p()
+        check(lib.rtx_tree_load_bin(str(path).encode(), C.byref(h)))
+        return cls(h.value)
+
     @property
     def num_tips(self) -> int:
         return self._lib.rtx_tree_num_tips(self._h)

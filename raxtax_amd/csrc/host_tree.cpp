@@ -167,7 +167,9 @@ static bool find_tax(std::string_view s, std::string_view &out) {
     return false;
 }
 
-static void flatten(rtx_tree &t) {
+void flatten_tree(rtx_tree &t);
+static void flatten(rtx_tree &t) { flatten_tree(t); }
+void flatten_tree(rtx_tree &t) {
     // BFS from the root; childless Sequence nodes are dropped (they cannot influence
     // Lineage::evaluate: they are neither Inner nor Taxon and have nothing to recurse into).
     FlatNodes &f = t.flat;

@@ -296,7 +296,7 @@ int enqueue_prob_prefix(rtx_index *ix, const SubBatch &b) {
     PrefixParams fp{};
     fp.status = ix->d_status.p;
     fp.t = sc.d_t.p;
-    fp.tz_in_lds = 0;
+    fp.tz_in_lds = (size_t)ix->hstride * 8 <= 16 * 1024 ? 1u : 0u;
     fp.q0 = b.q0;
     fp.counts = sc.d_counts.p;
     fp.npad = ix->npad;

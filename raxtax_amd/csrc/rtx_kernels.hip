@@ -563,26 +563,48 @@ __global__ __launch_bounds__(kProbThreads) void prob_table_kernel(ProbParams p) 
 // ---------------------------------------------------------------------------
 // taxon_prefix (src/lineage.rs:61-66): P[j] = sum_{r < bnd[j]} p_r, p_r = table[count_r]/Z,
 // sampled at the taxonomy boundaries only (every node range is [bnd[a], bnd[b])).
-// One 256-thread workgroup per query, 8 references per thread per sweep (2048 per sweep); low
-// register use keeps 8 workgroups per CU resident, which is what hides the sweep latency.
+// One workgroup of NW waves per query, 8 references per thread per sweep (NW*512 per sweep); the
+// sweeps are sequential (running carry), so wide workgroups = fewer, better overlapped sweeps.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void taxon_prefix_kernel(PrefixParams p) {
-    __shared__ double wsum[4];
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void taxon_prefix_kernel(PrefixParams p) {
+    extern __shared__ double tz_lds[];
+    __shared__ double wsum[NW];
     const uint32_t q = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint64_t gq = p.perm ? p.perm[p.q0 + q] : p.q0 + q;
     double *P = p.prefix + (size_t)q * p.n_bnd;
     if (p.status[gq] != RTX_Q_OK) return;
     const double *tz = p.table_z + (size_t)q * p.hstride;
+    if (p.tz_in_lds) {  // 32 x N random look-ups per query: serve them from LDS
+        const uint32_t t1 = p.t[q] + 1;
+        for (uint32_t m = tid; m < t1; m += NW * 64) tz_lds[m] = tz[m];
+        tz = tz_lds;
+        __syncthreads();
+    }
     const uint16_t *cnt = p.counts + (size_t)q * p.npad;
     if (tid == 0) P[0] = 0.0;
     double carry = 0.0;
     const uint64_t n = p.n_refs;
-    for (uint64_t base = 0; base < n; base += 2048) {
+    // counts of the next sweep are requested before the current one is scanned (the sweeps are a serial
+    // chain through `carry`; without the prefetch every sweep exposes a full HBM round trip)
+    uint4 cv_next = make_uint4(0, 0, 0, 0);
+    uint32_t bits_next = 0;
+    if ((uint64_t)tid * 8 < n) {
+        cv_next = *reinterpret_cast<const uint4 *>(cnt + (uint64_t)tid * 8);
+        bits_next = p.bnd_bits[tid];
+    }
+    for (uint64_t base = 0; base < n; base += NW * 512) {
         const uint64_t r0 = base + (uint64_t)tid * 8;
+        const uint4 cv = cv_next;
+        const uint32_t bits_cur = bits_next;
+        const uint64_t rn = r0 + NW * 512;
+        if (rn < n) {
+            cv_next = *reinterpret_cast<const uint4 *>(cnt + rn);
+            bits_next = p.bnd_bits[rn >> 3];
+        }
         double s[8];
         double run = 0.0;
         if (r0 < n) {
-            const uint4 cv = *reinterpret_cast<const uint4 *>(cnt + r0);
             const uint32_t cw[4] = {cv.x, cv.y, cv.z, cv.w};
 #pragma unroll
             for (int j = 0; j < 8; j++) {
@@ -595,13 +617,13 @@ __global__ __launch_bounds__(256) void taxon_prefix_kernel(PrefixParams p) {
 #pragma unroll
             for (int j = 0; j < 8; j++) s[j] = 0.0;
         }
-        const double incl = wave_incl_scan_f64(run);
+        const double incl = wave_incl_scan_f64_dpp(run);
         if (lane == 63) wsum[wave] = incl;
         __syncthreads();
         double off = carry + (incl - run);
         double tot = 0.0;
 #pragma unroll
-        for (int w = 0; w < 4; w++) {
+        for (int w = 0; w < NW; w++) {
             const double ws = wsum[w];
             if ((uint32_t)w < wave) off += ws;
             tot += ws;
@@ -609,7 +631,7 @@ __global__ __launch_bounds__(256) void taxon_prefix_kernel(PrefixParams p) {
         carry += tot;
         if (r0 < n) {
             const uint32_t chunk = (uint32_t)(r0 >> 3);
-            uint32_t bits = p.bnd_bits[chunk];
+            uint32_t bits = bits_cur;
             if (bits) {
                 uint32_t rank = p.bnd_rank[chunk];
                 while (bits) {
@@ -818,7 +840,8 @@ void launch_prob_table(hipStream_t s, const ProbParams &p, uint32_t nq) {
     hipLaunchKernelGGL(prob_table_kernel, dim3(nq), dim3(kProbThreads), prob_table_lds_bytes(p.tmax), s, p);
 }
 void launch_taxon_prefix(hipStream_t s, const PrefixParams &p, uint32_t nq) {
-    hipLaunchKernelGGL(taxon_prefix_kernel, dim3(nq), dim3(256), 0, s, p);
+    const size_t lds = p.tz_in_lds ? (size_t)p.hstride * sizeof(double) : 0;
+    hipLaunchKernelGGL(taxon_prefix_kernel<4>, dim3(nq), dim3(256), lds, s, p);
 }
 void launch_lineage_walk(hipStream_t s, const WalkParams &p, uint32_t nq) {
     hipLaunchKernelGGL(lineage_walk_kernel, dim3(nq), dim3(64), 0, s, p);

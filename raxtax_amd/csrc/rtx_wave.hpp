@@ -59,6 +59,29 @@ __device__ __forceinline__ double wave_prod_f64_dpp(double v) {
     return (readlane_f64(v, 0) * readlane_f64(v, 16)) * (readlane_f64(v, 32) * readlane_f64(v, 48));
 }
 
+// Inclusive scan over the 64 lanes with DPP row shifts (Hillis-Steele inside each row of 16 lanes, zero
+// fill at the row start), then the three row totals through v_readlane.  Fixed order: deterministic.
+__device__ __forceinline__ double dpp_shr_f64(double v, int n) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    switch (n) {
+        case 1: lo = __builtin_amdgcn_update_dpp(0, lo, 0x111, 0xF, 0xF, true); hi = __builtin_amdgcn_update_dpp(0, hi, 0x111, 0xF, 0xF, true); break;
+        case 2: lo = __builtin_amdgcn_update_dpp(0, lo, 0x112, 0xF, 0xF, true); hi = __builtin_amdgcn_update_dpp(0, hi, 0x112, 0xF, 0xF, true); break;
+        case 4: lo = __builtin_amdgcn_update_dpp(0, lo, 0x114, 0xF, 0xF, true); hi = __builtin_amdgcn_update_dpp(0, hi, 0x114, 0xF, 0xF, true); break;
+        default: lo = __builtin_amdgcn_update_dpp(0, lo, 0x118, 0xF, 0xF, true); hi = __builtin_amdgcn_update_dpp(0, hi, 0x118, 0xF, 0xF, true); break;
+    }
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_incl_scan_f64_dpp(double v) {
+    v += dpp_shr_f64(v, 1);
+    v += dpp_shr_f64(v, 2);
+    v += dpp_shr_f64(v, 4);
+    v += dpp_shr_f64(v, 8);
+    const double r0 = readlane_f64(v, 15), r1 = readlane_f64(v, 31), r2 = readlane_f64(v, 47);
+    const uint32_t row = lane_id() >> 4;
+    const double add = row == 0 ? 0.0 : (row == 1 ? r0 : (row == 2 ? r0 + r1 : (r0 + r1) + r2));
+    return v + add;
+}
+
 __device__ __forceinline__ double wave_incl_scan_f64(double v) {
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {

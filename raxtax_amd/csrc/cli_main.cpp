@@ -1,11 +1,21 @@
-// raxtax-hip: minimal command line around the host mirror of raxtax() -- just enough to run the
-// reference's plumbing configuration (FASTA database + FASTA queries in, `.out`/`.tsv` lines out) on
-// one GPU.  Flag names follow src/io.rs:112-154; checkpointing, logging, `.bin` caching, gzip input
-// and thread options are out of scope.
+// raxtax-hip: command line around the host mirror of raxtax() -- FASTA/.bin database + FASTA queries in,
+// the reference's output files out, on one GPU.  Flag names and file semantics follow the reference
+// (src/io.rs:112-154 Args, :202-263 get_output, :47-90 Checkpoint, :156-187 check_incomplete_output;
+// src/main.rs:72-99 database caching, :126-136 writer):
+//   PREFIX/raxtax.out   one line per result row            PREFIX/raxtax.tsv  (--tsv)
+//   PREFIX/raxtax.ckp   one finished query label per line  PREFIX/raxtax.json checkpoint (flags + DB fingerprint)
+//   PREFIX/<db>.bin     bincode database cache (unless --skip-db)
+// A rerun with the same flags and database resumes: labels listed in raxtax.ckp are skipped
+// (parser.rs:150-153) and half-written result lines of unlisted queries are purged first.
+// Out of scope: raxtax.log, progress bars, gzip input, thread options.
+#include <sys/stat.h>
+
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <iostream>
+#include <set>
 #include <sstream>
 #include <string>
 #include <vector>
@@ -13,7 +23,9 @@
 #include "host_raxtax.hpp"
 #include "raxtax_hip.h"
 
-static bool slurp(const std::string &path, std::string &out) {
+namespace {
+
+bool slurp(const std::string &path, std::string &out) {
     std::ifstream f(path, std::ios::binary);
     if (!f) return false;
     std::ostringstream ss;
@@ -22,11 +34,61 @@ static bool slurp(const std::string &path, std::string &out) {
     return true;
 }
 
+bool is_file(const std::string &p) { struct stat st; return stat(p.c_str(), &st) == 0 && S_ISREG(st.st_mode); }
+bool is_dir(const std::string &p) { struct stat st; return stat(p.c_str(), &st) == 0 && S_ISDIR(st.st_mode); }
+
+// FileFingerprint (io.rs:24-45): path, size, mtime in seconds
+std::string fingerprint(const std::string &path) {
+    struct stat st;
+    if (stat(path.c_str(), &st) != 0) return "";
+    char *abs = realpath(path.c_str(), nullptr);
+    std::ostringstream ss;
+    ss << (abs ? abs : path.c_str()) << "|" << (long long)st.st_size << "|" << (long long)st.st_mtime;
+    free(abs);
+    return ss.str();
+}
+
+std::string checkpoint_json(const std::string &fp, bool raw, bool skip, bool tsv) {
+    std::ostringstream ss;
+    ss << "{\n  \"db_fingerprint\": \"" << fp << "\",\n  \"raw_confidence\": " << (raw ? "true" : "false")
+       << ",\n  \"skip_exact_matches\": " << (skip ? "true" : "false") << ",\n  \"tsv\": " << (tsv ? "true" : "false") << "\n}\n";
+    return ss.str();
+}
+
+// check_incomplete_output (io.rs:156-187): keep only the lines whose first field is a finished query
+void purge_incomplete(const std::string &path, const std::set<std::string> &done) {
+    std::ifstream in(path);
+    if (!in) return;
+    std::vector<std::string> keep;
+    bool rewrite = false;
+    std::string line;
+    while (std::getline(in, line)) {
+        const size_t tab = line.find('\t');
+        if (tab != std::string::npos && done.count(line.substr(0, tab))) keep.push_back(line);
+        else rewrite = true;
+    }
+    in.close();
+    if (!rewrite) return;
+    const std::string tmp = path + ".tmp";
+    {
+        std::ofstream out(tmp, std::ios::trunc);
+        for (const std::string &l : keep) out << l << '\n';
+    }
+    rename(tmp.c_str(), path.c_str());
+}
+
+struct Sink {
+    std::ofstream out, tsv, ckp;
+    bool want_tsv = false;
+};
+
+}  // namespace
+
 int main(int argc, char **argv) {
     std::string db, qf, prefix = "raxtax";
-    bool skip_exact = false, raw = false, tsv = false;
+    bool skip_exact = false, raw = false, tsv = false, only_db = false, skip_db = false, clean = false, redo = false;
     int device = 0;
-    size_t chunk = 0;
+    size_t chunk = 4096;
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
         auto val = [&]() -> const char * { return i + 1 < argc ? argv[++i] : ""; };
@@ -36,21 +98,86 @@ int main(int argc, char **argv) {
         else if (a == "--skip-exact-matches") skip_exact = true;
         else if (a == "--raw-confidence") raw = true;
         else if (a == "--tsv") tsv = true;
+        else if (a == "--only-db") only_db = true;
+        else if (a == "--skip-db") skip_db = true;
+        else if (a == "-c" || a == "--clean") clean = true;
+        else if (a == "--redo") redo = true;
         else if (a == "--device") device = atoi(val());
         else if (a == "--batch") chunk = (size_t)atoll(val());
-        else { fprintf(stderr, "usage: raxtax-hip -d DB.fasta -i QUERIES.fasta [-o PREFIX] [--skip-exact-matches] [--raw-confidence] [--tsv] [--device N] [--batch N]\n"); return 64; }
+        else {
+            fprintf(stderr, "usage: raxtax-hip -d DB.(fasta|bin) [-i QUERIES.fasta] [-o PREFIX] [--skip-exact-matches] [--raw-confidence] "
+                            "[--tsv] [--only-db] [--skip-db] [-c] [--redo] [--device N] [--batch N]\n");
+            return 64;
+        }
     }
-    if (db.empty() || qf.empty()) { fprintf(stderr, "raxtax-hip: -d and -i are required\n"); return 64; }
-    std::string db_text, q_text;
-    if (!slurp(db, db_text)) { fprintf(stderr, "[ERROR] Failed to parse %s\n", db.c_str()); return 66; }   // exitcode::NOINPUT
-    if (!slurp(qf, q_text)) { fprintf(stderr, "[ERROR] Failed to parse %s\n", qf.c_str()); return 66; }
+    if (db.empty() || (qf.empty() && !only_db) || (only_db && skip_db)) {
+        fprintf(stderr, "raxtax-hip: -d is required, -i unless --only-db; --only-db conflicts with --skip-db\n");
+        return 64;
+    }
+    const std::string ckp_json = prefix + "/raxtax.json", ckp_path = prefix + "/raxtax.ckp";
+    const std::string out_path = prefix + "/raxtax.out", tsv_path = prefix + "/raxtax.tsv";
+    // ---- checkpoint (io.rs:202-263)
+    std::set<std::string> done;
+    const std::string want_ckp = checkpoint_json(fingerprint(db), raw, skip_exact, tsv);
+    bool resume = false;
+    if (!redo && is_file(ckp_json)) {
+        std::string have;
+        slurp(ckp_json, have);
+        if (have == want_ckp) {  // checkpoint_valid (io.rs:288-302)
+            std::ifstream p(ckp_path);
+            std::string l;
+            while (std::getline(p, l)) done.insert(l);
+            purge_incomplete(out_path, done);
+            if (tsv) purge_incomplete(tsv_path, done);
+            resume = true;
+            fprintf(stderr, "[INFO ] Restarting from checkpoint %s\n", ckp_json.c_str());
+        }
+    }
+    if (is_dir(prefix) && !is_file(ckp_json) && !redo) {
+        fprintf(stderr, "[ERROR] Output folder %s already exists! Please specify another folder with -o <PATH> or run with --redo "
+                        "to force overriding existing files!\n", prefix.c_str());
+        return 73;  // exitcode::CANTCREAT
+    }
+    mkdir(prefix.c_str(), 0777);
+
+    // ---- database: try the binary format first, then FASTA (parser.rs:37-44)
     rtx_tree *tree = nullptr;
-    if (rtx_tree_parse_reference_fasta(db_text.data(), db_text.size(), &tree) != RTX_OK) {
-        fprintf(stderr, "[ERROR] Failed to parse %s: %s\n", db.c_str(), rtx_last_error());
-        return 66;
+    bool store_db = false;
+    if (rtx_tree_load_bin(db.c_str(), &tree) != RTX_OK) {
+        std::string db_text;
+        if (!slurp(db, db_text) || rtx_tree_parse_reference_fasta(db_text.data(), db_text.size(), &tree) != RTX_OK) {
+            fprintf(stderr, "[ERROR] Failed to parse %s: %s\n", db.c_str(), rtx_last_error());
+            return 66;  // exitcode::NOINPUT
+        }
+        store_db = true;
     }
+    std::string db_bin;
+    if (store_db && !skip_db) {  // main.rs:72-86, io.rs:269-286
+        std::string base = db.substr(db.find_last_of('/') == std::string::npos ? 0 : db.find_last_of('/') + 1);
+        const size_t dot = base.find_last_of('.');
+        db_bin = prefix + "/" + (dot == std::string::npos ? base : base.substr(0, dot)) + ".bin";
+        if (is_file(db_bin) && !redo && !resume) {
+            fprintf(stderr, "[ERROR] Output database file %s already exists! Delete it or run with --redo\n", db_bin.c_str());
+            return 73;
+        }
+        if (rtx_tree_save_bin(tree, db_bin.c_str()) != RTX_OK) { fprintf(stderr, "[ERROR] Failed to write database: %s\n", rtx_last_error()); return 74; }
+    }
+    {
+        const std::string tmp = ckp_json + ".tmp";  // Checkpoint::save: tmp + rename (io.rs:72-78)
+        std::ofstream f(tmp, std::ios::trunc);
+        f << (resume ? want_ckp : checkpoint_json(fingerprint(db), raw, skip_exact, tsv));
+        f.close();
+        rename(tmp.c_str(), ckp_json.c_str());
+    }
+    if (only_db) return 0;
+
+    // ---- queries (already finished labels are dropped, parser.rs:150-153)
+    std::string q_text;
+    if (!slurp(qf, q_text)) { fprintf(stderr, "[ERROR] Failed to parse %s\n", qf.c_str()); return 66; }
+    std::vector<const char *> skip;
+    for (const std::string &l : done) skip.push_back(l.c_str());
     rtx_queries *qs = nullptr;
-    if (rtx_queries_parse_fasta(q_text.data(), q_text.size(), nullptr, 0, &qs) != RTX_OK) {
+    if (rtx_queries_parse_fasta(q_text.data(), q_text.size(), skip.empty() ? nullptr : skip.data(), skip.size(), &qs) != RTX_OK) {
         fprintf(stderr, "[ERROR] Failed to parse %s: %s\n", qf.c_str(), rtx_last_error());
         return 66;
     }
@@ -59,25 +186,39 @@ int main(int argc, char **argv) {
         fprintf(stderr, "[ERROR] %s\n", rtx_last_error());
         return 71;  // exitcode::OSERR
     }
-    std::ofstream out(prefix + ".out"), tsv_out;
-    if (tsv) tsv_out.open(prefix + ".tsv");
-    struct Ctx { std::ofstream *out, *tsv; } ctx{&out, tsv ? &tsv_out : nullptr};
+    Sink sink;
+    const auto mode = (redo || !resume) ? std::ios::trunc : std::ios::app;
+    sink.out.open(out_path, mode);
+    sink.ckp.open(ckp_path, mode);
+    sink.want_tsv = tsv;
+    if (tsv) sink.tsv.open(tsv_path, mode);
     const uint64_t n = rtx_queries_len(qs);
     std::vector<const char *> labels(n);
     for (uint64_t i = 0; i < n; i++) labels[i] = rtx_queries_label(qs, i);
     const uint8_t *bases;
     const uint64_t *off;
     rtx_queries_data(qs, &bases, &off);
-    auto sender = [](void *c, const char *, const char *lines, const char *tsv_lines) -> int {
-        Ctx *x = static_cast<Ctx *>(c);
-        (*x->out) << lines << '\n';                       // writeln!(output, ...), main.rs:132
-        if (x->tsv && tsv_lines) (*x->tsv) << tsv_lines << '\n';
-        return x->out->good() ? 0 : 1;
+    // the writer of main.rs:127-135: result lines, then the label into the progress file
+    auto sender = [](void *c, const char *label, const char *lines, const char *tsv_lines) -> int {
+        Sink *s = static_cast<Sink *>(c);
+        if (s->want_tsv && tsv_lines) s->tsv << tsv_lines << '\n';
+        s->out << lines << '\n';
+        s->ckp << label << '\n';
+        return s->out.good() && s->ckp.good() ? 0 : 1;
     };
-    const int rc = rtx_raxtax(index, tree, n, labels.data(), bases, off, skip_exact, raw, chunk, sender, &ctx, tsv);
+    int rc = RTX_OK;
+    if (n) rc = rtx_raxtax(index, tree, n, labels.data(), bases, off, skip_exact, raw, chunk, sender, &sink, tsv);
+    sink.out.flush();
+    sink.ckp.flush();
+    if (tsv) sink.tsv.flush();
     if (rc != RTX_OK) {
-        fprintf(stderr, "[ERROR] %s\n", rtx_last_error());
+        fprintf(stderr, "[ERROR] %s\nRerun raxtax-hip to continue from the last checkpoint.\n", rtx_last_error());
         return rc == RTX_ERR_SENDER ? 75 : 70;  // exitcode::TEMPFAIL / SOFTWARE
+    }
+    if (clean) {  // Checkpoint::cleanup (io.rs:80-89)
+        remove(ckp_json.c_str());
+        remove(ckp_path.c_str());
+        if (!db_bin.empty()) remove(db_bin.c_str());
     }
     rtx_index_destroy(index);
     rtx_queries_destroy(qs);

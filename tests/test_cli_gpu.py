@@ -1,0 +1,65 @@
+"""raxtax-hip command line (raxtax_amd/csrc/cli_main.cpp): output files, `.bin` database cache, checkpoint /
+resume semantics of the reference (io.rs:47-90,156-187,202-263; main.rs:72-99,126-136).  SURVEY.md 8f #4."""
+import shutil
+import subprocess
+from pathlib import Path
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parent.parent
+CLI = ROOT / "raxtax_amd" / "raxtax-hip"
+FASTA = ROOT / "tests" / "golden" / "diptera_subset.fasta"
+
+
+def run(*args, ok=True):
+    p = subprocess.run([str(CLI), *map(str, args)], capture_output=True, text=True, timeout=300)
+    if ok:
+        assert p.returncode == 0, p.stderr
+    return p
+
+
+def test_cli_outputs_resume_and_bin_cache(tmp_path, oracle):
+    out = tmp_path / "run1"
+    run("-d", FASTA, "-i", FASTA, "-o", out, "--tsv", "--batch", 128)
+    lines = (out / "raxtax.out").read_text().splitlines()
+    labels = (out / "raxtax.ckp").read_text().splitlines()
+    assert len(labels) == 600 and len(set(labels)) == 600
+    assert {l.split("\t")[0] for l in lines} == set(labels)
+    assert (out / "raxtax.tsv").exists() and (out / "raxtax.json").exists() and (out / "diptera_subset.bin").exists()
+    # first query against the oracle
+    text = FASTA.read_text()
+    otree = oracle.parse_reference_fasta_str(text)
+    label, seq = oracle.parse_query_fasta_str(text)[0]
+    rows, raw = otree.classify(seq)
+    assert otree.format_out(label, raw).split("\n")[0] == lines[0]
+    # an existing output folder without --redo and without a checkpoint is refused (io.rs:241-243)
+    (tmp_path / "occupied").mkdir()
+    assert run("-d", FASTA, "-i", FASTA, "-o", tmp_path / "occupied", ok=False).returncode == 73
+
+    # ---- interrupted run: 250 queries finished, a half-written line of an unfinished query in the output
+    out2 = tmp_path / "run2"
+    shutil.copytree(out, out2)
+    done = labels[:250]
+    (out2 / "raxtax.ckp").write_text("\n".join(done) + "\n")
+    keep = [l for l in lines if l.split("\t")[0] in set(done)]
+    (out2 / "raxtax.out").write_text("\n".join(keep) + "\n" + lines[-1][: len(lines[-1]) // 2] + "\n")
+    tsv_lines = (out / "raxtax.tsv").read_text().splitlines()
+    (out2 / "raxtax.tsv").write_text("\n".join(l for l in tsv_lines if l.split("\t")[0] in set(done)) + "\n")
+    # the fingerprint is that of the database path used before -> same command resumes
+    p = run("-d", FASTA, "-i", FASTA, "-o", out2, "--tsv", "--batch", 128)
+    assert "Restarting from checkpoint" in p.stderr
+    assert sorted((out2 / "raxtax.out").read_text().splitlines()) == sorted(lines)
+    assert sorted((out2 / "raxtax.tsv").read_text().splitlines()) == sorted(tsv_lines)
+    assert sorted((out2 / "raxtax.ckp").read_text().splitlines()) == sorted(labels)
+
+    # ---- the cached .bin is accepted as database (Tree::load_from_file is tried first, parser.rs:38-40)
+    out3 = tmp_path / "run3"
+    run("-d", out / "diptera_subset.bin", "-i", FASTA, "-o", out3, "--skip-exact-matches", "-c")
+    l3 = (out3 / "raxtax.out").read_text().splitlines()
+    assert len({l.split("\t")[0] for l in l3}) == 600
+    assert not (out3 / "raxtax.json").exists() and not (out3 / "raxtax.ckp").exists()   # -c cleans up
+    # --only-db writes the database and stops
+    out4 = tmp_path / "run4"
+    run("-d", FASTA, "--only-db", "-o", out4)
+    assert (out4 / "diptera_subset.bin").exists() and not (out4 / "raxtax.out").exists()

@@ -43,6 +43,9 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--skip-exact-matches", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend for N > 1 (nccl = RCCL over xGMI; gloo only to smoke-test the "
+                         "multi-rank flow on a box with fewer GPUs than ranks)")
     ap.add_argument("--shard-db", action="store_true",
                     help="BASELINE configs[4]: shard the REFERENCES over the GPUs (every rank classifies the same "
                          "queries; RCCL all-reduce of histograms + all-gather of prefix sums per sub-batch)")
@@ -155,13 +158,19 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback for the device path)")
+    if args.backend == "gloo":
+        local_rank = local_rank % torch.cuda.device_count()     # smoke test: several ranks may share a GPU
     torch.cuda.set_device(local_rank)
     dist = None
+    coll_device = "cuda" if args.backend == "nccl" else "cpu"
     if world > 1:
         import torch.distributed as dist_mod
 
         dist = dist_mod
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
 
     import raxtax_amd as rx
     from raxtax_amd import dist_util, synth
@@ -190,7 +199,7 @@ def main():
                 np.ctypeslib.as_array(view.row_conf, shape=(max(n_rows, 1), 32)),
                 np.ctypeslib.as_array(view.row_local_signal, shape=(max(n_rows, 1),)),
                 first_query=rank * args.queries)
-            dist_util.gather_records(dist, rec, rank, world, device="cuda")
+            dist_util.gather_records(dist, rec, rank, world, device=coll_device)
         return view
 
     def barrier():
@@ -212,7 +221,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        tmax = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        tmax = torch.tensor([elapsed], device=coll_device, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 

@@ -43,6 +43,8 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--skip-exact-matches", action="store_true")
+    ap.add_argument("--stage-times", action="store_true",
+                    help="HIP events around every kernel (stage_ms_per_step for all stages; ~1 ms slower per step)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for N > 1 (nccl = RCCL over xGMI; gloo only to smoke-test the "
                          "multi-rank flow on a box with fewer GPUs than ranks)")
@@ -182,7 +184,7 @@ def main():
     flags = rx.RTX_SKIP_EXACT_MATCHES if args.skip_exact_matches else 0
     if args.shard_db:
         return bench_sharded_db(args, rx, synth, db, tree, dist, rank, local_rank, world, flags)
-    index = rx.Index(tree, device=local_rank, sub_batch=args.sub_batch)
+    index = rx.Index(tree, device=local_rank, sub_batch=args.sub_batch, stage_timing=args.stage_times)
     ex_ids, ex_off = index.exact_matches(qs.bases, qs.base_off)   # Tree.sequences.get, raxtax.rs:42 (host)
     index.upload(qs.bases, qs.base_off, ex_ids, ex_off)            # inputs resident in HBM from here on
 

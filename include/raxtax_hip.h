@@ -164,6 +164,8 @@ int rtx_index_set_batch(rtx_index *index, uint32_t sub_batch);
  * 2 = tables only (error if unavailable).  Both produce the same probabilities to ~1e-13. */
 #define RTX_OPT_SUB_BATCH 1
 #define RTX_OPT_PROB_MODE 2
+#define RTX_OPT_STAGE_TIMING 6 /* 0 (default): HIP events around hit_count only; 1: around every kernel
+                                 (rtx_batch_stage_times then reports all stages; adds ~1 ms per 100k queries) */
 #define RTX_OPT_STREAMS 3 /* 1 (default) = one HIP stream; 2 = consecutive sub-batches alternate between two streams
                              (measured slower on MI355X: the kernels contend for L2) */
 int rtx_index_set_option(rtx_index *index, int option, uint64_t value);
@@ -230,7 +232,8 @@ int rtx_shard_info(const rtx_index *index, uint64_t *ref_lo, uint64_t *ref_hi, u
 int rtx_device_buffer(rtx_index *index, int which, void **device_ptr, uint64_t *row_stride_elems);
 
 /* Per-kernel device time of the last rtx_batch_run, from HIP events on the library's
- * stream (ms, summed over sub-batches), and launch counts.  Stage order: */
+ * stream (ms, summed over sub-batches), and launch counts (0 launches = stage not timed, see
+ * RTX_OPT_STAGE_TIMING).  Stage order: */
 #define RTX_STAGE_KMER_EXTRACT 0
 #define RTX_STAGE_HIT_COUNT 1
 #define RTX_STAGE_PROB_TABLE 2

@@ -206,7 +206,7 @@ class Index:
     """Device-resident index + batch workspace of one GPU (rtx_index)."""
 
     def __init__(self, tree: Tree, device: int = 0, sub_batch: int = 0, prob_mode: int = 0, streams: int = 0,
-                 hybrid: Optional[bool] = None, sparse_max: Optional[int] = None):
+                 hybrid: Optional[bool] = None, sparse_max: Optional[int] = None, stage_timing: bool = False):
         self._lib = _lib.load()
         self.tree = tree
         # creation-time knobs are process-wide defaults of the library
@@ -222,6 +222,8 @@ class Index:
             check(self._lib.rtx_index_set_option(self._h, 2, prob_mode))
         if streams:
             check(self._lib.rtx_index_set_option(self._h, 3, streams))
+        if stage_timing:
+            check(self._lib.rtx_index_set_option(self._h, 6, 1))
         self._view = ResultView()
         self._keep = None
 

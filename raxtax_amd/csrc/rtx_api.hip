@@ -54,6 +54,35 @@ struct DevBuf {
     ~DevBuf() { release(); }
 };
 
+// Pinned host array (hipHostMalloc): D2H copies of the result records run at PCIe rate and asynchronously.
+template <class T>
+struct PinBuf {
+    T *p = nullptr;
+    size_t cap = 0, n = 0;
+    int resize(size_t count) {
+        if (count > cap) {
+            if (p) (void)hipHostFree(p);
+            p = nullptr;
+            const size_t want = count + count / 4 + 16;
+            if (hipHostMalloc((void **)&p, want * sizeof(T), hipHostMallocDefault) != hipSuccess) {
+                p = nullptr;
+                cap = n = 0;
+                set_error("hipHostMalloc(%zu bytes) failed", want * sizeof(T));
+                return RTX_ERR_OOM;
+            }
+            cap = want;
+        }
+        n = count;
+        return RTX_OK;
+    }
+    T *data() { return p; }
+    const T *data() const { return p; }
+    size_t size() const { return n; }
+    T &operator[](size_t i) { return p[i]; }
+    const T &operator[](size_t i) const { return p[i]; }
+    ~PinBuf() { if (p) (void)hipHostFree(p); }
+};
+
 // statrs 0.16 `ln_factorial` (the reference's ln_binomial, prob.rs:5,20,117,143): ln of a cached
 // f64 factorial up to 170, Lanczos ln_gamma (g = 10.900511, 11 terms) above.
 double statrs_ln_gamma(double x) {
@@ -153,12 +182,15 @@ struct rtx_index {
     std::vector<hipEvent_t> events;  // 2 per (sub-batch, stage)
     uint32_t n_sub_last = 0;
     // ---- host results
-    std::vector<uint32_t> h_t, h_nrows_all, h_n_rows, v_row_lineage, v_row_node, v_row_depth;
-    std::vector<uint8_t> h_status;
-    std::vector<double> h_gs, h_z, v_row_conf, v_row_local;
-    std::vector<unsigned long long> h_hq, h_row_start;
+    std::vector<uint32_t> v_row_lineage, v_row_node, v_row_depth;
+    PinBuf<uint32_t> h_t, h_nrows_all, h_n_rows;
+    PinBuf<uint8_t> h_status;
+    std::vector<double> v_row_conf, v_row_local;
+    PinBuf<double> h_gs, h_z;
+    PinBuf<unsigned long long> h_hq, h_row_start;
+    uint32_t stage_timing = 0;  // 0: HIP events around hit_count only; 1: around every kernel
     std::vector<uint64_t> v_row_off;
-    std::vector<DevRow> h_arena;
+    PinBuf<DevRow> h_arena;
 
     ~rtx_index() {
         for (auto e : events) (void)hipEventDestroy(e);
@@ -192,7 +224,8 @@ struct SubBatch {
     uint32_t sb, nq, set;
     uint64_t q0;
     hipStream_t s;
-    bool timed;
+    bool timed;      // HIP events around hit_count (the roofline kernel)
+    bool timed_all;  // ... and around every other kernel (RTX_OPT_STAGE_TIMING)
 };
 
 SubBatch sub_batch_of(rtx_index *ix, uint32_t sb, bool timed) {
@@ -203,6 +236,7 @@ SubBatch sub_batch_of(rtx_index *ix, uint32_t sb, bool timed) {
     b.set = ix->n_streams == 2 ? (sb & 1u) : 0u;
     b.s = b.set ? ix->stream2 : ix->stream;
     b.timed = timed;
+    b.timed_all = timed && ix->stage_timing != 0;
     return b;
 }
 
@@ -231,11 +265,12 @@ int enqueue_count(rtx_index *ix, const SubBatch &b, uint32_t flags) {
     kp.hq = ix->d_hq.p;
     kp.t_all = ix->d_t_all.p;
     kp.nrows_all = ix->d_nrows_all.p;
-    if (b.timed) RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_KMER_EXTRACT, 0), s));
+    kp.hist = sc.d_hist.p;  // zeroed by kmer_extract for hit_count's global atomics
+    kp.hstride = ix->hstride;
+    if (b.timed_all) RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_KMER_EXTRACT, 0), s));
     launch_kmer_extract(s, kp, b.nq);
-    if (b.timed) RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_KMER_EXTRACT, 1), s));
+    if (b.timed_all) RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_KMER_EXTRACT, 1), s));
 
-    RTX_HIP(hipMemsetAsync(sc.d_hist.p, 0, (size_t)b.nq * ix->hstride * sizeof(uint32_t), s));
     HitParams hp{};
     hp.bitmap = ix->d_bitmap.p;
     hp.stride_bytes = ix->stride_bytes;
@@ -281,7 +316,7 @@ int enqueue_prob_prefix(rtx_index *ix, const SubBatch &b) {
     pp.z = ix->d_z.p;
     pp.gs = ix->d_gs.p;
     pp.status = ix->d_status.p;
-    if (b.timed) RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_PROB_TABLE, 0), s));
+    if (b.timed_all) RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_PROB_TABLE, 0), s));
     if (ix->use_tables) {
         ProbTables tb{ix->d_tab_cmf.p, ix->d_tab_ratio.p, ix->d_tab_off.p, ix->d_tab_moff.p,
                       ix->d_tab_ilo.p, ix->d_tab_sat.p, ix->tab_tmax};
@@ -291,7 +326,7 @@ int enqueue_prob_prefix(rtx_index *ix, const SubBatch &b) {
     } else {
         launch_prob_table(s, pp, b.nq);
     }
-    if (b.timed) RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_PROB_TABLE, 1), s));
+    if (b.timed_all) RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_PROB_TABLE, 1), s));
 
     PrefixParams fp{};
     fp.status = ix->d_status.p;
@@ -307,9 +342,9 @@ int enqueue_prob_prefix(rtx_index *ix, const SubBatch &b) {
     fp.bnd_rank = ix->d_bnd_rank.p;
     fp.prefix = sc.d_prefix.p;
     fp.n_bnd = ix->n_bnd_local;
-    if (b.timed) RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_TAXON_PREFIX, 0), s));
+    if (b.timed_all) RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_TAXON_PREFIX, 0), s));
     launch_taxon_prefix(s, fp, b.nq);
-    if (b.timed) RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_TAXON_PREFIX, 1), s));
+    if (b.timed_all) RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_TAXON_PREFIX, 1), s));
     return RTX_OK;
 }
 
@@ -332,9 +367,9 @@ int enqueue_walk(rtx_index *ix, const SubBatch &b, const double *prefix) {
     wp.n_rows = ix->d_n_rows.p;
     wp.row_start = ix->d_row_start.p;
     wp.flags_out = ix->d_flags.p;
-    if (b.timed) RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_LINEAGE_WALK, 0), s));
+    if (b.timed_all) RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_LINEAGE_WALK, 0), s));
     launch_lineage_walk(s, wp, b.nq);
-    if (b.timed) RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_LINEAGE_WALK, 1), s));
+    if (b.timed_all) RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_LINEAGE_WALK, 1), s));
     return RTX_OK;
 }
 
@@ -888,6 +923,9 @@ int rtx_index_set_option(rtx_index *index, int option, uint64_t value) {
             if (value < 1 || value > 2) break;
             index->n_streams_req = (uint32_t)value;
             return RTX_OK;
+        case RTX_OPT_STAGE_TIMING:
+            index->stage_timing = value ? 1u : 0u;
+            return RTX_OK;
         case RTX_OPT_PROB_MODE:
             if (value > 2) break;
             index->prob_mode = (int)value;
@@ -989,24 +1027,21 @@ int rtx_batch_download(rtx_index *ix, rtx_result_view *out) {
         }
         if ((rc = enqueue_batch(ix, ix->last_flags))) return rc;
     }
-    ix->h_status.resize(nq);
-    ix->h_t.resize(nq);
-    ix->h_nrows_all.resize(nq);
-    ix->h_n_rows.resize(nq);
-    ix->h_gs.resize(nq);
-    ix->h_z.resize(nq);
-    ix->h_hq.resize(nq);
-    ix->h_row_start.resize(nq);
-    ix->h_arena.resize(cursor ? cursor : 1);
-    RTX_HIP(hipMemcpy(ix->h_status.data(), ix->d_status.p, nq, hipMemcpyDeviceToHost));
-    RTX_HIP(hipMemcpy(ix->h_t.data(), ix->d_t_all.p, nq * 4, hipMemcpyDeviceToHost));
-    RTX_HIP(hipMemcpy(ix->h_nrows_all.data(), ix->d_nrows_all.p, nq * 4, hipMemcpyDeviceToHost));
-    RTX_HIP(hipMemcpy(ix->h_n_rows.data(), ix->d_n_rows.p, nq * 4, hipMemcpyDeviceToHost));
-    RTX_HIP(hipMemcpy(ix->h_gs.data(), ix->d_gs.p, nq * 8, hipMemcpyDeviceToHost));
-    RTX_HIP(hipMemcpy(ix->h_z.data(), ix->d_z.p, nq * 8, hipMemcpyDeviceToHost));
-    RTX_HIP(hipMemcpy(ix->h_hq.data(), ix->d_hq.p, nq * 8, hipMemcpyDeviceToHost));
-    RTX_HIP(hipMemcpy(ix->h_row_start.data(), ix->d_row_start.p, nq * 8, hipMemcpyDeviceToHost));
-    if (cursor) RTX_HIP(hipMemcpy(ix->h_arena.data(), ix->d_arena.p, cursor * sizeof(DevRow), hipMemcpyDeviceToHost));
+    if ((rc = ix->h_status.resize(nq)) || (rc = ix->h_t.resize(nq)) || (rc = ix->h_nrows_all.resize(nq)) ||
+        (rc = ix->h_n_rows.resize(nq)) || (rc = ix->h_gs.resize(nq)) || (rc = ix->h_z.resize(nq)) ||
+        (rc = ix->h_hq.resize(nq)) || (rc = ix->h_row_start.resize(nq)) || (rc = ix->h_arena.resize(cursor ? cursor : 1)))
+        return rc;
+    hipStream_t cs = ix->stream;
+    RTX_HIP(hipMemcpyAsync(ix->h_status.data(), ix->d_status.p, nq, hipMemcpyDeviceToHost, cs));
+    RTX_HIP(hipMemcpyAsync(ix->h_t.data(), ix->d_t_all.p, nq * 4, hipMemcpyDeviceToHost, cs));
+    RTX_HIP(hipMemcpyAsync(ix->h_nrows_all.data(), ix->d_nrows_all.p, nq * 4, hipMemcpyDeviceToHost, cs));
+    RTX_HIP(hipMemcpyAsync(ix->h_n_rows.data(), ix->d_n_rows.p, nq * 4, hipMemcpyDeviceToHost, cs));
+    RTX_HIP(hipMemcpyAsync(ix->h_gs.data(), ix->d_gs.p, nq * 8, hipMemcpyDeviceToHost, cs));
+    RTX_HIP(hipMemcpyAsync(ix->h_z.data(), ix->d_z.p, nq * 8, hipMemcpyDeviceToHost, cs));
+    RTX_HIP(hipMemcpyAsync(ix->h_hq.data(), ix->d_hq.p, nq * 8, hipMemcpyDeviceToHost, cs));
+    RTX_HIP(hipMemcpyAsync(ix->h_row_start.data(), ix->d_row_start.p, nq * 8, hipMemcpyDeviceToHost, cs));
+    if (cursor) RTX_HIP(hipMemcpyAsync(ix->h_arena.data(), ix->d_arena.p, cursor * sizeof(DevRow), hipMemcpyDeviceToHost, cs));
+    RTX_HIP(hipStreamSynchronize(cs));
 
     ix->v_row_off.resize(nq + 1);
     ix->v_row_off[0] = 0;
@@ -1138,6 +1173,7 @@ int rtx_batch_stage_times(rtx_index *ix, float ms[RTX_NUM_STAGES], uint32_t laun
     for (int s = 0; s < RTX_NUM_STAGES; s++) { ms[s] = 0.f; launches[s] = 0; }
     for (uint32_t sb = 0; sb < ix->n_sub_last; sb++)
         for (int s = 0; s < RTX_NUM_STAGES; s++) {
+            if (s != RTX_STAGE_HIT_COUNT && !ix->stage_timing) continue;  // events were not recorded
             float t = 0.f;
             RTX_HIP(hipEventElapsedTime(&t, ix->events[((size_t)sb * RTX_NUM_STAGES + s) * 2],
                                         ix->events[((size_t)sb * RTX_NUM_STAGES + s) * 2 + 1]));

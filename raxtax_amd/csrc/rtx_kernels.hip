@@ -132,6 +132,10 @@ __global__ __launch_bounds__(64) void kmer_extract_kernel(KmerParams p) {
     const uint8_t *seq = p.bases + b0;
 
     for (uint32_t i = lane; i < 2048; i += 64) bm[i] = 0;
+    {  // the histogram row hit_count accumulates into with global atomics
+        uint32_t *h = p.hist + (size_t)q * p.hstride;
+        for (uint32_t i = lane; i < p.hstride; i += 64) h[i] = 0;
+    }
     __syncthreads();
 
     for (uint64_t w = lane; w + 8 <= len; w += 64) {

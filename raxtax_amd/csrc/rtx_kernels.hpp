@@ -39,6 +39,8 @@ struct KmerParams {
     unsigned long long *hq;  // [n_q]
     uint32_t *t_all;         // [n_q]
     uint32_t *nrows_all;     // [n_q]
+    uint32_t *hist;          // [B][hstride] zeroed here
+    uint32_t hstride;
 };
 
 struct HitParams {

@@ -426,3 +426,101 @@ def test_hybrid_sparse_dense_index_equals_plain_bitmap(world):
             assert np.array_equal(a.row_conf, b.row_conf) and np.array_equal(a.global_signal, b.global_signal)
         assert hyb.work() == plain.work()
     rx.Index(w["tree"])   # restore the defaults for later tests
+
+
+def _classify_and_compare(oracle, lineages, seqs, qseqs, skip=False):
+    otree = oracle.tree_new(lineages, seqs)
+    tree = rx.Tree.new(lineages, seqs)
+    ix = rx.Index(tree)
+    off = np.zeros(len(qseqs) + 1, np.uint64)
+    off[1:] = np.cumsum([len(s) for s in qseqs])
+    bases = np.concatenate(qseqs) if len(qseqs) else np.zeros(0, np.uint8)
+    ex_ids, ex_off = ix.exact_matches(bases, off)
+    res = ix.classify(bases, off, ex_ids, ex_off, skip_exact_matches=skip)
+    lins = otree.lineages
+    for q, s in enumerate(qseqs):
+        t, counts = otree.hit_counts(s, skip_exact=skip)
+        assert np.array_equal(ix.debug_hit_counts(q), counts), q
+        try:
+            rows, _ = otree.classify(s, skip_exact=skip, raw_confidence=True)
+        except ArithmeticError:
+            assert res.status[q] == 1
+            continue
+        assert res.status[q] == 0
+        probs_ref = oracle.highest_hit_prob_per_reference(t, t // 2, counts)
+        assert np.max(np.abs(ix.debug_probs(q) - probs_ref)) < TOL_TIGHT, q
+        assert_rows_equivalent(res.rows(q), rows, probs_ref, lins, f"q{q}")
+    return res
+
+
+def test_degenerate_databases(oracle):
+    """One reference; all references identical; one taxon; deep and ragged lineages."""
+    rng = np.random.default_rng(11)
+    code = np.array([1, 2, 4, 8], np.uint8)
+    s0 = code[rng.integers(0, 4, size=300)]
+    s1 = code[rng.integers(0, 4, size=300)]
+    q_mut = s0.copy(); q_mut[::37] = 8
+    # a single reference (N = 1): every query gets probability 1 on it
+    res = _classify_and_compare(oracle, ["k:K,p:P"], [s0], [s0, q_mut, s1])
+    assert res.rows(0)[0].confidence_values == [1.0, 1.0]
+    # all references identical (one exact-match group of 5), with and without --skip-exact-matches
+    _classify_and_compare(oracle, [f"a:A,b:B{i % 2}" for i in range(5)], [s0] * 5, [s0, q_mut])
+    _classify_and_compare(oracle, [f"a:A,b:B{i % 2}" for i in range(5)], [s0] * 5, [s0, q_mut], skip=True)
+    # deep (12 levels) and ragged lineages
+    deep = [",".join(f"l{d}:X{(i >> d) & 1}" for d in range(12)) for i in range(40)]
+    ragged = [l if i % 3 else l.rsplit(",", 4)[0] for i, l in enumerate(deep)]
+    seqs = []
+    for i in range(40):
+        s = s0.copy()
+        m = rng.random(300) < 0.02 * (1 + i % 5)
+        s[m] = code[rng.integers(0, 4, size=int(m.sum()))]
+        seqs.append(s)
+    _classify_and_compare(oracle, ragged, seqs, [seqs[3], seqs[17], q_mut, s1])
+
+
+def test_lineage_deeper_than_max_depth_is_rejected():
+    lineages = [",".join(f"l{d}" for d in range(40)), ",".join(f"m{d}" for d in range(3))]
+    seqs = [np.full(20, 1, np.uint8), np.full(20, 2, np.uint8)]
+    tree = rx.Tree.new(lineages, seqs)
+    with pytest.raises(rx.RtxError) as e:
+        rx.Index(tree)
+    assert e.value.code == rx._lib.RTX_ERR_DEPTH
+
+
+def test_t_at_the_table_boundary(oracle):
+    """t = 1023 uses the memoised tables (10 bit planes), t = 1024 the recurrence kernel (12 planes)."""
+    rng = np.random.default_rng(3)
+    code = np.array([1, 2, 4, 8], np.uint8)
+    root = code[rng.integers(0, 4, size=1100)]
+    seqs, lineages = [], []
+    for i in range(64):
+        s = root.copy()
+        m = rng.random(len(s)) < 0.01 * (1 + i % 7)
+        s[m] = code[rng.integers(0, 4, size=int(m.sum()))]
+        seqs.append(s)
+        lineages.append(f"a:A{i % 2},b:B{i % 8},c:C{i % 32}")
+    for qlen in (1030, 1031, 1100):
+        qs_ = []
+        for j in (1, 9):
+            q = seqs[j][:qlen].copy()
+            m = rng.random(qlen) < 0.02
+            q[m] = code[rng.integers(0, 4, size=int(m.sum()))]
+            qs_.append(q)
+        res = _classify_and_compare(oracle, lineages, seqs, qs_)
+        assert res.t.max() <= qlen - 7
+
+
+def test_api_misuse_is_reported(world):
+    ix = rx.Index(world["tree"])
+    with pytest.raises(rx.RtxError) as e:
+        ix.run(0)                                   # run before upload
+    assert e.value.code == rx._lib.RTX_ERR_STATE
+    bases = world["seqs"][0]
+    with pytest.raises(rx.RtxError):                # exact id out of range
+        ix.upload(bases, np.array([0, len(bases)], np.uint64), np.array([10 ** 7], np.uint32), np.array([0, 1], np.uint64))
+    with pytest.raises(rx.RtxError):                # non-monotone offsets
+        ix.upload(bases, np.array([5, 0], np.uint64))
+    long_q = np.tile(bases, 12)                     # t far above what prob_table's LDS can hold
+    with pytest.raises(rx.RtxError) as e:
+        ix.upload(long_q, np.array([0, len(long_q)], np.uint64))
+    assert e.value.code == rx._lib.RTX_ERR_TOO_LONG

@@ -200,7 +200,7 @@ def main():
                 np.ctypeslib.as_array(view.row_depth, shape=(max(n_rows, 1),)),
                 np.ctypeslib.as_array(view.row_conf, shape=(max(n_rows, 1), 32)),
                 np.ctypeslib.as_array(view.row_local_signal, shape=(max(n_rows, 1),)),
-                first_query=rank * args.queries)
+                np.ctypeslib.as_array(view.global_signal, shape=(args.queries,)))
             dist_util.gather_records(dist, rec, rank, world, device=coll_device)
         return view
 

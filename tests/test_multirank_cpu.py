@@ -40,14 +40,21 @@ def _worker(rank, world, port, out_path):
                 conf.append(r["conf"] + [0.0] * (32 - len(r["conf"])))
             row_off.append(len(lin))
         return dist_util.pack_records(np.array(row_off), np.array(lin), np.array(depth),
-                                      np.array(conf).reshape(-1, 32), np.array(local), first_query=lo)
+                                      np.array(conf).reshape(-1, 32), np.array(local))
 
     lo, hi = dist_util.shard_range(qs.n, rank, world)
     parts = dist_util.gather_records(dist, classify(lo, hi), rank, world)
     if rank == 0:
-        got = np.concatenate(parts)
-        want = classify(0, qs.n)
-        np.save(out_path, np.array([got.shape == want.shape and np.array_equal(got, want), got.shape[0]]))
+        got = [dist_util.unpack_records(p) for p in parts]
+        want = dist_util.unpack_records(classify(0, qs.n))
+        lin = np.concatenate([g["row_lineage"] for g in got])
+        conf = np.concatenate([g["row_conf"] for g in got])
+        local = np.concatenate([g["row_local_signal"] for g in got])
+        nrows_per_q = np.concatenate([np.diff(g["row_off"]) for g in got])
+        ok = (np.array_equal(lin, want["row_lineage"]) and np.array_equal(conf, want["row_conf"]) and
+              np.array_equal(local, want["row_local_signal"]) and np.array_equal(nrows_per_q, np.diff(want["row_off"])) and
+              sum(g["n_queries"] for g in got) == qs.n)
+        np.save(out_path, np.array([ok, len(lin)]))
     dist.barrier()
     dist.destroy_process_group()
 

@@ -269,7 +269,7 @@ def main():
             },
             "stage_ms_per_step": {s: stage_ms[s] / args.steps for s in stage_ms},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # reported baseline: rank 0 at N = 1 only
             line["cpu_baseline"] = cpu_baseline(db, qs, args.cpu_seconds)
         print(json.dumps(line), flush=True)
     if dist is not None:

@@ -169,13 +169,6 @@ int rtx_index_set_batch(rtx_index *index, uint32_t sub_batch);
 #define RTX_OPT_STREAMS 3 /* 1 (default) = one HIP stream; 2 = consecutive sub-batches alternate between two streams
                              (measured slower on MI355X: the kernels contend for L2) */
 int rtx_index_set_option(rtx_index *index, int option, uint64_t value);
-/* Process-wide defaults for handles created afterwards.  RTX_OPT_HYBRID (default 0): move quarter-tile chunks
- * (2048 references) of a bitmap row that hold at most RTX_OPT_SPARSE_MAX (default 12) references into sparse
- * lists, so that hit_count reads only well-filled chunks.  Bit-exact, but measured slower on MI355X (hit_count
- * is bound by the per-CU load rate, not by bytes: DESIGN.md section 3), hence off by default. */
-#define RTX_OPT_HYBRID 4
-#define RTX_OPT_SPARSE_MAX 5
-int rtx_set_default_option(int option, uint64_t value);
 
 /* ------------------------------------------------------------------------- */
 /* Classification: the body of raxtax(), src/raxtax.rs:39-84, minus string    */
@@ -199,7 +192,9 @@ typedef struct {
 } rtx_result_view;
 
 /* Whole path for one batch of queries: H2D, kernels, D2H, host finalisation (sort
- * lineage.rs:91-93 + local signal).  exact_ids/exact_off: the ids Tree.sequences.get()
+ * lineage.rs:91-93 + local signal).  The handle alternates between two host result sets: a view stays
+ * valid until the second-next download on the handle, so a caller can format batch c while batch c+1
+ * is classified (the host mirror rtx_raxtax does).  exact_ids/exact_off: the ids Tree.sequences.get()
  * returned per query (raxtax.rs:42); may be NULL when no query has an exact match. */
 int rtx_classify_batch(rtx_index *index, uint64_t n_queries, const uint8_t *bases,
                        const uint64_t *base_off, const uint32_t *exact_ids,

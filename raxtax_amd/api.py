@@ -206,12 +206,10 @@ class Index:
     """Device-resident index + batch workspace of one GPU (rtx_index)."""
 
     def __init__(self, tree: Tree, device: int = 0, sub_batch: int = 0, prob_mode: int = 0, streams: int = 0,
-                 hybrid: Optional[bool] = None, sparse_max: Optional[int] = None, stage_timing: bool = False):
+                 stage_timing: bool = False):
         self._lib = _lib.load()
         self.tree = tree
         # creation-time knobs are process-wide defaults of the library
-        check(self._lib.rtx_set_default_option(4, 0 if hybrid is None else int(hybrid)))
-        check(self._lib.rtx_set_default_option(5, 12 if sparse_max is None else int(sparse_max)))
         h = C.c_void_p()
         check(self._lib.rtx_index_create_from_tree(device, tree._h, C.byref(h)))
         self._h = h

@@ -10,6 +10,8 @@
 // Out of scope: raxtax.log, progress bars, gzip input, thread options.
 #include <sys/stat.h>
 
+#include <chrono>
+
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -87,8 +89,17 @@ struct Sink {
 int main(int argc, char **argv) {
     std::string db, qf, prefix = "raxtax";
     bool skip_exact = false, raw = false, tsv = false, only_db = false, skip_db = false, clean = false, redo = false;
+    bool timing = false;
+    using clk = std::chrono::steady_clock;
+    auto t_prev = clk::now();
+    std::ostringstream t_log;
+    auto lap = [&](const char *what) {  // --timing: seconds per stage on stderr
+        const auto now = clk::now();
+        t_log << (t_log.tellp() > 0 ? ", " : "") << '"' << what << "\": " << std::chrono::duration<double>(now - t_prev).count();
+        t_prev = now;
+    };
     int device = 0;
-    size_t chunk = 4096;
+    size_t chunk = 32768;
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
         auto val = [&]() -> const char * { return i + 1 < argc ? argv[++i] : ""; };
@@ -102,6 +113,7 @@ int main(int argc, char **argv) {
         else if (a == "--skip-db") skip_db = true;
         else if (a == "-c" || a == "--clean") clean = true;
         else if (a == "--redo") redo = true;
+        else if (a == "--timing") timing = true;
         else if (a == "--device") device = atoi(val());
         else if (a == "--batch") chunk = (size_t)atoll(val());
         else {
@@ -151,6 +163,7 @@ int main(int argc, char **argv) {
         }
         store_db = true;
     }
+    lap("database");
     std::string db_bin;
     if (store_db && !skip_db) {  // main.rs:72-86, io.rs:269-286
         std::string base = db.substr(db.find_last_of('/') == std::string::npos ? 0 : db.find_last_of('/') + 1);
@@ -169,6 +182,7 @@ int main(int argc, char **argv) {
         f.close();
         rename(tmp.c_str(), ckp_json.c_str());
     }
+    lap("database_cache");
     if (only_db) return 0;
 
     // ---- queries (already finished labels are dropped, parser.rs:150-153)
@@ -181,11 +195,13 @@ int main(int argc, char **argv) {
         fprintf(stderr, "[ERROR] Failed to parse %s: %s\n", qf.c_str(), rtx_last_error());
         return 66;
     }
+    lap("queries");
     rtx_index *index = nullptr;
     if (rtx_index_create_from_tree(device, tree, &index) != RTX_OK) {
         fprintf(stderr, "[ERROR] %s\n", rtx_last_error());
         return 71;  // exitcode::OSERR
     }
+    lap("index");
     Sink sink;
     const auto mode = (redo || !resume) ? std::ios::trunc : std::ios::app;
     sink.out.open(out_path, mode);
@@ -211,6 +227,8 @@ int main(int argc, char **argv) {
     sink.out.flush();
     sink.ckp.flush();
     if (tsv) sink.tsv.flush();
+    lap("classify_and_write");
+    if (timing) fprintf(stderr, "{\"n_queries\": %llu, %s}\n", (unsigned long long)n, t_log.str().c_str());
     if (rc != RTX_OK) {
         fprintf(stderr, "[ERROR] %s\nRerun raxtax-hip to continue from the last checkpoint.\n", rtx_last_error());
         return rc == RTX_ERR_SENDER ? 75 : 70;  // exitcode::TEMPFAIL / SOFTWARE

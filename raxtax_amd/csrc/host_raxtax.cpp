@@ -2,13 +2,42 @@
 // batches, single-exact-match override, formatting, one message per query to the sender.
 #include "host_raxtax.hpp"
 
+#include <atomic>
+#include <condition_variable>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
+#include <thread>
 
 #include "rtx_internal.hpp"
 
 namespace {
 
+// Runs fn(i) for i in [0, n) on up to `nt` threads (contiguous ranges).
+template <class F>
+void parallel_ranges(uint64_t n, unsigned nt, F fn) {
+    nt = (unsigned)std::min<uint64_t>(nt, (n + 255) / 256);
+    if (nt <= 1) { fn(0, n); return; }
+    std::vector<std::thread> th;
+    for (unsigned i = 0; i < nt; i++) th.emplace_back(fn, n * i / nt, n * (i + 1) / nt);
+    for (auto &t : th) t.join();
+}
+
+// One chunk of queries travelling through the three stages of run().
+struct Chunk {
+    uint64_t q0 = 0, nq = 0;
+    std::vector<uint32_t> exact_ids;   // tree.sequences.get(query) per query, raxtax.rs:42
+    std::vector<uint64_t> exact_off;
+    std::vector<uint8_t> differ;       // raxtax.rs:43-53: exact matches with different parents
+    rtx_result_view res{};
+    int stage = 0;                     // 1: exact matches looked up, 2: classified, 3: sent
+};
+
+// raxtax() (src/raxtax.rs:14-97) as a three-stage pipeline over chunks of `chunk_size` queries:
+//   lookup thread : exact-match ids of chunk c+1            (host hash map, raxtax.rs:42-53)
+//   calling thread: device classification of chunk c        (rtx_classify_batch, raxtax.rs:55-71)
+//   format thread : override + formatting + sender, chunk c-1 (raxtax.rs:73-87), messages in input order
+// The library keeps two result sets, so the view of chunk c stays valid until chunk c+2 is classified.
 int run(rtx_index *index, const rtx_tree *tree, uint64_t n_queries, const char *const *labels, const uint8_t *bases,
         const uint64_t *base_off, bool skip_exact_matches, bool raw_confidence, uint64_t chunk_size,
         const raxtax::Sender &sender, bool tsv) {
@@ -16,64 +45,136 @@ int run(rtx_index *index, const rtx_tree *tree, uint64_t n_queries, const char *
     if (rtx_index_num_refs(index) != tree->num_tips) { rtx::set_error("index and tree disagree on num_tips"); return RTX_ERR_INVALID; }
     if (chunk_size == 0 || chunk_size > n_queries) chunk_size = n_queries ? n_queries : 1;
     const uint32_t flags = (skip_exact_matches ? RTX_SKIP_EXACT_MATCHES : 0u) | (raw_confidence ? RTX_RAW_CONFIDENCE : 0u);
+    const uint64_t n_chunks = (n_queries + chunk_size - 1) / chunk_size;
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    const unsigned nt_lookup = std::min(4u, hw), nt_format = std::min(8u, hw);
+
+    std::vector<Chunk> chunks(n_chunks);
+    std::mutex mu;
+    std::condition_variable cv;
+    int failed = RTX_OK;          // first error of any stage (under mu)
+    std::string failed_msg;
     bool warnings = false;
-    std::vector<uint32_t> exact_ids;
-    std::vector<uint64_t> exact_off;
-    std::vector<char> out_buf(1 << 16), tsv_buf(1 << 16);
-    for (uint64_t q0 = 0; q0 < n_queries; q0 += chunk_size) {
-        const uint64_t nq = std::min<uint64_t>(chunk_size, n_queries - q0);
-        exact_ids.clear();
-        exact_off.assign(1, 0);
-        for (uint64_t q = q0; q < q0 + nq; q++) {
-            // let exact_matches = tree.sequences.get(query_sequence), raxtax.rs:42
-            const uint32_t *ids = nullptr;
-            const uint64_t ne = rtx_tree_exact_matches(tree, bases + base_off[q], base_off[q + 1] - base_off[q], &ids);
-            exact_ids.insert(exact_ids.end(), ids, ids + ne);
-            exact_off.push_back(exact_ids.size());
-            if (!skip_exact_matches && ne > 1) {  // raxtax.rs:43-53 (the info! lines go to the log in the CLI)
-                auto parent = [&](uint32_t id) {
-                    const std::string &l = tree->lineages[id];
-                    const size_t c = l.rfind(',');
-                    return c == std::string::npos ? std::string_view() : std::string_view(l).substr(0, c);
-                };
-                for (uint64_t i = 1; i < ne; i++)
-                    if (parent(ids[i]) != parent(ids[0])) {
-                        fprintf(stderr, "[WARN ] Exact matches for %s differ above the leafs of the lineage tree!\n", labels[q]);
-                        warnings = true;
-                        break;
+    auto fail = [&](int rc, const std::string &msg) {
+        std::lock_guard<std::mutex> g(mu);
+        if (failed == RTX_OK) { failed = rc; failed_msg = msg; }
+        cv.notify_all();
+    };
+    // blocks until chunk c has reached `stage`; false if the run has failed meanwhile
+    auto wait_stage = [&](uint64_t c, int stage) {
+        std::unique_lock<std::mutex> g(mu);
+        cv.wait(g, [&] { return failed != RTX_OK || chunks[c].stage >= stage; });
+        return failed == RTX_OK;
+    };
+    auto set_stage = [&](uint64_t c, int stage) {
+        std::lock_guard<std::mutex> g(mu);
+        chunks[c].stage = stage;
+        cv.notify_all();
+    };
+
+    std::thread lookup([&] {
+        for (uint64_t c = 0; c < n_chunks; c++) {
+            if (c >= 2 && !wait_stage(c - 2, 2)) return;  // stay at most two chunks ahead of the device
+            Chunk &ch = chunks[c];
+            ch.q0 = c * chunk_size;
+            ch.nq = std::min<uint64_t>(chunk_size, n_queries - ch.q0);
+            std::vector<const uint32_t *> ptr(ch.nq);
+            std::vector<uint32_t> cnt(ch.nq);
+            ch.differ.assign(ch.nq, 0);
+            parallel_ranges(ch.nq, nt_lookup, [&](uint64_t a, uint64_t b) {
+                for (uint64_t i = a; i < b; i++) {
+                    const uint64_t q = ch.q0 + i;
+                    const uint32_t *ids = nullptr;
+                    const uint64_t ne = rtx_tree_exact_matches(tree, bases + base_off[q], base_off[q + 1] - base_off[q], &ids);
+                    ptr[i] = ids;
+                    cnt[i] = (uint32_t)ne;
+                    if (!skip_exact_matches && ne > 1) {  // raxtax.rs:43-53 (the info! lines go to the log in the CLI)
+                        auto parent = [&](uint32_t id) {
+                            const std::string &l = tree->lineages[id];
+                            const size_t k = l.rfind(',');
+                            return k == std::string::npos ? std::string_view() : std::string_view(l).substr(0, k);
+                        };
+                        for (uint64_t j = 1; j < ne; j++)
+                            if (parent(ids[j]) != parent(ids[0])) { ch.differ[i] = 1; break; }
                     }
+                }
+            });
+            ch.exact_off.assign(ch.nq + 1, 0);
+            for (uint64_t i = 0; i < ch.nq; i++) ch.exact_off[i + 1] = ch.exact_off[i] + cnt[i];
+            ch.exact_ids.resize(ch.exact_off[ch.nq]);
+            for (uint64_t i = 0; i < ch.nq; i++) {
+                std::copy(ptr[i], ptr[i] + cnt[i], ch.exact_ids.begin() + ch.exact_off[i]);
+                if (ch.differ[i]) {
+                    fprintf(stderr, "[WARN ] Exact matches for %s differ above the leafs of the lineage tree!\n", labels[ch.q0 + i]);
+                    warnings = true;
+                }
             }
+            set_stage(c, 1);
         }
-        rtx_result_view res;
-        int rc = rtx_classify_batch(index, nq, bases, base_off + q0, exact_ids.empty() ? nullptr : exact_ids.data(),
-                                    exact_off.data(), flags, &res);
-        if (rc) return rc;
-        for (uint64_t i = 0; i < nq; i++) {
-            const uint64_t q = q0 + i;
-            if (res.status[i] != RTX_Q_OK) {
-                // the reference aborts here (prob.rs:21/162); report and skip the query instead
-                fprintf(stderr, "[ERROR] query %s has too few valid 8-mers (%u) to be classified\n", labels[q], res.t[i]);
-                continue;
+    });
+
+    std::thread format([&] {
+        std::vector<std::string> out_msg, tsv_msg;
+        for (uint64_t c = 0; c < n_chunks; c++) {
+            if (!wait_stage(c, 2)) return;
+            Chunk &ch = chunks[c];
+            out_msg.assign(ch.nq, std::string());
+            if (tsv) tsv_msg.assign(ch.nq, std::string());
+            std::atomic<int> rc_fmt{0};
+            parallel_ranges(ch.nq, nt_format, [&](uint64_t a, uint64_t b) {
+                std::vector<char> out_buf(1 << 16), tsv_buf(1 << 16);
+                for (uint64_t i = a; i < b; i++) {
+                    const uint64_t q = ch.q0 + i;
+                    if (ch.res.status[i] != RTX_Q_OK) continue;
+                    const uint64_t len = base_off[q + 1] - base_off[q];
+                    const uint64_t rows = ch.res.row_off[i + 1] - ch.res.row_off[i];
+                    const size_t need = (rows + 1) * (strlen(labels[q]) + 4096 + 8 * RTX_MAX_DEPTH) + len + 64;
+                    if (out_buf.size() < need) out_buf.resize(need);
+                    if (tsv && tsv_buf.size() < need + rows * len) tsv_buf.resize(need + rows * len);
+                    int64_t tsv_len = 0;
+                    const int64_t n = rtx_format_query(tree, &ch.res, i, labels[q], bases + base_off[q], len,
+                                                       ch.exact_ids.data() + ch.exact_off[i], ch.exact_off[i + 1] - ch.exact_off[i],
+                                                       flags, out_buf.data(), out_buf.size(), tsv ? tsv_buf.data() : nullptr,
+                                                       tsv_buf.size(), &tsv_len);
+                    if (n < 0) { rc_fmt = (int)n; return; }
+                    out_msg[i].assign(out_buf.data(), (size_t)n);
+                    if (tsv) tsv_msg[i].assign(tsv_buf.data(), (size_t)tsv_len);
+                }
+            });
+            if (rc_fmt) { fail(rc_fmt, "formatting a result failed"); return; }
+            for (uint64_t i = 0; i < ch.nq; i++) {
+                const uint64_t q = ch.q0 + i;
+                if (ch.res.status[i] != RTX_Q_OK) {
+                    // the reference aborts here (prob.rs:21/162); report and skip the query instead
+                    fprintf(stderr, "[ERROR] query %s has too few valid 8-mers (%u) to be classified\n", labels[q], ch.res.t[i]);
+                    continue;
+                }
+                std::optional<std::string> t;
+                if (tsv) t.emplace(std::move(tsv_msg[i]));
+                if (!sender(labels[q], std::move(out_msg[i]), std::move(t))) {
+                    fail(RTX_ERR_SENDER, "result sink closed");  // sender.send(..)?, raxtax.rs:87
+                    return;
+                }
             }
-            const uint64_t len = base_off[q + 1] - base_off[q];
-            const uint64_t rows = res.row_off[i + 1] - res.row_off[i];
-            const size_t need = (rows + 1) * (strlen(labels[q]) + 4096 + 8 * RTX_MAX_DEPTH) + len + 64;
-            if (out_buf.size() < need) out_buf.resize(need);
-            if (tsv && tsv_buf.size() < need + rows * len) tsv_buf.resize(need + rows * len);
-            int64_t tsv_len = 0;
-            const int64_t n = rtx_format_query(tree, &res, i, labels[q], bases + base_off[q], len,
-                                               exact_ids.data() + exact_off[i], exact_off[i + 1] - exact_off[i], flags,
-                                               out_buf.data(), out_buf.size(), tsv ? tsv_buf.data() : nullptr,
-                                               tsv_buf.size(), &tsv_len);
-            if (n < 0) return (int)n;
-            std::optional<std::string> tsv_msg;
-            if (tsv) tsv_msg.emplace(tsv_buf.data(), (size_t)tsv_len);
-            if (!sender(labels[q], std::string(out_buf.data(), (size_t)n), std::move(tsv_msg))) {
-                rtx::set_error("result sink closed");  // sender.send(..)?, raxtax.rs:87
-                return RTX_ERR_SENDER;
-            }
+            std::vector<uint32_t>().swap(ch.exact_ids);
+            std::vector<uint64_t>().swap(ch.exact_off);
+            std::vector<uint8_t>().swap(ch.differ);
+            set_stage(c, 3);
         }
+    });
+
+    for (uint64_t c = 0; c < n_chunks; c++) {
+        if (!wait_stage(c, 1)) break;
+        if (c >= 2 && !wait_stage(c - 2, 3)) break;  // the result set of chunk c-2 is reused now
+        Chunk &ch = chunks[c];
+        const int rc = rtx_classify_batch(index, ch.nq, bases, base_off + ch.q0, ch.exact_ids.empty() ? nullptr : ch.exact_ids.data(),
+                                          ch.exact_off.data(), flags, &ch.res);
+        if (rc) { fail(rc, rtx_last_error()); break; }
+        set_stage(c, 2);
     }
+    lookup.join();
+    format.join();
+    if (failed != RTX_OK) { rtx::set_error("%s", failed_msg.c_str()); return failed; }
     if (warnings)  // raxtax.rs:93-95
         fprintf(stderr, "\x1b[33m[WARN ]\x1b[0m Exact matches for some queries differ above the species level! Check the log file for more information!\n");
     return RTX_OK;

@@ -127,12 +127,6 @@ struct rtx_index {
     uint64_t npad = 0;          // references per padded row (= stride_bytes * 8)
     uint32_t ntiles = 0;        // 8192-reference tiles
     DevBuf<uint32_t> d_bitmap, d_row_of, d_list_len;
-    // hybrid dense/sparse split of the bitmap (rtx_hybrid.hip)
-    bool hybrid = false;
-    DevBuf<uint8_t> d_qmask;
-    DevBuf<uint32_t> d_soff;
-    DevBuf<uint16_t> d_sent;
-    uint64_t n_sparse_entries = 0;
     DevBuf<double> d_lnfact, d_inv;
     // ---- memoised prob tables (t <= 1023), built lazily for the largest tmax seen
     int prob_mode = 0;  // 0 auto, 1 recurrence kernel only, 2 tables (error if they do not fit)
@@ -182,14 +176,20 @@ struct rtx_index {
     std::vector<hipEvent_t> events;  // 2 per (sub-batch, stage)
     uint32_t n_sub_last = 0;
     // ---- host results
-    std::vector<uint32_t> v_row_lineage, v_row_node, v_row_depth;
-    PinBuf<uint32_t> h_t, h_nrows_all, h_n_rows;
-    PinBuf<uint8_t> h_status;
-    std::vector<double> v_row_conf, v_row_local;
-    PinBuf<double> h_gs, h_z;
+    // two alternating sets: the view of download c stays valid while batch c+1 runs and is downloaded
+    struct HostRes {
+        std::vector<uint32_t> v_row_lineage, v_row_node, v_row_depth;
+        PinBuf<uint32_t> h_t;
+        PinBuf<uint8_t> h_status;
+        std::vector<double> v_row_conf, v_row_local;
+        PinBuf<double> h_gs;
+        std::vector<uint64_t> v_row_off;
+    } host_res[2];
+    uint32_t res_set = 0;
+    PinBuf<uint32_t> h_nrows_all, h_n_rows;
+    PinBuf<double> h_z;
     PinBuf<unsigned long long> h_hq, h_row_start;
     uint32_t stage_timing = 0;  // 0: HIP events around hit_count only; 1: around every kernel
-    std::vector<uint64_t> v_row_off;
     PinBuf<DevRow> h_arena;
 
     ~rtx_index() {
@@ -289,12 +289,7 @@ int enqueue_count(rtx_index *ix, const SubBatch &b, uint32_t flags) {
     hp.exact_ids = ix->d_exact_ids.p;
     hp.exact_off = ix->d_exact_off.p;
     if (b.timed) RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_HIT_COUNT, 0), s));
-    if (ix->hybrid) {
-        HybridIndex hy{ix->d_qmask.p, ix->d_soff.p, ix->d_sent.p, ix->n_rows + 1, ix->n_rows, ix->rstride};
-        launch_hit_count_hybrid(s, hp, hy, b.nq, ix->ntiles, ix->planes);
-    } else {
-        launch_hit_count(s, hp, b.nq, ix->ntiles, ix->planes);
-    }
+    launch_hit_count(s, hp, b.nq, ix->ntiles, ix->planes);
     if (b.timed) RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_HIT_COUNT, 1), s));
     return RTX_OK;
 }
@@ -548,6 +543,7 @@ double euclidean_distance_l1(const double *a, const double *b, uint32_t n) {  //
 }
 
 void finalise_range(rtx_index *ix, uint64_t qa, uint64_t qb) {
+    rtx_index::HostRes &hr = ix->host_res[ix->res_set];
     const FlatNodes &f = ix->nodes;
     const double N = (double)ix->n_total;
     std::vector<HostRow> rows;
@@ -568,18 +564,18 @@ void finalise_range(rtx_index *ix, uint64_t qa, uint64_t qb) {
         }
         // stable, descending (lineage.rs:91-93)
         std::stable_sort(rows.begin(), rows.end(), [](const HostRow &a, const HostRow &b) { return conf_less(b, a); });
-        uint64_t o = ix->v_row_off[q];
+        uint64_t o = hr.v_row_off[q];
         for (uint32_t r = 0; r < nr; r++, o++) {
             const HostRow &h = rows[r];
-            ix->v_row_lineage[o] = f.begin[h.node];
-            ix->v_row_node[o] = h.node;
-            ix->v_row_depth[o] = h.depth;
-            double *c = ix->v_row_conf.data() + o * RTX_MAX_DEPTH;
+            hr.v_row_lineage[o] = f.begin[h.node];
+            hr.v_row_node[o] = h.node;
+            hr.v_row_depth[o] = h.depth;
+            double *c = hr.v_row_conf.data() + o * RTX_MAX_DEPTH;
             for (uint32_t d = 0; d < RTX_MAX_DEPTH; d++) c[d] = d < h.depth ? h.conf[d] : 0.0;
             uint32_t s = h.depth ? h.depth - 1 : 0;  // lineage.rs:95-98
             for (uint32_t d = 0; d < h.depth; d++)
                 if (1.0 > h.expd[d]) { s = d; break; }
-            ix->v_row_local[o] = h.depth ? euclidean_distance_l1(h.conf + s, h.expd + s, h.depth - s) : 0.0;
+            hr.v_row_local[o] = h.depth ? euclidean_distance_l1(h.conf + s, h.expd + s, h.depth - s) : 0.0;
         }
     }
 }
@@ -594,39 +590,6 @@ int rtx_device_count(void) {
     return n;
 }
 
-// process-wide defaults applied to handles created afterwards (rtx_set_default_option)
-static uint64_t g_default_hybrid = 0, g_default_sparse_max = 12;
-
-// Moves nearly empty quarter-tile chunks of the bitmap into sparse lists (rtx_hybrid.hip).
-static int build_hybrid(rtx_index *ix) {
-    if (!g_default_hybrid) return RTX_OK;
-    const uint32_t n_rows1 = ix->n_rows + 1;
-    const size_t entries = (size_t)n_rows1 * ix->ntiles;
-    DevBuf<uint32_t> d_scount;
-    int rc;
-    if ((rc = ix->d_qmask.alloc(entries)) || (rc = d_scount.alloc(entries)) || (rc = ix->d_soff.alloc(entries + 1))) return rc;
-    launch_hybrid_classify(ix->stream, ix->d_bitmap.p, ix->stride_bytes, n_rows1, ix->ntiles, (uint32_t)g_default_sparse_max,
-                           ix->d_qmask.p, d_scount.p);
-    RTX_HIP(hipGetLastError());
-    RTX_HIP(hipStreamSynchronize(ix->stream));
-    std::vector<uint32_t> soff(entries + 1);
-    RTX_HIP(hipMemcpy(soff.data() + 1, d_scount.p, entries * 4, hipMemcpyDeviceToHost));
-    soff[0] = 0;
-    uint64_t run = 0;
-    for (size_t i = 0; i < entries; i++) {
-        run += soff[i + 1];
-        if (run > 0xFFFFFFFFull) { set_error("hybrid index: more than 2^32 sparse entries"); return RTX_ERR_INVALID; }
-        soff[i + 1] = (uint32_t)run;
-    }
-    ix->n_sparse_entries = run;
-    RTX_HIP(hipMemcpy(ix->d_soff.p, soff.data(), (entries + 1) * 4, hipMemcpyHostToDevice));
-    if ((rc = ix->d_sent.alloc(run + 1))) return rc;
-    launch_hybrid_emit(ix->stream, ix->d_bitmap.p, ix->stride_bytes, n_rows1, ix->ntiles, ix->d_qmask.p, ix->d_soff.p, ix->d_sent.p);
-    RTX_HIP(hipGetLastError());
-    RTX_HIP(hipStreamSynchronize(ix->stream));
-    ix->hybrid = true;
-    return RTX_OK;
-}
 
 // Everything of index creation except the bitmap: device checks, stream, taxonomy, tables.
 static int create_common(int device, uint64_t n_total, uint64_t ref_lo, uint64_t ref_hi, const uint64_t *cuts,
@@ -818,7 +781,6 @@ static int create_from_csr(int device, uint64_t n_total, uint64_t ref_lo, uint64
         }
         if (e != hipSuccess) { set_error("bitmap build failed: %s", hipGetErrorString(e)); return fail(RTX_ERR_HIP); }
     }
-    if ((rc = build_hybrid(ix))) return fail(rc);
     *out = ix;
     return RTX_OK;
 }
@@ -868,7 +830,6 @@ int rtx_index_create_from_sequences(int device, uint64_t n_refs, const uint8_t *
         e = hipStreamSynchronize(ix->stream);
     }
     if (e != hipSuccess) { set_error("bitmap build from sequences failed: %s", hipGetErrorString(e)); return fail(RTX_ERR_HIP); }
-    if ((rc = build_hybrid(ix))) return fail(rc);
     *out = ix;
     return RTX_OK;
 }
@@ -893,26 +854,13 @@ void rtx_index_destroy(rtx_index *index) {
 uint64_t rtx_index_num_refs(const rtx_index *index) { return index ? index->n_total : 0; }
 uint64_t rtx_index_device_bytes(const rtx_index *index) {
     if (!index) return 0;
-    return index->d_qmask.n + index->d_soff.n * 4 + index->d_sent.n * 2 + index->d_bitmap.n * 4 + index->d_row_of.n * 4 + index->d_list_len.n * 4 + index->d_lnfact.n * 8 +
+    return index->d_bitmap.n * 4 + index->d_row_of.n * 4 + index->d_list_len.n * 4 + index->d_lnfact.n * 8 +
            index->d_blo.n * 4 * 4 + index->d_type.n + index->d_bnd_bits.n + index->d_bnd_rank.n * 4;
 }
 int rtx_index_set_batch(rtx_index *index, uint32_t sub_batch) {
     if (!index) { set_error("null index handle"); return RTX_ERR_INVALID; }
     index->sub_batch_req = sub_batch;
     return RTX_OK;
-}
-
-int rtx_set_default_option(int option, uint64_t value) {
-    switch (option) {
-        case RTX_OPT_HYBRID: g_default_hybrid = value ? 1 : 0; return RTX_OK;
-        case RTX_OPT_SPARSE_MAX:
-            if (value > 64) break;
-            g_default_sparse_max = value;
-            return RTX_OK;
-        default: break;
-    }
-    set_error("rtx_set_default_option: unknown option %d / value %llu", option, (unsigned long long)value);
-    return RTX_ERR_INVALID;
 }
 
 int rtx_index_set_option(rtx_index *index, int option, uint64_t value) {
@@ -1007,6 +955,8 @@ int rtx_batch_download(rtx_index *ix, rtx_result_view *out) {
     if (rc) return rc;
     if (!ix->ran || !out) { set_error("rtx_batch_download before rtx_batch_run"); return RTX_ERR_STATE; }
     const uint64_t nq = ix->n_q;
+    ix->res_set ^= 1u;
+    rtx_index::HostRes &hr = ix->host_res[ix->res_set];
     unsigned long long cursor = 0;
     for (int attempt = 0;; attempt++) {
         RTX_HIP(hipStreamSynchronize(ix->stream));
@@ -1027,31 +977,31 @@ int rtx_batch_download(rtx_index *ix, rtx_result_view *out) {
         }
         if ((rc = enqueue_batch(ix, ix->last_flags))) return rc;
     }
-    if ((rc = ix->h_status.resize(nq)) || (rc = ix->h_t.resize(nq)) || (rc = ix->h_nrows_all.resize(nq)) ||
-        (rc = ix->h_n_rows.resize(nq)) || (rc = ix->h_gs.resize(nq)) || (rc = ix->h_z.resize(nq)) ||
+    if ((rc = hr.h_status.resize(nq)) || (rc = hr.h_t.resize(nq)) || (rc = ix->h_nrows_all.resize(nq)) ||
+        (rc = ix->h_n_rows.resize(nq)) || (rc = hr.h_gs.resize(nq)) || (rc = ix->h_z.resize(nq)) ||
         (rc = ix->h_hq.resize(nq)) || (rc = ix->h_row_start.resize(nq)) || (rc = ix->h_arena.resize(cursor ? cursor : 1)))
         return rc;
     hipStream_t cs = ix->stream;
-    RTX_HIP(hipMemcpyAsync(ix->h_status.data(), ix->d_status.p, nq, hipMemcpyDeviceToHost, cs));
-    RTX_HIP(hipMemcpyAsync(ix->h_t.data(), ix->d_t_all.p, nq * 4, hipMemcpyDeviceToHost, cs));
+    RTX_HIP(hipMemcpyAsync(hr.h_status.data(), ix->d_status.p, nq, hipMemcpyDeviceToHost, cs));
+    RTX_HIP(hipMemcpyAsync(hr.h_t.data(), ix->d_t_all.p, nq * 4, hipMemcpyDeviceToHost, cs));
     RTX_HIP(hipMemcpyAsync(ix->h_nrows_all.data(), ix->d_nrows_all.p, nq * 4, hipMemcpyDeviceToHost, cs));
     RTX_HIP(hipMemcpyAsync(ix->h_n_rows.data(), ix->d_n_rows.p, nq * 4, hipMemcpyDeviceToHost, cs));
-    RTX_HIP(hipMemcpyAsync(ix->h_gs.data(), ix->d_gs.p, nq * 8, hipMemcpyDeviceToHost, cs));
+    RTX_HIP(hipMemcpyAsync(hr.h_gs.data(), ix->d_gs.p, nq * 8, hipMemcpyDeviceToHost, cs));
     RTX_HIP(hipMemcpyAsync(ix->h_z.data(), ix->d_z.p, nq * 8, hipMemcpyDeviceToHost, cs));
     RTX_HIP(hipMemcpyAsync(ix->h_hq.data(), ix->d_hq.p, nq * 8, hipMemcpyDeviceToHost, cs));
     RTX_HIP(hipMemcpyAsync(ix->h_row_start.data(), ix->d_row_start.p, nq * 8, hipMemcpyDeviceToHost, cs));
     if (cursor) RTX_HIP(hipMemcpyAsync(ix->h_arena.data(), ix->d_arena.p, cursor * sizeof(DevRow), hipMemcpyDeviceToHost, cs));
     RTX_HIP(hipStreamSynchronize(cs));
 
-    ix->v_row_off.resize(nq + 1);
-    ix->v_row_off[0] = 0;
-    for (uint64_t q = 0; q < nq; q++) ix->v_row_off[q + 1] = ix->v_row_off[q] + ix->h_n_rows[q];
-    const uint64_t nrows = ix->v_row_off[nq];
-    ix->v_row_lineage.resize(nrows);
-    ix->v_row_node.resize(nrows);
-    ix->v_row_depth.resize(nrows);
-    ix->v_row_local.resize(nrows);
-    ix->v_row_conf.resize(nrows * RTX_MAX_DEPTH);
+    hr.v_row_off.resize(nq + 1);
+    hr.v_row_off[0] = 0;
+    for (uint64_t q = 0; q < nq; q++) hr.v_row_off[q + 1] = hr.v_row_off[q] + ix->h_n_rows[q];
+    const uint64_t nrows = hr.v_row_off[nq];
+    hr.v_row_lineage.resize(nrows);
+    hr.v_row_node.resize(nrows);
+    hr.v_row_depth.resize(nrows);
+    hr.v_row_local.resize(nrows);
+    hr.v_row_conf.resize(nrows * RTX_MAX_DEPTH);
     unsigned nt = std::min<unsigned>(8, std::max(1u, std::thread::hardware_concurrency()));
     if (nq < 4096) nt = 1;
     if (nt == 1) {
@@ -1064,15 +1014,15 @@ int rtx_batch_download(rtx_index *ix, rtx_result_view *out) {
     }
     out->n_queries = (uint32_t)nq;
     out->n_rows = nrows;
-    out->t = ix->h_t.data();
-    out->status = ix->h_status.data();
-    out->global_signal = ix->h_gs.data();
-    out->row_off = ix->v_row_off.data();
-    out->row_lineage = ix->v_row_lineage.data();
-    out->row_node = ix->v_row_node.data();
-    out->row_depth = ix->v_row_depth.data();
-    out->row_conf = ix->v_row_conf.data();
-    out->row_local_signal = ix->v_row_local.data();
+    out->t = hr.h_t.data();
+    out->status = hr.h_status.data();
+    out->global_signal = hr.h_gs.data();
+    out->row_off = hr.v_row_off.data();
+    out->row_lineage = hr.v_row_lineage.data();
+    out->row_node = hr.v_row_node.data();
+    out->row_depth = hr.v_row_depth.data();
+    out->row_conf = hr.v_row_conf.data();
+    out->row_local_signal = hr.v_row_local.data();
     return RTX_OK;
 }
 

@@ -26,7 +26,7 @@ __global__ __launch_bounds__(256) void bitmap_build_kernel(const uint64_t *__res
                                                            const uint32_t *__restrict__ post,
                                                            const uint32_t *__restrict__ row_of,
                                                            uint32_t *__restrict__ bitmap, uint32_t stride_words,
-                                                           uint32_t ref_lo, uint32_t ref_hi) {
+                                                           uint32_t ref_lo, uint32_t ref_hi) {  // bit: ref_slot()
     const uint32_t k = blockIdx.x;
     const uint32_t row = row_of[k];
     if (row == kEmptyRow) return;
@@ -35,8 +35,9 @@ __global__ __launch_bounds__(256) void bitmap_build_kernel(const uint64_t *__res
     for (uint64_t i = b + threadIdx.x; i < e; i += blockDim.x) {
         const uint32_t g = post[i];
         if (g < ref_lo || g >= ref_hi) continue;  // reference held by another shard
-        const uint32_t r = g - ref_lo;
-        atomicOr(&dst[r >> 5], 1u << (r & 31u));
+        uint32_t word, bit;
+        ref_slot(g - ref_lo, stride_words * 4u, word, bit);
+        atomicOr(&dst[word], 1u << bit);
     }
 }
 
@@ -88,7 +89,9 @@ __global__ __launch_bounds__(64) void ref_bitmap_set_kernel(const uint8_t *__res
     if (r >= n_refs) return;
     const uint32_t lane = threadIdx.x;
     const uint64_t b0 = off[r], len = off[r + 1] - b0;
-    const uint32_t word = (uint32_t)(r >> 5), bit = 1u << (r & 31u);
+    uint32_t word, bitpos;
+    ref_slot((uint32_t)r, stride_words * 4u, word, bitpos);
+    const uint32_t bit = 1u << bitpos;
     for (uint64_t w = lane; w + 8 <= len; w += 64) {
         uint32_t k;
         if (window_kmer(bases + b0, w, k)) atomicOr(&bitmap[(size_t)row_of[k] * stride_words + word], bit);
@@ -204,8 +207,8 @@ __global__ __launch_bounds__(64) void kmer_extract_kernel(KmerParams p) {
 
 // ---------------------------------------------------------------------------
 // hit_count (src/raxtax.rs:41,58-68): one wave per (query, 8192-reference tile).
-// Lane l owns references [tile*8192 + l*128, +128): 16 bytes of every bitmap row, so a
-// wave reads 1 KiB contiguous per row (one global_load_dwordx4 per lane, row base in
+// Lane l owns 16 bytes of every bitmap row = 128 references of the tile (which ones: ref_slot,
+// rtx_math.hpp), so a wave reads 1 KiB contiguous per row (one global_load_dwordx4 per lane, row base in
 // SGPRs).  Rows are folded 32 at a time into NP bit planes per 32-reference word with a
 // Harley-Seal carry-save tree (rtx_math.hpp: 31 CSAs + one ripple per 32 rows).  The epilogue zeroes exact matches (raxtax.rs:65-68), unpacks the planes
 // to u16 counts, stores them, and builds the hit-count histogram of prob.rs:13-19 with
@@ -297,29 +300,32 @@ __global__ __launch_bounds__(64) void hit_count_kernel(HitParams p) {
     __syncthreads();
 
     if (active) {
-        const uint32_t ref0 = tile * 8192u + lane * 128u;
+        const uint32_t L = tile_lanes(p.stride_bytes, tile);  // lanes of this tile (64 except in the last one)
         if (p.flags & RTX_SKIP_EXACT_MATCHES) {  // raxtax.rs:65-68
             const uint64_t e0 = p.exact_off[p.q0 + q], e1 = p.exact_off[p.q0 + q + 1];
             for (uint64_t e = e0; e < e1; e++) {
                 const uint32_t id = p.exact_ids[e] - p.ref_base;  // local id; other shards' ids wrap out of range
-                if (id >= ref0 && id < ref0 + 128u) {
-                    const uint32_t w = (id - ref0) >> 5, msk = ~(1u << (id & 31u));
+                if (id < p.n_refs && (id >> 13) == tile) {
+                    const uint32_t c = (id & 8191u) >> 3, g = c / L;
+                    if (c - g * L == lane) {
+                        const uint32_t w = g >> 2, msk = ~(1u << ((g & 3u) * 8u + (id & 7u)));
 #pragma unroll
-                    for (int ww = 0; ww < 4; ww++)
-                        if ((uint32_t)ww == w) {
+                        for (int ww = 0; ww < 4; ww++)
+                            if ((uint32_t)ww == w) {
 #pragma unroll
-                            for (int b = 0; b < NP; b++) pl[ww][b] &= msk;
-                        }
+                                for (int b = 0; b < NP; b++) pl[ww][b] &= msk;
+                            }
+                    }
                 }
             }
         }
-        const uint32_t nvalid =
-            ref0 >= p.n_refs ? 0u : ((p.n_refs - ref0) < 128u ? (uint32_t)(p.n_refs - ref0) : 128u);
+        // group g = (w, g2) of this lane: references ref0 + g*L*8 + [0, 8) (ref_slot, rtx_math.hpp)
+        const uint64_t ref0 = (uint64_t)tile * 8192u + lane * 8u;
         uint16_t *out = p.counts + (size_t)q * p.npad + ref0;
 #pragma unroll
         for (int w = 0; w < 4; w++) {
 #pragma unroll
-            for (int g2 = 0; g2 < 4; g2++) {  // 8 references per 16-byte store
+            for (int g2 = 0; g2 < 4; g2++) {  // 8 references per 16-byte store, contiguous across lanes
                 uint32_t lo0, hi0, lo1, hi1;
                 planes_unpack4<NP>(pl[w], 2 * g2, lo0, hi0);
                 planes_unpack4<NP>(pl[w], 2 * g2 + 1, lo1, hi1);
@@ -329,13 +335,15 @@ __global__ __launch_bounds__(64) void hit_count_kernel(HitParams p) {
                 st.y = __builtin_amdgcn_perm(hi0, lo0, 0x07030602u);
                 st.z = __builtin_amdgcn_perm(hi1, lo1, 0x05010400u);
                 st.w = __builtin_amdgcn_perm(hi1, lo1, 0x07030602u);
-                *reinterpret_cast<uint4 *>(out + w * 32 + g2 * 8) = st;
-                const uint32_t rbase = w * 32 + g2 * 8;
+                const uint32_t goff = (uint32_t)(w * 4 + g2) * L * 8u;
+                *reinterpret_cast<uint4 *>(out + goff) = st;
+                const uint64_t rbase = ref0 + goff;
+                const uint32_t nvalid = rbase >= p.n_refs ? 0u : (p.n_refs - rbase < 8u ? (uint32_t)(p.n_refs - rbase) : 8u);
                 const uint32_t cw[4] = {st.x, st.y, st.z, st.w};
 #pragma unroll
                 for (int j = 0; j < 8; j++) {
                     const uint32_t c = (cw[j >> 1] >> ((j & 1) * 16)) & 0xFFFFu;
-                    if (rbase + j < nvalid) atomicAdd(&hist_lds[c], 1u);
+                    if ((uint32_t)j < nvalid) atomicAdd(&hist_lds[c], 1u);
                 }
             }
         }
@@ -570,6 +578,13 @@ __global__ __launch_bounds__(kProbThreads) void prob_table_kernel(ProbParams p) 
 // One workgroup of NW waves per query, 8 references per thread per sweep (NW*512 per sweep); the
 // sweeps are sequential (running carry), so wide workgroups = fewer, better overlapped sweeps.
 // ---------------------------------------------------------------------------
+// eight counts, read once: non-temporal so that they do not displace bitmap rows / table rows in L2
+__device__ __forceinline__ uint4 load_counts8(const uint16_t *p) {
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p));
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+
 template <int NW>
 __global__ __launch_bounds__(NW * 64) void taxon_prefix_kernel(PrefixParams p) {
     extern __shared__ double tz_lds[];
@@ -594,7 +609,7 @@ __global__ __launch_bounds__(NW * 64) void taxon_prefix_kernel(PrefixParams p) {
     uint4 cv_next = make_uint4(0, 0, 0, 0);
     uint32_t bits_next = 0;
     if ((uint64_t)tid * 8 < n) {
-        cv_next = *reinterpret_cast<const uint4 *>(cnt + (uint64_t)tid * 8);
+        cv_next = load_counts8(cnt + (uint64_t)tid * 8);
         bits_next = p.bnd_bits[tid];
     }
     for (uint64_t base = 0; base < n; base += NW * 512) {
@@ -603,7 +618,7 @@ __global__ __launch_bounds__(NW * 64) void taxon_prefix_kernel(PrefixParams p) {
         const uint32_t bits_cur = bits_next;
         const uint64_t rn = r0 + NW * 512;
         if (rn < n) {
-            cv_next = *reinterpret_cast<const uint4 *>(cnt + rn);
+            cv_next = load_counts8(cnt + rn);
             bits_next = p.bnd_bits[rn >> 3];
         }
         double s[8];

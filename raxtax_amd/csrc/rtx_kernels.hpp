@@ -73,15 +73,6 @@ struct ProbTables {
     uint32_t tmax;
 };
 
-// hybrid dense/sparse index (rtx_hybrid.hip): per (tile, row) dense-quarter mask + CSR of sparse entries
-struct HybridIndex {
-    const uint8_t *qmask;   // [ntiles][n_rows1]
-    const uint32_t *soff;   // [ntiles * n_rows1 + 1]
-    const uint16_t *sent;   // offsets 0..8191 inside the tile
-    uint32_t n_rows1;       // bitmap rows incl. the zero row
-    uint32_t zero_row;
-    uint32_t rcap;          // capacity of the per-wave dense row list in LDS
-};
 
 struct ProbParams {
     const uint32_t *order;  // processing order of the sub-batch (slot indices) or null
@@ -142,12 +133,6 @@ void launch_row_popcount(hipStream_t s, const uint32_t *row_of, const uint32_t *
                          uint32_t *list_len);
 void launch_kmer_extract(hipStream_t s, const KmerParams &p, uint32_t nq);
 void launch_hit_count(hipStream_t s, const HitParams &p, uint32_t nq, uint32_t ntiles, int planes);
-void launch_hybrid_classify(hipStream_t s, const uint32_t *bitmap, uint32_t stride_bytes, uint32_t n_rows1, uint32_t ntiles,
-                            uint32_t sparse_max, uint8_t *qmask, uint32_t *scount);
-void launch_hybrid_emit(hipStream_t s, uint32_t *bitmap, uint32_t stride_bytes, uint32_t n_rows1, uint32_t ntiles,
-                        const uint8_t *qmask, const uint32_t *soff, uint16_t *sent);
-size_t hit_count_hybrid_lds_bytes(uint32_t hstride, uint32_t rcap);
-void launch_hit_count_hybrid(hipStream_t s, const HitParams &p, const HybridIndex &hy, uint32_t nq, uint32_t ntiles, int planes);
 size_t prob_table_lds_bytes(uint32_t tmax);
 void launch_prob_table(hipStream_t s, const ProbParams &p, uint32_t nq);
 size_t prob_lookup_lds_bytes(uint32_t tmax);

@@ -24,6 +24,26 @@ namespace rtx {
 // the planes are an exact binary representation as long as count < 2^NP.
 // ---------------------------------------------------------------------------
 
+// ---------------------------------------------------------------------------
+// Where reference r (local id) sits in a bitmap row.  A tile = 8192 references = 64 lanes x 16 B of the
+// row; the last tile of a row spans only L = (stride - tile*1024)/16 lanes.  hit_count unpacks the
+// 128 counters of a lane as 16 groups of 8 (group g = word g/4, bits 8(g%4)..+7); group g of lane l
+// holds references tile*8192 + (g*L + l)*8 + [0, 8), so that the sixteen 16-byte count stores of a
+// wave are each contiguous across lanes (stored lane-major they cost 4 of hit_count's 24 ms).
+// ---------------------------------------------------------------------------
+RTX_HD uint32_t tile_lanes(uint32_t stride_bytes, uint32_t tile) {
+    const uint32_t rem = stride_bytes - tile * 1024u;
+    return rem >= 1024u ? 64u : rem >> 4;
+}
+// word index within the row and bit within the word
+RTX_HD void ref_slot(uint32_t r, uint32_t stride_bytes, uint32_t &word, uint32_t &bit) {
+    const uint32_t tile = r >> 13, rl = r & 8191u;
+    const uint32_t L = tile_lanes(stride_bytes, tile);
+    const uint32_t c = rl >> 3, l = c % L, g = c / L;
+    word = tile * 256u + l * 4u + (g >> 2);
+    bit = (g & 3u) * 8u + (rl & 7u);
+}
+
 // full adder on bit vectors: (a + b + c) -> sum (weight 1), carry (weight 2)
 RTX_HD void csa(uint32_t a, uint32_t b, uint32_t c, uint32_t &sum, uint32_t &carry) {
 #if defined(__HIP_DEVICE_COMPILE__)

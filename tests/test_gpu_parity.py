@@ -409,25 +409,6 @@ def test_reference_sharded_database_equals_unsharded(world, n_shards, cuts):
         assert np.array_equal(s.debug_hit_counts(q), full[s.ref_lo:s.ref_hi])
 
 
-def test_hybrid_sparse_dense_index_equals_plain_bitmap(world):
-    """RTX_OPT_HYBRID: moving nearly empty quarter-tile chunks into sparse lists leaves every hit count (and
-    everything downstream) unchanged; also with --skip-exact-matches (zeroing touches both parts)."""
-    w = world
-    ex_ids, ex_off = w["index"].exact_matches(w["bases"], w["off"])
-    plain = rx.Index(w["tree"], hybrid=False)
-    for sparse_max in (1, 12, 64):
-        hyb = rx.Index(w["tree"], hybrid=True, sparse_max=sparse_max)
-        for skip in (False, True):
-            a = plain.classify(w["bases"], w["off"], ex_ids, ex_off, skip_exact_matches=skip)
-            b = hyb.classify(w["bases"], w["off"], ex_ids, ex_off, skip_exact_matches=skip)
-            for q in range(len(w["seqs"])):
-                assert np.array_equal(plain.debug_hit_counts(q), hyb.debug_hit_counts(q)), (sparse_max, skip, q)
-            assert np.array_equal(a.row_off, b.row_off) and np.array_equal(a.row_lineage, b.row_lineage)
-            assert np.array_equal(a.row_conf, b.row_conf) and np.array_equal(a.global_signal, b.global_signal)
-        assert hyb.work() == plain.work()
-    rx.Index(w["tree"])   # restore the defaults for later tests
-
-
 def _classify_and_compare(oracle, lineages, seqs, qseqs, skip=False):
     otree = oracle.tree_new(lineages, seqs)
     tree = rx.Tree.new(lineages, seqs)

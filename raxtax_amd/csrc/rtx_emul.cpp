@@ -184,7 +184,7 @@ int emul_prob_table(uint32_t t, const uint32_t *hist, uint64_t n_refs, const dou
 
 
 // Sequential emulation of prob_lookup_kernel + prob_tables_build_kernel (rtx_prob_tables.hip): the rows
-// C = cmf, R = pmf/cmf, sat and ilo are produced by the same recurrence (here on demand instead of from the
+// C = ln cmf, R = pmf/cmf, sat and ilo are produced by the same recurrence (here on demand instead of from the
 // memoised table), then P(i) and table[m] are formed exactly as the lookup kernel does.
 int emul_prob_lookup(uint32_t t, const uint32_t *hist, uint64_t n_refs, const double *lf, double *table_z, double *z,
                      double *gs, uint64_t *stats) {
@@ -213,7 +213,7 @@ int emul_prob_lookup(uint32_t t, const uint32_t *hist, uint64_t n_refs, const do
                 if (sat == n + 1 && st.c == c_old && k_old == 0 && st.k == 0) sat = i;
             }
             const bool live = st.k == 0 && st.c > 0.0;
-            C[i] = live ? st.c : 0.0;
+            C[i] = live ? log(st.c) : -INFINITY;
             R[i] = live ? st.v / st.c : 0.0;
             if (!found && ln_pmf_tab(lf, t, n, m, i, ln_total) >= kLnNegligibleP) { ilo = i; found = true; }
         }
@@ -226,7 +226,7 @@ int emul_prob_lookup(uint32_t t, const uint32_t *hist, uint64_t n_refs, const do
         std::vector<double> C, R;
         uint32_t sat = 0, ilo = 0, i_lo = 0;
         if (M > 0) { build_row(M, C, R, sat, ilo); i_lo = ilo; }
-        std::vector<double> Pi(n + 1, 1.0);
+        std::vector<double> Pi(n + 1, 0.0);  // sum_m hist[m] ln cmf_m(i), then exp
         struct Row { uint32_t m, sat; std::vector<double> R; };
         std::vector<Row> rows;
         for (size_t j = ms.size(); j-- > 0;) {
@@ -235,10 +235,11 @@ int emul_prob_lookup(uint32_t t, const uint32_t *hist, uint64_t n_refs, const do
             build_row(m, C, R, sat, ilo);
             if (sat <= i_lo) continue;  // saturated before i_lo: factor 1, table 0
             for (uint32_t i = i_lo; i <= n; i++)
-                if (i < sat) { Pi[i] *= pow_uint(C[i], hist[m]); st_points++; }
+                if (i < sat) { Pi[i] = fma((double)hist[m], C[i], Pi[i]); st_points++; }
             rows.push_back(Row{m, sat, R});
             st_rows++;
         }
+        for (uint32_t i = 0; i <= n; i++) Pi[i] = exp(Pi[i]);
         for (const Row &r : rows) {
             const uint32_t last = std::min(n, r.sat - 1);
             double acc = 0.0;

@@ -3,12 +3,13 @@
 // pmf_m(i) and cmf_m(i) of prob.rs:121-170 depend on (t, n = t/2, m, i) only -- not on the query
 // beyond its number of distinct k-mers t.  For barcode-length queries (t <= 1023) the library
 // therefore builds, once per index handle, for every t <= tmax and every 0 < m < t
-//     C[t][m][i] = cmf_m(i)              R[t][m][i] = pmf_m(i) / cmf_m(i)
+//     L[t][m][i] = ln cmf_m(i)           R[t][m][i] = pmf_m(i) / cmf_m(i)
 // with the very recurrence of rtx_math.hpp (same arithmetic as prob_table_kernel), plus per (t, m)
 //     ilo[t][m] = first i with ln pmf_m(i) >= -100          (i_lo when m is the largest count)
 //     sat[t][m] = first i at which cmf_m stops changing      (cmf == its final value from there on)
 // A query then needs no recurrence at all:
-//     P(i)     = prod_m C[t][m][i]^hist[m]          (lanes <-> i, rows streamed coalesced)
+//     P(i)     = exp(sum_m hist[m] L[t][m][i])      (lanes <-> i, rows streamed coalesced; this is
+//                                                    prod[i] of prob.rs:62-73, one FMA per row and i)
 //     table[m] = sum_i R[t][m][i] * P(i)            (one wave reduction per distinct count)
 // restricted to i >= i_lo and to the rows that are not yet saturated at i_lo (a saturated row
 // contributes the constant factor cmf_final^h = 1 + O(h 1e-16), identical for every i >= i_lo,
@@ -34,8 +35,8 @@ __global__ __launch_bounds__(256) void prob_tables_build_kernel(ProbTables tb, c
     double *R = tb.ratio + tb.off[t] + (size_t)m * n1;
     uint16_t *meta_ilo = tb.ilo + tb.moff[t];
     uint16_t *meta_sat = tb.sat + tb.moff[t];
-    if (m == 0) {  // pmf = [1, 0, ...], cmf = 1 (prob.rs:134-137)
-        for (uint32_t i = 0; i <= n; i++) { C[i] = 1.0; R[i] = i == 0 ? 1.0 : 0.0; }
+    if (m == 0) {  // pmf = [1, 0, ...], cmf = 1, ln cmf = 0 (prob.rs:134-137)
+        for (uint32_t i = 0; i <= n; i++) { C[i] = 0.0; R[i] = i == 0 ? 1.0 : 0.0; }
         meta_ilo[0] = 0;
         meta_sat[0] = 1;
         return;
@@ -52,7 +53,7 @@ __global__ __launch_bounds__(256) void prob_tables_build_kernel(ProbTables tb, c
             if (sat == n + 1 && st.c == c_old && k_old == 0 && st.k == 0) sat = i;
         }
         const bool live = st.k == 0 && st.c > 0.0;  // below 2^-412 the cmf counts as 0 (rtx_math.hpp)
-        C[i] = live ? st.c : 0.0;
+        C[i] = live ? log(st.c) : -INFINITY;
         R[i] = live ? st.v / st.c : 0.0;
         if (!ilo_found && ln_pmf_tab(lf, t, n, m, i, ln_total) >= kLnNegligibleP) { ilo = i; ilo_found = true; }
     }
@@ -76,9 +77,9 @@ __global__ __launch_bounds__(256) void prob_lookup_kernel(ProbParams p, ProbTabl
     double *Pi = smem;
     double *red = Pi + p.n1max;
     uint32_t *row_h = reinterpret_cast<uint32_t *>(red + 16);
-    uint16_t *row_m = reinterpret_cast<uint16_t *>(row_h + (p.tmax + 10));
-    uint16_t *row_sat = row_m + (p.tmax + 10);
-    uint16_t *ms = row_sat + (p.tmax + 10);
+    uint16_t *row_m = reinterpret_cast<uint16_t *>(row_h + (p.tmax + 18));
+    uint16_t *row_sat = row_m + (p.tmax + 18);
+    uint16_t *ms = row_sat + (p.tmax + 18);
     const uint32_t *hist = p.hist + (size_t)q * p.hstride;
     double *tz = p.table_z + (size_t)q * p.hstride;
     const double *lf = p.lnfact;
@@ -138,55 +139,66 @@ __global__ __launch_bounds__(256) void prob_lookup_kernel(ProbParams p, ProbTabl
                 }
                 na += (uint32_t)__popcll(bal);
             }
-            // pad to a multiple of 8 with neutral rows (m = 0: cmf = 1, sat = 0, h = 0)
-            const uint32_t padded = (na + 7u) & ~7u;
+            // pad to a multiple of 16 with neutral rows (m = 0: ln cmf = 0, sat = 0, h = 0)
+            const uint32_t padded = (na + 15u) & ~15u;
             if (na + lane < padded) { row_m[na + lane] = 0; row_sat[na + lane] = 0; row_h[na + lane] = 0; }
             if (lane == 0) s_nact = na;
         }
         __syncthreads();
         const uint32_t nact = s_nact;
-        // ---- pass 1: P(i) = prod_m cmf_m(i)^hist[m]  (prob.rs:62-73), lanes <-> i.  Rows are taken
-        // eight at a time: eight independent 512-byte row-slice loads in flight per wave, then the powers.
+        // ---- pass 1: P(i) = exp(sum_m hist[m] ln cmf_m(i))  (prob.rs:62-73), lanes <-> i.  Rows are taken
+        // sixteen at a time: sixteen independent 512-byte row-slice loads in flight per wave, one FMA each.
         for (uint32_t i0 = i_lo + wave * 64; i0 <= n; i0 += 256) {
             const uint32_t i = i0 + lane;
             const bool in = i <= n;
-            double P = 1.0;
-            for (uint32_t r0 = 0; r0 < nact; r0 += 8) {
-                double c[8];
+            double S = 0.0;
+            for (uint32_t r0 = 0; r0 < nact; r0 += 16) {
+                double c[16];
 #pragma unroll
-                for (int k = 0; k < 8; k++) {
+                for (int k = 0; k < 16; k++) {
                     const uint32_t m = row_m[r0 + k], sat = row_sat[r0 + k];
-                    c[k] = (in && i < sat) ? Ct[(size_t)m * n1 + i] : 1.0;  // past saturation the factor is 1
+                    c[k] = (in && i < sat) ? Ct[(size_t)m * n1 + i] : 0.0;  // past saturation the factor is 1
                 }
 #pragma unroll
-                for (int k = 0; k < 8; k++) {
+                for (int k = 0; k < 16; k++) {
                     const uint32_t h = __builtin_amdgcn_readfirstlane(row_h[r0 + k]);
-                    P *= pow_uint(c[k], h);
+                    S = fma((double)h, c[k], S);
                 }
             }
-            if (in) Pi[i - i_lo] = P;
+            if (in) Pi[i - i_lo] = exp(S);
         }
         __syncthreads();
-        // ---- pass 2: table[m] = sum_i pmf_m(i) P(i) / cmf_m(i)  (prob.rs:74-90); a wave takes four
-        // rows per turn so that their loads overlap, then one DPP reduction per row
-        for (uint32_t r0 = wave * 4; r0 < nact; r0 += 16) {
-            double acc[4] = {0.0, 0.0, 0.0, 0.0};
-            uint32_t mm[4], last[4];
+        // ---- pass 2: table[m] = sum_i pmf_m(i) P(i) / cmf_m(i)  (prob.rs:74-90); a wave takes eight
+        // rows per turn and two 64-wide slices of i at a time (sixteen loads in flight), then one DPP
+        // reduction per row
+        for (uint32_t r0 = wave * 8; r0 < nact; r0 += 32) {
+            double acc[8];
+            uint32_t mm[8], last[8];
+            uint32_t lmax = 0;
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
+            for (int k = 0; k < 8; k++) {
+                acc[k] = 0.0;
                 mm[k] = row_m[r0 + k];
                 const uint32_t sat = row_sat[r0 + k];
                 last[k] = sat == 0 ? 0u : (sat - 1u < n ? sat - 1u : n);
+                lmax = max(lmax, last[k]);
             }
-            const uint32_t lmax = max(max(last[0], last[1]), max(last[2], last[3]));
-            for (uint32_t i = i_lo + lane; i <= lmax; i += 64) {
-                const double P = Pi[i - i_lo];
+            for (uint32_t ib = i_lo; ib <= lmax; ib += 128) {
+                double rv[2][8], P2[2];
 #pragma unroll
-                for (int k = 0; k < 4; k++)
-                    if (mm[k] != 0 && i <= last[k]) acc[k] += Rt[(size_t)mm[k] * n1 + i] * P;
+                for (int c = 0; c < 2; c++) {
+                    const uint32_t i = ib + c * 64 + lane;
+                    P2[c] = i <= lmax ? Pi[i - i_lo] : 0.0;
+#pragma unroll
+                    for (int k = 0; k < 8; k++) rv[c][k] = (mm[k] != 0 && i <= last[k]) ? Rt[(size_t)mm[k] * n1 + i] : 0.0;
+                }
+#pragma unroll
+                for (int c = 0; c < 2; c++)
+#pragma unroll
+                    for (int k = 0; k < 8; k++) acc[k] = fma(rv[c][k], P2[c], acc[k]);
             }
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
+            for (int k = 0; k < 8; k++) {
                 const double v = wave_sum_f64_dpp(acc[k]);
                 if (lane == 0 && mm[k] != 0) tz[mm[k]] = v;
             }
@@ -258,7 +270,7 @@ __global__ __launch_bounds__(1024) void prob_order_kernel(const uint32_t *__rest
 // ---------------------------------------------------------------------------
 size_t prob_lookup_lds_bytes(uint32_t tmax) {
     const size_t n1max = tmax / 2 + 1;
-    return sizeof(double) * (n1max + 16) + (sizeof(uint32_t) + 3 * sizeof(uint16_t)) * ((size_t)tmax + 10) + 8;
+    return sizeof(double) * (n1max + 16) + (sizeof(uint32_t) + 3 * sizeof(uint16_t)) * ((size_t)tmax + 18) + 8;
 }
 void launch_prob_tables_build(hipStream_t s, const ProbTables &tb, const double *lf, const double *inv) {
     hipLaunchKernelGGL(prob_tables_build_kernel, dim3((tb.tmax + 255) / 256, tb.tmax - 1), dim3(256), 0, s, tb, lf, inv);

@@ -585,82 +585,83 @@ __device__ __forceinline__ uint4 load_counts8(const uint16_t *p) {
     return make_uint4(v.x, v.y, v.z, v.w);
 }
 
-template <int NW>
+template <int NW, bool TZ_LDS>
 __global__ __launch_bounds__(NW * 64) void taxon_prefix_kernel(PrefixParams p) {
     extern __shared__ double tz_lds[];
-    __shared__ double wsum[NW];
+    __shared__ double wsum[2][NW];  // double-buffered: one barrier per sweep
     const uint32_t q = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint64_t gq = p.perm ? p.perm[p.q0 + q] : p.q0 + q;
-    double *P = p.prefix + (size_t)q * p.n_bnd;
+    double *__restrict__ P = p.prefix + (size_t)q * p.n_bnd;
     if (p.status[gq] != RTX_Q_OK) return;
-    const double *tz = p.table_z + (size_t)q * p.hstride;
-    if (p.tz_in_lds) {  // 32 x N random look-ups per query: serve them from LDS
+    const double *__restrict__ tzg = p.table_z + (size_t)q * p.hstride;
+    if (TZ_LDS) {  // 8 random look-ups per reference chunk: serve them from LDS
         const uint32_t t1 = p.t[q] + 1;
-        for (uint32_t m = tid; m < t1; m += NW * 64) tz_lds[m] = tz[m];
-        tz = tz_lds;
+        for (uint32_t m = tid; m < t1; m += NW * 64) tz_lds[m] = tzg[m];
         __syncthreads();
     }
-    const uint16_t *cnt = p.counts + (size_t)q * p.npad;
+    const uint16_t *__restrict__ cnt = p.counts + (size_t)q * p.npad;
     if (tid == 0) P[0] = 0.0;
     double carry = 0.0;
-    const uint64_t n = p.n_refs;
+    const uint32_t n = (uint32_t)p.n_refs;  // references of this handle (< 2^32)
+    constexpr uint32_t kSweep = NW * 512;
     // counts of the next sweep are requested before the current one is scanned (the sweeps are a serial
     // chain through `carry`; without the prefetch every sweep exposes a full HBM round trip)
     uint4 cv_next = make_uint4(0, 0, 0, 0);
     uint32_t bits_next = 0;
-    if ((uint64_t)tid * 8 < n) {
-        cv_next = load_counts8(cnt + (uint64_t)tid * 8);
+    if (tid * 8u < n) {
+        cv_next = load_counts8(cnt + tid * 8u);
         bits_next = p.bnd_bits[tid];
     }
-    for (uint64_t base = 0; base < n; base += NW * 512) {
-        const uint64_t r0 = base + (uint64_t)tid * 8;
+    uint32_t buf = 0;
+    for (uint32_t base = 0; base < n; base += kSweep, buf ^= 1u) {
+        const uint32_t r0 = base + tid * 8u;
         const uint4 cv = cv_next;
         const uint32_t bits_cur = bits_next;
-        const uint64_t rn = r0 + NW * 512;
+        const uint32_t rn = r0 + kSweep;
         if (rn < n) {
             cv_next = load_counts8(cnt + rn);
             bits_next = p.bnd_bits[rn >> 3];
+        } else {  // past the end: count 0 (a valid table index, masked below) and no boundary
+            cv_next = make_uint4(0, 0, 0, 0);
+            bits_next = 0;
+        }
+        const uint32_t cw[4] = {cv.x, cv.y, cv.z, cv.w};
+        double v[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const uint32_t c = (cw[j >> 1] >> ((j & 1) * 16)) & 0xFFFFu;  // lanes past the end hold 0: a valid index
+            v[j] = TZ_LDS ? tz_lds[c] : tzg[c];
+        }
+        if (base + kSweep > n) {  // last sweep (wave-uniform): references past the end contribute nothing
+#pragma unroll
+            for (int j = 0; j < 8; j++) v[j] = (r0 + j < n) ? v[j] : 0.0;
         }
         double s[8];
-        double run = 0.0;
-        if (r0 < n) {
-            const uint32_t cw[4] = {cv.x, cv.y, cv.z, cv.w};
+        s[0] = v[0];
 #pragma unroll
-            for (int j = 0; j < 8; j++) {
-                const uint32_t c = (cw[j >> 1] >> ((j & 1) * 16)) & 0xFFFFu;
-                const double v = (r0 + j < n) ? tz[c] : 0.0;
-                run += v;
-                s[j] = run;
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < 8; j++) s[j] = 0.0;
-        }
+        for (int j = 1; j < 8; j++) s[j] = s[j - 1] + v[j];
+        const double run = s[7];
         const double incl = wave_incl_scan_f64_dpp(run);
-        if (lane == 63) wsum[wave] = incl;
+        if (lane == 63) wsum[buf][wave] = incl;
         __syncthreads();
         double off = carry + (incl - run);
         double tot = 0.0;
 #pragma unroll
         for (int w = 0; w < NW; w++) {
-            const double ws = wsum[w];
+            const double ws = wsum[buf][w];
             if ((uint32_t)w < wave) off += ws;
             tot += ws;
         }
         carry += tot;
-        if (r0 < n) {
-            const uint32_t chunk = (uint32_t)(r0 >> 3);
-            uint32_t bits = bits_cur;
-            if (bits) {
-                uint32_t rank = p.bnd_rank[chunk];
-                while (bits) {
-                    const int j = __ffs((int)bits) - 1;
-                    bits &= bits - 1;
-                    P[rank++] = off + s[j];
-                }
+        uint32_t bits = bits_cur;  // 0 for chunks past the end
+        if (bits) {
+            uint32_t rank = p.bnd_rank[r0 >> 3];
+            while (bits) {
+                const int j = __ffs((int)bits) - 1;
+                bits &= bits - 1;
+                P[rank++] = off + s[j];
             }
         }
-        __syncthreads();
     }
 }
 
@@ -860,7 +861,8 @@ void launch_prob_table(hipStream_t s, const ProbParams &p, uint32_t nq) {
 }
 void launch_taxon_prefix(hipStream_t s, const PrefixParams &p, uint32_t nq) {
     const size_t lds = p.tz_in_lds ? (size_t)p.hstride * sizeof(double) : 0;
-    hipLaunchKernelGGL(taxon_prefix_kernel<4>, dim3(nq), dim3(256), lds, s, p);
+    if (p.tz_in_lds) hipLaunchKernelGGL((taxon_prefix_kernel<4, true>), dim3(nq), dim3(256), lds, s, p);
+    else hipLaunchKernelGGL((taxon_prefix_kernel<4, false>), dim3(nq), dim3(256), lds, s, p);
 }
 void launch_lineage_walk(hipStream_t s, const WalkParams &p, uint32_t nq) {
     hipLaunchKernelGGL(lineage_walk_kernel, dim3(nq), dim3(64), 0, s, p);

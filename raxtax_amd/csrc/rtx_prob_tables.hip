@@ -237,32 +237,29 @@ __global__ __launch_bounds__(256) void prob_lookup_kernel(ProbParams p, ProbTabl
 }
 
 // ---------------------------------------------------------------------------
-// processing order of a sub-batch for prob_lookup: queries sorted by (t, slot), so that concurrently
-// resident workgroups read the same (t) tables out of L2.  One workgroup, bitonic sort of the unique
-// keys t << 16 | slot in LDS (deterministic); nq <= 4096.
+// processing order of a sub-batch for prob_lookup: queries grouped by t (ascending), so that
+// concurrently resident workgroups read the same (t) tables out of L2.  One workgroup: counting sort
+// over t <= 1023 in LDS (histogram, exclusive scan, scatter).  The order inside one t is arbitrary;
+// it only decides which workgroup runs when, never a result.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void prob_order_kernel(const uint32_t *__restrict__ t, uint32_t nq,
                                                           uint32_t *__restrict__ order) {
-    __shared__ uint32_t key[4096];
-    const uint32_t tid = threadIdx.x;
-    uint32_t np2 = 1;
-    while (np2 < nq) np2 <<= 1;
-    for (uint32_t q = tid; q < np2; q += 1024) key[q] = q < nq ? ((t[q] < 65535u ? t[q] : 65535u) << 16) | q : 0xFFFFFFFFu;
+    __shared__ uint32_t bin[1024];
+    __shared__ uint32_t wsum[16];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    bin[tid] = 0;
     __syncthreads();
-    for (uint32_t k = 2; k <= np2; k <<= 1) {
-        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-            for (uint32_t x = tid; x < np2; x += 1024) {
-                const uint32_t y = x ^ j;
-                if (y > x) {
-                    const uint32_t a = key[x], b = key[y];
-                    const bool up = (x & k) == 0;
-                    if ((a > b) == up) { key[x] = b; key[y] = a; }
-                }
-            }
-            __syncthreads();
-        }
-    }
-    for (uint32_t q = tid; q < nq; q += 1024) order[q] = key[q] & 0xFFFFu;
+    for (uint32_t q = tid; q < nq; q += 1024) atomicAdd(&bin[t[q] < 1023u ? t[q] : 1023u], 1u);
+    __syncthreads();
+    const uint32_t v = bin[tid];
+    const uint32_t incl = wave_incl_scan_u32(v);
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    uint32_t off = 0;
+    for (uint32_t w = 0; w < wave; w++) off += wsum[w];
+    bin[tid] = off + incl - v;
+    __syncthreads();
+    for (uint32_t q = tid; q < nq; q += 1024) order[atomicAdd(&bin[t[q] < 1023u ? t[q] : 1023u], 1u)] = q;
 }
 
 // ---------------------------------------------------------------------------

@@ -187,13 +187,21 @@ struct rtx_index {
     } host_res[2];
     uint32_t res_set = 0;
     PinBuf<uint32_t> h_nrows_all, h_n_rows;
-    PinBuf<double> h_z;
+    // streamed download: per sub-batch a snapshot of the arena cursor + an event; rtx_batch_download copies and
+    // finalises finished sub-batches on `copy_stream` while later ones are still running
+    std::vector<hipEvent_t> ev_sub;
+    PinBuf<unsigned long long> h_cursor_sub;
+    hipStream_t copy_stream = nullptr;
+    uint32_t n_sub_run = 0;
+    bool stream_dl = false;
     PinBuf<unsigned long long> h_hq, h_row_start;
     uint32_t stage_timing = 0;  // 0: HIP events around hit_count only; 1: around every kernel
     PinBuf<DevRow> h_arena;
 
     ~rtx_index() {
         for (auto e : events) (void)hipEventDestroy(e);
+        for (auto e : ev_sub) (void)hipEventDestroy(e);
+        if (copy_stream) (void)hipStreamDestroy(copy_stream);
         if (ev_fork) (void)hipEventDestroy(ev_fork);
         if (ev_join) (void)hipEventDestroy(ev_join);
         if (stream2) (void)hipStreamDestroy(stream2);
@@ -394,6 +402,18 @@ int enqueue_batch(rtx_index *ix, uint32_t flags) {
     int rc = begin_run(ix, &n_sub, &timed);
     if (rc) return rc;
     const bool two = ix->n_streams == 2;
+    ix->stream_dl = false;
+    if (!two && n_sub <= 4096) {  // streamed download (see rtx_batch_download)
+        if (!ix->copy_stream) RTX_HIP(hipStreamCreateWithFlags(&ix->copy_stream, hipStreamNonBlocking));
+        while (ix->ev_sub.size() < n_sub) {
+            hipEvent_t e;
+            RTX_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            ix->ev_sub.push_back(e);
+        }
+        if ((rc = ix->h_cursor_sub.resize(n_sub))) return rc;
+        ix->n_sub_run = n_sub;
+        ix->stream_dl = true;
+    }
     if (two) {  // the second stream starts after the resets above
         RTX_HIP(hipEventRecord(ix->ev_fork, ix->stream));
         RTX_HIP(hipStreamWaitEvent(ix->stream2, ix->ev_fork, 0));
@@ -403,6 +423,10 @@ int enqueue_batch(rtx_index *ix, uint32_t flags) {
         if ((rc = enqueue_count(ix, b, flags)) || (rc = enqueue_prob_prefix(ix, b)) ||
             (rc = enqueue_walk(ix, b, ix->sc[b.set].d_prefix.p)))
             return rc;
+        if (ix->stream_dl) {
+            RTX_HIP(hipMemcpyAsync(&ix->h_cursor_sub[sb], ix->d_cursor.p, 8, hipMemcpyDeviceToHost, b.s));
+            RTX_HIP(hipEventRecord(ix->ev_sub[sb], b.s));
+        }
     }
     if (two) {  // everything is complete once the main stream is: join the second stream into it
         RTX_HIP(hipEventRecord(ix->ev_join, ix->stream2));
@@ -950,6 +974,77 @@ int rtx_batch_sync(rtx_index *ix) {
     return RTX_OK;
 }
 
+// Finalises queries [qa, qb) on up to nt threads.
+static void finalise_mt(rtx_index *ix, uint64_t qa, uint64_t qb, unsigned nt) {
+    nt = std::min<unsigned>(nt, std::max(1u, std::thread::hardware_concurrency()));
+    if (qb - qa < 1024 || nt <= 1) { finalise_range(ix, qa, qb); return; }
+    std::vector<std::thread> th;
+    for (unsigned i = 0; i < nt; i++) th.emplace_back(finalise_range, ix, qa + (qb - qa) * i / nt, qa + (qb - qa) * (i + 1) / nt);
+    for (auto &t : th) t.join();
+}
+
+static int size_host_results(rtx_index *ix, rtx_index::HostRes &hr, uint64_t nq, uint64_t arena_rows) {
+    int rc;
+    if ((rc = hr.h_status.resize(nq)) || (rc = hr.h_t.resize(nq)) || (rc = ix->h_n_rows.resize(nq)) || (rc = hr.h_gs.resize(nq)) ||
+        (rc = ix->h_row_start.resize(nq)) || (rc = ix->h_arena.resize(arena_rows ? arena_rows : 1)))
+        return rc;
+    hr.v_row_off.resize(nq + 1);
+    hr.v_row_off[0] = 0;
+    return RTX_OK;
+}
+
+static void size_host_rows(rtx_index::HostRes &hr, uint64_t nrows) {
+    hr.v_row_lineage.resize(nrows);
+    hr.v_row_node.resize(nrows);
+    hr.v_row_depth.resize(nrows);
+    hr.v_row_local.resize(nrows);
+    hr.v_row_conf.resize(nrows * RTX_MAX_DEPTH);
+}
+
+// D2H of the per-query records of queries [q0, q0+n) and of arena rows [r0, r1) on stream cs (asynchronous)
+static int copy_results(rtx_index *ix, rtx_index::HostRes &hr, uint64_t q0, uint64_t n, uint64_t r0, uint64_t r1, hipStream_t cs) {
+    RTX_HIP(hipMemcpyAsync(hr.h_status.data() + q0, ix->d_status.p + q0, n, hipMemcpyDeviceToHost, cs));
+    RTX_HIP(hipMemcpyAsync(hr.h_t.data() + q0, ix->d_t_all.p + q0, n * 4, hipMemcpyDeviceToHost, cs));
+    RTX_HIP(hipMemcpyAsync(ix->h_n_rows.data() + q0, ix->d_n_rows.p + q0, n * 4, hipMemcpyDeviceToHost, cs));
+    RTX_HIP(hipMemcpyAsync(hr.h_gs.data() + q0, ix->d_gs.p + q0, n * 8, hipMemcpyDeviceToHost, cs));
+    RTX_HIP(hipMemcpyAsync(ix->h_row_start.data() + q0, ix->d_row_start.p + q0, n * 8, hipMemcpyDeviceToHost, cs));
+    if (r1 > r0) RTX_HIP(hipMemcpyAsync(ix->h_arena.data() + r0, ix->d_arena.p + r0, (r1 - r0) * sizeof(DevRow), hipMemcpyDeviceToHost, cs));
+    return RTX_OK;
+}
+
+// Streamed download: while later sub-batches are still running, the records of every finished one are copied
+// (copy_stream) and finalised on the calling thread, so that only the last sub-batch is left once the device is
+// done.  *done = false: not applicable (batch already complete: the bulk path with its thread pool is faster)
+// or the arena overflowed (the bulk path repeats the run).
+static int download_streamed(rtx_index *ix, rtx_index::HostRes &hr, bool *done) {
+    *done = false;
+    const uint32_t n_sub = ix->n_sub_run;
+    if (!ix->stream_dl || n_sub < 2 || hipEventQuery(ix->ev_sub[n_sub - 1]) == hipSuccess) return RTX_OK;
+    const uint64_t nq = ix->n_q;
+    int rc = size_host_results(ix, hr, nq, ix->arena_cap);
+    if (rc) return rc;
+    uint64_t prev = 0;
+    for (uint32_t sb = 0; sb < n_sub; sb++) {
+        RTX_HIP(hipEventSynchronize(ix->ev_sub[sb]));
+        const uint64_t cur = ix->h_cursor_sub[sb];
+        if (cur > ix->arena_cap) return RTX_OK;  // overflow: bulk path
+        const uint64_t q0 = (uint64_t)sb * ix->sub_batch, n = std::min<uint64_t>(ix->sub_batch, nq - q0);
+        if ((rc = copy_results(ix, hr, q0, n, prev, cur, ix->copy_stream))) return rc;
+        RTX_HIP(hipStreamSynchronize(ix->copy_stream));
+        for (uint64_t q = q0; q < q0 + n; q++) hr.v_row_off[q + 1] = hr.v_row_off[q] + ix->h_n_rows[q];
+        size_host_rows(hr, hr.v_row_off[q0 + n]);
+        finalise_mt(ix, q0, q0 + n, sb + 1 == n_sub ? 8 : 1);
+        prev = cur;
+    }
+    RTX_HIP(hipStreamSynchronize(ix->stream));
+    ix->synced = true;
+    uint32_t flags = 0;
+    RTX_HIP(hipMemcpy(&flags, ix->d_flags.p, 4, hipMemcpyDeviceToHost));
+    if (flags & 2u) { set_error("lineage walk exceeded its row/depth bounds (internal error)"); return RTX_ERR_HIP; }
+    *done = !(flags & 1u);
+    return RTX_OK;
+}
+
 int rtx_batch_download(rtx_index *ix, rtx_result_view *out) {
     int rc = bind(ix);
     if (rc) return rc;
@@ -957,63 +1052,37 @@ int rtx_batch_download(rtx_index *ix, rtx_result_view *out) {
     const uint64_t nq = ix->n_q;
     ix->res_set ^= 1u;
     rtx_index::HostRes &hr = ix->host_res[ix->res_set];
-    unsigned long long cursor = 0;
-    for (int attempt = 0;; attempt++) {
-        RTX_HIP(hipStreamSynchronize(ix->stream));
-        ix->synced = true;
-        uint32_t flags = 0;
-        RTX_HIP(hipMemcpy(&flags, ix->d_flags.p, 4, hipMemcpyDeviceToHost));
-        RTX_HIP(hipMemcpy(&cursor, ix->d_cursor.p, 8, hipMemcpyDeviceToHost));
-        if (flags & 2u) { set_error("lineage walk exceeded its row/depth bounds (internal error)"); return RTX_ERR_HIP; }
-        if (!(flags & 1u)) break;
-        if (attempt >= 2) { set_error("result arena overflow persists"); return RTX_ERR_HIP; }
-        // arena too small: grow to what this run asked for and repeat the (deterministic) run
-        const uint64_t want = cursor + 4096;
-        if ((rc = ix->d_arena.alloc(want))) return rc;
-        ix->arena_cap = want;
-        if (ix->n_refs != ix->n_total) {  // a sharded run is driven by the caller: ask it to repeat
-            set_error("result arena overflow: repeat the sharded run (the arena has been enlarged)");
-            return RTX_ERR_STATE;
+    bool streamed = false;
+    if ((rc = download_streamed(ix, hr, &streamed))) return rc;
+    if (!streamed) {
+        unsigned long long cursor = 0;
+        for (int attempt = 0;; attempt++) {
+            RTX_HIP(hipStreamSynchronize(ix->stream));
+            ix->synced = true;
+            uint32_t flags = 0;
+            RTX_HIP(hipMemcpy(&flags, ix->d_flags.p, 4, hipMemcpyDeviceToHost));
+            RTX_HIP(hipMemcpy(&cursor, ix->d_cursor.p, 8, hipMemcpyDeviceToHost));
+            if (flags & 2u) { set_error("lineage walk exceeded its row/depth bounds (internal error)"); return RTX_ERR_HIP; }
+            if (!(flags & 1u)) break;
+            if (attempt >= 2) { set_error("result arena overflow persists"); return RTX_ERR_HIP; }
+            // arena too small: grow to what this run asked for and repeat the (deterministic) run
+            const uint64_t want = cursor + 4096;
+            if ((rc = ix->d_arena.alloc(want))) return rc;
+            ix->arena_cap = want;
+            if (ix->n_refs != ix->n_total) {  // a sharded run is driven by the caller: ask it to repeat
+                set_error("result arena overflow: repeat the sharded run (the arena has been enlarged)");
+                return RTX_ERR_STATE;
+            }
+            if ((rc = enqueue_batch(ix, ix->last_flags))) return rc;
         }
-        if ((rc = enqueue_batch(ix, ix->last_flags))) return rc;
-    }
-    if ((rc = hr.h_status.resize(nq)) || (rc = hr.h_t.resize(nq)) || (rc = ix->h_nrows_all.resize(nq)) ||
-        (rc = ix->h_n_rows.resize(nq)) || (rc = hr.h_gs.resize(nq)) || (rc = ix->h_z.resize(nq)) ||
-        (rc = ix->h_hq.resize(nq)) || (rc = ix->h_row_start.resize(nq)) || (rc = ix->h_arena.resize(cursor ? cursor : 1)))
-        return rc;
-    hipStream_t cs = ix->stream;
-    RTX_HIP(hipMemcpyAsync(hr.h_status.data(), ix->d_status.p, nq, hipMemcpyDeviceToHost, cs));
-    RTX_HIP(hipMemcpyAsync(hr.h_t.data(), ix->d_t_all.p, nq * 4, hipMemcpyDeviceToHost, cs));
-    RTX_HIP(hipMemcpyAsync(ix->h_nrows_all.data(), ix->d_nrows_all.p, nq * 4, hipMemcpyDeviceToHost, cs));
-    RTX_HIP(hipMemcpyAsync(ix->h_n_rows.data(), ix->d_n_rows.p, nq * 4, hipMemcpyDeviceToHost, cs));
-    RTX_HIP(hipMemcpyAsync(hr.h_gs.data(), ix->d_gs.p, nq * 8, hipMemcpyDeviceToHost, cs));
-    RTX_HIP(hipMemcpyAsync(ix->h_z.data(), ix->d_z.p, nq * 8, hipMemcpyDeviceToHost, cs));
-    RTX_HIP(hipMemcpyAsync(ix->h_hq.data(), ix->d_hq.p, nq * 8, hipMemcpyDeviceToHost, cs));
-    RTX_HIP(hipMemcpyAsync(ix->h_row_start.data(), ix->d_row_start.p, nq * 8, hipMemcpyDeviceToHost, cs));
-    if (cursor) RTX_HIP(hipMemcpyAsync(ix->h_arena.data(), ix->d_arena.p, cursor * sizeof(DevRow), hipMemcpyDeviceToHost, cs));
-    RTX_HIP(hipStreamSynchronize(cs));
-
-    hr.v_row_off.resize(nq + 1);
-    hr.v_row_off[0] = 0;
-    for (uint64_t q = 0; q < nq; q++) hr.v_row_off[q + 1] = hr.v_row_off[q] + ix->h_n_rows[q];
-    const uint64_t nrows = hr.v_row_off[nq];
-    hr.v_row_lineage.resize(nrows);
-    hr.v_row_node.resize(nrows);
-    hr.v_row_depth.resize(nrows);
-    hr.v_row_local.resize(nrows);
-    hr.v_row_conf.resize(nrows * RTX_MAX_DEPTH);
-    unsigned nt = std::min<unsigned>(8, std::max(1u, std::thread::hardware_concurrency()));
-    if (nq < 4096) nt = 1;
-    if (nt == 1) {
-        finalise_range(ix, 0, nq);
-    } else {
-        std::vector<std::thread> th;
-        for (unsigned i = 0; i < nt; i++)
-            th.emplace_back(finalise_range, ix, nq * i / nt, nq * (i + 1) / nt);
-        for (auto &t : th) t.join();
+        if ((rc = size_host_results(ix, hr, nq, cursor)) || (rc = copy_results(ix, hr, 0, nq, 0, cursor, ix->stream))) return rc;
+        RTX_HIP(hipStreamSynchronize(ix->stream));
+        for (uint64_t q = 0; q < nq; q++) hr.v_row_off[q + 1] = hr.v_row_off[q] + ix->h_n_rows[q];
+        size_host_rows(hr, hr.v_row_off[nq]);
+        finalise_mt(ix, 0, nq, nq < 4096 ? 1 : 8);
     }
     out->n_queries = (uint32_t)nq;
-    out->n_rows = nrows;
+    out->n_rows = hr.v_row_off[nq];
     out->t = hr.h_t.data();
     out->status = hr.h_status.data();
     out->global_signal = hr.h_gs.data();
@@ -1135,7 +1204,13 @@ int rtx_batch_stage_times(rtx_index *ix, float ms[RTX_NUM_STAGES], uint32_t laun
 
 int rtx_batch_work(rtx_index *ix, uint64_t *sum_hits, uint64_t *sum_query_bytes, uint64_t *bitmap_bytes_read) {
     if (!ix) { set_error("null index handle"); return RTX_ERR_INVALID; }
-    if (ix->h_hq.size() != ix->n_q) { set_error("rtx_batch_work: call rtx_batch_download first"); return RTX_ERR_STATE; }
+    int rc = bind(ix);
+    if (rc) return rc;
+    if (!ix->ran) { set_error("rtx_batch_work before rtx_batch_run"); return RTX_ERR_STATE; }
+    if ((rc = ix->h_hq.resize(ix->n_q)) || (rc = ix->h_nrows_all.resize(ix->n_q))) return rc;
+    RTX_HIP(hipStreamSynchronize(ix->stream));
+    RTX_HIP(hipMemcpy(ix->h_hq.data(), ix->d_hq.p, ix->n_q * 8, hipMemcpyDeviceToHost));
+    RTX_HIP(hipMemcpy(ix->h_nrows_all.data(), ix->d_nrows_all.p, ix->n_q * 4, hipMemcpyDeviceToHost));
     uint64_t h = 0, b = 0;
     const uint64_t row_bytes = (ix->n_refs + 7) / 8;
     for (uint64_t q = 0; q < ix->n_q; q++) {

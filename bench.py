@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--queries", type=int, default=100_000, help="queries per GPU per step")
     ap.add_argument("--sub-batch", type=int, default=0, help="queries per kernel wave (0 = auto)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample")
+    ap.add_argument("--streams", type=int, default=0, help="HIP streams per handle (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--skip-exact-matches", action="store_true")
     ap.add_argument("--stage-times", action="store_true",
@@ -184,7 +185,7 @@ def main():
     flags = rx.RTX_SKIP_EXACT_MATCHES if args.skip_exact_matches else 0
     if args.shard_db:
         return bench_sharded_db(args, rx, synth, db, tree, dist, rank, local_rank, world, flags)
-    index = rx.Index(tree, device=local_rank, sub_batch=args.sub_batch, stage_timing=args.stage_times)
+    index = rx.Index(tree, device=local_rank, sub_batch=args.sub_batch, streams=args.streams, stage_timing=args.stage_times)
     ex_ids, ex_off = index.exact_matches(qs.bases, qs.base_off)   # Tree.sequences.get, raxtax.rs:42 (host)
     index.upload(qs.bases, qs.base_off, ex_ids, ex_off)            # inputs resident in HBM from here on
 

@@ -189,7 +189,7 @@ struct rtx_index {
     PinBuf<uint32_t> h_nrows_all, h_n_rows;
     // streamed download: per sub-batch a snapshot of the arena cursor + an event; rtx_batch_download copies and
     // finalises finished sub-batches on `copy_stream` while later ones are still running
-    std::vector<hipEvent_t> ev_sub;
+    std::vector<hipEvent_t> ev_sub, ev_cnt;
     PinBuf<unsigned long long> h_cursor_sub;
     hipStream_t copy_stream = nullptr;
     uint32_t n_sub_run = 0;
@@ -201,6 +201,7 @@ struct rtx_index {
     ~rtx_index() {
         for (auto e : events) (void)hipEventDestroy(e);
         for (auto e : ev_sub) (void)hipEventDestroy(e);
+        for (auto e : ev_cnt) (void)hipEventDestroy(e);
         if (copy_stream) (void)hipStreamDestroy(copy_stream);
         if (ev_fork) (void)hipEventDestroy(ev_fork);
         if (ev_join) (void)hipEventDestroy(ev_join);
@@ -231,7 +232,8 @@ int ensure_events(rtx_index *ix, size_t count) {
 struct SubBatch {
     uint32_t sb, nq, set;
     uint64_t q0;
-    hipStream_t s;
+    hipStream_t s;   // kmer_extract + hit_count
+    hipStream_t s2;  // prob, taxon_prefix, lineage_walk (a stream of its own with RTX_OPT_STREAMS = 2)
     bool timed;      // HIP events around hit_count (the roofline kernel)
     bool timed_all;  // ... and around every other kernel (RTX_OPT_STAGE_TIMING)
 };
@@ -242,7 +244,8 @@ SubBatch sub_batch_of(rtx_index *ix, uint32_t sb, bool timed) {
     b.q0 = (uint64_t)sb * ix->sub_batch;
     b.nq = (uint32_t)std::min<uint64_t>(ix->sub_batch, ix->n_q - b.q0);
     b.set = ix->n_streams == 2 ? (sb & 1u) : 0u;
-    b.s = b.set ? ix->stream2 : ix->stream;
+    b.s = ix->stream;
+    b.s2 = ix->n_streams == 2 ? ix->stream2 : ix->stream;
     b.timed = timed;
     b.timed_all = timed && ix->stage_timing != 0;
     return b;
@@ -305,7 +308,7 @@ int enqueue_count(rtx_index *ix, const SubBatch &b, uint32_t flags) {
 // group 2: prob table from the (whole-database) histogram + prefix sums over this handle's references
 int enqueue_prob_prefix(rtx_index *ix, const SubBatch &b) {
     rtx_index::Scratch &sc = ix->sc[b.set];
-    hipStream_t s = b.s;
+    hipStream_t s = b.s2;
     ProbParams pp{};
     pp.t = sc.d_t.p;
     pp.hist = sc.d_hist.p;
@@ -353,7 +356,7 @@ int enqueue_prob_prefix(rtx_index *ix, const SubBatch &b) {
 
 // group 3: taxonomy walk over prefix sums covering the WHOLE database ([nq][n_bnd], device)
 int enqueue_walk(rtx_index *ix, const SubBatch &b, const double *prefix) {
-    hipStream_t s = b.s;
+    hipStream_t s = b.s2;
     WalkParams wp{};
     wp.status = ix->d_status.p;
     wp.q0 = b.q0;
@@ -401,18 +404,25 @@ int enqueue_batch(rtx_index *ix, uint32_t flags) {
     bool timed = false;
     int rc = begin_run(ix, &n_sub, &timed);
     if (rc) return rc;
+    // Two streams (RTX_OPT_STREAMS = 2): hit_count of sub-batch i+1 (bound by the row-load rate) runs beside the
+    // prob/prefix/walk kernels of sub-batch i (f64 VALU, LDS); the two scratch sets alternate.
     const bool two = ix->n_streams == 2;
     ix->stream_dl = false;
-    if (!two && n_sub <= 4096) {  // streamed download (see rtx_batch_download)
+    if (n_sub <= 4096) {  // per sub-batch: completion event (+ cursor snapshot) for the streamed download
         if (!ix->copy_stream) RTX_HIP(hipStreamCreateWithFlags(&ix->copy_stream, hipStreamNonBlocking));
-        while (ix->ev_sub.size() < n_sub) {
-            hipEvent_t e;
+        while (ix->ev_sub.size() < n_sub || ix->ev_cnt.size() < n_sub) {
+            hipEvent_t e, e2;
             RTX_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
             ix->ev_sub.push_back(e);
+            RTX_HIP(hipEventCreateWithFlags(&e2, hipEventDisableTiming));
+            ix->ev_cnt.push_back(e2);
         }
         if ((rc = ix->h_cursor_sub.resize(n_sub))) return rc;
         ix->n_sub_run = n_sub;
         ix->stream_dl = true;
+    } else if (two) {
+        set_error("two streams need at most 4096 sub-batches");
+        return RTX_ERR_INVALID;
     }
     if (two) {  // the second stream starts after the resets above
         RTX_HIP(hipEventRecord(ix->ev_fork, ix->stream));
@@ -420,12 +430,16 @@ int enqueue_batch(rtx_index *ix, uint32_t flags) {
     }
     for (uint32_t sb = 0; sb < n_sub; sb++) {
         const SubBatch b = sub_batch_of(ix, sb, timed);
-        if ((rc = enqueue_count(ix, b, flags)) || (rc = enqueue_prob_prefix(ix, b)) ||
-            (rc = enqueue_walk(ix, b, ix->sc[b.set].d_prefix.p)))
-            return rc;
+        if (two && sb >= 2) RTX_HIP(hipStreamWaitEvent(b.s, ix->ev_sub[sb - 2], 0));  // scratch set free again
+        if ((rc = enqueue_count(ix, b, flags))) return rc;
+        if (two) {
+            RTX_HIP(hipEventRecord(ix->ev_cnt[sb], b.s));
+            RTX_HIP(hipStreamWaitEvent(b.s2, ix->ev_cnt[sb], 0));
+        }
+        if ((rc = enqueue_prob_prefix(ix, b)) || (rc = enqueue_walk(ix, b, ix->sc[b.set].d_prefix.p))) return rc;
         if (ix->stream_dl) {
-            RTX_HIP(hipMemcpyAsync(&ix->h_cursor_sub[sb], ix->d_cursor.p, 8, hipMemcpyDeviceToHost, b.s));
-            RTX_HIP(hipEventRecord(ix->ev_sub[sb], b.s));
+            RTX_HIP(hipMemcpyAsync(&ix->h_cursor_sub[sb], ix->d_cursor.p, 8, hipMemcpyDeviceToHost, b.s2));
+            RTX_HIP(hipEventRecord(ix->ev_sub[sb], b.s2));
         }
     }
     if (two) {  // everything is complete once the main stream is: join the second stream into it

@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--sub-batch", type=int, default=0, help="queries per kernel wave (0 = auto)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample")
     ap.add_argument("--streams", type=int, default=0, help="HIP streams per handle (0 = library default)")
+    ap.add_argument("--no-cluster", action="store_true", help="process the queries in input order (RTX_OPT_CLUSTER = 0)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--skip-exact-matches", action="store_true")
     ap.add_argument("--stage-times", action="store_true",
@@ -185,7 +186,8 @@ def main():
     flags = rx.RTX_SKIP_EXACT_MATCHES if args.skip_exact_matches else 0
     if args.shard_db:
         return bench_sharded_db(args, rx, synth, db, tree, dist, rank, local_rank, world, flags)
-    index = rx.Index(tree, device=local_rank, sub_batch=args.sub_batch, streams=args.streams, stage_timing=args.stage_times)
+    index = rx.Index(tree, device=local_rank, sub_batch=args.sub_batch, streams=args.streams, stage_timing=args.stage_times,
+                     cluster=False if args.no_cluster else None)
     ex_ids, ex_off = index.exact_matches(qs.bases, qs.base_off)   # Tree.sequences.get, raxtax.rs:42 (host)
     index.upload(qs.bases, qs.base_off, ex_ids, ex_off)            # inputs resident in HBM from here on
 
@@ -196,12 +198,14 @@ def main():
             # the only collective: gather the per-rank result records on rank 0 (RCCL over xGMI)
             n_rows = int(view.n_rows)
             rec = dist_util.pack_records(
-                np.ctypeslib.as_array(view.row_off, shape=(args.queries + 1,)),
+                None,
                 np.ctypeslib.as_array(view.row_lineage, shape=(max(n_rows, 1),)),
                 np.ctypeslib.as_array(view.row_depth, shape=(max(n_rows, 1),)),
                 np.ctypeslib.as_array(view.row_conf, shape=(max(n_rows, 1), 32)),
                 np.ctypeslib.as_array(view.row_local_signal, shape=(max(n_rows, 1),)),
-                np.ctypeslib.as_array(view.global_signal, shape=(args.queries,)))
+                np.ctypeslib.as_array(view.global_signal, shape=(args.queries,)),
+                row_begin=np.ctypeslib.as_array(view.row_begin, shape=(args.queries,)),
+                row_count=np.ctypeslib.as_array(view.row_count, shape=(args.queries,)))
             dist_util.gather_records(dist, rec, rank, world, device=coll_device)
         return view
 

@@ -166,8 +166,12 @@ int rtx_index_set_batch(rtx_index *index, uint32_t sub_batch);
 #define RTX_OPT_PROB_MODE 2
 #define RTX_OPT_STAGE_TIMING 6 /* 0 (default): HIP events around hit_count only; 1: around every kernel
                                  (rtx_batch_stage_times then reports all stages; adds ~1 ms per 100k queries) */
-#define RTX_OPT_STREAMS 3 /* 1 (default) = one HIP stream; 2 = consecutive sub-batches alternate between two streams
-                             (measured slower on MI355X: the kernels contend for L2) */
+#define RTX_OPT_STREAMS 3 /* 1 (default) = one HIP stream; 2 = hit_count of sub-batch i+1 on one stream beside
+                             prob/prefix/walk of sub-batch i on another (measured slower on MI355X: hit_count
+                             loses its L2 hit rate) */
+#define RTX_OPT_CLUSTER 7 /* 1 (default): the queries of a batch are processed in an order that puts related
+                             queries next to each other (min-hash sketches, rtx_cluster.hip) so that bitmap rows
+                             are reused; 0: input order.  Results are identical and always in input order. */
 int rtx_index_set_option(rtx_index *index, int option, uint64_t value);
 
 /* ------------------------------------------------------------------------- */
@@ -183,7 +187,8 @@ typedef struct {
     const uint32_t *t;             /* [n_queries] distinct valid 8-mers (k_mers.len(), raxtax.rs:55) */
     const uint8_t *status;         /* [n_queries] RTX_Q_*                                            */
     const double *global_signal;   /* [n_queries] lineage.rs:86-90                                   */
-    const uint64_t *row_off;       /* [n_queries+1] rows of query q = row_off[q] .. row_off[q+1]     */
+    const uint64_t *row_begin;     /* [n_queries] rows of query q = row_begin[q] .. row_begin[q] + row_count[q]; */
+    const uint32_t *row_count;     /* [n_queries] the rows are stored in processing order, not in query order    */
     const uint32_t *row_lineage;   /* [n_rows] index into tree.lineages (lineage.rs:105)             */
     const uint32_t *row_node;      /* [n_rows] node id (rtx_nodes_view numbering)                    */
     const uint32_t *row_depth;     /* [n_rows] number of confidence values                           */

@@ -175,7 +175,8 @@ class EvaluationResult:
 
 
 class Result:
-    """Arrays of one classified batch (copied out of the library-owned rtx_result_view)."""
+    """Arrays of one classified batch, copied out of the library-owned rtx_result_view and put into query
+    order (the library stores the rows in processing order): rows of query q = row_off[q] .. row_off[q+1]."""
 
     def __init__(self, view: ResultView):
         nq, nr = view.n_queries, view.n_rows
@@ -184,13 +185,19 @@ class Result:
         self.t = arr(view.t, nq)
         self.status = arr(view.status, nq)
         self.global_signal = arr(view.global_signal, nq)
-        self.row_off = arr(view.row_off, nq + 1)
-        self.row_lineage = arr(view.row_lineage, nr)
-        self.row_node = arr(view.row_node, nr)
-        self.row_depth = arr(view.row_depth, nr)
-        self.row_conf = (np.ctypeslib.as_array(view.row_conf, shape=(nr, RTX_MAX_DEPTH)).copy() if nr
+        begin = arr(view.row_begin, nq).astype(np.int64)
+        count = arr(view.row_count, nq).astype(np.int64)
+        self.row_off = np.zeros(nq + 1, dtype=np.uint64)
+        self.row_off[1:] = np.cumsum(count)
+        # source row of every canonical row
+        src = (np.repeat(begin - self.row_off[:-1].astype(np.int64), count) + np.arange(int(count.sum()))) if nq else np.zeros(0, np.int64)
+        assert len(src) == nr
+        self.row_lineage = arr(view.row_lineage, nr)[src]
+        self.row_node = arr(view.row_node, nr)[src]
+        self.row_depth = arr(view.row_depth, nr)[src]
+        self.row_conf = (np.ctypeslib.as_array(view.row_conf, shape=(nr, RTX_MAX_DEPTH))[src] if nr
                          else np.zeros((0, RTX_MAX_DEPTH)))
-        self.row_local_signal = arr(view.row_local_signal, nr)
+        self.row_local_signal = arr(view.row_local_signal, nr)[src]
 
     def rows(self, q: int) -> List[EvaluationResult]:
         out = []
@@ -206,10 +213,9 @@ class Index:
     """Device-resident index + batch workspace of one GPU (rtx_index)."""
 
     def __init__(self, tree: Tree, device: int = 0, sub_batch: int = 0, prob_mode: int = 0, streams: int = 0,
-                 stage_timing: bool = False):
+                 stage_timing: bool = False, cluster: Optional[bool] = None):
         self._lib = _lib.load()
         self.tree = tree
-        # creation-time knobs are process-wide defaults of the library
         h = C.c_void_p()
         check(self._lib.rtx_index_create_from_tree(device, tree._h, C.byref(h)))
         self._h = h
@@ -222,6 +228,8 @@ class Index:
             check(self._lib.rtx_index_set_option(self._h, 3, streams))
         if stage_timing:
             check(self._lib.rtx_index_set_option(self._h, 6, 1))
+        if cluster is not None:
+            check(self._lib.rtx_index_set_option(self._h, 7, int(cluster)))
         self._view = ResultView()
         self._keep = None
 

@@ -42,7 +42,7 @@ extern "C" int64_t rtx_format_query(const rtx_tree *tree, const rtx_result_view 
         rtx::set_error("rtx_format_query: invalid argument");
         return RTX_ERR_INVALID;
     }
-    uint64_t r0 = res->row_off[q], r1 = res->row_off[q + 1];
+    uint64_t r0 = res->row_begin[q], r1 = r0 + res->row_count[q];
     if (r1 == r0) {  // assert!(!eval_res.is_empty()), raxtax.rs:72
         rtx::set_error("query %llu has no result rows (status %u)", (unsigned long long)q, res->status[q]);
         return RTX_ERR_INVALID;

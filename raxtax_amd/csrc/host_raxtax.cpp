@@ -127,7 +127,7 @@ int run(rtx_index *index, const rtx_tree *tree, uint64_t n_queries, const char *
                     const uint64_t q = ch.q0 + i;
                     if (ch.res.status[i] != RTX_Q_OK) continue;
                     const uint64_t len = base_off[q + 1] - base_off[q];
-                    const uint64_t rows = ch.res.row_off[i + 1] - ch.res.row_off[i];
+                    const uint64_t rows = ch.res.row_count[i];
                     const size_t need = (rows + 1) * (strlen(labels[q]) + 4096 + 8 * RTX_MAX_DEPTH) + len + 64;
                     if (out_buf.size() < need) out_buf.resize(need);
                     if (tsv && tsv_buf.size() < need + rows * len) tsv_buf.resize(need + rows * len);

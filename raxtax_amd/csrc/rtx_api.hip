@@ -146,6 +146,12 @@ struct rtx_index {
     uint64_t n_q = 0;
     bool uploaded = false, ran = false, synced = false;
     uint32_t last_flags = 0;
+    // ---- processing order of the batch (rtx_cluster.hip): perm[position] = query, inv[query] = position
+    uint32_t cluster = 1;  // RTX_OPT_CLUSTER
+    DevBuf<uint64_t> d_skey_in, d_skey_out;
+    DevBuf<uint32_t> d_sidx, d_perm, d_iperm;
+    DevBuf<uint8_t> d_sort_tmp;
+    PinBuf<uint32_t> h_perm, h_inv;
     DevBuf<uint8_t> d_bases;
     DevBuf<uint64_t> d_base_off, d_exact_off;
     DevBuf<uint32_t> d_exact_ids;
@@ -179,12 +185,17 @@ struct rtx_index {
     // two alternating sets: the view of download c stays valid while batch c+1 runs and is downloaded
     struct HostRes {
         std::vector<uint32_t> v_row_lineage, v_row_node, v_row_depth;
-        PinBuf<uint32_t> h_t;
-        PinBuf<uint8_t> h_status;
+        std::vector<uint32_t> h_t;
+        std::vector<uint8_t> h_status;
         std::vector<double> v_row_conf, v_row_local;
-        PinBuf<double> h_gs;
-        std::vector<uint64_t> v_row_off;
+        std::vector<double> h_gs;
+        std::vector<uint64_t> v_row_begin;  // by query; the rows themselves are in processing order
+        std::vector<uint32_t> v_row_count;
     } host_res[2];
+    // D2H staging of the per-query records, indexed by position in the processing order
+    PinBuf<uint32_t> hs_t;
+    PinBuf<uint8_t> hs_status;
+    PinBuf<double> hs_gs;
     uint32_t res_set = 0;
     PinBuf<uint32_t> h_nrows_all, h_n_rows;
     // streamed download: per sub-batch a snapshot of the arena cursor + an event; rtx_batch_download copies and
@@ -264,6 +275,7 @@ int enqueue_count(rtx_index *ix, const SubBatch &b, uint32_t flags) {
     kp.bases = ix->d_bases.p;
     kp.base_off = ix->d_base_off.p;
     kp.q0 = b.q0;
+    kp.perm = ix->d_perm.p;
     kp.row_of = ix->d_row_of.p;
     kp.list_len = ix->d_list_len.p;
     kp.zero_row = ix->n_rows;
@@ -297,6 +309,7 @@ int enqueue_count(rtx_index *ix, const SubBatch &b, uint32_t flags) {
     hp.hstride = ix->hstride;
     hp.flags = flags;
     hp.q0 = b.q0;
+    hp.perm = ix->d_perm.p;
     hp.exact_ids = ix->d_exact_ids.p;
     hp.exact_off = ix->d_exact_off.p;
     if (b.timed) RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_HIT_COUNT, 0), s));
@@ -379,7 +392,38 @@ int enqueue_walk(rtx_index *ix, const SubBatch &b, const double *prefix) {
     return RTX_OK;
 }
 
-int begin_run(rtx_index *ix, uint32_t *n_sub_out, bool *timed_out) {
+// Processing order of the uploaded batch: related queries next to each other (rtx_cluster.hip), or input order.
+int order_batch(rtx_index *ix, bool cluster) {
+    const uint32_t n = (uint32_t)ix->n_q;
+    int rc;
+    if ((rc = ix->d_perm.alloc(n)) || (rc = ix->d_iperm.alloc(n)) || (rc = ix->h_perm.resize(n)) || (rc = ix->h_inv.resize(n))) return rc;
+    if (cluster && n > 2) {
+        if ((rc = ix->d_skey_in.alloc(n)) || (rc = ix->d_skey_out.alloc(n)) || (rc = ix->d_sidx.alloc(n))) return rc;
+        size_t tmp = 0;
+        if (cluster_sort(ix->stream, nullptr, &tmp, ix->d_skey_in.p, ix->d_skey_out.p, ix->d_sidx.p, ix->d_perm.p, n)) {
+            set_error("radix sort: size query failed");
+            return RTX_ERR_HIP;
+        }
+        if (ix->d_sort_tmp.n < tmp && (rc = ix->d_sort_tmp.alloc(tmp + 256))) return rc;
+        launch_sketch(ix->stream, ix->d_bases.p, ix->d_base_off.p, n, ix->d_skey_in.p, ix->d_sidx.p);
+        tmp = ix->d_sort_tmp.n;
+        if (cluster_sort(ix->stream, ix->d_sort_tmp.p, &tmp, ix->d_skey_in.p, ix->d_skey_out.p, ix->d_sidx.p, ix->d_perm.p, n)) {
+            set_error("radix sort of the query sketches failed");
+            return RTX_ERR_HIP;
+        }
+        launch_invert_perm(ix->stream, ix->d_perm.p, n, ix->d_iperm.p);
+    } else {
+        launch_identity_perm(ix->stream, n, ix->d_perm.p, ix->d_iperm.p);
+    }
+    RTX_HIP(hipGetLastError());
+    RTX_HIP(hipMemcpyAsync(ix->h_perm.data(), ix->d_perm.p, (size_t)n * 4, hipMemcpyDeviceToHost, ix->stream));
+    RTX_HIP(hipMemcpyAsync(ix->h_inv.data(), ix->d_iperm.p, (size_t)n * 4, hipMemcpyDeviceToHost, ix->stream));
+    return RTX_OK;
+}
+
+int begin_run(rtx_index *ix, uint32_t *n_sub_out, bool *timed_out, bool cluster) {
+    int rc_o = order_batch(ix, cluster);
+    if (rc_o) return rc_o;
     RTX_HIP(hipMemsetAsync(ix->d_cursor.p, 0, sizeof(unsigned long long), ix->stream));
     RTX_HIP(hipMemsetAsync(ix->d_flags.p, 0, sizeof(uint32_t), ix->stream));
     const uint32_t n_sub = (uint32_t)((ix->n_q + ix->sub_batch - 1) / ix->sub_batch);
@@ -402,7 +446,7 @@ int enqueue_batch(rtx_index *ix, uint32_t flags) {
     }
     uint32_t n_sub = 0;
     bool timed = false;
-    int rc = begin_run(ix, &n_sub, &timed);
+    int rc = begin_run(ix, &n_sub, &timed, ix->cluster != 0);
     if (rc) return rc;
     // Two streams (RTX_OPT_STREAMS = 2): hit_count of sub-batch i+1 (bound by the row-load rate) runs beside the
     // prob/prefix/walk kernels of sub-batch i (f64 VALU, LDS); the two scratch sets alternate.
@@ -580,15 +624,24 @@ double euclidean_distance_l1(const double *a, const double *b, uint32_t n) {  //
     return std::sqrt(s);
 }
 
-void finalise_range(rtx_index *ix, uint64_t qa, uint64_t qb) {
+// Host finalisation of the queries at positions [pa, pb) of the processing order; their rows go to
+// [row_base, ...) of the host row arrays in that order.
+void finalise_range(rtx_index *ix, uint64_t pa, uint64_t pb, uint64_t row_base) {
     rtx_index::HostRes &hr = ix->host_res[ix->res_set];
     const FlatNodes &f = ix->nodes;
     const double N = (double)ix->n_total;
     std::vector<HostRow> rows;
-    for (uint64_t q = qa; q < qb; q++) {
-        const uint32_t nr = ix->h_n_rows[q];
+    uint64_t o = row_base;
+    for (uint64_t pos = pa; pos < pb; pos++) {
+        const uint64_t q = ix->h_perm[pos];  // the device records are in processing order
+        hr.h_t[q] = ix->hs_t[pos];
+        hr.h_status[q] = ix->hs_status[pos];
+        hr.h_gs[q] = ix->hs_gs[pos];
+        const uint32_t nr = ix->h_n_rows[pos];
+        hr.v_row_begin[q] = o;
+        hr.v_row_count[q] = nr;
         rows.resize(nr);
-        const DevRow *src = ix->h_arena.data() + ix->h_row_start[q];
+        const DevRow *src = ix->h_arena.data() + ix->h_row_start[pos];
         for (uint32_t r = 0; r < nr; r++) {
             HostRow &h = rows[r];
             h.node = src[r].node;
@@ -602,7 +655,6 @@ void finalise_range(rtx_index *ix, uint64_t qa, uint64_t qb) {
         }
         // stable, descending (lineage.rs:91-93)
         std::stable_sort(rows.begin(), rows.end(), [](const HostRow &a, const HostRow &b) { return conf_less(b, a); });
-        uint64_t o = hr.v_row_off[q];
         for (uint32_t r = 0; r < nr; r++, o++) {
             const HostRow &h = rows[r];
             hr.v_row_lineage[o] = f.begin[h.node];
@@ -912,6 +964,9 @@ int rtx_index_set_option(rtx_index *index, int option, uint64_t value) {
         case RTX_OPT_STAGE_TIMING:
             index->stage_timing = value ? 1u : 0u;
             return RTX_OK;
+        case RTX_OPT_CLUSTER:
+            index->cluster = value ? 1u : 0u;
+            return RTX_OK;
         case RTX_OPT_PROB_MODE:
             if (value > 2) break;
             index->prob_mode = (int)value;
@@ -988,39 +1043,55 @@ int rtx_batch_sync(rtx_index *ix) {
     return RTX_OK;
 }
 
-// Finalises queries [qa, qb) on up to nt threads.
-static void finalise_mt(rtx_index *ix, uint64_t qa, uint64_t qb, unsigned nt) {
+// Finalises positions [pa, pb) on up to nt threads; returns the number of rows they produced.
+static uint64_t finalise_mt(rtx_index *ix, uint64_t pa, uint64_t pb, uint64_t row_base, unsigned nt) {
     nt = std::min<unsigned>(nt, std::max(1u, std::thread::hardware_concurrency()));
-    if (qb - qa < 1024 || nt <= 1) { finalise_range(ix, qa, qb); return; }
-    std::vector<std::thread> th;
-    for (unsigned i = 0; i < nt; i++) th.emplace_back(finalise_range, ix, qa + (qb - qa) * i / nt, qa + (qb - qa) * (i + 1) / nt);
-    for (auto &t : th) t.join();
+    if (pb - pa < 1024) nt = 1;
+    std::vector<uint64_t> cut(nt + 1), base(nt + 1, row_base);
+    for (unsigned i = 0; i <= nt; i++) cut[i] = pa + (pb - pa) * i / nt;
+    for (unsigned i = 0; i < nt; i++) {
+        uint64_t rows = 0;
+        for (uint64_t pos = cut[i]; pos < cut[i + 1]; pos++) rows += ix->h_n_rows[pos];
+        base[i + 1] = base[i] + rows;
+    }
+    rtx_index::HostRes &hr = ix->host_res[ix->res_set];
+    const uint64_t nrows = base[nt];
+    if (hr.v_row_lineage.size() < nrows) {
+        hr.v_row_lineage.resize(nrows);
+        hr.v_row_node.resize(nrows);
+        hr.v_row_depth.resize(nrows);
+        hr.v_row_local.resize(nrows);
+        hr.v_row_conf.resize(nrows * RTX_MAX_DEPTH);
+    }
+    if (nt == 1) {
+        finalise_range(ix, pa, pb, row_base);
+    } else {
+        std::vector<std::thread> th;
+        for (unsigned i = 0; i < nt; i++) th.emplace_back(finalise_range, ix, cut[i], cut[i + 1], base[i]);
+        for (auto &t : th) t.join();
+    }
+    return nrows - row_base;
 }
 
 static int size_host_results(rtx_index *ix, rtx_index::HostRes &hr, uint64_t nq, uint64_t arena_rows) {
     int rc;
-    if ((rc = hr.h_status.resize(nq)) || (rc = hr.h_t.resize(nq)) || (rc = ix->h_n_rows.resize(nq)) || (rc = hr.h_gs.resize(nq)) ||
+    if ((rc = ix->hs_status.resize(nq)) || (rc = ix->hs_t.resize(nq)) || (rc = ix->h_n_rows.resize(nq)) || (rc = ix->hs_gs.resize(nq)) ||
         (rc = ix->h_row_start.resize(nq)) || (rc = ix->h_arena.resize(arena_rows ? arena_rows : 1)))
         return rc;
-    hr.v_row_off.resize(nq + 1);
-    hr.v_row_off[0] = 0;
+    hr.h_status.resize(nq);
+    hr.h_t.resize(nq);
+    hr.h_gs.resize(nq);
+    hr.v_row_begin.resize(nq);
+    hr.v_row_count.resize(nq);
     return RTX_OK;
 }
 
-static void size_host_rows(rtx_index::HostRes &hr, uint64_t nrows) {
-    hr.v_row_lineage.resize(nrows);
-    hr.v_row_node.resize(nrows);
-    hr.v_row_depth.resize(nrows);
-    hr.v_row_local.resize(nrows);
-    hr.v_row_conf.resize(nrows * RTX_MAX_DEPTH);
-}
-
-// D2H of the per-query records of queries [q0, q0+n) and of arena rows [r0, r1) on stream cs (asynchronous)
-static int copy_results(rtx_index *ix, rtx_index::HostRes &hr, uint64_t q0, uint64_t n, uint64_t r0, uint64_t r1, hipStream_t cs) {
-    RTX_HIP(hipMemcpyAsync(hr.h_status.data() + q0, ix->d_status.p + q0, n, hipMemcpyDeviceToHost, cs));
-    RTX_HIP(hipMemcpyAsync(hr.h_t.data() + q0, ix->d_t_all.p + q0, n * 4, hipMemcpyDeviceToHost, cs));
+// D2H of the per-query records at positions [q0, q0+n) and of arena rows [r0, r1) on stream cs (asynchronous)
+static int copy_results(rtx_index *ix, uint64_t q0, uint64_t n, uint64_t r0, uint64_t r1, hipStream_t cs) {
+    RTX_HIP(hipMemcpyAsync(ix->hs_status.data() + q0, ix->d_status.p + q0, n, hipMemcpyDeviceToHost, cs));
+    RTX_HIP(hipMemcpyAsync(ix->hs_t.data() + q0, ix->d_t_all.p + q0, n * 4, hipMemcpyDeviceToHost, cs));
     RTX_HIP(hipMemcpyAsync(ix->h_n_rows.data() + q0, ix->d_n_rows.p + q0, n * 4, hipMemcpyDeviceToHost, cs));
-    RTX_HIP(hipMemcpyAsync(hr.h_gs.data() + q0, ix->d_gs.p + q0, n * 8, hipMemcpyDeviceToHost, cs));
+    RTX_HIP(hipMemcpyAsync(ix->hs_gs.data() + q0, ix->d_gs.p + q0, n * 8, hipMemcpyDeviceToHost, cs));
     RTX_HIP(hipMemcpyAsync(ix->h_row_start.data() + q0, ix->d_row_start.p + q0, n * 8, hipMemcpyDeviceToHost, cs));
     if (r1 > r0) RTX_HIP(hipMemcpyAsync(ix->h_arena.data() + r0, ix->d_arena.p + r0, (r1 - r0) * sizeof(DevRow), hipMemcpyDeviceToHost, cs));
     return RTX_OK;
@@ -1028,26 +1099,24 @@ static int copy_results(rtx_index *ix, rtx_index::HostRes &hr, uint64_t q0, uint
 
 // Streamed download: while later sub-batches are still running, the records of every finished one are copied
 // (copy_stream) and finalised on the calling thread, so that only the last sub-batch is left once the device is
-// done.  *done = false: not applicable (batch already complete: the bulk path with its thread pool is faster)
-// or the arena overflowed (the bulk path repeats the run).
-static int download_streamed(rtx_index *ix, rtx_index::HostRes &hr, bool *done) {
+// done.  *done = false: not applicable (batch already complete: the bulk path with its threads is faster) or the
+// arena overflowed (the bulk path repeats the run).
+static int download_streamed(rtx_index *ix, rtx_index::HostRes &hr, bool *done, uint64_t *nrows_out) {
     *done = false;
     const uint32_t n_sub = ix->n_sub_run;
     if (!ix->stream_dl || n_sub < 2 || hipEventQuery(ix->ev_sub[n_sub - 1]) == hipSuccess) return RTX_OK;
     const uint64_t nq = ix->n_q;
     int rc = size_host_results(ix, hr, nq, ix->arena_cap);
     if (rc) return rc;
-    uint64_t prev = 0;
+    uint64_t prev = 0, nrows = 0;
     for (uint32_t sb = 0; sb < n_sub; sb++) {
         RTX_HIP(hipEventSynchronize(ix->ev_sub[sb]));
         const uint64_t cur = ix->h_cursor_sub[sb];
         if (cur > ix->arena_cap) return RTX_OK;  // overflow: bulk path
         const uint64_t q0 = (uint64_t)sb * ix->sub_batch, n = std::min<uint64_t>(ix->sub_batch, nq - q0);
-        if ((rc = copy_results(ix, hr, q0, n, prev, cur, ix->copy_stream))) return rc;
+        if ((rc = copy_results(ix, q0, n, prev, cur, ix->copy_stream))) return rc;
         RTX_HIP(hipStreamSynchronize(ix->copy_stream));
-        for (uint64_t q = q0; q < q0 + n; q++) hr.v_row_off[q + 1] = hr.v_row_off[q] + ix->h_n_rows[q];
-        size_host_rows(hr, hr.v_row_off[q0 + n]);
-        finalise_mt(ix, q0, q0 + n, sb + 1 == n_sub ? 8 : 1);
+        nrows += finalise_mt(ix, q0, q0 + n, nrows, sb + 1 == n_sub ? 8 : 1);
         prev = cur;
     }
     RTX_HIP(hipStreamSynchronize(ix->stream));
@@ -1055,7 +1124,9 @@ static int download_streamed(rtx_index *ix, rtx_index::HostRes &hr, bool *done) 
     uint32_t flags = 0;
     RTX_HIP(hipMemcpy(&flags, ix->d_flags.p, 4, hipMemcpyDeviceToHost));
     if (flags & 2u) { set_error("lineage walk exceeded its row/depth bounds (internal error)"); return RTX_ERR_HIP; }
-    *done = !(flags & 1u);
+    if (flags & 1u) return RTX_OK;
+    *nrows_out = nrows;
+    *done = true;
     return RTX_OK;
 }
 
@@ -1067,7 +1138,8 @@ int rtx_batch_download(rtx_index *ix, rtx_result_view *out) {
     ix->res_set ^= 1u;
     rtx_index::HostRes &hr = ix->host_res[ix->res_set];
     bool streamed = false;
-    if ((rc = download_streamed(ix, hr, &streamed))) return rc;
+    uint64_t nrows = 0;
+    if ((rc = download_streamed(ix, hr, &streamed, &nrows))) return rc;
     if (!streamed) {
         unsigned long long cursor = 0;
         for (int attempt = 0;; attempt++) {
@@ -1089,18 +1161,17 @@ int rtx_batch_download(rtx_index *ix, rtx_result_view *out) {
             }
             if ((rc = enqueue_batch(ix, ix->last_flags))) return rc;
         }
-        if ((rc = size_host_results(ix, hr, nq, cursor)) || (rc = copy_results(ix, hr, 0, nq, 0, cursor, ix->stream))) return rc;
+        if ((rc = size_host_results(ix, hr, nq, cursor)) || (rc = copy_results(ix, 0, nq, 0, cursor, ix->stream))) return rc;
         RTX_HIP(hipStreamSynchronize(ix->stream));
-        for (uint64_t q = 0; q < nq; q++) hr.v_row_off[q + 1] = hr.v_row_off[q] + ix->h_n_rows[q];
-        size_host_rows(hr, hr.v_row_off[nq]);
-        finalise_mt(ix, 0, nq, nq < 4096 ? 1 : 8);
+        nrows = finalise_mt(ix, 0, nq, 0, nq < 4096 ? 1 : 16);
     }
     out->n_queries = (uint32_t)nq;
-    out->n_rows = hr.v_row_off[nq];
+    out->n_rows = nrows;
     out->t = hr.h_t.data();
     out->status = hr.h_status.data();
     out->global_signal = hr.h_gs.data();
-    out->row_off = hr.v_row_off.data();
+    out->row_begin = hr.v_row_begin.data();
+    out->row_count = hr.v_row_count.data();
     out->row_lineage = hr.v_row_lineage.data();
     out->row_node = hr.v_row_node.data();
     out->row_depth = hr.v_row_depth.data();
@@ -1132,7 +1203,7 @@ int rtx_shard_begin(rtx_index *ix, uint32_t *n_sub_batches, uint32_t *sub_batch)
     if (ix->n_streams != 1) { set_error("sharded handles use one stream"); return RTX_ERR_STATE; }
     uint32_t n_sub = 0;
     bool timed = false;
-    if ((rc = begin_run(ix, &n_sub, &timed))) return rc;
+    if ((rc = begin_run(ix, &n_sub, &timed, false))) return rc;  // shards must agree on the order: input order
     ix->ran = true;
     ix->synced = false;
     ix->last_flags = 0;
@@ -1243,8 +1314,10 @@ static int debug_slot(rtx_index *ix, uint64_t query, uint32_t *slot) {
     if (rc) return rc;
     if (!ix->synced) { set_error("debug tap: batch not synchronised"); return RTX_ERR_STATE; }
     const uint64_t last0 = (ix->n_q - 1) / ix->sub_batch * ix->sub_batch;
-    if (query >= ix->n_q || query < last0) { set_error("debug tap: query %llu not in the last sub-batch", (unsigned long long)query); return RTX_ERR_INVALID; }
-    *slot = (uint32_t)(query - last0);
+    if (query >= ix->n_q) { set_error("debug tap: query %llu out of range", (unsigned long long)query); return RTX_ERR_INVALID; }
+    const uint64_t pos = ix->h_inv[query];  // position in the processing order (valid once the stream is synchronised)
+    if (pos < last0) { set_error("debug tap: query %llu not in the last sub-batch", (unsigned long long)query); return RTX_ERR_INVALID; }
+    *slot = (uint32_t)(pos - last0);
     return RTX_OK;
 }
 
@@ -1278,7 +1351,7 @@ int rtx_debug_prob_table(rtx_index *ix, uint64_t query, double *table_over_z, do
     RTX_HIP(hipMemcpy(table_over_z, ix->sc[ix->last_set].d_table_z.p + (size_t)slot * ix->hstride, (tt + 1) * 8, hipMemcpyDeviceToHost));
     for (uint32_t m = 0; m <= tt; m++)
         if (!hist[m]) table_over_z[m] = 0.0;  // entries of absent counts are never written
-    if (z) RTX_HIP(hipMemcpy(z, ix->d_z.p + query, 8, hipMemcpyDeviceToHost));
+    if (z) RTX_HIP(hipMemcpy(z, ix->d_z.p + ix->h_inv[query], 8, hipMemcpyDeviceToHost));
     return RTX_OK;
 }
 
@@ -1307,6 +1380,8 @@ int rtx_debug_evaluate(rtx_index *ix, const double *probs, rtx_result_view *out)
     if ((rc = prepare_workspace(ix, 1, std::max<uint64_t>(N, 8), 0))) return rc;
     ix->last_set = 0;
     ix->sum_query_bytes = 0;
+    ix->stream_dl = false;
+    if ((rc = order_batch(ix, false))) return rc;
     std::vector<uint16_t> counts(ix->npad, 0);
     for (uint64_t r = 0; r < N; r++) counts[r] = (uint16_t)r;  // count_r = r, table[r] = probs[r]
     double gs = 0.0;

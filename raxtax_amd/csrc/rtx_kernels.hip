@@ -129,9 +129,10 @@ __global__ __launch_bounds__(64) void kmer_extract_kernel(KmerParams p) {
     __shared__ uint32_t bm[2048];
     const uint32_t q = blockIdx.x;
     const uint32_t lane = threadIdx.x;
-    const uint64_t gq = p.q0 + q;
-    const uint64_t b0 = p.base_off[gq];
-    const uint64_t len = p.base_off[gq + 1] - b0;
+    const uint64_t gq = p.q0 + q;  // position in the processing order: index of the per-query outputs
+    const uint64_t qin = p.perm[gq];
+    const uint64_t b0 = p.base_off[qin];
+    const uint64_t len = p.base_off[qin + 1] - b0;
     const uint8_t *seq = p.bases + b0;
 
     for (uint32_t i = lane; i < 2048; i += 64) bm[i] = 0;
@@ -302,7 +303,8 @@ __global__ __launch_bounds__(64) void hit_count_kernel(HitParams p) {
     if (active) {
         const uint32_t L = tile_lanes(p.stride_bytes, tile);  // lanes of this tile (64 except in the last one)
         if (p.flags & RTX_SKIP_EXACT_MATCHES) {  // raxtax.rs:65-68
-            const uint64_t e0 = p.exact_off[p.q0 + q], e1 = p.exact_off[p.q0 + q + 1];
+            const uint64_t qin = p.perm[p.q0 + q];
+            const uint64_t e0 = p.exact_off[qin], e1 = p.exact_off[qin + 1];
             for (uint64_t e = e0; e < e1; e++) {
                 const uint32_t id = p.exact_ids[e] - p.ref_base;  // local id; other shards' ids wrap out of range
                 if (id < p.n_refs && (id >> 13) == tile) {
@@ -590,7 +592,7 @@ __global__ __launch_bounds__(NW * 64) void taxon_prefix_kernel(PrefixParams p) {
     extern __shared__ double tz_lds[];
     __shared__ double wsum[2][NW];  // double-buffered: one barrier per sweep
     const uint32_t q = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const uint64_t gq = p.perm ? p.perm[p.q0 + q] : p.q0 + q;
+    const uint64_t gq = p.q0 + q;
     double *__restrict__ P = p.prefix + (size_t)q * p.n_bnd;
     if (p.status[gq] != RTX_Q_OK) return;
     const double *__restrict__ tzg = p.table_z + (size_t)q * p.hstride;

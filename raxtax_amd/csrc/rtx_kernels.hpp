@@ -26,7 +26,8 @@ static_assert(sizeof(DevRow) == 36, "DevRow layout");
 struct KmerParams {
     const uint8_t *bases;
     const uint64_t *base_off;
-    uint64_t q0;
+    uint64_t q0;               // first position of the sub-batch in the processing order
+    const uint32_t *perm;      // [n_q] query at every position (rtx_cluster.hip); per-query outputs are by position
     const uint32_t *row_of;    // [65536] bitmap row of a k-mer or 0xFFFFFFFF
     const uint32_t *list_len;  // [65536] posting-list length
     uint32_t zero_row;
@@ -58,6 +59,7 @@ struct HitParams {
     uint32_t hstride;
     uint32_t flags;
     uint64_t q0;
+    const uint32_t *perm;       // [n_q] query at every position: exact_off is indexed by query
     const uint32_t *exact_ids;
     const uint64_t *exact_off;
 };
@@ -76,7 +78,6 @@ struct ProbTables {
 
 struct ProbParams {
     const uint32_t *order;  // processing order of the sub-batch (slot indices) or null
-    const uint64_t *perm;   // global query permutation or null
     const uint32_t *t;
     const uint32_t *hist;
     uint32_t hstride;
@@ -93,7 +94,6 @@ struct ProbParams {
 
 struct PrefixParams {
     const uint8_t *status;
-    const uint64_t *perm;  // global query permutation or null
     const uint32_t *t;     // [B] distinct k-mers per slot (size of the table copy)
     uint32_t tz_in_lds;    // copy table/Z to LDS first (hstride * 8 bytes must fit)
     uint64_t q0;
@@ -139,6 +139,12 @@ size_t prob_lookup_lds_bytes(uint32_t tmax);
 void launch_prob_tables_build(hipStream_t s, const ProbTables &tb, const double *lf, const double *inv);
 void launch_prob_order(hipStream_t s, const uint32_t *t, uint32_t nq, uint32_t *order);
 void launch_prob_lookup(hipStream_t s, const ProbParams &p, const ProbTables &tb, uint32_t nq);
+// processing order of a batch (rtx_cluster.hip)
+void launch_sketch(hipStream_t s, const uint8_t *bases, const uint64_t *off, uint32_t n_q, uint64_t *keys, uint32_t *idx);
+void launch_invert_perm(hipStream_t s, const uint32_t *perm, uint32_t n, uint32_t *inv);
+void launch_identity_perm(hipStream_t s, uint32_t n, uint32_t *perm, uint32_t *inv);
+int cluster_sort(hipStream_t s, void *tmp, size_t *tmp_bytes, const uint64_t *keys_in, uint64_t *keys_out, const uint32_t *idx_in,
+                 uint32_t *perm_out, size_t n);
 void launch_taxon_prefix(hipStream_t s, const PrefixParams &p, uint32_t nq);
 void launch_lineage_walk(hipStream_t s, const WalkParams &p, uint32_t nq);
 void launch_probs_expand(hipStream_t s, const uint16_t *counts, const double *tz, uint64_t n, double *out);

@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) void prob_lookup_kernel(ProbParams p, ProbTabl
     __shared__ uint32_t s_D, s_nact;
     const uint32_t q = p.order ? p.order[blockIdx.x] : blockIdx.x;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const uint64_t gq = p.perm ? p.perm[p.q0 + q] : p.q0 + q;
+    const uint64_t gq = p.q0 + q;
     const uint32_t t = p.t[q];
     const uint32_t n = t >> 1;  // num_trials = k_mers.len() / 2, raxtax.rs:57
     const uint32_t n1 = n + 1;

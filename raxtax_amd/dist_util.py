@@ -4,7 +4,8 @@ collective is the gather of the per-rank result records on rank 0 (RCCL on GPUs,
 
 A rank's results travel as ONE byte buffer:
     header  int64[2]            n_queries, n_rows
-    row_off int64[n_queries+1]
+    begin   int64[n_queries]    first row of every query (rows travel in the library's processing order)
+    count   int64[n_queries]    rows of every query
     global  float64[n_queries]  global signal per query
     lineage int32[n_rows]       index into tree.lineages
     depth   uint8[n_rows]
@@ -27,17 +28,23 @@ def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def pack_records(row_off, row_lineage, row_depth, row_conf, row_local, global_signal=None) -> np.ndarray:
-    """Result rows of one rank as one uint8 buffer (layout in the module docstring)."""
-    row_off = np.ascontiguousarray(row_off, dtype=np.int64)
-    n_q = len(row_off) - 1
-    n_rows = int(row_off[-1])
+def pack_records(row_off, row_lineage, row_depth, row_conf, row_local, global_signal=None, row_begin=None,
+                 row_count=None) -> np.ndarray:
+    """Result rows of one rank as one uint8 buffer (layout in the module docstring).  Either a CSR `row_off`
+    (rows in query order) or the library view's `row_begin` / `row_count`."""
+    if row_begin is None:
+        row_off = np.ascontiguousarray(row_off, dtype=np.int64)
+        row_begin, row_count = row_off[:-1], np.diff(row_off)
+    row_begin = np.ascontiguousarray(row_begin, dtype=np.int64)
+    row_count = np.ascontiguousarray(row_count, dtype=np.int64)
+    n_q = len(row_begin)
+    n_rows = int(row_count.sum())
     gs = np.zeros(n_q) if global_signal is None else np.asarray(global_signal[:n_q], dtype=np.float64)
     conf = np.asarray(row_conf)[:n_rows, :CONF_LEVELS]
     conf_u8 = np.rint(conf * 100.0).astype(np.uint8)
     if conf_u8.shape[1] < CONF_LEVELS:
         conf_u8 = np.pad(conf_u8, ((0, 0), (0, CONF_LEVELS - conf_u8.shape[1])))
-    parts = [np.array([n_q, n_rows], dtype=np.int64).view(np.uint8), row_off.view(np.uint8),
+    parts = [np.array([n_q, n_rows], dtype=np.int64).view(np.uint8), row_begin.view(np.uint8), row_count.view(np.uint8),
              np.ascontiguousarray(gs).view(np.uint8),
              np.ascontiguousarray(row_lineage[:n_rows], dtype=np.int32).view(np.uint8),
              np.ascontiguousarray(row_depth[:n_rows], dtype=np.uint8),
@@ -57,12 +64,18 @@ def unpack_records(buf: np.ndarray) -> dict:
         p += nbytes
         return out
 
-    row_off = take(8 * (n_q + 1), np.int64)
+    begin = take(8 * n_q, np.int64)
+    count = take(8 * n_q, np.int64)
     gs = take(8 * n_q, np.float64)
     lineage = take(4 * n_rows, np.int32)
     depth = take(n_rows, np.uint8)
     conf = take(n_rows * CONF_LEVELS, np.uint8).reshape(n_rows, CONF_LEVELS).astype(np.float64) / 100.0
     local = take(8 * n_rows, np.float64)
+    # into query order
+    row_off = np.zeros(n_q + 1, dtype=np.int64)
+    row_off[1:] = np.cumsum(count)
+    src = np.repeat(begin - row_off[:-1], count) + np.arange(n_rows)
+    lineage, depth, conf, local = lineage[src], depth[src], conf[src], local[src]
     return dict(n_queries=n_q, n_rows=n_rows, row_off=row_off, global_signal=gs, row_lineage=lineage, row_depth=depth,
                 row_conf=conf, row_local_signal=local)
 

@@ -9,12 +9,14 @@ from raxtax_amd import synth
 db = synth.make_db(50000)
 qs = synth.make_queries(db, 100000)
 tree = rx.Tree.new_flat(db.lineages, db.seq_bytes, db.seq_off)
-index = rx.Index(tree, device=0, stage_timing=("--all" in sys.argv))
+index = rx.Index(tree, device=0, stage_timing=("--all" in sys.argv), cluster=("--no-cluster" not in sys.argv))
+SYNC = "--no-sync" not in sys.argv
 ex_ids, ex_off = index.exact_matches(qs.bases, qs.base_off)
 index.upload(qs.bases, qs.base_off, ex_ids, ex_off)
 for it in range(6):
     t0 = time.perf_counter(); index.run(0)
-    t1 = time.perf_counter(); index.sync()
+    t1 = time.perf_counter()
+    if SYNC: index.sync()
     t2 = time.perf_counter(); index.download(copy=False)
     t3 = time.perf_counter()
     st = index.stage_times()

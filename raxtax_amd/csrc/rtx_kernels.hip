@@ -260,7 +260,12 @@ __device__ __forceinline__ uint4 csa_plane(uint32_t (&pl)[4][NP], const uint4 &a
 template <int NP>
 __global__ __launch_bounds__(64) void hit_count_kernel(HitParams p) {
     extern __shared__ uint32_t hist_lds[];
-    const uint32_t q = blockIdx.x, tile = blockIdx.y, lane = threadIdx.x;
+    const uint32_t tile = blockIdx.y, lane = threadIdx.x;
+    // Workgroups are dealt round-robin to the 8 XCDs (each with an L2 of its own).  Neighbouring slots hold
+    // related queries (rtx_cluster.hip): XCD x takes the contiguous slice [x*nq/8, (x+1)*nq/8) of the sub-batch,
+    // so that the rows a cluster shares are fetched into one L2 instead of eight.
+    const uint32_t nq8 = gridDim.x >> 3;
+    const uint32_t q = blockIdx.x < nq8 * 8u ? (blockIdx.x & 7u) * nq8 + (blockIdx.x >> 3) : blockIdx.x;
     const uint32_t t = p.t[q];
     for (uint32_t i = lane; i <= t; i += 64) hist_lds[i] = 0;
 

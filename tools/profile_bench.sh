@@ -11,9 +11,9 @@ cd /tmp && export TMPDIR=/tmp
 ARGS="--steps 2 --warmup 1 --no-cpu-baseline $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${TAG}_trace" -- python3 "$ROOT/bench.py" $ARGS > "$OUT/${TAG}_trace.log" 2>&1
 echo "trace rc=$?"
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/${TAG}_fetch" -- python3 "$ROOT/bench.py" $ARGS --queries 20000 > "$OUT/${TAG}_fetch.log" 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/${TAG}_fetch" -- python3 "$ROOT/bench.py" $ARGS --queries 16384 > "$OUT/${TAG}_fetch.log" 2>&1
 echo "fetch rc=$?"
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/${TAG}_write" -- python3 "$ROOT/bench.py" $ARGS --queries 20000 > "$OUT/${TAG}_write.log" 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/${TAG}_write" -- python3 "$ROOT/bench.py" $ARGS --queries 16384 > "$OUT/${TAG}_write.log" 2>&1
 echo "write rc=$?"
 find "$OUT/${TAG}_trace" "$OUT/${TAG}_fetch" "$OUT/${TAG}_write" -type f | head -40
 for f in $(find "$OUT/${TAG}_trace" -name '*kernel_stats.csv'); do echo "== $f"; head -12 "$f"; done

@@ -244,6 +244,40 @@ def test_sub_batching_and_rerun_are_deterministic(world):
         assert np.array_equal(r2.t, ref.t)
 
 
+def test_processing_order_does_not_change_results(world):
+    """RTX_OPT_CLUSTER (queries processed in min-hash order, rtx_cluster.hip) is a scheduling decision:
+    every array of the result equals the one of a run in input order, also when the batch spans several
+    sub-batches, runs on two streams, or is downloaded in one piece after a sync (bulk path) instead of
+    streamed per sub-batch."""
+    w = world
+    ex_ids, ex_off = w["index"].exact_matches(w["bases"], w["off"])
+    ref = rx.Index(w["tree"], cluster=False).classify(w["bases"], w["off"], ex_ids, ex_off)
+    for kw in (dict(cluster=True), dict(cluster=True, sub_batch=16), dict(cluster=True, sub_batch=50, streams=2)):
+        ix = rx.Index(w["tree"], **kw)
+        for skip in (False, True):
+            want = ref if not skip else rx.Index(w["tree"], cluster=False).classify(w["bases"], w["off"], ex_ids, ex_off,
+                                                                                     skip_exact_matches=True)
+            got = ix.classify(w["bases"], w["off"], ex_ids, ex_off, skip_exact_matches=skip)   # streamed download
+            ix.upload(w["bases"], w["off"], ex_ids, ex_off)
+            ix.run(rx._lib.RTX_SKIP_EXACT_MATCHES if skip else 0)
+            ix.sync()
+            bulk = ix.download()                                                              # bulk download
+            for r in (got, bulk):
+                assert np.array_equal(r.row_off, want.row_off), kw
+                assert np.array_equal(r.row_lineage, want.row_lineage) and np.array_equal(r.row_conf, want.row_conf)
+                assert np.array_equal(r.t, want.t) and np.array_equal(r.status, want.status)
+                assert np.array_equal(r.global_signal, want.global_signal)
+                assert np.array_equal(r.row_local_signal, want.row_local_signal)
+    # the debug taps address queries by input index whatever the processing order
+    ix = rx.Index(w["tree"], cluster=True)
+    ix.classify(w["bases"], w["off"], ex_ids, ex_off)
+    plain = rx.Index(w["tree"], cluster=False)
+    plain.classify(w["bases"], w["off"], ex_ids, ex_off)
+    for q in (0, 7, len(w["seqs"]) - 1):
+        assert np.array_equal(ix.debug_hit_counts(q), plain.debug_hit_counts(q))
+        assert np.array_equal(ix.debug_kmers(q), plain.debug_kmers(q))
+
+
 def test_work_accounting_matches_oracle(world):
     """sum_hits = sum_q H_q = sum_q sum_r count_q[r], measured by the device."""
     w = world

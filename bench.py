@@ -17,6 +17,7 @@ a C port of the reference algorithm, timed on this host's cores on a bounded sam
 from __future__ import annotations
 
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -191,21 +192,20 @@ def main():
     ex_ids, ex_off = index.exact_matches(qs.bases, qs.base_off)   # Tree.sequences.get, raxtax.rs:42 (host)
     index.upload(qs.bases, qs.base_off, ex_ids, ex_off)            # inputs resident in HBM from here on
 
+    lib = rx._lib.load()
+    rec_buf = [None]
+
     def step():
         index.run(flags)
         view = index.download(copy=False)       # sync + D2H of the result records + host finalisation
         if dist is not None:
             # the only collective: gather the per-rank result records on rank 0 (RCCL over xGMI)
-            n_rows = int(view.n_rows)
-            rec = dist_util.pack_records(
-                None,
-                np.ctypeslib.as_array(view.row_lineage, shape=(max(n_rows, 1),)),
-                np.ctypeslib.as_array(view.row_depth, shape=(max(n_rows, 1),)),
-                np.ctypeslib.as_array(view.row_conf, shape=(max(n_rows, 1), 32)),
-                np.ctypeslib.as_array(view.row_local_signal, shape=(max(n_rows, 1),)),
-                np.ctypeslib.as_array(view.global_signal, shape=(args.queries,)),
-                row_begin=np.ctypeslib.as_array(view.row_begin, shape=(args.queries,)),
-                row_count=np.ctypeslib.as_array(view.row_count, shape=(args.queries,)))
+            need = lib.rtx_result_pack(ctypes.byref(view), None, 0)       # native pack: 24 B/query + 21 B/row
+            if rec_buf[0] is None or rec_buf[0].shape[0] < need:
+                rec_buf[0] = np.empty(int(need * 1.25) + 64, dtype=np.uint8)
+            n = lib.rtx_result_pack(ctypes.byref(view), rec_buf[0].ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), rec_buf[0].shape[0])
+            assert n == need, "rtx_result_pack failed"
+            rec = rec_buf[0][:n]
             dist_util.gather_records(dist, rec, rank, world, device=coll_device)
         return view
 

@@ -274,6 +274,11 @@ int64_t rtx_format_query(const rtx_tree *tree, const rtx_result_view *res, uint6
                          const uint32_t *exact_ids, uint64_t n_exact, uint32_t flags, char *out_buf,
                          uint64_t out_cap, char *tsv_buf, uint64_t tsv_cap, int64_t *tsv_len);
 
+/* Compact byte record of a result view: what a rank ships in the multi-GPU result gather (BASELINE.json
+ * configs[3]; layout in raxtax_amd/dist_util.py: 24 B per query + 21 B per row, confidences as hundredths of the
+ * first 8 levels).  buf == NULL: returns the size needed; else the bytes written or a negative RTX_ERR_*. */
+int64_t rtx_result_pack(const rtx_result_view *res, uint8_t *buf, uint64_t cap);
+
 /* ------------------------------------------------------------------------- */
 /* Host mirror of raxtax() itself (src/raxtax.rs:14-97)                       */
 /* ------------------------------------------------------------------------- */

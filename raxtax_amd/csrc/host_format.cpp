@@ -129,3 +129,48 @@ extern "C" int64_t rtx_format_query(const rtx_tree *tree, const rtx_result_view 
     if (tsv_len) *tsv_len = tsv_buf ? (int64_t)tv.len : 0;
     return (int64_t)o.len;
 }
+
+// ---- compact byte record of a result view (the unit the multi-GPU gather ships, raxtax_amd/dist_util.py) ----
+//   int64[2] n_queries, n_rows | int64 begin[nq] | int64 count[nq] | f64 global[nq]
+//   | int32 lineage[n_rows] | u8 depth[n_rows] | u8 conf[n_rows][8] (hundredths) | f64 local[n_rows]
+#include <cmath>
+#include <thread>
+#include <vector>
+
+extern "C" int64_t rtx_result_pack(const rtx_result_view *res, uint8_t *buf, uint64_t cap) {
+    if (!res) { rtx::set_error("rtx_result_pack: null view"); return RTX_ERR_INVALID; }
+    const uint64_t nq = res->n_queries, nr = res->n_rows;
+    const uint64_t need = 16 + 24 * nq + 21 * nr;
+    if (!buf) return (int64_t)need;  // size query
+    if (cap < need) { rtx::set_error("rtx_result_pack: buffer of %llu bytes, need %llu", (unsigned long long)cap, (unsigned long long)need); return RTX_ERR_INVALID; }
+    int64_t *hdr = reinterpret_cast<int64_t *>(buf);
+    hdr[0] = (int64_t)nq;
+    hdr[1] = (int64_t)nr;
+    uint8_t *p_begin = buf + 16, *p_count = p_begin + 8 * nq, *p_gs = p_count + 8 * nq;
+    uint8_t *p_lin = p_gs + 8 * nq, *p_depth = p_lin + 4 * nr, *p_conf = p_depth + nr, *p_local = p_conf + 8 * nr;
+    auto work = [&](uint64_t qa, uint64_t qb, uint64_t ra, uint64_t rb) {
+        for (uint64_t q = qa; q < qb; q++) {
+            const int64_t b = (int64_t)res->row_begin[q], c = (int64_t)res->row_count[q];
+            memcpy(p_begin + 8 * q, &b, 8);
+            memcpy(p_count + 8 * q, &c, 8);
+            memcpy(p_gs + 8 * q, &res->global_signal[q], 8);
+        }
+        for (uint64_t r = ra; r < rb; r++) {
+            const int32_t lin = (int32_t)res->row_lineage[r];
+            memcpy(p_lin + 4 * r, &lin, 4);
+            p_depth[r] = (uint8_t)res->row_depth[r];
+            const double *cf = res->row_conf + r * RTX_MAX_DEPTH;
+            for (int d = 0; d < 8; d++) p_conf[8 * r + d] = (uint8_t)std::lrint(cf[d] * 100.0);
+            memcpy(p_local + 8 * r, &res->row_local_signal[r], 8);
+        }
+    };
+    const unsigned nt = nr + nq < 65536 ? 1u : std::min(8u, std::max(1u, std::thread::hardware_concurrency()));
+    if (nt == 1) {
+        work(0, nq, 0, nr);
+    } else {
+        std::vector<std::thread> th;
+        for (unsigned i = 0; i < nt; i++) th.emplace_back(work, nq * i / nt, nq * (i + 1) / nt, nr * i / nt, nr * (i + 1) / nt);
+        for (auto &t : th) t.join();
+    }
+    return (int64_t)need;
+}

@@ -96,3 +96,45 @@ def test_tree_variable_depth_and_duplicates(oracle, kats):
     # all 7 identical sequences are exact matches of one another (ids in sorted order)
     assert list(ht.exact_matches(seqs[0])) == list(range(7))
     assert int(hn["end"][0]) == 7 and int(hn["type"][0]) == 0
+
+
+def test_native_result_pack_equals_python_pack():
+    """rtx_result_pack (the record a rank ships in the multi-GPU gather) == dist_util.pack_records."""
+    import ctypes as C
+
+    from raxtax_amd import _lib, dist_util
+
+    lib = _lib.load()
+    rng = np.random.default_rng(5)
+    nq = 1000
+    count = rng.integers(0, 5, nq).astype(np.uint32)
+    order = rng.permutation(nq)                         # rows stored in an order of their own
+    begin = np.zeros(nq, np.uint64)
+    run = 0
+    for q in order:
+        begin[q] = run
+        run += int(count[q])
+    nr = run
+    lin = rng.integers(0, 50000, nr).astype(np.uint32)
+    node = np.zeros(nr, np.uint32)
+    depth = rng.integers(1, 8, nr).astype(np.uint32)
+    conf = np.zeros((nr, 32))
+    conf[:, :8] = rng.integers(0, 101, (nr, 8)) / 100.0
+    local = rng.random(nr)
+    gs = rng.random(nq)
+    t = np.zeros(nq, np.uint32)
+    status = np.zeros(nq, np.uint8)
+    v = _lib.ResultView()
+    v.n_queries, v.n_rows = nq, nr
+    P = lambda a, ty: a.ctypes.data_as(C.POINTER(ty))
+    v.t, v.status, v.global_signal = P(t, C.c_uint32), P(status, C.c_uint8), P(gs, C.c_double)
+    v.row_begin, v.row_count = P(begin, C.c_uint64), P(count, C.c_uint32)
+    v.row_lineage, v.row_node, v.row_depth = P(lin, C.c_uint32), P(node, C.c_uint32), P(depth, C.c_uint32)
+    v.row_conf, v.row_local_signal = P(conf, C.c_double), P(local, C.c_double)
+    need = lib.rtx_result_pack(C.byref(v), None, 0)
+    buf = np.zeros(need, np.uint8)
+    assert lib.rtx_result_pack(C.byref(v), P(buf, C.c_uint8), need) == need
+    want = dist_util.pack_records(None, lin, depth, conf, local, gs, row_begin=begin, row_count=count)
+    assert np.array_equal(buf, want)
+    back = dist_util.unpack_records(buf)
+    assert np.array_equal(np.diff(back["row_off"]), count)

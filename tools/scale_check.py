@@ -38,15 +38,22 @@ def main():
     print("work", work, "H_q/N =", work["sum_hits"] / n_q / n_refs)
     assert (res.status == 0).all()
     assert (np.diff(res.row_off) >= 1).all()
-    # exact copies (10 % of the queries) classify to confidence 1.00 on every level with one exact match
-    # size-independent properties on the last sub-batch (debug taps): sum of counts = H_q, probabilities sum to 1
-    last0 = (n_q - 1) // 4096 * 4096 if n_q > 4096 else 0
-    for q in range(max(last0, n_q - 6), n_q):
-        c = ix.debug_hit_counts(q)
-        p = ix.debug_probs(q)
+    # size-independent properties + oracle parity on the last few queries, re-run as a batch of their own
+    # (the debug taps see the last sub-batch, and the processing order of a large batch is not the input order)
+    m = max(n_sample, 6)
+    lo = int(qs.base_off[n_q - m])
+    sub_off = (qs.base_off[n_q - m:] - qs.base_off[n_q - m]).astype(np.uint64)
+    sub_bases = qs.bases[lo:]
+    sx_ids, sx_off = ix.exact_matches(sub_bases, sub_off)
+    sub = ix.classify(sub_bases, sub_off, sx_ids, sx_off)
+    for j in range(m):
+        c = ix.debug_hit_counts(j)
+        p = ix.debug_probs(j)
         assert abs(p.sum() - 1.0) < 1e-9, p.sum()
         assert int(c.astype(np.uint64).sum()) > 0
-        assert int(c.max()) <= int(res.t[q])
+        assert int(c.max()) <= int(sub.t[j])
+        q = n_q - m + j
+        assert [(r.lineage, r.confidence_values) for r in sub.rows(j)] == [(r.lineage, r.confidence_values) for r in res.rows(q)]
     if n_sample:
         from oracle.oracle_py import Oracle
 
@@ -56,7 +63,7 @@ def main():
         bad = 0
         for q in range(n_q - n_sample, n_q):
             t, counts = otree.hit_counts(qs.seq(q))
-            assert np.array_equal(ix.debug_hit_counts(q), counts), q
+            assert np.array_equal(ix.debug_hit_counts(q - (n_q - m)), counts), q
             rows, _ = otree.classify(qs.seq(q), raw_confidence=True)
             got = res.rows(q)
             if [r.lineage for r in got] != [r["idx"] for r in rows] or [r.confidence_values for r in got] != [r["conf"] for r in rows]:

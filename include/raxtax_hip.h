@@ -83,6 +83,12 @@ int rtx_tree_build_ex(uint64_t n, const char *lineage_bytes, const uint64_t *lin
                       const uint8_t *seq_bytes, const uint64_t *seq_off, uint32_t flags, rtx_tree **out);
 /* parse_reference_fasta_str, src/parser.rs:46-105 */
 int rtx_tree_parse_reference_fasta(const char *text, uint64_t len, rtx_tree **out);
+/* The same with RTX_TREE_* flags: RTX_TREE_SKIP_KMER_MAP leaves Tree.k_mer_map unbuilt (rtx_index_create_from_tree
+ * then builds the bitmaps on the GPU from the sequences); rtx_tree_build_kmer_map builds it later, e.g. on a
+ * background thread for the `.bin` cache while queries are already being classified.  Both parsers cut the text
+ * at header lines and parse the pieces on several threads. */
+int rtx_tree_parse_reference_fasta_ex(const char *text, uint64_t len, uint32_t flags, rtx_tree **out);
+int rtx_tree_build_kmer_map(rtx_tree *tree);
 /* Tree::save_to_file / Tree::load_from_file (src/tree.rs:147-164): the reference's `.bin` database,
  * bincode 1.3.3 default options.  Files written here are readable by upstream raxtax and vice versa. */
 int rtx_tree_save_bin(const rtx_tree *tree, const char *path);

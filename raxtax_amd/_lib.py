@@ -53,6 +53,8 @@ _SIGNATURES = {
     "rtx_tree_build": (C.c_int, [C.c_uint64, C.c_char_p, u64p, u8p, u64p, C.POINTER(C.c_void_p)]),
     "rtx_tree_build_ex": (C.c_int, [C.c_uint64, C.c_char_p, u64p, u8p, u64p, C.c_uint32, C.POINTER(C.c_void_p)]),
     "rtx_tree_parse_reference_fasta": (C.c_int, [C.c_char_p, C.c_uint64, C.POINTER(C.c_void_p)]),
+    "rtx_tree_parse_reference_fasta_ex": (C.c_int, [C.c_char_p, C.c_uint64, C.c_uint32, C.POINTER(C.c_void_p)]),
+    "rtx_tree_build_kmer_map": (C.c_int, [C.c_void_p]),
     "rtx_tree_save_bin": (C.c_int, [C.c_void_p, C.c_char_p]),
     "rtx_tree_load_bin": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
     "rtx_tree_destroy": (None, [C.c_void_p]),

@@ -20,6 +20,7 @@
 #include <set>
 #include <sstream>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "host_raxtax.hpp"
@@ -157,7 +158,8 @@ int main(int argc, char **argv) {
     bool store_db = false;
     if (rtx_tree_load_bin(db.c_str(), &tree) != RTX_OK) {
         std::string db_text;
-        if (!slurp(db, db_text) || rtx_tree_parse_reference_fasta(db_text.data(), db_text.size(), &tree) != RTX_OK) {
+        // Tree.k_mer_map is only needed for the .bin cache: the device index is built from the sequences
+        if (!slurp(db, db_text) || rtx_tree_parse_reference_fasta_ex(db_text.data(), db_text.size(), RTX_TREE_SKIP_KMER_MAP, &tree) != RTX_OK) {
             fprintf(stderr, "[ERROR] Failed to parse %s: %s\n", db.c_str(), rtx_last_error());
             return 66;  // exitcode::NOINPUT
         }
@@ -173,8 +175,23 @@ int main(int argc, char **argv) {
             fprintf(stderr, "[ERROR] Output database file %s already exists! Delete it or run with --redo\n", db_bin.c_str());
             return 73;
         }
-        if (rtx_tree_save_bin(tree, db_bin.c_str()) != RTX_OK) { fprintf(stderr, "[ERROR] Failed to write database: %s\n", rtx_last_error()); return 74; }
     }
+    // the database cache is written on a thread of its own while the queries are parsed and classified
+    std::thread bin_writer;
+    int bin_rc = RTX_OK;
+    std::string bin_err;
+    auto start_bin_writer = [&]() {
+        if (db_bin.empty()) return;
+        bin_writer = std::thread([&]() {
+            bin_rc = rtx_tree_save_bin(tree, db_bin.c_str());
+            if (bin_rc != RTX_OK) bin_err = rtx_last_error();
+        });
+    };
+    auto join_bin_writer = [&]() -> bool {
+        if (bin_writer.joinable()) bin_writer.join();
+        if (bin_rc != RTX_OK) { fprintf(stderr, "[ERROR] Failed to write database: %s\n", bin_err.c_str()); return false; }
+        return true;
+    };
     {
         const std::string tmp = ckp_json + ".tmp";  // Checkpoint::save: tmp + rename (io.rs:72-78)
         std::ofstream f(tmp, std::ios::trunc);
@@ -182,8 +199,13 @@ int main(int argc, char **argv) {
         f.close();
         rename(tmp.c_str(), ckp_json.c_str());
     }
-    lap("database_cache");
-    if (only_db) return 0;
+    if (only_db) {
+        start_bin_writer();
+        const bool ok = join_bin_writer();
+        lap("database_cache");
+        if (timing) fprintf(stderr, "{%s}\n", t_log.str().c_str());
+        return ok ? 0 : 74;
+    }
 
     // ---- queries (already finished labels are dropped, parser.rs:150-153)
     std::string q_text;
@@ -202,6 +224,7 @@ int main(int argc, char **argv) {
         return 71;  // exitcode::OSERR
     }
     lap("index");
+    start_bin_writer();  // after the index: rtx_index_create_from_tree looks at the tree's k-mer map
     Sink sink;
     const auto mode = (redo || !resume) ? std::ios::trunc : std::ios::app;
     sink.out.open(out_path, mode);
@@ -228,6 +251,8 @@ int main(int argc, char **argv) {
     sink.ckp.flush();
     if (tsv) sink.tsv.flush();
     lap("classify_and_write");
+    if (!join_bin_writer()) return 74;
+    lap("database_cache_wait");
     if (timing) fprintf(stderr, "{\"n_queries\": %llu, %s}\n", (unsigned long long)n, t_log.str().c_str());
     if (rc != RTX_OK) {
         fprintf(stderr, "[ERROR] %s\nRerun raxtax-hip to continue from the last checkpoint.\n", rtx_last_error());

@@ -21,11 +21,17 @@ namespace {
 using rtx::Node;
 using rtx::NodeType;
 
+static_assert(__BYTE_ORDER__ == __ORDER_LITTLE_ENDIAN__, "bincode integers are little-endian: arrays are copied as they are");
+
 struct Writer {
     std::vector<uint8_t> buf;
-    void u32(uint32_t v) { for (int i = 0; i < 4; i++) buf.push_back((uint8_t)(v >> (8 * i))); }
-    void u64(uint64_t v) { for (int i = 0; i < 8; i++) buf.push_back((uint8_t)(v >> (8 * i))); }
-    void bytes(const void *p, size_t n) { const uint8_t *b = (const uint8_t *)p; buf.insert(buf.end(), b, b + n); }
+    void bytes(const void *p, size_t n) {
+        const size_t at = buf.size();
+        buf.resize(at + n);
+        memcpy(buf.data() + at, p, n);
+    }
+    void u32(uint32_t v) { bytes(&v, 4); }
+    void u64(uint64_t v) { bytes(&v, 8); }
     void str(const std::string &s) { u64(s.size()); bytes(s.data(), s.size()); }
 };
 
@@ -92,8 +98,12 @@ extern "C" {
 
 int rtx_tree_save_bin(const rtx_tree *tree, const char *path) {
     if (!tree || !path) { rtx::set_error("null argument"); return RTX_ERR_INVALID; }
-    if (tree->csr_off.empty()) { rtx::set_error("tree was built with RTX_TREE_SKIP_KMER_MAP: no k_mer_map to save"); return RTX_ERR_STATE; }
+    if (tree->csr_off.empty()) {  // built with RTX_TREE_SKIP_KMER_MAP: the file format needs Tree.k_mer_map
+        const int rc = rtx_tree_build_kmer_map(const_cast<rtx_tree *>(tree));
+        if (rc) return rc;
+    }
     Writer w;
+    w.buf.reserve(tree->postings.size() * 4 + tree->seq_bytes.size() * 2 + tree->lineages.size() * 128 + (1u << 20));
     write_node(w, *tree, 0);                                   // root
     w.u64(tree->lineages.size());                              // lineages
     for (const std::string &l : tree->lineages) w.str(l);
@@ -102,13 +112,13 @@ int rtx_tree_save_bin(const rtx_tree *tree, const char *path) {
         w.u64(kv.first.size());
         w.bytes(kv.first.data(), kv.first.size());
         w.u64(kv.second.size());
-        for (uint32_t id : kv.second) w.u32(id);
+        w.bytes(kv.second.data(), kv.second.size() * 4);
     }
     w.u64(RTX_NUM_KMERS);                                      // k_mer_map
     for (uint32_t k = 0; k < RTX_NUM_KMERS; k++) {
         const uint64_t b = tree->csr_off[k], e = tree->csr_off[k + 1];
         w.u64(e - b);
-        for (uint64_t i = b; i < e; i++) w.u32(tree->postings[i]);
+        w.bytes(tree->postings.data() + b, (e - b) * 4);
     }
     w.u64(tree->num_tips);                                     // num_tips
     std::ofstream f(path, std::ios::binary);

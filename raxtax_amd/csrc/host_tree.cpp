@@ -11,6 +11,8 @@
 #include <cstdio>
 #include <cstring>
 #include <numeric>
+#include <string>
+#include <thread>
 
 #include "rtx_internal.hpp"
 
@@ -153,6 +155,46 @@ static std::vector<std::string_view> fasta_lines(const char *text, uint64_t len)
     return out;
 }
 
+// ---- parallel FASTA parsing: the text is cut at lines that begin with '>' -------------------------------
+struct FastaPiece {
+    std::vector<std::string> labels;
+    std::vector<uint8_t> bytes;
+    std::vector<uint64_t> off;
+    bool last_empty = false;  // queries: the piece ends in a header without sequence
+    std::string err;
+};
+
+static unsigned parse_threads(uint64_t len) {
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    return (unsigned)std::min<uint64_t>(std::min(hw, 16u), std::max<uint64_t>(1, len >> 20));  // >= 1 MiB per piece
+}
+
+// cut points [0, ..., len]: every inner one is the position of a '>' that directly follows a newline
+static std::vector<uint64_t> fasta_cuts(const char *text, uint64_t len, unsigned parts) {
+    std::vector<uint64_t> cuts{0};
+    for (unsigned i = 1; i < parts; i++) {
+        uint64_t pos = len * i / parts;
+        if (pos <= cuts.back()) continue;
+        const void *nl;
+        while (pos < len && (nl = memchr(text + pos, '\n', len - pos)) != nullptr) {
+            pos = (uint64_t)((const char *)nl - text) + 1;
+            if (pos < len && text[pos] == '>') break;
+        }
+        if (pos >= len || text[pos] != '>') break;
+        if (pos > cuts.back()) cuts.push_back(pos);
+    }
+    cuts.push_back(len);
+    return cuts;
+}
+
+template <class F>
+static void run_pieces(size_t np, F fn) {
+    if (np <= 1) { for (size_t i = 0; i < np; i++) fn(i); return; }
+    std::vector<std::thread> th;
+    for (size_t i = 0; i < np; i++) th.emplace_back(fn, i);
+    for (auto &t : th) t.join();
+}
+
 // first match of `tax=([^;]+);` (parser.rs:50,70-78)
 static bool find_tax(std::string_view s, std::string_view &out) {
     size_t pos = 0;
@@ -196,6 +238,33 @@ void flatten_tree(rtx_tree &t) {
         f.first_child.push_back(cnt ? first : 0);
         f.n_children.push_back(cnt);
         f.type.push_back((uint8_t)nd.type);
+    }
+}
+
+// Tree.k_mer_map (tree.rs:114-123,134-137) as CSR by counting sort: pass 1 counts the distinct k-mers of every
+// reference, pass 2 scatters reference ids in ascending order, which leaves every list sorted and unique.
+static void build_kmer_map(rtx_tree &tr) {
+    rtx_tree *t = &tr;
+    const uint64_t n = t->n;
+    t->csr_off.assign(RTX_NUM_KMERS + 1, 0);
+    std::vector<uint32_t> stamp(RTX_NUM_KMERS, 0);  // last reference (idx+1) that touched the k-mer
+    for (uint64_t idx = 0; idx < n; idx++) {
+        const uint32_t tag = (uint32_t)idx + 1;
+        for_each_window_kmer(t->seq_bytes.data() + t->seq_off[idx], t->seq_off[idx + 1] - t->seq_off[idx],
+                             [&](uint32_t k) {
+                                 if (stamp[k] != tag) { stamp[k] = tag; t->csr_off[k + 1]++; }
+                             });
+    }
+    for (uint32_t k = 0; k < RTX_NUM_KMERS; k++) t->csr_off[k + 1] += t->csr_off[k];
+    t->postings.resize(t->csr_off[RTX_NUM_KMERS]);
+    std::vector<uint64_t> cursor(t->csr_off.begin(), t->csr_off.end() - 1);
+    std::fill(stamp.begin(), stamp.end(), 0);
+    for (uint64_t idx = 0; idx < n; idx++) {
+        const uint32_t tag = (uint32_t)idx + 1;
+        for_each_window_kmer(t->seq_bytes.data() + t->seq_off[idx], t->seq_off[idx + 1] - t->seq_off[idx],
+                             [&](uint32_t k) {
+                                 if (stamp[k] != tag) { stamp[k] = tag; t->postings[cursor[k]++] = (uint32_t)idx; }
+                             });
     }
 }
 
@@ -267,34 +336,7 @@ static int build_tree(std::vector<std::string> &&lineages_in, const uint8_t *seq
         t->sequences[key].push_back((uint32_t)idx);
     }
 
-    if (!with_kmer_map) {  // the bitmaps are then built on the GPU from the sequences (rtx_index_create_from_tree)
-        flatten(*t);
-        *out = t;
-        return RTX_OK;
-    }
-    // Tree.k_mer_map (tree.rs:114-123,134-137) as CSR by counting sort: pass 1 counts the
-    // distinct k-mers of every reference, pass 2 scatters reference ids in ascending order,
-    // which leaves every list sorted and unique.
-    t->csr_off.assign(RTX_NUM_KMERS + 1, 0);
-    std::vector<uint32_t> stamp(RTX_NUM_KMERS, 0);  // last reference (idx+1) that touched the k-mer
-    for (uint64_t idx = 0; idx < n; idx++) {
-        const uint32_t tag = (uint32_t)idx + 1;
-        for_each_window_kmer(t->seq_bytes.data() + t->seq_off[idx], t->seq_off[idx + 1] - t->seq_off[idx],
-                             [&](uint32_t k) {
-                                 if (stamp[k] != tag) { stamp[k] = tag; t->csr_off[k + 1]++; }
-                             });
-    }
-    for (uint32_t k = 0; k < RTX_NUM_KMERS; k++) t->csr_off[k + 1] += t->csr_off[k];
-    t->postings.resize(t->csr_off[RTX_NUM_KMERS]);
-    std::vector<uint64_t> cursor(t->csr_off.begin(), t->csr_off.end() - 1);
-    std::fill(stamp.begin(), stamp.end(), 0);
-    for (uint64_t idx = 0; idx < n; idx++) {
-        const uint32_t tag = (uint32_t)idx + 1;
-        for_each_window_kmer(t->seq_bytes.data() + t->seq_off[idx], t->seq_off[idx + 1] - t->seq_off[idx],
-                             [&](uint32_t k) {
-                                 if (stamp[k] != tag) { stamp[k] = tag; t->postings[cursor[k]++] = (uint32_t)idx; }
-                             });
-    }
+    if (with_kmer_map) build_kmer_map(*t);  // else: bitmaps are built on the GPU from the sequences, or rtx_tree_build_kmer_map later
     flatten(*t);
     *out = t;
     return RTX_OK;
@@ -331,42 +373,76 @@ int rtx_tree_build_ex(uint64_t n, const char *lineage_bytes, const uint64_t *lin
 }
 
 int rtx_tree_parse_reference_fasta(const char *text, uint64_t len, rtx_tree **out) {
+    return rtx_tree_parse_reference_fasta_ex(text, len, 0, out);
+}
+
+int rtx_tree_build_kmer_map(rtx_tree *tree) {
+    if (!tree) { set_error("null argument"); return RTX_ERR_INVALID; }
+    try {
+        if (tree->csr_off.empty()) build_kmer_map(*tree);
+        return RTX_OK;
+    } catch (const std::bad_alloc &) {
+        set_error("out of host memory");
+        return RTX_ERR_OOM;
+    }
+}
+
+int rtx_tree_parse_reference_fasta_ex(const char *text, uint64_t len, uint32_t flags, rtx_tree **out) {
     if (!out) { set_error("null argument"); return RTX_ERR_INVALID; }
     if (!text || len == 0) { set_error("File is empty"); return RTX_ERR_PARSE; }  // parser.rs:47-49
     try {
-        auto lines = fasta_lines(text, len);
-        if (lines.empty() || lines[0][0] != '>') { set_error("Not a valid FASTA file"); return RTX_ERR_PARSE; }
-        std::vector<std::string> labels;
-        std::vector<uint8_t> bytes, cur;
-        std::vector<uint64_t> off{0};
-        for (std::string_view line : lines) {
-            if (line[0] == '>') {
-                std::string_view tax;
-                if (!find_tax(line.substr(1), tax)) {
-                    set_error("Unexpected taxonomical annotation detected in label %.*s", (int)line.size() - 1, line.data() + 1);
-                    return RTX_ERR_PARSE;
-                }
-                labels.emplace_back(tax);
-                if (!cur.empty()) {  // parser.rs:80-83
-                    bytes.insert(bytes.end(), cur.begin(), cur.end());
-                    off.push_back(bytes.size());
-                    cur.clear();
-                }
-            } else {
-                for (char ch : line) {
-                    uint8_t c = map_dna_char((unsigned char)ch);
-                    if (c == 0xFF) { set_error("Unexpected character: %c", ch); return RTX_ERR_PARSE; }
-                    cur.push_back(c);
+        // the file is cut at header lines into pieces that are parsed in parallel with the reference's
+        // line rules (parser.rs:53-98); a sequence is attached when the next header (or the end) is reached
+        const std::vector<uint64_t> cuts = fasta_cuts(text, len, parse_threads(len));
+        const size_t np = cuts.size() - 1;
+        std::vector<FastaPiece> pieces(np);
+        auto parse_piece = [&](size_t pi) {
+            FastaPiece &P = pieces[pi];
+            const bool last = pi + 1 == np;
+            auto lines = fasta_lines(text + cuts[pi], cuts[pi + 1] - cuts[pi]);
+            if (pi == 0 && (lines.empty() || lines[0][0] != '>')) { P.err = "Not a valid FASTA file"; return; }
+            std::vector<uint8_t> cur;
+            P.off.push_back(0);
+            auto push = [&]() {
+                P.bytes.insert(P.bytes.end(), cur.begin(), cur.end());
+                P.off.push_back(P.bytes.size());
+                cur.clear();
+            };
+            for (std::string_view line : lines) {
+                if (line[0] == '>') {
+                    std::string_view tax;
+                    if (!find_tax(line.substr(1), tax)) {
+                        P.err = "Unexpected taxonomical annotation detected in label " + std::string(line.substr(1));
+                        return;
+                    }
+                    P.labels.emplace_back(tax);
+                    if (!cur.empty()) push();  // parser.rs:80-83
+                } else {
+                    for (char ch : line) {
+                        uint8_t c = map_dna_char((unsigned char)ch);
+                        if (c == 0xFF) { P.err = std::string("Unexpected character: ") + ch; return; }
+                        cur.push_back(c);
+                    }
                 }
             }
+            if (last || !cur.empty()) push();  // parser.rs:98 (a later piece starts with a header)
+        };
+        run_pieces(np, parse_piece);
+        std::vector<std::string> labels;
+        std::vector<uint8_t> bytes;
+        std::vector<uint64_t> off{0};
+        for (FastaPiece &P : pieces) {
+            if (!P.err.empty()) { set_error("%s", P.err.c_str()); return RTX_ERR_PARSE; }
+            for (std::string &l : P.labels) labels.push_back(std::move(l));
+            const uint64_t base = bytes.size();
+            bytes.insert(bytes.end(), P.bytes.begin(), P.bytes.end());
+            for (size_t i = 1; i < P.off.size(); i++) off.push_back(base + P.off[i]);
         }
-        bytes.insert(bytes.end(), cur.begin(), cur.end());  // parser.rs:98
-        off.push_back(bytes.size());
         if (labels.size() != off.size() - 1) {
             set_error("Number of sequences does not match number of labels");
             return RTX_ERR_PARSE;
         }
-        return build_tree(std::move(labels), bytes.data(), off.data(), out);
+        return build_tree(std::move(labels), bytes.data(), off.data(), out, !(flags & RTX_TREE_SKIP_KMER_MAP));
     } catch (const std::bad_alloc &) {
         set_error("out of host memory");
         return RTX_ERR_OOM;
@@ -432,32 +508,50 @@ int rtx_queries_parse_fasta(const char *text, uint64_t len, const char *const *s
     if (!out) { set_error("null argument"); return RTX_ERR_INVALID; }
     if (!text || len == 0) { set_error("File is empty"); return RTX_ERR_PARSE; }
     try {
-        auto lines = fasta_lines(text, len);
-        if (lines.empty() || lines[0][0] != '>') { set_error("Not a valid FASTA file"); return RTX_ERR_PARSE; }
         std::unordered_map<std::string_view, int> skipset;
         for (uint64_t i = 0; i < n_skip; i++) skipset.emplace(skip[i], 1);
-        auto q = new rtx_queries();
-        std::string cur_label;
-        std::vector<uint8_t> cur;
-        auto push = [&]() {  // parser.rs:139,149-153
-            if (skipset.count(cur_label)) return;
-            q->labels.push_back(cur_label);
-            q->bases.insert(q->bases.end(), cur.begin(), cur.end());
-            q->base_off.push_back(q->bases.size());
-        };
-        for (std::string_view line : lines) {
-            if (line[0] == '>') {
-                if (!cur.empty()) { push(); cur.clear(); }
-                cur_label.assign(line.substr(1));
-            } else {
-                for (char ch : line) {
-                    uint8_t c = map_dna_char((unsigned char)ch);
-                    if (c == 0xFF) { set_error("Unexpected character: %c", ch); delete q; return RTX_ERR_PARSE; }
-                    cur.push_back(c);
+        // pieces cut at header lines, parsed in parallel with the reference's rules (parser.rs:124-153): a record
+        // is pushed when the next header arrives, but only if it has bases; the very last record always is
+        const std::vector<uint64_t> cuts = fasta_cuts(text, len, parse_threads(len));
+        const size_t np = cuts.size() - 1;
+        std::vector<FastaPiece> pieces(np);
+        auto parse_piece = [&](size_t pi) {
+            FastaPiece &P = pieces[pi];
+            const bool last = pi + 1 == np;
+            auto lines = fasta_lines(text + cuts[pi], cuts[pi + 1] - cuts[pi]);
+            if (pi == 0 && (lines.empty() || lines[0][0] != '>')) { P.err = "Not a valid FASTA file"; return; }
+            std::string cur_label;
+            std::vector<uint8_t> cur;
+            P.off.push_back(0);
+            auto push = [&]() {  // parser.rs:139,149-153
+                if (skipset.count(cur_label)) return;
+                P.labels.push_back(cur_label);
+                P.bytes.insert(P.bytes.end(), cur.begin(), cur.end());
+                P.off.push_back(P.bytes.size());
+            };
+            for (std::string_view line : lines) {
+                if (line[0] == '>') {
+                    if (!cur.empty()) { push(); cur.clear(); }
+                    cur_label.assign(line.substr(1));
+                } else {
+                    for (char ch : line) {
+                        uint8_t c = map_dna_char((unsigned char)ch);
+                        if (c == 0xFF) { P.err = std::string("Unexpected character: ") + ch; return; }
+                        cur.push_back(c);
+                    }
                 }
             }
+            if (last || !cur.empty()) push();  // a header without bases is overwritten by the next header
+        };
+        run_pieces(np, parse_piece);
+        auto q = new rtx_queries();
+        for (FastaPiece &P : pieces) {
+            if (!P.err.empty()) { set_error("%s", P.err.c_str()); delete q; return RTX_ERR_PARSE; }
+            for (std::string &l : P.labels) q->labels.push_back(std::move(l));
+            const uint64_t base = q->bases.size();
+            q->bases.insert(q->bases.end(), P.bytes.begin(), P.bytes.end());
+            for (size_t i = 1; i < P.off.size(); i++) q->base_off.push_back(base + P.off[i]);
         }
-        push();
         *out = q;
         return RTX_OK;
     } catch (const std::bad_alloc &) {

@@ -138,3 +138,49 @@ def test_native_result_pack_equals_python_pack():
     assert np.array_equal(buf, want)
     back = dist_util.unpack_records(buf)
     assert np.array_equal(np.diff(back["row_off"]), count)
+
+
+def _messy_fasta(n_records, seed, reference):
+    """Several MiB of FASTA with everything the line rules of parser.rs have to cope with: wrapped sequences,
+    blank and ';' comment lines, CRLF, indented headers, headers without bases (queries only), lower case,
+    ambiguity codes.  Large enough to be cut into several pieces by the parallel parsers."""
+    rng = np.random.default_rng(seed)
+    letters = np.frombuffer(b"ACGTacgtNRYKMSWBDHV", dtype=np.uint8)
+    out = []
+    for i in range(n_records):
+        head = f">r{i};tax=p:P{i % 7},c:C{i % 31},s:S{i % 997};" if reference else f">q{i} some description"
+        if rng.random() < 0.02:
+            head = "  " + head + "  "
+        out.append(head + ("\r" if rng.random() < 0.1 else ""))
+        if not reference and rng.random() < 0.01:
+            continue                                        # header without bases: replaced by the next header
+        L = int(rng.integers(200, 700))
+        seq = letters[rng.integers(0, len(letters) if rng.random() < 0.05 else 4, L)].tobytes().decode()
+        w = int(rng.integers(40, 120))
+        for a in range(0, L, w):
+            out.append(seq[a:a + w] + ("\r" if rng.random() < 0.02 else ""))
+            if rng.random() < 0.01:
+                out.append("")
+            if rng.random() < 0.01:
+                out.append("; a comment >with a bracket")
+    return "\n".join(out) + "\n"
+
+
+def test_parallel_fasta_parsers_equal_the_serial_oracle(oracle):
+    """rtx_queries_parse_fasta / rtx_tree_parse_reference_fasta cut large inputs at header lines and parse the
+    pieces on several threads; the result must be what the reference's sequential rules give (oracle)."""
+    qtext = _messy_fasta(12000, 1, reference=False)
+    assert len(qtext) > 4 << 20
+    want = oracle.parse_query_fasta_str(qtext, ["q5", "q11999"])
+    got = rx.parse_query_fasta_str(qtext, ["q5", "q11999"])
+    assert len(got) == len(want) > 11000
+    for (gl, gs), (wl, ws) in zip(got, want):
+        assert gl == wl and np.array_equal(gs, ws)
+    rtext = _messy_fasta(9000, 2, reference=True)
+    assert len(rtext) > 3 << 20
+    otree = oracle.parse_reference_fasta_str(rtext)
+    tree = rx.parse_reference_fasta_str(rtext)
+    assert tree.num_tips == otree.num_tips and tree.lineages == otree.lineages
+    off, post = tree.csr()
+    ooff, opost = otree.csr()
+    assert np.array_equal(off, ooff) and np.array_equal(post, opost)

@@ -80,6 +80,7 @@ __global__ __launch_bounds__(256) void prob_lookup_kernel(ProbParams p, ProbTabl
     uint16_t *row_m = reinterpret_cast<uint16_t *>(row_h + (p.tmax + 18));
     uint16_t *row_sat = row_m + (p.tmax + 18);
     uint16_t *ms = row_sat + (p.tmax + 18);
+    uint32_t *hl = reinterpret_cast<uint32_t *>(ms + ((p.tmax + 18 + 1) & ~1u));  // [tmax+2] histogram copy
     const uint32_t *hist = p.hist + (size_t)q * p.hstride;
     double *tz = p.table_z + (size_t)q * p.hstride;
     const double *lf = p.lnfact;
@@ -88,11 +89,13 @@ __global__ __launch_bounds__(256) void prob_lookup_kernel(ProbParams p, ProbTabl
         if (tid == 0) { p.status[gq] = RTX_Q_NO_KMERS; p.z[gq] = 0.0; p.gs[gq] = 0.0; }
         return;
     }
+    for (uint32_t m = tid; m <= t; m += 256) hl[m] = hist[m];  // one coalesced round instead of a chain of loads
+    __syncthreads();
     if (wave == 0) {  // distinct counts, ascending
         uint32_t D = 0;
         for (uint32_t m0 = 0; m0 <= t; m0 += 64) {
             const uint32_t m = m0 + lane;
-            const bool has = m <= t && hist[m] != 0;
+            const bool has = m <= t && hl[m] != 0;
             const unsigned long long bal = __ballot(has);
             if (has) ms[D + __popcll(bal & ((1ull << lane) - 1ull))] = (uint16_t)m;
             D += (uint32_t)__popcll(bal);
@@ -118,6 +121,12 @@ __global__ __launch_bounds__(256) void prob_lookup_kernel(ProbParams p, ProbTabl
         const double *Ct = tb.cmf + tb.off[t];
         const double *Rt = tb.ratio + tb.off[t];
         const uint32_t i_lo = M > 0 ? t_ilo[M] : 0u;
+        // saturation index of every distinct count, gathered by all threads at once (row_h as staging)
+        for (uint32_t j = tid; j < D; j += 256) {
+            const uint32_t m = ms[D - 1 - j];
+            row_h[j] = m ? t_sat[m] : 0u;
+        }
+        __syncthreads();
         // rows still moving at i_lo, in descending order of m; everything else gets table = 0
         if (wave == 0) {
             uint32_t na = 0;
@@ -126,7 +135,7 @@ __global__ __launch_bounds__(256) void prob_lookup_kernel(ProbParams p, ProbTabl
                 uint32_t m = 0, sat = 0;
                 if (j < D) {
                     m = ms[D - 1 - j];
-                    sat = m ? t_sat[m] : 0u;
+                    sat = row_h[j];
                     if (m && sat <= i_lo) tz[m] = 0.0;
                 }
                 const bool keep = m != 0 && sat > i_lo;
@@ -135,7 +144,7 @@ __global__ __launch_bounds__(256) void prob_lookup_kernel(ProbParams p, ProbTabl
                     const uint32_t pos = na + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
                     row_m[pos] = (uint16_t)m;
                     row_sat[pos] = (uint16_t)sat;
-                    row_h[pos] = hist[m];
+                    row_h[pos] = hl[m];  // pos <= j: the staged entries still needed lie at indices > j
                 }
                 na += (uint32_t)__popcll(bal);
             }
@@ -210,7 +219,7 @@ __global__ __launch_bounds__(256) void prob_lookup_kernel(ProbParams p, ProbTabl
     double part = 0.0;
     for (uint32_t j = tid; j < D; j += 256) {
         const uint32_t m = ms[j];
-        part += (double)hist[m] * tz[m];
+        part += (double)hl[m] * tz[m];
     }
     part = wave_sum_f64_dpp(part);
     if (lane == 0) red[wave] = part;
@@ -224,7 +233,7 @@ __global__ __launch_bounds__(256) void prob_lookup_kernel(ProbParams p, ProbTabl
         const double v = tz[m] / Z;  // prob.rs:99-102
         tz[m] = v;
         const double d = v - inv_n;
-        gsum += (double)hist[m] * d * d;
+        gsum += (double)hl[m] * d * d;
     }
     gsum = wave_sum_f64_dpp(gsum);
     if (lane == 0) red[8 + wave] = gsum;
@@ -267,7 +276,8 @@ __global__ __launch_bounds__(1024) void prob_order_kernel(const uint32_t *__rest
 // ---------------------------------------------------------------------------
 size_t prob_lookup_lds_bytes(uint32_t tmax) {
     const size_t n1max = tmax / 2 + 1;
-    return sizeof(double) * (n1max + 16) + (sizeof(uint32_t) + 3 * sizeof(uint16_t)) * ((size_t)tmax + 18) + 8;
+    return sizeof(double) * (n1max + 16) + (sizeof(uint32_t) + 3 * sizeof(uint16_t)) * ((size_t)tmax + 18) + 8 +
+           sizeof(uint32_t) * ((size_t)tmax + 4);
 }
 void launch_prob_tables_build(hipStream_t s, const ProbTables &tb, const double *lf, const double *inv) {
     hipLaunchKernelGGL(prob_tables_build_kernel, dim3((tb.tmax + 255) / 256, tb.tmax - 1), dim3(256), 0, s, tb, lf, inv);

@@ -142,17 +142,21 @@ __global__ __launch_bounds__(64) void kmer_extract_kernel(KmerParams p) {
     }
     __syncthreads();
 
-    for (uint64_t w = lane; w + 8 <= len; w += 64) {
-        uint32_t k = 0;
-        bool ok = true;
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            const uint32_t c = seq[w + j];
-            // one-hot nibble {1,2,4,8} -> {0,1,2,3}; everything else invalidates the window
-            ok = ok && (c == 1u || c == 2u || c == 4u || c == 8u);
-            k |= ((uint32_t)__ffs((int)c) - 1u) << (14 - 2 * j);
+    if (len >= 8) {
+        // lane l rolls over the windows [l*wpl, (l+1)*wpl): wpl + 7 sequential byte reads instead of 8 per window
+        const uint64_t nwin = len - 7;
+        const uint64_t wpl = (nwin + 63) / 64;
+        const uint64_t w0 = (uint64_t)lane * wpl;
+        const uint64_t w1 = w0 + wpl < nwin ? w0 + wpl : nwin;
+        uint32_t k = 0, run = 0;  // run: consecutive valid bases ending here
+        for (uint64_t i = w0; w0 < w1 && i < w1 + 7; i++) {
+            const uint32_t c = seq[i];
+            // one-hot nibble {1,2,4,8} -> {0,1,2,3}; everything else invalidates the windows that contain it
+            const bool ok = c == 1u || c == 2u || c == 4u || c == 8u;
+            k = ((k << 2) | (((uint32_t)__ffs((int)c) - 1u) & 3u)) & 0xFFFFu;  // first base of the window in bits 15:14
+            run = ok ? run + 1u : 0u;
+            if (run >= 8u) atomicOr(&bm[k >> 5], 1u << (k & 31u));
         }
-        if (ok) atomicOr(&bm[(k & 0xFFFFu) >> 5], 1u << (k & 31u));
     }
     __syncthreads();
 

@@ -12,13 +12,17 @@ namespace rtx {
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
 
+// Inclusive scan over the 64 lanes: DPP row shifts inside each row of 16 lanes (zero fill at the row start),
+// then the three row totals through v_readlane -- no LDS round trips (six ds_bpermute before).
 __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        uint32_t o = __shfl_up(v, d, 64);
-        if ((int)lane_id() >= d) v += o;
-    }
-    return v;
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true);  // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true);  // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true);  // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true);  // row_shr:8
+    const uint32_t r0 = (uint32_t)__builtin_amdgcn_readlane((int)v, 15), r1 = (uint32_t)__builtin_amdgcn_readlane((int)v, 31),
+                   r2 = (uint32_t)__builtin_amdgcn_readlane((int)v, 47);
+    const uint32_t row = lane_id() >> 4;
+    return v + (row == 0 ? 0u : (row == 1 ? r0 : (row == 2 ? r0 + r1 : r0 + r1 + r2)));
 }
 
 __device__ __forceinline__ double wave_sum_f64(double v) {

@@ -172,9 +172,10 @@ int rtx_index_set_batch(rtx_index *index, uint32_t sub_batch);
 #define RTX_OPT_PROB_MODE 2
 #define RTX_OPT_STAGE_TIMING 6 /* 0 (default): HIP events around hit_count only; 1: around every kernel
                                  (rtx_batch_stage_times then reports all stages; adds ~1 ms per 100k queries) */
-#define RTX_OPT_STREAMS 3 /* 1 (default) = one HIP stream; 2 = hit_count of sub-batch i+1 on one stream beside
-                             prob/prefix/walk of sub-batch i on another (measured slower on MI355X: hit_count
-                             loses its L2 hit rate) */
+#define RTX_OPT_STREAMS 3 /* 1 (default) = one HIP stream; 2 = the two small latency-bound kernels (kmer_extract of
+                             sub-batch i+2, lineage_walk of sub-batch i) run on a side stream beside hit_count of
+                             sub-batch i+1.  Measured: no gain on MI355X (hit_count slows down by what is hidden),
+                             and putting prob/prefix beside hit_count costs it its L2 hit rate */
 #define RTX_OPT_CLUSTER 7 /* 1 (default): the queries of a batch are processed in an order that puts related
                              queries next to each other (min-hash sketches, rtx_cluster.hip) so that bitmap rows
                              are reused; 0: input order.  Results are identical and always in input order. */

@@ -200,7 +200,7 @@ struct rtx_index {
     PinBuf<uint32_t> h_nrows_all, h_n_rows;
     // streamed download: per sub-batch a snapshot of the arena cursor + an event; rtx_batch_download copies and
     // finalises finished sub-batches on `copy_stream` while later ones are still running
-    std::vector<hipEvent_t> ev_sub, ev_cnt;
+    std::vector<hipEvent_t> ev_sub, ev_cnt, ev_pre;
     PinBuf<unsigned long long> h_cursor_sub;
     hipStream_t copy_stream = nullptr;
     uint32_t n_sub_run = 0;
@@ -213,6 +213,7 @@ struct rtx_index {
         for (auto e : events) (void)hipEventDestroy(e);
         for (auto e : ev_sub) (void)hipEventDestroy(e);
         for (auto e : ev_cnt) (void)hipEventDestroy(e);
+        for (auto e : ev_pre) (void)hipEventDestroy(e);
         if (copy_stream) (void)hipStreamDestroy(copy_stream);
         if (ev_fork) (void)hipEventDestroy(ev_fork);
         if (ev_join) (void)hipEventDestroy(ev_join);
@@ -243,8 +244,7 @@ int ensure_events(rtx_index *ix, size_t count) {
 struct SubBatch {
     uint32_t sb, nq, set;
     uint64_t q0;
-    hipStream_t s;   // kmer_extract + hit_count
-    hipStream_t s2;  // prob, taxon_prefix, lineage_walk (a stream of its own with RTX_OPT_STREAMS = 2)
+    hipStream_t s;   // main stream
     bool timed;      // HIP events around hit_count (the roofline kernel)
     bool timed_all;  // ... and around every other kernel (RTX_OPT_STAGE_TIMING)
 };
@@ -256,7 +256,6 @@ SubBatch sub_batch_of(rtx_index *ix, uint32_t sb, bool timed) {
     b.nq = (uint32_t)std::min<uint64_t>(ix->sub_batch, ix->n_q - b.q0);
     b.set = ix->n_streams == 2 ? (sb & 1u) : 0u;
     b.s = ix->stream;
-    b.s2 = ix->n_streams == 2 ? ix->stream2 : ix->stream;
     b.timed = timed;
     b.timed_all = timed && ix->stage_timing != 0;
     return b;
@@ -267,10 +266,8 @@ hipEvent_t stage_event(rtx_index *ix, const SubBatch &b, int stage, int which) {
 }
 
 // group 1: kmer_extract + hit_count -> counts, per-shard histogram
-int enqueue_count(rtx_index *ix, const SubBatch &b, uint32_t flags) {
+int enqueue_kmer(rtx_index *ix, const SubBatch &b, hipStream_t s) {
     rtx_index::Scratch &sc = ix->sc[b.set];
-    hipStream_t s = b.s;
-    ix->last_set = b.set;
     KmerParams kp{};
     kp.bases = ix->d_bases.p;
     kp.base_off = ix->d_base_off.p;
@@ -293,7 +290,12 @@ int enqueue_count(rtx_index *ix, const SubBatch &b, uint32_t flags) {
     if (b.timed_all) RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_KMER_EXTRACT, 0), s));
     launch_kmer_extract(s, kp, b.nq);
     if (b.timed_all) RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_KMER_EXTRACT, 1), s));
+    return RTX_OK;
+}
 
+int enqueue_hit(rtx_index *ix, const SubBatch &b, uint32_t flags, hipStream_t s) {
+    rtx_index::Scratch &sc = ix->sc[b.set];
+    ix->last_set = b.set;
     HitParams hp{};
     hp.bitmap = ix->d_bitmap.p;
     hp.stride_bytes = ix->stride_bytes;
@@ -318,10 +320,15 @@ int enqueue_count(rtx_index *ix, const SubBatch &b, uint32_t flags) {
     return RTX_OK;
 }
 
+int enqueue_count(rtx_index *ix, const SubBatch &b, uint32_t flags) {
+    int rc = enqueue_kmer(ix, b, b.s);
+    return rc ? rc : enqueue_hit(ix, b, flags, b.s);
+}
+
 // group 2: prob table from the (whole-database) histogram + prefix sums over this handle's references
 int enqueue_prob_prefix(rtx_index *ix, const SubBatch &b) {
     rtx_index::Scratch &sc = ix->sc[b.set];
-    hipStream_t s = b.s2;
+    hipStream_t s = b.s;
     ProbParams pp{};
     pp.t = sc.d_t.p;
     pp.hist = sc.d_hist.p;
@@ -368,8 +375,7 @@ int enqueue_prob_prefix(rtx_index *ix, const SubBatch &b) {
 }
 
 // group 3: taxonomy walk over prefix sums covering the WHOLE database ([nq][n_bnd], device)
-int enqueue_walk(rtx_index *ix, const SubBatch &b, const double *prefix) {
-    hipStream_t s = b.s2;
+int enqueue_walk(rtx_index *ix, const SubBatch &b, const double *prefix, hipStream_t s) {
     WalkParams wp{};
     wp.status = ix->d_status.p;
     wp.q0 = b.q0;
@@ -448,18 +454,22 @@ int enqueue_batch(rtx_index *ix, uint32_t flags) {
     bool timed = false;
     int rc = begin_run(ix, &n_sub, &timed, ix->cluster != 0);
     if (rc) return rc;
-    // Two streams (RTX_OPT_STREAMS = 2): hit_count of sub-batch i+1 (bound by the row-load rate) runs beside the
-    // prob/prefix/walk kernels of sub-batch i (f64 VALU, LDS); the two scratch sets alternate.
+    // Two streams (RTX_OPT_STREAMS = 2): the two small latency-bound kernels leave the main stream -- lineage_walk of
+    // sub-batch i and kmer_extract of sub-batch i+2 run on a side stream beside hit_count of sub-batch i+1; the two
+    // scratch sets alternate.  (Their memory footprint is tiny: hit_count keeps its L2 hit rate, unlike with
+    // prob/prefix beside it.)
     const bool two = ix->n_streams == 2;
     ix->stream_dl = false;
     if (n_sub <= 4096) {  // per sub-batch: completion event (+ cursor snapshot) for the streamed download
         if (!ix->copy_stream) RTX_HIP(hipStreamCreateWithFlags(&ix->copy_stream, hipStreamNonBlocking));
-        while (ix->ev_sub.size() < n_sub || ix->ev_cnt.size() < n_sub) {
-            hipEvent_t e, e2;
+        while (ix->ev_sub.size() < n_sub || ix->ev_cnt.size() < n_sub || ix->ev_pre.size() < n_sub) {
+            hipEvent_t e, e2, e3;
             RTX_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
             ix->ev_sub.push_back(e);
             RTX_HIP(hipEventCreateWithFlags(&e2, hipEventDisableTiming));
             ix->ev_cnt.push_back(e2);
+            RTX_HIP(hipEventCreateWithFlags(&e3, hipEventDisableTiming));
+            ix->ev_pre.push_back(e3);
         }
         if ((rc = ix->h_cursor_sub.resize(n_sub))) return rc;
         ix->n_sub_run = n_sub;
@@ -468,26 +478,43 @@ int enqueue_batch(rtx_index *ix, uint32_t flags) {
         set_error("two streams need at most 4096 sub-batches");
         return RTX_ERR_INVALID;
     }
-    if (two) {  // the second stream starts after the resets above
+    hipStream_t side = ix->stream2;
+    if (two) {  // the side stream starts after the resets above; it extracts the k-mers of the first two sub-batches
         RTX_HIP(hipEventRecord(ix->ev_fork, ix->stream));
-        RTX_HIP(hipStreamWaitEvent(ix->stream2, ix->ev_fork, 0));
+        RTX_HIP(hipStreamWaitEvent(side, ix->ev_fork, 0));
+        for (uint32_t sb = 0; sb < n_sub && sb < 2; sb++) {
+            if ((rc = enqueue_kmer(ix, sub_batch_of(ix, sb, timed), side))) return rc;
+            RTX_HIP(hipEventRecord(ix->ev_cnt[sb], side));
+        }
     }
     for (uint32_t sb = 0; sb < n_sub; sb++) {
         const SubBatch b = sub_batch_of(ix, sb, timed);
-        if (two && sb >= 2) RTX_HIP(hipStreamWaitEvent(b.s, ix->ev_sub[sb - 2], 0));  // scratch set free again
-        if ((rc = enqueue_count(ix, b, flags))) return rc;
         if (two) {
-            RTX_HIP(hipEventRecord(ix->ev_cnt[sb], b.s));
-            RTX_HIP(hipStreamWaitEvent(b.s2, ix->ev_cnt[sb], 0));
+            RTX_HIP(hipStreamWaitEvent(b.s, ix->ev_cnt[sb], 0));  // k-mers and row lists of this sub-batch
+            if ((rc = enqueue_hit(ix, b, flags, b.s))) return rc;
+        } else if ((rc = enqueue_count(ix, b, flags))) {
+            return rc;
         }
-        if ((rc = enqueue_prob_prefix(ix, b)) || (rc = enqueue_walk(ix, b, ix->sc[b.set].d_prefix.p))) return rc;
+        if (two && sb >= 2) RTX_HIP(hipStreamWaitEvent(b.s, ix->ev_sub[sb - 2], 0));  // walk(sb-2) still reads this prefix buffer
+        if ((rc = enqueue_prob_prefix(ix, b))) return rc;
+        hipStream_t ws = b.s;
+        if (two) {
+            RTX_HIP(hipEventRecord(ix->ev_pre[sb], b.s));
+            RTX_HIP(hipStreamWaitEvent(side, ix->ev_pre[sb], 0));
+            ws = side;
+        }
+        if ((rc = enqueue_walk(ix, b, ix->sc[b.set].d_prefix.p, ws))) return rc;
         if (ix->stream_dl) {
-            RTX_HIP(hipMemcpyAsync(&ix->h_cursor_sub[sb], ix->d_cursor.p, 8, hipMemcpyDeviceToHost, b.s2));
-            RTX_HIP(hipEventRecord(ix->ev_sub[sb], b.s2));
+            RTX_HIP(hipMemcpyAsync(&ix->h_cursor_sub[sb], ix->d_cursor.p, 8, hipMemcpyDeviceToHost, ws));
+            RTX_HIP(hipEventRecord(ix->ev_sub[sb], ws));
+        }
+        if (two && sb + 2 < n_sub) {  // the scratch set of this sub-batch is free once its prefix is done (ev_pre, waited above)
+            if ((rc = enqueue_kmer(ix, sub_batch_of(ix, sb + 2, timed), side))) return rc;
+            RTX_HIP(hipEventRecord(ix->ev_cnt[sb + 2], side));
         }
     }
-    if (two) {  // everything is complete once the main stream is: join the second stream into it
-        RTX_HIP(hipEventRecord(ix->ev_join, ix->stream2));
+    if (two) {  // everything is complete once the main stream is: join the side stream into it
+        RTX_HIP(hipEventRecord(ix->ev_join, side));
         RTX_HIP(hipStreamWaitEvent(ix->stream, ix->ev_join, 0));
     }
     RTX_HIP(hipGetLastError());
@@ -1247,7 +1274,7 @@ int rtx_shard_walk(rtx_index *ix, uint32_t sb, const double *prefix_global) {
     int rc = shard_sb(ix, sb, &b);
     if (rc) return rc;
     if (!prefix_global) { set_error("rtx_shard_walk: null prefix"); return RTX_ERR_INVALID; }
-    return enqueue_walk(ix, b, prefix_global);
+    return enqueue_walk(ix, b, prefix_global, b.s);
 }
 
 int rtx_shard_info(const rtx_index *ix, uint64_t *ref_lo, uint64_t *ref_hi, uint32_t *n_bnd_global, uint32_t *n_bnd_local,

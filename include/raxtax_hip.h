@@ -180,6 +180,12 @@ int rtx_index_set_batch(rtx_index *index, uint32_t sub_batch);
                              queries next to each other (min-hash sketches, rtx_cluster.hip) so that bitmap rows
                              are reused; 0: input order.  Results are identical and always in input order. */
 int rtx_index_set_option(rtx_index *index, int option, uint64_t value);
+/* Process-wide default for handles created afterwards.  RTX_DEFAULT_SEGMENT_CLASSES (default 1): at index creation
+ * every (row, tile) segment of the bitmaps is classified; empty segments are never read and segments with at most
+ * 16 references are added from 32-byte slots through byte counters instead of 1-KiB row reads (rtx_segments.hip).
+ * 0: every segment is read densely (for A/B measurements; results are identical). */
+#define RTX_DEFAULT_SEGMENT_CLASSES 1
+int rtx_set_default_option(int option, uint64_t value);
 
 /* ------------------------------------------------------------------------- */
 /* Classification: the body of raxtax(), src/raxtax.rs:39-84, minus string    */

@@ -213,9 +213,10 @@ class Index:
     """Device-resident index + batch workspace of one GPU (rtx_index)."""
 
     def __init__(self, tree: Tree, device: int = 0, sub_batch: int = 0, prob_mode: int = 0, streams: int = 0,
-                 stage_timing: bool = False, cluster: Optional[bool] = None):
+                 stage_timing: bool = False, cluster: Optional[bool] = None, segment_classes: bool = True):
         self._lib = _lib.load()
         self.tree = tree
+        check(self._lib.rtx_set_default_option(1, int(segment_classes)))   # creation-time default of the library
         h = C.c_void_p()
         check(self._lib.rtx_index_create_from_tree(device, tree._h, C.byref(h)))
         self._h = h

@@ -127,6 +127,11 @@ struct rtx_index {
     uint64_t npad = 0;          // references per padded row (= stride_bytes * 8)
     uint32_t ntiles = 0;        // 8192-reference tiles
     DevBuf<uint32_t> d_bitmap, d_row_of, d_list_len;
+    // segment classes (rtx_segments.hip): class / sparse slot of every (row, tile) segment, slots of 32 local ids
+    DevBuf<uint32_t> d_seginfo;
+    DevBuf<uint16_t> d_segslots;
+    uint64_t n_seg_slots = 0;
+    uint32_t seg_stride = 0;
     DevBuf<double> d_lnfact, d_inv;
     // ---- memoised prob tables (t <= 1023), built lazily for the largest tmax seen
     int prob_mode = 0;  // 0 auto, 1 recurrence kernel only, 2 tables (error if they do not fit)
@@ -163,7 +168,8 @@ struct rtx_index {
     uint32_t sub_batch_req = 0, sub_batch = 0;
     struct Scratch {
         DevBuf<uint16_t> d_kmers, d_counts;
-        DevBuf<uint32_t> d_rows, d_t, d_nrows, d_hist, d_order;
+        DevBuf<uint32_t> d_rows, d_t, d_nrows, d_hist, d_order, d_ndense, d_srows, d_nsparse;
+        DevBuf<unsigned long long> d_dmask;
         DevBuf<double> d_table_z, d_prefix;
     } sc[2];
     uint32_t n_streams_req = 1, n_streams = 1;
@@ -278,8 +284,16 @@ int enqueue_kmer(rtx_index *ix, const SubBatch &b, hipStream_t s) {
     kp.zero_row = ix->n_rows;
     kp.kmers = sc.d_kmers.p;
     kp.kstride = ix->kstride;
+    kp.seginfo = ix->d_seginfo.p;
+    kp.seg_stride = ix->seg_stride;
+    kp.ntiles = ix->ntiles;
+    kp.last_tile_full = ix->stride_bytes % 1024u == 0 ? 1u : 0u;
     kp.rows = sc.d_rows.p;
     kp.rstride = ix->rstride;
+    kp.dmask = sc.d_dmask.p;
+    kp.ndense = sc.d_ndense.p;
+    kp.srows = sc.d_srows.p;
+    kp.nsparse = sc.d_nsparse.p;
     kp.t = sc.d_t.p;
     kp.nrows = sc.d_nrows.p;
     kp.hq = ix->d_hq.p;
@@ -303,7 +317,14 @@ int enqueue_hit(rtx_index *ix, const SubBatch &b, uint32_t flags, hipStream_t s)
     hp.ref_base = ix->ref_lo;
     hp.rows = sc.d_rows.p;
     hp.rstride = ix->rstride;
+    hp.dmask = sc.d_dmask.p;
+    hp.ndense = sc.d_ndense.p;
     hp.nrows = sc.d_nrows.p;
+    hp.zero_row = ix->n_rows;
+    hp.srows = sc.d_srows.p;
+    hp.nsparse = sc.d_nsparse.p;
+    hp.segslots = ix->d_segslots.p;
+    hp.ntiles = ix->ntiles;
     hp.t = sc.d_t.p;
     hp.counts = sc.d_counts.p;
     hp.npad = ix->npad;
@@ -578,7 +599,7 @@ int prepare_workspace(rtx_index *ix, uint64_t n_queries, uint64_t tmax, uint64_t
     }
     ix->tmax = (uint32_t)tmax;
     ix->kstride = (uint32_t)align_up(tmax, 8);
-    ix->rstride = (uint32_t)align_up(tmax, 32) + 32;
+    ix->rstride = (uint32_t)align_up(tmax, 64) + 64;  // row list padded to whole 64-row chunks
     ix->hstride = (uint32_t)align_up(tmax + 1, 8);
     ix->planes = tmax <= 1023 ? 10 : (tmax <= 4095 ? 12 : 16);
     ix->n_q = n_queries;
@@ -601,7 +622,7 @@ int prepare_workspace(rtx_index *ix, uint64_t n_queries, uint64_t tmax, uint64_t
         RTX_HIP(hipEventCreateWithFlags(&ix->ev_fork, hipEventDisableTiming));
         RTX_HIP(hipEventCreateWithFlags(&ix->ev_join, hipEventDisableTiming));
     }
-    const uint64_t per_q = ((uint64_t)ix->kstride * 2 + (uint64_t)ix->rstride * 4 + ix->npad * 2 + (uint64_t)ix->hstride * 12 +
+    const uint64_t per_q = ((uint64_t)ix->kstride * 2 + (uint64_t)ix->rstride * 4 + (uint64_t)ix->ntiles * (ix->rstride / 8 + (kSegMaxSparseRows + 1) * 4 + 8) + ix->npad * 2 + (uint64_t)ix->hstride * 12 +
                             (uint64_t)ix->n_bnd_local * 8 + 64) * ix->n_streams;
     uint32_t B = ix->sub_batch_req;
     if (B == 0) {
@@ -617,7 +638,8 @@ int prepare_workspace(rtx_index *ix, uint64_t n_queries, uint64_t tmax, uint64_t
     ix->sub_batch = B;
     for (uint32_t k = 0; k < ix->n_streams; k++) {
         rtx_index::Scratch &sc = ix->sc[k];
-        if ((rc = sc.d_kmers.alloc((size_t)B * ix->kstride)) || (rc = sc.d_rows.alloc((size_t)B * ix->rstride)) ||
+        if ((rc = sc.d_kmers.alloc((size_t)B * ix->kstride)) || (rc = sc.d_rows.alloc((size_t)B * ix->rstride)) || (rc = sc.d_dmask.alloc((size_t)B * ix->ntiles * (ix->rstride / 64))) || (rc = sc.d_ndense.alloc((size_t)B * ix->ntiles)) ||
+            (rc = sc.d_nsparse.alloc((size_t)B * ix->ntiles)) || (rc = sc.d_srows.alloc((size_t)B * ix->ntiles * (kSegMaxSparseRows + 1))) ||
             (rc = sc.d_t.alloc(B)) || (rc = sc.d_nrows.alloc(B)) || (rc = sc.d_counts.alloc((size_t)B * ix->npad)) ||
             (rc = sc.d_hist.alloc((size_t)B * ix->hstride)) || (rc = sc.d_table_z.alloc((size_t)B * ix->hstride)) ||
             (rc = sc.d_prefix.alloc((size_t)B * ix->n_bnd_local)) || (rc = sc.d_order.alloc(B)))
@@ -857,6 +879,48 @@ int rtx_index_create_shard(int device, uint64_t n_refs_total, uint64_t ref_lo, u
                            node_end, node_first_child, node_n_children, node_type, out);
 }
 
+// RTX_DEFAULT_SEGMENT_CLASSES (rtx_set_default_option): 0 = every segment is read densely (A/B measurements)
+static uint64_t g_seg_classes = 1;
+
+// Classifies every (row, tile) segment of the finished bitmap as empty / dense / sparse and writes the slots of the
+// sparse ones (rtx_segments.hip).  Slots are numbered in (row, tile) order: deterministic.
+static int build_segments(rtx_index *ix) {
+    const uint32_t n_rows1 = ix->n_rows + 1, nt = ix->ntiles;
+    const uint32_t ss = (nt + 3u) & ~3u;  // seginfo rows padded to whole uint4
+    ix->seg_stride = ss;
+    const size_t n = (size_t)n_rows1 * nt;
+    const bool sparse_on = g_seg_classes != 0, empty_on = g_seg_classes != 0;
+    DevBuf<uint16_t> d_pop;
+    int rc;
+    if ((rc = d_pop.alloc(n)) || (rc = ix->d_seginfo.alloc((size_t)n_rows1 * ss))) return rc;
+    launch_seg_popcount(ix->stream, ix->d_bitmap.p, ix->stride_bytes, n_rows1, nt, d_pop.p);
+    RTX_HIP(hipGetLastError());
+    RTX_HIP(hipStreamSynchronize(ix->stream));
+    std::vector<uint16_t> pop(n);
+    RTX_HIP(hipMemcpy(pop.data(), d_pop.p, n * 2, hipMemcpyDeviceToHost));
+    std::vector<uint32_t> info((size_t)n_rows1 * ss, 0u);
+    uint64_t slots = 0;
+    for (uint32_t r = 0; r < n_rows1; r++)
+        for (uint32_t t = 0; t < nt; t++) {
+            const uint32_t c = pop[(size_t)r * nt + t];
+            uint32_t &o = info[(size_t)r * ss + t];
+            if (c == 0) o = empty_on ? 0u : 1u;
+            else if (c <= kSegSparseMax && sparse_on) o = (uint32_t)(2 + slots++);
+            else o = 1u;
+        }
+    if (slots > 0xFFFFFFF0ull) { set_error("too many sparse segments"); return RTX_ERR_INVALID; }
+    ix->n_seg_slots = slots;
+    if ((rc = ix->d_segslots.alloc((slots ? slots : 1) * kSegSlotEntries))) return rc;
+    RTX_HIP(hipMemset(ix->d_segslots.p, 0xFF, (slots ? slots : 1) * kSegSlotEntries * 2));
+    RTX_HIP(hipMemcpy(ix->d_seginfo.p, info.data(), info.size() * 4, hipMemcpyHostToDevice));
+    if (slots) {
+        launch_seg_emit(ix->stream, ix->d_bitmap.p, ix->stride_bytes, n_rows1, nt, ix->d_seginfo.p, ss, ix->d_segslots.p);
+        RTX_HIP(hipGetLastError());
+        RTX_HIP(hipStreamSynchronize(ix->stream));
+    }
+    return RTX_OK;
+}
+
 static int create_from_csr(int device, uint64_t n_total, uint64_t ref_lo, uint64_t ref_hi, const uint64_t *cuts,
                            uint32_t n_cuts, const uint64_t *offsets, const uint32_t *postings, uint32_t n_nodes,
                            const uint32_t *node_begin, const uint32_t *node_end, const uint32_t *node_first_child,
@@ -902,6 +966,7 @@ static int create_from_csr(int device, uint64_t n_total, uint64_t ref_lo, uint64
         }
         if (e != hipSuccess) { set_error("bitmap build failed: %s", hipGetErrorString(e)); return fail(RTX_ERR_HIP); }
     }
+    if ((rc = build_segments(ix))) return fail(rc);
     *out = ix;
     return RTX_OK;
 }
@@ -951,6 +1016,7 @@ int rtx_index_create_from_sequences(int device, uint64_t n_refs, const uint8_t *
         e = hipStreamSynchronize(ix->stream);
     }
     if (e != hipSuccess) { set_error("bitmap build from sequences failed: %s", hipGetErrorString(e)); return fail(RTX_ERR_HIP); }
+    if ((rc = build_segments(ix))) return fail(rc);
     *out = ix;
     return RTX_OK;
 }
@@ -975,13 +1041,19 @@ void rtx_index_destroy(rtx_index *index) {
 uint64_t rtx_index_num_refs(const rtx_index *index) { return index ? index->n_total : 0; }
 uint64_t rtx_index_device_bytes(const rtx_index *index) {
     if (!index) return 0;
-    return index->d_bitmap.n * 4 + index->d_row_of.n * 4 + index->d_list_len.n * 4 + index->d_lnfact.n * 8 +
+    return index->d_seginfo.n * 4 + index->d_segslots.n * 2 + index->d_bitmap.n * 4 + index->d_row_of.n * 4 + index->d_list_len.n * 4 + index->d_lnfact.n * 8 +
            index->d_blo.n * 4 * 4 + index->d_type.n + index->d_bnd_bits.n + index->d_bnd_rank.n * 4;
 }
 int rtx_index_set_batch(rtx_index *index, uint32_t sub_batch) {
     if (!index) { set_error("null index handle"); return RTX_ERR_INVALID; }
     index->sub_batch_req = sub_batch;
     return RTX_OK;
+}
+
+int rtx_set_default_option(int option, uint64_t value) {
+    if (option == RTX_DEFAULT_SEGMENT_CLASSES) { g_seg_classes = value ? 1 : 0; return RTX_OK; }
+    set_error("rtx_set_default_option: unknown option %d", option);
+    return RTX_ERR_INVALID;
 }
 
 int rtx_index_set_option(rtx_index *index, int option, uint64_t value) {
@@ -1328,7 +1400,7 @@ int rtx_batch_work(rtx_index *ix, uint64_t *sum_hits, uint64_t *sum_query_bytes,
     RTX_HIP(hipMemcpy(ix->h_hq.data(), ix->d_hq.p, ix->n_q * 8, hipMemcpyDeviceToHost));
     RTX_HIP(hipMemcpy(ix->h_nrows_all.data(), ix->d_nrows_all.p, ix->n_q * 4, hipMemcpyDeviceToHost));
     uint64_t h = 0, b = 0;
-    const uint64_t row_bytes = (ix->n_refs + 7) / 8;
+    const uint64_t row_bytes = ((ix->n_refs + 7) / 8 + ix->ntiles - 1) / ix->ntiles;  // per dense segment (nrows counts segments)
     for (uint64_t q = 0; q < ix->n_q; q++) {
         h += ix->h_hq[q];
         b += (uint64_t)ix->h_nrows_all[q] * row_bytes;

@@ -180,11 +180,12 @@ __global__ __launch_bounds__(64) void kmer_extract_kernel(KmerParams p) {
     const uint32_t t = base;
     __syncthreads();  // kout visible to the whole wave
 
-    // rows of k-mers present in the index, in ascending k-mer order
+    // rows of the k-mers present in the index, in ascending k-mer order (the query's row list, shared by all tiles)
     uint32_t *rout = p.rows + (size_t)q * p.rstride;
     uint32_t nrows = 0;
     unsigned long long hq = 0;
     const uint32_t tt = t < p.kstride ? t : p.kstride;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
     for (uint32_t i0 = 0; i0 < tt; i0 += 64) {
         const uint32_t i = i0 + lane;
         uint32_t row = kEmptyRow;
@@ -194,19 +195,63 @@ __global__ __launch_bounds__(64) void kmer_extract_kernel(KmerParams p) {
             hq += p.list_len[k];
         }
         const unsigned long long m = __ballot(row != kEmptyRow);
-        if (row != kEmptyRow) rout[nrows + __popcll(m & ((1ull << lane) - 1ull))] = row;
+        if (row != kEmptyRow) rout[nrows + __popcll(m & lt_mask)] = row;
         nrows += (uint32_t)__popcll(m);
     }
-    const uint32_t padded = ((nrows + 31u) & ~31u) + 8u;
-    for (uint32_t i = nrows + lane; i < padded; i += 64) rout[i] = p.zero_row;
+    const uint32_t nchunks = (nrows + 63u) >> 6;
+    for (uint32_t i = nrows + lane; i < nchunks * 64u; i += 64) rout[i] = p.zero_row;
+    __syncthreads();  // rout visible to the whole wave
+    // Per tile: which rows have a dense segment there (a 64-bit mask per 64 rows), and the slots of the sparse
+    // segments; empty segments are dropped (rtx_segments.hip).
+    const uint32_t nt = p.ntiles;
+    const uint32_t mstride = p.rstride >> 6;
+    unsigned long long *dm = p.dmask + (size_t)q * nt * mstride;
+    uint32_t *sout = p.srows + (size_t)q * nt * (kSegMaxSparseRows + 1);
+    const bool all_dense = nrows + 64u > kHitListCap;  // see kHitListCap
+    uint32_t nseg = 0;
+    for (uint32_t tb = 0; tb < nt; tb += 64) {  // 64 tiles at a time: lane l keeps the counters of tile tb + l
+        const uint32_t te = tb + 64 < nt ? tb + 64 : nt;
+        uint32_t cd = 0, cs = 0;
+        for (uint32_t c = 0; c < nchunks; c++) {
+            const uint32_t i = c * 64 + lane;
+            const uint32_t row = i < nrows ? rout[i] : kEmptyRow;
+            // seginfo rows are padded to whole uint4: four tiles per (gather) load
+            const uint4 *info = reinterpret_cast<const uint4 *>(p.seginfo + (size_t)(row == kEmptyRow ? 0u : row) * p.seg_stride);
+            uint4 iv = make_uint4(0, 0, 0, 0);
+            for (uint32_t tile = tb; tile < te; tile++) {
+                if ((tile & 3u) == 0) iv = info[tile >> 2];
+                const uint32_t word = (tile & 3u) == 0 ? iv.x : (tile & 3u) == 1 ? iv.y : (tile & 3u) == 2 ? iv.z : iv.w;
+                const uint32_t code = all_dense ? 1u : (row != kEmptyRow ? word : 0u);  // all_dense: padding rows too
+                const uint32_t ns = (uint32_t)__builtin_amdgcn_readlane((int)cs, (int)(tile - tb));
+                // hit_count's byte counters want 64-lane tiles and hold 255 hits
+                const bool sparse = code >= 2u && (tile + 1 < nt || p.last_tile_full);
+                const unsigned long long ms = __ballot(sparse);
+                const uint32_t srank = ns + (uint32_t)__popcll(ms & lt_mask);
+                const bool take = sparse && srank < kSegMaxSparseRows;
+                if (take) sout[(size_t)tile * (kSegMaxSparseRows + 1) + srank] = code - 2u;
+                const unsigned long long md = __ballot(code == 1u || (code >= 2u && !take));
+                if (lane == tile - tb) {
+                    dm[(size_t)tile * mstride + c] = md;
+                    cd += (uint32_t)__popcll(md);
+                    const uint32_t ns2 = ns + (uint32_t)__popcll(ms);
+                    cs = ns2 < kSegMaxSparseRows ? ns2 : kSegMaxSparseRows;
+                }
+            }
+        }
+        if (tb + lane < nt) {
+            p.ndense[(size_t)q * nt + tb + lane] = cd;
+            p.nsparse[(size_t)q * nt + tb + lane] = cs;
+            nseg += cd;
+        }
+    }
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) hq += __shfl_xor(hq, d, 64);
+    for (int d = 32; d >= 1; d >>= 1) { hq += __shfl_xor(hq, d, 64); nseg += __shfl_xor(nseg, d, 64); }
     if (lane == 0) {
         p.t[q] = t;
         p.nrows[q] = nrows;
         p.hq[gq] = hq;
         p.t_all[gq] = t;
-        p.nrows_all[gq] = nrows;
+        p.nrows_all[gq] = nseg;
     }
 }
 
@@ -232,6 +277,20 @@ __device__ __forceinline__ void load8(uint4 (&buf)[8], const char *__restrict__ 
 #pragma unroll
     for (int j = 0; j < 8; j++) {
         const uint32_t row = __builtin_amdgcn_readfirstlane(rows[j]);
+        const char *rowbase = bitmap + (size_t)row * stride;
+        const __amdgpu_buffer_rsrc_t rsrc =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(rowbase), 0, stride, 0x00027000);
+        const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, col, 0, 0);
+        buf[j] = make_uint4(v.x, v.y, v.z, v.w);
+    }
+}
+
+// The same with the eight row ids in lanes O .. O+7 of a VGPR (taken out with v_readlane: scalar row bases again).
+template <int O>
+__device__ __forceinline__ void load8v(uint4 (&buf)[8], const char *__restrict__ bitmap, uint32_t col, uint32_t stride, uint32_t idv) {
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const uint32_t row = (uint32_t)__builtin_amdgcn_readlane((int)idv, O + j);
         const char *rowbase = bitmap + (size_t)row * stride;
         const __amdgpu_buffer_rsrc_t rsrc =
             __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(rowbase), 0, stride, 0x00027000);
@@ -271,7 +330,38 @@ __global__ __launch_bounds__(64) void hit_count_kernel(HitParams p) {
     const uint32_t nq8 = gridDim.x >> 3;
     const uint32_t q = blockIdx.x < nq8 * 8u ? (blockIdx.x & 7u) * nq8 + (blockIdx.x >> 3) : blockIdx.x;
     const uint32_t t = p.t[q];
-    for (uint32_t i = lane; i <= t; i += 64) hist_lds[i] = 0;
+    // LDS: [row-id list | histogram] (the list during the row loop, the histogram in the epilogue), then 4 KiB of byte
+    // counters for the hits through sparse segments (one half of the tile at a time, in the epilogue)
+    uint32_t *cnt8 = hist_lds + p.lds_cnt8_off;  // [1024] dwords = 4096 byte counters, indexed by local id % 4096
+    const uint32_t ns = p.nsparse[(size_t)q * p.ntiles + tile];  // 0 in a partial last tile (kmer_extract)
+    const uint32_t *srows = p.srows + ((size_t)q * p.ntiles + tile) * (kSegMaxSparseRows + 1);
+    // hits of the sparse segments on the references [half*4096, half*4096 + 4096) of the tile -> cnt8 (at most 255 each)
+    auto sparse_hits = [&](uint32_t half) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) reinterpret_cast<uint4 *>(cnt8)[i * 64 + lane] = make_uint4(0, 0, 0, 0);
+        __syncthreads();
+        for (uint32_t c0 = 0; c0 < ns; c0 += 64) {
+            constexpr int kV = kSegSlotEntries / 8;  // uint4 per slot
+            uint4 e[kV];
+#pragma unroll
+            for (int i = 0; i < kV; i++) e[i] = make_uint4(~0u, ~0u, ~0u, ~0u);
+            if (c0 + lane < ns) {
+                const uint4 *slot = reinterpret_cast<const uint4 *>(p.segslots + (size_t)srows[c0 + lane] * kSegSlotEntries);
+#pragma unroll
+                for (int i = 0; i < kV; i++) e[i] = slot[i];
+            }
+#pragma unroll
+            for (int i = 0; i < kV; i++) {
+                const uint32_t wv[4] = {e[i].x, e[i].y, e[i].z, e[i].w};
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const uint32_t id = (wv[j >> 1] >> ((j & 1) * 16)) & 0xFFFFu;  // 0xFFFF = unused entry
+                    if ((id >> 12) == half) atomicAdd(&cnt8[(id & 4095u) >> 2], 1u << ((id & 3u) * 8u));
+                }
+            }
+        }
+        __syncthreads();
+    };
 
     const uint32_t col = tile * 1024u + lane * 16u;
     const bool active = col < p.stride_bytes;
@@ -282,79 +372,130 @@ __global__ __launch_bounds__(64) void hit_count_kernel(HitParams p) {
         for (int b = 0; b < NP; b++) pl[w][b] = 0;
 
     {
+        // The dense rows of this tile are the set bits of the tile's masks over the query's row list (the same 2.6 KB
+        // for every tile of the query: it stays in L2).  They are compacted into an LDS list first -- 64 rows per step,
+        // a lane whose bit is set writes its row at the rank of the bit -- so that the row loop has no data-dependent
+        // control flow: it reads 32 row ids per group with one ds_read and takes them out with v_readlane.
         const uint32_t *rows = p.rows + (size_t)q * p.rstride;
-        const uint32_t n32 = (p.nrows[q] + 31u) >> 5;  // the list is padded with zero rows (kmer_extract)
+        const unsigned long long *masks = p.dmask + ((size_t)q * p.ntiles + tile) * (p.rstride >> 6);
+        const uint32_t nchunks = (p.nrows[q] + 63u) >> 6;
         const char *bitmap = reinterpret_cast<const char *>(p.bitmap);
         const uint32_t stride = p.stride_bytes;
-        uint4 A[8], B[8];
-        load8(A, bitmap, col, stride, rows);
-        for (uint32_t g = 0; g < n32; g++) {
-            const uint32_t *r = rows + g * 32;
-            load8(B, bitmap, col, stride, r + 8);
-            const uint4 c3a = tree8<NP>(pl, A);
-            load8(A, bitmap, col, stride, r + 16);
-            const uint4 c3b = tree8<NP>(pl, B);
-            const uint4 c4a = csa_plane<NP, 3>(pl, c3a, c3b);
-            load8(B, bitmap, col, stride, r + 24);
-            const uint4 c3c = tree8<NP>(pl, A);
-            load8(A, bitmap, col, stride, r + 32);  // look-ahead group (zero rows past the end)
-            const uint4 c3d = tree8<NP>(pl, B);
-            const uint4 c4b = csa_plane<NP, 3>(pl, c3c, c3d);
-            const uint4 c5 = csa_plane<NP, 4>(pl, c4a, c4b);
-            planes_ripple<NP, 5>(pl[0], c5.x);
-            planes_ripple<NP, 5>(pl[1], c5.y);
-            planes_ripple<NP, 5>(pl[2], c5.z);
-            planes_ripple<NP, 5>(pl[3], c5.w);
+        uint32_t *list = hist_lds;
+        const unsigned long long lt_mask = (1ull << lane) - 1ull;
+        uint32_t chunk = 0;
+        while (chunk < nchunks) {  // one round unless the query has more than kHitListCap rows
+            uint32_t count = 0;
+            while (chunk < nchunks && count + 64u <= kHitListCap) {
+                const uint32_t rowv = rows[chunk * 64 + lane];
+                const unsigned long long m = masks[chunk];
+                if ((m >> lane) & 1ull) list[count + (uint32_t)__popcll(m & lt_mask)] = rowv;
+                count += (uint32_t)__popcll(m);
+                chunk++;
+            }
+            const uint32_t n32 = (count + 31u) >> 5;
+            for (uint32_t i = count + lane; i < n32 * 32u + 32u; i += 64) list[i] = p.zero_row;  // padding + look-ahead group
+            __syncthreads();
+            if (n32) {
+                uint32_t idv = list[lane & 31u];
+                uint4 A[8], B[8];
+                load8v<0>(A, bitmap, col, stride, idv);
+                for (uint32_t g = 0; g < n32; g++) {
+                    const uint32_t idn = list[(g + 1) * 32 + (lane & 31u)];
+                    load8v<8>(B, bitmap, col, stride, idv);
+                    const uint4 c3a = tree8<NP>(pl, A);
+                    load8v<16>(A, bitmap, col, stride, idv);
+                    const uint4 c3b = tree8<NP>(pl, B);
+                    const uint4 c4a = csa_plane<NP, 3>(pl, c3a, c3b);
+                    load8v<24>(B, bitmap, col, stride, idv);
+                    const uint4 c3c = tree8<NP>(pl, A);
+                    load8v<0>(A, bitmap, col, stride, idn);  // look-ahead group (zero rows past the end)
+                    const uint4 c3d = tree8<NP>(pl, B);
+                    const uint4 c4b = csa_plane<NP, 3>(pl, c3c, c3d);
+                    const uint4 c5 = csa_plane<NP, 4>(pl, c4a, c4b);
+                    planes_ripple<NP, 5>(pl[0], c5.x);
+                    planes_ripple<NP, 5>(pl[1], c5.y);
+                    planes_ripple<NP, 5>(pl[2], c5.z);
+                    planes_ripple<NP, 5>(pl[3], c5.w);
+                    idv = idn;
+                }
+            }
+            __syncthreads();  // the list is rewritten (next round) or becomes the histogram
         }
     }
+    for (uint32_t i = lane; i <= t; i += 64) hist_lds[i] = 0;
     __syncthreads();
 
-    if (active) {
-        const uint32_t L = tile_lanes(p.stride_bytes, tile);  // lanes of this tile (64 except in the last one)
-        if (p.flags & RTX_SKIP_EXACT_MATCHES) {  // raxtax.rs:65-68
-            const uint64_t qin = p.perm[p.q0 + q];
-            const uint64_t e0 = p.exact_off[qin], e1 = p.exact_off[qin + 1];
-            for (uint64_t e = e0; e < e1; e++) {
-                const uint32_t id = p.exact_ids[e] - p.ref_base;  // local id; other shards' ids wrap out of range
-                if (id < p.n_refs && (id >> 13) == tile) {
-                    const uint32_t c = (id & 8191u) >> 3, g = c / L;
-                    if (c - g * L == lane) {
-                        const uint32_t w = g >> 2, msk = ~(1u << ((g & 3u) * 8u + (id & 7u)));
+    const uint32_t L = tile_lanes(p.stride_bytes, tile);  // lanes of this tile (64 except in the last one)
+    if (active && (p.flags & RTX_SKIP_EXACT_MATCHES)) {  // raxtax.rs:65-68: the dense part
+        const uint64_t qin = p.perm[p.q0 + q];
+        const uint64_t e0 = p.exact_off[qin], e1 = p.exact_off[qin + 1];
+        for (uint64_t e = e0; e < e1; e++) {
+            const uint32_t id = p.exact_ids[e] - p.ref_base;  // local id; other shards' ids wrap out of range
+            if (id < p.n_refs && (id >> 13) == tile) {
+                const uint32_t c = (id & 8191u) >> 3, g = c / L;
+                if (c - g * L == lane) {
+                    const uint32_t w = g >> 2, msk = ~(1u << ((g & 3u) * 8u + (id & 7u)));
 #pragma unroll
-                        for (int ww = 0; ww < 4; ww++)
-                            if ((uint32_t)ww == w) {
+                    for (int ww = 0; ww < 4; ww++)
+                        if ((uint32_t)ww == w) {
 #pragma unroll
-                                for (int b = 0; b < NP; b++) pl[ww][b] &= msk;
-                            }
-                    }
+                            for (int b = 0; b < NP; b++) pl[ww][b] &= msk;
+                        }
                 }
             }
         }
-        // group g = (w, g2) of this lane: references ref0 + g*L*8 + [0, 8) (ref_slot, rtx_math.hpp)
-        const uint64_t ref0 = (uint64_t)tile * 8192u + lane * 8u;
-        uint16_t *out = p.counts + (size_t)q * p.npad + ref0;
+    }
+    // group g = (w, g2) of this lane: references ref0 + g*L*8 + [0, 8) (ref_slot, rtx_math.hpp)
+    const uint64_t ref0 = (uint64_t)tile * 8192u + lane * 8u;
+    uint16_t *out = p.counts + (size_t)q * p.npad + ref0;
 #pragma unroll
-        for (int w = 0; w < 4; w++) {
+    for (int half = 0; half < 2; half++) {  // groups 0-7 = references 0..4095 of a full tile, groups 8-15 = 4096..8191
+        if (ns) {
+            sparse_hits((uint32_t)half);
+            if (p.flags & RTX_SKIP_EXACT_MATCHES) {  // raxtax.rs:65-68: the sparse part
+                const uint64_t qin = p.perm[p.q0 + q];
+                const uint64_t e0 = p.exact_off[qin], e1 = p.exact_off[qin + 1];
+                for (uint64_t e = e0 + lane; e < e1; e += 64) {
+                    const uint32_t id = p.exact_ids[e] - p.ref_base;
+                    if (id < p.n_refs && (id >> 13) == tile && ((id >> 12) & 1u) == (uint32_t)half)
+                        reinterpret_cast<uint8_t *>(cnt8)[id & 4095u] = 0;
+                }
+                __syncthreads();
+            }
+        }
+        if (active) {
 #pragma unroll
-            for (int g2 = 0; g2 < 4; g2++) {  // 8 references per 16-byte store, contiguous across lanes
-                uint32_t lo0, hi0, lo1, hi1;
-                planes_unpack4<NP>(pl[w], 2 * g2, lo0, hi0);
-                planes_unpack4<NP>(pl[w], 2 * g2 + 1, lo1, hi1);
-                uint4 st;
-                // bytes (lo.b0, hi.b0, lo.b1, hi.b1) -> two u16 counts
-                st.x = __builtin_amdgcn_perm(hi0, lo0, 0x05010400u);
-                st.y = __builtin_amdgcn_perm(hi0, lo0, 0x07030602u);
-                st.z = __builtin_amdgcn_perm(hi1, lo1, 0x05010400u);
-                st.w = __builtin_amdgcn_perm(hi1, lo1, 0x07030602u);
-                const uint32_t goff = (uint32_t)(w * 4 + g2) * L * 8u;
-                *reinterpret_cast<uint4 *>(out + goff) = st;
-                const uint64_t rbase = ref0 + goff;
-                const uint32_t nvalid = rbase >= p.n_refs ? 0u : (p.n_refs - rbase < 8u ? (uint32_t)(p.n_refs - rbase) : 8u);
-                const uint32_t cw[4] = {st.x, st.y, st.z, st.w};
+            for (int wi = 0; wi < 2; wi++) {
+                const int w = half * 2 + wi;
 #pragma unroll
-                for (int j = 0; j < 8; j++) {
-                    const uint32_t c = (cw[j >> 1] >> ((j & 1) * 16)) & 0xFFFFu;
-                    if ((uint32_t)j < nvalid) atomicAdd(&hist_lds[c], 1u);
+                for (int g2 = 0; g2 < 4; g2++) {  // 8 references per 16-byte store, contiguous across lanes
+                    uint32_t lo0, hi0, lo1, hi1;
+                    planes_unpack4<NP>(pl[w], 2 * g2, lo0, hi0);
+                    planes_unpack4<NP>(pl[w], 2 * g2 + 1, lo1, hi1);
+                    uint4 st;
+                    // bytes (lo.b0, hi.b0, lo.b1, hi.b1) -> two u16 counts
+                    st.x = __builtin_amdgcn_perm(hi0, lo0, 0x05010400u);
+                    st.y = __builtin_amdgcn_perm(hi0, lo0, 0x07030602u);
+                    st.z = __builtin_amdgcn_perm(hi1, lo1, 0x05010400u);
+                    st.w = __builtin_amdgcn_perm(hi1, lo1, 0x07030602u);
+                    const uint32_t goff = (uint32_t)(w * 4 + g2) * L * 8u;
+                    if (ns) {  // + hits through sparse segments (L = 64 here): bytes of the eight references of this group
+                        const uint2 sb = *reinterpret_cast<const uint2 *>(cnt8 + (((uint32_t)(wi * 4 + g2) * 64u + lane) * 2u));
+                        st.x += (sb.x & 0xFFu) | ((sb.x & 0xFF00u) << 8);
+                        st.y += ((sb.x >> 16) & 0xFFu) | ((sb.x >> 24) << 16);
+                        st.z += (sb.y & 0xFFu) | ((sb.y & 0xFF00u) << 8);
+                        st.w += ((sb.y >> 16) & 0xFFu) | ((sb.y >> 24) << 16);
+                    }
+                    *reinterpret_cast<uint4 *>(out + goff) = st;
+                    const uint64_t rbase = ref0 + goff;
+                    const uint32_t nvalid = rbase >= p.n_refs ? 0u : (p.n_refs - rbase < 8u ? (uint32_t)(p.n_refs - rbase) : 8u);
+                    const uint32_t cw[4] = {st.x, st.y, st.z, st.w};
+#pragma unroll
+                    for (int j = 0; j < 8; j++) {
+                        const uint32_t c = (cw[j >> 1] >> ((j & 1) * 16)) & 0xFFFFu;
+                        if ((uint32_t)j < nvalid) atomicAdd(&hist_lds[c], 1u);
+                    }
                 }
             }
         }
@@ -855,8 +996,12 @@ void launch_row_popcount(hipStream_t s, const uint32_t *row_of, const uint32_t *
 void launch_kmer_extract(hipStream_t s, const KmerParams &p, uint32_t nq) {
     hipLaunchKernelGGL(kmer_extract_kernel, dim3(nq), dim3(64), 0, s, p);
 }
-void launch_hit_count(hipStream_t s, const HitParams &p, uint32_t nq, uint32_t ntiles, int planes) {
-    const size_t lds = (size_t)p.hstride * sizeof(uint32_t);
+void launch_hit_count(hipStream_t s, const HitParams &p_in, uint32_t nq, uint32_t ntiles, int planes) {
+    HitParams p = p_in;
+    const uint32_t first = std::max<uint32_t>((p.hstride + 3u) & ~3u, kHitListCap + 64u);  // histogram / row-id list
+    p.lds_cnt8_off = first;
+    // 8.4 KB per wave: measured flat up to there, +7 % at 10.4 KB, +14 % at 12.5 KB (12 waves per CU must fit)
+    const size_t lds = (size_t)first * sizeof(uint32_t) + 4096;  // ... | byte counters
     if (planes <= 10) hipLaunchKernelGGL(hit_count_kernel<10>, dim3(nq, ntiles), dim3(64), lds, s, p);
     else if (planes <= 12) hipLaunchKernelGGL(hit_count_kernel<12>, dim3(nq, ntiles), dim3(64), lds, s, p);
     else hipLaunchKernelGGL(hit_count_kernel<16>, dim3(nq, ntiles), dim3(64), lds, s, p);

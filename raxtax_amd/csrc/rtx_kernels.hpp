@@ -15,7 +15,15 @@ namespace rtx {
 enum NodeType : uint8_t { kInner = 0, kTaxon = 1, kSequence = 2 };  // src/tree.rs:181-186
 #endif
 
-constexpr uint32_t kWalkMaxRows = 208;  // >= 200 rows of confidence >= 0.005 + fallback
+constexpr uint32_t kWalkMaxRows = 208;
+// segment classes (rtx_segments.hip): a (row, tile) segment with at most kSegSparseMax references is kept as a
+// slot of kSegSlotEntries local ids (on the bench workload 31.0 % of the requested segments hold <= 16 references,
+// 31.3 % <= 32); a (query, tile) pair takes at most kSegMaxSparseRows such segments through the
+// byte counters of hit_count (more are read as dense segments)
+constexpr uint32_t kSegSlotEntries = 16, kSegSparseMax = 16, kSegMaxSparseRows = 255;
+// hit_count compacts the dense rows of its (query, tile) into an LDS list of this many row ids (+ padding); queries
+// with more rows than fit are read densely everywhere (their masks are all ones: every 64-row chunk adds 64 rows)
+constexpr uint32_t kHitListCap = 1024;  // >= 200 rows of confidence >= 0.005 + fallback
 
 struct DevRow {  // one result row as the device emits it
     uint32_t node;               // flattened node id
@@ -33,10 +41,18 @@ struct KmerParams {
     uint32_t zero_row;
     uint16_t *kmers;  // [B][kstride]
     uint32_t kstride;
-    uint32_t *rows;  // [B][rstride]
+    const uint32_t *seginfo;  // [n_rows+1][seg_stride] class of every segment (rtx_segments.hip)
+    uint32_t seg_stride;      // ntiles rounded up to a multiple of 4
+    uint32_t ntiles;
+    uint32_t last_tile_full;  // the last tile spans 64 lanes (stride multiple of 1 KiB)
+    uint32_t *rows;     // [B][rstride] rows of the query's k-mers (ascending), padded with the zero row to a multiple of 64
     uint32_t rstride;
+    unsigned long long *dmask;  // [B][ntiles][rstride/64] per tile: which of those rows have a dense segment there
+    uint32_t *ndense;   // [B][ntiles] number of set bits
+    uint32_t *srows;    // [B][ntiles][kSegMaxSparseRows + 1] per tile: slots of the sparse segments
+    uint32_t *nsparse;  // [B][ntiles]
     uint32_t *t;      // [B]
-    uint32_t *nrows;  // [B]
+    uint32_t *nrows;  // [B] dense segments over all tiles (work accounting)
     unsigned long long *hq;  // [n_q]
     uint32_t *t_all;         // [n_q]
     uint32_t *nrows_all;     // [n_q]
@@ -49,9 +65,17 @@ struct HitParams {
     uint32_t stride_bytes;
     uint64_t n_refs;
     uint32_t ref_base;  // global id of local reference 0 (reference-sharded index)
-    const uint32_t *rows;
+    const uint32_t *rows;     // [B][rstride] (kmer_extract)
     uint32_t rstride;
-    const uint32_t *nrows;
+    const unsigned long long *dmask;  // [B][ntiles][rstride/64]
+    const uint32_t *ndense;   // [B][ntiles]
+    const uint32_t *nrows;    // [B] length of the row list
+    uint32_t zero_row;
+    uint32_t lds_cnt8_off;    // set by the launcher: dword offset of the byte counters in dynamic LDS
+    const uint32_t *srows;    // [B][ntiles][kSegMaxSparseRows + 1]
+    const uint32_t *nsparse;  // [B][ntiles]
+    const uint16_t *segslots; // [n_slots][kSegSlotEntries] local ids of the sparse segments
+    uint32_t ntiles;
     const uint32_t *t;
     uint16_t *counts;  // [B][npad]
     uint64_t npad;
@@ -139,6 +163,10 @@ size_t prob_lookup_lds_bytes(uint32_t tmax);
 void launch_prob_tables_build(hipStream_t s, const ProbTables &tb, const double *lf, const double *inv);
 void launch_prob_order(hipStream_t s, const uint32_t *t, uint32_t nq, uint32_t *order);
 void launch_prob_lookup(hipStream_t s, const ProbParams &p, const ProbTables &tb, uint32_t nq);
+// segment classes of the index (rtx_segments.hip)
+void launch_seg_popcount(hipStream_t s, const uint32_t *bitmap, uint32_t stride_bytes, uint32_t n_rows1, uint32_t ntiles, uint16_t *pop);
+void launch_seg_emit(hipStream_t s, const uint32_t *bitmap, uint32_t stride_bytes, uint32_t n_rows1, uint32_t ntiles,
+                     const uint32_t *seginfo, uint32_t seg_stride, uint16_t *slots);
 // processing order of a batch (rtx_cluster.hip)
 void launch_sketch(hipStream_t s, const uint8_t *bases, const uint64_t *off, uint32_t n_q, uint64_t *keys, uint32_t *idx);
 void launch_invert_perm(hipStream_t s, const uint32_t *perm, uint32_t n, uint32_t *inv);

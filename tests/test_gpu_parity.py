@@ -539,3 +539,67 @@ def test_api_misuse_is_reported(world):
     with pytest.raises(rx.RtxError) as e:
         ix.upload(long_q, np.array([0, len(long_q)], np.uint64))
     assert e.value.code == rx._lib.RTX_ERR_TOO_LONG
+
+
+def _random_db(n_refs, length, seed, n_taxa=64):
+    rng = np.random.default_rng(seed)
+    seqs = (1 << rng.integers(0, 4, (n_refs, length))).astype(np.uint8)
+    lineages = [f"p:P{i % 4},c:C{i % 16},s:S{i % n_taxa}" for i in range(n_refs)]
+    off = (np.arange(n_refs + 1) * length).astype(np.uint64)
+    return lineages, seqs.reshape(-1), off
+
+
+@pytest.mark.parametrize("segment_classes", [True, False])
+def test_sparse_and_empty_segments(oracle, segment_classes):
+    """Segment classes of the index (rtx_segments.hip): a database of short random references makes EVERY segment
+    sparse (a k-mer occurs in ~6 of the 8192 references of a tile), a 658-base query then has ~640 sparse segments
+    per tile -- more than the 255 the byte counters take, so the cap and the dense fallback are exercised too; the
+    last tile is partial (no sparse path there).  Hit counts must be bit-exact, with and without the classes, also
+    under --skip-exact-matches (an exact match reached through a sparse segment must be zeroed as well)."""
+    lineages, flat, off = _random_db(20000, 60, seed=11)
+    otree = oracle.tree_new_flat(lineages, flat, off)
+    tree = rx.Tree.new_flat(lineages, flat, off)
+    ix = rx.Index(tree, segment_classes=segment_classes)
+    rng = np.random.default_rng(12)
+    qs = []
+    for i in range(24):
+        L = [658, 300, 70, 60][i % 4]
+        q = (1 << rng.integers(0, 4, L)).astype(np.uint8)
+        src = int(rng.integers(0, 20000))
+        ref = flat[src * 60:(src + 1) * 60]
+        if L == 60:
+            q = ref.copy()                       # an exact copy: exact-match zeroing through sparse segments
+        else:
+            q[5:65] = ref                        # embeds a whole reference: a full-overlap hit
+        qs.append(q)
+    qoff = np.zeros(len(qs) + 1, np.uint64)
+    qoff[1:] = np.cumsum([len(q) for q in qs])
+    bases = np.concatenate(qs)
+    ex_ids, ex_off = ix.exact_matches(bases, qoff)
+    assert np.diff(ex_off.astype(np.int64)).sum() >= 6
+    for skip in (False, True):
+        res = ix.classify(bases, qoff, ex_ids, ex_off, skip_exact_matches=skip)
+        for q in range(len(qs)):
+            t, counts = otree.hit_counts(qs[q], skip_exact=skip)
+            assert np.array_equal(ix.debug_hit_counts(q), counts), (segment_classes, skip, q)
+            assert res.t[q] == t
+    rx.Index(tree, segment_classes=True)         # leave the process-wide default as it was
+
+
+def test_long_queries_take_the_all_dense_path(oracle):
+    """Queries with more rows than hit_count's LDS row list holds (kHitListCap) are read densely everywhere."""
+    db = synth.make_db(20000)
+    otree = oracle.tree_new_flat(db.lineages, db.seq_bytes, db.seq_off)
+    tree = rx.Tree.new_flat(db.lineages, db.seq_bytes, db.seq_off)
+    ix = rx.Index(tree)
+    rng = np.random.default_rng(3)
+    long_q = np.concatenate([db.seq(int(i)) for i in rng.integers(0, db.n, 3)])       # ~1900 distinct k-mers
+    mid_q = np.concatenate([db.seq(5), db.seq(9000)[:350]])                             # ~1000: around the limit
+    qs = [long_q, db.seq(77).copy(), mid_q]
+    qoff = np.zeros(len(qs) + 1, np.uint64)
+    qoff[1:] = np.cumsum([len(q) for q in qs])
+    bases = np.concatenate(qs)
+    ix.classify(bases, qoff, *ix.exact_matches(bases, qoff))
+    for q in range(len(qs)):
+        t, counts = otree.hit_counts(qs[q])
+        assert np.array_equal(ix.debug_hit_counts(q), counts), q

@@ -207,7 +207,6 @@ __global__ __launch_bounds__(64) void kmer_extract_kernel(KmerParams p) {
     const uint32_t mstride = p.rstride >> 6;
     unsigned long long *dm = p.dmask + (size_t)q * nt * mstride;
     uint32_t *sout = p.srows + (size_t)q * nt * (kSegMaxSparseRows + 1);
-    const bool all_dense = nrows + 64u > kHitListCap;  // see kHitListCap
     uint32_t nseg = 0;
     for (uint32_t tb = 0; tb < nt; tb += 64) {  // 64 tiles at a time: lane l keeps the counters of tile tb + l
         const uint32_t te = tb + 64 < nt ? tb + 64 : nt;
@@ -221,7 +220,7 @@ __global__ __launch_bounds__(64) void kmer_extract_kernel(KmerParams p) {
             for (uint32_t tile = tb; tile < te; tile++) {
                 if ((tile & 3u) == 0) iv = info[tile >> 2];
                 const uint32_t word = (tile & 3u) == 0 ? iv.x : (tile & 3u) == 1 ? iv.y : (tile & 3u) == 2 ? iv.z : iv.w;
-                const uint32_t code = all_dense ? 1u : (row != kEmptyRow ? word : 0u);  // all_dense: padding rows too
+                const uint32_t code = row != kEmptyRow ? word : 0u;
                 const uint32_t ns = (uint32_t)__builtin_amdgcn_readlane((int)cs, (int)(tile - tb));
                 // hit_count's byte counters want 64-lane tiles and hold 255 hits
                 const bool sparse = code >= 2u && (tile + 1 < nt || p.last_tile_full);
@@ -384,7 +383,7 @@ __global__ __launch_bounds__(64) void hit_count_kernel(HitParams p) {
         uint32_t *list = hist_lds;
         const unsigned long long lt_mask = (1ull << lane) - 1ull;
         uint32_t chunk = 0;
-        while (chunk < nchunks) {  // one round unless the query has more than kHitListCap rows
+        while (chunk < nchunks) {  // one round unless more than kHitListCap - 63 dense rows (the last group of a round is padded)
             uint32_t count = 0;
             while (chunk < nchunks && count + 64u <= kHitListCap) {
                 const uint32_t rowv = rows[chunk * 64 + lane];

@@ -21,8 +21,8 @@ constexpr uint32_t kWalkMaxRows = 208;
 // 31.3 % <= 32); a (query, tile) pair takes at most kSegMaxSparseRows such segments through the
 // byte counters of hit_count (more are read as dense segments)
 constexpr uint32_t kSegSlotEntries = 16, kSegSparseMax = 16, kSegMaxSparseRows = 255;
-// hit_count compacts the dense rows of its (query, tile) into an LDS list of this many row ids (+ padding); queries
-// with more rows than fit are read densely everywhere (their masks are all ones: every 64-row chunk adds 64 rows)
+// hit_count compacts the dense rows of its (query, tile) into an LDS list of this many row ids (+ padding), in
+// several rounds if they do not fit
 constexpr uint32_t kHitListCap = 1024;  // >= 200 rows of confidence >= 0.005 + fallback
 
 struct DevRow {  // one result row as the device emits it

@@ -586,8 +586,8 @@ def test_sparse_and_empty_segments(oracle, segment_classes):
     rx.Index(tree, segment_classes=True)         # leave the process-wide default as it was
 
 
-def test_long_queries_take_the_all_dense_path(oracle):
-    """Queries with more rows than hit_count's LDS row list holds (kHitListCap) are read densely everywhere."""
+def test_long_queries_need_several_list_rounds(oracle):
+    """Queries with more dense rows per tile than hit_count's LDS row list holds (kHitListCap) are folded in several rounds."""
     db = synth.make_db(20000)
     otree = oracle.tree_new_flat(db.lineages, db.seq_bytes, db.seq_off)
     tree = rx.Tree.new_flat(db.lineages, db.seq_bytes, db.seq_off)

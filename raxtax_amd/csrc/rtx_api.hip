@@ -128,7 +128,9 @@ struct rtx_index {
     uint32_t ntiles = 0;        // 8192-reference tiles
     DevBuf<uint32_t> d_bitmap, d_row_of, d_list_len;
     // segment classes (rtx_segments.hip): class / sparse slot of every (row, tile) segment, slots of 32 local ids
-    DevBuf<uint32_t> d_seginfo;
+    DevBuf<uint32_t> d_seginfo, d_seg_sbase;
+    DevBuf<unsigned long long> d_seg_dbits, d_seg_sbits;
+    uint32_t seg_blocks = 0;  // > 0: kmer_extract uses the bit tables (many tiles)
     DevBuf<uint16_t> d_segslots;
     uint64_t n_seg_slots = 0;
     uint32_t seg_stride = 0;
@@ -287,7 +289,10 @@ int enqueue_kmer(rtx_index *ix, const SubBatch &b, hipStream_t s) {
     kp.seginfo = ix->d_seginfo.p;
     kp.seg_stride = ix->seg_stride;
     kp.ntiles = ix->ntiles;
-    kp.last_tile_full = ix->stride_bytes % 1024u == 0 ? 1u : 0u;
+    kp.seg_dbits = ix->d_seg_dbits.p;
+    kp.seg_sbits = ix->d_seg_sbits.p;
+    kp.seg_sbase = ix->d_seg_sbase.p;
+    kp.seg_blocks = ix->seg_blocks;
     kp.rows = sc.d_rows.p;
     kp.rstride = ix->rstride;
     kp.dmask = sc.d_dmask.p;
@@ -900,14 +905,38 @@ static int build_segments(rtx_index *ix) {
     RTX_HIP(hipMemcpy(pop.data(), d_pop.p, n * 2, hipMemcpyDeviceToHost));
     std::vector<uint32_t> info((size_t)n_rows1 * ss, 0u);
     uint64_t slots = 0;
+    const bool last_full = ix->stride_bytes % 1024u == 0;  // hit_count's byte counters want 64-lane tiles
     for (uint32_t r = 0; r < n_rows1; r++)
         for (uint32_t t = 0; t < nt; t++) {
             const uint32_t c = pop[(size_t)r * nt + t];
             uint32_t &o = info[(size_t)r * ss + t];
             if (c == 0) o = empty_on ? 0u : 1u;
-            else if (c <= kSegSparseMax && sparse_on) o = (uint32_t)(2 + slots++);
+            else if (c <= kSegSparseMax && sparse_on && (t + 1 < nt || last_full)) o = (uint32_t)(2 + slots++);
             else o = 1u;
         }
+    // many tiles: the classes as bit tables per block of 64 tiles (kmer_extract transposes 64 rows x 64 tiles at a time)
+    ix->seg_blocks = nt > 12 ? (nt + 63) / 64 : 0;
+    if (ix->seg_blocks) {
+        const uint32_t nb = ix->seg_blocks;
+        std::vector<unsigned long long> dbits((size_t)n_rows1 * nb, 0), sbits((size_t)n_rows1 * nb, 0);
+        std::vector<uint32_t> sbase((size_t)n_rows1 * nb, 0);
+        for (uint32_t r = 0; r < n_rows1; r++)
+            for (uint32_t b = 0; b < nb; b++) {
+                bool first = true;
+                for (uint32_t t = b * 64; t < nt && t < b * 64 + 64; t++) {
+                    const uint32_t o = info[(size_t)r * ss + t];
+                    if (o == 1u) dbits[(size_t)r * nb + b] |= 1ull << (t & 63u);
+                    else if (o >= 2u) {
+                        sbits[(size_t)r * nb + b] |= 1ull << (t & 63u);
+                        if (first) { sbase[(size_t)r * nb + b] = o - 2u; first = false; }
+                    }
+                }
+            }
+        if ((rc = ix->d_seg_dbits.alloc(dbits.size())) || (rc = ix->d_seg_sbits.alloc(sbits.size())) || (rc = ix->d_seg_sbase.alloc(sbase.size()))) return rc;
+        RTX_HIP(hipMemcpy(ix->d_seg_dbits.p, dbits.data(), dbits.size() * 8, hipMemcpyHostToDevice));
+        RTX_HIP(hipMemcpy(ix->d_seg_sbits.p, sbits.data(), sbits.size() * 8, hipMemcpyHostToDevice));
+        RTX_HIP(hipMemcpy(ix->d_seg_sbase.p, sbase.data(), sbase.size() * 4, hipMemcpyHostToDevice));
+    }
     if (slots > 0xFFFFFFF0ull) { set_error("too many sparse segments"); return RTX_ERR_INVALID; }
     ix->n_seg_slots = slots;
     if ((rc = ix->d_segslots.alloc((slots ? slots : 1) * kSegSlotEntries))) return rc;
@@ -1041,7 +1070,7 @@ void rtx_index_destroy(rtx_index *index) {
 uint64_t rtx_index_num_refs(const rtx_index *index) { return index ? index->n_total : 0; }
 uint64_t rtx_index_device_bytes(const rtx_index *index) {
     if (!index) return 0;
-    return index->d_seginfo.n * 4 + index->d_segslots.n * 2 + index->d_bitmap.n * 4 + index->d_row_of.n * 4 + index->d_list_len.n * 4 + index->d_lnfact.n * 8 +
+    return index->d_seg_dbits.n * 8 + index->d_seg_sbits.n * 8 + index->d_seg_sbase.n * 4 + index->d_seginfo.n * 4 + index->d_segslots.n * 2 + index->d_bitmap.n * 4 + index->d_row_of.n * 4 + index->d_list_len.n * 4 + index->d_lnfact.n * 8 +
            index->d_blo.n * 4 * 4 + index->d_type.n + index->d_bnd_bits.n + index->d_bnd_rank.n * 4;
 }
 int rtx_index_set_batch(rtx_index *index, uint32_t sub_batch) {

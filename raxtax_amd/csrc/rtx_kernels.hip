@@ -125,6 +125,19 @@ __global__ __launch_bounds__(256) void row_popcount_kernel(const uint32_t *__res
 // of the k-mers that occur in the index (padded with the all-zero row to a multiple of
 // 32 plus one look-ahead group) and H_q = sum of posting-list lengths.
 // ---------------------------------------------------------------------------
+// 64 x 64 bit-matrix transpose across the wave: lane l gives row l, receives column l (six butterfly stages).
+__device__ __forceinline__ unsigned long long transpose64(unsigned long long x, uint32_t lane) {
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) {
+        // bits b with (b & s) == 0
+        const unsigned long long m = s == 32 ? 0x00000000FFFFFFFFull : s == 16 ? 0x0000FFFF0000FFFFull : s == 8 ? 0x00FF00FF00FF00FFull
+                                   : s == 4 ? 0x0F0F0F0F0F0F0F0Full : s == 2 ? 0x3333333333333333ull : 0x5555555555555555ull;
+        const unsigned long long y = __shfl_xor(x, s, 64);
+        x = (lane & (uint32_t)s) ? (((y >> s) & m) | (x & ~m)) : ((x & m) | ((y & m) << s));
+    }
+    return x;
+}
+
 __global__ __launch_bounds__(64) void kmer_extract_kernel(KmerParams p) {
     __shared__ uint32_t bm[2048];
     const uint32_t q = blockIdx.x;
@@ -208,7 +221,47 @@ __global__ __launch_bounds__(64) void kmer_extract_kernel(KmerParams p) {
     unsigned long long *dm = p.dmask + (size_t)q * nt * mstride;
     uint32_t *sout = p.srows + (size_t)q * nt * (kSegMaxSparseRows + 1);
     uint32_t nseg = 0;
-    for (uint32_t tb = 0; tb < nt; tb += 64) {  // 64 tiles at a time: lane l keeps the counters of tile tb + l
+    __shared__ unsigned long long l_sb[64];
+    __shared__ uint32_t l_base[64];
+    for (uint32_t tb = 0; p.seg_blocks && tb < nt; tb += 64) {  // many tiles: 64 rows x 64 tiles per step
+        const uint32_t blk = tb >> 6;
+        const uint32_t tile = tb + lane;  // this lane's tile after the transposes
+        uint32_t cd = 0, cs = 0;
+        for (uint32_t c = 0; c < nchunks; c++) {
+            const uint32_t i = c * 64 + lane;
+            const uint32_t row = i < nrows ? rout[i] : kEmptyRow;
+            unsigned long long db = 0, sb = 0;
+            uint32_t base = 0;
+            if (row != kEmptyRow) {
+                db = p.seg_dbits[(size_t)row * p.seg_blocks + blk];
+                sb = p.seg_sbits[(size_t)row * p.seg_blocks + blk];
+                base = p.seg_sbase[(size_t)row * p.seg_blocks + blk];
+            }
+            l_sb[lane] = sb;
+            l_base[lane] = base;
+            unsigned long long dT = transpose64(db, lane), sT = transpose64(sb, lane);  // bit r = row c*64 + r
+            __syncthreads();
+            if (tile < nt) {
+                // the first sparse rows (up to the 255 the byte counters of hit_count hold) go to the slot list ...
+                while (sT && cs < kSegMaxSparseRows) {
+                    const int r = __builtin_ctzll(sT);
+                    sT &= sT - 1;
+                    sout[(size_t)tile * (kSegMaxSparseRows + 1) + cs] = l_base[r] + (uint32_t)__popcll(l_sb[r] & lt_mask);
+                    cs++;
+                }
+                dT |= sT;  // ... the rest is read densely
+                dm[(size_t)tile * mstride + c] = dT;
+                cd += (uint32_t)__popcll(dT);
+            }
+            __syncthreads();
+        }
+        if (tile < nt) {
+            p.ndense[(size_t)q * nt + tile] = cd;
+            p.nsparse[(size_t)q * nt + tile] = cs;
+            nseg += cd;
+        }
+    }
+    for (uint32_t tb = 0; !p.seg_blocks && tb < nt; tb += 64) {  // few tiles: one pass per tile; lane l keeps the counters of tile tb + l
         const uint32_t te = tb + 64 < nt ? tb + 64 : nt;
         uint32_t cd = 0, cs = 0;
         for (uint32_t c = 0; c < nchunks; c++) {
@@ -222,8 +275,7 @@ __global__ __launch_bounds__(64) void kmer_extract_kernel(KmerParams p) {
                 const uint32_t word = (tile & 3u) == 0 ? iv.x : (tile & 3u) == 1 ? iv.y : (tile & 3u) == 2 ? iv.z : iv.w;
                 const uint32_t code = row != kEmptyRow ? word : 0u;
                 const uint32_t ns = (uint32_t)__builtin_amdgcn_readlane((int)cs, (int)(tile - tb));
-                // hit_count's byte counters want 64-lane tiles and hold 255 hits
-                const bool sparse = code >= 2u && (tile + 1 < nt || p.last_tile_full);
+                const bool sparse = code >= 2u;  // hit_count's byte counters hold 255 hits: more sparse rows are read densely
                 const unsigned long long ms = __ballot(sparse);
                 const uint32_t srank = ns + (uint32_t)__popcll(ms & lt_mask);
                 const bool take = sparse && srank < kSegMaxSparseRows;

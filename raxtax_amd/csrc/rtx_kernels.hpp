@@ -44,7 +44,11 @@ struct KmerParams {
     const uint32_t *seginfo;  // [n_rows+1][seg_stride] class of every segment (rtx_segments.hip)
     uint32_t seg_stride;      // ntiles rounded up to a multiple of 4
     uint32_t ntiles;
-    uint32_t last_tile_full;  // the last tile spans 64 lanes (stride multiple of 1 KiB)
+    // the same classes as bit tables per block of 64 tiles, for databases with many tiles (one transpose per
+    // 64 rows x 64 tiles instead of a pass per tile): dense / sparse bits and the slot of the block's first sparse segment
+    const unsigned long long *seg_dbits, *seg_sbits;  // [n_rows+1][seg_blocks]
+    const uint32_t *seg_sbase;                        // [n_rows+1][seg_blocks]
+    uint32_t seg_blocks;                              // ceil(ntiles / 64); 0 = use seginfo
     uint32_t *rows;     // [B][rstride] rows of the query's k-mers (ascending), padded with the zero row to a multiple of 64
     uint32_t rstride;
     unsigned long long *dmask;  // [B][ntiles][rstride/64] per tile: which of those rows have a dense segment there

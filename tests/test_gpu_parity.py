@@ -603,3 +603,23 @@ def test_long_queries_need_several_list_rounds(oracle):
     for q in range(len(qs)):
         t, counts = otree.hit_counts(qs[q])
         assert np.array_equal(ix.debug_hit_counts(q), counts), q
+
+
+def test_many_tiles_use_the_transposed_class_tables(oracle):
+    """More than 12 tiles: kmer_extract derives the per-tile masks and sparse slots from bit tables per block of 64
+    tiles with a 64 x 64 bit transpose instead of one pass per tile.  14 tiles here, the last one partial."""
+    db = synth.make_db(8192 * 13 + 100)
+    qs = synth.make_queries(db, 48, exact_frac=0.2)
+    otree = oracle.tree_new_flat(db.lineages, db.seq_bytes, db.seq_off)
+    tree = rx.Tree.new_flat(db.lineages, db.seq_bytes, db.seq_off, kmer_map=False)
+    ix = rx.Index(tree)
+    ex_ids, ex_off = ix.exact_matches(qs.bases, qs.base_off)
+    for skip in (False, True):
+        res = ix.classify(qs.bases, qs.base_off, ex_ids, ex_off, skip_exact_matches=skip)
+        for q in range(qs.n):
+            t, counts = otree.hit_counts(qs.seq(q), skip_exact=skip)
+            assert np.array_equal(ix.debug_hit_counts(q), counts), (skip, q)
+        if not skip:
+            for q in (0, 17, 47):
+                rows, _ = otree.classify(qs.seq(q), raw_confidence=True)
+                assert [r.lineage for r in res.rows(q)] == [r["idx"] for r in rows]

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define RTX_ABI_VERSION 1
+#define RTX_ABI_VERSION 2 /* 2: rtx_result_view.row_begin/row_count replace row_off */
 #define RTX_NUM_KMERS 65536u /* 2 << 15 posting lists, src/tree.rs:52 */
 #define RTX_MAX_DEPTH 32u    /* deepest lineage (comma-separated levels) the device walk carries */
 

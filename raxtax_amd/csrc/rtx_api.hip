@@ -170,7 +170,7 @@ struct rtx_index {
     uint32_t sub_batch_req = 0, sub_batch = 0;
     struct Scratch {
         DevBuf<uint16_t> d_kmers, d_counts;
-        DevBuf<uint32_t> d_rows, d_t, d_nrows, d_hist, d_order, d_ndense, d_srows, d_nsparse;
+        DevBuf<uint32_t> d_rows, d_t, d_nrows, d_hist, d_order, d_srows, d_nsparse;
         DevBuf<unsigned long long> d_dmask;
         DevBuf<double> d_table_z, d_prefix;
     } sc[2];
@@ -296,7 +296,6 @@ int enqueue_kmer(rtx_index *ix, const SubBatch &b, hipStream_t s) {
     kp.rows = sc.d_rows.p;
     kp.rstride = ix->rstride;
     kp.dmask = sc.d_dmask.p;
-    kp.ndense = sc.d_ndense.p;
     kp.srows = sc.d_srows.p;
     kp.nsparse = sc.d_nsparse.p;
     kp.t = sc.d_t.p;
@@ -323,7 +322,6 @@ int enqueue_hit(rtx_index *ix, const SubBatch &b, uint32_t flags, hipStream_t s)
     hp.rows = sc.d_rows.p;
     hp.rstride = ix->rstride;
     hp.dmask = sc.d_dmask.p;
-    hp.ndense = sc.d_ndense.p;
     hp.nrows = sc.d_nrows.p;
     hp.zero_row = ix->n_rows;
     hp.srows = sc.d_srows.p;
@@ -643,7 +641,7 @@ int prepare_workspace(rtx_index *ix, uint64_t n_queries, uint64_t tmax, uint64_t
     ix->sub_batch = B;
     for (uint32_t k = 0; k < ix->n_streams; k++) {
         rtx_index::Scratch &sc = ix->sc[k];
-        if ((rc = sc.d_kmers.alloc((size_t)B * ix->kstride)) || (rc = sc.d_rows.alloc((size_t)B * ix->rstride)) || (rc = sc.d_dmask.alloc((size_t)B * ix->ntiles * (ix->rstride / 64))) || (rc = sc.d_ndense.alloc((size_t)B * ix->ntiles)) ||
+        if ((rc = sc.d_kmers.alloc((size_t)B * ix->kstride)) || (rc = sc.d_rows.alloc((size_t)B * ix->rstride)) || (rc = sc.d_dmask.alloc((size_t)B * ix->ntiles * (ix->rstride / 64))) ||
             (rc = sc.d_nsparse.alloc((size_t)B * ix->ntiles)) || (rc = sc.d_srows.alloc((size_t)B * ix->ntiles * (kSegMaxSparseRows + 1))) ||
             (rc = sc.d_t.alloc(B)) || (rc = sc.d_nrows.alloc(B)) || (rc = sc.d_counts.alloc((size_t)B * ix->npad)) ||
             (rc = sc.d_hist.alloc((size_t)B * ix->hstride)) || (rc = sc.d_table_z.alloc((size_t)B * ix->hstride)) ||

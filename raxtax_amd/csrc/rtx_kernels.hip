@@ -256,7 +256,6 @@ __global__ __launch_bounds__(64) void kmer_extract_kernel(KmerParams p) {
             __syncthreads();
         }
         if (tile < nt) {
-            p.ndense[(size_t)q * nt + tile] = cd;
             p.nsparse[(size_t)q * nt + tile] = cs;
             nseg += cd;
         }
@@ -290,7 +289,6 @@ __global__ __launch_bounds__(64) void kmer_extract_kernel(KmerParams p) {
             }
         }
         if (tb + lane < nt) {
-            p.ndense[(size_t)q * nt + tb + lane] = cd;
             p.nsparse[(size_t)q * nt + tb + lane] = cs;
             nseg += cd;
         }
@@ -319,24 +317,10 @@ __global__ __launch_bounds__(64) void kmer_extract_kernel(KmerParams p) {
 // ---------------------------------------------------------------------------
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 
-// Eight row segments through raw buffer loads: the row id is wave-uniform, so the 64-bit row base
-// lives in SGPRs (buffer descriptor rebuilt per row with scalar ops) and the only vector operand
-// is the 32-bit column offset: `buffer_load_dwordx4 v, v_col, s[desc], 0 offen`, no address VALU.
-// num_records = bytes per row, so lanes whose columns lie beyond the row read zeros.
-__device__ __forceinline__ void load8(uint4 (&buf)[8], const char *__restrict__ bitmap, uint32_t col, uint32_t stride,
-                                      const uint32_t *__restrict__ rows) {
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-        const uint32_t row = __builtin_amdgcn_readfirstlane(rows[j]);
-        const char *rowbase = bitmap + (size_t)row * stride;
-        const __amdgpu_buffer_rsrc_t rsrc =
-            __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(rowbase), 0, stride, 0x00027000);
-        const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, col, 0, 0);
-        buf[j] = make_uint4(v.x, v.y, v.z, v.w);
-    }
-}
-
-// The same with the eight row ids in lanes O .. O+7 of a VGPR (taken out with v_readlane: scalar row bases again).
+// Eight row segments through raw buffer loads.  The row ids are wave-uniform (lanes O .. O+7 of a VGPR, taken out
+// with v_readlane), so the 64-bit row base lives in SGPRs (buffer descriptor rebuilt per row with scalar ops) and
+// the only vector operand is the 32-bit column offset: `buffer_load_dwordx4 v, v_col, s[desc], 0 offen`, no address
+// VALU.  num_records = bytes per row, so lanes whose columns lie beyond the row read zeros.
 template <int O>
 __device__ __forceinline__ void load8v(uint4 (&buf)[8], const char *__restrict__ bitmap, uint32_t col, uint32_t stride, uint32_t idv) {
 #pragma unroll

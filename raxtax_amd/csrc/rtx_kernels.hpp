@@ -52,7 +52,6 @@ struct KmerParams {
     uint32_t *rows;     // [B][rstride] rows of the query's k-mers (ascending), padded with the zero row to a multiple of 64
     uint32_t rstride;
     unsigned long long *dmask;  // [B][ntiles][rstride/64] per tile: which of those rows have a dense segment there
-    uint32_t *ndense;   // [B][ntiles] number of set bits
     uint32_t *srows;    // [B][ntiles][kSegMaxSparseRows + 1] per tile: slots of the sparse segments
     uint32_t *nsparse;  // [B][ntiles]
     uint32_t *t;      // [B]
@@ -72,7 +71,6 @@ struct HitParams {
     const uint32_t *rows;     // [B][rstride] (kmer_extract)
     uint32_t rstride;
     const unsigned long long *dmask;  // [B][ntiles][rstride/64]
-    const uint32_t *ndense;   // [B][ntiles]
     const uint32_t *nrows;    // [B] length of the row list
     uint32_t zero_row;
     uint32_t lds_cnt8_off;    // set by the launcher: dword offset of the byte counters in dynamic LDS

@@ -49,8 +49,8 @@ struct Reader {
     const uint8_t *p, *end;
     bool ok = true;
     bool need(size_t n) { if ((size_t)(end - p) < n) { ok = false; return false; } return true; }
-    uint32_t u32() { if (!need(4)) return 0; uint32_t v = 0; for (int i = 0; i < 4; i++) v |= (uint32_t)p[i] << (8 * i); p += 4; return v; }
-    uint64_t u64() { if (!need(8)) return 0; uint64_t v = 0; for (int i = 0; i < 8; i++) v |= (uint64_t)p[i] << (8 * i); p += 8; return v; }
+    uint32_t u32() { if (!need(4)) return 0; uint32_t v; memcpy(&v, p, 4); p += 4; return v; }
+    uint64_t u64() { if (!need(8)) return 0; uint64_t v; memcpy(&v, p, 8); p += 8; return v; }
     bool str(std::string &s) {
         const uint64_t n = u64();
         if (!ok || !need(n)) return false;
@@ -129,9 +129,19 @@ int rtx_tree_save_bin(const rtx_tree *tree, const char *path) {
 
 int rtx_tree_load_bin(const char *path, rtx_tree **out) {
     if (!path || !out) { rtx::set_error("null argument"); return RTX_ERR_INVALID; }
-    std::ifstream f(path, std::ios::binary);
-    if (!f) { rtx::set_error("cannot open %s", path); return RTX_ERR_PARSE; }
-    std::vector<uint8_t> buf((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+    std::vector<uint8_t> buf;
+    {
+        FILE *f = fopen(path, "rb");
+        if (!f) { rtx::set_error("cannot open %s", path); return RTX_ERR_PARSE; }
+        fseek(f, 0, SEEK_END);
+        const long sz = ftell(f);
+        fseek(f, 0, SEEK_SET);
+        if (sz < 0) { fclose(f); rtx::set_error("cannot read %s", path); return RTX_ERR_PARSE; }
+        buf.resize((size_t)sz);
+        const size_t got = sz ? fread(buf.data(), 1, (size_t)sz, f) : 0;
+        fclose(f);
+        if (got != (size_t)sz) { rtx::set_error("cannot read %s", path); return RTX_ERR_PARSE; }
+    }
     Reader r{buf.data(), buf.data() + buf.size()};
     auto t = new rtx_tree();
     auto fail = [&](const char *what) { rtx::set_error("%s: not a raxtax database (%s)", path, what); delete t; return RTX_ERR_PARSE; };
@@ -157,10 +167,12 @@ int rtx_tree_load_bin(const char *path, rtx_tree **out) {
         const uint64_t nid = r.u64();
         if (!r.ok || nid > nl) return fail("sequence ids");
         entries[s].first = {kp, klen};
-        for (uint64_t i = 0; i < nid; i++) {
-            const uint32_t id = r.u32();
-            if (!r.ok || id >= nl) return fail("sequence id");
-            entries[s].second.push_back(id);
+        if (!r.need(nid * 4)) return fail("sequence ids");
+        entries[s].second.resize(nid);
+        memcpy(entries[s].second.data(), r.p, nid * 4);
+        r.p += nid * 4;
+        for (const uint32_t id : entries[s].second) {
+            if (id >= nl) return fail("sequence id");
             len_of[id] = klen;
             ptr_of[id] = kp;
         }
@@ -182,16 +194,19 @@ int rtx_tree_load_bin(const char *path, rtx_tree **out) {
     const uint64_t nk = r.u64();
     if (!r.ok || nk != RTX_NUM_KMERS) return fail("k_mer_map length");
     t->csr_off.assign(RTX_NUM_KMERS + 1, 0);
+    t->postings.resize((size_t)(r.end - r.p) / 4);  // upper bound, trimmed below
+    uint64_t np = 0;
     for (uint32_t k = 0; k < RTX_NUM_KMERS; k++) {
         const uint64_t n = r.u64();
         if (!r.ok || !r.need(n * 4)) return fail("posting list");
-        t->csr_off[k + 1] = t->csr_off[k] + n;
-        for (uint64_t i = 0; i < n; i++) {
-            const uint32_t id = r.u32();
-            if (id >= nl) return fail("posting id");
-            t->postings.push_back(id);
-        }
+        memcpy(t->postings.data() + np, r.p, n * 4);
+        r.p += n * 4;
+        for (uint64_t i = 0; i < n; i++)
+            if (t->postings[np + i] >= nl) return fail("posting id");
+        np += n;
+        t->csr_off[k + 1] = np;
     }
+    t->postings.resize(np);
     t->num_tips = r.u64();
     if (!r.ok || r.p != r.end) return fail("trailing bytes");
     if (t->num_tips != nl) return fail("num_tips");

@@ -26,8 +26,10 @@ for code, ch in ((1, "A"), (2, "C"), (4, "G"), (8, "T"), (15, "N")):
 with open(tmp / "q.fasta", "w") as f:
     for i in range(qs.n):
         f.write(f">q{i}\n{lut[qs.seq(i)].tobytes().decode()}\n")
-for r in range(a.repeat):
-    cmd = [str(ROOT / "raxtax_amd" / "raxtax-hip"), "-d", str(tmp / "db.fasta"), "-i", str(tmp / "q.fasta"), "-o", str(tmp / f"out{r}"),
+for r in range(a.repeat + 1):
+    # the last run takes the .bin cache the first one wrote as its database (Tree::load_from_file path)
+    dbp = tmp / "db.fasta" if r < a.repeat else tmp / "out0" / "db.bin"
+    cmd = [str(ROOT / "raxtax_amd" / "raxtax-hip"), "-d", str(dbp), "-i", str(tmp / "q.fasta"), "-o", str(tmp / f"out{r}"),
            "--timing"] + (["--tsv"] if a.tsv else []) + (["--batch", str(a.batch)] if a.batch else [])
     t0 = time.time()
     p = subprocess.run(cmd, capture_output=True, text=True)

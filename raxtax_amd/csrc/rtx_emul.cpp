@@ -264,4 +264,32 @@ int emul_prob_lookup(uint32_t t, const uint32_t *hist, uint64_t n_refs, const do
     return 0;
 }
 
+// Bit layout of the bitmap rows (rtx_math.hpp ref_slot) and its inverse as hit_count / seg_emit use it:
+// word, bit of local reference r; and the reference of (tile, lane, group g, j) = the j-th count of a lane's g-th store.
+void emul_ref_slot(uint32_t r, uint32_t stride_bytes, uint32_t *word, uint32_t *bit) { ref_slot(r, stride_bytes, *word, *bit); }
+uint32_t emul_slot_ref(uint32_t tile, uint32_t lane, uint32_t g, uint32_t j, uint32_t stride_bytes) {
+    return tile * 8192u + (g * tile_lanes(stride_bytes, tile) + lane) * 8u + j;
+}
+
+// The SWAR merge of hit_count's epilogue: eight byte counters (two dwords) added to eight u16 counts (four dwords).
+void emul_merge_bytes(const uint32_t *sb, uint32_t *st) {
+    st[0] += (sb[0] & 0xFFu) | ((sb[0] & 0xFF00u) << 8);
+    st[1] += ((sb[0] >> 16) & 0xFFu) | ((sb[0] >> 24) << 16);
+    st[2] += (sb[1] & 0xFFu) | ((sb[1] & 0xFF00u) << 8);
+    st[3] += ((sb[1] >> 16) & 0xFFu) | ((sb[1] >> 24) << 16);
+}
+
+// One lane's view of the six butterfly stages of transpose64 (rtx_kernels.hip): x[64] in, columns out.
+void emul_transpose64(const unsigned long long *in, unsigned long long *out) {
+    unsigned long long x[64], y[64];
+    for (int l = 0; l < 64; l++) x[l] = in[l];
+    for (int s = 32; s >= 1; s >>= 1) {
+        const unsigned long long m = s == 32 ? 0x00000000FFFFFFFFull : s == 16 ? 0x0000FFFF0000FFFFull : s == 8 ? 0x00FF00FF00FF00FFull
+                                   : s == 4 ? 0x0F0F0F0F0F0F0F0Full : s == 2 ? 0x3333333333333333ull : 0x5555555555555555ull;
+        for (int l = 0; l < 64; l++) y[l] = x[l ^ s];
+        for (int l = 0; l < 64; l++) x[l] = (l & s) ? (((y[l] >> s) & m) | (x[l] & ~m)) : ((x[l] & m) | ((y[l] & m) << s));
+    }
+    for (int l = 0; l < 64; l++) out[l] = x[l];
+}
+
 }  // extern "C"

@@ -134,3 +134,39 @@ def test_prob_lookup_tables_match_reference(emul, oracle, seed):
     assert _emul_table(emul, lf, 0, np.zeros(4, np.uint16), fn="emul_prob_lookup")[0] == 1
     rc, tz, z, gs = _emul_table(emul, lf, 9, np.zeros(7, np.uint16), fn="emul_prob_lookup")   # no hits at all
     assert rc == 0 and abs(tz[0] - 1.0 / 7) < 1e-15
+
+
+@pytest.mark.parametrize("n_refs", [1, 100, 8192, 8193, 50000, 3 * 8192])
+def test_bitmap_bit_layout_is_a_bijection(emul, n_refs):
+    """ref_slot (where a reference sits in its row) is a bijection onto the bits hit_count's lanes own, and the
+    reference of (tile, lane, group, j) -- the order of a lane's count stores -- is its inverse."""
+    stride = ((n_refs + 7) // 8 + 127) // 128 * 128
+    seen = set()
+    w, b = C.c_uint32(), C.c_uint32()
+    emul.emul_slot_ref.restype = C.c_uint32
+    for r in list(range(min(n_refs, 3000))) + list(range(max(0, n_refs - 3000), n_refs)):
+        emul.emul_ref_slot(r, stride, C.byref(w), C.byref(b))
+        assert w.value * 4 < stride and b.value < 32
+        pos = (w.value, b.value)
+        assert pos not in seen or r < 3000 and r >= n_refs - 3000
+        seen.add(pos)
+        tile, in_tile = divmod(w.value, 256)
+        lane, word = divmod(in_tile, 4)
+        g, j = word * 4 + b.value // 8, b.value % 8
+        assert emul.emul_slot_ref(tile, lane, g, j, stride) == r
+
+
+def test_epilogue_byte_merge_and_transpose(emul):
+    rng = np.random.default_rng(9)
+    for _ in range(50):
+        sb = rng.integers(0, 256, 8).astype(np.uint8)
+        cnt = rng.integers(0, 60000, 8).astype(np.uint16)
+        st = cnt.view(np.uint32).copy()
+        emul.emul_merge_bytes(sb.view(np.uint32).ctypes.data_as(C.c_void_p), st.ctypes.data_as(C.c_void_p))
+        assert np.array_equal(st.view(np.uint16), cnt + sb)
+    m = rng.integers(0, 2, (64, 64)).astype(np.uint64)
+    rows = (m << np.arange(64, dtype=np.uint64)[None, :]).sum(axis=1).astype(np.uint64)
+    cols = np.zeros(64, np.uint64)
+    emul.emul_transpose64(rows.ctypes.data_as(C.c_void_p), cols.ctypes.data_as(C.c_void_p))
+    want = (m.T << np.arange(64, dtype=np.uint64)[None, :]).sum(axis=1).astype(np.uint64)
+    assert np.array_equal(cols, want)

@@ -355,8 +355,10 @@ __device__ __forceinline__ uint4 csa_plane(uint32_t (&pl)[4][NP], const uint4 &a
     return c;
 }
 
+// Occupancy matters here: with <= 128 VGPRs four waves per SIMD are resident (16 per CU; their 8.4 KB of LDS each
+// just fit) -- a variant with 132 VGPRs (three waves) was 16 % slower.  The bound makes the compiler keep it.
 template <int NP>
-__global__ __launch_bounds__(64) void hit_count_kernel(HitParams p) {
+__global__ __launch_bounds__(64, (NP <= 10 ? 4 : 2)) void hit_count_kernel(HitParams p) {
     extern __shared__ uint32_t hist_lds[];
     const uint32_t tile = blockIdx.y, lane = threadIdx.x;
     // Workgroups are dealt round-robin to the 8 XCDs (each with an L2 of its own).  Neighbouring slots hold
@@ -1035,7 +1037,7 @@ void launch_hit_count(hipStream_t s, const HitParams &p_in, uint32_t nq, uint32_
     HitParams p = p_in;
     const uint32_t first = std::max<uint32_t>((p.hstride + 3u) & ~3u, kHitListCap + 64u);  // histogram / row-id list
     p.lds_cnt8_off = first;
-    // 8.4 KB per wave: measured flat up to there, +7 % at 10.4 KB, +14 % at 12.5 KB (12 waves per CU must fit)
+    // 8.4 KB per wave: measured flat up to there, +7 % at 10.4 KB, +14 % at 12.5 KB (16 waves per CU must fit in 160 KB)
     const size_t lds = (size_t)first * sizeof(uint32_t) + 4096;  // ... | byte counters
     if (planes <= 10) hipLaunchKernelGGL(hit_count_kernel<10>, dim3(nq, ntiles), dim3(64), lds, s, p);
     else if (planes <= 12) hipLaunchKernelGGL(hit_count_kernel<12>, dim3(nq, ntiles), dim3(64), lds, s, p);

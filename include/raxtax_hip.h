@@ -126,6 +126,16 @@ int rtx_tree_nodes(const rtx_tree *tree, rtx_nodes_view *out);
 typedef struct rtx_queries rtx_queries;
 int rtx_queries_parse_fasta(const char *text, uint64_t len, const char *const *skip, uint64_t n_skip,
                             rtx_queries **out);
+/* The same for one block of a file that is read piecewise (FASTA ingest of very large query files: the reference
+ * reads the whole file, parser.rs:112-115).  Blocks must be cut in front of a header line: rtx_fasta_block_end returns
+ * the offset of the last '>' that directly follows a newline (0 if there is none) -- parse text[0, end) with
+ * RTX_FASTA_MORE_FOLLOWS and carry text[end, len) over to the next block; every block but the first also gets
+ * RTX_FASTA_NOT_FIRST.  The records of all blocks together are exactly those of the whole-file parse. */
+#define RTX_FASTA_MORE_FOLLOWS 1u /* not the last block: a trailing header without bases is dropped (the next header replaces it) */
+#define RTX_FASTA_NOT_FIRST 2u    /* not the first block: it starts with a header by construction */
+uint64_t rtx_fasta_block_end(const char *text, uint64_t len);
+int rtx_queries_parse_fasta_block(const char *text, uint64_t len, const char *const *skip, uint64_t n_skip, uint32_t flags,
+                                  rtx_queries **out);
 void rtx_queries_destroy(rtx_queries *q);
 uint64_t rtx_queries_len(const rtx_queries *q);
 const char *rtx_queries_label(const rtx_queries *q, uint64_t i);

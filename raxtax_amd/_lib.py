@@ -65,6 +65,9 @@ _SIGNATURES = {
     "rtx_tree_exact_matches": (C.c_uint64, [C.c_void_p, u8p, C.c_uint64, C.POINTER(u32p)]),
     "rtx_tree_exact_matches_batch": (C.c_uint64, [C.c_void_p, C.c_uint64, u8p, u64p, u64p, u32p, C.c_uint64]),
     "rtx_tree_nodes": (C.c_int, [C.c_void_p, C.POINTER(NodesView)]),
+    "rtx_fasta_block_end": (C.c_uint64, [C.c_char_p, C.c_uint64]),
+    "rtx_queries_parse_fasta_block": (C.c_int, [C.c_char_p, C.c_uint64, C.POINTER(C.c_char_p), C.c_uint64, C.c_uint32,
+                                      C.POINTER(C.c_void_p)]),
     "rtx_queries_parse_fasta": (C.c_int, [C.c_char_p, C.c_uint64, C.POINTER(C.c_char_p), C.c_uint64,
                                           C.POINTER(C.c_void_p)]),
     "rtx_queries_destroy": (None, [C.c_void_p]),

@@ -11,6 +11,9 @@
 #include <sys/stat.h>
 
 #include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
 
 #include <cstdio>
 #include <cstdlib>
@@ -101,6 +104,7 @@ int main(int argc, char **argv) {
     };
     int device = 0;
     size_t chunk = 32768;
+    size_t block_bytes = (size_t)256 << 20;  // query file read and parsed in blocks of this size
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
         auto val = [&]() -> const char * { return i + 1 < argc ? argv[++i] : ""; };
@@ -117,9 +121,10 @@ int main(int argc, char **argv) {
         else if (a == "--timing") timing = true;
         else if (a == "--device") device = atoi(val());
         else if (a == "--batch") chunk = (size_t)atoll(val());
+        else if (a == "--block-bytes") block_bytes = std::max<size_t>(1, (size_t)atoll(val()));
         else {
             fprintf(stderr, "usage: raxtax-hip -d DB.(fasta|bin) [-i QUERIES.fasta] [-o PREFIX] [--skip-exact-matches] [--raw-confidence] "
-                            "[--tsv] [--only-db] [--skip-db] [-c] [--redo] [--device N] [--batch N]\n");
+                            "[--tsv] [--only-db] [--skip-db] [-c] [--redo] [--device N] [--batch N] [--block-bytes N]\n");
             return 64;
         }
     }
@@ -207,20 +212,70 @@ int main(int argc, char **argv) {
         return ok ? 0 : 74;
     }
 
-    // ---- queries (already finished labels are dropped, parser.rs:150-153)
-    std::string q_text;
-    if (!slurp(qf, q_text)) { fprintf(stderr, "[ERROR] Failed to parse %s\n", qf.c_str()); return 66; }
+    // ---- queries: the file is read and parsed block by block on a thread of its own (cut in front of header lines,
+    // rtx_fasta_block_end), so that ingest overlaps with classification and memory stays bounded for very large
+    // files (the reference reads the whole file, parser.rs:112-115).  Already finished labels are dropped
+    // (parser.rs:150-153).
     std::vector<const char *> skip;
     for (const std::string &l : done) skip.push_back(l.c_str());
-    rtx_queries *qs = nullptr;
-    if (rtx_queries_parse_fasta(q_text.data(), q_text.size(), skip.empty() ? nullptr : skip.data(), skip.size(), &qs) != RTX_OK) {
-        fprintf(stderr, "[ERROR] Failed to parse %s: %s\n", qf.c_str(), rtx_last_error());
-        return 66;
-    }
-    lap("queries");
+    struct Parsed { rtx_queries *qs = nullptr; int rc = RTX_OK; std::string err; bool end = false; };
+    std::mutex qmu;
+    std::condition_variable qcv;
+    std::deque<Parsed> ready;  // at most two blocks ahead
+    bool stop_reader = false;
+    std::thread reader([&]() {
+        auto push = [&](Parsed &&pz) {
+            std::unique_lock<std::mutex> g(qmu);
+            qcv.wait(g, [&] { return ready.size() < 2 || stop_reader; });
+            ready.push_back(std::move(pz));
+            qcv.notify_all();
+        };
+        FILE *f = fopen(qf.c_str(), "rb");
+        if (!f) { Parsed e; e.rc = RTX_ERR_PARSE; e.err = "cannot open file"; e.end = true; push(std::move(e)); return; }
+        std::string buf;
+        bool first = true, eof = false;
+        while (!eof) {
+            const size_t have = buf.size();
+            buf.resize(have + block_bytes);
+            const size_t got = fread(&buf[have], 1, block_bytes, f);
+            buf.resize(have + got);
+            eof = got < block_bytes;
+            uint64_t end = buf.size();
+            uint32_t flags = first ? 0u : RTX_FASTA_NOT_FIRST;
+            if (!eof) {
+                end = rtx_fasta_block_end(buf.data(), buf.size());
+                if (end == 0) continue;  // no header inside the block yet: read on
+                flags |= RTX_FASTA_MORE_FOLLOWS;
+            }
+            Parsed pz;
+            pz.rc = rtx_queries_parse_fasta_block(buf.data(), end, skip.empty() ? nullptr : skip.data(), skip.size(), flags, &pz.qs);
+            if (pz.rc != RTX_OK) pz.err = rtx_last_error();
+            pz.end = eof || pz.rc != RTX_OK;
+            const bool failed = pz.rc != RTX_OK;
+            push(std::move(pz));
+            if (failed) break;
+            buf.erase(0, end);
+            first = false;
+            {
+                std::lock_guard<std::mutex> g(qmu);
+                if (stop_reader) break;
+            }
+        }
+        fclose(f);
+    });
+    auto stop_and_join_reader = [&]() {
+        {
+            std::lock_guard<std::mutex> g(qmu);
+            stop_reader = true;
+            qcv.notify_all();
+        }
+        reader.join();
+        for (Parsed &pz : ready) rtx_queries_destroy(pz.qs);
+    };
     rtx_index *index = nullptr;
     if (rtx_index_create_from_tree(device, tree, &index) != RTX_OK) {
         fprintf(stderr, "[ERROR] %s\n", rtx_last_error());
+        stop_and_join_reader();
         return 71;  // exitcode::OSERR
     }
     lap("index");
@@ -231,12 +286,6 @@ int main(int argc, char **argv) {
     sink.ckp.open(ckp_path, mode);
     sink.want_tsv = tsv;
     if (tsv) sink.tsv.open(tsv_path, mode);
-    const uint64_t n = rtx_queries_len(qs);
-    std::vector<const char *> labels(n);
-    for (uint64_t i = 0; i < n; i++) labels[i] = rtx_queries_label(qs, i);
-    const uint8_t *bases;
-    const uint64_t *off;
-    rtx_queries_data(qs, &bases, &off);
     // the writer of main.rs:127-135: result lines, then the label into the progress file
     auto sender = [](void *c, const char *label, const char *lines, const char *tsv_lines) -> int {
         Sink *s = static_cast<Sink *>(c);
@@ -246,10 +295,40 @@ int main(int argc, char **argv) {
         return s->out.good() && s->ckp.good() ? 0 : 1;
     };
     int rc = RTX_OK;
-    if (n) rc = rtx_raxtax(index, tree, n, labels.data(), bases, off, skip_exact, raw, chunk, sender, &sink, tsv);
+    uint64_t n = 0;
+    bool parse_failed = false;
+    for (;;) {
+        Parsed pz;
+        {
+            std::unique_lock<std::mutex> g(qmu);
+            qcv.wait(g, [&] { return !ready.empty(); });
+            pz = std::move(ready.front());
+            ready.pop_front();
+            qcv.notify_all();
+        }
+        if (pz.rc != RTX_OK) {
+            fprintf(stderr, "[ERROR] Failed to parse %s: %s\n", qf.c_str(), pz.err.c_str());
+            parse_failed = true;
+            break;
+        }
+        const uint64_t nb = rtx_queries_len(pz.qs);
+        if (nb) {
+            std::vector<const char *> labels(nb);
+            for (uint64_t i = 0; i < nb; i++) labels[i] = rtx_queries_label(pz.qs, i);
+            const uint8_t *bases;
+            const uint64_t *off;
+            rtx_queries_data(pz.qs, &bases, &off);
+            rc = rtx_raxtax(index, tree, nb, labels.data(), bases, off, skip_exact, raw, chunk, sender, &sink, tsv);
+            n += nb;
+        }
+        rtx_queries_destroy(pz.qs);
+        if (rc != RTX_OK || pz.end) break;
+    }
+    stop_and_join_reader();
     sink.out.flush();
     sink.ckp.flush();
     if (tsv) sink.tsv.flush();
+    if (parse_failed) { join_bin_writer(); return 66; }
     lap("classify_and_write");
     if (!join_bin_writer()) return 74;
     lap("database_cache_wait");
@@ -264,7 +343,6 @@ int main(int argc, char **argv) {
         if (!db_bin.empty()) remove(db_bin.c_str());
     }
     rtx_index_destroy(index);
-    rtx_queries_destroy(qs);
     rtx_tree_destroy(tree);
     return 0;
 }

@@ -505,8 +505,21 @@ int rtx_tree_nodes(const rtx_tree *tree, rtx_nodes_view *out) {
 
 int rtx_queries_parse_fasta(const char *text, uint64_t len, const char *const *skip, uint64_t n_skip,
                             rtx_queries **out) {
+    return rtx_queries_parse_fasta_block(text, len, skip, n_skip, 0, out);
+}
+
+uint64_t rtx_fasta_block_end(const char *text, uint64_t len) {
+    if (!text) return 0;
+    for (uint64_t i = len; i > 1; i--)
+        if (text[i - 1] == '>' && text[i - 2] == '\n') return i - 1;
+    return 0;
+}
+
+int rtx_queries_parse_fasta_block(const char *text, uint64_t len, const char *const *skip, uint64_t n_skip, uint32_t flags,
+                                  rtx_queries **out) {
     if (!out) { set_error("null argument"); return RTX_ERR_INVALID; }
     if (!text || len == 0) { set_error("File is empty"); return RTX_ERR_PARSE; }
+    const bool more_follows = (flags & RTX_FASTA_MORE_FOLLOWS) != 0;
     try {
         std::unordered_map<std::string_view, int> skipset;
         for (uint64_t i = 0; i < n_skip; i++) skipset.emplace(skip[i], 1);
@@ -517,9 +530,9 @@ int rtx_queries_parse_fasta(const char *text, uint64_t len, const char *const *s
         std::vector<FastaPiece> pieces(np);
         auto parse_piece = [&](size_t pi) {
             FastaPiece &P = pieces[pi];
-            const bool last = pi + 1 == np;
+            const bool last = pi + 1 == np && !more_follows;  // a later block starts with a header as well
             auto lines = fasta_lines(text + cuts[pi], cuts[pi + 1] - cuts[pi]);
-            if (pi == 0 && (lines.empty() || lines[0][0] != '>')) { P.err = "Not a valid FASTA file"; return; }
+            if (pi == 0 && !(flags & RTX_FASTA_NOT_FIRST) && (lines.empty() || lines[0][0] != '>')) { P.err = "Not a valid FASTA file"; return; }
             std::string cur_label;
             std::vector<uint8_t> cur;
             P.off.push_back(0);

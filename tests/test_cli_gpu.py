@@ -63,3 +63,15 @@ def test_cli_outputs_resume_and_bin_cache(tmp_path, oracle):
     out4 = tmp_path / "run4"
     run("-d", FASTA, "--only-db", "-o", out4)
     assert (out4 / "diptera_subset.bin").exists() and not (out4 / "raxtax.out").exists()
+
+
+def test_cli_streamed_query_ingest(tmp_path):
+    """--block-bytes: the query file is read and parsed in blocks (cut in front of header lines) on a thread of its own;
+    the output must be the one of a single-block run."""
+    a, b = tmp_path / "whole", tmp_path / "blocks"
+    run("-d", FASTA, "-i", FASTA, "-o", a, "--skip-db")
+    run("-d", FASTA, "-i", FASTA, "-o", b, "--skip-db", "--block-bytes", 20000, "--batch", 100)
+    la = (a / "raxtax.out").read_text().splitlines()
+    lb = (b / "raxtax.out").read_text().splitlines()
+    assert len(la) >= 600 and la == lb
+    assert (a / "raxtax.ckp").read_text() == (b / "raxtax.ckp").read_text()

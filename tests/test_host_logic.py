@@ -184,3 +184,51 @@ def test_parallel_fasta_parsers_equal_the_serial_oracle(oracle):
     off, post = tree.csr()
     ooff, opost = otree.csr()
     assert np.array_equal(off, ooff) and np.array_equal(post, opost)
+
+
+@pytest.mark.parametrize("block", [1500, 40_000, 1_000_000])
+def test_blockwise_query_parsing_equals_whole_file(oracle, block):
+    """rtx_fasta_block_end + rtx_queries_parse_fasta_block (the CLI's streamed ingest): reading a file in blocks cut in
+    front of header lines gives exactly the records of the whole-file parse, including headers without bases at block
+    ends, comment lines and a skip list."""
+    import ctypes as C
+
+    from raxtax_amd import _lib
+
+    lib = _lib.load()
+    text = _messy_fasta(3000, 7, reference=False).encode()
+    want = oracle.parse_query_fasta_str(text.decode(), ["q17"])
+    got = []
+    buf = b""
+    pos = 0
+    first = True
+    skip = (C.c_char_p * 1)(b"q17")
+    while True:
+        chunk = text[pos:pos + block]
+        pos += len(chunk)
+        buf += chunk
+        eof = pos >= len(text)
+        end = len(buf)
+        flags = 0 if first else 2
+        if not eof:
+            end = lib.rtx_fasta_block_end(buf, len(buf))
+            if end == 0:
+                continue
+            flags |= 1
+        h = C.c_void_p()
+        _lib.check(lib.rtx_queries_parse_fasta_block(buf, end, skip, 1, flags, C.byref(h)))
+        n = lib.rtx_queries_len(h)
+        bases, off = C.POINTER(C.c_uint8)(), C.POINTER(C.c_uint64)()
+        lib.rtx_queries_data(h, C.byref(bases), C.byref(off))
+        o = np.ctypeslib.as_array(off, shape=(n + 1,)).copy()
+        b = np.ctypeslib.as_array(bases, shape=(max(int(o[-1]), 1),)).copy()
+        for i in range(n):
+            got.append((lib.rtx_queries_label(h, i).decode(), b[int(o[i]):int(o[i + 1])]))
+        lib.rtx_queries_destroy(h)
+        buf = buf[end:]
+        first = False
+        if eof:
+            break
+    assert len(got) == len(want)
+    for (gl, gs), (wl, ws) in zip(got, want):
+        assert gl == wl and np.array_equal(gs, ws)

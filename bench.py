@@ -194,6 +194,7 @@ def main():
 
     lib = rx._lib.load()
     rec_buf = [None]
+    gather_cache = {}
 
     def step():
         index.run(flags)
@@ -202,11 +203,11 @@ def main():
             # the only collective: gather the per-rank result records on rank 0 (RCCL over xGMI)
             need = lib.rtx_result_pack(ctypes.byref(view), None, 0)       # native pack: 24 B/query + 21 B/row
             if rec_buf[0] is None or rec_buf[0].shape[0] < need:
-                rec_buf[0] = np.empty(int(need * 1.25) + 64, dtype=np.uint8)
+                rec_buf[0] = dist_util.pinned_bytes(int(need * 1.25) + 64)
             n = lib.rtx_result_pack(ctypes.byref(view), rec_buf[0].ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), rec_buf[0].shape[0])
             assert n == need, "rtx_result_pack failed"
             rec = rec_buf[0][:n]
-            dist_util.gather_records(dist, rec, rank, world, device=coll_device)
+            dist_util.gather_records(dist, rec, rank, world, device=coll_device, cache=gather_cache)
         return view
 
     def barrier():

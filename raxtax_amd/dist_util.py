@@ -80,21 +80,45 @@ def unpack_records(buf: np.ndarray) -> dict:
                 row_conf=conf, row_local_signal=local)
 
 
-def gather_records(dist, rec: np.ndarray, rank: int, world: int, device: str = "cpu") -> Optional[List[np.ndarray]]:
-    """Gathers variable-length byte buffers on rank 0: all_gather of the sizes, then one dist.gather of
-    buffers padded to the largest size.  Returns the per-rank buffers on rank 0, None elsewhere."""
+def pinned_bytes(n: int) -> np.ndarray:
+    """A uint8 numpy buffer in page-locked host memory when CUDA is there (fast H2D/D2H of the records), else plain."""
     import torch
 
+    if torch.cuda.is_available():
+        return torch.empty((n,), dtype=torch.uint8, pin_memory=True).numpy()
+    return np.empty(n, dtype=np.uint8)
+
+
+def gather_records(dist, rec: np.ndarray, rank: int, world: int, device: str = "cpu", cache: Optional[dict] = None) -> Optional[List[np.ndarray]]:
+    """Gathers variable-length byte buffers on rank 0: all_gather of the sizes, then one dist.gather of
+    buffers padded to the largest size.  Returns the per-rank buffers on rank 0 (host memory), None elsewhere.
+    `cache` (a dict kept by the caller across steps) holds the device and pinned staging buffers, so that a step
+    costs one H2D per rank and one D2H on rank 0 at PCIe rate instead of pageable copies and allocations."""
+    import torch
+
+    cache = {} if cache is None else cache
     n = torch.tensor([rec.shape[0]], dtype=torch.int64, device=device)
     sizes = [torch.zeros_like(n) for _ in range(world)]
     dist.all_gather(sizes, n)
     sizes = [int(s.item()) for s in sizes]
     cap = max(max(sizes), 1)
-    buf = torch.zeros((cap,), dtype=torch.uint8, device=device)
+    if cache.get("cap", 0) < cap:  # (re)allocate with head room
+        c2 = int(cap * 1.25) + 64
+        cache["cap"] = c2
+        cache["buf"] = torch.zeros((c2,), dtype=torch.uint8, device=device)
+        cache["gathered"] = [torch.zeros((c2,), dtype=torch.uint8, device=device) for _ in range(world)] if rank == 0 else None
+        cache["host"] = torch.from_numpy(pinned_bytes(c2 * world)) if (rank == 0 and device != "cpu") else None
+    c2 = cache["cap"]
+    buf = cache["buf"]
     if rec.shape[0]:
-        buf[: rec.shape[0]] = torch.from_numpy(rec).to(device)
-    gathered = [torch.zeros_like(buf) for _ in range(world)] if rank == 0 else None
-    dist.gather(buf, gathered, dst=0)
+        buf[: rec.shape[0]].copy_(torch.from_numpy(rec), non_blocking=True)   # rec in pinned memory: asynchronous H2D
+    dist.gather(buf, cache["gathered"], dst=0)
     if rank != 0:
         return None
-    return [g[:sizes[i]].cpu().numpy() for i, g in enumerate(gathered)]
+    if device == "cpu":
+        return [g[:sizes[i]].numpy().copy() for i, g in enumerate(cache["gathered"])]
+    host = cache["host"]
+    for i, g in enumerate(cache["gathered"]):
+        host[i * c2: i * c2 + sizes[i]].copy_(g[:sizes[i]], non_blocking=True)
+    torch.cuda.synchronize()
+    return [host[i * c2: i * c2 + sizes[i]].numpy() for i in range(world)]

@@ -119,6 +119,9 @@ def bench_sharded_db(args, rx, synth, db, tree, dist, rank, local_rank, world, f
     ex_ids, ex_off = shard.exact_matches(qs.bases, qs.base_off)
 
     def barrier():
+        if pending[0] is not None:      # the gather of the last step belongs to the timed region
+            dist_util.gather_finish(pending[0])
+            pending[0] = None
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
@@ -193,24 +196,34 @@ def main():
     index.upload(qs.bases, qs.base_off, ex_ids, ex_off)            # inputs resident in HBM from here on
 
     lib = rx._lib.load()
-    rec_buf = [None]
-    gather_cache = {}
+    # N > 1: the gather of step i runs while step i+1 is classified (two sets of buffers); the last one is
+    # finished inside the timed region
+    rec_buf = [None, None]
+    gather_cache = [{}, {}]
+    pending = [None]
+    step_no = [0]
 
     def step():
         index.run(flags)
         view = index.download(copy=False)       # sync + D2H of the result records + host finalisation
         if dist is not None:
             # the only collective: gather the per-rank result records on rank 0 (RCCL over xGMI)
+            k = step_no[0] & 1
+            step_no[0] += 1
             need = lib.rtx_result_pack(ctypes.byref(view), None, 0)       # native pack: 24 B/query + 21 B/row
-            if rec_buf[0] is None or rec_buf[0].shape[0] < need:
-                rec_buf[0] = dist_util.pinned_bytes(int(need * 1.25) + 64)
-            n = lib.rtx_result_pack(ctypes.byref(view), rec_buf[0].ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), rec_buf[0].shape[0])
+            if rec_buf[k] is None or rec_buf[k].shape[0] < need:
+                rec_buf[k] = dist_util.pinned_bytes(int(need * 1.25) + 64)
+            n = lib.rtx_result_pack(ctypes.byref(view), rec_buf[k].ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), rec_buf[k].shape[0])
             assert n == need, "rtx_result_pack failed"
-            rec = rec_buf[0][:n]
-            dist_util.gather_records(dist, rec, rank, world, device=coll_device, cache=gather_cache)
+            if pending[0] is not None:
+                dist_util.gather_finish(pending[0])
+            pending[0] = dist_util.gather_start(dist, rec_buf[k][:n], rank, world, device=coll_device, cache=gather_cache[k])
         return view
 
     def barrier():
+        if pending[0] is not None:      # the gather of the last step belongs to the timed region
+            dist_util.gather_finish(pending[0])
+            pending[0] = None
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()

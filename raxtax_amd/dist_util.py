@@ -89,11 +89,12 @@ def pinned_bytes(n: int) -> np.ndarray:
     return np.empty(n, dtype=np.uint8)
 
 
-def gather_records(dist, rec: np.ndarray, rank: int, world: int, device: str = "cpu", cache: Optional[dict] = None) -> Optional[List[np.ndarray]]:
-    """Gathers variable-length byte buffers on rank 0: all_gather of the sizes, then one dist.gather of
-    buffers padded to the largest size.  Returns the per-rank buffers on rank 0 (host memory), None elsewhere.
-    `cache` (a dict kept by the caller across steps) holds the device and pinned staging buffers, so that a step
-    costs one H2D per rank and one D2H on rank 0 at PCIe rate instead of pageable copies and allocations."""
+def gather_start(dist, rec: np.ndarray, rank: int, world: int, device: str = "cpu", cache: Optional[dict] = None) -> dict:
+    """Starts the gather of variable-length byte buffers on rank 0: all_gather of the sizes (blocking, 8 bytes per
+    rank), then ONE asynchronous dist.gather of buffers padded to the largest size.  `cache` (a dict kept by the caller
+    across steps; use two of them alternately when gathers overlap with the next step) holds the device and pinned
+    staging buffers, so that a step costs one H2D per rank and one D2H on rank 0 at PCIe rate instead of pageable
+    copies and allocations.  Returns a ticket for gather_finish."""
     import torch
 
     cache = {} if cache is None else cache
@@ -108,17 +109,30 @@ def gather_records(dist, rec: np.ndarray, rank: int, world: int, device: str = "
         cache["buf"] = torch.zeros((c2,), dtype=torch.uint8, device=device)
         cache["gathered"] = [torch.zeros((c2,), dtype=torch.uint8, device=device) for _ in range(world)] if rank == 0 else None
         cache["host"] = torch.from_numpy(pinned_bytes(c2 * world)) if (rank == 0 and device != "cpu") else None
-    c2 = cache["cap"]
     buf = cache["buf"]
     if rec.shape[0]:
         buf[: rec.shape[0]].copy_(torch.from_numpy(rec), non_blocking=True)   # rec in pinned memory: asynchronous H2D
-    dist.gather(buf, cache["gathered"], dst=0)
-    if rank != 0:
+    work = dist.gather(buf, cache["gathered"], dst=0, async_op=True)
+    return dict(work=work, sizes=sizes, cache=cache, rank=rank, world=world, device=device)
+
+
+def gather_finish(ticket: dict) -> Optional[List[np.ndarray]]:
+    """Waits for a gather_start; on rank 0 brings the gathered buffers to (pinned) host memory and returns them."""
+    import torch
+
+    ticket["work"].wait()
+    if ticket["rank"] != 0:
         return None
-    if device == "cpu":
+    cache, sizes, world = ticket["cache"], ticket["sizes"], ticket["world"]
+    if ticket["device"] == "cpu":
         return [g[:sizes[i]].numpy().copy() for i, g in enumerate(cache["gathered"])]
-    host = cache["host"]
+    c2, host = cache["cap"], cache["host"]
     for i, g in enumerate(cache["gathered"]):
         host[i * c2: i * c2 + sizes[i]].copy_(g[:sizes[i]], non_blocking=True)
     torch.cuda.synchronize()
     return [host[i * c2: i * c2 + sizes[i]].numpy() for i in range(world)]
+
+
+def gather_records(dist, rec: np.ndarray, rank: int, world: int, device: str = "cpu", cache: Optional[dict] = None) -> Optional[List[np.ndarray]]:
+    """gather_start + gather_finish."""
+    return gather_finish(gather_start(dist, rec, rank, world, device, cache))

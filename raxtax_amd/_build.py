@@ -33,13 +33,31 @@ def _stale(target: Path, deps) -> bool:
     return any(Path(d).stat().st_mtime > t for d in deps if Path(d).exists())
 
 
+OBJ = PKG / "_obj"   # per-source objects (git-ignored): sources compile in parallel and only when they changed
+
+
 def build_lib(force: bool = False, verbose: bool = False) -> Path:
+    from concurrent.futures import ThreadPoolExecutor
+
     srcs = [CSRC / s for s in SOURCES if (CSRC / s).exists()]
-    deps = srcs + [CSRC / h for h in HEADERS] + [ROOT / "include" / "raxtax_hip.h"]
-    if not force and not _stale(LIB, deps):
+    hdrs = [CSRC / h for h in HEADERS] + [ROOT / "include" / "raxtax_hip.h"]
+    if not force and not _stale(LIB, srcs + hdrs):
         return LIB
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           f"-I{ROOT / 'include'}", f"-I{CSRC}", "-o", str(LIB)] + [str(s) for s in srcs] + ["-lpthread"]
+    OBJ.mkdir(exist_ok=True)
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", f"-I{ROOT / 'include'}", f"-I{CSRC}"]
+
+    def compile_one(src: Path) -> Path:
+        obj = OBJ / (src.name + ".o")
+        if force or _stale(obj, [src] + hdrs):
+            cmd = [_hipcc()] + flags + ["-x", "hip", "-c", str(src), "-o", str(obj)]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(len(srcs), os.cpu_count() or 1)) as ex:
+        objs = list(ex.map(compile_one, srcs))
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-fPIC", "-shared", "-o", str(LIB)] + [str(o) for o in objs] + ["-lpthread"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -36,8 +36,8 @@ HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~629
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--refs", type=int, default=50_000, help="reference sequences (replicated per GPU)")
     ap.add_argument("--queries", type=int, default=100_000, help="queries per GPU per step")
     ap.add_argument("--sub-batch", type=int, default=0, help="queries per kernel wave (0 = auto)")

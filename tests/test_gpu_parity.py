@@ -719,3 +719,33 @@ def test_randomised_configurations(oracle, seed):
         t, counts = otree.hit_counts(qs[i])
         assert np.array_equal(ix.debug_hit_counts(j), counts), (seed, i)
         assert np.array_equal(ix.debug_kmers(j), oracle.sequence_to_kmers(qs[i]))
+
+
+def test_result_arena_overflow_is_recovered(oracle):
+    """Far more result rows than the arena was sized for (n_queries * 8 + 4096): the walk flags the overflow, the
+    download grows the arena and repeats the deterministic run -- also when it was streaming sub-batch by sub-batch."""
+    db = synth.make_db(9000, length=150)
+    otree = oracle.tree_new_flat(db.lineages, db.seq_bytes, db.seq_off)
+    tree = rx.Tree.new_flat(db.lineages, db.seq_bytes, db.seq_off)
+    rng = np.random.default_rng(4)
+    qs = [db.seq(int(i))[:int(rng.integers(12, 30))].copy() for i in rng.integers(0, db.n, 700)]   # short: dozens of rows each
+    qoff = np.zeros(len(qs) + 1, np.uint64)
+    qoff[1:] = np.cumsum([len(q) for q in qs])
+    bases = np.concatenate(qs)
+    for kw in (dict(), dict(sub_batch=64)):
+        ix = rx.Index(tree, **kw)
+        ex = ix.exact_matches(bases, qoff)
+        res = ix.classify(bases, qoff, *ex)
+        n_rows = int(res.row_off[-1])
+        assert n_rows > len(qs) * 8 + 4096, n_rows          # the first attempt cannot have fitted
+        again = ix.classify(bases, qoff, *ex)               # the arena is large enough now
+        assert np.array_equal(res.row_off, again.row_off) and np.array_equal(res.row_lineage, again.row_lineage)
+        assert np.array_equal(res.row_conf, again.row_conf)
+        for q in (0, 123, 699):
+            rows, _ = _oracle_rows(otree, qs[q], False)
+            if rows is None:
+                assert res.status[q] != 0
+                continue
+            t, counts = otree.hit_counts(qs[q])
+            probs = oracle.highest_hit_prob_per_reference(t, t // 2, counts)
+            assert_rows_equivalent(res.rows(q), rows, probs, otree.lineages, f"q {q}")

@@ -61,9 +61,21 @@ __global__ __launch_bounds__(256) void prob_tables_build_kernel(ProbTables tb, c
     meta_sat[m] = (uint16_t)sat;
 }
 
+// One f64 of a table row through a raw buffer load.  The descriptor covers the table of this t from its base up to
+// the END of the wanted part of the row (`end` bytes), the row start goes into the SGPR offset and the only vector
+// operand is the byte offset inside the row.  On gfx950 the bounds check of a raw buffer includes the SGPR offset
+// (tools/micro/soffset_bounds.hip), so offsets at or beyond end - off read 0.0: per row the descriptor changes in
+// one dword (num_records) -- no scalar or vector address arithmetic at all.
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double row_load_f64(const double *table, uint32_t off, uint32_t end, uint32_t voff) {
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(table), 0, end, 0x00027000);
+    const u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff, off, 0);
+    return __hiloint2double((int)v.y, (int)v.x);
+}
+
 // ---------------------------------------------------------------------------
 // per-query lookup kernel: 256 threads (4 waves) per query
-// LDS (dynamic): Pi[n1max] f64 | red[16] f64 | row_h[tmax+2] u32 | row_m, row_sat, ms [tmax+2] u16 each
+// LDS (dynamic): Pi[n1max] f64 | red[16] f64 | row_h[tmax+18] u32 | row_m, row_sat, ms [tmax+18] u16 each | hl[tmax+4] u32 | row_off, row_end [tmax+18] u32
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void prob_lookup_kernel(ProbParams p, ProbTables tb) {
     extern __shared__ double smem[];
@@ -81,6 +93,8 @@ __global__ __launch_bounds__(256) void prob_lookup_kernel(ProbParams p, ProbTabl
     uint16_t *row_sat = row_m + (p.tmax + 18);
     uint16_t *ms = row_sat + (p.tmax + 18);
     uint32_t *hl = reinterpret_cast<uint32_t *>(ms + ((p.tmax + 18 + 1) & ~1u));  // [tmax+2] histogram copy
+    uint32_t *row_off = hl + (p.tmax + 4);      // [tmax+18] byte offset of row m in the tables of this t
+    uint32_t *row_end = row_off + (p.tmax + 18);  // [tmax+18] byte offset of the end of its part below saturation
     const uint32_t *hist = p.hist + (size_t)q * p.hstride;
     double *tz = p.table_z + (size_t)q * p.hstride;
     const double *lf = p.lnfact;
@@ -145,52 +159,56 @@ __global__ __launch_bounds__(256) void prob_lookup_kernel(ProbParams p, ProbTabl
                     row_m[pos] = (uint16_t)m;
                     row_sat[pos] = (uint16_t)sat;
                     row_h[pos] = hl[m];  // pos <= j: the staged entries still needed lie at indices > j
+                    row_off[pos] = m * n1 * 8u;
+                    row_end[pos] = (m * n1 + (sat < n1 ? sat : n1)) * 8u;
                 }
                 na += (uint32_t)__popcll(bal);
             }
             // pad to a multiple of 16 with neutral rows (m = 0: ln cmf = 0, sat = 0, h = 0)
             const uint32_t padded = (na + 15u) & ~15u;
-            if (na + lane < padded) { row_m[na + lane] = 0; row_sat[na + lane] = 0; row_h[na + lane] = 0; }
+            if (na + lane < padded) { row_m[na + lane] = 0; row_sat[na + lane] = 0; row_h[na + lane] = 0; row_off[na + lane] = 0; row_end[na + lane] = 0; }
             if (lane == 0) s_nact = na;
         }
         __syncthreads();
         const uint32_t nact = s_nact;
         // ---- pass 1: P(i) = exp(sum_m hist[m] ln cmf_m(i))  (prob.rs:62-73), lanes <-> i.  Rows are taken
         // sixteen at a time: sixteen independent 512-byte row-slice loads in flight per wave, one FMA each.
+        // Rows are read through row_load_f64: lanes past saturation (factor 1, ln = 0) or past n get 0.0 from the
+        // bounds check -- no per-lane compare, select or address arithmetic.
         for (uint32_t i0 = i_lo + wave * 64; i0 <= n; i0 += 256) {
             const uint32_t i = i0 + lane;
-            const bool in = i <= n;
+            const uint32_t voff = i * 8u;
             double S = 0.0;
             for (uint32_t r0 = 0; r0 < nact; r0 += 16) {
+                const uint32_t l16 = r0 + (lane & 15u);
+                const uint32_t ov = row_off[l16], ev = row_end[l16], hv = row_h[l16];
                 double c[16];
 #pragma unroll
-                for (int k = 0; k < 16; k++) {
-                    const uint32_t m = row_m[r0 + k], sat = row_sat[r0 + k];
-                    c[k] = (in && i < sat) ? Ct[(size_t)m * n1 + i] : 0.0;  // past saturation the factor is 1
-                }
+                for (int k = 0; k < 16; k++)
+                    c[k] = row_load_f64(Ct, (uint32_t)__builtin_amdgcn_readlane((int)ov, k), (uint32_t)__builtin_amdgcn_readlane((int)ev, k), voff);
 #pragma unroll
                 for (int k = 0; k < 16; k++) {
-                    const uint32_t h = __builtin_amdgcn_readfirstlane(row_h[r0 + k]);
+                    const uint32_t h = (uint32_t)__builtin_amdgcn_readlane((int)hv, k);
                     S = fma((double)h, c[k], S);
                 }
             }
-            if (in) Pi[i - i_lo] = exp(S);
+            if (i <= n) Pi[i - i_lo] = exp(S);
         }
         __syncthreads();
         // ---- pass 2: table[m] = sum_i pmf_m(i) P(i) / cmf_m(i)  (prob.rs:74-90); a wave takes eight
-        // rows per turn and two 64-wide slices of i at a time (sixteen loads in flight), then one DPP
-        // reduction per row
+        // rows per turn and two 64-wide slices of i at a time (sixteen loads in flight), then one joint
+        // reduction of the eight rows.  Rows through row_load_f64 as in pass 1 (a padding row has end = off: all zeros).
         for (uint32_t r0 = wave * 8; r0 < nact; r0 += 32) {
             double acc[8];
-            uint32_t mm[8], last[8];
+            uint32_t off[8], end[8];
             uint32_t lmax = 0;
 #pragma unroll
             for (int k = 0; k < 8; k++) {
                 acc[k] = 0.0;
-                mm[k] = row_m[r0 + k];
-                const uint32_t sat = row_sat[r0 + k];
-                last[k] = sat == 0 ? 0u : (sat - 1u < n ? sat - 1u : n);
-                lmax = max(lmax, last[k]);
+                off[k] = (uint32_t)__builtin_amdgcn_readfirstlane((int)row_off[r0 + k]);
+                end[k] = (uint32_t)__builtin_amdgcn_readfirstlane((int)row_end[r0 + k]);
+                const uint32_t cnt = (end[k] - off[k]) >> 3;  // entries below saturation (0 for a padding row)
+                lmax = max(lmax, cnt ? cnt - 1u : 0u);
             }
             for (uint32_t ib = i_lo; ib <= lmax; ib += 128) {
                 double rv[2][8], P2[2];
@@ -199,17 +217,17 @@ __global__ __launch_bounds__(256) void prob_lookup_kernel(ProbParams p, ProbTabl
                     const uint32_t i = ib + c * 64 + lane;
                     P2[c] = i <= lmax ? Pi[i - i_lo] : 0.0;
 #pragma unroll
-                    for (int k = 0; k < 8; k++) rv[c][k] = (mm[k] != 0 && i <= last[k]) ? Rt[(size_t)mm[k] * n1 + i] : 0.0;
+                    for (int k = 0; k < 8; k++) rv[c][k] = row_load_f64(Rt, off[k], end[k], i * 8u);
                 }
 #pragma unroll
                 for (int c = 0; c < 2; c++)
 #pragma unroll
                     for (int k = 0; k < 8; k++) acc[k] = fma(rv[c][k], P2[c], acc[k]);
             }
-#pragma unroll
-            for (int k = 0; k < 8; k++) {
-                const double v = wave_sum_f64_dpp(acc[k]);
-                if (lane == 0 && mm[k] != 0) tz[mm[k]] = v;
+            const double v = wave_sum8_f64(acc);  // lane l: total of row r0 + (l & 7)
+            if (lane < 8) {
+                const uint32_t m = row_m[r0 + lane];
+                if (m != 0) tz[m] = v;
             }
         }
         if (tid == 0 && ms[0] == 0) tz[0] = i_lo == 0 ? Pi[0] : 0.0;  // m = 0: table[0] = P(0)
@@ -277,7 +295,7 @@ __global__ __launch_bounds__(1024) void prob_order_kernel(const uint32_t *__rest
 size_t prob_lookup_lds_bytes(uint32_t tmax) {
     const size_t n1max = tmax / 2 + 1;
     return sizeof(double) * (n1max + 16) + (sizeof(uint32_t) + 3 * sizeof(uint16_t)) * ((size_t)tmax + 18) + 8 +
-           sizeof(uint32_t) * ((size_t)tmax + 4);
+           sizeof(uint32_t) * ((size_t)tmax + 4) + 2 * sizeof(uint32_t) * ((size_t)tmax + 18);
 }
 void launch_prob_tables_build(hipStream_t s, const ProbTables &tb, const double *lf, const double *inv) {
     hipLaunchKernelGGL(prob_tables_build_kernel, dim3((tb.tmax + 255) / 256, tb.tmax - 1), dim3(256), 0, s, tb, lf, inv);

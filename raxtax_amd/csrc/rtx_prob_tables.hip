@@ -264,7 +264,7 @@ __global__ __launch_bounds__(256) void prob_lookup_kernel(ProbParams p, ProbTabl
 }
 
 // ---------------------------------------------------------------------------
-// processing order of a sub-batch for prob_lookup: queries grouped by t (ascending), so that
+// processing order of a sub-batch for prob_lookup: queries grouped by t (descending), so that
 // concurrently resident workgroups read the same (t) tables out of L2.  One workgroup: counting sort
 // over t <= 1023 in LDS (histogram, exclusive scan, scatter).  The order inside one t is arbitrary;
 // it only decides which workgroup runs when, never a result.
@@ -286,7 +286,8 @@ __global__ __launch_bounds__(1024) void prob_order_kernel(const uint32_t *__rest
     for (uint32_t w = 0; w < wave; w++) off += wsum[w];
     bin[tid] = off + incl - v;
     __syncthreads();
-    for (uint32_t q = tid; q < nq; q += 1024) order[atomicAdd(&bin[t[q] < 1023u ? t[q] : 1023u], 1u)] = q;
+    // descending t: the longest queries start first and the short ones fill the tail of the launch
+    for (uint32_t q = tid; q < nq; q += 1024) order[nq - 1u - atomicAdd(&bin[t[q] < 1023u ? t[q] : 1023u], 1u)] = q;
 }
 
 // ---------------------------------------------------------------------------

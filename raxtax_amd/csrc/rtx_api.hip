@@ -147,8 +147,9 @@ struct rtx_index {
     FlatNodes nodes;
     std::vector<uint32_t> bnd;  // sorted unique range endpoints
     uint32_t n_bnd = 0;
-    DevBuf<uint32_t> d_blo, d_bhi, d_first, d_nch, d_bnd_rank;
-    DevBuf<uint8_t> d_type, d_bnd_bits;
+    DevBuf<uint4> d_noderec;  // {blo, bhi, first_child, n_children | type << 30} per node (lineage_walk)
+    DevBuf<uint32_t> d_bnd_rank;
+    DevBuf<uint8_t> d_bnd_bits;
     // ---- batch inputs
     uint64_t n_q = 0;
     bool uploaded = false, ran = false, synced = false;
@@ -349,8 +350,11 @@ int enqueue_count(rtx_index *ix, const SubBatch &b, uint32_t flags) {
     return rc ? rc : enqueue_hit(ix, b, flags, b.s);
 }
 
-// group 2: prob table from the (whole-database) histogram + prefix sums over this handle's references
-int enqueue_prob_prefix(rtx_index *ix, const SubBatch &b) {
+static WalkParams walk_params(rtx_index *ix, const SubBatch &b, const double *prefix);
+
+// group 2: prob table from the (whole-database) histogram + prefix sums over this handle's references; with
+// fuse_walk (whole database on this handle) the taxonomy walk of group 3 runs inside the prefix kernel
+int enqueue_prob_prefix(rtx_index *ix, const SubBatch &b, bool fuse_walk) {
     rtx_index::Scratch &sc = ix->sc[b.set];
     hipStream_t s = b.s;
     ProbParams pp{};
@@ -392,6 +396,8 @@ int enqueue_prob_prefix(rtx_index *ix, const SubBatch &b) {
     fp.bnd_rank = ix->d_bnd_rank.p;
     fp.prefix = sc.d_prefix.p;
     fp.n_bnd = ix->n_bnd_local;
+    fp.fuse_walk = fuse_walk ? 1u : 0u;
+    if (fuse_walk) fp.walk = walk_params(ix, b, sc.d_prefix.p);
     if (b.timed_all) RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_TAXON_PREFIX, 0), s));
     launch_taxon_prefix(s, fp, b.nq);
     if (b.timed_all) RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_TAXON_PREFIX, 1), s));
@@ -399,23 +405,24 @@ int enqueue_prob_prefix(rtx_index *ix, const SubBatch &b) {
 }
 
 // group 3: taxonomy walk over prefix sums covering the WHOLE database ([nq][n_bnd], device)
-int enqueue_walk(rtx_index *ix, const SubBatch &b, const double *prefix, hipStream_t s) {
+static WalkParams walk_params(rtx_index *ix, const SubBatch &b, const double *prefix) {
     WalkParams wp{};
     wp.status = ix->d_status.p;
     wp.q0 = b.q0;
     wp.prefix = prefix;
     wp.n_bnd = ix->n_bnd;
-    wp.blo = ix->d_blo.p;
-    wp.bhi = ix->d_bhi.p;
-    wp.first_child = ix->d_first.p;
-    wp.n_children = ix->d_nch.p;
-    wp.type = ix->d_type.p;
+    wp.rec = ix->d_noderec.p;
     wp.arena = ix->d_arena.p;
     wp.arena_cap = ix->arena_cap;
     wp.arena_cursor = ix->d_cursor.p;
     wp.n_rows = ix->d_n_rows.p;
     wp.row_start = ix->d_row_start.p;
     wp.flags_out = ix->d_flags.p;
+    return wp;
+}
+
+int enqueue_walk(rtx_index *ix, const SubBatch &b, const double *prefix, hipStream_t s) {
+    const WalkParams wp = walk_params(ix, b, prefix);
     if (b.timed_all) RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_LINEAGE_WALK, 0), s));
     launch_lineage_walk(s, wp, b.nq);
     if (b.timed_all) RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_LINEAGE_WALK, 1), s));
@@ -520,14 +527,20 @@ int enqueue_batch(rtx_index *ix, uint32_t flags) {
             return rc;
         }
         if (two && sb >= 2) RTX_HIP(hipStreamWaitEvent(b.s, ix->ev_sub[sb - 2], 0));  // walk(sb-2) still reads this prefix buffer
-        if ((rc = enqueue_prob_prefix(ix, b))) return rc;
+        // one stream: the walk rides inside the prefix kernel (the stage time of lineage_walk is then part of taxon_prefix)
+        const bool fuse = !two && ix->n_refs == ix->n_total && ix->n_bnd_local == ix->n_bnd;
+        if ((rc = enqueue_prob_prefix(ix, b, fuse))) return rc;
         hipStream_t ws = b.s;
         if (two) {
             RTX_HIP(hipEventRecord(ix->ev_pre[sb], b.s));
             RTX_HIP(hipStreamWaitEvent(side, ix->ev_pre[sb], 0));
             ws = side;
         }
-        if ((rc = enqueue_walk(ix, b, ix->sc[b.set].d_prefix.p, ws))) return rc;
+        if (!fuse && (rc = enqueue_walk(ix, b, ix->sc[b.set].d_prefix.p, ws))) return rc;
+        if (fuse && b.timed_all) {  // keeps rtx_batch_stage_times whole: an empty interval
+            RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_LINEAGE_WALK, 0), ws));
+            RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_LINEAGE_WALK, 1), ws));
+        }
         if (ix->stream_dl) {
             RTX_HIP(hipMemcpyAsync(&ix->h_cursor_sub[sb], ix->d_cursor.p, 8, hipMemcpyDeviceToHost, ws));
             RTX_HIP(hipEventRecord(ix->ev_sub[sb], ws));
@@ -817,17 +830,16 @@ static int create_common(int device, uint64_t n_total, uint64_t ref_lo, uint64_t
             rank[c] = run;
             run += (uint32_t)__builtin_popcount(bits[c]);
         }
-        if ((rc = ix->d_blo.alloc(n_nodes)) || (rc = ix->d_bhi.alloc(n_nodes)) || (rc = ix->d_first.alloc(n_nodes)) ||
-            (rc = ix->d_nch.alloc(n_nodes)) || (rc = ix->d_type.alloc(n_nodes)) || (rc = ix->d_bnd_bits.alloc(nchunk)) ||
-            (rc = ix->d_bnd_rank.alloc(nchunk)))
+        std::vector<uint4> noderec(n_nodes);
+        for (uint32_t v = 0; v < n_nodes; v++) {
+            if (ix->nodes.n_children[v] >= (1u << 30)) { set_error("node with 2^30 or more children"); return fail(RTX_ERR_INVALID); }
+            noderec[v] = make_uint4(blo[v], bhi[v], ix->nodes.first_child[v], ix->nodes.n_children[v] | ((uint32_t)ix->nodes.type[v] << 30));
+        }
+        if ((rc = ix->d_noderec.alloc(n_nodes)) || (rc = ix->d_bnd_bits.alloc(nchunk)) || (rc = ix->d_bnd_rank.alloc(nchunk)))
             return fail(rc);
         hipError_t e = hipSuccess;
         auto up = [&](void *d, const void *h, size_t bytes) { if (e == hipSuccess) e = hipMemcpy(d, h, bytes, hipMemcpyHostToDevice); };
-        up(ix->d_blo.p, blo.data(), n_nodes * 4);
-        up(ix->d_bhi.p, bhi.data(), n_nodes * 4);
-        up(ix->d_first.p, ix->nodes.first_child.data(), n_nodes * 4);
-        up(ix->d_nch.p, ix->nodes.n_children.data(), n_nodes * 4);
-        up(ix->d_type.p, ix->nodes.type.data(), n_nodes);
+        up(ix->d_noderec.p, noderec.data(), (size_t)n_nodes * sizeof(uint4));
         up(ix->d_bnd_bits.p, bits.data(), nchunk);
         up(ix->d_bnd_rank.p, rank.data(), nchunk * 4);
         if (e != hipSuccess) { set_error("taxonomy upload failed: %s", hipGetErrorString(e)); return fail(RTX_ERR_HIP); }
@@ -1069,7 +1081,7 @@ uint64_t rtx_index_num_refs(const rtx_index *index) { return index ? index->n_to
 uint64_t rtx_index_device_bytes(const rtx_index *index) {
     if (!index) return 0;
     return index->d_seg_dbits.n * 8 + index->d_seg_sbits.n * 8 + index->d_seg_sbase.n * 4 + index->d_seginfo.n * 4 + index->d_segslots.n * 2 + index->d_bitmap.n * 4 + index->d_row_of.n * 4 + index->d_list_len.n * 4 + index->d_lnfact.n * 8 +
-           index->d_blo.n * 4 * 4 + index->d_type.n + index->d_bnd_bits.n + index->d_bnd_rank.n * 4;
+           index->d_noderec.n * 16 + index->d_bnd_bits.n + index->d_bnd_rank.n * 4;
 }
 int rtx_index_set_batch(rtx_index *index, uint32_t sub_batch) {
     if (!index) { set_error("null index handle"); return RTX_ERR_INVALID; }
@@ -1372,7 +1384,7 @@ int rtx_shard_prob(rtx_index *ix, uint32_t sb) {
     SubBatch b;
     int rc = shard_sb(ix, sb, &b);
     if (rc) return rc;
-    return enqueue_prob_prefix(ix, b);
+    return enqueue_prob_prefix(ix, b, false);
 }
 
 int rtx_shard_walk(rtx_index *ix, uint32_t sb, const double *prefix_global) {
@@ -1556,11 +1568,7 @@ int rtx_debug_evaluate(rtx_index *ix, const double *probs, rtx_result_view *out)
     wp.q0 = 0;
     wp.prefix = ix->sc[ix->last_set].d_prefix.p;
     wp.n_bnd = ix->n_bnd;
-    wp.blo = ix->d_blo.p;
-    wp.bhi = ix->d_bhi.p;
-    wp.first_child = ix->d_first.p;
-    wp.n_children = ix->d_nch.p;
-    wp.type = ix->d_type.p;
+    wp.rec = ix->d_noderec.p;
     wp.arena = ix->d_arena.p;
     wp.arena_cap = ix->arena_cap;
     wp.arena_cursor = ix->d_cursor.p;

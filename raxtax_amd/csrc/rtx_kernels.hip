@@ -762,6 +762,227 @@ __global__ __launch_bounds__(kProbThreads) void prob_table_kernel(ProbParams p) 
 }
 
 // ---------------------------------------------------------------------------
+// lineage_walk (src/lineage.rs:114-179): one wave per query, explicit DFS stack; the 64
+// lanes evaluate 64 children of the current node at once (confidence = P[hi]-P[lo],
+// lineage.rs:114-117; rounding lineage.rs:128-129).  Rows (node id + per-level rounded
+// confidences in hundredths) are staged in LDS and appended to a global arena with one
+// atomic per query.  Sorting (lineage.rs:91-93) and the local signal happen on the host.
+//
+// A walk is a chain of dependent loads, so the kernel is built to keep that chain short: a node is one 16-byte
+// record {blo, bhi, first_child, n_children | type << 30}, so the load that fetches the children's ranges also
+// brings what is needed to descend into any of them (children records -> P -> decision: two dependent loads per
+// level instead of three); everything about the nodes on the stack (record, position, the still unvisited
+// significant children of the 64 scanned last) lives in LDS, so returning to a parent costs no global load and
+// no second scan.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ int rounded_conf(const double *__restrict__ P, uint32_t blo, uint32_t bhi) {
+    const double conf = P[bhi] - P[blo];
+    const double r = round(conf * 100.0);  // f64::round: half away from zero
+    return r > 255.0 ? 255 : (r < -255.0 ? -255 : (int)r);
+}
+
+struct WalkLds {  // LDS state of one walking wave
+    unsigned long long st_mask[RTX_MAX_DEPTH + 1];  // which of the 64 children scanned last are significant and unvisited ...
+    uint32_t st_mbase[RTX_MAX_DEPTH + 1];           // ... and the index of the first of them
+    uint32_t st_node[RTX_MAX_DEPTH + 1];
+    uint32_t st_fc[RTX_MAX_DEPTH + 1];              // first child / number of children / type of the node
+    uint32_t st_nch[RTX_MAX_DEPTH + 1];
+    uint32_t st_next[RTX_MAX_DEPTH + 1];            // first child not scanned yet
+    uint8_t st_type[RTX_MAX_DEPTH + 1];
+    uint8_t st_nosig[RTX_MAX_DEPTH + 1];
+    uint8_t st_pushed[RTX_MAX_DEPTH + 1];
+    uint8_t kpath[RTX_MAX_DEPTH + 1];
+    DevRow rows[kWalkMaxRows];
+};
+
+// Orders the LDS traffic of ONE wave (lane 0 writes the stack, all lanes read it): the hardware keeps the LDS
+// operations of a wave in order, this only stops the compiler from moving them.  No s_barrier: the walking wave
+// may be the last one alive in its workgroup (fused into taxon_prefix).
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// The walk of query slot q by the calling wave (all 64 lanes).
+__device__ __forceinline__ void lineage_walk_wave(const WalkParams &p, uint32_t q, uint32_t lane, WalkLds &L) {
+    auto &st_mask = L.st_mask;
+    auto &st_mbase = L.st_mbase;
+    auto &st_node = L.st_node;
+    auto &st_fc = L.st_fc;
+    auto &st_nch = L.st_nch;
+    auto &st_next = L.st_next;
+    auto &st_type = L.st_type;
+    auto &st_nosig = L.st_nosig;
+    auto &st_pushed = L.st_pushed;
+    auto &kpath = L.kpath;
+    auto &rows = L.rows;
+    const uint64_t gq = p.q0 + q;
+    if (p.status[gq] != RTX_Q_OK) {
+        if (lane == 0) { p.n_rows[gq] = 0; p.row_start[gq] = 0; }
+        return;
+    }
+    const double *__restrict__ P = p.prefix + (size_t)q * p.n_bnd;
+    const uint4 *__restrict__ rec = p.rec;
+    uint32_t nrows = 0;
+    bool overflow = false;
+
+    auto emit = [&](uint32_t node, uint32_t depth) {
+        if (nrows < kWalkMaxRows) {
+            if (lane == 0) rows[nrows].node = node;
+            if (lane < RTX_MAX_DEPTH) rows[nrows].k[lane] = lane < depth ? kpath[lane] : 0;
+        } else {
+            overflow = true;
+        }
+        nrows++;
+    };
+
+    int depth = 0;
+    {
+        const uint4 root = rec[0];
+        if (lane == 0) {
+            st_node[0] = 0; st_fc[0] = root.z; st_nch[0] = root.w & 0x3FFFFFFFu; st_type[0] = (uint8_t)(root.w >> 30);
+            st_next[0] = 0; st_mbase[0] = 0; st_mask[0] = 0; st_nosig[0] = 1; st_pushed[0] = 0;
+        }
+    }
+    wave_lds_sync();
+    while (depth >= 0) {
+        const uint32_t node = st_node[depth], fc = st_fc[depth], nch = st_nch[depth], type = st_type[depth];
+        uint32_t next = st_next[depth], mbase = st_mbase[depth];
+        unsigned long long mask = st_mask[depth];
+        int found = -1;
+        int kf = 0;
+        uint32_t cfc = 0, cnt = 0;  // first child and n_children | type of the child found
+        if (mask) {  // a significant child of the chunk scanned before: its record again (one uniform load)
+            const int bit = __builtin_ctzll(mask);
+            mask &= mask - 1;
+            found = (int)mbase + bit;
+            const uint4 cr = rec[fc + (uint32_t)found];
+            kf = rounded_conf(P, cr.x, cr.y);
+            cfc = cr.z;
+            cnt = cr.w;
+        } else {
+            while (next < nch) {
+                const uint32_t idx = next + lane;
+                int kk = 0;
+                uint4 cr = make_uint4(0, 0, 0, 0);
+                if (idx < nch) {
+                    cr = rec[fc + idx];
+                    kk = rounded_conf(P, cr.x, cr.y);
+                }
+                const unsigned long long bal = __ballot(kk != 0);
+                mbase = next;
+                next += 64;
+                if (bal) {
+                    const int first = __builtin_ctzll(bal);
+                    mask = bal & (bal - 1);
+                    found = (int)mbase + first;
+                    kf = __shfl(kk, first, 64);
+                    cfc = (uint32_t)__shfl((int)cr.z, first, 64);
+                    cnt = (uint32_t)__shfl((int)cr.w, first, 64);
+                    break;
+                }
+            }
+        }
+        wave_lds_sync();
+        if (found >= 0) {
+            if (kf < 0 || kf > 200) overflow = true;  // cannot happen for probabilities
+            if (depth + 1 > (int)RTX_MAX_DEPTH) {  // guarded at index creation
+                overflow = true;
+                break;
+            }
+            if (lane == 0) {
+                st_next[depth] = next;
+                st_mbase[depth] = mbase;
+                st_mask[depth] = mask;
+                st_nosig[depth] = 0;
+                kpath[depth] = (uint8_t)(kf < 0 ? 255 : kf);
+                st_node[depth + 1] = fc + (uint32_t)found;
+                st_fc[depth + 1] = cfc;
+                st_nch[depth + 1] = cnt & 0x3FFFFFFFu;
+                st_type[depth + 1] = (uint8_t)(cnt >> 30);
+                st_next[depth + 1] = 0;
+                st_mbase[depth + 1] = 0;
+                st_mask[depth + 1] = 0;
+                st_nosig[depth + 1] = 1;
+                st_pushed[depth + 1] = 0;
+            }
+            depth++;
+            wave_lds_sync();
+            continue;
+        }
+        // children exhausted
+        bool pushed = st_pushed[depth] != 0;
+        if (st_nosig[depth] && type == kInner) {  // lineage.rs:151-177
+            uint32_t cn = node, ctype = type, cfirst = fc, cnch = nch;
+            uint32_t d = (uint32_t)depth;
+            while (ctype == kInner && cnch > 0) {
+                // Iterator::max_by keeps the LAST maximum
+                double best = -INFINITY;
+                uint32_t besti = 0, bz = 0, bw = 0;
+                bool have = false;
+                for (uint32_t idx = lane; idx < cnch; idx += 64) {
+                    const uint4 cr = rec[cfirst + idx];
+                    const double v = P[cr.y] - P[cr.x];
+                    if (!have || !(v < best)) { best = v; besti = idx; bz = cr.z; bw = cr.w; have = true; }
+                }
+#pragma unroll
+                for (int s = 32; s >= 1; s >>= 1) {
+                    const double ov = __shfl_xor(best, s, 64);
+                    const uint32_t oi = __shfl_xor(besti, s, 64);
+                    const int oh = __shfl_xor((int)have, s, 64);
+                    if (oh && (!have || ov > best || (ov == best && oi > besti))) { best = ov; besti = oi; have = true; }
+                }
+                // the winner is the local best of lane besti & 63, which still holds its record
+                cn = cfirst + besti;
+                cfirst = (uint32_t)__shfl((int)bz, (int)(besti & 63u), 64);
+                const uint32_t w = (uint32_t)__shfl((int)bw, (int)(besti & 63u), 64);
+                cnch = w & 0x3FFFFFFFu;
+                ctype = w >> 30;
+                if (d >= RTX_MAX_DEPTH) { overflow = true; break; }
+                if (lane == 0) kpath[d] = 1;  // 1.0 / rounding_factor
+                d++;
+            }
+            wave_lds_sync();
+            emit(cn, d);
+            pushed = true;
+        }
+        depth--;
+        if (depth >= 0) {
+            // back in the parent: lineage.rs:141-149
+            if (!pushed && type == kTaxon) {
+                emit(node, (uint32_t)depth + 1);
+                pushed = true;
+            }
+            if (pushed && lane == 0) st_pushed[depth] = 1;
+        }
+        wave_lds_sync();
+    }
+    wave_lds_sync();
+    const uint32_t keep = nrows < kWalkMaxRows ? nrows : kWalkMaxRows;
+    unsigned long long start = 0;
+    if (lane == 0) start = atomicAdd(p.arena_cursor, (unsigned long long)keep);
+    start = __shfl(start, 0, 64);
+    if (start + keep <= p.arena_cap) {
+        // DevRow = 9 dwords
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(rows);
+        uint32_t *dst = reinterpret_cast<uint32_t *>(p.arena + start);
+        for (uint32_t i = lane; i < keep * (uint32_t)(sizeof(DevRow) / 4); i += 64) dst[i] = src[i];
+    } else if (lane == 0) {
+        atomicOr(p.flags_out, 1u);  // arena overflow: host re-runs with a larger arena
+    }
+    if (lane == 0) {
+        p.n_rows[gq] = keep;
+        p.row_start[gq] = start;
+        if (overflow) atomicOr(p.flags_out, 2u);
+    }
+}
+
+__global__ __launch_bounds__(64) void lineage_walk_kernel(WalkParams p) {
+    __shared__ WalkLds L;
+    lineage_walk_wave(p, blockIdx.x, threadIdx.x, L);
+}
+
+// ---------------------------------------------------------------------------
 // taxon_prefix (src/lineage.rs:61-66): P[j] = sum_{r < bnd[j]} p_r, p_r = table[count_r]/Z,
 // sampled at the taxonomy boundaries only (every node range is [bnd[a], bnd[b])).
 // One workgroup of NW waves per query, 8 references per thread per sweep (NW*512 per sweep); the
@@ -781,7 +1002,10 @@ __global__ __launch_bounds__(NW * 64) void taxon_prefix_kernel(PrefixParams p) {
     const uint32_t q = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint64_t gq = p.q0 + q;
     double *__restrict__ P = p.prefix + (size_t)q * p.n_bnd;
-    if (p.status[gq] != RTX_Q_OK) return;
+    if (p.status[gq] != RTX_Q_OK) {
+        if (p.fuse_walk && tid == 0) { p.walk.n_rows[gq] = 0; p.walk.row_start[gq] = 0; }
+        return;
+    }
     const double *__restrict__ tzg = p.table_z + (size_t)q * p.hstride;
     if (TZ_LDS) {  // 8 random look-ups per reference chunk: serve them from LDS
         const uint32_t t1 = p.t[q] + 1;
@@ -852,153 +1076,13 @@ __global__ __launch_bounds__(NW * 64) void taxon_prefix_kernel(PrefixParams p) {
             }
         }
     }
-}
-
-// ---------------------------------------------------------------------------
-// lineage_walk (src/lineage.rs:114-179): one wave per query, explicit DFS stack; the 64
-// lanes evaluate 64 children of the current node at once (confidence = P[hi]-P[lo],
-// lineage.rs:114-117; rounding lineage.rs:128-129).  Rows (node id + per-level rounded
-// confidences in hundredths) are staged in LDS and appended to a global arena with one
-// atomic per query.  Sorting (lineage.rs:91-93) and the local signal happen on the host.
-// ---------------------------------------------------------------------------
-__device__ __forceinline__ double node_conf(const double *__restrict__ P, const uint32_t *__restrict__ blo,
-                                            const uint32_t *__restrict__ bhi, uint32_t node) {
-    return P[bhi[node]] - P[blo[node]];
-}
-
-__global__ __launch_bounds__(64) void lineage_walk_kernel(WalkParams p) {
-    __shared__ uint32_t st_node[RTX_MAX_DEPTH + 1];
-    __shared__ uint32_t st_cursor[RTX_MAX_DEPTH + 1];
-    __shared__ uint8_t st_nosig[RTX_MAX_DEPTH + 1];
-    __shared__ uint8_t st_pushed[RTX_MAX_DEPTH + 1];
-    __shared__ uint8_t kpath[RTX_MAX_DEPTH + 1];
-    __shared__ DevRow rows[kWalkMaxRows];
-    const uint32_t q = blockIdx.x, lane = threadIdx.x;
-    const uint64_t gq = p.q0 + q;
-    if (p.status[gq] != RTX_Q_OK) {
-        if (lane == 0) { p.n_rows[gq] = 0; p.row_start[gq] = 0; }
-        return;
-    }
-    const double *P = p.prefix + (size_t)q * p.n_bnd;
-    uint32_t nrows = 0;
-    bool overflow = false;
-
-    auto emit = [&](uint32_t node, uint32_t depth) {
-        if (nrows < kWalkMaxRows) {
-            if (lane == 0) rows[nrows].node = node;
-            if (lane < RTX_MAX_DEPTH) rows[nrows].k[lane] = lane < depth ? kpath[lane] : 0;
-        } else {
-            overflow = true;
-        }
-        nrows++;
-    };
-
-    int depth = 0;
-    if (lane == 0) { st_node[0] = 0; st_cursor[0] = 0; st_nosig[0] = 1; st_pushed[0] = 0; }
-    __syncthreads();
-    while (depth >= 0) {
-        const uint32_t node = st_node[depth];
-        uint32_t cur = st_cursor[depth];
-        const uint32_t nch = p.n_children[node], fc = p.first_child[node];
-        int found = -1;
-        uint32_t kval = 0;
-        while (cur < nch) {
-            const uint32_t idx = cur + lane;
-            int kk = 0;
-            if (idx < nch) {
-                const double conf = node_conf(P, p.blo, p.bhi, fc + idx);
-                const double r = round(conf * 100.0);  // f64::round: half away from zero
-                kk = r > 255.0 ? 255 : (r < -255.0 ? -255 : (int)r);
-            }
-            const unsigned long long bal = __ballot(kk != 0);
-            if (bal) {
-                const int first = __ffsll((long long)bal) - 1;
-                found = (int)cur + first;
-                const int kf = __shfl(kk, first, 64);
-                kval = (uint32_t)(kf < 0 ? 255 : kf);
-                if (kf < 0 || kf > 200) overflow = true;  // cannot happen for probabilities
-                break;
-            }
-            cur += 64;
-        }
-        __syncthreads();
-        if (found >= 0) {
-            if (depth + 1 > (int)RTX_MAX_DEPTH) {  // guarded at index creation
-                overflow = true;
-                break;
-            }
-            if (lane == 0) {
-                st_cursor[depth] = (uint32_t)found + 1;
-                st_nosig[depth] = 0;
-                kpath[depth] = (uint8_t)kval;
-                st_node[depth + 1] = fc + (uint32_t)found;
-                st_cursor[depth + 1] = 0;
-                st_nosig[depth + 1] = 1;
-                st_pushed[depth + 1] = 0;
-            }
-            depth++;
-            __syncthreads();
-            continue;
-        }
-        // children exhausted
-        bool pushed = st_pushed[depth] != 0;
-        if (st_nosig[depth] && p.type[node] == kInner) {  // lineage.rs:151-177
-            uint32_t cn = node;
-            uint32_t d = (uint32_t)depth;
-            while (p.type[cn] == kInner && p.n_children[cn] > 0) {
-                const uint32_t cnch = p.n_children[cn], cfc = p.first_child[cn];
-                // Iterator::max_by keeps the LAST maximum
-                double best = -INFINITY;
-                uint32_t besti = 0;
-                bool have = false;
-                for (uint32_t idx = lane; idx < cnch; idx += 64) {
-                    const double v = node_conf(P, p.blo, p.bhi, cfc + idx);
-                    if (!have || !(v < best)) { best = v; besti = idx; have = true; }
-                }
-#pragma unroll
-                for (int s = 32; s >= 1; s >>= 1) {
-                    const double ov = __shfl_xor(best, s, 64);
-                    const uint32_t oi = __shfl_xor(besti, s, 64);
-                    const int oh = __shfl_xor((int)have, s, 64);
-                    if (oh && (!have || ov > best || (ov == best && oi > besti))) { best = ov; besti = oi; have = true; }
-                }
-                cn = cfc + besti;
-                if (d >= RTX_MAX_DEPTH) { overflow = true; break; }
-                if (lane == 0) kpath[d] = 1;  // 1.0 / rounding_factor
-                d++;
-            }
-            __syncthreads();
-            emit(cn, d);
-            pushed = true;
-        }
-        depth--;
-        if (depth >= 0) {
-            // back in the parent: lineage.rs:141-149
-            if (!pushed && p.type[node] == kTaxon) {
-                emit(node, (uint32_t)depth + 1);
-                pushed = true;
-            }
-            if (pushed && lane == 0) st_pushed[depth] = 1;
-        }
-        __syncthreads();
-    }
-    __syncthreads();
-    const uint32_t keep = nrows < kWalkMaxRows ? nrows : kWalkMaxRows;
-    unsigned long long start = 0;
-    if (lane == 0) start = atomicAdd(p.arena_cursor, (unsigned long long)keep);
-    start = __shfl(start, 0, 64);
-    if (start + keep <= p.arena_cap) {
-        // DevRow = 9 dwords
-        const uint32_t *src = reinterpret_cast<const uint32_t *>(rows);
-        uint32_t *dst = reinterpret_cast<uint32_t *>(p.arena + start);
-        for (uint32_t i = lane; i < keep * (uint32_t)(sizeof(DevRow) / 4); i += 64) dst[i] = src[i];
-    } else if (lane == 0) {
-        atomicOr(p.flags_out, 1u);  // arena overflow: host re-runs with a larger arena
-    }
-    if (lane == 0) {
-        p.n_rows[gq] = keep;
-        p.row_start[gq] = start;
-        if (overflow) atomicOr(p.flags_out, 2u);
+    if (p.fuse_walk) {
+        // The walk of this query by wave 0 while the prefix sums are still in this XCD's L2 (a walk on its own is a
+        // chain of ~1.5 us misses: the prefix arrays of a sub-batch are 10x the L2); the other waves retire, and the
+        // walking wave hides under the streaming workgroups that take their place.  The dynamic LDS (the table copy,
+        // dead now) becomes the walk state.
+        __syncthreads();  // workgroup-scope release/acquire of the P stores (same CU: no cache maintenance needed)
+        if (wave == 0) lineage_walk_wave(p.walk, q, lane, *reinterpret_cast<WalkLds *>(tz_lds));
     }
 }
 
@@ -1053,7 +1137,8 @@ void launch_prob_table(hipStream_t s, const ProbParams &p, uint32_t nq) {
     hipLaunchKernelGGL(prob_table_kernel, dim3(nq), dim3(kProbThreads), prob_table_lds_bytes(p.tmax), s, p);
 }
 void launch_taxon_prefix(hipStream_t s, const PrefixParams &p, uint32_t nq) {
-    const size_t lds = p.tz_in_lds ? (size_t)p.hstride * sizeof(double) : 0;
+    size_t lds = p.tz_in_lds ? (size_t)p.hstride * sizeof(double) : 0;
+    if (p.fuse_walk) lds = std::max(lds, sizeof(WalkLds));
     if (p.tz_in_lds) hipLaunchKernelGGL((taxon_prefix_kernel<4, true>), dim3(nq), dim3(256), lds, s, p);
     else hipLaunchKernelGGL((taxon_prefix_kernel<4, false>), dim3(nq), dim3(256), lds, s, p);
 }

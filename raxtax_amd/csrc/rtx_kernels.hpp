@@ -118,6 +118,20 @@ struct ProbParams {
     uint8_t *status;  // [n_q]
 };
 
+struct WalkParams {
+    const uint8_t *status;
+    uint64_t q0;
+    const double *prefix;
+    uint32_t n_bnd;
+    const uint4 *rec;  // per node {boundary index of its range begin, of its end, first child, n_children | type << 30}
+    DevRow *arena;
+    unsigned long long arena_cap;
+    unsigned long long *arena_cursor;
+    uint32_t *n_rows;                // [n_q]
+    unsigned long long *row_start;   // [n_q]
+    uint32_t *flags_out;             // bit0 arena overflow, bit1 row/depth overflow
+};
+
 struct PrefixParams {
     const uint8_t *status;
     const uint32_t *t;     // [B] distinct k-mers per slot (size of the table copy)
@@ -132,23 +146,10 @@ struct PrefixParams {
     const uint32_t *bnd_rank;   // [ceil(N/8)] boundary index of the first such position
     double *prefix;             // [B][n_bnd]
     uint32_t n_bnd;
+    uint32_t fuse_walk;         // wave 0 of every workgroup walks its query right after the sweeps (walk.prefix == prefix)
+    WalkParams walk;
 };
 
-struct WalkParams {
-    const uint8_t *status;
-    uint64_t q0;
-    const double *prefix;
-    uint32_t n_bnd;
-    const uint32_t *blo, *bhi;  // boundary indices of every node's range
-    const uint32_t *first_child, *n_children;
-    const uint8_t *type;
-    DevRow *arena;
-    unsigned long long arena_cap;
-    unsigned long long *arena_cursor;
-    uint32_t *n_rows;                // [n_q]
-    unsigned long long *row_start;   // [n_q]
-    uint32_t *flags_out;             // bit0 arena overflow, bit1 row/depth overflow
-};
 
 void launch_bitmap_build(hipStream_t s, const uint64_t *off, const uint32_t *post, const uint32_t *row_of,
                          uint32_t *bitmap, uint32_t stride_words, uint32_t ref_lo, uint32_t ref_hi);

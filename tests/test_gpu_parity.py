@@ -702,7 +702,9 @@ def test_randomised_configurations(oracle, seed):
             try:
                 n_ties += bool(assert_rows_equivalent(res.rows(q), rows, probs_ref, olin, f"seed {seed} skip {skip} q {q}"))
             except AssertionError:
-                if phylo or not at_rounding_boundary(probs_ref):
+                # also with the phylogenetic database: a short truncated query ties dozens of references exactly and
+                # their taxa land on k + 0.5 hundredths (seed 5092: sixteen species at 0.075 +- 2e-16)
+                if not at_rounding_boundary(probs_ref):
                     raise
                 n_boundary += 1
     assert n_boundary <= 20, n_boundary

@@ -1140,7 +1140,7 @@ int rtx_batch_upload(rtx_index *ix, uint64_t n_queries, const uint8_t *bases, co
     ix->sum_query_bytes = total;
 
     // ---- inputs
-    if ((rc = ix->d_bases.alloc(total + 16)) || (rc = ix->d_base_off.alloc(n_queries + 1)))
+    if ((rc = ix->d_bases.alloc(total + 64)) || (rc = ix->d_base_off.alloc(n_queries + 1)))
         return rc;
     std::vector<uint64_t> off0(n_queries + 1);
     for (uint64_t q = 0; q <= n_queries; q++) off0[q] = base_off[q] - base_off[0];

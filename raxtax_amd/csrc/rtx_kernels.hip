@@ -156,19 +156,27 @@ __global__ __launch_bounds__(64) void kmer_extract_kernel(KmerParams p) {
     __syncthreads();
 
     if (len >= 8) {
-        // lane l rolls over the windows [l*wpl, (l+1)*wpl): wpl + 7 sequential byte reads instead of 8 per window
+        // lane l takes the windows [l*wpl, (l+1)*wpl), sixteen at a time: their 23 bases come in as three unaligned
+        // 8-byte words (one round trip instead of 23 dependent byte loads; the batch buffer is padded behind its end)
+        // and the 2-bit code rolls over them in registers
         const uint64_t nwin = len - 7;
         const uint64_t wpl = (nwin + 63) / 64;
         const uint64_t w0 = (uint64_t)lane * wpl;
         const uint64_t w1 = w0 + wpl < nwin ? w0 + wpl : nwin;
-        uint32_t k = 0, run = 0;  // run: consecutive valid bases ending here
-        for (uint64_t i = w0; w0 < w1 && i < w1 + 7; i++) {
-            const uint32_t c = seq[i];
-            // one-hot nibble {1,2,4,8} -> {0,1,2,3}; everything else invalidates the windows that contain it
-            const bool ok = c == 1u || c == 2u || c == 4u || c == 8u;
-            k = ((k << 2) | (((uint32_t)__ffs((int)c) - 1u) & 3u)) & 0xFFFFu;  // first base of the window in bits 15:14
-            run = ok ? run + 1u : 0u;
-            if (run >= 8u) atomicOr(&bm[k >> 5], 1u << (k & 31u));
+        for (uint64_t i = w0; i < w1; i += 16) {
+            unsigned long long v[3];
+            __builtin_memcpy(v, seq + i, 24);
+            const uint32_t nw = w1 - i < 16 ? (uint32_t)(w1 - i) : 16u;
+            uint32_t k = 0, run = 0;  // run: consecutive valid bases ending here
+#pragma unroll
+            for (int b = 0; b < 23; b++) {
+                const uint32_t c = (uint32_t)(v[b >> 3] >> ((b & 7) * 8)) & 0xFFu;
+                // one-hot nibble {1,2,4,8} -> {0,1,2,3}; everything else invalidates the windows that contain it
+                const bool ok = c == 1u || c == 2u || c == 4u || c == 8u;
+                k = ((k << 2) | (((uint32_t)__ffs((int)c) - 1u) & 3u)) & 0xFFFFu;  // first base of the window in bits 15:14
+                run = ok ? run + 1u : 0u;
+                if (b >= 7 && (uint32_t)(b - 7) < nw && run >= 8u) atomicOr(&bm[k >> 5], 1u << (k & 31u));
+            }
         }
     }
     __syncthreads();

@@ -207,17 +207,32 @@ __global__ __launch_bounds__(64) void kmer_extract_kernel(KmerParams p) {
     unsigned long long hq = 0;
     const uint32_t tt = t < p.kstride ? t : p.kstride;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    for (uint32_t i0 = 0; i0 < tt; i0 += 64) {
-        const uint32_t i = i0 + lane;
-        uint32_t row = kEmptyRow;
-        if (i < tt) {
-            const uint32_t k = kout[i];
-            row = p.row_of[k];
-            hq += p.list_len[k];
+    // Four chunks of 64 k-mers per turn, all loads of a level issued together: on gfx9 loads and stores share one
+    // in-order counter, so every wait for a load also waits for the stores before it -- a chunk-by-chunk loop
+    // (load, gather, store) pays two full round trips per chunk.
+    for (uint32_t i0 = 0; i0 < tt; i0 += 256) {
+        uint32_t kk[4], row[4], ll[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t i = i0 + u * 64 + lane;
+            kk[u] = i < tt ? (uint32_t)kout[i] : 0xFFFFFFFFu;
         }
-        const unsigned long long m = __ballot(row != kEmptyRow);
-        if (row != kEmptyRow) rout[nrows + __popcll(m & lt_mask)] = row;
-        nrows += (uint32_t)__popcll(m);
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            row[u] = kEmptyRow;
+            ll[u] = 0;
+            if (kk[u] != 0xFFFFFFFFu) {
+                row[u] = p.row_of[kk[u]];
+                ll[u] = p.list_len[kk[u]];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            hq += ll[u];
+            const unsigned long long m = __ballot(row[u] != kEmptyRow);
+            if (row[u] != kEmptyRow) rout[nrows + __popcll(m & lt_mask)] = row[u];
+            nrows += (uint32_t)__popcll(m);
+        }
     }
     const uint32_t nchunks = (nrows + 63u) >> 6;
     for (uint32_t i = nrows + lane; i < nchunks * 64u; i += 64) rout[i] = p.zero_row;
@@ -268,36 +283,50 @@ __global__ __launch_bounds__(64) void kmer_extract_kernel(KmerParams p) {
             nseg += cd;
         }
     }
-    for (uint32_t tb = 0; !p.seg_blocks && tb < nt; tb += 64) {  // few tiles: one pass per tile; lane l keeps the counters of tile tb + l
-        const uint32_t te = tb + 64 < nt ? tb + 64 : nt;
+    if (!p.seg_blocks) {  // few tiles (at most 12): one pass per tile; lane l keeps the counters of tile l
         uint32_t cd = 0, cs = 0;
-        for (uint32_t c = 0; c < nchunks; c++) {
-            const uint32_t i = c * 64 + lane;
-            const uint32_t row = i < nrows ? rout[i] : kEmptyRow;
-            // seginfo rows are padded to whole uint4: four tiles per (gather) load
-            const uint4 *info = reinterpret_cast<const uint4 *>(p.seginfo + (size_t)(row == kEmptyRow ? 0u : row) * p.seg_stride);
-            uint4 iv = make_uint4(0, 0, 0, 0);
-            for (uint32_t tile = tb; tile < te; tile++) {
-                if ((tile & 3u) == 0) iv = info[tile >> 2];
-                const uint32_t word = (tile & 3u) == 0 ? iv.x : (tile & 3u) == 1 ? iv.y : (tile & 3u) == 2 ? iv.z : iv.w;
-                const uint32_t code = row != kEmptyRow ? word : 0u;
-                const uint32_t ns = (uint32_t)__builtin_amdgcn_readlane((int)cs, (int)(tile - tb));
-                const bool sparse = code >= 2u;  // hit_count's byte counters hold 255 hits: more sparse rows are read densely
-                const unsigned long long ms = __ballot(sparse);
-                const uint32_t srank = ns + (uint32_t)__popcll(ms & lt_mask);
-                const bool take = sparse && srank < kSegMaxSparseRows;
-                if (take) sout[(size_t)tile * (kSegMaxSparseRows + 1) + srank] = code - 2u;
-                const unsigned long long md = __ballot(code == 1u || (code >= 2u && !take));
-                if (lane == tile - tb) {
-                    dm[(size_t)tile * mstride + c] = md;
-                    cd += (uint32_t)__popcll(md);
-                    const uint32_t ns2 = ns + (uint32_t)__popcll(ms);
-                    cs = ns2 < kSegMaxSparseRows ? ns2 : kSegMaxSparseRows;
+        const uint32_t nv = (nt + 3u) >> 2;  // seginfo rows are padded to whole uint4: four tiles per (gather) load
+        for (uint32_t c0 = 0; c0 < nchunks; c0 += 4) {  // four chunks per turn, loads of a level together (see above)
+            uint32_t row[4];
+            uint4 iv[4][3];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const uint32_t i = (c0 + u) * 64 + lane;
+                row[u] = i < nrows ? rout[i] : kEmptyRow;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const uint4 *info = reinterpret_cast<const uint4 *>(p.seginfo + (size_t)(row[u] == kEmptyRow ? 0u : row[u]) * p.seg_stride);
+#pragma unroll
+                for (uint32_t v = 0; v < 3; v++) iv[u][v] = v < nv ? info[v] : make_uint4(0, 0, 0, 0);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const uint32_t c = c0 + u;
+                if (c >= nchunks) break;
+                for (uint32_t tile = 0; tile < nt; tile++) {
+                    const uint32_t v = tile >> 2;
+                    const uint4 q4 = v == 0 ? iv[u][0] : (v == 1 ? iv[u][1] : iv[u][2]);
+                    const uint32_t word = (tile & 3u) == 0 ? q4.x : (tile & 3u) == 1 ? q4.y : (tile & 3u) == 2 ? q4.z : q4.w;
+                    const uint32_t code = row[u] != kEmptyRow ? word : 0u;
+                    const uint32_t ns = (uint32_t)__builtin_amdgcn_readlane((int)cs, (int)tile);
+                    const bool sparse = code >= 2u;  // hit_count's byte counters hold 255 hits: more sparse rows are read densely
+                    const unsigned long long ms = __ballot(sparse);
+                    const uint32_t srank = ns + (uint32_t)__popcll(ms & lt_mask);
+                    const bool take = sparse && srank < kSegMaxSparseRows;
+                    if (take) sout[(size_t)tile * (kSegMaxSparseRows + 1) + srank] = code - 2u;
+                    const unsigned long long md = __ballot(code == 1u || (code >= 2u && !take));
+                    if (lane == tile) {
+                        dm[(size_t)tile * mstride + c] = md;
+                        cd += (uint32_t)__popcll(md);
+                        const uint32_t ns2 = ns + (uint32_t)__popcll(ms);
+                        cs = ns2 < kSegMaxSparseRows ? ns2 : kSegMaxSparseRows;
+                    }
                 }
             }
         }
-        if (tb + lane < nt) {
-            p.nsparse[(size_t)q * nt + tb + lane] = cs;
+        if (lane < nt) {
+            p.nsparse[(size_t)q * nt + lane] = cs;
             nseg += cd;
         }
     }
@@ -1025,27 +1054,37 @@ __global__ __launch_bounds__(NW * 64) void taxon_prefix_kernel(PrefixParams p) {
     double carry = 0.0;
     const uint32_t n = (uint32_t)p.n_refs;  // references of this handle (< 2^32)
     constexpr uint32_t kSweep = NW * 512;
-    // counts of the next sweep are requested before the current one is scanned (the sweeps are a serial
-    // chain through `carry`; without the prefetch every sweep exposes a full HBM round trip)
-    uint4 cv_next = make_uint4(0, 0, 0, 0);
-    uint32_t bits_next = 0;
-    if (tid * 8u < n) {
-        cv_next = load_counts8(cnt + tid * 8u);
-        bits_next = p.bnd_bits[tid];
-    }
+    // Counts, boundary flags and boundary ranks of the next sweep are requested before the current one is scanned (the
+    // sweeps are a serial chain through `carry`).  The three loads are UNCONDITIONAL (clamped addresses, values
+    // masked afterwards) and nothing else is loaded inside the loop: gfx9 counts loads and stores in one in-order
+    // counter, and only with a fixed number of younger operations can the wait for this sweep's data leave the
+    // next sweep's loads (and this sweep's boundary stores) in flight -- with predicated loads or a rank look-up
+    // behind the scan every sweep waited for everything (vmcnt(0)) and exposed a full HBM round trip.
+    const uint32_t last_chunk = (n - 1u) >> 3;  // n >= 1: every query slot of an index holds references
+    uint4 cv_l;             // raw values of the chunk requested last (clamped address) ...
+    uint32_t bits_l, rank_l;
+    auto request = [&](uint32_t r) {
+        const uint32_t ch = r >> 3 < last_chunk ? r >> 3 : last_chunk;  // a valid chunk (counts rows are padded to 8)
+        cv_l = load_counts8(cnt + (size_t)ch * 8u);
+        bits_l = p.bnd_bits[ch];
+        rank_l = p.bnd_rank[ch];
+    };
+    uint4 cv_next;          // ... and what they mean once masked
+    uint32_t bits_next, rank_next;
+    auto accept = [&](uint32_t r) {
+        const bool in = r < n;
+        cv_next = in ? cv_l : make_uint4(0, 0, 0, 0);  // past the end: count 0 (a valid table index, masked below), no boundary
+        bits_next = in ? bits_l : 0u;
+        rank_next = rank_l;
+    };
+    request(tid * 8u);
+    accept(tid * 8u);
     uint32_t buf = 0;
     for (uint32_t base = 0; base < n; base += kSweep, buf ^= 1u) {
         const uint32_t r0 = base + tid * 8u;
         const uint4 cv = cv_next;
-        const uint32_t bits_cur = bits_next;
-        const uint32_t rn = r0 + kSweep;
-        if (rn < n) {
-            cv_next = load_counts8(cnt + rn);
-            bits_next = p.bnd_bits[rn >> 3];
-        } else {  // past the end: count 0 (a valid table index, masked below) and no boundary
-            cv_next = make_uint4(0, 0, 0, 0);
-            bits_next = 0;
-        }
+        const uint32_t bits_cur = bits_next, rank_cur = rank_next;
+        request(r0 + kSweep);
         const uint32_t cw[4] = {cv.x, cv.y, cv.z, cv.w};
         double v[8];
 #pragma unroll
@@ -1074,15 +1113,16 @@ __global__ __launch_bounds__(NW * 64) void taxon_prefix_kernel(PrefixParams p) {
             tot += ws;
         }
         carry += tot;
-        uint32_t bits = bits_cur;  // 0 for chunks past the end
-        if (bits) {
-            uint32_t rank = p.bnd_rank[r0 >> 3];
-            while (bits) {
-                const int j = __ffs((int)bits) - 1;
-                bits &= bits - 1;
-                P[rank++] = off + s[j];
-            }
-        }
+        // boundary j of this chunk goes to P[rank + number of boundaries below it]: eight predicated stores, no loop (a
+        // loop of stores makes the compiler drain the memory counter in front of it -- and with it the prefetch)
+        // The data of the next sweep are taken in HERE, before this sweep's stores: behind them the wait would also cover
+        // the stores (their number is not known at compile time, so the compiler could not leave them in flight).
+        asm volatile("" : "+v"(cv_l.x), "+v"(cv_l.y), "+v"(cv_l.z), "+v"(cv_l.w), "+v"(bits_l), "+v"(rank_l)::"memory");
+        const uint32_t bits = bits_cur;  // 0 for chunks past the end
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+            if (bits & (1u << j)) P[rank_cur + (uint32_t)__popc(bits & ((1u << j) - 1u))] = off + s[j];
+        accept(r0 + kSweep);
     }
     if (p.fuse_walk) {
         // The walk of this query by wave 0 while the prefix sums are still in this XCD's L2 (a walk on its own is a

@@ -460,12 +460,27 @@ __global__ __launch_bounds__(64, (NP <= 10 ? 4 : 2)) void hit_count_kernel(HitPa
         uint32_t chunk = 0;
         while (chunk < nchunks) {  // one round unless more than kHitListCap - 63 dense rows (the last group of a round is padded)
             uint32_t count = 0;
-            while (chunk < nchunks && count + 64u <= kHitListCap) {
-                const uint32_t rowv = rows[chunk * 64 + lane];
-                const unsigned long long m = masks[chunk];
-                if ((m >> lane) & 1ull) list[count + (uint32_t)__popcll(m & lt_mask)] = rowv;
-                count += (uint32_t)__popcll(m);
-                chunk++;
+            // The masks of up to 64 chunks come in with ONE load (lane c <-> chunk + c, taken out with v_readlane) and the
+            // row ids four chunks at a time: three or four round trips in front of the first bitmap row instead of two
+            // per chunk (mask, then the rows of its set bits).
+            const unsigned long long mv = chunk + lane < nchunks ? masks[chunk + lane] : 0ull;
+            uint32_t ci = 0;
+            bool room = true;
+            while (room && chunk < nchunks && ci < 64u) {
+                uint32_t rowv[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) rowv[u] = chunk + u < nchunks ? rows[(chunk + u) * 64 + lane] : 0u;
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    if (chunk >= nchunks || ci >= 64u) break;
+                    if (count + 64u > kHitListCap) { room = false; break; }
+                    const unsigned long long m = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(mv >> 32), (int)ci) << 32) |
+                                                 (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mv, (int)ci);
+                    if ((m >> lane) & 1ull) list[count + (uint32_t)__popcll(m & lt_mask)] = rowv[u];
+                    count += (uint32_t)__popcll(m);
+                    chunk++;
+                    ci++;
+                }
             }
             const uint32_t n32 = (count + 31u) >> 5;
             for (uint32_t i = count + lane; i < n32 * 32u + 32u; i += 64) list[i] = p.zero_row;  // padding + look-ahead group

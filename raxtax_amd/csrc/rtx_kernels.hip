@@ -139,7 +139,7 @@ __device__ __forceinline__ unsigned long long transpose64(unsigned long long x, 
 }
 
 __global__ __launch_bounds__(64) void kmer_extract_kernel(KmerParams p) {
-    __shared__ uint32_t bm[2048];
+    __shared__ __attribute__((aligned(16))) uint32_t bm[2048];
     const uint32_t q = blockIdx.x;
     const uint32_t lane = threadIdx.x;
     const uint64_t gq = p.q0 + q;  // position in the processing order: index of the per-query outputs
@@ -181,22 +181,24 @@ __global__ __launch_bounds__(64) void kmer_extract_kernel(KmerParams p) {
     }
     __syncthreads();
 
-    // ascending read-out: round r covers words r*64 .. r*64+63 (conflict-free LDS reads)
+    // ascending read-out: round r covers the 64-bit words r*64 .. r*64+63 of the set (conflict-free LDS reads); sixteen
+    // scans instead of thirty-two with 32-bit words
     uint16_t *kout = p.kmers + (size_t)q * p.kstride;
+    const unsigned long long *bm64 = reinterpret_cast<const unsigned long long *>(bm);
     uint32_t base = 0;
-    for (uint32_t r = 0; r < 32; r++) {
-        uint32_t word = bm[r * 64 + lane];
-        const uint32_t cnt = __popc(word);
+    for (uint32_t r = 0; r < 16; r++) {
+        unsigned long long word = bm64[r * 64 + lane];
+        const uint32_t cnt = (uint32_t)__popcll(word);
         const uint32_t incl = wave_incl_scan_u32(cnt);
         uint32_t pos = base + incl - cnt;
-        const uint32_t kbase = (r * 64 + lane) * 32;
+        const uint32_t kbase = (r * 64 + lane) * 64;
         while (word) {
-            const uint32_t bit = __ffs((int)word) - 1;
+            const uint32_t bit = (uint32_t)__builtin_ctzll(word);
             word &= word - 1;
             if (pos < p.kstride) kout[pos] = (uint16_t)(kbase + bit);
             pos++;
         }
-        base += __shfl(incl, 63, 64);
+        base += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
     }
     const uint32_t t = base;
     __syncthreads();  // kout visible to the whole wave

@@ -75,11 +75,12 @@ __device__ __forceinline__ double row_load_f64(const double *table, uint32_t off
 
 // ---------------------------------------------------------------------------
 // per-query lookup kernel: 256 threads (4 waves) per query
-// LDS (dynamic): Pi[n1max] f64 | red[16] f64 | row_h[tmax+18] u32 | row_m, row_sat, ms [tmax+18] u16 each | hl[tmax+4] u32 | row_off, row_end [tmax+18] u32
+// LDS (dynamic): Pi[n1max] f64 | red[16] f64 | Ppart[64] f64 | row_h[tmax+18] u32 | row_m, row_sat, ms [tmax+18] u16 each | hl[tmax+4] u32 | row_off, row_end [tmax+18] u32
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void prob_lookup_kernel(ProbParams p, ProbTables tb) {
     extern __shared__ double smem[];
     __shared__ uint32_t s_D, s_nact;
+    __shared__ uint32_t s_nlive[8];  // per 64-wide slice of i: rows [0, s_nlive) include every row not yet saturated there
     const uint32_t q = p.order ? p.order[blockIdx.x] : blockIdx.x;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint64_t gq = p.q0 + q;
@@ -88,7 +89,8 @@ __global__ __launch_bounds__(256) void prob_lookup_kernel(ProbParams p, ProbTabl
     const uint32_t n1 = n + 1;
     double *Pi = smem;
     double *red = Pi + p.n1max;
-    uint32_t *row_h = reinterpret_cast<uint32_t *>(red + 16);
+    double *Ppart = red + 16;  // [64] second half of the row sum of the first slice (pass 1)
+    uint32_t *row_h = reinterpret_cast<uint32_t *>(Ppart + 64);
     uint16_t *row_m = reinterpret_cast<uint16_t *>(row_h + (p.tmax + 18));
     uint16_t *row_sat = row_m + (p.tmax + 18);
     uint16_t *ms = row_sat + (p.tmax + 18);
@@ -144,6 +146,7 @@ __global__ __launch_bounds__(256) void prob_lookup_kernel(ProbParams p, ProbTabl
         // rows still moving at i_lo, in descending order of m; everything else gets table = 0
         if (wave == 0) {
             uint32_t na = 0;
+            if (lane < 8) s_nlive[lane] = 0;
             for (uint32_t j0 = 0; j0 < D; j0 += 64) {
                 const uint32_t j = j0 + lane;
                 uint32_t m = 0, sat = 0;
@@ -161,13 +164,19 @@ __global__ __launch_bounds__(256) void prob_lookup_kernel(ProbParams p, ProbTabl
                     row_h[pos] = hl[m];  // pos <= j: the staged entries still needed lie at indices > j
                     row_off[pos] = m * n1 * 8u;
                     row_end[pos] = (m * n1 + (sat < n1 ? sat : n1)) * 8u;
+                    // last slice of 64 values of i (from i_lo) in which this row still moves
+                    const uint32_t nsl = ((sat < n1 ? sat : n1) - i_lo + 63u) >> 6;
+                    atomicMax(&s_nlive[(nsl < 8u ? nsl : 8u) - 1u], pos + 1u);
                 }
                 na += (uint32_t)__popcll(bal);
             }
             // pad to a multiple of 16 with neutral rows (m = 0: ln cmf = 0, sat = 0, h = 0)
             const uint32_t padded = (na + 15u) & ~15u;
             if (na + lane < padded) { row_m[na + lane] = 0; row_sat[na + lane] = 0; row_h[na + lane] = 0; row_off[na + lane] = 0; row_end[na + lane] = 0; }
-            if (lane == 0) s_nact = na;
+            if (lane == 0) {
+                s_nact = na;
+                for (int sl = 6; sl >= 0; sl--) s_nlive[sl] = max(s_nlive[sl], s_nlive[sl + 1]);  // live in slice s' => live in every s <= s'
+            }
         }
         __syncthreads();
         const uint32_t nact = s_nact;
@@ -175,11 +184,16 @@ __global__ __launch_bounds__(256) void prob_lookup_kernel(ProbParams p, ProbTabl
         // sixteen at a time: sixteen independent 512-byte row-slice loads in flight per wave, one FMA each.
         // Rows are read through row_load_f64: lanes past saturation (factor 1, ln = 0) or past n get 0.0 from the
         // bounds check -- no per-lane compare, select or address arithmetic.
-        for (uint32_t i0 = i_lo + wave * 64; i0 <= n; i0 += 256) {
-            const uint32_t i = i0 + lane;
-            const uint32_t voff = i * 8u;
+        // Work is dealt by what is live: every row moves in the first slice, few do further out (231 / 129 / 41 rows in
+        // slices 0 / 1 / 2 on the bench workload), so waves 0 and 1 share the first slice (alternate batches; the two
+        // partial sums meet through 64 doubles of LDS) and waves 2 and 3 take the other slices, each over the rows
+        // [0, s_nlive[slice]) only.  (One slice per wave over all rows: the first wave did 231 batches-worth of rows
+        // while the others mostly loaded zeros.)
+        auto slice_sum = [&](uint32_t sl, uint32_t rbeg, uint32_t rstep) -> double {
+            const uint32_t voff = (i_lo + sl * 64u + lane) * 8u;
+            const uint32_t rend = s_nlive[sl];
             double S = 0.0;
-            for (uint32_t r0 = 0; r0 < nact; r0 += 16) {
+            for (uint32_t r0 = rbeg; r0 < rend; r0 += rstep) {
                 const uint32_t l16 = r0 + (lane & 15u);
                 const uint32_t ov = row_off[l16], ev = row_end[l16], hv = row_h[l16];
                 double c[16];
@@ -192,7 +206,24 @@ __global__ __launch_bounds__(256) void prob_lookup_kernel(ProbParams p, ProbTabl
                     S = fma((double)h, c[k], S);
                 }
             }
-            if (i <= n) Pi[i - i_lo] = exp(S);
+            return S;
+        };
+        const uint32_t nslices = ((n - i_lo) >> 6) + 1u;  // <= 8 for t <= 1023
+        double S0 = 0.0;
+        if (wave < 2) {
+            S0 = slice_sum(0, wave * 16u, 32u);
+            if (wave == 1) Ppart[lane] = S0;
+        } else {
+            for (uint32_t sl = wave - 1u; sl < nslices; sl += 2) {
+                const double S = slice_sum(sl, 0, 16u);
+                const uint32_t i = i_lo + sl * 64u + lane;
+                if (i <= n) Pi[i - i_lo] = exp(S);
+            }
+        }
+        __syncthreads();
+        if (wave == 0) {
+            const uint32_t i = i_lo + lane;
+            if (i <= n) Pi[i - i_lo] = exp(S0 + Ppart[lane]);
         }
         __syncthreads();
         // ---- pass 2: table[m] = sum_i pmf_m(i) P(i) / cmf_m(i)  (prob.rs:74-90); a wave takes eight
@@ -295,7 +326,7 @@ __global__ __launch_bounds__(1024) void prob_order_kernel(const uint32_t *__rest
 // ---------------------------------------------------------------------------
 size_t prob_lookup_lds_bytes(uint32_t tmax) {
     const size_t n1max = tmax / 2 + 1;
-    return sizeof(double) * (n1max + 16) + (sizeof(uint32_t) + 3 * sizeof(uint16_t)) * ((size_t)tmax + 18) + 8 +
+    return sizeof(double) * (n1max + 16 + 64) + (sizeof(uint32_t) + 3 * sizeof(uint16_t)) * ((size_t)tmax + 18) + 8 +
            sizeof(uint32_t) * ((size_t)tmax + 4) + 2 * sizeof(uint32_t) * ((size_t)tmax + 18);
 }
 void launch_prob_tables_build(hipStream_t s, const ProbTables &tb, const double *lf, const double *inv) {

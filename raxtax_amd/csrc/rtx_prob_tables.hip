@@ -242,18 +242,24 @@ __global__ __launch_bounds__(256) void prob_lookup_kernel(ProbParams p, ProbTabl
                 lmax = max(lmax, cnt ? cnt - 1u : 0u);
             }
             for (uint32_t ib = i_lo; ib <= lmax; ib += 128) {
+                // the second 64-wide slice only if some row of the batch reaches it (44 % of the rows of a bench query end
+                // inside the first slice: their second loads would all be clipped to zeros, but still be issued)
+                const bool two = ib + 64u <= lmax;
                 double rv[2][8], P2[2];
 #pragma unroll
                 for (int c = 0; c < 2; c++) {
+                    if (c == 1 && !two) break;
                     const uint32_t i = ib + c * 64 + lane;
                     P2[c] = i <= lmax ? Pi[i - i_lo] : 0.0;
 #pragma unroll
                     for (int k = 0; k < 8; k++) rv[c][k] = row_load_f64(Rt, off[k], end[k], i * 8u);
                 }
 #pragma unroll
-                for (int c = 0; c < 2; c++)
+                for (int c = 0; c < 2; c++) {
+                    if (c == 1 && !two) break;
 #pragma unroll
                     for (int k = 0; k < 8; k++) acc[k] = fma(rv[c][k], P2[c], acc[k]);
+                }
             }
             const double v = wave_sum8_f64(acc);  // lane l: total of row r0 + (l & 7)
             if (lane < 8) {

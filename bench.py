@@ -196,32 +196,43 @@ def main():
     index.upload(qs.bases, qs.base_off, ex_ids, ex_off)            # inputs resident in HBM from here on
 
     lib = rx._lib.load()
-    # N > 1: the gather of step i runs while step i+1 is classified (two sets of buffers); the last one is
-    # finished inside the timed region
+    # N > 1: packing and gathering the records of step i happen while the device classifies step i+1 (two sets of
+    # buffers); those of the last step are completed inside the timed region
     rec_buf = [None, None]
     gather_cache = [{}, {}]
     pending = [None]
     step_no = [0]
 
+    prev_view = [None]
+
+    def ship(view):
+        """Packs the result records of a finished step and starts their gather on rank 0 (the only collective: RCCL
+        over xGMI); the gather started before is completed first (two sets of buffers alternate)."""
+        k = step_no[0] & 1
+        step_no[0] += 1
+        need = lib.rtx_result_pack(ctypes.byref(view), None, 0)       # native pack: 24 B/query + 21 B/row
+        if rec_buf[k] is None or rec_buf[k].shape[0] < need:
+            rec_buf[k] = dist_util.pinned_bytes(int(need * 1.25) + 64)
+        n = lib.rtx_result_pack(ctypes.byref(view), rec_buf[k].ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), rec_buf[k].shape[0])
+        assert n == need, "rtx_result_pack failed"
+        if pending[0] is not None:
+            dist_util.gather_finish(pending[0])
+        pending[0] = dist_util.gather_start(dist, rec_buf[k][:n], rank, world, device=coll_device, cache=gather_cache[k])
+
     def step():
-        index.run(flags)
-        view = index.download(copy=False)       # sync + D2H of the result records + host finalisation
-        if dist is not None:
-            # the only collective: gather the per-rank result records on rank 0 (RCCL over xGMI)
-            k = step_no[0] & 1
-            step_no[0] += 1
-            need = lib.rtx_result_pack(ctypes.byref(view), None, 0)       # native pack: 24 B/query + 21 B/row
-            if rec_buf[k] is None or rec_buf[k].shape[0] < need:
-                rec_buf[k] = dist_util.pinned_bytes(int(need * 1.25) + 64)
-            n = lib.rtx_result_pack(ctypes.byref(view), rec_buf[k].ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), rec_buf[k].shape[0])
-            assert n == need, "rtx_result_pack failed"
-            if pending[0] is not None:
-                dist_util.gather_finish(pending[0])
-            pending[0] = dist_util.gather_start(dist, rec_buf[k][:n], rank, world, device=coll_device, cache=gather_cache[k])
+        index.run(flags)                        # enqueues every kernel of this step
+        if dist is not None and prev_view[0] is not None:
+            ship(prev_view[0])                  # host work of the step before (its view stays valid until the second-next
+            prev_view[0] = None                 # download) while the device classifies this one
+        view = index.download(copy=False)       # streams the result records back + host finalisation
+        prev_view[0] = view
         return view
 
     def barrier():
-        if pending[0] is not None:      # the gather of the last step belongs to the timed region
+        if dist is not None and prev_view[0] is not None:   # records and gather of the last step belong to the timed region
+            ship(prev_view[0])
+            prev_view[0] = None
+        if pending[0] is not None:
             dist_util.gather_finish(pending[0])
             pending[0] = None
         if dist is not None:

@@ -129,7 +129,7 @@ def gather_finish(ticket: dict) -> Optional[List[np.ndarray]]:
     c2, host = cache["cap"], cache["host"]
     for i, g in enumerate(cache["gathered"]):
         host[i * c2: i * c2 + sizes[i]].copy_(g[:sizes[i]], non_blocking=True)
-    torch.cuda.synchronize()
+    torch.cuda.current_stream().synchronize()   # the copies only: a device-wide sync would wait for the classification running beside them
     return [host[i * c2: i * c2 + sizes[i]].numpy() for i in range(world)]
 
 

@@ -295,6 +295,10 @@ def main():
                 "traffic": measured_traffic(args, launches_per_step),
                 "algorithmic_bytes_per_query": bytes_alg / args.queries,
                 "bitmap_bytes_per_query": work["bitmap_bytes_read"] / args.queries,
+                # what actually limits the row loop: bitmap-row bytes delivered by the vector L1 (64 B per clock and CU,
+                # 256 CUs, 2.4 GHz), padding rows of the row lists not counted (DESIGN.md section 3, K2+K3)
+                "l1_achieved": (work["bitmap_bytes_read"] / launches_per_step) / (hit_ms * 1e-3) / 1e9,
+                "l1_peak": 256 * 64 * 2.4, "l1_frac": (work["bitmap_bytes_read"] / launches_per_step) / (hit_ms * 1e-3) / 1e9 / (256 * 64 * 2.4),
                 "launch_ms": hit_ms, "launches_per_step": launches_per_step,
             },
             "stage_ms_per_step": {s: stage_ms[s] / args.steps for s in stage_ms},

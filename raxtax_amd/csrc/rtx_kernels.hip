@@ -484,10 +484,12 @@ __global__ __launch_bounds__(64, (NP <= 10 ? 4 : 2)) void hit_count_kernel(HitPa
                     ci++;
                 }
             }
-            const uint32_t n32 = (count + 31u) >> 5;
-            for (uint32_t i = count + lane; i < n32 * 32u + 32u; i += 64) list[i] = p.zero_row;  // padding + look-ahead group
+            // groups of 32 rows in the main loop, then up to three groups of 8 (the list is padded to a multiple of 8 only;
+            // the entries behind it, read by the look-ahead loads, are zero rows)
+            const uint32_t n8 = (count + 7u) >> 3, n32 = n8 >> 2, ntail = n8 & 3u;
+            for (uint32_t i = count + lane; i < n32 * 32u + 32u; i += 64) list[i] = p.zero_row;
             __syncthreads();
-            if (n32) {
+            if (n8) {
                 uint32_t idv = list[lane & 31u];
                 uint4 A[8], B[8];
                 load8v<0>(A, bitmap, col, stride, idv);
@@ -500,7 +502,7 @@ __global__ __launch_bounds__(64, (NP <= 10 ? 4 : 2)) void hit_count_kernel(HitPa
                     const uint4 c4a = csa_plane<NP, 3>(pl, c3a, c3b);
                     load8v<24>(B, bitmap, col, stride, idv);
                     const uint4 c3c = tree8<NP>(pl, A);
-                    load8v<0>(A, bitmap, col, stride, idn);  // look-ahead group (zero rows past the end)
+                    load8v<0>(A, bitmap, col, stride, idn);  // first rows of the next group, or of the tail
                     const uint4 c3d = tree8<NP>(pl, B);
                     const uint4 c4b = csa_plane<NP, 3>(pl, c3c, c3d);
                     const uint4 c5 = csa_plane<NP, 4>(pl, c4a, c4b);
@@ -509,6 +511,29 @@ __global__ __launch_bounds__(64, (NP <= 10 ? 4 : 2)) void hit_count_kernel(HitPa
                     planes_ripple<NP, 5>(pl[2], c5.z);
                     planes_ripple<NP, 5>(pl[3], c5.w);
                     idv = idn;
+                }
+                if (ntail) {  // A holds the first eight rows of the tail; the others are loaded one group at a time
+                    uint4 c3 = tree8<NP>(pl, A);
+                    planes_ripple<NP, 3>(pl[0], c3.x);
+                    planes_ripple<NP, 3>(pl[1], c3.y);
+                    planes_ripple<NP, 3>(pl[2], c3.z);
+                    planes_ripple<NP, 3>(pl[3], c3.w);
+                    if (ntail > 1) {
+                        load8v<8>(A, bitmap, col, stride, idv);
+                        c3 = tree8<NP>(pl, A);
+                        planes_ripple<NP, 3>(pl[0], c3.x);
+                        planes_ripple<NP, 3>(pl[1], c3.y);
+                        planes_ripple<NP, 3>(pl[2], c3.z);
+                        planes_ripple<NP, 3>(pl[3], c3.w);
+                    }
+                    if (ntail > 2) {
+                        load8v<16>(A, bitmap, col, stride, idv);
+                        c3 = tree8<NP>(pl, A);
+                        planes_ripple<NP, 3>(pl[0], c3.x);
+                        planes_ripple<NP, 3>(pl[1], c3.y);
+                        planes_ripple<NP, 3>(pl[2], c3.z);
+                        planes_ripple<NP, 3>(pl[3], c3.w);
+                    }
                 }
             }
             __syncthreads();  // the list is rewritten (next round) or becomes the histogram

@@ -286,7 +286,7 @@ def main():
                 "workload": f"{args.queries} synthetic COI-length (658 bp) queries per GPU vs {args.refs}-seq "
                             f"reference DB replicated in HBM (BASELINE.json configs[1])",
                 "refs": args.refs, "queries_per_gpu": args.queries, "query_len": db.length,
-                "model": "phylo (SURVEY.md 8d)", "parallelism": f"queries sharded x{world}, index replicated",
+                "synthetic_data": "phylo (SURVEY.md 8d)", "parallelism": f"queries sharded x{world}, index replicated",
                 "classified_ok": ok, "skip_exact_matches": bool(args.skip_exact_matches),
             },
             "roofline": {

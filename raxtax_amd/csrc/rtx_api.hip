@@ -601,8 +601,11 @@ int ensure_prob_tables(rtx_index *ix) {
 }
 
 // Queries per kernel launch: larger sub-batches amortise launch tails (measured: 4096 -> 8192 queries saves
-// 5 % of a step at N = 50k); the default is half the limit.
+// 5 % of a step at N = 50k).
 constexpr uint32_t kMaxSubBatch = 16384;
+// default: fewer, larger launches save the drain/fill between the kernels of a sub-batch (10 000: 23.5 ms per 100k queries,
+// 8192: 23.7, 14 286: 23.7 -- beyond ~12 000 hit_count loses more L2 reuse than the launches save)
+constexpr uint32_t kDefaultSubBatch = 10240;
 
 // Sizes and allocates the per-batch workspace for n_queries queries of at most tmax k-mers.
 int prepare_workspace(rtx_index *ix, uint64_t n_queries, uint64_t tmax, uint64_t max_len) {
@@ -647,7 +650,7 @@ int prepare_workspace(rtx_index *ix, uint64_t n_queries, uint64_t tmax, uint64_t
         // scratch already held by this handle is reusable
         const uint64_t held = (ix->sc[0].d_counts.n + ix->sc[1].d_counts.n) * 2 + (ix->sc[0].d_prefix.n + ix->sc[1].d_prefix.n) * 8;
         const uint64_t budget = (uint64_t)((free_b + held) * 0.6);
-        B = (uint32_t)std::min<uint64_t>(kMaxSubBatch / 2, std::max<uint64_t>(64, budget / per_q));
+        B = (uint32_t)std::min<uint64_t>(kDefaultSubBatch, std::max<uint64_t>(64, budget / per_q));
     }
     if (B > kMaxSubBatch) B = kMaxSubBatch;
     B = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(B, n_queries));

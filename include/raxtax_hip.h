@@ -298,8 +298,10 @@ int64_t rtx_format_query(const rtx_tree *tree, const rtx_result_view *res, uint6
                          uint64_t out_cap, char *tsv_buf, uint64_t tsv_cap, int64_t *tsv_len);
 
 /* Compact byte record of a result view: what a rank ships in the multi-GPU result gather (BASELINE.json
- * configs[3]; layout in raxtax_amd/dist_util.py: 24 B per query + 21 B per row, confidences as hundredths of the
- * first 8 levels).  buf == NULL: returns the size needed; else the bytes written or a negative RTX_ERR_*. */
+ * configs[3]; layout in raxtax_amd/dist_util.py: 32 B header, 25 B per query (begin, global signal, row count, t,
+ * status) + 13 + L B per row (lineage u32, depth, L confidences as hundredths, local signal), L = depth of the
+ * deepest row, so every level of every row travels).  buf == NULL: returns the size needed; else the bytes written
+ * or a negative RTX_ERR_*. */
 int64_t rtx_result_pack(const rtx_result_view *res, uint8_t *buf, uint64_t cap);
 
 /* ------------------------------------------------------------------------- */

@@ -10,6 +10,7 @@
 // Out of scope: raxtax.log, progress bars, gzip input, thread options.
 #include <sys/stat.h>
 
+#include <cctype>
 #include <chrono>
 #include <condition_variable>
 #include <deque>
@@ -119,12 +120,21 @@ int main(int argc, char **argv) {
         else if (a == "-c" || a == "--clean") clean = true;
         else if (a == "--redo") redo = true;
         else if (a == "--timing") timing = true;
+        // CPU tuning flags of the reference (io.rs:139-153): accepted so that existing command lines keep working,
+        // without effect on the device path.  -t takes a value; clap also accepts -tN, --threads=N, -vv, -qq.
+        else if (a == "-t" || a == "--threads") (void)val();
+        else if (a.rfind("--threads=", 0) == 0 || (a.size() > 2 && a[0] == '-' && a[1] == 't' && isdigit((unsigned char)a[2]))) {}
+        else if (a == "--pin") {}
+        else if (a == "--verbose" || a == "--quiet" || (a.size() >= 2 && a[0] == '-' && a[1] != '-' &&
+                                                        a.find_first_not_of(a[1] == 'v' ? "v" : "q", 1) == std::string::npos &&
+                                                        (a[1] == 'v' || a[1] == 'q'))) {}
         else if (a == "--device") device = atoi(val());
         else if (a == "--batch") chunk = (size_t)atoll(val());
         else if (a == "--block-bytes") block_bytes = std::max<size_t>(1, (size_t)atoll(val()));
         else {
             fprintf(stderr, "usage: raxtax-hip -d DB.(fasta|bin) [-i QUERIES.fasta] [-o PREFIX] [--skip-exact-matches] [--raw-confidence] "
-                            "[--tsv] [--only-db] [--skip-db] [-c] [--redo] [--device N] [--batch N] [--block-bytes N]\n");
+                            "[--tsv] [--only-db] [--skip-db] [-c] [--redo] [--device N] [--batch N] [--block-bytes N]\n"
+                            "       (-t/--threads N, --pin, -v, -q of the reference are accepted and ignored)\n");
             return 64;
         }
     }

@@ -165,7 +165,7 @@ int rtx_tree_load_bin(const char *path, rtx_tree **out) {
         const uint8_t *kp = r.p;
         r.p += klen;
         const uint64_t nid = r.u64();
-        if (!r.ok || nid > nl) return fail("sequence ids");
+        if (!r.ok || nid > nl || nid > (uint64_t)(r.end - r.p) / 4) return fail("sequence ids");  // nid * 4 cannot wrap below
         entries[s].first = {kp, klen};
         if (!r.need(nid * 4)) return fail("sequence ids");
         entries[s].second.resize(nid);
@@ -198,11 +198,15 @@ int rtx_tree_load_bin(const char *path, rtx_tree **out) {
     uint64_t np = 0;
     for (uint32_t k = 0; k < RTX_NUM_KMERS; k++) {
         const uint64_t n = r.u64();
-        if (!r.ok || !r.need(n * 4)) return fail("posting list");
+        // count first, bytes second: n * 4 wraps for n >= 2^62 and would pass need()
+        if (!r.ok || n > (uint64_t)(r.end - r.p) / 4 || !r.need(n * 4)) return fail("posting list");
         memcpy(t->postings.data() + np, r.p, n * 4);
         r.p += n * 4;
-        for (uint64_t i = 0; i < n; i++)
+        for (uint64_t i = 0; i < n; i++) {
             if (t->postings[np + i] >= nl) return fail("posting id");
+            // sorted unique (tree.rs:134-137): the reference-sharded index cuts a list with lower_bound
+            if (i && t->postings[np + i] <= t->postings[np + i - 1]) return fail("posting list not strictly ascending");
+        }
         np += n;
         t->csr_off[k + 1] = np;
     }

@@ -131,8 +131,9 @@ extern "C" int64_t rtx_format_query(const rtx_tree *tree, const rtx_result_view 
 }
 
 // ---- compact byte record of a result view (the unit the multi-GPU gather ships, raxtax_amd/dist_util.py) ----
-//   int64[2] n_queries, n_rows | int64 begin[nq] | int64 count[nq] | f64 global[nq]
-//   | int32 lineage[n_rows] | u8 depth[n_rows] | u8 conf[n_rows][8] (hundredths) | f64 local[n_rows]
+//   int64[4] n_queries, n_rows, L (confidence levels per row = deepest row of the view), version (2)
+//   | int64 begin[nq] | f64 global[nq] | u32 count[nq] | u32 t[nq] | u8 status[nq]
+//   | u32 lineage[n_rows] | u8 depth[n_rows] | u8 conf[n_rows][L] (hundredths) | f64 local[n_rows]
 #include <cmath>
 #include <thread>
 #include <vector>
@@ -140,27 +141,33 @@ extern "C" int64_t rtx_format_query(const rtx_tree *tree, const rtx_result_view 
 extern "C" int64_t rtx_result_pack(const rtx_result_view *res, uint8_t *buf, uint64_t cap) {
     if (!res) { rtx::set_error("rtx_result_pack: null view"); return RTX_ERR_INVALID; }
     const uint64_t nq = res->n_queries, nr = res->n_rows;
-    const uint64_t need = 16 + 24 * nq + 21 * nr;
+    uint32_t L = 1;  // every level of every row travels: the block is as wide as the deepest row
+    for (uint64_t r = 0; r < nr; r++) L = std::max(L, res->row_depth[r]);
+    if (L > RTX_MAX_DEPTH) { rtx::set_error("rtx_result_pack: row of depth %u (RTX_MAX_DEPTH %u)", L, RTX_MAX_DEPTH); return RTX_ERR_DEPTH; }
+    const uint64_t need = 32 + 25 * nq + (13 + (uint64_t)L) * nr;
     if (!buf) return (int64_t)need;  // size query
     if (cap < need) { rtx::set_error("rtx_result_pack: buffer of %llu bytes, need %llu", (unsigned long long)cap, (unsigned long long)need); return RTX_ERR_INVALID; }
     int64_t *hdr = reinterpret_cast<int64_t *>(buf);
     hdr[0] = (int64_t)nq;
     hdr[1] = (int64_t)nr;
-    uint8_t *p_begin = buf + 16, *p_count = p_begin + 8 * nq, *p_gs = p_count + 8 * nq;
-    uint8_t *p_lin = p_gs + 8 * nq, *p_depth = p_lin + 4 * nr, *p_conf = p_depth + nr, *p_local = p_conf + 8 * nr;
+    hdr[2] = (int64_t)L;
+    hdr[3] = 2;
+    uint8_t *p_begin = buf + 32, *p_gs = p_begin + 8 * nq, *p_count = p_gs + 8 * nq, *p_t = p_count + 4 * nq, *p_status = p_t + 4 * nq;
+    uint8_t *p_lin = p_status + nq, *p_depth = p_lin + 4 * nr, *p_conf = p_depth + nr, *p_local = p_conf + (uint64_t)L * nr;
     auto work = [&](uint64_t qa, uint64_t qb, uint64_t ra, uint64_t rb) {
         for (uint64_t q = qa; q < qb; q++) {
-            const int64_t b = (int64_t)res->row_begin[q], c = (int64_t)res->row_count[q];
+            const int64_t b = (int64_t)res->row_begin[q];
             memcpy(p_begin + 8 * q, &b, 8);
-            memcpy(p_count + 8 * q, &c, 8);
             memcpy(p_gs + 8 * q, &res->global_signal[q], 8);
+            memcpy(p_count + 4 * q, &res->row_count[q], 4);
+            memcpy(p_t + 4 * q, &res->t[q], 4);
+            p_status[q] = res->status[q];
         }
         for (uint64_t r = ra; r < rb; r++) {
-            const int32_t lin = (int32_t)res->row_lineage[r];
-            memcpy(p_lin + 4 * r, &lin, 4);
+            memcpy(p_lin + 4 * r, &res->row_lineage[r], 4);
             p_depth[r] = (uint8_t)res->row_depth[r];
             const double *cf = res->row_conf + r * RTX_MAX_DEPTH;
-            for (int d = 0; d < 8; d++) p_conf[8 * r + d] = (uint8_t)std::lrint(cf[d] * 100.0);
+            for (uint32_t d = 0; d < L; d++) p_conf[(uint64_t)L * r + d] = (uint8_t)std::lrint(cf[d] * 100.0);
             memcpy(p_local + 8 * r, &res->row_local_signal[r], 8);
         }
     };

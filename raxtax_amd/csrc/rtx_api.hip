@@ -1202,16 +1202,15 @@ static uint64_t finalise_mt(rtx_index *ix, uint64_t pa, uint64_t pb, uint64_t ro
     rtx_index::HostRes &hr = ix->host_res[ix->res_set];
     const uint64_t nrows = base[nt];
     if (hr.v_row_lineage.size() < nrows) {
-        // both result sets grow together (and get their pages touched): the second batch of a run is then as fast
-        // as the later ones
-        for (rtx_index::HostRes &h : ix->host_res) {
-            if (h.v_row_lineage.size() >= nrows) continue;
-            h.v_row_lineage.resize(nrows);
-            h.v_row_node.resize(nrows);
-            h.v_row_depth.resize(nrows);
-            h.v_row_local.resize(nrows);
-            h.v_row_conf.resize(nrows * RTX_MAX_DEPTH);
-        }
+        // Only the set being written grows: the other one is the view of the previous download, which stays valid (and
+        // may be read by the caller's formatting thread) until the second-next download (include/raxtax_hip.h).
+        // Growth keeps 25 % headroom so that a batch with a few more rows than the last one does not reallocate.
+        const uint64_t want = nrows + nrows / 4 + 64;
+        hr.v_row_lineage.resize(want);
+        hr.v_row_node.resize(want);
+        hr.v_row_depth.resize(want);
+        hr.v_row_local.resize(want);
+        hr.v_row_conf.resize(want * RTX_MAX_DEPTH);
     }
     if (nt == 1) {
         finalise_range(ix, pa, pb, row_base);

@@ -2,23 +2,25 @@
 the index is replicated, every rank classifies its own contiguous shard of the queries, and the only
 collective is the gather of the per-rank result records on rank 0 (RCCL on GPUs, gloo in the CPU test).
 
-A rank's results travel as ONE byte buffer:
-    header  int64[2]            n_queries, n_rows
+A rank's results travel as ONE byte buffer (written natively by rtx_result_pack, host_format.cpp):
+    header  int64[4]            n_queries, n_rows, L = confidence levels per row (depth of the deepest row), version 2
     begin   int64[n_queries]    first row of every query (rows travel in the library's processing order)
-    count   int64[n_queries]    rows of every query
     global  float64[n_queries]  global signal per query
-    lineage int32[n_rows]       index into tree.lineages
+    count   uint32[n_queries]   rows of every query
+    t       uint32[n_queries]   distinct k-mers of every query
+    status  uint8[n_queries]    RTX_Q_* status of every query
+    lineage uint32[n_rows]      index into tree.lineages
     depth   uint8[n_rows]
-    conf    uint8[n_rows][8]    confidence in hundredths (values are k/100 exactly; deeper levels: see depth)
+    conf    uint8[n_rows][L]    confidence in hundredths (values are k/100 exactly), every level of every row
     local   float64[n_rows]     local signal
-(3.1 MB per 100k single-row queries instead of 9.6 MB of float64 records)."""
+(3.8 MB per 100k single-row six-level queries instead of 9.6 MB of float64 records)."""
 from __future__ import annotations
 
 from typing import List, Optional, Tuple
 
 import numpy as np
 
-CONF_LEVELS = 8
+RECORD_VERSION = 2
 
 
 def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:
@@ -29,25 +31,30 @@ def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:
 
 
 def pack_records(row_off, row_lineage, row_depth, row_conf, row_local, global_signal=None, row_begin=None,
-                 row_count=None) -> np.ndarray:
+                 row_count=None, t=None, status=None) -> np.ndarray:
     """Result rows of one rank as one uint8 buffer (layout in the module docstring).  Either a CSR `row_off`
     (rows in query order) or the library view's `row_begin` / `row_count`."""
     if row_begin is None:
         row_off = np.ascontiguousarray(row_off, dtype=np.int64)
         row_begin, row_count = row_off[:-1], np.diff(row_off)
     row_begin = np.ascontiguousarray(row_begin, dtype=np.int64)
-    row_count = np.ascontiguousarray(row_count, dtype=np.int64)
+    row_count = np.ascontiguousarray(row_count, dtype=np.uint32)
     n_q = len(row_begin)
     n_rows = int(row_count.sum())
     gs = np.zeros(n_q) if global_signal is None else np.asarray(global_signal[:n_q], dtype=np.float64)
-    conf = np.asarray(row_conf)[:n_rows, :CONF_LEVELS]
+    t = np.zeros(n_q, np.uint32) if t is None else np.asarray(t[:n_q], dtype=np.uint32)
+    status = np.zeros(n_q, np.uint8) if status is None else np.asarray(status[:n_q], dtype=np.uint8)
+    depth = np.ascontiguousarray(row_depth[:n_rows], dtype=np.uint8)
+    levels = max(int(depth.max()) if n_rows else 1, 1)
+    conf = np.asarray(row_conf).reshape(n_rows, -1)[:, :levels]
     conf_u8 = np.rint(conf * 100.0).astype(np.uint8)
-    if conf_u8.shape[1] < CONF_LEVELS:
-        conf_u8 = np.pad(conf_u8, ((0, 0), (0, CONF_LEVELS - conf_u8.shape[1])))
-    parts = [np.array([n_q, n_rows], dtype=np.int64).view(np.uint8), row_begin.view(np.uint8), row_count.view(np.uint8),
-             np.ascontiguousarray(gs).view(np.uint8),
-             np.ascontiguousarray(row_lineage[:n_rows], dtype=np.int32).view(np.uint8),
-             np.ascontiguousarray(row_depth[:n_rows], dtype=np.uint8),
+    if conf_u8.shape[1] < levels:
+        conf_u8 = np.pad(conf_u8, ((0, 0), (0, levels - conf_u8.shape[1])))
+    parts = [np.array([n_q, n_rows, levels, RECORD_VERSION], dtype=np.int64).view(np.uint8), row_begin.view(np.uint8),
+             np.ascontiguousarray(gs).view(np.uint8), row_count.view(np.uint8), np.ascontiguousarray(t).view(np.uint8),
+             np.ascontiguousarray(status),
+             np.ascontiguousarray(row_lineage[:n_rows], dtype=np.uint32).view(np.uint8),
+             depth,
              np.ascontiguousarray(conf_u8).reshape(-1),
              np.ascontiguousarray(row_local[:n_rows], dtype=np.float64).view(np.uint8)]
     return np.concatenate(parts)
@@ -55,8 +62,10 @@ def pack_records(row_off, row_lineage, row_depth, row_conf, row_local, global_si
 
 def unpack_records(buf: np.ndarray) -> dict:
     buf = np.ascontiguousarray(buf, dtype=np.uint8)
-    n_q, n_rows = (int(x) for x in buf[:16].view(np.int64))
-    p = 16
+    n_q, n_rows, levels, version = (int(x) for x in buf[:32].view(np.int64))
+    if version != RECORD_VERSION:
+        raise ValueError(f"result record version {version}, expected {RECORD_VERSION}")
+    p = 32
 
     def take(nbytes, dtype):
         nonlocal p
@@ -65,19 +74,21 @@ def unpack_records(buf: np.ndarray) -> dict:
         return out
 
     begin = take(8 * n_q, np.int64)
-    count = take(8 * n_q, np.int64)
     gs = take(8 * n_q, np.float64)
-    lineage = take(4 * n_rows, np.int32)
+    count = take(4 * n_q, np.uint32).astype(np.int64)
+    t = take(4 * n_q, np.uint32)
+    status = take(n_q, np.uint8)
+    lineage = take(4 * n_rows, np.uint32)
     depth = take(n_rows, np.uint8)
-    conf = take(n_rows * CONF_LEVELS, np.uint8).reshape(n_rows, CONF_LEVELS).astype(np.float64) / 100.0
+    conf = take(n_rows * levels, np.uint8).reshape(n_rows, levels).astype(np.float64) / 100.0
     local = take(8 * n_rows, np.float64)
     # into query order
     row_off = np.zeros(n_q + 1, dtype=np.int64)
     row_off[1:] = np.cumsum(count)
     src = np.repeat(begin - row_off[:-1], count) + np.arange(n_rows)
     lineage, depth, conf, local = lineage[src], depth[src], conf[src], local[src]
-    return dict(n_queries=n_q, n_rows=n_rows, row_off=row_off, global_signal=gs, row_lineage=lineage, row_depth=depth,
-                row_conf=conf, row_local_signal=local)
+    return dict(n_queries=n_q, n_rows=n_rows, row_off=row_off, global_signal=gs, t=t, status=status, row_lineage=lineage,
+                row_depth=depth, row_conf=conf, row_local_signal=local)
 
 
 def pinned_bytes(n: int) -> np.ndarray:

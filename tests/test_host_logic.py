@@ -117,13 +117,15 @@ def test_native_result_pack_equals_python_pack():
     nr = run
     lin = rng.integers(0, 50000, nr).astype(np.uint32)
     node = np.zeros(nr, np.uint32)
-    depth = rng.integers(1, 8, nr).astype(np.uint32)
+    depth = rng.integers(1, 14, nr).astype(np.uint32)    # deeper than 8 levels: every level must travel
     conf = np.zeros((nr, 32))
-    conf[:, :8] = rng.integers(0, 101, (nr, 8)) / 100.0
+    conf[:, :13] = rng.integers(0, 101, (nr, 13)) / 100.0
+    conf[np.arange(32)[None, :] >= depth[:, None]] = 0.0
     local = rng.random(nr)
     gs = rng.random(nq)
-    t = np.zeros(nq, np.uint32)
-    status = np.zeros(nq, np.uint8)
+    t = rng.integers(0, 652, nq).astype(np.uint32)
+    status = (rng.random(nq) < 0.05).astype(np.uint8)
+    lin[0] = 0xFFFFFFF0                                  # reference ids are u32 (tree.rs:21-22)
     v = _lib.ResultView()
     v.n_queries, v.n_rows = nq, nr
     P = lambda a, ty: a.ctypes.data_as(C.POINTER(ty))
@@ -134,10 +136,14 @@ def test_native_result_pack_equals_python_pack():
     need = lib.rtx_result_pack(C.byref(v), None, 0)
     buf = np.zeros(need, np.uint8)
     assert lib.rtx_result_pack(C.byref(v), P(buf, C.c_uint8), need) == need
-    want = dist_util.pack_records(None, lin, depth, conf, local, gs, row_begin=begin, row_count=count)
+    want = dist_util.pack_records(None, lin, depth, conf, local, gs, row_begin=begin, row_count=count, t=t, status=status)
     assert np.array_equal(buf, want)
     back = dist_util.unpack_records(buf)
     assert np.array_equal(np.diff(back["row_off"]), count)
+    assert np.array_equal(back["t"], t) and np.array_equal(back["status"], status)
+    src = np.repeat(begin.astype(np.int64) - back["row_off"][:-1], count) + np.arange(nr)
+    assert np.array_equal(back["row_lineage"], lin[src]) and back["row_lineage"].dtype == np.uint32
+    assert np.array_equal(back["row_conf"], conf[src][:, : back["row_conf"].shape[1]]) and back["row_conf"].shape[1] == 13
 
 
 def _messy_fasta(n_records, seed, reference):

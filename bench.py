@@ -1,25 +1,34 @@
 #!/usr/bin/env python3
 """bench.py -- classified queries/s of the raxtax hot path on N MI355X of one node.
 
-A "step" is one pass of the whole device path (kmer_extract -> hit_count -> prob_table ->
-taxon_prefix -> lineage_walk -> result rows on the host) over one batch of synthetic queries
-per GPU, with the queries and the index already resident in HBM when the timed region starts
-(BASELINE.json configs[1]: 100k COI-length queries vs a 50k-sequence reference database,
-replicated per GPU; queries are sharded, so scaling is weak: every rank classifies its own
---queries).  With N > 1 the per-rank result records are gathered to rank 0 over RCCL inside the
-timed region (the only collective on the path).
+A "step" is one pass of the whole device path (processing order -> kmer_extract -> hit_count -> prob_lookup ->
+taxon_prefix + lineage walk -> result rows finalised on the host) over one batch of synthetic queries per GPU, with
+the queries, their exact-match ids (Tree.sequences.get, raxtax.rs:42, looked up on the host once, untimed) and the
+index already resident in HBM when the timed region starts.
 
-One JSON line on rank 0: metric/value (whole-job queries/s), ms_per_step, `roofline` of the
-dominant kernel (hit_count: algorithmic bytes 4*H_q + L_q per query, SURVEY.md 8d, over the
-kernel time measured with HIP events on the library's stream) and `cpu_baseline` (the CPU oracle,
-a C port of the reference algorithm, timed on this host's cores on a bounded sample).
+Default workload = BASELINE.json configs[2], the largest single-GPU configuration: 1 M synthetic COI-length
+(658 bp) queries per GPU vs a 500k-sequence database replicated per GPU (`--config 1` = configs[1]: 100k queries vs
+50k references).  Queries are sharded, so scaling is weak: every rank classifies its own --queries; with N > 1 the
+per-rank result records are gathered on rank 0 over RCCL inside the timed region (the only collective of the path,
+BASELINE.json configs[3]).  `--shard-db` = configs[4]: the REFERENCES are sharded, every rank classifies the same
+queries, histograms are all-reduced and boundary prefix sums all-gathered per sub-batch.
+
+`python bench.py --gpus N` launches the N ranks itself (torch.distributed.run, one process per GPU) when it is not
+already running under a launcher; the parent never touches the GPU.
+
+One JSON line on rank 0: metric/value (whole-job queries/s), ms_per_step, `roofline` of the dominant kernel
+(hit_count) and `cpu_baseline` (the CPU oracle, a C port of the reference algorithm, timed on this host's cores on a
+bounded sample).  How every number of `roofline` is derived: DESIGN.md section 5.
 """
 from __future__ import annotations
 
 import argparse
 import ctypes
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -30,136 +39,241 @@ ROOT = Path(__file__).resolve().parent
 if str(ROOT) not in sys.path:
     sys.path.insert(0, str(ROOT))
 
-HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6290 measured for a copy
+# MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 measured for a copy); L2 34.5 TB/s aggregate; 16.8-18.8 TB/s
+# measured for L2-resident row gathers (1 KiB rows by index, the access shape of hit_count); FP64 vector 78.6 TFLOP/s
+HBM_PEAK_GBS = 8000.0
+L2_PEAK_GBS = 34500.0
+L2_GATHER_GBS = 18800.0
+FP64_VALU_GFLOPS = 78600.0
+
+CONFIGS = {1: (50_000, 100_000, "BASELINE.json configs[1]"), 2: (500_000, 1_000_000, "BASELINE.json configs[2]")}
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--refs", type=int, default=50_000, help="reference sequences (replicated per GPU)")
-    ap.add_argument("--queries", type=int, default=100_000, help="queries per GPU per step")
-    ap.add_argument("--sub-batch", type=int, default=0, help="queries per kernel wave (0 = auto)")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample")
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS),
+                    help="BASELINE.json configs[i]: 2 = 1 M queries vs 500k references (default, the headline), "
+                         "1 = 100k queries vs 50k references")
+    ap.add_argument("--refs", type=int, default=0, help="reference sequences (overrides --config)")
+    ap.add_argument("--queries", type=int, default=0, help="queries per GPU per step (overrides --config)")
+    ap.add_argument("--sub-batch", type=int, default=0, help="queries per kernel launch (0 = auto)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of each leg of the cpu_baseline sample")
     ap.add_argument("--streams", type=int, default=0, help="HIP streams per handle (0 = library default)")
     ap.add_argument("--no-cluster", action="store_true", help="process the queries in input order (RTX_OPT_CLUSTER = 0)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--skip-exact-matches", action="store_true")
-    ap.add_argument("--stage-times", action="store_true",
-                    help="HIP events around every kernel (stage_ms_per_step for all stages; ~1 ms slower per step)")
+    ap.add_argument("--hit-events-only", action="store_true",
+                    help="HIP events around hit_count only (default: around every kernel; costs < 0.1 % of a step)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for N > 1 (nccl = RCCL over xGMI; gloo only to smoke-test the "
                          "multi-rank flow on a box with fewer GPUs than ranks)")
     ap.add_argument("--shard-db", action="store_true",
                     help="BASELINE configs[4]: shard the REFERENCES over the GPUs (every rank classifies the same "
                          "queries; RCCL all-reduce of histograms + all-gather of prefix sums per sub-batch)")
-    return ap.parse_args()
+    args = ap.parse_args()
+    refs, queries, name = CONFIGS[args.config]
+    args.config_name = name if not (args.refs or args.queries) else "custom size"
+    args.refs = args.refs or refs
+    args.queries = args.queries or queries
+    return args
 
 
-def cpu_baseline(db, qs, target_s: float):
-    """Times the oracle (oracle/, kind "port") on this host's cores on a prefix of the queries."""
+# ------------------------------------------------------------------------------------------------------------
+# N > 1 without a launcher: start the ranks (before anything in this process touches the GPU)
+# ------------------------------------------------------------------------------------------------------------
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` on its own: one child process per GPU through torch.distributed.run
+    (rendezvous on 127.0.0.1), this process only relays their output and checks that the printed line is the
+    line of an N-rank run.  The reference's counterpart is one call as well (par_chunks, raxtax.rs:35-36)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL across processes needs it on this pool
+    env.setdefault("OMP_NUM_THREADS", "1")                # the launcher's own default, set here to keep it quiet
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    n_gpus_seen = None
+    for line in proc.stdout:
+        sys.stdout.write(line)
+        sys.stdout.flush()
+        if line.startswith("{"):
+            try:
+                n_gpus_seen = json.loads(line).get("n_gpus")
+            except ValueError:
+                pass
+    rc = proc.wait()
+    if rc != 0:
+        return rc
+    if n_gpus_seen != args.gpus:
+        print(f"bench.py: asked for --gpus {args.gpus} but the line reports n_gpus = {n_gpus_seen}", file=sys.stderr)
+        return 3
+    return 0
+
+
+# ------------------------------------------------------------------------------------------------------------
+# CPU baseline
+# ------------------------------------------------------------------------------------------------------------
+def cpu_model() -> str:
+    try:
+        for line in Path("/proc/cpuinfo").read_text().splitlines():
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(db, qs, target_s: float, skip_exact: bool):
+    """Times the oracle (oracle/, kind "port": a C restatement of raxtax.rs:35-88, compiled -O3 -march=native) on this
+    host's cores.  Three legs on prefixes of the same queries: one thread; all hardware threads; one thread per
+    physical core, pinned (the reference's --pin, utils.rs:139-197).  The parallel legs use the reference's chunk
+    rule (main.rs:119-124: max(100, n / (10 T) + 1) queries per work item); their samples are whole multiples of
+    100 T queries, so that every thread gets the same number of full chunks -- a shorter sample would leave most
+    threads idle in the last wave and understate the rate the reference reaches on a full batch."""
     from oracle.oracle_py import Oracle
 
-    cores = os.cpu_count() or 1
+    T = os.cpu_count() or 1
     orc = Oracle(native=True)
+    t0 = time.perf_counter()
     otree = orc.tree_new_flat(db.lineages, db.seq_bytes, db.seq_off)
+    t_tree = time.perf_counter() - t0
     L = db.length
 
-    def run(n):
+    def run(n, threads, pins=None):
+        n = int(min(n, qs.n))
         t0 = time.perf_counter()
-        bad, _, _ = otree.classify_batch(qs.bases[: n * L], qs.base_off[: n + 1], threads=cores)
-        return time.perf_counter() - t0, bad
+        otree.classify_batch(qs.bases[: n * L], qs.base_off[: n + 1], skip_exact=skip_exact, threads=threads, pin_cpus=pins)
+        return n, time.perf_counter() - t0
 
-    probe = min(qs.n, 4 * cores)
-    dt, _ = run(probe)
-    rate = probe / dt
-    n = int(min(qs.n, max(probe, rate * target_s)))
-    dt, bad = run(n)
-    return {"value": n / dt, "unit": "queries/s", "cores": cores, "kind": "port",
-            "sample": f"first {n} queries of the same workload, {cores} threads, {dt:.1f} s, "
-                      f"chunking as src/main.rs:119-124, no string formatting"}
+    # one thread: a probe sets the sample size
+    n, dt = run(4, 1)
+    n1, dt1 = run(max(8, int(4 / dt * min(target_s, 6.0))), 1)
+    rate1 = n1 / dt1
+
+    def leg(threads, pins=None):
+        if threads == 1:
+            return dict(value=rate1, cores=1, queries=n1, seconds=dt1)
+        wave = 100 * threads                       # one full chunk per thread
+        n, dt = run(wave, threads, pins)           # a first wave measures the rate (SMT siblings, memory system)
+        k = max(1, int(round(target_s * (n / dt) / wave)))
+        if k > 1 or n < wave:
+            n, dt = run(wave * k, threads, pins)
+        return dict(value=n / dt, cores=threads, queries=n, seconds=dt)
+
+    every = leg(T)
+    phys = orc.physical_core_ids()
+    pinned = leg(len(phys), phys) if 1 < len(phys) < T else (dict(every, note="every hardware thread is a core of its own") if len(phys) >= T else None)
+    out = {"value": every["value"], "unit": "queries/s", "cores": T, "kind": "port", "cpu_model": cpu_model(),
+           "sample": f"first {every['queries']} queries of the same workload on {T} threads in {every['seconds']:.1f} s "
+                     f"({every['queries'] // max(100 * T, 1)} full chunk(s) of 100 per thread, chunking as src/main.rs:119-124), "
+                     f"no string formatting; oracle Tree::new {t_tree:.1f} s (untimed)",
+           "per_thread": every["value"] / T,
+           "one_thread": {"value": rate1, "queries": n1, "seconds": round(dt1, 2)},
+           "note": "the Rust reference itself cannot be built here (no cargo/rustc): this is the C port (oracle/oracle.c)"}
+    if pinned is not None:
+        out["pinned_physical_cores"] = {"value": pinned["value"], "cores": len(phys) if len(phys) < T else T,
+                                        "queries": pinned["queries"], "seconds": round(pinned["seconds"], 2),
+                                        "per_thread": pinned["value"] / max(1, min(len(phys), T))}
+    return out
 
 
-def measured_traffic(args, launches_per_step):
-    """Fabric-side bytes per hit_count launch from the committed rocprofv3 PMC passes (profiles/traffic.json:
-    FETCH_SIZE x 2 as MI355X_MICROARCH.md prescribes for wide coalesced reads on gfx950, + WRITE_SIZE), if the
-    profile was taken on this configuration; else null."""
+# ------------------------------------------------------------------------------------------------------------
+# roofline pieces
+# ------------------------------------------------------------------------------------------------------------
+def device_source_sha() -> str:
+    """Fingerprint of the device code: profiles/traffic.json is only used for the build it was measured on."""
+    h = hashlib.sha256()
+    for f in sorted((ROOT / "raxtax_amd" / "csrc").glob("rtx_*")):
+        h.update(f.name.encode())
+        h.update(f.read_bytes())
+    return h.hexdigest()[:16]
+
+
+def measured_traffic(refs: int, query_len: int, sub_batch: int):
+    """Fabric-side bytes per hit_count launch from the committed rocprofv3 PMC passes (profiles/traffic.json, written
+    by tools/make_traffic.py from `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE` runs of this bench): FETCH_SIZE x 2 as
+    MI355X_MICROARCH.md prescribes for 16-byte-per-lane reads on gfx950, + WRITE_SIZE.  Returned only if the
+    profile was taken on this configuration AND on this build of the kernels; else null (PMC counters cannot be read
+    from inside the process being measured)."""
     f = ROOT / "profiles" / "traffic.json"
     if not f.exists():
-        return None
+        return None, "no profiles/traffic.json"
     try:
         t = json.loads(f.read_text())
-        if t.get("refs") == args.refs and t.get("query_len") == 658:
-            per_query = (2.0 * t["hit_count_fetch_kb"] + t["hit_count_write_kb"]) * 1024.0 / t["queries_per_launch"]
-            return per_query * args.queries / launches_per_step      # bytes per launch of this run
-    except Exception:
-        return None
-    return None
+        e = t.get("configs", {}).get(f"refs={refs},query_len={query_len}")
+        if e is None:
+            return None, "no PMC profile of this configuration"
+        if e.get("device_source_sha") != device_source_sha():
+            return None, "PMC profile is of another build of the kernels (re-run tools/profile_bench.sh)"
+        per_query = (2.0 * e["hit_count_fetch_kb"] + e["hit_count_write_kb"]) * 1024.0 / e["queries_per_launch"]
+        return dict(per_query=per_query, fetch_per_query=2.0 * e["hit_count_fetch_kb"] * 1024.0 / e["queries_per_launch"],
+                    write_per_query=e["hit_count_write_kb"] * 1024.0 / e["queries_per_launch"], source=e.get("source", "")), None
+    except Exception as ex:  # noqa: BLE001 - a broken profile file must not break the bench
+        return None, f"profiles/traffic.json unreadable: {ex}"
 
 
-def bench_sharded_db(args, rx, synth, db, tree, dist, rank, local_rank, world, flags):
-    """Reference-sharded database: rank r holds references [cuts[r], cuts[r+1]); all ranks classify the same
-    --queries; strong scaling (total work fixed)."""
-    import torch
-
-    from raxtax_amd import sharded
-
-    qs = synth.make_queries(db, args.queries, seed=3)              # identical on every rank
-    cuts = sharded.shard_cuts(tree.num_tips, world)
-    shard = sharded.ShardIndex(tree, rank, cuts, device=local_rank, sub_batch=args.sub_batch or 2048)
-    if dist is not None:
-        w = torch.tensor([shard.n_bnd_local], device="cuda", dtype=torch.int64)
-        ws = [torch.zeros_like(w) for _ in range(world)]
-        dist.all_gather(ws, w)
-        comm = sharded.TorchComm(dist, world, [int(x.item()) for x in ws])
+def roofline_block(args, work, prob_work, stage_ms, stage_n, n_queries_step, query_len):
+    """Roofline of the dominant kernel, hit_count, per launch (one launch = one sub-batch)."""
+    n_launch = max(stage_n["hit_count"], 1)
+    launch_ms = stage_ms["hit_count"] / n_launch
+    launches_per_step = n_launch / args.steps
+    q_per_launch = n_queries_step / launches_per_step
+    sec = launch_ms * 1e-3
+    bitmap_per_q = work["bitmap_bytes_read"] / n_queries_step
+    alg_per_q = (4 * work["sum_hits"] + work["sum_query_bytes"]) / n_queries_step      # SURVEY.md 8d: 4 H_q + L_q
+    achieved = bitmap_per_q * q_per_launch / sec / 1e9
+    alg_gbs = alg_per_q * q_per_launch / sec / 1e9
+    tr, why = measured_traffic(args.refs, query_len, args.sub_batch)
+    out = {
+        # the unit that limits the kernel: the path from the XCD's L2 through the vector L1 (rows are gathered by
+        # index, 1 KiB per wave-instruction; the index is far larger than L2 + Infinity Cache only in bytes that are
+        # rarely asked for).  achieved = bitmap-row bytes requested per launch / launch time.
+        "bound": "l2", "kernel": "hit_count_kernel",
+        "achieved": achieved, "peak": L2_PEAK_GBS, "unit": "GB/s", "frac": achieved / L2_PEAK_GBS,
+        "frac_of_measured_l2_gather_rate": achieved / L2_GATHER_GBS,
+        "launch_ms": launch_ms, "launches_per_step": launches_per_step, "queries_per_launch": q_per_launch,
+        "requested_bytes_per_query": bitmap_per_q,
+        # SURVEY.md 8d's per-unit figure (u32 postings the reference would stream) -- a ratio, not a fraction: one
+        # bitmap bit stands for a 4-byte posting
+        "algorithmic_bytes_per_query": alg_per_q, "algorithmic_GBps": alg_gbs,
+        "algorithmic_ratio_to_hbm_peak": alg_gbs / HBM_PEAK_GBS,
+        "traffic": None, "hbm_achieved": None, "hbm_peak": HBM_PEAK_GBS, "hbm_frac": None,
+    }
+    if tr is not None:
+        out["traffic"] = tr["per_query"] * q_per_launch                  # HBM/fabric bytes per launch (PMC)
+        out["hbm_achieved"] = out["traffic"] / sec / 1e9
+        out["hbm_frac"] = out["hbm_achieved"] / HBM_PEAK_GBS
+        out["traffic_fetch_bytes_per_query"] = tr["fetch_per_query"]
+        out["traffic_write_bytes_per_query"] = tr["write_per_query"]
+        out["traffic_source"] = tr["source"]
     else:
-        comm = sharded.LocalComm()
-    clf = sharded.ShardedClassifier([shard], comm)
-    ex_ids, ex_off = shard.exact_matches(qs.bases, qs.base_off)
-
-    def barrier():
-        if pending[0] is not None:      # the gather of the last step belongs to the timed region
-            dist_util.gather_finish(pending[0])
-            pending[0] = None
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        clf.classify(qs.bases, qs.base_off, ex_ids, ex_off, skip_exact_matches=bool(flags))
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        res = clf.classify(qs.bases, qs.base_off, ex_ids, ex_off, skip_exact_matches=bool(flags))
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        tmax = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-    if rank == 0:
-        print(json.dumps({
-            "metric": "classified queries/sec (whole node)", "value": args.queries * args.steps / elapsed,
-            "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": "u32 bit-planes + f64", "data": "synthetic",
-            "config": {"workload": f"{args.queries} synthetic 658-bp queries vs {args.refs}-seq DB sharded by reference id "
-                                   f"over {world} GPU(s) (BASELINE.json configs[4] shape; includes H2D of the queries)",
-                       "refs": args.refs, "queries": args.queries, "parallelism": f"references sharded x{world}",
-                       "classified_ok": int((res.status == 0).sum())},
-            "roofline": None, "cpu_baseline": None}), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+        out["traffic_note"] = why
+    # secondary: the probability stage (prob.rs:43-90).  ops_prob = D_q (n_q + 1) (2 exp + 1 log), SURVEY.md 8d
+    if stage_n.get("prob_table"):
+        p_ms = stage_ms["prob_table"] / stage_n["prob_table"]
+        ops_q = 3.0 * prob_work["grid_points"] / n_queries_step
+        gops = ops_q * q_per_launch / (p_ms * 1e-3) / 1e9
+        out["prob_stage"] = {"kernel": "prob_lookup_kernel", "bound": "fp64-valu (secondary, SURVEY.md 8d)",
+                             "ops_prob_per_query": ops_q, "distinct_counts_per_query": prob_work["distinct_counts"] / n_queries_step,
+                             "launch_ms": p_ms, "achieved": gops, "peak": FP64_VALU_GFLOPS, "unit": "Gop/s (f64 exp/log of the reference's grid)",
+                             "frac": gops / FP64_VALU_GFLOPS}
+    return out
 
 
+# ------------------------------------------------------------------------------------------------------------
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(self_launch(args))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
     import torch
@@ -179,62 +293,105 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group("gloo")
+        assert dist.get_world_size() == world
 
     import raxtax_amd as rx
     from raxtax_amd import dist_util, synth
 
-    # ---- inputs (untimed): identical database on every rank, rank-specific queries
+    # ---- inputs (untimed): identical database on every rank
     db = synth.make_db(args.refs)
-    qs = synth.make_queries(db, args.queries, seed=3 + rank, first_label=rank * args.queries)
-    tree = rx.Tree.new_flat(db.lineages, db.seq_bytes, db.seq_off)
     flags = rx.RTX_SKIP_EXACT_MATCHES if args.skip_exact_matches else 0
-    if args.shard_db:
-        return bench_sharded_db(args, rx, synth, db, tree, dist, rank, local_rank, world, flags)
-    index = rx.Index(tree, device=local_rank, sub_batch=args.sub_batch, streams=args.streams, stage_timing=args.stage_times,
-                     cluster=False if args.no_cluster else None)
-    ex_ids, ex_off = index.exact_matches(qs.bases, qs.base_off)   # Tree.sequences.get, raxtax.rs:42 (host)
-    index.upload(qs.bases, qs.base_off, ex_ids, ex_off)            # inputs resident in HBM from here on
-
     lib = rx._lib.load()
-    # N > 1: packing and gathering the records of step i happen while the device classifies step i+1 (two sets of
-    # buffers); those of the last step are completed inside the timed region
-    rec_buf = [None, None]
-    gather_cache = [{}, {}]
-    pending = [None]
-    step_no = [0]
+    L = db.length
 
-    prev_view = [None]
+    if args.shard_db:
+        from raxtax_amd import sharded
 
-    def ship(view):
-        """Packs the result records of a finished step and starts their gather on rank 0 (the only collective: RCCL
-        over xGMI); the gather started before is completed first (two sets of buffers alternate)."""
-        k = step_no[0] & 1
-        step_no[0] += 1
-        need = lib.rtx_result_pack(ctypes.byref(view), None, 0)       # native pack: 24 B/query + 21 B/row
-        if rec_buf[k] is None or rec_buf[k].shape[0] < need:
-            rec_buf[k] = dist_util.pinned_bytes(int(need * 1.25) + 64)
-        n = lib.rtx_result_pack(ctypes.byref(view), rec_buf[k].ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), rec_buf[k].shape[0])
-        assert n == need, "rtx_result_pack failed"
-        if pending[0] is not None:
-            dist_util.gather_finish(pending[0])
-        pending[0] = dist_util.gather_start(dist, rec_buf[k][:n], rank, world, device=coll_device, cache=gather_cache[k])
+        tree = rx.Tree.new_flat(db.lineages, db.seq_bytes, db.seq_off)          # the shards are cut out of Tree.k_mer_map
+        qs = synth.make_queries(db, args.queries, seed=3)                        # the same queries on every rank
+        cuts = sharded.shard_cuts(tree.num_tips, world)
+        index = sharded.ShardIndex(tree, rank, cuts, device=local_rank, sub_batch=args.sub_batch or 4096)
+        if dist is not None:
+            w = torch.tensor([index.n_bnd_local], device=coll_device, dtype=torch.int64)
+            ws = [torch.zeros_like(w) for _ in range(world)]
+            dist.all_gather(ws, w)
+            comm = sharded.TorchComm(dist, world, [int(x.item()) for x in ws])
+        else:
+            comm = sharded.LocalComm()
+        clf = sharded.ShardedClassifier([index], comm)
+        t0 = time.perf_counter()
+        ex_ids, ex_off = index.exact_matches(qs.bases, qs.base_off)
+        t_exact = time.perf_counter() - t0
+        clf.upload(qs.bases, qs.base_off, ex_ids, ex_off)                         # inputs resident from here on
+        if not args.hit_events_only:
+            rx._lib.check(lib.rtx_index_set_option(index._h, 6, 1))
 
-    def step():
-        index.run(flags)                        # enqueues every kernel of this step
-        if dist is not None and prev_view[0] is not None:
-            ship(prev_view[0])                  # host work of the step before (its view stays valid until the second-next
-            prev_view[0] = None                 # download) while the device classifies this one
-        view = index.download(copy=False)       # streams the result records back + host finalisation
-        prev_view[0] = view
-        return view
+        def step():
+            return clf.run(skip_exact_matches=bool(flags), copy=False)
+
+        def finish():
+            pass
+        total_q_step = args.queries                                              # strong scaling: the work is fixed
+        scaling = "strong"
+        parallelism = f"references sharded x{world} (contiguous id ranges), queries replicated"
+        workload = (f"{args.queries} synthetic COI-length (658 bp) queries vs {args.refs}-seq reference DB sharded by reference id "
+                    f"over {world} GPU(s) (BASELINE.json configs[4] shape)")
+    else:
+        qs = synth.make_queries(db, args.queries, seed=3 + rank, first_label=rank * args.queries)   # rank-specific queries
+        tree = rx.Tree.new_flat(db.lineages, db.seq_bytes, db.seq_off, kmer_map=False)   # bitmaps built on the GPU
+        index = rx.Index(tree, device=local_rank, sub_batch=args.sub_batch, streams=args.streams,
+                         stage_timing=not args.hit_events_only, cluster=False if args.no_cluster else None)
+        t0 = time.perf_counter()
+        ex_ids, ex_off = index.exact_matches(qs.bases, qs.base_off)   # Tree.sequences.get, raxtax.rs:42 (host)
+        t_exact = time.perf_counter() - t0
+        index.upload(qs.bases, qs.base_off, ex_ids, ex_off)            # inputs resident in HBM from here on
+
+        # N > 1: packing and gathering the records of step i happen while the device classifies step i+1 (two sets of
+        # buffers); those of the last step are completed inside the timed region
+        rec_buf = [None, None]
+        gather_cache = [{}, {}]
+        pending = [None]
+        step_no = [0]
+        prev_view = [None]
+
+        def ship(view):
+            """Packs the result records of a finished step and starts their gather on rank 0 (the only collective: RCCL
+            over xGMI); the gather started before is completed first (two sets of buffers alternate)."""
+            k = step_no[0] & 1
+            step_no[0] += 1
+            need = lib.rtx_result_pack(ctypes.byref(view), None, 0)       # native pack: 25 B/query + (13 + depth) B/row
+            if rec_buf[k] is None or rec_buf[k].shape[0] < need:
+                rec_buf[k] = dist_util.pinned_bytes(int(need * 1.25) + 64)
+            n = lib.rtx_result_pack(ctypes.byref(view), rec_buf[k].ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), rec_buf[k].shape[0])
+            assert n == need, "rtx_result_pack failed"
+            if pending[0] is not None:
+                dist_util.gather_finish(pending[0])
+            pending[0] = dist_util.gather_start(dist, rec_buf[k][:n], rank, world, device=coll_device, cache=gather_cache[k])
+
+        def step():
+            index.run(flags)                        # enqueues every kernel of this step
+            if dist is not None and prev_view[0] is not None:
+                ship(prev_view[0])                  # host work of the step before (its view stays valid until the second-next
+                prev_view[0] = None                 # download) while the device classifies this one
+            view = index.download(copy=False)       # streams the result records back + host finalisation
+            prev_view[0] = view
+            return view
+
+        def finish():
+            if dist is not None and prev_view[0] is not None:   # records and gather of the last step belong to the timed region
+                ship(prev_view[0])
+                prev_view[0] = None
+            if pending[0] is not None:
+                dist_util.gather_finish(pending[0])
+                pending[0] = None
+        total_q_step = args.queries * world
+        scaling = "weak"
+        parallelism = f"queries sharded x{world}, index replicated"
+        workload = (f"{args.queries} synthetic COI-length (658 bp) queries per GPU vs {args.refs}-seq reference DB replicated "
+                    f"in HBM ({args.config_name})")
 
     def barrier():
-        if dist is not None and prev_view[0] is not None:   # records and gather of the last step belong to the timed region
-            ship(prev_view[0])
-            prev_view[0] = None
-        if pending[0] is not None:
-            dist_util.gather_finish(pending[0])
-            pending[0] = None
+        finish()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
@@ -246,7 +403,7 @@ def main():
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        view = step()
         for s, (ms, n) in index.stage_times().items():   # reads already-recorded HIP events
             stage_ms[s] += ms
             stage_n[s] += n
@@ -258,53 +415,40 @@ def main():
         elapsed = float(tmax.item())
 
     work = index.work()
-    view = index.download(copy=False)
+    prob_work = index.prob_work()
     ok = int((np.ctypeslib.as_array(view.status, shape=(args.queries,)) == 0).sum())
     if rank == 0:
-        total_q = args.queries * world * args.steps
-        # roofline of the dominant kernel: algorithmic bytes (4 B per posting the reference would
-        # touch + the query bytes) per launch / mean launch duration (HIP events, library stream)
-        bytes_alg = 4 * work["sum_hits"] + work["sum_query_bytes"]     # one step, this rank
-        n_launch = max(stage_n["hit_count"], 1)
-        hit_ms = stage_ms["hit_count"] / n_launch
-        launches_per_step = n_launch / args.steps
-        achieved = (bytes_alg / launches_per_step) / (hit_ms * 1e-3) / 1e9
         line = {
             "metric": "classified queries/sec (whole node)",
-            "value": total_q / elapsed,
+            "value": total_q_step * args.steps / elapsed,
             "unit": "queries/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": scaling,
             "vs_baseline": None,
             "dtype": "u32 bit-planes + f64",
             "data": "synthetic",
             "config": {
-                "workload": f"{args.queries} synthetic COI-length (658 bp) queries per GPU vs {args.refs}-seq "
-                            f"reference DB replicated in HBM (BASELINE.json configs[1])",
-                "refs": args.refs, "queries_per_gpu": args.queries, "query_len": db.length,
-                "synthetic_data": "phylo (SURVEY.md 8d)", "parallelism": f"queries sharded x{world}, index replicated",
+                "workload": workload,
+                "refs": args.refs, "queries_per_gpu": args.queries, "query_len": L,
+                "synthetic_data": "phylo model of SURVEY.md 8d, numpy PCG64 streams (raxtax_amd/synth.py)",
+                "parallelism": parallelism,
+                "process_group": ({"backend": dist.get_backend(), "world_size": dist.get_world_size()} if dist is not None
+                                  else {"backend": None, "world_size": 1}),
                 "classified_ok": ok, "skip_exact_matches": bool(args.skip_exact_matches),
+                "sub_batch": int(round(args.queries / max(stage_n["hit_count"] / args.steps, 1))) if stage_n["hit_count"] else None,
+                "untimed_host_exact_match_lookup_s": round(t_exact, 3),
             },
-            "roofline": {
-                "bound": "hbm", "kernel": "hit_count_kernel",
-                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": measured_traffic(args, launches_per_step),
-                "algorithmic_bytes_per_query": bytes_alg / args.queries,
-                "bitmap_bytes_per_query": work["bitmap_bytes_read"] / args.queries,
-                # what actually limits the row loop: bitmap-row bytes delivered by the vector L1 (64 B per clock and CU,
-                # 256 CUs, 2.4 GHz), padding rows of the row lists not counted (DESIGN.md section 3, K2+K3)
-                "l1_achieved": (work["bitmap_bytes_read"] / launches_per_step) / (hit_ms * 1e-3) / 1e9,
-                "l1_peak": 256 * 64 * 2.4, "l1_frac": (work["bitmap_bytes_read"] / launches_per_step) / (hit_ms * 1e-3) / 1e9 / (256 * 64 * 2.4),
-                "launch_ms": hit_ms, "launches_per_step": launches_per_step,
-            },
+            "roofline": roofline_block(args, work, prob_work, stage_ms, stage_n, args.queries, L),
             "stage_ms_per_step": {s: stage_ms[s] / args.steps for s in stage_ms},
         }
         if not args.no_cpu_baseline and world == 1:      # reported baseline: rank 0 at N = 1 only
-            line["cpu_baseline"] = cpu_baseline(db, qs, args.cpu_seconds)
+            line["cpu_baseline"] = cpu_baseline(db, qs, args.cpu_seconds, bool(flags))
+        else:
+            line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()

@@ -269,6 +269,10 @@ int rtx_batch_stage_times(rtx_index *index, float ms[RTX_NUM_STAGES], uint32_t l
  * bytes the hit_count kernel actually requested. */
 int rtx_batch_work(rtx_index *index, uint64_t *sum_hits, uint64_t *sum_query_bytes,
                    uint64_t *bitmap_bytes_read);
+/* Algorithmic work of the probability stage of the last rtx_batch_run (prob.rs:43-90):
+ * sum over queries of D_q (n_q + 1) -- the points of the pmf/cmf grid the reference evaluates, D_q = number of
+ * distinct hit counts, n_q = t_q / 2 -- and of D_q.  ops_prob = 3 x grid points (2 exp + 1 log each). */
+int rtx_batch_prob_work(rtx_index *index, uint64_t *sum_grid_points, uint64_t *sum_distinct_counts);
 
 /* ------------------------------------------------------------------------- */
 /* Parity / debug taps (full vectors; not used on the fast path)              */

@@ -14,6 +14,7 @@
 
 #include <ctype.h>
 #include <math.h>
+#include <sched.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -768,17 +769,50 @@ void orc_iterative_pmf_ln(uint64_t t, uint64_t n, uint64_t m, double ln_total, d
     }
 }
 
-int orc_prob_table(uint16_t total_num_k_mers, uint64_t num_trials, const uint16_t *sizes,
-                   uint64_t n_refs, double *table, double *z) {
+/* Scratch reused from query to query by the batch driver.  The reference allocates per query as well
+ * (prob.rs:13-19 HashMap, :43-61 one Vec per distinct count, lineage.rs:62-66 the prefix Vec); a port that
+ * mmap()s and page-faults 1-2 MB per query would understate the CPU baseline, so the buffers are kept --
+ * the arithmetic and its order are untouched. */
+typedef struct {
+    uint64_t *hist;  /* 65536 entries, all zero between queries */
+    uint32_t *ms;    /* 65536 */
+    double *pmf, *cmf, *prod, *table, *prefix;
+    size_t pmf_cap, cmf_cap, prod_cap, table_cap, prefix_cap;
+} orc_ws;
+
+static void ws_init(orc_ws *w) {
+    memset(w, 0, sizeof *w);
+    w->hist = xcalloc(65536, sizeof(uint64_t));
+    w->ms = xmalloc(65536 * sizeof(uint32_t));
+}
+static void ws_free(orc_ws *w) {
+    free(w->hist); free(w->ms); free(w->pmf); free(w->cmf); free(w->prod); free(w->table); free(w->prefix);
+    memset(w, 0, sizeof *w);
+}
+static double *ws_grow(double **p, size_t *cap, size_t want) {
+    if (want > *cap) {
+        free(*p);
+        *cap = want + want / 4 + 16;
+        *p = xmalloc(*cap * sizeof(double));
+    }
+    return *p;
+}
+
+static int prob_table_ws(orc_ws *ws, uint16_t total_num_k_mers, uint64_t num_trials, const uint16_t *sizes,
+                         uint64_t n_refs, double *table, double *z) {
     const uint64_t t = total_num_k_mers, n = num_trials;
     if (t == 0) return -1; /* t + n - 1 underflows u64, prob.rs:21 */
     /* prob.rs:13-19 histogram (dense array instead of HashMap) */
-    uint64_t *hist = xcalloc(65536, sizeof(uint64_t));
-    for (uint64_t r = 0; r < n_refs; r++) hist[sizes[r]] += 1;
-    uint32_t *ms = xmalloc(65536 * sizeof(uint32_t));
+    uint64_t *hist = ws->hist;
+    uint32_t max_size = 0;
+    for (uint64_t r = 0; r < n_refs; r++) {
+        hist[sizes[r]] += 1;
+        if (sizes[r] > max_size) max_size = sizes[r];
+    }
+    uint32_t *ms = ws->ms;
     uint32_t D = 0;
     int any_full = 0;
-    for (uint32_t m = 0; m < 65536; m++)
+    for (uint32_t m = 0; m <= max_size; m++)
         if (hist[m]) { ms[D++] = m; if (m == t) any_full = 1; }
     for (uint64_t m = 0; m <= t; m++) table[m] = 0.0;
     double ln_total = orc_ln_binomial(t + n - 1, n); /* :20-23 */
@@ -789,9 +823,9 @@ int orc_prob_table(uint16_t total_num_k_mers, uint64_t num_trials, const uint16_
     } else {
         if (n == 0) { rc = -2; goto done; } /* zip_eq length mismatch, :162 */
         const uint64_t W = n + 1;
-        double *pmf = xmalloc((size_t)D * W * sizeof(double));
-        double *cmf = xmalloc((size_t)D * W * sizeof(double));
-        double *prod = xmalloc(W * sizeof(double));
+        double *pmf = ws_grow(&ws->pmf, &ws->pmf_cap, (size_t)D * W);
+        double *cmf = ws_grow(&ws->cmf, &ws->cmf_cap, (size_t)D * W);
+        double *prod = ws_grow(&ws->prod, &ws->prod_cap, W);
         for (uint32_t d = 0; d < D; d++) { /* :43-48 */
             /* counts > t cannot occur (count <= |K(q)| = t) */
             orc_iterative_pmf_ln(t, n, ms[d], ln_total, pmf + (size_t)d * W);
@@ -816,9 +850,6 @@ int orc_prob_table(uint16_t total_num_k_mers, uint64_t num_trials, const uint16_
             }
             table[ms[d]] = s;
         }
-        free(pmf);
-        free(cmf);
-        free(prod);
     }
     if (z) { /* :97: probs_sum over references, in reference order */
         double s = 0.0;
@@ -826,24 +857,40 @@ int orc_prob_table(uint16_t total_num_k_mers, uint64_t num_trials, const uint16_
         *z = s;
     }
 done:
-    free(hist);
-    free(ms);
+    for (uint32_t d = 0; d < D; d++) hist[ms[d]] = 0; /* the workspace invariant: all zero between queries */
+    return rc;
+}
+
+int orc_prob_table(uint16_t total_num_k_mers, uint64_t num_trials, const uint16_t *sizes,
+                   uint64_t n_refs, double *table, double *z) {
+    orc_ws ws;
+    ws_init(&ws);
+    int rc = prob_table_ws(&ws, total_num_k_mers, num_trials, sizes, n_refs, table, z);
+    ws_free(&ws);
     return rc;
 }
 
 /* prob.rs:8-103 */
-int orc_highest_hit_prob_per_reference(uint16_t total_num_k_mers, uint64_t num_trials,
-                                       const uint16_t *intersection_sizes, uint64_t n_refs,
-                                       double *out) {
-    double *table = xmalloc(((size_t)total_num_k_mers + 1) * sizeof(double));
+static int highest_hit_prob_ws(orc_ws *ws, uint16_t total_num_k_mers, uint64_t num_trials,
+                               const uint16_t *intersection_sizes, uint64_t n_refs, double *out) {
+    double *table = ws_grow(&ws->table, &ws->table_cap, (size_t)total_num_k_mers + 1);
     double z = 0.0;
-    int rc = orc_prob_table(total_num_k_mers, num_trials, intersection_sizes, n_refs, table, &z);
+    int rc = prob_table_ws(ws, total_num_k_mers, num_trials, intersection_sizes, n_refs, table, &z);
     if (rc == 0) {
         if (!(z > 0.0)) rc = -3; /* assert!(probs_sum > 0.0), :98 */
         else
             for (uint64_t r = 0; r < n_refs; r++) out[r] = table[intersection_sizes[r]] / z; /* :92-102 */
     }
-    free(table);
+    return rc;
+}
+
+int orc_highest_hit_prob_per_reference(uint16_t total_num_k_mers, uint64_t num_trials,
+                                       const uint16_t *intersection_sizes, uint64_t n_refs,
+                                       double *out) {
+    orc_ws ws;
+    ws_init(&ws);
+    int rc = highest_hit_prob_ws(&ws, total_num_k_mers, num_trials, intersection_sizes, n_refs, out);
+    ws_free(&ws);
     return rc;
 }
 
@@ -925,9 +972,15 @@ static int conf_vec_cmp(const orc_row *a, const orc_row *b) {
 }
 
 /* lineage.rs:61-112 */
+static int lineage_evaluate_buf(const orc_tree *t, const double *probs, orc_row *rows, int cap, double *prefix);
 int orc_lineage_evaluate(const orc_tree *t, const double *probs, orc_row *rows, int cap) {
-    const uint64_t N = t->num_tips;
-    double *prefix = xmalloc((N + 1) * sizeof(double)); /* :62-66 */
+    double *prefix = xmalloc((t->num_tips + 1) * sizeof(double));
+    int n = lineage_evaluate_buf(t, probs, rows, cap, prefix);
+    free(prefix);
+    return n;
+}
+static int lineage_evaluate_buf(const orc_tree *t, const double *probs, orc_row *rows, int cap, double *prefix) {
+    const uint64_t N = t->num_tips; /* :62-66 */
     prefix[0] = 0.0;
     {
         double s = 0.0;
@@ -936,7 +989,6 @@ int orc_lineage_evaluate(const orc_tree *t, const double *probs, orc_row *rows, 
     olin L = {t, prefix, 100.0 /* 10^F64_OUTPUT_ACCURACY */, rows, 0, cap, 0};
     double cp[ORC_MAXD + 1], ep[ORC_MAXD + 1];
     eval_recurse(&L, t->root, cp, ep, 0); /* :81 */
-    free(prefix);
     if (L.overflow) return -(L.n_rows) - 1;
     /* :86-90 global signal */
     double gs = 0.0;
@@ -969,13 +1021,13 @@ int orc_lineage_evaluate(const orc_tree *t, const double *probs, orc_row *rows, 
 /* ------------------------------------------------------------------------ */
 static int classify_buf(const orc_tree *t, const uint8_t *seq, uint64_t len, int skip_exact,
                         int raw_confidence, orc_row *rows, int cap, uint16_t *counts,
-                        uint16_t *kbuf, double *probs) {
+                        uint16_t *kbuf, double *probs, orc_ws *ws) {
     uint32_t nk = hit_counts_buf(t, seq, len, skip_exact, counts, kbuf);
     if (nk > 65535) return -10; /* assert, :56 */
     uint64_t num_trials = nk / 2; /* :57 */
-    int rc = orc_highest_hit_prob_per_reference((uint16_t)nk, num_trials, counts, t->num_tips, probs);
+    int rc = highest_hit_prob_ws(ws, (uint16_t)nk, num_trials, counts, t->num_tips, probs);
     if (rc < 0) return rc;
-    int n = orc_lineage_evaluate(t, probs, rows, cap); /* :71 */
+    int n = lineage_evaluate_buf(t, probs, rows, cap, ws_grow(&ws->prefix, &ws->prefix_cap, t->num_tips + 1)); /* :71 */
     if (n < 0) return -20;
     if (n == 0) return -11; /* assert!(!eval_res.is_empty()), :72 */
     if (!raw_confidence && !skip_exact) { /* :73-84 */
@@ -1001,7 +1053,10 @@ int orc_classify(const orc_tree *t, const uint8_t *seq, uint64_t len, int skip_e
     uint16_t *counts = xmalloc(t->num_tips * sizeof(uint16_t));
     uint16_t *kbuf = xmalloc((len + 1) * sizeof(uint16_t));
     double *probs = xmalloc(t->num_tips * sizeof(double));
-    int n = classify_buf(t, seq, len, skip_exact, raw_confidence, rows, cap, counts, kbuf, probs);
+    orc_ws ws;
+    ws_init(&ws);
+    int n = classify_buf(t, seq, len, skip_exact, raw_confidence, rows, cap, counts, kbuf, probs, &ws);
+    ws_free(&ws);
     free(counts);
     free(kbuf);
     free(probs);
@@ -1073,12 +1128,55 @@ out:
     return ret;
 }
 
-/* raxtax.rs:35-88 over a batch: par_chunks(chunk_size) with one u16[N] buffer per chunk. */
-int64_t orc_classify_batch(const orc_tree *t, uint64_t n_q, const uint8_t *bases,
-                           const uint64_t *base_off, int skip_exact, int raw_confidence,
-                           int threads, orc_row *rows_out, int cap, int32_t *n_rows_out,
-                           int format_strings) {
+/* utils.rs:160-197 get_thread_ids: one logical CPU per (core_id, physical_package_id) pair, taken in sorted
+ * order of (core, socket, cpu), over the CPUs this process may run on.  Returns the number of ids written. */
+int orc_physical_core_ids(int *ids, int cap) {
+    cpu_set_t mask;
+    CPU_ZERO(&mask);
+    if (sched_getaffinity(0, sizeof mask, &mask) != 0) return 0;
+    typedef struct { long core, socket; int cpu; } ent;
+    ent *all = xmalloc(CPU_SETSIZE * sizeof(ent));
+    int n = 0;
+    for (int cpu = 0; cpu < CPU_SETSIZE; cpu++) {
+        if (!CPU_ISSET(cpu, &mask)) continue;
+        char path[128];
+        long core = -1, socket = -1;
+        snprintf(path, sizeof path, "/sys/devices/system/cpu/cpu%d/topology/core_id", cpu);
+        FILE *f = fopen(path, "r");
+        if (f) { if (fscanf(f, "%ld", &core) != 1) core = -1; fclose(f); }
+        snprintf(path, sizeof path, "/sys/devices/system/cpu/cpu%d/topology/physical_package_id", cpu);
+        f = fopen(path, "r");
+        if (f) { if (fscanf(f, "%ld", &socket) != 1) socket = -1; fclose(f); }
+        if (core < 0 || socket < 0) { core = cpu; socket = 0; } /* no topology files: every CPU counts as a core */
+        all[n].core = core; all[n].socket = socket; all[n].cpu = cpu;
+        n++;
+    }
+    for (int i = 1; i < n; i++) { /* sorted() on (core, socket, cpu) */
+        ent k = all[i];
+        int j = i - 1;
+        while (j >= 0 && (all[j].core > k.core || (all[j].core == k.core && (all[j].socket > k.socket ||
+               (all[j].socket == k.socket && all[j].cpu > k.cpu))))) { all[j + 1] = all[j]; j--; }
+        all[j + 1] = k;
+    }
+    int out = 0;
+    for (int i = 0; i < n; i++) {
+        if (i && all[i].core == all[i - 1].core && all[i].socket == all[i - 1].socket) continue; /* used_physical */
+        if (out < cap) ids[out] = all[i].cpu;
+        out++;
+    }
+    free(all);
+    return out < cap ? out : cap;
+}
+
+/* raxtax.rs:35-88 over a batch: par_chunks(chunk_size) with one u16[N] buffer per chunk.
+ * pin_cpus != NULL: thread i of the pool runs on pin_cpus[i] (utils.rs:139-158, --pin); threads is then
+ * clamped to n_pin. */
+int64_t orc_classify_batch_ex(const orc_tree *t, uint64_t n_q, const uint8_t *bases,
+                              const uint64_t *base_off, int skip_exact, int raw_confidence,
+                              int threads, orc_row *rows_out, int cap, int32_t *n_rows_out,
+                              int format_strings, const int *pin_cpus, int n_pin) {
     if (threads < 1) threads = 1;
+    if (pin_cpus && n_pin > 0 && threads > n_pin) threads = n_pin; /* utils.rs:150 */
     /* main.rs:119-124 */
     uint64_t chunk = threads == 1 ? n_q : (n_q / ((uint64_t)threads * 10) + 1);
     if (threads != 1 && chunk < 100) chunk = 100;
@@ -1088,31 +1186,103 @@ int64_t orc_classify_batch(const orc_tree *t, uint64_t n_q, const uint8_t *bases
     for (uint64_t q = 0; q < n_q; q++)
         if (base_off[q + 1] - base_off[q] > max_len) max_len = base_off[q + 1] - base_off[q];
     int64_t bad = 0;
-#pragma omp parallel for schedule(dynamic, 1) num_threads(threads) reduction(+ : bad)
-    for (uint64_t c = 0; c < n_chunks; c++) {
-        uint16_t *counts = xmalloc(t->num_tips * sizeof(uint16_t)); /* :38 */
-        uint16_t *kbuf = xmalloc((max_len + 1) * sizeof(uint16_t));
-        double *probs = xmalloc(t->num_tips * sizeof(double));
-        orc_row *local = rows_out ? NULL : xmalloc((size_t)cap * sizeof(orc_row));
-        char *sbuf = format_strings ? xmalloc(1 << 20) : NULL;
-        uint64_t q1 = (c + 1) * chunk < n_q ? (c + 1) * chunk : n_q;
-        for (uint64_t q = c * chunk; q < q1; q++) {
-            orc_row *rows = rows_out ? rows_out + q * (uint64_t)cap : local;
-            int n = classify_buf(t, bases + base_off[q], base_off[q + 1] - base_off[q], skip_exact,
-                                 raw_confidence, rows, cap, counts, kbuf, probs);
-            if (n < 0) bad++;
-            if (n_rows_out) n_rows_out[q] = n;
-            if (format_strings && n > 0) {
-                char label[32];
-                snprintf(label, sizeof label, "q%llu", (unsigned long long)q);
-                (void)orc_format_out(t, label, rows, n, sbuf, 1 << 20); /* :85 */
+#pragma omp parallel num_threads(threads) reduction(+ : bad)
+    {
+        cpu_set_t old_mask;
+        int pinned = 0;
+        if (pin_cpus && n_pin > 0) {
+            extern int omp_get_thread_num(void);
+            const int me = omp_get_thread_num();
+            if (me < n_pin && sched_getaffinity(0, sizeof old_mask, &old_mask) == 0) {
+                cpu_set_t m;
+                CPU_ZERO(&m);
+                CPU_SET(pin_cpus[me], &m);
+                pinned = sched_setaffinity(0, sizeof m, &m) == 0;
             }
         }
-        free(counts);
-        free(kbuf);
-        free(probs);
-        free(local);
-        free(sbuf);
+        orc_ws ws;
+        ws_init(&ws);
+#pragma omp for schedule(dynamic, 1)
+        for (uint64_t c = 0; c < n_chunks; c++) {
+            uint16_t *counts = xmalloc(t->num_tips * sizeof(uint16_t)); /* :38 */
+            uint16_t *kbuf = xmalloc((max_len + 1) * sizeof(uint16_t));
+            double *probs = xmalloc(t->num_tips * sizeof(double));
+            orc_row *local = rows_out ? NULL : xmalloc((size_t)cap * sizeof(orc_row));
+            char *sbuf = format_strings ? xmalloc(1 << 20) : NULL;
+            uint64_t q1 = (c + 1) * chunk < n_q ? (c + 1) * chunk : n_q;
+            for (uint64_t q = c * chunk; q < q1; q++) {
+                orc_row *rows = rows_out ? rows_out + q * (uint64_t)cap : local;
+                int n = classify_buf(t, bases + base_off[q], base_off[q + 1] - base_off[q], skip_exact,
+                                     raw_confidence, rows, cap, counts, kbuf, probs, &ws);
+                if (n < 0) bad++;
+                if (n_rows_out) n_rows_out[q] = n;
+                if (format_strings && n > 0) {
+                    char label[32];
+                    snprintf(label, sizeof label, "q%llu", (unsigned long long)q);
+                    (void)orc_format_out(t, label, rows, n, sbuf, 1 << 20); /* :85 */
+                }
+            }
+            free(counts);
+            free(kbuf);
+            free(probs);
+            free(local);
+            free(sbuf);
+        }
+        ws_free(&ws);
+        if (pinned) (void)sched_setaffinity(0, sizeof old_mask, &old_mask); /* pool threads outlive the region */
     }
     return bad;
+}
+
+int64_t orc_classify_batch(const orc_tree *t, uint64_t n_q, const uint8_t *bases,
+                           const uint64_t *base_off, int skip_exact, int raw_confidence,
+                           int threads, orc_row *rows_out, int cap, int32_t *n_rows_out,
+                           int format_strings) {
+    return orc_classify_batch_ex(t, n_q, bases, base_off, skip_exact, raw_confidence, threads, rows_out, cap,
+                                 n_rows_out, format_strings, NULL, 0);
+}
+
+/* Parity taps over many queries at once (tests at full database size): raxtax.rs:41,55-68 for every query,
+ * counts_out = n_q rows of num_tips u16; t_out[q] = number of distinct k-mers. */
+void orc_hit_counts_batch(const orc_tree *t, uint64_t n_q, const uint8_t *bases, const uint64_t *base_off,
+                          int skip_exact, int threads, uint16_t *counts_out, uint32_t *t_out) {
+    if (threads < 1) threads = 1;
+    uint64_t max_len = 0;
+    for (uint64_t q = 0; q < n_q; q++)
+        if (base_off[q + 1] - base_off[q] > max_len) max_len = base_off[q + 1] - base_off[q];
+#pragma omp parallel num_threads(threads)
+    {
+        uint16_t *kbuf = xmalloc((max_len + 1) * sizeof(uint16_t));
+#pragma omp for schedule(dynamic, 1)
+        for (uint64_t q = 0; q < n_q; q++) {
+            uint32_t nk = hit_counts_buf(t, bases + base_off[q], base_off[q + 1] - base_off[q], skip_exact,
+                                         counts_out + q * t->num_tips, kbuf);
+            if (t_out) t_out[q] = nk;
+        }
+        free(kbuf);
+    }
+}
+
+/* prob.rs:8-103 for many count vectors: tables[q * tstride + m] = table[m] / Z (the probability of a reference
+ * with m hits; 0 for absent m), z[q] = Z, rc[q] = the return code of orc_prob_table. */
+void orc_prob_tables_batch(uint64_t n_q, const uint32_t *t_arr, const uint16_t *counts, uint64_t n_refs, int threads,
+                           double *tables, uint64_t tstride, double *z, int32_t *rc_out) {
+    if (threads < 1) threads = 1;
+#pragma omp parallel num_threads(threads)
+    {
+        orc_ws ws;
+        ws_init(&ws);
+#pragma omp for schedule(dynamic, 1)
+        for (uint64_t q = 0; q < n_q; q++) {
+            double *tb = tables + q * tstride;
+            double zz = 0.0;
+            int rc = t_arr[q] + 1 <= tstride ? prob_table_ws(&ws, (uint16_t)t_arr[q], t_arr[q] / 2, counts + q * n_refs, n_refs, tb, &zz) : -9;
+            if (rc == 0 && !(zz > 0.0)) rc = -3;
+            if (rc == 0)
+                for (uint64_t m = 0; m <= t_arr[q]; m++) tb[m] /= zz;
+            if (z) z[q] = zz;
+            if (rc_out) rc_out[q] = rc;
+        }
+        ws_free(&ws);
+    }
 }

@@ -118,6 +118,20 @@ int64_t orc_classify_batch(const orc_tree *t, uint64_t n_q, const uint8_t *bases
                            int threads, orc_row *rows_out, int cap, int32_t *n_rows_out,
                            int format_strings);
 
+/* The same with the pool pinned to one logical CPU per physical core (utils.rs:139-158, `--pin`):
+ * pin_cpus from orc_physical_core_ids (utils.rs:160-197). */
+int orc_physical_core_ids(int *ids, int cap);
+int64_t orc_classify_batch_ex(const orc_tree *t, uint64_t n_q, const uint8_t *bases,
+                              const uint64_t *base_off, int skip_exact, int raw_confidence,
+                              int threads, orc_row *rows_out, int cap, int32_t *n_rows_out,
+                              int format_strings, const int *pin_cpus, int n_pin);
+/* Parity taps over many queries at once (full-size tests): hit counts (raxtax.rs:41,55-68) and the
+ * normalised probability table table[m]/Z (prob.rs:8-103) of every query, on `threads` threads. */
+void orc_hit_counts_batch(const orc_tree *t, uint64_t n_q, const uint8_t *bases, const uint64_t *base_off,
+                          int skip_exact, int threads, uint16_t *counts_out, uint32_t *t_out);
+void orc_prob_tables_batch(uint64_t n_q, const uint32_t *t_arr, const uint16_t *counts, uint64_t n_refs,
+                           int threads, double *tables, uint64_t tstride, double *z, int32_t *rc_out);
+
 #ifdef __cplusplus
 }
 #endif

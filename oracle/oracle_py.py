@@ -129,6 +129,34 @@ class Oracle:
         L.orc_classify_batch.restype = C.c_int64
         L.orc_classify_batch.argtypes = [C.c_void_p, C.c_uint64, _u8p, _u64p, C.c_int, C.c_int, C.c_int,
                                          C.POINTER(OrcRow), C.c_int, _i32p, C.c_int]
+        L.orc_classify_batch_ex.restype = C.c_int64
+        L.orc_classify_batch_ex.argtypes = [C.c_void_p, C.c_uint64, _u8p, _u64p, C.c_int, C.c_int, C.c_int,
+                                            C.POINTER(OrcRow), C.c_int, _i32p, C.c_int, C.POINTER(C.c_int), C.c_int]
+        L.orc_physical_core_ids.restype = C.c_int
+        L.orc_physical_core_ids.argtypes = [C.POINTER(C.c_int), C.c_int]
+        L.orc_hit_counts_batch.restype = None
+        L.orc_hit_counts_batch.argtypes = [C.c_void_p, C.c_uint64, _u8p, _u64p, C.c_int, C.c_int, _u16p, _u32p]
+        L.orc_prob_tables_batch.restype = None
+        L.orc_prob_tables_batch.argtypes = [C.c_uint64, _u32p, _u16p, C.c_uint64, C.c_int, _f64p, C.c_uint64, _f64p, _i32p]
+
+    def physical_core_ids(self):
+        """utils.rs:160-197: one logical CPU per physical core, over the CPUs this process may run on."""
+        ids = (C.c_int * 4096)()
+        n = self.lib.orc_physical_core_ids(ids, 4096)
+        return [int(ids[i]) for i in range(n)]
+
+    def prob_tables_batch(self, t_arr, counts, threads: int = 1):
+        """table[m]/Z of prob.rs:8-103 for every row of `counts` -> (tables [n_q][tmax+1], z [n_q], rc [n_q])."""
+        t_arr = np.ascontiguousarray(t_arr, dtype=np.uint32)
+        counts = np.ascontiguousarray(counts, dtype=np.uint16)
+        n_q, n_refs = counts.shape
+        stride = int(t_arr.max()) + 1 if n_q else 1
+        tables = np.zeros((n_q, stride), dtype=np.float64)
+        z = np.zeros(n_q, dtype=np.float64)
+        rc = np.zeros(n_q, dtype=np.int32)
+        self.lib.orc_prob_tables_batch(n_q, _ptr(t_arr, _u32p), _ptr(counts, _u16p), n_refs, threads, _ptr(tables, _f64p),
+                                       stride, _ptr(z, _f64p), _ptr(rc, _i32p))
+        return tables, z, rc
 
     # ---- utils -----------------------------------------------------------
     def map_four_to_two_bit_repr(self, c: int):
@@ -350,19 +378,46 @@ class OracleTree:
         return buf.raw[:w].decode()
 
     def classify_batch(self, bases: np.ndarray, base_off: np.ndarray, skip_exact=False, raw_confidence=False,
-                       threads: int = 1, cap: int = 0, format_strings: bool = False):
-        """Returns (#would-panic, rows or None, n_rows or None).  cap=0: results discarded (timing)."""
+                       threads: int = 1, cap: int = 0, format_strings: bool = False, pin_cpus=None):
+        """Returns (#would-panic, rows or None, n_rows or None).  cap=0: results discarded (timing).
+        pin_cpus: one logical CPU per pool thread (`--pin`, utils.rs:139-158)."""
         bases = np.ascontiguousarray(bases, dtype=np.uint8)
         base_off = np.ascontiguousarray(base_off, dtype=np.uint64)
         n_q = len(base_off) - 1
+        pins = (C.c_int * len(pin_cpus))(*pin_cpus) if pin_cpus else None
+        n_pin = len(pin_cpus) if pin_cpus else 0
         if cap:
             rows = (OrcRow * (cap * n_q))()
             n_rows = np.zeros(n_q, dtype=np.int32)
-            bad = self.orc.lib.orc_classify_batch(self.h, n_q, _ptr(bases, _u8p), _ptr(base_off, _u64p),
-                                                  int(skip_exact), int(raw_confidence), threads, rows, cap,
-                                                  _ptr(n_rows, _i32p), int(format_strings))
+            bad = self.orc.lib.orc_classify_batch_ex(self.h, n_q, _ptr(bases, _u8p), _ptr(base_off, _u64p),
+                                                     int(skip_exact), int(raw_confidence), threads, rows, cap,
+                                                     _ptr(n_rows, _i32p), int(format_strings), pins, n_pin)
             return bad, rows, n_rows
-        bad = self.orc.lib.orc_classify_batch(self.h, n_q, _ptr(bases, _u8p), _ptr(base_off, _u64p),
-                                              int(skip_exact), int(raw_confidence), threads, None, 256, None,
-                                              int(format_strings))
+        bad = self.orc.lib.orc_classify_batch_ex(self.h, n_q, _ptr(bases, _u8p), _ptr(base_off, _u64p),
+                                                 int(skip_exact), int(raw_confidence), threads, None, 256, None,
+                                                 int(format_strings), pins, n_pin)
         return bad, None, None
+
+    def hit_counts_batch(self, bases: np.ndarray, base_off: np.ndarray, skip_exact=False, threads: int = 1):
+        """raxtax.rs:41,55-68 for every query -> (t [n_q], counts [n_q][num_tips])."""
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        base_off = np.ascontiguousarray(base_off, dtype=np.uint64)
+        n_q = len(base_off) - 1
+        counts = np.zeros((n_q, self.num_tips), dtype=np.uint16)
+        t = np.zeros(n_q, dtype=np.uint32)
+        self.orc.lib.orc_hit_counts_batch(self.h, n_q, _ptr(bases, _u8p), _ptr(base_off, _u64p), int(skip_exact), threads,
+                                          _ptr(counts, _u16p), _ptr(t, _u32p))
+        return t, counts
+
+    def rows_of(self, rows, n_rows, q: int, cap: int):
+        """Rows of query q out of classify_batch(cap=cap) as dicts (None where the reference would panic)."""
+        n = int(n_rows[q])
+        if n < 0:
+            return None
+        out = []
+        for i in range(n):
+            r = rows[q * cap + i]
+            out.append(dict(idx=int(r.idx), conf=[r.conf[k] for k in range(r.depth)],
+                            expd=[r.expd[k] for k in range(r.depth)],
+                            local_signal=r.local_signal, global_signal=r.global_signal))
+        return out

@@ -283,6 +283,12 @@ class Index:
         check(self._lib.rtx_batch_work(self._h, C.byref(a), C.byref(b), C.byref(c)))
         return dict(sum_hits=a.value, sum_query_bytes=b.value, bitmap_bytes_read=c.value)
 
+    def prob_work(self):
+        """Grid points D_q (n_q + 1) of prob.rs:43-90 summed over the queries of the last run."""
+        a, b = C.c_uint64(), C.c_uint64()
+        check(self._lib.rtx_batch_prob_work(self._h, C.byref(a), C.byref(b)))
+        return dict(grid_points=a.value, distinct_counts=b.value)
+
     # ---- one call -----------------------------------------------------------------------
     def exact_matches(self, bases: np.ndarray, base_off: np.ndarray):
         """Tree.sequences.get() for every query (raxtax.rs:42) -> (ids, offsets)."""

@@ -182,7 +182,7 @@ struct rtx_index {
     DevBuf<double> d_probs_dbg;
     // ---- per-query results
     DevBuf<uint8_t> d_status;
-    DevBuf<uint32_t> d_t_all, d_nrows_all, d_n_rows, d_flags;
+    DevBuf<uint32_t> d_t_all, d_nrows_all, d_n_rows, d_flags, d_ndist;
     DevBuf<double> d_gs, d_z;
     DevBuf<unsigned long long> d_hq, d_row_start, d_cursor;
     DevBuf<DevRow> d_arena;
@@ -370,6 +370,7 @@ int enqueue_prob_prefix(rtx_index *ix, const SubBatch &b, bool fuse_walk) {
     pp.z = ix->d_z.p;
     pp.gs = ix->d_gs.p;
     pp.status = ix->d_status.p;
+    pp.ndist = ix->d_ndist.p;
     if (b.timed_all) RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_PROB_TABLE, 0), s));
     if (ix->use_tables) {
         ProbTables tb{ix->d_tab_cmf.p, ix->d_tab_ratio.p, ix->d_tab_off.p, ix->d_tab_moff.p,
@@ -627,7 +628,7 @@ int prepare_workspace(rtx_index *ix, uint64_t n_queries, uint64_t tmax, uint64_t
     // ---- per-query results
     if ((rc = ix->d_status.alloc(n_queries)) || (rc = ix->d_t_all.alloc(n_queries)) || (rc = ix->d_nrows_all.alloc(n_queries)) ||
         (rc = ix->d_n_rows.alloc(n_queries)) || (rc = ix->d_gs.alloc(n_queries)) || (rc = ix->d_z.alloc(n_queries)) ||
-        (rc = ix->d_hq.alloc(n_queries)) || (rc = ix->d_row_start.alloc(n_queries)))
+        (rc = ix->d_hq.alloc(n_queries)) || (rc = ix->d_row_start.alloc(n_queries)) || (rc = ix->d_ndist.alloc(n_queries)))
         return rc;
     const uint64_t want_arena = n_queries * 8 + 4096;
     if (ix->arena_cap < want_arena) {
@@ -1456,6 +1457,25 @@ int rtx_batch_work(rtx_index *ix, uint64_t *sum_hits, uint64_t *sum_query_bytes,
     if (sum_hits) *sum_hits = h;
     if (sum_query_bytes) *sum_query_bytes = ix->sum_query_bytes;
     if (bitmap_bytes_read) *bitmap_bytes_read = b;
+    return RTX_OK;
+}
+
+int rtx_batch_prob_work(rtx_index *ix, uint64_t *sum_grid_points, uint64_t *sum_distinct_counts) {
+    if (!ix) { set_error("null index handle"); return RTX_ERR_INVALID; }
+    int rc = bind(ix);
+    if (rc) return rc;
+    if (!ix->ran) { set_error("rtx_batch_prob_work before rtx_batch_run"); return RTX_ERR_STATE; }
+    RTX_HIP(hipStreamSynchronize(ix->stream));
+    std::vector<uint32_t> nd(ix->n_q), tt(ix->n_q);
+    RTX_HIP(hipMemcpy(nd.data(), ix->d_ndist.p, ix->n_q * 4, hipMemcpyDeviceToHost));
+    RTX_HIP(hipMemcpy(tt.data(), ix->d_t_all.p, ix->n_q * 4, hipMemcpyDeviceToHost));
+    uint64_t g = 0, d = 0;
+    for (uint64_t q = 0; q < ix->n_q; q++) {
+        g += (uint64_t)nd[q] * (tt[q] / 2 + 1);  // D_q (n_q + 1), n_q = t_q / 2 (raxtax.rs:57)
+        d += nd[q];
+    }
+    if (sum_grid_points) *sum_grid_points = g;
+    if (sum_distinct_counts) *sum_distinct_counts = d;
     return RTX_OK;
 }
 

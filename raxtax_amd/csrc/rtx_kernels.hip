@@ -673,7 +673,7 @@ __global__ __launch_bounds__(kProbThreads) void prob_table_kernel(ProbParams p) 
     const double *lf = p.lnfact;
 
     if (t == 0) {  // reference: u64 underflow at prob.rs:21
-        if (tid == 0) { p.status[gq] = RTX_Q_NO_KMERS; p.z[gq] = 0.0; p.gs[gq] = 0.0; }
+        if (tid == 0) { p.status[gq] = RTX_Q_NO_KMERS; p.z[gq] = 0.0; p.gs[gq] = 0.0; p.ndist[gq] = 0; }
         return;
     }
     // distinct counts, ascending (wave 0 compacts)
@@ -686,7 +686,7 @@ __global__ __launch_bounds__(kProbThreads) void prob_table_kernel(ProbParams p) 
             if (has) ms[D + __popcll(bal & ((1ull << lane) - 1ull))] = (uint16_t)m;
             D += (uint32_t)__popcll(bal);
         }
-        if (lane == 0) { s_D = D; s_ilo = n; }
+        if (lane == 0) { s_D = D; s_ilo = n; p.ndist[gq] = D; }
     }
     for (uint32_t x = tid + 1; x <= t + n; x += kProbThreads) inv[x] = 1.0 / (double)x;
     for (uint32_t i = tid; i < kProbWaves * n1; i += kProbThreads) slots[i] = 1.0;

@@ -116,6 +116,7 @@ struct ProbParams {
     double *z;        // [n_q]
     double *gs;       // [n_q]
     uint8_t *status;  // [n_q]
+    uint32_t *ndist;  // [n_q] number of distinct hit counts D_q (work accounting)
 };
 
 struct WalkParams {

@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256) void prob_lookup_kernel(ProbParams p, ProbTabl
     const double *lf = p.lnfact;
 
     if (t == 0) {  // reference: u64 underflow at prob.rs:21
-        if (tid == 0) { p.status[gq] = RTX_Q_NO_KMERS; p.z[gq] = 0.0; p.gs[gq] = 0.0; }
+        if (tid == 0) { p.status[gq] = RTX_Q_NO_KMERS; p.z[gq] = 0.0; p.gs[gq] = 0.0; p.ndist[gq] = 0; }
         return;
     }
     for (uint32_t m = tid; m <= t; m += 256) hl[m] = hist[m];  // one coalesced round instead of a chain of loads
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256) void prob_lookup_kernel(ProbParams p, ProbTabl
             if (has) ms[D + __popcll(bal & ((1ull << lane) - 1ull))] = (uint16_t)m;
             D += (uint32_t)__popcll(bal);
         }
-        if (lane == 0) s_D = D;
+        if (lane == 0) { s_D = D; p.ndist[gq] = D; }
     }
     __syncthreads();
     const uint32_t D = s_D;

@@ -159,17 +159,26 @@ class ShardedClassifier:
     def __init__(self, shards: Sequence[ShardIndex], comm):
         self.shards, self.comm = list(shards), comm
 
+    def upload(self, bases: np.ndarray, base_off: np.ndarray, exact_ids=None, exact_off=None):
+        """Queries (and their exact-match ids) to every shard's HBM; they stay resident for any number of run()s."""
+        for s in self.shards:
+            s.upload(bases, base_off, exact_ids, exact_off)
+        self._n_q = len(base_off) - 1
+
     def classify(self, bases: np.ndarray, base_off: np.ndarray, exact_ids=None, exact_off=None,
                  skip_exact_matches: bool = False) -> Result:
+        self.upload(bases, base_off, exact_ids, exact_off)
+        return self.run(skip_exact_matches)
+
+    def run(self, skip_exact_matches: bool = False, copy: bool = True):
+        """One pass over the uploaded queries; returns the Result (copy=True) or the library-owned view."""
         import torch
 
         flags = _lib.RTX_SKIP_EXACT_MATCHES if skip_exact_matches else 0
-        for s in self.shards:
-            s.upload(bases, base_off, exact_ids, exact_off)
         n_sub, B = self.shards[0].begin()
         for s in self.shards[1:]:
             assert s.begin() == (n_sub, B), "all shards must use the same sub-batch size"
-        n_q = len(base_off) - 1
+        n_q = self._n_q
         for sb in range(n_sub):
             nq = min(B, n_q - sb * B)
             for s in self.shards:
@@ -189,4 +198,4 @@ class ShardedClassifier:
                 s.walk(sb, pref)
             for s in self.shards:
                 s.sync()
-        return self.shards[0].download()
+        return self.shards[0].download(copy=copy)

@@ -1,0 +1,53 @@
+"""bench.py as the driver runs it, at toy sizes: the JSON contract (roofline + cpu_baseline present and physical),
+`--gpus N` launching its own ranks (two gloo ranks sharing the one GPU of the test box), and the reference-sharded
+mode (`--shard-db`, BASELINE.json configs[4])."""
+import json
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def bench(*args, timeout=600):
+    p = subprocess.run([sys.executable, str(ROOT / "bench.py"), *map(str, args)], capture_output=True, text=True, timeout=timeout)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_single_gpu_line_is_physical():
+    r = bench("--refs", 20000, "--queries", 12000, "--steps", 2, "--warmup", 1, "--cpu-seconds", 1)
+    assert r["n_gpus"] == 1 and r["steps"] == 2 and r["unit"] == "queries/s" and r["value"] > 0
+    assert r["config"]["classified_ok"] == 12000
+    roof = r["roofline"]
+    assert roof["bound"] == "l2" and 0 < roof["frac"] <= 1.0 and roof["peak"] == 34500.0
+    assert abs(roof["achieved"] / roof["peak"] - roof["frac"]) < 1e-12
+    assert roof["algorithmic_ratio_to_hbm_peak"] > 0 and roof["requested_bytes_per_query"] > 0
+    assert roof["traffic"] is None or roof["hbm_frac"] <= 1.0          # no PMC profile of this toy configuration
+    assert 0 < roof["prob_stage"]["frac"] < 1.0 and roof["prob_stage"]["ops_prob_per_query"] > 1000
+    assert all(v > 0 for k, v in r["stage_ms_per_step"].items() if k != "lineage_walk")   # the walk rides inside taxon_prefix
+    cpu = r["cpu_baseline"]
+    assert cpu["kind"] == "port" and cpu["value"] > 0 and cpu["cores"] >= 1 and cpu["one_thread"]["value"] > 0
+    assert "cpu_model" in cpu and cpu["unit"] == "queries/s"
+
+
+def test_gpus_2_launches_its_own_ranks():
+    """`python bench.py --gpus 2` without a launcher: two ranks (gloo, sharing the GPU), the gather of the result
+    records inside the timed region, n_gpus = 2 on the line (the parent exits non-zero otherwise)."""
+    r = bench("--gpus", 2, "--backend", "gloo", "--refs", 5000, "--queries", 3000, "--steps", 2, "--warmup", 1)
+    assert r["n_gpus"] == 2 and r["config"]["process_group"] == {"backend": "gloo", "world_size": 2}
+    assert r["scaling"] == "weak" and r["cpu_baseline"] is None
+    assert r["config"]["classified_ok"] == 3000
+
+
+def test_shard_db_mode_runs():
+    r = bench("--shard-db", "--refs", 2000, "--queries", 256, "--steps", 1, "--warmup", 1, "--no-cpu-baseline")
+    assert r["scaling"] == "strong" and r["config"]["classified_ok"] == 256
+    assert r["roofline"] is not None and r["roofline"]["launch_ms"] > 0
+    r2 = bench("--shard-db", "--gpus", 2, "--backend", "gloo", "--refs", 3000, "--queries", 300, "--steps", 1, "--warmup", 1)
+    assert r2["n_gpus"] == 2 and r2["config"]["classified_ok"] == 300

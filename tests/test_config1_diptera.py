@@ -36,6 +36,7 @@ def test_oracle_self_classification_plumbing(oracle):
 @pytest.mark.parametrize("skip,raw", [(False, False), (True, False), (False, True)])
 def test_gpu_self_classification_matches_oracle(oracle, skip, raw):
     import raxtax_amd as rx
+    from gpu_common import Excuses
     from test_gpu_parity import assert_rows_equivalent
 
     text = FASTA.read_text()
@@ -53,6 +54,8 @@ def test_gpu_self_classification_matches_oracle(oracle, skip, raw):
     rx.raxtax(queries, ix, skip, raw, 0, lambda l, o, t: got.__setitem__(l, o), False)
     assert set(got) == set(want)
     diff = [l for l in want if got[l] != want[l]]
+    ex = Excuses(f"diptera600/skip={int(skip)}/raw={int(raw)}")
+    ex.checked = len(want)
     # identical text, except exact floating-point ties between sibling taxa
     for l in diff:
         seq = dict(queries)[l]
@@ -61,7 +64,9 @@ def test_gpu_self_classification_matches_oracle(oracle, skip, raw):
         rows, _ = otree.classify(seq, skip_exact=skip, raw_confidence=True)
         res = ix.classify(seq, np.array([0, len(seq)], np.uint64),
                           *ix.exact_matches(seq, np.array([0, len(seq)], np.uint64)), skip_exact_matches=skip)
-        assert_rows_equivalent(res.rows(0), rows, probs, lins, l)
+        ties = assert_rows_equivalent(res.rows(0), rows, probs, lins, l)
+        assert ties > 0, f"{l}: text differs from the oracle's without a tie"
+        ex.tie()
     # real barcodes with duplicates: once the exact matches are zeroed (--skip-exact-matches) sibling
-    # species with identical hit counts tie exactly in ~6 % of the queries
-    assert len(diff) <= (0.10 if skip else 0.02) * len(want)
+    # species with identical hit counts tie exactly in a few per cent of the queries; the count is pinned
+    ex.check()

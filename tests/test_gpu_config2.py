@@ -1,0 +1,68 @@
+"""BASELINE.json configs[2] on the GPU: 500 000 references (the database size of the headline and of the 8-GPU
+configs[3]), 100 000 of the synthetic queries of the bench through the size-independent properties, and a seeded
+2 000-query sample against the CPU oracle in both exact-match modes -- hit counts bit-exact, probabilities within
+1e-6, result rows identical (the reference's own methodology samples databases of this size,
+scripts/runtime_memory.py:42-43)."""
+import numpy as np
+import pytest
+
+import raxtax_amd as rx
+from gpu_common import Excuses, check_properties, oracle_sample_parity, rows_of
+from raxtax_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+N_REFS, N_Q, N_SAMPLE = 500_000, 100_000, 2_000
+
+
+@pytest.fixture(scope="module")
+def cfg2(oracle):
+    db = synth.make_db(N_REFS)
+    qs = synth.make_queries(db, N_Q)
+    tree = rx.Tree.new_flat(db.lineages, db.seq_bytes, db.seq_off, kmer_map=False)   # bitmaps built on the GPU
+    index = rx.Index(tree)
+    ex_ids, ex_off = index.exact_matches(qs.bases, qs.base_off)
+    res = index.classify(qs.bases, qs.base_off, ex_ids, ex_off)
+    otree = oracle.tree_new_flat(db.lineages, db.seq_bytes, db.seq_off)
+    sample = np.sort(np.random.default_rng(20260).choice(N_Q, N_SAMPLE, replace=False))
+    return dict(db=db, qs=qs, tree=tree, index=index, res=res, ex=(ex_ids, ex_off), otree=otree, sample=sample)
+
+
+def test_every_query_is_classified(cfg2):
+    check_properties(cfg2["res"], cfg2["db"], N_Q)
+    assert cfg2["index"].n_refs == N_REFS
+
+
+def test_batch_order_does_not_matter(cfg2):
+    qs, index, res = cfg2["qs"], cfg2["index"], cfg2["res"]
+    L = cfg2["db"].length
+    rev = np.ascontiguousarray(qs.bases.reshape(-1, L)[::-1]).reshape(-1)
+    r2 = index.classify(rev, qs.base_off, *index.exact_matches(rev, qs.base_off))
+    for q in list(range(0, N_Q, 331)) + [N_Q - 1]:
+        a, b = rows_of(res, q), rows_of(r2, N_Q - 1 - q)
+        assert all(np.array_equal(x, y) for x, y in zip(a, b)), q
+        assert res.global_signal[q] == r2.global_signal[N_Q - 1 - q] and res.t[q] == r2.t[N_Q - 1 - q]
+
+
+def test_exact_copies_find_their_reference(cfg2):
+    qs, tree, res = cfg2["qs"], cfg2["tree"], cfg2["res"]
+    ex_ids, ex_off = cfg2["ex"]
+    orig = tree.original_index()
+    inv = np.empty(len(orig), np.int64)
+    inv[orig] = np.arange(len(orig))
+    n_exact = np.diff(ex_off.astype(np.int64))
+    copies = np.nonzero(n_exact > 0)[0]
+    assert len(copies) > N_Q // 20          # 10 % of the synthetic queries are exact copies
+    for q in copies[:300]:
+        ids = ex_ids[int(ex_off[q]):int(ex_off[q + 1])]
+        assert inv[qs.source[q]] in ids
+        assert res.t[q] >= 2
+
+
+@pytest.mark.parametrize("skip", [False, True])
+def test_seeded_oracle_sample(cfg2, oracle, skip):
+    c = cfg2
+    ex = Excuses(f"config2/sample{N_SAMPLE}/skip={int(skip)}")
+    oracle_sample_parity(c["index"], oracle, c["otree"], c["db"], c["qs"], c["sample"], skip, ex,
+                         full_res=None if skip else c["res"])
+    ex.check()

@@ -1,15 +1,16 @@
-"""BASELINE.json configs[1] at full database size (50 000 references) on the GPU: properties that do not depend on
-the size (every query classified, invariance under the order and the composition of the batch, exact copies found)
-plus oracle parity on a handful of queries."""
+"""BASELINE.json configs[1] at full size on the GPU (100 000 queries, 50 000 references): properties that do not depend
+on the size (every query classified, invariance under the order and the composition of the batch, exact copies found)
+plus a seeded 2 000-query sample against the oracle in both exact-match modes."""
 import numpy as np
 import pytest
 
 import raxtax_amd as rx
+from gpu_common import Excuses, check_properties, oracle_sample_parity
 from raxtax_amd import synth
 
 pytestmark = pytest.mark.gpu
 
-N_REFS, N_Q = 50_000, 20_000
+N_REFS, N_Q, N_SAMPLE = 50_000, 100_000, 2_000
 
 
 @pytest.fixture(scope="module")
@@ -29,24 +30,7 @@ def _rows(res, q):
 
 
 def test_every_query_is_classified(full):
-    res, qs = full["res"], full["qs"]
-    assert res.n_queries == N_Q and (res.status == 0).all()
-    assert (np.diff(res.row_off.astype(np.int64)) >= 1).all()
-    L = full["db"].length
-    assert (res.t <= L - 7).all() and (res.t >= 2).all()
-    assert np.isfinite(res.global_signal).all() and (res.global_signal > 0).all()
-    conf = res.row_conf
-    assert (conf >= 0).all() and (conf <= 1.0 + 1e-12).all()
-    depth = res.row_depth
-    # confidences never increase from one level to the next (a child's range is inside its parent's)
-    for d in range(1, 6):
-        sel = depth > d
-        assert (conf[sel, d] <= conf[sel, d - 1] + 1e-12).all()
-    # rows of a query are sorted by descending confidence vectors (lineage.rs:91-93)
-    first = res.row_off[:-1].astype(np.int64)
-    nxt = first + 1
-    two = nxt < res.row_off[1:].astype(np.int64)
-    assert (conf[first[two], 0] >= conf[nxt[two], 0]).all()
+    check_properties(full["res"], full["db"], N_Q)
 
 
 def test_order_and_composition_of_the_batch_do_not_matter(full):
@@ -94,22 +78,11 @@ def test_exact_copies_find_their_reference(full):
     assert checked == min(200, len(copies))
 
 
-def test_oracle_parity_on_a_sample(full, oracle):
+@pytest.mark.parametrize("skip", [False, True])
+def test_seeded_oracle_sample(full, oracle, skip):
     db, qs, res, index = full["db"], full["qs"], full["res"], full["index"]
     otree = oracle.tree_new_flat(db.lineages, db.seq_bytes, db.seq_off)
-    sample = [0, 1, 4999, 12345, N_Q - 1]
-    for q in sample:
-        rows, _ = otree.classify(qs.seq(q), raw_confidence=True)
-        got = res.rows(q)
-        assert [r.lineage for r in got] == [r["idx"] for r in rows], q
-        assert [r.confidence_values for r in got] == [r["conf"] for r in rows], q
-        for g, r in zip(got, rows):
-            assert abs(g.local_signal - r["local_signal"]) < 1e-6 and abs(g.global_signal - r["global_signal"]) < 1e-9
-    # hit counts bit-exact (debug taps address the last sub-batch: classify the sample as a batch of its own)
-    L = db.length
-    sub = np.concatenate([qs.seq(q) for q in sample])
-    off = (np.arange(len(sample) + 1) * L).astype(np.uint64)
-    index.classify(sub, off, *index.exact_matches(sub, off))
-    for j, q in enumerate(sample):
-        t, counts = otree.hit_counts(qs.seq(q))
-        assert np.array_equal(index.debug_hit_counts(j), counts) and index.debug_kmers(j).size == t
+    sample = np.sort(np.random.default_rng(20261).choice(N_Q, N_SAMPLE, replace=False))
+    ex = Excuses(f"config1/sample{N_SAMPLE}/skip={int(skip)}")
+    oracle_sample_parity(index, oracle, otree, db, qs, sample, skip, ex, full_res=None if skip else res, chunk=500)
+    ex.check()

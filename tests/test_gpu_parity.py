@@ -9,6 +9,7 @@ import numpy as np
 import pytest
 
 import raxtax_amd as rx
+from gpu_common import Excuses
 from raxtax_amd import synth
 
 pytestmark = pytest.mark.gpu
@@ -131,6 +132,7 @@ def test_stagewise_parity(world, oracle, skip):
     assert res.n_queries == n_q
     n_checked_rows = n_tie_rows = n_tie_regular = 0
     lineages = otree.lineages
+    exc = Excuses(f"stagewise/skip={int(skip)}")
     for q in range(n_q):
         seq = w["seqs"][q]
         # --- K1: distinct 8-mers, ascending (utils.rs:27-40)
@@ -155,6 +157,8 @@ def test_stagewise_parity(world, oracle, skip):
         ties = assert_rows_equivalent(got, rows, probs_ref, lineages, w["labels"][q])
         n_tie_rows += ties
         n_tie_regular += bool(ties) and len(seq) == w["db"].length
+        exc.checked += 1
+        exc.tie(ties)
         for g in got:
             assert abs(g.global_signal - rows[0]["global_signal"]) < TOL_TIGHT
         if [g.lineage for g in got] == [r["idx"] for r in rows]:
@@ -165,6 +169,7 @@ def test_stagewise_parity(world, oracle, skip):
     # exact ties are a feature of the degenerate short queries (a handful of k-mers shared by whole
     # clades); full-length queries essentially never produce one
     assert n_tie_regular <= 0.02 * n_q, (n_tie_regular, n_tie_rows)
+    exc.check()
 
 
 @pytest.mark.parametrize("skip,raw", [(False, False), (False, True), (True, False)])
@@ -176,20 +181,23 @@ def test_formatted_output_matches_oracle(world, skip, raw):
     res = ix.classify(w["bases"], w["off"], ex_ids, ex_off, skip_exact_matches=skip)
     flags = (rx.RTX_SKIP_EXACT_MATCHES if skip else 0) | (rx.RTX_RAW_CONFIDENCE if raw else 0)
     n_override = n_tied = 0
+    exc = Excuses(f"formatted/skip={int(skip)}/raw={int(raw)}")
     for q, seq in enumerate(w["seqs"]):
         if res.status[q] != 0:
             continue
+        exc.checked += 1
         ex = ex_ids[int(ex_off[q]):int(ex_off[q + 1])]
         out, tsv = ix.format_query(q, w["labels"][q], seq, ex, flags, tsv=True)
         rows, rawrows = otree.classify(seq, skip_exact=skip, raw_confidence=raw)
         if [r.lineage for r in res.rows(q)] != [r["idx"] for r in otree.classify(seq, skip_exact=skip,
                                                                                   raw_confidence=True)[0]]:
-            n_tied += 1      # exact tie between sibling taxa, see assert_rows_equivalent
+            n_tied += 1      # exact tie between sibling taxa (verified as one by test_stagewise_parity on the same queries)
+            exc.tie()
             continue
         assert out == otree.format_out(w["labels"][q], rawrows), w["labels"][q]
         assert tsv == otree.format_tsv(w["labels"][q], rawrows, seq), w["labels"][q]
         n_override += (len(ex) == 1 and not skip and not raw)
-    assert n_tied <= 3
+    exc.check()
     if not skip and not raw:
         assert n_override > 5
 
@@ -219,6 +227,33 @@ def test_raxtax_mirror_end_to_end(world):
 
     with pytest.raises(Closed):
         rx.raxtax(queries[:3], w["index"], False, False, 0, closed, False)
+
+
+def test_raxtax_mirror_chunks_with_very_different_row_counts(world):
+    """Several chunks whose result-row counts differ by two orders of magnitude (one or two rows per full-length
+    query, dozens per 12-30-base fragment): the pipelined host mirror formats chunk c-1 out of one result set while
+    chunk c is downloaded into the other -- a set must never be reallocated while its view is being read.  The text
+    must equal that of one call with everything in a single chunk, whatever the chunk size."""
+    w = world
+    db = w["db"]
+    rng = np.random.default_rng(9)
+    queries = []
+    for c in range(6):
+        for i in range(90):
+            src = db.seq(int(rng.integers(0, db.n)))
+            if c % 2:
+                a = int(rng.integers(0, 600))
+                queries.append((f"c{c}_{i}", src[a:a + int(rng.integers(12, 30))].copy()))     # dozens of rows each
+            else:
+                queries.append((f"c{c}_{i}", src.copy()))
+    single = []
+    rx.raxtax(queries, w["index"], True, False, 0, lambda l, o, t: single.append((l, o, t)), True)
+    n_lines = [o.count("\n") + 1 for _, o, _ in single]
+    assert max(n_lines) >= 20 * min(n_lines)
+    for chunk in (90, 64, 17):
+        got = []
+        rx.raxtax(queries, w["index"], True, False, chunk, lambda l, o, t: got.append((l, o, t)), True)
+        assert got == single, chunk
 
 
 @pytest.mark.parametrize("name", ["F8_tree_construction", "F9_variable_lineage_length", "F10_likelihood_edge_case"])
@@ -678,6 +713,7 @@ def test_randomised_configurations(oracle, seed):
     olin = otree.lineages
     onodes = otree.nodes()
     n_ties = n_boundary = 0
+    exc = Excuses(f"fuzz/seed={seed}")
 
     def at_rounding_boundary(probs):
         """Some taxon's confidence x 100 lies within 1e-6 of k + 0.5: `round` may go either way in two correct
@@ -699,14 +735,20 @@ def test_randomised_configurations(oracle, seed):
                 continue
             assert res.status[q] == 0
             probs_ref = oracle.highest_hit_prob_per_reference(t, t // 2, counts)
+            exc.checked += 1
             try:
-                n_ties += bool(assert_rows_equivalent(res.rows(q), rows, probs_ref, olin, f"seed {seed} skip {skip} q {q}"))
+                k = assert_rows_equivalent(res.rows(q), rows, probs_ref, olin, f"seed {seed} skip {skip} q {q}")
+                n_ties += bool(k)
+                exc.tie(k)
             except AssertionError:
                 # also with the phylogenetic database: a short truncated query ties dozens of references exactly and
                 # their taxa land on k + 0.5 hundredths (seed 5092: sixteen species at 0.075 +- 2e-16)
                 if not at_rounding_boundary(probs_ref):
                     raise
                 n_boundary += 1
+                exc.boundary()
+    if seed in (101, 202, 303, 404):       # the seeds of the suite have committed expectations; extra seeds (RTX_FUZZ_SEEDS) only the bounds below
+        exc.check()
     assert n_boundary <= 20, n_boundary
     # exact ties between sibling taxa (accepted above only if the confidences agree to 1e-9) belong to degenerate
     # inputs: random references, very short sequences; realistic full-length data essentially never produce one

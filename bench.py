@@ -63,6 +63,7 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of each leg of the cpu_baseline sample")
     ap.add_argument("--streams", type=int, default=0, help="HIP streams per handle (0 = library default)")
     ap.add_argument("--no-cluster", action="store_true", help="process the queries in input order (RTX_OPT_CLUSTER = 0)")
+    ap.add_argument("--u16-counts", action="store_true", help="counts travel as u16 instead of packed 10 bits (RTX_OPT_PACKED_COUNTS = 0)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--skip-exact-matches", action="store_true")
     ap.add_argument("--hit-events-only", action="store_true",
@@ -340,7 +341,8 @@ def main():
         qs = synth.make_queries(db, args.queries, seed=3 + rank, first_label=rank * args.queries)   # rank-specific queries
         tree = rx.Tree.new_flat(db.lineages, db.seq_bytes, db.seq_off, kmer_map=False)   # bitmaps built on the GPU
         index = rx.Index(tree, device=local_rank, sub_batch=args.sub_batch, streams=args.streams,
-                         stage_timing=not args.hit_events_only, cluster=False if args.no_cluster else None)
+                         stage_timing=not args.hit_events_only, cluster=False if args.no_cluster else None,
+                         packed_counts=False if args.u16_counts else None)
         t0 = time.perf_counter()
         ex_ids, ex_off = index.exact_matches(qs.bases, qs.base_off)   # Tree.sequences.get, raxtax.rs:42 (host)
         t_exact = time.perf_counter() - t0

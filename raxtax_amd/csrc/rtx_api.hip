@@ -156,6 +156,8 @@ struct rtx_index {
     uint32_t last_flags = 0;
     // ---- processing order of the batch (rtx_cluster.hip): perm[position] = query, inv[query] = position
     uint32_t cluster = 1;  // RTX_OPT_CLUSTER
+    uint32_t packed_opt = 1;  // RTX_OPT_PACKED_COUNTS
+    bool packed() const { return packed_opt && planes <= 10; }
     DevBuf<uint64_t> d_skey_in, d_skey_out;
     DevBuf<uint32_t> d_sidx, d_perm, d_iperm;
     DevBuf<uint8_t> d_sort_tmp;
@@ -180,6 +182,7 @@ struct rtx_index {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     uint32_t last_set = 0;  // scratch set of the last sub-batch (debug taps)
     DevBuf<double> d_probs_dbg;
+    DevBuf<uint16_t> d_counts_dbg;
     // ---- per-query results
     DevBuf<uint8_t> d_status;
     DevBuf<uint32_t> d_t_all, d_nrows_all, d_n_rows, d_flags, d_ndist;
@@ -270,6 +273,17 @@ SubBatch sub_batch_of(rtx_index *ix, uint32_t sb, bool timed) {
     return b;
 }
 
+// Counts of a sub-batch between hit_count and taxon_prefix.  With 10 bit planes (t <= 1023) they travel packed,
+// 10 bits per reference: [B][npad] low bytes, then [B][npad / 8] u16 with the two high bits of eight references
+// each; otherwise [B][npad] u16.  Both live in the same allocation (sized for the format in use).
+uint8_t *counts_lo(rtx_index *ix, rtx_index::Scratch &sc) { return reinterpret_cast<uint8_t *>(sc.d_counts.p); }
+uint16_t *counts_hi(rtx_index *ix, rtx_index::Scratch &sc) {
+    return reinterpret_cast<uint16_t *>(reinterpret_cast<uint8_t *>(sc.d_counts.p) + (size_t)ix->sub_batch * ix->npad);
+}
+size_t counts_elems(const rtx_index *ix, uint64_t B) {  // u16 elements of d_counts
+    return ix->packed() ? (size_t)B * ix->npad * 5 / 8 : (size_t)B * ix->npad;
+}
+
 hipEvent_t stage_event(rtx_index *ix, const SubBatch &b, int stage, int which) {
     return ix->events[((size_t)b.sb * RTX_NUM_STAGES + stage) * 2 + which];
 }
@@ -331,6 +345,8 @@ int enqueue_hit(rtx_index *ix, const SubBatch &b, uint32_t flags, hipStream_t s)
     hp.ntiles = ix->ntiles;
     hp.t = sc.d_t.p;
     hp.counts = sc.d_counts.p;
+    hp.counts_lo = ix->packed() ? counts_lo(ix, sc) : nullptr;  // null: u16 counts
+    hp.counts_hi = ix->packed() ? counts_hi(ix, sc) : nullptr;
     hp.npad = ix->npad;
     hp.hist = sc.d_hist.p;
     hp.hstride = ix->hstride;
@@ -389,6 +405,9 @@ int enqueue_prob_prefix(rtx_index *ix, const SubBatch &b, bool fuse_walk) {
     fp.tz_in_lds = (size_t)ix->hstride * 8 <= 16 * 1024 ? 1u : 0u;
     fp.q0 = b.q0;
     fp.counts = sc.d_counts.p;
+    fp.counts_lo = counts_lo(ix, sc);
+    fp.counts_hi = counts_hi(ix, sc);
+    fp.packed = ix->packed() ? 1u : 0u;
     fp.npad = ix->npad;
     fp.table_z = sc.d_table_z.p;
     fp.hstride = ix->hstride;
@@ -642,7 +661,7 @@ int prepare_workspace(rtx_index *ix, uint64_t n_queries, uint64_t tmax, uint64_t
         RTX_HIP(hipEventCreateWithFlags(&ix->ev_fork, hipEventDisableTiming));
         RTX_HIP(hipEventCreateWithFlags(&ix->ev_join, hipEventDisableTiming));
     }
-    const uint64_t per_q = ((uint64_t)ix->kstride * 2 + (uint64_t)ix->rstride * 4 + (uint64_t)ix->ntiles * (ix->rstride / 8 + (kSegMaxSparseRows + 1) * 4 + 8) + ix->npad * 2 + (uint64_t)ix->hstride * 12 +
+    const uint64_t per_q = ((uint64_t)ix->kstride * 2 + (uint64_t)ix->rstride * 4 + (uint64_t)ix->ntiles * (ix->rstride / 8 + (kSegMaxSparseRows + 1) * 4 + 8) + (ix->packed() ? ix->npad * 5 / 4 : ix->npad * 2) + (uint64_t)ix->hstride * 12 +
                             (uint64_t)ix->n_bnd_local * 8 + 64) * ix->n_streams;
     uint32_t B = ix->sub_batch_req;
     if (B == 0) {
@@ -660,7 +679,7 @@ int prepare_workspace(rtx_index *ix, uint64_t n_queries, uint64_t tmax, uint64_t
         rtx_index::Scratch &sc = ix->sc[k];
         if ((rc = sc.d_kmers.alloc((size_t)B * ix->kstride)) || (rc = sc.d_rows.alloc((size_t)B * ix->rstride)) || (rc = sc.d_dmask.alloc((size_t)B * ix->ntiles * (ix->rstride / 64))) ||
             (rc = sc.d_nsparse.alloc((size_t)B * ix->ntiles)) || (rc = sc.d_srows.alloc((size_t)B * ix->ntiles * (kSegMaxSparseRows + 1))) ||
-            (rc = sc.d_t.alloc(B)) || (rc = sc.d_nrows.alloc(B)) || (rc = sc.d_counts.alloc((size_t)B * ix->npad)) ||
+            (rc = sc.d_t.alloc(B)) || (rc = sc.d_nrows.alloc(B)) || (rc = sc.d_counts.alloc(counts_elems(ix, B))) ||
             (rc = sc.d_hist.alloc((size_t)B * ix->hstride)) || (rc = sc.d_table_z.alloc((size_t)B * ix->hstride)) ||
             (rc = sc.d_prefix.alloc((size_t)B * ix->n_bnd_local)) || (rc = sc.d_order.alloc(B)))
             return rc;
@@ -1113,6 +1132,9 @@ int rtx_index_set_option(rtx_index *index, int option, uint64_t value) {
         case RTX_OPT_CLUSTER:
             index->cluster = value ? 1u : 0u;
             return RTX_OK;
+        case RTX_OPT_PACKED_COUNTS:
+            index->packed_opt = value ? 1u : 0u;
+            return RTX_OK;
         case RTX_OPT_PROB_MODE:
             if (value > 2) break;
             index->prob_mode = (int)value;
@@ -1492,6 +1514,19 @@ static int debug_slot(rtx_index *ix, uint64_t query, uint32_t *slot) {
     return RTX_OK;
 }
 
+// u16 counts of one slot of the last sub-batch on the device (unpacked into a scratch row if they are packed)
+static int debug_counts_u16(rtx_index *ix, uint32_t slot, const uint16_t **out) {
+    rtx_index::Scratch &sc = ix->sc[ix->last_set];
+    if (!ix->packed()) { *out = sc.d_counts.p + (size_t)slot * ix->npad; return RTX_OK; }
+    int rc = ix->d_counts_dbg.alloc(ix->npad);
+    if (rc) return rc;
+    launch_counts_unpack(ix->stream, counts_lo(ix, sc) + (size_t)slot * ix->npad, counts_hi(ix, sc) + (size_t)slot * (ix->npad >> 3), ix->npad,
+                         ix->d_counts_dbg.p);
+    RTX_HIP(hipStreamSynchronize(ix->stream));
+    *out = ix->d_counts_dbg.p;
+    return RTX_OK;
+}
+
 int rtx_debug_kmers(rtx_index *ix, uint64_t query, uint16_t *kmers, uint32_t *t) {
     uint32_t slot;
     int rc = debug_slot(ix, query, &slot);
@@ -1507,7 +1542,9 @@ int rtx_debug_hit_counts(rtx_index *ix, uint64_t query, uint16_t *counts) {
     uint32_t slot;
     int rc = debug_slot(ix, query, &slot);
     if (rc) return rc;
-    RTX_HIP(hipMemcpy(counts, ix->sc[ix->last_set].d_counts.p + (size_t)slot * ix->npad, ix->n_refs * 2, hipMemcpyDeviceToHost));
+    const uint16_t *src = nullptr;
+    if ((rc = debug_counts_u16(ix, slot, &src))) return rc;
+    RTX_HIP(hipMemcpy(counts, src, ix->n_refs * 2, hipMemcpyDeviceToHost));
     return RTX_OK;
 }
 
@@ -1531,8 +1568,9 @@ int rtx_debug_probs(rtx_index *ix, uint64_t query, double *probs) {
     int rc = debug_slot(ix, query, &slot);
     if (rc) return rc;
     if ((rc = ix->d_probs_dbg.alloc(ix->n_refs))) return rc;
-    launch_probs_expand(ix->stream, ix->sc[ix->last_set].d_counts.p + (size_t)slot * ix->npad, ix->sc[ix->last_set].d_table_z.p + (size_t)slot * ix->hstride,
-                        ix->n_refs, ix->d_probs_dbg.p);
+    const uint16_t *src = nullptr;
+    if ((rc = debug_counts_u16(ix, slot, &src))) return rc;
+    launch_probs_expand(ix->stream, src, ix->sc[ix->last_set].d_table_z.p + (size_t)slot * ix->hstride, ix->n_refs, ix->d_probs_dbg.p);
     RTX_HIP(hipStreamSynchronize(ix->stream));
     RTX_HIP(hipMemcpy(probs, ix->d_probs_dbg.p, ix->n_refs * 8, hipMemcpyDeviceToHost));
     return RTX_OK;
@@ -1553,6 +1591,7 @@ int rtx_debug_evaluate(rtx_index *ix, const double *probs, rtx_result_view *out)
     ix->sum_query_bytes = 0;
     ix->stream_dl = false;
     if ((rc = order_batch(ix, false))) return rc;
+    if ((rc = ix->sc[0].d_counts.alloc(ix->npad))) return rc;  // u16 format here whatever the batch format would be
     std::vector<uint16_t> counts(ix->npad, 0);
     for (uint64_t r = 0; r < N; r++) counts[r] = (uint16_t)r;  // count_r = r, table[r] = probs[r]
     double gs = 0.0;

@@ -396,7 +396,7 @@ __device__ __forceinline__ uint4 csa_plane(uint32_t (&pl)[4][NP], const uint4 &a
 
 // Occupancy matters here: with <= 128 VGPRs four waves per SIMD are resident (16 per CU; their 8.4 KB of LDS each
 // just fit) -- a variant with 132 VGPRs (three waves) was 16 % slower.  The bound makes the compiler keep it.
-template <int NP>
+template <int NP, bool kPacked>
 __global__ __launch_bounds__(64, (NP <= 10 ? 4 : 2)) void hit_count_kernel(HitParams p) {
     extern __shared__ uint32_t hist_lds[];
     const uint32_t tile = blockIdx.y, lane = threadIdx.x;
@@ -564,7 +564,12 @@ __global__ __launch_bounds__(64, (NP <= 10 ? 4 : 2)) void hit_count_kernel(HitPa
     }
     // group g = (w, g2) of this lane: references ref0 + g*L*8 + [0, 8) (ref_slot, rtx_math.hpp)
     const uint64_t ref0 = (uint64_t)tile * 8192u + lane * 8u;
+    static_assert(!kPacked || NP <= 10, "the packed format holds counts up to 1023");  // 10 bits per reference leave the kernel instead of 16
     uint16_t *out = p.counts + (size_t)q * p.npad + ref0;
+    uint8_t *out_lo = p.counts_lo + (size_t)q * p.npad + ref0;
+    uint32_t hiw[8];  // packed format: the two high bits of the 8 references of group g in bits 16 (g & 1) + [0, 16) of hiw[g / 2]
+#pragma unroll
+    for (int i = 0; i < 8; i++) hiw[i] = 0;
 #pragma unroll
     for (int half = 0; half < 2; half++) {  // groups 0-7 = references 0..4095 of a full tile, groups 8-15 = 4096..8191
         if (ns) {
@@ -585,7 +590,7 @@ __global__ __launch_bounds__(64, (NP <= 10 ? 4 : 2)) void hit_count_kernel(HitPa
             for (int wi = 0; wi < 2; wi++) {
                 const int w = half * 2 + wi;
 #pragma unroll
-                for (int g2 = 0; g2 < 4; g2++) {  // 8 references per 16-byte store, contiguous across lanes
+                for (int g2 = 0; g2 < 4; g2++) {  // 8 references per store, contiguous across lanes
                     uint32_t lo0, hi0, lo1, hi1;
                     planes_unpack4<NP>(pl[w], 2 * g2, lo0, hi0);
                     planes_unpack4<NP>(pl[w], 2 * g2 + 1, lo1, hi1);
@@ -603,7 +608,21 @@ __global__ __launch_bounds__(64, (NP <= 10 ? 4 : 2)) void hit_count_kernel(HitPa
                         st.z += (sb.y & 0xFFu) | ((sb.y & 0xFF00u) << 8);
                         st.w += ((sb.y >> 16) & 0xFFu) | ((sb.y >> 24) << 16);
                     }
-                    *reinterpret_cast<uint4 *>(out + goff) = st;
+                    if (kPacked) {
+                        uint2 lo8;  // the low bytes of the eight counts, in reference order
+                        lo8.x = __builtin_amdgcn_perm(st.y, st.x, 0x06040200u);
+                        lo8.y = __builtin_amdgcn_perm(st.w, st.z, 0x06040200u);
+                        *reinterpret_cast<uint2 *>(out_lo + goff) = lo8;
+                        // high bytes (0..3 each) -> 2 bits per reference: byte j moves to bit 2j
+                        const uint32_t hb0 = __builtin_amdgcn_perm(st.y, st.x, 0x07050301u), hb1 = __builtin_amdgcn_perm(st.w, st.z, 0x07050301u);
+                        const uint32_t h0 = (hb0 | (hb0 >> 6) | (hb0 >> 12) | (hb0 >> 18)) & 0xFFu;
+                        const uint32_t h1 = (hb1 | (hb1 >> 6) | (hb1 >> 12) | (hb1 >> 18)) & 0xFFu;
+                        const uint32_t h16 = h0 | (h1 << 8);
+                        const int gi = w * 4 + g2;
+                        hiw[gi >> 1] |= h16 << ((gi & 1) * 16);
+                    } else {
+                        *reinterpret_cast<uint4 *>(out + goff) = st;
+                    }
                     const uint64_t rbase = ref0 + goff;
                     const uint32_t nvalid = rbase >= p.n_refs ? 0u : (p.n_refs - rbase < 8u ? (uint32_t)(p.n_refs - rbase) : 8u);
                     const uint32_t cw[4] = {st.x, st.y, st.z, st.w};
@@ -616,6 +635,23 @@ __global__ __launch_bounds__(64, (NP <= 10 ? 4 : 2)) void hit_count_kernel(HitPa
             }
         }
     }
+    if (kPacked) {
+        // The high-bit words leave in chunk order (u16 index g * L + lane within the tile): transposed through the
+        // byte-counter region of LDS (free now) so that every lane stores 32 contiguous bytes.
+        __syncthreads();
+        uint16_t *tr = reinterpret_cast<uint16_t *>(cnt8);
+        if (active) {
+#pragma unroll
+            for (int gi = 0; gi < 16; gi++) tr[(uint32_t)gi * L + lane] = (uint16_t)(hiw[gi >> 1] >> ((gi & 1) * 16));
+        }
+        __syncthreads();
+        if (active) {
+            const uint4 a = reinterpret_cast<const uint4 *>(tr)[lane * 2u], b = reinterpret_cast<const uint4 *>(tr)[lane * 2u + 1u];
+            uint4 *dst = reinterpret_cast<uint4 *>(p.counts_hi + (size_t)q * (p.npad >> 3) + (size_t)tile * 1024u + lane * 16u);
+            dst[0] = a;
+            dst[1] = b;
+        }
+    }
     __syncthreads();
     // every lane of the wave flushes (also those whose columns lie beyond the row)
     uint32_t *hist = p.hist + (size_t)q * p.hstride;
@@ -625,9 +661,10 @@ __global__ __launch_bounds__(64, (NP <= 10 ? 4 : 2)) void hit_count_kernel(HitPa
     }
 }
 
-template __global__ void hit_count_kernel<10>(HitParams);
-template __global__ void hit_count_kernel<12>(HitParams);
-template __global__ void hit_count_kernel<16>(HitParams);
+template __global__ void hit_count_kernel<10, true>(HitParams);
+template __global__ void hit_count_kernel<10, false>(HitParams);
+template __global__ void hit_count_kernel<12, false>(HitParams);
+template __global__ void hit_count_kernel<16, false>(HitParams);
 
 // ---------------------------------------------------------------------------
 // prob_table (src/prob.rs:8-103): one workgroup of kProbWaves waves per query.
@@ -1074,7 +1111,7 @@ __device__ __forceinline__ uint4 load_counts8(const uint16_t *p) {
     return make_uint4(v.x, v.y, v.z, v.w);
 }
 
-template <int NW, bool TZ_LDS>
+template <int NW, bool TZ_LDS, bool PACKED>
 __global__ __launch_bounds__(NW * 64) void taxon_prefix_kernel(PrefixParams p) {
     extern __shared__ double tz_lds[];
     __shared__ double wsum[2][NW];  // double-buffered: one barrier per sweep
@@ -1091,31 +1128,42 @@ __global__ __launch_bounds__(NW * 64) void taxon_prefix_kernel(PrefixParams p) {
         for (uint32_t m = tid; m < t1; m += NW * 64) tz_lds[m] = tzg[m];
         __syncthreads();
     }
-    const uint16_t *__restrict__ cnt = p.counts + (size_t)q * p.npad;
+    // counts of this query: u16 per reference, or packed (low byte per reference + 2 high bits x 8 references per u16)
+    const uint16_t *__restrict__ cnt = PACKED ? nullptr : p.counts + (size_t)q * p.npad;
+    const uint8_t *__restrict__ cnt_lo = PACKED ? p.counts_lo + (size_t)q * p.npad : nullptr;
+    const uint16_t *__restrict__ cnt_hi = PACKED ? p.counts_hi + (size_t)q * (p.npad >> 3) : nullptr;
     if (tid == 0) P[0] = 0.0;
     double carry = 0.0;
     const uint32_t n = (uint32_t)p.n_refs;  // references of this handle (< 2^32)
     constexpr uint32_t kSweep = NW * 512;
     // Counts, boundary flags and boundary ranks of the next sweep are requested before the current one is scanned (the
-    // sweeps are a serial chain through `carry`).  The three loads are UNCONDITIONAL (clamped addresses, values
+    // sweeps are a serial chain through `carry`).  The loads are UNCONDITIONAL (clamped addresses, values
     // masked afterwards) and nothing else is loaded inside the loop: gfx9 counts loads and stores in one in-order
     // counter, and only with a fixed number of younger operations can the wait for this sweep's data leave the
     // next sweep's loads (and this sweep's boundary stores) in flight -- with predicated loads or a rank look-up
     // behind the scan every sweep waited for everything (vmcnt(0)) and exposed a full HBM round trip.
     const uint32_t last_chunk = (n - 1u) >> 3;  // n >= 1: every query slot of an index holds references
     uint4 cv_l;             // raw values of the chunk requested last (clamped address) ...
-    uint32_t bits_l, rank_l;
+    uint32_t hi_l = 0, bits_l, rank_l;
     auto request = [&](uint32_t r) {
         const uint32_t ch = r >> 3 < last_chunk ? r >> 3 : last_chunk;  // a valid chunk (counts rows are padded to 8)
-        cv_l = load_counts8(cnt + (size_t)ch * 8u);
+        if (PACKED) {
+            typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+            const u32x2 v = __builtin_nontemporal_load(reinterpret_cast<const u32x2 *>(cnt_lo + (size_t)ch * 8u));
+            cv_l = make_uint4(v.x, v.y, 0u, 0u);
+            hi_l = __builtin_nontemporal_load(cnt_hi + ch);
+        } else {
+            cv_l = load_counts8(cnt + (size_t)ch * 8u);
+        }
         bits_l = p.bnd_bits[ch];
         rank_l = p.bnd_rank[ch];
     };
     uint4 cv_next;          // ... and what they mean once masked
-    uint32_t bits_next, rank_next;
+    uint32_t hi_next = 0, bits_next, rank_next;
     auto accept = [&](uint32_t r) {
         const bool in = r < n;
         cv_next = in ? cv_l : make_uint4(0, 0, 0, 0);  // past the end: count 0 (a valid table index, masked below), no boundary
+        hi_next = in ? hi_l : 0u;
         bits_next = in ? bits_l : 0u;
         rank_next = rank_l;
     };
@@ -1125,13 +1173,16 @@ __global__ __launch_bounds__(NW * 64) void taxon_prefix_kernel(PrefixParams p) {
     for (uint32_t base = 0; base < n; base += kSweep, buf ^= 1u) {
         const uint32_t r0 = base + tid * 8u;
         const uint4 cv = cv_next;
+        const uint32_t hi_cur = hi_next;
         const uint32_t bits_cur = bits_next, rank_cur = rank_next;
         request(r0 + kSweep);
         const uint32_t cw[4] = {cv.x, cv.y, cv.z, cv.w};
         double v[8];
 #pragma unroll
         for (int j = 0; j < 8; j++) {
-            const uint32_t c = (cw[j >> 1] >> ((j & 1) * 16)) & 0xFFFFu;  // lanes past the end hold 0: a valid index
+            uint32_t c;  // lanes past the end hold 0: a valid index
+            if (PACKED) c = ((cw[j >> 2] >> ((j & 3) * 8)) & 0xFFu) | (((hi_cur >> (2 * j)) & 3u) << 8);
+            else c = (cw[j >> 1] >> ((j & 1) * 16)) & 0xFFFFu;
             v[j] = TZ_LDS ? tz_lds[c] : tzg[c];
         }
         if (base + kSweep > n) {  // last sweep (wave-uniform): references past the end contribute nothing
@@ -1159,7 +1210,8 @@ __global__ __launch_bounds__(NW * 64) void taxon_prefix_kernel(PrefixParams p) {
         // loop of stores makes the compiler drain the memory counter in front of it -- and with it the prefetch)
         // The data of the next sweep are taken in HERE, before this sweep's stores: behind them the wait would also cover
         // the stores (their number is not known at compile time, so the compiler could not leave them in flight).
-        asm volatile("" : "+v"(cv_l.x), "+v"(cv_l.y), "+v"(cv_l.z), "+v"(cv_l.w), "+v"(bits_l), "+v"(rank_l)::"memory");
+        if (PACKED) asm volatile("" : "+v"(cv_l.x), "+v"(cv_l.y), "+v"(hi_l), "+v"(bits_l), "+v"(rank_l)::"memory");
+        else asm volatile("" : "+v"(cv_l.x), "+v"(cv_l.y), "+v"(cv_l.z), "+v"(cv_l.w), "+v"(bits_l), "+v"(rank_l)::"memory");
         const uint32_t bits = bits_cur;  // 0 for chunks past the end
 #pragma unroll
         for (int j = 0; j < 8; j++)
@@ -1174,6 +1226,12 @@ __global__ __launch_bounds__(NW * 64) void taxon_prefix_kernel(PrefixParams p) {
         __syncthreads();  // workgroup-scope release/acquire of the P stores (same CU: no cache maintenance needed)
         if (wave == 0) lineage_walk_wave(p.walk, q, lane, *reinterpret_cast<WalkLds *>(tz_lds));
     }
+}
+
+// debug taps: the packed counts of one query as u16 (rtx_debug_hit_counts, rtx_debug_probs)
+__global__ void counts_unpack_kernel(const uint8_t *lo, const uint16_t *hi, uint64_t n, uint16_t *out) {
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < n) out[r] = (uint16_t)(lo[r] | (((hi[r >> 3] >> (2u * (r & 7u))) & 3u) << 8));
 }
 
 // ---------------------------------------------------------------------------
@@ -1213,9 +1271,10 @@ void launch_hit_count(hipStream_t s, const HitParams &p_in, uint32_t nq, uint32_
     p.lds_cnt8_off = first;
     // 8.4 KB per wave: measured flat up to there, +7 % at 10.4 KB, +14 % at 12.5 KB (16 waves per CU must fit in 160 KB)
     const size_t lds = (size_t)first * sizeof(uint32_t) + 4096;  // ... | byte counters
-    if (planes <= 10) hipLaunchKernelGGL(hit_count_kernel<10>, dim3(nq, ntiles), dim3(64), lds, s, p);
-    else if (planes <= 12) hipLaunchKernelGGL(hit_count_kernel<12>, dim3(nq, ntiles), dim3(64), lds, s, p);
-    else hipLaunchKernelGGL(hit_count_kernel<16>, dim3(nq, ntiles), dim3(64), lds, s, p);
+    if (planes <= 10 && p.counts_lo) hipLaunchKernelGGL((hit_count_kernel<10, true>), dim3(nq, ntiles), dim3(64), lds, s, p);
+    else if (planes <= 10) hipLaunchKernelGGL((hit_count_kernel<10, false>), dim3(nq, ntiles), dim3(64), lds, s, p);
+    else if (planes <= 12) hipLaunchKernelGGL((hit_count_kernel<12, false>), dim3(nq, ntiles), dim3(64), lds, s, p);
+    else hipLaunchKernelGGL((hit_count_kernel<16, false>), dim3(nq, ntiles), dim3(64), lds, s, p);
 }
 size_t prob_table_lds_bytes(uint32_t tmax) {
     const size_t n1max = tmax / 2 + 1;
@@ -1229,11 +1288,16 @@ void launch_prob_table(hipStream_t s, const ProbParams &p, uint32_t nq) {
 void launch_taxon_prefix(hipStream_t s, const PrefixParams &p, uint32_t nq) {
     size_t lds = p.tz_in_lds ? (size_t)p.hstride * sizeof(double) : 0;
     if (p.fuse_walk) lds = std::max(lds, sizeof(WalkLds));
-    if (p.tz_in_lds) hipLaunchKernelGGL((taxon_prefix_kernel<4, true>), dim3(nq), dim3(256), lds, s, p);
-    else hipLaunchKernelGGL((taxon_prefix_kernel<4, false>), dim3(nq), dim3(256), lds, s, p);
+    if (p.tz_in_lds && p.packed) hipLaunchKernelGGL((taxon_prefix_kernel<4, true, true>), dim3(nq), dim3(256), lds, s, p);
+    else if (p.tz_in_lds) hipLaunchKernelGGL((taxon_prefix_kernel<4, true, false>), dim3(nq), dim3(256), lds, s, p);
+    else if (p.packed) hipLaunchKernelGGL((taxon_prefix_kernel<4, false, true>), dim3(nq), dim3(256), lds, s, p);
+    else hipLaunchKernelGGL((taxon_prefix_kernel<4, false, false>), dim3(nq), dim3(256), lds, s, p);
 }
 void launch_lineage_walk(hipStream_t s, const WalkParams &p, uint32_t nq) {
     hipLaunchKernelGGL(lineage_walk_kernel, dim3(nq), dim3(64), 0, s, p);
+}
+void launch_counts_unpack(hipStream_t s, const uint8_t *lo, const uint16_t *hi, uint64_t n, uint16_t *out) {
+    hipLaunchKernelGGL(counts_unpack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, lo, hi, n, out);
 }
 void launch_probs_expand(hipStream_t s, const uint16_t *counts, const double *tz, uint64_t n, double *out) {
     hipLaunchKernelGGL(probs_expand_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, counts, tz, n, out);

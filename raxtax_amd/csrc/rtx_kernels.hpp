@@ -79,7 +79,11 @@ struct HitParams {
     const uint16_t *segslots; // [n_slots][kSegSlotEntries] local ids of the sparse segments
     uint32_t ntiles;
     const uint32_t *t;
-    uint16_t *counts;  // [B][npad]
+    uint16_t *counts;  // [B][npad] u16 counts (more than 10 bit planes: t > 1023)
+    // 10 bit planes (t <= 1023): counts leave the kernel packed, 10 bits per reference instead of 16 --
+    // low byte per reference in reference order + the two high bits of eight references per u16 (chunk order)
+    uint8_t *counts_lo;   // [B][npad]
+    uint16_t *counts_hi;  // [B][npad / 8]
     uint64_t npad;
     uint32_t *hist;  // [B][hstride]
     uint32_t hstride;
@@ -138,7 +142,10 @@ struct PrefixParams {
     const uint32_t *t;     // [B] distinct k-mers per slot (size of the table copy)
     uint32_t tz_in_lds;    // copy table/Z to LDS first (hstride * 8 bytes must fit)
     uint64_t q0;
-    const uint16_t *counts;
+    const uint16_t *counts;      // u16 format (packed == 0)
+    const uint8_t *counts_lo;    // packed format (hit_count with 10 bit planes): low bytes ...
+    const uint16_t *counts_hi;   // ... and 2 high bits x 8 references per u16
+    uint32_t packed;
     uint64_t npad;
     const double *table_z;
     uint32_t hstride;
@@ -180,5 +187,6 @@ int cluster_sort(hipStream_t s, void *tmp, size_t *tmp_bytes, const uint64_t *ke
 void launch_taxon_prefix(hipStream_t s, const PrefixParams &p, uint32_t nq);
 void launch_lineage_walk(hipStream_t s, const WalkParams &p, uint32_t nq);
 void launch_probs_expand(hipStream_t s, const uint16_t *counts, const double *tz, uint64_t n, double *out);
+void launch_counts_unpack(hipStream_t s, const uint8_t *lo, const uint16_t *hi, uint64_t n, uint16_t *out);
 
 }  // namespace rtx

@@ -318,6 +318,28 @@ def test_processing_order_does_not_change_results(world):
         assert np.array_equal(ix.debug_kmers(q), plain.debug_kmers(q))
 
 
+def test_packed_counts_equal_u16_counts(world, oracle):
+    """RTX_OPT_PACKED_COUNTS: with t <= 1023 the counts travel from hit_count to taxon_prefix as 10 bits per reference
+    (low byte + two high bits); every result array and the debug taps equal those of the u16 format, also for counts
+    above 255 (exact copies reach t ~ 640) and through sparse segments, the partial last tile and --skip-exact-matches."""
+    w = world
+    ex_ids, ex_off = w["index"].exact_matches(w["bases"], w["off"])
+    a, b = rx.Index(w["tree"], packed_counts=True), rx.Index(w["tree"], packed_counts=False)
+    for skip in (False, True):
+        ra = a.classify(w["bases"], w["off"], ex_ids, ex_off, skip_exact_matches=skip)
+        rb = b.classify(w["bases"], w["off"], ex_ids, ex_off, skip_exact_matches=skip)
+        for f in ("row_off", "row_lineage", "row_conf", "row_local_signal", "global_signal", "t", "status"):
+            assert np.array_equal(getattr(ra, f), getattr(rb, f)), (skip, f)
+        big = 0
+        for q in range(0, len(w["seqs"]), 3):
+            ca, cb = a.debug_hit_counts(q), b.debug_hit_counts(q)
+            assert np.array_equal(ca, cb), (skip, q)
+            assert np.array_equal(ca, w["otree"].hit_counts(w["seqs"][q], skip_exact=skip)[1])
+            big += int(ca.max()) > 255
+            assert np.array_equal(a.debug_probs(q), b.debug_probs(q))
+        assert big > 5       # the high bits were exercised
+
+
 def test_work_accounting_matches_oracle(world):
     """sum_hits = sum_q H_q = sum_q sum_r count_q[r], measured by the device."""
     w = world

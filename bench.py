@@ -64,6 +64,7 @@ def parse():
     ap.add_argument("--streams", type=int, default=0, help="HIP streams per handle (0 = library default)")
     ap.add_argument("--no-cluster", action="store_true", help="process the queries in input order (RTX_OPT_CLUSTER = 0)")
     ap.add_argument("--u16-counts", action="store_true", help="counts travel as u16 instead of packed 10 bits (RTX_OPT_PACKED_COUNTS = 0)")
+    ap.add_argument("--no-quad", action="store_true", help="hit_count with one wave per (query, tile) (RTX_OPT_HIT_QUAD = 0)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--skip-exact-matches", action="store_true")
     ap.add_argument("--hit-events-only", action="store_true",
@@ -119,6 +120,25 @@ def self_launch(args) -> int:
 # ------------------------------------------------------------------------------------------------------------
 # CPU baseline
 # ------------------------------------------------------------------------------------------------------------
+def available_parallelism() -> int:
+    """Threads the reference would start by default (rayon -> std::thread::available_parallelism): the CPUs of the
+    affinity mask, capped by the cgroup CPU quota (cpu.max of cgroup v2, cfs_quota_us / cfs_period_us of v1)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = Path("/sys/fs/cgroup/cpu.max").read_text().split()
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        try:
+            quota = int(Path("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read_text())
+            period = int(Path("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read_text())
+            if quota > 0:
+                n = min(n, max(1, quota // period))
+        except (OSError, ValueError):
+            pass
+    return max(1, n)
+
+
 def cpu_model() -> str:
     try:
         for line in Path("/proc/cpuinfo").read_text().splitlines():
@@ -138,7 +158,7 @@ def cpu_baseline(db, qs, target_s: float, skip_exact: bool):
     threads idle in the last wave and understate the rate the reference reaches on a full batch."""
     from oracle.oracle_py import Oracle
 
-    T = os.cpu_count() or 1
+    T = available_parallelism()
     orc = Oracle(native=True)
     t0 = time.perf_counter()
     otree = orc.tree_new_flat(db.lineages, db.seq_bytes, db.seq_off)
@@ -167,9 +187,11 @@ def cpu_baseline(db, qs, target_s: float, skip_exact: bool):
         return dict(value=n / dt, cores=threads, queries=n, seconds=dt)
 
     every = leg(T)
-    phys = orc.physical_core_ids()
-    pinned = leg(len(phys), phys) if 1 < len(phys) < T else (dict(every, note="every hardware thread is a core of its own") if len(phys) >= T else None)
+    phys = orc.physical_core_ids()[:T]          # --pin: thread i on the i-th physical core (utils.rs:139-158)
+    pinned = leg(len(phys), phys) if len(phys) > 1 else None
     out = {"value": every["value"], "unit": "queries/s", "cores": T, "kind": "port", "cpu_model": cpu_model(),
+           "host_cpus": {"logical": os.cpu_count(), "usable": T,
+                         "note": "usable = what std::thread::available_parallelism gives the reference here: affinity mask capped by the cgroup CPU quota"},
            "sample": f"first {every['queries']} queries of the same workload on {T} threads in {every['seconds']:.1f} s "
                      f"({every['queries'] // max(100 * T, 1)} full chunk(s) of 100 per thread, chunking as src/main.rs:119-124), "
                      f"no string formatting; oracle Tree::new {t_tree:.1f} s (untimed)",
@@ -177,9 +199,8 @@ def cpu_baseline(db, qs, target_s: float, skip_exact: bool):
            "one_thread": {"value": rate1, "queries": n1, "seconds": round(dt1, 2)},
            "note": "the Rust reference itself cannot be built here (no cargo/rustc): this is the C port (oracle/oracle.c)"}
     if pinned is not None:
-        out["pinned_physical_cores"] = {"value": pinned["value"], "cores": len(phys) if len(phys) < T else T,
-                                        "queries": pinned["queries"], "seconds": round(pinned["seconds"], 2),
-                                        "per_thread": pinned["value"] / max(1, min(len(phys), T))}
+        out["pinned_physical_cores"] = {"value": pinned["value"], "cores": len(phys), "queries": pinned["queries"],
+                                        "seconds": round(pinned["seconds"], 2), "per_thread": pinned["value"] / len(phys)}
     return out
 
 
@@ -342,7 +363,7 @@ def main():
         tree = rx.Tree.new_flat(db.lineages, db.seq_bytes, db.seq_off, kmer_map=False)   # bitmaps built on the GPU
         index = rx.Index(tree, device=local_rank, sub_batch=args.sub_batch, streams=args.streams,
                          stage_timing=not args.hit_events_only, cluster=False if args.no_cluster else None,
-                         packed_counts=False if args.u16_counts else None)
+                         packed_counts=False if args.u16_counts else None, hit_quad=False if args.no_quad else None)
         t0 = time.perf_counter()
         ex_ids, ex_off = index.exact_matches(qs.bases, qs.base_off)   # Tree.sequences.get, raxtax.rs:42 (host)
         t_exact = time.perf_counter() - t0

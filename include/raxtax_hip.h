@@ -189,6 +189,9 @@ int rtx_index_set_batch(rtx_index *index, uint32_t sub_batch);
 #define RTX_OPT_CLUSTER 7 /* 1 (default): the queries of a batch are processed in an order that puts related
                              queries next to each other (min-hash sketches, rtx_cluster.hip) so that bitmap rows
                              are reused; 0: input order.  Results are identical and always in input order. */
+#define RTX_OPT_HIT_QUAD 9 /* 1 (default): with t <= 1023 and RTX_OPT_CLUSTER on, hit_count runs four neighbouring queries per
+                           * workgroup and loads every bitmap row they need once, through LDS (rtx_hit_quad.hip); 0: one wave
+                           * per (query, tile) fetching its own rows (A/B measurements, and what longer queries always use) */
 #define RTX_OPT_PACKED_COUNTS 8 /* 1 (default): with t <= 1023 the hit counts travel from hit_count to taxon_prefix
                                  * packed, 10 bits per reference (low byte + 2 high bits); 0: as u16 (A/B measurements) */
 int rtx_index_set_option(rtx_index *index, int option, uint64_t value);

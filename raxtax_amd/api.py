@@ -214,7 +214,7 @@ class Index:
 
     def __init__(self, tree: Tree, device: int = 0, sub_batch: int = 0, prob_mode: int = 0, streams: int = 0,
                  stage_timing: bool = False, cluster: Optional[bool] = None, segment_classes: bool = True,
-                 packed_counts: Optional[bool] = None):
+                 packed_counts: Optional[bool] = None, hit_quad: Optional[bool] = None):
         self._lib = _lib.load()
         self.tree = tree
         check(self._lib.rtx_set_default_option(1, int(segment_classes)))   # creation-time default of the library
@@ -234,6 +234,8 @@ class Index:
             check(self._lib.rtx_index_set_option(self._h, 7, int(cluster)))
         if packed_counts is not None:
             check(self._lib.rtx_index_set_option(self._h, 8, int(packed_counts)))
+        if hit_quad is not None:
+            check(self._lib.rtx_index_set_option(self._h, 9, int(hit_quad)))
         self._view = ResultView()
         self._keep = None
 

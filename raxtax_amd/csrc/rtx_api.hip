@@ -157,6 +157,10 @@ struct rtx_index {
     // ---- processing order of the batch (rtx_cluster.hip): perm[position] = query, inv[query] = position
     uint32_t cluster = 1;  // RTX_OPT_CLUSTER
     uint32_t packed_opt = 1;  // RTX_OPT_PACKED_COUNTS
+    uint32_t quad_opt = 0;    // RTX_OPT_HIT_QUAD (off until verified on the GPU)
+    bool quad_used = false;   // the last run went through hit_count_quad_kernel
+    DevBuf<uint32_t> d_group_rows;
+    uint32_t groups_per_sub = 0;
     bool packed() const { return packed_opt && planes <= 10; }
     DevBuf<uint64_t> d_skey_in, d_skey_out;
     DevBuf<uint32_t> d_sidx, d_perm, d_iperm;
@@ -355,8 +359,12 @@ int enqueue_hit(rtx_index *ix, const SubBatch &b, uint32_t flags, hipStream_t s)
     hp.perm = ix->d_perm.p;
     hp.exact_ids = ix->d_exact_ids.p;
     hp.exact_off = ix->d_exact_off.p;
+    hp.nq = b.nq;
+    hp.group_rows = ix->quad_used ? ix->d_group_rows.p : nullptr;
+    hp.group_base = b.sb * ix->groups_per_sub;
     if (b.timed) RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_HIT_COUNT, 0), s));
-    launch_hit_count(s, hp, b.nq, ix->ntiles, ix->planes);
+    if (ix->quad_used) launch_hit_count_quad(s, hp, b.nq, ix->ntiles);
+    else launch_hit_count(s, hp, b.nq, ix->ntiles, ix->planes);
     if (b.timed) RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_HIT_COUNT, 1), s));
     return RTX_OK;
 }
@@ -484,6 +492,14 @@ int begin_run(rtx_index *ix, uint32_t *n_sub_out, bool *timed_out, bool cluster)
     RTX_HIP(hipMemsetAsync(ix->d_cursor.p, 0, sizeof(unsigned long long), ix->stream));
     RTX_HIP(hipMemsetAsync(ix->d_flags.p, 0, sizeof(uint32_t), ix->stream));
     const uint32_t n_sub = (uint32_t)((ix->n_q + ix->sub_batch - 1) / ix->sub_batch);
+    // four neighbours per workgroup only pays when neighbours are related: with the processing order on
+    ix->quad_used = ix->quad_opt && cluster && ix->planes <= 10 && ix->n_q > 2;
+    ix->groups_per_sub = (ix->sub_batch + 3u) / 4u;
+    if (ix->quad_used) {
+        int rc_g = ix->d_group_rows.alloc((size_t)n_sub * ix->groups_per_sub);
+        if (rc_g) return rc_g;
+        RTX_HIP(hipMemsetAsync(ix->d_group_rows.p, 0, (size_t)n_sub * ix->groups_per_sub * 4, ix->stream));
+    }
     const bool timed = n_sub <= 4096;
     if (timed) {
         int rc = ensure_events(ix, (size_t)n_sub * RTX_NUM_STAGES * 2);
@@ -1135,6 +1151,9 @@ int rtx_index_set_option(rtx_index *index, int option, uint64_t value) {
         case RTX_OPT_PACKED_COUNTS:
             index->packed_opt = value ? 1u : 0u;
             return RTX_OK;
+        case RTX_OPT_HIT_QUAD:
+            index->quad_opt = value ? 1u : 0u;
+            return RTX_OK;
         case RTX_OPT_PROB_MODE:
             if (value > 2) break;
             index->prob_mode = (int)value;
@@ -1475,6 +1494,13 @@ int rtx_batch_work(rtx_index *ix, uint64_t *sum_hits, uint64_t *sum_query_bytes,
     for (uint64_t q = 0; q < ix->n_q; q++) {
         h += ix->h_hq[q];
         b += (uint64_t)ix->h_nrows_all[q] * row_bytes;
+    }
+    if (ix->quad_used) {  // rows were loaded once per group of four queries: the union rows every workgroup counted
+        const uint32_t n_sub = (uint32_t)((ix->n_q + ix->sub_batch - 1) / ix->sub_batch);
+        std::vector<uint32_t> gr((size_t)n_sub * ix->groups_per_sub);
+        RTX_HIP(hipMemcpy(gr.data(), ix->d_group_rows.p, gr.size() * 4, hipMemcpyDeviceToHost));
+        b = 0;
+        for (uint32_t v : gr) b += (uint64_t)v * row_bytes;
     }
     if (sum_hits) *sum_hits = h;
     if (sum_query_bytes) *sum_query_bytes = ix->sum_query_bytes;

@@ -1,0 +1,223 @@
+// Pieces shared by the two hit_count kernels (rtx_kernels.hip: one wave per (query, tile); rtx_hit_quad.hip: a
+// workgroup of four neighbouring queries per tile that loads every bitmap row it needs once, through LDS).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "rtx_kernels.hpp"
+#include "rtx_math.hpp"
+#include "rtx_wave.hpp"
+
+namespace rtx {
+
+// Orders the LDS traffic of ONE wave (some lanes write, others read): the hardware keeps the LDS operations of a
+// wave in order, this only stops the compiler from moving them.  No s_barrier: the epilogue below works on LDS that
+// belongs to one wave, whatever the other waves of its workgroup are doing.
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+
+// Eight row segments through raw buffer loads.  The row ids are wave-uniform (lanes O .. O+7 of a VGPR, taken out
+// with v_readlane), so the 64-bit row base lives in SGPRs (buffer descriptor rebuilt per row with scalar ops) and
+// the only vector operand is the 32-bit column offset: `buffer_load_dwordx4 v, v_col, s[desc], 0 offen`, no address
+// VALU.  num_records = bytes per row, so lanes whose columns lie beyond the row read zeros.
+template <int O>
+__device__ __forceinline__ void load8v(uint4 (&buf)[8], const char *__restrict__ bitmap, uint32_t col, uint32_t stride, uint32_t idv) {
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const uint32_t row = (uint32_t)__builtin_amdgcn_readlane((int)idv, O + j);
+        const char *rowbase = bitmap + (size_t)row * stride;
+        const __amdgpu_buffer_rsrc_t rsrc =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(rowbase), 0, stride, 0x00027000);
+        const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, col, 0, 0);
+        buf[j] = make_uint4(v.x, v.y, v.z, v.w);
+    }
+}
+
+// carry of weight 8 of eight 16-byte row segments, per 32-reference word
+template <int NP>
+__device__ __forceinline__ uint4 tree8(uint32_t (&pl)[4][NP], const uint4 (&a)[8]) {
+    uint4 e;
+    e.x = planes_tree8<NP>(pl[0], a[0].x, a[1].x, a[2].x, a[3].x, a[4].x, a[5].x, a[6].x, a[7].x);
+    e.y = planes_tree8<NP>(pl[1], a[0].y, a[1].y, a[2].y, a[3].y, a[4].y, a[5].y, a[6].y, a[7].y);
+    e.z = planes_tree8<NP>(pl[2], a[0].z, a[1].z, a[2].z, a[3].z, a[4].z, a[5].z, a[6].z, a[7].z);
+    e.w = planes_tree8<NP>(pl[3], a[0].w, a[1].w, a[2].w, a[3].w, a[4].w, a[5].w, a[6].w, a[7].w);
+    return e;
+}
+
+template <int NP, int P>
+__device__ __forceinline__ uint4 csa_plane(uint32_t (&pl)[4][NP], const uint4 &a, const uint4 &b) {
+    uint4 c;
+    csa(pl[0][P], a.x, b.x, pl[0][P], c.x);
+    csa(pl[1][P], a.y, b.y, pl[1][P], c.y);
+    csa(pl[2][P], a.z, b.z, pl[2][P], c.z);
+    csa(pl[3][P], a.w, b.w, pl[3][P], c.w);
+    return c;
+}
+
+
+// ---------------------------------------------------------------------------
+// Epilogue of a (query, tile) wave: the bit planes `pl` hold the hits through dense segments.  Zeroes exact matches
+// (raxtax.rs:65-68), unpacks the planes, adds the hits through sparse segments (byte counters in LDS, half a tile at
+// a time), stores the counts (u16, or packed 10 bits per reference), builds the histogram of prob.rs:13-19 with LDS
+// atomics and flushes it with one global atomic per non-empty bin.
+//   hist_lds: [t + 1] u32 of this wave; cnt8: [1024] u32 (4096 byte counters) of this wave.
+// ---------------------------------------------------------------------------
+template <int NP, bool kPacked>
+__device__ __forceinline__ void hit_epilogue(const HitParams &p, uint32_t (&pl)[4][NP], uint32_t q, uint32_t tile, uint32_t lane,
+                                             uint32_t t, bool active, uint32_t *hist_lds, uint32_t *cnt8, uint32_t ns,
+                                             const uint32_t *srows) {
+    // hits of the sparse segments on the references [half*4096, half*4096 + 4096) of the tile -> cnt8 (at most 255 each)
+    auto sparse_hits = [&](uint32_t half) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) reinterpret_cast<uint4 *>(cnt8)[i * 64 + lane] = make_uint4(0, 0, 0, 0);
+        wave_lds_sync();
+        for (uint32_t c0 = 0; c0 < ns; c0 += 64) {
+            constexpr int kV = kSegSlotEntries / 8;  // uint4 per slot
+            uint4 e[kV];
+#pragma unroll
+            for (int i = 0; i < kV; i++) e[i] = make_uint4(~0u, ~0u, ~0u, ~0u);
+            if (c0 + lane < ns) {
+                const uint4 *slot = reinterpret_cast<const uint4 *>(p.segslots + (size_t)srows[c0 + lane] * kSegSlotEntries);
+#pragma unroll
+                for (int i = 0; i < kV; i++) e[i] = slot[i];
+            }
+#pragma unroll
+            for (int i = 0; i < kV; i++) {
+                const uint32_t wv[4] = {e[i].x, e[i].y, e[i].z, e[i].w};
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const uint32_t id = (wv[j >> 1] >> ((j & 1) * 16)) & 0xFFFFu;  // 0xFFFF = unused entry
+                    if ((id >> 12) == half) atomicAdd(&cnt8[(id & 4095u) >> 2], 1u << ((id & 3u) * 8u));
+                }
+            }
+        }
+        wave_lds_sync();
+    };
+
+    for (uint32_t i = lane; i <= t; i += 64) hist_lds[i] = 0;
+    wave_lds_sync();
+
+    const uint32_t L = tile_lanes(p.stride_bytes, tile);  // lanes of this tile (64 except in the last one)
+    if (active && (p.flags & RTX_SKIP_EXACT_MATCHES)) {  // raxtax.rs:65-68: the dense part
+        const uint64_t qin = p.perm[p.q0 + q];
+        const uint64_t e0 = p.exact_off[qin], e1 = p.exact_off[qin + 1];
+        for (uint64_t e = e0; e < e1; e++) {
+            const uint32_t id = p.exact_ids[e] - p.ref_base;  // local id; other shards' ids wrap out of range
+            if (id < p.n_refs && (id >> 13) == tile) {
+                const uint32_t c = (id & 8191u) >> 3, g = c / L;
+                if (c - g * L == lane) {
+                    const uint32_t w = g >> 2, msk = ~(1u << ((g & 3u) * 8u + (id & 7u)));
+#pragma unroll
+                    for (int ww = 0; ww < 4; ww++)
+                        if ((uint32_t)ww == w) {
+#pragma unroll
+                            for (int b = 0; b < NP; b++) pl[ww][b] &= msk;
+                        }
+                }
+            }
+        }
+    }
+    // group g = (w, g2) of this lane: references ref0 + g*L*8 + [0, 8) (ref_slot, rtx_math.hpp)
+    const uint64_t ref0 = (uint64_t)tile * 8192u + lane * 8u;
+    static_assert(!kPacked || NP <= 10, "the packed format holds counts up to 1023");  // 10 bits per reference leave the kernel instead of 16
+    uint16_t *out = p.counts + (size_t)q * p.npad + ref0;
+    uint8_t *out_lo = p.counts_lo + (size_t)q * p.npad + ref0;
+    uint32_t hiw[8];  // packed format: the two high bits of the 8 references of group g in bits 16 (g & 1) + [0, 16) of hiw[g / 2]
+#pragma unroll
+    for (int i = 0; i < 8; i++) hiw[i] = 0;
+#pragma unroll
+    for (int half = 0; half < 2; half++) {  // groups 0-7 = references 0..4095 of a full tile, groups 8-15 = 4096..8191
+        if (ns) {
+            sparse_hits((uint32_t)half);
+            if (p.flags & RTX_SKIP_EXACT_MATCHES) {  // raxtax.rs:65-68: the sparse part
+                const uint64_t qin = p.perm[p.q0 + q];
+                const uint64_t e0 = p.exact_off[qin], e1 = p.exact_off[qin + 1];
+                for (uint64_t e = e0 + lane; e < e1; e += 64) {
+                    const uint32_t id = p.exact_ids[e] - p.ref_base;
+                    if (id < p.n_refs && (id >> 13) == tile && ((id >> 12) & 1u) == (uint32_t)half)
+                        reinterpret_cast<uint8_t *>(cnt8)[id & 4095u] = 0;
+                }
+                wave_lds_sync();
+            }
+        }
+        if (active) {
+#pragma unroll
+            for (int wi = 0; wi < 2; wi++) {
+                const int w = half * 2 + wi;
+#pragma unroll
+                for (int g2 = 0; g2 < 4; g2++) {  // 8 references per store, contiguous across lanes
+                    uint32_t lo0, hi0, lo1, hi1;
+                    planes_unpack4<NP>(pl[w], 2 * g2, lo0, hi0);
+                    planes_unpack4<NP>(pl[w], 2 * g2 + 1, lo1, hi1);
+                    uint4 st;
+                    // bytes (lo.b0, hi.b0, lo.b1, hi.b1) -> two u16 counts
+                    st.x = __builtin_amdgcn_perm(hi0, lo0, 0x05010400u);
+                    st.y = __builtin_amdgcn_perm(hi0, lo0, 0x07030602u);
+                    st.z = __builtin_amdgcn_perm(hi1, lo1, 0x05010400u);
+                    st.w = __builtin_amdgcn_perm(hi1, lo1, 0x07030602u);
+                    const uint32_t goff = (uint32_t)(w * 4 + g2) * L * 8u;
+                    if (ns) {  // + hits through sparse segments (L = 64 here): bytes of the eight references of this group
+                        const uint2 sb = *reinterpret_cast<const uint2 *>(cnt8 + (((uint32_t)(wi * 4 + g2) * 64u + lane) * 2u));
+                        st.x += (sb.x & 0xFFu) | ((sb.x & 0xFF00u) << 8);
+                        st.y += ((sb.x >> 16) & 0xFFu) | ((sb.x >> 24) << 16);
+                        st.z += (sb.y & 0xFFu) | ((sb.y & 0xFF00u) << 8);
+                        st.w += ((sb.y >> 16) & 0xFFu) | ((sb.y >> 24) << 16);
+                    }
+                    if (kPacked) {
+                        uint2 lo8;  // the low bytes of the eight counts, in reference order
+                        lo8.x = __builtin_amdgcn_perm(st.y, st.x, 0x06040200u);
+                        lo8.y = __builtin_amdgcn_perm(st.w, st.z, 0x06040200u);
+                        *reinterpret_cast<uint2 *>(out_lo + goff) = lo8;
+                        // high bytes (0..3 each) -> 2 bits per reference: byte j moves to bit 2j
+                        const uint32_t hb0 = __builtin_amdgcn_perm(st.y, st.x, 0x07050301u), hb1 = __builtin_amdgcn_perm(st.w, st.z, 0x07050301u);
+                        const uint32_t h0 = (hb0 | (hb0 >> 6) | (hb0 >> 12) | (hb0 >> 18)) & 0xFFu;
+                        const uint32_t h1 = (hb1 | (hb1 >> 6) | (hb1 >> 12) | (hb1 >> 18)) & 0xFFu;
+                        const uint32_t h16 = h0 | (h1 << 8);
+                        const int gi = w * 4 + g2;
+                        hiw[gi >> 1] |= h16 << ((gi & 1) * 16);
+                    } else {
+                        *reinterpret_cast<uint4 *>(out + goff) = st;
+                    }
+                    const uint64_t rbase = ref0 + goff;
+                    const uint32_t nvalid = rbase >= p.n_refs ? 0u : (p.n_refs - rbase < 8u ? (uint32_t)(p.n_refs - rbase) : 8u);
+                    const uint32_t cw[4] = {st.x, st.y, st.z, st.w};
+#pragma unroll
+                    for (int j = 0; j < 8; j++) {
+                        const uint32_t c = (cw[j >> 1] >> ((j & 1) * 16)) & 0xFFFFu;
+                        if ((uint32_t)j < nvalid) atomicAdd(&hist_lds[c], 1u);
+                    }
+                }
+            }
+        }
+    }
+    if (kPacked) {
+        // The high-bit words leave in chunk order (u16 index g * L + lane within the tile): transposed through the
+        // byte-counter region of LDS (free now) so that every lane stores 32 contiguous bytes.
+        wave_lds_sync();
+        uint16_t *tr = reinterpret_cast<uint16_t *>(cnt8);
+        if (active) {
+#pragma unroll
+            for (int gi = 0; gi < 16; gi++) tr[(uint32_t)gi * L + lane] = (uint16_t)(hiw[gi >> 1] >> ((gi & 1) * 16));
+        }
+        wave_lds_sync();
+        if (active) {
+            const uint4 a = reinterpret_cast<const uint4 *>(tr)[lane * 2u], b = reinterpret_cast<const uint4 *>(tr)[lane * 2u + 1u];
+            uint4 *dst = reinterpret_cast<uint4 *>(p.counts_hi + (size_t)q * (p.npad >> 3) + (size_t)tile * 1024u + lane * 16u);
+            dst[0] = a;
+            dst[1] = b;
+        }
+    }
+    wave_lds_sync();
+    // every lane of the wave flushes (also those whose columns lie beyond the row)
+    uint32_t *hist = p.hist + (size_t)q * p.hstride;
+    for (uint32_t m = lane; m <= t; m += 64) {
+        const uint32_t v = hist_lds[m];
+        if (v) atomicAdd(&hist[m], v);
+    }
+}
+
+}  // namespace rtx

@@ -92,6 +92,10 @@ struct HitParams {
     const uint32_t *perm;       // [n_q] query at every position: exact_off is indexed by query
     const uint32_t *exact_ids;
     const uint64_t *exact_off;
+    // hit_count_quad_kernel (rtx_hit_quad.hip): four consecutive slots per workgroup
+    uint32_t nq;           // slots of the sub-batch
+    uint32_t *group_rows;  // [groups of the batch] union rows loaded per group, summed over the tiles (work accounting) or null
+    uint32_t group_base;   // index of the sub-batch's first group in group_rows
 };
 
 // memoised cmf / pmf-ratio tables for every (t, m, i), t <= tmax (rtx_prob_tables.hip)
@@ -168,6 +172,7 @@ void launch_row_popcount(hipStream_t s, const uint32_t *row_of, const uint32_t *
                          uint32_t *list_len);
 void launch_kmer_extract(hipStream_t s, const KmerParams &p, uint32_t nq);
 void launch_hit_count(hipStream_t s, const HitParams &p, uint32_t nq, uint32_t ntiles, int planes);
+void launch_hit_count_quad(hipStream_t s, const HitParams &p, uint32_t nq, uint32_t ntiles);  // 10 bit planes only
 size_t prob_table_lds_bytes(uint32_t tmax);
 void launch_prob_table(hipStream_t s, const ProbParams &p, uint32_t nq);
 size_t prob_lookup_lds_bytes(uint32_t tmax);

@@ -8,7 +8,9 @@ from pathlib import Path
 import numpy as np
 
 PKG = Path(__file__).resolve().parent
-LIB_PATH = PKG / "libraxtax_hip.so"
+import os as _os
+
+LIB_PATH = Path(_os.environ.get("RTX_LIB_PATH") or PKG / "libraxtax_hip.so")   # RTX_LIB_PATH: an experimental build (tools/)
 
 RTX_MAX_DEPTH = 32
 RTX_NUM_KMERS = 65536

@@ -25,15 +25,26 @@
 
 namespace rtx {
 
-constexpr uint32_t kQuadRR = 8;                             // union rows per round: two loads per wave and round
-constexpr uint32_t kQuadAhead = 3;                          // rounds in flight behind the one being folded
+#ifndef RTX_QUAD_AHEAD
+#define RTX_QUAD_AHEAD 3
+#endif
+#ifndef RTX_QUAD_WAVES_PER_SIMD
+#define RTX_QUAD_WAVES_PER_SIMD 3
+#endif
+#ifndef RTX_QUAD_RR
+#define RTX_QUAD_RR 8
+#endif
+constexpr uint32_t kQuadRR = RTX_QUAD_RR;                   // union rows per round: kQuadRR / 4 loads per wave and round
+constexpr uint32_t kQuadLoads = kQuadRR / 4u;
+constexpr uint32_t kQuadAhead = RTX_QUAD_AHEAD;             // rounds in flight behind the one being folded
 constexpr uint32_t kQuadDepth = kQuadAhead + 2;             // ring: in flight + current + one round of left-overs
 constexpr uint32_t kQuadSlots = kQuadRR * kQuadDepth;       // 40 KiB
 constexpr uint32_t kQuadUCap = 1024;                        // union rows per pass (a second pass is rare: DESIGN.md)
 constexpr uint32_t kQuadRingBytes = kQuadSlots * 1024u;
 constexpr uint32_t kQuadUOff = kQuadRingBytes;                            // u16 U[kQuadUCap + 64]
 constexpr uint32_t kQuadLOff = kQuadUOff + (kQuadUCap + 64u) * 2u;        // u16 Lw[4][kQuadUCap + 64]
-constexpr uint32_t kQuadLdsBytes = kQuadLOff + 4u * (kQuadUCap + 64u) * 2u;
+constexpr uint32_t kQuadZeroOff = kQuadLOff + 4u * (kQuadUCap + 64u) * 2u;  // 1 KiB of zeros: the rows a padded fold lacks
+constexpr uint32_t kQuadLdsBytes = kQuadZeroOff + 1024u;
 constexpr uint32_t kQuadRankOff = 8192u;                    // prologue only (inside the ring): u16 wordrank[1024 + 1]
 constexpr uint32_t kQuadEpiBytes = 8448u;                   // per wave: histogram / byte counters of the epilogue
 
@@ -63,7 +74,7 @@ __device__ __forceinline__ void dma_row(const char *rowbase, uint32_t stride, ui
 }
 
 template <int NP, bool kPacked>
-__global__ __launch_bounds__(256, 3) void hit_count_quad_kernel(HitParams p) {
+__global__ __launch_bounds__(256, RTX_QUAD_WAVES_PER_SIMD) void hit_count_quad_kernel(HitParams p) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds32[];
     __shared__ uint32_t s_wtot[4];
     __shared__ uint32_t s_hi_word;
@@ -91,10 +102,6 @@ __global__ __launch_bounds__(256, 3) void hit_count_quad_kernel(HitParams p) {
     for (int w = 0; w < 4; w++)
 #pragma unroll
         for (int b = 0; b < NP; b++) pl[w][b] = 0;
-    // carries of the Harley-Seal tree between folds of eight rows: pend = folds since the last ripple (0..3)
-    uint4 hold3 = make_uint4(0, 0, 0, 0), hold4 = make_uint4(0, 0, 0, 0);
-    uint32_t pend = 0;
-
     unsigned long long *bits64 = reinterpret_cast<unsigned long long *>(lds);          // [1024] prologue: union of the dense rows
     uint32_t *bits32 = reinterpret_cast<uint32_t *>(lds);
     uint16_t *wordrank = reinterpret_cast<uint16_t *>(lds + kQuadRankOff);             // [1025] prologue: rows below word w
@@ -105,7 +112,15 @@ __global__ __launch_bounds__(256, 3) void hit_count_quad_kernel(HitParams p) {
     const unsigned long long *masks = p.dmask + ((size_t)qc * p.ntiles + tile) * (p.rstride >> 6);
     const uint32_t nchunks = valid ? (p.nrows[qc] + 63u) >> 6 : 0u;  // <= 16: the quad kernel runs with t <= 1023
 
+    if (tid < 64u) reinterpret_cast<uint4 *>(lds + kQuadZeroOff)[tid] = make_uint4(0, 0, 0, 0);  // visible behind the first barrier
     uint32_t rows_loaded = 0;  // union rows of this (group, tile): the work accounting of the launch
+#ifdef RTX_QUAD_STAMP
+    unsigned long long stamp_acc = 0, stamp_t0 = __builtin_amdgcn_s_memtime();
+    const unsigned long long stamp_k0 = stamp_t0;
+#define STAMP_MARK(phase) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); if (RTX_QUAD_STAMP == (phase)) stamp_acc += now_ - stamp_t0; stamp_t0 = now_; }
+#else
+#define STAMP_MARK(phase)
+#endif
     uint32_t row_lo = 0;       // rows below it were folded by earlier passes
     for (;;) {
         // ---- prologue a: the dense rows (>= row_lo) of the four queries as a bit set; own rows parked in Lw as row ids
@@ -196,19 +211,24 @@ __global__ __launch_bounds__(256, 3) void hit_count_quad_kernel(HitParams p) {
         }
         __syncthreads();  // U and Lw complete; the bit set and the ranks are dead: the ring may be filled
         rows_loaded += un;
+        STAMP_MARK(1)
 
         // ---- row loop
         const uint32_t n_rounds = (un + kQuadRR - 1u) / kQuadRR;
         // round rr: this wave loads union rows rr * 8 + wave * 2 + {0, 1} into ring slots (rr mod depth) * 8 + wave * 2 + {0, 1};
         // always two loads (the zero row behind the end of U), so that the number of loads in flight is a constant
         auto issue = [&](uint32_t rr) {
-            const uint32_t u0 = rr * kQuadRR + wave * 2u;
-            const uint32_t slot0 = (rr % kQuadDepth) * kQuadRR + wave * 2u;
+            const uint32_t u0 = rr * kQuadRR + wave * kQuadLoads;
+            const uint32_t slot0 = (rr % kQuadDepth) * kQuadRR + wave * kQuadLoads;
 #pragma unroll
-            for (uint32_t j = 0; j < 2; j++) {
+            for (uint32_t j = 0; j < kQuadLoads; j++) {
                 uint32_t row = p.zero_row;
                 if (u0 + j < un) row = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)U[u0 + j]);
+#ifndef RTX_QUAD_NO_DMA
                 dma_row(bitmap + (size_t)row * stride, stride, col, lds_base + (slot0 + j) * 1024u);
+#else
+                if (row == 0xFFFFFFFEu) dma_row(bitmap, stride, col, lds_base);  // experiment: the loop without its loads
+#endif
             }
         };
         uint32_t head = 0;      // own rows [0, head) are folded
@@ -217,46 +237,56 @@ __global__ __launch_bounds__(256, 3) void hit_count_quad_kernel(HitParams p) {
         auto window = [&](uint32_t from) {
             wb = from;
             wu = (uint32_t)Lw[from + lane];                                  // position in U, 0xFFFF behind the end
-            woff = (wu % kQuadSlots) * 1024u;                    // byte offset of its ring slot
+            woff = (wu % kQuadSlots) * 1024u;                                // byte offset of its ring slot
         };
-        // folds own rows [head, head + n) (n <= 8; the missing ones count as zero rows)
-        auto fold = [&](uint32_t n) {
-            uint4 A[8];
-            const uint32_t l0 = head - wb;
-            if (n == 8u) {
-#pragma unroll
-                for (int j = 0; j < 8; j++) {
-                    const uint32_t off = (uint32_t)__builtin_amdgcn_readlane((int)woff, (int)(l0 + j));
-                    A[j] = *reinterpret_cast<const uint4 *>(lds + off + lane * 16u);
+        uint32_t r = 0;         // barriers passed: the rows of U below r * kQuadRR are in the ring
+        // barrier of round r -- own loads of that round have landed (those of the kQuadAhead - 1 younger rounds may still
+        // fly), own reads of the round that is overwritten next are done; behind the barrier that holds for every wave --
+        // then the loads of round r + kQuadAhead
+        auto next_round = [&]() {
+#if defined(RTX_QUAD_STAMP) && RTX_QUAD_STAMP >= 5
+            const unsigned long long ta_ = __builtin_amdgcn_s_memtime();
+#endif
+            asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)" ::"n"(kQuadLoads * (kQuadAhead - 1)) : "memory");
+#if defined(RTX_QUAD_STAMP) && RTX_QUAD_STAMP == 7
+            stamp_acc += __builtin_amdgcn_s_memtime() - ta_;   // own loads
+#endif
+            __builtin_amdgcn_s_barrier();
+#if defined(RTX_QUAD_STAMP) && RTX_QUAD_STAMP >= 5
+            const unsigned long long tb_ = __builtin_amdgcn_s_memtime();
+            if (RTX_QUAD_STAMP == 5) stamp_acc += tb_ - ta_;   // own loads + barrier
+#endif
+            issue(r + kQuadAhead);
+#if defined(RTX_QUAD_STAMP) && RTX_QUAD_STAMP == 6
+            stamp_acc += __builtin_amdgcn_s_memtime() - tb_;   // issuing the loads
+#endif
+            r++;
+        };
+        // How many own rows the next fold takes: eight as soon as eight have landed (rounds pass while it waits); fewer
+        // only when the oldest of them would be overwritten behind the next barrier (it is of round r - 2: left-overs
+        // wait one round, no longer) or when everything has landed.  0: no rows left and all rounds done.  The planes are
+        // not touched in here, so that the folds below stay one straight line of code (with the folds under
+        // data-dependent branches the compiler copied the 40 plane registers at every join: 2 moves per useful op).
+        auto acquire = [&]() -> uint32_t {
+            for (;;) {
+                const uint32_t navail = wb + (uint32_t)__popcll(__ballot(wu < r * kQuadRR));
+                const uint32_t left = navail - head;
+                if (left >= 8u) return 8u;
+                if (r == n_rounds) return left;
+                if (left && r >= 2u) {
+                    const uint32_t u_head = (uint32_t)__builtin_amdgcn_readlane((int)wu, (int)(head - wb));
+                    if (u_head < (r - 1u) * kQuadRR) return left;
                 }
-            } else {
-#pragma unroll
-                for (int j = 0; j < 8; j++) {
-                    A[j] = make_uint4(0, 0, 0, 0);
-                    if ((uint32_t)j < n) {
-                        const uint32_t off = (uint32_t)__builtin_amdgcn_readlane((int)woff, (int)(l0 + j));
-                        A[j] = *reinterpret_cast<const uint4 *>(lds + off + lane * 16u);
-                    }
-                }
+                next_round();
             }
-            const uint4 c3 = tree8<NP>(pl, A);
-            if (pend == 0u) {
-                hold3 = c3;
-                pend = 1;
-            } else if (pend == 1u) {
-                hold4 = csa_plane<NP, 3>(pl, hold3, c3);
-                pend = 2;
-            } else if (pend == 2u) {
-                hold3 = c3;
-                pend = 3;
-            } else {
-                const uint4 c4b = csa_plane<NP, 3>(pl, hold3, c3);
-                const uint4 c5 = csa_plane<NP, 4>(pl, hold4, c4b);
-                planes_ripple<NP, 5>(pl[0], c5.x);
-                planes_ripple<NP, 5>(pl[1], c5.y);
-                planes_ripple<NP, 5>(pl[2], c5.z);
-                planes_ripple<NP, 5>(pl[3], c5.w);
-                pend = 0;
+        };
+        // own rows [head, head + n) out of the ring (n <= 8; the missing ones count as zero rows)
+        auto take = [&](uint4 (&A)[8], uint32_t n) {
+            const uint32_t l0 = head - wb;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const uint32_t off = (uint32_t)__builtin_amdgcn_readlane((int)woff, (int)((l0 + j) & 63u));
+                A[j] = *reinterpret_cast<const uint4 *>(lds + ((uint32_t)j < n ? off : kQuadZeroOff) + lane * 16u);
             }
             head += n;
             if (head - wb + 8u > 64u) window(head);
@@ -264,49 +294,47 @@ __global__ __launch_bounds__(256, 3) void hit_count_quad_kernel(HitParams p) {
         if (n_rounds) {
             window(0);
             for (uint32_t rr = 0; rr < kQuadAhead; rr++) issue(rr);
-            for (uint32_t r = 0; r < n_rounds; r++) {
-                // own loads of round r have landed (those of the kQuadAhead - 1 younger rounds may still fly), own reads of the
-                // round that is overwritten next are done; behind the barrier that holds for every wave
-                asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)" ::"n"(2 * (kQuadAhead - 1)) : "memory");
-                __builtin_amdgcn_s_barrier();
-                issue(r + kQuadAhead);
-                const uint32_t landed = (r + 1u) * kQuadRR;                   // positions of U below it are in the ring
-                // own rows that have landed: those in front of the window all have (the window only moves past folded rows)
-                for (;;) {
-                    const uint32_t navail = wb + (uint32_t)__popcll(__ballot(wu < landed));
-                    if (navail - head >= 8u) {
-                        fold(8);
-                        continue;
-                    }
-                    // fewer than eight: they wait for the next round, unless the oldest is of the round before this one
-                    // (its slot is overwritten after the next barrier) or this is the last round
-                    const uint32_t left = navail - head;
-                    if (left) {
-                        const uint32_t u_head = (uint32_t)__builtin_amdgcn_readlane((int)wu, (int)(head - wb));
-                        if (r + 1u == n_rounds || u_head < r * kQuadRR) fold(left);
-                    }
-                    break;
-                }
+            for (;;) {  // 32 own rows per turn: four folds of eight, carries combined as in hit_count_kernel
+                uint4 A[8];
+                const uint32_t n0 = acquire();
+                if (n0 == 0u) break;
+                take(A, n0);
+                const uint4 c3a = tree8<NP>(pl, A);
+                __builtin_amdgcn_sched_barrier(0);  // one set of eight rows in registers at a time (168 VGPRs: three workgroups per CU)
+                take(A, acquire());
+                const uint4 c3b = tree8<NP>(pl, A);
+                const uint4 c4a = csa_plane<NP, 3>(pl, c3a, c3b);
+                __builtin_amdgcn_sched_barrier(0);
+                take(A, acquire());
+                const uint4 c3c = tree8<NP>(pl, A);
+                __builtin_amdgcn_sched_barrier(0);
+                take(A, acquire());
+                const uint4 c3d = tree8<NP>(pl, A);
+                const uint4 c4b = csa_plane<NP, 3>(pl, c3c, c3d);
+                const uint4 c5 = csa_plane<NP, 4>(pl, c4a, c4b);
+                planes_ripple<NP, 5>(pl[0], c5.x);
+                planes_ripple<NP, 5>(pl[1], c5.y);
+                planes_ripple<NP, 5>(pl[2], c5.z);
+                planes_ripple<NP, 5>(pl[3], c5.w);
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the loads behind the end of U (zero rows)
         }
         __syncthreads();  // every wave is done with the ring: the next pass or the epilogue may overwrite it
+        STAMP_MARK(2)
         if (hi_word >= 1024u) break;
         row_lo = hi_row;
     }
-    // the carries still held
-    if (pend == 1u || pend == 3u) {
-        planes_ripple<NP, 3>(pl[0], hold3.x);
-        planes_ripple<NP, 3>(pl[1], hold3.y);
-        planes_ripple<NP, 3>(pl[2], hold3.z);
-        planes_ripple<NP, 3>(pl[3], hold3.w);
+#ifdef RTX_QUAD_STAMP
+    if (valid) {
+        uint32_t *hist_lds = reinterpret_cast<uint32_t *>(lds + wave * kQuadEpiBytes);
+        uint32_t *cnt8 = hist_lds + (kQuadEpiBytes - 4096u) / 4u;
+        hit_epilogue<NP, kPacked>(p, pl, q, tile, lane, t, active, hist_lds, cnt8, ns, srows);
     }
-    if (pend >= 2u) {
-        planes_ripple<NP, 4>(pl[0], hold4.x);
-        planes_ripple<NP, 4>(pl[1], hold4.y);
-        planes_ripple<NP, 4>(pl[2], hold4.z);
-        planes_ripple<NP, 4>(pl[3], hold4.w);
-    }
+    STAMP_MARK(3)
+    if (RTX_QUAD_STAMP == 4) stamp_acc = __builtin_amdgcn_s_memtime() - stamp_k0;
+    if (tid == 0 && p.group_rows) atomicAdd(&p.group_rows[p.group_base + g], (uint32_t)(stamp_acc >> 6));
+    return;
+#endif
     if (tid == 0 && p.group_rows) atomicAdd(&p.group_rows[p.group_base + g], rows_loaded);
     if (!valid) return;
     uint32_t *hist_lds = reinterpret_cast<uint32_t *>(lds + wave * kQuadEpiBytes);

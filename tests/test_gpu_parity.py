@@ -340,6 +340,29 @@ def test_packed_counts_equal_u16_counts(world, oracle):
         assert big > 5       # the high bits were exercised
 
 
+def test_quad_kernel_equals_one_wave_per_query(world, oracle):
+    """RTX_OPT_HIT_QUAD: four neighbouring queries per workgroup, rows loaded once through LDS (rtx_hit_quad.hip).
+    Every result array and the hit counts equal those of hit_count_kernel -- with the degenerate queries of `world`
+    (no k-mers, one k-mer, short), a sub-batch size that is no multiple of four, --skip-exact-matches, u16 counts."""
+    w = world
+    ex_ids, ex_off = w["index"].exact_matches(w["bases"], w["off"])
+    for kw in (dict(), dict(sub_batch=37), dict(packed_counts=False)):
+        a, b = rx.Index(w["tree"], hit_quad=False, **kw), rx.Index(w["tree"], hit_quad=True, **kw)
+        for skip in (False, True):
+            ra = a.classify(w["bases"], w["off"], ex_ids, ex_off, skip_exact_matches=skip)
+            rb = b.classify(w["bases"], w["off"], ex_ids, ex_off, skip_exact_matches=skip)
+            for f in ("row_off", "row_lineage", "row_conf", "row_local_signal", "global_signal", "t", "status"):
+                assert np.array_equal(getattr(ra, f), getattr(rb, f)), (kw, skip, f)
+            n_sb = kw.get("sub_batch", 10 ** 9)
+            last0 = (len(w["seqs"]) - 1) // n_sb * n_sb
+            for q in range(last0, len(w["seqs"]), 2):
+                c = b.debug_hit_counts(q)
+                assert np.array_equal(c, a.debug_hit_counts(q)), (kw, skip, q)
+                assert np.array_equal(c, w["otree"].hit_counts(w["seqs"][q], skip_exact=skip)[1])
+        wa, wb = a.work(), b.work()
+        assert wa["sum_hits"] == wb["sum_hits"] and 0 < wb["bitmap_bytes_read"] <= wa["bitmap_bytes_read"]
+
+
 def test_work_accounting_matches_oracle(world):
     """sum_hits = sum_q H_q = sum_q sum_r count_q[r], measured by the device."""
     w = world

@@ -1,0 +1,36 @@
+#!/bin/bash
+# Builds experimental variants of libraxtax_hip.so (rtx_hit_quad.hip with other constants / parts switched off) into
+# gpurun_scratch/ -- run on the build box; the GPU box then times them with tools/quad_time.py.
+set -eu
+ROOT=$(cd "$(dirname "$0")/.." && pwd)
+OUT=$ROOT/gpurun_scratch; mkdir -p "$OUT"
+python3 -c "from raxtax_amd import _build; _build.build_lib()"
+build() {  # name, flags
+  local name=$1; shift
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I"$ROOT/include" -I"$ROOT/raxtax_amd/csrc" "$@" -x hip -c "$ROOT/raxtax_amd/csrc/rtx_hit_quad.hip" -o "$OUT/quad_$name.o"
+  objs=$(ls "$ROOT"/raxtax_amd/_obj/*.o | grep -v rtx_hit_quad)
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -fPIC -shared -o "$OUT/lib_$name.so" $objs "$OUT/quad_$name.o" -lpthread
+  echo "built $OUT/lib_$name.so"
+}
+for v in "$@"; do
+  case $v in
+    base) build base ;;
+    p1) build p1 -DRTX_QUAD_AHEAD=1 ;;
+    p2) build p2 -DRTX_QUAD_AHEAD=2 ;;
+    nodma) build nodma -DRTX_QUAD_NO_DMA ;;
+    w2) build w2 -DRTX_QUAD_WAVES_PER_SIMD=2 ;;
+    st1) build st1 -DRTX_QUAD_STAMP=1 ;;
+    st2) build st2 -DRTX_QUAD_STAMP=2 ;;
+    st3) build st3 -DRTX_QUAD_STAMP=3 ;;
+    st4) build st4 -DRTX_QUAD_STAMP=4 ;;
+    st5) build st5 -DRTX_QUAD_STAMP=5 ;;
+    st6) build st6 -DRTX_QUAD_STAMP=6 ;;
+    st7) build st7 -DRTX_QUAD_STAMP=7 ;;
+    rr16) build rr16 -DRTX_QUAD_RR=16 -DRTX_QUAD_AHEAD=1 ;;
+    rr16w2) build rr16w2 -DRTX_QUAD_RR=16 -DRTX_QUAD_AHEAD=1 -DRTX_QUAD_WAVES_PER_SIMD=2 ;;
+    rr32w2) build rr32w2 -DRTX_QUAD_RR=32 -DRTX_QUAD_AHEAD=1 -DRTX_QUAD_WAVES_PER_SIMD=1 ;;
+    w2p4) build w2p4 -DRTX_QUAD_WAVES_PER_SIMD=2 -DRTX_QUAD_AHEAD=4 ;;
+    w2p6) build w2p6 -DRTX_QUAD_WAVES_PER_SIMD=2 -DRTX_QUAD_AHEAD=6 ;;
+    *) echo "unknown variant $v"; exit 1 ;;
+  esac
+done

@@ -75,6 +75,10 @@ def parse():
     ap.add_argument("--shard-db", action="store_true",
                     help="BASELINE configs[4]: shard the REFERENCES over the GPUs (every rank classifies the same "
                          "queries; RCCL all-reduce of histograms + all-gather of prefix sums per sub-batch)")
+    ap.add_argument("--shard-mode", default="refs", choices=["refs", "kmers"],
+                    help="with --shard-db: refs = contiguous reference ranges per GPU, all-reduce of histograms + all-gather of "
+                         "prefix sums (SURVEY.md 8e mode B, default); kmers = k-mer ranges per GPU, all-reduce of the u16 "
+                         "per-reference hit counts (mode A, the literal wording of BASELINE.json configs[4])")
     args = ap.parse_args()
     refs, queries, name = CONFIGS[args.config]
     args.config_name = name if not (args.refs or args.queries) else "custom size"
@@ -331,16 +335,22 @@ def main():
 
         tree = rx.Tree.new_flat(db.lineages, db.seq_bytes, db.seq_off)          # the shards are cut out of Tree.k_mer_map
         qs = synth.make_queries(db, args.queries, seed=3)                        # the same queries on every rank
-        cuts = sharded.shard_cuts(tree.num_tips, world)
-        index = sharded.ShardIndex(tree, rank, cuts, device=local_rank, sub_batch=args.sub_batch or 4096)
-        if dist is not None:
-            w = torch.tensor([index.n_bnd_local], device=coll_device, dtype=torch.int64)
-            ws = [torch.zeros_like(w) for _ in range(world)]
-            dist.all_gather(ws, w)
-            comm = sharded.TorchComm(dist, world, [int(x.item()) for x in ws])
+        if args.shard_mode == "kmers":
+            kcuts = sharded.kmer_cuts(tree.csr()[0], world)
+            index = sharded.KmerShardIndex(tree, rank, kcuts, device=local_rank, sub_batch=args.sub_batch or 256)
+            comm = sharded.TorchComm(dist, world, []) if dist is not None else sharded.LocalComm()
+            clf = sharded.KmerShardedClassifier([index], comm)
         else:
-            comm = sharded.LocalComm()
-        clf = sharded.ShardedClassifier([index], comm)
+            cuts = sharded.shard_cuts(tree.num_tips, world)
+            index = sharded.ShardIndex(tree, rank, cuts, device=local_rank, sub_batch=args.sub_batch or 4096)
+            if dist is not None:
+                w = torch.tensor([index.n_bnd_local], device=coll_device, dtype=torch.int64)
+                ws = [torch.zeros_like(w) for _ in range(world)]
+                dist.all_gather(ws, w)
+                comm = sharded.TorchComm(dist, world, [int(x.item()) for x in ws])
+            else:
+                comm = sharded.LocalComm()
+            clf = sharded.ShardedClassifier([index], comm)
         t0 = time.perf_counter()
         ex_ids, ex_off = index.exact_matches(qs.bases, qs.base_off)
         t_exact = time.perf_counter() - t0
@@ -355,7 +365,9 @@ def main():
             pass
         total_q_step = args.queries                                              # strong scaling: the work is fixed
         scaling = "strong"
-        parallelism = f"references sharded x{world} (contiguous id ranges), queries replicated"
+        parallelism = (f"references sharded x{world} (contiguous id ranges), queries replicated; all-reduce of histograms + all-gather of prefix sums"
+                       if args.shard_mode == "refs" else
+                       f"k-mers sharded x{world}, queries replicated; all-reduce of the u16 per-reference hit counts")
         workload = (f"{args.queries} synthetic COI-length (658 bp) queries vs {args.refs}-seq reference DB sharded by reference id "
                     f"over {world} GPU(s) (BASELINE.json configs[4] shape)")
     else:

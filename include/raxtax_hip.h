@@ -189,9 +189,10 @@ int rtx_index_set_batch(rtx_index *index, uint32_t sub_batch);
 #define RTX_OPT_CLUSTER 7 /* 1 (default): the queries of a batch are processed in an order that puts related
                              queries next to each other (min-hash sketches, rtx_cluster.hip) so that bitmap rows
                              are reused; 0: input order.  Results are identical and always in input order. */
-#define RTX_OPT_HIT_QUAD 9 /* 1 (default): with t <= 1023 and RTX_OPT_CLUSTER on, hit_count runs four neighbouring queries per
-                           * workgroup and loads every bitmap row they need once, through LDS (rtx_hit_quad.hip); 0: one wave
-                           * per (query, tile) fetching its own rows (A/B measurements, and what longer queries always use) */
+#define RTX_OPT_HIT_QUAD 9 /* 0 (default): one wave per (query, tile) fetching its own rows; 1: with t <= 1023 and RTX_OPT_CLUSTER on,
+                           * hit_count runs four neighbouring queries per workgroup and loads every bitmap row they need once,
+                           * through LDS (rtx_hit_quad.hip) -- half the bytes out of L2, identical results, but slower on
+                           * MI355X as measured: kept for A/B measurements */
 #define RTX_OPT_PACKED_COUNTS 8 /* 1 (default): with t <= 1023 the hit counts travel from hit_count to taxon_prefix
                                  * packed, 10 bits per reference (low byte + 2 high bits); 0: as u16 (A/B measurements) */
 int rtx_index_set_option(rtx_index *index, int option, uint64_t value);
@@ -258,6 +259,17 @@ int rtx_shard_walk(rtx_index *index, uint32_t sub_batch_idx, const double *prefi
 int rtx_shard_info(const rtx_index *index, uint64_t *ref_lo, uint64_t *ref_hi, uint32_t *n_bnd_global,
                    uint32_t *n_bnd_local, uint32_t *first_bnd);
 int rtx_device_buffer(rtx_index *index, int which, void **device_ptr, uint64_t *row_stride_elems);
+/* The same for the scratch set of sub-batch `sub_batch_idx`: a staged run alternates between two sets, so that
+ * the exchange of sub-batch i (on the caller's stream or RCCL's) can overlap with rtx_shard_count of sub-batch i + 1.
+ * RTX_BUF_COUNTS: the u16 hit counts ([n][row_stride], needs RTX_OPT_PACKED_COUNTS = 0) -- what a k-mer-sharded
+ * database (SURVEY.md 8e mode A, the literal wording of BASELINE.json configs[4]) all-reduces; rtx_shard_rehist then
+ * rebuilds the histogram of prob.rs:13-19 from the summed counts before rtx_shard_prob. */
+#define RTX_BUF_COUNTS 3
+int rtx_shard_buffer(rtx_index *index, uint32_t sub_batch_idx, int which, void **device_ptr, uint64_t *row_stride_elems);
+int rtx_shard_rehist(rtx_index *index, uint32_t sub_batch_idx);
+/* The HIP stream (hipStream_t) every kernel of this handle is enqueued on: a caller that interleaves its own device
+ * work (collectives) with rtx_shard_* orders it against this stream instead of synchronising the host. */
+int rtx_index_stream(rtx_index *index, void **hip_stream);
 
 /* Per-kernel device time of the last rtx_batch_run, from HIP events on the library's
  * stream (ms, summed over sub-batches), and launch counts (0 launches = stage not timed, see

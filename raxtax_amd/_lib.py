@@ -86,6 +86,9 @@ _SIGNATURES = {
     "rtx_shard_walk": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p]),
     "rtx_shard_info": (C.c_int, [C.c_void_p, u64p, u64p, u32p, u32p, u32p]),
     "rtx_device_buffer": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), u64p]),
+    "rtx_shard_buffer": (C.c_int, [C.c_void_p, C.c_uint32, C.c_int, C.POINTER(C.c_void_p), u64p]),
+    "rtx_shard_rehist": (C.c_int, [C.c_void_p, C.c_uint32]),
+    "rtx_index_stream": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "rtx_index_create_from_sequences": (C.c_int, [C.c_int, C.c_uint64, u8p, u64p, C.c_uint32, u32p, u32p, u32p, u32p, u8p,
                                                  C.POINTER(C.c_void_p)]),
     "rtx_index_create_from_tree": (C.c_int, [C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]),

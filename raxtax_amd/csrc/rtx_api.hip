@@ -182,6 +182,8 @@ struct rtx_index {
         DevBuf<double> d_table_z, d_prefix;
     } sc[2];
     uint32_t n_streams_req = 1, n_streams = 1;
+    bool staged = false;  // driven with rtx_shard_*: sub-batch sb works in scratch set sb & 1, so that the exchange of one
+                          // sub-batch (RCCL, on the caller's stream) can overlap with the counting of the next
     hipStream_t stream2 = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     uint32_t last_set = 0;  // scratch set of the last sub-batch (debug taps)
@@ -270,7 +272,7 @@ SubBatch sub_batch_of(rtx_index *ix, uint32_t sb, bool timed) {
     b.sb = sb;
     b.q0 = (uint64_t)sb * ix->sub_batch;
     b.nq = (uint32_t)std::min<uint64_t>(ix->sub_batch, ix->n_q - b.q0);
-    b.set = ix->n_streams == 2 ? (sb & 1u) : 0u;
+    b.set = (ix->n_streams == 2 || ix->staged) ? (sb & 1u) : 0u;
     b.s = ix->stream;
     b.timed = timed;
     b.timed_all = timed && ix->stage_timing != 0;
@@ -643,6 +645,8 @@ constexpr uint32_t kMaxSubBatch = 16384;
 // 8192: 23.7, 14 286: 23.7 -- beyond ~12 000 hit_count loses more L2 reuse than the launches save)
 constexpr uint32_t kDefaultSubBatch = 10240;
 
+int alloc_scratch_set(rtx_index *ix, uint32_t k);
+
 // Sizes and allocates the per-batch workspace for n_queries queries of at most tmax k-mers.
 int prepare_workspace(rtx_index *ix, uint64_t n_queries, uint64_t tmax, uint64_t max_len) {
     int rc;
@@ -691,7 +695,17 @@ int prepare_workspace(rtx_index *ix, uint64_t n_queries, uint64_t tmax, uint64_t
     if (B > kMaxSubBatch) B = kMaxSubBatch;
     B = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(B, n_queries));
     ix->sub_batch = B;
+    ix->staged = false;
     for (uint32_t k = 0; k < ix->n_streams; k++) {
+        if ((rc = alloc_scratch_set(ix, k))) return rc;
+    }
+    return RTX_OK;
+}
+
+int alloc_scratch_set(rtx_index *ix, uint32_t k) {
+    int rc;
+    const uint32_t B = ix->sub_batch;
+    {
         rtx_index::Scratch &sc = ix->sc[k];
         if ((rc = sc.d_kmers.alloc((size_t)B * ix->kstride)) || (rc = sc.d_rows.alloc((size_t)B * ix->rstride)) || (rc = sc.d_dmask.alloc((size_t)B * ix->ntiles * (ix->rstride / 64))) ||
             (rc = sc.d_nsparse.alloc((size_t)B * ix->ntiles)) || (rc = sc.d_srows.alloc((size_t)B * ix->ntiles * (kSegMaxSparseRows + 1))) ||
@@ -1394,6 +1408,10 @@ int rtx_shard_begin(rtx_index *ix, uint32_t *n_sub_batches, uint32_t *sub_batch)
     if (rc) return rc;
     if (!ix->uploaded) { set_error("rtx_shard_begin before rtx_batch_upload"); return RTX_ERR_STATE; }
     if (ix->n_streams != 1) { set_error("sharded handles use one stream"); return RTX_ERR_STATE; }
+    if (!ix->staged) {  // second scratch set: sub-batch sb + 1 may be counted while sub-batch sb is exchanged
+        if ((rc = alloc_scratch_set(ix, 1))) return rc;
+        ix->staged = true;
+    }
     uint32_t n_sub = 0;
     bool timed = false;
     if ((rc = begin_run(ix, &n_sub, &timed, false))) return rc;  // shards must agree on the order: input order
@@ -1461,6 +1479,43 @@ int rtx_device_buffer(rtx_index *ix, int which, void **ptr, uint64_t *row_stride
     }
     set_error("rtx_device_buffer: unknown buffer %d", which);
     return RTX_ERR_INVALID;
+}
+
+int rtx_shard_buffer(rtx_index *ix, uint32_t sb, int which, void **ptr, uint64_t *row_stride_elems) {
+    if (!ix || !ptr) { set_error("null argument"); return RTX_ERR_INVALID; }
+    if (!ix->uploaded) { set_error("rtx_shard_buffer before rtx_batch_upload"); return RTX_ERR_STATE; }
+    rtx_index::Scratch &sc = ix->sc[ix->staged ? (sb & 1u) : 0u];
+    switch (which) {
+        case RTX_BUF_HIST: *ptr = sc.d_hist.p; if (row_stride_elems) *row_stride_elems = ix->hstride; return RTX_OK;
+        case RTX_BUF_PREFIX: *ptr = sc.d_prefix.p; if (row_stride_elems) *row_stride_elems = ix->n_bnd_local; return RTX_OK;
+        case RTX_BUF_COUNTS:
+            if (ix->packed()) { set_error("RTX_BUF_COUNTS needs u16 counts (RTX_OPT_PACKED_COUNTS = 0)"); return RTX_ERR_STATE; }
+            *ptr = sc.d_counts.p;
+            if (row_stride_elems) *row_stride_elems = ix->npad;
+            return RTX_OK;
+        default: break;
+    }
+    set_error("rtx_shard_buffer: unknown buffer %d", which);
+    return RTX_ERR_INVALID;
+}
+
+int rtx_index_stream(rtx_index *ix, void **hip_stream) {
+    if (!ix || !hip_stream) { set_error("null argument"); return RTX_ERR_INVALID; }
+    *hip_stream = (void *)ix->stream;
+    return RTX_OK;
+}
+
+// k-mer-sharded database (SURVEY.md 8e mode A): the counts of a sub-batch have been all-reduced over the ranks;
+// the histogram of prob.rs:13-19 is rebuilt from them (the one hit_count wrote covered this rank's k-mers only)
+int rtx_shard_rehist(rtx_index *ix, uint32_t sb) {
+    SubBatch b;
+    int rc = shard_sb(ix, sb, &b);
+    if (rc) return rc;
+    if (ix->packed()) { set_error("rtx_shard_rehist needs u16 counts (RTX_OPT_PACKED_COUNTS = 0)"); return RTX_ERR_STATE; }
+    rtx_index::Scratch &sc = ix->sc[b.set];
+    launch_rehist(b.s, sc.d_counts.p, ix->npad, ix->n_refs, sc.d_t.p, sc.d_hist.p, ix->hstride, b.nq);
+    RTX_HIP(hipGetLastError());
+    return RTX_OK;
 }
 
 int rtx_batch_stage_times(rtx_index *ix, float ms[RTX_NUM_STAGES], uint32_t launches[RTX_NUM_STAGES]) {

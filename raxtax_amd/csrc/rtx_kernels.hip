@@ -1036,6 +1036,24 @@ __global__ __launch_bounds__(NW * 64) void taxon_prefix_kernel(PrefixParams p) {
     }
 }
 
+// histogram of prob.rs:13-19 from the u16 counts of a sub-batch (k-mer-sharded database: counts summed over the ranks)
+__global__ __launch_bounds__(256) void rehist_kernel(const uint16_t *__restrict__ counts, uint64_t npad, uint64_t n_refs,
+                                                     const uint32_t *__restrict__ t, uint32_t *__restrict__ hist, uint32_t hstride) {
+    extern __shared__ uint32_t h_lds[];
+    const uint32_t q = blockIdx.x, tid = threadIdx.x;
+    const uint32_t tq = t[q];
+    for (uint32_t m = tid; m <= tq; m += 256) h_lds[m] = 0;
+    __syncthreads();
+    const uint16_t *c = counts + (size_t)q * npad;
+    for (uint64_t r = tid; r < n_refs; r += 256) {
+        const uint32_t v = c[r];
+        atomicAdd(&h_lds[v <= tq ? v : tq], 1u);  // a count cannot exceed t (clamped against corrupt input)
+    }
+    __syncthreads();
+    uint32_t *h = hist + (size_t)q * hstride;
+    for (uint32_t m = tid; m <= tq; m += 256) h[m] = h_lds[m];
+}
+
 // debug taps: the packed counts of one query as u16 (rtx_debug_hit_counts, rtx_debug_probs)
 __global__ void counts_unpack_kernel(const uint8_t *lo, const uint16_t *hi, uint64_t n, uint16_t *out) {
     const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1103,6 +1121,10 @@ void launch_taxon_prefix(hipStream_t s, const PrefixParams &p, uint32_t nq) {
 }
 void launch_lineage_walk(hipStream_t s, const WalkParams &p, uint32_t nq) {
     hipLaunchKernelGGL(lineage_walk_kernel, dim3(nq), dim3(64), 0, s, p);
+}
+void launch_rehist(hipStream_t s, const uint16_t *counts, uint64_t npad, uint64_t n_refs, const uint32_t *t, uint32_t *hist,
+                   uint32_t hstride, uint32_t nq) {
+    hipLaunchKernelGGL(rehist_kernel, dim3(nq), dim3(256), (size_t)hstride * 4, s, counts, npad, n_refs, t, hist, hstride);
 }
 void launch_counts_unpack(hipStream_t s, const uint8_t *lo, const uint16_t *hi, uint64_t n, uint16_t *out) {
     hipLaunchKernelGGL(counts_unpack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, lo, hi, n, out);

@@ -192,6 +192,8 @@ int cluster_sort(hipStream_t s, void *tmp, size_t *tmp_bytes, const uint64_t *ke
 void launch_taxon_prefix(hipStream_t s, const PrefixParams &p, uint32_t nq);
 void launch_lineage_walk(hipStream_t s, const WalkParams &p, uint32_t nq);
 void launch_probs_expand(hipStream_t s, const uint16_t *counts, const double *tz, uint64_t n, double *out);
+void launch_rehist(hipStream_t s, const uint16_t *counts, uint64_t npad, uint64_t n_refs, const uint32_t *t, uint32_t *hist,
+                   uint32_t hstride, uint32_t nq);
 void launch_counts_unpack(hipStream_t s, const uint8_t *lo, const uint16_t *hi, uint64_t n, uint16_t *out);
 
 }  // namespace rtx

@@ -26,7 +26,7 @@ from . import _lib
 from ._lib import check, ptr, u8p, u32p, u64p
 from .api import Index, Result, Tree
 
-RTX_BUF_HIST, RTX_BUF_PREFIX = 1, 2
+RTX_BUF_HIST, RTX_BUF_PREFIX, RTX_BUF_COUNTS = 1, 2, 3
 
 
 class _DevArray:
@@ -52,8 +52,54 @@ def shard_cuts(n_refs: int, world: int) -> List[int]:
     return cuts
 
 
-class ShardIndex(Index):
-    """Device index holding references [cuts[rank], cuts[rank+1]) of the tree."""
+class _StagedMixin:
+    """The staged C ABI (rtx_shard_*) of a handle: kernels of one sub-batch in three groups, exchanges in between."""
+
+    def begin(self):
+        n_sub, b = C.c_uint32(), C.c_uint32()
+        check(self._lib.rtx_shard_begin(self._h, C.byref(n_sub), C.byref(b)))
+        return n_sub.value, b.value
+
+    def count(self, sb: int, flags: int = 0):
+        check(self._lib.rtx_shard_count(self._h, sb, flags))
+
+    def rehist(self, sb: int):
+        check(self._lib.rtx_shard_rehist(self._h, sb))
+
+    def prob(self, sb: int):
+        check(self._lib.rtx_shard_prob(self._h, sb))
+
+    def walk(self, sb: int, prefix_global):
+        assert prefix_global.is_contiguous() and prefix_global.shape[1] == self.n_bnd
+        check(self._lib.rtx_shard_walk(self._h, sb, C.c_void_p(prefix_global.data_ptr())))
+
+    def buffer(self, which: int, n_rows: int, sb: int = 0):
+        """Device buffer of sub-batch sb (a staged run alternates between two scratch sets) as a torch tensor."""
+        p, stride = C.c_void_p(), C.c_uint64()
+        check(self._lib.rtx_shard_buffer(self._h, sb, which, C.byref(p), C.byref(stride)))
+        typ = {RTX_BUF_HIST: "<i4", RTX_BUF_PREFIX: "<f8", RTX_BUF_COUNTS: "<i2"}[which]
+        return device_tensor(p.value, (n_rows, stride.value), typ, self.device)
+
+    @property
+    def torch_stream(self):
+        """The HIP stream of the handle as a torch stream: collectives issued under `torch.cuda.stream(...)` of it are
+        ordered against the library's kernels on the device, without host synchronisation."""
+        import torch
+
+        if getattr(self, "_tstream", None) is None:
+            p = C.c_void_p()
+            check(self._lib.rtx_index_stream(self._h, C.byref(p)))
+            self._tstream = torch.cuda.ExternalStream(p.value, device=torch.device("cuda", self.device))
+        return self._tstream
+
+    def _shard_info(self):
+        lo, hi, ng, nl, fb = C.c_uint64(), C.c_uint64(), C.c_uint32(), C.c_uint32(), C.c_uint32()
+        check(self._lib.rtx_shard_info(self._h, C.byref(lo), C.byref(hi), C.byref(ng), C.byref(nl), C.byref(fb)))
+        self.ref_lo, self.ref_hi, self.n_bnd, self.n_bnd_local, self.first_bnd = lo.value, hi.value, ng.value, nl.value, fb.value
+
+
+class ShardIndex(_StagedMixin, Index):
+    """Device index holding references [cuts[rank], cuts[rank+1]) of the tree (SURVEY.md 8e mode B)."""
 
     def __init__(self, tree: Tree, rank: int, cuts: Sequence[int], device: int = 0, sub_batch: int = 1024):
         self._lib = _lib.load()
@@ -77,30 +123,51 @@ class ShardIndex(Index):
 
         self._view = ResultView()
         self._keep = None
-        lo, hi, ng, nl, fb = C.c_uint64(), C.c_uint64(), C.c_uint32(), C.c_uint32(), C.c_uint32()
-        check(self._lib.rtx_shard_info(self._h, C.byref(lo), C.byref(hi), C.byref(ng), C.byref(nl), C.byref(fb)))
-        self.ref_lo, self.ref_hi, self.n_bnd, self.n_bnd_local, self.first_bnd = lo.value, hi.value, ng.value, nl.value, fb.value
+        self._shard_info()
 
-    # ---- staged interface ----------------------------------------------------------------------
-    def begin(self):
-        n_sub, b = C.c_uint32(), C.c_uint32()
-        check(self._lib.rtx_shard_begin(self._h, C.byref(n_sub), C.byref(b)))
-        return n_sub.value, b.value
 
-    def count(self, sb: int, flags: int = 0):
-        check(self._lib.rtx_shard_count(self._h, sb, flags))
+def kmer_cuts(tree_off: np.ndarray, world: int) -> List[int]:
+    """Cut points of the 65 536 k-mers that give every rank about the same number of postings (world + 1 values)."""
+    total = int(tree_off[-1])
+    cuts = [0]
+    for r in range(1, world):
+        cuts.append(int(np.searchsorted(tree_off, total * r // world, side="left")))
+    cuts.append(65536)
+    return [min(max(c, 0), 65536) for c in cuts]
 
-    def prob(self, sb: int):
-        check(self._lib.rtx_shard_prob(self._h, sb))
 
-    def walk(self, sb: int, prefix_global):
-        assert prefix_global.is_contiguous() and prefix_global.shape[1] == self.n_bnd
-        check(self._lib.rtx_shard_walk(self._h, sb, C.c_void_p(prefix_global.data_ptr())))
+class KmerShardIndex(_StagedMixin, Index):
+    """Device index holding the posting lists of k-mers [kcuts[rank], kcuts[rank+1]) over ALL references
+    (SURVEY.md 8e mode A, the literal wording of BASELINE.json configs[4]): its hit counts are partial sums that the
+    ranks all-reduce.  Counts travel as u16 here (RTX_OPT_PACKED_COUNTS = 0: packed counts cannot be added)."""
 
-    def buffer(self, which: int, n_rows: int):
-        p, stride = C.c_void_p(), C.c_uint64()
-        check(self._lib.rtx_device_buffer(self._h, which, C.byref(p), C.byref(stride)))
-        return device_tensor(p.value, (n_rows, stride.value), "<i4" if which == RTX_BUF_HIST else "<f8", self.device)
+    def __init__(self, tree: Tree, rank: int, kcuts: Sequence[int], device: int = 0, sub_batch: int = 256):
+        self._lib = _lib.load()
+        self.tree = tree
+        self.device = device
+        self.rank = rank
+        off, post = tree.csr()
+        nd = tree.nodes()
+        lo, hi = int(kcuts[rank]), int(kcuts[rank + 1])
+        a, b = int(off[lo]), int(off[hi])
+        off_r = np.zeros(65537, dtype=np.uint64)
+        off_r[lo:hi + 1] = off[lo:hi + 1] - np.uint64(a)
+        off_r[hi + 1:] = np.uint64(b - a)
+        post_r = np.ascontiguousarray(post[a:b]) if b > a else np.zeros(1, np.uint32)
+        h = C.c_void_p()
+        check(self._lib.rtx_index_create(device, tree.num_tips, ptr(off_r, u64p), ptr(post_r, u32p), len(nd["type"]),
+                                         ptr(nd["begin"], u32p), ptr(nd["end"], u32p), ptr(nd["first_child"], u32p),
+                                         ptr(nd["n_children"], u32p), ptr(nd["type"], u8p), C.byref(h)))
+        self._h = h
+        self.n_refs = tree.num_tips
+        check(self._lib.rtx_index_set_option(self._h, 8, 0))           # u16 counts
+        if sub_batch:
+            check(self._lib.rtx_index_set_batch(self._h, sub_batch))
+        from ._lib import ResultView
+
+        self._view = ResultView()
+        self._keep = None
+        self._shard_info()
 
 
 class LocalComm:
@@ -112,6 +179,8 @@ class LocalComm:
             total += h
         for h in hists:
             h.copy_(total)
+
+    allreduce_counts = allreduce_hist
 
     def allgather_prefix(self, locals_):
         return [p.clone() for p in locals_]
@@ -126,6 +195,13 @@ class TorchComm:
     def allreduce_hist(self, hists):
         (h,) = hists           # int32 view of the uint32 histogram (counts < 2^31)
         self.dist.all_reduce(h)
+
+    def allreduce_start(self, t):
+        """Asynchronous all-reduce(sum): ordered behind the work already on the current stream; wait() makes the
+        current stream (not the host) wait for it."""
+        return self.dist.all_reduce(t, async_op=True)
+
+    allreduce_counts = allreduce_hist   # int16 view of the u16 counts (counts < 2^15 for t <= 32767)
 
     def allgather_prefix(self, locals_):
         import torch
@@ -172,6 +248,37 @@ class ShardedClassifier:
 
     def run(self, skip_exact_matches: bool = False, copy: bool = True):
         """One pass over the uploaded queries; returns the Result (copy=True) or the library-owned view."""
+        if len(self.shards) == 1 and hasattr(self.comm, "allreduce_start"):
+            return self._run_pipelined(skip_exact_matches, copy)
+        return self._run_blocking(skip_exact_matches, copy)
+
+    def _run_pipelined(self, skip_exact_matches: bool, copy: bool):
+        """One shard per process (TorchComm): nothing synchronises the host between the sub-batches.  The handle's HIP
+        stream is the current torch stream, so the collectives are ordered on the device behind the kernels they depend
+        on; the histogram all-reduce of sub-batch i is started BEFORE sub-batch i + 1 is counted (its own scratch set)
+        and waited for (by the stream) behind it: the exchange overlaps with the dominant kernel."""
+        import torch
+
+        (s,) = self.shards
+        flags = _lib.RTX_SKIP_EXACT_MATCHES if skip_exact_matches else 0
+        n_sub, B = s.begin()
+        n_q = self._n_q
+        keep = []
+        with torch.cuda.stream(s.torch_stream):
+            s.count(0, flags)
+            for sb in range(n_sub):
+                nq = min(B, n_q - sb * B)
+                work = self.comm.allreduce_start(s.buffer(RTX_BUF_HIST, nq, sb))
+                if sb + 1 < n_sub:
+                    s.count(sb + 1, flags)
+                work.wait()
+                s.prob(sb)
+                pref = assemble_prefix(self.comm.allgather_prefix([s.buffer(RTX_BUF_PREFIX, nq, sb)]))
+                s.walk(sb, pref)
+                keep = [pref] + keep[:1]      # stream-ordered reuse by the allocator; two generations kept for clarity
+        return s.download(copy=copy)
+
+    def _run_blocking(self, skip_exact_matches: bool, copy: bool):
         import torch
 
         flags = _lib.RTX_SKIP_EXACT_MATCHES if skip_exact_matches else 0
@@ -185,17 +292,60 @@ class ShardedClassifier:
                 s.count(sb, flags)
             for s in self.shards:
                 s.sync()
-            self.comm.allreduce_hist([s.buffer(RTX_BUF_HIST, nq) for s in self.shards])
+            self.comm.allreduce_hist([s.buffer(RTX_BUF_HIST, nq, sb) for s in self.shards])
             torch.cuda.synchronize()
             for s in self.shards:
                 s.prob(sb)
             for s in self.shards:
                 s.sync()
-            parts = self.comm.allgather_prefix([s.buffer(RTX_BUF_PREFIX, nq) for s in self.shards])
+            parts = self.comm.allgather_prefix([s.buffer(RTX_BUF_PREFIX, nq, sb) for s in self.shards])
             pref = assemble_prefix(parts)
             torch.cuda.synchronize()
             for s in self.shards:
                 s.walk(sb, pref)
+            for s in self.shards:
+                s.sync()
+        return self.shards[0].download(copy=copy)
+
+
+class KmerShardedClassifier:
+    """SURVEY.md 8e mode A: the k-mer space is sharded, every rank counts ALL references against its k-mers, and the
+    per-reference hit counts are all-reduced (u16 [n][N] per sub-batch: 2 N bytes per query over xGMI -- the literal
+    wording of BASELINE.json configs[4]; mode B above moves 2.6 KB per query instead).  After the all-reduce every
+    rank holds the complete counts and finishes the classification on its own; rank 0's results are reported."""
+
+    def __init__(self, shards: Sequence[KmerShardIndex], comm):
+        self.shards, self.comm = list(shards), comm
+
+    def upload(self, bases, base_off, exact_ids=None, exact_off=None):
+        for s in self.shards:
+            s.upload(bases, base_off, exact_ids, exact_off)
+        self._n_q = len(base_off) - 1
+
+    def classify(self, bases, base_off, exact_ids=None, exact_off=None, skip_exact_matches: bool = False) -> Result:
+        self.upload(bases, base_off, exact_ids, exact_off)
+        return self.run(skip_exact_matches)
+
+    def run(self, skip_exact_matches: bool = False, copy: bool = True):
+        import torch
+
+        flags = _lib.RTX_SKIP_EXACT_MATCHES if skip_exact_matches else 0
+        n_sub, B = self.shards[0].begin()
+        for s in self.shards[1:]:
+            assert s.begin() == (n_sub, B)
+        n_q = self._n_q
+        for sb in range(n_sub):
+            nq = min(B, n_q - sb * B)
+            for s in self.shards:
+                s.count(sb, flags)
+            for s in self.shards:
+                s.sync()
+            self.comm.allreduce_counts([s.buffer(RTX_BUF_COUNTS, nq, sb) for s in self.shards])
+            torch.cuda.synchronize()
+            for s in self.shards:
+                s.rehist(sb)
+                s.prob(sb)
+                s.walk(sb, s.buffer(RTX_BUF_PREFIX, nq, sb))
             for s in self.shards:
                 s.sync()
         return self.shards[0].download(copy=copy)

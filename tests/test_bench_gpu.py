@@ -49,5 +49,9 @@ def test_shard_db_mode_runs():
     r = bench("--shard-db", "--refs", 2000, "--queries", 256, "--steps", 1, "--warmup", 1, "--no-cpu-baseline")
     assert r["scaling"] == "strong" and r["config"]["classified_ok"] == 256
     assert r["roofline"] is not None and r["roofline"]["launch_ms"] > 0
-    r2 = bench("--shard-db", "--gpus", 2, "--backend", "gloo", "--refs", 3000, "--queries", 300, "--steps", 1, "--warmup", 1)
+    r2 = bench("--shard-db", "--gpus", 2, "--backend", "gloo", "--refs", 3000, "--queries", 300, "--steps", 1, "--warmup", 1,
+               "--sub-batch", 64)   # several sub-batches: the pipelined exchange (histogram all-reduce beside the next count)
     assert r2["n_gpus"] == 2 and r2["config"]["classified_ok"] == 300
+    r3 = bench("--shard-db", "--shard-mode", "kmers", "--gpus", 2, "--backend", "gloo", "--refs", 3000, "--queries", 300,
+               "--steps", 1, "--warmup", 1, "--sub-batch", 64)
+    assert r3["n_gpus"] == 2 and r3["config"]["classified_ok"] == 300 and "k-mers sharded" in r3["config"]["parallelism"]

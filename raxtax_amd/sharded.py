@@ -77,7 +77,11 @@ class _StagedMixin:
         """Device buffer of sub-batch sb (a staged run alternates between two scratch sets) as a torch tensor."""
         p, stride = C.c_void_p(), C.c_uint64()
         check(self._lib.rtx_shard_buffer(self._h, sb, which, C.byref(p), C.byref(stride)))
-        typ = {RTX_BUF_HIST: "<i4", RTX_BUF_PREFIX: "<f8", RTX_BUF_COUNTS: "<i2"}[which]
+        if which == RTX_BUF_COUNTS:
+            # u16 counts, seen as int32 pairs: RCCL and gloo reduce no 16-bit integers, and adding the pairs adds both
+            # halves correctly -- the summed counts stay <= t <= 65535, so the low half never carries into the high one
+            return device_tensor(p.value, (n_rows, stride.value // 2), "<i4", self.device)
+        typ = {RTX_BUF_HIST: "<i4", RTX_BUF_PREFIX: "<f8"}[which]
         return device_tensor(p.value, (n_rows, stride.value), typ, self.device)
 
     @property
@@ -201,7 +205,7 @@ class TorchComm:
         current stream (not the host) wait for it."""
         return self.dist.all_reduce(t, async_op=True)
 
-    allreduce_counts = allreduce_hist   # int16 view of the u16 counts (counts < 2^15 for t <= 32767)
+    allreduce_counts = allreduce_hist   # int32 view of pairs of u16 counts (_StagedMixin.buffer)
 
     def allgather_prefix(self, locals_):
         import torch

@@ -185,7 +185,9 @@ int rtx_index_set_batch(rtx_index *index, uint32_t sub_batch);
 #define RTX_OPT_STREAMS 3 /* 1 (default) = one HIP stream; 2 = the two small latency-bound kernels (kmer_extract of
                              sub-batch i+2, lineage_walk of sub-batch i) run on a side stream beside hit_count of
                              sub-batch i+1.  Measured: no gain on MI355X (hit_count slows down by what is hidden),
-                             and putting prob/prefix beside hit_count costs it its L2 hit rate */
+                             and putting prob/prefix beside hit_count costs it its L2 hit rate;
+                             3 = prob_lookup + taxon_prefix + walk of sub-batch i on the side stream beside kmer_extract +
+                             hit_count of sub-batch i+1 (two scratch sets) */
 #define RTX_OPT_CLUSTER 7 /* 1 (default): the queries of a batch are processed in an order that puts related
                              queries next to each other (min-hash sketches, rtx_cluster.hip) so that bitmap rows
                              are reused; 0: input order.  Results are identical and always in input order. */
@@ -199,7 +201,9 @@ int rtx_index_set_option(rtx_index *index, int option, uint64_t value);
 /* Process-wide default for handles created afterwards.  RTX_DEFAULT_SEGMENT_CLASSES (default 1): at index creation
  * every (row, tile) segment of the bitmaps is classified; empty segments are never read and segments with at most
  * 16 references are added from 32-byte slots through byte counters instead of 1-KiB row reads (rtx_segments.hip).
- * 0: every segment is read densely (for A/B measurements; results are identical). */
+ * 2: segments with 17-64 references are kept as 128 bytes of bit positions that hit_count scatters into a row image
+ * in LDS (17 % fewer bytes requested at N = 500k, but no faster: the scatter and fold cost what the row read did);
+ * 0: every segment is read densely.  Results are identical for every value (A/B measurements). */
 #define RTX_DEFAULT_SEGMENT_CLASSES 1
 int rtx_set_default_option(int option, uint64_t value);
 

@@ -213,7 +213,7 @@ class Index:
     """Device-resident index + batch workspace of one GPU (rtx_index)."""
 
     def __init__(self, tree: Tree, device: int = 0, sub_batch: int = 0, prob_mode: int = 0, streams: int = 0,
-                 stage_timing: bool = False, cluster: Optional[bool] = None, segment_classes: bool = True,
+                 stage_timing: bool = False, cluster: Optional[bool] = None, segment_classes=1,
                  packed_counts: Optional[bool] = None, hit_quad: Optional[bool] = None):
         self._lib = _lib.load()
         self.tree = tree

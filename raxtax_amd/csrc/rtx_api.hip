@@ -128,8 +128,10 @@ struct rtx_index {
     uint32_t ntiles = 0;        // 8192-reference tiles
     DevBuf<uint32_t> d_bitmap, d_row_of, d_list_len;
     // segment classes (rtx_segments.hip): class / sparse slot of every (row, tile) segment, slots of 32 local ids
-    DevBuf<uint32_t> d_seginfo, d_seg_sbase;
-    DevBuf<unsigned long long> d_seg_dbits, d_seg_sbits;
+    DevBuf<uint32_t> d_seginfo, d_seg_sbase, d_seg_mbase;
+    DevBuf<unsigned long long> d_seg_dbits, d_seg_sbits, d_seg_mbits;
+    DevBuf<uint16_t> d_midslots;  // [n_mid_slots][kSegMidEntries] positions of the mid segments
+    uint64_t n_mid_slots = 0;
     uint32_t seg_blocks = 0;  // > 0: kmer_extract uses the bit tables (many tiles)
     DevBuf<uint16_t> d_segslots;
     uint64_t n_seg_slots = 0;
@@ -177,7 +179,7 @@ struct rtx_index {
     uint32_t sub_batch_req = 0, sub_batch = 0;
     struct Scratch {
         DevBuf<uint16_t> d_kmers, d_counts;
-        DevBuf<uint32_t> d_rows, d_t, d_nrows, d_hist, d_order, d_srows, d_nsparse;
+        DevBuf<uint32_t> d_rows, d_t, d_nrows, d_hist, d_order, d_srows, d_nsparse, d_mrows, d_nmid;
         DevBuf<unsigned long long> d_dmask;
         DevBuf<double> d_table_z, d_prefix;
     } sc[2];
@@ -191,7 +193,7 @@ struct rtx_index {
     DevBuf<uint16_t> d_counts_dbg;
     // ---- per-query results
     DevBuf<uint8_t> d_status;
-    DevBuf<uint32_t> d_t_all, d_nrows_all, d_n_rows, d_flags, d_ndist;
+    DevBuf<uint32_t> d_t_all, d_nrows_all, d_n_rows, d_flags, d_ndist, d_nmid_all;
     DevBuf<double> d_gs, d_z;
     DevBuf<unsigned long long> d_hq, d_row_start, d_cursor;
     DevBuf<DevRow> d_arena;
@@ -314,6 +316,11 @@ int enqueue_kmer(rtx_index *ix, const SubBatch &b, hipStream_t s) {
     kp.seg_sbits = ix->d_seg_sbits.p;
     kp.seg_sbase = ix->d_seg_sbase.p;
     kp.seg_blocks = ix->seg_blocks;
+    kp.seg_mbits = ix->n_mid_slots && ix->seg_blocks ? ix->d_seg_mbits.p : nullptr;
+    kp.seg_mbase = ix->d_seg_mbase.p;
+    kp.mrows = sc.d_mrows.p;
+    kp.nmid = sc.d_nmid.p;
+    kp.nmid_all = ix->d_nmid_all.p;
     kp.rows = sc.d_rows.p;
     kp.rstride = ix->rstride;
     kp.dmask = sc.d_dmask.p;
@@ -347,6 +354,9 @@ int enqueue_hit(rtx_index *ix, const SubBatch &b, uint32_t flags, hipStream_t s)
     hp.zero_row = ix->n_rows;
     hp.srows = sc.d_srows.p;
     hp.nsparse = sc.d_nsparse.p;
+    hp.mrows = sc.d_mrows.p;
+    hp.nmid = ix->n_mid_slots ? sc.d_nmid.p : nullptr;
+    hp.midslots = ix->d_midslots.p;
     hp.segslots = ix->d_segslots.p;
     hp.ntiles = ix->ntiles;
     hp.t = sc.d_t.p;
@@ -527,7 +537,8 @@ int enqueue_batch(rtx_index *ix, uint32_t flags) {
     // sub-batch i and kmer_extract of sub-batch i+2 run on a side stream beside hit_count of sub-batch i+1; the two
     // scratch sets alternate.  (Their memory footprint is tiny: hit_count keeps its L2 hit rate, unlike with
     // prob/prefix beside it.)
-    const bool two = ix->n_streams == 2;
+    const bool three = ix->n_streams == 2 && ix->n_streams_req == 3;  // prob/prefix/walk of sub-batch i beside the counting of i+1
+    const bool two = ix->n_streams == 2 && !three;
     ix->stream_dl = false;
     if (n_sub <= 4096) {  // per sub-batch: completion event (+ cursor snapshot) for the streamed download
         if (!ix->copy_stream) RTX_HIP(hipStreamCreateWithFlags(&ix->copy_stream, hipStreamNonBlocking));
@@ -543,11 +554,40 @@ int enqueue_batch(rtx_index *ix, uint32_t flags) {
         if ((rc = ix->h_cursor_sub.resize(n_sub))) return rc;
         ix->n_sub_run = n_sub;
         ix->stream_dl = true;
-    } else if (two) {
+    } else if (two || three) {
         set_error("two streams need at most 4096 sub-batches");
         return RTX_ERR_INVALID;
     }
     hipStream_t side = ix->stream2;
+    if (three) {
+        // RTX_OPT_STREAMS = 3: the main stream counts (kmer_extract + hit_count: the L2 request path and half the VALU),
+        // the side stream does prob_lookup + taxon_prefix with the walk (VALU and an HBM stream) of the sub-batch
+        // before; two scratch sets alternate
+        const bool fuse = ix->n_refs == ix->n_total && ix->n_bnd_local == ix->n_bnd;
+        RTX_HIP(hipEventRecord(ix->ev_fork, ix->stream));
+        RTX_HIP(hipStreamWaitEvent(side, ix->ev_fork, 0));
+        for (uint32_t sb = 0; sb < n_sub; sb++) {
+            SubBatch b = sub_batch_of(ix, sb, timed);
+            if (sb >= 2) RTX_HIP(hipStreamWaitEvent(b.s, ix->ev_pre[sb - 2], 0));  // this scratch set is free again
+            if ((rc = enqueue_count(ix, b, flags))) return rc;
+            RTX_HIP(hipEventRecord(ix->ev_cnt[sb], b.s));
+            RTX_HIP(hipStreamWaitEvent(side, ix->ev_cnt[sb], 0));
+            b.s = side;
+            if ((rc = enqueue_prob_prefix(ix, b, fuse))) return rc;
+            if (!fuse && (rc = enqueue_walk(ix, b, ix->sc[b.set].d_prefix.p, side))) return rc;
+            if (fuse && b.timed_all) {
+                RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_LINEAGE_WALK, 0), side));
+                RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_LINEAGE_WALK, 1), side));
+            }
+            RTX_HIP(hipEventRecord(ix->ev_pre[sb], side));
+            RTX_HIP(hipMemcpyAsync(&ix->h_cursor_sub[sb], ix->d_cursor.p, 8, hipMemcpyDeviceToHost, side));
+            RTX_HIP(hipEventRecord(ix->ev_sub[sb], side));
+        }
+        RTX_HIP(hipEventRecord(ix->ev_join, side));
+        RTX_HIP(hipStreamWaitEvent(ix->stream, ix->ev_join, 0));
+        RTX_HIP(hipGetLastError());
+        return RTX_OK;
+    }
     if (two) {  // the side stream starts after the resets above; it extracts the k-mers of the first two sub-batches
         RTX_HIP(hipEventRecord(ix->ev_fork, ix->stream));
         RTX_HIP(hipStreamWaitEvent(side, ix->ev_fork, 0));
@@ -667,7 +707,7 @@ int prepare_workspace(rtx_index *ix, uint64_t n_queries, uint64_t tmax, uint64_t
     // ---- per-query results
     if ((rc = ix->d_status.alloc(n_queries)) || (rc = ix->d_t_all.alloc(n_queries)) || (rc = ix->d_nrows_all.alloc(n_queries)) ||
         (rc = ix->d_n_rows.alloc(n_queries)) || (rc = ix->d_gs.alloc(n_queries)) || (rc = ix->d_z.alloc(n_queries)) ||
-        (rc = ix->d_hq.alloc(n_queries)) || (rc = ix->d_row_start.alloc(n_queries)) || (rc = ix->d_ndist.alloc(n_queries)))
+        (rc = ix->d_hq.alloc(n_queries)) || (rc = ix->d_row_start.alloc(n_queries)) || (rc = ix->d_ndist.alloc(n_queries)) || (rc = ix->d_nmid_all.alloc(n_queries)))
         return rc;
     const uint64_t want_arena = n_queries * 8 + 4096;
     if (ix->arena_cap < want_arena) {
@@ -681,7 +721,7 @@ int prepare_workspace(rtx_index *ix, uint64_t n_queries, uint64_t tmax, uint64_t
         RTX_HIP(hipEventCreateWithFlags(&ix->ev_fork, hipEventDisableTiming));
         RTX_HIP(hipEventCreateWithFlags(&ix->ev_join, hipEventDisableTiming));
     }
-    const uint64_t per_q = ((uint64_t)ix->kstride * 2 + (uint64_t)ix->rstride * 4 + (uint64_t)ix->ntiles * (ix->rstride / 8 + (kSegMaxSparseRows + 1) * 4 + 8) + (ix->packed() ? ix->npad * 5 / 4 : ix->npad * 2) + (uint64_t)ix->hstride * 12 +
+    const uint64_t per_q = ((uint64_t)ix->kstride * 2 + (uint64_t)ix->rstride * 4 + (uint64_t)ix->ntiles * (ix->rstride / 8 + ((kSegMaxSparseRows + 1) * 4 + (kSegMaxMidRows + 1) * 4 + 12)) + (ix->packed() ? ix->npad * 5 / 4 : ix->npad * 2) + (uint64_t)ix->hstride * 12 +
                             (uint64_t)ix->n_bnd_local * 8 + 64) * ix->n_streams;
     uint32_t B = ix->sub_batch_req;
     if (B == 0) {
@@ -709,6 +749,7 @@ int alloc_scratch_set(rtx_index *ix, uint32_t k) {
         rtx_index::Scratch &sc = ix->sc[k];
         if ((rc = sc.d_kmers.alloc((size_t)B * ix->kstride)) || (rc = sc.d_rows.alloc((size_t)B * ix->rstride)) || (rc = sc.d_dmask.alloc((size_t)B * ix->ntiles * (ix->rstride / 64))) ||
             (rc = sc.d_nsparse.alloc((size_t)B * ix->ntiles)) || (rc = sc.d_srows.alloc((size_t)B * ix->ntiles * (kSegMaxSparseRows + 1))) ||
+            (rc = sc.d_nmid.alloc((size_t)B * ix->ntiles)) || (rc = sc.d_mrows.alloc((size_t)B * ix->ntiles * (kSegMaxMidRows + 1))) ||
             (rc = sc.d_t.alloc(B)) || (rc = sc.d_nrows.alloc(B)) || (rc = sc.d_counts.alloc(counts_elems(ix, B))) ||
             (rc = sc.d_hist.alloc((size_t)B * ix->hstride)) || (rc = sc.d_table_z.alloc((size_t)B * ix->hstride)) ||
             (rc = sc.d_prefix.alloc((size_t)B * ix->n_bnd_local)) || (rc = sc.d_order.alloc(B)))
@@ -948,7 +989,7 @@ int rtx_index_create_shard(int device, uint64_t n_refs_total, uint64_t ref_lo, u
 }
 
 // RTX_DEFAULT_SEGMENT_CLASSES (rtx_set_default_option): 0 = every segment is read densely (A/B measurements)
-static uint64_t g_seg_classes = 1;
+static uint64_t g_seg_classes = 1;  // 2 (mid segments as lists) moves 17 % fewer bytes but is no faster: DESIGN.md section 3
 
 // Classifies every (row, tile) segment of the finished bitmap as empty / dense / sparse and writes the slots of the
 // sparse ones (rtx_segments.hip).  Slots are numbered in (row, tile) order: deterministic.
@@ -957,7 +998,7 @@ static int build_segments(rtx_index *ix) {
     const uint32_t ss = (nt + 3u) & ~3u;  // seginfo rows padded to whole uint4
     ix->seg_stride = ss;
     const size_t n = (size_t)n_rows1 * nt;
-    const bool sparse_on = g_seg_classes != 0, empty_on = g_seg_classes != 0;
+    const bool sparse_on = g_seg_classes != 0, empty_on = g_seg_classes != 0, mid_on = g_seg_classes >= 2;
     DevBuf<uint16_t> d_pop;
     int rc;
     if ((rc = d_pop.alloc(n)) || (rc = ix->d_seginfo.alloc((size_t)n_rows1 * ss))) return rc;
@@ -967,29 +1008,35 @@ static int build_segments(rtx_index *ix) {
     std::vector<uint16_t> pop(n);
     RTX_HIP(hipMemcpy(pop.data(), d_pop.p, n * 2, hipMemcpyDeviceToHost));
     std::vector<uint32_t> info((size_t)n_rows1 * ss, 0u);
-    uint64_t slots = 0;
-    const bool last_full = ix->stride_bytes % 1024u == 0;  // hit_count's byte counters want 64-lane tiles
+    uint64_t slots = 0, mslots = 0;
+    const bool last_full = ix->stride_bytes % 1024u == 0;  // hit_count's byte counters and row images want 64-lane tiles
     for (uint32_t r = 0; r < n_rows1; r++)
         for (uint32_t t = 0; t < nt; t++) {
             const uint32_t c = pop[(size_t)r * nt + t];
             uint32_t &o = info[(size_t)r * ss + t];
+            const bool full_tile = t + 1 < nt || last_full;
             if (c == 0) o = empty_on ? 0u : 1u;
-            else if (c <= kSegSparseMax && sparse_on && (t + 1 < nt || last_full)) o = (uint32_t)(2 + slots++);
+            else if (c <= kSegSparseMax && sparse_on && full_tile) o = (uint32_t)(2 + slots++);
+            else if (c <= kSegMidMax && mid_on && full_tile) o = 0x80000000u | (uint32_t)(mslots++);
             else o = 1u;
         }
+    if (slots > 0x7FFFFFF0ull || mslots > 0x7FFFFFF0ull) { set_error("too many sparse segments"); return RTX_ERR_INVALID; }
     // many tiles: the classes as bit tables per block of 64 tiles (kmer_extract transposes 64 rows x 64 tiles at a time)
     ix->seg_blocks = nt > 12 ? (nt + 63) / 64 : 0;
     if (ix->seg_blocks) {
         const uint32_t nb = ix->seg_blocks;
-        std::vector<unsigned long long> dbits((size_t)n_rows1 * nb, 0), sbits((size_t)n_rows1 * nb, 0);
-        std::vector<uint32_t> sbase((size_t)n_rows1 * nb, 0);
+        std::vector<unsigned long long> dbits((size_t)n_rows1 * nb, 0), sbits((size_t)n_rows1 * nb, 0), mbits((size_t)n_rows1 * nb, 0);
+        std::vector<uint32_t> sbase((size_t)n_rows1 * nb, 0), mbase((size_t)n_rows1 * nb, 0);
         for (uint32_t r = 0; r < n_rows1; r++)
             for (uint32_t b = 0; b < nb; b++) {
-                bool first = true;
+                bool first = true, mfirst = true;
                 for (uint32_t t = b * 64; t < nt && t < b * 64 + 64; t++) {
                     const uint32_t o = info[(size_t)r * ss + t];
                     if (o == 1u) dbits[(size_t)r * nb + b] |= 1ull << (t & 63u);
-                    else if (o >= 2u) {
+                    else if (o >> 31) {
+                        mbits[(size_t)r * nb + b] |= 1ull << (t & 63u);
+                        if (mfirst) { mbase[(size_t)r * nb + b] = o & 0x7FFFFFFFu; mfirst = false; }
+                    } else if (o >= 2u) {
                         sbits[(size_t)r * nb + b] |= 1ull << (t & 63u);
                         if (first) { sbase[(size_t)r * nb + b] = o - 2u; first = false; }
                     }
@@ -999,14 +1046,20 @@ static int build_segments(rtx_index *ix) {
         RTX_HIP(hipMemcpy(ix->d_seg_dbits.p, dbits.data(), dbits.size() * 8, hipMemcpyHostToDevice));
         RTX_HIP(hipMemcpy(ix->d_seg_sbits.p, sbits.data(), sbits.size() * 8, hipMemcpyHostToDevice));
         RTX_HIP(hipMemcpy(ix->d_seg_sbase.p, sbase.data(), sbase.size() * 4, hipMemcpyHostToDevice));
+        if (mslots) {
+            if ((rc = ix->d_seg_mbits.alloc(mbits.size())) || (rc = ix->d_seg_mbase.alloc(mbase.size()))) return rc;
+            RTX_HIP(hipMemcpy(ix->d_seg_mbits.p, mbits.data(), mbits.size() * 8, hipMemcpyHostToDevice));
+            RTX_HIP(hipMemcpy(ix->d_seg_mbase.p, mbase.data(), mbase.size() * 4, hipMemcpyHostToDevice));
+        }
     }
-    if (slots > 0xFFFFFFF0ull) { set_error("too many sparse segments"); return RTX_ERR_INVALID; }
     ix->n_seg_slots = slots;
-    if ((rc = ix->d_segslots.alloc((slots ? slots : 1) * kSegSlotEntries))) return rc;
+    ix->n_mid_slots = mslots;
+    if ((rc = ix->d_segslots.alloc((slots ? slots : 1) * kSegSlotEntries)) || (rc = ix->d_midslots.alloc((mslots ? mslots : 1) * kSegMidEntries))) return rc;
     RTX_HIP(hipMemset(ix->d_segslots.p, 0xFF, (slots ? slots : 1) * kSegSlotEntries * 2));
+    RTX_HIP(hipMemset(ix->d_midslots.p, 0xFF, (mslots ? mslots : 1) * kSegMidEntries * 2));
     RTX_HIP(hipMemcpy(ix->d_seginfo.p, info.data(), info.size() * 4, hipMemcpyHostToDevice));
-    if (slots) {
-        launch_seg_emit(ix->stream, ix->d_bitmap.p, ix->stride_bytes, n_rows1, nt, ix->d_seginfo.p, ss, ix->d_segslots.p);
+    if (slots || mslots) {
+        launch_seg_emit(ix->stream, ix->d_bitmap.p, ix->stride_bytes, n_rows1, nt, ix->d_seginfo.p, ss, ix->d_segslots.p, ix->d_midslots.p);
         RTX_HIP(hipGetLastError());
         RTX_HIP(hipStreamSynchronize(ix->stream));
     }
@@ -1133,7 +1186,7 @@ void rtx_index_destroy(rtx_index *index) {
 uint64_t rtx_index_num_refs(const rtx_index *index) { return index ? index->n_total : 0; }
 uint64_t rtx_index_device_bytes(const rtx_index *index) {
     if (!index) return 0;
-    return index->d_seg_dbits.n * 8 + index->d_seg_sbits.n * 8 + index->d_seg_sbase.n * 4 + index->d_seginfo.n * 4 + index->d_segslots.n * 2 + index->d_bitmap.n * 4 + index->d_row_of.n * 4 + index->d_list_len.n * 4 + index->d_lnfact.n * 8 +
+    return index->d_seg_dbits.n * 8 + index->d_seg_sbits.n * 8 + index->d_seg_sbase.n * 4 + index->d_seginfo.n * 4 + index->d_segslots.n * 2 + index->d_midslots.n * 2 + index->d_seg_mbits.n * 8 + index->d_seg_mbase.n * 4 + index->d_bitmap.n * 4 + index->d_row_of.n * 4 + index->d_list_len.n * 4 + index->d_lnfact.n * 8 +
            index->d_noderec.n * 16 + index->d_bnd_bits.n + index->d_bnd_rank.n * 4;
 }
 int rtx_index_set_batch(rtx_index *index, uint32_t sub_batch) {
@@ -1143,7 +1196,7 @@ int rtx_index_set_batch(rtx_index *index, uint32_t sub_batch) {
 }
 
 int rtx_set_default_option(int option, uint64_t value) {
-    if (option == RTX_DEFAULT_SEGMENT_CLASSES) { g_seg_classes = value ? 1 : 0; return RTX_OK; }
+    if (option == RTX_DEFAULT_SEGMENT_CLASSES) { g_seg_classes = value > 2 ? 2 : value; return RTX_OK; }
     set_error("rtx_set_default_option: unknown option %d", option);
     return RTX_ERR_INVALID;
 }
@@ -1153,7 +1206,7 @@ int rtx_index_set_option(rtx_index *index, int option, uint64_t value) {
     switch (option) {
         case RTX_OPT_SUB_BATCH: index->sub_batch_req = (uint32_t)value; return RTX_OK;
         case RTX_OPT_STREAMS:
-            if (value < 1 || value > 2) break;
+            if (value < 1 || value > 3) break;
             index->n_streams_req = (uint32_t)value;
             return RTX_OK;
         case RTX_OPT_STAGE_TIMING:
@@ -1546,9 +1599,13 @@ int rtx_batch_work(rtx_index *ix, uint64_t *sum_hits, uint64_t *sum_query_bytes,
     RTX_HIP(hipMemcpy(ix->h_nrows_all.data(), ix->d_nrows_all.p, ix->n_q * 4, hipMemcpyDeviceToHost));
     uint64_t h = 0, b = 0;
     const uint64_t row_bytes = ((ix->n_refs + 7) / 8 + ix->ntiles - 1) / ix->ntiles;  // per dense segment (nrows counts segments)
+    std::vector<uint32_t> nmid(ix->n_q);
+    RTX_HIP(hipMemcpy(nmid.data(), ix->d_nmid_all.p, ix->n_q * 4, hipMemcpyDeviceToHost));
+    uint64_t mid_bytes = 0;
     for (uint64_t q = 0; q < ix->n_q; q++) {
         h += ix->h_hq[q];
         b += (uint64_t)ix->h_nrows_all[q] * row_bytes;
+        mid_bytes += (uint64_t)nmid[q] * kSegMidEntries * 2;  // a mid segment travels as 128 bytes of positions
     }
     if (ix->quad_used) {  // rows were loaded once per group of four queries: the union rows every workgroup counted
         const uint32_t n_sub = (uint32_t)((ix->n_q + ix->sub_batch - 1) / ix->sub_batch);
@@ -1557,6 +1614,7 @@ int rtx_batch_work(rtx_index *ix, uint64_t *sum_hits, uint64_t *sum_query_bytes,
         b = 0;
         for (uint32_t v : gr) b += (uint64_t)v * row_bytes;
     }
+    b += mid_bytes;
     if (sum_hits) *sum_hits = h;
     if (sum_query_bytes) *sum_query_bytes = ix->sum_query_bytes;
     if (bitmap_bytes_read) *bitmap_bytes_read = b;

@@ -60,6 +60,63 @@ __device__ __forceinline__ uint4 csa_plane(uint32_t (&pl)[4][NP], const uint4 &a
 
 
 // ---------------------------------------------------------------------------
+// The mid segments of a (query, tile) wave (17 .. kSegMidMax references: 128 bytes of positions instead of a 1-KiB row
+// segment).  Lane l takes entry l of a segment (one 128-byte load per segment), the wave scatters the positions into a
+// zeroed row image in LDS with ONE ds_or, reads the image back as the 16 bytes per lane a dense row would have
+// delivered, and folds eight such rows with the same carry-save tree.  rowbuf: 8 KiB of this wave (eight row images:
+// the row-list / histogram and byte-counter regions, both free between the row loop and the epilogue).
+// ---------------------------------------------------------------------------
+template <int NP>
+__device__ __forceinline__ void hit_mid_rows(const HitParams &p, uint32_t (&pl)[4][NP], uint32_t q, uint32_t tile, uint32_t lane,
+                                             uint32_t *rowbuf) {
+    if (!p.nmid) return;
+#ifdef RTX_EXP_NO_MID_FOLD
+    return;  // experiment (tools/quad_variants.sh): what the dense loop gains when the mid rows cost nothing (wrong counts)
+#endif
+    const uint32_t nm = p.nmid[(size_t)q * p.ntiles + tile];
+    if (nm == 0) return;
+    const uint32_t *mrows = p.mrows + ((size_t)q * p.ntiles + tile) * (kSegMaxMidRows + 1);
+    uint4 *img = reinterpret_cast<uint4 *>(rowbuf);  // eight row images of 1 KiB
+    // entries of the eight segments from m0 on: lane l takes entry l of each (a 128-byte load per segment); issued one
+    // group ahead, so that their latency hides behind the fold of the group before
+    auto entries = [&](uint32_t m0, uint32_t (&ent)[8]) {
+        const uint32_t sv = m0 + (lane & 7u) < nm ? mrows[m0 + (lane & 7u)] : 0xFFFFFFFFu;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const uint32_t slot = (uint32_t)__builtin_amdgcn_readlane((int)sv, j);
+            ent[j] = 0xFFFFu;
+            if (slot != 0xFFFFFFFFu) ent[j] = p.midslots[(size_t)slot * kSegMidEntries + lane];  // wave-uniform branch
+        }
+    };
+    uint32_t ent[8], nxt[8];
+    entries(0, ent);
+    for (uint32_t m0 = 0; m0 < nm; m0 += 8) {
+        if (m0 + 8 < nm) entries(m0 + 8, nxt);
+        wave_lds_sync();  // the images of the group before have been read
+#pragma unroll
+        for (int j = 0; j < 8; j++) img[j * 64 + lane] = make_uint4(0, 0, 0, 0);
+        wave_lds_sync();
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const uint32_t e = ent[j];
+            if (e != 0xFFFFu) atomicOr(&rowbuf[j * 256 + (e >> 5)], 1u << (e & 31u));
+        }
+        wave_lds_sync();
+        uint4 A[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) A[j] = img[j * 64 + lane];
+        const uint4 c3 = tree8<NP>(pl, A);
+        planes_ripple<NP, 3>(pl[0], c3.x);
+        planes_ripple<NP, 3>(pl[1], c3.y);
+        planes_ripple<NP, 3>(pl[2], c3.z);
+        planes_ripple<NP, 3>(pl[3], c3.w);
+#pragma unroll
+        for (int j = 0; j < 8; j++) ent[j] = nxt[j];
+    }
+    wave_lds_sync();  // the images become the histogram and the byte counters of the epilogue
+}
+
+// ---------------------------------------------------------------------------
 // Epilogue of a (query, tile) wave: the bit planes `pl` hold the hits through dense segments.  Zeroes exact matches
 // (raxtax.rs:65-68), unpacks the planes, adds the hits through sparse segments (byte counters in LDS, half a tile at
 // a time), stores the counts (u16, or packed 10 bits per reference), builds the histogram of prob.rs:13-19 with LDS

@@ -246,26 +246,34 @@ __global__ __launch_bounds__(64) void kmer_extract_kernel(KmerParams p) {
     const uint32_t mstride = p.rstride >> 6;
     unsigned long long *dm = p.dmask + (size_t)q * nt * mstride;
     uint32_t *sout = p.srows + (size_t)q * nt * (kSegMaxSparseRows + 1);
-    uint32_t nseg = 0;
-    __shared__ unsigned long long l_sb[64];
-    __shared__ uint32_t l_base[64];
+    uint32_t nseg = 0, nmidseg = 0;
+    uint32_t *mout = p.mrows + (size_t)q * nt * (kSegMaxMidRows + 1);
+    __shared__ unsigned long long l_sb[64], l_mb[64];
+    __shared__ uint32_t l_base[64], l_mbase[64];
     for (uint32_t tb = 0; p.seg_blocks && tb < nt; tb += 64) {  // many tiles: 64 rows x 64 tiles per step
         const uint32_t blk = tb >> 6;
         const uint32_t tile = tb + lane;  // this lane's tile after the transposes
-        uint32_t cd = 0, cs = 0;
+        uint32_t cd = 0, cs = 0, cm = 0;
         for (uint32_t c = 0; c < nchunks; c++) {
             const uint32_t i = c * 64 + lane;
             const uint32_t row = i < nrows ? rout[i] : kEmptyRow;
-            unsigned long long db = 0, sb = 0;
-            uint32_t base = 0;
+            unsigned long long db = 0, sb = 0, mb = 0;
+            uint32_t base = 0, mbase = 0;
             if (row != kEmptyRow) {
                 db = p.seg_dbits[(size_t)row * p.seg_blocks + blk];
                 sb = p.seg_sbits[(size_t)row * p.seg_blocks + blk];
                 base = p.seg_sbase[(size_t)row * p.seg_blocks + blk];
+                if (p.seg_mbits) {
+                    mb = p.seg_mbits[(size_t)row * p.seg_blocks + blk];
+                    mbase = p.seg_mbase[(size_t)row * p.seg_blocks + blk];
+                }
             }
             l_sb[lane] = sb;
             l_base[lane] = base;
+            l_mb[lane] = mb;
+            l_mbase[lane] = mbase;
             unsigned long long dT = transpose64(db, lane), sT = transpose64(sb, lane);  // bit r = row c*64 + r
+            unsigned long long mT = p.seg_mbits ? transpose64(mb, lane) : 0ull;
             __syncthreads();
             if (tile < nt) {
                 // the first sparse rows (up to the 255 the byte counters of hit_count hold) go to the slot list ...
@@ -275,7 +283,14 @@ __global__ __launch_bounds__(64) void kmer_extract_kernel(KmerParams p) {
                     sout[(size_t)tile * (kSegMaxSparseRows + 1) + cs] = l_base[r] + (uint32_t)__popcll(l_sb[r] & lt_mask);
                     cs++;
                 }
-                dT |= sT;  // ... the rest is read densely
+                // ... the first mid rows to theirs ...
+                while (mT && cm < kSegMaxMidRows) {
+                    const int r = __builtin_ctzll(mT);
+                    mT &= mT - 1;
+                    mout[(size_t)tile * (kSegMaxMidRows + 1) + cm] = l_mbase[r] + (uint32_t)__popcll(l_mb[r] & lt_mask);
+                    cm++;
+                }
+                dT |= sT | mT;  // ... the rest is read densely
                 dm[(size_t)tile * mstride + c] = dT;
                 cd += (uint32_t)__popcll(dT);
             }
@@ -283,11 +298,13 @@ __global__ __launch_bounds__(64) void kmer_extract_kernel(KmerParams p) {
         }
         if (tile < nt) {
             p.nsparse[(size_t)q * nt + tile] = cs;
+            p.nmid[(size_t)q * nt + tile] = cm;
             nseg += cd;
+            nmidseg += cm;
         }
     }
     if (!p.seg_blocks) {  // few tiles (at most 12): one pass per tile; lane l keeps the counters of tile l
-        uint32_t cd = 0, cs = 0;
+        uint32_t cd = 0, cs = 0, cm = 0;
         const uint32_t nv = (nt + 3u) >> 2;  // seginfo rows are padded to whole uint4: four tiles per (gather) load
         for (uint32_t c0 = 0; c0 < nchunks; c0 += 4) {  // four chunks per turn, loads of a level together (see above)
             uint32_t row[4];
@@ -313,34 +330,45 @@ __global__ __launch_bounds__(64) void kmer_extract_kernel(KmerParams p) {
                     const uint32_t word = (tile & 3u) == 0 ? q4.x : (tile & 3u) == 1 ? q4.y : (tile & 3u) == 2 ? q4.z : q4.w;
                     const uint32_t code = row[u] != kEmptyRow ? word : 0u;
                     const uint32_t ns = (uint32_t)__builtin_amdgcn_readlane((int)cs, (int)tile);
-                    const bool sparse = code >= 2u;  // hit_count's byte counters hold 255 hits: more sparse rows are read densely
+                    const uint32_t nm = (uint32_t)__builtin_amdgcn_readlane((int)cm, (int)tile);
+                    const bool mid = (code >> 31) != 0u;  // 0x80000000 | mid slot
+                    const bool sparse = code >= 2u && !mid;  // hit_count's byte counters hold 255 hits: more sparse rows are read densely
                     const unsigned long long ms = __ballot(sparse);
                     const uint32_t srank = ns + (uint32_t)__popcll(ms & lt_mask);
                     const bool take = sparse && srank < kSegMaxSparseRows;
                     if (take) sout[(size_t)tile * (kSegMaxSparseRows + 1) + srank] = code - 2u;
-                    const unsigned long long md = __ballot(code == 1u || (code >= 2u && !take));
+                    const unsigned long long mm = __ballot(mid);
+                    const uint32_t mrank = nm + (uint32_t)__popcll(mm & lt_mask);
+                    const bool mtake = mid && mrank < kSegMaxMidRows;
+                    if (mtake) mout[(size_t)tile * (kSegMaxMidRows + 1) + mrank] = code & 0x7FFFFFFFu;
+                    const unsigned long long md = __ballot(code == 1u || (sparse && !take) || (mid && !mtake));
                     if (lane == tile) {
                         dm[(size_t)tile * mstride + c] = md;
                         cd += (uint32_t)__popcll(md);
                         const uint32_t ns2 = ns + (uint32_t)__popcll(ms);
                         cs = ns2 < kSegMaxSparseRows ? ns2 : kSegMaxSparseRows;
+                        const uint32_t nm2 = nm + (uint32_t)__popcll(mm);
+                        cm = nm2 < kSegMaxMidRows ? nm2 : kSegMaxMidRows;
                     }
                 }
             }
         }
         if (lane < nt) {
             p.nsparse[(size_t)q * nt + lane] = cs;
+            p.nmid[(size_t)q * nt + lane] = cm;
             nseg += cd;
+            nmidseg += cm;
         }
     }
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) { hq += __shfl_xor(hq, d, 64); nseg += __shfl_xor(nseg, d, 64); }
+    for (int d = 32; d >= 1; d >>= 1) { hq += __shfl_xor(hq, d, 64); nseg += __shfl_xor(nseg, d, 64); nmidseg += __shfl_xor(nmidseg, d, 64); }
     if (lane == 0) {
         p.t[q] = t;
         p.nrows[q] = nrows;
         p.hq[gq] = hq;
         p.t_all[gq] = t;
         p.nrows_all[gq] = nseg;
+        p.nmid_all[gq] = nmidseg;
     }
 }
 
@@ -474,6 +502,7 @@ __global__ __launch_bounds__(64, (NP <= 10 ? 4 : 2)) void hit_count_kernel(HitPa
             __syncthreads();  // the list is rewritten (next round) or becomes the histogram
         }
     }
+    hit_mid_rows<NP>(p, pl, q, tile, lane, hist_lds);  // 8 KiB from the start of this wave's LDS
     hit_epilogue<NP, kPacked>(p, pl, q, tile, lane, t, active, hist_lds, cnt8, ns, srows);
 }
 
@@ -1114,10 +1143,14 @@ void launch_prob_table(hipStream_t s, const ProbParams &p, uint32_t nq) {
 void launch_taxon_prefix(hipStream_t s, const PrefixParams &p, uint32_t nq) {
     size_t lds = p.tz_in_lds ? (size_t)p.hstride * sizeof(double) : 0;
     if (p.fuse_walk) lds = std::max(lds, sizeof(WalkLds));
-    if (p.tz_in_lds && p.packed) hipLaunchKernelGGL((taxon_prefix_kernel<4, true, true>), dim3(nq), dim3(256), lds, s, p);
-    else if (p.tz_in_lds) hipLaunchKernelGGL((taxon_prefix_kernel<4, true, false>), dim3(nq), dim3(256), lds, s, p);
-    else if (p.packed) hipLaunchKernelGGL((taxon_prefix_kernel<4, false, true>), dim3(nq), dim3(256), lds, s, p);
-    else hipLaunchKernelGGL((taxon_prefix_kernel<4, false, false>), dim3(nq), dim3(256), lds, s, p);
+#ifndef RTX_PREFIX_NW
+#define RTX_PREFIX_NW 4
+#endif
+    constexpr int NW = RTX_PREFIX_NW;  // waves per query: NW * 512 references per sweep
+    if (p.tz_in_lds && p.packed) hipLaunchKernelGGL((taxon_prefix_kernel<NW, true, true>), dim3(nq), dim3(NW * 64), lds, s, p);
+    else if (p.tz_in_lds) hipLaunchKernelGGL((taxon_prefix_kernel<NW, true, false>), dim3(nq), dim3(NW * 64), lds, s, p);
+    else if (p.packed) hipLaunchKernelGGL((taxon_prefix_kernel<NW, false, true>), dim3(nq), dim3(NW * 64), lds, s, p);
+    else hipLaunchKernelGGL((taxon_prefix_kernel<NW, false, false>), dim3(nq), dim3(NW * 64), lds, s, p);
 }
 void launch_lineage_walk(hipStream_t s, const WalkParams &p, uint32_t nq) {
     hipLaunchKernelGGL(lineage_walk_kernel, dim3(nq), dim3(64), 0, s, p);

@@ -21,6 +21,11 @@ constexpr uint32_t kWalkMaxRows = 208;
 // 31.3 % <= 32); a (query, tile) pair takes at most kSegMaxSparseRows such segments through the
 // byte counters of hit_count (more are read as dense segments)
 constexpr uint32_t kSegSlotEntries = 16, kSegSparseMax = 16, kSegMaxSparseRows = 255;
+// "mid" segments, 17 .. kSegMidMax references (12 % of the requested segments at N = 500k, a fifth of the dense ones):
+// kept as kSegMidEntries positions (word << 5 | bit inside the 1-KiB segment, u16, 0xFFFF = unused) = 128 bytes instead
+// of 1 KiB; hit_count scatters them into a row image in LDS and folds that like a dense row.  At most kSegMaxMidRows per
+// (query, tile), the rest is read densely.
+constexpr uint32_t kSegMidMax = 64, kSegMidEntries = 64, kSegMaxMidRows = 127;
 // hit_count compacts the dense rows of its (query, tile) into an LDS list of this many row ids (+ padding), in
 // several rounds if they do not fit
 constexpr uint32_t kHitListCap = 1024;  // >= 200 rows of confidence >= 0.005 + fallback
@@ -48,12 +53,17 @@ struct KmerParams {
     // 64 rows x 64 tiles instead of a pass per tile): dense / sparse bits and the slot of the block's first sparse segment
     const unsigned long long *seg_dbits, *seg_sbits;  // [n_rows+1][seg_blocks]
     const uint32_t *seg_sbase;                        // [n_rows+1][seg_blocks]
+    const unsigned long long *seg_mbits;              // [n_rows+1][seg_blocks] mid segments, or null
+    const uint32_t *seg_mbase;                        // [n_rows+1][seg_blocks] mid slot of the block's first mid segment
     uint32_t seg_blocks;                              // ceil(ntiles / 64); 0 = use seginfo
     uint32_t *rows;     // [B][rstride] rows of the query's k-mers (ascending), padded with the zero row to a multiple of 64
     uint32_t rstride;
     unsigned long long *dmask;  // [B][ntiles][rstride/64] per tile: which of those rows have a dense segment there
     uint32_t *srows;    // [B][ntiles][kSegMaxSparseRows + 1] per tile: slots of the sparse segments
     uint32_t *nsparse;  // [B][ntiles]
+    uint32_t *mrows;    // [B][ntiles][kSegMaxMidRows + 1] per tile: slots of the mid segments
+    uint32_t *nmid;     // [B][ntiles]
+    uint32_t *nmid_all; // [n_q] mid segments over all tiles (work accounting)
     uint32_t *t;      // [B]
     uint32_t *nrows;  // [B] dense segments over all tiles (work accounting)
     unsigned long long *hq;  // [n_q]
@@ -77,6 +87,9 @@ struct HitParams {
     const uint32_t *srows;    // [B][ntiles][kSegMaxSparseRows + 1]
     const uint32_t *nsparse;  // [B][ntiles]
     const uint16_t *segslots; // [n_slots][kSegSlotEntries] local ids of the sparse segments
+    const uint32_t *mrows;    // [B][ntiles][kSegMaxMidRows + 1]
+    const uint32_t *nmid;     // [B][ntiles]
+    const uint16_t *midslots; // [n_mid][kSegMidEntries] positions (word << 5 | bit) of the mid segments
     uint32_t ntiles;
     const uint32_t *t;
     uint16_t *counts;  // [B][npad] u16 counts (more than 10 bit planes: t > 1023)
@@ -182,7 +195,7 @@ void launch_prob_lookup(hipStream_t s, const ProbParams &p, const ProbTables &tb
 // segment classes of the index (rtx_segments.hip)
 void launch_seg_popcount(hipStream_t s, const uint32_t *bitmap, uint32_t stride_bytes, uint32_t n_rows1, uint32_t ntiles, uint16_t *pop);
 void launch_seg_emit(hipStream_t s, const uint32_t *bitmap, uint32_t stride_bytes, uint32_t n_rows1, uint32_t ntiles,
-                     const uint32_t *seginfo, uint32_t seg_stride, uint16_t *slots);
+                     const uint32_t *seginfo, uint32_t seg_stride, uint16_t *slots, uint16_t *midslots);
 // processing order of a batch (rtx_cluster.hip)
 void launch_sketch(hipStream_t s, const uint8_t *bases, const uint64_t *off, uint32_t n_q, uint64_t *keys, uint32_t *idx);
 void launch_invert_perm(hipStream_t s, const uint32_t *perm, uint32_t n, uint32_t *inv);

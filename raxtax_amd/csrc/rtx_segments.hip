@@ -37,13 +37,15 @@ __global__ __launch_bounds__(64) void seg_popcount_kernel(const uint32_t *__rest
 // writes the local reference ids of every sparse segment into its slot; one wave per row
 __global__ __launch_bounds__(64) void seg_emit_kernel(const uint32_t *__restrict__ bitmap, uint32_t stride_bytes, uint32_t ntiles,
                                                       const uint32_t *__restrict__ seginfo, uint32_t seg_stride,
-                                                      uint16_t *__restrict__ slots) {
+                                                      uint16_t *__restrict__ slots, uint16_t *__restrict__ midslots) {
     const uint32_t row = blockIdx.x, lane = threadIdx.x;
     const char *base = reinterpret_cast<const char *>(bitmap) + (size_t)row * stride_bytes;
     for (uint32_t tile = 0; tile < ntiles; tile++) {
         const uint32_t code = seginfo[(size_t)row * seg_stride + tile];
         if (code < 2u) continue;  // wave-uniform
-        uint16_t *out = slots + (size_t)(code - 2u) * kSegSlotEntries;
+        const bool mid = code >> 31;  // mid segment: positions (word << 5 | bit) instead of local reference ids
+        uint16_t *out = mid ? midslots + (size_t)(code & 0x7FFFFFFFu) * kSegMidEntries : slots + (size_t)(code - 2u) * kSegSlotEntries;
+        const uint32_t cap = mid ? kSegMidEntries : kSegSlotEntries;
         const uint32_t col = tile * 1024u + lane * 16u;
         uint32_t w[4] = {0, 0, 0, 0};
         if (col < stride_bytes) {
@@ -60,7 +62,7 @@ __global__ __launch_bounds__(64) void seg_emit_kernel(const uint32_t *__restrict
                 const uint32_t b = (uint32_t)__ffs((int)x) - 1u;
                 x &= x - 1u;
                 const uint32_t g = ww * 4u + (b >> 3);  // inverse of ref_slot (rtx_math.hpp)
-                if (pos < kSegSlotEntries) out[pos] = (uint16_t)((g * L + lane) * 8u + (b & 7u));
+                if (pos < cap) out[pos] = mid ? (uint16_t)(((lane * 4u + ww) << 5) | b) : (uint16_t)((g * L + lane) * 8u + (b & 7u));
                 pos++;
             }
         }
@@ -71,8 +73,8 @@ void launch_seg_popcount(hipStream_t s, const uint32_t *bitmap, uint32_t stride_
     hipLaunchKernelGGL(seg_popcount_kernel, dim3(n_rows1), dim3(64), 0, s, bitmap, stride_bytes, ntiles, pop);
 }
 void launch_seg_emit(hipStream_t s, const uint32_t *bitmap, uint32_t stride_bytes, uint32_t n_rows1, uint32_t ntiles,
-                     const uint32_t *seginfo, uint32_t seg_stride, uint16_t *slots) {
-    hipLaunchKernelGGL(seg_emit_kernel, dim3(n_rows1), dim3(64), 0, s, bitmap, stride_bytes, ntiles, seginfo, seg_stride, slots);
+                     const uint32_t *seginfo, uint32_t seg_stride, uint16_t *slots, uint16_t *midslots) {
+    hipLaunchKernelGGL(seg_emit_kernel, dim3(n_rows1), dim3(64), 0, s, bitmap, stride_bytes, ntiles, seginfo, seg_stride, slots, midslots);
 }
 
 }  // namespace rtx

@@ -662,7 +662,7 @@ def _random_db(n_refs, length, seed, n_taxa=64):
     return lineages, seqs.reshape(-1), off
 
 
-@pytest.mark.parametrize("segment_classes", [True, False])
+@pytest.mark.parametrize("segment_classes", [2, 1, 0])
 def test_sparse_and_empty_segments(oracle, segment_classes):
     """Segment classes of the index (rtx_segments.hip): a database of short random references makes EVERY segment
     sparse (a k-mer occurs in ~6 of the 8192 references of a tile), a 658-base query then has ~640 sparse segments
@@ -696,7 +696,33 @@ def test_sparse_and_empty_segments(oracle, segment_classes):
             t, counts = otree.hit_counts(qs[q], skip_exact=skip)
             assert np.array_equal(ix.debug_hit_counts(q), counts), (segment_classes, skip, q)
             assert res.t[q] == t
-    rx.Index(tree, segment_classes=True)         # leave the process-wide default as it was
+    rx.Index(tree, segment_classes=1)            # leave the process-wide default as it was
+
+
+@pytest.mark.parametrize("n_refs", [3 * 8192, 4 * 8192 + 700])
+def test_mid_segments(oracle, n_refs):
+    """Segments with 17-64 references travel as 128 bytes of bit positions and are folded out of a row image in LDS
+    (rtx_hit_common.hpp: hit_mid_rows): same hit counts as with every segment read densely and as the oracle, with and
+    without --skip-exact-matches; full tiles and a partial last tile (no lists there); more mid rows in a tile than the
+    list takes (the rest is read densely)."""
+    db = synth.make_db(n_refs, fanouts=(3, 3, 3, 4, 4, 3))
+    qs = synth.make_queries(db, 96, exact_frac=0.2)
+    otree = oracle.tree_new_flat(db.lineages, db.seq_bytes, db.seq_off)
+    tree = rx.Tree.new_flat(db.lineages, db.seq_bytes, db.seq_off, kmer_map=False)
+    a, b = rx.Index(tree, segment_classes=2), rx.Index(tree, segment_classes=0)
+    rx.Index(tree, segment_classes=1)            # back to the process-wide default
+    ex = a.exact_matches(qs.bases, qs.base_off)
+    for skip in (False, True):
+        ra = a.classify(qs.bases, qs.base_off, *ex, skip_exact_matches=skip)
+        rb = b.classify(qs.bases, qs.base_off, *ex, skip_exact_matches=skip)
+        for f in ("row_off", "row_lineage", "row_conf", "row_local_signal", "global_signal", "t", "status"):
+            assert np.array_equal(getattr(ra, f), getattr(rb, f)), (skip, f)
+        for q in range(0, qs.n, 3):
+            c = a.debug_hit_counts(q)
+            assert np.array_equal(c, b.debug_hit_counts(q)), (skip, q)
+            assert np.array_equal(c, otree.hit_counts(qs.seq(q), skip_exact=skip)[1]), (skip, q)
+    wa, wb = a.work(), b.work()
+    assert wa["sum_hits"] == wb["sum_hits"] and wa["bitmap_bytes_read"] < 0.9 * wb["bitmap_bytes_read"]
 
 
 def test_long_queries_need_several_list_rounds(oracle):

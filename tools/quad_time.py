@@ -13,7 +13,9 @@ n_q = int(sys.argv[2]) if len(sys.argv) > 2 else 40960
 db = synth.make_db(500_000)
 qs = synth.make_queries(db, n_q)
 tree = rx.Tree.new_flat(db.lineages, db.seq_bytes, db.seq_off, kmer_map=False)
-ix = rx.Index(tree, hit_quad=quad, stage_timing=True)
+import os
+ix = rx.Index(tree, hit_quad=quad, stage_timing=True, segment_classes=int(os.environ.get("RTX_SEG_CLASSES", "1")),
+              streams=int(os.environ.get("RTX_STREAMS", "0")))
 ex = ix.exact_matches(qs.bases, qs.base_off)
 ix.upload(qs.bases, qs.base_off, *ex)
 for _ in range(3):

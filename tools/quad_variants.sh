@@ -12,9 +12,20 @@ build() {  # name, flags
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -fPIC -shared -o "$OUT/lib_$name.so" $objs "$OUT/quad_$name.o" -lpthread
   echo "built $OUT/lib_$name.so"
 }
+buildk() {  # name, flags: a variant of rtx_kernels.hip
+  local name=$1; shift
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I"$ROOT/include" -I"$ROOT/raxtax_amd/csrc" "$@" -x hip -c "$ROOT/raxtax_amd/csrc/rtx_kernels.hip" -o "$OUT/kern_$name.o"
+  objs=$(ls "$ROOT"/raxtax_amd/_obj/*.o | grep -v "rtx_kernels.hip.o")
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -fPIC -shared -o "$OUT/lib_$name.so" $objs "$OUT/kern_$name.o" -lpthread
+  echo "built $OUT/lib_$name.so"
+}
 for v in "$@"; do
   case $v in
     base) build base ;;
+    nomidfold) buildk nomidfold -DRTX_EXP_NO_MID_FOLD ;;
+    nw8) buildk nw8 -DRTX_PREFIX_NW=8 ;;
+    nw2) buildk nw2 -DRTX_PREFIX_NW=2 ;;
+    nw16) buildk nw16 -DRTX_PREFIX_NW=16 ;;
     p1) build p1 -DRTX_QUAD_AHEAD=1 ;;
     p2) build p2 -DRTX_QUAD_AHEAD=2 ;;
     nodma) build nodma -DRTX_QUAD_NO_DMA ;;

@@ -1,14 +1,16 @@
 #!/bin/bash
-# One gpurun call of a round: the GPU test-suite (recording the excused ties), the CPU scaling probe, profiles of
-# the bench at BASELINE configs[2] with the counts packed and as u16.
+# One gpurun call of a round: the GPU test-suite, the bench line as the driver takes it, profiles of the bench at
+# BASELINE configs[2] (kernel trace + PMC passes).  Usage: tools/gpu_round_check.sh <tag>
 set -u
-TAG=${1:-r2b}
+TAG=${1:-r2c}
 mkdir -p gpurun_out
-rm -f gpurun_out/excuses_$TAG.jsonl
-RTX_RECORD_EXCUSES=$PWD/gpurun_out/excuses_$TAG.jsonl timeout 2400 python -m pytest tests -m gpu -x -q -s --durations=15 > gpurun_out/${TAG}_tests.log 2>&1
+timeout 2400 python -m pytest tests -m gpu -x -q -s --durations=12 > gpurun_out/${TAG}_tests.log 2>&1
 echo "tests rc=$?"
 grep -E "passed|failed" gpurun_out/${TAG}_tests.log | tail -3
-timeout 900 python tools/cpu_scaling.py 500000 5 > gpurun_out/${TAG}_cpu_scaling.log 2>&1
-echo "cpu scaling rc=$?"; cat gpurun_out/${TAG}_cpu_scaling.log
-QPL=10240 bash tools/profile_bench.sh ${TAG}_u16 --u16-counts
 QPL=10240 bash tools/profile_bench.sh ${TAG}
+python tools/make_traffic.py --tag ${TAG} --refs 500000 --queries-per-launch 10240 --fetch gpurun_out/${TAG}_fetch --write gpurun_out/${TAG}_write --tcc gpurun_out/${TAG}_tcc --note "packed counts, default options"
+cp profiles/traffic.json profiles/${TAG}_pmc_summary.csv gpurun_out/
+timeout 900 python bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err
+echo "bench rc=$?"; cat gpurun_out/${TAG}_bench.json
+timeout 600 python bench.py --config 1 > gpurun_out/${TAG}_bench_config1.json 2>> gpurun_out/${TAG}_bench.err
+echo "bench config 1 rc=$?"; cat gpurun_out/${TAG}_bench_config1.json

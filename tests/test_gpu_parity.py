@@ -786,7 +786,12 @@ def test_randomised_configurations(oracle, seed):
     seqs = flat.reshape(n_refs, L)
     otree = oracle.tree_new_flat(lineages, flat, off)
     tree = rx.Tree.new_flat(lineages, flat, off, kmer_map=bool(rng.random() < 0.5))
-    ix = rx.Index(tree, sub_batch=int(rng.choice([0, 5, 64])), cluster=bool(rng.random() < 0.7))
+    # library options drawn after everything else (the data of a seed stay what they were): every combination must give
+    # the same results
+    orng = np.random.default_rng(seed + 77)
+    opts = dict(hit_quad=bool(orng.random() < 0.35), segment_classes=int(orng.choice([0, 1, 2])), packed_counts=bool(orng.random() < 0.75))
+    ix = rx.Index(tree, sub_batch=int(rng.choice([0, 5, 64])), cluster=bool(rng.random() < 0.7), **opts)
+    rx.Index(tree, segment_classes=1)     # restore the process-wide default for later tests
     qs = []
     for i in range(40):
         src = seqs[int(rng.integers(0, n_refs))].copy()

@@ -842,7 +842,7 @@ def test_randomised_configurations(oracle, seed):
             exc.checked += 1
             try:
                 k = assert_rows_equivalent(res.rows(q), rows, probs_ref, olin, f"seed {seed} skip {skip} q {q}")
-                n_ties += bool(k)
+                n_ties += bool(k) and len(qs[q]) >= L       # truncated queries (down to 8 bases) tie whole clades by construction
                 exc.tie(k)
             except AssertionError:
                 # also with the phylogenetic database: a short truncated query ties dozens of references exactly and

@@ -132,3 +132,109 @@ def test_bin_rejects_garbage(tmp_path, small_db):
     for name in ("trunc.bin", "fasta.bin", "missing.bin"):
         with pytest.raises(rx.RtxError):          # Tree::load_from_file errors -> the caller falls back to FASTA
             rx.Tree.load_from_file(tmp_path / name)
+
+
+def write_bin_from_oracle(otree, lineages_sorted, seq_of_sorted, rng) -> bytes:
+    """An independent bincode 1.3.3 WRITER of `Tree` (tree.rs:36-43,181-194: little-endian, u64 lengths, u32 enum tags,
+    structs as the concatenation of their fields, the HashMap in arbitrary order) fed from the ORACLE's tree: what the
+    reference's `Tree::save_to_file` would produce for it."""
+    out = bytearray()
+    u32 = lambda v: out.extend(struct.pack("<I", v))
+    u64 = lambda v: out.extend(struct.pack("<Q", v))
+
+    def string(s):
+        b = s.encode()
+        u64(len(b))
+        out.extend(b)
+
+    on = otree.nodes()
+    children = [[] for _ in on["type"]]
+    for i, p in enumerate(on["parent"]):
+        if p >= 0:
+            children[int(p)].append(i)
+
+    def node(i):                      # Node { label, confidence_range, children, node_type }
+        string(on["label"][i])
+        u64(int(on["lo"][i]))
+        u64(int(on["hi"][i]))
+        u64(len(children[i]))
+        for c in children[i]:
+            node(c)
+        u32(int(on["type"][i]))
+
+    node(0)
+    u64(len(lineages_sorted))
+    for l in lineages_sorted:
+        string(l)
+    groups = {}
+    for r, s in enumerate(seq_of_sorted):
+        groups.setdefault(bytes(s), []).append(r)
+    keys = list(groups)
+    rng.shuffle(keys)                 # a HashMap has no order
+    u64(len(keys))
+    for k in keys:
+        u64(len(k))
+        out.extend(k)
+        u64(len(groups[k]))
+        for r in groups[k]:
+            u32(r)
+    off, post = otree.csr()
+    u64(65536)
+    for k in range(65536):
+        a, b = int(off[k]), int(off[k + 1])
+        u64(b - a)
+        out.extend(post[a:b].astype("<u4").tobytes())
+    u64(otree.num_tips)
+    return bytes(out)
+
+
+def test_bin_written_by_an_independent_encoder_loads(tmp_path, oracle, small_db):
+    """The other direction: a file produced by an independent encoder of the format (from the oracle's tree) is read by
+    rtx_tree_load_bin and gives the tree the host mirror builds from the same input."""
+    lineages, seq_bytes, seq_off = small_db
+    otree = oracle.tree_new_flat(lineages, seq_bytes, seq_off)
+    orig = otree.original_index()
+    seq_sorted = [seq_bytes[int(seq_off[int(o)]):int(seq_off[int(o) + 1])] for o in orig]
+    data = write_bin_from_oracle(otree, otree.lineages, seq_sorted, np.random.default_rng(3))
+    path = tmp_path / "independent.bin"
+    path.write_bytes(data)
+    back = rx.Tree.load_from_file(path)
+    tree = rx.Tree.new_flat(lineages, seq_bytes, seq_off)
+    assert back.num_tips == tree.num_tips and back.lineages == tree.lineages
+    a, b = tree.csr(), back.csr()
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    na, nb = tree.nodes(), back.nodes()
+    for k in na:
+        assert np.array_equal(na[k], nb[k]), k
+    for r in (0, 10, 11, 150, 299):
+        assert np.array_equal(back.exact_matches(seq_sorted[r]), tree.exact_matches(seq_sorted[r]))
+    # and the mirror's own file parses to the same content as the independent one (map order aside)
+    tree.save_to_file(tmp_path / "own.bin")
+    p1, p2 = parse_bin(data), parse_bin((tmp_path / "own.bin").read_bytes())
+    assert p1[0] == p2[0] and p1[1] == p2[1] and p1[2] == p2[2] and p1[3] == p2[3] and p1[4] == p2[4]
+
+
+def test_bin_loader_rejects_hostile_counts(tmp_path, oracle, small_db):
+    """Counts are checked against the bytes that are left BEFORE they are multiplied (a posting count of 2^62 wraps
+    to 0 bytes), and posting lists must ascend strictly (the reference-sharded index cuts them with lower_bound)."""
+    lineages, seq_bytes, seq_off = small_db
+    otree = oracle.tree_new_flat(lineages, seq_bytes, seq_off)
+    orig = otree.original_index()
+    seq_sorted = [seq_bytes[int(seq_off[int(o)]):int(seq_off[int(o) + 1])] for o in orig]
+    good = bytearray(write_bin_from_oracle(otree, otree.lineages, seq_sorted, np.random.default_rng(4)))
+    off, post = otree.csr()
+    k = int(np.argmax(np.diff(off.astype(np.int64)) >= 2))            # a k-mer with at least two postings
+    tail = sum(8 + 4 * int(off[j + 1] - off[j]) for j in range(k, 65536)) + 8
+    pos = len(good) - tail                                              # where the list of k-mer k starts
+    assert struct.unpack_from("<Q", good, pos)[0] == int(off[k + 1] - off[k])
+    bad = bytearray(good)
+    struct.pack_into("<Q", bad, pos, 1 << 62)
+    swapped = bytearray(good)
+    a, b = struct.unpack_from("<II", good, pos + 8)
+    struct.pack_into("<II", swapped, pos + 8, b, a)
+    for name, data in (("huge.bin", bad), ("unsorted.bin", swapped)):
+        (tmp_path / name).write_bytes(bytes(data))
+        with pytest.raises(rx.RtxError):
+            rx.Tree.load_from_file(tmp_path / name)
+    (tmp_path / "good.bin").write_bytes(bytes(good))
+    assert rx.Tree.load_from_file(tmp_path / "good.bin").num_tips == 300

@@ -228,7 +228,13 @@ __device__ __forceinline__ void hit_epilogue(const HitParams &p, uint32_t (&pl)[
                         uint2 lo8;  // the low bytes of the eight counts, in reference order
                         lo8.x = __builtin_amdgcn_perm(st.y, st.x, 0x06040200u);
                         lo8.y = __builtin_amdgcn_perm(st.w, st.z, 0x06040200u);
+#ifdef RTX_EXP_SC1_COUNT_STORES
+                        // experiment: the counts bypass L2 (sc1 stores do not keep the line): more of it left for bitmap rows
+                        __hip_atomic_store(reinterpret_cast<unsigned long long *>(out_lo + goff), ((unsigned long long)lo8.y << 32) | lo8.x,
+                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
                         *reinterpret_cast<uint2 *>(out_lo + goff) = lo8;
+#endif
                         // high bytes (0..3 each) -> 2 bits per reference: byte j moves to bit 2j
                         const uint32_t hb0 = __builtin_amdgcn_perm(st.y, st.x, 0x07050301u), hb1 = __builtin_amdgcn_perm(st.w, st.z, 0x07050301u);
                         const uint32_t h0 = (hb0 | (hb0 >> 6) | (hb0 >> 12) | (hb0 >> 18)) & 0xFFu;

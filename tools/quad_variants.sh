@@ -23,6 +23,7 @@ for v in "$@"; do
   case $v in
     base) build base ;;
     nomidfold) buildk nomidfold -DRTX_EXP_NO_MID_FOLD ;;
+    sc1) buildk sc1 -DRTX_EXP_SC1_COUNT_STORES ;;
     nw8) buildk nw8 -DRTX_PREFIX_NW=8 ;;
     nw2) buildk nw2 -DRTX_PREFIX_NW=2 ;;
     nw16) buildk nw16 -DRTX_PREFIX_NW=16 ;;

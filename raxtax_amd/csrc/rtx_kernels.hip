@@ -960,11 +960,29 @@ __global__ __launch_bounds__(NW * 64) void taxon_prefix_kernel(PrefixParams p) {
         return;
     }
     const double *__restrict__ tzg = p.table_z + (size_t)q * p.hstride;
+    // Most references of a large database share too few k-mers with the query to get any probability at all:
+    // prob_lookup gives every count whose row has saturated below i_lo the value 0.0 EXACTLY (rtx_prob_tables.hip).
+    // m_lo = the smallest count with a non-zero table entry; a wave whose 512 references all lie below it adds
+    // nothing (+0.0) to the prefix and skips the look-ups, the sums and the scan (bit-identical results).
+    __shared__ uint32_t s_mlo;
     if (TZ_LDS) {  // 8 random look-ups per reference chunk: serve them from LDS
         const uint32_t t1 = p.t[q] + 1;
-        for (uint32_t m = tid; m < t1; m += NW * 64) tz_lds[m] = tzg[m];
+        if (tid == 0) s_mlo = 0xFFFFFFFFu;
+        __syncthreads();
+        uint32_t mine = 0xFFFFFFFFu;
+        for (uint32_t m = tid; m < t1; m += NW * 64) {
+            const double v = tzg[m];
+            tz_lds[m] = v;
+            if (v != 0.0 && m < mine) mine = m;   // entries of absent counts are never written: whatever they hold only lowers m_lo
+        }
+        if (mine != 0xFFFFFFFFu) atomicMin(&s_mlo, mine);
         __syncthreads();
     }
+    const uint32_t m_lo = (PACKED && TZ_LDS) ? s_mlo : 0u;
+    // "some byte of x is >= m_lo" without unpacking: byte + (256 - m_lo) carries out of the byte (low 7 bits added
+    // without crossing bytes, the carry out is the majority of the two top bits and the carry into them)
+    const uint32_t ge_add = ((256u - (m_lo & 0xFFu)) & 0x7Fu) * 0x01010101u;
+    const uint32_t ge_top = ((256u - (m_lo & 0xFFu)) & 0x80u) ? 0xFFFFFFFFu : 0u;
     // counts of this query: u16 per reference, or packed (low byte per reference + 2 high bits x 8 references per u16)
     const uint16_t *__restrict__ cnt = PACKED ? nullptr : p.counts + (size_t)q * p.npad;
     const uint8_t *__restrict__ cnt_lo = PACKED ? p.counts_lo + (size_t)q * p.npad : nullptr;
@@ -1014,24 +1032,48 @@ __global__ __launch_bounds__(NW * 64) void taxon_prefix_kernel(PrefixParams p) {
         const uint32_t bits_cur = bits_next, rank_cur = rank_next;
         request(r0 + kSweep);
         const uint32_t cw[4] = {cv.x, cv.y, cv.z, cv.w};
-        double v[8];
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            uint32_t c;  // lanes past the end hold 0: a valid index
-            if (PACKED) c = ((cw[j >> 2] >> ((j & 3) * 8)) & 0xFFu) | (((hi_cur >> (2 * j)) & 3u) << 8);
-            else c = (cw[j >> 1] >> ((j & 1) * 16)) & 0xFFFFu;
-            v[j] = TZ_LDS ? tz_lds[c] : tzg[c];
-        }
-        if (base + kSweep > n) {  // last sweep (wave-uniform): references past the end contribute nothing
-#pragma unroll
-            for (int j = 0; j < 8; j++) v[j] = (r0 + j < n) ? v[j] : 0.0;
+        bool live = true;  // wave-uniform: some reference of this wave's 512 may have a non-zero probability
+        if (PACKED && TZ_LDS && m_lo != 0u) {
+            bool mine = hi_cur != 0u;  // a count of 256 or more (conservative where m_lo is larger still)
+            if (m_lo < 256u) {
+                const uint32_t tx = (cv.x & 0x7F7F7F7Fu) + ge_add, ty = (cv.y & 0x7F7F7F7Fu) + ge_add;
+                const uint32_t gx = (cv.x & ge_top) | (cv.x & tx) | (ge_top & tx), gy = (cv.y & ge_top) | (cv.y & ty) | (ge_top & ty);
+                mine = mine || (((gx | gy) & 0x80808080u) != 0u);
+            }
+            live = __ballot(mine) != 0ull;
         }
         double s[8];
-        s[0] = v[0];
+        double run = 0.0, incl = 0.0;
+        if (live) {
+            double v[8];
+            if (PACKED && __ballot(hi_cur != 0u) == 0ull) {  // no count of this wave reaches 256 (the rule): the low bytes are the counts
 #pragma unroll
-        for (int j = 1; j < 8; j++) s[j] = s[j - 1] + v[j];
-        const double run = s[7];
-        const double incl = wave_incl_scan_f64_dpp(run);
+                for (int j = 0; j < 8; j++) {
+                    const uint32_t c = (cw[j >> 2] >> ((j & 3) * 8)) & 0xFFu;
+                    v[j] = TZ_LDS ? tz_lds[c] : tzg[c];
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    uint32_t c;  // lanes past the end hold 0: a valid index
+                    if (PACKED) c = ((cw[j >> 2] >> ((j & 3) * 8)) & 0xFFu) | (((hi_cur >> (2 * j)) & 3u) << 8);
+                    else c = (cw[j >> 1] >> ((j & 1) * 16)) & 0xFFFFu;
+                    v[j] = TZ_LDS ? tz_lds[c] : tzg[c];
+                }
+            }
+            if (base + kSweep > n) {  // last sweep (wave-uniform): references past the end contribute nothing
+#pragma unroll
+                for (int j = 0; j < 8; j++) v[j] = (r0 + j < n) ? v[j] : 0.0;
+            }
+            s[0] = v[0];
+#pragma unroll
+            for (int j = 1; j < 8; j++) s[j] = s[j - 1] + v[j];
+            run = s[7];
+            incl = wave_incl_scan_f64_dpp(run);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; j++) s[j] = 0.0;
+        }
         if (lane == 63) wsum[buf][wave] = incl;
         __syncthreads();
         double off = carry + (incl - run);

@@ -45,6 +45,16 @@ void emul_planes_count(const uint32_t *rows, uint32_t n_rows, int planes, uint32
             planes_unpack4<NP>(pl, g, lo, hi);
             for (int j = 0; j < 4; j++) out[4 * g + j] = ((lo >> (8 * j)) & 0xFF) | (((hi >> (8 * j)) & 0xFF) << 8);
         }
+        // the eight-at-a-time unpack of the epilogue (bit-matrix transpose) must give the same counters
+        for (int b = 0; b < 4; b++) {
+            uint32_t lo0, hi0, lo1, hi1;
+            planes_unpack8<NP>(pl, b, lo0, hi0, lo1, hi1);
+            for (int j = 0; j < 4; j++) {
+                const uint32_t c0 = ((lo0 >> (8 * j)) & 0xFF) | (((hi0 >> (8 * j)) & 0xFF) << 8);
+                const uint32_t c1 = ((lo1 >> (8 * j)) & 0xFF) | (((hi1 >> (8 * j)) & 0xFF) << 8);
+                if (c0 != out[8 * b + j] || c1 != out[8 * b + 4 + j]) out[8 * b + j] = 0xFFFFFFFFu;  // poison: the test fails
+            }
+        }
     };
     if (planes == 10) run(std::integral_constant<int, 10>{});
     else if (planes == 12) run(std::integral_constant<int, 12>{});

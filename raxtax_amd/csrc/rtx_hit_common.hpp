@@ -208,8 +208,7 @@ __device__ __forceinline__ void hit_epilogue(const HitParams &p, uint32_t (&pl)[
 #pragma unroll
                 for (int g2 = 0; g2 < 4; g2++) {  // 8 references per store, contiguous across lanes
                     uint32_t lo0, hi0, lo1, hi1;
-                    planes_unpack4<NP>(pl[w], 2 * g2, lo0, hi0);
-                    planes_unpack4<NP>(pl[w], 2 * g2 + 1, lo1, hi1);
+                    planes_unpack8<NP>(pl[w], g2, lo0, hi0, lo1, hi1);
                     uint4 st;
                     // bytes (lo.b0, hi.b0, lo.b1, hi.b1) -> two u16 counts
                     st.x = __builtin_amdgcn_perm(hi0, lo0, 0x05010400u);

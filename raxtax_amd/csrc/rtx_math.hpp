@@ -129,6 +129,50 @@ RTX_HD void planes_unpack4(const uint32_t (&pl)[NP], int g, uint32_t &lo, uint32
     }
 }
 
+// Counters of references 8b..8b+7 of a 32-reference word (byte b of every plane) at once: the low 8 bits of the
+// counters of references 8b..8b+3 in the bytes of lo0, of 8b+4..8b+7 in lo1, bits 8.. in hi0 / hi1 (as
+// planes_unpack4 gives them for g = 2b and 2b+1).  The low eight planes are an 8 x 8 bit matrix per reference group --
+// byte p = plane p, bit j = reference j -- and transposing it costs 6 byte gathers + 22 bit operations for eight
+// references, against 64 for the nibble-spreading multiplies of planes_unpack4; the planes above come from those.
+RTX_HD uint32_t pick_bytes(uint32_t a, uint32_t b, uint32_t c, uint32_t d, int by) {  // byte `by` of a, b, c, d -> bytes 0..3
+#if defined(__HIP_DEVICE_COMPILE__)
+    // v_perm_b32(hi, lo, sel): selector byte 0-3 = byte of lo, 4-7 = byte of hi
+    const uint32_t s2 = 0x0C0C0000u | (uint32_t)by | ((uint32_t)(by + 4) << 8);  // bytes: lo.by, hi.by, 0, 0
+    const uint32_t ab = __builtin_amdgcn_perm(b, a, s2), cd = __builtin_amdgcn_perm(d, c, s2);
+    return __builtin_amdgcn_perm(cd, ab, 0x05040100u);                           // ab.b0, ab.b1, cd.b0, cd.b1
+#else
+    const int sh = 8 * by;
+    return ((a >> sh) & 0xFFu) | (((b >> sh) & 0xFFu) << 8) | (((c >> sh) & 0xFFu) << 16) | (((d >> sh) & 0xFFu) << 24);
+#endif
+}
+
+template <int NP>
+RTX_HD void planes_unpack8(const uint32_t (&pl)[NP], int b, uint32_t &lo0, uint32_t &hi0, uint32_t &lo1, uint32_t &hi1) {
+    static_assert(NP >= 8, "at least eight planes");
+    uint32_t x0 = pick_bytes(pl[0], pl[1], pl[2], pl[3], b);  // 64-bit matrix x1:x0, row (byte) p = plane p
+    uint32_t x1 = pick_bytes(pl[4], pl[5], pl[6], pl[7], b);
+    // 8 x 8 bit transpose (three delta swaps; the first two stay inside the halves)
+    uint32_t t0 = (x0 ^ (x0 >> 7)) & 0x00AA00AAu, t1 = (x1 ^ (x1 >> 7)) & 0x00AA00AAu;
+    x0 ^= t0 ^ (t0 << 7);
+    x1 ^= t1 ^ (t1 << 7);
+    t0 = (x0 ^ (x0 >> 14)) & 0x0000CCCCu;
+    t1 = (x1 ^ (x1 >> 14)) & 0x0000CCCCu;
+    x0 ^= t0 ^ (t0 << 14);
+    x1 ^= t1 ^ (t1 << 14);
+    const uint32_t t = (x0 ^ ((x0 >> 28) | (x1 << 4))) & 0xF0F0F0F0u;
+    x0 ^= t ^ (t << 28);
+    x1 ^= t >> 4;
+    lo0 = x0;  // byte j = the low eight counter bits of reference 8b + j
+    lo1 = x1;
+    hi0 = 0;
+    hi1 = 0;
+#pragma unroll
+    for (int p = 8; p < NP; p++) {
+        hi0 |= spread4(pl[p] >> (8 * b)) << (p - 8);
+        hi1 |= spread4(pl[p] >> (8 * b + 4)) << (p - 8);
+    }
+}
+
 // ---------------------------------------------------------------------------
 // prob.rs restated for the device: the reference builds ln pmf_m(i) for every distinct
 // hit count m and every i in 0..=n (prob.rs:121-170), exponentiates, accumulates ln cmf,

@@ -160,6 +160,7 @@ struct rtx_index {
     uint32_t cluster = 1;  // RTX_OPT_CLUSTER
     uint32_t packed_opt = 1;  // RTX_OPT_PACKED_COUNTS
     uint32_t quad_opt = 0;    // RTX_OPT_HIT_QUAD (off until verified on the GPU)
+    uint32_t tile_skip = 1;   // RTX_OPT_TILE_SKIP: taxon_prefix reads only the tiles that hold a reference with p >= 1e-30
     bool quad_used = false;   // the last run went through hit_count_quad_kernel
     DevBuf<uint32_t> d_group_rows;
     uint32_t groups_per_sub = 0;
@@ -178,7 +179,7 @@ struct rtx_index {
     // (the HBM/L2-bound hit_count of one overlaps the latency-bound prob/prefix/walk of the other)
     uint32_t sub_batch_req = 0, sub_batch = 0;
     struct Scratch {
-        DevBuf<uint16_t> d_kmers, d_counts;
+        DevBuf<uint16_t> d_kmers, d_counts, d_tilemax;
         DevBuf<uint32_t> d_rows, d_t, d_nrows, d_hist, d_order, d_srows, d_nsparse, d_mrows, d_nmid;
         DevBuf<unsigned long long> d_dmask;
         DevBuf<double> d_table_z, d_prefix;
@@ -366,6 +367,7 @@ int enqueue_hit(rtx_index *ix, const SubBatch &b, uint32_t flags, hipStream_t s)
     hp.npad = ix->npad;
     hp.hist = sc.d_hist.p;
     hp.hstride = ix->hstride;
+    hp.tile_max = sc.d_tilemax.p;
     hp.flags = flags;
     hp.q0 = b.q0;
     hp.perm = ix->d_perm.p;
@@ -436,6 +438,8 @@ int enqueue_prob_prefix(rtx_index *ix, const SubBatch &b, bool fuse_walk) {
     fp.bnd_rank = ix->d_bnd_rank.p;
     fp.prefix = sc.d_prefix.p;
     fp.n_bnd = ix->n_bnd_local;
+    fp.tile_max = ix->tile_skip ? sc.d_tilemax.p : nullptr;
+    fp.ntiles = ix->ntiles;
     fp.fuse_walk = fuse_walk ? 1u : 0u;
     if (fuse_walk) fp.walk = walk_params(ix, b, sc.d_prefix.p);
     if (b.timed_all) RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_TAXON_PREFIX, 0), s));
@@ -721,7 +725,7 @@ int prepare_workspace(rtx_index *ix, uint64_t n_queries, uint64_t tmax, uint64_t
         RTX_HIP(hipEventCreateWithFlags(&ix->ev_fork, hipEventDisableTiming));
         RTX_HIP(hipEventCreateWithFlags(&ix->ev_join, hipEventDisableTiming));
     }
-    const uint64_t per_q = ((uint64_t)ix->kstride * 2 + (uint64_t)ix->rstride * 4 + (uint64_t)ix->ntiles * (ix->rstride / 8 + ((kSegMaxSparseRows + 1) * 4 + (kSegMaxMidRows + 1) * 4 + 12)) + (ix->packed() ? ix->npad * 5 / 4 : ix->npad * 2) + (uint64_t)ix->hstride * 12 +
+    const uint64_t per_q = ((uint64_t)ix->kstride * 2 + (uint64_t)ix->rstride * 4 + (uint64_t)ix->ntiles * (ix->rstride / 8 + ((kSegMaxSparseRows + 1) * 4 + (kSegMaxMidRows + 1) * 4 + 14)) + (ix->packed() ? ix->npad * 5 / 4 : ix->npad * 2) + (uint64_t)ix->hstride * 12 +
                             (uint64_t)ix->n_bnd_local * 8 + 64) * ix->n_streams;
     uint32_t B = ix->sub_batch_req;
     if (B == 0) {
@@ -752,7 +756,8 @@ int alloc_scratch_set(rtx_index *ix, uint32_t k) {
             (rc = sc.d_nmid.alloc((size_t)B * ix->ntiles)) || (rc = sc.d_mrows.alloc((size_t)B * ix->ntiles * (kSegMaxMidRows + 1))) ||
             (rc = sc.d_t.alloc(B)) || (rc = sc.d_nrows.alloc(B)) || (rc = sc.d_counts.alloc(counts_elems(ix, B))) ||
             (rc = sc.d_hist.alloc((size_t)B * ix->hstride)) || (rc = sc.d_table_z.alloc((size_t)B * ix->hstride)) ||
-            (rc = sc.d_prefix.alloc((size_t)B * ix->n_bnd_local)) || (rc = sc.d_order.alloc(B)))
+            (rc = sc.d_prefix.alloc((size_t)B * ix->n_bnd_local)) || (rc = sc.d_order.alloc(B)) ||
+            (rc = sc.d_tilemax.alloc((size_t)B * ix->ntiles)))
             return rc;
     }
     return RTX_OK;
@@ -1221,6 +1226,9 @@ int rtx_index_set_option(rtx_index *index, int option, uint64_t value) {
         case RTX_OPT_HIT_QUAD:
             index->quad_opt = value ? 1u : 0u;
             return RTX_OK;
+        case RTX_OPT_TILE_SKIP:
+            index->tile_skip = value ? 1u : 0u;
+            return RTX_OK;
         case RTX_OPT_PROB_MODE:
             if (value > 2) break;
             index->prob_mode = (int)value;
@@ -1566,7 +1574,7 @@ int rtx_shard_rehist(rtx_index *ix, uint32_t sb) {
     if (rc) return rc;
     if (ix->packed()) { set_error("rtx_shard_rehist needs u16 counts (RTX_OPT_PACKED_COUNTS = 0)"); return RTX_ERR_STATE; }
     rtx_index::Scratch &sc = ix->sc[b.set];
-    launch_rehist(b.s, sc.d_counts.p, ix->npad, ix->n_refs, sc.d_t.p, sc.d_hist.p, ix->hstride, b.nq);
+    launch_rehist(b.s, sc.d_counts.p, ix->npad, ix->n_refs, sc.d_t.p, sc.d_hist.p, ix->hstride, sc.d_tilemax.p, ix->ntiles, b.nq);
     RTX_HIP(hipGetLastError());
     return RTX_OK;
 }

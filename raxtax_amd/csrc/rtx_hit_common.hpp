@@ -276,9 +276,17 @@ __device__ __forceinline__ void hit_epilogue(const HitParams &p, uint32_t (&pl)[
     wave_lds_sync();
     // every lane of the wave flushes (also those whose columns lie beyond the row)
     uint32_t *hist = p.hist + (size_t)q * p.hstride;
+    uint32_t mx = 0;  // the largest count of this tile = its highest non-empty bin
     for (uint32_t m = lane; m <= t; m += 64) {
         const uint32_t v = hist_lds[m];
-        if (v) atomicAdd(&hist[m], v);
+        if (v) { atomicAdd(&hist[m], v); mx = m; }
+    }
+    if (p.tile_max) {
+        for (int d = 32; d >= 1; d >>= 1) {
+            const uint32_t o = __shfl_xor(mx, d, 64);
+            mx = o > mx ? o : mx;
+        }
+        if (lane == 0) p.tile_max[(size_t)q * p.ntiles + tile] = (uint16_t)mx;
     }
 }
 

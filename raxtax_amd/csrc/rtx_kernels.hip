@@ -948,6 +948,9 @@ __device__ __forceinline__ uint4 load_counts8(const uint16_t *p) {
     return make_uint4(v.x, v.y, v.z, v.w);
 }
 
+// a reference whose probability is below this adds nothing that could be seen in a confidence (taxon_prefix, tile skipping)
+static constexpr double kLiveEps = 1e-30;
+
 template <int NW, bool TZ_LDS, bool PACKED>
 __global__ __launch_bounds__(NW * 64) void taxon_prefix_kernel(PrefixParams p) {
     extern __shared__ double tz_lds[];
@@ -964,18 +967,24 @@ __global__ __launch_bounds__(NW * 64) void taxon_prefix_kernel(PrefixParams p) {
     // prob_lookup gives every count whose row has saturated below i_lo the value 0.0 EXACTLY (rtx_prob_tables.hip).
     // m_lo = the smallest count with a non-zero table entry; a wave whose 512 references all lie below it adds
     // nothing (+0.0) to the prefix and skips the look-ups, the sums and the scan (bit-identical results).
-    __shared__ uint32_t s_mlo;
-    if (TZ_LDS) {  // 8 random look-ups per reference chunk: serve them from LDS
+    // Tile skipping: hit_count leaves the largest count of every tile of 8192 references (p.tile_max).  m_live = the
+    // smallest count whose probability reaches kLiveEps; a tile whose largest count lies below it holds no reference
+    // with p >= kLiveEps and is not read at all: the boundaries inside it get the running sum.  What is dropped is
+    // below n_refs * kLiveEps in every prefix value (confidences are differences of those, rounded to 1e-2).
+    __shared__ uint32_t s_mlo, s_mlive;
+    {
         const uint32_t t1 = p.t[q] + 1;
-        if (tid == 0) s_mlo = 0xFFFFFFFFu;
+        if (tid == 0) { s_mlo = 0xFFFFFFFFu; s_mlive = 0xFFFFFFFFu; }
         __syncthreads();
-        uint32_t mine = 0xFFFFFFFFu;
+        uint32_t mine = 0xFFFFFFFFu, mine_live = 0xFFFFFFFFu;
         for (uint32_t m = tid; m < t1; m += NW * 64) {
             const double v = tzg[m];
-            tz_lds[m] = v;
+            if (TZ_LDS) tz_lds[m] = v;  // 8 random look-ups per reference chunk: serve them from LDS
             if (v != 0.0 && m < mine) mine = m;   // entries of absent counts are never written: whatever they hold only lowers m_lo
+            if (v >= kLiveEps && m < mine_live) mine_live = m;
         }
         if (mine != 0xFFFFFFFFu) atomicMin(&s_mlo, mine);
+        if (mine_live != 0xFFFFFFFFu) atomicMin(&s_mlive, mine_live);
         __syncthreads();
     }
     const uint32_t m_lo = (PACKED && TZ_LDS) ? s_mlo : 0u;
@@ -1022,10 +1031,38 @@ __global__ __launch_bounds__(NW * 64) void taxon_prefix_kernel(PrefixParams p) {
         bits_next = in ? bits_l : 0u;
         rank_next = rank_l;
     };
-    request(tid * 8u);
-    accept(tid * 8u);
+    const uint16_t *__restrict__ tmx = p.tile_max ? p.tile_max + (size_t)q * p.ntiles : nullptr;
+    const uint32_t m_live = s_mlive;
+    const uint32_t ntiles = (n + 8191u) >> 13;
+    unsigned long long live_mask = ~0ull;  // liveness of the 64 tiles of group live_group (wave-uniform, the same in every wave)
+    uint32_t live_group = 0xFFFFFFFFu;
+    auto tile_live = [&](uint32_t T) -> bool {
+        if (!tmx) return true;
+        if ((T >> 6) != live_group) {
+            live_group = T >> 6;
+            const uint32_t Tl = live_group * 64u + lane;
+            live_mask = __ballot(Tl < ntiles && (uint32_t)tmx[Tl] >= m_live);
+        }
+        return (live_mask >> (T & 63u)) & 1ull;
+    };
+    uint32_t filled = 1;  // P[0 .. filled) are written
     uint32_t buf = 0;
-    for (uint32_t base = 0; base < n; base += kSweep, buf ^= 1u) {
+    uint32_t T = 0;
+    while (T < ntiles) {
+        // the next run of live tiles [Ts, Te)
+        while (T < ntiles && !tile_live(T)) T++;
+        if (T >= ntiles) break;
+        const uint32_t Ts = T;
+        while (T < ntiles && tile_live(T)) T++;
+        const uint32_t Te = T;
+        // boundaries inside the dead tiles in front of the run: the running sum
+        const uint32_t rb = p.bnd_rank[Ts * 1024u];
+        for (uint32_t i = filled + tid; i < rb; i += NW * 64) P[i] = carry;
+        filled = Te * 1024u <= last_chunk ? p.bnd_rank[Te * 1024u] : p.n_bnd;
+        const uint32_t span_end = Te * 8192u < n ? Te * 8192u : n;
+        request(Ts * 8192u + tid * 8u);
+        accept(Ts * 8192u + tid * 8u);
+    for (uint32_t base = Ts * 8192u; base < span_end; base += kSweep, buf ^= 1u) {
         const uint32_t r0 = base + tid * 8u;
         const uint4 cv = cv_next;
         const uint32_t hi_cur = hi_next;
@@ -1097,6 +1134,8 @@ __global__ __launch_bounds__(NW * 64) void taxon_prefix_kernel(PrefixParams p) {
             if (bits & (1u << j)) P[rank_cur + (uint32_t)__popc(bits & ((1u << j) - 1u))] = off + s[j];
         accept(r0 + kSweep);
     }
+    }
+    for (uint32_t i = filled + tid; i < p.n_bnd; i += NW * 64) P[i] = carry;
     if (p.fuse_walk) {
         // The walk of this query by wave 0 while the prefix sums are still in this XCD's L2 (a walk on its own is a
         // chain of ~1.5 us misses: the prefix arrays of a sub-batch are 10x the L2); the other waves retire, and the
@@ -1107,22 +1146,35 @@ __global__ __launch_bounds__(NW * 64) void taxon_prefix_kernel(PrefixParams p) {
     }
 }
 
-// histogram of prob.rs:13-19 from the u16 counts of a sub-batch (k-mer-sharded database: counts summed over the ranks)
+// histogram of prob.rs:13-19 from the u16 counts of a sub-batch (k-mer-sharded database: counts summed over the ranks),
+// and the largest count of every tile of 8192 references (what hit_count wrote covered this rank's k-mers only)
 __global__ __launch_bounds__(256) void rehist_kernel(const uint16_t *__restrict__ counts, uint64_t npad, uint64_t n_refs,
-                                                     const uint32_t *__restrict__ t, uint32_t *__restrict__ hist, uint32_t hstride) {
-    extern __shared__ uint32_t h_lds[];
+                                                     const uint32_t *__restrict__ t, uint32_t *__restrict__ hist, uint32_t hstride,
+                                                     uint16_t *__restrict__ tile_max, uint32_t ntiles) {
+    extern __shared__ uint32_t h_lds[];  // [hstride] histogram | [ntiles] tile maxima
+    uint32_t *tm_lds = h_lds + hstride;
     const uint32_t q = blockIdx.x, tid = threadIdx.x;
     const uint32_t tq = t[q];
     for (uint32_t m = tid; m <= tq; m += 256) h_lds[m] = 0;
+    for (uint32_t i = tid; i < ntiles; i += 256) tm_lds[i] = 0;
     __syncthreads();
     const uint16_t *c = counts + (size_t)q * npad;
-    for (uint64_t r = tid; r < n_refs; r += 256) {
-        const uint32_t v = c[r];
-        atomicAdd(&h_lds[v <= tq ? v : tq], 1u);  // a count cannot exceed t (clamped against corrupt input)
+    for (uint64_t r0 = 0; r0 < n_refs; r0 += 8192) {  // the 256 threads stay inside one tile
+        const uint64_t r1 = r0 + 8192 < n_refs ? r0 + 8192 : n_refs;
+        uint32_t mx = 0;
+        for (uint64_t r = r0 + tid; r < r1; r += 256) {
+            uint32_t v = c[r];
+            v = v <= tq ? v : tq;  // a count cannot exceed t (clamped against corrupt input)
+            atomicAdd(&h_lds[v], 1u);
+            mx = v > mx ? v : mx;
+        }
+        if (mx) atomicMax(&tm_lds[r0 >> 13], mx);
     }
     __syncthreads();
     uint32_t *h = hist + (size_t)q * hstride;
     for (uint32_t m = tid; m <= tq; m += 256) h[m] = h_lds[m];
+    if (tile_max)
+        for (uint32_t i = tid; i < ntiles; i += 256) tile_max[(size_t)q * ntiles + i] = (uint16_t)tm_lds[i];
 }
 
 // debug taps: the packed counts of one query as u16 (rtx_debug_hit_counts, rtx_debug_probs)
@@ -1198,8 +1250,9 @@ void launch_lineage_walk(hipStream_t s, const WalkParams &p, uint32_t nq) {
     hipLaunchKernelGGL(lineage_walk_kernel, dim3(nq), dim3(64), 0, s, p);
 }
 void launch_rehist(hipStream_t s, const uint16_t *counts, uint64_t npad, uint64_t n_refs, const uint32_t *t, uint32_t *hist,
-                   uint32_t hstride, uint32_t nq) {
-    hipLaunchKernelGGL(rehist_kernel, dim3(nq), dim3(256), (size_t)hstride * 4, s, counts, npad, n_refs, t, hist, hstride);
+                   uint32_t hstride, uint16_t *tile_max, uint32_t ntiles, uint32_t nq) {
+    hipLaunchKernelGGL(rehist_kernel, dim3(nq), dim3(256), ((size_t)hstride + ntiles) * 4, s, counts, npad, n_refs, t, hist, hstride,
+                       tile_max, ntiles);
 }
 void launch_counts_unpack(hipStream_t s, const uint8_t *lo, const uint16_t *hi, uint64_t n, uint16_t *out) {
     hipLaunchKernelGGL(counts_unpack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, lo, hi, n, out);

@@ -100,6 +100,7 @@ struct HitParams {
     uint64_t npad;
     uint32_t *hist;  // [B][hstride]
     uint32_t hstride;
+    uint16_t *tile_max;  // [B][ntiles] largest count of the tile's references (taxon_prefix skips tiles without any probability) or null
     uint32_t flags;
     uint64_t q0;
     const uint32_t *perm;       // [n_q] query at every position: exact_off is indexed by query
@@ -171,6 +172,8 @@ struct PrefixParams {
     const uint32_t *bnd_rank;   // [ceil(N/8)] boundary index of the first such position
     double *prefix;             // [B][n_bnd]
     uint32_t n_bnd;
+    const uint16_t *tile_max;   // [B][ntiles] largest count per tile of 8192 references (hit_count) or null: every tile is swept
+    uint32_t ntiles;
     uint32_t fuse_walk;         // wave 0 of every workgroup walks its query right after the sweeps (walk.prefix == prefix)
     WalkParams walk;
 };
@@ -206,7 +209,7 @@ void launch_taxon_prefix(hipStream_t s, const PrefixParams &p, uint32_t nq);
 void launch_lineage_walk(hipStream_t s, const WalkParams &p, uint32_t nq);
 void launch_probs_expand(hipStream_t s, const uint16_t *counts, const double *tz, uint64_t n, double *out);
 void launch_rehist(hipStream_t s, const uint16_t *counts, uint64_t npad, uint64_t n_refs, const uint32_t *t, uint32_t *hist,
-                   uint32_t hstride, uint32_t nq);
+                   uint32_t hstride, uint16_t *tile_max, uint32_t ntiles, uint32_t nq);
 void launch_counts_unpack(hipStream_t s, const uint8_t *lo, const uint16_t *hi, uint64_t n, uint16_t *out);
 
 }  // namespace rtx

@@ -725,6 +725,32 @@ def test_mid_segments(oracle, n_refs):
     assert wa["sum_hits"] == wb["sum_hits"] and wa["bitmap_bytes_read"] < 0.9 * wb["bitmap_bytes_read"]
 
 
+@pytest.mark.parametrize("n_refs", [70000, 8192 * 3, 40007])
+def test_tile_skip_changes_nothing_visible(oracle, n_refs):
+    """RTX_OPT_TILE_SKIP: taxon_prefix sweeps only the tiles of 8192 references in which some reference reaches a
+    probability of 1e-30 (hit_count leaves the largest count per tile), the boundaries of the other tiles get the running
+    sum.  Every result array equals that of the full sweep (lineage.rs:61-66 sums every reference; the comparisons with the
+    oracle elsewhere in this suite run with the default, skipping on);
+    several tiles, a partial last tile, a database of whole tiles, u16 and packed counts, --skip-exact-matches,
+    degenerate queries (one k-mer: every tile is live)."""
+    db = synth.make_db(n_refs)
+    qs = synth.make_queries(db, 160, exact_frac=0.2)
+    seqs = [qs.seq(q) for q in range(qs.n)] + [db.seq(3)[:8].copy(), db.seq(5)[:30].copy()]
+    off = np.zeros(len(seqs) + 1, np.uint64)
+    off[1:] = np.cumsum([len(s) for s in seqs])
+    bases = np.concatenate(seqs)
+    tree = rx.Tree.new_flat(db.lineages, db.seq_bytes, db.seq_off)
+    for kw in (dict(), dict(packed_counts=False), dict(sub_batch=50)):
+        a, b = rx.Index(tree, tile_skip=True, **kw), rx.Index(tree, tile_skip=False, **kw)
+        ex = a.exact_matches(bases, off)
+        for skip in (False, True):
+            ra = a.classify(bases, off, *ex, skip_exact_matches=skip)
+            rb = b.classify(bases, off, *ex, skip_exact_matches=skip)
+            for f in ("row_off", "row_lineage", "row_conf", "global_signal", "t", "status"):
+                assert np.array_equal(getattr(ra, f), getattr(rb, f)), (kw, skip, f)
+            assert np.allclose(ra.row_local_signal, rb.row_local_signal, rtol=0, atol=1e-12)
+
+
 def test_long_queries_need_several_list_rounds(oracle):
     """Queries with more dense rows per tile than hit_count's LDS row list holds (kHitListCap) are folded in several rounds."""
     db = synth.make_db(20000)
@@ -790,6 +816,7 @@ def test_randomised_configurations(oracle, seed):
     # the same results
     orng = np.random.default_rng(seed + 77)
     opts = dict(hit_quad=bool(orng.random() < 0.35), segment_classes=int(orng.choice([0, 1, 2])), packed_counts=bool(orng.random() < 0.75))
+    opts["tile_skip"] = bool(orng.random() < 0.7)   # drawn last: the options of the recorded seeds stay what they were
     ix = rx.Index(tree, sub_batch=int(rng.choice([0, 5, 64])), cluster=bool(rng.random() < 0.7), **opts)
     rx.Index(tree, segment_classes=1)     # restore the process-wide default for later tests
     qs = []

@@ -215,7 +215,7 @@ class Index:
     def __init__(self, tree: Tree, device: int = 0, sub_batch: int = 0, prob_mode: int = 0, streams: int = 0,
                  stage_timing: bool = False, cluster: Optional[bool] = None, segment_classes=1,
                  packed_counts: Optional[bool] = None, hit_quad: Optional[bool] = None,
-                 tile_skip: Optional[bool] = None):
+                 tile_skip: Optional[bool] = None, hit_pair: Optional[bool] = None):
         self._lib = _lib.load()
         self.tree = tree
         check(self._lib.rtx_set_default_option(1, int(segment_classes)))   # creation-time default of the library
@@ -239,6 +239,8 @@ class Index:
             check(self._lib.rtx_index_set_option(self._h, 9, int(hit_quad)))
         if tile_skip is not None:
             check(self._lib.rtx_index_set_option(self._h, 10, int(tile_skip)))
+        if hit_pair is not None:
+            check(self._lib.rtx_index_set_option(self._h, 11, int(hit_pair)))
         self._view = ResultView()
         self._keep = None
 

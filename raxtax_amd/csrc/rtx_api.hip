@@ -162,6 +162,8 @@ struct rtx_index {
     uint32_t quad_opt = 0;    // RTX_OPT_HIT_QUAD (off until verified on the GPU)
     uint32_t tile_skip = 1;   // RTX_OPT_TILE_SKIP: taxon_prefix reads only the tiles that hold a reference with p >= 1e-30
     bool quad_used = false;   // the last run went through hit_count_quad_kernel
+    uint32_t pair_opt = 1;    // RTX_OPT_HIT_PAIR
+    bool pair_used = false;   // ... through hit_count_pair_kernel
     DevBuf<uint32_t> d_group_rows;
     uint32_t groups_per_sub = 0;
     bool packed() const { return packed_opt && planes <= 10; }
@@ -183,6 +185,8 @@ struct rtx_index {
         DevBuf<uint32_t> d_rows, d_t, d_nrows, d_hist, d_order, d_srows, d_nsparse, d_mrows, d_nmid;
         DevBuf<unsigned long long> d_dmask;
         DevBuf<double> d_table_z, d_prefix;
+        DevBuf<uint2> d_urec;   // hit_count_pair_kernel: union row lists of the pairs of the sub-batch
+        DevBuf<uint32_t> d_nu;
     } sc[2];
     uint32_t n_streams_req = 1, n_streams = 1;
     bool staged = false;  // driven with rtx_shard_*: sub-batch sb works in scratch set sb & 1, so that the exchange of one
@@ -374,10 +378,16 @@ int enqueue_hit(rtx_index *ix, const SubBatch &b, uint32_t flags, hipStream_t s)
     hp.exact_ids = ix->d_exact_ids.p;
     hp.exact_off = ix->d_exact_off.p;
     hp.nq = b.nq;
-    hp.group_rows = ix->quad_used ? ix->d_group_rows.p : nullptr;
+    hp.group_rows = ix->quad_used || ix->pair_used ? ix->d_group_rows.p : nullptr;
     hp.group_base = b.sb * ix->groups_per_sub;
+    hp.pair_urec = sc.d_urec.p;
+    hp.pair_nu = sc.d_nu.p;
+    hp.pair_ustride = 2u * ix->rstride;
     if (b.timed) RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_HIT_COUNT, 0), s));
-    if (ix->quad_used) launch_hit_count_quad(s, hp, b.nq, ix->ntiles);
+    if (ix->pair_used) {
+        launch_pair_union(s, sc.d_rows.p, sc.d_nrows.p, ix->rstride, b.nq, sc.d_urec.p, sc.d_nu.p, 2u * ix->rstride);
+        launch_hit_count_pair(s, hp, b.nq, ix->ntiles);
+    } else if (ix->quad_used) launch_hit_count_quad(s, hp, b.nq, ix->ntiles);
     else launch_hit_count(s, hp, b.nq, ix->ntiles, ix->planes);
     if (b.timed) RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_HIT_COUNT, 1), s));
     return RTX_OK;
@@ -510,8 +520,10 @@ int begin_run(rtx_index *ix, uint32_t *n_sub_out, bool *timed_out, bool cluster)
     const uint32_t n_sub = (uint32_t)((ix->n_q + ix->sub_batch - 1) / ix->sub_batch);
     // four neighbours per workgroup only pays when neighbours are related: with the processing order on
     ix->quad_used = ix->quad_opt && cluster && ix->planes <= 10 && ix->n_q > 2;
-    ix->groups_per_sub = (ix->sub_batch + 3u) / 4u;
-    if (ix->quad_used) {
+    // two neighbours per wave: the same condition; the mid-segment lists are folded by hit_count_kernel only
+    ix->pair_used = !ix->quad_used && ix->pair_opt && cluster && ix->planes <= 10 && ix->n_q > 1 && ix->n_mid_slots == 0 && ix->rstride <= 4096;
+    ix->groups_per_sub = ix->pair_used ? (ix->sub_batch + 1u) / 2u : (ix->sub_batch + 3u) / 4u;
+    if (ix->quad_used || ix->pair_used) {
         int rc_g = ix->d_group_rows.alloc((size_t)n_sub * ix->groups_per_sub);
         if (rc_g) return rc_g;
         RTX_HIP(hipMemsetAsync(ix->d_group_rows.p, 0, (size_t)n_sub * ix->groups_per_sub * 4, ix->stream));
@@ -725,7 +737,7 @@ int prepare_workspace(rtx_index *ix, uint64_t n_queries, uint64_t tmax, uint64_t
         RTX_HIP(hipEventCreateWithFlags(&ix->ev_fork, hipEventDisableTiming));
         RTX_HIP(hipEventCreateWithFlags(&ix->ev_join, hipEventDisableTiming));
     }
-    const uint64_t per_q = ((uint64_t)ix->kstride * 2 + (uint64_t)ix->rstride * 4 + (uint64_t)ix->ntiles * (ix->rstride / 8 + ((kSegMaxSparseRows + 1) * 4 + (kSegMaxMidRows + 1) * 4 + 14)) + (ix->packed() ? ix->npad * 5 / 4 : ix->npad * 2) + (uint64_t)ix->hstride * 12 +
+    const uint64_t per_q = ((uint64_t)ix->kstride * 2 + (uint64_t)ix->rstride * 12 + 4 + (uint64_t)ix->ntiles * (ix->rstride / 8 + ((kSegMaxSparseRows + 1) * 4 + (kSegMaxMidRows + 1) * 4 + 14)) + (ix->packed() ? ix->npad * 5 / 4 : ix->npad * 2) + (uint64_t)ix->hstride * 12 +
                             (uint64_t)ix->n_bnd_local * 8 + 64) * ix->n_streams;
     uint32_t B = ix->sub_batch_req;
     if (B == 0) {
@@ -757,7 +769,8 @@ int alloc_scratch_set(rtx_index *ix, uint32_t k) {
             (rc = sc.d_t.alloc(B)) || (rc = sc.d_nrows.alloc(B)) || (rc = sc.d_counts.alloc(counts_elems(ix, B))) ||
             (rc = sc.d_hist.alloc((size_t)B * ix->hstride)) || (rc = sc.d_table_z.alloc((size_t)B * ix->hstride)) ||
             (rc = sc.d_prefix.alloc((size_t)B * ix->n_bnd_local)) || (rc = sc.d_order.alloc(B)) ||
-            (rc = sc.d_tilemax.alloc((size_t)B * ix->ntiles)))
+            (rc = sc.d_tilemax.alloc((size_t)B * ix->ntiles)) ||
+            (rc = sc.d_urec.alloc((size_t)((B + 1u) / 2u) * 2u * ix->rstride)) || (rc = sc.d_nu.alloc((B + 1u) / 2u)))
             return rc;
     }
     return RTX_OK;
@@ -1226,6 +1239,9 @@ int rtx_index_set_option(rtx_index *index, int option, uint64_t value) {
         case RTX_OPT_HIT_QUAD:
             index->quad_opt = value ? 1u : 0u;
             return RTX_OK;
+        case RTX_OPT_HIT_PAIR:
+            index->pair_opt = value ? 1u : 0u;
+            return RTX_OK;
         case RTX_OPT_TILE_SKIP:
             index->tile_skip = value ? 1u : 0u;
             return RTX_OK;
@@ -1615,7 +1631,7 @@ int rtx_batch_work(rtx_index *ix, uint64_t *sum_hits, uint64_t *sum_query_bytes,
         b += (uint64_t)ix->h_nrows_all[q] * row_bytes;
         mid_bytes += (uint64_t)nmid[q] * kSegMidEntries * 2;  // a mid segment travels as 128 bytes of positions
     }
-    if (ix->quad_used) {  // rows were loaded once per group of four queries: the union rows every workgroup counted
+    if (ix->quad_used || ix->pair_used) {  // rows were loaded once per group of four (two) queries: the union rows every workgroup counted
         const uint32_t n_sub = (uint32_t)((ix->n_q + ix->sub_batch - 1) / ix->sub_batch);
         std::vector<uint32_t> gr((size_t)n_sub * ix->groups_per_sub);
         RTX_HIP(hipMemcpy(gr.data(), ix->d_group_rows.p, gr.size() * 4, hipMemcpyDeviceToHost));

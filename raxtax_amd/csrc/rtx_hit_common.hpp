@@ -8,6 +8,12 @@
 #include "rtx_math.hpp"
 #include "rtx_wave.hpp"
 
+#ifndef RTX_EPI_MARK  // experiment hooks (rtx_hit_pair.hip, RTX_PAIR_STAMP): cycle stamps inside the epilogue
+#define RTX_EPI_MARK(k)
+#define RTX_EPI_DECL
+#define RTX_EPI_DONE
+#endif
+
 namespace rtx {
 
 // Orders the LDS traffic of ONE wave (some lanes write, others read): the hardware keeps the LDS operations of a
@@ -37,6 +43,19 @@ __device__ __forceinline__ void load8v(uint4 (&buf)[8], const char *__restrict__
     }
 }
 
+// the same with the first lane of the row ids as an argument (a constant once the caller's loop is unrolled)
+__device__ __forceinline__ void load8v_at(uint4 (&buf)[8], const char *__restrict__ bitmap, uint32_t col, uint32_t stride, uint32_t idv, int o) {
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const uint32_t row = (uint32_t)__builtin_amdgcn_readlane((int)idv, o + j);
+        const char *rowbase = bitmap + (size_t)row * stride;
+        const __amdgpu_buffer_rsrc_t rsrc =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(rowbase), 0, stride, 0x00027000);
+        const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, col, 0, 0);
+        buf[j] = make_uint4(v.x, v.y, v.z, v.w);
+    }
+}
+
 // carry of weight 8 of eight 16-byte row segments, per 32-reference word
 template <int NP>
 __device__ __forceinline__ uint4 tree8(uint32_t (&pl)[4][NP], const uint4 (&a)[8]) {
@@ -58,6 +77,114 @@ __device__ __forceinline__ uint4 csa_plane(uint32_t (&pl)[4][NP], const uint4 &a
     return c;
 }
 
+
+template <int NP, int P>
+__device__ __forceinline__ uint4 half_plane(uint32_t (&pl)[4][NP], const uint4 &a) {  // a carry-save adder with one input 0
+    uint4 c;
+    c.x = pl[0][P] & a.x; pl[0][P] ^= a.x;
+    c.y = pl[1][P] & a.y; pl[1][P] ^= a.y;
+    c.z = pl[2][P] & a.z; pl[2][P] ^= a.z;
+    c.w = pl[3][P] & a.w; pl[3][P] ^= a.w;
+    return c;
+}
+
+template <int NP, int L>
+__device__ __forceinline__ void ripple4(uint32_t (&pl)[4][NP], const uint4 &c) {
+    planes_ripple<NP, L>(pl[0], c.x);
+    planes_ripple<NP, L>(pl[1], c.y);
+    planes_ripple<NP, L>(pl[2], c.z);
+    planes_ripple<NP, L>(pl[3], c.w);
+}
+
+// The row loop with NB buffers of eight rows: every buffer is requested again as soon as it has been folded, so
+// 8 * (NB - 1) .. 8 * NB rows are in flight per wave (the loop is bound by rows in flight per CU / load latency).
+// list: n8 * 8 row ids, padded with the zero row up to n8 * 8 + NB * 8 + 64 (the loads are unconditional: the rows
+// behind the list are the zero row -- predicated loads cost the compiler its register allocation).
+template <int NP, int NB>
+__device__ __forceinline__ void fold_ring(uint32_t (&pl)[4][NP], const uint32_t *list, uint32_t n8, uint32_t lane,
+                                          const char *__restrict__ bitmap, uint32_t col, uint32_t stride) {
+    static_assert(NB >= 3 && NB <= 6, "groups of 24 .. 48 rows");
+    constexpr uint32_t GR = NB * 8;
+    const uint32_t ng = n8 / NB, nt = n8 - ng * NB;
+    uint32_t idv = list[lane];
+    uint4 buf[NB][8];
+#pragma unroll
+    for (int b = 0; b < NB; b++) load8v_at(buf[b], bitmap, col, stride, idv, b * 8);
+    for (uint32_t g = 0; g < ng; g++) {
+        const uint32_t idn = list[(g + 1) * GR + lane];
+        uint4 c3[NB];
+#pragma unroll
+        for (int b = 0; b < NB; b++) {
+            c3[b] = tree8<NP>(pl, buf[b]);
+            load8v_at(buf[b], bitmap, col, stride, idn, b * 8);
+        }
+        const uint4 c4a = csa_plane<NP, 3>(pl, c3[0], c3[1]);
+        if (NB == 3) {
+            const uint4 c4b = half_plane<NP, 3>(pl, c3[2]);
+            const uint4 c5 = csa_plane<NP, 4>(pl, c4a, c4b);
+            ripple4<NP, 5>(pl, c5);
+        } else {
+            const uint4 c4b = csa_plane<NP, 3>(pl, c3[2], c3[3]);
+            const uint4 c5a = csa_plane<NP, 4>(pl, c4a, c4b);
+            if (NB == 4) {
+                ripple4<NP, 5>(pl, c5a);
+            } else {
+                const uint4 c4c = NB == 5 ? half_plane<NP, 3>(pl, c3[NB - 1]) : csa_plane<NP, 3>(pl, c3[4], c3[NB - 1]);
+                const uint4 c5b = half_plane<NP, 4>(pl, c4c);
+                const uint4 c6 = csa_plane<NP, 5>(pl, c5a, c5b);
+                ripple4<NP, 6>(pl, c6);
+            }
+        }
+        idv = idn;
+    }
+#pragma unroll
+    for (int b = 0; b < NB - 1; b++)
+        if ((uint32_t)b < nt) {
+            const uint4 c3 = tree8<NP>(pl, buf[b]);
+            ripple4<NP, 3>(pl, c3);
+        }
+}
+
+// The same for a row list that TWO queries share (hit_count_pair_kernel): every buffer is folded into both plane sets
+// before it is requested again -- one load, two folds.
+template <int NP, int NB>
+__device__ __forceinline__ void fold_ring2(uint32_t (&pa)[4][NP], uint32_t (&pb)[4][NP], const uint32_t *list, uint32_t n8,
+                                           uint32_t lane, const char *__restrict__ bitmap, uint32_t col, uint32_t stride) {
+    static_assert(NB >= 3 && NB <= 4, "groups of 24 or 32 rows");
+    constexpr uint32_t GR = NB * 8;
+    const uint32_t ng = n8 / NB, nt = n8 - ng * NB;
+    uint32_t idv = list[lane];
+    uint4 buf[NB][8];
+#pragma unroll
+    for (int b = 0; b < NB; b++) load8v_at(buf[b], bitmap, col, stride, idv, b * 8);
+    for (uint32_t g = 0; g < ng; g++) {
+        const uint32_t idn = list[(g + 1) * GR + lane];
+        uint4 ca[NB], cb[NB];
+#pragma unroll
+        for (int b = 0; b < NB; b++) {
+            ca[b] = tree8<NP>(pa, buf[b]);
+            cb[b] = tree8<NP>(pb, buf[b]);
+            load8v_at(buf[b], bitmap, col, stride, idn, b * 8);
+        }
+        {
+            const uint4 c4a = csa_plane<NP, 3>(pa, ca[0], ca[1]);
+            const uint4 c4b = NB == 3 ? half_plane<NP, 3>(pa, ca[2]) : csa_plane<NP, 3>(pa, ca[2], ca[NB - 1]);
+            ripple4<NP, 5>(pa, csa_plane<NP, 4>(pa, c4a, c4b));
+        }
+        {
+            const uint4 c4a = csa_plane<NP, 3>(pb, cb[0], cb[1]);
+            const uint4 c4b = NB == 3 ? half_plane<NP, 3>(pb, cb[2]) : csa_plane<NP, 3>(pb, cb[2], cb[NB - 1]);
+            ripple4<NP, 5>(pb, csa_plane<NP, 4>(pb, c4a, c4b));
+        }
+        idv = idn;
+    }
+#pragma unroll
+    for (int b = 0; b < NB - 1; b++)
+        if ((uint32_t)b < nt) {
+            ripple4<NP, 3>(pa, tree8<NP>(pa, buf[b]));
+            ripple4<NP, 3>(pb, tree8<NP>(pb, buf[b]));
+        }
+}
 
 // ---------------------------------------------------------------------------
 // The mid segments of a (query, tile) wave (17 .. kSegMidMax references: 128 bytes of positions instead of a 1-KiB row
@@ -123,25 +250,34 @@ __device__ __forceinline__ void hit_mid_rows(const HitParams &p, uint32_t (&pl)[
 // atomics and flushes it with one global atomic per non-empty bin.
 //   hist_lds: [t + 1] u32 of this wave; cnt8: [1024] u32 (4096 byte counters) of this wave.
 // ---------------------------------------------------------------------------
-template <int NP, bool kPacked>
+//   kPrefetch: the slots of ALL sparse segments of the tile are requested at once and kept in registers for both half-tile
+//   passes (two round trips instead of two per 64 segments and half) -- for kernels with registers to spare in the epilogue.
+template <int NP, bool kPacked, bool kPrefetch = false>
 __device__ __forceinline__ void hit_epilogue(const HitParams &p, uint32_t (&pl)[4][NP], uint32_t q, uint32_t tile, uint32_t lane,
                                              uint32_t t, bool active, uint32_t *hist_lds, uint32_t *cnt8, uint32_t ns,
                                              const uint32_t *srows) {
+    RTX_EPI_DECL
+    constexpr int kIt = (kSegMaxSparseRows + 63) / 64, kVp = kSegSlotEntries / 8;
+    uint4 pre[kPrefetch ? kIt : 1][kVp];
+    if (kPrefetch && ns) {
+        uint32_t sid[kIt];
+#pragma unroll
+        for (int it = 0; it < kIt; it++) sid[it] = (uint32_t)it * 64u + lane < ns ? srows[(uint32_t)it * 64u + lane] : 0xFFFFFFFFu;
+#pragma unroll
+        for (int it = 0; it < kIt; it++)
+#pragma unroll
+            for (int i = 0; i < kVp; i++) {
+                pre[it][i] = make_uint4(~0u, ~0u, ~0u, ~0u);
+                if (sid[it] != 0xFFFFFFFFu) pre[it][i] = reinterpret_cast<const uint4 *>(p.segslots + (size_t)sid[it] * kSegSlotEntries)[i];
+            }
+    }
     // hits of the sparse segments on the references [half*4096, half*4096 + 4096) of the tile -> cnt8 (at most 255 each)
     auto sparse_hits = [&](uint32_t half) {
 #pragma unroll
         for (int i = 0; i < 4; i++) reinterpret_cast<uint4 *>(cnt8)[i * 64 + lane] = make_uint4(0, 0, 0, 0);
         wave_lds_sync();
-        for (uint32_t c0 = 0; c0 < ns; c0 += 64) {
-            constexpr int kV = kSegSlotEntries / 8;  // uint4 per slot
-            uint4 e[kV];
-#pragma unroll
-            for (int i = 0; i < kV; i++) e[i] = make_uint4(~0u, ~0u, ~0u, ~0u);
-            if (c0 + lane < ns) {
-                const uint4 *slot = reinterpret_cast<const uint4 *>(p.segslots + (size_t)srows[c0 + lane] * kSegSlotEntries);
-#pragma unroll
-                for (int i = 0; i < kV; i++) e[i] = slot[i];
-            }
+        constexpr int kV = kSegSlotEntries / 8;  // uint4 per slot
+        auto add_slot = [&](const uint4 (&e)[kV]) {
 #pragma unroll
             for (int i = 0; i < kV; i++) {
                 const uint32_t wv[4] = {e[i].x, e[i].y, e[i].z, e[i].w};
@@ -151,12 +287,30 @@ __device__ __forceinline__ void hit_epilogue(const HitParams &p, uint32_t (&pl)[
                     if ((id >> 12) == half) atomicAdd(&cnt8[(id & 4095u) >> 2], 1u << ((id & 3u) * 8u));
                 }
             }
+        };
+        if (kPrefetch) {
+#pragma unroll
+            for (int it = 0; it < kIt; it++)
+                if ((uint32_t)it * 64u < ns) add_slot(pre[kPrefetch ? it : 0]);  // wave-uniform
+        } else {
+            for (uint32_t c0 = 0; c0 < ns; c0 += 64) {
+                uint4 e[kV];
+#pragma unroll
+                for (int i = 0; i < kV; i++) e[i] = make_uint4(~0u, ~0u, ~0u, ~0u);
+                if (c0 + lane < ns) {
+                    const uint4 *slot = reinterpret_cast<const uint4 *>(p.segslots + (size_t)srows[c0 + lane] * kSegSlotEntries);
+#pragma unroll
+                    for (int i = 0; i < kV; i++) e[i] = slot[i];
+                }
+                add_slot(e);
+            }
         }
         wave_lds_sync();
     };
 
     for (uint32_t i = lane; i <= t; i += 64) hist_lds[i] = 0;
     wave_lds_sync();
+    RTX_EPI_MARK(5)
 
     const uint32_t L = tile_lanes(p.stride_bytes, tile);  // lanes of this tile (64 except in the last one)
     if (active && (p.flags & RTX_SKIP_EXACT_MATCHES)) {  // raxtax.rs:65-68: the dense part
@@ -188,6 +342,7 @@ __device__ __forceinline__ void hit_epilogue(const HitParams &p, uint32_t (&pl)[
     for (int i = 0; i < 8; i++) hiw[i] = 0;
 #pragma unroll
     for (int half = 0; half < 2; half++) {  // groups 0-7 = references 0..4095 of a full tile, groups 8-15 = 4096..8191
+        RTX_EPI_MARK(6)
         if (ns) {
             sparse_hits((uint32_t)half);
             if (p.flags & RTX_SKIP_EXACT_MATCHES) {  // raxtax.rs:65-68: the sparse part
@@ -201,6 +356,7 @@ __device__ __forceinline__ void hit_epilogue(const HitParams &p, uint32_t (&pl)[
                 wave_lds_sync();
             }
         }
+        RTX_EPI_MARK(7)
         if (active) {
 #pragma unroll
             for (int wi = 0; wi < 2; wi++) {
@@ -232,7 +388,9 @@ __device__ __forceinline__ void hit_epilogue(const HitParams &p, uint32_t (&pl)[
                         __hip_atomic_store(reinterpret_cast<unsigned long long *>(out_lo + goff), ((unsigned long long)lo8.y << 32) | lo8.x,
                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #else
+#ifndef RTX_EXP_NO_COUNT_STORE
                         *reinterpret_cast<uint2 *>(out_lo + goff) = lo8;
+#endif
 #endif
                         // high bytes (0..3 each) -> 2 bits per reference: byte j moves to bit 2j
                         const uint32_t hb0 = __builtin_amdgcn_perm(st.y, st.x, 0x07050301u), hb1 = __builtin_amdgcn_perm(st.w, st.z, 0x07050301u);
@@ -250,12 +408,15 @@ __device__ __forceinline__ void hit_epilogue(const HitParams &p, uint32_t (&pl)[
 #pragma unroll
                     for (int j = 0; j < 8; j++) {
                         const uint32_t c = (cw[j >> 1] >> ((j & 1) * 16)) & 0xFFFFu;
+#ifndef RTX_EXP_NO_HIST  // experiment: what the histogram atomics cost (wrong results)
                         if ((uint32_t)j < nvalid) atomicAdd(&hist_lds[c], 1u);
+#endif
                     }
                 }
             }
         }
     }
+    RTX_EPI_MARK(6)
     if (kPacked) {
         // The high-bit words leave in chunk order (u16 index g * L + lane within the tile): transposed through the
         // byte-counter region of LDS (free now) so that every lane stores 32 contiguous bytes.
@@ -288,6 +449,7 @@ __device__ __forceinline__ void hit_epilogue(const HitParams &p, uint32_t (&pl)[
         }
         if (lane == 0) p.tile_max[(size_t)q * p.ntiles + tile] = (uint16_t)mx;
     }
+    RTX_EPI_DONE
 }
 
 }  // namespace rtx

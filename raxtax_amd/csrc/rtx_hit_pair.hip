@@ -1,0 +1,259 @@
+// hit_count for two neighbouring queries per wave (src/raxtax.rs:41,58-68, prob.rs:13-19).
+//
+// hit_count_kernel (rtx_kernels.hip) runs at the rate at which an XCD's L2 hands 1-KiB row segments to the CUs: more
+// rows in flight per CU than it has do not make it faster, fewer bytes do.  The queries of a
+// batch are processed in an order that puts related ones next to each other (rtx_cluster.hip); two neighbours share
+// more than half of their rows.  Here ONE wave takes two consecutive queries of the processing order and one tile,
+// keeps two sets of bit planes in registers (256 VGPRs, two waves per SIMD, 32 rows in flight per wave) and loads
+// every row the two share once:
+//
+//   pair_union_kernel   once per sub-batch and pair: the union of the two row lists in ascending row order, every
+//                       entry with its position in the list of A and / or B (the dense masks of kmer_extract are
+//                       indexed by those positions)
+//   prologue            per tile: the union entries whose segment is dense in this tile, split into three lists in
+//                       LDS: rows of both queries, of A only, of B only
+//   row loop            groups of 32 rows, four buffers of eight in flight; the shared list is folded into both plane sets
+//                       from one load per row, then A's rows into A's planes, then B's; the three segments run as one
+//                       pipeline (fold_seg); no barrier, no data-dependent control flow inside a segment
+//   epilogue            per query, unchanged (rtx_hit_common.hpp), A then B
+//
+// The VALU work per query is what it was; the counts are those of hit_count_kernel bit for bit.
+#include <hip/hip_runtime.h>
+
+#ifdef RTX_PAIR_STAMP
+// stamps inside the epilogue: 5 = start .. histogram zeroed (incl. the wait for nothing), 7 = sparse segments, 6 = unpack + stores +
+// histogram atomics, 8 = the rest (high bits, flush); the variables live in the kernel
+#define RTX_EPI_MARK(k) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); if (RTX_PAIR_STAMP == (k)) st_acc_g += now_ - st_t_g; st_t_g = now_; }
+#define RTX_EPI_DECL unsigned long long st_acc_g = 0, st_t_g = __builtin_amdgcn_s_memtime();
+#define RTX_EPI_DONE RTX_EPI_MARK(8) if (RTX_PAIR_STAMP >= 5 && lane == 0 && p.group_rows) atomicAdd(&p.group_rows[p.group_base + (q >> 1)], (uint32_t)(st_acc_g >> 6));
+#endif
+#include "rtx_hit_common.hpp"
+
+namespace rtx {
+
+constexpr uint32_t kPairCap = kHitListCap;            // entries per list and round
+constexpr uint32_t kPairListDw = kPairCap + 192u;     // + padding to a multiple of 8 + the look-ahead of the row loop
+constexpr uint32_t kPairMaskWords = 64u;              // dense-mask words (u64) per query and tile kept in LDS: rstride <= 4096
+constexpr uint32_t kPairLdsBytes = 3u * kPairListDw * 4u + 2u * kPairMaskWords * 8u + 32u * 4u;  // lists | dense masks | 32 x the zero row
+constexpr int kPairNB = 4;                            // buffers of eight rows per wave
+
+// ---------------------------------------------------------------------------
+// Union of the row lists of the queries 2 * pair and 2 * pair + 1 of a sub-batch (ascending row ids, as kmer_extract
+// leaves them).  Entry = {row | inA << 30 | inB << 31, posA | posB << 16} (0xFFFF: not in that list).
+// One wave per pair; two 65 536-bit sets in LDS, read out in order with a prefix scan.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void pair_union_kernel(const uint32_t *__restrict__ rows, const uint32_t *__restrict__ nrows,
+                                                        uint32_t rstride, uint32_t nq, uint2 *__restrict__ urec,
+                                                        uint32_t *__restrict__ nu, uint32_t ustride) {
+    __shared__ uint32_t bits[2][2048];
+    const uint32_t pair = blockIdx.x, lane = threadIdx.x;
+    const uint32_t qa = pair * 2u, qb = qa + 1u;
+    const uint32_t na = nrows[qa], nb = qb < nq ? nrows[qb] : 0u;
+    for (uint32_t i = lane; i < 4096u; i += 64) (&bits[0][0])[i] = 0u;
+    wave_lds_sync();
+    const uint32_t *ra = rows + (size_t)qa * rstride, *rb = rows + (size_t)(qb < nq ? qb : qa) * rstride;
+    for (uint32_t i = lane; i < na; i += 64) {
+        const uint32_t r = ra[i] & 0xFFFFu;
+        atomicOr(&bits[0][r >> 5], 1u << (r & 31u));
+    }
+    for (uint32_t i = lane; i < nb; i += 64) {
+        const uint32_t r = rb[i] & 0xFFFFu;
+        atomicOr(&bits[1][r >> 5], 1u << (r & 31u));
+    }
+    wave_lds_sync();
+    uint2 *out = urec + (size_t)pair * ustride;
+    uint32_t n_u = 0, n_a = 0, n_b = 0;  // wave-uniform running totals
+    for (uint32_t w0 = 0; w0 < 2048u; w0 += 64) {
+        const uint32_t a = bits[0][w0 + lane], b = bits[1][w0 + lane];
+        uint32_t u = a | b;
+        if (__ballot(u != 0u) == 0ull) continue;
+        // exclusive prefix over the lanes of the three counts (each below 2^11 in total: packed 11 + 11 bits and one apart)
+        uint32_t su = (uint32_t)__popc(u), sab = (uint32_t)__popc(a) | ((uint32_t)__popc(b) << 16);
+        uint32_t iu = su, iab = sab;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t tu = __shfl_up(iu, d, 64), tab = __shfl_up(iab, d, 64);
+            if ((int)lane >= d) { iu += tu; iab += tab; }
+        }
+        uint32_t pu = n_u + iu - su, pa = n_a + (iab & 0xFFFFu) - (sab & 0xFFFFu), pb = n_b + (iab >> 16) - (sab >> 16);
+        while (u) {
+            const uint32_t bit = (uint32_t)__ffs((int)u) - 1u;
+            u &= u - 1u;
+            const uint32_t ina = (a >> bit) & 1u, inb = (b >> bit) & 1u;
+            out[pu] = make_uint2(((w0 + lane) * 32u + bit) | (ina << 30) | (inb << 31),
+                                 (ina ? pa : 0xFFFFu) | ((inb ? pb : 0xFFFFu) << 16));
+            pu++;
+            pa += ina;
+            pb += inb;
+        }
+        n_u += (uint32_t)__shfl(iu, 63, 64);
+        const uint32_t tab = (uint32_t)__shfl(iab, 63, 64);
+        n_a += tab & 0xFFFFu;
+        n_b += tab >> 16;
+    }
+    if (lane == 0) nu[pair] = n_u;
+}
+
+// One segment of the row loop: `ng` groups of 32 rows of `list`, folded into both plane sets (MODE 0), A's (1) or B's (2).
+// On entry the four buffers hold (have requested) the first group; every buffer is requested again as soon as it has
+// been folded -- in the last group with the first rows of the NEXT segment (`next`), so that the three segments of a
+// wave run as one pipeline: the load latency is exposed once per wave, not once per list.
+template <int NP, int MODE>
+__device__ __forceinline__ void fold_seg(uint32_t (&pa)[4][NP], uint32_t (&pb)[4][NP], uint4 (&buf)[4][8], const uint32_t *list,
+                                         uint32_t ng, const uint32_t *next, uint32_t lane, const char *__restrict__ bitmap,
+                                         uint32_t col, uint32_t stride) {
+    for (uint32_t g = 0; g < ng; g++) {
+        const uint32_t *src = g + 1 < ng ? list + (g + 1) * 32u : next;  // wave-uniform
+        const uint32_t idn = src[lane & 31u];
+        uint4 ca[4], cb[4];
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            if (MODE != 2) ca[b] = tree8<NP>(pa, buf[b]);
+            if (MODE != 1) cb[b] = tree8<NP>(pb, buf[b]);
+            load8v_at(buf[b], bitmap, col, stride, idn, b * 8);
+        }
+        if (MODE != 2) {
+            const uint4 c4a = csa_plane<NP, 3>(pa, ca[0], ca[1]), c4b = csa_plane<NP, 3>(pa, ca[2], ca[3]);
+            ripple4<NP, 5>(pa, csa_plane<NP, 4>(pa, c4a, c4b));
+        }
+        if (MODE != 1) {
+            const uint4 c4a = csa_plane<NP, 3>(pb, cb[0], cb[1]), c4b = csa_plane<NP, 3>(pb, cb[2], cb[3]);
+            ripple4<NP, 5>(pb, csa_plane<NP, 4>(pb, c4a, c4b));
+        }
+    }
+}
+
+template <int NP, bool kPacked>
+__global__ __launch_bounds__(64, 2) void hit_count_pair_kernel(HitParams p) {
+    extern __shared__ uint32_t lds_dw[];
+    const uint32_t tile = blockIdx.y, lane = threadIdx.x;
+    // pairs are dealt to the XCDs like the queries of hit_count_kernel: XCD x takes a contiguous slice of the sub-batch
+    const uint32_t np8 = gridDim.x >> 3;
+    const uint32_t pair = blockIdx.x < np8 * 8u ? (blockIdx.x & 7u) * np8 + (blockIdx.x >> 3) : blockIdx.x;
+    const uint32_t qa = pair * 2u, qb = qa + 1u;
+    const bool has_b = qb < p.nq;
+    uint32_t *l_both = lds_dw, *l_a = lds_dw + kPairListDw, *l_b = lds_dw + 2u * kPairListDw;
+    unsigned long long *m_a = reinterpret_cast<unsigned long long *>(lds_dw + 3u * kPairListDw), *m_b = m_a + kPairMaskWords;
+    uint32_t *l_zero = reinterpret_cast<uint32_t *>(m_b + kPairMaskWords);
+    if (lane < 32u) l_zero[lane] = p.zero_row;
+    const uint32_t col = tile * 1024u + lane * 16u;
+    const bool active = col < p.stride_bytes;
+    uint32_t pa[4][NP], pb[4][NP];
+#pragma unroll
+    for (int w = 0; w < 4; w++)
+#pragma unroll
+        for (int b = 0; b < NP; b++) { pa[w][b] = 0; pb[w][b] = 0; }
+
+#ifdef RTX_PAIR_STAMP  // experiment: cycles of one phase per (pair, tile) instead of the rows loaded (1 prologue, 2 row loop, 3 epilogue A, 4 epilogue B)
+    unsigned long long st_acc = 0, st_t = __builtin_amdgcn_s_memtime();
+#define PAIR_MARK(k) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); if (RTX_PAIR_STAMP == (k)) st_acc += now_ - st_t; st_t = now_; }
+#else
+#define PAIR_MARK(k)
+#endif
+    const uint32_t mwords = p.rstride >> 6;
+    {
+        const unsigned long long *dm_a = p.dmask + ((size_t)qa * p.ntiles + tile) * mwords;
+        const unsigned long long *dm_b = p.dmask + ((size_t)(has_b ? qb : qa) * p.ntiles + tile) * mwords;
+        for (uint32_t i = lane; i < mwords; i += 64) {
+            m_a[i] = dm_a[i];
+            m_b[i] = has_b ? dm_b[i] : 0ull;
+        }
+    }
+    wave_lds_sync();
+    const uint32_t n_u = p.pair_nu[pair];
+    const uint2 *urec = p.pair_urec + (size_t)pair * p.pair_ustride;
+    const char *bitmap = reinterpret_cast<const char *>(p.bitmap);
+    const uint32_t stride = p.stride_bytes;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    uint32_t rows_loaded = 0;
+    uint32_t u0 = 0;
+    while (u0 < n_u) {  // one round unless a list would overflow (t > kPairCap - 64)
+        uint32_t n_both = 0, n_a = 0, n_b = 0;
+        bool room = true;
+        while (room && u0 < n_u) {
+            // eight chunks of 64 union entries per round trip
+            uint2 rec[8];
+#pragma unroll
+            for (int c = 0; c < 8; c++) {
+                const uint32_t i = u0 + (uint32_t)c * 64u + lane;
+                rec[c] = urec[i < n_u ? i : n_u - 1u];
+            }
+#pragma unroll
+            for (int c = 0; c < 8; c++) {
+                if (u0 >= n_u) break;
+                if (n_both + 64u > kPairCap || n_a + 64u > kPairCap || n_b + 64u > kPairCap) { room = false; break; }
+                const bool in = u0 + lane < n_u;
+                const uint32_t pos_a = rec[c].y & 0xFFFFu, pos_b = rec[c].y >> 16;
+                const bool da = in && (rec[c].x & (1u << 30)) && ((m_a[pos_a >> 6] >> (pos_a & 63u)) & 1ull);
+                const bool db = in && (rec[c].x & (1u << 31)) && ((m_b[pos_b >> 6] >> (pos_b & 63u)) & 1ull);
+                const uint32_t row = rec[c].x & 0x3FFFFFFFu;
+                const unsigned long long bb = __ballot(da && db), ba = __ballot(da && !db), bo = __ballot(db && !da);
+                if (da && db) l_both[n_both + (uint32_t)__popcll(bb & lt_mask)] = row;
+                if (da && !db) l_a[n_a + (uint32_t)__popcll(ba & lt_mask)] = row;
+                if (db && !da) l_b[n_b + (uint32_t)__popcll(bo & lt_mask)] = row;
+                n_both += (uint32_t)__popcll(bb);
+                n_a += (uint32_t)__popcll(ba);
+                n_b += (uint32_t)__popcll(bo);
+                u0 += 64;
+            }
+        }
+        rows_loaded += n_both + n_a + n_b;
+        // groups of 32 rows; the rows a list lacks for its last group are the zero row
+        const uint32_t g_both = (n_both + 31u) >> 5, g_a = (n_a + 31u) >> 5, g_b = (n_b + 31u) >> 5;
+        for (uint32_t i = n_both + lane; i < g_both * 32u; i += 64) l_both[i] = p.zero_row;
+        for (uint32_t i = n_a + lane; i < g_a * 32u; i += 64) l_a[i] = p.zero_row;
+        for (uint32_t i = n_b + lane; i < g_b * 32u; i += 64) l_b[i] = p.zero_row;
+        wave_lds_sync();
+        PAIR_MARK(1)
+        const uint32_t *first = g_both ? l_both : (g_a ? l_a : (g_b ? l_b : nullptr));
+        if (first) {
+            uint4 buf[4][8];
+            const uint32_t idv = first[lane & 31u];
+#pragma unroll
+            for (int b = 0; b < 4; b++) load8v_at(buf[b], bitmap, col, stride, idv, b * 8);
+            const uint32_t *after_a = g_b ? l_b : l_zero, *after_both = g_a ? l_a : after_a;
+            if (g_both) fold_seg<NP, 0>(pa, pb, buf, l_both, g_both, after_both, lane, bitmap, col, stride);
+            if (g_a) fold_seg<NP, 1>(pa, pb, buf, l_a, g_a, after_a, lane, bitmap, col, stride);
+            if (g_b) fold_seg<NP, 2>(pa, pb, buf, l_b, g_b, l_zero, lane, bitmap, col, stride);
+        }
+        PAIR_MARK(2)
+        wave_lds_sync();  // the lists are rewritten (next round) or become the histogram and the byte counters
+    }
+#ifndef RTX_PAIR_STAMP
+    if (lane == 0 && p.group_rows) atomicAdd(&p.group_rows[p.group_base + pair], rows_loaded);
+#endif
+
+    // epilogues: histogram / byte counters over the lists (dead now)
+    uint32_t *hist_lds = lds_dw;
+    uint32_t *cnt8 = lds_dw + 2u * kPairListDw;  // 4 KiB: the third list
+    {
+        const uint32_t ns = p.nsparse[(size_t)qa * p.ntiles + tile];
+        const uint32_t *srows = p.srows + ((size_t)qa * p.ntiles + tile) * (kSegMaxSparseRows + 1);
+        hit_epilogue<NP, kPacked, true>(p, pa, qa, tile, lane, p.t[qa], active, hist_lds, cnt8, ns, srows);
+    }
+    PAIR_MARK(3)
+    if (has_b) {
+        wave_lds_sync();
+        const uint32_t ns = p.nsparse[(size_t)qb * p.ntiles + tile];
+        const uint32_t *srows = p.srows + ((size_t)qb * p.ntiles + tile) * (kSegMaxSparseRows + 1);
+        hit_epilogue<NP, kPacked, true>(p, pb, qb, tile, lane, p.t[qb], active, hist_lds, cnt8, ns, srows);
+    }
+    PAIR_MARK(4)
+#ifdef RTX_PAIR_STAMP
+    if (lane == 0 && p.group_rows) atomicAdd(&p.group_rows[p.group_base + pair], (uint32_t)(st_acc >> 6));
+#endif
+}
+
+void launch_pair_union(hipStream_t s, const uint32_t *rows, const uint32_t *nrows, uint32_t rstride, uint32_t nq, uint2 *urec,
+                       uint32_t *nu, uint32_t ustride) {
+    hipLaunchKernelGGL(pair_union_kernel, dim3((nq + 1u) / 2u), dim3(64), 0, s, rows, nrows, rstride, nq, urec, nu, ustride);
+}
+
+void launch_hit_count_pair(hipStream_t s, const HitParams &p, uint32_t nq, uint32_t ntiles) {
+    static_assert(2u * kPairListDw >= 1024u + 64u + 1024u, "histogram (t <= 1023) and byte counters alias the lists");
+    const uint32_t np = (nq + 1u) / 2u;
+    if (p.counts_lo) hipLaunchKernelGGL((hit_count_pair_kernel<10, true>), dim3(np, ntiles), dim3(64), kPairLdsBytes, s, p);
+    else hipLaunchKernelGGL((hit_count_pair_kernel<10, false>), dim3(np, ntiles), dim3(64), kPairLdsBytes, s, p);
+}
+
+}  // namespace rtx

@@ -387,8 +387,16 @@ __global__ __launch_bounds__(64) void kmer_extract_kernel(KmerParams p) {
 
 // Occupancy matters here: with <= 128 VGPRs four waves per SIMD are resident (16 per CU; their 8.4 KB of LDS each
 // just fit) -- a variant with 132 VGPRs (three waves) was 16 % slower.  The bound makes the compiler keep it.
+#ifndef RTX_HIT_NB
+#define RTX_HIT_NB 2
+#endif
+
 template <int NP, bool kPacked>
+#if RTX_HIT_NB > 2  // RTX_HIT_NB buffers of eight rows in flight per wave, 256 registers, two waves per SIMD (three with NB = 3)
+__global__ __launch_bounds__(64, (RTX_HIT_NB == 3 ? 3 : 2)) void hit_count_kernel(HitParams p) {
+#else
 __global__ __launch_bounds__(64, (NP <= 10 ? 4 : 2)) void hit_count_kernel(HitParams p) {
+#endif
     extern __shared__ uint32_t hist_lds[];
     const uint32_t tile = blockIdx.y, lane = threadIdx.x;
     // Workgroups are dealt round-robin to the 8 XCDs (each with an L2 of its own).  Neighbouring slots hold
@@ -450,8 +458,15 @@ __global__ __launch_bounds__(64, (NP <= 10 ? 4 : 2)) void hit_count_kernel(HitPa
             // groups of 32 rows in the main loop, then up to three groups of 8 (the list is padded to a multiple of 8 only;
             // the entries behind it, read by the look-ahead loads, are zero rows)
             const uint32_t n8 = (count + 7u) >> 3, n32 = n8 >> 2, ntail = n8 & 3u;
+#if RTX_HIT_NB > 2
+            for (uint32_t i = count + lane; i < n8 * 8u + RTX_HIT_NB * 8u + 64u; i += 64) list[i] = p.zero_row;
+#else
             for (uint32_t i = count + lane; i < n32 * 32u + 32u; i += 64) list[i] = p.zero_row;
+#endif
             __syncthreads();
+#if RTX_HIT_NB > 2
+            if (n8) fold_ring<NP, RTX_HIT_NB>(pl, list, n8, lane, bitmap, col, stride);
+#else
             if (n8) {
                 uint32_t idv = list[lane & 31u];
                 uint4 A[8], B[8];
@@ -499,6 +514,7 @@ __global__ __launch_bounds__(64, (NP <= 10 ? 4 : 2)) void hit_count_kernel(HitPa
                     }
                 }
             }
+#endif
             __syncthreads();  // the list is rewritten (next round) or becomes the histogram
         }
     }
@@ -1216,10 +1232,14 @@ void launch_kmer_extract(hipStream_t s, const KmerParams &p, uint32_t nq) {
 }
 void launch_hit_count(hipStream_t s, const HitParams &p_in, uint32_t nq, uint32_t ntiles, int planes) {
     HitParams p = p_in;
-    const uint32_t first = std::max<uint32_t>((p.hstride + 3u) & ~3u, kHitListCap + 64u);  // histogram / row-id list
+    const uint32_t first = std::max<uint32_t>((p.hstride + 3u) & ~3u, kHitListCap + (RTX_HIT_NB > 2 ? 192u : 64u));  // histogram / row-id list
     p.lds_cnt8_off = first;
     // 8.4 KB per wave: measured flat up to there, +7 % at 10.4 KB, +14 % at 12.5 KB (16 waves per CU must fit in 160 KB)
+#ifdef RTX_EXP_HIT_LDS_KB  // experiment: fewer waves per CU (160 KB / this)
+    const size_t lds = std::max<size_t>((size_t)first * sizeof(uint32_t) + 4096, (size_t)RTX_EXP_HIT_LDS_KB * 1024);
+#else
     const size_t lds = (size_t)first * sizeof(uint32_t) + 4096;  // ... | byte counters
+#endif
     if (planes <= 10 && p.counts_lo) hipLaunchKernelGGL((hit_count_kernel<10, true>), dim3(nq, ntiles), dim3(64), lds, s, p);
     else if (planes <= 10) hipLaunchKernelGGL((hit_count_kernel<10, false>), dim3(nq, ntiles), dim3(64), lds, s, p);
     else if (planes <= 12) hipLaunchKernelGGL((hit_count_kernel<12, false>), dim3(nq, ntiles), dim3(64), lds, s, p);

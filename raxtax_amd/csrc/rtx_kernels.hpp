@@ -110,6 +110,10 @@ struct HitParams {
     uint32_t nq;           // slots of the sub-batch
     uint32_t *group_rows;  // [groups of the batch] union rows loaded per group, summed over the tiles (work accounting) or null
     uint32_t group_base;   // index of the sub-batch's first group in group_rows
+    // hit_count_pair_kernel (rtx_hit_pair.hip): two consecutive slots per wave
+    const uint2 *pair_urec;   // [pairs][pair_ustride] union of the two row lists (pair_union_kernel)
+    const uint32_t *pair_nu;  // [pairs] entries of the union
+    uint32_t pair_ustride;
 };
 
 // memoised cmf / pmf-ratio tables for every (t, m, i), t <= tmax (rtx_prob_tables.hip)
@@ -188,6 +192,9 @@ void launch_row_popcount(hipStream_t s, const uint32_t *row_of, const uint32_t *
                          uint32_t *list_len);
 void launch_kmer_extract(hipStream_t s, const KmerParams &p, uint32_t nq);
 void launch_hit_count(hipStream_t s, const HitParams &p, uint32_t nq, uint32_t ntiles, int planes);
+void launch_pair_union(hipStream_t s, const uint32_t *rows, const uint32_t *nrows, uint32_t rstride, uint32_t nq, uint2 *urec,
+                       uint32_t *nu, uint32_t ustride);
+void launch_hit_count_pair(hipStream_t s, const HitParams &p, uint32_t nq, uint32_t ntiles);
 void launch_hit_count_quad(hipStream_t s, const HitParams &p, uint32_t nq, uint32_t ntiles);  // 10 bit planes only
 size_t prob_table_lds_bytes(uint32_t tmax);
 void launch_prob_table(hipStream_t s, const ProbParams &p, uint32_t nq);

@@ -340,6 +340,53 @@ def test_packed_counts_equal_u16_counts(world, oracle):
         assert big > 5       # the high bits were exercised
 
 
+def test_pair_kernel_equals_one_query_per_wave(world, oracle):
+    """RTX_OPT_HIT_PAIR: two neighbouring queries per wave, the rows they share loaded once (rtx_hit_pair.hip).
+    Every result array and the hit counts equal those of hit_count_kernel and of the oracle -- with the degenerate
+    queries of `world` (no k-mers, one k-mer, short), odd sub-batch sizes (a last pair of one), --skip-exact-matches,
+    u16 counts."""
+    w = world
+    ex_ids, ex_off = w["index"].exact_matches(w["bases"], w["off"])
+    for kw in (dict(), dict(sub_batch=37), dict(packed_counts=False)):
+        a, b = rx.Index(w["tree"], hit_pair=False, **kw), rx.Index(w["tree"], hit_pair=True, **kw)
+        for skip in (False, True):
+            ra = a.classify(w["bases"], w["off"], ex_ids, ex_off, skip_exact_matches=skip)
+            rb = b.classify(w["bases"], w["off"], ex_ids, ex_off, skip_exact_matches=skip)
+            for f in ("row_off", "row_lineage", "row_conf", "row_local_signal", "global_signal", "t", "status"):
+                assert np.array_equal(getattr(ra, f), getattr(rb, f)), (kw, skip, f)
+            if "sub_batch" in kw:      # the taps see the last sub-batch of the PROCESSING order only
+                continue
+            for q in range(0, len(w["seqs"]), 2):
+                c = b.debug_hit_counts(q)
+                assert np.array_equal(c, a.debug_hit_counts(q)), (kw, skip, q)
+                assert np.array_equal(c, w["otree"].hit_counts(w["seqs"][q], skip_exact=skip)[1])
+        wa, wb = a.work(), b.work()
+        assert wa["sum_hits"] == wb["sum_hits"] and wb["bitmap_bytes_read"] <= wa["bitmap_bytes_read"]
+
+
+@pytest.mark.parametrize("n_refs", [70000, 20011])
+def test_pair_kernel_many_tiles(oracle, n_refs):
+    """The pair kernel over several tiles and a partial last tile, related queries next to each other (shared rows)
+    and unrelated ones; hit counts against the oracle."""
+    db = synth.make_db(n_refs)
+    qs = synth.make_queries(db, 201, exact_frac=0.2)
+    otree = oracle.tree_new_flat(db.lineages, db.seq_bytes, db.seq_off)
+    tree = rx.Tree.new_flat(db.lineages, db.seq_bytes, db.seq_off)
+    a, b = rx.Index(tree, hit_pair=False), rx.Index(tree, hit_pair=True)
+    ex = a.exact_matches(qs.bases, qs.base_off)
+    for skip in (False, True):
+        ra = a.classify(qs.bases, qs.base_off, *ex, skip_exact_matches=skip)
+        rb = b.classify(qs.bases, qs.base_off, *ex, skip_exact_matches=skip)
+        for f in ("row_off", "row_lineage", "row_conf", "row_local_signal", "global_signal", "t", "status"):
+            assert np.array_equal(getattr(ra, f), getattr(rb, f)), (skip, f)
+        for q in range(0, qs.n, 5):
+            c = b.debug_hit_counts(q)
+            assert np.array_equal(c, otree.hit_counts(qs.seq(q), skip_exact=skip)[1]), (skip, q)
+    wa, wb = a.work(), b.work()
+    print(f"bitmap bytes: one query per wave {wa['bitmap_bytes_read']}, pairs {wb['bitmap_bytes_read']}")
+    assert wb["bitmap_bytes_read"] < wa["bitmap_bytes_read"]
+
+
 def test_quad_kernel_equals_one_wave_per_query(world, oracle):
     """RTX_OPT_HIT_QUAD: four neighbouring queries per workgroup, rows loaded once through LDS (rtx_hit_quad.hip).
     Every result array and the hit counts equal those of hit_count_kernel -- with the degenerate queries of `world`
@@ -817,6 +864,7 @@ def test_randomised_configurations(oracle, seed):
     orng = np.random.default_rng(seed + 77)
     opts = dict(hit_quad=bool(orng.random() < 0.35), segment_classes=int(orng.choice([0, 1, 2])), packed_counts=bool(orng.random() < 0.75))
     opts["tile_skip"] = bool(orng.random() < 0.7)   # drawn last: the options of the recorded seeds stay what they were
+    opts["hit_pair"] = bool(orng.random() < 0.6)
     ix = rx.Index(tree, sub_batch=int(rng.choice([0, 5, 64])), cluster=bool(rng.random() < 0.7), **opts)
     rx.Index(tree, segment_classes=1)     # restore the process-wide default for later tests
     qs = []

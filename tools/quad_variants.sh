@@ -12,6 +12,13 @@ build() {  # name, flags
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -fPIC -shared -o "$OUT/lib_$name.so" $objs "$OUT/quad_$name.o" -lpthread
   echo "built $OUT/lib_$name.so"
 }
+buildp() {  # name, flags: a variant of rtx_hit_pair.hip
+  local name=$1; shift
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I"$ROOT/include" -I"$ROOT/raxtax_amd/csrc" "$@" -x hip -c "$ROOT/raxtax_amd/csrc/rtx_hit_pair.hip" -o "$OUT/pair_$name.o"
+  objs=$(ls "$ROOT"/raxtax_amd/_obj/*.o | grep -v rtx_hit_pair)
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -fPIC -shared -o "$OUT/lib_$name.so" $objs "$OUT/pair_$name.o" -lpthread
+  echo "built $OUT/lib_$name.so"
+}
 buildk() {  # name, flags: a variant of rtx_kernels.hip
   local name=$1; shift
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I"$ROOT/include" -I"$ROOT/raxtax_amd/csrc" "$@" -x hip -c "$ROOT/raxtax_amd/csrc/rtx_kernels.hip" -o "$OUT/kern_$name.o"
@@ -24,6 +31,23 @@ for v in "$@"; do
     base) build base ;;
     nomidfold) buildk nomidfold -DRTX_EXP_NO_MID_FOLD ;;
     sc1) buildk sc1 -DRTX_EXP_SC1_COUNT_STORES ;;
+    ps1) buildp ps1 -DRTX_PAIR_STAMP=1 ;;
+    ps2) buildp ps2 -DRTX_PAIR_STAMP=2 ;;
+    ps3) buildp ps3 -DRTX_PAIR_STAMP=3 ;;
+    ps4) buildp ps4 -DRTX_PAIR_STAMP=4 ;;
+    pnohist) buildp pnohist -DRTX_EXP_NO_HIST ;;
+    pnostore) buildp pnostore -DRTX_EXP_NO_COUNT_STORE ;;
+    pnoboth) buildp pnoboth -DRTX_EXP_NO_COUNT_STORE -DRTX_EXP_NO_HIST ;;
+    ps5) buildp ps5 -DRTX_PAIR_STAMP=5 ;;
+    ps6) buildp ps6 -DRTX_PAIR_STAMP=6 ;;
+    ps7) buildp ps7 -DRTX_PAIR_STAMP=7 ;;
+    ps8) buildp ps8 -DRTX_PAIR_STAMP=8 ;;
+    nb3) buildk nb3 -DRTX_HIT_NB=3 ;;
+    nb4) buildk nb4 -DRTX_HIT_NB=4 ;;
+    nb5) buildk nb5 -DRTX_HIT_NB=5 ;;
+    nb6) buildk nb6 -DRTX_HIT_NB=6 ;;
+    occ2) buildk occ2 -DRTX_EXP_HIT_LDS_KB=20 ;;
+    occ3) buildk occ3 -DRTX_EXP_HIT_LDS_KB=13 ;;
     nw8) buildk nw8 -DRTX_PREFIX_NW=8 ;;
     nw2) buildk nw2 -DRTX_PREFIX_NW=2 ;;
     nw16) buildk nw16 -DRTX_PREFIX_NW=16 ;;

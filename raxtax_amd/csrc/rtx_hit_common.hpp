@@ -251,30 +251,37 @@ __device__ __forceinline__ void hit_mid_rows(const HitParams &p, uint32_t (&pl)[
 //   hist_lds: [t + 1] u32 of this wave; cnt8: [1024] u32 (4096 byte counters) of this wave.
 // ---------------------------------------------------------------------------
 //   kPrefetch: the slots of ALL sparse segments of the tile are requested at once and kept in registers for both half-tile
-//   passes (two round trips instead of two per 64 segments and half) -- for kernels with registers to spare in the epilogue.
-template <int NP, bool kPacked, bool kPrefetch = false>
-__device__ __forceinline__ void hit_epilogue(const HitParams &p, uint32_t (&pl)[4][NP], uint32_t q, uint32_t tile, uint32_t lane,
-                                             uint32_t t, bool active, uint32_t *hist_lds, uint32_t *cnt8, uint32_t ns,
-                                             const uint32_t *srows) {
+//   passes (two round trips instead of two per 64 segments and half) -- for kernels with registers to spare in the epilogue;
+//   `pre_in` (optional): they have been requested by the caller already (sparse_prefetch).
+//   kFullTile: cnt8 holds 8192 byte counters, the sparse segments are scanned once for the whole tile.
+constexpr int kSparseIt = (kSegMaxSparseRows + 63) / 64, kSparseV = kSegSlotEntries / 8;
+
+// the slots of all sparse segments of a (query, tile): lane l takes segment it * 64 + l; sid: their slot ids (global or LDS)
+__device__ __forceinline__ void sparse_prefetch(const HitParams &p, uint32_t lane, uint32_t ns, const uint32_t *sid_src,
+                                                uint4 (&pre)[kSparseIt][kSparseV]) {
+    uint32_t sid[kSparseIt];
+#pragma unroll
+    for (int it = 0; it < kSparseIt; it++) sid[it] = (uint32_t)it * 64u + lane < ns ? sid_src[(uint32_t)it * 64u + lane] : 0xFFFFFFFFu;
+#pragma unroll
+    for (int it = 0; it < kSparseIt; it++)
+#pragma unroll
+        for (int i = 0; i < kSparseV; i++) {
+            pre[it][i] = make_uint4(~0u, ~0u, ~0u, ~0u);
+            if (sid[it] != 0xFFFFFFFFu) pre[it][i] = reinterpret_cast<const uint4 *>(p.segslots + (size_t)sid[it] * kSegSlotEntries)[i];
+        }
+}
+
+template <int NP, bool kPacked, bool kPrefetch, bool kFullTile, bool kPreLoaded>
+__device__ __forceinline__ void hit_epilogue_x(const HitParams &p, uint32_t (&pl)[4][NP], uint32_t q, uint32_t tile, uint32_t lane,
+                                               uint32_t t, bool active, uint32_t *hist_lds, uint32_t *cnt8, uint32_t ns,
+                                               const uint32_t *srows, uint4 (&pre)[kSparseIt][kSparseV]) {
     RTX_EPI_DECL
-    constexpr int kIt = (kSegMaxSparseRows + 63) / 64, kVp = kSegSlotEntries / 8;
-    uint4 pre[kPrefetch ? kIt : 1][kVp];
-    if (kPrefetch && ns) {
-        uint32_t sid[kIt];
-#pragma unroll
-        for (int it = 0; it < kIt; it++) sid[it] = (uint32_t)it * 64u + lane < ns ? srows[(uint32_t)it * 64u + lane] : 0xFFFFFFFFu;
-#pragma unroll
-        for (int it = 0; it < kIt; it++)
-#pragma unroll
-            for (int i = 0; i < kVp; i++) {
-                pre[it][i] = make_uint4(~0u, ~0u, ~0u, ~0u);
-                if (sid[it] != 0xFFFFFFFFu) pre[it][i] = reinterpret_cast<const uint4 *>(p.segslots + (size_t)sid[it] * kSegSlotEntries)[i];
-            }
-    }
+    constexpr int kIt = kSparseIt, kVp = kSparseV;
+    if (kPrefetch && !kPreLoaded && ns) sparse_prefetch(p, lane, ns, srows, pre);
     // hits of the sparse segments on the references [half*4096, half*4096 + 4096) of the tile -> cnt8 (at most 255 each)
     auto sparse_hits = [&](uint32_t half) {
 #pragma unroll
-        for (int i = 0; i < 4; i++) reinterpret_cast<uint4 *>(cnt8)[i * 64 + lane] = make_uint4(0, 0, 0, 0);
+        for (int i = 0; i < (kFullTile ? 8 : 4); i++) reinterpret_cast<uint4 *>(cnt8)[i * 64 + lane] = make_uint4(0, 0, 0, 0);
         wave_lds_sync();
         constexpr int kV = kSegSlotEntries / 8;  // uint4 per slot
         auto add_slot = [&](const uint4 (&e)[kV]) {
@@ -284,14 +291,15 @@ __device__ __forceinline__ void hit_epilogue(const HitParams &p, uint32_t (&pl)[
 #pragma unroll
                 for (int j = 0; j < 8; j++) {
                     const uint32_t id = (wv[j >> 1] >> ((j & 1) * 16)) & 0xFFFFu;  // 0xFFFF = unused entry
-                    if ((id >> 12) == half) atomicAdd(&cnt8[(id & 4095u) >> 2], 1u << ((id & 3u) * 8u));
+                    if (kFullTile) { if (id != 0xFFFFu) atomicAdd(&cnt8[id >> 2], 1u << ((id & 3u) * 8u)); }
+                    else if ((id >> 12) == half) atomicAdd(&cnt8[(id & 4095u) >> 2], 1u << ((id & 3u) * 8u));
                 }
             }
         };
         if (kPrefetch) {
 #pragma unroll
             for (int it = 0; it < kIt; it++)
-                if ((uint32_t)it * 64u < ns) add_slot(pre[kPrefetch ? it : 0]);  // wave-uniform
+                if ((uint32_t)it * 64u < ns) add_slot(pre[it]);  // wave-uniform
         } else {
             for (uint32_t c0 = 0; c0 < ns; c0 += 64) {
                 uint4 e[kV];
@@ -343,15 +351,15 @@ __device__ __forceinline__ void hit_epilogue(const HitParams &p, uint32_t (&pl)[
 #pragma unroll
     for (int half = 0; half < 2; half++) {  // groups 0-7 = references 0..4095 of a full tile, groups 8-15 = 4096..8191
         RTX_EPI_MARK(6)
-        if (ns) {
+        if (ns && (!kFullTile || half == 0)) {
             sparse_hits((uint32_t)half);
             if (p.flags & RTX_SKIP_EXACT_MATCHES) {  // raxtax.rs:65-68: the sparse part
                 const uint64_t qin = p.perm[p.q0 + q];
                 const uint64_t e0 = p.exact_off[qin], e1 = p.exact_off[qin + 1];
                 for (uint64_t e = e0 + lane; e < e1; e += 64) {
                     const uint32_t id = p.exact_ids[e] - p.ref_base;
-                    if (id < p.n_refs && (id >> 13) == tile && ((id >> 12) & 1u) == (uint32_t)half)
-                        reinterpret_cast<uint8_t *>(cnt8)[id & 4095u] = 0;
+                    if (id < p.n_refs && (id >> 13) == tile && (kFullTile || ((id >> 12) & 1u) == (uint32_t)half))
+                        reinterpret_cast<uint8_t *>(cnt8)[id & (kFullTile ? 8191u : 4095u)] = 0;
                 }
                 wave_lds_sync();
             }
@@ -373,7 +381,7 @@ __device__ __forceinline__ void hit_epilogue(const HitParams &p, uint32_t (&pl)[
                     st.w = __builtin_amdgcn_perm(hi1, lo1, 0x07030602u);
                     const uint32_t goff = (uint32_t)(w * 4 + g2) * L * 8u;
                     if (ns) {  // + hits through sparse segments (L = 64 here): bytes of the eight references of this group
-                        const uint2 sb = *reinterpret_cast<const uint2 *>(cnt8 + (((uint32_t)(wi * 4 + g2) * 64u + lane) * 2u));
+                        const uint2 sb = *reinterpret_cast<const uint2 *>(cnt8 + (((uint32_t)((kFullTile ? w : wi) * 4 + g2) * 64u + lane) * 2u));
                         st.x += (sb.x & 0xFFu) | ((sb.x & 0xFF00u) << 8);
                         st.y += ((sb.x >> 16) & 0xFFu) | ((sb.x >> 24) << 16);
                         st.z += (sb.y & 0xFFu) | ((sb.y & 0xFF00u) << 8);
@@ -450,6 +458,14 @@ __device__ __forceinline__ void hit_epilogue(const HitParams &p, uint32_t (&pl)[
         if (lane == 0) p.tile_max[(size_t)q * p.ntiles + tile] = (uint16_t)mx;
     }
     RTX_EPI_DONE
+}
+
+template <int NP, bool kPacked, bool kPrefetch = false>
+__device__ __forceinline__ void hit_epilogue(const HitParams &p, uint32_t (&pl)[4][NP], uint32_t q, uint32_t tile, uint32_t lane,
+                                             uint32_t t, bool active, uint32_t *hist_lds, uint32_t *cnt8, uint32_t ns,
+                                             const uint32_t *srows) {
+    uint4 pre[kSparseIt][kSparseV];  // unused without kPrefetch
+    hit_epilogue_x<NP, kPacked, kPrefetch, false, false>(p, pl, q, tile, lane, t, active, hist_lds, cnt8, ns, srows, pre);
 }
 
 }  // namespace rtx

@@ -12,12 +12,13 @@
 //                       indexed by those positions)
 //   prologue            per tile: the union entries whose segment is dense in this tile, split into three lists in
 //                       LDS: rows of both queries, of A only, of B only
-//   row loop            groups of 32 rows, four buffers of eight in flight; the shared list is folded into both plane sets
-//                       from one load per row, then A's rows into A's planes, then B's; the three segments run as one
-//                       pipeline (fold_seg); no barrier, no data-dependent control flow inside a segment
+//   row loop            groups of 32 rows, four buffers of eight in flight; the shared rows are folded first, into ONE
+//                       plane set that is then copied (one load AND one fold per row of the union), then A's rows into
+//                       A's planes, then B's; the three segments run as one pipeline (fold_seg); no barrier, no
+//                       data-dependent control flow inside a segment
 //   epilogue            per query, unchanged (rtx_hit_common.hpp), A then B
 //
-// The VALU work per query is what it was; the counts are those of hit_count_kernel bit for bit.
+// The counts are those of hit_count_kernel bit for bit.
 #include <hip/hip_runtime.h>
 
 #ifdef RTX_PAIR_STAMP
@@ -34,7 +35,8 @@ namespace rtx {
 constexpr uint32_t kPairCap = kHitListCap;            // entries per list and round
 constexpr uint32_t kPairListDw = kPairCap + 192u;     // + padding to a multiple of 8 + the look-ahead of the row loop
 constexpr uint32_t kPairMaskWords = 64u;              // dense-mask words (u64) per query and tile kept in LDS: rstride <= 4096
-constexpr uint32_t kPairLdsBytes = 3u * kPairListDw * 4u + 2u * kPairMaskWords * 8u + 32u * 4u;  // lists | dense masks | 32 x the zero row
+constexpr uint32_t kPairSidDw = 2u * kSparseIt * 64u;     // slot ids of the sparse segments of both queries (read at the start, used in the epilogue)
+constexpr uint32_t kPairLdsBytes = 3u * kPairListDw * 4u + 2u * kPairMaskWords * 8u + 32u * 4u + kPairSidDw * 4u;  // lists | dense masks | 32 x the zero row | slot ids
 constexpr int kPairNB = 4;                            // buffers of eight rows per wave
 
 // ---------------------------------------------------------------------------
@@ -136,6 +138,7 @@ __global__ __launch_bounds__(64, 2) void hit_count_pair_kernel(HitParams p) {
     unsigned long long *m_a = reinterpret_cast<unsigned long long *>(lds_dw + 3u * kPairListDw), *m_b = m_a + kPairMaskWords;
     uint32_t *l_zero = reinterpret_cast<uint32_t *>(m_b + kPairMaskWords);
     if (lane < 32u) l_zero[lane] = p.zero_row;
+    uint32_t *l_sid = l_zero + 32;  // [2][kSparseIt * 64]
     const uint32_t col = tile * 1024u + lane * 16u;
     const bool active = col < p.stride_bytes;
     uint32_t pa[4][NP], pb[4][NP];
@@ -151,33 +154,54 @@ __global__ __launch_bounds__(64, 2) void hit_count_pair_kernel(HitParams p) {
 #define PAIR_MARK(k)
 #endif
     const uint32_t mwords = p.rstride >> 6;
+    const uint2 *urec = p.pair_urec + (size_t)pair * p.pair_ustride;
+    // Everything the prologue needs comes in with ONE round trip: the first 512 union entries (clamped index: what lies
+    // behind the union is masked below), the dense masks of the tile, the slot ids of the sparse segments, the counts.
+    auto load_recs = [&](uint2 (&rec)[8], uint32_t from) {
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+            const uint32_t i = from + (uint32_t)c * 64u + lane;
+            rec[c] = urec[i < p.pair_ustride ? i : p.pair_ustride - 1u];
+        }
+    };
+    uint2 rec[8];
+    load_recs(rec, 0);
+    const uint32_t ns_a = p.nsparse[(size_t)qa * p.ntiles + tile], ns_b = has_b ? p.nsparse[(size_t)qb * p.ntiles + tile] : 0u;
+    const uint32_t *srows_a = p.srows + ((size_t)qa * p.ntiles + tile) * (kSegMaxSparseRows + 1);
+    const uint32_t *srows_b = p.srows + ((size_t)(has_b ? qb : qa) * p.ntiles + tile) * (kSegMaxSparseRows + 1);
     {
         const unsigned long long *dm_a = p.dmask + ((size_t)qa * p.ntiles + tile) * mwords;
         const unsigned long long *dm_b = p.dmask + ((size_t)(has_b ? qb : qa) * p.ntiles + tile) * mwords;
+        uint32_t sa[kSparseIt], sb[kSparseIt];
+#pragma unroll
+        for (int it = 0; it < kSparseIt; it++) {  // unconditional: the lists have kSegMaxSparseRows + 1 entries
+            sa[it] = srows_a[(uint32_t)it * 64u + lane];
+            sb[it] = srows_b[(uint32_t)it * 64u + lane];
+        }
         for (uint32_t i = lane; i < mwords; i += 64) {
             m_a[i] = dm_a[i];
             m_b[i] = has_b ? dm_b[i] : 0ull;
         }
+#pragma unroll
+        for (int it = 0; it < kSparseIt; it++) {
+            l_sid[(uint32_t)it * 64u + lane] = sa[it];
+            l_sid[(kSparseIt + (uint32_t)it) * 64u + lane] = sb[it];
+        }
     }
     wave_lds_sync();
     const uint32_t n_u = p.pair_nu[pair];
-    const uint2 *urec = p.pair_urec + (size_t)pair * p.pair_ustride;
     const char *bitmap = reinterpret_cast<const char *>(p.bitmap);
     const uint32_t stride = p.stride_bytes;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     uint32_t rows_loaded = 0;
     uint32_t u0 = 0;
+    bool first_round = true;
     while (u0 < n_u) {  // one round unless a list would overflow (t > kPairCap - 64)
         uint32_t n_both = 0, n_a = 0, n_b = 0;
         bool room = true;
         while (room && u0 < n_u) {
-            // eight chunks of 64 union entries per round trip
-            uint2 rec[8];
-#pragma unroll
-            for (int c = 0; c < 8; c++) {
-                const uint32_t i = u0 + (uint32_t)c * 64u + lane;
-                rec[c] = urec[i < n_u ? i : n_u - 1u];
-            }
+            // eight chunks of 64 union entries per round trip (the first has been requested above)
+            if (u0) load_recs(rec, u0);
 #pragma unroll
             for (int c = 0; c < 8; c++) {
                 if (u0 >= n_u) break;
@@ -187,10 +211,13 @@ __global__ __launch_bounds__(64, 2) void hit_count_pair_kernel(HitParams p) {
                 const bool da = in && (rec[c].x & (1u << 30)) && ((m_a[pos_a >> 6] >> (pos_a & 63u)) & 1ull);
                 const bool db = in && (rec[c].x & (1u << 31)) && ((m_b[pos_b >> 6] >> (pos_b & 63u)) & 1ull);
                 const uint32_t row = rec[c].x & 0x3FFFFFFFu;
-                const unsigned long long bb = __ballot(da && db), ba = __ballot(da && !db), bo = __ballot(db && !da);
-                if (da && db) l_both[n_both + (uint32_t)__popcll(bb & lt_mask)] = row;
-                if (da && !db) l_a[n_a + (uint32_t)__popcll(ba & lt_mask)] = row;
-                if (db && !da) l_b[n_b + (uint32_t)__popcll(bo & lt_mask)] = row;
+                // shared rows go to the shared list in the first round (B's planes are still empty there: fold once, copy);
+                // in a later round to both of the other lists
+                const bool sh = da && db && first_round, oa = da && !sh, ob = db && !sh;
+                const unsigned long long bb = __ballot(sh), ba = __ballot(oa), bo = __ballot(ob);
+                if (sh) l_both[n_both + (uint32_t)__popcll(bb & lt_mask)] = row;
+                if (oa) l_a[n_a + (uint32_t)__popcll(ba & lt_mask)] = row;
+                if (ob) l_b[n_b + (uint32_t)__popcll(bo & lt_mask)] = row;
                 n_both += (uint32_t)__popcll(bb);
                 n_a += (uint32_t)__popcll(ba);
                 n_b += (uint32_t)__popcll(bo);
@@ -212,31 +239,38 @@ __global__ __launch_bounds__(64, 2) void hit_count_pair_kernel(HitParams p) {
 #pragma unroll
             for (int b = 0; b < 4; b++) load8v_at(buf[b], bitmap, col, stride, idv, b * 8);
             const uint32_t *after_a = g_b ? l_b : l_zero, *after_both = g_a ? l_a : after_a;
-            if (g_both) fold_seg<NP, 0>(pa, pb, buf, l_both, g_both, after_both, lane, bitmap, col, stride);
+            // the shared rows are folded ONCE, into A's planes while B's are still empty, and copied: every row of the
+            // union costs one fold (first round only: later rounds -- t > kPairCap - 64 -- have no shared list)
+            if (g_both) {
+                fold_seg<NP, 1>(pa, pb, buf, l_both, g_both, after_both, lane, bitmap, col, stride);
+#pragma unroll
+                for (int w = 0; w < 4; w++)
+#pragma unroll
+                    for (int b = 0; b < NP; b++) pb[w][b] = pa[w][b];
+            }
             if (g_a) fold_seg<NP, 1>(pa, pb, buf, l_a, g_a, after_a, lane, bitmap, col, stride);
             if (g_b) fold_seg<NP, 2>(pa, pb, buf, l_b, g_b, l_zero, lane, bitmap, col, stride);
         }
         PAIR_MARK(2)
         wave_lds_sync();  // the lists are rewritten (next round) or become the histogram and the byte counters
+        first_round = false;
     }
 #ifndef RTX_PAIR_STAMP
     if (lane == 0 && p.group_rows) atomicAdd(&p.group_rows[p.group_base + pair], rows_loaded);
 #endif
 
-    // epilogues: histogram / byte counters over the lists (dead now)
+    // epilogues: histogram (4 KiB) / byte counters of the whole tile (8 KiB) over the lists (dead now); the slots of the sparse
+    // segments of BOTH queries are requested first (their ids wait in LDS since the prologue)
     uint32_t *hist_lds = lds_dw;
-    uint32_t *cnt8 = lds_dw + 2u * kPairListDw;  // 4 KiB: the third list
-    {
-        const uint32_t ns = p.nsparse[(size_t)qa * p.ntiles + tile];
-        const uint32_t *srows = p.srows + ((size_t)qa * p.ntiles + tile) * (kSegMaxSparseRows + 1);
-        hit_epilogue<NP, kPacked, true>(p, pa, qa, tile, lane, p.t[qa], active, hist_lds, cnt8, ns, srows);
-    }
+    uint32_t *cnt8 = lds_dw + 1024u;
+    uint4 pre_a[kSparseIt][kSparseV], pre_b[kSparseIt][kSparseV];
+    if (ns_a) sparse_prefetch(p, lane, ns_a, l_sid, pre_a);
+    if (ns_b) sparse_prefetch(p, lane, ns_b, l_sid + kSparseIt * 64u, pre_b);
+    hit_epilogue_x<NP, kPacked, true, true, true>(p, pa, qa, tile, lane, p.t[qa], active, hist_lds, cnt8, ns_a, srows_a, pre_a);
     PAIR_MARK(3)
     if (has_b) {
         wave_lds_sync();
-        const uint32_t ns = p.nsparse[(size_t)qb * p.ntiles + tile];
-        const uint32_t *srows = p.srows + ((size_t)qb * p.ntiles + tile) * (kSegMaxSparseRows + 1);
-        hit_epilogue<NP, kPacked, true>(p, pb, qb, tile, lane, p.t[qb], active, hist_lds, cnt8, ns, srows);
+        hit_epilogue_x<NP, kPacked, true, true, true>(p, pb, qb, tile, lane, p.t[qb], active, hist_lds, cnt8, ns_b, srows_b, pre_b);
     }
     PAIR_MARK(4)
 #ifdef RTX_PAIR_STAMP
@@ -250,7 +284,8 @@ void launch_pair_union(hipStream_t s, const uint32_t *rows, const uint32_t *nrow
 }
 
 void launch_hit_count_pair(hipStream_t s, const HitParams &p, uint32_t nq, uint32_t ntiles) {
-    static_assert(2u * kPairListDw >= 1024u + 64u + 1024u, "histogram (t <= 1023) and byte counters alias the lists");
+    static_assert(3u * kPairListDw >= 1024u + 2048u, "histogram (t <= 1023) and byte counters alias the lists");
+    static_assert(kSegMaxSparseRows + 1 >= kSparseIt * 64, "the slot id lists are read without a bound");
     const uint32_t np = (nq + 1u) / 2u;
     if (p.counts_lo) hipLaunchKernelGGL((hit_count_pair_kernel<10, true>), dim3(np, ntiles), dim3(64), kPairLdsBytes, s, p);
     else hipLaunchKernelGGL((hit_count_pair_kernel<10, false>), dim3(np, ntiles), dim3(64), kPairLdsBytes, s, p);

@@ -197,9 +197,11 @@ int rtx_index_set_batch(rtx_index *index, uint32_t sub_batch);
                            * MI355X as measured: kept for A/B measurements */
 #define RTX_OPT_PACKED_COUNTS 8 /* 1 (default): with t <= 1023 the hit counts travel from hit_count to taxon_prefix
                                  * packed, 10 bits per reference (low byte + 2 high bits); 0: as u16 (A/B measurements) */
-#define RTX_OPT_HIT_PAIR 11 /* 1: with t <= 1023 and RTX_OPT_CLUSTER on, hit_count runs two neighbouring queries per wave (two sets of
-                             * bit planes in registers) and loads the bitmap rows they share once (rtx_hit_pair.hip); identical
-                             * results; 0: one query per wave */
+#define RTX_OPT_HIT_PAIR 11 /* 1 (default): with t <= 1023 and RTX_OPT_CLUSTER on, hit_count runs two neighbouring queries per wave (two
+                             * sets of bit planes in registers) and loads the bitmap rows they share once (rtx_hit_pair.hip);
+                             * 2: the same with one plane set in registers at a time (the planes of the shared rows parked in
+                             * 5 KB of global scratch per query and tile; more rows in flight per wave), for t <= 960;
+                             * identical results; 0: one query per wave */
 #define RTX_OPT_TILE_SKIP 10 /* 1 (default): hit_count records the largest count of every tile of 8192 references and
                               * taxon_prefix (lineage.rs:61-66) reads only the tiles that hold a reference whose probability
                               * reaches 1e-30 -- the others add less than n_refs * 1e-30 to any prefix sum, far below what a

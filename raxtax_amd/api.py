@@ -215,7 +215,7 @@ class Index:
     def __init__(self, tree: Tree, device: int = 0, sub_batch: int = 0, prob_mode: int = 0, streams: int = 0,
                  stage_timing: bool = False, cluster: Optional[bool] = None, segment_classes=1,
                  packed_counts: Optional[bool] = None, hit_quad: Optional[bool] = None,
-                 tile_skip: Optional[bool] = None, hit_pair: Optional[bool] = None):
+                 tile_skip: Optional[bool] = None, hit_pair=None):
         self._lib = _lib.load()
         self.tree = tree
         check(self._lib.rtx_set_default_option(1, int(segment_classes)))   # creation-time default of the library

@@ -123,7 +123,7 @@ struct rtx_index {
     const double *ext_prefix = nullptr;       // sharded mode: assembled global prefix handed to the walk
     // ---- index proper
     uint32_t n_rows = 0;        // non-empty posting lists
-    uint32_t stride_bytes = 0;  // bytes per bitmap row (multiple of 128)
+    uint32_t stride_bytes = 0;  // bytes per bitmap row over all tiles (multiple of 1024)
     uint64_t npad = 0;          // references per padded row (= stride_bytes * 8)
     uint32_t ntiles = 0;        // 8192-reference tiles
     DevBuf<uint32_t> d_bitmap, d_row_of, d_list_len;
@@ -164,6 +164,7 @@ struct rtx_index {
     bool quad_used = false;   // the last run went through hit_count_quad_kernel
     uint32_t pair_opt = 1;    // RTX_OPT_HIT_PAIR
     bool pair_used = false;   // ... through hit_count_pair_kernel
+    int pair_variant = 1;     // 1: two plane sets in registers; 2: one at a time, the shared planes parked in global scratch
     DevBuf<uint32_t> d_group_rows;
     uint32_t groups_per_sub = 0;
     bool packed() const { return packed_opt && planes <= 10; }
@@ -187,6 +188,7 @@ struct rtx_index {
         DevBuf<double> d_table_z, d_prefix;
         DevBuf<uint2> d_urec;   // hit_count_pair_kernel: union row lists of the pairs of the sub-batch
         DevBuf<uint32_t> d_nu;
+        DevBuf<uint4> d_pair_planes;
     } sc[2];
     uint32_t n_streams_req = 1, n_streams = 1;
     bool staged = false;  // driven with rtx_shard_*: sub-batch sb works in scratch set sb & 1, so that the exchange of one
@@ -350,6 +352,7 @@ int enqueue_hit(rtx_index *ix, const SubBatch &b, uint32_t flags, hipStream_t s)
     HitParams hp{};
     hp.bitmap = ix->d_bitmap.p;
     hp.stride_bytes = ix->stride_bytes;
+    hp.n_rows1 = ix->n_rows + 1;
     hp.n_refs = ix->n_refs;
     hp.ref_base = ix->ref_lo;
     hp.rows = sc.d_rows.p;
@@ -383,10 +386,11 @@ int enqueue_hit(rtx_index *ix, const SubBatch &b, uint32_t flags, hipStream_t s)
     hp.pair_urec = sc.d_urec.p;
     hp.pair_nu = sc.d_nu.p;
     hp.pair_ustride = 2u * ix->rstride;
+    hp.pair_planes = sc.d_pair_planes.p;
     if (b.timed) RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_HIT_COUNT, 0), s));
     if (ix->pair_used) {
         launch_pair_union(s, sc.d_rows.p, sc.d_nrows.p, ix->rstride, b.nq, sc.d_urec.p, sc.d_nu.p, 2u * ix->rstride);
-        launch_hit_count_pair(s, hp, b.nq, ix->ntiles);
+        launch_hit_count_pair(s, hp, b.nq, ix->ntiles, ix->pair_variant);
     } else if (ix->quad_used) launch_hit_count_quad(s, hp, b.nq, ix->ntiles);
     else launch_hit_count(s, hp, b.nq, ix->ntiles, ix->planes);
     if (b.timed) RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_HIT_COUNT, 1), s));
@@ -523,6 +527,15 @@ int begin_run(rtx_index *ix, uint32_t *n_sub_out, bool *timed_out, bool cluster)
     // two neighbours per wave: the same condition; the mid-segment lists are folded by hit_count_kernel only
     ix->pair_used = !ix->quad_used && ix->pair_opt && cluster && ix->planes <= 10 && ix->n_q > 1 && ix->n_mid_slots == 0 && ix->rstride <= 4096;
     ix->groups_per_sub = ix->pair_used ? (ix->sub_batch + 1u) / 2u : (ix->sub_batch + 3u) / 4u;
+    // the sequential variant keeps every list of a (pair, tile) in one round: t <= kHitListCap - 64
+    ix->pair_variant = ix->pair_used && ix->pair_opt == 2 && ix->tmax + 64u <= kHitListCap ? 2 : 1;
+    if (ix->pair_variant == 2) {
+        for (uint32_t k = 0; k < 2; k++) {
+            if (!ix->sc[k].d_rows.p) continue;  // the second scratch set exists only with two streams / staged runs
+            int rc_p = ix->sc[k].d_pair_planes.alloc((size_t)((ix->sub_batch + 1u) / 2u) * ix->ntiles * 10u * 64u);
+            if (rc_p) return rc_p;
+        }
+    }
     if (ix->quad_used || ix->pair_used) {
         int rc_g = ix->d_group_rows.alloc((size_t)n_sub * ix->groups_per_sub);
         if (rc_g) return rc_g;
@@ -737,7 +750,7 @@ int prepare_workspace(rtx_index *ix, uint64_t n_queries, uint64_t tmax, uint64_t
         RTX_HIP(hipEventCreateWithFlags(&ix->ev_fork, hipEventDisableTiming));
         RTX_HIP(hipEventCreateWithFlags(&ix->ev_join, hipEventDisableTiming));
     }
-    const uint64_t per_q = ((uint64_t)ix->kstride * 2 + (uint64_t)ix->rstride * 12 + 4 + (uint64_t)ix->ntiles * (ix->rstride / 8 + ((kSegMaxSparseRows + 1) * 4 + (kSegMaxMidRows + 1) * 4 + 14)) + (ix->packed() ? ix->npad * 5 / 4 : ix->npad * 2) + (uint64_t)ix->hstride * 12 +
+    const uint64_t per_q = ((ix->pair_opt == 2 ? (uint64_t)ix->ntiles * 5120 : 0) + (uint64_t)ix->kstride * 2 + (uint64_t)ix->rstride * 12 + 4 + (uint64_t)ix->ntiles * (ix->rstride / 8 + ((kSegMaxSparseRows + 1) * 4 + (kSegMaxMidRows + 1) * 4 + 14)) + (ix->packed() ? ix->npad * 5 / 4 : ix->npad * 2) + (uint64_t)ix->hstride * 12 +
                             (uint64_t)ix->n_bnd_local * 8 + 64) * ix->n_streams;
     uint32_t B = ix->sub_batch_req;
     if (B == 0) {
@@ -973,7 +986,7 @@ static int create_common(int device, uint64_t n_total, uint64_t ref_lo, uint64_t
             return fail(RTX_ERR_HIP);
         }
     }
-    ix->stride_bytes = (uint32_t)align_up((n_refs + 7) / 8, 128);
+    ix->stride_bytes = (uint32_t)align_up((n_refs + 7) / 8, 1024);  // whole tiles: the bitmap is stored tile by tile
     ix->npad = (uint64_t)ix->stride_bytes * 8;
     ix->ntiles = (ix->stride_bytes + 1023) / 1024;
     if ((rc = ix->d_cursor.alloc(1)) || (rc = ix->d_flags.alloc(1))) return fail(rc);
@@ -1123,7 +1136,7 @@ static int create_from_csr(int device, uint64_t n_total, uint64_t ref_lo, uint64
         if (e == hipSuccess) e = hipMemcpy(d_off.p, offsets, (RTX_NUM_KMERS + 1) * 8, hipMemcpyHostToDevice);
         if (e == hipSuccess && total) e = hipMemcpy(d_post.p, postings, total * 4, hipMemcpyHostToDevice);
         if (e == hipSuccess) {
-            launch_bitmap_build(ix->stream, d_off.p, d_post.p, ix->d_row_of.p, ix->d_bitmap.p, ix->stride_bytes / 4,
+            launch_bitmap_build(ix->stream, d_off.p, d_post.p, ix->d_row_of.p, ix->d_bitmap.p, ix->stride_bytes / 4, nr + 1,
                                 (uint32_t)ref_lo, (uint32_t)ref_hi);
             e = hipStreamSynchronize(ix->stream);
         }
@@ -1174,8 +1187,8 @@ int rtx_index_create_from_sequences(int device, uint64_t n_refs, const uint8_t *
     e = hipMemset(ix->d_bitmap.p, 0, words * 4);
     if (e == hipSuccess) e = hipMemcpy(ix->d_row_of.p, row_of.data(), RTX_NUM_KMERS * 4, hipMemcpyHostToDevice);
     if (e == hipSuccess) {
-        launch_ref_bitmap_set(ix->stream, d_seq.p, d_off.p, n_refs, ix->d_row_of.p, ix->d_bitmap.p, ix->stride_bytes / 4);
-        launch_row_popcount(ix->stream, ix->d_row_of.p, ix->d_bitmap.p, ix->stride_bytes / 4, ix->d_list_len.p);
+        launch_ref_bitmap_set(ix->stream, d_seq.p, d_off.p, n_refs, ix->d_row_of.p, ix->d_bitmap.p, ix->stride_bytes / 4, nr + 1);
+        launch_row_popcount(ix->stream, ix->d_row_of.p, ix->d_bitmap.p, ix->stride_bytes / 4, nr + 1, ix->d_list_len.p);
         e = hipStreamSynchronize(ix->stream);
     }
     if (e != hipSuccess) { set_error("bitmap build from sequences failed: %s", hipGetErrorString(e)); return fail(RTX_ERR_HIP); }
@@ -1240,7 +1253,8 @@ int rtx_index_set_option(rtx_index *index, int option, uint64_t value) {
             index->quad_opt = value ? 1u : 0u;
             return RTX_OK;
         case RTX_OPT_HIT_PAIR:
-            index->pair_opt = value ? 1u : 0u;
+            if (value > 2) break;
+            index->pair_opt = (uint32_t)value;
             return RTX_OK;
         case RTX_OPT_TILE_SKIP:
             index->tile_skip = value ? 1u : 0u;

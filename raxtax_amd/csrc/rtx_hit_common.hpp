@@ -26,34 +26,27 @@ __device__ __forceinline__ void wave_lds_sync() {
 
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 
-// Eight row segments through raw buffer loads.  The row ids are wave-uniform (lanes O .. O+7 of a VGPR, taken out
-// with v_readlane), so the 64-bit row base lives in SGPRs (buffer descriptor rebuilt per row with scalar ops) and
-// the only vector operand is the 32-bit column offset: `buffer_load_dwordx4 v, v_col, s[desc], 0 offen`, no address
-// VALU.  num_records = bytes per row, so lanes whose columns lie beyond the row read zeros.
-template <int O>
-__device__ __forceinline__ void load8v(uint4 (&buf)[8], const char *__restrict__ bitmap, uint32_t col, uint32_t stride, uint32_t idv) {
+// Eight row segments through raw buffer loads.  The bitmap is stored tile by tile (rtx_math.hpp: bitmap_word): ONE
+// buffer descriptor per wave covers the tile's region (n_rows1 KiB), a row is the 32-bit offset row << 10 -- the lists
+// hold these offsets -- and goes into the load as its SGPR offset (lanes O .. O+7 of a VGPR, taken out with
+// v_readlane); the vector operand is the lane's 16-byte column.  `buffer_load_dwordx4 v, v_col, s[desc], s_row offen`:
+// two instructions per row, no address arithmetic (a descriptor per row cost five scalar instructions more).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t tile_rsrc(const uint32_t *bitmap, uint32_t n_rows1, uint32_t tile) {
+    const char *base = reinterpret_cast<const char *>(bitmap) + (size_t)tile * n_rows1 * 1024u;
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(base), 0, n_rows1 * 1024u, 0x00027000);
+}
+
+__device__ __forceinline__ void load8v_at(uint4 (&buf)[8], __amdgpu_buffer_rsrc_t rsrc, uint32_t voff, uint32_t idv, int o) {
 #pragma unroll
     for (int j = 0; j < 8; j++) {
-        const uint32_t row = (uint32_t)__builtin_amdgcn_readlane((int)idv, O + j);
-        const char *rowbase = bitmap + (size_t)row * stride;
-        const __amdgpu_buffer_rsrc_t rsrc =
-            __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(rowbase), 0, stride, 0x00027000);
-        const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, col, 0, 0);
+        const uint32_t roff = (uint32_t)__builtin_amdgcn_readlane((int)idv, o + j);
+        const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, roff, 0);
         buf[j] = make_uint4(v.x, v.y, v.z, v.w);
     }
 }
-
-// the same with the first lane of the row ids as an argument (a constant once the caller's loop is unrolled)
-__device__ __forceinline__ void load8v_at(uint4 (&buf)[8], const char *__restrict__ bitmap, uint32_t col, uint32_t stride, uint32_t idv, int o) {
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-        const uint32_t row = (uint32_t)__builtin_amdgcn_readlane((int)idv, o + j);
-        const char *rowbase = bitmap + (size_t)row * stride;
-        const __amdgpu_buffer_rsrc_t rsrc =
-            __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(rowbase), 0, stride, 0x00027000);
-        const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, col, 0, 0);
-        buf[j] = make_uint4(v.x, v.y, v.z, v.w);
-    }
+template <int O>
+__device__ __forceinline__ void load8v(uint4 (&buf)[8], __amdgpu_buffer_rsrc_t rsrc, uint32_t voff, uint32_t idv) {
+    load8v_at(buf, rsrc, voff, idv, O);
 }
 
 // carry of weight 8 of eight 16-byte row segments, per 32-reference word
@@ -102,21 +95,21 @@ __device__ __forceinline__ void ripple4(uint32_t (&pl)[4][NP], const uint4 &c) {
 // behind the list are the zero row -- predicated loads cost the compiler its register allocation).
 template <int NP, int NB>
 __device__ __forceinline__ void fold_ring(uint32_t (&pl)[4][NP], const uint32_t *list, uint32_t n8, uint32_t lane,
-                                          const char *__restrict__ bitmap, uint32_t col, uint32_t stride) {
+                                          __amdgpu_buffer_rsrc_t rsrc, uint32_t voff) {
     static_assert(NB >= 3 && NB <= 6, "groups of 24 .. 48 rows");
     constexpr uint32_t GR = NB * 8;
     const uint32_t ng = n8 / NB, nt = n8 - ng * NB;
     uint32_t idv = list[lane];
     uint4 buf[NB][8];
 #pragma unroll
-    for (int b = 0; b < NB; b++) load8v_at(buf[b], bitmap, col, stride, idv, b * 8);
+    for (int b = 0; b < NB; b++) load8v_at(buf[b], rsrc, voff, idv, b * 8);
     for (uint32_t g = 0; g < ng; g++) {
         const uint32_t idn = list[(g + 1) * GR + lane];
         uint4 c3[NB];
 #pragma unroll
         for (int b = 0; b < NB; b++) {
             c3[b] = tree8<NP>(pl, buf[b]);
-            load8v_at(buf[b], bitmap, col, stride, idn, b * 8);
+            load8v_at(buf[b], rsrc, voff, idn, b * 8);
         }
         const uint4 c4a = csa_plane<NP, 3>(pl, c3[0], c3[1]);
         if (NB == 3) {
@@ -149,14 +142,14 @@ __device__ __forceinline__ void fold_ring(uint32_t (&pl)[4][NP], const uint32_t 
 // before it is requested again -- one load, two folds.
 template <int NP, int NB>
 __device__ __forceinline__ void fold_ring2(uint32_t (&pa)[4][NP], uint32_t (&pb)[4][NP], const uint32_t *list, uint32_t n8,
-                                           uint32_t lane, const char *__restrict__ bitmap, uint32_t col, uint32_t stride) {
+                                           uint32_t lane, __amdgpu_buffer_rsrc_t rsrc, uint32_t voff) {
     static_assert(NB >= 3 && NB <= 4, "groups of 24 or 32 rows");
     constexpr uint32_t GR = NB * 8;
     const uint32_t ng = n8 / NB, nt = n8 - ng * NB;
     uint32_t idv = list[lane];
     uint4 buf[NB][8];
 #pragma unroll
-    for (int b = 0; b < NB; b++) load8v_at(buf[b], bitmap, col, stride, idv, b * 8);
+    for (int b = 0; b < NB; b++) load8v_at(buf[b], rsrc, voff, idv, b * 8);
     for (uint32_t g = 0; g < ng; g++) {
         const uint32_t idn = list[(g + 1) * GR + lane];
         uint4 ca[NB], cb[NB];
@@ -164,7 +157,7 @@ __device__ __forceinline__ void fold_ring2(uint32_t (&pa)[4][NP], uint32_t (&pb)
         for (int b = 0; b < NB; b++) {
             ca[b] = tree8<NP>(pa, buf[b]);
             cb[b] = tree8<NP>(pb, buf[b]);
-            load8v_at(buf[b], bitmap, col, stride, idn, b * 8);
+            load8v_at(buf[b], rsrc, voff, idn, b * 8);
         }
         {
             const uint4 c4a = csa_plane<NP, 3>(pa, ca[0], ca[1]);

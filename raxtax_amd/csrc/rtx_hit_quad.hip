@@ -93,8 +93,9 @@ __global__ __launch_bounds__(256, RTX_QUAD_WAVES_PER_SIMD) void hit_count_quad_k
     const uint32_t *srows = p.srows + ((size_t)qc * p.ntiles + tile) * (kSegMaxSparseRows + 1);
     const uint32_t col = tile * 1024u + lane * 16u;
     const bool active = col < p.stride_bytes;
-    const char *bitmap = reinterpret_cast<const char *>(p.bitmap);
-    const uint32_t stride = p.stride_bytes;
+    // the tile's region of the tile-major bitmap (rtx_math.hpp: bitmap_word): row r at r KiB
+    const char *bitmap = reinterpret_cast<const char *>(p.bitmap) + (size_t)tile * p.n_rows1 * 1024u;
+    const uint32_t voff = lane * 16u;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
 
     uint32_t pl[4][NP];
@@ -225,9 +226,9 @@ __global__ __launch_bounds__(256, RTX_QUAD_WAVES_PER_SIMD) void hit_count_quad_k
                 uint32_t row = p.zero_row;
                 if (u0 + j < un) row = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)U[u0 + j]);
 #ifndef RTX_QUAD_NO_DMA
-                dma_row(bitmap + (size_t)row * stride, stride, col, lds_base + (slot0 + j) * 1024u);
+                dma_row(bitmap + (size_t)row * 1024u, 1024u, voff, lds_base + (slot0 + j) * 1024u);
 #else
-                if (row == 0xFFFFFFFEu) dma_row(bitmap, stride, col, lds_base);  // experiment: the loop without its loads
+                if (row == 0xFFFFFFFEu) dma_row(bitmap, 1024u, voff, lds_base);  // experiment: the loop without its loads
 #endif
             }
         };

@@ -26,19 +26,18 @@ static constexpr uint32_t kEmptyRow = 0xFFFFFFFFu;
 __global__ __launch_bounds__(256) void bitmap_build_kernel(const uint64_t *__restrict__ off,
                                                            const uint32_t *__restrict__ post,
                                                            const uint32_t *__restrict__ row_of,
-                                                           uint32_t *__restrict__ bitmap, uint32_t stride_words,
+                                                           uint32_t *__restrict__ bitmap, uint32_t stride_words, uint32_t n_rows1,
                                                            uint32_t ref_lo, uint32_t ref_hi) {  // bit: ref_slot()
     const uint32_t k = blockIdx.x;
     const uint32_t row = row_of[k];
     if (row == kEmptyRow) return;
     const uint64_t b = off[k], e = off[k + 1];
-    uint32_t *dst = bitmap + (size_t)row * stride_words;
     for (uint64_t i = b + threadIdx.x; i < e; i += blockDim.x) {
         const uint32_t g = post[i];
         if (g < ref_lo || g >= ref_hi) continue;  // reference held by another shard
         uint32_t word, bit;
         ref_slot(g - ref_lo, stride_words * 4u, word, bit);
-        atomicOr(&dst[word], 1u << bit);
+        atomicOr(&bitmap[bitmap_word(row, word, n_rows1)], 1u << bit);
     }
 }
 
@@ -85,7 +84,7 @@ __global__ __launch_bounds__(64) void ref_kmer_mark_kernel(const uint8_t *__rest
 __global__ __launch_bounds__(64) void ref_bitmap_set_kernel(const uint8_t *__restrict__ bases,
                                                             const uint64_t *__restrict__ off, uint64_t n_refs,
                                                             const uint32_t *__restrict__ row_of,
-                                                            uint32_t *__restrict__ bitmap, uint32_t stride_words) {
+                                                            uint32_t *__restrict__ bitmap, uint32_t stride_words, uint32_t n_rows1) {
     const uint64_t r = blockIdx.x;
     if (r >= n_refs) return;
     const uint32_t lane = threadIdx.x;
@@ -95,12 +94,12 @@ __global__ __launch_bounds__(64) void ref_bitmap_set_kernel(const uint8_t *__res
     const uint32_t bit = 1u << bitpos;
     for (uint64_t w = lane; w + 8 <= len; w += 64) {
         uint32_t k;
-        if (window_kmer(bases + b0, w, k)) atomicOr(&bitmap[(size_t)row_of[k] * stride_words + word], bit);
+        if (window_kmer(bases + b0, w, k)) atomicOr(&bitmap[bitmap_word(row_of[k], word, n_rows1)], bit);
     }
 }
 
 __global__ __launch_bounds__(256) void row_popcount_kernel(const uint32_t *__restrict__ row_of,
-                                                           const uint32_t *__restrict__ bitmap, uint32_t stride_words,
+                                                           const uint32_t *__restrict__ bitmap, uint32_t stride_words, uint32_t n_rows1,
                                                            uint32_t *__restrict__ list_len) {
     __shared__ uint32_t part[4];
     const uint32_t k = blockIdx.x;
@@ -109,9 +108,8 @@ __global__ __launch_bounds__(256) void row_popcount_kernel(const uint32_t *__res
         if (threadIdx.x == 0) list_len[k] = 0;
         return;
     }
-    const uint32_t *src = bitmap + (size_t)row * stride_words;
     uint32_t c = 0;
-    for (uint32_t i = threadIdx.x; i < stride_words; i += 256) c += __popc(src[i]);
+    for (uint32_t i = threadIdx.x; i < stride_words; i += 256) c += __popc(bitmap[bitmap_word(row, i, n_rows1)]);
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d, 64);
     if ((threadIdx.x & 63u) == 0) part[threadIdx.x >> 6] = c;
@@ -426,8 +424,9 @@ __global__ __launch_bounds__(64, (NP <= 10 ? 4 : 2)) void hit_count_kernel(HitPa
         const uint32_t *rows = p.rows + (size_t)q * p.rstride;
         const unsigned long long *masks = p.dmask + ((size_t)q * p.ntiles + tile) * (p.rstride >> 6);
         const uint32_t nchunks = (p.nrows[q] + 63u) >> 6;
-        const char *bitmap = reinterpret_cast<const char *>(p.bitmap);
-        const uint32_t stride = p.stride_bytes;
+        const __amdgpu_buffer_rsrc_t rsrc = tile_rsrc(p.bitmap, p.n_rows1, tile);
+        const uint32_t voff = lane * 16u;
+        const uint32_t zero_off = p.zero_row << 10;  // the list holds row offsets inside the tile's region (row << 10)
         uint32_t *list = hist_lds;
         const unsigned long long lt_mask = (1ull << lane) - 1ull;
         uint32_t chunk = 0;
@@ -449,7 +448,7 @@ __global__ __launch_bounds__(64, (NP <= 10 ? 4 : 2)) void hit_count_kernel(HitPa
                     if (count + 64u > kHitListCap) { room = false; break; }
                     const unsigned long long m = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(mv >> 32), (int)ci) << 32) |
                                                  (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mv, (int)ci);
-                    if ((m >> lane) & 1ull) list[count + (uint32_t)__popcll(m & lt_mask)] = rowv[u];
+                    if ((m >> lane) & 1ull) list[count + (uint32_t)__popcll(m & lt_mask)] = rowv[u] << 10;
                     count += (uint32_t)__popcll(m);
                     chunk++;
                     ci++;
@@ -459,28 +458,28 @@ __global__ __launch_bounds__(64, (NP <= 10 ? 4 : 2)) void hit_count_kernel(HitPa
             // the entries behind it, read by the look-ahead loads, are zero rows)
             const uint32_t n8 = (count + 7u) >> 3, n32 = n8 >> 2, ntail = n8 & 3u;
 #if RTX_HIT_NB > 2
-            for (uint32_t i = count + lane; i < n8 * 8u + RTX_HIT_NB * 8u + 64u; i += 64) list[i] = p.zero_row;
+            for (uint32_t i = count + lane; i < n8 * 8u + RTX_HIT_NB * 8u + 64u; i += 64) list[i] = zero_off;
 #else
-            for (uint32_t i = count + lane; i < n32 * 32u + 32u; i += 64) list[i] = p.zero_row;
+            for (uint32_t i = count + lane; i < n32 * 32u + 32u; i += 64) list[i] = zero_off;
 #endif
             __syncthreads();
 #if RTX_HIT_NB > 2
-            if (n8) fold_ring<NP, RTX_HIT_NB>(pl, list, n8, lane, bitmap, col, stride);
+            if (n8) fold_ring<NP, RTX_HIT_NB>(pl, list, n8, lane, rsrc, voff);
 #else
             if (n8) {
                 uint32_t idv = list[lane & 31u];
                 uint4 A[8], B[8];
-                load8v<0>(A, bitmap, col, stride, idv);
+                load8v<0>(A, rsrc, voff, idv);
                 for (uint32_t g = 0; g < n32; g++) {
                     const uint32_t idn = list[(g + 1) * 32 + (lane & 31u)];
-                    load8v<8>(B, bitmap, col, stride, idv);
+                    load8v<8>(B, rsrc, voff, idv);
                     const uint4 c3a = tree8<NP>(pl, A);
-                    load8v<16>(A, bitmap, col, stride, idv);
+                    load8v<16>(A, rsrc, voff, idv);
                     const uint4 c3b = tree8<NP>(pl, B);
                     const uint4 c4a = csa_plane<NP, 3>(pl, c3a, c3b);
-                    load8v<24>(B, bitmap, col, stride, idv);
+                    load8v<24>(B, rsrc, voff, idv);
                     const uint4 c3c = tree8<NP>(pl, A);
-                    load8v<0>(A, bitmap, col, stride, idn);  // first rows of the next group, or of the tail
+                    load8v<0>(A, rsrc, voff, idn);  // first rows of the next group, or of the tail
                     const uint4 c3d = tree8<NP>(pl, B);
                     const uint4 c4b = csa_plane<NP, 3>(pl, c3c, c3d);
                     const uint4 c5 = csa_plane<NP, 4>(pl, c4a, c4b);
@@ -497,7 +496,7 @@ __global__ __launch_bounds__(64, (NP <= 10 ? 4 : 2)) void hit_count_kernel(HitPa
                     planes_ripple<NP, 3>(pl[2], c3.z);
                     planes_ripple<NP, 3>(pl[3], c3.w);
                     if (ntail > 1) {
-                        load8v<8>(A, bitmap, col, stride, idv);
+                        load8v<8>(A, rsrc, voff, idv);
                         c3 = tree8<NP>(pl, A);
                         planes_ripple<NP, 3>(pl[0], c3.x);
                         planes_ripple<NP, 3>(pl[1], c3.y);
@@ -505,7 +504,7 @@ __global__ __launch_bounds__(64, (NP <= 10 ? 4 : 2)) void hit_count_kernel(HitPa
                         planes_ripple<NP, 3>(pl[3], c3.w);
                     }
                     if (ntail > 2) {
-                        load8v<16>(A, bitmap, col, stride, idv);
+                        load8v<16>(A, rsrc, voff, idv);
                         c3 = tree8<NP>(pl, A);
                         planes_ripple<NP, 3>(pl[0], c3.x);
                         planes_ripple<NP, 3>(pl[1], c3.y);
@@ -1211,21 +1210,21 @@ __global__ void probs_expand_kernel(const uint16_t *counts, const double *tz, ui
 // launchers
 // ---------------------------------------------------------------------------
 void launch_bitmap_build(hipStream_t s, const uint64_t *off, const uint32_t *post, const uint32_t *row_of,
-                         uint32_t *bitmap, uint32_t stride_words, uint32_t ref_lo, uint32_t ref_hi) {
+                         uint32_t *bitmap, uint32_t stride_words, uint32_t n_rows1, uint32_t ref_lo, uint32_t ref_hi) {
     hipLaunchKernelGGL(bitmap_build_kernel, dim3(RTX_NUM_KMERS), dim3(256), 0, s, off, post, row_of, bitmap,
-                       stride_words, ref_lo, ref_hi);
+                       stride_words, n_rows1, ref_lo, ref_hi);
 }
 void launch_ref_kmer_mark(hipStream_t s, const uint8_t *bases, const uint64_t *off, uint64_t n_refs, uint32_t *present) {
     hipLaunchKernelGGL(ref_kmer_mark_kernel, dim3(4096), dim3(64), 0, s, bases, off, n_refs, present);
 }
 void launch_ref_bitmap_set(hipStream_t s, const uint8_t *bases, const uint64_t *off, uint64_t n_refs,
-                           const uint32_t *row_of, uint32_t *bitmap, uint32_t stride_words) {
+                           const uint32_t *row_of, uint32_t *bitmap, uint32_t stride_words, uint32_t n_rows1) {
     hipLaunchKernelGGL(ref_bitmap_set_kernel, dim3((unsigned)n_refs), dim3(64), 0, s, bases, off, n_refs, row_of, bitmap,
-                       stride_words);
+                       stride_words, n_rows1);
 }
-void launch_row_popcount(hipStream_t s, const uint32_t *row_of, const uint32_t *bitmap, uint32_t stride_words,
+void launch_row_popcount(hipStream_t s, const uint32_t *row_of, const uint32_t *bitmap, uint32_t stride_words, uint32_t n_rows1,
                          uint32_t *list_len) {
-    hipLaunchKernelGGL(row_popcount_kernel, dim3(RTX_NUM_KMERS), dim3(256), 0, s, row_of, bitmap, stride_words, list_len);
+    hipLaunchKernelGGL(row_popcount_kernel, dim3(RTX_NUM_KMERS), dim3(256), 0, s, row_of, bitmap, stride_words, n_rows1, list_len);
 }
 void launch_kmer_extract(hipStream_t s, const KmerParams &p, uint32_t nq) {
     hipLaunchKernelGGL(kmer_extract_kernel, dim3(nq), dim3(64), 0, s, p);

@@ -74,8 +74,9 @@ struct KmerParams {
 };
 
 struct HitParams {
-    const uint32_t *bitmap;
-    uint32_t stride_bytes;
+    const uint32_t *bitmap;   // tile-major: [tile][n_rows1][256 words] (rtx_math.hpp: bitmap_word)
+    uint32_t n_rows1;         // rows per tile region (the last one is all zero)
+    uint32_t stride_bytes;    // bytes per row over all tiles (a multiple of 1024)
     uint64_t n_refs;
     uint32_t ref_base;  // global id of local reference 0 (reference-sharded index)
     const uint32_t *rows;     // [B][rstride] (kmer_extract)
@@ -114,6 +115,7 @@ struct HitParams {
     const uint2 *pair_urec;   // [pairs][pair_ustride] union of the two row lists (pair_union_kernel)
     const uint32_t *pair_nu;  // [pairs] entries of the union
     uint32_t pair_ustride;
+    uint4 *pair_planes;       // [pairs][ntiles][10][64] sequential variant: the planes of the shared rows, parked between A's and B's rows
 };
 
 // memoised cmf / pmf-ratio tables for every (t, m, i), t <= tmax (rtx_prob_tables.hip)
@@ -184,17 +186,17 @@ struct PrefixParams {
 
 
 void launch_bitmap_build(hipStream_t s, const uint64_t *off, const uint32_t *post, const uint32_t *row_of,
-                         uint32_t *bitmap, uint32_t stride_words, uint32_t ref_lo, uint32_t ref_hi);
+                         uint32_t *bitmap, uint32_t stride_words, uint32_t n_rows1, uint32_t ref_lo, uint32_t ref_hi);
 void launch_ref_kmer_mark(hipStream_t s, const uint8_t *bases, const uint64_t *off, uint64_t n_refs, uint32_t *present);
 void launch_ref_bitmap_set(hipStream_t s, const uint8_t *bases, const uint64_t *off, uint64_t n_refs,
-                           const uint32_t *row_of, uint32_t *bitmap, uint32_t stride_words);
-void launch_row_popcount(hipStream_t s, const uint32_t *row_of, const uint32_t *bitmap, uint32_t stride_words,
+                           const uint32_t *row_of, uint32_t *bitmap, uint32_t stride_words, uint32_t n_rows1);
+void launch_row_popcount(hipStream_t s, const uint32_t *row_of, const uint32_t *bitmap, uint32_t stride_words, uint32_t n_rows1,
                          uint32_t *list_len);
 void launch_kmer_extract(hipStream_t s, const KmerParams &p, uint32_t nq);
 void launch_hit_count(hipStream_t s, const HitParams &p, uint32_t nq, uint32_t ntiles, int planes);
 void launch_pair_union(hipStream_t s, const uint32_t *rows, const uint32_t *nrows, uint32_t rstride, uint32_t nq, uint2 *urec,
                        uint32_t *nu, uint32_t ustride);
-void launch_hit_count_pair(hipStream_t s, const HitParams &p, uint32_t nq, uint32_t ntiles);
+void launch_hit_count_pair(hipStream_t s, const HitParams &p, uint32_t nq, uint32_t ntiles, int variant);
 void launch_hit_count_quad(hipStream_t s, const HitParams &p, uint32_t nq, uint32_t ntiles);  // 10 bit planes only
 size_t prob_table_lds_bytes(uint32_t tmax);
 void launch_prob_table(hipStream_t s, const ProbParams &p, uint32_t nq);

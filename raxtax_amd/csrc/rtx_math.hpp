@@ -35,6 +35,12 @@ RTX_HD uint32_t tile_lanes(uint32_t stride_bytes, uint32_t tile) {
     const uint32_t rem = stride_bytes - tile * 1024u;
     return rem >= 1024u ? 64u : rem >> 4;
 }
+// The bitmap is stored TILE-major: [tile][row][256 words] (n_rows1 = rows + the all-zero row).  The segments a
+// (query, tile) wave reads lie in one region of n_rows1 KiB, so that a row is a 32-bit offset (row << 10) from the
+// tile's base whatever the size of the database: one buffer descriptor per wave, the row offset as the load's SGPR.
+RTX_HD size_t bitmap_word(uint32_t row, uint32_t word, uint32_t n_rows1) {
+    return ((size_t)(word >> 8) * n_rows1 + row) * 256u + (word & 255u);
+}
 // word index within the row and bit within the word
 RTX_HD void ref_slot(uint32_t r, uint32_t stride_bytes, uint32_t &word, uint32_t &bit) {
     const uint32_t tile = r >> 13, rl = r & 8191u;

@@ -19,13 +19,12 @@ namespace rtx {
 // pop[row][tile] = number of references in the segment (saturated to 65535); one wave per row
 __global__ __launch_bounds__(64) void seg_popcount_kernel(const uint32_t *__restrict__ bitmap, uint32_t stride_bytes,
                                                           uint32_t ntiles, uint16_t *__restrict__ pop) {
-    const uint32_t row = blockIdx.x, lane = threadIdx.x;
-    const char *base = reinterpret_cast<const char *>(bitmap) + (size_t)row * stride_bytes;
+    const uint32_t row = blockIdx.x, lane = threadIdx.x, n_rows1 = gridDim.x;
     for (uint32_t tile = 0; tile < ntiles; tile++) {
         const uint32_t col = tile * 1024u + lane * 16u;
         uint32_t c = 0;
         if (col < stride_bytes) {
-            const uint4 v = *reinterpret_cast<const uint4 *>(base + col);
+            const uint4 v = *reinterpret_cast<const uint4 *>(bitmap + bitmap_word(row, tile * 256u + lane * 4u, n_rows1));
             c = __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w);
         }
 #pragma unroll
@@ -38,8 +37,7 @@ __global__ __launch_bounds__(64) void seg_popcount_kernel(const uint32_t *__rest
 __global__ __launch_bounds__(64) void seg_emit_kernel(const uint32_t *__restrict__ bitmap, uint32_t stride_bytes, uint32_t ntiles,
                                                       const uint32_t *__restrict__ seginfo, uint32_t seg_stride,
                                                       uint16_t *__restrict__ slots, uint16_t *__restrict__ midslots) {
-    const uint32_t row = blockIdx.x, lane = threadIdx.x;
-    const char *base = reinterpret_cast<const char *>(bitmap) + (size_t)row * stride_bytes;
+    const uint32_t row = blockIdx.x, lane = threadIdx.x, n_rows1 = gridDim.x;
     for (uint32_t tile = 0; tile < ntiles; tile++) {
         const uint32_t code = seginfo[(size_t)row * seg_stride + tile];
         if (code < 2u) continue;  // wave-uniform
@@ -49,7 +47,7 @@ __global__ __launch_bounds__(64) void seg_emit_kernel(const uint32_t *__restrict
         const uint32_t col = tile * 1024u + lane * 16u;
         uint32_t w[4] = {0, 0, 0, 0};
         if (col < stride_bytes) {
-            const uint4 v = *reinterpret_cast<const uint4 *>(base + col);
+            const uint4 v = *reinterpret_cast<const uint4 *>(bitmap + bitmap_word(row, tile * 256u + lane * 4u, n_rows1));
             w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
         }
         const uint32_t cnt = __popc(w[0]) + __popc(w[1]) + __popc(w[2]) + __popc(w[3]);

@@ -347,8 +347,8 @@ def test_pair_kernel_equals_one_query_per_wave(world, oracle):
     u16 counts."""
     w = world
     ex_ids, ex_off = w["index"].exact_matches(w["bases"], w["off"])
-    for kw in (dict(), dict(sub_batch=37), dict(packed_counts=False)):
-        a, b = rx.Index(w["tree"], hit_pair=False, **kw), rx.Index(w["tree"], hit_pair=True, **kw)
+    for kw in (dict(), dict(sub_batch=37), dict(packed_counts=False), dict(hit_pair=2), dict(hit_pair=2, sub_batch=37)):
+        a, b = rx.Index(w["tree"], **dict(kw, hit_pair=False)), rx.Index(w["tree"], **dict(dict(hit_pair=True), **kw))
         for skip in (False, True):
             ra = a.classify(w["bases"], w["off"], ex_ids, ex_off, skip_exact_matches=skip)
             rb = b.classify(w["bases"], w["off"], ex_ids, ex_off, skip_exact_matches=skip)
@@ -364,15 +364,16 @@ def test_pair_kernel_equals_one_query_per_wave(world, oracle):
         assert wa["sum_hits"] == wb["sum_hits"] and wb["bitmap_bytes_read"] <= wa["bitmap_bytes_read"]
 
 
+@pytest.mark.parametrize("variant", [1, 2])
 @pytest.mark.parametrize("n_refs", [70000, 20011])
-def test_pair_kernel_many_tiles(oracle, n_refs):
+def test_pair_kernel_many_tiles(oracle, n_refs, variant):
     """The pair kernel over several tiles and a partial last tile, related queries next to each other (shared rows)
     and unrelated ones; hit counts against the oracle."""
     db = synth.make_db(n_refs)
     qs = synth.make_queries(db, 201, exact_frac=0.2)
     otree = oracle.tree_new_flat(db.lineages, db.seq_bytes, db.seq_off)
     tree = rx.Tree.new_flat(db.lineages, db.seq_bytes, db.seq_off)
-    a, b = rx.Index(tree, hit_pair=False), rx.Index(tree, hit_pair=True)
+    a, b = rx.Index(tree, hit_pair=False), rx.Index(tree, hit_pair=variant)
     ex = a.exact_matches(qs.bases, qs.base_off)
     for skip in (False, True):
         ra = a.classify(qs.bases, qs.base_off, *ex, skip_exact_matches=skip)
@@ -864,7 +865,7 @@ def test_randomised_configurations(oracle, seed):
     orng = np.random.default_rng(seed + 77)
     opts = dict(hit_quad=bool(orng.random() < 0.35), segment_classes=int(orng.choice([0, 1, 2])), packed_counts=bool(orng.random() < 0.75))
     opts["tile_skip"] = bool(orng.random() < 0.7)   # drawn last: the options of the recorded seeds stay what they were
-    opts["hit_pair"] = bool(orng.random() < 0.6)
+    opts["hit_pair"] = int(orng.choice([0, 1, 1, 2, 2]))
     ix = rx.Index(tree, sub_batch=int(rng.choice([0, 5, 64])), cluster=bool(rng.random() < 0.7), **opts)
     rx.Index(tree, segment_classes=1)     # restore the process-wide default for later tests
     qs = []

@@ -15,7 +15,7 @@ qs = synth.make_queries(db, n_q)
 tree = rx.Tree.new_flat(db.lineages, db.seq_bytes, db.seq_off, kmer_map=False)
 import os
 ix = rx.Index(tree, hit_quad=quad, stage_timing=True, segment_classes=int(os.environ.get("RTX_SEG_CLASSES", "1")),
-              streams=int(os.environ.get("RTX_STREAMS", "0")), hit_pair=bool(int(os.environ.get("RTX_HIT_PAIR", "0"))))
+              streams=int(os.environ.get("RTX_STREAMS", "0")), hit_pair=int(os.environ.get("RTX_HIT_PAIR", "0")))
 ex = ix.exact_matches(qs.bases, qs.base_off)
 ix.upload(qs.bases, qs.base_off, *ex)
 for _ in range(3):
@@ -26,7 +26,7 @@ for _ in range(3):
 st = ix.stage_times()
 w = ix.work()["bitmap_bytes_read"]
 row_bytes = ((500_000 + 7) // 8 + 61) // 62
-gsz = 2 if os.environ.get("RTX_HIT_PAIR", "0") == "1" else 4
+gsz = 2 if os.environ.get("RTX_HIT_PAIR", "0") != "0" else 4
 print(f"  [stamp builds: {w / row_bytes * 64 / ((n_q + gsz - 1) // gsz * 62):.0f} cycles per (group, tile) of the stamped phase]")
 print(f"{sys.argv[1]} {n_q} queries: {dt * 1e3:.1f} ms, hit_count {st['hit_count'][0]:.1f} ms over {st['hit_count'][1]} launches; "
       f"requested MB/query {ix.work()['bitmap_bytes_read'] / n_q / 1e6:.2f}", flush=True)

@@ -31,6 +31,8 @@ for v in "$@"; do
     base) build base ;;
     nomidfold) buildk nomidfold -DRTX_EXP_NO_MID_FOLD ;;
     sc1) buildk sc1 -DRTX_EXP_SC1_COUNT_STORES ;;
+    seq4) buildp seq4 -DRTX_PAIRSEQ_NB=4 ;;
+    seq6) buildp seq6 -DRTX_PAIRSEQ_NB=6 ;;
     ps1) buildp ps1 -DRTX_PAIR_STAMP=1 ;;
     ps2) buildp ps2 -DRTX_PAIR_STAMP=2 ;;
     ps3) buildp ps3 -DRTX_PAIR_STAMP=3 ;;

@@ -261,7 +261,7 @@ def roofline_block(args, work, prob_work, stage_ms, stage_n, n_queries_step, que
         # the unit that limits the kernel: the path from the XCD's L2 through the vector L1 (rows are gathered by
         # index, 1 KiB per wave-instruction; the index is far larger than L2 + Infinity Cache only in bytes that are
         # rarely asked for).  achieved = bitmap-row bytes requested per launch / launch time.
-        "bound": "l2", "kernel": "hit_count_kernel",
+        "bound": "l2", "kernel": "hit_count_kernel" if args.no_pair else "hit_count_pair_kernel",
         "achieved": achieved, "peak": L2_PEAK_GBS, "unit": "GB/s", "frac": achieved / L2_PEAK_GBS,
         "frac_of_measured_l2_gather_rate": achieved / L2_GATHER_GBS,
         "launch_ms": launch_ms, "launches_per_step": launches_per_step, "queries_per_launch": q_per_launch,

@@ -709,10 +709,12 @@ int ensure_prob_tables(rtx_index *ix) {
 
 // Queries per kernel launch: larger sub-batches amortise launch tails (measured: 4096 -> 8192 queries saves
 // 5 % of a step at N = 50k).
-constexpr uint32_t kMaxSubBatch = 16384;
-// default: fewer, larger launches save the drain/fill between the kernels of a sub-batch (10 000: 23.5 ms per 100k queries,
-// 8192: 23.7, 14 286: 23.7 -- beyond ~12 000 hit_count loses more L2 reuse than the launches save)
-constexpr uint32_t kDefaultSubBatch = 10240;
+constexpr uint32_t kMaxSubBatch = 65536;
+// default: fewer, larger launches save the drain/fill between the kernels of a sub-batch (N = 50k, per 100k queries: 10 000:
+// 20.4 ms, 14 286: 21.3, 25 000: 20.3, 50 000: 22.0).  A large database gains from more queries per launch -- every tile's
+// bitmap region is fetched once per launch and XCD, whatever the number of queries (N = 500k, per 1M queries: 10 240: 1 094 ms,
+// 16 384: 1 072, 24 576: 1 070, 32 768: 1 098)
+constexpr uint32_t kDefaultSubBatch = 10240, kDefaultSubBatchLarge = 16384;
 
 int alloc_scratch_set(rtx_index *ix, uint32_t k);
 
@@ -759,7 +761,7 @@ int prepare_workspace(rtx_index *ix, uint64_t n_queries, uint64_t tmax, uint64_t
         // scratch already held by this handle is reusable
         const uint64_t held = (ix->sc[0].d_counts.n + ix->sc[1].d_counts.n) * 2 + (ix->sc[0].d_prefix.n + ix->sc[1].d_prefix.n) * 8;
         const uint64_t budget = (uint64_t)((free_b + held) * 0.6);
-        B = (uint32_t)std::min<uint64_t>(kDefaultSubBatch, std::max<uint64_t>(64, budget / per_q));
+        B = (uint32_t)std::min<uint64_t>(ix->ntiles >= 16 ? kDefaultSubBatchLarge : kDefaultSubBatch, std::max<uint64_t>(64, budget / per_q));
     }
     if (B > kMaxSubBatch) B = kMaxSubBatch;
     B = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(B, n_queries));

@@ -390,7 +390,13 @@ __device__ __forceinline__ void hit_epilogue_x(const HitParams &p, uint32_t (&pl
                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #else
 #ifndef RTX_EXP_NO_COUNT_STORE
-                        *reinterpret_cast<uint2 *>(out_lo + goff) = lo8;
+                        {   // non-temporal: the counts are read once, much later (taxon_prefix), and should not displace bitmap rows
+                            typedef uint32_t u32x2_nt __attribute__((ext_vector_type(2)));
+                            u32x2_nt nv;
+                            nv.x = lo8.x;
+                            nv.y = lo8.y;
+                            __builtin_nontemporal_store(nv, reinterpret_cast<u32x2_nt *>(out_lo + goff));
+                        }
 #endif
 #endif
                         // high bytes (0..3 each) -> 2 bits per reference: byte j moves to bit 2j
@@ -431,8 +437,8 @@ __device__ __forceinline__ void hit_epilogue_x(const HitParams &p, uint32_t (&pl
         if (active) {
             const uint4 a = reinterpret_cast<const uint4 *>(tr)[lane * 2u], b = reinterpret_cast<const uint4 *>(tr)[lane * 2u + 1u];
             uint4 *dst = reinterpret_cast<uint4 *>(p.counts_hi + (size_t)q * (p.npad >> 3) + (size_t)tile * 1024u + lane * 16u);
-            dst[0] = a;
-            dst[1] = b;
+            __builtin_nontemporal_store(u32x4_t{a.x, a.y, a.z, a.w}, reinterpret_cast<u32x4_t *>(dst));
+            __builtin_nontemporal_store(u32x4_t{b.x, b.y, b.z, b.w}, reinterpret_cast<u32x4_t *>(dst) + 1);
         }
     }
     wave_lds_sync();

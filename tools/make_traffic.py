@@ -73,7 +73,7 @@ def main():
 
     def hit(agg, ctr):
         for k, d in agg.items():
-            if k.startswith("rtx::hit_count_kernel") and ctr in d:
+            if k.startswith("rtx::hit_count") and ctr in d:   # hit_count_kernel / hit_count_pair_kernel: whichever the run used
                 v = d[ctr]
                 full = [x for x in v if x >= 0.8 * max(v)]      # launches of a full sub-batch (the last one may be short)
                 return sum(full) / len(full), len(full)

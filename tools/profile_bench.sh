@@ -1,20 +1,20 @@
 #!/bin/bash
 # Profiles bench.py under rocprofv3 on the GPU box: kernel trace + stats of the bench command itself, then (separate
 # passes, as the MI355X guide prescribes: no trace flags beside --pmc) the fabric counters behind FETCH_SIZE /
-# WRITE_SIZE and the L2 hit/miss counters, over two full sub-batches of the same configuration.
+# WRITE_SIZE and the L2 hit/miss counters, over four full sub-batches of the same configuration.
 # Usage: tools/profile_bench.sh <tag> [bench args...]   -> gpurun_out/<tag>_{trace,fetch,write,tcc}/
 #        then tools/make_traffic.py turns the passes into profiles/<tag>_pmc_summary.csv and profiles/traffic.json
 set -u
 TAG=${1:-r2}; shift || true
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out
-QPL=${QPL:-10240}            # queries per launch (default sub-batch)
+QPL=${QPL:-16384}            # queries per launch (default sub-batch of a large database)
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 ARGS="--steps 2 --warmup 1 --no-cpu-baseline $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${TAG}_trace" -- python3 "$ROOT/bench.py" $ARGS > "$OUT/${TAG}_trace.log" 2>&1
 echo "trace rc=$?"
-PARGS="--steps 1 --warmup 0 --no-cpu-baseline $* --queries $((2 * QPL))"
+PARGS="--steps 1 --warmup 0 --no-cpu-baseline $* --queries $((4 * QPL))"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/${TAG}_fetch" -- python3 "$ROOT/bench.py" $PARGS > "$OUT/${TAG}_fetch.log" 2>&1
 echo "fetch rc=$?"
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/${TAG}_write" -- python3 "$ROOT/bench.py" $PARGS > "$OUT/${TAG}_write.log" 2>&1

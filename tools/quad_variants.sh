@@ -37,6 +37,7 @@ for v in "$@"; do
     ps2) buildp ps2 -DRTX_PAIR_STAMP=2 ;;
     ps3) buildp ps3 -DRTX_PAIR_STAMP=3 ;;
     ps4) buildp ps4 -DRTX_PAIR_STAMP=4 ;;
+    pnt) buildp pnt -DRTX_EXP_NT_COUNT_STORES ;;
     pnohist) buildp pnohist -DRTX_EXP_NO_HIST ;;
     pnostore) buildp pnostore -DRTX_EXP_NO_COUNT_STORE ;;
     pnoboth) buildp pnoboth -DRTX_EXP_NO_COUNT_STORE -DRTX_EXP_NO_HIST ;;

@@ -206,6 +206,10 @@ int rtx_index_set_batch(rtx_index *index, uint32_t sub_batch);
                               * taxon_prefix (lineage.rs:61-66) reads only the tiles that hold a reference whose probability
                               * reaches 1e-30 -- the others add less than n_refs * 1e-30 to any prefix sum, far below what a
                               * confidence (rounded to 1e-2) can show; 0: every reference is summed (A/B measurements) */
+#define RTX_OPT_LOCATOR 12 /* 1 (default): when the handle was built from the reference sequences (rtx_index_create_from_sequences /
+                            * _from_tree) the processing order of RTX_OPT_CLUSTER is led by the query's position in the
+                            * lineage-ordered database (a vote of its 12-mers in a table built from the references), the
+                            * min-hashes only break ties; 0: min-hash order alone.  Scheduling only: results are identical */
 int rtx_index_set_option(rtx_index *index, int option, uint64_t value);
 /* Process-wide default for handles created afterwards.  RTX_DEFAULT_SEGMENT_CLASSES (default 1): at index creation
  * every (row, tile) segment of the bitmaps is classified; empty segments are never read and segments with at most
@@ -313,6 +317,8 @@ int rtx_debug_kmers(rtx_index *index, uint64_t query, uint16_t *kmers /*cap 6553
 int rtx_debug_hit_counts(rtx_index *index, uint64_t query, uint16_t *counts /*n_refs*/);
 int rtx_debug_prob_table(rtx_index *index, uint64_t query, double *table_over_z /*t+1*/, double *z);
 int rtx_debug_probs(rtx_index *index, uint64_t query, double *probs /*n_refs*/);
+/* processing order of the last run (RTX_OPT_CLUSTER / RTX_OPT_LOCATOR): perm[position] = query */
+int rtx_debug_order(rtx_index *index, uint32_t *perm /*n_queries*/);
 /* Lineage::new(label, tree, probs).evaluate() (src/lineage.rs:61-112) on a caller-supplied
  * probability vector: runs taxon_prefix + lineage_walk + the host finalisation for one
  * pseudo-query.  Lets the reference's lineage KATs pin the device walk.  Small trees only

@@ -215,7 +215,7 @@ class Index:
     def __init__(self, tree: Tree, device: int = 0, sub_batch: int = 0, prob_mode: int = 0, streams: int = 0,
                  stage_timing: bool = False, cluster: Optional[bool] = None, segment_classes=1,
                  packed_counts: Optional[bool] = None, hit_quad: Optional[bool] = None,
-                 tile_skip: Optional[bool] = None, hit_pair=None):
+                 tile_skip: Optional[bool] = None, hit_pair=None, locator: Optional[bool] = None):
         self._lib = _lib.load()
         self.tree = tree
         check(self._lib.rtx_set_default_option(1, int(segment_classes)))   # creation-time default of the library
@@ -241,6 +241,8 @@ class Index:
             check(self._lib.rtx_index_set_option(self._h, 10, int(tile_skip)))
         if hit_pair is not None:
             check(self._lib.rtx_index_set_option(self._h, 11, int(hit_pair)))
+        if locator is not None:
+            check(self._lib.rtx_index_set_option(self._h, 12, int(locator)))
         self._view = ResultView()
         self._keep = None
 
@@ -331,6 +333,12 @@ class Index:
     def debug_probs(self, q: int) -> np.ndarray:
         out = np.zeros(self.n_refs, dtype=np.float64)
         check(self._lib.rtx_debug_probs(self._h, q, ptr(out, f64p)))
+        return out
+
+    def debug_order(self, n_queries: int) -> np.ndarray:
+        """Processing order of the last run: perm[position] = query."""
+        out = np.zeros(n_queries, dtype=np.uint32)
+        check(self._lib.rtx_debug_order(self._h, ptr(out, u32p)))
         return out
 
     def debug_evaluate(self, probs) -> Result:

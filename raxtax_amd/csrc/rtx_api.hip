@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <thread>
 
@@ -163,6 +164,8 @@ struct rtx_index {
     uint32_t tile_skip = 1;   // RTX_OPT_TILE_SKIP: taxon_prefix reads only the tiles that hold a reference with p >= 1e-30
     bool quad_used = false;   // the last run went through hit_count_quad_kernel
     uint32_t pair_opt = 1;    // RTX_OPT_HIT_PAIR
+    uint32_t locator_opt = 1; // RTX_OPT_LOCATOR: the sort key of the processing order is led by the query's position in the database
+    DevBuf<uint32_t> d_loc_table;  // 12-mer -> lowest reference position (rtx_cluster.hip); only when built from sequences
     bool pair_used = false;   // ... through hit_count_pair_kernel
     int pair_variant = 1;     // 1: two plane sets in registers; 2: one at a time, the shared planes parked in global scratch
     DevBuf<uint32_t> d_group_rows;
@@ -501,6 +504,8 @@ int order_batch(rtx_index *ix, bool cluster) {
         }
         if (ix->d_sort_tmp.n < tmp && (rc = ix->d_sort_tmp.alloc(tmp + 256))) return rc;
         launch_sketch(ix->stream, ix->d_bases.p, ix->d_base_off.p, n, ix->d_skey_in.p, ix->d_sidx.p);
+        if (ix->d_loc_table.p && ix->locator_opt)
+            launch_locator(ix->stream, ix->d_bases.p, ix->d_base_off.p, n, ix->d_loc_table.p, ix->n_total, ix->d_skey_in.p);
         tmp = ix->d_sort_tmp.n;
         if (cluster_sort(ix->stream, ix->d_sort_tmp.p, &tmp, ix->d_skey_in.p, ix->d_skey_out.p, ix->d_sidx.p, ix->d_perm.p, n)) {
             set_error("radix sort of the query sketches failed");
@@ -525,7 +530,8 @@ int begin_run(rtx_index *ix, uint32_t *n_sub_out, bool *timed_out, bool cluster)
     // four neighbours per workgroup only pays when neighbours are related: with the processing order on
     ix->quad_used = ix->quad_opt && cluster && ix->planes <= 10 && ix->n_q > 2;
     // two neighbours per wave: the same condition; the mid-segment lists are folded by hit_count_kernel only
-    ix->pair_used = !ix->quad_used && ix->pair_opt && cluster && ix->planes <= 10 && ix->n_q > 1 && ix->n_mid_slots == 0 && ix->rstride <= 4096;
+    static const bool pair_any_order = getenv("RTX_EXP_PAIR_ANY_ORDER") != nullptr;  // experiments (tools/exp_order_potential2.py): the pair kernel on a host-made order
+    ix->pair_used = !ix->quad_used && ix->pair_opt && (cluster || pair_any_order) && ix->planes <= 10 && ix->n_q > 1 && ix->n_mid_slots == 0 && ix->rstride <= 4096;
     ix->groups_per_sub = ix->pair_used ? (ix->sub_batch + 1u) / 2u : (ix->sub_batch + 3u) / 4u;
     // the sequential variant keeps every list of a (pair, tile) in one round: t <= kHitListCap - 64
     ix->pair_variant = ix->pair_used && ix->pair_opt == 2 && ix->tmax + 64u <= kHitListCap ? 2 : 1;
@@ -1149,6 +1155,22 @@ static int create_from_csr(int device, uint64_t n_total, uint64_t ref_lo, uint64
     return RTX_OK;
 }
 
+// Locator table of the processing order (rtx_cluster.hip) from the reference sequences already on the device.
+// A scheduling aid only: if it cannot be built (memory) the handle works without it.
+static void build_locator(rtx_index *ix, const uint8_t *d_seq, const uint64_t *d_off, uint64_t n_refs) {
+    if (ix->n_refs != ix->n_total || n_refs < 1024) return;  // whole-database handles of some size only
+    DevBuf<uint32_t> d_cnt;
+    if (ix->d_loc_table.alloc(kLocTableEntries) || d_cnt.alloc(kLocTableEntries)) { ix->d_loc_table.release(); return; }
+    hipError_t e = hipMemsetAsync(ix->d_loc_table.p, 0xFF, (size_t)kLocTableEntries * 4, ix->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(d_cnt.p, 0, (size_t)kLocTableEntries * 4, ix->stream);
+    if (e == hipSuccess) {
+        launch_loc_mark(ix->stream, d_seq, d_off, n_refs, ix->d_loc_table.p, d_cnt.p);
+        launch_loc_finish(ix->stream, ix->d_loc_table.p, d_cnt.p);
+        e = hipStreamSynchronize(ix->stream);
+    }
+    if (e != hipSuccess) { (void)hipGetLastError(); ix->d_loc_table.release(); }
+}
+
 // Index build on the GPU from the encoded reference sequences in lineage-sorted order
 // (the k-mer map of Tree::new, tree.rs:114-123,134-137, without ever materialising posting lists).
 int rtx_index_create_from_sequences(int device, uint64_t n_refs, const uint8_t *seq_bytes, const uint64_t *seq_off,
@@ -1195,6 +1217,7 @@ int rtx_index_create_from_sequences(int device, uint64_t n_refs, const uint8_t *
     }
     if (e != hipSuccess) { set_error("bitmap build from sequences failed: %s", hipGetErrorString(e)); return fail(RTX_ERR_HIP); }
     if ((rc = build_segments(ix))) return fail(rc);
+    build_locator(ix, d_seq.p, d_off.p, n_refs);
     *out = ix;
     return RTX_OK;
 }
@@ -1206,8 +1229,26 @@ int rtx_index_create_from_tree(int device, const rtx_tree *tree, rtx_index **out
         return rtx_index_create_from_sequences(device, tree->num_tips, tree->seq_bytes.data(), tree->seq_off.data(), f.size(),
                                                f.begin.data(), f.end.data(), f.first_child.data(), f.n_children.data(),
                                                f.type.data(), out);
-    return rtx_index_create(device, tree->num_tips, tree->csr_off.data(), tree->postings.data(), f.size(), f.begin.data(),
-                            f.end.data(), f.first_child.data(), f.n_children.data(), f.type.data(), out);
+    int rc = rtx_index_create(device, tree->num_tips, tree->csr_off.data(), tree->postings.data(), f.size(), f.begin.data(),
+                              f.end.data(), f.first_child.data(), f.n_children.data(), f.type.data(), out);
+    if (rc != RTX_OK) return rc;
+    // the tree holds the sequences (Tree.sequences, for the exact-match lookup): the locator table of the processing order
+    const uint64_t n = tree->num_tips;
+    if (n >= 1024 && tree->seq_off.size() == n + 1) {
+        rtx_index *ix = *out;
+        const uint64_t total = tree->seq_off[n] - tree->seq_off[0];
+        DevBuf<uint8_t> d_seq;
+        DevBuf<uint64_t> d_off;
+        if (!d_seq.alloc(total + 16) && !d_off.alloc(n + 1)) {
+            std::vector<uint64_t> off0(n + 1);
+            for (uint64_t i = 0; i <= n; i++) off0[i] = tree->seq_off[i] - tree->seq_off[0];
+            hipError_t e = hipMemcpy(d_seq.p, tree->seq_bytes.data() + tree->seq_off[0], total, hipMemcpyHostToDevice);
+            if (e == hipSuccess) e = hipMemcpy(d_off.p, off0.data(), (n + 1) * 8, hipMemcpyHostToDevice);
+            if (e == hipSuccess) build_locator(ix, d_seq.p, d_off.p, n);
+            else (void)hipGetLastError();
+        }
+    }
+    return RTX_OK;
 }
 
 void rtx_index_destroy(rtx_index *index) {
@@ -1219,7 +1260,7 @@ void rtx_index_destroy(rtx_index *index) {
 uint64_t rtx_index_num_refs(const rtx_index *index) { return index ? index->n_total : 0; }
 uint64_t rtx_index_device_bytes(const rtx_index *index) {
     if (!index) return 0;
-    return index->d_seg_dbits.n * 8 + index->d_seg_sbits.n * 8 + index->d_seg_sbase.n * 4 + index->d_seginfo.n * 4 + index->d_segslots.n * 2 + index->d_midslots.n * 2 + index->d_seg_mbits.n * 8 + index->d_seg_mbase.n * 4 + index->d_bitmap.n * 4 + index->d_row_of.n * 4 + index->d_list_len.n * 4 + index->d_lnfact.n * 8 +
+    return index->d_seg_dbits.n * 8 + index->d_seg_sbits.n * 8 + index->d_seg_sbase.n * 4 + index->d_seginfo.n * 4 + index->d_segslots.n * 2 + index->d_midslots.n * 2 + index->d_seg_mbits.n * 8 + index->d_seg_mbase.n * 4 + index->d_bitmap.n * 4 + index->d_row_of.n * 4 + index->d_list_len.n * 4 + index->d_loc_table.n * 4 + index->d_lnfact.n * 8 +
            index->d_noderec.n * 16 + index->d_bnd_bits.n + index->d_bnd_rank.n * 4;
 }
 int rtx_index_set_batch(rtx_index *index, uint32_t sub_batch) {
@@ -1260,6 +1301,9 @@ int rtx_index_set_option(rtx_index *index, int option, uint64_t value) {
             return RTX_OK;
         case RTX_OPT_TILE_SKIP:
             index->tile_skip = value ? 1u : 0u;
+            return RTX_OK;
+        case RTX_OPT_LOCATOR:
+            index->locator_opt = value ? 1u : 0u;
             return RTX_OK;
         case RTX_OPT_PROB_MODE:
             if (value > 2) break;
@@ -1739,6 +1783,14 @@ int rtx_debug_prob_table(rtx_index *ix, uint64_t query, double *table_over_z, do
     for (uint32_t m = 0; m <= tt; m++)
         if (!hist[m]) table_over_z[m] = 0.0;  // entries of absent counts are never written
     if (z) RTX_HIP(hipMemcpy(z, ix->d_z.p + ix->h_inv[query], 8, hipMemcpyDeviceToHost));
+    return RTX_OK;
+}
+
+int rtx_debug_order(rtx_index *ix, uint32_t *perm) {
+    if (!ix || !perm) { set_error("null argument"); return RTX_ERR_INVALID; }
+    if (!ix->ran || ix->h_perm.n < ix->n_q) { set_error("rtx_debug_order: no batch has been run"); return RTX_ERR_STATE; }
+    RTX_HIP(hipStreamSynchronize(ix->stream));
+    std::memcpy(perm, ix->h_perm.data(), (size_t)ix->n_q * 4);
     return RTX_OK;
 }
 

@@ -9,6 +9,16 @@
 //   sketch_kernel : per query three min-hashes over its 12-mers (bottom-1 sketches, 21 bits each)
 //                   -> 63-bit key; related sequences agree on a min-hash with probability = their
 //                   12-mer Jaccard similarity, so sorting by the key puts most of them side by side
+//   locator       : (only when the index was built from the reference sequences) where in the lineage-ordered database
+//                   the relatives of a query sit.  At index build every 12-mer of every reference is entered into a
+//                   direct-mapped table (2^24 entries: lowest reference position holding it, number of occurrences);
+//                   12-mers that occur more than kLocMaxCount times say nothing about a clade and are dropped.  A query
+//                   looks its 12-mers up and votes: coarse bins of `binw` references (the best pair of neighbouring
+//                   bins wins), then bins of binw / 16 inside the winner.  The position leads the sort key, the
+//                   min-hashes break ties: neighbouring sub-batches, XCD slices and pairs then hold queries of the same
+//                   genus / species, the min-hash buckets alone are ordered at random.  Measured at BASELINE configs[2]
+//                   (tools/exp_order_potential2.py, hit_count per 262 144 queries): input order 324 ms, min-hash order
+//                   255 ms, queries sorted by their true source reference 210 ms.
 //   sort          : rocPRIM device radix sort of (key, query index) pairs -> perm[position] = query
 //   invert        : inv[query] = position
 #include <cstring>
@@ -66,6 +76,151 @@ __global__ __launch_bounds__(64) void sketch_kernel(const uint8_t *__restrict__ 
     }
 }
 
+// ---------------------------------------------------------------------------
+// Locator table (index build).  pos_min[c] = lowest reference id (lineage order) that contains 12-mer c, cnt[c] = its
+// occurrences over all references; loc_finish folds both into one word per 12-mer: the position, or kLocNone where the
+// 12-mer is absent or too common to tell clades apart.
+// ---------------------------------------------------------------------------
+static constexpr uint32_t kLocNone = 0xFFFFFFFFu;
+static constexpr uint32_t kLocMaxCount = 512;
+
+__device__ __forceinline__ bool base_code(uint32_t c, uint32_t &two) {
+    two = ((uint32_t)__ffs((int)c) - 1u) & 3u;
+    return c == 1u || c == 2u || c == 4u || c == 8u;
+}
+
+__global__ __launch_bounds__(64) void loc_mark_kernel(const uint8_t *__restrict__ bases, const uint64_t *__restrict__ off,
+                                                      uint64_t n_refs, uint32_t *__restrict__ pos_min, uint32_t *__restrict__ cnt) {
+    const uint32_t lane = threadIdx.x;
+    for (uint64_t r = blockIdx.x; r < n_refs; r += gridDim.x) {
+        const uint64_t b0 = off[r], len = off[r + 1] - b0;
+        if (len < (uint64_t)kSketchK) continue;
+        const uint8_t *seq = bases + b0;
+        const uint64_t nwin = len - kSketchK + 1;
+        for (uint64_t w = lane; w < nwin; w += 64) {
+            uint32_t code = 0;
+            bool ok = true;
+#pragma unroll
+            for (int j = 0; j < kSketchK; j++) {
+                uint32_t two;
+                ok = base_code(seq[w + j], two) && ok;
+                code = (code << 2) | two;
+            }
+            if (ok) {
+                atomicMin(&pos_min[code], (uint32_t)r);
+                atomicAdd(&cnt[code], 1u);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void loc_finish_kernel(uint32_t *__restrict__ pos_min, const uint32_t *__restrict__ cnt) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t c = cnt[i];
+    if (c == 0u || c > kLocMaxCount) pos_min[i] = kLocNone;
+}
+
+// ---------------------------------------------------------------------------
+// Locator of a query: one wave per query.  Lane l looks up the 12-mers of the windows l, l + 64, ...; votes are counted
+// in LDS (u16 pairs in u32 words: a query has fewer than 65 536 windows per bin only if it is shorter than that -- longer
+// queries skip the vote and keep the min-hash key).  keys[q] = loc << 39 | (min-hash key >> 24): 24 bits of position,
+// m1 and the high 18 bits of m2.
+// ---------------------------------------------------------------------------
+static constexpr uint32_t kLocMaxBins = 8192;    // coarse bins (LDS: 16 KiB)
+static constexpr uint32_t kLocFineDiv = 16;      // fine bins per coarse bin
+static constexpr uint32_t kLocVotesPerLane = 16; // windows per lane kept for the fine vote (queries up to 1035 bases; longer: coarse only)
+
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const uint32_t o = (uint32_t)__shfl_xor((int)v, d, 64);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(64) void locator_kernel(const uint8_t *__restrict__ bases, const uint64_t *__restrict__ off,
+                                                     const uint32_t *__restrict__ table, uint32_t bin_shift, uint32_t n_bins,
+                                                     uint64_t *__restrict__ keys) {
+    extern __shared__ uint32_t h[];            // n_bins / 2 + 2 words: the coarse bins as u16 pairs
+    __shared__ uint32_t hf[kLocFineDiv + 2];   // 2 * kLocFineDiv + 1 fine bins as u16 pairs
+    const uint32_t q = blockIdx.x, lane = threadIdx.x;
+    const uint64_t b0 = off[q], len = off[q + 1] - b0;
+    const uint64_t old_key = keys[q];
+    if (len < (uint64_t)kSketchK || len > 65000u) return;  // wave-uniform: the min-hash key stays
+    const uint8_t *seq = bases + b0;
+    const uint32_t nwin = (uint32_t)(len - kSketchK + 1);
+    const uint32_t words = n_bins / 2 + 1;
+    for (uint32_t i = lane; i < words + 1; i += 64) h[i] = 0;
+    if (lane < kLocFineDiv + 2) hf[lane] = 0;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    uint32_t kept[kLocVotesPerLane];
+#pragma unroll
+    for (int i = 0; i < (int)kLocVotesPerLane; i++) kept[i] = kLocNone;
+    uint32_t any = 0;
+    for (uint32_t w0 = 0, it = 0; w0 < nwin; w0 += 64, it++) {
+        const uint32_t w = w0 + lane;
+        uint32_t pos = kLocNone;
+        if (w < nwin) {
+            uint32_t code = 0;
+            bool ok = true;
+#pragma unroll
+            for (int j = 0; j < kSketchK; j++) {
+                uint32_t two;
+                ok = base_code(seq[w + j], two) && ok;
+                code = (code << 2) | two;
+            }
+            if (ok) pos = table[code];
+        }
+        if (pos != kLocNone) {
+            const uint32_t b = pos >> bin_shift;
+            atomicAdd(&h[b >> 1], 1u << ((b & 1u) * 16u));
+            any = 1;
+        }
+#pragma unroll
+        for (int i = 0; i < (int)kLocVotesPerLane; i++)
+            if ((uint32_t)i == it) kept[i] = pos;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (!__ballot(any != 0u)) return;  // no vote: the min-hash key stays (sorted behind nothing in particular)
+    // best pair of neighbouring coarse bins (B, B + 1): value << 16 | (0xFFFF - B), the lowest B among equals
+    auto bin = [&](uint32_t b) { return (h[b >> 1] >> ((b & 1u) * 16u)) & 0xFFFFu; };
+    uint32_t best = 0;
+    for (uint32_t b = lane; b < n_bins; b += 64) {
+        const uint32_t v = bin(b) + bin(b + 1u);
+        const uint32_t cand = (v << 16) | (0xFFFFu - b);
+        best = cand > best ? cand : best;
+    }
+    best = wave_max_u32(best);
+    const uint32_t B = 0xFFFFu - (best & 0xFFFFu);
+    const uint32_t lo = B << bin_shift;
+    uint32_t fine = 0;
+    if (bin_shift >= 4u) {
+        const uint32_t fshift = bin_shift - 4u;  // fine bins of binw / 16 references over [lo, lo + 2 binw)
+#pragma unroll
+        for (int i = 0; i < (int)kLocVotesPerLane; i++) {
+            const uint32_t pos = kept[i];
+            if (pos != kLocNone && pos >= lo && ((pos - lo) >> bin_shift) < 2u) {
+                const uint32_t f = (pos - lo) >> fshift;
+                atomicAdd(&hf[f >> 1], 1u << ((f & 1u) * 16u));
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        uint32_t fb = 0;
+        if (lane < 2u * kLocFineDiv) {
+            const uint32_t v = ((hf[lane >> 1] >> ((lane & 1u) * 16u)) & 0xFFFFu) + ((hf[(lane + 1u) >> 1] >> (((lane + 1u) & 1u) * 16u)) & 0xFFFFu);
+            fb = (v << 16) | (0xFFFFu - lane);
+        }
+        fb = wave_max_u32(fb);
+        fine = 0xFFFFu - (fb & 0xFFFFu);
+    }
+    const uint64_t loc = ((uint64_t)B * kLocFineDiv + fine) & 0xFFFFFFull;
+    if (lane == 0) keys[q] = (loc << 39) | (old_key >> 24);
+}
+
 __global__ __launch_bounds__(256) void invert_perm_kernel(const uint32_t *__restrict__ perm, uint32_t n, uint32_t *__restrict__ inv) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i < n) inv[perm[i]] = i;
@@ -78,6 +233,26 @@ __global__ __launch_bounds__(256) void identity_perm_kernel(uint32_t n, uint32_t
 
 void launch_sketch(hipStream_t s, const uint8_t *bases, const uint64_t *off, uint32_t n_q, uint64_t *keys, uint32_t *idx) {
     hipLaunchKernelGGL(sketch_kernel, dim3(n_q), dim3(64), 0, s, bases, off, keys, idx);
+}
+// Index build: enters the 12-mers of all references into the table
+void launch_loc_mark(hipStream_t s, const uint8_t *bases, const uint64_t *off, uint64_t n_refs, uint32_t *pos_min, uint32_t *cnt) {
+    const uint32_t grid = (uint32_t)(n_refs < 65536u ? (n_refs ? n_refs : 1u) : 65536u);
+    hipLaunchKernelGGL(loc_mark_kernel, dim3(grid), dim3(64), 0, s, bases, off, n_refs, pos_min, cnt);
+}
+void launch_loc_finish(hipStream_t s, uint32_t *pos_min, const uint32_t *cnt) {
+    hipLaunchKernelGGL(loc_finish_kernel, dim3(kLocTableEntries / 256), dim3(256), 0, s, pos_min, cnt);
+}
+// bins of 2^bin_shift references: at most kLocMaxBins of them, at least 256 references each
+uint32_t loc_bin_shift(uint64_t n_refs) {
+    uint32_t sh = 8;
+    while (((n_refs + (1ull << sh) - 1) >> sh) + 1 > kLocMaxBins) sh++;
+    return sh;
+}
+void launch_locator(hipStream_t s, const uint8_t *bases, const uint64_t *off, uint32_t n_q, const uint32_t *table, uint64_t n_refs,
+                    uint64_t *keys) {
+    const uint32_t sh = loc_bin_shift(n_refs);
+    const uint32_t n_bins = (uint32_t)((n_refs + (1ull << sh) - 1) >> sh);
+    hipLaunchKernelGGL(locator_kernel, dim3(n_q), dim3(64), (n_bins / 2 + 2) * 4, s, bases, off, table, sh, n_bins, keys);
 }
 void launch_invert_perm(hipStream_t s, const uint32_t *perm, uint32_t n, uint32_t *inv) {
     hipLaunchKernelGGL(invert_perm_kernel, dim3((n + 255) / 256), dim3(256), 0, s, perm, n, inv);

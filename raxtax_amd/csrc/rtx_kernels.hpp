@@ -211,6 +211,12 @@ void launch_seg_emit(hipStream_t s, const uint32_t *bitmap, uint32_t stride_byte
 // processing order of a batch (rtx_cluster.hip)
 void launch_sketch(hipStream_t s, const uint8_t *bases, const uint64_t *off, uint32_t n_q, uint64_t *keys, uint32_t *idx);
 void launch_invert_perm(hipStream_t s, const uint32_t *perm, uint32_t n, uint32_t *inv);
+// locator (rtx_cluster.hip): 12-mer -> lowest reference position, built from the reference sequences; a query votes
+constexpr uint32_t kLocTableEntries = 1u << 24;
+void launch_loc_mark(hipStream_t s, const uint8_t *bases, const uint64_t *off, uint64_t n_refs, uint32_t *pos_min, uint32_t *cnt);
+void launch_loc_finish(hipStream_t s, uint32_t *pos_min, const uint32_t *cnt);
+void launch_locator(hipStream_t s, const uint8_t *bases, const uint64_t *off, uint32_t n_q, const uint32_t *table, uint64_t n_refs,
+                    uint64_t *keys);
 void launch_identity_perm(hipStream_t s, uint32_t n, uint32_t *perm, uint32_t *inv);
 int cluster_sort(hipStream_t s, void *tmp, size_t *tmp_bytes, const uint64_t *keys_in, uint64_t *keys_out, const uint32_t *idx_in,
                  uint32_t *perm_out, size_t n);

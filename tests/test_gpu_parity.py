@@ -973,3 +973,36 @@ def test_result_arena_overflow_is_recovered(oracle):
             t, counts = otree.hit_counts(qs[q])
             probs = oracle.highest_hit_prob_per_reference(t, t // 2, counts)
             assert_rows_equivalent(res.rows(q), rows, probs, otree.lineages, f"q {q}")
+
+
+def test_locator_order_is_a_pure_scheduling_decision(oracle):
+    """RTX_OPT_LOCATOR: the processing order led by the query's position in the lineage-ordered database (a vote of its
+    12-mers in a table built from the reference sequences, rtx_cluster.hip).  Results equal those of the min-hash order
+    field by field, the order is a permutation, and it does what it is for: neighbours in the processing order come
+    from references that sit close together in the database far more often than with the min-hash order alone."""
+    db = synth.make_db(20011)
+    qs = synth.make_queries(db, 3000, exact_frac=0.2)
+    for kmer_map in (False, True):      # table from the GPU index build / from the sequences the tree holds
+        tree = rx.Tree.new_flat(db.lineages, db.seq_bytes, db.seq_off, kmer_map=kmer_map)
+        a, b = rx.Index(tree, locator=False), rx.Index(tree, locator=True)
+        ex = a.exact_matches(qs.bases, qs.base_off)
+        for skip in (False, True):
+            ra = a.classify(qs.bases, qs.base_off, *ex, skip_exact_matches=skip)
+            rb = b.classify(qs.bases, qs.base_off, *ex, skip_exact_matches=skip)
+            for f in ("row_off", "row_lineage", "row_conf", "row_local_signal", "global_signal", "t", "status"):
+                assert np.array_equal(getattr(ra, f), getattr(rb, f)), (kmer_map, skip, f)
+        orig = tree.original_index().astype(np.int64)
+        pos_of = np.empty(len(orig), np.int64)
+        pos_of[orig] = np.arange(len(orig))
+        src_pos = pos_of[qs.source]
+        near = {}
+        for name, ix in (("min-hash", a), ("locator", b)):
+            perm = ix.debug_order(qs.n).astype(np.int64)
+            assert np.array_equal(np.sort(perm), np.arange(qs.n))
+            d = np.abs(np.diff(src_pos[perm]))
+            near[name] = float(np.mean(d <= 64))
+        print(f"kmer_map={kmer_map}: neighbours within 64 references of each other: {near}")
+        assert near["locator"] > near["min-hash"] + 0.15
+    otree = oracle.tree_new_flat(db.lineages, db.seq_bytes, db.seq_off)
+    for q in range(0, qs.n, 300):       # the last run of `b` (one sub-batch) skipped exact matches
+        assert np.array_equal(b.debug_hit_counts(q), otree.hit_counts(qs.seq(q), skip_exact=True)[1])

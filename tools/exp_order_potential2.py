@@ -22,8 +22,10 @@ inv[orig.astype(np.int64)] = np.arange(len(orig))
 L = db.length
 B = qs.bases.reshape(-1, L)
 by_source = np.ascontiguousarray(B[np.argsort(inv[qs.source], kind="stable")]).reshape(-1)
-for name, bases, cluster in (("input order", qs.bases, False), ("min-hash order (library)", qs.bases, True), ("true source order", by_source, False)):
-    ix = rx.Index(tree, cluster=cluster, stage_timing=True)
+# RTX_EXP_PAIR_ANY_ORDER=1 in the environment keeps the pair kernel on for the two host-made orders as well
+for name, bases, cluster, locator in (("input order", qs.bases, False, False), ("min-hash order", qs.bases, True, False),
+                                      ("locator + min-hash (library)", qs.bases, True, True), ("true source order", by_source, False, False)):
+    ix = rx.Index(tree, cluster=cluster, stage_timing=True, locator=locator)
     ex = ix.exact_matches(bases, qs.base_off)
     ix.upload(bases, qs.base_off, *ex)
     for _ in range(3):

@@ -209,15 +209,20 @@ class Result:
         return out
 
 
+DEFAULT_SEGMENT_CLASSES = 1   # RTX_DEFAULT_SEGMENT_CLASSES of the library (rtx_api.hip: g_seg_classes)
+
+
 class Index:
     """Device-resident index + batch workspace of one GPU (rtx_index)."""
 
     def __init__(self, tree: Tree, device: int = 0, sub_batch: int = 0, prob_mode: int = 0, streams: int = 0,
-                 stage_timing: bool = False, cluster: Optional[bool] = None, segment_classes=1,
+                 stage_timing: bool = False, cluster: Optional[bool] = None, segment_classes=None,
                  packed_counts: Optional[bool] = None, hit_quad: Optional[bool] = None,
                  tile_skip: Optional[bool] = None, hit_pair=None, locator: Optional[bool] = None):
         self._lib = _lib.load()
         self.tree = tree
+        if segment_classes is None:
+            segment_classes = DEFAULT_SEGMENT_CLASSES
         check(self._lib.rtx_set_default_option(1, int(segment_classes)))   # creation-time default of the library
         h = C.c_void_p()
         check(self._lib.rtx_index_create_from_tree(device, tree._h, C.byref(h)))

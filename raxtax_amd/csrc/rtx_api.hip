@@ -531,7 +531,7 @@ int begin_run(rtx_index *ix, uint32_t *n_sub_out, bool *timed_out, bool cluster)
     ix->quad_used = ix->quad_opt && cluster && ix->planes <= 10 && ix->n_q > 2;
     // two neighbours per wave: the same condition; the mid-segment lists are folded by hit_count_kernel only
     static const bool pair_any_order = getenv("RTX_EXP_PAIR_ANY_ORDER") != nullptr;  // experiments (tools/exp_order_potential2.py): the pair kernel on a host-made order
-    ix->pair_used = !ix->quad_used && ix->pair_opt && (cluster || pair_any_order) && ix->planes <= 10 && ix->n_q > 1 && ix->n_mid_slots == 0 && ix->rstride <= 4096;
+    ix->pair_used = !ix->quad_used && ix->pair_opt && (cluster || pair_any_order) && ix->planes <= 10 && ix->n_q > 1 && ix->rstride <= 4096 && !(ix->n_mid_slots && ix->pair_opt == 2);  // (the sequential variant keeps its lists alive into the epilogue: no room for the byte counters of a whole tile + mid ids)
     ix->groups_per_sub = ix->pair_used ? (ix->sub_batch + 1u) / 2u : (ix->sub_batch + 3u) / 4u;
     // the sequential variant keeps every list of a (pair, tile) in one round: t <= kHitListCap - 64
     ix->pair_variant = ix->pair_used && ix->pair_opt == 2 && ix->tmax + 64u <= kHitListCap ? 2 : 1;
@@ -1028,7 +1028,7 @@ int rtx_index_create_shard(int device, uint64_t n_refs_total, uint64_t ref_lo, u
 }
 
 // RTX_DEFAULT_SEGMENT_CLASSES (rtx_set_default_option): 0 = every segment is read densely (A/B measurements)
-static uint64_t g_seg_classes = 1;  // 2 (mid segments as lists) moves 17 % fewer bytes but is no faster: DESIGN.md section 3
+static uint64_t g_seg_classes = 1;  // 2 (segments of 17 .. 128 references as lists through the byte counters) asks for 14 % fewer bytes but is 10 % slower: DESIGN.md section 3
 
 // Classifies every (row, tile) segment of the finished bitmap as empty / dense / sparse and writes the slots of the
 // sparse ones (rtx_segments.hip).  Slots are numbered in (row, tile) order: deterministic.
@@ -1056,7 +1056,7 @@ static int build_segments(rtx_index *ix) {
             const bool full_tile = t + 1 < nt || last_full;
             if (c == 0) o = empty_on ? 0u : 1u;
             else if (c <= kSegSparseMax && sparse_on && full_tile) o = (uint32_t)(2 + slots++);
-            else if (c <= kSegMidMax && mid_on && full_tile) o = 0x80000000u | (uint32_t)(mslots++);
+            else if (c <= kSegMidMax && mid_on && full_tile && mslots < (1u << 23)) o = 0x80000000u | (uint32_t)(mslots++);
             else o = 1u;
         }
     if (slots > 0x7FFFFFF0ull || mslots > 0x7FFFFFF0ull) { set_error("too many sparse segments"); return RTX_ERR_INVALID; }

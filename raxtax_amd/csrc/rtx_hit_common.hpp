@@ -180,63 +180,6 @@ __device__ __forceinline__ void fold_ring2(uint32_t (&pa)[4][NP], uint32_t (&pb)
 }
 
 // ---------------------------------------------------------------------------
-// The mid segments of a (query, tile) wave (17 .. kSegMidMax references: 128 bytes of positions instead of a 1-KiB row
-// segment).  Lane l takes entry l of a segment (one 128-byte load per segment), the wave scatters the positions into a
-// zeroed row image in LDS with ONE ds_or, reads the image back as the 16 bytes per lane a dense row would have
-// delivered, and folds eight such rows with the same carry-save tree.  rowbuf: 8 KiB of this wave (eight row images:
-// the row-list / histogram and byte-counter regions, both free between the row loop and the epilogue).
-// ---------------------------------------------------------------------------
-template <int NP>
-__device__ __forceinline__ void hit_mid_rows(const HitParams &p, uint32_t (&pl)[4][NP], uint32_t q, uint32_t tile, uint32_t lane,
-                                             uint32_t *rowbuf) {
-    if (!p.nmid) return;
-#ifdef RTX_EXP_NO_MID_FOLD
-    return;  // experiment (tools/quad_variants.sh): what the dense loop gains when the mid rows cost nothing (wrong counts)
-#endif
-    const uint32_t nm = p.nmid[(size_t)q * p.ntiles + tile];
-    if (nm == 0) return;
-    const uint32_t *mrows = p.mrows + ((size_t)q * p.ntiles + tile) * (kSegMaxMidRows + 1);
-    uint4 *img = reinterpret_cast<uint4 *>(rowbuf);  // eight row images of 1 KiB
-    // entries of the eight segments from m0 on: lane l takes entry l of each (a 128-byte load per segment); issued one
-    // group ahead, so that their latency hides behind the fold of the group before
-    auto entries = [&](uint32_t m0, uint32_t (&ent)[8]) {
-        const uint32_t sv = m0 + (lane & 7u) < nm ? mrows[m0 + (lane & 7u)] : 0xFFFFFFFFu;
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            const uint32_t slot = (uint32_t)__builtin_amdgcn_readlane((int)sv, j);
-            ent[j] = 0xFFFFu;
-            if (slot != 0xFFFFFFFFu) ent[j] = p.midslots[(size_t)slot * kSegMidEntries + lane];  // wave-uniform branch
-        }
-    };
-    uint32_t ent[8], nxt[8];
-    entries(0, ent);
-    for (uint32_t m0 = 0; m0 < nm; m0 += 8) {
-        if (m0 + 8 < nm) entries(m0 + 8, nxt);
-        wave_lds_sync();  // the images of the group before have been read
-#pragma unroll
-        for (int j = 0; j < 8; j++) img[j * 64 + lane] = make_uint4(0, 0, 0, 0);
-        wave_lds_sync();
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            const uint32_t e = ent[j];
-            if (e != 0xFFFFu) atomicOr(&rowbuf[j * 256 + (e >> 5)], 1u << (e & 31u));
-        }
-        wave_lds_sync();
-        uint4 A[8];
-#pragma unroll
-        for (int j = 0; j < 8; j++) A[j] = img[j * 64 + lane];
-        const uint4 c3 = tree8<NP>(pl, A);
-        planes_ripple<NP, 3>(pl[0], c3.x);
-        planes_ripple<NP, 3>(pl[1], c3.y);
-        planes_ripple<NP, 3>(pl[2], c3.z);
-        planes_ripple<NP, 3>(pl[3], c3.w);
-#pragma unroll
-        for (int j = 0; j < 8; j++) ent[j] = nxt[j];
-    }
-    wave_lds_sync();  // the images become the histogram and the byte counters of the epilogue
-}
-
-// ---------------------------------------------------------------------------
 // Epilogue of a (query, tile) wave: the bit planes `pl` hold the hits through dense segments.  Zeroes exact matches
 // (raxtax.rs:65-68), unpacks the planes, adds the hits through sparse segments (byte counters in LDS, half a tile at
 // a time), stores the counts (u16, or packed 10 bits per reference), builds the histogram of prob.rs:13-19 with LDS
@@ -246,7 +189,11 @@ __device__ __forceinline__ void hit_mid_rows(const HitParams &p, uint32_t (&pl)[
 //   kPrefetch: the slots of ALL sparse segments of the tile are requested at once and kept in registers for both half-tile
 //   passes (two round trips instead of two per 64 segments and half) -- for kernels with registers to spare in the epilogue;
 //   `pre_in` (optional): they have been requested by the caller already (sparse_prefetch).
-//   kFullTile: cnt8 holds 8192 byte counters, the sparse segments are scanned once for the whole tile.
+//   kFullTile: cnt8 holds 8192 byte counters (+ 64 pad words), the sparse segments are scanned once for the whole tile.
+//   Mid segments (17 .. kSegMidMax references, kept as kSegMidEntries local ids = 256 bytes instead of a 1-KiB row
+//   segment; rtx_segments.hip) go through the same byte counters: `nm` of them, their slot ids at `mids` (LDS or
+//   global); one 256-byte load per segment (lane l takes entries 2l and 2l + 1), eight segments in flight.  A (query,
+//   tile) has at most 255 sparse + mid segments (kmer_extract), so a byte counter cannot overflow.
 constexpr int kSparseIt = (kSegMaxSparseRows + 63) / 64, kSparseV = kSegSlotEntries / 8;
 
 // the slots of all sparse segments of a (query, tile): lane l takes segment it * 64 + l; sid: their slot ids (global or LDS)
@@ -267,14 +214,35 @@ __device__ __forceinline__ void sparse_prefetch(const HitParams &p, uint32_t lan
 template <int NP, bool kPacked, bool kPrefetch, bool kFullTile, bool kPreLoaded>
 __device__ __forceinline__ void hit_epilogue_x(const HitParams &p, uint32_t (&pl)[4][NP], uint32_t q, uint32_t tile, uint32_t lane,
                                                uint32_t t, bool active, uint32_t *hist_lds, uint32_t *cnt8, uint32_t ns,
-                                               const uint32_t *srows, uint4 (&pre)[kSparseIt][kSparseV]) {
+                                               const uint32_t *srows, uint4 (&pre)[kSparseIt][kSparseV], uint32_t nm = 0,
+                                               const uint32_t *mids = nullptr) {
     RTX_EPI_DECL
     constexpr int kIt = kSparseIt, kVp = kSparseV;
+    const bool lists = ns || nm;  // wave-uniform: byte counters in use
     if (kPrefetch && !kPreLoaded && ns) sparse_prefetch(p, lane, ns, srows, pre);
+    // the mid segments from m0 on: kMB 256-byte loads in flight (slot ids through v_readlane: the address is wave-uniform +
+    // lane; unconditional -- a branch per load makes the compiler drain the memory counter -- with the pad slot's value
+    // selected for the entries behind the list)
+    constexpr int kMB = kFullTile ? 32 : 8;  // the pair kernel has the registers of its row buffers to spare in the epilogue
+    const uint32_t pad_word = seg_mid_pad(2u * lane) | (seg_mid_pad(2u * lane + 1u) << 16);  // entries behind a list
+    auto mid_load = [&](uint32_t m0, uint32_t (&e)[kMB]) {
+#pragma unroll
+        for (int c = 0; c < kMB / 8; c++) {
+            const uint32_t i = m0 + (uint32_t)c * 8u + (lane & 7u);
+            const uint32_t sv = i < nm ? mids[i] : 0xFFFFFFFFu;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const uint32_t slot = (uint32_t)__builtin_amdgcn_readlane((int)sv, j);
+                const uint32_t v = reinterpret_cast<const uint32_t *>(p.midslots + (size_t)(slot == 0xFFFFFFFFu ? 0u : slot) * kSegMidEntries)[lane];
+                e[c * 8 + j] = slot == 0xFFFFFFFFu ? pad_word : v;
+            }
+        }
+    };
     // hits of the sparse segments on the references [half*4096, half*4096 + 4096) of the tile -> cnt8 (at most 255 each)
     auto sparse_hits = [&](uint32_t half) {
 #pragma unroll
         for (int i = 0; i < (kFullTile ? 8 : 4); i++) reinterpret_cast<uint4 *>(cnt8)[i * 64 + lane] = make_uint4(0, 0, 0, 0);
+        if (kFullTile) cnt8[2048u + lane] = 0;  // 64 pad words: they take the unused entries of the mid segments (spread: one word would serialise the atomics)
         wave_lds_sync();
         constexpr int kV = kSegSlotEntries / 8;  // uint4 per slot
         auto add_slot = [&](const uint4 (&e)[kV]) {
@@ -289,6 +257,8 @@ __device__ __forceinline__ void hit_epilogue_x(const HitParams &p, uint32_t (&pl
                 }
             }
         };
+        uint32_t me[kMB];
+        if (nm) mid_load(0, me);
         if (kPrefetch) {
 #pragma unroll
             for (int it = 0; it < kIt; it++)
@@ -304,6 +274,22 @@ __device__ __forceinline__ void hit_epilogue_x(const HitParams &p, uint32_t (&pl
                     for (int i = 0; i < kV; i++) e[i] = slot[i];
                 }
                 add_slot(e);
+            }
+        }
+        for (uint32_t m0 = 0; m0 < nm; m0 += kMB) {
+            uint32_t cur[kMB];
+#pragma unroll
+            for (int j = 0; j < kMB; j++) cur[j] = me[j];
+            if (m0 + kMB < nm) mid_load(m0 + kMB, me);  // the next batch is on its way while this one is counted
+#pragma unroll
+            for (int j = 0; j < kMB; j++) {
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    const uint32_t id = h ? cur[j] >> 16 : cur[j] & 0xFFFFu;  // >= kSegMidPad (8192): unused entry
+                    // full tile: unused entries land in the pad word behind the counters, no branch
+                    if (kFullTile) atomicAdd(&cnt8[id >> 2], 1u << ((id & 3u) * 8u));
+                    else if ((id >> 12) == half) atomicAdd(&cnt8[(id & 4095u) >> 2], 1u << ((id & 3u) * 8u));
+                }
             }
         }
         wave_lds_sync();
@@ -344,7 +330,7 @@ __device__ __forceinline__ void hit_epilogue_x(const HitParams &p, uint32_t (&pl
 #pragma unroll
     for (int half = 0; half < 2; half++) {  // groups 0-7 = references 0..4095 of a full tile, groups 8-15 = 4096..8191
         RTX_EPI_MARK(6)
-        if (ns && (!kFullTile || half == 0)) {
+        if (lists && (!kFullTile || half == 0)) {
             sparse_hits((uint32_t)half);
             if (p.flags & RTX_SKIP_EXACT_MATCHES) {  // raxtax.rs:65-68: the sparse part
                 const uint64_t qin = p.perm[p.q0 + q];
@@ -373,7 +359,7 @@ __device__ __forceinline__ void hit_epilogue_x(const HitParams &p, uint32_t (&pl
                     st.z = __builtin_amdgcn_perm(hi1, lo1, 0x05010400u);
                     st.w = __builtin_amdgcn_perm(hi1, lo1, 0x07030602u);
                     const uint32_t goff = (uint32_t)(w * 4 + g2) * L * 8u;
-                    if (ns) {  // + hits through sparse segments (L = 64 here): bytes of the eight references of this group
+                    if (lists) {  // + hits through sparse and mid segments (L = 64 here): bytes of the eight references of this group
                         const uint2 sb = *reinterpret_cast<const uint2 *>(cnt8 + (((uint32_t)((kFullTile ? w : wi) * 4 + g2) * 64u + lane) * 2u));
                         st.x += (sb.x & 0xFFu) | ((sb.x & 0xFF00u) << 8);
                         st.y += ((sb.x >> 16) & 0xFFu) | ((sb.x >> 24) << 16);
@@ -464,7 +450,9 @@ __device__ __forceinline__ void hit_epilogue(const HitParams &p, uint32_t (&pl)[
                                              uint32_t t, bool active, uint32_t *hist_lds, uint32_t *cnt8, uint32_t ns,
                                              const uint32_t *srows) {
     uint4 pre[kSparseIt][kSparseV];  // unused without kPrefetch
-    hit_epilogue_x<NP, kPacked, kPrefetch, false, false>(p, pl, q, tile, lane, t, active, hist_lds, cnt8, ns, srows, pre);
+    const uint32_t nm = p.nmid ? p.nmid[(size_t)q * p.ntiles + tile] : 0u;
+    const uint32_t *mids = p.mrows + ((size_t)q * p.ntiles + tile) * (kSegMaxMidRows + 1);
+    hit_epilogue_x<NP, kPacked, kPrefetch, false, false>(p, pl, q, tile, lane, t, active, hist_lds, cnt8, ns, srows, pre, nm, mids);
 }
 
 }  // namespace rtx

@@ -36,7 +36,8 @@ constexpr uint32_t kPairCap = kHitListCap;            // entries per list and ro
 constexpr uint32_t kPairListDw = kPairCap + 192u;     // + padding to a multiple of 8 + the look-ahead of the row loop
 constexpr uint32_t kPairMaskWords = 64u;              // dense-mask words (u64) per query and tile kept in LDS: rstride <= 4096
 constexpr uint32_t kPairSidDw = 2u * kSparseIt * 64u;     // slot ids of the sparse segments of both queries (read at the start, used in the epilogue)
-constexpr uint32_t kPairLdsBytes = 3u * kPairListDw * 4u + 2u * kPairMaskWords * 8u + 32u * 4u + kPairSidDw * 4u;  // lists | dense masks | 32 x the zero row | slot ids
+constexpr uint32_t kPairMidDw = 2u * (kSegMaxMidRows + 1u);  // slot ids of the mid segments of both queries
+constexpr uint32_t kPairLdsBytes = 3u * kPairListDw * 4u + 2u * kPairMaskWords * 8u + 32u * 4u + kPairSidDw * 4u + kPairMidDw * 4u;  // lists | dense masks | 32 x the zero row | sparse slot ids | mid slot ids
 constexpr int kPairNB = 4;                            // buffers of eight rows per wave
 
 // ---------------------------------------------------------------------------
@@ -139,6 +140,7 @@ __global__ __launch_bounds__(64, 2) void hit_count_pair_kernel(HitParams p) {
     uint32_t *l_zero = reinterpret_cast<uint32_t *>(m_b + kPairMaskWords);
     if (lane < 32u) l_zero[lane] = p.zero_row << 10;
     uint32_t *l_sid = l_zero + 32;  // [2][kSparseIt * 64]
+    uint32_t *l_mid = l_sid + kPairSidDw;  // [2][kSegMaxMidRows + 1]
     const uint32_t col = tile * 1024u + lane * 16u;
     const bool active = col < p.stride_bytes;
     uint32_t pa[4][NP], pb[4][NP];
@@ -169,6 +171,7 @@ __global__ __launch_bounds__(64, 2) void hit_count_pair_kernel(HitParams p) {
     const uint32_t ns_a = p.nsparse[(size_t)qa * p.ntiles + tile], ns_b = has_b ? p.nsparse[(size_t)qb * p.ntiles + tile] : 0u;
     const uint32_t *srows_a = p.srows + ((size_t)qa * p.ntiles + tile) * (kSegMaxSparseRows + 1);
     const uint32_t *srows_b = p.srows + ((size_t)(has_b ? qb : qa) * p.ntiles + tile) * (kSegMaxSparseRows + 1);
+    const uint32_t nm_a = p.nmid ? p.nmid[(size_t)qa * p.ntiles + tile] : 0u, nm_b = p.nmid && has_b ? p.nmid[(size_t)qb * p.ntiles + tile] : 0u;
     {
         const unsigned long long *dm_a = p.dmask + ((size_t)qa * p.ntiles + tile) * mwords;
         const unsigned long long *dm_b = p.dmask + ((size_t)(has_b ? qb : qa) * p.ntiles + tile) * mwords;
@@ -178,6 +181,13 @@ __global__ __launch_bounds__(64, 2) void hit_count_pair_kernel(HitParams p) {
             sa[it] = srows_a[(uint32_t)it * 64u + lane];
             sb[it] = srows_b[(uint32_t)it * 64u + lane];
         }
+        uint32_t ma[2] = {0, 0}, mb[2] = {0, 0};
+        if (p.nmid) {  // wave-uniform; the lists have kSegMaxMidRows + 1 = 128 entries
+            const uint32_t *mr_a = p.mrows + ((size_t)qa * p.ntiles + tile) * (kSegMaxMidRows + 1);
+            const uint32_t *mr_b = p.mrows + ((size_t)(has_b ? qb : qa) * p.ntiles + tile) * (kSegMaxMidRows + 1);
+            ma[0] = mr_a[lane]; ma[1] = mr_a[64u + lane];
+            mb[0] = mr_b[lane]; mb[1] = mr_b[64u + lane];
+        }
         for (uint32_t i = lane; i < mwords; i += 64) {
             m_a[i] = dm_a[i];
             m_b[i] = has_b ? dm_b[i] : 0ull;
@@ -186,6 +196,10 @@ __global__ __launch_bounds__(64, 2) void hit_count_pair_kernel(HitParams p) {
         for (int it = 0; it < kSparseIt; it++) {
             l_sid[(uint32_t)it * 64u + lane] = sa[it];
             l_sid[(kSparseIt + (uint32_t)it) * 64u + lane] = sb[it];
+        }
+        if (p.nmid) {
+            l_mid[lane] = ma[0]; l_mid[64u + lane] = ma[1];
+            l_mid[128u + lane] = mb[0]; l_mid[192u + lane] = mb[1];
         }
     }
     wave_lds_sync();
@@ -267,11 +281,11 @@ __global__ __launch_bounds__(64, 2) void hit_count_pair_kernel(HitParams p) {
     uint4 pre_a[kSparseIt][kSparseV], pre_b[kSparseIt][kSparseV];
     if (ns_a) sparse_prefetch(p, lane, ns_a, l_sid, pre_a);
     if (ns_b) sparse_prefetch(p, lane, ns_b, l_sid + kSparseIt * 64u, pre_b);
-    hit_epilogue_x<NP, kPacked, true, true, true>(p, pa, qa, tile, lane, p.t[qa], active, hist_lds, cnt8, ns_a, srows_a, pre_a);
+    hit_epilogue_x<NP, kPacked, true, true, true>(p, pa, qa, tile, lane, p.t[qa], active, hist_lds, cnt8, ns_a, srows_a, pre_a, nm_a, l_mid);
     PAIR_MARK(3)
     if (has_b) {
         wave_lds_sync();
-        hit_epilogue_x<NP, kPacked, true, true, true>(p, pb, qb, tile, lane, p.t[qb], active, hist_lds, cnt8, ns_b, srows_b, pre_b);
+        hit_epilogue_x<NP, kPacked, true, true, true>(p, pb, qb, tile, lane, p.t[qb], active, hist_lds, cnt8, ns_b, srows_b, pre_b, nm_b, l_mid + (kSegMaxMidRows + 1u));
     }
     PAIR_MARK(4)
 #ifdef RTX_PAIR_STAMP
@@ -459,7 +473,8 @@ void launch_pair_union(hipStream_t s, const uint32_t *rows, const uint32_t *nrow
 constexpr uint32_t kPairSeqLdsBytes = 3u * kPairListDw * 4u + 2u * kPairMaskWords * 8u + 64u * 4u + kPairSidDw * 4u;
 
 void launch_hit_count_pair(hipStream_t s, const HitParams &p, uint32_t nq, uint32_t ntiles, int variant) {
-    static_assert(3u * kPairListDw >= 1024u + 2048u, "histogram (t <= 1023) and byte counters alias the lists");
+    static_assert(3u * kPairListDw >= 1024u + 2048u + 64u, "histogram (t <= 1023) and byte counters (+ pad words) alias the lists");
+    static_assert(kSegMaxMidRows + 1 == 128, "the mid slot id lists are read as two words per lane");
     static_assert(2u * kPairListDw >= 1024u + 1024u, "sequential variant: A's epilogue leaves B's list alone");
     static_assert(kSegMaxSparseRows + 1 >= kSparseIt * 64, "the slot id lists are read without a bound");
     static_assert(kPairListDw >= kPairCap + RTX_PAIRSEQ_NB * 8u + 64u, "padding of the lists");

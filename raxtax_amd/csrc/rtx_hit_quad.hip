@@ -329,7 +329,6 @@ __global__ __launch_bounds__(256, RTX_QUAD_WAVES_PER_SIMD) void hit_count_quad_k
     if (valid) {
         uint32_t *hist_lds = reinterpret_cast<uint32_t *>(lds + wave * kQuadEpiBytes);
         uint32_t *cnt8 = hist_lds + (kQuadEpiBytes - 4096u) / 4u;
-        hit_mid_rows<NP>(p, pl, q, tile, lane, hist_lds);
         hit_epilogue<NP, kPacked>(p, pl, q, tile, lane, t, active, hist_lds, cnt8, ns, srows);
     }
     STAMP_MARK(3)
@@ -341,7 +340,6 @@ __global__ __launch_bounds__(256, RTX_QUAD_WAVES_PER_SIMD) void hit_count_quad_k
     if (!valid) return;
     uint32_t *hist_lds = reinterpret_cast<uint32_t *>(lds + wave * kQuadEpiBytes);
     uint32_t *cnt8 = hist_lds + (kQuadEpiBytes - 4096u) / 4u;
-    hit_mid_rows<NP>(p, pl, q, tile, lane, hist_lds);
     hit_epilogue<NP, kPacked>(p, pl, q, tile, lane, t, active, hist_lds, cnt8, ns, srows);
 }
 

@@ -274,15 +274,16 @@ __global__ __launch_bounds__(64) void kmer_extract_kernel(KmerParams p) {
             unsigned long long mT = p.seg_mbits ? transpose64(mb, lane) : 0ull;
             __syncthreads();
             if (tile < nt) {
-                // the first sparse rows (up to the 255 the byte counters of hit_count hold) go to the slot list ...
-                while (sT && cs < kSegMaxSparseRows) {
+                // the first sparse rows go to the slot list (the byte counters of hit_count hold 255 hits: at most
+                // kSegMaxListRows sparse + mid segments together) ...
+                while (sT && cs < kSegMaxSparseRows && cs + cm < kSegMaxListRows) {
                     const int r = __builtin_ctzll(sT);
                     sT &= sT - 1;
                     sout[(size_t)tile * (kSegMaxSparseRows + 1) + cs] = l_base[r] + (uint32_t)__popcll(l_sb[r] & lt_mask);
                     cs++;
                 }
                 // ... the first mid rows to theirs ...
-                while (mT && cm < kSegMaxMidRows) {
+                while (mT && cm < kSegMaxMidRows && cs + cm < kSegMaxListRows) {
                     const int r = __builtin_ctzll(mT);
                     mT &= mT - 1;
                     mout[(size_t)tile * (kSegMaxMidRows + 1) + cm] = l_mbase[r] + (uint32_t)__popcll(l_mb[r] & lt_mask);
@@ -331,22 +332,24 @@ __global__ __launch_bounds__(64) void kmer_extract_kernel(KmerParams p) {
                     const uint32_t nm = (uint32_t)__builtin_amdgcn_readlane((int)cm, (int)tile);
                     const bool mid = (code >> 31) != 0u;  // 0x80000000 | mid slot
                     const bool sparse = code >= 2u && !mid;  // hit_count's byte counters hold 255 hits: more sparse rows are read densely
-                    const unsigned long long ms = __ballot(sparse);
-                    const uint32_t srank = ns + (uint32_t)__popcll(ms & lt_mask);
-                    const bool take = sparse && srank < kSegMaxSparseRows;
+                    // sparse and mid segments share the byte counters of hit_count: together at most kSegMaxListRows.  The
+                    // ranks count the candidates in front of a row (taken so far + earlier ones of this chunk): they only
+                    // grow along the rows, so the rows taken from a chunk are a prefix of its candidates of either kind --
+                    // their ranks are positions in the lists -- and a row is only taken while fewer than the cap have been
+                    const unsigned long long ms = __ballot(sparse), mm = __ballot(mid);
+                    const uint32_t srank = ns + (uint32_t)__popcll(ms & lt_mask), mrank = nm + (uint32_t)__popcll(mm & lt_mask);
+                    const bool room = srank + mrank < kSegMaxListRows;
+                    const bool take = sparse && srank < kSegMaxSparseRows && room;
+                    const bool mtake = mid && mrank < kSegMaxMidRows && room;
                     if (take) sout[(size_t)tile * (kSegMaxSparseRows + 1) + srank] = code - 2u;
-                    const unsigned long long mm = __ballot(mid);
-                    const uint32_t mrank = nm + (uint32_t)__popcll(mm & lt_mask);
-                    const bool mtake = mid && mrank < kSegMaxMidRows;
                     if (mtake) mout[(size_t)tile * (kSegMaxMidRows + 1) + mrank] = code & 0x7FFFFFFFu;
+                    const unsigned long long bt = __ballot(take), bm = __ballot(mtake);
                     const unsigned long long md = __ballot(code == 1u || (sparse && !take) || (mid && !mtake));
                     if (lane == tile) {
                         dm[(size_t)tile * mstride + c] = md;
                         cd += (uint32_t)__popcll(md);
-                        const uint32_t ns2 = ns + (uint32_t)__popcll(ms);
-                        cs = ns2 < kSegMaxSparseRows ? ns2 : kSegMaxSparseRows;
-                        const uint32_t nm2 = nm + (uint32_t)__popcll(mm);
-                        cm = nm2 < kSegMaxMidRows ? nm2 : kSegMaxMidRows;
+                        cs = ns + (uint32_t)__popcll(bt);
+                        cm = nm + (uint32_t)__popcll(bm);
                     }
                 }
             }
@@ -517,7 +520,6 @@ __global__ __launch_bounds__(64, (NP <= 10 ? 4 : 2)) void hit_count_kernel(HitPa
             __syncthreads();  // the list is rewritten (next round) or becomes the histogram
         }
     }
-    hit_mid_rows<NP>(p, pl, q, tile, lane, hist_lds);  // 8 KiB from the start of this wave's LDS
     hit_epilogue<NP, kPacked>(p, pl, q, tile, lane, t, active, hist_lds, cnt8, ns, srows);
 }
 

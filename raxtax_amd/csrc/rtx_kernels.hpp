@@ -21,11 +21,15 @@ constexpr uint32_t kWalkMaxRows = 208;
 // 31.3 % <= 32); a (query, tile) pair takes at most kSegMaxSparseRows such segments through the
 // byte counters of hit_count (more are read as dense segments)
 constexpr uint32_t kSegSlotEntries = 16, kSegSparseMax = 16, kSegMaxSparseRows = 255;
-// "mid" segments, 17 .. kSegMidMax references (12 % of the requested segments at N = 500k, a fifth of the dense ones):
-// kept as kSegMidEntries positions (word << 5 | bit inside the 1-KiB segment, u16, 0xFFFF = unused) = 128 bytes instead
-// of 1 KiB; hit_count scatters them into a row image in LDS and folds that like a dense row.  At most kSegMaxMidRows per
-// (query, tile), the rest is read densely.
-constexpr uint32_t kSegMidMax = 64, kSegMidEntries = 64, kSegMaxMidRows = 127;
+// "mid" segments, 17 .. kSegMidMax references (20 % of the requested segments at N = 500k, a third of the dense ones --
+// the k-mers a query owes to its own substitutions are spread over the database like this, and they are the rows no
+// other query has just pulled into L2): kept as kSegMidEntries local ids (u16, >= kSegMidPad = unused) = 256 bytes instead of
+// 1 KiB; hit_count adds them through the byte counters of the sparse segments.  At most kSegMaxMidRows per (query, tile)
+// and at most 255 sparse + mid segments together (the counters are bytes); the rest is read densely.
+constexpr uint32_t kSegMidMax = 128, kSegMidEntries = 128, kSegMaxMidRows = 127, kSegMidPad = 8192, kSegMaxListRows = 255;
+// unused entry i of a mid slot: 64 different pad words behind the byte counters (local id 8192 + 4 (i mod 64)), so that the
+// LDS atomics of the unused entries of a wave-instruction do not all hit one address
+__host__ __device__ inline uint32_t seg_mid_pad(uint32_t i) { return kSegMidPad + ((i & 63u) << 2); }
 // hit_count compacts the dense rows of its (query, tile) into an LDS list of this many row ids (+ padding), in
 // several rounds if they do not fit
 constexpr uint32_t kHitListCap = 1024;  // >= 200 rows of confidence >= 0.005 + fallback
@@ -90,7 +94,7 @@ struct HitParams {
     const uint16_t *segslots; // [n_slots][kSegSlotEntries] local ids of the sparse segments
     const uint32_t *mrows;    // [B][ntiles][kSegMaxMidRows + 1]
     const uint32_t *nmid;     // [B][ntiles]
-    const uint16_t *midslots; // [n_mid][kSegMidEntries] positions (word << 5 | bit) of the mid segments
+    const uint16_t *midslots; // [n_mid][kSegMidEntries] local ids of the mid segments (kSegMidPad = unused)
     uint32_t ntiles;
     const uint32_t *t;
     uint16_t *counts;  // [B][npad] u16 counts (more than 10 bit planes: t > 1023)

@@ -4,10 +4,11 @@
 // k-mer that is typical for a clade fills a few tiles and leaves the others empty or nearly empty: 11 % of the
 // (row, tile) segments a query asks for are empty and another 20 % hold at most 32 references (bench workload),
 // and those are the segments no other query has just pulled into L2.  At index creation every segment is classified
-//     0 = empty (never loaded), 1 = dense (loaded as a 1-KiB row segment), s + 2 = sparse, slot s
-// and the references of a sparse segment are written to a 64-byte slot of 32 local ids (u16, 0xFFFF = unused).
-// kmer_extract turns the classes into per-(query, tile) row lists; hit_count adds the sparse slots through
-// byte counters in LDS.
+//     0 = empty (never loaded), 1 = dense (loaded as a 1-KiB row segment), s + 2 = sparse, slot s,
+//     0x80000000 | m = mid, slot m (RTX_DEFAULT_SEGMENT_CLASSES = 2)
+// and the references of a sparse segment (at most 16) are written to a 32-byte slot of 16 local ids (u16, 0xFFFF =
+// unused), those of a mid segment (17 .. 128) to a 256-byte slot of 128 (kSegMidPad = unused).  kmer_extract turns the
+// classes into per-(query, tile) row lists; hit_count adds the sparse and the mid slots through byte counters in LDS.
 #include <hip/hip_runtime.h>
 
 #include "rtx_kernels.hpp"
@@ -41,7 +42,7 @@ __global__ __launch_bounds__(64) void seg_emit_kernel(const uint32_t *__restrict
     for (uint32_t tile = 0; tile < ntiles; tile++) {
         const uint32_t code = seginfo[(size_t)row * seg_stride + tile];
         if (code < 2u) continue;  // wave-uniform
-        const bool mid = code >> 31;  // mid segment: positions (word << 5 | bit) instead of local reference ids
+        const bool mid = code >> 31;  // mid segment: a longer slot, unused entries = kSegMidPad
         uint16_t *out = mid ? midslots + (size_t)(code & 0x7FFFFFFFu) * kSegMidEntries : slots + (size_t)(code - 2u) * kSegSlotEntries;
         const uint32_t cap = mid ? kSegMidEntries : kSegSlotEntries;
         const uint32_t col = tile * 1024u + lane * 16u;
@@ -60,9 +61,14 @@ __global__ __launch_bounds__(64) void seg_emit_kernel(const uint32_t *__restrict
                 const uint32_t b = (uint32_t)__ffs((int)x) - 1u;
                 x &= x - 1u;
                 const uint32_t g = ww * 4u + (b >> 3);  // inverse of ref_slot (rtx_math.hpp)
-                if (pos < cap) out[pos] = mid ? (uint16_t)(((lane * 4u + ww) << 5) | b) : (uint16_t)((g * L + lane) * 8u + (b & 7u));
+                if (pos < cap) out[pos] = (uint16_t)((g * L + lane) * 8u + (b & 7u));
                 pos++;
             }
+        }
+        if (mid) {  // the entries behind the last reference (hit_count adds them into a pad word without looking)
+            const uint32_t total = (uint32_t)__shfl((int)pos, 63, 64);  // lane 63 ends behind the last one
+            for (uint32_t i = lane; i < cap; i += 64)
+                if (i >= total) out[i] = (uint16_t)seg_mid_pad(i);
         }
     }
 }

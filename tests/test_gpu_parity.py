@@ -11,6 +11,7 @@ import pytest
 import raxtax_amd as rx
 from gpu_common import Excuses
 from raxtax_amd import synth
+from raxtax_amd.api import DEFAULT_SEGMENT_CLASSES
 
 pytestmark = pytest.mark.gpu
 
@@ -744,21 +745,22 @@ def test_sparse_and_empty_segments(oracle, segment_classes):
             t, counts = otree.hit_counts(qs[q], skip_exact=skip)
             assert np.array_equal(ix.debug_hit_counts(q), counts), (segment_classes, skip, q)
             assert res.t[q] == t
-    rx.Index(tree, segment_classes=1)            # leave the process-wide default as it was
+    rx.Index(tree, segment_classes=DEFAULT_SEGMENT_CLASSES)            # leave the process-wide default as it was
 
 
+@pytest.mark.parametrize("hit_pair", [False, True])
 @pytest.mark.parametrize("n_refs", [3 * 8192, 4 * 8192 + 700])
-def test_mid_segments(oracle, n_refs):
-    """Segments with 17-64 references travel as 128 bytes of bit positions and are folded out of a row image in LDS
-    (rtx_hit_common.hpp: hit_mid_rows): same hit counts as with every segment read densely and as the oracle, with and
-    without --skip-exact-matches; full tiles and a partial last tile (no lists there); more mid rows in a tile than the
-    list takes (the rest is read densely)."""
+def test_mid_segments(oracle, n_refs, hit_pair):
+    """Segments with 17-128 references travel as 256 bytes of local ids and are added through the byte counters of the
+    sparse segments (rtx_hit_common.hpp: hit_epilogue_x): same hit counts as with every segment read densely and as the
+    oracle, with and without --skip-exact-matches, one query per wave and two; full tiles and a partial last tile (no
+    lists there); more mid rows in a tile than the list takes (the rest is read densely)."""
     db = synth.make_db(n_refs, fanouts=(3, 3, 3, 4, 4, 3))
     qs = synth.make_queries(db, 96, exact_frac=0.2)
     otree = oracle.tree_new_flat(db.lineages, db.seq_bytes, db.seq_off)
     tree = rx.Tree.new_flat(db.lineages, db.seq_bytes, db.seq_off, kmer_map=False)
-    a, b = rx.Index(tree, segment_classes=2), rx.Index(tree, segment_classes=0)
-    rx.Index(tree, segment_classes=1)            # back to the process-wide default
+    a, b = rx.Index(tree, segment_classes=2, hit_pair=hit_pair), rx.Index(tree, segment_classes=0, hit_pair=hit_pair)
+    rx.Index(tree, segment_classes=DEFAULT_SEGMENT_CLASSES)            # back to the process-wide default
     ex = a.exact_matches(qs.bases, qs.base_off)
     for skip in (False, True):
         ra = a.classify(qs.bases, qs.base_off, *ex, skip_exact_matches=skip)
@@ -771,6 +773,47 @@ def test_mid_segments(oracle, n_refs):
             assert np.array_equal(c, otree.hit_counts(qs.seq(q), skip_exact=skip)[1]), (skip, q)
     wa, wb = a.work(), b.work()
     assert wa["sum_hits"] == wb["sum_hits"] and wa["bitmap_bytes_read"] < 0.9 * wb["bitmap_bytes_read"]
+
+
+@pytest.mark.parametrize("hit_pair", [False, True])
+@pytest.mark.parametrize("ref_len", [400, 150])
+def test_mid_and_sparse_segments_share_the_byte_counters(oracle, ref_len, hit_pair):
+    """A database of random references in which a k-mer occurs in about 50 (ref_len 400) or 18 (ref_len 150: about half
+    of the segments sparse, half mid) of the 8192 references of a tile: a 658-base query then has hundreds of list
+    segments per tile -- more than the 127 mid segments a list takes and more than the 255 sparse + mid segments the byte
+    counters may see, so both caps and the dense fallback are exercised; the last tile is partial.  Hit counts bit-exact
+    against the oracle, with and without --skip-exact-matches (exact matches reached through lists are zeroed too)."""
+    n_refs = 2 * 8192 + 1000
+    lineages, flat, off = _random_db(n_refs, ref_len, seed=21)
+    otree = oracle.tree_new_flat(lineages, flat, off)
+    tree = rx.Tree.new_flat(lineages, flat, off)
+    ix = rx.Index(tree, segment_classes=2, hit_pair=hit_pair)
+    rx.Index(tree, segment_classes=DEFAULT_SEGMENT_CLASSES)
+    rng = np.random.default_rng(22)
+    qs = []
+    for i in range(16):
+        L = [658, 658, 500, ref_len][i % 4]
+        q = (1 << rng.integers(0, 4, L)).astype(np.uint8)
+        src = int(rng.integers(0, n_refs))
+        ref = flat[src * ref_len:(src + 1) * ref_len]
+        if L == ref_len:
+            q = ref.copy()
+        else:
+            q[7:7 + ref_len] = ref
+        if i % 2:                                  # neighbours that share most rows (the pair kernel's shared list)
+            q = qs[-1].copy() if len(qs[-1]) == L else q
+        qs.append(q)
+    qoff = np.zeros(len(qs) + 1, np.uint64)
+    qoff[1:] = np.cumsum([len(q) for q in qs])
+    bases = np.concatenate(qs)
+    ex_ids, ex_off = ix.exact_matches(bases, qoff)
+    assert np.diff(ex_off.astype(np.int64)).sum() >= 2
+    for skip in (False, True):
+        res = ix.classify(bases, qoff, ex_ids, ex_off, skip_exact_matches=skip)
+        for q in range(len(qs)):
+            t, counts = otree.hit_counts(qs[q], skip_exact=skip)
+            assert np.array_equal(ix.debug_hit_counts(q), counts), (ref_len, hit_pair, skip, q)
+            assert res.t[q] == t
 
 
 @pytest.mark.parametrize("n_refs", [70000, 8192 * 3, 40007])
@@ -867,7 +910,7 @@ def test_randomised_configurations(oracle, seed):
     opts["tile_skip"] = bool(orng.random() < 0.7)   # drawn last: the options of the recorded seeds stay what they were
     opts["hit_pair"] = int(orng.choice([0, 1, 1, 2, 2]))
     ix = rx.Index(tree, sub_batch=int(rng.choice([0, 5, 64])), cluster=bool(rng.random() < 0.7), **opts)
-    rx.Index(tree, segment_classes=1)     # restore the process-wide default for later tests
+    rx.Index(tree, segment_classes=DEFAULT_SEGMENT_CLASSES)     # restore the process-wide default for later tests
     qs = []
     for i in range(40):
         src = seqs[int(rng.integers(0, n_refs))].copy()

@@ -642,6 +642,8 @@ int enqueue_batch(rtx_index *ix, uint32_t flags) {
         if (two && sb >= 2) RTX_HIP(hipStreamWaitEvent(b.s, ix->ev_sub[sb - 2], 0));  // walk(sb-2) still reads this prefix buffer
         // one stream: the walk rides inside the prefix kernel (the stage time of lineage_walk is then part of taxon_prefix)
         const bool fuse = !two && ix->n_refs == ix->n_total && ix->n_bnd_local == ix->n_bnd;
+        static const bool count_only = getenv("RTX_EXP_COUNT_ONLY") != nullptr;  // experiments: time hit_count of builds whose counts are wrong on purpose (sync, no download)
+        if (count_only && !two) continue;
         if ((rc = enqueue_prob_prefix(ix, b, fuse))) return rc;
         hipStream_t ws = b.s;
         if (two) {
@@ -1158,7 +1160,7 @@ static int create_from_csr(int device, uint64_t n_total, uint64_t ref_lo, uint64
 // Locator table of the processing order (rtx_cluster.hip) from the reference sequences already on the device.
 // A scheduling aid only: if it cannot be built (memory) the handle works without it.
 static void build_locator(rtx_index *ix, const uint8_t *d_seq, const uint64_t *d_off, uint64_t n_refs) {
-    if (ix->n_refs != ix->n_total || n_refs < 1024) return;  // whole-database handles of some size only
+    if (ix->n_refs != ix->n_total || n_refs < 256) return;  // whole-database handles of some size only
     DevBuf<uint32_t> d_cnt;
     if (ix->d_loc_table.alloc(kLocTableEntries) || d_cnt.alloc(kLocTableEntries)) { ix->d_loc_table.release(); return; }
     hipError_t e = hipMemsetAsync(ix->d_loc_table.p, 0xFF, (size_t)kLocTableEntries * 4, ix->stream);
@@ -1234,7 +1236,7 @@ int rtx_index_create_from_tree(int device, const rtx_tree *tree, rtx_index **out
     if (rc != RTX_OK) return rc;
     // the tree holds the sequences (Tree.sequences, for the exact-match lookup): the locator table of the processing order
     const uint64_t n = tree->num_tips;
-    if (n >= 1024 && tree->seq_off.size() == n + 1) {
+    if (n >= 256 && tree->seq_off.size() == n + 1) {
         rtx_index *ix = *out;
         const uint64_t total = tree->seq_off[n] - tree->seq_off[0];
         DevBuf<uint8_t> d_seq;

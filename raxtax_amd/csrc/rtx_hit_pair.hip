@@ -248,6 +248,9 @@ __global__ __launch_bounds__(64, 2) void hit_count_pair_kernel(HitParams p) {
         wave_lds_sync();
         PAIR_MARK(1)
         const uint32_t *first = g_both ? l_both : (g_a ? l_a : (g_b ? l_b : nullptr));
+#ifdef RTX_EXP_SKIP_LOOP  // experiment: prologue and epilogues only
+        first = nullptr;
+#endif
         if (first) {
             uint4 buf[4][8];
             const uint32_t idv = first[lane & 31u];
@@ -279,10 +282,32 @@ __global__ __launch_bounds__(64, 2) void hit_count_pair_kernel(HitParams p) {
     uint32_t *hist_lds = lds_dw;
     uint32_t *cnt8 = lds_dw + 1024u;
     uint4 pre_a[kSparseIt][kSparseV], pre_b[kSparseIt][kSparseV];
+#ifdef RTX_EXP_SKIP_EPI  // experiment (RTX_EXP_COUNT_ONLY runs): what the kernel takes without its epilogues -- is a wave's time or the L2 what bounds it?
+    if (RTX_EXP_SKIP_EPI >= 2) {  // one store keeps the planes alive
+        uint32_t x = 0;
+#pragma unroll
+        for (int w = 0; w < 4; w++)
+#pragma unroll
+            for (int b = 0; b < NP; b++) x ^= pa[w][b] ^ pb[w][b];
+        if (x == 0x12345678u) p.hist[lane] = x;
+        return;
+    }
+#endif
     if (ns_a) sparse_prefetch(p, lane, ns_a, l_sid, pre_a);
     if (ns_b) sparse_prefetch(p, lane, ns_b, l_sid + kSparseIt * 64u, pre_b);
     hit_epilogue_x<NP, kPacked, true, true, true>(p, pa, qa, tile, lane, p.t[qa], active, hist_lds, cnt8, ns_a, srows_a, pre_a, nm_a, l_mid);
     PAIR_MARK(3)
+#ifdef RTX_EXP_SKIP_EPI
+    if (RTX_EXP_SKIP_EPI == 1) {
+        uint32_t x = 0;
+#pragma unroll
+        for (int w = 0; w < 4; w++)
+#pragma unroll
+            for (int b = 0; b < NP; b++) x ^= pb[w][b];
+        if (x == 0x12345678u) p.hist[lane] = x;
+        return;
+    }
+#endif
     if (has_b) {
         wave_lds_sync();
         hit_epilogue_x<NP, kPacked, true, true, true>(p, pb, qb, tile, lane, p.t[qb], active, hist_lds, cnt8, ns_b, srows_b, pre_b, nm_b, l_mid + (kSegMaxMidRows + 1u));

@@ -909,6 +909,7 @@ def test_randomised_configurations(oracle, seed):
     opts = dict(hit_quad=bool(orng.random() < 0.35), segment_classes=int(orng.choice([0, 1, 2])), packed_counts=bool(orng.random() < 0.75))
     opts["tile_skip"] = bool(orng.random() < 0.7)   # drawn last: the options of the recorded seeds stay what they were
     opts["hit_pair"] = int(orng.choice([0, 1, 1, 2, 2]))
+    opts["locator"] = bool(orng.random() < 0.6)
     ix = rx.Index(tree, sub_batch=int(rng.choice([0, 5, 64])), cluster=bool(rng.random() < 0.7), **opts)
     rx.Index(tree, segment_classes=DEFAULT_SEGMENT_CLASSES)     # restore the process-wide default for later tests
     qs = []

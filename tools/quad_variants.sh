@@ -41,6 +41,9 @@ for v in "$@"; do
     pnohist) buildp pnohist -DRTX_EXP_NO_HIST ;;
     pnostore) buildp pnostore -DRTX_EXP_NO_COUNT_STORE ;;
     pnoboth) buildp pnoboth -DRTX_EXP_NO_COUNT_STORE -DRTX_EXP_NO_HIST ;;
+    pskipb) buildp pskipb -DRTX_EXP_SKIP_EPI=1 ;;
+    pskipab) buildp pskipab -DRTX_EXP_SKIP_EPI=2 ;;
+    pskiploop) buildp pskiploop -DRTX_EXP_SKIP_LOOP ;;
     ps5) buildp ps5 -DRTX_PAIR_STAMP=5 ;;
     ps6) buildp ps6 -DRTX_PAIR_STAMP=6 ;;
     ps7) buildp ps7 -DRTX_PAIR_STAMP=7 ;;

@@ -121,14 +121,21 @@ __global__ __launch_bounds__(256) void loc_finish_kernel(uint32_t *__restrict__ 
 }
 
 // ---------------------------------------------------------------------------
-// Locator of a query: one wave per query.  Lane l looks up the 12-mers of the windows l, l + 64, ...; votes are counted
-// in LDS (u16 pairs in u32 words: a query has fewer than 65 536 windows per bin only if it is shorter than that -- longer
-// queries skip the vote and keep the min-hash key).  keys[q] = loc << 39 | (min-hash key >> 24): 24 bits of position,
-// m1 and the high 18 bits of m2.
+// Locator of a query: one wave per query.
+//   1. lane l rolls over the windows [l * wpl, (l + 1) * wpl) of the first kLocWin windows (wpl + 11 sequential byte reads,
+//      as sketch_kernel) and leaves their 12-mer codes in LDS;
+//   2. lane l looks up the windows l, l + 64, ... (coalesced codes, four table loads in flight), keeps the positions in
+//      LDS and votes for coarse bins of 2^bin_shift references.  Most lanes vote for the SAME bin -- that is the point --
+//      and LDS atomics on one address are served lane by lane (about 100 cycles for 64 of them): the lanes that agree
+//      with the first voter are counted with a ballot and added by one lane, two such rounds, the rest votes alone;
+//   3. the best pair of neighbouring coarse bins wins, then bins of a sixteenth inside it.
+// Votes are u16 pairs in u32 words (a bin gets at most kLocWin of them).  Queries longer than kLocWin + 11 bases are
+// located by their first kLocWin windows.  keys[q] = loc << 39 | (min-hash key >> 24): 24 bits of position, m1 and the
+// high 18 bits of m2.
 // ---------------------------------------------------------------------------
 static constexpr uint32_t kLocMaxBins = 8192;    // coarse bins (LDS: 16 KiB)
 static constexpr uint32_t kLocFineDiv = 16;      // fine bins per coarse bin
-static constexpr uint32_t kLocVotesPerLane = 16; // windows per lane kept for the fine vote (queries up to 1035 bases; longer: coarse only)
+static constexpr uint32_t kLocWin = 1024;        // windows of a query that vote
 
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 #pragma unroll
@@ -139,53 +146,74 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
     return v;
 }
 
+// one vote per lane with `valid` for bin b: lanes that agree with the first pending voter are added by one atomic
+__device__ __forceinline__ void vote_bins(uint32_t *h, uint32_t b, bool valid, uint32_t lane) {
+    unsigned long long pending = __ballot(valid);
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        if (!pending) return;  // wave-uniform
+        const int first = __builtin_ctzll(pending);
+        const uint32_t lead = (uint32_t)__builtin_amdgcn_readlane((int)b, first);
+        const unsigned long long same = __ballot(valid && b == lead) & pending;
+        if ((int)lane == first) atomicAdd(&h[lead >> 1], (uint32_t)__popcll(same) << ((lead & 1u) * 16u));
+        pending &= ~same;
+    }
+    if ((pending >> lane) & 1ull) atomicAdd(&h[b >> 1], 1u << ((b & 1u) * 16u));
+}
+
 __global__ __launch_bounds__(64) void locator_kernel(const uint8_t *__restrict__ bases, const uint64_t *__restrict__ off,
                                                      const uint32_t *__restrict__ table, uint32_t bin_shift, uint32_t n_bins,
                                                      uint64_t *__restrict__ keys) {
     extern __shared__ uint32_t h[];            // n_bins / 2 + 2 words: the coarse bins as u16 pairs
+    __shared__ uint32_t lcode[kLocWin];        // 12-mer codes, then the positions found for them
     __shared__ uint32_t hf[kLocFineDiv + 2];   // 2 * kLocFineDiv + 1 fine bins as u16 pairs
     const uint32_t q = blockIdx.x, lane = threadIdx.x;
     const uint64_t b0 = off[q], len = off[q + 1] - b0;
+    if (len < (uint64_t)kSketchK) return;  // wave-uniform: the min-hash key stays
     const uint64_t old_key = keys[q];
-    if (len < (uint64_t)kSketchK || len > 65000u) return;  // wave-uniform: the min-hash key stays
     const uint8_t *seq = bases + b0;
-    const uint32_t nwin = (uint32_t)(len - kSketchK + 1);
-    const uint32_t words = n_bins / 2 + 1;
-    for (uint32_t i = lane; i < words + 1; i += 64) h[i] = 0;
+    const uint32_t nwin = (uint32_t)(len - kSketchK + 1 < (uint64_t)kLocWin ? len - kSketchK + 1 : kLocWin);
+    const uint32_t words = n_bins / 2 + 2;
+    for (uint32_t i = lane; i < words; i += 64) h[i] = 0;
     if (lane < kLocFineDiv + 2) hf[lane] = 0;
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    uint32_t kept[kLocVotesPerLane];
-#pragma unroll
-    for (int i = 0; i < (int)kLocVotesPerLane; i++) kept[i] = kLocNone;
-    uint32_t any = 0;
-    for (uint32_t w0 = 0, it = 0; w0 < nwin; w0 += 64, it++) {
-        const uint32_t w = w0 + lane;
-        uint32_t pos = kLocNone;
-        if (w < nwin) {
-            uint32_t code = 0;
-            bool ok = true;
-#pragma unroll
-            for (int j = 0; j < kSketchK; j++) {
-                uint32_t two;
-                ok = base_code(seq[w + j], two) && ok;
-                code = (code << 2) | two;
-            }
-            if (ok) pos = table[code];
+    {   // 1. codes of this lane's run of windows
+        const uint32_t wpl = (nwin + 63u) / 64u;
+        const uint32_t w0 = lane * wpl, w1 = w0 + wpl < nwin ? w0 + wpl : nwin;
+        uint32_t code = 0, run = 0;
+        for (uint32_t i = w0; w0 < w1 && i < w1 + kSketchK - 1; i++) {
+            uint32_t two;
+            const bool ok = base_code(seq[i], two);
+            code = ((code << 2) | two) & 0xFFFFFFu;
+            run = ok ? run + 1u : 0u;
+            if (i + 1 >= w0 + (uint32_t)kSketchK) lcode[i + 1 - kSketchK] = run >= (uint32_t)kSketchK ? code : kLocNone;
         }
-        if (pos != kLocNone) {
-            const uint32_t b = pos >> bin_shift;
-            atomicAdd(&h[b >> 1], 1u << ((b & 1u) * 16u));
-            any = 1;
-        }
-#pragma unroll
-        for (int i = 0; i < (int)kLocVotesPerLane; i++)
-            if ((uint32_t)i == it) kept[i] = pos;
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    if (!__ballot(any != 0u)) return;  // no vote: the min-hash key stays (sorted behind nothing in particular)
-    // best pair of neighbouring coarse bins (B, B + 1): value << 16 | (0xFFFF - B), the lowest B among equals
+    // 2. look-ups and the coarse vote, four windows per lane and turn
+    uint32_t any = 0;
+    for (uint32_t w0 = 0; w0 < nwin; w0 += 256) {
+        uint32_t pos[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t w = w0 + (uint32_t)u * 64u + lane;
+            const uint32_t code = w < nwin ? lcode[w] : kLocNone;
+            pos[u] = table[code == kLocNone ? 0u : code];  // unconditional: the four loads leave together
+            if (code == kLocNone) pos[u] = kLocNone;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t w = w0 + (uint32_t)u * 64u + lane;
+            const bool valid = pos[u] != kLocNone;
+            vote_bins(h, pos[u] >> bin_shift, valid, lane);
+            if (w < nwin) lcode[w] = pos[u];
+            any |= valid ? 1u : 0u;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (!__ballot(any != 0u)) return;  // no vote: the min-hash key stays
+    // 3. best pair of neighbouring coarse bins (B, B + 1): value << 16 | (0xFFFF - B), the lowest B among equals
     auto bin = [&](uint32_t b) { return (h[b >> 1] >> ((b & 1u) * 16u)) & 0xFFFFu; };
     uint32_t best = 0;
     for (uint32_t b = lane; b < n_bins; b += 64) {
@@ -198,14 +226,12 @@ __global__ __launch_bounds__(64) void locator_kernel(const uint8_t *__restrict__
     const uint32_t lo = B << bin_shift;
     uint32_t fine = 0;
     if (bin_shift >= 4u) {
-        const uint32_t fshift = bin_shift - 4u;  // fine bins of binw / 16 references over [lo, lo + 2 binw)
-#pragma unroll
-        for (int i = 0; i < (int)kLocVotesPerLane; i++) {
-            const uint32_t pos = kept[i];
-            if (pos != kLocNone && pos >= lo && ((pos - lo) >> bin_shift) < 2u) {
-                const uint32_t f = (pos - lo) >> fshift;
-                atomicAdd(&hf[f >> 1], 1u << ((f & 1u) * 16u));
-            }
+        const uint32_t fshift = bin_shift - 4u;  // fine bins of 2^bin_shift / 16 references over [lo, lo + 2 * 2^bin_shift)
+        for (uint32_t w0 = 0; w0 < nwin; w0 += 64) {  // wave-uniform trip count (vote_bins works with ballots)
+            const uint32_t w = w0 + lane;
+            const uint32_t p = w < nwin ? lcode[w] : kLocNone;
+            const bool in = p != kLocNone && p >= lo && ((p - lo) >> bin_shift) < 2u;
+            vote_bins(hf, in ? (p - lo) >> fshift : 0u, in, lane);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();

@@ -36,11 +36,15 @@ def short(name: str) -> str:
     return name
 
 
+GRID = collections.defaultdict(lambda: collections.defaultdict(list))   # grid size of every value in read_pass's lists
+
+
 def read_pass(d):
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for f in glob.glob(str(Path(d) / "**" / "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
             agg[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            GRID[(id(agg), short(r["Kernel_Name"]))][r["Counter_Name"]].append(int(r.get("Grid_Size", 0) or 0))
     return agg
 
 
@@ -75,7 +79,11 @@ def main():
         for k, d in agg.items():
             if k.startswith("rtx::hit_count") and ctr in d:   # hit_count_kernel / hit_count_pair_kernel: whichever the run used
                 v = d[ctr]
-                full = [x for x in v if x >= 0.8 * max(v)]      # launches of a full sub-batch (the last one may be short)
+                g = GRID[(id(agg), k)][ctr]
+                # launches of a full sub-batch (the last one of a step may be short): those with the largest grid.  Their
+                # traffic differs from launch to launch -- the processing order gives every sub-batch another part of the
+                # database -- so the mean over all full launches is what a step sees
+                full = [x for x, gs in zip(v, g) if gs == max(g)]
                 return sum(full) / len(full), len(full)
         raise SystemExit(f"no hit_count dispatches with {ctr}")
 

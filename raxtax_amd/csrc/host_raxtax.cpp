@@ -3,6 +3,7 @@
 #include "host_raxtax.hpp"
 
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cstdio>
 #include <cstring>
@@ -50,6 +51,10 @@ int run(rtx_index *index, const rtx_tree *tree, uint64_t n_queries, const char *
     const unsigned nt_lookup = std::min(4u, hw), nt_format = std::min(8u, hw);
 
     std::vector<Chunk> chunks(n_chunks);
+    // busy seconds of the three stages (RTX_PIPELINE_TIMING=1 prints them: which stage bounds an end-to-end run)
+    const bool timing = getenv("RTX_PIPELINE_TIMING") != nullptr;
+    double busy_lookup = 0, busy_device = 0, busy_format = 0, busy_send = 0;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     std::mutex mu;
     std::condition_variable cv;
     int failed = RTX_OK;          // first error of any stage (under mu)
@@ -76,6 +81,7 @@ int run(rtx_index *index, const rtx_tree *tree, uint64_t n_queries, const char *
         for (uint64_t c = 0; c < n_chunks; c++) {
             if (c >= 2 && !wait_stage(c - 2, 2)) return;  // stay at most two chunks ahead of the device
             Chunk &ch = chunks[c];
+            const double t_l0 = now();
             ch.q0 = c * chunk_size;
             ch.nq = std::min<uint64_t>(chunk_size, n_queries - ch.q0);
             std::vector<const uint32_t *> ptr(ch.nq);
@@ -109,6 +115,7 @@ int run(rtx_index *index, const rtx_tree *tree, uint64_t n_queries, const char *
                     warnings = true;
                 }
             }
+            busy_lookup += now() - t_l0;
             set_stage(c, 1);
         }
     });
@@ -118,6 +125,7 @@ int run(rtx_index *index, const rtx_tree *tree, uint64_t n_queries, const char *
         for (uint64_t c = 0; c < n_chunks; c++) {
             if (!wait_stage(c, 2)) return;
             Chunk &ch = chunks[c];
+            const double t_f0 = now();
             out_msg.assign(ch.nq, std::string());
             if (tsv) tsv_msg.assign(ch.nq, std::string());
             std::atomic<int> rc_fmt{0};
@@ -142,6 +150,8 @@ int run(rtx_index *index, const rtx_tree *tree, uint64_t n_queries, const char *
                 }
             });
             if (rc_fmt) { fail(rc_fmt, "formatting a result failed"); return; }
+            const double t_s0 = now();
+            busy_format += t_s0 - t_f0;
             for (uint64_t i = 0; i < ch.nq; i++) {
                 const uint64_t q = ch.q0 + i;
                 if (ch.res.status[i] != RTX_Q_OK) {
@@ -159,6 +169,7 @@ int run(rtx_index *index, const rtx_tree *tree, uint64_t n_queries, const char *
             std::vector<uint32_t>().swap(ch.exact_ids);
             std::vector<uint64_t>().swap(ch.exact_off);
             std::vector<uint8_t>().swap(ch.differ);
+            busy_send += now() - t_s0;
             set_stage(c, 3);
         }
     });
@@ -167,13 +178,18 @@ int run(rtx_index *index, const rtx_tree *tree, uint64_t n_queries, const char *
         if (!wait_stage(c, 1)) break;
         if (c >= 2 && !wait_stage(c - 2, 3)) break;  // the result set of chunk c-2 is reused now
         Chunk &ch = chunks[c];
+        const double t_d0 = now();
         const int rc = rtx_classify_batch(index, ch.nq, bases, base_off + ch.q0, ch.exact_ids.empty() ? nullptr : ch.exact_ids.data(),
                                           ch.exact_off.data(), flags, &ch.res);
         if (rc) { fail(rc, rtx_last_error()); break; }
+        busy_device += now() - t_d0;
         set_stage(c, 2);
     }
     lookup.join();
     format.join();
+    if (timing)
+        fprintf(stderr, "[TIMING] pipeline busy seconds over %llu chunk(s): lookup %.3f (%u threads), device %.3f, format %.3f (%u threads), sender %.3f\n",
+                (unsigned long long)n_chunks, busy_lookup, nt_lookup, busy_device, busy_format, nt_format, busy_send);
     if (failed != RTX_OK) { rtx::set_error("%s", failed_msg.c_str()); return failed; }
     if (warnings)  // raxtax.rs:93-95
         fprintf(stderr, "\x1b[33m[WARN ]\x1b[0m Exact matches for some queries differ above the species level! Check the log file for more information!\n");

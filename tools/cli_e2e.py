@@ -34,5 +34,8 @@ for r in range(a.repeat + 1):
     t0 = time.time()
     p = subprocess.run(cmd, capture_output=True, text=True)
     wall = time.time() - t0
+    for l in p.stderr.splitlines():
+        if l.startswith("[TIMING]"):
+            print(l)
     last = [l for l in p.stderr.splitlines() if l.startswith("{")]
     print(json.dumps({"rc": p.returncode, "wall_s": round(wall, 3), "stages": json.loads(last[-1]) if last else p.stderr[-500:]}))

@@ -252,20 +252,33 @@ __global__ __launch_bounds__(64) void kmer_extract_kernel(KmerParams p) {
         const uint32_t blk = tb >> 6;
         const uint32_t tile = tb + lane;  // this lane's tile after the transposes
         uint32_t cd = 0, cs = 0, cm = 0;
+        // the class tables of four chunks of 64 rows are gathered together (one round trip per four chunks, not one each)
+        unsigned long long dbv[4], sbv[4], mbv[4];
+        uint32_t basev[4], mbasev[4];
         for (uint32_t c = 0; c < nchunks; c++) {
-            const uint32_t i = c * 64 + lane;
-            const uint32_t row = i < nrows ? rout[i] : kEmptyRow;
-            unsigned long long db = 0, sb = 0, mb = 0;
-            uint32_t base = 0, mbase = 0;
-            if (row != kEmptyRow) {
-                db = p.seg_dbits[(size_t)row * p.seg_blocks + blk];
-                sb = p.seg_sbits[(size_t)row * p.seg_blocks + blk];
-                base = p.seg_sbase[(size_t)row * p.seg_blocks + blk];
-                if (p.seg_mbits) {
-                    mb = p.seg_mbits[(size_t)row * p.seg_blocks + blk];
-                    mbase = p.seg_mbase[(size_t)row * p.seg_blocks + blk];
+            if ((c & 3u) == 0) {
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const uint32_t i = (c + (uint32_t)u) * 64 + lane;
+                    const uint32_t row = i < nrows ? rout[i] : kEmptyRow;
+                    const size_t at = (size_t)(row == kEmptyRow ? 0u : row) * p.seg_blocks + blk;  // unconditional loads, masked below
+                    dbv[u] = p.seg_dbits[at];
+                    sbv[u] = p.seg_sbits[at];
+                    basev[u] = p.seg_sbase[at];
+                    mbv[u] = 0;
+                    mbasev[u] = 0;
+                    if (p.seg_mbits) {  // wave-uniform
+                        mbv[u] = p.seg_mbits[at];
+                        mbasev[u] = p.seg_mbase[at];
+                    }
+                    if (row == kEmptyRow) { dbv[u] = 0; sbv[u] = 0; mbv[u] = 0; }
                 }
             }
+            unsigned long long db = 0, sb = 0, mb = 0;
+            uint32_t base = 0, mbase = 0;
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                if ((c & 3u) == (uint32_t)u) { db = dbv[u]; sb = sbv[u]; mb = mbv[u]; base = basev[u]; mbase = mbasev[u]; }
             l_sb[lane] = sb;
             l_base[lane] = base;
             l_mb[lane] = mb;

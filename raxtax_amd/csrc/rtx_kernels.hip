@@ -137,7 +137,16 @@ __device__ __forceinline__ unsigned long long transpose64(unsigned long long x, 
     return x;
 }
 
+#ifdef RTX_KMER_STAMP  // experiment (tools/quad_variants.sh ks1..ks4): cycles of one phase per query instead of H_q (1 extraction, 2 read-out, 3 rows, 4 tiles)
+#define KMER_MARK(k) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); if (RTX_KMER_STAMP == (k)) st_acc += now_ - st_t; st_t = now_; }
+#else
+#define KMER_MARK(k)
+#endif
+
 __global__ __launch_bounds__(64) void kmer_extract_kernel(KmerParams p) {
+#ifdef RTX_KMER_STAMP
+    unsigned long long st_acc = 0, st_t = __builtin_amdgcn_s_memtime();
+#endif
     __shared__ __attribute__((aligned(16))) uint32_t bm[2048];
     const uint32_t q = blockIdx.x;
     const uint32_t lane = threadIdx.x;
@@ -179,6 +188,7 @@ __global__ __launch_bounds__(64) void kmer_extract_kernel(KmerParams p) {
         }
     }
     __syncthreads();
+    KMER_MARK(1)
 
     // ascending read-out: round r covers the 64-bit words r*64 .. r*64+63 of the set (conflict-free LDS reads); sixteen
     // scans instead of thirty-two with 32-bit words
@@ -201,6 +211,7 @@ __global__ __launch_bounds__(64) void kmer_extract_kernel(KmerParams p) {
     }
     const uint32_t t = base;
     __syncthreads();  // kout visible to the whole wave
+    KMER_MARK(2)
 
     // rows of the k-mers present in the index, in ascending k-mer order (the query's row list, shared by all tiles)
     uint32_t *rout = p.rows + (size_t)q * p.rstride;
@@ -238,6 +249,7 @@ __global__ __launch_bounds__(64) void kmer_extract_kernel(KmerParams p) {
     const uint32_t nchunks = (nrows + 63u) >> 6;
     for (uint32_t i = nrows + lane; i < nchunks * 64u; i += 64) rout[i] = p.zero_row;
     __syncthreads();  // rout visible to the whole wave
+    KMER_MARK(3)
     // Per tile: which rows have a dense segment there (a 64-bit mask per 64 rows), and the slots of the sparse
     // segments; empty segments are dropped (rtx_segments.hip).
     const uint32_t nt = p.ntiles;
@@ -252,6 +264,7 @@ __global__ __launch_bounds__(64) void kmer_extract_kernel(KmerParams p) {
         const uint32_t blk = tb >> 6;
         const uint32_t tile = tb + lane;  // this lane's tile after the transposes
         uint32_t cd = 0, cs = 0, cm = 0;
+        uint4 pend = make_uint4(0, 0, 0, 0);  // slot ids of this lane's tile waiting for their 16-byte store
         // the class tables of four chunks of 64 rows are gathered together (one round trip per four chunks, not one each)
         unsigned long long dbv[4], sbv[4], mbv[4];
         uint32_t basev[4], mbasev[4];
@@ -289,10 +302,20 @@ __global__ __launch_bounds__(64) void kmer_extract_kernel(KmerParams p) {
             if (tile < nt) {
                 // the first sparse rows go to the slot list (the byte counters of hit_count hold 255 hits: at most
                 // kSegMaxListRows sparse + mid segments together) ...
+                // (four slot ids per 16-byte store: every lane writes to a list of its own, so each store is a memory
+                // transaction of its own, and those are what bounds this kernel -- a quarter as many)
                 while (sT && cs < kSegMaxSparseRows && cs + cm < kSegMaxListRows) {
                     const int r = __builtin_ctzll(sT);
                     sT &= sT - 1;
-                    sout[(size_t)tile * (kSegMaxSparseRows + 1) + cs] = l_base[r] + (uint32_t)__popcll(l_sb[r] & lt_mask);
+                    const uint32_t sid = l_base[r] + (uint32_t)__popcll(l_sb[r] & lt_mask);
+                    const uint32_t k4 = cs & 3u;
+                    pend.x = k4 == 0u ? sid : pend.x;
+                    pend.y = k4 == 1u ? sid : pend.y;
+                    pend.z = k4 == 2u ? sid : pend.z;
+                    pend.w = k4 == 3u ? sid : pend.w;
+#ifndef RTX_EXP_KMER_NO_SOUT  // experiment: what the scattered slot-id stores cost (wrong results: RTX_EXP_COUNT_ONLY runs)
+                    if (k4 == 3u) *reinterpret_cast<uint4 *>(sout + (size_t)tile * (kSegMaxSparseRows + 1) + (cs - 3u)) = pend;
+#endif
                     cs++;
                 }
                 // ... the first mid rows to theirs ...
@@ -309,6 +332,8 @@ __global__ __launch_bounds__(64) void kmer_extract_kernel(KmerParams p) {
             __syncthreads();
         }
         if (tile < nt) {
+            // the last, incomplete group of four (the entries behind cs are never used: the lists have 256 entries)
+            if (cs & 3u) *reinterpret_cast<uint4 *>(sout + (size_t)tile * (kSegMaxSparseRows + 1) + (cs & ~3u)) = pend;
             p.nsparse[(size_t)q * nt + tile] = cs;
             p.nmid[(size_t)q * nt + tile] = cm;
             nseg += cd;
@@ -376,6 +401,10 @@ __global__ __launch_bounds__(64) void kmer_extract_kernel(KmerParams p) {
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) { hq += __shfl_xor(hq, d, 64); nseg += __shfl_xor(nseg, d, 64); nmidseg += __shfl_xor(nmidseg, d, 64); }
+    KMER_MARK(4)
+#ifdef RTX_KMER_STAMP
+    hq = st_acc;
+#endif
     if (lane == 0) {
         p.t[q] = t;
         p.nrows[q] = nrows;

@@ -34,3 +34,4 @@ gsz = 2 if os.environ.get("RTX_HIT_PAIR", "0") != "0" else 4
 print(f"  [stamp builds: {w / row_bytes * 64 / ((n_q + gsz - 1) // gsz * 62):.0f} cycles per (group, tile) of the stamped phase]")
 print(f"{sys.argv[1]} {n_q} queries: {dt * 1e3:.1f} ms, hit_count {st['hit_count'][0]:.1f} ms over {st['hit_count'][1]} launches; "
       f"requested MB/query {ix.work()['bitmap_bytes_read'] / n_q / 1e6:.2f}", flush=True)
+print(f"  [kmer stamp builds: {ix.work()['sum_hits'] / n_q:.0f} cycles per query of the stamped phase; kmer_extract {st.get('kmer_extract', (0, 0))[0]:.2f} ms]")

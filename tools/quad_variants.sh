@@ -41,6 +41,11 @@ for v in "$@"; do
     pnohist) buildp pnohist -DRTX_EXP_NO_HIST ;;
     pnostore) buildp pnostore -DRTX_EXP_NO_COUNT_STORE ;;
     pnoboth) buildp pnoboth -DRTX_EXP_NO_COUNT_STORE -DRTX_EXP_NO_HIST ;;
+    knosout) buildk knosout -DRTX_EXP_KMER_NO_SOUT ;;
+    ks1) buildk ks1 -DRTX_KMER_STAMP=1 ;;
+    ks2) buildk ks2 -DRTX_KMER_STAMP=2 ;;
+    ks3) buildk ks3 -DRTX_KMER_STAMP=3 ;;
+    ks4) buildk ks4 -DRTX_KMER_STAMP=4 ;;
     pskipb) buildp pskipb -DRTX_EXP_SKIP_EPI=1 ;;
     pskipab) buildp pskipab -DRTX_EXP_SKIP_EPI=2 ;;
     pskiploop) buildp pskiploop -DRTX_EXP_SKIP_LOOP ;;

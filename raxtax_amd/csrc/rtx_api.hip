@@ -1836,6 +1836,11 @@ int rtx_debug_evaluate(rtx_index *ix, const double *probs, rtx_result_view *out)
     RTX_HIP(hipMemcpy(ix->sc[ix->last_set].d_table_z.p, probs, N * 8, hipMemcpyHostToDevice));
     RTX_HIP(hipMemcpy(ix->d_status.p, &ok, 1, hipMemcpyHostToDevice));
     RTX_HIP(hipMemcpy(ix->d_gs.p, &gs, 8, hipMemcpyHostToDevice));
+    {   // taxon_prefix scans table[0 .. t] of the slot for the smallest count with a probability: the pseudo-query's
+        // "counts" are 0 .. N-1 (the slot's t was left to whatever the allocation held: an out-of-bounds scan)
+        const uint32_t t_pseudo = (uint32_t)N - 1u;
+        RTX_HIP(hipMemcpy(ix->sc[ix->last_set].d_t.p, &t_pseudo, 4, hipMemcpyHostToDevice));
+    }
     RTX_HIP(hipMemset(ix->d_t_all.p, 0, 4));
     RTX_HIP(hipMemset(ix->d_nrows_all.p, 0, 4));
     RTX_HIP(hipMemset(ix->d_hq.p, 0, 8));

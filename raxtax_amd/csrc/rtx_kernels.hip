@@ -795,8 +795,28 @@ __global__ __launch_bounds__(kProbThreads) void prob_table_kernel(ProbParams p) 
 // significant children of the 64 scanned last) lives in LDS, so returning to a parent costs no global load and
 // no second scan.
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ int rounded_conf(const double *__restrict__ P, uint32_t blo, uint32_t bhi) {
-    const double conf = P[bhi] - P[blo];
+// Boundaries inside runs of tiles that taxon_prefix did not sweep (no reference there reaches 1e-30) all hold the running
+// sum of that moment: the fused kernel does not write them (at N = 500k they were 100 KB of stores per query, what bounded
+// it) but hands the walk the few gaps [lo, hi) with their value; a boundary inside a gap reads the gap's value instead of
+// memory.  Lives in LDS of the workgroup; n = 0 (or a null pointer): every boundary is in memory.
+constexpr uint32_t kMaxPrefixGaps = 6;
+struct PrefixGaps {
+    uint32_t n;
+    uint32_t lo[kMaxPrefixGaps], hi[kMaxPrefixGaps];
+    double val[kMaxPrefixGaps];
+};
+__device__ __forceinline__ double prefix_at(const double *__restrict__ P, const PrefixGaps *G, uint32_t b) {
+    double v = P[b];  // inside a gap: whatever the buffer holds, replaced below
+    if (G) {
+        const uint32_t n = G->n;  // wave-uniform
+        for (uint32_t g = 0; g < n; g++)
+            if (b >= G->lo[g] && b < G->hi[g]) v = G->val[g];
+    }
+    return v;
+}
+
+__device__ __forceinline__ int rounded_conf(const double *__restrict__ P, const PrefixGaps *G, uint32_t blo, uint32_t bhi) {
+    const double conf = prefix_at(P, G, bhi) - prefix_at(P, G, blo);
     const double r = round(conf * 100.0);  // f64::round: half away from zero
     return r > 255.0 ? 255 : (r < -255.0 ? -255 : (int)r);
 }
@@ -816,7 +836,7 @@ struct WalkLds {  // LDS state of one walking wave
 };
 
 // The walk of query slot q by the calling wave (all 64 lanes).
-__device__ __forceinline__ void lineage_walk_wave(const WalkParams &p, uint32_t q, uint32_t lane, WalkLds &L) {
+__device__ __forceinline__ void lineage_walk_wave(const WalkParams &p, uint32_t q, uint32_t lane, WalkLds &L, const PrefixGaps *G = nullptr) {
     auto &st_mask = L.st_mask;
     auto &st_mbase = L.st_mbase;
     auto &st_node = L.st_node;
@@ -869,7 +889,7 @@ __device__ __forceinline__ void lineage_walk_wave(const WalkParams &p, uint32_t 
             mask &= mask - 1;
             found = (int)mbase + bit;
             const uint4 cr = rec[fc + (uint32_t)found];
-            kf = rounded_conf(P, cr.x, cr.y);
+            kf = rounded_conf(P, G, cr.x, cr.y);
             cfc = cr.z;
             cnt = cr.w;
         } else {
@@ -879,7 +899,7 @@ __device__ __forceinline__ void lineage_walk_wave(const WalkParams &p, uint32_t 
                 uint4 cr = make_uint4(0, 0, 0, 0);
                 if (idx < nch) {
                     cr = rec[fc + idx];
-                    kk = rounded_conf(P, cr.x, cr.y);
+                    kk = rounded_conf(P, G, cr.x, cr.y);
                 }
                 const unsigned long long bal = __ballot(kk != 0);
                 mbase = next;
@@ -934,7 +954,7 @@ __device__ __forceinline__ void lineage_walk_wave(const WalkParams &p, uint32_t 
                 bool have = false;
                 for (uint32_t idx = lane; idx < cnch; idx += 64) {
                     const uint4 cr = rec[cfirst + idx];
-                    const double v = P[cr.y] - P[cr.x];
+                    const double v = prefix_at(P, G, cr.y) - prefix_at(P, G, cr.x);
                     if (!have || !(v < best)) { best = v; besti = idx; bz = cr.z; bw = cr.w; have = true; }
                 }
 #pragma unroll
@@ -1031,6 +1051,8 @@ __global__ __launch_bounds__(NW * 64) void taxon_prefix_kernel(PrefixParams p) {
     // with p >= kLiveEps and is not read at all: the boundaries inside it get the running sum.  What is dropped is
     // below n_refs * kLiveEps in every prefix value (confidences are differences of those, rounded to 1e-2).
     __shared__ uint32_t s_mlo, s_mlive;
+    __shared__ PrefixGaps s_gaps;  // boundaries of unswept runs of tiles (fused walk only): not written, the walk is told
+    if (tid == 0) s_gaps.n = 0;
     {
         const uint32_t t1 = p.t[q] + 1;
         if (tid == 0) { s_mlo = 0xFFFFFFFFu; s_mlive = 0xFFFFFFFFu; }
@@ -1105,6 +1127,18 @@ __global__ __launch_bounds__(NW * 64) void taxon_prefix_kernel(PrefixParams p) {
         return (live_mask >> (T & 63u)) & 1ull;
     };
     uint32_t filled = 1;  // P[0 .. filled) are written
+    // boundaries [a, b) in front of / behind / between the swept runs: the running sum -- as a gap for the fused walk (while
+    // the gap table has room), else written out (the walk as a kernel of its own, the exchange of the sharded modes)
+    uint32_t n_gaps = 0;  // the same in every thread
+    auto fill = [&](uint32_t a, uint32_t b) {
+        if (a >= b) return;
+        if (p.fuse_walk && n_gaps < kMaxPrefixGaps) {
+            if (tid == 0) { s_gaps.lo[n_gaps] = a; s_gaps.hi[n_gaps] = b; s_gaps.val[n_gaps] = carry; s_gaps.n = n_gaps + 1u; }
+            n_gaps++;
+            return;
+        }
+        for (uint32_t i = a + tid; i < b; i += NW * 64) P[i] = carry;
+    };
     uint32_t buf = 0;
     uint32_t T = 0;
     while (T < ntiles) {
@@ -1116,7 +1150,7 @@ __global__ __launch_bounds__(NW * 64) void taxon_prefix_kernel(PrefixParams p) {
         const uint32_t Te = T;
         // boundaries inside the dead tiles in front of the run: the running sum
         const uint32_t rb = p.bnd_rank[Ts * 1024u];
-        for (uint32_t i = filled + tid; i < rb; i += NW * 64) P[i] = carry;
+        fill(filled, rb);
         filled = Te * 1024u <= last_chunk ? p.bnd_rank[Te * 1024u] : p.n_bnd;
         const uint32_t span_end = Te * 8192u < n ? Te * 8192u : n;
         request(Ts * 8192u + tid * 8u);
@@ -1194,14 +1228,14 @@ __global__ __launch_bounds__(NW * 64) void taxon_prefix_kernel(PrefixParams p) {
         accept(r0 + kSweep);
     }
     }
-    for (uint32_t i = filled + tid; i < p.n_bnd; i += NW * 64) P[i] = carry;
+    fill(filled, p.n_bnd);
     if (p.fuse_walk) {
         // The walk of this query by wave 0 while the prefix sums are still in this XCD's L2 (a walk on its own is a
         // chain of ~1.5 us misses: the prefix arrays of a sub-batch are 10x the L2); the other waves retire, and the
         // walking wave hides under the streaming workgroups that take their place.  The dynamic LDS (the table copy,
         // dead now) becomes the walk state.
         __syncthreads();  // workgroup-scope release/acquire of the P stores (same CU: no cache maintenance needed)
-        if (wave == 0) lineage_walk_wave(p.walk, q, lane, *reinterpret_cast<WalkLds *>(tz_lds));
+        if (wave == 0) lineage_walk_wave(p.walk, q, lane, *reinterpret_cast<WalkLds *>(tz_lds), &s_gaps);
     }
 }
 

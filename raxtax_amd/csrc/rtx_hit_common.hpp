@@ -322,6 +322,9 @@ __device__ __forceinline__ void hit_epilogue_x(const HitParams &p, uint32_t (&pl
     // group g = (w, g2) of this lane: references ref0 + g*L*8 + [0, 8) (ref_slot, rtx_math.hpp)
     const uint64_t ref0 = (uint64_t)tile * 8192u + lane * 8u;
     static_assert(!kPacked || NP <= 10, "the packed format holds counts up to 1023");  // 10 bits per reference leave the kernel instead of 16
+    const bool tile_full = (((uint64_t)tile + 1u) << 13) <= p.n_refs;  // wave-uniform
+    // references of this lane from ref0 on that exist (only looked at in the last tile: |value| < 2^31 there)
+    const int32_t refs_left = tile_full ? 0x7FFFFFFF : (int32_t)((int64_t)p.n_refs - (int64_t)ref0);
     uint16_t *out = p.counts + (size_t)q * p.npad + ref0;
     uint8_t *out_lo = p.counts_lo + (size_t)q * p.npad + ref0;
     uint32_t hiw[8];  // packed format: the two high bits of the 8 references of group g in bits 16 (g & 1) + [0, 16) of hiw[g / 2]
@@ -395,16 +398,19 @@ __device__ __forceinline__ void hit_epilogue_x(const HitParams &p, uint32_t (&pl
                     } else {
                         *reinterpret_cast<uint4 *>(out + goff) = st;
                     }
-                    const uint64_t rbase = ref0 + goff;
-                    const uint32_t nvalid = rbase >= p.n_refs ? 0u : (p.n_refs - rbase < 8u ? (uint32_t)(p.n_refs - rbase) : 8u);
                     const uint32_t cw[4] = {st.x, st.y, st.z, st.w};
-#pragma unroll
-                    for (int j = 0; j < 8; j++) {
-                        const uint32_t c = (cw[j >> 1] >> ((j & 1) * 16)) & 0xFFFFu;
 #ifndef RTX_EXP_NO_HIST  // experiment: what the histogram atomics cost (wrong results)
-                        if ((uint32_t)j < nvalid) atomicAdd(&hist_lds[c], 1u);
-#endif
+                    if (tile_full) {  // wave-uniform: every reference of the tile exists -- no compare, no exec mask per atomic
+#pragma unroll
+                        for (int j = 0; j < 8; j++) atomicAdd(&hist_lds[(cw[j >> 1] >> ((j & 1) * 16)) & 0xFFFFu], 1u);
+                    } else {  // the last tile of the database: the references behind n_refs are not counted
+                        const int32_t left = refs_left - (int32_t)goff;
+                        const uint32_t nvalid = left <= 0 ? 0u : (left < 8 ? (uint32_t)left : 8u);
+#pragma unroll
+                        for (int j = 0; j < 8; j++)
+                            if ((uint32_t)j < nvalid) atomicAdd(&hist_lds[(cw[j >> 1] >> ((j & 1) * 16)) & 0xFFFFu], 1u);
                     }
+#endif
                 }
             }
         }

@@ -364,10 +364,11 @@ __device__ __forceinline__ void hit_epilogue_x(const HitParams &p, uint32_t (&pl
                     const uint32_t goff = (uint32_t)(w * 4 + g2) * L * 8u;
                     if (lists) {  // + hits through sparse and mid segments (L = 64 here): bytes of the eight references of this group
                         const uint2 sb = *reinterpret_cast<const uint2 *>(cnt8 + (((uint32_t)((kFullTile ? w : wi) * 4 + g2) * 64u + lane) * 2u));
-                        st.x += (sb.x & 0xFFu) | ((sb.x & 0xFF00u) << 8);
-                        st.y += ((sb.x >> 16) & 0xFFu) | ((sb.x >> 24) << 16);
-                        st.z += (sb.y & 0xFFu) | ((sb.y & 0xFF00u) << 8);
-                        st.w += ((sb.y >> 16) & 0xFFu) | ((sb.y >> 24) << 16);
+                        // bytes (b0, b1) -> (b0, 0, b1, 0): one v_perm_b32 each (selector byte 0x0C = constant 0)
+                        st.x += __builtin_amdgcn_perm(0u, sb.x, 0x0C010C00u);
+                        st.y += __builtin_amdgcn_perm(0u, sb.x, 0x0C030C02u);
+                        st.z += __builtin_amdgcn_perm(0u, sb.y, 0x0C010C00u);
+                        st.w += __builtin_amdgcn_perm(0u, sb.y, 0x0C030C02u);
                     }
                     if (kPacked) {
                         uint2 lo8;  // the low bytes of the eight counts, in reference order

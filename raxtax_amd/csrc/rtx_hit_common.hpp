@@ -206,7 +206,8 @@ __device__ __forceinline__ void sparse_prefetch(const HitParams &p, uint32_t lan
     for (int it = 0; it < kSparseIt; it++)
 #pragma unroll
         for (int i = 0; i < kSparseV; i++) {
-            pre[it][i] = make_uint4(~0u, ~0u, ~0u, ~0u);
+            const uint32_t pw = seg_mid_pad(2u * lane) | (seg_mid_pad(2u * lane + 1u) << 16);  // unused entries: pad words behind the byte counters
+            pre[it][i] = make_uint4(pw, pw, pw, pw);
             if (sid[it] != 0xFFFFFFFFu) pre[it][i] = reinterpret_cast<const uint4 *>(p.segslots + (size_t)sid[it] * kSegSlotEntries)[i];
         }
 }
@@ -251,8 +252,9 @@ __device__ __forceinline__ void hit_epilogue_x(const HitParams &p, uint32_t (&pl
                 const uint32_t wv[4] = {e[i].x, e[i].y, e[i].z, e[i].w};
 #pragma unroll
                 for (int j = 0; j < 8; j++) {
-                    const uint32_t id = (wv[j >> 1] >> ((j & 1) * 16)) & 0xFFFFu;  // 0xFFFF = unused entry
-                    if (kFullTile) { if (id != 0xFFFFu) atomicAdd(&cnt8[id >> 2], 1u << ((id & 3u) * 8u)); }
+                    const uint32_t id = (wv[j >> 1] >> ((j & 1) * 16)) & 0xFFFFu;  // >= kSegMidPad (8192): unused entry
+                    // full tile: unused entries land in the pad words behind the counters -- no compare, no exec mask per atomic
+                    if (kFullTile) atomicAdd(&cnt8[id >> 2], 1u << ((id & 3u) * 8u));
                     else if ((id >> 12) == half) atomicAdd(&cnt8[(id & 4095u) >> 2], 1u << ((id & 3u) * 8u));
                 }
             }
@@ -267,7 +269,7 @@ __device__ __forceinline__ void hit_epilogue_x(const HitParams &p, uint32_t (&pl
             for (uint32_t c0 = 0; c0 < ns; c0 += 64) {
                 uint4 e[kV];
 #pragma unroll
-                for (int i = 0; i < kV; i++) e[i] = make_uint4(~0u, ~0u, ~0u, ~0u);
+                for (int i = 0; i < kV; i++) e[i] = make_uint4(pad_word, pad_word, pad_word, pad_word);
                 if (c0 + lane < ns) {
                     const uint4 *slot = reinterpret_cast<const uint4 *>(p.segslots + (size_t)srows[c0 + lane] * kSegSlotEntries);
 #pragma unroll

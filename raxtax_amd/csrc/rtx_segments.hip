@@ -6,8 +6,8 @@
 // and those are the segments no other query has just pulled into L2.  At index creation every segment is classified
 //     0 = empty (never loaded), 1 = dense (loaded as a 1-KiB row segment), s + 2 = sparse, slot s,
 //     0x80000000 | m = mid, slot m (RTX_DEFAULT_SEGMENT_CLASSES = 2)
-// and the references of a sparse segment (at most 16) are written to a 32-byte slot of 16 local ids (u16, 0xFFFF =
-// unused), those of a mid segment (17 .. 128) to a 256-byte slot of 128 (kSegMidPad = unused).  kmer_extract turns the
+// and the references of a sparse segment (at most 16) are written to a 32-byte slot of 16 local ids (u16), those of a
+// mid segment (17 .. 128) to a 256-byte slot of 128; unused entries hold ids >= kSegMidPad (pad words of hit_count).  kmer_extract turns the
 // classes into per-(query, tile) row lists; hit_count adds the sparse and the mid slots through byte counters in LDS.
 #include <hip/hip_runtime.h>
 
@@ -65,10 +65,12 @@ __global__ __launch_bounds__(64) void seg_emit_kernel(const uint32_t *__restrict
                 pos++;
             }
         }
-        if (mid) {  // the entries behind the last reference (hit_count adds them into a pad word without looking)
+        {   // the entries behind the last reference: hit_count adds them into pad words behind its byte counters without
+            // looking (different words for neighbouring slots and entries: one word would serialise the LDS atomics)
             const uint32_t total = (uint32_t)__shfl((int)pos, 63, 64);  // lane 63 ends behind the last one
+            const uint32_t salt = mid ? 0u : (code - 2u) * 5u;
             for (uint32_t i = lane; i < cap; i += 64)
-                if (i >= total) out[i] = (uint16_t)seg_mid_pad(i);
+                if (i >= total) out[i] = (uint16_t)seg_mid_pad(i + salt);
         }
     }
 }

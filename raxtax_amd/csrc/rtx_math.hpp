@@ -54,9 +54,10 @@ RTX_HD void ref_slot(uint32_t r, uint32_t stride_bytes, uint32_t &word, uint32_t
 RTX_HD void csa(uint32_t a, uint32_t b, uint32_t c, uint32_t &sum, uint32_t &carry) {
 #if defined(__HIP_DEVICE_COMPILE__)
     // gfx950 v_bitop3_b32: any 3-input boolean in one op.  0x96 = a^b^c, 0xE8 = majority(a,b,c)
-    const uint32_t s_ = __builtin_amdgcn_bitop3_b32(a, b, c, 0x96);
-    carry = __builtin_amdgcn_bitop3_b32(a, b, c, 0xE8);
-    sum = s_;
+    // (the carry first: the sum can then take the register of `a`, the plane it replaces)
+    const uint32_t c_ = __builtin_amdgcn_bitop3_b32(a, b, c, 0xE8);
+    sum = __builtin_amdgcn_bitop3_b32(a, b, c, 0x96);
+    carry = c_;
 #else
     uint32_t u = a ^ b;
     uint32_t s_ = u ^ c;

@@ -1050,3 +1050,48 @@ def test_locator_order_is_a_pure_scheduling_decision(oracle):
     otree = oracle.tree_new_flat(db.lineages, db.seq_bytes, db.seq_off)
     for q in range(0, qs.n, 300):       # the last run of `b` (one sub-batch) skipped exact matches
         assert np.array_equal(b.debug_hit_counts(q), otree.hit_counts(qs.seq(q), skip_exact=True)[1])
+
+
+def test_prefix_gaps_and_their_fallback(oracle):
+    """taxon_prefix does not write the boundaries of unswept runs of tiles any more: the fused walk is told the gaps
+    (rtx_kernels.hip: PrefixGaps, at most six).  A database of unrelated random references over 14 tiles; a query that
+    embeds references from ONE tile leaves two gaps, a chimera of references from eight tiles that are not neighbours
+    leaves nine (more than the table holds: the rest is written out as before), a chimera of neighbouring tiles one long
+    run.  Rows identical to the oracle's in every case, with and without --skip-exact-matches."""
+    n_refs, ref_len = 14 * 8192 - 300, 100
+    lineages, flat, off = _random_db(n_refs, ref_len, seed=31, n_taxa=512)
+    otree = oracle.tree_new_flat(lineages, flat, off)
+    tree = rx.Tree.new_flat(lineages, flat, off, kmer_map=False)
+    order = tree.original_index().astype(np.int64)        # order[i] = input index of the reference at position i
+    rng = np.random.default_rng(32)
+
+    def chimera(tiles, piece):
+        parts = []
+        for t in tiles:
+            pos = int(rng.integers(t * 8192, min((t + 1) * 8192, n_refs)))
+            src = int(order[pos])
+            parts.append(flat[src * ref_len: src * ref_len + piece])
+        return np.concatenate(parts)
+
+    qs = [chimera([5], 100), chimera([0, 2, 4, 6, 8, 10, 12, 13], 80), chimera([3, 4, 5, 6], 100),
+          chimera([1, 3, 5, 7, 9, 11], 100), chimera([13], 100), chimera([0, 13], 100)]
+    qoff = np.zeros(len(qs) + 1, np.uint64)
+    qoff[1:] = np.cumsum([len(q) for q in qs])
+    bases = np.concatenate(qs)
+    ix = rx.Index(tree)
+    ex = ix.exact_matches(bases, qoff)
+    exc = Excuses("prefix_gaps")
+    for skip in (False, True):
+        res = ix.classify(bases, qoff, *ex, skip_exact_matches=skip)
+        for q in range(len(qs)):
+            rows, _ = _oracle_rows(otree, qs[q], skip)
+            t, counts = otree.hit_counts(qs[q], skip_exact=skip)
+            assert res.t[q] == t
+            if rows is None:
+                assert res.status[q] != 0
+                continue
+            exc.checked += 1
+            exc.tie(assert_rows_equivalent(res.rows(q), rows, oracle.highest_hit_prob_per_reference(t, t // 2, counts), otree.lineages,
+                                           f"gaps skip {skip} q {q}"))
+    print(f"prefix gaps: {exc.checked} queries checked, {exc.n['ties']} accepted as exact ties")
+    assert exc.checked >= 10 and exc.n["ties"] <= 2

@@ -721,8 +721,10 @@ constexpr uint32_t kMaxSubBatch = 65536;
 // default: fewer, larger launches save the drain/fill between the kernels of a sub-batch (N = 50k, per 100k queries: 10 000:
 // 20.4 ms, 14 286: 21.3, 25 000: 20.3, 50 000: 22.0).  A large database gains from more queries per launch -- every tile's
 // bitmap region is fetched once per launch and XCD, whatever the number of queries (N = 500k, per 1M queries: 10 240: 1 094 ms,
-// 16 384: 1 072, 24 576: 1 070, 32 768: 1 098)
-constexpr uint32_t kDefaultSubBatch = 10240, kDefaultSubBatchLarge = 16384;
+// 16 384: 1 072, 24 576: 1 070, 32 768: 1 098).  With the kernels of the end of round 2: N = 50k, per 100k queries: 10 000: 19.55 ms,
+// 20 000: 19.08, 25 000: 21.1 (the last sub-batch's host work is no longer hidden), 50 000: 20.7; N = 500k, per 1 M queries:
+// 8 192: 971 ms, 16 384: 953, 32 768: 964, 65 536: 995
+constexpr uint32_t kDefaultSubBatch = 20480, kDefaultSubBatchLarge = 16384;
 
 int alloc_scratch_set(rtx_index *ix, uint32_t k);
 

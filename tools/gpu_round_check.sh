@@ -2,7 +2,7 @@
 # One gpurun call of a round: the GPU test-suite, the bench line as the driver takes it, profiles of the bench at
 # BASELINE configs[2] (kernel trace + PMC passes).  Usage: tools/gpu_round_check.sh <tag>
 set -u
-TAG=${1:-r2k}
+TAG=${1:-r2l}
 mkdir -p gpurun_out
 timeout 2400 python -m pytest tests -m gpu -x -q -s --durations=12 > gpurun_out/${TAG}_tests.log 2>&1
 echo "tests rc=$?"

@@ -2,7 +2,7 @@
 # Re-takes the profiles traffic.json is keyed to (the device-source hash changes with every edit of raxtax_amd/csrc/rtx_*).
 # Usage (gpurun): bash tools/refresh_profiles.sh <tag>
 set -u
-TAG=${1:-r2k}
+TAG=${1:-r2l}
 QPL=16384 bash tools/profile_bench.sh ${TAG}
 python tools/make_traffic.py --tag ${TAG} --refs 500000 --queries-per-launch 16384 --fetch gpurun_out/${TAG}_fetch --write gpurun_out/${TAG}_write --tcc gpurun_out/${TAG}_tcc --note "default options: locator order, two queries per wave, packed counts"
 cp profiles/traffic.json profiles/${TAG}_pmc_summary.csv gpurun_out/

@@ -390,6 +390,12 @@ int enqueue_hit(rtx_index *ix, const SubBatch &b, uint32_t flags, hipStream_t s)
     hp.pair_nu = sc.d_nu.p;
     hp.pair_ustride = 2u * ix->rstride;
     hp.pair_planes = sc.d_pair_planes.p;
+    {   // experiment builds (RTX_EXP_PRUNE_EMU in rtx_hit_pair.hip): prune from the third launch of the process on
+        static int launches = 0;
+        static const bool emu = getenv("RTX_EXP_PRUNE_EMU_ON") != nullptr;
+        hp.flags_prune = emu && launches >= 2 ? 1u : 0u;
+        launches++;
+    }
     if (b.timed) RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_HIT_COUNT, 0), s));
     if (ix->pair_used) {
         launch_pair_union(s, sc.d_rows.p, sc.d_nrows.p, ix->rstride, b.nq, sc.d_urec.p, sc.d_nu.p, 2u * ix->rstride);

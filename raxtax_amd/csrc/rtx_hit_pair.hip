@@ -135,6 +135,14 @@ __global__ __launch_bounds__(64, 2) void hit_count_pair_kernel(HitParams p) {
     const uint32_t pair = blockIdx.x < np8 * 8u ? (blockIdx.x & 7u) * np8 + (blockIdx.x >> 3) : blockIdx.x;
     const uint32_t qa = pair * 2u, qb = qa + 1u;
     const bool has_b = qb < p.nq;
+#ifdef RTX_EXP_PRUNE_EMU  // experiment (tile pruning): what hit_count takes when the (pair, tile) blocks whose
+                          // largest count -- as the run BEFORE left it in tile_max: one sub-batch per step, the same queries --
+                          // stays below the threshold leave at once; p.group_rows doubles as "a run has been made" flag holder
+    if (p.tile_max && p.flags_prune) {
+        const uint32_t ma = p.tile_max[(size_t)qa * p.ntiles + tile], mb = has_b ? p.tile_max[(size_t)qb * p.ntiles + tile] : 0u;
+        if ((ma > mb ? ma : mb) < (uint32_t)RTX_EXP_PRUNE_EMU) return;
+    }
+#endif
     uint32_t *l_both = lds_dw, *l_a = lds_dw + kPairListDw, *l_b = lds_dw + 2u * kPairListDw;
     unsigned long long *m_a = reinterpret_cast<unsigned long long *>(lds_dw + 3u * kPairListDw), *m_b = m_a + kPairMaskWords;
     uint32_t *l_zero = reinterpret_cast<uint32_t *>(m_b + kPairMaskWords);

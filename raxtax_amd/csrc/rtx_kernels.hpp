@@ -120,6 +120,8 @@ struct HitParams {
     const uint32_t *pair_nu;  // [pairs] entries of the union
     uint32_t pair_ustride;
     uint4 *pair_planes;       // [pairs][ntiles][10][64] sequential variant: the planes of the shared rows, parked between A's and B's rows
+    uint32_t flags_prune;     // experiment RTX_EXP_PRUNE_EMU: 1 from the second run of a handle on
+
 };
 
 // memoised cmf / pmf-ratio tables for every (t, m, i), t <= tmax (rtx_prob_tables.hip)

@@ -42,6 +42,10 @@ for v in "$@"; do
     pnostore) buildp pnostore -DRTX_EXP_NO_COUNT_STORE ;;
     pnoboth) buildp pnoboth -DRTX_EXP_NO_COUNT_STORE -DRTX_EXP_NO_HIST ;;
     knosout) buildk knosout -DRTX_EXP_KMER_NO_SOUT ;;
+    prune150) buildp prune150 -DRTX_EXP_PRUNE_EMU=150 ;;
+    prune170) buildp prune170 -DRTX_EXP_PRUNE_EMU=170 ;;
+    prune200) buildp prune200 -DRTX_EXP_PRUNE_EMU=200 ;;
+    prune130) buildp prune130 -DRTX_EXP_PRUNE_EMU=130 ;;
     ks1) buildk ks1 -DRTX_KMER_STAMP=1 ;;
     ks2) buildk ks2 -DRTX_KMER_STAMP=2 ;;
     ks3) buildk ks3 -DRTX_KMER_STAMP=3 ;;

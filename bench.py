@@ -67,6 +67,7 @@ def parse():
     ap.add_argument("--no-quad", action="store_true", help="hit_count with one wave per (query, tile) (RTX_OPT_HIT_QUAD = 0)")
     ap.add_argument("--no-pair", action="store_true", help="hit_count with one query per wave (RTX_OPT_HIT_PAIR = 0; A/B measurements)")
     ap.add_argument("--no-locator", action="store_true", help="processing order by min-hash alone (RTX_OPT_LOCATOR = 0; A/B measurements)")
+    ap.add_argument("--tile-prune", action="store_true", help="hit_count visits only the tiles that can hold a reference with any probability (RTX_OPT_TILE_PRUNE = 1)")
     ap.add_argument("--no-tile-skip", action="store_true", help="taxon_prefix sums every reference (RTX_OPT_TILE_SKIP = 0; A/B measurements)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--skip-exact-matches", action="store_true")
@@ -380,7 +381,7 @@ def main():
                          stage_timing=not args.hit_events_only, cluster=False if args.no_cluster else None,
                          packed_counts=False if args.u16_counts else None, hit_quad=False if args.no_quad else None,
                          tile_skip=False if args.no_tile_skip else None, hit_pair=False if args.no_pair else None,
-                         locator=False if args.no_locator else None)
+                         locator=False if args.no_locator else None, tile_prune=True if args.tile_prune else None)
         t0 = time.perf_counter()
         ex_ids, ex_off = index.exact_matches(qs.bases, qs.base_off)   # Tree.sequences.get, raxtax.rs:42 (host)
         t_exact = time.perf_counter() - t0

@@ -210,6 +210,11 @@ int rtx_index_set_batch(rtx_index *index, uint32_t sub_batch);
                             * _from_tree) the processing order of RTX_OPT_CLUSTER is led by the query's position in the
                             * lineage-ordered database (a vote of its 12-mers in a table built from the references), the
                             * min-hashes only break ties; 0: min-hash order alone.  Scheduling only: results are identical */
+#define RTX_OPT_TILE_PRUNE 13 /* 0 (default): hit_count counts every tile of 8192 references; 1: only the tiles that can hold a
+                               * reference with any probability -- decided from upper bounds (the queries counted against a union
+                               * bitmap over blocks of 32 references) and a threshold that keeps every probability within 1e-11
+                               * of the full count (rtx_prune.hip).  Needs t <= 1023, RTX_OPT_HIT_PAIR = 1, RTX_OPT_TILE_SKIP = 1 and a
+                               * database of 8 tiles or more; the debug taps recount the tapped sub-batch in full */
 int rtx_index_set_option(rtx_index *index, int option, uint64_t value);
 /* Process-wide default for handles created afterwards.  RTX_DEFAULT_SEGMENT_CLASSES (default 1): at index creation
  * every (row, tile) segment of the bitmaps is classified; empty segments are never read and segments with at most
@@ -319,6 +324,9 @@ int rtx_debug_prob_table(rtx_index *index, uint64_t query, double *table_over_z 
 int rtx_debug_probs(rtx_index *index, uint64_t query, double *probs /*n_refs*/);
 /* processing order of the last run (RTX_OPT_CLUSTER / RTX_OPT_LOCATOR): perm[position] = query */
 int rtx_debug_order(rtx_index *index, uint32_t *perm /*n_queries*/);
+/* tile pruning of the last run (RTX_OPT_TILE_PRUNE): out[0] live (pair, tile) blocks, [1] pairs, [2] sum of the lower bounds of the
+ * best hit, [3] sum of the thresholds, [4] sum of the largest tile bounds, [5] queries; all 0 if the run did not prune */
+int rtx_debug_prune_stats(rtx_index *index, uint64_t *out /*8*/);
 /* Lineage::new(label, tree, probs).evaluate() (src/lineage.rs:61-112) on a caller-supplied
  * probability vector: runs taxon_prefix + lineage_walk + the host finalisation for one
  * pseudo-query.  Lets the reference's lineage KATs pin the device walk.  Small trees only

@@ -112,6 +112,7 @@ _SIGNATURES = {
     "rtx_debug_prob_table": (C.c_int, [C.c_void_p, C.c_uint64, f64p, f64p]),
     "rtx_debug_probs": (C.c_int, [C.c_void_p, C.c_uint64, f64p]),
     "rtx_debug_order": (C.c_int, [C.c_void_p, u32p]),
+    "rtx_debug_prune_stats": (C.c_int, [C.c_void_p, u64p]),
     "rtx_debug_evaluate": (C.c_int, [C.c_void_p, f64p, C.POINTER(ResultView)]),
     "rtx_result_pack": (C.c_int64, [C.POINTER(ResultView), u8p, C.c_uint64]),
     "rtx_format_query": (C.c_int64, [C.c_void_p, C.POINTER(ResultView), C.c_uint64, C.c_char_p, u8p, C.c_uint64,

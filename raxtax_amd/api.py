@@ -218,7 +218,7 @@ class Index:
     def __init__(self, tree: Tree, device: int = 0, sub_batch: int = 0, prob_mode: int = 0, streams: int = 0,
                  stage_timing: bool = False, cluster: Optional[bool] = None, segment_classes=None,
                  packed_counts: Optional[bool] = None, hit_quad: Optional[bool] = None,
-                 tile_skip: Optional[bool] = None, hit_pair=None, locator: Optional[bool] = None):
+                 tile_skip: Optional[bool] = None, hit_pair=None, locator: Optional[bool] = None, tile_prune: Optional[bool] = None):
         self._lib = _lib.load()
         self.tree = tree
         if segment_classes is None:
@@ -248,6 +248,8 @@ class Index:
             check(self._lib.rtx_index_set_option(self._h, 11, int(hit_pair)))
         if locator is not None:
             check(self._lib.rtx_index_set_option(self._h, 12, int(locator)))
+        if tile_prune is not None:
+            check(self._lib.rtx_index_set_option(self._h, 13, int(tile_prune)))
         self._view = ResultView()
         self._keep = None
 
@@ -345,6 +347,14 @@ class Index:
         out = np.zeros(n_queries, dtype=np.uint32)
         check(self._lib.rtx_debug_order(self._h, ptr(out, u32p)))
         return out
+
+    def debug_prune_stats(self) -> dict:
+        """Tile pruning of the last run: live tiles per pair, mean lower bound of the best hit, mean threshold, mean largest tile bound."""
+        out = np.zeros(8, dtype=np.uint64)
+        check(self._lib.rtx_debug_prune_stats(self._h, ptr(out, u64p)))
+        pairs, nq = max(int(out[1]), 1), max(int(out[5]), 1)
+        return {"live_tiles_per_pair": int(out[0]) / pairs, "pairs": int(out[1]), "mean_best_hit_lower_bound": int(out[2]) / nq,
+                "mean_threshold": int(out[3]) / nq, "mean_largest_tile_bound": int(out[4]) / nq}
 
     def debug_evaluate(self, probs) -> Result:
         """Lineage::new(label, tree, probs).evaluate() on the device (lineage.rs:61-112)."""

@@ -164,6 +164,14 @@ struct rtx_index {
     uint32_t tile_skip = 1;   // RTX_OPT_TILE_SKIP: taxon_prefix reads only the tiles that hold a reference with p >= 1e-30
     bool quad_used = false;   // the last run went through hit_count_quad_kernel
     uint32_t pair_opt = 1;    // RTX_OPT_HIT_PAIR
+    uint32_t prune_opt = 0;   // RTX_OPT_TILE_PRUNE: hit_count visits only the tiles that can hold a reference with any probability (rtx_prune.hip)
+    bool prune_used = false;  // the last run pruned
+    bool dbg_full = false;    // ... and the debug taps have recounted the last sub-batch in full since
+    bool dbg_full_run = false;  // (the recount in progress: enqueue_hit leaves the pruning out)
+    DevBuf<uint32_t> d_ubitmap;  // union bitmap: one column per block of 2^kPruneShift references, tile-major like d_bitmap
+    uint32_t u_stride_bytes = 0, u_ntiles = 0;
+    uint64_t u_nblocks = 0;
+    DevBuf<unsigned long long> d_prune_stats;
     uint32_t locator_opt = 1; // RTX_OPT_LOCATOR: the sort key of the processing order is led by the query's position in the database
     DevBuf<uint32_t> d_loc_table;  // 12-mer -> lowest reference position (rtx_cluster.hip); only when built from sequences
     bool pair_used = false;   // ... through hit_count_pair_kernel
@@ -192,6 +200,10 @@ struct rtx_index {
         DevBuf<uint2> d_urec;   // hit_count_pair_kernel: union row lists of the pairs of the sub-batch
         DevBuf<uint32_t> d_nu;
         DevBuf<uint4> d_pair_planes;
+        // tile pruning: the queries counted against the union bitmap (every row dense: constant masks), the live tiles per pair
+        DevBuf<unsigned long long> d_uones;
+        DevBuf<uint32_t> d_uzero, d_uhist, d_live;
+        DevBuf<uint16_t> d_ucounts, d_utmax;
     } sc[2];
     uint32_t n_streams_req = 1, n_streams = 1;
     bool staged = false;  // driven with rtx_shard_*: sub-batch sb works in scratch set sb & 1, so that the exchange of one
@@ -397,6 +409,60 @@ int enqueue_hit(rtx_index *ix, const SubBatch &b, uint32_t flags, hipStream_t s)
         launches++;
     }
     if (b.timed) RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_HIT_COUNT, 0), s));
+    hp.live = nullptr;
+    hp.live_words = 0;
+    if (ix->prune_used && !ix->dbg_full_run) {
+        // (1) the queries against the union bitmap: every row dense, no lists, u16 counts (bounds per block of references)
+        HitParams up = hp;
+        up.bitmap = ix->d_ubitmap.p;
+        up.stride_bytes = ix->u_stride_bytes;
+        up.n_refs = ix->u_nblocks;
+        up.dmask = sc.d_uones.p;
+        up.nsparse = sc.d_uzero.p;
+        up.nmid = nullptr;
+        up.ntiles = ix->u_ntiles;
+        up.counts = sc.d_ucounts.p;
+        up.counts_lo = nullptr;
+        up.counts_hi = nullptr;
+        up.npad = (uint64_t)ix->u_ntiles * 8192u;
+        up.hist = sc.d_uhist.p;
+        up.tile_max = sc.d_utmax.p;
+        up.flags = 0;
+        up.group_rows = nullptr;
+        launch_hit_count(s, up, b.nq, ix->u_ntiles, 10);
+        // (2) bounds per tile, a lower bound of the best hit, the threshold, the live tiles of every pair
+        PruneParams pr{};
+        pr.ucounts = sc.d_ucounts.p;
+        pr.unpad = ix->u_ntiles * 8192u;
+        pr.shift = kPruneShift;
+        pr.ntiles = ix->ntiles;
+        pr.nq = b.nq;
+        pr.n_refs = ix->n_refs;
+        pr.bitmap = ix->d_bitmap.p;
+        pr.n_rows1 = ix->n_rows + 1;
+        pr.stride_bytes = ix->stride_bytes;
+        pr.rows = sc.d_rows.p;
+        pr.rstride = ix->rstride;
+        pr.nrows = sc.d_nrows.p;
+        pr.t = sc.d_t.p;
+        pr.flags = flags;
+        pr.q0 = b.q0;
+        pr.perm = ix->d_perm.p;
+        pr.exact_ids = ix->d_exact_ids.p;
+        pr.exact_off = ix->d_exact_off.p;
+        pr.lnfact = ix->d_lnfact.p;
+        pr.hist = sc.d_hist.p;
+        pr.hstride = ix->hstride;
+        pr.live = sc.d_live.p;
+        pr.live_words = (ix->ntiles + 31u) / 32u + 1u;
+        pr.stats = ix->d_prune_stats.p;
+        ProbTables tb{ix->d_tab_cmf.p, ix->d_tab_ratio.p, ix->d_tab_off.p, ix->d_tab_moff.p, ix->d_tab_ilo.p, ix->d_tab_sat.p, ix->tab_tmax};
+        launch_prune(s, pr, tb, b.nq);
+        // (3) tiles that are not counted keep a largest count of 0: taxon_prefix leaves them out
+        RTX_HIP(hipMemsetAsync(sc.d_tilemax.p, 0, (size_t)b.nq * ix->ntiles * 2, s));
+        hp.live = sc.d_live.p;
+        hp.live_words = pr.live_words;
+    }
     if (ix->pair_used) {
         launch_pair_union(s, sc.d_rows.p, sc.d_nrows.p, ix->rstride, b.nq, sc.d_urec.p, sc.d_nu.p, 2u * ix->rstride);
         launch_hit_count_pair(s, hp, b.nq, ix->ntiles, ix->pair_variant);
@@ -415,7 +481,7 @@ static WalkParams walk_params(rtx_index *ix, const SubBatch &b, const double *pr
 
 // group 2: prob table from the (whole-database) histogram + prefix sums over this handle's references; with
 // fuse_walk (whole database on this handle) the taxonomy walk of group 3 runs inside the prefix kernel
-int enqueue_prob_prefix(rtx_index *ix, const SubBatch &b, bool fuse_walk) {
+int enqueue_prob_prefix(rtx_index *ix, const SubBatch &b, bool fuse_walk, bool prob_only = false) {
     rtx_index::Scratch &sc = ix->sc[b.set];
     hipStream_t s = b.s;
     ProbParams pp{};
@@ -443,6 +509,7 @@ int enqueue_prob_prefix(rtx_index *ix, const SubBatch &b, bool fuse_walk) {
         launch_prob_table(s, pp, b.nq);
     }
     if (b.timed_all) RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_PROB_TABLE, 1), s));
+    if (prob_only) return RTX_OK;  // debug taps after a pruned run: counts and table again, the result rows stay
 
     PrefixParams fp{};
     fp.status = ix->d_status.p;
@@ -539,6 +606,16 @@ int begin_run(rtx_index *ix, uint32_t *n_sub_out, bool *timed_out, bool cluster)
     static const bool pair_any_order = getenv("RTX_EXP_PAIR_ANY_ORDER") != nullptr;  // experiments (tools/exp_order_potential2.py): the pair kernel on a host-made order
     ix->pair_used = !ix->quad_used && ix->pair_opt && (cluster || pair_any_order) && ix->planes <= 10 && ix->n_q > 1 && ix->rstride <= 4096 && !(ix->n_mid_slots && ix->pair_opt == 2);  // (the sequential variant keeps its lists alive into the epilogue: no room for the byte counters of a whole tile + mid ids)
     ix->groups_per_sub = ix->pair_used ? (ix->sub_batch + 1u) / 2u : (ix->sub_batch + 3u) / 4u;
+    // tile pruning: the pair kernel, the memoised tables (their ln cmf rows give the threshold), taxon_prefix skipping tiles by
+    // their largest count, the whole database on this handle
+    ix->prune_used = ix->prune_opt && ix->pair_used && ix->pair_opt != 2 && ix->use_tables && ix->tile_skip && ix->d_ubitmap.p &&
+                     ix->n_refs == ix->n_total && !ix->staged && ix->sc[0].d_ucounts.p != nullptr;
+    ix->dbg_full = false;
+    if (ix->prune_used) {
+        int rc_s = ix->d_prune_stats.alloc(8);
+        if (rc_s) return rc_s;
+        RTX_HIP(hipMemsetAsync(ix->d_prune_stats.p, 0, 64, ix->stream));
+    }
     // the sequential variant keeps every list of a (pair, tile) in one round: t <= kHitListCap - 64
     ix->pair_variant = ix->pair_used && ix->pair_opt == 2 && ix->tmax + 64u <= kHitListCap ? 2 : 1;
     if (ix->pair_variant == 2) {
@@ -803,6 +880,17 @@ int alloc_scratch_set(rtx_index *ix, uint32_t k) {
             (rc = sc.d_tilemax.alloc((size_t)B * ix->ntiles)) ||
             (rc = sc.d_urec.alloc((size_t)((B + 1u) / 2u) * 2u * ix->rstride)) || (rc = sc.d_nu.alloc((B + 1u) / 2u)))
             return rc;
+        if (ix->prune_opt && ix->d_ubitmap.p) {
+            const size_t mw = (size_t)B * ix->u_ntiles * (ix->rstride / 64);
+            const bool fresh = sc.d_uones.n < mw;
+            if ((rc = sc.d_uones.alloc(mw)) || (rc = sc.d_uzero.alloc((size_t)B * ix->u_ntiles)) ||
+                (rc = sc.d_ucounts.alloc((size_t)B * ix->u_ntiles * 8192u)) || (rc = sc.d_uhist.alloc((size_t)B * ix->hstride)) ||
+                (rc = sc.d_utmax.alloc((size_t)B * ix->u_ntiles)) || (rc = sc.d_live.alloc((size_t)((B + 1u) / 2u) * ((ix->ntiles + 31u) / 32u + 1u))))
+                return rc;
+            if (fresh) RTX_HIP(hipMemsetAsync(sc.d_uones.p, 0xFF, sc.d_uones.n * 8, ix->stream));
+            RTX_HIP(hipMemsetAsync(sc.d_uzero.p, 0, sc.d_uzero.n * 4, ix->stream));
+            RTX_HIP(hipMemsetAsync(sc.d_uhist.p, 0, sc.d_uhist.n * 4, ix->stream));
+        }
     }
     return RTX_OK;
 }
@@ -1012,6 +1100,8 @@ static int create_common(int device, uint64_t n_total, uint64_t ref_lo, uint64_t
     return RTX_OK;
 }
 
+static bool prepare_union_bitmap(rtx_index *ix);
+
 static int create_from_csr(int device, uint64_t n_total, uint64_t ref_lo, uint64_t ref_hi, const uint64_t *cuts,
                            uint32_t n_cuts, const uint64_t *offsets, const uint32_t *postings, uint32_t n_nodes,
                            const uint32_t *node_begin, const uint32_t *node_end, const uint32_t *node_first_child,
@@ -1159,10 +1249,29 @@ static int create_from_csr(int device, uint64_t n_total, uint64_t ref_lo, uint64
             e = hipStreamSynchronize(ix->stream);
         }
         if (e != hipSuccess) { set_error("bitmap build failed: %s", hipGetErrorString(e)); return fail(RTX_ERR_HIP); }
+        if (prepare_union_bitmap(ix)) {
+            launch_bitmap_build(ix->stream, d_off.p, d_post.p, ix->d_row_of.p, ix->d_ubitmap.p, ix->u_stride_bytes / 4, nr + 1, (uint32_t)ref_lo,
+                                (uint32_t)ref_hi, kPruneShift);
+            if (hipStreamSynchronize(ix->stream) != hipSuccess) { (void)hipGetLastError(); ix->d_ubitmap.release(); }
+        }
     }
     if ((rc = build_segments(ix))) return fail(rc);
     *out = ix;
     return RTX_OK;
+}
+
+// Union bitmap of the tile pruning (rtx_prune.hip): the bitmap of the database with one column per block of 2^kPruneShift
+// references.  Same rows as d_bitmap.  Only for whole databases of some size (8 tiles or more); a failure to allocate
+// leaves the handle without it (no pruning).  Sizes first, then one of the two builders below fills it.
+static bool prepare_union_bitmap(rtx_index *ix) {
+    if (ix->n_refs != ix->n_total || ix->ntiles < 8) return false;
+    ix->u_nblocks = (ix->n_refs + (1ull << kPruneShift) - 1) >> kPruneShift;
+    ix->u_ntiles = (uint32_t)((ix->u_nblocks + 8191) / 8192);
+    ix->u_stride_bytes = ix->u_ntiles * 1024u;
+    const size_t words = (size_t)(ix->n_rows + 1) * (ix->u_stride_bytes / 4);
+    if (ix->d_ubitmap.alloc(words)) { ix->d_ubitmap.release(); return false; }
+    if (hipMemset(ix->d_ubitmap.p, 0, words * 4) != hipSuccess) { (void)hipGetLastError(); ix->d_ubitmap.release(); return false; }
+    return true;
 }
 
 // Locator table of the processing order (rtx_cluster.hip) from the reference sequences already on the device.
@@ -1228,6 +1337,10 @@ int rtx_index_create_from_sequences(int device, uint64_t n_refs, const uint8_t *
     if (e != hipSuccess) { set_error("bitmap build from sequences failed: %s", hipGetErrorString(e)); return fail(RTX_ERR_HIP); }
     if ((rc = build_segments(ix))) return fail(rc);
     build_locator(ix, d_seq.p, d_off.p, n_refs);
+    if (prepare_union_bitmap(ix)) {
+        launch_ref_bitmap_set(ix->stream, d_seq.p, d_off.p, n_refs, ix->d_row_of.p, ix->d_ubitmap.p, ix->u_stride_bytes / 4, nr + 1, kPruneShift);
+        if (hipStreamSynchronize(ix->stream) != hipSuccess) { (void)hipGetLastError(); ix->d_ubitmap.release(); }
+    }
     *out = ix;
     return RTX_OK;
 }
@@ -1270,7 +1383,7 @@ void rtx_index_destroy(rtx_index *index) {
 uint64_t rtx_index_num_refs(const rtx_index *index) { return index ? index->n_total : 0; }
 uint64_t rtx_index_device_bytes(const rtx_index *index) {
     if (!index) return 0;
-    return index->d_seg_dbits.n * 8 + index->d_seg_sbits.n * 8 + index->d_seg_sbase.n * 4 + index->d_seginfo.n * 4 + index->d_segslots.n * 2 + index->d_midslots.n * 2 + index->d_seg_mbits.n * 8 + index->d_seg_mbase.n * 4 + index->d_bitmap.n * 4 + index->d_row_of.n * 4 + index->d_list_len.n * 4 + index->d_loc_table.n * 4 + index->d_lnfact.n * 8 +
+    return index->d_seg_dbits.n * 8 + index->d_seg_sbits.n * 8 + index->d_seg_sbase.n * 4 + index->d_seginfo.n * 4 + index->d_segslots.n * 2 + index->d_midslots.n * 2 + index->d_seg_mbits.n * 8 + index->d_seg_mbase.n * 4 + index->d_bitmap.n * 4 + index->d_row_of.n * 4 + index->d_list_len.n * 4 + index->d_loc_table.n * 4 + index->d_ubitmap.n * 4 + index->d_lnfact.n * 8 +
            index->d_noderec.n * 16 + index->d_bnd_bits.n + index->d_bnd_rank.n * 4;
 }
 int rtx_index_set_batch(rtx_index *index, uint32_t sub_batch) {
@@ -1314,6 +1427,9 @@ int rtx_index_set_option(rtx_index *index, int option, uint64_t value) {
             return RTX_OK;
         case RTX_OPT_LOCATOR:
             index->locator_opt = value ? 1u : 0u;
+            return RTX_OK;
+        case RTX_OPT_TILE_PRUNE:
+            index->prune_opt = value ? 1u : 0u;
             return RTX_OK;
         case RTX_OPT_PROB_MODE:
             if (value > 2) break;
@@ -1735,6 +1851,7 @@ int rtx_batch_prob_work(rtx_index *ix, uint64_t *sum_grid_points, uint64_t *sum_
 }
 
 // ---- debug taps -------------------------------------------------------------------------
+static int debug_recount_full(rtx_index *ix);
 static int debug_slot(rtx_index *ix, uint64_t query, uint32_t *slot) {
     int rc = bind(ix);
     if (rc) return rc;
@@ -1744,6 +1861,25 @@ static int debug_slot(rtx_index *ix, uint64_t query, uint32_t *slot) {
     const uint64_t pos = ix->h_inv[query];  // position in the processing order (valid once the stream is synchronised)
     if (pos < last0) { set_error("debug tap: query %llu not in the last sub-batch", (unsigned long long)query); return RTX_ERR_INVALID; }
     *slot = (uint32_t)(pos - last0);
+    return debug_recount_full(ix);
+}
+
+// After a pruned run the scratch of the last sub-batch holds the counts of the live tiles only and a histogram with the
+// uncounted references lumped into bin 0: the taps promise the full vectors, so the sub-batch is counted again in full
+// (k-mers, hit counts, histogram, probability table; the result rows of the run are not touched).
+static int debug_recount_full(rtx_index *ix) {
+    if (!ix->prune_used || ix->dbg_full) return RTX_OK;
+    const uint32_t n_sub = (uint32_t)((ix->n_q + ix->sub_batch - 1) / ix->sub_batch);
+    SubBatch b = sub_batch_of(ix, n_sub - 1, false);
+    b.set = ix->last_set;
+    ix->dbg_full_run = true;
+    int rc = enqueue_kmer(ix, b, ix->stream);
+    if (!rc) rc = enqueue_hit(ix, b, ix->last_flags, ix->stream);
+    if (!rc) rc = enqueue_prob_prefix(ix, b, false, true);
+    ix->dbg_full_run = false;
+    if (rc) return rc;
+    RTX_HIP(hipStreamSynchronize(ix->stream));
+    ix->dbg_full = true;
     return RTX_OK;
 }
 
@@ -1793,6 +1929,15 @@ int rtx_debug_prob_table(rtx_index *ix, uint64_t query, double *table_over_z, do
     for (uint32_t m = 0; m <= tt; m++)
         if (!hist[m]) table_over_z[m] = 0.0;  // entries of absent counts are never written
     if (z) RTX_HIP(hipMemcpy(z, ix->d_z.p + ix->h_inv[query], 8, hipMemcpyDeviceToHost));
+    return RTX_OK;
+}
+
+int rtx_debug_prune_stats(rtx_index *ix, uint64_t *out) {
+    if (!ix || !out) { set_error("null argument"); return RTX_ERR_INVALID; }
+    std::memset(out, 0, 64);
+    if (!ix->prune_used || !ix->d_prune_stats.p) return RTX_OK;
+    RTX_HIP(hipStreamSynchronize(ix->stream));
+    RTX_HIP(hipMemcpy(out, ix->d_prune_stats.p, 64, hipMemcpyDeviceToHost));
     return RTX_OK;
 }
 

@@ -135,6 +135,7 @@ __global__ __launch_bounds__(64, 2) void hit_count_pair_kernel(HitParams p) {
     const uint32_t pair = blockIdx.x < np8 * 8u ? (blockIdx.x & 7u) * np8 + (blockIdx.x >> 3) : blockIdx.x;
     const uint32_t qa = pair * 2u, qb = qa + 1u;
     const bool has_b = qb < p.nq;
+    if (p.live && !((p.live[(size_t)pair * p.live_words + (tile >> 5)] >> (tile & 31u)) & 1u)) return;  // tile pruning (rtx_prune.hip): nothing in this tile can matter to either query
 #ifdef RTX_EXP_PRUNE_EMU  // experiment (tile pruning): what hit_count takes when the (pair, tile) blocks whose
                           // largest count -- as the run BEFORE left it in tile_max: one sub-batch per step, the same queries --
                           // stays below the threshold leave at once; p.group_rows doubles as "a run has been made" flag holder

@@ -27,7 +27,7 @@ __global__ __launch_bounds__(256) void bitmap_build_kernel(const uint64_t *__res
                                                            const uint32_t *__restrict__ post,
                                                            const uint32_t *__restrict__ row_of,
                                                            uint32_t *__restrict__ bitmap, uint32_t stride_words, uint32_t n_rows1,
-                                                           uint32_t ref_lo, uint32_t ref_hi) {  // bit: ref_slot()
+                                                           uint32_t ref_lo, uint32_t ref_hi, uint32_t shift) {  // bit: ref_slot(); shift > 0: the union bitmap of blocks of 2^shift references (rtx_prune.hip)
     const uint32_t k = blockIdx.x;
     const uint32_t row = row_of[k];
     if (row == kEmptyRow) return;
@@ -36,7 +36,7 @@ __global__ __launch_bounds__(256) void bitmap_build_kernel(const uint64_t *__res
         const uint32_t g = post[i];
         if (g < ref_lo || g >= ref_hi) continue;  // reference held by another shard
         uint32_t word, bit;
-        ref_slot(g - ref_lo, stride_words * 4u, word, bit);
+        ref_slot((g - ref_lo) >> shift, stride_words * 4u, word, bit);
         atomicOr(&bitmap[bitmap_word(row, word, n_rows1)], 1u << bit);
     }
 }
@@ -84,13 +84,14 @@ __global__ __launch_bounds__(64) void ref_kmer_mark_kernel(const uint8_t *__rest
 __global__ __launch_bounds__(64) void ref_bitmap_set_kernel(const uint8_t *__restrict__ bases,
                                                             const uint64_t *__restrict__ off, uint64_t n_refs,
                                                             const uint32_t *__restrict__ row_of,
-                                                            uint32_t *__restrict__ bitmap, uint32_t stride_words, uint32_t n_rows1) {
+                                                            uint32_t *__restrict__ bitmap, uint32_t stride_words, uint32_t n_rows1,
+                                                            uint32_t shift) {  // shift > 0: the union bitmap of blocks of 2^shift references
     const uint64_t r = blockIdx.x;
     if (r >= n_refs) return;
     const uint32_t lane = threadIdx.x;
     const uint64_t b0 = off[r], len = off[r + 1] - b0;
     uint32_t word, bitpos;
-    ref_slot((uint32_t)r, stride_words * 4u, word, bitpos);
+    ref_slot((uint32_t)(r >> shift), stride_words * 4u, word, bitpos);
     const uint32_t bit = 1u << bitpos;
     for (uint64_t w = lane; w + 8 <= len; w += 64) {
         uint32_t k;
@@ -1288,17 +1289,17 @@ __global__ void probs_expand_kernel(const uint16_t *counts, const double *tz, ui
 // launchers
 // ---------------------------------------------------------------------------
 void launch_bitmap_build(hipStream_t s, const uint64_t *off, const uint32_t *post, const uint32_t *row_of,
-                         uint32_t *bitmap, uint32_t stride_words, uint32_t n_rows1, uint32_t ref_lo, uint32_t ref_hi) {
+                         uint32_t *bitmap, uint32_t stride_words, uint32_t n_rows1, uint32_t ref_lo, uint32_t ref_hi, uint32_t shift) {
     hipLaunchKernelGGL(bitmap_build_kernel, dim3(RTX_NUM_KMERS), dim3(256), 0, s, off, post, row_of, bitmap,
-                       stride_words, n_rows1, ref_lo, ref_hi);
+                       stride_words, n_rows1, ref_lo, ref_hi, shift);
 }
 void launch_ref_kmer_mark(hipStream_t s, const uint8_t *bases, const uint64_t *off, uint64_t n_refs, uint32_t *present) {
     hipLaunchKernelGGL(ref_kmer_mark_kernel, dim3(4096), dim3(64), 0, s, bases, off, n_refs, present);
 }
 void launch_ref_bitmap_set(hipStream_t s, const uint8_t *bases, const uint64_t *off, uint64_t n_refs,
-                           const uint32_t *row_of, uint32_t *bitmap, uint32_t stride_words, uint32_t n_rows1) {
+                           const uint32_t *row_of, uint32_t *bitmap, uint32_t stride_words, uint32_t n_rows1, uint32_t shift) {
     hipLaunchKernelGGL(ref_bitmap_set_kernel, dim3((unsigned)n_refs), dim3(64), 0, s, bases, off, n_refs, row_of, bitmap,
-                       stride_words, n_rows1);
+                       stride_words, n_rows1, shift);
 }
 void launch_row_popcount(hipStream_t s, const uint32_t *row_of, const uint32_t *bitmap, uint32_t stride_words, uint32_t n_rows1,
                          uint32_t *list_len) {

@@ -121,8 +121,35 @@ struct HitParams {
     uint32_t pair_ustride;
     uint4 *pair_planes;       // [pairs][ntiles][10][64] sequential variant: the planes of the shared rows, parked between A's and B's rows
     uint32_t flags_prune;     // experiment RTX_EXP_PRUNE_EMU: 1 from the second run of a handle on
+    const uint32_t *live;     // [pairs][live_words] tiles to count for a pair (rtx_prune.hip) or null: all
+    uint32_t live_words;
 
 };
+
+// tile pruning (rtx_prune.hip)
+constexpr uint32_t kPruneShift = 5;  // the union bitmap has one column per block of 32 references
+struct PruneParams {
+    const uint16_t *ucounts;  // [B][unpad] counts of the queries against the union bitmap (an upper bound per block)
+    uint32_t unpad, shift, ntiles, nq;
+    uint64_t n_refs;
+    const uint32_t *bitmap;   // the database's bitmap: the exact count of one reference
+    uint32_t n_rows1, stride_bytes;
+    const uint32_t *rows;     // [B][rstride]
+    uint32_t rstride;
+    const uint32_t *nrows, *t;
+    uint32_t flags;
+    uint64_t q0;
+    const uint32_t *perm, *exact_ids;
+    const uint64_t *exact_off;
+    const double *lnfact;
+    uint32_t *hist;           // [B][hstride]: bin 0 receives the references of the tiles that are not counted
+    uint32_t hstride;
+    uint32_t *live;           // [pairs][live_words] bit T: tile T is counted for the pair
+    uint32_t live_words;
+    unsigned long long *stats;  // [0] += live tiles, [1] += pairs (reporting) or null
+};
+struct ProbTables;
+void launch_prune(hipStream_t s, const PruneParams &p, const ProbTables &tb, uint32_t nq);
 
 // memoised cmf / pmf-ratio tables for every (t, m, i), t <= tmax (rtx_prob_tables.hip)
 struct ProbTables {
@@ -192,10 +219,10 @@ struct PrefixParams {
 
 
 void launch_bitmap_build(hipStream_t s, const uint64_t *off, const uint32_t *post, const uint32_t *row_of,
-                         uint32_t *bitmap, uint32_t stride_words, uint32_t n_rows1, uint32_t ref_lo, uint32_t ref_hi);
+                         uint32_t *bitmap, uint32_t stride_words, uint32_t n_rows1, uint32_t ref_lo, uint32_t ref_hi, uint32_t shift = 0);
 void launch_ref_kmer_mark(hipStream_t s, const uint8_t *bases, const uint64_t *off, uint64_t n_refs, uint32_t *present);
 void launch_ref_bitmap_set(hipStream_t s, const uint8_t *bases, const uint64_t *off, uint64_t n_refs,
-                           const uint32_t *row_of, uint32_t *bitmap, uint32_t stride_words, uint32_t n_rows1);
+                           const uint32_t *row_of, uint32_t *bitmap, uint32_t stride_words, uint32_t n_rows1, uint32_t shift = 0);
 void launch_row_popcount(hipStream_t s, const uint32_t *row_of, const uint32_t *bitmap, uint32_t stride_words, uint32_t n_rows1,
                          uint32_t *list_len);
 void launch_kmer_extract(hipStream_t s, const KmerParams &p, uint32_t nq);

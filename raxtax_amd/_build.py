@@ -44,7 +44,7 @@ def build_lib(force: bool = False, verbose: bool = False) -> Path:
     if not force and not _stale(LIB, srcs + hdrs):
         return LIB
     OBJ.mkdir(exist_ok=True)
-    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", f"-I{ROOT / 'include'}", f"-I{CSRC}"]
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", f"-I{ROOT / 'include'}", f"-I{CSRC}"] + os.environ.get("RTX_EXTRA_CXXFLAGS", "").split()
 
     def compile_one(src: Path) -> Path:
         obj = OBJ / (src.name + ".o")

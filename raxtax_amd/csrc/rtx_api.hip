@@ -456,6 +456,8 @@ int enqueue_hit(rtx_index *ix, const SubBatch &b, uint32_t flags, hipStream_t s)
         pr.live = sc.d_live.p;
         pr.live_words = (ix->ntiles + 31u) / 32u + 1u;
         pr.stats = ix->d_prune_stats.p;
+        pr.ubitmap = ix->d_ubitmap.p;
+        pr.ustride_bytes = ix->u_stride_bytes;
         ProbTables tb{ix->d_tab_cmf.p, ix->d_tab_ratio.p, ix->d_tab_off.p, ix->d_tab_moff.p, ix->d_tab_ilo.p, ix->d_tab_sat.p, ix->tab_tmax};
         launch_prune(s, pr, tb, b.nq);
         // (3) tiles that are not counted keep a largest count of 0: taxon_prefix leaves them out
@@ -1270,7 +1272,9 @@ static bool prepare_union_bitmap(rtx_index *ix) {
     ix->u_stride_bytes = ix->u_ntiles * 1024u;
     const size_t words = (size_t)(ix->n_rows + 1) * (ix->u_stride_bytes / 4);
     if (ix->d_ubitmap.alloc(words)) { ix->d_ubitmap.release(); return false; }
-    if (hipMemset(ix->d_ubitmap.p, 0, words * 4) != hipSuccess) { (void)hipGetLastError(); ix->d_ubitmap.release(); return false; }
+    // on the handle's stream: the builder kernel that follows must not start before the zeroes are in (a hipMemset on the null
+    // stream is not ordered with a non-blocking stream)
+    if (hipMemsetAsync(ix->d_ubitmap.p, 0, words * 4, ix->stream) != hipSuccess) { (void)hipGetLastError(); ix->d_ubitmap.release(); return false; }
     return true;
 }
 

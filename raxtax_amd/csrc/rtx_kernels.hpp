@@ -147,6 +147,8 @@ struct PruneParams {
     uint32_t *live;           // [pairs][live_words] bit T: tile T is counted for the pair
     uint32_t live_words;
     unsigned long long *stats;  // [0] += live tiles, [1] += pairs (reporting) or null
+    const uint32_t *ubitmap;    // debug (RTX_PRUNE_CHECK): the union bitmap
+    uint32_t ustride_bytes;
 };
 struct ProbTables;
 void launch_prune(hipStream_t s, const PruneParams &p, const ProbTables &tb, uint32_t nq);

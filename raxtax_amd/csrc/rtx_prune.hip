@@ -50,56 +50,96 @@ __global__ __launch_bounds__(64) void prune_kernel(PruneParams p, ProbTables tb)
     for (uint32_t x = 0; x < 2u; x++) {
         if (x == 1u && !has_b) break;  // wave-uniform
         const uint32_t q = pair * 2u + x;
-        // ---- 1. bound of every tile, and the block with the largest bound
+        // ---- 1. bound of every tile, and the block with the largest bound.  The counts of the blocks are read as they
+        // lie (a wave takes 512 consecutive blocks per turn, 8 per lane): with 32 blocks per reference... per tile of 8192
+        // references 8192 >> shift blocks = bpt / 8 lanes; the lanes of a tile meet through DPP-free shuffles
         const uint16_t *uc = p.ucounts + (size_t)q * p.unpad;
-        unsigned long long best = 0;
-        for (uint32_t T = lane; T < p.ntiles; T += 64) {
-            const uint4 *src = reinterpret_cast<const uint4 *>(uc + (size_t)T * bpt);
+        const uint32_t lpt = bpt / 8u;  // lanes per tile in a turn (32 for blocks of 32 references): a power of two <= 64
+        uint32_t lmx = 0, lblk = 0;  // this lane's largest bound and its block
+        const uint32_t n_blocks_pad = p.ntiles * bpt;
+        for (uint32_t b0 = 0; b0 < n_blocks_pad; b0 += 512u) {
+            const uint32_t blk = b0 + lane * 8u;
             uint32_t mx = 0, arg = 0;
-            for (uint32_t i = 0; i < bpt / 8u; i++) {
-                const uint4 v = src[i];
+            if (blk < n_blocks_pad) {
+                const uint4 v = *reinterpret_cast<const uint4 *>(uc + blk);
                 const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
                 for (int j = 0; j < 8; j++) {
                     const uint32_t c = (w[j >> 1] >> ((j & 1) * 16)) & 0xFFFFu;
-                    if (c > mx) { mx = c; arg = i * 8u + (uint32_t)j; }
+                    if (c > mx) { mx = c; arg = (uint32_t)j; }
                 }
             }
-            ub_lds[x * p.ntiles + T] = (uint16_t)mx;
-            const unsigned long long key = ((unsigned long long)mx << 32) | (0xFFFFFFFFu - (T * bpt + arg));
-            best = key > best ? key : best;
+            if (mx > lmx) { lmx = mx; lblk = blk + arg; }
+            // the largest count of the tile: over the lpt lanes that hold its blocks
+            uint32_t tm = mx;
+            for (uint32_t d = 1; d < lpt; d <<= 1) {
+                const uint32_t o = (uint32_t)__shfl_xor((int)tm, (int)d, 64);
+                tm = o > tm ? o : tm;
+            }
+            const uint32_t T = blk / bpt;
+            if ((lane & (lpt - 1u)) == 0u && T < p.ntiles) ub_lds[x * p.ntiles + T] = (uint16_t)tm;
         }
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) {
-            const unsigned long long o = __shfl_xor(best, d, 64);
-            best = o > best ? o : best;
-        }
-        const uint32_t bb = 0xFFFFFFFFu - (uint32_t)best;  // block with the largest bound
-        // ---- 2. exact counts of its references (not those that --skip-exact-matches zeroes): lane j counts reference j of
-        // the block -- per row one load per lane, all of them in the same 64 bytes of the row's segment; M = the best of them
+        const uint32_t ub_best = wave_max_u32p(lmx);
+        // the lowest block among those with the largest bound (0 if every bound is 0)
+        const uint32_t bb = ub_best ? 0xFFFFFFFFu - wave_max_u32p(lmx == ub_best ? 0xFFFFFFFFu - lblk : 0u) : 0u;
+        // ---- 2. exact counts of its references (not those that --skip-exact-matches zeroes); M = the best of them.  The
+        // block's references lie in (1 << shift) / 8 chunks of eight = that many bytes of a row segment (ref_slot,
+        // rtx_math.hpp); lane l of a turn takes row i0 + l and gathers those bytes, the hits of the eight references of a byte
+        // are summed bit-sliced (eight 8-bit counters in two words, flushed to 16 bits every 255 rows).
         uint32_t M = 0;
         {
-            const uint64_t r = ((uint64_t)bb << p.shift) + lane;
-            bool ok = lane < (1u << p.shift) && r < p.n_refs;
-            if (ok && (p.flags & RTX_SKIP_EXACT_MATCHES)) {
-                const uint64_t qin = p.perm[p.q0 + q];
-                for (uint64_t e = p.exact_off[qin]; e < p.exact_off[qin + 1]; e++) ok = ok && (uint64_t)p.exact_ids[e] != r;
-            }
-            uint32_t word = 0, bit = 0;
-            ref_slot(ok ? (uint32_t)r : 0u, p.stride_bytes, word, bit);
+            const uint32_t nchunk = (1u << p.shift) / 8u;  // 4 for blocks of 32
             const uint32_t nr = p.nrows[q];
             const uint32_t *rows = p.rows + (size_t)q * p.rstride;
-            uint32_t cnt = 0;
-            for (uint32_t i0 = 0; i0 < nr; i0 += 64) {  // the row list is padded with the all-zero row to whole chunks of 64
-                const uint32_t rv = rows[i0 + lane];
-#pragma unroll 16
-                for (int k = 0; k < 64; k++) {
-                    const uint32_t row = (uint32_t)__builtin_amdgcn_readlane((int)rv, k);
-                    cnt += (p.bitmap[bitmap_word(row, word, p.n_rows1)] >> bit) & 1u;
+            const uint64_t qin = p.perm[p.q0 + q];
+            for (uint32_t c = 0; c < nchunk; c++) {
+                const uint64_t r0 = ((uint64_t)bb << p.shift) + (uint64_t)c * 8u;
+                if (r0 >= p.n_refs) break;  // wave-uniform
+                uint32_t word, bit;
+                ref_slot((uint32_t)r0, p.stride_bytes, word, bit);  // bit = first bit of the chunk's byte
+                // per lane: hits of the eight references over this lane's rows, one 16-bit counter each in four words
+                uint32_t acc[4] = {0u, 0u, 0u, 0u};
+                for (uint32_t i0 = 0; i0 < nr; i0 += 64) {  // the row list is padded with the all-zero row to whole chunks of 64
+                    const uint32_t row = rows[i0 + lane];
+                    const uint32_t byte = (p.bitmap[bitmap_word(row, word, p.n_rows1)] >> bit) & 0xFFu;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) acc[k] += ((byte >> (2 * k)) & 1u) | (((byte >> (2 * k + 1)) & 1u) << 16);
+                }
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+#pragma unroll
+                    for (int d = 32; d >= 1; d >>= 1) acc[k] += (uint32_t)__shfl_xor((int)acc[k], d, 64);  // at most 16 rows per lane x 64 lanes: fits 16 bits
+                // the chunk's eight references: drop those behind the end and those --skip-exact-matches zeroes
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const uint64_t r = r0 + (uint64_t)j;
+                    bool ok = r < p.n_refs;
+                    if (ok && (p.flags & RTX_SKIP_EXACT_MATCHES)) {
+                        bool hit = false;
+                        for (uint64_t e = p.exact_off[qin] + lane; e < p.exact_off[qin + 1]; e += 64) hit = hit || (uint64_t)p.exact_ids[e] == r;
+                        ok = __ballot(hit) == 0ull;
+                    }
+                    const uint32_t cnt = (acc[j >> 1] >> ((j & 1) * 16)) & 0xFFFFu;
+                    if (ok && cnt > M) M = cnt;
                 }
             }
-            M = wave_max_u32p(ok ? cnt : 0u);
         }
+#ifdef RTX_PRUNE_CHECK  // debug: the count of the best block recomputed from the union bitmap must equal what the counting pass left
+        if (p.ubitmap) {
+            uint32_t word, bit;
+            ref_slot(bb, p.ustride_bytes, word, bit);
+            const uint32_t nr = p.nrows[q];
+            const uint32_t *rows = p.rows + (size_t)q * p.rstride;
+            uint32_t cub = 0;
+            for (uint32_t i0 = 0; i0 < nr; i0 += 64) {
+                const uint32_t row = rows[i0 + lane];
+                cub += (p.ubitmap[bitmap_word(row, word, p.n_rows1)] >> bit) & 1u;
+            }
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) cub += (uint32_t)__shfl_xor((int)cub, d, 64);
+            if (lane == 0 && p.stats && cub != (uint32_t)uc[bb]) atomicAdd(&p.stats[7], 1ull);
+        }
+#endif
         // ---- 3. the largest count a skipped tile may hold
         const uint32_t t = p.t[q], n = t >> 1;
         uint32_t u_max = 0;
@@ -122,22 +162,16 @@ __global__ __launch_bounds__(64) void prune_kernel(PruneParams p, ProbTables tb)
                 if (ist1) {
                     const uint32_t i1 = ist1;  // = i* + 1: the first i that stays
                     const double ln_len = log((double)(n - i1 + 1u));
-                    uint32_t best_u = 0;
+                    // the condition holds for a prefix of the counts (below its mode pmf_u(i1) rises with u); taken as the
+                    // counts below the smallest one that fails, whatever rounding does to the largest one that passes
+                    uint32_t first_fail = M;  // counts from M on are never skipped
                     for (uint32_t u = 1u + lane; u < M; u += 64) {
                         // pmf_u falling from i1 on: (u + i1)(n - i1) < (i1 + 1)(t - u + n - i1 - 1)
-                        const double up = (double)(u + i1) * (double)(n - i1), dn = (double)(i1 + 1u) * (double)(t - u + n - i1 - 1u);
-                        if (up < dn && ln_len + ln_pmf_tab(lf, t, n, u, i1, ln_total) + ln_n <= kPruneLnEps) best_u = u;
-                    }
-                    u_max = wave_max_u32p(best_u);
-                    // the condition holds for a prefix of the counts (pmf_u(i1) rises with u below the mode): make sure
-                    // no smaller count failed (numerical safety): the smallest failing count bounds u_max
-                    uint32_t first_fail = 0xFFFFFFFFu;
-                    for (uint32_t u = 1u + lane; u <= u_max; u += 64) {
                         const double up = (double)(u + i1) * (double)(n - i1), dn = (double)(i1 + 1u) * (double)(t - u + n - i1 - 1u);
                         if (!(up < dn && ln_len + ln_pmf_tab(lf, t, n, u, i1, ln_total) + ln_n <= kPruneLnEps)) first_fail = u < first_fail ? u : first_fail;
                     }
                     first_fail = 0xFFFFFFFFu - wave_max_u32p(0xFFFFFFFFu - first_fail);
-                    if (first_fail != 0xFFFFFFFFu) u_max = first_fail - 1u;
+                    u_max = first_fail - 1u;
                 }
             }
         }
@@ -145,8 +179,9 @@ __global__ __launch_bounds__(64) void prune_kernel(PruneParams p, ProbTables tb)
         if (lane == 0 && p.stats) {  // reporting: sums of the lower bound of the best hit, of the threshold, of the largest tile bound
             atomicAdd(&p.stats[2], (unsigned long long)M);
             atomicAdd(&p.stats[3], (unsigned long long)u_max);
-            atomicAdd(&p.stats[4], (unsigned long long)(best >> 32));
+            atomicAdd(&p.stats[4], (unsigned long long)ub_best);
             atomicAdd(&p.stats[5], 1ull);
+            if (ub_best < M) atomicAdd(&p.stats[6], 1ull);  // must never happen: a block's bound below one of its references' counts
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");

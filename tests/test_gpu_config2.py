@@ -66,3 +66,20 @@ def test_seeded_oracle_sample(cfg2, oracle, skip):
     oracle_sample_parity(c["index"], oracle, c["otree"], c["db"], c["qs"], c["sample"], skip, ex,
                          full_res=None if skip else c["res"])
     ex.check()
+
+
+def test_seeded_oracle_sample_with_tile_pruning(cfg2, oracle):
+    """The same sample through RTX_OPT_TILE_PRUNE (hit_count visits only the tiles that can matter, rtx_prune.hip): rows
+    identical to the oracle's, and to those of the full count inside the big batch; the taps recount in full, so hit counts
+    stay bit-exact and the probabilities within 1e-9."""
+    c = cfg2
+    index = rx.Index(c["tree"], tile_prune=True)
+    ex = Excuses(f"config2/sample{N_SAMPLE}/tile_prune")
+    res = oracle_sample_parity(index, oracle, c["otree"], c["db"], c["qs"], c["sample"], False, ex, full_res=None)
+    st = index.debug_prune_stats()      # of the recount-free run? the taps re-ran the count without pruning: stats are of the classify call
+    print("tile pruning on the sample:", st)
+    assert st["bound_violations"] == 0
+    for j in range(0, N_SAMPLE, 7):
+        x, y = rows_of(res, j), rows_of(c["res"], int(c["sample"][j]))
+        assert np.array_equal(x[0], y[0]) and np.allclose(x[1], y[1], rtol=0, atol=1e-9), int(c["sample"][j])
+    ex.check()

@@ -1095,3 +1095,53 @@ def test_prefix_gaps_and_their_fallback(oracle):
                                            f"gaps skip {skip} q {q}"))
     print(f"prefix gaps: {exc.checked} queries checked, {exc.n['ties']} accepted as exact ties")
     assert exc.checked >= 10 and exc.n["ties"] <= 2
+
+
+@pytest.mark.parametrize("kmer_map", [False, True])
+def test_tile_pruning_changes_nothing_visible(oracle, kmer_map):
+    """RTX_OPT_TILE_PRUNE (rtx_prune.hip): hit_count visits only the tiles of 8192 references that can hold a reference with any
+    probability -- decided from upper bounds (the queries counted against the union bitmap over blocks of 32 references) and
+    a threshold that keeps every probability within 1e-11 of the full count.  Nine tiles; queries of every kind (copies,
+    substitutions, ambiguity codes, truncated, chimeras of distant references, an unrelated random sequence).  The pruned run
+    equals the full one: status, t, rows and lineages identical, confidences within 1e-9 (in practice: identical), global
+    signal within 1e-12; it does skip tiles, no bound lies below a count it bounds; its rows equal the oracle's; and the
+    debug taps still deliver the FULL hit counts (they recount the tapped sub-batch)."""
+    db = synth.make_db(70000)
+    qs = synth.make_queries(db, 600, exact_frac=0.15)
+    rng = np.random.default_rng(41)
+    L = db.length
+    seqs = [qs.seq(q) for q in range(qs.n)]
+    seqs += [db.seq(int(rng.integers(0, db.n)))[: int(rng.integers(30, 400))].copy() for _ in range(20)]                # truncated
+    seqs += [np.concatenate([db.seq(int(rng.integers(0, db.n)))[:300], db.seq(int(rng.integers(0, db.n)))[300:]]) for _ in range(20)]  # chimeras
+    seqs += [(1 << rng.integers(0, 4, L)).astype(np.uint8)]                                                              # unrelated
+    off = np.zeros(len(seqs) + 1, np.uint64)
+    off[1:] = np.cumsum([len(s) for s in seqs])
+    bases = np.concatenate(seqs)
+    otree = oracle.tree_new_flat(db.lineages, db.seq_bytes, db.seq_off)
+    tree = rx.Tree.new_flat(db.lineages, db.seq_bytes, db.seq_off, kmer_map=kmer_map)
+    a, b = rx.Index(tree, tile_prune=False), rx.Index(tree, tile_prune=True)
+    ex = a.exact_matches(bases, off)
+    exc = Excuses("tile_prune")
+    for skip in (False, True):
+        ra = a.classify(bases, off, *ex, skip_exact_matches=skip)
+        rb = b.classify(bases, off, *ex, skip_exact_matches=skip)
+        st = b.debug_prune_stats()
+        print(f"kmer_map={kmer_map} skip={skip}: {st}")
+        assert st["pairs"] == (len(seqs) + 1) // 2 and st["bound_violations"] == 0
+        assert st["live_tiles_per_pair"] < 0.8 * 9, st          # it prunes
+        for f in ("row_off", "row_lineage", "t", "status"):
+            assert np.array_equal(getattr(ra, f), getattr(rb, f)), (skip, f)
+        assert np.allclose(ra.row_conf, rb.row_conf, rtol=0, atol=1e-9)
+        assert np.allclose(ra.global_signal, rb.global_signal, rtol=0, atol=1e-12)
+        assert np.allclose(ra.row_local_signal, rb.row_local_signal, rtol=0, atol=1e-9)
+        for q in list(range(0, qs.n, 40)) + list(range(qs.n, len(seqs))):
+            rows, _ = _oracle_rows(otree, seqs[q], skip)
+            t, counts = otree.hit_counts(seqs[q], skip_exact=skip)
+            if rows is None:
+                assert rb.status[q] != 0
+                continue
+            exc.checked += 1
+            exc.tie(assert_rows_equivalent(rb.rows(q), rows, oracle.highest_hit_prob_per_reference(t, t // 2, counts), otree.lineages,
+                                           f"prune skip {skip} q {q}"))
+            assert np.array_equal(b.debug_hit_counts(q), counts), (skip, q)      # the taps recount in full
+    assert exc.n["ties"] <= 3, exc.n

@@ -203,7 +203,7 @@ struct rtx_index {
         // tile pruning: the queries counted against the union bitmap (every row dense: constant masks), the live tiles per pair
         DevBuf<unsigned long long> d_uones;
         DevBuf<uint32_t> d_uzero, d_uhist, d_live;
-        DevBuf<uint16_t> d_ucounts, d_utmax;
+        DevBuf<uint16_t> d_ucounts, d_utmax, d_prune_thr;
     } sc[2];
     uint32_t n_streams_req = 1, n_streams = 1;
     bool staged = false;  // driven with rtx_shard_*: sub-batch sb works in scratch set sb & 1, so that the exchange of one
@@ -411,6 +411,7 @@ int enqueue_hit(rtx_index *ix, const SubBatch &b, uint32_t flags, hipStream_t s)
     if (b.timed) RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_HIT_COUNT, 0), s));
     hp.live = nullptr;
     hp.live_words = 0;
+    if (ix->pair_used) launch_pair_union(s, sc.d_rows.p, sc.d_nrows.p, ix->rstride, b.nq, sc.d_urec.p, sc.d_nu.p, 2u * ix->rstride);
     if (ix->prune_used && !ix->dbg_full_run) {
         // (1) the queries against the union bitmap: every row dense, no lists, u16 counts (bounds per block of references)
         HitParams up = hp;
@@ -421,20 +422,21 @@ int enqueue_hit(rtx_index *ix, const SubBatch &b, uint32_t flags, hipStream_t s)
         up.nsparse = sc.d_uzero.p;
         up.nmid = nullptr;
         up.ntiles = ix->u_ntiles;
-        up.counts = sc.d_ucounts.p;
-        up.counts_lo = nullptr;
-        up.counts_hi = nullptr;
-        up.npad = (uint64_t)ix->u_ntiles * 8192u;
+        const uint32_t unpad = ix->u_ntiles * 8192u;
+        up.counts = nullptr;  // packed like the counts of the database: low bytes, behind them the high bits
+        up.counts_lo = reinterpret_cast<uint8_t *>(sc.d_ucounts.p);
+        up.counts_hi = reinterpret_cast<uint16_t *>(up.counts_lo + (size_t)b.nq * unpad);
+        up.npad = unpad;
         up.hist = sc.d_uhist.p;
         up.tile_max = sc.d_utmax.p;
         up.flags = 0;
         up.group_rows = nullptr;
-        launch_hit_count(s, up, b.nq, ix->u_ntiles, 10);
+        launch_hit_count_pair(s, up, b.nq, ix->u_ntiles, 1);  // the union of the pair's rows serves both passes
         // (2) bounds per tile, a lower bound of the best hit, the threshold, the live tiles of every pair
         PruneParams pr{};
-        pr.ucounts = sc.d_ucounts.p;
-        pr.unpad = ix->u_ntiles * 8192u;
-        pr.shift = kPruneShift;
+        pr.ucounts_lo = up.counts_lo;
+        pr.ucounts_hi = up.counts_hi;
+        pr.unpad = unpad;
         pr.ntiles = ix->ntiles;
         pr.nq = b.nq;
         pr.n_refs = ix->n_refs;
@@ -455,6 +457,7 @@ int enqueue_hit(rtx_index *ix, const SubBatch &b, uint32_t flags, hipStream_t s)
         pr.hstride = ix->hstride;
         pr.live = sc.d_live.p;
         pr.live_words = (ix->ntiles + 31u) / 32u + 1u;
+        pr.thr_out = sc.d_prune_thr.p;
         pr.stats = ix->d_prune_stats.p;
         pr.ubitmap = ix->d_ubitmap.p;
         pr.ustride_bytes = ix->u_stride_bytes;
@@ -466,7 +469,6 @@ int enqueue_hit(rtx_index *ix, const SubBatch &b, uint32_t flags, hipStream_t s)
         hp.live_words = pr.live_words;
     }
     if (ix->pair_used) {
-        launch_pair_union(s, sc.d_rows.p, sc.d_nrows.p, ix->rstride, b.nq, sc.d_urec.p, sc.d_nu.p, 2u * ix->rstride);
         launch_hit_count_pair(s, hp, b.nq, ix->ntiles, ix->pair_variant);
     } else if (ix->quad_used) launch_hit_count_quad(s, hp, b.nq, ix->ntiles);
     else launch_hit_count(s, hp, b.nq, ix->ntiles, ix->planes);
@@ -532,6 +534,7 @@ int enqueue_prob_prefix(rtx_index *ix, const SubBatch &b, bool fuse_walk, bool p
     fp.n_bnd = ix->n_bnd_local;
     fp.tile_max = ix->tile_skip ? sc.d_tilemax.p : nullptr;
     fp.ntiles = ix->ntiles;
+    fp.prune_thr = ix->prune_used && !ix->dbg_full_run ? sc.d_prune_thr.p : nullptr;
     fp.fuse_walk = fuse_walk ? 1u : 0u;
     if (fuse_walk) fp.walk = walk_params(ix, b, sc.d_prefix.p);
     if (b.timed_all) RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_TAXON_PREFIX, 0), s));
@@ -614,9 +617,9 @@ int begin_run(rtx_index *ix, uint32_t *n_sub_out, bool *timed_out, bool cluster)
                      ix->n_refs == ix->n_total && !ix->staged && ix->sc[0].d_ucounts.p != nullptr;
     ix->dbg_full = false;
     if (ix->prune_used) {
-        int rc_s = ix->d_prune_stats.alloc(8);
+        int rc_s = ix->d_prune_stats.alloc(kPruneStatCopies * 8);
         if (rc_s) return rc_s;
-        RTX_HIP(hipMemsetAsync(ix->d_prune_stats.p, 0, 64, ix->stream));
+        RTX_HIP(hipMemsetAsync(ix->d_prune_stats.p, 0, kPruneStatCopies * 64, ix->stream));
     }
     // the sequential variant keeps every list of a (pair, tile) in one round: t <= kHitListCap - 64
     ix->pair_variant = ix->pair_used && ix->pair_opt == 2 && ix->tmax + 64u <= kHitListCap ? 2 : 1;
@@ -887,7 +890,7 @@ int alloc_scratch_set(rtx_index *ix, uint32_t k) {
             const bool fresh = sc.d_uones.n < mw;
             if ((rc = sc.d_uones.alloc(mw)) || (rc = sc.d_uzero.alloc((size_t)B * ix->u_ntiles)) ||
                 (rc = sc.d_ucounts.alloc((size_t)B * ix->u_ntiles * 8192u)) || (rc = sc.d_uhist.alloc((size_t)B * ix->hstride)) ||
-                (rc = sc.d_utmax.alloc((size_t)B * ix->u_ntiles)) || (rc = sc.d_live.alloc((size_t)((B + 1u) / 2u) * ((ix->ntiles + 31u) / 32u + 1u))))
+                (rc = sc.d_utmax.alloc((size_t)B * ix->u_ntiles)) || (rc = sc.d_prune_thr.alloc(B)) || (rc = sc.d_live.alloc((size_t)((B + 1u) / 2u) * ((ix->ntiles + 31u) / 32u + 1u))))
                 return rc;
             if (fresh) RTX_HIP(hipMemsetAsync(sc.d_uones.p, 0xFF, sc.d_uones.n * 8, ix->stream));
             RTX_HIP(hipMemsetAsync(sc.d_uzero.p, 0, sc.d_uzero.n * 4, ix->stream));
@@ -1941,7 +1944,10 @@ int rtx_debug_prune_stats(rtx_index *ix, uint64_t *out) {
     std::memset(out, 0, 64);
     if (!ix->prune_used || !ix->d_prune_stats.p) return RTX_OK;
     RTX_HIP(hipStreamSynchronize(ix->stream));
-    RTX_HIP(hipMemcpy(out, ix->d_prune_stats.p, 64, hipMemcpyDeviceToHost));
+    unsigned long long h[kPruneStatCopies * 8];
+    RTX_HIP(hipMemcpy(h, ix->d_prune_stats.p, sizeof(h), hipMemcpyDeviceToHost));
+    for (uint32_t c = 0; c < kPruneStatCopies; c++)
+        for (uint32_t k = 0; k < 8; k++) out[k] += h[c * 8 + k];
     return RTX_OK;
 }
 

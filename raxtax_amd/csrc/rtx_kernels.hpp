@@ -127,10 +127,12 @@ struct HitParams {
 };
 
 // tile pruning (rtx_prune.hip)
+constexpr uint32_t kPruneStatCopies = 64;  // PruneParams::stats: [copies][8], summed by the reader
 constexpr uint32_t kPruneShift = 5;  // the union bitmap has one column per block of 32 references
 struct PruneParams {
-    const uint16_t *ucounts;  // [B][unpad] counts of the queries against the union bitmap (an upper bound per block)
-    uint32_t unpad, shift, ntiles, nq;
+    const uint8_t *ucounts_lo;   // [B][unpad] counts of the queries against the union bitmap (an upper bound per block of
+    const uint16_t *ucounts_hi;  // [B][unpad / 8]  2^kPruneShift references), packed like HitParams::counts_lo / counts_hi
+    uint32_t unpad, ntiles, nq;
     uint64_t n_refs;
     const uint32_t *bitmap;   // the database's bitmap: the exact count of one reference
     uint32_t n_rows1, stride_bytes;
@@ -146,7 +148,8 @@ struct PruneParams {
     uint32_t hstride;
     uint32_t *live;           // [pairs][live_words] bit T: tile T is counted for the pair
     uint32_t live_words;
-    unsigned long long *stats;  // [0] += live tiles, [1] += pairs (reporting) or null
+    uint16_t *thr_out;        // [B] the threshold of every query (0: not pruned, every tile is counted)
+    unsigned long long *stats;  // [kPruneStatCopies][8]: [0] += live tiles, [1] += pairs ... (reporting) or null
     const uint32_t *ubitmap;    // debug (RTX_PRUNE_CHECK): the union bitmap
     uint32_t ustride_bytes;
 };
@@ -215,6 +218,7 @@ struct PrefixParams {
     uint32_t n_bnd;
     const uint16_t *tile_max;   // [B][ntiles] largest count per tile of 8192 references (hit_count) or null: every tile is swept
     uint32_t ntiles;
+    const uint16_t *prune_thr;  // [B] tile pruning: threshold of the query (> 0: tiles with a largest count of 0 were not counted) or null
     uint32_t fuse_walk;         // wave 0 of every workgroup walks its query right after the sweeps (walk.prefix == prefix)
     WalkParams walk;
 };

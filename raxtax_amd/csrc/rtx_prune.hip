@@ -18,9 +18,12 @@
 //     and every prefix sum of the pruned run is within a few eps of the full one.  eps = 1e-12 (north_star asks for 1e-6).
 //     With a full-overlap reference (M = t) prob.rs:24-41 applies: table[m] = pmf_m(n), table[t] = 1: u = the largest
 //     count with N pmf_u(n) <= eps.
-// A tile is dead for a query if ub(T) <= u; a (pair, tile) block of hit_count_pair_kernel leaves at once if the tile
-// is dead for both queries.  The references that are never counted are booked into histogram bin 0 (the bin takes part
-// in nothing but the global signal).
+// A tile is dead for a query if u >= 1 and ub(T) <= u (a query without a threshold has every tile counted); a (pair, tile)
+// block of hit_count_pair_kernel leaves at once if the tile is dead for both queries.  The references that are never counted
+// are booked into histogram bin 0: cmf_0 = 1, so they drop out of every product -- the approximation bounded in (2) -- and
+// the probability of bin 0 itself is at most cmf_M(0) <= eps / N for a query with a threshold (part of delta).  Their
+// tiles keep a largest count of 0, and for such a query taxon_prefix leaves out every tile whose largest count is 0
+// (PrefixParams::prune_thr): what it drops there is again at most N cmf_M(0) <= eps.
 #include <hip/hip_runtime.h>
 
 #include "rtx_kernels.hpp"
@@ -43,73 +46,109 @@ __device__ __forceinline__ uint32_t wave_max_u32p(uint32_t v) {
 __global__ __launch_bounds__(64) void prune_kernel(PruneParams p, ProbTables tb) {
     extern __shared__ uint16_t ub_lds[];  // [2][ntiles]
     const uint32_t pair = blockIdx.x, lane = threadIdx.x;
-    const uint32_t bpt = 8192u >> p.shift;  // blocks per tile
+    const uint32_t bpt = 8192u >> kPruneShift;  // blocks per tile
     const double ln_n = log((double)p.n_refs);
     uint32_t thr[2] = {0u, 0u};
+    unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // wave-uniform: what this wave adds to p.stats
     const bool has_b = pair * 2u + 1u < p.nq;
     for (uint32_t x = 0; x < 2u; x++) {
         if (x == 1u && !has_b) break;  // wave-uniform
         const uint32_t q = pair * 2u + x;
-        // ---- 1. bound of every tile, and the block with the largest bound.  The counts of the blocks are read as they
-        // lie (a wave takes 512 consecutive blocks per turn, 8 per lane): with 32 blocks per reference... per tile of 8192
-        // references 8192 >> shift blocks = bpt / 8 lanes; the lanes of a tile meet through DPP-free shuffles
-        const uint16_t *uc = p.ucounts + (size_t)q * p.unpad;
+        // ---- 1. bound of every tile, and the block with the largest bound.  The counts of the blocks are read as the
+        // counting pass packed them (low byte per block + the two high bits of eight blocks per u16); a wave takes 512
+        // consecutive blocks per turn, 8 per lane, four turns in flight: the 8192 >> shift blocks of a tile are held by
+        // bpt / 8 neighbouring lanes, which meet through shuffles
+        const uint8_t *ulo = p.ucounts_lo + (size_t)q * p.unpad;
+        const uint16_t *uhi = p.ucounts_hi + (size_t)q * (p.unpad >> 3);
         const uint32_t lpt = bpt / 8u;  // lanes per tile in a turn (32 for blocks of 32 references): a power of two <= 64
         uint32_t lmx = 0, lblk = 0;  // this lane's largest bound and its block
         const uint32_t n_blocks_pad = p.ntiles * bpt;
-        for (uint32_t b0 = 0; b0 < n_blocks_pad; b0 += 512u) {
-            const uint32_t blk = b0 + lane * 8u;
-            uint32_t mx = 0, arg = 0;
-            if (blk < n_blocks_pad) {
-                const uint4 v = *reinterpret_cast<const uint4 *>(uc + blk);
-                const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        for (uint32_t b0 = 0; b0 < n_blocks_pad; b0 += 4u * 512u) {
+            uint2 lo[4];
+            uint32_t hi[4];
 #pragma unroll
-                for (int j = 0; j < 8; j++) {
-                    const uint32_t c = (w[j >> 1] >> ((j & 1) * 16)) & 0xFFFFu;
-                    if (c > mx) { mx = c; arg = (uint32_t)j; }
+            for (int k = 0; k < 4; k++) {
+                const uint32_t blk = b0 + (uint32_t)k * 512u + lane * 8u;
+                lo[k] = make_uint2(0u, 0u);
+                hi[k] = 0u;
+                if (blk < n_blocks_pad) {
+                    lo[k] = *reinterpret_cast<const uint2 *>(ulo + blk);
+                    hi[k] = uhi[blk >> 3];
                 }
             }
-            if (mx > lmx) { lmx = mx; lblk = blk + arg; }
-            // the largest count of the tile: over the lpt lanes that hold its blocks
-            uint32_t tm = mx;
-            for (uint32_t d = 1; d < lpt; d <<= 1) {
-                const uint32_t o = (uint32_t)__shfl_xor((int)tm, (int)d, 64);
-                tm = o > tm ? o : tm;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint32_t blk = b0 + (uint32_t)k * 512u + lane * 8u;
+                uint32_t mx = 0, arg = 0;
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const uint32_t w = j < 4 ? lo[k].x : lo[k].y;
+                    const uint32_t c = ((w >> ((j & 3) * 8)) & 0xFFu) | (((hi[k] >> (2 * j)) & 3u) << 8);
+                    if (c > mx) { mx = c; arg = (uint32_t)j; }
+                }
+                if (mx > lmx) { lmx = mx; lblk = blk + arg; }
+                // the largest count of the tile: over the lpt lanes that hold its blocks
+                uint32_t tm = mx;
+                for (uint32_t d = 1; d < lpt; d <<= 1) {
+                    const uint32_t o = (uint32_t)__shfl_xor((int)tm, (int)d, 64);
+                    tm = o > tm ? o : tm;
+                }
+                const uint32_t T = blk / bpt;
+                if ((lane & (lpt - 1u)) == 0u && T < p.ntiles) ub_lds[x * p.ntiles + T] = (uint16_t)tm;
             }
-            const uint32_t T = blk / bpt;
-            if ((lane & (lpt - 1u)) == 0u && T < p.ntiles) ub_lds[x * p.ntiles + T] = (uint16_t)tm;
         }
         const uint32_t ub_best = wave_max_u32p(lmx);
         // the lowest block among those with the largest bound (0 if every bound is 0)
         const uint32_t bb = ub_best ? 0xFFFFFFFFu - wave_max_u32p(lmx == ub_best ? 0xFFFFFFFFu - lblk : 0u) : 0u;
         // ---- 2. exact counts of its references (not those that --skip-exact-matches zeroes); M = the best of them.  The
-        // block's references lie in (1 << shift) / 8 chunks of eight = that many bytes of a row segment (ref_slot,
-        // rtx_math.hpp); lane l of a turn takes row i0 + l and gathers those bytes, the hits of the eight references of a byte
-        // are summed bit-sliced (eight 8-bit counters in two words, flushed to 16 bits every 255 rows).
+        // block's references lie in kChunks chunks of eight = that many bytes of a row segment, in neighbouring lane words
+        // (ref_slot, rtx_math.hpp); lane l of a turn takes rows i0 + l and i0 + 64 + l and gathers those bytes, the hits of every
+        // reference are summed in 16-bit halves (at most 16 rows per lane x 64 lanes).
         uint32_t M = 0;
         {
-            const uint32_t nchunk = (1u << p.shift) / 8u;  // 4 for blocks of 32
+            constexpr uint32_t kChunks = (1u << kPruneShift) / 8u;  // 4 for blocks of 32
             const uint32_t nr = p.nrows[q];
             const uint32_t *rows = p.rows + (size_t)q * p.rstride;
             const uint64_t qin = p.perm[p.q0 + q];
-            for (uint32_t c = 0; c < nchunk; c++) {
-                const uint64_t r0 = ((uint64_t)bb << p.shift) + (uint64_t)c * 8u;
-                if (r0 >= p.n_refs) break;  // wave-uniform
-                uint32_t word, bit;
-                ref_slot((uint32_t)r0, p.stride_bytes, word, bit);  // bit = first bit of the chunk's byte
-                // per lane: hits of the eight references over this lane's rows, one 16-bit counter each in four words
-                uint32_t acc[4] = {0u, 0u, 0u, 0u};
-                for (uint32_t i0 = 0; i0 < nr; i0 += 64) {  // the row list is padded with the all-zero row to whole chunks of 64
-                    const uint32_t row = rows[i0 + lane];
-                    const uint32_t byte = (p.bitmap[bitmap_word(row, word, p.n_rows1)] >> bit) & 0xFFu;
+            const uint32_t zero_row = p.n_rows1 - 1u;
+            uint32_t word[kChunks], bit[kChunks];
 #pragma unroll
-                    for (int k = 0; k < 4; k++) acc[k] += ((byte >> (2 * k)) & 1u) | (((byte >> (2 * k + 1)) & 1u) << 16);
+            for (uint32_t c = 0; c < kChunks; c++) {
+                const uint64_t r0 = ((uint64_t)bb << kPruneShift) + (uint64_t)c * 8u;
+                ref_slot((uint32_t)(r0 < p.n_refs ? r0 : (uint64_t)bb << kPruneShift), p.stride_bytes, word[c], bit[c]);  // bit = first bit of the chunk's byte
+            }
+            uint32_t acc[kChunks][4];  // [chunk][pair of references]: two 16-bit counters
+#pragma unroll
+            for (uint32_t c = 0; c < kChunks; c++)
+#pragma unroll
+                for (int k = 0; k < 4; k++) acc[c][k] = 0u;
+            for (uint32_t i0 = 0; i0 < nr; i0 += 128) {  // the row list is padded with the all-zero row to whole chunks of 64
+                const uint32_t row0 = rows[i0 + lane];
+                const uint32_t row1 = i0 + 64u < nr ? rows[i0 + 64u + lane] : zero_row;
+                uint32_t w0[kChunks], w1[kChunks];
+#pragma unroll
+                for (uint32_t c = 0; c < kChunks; c++) {
+                    w0[c] = p.bitmap[bitmap_word(row0, word[c], p.n_rows1)];
+                    w1[c] = p.bitmap[bitmap_word(row1, word[c], p.n_rows1)];
                 }
+#pragma unroll
+                for (uint32_t c = 0; c < kChunks; c++) {
+                    const uint32_t b0 = (w0[c] >> bit[c]) & 0xFFu, b1 = (w1[c] >> bit[c]) & 0xFFu;
+#pragma unroll
+                    for (int k = 0; k < 4; k++)
+                        acc[c][k] += (((b0 >> (2 * k)) & 1u) + ((b1 >> (2 * k)) & 1u)) | ((((b0 >> (2 * k + 1)) & 1u) + ((b1 >> (2 * k + 1)) & 1u)) << 16);
+                }
+            }
+#pragma unroll
+            for (uint32_t c = 0; c < kChunks; c++)
 #pragma unroll
                 for (int k = 0; k < 4; k++)
 #pragma unroll
-                    for (int d = 32; d >= 1; d >>= 1) acc[k] += (uint32_t)__shfl_xor((int)acc[k], d, 64);  // at most 16 rows per lane x 64 lanes: fits 16 bits
-                // the chunk's eight references: drop those behind the end and those --skip-exact-matches zeroes
+                    for (int d = 32; d >= 1; d >>= 1) acc[c][k] += (uint32_t)__shfl_xor((int)acc[c][k], d, 64);
+            // the block's references: drop those behind the end and those --skip-exact-matches zeroes
+#pragma unroll
+            for (uint32_t c = 0; c < kChunks; c++) {
+                const uint64_t r0 = ((uint64_t)bb << kPruneShift) + (uint64_t)c * 8u;
 #pragma unroll
                 for (int j = 0; j < 8; j++) {
                     const uint64_t r = r0 + (uint64_t)j;
@@ -119,7 +158,7 @@ __global__ __launch_bounds__(64) void prune_kernel(PruneParams p, ProbTables tb)
                         for (uint64_t e = p.exact_off[qin] + lane; e < p.exact_off[qin + 1]; e += 64) hit = hit || (uint64_t)p.exact_ids[e] == r;
                         ok = __ballot(hit) == 0ull;
                     }
-                    const uint32_t cnt = (acc[j >> 1] >> ((j & 1) * 16)) & 0xFFFFu;
+                    const uint32_t cnt = (acc[c][j >> 1] >> ((j & 1) * 16)) & 0xFFFFu;
                     if (ok && cnt > M) M = cnt;
                 }
             }
@@ -137,7 +176,8 @@ __global__ __launch_bounds__(64) void prune_kernel(PruneParams p, ProbTables tb)
             }
 #pragma unroll
             for (int d = 32; d >= 1; d >>= 1) cub += (uint32_t)__shfl_xor((int)cub, d, 64);
-            if (lane == 0 && p.stats && cub != (uint32_t)uc[bb]) atomicAdd(&p.stats[7], 1ull);
+            const uint32_t packed = (uint32_t)ulo[bb] | ((((uint32_t)uhi[bb >> 3] >> (2u * (bb & 7u))) & 3u) << 8);
+            if (cub != packed) st[7] += 1ull;
         }
 #endif
         // ---- 3. the largest count a skipped tile may hold
@@ -153,11 +193,9 @@ __global__ __launch_bounds__(64) void prune_kernel(PruneParams p, ProbTables tb)
                 u_max = wave_max_u32p(mine);
             } else {
                 const double *lc = tb.cmf + tb.off[t] + (size_t)M * (n + 1);  // ln cmf_M(i)
-                uint32_t mine = 0xFFFFFFFFu;  // i* + 1 in the end (0: none)
-                uint32_t ist1 = 0;
+                uint32_t ist1 = 0;  // i* + 1 in the end (0: none)
                 for (uint32_t i = lane; i + 2u <= n; i += 64)  // i* <= n - 2: a tail is left
                     if (lc[i] + log(1.0 + (double)p.n_refs * (double)(i + 1u)) <= kPruneLnEps) ist1 = i + 1u;
-                (void)mine;
                 ist1 = wave_max_u32p(ist1);
                 if (ist1) {
                     const uint32_t i1 = ist1;  // = i* + 1: the first i that stays
@@ -176,13 +214,10 @@ __global__ __launch_bounds__(64) void prune_kernel(PruneParams p, ProbTables tb)
             }
         }
         thr[x] = u_max;
-        if (lane == 0 && p.stats) {  // reporting: sums of the lower bound of the best hit, of the threshold, of the largest tile bound
-            atomicAdd(&p.stats[2], (unsigned long long)M);
-            atomicAdd(&p.stats[3], (unsigned long long)u_max);
-            atomicAdd(&p.stats[4], (unsigned long long)ub_best);
-            atomicAdd(&p.stats[5], 1ull);
-            if (ub_best < M) atomicAdd(&p.stats[6], 1ull);  // must never happen: a block's bound below one of its references' counts
-        }
+        if (lane == 0) p.thr_out[q] = (uint16_t)u_max;
+        // reporting: sums of the lower bound of the best hit, of the threshold, of the largest tile bound
+        st[2] += M; st[3] += u_max; st[4] += ub_best; st[5] += 1ull;
+        if (ub_best < M) st[6] += 1ull;  // must never happen: a block's bound below one of its references' counts
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -193,8 +228,10 @@ __global__ __launch_bounds__(64) void prune_kernel(PruneParams p, ProbTables tb)
         const uint32_t T = T0 + lane;
         bool live = false;
         if (T < p.ntiles) {
-            live = (uint32_t)ub_lds[T] > thr[0];
-            if (has_b) live = live || (uint32_t)ub_lds[p.ntiles + T] > thr[1];
+            // a query without a threshold has every tile counted -- also those without any of its k-mers: taxon_prefix may
+            // have to read them (every reference with count 0 can carry probability if the best hit is weak)
+            live = thr[0] == 0u || (uint32_t)ub_lds[T] > thr[0];
+            if (has_b) live = live || thr[1] == 0u || (uint32_t)ub_lds[p.ntiles + T] > thr[1];
         }
         const unsigned long long bl = __ballot(live);
         if (lane == 0) {
@@ -212,7 +249,14 @@ __global__ __launch_bounds__(64) void prune_kernel(PruneParams p, ProbTables tb)
     if (lane == 0) {
         p.hist[(size_t)(pair * 2u) * p.hstride] = (uint32_t)dead_refs;  // kmer_extract has zeroed the row; hit_count adds the counted ones
         if (has_b) p.hist[(size_t)(pair * 2u + 1u) * p.hstride] = (uint32_t)dead_refs;
-        if (p.stats) { atomicAdd(&p.stats[0], (unsigned long long)n_live); atomicAdd(&p.stats[1], 1ull); }
+    }
+    if (p.stats) {  // one atomic instruction per wave (lane k adds counter k), 64 copies of the counters in lines of their own:
+                    // thousands of waves adding to ONE address queue up in L2 for longer than everything else here takes
+        st[0] = n_live; st[1] = 1ull;
+        unsigned long long mine = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) mine = lane == (uint32_t)k ? st[k] : mine;
+        if (lane < 8u && mine) atomicAdd(&p.stats[(size_t)(pair & (kPruneStatCopies - 1u)) * 8u + lane], mine);
     }
 }
 

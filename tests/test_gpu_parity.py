@@ -1114,6 +1114,12 @@ def test_tile_pruning_changes_nothing_visible(oracle, kmer_map):
     seqs += [db.seq(int(rng.integers(0, db.n)))[: int(rng.integers(30, 400))].copy() for _ in range(20)]                # truncated
     seqs += [np.concatenate([db.seq(int(rng.integers(0, db.n)))[:300], db.seq(int(rng.integers(0, db.n)))[300:]]) for _ in range(20)]  # chimeras
     seqs += [(1 << rng.integers(0, 4, L)).astype(np.uint8)]                                                              # unrelated
+    n_strong = len(seqs)
+    # weak best hits (12 - 30 % substitutions: 35 % ... 6 % of the 8-mers survive): queries that get a low threshold or none,
+    # and for which a reference WITHOUT any hit can carry more than the 1e-30 below which taxon_prefix drops a tile
+    for i, mu in enumerate((0.12, 0.2, 0.3)):
+        w = synth.make_queries(db, 40, seed=50 + i, mu_q=mu, exact_frac=0.0)
+        seqs += [w.seq(q) for q in range(w.n)]
     off = np.zeros(len(seqs) + 1, np.uint64)
     off[1:] = np.cumsum([len(s) for s in seqs])
     bases = np.concatenate(seqs)
@@ -1128,13 +1134,13 @@ def test_tile_pruning_changes_nothing_visible(oracle, kmer_map):
         st = b.debug_prune_stats()
         print(f"kmer_map={kmer_map} skip={skip}: {st}")
         assert st["pairs"] == (len(seqs) + 1) // 2 and st["bound_violations"] == 0
-        assert st["live_tiles_per_pair"] < 0.8 * 9, st          # it prunes
+        assert st["live_tiles_per_pair"] < 0.85 * 9, st         # it prunes
         for f in ("row_off", "row_lineage", "t", "status"):
             assert np.array_equal(getattr(ra, f), getattr(rb, f)), (skip, f)
         assert np.allclose(ra.row_conf, rb.row_conf, rtol=0, atol=1e-9)
         assert np.allclose(ra.global_signal, rb.global_signal, rtol=0, atol=1e-12)
         assert np.allclose(ra.row_local_signal, rb.row_local_signal, rtol=0, atol=1e-9)
-        for q in list(range(0, qs.n, 40)) + list(range(qs.n, len(seqs))):
+        for q in list(range(0, qs.n, 40)) + list(range(qs.n, n_strong)) + list(range(n_strong, len(seqs), 5)):
             rows, _ = _oracle_rows(otree, seqs[q], skip)
             t, counts = otree.hit_counts(seqs[q], skip_exact=skip)
             if rows is None:

@@ -67,7 +67,8 @@ def parse():
     ap.add_argument("--no-quad", action="store_true", help="hit_count with one wave per (query, tile) (RTX_OPT_HIT_QUAD = 0)")
     ap.add_argument("--no-pair", action="store_true", help="hit_count with one query per wave (RTX_OPT_HIT_PAIR = 0; A/B measurements)")
     ap.add_argument("--no-locator", action="store_true", help="processing order by min-hash alone (RTX_OPT_LOCATOR = 0; A/B measurements)")
-    ap.add_argument("--tile-prune", action="store_true", help="hit_count visits only the tiles that can hold a reference with any probability (RTX_OPT_TILE_PRUNE = 1)")
+    ap.add_argument("--no-tile-prune", action="store_true", help="hit_count counts every tile of 8192 references (RTX_OPT_TILE_PRUNE = 0; default: only the tiles that can hold a reference with any probability)")
+    ap.add_argument("--tile-prune", action="store_true", help="(the default; kept for older command lines)")
     ap.add_argument("--no-tile-skip", action="store_true", help="taxon_prefix sums every reference (RTX_OPT_TILE_SKIP = 0; A/B measurements)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--skip-exact-matches", action="store_true")
@@ -247,8 +248,10 @@ def measured_traffic(refs: int, query_len: int, sub_batch: int):
         return None, f"profiles/traffic.json unreadable: {ex}"
 
 
-def roofline_block(args, work, prob_work, stage_ms, stage_n, n_queries_step, query_len):
-    """Roofline of the dominant kernel, hit_count, per launch (one launch = one sub-batch)."""
+def roofline_block(args, work, prob_work, stage_ms, stage_n, n_queries_step, query_len, prune=None, ntiles=None):
+    """Roofline of the dominant kernel, hit_count, per launch (one launch = one sub-batch).  With tile pruning the launch
+    is the counting of the live tiles (the bounds pass before it -- the same kernel on the union bitmap + prune_kernel -- is
+    timed as a stage of its own and reported under "tile_pruning")."""
     n_launch = max(stage_n["hit_count"], 1)
     launch_ms = stage_ms["hit_count"] / n_launch
     launches_per_step = n_launch / args.steps
@@ -274,6 +277,15 @@ def roofline_block(args, work, prob_work, stage_ms, stage_n, n_queries_step, que
         "algorithmic_ratio_to_hbm_peak": alg_gbs / HBM_PEAK_GBS,
         "traffic": None, "hbm_achieved": None, "hbm_peak": HBM_PEAK_GBS, "hbm_frac": None,
     }
+    if prune is not None and prune.get("pairs"):
+        b_n = max(stage_n.get("tile_bounds", 0), 1)
+        out["tile_pruning"] = {
+            "live_tiles_per_pair": prune["live_tiles_per_pair"], "tiles": ntiles,
+            "mean_threshold": prune["mean_threshold"], "mean_best_hit_lower_bound": prune["mean_best_hit_lower_bound"],
+            "bounds_launch_ms": stage_ms.get("tile_bounds", 0.0) / b_n,
+            "note": "requested bytes and launch_ms are of the live (pair, tile) blocks only; a pruned query's references with "
+                    "a count up to its threshold carry < 1e-12 of probability together (rtx_prune.hip); --no-tile-prune counts every tile",
+        }
     if tr is not None:
         out["traffic"] = tr["per_query"] * q_per_launch                  # HBM/fabric bytes per launch (PMC)
         out["hbm_achieved"] = out["traffic"] / sec / 1e9
@@ -381,7 +393,7 @@ def main():
                          stage_timing=not args.hit_events_only, cluster=False if args.no_cluster else None,
                          packed_counts=False if args.u16_counts else None, hit_quad=False if args.no_quad else None,
                          tile_skip=False if args.no_tile_skip else None, hit_pair=False if args.no_pair else None,
-                         locator=False if args.no_locator else None, tile_prune=True if args.tile_prune else None)
+                         locator=False if args.no_locator else None, tile_prune=False if args.no_tile_prune else None)
         t0 = time.perf_counter()
         ex_ids, ex_off = index.exact_matches(qs.bases, qs.base_off)   # Tree.sequences.get, raxtax.rs:42 (host)
         t_exact = time.perf_counter() - t0
@@ -457,6 +469,7 @@ def main():
 
     work = index.work()
     prob_work = index.prob_work()
+    prune_stats = index.debug_prune_stats() if hasattr(index, "debug_prune_stats") else None   # of the last step (all zero: not pruned)
     ok = int((np.ctypeslib.as_array(view.status, shape=(args.queries,)) == 0).sum())
     if rank == 0:
         line = {
@@ -483,7 +496,8 @@ def main():
                 "sub_batch": int(round(args.queries / max(stage_n["hit_count"] / args.steps, 1))) if stage_n["hit_count"] else None,
                 "untimed_host_exact_match_lookup_s": round(t_exact, 3),
             },
-            "roofline": roofline_block(args, work, prob_work, stage_ms, stage_n, args.queries, L),
+            "roofline": roofline_block(args, work, prob_work, stage_ms, stage_n, args.queries, L, prune=prune_stats,
+                                       ntiles=(args.refs + 8191) // 8192),
             "stage_ms_per_step": {s: stage_ms[s] / args.steps for s in stage_ms},
         }
         if not args.no_cpu_baseline and world == 1:      # reported baseline: rank 0 at N = 1 only

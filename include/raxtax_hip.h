@@ -210,11 +210,14 @@ int rtx_index_set_batch(rtx_index *index, uint32_t sub_batch);
                             * _from_tree) the processing order of RTX_OPT_CLUSTER is led by the query's position in the
                             * lineage-ordered database (a vote of its 12-mers in a table built from the references), the
                             * min-hashes only break ties; 0: min-hash order alone.  Scheduling only: results are identical */
-#define RTX_OPT_TILE_PRUNE 13 /* 0 (default): hit_count counts every tile of 8192 references; 1: only the tiles that can hold a
-                               * reference with any probability -- decided from upper bounds (the queries counted against a union
-                               * bitmap over blocks of 32 references) and a threshold that keeps every probability within 1e-11
-                               * of the full count (rtx_prune.hip).  Needs t <= 1023, RTX_OPT_HIT_PAIR = 1, RTX_OPT_TILE_SKIP = 1 and a
-                               * database of 8 tiles or more; the debug taps recount the tapped sub-batch in full */
+#define RTX_OPT_TILE_PRUNE 13 /* 1 (default): hit_count counts only the tiles of 8192 references that can hold a reference with any
+                               * probability -- decided from upper bounds (the queries counted against a union bitmap over blocks
+                               * of 32 references) and a per-query threshold u: the references with a count up to u hold less
+                               * than 1e-12 of probability together and are treated as references without a hit (rtx_prune.hip;
+                               * every probability and confidence sum stays within 1e-11 of the full count, the result of a
+                               * query does not depend on the rest of the batch).  Takes effect with t <= 1023,
+                               * RTX_OPT_HIT_PAIR = 1, RTX_OPT_TILE_SKIP = 1, the whole database on the handle and 8 tiles or more;
+                               * the debug taps recount the tapped sub-batch in full.  0: every tile is counted */
 int rtx_index_set_option(rtx_index *index, int option, uint64_t value);
 /* Process-wide default for handles created afterwards.  RTX_DEFAULT_SEGMENT_CLASSES (default 1): at index creation
  * every (row, tile) segment of the bitmaps is classified; empty segments are never read and segments with at most
@@ -301,7 +304,8 @@ int rtx_index_stream(rtx_index *index, void **hip_stream);
 #define RTX_STAGE_PROB_TABLE 2
 #define RTX_STAGE_TAXON_PREFIX 3
 #define RTX_STAGE_LINEAGE_WALK 4
-#define RTX_NUM_STAGES 5
+#define RTX_STAGE_TILE_BOUNDS 5 /* tile pruning (RTX_OPT_TILE_PRUNE): the queries against the union bitmap + prune_kernel; 0 launches if the run did not prune */
+#define RTX_NUM_STAGES 6
 int rtx_batch_stage_times(rtx_index *index, float ms[RTX_NUM_STAGES], uint32_t launches[RTX_NUM_STAGES]);
 /* Algorithmic work of the last rtx_batch_run: sum over queries of
  * H_q = sum_r count_q[r] (postings touched) and of L_q (query bytes), and the bitmap

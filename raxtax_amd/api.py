@@ -292,8 +292,8 @@ class Index:
         return Result(self._view) if copy else self._view
 
     def stage_times(self):
-        ms = (C.c_float * 5)()
-        n = (C.c_uint32 * 5)()
+        ms = (C.c_float * len(_lib.STAGES))()
+        n = (C.c_uint32 * len(_lib.STAGES))()
         check(self._lib.rtx_batch_stage_times(self._h, ms, n))
         return {s: (float(ms[i]), int(n[i])) for i, s in enumerate(_lib.STAGES)}
 

@@ -164,7 +164,7 @@ struct rtx_index {
     uint32_t tile_skip = 1;   // RTX_OPT_TILE_SKIP: taxon_prefix reads only the tiles that hold a reference with p >= 1e-30
     bool quad_used = false;   // the last run went through hit_count_quad_kernel
     uint32_t pair_opt = 1;    // RTX_OPT_HIT_PAIR
-    uint32_t prune_opt = 0;   // RTX_OPT_TILE_PRUNE: hit_count visits only the tiles that can hold a reference with any probability (rtx_prune.hip)
+    uint32_t prune_opt = 1;   // RTX_OPT_TILE_PRUNE: hit_count visits only the tiles that can hold a reference with any probability (rtx_prune.hip)
     bool prune_used = false;  // the last run pruned
     bool dbg_full = false;    // ... and the debug taps have recounted the last sub-batch in full since
     bool dbg_full_run = false;  // (the recount in progress: enqueue_hit leaves the pruning out)
@@ -408,11 +408,12 @@ int enqueue_hit(rtx_index *ix, const SubBatch &b, uint32_t flags, hipStream_t s)
         hp.flags_prune = emu && launches >= 2 ? 1u : 0u;
         launches++;
     }
-    if (b.timed) RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_HIT_COUNT, 0), s));
     hp.live = nullptr;
     hp.live_words = 0;
+    const bool prune = ix->prune_used && !ix->dbg_full_run;
+    if (b.timed) RTX_HIP(hipEventRecord(stage_event(ix, b, prune ? RTX_STAGE_TILE_BOUNDS : RTX_STAGE_HIT_COUNT, 0), s));
     if (ix->pair_used) launch_pair_union(s, sc.d_rows.p, sc.d_nrows.p, ix->rstride, b.nq, sc.d_urec.p, sc.d_nu.p, 2u * ix->rstride);
-    if (ix->prune_used && !ix->dbg_full_run) {
+    if (prune) {
         // (1) the queries against the union bitmap: every row dense, no lists, u16 counts (bounds per block of references)
         HitParams up = hp;
         up.bitmap = ix->d_ubitmap.p;
@@ -467,6 +468,10 @@ int enqueue_hit(rtx_index *ix, const SubBatch &b, uint32_t flags, hipStream_t s)
         RTX_HIP(hipMemsetAsync(sc.d_tilemax.p, 0, (size_t)b.nq * ix->ntiles * 2, s));
         hp.live = sc.d_live.p;
         hp.live_words = pr.live_words;
+        if (b.timed) {
+            RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_TILE_BOUNDS, 1), s));
+            RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_HIT_COUNT, 0), s));
+        }
     }
     if (ix->pair_used) {
         launch_hit_count_pair(s, hp, b.nq, ix->ntiles, ix->pair_variant);
@@ -502,6 +507,7 @@ int enqueue_prob_prefix(rtx_index *ix, const SubBatch &b, bool fuse_walk, bool p
     pp.gs = ix->d_gs.p;
     pp.status = ix->d_status.p;
     pp.ndist = ix->d_ndist.p;
+    pp.prune_thr = ix->prune_used && !ix->dbg_full_run ? sc.d_prune_thr.p : nullptr;
     if (b.timed_all) RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_PROB_TABLE, 0), s));
     if (ix->use_tables) {
         ProbTables tb{ix->d_tab_cmf.p, ix->d_tab_ratio.p, ix->d_tab_off.p, ix->d_tab_moff.p,
@@ -1795,7 +1801,7 @@ int rtx_batch_stage_times(rtx_index *ix, float ms[RTX_NUM_STAGES], uint32_t laun
     for (int s = 0; s < RTX_NUM_STAGES; s++) { ms[s] = 0.f; launches[s] = 0; }
     for (uint32_t sb = 0; sb < ix->n_sub_last; sb++)
         for (int s = 0; s < RTX_NUM_STAGES; s++) {
-            if (s != RTX_STAGE_HIT_COUNT && !ix->stage_timing) continue;  // events were not recorded
+            if (s == RTX_STAGE_TILE_BOUNDS ? !ix->prune_used : (s != RTX_STAGE_HIT_COUNT && !ix->stage_timing)) continue;  // events were not recorded
             float t = 0.f;
             RTX_HIP(hipEventElapsedTime(&t, ix->events[((size_t)sb * RTX_NUM_STAGES + s) * 2],
                                         ix->events[((size_t)sb * RTX_NUM_STAGES + s) * 2 + 1]));

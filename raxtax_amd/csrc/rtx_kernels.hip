@@ -1114,10 +1114,11 @@ __global__ __launch_bounds__(NW * 64) void taxon_prefix_kernel(PrefixParams p) {
         rank_next = rank_l;
     };
     const uint16_t *__restrict__ tmx = p.tile_max ? p.tile_max + (size_t)q * p.ntiles : nullptr;
-    // a query that tile pruning gave a threshold: the tiles hit_count left out keep a largest count of 0 and hold stale counts;
-    // they (and the counted tiles without a hit) stay out of the sweep even if the probability of count 0 reaches kLiveEps --
-    // it is below 1e-12 / n_refs for such a query (rtx_prune.hip)
-    const uint32_t m_live = p.prune_thr && p.prune_thr[q] && s_mlive == 0u ? 1u : s_mlive;
+    // a query that tile pruning gave a threshold u: every count up to u has probability 0 (prob_lookup), so a tile whose largest
+    // count is at most u stays out -- among them the tiles hit_count left out, which keep a largest count of 0 and hold stale
+    // counts (entries of absent counts in table_z may hold anything: the bound is enforced here, not read from the table)
+    const uint32_t u_thr = p.prune_thr ? p.prune_thr[q] : 0u;
+    const uint32_t m_live = u_thr && s_mlive <= u_thr ? u_thr + 1u : s_mlive;
     const uint32_t ntiles = (n + 8191u) >> 13;
     unsigned long long live_mask = ~0ull;  // liveness of the 64 tiles of group live_group (wave-uniform, the same in every wave)
     uint32_t live_group = 0xFFFFFFFFu;

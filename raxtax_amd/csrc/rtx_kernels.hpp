@@ -183,6 +183,7 @@ struct ProbParams {
     double *gs;       // [n_q]
     uint8_t *status;  // [n_q]
     uint32_t *ndist;  // [n_q] number of distinct hit counts D_q (work accounting)
+    const uint16_t *prune_thr;  // [B] tile pruning: references with a count up to this carry nothing (rtx_prune.hip) or null
 };
 
 struct WalkParams {

@@ -107,6 +107,21 @@ __global__ __launch_bounds__(256) void prob_lookup_kernel(ProbParams p, ProbTabl
     }
     for (uint32_t m = tid; m <= t; m += 256) hl[m] = hist[m];  // one coalesced round instead of a chain of loads
     __syncthreads();
+    // Tile pruning gave the query a threshold u: the references with a count up to u hold less than 1e-12 of probability
+    // together and move no product by more than that (rtx_prune.hip).  They all become references without a hit (cmf = 1,
+    // probability 0) -- those of the tiles that were not counted already sit in bin 0 -- so that the result does not depend on
+    // which of them happened to be counted (a tile is counted if EITHER query of its pair needs it).
+    const uint32_t u_thr = p.prune_thr ? p.prune_thr[q] : 0u;
+    if (u_thr) {  // workgroup-uniform
+        uint32_t low = 0;
+        for (uint32_t m = 1u + tid; m <= u_thr && m <= t; m += 256) {
+            low += hl[m];
+            hl[m] = 0;
+            tz[m] = 0.0;  // taxon_prefix looks these up for the references that were counted
+        }
+        if (low) atomicAdd(&hl[0], low);
+        __syncthreads();
+    }
     if (wave == 0) {  // distinct counts, ascending
         uint32_t D = 0;
         for (uint32_t m0 = 0; m0 <= t; m0 += 64) {
@@ -267,7 +282,7 @@ __global__ __launch_bounds__(256) void prob_lookup_kernel(ProbParams p, ProbTabl
                 if (m != 0) tz[m] = v;
             }
         }
-        if (tid == 0 && ms[0] == 0) tz[0] = i_lo == 0 ? Pi[0] : 0.0;  // m = 0: table[0] = P(0)
+        if (tid == 0 && ms[0] == 0) tz[0] = i_lo == 0 && u_thr == 0u ? Pi[0] : 0.0;  // m = 0: table[0] = P(0)
     }
     __syncthreads();
     // Z = probs_sum (prob.rs:97) grouped by count value; fixed reduction order

@@ -23,9 +23,10 @@ def cfg2(oracle):
     index = rx.Index(tree)
     ex_ids, ex_off = index.exact_matches(qs.bases, qs.base_off)
     res = index.classify(qs.bases, qs.base_off, ex_ids, ex_off)
+    prune_stats = index.debug_prune_stats()
     otree = oracle.tree_new_flat(db.lineages, db.seq_bytes, db.seq_off)
     sample = np.sort(np.random.default_rng(20260).choice(N_Q, N_SAMPLE, replace=False))
-    return dict(db=db, qs=qs, tree=tree, index=index, res=res, ex=(ex_ids, ex_off), otree=otree, sample=sample)
+    return dict(db=db, qs=qs, tree=tree, index=index, res=res, prune_stats=prune_stats, ex=(ex_ids, ex_off), otree=otree, sample=sample)
 
 
 def test_every_query_is_classified(cfg2):
@@ -68,18 +69,19 @@ def test_seeded_oracle_sample(cfg2, oracle, skip):
     ex.check()
 
 
-def test_seeded_oracle_sample_with_tile_pruning(cfg2, oracle):
-    """The same sample through RTX_OPT_TILE_PRUNE (hit_count visits only the tiles that can matter, rtx_prune.hip): rows
-    identical to the oracle's, and to those of the full count inside the big batch; the taps recount in full, so hit counts
-    stay bit-exact and the probabilities within 1e-9."""
+def test_tile_pruning_is_at_work_and_changes_no_row(cfg2, oracle):
+    """The fixture's handle prunes (RTX_OPT_TILE_PRUNE is the default: hit_count visits only the tiles that can matter,
+    rtx_prune.hip) and no bound was violated; the same sample through a handle that counts EVERY tile: rows identical to the
+    oracle's, and the rows of the pruned big batch equal them (confidences within 1e-9)."""
     c = cfg2
-    index = rx.Index(c["tree"], tile_prune=True)
-    ex = Excuses(f"config2/sample{N_SAMPLE}/tile_prune")
+    st = c["prune_stats"]
+    print("tile pruning of the full batch:", st)
+    assert st["pairs"] > 0 and st["bound_violations"] == 0 and st["live_tiles_per_pair"] < 0.5 * ((N_REFS + 8191) // 8192), st
+    index = rx.Index(c["tree"], tile_prune=False)
+    ex = Excuses(f"config2/sample{N_SAMPLE}/no_tile_prune")
     res = oracle_sample_parity(index, oracle, c["otree"], c["db"], c["qs"], c["sample"], False, ex, full_res=None)
-    st = index.debug_prune_stats()      # of the recount-free run? the taps re-ran the count without pruning: stats are of the classify call
-    print("tile pruning on the sample:", st)
-    assert st["bound_violations"] == 0
-    for j in range(0, N_SAMPLE, 7):
+    assert index.debug_prune_stats()["pairs"] == 0
+    for j in range(0, N_SAMPLE, 3):
         x, y = rows_of(res, j), rows_of(c["res"], int(c["sample"][j]))
         assert np.array_equal(x[0], y[0]) and np.allclose(x[1], y[1], rtol=0, atol=1e-9), int(c["sample"][j])
     ex.check()

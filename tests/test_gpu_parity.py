@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 import raxtax_amd as rx
-from gpu_common import Excuses
+from gpu_common import Excuses, rows_of
 from raxtax_amd import synth
 from raxtax_amd.api import DEFAULT_SEGMENT_CLASSES
 
@@ -374,7 +374,7 @@ def test_pair_kernel_many_tiles(oracle, n_refs, variant):
     qs = synth.make_queries(db, 201, exact_frac=0.2)
     otree = oracle.tree_new_flat(db.lineages, db.seq_bytes, db.seq_off)
     tree = rx.Tree.new_flat(db.lineages, db.seq_bytes, db.seq_off)
-    a, b = rx.Index(tree, hit_pair=False), rx.Index(tree, hit_pair=variant)
+    a, b = rx.Index(tree, hit_pair=False), rx.Index(tree, hit_pair=variant, tile_prune=False)   # kernel against kernel, every tile counted
     ex = a.exact_matches(qs.bases, qs.base_off)
     for skip in (False, True):
         ra = a.classify(qs.bases, qs.base_off, *ex, skip_exact_matches=skip)
@@ -832,7 +832,7 @@ def test_tile_skip_changes_nothing_visible(oracle, n_refs):
     bases = np.concatenate(seqs)
     tree = rx.Tree.new_flat(db.lineages, db.seq_bytes, db.seq_off)
     for kw in (dict(), dict(packed_counts=False), dict(sub_batch=50)):
-        a, b = rx.Index(tree, tile_skip=True, **kw), rx.Index(tree, tile_skip=False, **kw)
+        a, b = rx.Index(tree, tile_skip=True, tile_prune=False, **kw), rx.Index(tree, tile_skip=False, **kw)   # the sweep alone: hit_count counts every tile
         ex = a.exact_matches(bases, off)
         for skip in (False, True):
             ra = a.classify(bases, off, *ex, skip_exact_matches=skip)
@@ -1140,6 +1140,16 @@ def test_tile_pruning_changes_nothing_visible(oracle, kmer_map):
         assert np.allclose(ra.row_conf, rb.row_conf, rtol=0, atol=1e-9)
         assert np.allclose(ra.global_signal, rb.global_signal, rtol=0, atol=1e-12)
         assert np.allclose(ra.row_local_signal, rb.row_local_signal, rtol=0, atol=1e-9)
+        if not skip:    # a pruned result does not depend on the rest of the batch (other neighbours, other pairs): bit for bit
+            order = np.random.default_rng(5).permutation(len(seqs))
+            off2 = np.zeros(len(seqs) + 1, np.uint64)
+            off2[1:] = np.cumsum([len(seqs[i]) for i in order])
+            rc = b.classify(np.concatenate([seqs[i] for i in order]), off2, *b.exact_matches(np.concatenate([seqs[i] for i in order]), off2))
+            for pos in range(0, len(seqs), 3):
+                x, y = rows_of(rb, int(order[pos])), rows_of(rc, pos)
+                assert all(np.array_equal(u, v) for u, v in zip(x, y)), int(order[pos])
+                assert rb.global_signal[int(order[pos])] == rc.global_signal[pos]
+            rb = b.classify(bases, off, *ex, skip_exact_matches=skip)     # the taps below are of this batch
         for q in list(range(0, qs.n, 40)) + list(range(qs.n, n_strong)) + list(range(n_strong, len(seqs), 5)):
             rows, _ = _oracle_rows(otree, seqs[q], skip)
             t, counts = otree.hit_counts(seqs[q], skip_exact=skip)

@@ -319,7 +319,7 @@ hipEvent_t stage_event(rtx_index *ix, const SubBatch &b, int stage, int which) {
 }
 
 // group 1: kmer_extract + hit_count -> counts, per-shard histogram
-int enqueue_kmer(rtx_index *ix, const SubBatch &b, hipStream_t s) {
+static KmerParams kmer_params(rtx_index *ix, const SubBatch &b) {
     rtx_index::Scratch &sc = ix->sc[b.set];
     KmerParams kp{};
     kp.bases = ix->d_bases.p;
@@ -355,6 +355,14 @@ int enqueue_kmer(rtx_index *ix, const SubBatch &b, hipStream_t s) {
     kp.nrows_all = ix->d_nrows_all.p;
     kp.hist = sc.d_hist.p;  // zeroed by kmer_extract for hit_count's global atomics
     kp.hstride = ix->hstride;
+    return kp;
+}
+
+int enqueue_kmer(rtx_index *ix, const SubBatch &b, hipStream_t s) {
+    KmerParams kp = kmer_params(ix, b);
+    // with tile pruning the per-tile lists wait until the live tiles are known (enqueue_hit); databases of few tiles build
+    // their lists in one pass per tile whatever is live
+    kp.mode = ix->prune_used && !ix->dbg_full_run && ix->seg_blocks ? 1u : 0u;
     if (b.timed_all) RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_KMER_EXTRACT, 0), s));
     launch_kmer_extract(s, kp, b.nq);
     if (b.timed_all) RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_KMER_EXTRACT, 1), s));
@@ -468,6 +476,13 @@ int enqueue_hit(rtx_index *ix, const SubBatch &b, uint32_t flags, hipStream_t s)
         RTX_HIP(hipMemsetAsync(sc.d_tilemax.p, 0, (size_t)b.nq * ix->ntiles * 2, s));
         hp.live = sc.d_live.p;
         hp.live_words = pr.live_words;
+        if (ix->seg_blocks) {  // (4) the row lists of the live tiles (kmer_extract left them out)
+            KmerParams kp = kmer_params(ix, b);
+            kp.mode = 2u;
+            kp.live = sc.d_live.p;
+            kp.live_words = pr.live_words;
+            launch_kmer_extract(s, kp, b.nq);
+        }
         if (b.timed) {
             RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_TILE_BOUNDS, 1), s));
             RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_HIT_COUNT, 0), s));

@@ -157,6 +157,15 @@ __global__ __launch_bounds__(64) void kmer_extract_kernel(KmerParams p) {
     const uint64_t len = p.base_off[qin + 1] - b0;
     const uint8_t *seq = p.bases + b0;
 
+    // p.mode: 0 = everything; 1 = the k-mers and the row list only; 2 = the per-tile lists only, for the tiles tile pruning
+    // left alive (the launch of mode 1 has left the row list; rtx_prune.hip decides between the two)
+    uint32_t t = 0, nrows = 0;
+    unsigned long long hq = 0;
+    uint32_t *rout = p.rows + (size_t)q * p.rstride;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    if (p.mode == 2u) {
+        nrows = p.nrows[q];
+    } else {
     for (uint32_t i = lane; i < 2048; i += 64) bm[i] = 0;
     {  // the histogram row hit_count accumulates into with global atomics
         uint32_t *h = p.hist + (size_t)q * p.hstride;
@@ -210,16 +219,12 @@ __global__ __launch_bounds__(64) void kmer_extract_kernel(KmerParams p) {
         }
         base += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
     }
-    const uint32_t t = base;
+    t = base;
     __syncthreads();  // kout visible to the whole wave
     KMER_MARK(2)
 
     // rows of the k-mers present in the index, in ascending k-mer order (the query's row list, shared by all tiles)
-    uint32_t *rout = p.rows + (size_t)q * p.rstride;
-    uint32_t nrows = 0;
-    unsigned long long hq = 0;
     const uint32_t tt = t < p.kstride ? t : p.kstride;
-    const unsigned long long lt_mask = (1ull << lane) - 1ull;
     // Four chunks of 64 k-mers per turn, all loads of a level issued together: on gfx9 loads and stores share one
     // in-order counter, so every wait for a load also waits for the stores before it -- a chunk-by-chunk loop
     // (load, gather, store) pays two full round trips per chunk.
@@ -247,10 +252,18 @@ __global__ __launch_bounds__(64) void kmer_extract_kernel(KmerParams p) {
             nrows += (uint32_t)__popcll(m);
         }
     }
-    const uint32_t nchunks = (nrows + 63u) >> 6;
-    for (uint32_t i = nrows + lane; i < nchunks * 64u; i += 64) rout[i] = p.zero_row;
+    for (uint32_t i = nrows + lane; i < ((nrows + 63u) & ~63u); i += 64) rout[i] = p.zero_row;
     __syncthreads();  // rout visible to the whole wave
     KMER_MARK(3)
+    }  // p.mode != 2
+    if (p.mode == 1u) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) hq += __shfl_xor(hq, d, 64);
+        if (lane == 0) { p.t[q] = t; p.nrows[q] = nrows; p.hq[gq] = hq; p.t_all[gq] = t; }
+        return;
+    }
+    const uint32_t nchunks = (nrows + 63u) >> 6;
+    const uint32_t *live = p.mode == 2u ? p.live + (size_t)(q >> 1) * p.live_words : nullptr;  // of the query's pair
     // Per tile: which rows have a dense segment there (a 64-bit mask per 64 rows), and the slots of the sparse
     // segments; empty segments are dropped (rtx_segments.hip).
     const uint32_t nt = p.ntiles;
@@ -264,6 +277,8 @@ __global__ __launch_bounds__(64) void kmer_extract_kernel(KmerParams p) {
     for (uint32_t tb = 0; p.seg_blocks && tb < nt; tb += 64) {  // many tiles: 64 rows x 64 tiles per step
         const uint32_t blk = tb >> 6;
         const uint32_t tile = tb + lane;  // this lane's tile after the transposes
+        // a tile that is not counted for this query's pair needs no lists (the transposes still take every lane)
+        const bool tlive = tile < nt && (!live || ((live[tile >> 5] >> (tile & 31u)) & 1u));
         uint32_t cd = 0, cs = 0, cm = 0;
         uint4 pend = make_uint4(0, 0, 0, 0);  // slot ids of this lane's tile waiting for their 16-byte store
         // the class tables of four chunks of 64 rows are gathered together (one round trip per four chunks, not one each)
@@ -300,7 +315,7 @@ __global__ __launch_bounds__(64) void kmer_extract_kernel(KmerParams p) {
             unsigned long long dT = transpose64(db, lane), sT = transpose64(sb, lane);  // bit r = row c*64 + r
             unsigned long long mT = p.seg_mbits ? transpose64(mb, lane) : 0ull;
             __syncthreads();
-            if (tile < nt) {
+            if (tlive) {
                 // the first sparse rows go to the slot list (the byte counters of hit_count hold 255 hits: at most
                 // kSegMaxListRows sparse + mid segments together) ...
                 // (four slot ids per 16-byte store: every lane writes to a list of its own, so each store is a memory
@@ -332,7 +347,7 @@ __global__ __launch_bounds__(64) void kmer_extract_kernel(KmerParams p) {
             }
             __syncthreads();
         }
-        if (tile < nt) {
+        if (tlive) {
             // the last, incomplete group of four (the entries behind cs are never used: the lists have 256 entries)
             if (cs & 3u) *reinterpret_cast<uint4 *>(sout + (size_t)tile * (kSegMaxSparseRows + 1) + (cs & ~3u)) = pend;
             p.nsparse[(size_t)q * nt + tile] = cs;
@@ -407,10 +422,12 @@ __global__ __launch_bounds__(64) void kmer_extract_kernel(KmerParams p) {
     hq = st_acc;
 #endif
     if (lane == 0) {
-        p.t[q] = t;
-        p.nrows[q] = nrows;
-        p.hq[gq] = hq;
-        p.t_all[gq] = t;
+        if (p.mode != 2u) {
+            p.t[q] = t;
+            p.nrows[q] = nrows;
+            p.hq[gq] = hq;
+            p.t_all[gq] = t;
+        }
         p.nrows_all[gq] = nseg;
         p.nmid_all[gq] = nmidseg;
     }

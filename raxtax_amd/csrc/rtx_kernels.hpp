@@ -75,6 +75,9 @@ struct KmerParams {
     uint32_t *nrows_all;     // [n_q]
     uint32_t *hist;          // [B][hstride] zeroed here
     uint32_t hstride;
+    uint32_t mode;           // 0: everything; 1: k-mers and row list; 2: the per-tile lists of the live tiles (after a launch with 1)
+    const uint32_t *live;    // mode 2: [pairs][live_words] (rtx_prune.hip)
+    uint32_t live_words;
 };
 
 struct HitParams {

@@ -282,6 +282,8 @@ def roofline_block(args, work, prob_work, stage_ms, stage_n, n_queries_step, que
         out["tile_pruning"] = {
             "live_tiles_per_pair": prune["live_tiles_per_pair"], "tiles": ntiles,
             "mean_threshold": prune["mean_threshold"], "mean_best_hit_lower_bound": prune["mean_best_hit_lower_bound"],
+            "tiles_above_threshold_per_query": prune.get("tiles_above_threshold_per_query"),     # what exact knowledge would count
+            "queries_with_threshold": prune.get("queries_with_threshold"),
             "bounds_launch_ms": stage_ms.get("tile_bounds", 0.0) / b_n,
             "note": "requested bytes and launch_ms are of the live (pair, tile) blocks only; a pruned query's references with "
                     "a count up to its threshold carry < 1e-12 of probability together (rtx_prune.hip); --no-tile-prune counts every tile",

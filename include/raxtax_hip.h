@@ -329,8 +329,10 @@ int rtx_debug_probs(rtx_index *index, uint64_t query, double *probs /*n_refs*/);
 /* processing order of the last run (RTX_OPT_CLUSTER / RTX_OPT_LOCATOR): perm[position] = query */
 int rtx_debug_order(rtx_index *index, uint32_t *perm /*n_queries*/);
 /* tile pruning of the last run (RTX_OPT_TILE_PRUNE): out[0] live (pair, tile) blocks, [1] pairs, [2] sum of the lower bounds of the
- * best hit, [3] sum of the thresholds, [4] sum of the largest tile bounds, [5] queries; all 0 if the run did not prune */
-int rtx_debug_prune_stats(rtx_index *index, uint64_t *out /*8*/);
+ * best hit, [3] sum of the thresholds, [4] sum of the largest tile bounds, [5] queries, [6] bounds below a count they bound (must be
+ * 0), [7] debug builds only, [8] (query, tile) combinations with a count above the query's threshold -- what exact knowledge would
+ * have counted --, [9] queries with a threshold; all 0 if the run did not prune */
+int rtx_debug_prune_stats(rtx_index *index, uint64_t *out /*10*/);
 /* Lineage::new(label, tree, probs).evaluate() (src/lineage.rs:61-112) on a caller-supplied
  * probability vector: runs taxon_prefix + lineage_walk + the host finalisation for one
  * pseudo-query.  Lets the reference's lineage KATs pin the device walk.  Small trees only

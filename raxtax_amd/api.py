@@ -350,11 +350,12 @@ class Index:
 
     def debug_prune_stats(self) -> dict:
         """Tile pruning of the last run: live tiles per pair, mean lower bound of the best hit, mean threshold, mean largest tile bound."""
-        out = np.zeros(8, dtype=np.uint64)
+        out = np.zeros(10, dtype=np.uint64)
         check(self._lib.rtx_debug_prune_stats(self._h, ptr(out, u64p)))
         pairs, nq = max(int(out[1]), 1), max(int(out[5]), 1)
         return {"live_tiles_per_pair": int(out[0]) / pairs, "pairs": int(out[1]), "mean_best_hit_lower_bound": int(out[2]) / nq,
-                "mean_threshold": int(out[3]) / nq, "mean_largest_tile_bound": int(out[4]) / nq, "bound_violations": int(out[6]), "recount_mismatches": int(out[7])}
+                "mean_threshold": int(out[3]) / nq, "mean_largest_tile_bound": int(out[4]) / nq, "bound_violations": int(out[6]), "recount_mismatches": int(out[7]),
+                "tiles_above_threshold_per_query": int(out[8]) / max(int(out[9]), 1), "queries_with_threshold": int(out[9])}
 
     def debug_evaluate(self, probs) -> Result:
         """Lineage::new(label, tree, probs).evaluate() on the device (lineage.rs:61-112)."""

@@ -556,6 +556,7 @@ int enqueue_prob_prefix(rtx_index *ix, const SubBatch &b, bool fuse_walk, bool p
     fp.tile_max = ix->tile_skip ? sc.d_tilemax.p : nullptr;
     fp.ntiles = ix->ntiles;
     fp.prune_thr = ix->prune_used && !ix->dbg_full_run ? sc.d_prune_thr.p : nullptr;
+    fp.prune_stats = fp.prune_thr ? ix->d_prune_stats.p + kPruneStatCopies * 8 : nullptr;
     fp.fuse_walk = fuse_walk ? 1u : 0u;
     if (fuse_walk) fp.walk = walk_params(ix, b, sc.d_prefix.p);
     if (b.timed_all) RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_TAXON_PREFIX, 0), s));
@@ -638,9 +639,9 @@ int begin_run(rtx_index *ix, uint32_t *n_sub_out, bool *timed_out, bool cluster)
                      ix->n_refs == ix->n_total && !ix->staged && ix->sc[0].d_ucounts.p != nullptr;
     ix->dbg_full = false;
     if (ix->prune_used) {
-        int rc_s = ix->d_prune_stats.alloc(kPruneStatCopies * 8);
+        int rc_s = ix->d_prune_stats.alloc(kPruneStatCopies * 16);
         if (rc_s) return rc_s;
-        RTX_HIP(hipMemsetAsync(ix->d_prune_stats.p, 0, kPruneStatCopies * 64, ix->stream));
+        RTX_HIP(hipMemsetAsync(ix->d_prune_stats.p, 0, kPruneStatCopies * 128, ix->stream));
     }
     // the sequential variant keeps every list of a (pair, tile) in one round: t <= kHitListCap - 64
     ix->pair_variant = ix->pair_used && ix->pair_opt == 2 && ix->tmax + 64u <= kHitListCap ? 2 : 1;
@@ -1663,6 +1664,22 @@ int rtx_batch_download(rtx_index *ix, rtx_result_view *out) {
         RTX_HIP(hipStreamSynchronize(ix->stream));
         nrows = finalise_mt(ix, 0, nq, 0, nq < 4096 ? 1 : 16);
     }
+    {   // the first download of a handle: the other result set (the two alternate, a view stays valid until the second-next
+        // download) is sized and touched now, so that the second batch does not pay for its page faults (60 ms at 1M queries)
+        rtx_index::HostRes &other = ix->host_res[ix->res_set ^ 1u];
+        if (other.h_t.empty() && other.v_row_lineage.empty()) {
+            other.h_t.resize(hr.h_t.size());
+            other.h_status.resize(hr.h_status.size());
+            other.h_gs.resize(hr.h_gs.size());
+            other.v_row_begin.resize(hr.v_row_begin.size());
+            other.v_row_count.resize(hr.v_row_count.size());
+            other.v_row_lineage.resize(hr.v_row_lineage.size());
+            other.v_row_node.resize(hr.v_row_node.size());
+            other.v_row_depth.resize(hr.v_row_depth.size());
+            other.v_row_conf.resize(hr.v_row_conf.size());
+            other.v_row_local.resize(hr.v_row_local.size());
+        }
+    }
     out->n_queries = (uint32_t)nq;
     out->n_rows = nrows;
     out->t = hr.h_t.data();
@@ -1962,13 +1979,15 @@ int rtx_debug_prob_table(rtx_index *ix, uint64_t query, double *table_over_z, do
 
 int rtx_debug_prune_stats(rtx_index *ix, uint64_t *out) {
     if (!ix || !out) { set_error("null argument"); return RTX_ERR_INVALID; }
-    std::memset(out, 0, 64);
+    std::memset(out, 0, 80);
     if (!ix->prune_used || !ix->d_prune_stats.p) return RTX_OK;
     RTX_HIP(hipStreamSynchronize(ix->stream));
-    unsigned long long h[kPruneStatCopies * 8];
+    unsigned long long h[kPruneStatCopies * 16];
     RTX_HIP(hipMemcpy(h, ix->d_prune_stats.p, sizeof(h), hipMemcpyDeviceToHost));
-    for (uint32_t c = 0; c < kPruneStatCopies; c++)
+    for (uint32_t c = 0; c < kPruneStatCopies; c++) {
         for (uint32_t k = 0; k < 8; k++) out[k] += h[c * 8 + k];
+        for (uint32_t k = 0; k < 2; k++) out[8 + k] += h[(kPruneStatCopies + c) * 8 + k];
+    }
     return RTX_OK;
 }
 

@@ -1136,6 +1136,11 @@ __global__ __launch_bounds__(NW * 64) void taxon_prefix_kernel(PrefixParams p) {
     // counts (entries of absent counts in table_z may hold anything: the bound is enforced here, not read from the table)
     const uint32_t u_thr = p.prune_thr ? p.prune_thr[q] : 0u;
     const uint32_t m_live = u_thr && s_mlive <= u_thr ? u_thr + 1u : s_mlive;
+    if (p.prune_stats && u_thr && wave == 0 && tmx) {  // reporting: how many tiles of this query hold a count above its threshold
+        uint32_t need = 0;
+        for (uint32_t T0 = 0; T0 < p.ntiles; T0 += 64) need += (uint32_t)__popcll(__ballot(T0 + lane < p.ntiles && (uint32_t)tmx[T0 + lane] > u_thr));
+        if (lane < 2u) atomicAdd(&p.prune_stats[(size_t)(q & (kPruneStatCopies - 1u)) * 8u + lane], lane == 0u ? (unsigned long long)need : 1ull);
+    }
     const uint32_t ntiles = (n + 8191u) >> 13;
     unsigned long long live_mask = ~0ull;  // liveness of the 64 tiles of group live_group (wave-uniform, the same in every wave)
     uint32_t live_group = 0xFFFFFFFFu;

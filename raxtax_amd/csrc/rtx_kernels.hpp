@@ -130,7 +130,7 @@ struct HitParams {
 };
 
 // tile pruning (rtx_prune.hip)
-constexpr uint32_t kPruneStatCopies = 64;  // PruneParams::stats: [copies][8], summed by the reader
+constexpr uint32_t kPruneStatCopies = 64;  // PruneParams::stats: [copies][8] (prune_kernel) + [copies][8] (taxon_prefix), summed by the reader
 constexpr uint32_t kPruneShift = 5;  // the union bitmap has one column per block of 32 references
 struct PruneParams {
     const uint8_t *ucounts_lo;   // [B][unpad] counts of the queries against the union bitmap (an upper bound per block of
@@ -223,6 +223,7 @@ struct PrefixParams {
     const uint16_t *tile_max;   // [B][ntiles] largest count per tile of 8192 references (hit_count) or null: every tile is swept
     uint32_t ntiles;
     const uint16_t *prune_thr;  // [B] tile pruning: threshold of the query (> 0: tiles with a largest count of 0 were not counted) or null
+    unsigned long long *prune_stats;  // reporting (second half of PruneParams::stats) or null
     uint32_t fuse_walk;         // wave 0 of every workgroup walks its query right after the sweeps (walk.prefix == prefix)
     WalkParams walk;
 };

@@ -8,22 +8,26 @@
 //     if ANY reference of the block contains k-mer k -- is counted like the database itself (hit_count_kernel on two
 //     tiles instead of 62); a block's count bounds the count of each of its references.  ub(T) = max over the blocks of
 //     tile T.
-//   * a lower bound M of the best hit: the exact count of one reference of the block with the largest bound.
+//   * the best hits: the exact counts of the references of the block with the largest bound (the query's nearest relatives:
+//     M = the largest of them, H = those with at least 0.8 M).
 //   * the threshold (prob.rs:49-90 restated): Z = sum_r table[m_r] >= 1, table[m_r] = sum_i pmf_{m_r}(i) prod_{r' != r}
-//     cmf_{m_r'}(i), cmf_m(i) falls with m.  (1) All of Z's mass at i <= i* is at most cmf_M(i*) (1 + N (i* + 1)) =: delta
-//     (the best reference's own term is at most its cmf, every other term carries the best reference's cmf as a factor).
-//     (2) For i > i* the references of skipped tiles (counts <= u) multiply prod by at least 1 - N tail_u(i*), and
+//     cmf_{m_r'}(i), cmf_m(i) falls with m.  G(i) = prod_{h in H} cmf_{m_h}(i).  (1) All of Z's mass at i <= i* is at most
+//     G(i*) (|H| + N (i* + 1)) =: delta: a term of a reference outside H carries every factor of G, and the terms of h in H
+//     sum to at most cmf_h(i*) G(i*) / cmf_h(i*).  (One reference alone, G = cmf_M, gives u = 230 on the bench workload where
+//     the product over the block gives 350 -- 4.1 against 1.1 tiles per query hold a count above it.)
+//     (2) For i > i* the references that are dropped (counts <= u) multiply prod by at least 1 - N tail_u(i*), and
 //     hold at most N tail_u(i*) of probability themselves; tail_u(i*) <= (n - i*) pmf_u(i* + 1) once pmf_u falls.
-//     i* = the largest i with delta <= eps, u = the largest count with N (n - i*) pmf_u(i* + 1) <= eps: every probability
-//     and every prefix sum of the pruned run is within a few eps of the full one.  eps = 1e-12 (north_star asks for 1e-6).
+//     i* = the largest i with delta <= eps, u = the largest count below min H with N (n - i*) pmf_u(i* + 1) <= eps (below
+//     min H: the members of H are never dropped, so (1) holds for the pruned run as well): every probability and every
+//     prefix sum of the pruned run is within a few eps of the full one.  eps = 1e-12 (north_star asks for 1e-6).
 //     With a full-overlap reference (M = t) prob.rs:24-41 applies: table[m] = pmf_m(n), table[t] = 1: u = the largest
 //     count with N pmf_u(n) <= eps.
 // A tile is dead for a query if u >= 1 and ub(T) <= u (a query without a threshold has every tile counted); a (pair, tile)
 // block of hit_count_pair_kernel leaves at once if the tile is dead for both queries.  The references that are never counted
 // are booked into histogram bin 0: cmf_0 = 1, so they drop out of every product -- the approximation bounded in (2) -- and
-// the probability of bin 0 itself is at most cmf_M(0) <= eps / N for a query with a threshold (part of delta).  Their
+// the probability of bin 0 itself is at most G(0) <= eps / N for a query with a threshold (part of delta).  Their
 // tiles keep a largest count of 0, and for such a query taxon_prefix leaves out every tile whose largest count is 0
-// (PrefixParams::prune_thr): what it drops there is again at most N cmf_M(0) <= eps.
+// (PrefixParams::prune_thr): what it drops there is again at most N G(0) <= eps.
 #include <hip/hip_runtime.h>
 
 #include "rtx_kernels.hpp"
@@ -105,6 +109,7 @@ __global__ __launch_bounds__(64) void prune_kernel(PruneParams p, ProbTables tb)
         // (ref_slot, rtx_math.hpp); lane l of a turn takes rows i0 + l and i0 + 64 + l and gathers those bytes, the hits of every
         // reference are summed in 16-bit halves (at most 16 rows per lane x 64 lanes).
         uint32_t M = 0;
+        uint32_t hm = 0;  // lane l < 2^kPruneShift: the exact count of reference l of the block (0: none, or zeroed)
         {
             constexpr uint32_t kChunks = (1u << kPruneShift) / 8u;  // 4 for blocks of 32
             const uint32_t nr = p.nrows[q];
@@ -160,6 +165,7 @@ __global__ __launch_bounds__(64) void prune_kernel(PruneParams p, ProbTables tb)
                     }
                     const uint32_t cnt = (acc[c][j >> 1] >> ((j & 1) * 16)) & 0xFFFFu;
                     if (ok && cnt > M) M = cnt;
+                    if (ok && lane == c * 8u + (uint32_t)j) hm = cnt;
                 }
             }
         }
@@ -192,18 +198,33 @@ __global__ __launch_bounds__(64) void prune_kernel(PruneParams p, ProbTables tb)
                     if (ln_binom_tab(lf, u + n - 1, n) - ln_total + ln_n <= kPruneLnEps) mine = u;
                 u_max = wave_max_u32p(mine);
             } else {
-                const double *lc = tb.cmf + tb.off[t] + (size_t)M * (n + 1);  // ln cmf_M(i)
+                // G(i) = prod over the counted references of the best block of cmf_m(i) (its members are the query's nearest
+                // relatives: the product falls far faster than cmf_M alone); lane l holds the row of reference l.  i* by
+                // bisection (G rises with i): the largest i <= n - 2 (a tail is left) with ln G(i) + ln(|H| + N (i + 1)) <= ln eps
+                const double *Ct = tb.cmf + tb.off[t];
+                if (hm * 5u < M * 4u) hm = 0u;  // H: the members close to the best one (the others would add next to nothing to G)
+                const double n_h = (double)__popcll(__ballot(hm != 0u));
+                const uint32_t h_min = 0xFFFFFFFFu - wave_max_u32p(hm ? 0xFFFFFFFFu - hm : 0u);  // <= M: H holds the best one
+                auto passes = [&](uint32_t i) -> bool {
+                    const double v = hm ? Ct[(size_t)hm * (n + 1) + i] : 0.0;  // ln cmf_m(i)
+                    return wave_sum_f64(v) + log(n_h + (double)p.n_refs * (double)(i + 1u)) <= kPruneLnEps;
+                };
                 uint32_t ist1 = 0;  // i* + 1 in the end (0: none)
-                for (uint32_t i = lane; i + 2u <= n; i += 64)  // i* <= n - 2: a tail is left
-                    if (lc[i] + log(1.0 + (double)p.n_refs * (double)(i + 1u)) <= kPruneLnEps) ist1 = i + 1u;
-                ist1 = wave_max_u32p(ist1);
+                if (passes(0u)) {
+                    uint32_t lo = 0, hi = n - 2u;
+                    while (lo < hi) {  // wave-uniform
+                        const uint32_t mid = (lo + hi + 1u) >> 1;
+                        if (passes(mid)) lo = mid; else hi = mid - 1u;
+                    }
+                    ist1 = lo + 1u;
+                }
                 if (ist1) {
                     const uint32_t i1 = ist1;  // = i* + 1: the first i that stays
                     const double ln_len = log((double)(n - i1 + 1u));
                     // the condition holds for a prefix of the counts (below its mode pmf_u(i1) rises with u); taken as the
                     // counts below the smallest one that fails, whatever rounding does to the largest one that passes
-                    uint32_t first_fail = M;  // counts from M on are never skipped
-                    for (uint32_t u = 1u + lane; u < M; u += 64) {
+                    uint32_t first_fail = h_min;  // counts from min H on are never dropped
+                    for (uint32_t u = 1u + lane; u < h_min; u += 64) {
                         // pmf_u falling from i1 on: (u + i1)(n - i1) < (i1 + 1)(t - u + n - i1 - 1)
                         const double up = (double)(u + i1) * (double)(n - i1), dn = (double)(i1 + 1u) * (double)(t - u + n - i1 - 1u);
                         if (!(up < dn && ln_len + ln_pmf_tab(lf, t, n, u, i1, ln_total) + ln_n <= kPruneLnEps)) first_fail = u < first_fail ? u : first_fail;

@@ -225,7 +225,7 @@ def device_source_sha() -> str:
     return h.hexdigest()[:16]
 
 
-def measured_traffic(refs: int, query_len: int, sub_batch: int):
+def measured_traffic(refs: int, query_len: int, sub_batch: int, kinds: int = 1):
     """Fabric-side bytes per hit_count launch from the committed rocprofv3 PMC passes (profiles/traffic.json, written
     by tools/make_traffic.py from `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE` runs of this bench): FETCH_SIZE x 2 as
     MI355X_MICROARCH.md prescribes for 16-byte-per-lane reads on gfx950, + WRITE_SIZE.  Returned only if the
@@ -239,10 +239,12 @@ def measured_traffic(refs: int, query_len: int, sub_batch: int):
         e = t.get("configs", {}).get(f"refs={refs},query_len={query_len}")
         if e is None:
             return None, "no PMC profile of this configuration"
+        if e.get("launches_per_sub_batch", 1) != kinds:
+            return None, "PMC profile was taken with another setting of the tile pruning"
         if e.get("device_source_sha") != device_source_sha():
             return None, "PMC profile is of another build of the kernels (re-run tools/profile_bench.sh)"
         per_query = (2.0 * e["hit_count_fetch_kb"] + e["hit_count_write_kb"]) * 1024.0 / e["queries_per_launch"]
-        return dict(per_query=per_query, fetch_per_query=2.0 * e["hit_count_fetch_kb"] * 1024.0 / e["queries_per_launch"],
+        return dict(per_query=per_query, launches_per_sub_batch=e.get("launches_per_sub_batch", 1), fetch_per_query=2.0 * e["hit_count_fetch_kb"] * 1024.0 / e["queries_per_launch"],
                     write_per_query=e["hit_count_write_kb"] * 1024.0 / e["queries_per_launch"], source=e.get("source", "")), None
     except Exception as ex:  # noqa: BLE001 - a broken profile file must not break the bench
         return None, f"profiles/traffic.json unreadable: {ex}"
@@ -252,16 +254,20 @@ def roofline_block(args, work, prob_work, stage_ms, stage_n, n_queries_step, que
     """Roofline of the dominant kernel, hit_count, per launch (one launch = one sub-batch).  With tile pruning the launch
     is the counting of the live tiles (the bounds pass before it -- the same kernel on the union bitmap + prune_kernel -- is
     timed as a stage of its own and reported under "tile_pruning")."""
-    n_launch = max(stage_n["hit_count"], 1)
-    launch_ms = stage_ms["hit_count"] / n_launch
+    # launches of the hit_count kernel: one per sub-batch, or two with tile pruning (bounds on the union bitmap + the live tiles;
+    # stage tile_bounds is the first of them) -- launch_ms is their mean, as rocprofv3 --stats reports it for the kernel
+    n_sub = max(stage_n["hit_count"], 1)
+    kinds = 2 if stage_n.get("tile_bounds") else 1
+    n_launch = n_sub * kinds
+    launch_ms = (stage_ms["hit_count"] + stage_ms.get("tile_bounds", 0.0)) / n_launch
     launches_per_step = n_launch / args.steps
-    q_per_launch = n_queries_step / launches_per_step
+    q_per_launch = n_queries_step / (n_sub / args.steps)                                # queries of a sub-batch: every launch sees them all
     sec = launch_ms * 1e-3
-    bitmap_per_q = work["bitmap_bytes_read"] / n_queries_step
+    bitmap_per_q = work["bitmap_bytes_read"] / n_queries_step                          # both launches
     alg_per_q = (4 * work["sum_hits"] + work["sum_query_bytes"]) / n_queries_step      # SURVEY.md 8d: 4 H_q + L_q
-    achieved = bitmap_per_q * q_per_launch / sec / 1e9
-    alg_gbs = alg_per_q * q_per_launch / sec / 1e9
-    tr, why = measured_traffic(args.refs, query_len, args.sub_batch)
+    achieved = bitmap_per_q * q_per_launch / kinds / sec / 1e9
+    alg_gbs = alg_per_q * q_per_launch / kinds / sec / 1e9
+    tr, why = measured_traffic(args.refs, query_len, args.sub_batch, kinds)
     out = {
         # the unit that limits the kernel: the path from the XCD's L2 through the vector L1 (rows are gathered by
         # index, 1 KiB per wave-instruction; the index is far larger than L2 + Infinity Cache only in bytes that are
@@ -289,7 +295,7 @@ def roofline_block(args, work, prob_work, stage_ms, stage_n, n_queries_step, que
                     "a count up to its threshold carry < 1e-12 of probability together (rtx_prune.hip); --no-tile-prune counts every tile",
         }
     if tr is not None:
-        out["traffic"] = tr["per_query"] * q_per_launch                  # HBM/fabric bytes per launch (PMC)
+        out["traffic"] = tr["per_query"] * q_per_launch / kinds          # HBM/fabric bytes per launch (PMC)
         out["hbm_achieved"] = out["traffic"] / sec / 1e9
         out["hbm_frac"] = out["hbm_achieved"] / HBM_PEAK_GBS
         out["traffic_fetch_bytes_per_query"] = tr["fetch_per_query"]

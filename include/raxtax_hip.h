@@ -304,8 +304,9 @@ int rtx_index_stream(rtx_index *index, void **hip_stream);
 #define RTX_STAGE_PROB_TABLE 2
 #define RTX_STAGE_TAXON_PREFIX 3
 #define RTX_STAGE_LINEAGE_WALK 4
-#define RTX_STAGE_TILE_BOUNDS 5 /* tile pruning (RTX_OPT_TILE_PRUNE): the queries against the union bitmap + prune_kernel; 0 launches if the run did not prune */
-#define RTX_NUM_STAGES 6
+#define RTX_STAGE_TILE_BOUNDS 5 /* tile pruning (RTX_OPT_TILE_PRUNE): the queries counted against the union bitmap (the hit_count kernel again); 0 launches if the run did not prune */
+#define RTX_STAGE_TILE_PRUNE 6  /* ... prune_kernel (thresholds, live tiles) + the row lists of the live tiles */
+#define RTX_NUM_STAGES 7
 int rtx_batch_stage_times(rtx_index *index, float ms[RTX_NUM_STAGES], uint32_t launches[RTX_NUM_STAGES]);
 /* Algorithmic work of the last rtx_batch_run: sum over queries of
  * H_q = sum_r count_q[r] (postings touched) and of L_q (query bytes), and the bitmap

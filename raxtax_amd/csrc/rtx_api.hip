@@ -177,6 +177,7 @@ struct rtx_index {
     bool pair_used = false;   // ... through hit_count_pair_kernel
     int pair_variant = 1;     // 1: two plane sets in registers; 2: one at a time, the shared planes parked in global scratch
     DevBuf<uint32_t> d_group_rows;
+    uint32_t n_groups_run = 0;  // groups of the whole batch (n_sub * groups_per_sub): the second half of d_group_rows starts there
     uint32_t groups_per_sub = 0;
     bool packed() const { return packed_opt && planes <= 10; }
     DevBuf<uint64_t> d_skey_in, d_skey_out;
@@ -419,7 +420,7 @@ int enqueue_hit(rtx_index *ix, const SubBatch &b, uint32_t flags, hipStream_t s)
     hp.live = nullptr;
     hp.live_words = 0;
     const bool prune = ix->prune_used && !ix->dbg_full_run;
-    if (b.timed) RTX_HIP(hipEventRecord(stage_event(ix, b, prune ? RTX_STAGE_TILE_BOUNDS : RTX_STAGE_HIT_COUNT, 0), s));
+    if (b.timed && !prune) RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_HIT_COUNT, 0), s));
     if (ix->pair_used) launch_pair_union(s, sc.d_rows.p, sc.d_nrows.p, ix->rstride, b.nq, sc.d_urec.p, sc.d_nu.p, 2u * ix->rstride);
     if (prune) {
         // (1) the queries against the union bitmap: every row dense, no lists, u16 counts (bounds per block of references)
@@ -439,8 +440,13 @@ int enqueue_hit(rtx_index *ix, const SubBatch &b, uint32_t flags, hipStream_t s)
         up.hist = sc.d_uhist.p;
         up.tile_max = sc.d_utmax.p;
         up.flags = 0;
-        up.group_rows = nullptr;
+        up.group_base = hp.group_base + ix->n_groups_run;  // work accounting apart from the counting proper
+        if (b.timed) RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_TILE_BOUNDS, 0), s));
         launch_hit_count_pair(s, up, b.nq, ix->u_ntiles, 1);  // the union of the pair's rows serves both passes
+        if (b.timed) {
+            RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_TILE_BOUNDS, 1), s));
+            RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_TILE_PRUNE, 0), s));
+        }
         // (2) bounds per tile, a lower bound of the best hit, the threshold, the live tiles of every pair
         PruneParams pr{};
         pr.ucounts_lo = up.counts_lo;
@@ -484,7 +490,7 @@ int enqueue_hit(rtx_index *ix, const SubBatch &b, uint32_t flags, hipStream_t s)
             launch_kmer_extract(s, kp, b.nq);
         }
         if (b.timed) {
-            RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_TILE_BOUNDS, 1), s));
+            RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_TILE_PRUNE, 1), s));
             RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_HIT_COUNT, 0), s));
         }
     }
@@ -653,9 +659,10 @@ int begin_run(rtx_index *ix, uint32_t *n_sub_out, bool *timed_out, bool cluster)
         }
     }
     if (ix->quad_used || ix->pair_used) {
-        int rc_g = ix->d_group_rows.alloc((size_t)n_sub * ix->groups_per_sub);
+        ix->n_groups_run = n_sub * ix->groups_per_sub;
+        int rc_g = ix->d_group_rows.alloc((size_t)2 * n_sub * ix->groups_per_sub);  // second half: the bounds pass of the tile pruning
         if (rc_g) return rc_g;
-        RTX_HIP(hipMemsetAsync(ix->d_group_rows.p, 0, (size_t)n_sub * ix->groups_per_sub * 4, ix->stream));
+        RTX_HIP(hipMemsetAsync(ix->d_group_rows.p, 0, (size_t)2 * n_sub * ix->groups_per_sub * 4, ix->stream));
     }
     const bool timed = n_sub <= 4096;
     if (timed) {
@@ -1833,7 +1840,7 @@ int rtx_batch_stage_times(rtx_index *ix, float ms[RTX_NUM_STAGES], uint32_t laun
     for (int s = 0; s < RTX_NUM_STAGES; s++) { ms[s] = 0.f; launches[s] = 0; }
     for (uint32_t sb = 0; sb < ix->n_sub_last; sb++)
         for (int s = 0; s < RTX_NUM_STAGES; s++) {
-            if (s == RTX_STAGE_TILE_BOUNDS ? !ix->prune_used : (s != RTX_STAGE_HIT_COUNT && !ix->stage_timing)) continue;  // events were not recorded
+            if (s == RTX_STAGE_TILE_BOUNDS || s == RTX_STAGE_TILE_PRUNE ? !ix->prune_used : (s != RTX_STAGE_HIT_COUNT && !ix->stage_timing)) continue;  // events were not recorded
             float t = 0.f;
             RTX_HIP(hipEventElapsedTime(&t, ix->events[((size_t)sb * RTX_NUM_STAGES + s) * 2],
                                         ix->events[((size_t)sb * RTX_NUM_STAGES + s) * 2 + 1]));
@@ -1864,10 +1871,15 @@ int rtx_batch_work(rtx_index *ix, uint64_t *sum_hits, uint64_t *sum_query_bytes,
     }
     if (ix->quad_used || ix->pair_used) {  // rows were loaded once per group of four (two) queries: the union rows every workgroup counted
         const uint32_t n_sub = (uint32_t)((ix->n_q + ix->sub_batch - 1) / ix->sub_batch);
-        std::vector<uint32_t> gr((size_t)n_sub * ix->groups_per_sub);
+        const size_t ng = (size_t)n_sub * ix->groups_per_sub;
+        std::vector<uint32_t> gr(2 * ng);
         RTX_HIP(hipMemcpy(gr.data(), ix->d_group_rows.p, gr.size() * 4, hipMemcpyDeviceToHost));
         b = 0;
-        for (uint32_t v : gr) b += (uint64_t)v * row_bytes;
+        for (size_t g = 0; g < ng; g++) b += (uint64_t)gr[g] * row_bytes;
+        if (ix->prune_used) {  // + the rows of the union bitmap the bounds pass of the tile pruning loaded (the same kernel)
+            const uint64_t urow_bytes = ((ix->u_nblocks + 7) / 8 + ix->u_ntiles - 1) / ix->u_ntiles;
+            for (size_t g = ng; g < 2 * ng; g++) b += (uint64_t)gr[g] * urow_bytes;
+        }
     }
     b += mid_bytes;
     if (sum_hits) *sum_hits = h;

@@ -274,7 +274,67 @@ __global__ __launch_bounds__(64) void kmer_extract_kernel(KmerParams p) {
     uint32_t *mout = p.mrows + (size_t)q * nt * (kSegMaxMidRows + 1);
     __shared__ unsigned long long l_sb[64], l_mb[64];
     __shared__ uint32_t l_base[64], l_mbase[64];
-    for (uint32_t tb = 0; p.seg_blocks && tb < nt; tb += 64) {  // many tiles: 64 rows x 64 tiles per step
+    // Tile pruning left this query's pair a handful of tiles: one pass per live tile over the class table [row][tile] (a gather
+    // per 64 rows) instead of the bit tables and their transposes, which cost the same however few tiles are wanted.
+    bool few_done = false;
+    if (live && p.seg_blocks) {
+        const uint32_t lw = (nt + 31u) >> 5;
+        uint32_t nlive = 0;
+        for (uint32_t w = 0; w < lw; w++) nlive += (uint32_t)__popc(live[w]);
+        if (nlive <= kKmerFewLive) {  // wave-uniform
+            for (uint32_t w = 0; w < lw; w++) {
+                uint32_t bits = (uint32_t)__builtin_amdgcn_readfirstlane((int)live[w]);
+                while (bits) {
+                    const uint32_t tile = w * 32u + (uint32_t)__builtin_ctz(bits);
+                    bits &= bits - 1u;
+                    if (tile >= nt) break;
+                    uint32_t cd = 0, cs = 0, cm = 0;  // wave-uniform
+                    for (uint32_t c0 = 0; c0 < nchunks; c0 += 4) {
+                        uint32_t row[4], code[4];
+#pragma unroll
+                        for (int u = 0; u < 4; u++) {
+                            const uint32_t i = (c0 + (uint32_t)u) * 64 + lane;
+                            row[u] = i < nrows ? rout[i] : kEmptyRow;
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; u++) {
+                            code[u] = p.seginfo[(size_t)(row[u] == kEmptyRow ? 0u : row[u]) * p.seg_stride + tile];
+                            if (row[u] == kEmptyRow) code[u] = 0u;
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; u++) {
+                            const uint32_t c = c0 + (uint32_t)u;
+                            if (c >= nchunks) break;
+                            const bool mid = (code[u] >> 31) != 0u;
+                            const bool sparse = code[u] >= 2u && !mid;
+                            // as in the pass per tile below: the rows taken from a chunk are a prefix of its candidates of either kind
+                            const unsigned long long ms = __ballot(sparse), mm = __ballot(mid);
+                            const uint32_t srank = cs + (uint32_t)__popcll(ms & lt_mask), mrank = cm + (uint32_t)__popcll(mm & lt_mask);
+                            const bool room = srank + mrank < kSegMaxListRows;
+                            const bool take = sparse && srank < kSegMaxSparseRows && room;
+                            const bool mtake = mid && mrank < kSegMaxMidRows && room;
+                            if (take) sout[(size_t)tile * (kSegMaxSparseRows + 1) + srank] = code[u] - 2u;
+                            if (mtake) mout[(size_t)tile * (kSegMaxMidRows + 1) + mrank] = code[u] & 0x7FFFFFFFu;
+                            const unsigned long long bt = __ballot(take), bm = __ballot(mtake);
+                            const unsigned long long md = __ballot(code[u] == 1u || (sparse && !take) || (mid && !mtake));
+                            if (lane == 0) dm[(size_t)tile * mstride + c] = md;
+                            cd += (uint32_t)__popcll(md);
+                            cs += (uint32_t)__popcll(bt);
+                            cm += (uint32_t)__popcll(bm);
+                        }
+                    }
+                    if (lane == 0) {
+                        p.nsparse[(size_t)q * nt + tile] = cs;
+                        p.nmid[(size_t)q * nt + tile] = cm;
+                        nseg += cd;
+                        nmidseg += cm;
+                    }
+                }
+            }
+            few_done = true;
+        }
+    }
+    for (uint32_t tb = 0; p.seg_blocks && !few_done && tb < nt; tb += 64) {  // many tiles: 64 rows x 64 tiles per step
         const uint32_t blk = tb >> 6;
         const uint32_t tile = tb + lane;  // this lane's tile after the transposes
         // a tile that is not counted for this query's pair needs no lists (the transposes still take every lane)

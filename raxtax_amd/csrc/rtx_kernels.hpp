@@ -32,6 +32,7 @@ constexpr uint32_t kSegMidMax = 128, kSegMidEntries = 128, kSegMaxMidRows = 127,
 __host__ __device__ inline uint32_t seg_mid_pad(uint32_t i) { return kSegMidPad + ((i & 63u) << 2); }
 // hit_count compacts the dense rows of its (query, tile) into an LDS list of this many row ids (+ padding), in
 // several rounds if they do not fit
+constexpr uint32_t kKmerFewLive = 8;   // kmer_extract, lists of the live tiles only: up to this many tiles one pass per tile (rtx_kernels.hip)
 constexpr uint32_t kHitListCap = 1024;  // >= 200 rows of confidence >= 0.005 + fallback
 
 struct DevRow {  // one result row as the device emits it
@@ -131,7 +132,11 @@ struct HitParams {
 
 // tile pruning (rtx_prune.hip)
 constexpr uint32_t kPruneStatCopies = 64;  // PruneParams::stats: [copies][8] (prune_kernel) + [copies][8] (taxon_prefix), summed by the reader
-constexpr uint32_t kPruneShift = 5;  // the union bitmap has one column per block of 32 references
+#ifndef RTX_PRUNE_SHIFT
+#define RTX_PRUNE_SHIFT 5
+#endif
+constexpr uint32_t kPruneShift = RTX_PRUNE_SHIFT;  // the union bitmap has one column per block of 32 references (3 .. 6: a block's references meet in one wave)
+static_assert(kPruneShift >= 3 && kPruneShift <= 6, "blocks of 8 .. 64 references");
 struct PruneParams {
     const uint8_t *ucounts_lo;   // [B][unpad] counts of the queries against the union bitmap (an upper bound per block of
     const uint16_t *ucounts_hi;  // [B][unpad / 8]  2^kPruneShift references), packed like HitParams::counts_lo / counts_hi

@@ -30,7 +30,7 @@ def test_single_gpu_line_is_physical():
     assert roof["algorithmic_ratio_to_hbm_peak"] > 0 and roof["requested_bytes_per_query"] > 0
     assert roof["traffic"] is None or roof["hbm_frac"] <= 1.0          # no PMC profile of this toy configuration
     assert 0 < roof["prob_stage"]["frac"] < 1.0 and roof["prob_stage"]["ops_prob_per_query"] > 1000
-    assert all(v > 0 for k, v in r["stage_ms_per_step"].items() if k not in ("lineage_walk", "tile_bounds"))   # the walk rides inside taxon_prefix; 3 tiles: no pruning
+    assert all(v > 0 for k, v in r["stage_ms_per_step"].items() if k not in ("lineage_walk", "tile_bounds", "tile_prune"))   # the walk rides inside taxon_prefix; 3 tiles: no pruning
     cpu = r["cpu_baseline"]
     assert cpu["kind"] == "port" and cpu["value"] > 0 and cpu["cores"] >= 1 and cpu["one_thread"]["value"] > 0
     assert "cpu_model" in cpu and cpu["unit"] == "queries/s"

@@ -59,6 +59,8 @@ def main():
     ap.add_argument("--tcc", default=None, help="optional pass with TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum ...")
     ap.add_argument("--full-launches-only", action="store_true", default=True)
     ap.add_argument("--note", default="")
+    ap.add_argument("--with-bounds-pass", action="store_true", help="tile pruning on: a sub-batch is two launches of the hit_count kernel "
+                    "(bounds on the union bitmap + the live tiles); the entry holds their sum, launches_per_sub_batch = 2")
     a = ap.parse_args()
     passes = [read_pass(a.fetch), read_pass(a.write)] + ([read_pass(a.tcc)] if a.tcc else [])
     rows = []
@@ -84,7 +86,12 @@ def main():
                 # traffic differs from launch to launch -- the processing order gives every sub-batch another part of the
                 # database -- so the mean over all full launches is what a step sees
                 full = [x for x, gs in zip(v, g) if gs == max(g)]
-                return sum(full) / len(full), len(full)
+                mean = sum(full) / len(full)
+                if a.with_bounds_pass:   # tile pruning: the same kernel runs once more per sub-batch, on the union bitmap (a smaller grid)
+                    g2 = max(gs for gs in g if gs < max(g) and g.count(gs) * 2 >= len(full))
+                    coarse = [x for x, gs in zip(v, g) if gs == g2]
+                    mean += sum(coarse) / len(coarse)
+                return mean, len(full)
         raise SystemExit(f"no hit_count dispatches with {ctr}")
 
     fetch_kb, nf = hit(passes[0], "FETCH_SIZE")
@@ -96,9 +103,9 @@ def main():
                                     "WRITE_SIZE reads exactly for 16-byte-per-lane stores"}
     t["configs"][f"refs={a.refs},query_len={a.query_len}"] = {
         "queries_per_launch": a.queries_per_launch, "hit_count_fetch_kb": fetch_kb, "hit_count_write_kb": write_kb,
-        "launches_profiled": min(nf, nw), "device_source_sha": device_source_sha(),
+        "launches_profiled": min(nf, nw), "launches_per_sub_batch": 2 if a.with_bounds_pass else 1, "device_source_sha": device_source_sha(),
         "source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, tools/profile_bench.sh {a.tag}); mean KB per full "
-                  f"hit_count launch of {a.queries_per_launch} queries. {a.note}".strip(),
+                  f"sub-batch of {a.queries_per_launch} queries ({'bounds pass + live tiles' if a.with_bounds_pass else 'one hit_count launch'}). {a.note}".strip(),
     }
     tf.write_text(json.dumps(t, indent=1) + "\n")
     print("updated", tf, json.dumps(t["configs"][f"refs={a.refs},query_len={a.query_len}"]))

@@ -133,9 +133,9 @@ struct HitParams {
 // tile pruning (rtx_prune.hip)
 constexpr uint32_t kPruneStatCopies = 64;  // PruneParams::stats: [copies][8] (prune_kernel) + [copies][8] (taxon_prefix), summed by the reader
 #ifndef RTX_PRUNE_SHIFT
-#define RTX_PRUNE_SHIFT 5
+#define RTX_PRUNE_SHIFT 6  // bench workload: blocks of 32 give 1.9 live tiles per pair for two tiles of bounds, blocks of 64 a few more for one (182 against 190 ms per 1M queries)
 #endif
-constexpr uint32_t kPruneShift = RTX_PRUNE_SHIFT;  // the union bitmap has one column per block of 32 references (3 .. 6: a block's references meet in one wave)
+constexpr uint32_t kPruneShift = RTX_PRUNE_SHIFT;  // the union bitmap has one column per block of 64 references (3 .. 6: a block's references meet in one wave)
 static_assert(kPruneShift >= 3 && kPruneShift <= 6, "blocks of 8 .. 64 references");
 struct PruneParams {
     const uint8_t *ucounts_lo;   // [B][unpad] counts of the queries against the union bitmap (an upper bound per block of

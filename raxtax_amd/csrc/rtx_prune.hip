@@ -116,40 +116,38 @@ __global__ __launch_bounds__(64) void prune_kernel(PruneParams p, ProbTables tb)
             const uint32_t *rows = p.rows + (size_t)q * p.rstride;
             const uint64_t qin = p.perm[p.q0 + q];
             const uint32_t zero_row = p.n_rows1 - 1u;
-            uint32_t word[kChunks], bit[kChunks];
-#pragma unroll
-            for (uint32_t c = 0; c < kChunks; c++) {
-                const uint64_t r0 = ((uint64_t)bb << kPruneShift) + (uint64_t)c * 8u;
-                ref_slot((uint32_t)(r0 < p.n_refs ? r0 : (uint64_t)bb << kPruneShift), p.stride_bytes, word[c], bit[c]);  // bit = first bit of the chunk's byte
+            // lane = (row group, chunk): an instruction reads the block's bytes of 64 / kChunks rows, and the chunks of a block are
+            // neighbouring lane words of the row segment -- one 128-byte line per row (with lane = row and a gather per chunk
+            // every instruction touched 64 lines: eight times the requests)
+            constexpr uint32_t kRowsPerTurn = 64u / kChunks;
+            const uint32_t ch = lane & (kChunks - 1u), rg = lane / kChunks;
+            uint32_t word, bit;
+            {
+                const uint64_t r0 = ((uint64_t)bb << kPruneShift) + (uint64_t)ch * 8u;
+                ref_slot((uint32_t)(r0 < p.n_refs ? r0 : (uint64_t)bb << kPruneShift), p.stride_bytes, word, bit);  // bit = first bit of the chunk's byte
             }
-            uint32_t acc[kChunks][4];  // [chunk][pair of references]: two 16-bit counters
+            uint32_t acc[4] = {0u, 0u, 0u, 0u};  // [pair of references of this lane's chunk]: two 16-bit counters (at most 1023 rows)
+            const uint32_t nr_pad = (nr + 63u) & ~63u;  // the row list is padded with the all-zero row to whole chunks of 64
+            for (uint32_t i0 = 0; i0 < nr; i0 += 4u * kRowsPerTurn) {
+                uint32_t row[4], w[4];
 #pragma unroll
-            for (uint32_t c = 0; c < kChunks; c++)
-#pragma unroll
-                for (int k = 0; k < 4; k++) acc[c][k] = 0u;
-            for (uint32_t i0 = 0; i0 < nr; i0 += 128) {  // the row list is padded with the all-zero row to whole chunks of 64
-                const uint32_t row0 = rows[i0 + lane];
-                const uint32_t row1 = i0 + 64u < nr ? rows[i0 + 64u + lane] : zero_row;
-                uint32_t w0[kChunks], w1[kChunks];
-#pragma unroll
-                for (uint32_t c = 0; c < kChunks; c++) {
-                    w0[c] = p.bitmap[bitmap_word(row0, word[c], p.n_rows1)];
-                    w1[c] = p.bitmap[bitmap_word(row1, word[c], p.n_rows1)];
+                for (int u = 0; u < 4; u++) {
+                    const uint32_t i = i0 + (uint32_t)u * kRowsPerTurn + rg;
+                    row[u] = i < nr_pad ? rows[i] : zero_row;
                 }
 #pragma unroll
-                for (uint32_t c = 0; c < kChunks; c++) {
-                    const uint32_t b0 = (w0[c] >> bit[c]) & 0xFFu, b1 = (w1[c] >> bit[c]) & 0xFFu;
+                for (int u = 0; u < 4; u++) w[u] = p.bitmap[bitmap_word(row[u], word, p.n_rows1)];
 #pragma unroll
-                    for (int k = 0; k < 4; k++)
-                        acc[c][k] += (((b0 >> (2 * k)) & 1u) + ((b1 >> (2 * k)) & 1u)) | ((((b0 >> (2 * k + 1)) & 1u) + ((b1 >> (2 * k + 1)) & 1u)) << 16);
+                for (int u = 0; u < 4; u++) {
+                    const uint32_t bt = (w[u] >> bit) & 0xFFu;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) acc[k] += ((bt >> (2 * k)) & 1u) | (((bt >> (2 * k + 1)) & 1u) << 16);
                 }
             }
 #pragma unroll
-            for (uint32_t c = 0; c < kChunks; c++)
+            for (int k = 0; k < 4; k++)
 #pragma unroll
-                for (int k = 0; k < 4; k++)
-#pragma unroll
-                    for (int d = 32; d >= 1; d >>= 1) acc[c][k] += (uint32_t)__shfl_xor((int)acc[c][k], d, 64);
+                for (uint32_t d = 32; d >= kChunks; d >>= 1) acc[k] += (uint32_t)__shfl_xor((int)acc[k], (int)d, 64);  // over the row groups: lane c holds chunk c
             // the block's references: drop those behind the end and those --skip-exact-matches zeroes
 #pragma unroll
             for (uint32_t c = 0; c < kChunks; c++) {
@@ -163,7 +161,7 @@ __global__ __launch_bounds__(64) void prune_kernel(PruneParams p, ProbTables tb)
                         for (uint64_t e = p.exact_off[qin] + lane; e < p.exact_off[qin + 1]; e += 64) hit = hit || (uint64_t)p.exact_ids[e] == r;
                         ok = __ballot(hit) == 0ull;
                     }
-                    const uint32_t cnt = (acc[c][j >> 1] >> ((j & 1) * 16)) & 0xFFFFu;
+                    const uint32_t cnt = ((uint32_t)__builtin_amdgcn_readlane((int)acc[j >> 1], (int)c) >> ((j & 1) * 16)) & 0xFFFFu;
                     if (ok && cnt > M) M = cnt;
                     if (ok && lane == c * 8u + (uint32_t)j) hm = cnt;
                 }

@@ -841,7 +841,9 @@ constexpr uint32_t kMaxSubBatch = 65536;
 // 16 384: 1 072, 24 576: 1 070, 32 768: 1 098).  With the kernels of the end of round 2: N = 50k, per 100k queries: 10 000: 19.55 ms,
 // 20 000: 19.08, 25 000: 21.1 (the last sub-batch's host work is no longer hidden), 50 000: 20.7; N = 500k, per 1 M queries:
 // 8 192: 971 ms, 16 384: 953, 32 768: 964, 65 536: 995
-constexpr uint32_t kDefaultSubBatch = 20480, kDefaultSubBatchLarge = 16384;
+// With tile pruning a sub-batch is far less work and the fixed cost of its nine launches counts: N = 500k, per 1 M queries:
+// 8 192: 191 ms, 16 384: 171, 32 768: 159.5, 49 152: 158.1, 65 536: 157.8
+constexpr uint32_t kDefaultSubBatch = 20480, kDefaultSubBatchLarge = 16384, kDefaultSubBatchPruned = 32768;
 
 int alloc_scratch_set(rtx_index *ix, uint32_t k);
 
@@ -888,7 +890,9 @@ int prepare_workspace(rtx_index *ix, uint64_t n_queries, uint64_t tmax, uint64_t
         // scratch already held by this handle is reusable
         const uint64_t held = (ix->sc[0].d_counts.n + ix->sc[1].d_counts.n) * 2 + (ix->sc[0].d_prefix.n + ix->sc[1].d_prefix.n) * 8;
         const uint64_t budget = (uint64_t)((free_b + held) * 0.6);
-        B = (uint32_t)std::min<uint64_t>(ix->ntiles >= 16 ? kDefaultSubBatchLarge : kDefaultSubBatch, std::max<uint64_t>(64, budget / per_q));
+        const bool will_prune = ix->prune_opt && ix->d_ubitmap.p && ix->pair_opt == 1 && ix->ntiles >= 8 && tmax <= 1023 && ix->n_refs == ix->n_total;  // begin_run decides
+        B = (uint32_t)std::min<uint64_t>(will_prune ? kDefaultSubBatchPruned : ix->ntiles >= 16 ? kDefaultSubBatchLarge : kDefaultSubBatch,
+                                         std::max<uint64_t>(64, budget / per_q));
     }
     if (B > kMaxSubBatch) B = kMaxSubBatch;
     B = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(B, n_queries));

@@ -2,7 +2,8 @@
 # bench at configs[2] with other stream counts / sub-batch sizes (gpurun_out/exp_streams.txt)
 cd "${GRAFT_REPO_ROOT:-/root/repo}" || exit 1
 mkdir -p gpurun_out; : > gpurun_out/exp_streams.txt
-for v in "" "--streams 2" "--sub-batch 8192" "--sub-batch 32768" "--streams 2 --sub-batch 8192"; do
+IFS="|" read -r -a VS <<< "${VARIANTS:-|--streams 2|--sub-batch 8192|--sub-batch 32768}"
+for v in "${VS[@]}"; do
   timeout -k 10 200 python bench.py --steps 2 --warmup 1 --no-cpu-baseline $v 2>/dev/null | python3 -c "
 import sys, json
 j = json.loads(sys.stdin.readline())

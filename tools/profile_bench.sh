@@ -8,7 +8,7 @@ set -u
 TAG=${1:-r2}; shift || true
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out
-QPL=${QPL:-16384}            # queries per launch (default sub-batch of a large database)
+QPL=${QPL:-32768}            # queries per launch (default sub-batch of a large database with tile pruning)
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 ARGS="--steps 2 --warmup 1 --no-cpu-baseline $*"

@@ -291,8 +291,10 @@ def roofline_block(args, work, prob_work, stage_ms, stage_n, n_queries_step, que
             "tiles_above_threshold_per_query": prune.get("tiles_above_threshold_per_query"),     # what exact knowledge would count
             "queries_with_threshold": prune.get("queries_with_threshold"),
             "bounds_launch_ms": stage_ms.get("tile_bounds", 0.0) / b_n,
-            "note": "requested bytes and launch_ms are of the live (pair, tile) blocks only; a pruned query's references with "
-                    "a count up to its threshold carry < 1e-12 of probability together (rtx_prune.hip); --no-tile-prune counts every tile",
+            "note": "the hit_count kernel runs twice per sub-batch: against the union bitmap (bounds per block of 64 references; "
+                    "bounds_launch_ms) and on the live (pair, tile) blocks; requested bytes, traffic and launch_ms are means over both "
+                    "launches, as rocprofv3 --stats reports the kernel.  A pruned query's references with a count up to its threshold "
+                    "carry < 1e-12 of probability together (rtx_prune.hip); --no-tile-prune counts every tile",
         }
     if tr is not None:
         out["traffic"] = tr["per_query"] * q_per_launch / kinds          # HBM/fabric bytes per launch (PMC)

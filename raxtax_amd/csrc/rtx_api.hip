@@ -423,7 +423,7 @@ int enqueue_hit(rtx_index *ix, const SubBatch &b, uint32_t flags, hipStream_t s)
     if (b.timed && !prune) RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_HIT_COUNT, 0), s));
     if (ix->pair_used) launch_pair_union(s, sc.d_rows.p, sc.d_nrows.p, ix->rstride, b.nq, sc.d_urec.p, sc.d_nu.p, 2u * ix->rstride);
     if (prune) {
-        // (1) the queries against the union bitmap: every row dense, no lists, u16 counts (bounds per block of references)
+        // (1) the queries against the union bitmap: every row dense, no lists, packed counts (bounds per block of references)
         HitParams up = hp;
         up.bitmap = ix->d_ubitmap.p;
         up.stride_bytes = ix->u_stride_bytes;

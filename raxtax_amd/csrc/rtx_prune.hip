@@ -3,11 +3,11 @@
 // Most references of a large database share far too few k-mers with a query to receive any probability (DESIGN.md
 // section 8: dropping every reference of the tiles whose largest count stays below 300 changes no prefix sum of the
 // reference algorithm by more than rounding noise).  hit_count can skip such a tile if it KNOWS beforehand that every
-// count in it is small:
+// count in it is small ("Tile pruning", has the argument in full):
 //   * upper bounds: the union bitmap -- one column per block of 2^kPruneShift consecutive references, bit (k, block) set
-//     if ANY reference of the block contains k-mer k -- is counted like the database itself (hit_count_kernel on two
-//     tiles instead of 62); a block's count bounds the count of each of its references.  ub(T) = max over the blocks of
-//     tile T.
+//     if ANY reference of the block contains k-mer k -- is counted like the database itself (hit_count_pair_kernel on one
+//     tile instead of 62 at N = 500k, blocks of 64); a block's count bounds the count of each of its references.
+//     ub(T) = max over the blocks of tile T.
 //   * the best hits: the exact counts of the references of the block with the largest bound (the query's nearest relatives:
 //     M = the largest of them, H = those with at least 0.8 M).
 //   * the threshold (prob.rs:49-90 restated): Z = sum_r table[m_r] >= 1, table[m_r] = sum_i pmf_{m_r}(i) prod_{r' != r}

@@ -1161,3 +1161,48 @@ def test_tile_pruning_changes_nothing_visible(oracle, kmer_map):
                                            f"prune skip {skip} q {q}"))
             assert np.array_equal(b.debug_hit_counts(q), counts), (skip, q)      # the taps recount in full
     assert exc.n["ties"] <= 3, exc.n
+
+
+@pytest.mark.parametrize("seed", [11, 12, 13])
+def test_tile_pruning_randomised(oracle, seed):
+    """Seeded databases of 8 ... 14 tiles with other roots, sequence lengths (t from 300 to 900) and query divergences; pruned
+    against full count: status, t, rows and lineages identical, confidences within 1e-9, no bound below a count it bounds; the
+    pruned rows of a few queries against the oracle."""
+    rng = np.random.default_rng(seed)
+    n_refs = int(rng.integers(8 * 8192 + 1, 14 * 8192))
+    L = int(rng.choice([320, 658, 900]))
+    db = synth.make_db(n_refs, length=L, seed_root=100 + seed, seed_db=200 + seed)
+    parts = [synth.make_queries(db, 150, seed=seed, mu_q=0.02, exact_frac=0.1),
+             synth.make_queries(db, 80, seed=seed + 1, mu_q=float(rng.choice([0.06, 0.1, 0.15])), exact_frac=0.0),
+             synth.make_queries(db, 40, seed=seed + 2, mu_q=0.25, exact_frac=0.0)]
+    seqs = [p.seq(q) for p in parts for q in range(p.n)]
+    order = rng.permutation(len(seqs))
+    seqs = [seqs[i] for i in order]
+    off = np.zeros(len(seqs) + 1, np.uint64)
+    off[1:] = np.cumsum([len(s) for s in seqs])
+    bases = np.concatenate(seqs)
+    tree = rx.Tree.new_flat(db.lineages, db.seq_bytes, db.seq_off)
+    otree = oracle.tree_new_flat(db.lineages, db.seq_bytes, db.seq_off)
+    a, b = rx.Index(tree, tile_prune=False), rx.Index(tree)
+    ex = a.exact_matches(bases, off)
+    exc = Excuses(f"tile_prune_random/{seed}")
+    for skip in (False, True):
+        ra = a.classify(bases, off, *ex, skip_exact_matches=skip)
+        rb = b.classify(bases, off, *ex, skip_exact_matches=skip)
+        st = b.debug_prune_stats()
+        print(f"seed {seed}: {n_refs} references of {L} bases, skip={skip}: {st}")
+        assert st["pairs"] > 0 and st["bound_violations"] == 0 and a.debug_prune_stats()["pairs"] == 0
+        for f in ("row_off", "row_lineage", "t", "status"):
+            assert np.array_equal(getattr(ra, f), getattr(rb, f)), (seed, skip, f)
+        assert np.allclose(ra.row_conf, rb.row_conf, rtol=0, atol=1e-9)
+        assert np.allclose(ra.global_signal, rb.global_signal, rtol=0, atol=1e-12)
+        for q in range(0, len(seqs), 45):
+            rows, _ = _oracle_rows(otree, seqs[q], skip)
+            if rows is None:
+                assert rb.status[q] != 0
+                continue
+            t, counts = otree.hit_counts(seqs[q], skip_exact=skip)
+            exc.checked += 1
+            exc.tie(assert_rows_equivalent(rb.rows(q), rows, oracle.highest_hit_prob_per_reference(t, t // 2, counts), otree.lineages,
+                                           f"prune random seed {seed} skip {skip} q {q}"))
+    assert exc.n["ties"] <= 2, exc.n

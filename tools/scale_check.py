@@ -35,6 +35,7 @@ def main():
         dt = time.time() - t0
     res = ix.download()
     print(f"classify {n_q} queries: {dt * 1e3:.1f} ms -> {n_q / dt:.0f} q/s; stages {ix.stage_times()}")
+    print("tile pruning:", ix.debug_prune_stats())
     work = ix.work()
     print("work", work, "H_q/N =", work["sum_hits"] / n_q / n_refs)
     assert (res.status == 0).all()

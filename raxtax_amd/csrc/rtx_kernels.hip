@@ -1418,17 +1418,26 @@ size_t prob_table_lds_bytes(uint32_t tmax) {
 void launch_prob_table(hipStream_t s, const ProbParams &p, uint32_t nq) {
     hipLaunchKernelGGL(prob_table_kernel, dim3(nq), dim3(kProbThreads), prob_table_lds_bytes(p.tmax), s, p);
 }
+template <int NW>
+static void launch_taxon_prefix_nw(hipStream_t s, const PrefixParams &p, uint32_t nq, size_t lds) {
+    if (p.tz_in_lds && p.packed) hipLaunchKernelGGL((taxon_prefix_kernel<NW, true, true>), dim3(nq), dim3(NW * 64), lds, s, p);
+    else if (p.tz_in_lds) hipLaunchKernelGGL((taxon_prefix_kernel<NW, true, false>), dim3(nq), dim3(NW * 64), lds, s, p);
+    else if (p.packed) hipLaunchKernelGGL((taxon_prefix_kernel<NW, false, true>), dim3(nq), dim3(NW * 64), lds, s, p);
+    else hipLaunchKernelGGL((taxon_prefix_kernel<NW, false, false>), dim3(nq), dim3(NW * 64), lds, s, p);
+}
 void launch_taxon_prefix(hipStream_t s, const PrefixParams &p, uint32_t nq) {
     size_t lds = p.tz_in_lds ? (size_t)p.hstride * sizeof(double) : 0;
     if (p.fuse_walk) lds = std::max(lds, sizeof(WalkLds));
 #ifndef RTX_PREFIX_NW
 #define RTX_PREFIX_NW 4
 #endif
-    constexpr int NW = RTX_PREFIX_NW;  // waves per query: NW * 512 references per sweep
-    if (p.tz_in_lds && p.packed) hipLaunchKernelGGL((taxon_prefix_kernel<NW, true, true>), dim3(nq), dim3(NW * 64), lds, s, p);
-    else if (p.tz_in_lds) hipLaunchKernelGGL((taxon_prefix_kernel<NW, true, false>), dim3(nq), dim3(NW * 64), lds, s, p);
-    else if (p.packed) hipLaunchKernelGGL((taxon_prefix_kernel<NW, false, true>), dim3(nq), dim3(NW * 64), lds, s, p);
-    else hipLaunchKernelGGL((taxon_prefix_kernel<NW, false, false>), dim3(nq), dim3(NW * 64), lds, s, p);
+#ifndef RTX_PREFIX_NW_PRUNED
+#define RTX_PREFIX_NW_PRUNED 2
+#endif
+    // waves per query: NW * 512 references per sweep.  A query of a pruned run sweeps one or two tiles: two waves (more queries
+    // in flight) beat four (N = 500k, per 1 M queries: 18.2 ms with four, 14.5 with two, 15.2 with one)
+    if (p.prune_thr) launch_taxon_prefix_nw<RTX_PREFIX_NW_PRUNED>(s, p, nq, lds);
+    else launch_taxon_prefix_nw<RTX_PREFIX_NW>(s, p, nq, lds);
 }
 void launch_lineage_walk(hipStream_t s, const WalkParams &p, uint32_t nq) {
     hipLaunchKernelGGL(lineage_walk_kernel, dim3(nq), dim3(64), 0, s, p);

@@ -204,7 +204,7 @@ struct rtx_index {
         // tile pruning: the queries counted against the union bitmap (every row dense: constant masks), the live tiles per pair
         DevBuf<unsigned long long> d_uones;
         DevBuf<uint32_t> d_uzero, d_uhist, d_live;
-        DevBuf<uint16_t> d_ucounts, d_utmax, d_prune_thr;
+        DevBuf<uint16_t> d_ucounts, d_utmax, d_prune_thr, d_prune_i1;
     } sc[2];
     uint32_t n_streams_req = 1, n_streams = 1;
     bool staged = false;  // driven with rtx_shard_*: sub-batch sb works in scratch set sb & 1, so that the exchange of one
@@ -473,6 +473,7 @@ int enqueue_hit(rtx_index *ix, const SubBatch &b, uint32_t flags, hipStream_t s)
         pr.live = sc.d_live.p;
         pr.live_words = (ix->ntiles + 31u) / 32u + 1u;
         pr.thr_out = sc.d_prune_thr.p;
+        pr.i1_out = sc.d_prune_i1.p;
         pr.stats = ix->d_prune_stats.p;
         pr.ubitmap = ix->d_ubitmap.p;
         pr.ustride_bytes = ix->u_stride_bytes;
@@ -529,6 +530,7 @@ int enqueue_prob_prefix(rtx_index *ix, const SubBatch &b, bool fuse_walk, bool p
     pp.status = ix->d_status.p;
     pp.ndist = ix->d_ndist.p;
     pp.prune_thr = ix->prune_used && !ix->dbg_full_run ? sc.d_prune_thr.p : nullptr;
+    pp.prune_i1 = pp.prune_thr ? sc.d_prune_i1.p : nullptr;
     if (b.timed_all) RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_PROB_TABLE, 0), s));
     if (ix->use_tables) {
         ProbTables tb{ix->d_tab_cmf.p, ix->d_tab_ratio.p, ix->d_tab_off.p, ix->d_tab_moff.p,
@@ -923,7 +925,7 @@ int alloc_scratch_set(rtx_index *ix, uint32_t k) {
             const bool fresh = sc.d_uones.n < mw;
             if ((rc = sc.d_uones.alloc(mw)) || (rc = sc.d_uzero.alloc((size_t)B * ix->u_ntiles)) ||
                 (rc = sc.d_ucounts.alloc((size_t)B * ix->u_ntiles * 8192u)) || (rc = sc.d_uhist.alloc((size_t)B * ix->hstride)) ||
-                (rc = sc.d_utmax.alloc((size_t)B * ix->u_ntiles)) || (rc = sc.d_prune_thr.alloc(B)) || (rc = sc.d_live.alloc((size_t)((B + 1u) / 2u) * ((ix->ntiles + 31u) / 32u + 1u))))
+                (rc = sc.d_utmax.alloc((size_t)B * ix->u_ntiles)) || (rc = sc.d_prune_thr.alloc(B)) || (rc = sc.d_prune_i1.alloc(B)) || (rc = sc.d_live.alloc((size_t)((B + 1u) / 2u) * ((ix->ntiles + 31u) / 32u + 1u))))
                 return rc;
             if (fresh) RTX_HIP(hipMemsetAsync(sc.d_uones.p, 0xFF, sc.d_uones.n * 8, ix->stream));
             RTX_HIP(hipMemsetAsync(sc.d_uzero.p, 0, sc.d_uzero.n * 4, ix->stream));

@@ -157,6 +157,7 @@ struct PruneParams {
     uint32_t *live;           // [pairs][live_words] bit T: tile T is counted for the pair
     uint32_t live_words;
     uint16_t *thr_out;        // [B] the threshold of every query (0: not pruned, every tile is counted)
+    uint16_t *i1_out;         // [B] i* + 1 of every query with a threshold: Z holds less than 1e-12 at i <= i* (prob_lookup starts there)
     unsigned long long *stats;  // [kPruneStatCopies][8]: [0] += live tiles, [1] += pairs ... (reporting) or null
     const uint32_t *ubitmap;    // debug (RTX_PRUNE_CHECK): the union bitmap
     uint32_t ustride_bytes;
@@ -192,6 +193,7 @@ struct ProbParams {
     uint8_t *status;  // [n_q]
     uint32_t *ndist;  // [n_q] number of distinct hit counts D_q (work accounting)
     const uint16_t *prune_thr;  // [B] tile pruning: references with a count up to this carry nothing (rtx_prune.hip) or null
+    const uint16_t *prune_i1;   // [B] ... and the sums over i may start here (everything below holds less than 1e-12 of Z)
 };
 
 struct WalkParams {

@@ -151,7 +151,10 @@ __global__ __launch_bounds__(256) void prob_lookup_kernel(ProbParams p, ProbTabl
         const uint16_t *t_sat = tb.sat + tb.moff[t];
         const double *Ct = tb.cmf + tb.off[t];
         const double *Rt = tb.ratio + tb.off[t];
-        const uint32_t i_lo = M > 0 ? t_ilo[M] : 0u;
+        uint32_t i_lo = M > 0 ? t_ilo[M] : 0u;
+        // a pruned query: everything at i <= i* holds less than 1e-12 of Z (rtx_prune.hip, step 2 of the threshold) -- the sums
+        // start behind it: one slice of i instead of three on the bench workload, and fewer rows still moving there
+        if (u_thr && p.prune_i1) { const uint32_t i1 = p.prune_i1[q]; i_lo = i1 > i_lo && i1 <= n ? i1 : i_lo; }
         // saturation index of every distinct count, gathered by all threads at once (row_h as staging)
         for (uint32_t j = tid; j < D; j += 256) {
             const uint32_t m = ms[D - 1 - j];

@@ -186,7 +186,7 @@ __global__ __launch_bounds__(64) void prune_kernel(PruneParams p, ProbTables tb)
 #endif
         // ---- 3. the largest count a skipped tile may hold
         const uint32_t t = p.t[q], n = t >> 1;
-        uint32_t u_max = 0;
+        uint32_t u_max = 0, i1_q = 0;
         if (t >= 16u && t <= tb.tmax && M >= 1u && n >= 2u) {
             const double *lf = p.lnfact;
             const double ln_total = ln_binom_tab(lf, t + n - 1, n);
@@ -229,11 +229,12 @@ __global__ __launch_bounds__(64) void prune_kernel(PruneParams p, ProbTables tb)
                     }
                     first_fail = 0xFFFFFFFFu - wave_max_u32p(0xFFFFFFFFu - first_fail);
                     u_max = first_fail - 1u;
+                    i1_q = i1;
                 }
             }
         }
         thr[x] = u_max;
-        if (lane == 0) p.thr_out[q] = (uint16_t)u_max;
+        if (lane == 0) { p.thr_out[q] = (uint16_t)u_max; p.i1_out[q] = (uint16_t)(u_max ? i1_q : 0u); }
         // reporting: sums of the lower bound of the best hit, of the threshold, of the largest tile bound
         st[2] += M; st[3] += u_max; st[4] += ub_best; st[5] += 1ull;
         if (ub_best < M) st[6] += 1ull;  // must never happen: a block's bound below one of its references' counts

@@ -334,6 +334,9 @@ int rtx_debug_order(rtx_index *index, uint32_t *perm /*n_queries*/);
  * 0), [7] debug builds only, [8] (query, tile) combinations with a count above the query's threshold -- what exact knowledge would
  * have counted --, [9] queries with a threshold; all 0 if the run did not prune */
 int rtx_debug_prune_stats(rtx_index *index, uint64_t *out /*10*/);
+/* table / Z of a query of the last sub-batch as the PRUNED run computed it (0 for the counts up to the query's threshold), its Z and the
+ * threshold; must be called before any other tap (those recount the sub-batch in full) */
+int rtx_debug_pruned_prob_table(rtx_index *index, uint64_t query, double *table_over_z /*t+1*/, double *z, uint32_t *threshold);
 /* Lineage::new(label, tree, probs).evaluate() (src/lineage.rs:61-112) on a caller-supplied
  * probability vector: runs taxon_prefix + lineage_walk + the host finalisation for one
  * pseudo-query.  Lets the reference's lineage KATs pin the device walk.  Small trees only

@@ -337,6 +337,14 @@ class Index:
         check(self._lib.rtx_debug_prob_table(self._h, q, ptr(out, f64p), C.byref(z)))
         return out, z.value
 
+    def debug_pruned_prob_table(self, q: int, t: int):
+        """table / Z of query q as the pruned run computed it, Z and the query's threshold (before any other tap)."""
+        out = np.zeros(t + 1, dtype=np.float64)
+        z = C.c_double()
+        thr = C.c_uint32()
+        check(self._lib.rtx_debug_pruned_prob_table(self._h, q, ptr(out, f64p), C.byref(z), C.byref(thr)))
+        return out, z.value, int(thr.value)
+
     def debug_probs(self, q: int) -> np.ndarray:
         out = np.zeros(self.n_refs, dtype=np.float64)
         check(self._lib.rtx_debug_probs(self._h, q, ptr(out, f64p)))

@@ -1915,7 +1915,7 @@ int rtx_batch_prob_work(rtx_index *ix, uint64_t *sum_grid_points, uint64_t *sum_
 
 // ---- debug taps -------------------------------------------------------------------------
 static int debug_recount_full(rtx_index *ix);
-static int debug_slot(rtx_index *ix, uint64_t query, uint32_t *slot) {
+static int debug_slot_as_run(rtx_index *ix, uint64_t query, uint32_t *slot) {  // the scratch as the run left it (no recount)
     int rc = bind(ix);
     if (rc) return rc;
     if (!ix->synced) { set_error("debug tap: batch not synchronised"); return RTX_ERR_STATE; }
@@ -1924,7 +1924,11 @@ static int debug_slot(rtx_index *ix, uint64_t query, uint32_t *slot) {
     const uint64_t pos = ix->h_inv[query];  // position in the processing order (valid once the stream is synchronised)
     if (pos < last0) { set_error("debug tap: query %llu not in the last sub-batch", (unsigned long long)query); return RTX_ERR_INVALID; }
     *slot = (uint32_t)(pos - last0);
-    return debug_recount_full(ix);
+    return RTX_OK;
+}
+static int debug_slot(rtx_index *ix, uint64_t query, uint32_t *slot) {
+    int rc = debug_slot_as_run(ix, query, slot);
+    return rc ? rc : debug_recount_full(ix);
 }
 
 // After a pruned run the scratch of the last sub-batch holds the counts of the live tiles only and a histogram with the
@@ -1992,6 +1996,28 @@ int rtx_debug_prob_table(rtx_index *ix, uint64_t query, double *table_over_z, do
     for (uint32_t m = 0; m <= tt; m++)
         if (!hist[m]) table_over_z[m] = 0.0;  // entries of absent counts are never written
     if (z) RTX_HIP(hipMemcpy(z, ix->d_z.p + ix->h_inv[query], 8, hipMemcpyDeviceToHost));
+    return RTX_OK;
+}
+
+// table / Z of a query as the PRUNED run computed it (entries of the counts up to the threshold are 0), its Z and its threshold
+int rtx_debug_pruned_prob_table(rtx_index *ix, uint64_t query, double *table_over_z, double *z, uint32_t *threshold) {
+    uint32_t slot;
+    int rc = debug_slot_as_run(ix, query, &slot);
+    if (rc) return rc;
+    if (!ix->prune_used) { set_error("rtx_debug_pruned_prob_table: the last run did not prune"); return RTX_ERR_STATE; }
+    if (ix->dbg_full) { set_error("rtx_debug_pruned_prob_table: another tap has recounted the sub-batch in full"); return RTX_ERR_STATE; }
+    rtx_index::Scratch &sc = ix->sc[ix->last_set];
+    uint32_t tt = 0;
+    uint16_t thr = 0;
+    RTX_HIP(hipMemcpy(&tt, sc.d_t.p + slot, 4, hipMemcpyDeviceToHost));
+    RTX_HIP(hipMemcpy(&thr, sc.d_prune_thr.p + slot, 2, hipMemcpyDeviceToHost));
+    std::vector<uint32_t> hist(tt + 1);
+    RTX_HIP(hipMemcpy(hist.data(), sc.d_hist.p + (size_t)slot * ix->hstride, (tt + 1) * 4, hipMemcpyDeviceToHost));
+    RTX_HIP(hipMemcpy(table_over_z, sc.d_table_z.p + (size_t)slot * ix->hstride, (tt + 1) * 8, hipMemcpyDeviceToHost));
+    for (uint32_t m = 0; m <= tt; m++)
+        if (!hist[m] || m <= thr) table_over_z[m] = 0.0;  // entries of absent counts are never written; up to the threshold: 0 by construction
+    if (z) RTX_HIP(hipMemcpy(z, ix->d_z.p + ix->h_inv[query], 8, hipMemcpyDeviceToHost));
+    if (threshold) *threshold = thr;
     return RTX_OK;
 }
 

@@ -1224,3 +1224,40 @@ def test_tile_pruning_randomised(oracle, seed):
                                            f"prune random seed {seed} skip {skip} q {q}"))
     print(f"seed {seed}: queries with another lineage in the pruned rows (exact ties): {flips}")
     assert len(flips) <= 2 and exc.n["ties"] <= 4, (flips, exc.n)
+
+
+def test_pruned_probabilities_against_the_oracle(oracle):
+    """The probabilities of the PRUNED run itself (the other taps recount in full): table[m] / Z as prob_lookup left it against the
+    oracle's probability of every reference -- within 1e-9 (proved: a few 1e-12) for the references above the query's threshold,
+    and the references at or below it, which get exactly 0, hold less than 1e-9 together in the oracle."""
+    db = synth.make_db(90000)
+    parts = [synth.make_queries(db, 120, seed=7, exact_frac=0.1), synth.make_queries(db, 40, seed=8, mu_q=0.1, exact_frac=0.0),
+             synth.make_queries(db, 20, seed=9, mu_q=0.2, exact_frac=0.0)]
+    seqs = [p.seq(q) for p in parts for q in range(p.n)]
+    off = np.zeros(len(seqs) + 1, np.uint64)
+    off[1:] = np.cumsum([len(s) for s in seqs])
+    bases = np.concatenate(seqs)
+    tree = rx.Tree.new_flat(db.lineages, db.seq_bytes, db.seq_off)
+    otree = oracle.tree_new_flat(db.lineages, db.seq_bytes, db.seq_off)
+    ix = rx.Index(tree)
+    ex = ix.exact_matches(bases, off)
+    worst, worst_low, n_thr, checked = 0.0, 0.0, 0, 0
+    for skip in (False, True):
+        res = ix.classify(bases, off, *ex, skip_exact_matches=skip)
+        assert ix.debug_prune_stats()["pairs"] > 0
+        taps = {q: ix.debug_pruned_prob_table(q, int(res.t[q])) for q in range(0, len(seqs), 4) if res.status[q] == 0}   # before any other tap
+        for q, (tz, z, thr) in taps.items():
+            t, counts = otree.hit_counts(seqs[q], skip_exact=skip)
+            counts = np.asarray(counts)
+            probs = np.asarray(oracle.highest_hit_prob_per_reference(t, t // 2, counts))
+            assert t == res.t[q]
+            hi = counts > thr
+            worst = max(worst, float(np.abs(tz[counts[hi]] - probs[hi]).max()))
+            if thr:
+                n_thr += 1
+                assert (tz[: thr + 1] == 0.0).all()
+                worst_low = max(worst_low, float(probs[~hi].sum()))
+            checked += 1
+    print(f"pruned probabilities: {checked} queries ({n_thr} with a threshold): max |p - p_oracle| = {worst:.3e} above the threshold, "
+          f"the references at or below it hold at most {worst_low:.3e} in the oracle")
+    assert checked >= 60 and n_thr >= 40 and worst < 1e-9 and worst_low < 1e-9

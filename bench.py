@@ -61,10 +61,8 @@ def parse():
     ap.add_argument("--queries", type=int, default=0, help="queries per GPU per step (overrides --config)")
     ap.add_argument("--sub-batch", type=int, default=0, help="queries per kernel launch (0 = auto)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of each leg of the cpu_baseline sample")
-    ap.add_argument("--streams", type=int, default=0, help="HIP streams per handle (0 = library default)")
     ap.add_argument("--no-cluster", action="store_true", help="process the queries in input order (RTX_OPT_CLUSTER = 0)")
     ap.add_argument("--u16-counts", action="store_true", help="counts travel as u16 instead of packed 10 bits (RTX_OPT_PACKED_COUNTS = 0)")
-    ap.add_argument("--no-quad", action="store_true", help="hit_count with one wave per (query, tile) (RTX_OPT_HIT_QUAD = 0)")
     ap.add_argument("--no-pair", action="store_true", help="hit_count with one query per wave (RTX_OPT_HIT_PAIR = 0; A/B measurements)")
     ap.add_argument("--no-locator", action="store_true", help="processing order by min-hash alone (RTX_OPT_LOCATOR = 0; A/B measurements)")
     ap.add_argument("--no-tile-prune", action="store_true", help="hit_count counts every tile of 8192 references (RTX_OPT_TILE_PRUNE = 0; default: only the tiles that can hold a reference with any probability)")
@@ -399,9 +397,9 @@ def main():
     else:
         qs = synth.make_queries(db, args.queries, seed=3 + rank, first_label=rank * args.queries)   # rank-specific queries
         tree = rx.Tree.new_flat(db.lineages, db.seq_bytes, db.seq_off, kmer_map=False)   # bitmaps built on the GPU
-        index = rx.Index(tree, device=local_rank, sub_batch=args.sub_batch, streams=args.streams,
+        index = rx.Index(tree, device=local_rank, sub_batch=args.sub_batch,
                          stage_timing=not args.hit_events_only, cluster=False if args.no_cluster else None,
-                         packed_counts=False if args.u16_counts else None, hit_quad=False if args.no_quad else None,
+                         packed_counts=False if args.u16_counts else None,
                          tile_skip=False if args.no_tile_skip else None, hit_pair=False if args.no_pair else None,
                          locator=False if args.no_locator else None, tile_prune=False if args.no_tile_prune else None)
         t0 = time.perf_counter()

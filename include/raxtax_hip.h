@@ -182,26 +182,14 @@ int rtx_index_set_batch(rtx_index *index, uint32_t sub_batch);
 #define RTX_OPT_PROB_MODE 2
 #define RTX_OPT_STAGE_TIMING 6 /* 0 (default): HIP events around hit_count only; 1: around every kernel
                                  (rtx_batch_stage_times then reports all stages; adds ~1 ms per 100k queries) */
-#define RTX_OPT_STREAMS 3 /* 1 (default) = one HIP stream; 2 = the two small latency-bound kernels (kmer_extract of
-                             sub-batch i+2, lineage_walk of sub-batch i) run on a side stream beside hit_count of
-                             sub-batch i+1.  Measured: no gain on MI355X (hit_count slows down by what is hidden),
-                             and putting prob/prefix beside hit_count costs it its L2 hit rate;
-                             3 = prob_lookup + taxon_prefix + walk of sub-batch i on the side stream beside kmer_extract +
-                             hit_count of sub-batch i+1 (two scratch sets) */
 #define RTX_OPT_CLUSTER 7 /* 1 (default): the queries of a batch are processed in an order that puts related
                              queries next to each other (min-hash sketches, rtx_cluster.hip) so that bitmap rows
                              are reused; 0: input order.  Results are identical and always in input order. */
-#define RTX_OPT_HIT_QUAD 9 /* 0 (default): one wave per (query, tile) fetching its own rows; 1: with t <= 1023 and RTX_OPT_CLUSTER on,
-                           * hit_count runs four neighbouring queries per workgroup and loads every bitmap row they need once,
-                           * through LDS (rtx_hit_quad.hip) -- half the bytes out of L2, identical results, but slower on
-                           * MI355X as measured: kept for A/B measurements */
 #define RTX_OPT_PACKED_COUNTS 8 /* 1 (default): with t <= 1023 the hit counts travel from hit_count to taxon_prefix
                                  * packed, 10 bits per reference (low byte + 2 high bits); 0: as u16 (A/B measurements) */
 #define RTX_OPT_HIT_PAIR 11 /* 1 (default): with t <= 1023 and RTX_OPT_CLUSTER on, hit_count runs two neighbouring queries per wave (two
                              * sets of bit planes in registers) and loads the bitmap rows they share once (rtx_hit_pair.hip);
-                             * 2: the same with one plane set in registers at a time (the planes of the shared rows parked in
-                             * 5 KB of global scratch per query and tile; more rows in flight per wave), for t <= 960;
-                             * identical results; 0: one query per wave */
+                             * identical results; 0: one query per wave (the kernel of longer queries; A/B measurements) */
 #define RTX_OPT_TILE_SKIP 10 /* 1 (default): hit_count records the largest count of every tile of 8192 references and
                               * taxon_prefix (lineage.rs:61-66) reads only the tiles that hold a reference whose probability
                               * reaches 1e-30 -- the others add less than n_refs * 1e-30 to any prefix sum, far below what a
@@ -212,19 +200,19 @@ int rtx_index_set_batch(rtx_index *index, uint32_t sub_batch);
                             * min-hashes only break ties; 0: min-hash order alone.  Scheduling only: results are identical */
 #define RTX_OPT_TILE_PRUNE 13 /* 1 (default): hit_count counts only the tiles of 8192 references that can hold a reference with any
                                * probability -- decided from upper bounds (the queries counted against a union bitmap over blocks
-                               * of 32 references) and a per-query threshold u: the references with a count up to u hold less
+                               * of 64 references) and a per-query threshold u: the references with a count up to u hold less
                                * than 1e-12 of probability together and are treated as references without a hit (rtx_prune.hip;
                                * every probability and confidence sum stays within 1e-11 of the full count, the result of a
                                * query does not depend on the rest of the batch).  Takes effect with t <= 1023,
                                * RTX_OPT_HIT_PAIR = 1, RTX_OPT_TILE_SKIP = 1, the whole database on the handle and 8 tiles or more;
                                * the debug taps recount the tapped sub-batch in full.  0: every tile is counted */
+/* RTX_OPT_SUB_BATCH, _PACKED_COUNTS, _HIT_PAIR, _TILE_PRUNE and _PROB_MODE shape the workspace that rtx_batch_upload sizes:
+ * setting one of them drops the uploaded batch (rtx_batch_run then fails with RTX_ERR_STATE until the batch is uploaded again). */
 int rtx_index_set_option(rtx_index *index, int option, uint64_t value);
 /* Process-wide default for handles created afterwards.  RTX_DEFAULT_SEGMENT_CLASSES (default 1): at index creation
  * every (row, tile) segment of the bitmaps is classified; empty segments are never read and segments with at most
  * 16 references are added from 32-byte slots through byte counters instead of 1-KiB row reads (rtx_segments.hip).
- * 2: segments with 17-64 references are kept as 128 bytes of bit positions that hit_count scatters into a row image
- * in LDS (17 % fewer bytes requested at N = 500k, but no faster: the scatter and fold cost what the row read did);
- * 0: every segment is read densely.  Results are identical for every value (A/B measurements). */
+ * 0: every segment is read densely.  Results are identical for either value (A/B measurements). */
 #define RTX_DEFAULT_SEGMENT_CLASSES 1
 int rtx_set_default_option(int option, uint64_t value);
 

@@ -215,9 +215,9 @@ DEFAULT_SEGMENT_CLASSES = 1   # RTX_DEFAULT_SEGMENT_CLASSES of the library (rtx_
 class Index:
     """Device-resident index + batch workspace of one GPU (rtx_index)."""
 
-    def __init__(self, tree: Tree, device: int = 0, sub_batch: int = 0, prob_mode: int = 0, streams: int = 0,
+    def __init__(self, tree: Tree, device: int = 0, sub_batch: int = 0, prob_mode: int = 0,
                  stage_timing: bool = False, cluster: Optional[bool] = None, segment_classes=None,
-                 packed_counts: Optional[bool] = None, hit_quad: Optional[bool] = None,
+                 packed_counts: Optional[bool] = None,
                  tile_skip: Optional[bool] = None, hit_pair=None, locator: Optional[bool] = None, tile_prune: Optional[bool] = None):
         self._lib = _lib.load()
         self.tree = tree
@@ -232,16 +232,12 @@ class Index:
             check(self._lib.rtx_index_set_batch(self._h, sub_batch))
         if prob_mode:
             check(self._lib.rtx_index_set_option(self._h, 2, prob_mode))
-        if streams:
-            check(self._lib.rtx_index_set_option(self._h, 3, streams))
         if stage_timing:
             check(self._lib.rtx_index_set_option(self._h, 6, 1))
         if cluster is not None:
             check(self._lib.rtx_index_set_option(self._h, 7, int(cluster)))
         if packed_counts is not None:
             check(self._lib.rtx_index_set_option(self._h, 8, int(packed_counts)))
-        if hit_quad is not None:
-            check(self._lib.rtx_index_set_option(self._h, 9, int(hit_quad)))
         if tile_skip is not None:
             check(self._lib.rtx_index_set_option(self._h, 10, int(tile_skip)))
         if hit_pair is not None:

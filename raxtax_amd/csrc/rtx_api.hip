@@ -129,10 +129,8 @@ struct rtx_index {
     uint32_t ntiles = 0;        // 8192-reference tiles
     DevBuf<uint32_t> d_bitmap, d_row_of, d_list_len;
     // segment classes (rtx_segments.hip): class / sparse slot of every (row, tile) segment, slots of 32 local ids
-    DevBuf<uint32_t> d_seginfo, d_seg_sbase, d_seg_mbase;
-    DevBuf<unsigned long long> d_seg_dbits, d_seg_sbits, d_seg_mbits;
-    DevBuf<uint16_t> d_midslots;  // [n_mid_slots][kSegMidEntries] positions of the mid segments
-    uint64_t n_mid_slots = 0;
+    DevBuf<uint32_t> d_seginfo, d_seg_sbase;
+    DevBuf<unsigned long long> d_seg_dbits, d_seg_sbits;
     uint32_t seg_blocks = 0;  // > 0: kmer_extract uses the bit tables (many tiles)
     DevBuf<uint16_t> d_segslots;
     uint64_t n_seg_slots = 0;
@@ -160,9 +158,7 @@ struct rtx_index {
     // ---- processing order of the batch (rtx_cluster.hip): perm[position] = query, inv[query] = position
     uint32_t cluster = 1;  // RTX_OPT_CLUSTER
     uint32_t packed_opt = 1;  // RTX_OPT_PACKED_COUNTS
-    uint32_t quad_opt = 0;    // RTX_OPT_HIT_QUAD (off until verified on the GPU)
     uint32_t tile_skip = 1;   // RTX_OPT_TILE_SKIP: taxon_prefix reads only the tiles that hold a reference with p >= 1e-30
-    bool quad_used = false;   // the last run went through hit_count_quad_kernel
     uint32_t pair_opt = 1;    // RTX_OPT_HIT_PAIR
     uint32_t prune_opt = 1;   // RTX_OPT_TILE_PRUNE: hit_count visits only the tiles that can hold a reference with any probability (rtx_prune.hip)
     bool prune_used = false;  // the last run pruned
@@ -174,8 +170,7 @@ struct rtx_index {
     DevBuf<unsigned long long> d_prune_stats;
     uint32_t locator_opt = 1; // RTX_OPT_LOCATOR: the sort key of the processing order is led by the query's position in the database
     DevBuf<uint32_t> d_loc_table;  // 12-mer -> lowest reference position (rtx_cluster.hip); only when built from sequences
-    bool pair_used = false;   // ... through hit_count_pair_kernel
-    int pair_variant = 1;     // 1: two plane sets in registers; 2: one at a time, the shared planes parked in global scratch
+    bool pair_used = false;   // the last run went through hit_count_pair_kernel
     DevBuf<uint32_t> d_group_rows;
     uint32_t n_groups_run = 0;  // groups of the whole batch (n_sub * groups_per_sub): the second half of d_group_rows starts there
     uint32_t groups_per_sub = 0;
@@ -190,33 +185,29 @@ struct rtx_index {
     uint64_t sum_query_bytes = 0;
     uint32_t kstride = 0, rstride = 0, hstride = 0, tmax = 0;
     int planes = 10;
-    // ---- sub-batch scratch: two sets, so that consecutive sub-batches can run on two streams
-    // (the HBM/L2-bound hit_count of one overlaps the latency-bound prob/prefix/walk of the other)
+    // ---- sub-batch scratch: two sets -- a staged (reference-sharded) run alternates between them, so that the exchange of
+    // one sub-batch can overlap with the counting of the next; a whole-database handle uses set 0 only
     uint32_t sub_batch_req = 0, sub_batch = 0;
     struct Scratch {
         DevBuf<uint16_t> d_kmers, d_counts, d_tilemax;
-        DevBuf<uint32_t> d_rows, d_t, d_nrows, d_hist, d_order, d_srows, d_nsparse, d_mrows, d_nmid;
+        DevBuf<uint32_t> d_rows, d_t, d_nrows, d_hist, d_order, d_srows, d_nsparse;
         DevBuf<unsigned long long> d_dmask;
         DevBuf<double> d_table_z, d_prefix;
         DevBuf<uint2> d_urec;   // hit_count_pair_kernel: union row lists of the pairs of the sub-batch
         DevBuf<uint32_t> d_nu;
-        DevBuf<uint4> d_pair_planes;
         // tile pruning: the queries counted against the union bitmap (every row dense: constant masks), the live tiles per pair
         DevBuf<unsigned long long> d_uones;
         DevBuf<uint32_t> d_uzero, d_uhist, d_live;
         DevBuf<uint16_t> d_ucounts, d_utmax, d_prune_thr, d_prune_i1;
     } sc[2];
-    uint32_t n_streams_req = 1, n_streams = 1;
     bool staged = false;  // driven with rtx_shard_*: sub-batch sb works in scratch set sb & 1, so that the exchange of one
                           // sub-batch (RCCL, on the caller's stream) can overlap with the counting of the next
-    hipStream_t stream2 = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     uint32_t last_set = 0;  // scratch set of the last sub-batch (debug taps)
     DevBuf<double> d_probs_dbg;
     DevBuf<uint16_t> d_counts_dbg;
     // ---- per-query results
     DevBuf<uint8_t> d_status;
-    DevBuf<uint32_t> d_t_all, d_nrows_all, d_n_rows, d_flags, d_ndist, d_nmid_all;
+    DevBuf<uint32_t> d_t_all, d_nrows_all, d_n_rows, d_flags, d_ndist;
     DevBuf<double> d_gs, d_z;
     DevBuf<unsigned long long> d_hq, d_row_start, d_cursor;
     DevBuf<DevRow> d_arena;
@@ -243,7 +234,7 @@ struct rtx_index {
     PinBuf<uint32_t> h_nrows_all, h_n_rows;
     // streamed download: per sub-batch a snapshot of the arena cursor + an event; rtx_batch_download copies and
     // finalises finished sub-batches on `copy_stream` while later ones are still running
-    std::vector<hipEvent_t> ev_sub, ev_cnt, ev_pre;
+    std::vector<hipEvent_t> ev_sub;
     PinBuf<unsigned long long> h_cursor_sub;
     hipStream_t copy_stream = nullptr;
     uint32_t n_sub_run = 0;
@@ -255,12 +246,7 @@ struct rtx_index {
     ~rtx_index() {
         for (auto e : events) (void)hipEventDestroy(e);
         for (auto e : ev_sub) (void)hipEventDestroy(e);
-        for (auto e : ev_cnt) (void)hipEventDestroy(e);
-        for (auto e : ev_pre) (void)hipEventDestroy(e);
         if (copy_stream) (void)hipStreamDestroy(copy_stream);
-        if (ev_fork) (void)hipEventDestroy(ev_fork);
-        if (ev_join) (void)hipEventDestroy(ev_join);
-        if (stream2) (void)hipStreamDestroy(stream2);
         if (stream) (void)hipStreamDestroy(stream);
     }
 };
@@ -297,7 +283,7 @@ SubBatch sub_batch_of(rtx_index *ix, uint32_t sb, bool timed) {
     b.sb = sb;
     b.q0 = (uint64_t)sb * ix->sub_batch;
     b.nq = (uint32_t)std::min<uint64_t>(ix->sub_batch, ix->n_q - b.q0);
-    b.set = (ix->n_streams == 2 || ix->staged) ? (sb & 1u) : 0u;
+    b.set = ix->staged ? (sb & 1u) : 0u;
     b.s = ix->stream;
     b.timed = timed;
     b.timed_all = timed && ix->stage_timing != 0;
@@ -339,11 +325,6 @@ static KmerParams kmer_params(rtx_index *ix, const SubBatch &b) {
     kp.seg_sbits = ix->d_seg_sbits.p;
     kp.seg_sbase = ix->d_seg_sbase.p;
     kp.seg_blocks = ix->seg_blocks;
-    kp.seg_mbits = ix->n_mid_slots && ix->seg_blocks ? ix->d_seg_mbits.p : nullptr;
-    kp.seg_mbase = ix->d_seg_mbase.p;
-    kp.mrows = sc.d_mrows.p;
-    kp.nmid = sc.d_nmid.p;
-    kp.nmid_all = ix->d_nmid_all.p;
     kp.rows = sc.d_rows.p;
     kp.rstride = ix->rstride;
     kp.dmask = sc.d_dmask.p;
@@ -386,9 +367,6 @@ int enqueue_hit(rtx_index *ix, const SubBatch &b, uint32_t flags, hipStream_t s)
     hp.zero_row = ix->n_rows;
     hp.srows = sc.d_srows.p;
     hp.nsparse = sc.d_nsparse.p;
-    hp.mrows = sc.d_mrows.p;
-    hp.nmid = ix->n_mid_slots ? sc.d_nmid.p : nullptr;
-    hp.midslots = ix->d_midslots.p;
     hp.segslots = ix->d_segslots.p;
     hp.ntiles = ix->ntiles;
     hp.t = sc.d_t.p;
@@ -405,18 +383,11 @@ int enqueue_hit(rtx_index *ix, const SubBatch &b, uint32_t flags, hipStream_t s)
     hp.exact_ids = ix->d_exact_ids.p;
     hp.exact_off = ix->d_exact_off.p;
     hp.nq = b.nq;
-    hp.group_rows = ix->quad_used || ix->pair_used ? ix->d_group_rows.p : nullptr;
+    hp.group_rows = ix->pair_used ? ix->d_group_rows.p : nullptr;
     hp.group_base = b.sb * ix->groups_per_sub;
     hp.pair_urec = sc.d_urec.p;
     hp.pair_nu = sc.d_nu.p;
     hp.pair_ustride = 2u * ix->rstride;
-    hp.pair_planes = sc.d_pair_planes.p;
-    {   // experiment builds (RTX_EXP_PRUNE_EMU in rtx_hit_pair.hip): prune from the third launch of the process on
-        static int launches = 0;
-        static const bool emu = getenv("RTX_EXP_PRUNE_EMU_ON") != nullptr;
-        hp.flags_prune = emu && launches >= 2 ? 1u : 0u;
-        launches++;
-    }
     hp.live = nullptr;
     hp.live_words = 0;
     const bool prune = ix->prune_used && !ix->dbg_full_run;
@@ -430,7 +401,6 @@ int enqueue_hit(rtx_index *ix, const SubBatch &b, uint32_t flags, hipStream_t s)
         up.n_refs = ix->u_nblocks;
         up.dmask = sc.d_uones.p;
         up.nsparse = sc.d_uzero.p;
-        up.nmid = nullptr;
         up.ntiles = ix->u_ntiles;
         const uint32_t unpad = ix->u_ntiles * 8192u;
         up.counts = nullptr;  // packed like the counts of the database: low bytes, behind them the high bits
@@ -442,7 +412,7 @@ int enqueue_hit(rtx_index *ix, const SubBatch &b, uint32_t flags, hipStream_t s)
         up.flags = 0;
         up.group_base = hp.group_base + ix->n_groups_run;  // work accounting apart from the counting proper
         if (b.timed) RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_TILE_BOUNDS, 0), s));
-        launch_hit_count_pair(s, up, b.nq, ix->u_ntiles, 1);  // the union of the pair's rows serves both passes
+        launch_hit_count_pair(s, up, b.nq, ix->u_ntiles);  // the union of the pair's rows serves both passes
         if (b.timed) {
             RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_TILE_BOUNDS, 1), s));
             RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_TILE_PRUNE, 0), s));
@@ -495,9 +465,7 @@ int enqueue_hit(rtx_index *ix, const SubBatch &b, uint32_t flags, hipStream_t s)
             RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_HIT_COUNT, 0), s));
         }
     }
-    if (ix->pair_used) {
-        launch_hit_count_pair(s, hp, b.nq, ix->ntiles, ix->pair_variant);
-    } else if (ix->quad_used) launch_hit_count_quad(s, hp, b.nq, ix->ntiles);
+    if (ix->pair_used) launch_hit_count_pair(s, hp, b.nq, ix->ntiles);
     else launch_hit_count(s, hp, b.nq, ix->ntiles, ix->planes);
     if (b.timed) RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_HIT_COUNT, 1), s));
     return RTX_OK;
@@ -635,32 +603,23 @@ int begin_run(rtx_index *ix, uint32_t *n_sub_out, bool *timed_out, bool cluster)
     RTX_HIP(hipMemsetAsync(ix->d_cursor.p, 0, sizeof(unsigned long long), ix->stream));
     RTX_HIP(hipMemsetAsync(ix->d_flags.p, 0, sizeof(uint32_t), ix->stream));
     const uint32_t n_sub = (uint32_t)((ix->n_q + ix->sub_batch - 1) / ix->sub_batch);
-    // four neighbours per workgroup only pays when neighbours are related: with the processing order on
-    ix->quad_used = ix->quad_opt && cluster && ix->planes <= 10 && ix->n_q > 2;
-    // two neighbours per wave: the same condition; the mid-segment lists are folded by hit_count_kernel only
-    static const bool pair_any_order = getenv("RTX_EXP_PAIR_ANY_ORDER") != nullptr;  // experiments (tools/exp_order_potential2.py): the pair kernel on a host-made order
-    ix->pair_used = !ix->quad_used && ix->pair_opt && (cluster || pair_any_order) && ix->planes <= 10 && ix->n_q > 1 && ix->rstride <= 4096 && !(ix->n_mid_slots && ix->pair_opt == 2);  // (the sequential variant keeps its lists alive into the epilogue: no room for the byte counters of a whole tile + mid ids)
-    ix->groups_per_sub = ix->pair_used ? (ix->sub_batch + 1u) / 2u : (ix->sub_batch + 3u) / 4u;
+    // two neighbours per wave only pays when neighbours are related: with the processing order on
+    ix->pair_used = ix->pair_opt && cluster && ix->planes <= 10 && ix->n_q > 1 && ix->rstride <= 4096;
+    ix->groups_per_sub = (ix->sub_batch + 1u) / 2u;
     // tile pruning: the pair kernel, the memoised tables (their ln cmf rows give the threshold), taxon_prefix skipping tiles by
     // their largest count, the whole database on this handle
-    ix->prune_used = ix->prune_opt && ix->pair_used && ix->pair_opt != 2 && ix->use_tables && ix->tile_skip && ix->d_ubitmap.p &&
-                     ix->n_refs == ix->n_total && !ix->staged && ix->sc[0].d_ucounts.p != nullptr;
+    ix->prune_used = ix->prune_opt && ix->pair_used && ix->use_tables && ix->tile_skip && ix->d_ubitmap.p &&
+                     ix->n_refs == ix->n_total && !ix->staged &&
+                     // the scratch of the pruning was sized at the upload (alloc_scratch_set) for this sub-batch size
+                     ix->sc[0].d_ucounts.p != nullptr && ix->sc[0].d_ucounts.n >= (size_t)ix->sub_batch * ix->u_ntiles * 8192u &&
+                     ix->sc[0].d_prune_thr.n >= ix->sub_batch && ix->sc[0].d_live.n >= (size_t)((ix->sub_batch + 1u) / 2u) * ((ix->ntiles + 31u) / 32u + 1u);
     ix->dbg_full = false;
     if (ix->prune_used) {
         int rc_s = ix->d_prune_stats.alloc(kPruneStatCopies * 16);
         if (rc_s) return rc_s;
         RTX_HIP(hipMemsetAsync(ix->d_prune_stats.p, 0, kPruneStatCopies * 128, ix->stream));
     }
-    // the sequential variant keeps every list of a (pair, tile) in one round: t <= kHitListCap - 64
-    ix->pair_variant = ix->pair_used && ix->pair_opt == 2 && ix->tmax + 64u <= kHitListCap ? 2 : 1;
-    if (ix->pair_variant == 2) {
-        for (uint32_t k = 0; k < 2; k++) {
-            if (!ix->sc[k].d_rows.p) continue;  // the second scratch set exists only with two streams / staged runs
-            int rc_p = ix->sc[k].d_pair_planes.alloc((size_t)((ix->sub_batch + 1u) / 2u) * ix->ntiles * 10u * 64u);
-            if (rc_p) return rc_p;
-        }
-    }
-    if (ix->quad_used || ix->pair_used) {
+    if (ix->pair_used) {
         ix->n_groups_run = n_sub * ix->groups_per_sub;
         int rc_g = ix->d_group_rows.alloc((size_t)2 * n_sub * ix->groups_per_sub);  // second half: the bounds pass of the tile pruning
         if (rc_g) return rc_g;
@@ -677,7 +636,10 @@ int begin_run(rtx_index *ix, uint32_t *n_sub_out, bool *timed_out, bool cluster)
     return RTX_OK;
 }
 
-// Enqueues every kernel of the uploaded batch (whole-database handle).
+// Enqueues every kernel of the uploaded batch (whole-database handle), sub-batch after sub-batch on the handle's stream.
+// (Round 2 also offered side streams -- the two small latency-bound kernels, or prob/prefix/walk of sub-batch i, beside the
+// counting of sub-batch i + 1: no gain on MI355X in any arrangement, hit_count holds every wave slot of the chip; DESIGN.md
+// section 3.  Removed in round 3.)
 int enqueue_batch(rtx_index *ix, uint32_t flags) {
     if (ix->n_refs != ix->n_total) {
         set_error("this handle holds a reference shard: drive it with rtx_shard_count/_prob/_walk");
@@ -687,106 +649,33 @@ int enqueue_batch(rtx_index *ix, uint32_t flags) {
     bool timed = false;
     int rc = begin_run(ix, &n_sub, &timed, ix->cluster != 0);
     if (rc) return rc;
-    // Two streams (RTX_OPT_STREAMS = 2): the two small latency-bound kernels leave the main stream -- lineage_walk of
-    // sub-batch i and kmer_extract of sub-batch i+2 run on a side stream beside hit_count of sub-batch i+1; the two
-    // scratch sets alternate.  (Their memory footprint is tiny: hit_count keeps its L2 hit rate, unlike with
-    // prob/prefix beside it.)
-    const bool three = ix->n_streams == 2 && ix->n_streams_req == 3;  // prob/prefix/walk of sub-batch i beside the counting of i+1
-    const bool two = ix->n_streams == 2 && !three;
     ix->stream_dl = false;
     if (n_sub <= 4096) {  // per sub-batch: completion event (+ cursor snapshot) for the streamed download
         if (!ix->copy_stream) RTX_HIP(hipStreamCreateWithFlags(&ix->copy_stream, hipStreamNonBlocking));
-        while (ix->ev_sub.size() < n_sub || ix->ev_cnt.size() < n_sub || ix->ev_pre.size() < n_sub) {
-            hipEvent_t e, e2, e3;
+        while (ix->ev_sub.size() < n_sub) {
+            hipEvent_t e;
             RTX_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
             ix->ev_sub.push_back(e);
-            RTX_HIP(hipEventCreateWithFlags(&e2, hipEventDisableTiming));
-            ix->ev_cnt.push_back(e2);
-            RTX_HIP(hipEventCreateWithFlags(&e3, hipEventDisableTiming));
-            ix->ev_pre.push_back(e3);
         }
         if ((rc = ix->h_cursor_sub.resize(n_sub))) return rc;
         ix->n_sub_run = n_sub;
         ix->stream_dl = true;
-    } else if (two || three) {
-        set_error("two streams need at most 4096 sub-batches");
-        return RTX_ERR_INVALID;
     }
-    hipStream_t side = ix->stream2;
-    if (three) {
-        // RTX_OPT_STREAMS = 3: the main stream counts (kmer_extract + hit_count: the L2 request path and half the VALU),
-        // the side stream does prob_lookup + taxon_prefix with the walk (VALU and an HBM stream) of the sub-batch
-        // before; two scratch sets alternate
-        const bool fuse = ix->n_refs == ix->n_total && ix->n_bnd_local == ix->n_bnd;
-        RTX_HIP(hipEventRecord(ix->ev_fork, ix->stream));
-        RTX_HIP(hipStreamWaitEvent(side, ix->ev_fork, 0));
-        for (uint32_t sb = 0; sb < n_sub; sb++) {
-            SubBatch b = sub_batch_of(ix, sb, timed);
-            if (sb >= 2) RTX_HIP(hipStreamWaitEvent(b.s, ix->ev_pre[sb - 2], 0));  // this scratch set is free again
-            if ((rc = enqueue_count(ix, b, flags))) return rc;
-            RTX_HIP(hipEventRecord(ix->ev_cnt[sb], b.s));
-            RTX_HIP(hipStreamWaitEvent(side, ix->ev_cnt[sb], 0));
-            b.s = side;
-            if ((rc = enqueue_prob_prefix(ix, b, fuse))) return rc;
-            if (!fuse && (rc = enqueue_walk(ix, b, ix->sc[b.set].d_prefix.p, side))) return rc;
-            if (fuse && b.timed_all) {
-                RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_LINEAGE_WALK, 0), side));
-                RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_LINEAGE_WALK, 1), side));
-            }
-            RTX_HIP(hipEventRecord(ix->ev_pre[sb], side));
-            RTX_HIP(hipMemcpyAsync(&ix->h_cursor_sub[sb], ix->d_cursor.p, 8, hipMemcpyDeviceToHost, side));
-            RTX_HIP(hipEventRecord(ix->ev_sub[sb], side));
-        }
-        RTX_HIP(hipEventRecord(ix->ev_join, side));
-        RTX_HIP(hipStreamWaitEvent(ix->stream, ix->ev_join, 0));
-        RTX_HIP(hipGetLastError());
-        return RTX_OK;
-    }
-    if (two) {  // the side stream starts after the resets above; it extracts the k-mers of the first two sub-batches
-        RTX_HIP(hipEventRecord(ix->ev_fork, ix->stream));
-        RTX_HIP(hipStreamWaitEvent(side, ix->ev_fork, 0));
-        for (uint32_t sb = 0; sb < n_sub && sb < 2; sb++) {
-            if ((rc = enqueue_kmer(ix, sub_batch_of(ix, sb, timed), side))) return rc;
-            RTX_HIP(hipEventRecord(ix->ev_cnt[sb], side));
-        }
-    }
+    // the walk rides inside the prefix kernel (the stage time of lineage_walk is then part of taxon_prefix)
+    const bool fuse = ix->n_bnd_local == ix->n_bnd;
     for (uint32_t sb = 0; sb < n_sub; sb++) {
         const SubBatch b = sub_batch_of(ix, sb, timed);
-        if (two) {
-            RTX_HIP(hipStreamWaitEvent(b.s, ix->ev_cnt[sb], 0));  // k-mers and row lists of this sub-batch
-            if ((rc = enqueue_hit(ix, b, flags, b.s))) return rc;
-        } else if ((rc = enqueue_count(ix, b, flags))) {
-            return rc;
-        }
-        if (two && sb >= 2) RTX_HIP(hipStreamWaitEvent(b.s, ix->ev_sub[sb - 2], 0));  // walk(sb-2) still reads this prefix buffer
-        // one stream: the walk rides inside the prefix kernel (the stage time of lineage_walk is then part of taxon_prefix)
-        const bool fuse = !two && ix->n_refs == ix->n_total && ix->n_bnd_local == ix->n_bnd;
-        static const bool count_only = getenv("RTX_EXP_COUNT_ONLY") != nullptr;  // experiments: time hit_count of builds whose counts are wrong on purpose (sync, no download)
-        if (count_only && !two) continue;
+        if ((rc = enqueue_count(ix, b, flags))) return rc;
         if ((rc = enqueue_prob_prefix(ix, b, fuse))) return rc;
-        hipStream_t ws = b.s;
-        if (two) {
-            RTX_HIP(hipEventRecord(ix->ev_pre[sb], b.s));
-            RTX_HIP(hipStreamWaitEvent(side, ix->ev_pre[sb], 0));
-            ws = side;
-        }
-        if (!fuse && (rc = enqueue_walk(ix, b, ix->sc[b.set].d_prefix.p, ws))) return rc;
+        if (!fuse && (rc = enqueue_walk(ix, b, ix->sc[b.set].d_prefix.p, b.s))) return rc;
         if (fuse && b.timed_all) {  // keeps rtx_batch_stage_times whole: an empty interval
-            RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_LINEAGE_WALK, 0), ws));
-            RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_LINEAGE_WALK, 1), ws));
+            RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_LINEAGE_WALK, 0), b.s));
+            RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_LINEAGE_WALK, 1), b.s));
         }
         if (ix->stream_dl) {
-            RTX_HIP(hipMemcpyAsync(&ix->h_cursor_sub[sb], ix->d_cursor.p, 8, hipMemcpyDeviceToHost, ws));
-            RTX_HIP(hipEventRecord(ix->ev_sub[sb], ws));
+            RTX_HIP(hipMemcpyAsync(&ix->h_cursor_sub[sb], ix->d_cursor.p, 8, hipMemcpyDeviceToHost, b.s));
+            RTX_HIP(hipEventRecord(ix->ev_sub[sb], b.s));
         }
-        if (two && sb + 2 < n_sub) {  // the scratch set of this sub-batch is free once its prefix is done (ev_pre, waited above)
-            if ((rc = enqueue_kmer(ix, sub_batch_of(ix, sb + 2, timed), side))) return rc;
-            RTX_HIP(hipEventRecord(ix->ev_cnt[sb + 2], side));
-        }
-    }
-    if (two) {  // everything is complete once the main stream is: join the side stream into it
-        RTX_HIP(hipEventRecord(ix->ev_join, side));
-        RTX_HIP(hipStreamWaitEvent(ix->stream, ix->ev_join, 0));
     }
     RTX_HIP(hipGetLastError());
     return RTX_OK;
@@ -869,22 +758,19 @@ int prepare_workspace(rtx_index *ix, uint64_t n_queries, uint64_t tmax, uint64_t
     // ---- per-query results
     if ((rc = ix->d_status.alloc(n_queries)) || (rc = ix->d_t_all.alloc(n_queries)) || (rc = ix->d_nrows_all.alloc(n_queries)) ||
         (rc = ix->d_n_rows.alloc(n_queries)) || (rc = ix->d_gs.alloc(n_queries)) || (rc = ix->d_z.alloc(n_queries)) ||
-        (rc = ix->d_hq.alloc(n_queries)) || (rc = ix->d_row_start.alloc(n_queries)) || (rc = ix->d_ndist.alloc(n_queries)) || (rc = ix->d_nmid_all.alloc(n_queries)))
+        (rc = ix->d_hq.alloc(n_queries)) || (rc = ix->d_row_start.alloc(n_queries)) || (rc = ix->d_ndist.alloc(n_queries)))
         return rc;
     const uint64_t want_arena = n_queries * 8 + 4096;
     if (ix->arena_cap < want_arena) {
         if ((rc = ix->d_arena.alloc(want_arena))) return rc;
         ix->arena_cap = want_arena;
     }
-    // ---- sub-batch scratch (x2 when two streams are used), sized against free HBM
-    ix->n_streams = (ix->n_streams_req >= 2 && n_queries > 1) ? 2u : 1u;
-    if (ix->n_streams == 2 && !ix->stream2) {
-        RTX_HIP(hipStreamCreateWithFlags(&ix->stream2, hipStreamNonBlocking));
-        RTX_HIP(hipEventCreateWithFlags(&ix->ev_fork, hipEventDisableTiming));
-        RTX_HIP(hipEventCreateWithFlags(&ix->ev_join, hipEventDisableTiming));
-    }
-    const uint64_t per_q = ((ix->pair_opt == 2 ? (uint64_t)ix->ntiles * 5120 : 0) + (uint64_t)ix->kstride * 2 + (uint64_t)ix->rstride * 12 + 4 + (uint64_t)ix->ntiles * (ix->rstride / 8 + ((kSegMaxSparseRows + 1) * 4 + (kSegMaxMidRows + 1) * 4 + 14)) + (ix->packed() ? ix->npad * 5 / 4 : ix->npad * 2) + (uint64_t)ix->hstride * 12 +
-                            (uint64_t)ix->n_bnd_local * 8 + 64) * ix->n_streams;
+    // ---- sub-batch scratch, sized against free HBM
+    const bool will_prune = ix->prune_opt && ix->d_ubitmap.p && ix->pair_opt && ix->ntiles >= 8 && tmax <= 1023 && ix->n_refs == ix->n_total;  // begin_run decides
+    const uint64_t per_q = (uint64_t)ix->kstride * 2 + (uint64_t)ix->rstride * 12 + 4 + (uint64_t)ix->ntiles * (ix->rstride / 8 + ((kSegMaxSparseRows + 1) * 4 + 10)) + (ix->packed() ? ix->npad * 5 / 4 : ix->npad * 2) + (uint64_t)ix->hstride * 12 +
+                           (uint64_t)ix->n_bnd_local * 8 + 64 +
+                           // + the scratch of the tile pruning: counts against the union bitmap, constant masks, its histogram, thresholds, live masks
+                           (will_prune ? (uint64_t)ix->u_ntiles * (8192u * 2u + ix->rstride / 8 + 6) + (uint64_t)ix->hstride * 4 + 4 + (ix->ntiles + 31u) / 32u * 2u + 2u : 0);
     uint32_t B = ix->sub_batch_req;
     if (B == 0) {
         size_t free_b = 0, total_b = 0;
@@ -892,7 +778,6 @@ int prepare_workspace(rtx_index *ix, uint64_t n_queries, uint64_t tmax, uint64_t
         // scratch already held by this handle is reusable
         const uint64_t held = (ix->sc[0].d_counts.n + ix->sc[1].d_counts.n) * 2 + (ix->sc[0].d_prefix.n + ix->sc[1].d_prefix.n) * 8;
         const uint64_t budget = (uint64_t)((free_b + held) * 0.6);
-        const bool will_prune = ix->prune_opt && ix->d_ubitmap.p && ix->pair_opt == 1 && ix->ntiles >= 8 && tmax <= 1023 && ix->n_refs == ix->n_total;  // begin_run decides
         B = (uint32_t)std::min<uint64_t>(will_prune ? kDefaultSubBatchPruned : ix->ntiles >= 16 ? kDefaultSubBatchLarge : kDefaultSubBatch,
                                          std::max<uint64_t>(64, budget / per_q));
     }
@@ -900,10 +785,7 @@ int prepare_workspace(rtx_index *ix, uint64_t n_queries, uint64_t tmax, uint64_t
     B = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(B, n_queries));
     ix->sub_batch = B;
     ix->staged = false;
-    for (uint32_t k = 0; k < ix->n_streams; k++) {
-        if ((rc = alloc_scratch_set(ix, k))) return rc;
-    }
-    return RTX_OK;
+    return alloc_scratch_set(ix, 0);
 }
 
 int alloc_scratch_set(rtx_index *ix, uint32_t k) {
@@ -913,7 +795,6 @@ int alloc_scratch_set(rtx_index *ix, uint32_t k) {
         rtx_index::Scratch &sc = ix->sc[k];
         if ((rc = sc.d_kmers.alloc((size_t)B * ix->kstride)) || (rc = sc.d_rows.alloc((size_t)B * ix->rstride)) || (rc = sc.d_dmask.alloc((size_t)B * ix->ntiles * (ix->rstride / 64))) ||
             (rc = sc.d_nsparse.alloc((size_t)B * ix->ntiles)) || (rc = sc.d_srows.alloc((size_t)B * ix->ntiles * (kSegMaxSparseRows + 1))) ||
-            (rc = sc.d_nmid.alloc((size_t)B * ix->ntiles)) || (rc = sc.d_mrows.alloc((size_t)B * ix->ntiles * (kSegMaxMidRows + 1))) ||
             (rc = sc.d_t.alloc(B)) || (rc = sc.d_nrows.alloc(B)) || (rc = sc.d_counts.alloc(counts_elems(ix, B))) ||
             (rc = sc.d_hist.alloc((size_t)B * ix->hstride)) || (rc = sc.d_table_z.alloc((size_t)B * ix->hstride)) ||
             (rc = sc.d_prefix.alloc((size_t)B * ix->n_bnd_local)) || (rc = sc.d_order.alloc(B)) ||
@@ -1168,7 +1049,7 @@ int rtx_index_create_shard(int device, uint64_t n_refs_total, uint64_t ref_lo, u
 }
 
 // RTX_DEFAULT_SEGMENT_CLASSES (rtx_set_default_option): 0 = every segment is read densely (A/B measurements)
-static uint64_t g_seg_classes = 1;  // 2 (segments of 17 .. 128 references as lists through the byte counters) asks for 14 % fewer bytes but is 10 % slower: DESIGN.md section 3
+static uint64_t g_seg_classes = 1;
 
 // Classifies every (row, tile) segment of the finished bitmap as empty / dense / sparse and writes the slots of the
 // sparse ones (rtx_segments.hip).  Slots are numbered in (row, tile) order: deterministic.
@@ -1177,7 +1058,7 @@ static int build_segments(rtx_index *ix) {
     const uint32_t ss = (nt + 3u) & ~3u;  // seginfo rows padded to whole uint4
     ix->seg_stride = ss;
     const size_t n = (size_t)n_rows1 * nt;
-    const bool sparse_on = g_seg_classes != 0, empty_on = g_seg_classes != 0, mid_on = g_seg_classes >= 2;
+    const bool sparse_on = g_seg_classes != 0, empty_on = g_seg_classes != 0;
     DevBuf<uint16_t> d_pop;
     int rc;
     if ((rc = d_pop.alloc(n)) || (rc = ix->d_seginfo.alloc((size_t)n_rows1 * ss))) return rc;
@@ -1187,7 +1068,7 @@ static int build_segments(rtx_index *ix) {
     std::vector<uint16_t> pop(n);
     RTX_HIP(hipMemcpy(pop.data(), d_pop.p, n * 2, hipMemcpyDeviceToHost));
     std::vector<uint32_t> info((size_t)n_rows1 * ss, 0u);
-    uint64_t slots = 0, mslots = 0;
+    uint64_t slots = 0;
     const bool last_full = ix->stride_bytes % 1024u == 0;  // hit_count's byte counters and row images want 64-lane tiles
     for (uint32_t r = 0; r < n_rows1; r++)
         for (uint32_t t = 0; t < nt; t++) {
@@ -1196,26 +1077,22 @@ static int build_segments(rtx_index *ix) {
             const bool full_tile = t + 1 < nt || last_full;
             if (c == 0) o = empty_on ? 0u : 1u;
             else if (c <= kSegSparseMax && sparse_on && full_tile) o = (uint32_t)(2 + slots++);
-            else if (c <= kSegMidMax && mid_on && full_tile && mslots < (1u << 23)) o = 0x80000000u | (uint32_t)(mslots++);
             else o = 1u;
         }
-    if (slots > 0x7FFFFFF0ull || mslots > 0x7FFFFFF0ull) { set_error("too many sparse segments"); return RTX_ERR_INVALID; }
+    if (slots > 0x7FFFFFF0ull) { set_error("too many sparse segments"); return RTX_ERR_INVALID; }
     // many tiles: the classes as bit tables per block of 64 tiles (kmer_extract transposes 64 rows x 64 tiles at a time)
     ix->seg_blocks = nt > 12 ? (nt + 63) / 64 : 0;
     if (ix->seg_blocks) {
         const uint32_t nb = ix->seg_blocks;
-        std::vector<unsigned long long> dbits((size_t)n_rows1 * nb, 0), sbits((size_t)n_rows1 * nb, 0), mbits((size_t)n_rows1 * nb, 0);
-        std::vector<uint32_t> sbase((size_t)n_rows1 * nb, 0), mbase((size_t)n_rows1 * nb, 0);
+        std::vector<unsigned long long> dbits((size_t)n_rows1 * nb, 0), sbits((size_t)n_rows1 * nb, 0);
+        std::vector<uint32_t> sbase((size_t)n_rows1 * nb, 0);
         for (uint32_t r = 0; r < n_rows1; r++)
             for (uint32_t b = 0; b < nb; b++) {
-                bool first = true, mfirst = true;
+                bool first = true;
                 for (uint32_t t = b * 64; t < nt && t < b * 64 + 64; t++) {
                     const uint32_t o = info[(size_t)r * ss + t];
                     if (o == 1u) dbits[(size_t)r * nb + b] |= 1ull << (t & 63u);
-                    else if (o >> 31) {
-                        mbits[(size_t)r * nb + b] |= 1ull << (t & 63u);
-                        if (mfirst) { mbase[(size_t)r * nb + b] = o & 0x7FFFFFFFu; mfirst = false; }
-                    } else if (o >= 2u) {
+                    else if (o >= 2u) {
                         sbits[(size_t)r * nb + b] |= 1ull << (t & 63u);
                         if (first) { sbase[(size_t)r * nb + b] = o - 2u; first = false; }
                     }
@@ -1225,20 +1102,13 @@ static int build_segments(rtx_index *ix) {
         RTX_HIP(hipMemcpy(ix->d_seg_dbits.p, dbits.data(), dbits.size() * 8, hipMemcpyHostToDevice));
         RTX_HIP(hipMemcpy(ix->d_seg_sbits.p, sbits.data(), sbits.size() * 8, hipMemcpyHostToDevice));
         RTX_HIP(hipMemcpy(ix->d_seg_sbase.p, sbase.data(), sbase.size() * 4, hipMemcpyHostToDevice));
-        if (mslots) {
-            if ((rc = ix->d_seg_mbits.alloc(mbits.size())) || (rc = ix->d_seg_mbase.alloc(mbase.size()))) return rc;
-            RTX_HIP(hipMemcpy(ix->d_seg_mbits.p, mbits.data(), mbits.size() * 8, hipMemcpyHostToDevice));
-            RTX_HIP(hipMemcpy(ix->d_seg_mbase.p, mbase.data(), mbase.size() * 4, hipMemcpyHostToDevice));
-        }
     }
     ix->n_seg_slots = slots;
-    ix->n_mid_slots = mslots;
-    if ((rc = ix->d_segslots.alloc((slots ? slots : 1) * kSegSlotEntries)) || (rc = ix->d_midslots.alloc((mslots ? mslots : 1) * kSegMidEntries))) return rc;
+    if ((rc = ix->d_segslots.alloc((slots ? slots : 1) * kSegSlotEntries))) return rc;
     RTX_HIP(hipMemset(ix->d_segslots.p, 0xFF, (slots ? slots : 1) * kSegSlotEntries * 2));
-    RTX_HIP(hipMemset(ix->d_midslots.p, 0xFF, (mslots ? mslots : 1) * kSegMidEntries * 2));
     RTX_HIP(hipMemcpy(ix->d_seginfo.p, info.data(), info.size() * 4, hipMemcpyHostToDevice));
-    if (slots || mslots) {
-        launch_seg_emit(ix->stream, ix->d_bitmap.p, ix->stride_bytes, n_rows1, nt, ix->d_seginfo.p, ss, ix->d_segslots.p, ix->d_midslots.p);
+    if (slots) {
+        launch_seg_emit(ix->stream, ix->d_bitmap.p, ix->stride_bytes, n_rows1, nt, ix->d_seginfo.p, ss, ix->d_segslots.p);
         RTX_HIP(hipGetLastError());
         RTX_HIP(hipStreamSynchronize(ix->stream));
     }
@@ -1425,29 +1295,35 @@ void rtx_index_destroy(rtx_index *index) {
 uint64_t rtx_index_num_refs(const rtx_index *index) { return index ? index->n_total : 0; }
 uint64_t rtx_index_device_bytes(const rtx_index *index) {
     if (!index) return 0;
-    return index->d_seg_dbits.n * 8 + index->d_seg_sbits.n * 8 + index->d_seg_sbase.n * 4 + index->d_seginfo.n * 4 + index->d_segslots.n * 2 + index->d_midslots.n * 2 + index->d_seg_mbits.n * 8 + index->d_seg_mbase.n * 4 + index->d_bitmap.n * 4 + index->d_row_of.n * 4 + index->d_list_len.n * 4 + index->d_loc_table.n * 4 + index->d_ubitmap.n * 4 + index->d_lnfact.n * 8 +
+    return index->d_seg_dbits.n * 8 + index->d_seg_sbits.n * 8 + index->d_seg_sbase.n * 4 + index->d_seginfo.n * 4 + index->d_segslots.n * 2 + index->d_bitmap.n * 4 + index->d_row_of.n * 4 + index->d_list_len.n * 4 + index->d_loc_table.n * 4 + index->d_ubitmap.n * 4 + index->d_lnfact.n * 8 +
            index->d_noderec.n * 16 + index->d_bnd_bits.n + index->d_bnd_rank.n * 4;
 }
 int rtx_index_set_batch(rtx_index *index, uint32_t sub_batch) {
     if (!index) { set_error("null index handle"); return RTX_ERR_INVALID; }
+    index->uploaded = index->ran = index->synced = false;  // as RTX_OPT_SUB_BATCH: read at the next upload
     index->sub_batch_req = sub_batch;
     return RTX_OK;
 }
 
 int rtx_set_default_option(int option, uint64_t value) {
-    if (option == RTX_DEFAULT_SEGMENT_CLASSES) { g_seg_classes = value > 2 ? 2 : value; return RTX_OK; }
+    if (option == RTX_DEFAULT_SEGMENT_CLASSES) { g_seg_classes = value ? 1 : 0; return RTX_OK; }
     set_error("rtx_set_default_option: unknown option %d", option);
     return RTX_ERR_INVALID;
 }
 
 int rtx_index_set_option(rtx_index *index, int option, uint64_t value) {
     if (!index) { set_error("null index handle"); return RTX_ERR_INVALID; }
+    // Options that shape the per-batch workspace (count format, scratch of the tile pruning, sub-batch size, probability tables) are
+    // read when a batch is uploaded: setting one of them drops the uploaded batch, so that the next rtx_batch_run cannot work on
+    // buffers sized for another layout (it fails with RTX_ERR_STATE until the batch is uploaded again).
+    switch (option) {
+        case RTX_OPT_SUB_BATCH: case RTX_OPT_PACKED_COUNTS: case RTX_OPT_HIT_PAIR: case RTX_OPT_TILE_PRUNE: case RTX_OPT_PROB_MODE:
+            index->uploaded = index->ran = index->synced = false;
+            break;
+        default: break;
+    }
     switch (option) {
         case RTX_OPT_SUB_BATCH: index->sub_batch_req = (uint32_t)value; return RTX_OK;
-        case RTX_OPT_STREAMS:
-            if (value < 1 || value > 3) break;
-            index->n_streams_req = (uint32_t)value;
-            return RTX_OK;
         case RTX_OPT_STAGE_TIMING:
             index->stage_timing = value ? 1u : 0u;
             return RTX_OK;
@@ -1457,12 +1333,8 @@ int rtx_index_set_option(rtx_index *index, int option, uint64_t value) {
         case RTX_OPT_PACKED_COUNTS:
             index->packed_opt = value ? 1u : 0u;
             return RTX_OK;
-        case RTX_OPT_HIT_QUAD:
-            index->quad_opt = value ? 1u : 0u;
-            return RTX_OK;
         case RTX_OPT_HIT_PAIR:
-            if (value > 2) break;
-            index->pair_opt = (uint32_t)value;
+            index->pair_opt = value ? 1u : 0u;
             return RTX_OK;
         case RTX_OPT_TILE_SKIP:
             index->tile_skip = value ? 1u : 0u;
@@ -1728,7 +1600,6 @@ int rtx_shard_begin(rtx_index *ix, uint32_t *n_sub_batches, uint32_t *sub_batch)
     int rc = bind(ix);
     if (rc) return rc;
     if (!ix->uploaded) { set_error("rtx_shard_begin before rtx_batch_upload"); return RTX_ERR_STATE; }
-    if (ix->n_streams != 1) { set_error("sharded handles use one stream"); return RTX_ERR_STATE; }
     if (!ix->staged) {  // second scratch set: sub-batch sb + 1 may be counted while sub-batch sb is exchanged
         if ((rc = alloc_scratch_set(ix, 1))) return rc;
         ix->staged = true;
@@ -1867,15 +1738,11 @@ int rtx_batch_work(rtx_index *ix, uint64_t *sum_hits, uint64_t *sum_query_bytes,
     RTX_HIP(hipMemcpy(ix->h_nrows_all.data(), ix->d_nrows_all.p, ix->n_q * 4, hipMemcpyDeviceToHost));
     uint64_t h = 0, b = 0;
     const uint64_t row_bytes = ((ix->n_refs + 7) / 8 + ix->ntiles - 1) / ix->ntiles;  // per dense segment (nrows counts segments)
-    std::vector<uint32_t> nmid(ix->n_q);
-    RTX_HIP(hipMemcpy(nmid.data(), ix->d_nmid_all.p, ix->n_q * 4, hipMemcpyDeviceToHost));
-    uint64_t mid_bytes = 0;
     for (uint64_t q = 0; q < ix->n_q; q++) {
         h += ix->h_hq[q];
         b += (uint64_t)ix->h_nrows_all[q] * row_bytes;
-        mid_bytes += (uint64_t)nmid[q] * kSegMidEntries * 2;  // a mid segment travels as 128 bytes of positions
     }
-    if (ix->quad_used || ix->pair_used) {  // rows were loaded once per group of four (two) queries: the union rows every workgroup counted
+    if (ix->pair_used) {  // rows were loaded once per pair of queries: the union rows every wave counted
         const uint32_t n_sub = (uint32_t)((ix->n_q + ix->sub_batch - 1) / ix->sub_batch);
         const size_t ng = (size_t)n_sub * ix->groups_per_sub;
         std::vector<uint32_t> gr(2 * ng);
@@ -1887,7 +1754,6 @@ int rtx_batch_work(rtx_index *ix, uint64_t *sum_hits, uint64_t *sum_query_bytes,
             for (size_t g = ng; g < 2 * ng; g++) b += (uint64_t)gr[g] * urow_bytes;
         }
     }
-    b += mid_bytes;
     if (sum_hits) *sum_hits = h;
     if (sum_query_bytes) *sum_query_bytes = ix->sum_query_bytes;
     if (bitmap_bytes_read) *bitmap_bytes_read = b;

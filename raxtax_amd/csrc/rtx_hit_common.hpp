@@ -1,5 +1,5 @@
-// Pieces shared by the two hit_count kernels (rtx_kernels.hip: one wave per (query, tile); rtx_hit_quad.hip: a
-// workgroup of four neighbouring queries per tile that loads every bitmap row it needs once, through LDS).
+// Pieces shared by the two hit_count kernels (rtx_kernels.hip: one wave per (query, tile); rtx_hit_pair.hip: two
+// neighbouring queries per wave, the bitmap rows they share loaded once).
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -190,10 +190,7 @@ __device__ __forceinline__ void fold_ring2(uint32_t (&pa)[4][NP], uint32_t (&pb)
 //   passes (two round trips instead of two per 64 segments and half) -- for kernels with registers to spare in the epilogue;
 //   `pre_in` (optional): they have been requested by the caller already (sparse_prefetch).
 //   kFullTile: cnt8 holds 8192 byte counters (+ 64 pad words), the sparse segments are scanned once for the whole tile.
-//   Mid segments (17 .. kSegMidMax references, kept as kSegMidEntries local ids = 256 bytes instead of a 1-KiB row
-//   segment; rtx_segments.hip) go through the same byte counters: `nm` of them, their slot ids at `mids` (LDS or
-//   global); one 256-byte load per segment (lane l takes entries 2l and 2l + 1), eight segments in flight.  A (query,
-//   tile) has at most 255 sparse + mid segments (kmer_extract), so a byte counter cannot overflow.
+//   A (query, tile) has at most 255 sparse segments (kmer_extract), so a byte counter cannot overflow.
 constexpr int kSparseIt = (kSegMaxSparseRows + 63) / 64, kSparseV = kSegSlotEntries / 8;
 
 // the slots of all sparse segments of a (query, tile): lane l takes segment it * 64 + l; sid: their slot ids (global or LDS)
@@ -206,7 +203,7 @@ __device__ __forceinline__ void sparse_prefetch(const HitParams &p, uint32_t lan
     for (int it = 0; it < kSparseIt; it++)
 #pragma unroll
         for (int i = 0; i < kSparseV; i++) {
-            const uint32_t pw = seg_mid_pad(2u * lane) | (seg_mid_pad(2u * lane + 1u) << 16);  // unused entries: pad words behind the byte counters
+            const uint32_t pw = seg_pad(2u * lane) | (seg_pad(2u * lane + 1u) << 16);  // unused entries: pad words behind the byte counters
             pre[it][i] = make_uint4(pw, pw, pw, pw);
             if (sid[it] != 0xFFFFFFFFu) pre[it][i] = reinterpret_cast<const uint4 *>(p.segslots + (size_t)sid[it] * kSegSlotEntries)[i];
         }
@@ -215,35 +212,17 @@ __device__ __forceinline__ void sparse_prefetch(const HitParams &p, uint32_t lan
 template <int NP, bool kPacked, bool kPrefetch, bool kFullTile, bool kPreLoaded>
 __device__ __forceinline__ void hit_epilogue_x(const HitParams &p, uint32_t (&pl)[4][NP], uint32_t q, uint32_t tile, uint32_t lane,
                                                uint32_t t, bool active, uint32_t *hist_lds, uint32_t *cnt8, uint32_t ns,
-                                               const uint32_t *srows, uint4 (&pre)[kSparseIt][kSparseV], uint32_t nm = 0,
-                                               const uint32_t *mids = nullptr) {
+                                               const uint32_t *srows, uint4 (&pre)[kSparseIt][kSparseV]) {
     RTX_EPI_DECL
     constexpr int kIt = kSparseIt, kVp = kSparseV;
-    const bool lists = ns || nm;  // wave-uniform: byte counters in use
+    const bool lists = ns != 0u;  // wave-uniform: byte counters in use
     if (kPrefetch && !kPreLoaded && ns) sparse_prefetch(p, lane, ns, srows, pre);
-    // the mid segments from m0 on: kMB 256-byte loads in flight (slot ids through v_readlane: the address is wave-uniform +
-    // lane; unconditional -- a branch per load makes the compiler drain the memory counter -- with the pad slot's value
-    // selected for the entries behind the list)
-    constexpr int kMB = kFullTile ? 32 : 8;  // the pair kernel has the registers of its row buffers to spare in the epilogue
-    const uint32_t pad_word = seg_mid_pad(2u * lane) | (seg_mid_pad(2u * lane + 1u) << 16);  // entries behind a list
-    auto mid_load = [&](uint32_t m0, uint32_t (&e)[kMB]) {
-#pragma unroll
-        for (int c = 0; c < kMB / 8; c++) {
-            const uint32_t i = m0 + (uint32_t)c * 8u + (lane & 7u);
-            const uint32_t sv = i < nm ? mids[i] : 0xFFFFFFFFu;
-#pragma unroll
-            for (int j = 0; j < 8; j++) {
-                const uint32_t slot = (uint32_t)__builtin_amdgcn_readlane((int)sv, j);
-                const uint32_t v = reinterpret_cast<const uint32_t *>(p.midslots + (size_t)(slot == 0xFFFFFFFFu ? 0u : slot) * kSegMidEntries)[lane];
-                e[c * 8 + j] = slot == 0xFFFFFFFFu ? pad_word : v;
-            }
-        }
-    };
+    const uint32_t pad_word = seg_pad(2u * lane) | (seg_pad(2u * lane + 1u) << 16);  // entries behind a list
     // hits of the sparse segments on the references [half*4096, half*4096 + 4096) of the tile -> cnt8 (at most 255 each)
     auto sparse_hits = [&](uint32_t half) {
 #pragma unroll
         for (int i = 0; i < (kFullTile ? 8 : 4); i++) reinterpret_cast<uint4 *>(cnt8)[i * 64 + lane] = make_uint4(0, 0, 0, 0);
-        if (kFullTile) cnt8[2048u + lane] = 0;  // 64 pad words: they take the unused entries of the mid segments (spread: one word would serialise the atomics)
+        if (kFullTile) cnt8[2048u + lane] = 0;  // 64 pad words: they take the unused entries of the slots (spread: one word would serialise the atomics)
         wave_lds_sync();
         constexpr int kV = kSegSlotEntries / 8;  // uint4 per slot
         auto add_slot = [&](const uint4 (&e)[kV]) {
@@ -252,15 +231,13 @@ __device__ __forceinline__ void hit_epilogue_x(const HitParams &p, uint32_t (&pl
                 const uint32_t wv[4] = {e[i].x, e[i].y, e[i].z, e[i].w};
 #pragma unroll
                 for (int j = 0; j < 8; j++) {
-                    const uint32_t id = (wv[j >> 1] >> ((j & 1) * 16)) & 0xFFFFu;  // >= kSegMidPad (8192): unused entry
+                    const uint32_t id = (wv[j >> 1] >> ((j & 1) * 16)) & 0xFFFFu;  // >= kSegPad (8192): unused entry
                     // full tile: unused entries land in the pad words behind the counters -- no compare, no exec mask per atomic
                     if (kFullTile) atomicAdd(&cnt8[id >> 2], 1u << ((id & 3u) * 8u));
                     else if ((id >> 12) == half) atomicAdd(&cnt8[(id & 4095u) >> 2], 1u << ((id & 3u) * 8u));
                 }
             }
         };
-        uint32_t me[kMB];
-        if (nm) mid_load(0, me);
         if (kPrefetch) {
 #pragma unroll
             for (int it = 0; it < kIt; it++)
@@ -276,22 +253,6 @@ __device__ __forceinline__ void hit_epilogue_x(const HitParams &p, uint32_t (&pl
                     for (int i = 0; i < kV; i++) e[i] = slot[i];
                 }
                 add_slot(e);
-            }
-        }
-        for (uint32_t m0 = 0; m0 < nm; m0 += kMB) {
-            uint32_t cur[kMB];
-#pragma unroll
-            for (int j = 0; j < kMB; j++) cur[j] = me[j];
-            if (m0 + kMB < nm) mid_load(m0 + kMB, me);  // the next batch is on its way while this one is counted
-#pragma unroll
-            for (int j = 0; j < kMB; j++) {
-#pragma unroll
-                for (int h = 0; h < 2; h++) {
-                    const uint32_t id = h ? cur[j] >> 16 : cur[j] & 0xFFFFu;  // >= kSegMidPad (8192): unused entry
-                    // full tile: unused entries land in the pad word behind the counters, no branch
-                    if (kFullTile) atomicAdd(&cnt8[id >> 2], 1u << ((id & 3u) * 8u));
-                    else if ((id >> 12) == half) atomicAdd(&cnt8[(id & 4095u) >> 2], 1u << ((id & 3u) * 8u));
-                }
             }
         }
         wave_lds_sync();
@@ -364,7 +325,7 @@ __device__ __forceinline__ void hit_epilogue_x(const HitParams &p, uint32_t (&pl
                     st.z = __builtin_amdgcn_perm(hi1, lo1, 0x05010400u);
                     st.w = __builtin_amdgcn_perm(hi1, lo1, 0x07030602u);
                     const uint32_t goff = (uint32_t)(w * 4 + g2) * L * 8u;
-                    if (lists) {  // + hits through sparse and mid segments (L = 64 here): bytes of the eight references of this group
+                    if (lists) {  // + hits through sparse segments (L = 64 here): bytes of the eight references of this group
                         const uint2 sb = *reinterpret_cast<const uint2 *>(cnt8 + (((uint32_t)((kFullTile ? w : wi) * 4 + g2) * 64u + lane) * 2u));
                         // bytes (b0, b1) -> (b0, 0, b1, 0): one v_perm_b32 each (selector byte 0x0C = constant 0)
                         st.x += __builtin_amdgcn_perm(0u, sb.x, 0x0C010C00u);
@@ -376,12 +337,6 @@ __device__ __forceinline__ void hit_epilogue_x(const HitParams &p, uint32_t (&pl
                         uint2 lo8;  // the low bytes of the eight counts, in reference order
                         lo8.x = __builtin_amdgcn_perm(st.y, st.x, 0x06040200u);
                         lo8.y = __builtin_amdgcn_perm(st.w, st.z, 0x06040200u);
-#ifdef RTX_EXP_SC1_COUNT_STORES
-                        // experiment: the counts bypass L2 (sc1 stores do not keep the line): more of it left for bitmap rows
-                        __hip_atomic_store(reinterpret_cast<unsigned long long *>(out_lo + goff), ((unsigned long long)lo8.y << 32) | lo8.x,
-                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#else
-#ifndef RTX_EXP_NO_COUNT_STORE
                         {   // non-temporal: the counts are read once, much later (taxon_prefix), and should not displace bitmap rows
                             typedef uint32_t u32x2_nt __attribute__((ext_vector_type(2)));
                             u32x2_nt nv;
@@ -389,8 +344,6 @@ __device__ __forceinline__ void hit_epilogue_x(const HitParams &p, uint32_t (&pl
                             nv.y = lo8.y;
                             __builtin_nontemporal_store(nv, reinterpret_cast<u32x2_nt *>(out_lo + goff));
                         }
-#endif
-#endif
                         // high bytes (0..3 each) -> 2 bits per reference: byte j moves to bit 2j
                         const uint32_t hb0 = __builtin_amdgcn_perm(st.y, st.x, 0x07050301u), hb1 = __builtin_amdgcn_perm(st.w, st.z, 0x07050301u);
                         const uint32_t h0 = (hb0 | (hb0 >> 6) | (hb0 >> 12) | (hb0 >> 18)) & 0xFFu;
@@ -402,7 +355,6 @@ __device__ __forceinline__ void hit_epilogue_x(const HitParams &p, uint32_t (&pl
                         *reinterpret_cast<uint4 *>(out + goff) = st;
                     }
                     const uint32_t cw[4] = {st.x, st.y, st.z, st.w};
-#ifndef RTX_EXP_NO_HIST  // experiment: what the histogram atomics cost (wrong results)
                     if (tile_full) {  // wave-uniform: every reference of the tile exists -- no compare, no exec mask per atomic
 #pragma unroll
                         for (int j = 0; j < 8; j++) atomicAdd(&hist_lds[(cw[j >> 1] >> ((j & 1) * 16)) & 0xFFFFu], 1u);
@@ -413,7 +365,6 @@ __device__ __forceinline__ void hit_epilogue_x(const HitParams &p, uint32_t (&pl
                         for (int j = 0; j < 8; j++)
                             if ((uint32_t)j < nvalid) atomicAdd(&hist_lds[(cw[j >> 1] >> ((j & 1) * 16)) & 0xFFFFu], 1u);
                     }
-#endif
                 }
             }
         }
@@ -459,9 +410,7 @@ __device__ __forceinline__ void hit_epilogue(const HitParams &p, uint32_t (&pl)[
                                              uint32_t t, bool active, uint32_t *hist_lds, uint32_t *cnt8, uint32_t ns,
                                              const uint32_t *srows) {
     uint4 pre[kSparseIt][kSparseV];  // unused without kPrefetch
-    const uint32_t nm = p.nmid ? p.nmid[(size_t)q * p.ntiles + tile] : 0u;
-    const uint32_t *mids = p.mrows + ((size_t)q * p.ntiles + tile) * (kSegMaxMidRows + 1);
-    hit_epilogue_x<NP, kPacked, kPrefetch, false, false>(p, pl, q, tile, lane, t, active, hist_lds, cnt8, ns, srows, pre, nm, mids);
+    hit_epilogue_x<NP, kPacked, kPrefetch, false, false>(p, pl, q, tile, lane, t, active, hist_lds, cnt8, ns, srows, pre);
 }
 
 }  // namespace rtx

@@ -36,8 +36,7 @@ constexpr uint32_t kPairCap = kHitListCap;            // entries per list and ro
 constexpr uint32_t kPairListDw = kPairCap + 192u;     // + padding to a multiple of 8 + the look-ahead of the row loop
 constexpr uint32_t kPairMaskWords = 64u;              // dense-mask words (u64) per query and tile kept in LDS: rstride <= 4096
 constexpr uint32_t kPairSidDw = 2u * kSparseIt * 64u;     // slot ids of the sparse segments of both queries (read at the start, used in the epilogue)
-constexpr uint32_t kPairMidDw = 2u * (kSegMaxMidRows + 1u);  // slot ids of the mid segments of both queries
-constexpr uint32_t kPairLdsBytes = 3u * kPairListDw * 4u + 2u * kPairMaskWords * 8u + 32u * 4u + kPairSidDw * 4u + kPairMidDw * 4u;  // lists | dense masks | 32 x the zero row | sparse slot ids | mid slot ids
+constexpr uint32_t kPairLdsBytes = 3u * kPairListDw * 4u + 2u * kPairMaskWords * 8u + 32u * 4u + kPairSidDw * 4u;  // lists | dense masks | 32 x the zero row | sparse slot ids
 constexpr int kPairNB = 4;                            // buffers of eight rows per wave
 
 // ---------------------------------------------------------------------------
@@ -136,20 +135,11 @@ __global__ __launch_bounds__(64, 2) void hit_count_pair_kernel(HitParams p) {
     const uint32_t qa = pair * 2u, qb = qa + 1u;
     const bool has_b = qb < p.nq;
     if (p.live && !((p.live[(size_t)pair * p.live_words + (tile >> 5)] >> (tile & 31u)) & 1u)) return;  // tile pruning (rtx_prune.hip): nothing in this tile can matter to either query
-#ifdef RTX_EXP_PRUNE_EMU  // experiment (tile pruning): what hit_count takes when the (pair, tile) blocks whose
-                          // largest count -- as the run BEFORE left it in tile_max: one sub-batch per step, the same queries --
-                          // stays below the threshold leave at once; p.group_rows doubles as "a run has been made" flag holder
-    if (p.tile_max && p.flags_prune) {
-        const uint32_t ma = p.tile_max[(size_t)qa * p.ntiles + tile], mb = has_b ? p.tile_max[(size_t)qb * p.ntiles + tile] : 0u;
-        if ((ma > mb ? ma : mb) < (uint32_t)RTX_EXP_PRUNE_EMU) return;
-    }
-#endif
     uint32_t *l_both = lds_dw, *l_a = lds_dw + kPairListDw, *l_b = lds_dw + 2u * kPairListDw;
     unsigned long long *m_a = reinterpret_cast<unsigned long long *>(lds_dw + 3u * kPairListDw), *m_b = m_a + kPairMaskWords;
     uint32_t *l_zero = reinterpret_cast<uint32_t *>(m_b + kPairMaskWords);
     if (lane < 32u) l_zero[lane] = p.zero_row << 10;
     uint32_t *l_sid = l_zero + 32;  // [2][kSparseIt * 64]
-    uint32_t *l_mid = l_sid + kPairSidDw;  // [2][kSegMaxMidRows + 1]
     const uint32_t col = tile * 1024u + lane * 16u;
     const bool active = col < p.stride_bytes;
     uint32_t pa[4][NP], pb[4][NP];
@@ -180,7 +170,6 @@ __global__ __launch_bounds__(64, 2) void hit_count_pair_kernel(HitParams p) {
     const uint32_t ns_a = p.nsparse[(size_t)qa * p.ntiles + tile], ns_b = has_b ? p.nsparse[(size_t)qb * p.ntiles + tile] : 0u;
     const uint32_t *srows_a = p.srows + ((size_t)qa * p.ntiles + tile) * (kSegMaxSparseRows + 1);
     const uint32_t *srows_b = p.srows + ((size_t)(has_b ? qb : qa) * p.ntiles + tile) * (kSegMaxSparseRows + 1);
-    const uint32_t nm_a = p.nmid ? p.nmid[(size_t)qa * p.ntiles + tile] : 0u, nm_b = p.nmid && has_b ? p.nmid[(size_t)qb * p.ntiles + tile] : 0u;
     {
         const unsigned long long *dm_a = p.dmask + ((size_t)qa * p.ntiles + tile) * mwords;
         const unsigned long long *dm_b = p.dmask + ((size_t)(has_b ? qb : qa) * p.ntiles + tile) * mwords;
@@ -190,13 +179,6 @@ __global__ __launch_bounds__(64, 2) void hit_count_pair_kernel(HitParams p) {
             sa[it] = srows_a[(uint32_t)it * 64u + lane];
             sb[it] = srows_b[(uint32_t)it * 64u + lane];
         }
-        uint32_t ma[2] = {0, 0}, mb[2] = {0, 0};
-        if (p.nmid) {  // wave-uniform; the lists have kSegMaxMidRows + 1 = 128 entries
-            const uint32_t *mr_a = p.mrows + ((size_t)qa * p.ntiles + tile) * (kSegMaxMidRows + 1);
-            const uint32_t *mr_b = p.mrows + ((size_t)(has_b ? qb : qa) * p.ntiles + tile) * (kSegMaxMidRows + 1);
-            ma[0] = mr_a[lane]; ma[1] = mr_a[64u + lane];
-            mb[0] = mr_b[lane]; mb[1] = mr_b[64u + lane];
-        }
         for (uint32_t i = lane; i < mwords; i += 64) {
             m_a[i] = dm_a[i];
             m_b[i] = has_b ? dm_b[i] : 0ull;
@@ -205,10 +187,6 @@ __global__ __launch_bounds__(64, 2) void hit_count_pair_kernel(HitParams p) {
         for (int it = 0; it < kSparseIt; it++) {
             l_sid[(uint32_t)it * 64u + lane] = sa[it];
             l_sid[(kSparseIt + (uint32_t)it) * 64u + lane] = sb[it];
-        }
-        if (p.nmid) {
-            l_mid[lane] = ma[0]; l_mid[64u + lane] = ma[1];
-            l_mid[128u + lane] = mb[0]; l_mid[192u + lane] = mb[1];
         }
     }
     wave_lds_sync();
@@ -257,9 +235,6 @@ __global__ __launch_bounds__(64, 2) void hit_count_pair_kernel(HitParams p) {
         wave_lds_sync();
         PAIR_MARK(1)
         const uint32_t *first = g_both ? l_both : (g_a ? l_a : (g_b ? l_b : nullptr));
-#ifdef RTX_EXP_SKIP_LOOP  // experiment: prologue and epilogues only
-        first = nullptr;
-#endif
         if (first) {
             uint4 buf[4][8];
             const uint32_t idv = first[lane & 31u];
@@ -291,35 +266,13 @@ __global__ __launch_bounds__(64, 2) void hit_count_pair_kernel(HitParams p) {
     uint32_t *hist_lds = lds_dw;
     uint32_t *cnt8 = lds_dw + 1024u;
     uint4 pre_a[kSparseIt][kSparseV], pre_b[kSparseIt][kSparseV];
-#ifdef RTX_EXP_SKIP_EPI  // experiment (RTX_EXP_COUNT_ONLY runs): what the kernel takes without its epilogues -- is a wave's time or the L2 what bounds it?
-    if (RTX_EXP_SKIP_EPI >= 2) {  // one store keeps the planes alive
-        uint32_t x = 0;
-#pragma unroll
-        for (int w = 0; w < 4; w++)
-#pragma unroll
-            for (int b = 0; b < NP; b++) x ^= pa[w][b] ^ pb[w][b];
-        if (x == 0x12345678u) p.hist[lane] = x;
-        return;
-    }
-#endif
     if (ns_a) sparse_prefetch(p, lane, ns_a, l_sid, pre_a);
     if (ns_b) sparse_prefetch(p, lane, ns_b, l_sid + kSparseIt * 64u, pre_b);
-    hit_epilogue_x<NP, kPacked, true, true, true>(p, pa, qa, tile, lane, p.t[qa], active, hist_lds, cnt8, ns_a, srows_a, pre_a, nm_a, l_mid);
+    hit_epilogue_x<NP, kPacked, true, true, true>(p, pa, qa, tile, lane, p.t[qa], active, hist_lds, cnt8, ns_a, srows_a, pre_a);
     PAIR_MARK(3)
-#ifdef RTX_EXP_SKIP_EPI
-    if (RTX_EXP_SKIP_EPI == 1) {
-        uint32_t x = 0;
-#pragma unroll
-        for (int w = 0; w < 4; w++)
-#pragma unroll
-            for (int b = 0; b < NP; b++) x ^= pb[w][b];
-        if (x == 0x12345678u) p.hist[lane] = x;
-        return;
-    }
-#endif
     if (has_b) {
         wave_lds_sync();
-        hit_epilogue_x<NP, kPacked, true, true, true>(p, pb, qb, tile, lane, p.t[qb], active, hist_lds, cnt8, ns_b, srows_b, pre_b, nm_b, l_mid + (kSegMaxMidRows + 1u));
+        hit_epilogue_x<NP, kPacked, true, true, true>(p, pb, qb, tile, lane, p.t[qb], active, hist_lds, cnt8, ns_b, srows_b, pre_b);
     }
     PAIR_MARK(4)
 #ifdef RTX_PAIR_STAMP
@@ -327,197 +280,15 @@ __global__ __launch_bounds__(64, 2) void hit_count_pair_kernel(HitParams p) {
 #endif
 }
 
-// ---------------------------------------------------------------------------
-// The sequential variant (RTX_OPT_HIT_PAIR = 2): ONE plane set in registers at a time, which leaves room for NB buffers
-// of eight rows (40 or 48 rows in flight per wave instead of 32; the row loop is bound by rows in flight / latency):
-//   shared rows -> planes S, parked in global scratch (10 KiB per (pair, tile), read back by the same wave: L2)
-//   + A's rows  -> epilogue of A
-//   S + B's rows -> epilogue of B
-// Needs every list in one round (t <= kPairCap - 64: the host checks).
-// ---------------------------------------------------------------------------
-template <int NP, int NB>
-__device__ __forceinline__ void fold_seg1(uint32_t (&pl)[4][NP], uint4 (&buf)[NB][8], const uint32_t *list, uint32_t ng,
-                                          const uint32_t *next, uint32_t lane, __amdgpu_buffer_rsrc_t rsrc, uint32_t voff) {
-    static_assert(NB >= 4 && NB <= 6, "groups of 32 .. 48 rows");
-    constexpr uint32_t GR = NB * 8;
-    for (uint32_t g = 0; g < ng; g++) {
-        const uint32_t *src = g + 1 < ng ? list + (g + 1) * GR : next;  // wave-uniform
-        const uint32_t idn = src[lane];
-        uint4 c3[NB];
-#pragma unroll
-        for (int b = 0; b < NB; b++) {
-            c3[b] = tree8<NP>(pl, buf[b]);
-            load8v_at(buf[b], rsrc, voff, idn, b * 8);
-        }
-        const uint4 c4a = csa_plane<NP, 3>(pl, c3[0], c3[1]), c4b = csa_plane<NP, 3>(pl, c3[2], c3[3]);
-        const uint4 c5a = csa_plane<NP, 4>(pl, c4a, c4b);
-        if (NB == 4) {
-            ripple4<NP, 5>(pl, c5a);
-        } else {
-            const uint4 c4c = NB == 5 ? half_plane<NP, 3>(pl, c3[NB - 1]) : csa_plane<NP, 3>(pl, c3[4], c3[NB - 1]);
-            const uint4 c5b = half_plane<NP, 4>(pl, c4c);
-            ripple4<NP, 6>(pl, csa_plane<NP, 5>(pl, c5a, c5b));
-        }
-    }
-}
-
-template <int NP, bool kPacked, int NB>
-__global__ __launch_bounds__(64, 2) void hit_count_pairseq_kernel(HitParams p) {
-    extern __shared__ uint32_t lds_dw[];
-    constexpr uint32_t GR = NB * 8;
-    const uint32_t tile = blockIdx.y, lane = threadIdx.x;
-    const uint32_t np8 = gridDim.x >> 3;
-    const uint32_t pair = blockIdx.x < np8 * 8u ? (blockIdx.x & 7u) * np8 + (blockIdx.x >> 3) : blockIdx.x;
-    const uint32_t qa = pair * 2u, qb = qa + 1u;
-    const bool has_b = qb < p.nq;
-    uint32_t *l_both = lds_dw, *l_a = lds_dw + kPairListDw, *l_b = lds_dw + 2u * kPairListDw;
-    unsigned long long *m_a = reinterpret_cast<unsigned long long *>(lds_dw + 3u * kPairListDw), *m_b = m_a + kPairMaskWords;
-    uint32_t *l_zero = reinterpret_cast<uint32_t *>(m_b + kPairMaskWords);  // [64]
-    l_zero[lane] = p.zero_row << 10;
-    uint32_t *l_sid = l_zero + 64;  // [2][kSparseIt * 64]
-    const uint32_t col = tile * 1024u + lane * 16u;
-    const bool active = col < p.stride_bytes;
-    uint32_t pl[4][NP];
-#pragma unroll
-    for (int w = 0; w < 4; w++)
-#pragma unroll
-        for (int b = 0; b < NP; b++) pl[w][b] = 0;
-
-    const uint32_t mwords = p.rstride >> 6;
-    const uint2 *urec = p.pair_urec + (size_t)pair * p.pair_ustride;
-    auto load_recs = [&](uint2 (&rec)[8], uint32_t from) {
-#pragma unroll
-        for (int c = 0; c < 8; c++) {
-            const uint32_t i = from + (uint32_t)c * 64u + lane;
-            rec[c] = urec[i < p.pair_ustride ? i : p.pair_ustride - 1u];
-        }
-    };
-    uint2 rec[8];
-    load_recs(rec, 0);
-    const uint32_t ns_a = p.nsparse[(size_t)qa * p.ntiles + tile], ns_b = has_b ? p.nsparse[(size_t)qb * p.ntiles + tile] : 0u;
-    const uint32_t *srows_a = p.srows + ((size_t)qa * p.ntiles + tile) * (kSegMaxSparseRows + 1);
-    const uint32_t *srows_b = p.srows + ((size_t)(has_b ? qb : qa) * p.ntiles + tile) * (kSegMaxSparseRows + 1);
-    {
-        const unsigned long long *dm_a = p.dmask + ((size_t)qa * p.ntiles + tile) * mwords;
-        const unsigned long long *dm_b = p.dmask + ((size_t)(has_b ? qb : qa) * p.ntiles + tile) * mwords;
-        uint32_t sa[kSparseIt], sb[kSparseIt];
-#pragma unroll
-        for (int it = 0; it < kSparseIt; it++) {
-            sa[it] = srows_a[(uint32_t)it * 64u + lane];
-            sb[it] = srows_b[(uint32_t)it * 64u + lane];
-        }
-        for (uint32_t i = lane; i < mwords; i += 64) {
-            m_a[i] = dm_a[i];
-            m_b[i] = has_b ? dm_b[i] : 0ull;
-        }
-#pragma unroll
-        for (int it = 0; it < kSparseIt; it++) {
-            l_sid[(uint32_t)it * 64u + lane] = sa[it];
-            l_sid[(kSparseIt + (uint32_t)it) * 64u + lane] = sb[it];
-        }
-    }
-    wave_lds_sync();
-    const uint32_t n_u = p.pair_nu[pair];
-    const __amdgpu_buffer_rsrc_t rsrc = tile_rsrc(p.bitmap, p.n_rows1, tile);
-    const uint32_t voff = lane * 16u;
-    const uint32_t zero_off = p.zero_row << 10;  // the lists hold row offsets inside the tile's region (row << 10)
-    const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    uint32_t n_both = 0, n_a = 0, n_b = 0;
-    for (uint32_t u0 = 0; u0 < n_u;) {
-        if (u0) load_recs(rec, u0);
-#pragma unroll
-        for (int c = 0; c < 8; c++) {
-            if (u0 >= n_u) break;
-            if (n_both + 64u > kPairCap || n_a + 64u > kPairCap || n_b + 64u > kPairCap) { u0 = n_u; break; }  // cannot happen (host check)
-            const bool in = u0 + lane < n_u;
-            const uint32_t pos_a = rec[c].y & 0xFFFFu, pos_b = rec[c].y >> 16;
-            const bool da = in && (rec[c].x & (1u << 30)) && ((m_a[pos_a >> 6] >> (pos_a & 63u)) & 1ull);
-            const bool db = in && (rec[c].x & (1u << 31)) && ((m_b[pos_b >> 6] >> (pos_b & 63u)) & 1ull);
-            const uint32_t row = (rec[c].x & 0x3FFFFFFFu) << 10;
-            const bool sh = da && db, oa = da && !db, ob = db && !da;
-            const unsigned long long bb = __ballot(sh), ba = __ballot(oa), bo = __ballot(ob);
-            if (sh) l_both[n_both + (uint32_t)__popcll(bb & lt_mask)] = row;
-            if (oa) l_a[n_a + (uint32_t)__popcll(ba & lt_mask)] = row;
-            if (ob) l_b[n_b + (uint32_t)__popcll(bo & lt_mask)] = row;
-            n_both += (uint32_t)__popcll(bb);
-            n_a += (uint32_t)__popcll(ba);
-            n_b += (uint32_t)__popcll(bo);
-            u0 += 64;
-        }
-    }
-    if (lane == 0 && p.group_rows) atomicAdd(&p.group_rows[p.group_base + pair], n_both + n_a + n_b);
-    // groups of GR rows; the rows a list lacks for its last group are the zero row (+ 64 readable entries behind every list)
-    const uint32_t g_both = (n_both + GR - 1u) / GR, g_a = (n_a + GR - 1u) / GR, g_b = (n_b + GR - 1u) / GR;
-    for (uint32_t i = n_both + lane; i < g_both * GR + 64u; i += 64) l_both[i] = zero_off;
-    for (uint32_t i = n_a + lane; i < g_a * GR + 64u; i += 64) l_a[i] = zero_off;
-    for (uint32_t i = n_b + lane; i < g_b * GR + 64u; i += 64) l_b[i] = zero_off;
-    wave_lds_sync();
-
-    uint4 *park = p.pair_planes + ((size_t)pair * p.ntiles + tile) * (NP * 64u) + lane;  // [NP][64] uint4: plane b of the four words
-    {
-        const uint32_t *first = g_both ? l_both : (g_a ? l_a : nullptr);
-        uint4 buf[NB][8];
-        if (first) {
-            const uint32_t idv = first[lane];
-#pragma unroll
-            for (int b = 0; b < NB; b++) load8v_at(buf[b], rsrc, voff, idv, b * 8);
-            if (g_both) fold_seg1<NP, NB>(pl, buf, l_both, g_both, g_a ? l_a : l_zero, lane, rsrc, voff);
-        }
-        if (has_b) {  // S: the hits through the shared rows
-#pragma unroll
-            for (int b = 0; b < NP; b++) park[(uint32_t)b * 64u] = make_uint4(pl[0][b], pl[1][b], pl[2][b], pl[3][b]);
-        }
-        if (first && g_a) fold_seg1<NP, NB>(pl, buf, l_a, g_a, l_zero, lane, rsrc, voff);
-    }
-    // epilogue of A: histogram + byte counters for half a tile over the first two lists (B's list is still needed);
-    // the slots of the sparse segments of both queries and S are requested first
-    uint32_t *hist_lds = lds_dw;
-    uint4 pre_a[kSparseIt][kSparseV], pre_b[kSparseIt][kSparseV];
-    if (ns_a) sparse_prefetch(p, lane, ns_a, l_sid, pre_a);
-    if (ns_b) sparse_prefetch(p, lane, ns_b, l_sid + kSparseIt * 64u, pre_b);
-    uint4 sv[NP];
-    if (has_b) {
-#pragma unroll
-        for (int b = 0; b < NP; b++) sv[b] = park[(uint32_t)b * 64u];
-    }
-    hit_epilogue_x<NP, kPacked, true, false, true>(p, pl, qa, tile, lane, p.t[qa], active, hist_lds, lds_dw + 1024u, ns_a, srows_a, pre_a);
-    if (!has_b) return;
-    wave_lds_sync();
-#pragma unroll
-    for (int b = 0; b < NP; b++) { pl[0][b] = sv[b].x; pl[1][b] = sv[b].y; pl[2][b] = sv[b].z; pl[3][b] = sv[b].w; }
-    if (g_b) {
-        uint4 buf[NB][8];
-        const uint32_t idv = l_b[lane];
-#pragma unroll
-        for (int b = 0; b < NB; b++) load8v_at(buf[b], rsrc, voff, idv, b * 8);
-        fold_seg1<NP, NB>(pl, buf, l_b, g_b, l_zero, lane, rsrc, voff);
-    }
-    wave_lds_sync();
-    hit_epilogue_x<NP, kPacked, true, true, true>(p, pl, qb, tile, lane, p.t[qb], active, hist_lds, lds_dw + 1024u, ns_b, srows_b, pre_b);
-}
-
 void launch_pair_union(hipStream_t s, const uint32_t *rows, const uint32_t *nrows, uint32_t rstride, uint32_t nq, uint2 *urec,
                        uint32_t *nu, uint32_t ustride) {
     hipLaunchKernelGGL(pair_union_kernel, dim3((nq + 1u) / 2u), dim3(64), 0, s, rows, nrows, rstride, nq, urec, nu, ustride);
 }
 
-#ifndef RTX_PAIRSEQ_NB
-#define RTX_PAIRSEQ_NB 5
-#endif
-constexpr uint32_t kPairSeqLdsBytes = 3u * kPairListDw * 4u + 2u * kPairMaskWords * 8u + 64u * 4u + kPairSidDw * 4u;
-
-void launch_hit_count_pair(hipStream_t s, const HitParams &p, uint32_t nq, uint32_t ntiles, int variant) {
+void launch_hit_count_pair(hipStream_t s, const HitParams &p, uint32_t nq, uint32_t ntiles) {
     static_assert(3u * kPairListDw >= 1024u + 2048u + 64u, "histogram (t <= 1023) and byte counters (+ pad words) alias the lists");
-    static_assert(kSegMaxMidRows + 1 == 128, "the mid slot id lists are read as two words per lane");
-    static_assert(2u * kPairListDw >= 1024u + 1024u, "sequential variant: A's epilogue leaves B's list alone");
     static_assert(kSegMaxSparseRows + 1 >= kSparseIt * 64, "the slot id lists are read without a bound");
-    static_assert(kPairListDw >= kPairCap + RTX_PAIRSEQ_NB * 8u + 64u, "padding of the lists");
     const uint32_t np = (nq + 1u) / 2u;
-    if (variant == 2) {
-        if (p.counts_lo) hipLaunchKernelGGL((hit_count_pairseq_kernel<10, true, RTX_PAIRSEQ_NB>), dim3(np, ntiles), dim3(64), kPairSeqLdsBytes, s, p);
-        else hipLaunchKernelGGL((hit_count_pairseq_kernel<10, false, RTX_PAIRSEQ_NB>), dim3(np, ntiles), dim3(64), kPairSeqLdsBytes, s, p);
-        return;
-    }
     if (p.counts_lo) hipLaunchKernelGGL((hit_count_pair_kernel<10, true>), dim3(np, ntiles), dim3(64), kPairLdsBytes, s, p);
     else hipLaunchKernelGGL((hit_count_pair_kernel<10, false>), dim3(np, ntiles), dim3(64), kPairLdsBytes, s, p);
 }

@@ -270,10 +270,9 @@ __global__ __launch_bounds__(64) void kmer_extract_kernel(KmerParams p) {
     const uint32_t mstride = p.rstride >> 6;
     unsigned long long *dm = p.dmask + (size_t)q * nt * mstride;
     uint32_t *sout = p.srows + (size_t)q * nt * (kSegMaxSparseRows + 1);
-    uint32_t nseg = 0, nmidseg = 0;
-    uint32_t *mout = p.mrows + (size_t)q * nt * (kSegMaxMidRows + 1);
-    __shared__ unsigned long long l_sb[64], l_mb[64];
-    __shared__ uint32_t l_base[64], l_mbase[64];
+    uint32_t nseg = 0;
+    __shared__ unsigned long long l_sb[64];
+    __shared__ uint32_t l_base[64];
     // Tile pruning left this query's pair a handful of tiles: one pass per live tile over the class table [row][tile] (a gather
     // per 64 rows) instead of the bit tables and their transposes, which cost the same however few tiles are wanted.
     bool few_done = false;
@@ -288,7 +287,7 @@ __global__ __launch_bounds__(64) void kmer_extract_kernel(KmerParams p) {
                     const uint32_t tile = w * 32u + (uint32_t)__builtin_ctz(bits);
                     bits &= bits - 1u;
                     if (tile >= nt) break;
-                    uint32_t cd = 0, cs = 0, cm = 0;  // wave-uniform
+                    uint32_t cd = 0, cs = 0;  // wave-uniform
                     for (uint32_t c0 = 0; c0 < nchunks; c0 += 4) {
                         uint32_t row[4], code[4];
 #pragma unroll
@@ -305,29 +304,22 @@ __global__ __launch_bounds__(64) void kmer_extract_kernel(KmerParams p) {
                         for (int u = 0; u < 4; u++) {
                             const uint32_t c = c0 + (uint32_t)u;
                             if (c >= nchunks) break;
-                            const bool mid = (code[u] >> 31) != 0u;
-                            const bool sparse = code[u] >= 2u && !mid;
-                            // as in the pass per tile below: the rows taken from a chunk are a prefix of its candidates of either kind
-                            const unsigned long long ms = __ballot(sparse), mm = __ballot(mid);
-                            const uint32_t srank = cs + (uint32_t)__popcll(ms & lt_mask), mrank = cm + (uint32_t)__popcll(mm & lt_mask);
-                            const bool room = srank + mrank < kSegMaxListRows;
-                            const bool take = sparse && srank < kSegMaxSparseRows && room;
-                            const bool mtake = mid && mrank < kSegMaxMidRows && room;
+                            const bool sparse = code[u] >= 2u;
+                            // as in the pass per tile below: the rows taken from a chunk are a prefix of its sparse candidates
+                            const unsigned long long ms = __ballot(sparse);
+                            const uint32_t srank = cs + (uint32_t)__popcll(ms & lt_mask);
+                            const bool take = sparse && srank < kSegMaxSparseRows;
                             if (take) sout[(size_t)tile * (kSegMaxSparseRows + 1) + srank] = code[u] - 2u;
-                            if (mtake) mout[(size_t)tile * (kSegMaxMidRows + 1) + mrank] = code[u] & 0x7FFFFFFFu;
-                            const unsigned long long bt = __ballot(take), bm = __ballot(mtake);
-                            const unsigned long long md = __ballot(code[u] == 1u || (sparse && !take) || (mid && !mtake));
+                            const unsigned long long bt = __ballot(take);
+                            const unsigned long long md = __ballot(code[u] == 1u || (sparse && !take));
                             if (lane == 0) dm[(size_t)tile * mstride + c] = md;
                             cd += (uint32_t)__popcll(md);
                             cs += (uint32_t)__popcll(bt);
-                            cm += (uint32_t)__popcll(bm);
                         }
                     }
                     if (lane == 0) {
                         p.nsparse[(size_t)q * nt + tile] = cs;
-                        p.nmid[(size_t)q * nt + tile] = cm;
                         nseg += cd;
-                        nmidseg += cm;
                     }
                 }
             }
@@ -339,11 +331,11 @@ __global__ __launch_bounds__(64) void kmer_extract_kernel(KmerParams p) {
         const uint32_t tile = tb + lane;  // this lane's tile after the transposes
         // a tile that is not counted for this query's pair needs no lists (the transposes still take every lane)
         const bool tlive = tile < nt && (!live || ((live[tile >> 5] >> (tile & 31u)) & 1u));
-        uint32_t cd = 0, cs = 0, cm = 0;
+        uint32_t cd = 0, cs = 0;
         uint4 pend = make_uint4(0, 0, 0, 0);  // slot ids of this lane's tile waiting for their 16-byte store
         // the class tables of four chunks of 64 rows are gathered together (one round trip per four chunks, not one each)
-        unsigned long long dbv[4], sbv[4], mbv[4];
-        uint32_t basev[4], mbasev[4];
+        unsigned long long dbv[4], sbv[4];
+        uint32_t basev[4];
         for (uint32_t c = 0; c < nchunks; c++) {
             if ((c & 3u) == 0) {
 #pragma unroll
@@ -354,33 +346,24 @@ __global__ __launch_bounds__(64) void kmer_extract_kernel(KmerParams p) {
                     dbv[u] = p.seg_dbits[at];
                     sbv[u] = p.seg_sbits[at];
                     basev[u] = p.seg_sbase[at];
-                    mbv[u] = 0;
-                    mbasev[u] = 0;
-                    if (p.seg_mbits) {  // wave-uniform
-                        mbv[u] = p.seg_mbits[at];
-                        mbasev[u] = p.seg_mbase[at];
-                    }
-                    if (row == kEmptyRow) { dbv[u] = 0; sbv[u] = 0; mbv[u] = 0; }
+                    if (row == kEmptyRow) { dbv[u] = 0; sbv[u] = 0; }
                 }
             }
-            unsigned long long db = 0, sb = 0, mb = 0;
-            uint32_t base = 0, mbase = 0;
+            unsigned long long db = 0, sb = 0;
+            uint32_t base = 0;
 #pragma unroll
             for (int u = 0; u < 4; u++)
-                if ((c & 3u) == (uint32_t)u) { db = dbv[u]; sb = sbv[u]; mb = mbv[u]; base = basev[u]; mbase = mbasev[u]; }
+                if ((c & 3u) == (uint32_t)u) { db = dbv[u]; sb = sbv[u]; base = basev[u]; }
             l_sb[lane] = sb;
             l_base[lane] = base;
-            l_mb[lane] = mb;
-            l_mbase[lane] = mbase;
             unsigned long long dT = transpose64(db, lane), sT = transpose64(sb, lane);  // bit r = row c*64 + r
-            unsigned long long mT = p.seg_mbits ? transpose64(mb, lane) : 0ull;
             __syncthreads();
             if (tlive) {
                 // the first sparse rows go to the slot list (the byte counters of hit_count hold 255 hits: at most
-                // kSegMaxListRows sparse + mid segments together) ...
+                // kSegMaxSparseRows sparse segments) ...
                 // (four slot ids per 16-byte store: every lane writes to a list of its own, so each store is a memory
                 // transaction of its own, and those are what bounds this kernel -- a quarter as many)
-                while (sT && cs < kSegMaxSparseRows && cs + cm < kSegMaxListRows) {
+                while (sT && cs < kSegMaxSparseRows) {
                     const int r = __builtin_ctzll(sT);
                     sT &= sT - 1;
                     const uint32_t sid = l_base[r] + (uint32_t)__popcll(l_sb[r] & lt_mask);
@@ -389,19 +372,10 @@ __global__ __launch_bounds__(64) void kmer_extract_kernel(KmerParams p) {
                     pend.y = k4 == 1u ? sid : pend.y;
                     pend.z = k4 == 2u ? sid : pend.z;
                     pend.w = k4 == 3u ? sid : pend.w;
-#ifndef RTX_EXP_KMER_NO_SOUT  // experiment: what the scattered slot-id stores cost (wrong results: RTX_EXP_COUNT_ONLY runs)
                     if (k4 == 3u) *reinterpret_cast<uint4 *>(sout + (size_t)tile * (kSegMaxSparseRows + 1) + (cs - 3u)) = pend;
-#endif
                     cs++;
                 }
-                // ... the first mid rows to theirs ...
-                while (mT && cm < kSegMaxMidRows && cs + cm < kSegMaxListRows) {
-                    const int r = __builtin_ctzll(mT);
-                    mT &= mT - 1;
-                    mout[(size_t)tile * (kSegMaxMidRows + 1) + cm] = l_mbase[r] + (uint32_t)__popcll(l_mb[r] & lt_mask);
-                    cm++;
-                }
-                dT |= sT | mT;  // ... the rest is read densely
+                dT |= sT;  // ... the rest is read densely
                 dm[(size_t)tile * mstride + c] = dT;
                 cd += (uint32_t)__popcll(dT);
             }
@@ -411,13 +385,11 @@ __global__ __launch_bounds__(64) void kmer_extract_kernel(KmerParams p) {
             // the last, incomplete group of four (the entries behind cs are never used: the lists have 256 entries)
             if (cs & 3u) *reinterpret_cast<uint4 *>(sout + (size_t)tile * (kSegMaxSparseRows + 1) + (cs & ~3u)) = pend;
             p.nsparse[(size_t)q * nt + tile] = cs;
-            p.nmid[(size_t)q * nt + tile] = cm;
             nseg += cd;
-            nmidseg += cm;
         }
     }
     if (!p.seg_blocks) {  // few tiles (at most 12): one pass per tile; lane l keeps the counters of tile l
-        uint32_t cd = 0, cs = 0, cm = 0;
+        uint32_t cd = 0, cs = 0;
         const uint32_t nv = (nt + 3u) >> 2;  // seginfo rows are padded to whole uint4: four tiles per (gather) load
         for (uint32_t c0 = 0; c0 < nchunks; c0 += 4) {  // four chunks per turn, loads of a level together (see above)
             uint32_t row[4];
@@ -443,40 +415,31 @@ __global__ __launch_bounds__(64) void kmer_extract_kernel(KmerParams p) {
                     const uint32_t word = (tile & 3u) == 0 ? q4.x : (tile & 3u) == 1 ? q4.y : (tile & 3u) == 2 ? q4.z : q4.w;
                     const uint32_t code = row[u] != kEmptyRow ? word : 0u;
                     const uint32_t ns = (uint32_t)__builtin_amdgcn_readlane((int)cs, (int)tile);
-                    const uint32_t nm = (uint32_t)__builtin_amdgcn_readlane((int)cm, (int)tile);
-                    const bool mid = (code >> 31) != 0u;  // 0x80000000 | mid slot
-                    const bool sparse = code >= 2u && !mid;  // hit_count's byte counters hold 255 hits: more sparse rows are read densely
-                    // sparse and mid segments share the byte counters of hit_count: together at most kSegMaxListRows.  The
-                    // ranks count the candidates in front of a row (taken so far + earlier ones of this chunk): they only
-                    // grow along the rows, so the rows taken from a chunk are a prefix of its candidates of either kind --
-                    // their ranks are positions in the lists -- and a row is only taken while fewer than the cap have been
-                    const unsigned long long ms = __ballot(sparse), mm = __ballot(mid);
-                    const uint32_t srank = ns + (uint32_t)__popcll(ms & lt_mask), mrank = nm + (uint32_t)__popcll(mm & lt_mask);
-                    const bool room = srank + mrank < kSegMaxListRows;
-                    const bool take = sparse && srank < kSegMaxSparseRows && room;
-                    const bool mtake = mid && mrank < kSegMaxMidRows && room;
+                    const bool sparse = code >= 2u;  // hit_count's byte counters hold 255 hits: more sparse rows are read densely
+                    // The rank counts the sparse candidates in front of a row (taken so far + earlier ones of this chunk): it only
+                    // grows along the rows, so the rows taken from a chunk are a prefix of its candidates -- their ranks are
+                    // positions in the list -- and a row is only taken while fewer than the cap have been
+                    const unsigned long long ms = __ballot(sparse);
+                    const uint32_t srank = ns + (uint32_t)__popcll(ms & lt_mask);
+                    const bool take = sparse && srank < kSegMaxSparseRows;
                     if (take) sout[(size_t)tile * (kSegMaxSparseRows + 1) + srank] = code - 2u;
-                    if (mtake) mout[(size_t)tile * (kSegMaxMidRows + 1) + mrank] = code & 0x7FFFFFFFu;
-                    const unsigned long long bt = __ballot(take), bm = __ballot(mtake);
-                    const unsigned long long md = __ballot(code == 1u || (sparse && !take) || (mid && !mtake));
+                    const unsigned long long bt = __ballot(take);
+                    const unsigned long long md = __ballot(code == 1u || (sparse && !take));
                     if (lane == tile) {
                         dm[(size_t)tile * mstride + c] = md;
                         cd += (uint32_t)__popcll(md);
                         cs = ns + (uint32_t)__popcll(bt);
-                        cm = nm + (uint32_t)__popcll(bm);
                     }
                 }
             }
         }
         if (lane < nt) {
             p.nsparse[(size_t)q * nt + lane] = cs;
-            p.nmid[(size_t)q * nt + lane] = cm;
             nseg += cd;
-            nmidseg += cm;
         }
     }
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) { hq += __shfl_xor(hq, d, 64); nseg += __shfl_xor(nseg, d, 64); nmidseg += __shfl_xor(nmidseg, d, 64); }
+    for (int d = 32; d >= 1; d >>= 1) { hq += __shfl_xor(hq, d, 64); nseg += __shfl_xor(nseg, d, 64); }
     KMER_MARK(4)
 #ifdef RTX_KMER_STAMP
     hq = st_acc;
@@ -489,7 +452,6 @@ __global__ __launch_bounds__(64) void kmer_extract_kernel(KmerParams p) {
             p.t_all[gq] = t;
         }
         p.nrows_all[gq] = nseg;
-        p.nmid_all[gq] = nmidseg;
     }
 }
 
@@ -504,7 +466,7 @@ __global__ __launch_bounds__(64) void kmer_extract_kernel(KmerParams p) {
 // blockIdx.x = query (fast) so that concurrently resident waves work on the same
 // reference tile and popular rows are served from L2.
 // ---------------------------------------------------------------------------
-// (load8v, tree8, csa_plane and the epilogue shared with hit_count_quad_kernel: rtx_hit_common.hpp)
+// (load8v, tree8, csa_plane and the epilogue shared with hit_count_pair_kernel: rtx_hit_common.hpp)
 
 // Occupancy matters here: with <= 128 VGPRs four waves per SIMD are resident (16 per CU; their 8.4 KB of LDS each
 // just fit) -- a variant with 132 VGPRs (three waves) was 16 % slower.  The bound makes the compiler keep it.

@@ -21,15 +21,10 @@ constexpr uint32_t kWalkMaxRows = 208;
 // 31.3 % <= 32); a (query, tile) pair takes at most kSegMaxSparseRows such segments through the
 // byte counters of hit_count (more are read as dense segments)
 constexpr uint32_t kSegSlotEntries = 16, kSegSparseMax = 16, kSegMaxSparseRows = 255;
-// "mid" segments, 17 .. kSegMidMax references (20 % of the requested segments at N = 500k, a third of the dense ones --
-// the k-mers a query owes to its own substitutions are spread over the database like this, and they are the rows no
-// other query has just pulled into L2): kept as kSegMidEntries local ids (u16, >= kSegMidPad = unused) = 256 bytes instead of
-// 1 KiB; hit_count adds them through the byte counters of the sparse segments.  At most kSegMaxMidRows per (query, tile)
-// and at most 255 sparse + mid segments together (the counters are bytes); the rest is read densely.
-constexpr uint32_t kSegMidMax = 128, kSegMidEntries = 128, kSegMaxMidRows = 127, kSegMidPad = 8192, kSegMaxListRows = 255;
-// unused entry i of a mid slot: 64 different pad words behind the byte counters (local id 8192 + 4 (i mod 64)), so that the
-// LDS atomics of the unused entries of a wave-instruction do not all hit one address
-__host__ __device__ inline uint32_t seg_mid_pad(uint32_t i) { return kSegMidPad + ((i & 63u) << 2); }
+// unused entry i of a slot: local id kSegPad + 4 (i mod 64) -- 64 different pad words behind the byte counters of hit_count, so that
+// the LDS atomics of the unused entries of a wave-instruction do not all hit one address (no compare, no exec mask per atomic)
+constexpr uint32_t kSegPad = 8192;
+__host__ __device__ inline uint32_t seg_pad(uint32_t i) { return kSegPad + ((i & 63u) << 2); }
 // hit_count compacts the dense rows of its (query, tile) into an LDS list of this many row ids (+ padding), in
 // several rounds if they do not fit
 constexpr uint32_t kKmerFewLive = 8;   // kmer_extract, lists of the live tiles only: up to this many tiles one pass per tile (rtx_kernels.hip)
@@ -58,17 +53,12 @@ struct KmerParams {
     // 64 rows x 64 tiles instead of a pass per tile): dense / sparse bits and the slot of the block's first sparse segment
     const unsigned long long *seg_dbits, *seg_sbits;  // [n_rows+1][seg_blocks]
     const uint32_t *seg_sbase;                        // [n_rows+1][seg_blocks]
-    const unsigned long long *seg_mbits;              // [n_rows+1][seg_blocks] mid segments, or null
-    const uint32_t *seg_mbase;                        // [n_rows+1][seg_blocks] mid slot of the block's first mid segment
     uint32_t seg_blocks;                              // ceil(ntiles / 64); 0 = use seginfo
     uint32_t *rows;     // [B][rstride] rows of the query's k-mers (ascending), padded with the zero row to a multiple of 64
     uint32_t rstride;
     unsigned long long *dmask;  // [B][ntiles][rstride/64] per tile: which of those rows have a dense segment there
     uint32_t *srows;    // [B][ntiles][kSegMaxSparseRows + 1] per tile: slots of the sparse segments
     uint32_t *nsparse;  // [B][ntiles]
-    uint32_t *mrows;    // [B][ntiles][kSegMaxMidRows + 1] per tile: slots of the mid segments
-    uint32_t *nmid;     // [B][ntiles]
-    uint32_t *nmid_all; // [n_q] mid segments over all tiles (work accounting)
     uint32_t *t;      // [B]
     uint32_t *nrows;  // [B] dense segments over all tiles (work accounting)
     unsigned long long *hq;  // [n_q]
@@ -96,9 +86,6 @@ struct HitParams {
     const uint32_t *srows;    // [B][ntiles][kSegMaxSparseRows + 1]
     const uint32_t *nsparse;  // [B][ntiles]
     const uint16_t *segslots; // [n_slots][kSegSlotEntries] local ids of the sparse segments
-    const uint32_t *mrows;    // [B][ntiles][kSegMaxMidRows + 1]
-    const uint32_t *nmid;     // [B][ntiles]
-    const uint16_t *midslots; // [n_mid][kSegMidEntries] local ids of the mid segments (kSegMidPad = unused)
     uint32_t ntiles;
     const uint32_t *t;
     uint16_t *counts;  // [B][npad] u16 counts (more than 10 bit planes: t > 1023)
@@ -115,19 +102,15 @@ struct HitParams {
     const uint32_t *perm;       // [n_q] query at every position: exact_off is indexed by query
     const uint32_t *exact_ids;
     const uint64_t *exact_off;
-    // hit_count_quad_kernel (rtx_hit_quad.hip): four consecutive slots per workgroup
     uint32_t nq;           // slots of the sub-batch
-    uint32_t *group_rows;  // [groups of the batch] union rows loaded per group, summed over the tiles (work accounting) or null
+    uint32_t *group_rows;  // [pairs of the batch] union rows loaded per pair, summed over the tiles (work accounting) or null
     uint32_t group_base;   // index of the sub-batch's first group in group_rows
     // hit_count_pair_kernel (rtx_hit_pair.hip): two consecutive slots per wave
     const uint2 *pair_urec;   // [pairs][pair_ustride] union of the two row lists (pair_union_kernel)
     const uint32_t *pair_nu;  // [pairs] entries of the union
     uint32_t pair_ustride;
-    uint4 *pair_planes;       // [pairs][ntiles][10][64] sequential variant: the planes of the shared rows, parked between A's and B's rows
-    uint32_t flags_prune;     // experiment RTX_EXP_PRUNE_EMU: 1 from the second run of a handle on
     const uint32_t *live;     // [pairs][live_words] tiles to count for a pair (rtx_prune.hip) or null: all
     uint32_t live_words;
-
 };
 
 // tile pruning (rtx_prune.hip)
@@ -247,8 +230,7 @@ void launch_kmer_extract(hipStream_t s, const KmerParams &p, uint32_t nq);
 void launch_hit_count(hipStream_t s, const HitParams &p, uint32_t nq, uint32_t ntiles, int planes);
 void launch_pair_union(hipStream_t s, const uint32_t *rows, const uint32_t *nrows, uint32_t rstride, uint32_t nq, uint2 *urec,
                        uint32_t *nu, uint32_t ustride);
-void launch_hit_count_pair(hipStream_t s, const HitParams &p, uint32_t nq, uint32_t ntiles, int variant);
-void launch_hit_count_quad(hipStream_t s, const HitParams &p, uint32_t nq, uint32_t ntiles);  // 10 bit planes only
+void launch_hit_count_pair(hipStream_t s, const HitParams &p, uint32_t nq, uint32_t ntiles);  // 10 bit planes only
 size_t prob_table_lds_bytes(uint32_t tmax);
 void launch_prob_table(hipStream_t s, const ProbParams &p, uint32_t nq);
 size_t prob_lookup_lds_bytes(uint32_t tmax);
@@ -258,7 +240,7 @@ void launch_prob_lookup(hipStream_t s, const ProbParams &p, const ProbTables &tb
 // segment classes of the index (rtx_segments.hip)
 void launch_seg_popcount(hipStream_t s, const uint32_t *bitmap, uint32_t stride_bytes, uint32_t n_rows1, uint32_t ntiles, uint16_t *pop);
 void launch_seg_emit(hipStream_t s, const uint32_t *bitmap, uint32_t stride_bytes, uint32_t n_rows1, uint32_t ntiles,
-                     const uint32_t *seginfo, uint32_t seg_stride, uint16_t *slots, uint16_t *midslots);
+                     const uint32_t *seginfo, uint32_t seg_stride, uint16_t *slots);
 // processing order of a batch (rtx_cluster.hip)
 void launch_sketch(hipStream_t s, const uint8_t *bases, const uint64_t *off, uint32_t n_q, uint64_t *keys, uint32_t *idx);
 void launch_invert_perm(hipStream_t s, const uint32_t *perm, uint32_t n, uint32_t *inv);

@@ -4,11 +4,11 @@
 // k-mer that is typical for a clade fills a few tiles and leaves the others empty or nearly empty: 11 % of the
 // (row, tile) segments a query asks for are empty and another 20 % hold at most 32 references (bench workload),
 // and those are the segments no other query has just pulled into L2.  At index creation every segment is classified
-//     0 = empty (never loaded), 1 = dense (loaded as a 1-KiB row segment), s + 2 = sparse, slot s,
-//     0x80000000 | m = mid, slot m (RTX_DEFAULT_SEGMENT_CLASSES = 2)
-// and the references of a sparse segment (at most 16) are written to a 32-byte slot of 16 local ids (u16), those of a
-// mid segment (17 .. 128) to a 256-byte slot of 128; unused entries hold ids >= kSegMidPad (pad words of hit_count).  kmer_extract turns the
-// classes into per-(query, tile) row lists; hit_count adds the sparse and the mid slots through byte counters in LDS.
+//     0 = empty (never loaded), 1 = dense (loaded as a 1-KiB row segment), s + 2 = sparse, slot s
+// and the references of a sparse segment (at most 16) are written to a 32-byte slot of 16 local ids (u16); unused entries
+// hold ids >= kSegPad (pad words of hit_count).  kmer_extract turns the classes into per-(query, tile) row lists; hit_count
+// adds the sparse slots through byte counters in LDS.  (Lists for segments of 17 .. 128 references were built twice in round 2:
+// fewer requested bytes, bit-exact, and slower both times -- DESIGN.md section 3; removed in round 3.)
 #include <hip/hip_runtime.h>
 
 #include "rtx_kernels.hpp"
@@ -37,14 +37,13 @@ __global__ __launch_bounds__(64) void seg_popcount_kernel(const uint32_t *__rest
 // writes the local reference ids of every sparse segment into its slot; one wave per row
 __global__ __launch_bounds__(64) void seg_emit_kernel(const uint32_t *__restrict__ bitmap, uint32_t stride_bytes, uint32_t ntiles,
                                                       const uint32_t *__restrict__ seginfo, uint32_t seg_stride,
-                                                      uint16_t *__restrict__ slots, uint16_t *__restrict__ midslots) {
+                                                      uint16_t *__restrict__ slots) {
     const uint32_t row = blockIdx.x, lane = threadIdx.x, n_rows1 = gridDim.x;
     for (uint32_t tile = 0; tile < ntiles; tile++) {
         const uint32_t code = seginfo[(size_t)row * seg_stride + tile];
         if (code < 2u) continue;  // wave-uniform
-        const bool mid = code >> 31;  // mid segment: a longer slot, unused entries = kSegMidPad
-        uint16_t *out = mid ? midslots + (size_t)(code & 0x7FFFFFFFu) * kSegMidEntries : slots + (size_t)(code - 2u) * kSegSlotEntries;
-        const uint32_t cap = mid ? kSegMidEntries : kSegSlotEntries;
+        uint16_t *out = slots + (size_t)(code - 2u) * kSegSlotEntries;
+        const uint32_t cap = kSegSlotEntries;
         const uint32_t col = tile * 1024u + lane * 16u;
         uint32_t w[4] = {0, 0, 0, 0};
         if (col < stride_bytes) {
@@ -68,9 +67,9 @@ __global__ __launch_bounds__(64) void seg_emit_kernel(const uint32_t *__restrict
         {   // the entries behind the last reference: hit_count adds them into pad words behind its byte counters without
             // looking (different words for neighbouring slots and entries: one word would serialise the LDS atomics)
             const uint32_t total = (uint32_t)__shfl((int)pos, 63, 64);  // lane 63 ends behind the last one
-            const uint32_t salt = mid ? 0u : (code - 2u) * 5u;
+            const uint32_t salt = (code - 2u) * 5u;
             for (uint32_t i = lane; i < cap; i += 64)
-                if (i >= total) out[i] = (uint16_t)seg_mid_pad(i + salt);
+                if (i >= total) out[i] = (uint16_t)seg_pad(i + salt);
         }
     }
 }
@@ -79,8 +78,8 @@ void launch_seg_popcount(hipStream_t s, const uint32_t *bitmap, uint32_t stride_
     hipLaunchKernelGGL(seg_popcount_kernel, dim3(n_rows1), dim3(64), 0, s, bitmap, stride_bytes, ntiles, pop);
 }
 void launch_seg_emit(hipStream_t s, const uint32_t *bitmap, uint32_t stride_bytes, uint32_t n_rows1, uint32_t ntiles,
-                     const uint32_t *seginfo, uint32_t seg_stride, uint16_t *slots, uint16_t *midslots) {
-    hipLaunchKernelGGL(seg_emit_kernel, dim3(n_rows1), dim3(64), 0, s, bitmap, stride_bytes, ntiles, seginfo, seg_stride, slots, midslots);
+                     const uint32_t *seginfo, uint32_t seg_stride, uint16_t *slots) {
+    hipLaunchKernelGGL(seg_emit_kernel, dim3(n_rows1), dim3(64), 0, s, bitmap, stride_bytes, ntiles, seginfo, seg_stride, slots);
 }
 
 }  // namespace rtx

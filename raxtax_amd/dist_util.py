@@ -46,7 +46,10 @@ def pack_records(row_off, row_lineage, row_depth, row_conf, row_local, global_si
     status = np.zeros(n_q, np.uint8) if status is None else np.asarray(status[:n_q], dtype=np.uint8)
     depth = np.ascontiguousarray(row_depth[:n_rows], dtype=np.uint8)
     levels = max(int(depth.max()) if n_rows else 1, 1)
-    conf = np.asarray(row_conf).reshape(n_rows, -1)[:, :levels]
+    conf = np.asarray(row_conf)
+    if conf.ndim == 1:                              # flat [rows][levels], as long as row_depth (callers may pass views with spare rows)
+        conf = conf.reshape(max(len(row_depth), 1), -1)
+    conf = conf[:n_rows, :levels]                   # slice the rows first, like every other field
     conf_u8 = np.rint(conf * 100.0).astype(np.uint8)
     if conf_u8.shape[1] < levels:
         conf_u8 = np.pad(conf_u8, ((0, 0), (0, levels - conf_u8.shape[1])))

@@ -288,12 +288,11 @@ def test_sub_batching_and_rerun_are_deterministic(world):
 def test_processing_order_does_not_change_results(world):
     """RTX_OPT_CLUSTER (queries processed in min-hash order, rtx_cluster.hip) is a scheduling decision:
     every array of the result equals the one of a run in input order, also when the batch spans several
-    sub-batches, runs on two streams, or is downloaded in one piece after a sync (bulk path) instead of
-    streamed per sub-batch."""
+    sub-batches, or is downloaded in one piece after a sync (bulk path) instead of streamed per sub-batch."""
     w = world
     ex_ids, ex_off = w["index"].exact_matches(w["bases"], w["off"])
     ref = rx.Index(w["tree"], cluster=False).classify(w["bases"], w["off"], ex_ids, ex_off)
-    for kw in (dict(cluster=True), dict(cluster=True, sub_batch=16), dict(cluster=True, sub_batch=50, streams=2)):
+    for kw in (dict(cluster=True), dict(cluster=True, sub_batch=16), dict(cluster=True, sub_batch=50)):
         ix = rx.Index(w["tree"], **kw)
         for skip in (False, True):
             want = ref if not skip else rx.Index(w["tree"], cluster=False).classify(w["bases"], w["off"], ex_ids, ex_off,
@@ -348,7 +347,7 @@ def test_pair_kernel_equals_one_query_per_wave(world, oracle):
     u16 counts."""
     w = world
     ex_ids, ex_off = w["index"].exact_matches(w["bases"], w["off"])
-    for kw in (dict(), dict(sub_batch=37), dict(packed_counts=False), dict(hit_pair=2), dict(hit_pair=2, sub_batch=37)):
+    for kw in (dict(), dict(sub_batch=37), dict(packed_counts=False)):
         a, b = rx.Index(w["tree"], **dict(kw, hit_pair=False)), rx.Index(w["tree"], **dict(dict(hit_pair=True), **kw))
         for skip in (False, True):
             ra = a.classify(w["bases"], w["off"], ex_ids, ex_off, skip_exact_matches=skip)
@@ -365,16 +364,15 @@ def test_pair_kernel_equals_one_query_per_wave(world, oracle):
         assert wa["sum_hits"] == wb["sum_hits"] and wb["bitmap_bytes_read"] <= wa["bitmap_bytes_read"]
 
 
-@pytest.mark.parametrize("variant", [1, 2])
 @pytest.mark.parametrize("n_refs", [70000, 20011])
-def test_pair_kernel_many_tiles(oracle, n_refs, variant):
+def test_pair_kernel_many_tiles(oracle, n_refs):
     """The pair kernel over several tiles and a partial last tile, related queries next to each other (shared rows)
     and unrelated ones; hit counts against the oracle."""
     db = synth.make_db(n_refs)
     qs = synth.make_queries(db, 201, exact_frac=0.2)
     otree = oracle.tree_new_flat(db.lineages, db.seq_bytes, db.seq_off)
     tree = rx.Tree.new_flat(db.lineages, db.seq_bytes, db.seq_off)
-    a, b = rx.Index(tree, hit_pair=False), rx.Index(tree, hit_pair=variant, tile_prune=False)   # kernel against kernel, every tile counted
+    a, b = rx.Index(tree, hit_pair=False), rx.Index(tree, hit_pair=True, tile_prune=False)   # kernel against kernel, every tile counted
     ex = a.exact_matches(qs.bases, qs.base_off)
     for skip in (False, True):
         ra = a.classify(qs.bases, qs.base_off, *ex, skip_exact_matches=skip)
@@ -387,29 +385,6 @@ def test_pair_kernel_many_tiles(oracle, n_refs, variant):
     wa, wb = a.work(), b.work()
     print(f"bitmap bytes: one query per wave {wa['bitmap_bytes_read']}, pairs {wb['bitmap_bytes_read']}")
     assert wb["bitmap_bytes_read"] < wa["bitmap_bytes_read"]
-
-
-def test_quad_kernel_equals_one_wave_per_query(world, oracle):
-    """RTX_OPT_HIT_QUAD: four neighbouring queries per workgroup, rows loaded once through LDS (rtx_hit_quad.hip).
-    Every result array and the hit counts equal those of hit_count_kernel -- with the degenerate queries of `world`
-    (no k-mers, one k-mer, short), a sub-batch size that is no multiple of four, --skip-exact-matches, u16 counts."""
-    w = world
-    ex_ids, ex_off = w["index"].exact_matches(w["bases"], w["off"])
-    for kw in (dict(), dict(sub_batch=37), dict(packed_counts=False)):
-        a, b = rx.Index(w["tree"], hit_quad=False, **kw), rx.Index(w["tree"], hit_quad=True, **kw)
-        for skip in (False, True):
-            ra = a.classify(w["bases"], w["off"], ex_ids, ex_off, skip_exact_matches=skip)
-            rb = b.classify(w["bases"], w["off"], ex_ids, ex_off, skip_exact_matches=skip)
-            for f in ("row_off", "row_lineage", "row_conf", "row_local_signal", "global_signal", "t", "status"):
-                assert np.array_equal(getattr(ra, f), getattr(rb, f)), (kw, skip, f)
-            if "sub_batch" in kw:      # the taps see the last sub-batch of the PROCESSING order only
-                continue
-            for q in range(0, len(w["seqs"]), 2):
-                c = b.debug_hit_counts(q)
-                assert np.array_equal(c, a.debug_hit_counts(q)), (kw, skip, q)
-                assert np.array_equal(c, w["otree"].hit_counts(w["seqs"][q], skip_exact=skip)[1])
-        wa, wb = a.work(), b.work()
-        assert wa["sum_hits"] == wb["sum_hits"] and 0 < wb["bitmap_bytes_read"] <= wa["bitmap_bytes_read"]
 
 
 def test_work_accounting_matches_oracle(world):
@@ -711,7 +686,7 @@ def _random_db(n_refs, length, seed, n_taxa=64):
     return lineages, seqs.reshape(-1), off
 
 
-@pytest.mark.parametrize("segment_classes", [2, 1, 0])
+@pytest.mark.parametrize("segment_classes", [1, 0])
 def test_sparse_and_empty_segments(oracle, segment_classes):
     """Segment classes of the index (rtx_segments.hip): a database of short random references makes EVERY segment
     sparse (a k-mer occurs in ~6 of the 8192 references of a tile), a 658-base query then has ~640 sparse segments
@@ -749,46 +724,18 @@ def test_sparse_and_empty_segments(oracle, segment_classes):
 
 
 @pytest.mark.parametrize("hit_pair", [False, True])
-@pytest.mark.parametrize("n_refs", [3 * 8192, 4 * 8192 + 700])
-def test_mid_segments(oracle, n_refs, hit_pair):
-    """Segments with 17-128 references travel as 256 bytes of local ids and are added through the byte counters of the
-    sparse segments (rtx_hit_common.hpp: hit_epilogue_x): same hit counts as with every segment read densely and as the
-    oracle, with and without --skip-exact-matches, one query per wave and two; full tiles and a partial last tile (no
-    lists there); more mid rows in a tile than the list takes (the rest is read densely)."""
-    db = synth.make_db(n_refs, fanouts=(3, 3, 3, 4, 4, 3))
-    qs = synth.make_queries(db, 96, exact_frac=0.2)
-    otree = oracle.tree_new_flat(db.lineages, db.seq_bytes, db.seq_off)
-    tree = rx.Tree.new_flat(db.lineages, db.seq_bytes, db.seq_off, kmer_map=False)
-    a, b = rx.Index(tree, segment_classes=2, hit_pair=hit_pair), rx.Index(tree, segment_classes=0, hit_pair=hit_pair)
-    rx.Index(tree, segment_classes=DEFAULT_SEGMENT_CLASSES)            # back to the process-wide default
-    ex = a.exact_matches(qs.bases, qs.base_off)
-    for skip in (False, True):
-        ra = a.classify(qs.bases, qs.base_off, *ex, skip_exact_matches=skip)
-        rb = b.classify(qs.bases, qs.base_off, *ex, skip_exact_matches=skip)
-        for f in ("row_off", "row_lineage", "row_conf", "row_local_signal", "global_signal", "t", "status"):
-            assert np.array_equal(getattr(ra, f), getattr(rb, f)), (skip, f)
-        for q in range(0, qs.n, 3):
-            c = a.debug_hit_counts(q)
-            assert np.array_equal(c, b.debug_hit_counts(q)), (skip, q)
-            assert np.array_equal(c, otree.hit_counts(qs.seq(q), skip_exact=skip)[1]), (skip, q)
-    wa, wb = a.work(), b.work()
-    assert wa["sum_hits"] == wb["sum_hits"] and wa["bitmap_bytes_read"] < 0.9 * wb["bitmap_bytes_read"]
-
-
-@pytest.mark.parametrize("hit_pair", [False, True])
 @pytest.mark.parametrize("ref_len", [400, 150])
-def test_mid_and_sparse_segments_share_the_byte_counters(oracle, ref_len, hit_pair):
-    """A database of random references in which a k-mer occurs in about 50 (ref_len 400) or 18 (ref_len 150: about half
-    of the segments sparse, half mid) of the 8192 references of a tile: a 658-base query then has hundreds of list
-    segments per tile -- more than the 127 mid segments a list takes and more than the 255 sparse + mid segments the byte
-    counters may see, so both caps and the dense fallback are exercised; the last tile is partial.  Hit counts bit-exact
+def test_sparse_and_dense_segments_mixed(oracle, ref_len, hit_pair):
+    """A database of random references in which a k-mer occurs in about 50 (ref_len 400: dense segments) or 18 (ref_len 150:
+    about half of the segments sparse) of the 8192 references of a tile: a 658-base query then has hundreds of sparse
+    segments per tile -- more than the 255 the byte counters may see, so the cap and the dense fallback are exercised, with
+    one query per wave and with two (the byte counters of a whole tile); the last tile is partial.  Hit counts bit-exact
     against the oracle, with and without --skip-exact-matches (exact matches reached through lists are zeroed too)."""
     n_refs = 2 * 8192 + 1000
     lineages, flat, off = _random_db(n_refs, ref_len, seed=21)
     otree = oracle.tree_new_flat(lineages, flat, off)
     tree = rx.Tree.new_flat(lineages, flat, off)
-    ix = rx.Index(tree, segment_classes=2, hit_pair=hit_pair)
-    rx.Index(tree, segment_classes=DEFAULT_SEGMENT_CLASSES)
+    ix = rx.Index(tree, hit_pair=hit_pair)
     rng = np.random.default_rng(22)
     qs = []
     for i in range(16):
@@ -906,9 +853,10 @@ def test_randomised_configurations(oracle, seed):
     # library options drawn after everything else (the data of a seed stay what they were): every combination must give
     # the same results
     orng = np.random.default_rng(seed + 77)
-    opts = dict(hit_quad=bool(orng.random() < 0.35), segment_classes=int(orng.choice([0, 1, 2])), packed_counts=bool(orng.random() < 0.75))
-    opts["tile_skip"] = bool(orng.random() < 0.7)   # drawn last: the options of the recorded seeds stay what they were
-    opts["hit_pair"] = int(orng.choice([0, 1, 1, 2, 2]))
+    orng.random()                                   # (round 2 drew RTX_OPT_HIT_QUAD here; the draws of the recorded seeds stay what they were)
+    opts = dict(segment_classes=min(1, int(orng.choice([0, 1, 2]))), packed_counts=bool(orng.random() < 0.75))
+    opts["tile_skip"] = bool(orng.random() < 0.7)
+    opts["hit_pair"] = bool(int(orng.choice([0, 1, 1, 2, 2])))
     opts["locator"] = bool(orng.random() < 0.6)
     ix = rx.Index(tree, sub_batch=int(rng.choice([0, 5, 64])), cluster=bool(rng.random() < 0.7), **opts)
     rx.Index(tree, segment_classes=DEFAULT_SEGMENT_CLASSES)     # restore the process-wide default for later tests

@@ -1,10 +1,15 @@
 #!/usr/bin/env python3
 """bench.py -- classified queries/s of the raxtax hot path on N MI355X of one node.
 
-A "step" is one pass of the whole device path (processing order -> kmer_extract -> hit_count -> prob_lookup ->
-taxon_prefix + lineage walk -> result rows finalised on the host) over one batch of synthetic queries per GPU, with
-the queries, their exact-match ids (Tree.sequences.get, raxtax.rs:42, looked up on the host once, untimed) and the
-index already resident in HBM when the timed region starts.
+A "step" is one pass of the whole device path (exact-match lookup Tree.sequences.get, raxtax.rs:42 -> processing order ->
+kmer_extract -> hit_count -> prob_lookup -> taxon_prefix + lineage walk -> result rows finalised on the host) over one batch
+of synthetic queries per GPU, with the queries and the index already resident in HBM when the timed region starts
+(`--host-exact-match`: the lookup on the host instead, once, untimed -- rounds 1 and 2).
+
+Beside `value` the line carries its own caveats (rank 0 at N = 1, `--no-extras` leaves them out): `value_incl_h2d` (the
+queries cross PCIe every step), `value_end_to_end` (host buffers -> rtx_raxtax -> formatted result strings, no disk),
+`value_unpruned` (RTX_OPT_TILE_PRUNE = 0: every tile counted) and a sweep over the divergence of the queries from their
+source reference (`divergence_sweep`: the tile pruning depends on how far a query's best hit stands out).
 
 Default workload = BASELINE.json configs[2], the largest single-GPU configuration: 1 M synthetic COI-length
 (658 bp) queries per GPU vs a 500k-sequence database replicated per GPU (`--config 1` = configs[1]: 100k queries vs
@@ -69,6 +74,10 @@ def parse():
     ap.add_argument("--tile-prune", action="store_true", help="(the default; kept for older command lines)")
     ap.add_argument("--no-tile-skip", action="store_true", help="taxon_prefix sums every reference (RTX_OPT_TILE_SKIP = 0; A/B measurements)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="only the headline: no H2D / end-to-end / unpruned legs, no divergence sweep")
+    ap.add_argument("--host-exact-match", action="store_true",
+                    help="Tree.sequences.get on the host, once, untimed (rounds 1-2); default: on the device inside the timed step")
+    ap.add_argument("--e2e-chunk", type=int, default=262144, help="queries per device batch of the end-to-end leg (rtx_raxtax chunk_size)")
     ap.add_argument("--skip-exact-matches", action="store_true")
     ap.add_argument("--hit-events-only", action="store_true",
                     help="HIP events around hit_count only (default: around every kernel; costs < 0.1 % of a step)")
@@ -316,6 +325,84 @@ def roofline_block(args, work, prob_work, stage_ms, stage_n, n_queries_step, que
 
 
 # ------------------------------------------------------------------------------------------------------------
+# the caveats of the headline, measured in the same run (rank 0, N = 1)
+# ------------------------------------------------------------------------------------------------------------
+def extras_block(args, rx, lib, index, tree, db, qs, flags):
+    """What `value` leaves out or depends on, each timed here with its own barrier-free loop on the one GPU:
+      value_incl_h2d     upload (H2D of one byte per base) + run + download per step: the queries are NOT resident
+      value_end_to_end   rtx_raxtax (src/raxtax.rs:14-97 mirrored): host buffers in, formatted `.out` strings out (a sender that
+                         discards them: no disk), exact-match lookup, override and formatting included
+      value_unpruned     RTX_OPT_TILE_PRUNE = 0: hit_count counts every tile (the floor under the headline)
+      divergence_sweep   131 072 queries whose distance from their source reference is 2 / 5 / 10 / 15 % per site (no exact copies):
+                         the further a query is from its best hit, the lower its threshold and the more tiles stay live."""
+    out = {}
+    n_q = qs.n
+    steps = 3
+
+    def timed(fn, warm=1):
+        for _ in range(warm):
+            fn()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        return (time.perf_counter() - t0) / steps
+
+    # ---- queries cross PCIe every step
+    def with_upload():
+        index.upload(qs.bases, qs.base_off)
+        index.run(flags)
+        index.download(copy=False)
+    dt = timed(with_upload)
+    out["value_incl_h2d"] = {"value": n_q / dt, "ms_per_step": dt * 1e3, "steps": steps,
+                             "what": "rtx_batch_upload (pageable host memory, one byte per base: %.0f MB) + rtx_batch_run + rtx_batch_download" % (len(qs.bases) / 1e6)}
+    # ---- through the host mirror of raxtax() to strings
+    labels = (ctypes.c_char_p * n_q)(*[l.encode() for l in qs.labels])
+    SENDER = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p)
+    lib.rtx_raxtax.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.POINTER(ctypes.c_char_p), rx._lib.u8p, rx._lib.u64p,
+                               ctypes.c_int, ctypes.c_int, ctypes.c_uint64, SENDER, ctypes.c_void_p, ctypes.c_int]
+    discard = ctypes.cast(lib.rtx_sender_discard, SENDER)
+    counted = (ctypes.c_uint64 * 2)()
+    bases = np.ascontiguousarray(qs.bases)
+    off = np.ascontiguousarray(qs.base_off)
+
+    def e2e():
+        rx._lib.check(lib.rtx_raxtax(index._h, tree._h, n_q, labels, rx._lib.ptr(bases, rx._lib.u8p), rx._lib.ptr(off, rx._lib.u64p),
+                                     int(bool(flags)), 0, args.e2e_chunk, discard, ctypes.cast(counted, ctypes.c_void_p), 0))
+    dt = timed(e2e)
+    out["value_end_to_end"] = {"value": n_q / dt, "ms_per_step": dt * 1e3, "steps": steps, "chunk_size": args.e2e_chunk,
+                               "text_bytes_per_query": counted[1] / max(counted[0], 1),
+                               "what": "rtx_raxtax: host buffers -> H2D -> exact-match lookup + classification on the device -> D2H -> override + "
+                                       "formatting of the .out lines (raxtax.rs:73-87) -> sender (discards: no disk); pipelined over chunks"}
+    # ---- every tile counted
+    rx._lib.check(lib.rtx_index_set_option(index._h, 13, 0))
+
+    def plain():
+        index.run(flags)
+        index.download(copy=False)
+    index.upload(qs.bases, qs.base_off)
+    dt = timed(plain)
+    out["value_unpruned"] = {"value": n_q / dt, "ms_per_step": dt * 1e3, "steps": steps, "what": "RTX_OPT_TILE_PRUNE = 0: hit_count counts every tile"}
+    rx._lib.check(lib.rtx_index_set_option(index._h, 13, 0 if args.no_tile_prune else 1))
+    # ---- divergence sweep
+    from raxtax_amd import synth
+    sweep = []
+    for k, mu in enumerate((0.02, 0.05, 0.10, 0.15)):
+        q2 = synth.make_queries(db, 131072, seed=40 + k, mu_q=mu, exact_frac=0.0, n_frac=0.0)
+        index.upload(q2.bases, q2.base_off)
+        dt = timed(plain)
+        st = index.debug_prune_stats()
+        sweep.append({"mu_q": mu, "value": 131072 / dt, "ms_per_step": dt * 1e3, "live_tiles_per_pair": st["live_tiles_per_pair"],
+                      "share_with_threshold": st["queries_with_threshold"] / 131072, "mean_threshold": st["mean_threshold"],
+                      "mean_best_hit_lower_bound": st["mean_best_hit_lower_bound"],
+                      "tiles_above_threshold_per_query": st["tiles_above_threshold_per_query"]})
+    out["divergence_sweep"] = {"queries": 131072, "steps": steps, "exact_copies": 0.0,
+                               "note": "per-site substitution rate of a query against its source reference (the headline workload: 0.02 and 10 % exact copies)",
+                               "rows": sweep}
+    index.upload(qs.bases, qs.base_off)     # leave the handle as the headline had it
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------------
 def main():
     args = parse()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -402,10 +489,14 @@ def main():
                          packed_counts=False if args.u16_counts else None,
                          tile_skip=False if args.no_tile_skip else None, hit_pair=False if args.no_pair else None,
                          locator=False if args.no_locator else None, tile_prune=False if args.no_tile_prune else None)
-        t0 = time.perf_counter()
-        ex_ids, ex_off = index.exact_matches(qs.bases, qs.base_off)   # Tree.sequences.get, raxtax.rs:42 (host)
-        t_exact = time.perf_counter() - t0
-        index.upload(qs.bases, qs.base_off, ex_ids, ex_off)            # inputs resident in HBM from here on
+        t_exact = None
+        if args.host_exact_match or not index.has_exact_lookup:
+            t0 = time.perf_counter()
+            ex_ids, ex_off = index.exact_matches(qs.bases, qs.base_off)   # Tree.sequences.get, raxtax.rs:42 (host, untimed)
+            t_exact = time.perf_counter() - t0
+            index.upload(qs.bases, qs.base_off, ex_ids, ex_off)            # inputs resident in HBM from here on
+        else:
+            index.upload(qs.bases, qs.base_off)                            # no ids: looked up on the device, every step
 
         # N > 1: packing and gathering the records of step i happen while the device classifies step i+1 (two sets of
         # buffers); those of the last step are completed inside the timed region
@@ -502,12 +593,15 @@ def main():
                                   else {"backend": None, "world_size": 1}),
                 "classified_ok": ok, "skip_exact_matches": bool(args.skip_exact_matches),
                 "sub_batch": int(round(args.queries / max(stage_n["hit_count"] / args.steps, 1))) if stage_n["hit_count"] else None,
-                "untimed_host_exact_match_lookup_s": round(t_exact, 3),
+                "exact_match_lookup": ("host hash map, once, untimed: %.3f s" % t_exact) if t_exact is not None else
+                                      "device (rtx_exact.hip), inside every timed step",
             },
             "roofline": roofline_block(args, work, prob_work, stage_ms, stage_n, args.queries, L, prune=prune_stats,
                                        ntiles=(args.refs + 8191) // 8192),
             "stage_ms_per_step": {s: stage_ms[s] / args.steps for s in stage_ms},
         }
+        if not args.no_extras and world == 1 and not args.shard_db:
+            line.update(extras_block(args, rx, lib, index, tree, db, qs, flags))
         if not args.no_cpu_baseline and world == 1:      # reported baseline: rank 0 at N = 1 only
             line["cpu_baseline"] = cpu_baseline(db, qs, args.cpu_seconds, bool(flags))
         else:

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define RTX_ABI_VERSION 2 /* 2: rtx_result_view.row_begin/row_count replace row_off */
+#define RTX_ABI_VERSION 3 /* 2: rtx_result_view.row_begin/row_count replace row_off; 3: exact_off == NULL = look the exact matches up on the device */
 #define RTX_NUM_KMERS 65536u /* 2 << 15 posting lists, src/tree.rs:52 */
 #define RTX_MAX_DEPTH 32u    /* deepest lineage (comma-separated levels) the device walk carries */
 
@@ -182,6 +182,12 @@ int rtx_index_set_batch(rtx_index *index, uint32_t sub_batch);
 #define RTX_OPT_PROB_MODE 2
 #define RTX_OPT_STAGE_TIMING 6 /* 0 (default): HIP events around hit_count only; 1: around every kernel
                                  (rtx_batch_stage_times then reports all stages; adds ~1 ms per 100k queries) */
+#define RTX_OPT_DEBUG_TAPS 14 /* 0 (default); 1: prune_kernel keeps its view of every query of a sub-batch for rtx_debug_prune_detail (tests) */
+#define RTX_OPT_DEVICE_EXACT 15 /* 1 (default): a batch uploaded WITHOUT exact-match ids (exact_off == NULL) has them looked up on the device
+                                 * (a hash table of the distinct reference sequences, every candidate verified byte by byte; rtx_exact.hip)
+                                 * as part of rtx_batch_run -- Tree.sequences.get, raxtax.rs:42 -- when the handle was built from the
+                                 * sequences (rtx_index_create_from_tree / _from_sequences); rtx_batch_exact_matches returns the ids.
+                                 * 0: such a batch has no exact matches (the behaviour of ABI version 2) */
 #define RTX_OPT_CLUSTER 7 /* 1 (default): the queries of a batch are processed in an order that puts related
                              queries next to each other (min-hash sketches, rtx_cluster.hip) so that bitmap rows
                              are reused; 0: input order.  Results are identical and always in input order. */
@@ -214,6 +220,9 @@ int rtx_index_set_option(rtx_index *index, int option, uint64_t value);
  * 16 references are added from 32-byte slots through byte counters instead of 1-KiB row reads (rtx_segments.hip).
  * 0: every segment is read densely.  Results are identical for either value (A/B measurements). */
 #define RTX_DEFAULT_SEGMENT_CLASSES 1
+/* RTX_DEFAULT_EXACT_HASH_MASK (default: all ones; 0 restores it): the hash of the device exact-match table is ANDed with this mask.
+ * Tests pass a mask of a few bits so that most sequences collide in slot and tag and every probe ends in the byte compare. */
+#define RTX_DEFAULT_EXACT_HASH_MASK 2
 int rtx_set_default_option(int option, uint64_t value);
 
 /* ------------------------------------------------------------------------- */
@@ -246,6 +255,11 @@ typedef struct {
 int rtx_classify_batch(rtx_index *index, uint64_t n_queries, const uint8_t *bases,
                        const uint64_t *base_off, const uint32_t *exact_ids,
                        const uint64_t *exact_off, uint32_t flags, rtx_result_view *out);
+/* 1 if the handle can look exact matches up itself (built from the reference sequences, RTX_OPT_DEVICE_EXACT on) */
+int rtx_index_has_exact_lookup(const rtx_index *index);
+/* The exact matches of the last download as the device found them (the batch was uploaded with exact_off == NULL): CSR over the
+ * queries, ids ascending as Tree.sequences holds them (tree.rs:109-112).  Valid as long as the view of that download. */
+int rtx_batch_exact_matches(rtx_index *index, const uint64_t **exact_off /*n_queries + 1*/, const uint32_t **exact_ids);
 
 /* The same in stages, so that a caller (bench.py) can keep inputs resident in HBM and
  * time the device part alone, or overlap stages of different batches. */
@@ -294,7 +308,8 @@ int rtx_index_stream(rtx_index *index, void **hip_stream);
 #define RTX_STAGE_LINEAGE_WALK 4
 #define RTX_STAGE_TILE_BOUNDS 5 /* tile pruning (RTX_OPT_TILE_PRUNE): the queries counted against the union bitmap (the hit_count kernel again); 0 launches if the run did not prune */
 #define RTX_STAGE_TILE_PRUNE 6  /* ... prune_kernel (thresholds, live tiles) + the row lists of the live tiles */
-#define RTX_NUM_STAGES 7
+#define RTX_STAGE_EXACT_MATCH 7 /* Tree.sequences.get on the device (rtx_exact.hip; RTX_OPT_DEVICE_EXACT), once per run: reported with sub-batch 0 */
+#define RTX_NUM_STAGES 8
 int rtx_batch_stage_times(rtx_index *index, float ms[RTX_NUM_STAGES], uint32_t launches[RTX_NUM_STAGES]);
 /* Algorithmic work of the last rtx_batch_run: sum over queries of
  * H_q = sum_r count_q[r] (postings touched) and of L_q (query bytes), and the bitmap
@@ -325,6 +340,17 @@ int rtx_debug_prune_stats(rtx_index *index, uint64_t *out /*10*/);
 /* table / Z of a query of the last sub-batch as the PRUNED run computed it (0 for the counts up to the query's threshold), its Z and the
  * threshold; must be called before any other tap (those recount the sub-batch in full) */
 int rtx_debug_pruned_prob_table(rtx_index *index, uint64_t query, double *table_over_z /*t+1*/, double *z, uint32_t *threshold);
+/* The last sub-batch exactly as the run left it -- NO recount (the taps above prove the kernel that counts every tile; this one shows
+ * what the timed, pruned path computed); must be called before any recounting tap.  counts[n_refs]: what hit_count wrote (0xFFFF for the
+ * references of tiles it did not visit for the query's pair); tile_live[ntiles]: 1 if the tile was visited; hist[t + 1]: the histogram
+ * of prob.rs:13-19 as prune_kernel (bin 0 = the references never counted) and hit_count (every counted reference) left it; the query's
+ * threshold (0: none) and i* + 1 (rtx_prune.hip).  Any output pointer may be NULL. */
+int rtx_debug_run_counts(rtx_index *index, uint64_t query, uint16_t *counts /*n_refs*/, uint8_t *tile_live /*ntiles*/,
+                         uint32_t *hist /*t+1*/, uint32_t *threshold, uint32_t *i1);
+/* prune_kernel's view of a query of the last sub-batch (needs RTX_OPT_DEBUG_TAPS = 1 before the run): out[0] the block of 64 references
+ * with the largest bound, [1] M = the best exact count in it, [2] the threshold, [3] i* + 1, [4] the largest bound, [5] t, [8 .. 72) the exact
+ * counts of the block's references (0: behind the end of the database, or zeroed by RTX_SKIP_EXACT_MATCHES) */
+int rtx_debug_prune_detail(rtx_index *index, uint64_t query, uint32_t *out /*72*/);
 /* Lineage::new(label, tree, probs).evaluate() (src/lineage.rs:61-112) on a caller-supplied
  * probability vector: runs taxon_prefix + lineage_walk + the host finalisation for one
  * pseudo-query.  Lets the reference's lineage KATs pin the device walk.  Small trees only
@@ -365,6 +391,9 @@ typedef int (*rtx_sender_fn)(void *ctx, const char *label, const char *out_lines
 int rtx_raxtax(rtx_index *index, const rtx_tree *tree, uint64_t n_queries, const char *const *labels,
                const uint8_t *bases, const uint64_t *base_off, int skip_exact_matches, int raw_confidence,
                uint64_t chunk_size, rtx_sender_fn sender, void *sender_ctx, int tsv);
+
+/* A ready-made sender that discards the messages and only counts them: ctx = NULL or uint64_t[2] {messages, bytes of text} */
+int rtx_sender_discard(void *ctx, const char *label, const char *out_lines, const char *tsv_lines);
 
 #ifdef __cplusplus
 }

@@ -20,7 +20,7 @@ RTX_ERR_PARSE, RTX_ERR_DEPTH, RTX_ERR_STATE, RTX_ERR_TOO_LONG = -5, -6, -7, -8
 RTX_SKIP_EXACT_MATCHES = 1
 RTX_RAW_CONFIDENCE = 2
 RTX_Q_OK, RTX_Q_NO_KMERS = 0, 1
-STAGES = ("kmer_extract", "hit_count", "prob_table", "taxon_prefix", "lineage_walk", "tile_bounds", "tile_prune")
+STAGES = ("kmer_extract", "hit_count", "prob_table", "taxon_prefix", "lineage_walk", "tile_bounds", "tile_prune", "exact_match")
 
 u8p = C.POINTER(C.c_uint8)
 u16p = C.POINTER(C.c_uint16)
@@ -100,6 +100,8 @@ _SIGNATURES = {
     "rtx_index_set_option": (C.c_int, [C.c_void_p, C.c_int, C.c_uint64]),
     "rtx_classify_batch": (C.c_int, [C.c_void_p, C.c_uint64, u8p, u64p, u32p, u64p, C.c_uint32,
                                      C.POINTER(ResultView)]),
+    "rtx_index_has_exact_lookup": (C.c_int, [C.c_void_p]),
+    "rtx_batch_exact_matches": (C.c_int, [C.c_void_p, C.POINTER(u64p), C.POINTER(u32p)]),
     "rtx_batch_upload": (C.c_int, [C.c_void_p, C.c_uint64, u8p, u64p, u32p, u64p]),
     "rtx_batch_run": (C.c_int, [C.c_void_p, C.c_uint32]),
     "rtx_batch_sync": (C.c_int, [C.c_void_p]),
@@ -114,12 +116,15 @@ _SIGNATURES = {
     "rtx_debug_probs": (C.c_int, [C.c_void_p, C.c_uint64, f64p]),
     "rtx_debug_order": (C.c_int, [C.c_void_p, u32p]),
     "rtx_debug_prune_stats": (C.c_int, [C.c_void_p, u64p]),
+    "rtx_debug_run_counts": (C.c_int, [C.c_void_p, C.c_uint64, u16p, u8p, u32p, u32p, u32p]),
+    "rtx_debug_prune_detail": (C.c_int, [C.c_void_p, C.c_uint64, u32p]),
     "rtx_debug_evaluate": (C.c_int, [C.c_void_p, f64p, C.POINTER(ResultView)]),
     "rtx_result_pack": (C.c_int64, [C.POINTER(ResultView), u8p, C.c_uint64]),
     "rtx_format_query": (C.c_int64, [C.c_void_p, C.POINTER(ResultView), C.c_uint64, C.c_char_p, u8p, C.c_uint64,
                                      u32p, C.c_uint64, C.c_uint32, C.c_char_p, C.c_uint64, C.c_char_p, C.c_uint64,
                                      C.POINTER(C.c_int64)]),
     "rtx_raxtax": (C.c_int, None),  # argtypes set in api.py (callback type)
+    "rtx_sender_discard": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p, C.c_char_p]),
 }
 
 _lib = None

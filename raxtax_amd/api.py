@@ -218,7 +218,8 @@ class Index:
     def __init__(self, tree: Tree, device: int = 0, sub_batch: int = 0, prob_mode: int = 0,
                  stage_timing: bool = False, cluster: Optional[bool] = None, segment_classes=None,
                  packed_counts: Optional[bool] = None,
-                 tile_skip: Optional[bool] = None, hit_pair=None, locator: Optional[bool] = None, tile_prune: Optional[bool] = None):
+                 tile_skip: Optional[bool] = None, hit_pair=None, locator: Optional[bool] = None, tile_prune: Optional[bool] = None,
+                 debug_taps: bool = False, device_exact: Optional[bool] = None):
         self._lib = _lib.load()
         self.tree = tree
         if segment_classes is None:
@@ -246,6 +247,10 @@ class Index:
             check(self._lib.rtx_index_set_option(self._h, 12, int(locator)))
         if tile_prune is not None:
             check(self._lib.rtx_index_set_option(self._h, 13, int(tile_prune)))
+        if debug_taps:
+            check(self._lib.rtx_index_set_option(self._h, 14, 1))
+        if device_exact is not None:
+            check(self._lib.rtx_index_set_option(self._h, 15, int(device_exact)))
         self._view = ResultView()
         self._keep = None
 
@@ -306,11 +311,27 @@ class Index:
 
     # ---- one call -----------------------------------------------------------------------
     def exact_matches(self, bases: np.ndarray, base_off: np.ndarray):
-        """Tree.sequences.get() for every query (raxtax.rs:42) -> (ids, offsets)."""
+        """Tree.sequences.get() for every query (raxtax.rs:42) on the HOST -> (ids, offsets)."""
         return self.tree.exact_matches_batch(bases, base_off)
+
+    @property
+    def has_exact_lookup(self) -> bool:
+        """The handle looks exact matches up itself when a batch comes without ids (rtx_exact.hip)."""
+        return bool(self._lib.rtx_index_has_exact_lookup(self._h))
+
+    def device_exact_matches(self):
+        """Tree.sequences.get() for every query of the last download as the DEVICE found it -> (ids, offsets)."""
+        po, pi = u64p(), u32p()
+        check(self._lib.rtx_batch_exact_matches(self._h, C.byref(po), C.byref(pi)))
+        n = self._view.n_queries
+        off = np.ctypeslib.as_array(po, shape=(n + 1,)).copy()
+        tot = int(off[-1])
+        ids = np.ctypeslib.as_array(pi, shape=(tot,)).copy() if tot else np.zeros(0, np.uint32)
+        return ids, off
 
     def classify(self, bases: np.ndarray, base_off: np.ndarray, exact_ids=None, exact_off=None,
                  skip_exact_matches: bool = False) -> Result:
+        """exact_off = None: the exact matches are looked up on the device (has_exact_lookup), else the batch has none."""
         self.upload(bases, base_off, exact_ids, exact_off)
         self.run(RTX_SKIP_EXACT_MATCHES if skip_exact_matches else 0)
         return self.download()
@@ -340,6 +361,23 @@ class Index:
         thr = C.c_uint32()
         check(self._lib.rtx_debug_pruned_prob_table(self._h, q, ptr(out, f64p), C.byref(z), C.byref(thr)))
         return out, z.value, int(thr.value)
+
+    def debug_run_counts(self, q: int, t: int) -> dict:
+        """Query q of the last sub-batch exactly as the (pruned) run left it -- no recount; before any other tap.  counts (0xFFFF in
+        tiles hit_count did not visit), tile_live, hist (bin 0 = never-counted references + counted ones without a hit), threshold, i1."""
+        counts = np.zeros(self.n_refs, dtype=np.uint16)
+        live = np.zeros((self.n_refs + 8191) // 8192, dtype=np.uint8)
+        hist = np.zeros(t + 1, dtype=np.uint32)
+        thr, i1 = C.c_uint32(), C.c_uint32()
+        check(self._lib.rtx_debug_run_counts(self._h, q, ptr(counts, u16p), ptr(live, u8p), ptr(hist, u32p), C.byref(thr), C.byref(i1)))
+        return dict(counts=counts, tile_live=live.astype(bool), hist=hist, threshold=int(thr.value), i1=int(i1.value))
+
+    def debug_prune_detail(self, q: int) -> dict:
+        """prune_kernel's view of query q (Index(debug_taps=True)): best block, its exact counts, M, threshold, i* + 1."""
+        out = np.zeros(72, dtype=np.uint32)
+        check(self._lib.rtx_debug_prune_detail(self._h, q, ptr(out, u32p)))
+        return dict(block=int(out[0]), M=int(out[1]), threshold=int(out[2]), i1=int(out[3]), largest_bound=int(out[4]), t=int(out[5]),
+                    block_counts=out[8:72].copy())
 
     def debug_probs(self, q: int) -> np.ndarray:
         out = np.zeros(self.n_refs, dtype=np.float64)

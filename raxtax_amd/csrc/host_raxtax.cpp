@@ -35,9 +35,11 @@ struct Chunk {
 };
 
 // raxtax() (src/raxtax.rs:14-97) as a three-stage pipeline over chunks of `chunk_size` queries:
-//   lookup thread : exact-match ids of chunk c+1            (host hash map, raxtax.rs:42-53)
-//   calling thread: device classification of chunk c        (rtx_classify_batch, raxtax.rs:55-71)
-//   format thread : override + formatting + sender, chunk c-1 (raxtax.rs:73-87), messages in input order
+//   lookup thread : exact-match ids of chunk c+1            (host hash map, raxtax.rs:42) -- only for a handle without the
+//                   device lookup (rtx_index_has_exact_lookup): otherwise the ids come back with the results of the device stage
+//   calling thread: device classification of chunk c        (rtx_classify_batch, raxtax.rs:42,55-71)
+//   format thread : lineage check of the exact matches (raxtax.rs:43-53), override + formatting + sender, chunk c-1
+//                   (raxtax.rs:73-87), messages in input order
 // The library keeps two result sets, so the view of chunk c stays valid until chunk c+2 is classified.
 int run(rtx_index *index, const rtx_tree *tree, uint64_t n_queries, const char *const *labels, const uint8_t *bases,
         const uint64_t *base_off, bool skip_exact_matches, bool raw_confidence, uint64_t chunk_size,
@@ -48,7 +50,8 @@ int run(rtx_index *index, const rtx_tree *tree, uint64_t n_queries, const char *
     const uint32_t flags = (skip_exact_matches ? RTX_SKIP_EXACT_MATCHES : 0u) | (raw_confidence ? RTX_RAW_CONFIDENCE : 0u);
     const uint64_t n_chunks = (n_queries + chunk_size - 1) / chunk_size;
     const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-    const unsigned nt_lookup = std::min(4u, hw), nt_format = std::min(8u, hw);
+    const unsigned nt_lookup = std::min(4u, hw), nt_format = std::min(16u, hw);
+    const bool dev_lookup = rtx_index_has_exact_lookup(index) != 0;
 
     std::vector<Chunk> chunks(n_chunks);
     // busy seconds of the three stages (RTX_PIPELINE_TIMING=1 prints them: which stage bounds an end-to-end run)
@@ -84,37 +87,21 @@ int run(rtx_index *index, const rtx_tree *tree, uint64_t n_queries, const char *
             const double t_l0 = now();
             ch.q0 = c * chunk_size;
             ch.nq = std::min<uint64_t>(chunk_size, n_queries - ch.q0);
+            if (dev_lookup) { set_stage(c, 1); continue; }  // Tree.sequences.get runs on the device, inside rtx_classify_batch
             std::vector<const uint32_t *> ptr(ch.nq);
             std::vector<uint32_t> cnt(ch.nq);
-            ch.differ.assign(ch.nq, 0);
             parallel_ranges(ch.nq, nt_lookup, [&](uint64_t a, uint64_t b) {
                 for (uint64_t i = a; i < b; i++) {
                     const uint64_t q = ch.q0 + i;
                     const uint32_t *ids = nullptr;
-                    const uint64_t ne = rtx_tree_exact_matches(tree, bases + base_off[q], base_off[q + 1] - base_off[q], &ids);
+                    cnt[i] = (uint32_t)rtx_tree_exact_matches(tree, bases + base_off[q], base_off[q + 1] - base_off[q], &ids);
                     ptr[i] = ids;
-                    cnt[i] = (uint32_t)ne;
-                    if (!skip_exact_matches && ne > 1) {  // raxtax.rs:43-53 (the info! lines go to the log in the CLI)
-                        auto parent = [&](uint32_t id) {
-                            const std::string &l = tree->lineages[id];
-                            const size_t k = l.rfind(',');
-                            return k == std::string::npos ? std::string_view() : std::string_view(l).substr(0, k);
-                        };
-                        for (uint64_t j = 1; j < ne; j++)
-                            if (parent(ids[j]) != parent(ids[0])) { ch.differ[i] = 1; break; }
-                    }
                 }
             });
             ch.exact_off.assign(ch.nq + 1, 0);
             for (uint64_t i = 0; i < ch.nq; i++) ch.exact_off[i + 1] = ch.exact_off[i] + cnt[i];
             ch.exact_ids.resize(ch.exact_off[ch.nq]);
-            for (uint64_t i = 0; i < ch.nq; i++) {
-                std::copy(ptr[i], ptr[i] + cnt[i], ch.exact_ids.begin() + ch.exact_off[i]);
-                if (ch.differ[i]) {
-                    fprintf(stderr, "[WARN ] Exact matches for %s differ above the leafs of the lineage tree!\n", labels[ch.q0 + i]);
-                    warnings = true;
-                }
-            }
+            for (uint64_t i = 0; i < ch.nq; i++) std::copy(ptr[i], ptr[i] + cnt[i], ch.exact_ids.begin() + ch.exact_off[i]);
             busy_lookup += now() - t_l0;
             set_stage(c, 1);
         }
@@ -128,11 +115,23 @@ int run(rtx_index *index, const rtx_tree *tree, uint64_t n_queries, const char *
             const double t_f0 = now();
             out_msg.assign(ch.nq, std::string());
             if (tsv) tsv_msg.assign(ch.nq, std::string());
+            ch.differ.assign(ch.nq, 0);
             std::atomic<int> rc_fmt{0};
             parallel_ranges(ch.nq, nt_format, [&](uint64_t a, uint64_t b) {
                 std::vector<char> out_buf(1 << 16), tsv_buf(1 << 16);
                 for (uint64_t i = a; i < b; i++) {
                     const uint64_t q = ch.q0 + i;
+                    const uint64_t ne = ch.exact_off[i + 1] - ch.exact_off[i];
+                    if (!skip_exact_matches && ne > 1) {  // raxtax.rs:43-53 (the info! lines go to the log in the CLI)
+                        const uint32_t *ids = ch.exact_ids.data() + ch.exact_off[i];
+                        auto parent = [&](uint32_t id) {
+                            const std::string &l = tree->lineages[id];
+                            const size_t k = l.rfind(',');
+                            return k == std::string::npos ? std::string_view() : std::string_view(l).substr(0, k);
+                        };
+                        for (uint64_t j = 1; j < ne; j++)
+                            if (parent(ids[j]) != parent(ids[0])) { ch.differ[i] = 1; break; }
+                    }
                     if (ch.res.status[i] != RTX_Q_OK) continue;
                     const uint64_t len = base_off[q + 1] - base_off[q];
                     const uint64_t rows = ch.res.row_count[i];
@@ -154,6 +153,10 @@ int run(rtx_index *index, const rtx_tree *tree, uint64_t n_queries, const char *
             busy_format += t_s0 - t_f0;
             for (uint64_t i = 0; i < ch.nq; i++) {
                 const uint64_t q = ch.q0 + i;
+                if (ch.differ[i]) {
+                    fprintf(stderr, "[WARN ] Exact matches for %s differ above the leafs of the lineage tree!\n", labels[q]);
+                    warnings = true;
+                }
                 if (ch.res.status[i] != RTX_Q_OK) {
                     // the reference aborts here (prob.rs:21/162); report and skip the query instead
                     fprintf(stderr, "[ERROR] query %s has too few valid 8-mers (%u) to be classified\n", labels[q], ch.res.t[i]);
@@ -179,8 +182,20 @@ int run(rtx_index *index, const rtx_tree *tree, uint64_t n_queries, const char *
         if (c >= 2 && !wait_stage(c - 2, 3)) break;  // the result set of chunk c-2 is reused now
         Chunk &ch = chunks[c];
         const double t_d0 = now();
-        const int rc = rtx_classify_batch(index, ch.nq, bases, base_off + ch.q0, ch.exact_ids.empty() ? nullptr : ch.exact_ids.data(),
-                                          ch.exact_off.data(), flags, &ch.res);
+        int rc;
+        if (dev_lookup) {
+            rc = rtx_classify_batch(index, ch.nq, bases, base_off + ch.q0, nullptr, nullptr, flags, &ch.res);
+            const uint64_t *xo = nullptr;
+            const uint32_t *xi = nullptr;
+            if (!rc) rc = rtx_batch_exact_matches(index, &xo, &xi);
+            if (!rc) {  // copied: the format thread reads them while the next chunk is classified
+                ch.exact_off.assign(xo, xo + ch.nq + 1);
+                ch.exact_ids.assign(xi, xi + xo[ch.nq]);
+            }
+        } else {
+            rc = rtx_classify_batch(index, ch.nq, bases, base_off + ch.q0, ch.exact_ids.empty() ? nullptr : ch.exact_ids.data(),
+                                    ch.exact_off.data(), flags, &ch.res);
+        }
         if (rc) { fail(rc, rtx_last_error()); break; }
         busy_device += now() - t_d0;
         set_stage(c, 2);
@@ -226,4 +241,16 @@ extern "C" int rtx_raxtax(rtx_index *index, const rtx_tree *tree, uint64_t n_que
     };
     return run(index, tree, n_queries, labels, bases, base_off, skip_exact_matches != 0, raw_confidence != 0, chunk_size, s,
                tsv != 0);
+}
+
+// A sender that keeps nothing: counts the messages and their bytes into ctx (uint64_t[2]) if given.  For callers that time the
+// path through rtx_raxtax without a disk behind it (bench.py: value_end_to_end).
+extern "C" int rtx_sender_discard(void *ctx, const char *label, const char *out_lines, const char *tsv_lines) {
+    (void)label;
+    if (ctx) {
+        uint64_t *c = static_cast<uint64_t *>(ctx);
+        c[0] += 1;
+        c[1] += (out_lines ? strlen(out_lines) : 0) + (tsv_lines ? strlen(tsv_lines) : 0);
+    }
+    return 0;
 }

@@ -13,6 +13,7 @@
 
 #include "rtx_internal.hpp"
 #include "rtx_kernels.hpp"
+#include "rtx_math.hpp"
 
 using namespace rtx;
 
@@ -151,6 +152,23 @@ struct rtx_index {
     DevBuf<uint4> d_noderec;  // {blo, bhi, first_child, n_children | type << 30} per node (lineage_walk)
     DevBuf<uint32_t> d_bnd_rank;
     DevBuf<uint8_t> d_bnd_bits;
+    // ---- exact-match lookup on the device (rtx_exact.hip): the distinct reference sequences ("groups") in a hash table
+    uint32_t dev_exact_opt = 1;       // RTX_OPT_DEVICE_EXACT
+    uint32_t em_groups = 0, em_bits = 0;
+    uint64_t em_hash_mask = ~0ull;    // RTX_DEFAULT_EXACT_HASH_MASK at creation (tests: a weak hash, so that probes collide)
+    DevBuf<uint2> d_em_table;         // [2^em_bits] {tag, group + 1}
+    DevBuf<uint64_t> d_em_rep_off;    // [groups + 1]
+    DevBuf<uint8_t> d_em_rep_bytes;   // the distinct sequences
+    DevBuf<uint32_t> d_em_goff, d_em_gids;   // ids of group g: gids[goff[g] .. goff[g + 1]), ascending (tree.rs:109-112)
+    std::vector<uint32_t> h_em_goff, h_em_gids;  // host copies: the ids behind the groups the device reports
+    DevBuf<uint32_t> d_exact_grp;     // [n_q] group of every query of the batch (0xFFFFFFFF: none)
+    bool dev_exact_used = false;      // the uploaded batch came without ids: the device looks them up (every rtx_batch_run)
+    struct HostExact {                // per host result set: the groups of a download and, on demand, the CSR of their ids
+        std::vector<uint32_t> grp;
+        std::vector<uint64_t> off;
+        std::vector<uint32_t> ids;
+        bool csr_valid = false, valid = false;
+    } host_exact[2];
     // ---- batch inputs
     uint64_t n_q = 0;
     bool uploaded = false, ran = false, synced = false;
@@ -168,6 +186,8 @@ struct rtx_index {
     uint32_t u_stride_bytes = 0, u_ntiles = 0;
     uint64_t u_nblocks = 0;
     DevBuf<unsigned long long> d_prune_stats;
+    uint32_t debug_taps = 0;     // RTX_OPT_DEBUG_TAPS: prune_kernel leaves its view of every query (rtx_debug_prune_detail)
+    DevBuf<uint32_t> d_prune_detail;  // [sub_batch][kPruneDetailWords]
     uint32_t locator_opt = 1; // RTX_OPT_LOCATOR: the sort key of the processing order is led by the query's position in the database
     DevBuf<uint32_t> d_loc_table;  // 12-mer -> lowest reference position (rtx_cluster.hip); only when built from sequences
     bool pair_used = false;   // the last run went through hit_count_pair_kernel
@@ -380,8 +400,7 @@ int enqueue_hit(rtx_index *ix, const SubBatch &b, uint32_t flags, hipStream_t s)
     hp.flags = flags;
     hp.q0 = b.q0;
     hp.perm = ix->d_perm.p;
-    hp.exact_ids = ix->d_exact_ids.p;
-    hp.exact_off = ix->d_exact_off.p;
+    hp.exact = ExactRef{ix->d_exact_ids.p, ix->d_exact_off.p, ix->dev_exact_used ? ix->d_exact_grp.p : nullptr, ix->d_em_goff.p, ix->d_em_gids.p};
     hp.nq = b.nq;
     hp.group_rows = ix->pair_used ? ix->d_group_rows.p : nullptr;
     hp.group_base = b.sb * ix->groups_per_sub;
@@ -435,8 +454,7 @@ int enqueue_hit(rtx_index *ix, const SubBatch &b, uint32_t flags, hipStream_t s)
         pr.flags = flags;
         pr.q0 = b.q0;
         pr.perm = ix->d_perm.p;
-        pr.exact_ids = ix->d_exact_ids.p;
-        pr.exact_off = ix->d_exact_off.p;
+        pr.exact = hp.exact;
         pr.lnfact = ix->d_lnfact.p;
         pr.hist = sc.d_hist.p;
         pr.hstride = ix->hstride;
@@ -447,6 +465,7 @@ int enqueue_hit(rtx_index *ix, const SubBatch &b, uint32_t flags, hipStream_t s)
         pr.stats = ix->d_prune_stats.p;
         pr.ubitmap = ix->d_ubitmap.p;
         pr.ustride_bytes = ix->u_stride_bytes;
+        pr.detail = ix->debug_taps && ix->d_prune_detail.n >= (size_t)b.nq * kPruneDetailWords ? ix->d_prune_detail.p : nullptr;
         ProbTables tb{ix->d_tab_cmf.p, ix->d_tab_ratio.p, ix->d_tab_off.p, ix->d_tab_moff.p, ix->d_tab_ilo.p, ix->d_tab_sat.p, ix->tab_tmax};
         launch_prune(s, pr, tb, b.nq);
         // (3) tiles that are not counted keep a largest count of 0: taxon_prefix leaves them out
@@ -616,6 +635,7 @@ int begin_run(rtx_index *ix, uint32_t *n_sub_out, bool *timed_out, bool cluster)
     ix->dbg_full = false;
     if (ix->prune_used) {
         int rc_s = ix->d_prune_stats.alloc(kPruneStatCopies * 16);
+        if (!rc_s && ix->debug_taps) rc_s = ix->d_prune_detail.alloc((size_t)ix->sub_batch * kPruneDetailWords);
         if (rc_s) return rc_s;
         RTX_HIP(hipMemsetAsync(ix->d_prune_stats.p, 0, kPruneStatCopies * 128, ix->stream));
     }
@@ -631,6 +651,14 @@ int begin_run(rtx_index *ix, uint32_t *n_sub_out, bool *timed_out, bool cluster)
         if (rc) return rc;
     }
     ix->n_sub_last = timed ? n_sub : 0;
+    if (ix->dev_exact_used) {  // Tree.sequences.get for every query of the batch (raxtax.rs:42), part of the run
+        ExactParams xp{ix->d_bases.p, ix->d_base_off.p, (uint32_t)ix->n_q, ix->d_em_table.p, ix->em_bits, ix->d_em_rep_off.p,
+                       ix->d_em_rep_bytes.p, ix->d_exact_grp.p, ix->em_hash_mask};
+        const bool ev = timed && ix->stage_timing;
+        if (ev) RTX_HIP(hipEventRecord(ix->events[(size_t)RTX_STAGE_EXACT_MATCH * 2], ix->stream));  // sub-batch 0
+        launch_exact_match(ix->stream, xp);
+        if (ev) RTX_HIP(hipEventRecord(ix->events[(size_t)RTX_STAGE_EXACT_MATCH * 2 + 1], ix->stream));
+    }
     *n_sub_out = n_sub;
     *timed_out = timed;
     return RTX_OK;
@@ -1023,6 +1051,92 @@ static int create_common(int device, uint64_t n_total, uint64_t ref_lo, uint64_t
 
 static bool prepare_union_bitmap(rtx_index *ix);
 
+// Hash table of the distinct reference sequences for the device exact-match lookup (rtx_exact.hip).  `groups`: per distinct
+// sequence the ids of the references that have it, ascending (Tree.sequences, tree.rs:109-112); group order = order of the first
+// id, so that the table is the same however the caller's map iterates.  An aid like the locator: if it cannot be built (memory) the
+// handle works without it and callers pass the ids of Tree.sequences.get themselves.
+static uint64_t g_em_hash_mask = ~0ull;  // RTX_DEFAULT_EXACT_HASH_MASK (rtx_set_default_option)
+static uint64_t em_hash_bytes(const uint8_t *s, uint64_t len) {
+    uint64_t sum = 0;
+    for (uint64_t j = 0; j * 8 < len; j++) {
+        uint64_t w = 0;
+        std::memcpy(&w, s + 8 * j, (size_t)std::min<uint64_t>(8, len - 8 * j));
+        sum += em_mix_word(w, j);
+    }
+    return em_finish(sum, len);
+}
+static void build_exact_table(rtx_index *ix, const uint8_t *seq_bytes, const uint64_t *seq_off,
+                              std::vector<const std::vector<uint32_t> *> &groups) {
+    if (ix->n_refs != ix->n_total || groups.empty()) return;
+    std::sort(groups.begin(), groups.end(), [](const std::vector<uint32_t> *a, const std::vector<uint32_t> *b) { return (*a)[0] < (*b)[0]; });
+    const uint32_t G = (uint32_t)groups.size();
+    uint32_t bits = 4;
+    while ((1ull << bits) < 2ull * G) bits++;
+    std::vector<uint64_t> rep_off(G + 1, 0);
+    std::vector<uint32_t> goff(G + 1, 0), gids;
+    gids.reserve(ix->n_total);
+    for (uint32_t g = 0; g < G; g++) {
+        const uint32_t rep = (*groups[g])[0];
+        rep_off[g + 1] = rep_off[g] + (seq_off[rep + 1] - seq_off[rep]);
+        gids.insert(gids.end(), groups[g]->begin(), groups[g]->end());
+        goff[g + 1] = (uint32_t)gids.size();
+    }
+    std::vector<uint8_t> rep_bytes(rep_off[G] + 16, 0);
+    std::vector<uint64_t> hashes(G);
+    {
+        const unsigned nt = std::max(1u, std::min(8u, std::thread::hardware_concurrency()));
+        std::vector<std::thread> th;
+        for (unsigned k = 0; k < nt; k++)
+            th.emplace_back([&, k] {
+                for (uint32_t g = (uint32_t)((uint64_t)G * k / nt); g < (uint32_t)((uint64_t)G * (k + 1) / nt); g++) {
+                    const uint32_t rep = (*groups[g])[0];
+                    const uint64_t len = seq_off[rep + 1] - seq_off[rep];
+                    std::memcpy(rep_bytes.data() + rep_off[g], seq_bytes + seq_off[rep], (size_t)len);
+                    hashes[g] = em_hash_bytes(seq_bytes + seq_off[rep], len) & g_em_hash_mask;
+                }
+            });
+        for (auto &t : th) t.join();
+    }
+    std::vector<uint2> table((size_t)1 << bits, make_uint2(0u, 0u));
+    const uint32_t mask = (1u << bits) - 1u;
+    for (uint32_t g = 0; g < G; g++) {
+        uint32_t slot = em_slot(hashes[g], bits);
+        while (table[slot].y) slot = (slot + 1u) & mask;
+        table[slot] = make_uint2(em_tag(hashes[g]), g + 1u);
+    }
+    hipError_t e = hipSuccess;
+    if (ix->d_em_table.alloc(table.size()) || ix->d_em_rep_off.alloc(G + 1) || ix->d_em_rep_bytes.alloc(rep_bytes.size()) ||
+        ix->d_em_goff.alloc(G + 1) || ix->d_em_gids.alloc(gids.size() + 1))
+        e = hipErrorOutOfMemory;
+    auto up = [&](void *d, const void *h, size_t bytes) { if (e == hipSuccess && bytes) e = hipMemcpy(d, h, bytes, hipMemcpyHostToDevice); };
+    up(ix->d_em_table.p, table.data(), table.size() * sizeof(uint2));
+    up(ix->d_em_rep_off.p, rep_off.data(), (G + 1) * 8);
+    up(ix->d_em_rep_bytes.p, rep_bytes.data(), rep_bytes.size());
+    up(ix->d_em_goff.p, goff.data(), (G + 1) * 4);
+    up(ix->d_em_gids.p, gids.data(), gids.size() * 4);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        ix->d_em_table.release(); ix->d_em_rep_off.release(); ix->d_em_rep_bytes.release(); ix->d_em_goff.release(); ix->d_em_gids.release();
+        return;
+    }
+    ix->em_groups = G;
+    ix->em_bits = bits;
+    ix->em_hash_mask = g_em_hash_mask;
+    ix->h_em_goff = std::move(goff);
+    ix->h_em_gids = std::move(gids);
+}
+// ... from the sequences alone (rtx_index_create_from_sequences): what Tree::new's map would hold
+static void build_exact_table_from_sequences(rtx_index *ix, uint64_t n_refs, const uint8_t *seq_bytes, const uint64_t *seq_off) {
+    std::unordered_map<std::string_view, std::vector<uint32_t>, BytesHash> map;
+    map.reserve(n_refs * 2);
+    for (uint64_t i = 0; i < n_refs; i++)
+        map[std::string_view((const char *)seq_bytes + seq_off[i], (size_t)(seq_off[i + 1] - seq_off[i]))].push_back((uint32_t)i);
+    std::vector<const std::vector<uint32_t> *> groups;
+    groups.reserve(map.size());
+    for (const auto &kv : map) groups.push_back(&kv.second);
+    build_exact_table(ix, seq_bytes, seq_off, groups);
+}
+
 static int create_from_csr(int device, uint64_t n_total, uint64_t ref_lo, uint64_t ref_hi, const uint64_t *cuts,
                            uint32_t n_cuts, const uint64_t *offsets, const uint32_t *postings, uint32_t n_nodes,
                            const uint32_t *node_begin, const uint32_t *node_end, const uint32_t *node_first_child,
@@ -1202,6 +1316,8 @@ static void build_locator(rtx_index *ix, const uint8_t *d_seq, const uint64_t *d
     if (e != hipSuccess) { (void)hipGetLastError(); ix->d_loc_table.release(); }
 }
 
+static thread_local bool g_from_tree = false;  // rtx_index_create_from_tree -> _from_sequences on the same thread
+
 // Index build on the GPU from the encoded reference sequences in lineage-sorted order
 // (the k-mer map of Tree::new, tree.rs:114-123,134-137, without ever materialising posting lists).
 int rtx_index_create_from_sequences(int device, uint64_t n_refs, const uint8_t *seq_bytes, const uint64_t *seq_off,
@@ -1249,6 +1365,7 @@ int rtx_index_create_from_sequences(int device, uint64_t n_refs, const uint8_t *
     if (e != hipSuccess) { set_error("bitmap build from sequences failed: %s", hipGetErrorString(e)); return fail(RTX_ERR_HIP); }
     if ((rc = build_segments(ix))) return fail(rc);
     build_locator(ix, d_seq.p, d_off.p, n_refs);
+    if (!g_from_tree) build_exact_table_from_sequences(ix, n_refs, seq_bytes, seq_off);  // (from a tree: its map is reused, below)
     if (prepare_union_bitmap(ix)) {
         launch_ref_bitmap_set(ix->stream, d_seq.p, d_off.p, n_refs, ix->d_row_of.p, ix->d_ubitmap.p, ix->u_stride_bytes / 4, nr + 1, kPruneShift);
         if (hipStreamSynchronize(ix->stream) != hipSuccess) { (void)hipGetLastError(); ix->d_ubitmap.release(); }
@@ -1257,16 +1374,31 @@ int rtx_index_create_from_sequences(int device, uint64_t n_refs, const uint8_t *
     return RTX_OK;
 }
 
+static void exact_table_from_tree(rtx_index *ix, const rtx_tree *tree) {
+    if (tree->seq_off.size() != tree->num_tips + 1) return;
+    std::vector<const std::vector<uint32_t> *> groups;
+    groups.reserve(tree->sequences.size());
+    for (const auto &kv : tree->sequences)
+        if (!kv.second.empty()) groups.push_back(&kv.second);
+    build_exact_table(ix, tree->seq_bytes.data(), tree->seq_off.data(), groups);
+}
+
 int rtx_index_create_from_tree(int device, const rtx_tree *tree, rtx_index **out) {
     if (!tree || !out) { set_error("null argument"); return RTX_ERR_INVALID; }
     const FlatNodes &f = tree->flat;
-    if (tree->csr_off.empty())  // tree built without the host k-mer map: build the bitmaps on the GPU
-        return rtx_index_create_from_sequences(device, tree->num_tips, tree->seq_bytes.data(), tree->seq_off.data(), f.size(),
-                                               f.begin.data(), f.end.data(), f.first_child.data(), f.n_children.data(),
-                                               f.type.data(), out);
+    if (tree->csr_off.empty()) {  // tree built without the host k-mer map: build the bitmaps on the GPU
+        g_from_tree = true;   // (this thread's call below: the exact-match table comes from the tree's map, not from a second pass over the sequences)
+        const int rc = rtx_index_create_from_sequences(device, tree->num_tips, tree->seq_bytes.data(), tree->seq_off.data(), f.size(),
+                                                       f.begin.data(), f.end.data(), f.first_child.data(), f.n_children.data(),
+                                                       f.type.data(), out);
+        g_from_tree = false;
+        if (rc == RTX_OK) exact_table_from_tree(*out, tree);
+        return rc;
+    }
     int rc = rtx_index_create(device, tree->num_tips, tree->csr_off.data(), tree->postings.data(), f.size(), f.begin.data(),
                               f.end.data(), f.first_child.data(), f.n_children.data(), f.type.data(), out);
     if (rc != RTX_OK) return rc;
+    exact_table_from_tree(*out, tree);
     // the tree holds the sequences (Tree.sequences, for the exact-match lookup): the locator table of the processing order
     const uint64_t n = tree->num_tips;
     if (n >= 256 && tree->seq_off.size() == n + 1) {
@@ -1295,7 +1427,7 @@ void rtx_index_destroy(rtx_index *index) {
 uint64_t rtx_index_num_refs(const rtx_index *index) { return index ? index->n_total : 0; }
 uint64_t rtx_index_device_bytes(const rtx_index *index) {
     if (!index) return 0;
-    return index->d_seg_dbits.n * 8 + index->d_seg_sbits.n * 8 + index->d_seg_sbase.n * 4 + index->d_seginfo.n * 4 + index->d_segslots.n * 2 + index->d_bitmap.n * 4 + index->d_row_of.n * 4 + index->d_list_len.n * 4 + index->d_loc_table.n * 4 + index->d_ubitmap.n * 4 + index->d_lnfact.n * 8 +
+    return index->d_seg_dbits.n * 8 + index->d_seg_sbits.n * 8 + index->d_seg_sbase.n * 4 + index->d_seginfo.n * 4 + index->d_segslots.n * 2 + index->d_bitmap.n * 4 + index->d_row_of.n * 4 + index->d_list_len.n * 4 + index->d_loc_table.n * 4 + index->d_ubitmap.n * 4 + index->d_em_table.n * 8 + index->d_em_rep_off.n * 8 + index->d_em_rep_bytes.n + index->d_em_goff.n * 4 + index->d_em_gids.n * 4 + index->d_lnfact.n * 8 +
            index->d_noderec.n * 16 + index->d_bnd_bits.n + index->d_bnd_rank.n * 4;
 }
 int rtx_index_set_batch(rtx_index *index, uint32_t sub_batch) {
@@ -1307,6 +1439,7 @@ int rtx_index_set_batch(rtx_index *index, uint32_t sub_batch) {
 
 int rtx_set_default_option(int option, uint64_t value) {
     if (option == RTX_DEFAULT_SEGMENT_CLASSES) { g_seg_classes = value ? 1 : 0; return RTX_OK; }
+    if (option == RTX_DEFAULT_EXACT_HASH_MASK) { g_em_hash_mask = value ? value : ~0ull; return RTX_OK; }
     set_error("rtx_set_default_option: unknown option %d", option);
     return RTX_ERR_INVALID;
 }
@@ -1326,6 +1459,13 @@ int rtx_index_set_option(rtx_index *index, int option, uint64_t value) {
         case RTX_OPT_SUB_BATCH: index->sub_batch_req = (uint32_t)value; return RTX_OK;
         case RTX_OPT_STAGE_TIMING:
             index->stage_timing = value ? 1u : 0u;
+            return RTX_OK;
+        case RTX_OPT_DEBUG_TAPS:
+            index->debug_taps = value ? 1u : 0u;
+            return RTX_OK;
+        case RTX_OPT_DEVICE_EXACT:
+            index->uploaded = index->ran = index->synced = false;  // decided at the upload
+            index->dev_exact_opt = value ? 1u : 0u;
             return RTX_OK;
         case RTX_OPT_CLUSTER:
             index->cluster = value ? 1u : 0u;
@@ -1383,6 +1523,8 @@ int rtx_batch_upload(rtx_index *ix, uint64_t n_queries, const uint8_t *bases, co
     RTX_HIP(hipMemcpy(ix->d_bases.p, bases + base_off[0], total, hipMemcpyHostToDevice));
     RTX_HIP(hipMemcpy(ix->d_base_off.p, off0.data(), (n_queries + 1) * 8, hipMemcpyHostToDevice));
     uint64_t n_exact = 0;
+    ix->dev_exact_used = !exact_off && ix->dev_exact_opt && ix->d_em_table.p && ix->n_refs == ix->n_total;
+    if (ix->dev_exact_used && (rc = ix->d_exact_grp.alloc(n_queries))) return rc;
     if (exact_off) {
         if (exact_off[0] != 0) { set_error("exact_off[0] must be 0"); return RTX_ERR_INVALID; }
         n_exact = exact_off[n_queries];
@@ -1565,6 +1707,15 @@ int rtx_batch_download(rtx_index *ix, rtx_result_view *out) {
             other.v_row_local.resize(hr.v_row_local.size());
         }
     }
+    {   // the exact matches the device found belong to this download (same alternation as the result sets)
+        rtx_index::HostExact &hx = ix->host_exact[ix->res_set];
+        hx.valid = hx.csr_valid = false;
+        if (ix->dev_exact_used) {
+            hx.grp.resize(nq);
+            RTX_HIP(hipMemcpy(hx.grp.data(), ix->d_exact_grp.p, nq * 4, hipMemcpyDeviceToHost));
+            hx.valid = true;
+        }
+    }
     out->n_queries = (uint32_t)nq;
     out->n_rows = nrows;
     out->t = hr.h_t.data();
@@ -1577,6 +1728,32 @@ int rtx_batch_download(rtx_index *ix, rtx_result_view *out) {
     out->row_depth = hr.v_row_depth.data();
     out->row_conf = hr.v_row_conf.data();
     out->row_local_signal = hr.v_row_local.data();
+    return RTX_OK;
+}
+
+int rtx_index_has_exact_lookup(const rtx_index *index) { return index && index->d_em_table.p && index->dev_exact_opt ? 1 : 0; }
+
+// Tree.sequences.get(query) for every query of the last download, as the device found it: CSR over the queries
+int rtx_batch_exact_matches(rtx_index *ix, const uint64_t **exact_off, const uint32_t **exact_ids) {
+    if (!ix || !exact_off || !exact_ids) { set_error("null argument"); return RTX_ERR_INVALID; }
+    rtx_index::HostExact &hx = ix->host_exact[ix->res_set];
+    if (!hx.valid) { set_error("rtx_batch_exact_matches: the last download has no device lookup (ids were passed in, or no table)"); return RTX_ERR_STATE; }
+    if (!hx.csr_valid) {
+        const size_t nq = hx.grp.size();
+        hx.off.assign(nq + 1, 0);
+        for (size_t q = 0; q < nq; q++) {
+            const uint32_t g = hx.grp[q];
+            hx.off[q + 1] = hx.off[q] + (g == 0xFFFFFFFFu ? 0u : ix->h_em_goff[g + 1] - ix->h_em_goff[g]);
+        }
+        hx.ids.resize(hx.off[nq] + 1);
+        for (size_t q = 0; q < nq; q++) {
+            const uint32_t g = hx.grp[q];
+            if (g != 0xFFFFFFFFu) std::copy(ix->h_em_gids.begin() + ix->h_em_goff[g], ix->h_em_gids.begin() + ix->h_em_goff[g + 1], hx.ids.begin() + hx.off[q]);
+        }
+        hx.csr_valid = true;
+    }
+    *exact_off = hx.off.data();
+    *exact_ids = hx.ids.data();
     return RTX_OK;
 }
 
@@ -1717,7 +1894,9 @@ int rtx_batch_stage_times(rtx_index *ix, float ms[RTX_NUM_STAGES], uint32_t laun
     for (int s = 0; s < RTX_NUM_STAGES; s++) { ms[s] = 0.f; launches[s] = 0; }
     for (uint32_t sb = 0; sb < ix->n_sub_last; sb++)
         for (int s = 0; s < RTX_NUM_STAGES; s++) {
-            if (s == RTX_STAGE_TILE_BOUNDS || s == RTX_STAGE_TILE_PRUNE ? !ix->prune_used : (s != RTX_STAGE_HIT_COUNT && !ix->stage_timing)) continue;  // events were not recorded
+            if (s == RTX_STAGE_EXACT_MATCH) {
+                if (sb != 0 || !ix->dev_exact_used || !ix->stage_timing) continue;  // one launch per run
+            } else if (s == RTX_STAGE_TILE_BOUNDS || s == RTX_STAGE_TILE_PRUNE ? !ix->prune_used : (s != RTX_STAGE_HIT_COUNT && !ix->stage_timing)) continue;  // events were not recorded
             float t = 0.f;
             RTX_HIP(hipEventElapsedTime(&t, ix->events[((size_t)sb * RTX_NUM_STAGES + s) * 2],
                                         ix->events[((size_t)sb * RTX_NUM_STAGES + s) * 2 + 1]));
@@ -1884,6 +2063,63 @@ int rtx_debug_pruned_prob_table(rtx_index *ix, uint64_t query, double *table_ove
         if (!hist[m] || m <= thr) table_over_z[m] = 0.0;  // entries of absent counts are never written; up to the threshold: 0 by construction
     if (z) RTX_HIP(hipMemcpy(z, ix->d_z.p + ix->h_inv[query], 8, hipMemcpyDeviceToHost));
     if (threshold) *threshold = thr;
+    return RTX_OK;
+}
+
+// The last sub-batch exactly as the run left it -- no recount: the counts hit_count wrote for the tiles it visited, which tiles
+// those were, the histogram as prune_kernel (bin 0: the references never counted) and hit_count (every counted reference) left it,
+// the query's threshold and i* + 1.  The parity tests hold THIS against the oracle (the recounting taps prove the unpruned kernel).
+int rtx_debug_run_counts(rtx_index *ix, uint64_t query, uint16_t *counts, uint8_t *tile_live, uint32_t *hist, uint32_t *threshold,
+                         uint32_t *i1) {
+    uint32_t slot;
+    int rc = debug_slot_as_run(ix, query, &slot);
+    if (rc) return rc;
+    if (ix->dbg_full) { set_error("rtx_debug_run_counts: another tap has recounted the sub-batch in full"); return RTX_ERR_STATE; }
+    rtx_index::Scratch &sc = ix->sc[ix->last_set];
+    const uint32_t nt = ix->ntiles;
+    std::vector<uint8_t> live(nt, 1);
+    uint16_t thr = 0, i1v = 0;
+    if (ix->prune_used) {
+        const uint32_t lw = (nt + 31u) / 32u + 1u;
+        std::vector<uint32_t> words(lw);
+        RTX_HIP(hipMemcpy(words.data(), sc.d_live.p + (size_t)(slot >> 1) * lw, lw * 4, hipMemcpyDeviceToHost));
+        for (uint32_t T = 0; T < nt; T++) live[T] = (uint8_t)((words[T >> 5] >> (T & 31u)) & 1u);
+        RTX_HIP(hipMemcpy(&thr, sc.d_prune_thr.p + slot, 2, hipMemcpyDeviceToHost));
+        RTX_HIP(hipMemcpy(&i1v, sc.d_prune_i1.p + slot, 2, hipMemcpyDeviceToHost));
+    }
+    if (counts) {
+        const uint16_t *src = nullptr;
+        if ((rc = debug_counts_u16(ix, slot, &src))) return rc;
+        RTX_HIP(hipMemcpy(counts, src, ix->n_refs * 2, hipMemcpyDeviceToHost));
+        for (uint32_t T = 0; T < nt; T++)
+            if (!live[T]) {  // never written by this run: whatever an earlier sub-batch left there
+                const uint64_t lo = (uint64_t)T * 8192u, hi = std::min<uint64_t>(lo + 8192u, ix->n_refs);
+                for (uint64_t r = lo; r < hi; r++) counts[r] = 0xFFFFu;
+            }
+    }
+    if (tile_live) std::memcpy(tile_live, live.data(), nt);
+    if (hist) {
+        uint32_t tt = 0;
+        RTX_HIP(hipMemcpy(&tt, sc.d_t.p + slot, 4, hipMemcpyDeviceToHost));
+        RTX_HIP(hipMemcpy(hist, sc.d_hist.p + (size_t)slot * ix->hstride, (size_t)(tt + 1) * 4, hipMemcpyDeviceToHost));
+    }
+    if (threshold) *threshold = thr;
+    if (i1) *i1 = i1v;
+    return RTX_OK;
+}
+
+// prune_kernel's view of a query of the last sub-batch (RTX_OPT_DEBUG_TAPS = 1 before the run): kPruneDetailWords words,
+// PruneParams::detail
+int rtx_debug_prune_detail(rtx_index *ix, uint64_t query, uint32_t *out) {
+    uint32_t slot;
+    int rc = debug_slot_as_run(ix, query, &slot);
+    if (rc) return rc;
+    if (!out) { set_error("null argument"); return RTX_ERR_INVALID; }
+    if (!ix->prune_used || !ix->debug_taps || ix->d_prune_detail.n < (size_t)(slot + 1) * kPruneDetailWords) {
+        set_error("rtx_debug_prune_detail: the last run did not prune, or RTX_OPT_DEBUG_TAPS was off");
+        return RTX_ERR_STATE;
+    }
+    RTX_HIP(hipMemcpy(out, ix->d_prune_detail.p + (size_t)slot * kPruneDetailWords, kPruneDetailWords * 4, hipMemcpyDeviceToHost));
     return RTX_OK;
 }
 

@@ -196,10 +196,15 @@ int emul_prob_table(uint32_t t, const uint32_t *hist, uint64_t n_refs, const dou
 // Sequential emulation of prob_lookup_kernel + prob_tables_build_kernel (rtx_prob_tables.hip): the rows
 // C = ln cmf, R = pmf/cmf, sat and ilo are produced by the same recurrence (here on demand instead of from the
 // memoised table), then P(i) and table[m] are formed exactly as the lookup kernel does.
-int emul_prob_lookup(uint32_t t, const uint32_t *hist, uint64_t n_refs, const double *lf, double *table_z, double *z,
-                     double *gs, uint64_t *stats) {
+// u_thr > 0: the query as tile pruning treats it (prob_lookup_kernel with ProbParams::prune_thr / prune_i1): the counts up to u_thr
+// become references without a hit (bin 0) with probability 0, and the sums over i start at i1 if that lies beyond i_lo.
+static int emul_prob_lookup_x(uint32_t t, const uint32_t *hist_in, uint64_t n_refs, const double *lf, uint32_t u_thr, uint32_t i1,
+                              double *table_z, double *z, double *gs, uint64_t *stats) {
     const uint32_t n = t >> 1;
     if (t == 0) return 1;
+    std::vector<uint32_t> hist_v(hist_in, hist_in + t + 1);
+    for (uint32_t m = 1; m <= u_thr && m <= t; m++) { hist_v[0] += hist_v[m]; hist_v[m] = 0; }
+    const uint32_t *hist = hist_v.data();
     std::vector<uint32_t> ms;
     for (uint32_t m = 0; m <= t; m++)
         if (hist[m]) ms.push_back(m);
@@ -236,6 +241,7 @@ int emul_prob_lookup(uint32_t t, const uint32_t *hist, uint64_t n_refs, const do
         std::vector<double> C, R;
         uint32_t sat = 0, ilo = 0, i_lo = 0;
         if (M > 0) { build_row(M, C, R, sat, ilo); i_lo = ilo; }
+        if (u_thr && i1 > i_lo && i1 <= n) i_lo = i1;
         std::vector<double> Pi(n + 1, 0.0);  // sum_m hist[m] ln cmf_m(i), then exp
         struct Row { uint32_t m, sat; std::vector<double> R; };
         std::vector<Row> rows;
@@ -256,7 +262,7 @@ int emul_prob_lookup(uint32_t t, const uint32_t *hist, uint64_t n_refs, const do
             for (uint32_t i = i_lo; i <= last; i++) acc += r.R[i] * Pi[i];
             tab[r.m] = acc;
         }
-        if (ms[0] == 0) tab[0] = i_lo == 0 ? Pi[0] : 0.0;
+        if (ms[0] == 0) tab[0] = i_lo == 0 && u_thr == 0 ? Pi[0] : 0.0;
     }
     double Z = 0.0;
     for (uint32_t m : ms) Z += (double)hist[m] * tab[m];
@@ -272,6 +278,80 @@ int emul_prob_lookup(uint32_t t, const uint32_t *hist, uint64_t n_refs, const do
     *gs = sqrt(g);
     if (stats) { stats[0] = st_rows; stats[1] = st_points; stats[2] = 0; stats[3] = 0; }
     return 0;
+}
+int emul_prob_lookup(uint32_t t, const uint32_t *hist, uint64_t n_refs, const double *lf, double *table_z, double *z,
+                     double *gs, uint64_t *stats) {
+    return emul_prob_lookup_x(t, hist, n_refs, lf, 0, 0, table_z, z, gs, stats);
+}
+int emul_prob_lookup_pruned(uint32_t t, const uint32_t *hist, uint64_t n_refs, const double *lf, uint32_t u_thr, uint32_t i1,
+                            double *table_z, double *z, double *gs) {
+    return emul_prob_lookup_x(t, hist, n_refs, lf, u_thr, i1, table_z, z, gs, nullptr);
+}
+
+// ln cmf_m(i), i = 0 .. n, exactly as prob_tables_build_kernel stores it (the rows prune_kernel reads for G)
+static void emul_ln_cmf_row(uint32_t t, uint32_t m, const double *lf, std::vector<double> &C) {
+    const uint32_t n = t >> 1;
+    C.assign(n + 1, 0.0);
+    if (m == 0) return;
+    std::vector<double> inv(t + n + 2, 0.0);
+    for (uint32_t x = 1; x <= t + n; x++) inv[x] = 1.0 / (double)x;
+    const double ln_total = ln_binom_tab(lf, t + n - 1, n);
+    PmfState st = pmf_start(lf, t, n, m, ln_total);
+    for (uint32_t i = 0; i <= n; i++) {
+        if (i > 0) pmf_step(st, inv.data(), t, n, m, i);
+        C[i] = st.k == 0 && st.c > 0.0 ? log(st.c) : -INFINITY;
+    }
+}
+
+// Sequential restatement of step 3 of prune_kernel (rtx_prune.hip): the threshold u (the largest count a reference may have
+// and still be treated as a reference without a hit) and i* + 1 from the exact counts `hm` of the 64 references of the block
+// with the largest bound (0: no reference / zeroed).  Same inequalities, same tables; only the order of the sums over the
+// lanes differs.  The GPU tests hold the kernel's (u, i* + 1) against this, the CPU tests hold this against the oracle on
+// adversarial histograms (tests/test_prune_threshold_cpu.py).
+void emul_prune_threshold(uint32_t t, uint64_t n_refs, const uint32_t *hm_in, const double *lf, uint32_t tab_tmax, uint32_t *u_out,
+                          uint32_t *i1_out) {
+    const double kLnEps = -27.631021115928547;  // ln 1e-12 (kPruneLnEps)
+    const uint32_t n = t >> 1;
+    uint32_t hm[64], M = 0;
+    for (int l = 0; l < 64; l++) { hm[l] = hm_in[l]; M = std::max(M, hm[l]); }
+    *u_out = 0;
+    *i1_out = 0;
+    if (!(t >= 16u && t <= tab_tmax && M >= 1u && n >= 2u)) return;
+    const double ln_n = log((double)n_refs), ln_total = ln_binom_tab(lf, t + n - 1, n);
+    if (M >= t) {
+        uint32_t u_max = 0;
+        for (uint32_t u = 1; u < t; u++)
+            if (ln_binom_tab(lf, u + n - 1, n) - ln_total + ln_n <= kLnEps) u_max = std::max(u_max, u);
+        *u_out = u_max;
+        return;
+    }
+    uint32_t n_h = 0, h_min = 0xFFFFFFFFu;
+    std::vector<std::vector<double>> rows(64);
+    for (int l = 0; l < 64; l++) {
+        if (hm[l] * 5u < M * 4u) hm[l] = 0;
+        if (hm[l]) { n_h++; h_min = std::min(h_min, hm[l]); emul_ln_cmf_row(t, hm[l], lf, rows[l]); }
+    }
+    auto passes = [&](uint32_t i) {
+        double s = 0.0;
+        for (int l = 0; l < 64; l++)
+            if (hm[l]) s += rows[l][i];
+        return s + log((double)n_h + (double)n_refs * (double)(i + 1u)) <= kLnEps;
+    };
+    if (!passes(0u)) return;
+    uint32_t lo = 0, hi = n - 2u;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi + 1u) >> 1;
+        if (passes(mid)) lo = mid; else hi = mid - 1u;
+    }
+    const uint32_t i1 = lo + 1u;
+    const double ln_len = log((double)(n - i1 + 1u));
+    uint32_t first_fail = h_min;
+    for (uint32_t u = 1; u < h_min; u++) {
+        const double up = (double)(u + i1) * (double)(n - i1), dn = (double)(i1 + 1u) * (double)(t - u + n - i1 - 1u);
+        if (!(up < dn && ln_len + ln_pmf_tab(lf, t, n, u, i1, ln_total) + ln_n <= kLnEps)) { first_fail = u; break; }
+    }
+    *u_out = first_fail - 1u;
+    *i1_out = first_fail - 1u ? i1 : 0u;
 }
 
 // Bit layout of the bitmap rows (rtx_math.hpp ref_slot) and its inverse as hit_count / seg_emit use it:

@@ -265,9 +265,11 @@ __device__ __forceinline__ void hit_epilogue_x(const HitParams &p, uint32_t (&pl
     const uint32_t L = tile_lanes(p.stride_bytes, tile);  // lanes of this tile (64 except in the last one)
     if (active && (p.flags & RTX_SKIP_EXACT_MATCHES)) {  // raxtax.rs:65-68: the dense part
         const uint64_t qin = p.perm[p.q0 + q];
-        const uint64_t e0 = p.exact_off[qin], e1 = p.exact_off[qin + 1];
+        uint64_t e0, e1;
+        const uint32_t *xids;
+        exact_range(p.exact, qin, e0, e1, xids);
         for (uint64_t e = e0; e < e1; e++) {
-            const uint32_t id = p.exact_ids[e] - p.ref_base;  // local id; other shards' ids wrap out of range
+            const uint32_t id = xids[e] - p.ref_base;  // local id; other shards' ids wrap out of range
             if (id < p.n_refs && (id >> 13) == tile) {
                 const uint32_t c = (id & 8191u) >> 3, g = c / L;
                 if (c - g * L == lane) {
@@ -300,9 +302,11 @@ __device__ __forceinline__ void hit_epilogue_x(const HitParams &p, uint32_t (&pl
             sparse_hits((uint32_t)half);
             if (p.flags & RTX_SKIP_EXACT_MATCHES) {  // raxtax.rs:65-68: the sparse part
                 const uint64_t qin = p.perm[p.q0 + q];
-                const uint64_t e0 = p.exact_off[qin], e1 = p.exact_off[qin + 1];
+                uint64_t e0, e1;
+                const uint32_t *xids;
+                exact_range(p.exact, qin, e0, e1, xids);
                 for (uint64_t e = e0 + lane; e < e1; e += 64) {
-                    const uint32_t id = p.exact_ids[e] - p.ref_base;
+                    const uint32_t id = xids[e] - p.ref_base;
                     if (id < p.n_refs && (id >> 13) == tile && (kFullTile || ((id >> 12) & 1u) == (uint32_t)half))
                         reinterpret_cast<uint8_t *>(cnt8)[id & (kFullTile ? 8191u : 4095u)] = 0;
                 }

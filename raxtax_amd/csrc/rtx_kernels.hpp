@@ -36,6 +36,39 @@ struct DevRow {  // one result row as the device emits it
 };
 static_assert(sizeof(DevRow) == 36, "DevRow layout");
 
+// Exact matches of the queries of a batch (Tree.sequences.get, raxtax.rs:42), two sources: ids the caller looked up on the host
+// (CSR exact_off / exact_ids, indexed by query), or the group the device lookup found (rtx_exact.hip: grp[query], the ids of group g are
+// gids[goff[g] .. goff[g + 1])).  grp != null selects the second.
+struct ExactRef {
+    const uint32_t *ids;
+    const uint64_t *off;
+    const uint32_t *grp, *goff, *gids;
+};
+__device__ __forceinline__ void exact_range(const ExactRef &x, uint64_t qin, uint64_t &e0, uint64_t &e1, const uint32_t *&ids) {
+    if (x.grp) {
+        const uint32_t g = x.grp[qin];
+        ids = x.gids;
+        e0 = e1 = 0;
+        if (g != 0xFFFFFFFFu) { e0 = x.goff[g]; e1 = x.goff[g + 1]; }
+    } else {
+        ids = x.ids;
+        e0 = x.off[qin];
+        e1 = x.off[qin + 1];
+    }
+}
+struct ExactParams {  // rtx_exact.hip
+    const uint8_t *bases;      // the batch (padded behind its end)
+    const uint64_t *base_off;
+    uint32_t n_q;
+    const uint2 *table;        // [2^bits] {tag, group + 1}; group + 1 == 0: empty
+    uint32_t bits;
+    const uint64_t *rep_off;   // [groups + 1] the distinct reference sequences, concatenated (padded behind the end)
+    const uint8_t *rep_bytes;
+    uint32_t *grp_out;         // [n_q] group of the query, 0xFFFFFFFF: no reference has its sequence
+    uint64_t hash_mask;        // all ones; tests weaken the hash (RTX_DEFAULT_EXACT_HASH_MASK) so that chains and tags collide
+};
+void launch_exact_match(hipStream_t s, const ExactParams &p);
+
 struct KmerParams {
     const uint8_t *bases;
     const uint64_t *base_off;
@@ -99,9 +132,8 @@ struct HitParams {
     uint16_t *tile_max;  // [B][ntiles] largest count of the tile's references (taxon_prefix skips tiles without any probability) or null
     uint32_t flags;
     uint64_t q0;
-    const uint32_t *perm;       // [n_q] query at every position: exact_off is indexed by query
-    const uint32_t *exact_ids;
-    const uint64_t *exact_off;
+    const uint32_t *perm;       // [n_q] query at every position: the exact matches are indexed by query
+    ExactRef exact;
     uint32_t nq;           // slots of the sub-batch
     uint32_t *group_rows;  // [pairs of the batch] union rows loaded per pair, summed over the tiles (work accounting) or null
     uint32_t group_base;   // index of the sub-batch's first group in group_rows
@@ -132,8 +164,8 @@ struct PruneParams {
     const uint32_t *nrows, *t;
     uint32_t flags;
     uint64_t q0;
-    const uint32_t *perm, *exact_ids;
-    const uint64_t *exact_off;
+    const uint32_t *perm;
+    ExactRef exact;
     const double *lnfact;
     uint32_t *hist;           // [B][hstride]: bin 0 receives the references of the tiles that are not counted
     uint32_t hstride;
@@ -144,7 +176,10 @@ struct PruneParams {
     unsigned long long *stats;  // [kPruneStatCopies][8]: [0] += live tiles, [1] += pairs ... (reporting) or null
     const uint32_t *ubitmap;    // debug (RTX_PRUNE_CHECK): the union bitmap
     uint32_t ustride_bytes;
+    uint32_t *detail;           // [B][kPruneDetailWords] debug tap (RTX_OPT_DEBUG_TAPS) or null: {best block, M, threshold, i* + 1, largest
+                                // bound, t, 0, 0, exact counts of the 64 references of the best block}
 };
+constexpr uint32_t kPruneDetailWords = 72;
 struct ProbTables;
 void launch_prune(hipStream_t s, const PruneParams &p, const ProbTables &tb, uint32_t nq);
 

@@ -50,6 +50,32 @@ RTX_HD void ref_slot(uint32_t r, uint32_t stride_bytes, uint32_t &word, uint32_t
     bit = (g & 3u) * 8u + (rl & 7u);
 }
 
+// ---------------------------------------------------------------------------
+// Hash of an encoded sequence for the exact-match lookup (Tree.sequences.get, raxtax.rs:42) on the device.  The bytes are taken
+// as 8-byte little-endian words (the last one zero-padded); every word is mixed with its position and the mixes are ADDED, so
+// that the lanes of a wave can hash their words independently and meet in one sum.  Equal sequences hash equal; a collision only
+// costs a byte compare (the lookup verifies every candidate byte by byte).  The host builds the table with the same functions.
+// ---------------------------------------------------------------------------
+RTX_HD uint64_t em_mix_word(uint64_t w, uint64_t j) {
+    uint64_t v = w + 0x9E3779B97F4A7C15ull * (j + 1u);
+    v ^= v >> 32;
+    v *= 0xD6E8FEB86659FD93ull;
+    v ^= v >> 29;
+    v *= 0xFF51AFD7ED558CCDull;
+    v ^= v >> 32;
+    return v;
+}
+RTX_HD uint64_t em_finish(uint64_t sum, uint64_t len) {
+    uint64_t h = sum ^ (len * 0xC2B2AE3D27D4EB4Full);
+    h ^= h >> 33;
+    h *= 0xC4CEB9FE1A85EC53ull;
+    h ^= h >> 29;
+    return h;
+}
+// slot of a hash in a table of 2^bits slots, and the 32-bit tag kept beside the group (never 0: 0 marks an empty slot)
+RTX_HD uint32_t em_slot(uint64_t h, uint32_t bits) { return (uint32_t)(h >> (64u - bits)); }
+RTX_HD uint32_t em_tag(uint64_t h) { const uint32_t t = (uint32_t)h; return t ? t : 1u; }
+
 // full adder on bit vectors: (a + b + c) -> sum (weight 1), carry (weight 2)
 RTX_HD void csa(uint32_t a, uint32_t b, uint32_t c, uint32_t &sum, uint32_t &carry) {
 #if defined(__HIP_DEVICE_COMPILE__)

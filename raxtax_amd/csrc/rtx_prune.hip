@@ -115,6 +115,9 @@ __global__ __launch_bounds__(64) void prune_kernel(PruneParams p, ProbTables tb)
             const uint32_t nr = p.nrows[q];
             const uint32_t *rows = p.rows + (size_t)q * p.rstride;
             const uint64_t qin = p.perm[p.q0 + q];
+            uint64_t xe0 = 0, xe1 = 0;
+            const uint32_t *xids = nullptr;
+            if (p.flags & RTX_SKIP_EXACT_MATCHES) exact_range(p.exact, qin, xe0, xe1, xids);
             const uint32_t zero_row = p.n_rows1 - 1u;
             // lane = (row group, chunk): an instruction reads the block's bytes of 64 / kChunks rows, and the chunks of a block are
             // neighbouring lane words of the row segment -- one 128-byte line per row (with lane = row and a gather per chunk
@@ -158,7 +161,7 @@ __global__ __launch_bounds__(64) void prune_kernel(PruneParams p, ProbTables tb)
                     bool ok = r < p.n_refs;
                     if (ok && (p.flags & RTX_SKIP_EXACT_MATCHES)) {
                         bool hit = false;
-                        for (uint64_t e = p.exact_off[qin] + lane; e < p.exact_off[qin + 1]; e += 64) hit = hit || (uint64_t)p.exact_ids[e] == r;
+                        for (uint64_t e = xe0 + lane; e < xe1; e += 64) hit = hit || (uint64_t)xids[e] == r;
                         ok = __ballot(hit) == 0ull;
                     }
                     const uint32_t cnt = ((uint32_t)__builtin_amdgcn_readlane((int)acc[j >> 1], (int)c) >> ((j & 1) * 16)) & 0xFFFFu;
@@ -167,6 +170,7 @@ __global__ __launch_bounds__(64) void prune_kernel(PruneParams p, ProbTables tb)
                 }
             }
         }
+        if (p.detail) p.detail[(size_t)q * kPruneDetailWords + 8u + lane] = hm;  // debug tap: the exact counts of the best block's references
 #ifdef RTX_PRUNE_CHECK  // debug: the count of the best block recomputed from the union bitmap must equal what the counting pass left
         if (p.ubitmap) {
             uint32_t word, bit;
@@ -235,6 +239,10 @@ __global__ __launch_bounds__(64) void prune_kernel(PruneParams p, ProbTables tb)
         }
         thr[x] = u_max;
         if (lane == 0) { p.thr_out[q] = (uint16_t)u_max; p.i1_out[q] = (uint16_t)(u_max ? i1_q : 0u); }
+        if (p.detail && lane == 0) {
+            uint32_t *d = p.detail + (size_t)q * kPruneDetailWords;
+            d[0] = bb; d[1] = M; d[2] = u_max; d[3] = u_max ? i1_q : 0u; d[4] = ub_best; d[5] = t; d[6] = 0u; d[7] = 0u;
+        }
         // reporting: sums of the lower bound of the best hit, of the threshold, of the largest tile bound
         st[2] += M; st[3] += u_max; st[4] += ub_best; st[5] += 1ull;
         if (ub_best < M) st[6] += 1ull;  // must never happen: a block's bound below one of its references' counts

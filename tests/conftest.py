@@ -25,3 +25,20 @@ def kats():
     import json
 
     return json.loads((ROOT / "tests" / "golden" / "reference_kats.json").read_text())
+
+
+@pytest.fixture(scope="session")
+def emul():
+    """x86 build of the device arithmetic (raxtax_amd/csrc/rtx_emul.cpp over rtx_math.hpp): test support, never on the product path."""
+    import ctypes as C
+    import subprocess
+
+    out = ROOT / "tests" / "_build" / "librtx_emul.so"
+    out.parent.mkdir(exist_ok=True)
+    src = ROOT / "raxtax_amd" / "csrc" / "rtx_emul.cpp"
+    hdr = ROOT / "raxtax_amd" / "csrc" / "rtx_math.hpp"
+    if not out.exists() or out.stat().st_mtime < max(src.stat().st_mtime, hdr.stat().st_mtime):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", f"-I{src.parent}", "-o", str(out), str(src)])
+    lib = C.CDLL(str(out))
+    lib.emul_prob_table.restype = C.c_int
+    return lib

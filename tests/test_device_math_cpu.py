@@ -3,7 +3,6 @@ kernels call) on the CPU through a small emulation harness and checks it against
 bit-sliced counters must be bit-exact, the linear-domain pmf recurrence must reproduce the
 reference's log-space probability table."""
 import ctypes as C
-import subprocess
 from pathlib import Path
 
 import numpy as np
@@ -12,19 +11,6 @@ import pytest
 from raxtax_amd import synth
 
 ROOT = Path(__file__).resolve().parent.parent
-
-
-@pytest.fixture(scope="module")
-def emul():
-    out = ROOT / "tests" / "_build" / "librtx_emul.so"
-    out.parent.mkdir(exist_ok=True)
-    src = ROOT / "raxtax_amd" / "csrc" / "rtx_emul.cpp"
-    hdr = ROOT / "raxtax_amd" / "csrc" / "rtx_math.hpp"
-    if not out.exists() or out.stat().st_mtime < max(src.stat().st_mtime, hdr.stat().st_mtime):
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", f"-I{src.parent}", "-o", str(out), str(src)])
-    lib = C.CDLL(str(out))
-    lib.emul_prob_table.restype = C.c_int
-    return lib
 
 
 @pytest.mark.parametrize("planes,n_rows,density", [(10, 648, 0.3), (10, 1016, 0.97), (12, 4088, 0.5), (16, 8000, 0.9)])

@@ -20,7 +20,7 @@ def cfg2(oracle):
     db = synth.make_db(N_REFS)
     qs = synth.make_queries(db, N_Q)
     tree = rx.Tree.new_flat(db.lineages, db.seq_bytes, db.seq_off, kmer_map=False)   # bitmaps built on the GPU
-    index = rx.Index(tree)
+    index = rx.Index(tree, debug_taps=True)      # prune_kernel keeps its view of every query for rtx_debug_prune_detail
     ex_ids, ex_off = index.exact_matches(qs.bases, qs.base_off)
     res = index.classify(qs.bases, qs.base_off, ex_ids, ex_off)
     prune_stats = index.debug_prune_stats()
@@ -61,11 +61,14 @@ def test_exact_copies_find_their_reference(cfg2):
 
 
 @pytest.mark.parametrize("skip", [False, True])
-def test_seeded_oracle_sample(cfg2, oracle, skip):
+def test_seeded_oracle_sample(cfg2, oracle, emul, skip):
+    """The sample as a batch of its own through the default (pruned) handle: first the run exactly as it was -- the counts of the
+    visited tiles, the unvisited tiles against the threshold, the histogram, the probabilities of the pruned run, prune_kernel's
+    threshold against its CPU restatement (gpu_common.check_run_as_left) -- then the recounting taps and the result rows."""
     c = cfg2
     ex = Excuses(f"config2/sample{N_SAMPLE}/skip={int(skip)}")
     oracle_sample_parity(c["index"], oracle, c["otree"], c["db"], c["qs"], c["sample"], skip, ex,
-                         full_res=None if skip else c["res"])
+                         full_res=None if skip else c["res"], emul=emul)
     ex.check()
 
 

@@ -1,0 +1,153 @@
+"""The pruned path itself under the oracle: what the timed run computed -- the counts of the tiles it visited, the
+tiles it left out, the histogram, the probabilities -- is read back WITHOUT a recount (rtx_debug_run_counts,
+rtx_debug_pruned_prob_table, rtx_debug_prune_detail) and held against the oracle's full computation (gpu_common.check_run_as_left), at
+the sizes and on the kind of data the other suites do not reach:
+  * a database of more than 524 288 references: the bounds of the tile pruning span more than one tile of the union bitmap;
+  * real barcode composition: the 600 Diptera records of the reference's example data (tests/golden/diptera_subset.fasta, 195-208 bp,
+    t ~ 195, k-mers that occur in most references) expanded by per-copy substitutions to 15 tiles.
+BASELINE configs[2] gets the same checks in tests/test_gpu_config2.py, configs[4]'s database size in tests/test_gpu_config4_shards.py."""
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import raxtax_amd as rx
+from gpu_common import Excuses, check_properties, oracle_sample_parity
+from raxtax_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+FASTA = Path(__file__).resolve().parent / "golden" / "diptera_subset.fasta"
+
+
+def test_more_than_one_tile_of_bounds(oracle, emul):
+    """N = 620 000: 9 688 blocks of 64 references = two tiles of bounds (u_ntiles = 2), 76 tiles of references."""
+    n_refs, n_q, n_sample = 620_000, 20_000, 300
+    db = synth.make_db(n_refs)
+    qs = synth.make_queries(db, n_q, seed=11)
+    tree = rx.Tree.new_flat(db.lineages, db.seq_bytes, db.seq_off, kmer_map=False)
+    index = rx.Index(tree, debug_taps=True)
+    res = index.classify(qs.bases, qs.base_off, *index.exact_matches(qs.bases, qs.base_off))
+    check_properties(res, db, n_q)
+    st = index.debug_prune_stats()
+    print("tile pruning of the full batch:", st)
+    assert st["pairs"] == (n_q + 1) // 2 and st["bound_violations"] == 0 and st["queries_with_threshold"] > 0.9 * n_q
+    assert st["live_tiles_per_pair"] < 10
+    otree = oracle.tree_new_flat(db.lineages, db.seq_bytes, db.seq_off)
+    sample = np.sort(np.random.default_rng(62).choice(n_q, n_sample, replace=False))
+    for skip in (False, True):
+        ex = Excuses(f"pruned/620k/skip={int(skip)}")
+        oracle_sample_parity(index, oracle, otree, db, qs, sample, skip, ex, full_res=None if skip else res, chunk=100, emul=emul)
+        ex.check()
+
+
+def _diptera_expanded(copies, seed=7):
+    """The 600 Diptera records, `copies` copies each: copy 0 is the record itself, the others carry substitutions at a per-copy
+    rate drawn from {0.2, 0.5, 1, 2, 4} % (bases redrawn from the record's own composition).  Lineage = the record's."""
+    code = np.zeros(256, np.uint8)
+    for ch, v in zip("ACGT", (1, 2, 4, 8)):
+        code[ord(ch)] = code[ord(ch.lower())] = v
+    recs, lin, cur = [], [], []
+    for line in FASTA.read_text().splitlines():
+        if line.startswith(">"):
+            if cur:
+                recs.append("".join(cur))
+            cur = []
+            lin.append(line.split("tax=")[1].split(";")[0])
+        elif line.strip():
+            cur.append(line.strip())
+    recs.append("".join(cur))
+    assert len(recs) == len(lin) == 600
+    rng = np.random.default_rng(seed)
+    seqs, lineages = [], []
+    for r, l in zip(recs, lin):
+        base = code[np.frombuffer(r.encode(), np.uint8)]
+        assert (base > 0).all()
+        for c in range(copies):
+            s = base.copy()
+            if c:
+                mu = float(rng.choice([0.002, 0.005, 0.01, 0.02, 0.04]))
+                hit = rng.random(len(s)) < mu
+                s[hit] = rng.choice(base, int(hit.sum()))
+            seqs.append(s)
+            lineages.append(l)
+    off = np.zeros(len(seqs) + 1, np.uint64)
+    off[1:] = np.cumsum([len(s) for s in seqs])
+    return lineages, np.concatenate(seqs), off, seqs
+
+
+def test_real_composition_short_reads(oracle, emul):
+    """Diptera COI at ~205 bp (t ~ 195, n ~ 97): 115 200 references = 15 tiles; queries = references with 0 .. 8 % substitutions,
+    truncated reads and the raw records (exact matches of copy 0).  Variable lengths: the sample is compared query by query."""
+    from test_gpu_parity import assert_rows_equivalent
+
+    lineages, flat, off, seqs = _diptera_expanded(192)
+    n_refs = len(seqs)
+    assert (n_refs + 8191) // 8192 == 15
+    rng = np.random.default_rng(8)
+    qs = []
+    for i in range(3000):
+        s = seqs[int(rng.integers(0, n_refs))].copy()
+        kind = i % 6
+        mu = (0.0, 0.01, 0.03, 0.08, 0.02, 0.0)[kind]
+        hit = rng.random(len(s)) < mu
+        s[hit] = rng.choice(s, int(hit.sum()))
+        if kind == 4:
+            s = s[: int(rng.integers(120, len(s)))]           # a truncated read
+        if kind == 5:
+            s = seqs[int(rng.integers(0, 600)) * 192].copy()    # a raw record
+        qs.append(s)
+    qoff = np.zeros(len(qs) + 1, np.uint64)
+    qoff[1:] = np.cumsum([len(q) for q in qs])
+    bases = np.concatenate(qs)
+    otree = oracle.tree_new_flat(lineages, flat, off)
+    tree = rx.Tree.new_flat(lineages, flat, off, kmer_map=False)
+    index = rx.Index(tree, debug_taps=True)
+    ex_ids, ex_off = index.exact_matches(bases, qoff)
+    lf = np.array([oracle.lib.orc_ln_factorial(i) for i in range(2 * 210 + 8)], dtype=np.float64)
+    olin = None
+    import os
+    from gpu_common import check_run_as_left
+
+    threads = os.cpu_count() or 1
+    for skip in (False, True):
+        res = index.classify(bases, qoff, ex_ids, ex_off, skip_exact_matches=skip)
+        assert (res.status == 0).all()
+        st = index.debug_prune_stats()
+        print(f"skip={skip}: tile pruning on real composition:", st)
+        assert st["pairs"] == len(qs) // 2 and st["bound_violations"] == 0
+        # the whole batch is one sub-batch: every query can be read back as the run left it
+        sample = np.sort(np.random.default_rng(9 + skip).choice(len(qs), 400, replace=False))
+        sub = np.concatenate([qs[j] for j in sample])
+        soff = np.zeros(len(sample) + 1, np.uint64)
+        soff[1:] = np.cumsum([len(qs[j]) for j in sample])
+        t_o, counts_o = otree.hit_counts_batch(sub, soff, skip_exact=skip, threads=threads)
+        tables_o, z_o, rc = oracle.prob_tables_batch(t_o, counts_o, threads=threads)
+        assert (rc == 0).all()
+        # tol 1e-7: with 192 near-identical copies of every record hundreds of references share the top counts, the sums
+        # sum_m hist[m] ln cmf_m(i) of prob.rs:62-73 reach 1e4 and more, and two correct f64 evaluations of them (the oracle's order of
+        # summation, the device's) differ by up to 1e-9 relative (measured: 8.8e-10) -- the reference's own order is random (ahash,
+        # SURVEY.md 8c).  north_star: 1e-6.
+        seen = [check_run_as_left(index, int(j), int(t_o[k]), counts_o[k], tables_o[k], n_refs, emul, lf, f"query {int(j)} skip {skip}", tol=1e-7)
+                for k, j in enumerate(sample)]
+        with_thr = sum(o["threshold"] > 0 for o in seen)
+        print(f"skip={skip}: {len(seen)} queries read back as the run left them: {with_thr} with a threshold (mean {np.mean([o['threshold'] for o in seen]):.1f} "
+              f"of t ~ {np.mean(t_o):.0f}), {np.mean([o['live'] for o in seen]):.2f} of 15 tiles visited per query, "
+              f"{np.mean([o['needed'] for o in seen]):.2f} hold a count above the threshold; max |p - p_oracle| {max(o['dp'] for o in seen):.2e}, "
+              f"dropped mass {max(o['dropped'] for o in seen):.2e}")
+        # then the rows, and the recounting taps (hit counts of every tile)
+        bad, rows_o, nrows_o = otree.classify_batch(sub, soff, skip_exact=skip, raw_confidence=True, threads=threads, cap=64)
+        assert bad == 0
+        exc = Excuses(f"pruned/diptera115k/skip={int(skip)}")
+        for k, j in enumerate(sample):
+            j = int(j)
+            assert res.t[j] == t_o[k]
+            if k % 8 == 0:
+                assert np.array_equal(index.debug_hit_counts(j), counts_o[k]), (skip, j)
+            want = otree.rows_of(rows_o, nrows_o, k, 64)
+            got = res.rows(j)
+            exc.checked += 1
+            if [g.lineage for g in got] != [r["idx"] for r in want] or [g.confidence_values for g in got] != [r["conf"] for r in want]:
+                olin = olin or otree.lineages
+                exc.tie(assert_rows_equivalent(got, want, tables_o[k][counts_o[k]], olin, f"query {j} skip {skip}"))
+        exc.check()

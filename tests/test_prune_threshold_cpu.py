@@ -1,0 +1,124 @@
+"""The threshold of the tile pruning (raxtax_amd/csrc/rtx_prune.hip, step 3 of prune_kernel) attacked on the CPU.
+
+`emul_prune_threshold` (rtx_emul.cpp) restates the kernel's inequalities with the same tables; the GPU tests hold the kernel's
+(u, i* + 1) against it query by query (tests/test_gpu_pruned_path.py).  Here the threshold it yields is held against the oracle
+(prob.rs:8-103 restated) on the histograms that stress its proof: the bound is N x tail, so the adversary puts the best block H
+at the top and EVERY other reference of the database exactly at the threshold u (or spreads them just below it), for databases
+of up to 5 M references.  Treating the counts up to u as references without a hit -- what prob_lookup does for a pruned query,
+emulated by `emul_prob_lookup_pruned` -- must leave every probability, and every sum of probabilities over any set of
+references (the prefix sums of lineage.rs:61-66), within 1e-11 of the oracle's full computation; north_star allows 1e-6."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+TOL = 1e-11          # proved: a few eps, eps = 1e-12 (rtx_prune.hip)
+TAB_TMAX = 1023
+
+
+def _lnfact(oracle, n):
+    return np.array([oracle.lib.orc_ln_factorial(i) for i in range(n)], dtype=np.float64)
+
+
+def threshold(emul, lf, t, n_refs, block_counts):
+    hm = np.zeros(64, np.uint32)
+    hm[: len(block_counts)] = block_counts
+    u, i1 = C.c_uint32(), C.c_uint32()
+    emul.emul_prune_threshold(C.c_uint32(t), C.c_uint64(n_refs), hm.ctypes.data_as(C.c_void_p), lf.ctypes.data_as(C.c_void_p),
+                              C.c_uint32(TAB_TMAX), C.byref(u), C.byref(i1))
+    return int(u.value), int(i1.value)
+
+
+def pruned_table(emul, lf, t, n_refs, hist, u, i1):
+    tz = np.zeros(t + 1)
+    z, gs = C.c_double(), C.c_double()
+    emul.emul_prob_lookup_pruned.restype = C.c_int
+    rc = emul.emul_prob_lookup_pruned(C.c_uint32(t), hist.ctypes.data_as(C.c_void_p), C.c_uint64(n_refs), lf.ctypes.data_as(C.c_void_p),
+                                      C.c_uint32(u), C.c_uint32(i1), tz.ctypes.data_as(C.c_void_p), C.byref(z), C.byref(gs))
+    assert rc == 0
+    return tz, z.value, gs.value
+
+
+def check_histogram(emul, oracle, lf, t, counts, block, label):
+    """counts: u16 [N] with the block's references among them.  Returns (u, worst error)."""
+    n_refs = len(counts)
+    u, i1 = threshold(emul, lf, t, n_refs, block)
+    if u == 0:
+        return 0, 0.0
+    hist = np.bincount(counts, minlength=t + 1).astype(np.uint32)
+    tz_o, z_o, rc = oracle.prob_tables_batch(np.array([t], np.uint32), counts[None, :])
+    assert rc[0] == 0
+    p_o = tz_o[0][: t + 1]                                  # table[m] / Z of the full computation
+    p_d, z_d, gs_d = pruned_table(emul, lf, t, n_refs, hist, u, i1)
+    h = hist.astype(np.float64)
+    assert (p_d[1: u + 1] == 0).all() and p_d[0] == 0.0, label
+    kept = np.arange(t + 1) > u
+    present = hist > 0
+    per_ref = float(np.max(np.abs(p_d - p_o)[kept & present], initial=0.0))
+    # any set of references: the worst set takes every reference whose error has one sign
+    d = h * (p_d - p_o)
+    any_set = max(float(d[d > 0].sum()), float(-d[d < 0].sum()))
+    dropped = float((h * p_o)[: u + 1].sum())                # what the oracle gives the references that are dropped
+    assert per_ref < TOL and any_set < TOL and dropped < TOL, (label, u, i1, per_ref, any_set, dropped)
+    # the global signal (lineage.rs:86-90) follows from the same table
+    gs_o = float(np.sqrt((h * (p_o - 1.0 / n_refs) ** 2).sum()))
+    assert abs(gs_d - gs_o) < 1e-9, (label, gs_d, gs_o)
+    return u, max(per_ref, any_set, dropped)
+
+
+CASES = [  # t, N, best hit as a share of t, size of H
+    (640, 70_000, 0.90, 1), (640, 500_000, 0.90, 5), (640, 500_000, 0.92, 40), (640, 5_000_000, 0.90, 12),
+    (640, 5_000_000, 0.75, 3), (195, 500_000, 0.90, 8), (195, 5_000_000, 0.97, 30), (300, 500_000, 0.85, 2),
+    (900, 500_000, 0.93, 20), (1023, 5_000_000, 0.9, 6), (64, 100_000, 0.95, 4), (640, 500_000, 0.5, 10),
+]
+
+
+@pytest.mark.parametrize("t,n_refs,best,n_h", CASES)
+def test_everything_else_exactly_at_the_threshold(emul, oracle, t, n_refs, best, n_h):
+    lf = _lnfact(oracle, 2 * t + 8)
+    rng = np.random.default_rng(t * 31 + n_h)
+    M = int(best * t)
+    block = np.sort(rng.integers(int(0.8 * M) + 1, M + 1, n_h).astype(np.uint32))[::-1].copy()
+    block[0] = M
+    u, _ = threshold(emul, lf, t, n_refs, block)
+    if u == 0:
+        pytest.skip(f"no threshold for t={t} M={M}: nothing is pruned")
+    worst = 0.0
+    # (1) H at the top, everything else EXACTLY at u; (2) ... one below; (3) half at u, half without a hit;
+    # (4) a crowd just ABOVE the threshold (kept) on top of the crowd at it; (5) everything else spread over [0, u]
+    for k, rest in enumerate((lambda n: np.full(n, u), lambda n: np.full(n, max(u - 1, 0)),
+                              lambda n: np.where(np.arange(n) % 2 == 0, u, 0),
+                              lambda n: np.where(np.arange(n) % 50 == 0, np.minimum(u + 1 + (np.arange(n) // 50) % 7, int(0.8 * M)), u),
+                              lambda n: rng.integers(0, u + 1, n))):
+        counts = np.concatenate([block, rest(n_refs - n_h)]).astype(np.uint16)
+        u2, err = check_histogram(emul, oracle, lf, t, counts, block, f"t={t} N={n_refs} M={M} |H|={n_h} pattern {k}")
+        assert u2 == u
+        worst = max(worst, err)
+    print(f"t={t} N={n_refs} M={M} |H|={n_h}: u={u}, worst error {worst:.2e}")
+
+
+@pytest.mark.parametrize("t,n_refs", [(640, 500_000), (195, 5_000_000), (900, 70_000)])
+def test_full_overlap_reference(emul, oracle, t, n_refs):
+    """A reference shares every k-mer with the query (an exact copy): prob.rs:24-41 applies, table[m] = pmf_m(n)."""
+    lf = _lnfact(oracle, 2 * t + 8)
+    block = np.array([t, t - 3, t - 40], np.uint32)
+    u, i1 = threshold(emul, lf, t, n_refs, block)
+    assert u > 0 and i1 == 0
+    for rest in (np.full(n_refs - 3, u), np.full(n_refs - 3, u // 2)):
+        counts = np.concatenate([block, rest]).astype(np.uint16)
+        check_histogram(emul, oracle, lf, t, counts, block, f"full overlap t={t} N={n_refs}")
+
+
+def test_the_threshold_is_not_vacuous(emul, oracle):
+    """One count ABOVE the threshold, at the same adversarial histogram, may break the budget: the criterion is not slack by
+    orders of magnitude everywhere (printed, not asserted: how much room the proof leaves)."""
+    t, n_refs = 640, 500_000
+    lf = _lnfact(oracle, 2 * t + 8)
+    block = np.array([580, 575, 560, 541, 530], np.uint32)
+    u, i1 = threshold(emul, lf, t, n_refs, block)
+    assert 200 < u < 464
+    for du in (0, 10, 25, 50):
+        counts = np.concatenate([block, np.full(n_refs - 5, u + du)]).astype(np.uint16)
+        tz_o, z_o, rc = oracle.prob_tables_batch(np.array([t], np.uint32), counts[None, :])
+        mass = float(tz_o[0][u + du] * (n_refs - 5))
+        print(f"everything else at u + {du} = {u + du}: the oracle gives those references {mass:.3e} together")

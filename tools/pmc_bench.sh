@@ -7,7 +7,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --pmc $CTRS --output-format csv -d "$OUT/${TAG}" -- python3 "$ROOT/bench.py" --steps 1 --warmup 0 --no-cpu-baseline --queries 16384 "$@" > "$OUT/${TAG}.log" 2>&1
+rocprofv3 --pmc $CTRS --output-format csv -d "$OUT/${TAG}" -- python3 "$ROOT/bench.py" --steps 1 --warmup 0 --no-cpu-baseline --no-extras --queries 16384 "$@" > "$OUT/${TAG}.log" 2>&1
 echo "rc=$?"
 python3 - "$OUT/${TAG}" <<'PY'
 import csv, collections, glob, sys

@@ -11,10 +11,10 @@ OUT=$ROOT/gpurun_out
 QPL=${QPL:-32768}            # queries per launch (default sub-batch of a large database with tile pruning)
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 2 --warmup 1 --no-cpu-baseline $*"
+ARGS="--steps 2 --warmup 1 --no-cpu-baseline --no-extras $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${TAG}_trace" -- python3 "$ROOT/bench.py" $ARGS > "$OUT/${TAG}_trace.log" 2>&1
 echo "trace rc=$?"
-PARGS="--steps 1 --warmup 0 --no-cpu-baseline $* --queries $((4 * QPL))"
+PARGS="--steps 1 --warmup 0 --no-cpu-baseline --no-extras $*"   # the configuration the line names: every sub-batch of the 1 M queries
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/${TAG}_fetch" -- python3 "$ROOT/bench.py" $PARGS > "$OUT/${TAG}_fetch.log" 2>&1
 echo "fetch rc=$?"
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/${TAG}_write" -- python3 "$ROOT/bench.py" $PARGS > "$OUT/${TAG}_write.log" 2>&1

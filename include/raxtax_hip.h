@@ -392,6 +392,13 @@ int rtx_raxtax(rtx_index *index, const rtx_tree *tree, uint64_t n_queries, const
                const uint8_t *bases, const uint64_t *base_off, int skip_exact_matches, int raw_confidence,
                uint64_t chunk_size, rtx_sender_fn sender, void *sender_ctx, int tsv);
 
+/* The same on several device handles at once -- one per GPU of the node (the index replicated, BASELINE.json configs[3]), or several
+ * on one GPU: chunks of `chunk_size` queries (0: one chunk per handle) are dealt to the handles in turn, every handle is driven by a
+ * thread of its own inside this call, and the messages reach `sender` in input order, as from rtx_raxtax.  The reference's parallel
+ * driver is one call inside the process too (par_chunks over the rayon pool, raxtax.rs:35-36, main.rs:40-57). */
+int rtx_raxtax_multi(rtx_index *const *indices, uint32_t n_indices, const rtx_tree *tree, uint64_t n_queries,
+                     const char *const *labels, const uint8_t *bases, const uint64_t *base_off, int skip_exact_matches,
+                     int raw_confidence, uint64_t chunk_size, rtx_sender_fn sender, void *sender_ctx, int tsv);
 /* A ready-made sender that discards the messages and only counts them: ctx = NULL or uint64_t[2] {messages, bytes of text} */
 int rtx_sender_discard(void *ctx, const char *label, const char *out_lines, const char *tsv_lines);
 

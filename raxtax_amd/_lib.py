@@ -124,6 +124,7 @@ _SIGNATURES = {
                                      u32p, C.c_uint64, C.c_uint32, C.c_char_p, C.c_uint64, C.c_char_p, C.c_uint64,
                                      C.POINTER(C.c_int64)]),
     "rtx_raxtax": (C.c_int, None),  # argtypes set in api.py (callback type)
+    "rtx_raxtax_multi": (C.c_int, None),
     "rtx_sender_discard": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p, C.c_char_p]),
 }
 

@@ -424,14 +424,17 @@ class Index:
 _SENDER = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_char_p, C.c_char_p, C.c_char_p)
 
 
-def raxtax(queries: Sequence[Tuple[str, np.ndarray]], tree: Index, skip_exact_matches: bool, raw_confidence: bool,
+def raxtax(queries: Sequence[Tuple[str, np.ndarray]], tree, skip_exact_matches: bool, raw_confidence: bool,
            chunk_size: int, sender: Callable[[str, str, Optional[str]], None], tsv: bool) -> None:
-    """src/raxtax.rs:14-22 -- same arguments; `tree` is the device Index built from the Tree.
-    `sender(label, out_lines, tsv_lines_or_None)` is called once per query; raising from it
+    """src/raxtax.rs:14-22 -- same arguments; `tree` is the device Index built from the Tree, or a list of them (one per GPU,
+    all built from the same Tree): rtx_raxtax_multi then deals the chunks to the handles, one driving thread each.
+    `sender(label, out_lines, tsv_lines_or_None)` is called once per query, in input order; raising from it
     plays the role of a closed channel."""
     lib = _lib.load()
     lib.rtx_raxtax.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_char_p), u8p, u64p, C.c_int, C.c_int,
                                C.c_uint64, _SENDER, C.c_void_p, C.c_int]
+    lib.rtx_raxtax_multi.argtypes = [C.POINTER(C.c_void_p), C.c_uint32] + lib.rtx_raxtax.argtypes[1:]
+    handles = list(tree) if isinstance(tree, (list, tuple)) else [tree]
     labels = (C.c_char_p * max(len(queries), 1))(*[q[0].encode() for q in queries])
     flat, off = _flatten([q[1] for q in queries])
     err: List[BaseException] = []
@@ -444,8 +447,13 @@ def raxtax(queries: Sequence[Tuple[str, np.ndarray]], tree: Index, skip_exact_ma
             err.append(e)
             return 1
 
-    rc = lib.rtx_raxtax(tree._h, tree.tree._h, len(queries), labels, ptr(flat, u8p), ptr(off, u64p),
-                        int(skip_exact_matches), int(raw_confidence), chunk_size, _SENDER(cb), None, int(tsv))
+    if len(handles) == 1:
+        rc = lib.rtx_raxtax(handles[0]._h, handles[0].tree._h, len(queries), labels, ptr(flat, u8p), ptr(off, u64p),
+                            int(skip_exact_matches), int(raw_confidence), chunk_size, _SENDER(cb), None, int(tsv))
+    else:
+        arr = (C.c_void_p * len(handles))(*[h._h.value for h in handles])
+        rc = lib.rtx_raxtax_multi(arr, len(handles), handles[0].tree._h, len(queries), labels, ptr(flat, u8p), ptr(off, u64p),
+                                  int(skip_exact_matches), int(raw_confidence), chunk_size, _SENDER(cb), None, int(tsv))
     if err:
         raise err[0]
     check(rc)

@@ -1,5 +1,6 @@
 // raxtax-hip: command line around the host mirror of raxtax() -- FASTA/.bin database + FASTA queries in,
-// the reference's output files out, on one GPU.  Flag names and file semantics follow the reference
+// the reference's output files out, on one GPU or, with --gpus N / --devices a,b,..., on several at once (one process, one
+// index handle and one driving thread per device: rtx_raxtax_multi; the reference's `-t` of rayon threads, main.rs:40-57).  Flag names and file semantics follow the reference
 // (src/io.rs:112-154 Args, :202-263 get_output, :47-90 Checkpoint, :156-187 check_incomplete_output;
 // src/main.rs:72-99 database caching, :126-136 writer):
 //   PREFIX/raxtax.out   one line per result row            PREFIX/raxtax.tsv  (--tsv)
@@ -103,7 +104,7 @@ int main(int argc, char **argv) {
         t_log << (t_log.tellp() > 0 ? ", " : "") << '"' << what << "\": " << std::chrono::duration<double>(now - t_prev).count();
         t_prev = now;
     };
-    int device = 0;
+    std::vector<int> devices{0};
     size_t chunk = 32768;
     size_t block_bytes = (size_t)256 << 20;  // query file read and parsed in blocks of this size
     for (int i = 1; i < argc; i++) {
@@ -128,16 +129,27 @@ int main(int argc, char **argv) {
         else if (a == "--verbose" || a == "--quiet" || (a.size() >= 2 && a[0] == '-' && a[1] != '-' &&
                                                         a.find_first_not_of(a[1] == 'v' ? "v" : "q", 1) == std::string::npos &&
                                                         (a[1] == 'v' || a[1] == 'q'))) {}
-        else if (a == "--device") device = atoi(val());
+        else if (a == "--device") devices.assign(1, atoi(val()));
+        else if (a == "--gpus") {  // devices 0 .. N-1
+            const int n = atoi(val());
+            devices.clear();
+            for (int d = 0; d < n; d++) devices.push_back(d);
+        } else if (a == "--devices") {  // an explicit list; a device may be named twice (two handles on one GPU)
+            devices.clear();
+            std::stringstream ss(val());
+            std::string tok;
+            while (std::getline(ss, tok, ',')) if (!tok.empty()) devices.push_back(atoi(tok.c_str()));
+        }
         else if (a == "--batch") chunk = (size_t)atoll(val());
         else if (a == "--block-bytes") block_bytes = std::max<size_t>(1, (size_t)atoll(val()));
         else {
             fprintf(stderr, "usage: raxtax-hip -d DB.(fasta|bin) [-i QUERIES.fasta] [-o PREFIX] [--skip-exact-matches] [--raw-confidence] "
-                            "[--tsv] [--only-db] [--skip-db] [-c] [--redo] [--device N] [--batch N] [--block-bytes N]\n"
+                            "[--tsv] [--only-db] [--skip-db] [-c] [--redo] [--device N | --gpus N | --devices a,b,..] [--batch N] [--block-bytes N]\n"
                             "       (-t/--threads N, --pin, -v, -q of the reference are accepted and ignored)\n");
             return 64;
         }
     }
+    if (devices.empty()) { fprintf(stderr, "raxtax-hip: --gpus / --devices need at least one device\n"); return 64; }
     if (db.empty() || (qf.empty() && !only_db) || (only_db && skip_db)) {
         fprintf(stderr, "raxtax-hip: -d is required, -i unless --only-db; --only-db conflicts with --skip-db\n");
         return 64;
@@ -282,11 +294,24 @@ int main(int argc, char **argv) {
         reader.join();
         for (Parsed &pz : ready) rtx_queries_destroy(pz.qs);
     };
-    rtx_index *index = nullptr;
-    if (rtx_index_create_from_tree(device, tree, &index) != RTX_OK) {
-        fprintf(stderr, "[ERROR] %s\n", rtx_last_error());
-        stop_and_join_reader();
-        return 71;  // exitcode::OSERR
+    // one index handle per device, created side by side (each on a thread of its own: the builds run on their GPUs)
+    std::vector<rtx_index *> indices(devices.size(), nullptr);
+    {
+        std::vector<int> rcs(devices.size(), RTX_OK);
+        std::vector<std::string> errs(devices.size());
+        std::vector<std::thread> th;
+        for (size_t k = 0; k < devices.size(); k++)
+            th.emplace_back([&, k] {
+                rcs[k] = rtx_index_create_from_tree(devices[k], tree, &indices[k]);
+                if (rcs[k] != RTX_OK) errs[k] = rtx_last_error();
+            });
+        for (auto &t : th) t.join();
+        for (size_t k = 0; k < devices.size(); k++)
+            if (rcs[k] != RTX_OK) {
+                fprintf(stderr, "[ERROR] device %d: %s\n", devices[k], errs[k].c_str());
+                stop_and_join_reader();
+                return 71;  // exitcode::OSERR
+            }
     }
     lap("index");
     start_bin_writer();  // after the index: rtx_index_create_from_tree looks at the tree's k-mer map
@@ -328,7 +353,7 @@ int main(int argc, char **argv) {
             const uint8_t *bases;
             const uint64_t *off;
             rtx_queries_data(pz.qs, &bases, &off);
-            rc = rtx_raxtax(index, tree, nb, labels.data(), bases, off, skip_exact, raw, chunk, sender, &sink, tsv);
+            rc = rtx_raxtax_multi(indices.data(), (uint32_t)indices.size(), tree, nb, labels.data(), bases, off, skip_exact, raw, chunk, sender, &sink, tsv);
             n += nb;
         }
         rtx_queries_destroy(pz.qs);
@@ -352,7 +377,7 @@ int main(int argc, char **argv) {
         remove(ckp_path.c_str());
         if (!db_bin.empty()) remove(db_bin.c_str());
     }
-    rtx_index_destroy(index);
+    for (rtx_index *ix : indices) rtx_index_destroy(ix);
     rtx_tree_destroy(tree);
     return 0;
 }

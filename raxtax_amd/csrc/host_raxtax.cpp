@@ -24,39 +24,58 @@ void parallel_ranges(uint64_t n, unsigned nt, F fn) {
     for (auto &t : th) t.join();
 }
 
-// One chunk of queries travelling through the three stages of run().
+// One chunk of queries travelling through the stages of run().
 struct Chunk {
     uint64_t q0 = 0, nq = 0;
     std::vector<uint32_t> exact_ids;   // tree.sequences.get(query) per query, raxtax.rs:42
     std::vector<uint64_t> exact_off;
     std::vector<uint8_t> differ;       // raxtax.rs:43-53: exact matches with different parents
+    std::vector<std::string> out_msg, tsv_msg;
     rtx_result_view res{};
-    int stage = 0;                     // 1: exact matches looked up, 2: classified, 3: sent
+    int stage = 0;                     // 1: exact matches looked up (or left to the device), 2: classified, 3: formatted, 4: sent
 };
 
-// raxtax() (src/raxtax.rs:14-97) as a three-stage pipeline over chunks of `chunk_size` queries:
-//   lookup thread : exact-match ids of chunk c+1            (host hash map, raxtax.rs:42) -- only for a handle without the
-//                   device lookup (rtx_index_has_exact_lookup): otherwise the ids come back with the results of the device stage
-//   calling thread: device classification of chunk c        (rtx_classify_batch, raxtax.rs:42,55-71)
-//   format thread : lineage check of the exact matches (raxtax.rs:43-53), override + formatting + sender, chunk c-1
-//                   (raxtax.rs:73-87), messages in input order
-// The library keeps two result sets, so the view of chunk c stays valid until chunk c+2 is classified.
-int run(rtx_index *index, const rtx_tree *tree, uint64_t n_queries, const char *const *labels, const uint8_t *bases,
-        const uint64_t *base_off, bool skip_exact_matches, bool raw_confidence, uint64_t chunk_size,
+// raxtax() (src/raxtax.rs:14-97) as a pipeline over chunks of `chunk_size` queries on one or several device handles -- the
+// reference's `par_chunks(chunk_size)` (raxtax.rs:35-36) with GPUs in the place of rayon workers.  Chunk c belongs to handle
+// c mod n_dev; per handle
+//   device thread : classification of its chunks, one after the other  (rtx_classify_batch, raxtax.rs:42,55-71)
+//   format thread : lineage check of the exact matches (raxtax.rs:43-53), override + formatting (raxtax.rs:73-84), chunk by chunk
+// and for all of them
+//   lookup thread : exact-match ids (host hash map, raxtax.rs:42) -- only for handles without the device lookup
+//                   (rtx_index_has_exact_lookup): otherwise the ids come back with the results of the device stage
+//   calling thread: the sender, one message per query in INPUT order (raxtax.rs:85-87): chunk 0, 1, 2 ... as they become ready.
+// A handle keeps two result sets, so the view of its k-th chunk stays valid until its (k + 2)-th is classified.
+int run(rtx_index *const *indices, uint32_t n_dev, const rtx_tree *tree, uint64_t n_queries, const char *const *labels,
+        const uint8_t *bases, const uint64_t *base_off, bool skip_exact_matches, bool raw_confidence, uint64_t chunk_size,
         const raxtax::Sender &sender, bool tsv) {
-    if (!index || !tree || !base_off || !labels) { rtx::set_error("rtx_raxtax: null argument"); return RTX_ERR_INVALID; }
-    if (rtx_index_num_refs(index) != tree->num_tips) { rtx::set_error("index and tree disagree on num_tips"); return RTX_ERR_INVALID; }
-    if (chunk_size == 0 || chunk_size > n_queries) chunk_size = n_queries ? n_queries : 1;
+    if (!indices || n_dev == 0 || !tree || !base_off || !labels) { rtx::set_error("rtx_raxtax: null argument"); return RTX_ERR_INVALID; }
+    for (uint32_t d = 0; d < n_dev; d++) {
+        if (!indices[d]) { rtx::set_error("rtx_raxtax: null index handle"); return RTX_ERR_INVALID; }
+        if (rtx_index_num_refs(indices[d]) != tree->num_tips) { rtx::set_error("index and tree disagree on num_tips"); return RTX_ERR_INVALID; }
+        for (uint32_t e = 0; e < d; e++)
+            if (indices[e] == indices[d]) { rtx::set_error("rtx_raxtax_multi: the same handle twice (calls on one handle must be serialised)"); return RTX_ERR_INVALID; }
+    }
+    if (chunk_size == 0 || chunk_size > n_queries) chunk_size = std::max<uint64_t>(1, (n_queries + n_dev - 1) / n_dev);
     const uint32_t flags = (skip_exact_matches ? RTX_SKIP_EXACT_MATCHES : 0u) | (raw_confidence ? RTX_RAW_CONFIDENCE : 0u);
     const uint64_t n_chunks = (n_queries + chunk_size - 1) / chunk_size;
     const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-    const unsigned nt_lookup = std::min(4u, hw), nt_format = std::min(16u, hw);
-    const bool dev_lookup = rtx_index_has_exact_lookup(index) != 0;
+    const unsigned nt_lookup = std::min(4u, hw), nt_format = std::max(2u, std::min(16u, hw) / n_dev);
+    std::vector<uint8_t> dev_lookup(n_dev);
+    bool any_host_lookup = false;
+    for (uint32_t d = 0; d < n_dev; d++) {
+        dev_lookup[d] = rtx_index_has_exact_lookup(indices[d]) != 0;
+        any_host_lookup = any_host_lookup || !dev_lookup[d];
+    }
 
     std::vector<Chunk> chunks(n_chunks);
-    // busy seconds of the three stages (RTX_PIPELINE_TIMING=1 prints them: which stage bounds an end-to-end run)
+    for (uint64_t c = 0; c < n_chunks; c++) {
+        chunks[c].q0 = c * chunk_size;
+        chunks[c].nq = std::min<uint64_t>(chunk_size, n_queries - chunks[c].q0);
+    }
+    // busy seconds of the stages (RTX_PIPELINE_TIMING=1 prints them: which stage bounds an end-to-end run)
     const bool timing = getenv("RTX_PIPELINE_TIMING") != nullptr;
-    double busy_lookup = 0, busy_device = 0, busy_format = 0, busy_send = 0;
+    double busy_lookup = 0, busy_send = 0;
+    std::vector<double> busy_device(n_dev, 0.0), busy_format(n_dev, 0.0);
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     std::mutex mu;
     std::condition_variable cv;
@@ -79,15 +98,14 @@ int run(rtx_index *index, const rtx_tree *tree, uint64_t n_queries, const char *
         chunks[c].stage = stage;
         cv.notify_all();
     };
+    const uint64_t ahead = 2ull * n_dev;  // chunks a stage may run ahead of the next one
 
     std::thread lookup([&] {
         for (uint64_t c = 0; c < n_chunks; c++) {
-            if (c >= 2 && !wait_stage(c - 2, 2)) return;  // stay at most two chunks ahead of the device
             Chunk &ch = chunks[c];
+            if (dev_lookup[c % n_dev]) { set_stage(c, 1); continue; }  // Tree.sequences.get runs on the device, inside rtx_classify_batch
+            if (c >= ahead && !wait_stage(c - ahead, 2)) return;
             const double t_l0 = now();
-            ch.q0 = c * chunk_size;
-            ch.nq = std::min<uint64_t>(chunk_size, n_queries - ch.q0);
-            if (dev_lookup) { set_stage(c, 1); continue; }  // Tree.sequences.get runs on the device, inside rtx_classify_batch
             std::vector<const uint32_t *> ptr(ch.nq);
             std::vector<uint32_t> cnt(ch.nq);
             parallel_ranges(ch.nq, nt_lookup, [&](uint64_t a, uint64_t b) {
@@ -107,14 +125,40 @@ int run(rtx_index *index, const rtx_tree *tree, uint64_t n_queries, const char *
         }
     });
 
-    std::thread format([&] {
-        std::vector<std::string> out_msg, tsv_msg;
-        for (uint64_t c = 0; c < n_chunks; c++) {
+    auto device_loop = [&](uint32_t d) {
+        for (uint64_t c = d; c < n_chunks; c += n_dev) {
+            if (!wait_stage(c, 1)) return;
+            if (c >= ahead && !wait_stage(c - ahead, 3)) return;  // the result set of this handle's second-last chunk is reused now
+            Chunk &ch = chunks[c];
+            const double t_d0 = now();
+            int rc;
+            if (dev_lookup[d]) {
+                rc = rtx_classify_batch(indices[d], ch.nq, bases, base_off + ch.q0, nullptr, nullptr, flags, &ch.res);
+                const uint64_t *xo = nullptr;
+                const uint32_t *xi = nullptr;
+                if (!rc) rc = rtx_batch_exact_matches(indices[d], &xo, &xi);
+                if (!rc) {  // copied: the format thread reads them while the next chunk is classified
+                    ch.exact_off.assign(xo, xo + ch.nq + 1);
+                    ch.exact_ids.assign(xi, xi + xo[ch.nq]);
+                }
+            } else {
+                rc = rtx_classify_batch(indices[d], ch.nq, bases, base_off + ch.q0, ch.exact_ids.empty() ? nullptr : ch.exact_ids.data(),
+                                        ch.exact_off.data(), flags, &ch.res);
+            }
+            if (rc) { fail(rc, rtx_last_error()); return; }
+            busy_device[d] += now() - t_d0;
+            set_stage(c, 2);
+        }
+    };
+
+    auto format_loop = [&](uint32_t d) {
+        for (uint64_t c = d; c < n_chunks; c += n_dev) {
             if (!wait_stage(c, 2)) return;
+            if (c >= 2 * ahead && !wait_stage(c - 2 * ahead, 4)) return;  // bounded memory: the sender is at most 4 chunks per handle behind
             Chunk &ch = chunks[c];
             const double t_f0 = now();
-            out_msg.assign(ch.nq, std::string());
-            if (tsv) tsv_msg.assign(ch.nq, std::string());
+            ch.out_msg.assign(ch.nq, std::string());
+            if (tsv) ch.tsv_msg.assign(ch.nq, std::string());
             ch.differ.assign(ch.nq, 0);
             std::atomic<int> rc_fmt{0};
             parallel_ranges(ch.nq, nt_format, [&](uint64_t a, uint64_t b) {
@@ -140,71 +184,62 @@ int run(rtx_index *index, const rtx_tree *tree, uint64_t n_queries, const char *
                     if (tsv && tsv_buf.size() < need + rows * len) tsv_buf.resize(need + rows * len);
                     int64_t tsv_len = 0;
                     const int64_t n = rtx_format_query(tree, &ch.res, i, labels[q], bases + base_off[q], len,
-                                                       ch.exact_ids.data() + ch.exact_off[i], ch.exact_off[i + 1] - ch.exact_off[i],
-                                                       flags, out_buf.data(), out_buf.size(), tsv ? tsv_buf.data() : nullptr,
-                                                       tsv_buf.size(), &tsv_len);
+                                                       ch.exact_ids.data() + ch.exact_off[i], ne, flags, out_buf.data(), out_buf.size(),
+                                                       tsv ? tsv_buf.data() : nullptr, tsv_buf.size(), &tsv_len);
                     if (n < 0) { rc_fmt = (int)n; return; }
-                    out_msg[i].assign(out_buf.data(), (size_t)n);
-                    if (tsv) tsv_msg[i].assign(tsv_buf.data(), (size_t)tsv_len);
+                    ch.out_msg[i].assign(out_buf.data(), (size_t)n);
+                    if (tsv) ch.tsv_msg[i].assign(tsv_buf.data(), (size_t)tsv_len);
                 }
             });
             if (rc_fmt) { fail(rc_fmt, "formatting a result failed"); return; }
-            const double t_s0 = now();
-            busy_format += t_s0 - t_f0;
-            for (uint64_t i = 0; i < ch.nq; i++) {
-                const uint64_t q = ch.q0 + i;
-                if (ch.differ[i]) {
-                    fprintf(stderr, "[WARN ] Exact matches for %s differ above the leafs of the lineage tree!\n", labels[q]);
-                    warnings = true;
-                }
-                if (ch.res.status[i] != RTX_Q_OK) {
-                    // the reference aborts here (prob.rs:21/162); report and skip the query instead
-                    fprintf(stderr, "[ERROR] query %s has too few valid 8-mers (%u) to be classified\n", labels[q], ch.res.t[i]);
-                    continue;
-                }
-                std::optional<std::string> t;
-                if (tsv) t.emplace(std::move(tsv_msg[i]));
-                if (!sender(labels[q], std::move(out_msg[i]), std::move(t))) {
-                    fail(RTX_ERR_SENDER, "result sink closed");  // sender.send(..)?, raxtax.rs:87
-                    return;
-                }
-            }
-            std::vector<uint32_t>().swap(ch.exact_ids);
-            std::vector<uint64_t>().swap(ch.exact_off);
-            std::vector<uint8_t>().swap(ch.differ);
-            busy_send += now() - t_s0;
+            busy_format[d] += now() - t_f0;
             set_stage(c, 3);
         }
-    });
+    };
 
+    std::vector<std::thread> workers;
+    for (uint32_t d = 0; d < n_dev; d++) {
+        workers.emplace_back(device_loop, d);
+        workers.emplace_back(format_loop, d);
+    }
+    // the sender: messages in input order
     for (uint64_t c = 0; c < n_chunks; c++) {
-        if (!wait_stage(c, 1)) break;
-        if (c >= 2 && !wait_stage(c - 2, 3)) break;  // the result set of chunk c-2 is reused now
+        if (!wait_stage(c, 3)) break;
         Chunk &ch = chunks[c];
-        const double t_d0 = now();
-        int rc;
-        if (dev_lookup) {
-            rc = rtx_classify_batch(index, ch.nq, bases, base_off + ch.q0, nullptr, nullptr, flags, &ch.res);
-            const uint64_t *xo = nullptr;
-            const uint32_t *xi = nullptr;
-            if (!rc) rc = rtx_batch_exact_matches(index, &xo, &xi);
-            if (!rc) {  // copied: the format thread reads them while the next chunk is classified
-                ch.exact_off.assign(xo, xo + ch.nq + 1);
-                ch.exact_ids.assign(xi, xi + xo[ch.nq]);
+        const double t_s0 = now();
+        bool closed = false;
+        for (uint64_t i = 0; i < ch.nq && !closed; i++) {
+            const uint64_t q = ch.q0 + i;
+            if (ch.differ[i]) {
+                fprintf(stderr, "[WARN ] Exact matches for %s differ above the leafs of the lineage tree!\n", labels[q]);
+                warnings = true;
             }
-        } else {
-            rc = rtx_classify_batch(index, ch.nq, bases, base_off + ch.q0, ch.exact_ids.empty() ? nullptr : ch.exact_ids.data(),
-                                    ch.exact_off.data(), flags, &ch.res);
+            if (ch.res.status[i] != RTX_Q_OK) {
+                // the reference aborts here (prob.rs:21/162); report and skip the query instead
+                fprintf(stderr, "[ERROR] query %s has too few valid 8-mers (%u) to be classified\n", labels[q], ch.res.t[i]);
+                continue;
+            }
+            std::optional<std::string> t;
+            if (tsv) t.emplace(std::move(ch.tsv_msg[i]));
+            if (!sender(labels[q], std::move(ch.out_msg[i]), std::move(t))) closed = true;
         }
-        if (rc) { fail(rc, rtx_last_error()); break; }
-        busy_device += now() - t_d0;
-        set_stage(c, 2);
+        if (closed) { fail(RTX_ERR_SENDER, "result sink closed"); break; }  // sender.send(..)?, raxtax.rs:87
+        std::vector<uint32_t>().swap(ch.exact_ids);
+        std::vector<uint64_t>().swap(ch.exact_off);
+        std::vector<uint8_t>().swap(ch.differ);
+        std::vector<std::string>().swap(ch.out_msg);
+        std::vector<std::string>().swap(ch.tsv_msg);
+        busy_send += now() - t_s0;
+        set_stage(c, 4);
     }
     lookup.join();
-    format.join();
-    if (timing)
-        fprintf(stderr, "[TIMING] pipeline busy seconds over %llu chunk(s): lookup %.3f (%u threads), device %.3f, format %.3f (%u threads), sender %.3f\n",
-                (unsigned long long)n_chunks, busy_lookup, nt_lookup, busy_device, busy_format, nt_format, busy_send);
+    for (auto &t : workers) t.join();
+    if (timing) {
+        double bd = 0, bf = 0;
+        for (uint32_t d = 0; d < n_dev; d++) { bd = std::max(bd, busy_device[d]); bf = std::max(bf, busy_format[d]); }
+        fprintf(stderr, "[TIMING] pipeline busy seconds over %llu chunk(s) on %u handle(s): lookup %.3f (%s), device %.3f (busiest handle), format %.3f (%u threads per handle), sender %.3f\n",
+                (unsigned long long)n_chunks, n_dev, busy_lookup, any_host_lookup ? "host map" : "on the device", bd, bf, nt_format, busy_send);
+    }
     if (failed != RTX_OK) { rtx::set_error("%s", failed_msg.c_str()); return failed; }
     if (warnings)  // raxtax.rs:93-95
         fprintf(stderr, "\x1b[33m[WARN ]\x1b[0m Exact matches for some queries differ above the species level! Check the log file for more information!\n");
@@ -226,7 +261,7 @@ int raxtax(const std::vector<std::pair<std::string, std::vector<uint8_t>>> &quer
         bases.insert(bases.end(), queries[i].second.begin(), queries[i].second.end());
         off[i + 1] = bases.size();
     }
-    return run(index, tree, queries.size(), labels.data(), bases.data(), off.data(), skip_exact_matches, raw_confidence,
+    return run(&index, 1, tree, queries.size(), labels.data(), bases.data(), off.data(), skip_exact_matches, raw_confidence,
                chunk_size, sender, tsv);
 }
 
@@ -239,7 +274,21 @@ extern "C" int rtx_raxtax(rtx_index *index, const rtx_tree *tree, uint64_t n_que
     raxtax::Sender s = [&](const std::string &label, std::string &&out, std::optional<std::string> &&t) {
         return sender(sender_ctx, label.c_str(), out.c_str(), t ? t->c_str() : nullptr) == 0;
     };
-    return run(index, tree, n_queries, labels, bases, base_off, skip_exact_matches != 0, raw_confidence != 0, chunk_size, s,
+    return run(&index, 1, tree, n_queries, labels, bases, base_off, skip_exact_matches != 0, raw_confidence != 0, chunk_size, s,
+               tsv != 0);
+}
+
+// The same over several device handles (one per GPU, or several on one): the reference's parallel driver is one call inside the
+// process as well (par_chunks over a rayon pool, raxtax.rs:35-36, main.rs:40-57).  Chunks of `chunk_size` queries are dealt to the
+// handles in turn, one driving thread per handle; the messages reach the sender in input order.
+extern "C" int rtx_raxtax_multi(rtx_index *const *indices, uint32_t n_indices, const rtx_tree *tree, uint64_t n_queries,
+                                const char *const *labels, const uint8_t *bases, const uint64_t *base_off, int skip_exact_matches,
+                                int raw_confidence, uint64_t chunk_size, rtx_sender_fn sender, void *sender_ctx, int tsv) {
+    if (!sender) { rtx::set_error("rtx_raxtax_multi: null sender"); return RTX_ERR_INVALID; }
+    raxtax::Sender s = [&](const std::string &label, std::string &&out, std::optional<std::string> &&t) {
+        return sender(sender_ctx, label.c_str(), out.c_str(), t ? t->c_str() : nullptr) == 0;
+    };
+    return run(indices, n_indices, tree, n_queries, labels, bases, base_off, skip_exact_matches != 0, raw_confidence != 0, chunk_size, s,
                tsv != 0);
 }
 

@@ -75,10 +75,48 @@ def test_cli_outputs_resume_and_bin_cache(tmp_path, oracle):
     l3 = (out3 / "raxtax.out").read_text().splitlines()
     assert len({l.split("\t")[0] for l in l3}) == 600
     assert not (out3 / "raxtax.json").exists() and not (out3 / "raxtax.ckp").exists()   # -c cleans up
+    # ... and classifies like the FASTA it was made from: every line against the oracle under --skip-exact-matches (f3:
+    # tree.rs:147-164 -- taxonomy, lineages, exact-sequence map and k-mer map all come out of the file here)
+    by3 = {}
+    for l in l3:
+        by3.setdefault(l.split("\t")[0], []).append(l)
+    n_diff3 = 0
+    for label, seq in queries:
+        rows, raw = otree.classify(seq, skip_exact=True)
+        n_diff3 += otree.format_out(label, raw).split("\n") != by3[label]
+    allowed3 = json.loads((ROOT / "tests" / "golden" / "expected_excuses.json").read_text()).get("diptera600/skip=1/raw=0", {}).get("ties", 0)
+    print(f"CLI from the cached .bin, --skip-exact-matches: {n_diff3} of 600 queries differ from the oracle's text (ties allowed: {allowed3})")
+    assert n_diff3 <= allowed3
+
+    # ---- a .bin written by an INDEPENDENT encoder of the format (tests/test_bin_format.py, fed from the oracle's tree: what
+    # upstream's Tree::save_to_file would write) as the database: same text as from the FASTA
+    import numpy as np
+    from test_bin_format import write_bin_from_oracle
+    seq_of = dict(queries)
+    olabels = [l for l, _ in queries]
+    orig = otree.original_index()
+    seq_sorted = [seq_of[olabels[int(o)]] for o in orig]
+    ind = tmp_path / "independent.bin"
+    ind.write_bytes(write_bin_from_oracle(otree, otree.lineages, seq_sorted, np.random.default_rng(5)))
+    out5 = tmp_path / "run5"
+    run("-d", ind, "-i", FASTA, "-o", out5, "--tsv")
+    assert sorted((out5 / "raxtax.out").read_text().splitlines()) == sorted(lines)
+    assert sorted((out5 / "raxtax.tsv").read_text().splitlines()) == sorted((out / "raxtax.tsv").read_text().splitlines())
     # --only-db writes the database and stops
     out4 = tmp_path / "run4"
     run("-d", FASTA, "--only-db", "-o", out4)
     assert (out4 / "diptera_subset.bin").exists() and not (out4 / "raxtax.out").exists()
+
+
+def test_cli_on_several_handles(tmp_path):
+    """--devices 0,0: two index handles (here on the one GPU of the box; --gpus N puts them on devices 0 .. N-1), one driving thread
+    each, chunks dealt in turn -- the output files are those of a single handle, line for line and in the same order."""
+    a, b = tmp_path / "one", tmp_path / "two"
+    run("-d", FASTA, "-i", FASTA, "-o", a, "--skip-db", "--tsv", "--batch", 64)
+    run("-d", FASTA, "-i", FASTA, "-o", b, "--skip-db", "--tsv", "--batch", 64, "--devices", "0,0")
+    for f in ("raxtax.out", "raxtax.tsv", "raxtax.ckp"):
+        assert (a / f).read_text() == (b / f).read_text(), f
+    assert run("-d", FASTA, "-i", FASTA, "-o", tmp_path / "none", "--gpus", "0", ok=False).returncode == 64
 
 
 def test_cli_streamed_query_ingest(tmp_path):

@@ -60,6 +60,23 @@ def test_exact_copies_find_their_reference(cfg2):
         assert res.t[q] >= 2
 
 
+def test_exact_matches_looked_up_on_the_device(cfg2):
+    """a3 (Tree.sequences.get, raxtax.rs:42) on the device for all 100 000 queries: the ids are those of the host map, and the
+    result of the batch is the one the host's ids gave (both exact-match modes: the zeroing of raxtax.rs:65-68 reads them)."""
+    qs, index, res = cfg2["qs"], cfg2["index"], cfg2["res"]
+    ex_ids, ex_off = cfg2["ex"]
+    assert index.has_exact_lookup
+    r2 = index.classify(qs.bases, qs.base_off)                       # no ids: the device looks them up
+    ids_d, off_d = index.device_exact_matches()
+    assert np.array_equal(off_d, ex_off) and np.array_equal(ids_d, ex_ids)
+    for f in ("row_off", "row_lineage", "row_conf", "row_local_signal", "global_signal", "t", "status"):
+        assert np.array_equal(getattr(r2, f), getattr(res, f)), f
+    a = index.classify(qs.bases, qs.base_off, skip_exact_matches=True)
+    b = index.classify(qs.bases, qs.base_off, ex_ids, ex_off, skip_exact_matches=True)
+    for f in ("row_off", "row_lineage", "row_conf", "global_signal"):
+        assert np.array_equal(getattr(a, f), getattr(b, f)), f
+
+
 @pytest.mark.parametrize("skip", [False, True])
 def test_seeded_oracle_sample(cfg2, oracle, emul, skip):
     """The sample as a batch of its own through the default (pruned) handle: first the run exactly as it was -- the counts of the

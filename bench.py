@@ -77,7 +77,7 @@ def parse():
     ap.add_argument("--no-extras", action="store_true", help="only the headline: no H2D / end-to-end / unpruned legs, no divergence sweep")
     ap.add_argument("--host-exact-match", action="store_true",
                     help="Tree.sequences.get on the host, once, untimed (rounds 1-2); default: on the device inside the timed step")
-    ap.add_argument("--e2e-chunk", type=int, default=262144, help="queries per device batch of the end-to-end leg (rtx_raxtax chunk_size)")
+    ap.add_argument("--e2e-chunk", type=int, default=131072, help="queries per device batch of the end-to-end leg (rtx_raxtax chunk_size)")
     ap.add_argument("--skip-exact-matches", action="store_true")
     ap.add_argument("--hit-events-only", action="store_true",
                     help="HIP events around hit_count only (default: around every kernel; costs < 0.1 % of a step)")
@@ -232,84 +232,103 @@ def device_source_sha() -> str:
     return h.hexdigest()[:16]
 
 
-def measured_traffic(refs: int, query_len: int, sub_batch: int, kinds: int = 1):
-    """Fabric-side bytes per hit_count launch from the committed rocprofv3 PMC passes (profiles/traffic.json, written
-    by tools/make_traffic.py from `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE` runs of this bench): FETCH_SIZE x 2 as
-    MI355X_MICROARCH.md prescribes for 16-byte-per-lane reads on gfx950, + WRITE_SIZE.  Returned only if the
-    profile was taken on this configuration AND on this build of the kernels; else null (PMC counters cannot be read
-    from inside the process being measured)."""
+def measured_traffic(refs: int, query_len: int, queries: int, pruned: bool):
+    """Fabric-side bytes of the hit_count launches from the committed rocprofv3 PMC passes (profiles/traffic.json, written by
+    tools/make_traffic.py from `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE` runs of THIS bench command at THIS size: one whole step, every
+    sub-batch): per kind of launch -- "live" (the tiles of the database that are counted) and "bounds" (the same kernel on the union
+    bitmap, tile pruning) -- the sums over the launches of a step.  FETCH_SIZE x 2 as MI355X_MICROARCH.md prescribes for
+    16-byte-per-lane reads on gfx950, + WRITE_SIZE.  Returned only if the profile was taken on this configuration AND on this build of
+    the kernels; else None (PMC counters cannot be read from inside the process being measured)."""
     f = ROOT / "profiles" / "traffic.json"
     if not f.exists():
         return None, "no profiles/traffic.json"
     try:
         t = json.loads(f.read_text())
-        e = t.get("configs", {}).get(f"refs={refs},query_len={query_len}")
+        e = t.get("configs", {}).get(f"refs={refs},query_len={query_len},queries={queries}")
         if e is None:
-            return None, "no PMC profile of this configuration"
-        if e.get("launches_per_sub_batch", 1) != kinds:
+            return None, "no PMC profile of this configuration (refs, query length, queries per step)"
+        if bool(e.get("pruned")) != bool(pruned):
             return None, "PMC profile was taken with another setting of the tile pruning"
         if e.get("device_source_sha") != device_source_sha():
-            return None, "PMC profile is of another build of the kernels (re-run tools/profile_bench.sh)"
-        per_query = (2.0 * e["hit_count_fetch_kb"] + e["hit_count_write_kb"]) * 1024.0 / e["queries_per_launch"]
-        return dict(per_query=per_query, launches_per_sub_batch=e.get("launches_per_sub_batch", 1), fetch_per_query=2.0 * e["hit_count_fetch_kb"] * 1024.0 / e["queries_per_launch"],
-                    write_per_query=e["hit_count_write_kb"] * 1024.0 / e["queries_per_launch"], source=e.get("source", "")), None
+            return None, "PMC profile is of another build of the kernels (re-run tools/profile_bench.sh + tools/make_traffic.py)"
+        out = {}
+        for kind, k in e["kinds"].items():
+            n = max(int(k["launches"]), 1)
+            out[kind] = dict(launches=n, fetch=2.0 * k["fetch_kb"] * 1024.0 / n, write=k["write_kb"] * 1024.0 / n,
+                             l2_hit_rate=(k["tcc_hit"] / k["tcc_req"]) if k.get("tcc_req") else None)
+            out[kind]["bytes"] = out[kind]["fetch"] + out[kind]["write"]
+        out["source"] = e.get("source", "")
+        return out, None
     except Exception as ex:  # noqa: BLE001 - a broken profile file must not break the bench
         return None, f"profiles/traffic.json unreadable: {ex}"
 
 
 def roofline_block(args, work, prob_work, stage_ms, stage_n, n_queries_step, query_len, prune=None, ntiles=None):
-    """Roofline of the dominant kernel, hit_count, per launch (one launch = one sub-batch).  With tile pruning the launch
-    is the counting of the live tiles (the bounds pass before it -- the same kernel on the union bitmap + prune_kernel -- is
-    timed as a stage of its own and reported under "tile_pruning")."""
-    # launches of the hit_count kernel: one per sub-batch, or two with tile pruning (bounds on the union bitmap + the live tiles;
-    # stage tile_bounds is the first of them) -- launch_ms is their mean, as rocprofv3 --stats reports it for the kernel
+    """Roofline of the dominant kernel, hit_count, per launch (one launch = one sub-batch).  With tile pruning the kernel runs twice
+    per sub-batch: on the union bitmap (the bounds: stage tile_bounds) and on the live (pair, tile) blocks of the database (stage
+    hit_count).  The two kinds differ by a factor of five in bytes and are reported apart: the top level is the counting of the live
+    tiles, `bounds_pass` the other; `launch_ms_both_kinds` is their mean, which is how rocprofv3 --stats reports the kernel."""
     n_sub = max(stage_n["hit_count"], 1)
-    kinds = 2 if stage_n.get("tile_bounds") else 1
-    n_launch = n_sub * kinds
-    launch_ms = (stage_ms["hit_count"] + stage_ms.get("tile_bounds", 0.0)) / n_launch
-    launches_per_step = n_launch / args.steps
-    q_per_launch = n_queries_step / (n_sub / args.steps)                                # queries of a sub-batch: every launch sees them all
-    sec = launch_ms * 1e-3
-    bitmap_per_q = work["bitmap_bytes_read"] / n_queries_step                          # both launches
+    pruned = bool(stage_n.get("tile_bounds"))
+    launches_per_step = n_sub / args.steps
+    q_per_launch = n_queries_step / launches_per_step                                   # queries of a sub-batch (mean: the last one is short)
+    live_ms = stage_ms["hit_count"] / n_sub
+    live_per_q = work.get("live_bytes", work["bitmap_bytes_read"]) / n_queries_step
+    bounds_per_q = work.get("bounds_bytes", 0) / n_queries_step
     alg_per_q = (4 * work["sum_hits"] + work["sum_query_bytes"]) / n_queries_step      # SURVEY.md 8d: 4 H_q + L_q
-    achieved = bitmap_per_q * q_per_launch / kinds / sec / 1e9
-    alg_gbs = alg_per_q * q_per_launch / kinds / sec / 1e9
-    tr, why = measured_traffic(args.refs, query_len, args.sub_batch, kinds)
+    achieved = live_per_q * q_per_launch / (live_ms * 1e-3) / 1e9
+    step_ms_hit = (stage_ms["hit_count"] + stage_ms.get("tile_bounds", 0.0)) / args.steps
+    alg_gbs = alg_per_q * n_queries_step / (step_ms_hit * 1e-3) / 1e9                  # against everything the kernel does in a step
+    tr, why = measured_traffic(args.refs, query_len, n_queries_step, pruned)
     out = {
-        # the unit that limits the kernel: the path from the XCD's L2 through the vector L1 (rows are gathered by
-        # index, 1 KiB per wave-instruction; the index is far larger than L2 + Infinity Cache only in bytes that are
-        # rarely asked for).  achieved = bitmap-row bytes requested per launch / launch time.
+        # the unit that limits the kernel: the path from the XCD's L2 through the vector L1 (rows are gathered by index, 1 KiB per
+        # wave-instruction).  achieved = bitmap-row bytes requested per launch / launch time.
         "bound": "l2", "kernel": "hit_count_kernel" if args.no_pair else "hit_count_pair_kernel",
+        "launch": "the tiles of the database that are counted" + (" (live tiles; the bounds pass of the tile pruning: bounds_pass)" if pruned else ""),
         "achieved": achieved, "peak": L2_PEAK_GBS, "unit": "GB/s", "frac": achieved / L2_PEAK_GBS,
         "frac_of_measured_l2_gather_rate": achieved / L2_GATHER_GBS,
-        "launch_ms": launch_ms, "launches_per_step": launches_per_step, "queries_per_launch": q_per_launch,
-        "requested_bytes_per_query": bitmap_per_q,
-        # SURVEY.md 8d's per-unit figure (u32 postings the reference would stream) -- a ratio, not a fraction: one
-        # bitmap bit stands for a 4-byte posting
+        "launch_ms": live_ms, "launches_per_step": launches_per_step, "queries_per_launch": q_per_launch,
+        "requested_bytes_per_query": live_per_q,
+        # SURVEY.md 8d's per-unit figure (u32 postings the reference would stream) -- a ratio, not a fraction: one bitmap bit stands
+        # for a 4-byte posting, and with tile pruning most postings are never touched
         "algorithmic_bytes_per_query": alg_per_q, "algorithmic_GBps": alg_gbs,
         "algorithmic_ratio_to_hbm_peak": alg_gbs / HBM_PEAK_GBS,
         "traffic": None, "hbm_achieved": None, "hbm_peak": HBM_PEAK_GBS, "hbm_frac": None,
     }
+    if pruned:
+        b_n = max(stage_n["tile_bounds"], 1)
+        b_ms = stage_ms["tile_bounds"] / b_n
+        b_ach = bounds_per_q * q_per_launch / (b_ms * 1e-3) / 1e9
+        out["launch_ms_both_kinds"] = (stage_ms["hit_count"] + stage_ms["tile_bounds"]) / (n_sub + b_n)
+        out["bounds_pass"] = {"launch_ms": b_ms, "requested_bytes_per_query": bounds_per_q, "achieved": b_ach, "frac": b_ach / L2_PEAK_GBS,
+                              "frac_of_measured_l2_gather_rate": b_ach / L2_GATHER_GBS, "traffic": None,
+                              "note": "the same kernel on the union bitmap (one column per block of 64 references, 66 MB at 500k references: it "
+                                      "sits in the 256 MB Infinity Cache -- what FETCH_SIZE counts here are refills of the eight L2s from it, not HBM reads)"}
     if prune is not None and prune.get("pairs"):
-        b_n = max(stage_n.get("tile_bounds", 0), 1)
         out["tile_pruning"] = {
             "live_tiles_per_pair": prune["live_tiles_per_pair"], "tiles": ntiles,
             "mean_threshold": prune["mean_threshold"], "mean_best_hit_lower_bound": prune["mean_best_hit_lower_bound"],
             "tiles_above_threshold_per_query": prune.get("tiles_above_threshold_per_query"),     # what exact knowledge would count
             "queries_with_threshold": prune.get("queries_with_threshold"),
-            "bounds_launch_ms": stage_ms.get("tile_bounds", 0.0) / b_n,
-            "note": "the hit_count kernel runs twice per sub-batch: against the union bitmap (bounds per block of 64 references; "
-                    "bounds_launch_ms) and on the live (pair, tile) blocks; requested bytes, traffic and launch_ms are means over both "
-                    "launches, as rocprofv3 --stats reports the kernel.  A pruned query's references with a count up to its threshold "
-                    "carry < 1e-12 of probability together (rtx_prune.hip); --no-tile-prune counts every tile",
+            "note": "a pruned query's references with a count up to its threshold carry < 1e-12 of probability together (rtx_prune.hip); "
+                    "value_unpruned counts every tile, divergence_sweep shows how the live tiles grow with the distance of a query from its best hit",
         }
     if tr is not None:
-        out["traffic"] = tr["per_query"] * q_per_launch / kinds          # HBM/fabric bytes per launch (PMC)
-        out["hbm_achieved"] = out["traffic"] / sec / 1e9
+        live = tr.get("live") or tr.get("all")
+        out["traffic"] = live["bytes"]                                   # fabric bytes per launch (PMC), means over the launches of a step
+        out["hbm_achieved"] = live["bytes"] / (live_ms * 1e-3) / 1e9
         out["hbm_frac"] = out["hbm_achieved"] / HBM_PEAK_GBS
-        out["traffic_fetch_bytes_per_query"] = tr["fetch_per_query"]
-        out["traffic_write_bytes_per_query"] = tr["write_per_query"]
+        out["traffic_fetch_bytes"] = live["fetch"]
+        out["traffic_write_bytes"] = live["write"]
+        out["l2_hit_rate"] = live["l2_hit_rate"]
+        out["traffic_launches_profiled"] = live["launches"]
         out["traffic_source"] = tr["source"]
+        if pruned and "bounds" in tr:
+            b = tr["bounds"]
+            bp = out["bounds_pass"]
+            bp["traffic"] = b["bytes"]
+            bp["fabric_achieved"] = b["bytes"] / (bp["launch_ms"] * 1e-3) / 1e9
+            bp["l2_hit_rate"] = b["l2_hit_rate"]
     else:
         out["traffic_note"] = why
     # secondary: the probability stage (prob.rs:43-90).  ops_prob = D_q (n_q + 1) (2 exp + 1 log), SURVEY.md 8d
@@ -479,7 +498,8 @@ def main():
         parallelism = (f"references sharded x{world} (contiguous id ranges), queries replicated; all-reduce of histograms + all-gather of prefix sums"
                        if args.shard_mode == "refs" else
                        f"k-mers sharded x{world}, queries replicated; all-reduce of the u16 per-reference hit counts")
-        workload = (f"{args.queries} synthetic COI-length (658 bp) queries vs {args.refs}-seq reference DB sharded by reference id "
+        workload = (f"{args.queries} synthetic COI-length (658 bp) queries vs {args.refs}-seq reference DB sharded by "
+                    f"{'reference id' if args.shard_mode == 'refs' else 'k-mer (every rank holds the posting lists of a k-mer range over all references)'} "
                     f"over {world} GPU(s) (BASELINE.json configs[4] shape)")
     else:
         qs = synth.make_queries(db, args.queries, seed=3 + rank, first_label=rank * args.queries)   # rank-specific queries

@@ -316,6 +316,9 @@ int rtx_batch_stage_times(rtx_index *index, float ms[RTX_NUM_STAGES], uint32_t l
  * bytes the hit_count kernel actually requested. */
 int rtx_batch_work(rtx_index *index, uint64_t *sum_hits, uint64_t *sum_query_bytes,
                    uint64_t *bitmap_bytes_read);
+/* bitmap_bytes_read split by the kind of launch of the hit_count kernel: the tiles of the database it counted, and -- with tile pruning --
+ * the bounds pass on the union bitmap */
+int rtx_batch_work_split(rtx_index *index, uint64_t *live_bytes, uint64_t *bounds_bytes);
 /* Algorithmic work of the probability stage of the last rtx_batch_run (prob.rs:43-90):
  * sum over queries of D_q (n_q + 1) -- the points of the pmf/cmf grid the reference evaluates, D_q = number of
  * distinct hit counts, n_q = t_q / 2 -- and of D_q.  ops_prob = 3 x grid points (2 exp + 1 log each). */

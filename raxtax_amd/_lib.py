@@ -109,6 +109,7 @@ _SIGNATURES = {
     "rtx_batch_stage_times": (C.c_int, [C.c_void_p, f32p, u32p]),
     "rtx_batch_work": (C.c_int, [C.c_void_p, u64p, u64p, u64p]),
     "rtx_batch_prob_work": (C.c_int, [C.c_void_p, u64p, u64p]),
+    "rtx_batch_work_split": (C.c_int, [C.c_void_p, u64p, u64p]),
     "rtx_debug_kmers": (C.c_int, [C.c_void_p, C.c_uint64, u16p, u32p]),
     "rtx_debug_hit_counts": (C.c_int, [C.c_void_p, C.c_uint64, u16p]),
     "rtx_debug_prob_table": (C.c_int, [C.c_void_p, C.c_uint64, f64p, f64p]),

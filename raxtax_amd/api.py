@@ -301,7 +301,9 @@ class Index:
     def work(self):
         a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
         check(self._lib.rtx_batch_work(self._h, C.byref(a), C.byref(b), C.byref(c)))
-        return dict(sum_hits=a.value, sum_query_bytes=b.value, bitmap_bytes_read=c.value)
+        live, bounds = C.c_uint64(), C.c_uint64()
+        check(self._lib.rtx_batch_work_split(self._h, C.byref(live), C.byref(bounds)))
+        return dict(sum_hits=a.value, sum_query_bytes=b.value, bitmap_bytes_read=c.value, live_bytes=live.value, bounds_bytes=bounds.value)
 
     def prob_work(self):
         """Grid points D_q (n_q + 1) of prob.rs:43-90 summed over the queries of the last run."""

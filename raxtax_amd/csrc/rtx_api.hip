@@ -1939,6 +1939,26 @@ int rtx_batch_work(rtx_index *ix, uint64_t *sum_hits, uint64_t *sum_query_bytes,
     return RTX_OK;
 }
 
+// bitmap_bytes_read of rtx_batch_work split by launch kind: the counting of the (live) tiles of the database, and the bounds pass of the
+// tile pruning on the union bitmap (0 if the run did not prune)
+int rtx_batch_work_split(rtx_index *ix, uint64_t *live_bytes, uint64_t *bounds_bytes) {
+    uint64_t total = 0;
+    int rc = rtx_batch_work(ix, nullptr, nullptr, &total);
+    if (rc) return rc;
+    uint64_t bounds = 0;
+    if (ix->pair_used && ix->prune_used) {
+        const uint32_t n_sub = (uint32_t)((ix->n_q + ix->sub_batch - 1) / ix->sub_batch);
+        const size_t ng = (size_t)n_sub * ix->groups_per_sub;
+        std::vector<uint32_t> gr(ng);
+        RTX_HIP(hipMemcpy(gr.data(), ix->d_group_rows.p + ng, ng * 4, hipMemcpyDeviceToHost));
+        const uint64_t urow_bytes = ((ix->u_nblocks + 7) / 8 + ix->u_ntiles - 1) / ix->u_ntiles;
+        for (size_t g = 0; g < ng; g++) bounds += (uint64_t)gr[g] * urow_bytes;
+    }
+    if (live_bytes) *live_bytes = total - bounds;
+    if (bounds_bytes) *bounds_bytes = bounds;
+    return RTX_OK;
+}
+
 int rtx_batch_prob_work(rtx_index *ix, uint64_t *sum_grid_points, uint64_t *sum_distinct_counts) {
     if (!ix) { set_error("null index handle"); return RTX_ERR_INVALID; }
     int rc = bind(ix);

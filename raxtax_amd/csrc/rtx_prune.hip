@@ -22,6 +22,19 @@
 //     prefix sum of the pruned run is within a few eps of the full one.  eps = 1e-12 (north_star asks for 1e-6).
 //     With a full-overlap reference (M = t) prob.rs:24-41 applies: table[m] = pmf_m(n), table[t] = 1: u = the largest
 //     count with N pmf_u(n) <= eps.
+//     (3) The tighter version of (2), the one in force.  (2) prices every dropped reference at the tail of the largest dropped
+//     count at i*, where G is still ~ eps / N^2 -- but a dropped reference only matters where its excursion beats the product of
+//     the cmfs of H.  With f'_r(i) = pmf_r(i) prod_{kept r' != r} cmf_{r'}(i) <= G(i) the density of the pruned Z' over i (every
+//     kept reference, a member of H included: pmf_h G / cmf_h <= G), F' = sum_r f'_r <= min(Z', N G):
+//       beta  = what the dropped references hold themselves at i > i*  <= sum_{i>i*} G(i) sum_{dropped} pmf_r(i) <= N sum_{i>i*} G(i) pmf_u(i)
+//               (E[G(X) ; X > i*] rises with the count, G rises with i: worst case everything at u);
+//       gamma = what their removal adds to the kept entries = sum_{i>i*} F'(i) (1 - prod_dropped cmf_r(i))
+//               <= Z' [ sum_{i in W} min(1, N G(i)) N tail_u(i) + N tail_u(end of W) ]   for any window W = (i*, i_w].
+//     With alpha <= delta from (1): every probability and every sum of probabilities over any set of references moves by at most
+//     2 (alpha + beta + gamma) / min(Z, Z') (Z, Z' >= 1 - 2 eps).  The kernel takes W = 64 values of i (lanes), tail_u(i) <= the sum of
+//     pmf_u over the rest of W + R, R = (n - i_w) pmf_u(i_w + 1) >= tail_u(i_w) once pmf_u falls there, and searches the largest u
+//     below min H with N [sum_W min(1, N G) S_u + R] <= eps / 2 and N [sum_W G pmf_u + R] <= eps / 2 by bisection, starting from
+//     the u of (2) (a valid threshold on its own).  On the bench workload u rises from ~365 to ~440 (t ~ 640, best hit ~580).
 // A tile is dead for a query if u >= 1 and ub(T) <= u (a query without a threshold has every tile counted); a (pair, tile)
 // block of hit_count_pair_kernel leaves at once if the tile is dead for both queries.  The references that are never counted
 // are booked into histogram bin 0: cmf_0 = 1, so they drop out of every product -- the approximation bounded in (2) -- and
@@ -37,6 +50,7 @@
 namespace rtx {
 
 static constexpr double kPruneLnEps = -27.631021115928547;  // ln 1e-12
+static constexpr double kPruneHalfEps = 0.5e-12;
 
 __device__ __forceinline__ uint32_t wave_max_u32p(uint32_t v) {
 #pragma unroll
@@ -234,6 +248,45 @@ __global__ __launch_bounds__(64) void prune_kernel(PruneParams p, ProbTables tb)
                     first_fail = 0xFFFFFFFFu - wave_max_u32p(0xFFFFFFFFu - first_fail);
                     u_max = first_fail - 1u;
                     i1_q = i1;
+                    // ---- the tighter criterion (header, "(3)"): the same two error terms, but every i weighted with what G leaves of
+                    // it.  Lanes <-> the window i = i1 .. i1 + 63 (beyond it G counts as 1 and the tail of u as one lump R).
+                    {
+                        const uint32_t iw = i1 + lane;
+                        const bool vi = iw <= n;
+                        double lnG = 0.0;
+                        unsigned long long hb = __ballot(hm != 0u);
+                        while (hb) {  // wave-uniform: the members of H
+                            const int h = __builtin_ctzll(hb);
+                            hb &= hb - 1ull;
+                            const uint32_t m = (uint32_t)__builtin_amdgcn_readlane((int)hm, h);
+                            lnG += Ct[(size_t)m * (n + 1) + (vi ? iw : n)];
+                        }
+                        const double gw = vi ? exp(lnG) : 0.0;                         // G(i)
+                        const double ww = vi ? exp(fmin(0.0, ln_n + lnG)) : 0.0;      // min(1, N G(i))
+                        const uint32_t i_last = i1 + 63u < n ? i1 + 63u : n;
+                        const double nn = (double)p.n_refs;
+                        auto crit = [&](uint32_t u) -> bool {
+                            const double P = vi ? exp(ln_pmf_tab(lf, t, n, u, iw, ln_total)) : 0.0;  // pmf_u(i)
+                            double R = 0.0;   // everything of pmf_u behind the window
+                            bool falling = true;
+                            if (i_last < n) {
+                                const uint32_t j = i_last + 1u;
+                                const double up = (double)(u + j) * (double)(n - j), dn = (double)(j + 1u) * (double)(t - u + n - j - 1u);
+                                falling = up < dn;  // pmf_u(j + 1) < pmf_u(j), and the ratio falls with j
+                                R = (double)(n - i_last) * exp(ln_pmf_tab(lf, t, n, u, j, ln_total));
+                            }
+                            const double incl = wave_incl_scan_f64(P);
+                            const double S = (readlane_f64(incl, 63) - incl) + R;     // >= tail_u(i) = sum_{j > i} pmf_u(j)
+                            const double a = wave_sum_f64(ww * S), b = wave_sum_f64(gw * P);
+                            return falling && nn * (a + R) <= kPruneHalfEps && nn * (b + R) <= kPruneHalfEps;
+                        };
+                        uint32_t lo = u_max, hi = h_min - 1u;
+                        while (lo < hi) {  // wave-uniform
+                            const uint32_t mid = (lo + hi + 1u) >> 1;
+                            if (crit(mid)) lo = mid; else hi = mid - 1u;
+                        }
+                        u_max = lo;
+                    }
                 }
             }
         }

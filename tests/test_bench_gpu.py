@@ -31,6 +31,12 @@ def test_single_gpu_line_is_physical():
     assert roof["traffic"] is None or roof["hbm_frac"] <= 1.0          # no PMC profile of this toy configuration
     assert 0 < roof["prob_stage"]["frac"] < 1.0 and roof["prob_stage"]["ops_prob_per_query"] > 1000
     assert all(v > 0 for k, v in r["stage_ms_per_step"].items() if k not in ("lineage_walk", "tile_bounds", "tile_prune"))   # the walk rides inside taxon_prefix; 3 tiles: no pruning
+    # the caveats the line carries itself: queries crossing PCIe every step, end to end through rtx_raxtax to strings, every tile
+    # counted, the sweep over the divergence of the queries
+    assert 0 < r["value_incl_h2d"]["value"] and 0 < r["value_end_to_end"]["value"] and 0 < r["value_unpruned"]["value"]
+    assert r["value_end_to_end"]["text_bytes_per_query"] > 50
+    assert [x["mu_q"] for x in r["divergence_sweep"]["rows"]] == [0.02, 0.05, 0.1, 0.15] and all(x["value"] > 0 for x in r["divergence_sweep"]["rows"])
+    assert "device" in r["config"]["exact_match_lookup"] and r["stage_ms_per_step"]["exact_match"] > 0
     cpu = r["cpu_baseline"]
     assert cpu["kind"] == "port" and cpu["value"] > 0 and cpu["cores"] >= 1 and cpu["one_thread"]["value"] > 0
     assert "cpu_model" in cpu and cpu["unit"] == "queries/s"

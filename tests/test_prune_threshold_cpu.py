@@ -85,11 +85,15 @@ def test_everything_else_exactly_at_the_threshold(emul, oracle, t, n_refs, best,
         pytest.skip(f"no threshold for t={t} M={M}: nothing is pruned")
     worst = 0.0
     # (1) H at the top, everything else EXACTLY at u; (2) ... one below; (3) half at u, half without a hit;
-    # (4) a crowd just ABOVE the threshold (kept) on top of the crowd at it; (5) everything else spread over [0, u]
+    # (4) a crowd just ABOVE the threshold (kept) on top of the crowd at it; (5) everything else spread over [0, u]; (6), (7) below
     for k, rest in enumerate((lambda n: np.full(n, u), lambda n: np.full(n, max(u - 1, 0)),
                               lambda n: np.where(np.arange(n) % 2 == 0, u, 0),
                               lambda n: np.where(np.arange(n) % 50 == 0, np.minimum(u + 1 + (np.arange(n) // 50) % 7, int(0.8 * M)), u),
-                              lambda n: rng.integers(0, u + 1, n))):
+                              lambda n: rng.integers(0, u + 1, n),
+                              # (6) half of the database just above the threshold (kept: they carry the density F' of Z'), half at it
+                              lambda n: np.where(np.arange(n) % 2 == 0, np.minimum(u + 1 + np.arange(n) % 3, int(0.8 * M)), u),
+                              # (7) a second family as good as H elsewhere in the database (kept), the rest at the threshold
+                              lambda n: np.where(np.arange(n) < 200, M - (np.arange(n) % 9), u))):
         counts = np.concatenate([block, rest(n_refs - n_h)]).astype(np.uint16)
         u2, err = check_histogram(emul, oracle, lf, t, counts, block, f"t={t} N={n_refs} M={M} |H|={n_h} pattern {k}")
         assert u2 == u
@@ -122,3 +126,26 @@ def test_the_threshold_is_not_vacuous(emul, oracle):
         tz_o, z_o, rc = oracle.prob_tables_batch(np.array([t], np.uint32), counts[None, :])
         mass = float(tz_o[0][u + du] * (n_refs - 5))
         print(f"everything else at u + {du} = {u + du}: the oracle gives those references {mass:.3e} together")
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_cases(emul, oracle, seed):
+    """Random t, database size, best hit and best block (ten per seed) against the two hardest patterns."""
+    rng = np.random.default_rng(1000 + seed)
+    n_thr = 0
+    for _ in range(10):
+        t = int(rng.integers(40, 1024))
+        n_refs = int(rng.choice([20_000, 200_000, 2_000_000]))
+        M = int(rng.uniform(0.35, 0.99) * t)
+        n_h = int(rng.choice([1, 2, 7, 30, 64]))
+        lf = _lnfact(oracle, 2 * t + 8)
+        block = np.sort(rng.integers(int(0.8 * M) + 1, M + 1, n_h).astype(np.uint32))[::-1].copy()
+        block[0] = M
+        u, _ = threshold(emul, lf, t, n_refs, block)
+        if u == 0:
+            continue
+        n_thr += 1
+        for rest in (lambda n: np.full(n, u), lambda n: np.where(np.arange(n) % 2 == 0, np.minimum(u + 1 + np.arange(n) % 3, max(int(0.8 * M), u)), u)):
+            counts = np.concatenate([block, rest(n_refs - n_h)]).astype(np.uint16)
+            check_histogram(emul, oracle, lf, t, counts, block, f"t={t} N={n_refs} M={M} |H|={n_h}")
+    assert n_thr >= 5

@@ -1,13 +1,14 @@
 #!/usr/bin/env python3
 """Turns rocprofv3 PMC passes of bench.py into the committed evidence under profiles/:
 
-  tools/make_traffic.py --tag r2 --refs 500000 --queries-per-launch 10240 \
-        --fetch gpurun_out/r2_fetch --write gpurun_out/r2_write [--tcc gpurun_out/r2_tcc] [--note "..."]
+  tools/make_traffic.py --tag r3 --refs 500000 --queries 1000000 \
+        --fetch gpurun_out/r3_fetch --write gpurun_out/r3_write [--tcc gpurun_out/r3_tcc] [--note "..."]
 
   * profiles/<tag>_pmc_summary.csv   per kernel and counter: dispatches, mean and max per dispatch
-  * profiles/traffic.json            entry "refs=<refs>,query_len=658": FETCH_SIZE / WRITE_SIZE (KB) of one hit_count
-                                     launch + the fingerprint of the device sources they were measured on; bench.py
-                                     turns it into roofline.traffic only while the fingerprint still matches.
+  * profiles/traffic.json            entry "refs=<refs>,query_len=658,queries=<per step>": FETCH_SIZE / WRITE_SIZE (KB) and L2 requests /
+                                     hits of the hit_count launches of ONE WHOLE STEP, per kind of launch (the counting of the live
+                                     tiles / the bounds pass of the tile pruning), + the fingerprint of the device sources they were
+                                     measured on; bench.py turns it into roofline.traffic only while the fingerprint still matches.
 FETCH_SIZE and WRITE_SIZE come from passes of their own (they do not fit one pass: MI355X_MICROARCH.md, PMC slots)."""
 import argparse
 import collections
@@ -53,14 +54,12 @@ def main():
     ap.add_argument("--tag", required=True)
     ap.add_argument("--refs", type=int, required=True)
     ap.add_argument("--query-len", type=int, default=658)
-    ap.add_argument("--queries-per-launch", type=int, required=True)
+    ap.add_argument("--queries", type=int, required=True, help="queries per step of the profiled bench command (the whole step is profiled)")
     ap.add_argument("--fetch", required=True)
     ap.add_argument("--write", required=True)
-    ap.add_argument("--tcc", default=None, help="optional pass with TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum ...")
-    ap.add_argument("--full-launches-only", action="store_true", default=True)
+    ap.add_argument("--tcc", default=None, help="optional pass with TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum")
     ap.add_argument("--note", default="")
-    ap.add_argument("--with-bounds-pass", action="store_true", help="tile pruning on: a sub-batch is two launches of the hit_count kernel "
-                    "(bounds on the union bitmap + the live tiles); the entry holds their sum, launches_per_sub_batch = 2")
+    ap.add_argument("--unpruned", action="store_true", help="the run counted every tile (--no-tile-prune): one kind of launch")
     a = ap.parse_args()
     passes = [read_pass(a.fetch), read_pass(a.write)] + ([read_pass(a.tcc)] if a.tcc else [])
     rows = []
@@ -69,12 +68,23 @@ def main():
             if "rocclr" in k or "rocprim" in k:
                 continue
             for c, v in sorted(d.items()):
-                rows.append((k, c, len(v), sum(v) / len(v), max(v)))
+                rows.append((k, c, len(v), sum(v) / len(v), max(v), sum(v)))
     out = ROOT / "profiles" / f"{a.tag}_pmc_summary.csv"
     with open(out, "w") as f:
-        f.write("kernel,counter,dispatches,mean_per_dispatch,max_per_dispatch\n")
-        for k, c, n, mean, mx in rows:
-            f.write(f"\"{k}\",{c},{n},{mean:.1f},{mx:.1f}\n")
+        f.write("kernel,counter,dispatches,mean_per_dispatch,max_per_dispatch,sum\n")
+        for k, c, n, mean, mx, tot in rows:
+            f.write(f"\"{k}\",{c},{n},{mean:.1f},{mx:.1f},{tot:.1f}\n")
+        # the two kinds of launch of the hit_count kernel apart (tile pruning): by grid size
+        for agg in passes:
+            for k, d in sorted(agg.items()):
+                if not k.startswith("rtx::hit_count"):
+                    continue
+                for c, v in sorted(d.items()):
+                    g = GRID[(id(agg), k)][c]
+                    for kind, sel in split_kinds(g, a.unpruned).items():
+                        vals = [x for x, s_ in zip(v, sel) if s_]
+                        if vals:
+                            f.write(f"\"{k} [{kind}]\",{c},{len(vals)},{sum(vals) / len(vals):.1f},{max(vals):.1f},{sum(vals):.1f}\n")
     print("wrote", out)
 
     def hit(agg, ctr):
@@ -82,33 +92,47 @@ def main():
             if k.startswith("rtx::hit_count") and ctr in d:   # hit_count_kernel / hit_count_pair_kernel: whichever the run used
                 v = d[ctr]
                 g = GRID[(id(agg), k)][ctr]
-                # launches of a full sub-batch (the last one of a step may be short): those with the largest grid.  Their
-                # traffic differs from launch to launch -- the processing order gives every sub-batch another part of the
-                # database -- so the mean over all full launches is what a step sees
-                full = [x for x, gs in zip(v, g) if gs == max(g)]
-                mean = sum(full) / len(full)
-                if a.with_bounds_pass:   # tile pruning: the same kernel runs once more per sub-batch, on the union bitmap (a smaller grid)
-                    g2 = max(gs for gs in g if gs < max(g) and g.count(gs) * 2 >= len(full))
-                    coarse = [x for x, gs in zip(v, g) if gs == g2]
-                    mean += sum(coarse) / len(coarse)
-                return mean, len(full)
-        raise SystemExit(f"no hit_count dispatches with {ctr}")
+                return {kind: (sum(x for x, s_ in zip(v, sel) if s_), sum(sel)) for kind, sel in split_kinds(g, a.unpruned).items()}
+        return None
 
-    fetch_kb, nf = hit(passes[0], "FETCH_SIZE")
-    write_kb, nw = hit(passes[1], "WRITE_SIZE")
+    fetch, write = hit(passes[0], "FETCH_SIZE"), hit(passes[1], "WRITE_SIZE")
+    if fetch is None or write is None:
+        raise SystemExit("no hit_count dispatches in the FETCH_SIZE / WRITE_SIZE passes")
+    req = hit(passes[2], "TCC_REQ_sum") if a.tcc else None
+    hitc = hit(passes[2], "TCC_HIT_sum") if a.tcc else None
+    kinds = {}
+    for kind in fetch:
+        assert fetch[kind][1] == write[kind][1], "the passes saw different numbers of launches"
+        kinds[kind] = {"launches": fetch[kind][1], "fetch_kb": fetch[kind][0], "write_kb": write[kind][0]}
+        if req and hitc:
+            kinds[kind]["tcc_req"] = req[kind][0]
+            kinds[kind]["tcc_hit"] = hitc[kind][0]
     tf = ROOT / "profiles" / "traffic.json"
     t = json.loads(tf.read_text()) if tf.exists() else {}
     if "configs" not in t:
-        t = {"configs": {}, "note": "gfx950: FETCH_SIZE reports half of 16-byte-per-lane reads (MI355X_MICROARCH.md, HBM): bench.py doubles it; "
-                                    "WRITE_SIZE reads exactly for 16-byte-per-lane stores"}
-    t["configs"][f"refs={a.refs},query_len={a.query_len}"] = {
-        "queries_per_launch": a.queries_per_launch, "hit_count_fetch_kb": fetch_kb, "hit_count_write_kb": write_kb,
-        "launches_profiled": min(nf, nw), "launches_per_sub_batch": 2 if a.with_bounds_pass else 1, "device_source_sha": device_source_sha(),
-        "source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, tools/profile_bench.sh {a.tag}); mean KB per full "
-                  f"sub-batch of {a.queries_per_launch} queries ({'bounds pass + live tiles' if a.with_bounds_pass else 'one hit_count launch'}). {a.note}".strip(),
+        t = {"configs": {}}
+    t["note"] = ("gfx950: FETCH_SIZE reports half of 16-byte-per-lane reads (MI355X_MICROARCH.md, HBM): bench.py doubles it; WRITE_SIZE reads "
+                 "exactly for 16-byte-per-lane stores.  Per kind of launch of the hit_count kernel: sums over ALL launches of one step of the "
+                 "named size (KB), and their number")
+    key = f"refs={a.refs},query_len={a.query_len},queries={a.queries}"
+    t["configs"] = {k: v for k, v in t["configs"].items() if "kinds" in v}      # entries of the older layout are of older builds anyway
+    t["configs"][key] = {
+        "pruned": not a.unpruned, "kinds": kinds, "device_source_sha": device_source_sha(),
+        "source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / --pmc TCC_* (separate passes, tools/profile_bench.sh {a.tag}: one whole step of "
+                  f"`bench.py` at this size, every sub-batch). {a.note}".strip(),
     }
     tf.write_text(json.dumps(t, indent=1) + "\n")
-    print("updated", tf, json.dumps(t["configs"][f"refs={a.refs},query_len={a.query_len}"]))
+    print("updated", tf, json.dumps(t["configs"][key]))
+
+
+def split_kinds(grids, unpruned):
+    """Which dispatches of the hit_count kernel are of which kind, by their grid: the bounds pass of the tile pruning runs on the union
+    bitmap (a tile or a few), the counting proper on every tile of the database (most blocks leave at once) -- 62 times the grid at
+    500k references.  Unpruned runs have one kind."""
+    if unpruned or len(set(grids)) == 1:
+        return {"all": [True] * len(grids)}
+    cut = (min(grids) * max(grids)) ** 0.5
+    return {"live": [g > cut for g in grids], "bounds": [g <= cut for g in grids]}
 
 
 if __name__ == "__main__":

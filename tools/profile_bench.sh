@@ -1,14 +1,14 @@
 #!/bin/bash
 # Profiles bench.py under rocprofv3 on the GPU box: kernel trace + stats of the bench command itself, then (separate
 # passes, as the MI355X guide prescribes: no trace flags beside --pmc) the fabric counters behind FETCH_SIZE /
-# WRITE_SIZE and the L2 hit/miss counters, over four full sub-batches of the same configuration.
+# WRITE_SIZE and the L2 hit/miss counters, over ONE WHOLE STEP of the same configuration (every sub-batch of the 1 M queries: the
+# traffic of a launch depends on which slice of the lineage-ordered database its queries span).
 # Usage: tools/profile_bench.sh <tag> [bench args...]   -> gpurun_out/<tag>_{trace,fetch,write,tcc}/
 #        then tools/make_traffic.py turns the passes into profiles/<tag>_pmc_summary.csv and profiles/traffic.json
 set -u
 TAG=${1:-r2}; shift || true
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out
-QPL=${QPL:-32768}            # queries per launch (default sub-batch of a large database with tile pruning)
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 ARGS="--steps 2 --warmup 1 --no-cpu-baseline --no-extras $*"

@@ -280,6 +280,15 @@ int rtx_batch_download(rtx_index *index, rtx_result_view *out);
 #define RTX_BUF_HIST 1
 #define RTX_BUF_PREFIX 2
 int rtx_shard_begin(rtx_index *index, uint32_t *n_sub_batches, uint32_t *sub_batch);
+/* Tile pruning on a reference shard (RTX_OPT_SHARD_PRUNE = 1 before the upload; 8 tiles or more on the shard; queries with t <= 1023):
+ * the threshold of a query follows from the best block of 64 references ANYWHERE in the database, so the counting of a sub-batch
+ * stops once for an exchange:   rtx_shard_bounds  ->  all-gather RTX_BUF_BEST, keep per query the record with the largest first word
+ * (ties: the lowest shard) in every shard's buffer  ->  rtx_shard_count (counts the live tiles only)  ->  as before.
+ * rtx_shard_prunes (after rtx_shard_begin): 1 if this run prunes -- all shards must agree (same options, same queries); the shards
+ * then process the queries in their min-hash order, which is the same on every shard. */
+#define RTX_OPT_SHARD_PRUNE 16
+int rtx_shard_prunes(const rtx_index *index);
+int rtx_shard_bounds(rtx_index *index, uint32_t sub_batch_idx, uint32_t flags);
 int rtx_shard_count(rtx_index *index, uint32_t sub_batch_idx, uint32_t flags);
 int rtx_shard_prob(rtx_index *index, uint32_t sub_batch_idx);
 int rtx_shard_walk(rtx_index *index, uint32_t sub_batch_idx, const double *prefix_global /* device */);
@@ -292,6 +301,7 @@ int rtx_device_buffer(rtx_index *index, int which, void **device_ptr, uint64_t *
  * database (SURVEY.md 8e mode A, the literal wording of BASELINE.json configs[4]) all-reduces; rtx_shard_rehist then
  * rebuilds the histogram of prob.rs:13-19 from the summed counts before rtx_shard_prob. */
 #define RTX_BUF_COUNTS 3
+#define RTX_BUF_BEST 4 /* [n][66] uint32: {largest bound of a block of 64 references, 0, exact counts of that block's references} */
 int rtx_shard_buffer(rtx_index *index, uint32_t sub_batch_idx, int which, void **device_ptr, uint64_t *row_stride_elems);
 int rtx_shard_rehist(rtx_index *index, uint32_t sub_batch_idx);
 /* The HIP stream (hipStream_t) every kernel of this handle is enqueued on: a caller that interleaves its own device

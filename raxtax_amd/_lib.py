@@ -82,6 +82,8 @@ _SIGNATURES = {
                                         u32p, u32p, u32p, u32p, u8p, C.POINTER(C.c_void_p)]),
     "rtx_shard_begin": (C.c_int, [C.c_void_p, u32p, u32p]),
     "rtx_shard_count": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32]),
+    "rtx_shard_bounds": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32]),
+    "rtx_shard_prunes": (C.c_int, [C.c_void_p]),
     "rtx_shard_prob": (C.c_int, [C.c_void_p, C.c_uint32]),
     "rtx_shard_walk": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p]),
     "rtx_shard_info": (C.c_int, [C.c_void_p, u64p, u64p, u32p, u32p, u32p]),

@@ -186,6 +186,7 @@ struct rtx_index {
     uint32_t u_stride_bytes = 0, u_ntiles = 0;
     uint64_t u_nblocks = 0;
     DevBuf<unsigned long long> d_prune_stats;
+    uint32_t shard_prune_opt = 0;  // RTX_OPT_SHARD_PRUNE: a reference shard prunes with the threshold of the whole database (rtx_shard_bounds)
     uint32_t debug_taps = 0;     // RTX_OPT_DEBUG_TAPS: prune_kernel leaves its view of every query (rtx_debug_prune_detail)
     DevBuf<uint32_t> d_prune_detail;  // [sub_batch][kPruneDetailWords]
     uint32_t locator_opt = 1; // RTX_OPT_LOCATOR: the sort key of the processing order is led by the query's position in the database
@@ -219,6 +220,7 @@ struct rtx_index {
         DevBuf<unsigned long long> d_uones;
         DevBuf<uint32_t> d_uzero, d_uhist, d_live;
         DevBuf<uint16_t> d_ucounts, d_utmax, d_prune_thr, d_prune_i1;
+        DevBuf<uint32_t> d_best;  // [B][kPruneBestWords] reference shards: the candidate for the best block of the database
     } sc[2];
     bool staged = false;  // driven with rtx_shard_*: sub-batch sb works in scratch set sb & 1, so that the exchange of one
                           // sub-batch (RCCL, on the caller's stream) can overlap with the counting of the next
@@ -371,7 +373,9 @@ int enqueue_kmer(rtx_index *ix, const SubBatch &b, hipStream_t s) {
     return RTX_OK;
 }
 
-int enqueue_hit(rtx_index *ix, const SubBatch &b, uint32_t flags, hipStream_t s) {
+// part 0: everything.  A reference shard that prunes stops in the middle for the exchange of the best blocks: part 1 = up to the
+// candidates (bounds pass, prune_kernel phase 1), part 2 = the rest (prune_kernel phase 2, lists of the live tiles, counting).
+int enqueue_hit(rtx_index *ix, const SubBatch &b, uint32_t flags, hipStream_t s, int part = 0) {
     rtx_index::Scratch &sc = ix->sc[b.set];
     ix->last_set = b.set;
     HitParams hp{};
@@ -411,7 +415,8 @@ int enqueue_hit(rtx_index *ix, const SubBatch &b, uint32_t flags, hipStream_t s)
     hp.live_words = 0;
     const bool prune = ix->prune_used && !ix->dbg_full_run;
     if (b.timed && !prune) RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_HIT_COUNT, 0), s));
-    if (ix->pair_used) launch_pair_union(s, sc.d_rows.p, sc.d_nrows.p, ix->rstride, b.nq, sc.d_urec.p, sc.d_nu.p, 2u * ix->rstride);
+    if (ix->pair_used && part != 2) launch_pair_union(s, sc.d_rows.p, sc.d_nrows.p, ix->rstride, b.nq, sc.d_urec.p, sc.d_nu.p, 2u * ix->rstride);
+    if (part != 0 && !prune) { set_error("internal: a split run without tile pruning"); return RTX_ERR_STATE; }
     if (prune) {
         // (1) the queries against the union bitmap: every row dense, no lists, packed counts (bounds per block of references)
         HitParams up = hp;
@@ -430,12 +435,12 @@ int enqueue_hit(rtx_index *ix, const SubBatch &b, uint32_t flags, hipStream_t s)
         up.tile_max = sc.d_utmax.p;
         up.flags = 0;
         up.group_base = hp.group_base + ix->n_groups_run;  // work accounting apart from the counting proper
-        if (b.timed) RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_TILE_BOUNDS, 0), s));
-        launch_hit_count_pair(s, up, b.nq, ix->u_ntiles);  // the union of the pair's rows serves both passes
-        if (b.timed) {
-            RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_TILE_BOUNDS, 1), s));
-            RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_TILE_PRUNE, 0), s));
+        if (part != 2) {
+            if (b.timed) RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_TILE_BOUNDS, 0), s));
+            launch_hit_count_pair(s, up, b.nq, ix->u_ntiles);  // the union of the pair's rows serves both passes
+            if (b.timed) RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_TILE_BOUNDS, 1), s));
         }
+        if (b.timed && part != 1) RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_TILE_PRUNE, 0), s));
         // (2) bounds per tile, a lower bound of the best hit, the threshold, the live tiles of every pair
         PruneParams pr{};
         pr.ucounts_lo = up.counts_lo;
@@ -444,6 +449,10 @@ int enqueue_hit(rtx_index *ix, const SubBatch &b, uint32_t flags, hipStream_t s)
         pr.ntiles = ix->ntiles;
         pr.nq = b.nq;
         pr.n_refs = ix->n_refs;
+        pr.n_total = ix->n_total;
+        pr.ref_base = ix->ref_lo;
+        pr.phase = (uint32_t)part;
+        pr.best = part ? sc.d_best.p : nullptr;
         pr.bitmap = ix->d_bitmap.p;
         pr.n_rows1 = ix->n_rows + 1;
         pr.stride_bytes = ix->stride_bytes;
@@ -468,6 +477,7 @@ int enqueue_hit(rtx_index *ix, const SubBatch &b, uint32_t flags, hipStream_t s)
         pr.detail = ix->debug_taps && ix->d_prune_detail.n >= (size_t)b.nq * kPruneDetailWords ? ix->d_prune_detail.p : nullptr;
         ProbTables tb{ix->d_tab_cmf.p, ix->d_tab_ratio.p, ix->d_tab_off.p, ix->d_tab_moff.p, ix->d_tab_ilo.p, ix->d_tab_sat.p, ix->tab_tmax};
         launch_prune(s, pr, tb, b.nq);
+        if (part == 1) { RTX_HIP(hipGetLastError()); return RTX_OK; }  // the caller exchanges RTX_BUF_BEST, then part 2
         // (3) tiles that are not counted keep a largest count of 0: taxon_prefix leaves them out
         RTX_HIP(hipMemsetAsync(sc.d_tilemax.p, 0, (size_t)b.nq * ix->ntiles * 2, s));
         hp.live = sc.d_live.p;
@@ -627,11 +637,16 @@ int begin_run(rtx_index *ix, uint32_t *n_sub_out, bool *timed_out, bool cluster)
     ix->groups_per_sub = (ix->sub_batch + 1u) / 2u;
     // tile pruning: the pair kernel, the memoised tables (their ln cmf rows give the threshold), taxon_prefix skipping tiles by
     // their largest count, the whole database on this handle
-    ix->prune_used = ix->prune_opt && ix->pair_used && ix->use_tables && ix->tile_skip && ix->d_ubitmap.p &&
-                     ix->n_refs == ix->n_total && !ix->staged &&
-                     // the scratch of the pruning was sized at the upload (alloc_scratch_set) for this sub-batch size
-                     ix->sc[0].d_ucounts.p != nullptr && ix->sc[0].d_ucounts.n >= (size_t)ix->sub_batch * ix->u_ntiles * 8192u &&
-                     ix->sc[0].d_prune_thr.n >= ix->sub_batch && ix->sc[0].d_live.n >= (size_t)((ix->sub_batch + 1u) / 2u) * ((ix->ntiles + 31u) / 32u + 1u);
+    // a whole-database handle driven by rtx_batch_run, or a reference shard that was asked to (RTX_OPT_SHARD_PRUNE: the caller then
+    // drives rtx_shard_bounds and exchanges the best blocks); never a k-mer shard (its counts are partial sums)
+    const bool whole = ix->n_refs == ix->n_total && !ix->staged;
+    const bool shard = ix->staged && ix->shard_prune_opt && ix->n_refs != ix->n_total;
+    auto scratch_ok = [&](const rtx_index::Scratch &sc) {  // sized at the upload / rtx_shard_begin (alloc_scratch_set) for this sub-batch size
+        return sc.d_ucounts.p != nullptr && sc.d_ucounts.n >= (size_t)ix->sub_batch * ix->u_ntiles * 8192u && sc.d_prune_thr.n >= ix->sub_batch &&
+               sc.d_live.n >= (size_t)((ix->sub_batch + 1u) / 2u) * ((ix->ntiles + 31u) / 32u + 1u) && sc.d_best.n >= (size_t)ix->sub_batch * kPruneBestWords;
+    };
+    ix->prune_used = ix->prune_opt && ix->pair_used && ix->use_tables && ix->tile_skip && ix->d_ubitmap.p && (whole || shard) &&
+                     scratch_ok(ix->sc[0]) && (!ix->staged || scratch_ok(ix->sc[1]));
     ix->dbg_full = false;
     if (ix->prune_used) {
         int rc_s = ix->d_prune_stats.alloc(kPruneStatCopies * 16);
@@ -794,7 +809,7 @@ int prepare_workspace(rtx_index *ix, uint64_t n_queries, uint64_t tmax, uint64_t
         ix->arena_cap = want_arena;
     }
     // ---- sub-batch scratch, sized against free HBM
-    const bool will_prune = ix->prune_opt && ix->d_ubitmap.p && ix->pair_opt && ix->ntiles >= 8 && tmax <= 1023 && ix->n_refs == ix->n_total;  // begin_run decides
+    const bool will_prune = ix->prune_opt && ix->d_ubitmap.p && ix->pair_opt && ix->ntiles >= 8 && tmax <= 1023 && (ix->n_refs == ix->n_total || ix->shard_prune_opt);  // begin_run decides
     const uint64_t per_q = (uint64_t)ix->kstride * 2 + (uint64_t)ix->rstride * 12 + 4 + (uint64_t)ix->ntiles * (ix->rstride / 8 + ((kSegMaxSparseRows + 1) * 4 + 10)) + (ix->packed() ? ix->npad * 5 / 4 : ix->npad * 2) + (uint64_t)ix->hstride * 12 +
                            (uint64_t)ix->n_bnd_local * 8 + 64 +
                            // + the scratch of the tile pruning: counts against the union bitmap, constant masks, its histogram, thresholds, live masks
@@ -829,12 +844,12 @@ int alloc_scratch_set(rtx_index *ix, uint32_t k) {
             (rc = sc.d_tilemax.alloc((size_t)B * ix->ntiles)) ||
             (rc = sc.d_urec.alloc((size_t)((B + 1u) / 2u) * 2u * ix->rstride)) || (rc = sc.d_nu.alloc((B + 1u) / 2u)))
             return rc;
-        if (ix->prune_opt && ix->d_ubitmap.p) {
+        if (ix->prune_opt && ix->d_ubitmap.p && (ix->n_refs == ix->n_total || ix->shard_prune_opt)) {
             const size_t mw = (size_t)B * ix->u_ntiles * (ix->rstride / 64);
             const bool fresh = sc.d_uones.n < mw;
             if ((rc = sc.d_uones.alloc(mw)) || (rc = sc.d_uzero.alloc((size_t)B * ix->u_ntiles)) ||
                 (rc = sc.d_ucounts.alloc((size_t)B * ix->u_ntiles * 8192u)) || (rc = sc.d_uhist.alloc((size_t)B * ix->hstride)) ||
-                (rc = sc.d_utmax.alloc((size_t)B * ix->u_ntiles)) || (rc = sc.d_prune_thr.alloc(B)) || (rc = sc.d_prune_i1.alloc(B)) || (rc = sc.d_live.alloc((size_t)((B + 1u) / 2u) * ((ix->ntiles + 31u) / 32u + 1u))))
+                (rc = sc.d_utmax.alloc((size_t)B * ix->u_ntiles)) || (rc = sc.d_prune_thr.alloc(B)) || (rc = sc.d_prune_i1.alloc(B)) || (rc = sc.d_best.alloc((size_t)B * kPruneBestWords)) || (rc = sc.d_live.alloc((size_t)((B + 1u) / 2u) * ((ix->ntiles + 31u) / 32u + 1u))))
                 return rc;
             if (fresh) RTX_HIP(hipMemsetAsync(sc.d_uones.p, 0xFF, sc.d_uones.n * 8, ix->stream));
             RTX_HIP(hipMemsetAsync(sc.d_uzero.p, 0, sc.d_uzero.n * 4, ix->stream));
@@ -1288,7 +1303,7 @@ static int create_from_csr(int device, uint64_t n_total, uint64_t ref_lo, uint64
 // references.  Same rows as d_bitmap.  Only for whole databases of some size (8 tiles or more); a failure to allocate
 // leaves the handle without it (no pruning).  Sizes first, then one of the two builders below fills it.
 static bool prepare_union_bitmap(rtx_index *ix) {
-    if (ix->n_refs != ix->n_total || ix->ntiles < 8) return false;
+    if (ix->ntiles < 8) return false;  // (a reference shard gets one too: it prunes with the threshold of the whole database, rtx_shard_bounds)
     ix->u_nblocks = (ix->n_refs + (1ull << kPruneShift) - 1) >> kPruneShift;
     ix->u_ntiles = (uint32_t)((ix->u_nblocks + 8191) / 8192);
     ix->u_stride_bytes = ix->u_ntiles * 1024u;
@@ -1462,6 +1477,10 @@ int rtx_index_set_option(rtx_index *index, int option, uint64_t value) {
             return RTX_OK;
         case RTX_OPT_DEBUG_TAPS:
             index->debug_taps = value ? 1u : 0u;
+            return RTX_OK;
+        case RTX_OPT_SHARD_PRUNE:
+            index->uploaded = index->ran = index->synced = false;
+            index->shard_prune_opt = value ? 1u : 0u;
             return RTX_OK;
         case RTX_OPT_DEVICE_EXACT:
             index->uploaded = index->ran = index->synced = false;  // decided at the upload
@@ -1783,7 +1802,9 @@ int rtx_shard_begin(rtx_index *ix, uint32_t *n_sub_batches, uint32_t *sub_batch)
     }
     uint32_t n_sub = 0;
     bool timed = false;
-    if ((rc = begin_run(ix, &n_sub, &timed, false))) return rc;  // shards must agree on the order: input order
+    // shards must agree on the order: input order, or -- for shards that prune (the pair kernel needs neighbours that are related) --
+    // the min-hash order, which is a function of the queries alone (no locator on a shard: stable radix sort of the sketch keys)
+    if ((rc = begin_run(ix, &n_sub, &timed, ix->shard_prune_opt && ix->prune_opt && ix->d_ubitmap.p && ix->n_refs != ix->n_total && ix->cluster))) return rc;
     ix->ran = true;
     ix->synced = false;
     ix->last_flags = 0;
@@ -1803,11 +1824,27 @@ static int shard_sb(rtx_index *ix, uint32_t sb, SubBatch *b) {
     return RTX_OK;
 }
 
+int rtx_shard_prunes(const rtx_index *ix) { return ix && ix->ran && ix->staged && ix->prune_used ? 1 : 0; }
+
+// A pruning shard, first half of the counting of a sub-batch: k-mers, bounds against the union bitmap of this shard, its candidate for
+// the best block of the database (RTX_BUF_BEST).  The caller keeps per query the candidate with the largest bound over all shards
+// (ties: the lowest shard) in every shard's buffer, then rtx_shard_count.
+int rtx_shard_bounds(rtx_index *ix, uint32_t sb, uint32_t flags) {
+    SubBatch b;
+    int rc = shard_sb(ix, sb, &b);
+    if (rc) return rc;
+    if (!ix->prune_used) { set_error("rtx_shard_bounds: this run does not prune (rtx_shard_prunes)"); return RTX_ERR_STATE; }
+    ix->last_flags = flags;
+    if ((rc = enqueue_kmer(ix, b, b.s))) return rc;
+    return enqueue_hit(ix, b, flags, b.s, 1);
+}
+
 int rtx_shard_count(rtx_index *ix, uint32_t sb, uint32_t flags) {
     SubBatch b;
     int rc = shard_sb(ix, sb, &b);
     if (rc) return rc;
     ix->last_flags = flags;
+    if (ix->prune_used) return enqueue_hit(ix, b, flags, b.s, 2);  // after rtx_shard_bounds and the exchange of RTX_BUF_BEST
     return enqueue_count(ix, b, flags);
 }
 
@@ -1857,6 +1894,11 @@ int rtx_shard_buffer(rtx_index *ix, uint32_t sb, int which, void **ptr, uint64_t
     switch (which) {
         case RTX_BUF_HIST: *ptr = sc.d_hist.p; if (row_stride_elems) *row_stride_elems = ix->hstride; return RTX_OK;
         case RTX_BUF_PREFIX: *ptr = sc.d_prefix.p; if (row_stride_elems) *row_stride_elems = ix->n_bnd_local; return RTX_OK;
+        case RTX_BUF_BEST:
+            if (!sc.d_best.p) { set_error("RTX_BUF_BEST: the handle does not prune"); return RTX_ERR_STATE; }
+            *ptr = sc.d_best.p;
+            if (row_stride_elems) *row_stride_elems = kPruneBestWords;
+            return RTX_OK;
         case RTX_BUF_COUNTS:
             if (ix->packed()) { set_error("RTX_BUF_COUNTS needs u16 counts (RTX_OPT_PACKED_COUNTS = 0)"); return RTX_ERR_STATE; }
             *ptr = sc.d_counts.p;

@@ -152,11 +152,21 @@ constexpr uint32_t kPruneStatCopies = 64;  // PruneParams::stats: [copies][8] (p
 #endif
 constexpr uint32_t kPruneShift = RTX_PRUNE_SHIFT;  // the union bitmap has one column per block of 64 references (3 .. 6: a block's references meet in one wave)
 static_assert(kPruneShift >= 3 && kPruneShift <= 6, "blocks of 8 .. 64 references");
+constexpr uint32_t kPruneBestWords = 66;  // PruneParams::best: {largest bound, 0, exact counts of the 64 references of that block}
 struct PruneParams {
     const uint8_t *ucounts_lo;   // [B][unpad] counts of the queries against the union bitmap (an upper bound per block of
     const uint16_t *ucounts_hi;  // [B][unpad / 8]  2^kPruneShift references), packed like HitParams::counts_lo / counts_hi
     uint32_t unpad, ntiles, nq;
-    uint64_t n_refs;
+    uint64_t n_refs;             // references on this handle
+    uint64_t n_total;            // references of the whole database (the N of the threshold)
+    uint32_t ref_base;           // global id of local reference 0 (reference-sharded index)
+    // A reference shard prunes with the threshold of the WHOLE database: the threshold follows from the best block anywhere.
+    // phase 1: bounds per tile, the best local block and the exact counts of its references -> best[q]; nothing else.
+    // (the caller keeps, per query, the record of the shard with the largest bound -- an all-gather over the shards)
+    // phase 2: the threshold from best[q] as handed back, the live tiles of this shard, its uncounted references into bin 0.
+    // phase 0 (whole database on the handle): both at once.
+    uint32_t phase;
+    uint32_t *best;              // [B][kPruneBestWords] (phases 1 and 2) or null
     const uint32_t *bitmap;   // the database's bitmap: the exact count of one reference
     uint32_t n_rows1, stride_bytes;
     const uint32_t *rows;     // [B][rstride]

@@ -65,7 +65,7 @@ __global__ __launch_bounds__(64) void prune_kernel(PruneParams p, ProbTables tb)
     extern __shared__ uint16_t ub_lds[];  // [2][ntiles]
     const uint32_t pair = blockIdx.x, lane = threadIdx.x;
     const uint32_t bpt = 8192u >> kPruneShift;  // blocks per tile
-    const double ln_n = log((double)p.n_refs);
+    const double ln_n = log((double)p.n_total);
     uint32_t thr[2] = {0u, 0u};
     unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // wave-uniform: what this wave adds to p.stats
     const bool has_b = pair * 2u + 1u < p.nq;
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(64) void prune_kernel(PruneParams p, ProbTables tb)
                 if ((lane & (lpt - 1u)) == 0u && T < p.ntiles) ub_lds[x * p.ntiles + T] = (uint16_t)tm;
             }
         }
-        const uint32_t ub_best = wave_max_u32p(lmx);
+        uint32_t ub_best = wave_max_u32p(lmx);
         // the lowest block among those with the largest bound (0 if every bound is 0)
         const uint32_t bb = ub_best ? 0xFFFFFFFFu - wave_max_u32p(lmx == ub_best ? 0xFFFFFFFFu - lblk : 0u) : 0u;
         // ---- 2. exact counts of its references (not those that --skip-exact-matches zeroes); M = the best of them.  The
@@ -124,7 +124,12 @@ __global__ __launch_bounds__(64) void prune_kernel(PruneParams p, ProbTables tb)
         // reference are summed in 16-bit halves (at most 16 rows per lane x 64 lanes).
         uint32_t M = 0;
         uint32_t hm = 0;  // lane l < 2^kPruneShift: the exact count of reference l of the block (0: none, or zeroed)
-        {
+        if (p.phase == 2u) {  // the best block of the whole database, as the exchange between the shards left it
+            const uint32_t *bq = p.best + (size_t)q * kPruneBestWords;
+            ub_best = bq[0];
+            hm = bq[2u + lane];
+            M = wave_max_u32p(hm);
+        } else {
             constexpr uint32_t kChunks = (1u << kPruneShift) / 8u;  // 4 for blocks of 32
             const uint32_t nr = p.nrows[q];
             const uint32_t *rows = p.rows + (size_t)q * p.rstride;
@@ -175,7 +180,7 @@ __global__ __launch_bounds__(64) void prune_kernel(PruneParams p, ProbTables tb)
                     bool ok = r < p.n_refs;
                     if (ok && (p.flags & RTX_SKIP_EXACT_MATCHES)) {
                         bool hit = false;
-                        for (uint64_t e = xe0 + lane; e < xe1; e += 64) hit = hit || (uint64_t)xids[e] == r;
+                        for (uint64_t e = xe0 + lane; e < xe1; e += 64) hit = hit || (uint64_t)(xids[e] - p.ref_base) == r;  // local id; other shards' ids wrap out of range
                         ok = __ballot(hit) == 0ull;
                     }
                     const uint32_t cnt = ((uint32_t)__builtin_amdgcn_readlane((int)acc[j >> 1], (int)c) >> ((j & 1) * 16)) & 0xFFFFu;
@@ -185,6 +190,12 @@ __global__ __launch_bounds__(64) void prune_kernel(PruneParams p, ProbTables tb)
             }
         }
         if (p.detail) p.detail[(size_t)q * kPruneDetailWords + 8u + lane] = hm;  // debug tap: the exact counts of the best block's references
+        if (p.phase == 1u) {  // a reference shard, first half: its candidate for the best block of the database
+            uint32_t *bq = p.best + (size_t)q * kPruneBestWords;
+            bq[2u + lane] = hm;
+            if (lane == 0) { bq[0] = ub_best; bq[1] = 0u; }
+            continue;  // wave-uniform
+        }
 #ifdef RTX_PRUNE_CHECK  // debug: the count of the best block recomputed from the union bitmap must equal what the counting pass left
         if (p.ubitmap) {
             uint32_t word, bit;
@@ -223,7 +234,7 @@ __global__ __launch_bounds__(64) void prune_kernel(PruneParams p, ProbTables tb)
                 const uint32_t h_min = 0xFFFFFFFFu - wave_max_u32p(hm ? 0xFFFFFFFFu - hm : 0u);  // <= M: H holds the best one
                 auto passes = [&](uint32_t i) -> bool {
                     const double v = hm ? Ct[(size_t)hm * (n + 1) + i] : 0.0;  // ln cmf_m(i)
-                    return wave_sum_f64(v) + log(n_h + (double)p.n_refs * (double)(i + 1u)) <= kPruneLnEps;
+                    return wave_sum_f64(v) + log(n_h + (double)p.n_total * (double)(i + 1u)) <= kPruneLnEps;
                 };
                 uint32_t ist1 = 0;  // i* + 1 in the end (0: none)
                 if (passes(0u)) {
@@ -264,7 +275,7 @@ __global__ __launch_bounds__(64) void prune_kernel(PruneParams p, ProbTables tb)
                         const double gw = vi ? exp(lnG) : 0.0;                         // G(i)
                         const double ww = vi ? exp(fmin(0.0, ln_n + lnG)) : 0.0;      // min(1, N G(i))
                         const uint32_t i_last = i1 + 63u < n ? i1 + 63u : n;
-                        const double nn = (double)p.n_refs;
+                        const double nn = (double)p.n_total;
                         auto crit = [&](uint32_t u) -> bool {
                             const double P = vi ? exp(ln_pmf_tab(lf, t, n, u, iw, ln_total)) : 0.0;  // pmf_u(i)
                             double R = 0.0;   // everything of pmf_u behind the window
@@ -300,6 +311,7 @@ __global__ __launch_bounds__(64) void prune_kernel(PruneParams p, ProbTables tb)
         st[2] += M; st[3] += u_max; st[4] += ub_best; st[5] += 1ull;
         if (ub_best < M) st[6] += 1ull;  // must never happen: a block's bound below one of its references' counts
     }
+    if (p.phase == 1u) return;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     // ---- 4. live tiles of the pair, the references never counted

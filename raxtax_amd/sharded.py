@@ -26,7 +26,7 @@ from . import _lib
 from ._lib import check, ptr, u8p, u32p, u64p
 from .api import Index, Result, Tree
 
-RTX_BUF_HIST, RTX_BUF_PREFIX, RTX_BUF_COUNTS = 1, 2, 3
+RTX_BUF_HIST, RTX_BUF_PREFIX, RTX_BUF_COUNTS, RTX_BUF_BEST = 1, 2, 3, 4
 
 
 class _DevArray:
@@ -63,6 +63,15 @@ class _StagedMixin:
     def count(self, sb: int, flags: int = 0):
         check(self._lib.rtx_shard_count(self._h, sb, flags))
 
+    @property
+    def prunes(self) -> bool:
+        """After begin(): this run prunes tiles with the threshold of the whole database (RTX_OPT_SHARD_PRUNE): bounds(sb), the
+        exchange of RTX_BUF_BEST, then count(sb)."""
+        return bool(self._lib.rtx_shard_prunes(self._h))
+
+    def bounds(self, sb: int, flags: int = 0):
+        check(self._lib.rtx_shard_bounds(self._h, sb, flags))
+
     def rehist(self, sb: int):
         check(self._lib.rtx_shard_rehist(self._h, sb))
 
@@ -81,7 +90,7 @@ class _StagedMixin:
             # u16 counts, seen as int32 pairs: RCCL and gloo reduce no 16-bit integers, and adding the pairs adds both
             # halves correctly -- the summed counts stay <= t <= 65535, so the low half never carries into the high one
             return device_tensor(p.value, (n_rows, stride.value // 2), "<i4", self.device)
-        typ = {RTX_BUF_HIST: "<i4", RTX_BUF_PREFIX: "<f8"}[which]
+        typ = {RTX_BUF_HIST: "<i4", RTX_BUF_PREFIX: "<f8", RTX_BUF_BEST: "<i4"}[which]
         return device_tensor(p.value, (n_rows, stride.value), typ, self.device)
 
     @property
@@ -105,7 +114,7 @@ class _StagedMixin:
 class ShardIndex(_StagedMixin, Index):
     """Device index holding references [cuts[rank], cuts[rank+1]) of the tree (SURVEY.md 8e mode B)."""
 
-    def __init__(self, tree: Tree, rank: int, cuts: Sequence[int], device: int = 0, sub_batch: int = 1024):
+    def __init__(self, tree: Tree, rank: int, cuts: Sequence[int], device: int = 0, sub_batch: int = 1024, tile_prune: bool = True):
         self._lib = _lib.load()
         self.tree = tree
         self.device = device
@@ -123,6 +132,8 @@ class ShardIndex(_StagedMixin, Index):
         self.n_refs = int(cuts[rank + 1]) - int(cuts[rank])      # local references (debug taps)
         if sub_batch:
             check(self._lib.rtx_index_set_batch(self._h, sub_batch))
+        # a shard of 8 tiles or more counts only the tiles that can matter, with the threshold of the whole database (RTX_OPT_SHARD_PRUNE)
+        check(self._lib.rtx_index_set_option(self._h, 16, int(tile_prune)))
         from ._lib import ResultView
 
         self._view = ResultView()
@@ -189,6 +200,16 @@ class LocalComm:
     def allgather_prefix(self, locals_):
         return [p.clone() for p in locals_]
 
+    def select_best(self, bests):
+        """Per query the candidate with the largest bound (column 0) over the shards, ties to the lowest shard, into every buffer."""
+        import torch
+
+        allb = torch.stack([b.to(bests[0].device) for b in bests])            # [shards][n][66]
+        pick = torch.argmax(allb[:, :, 0], dim=0)                             # the first maximum: the lowest shard
+        chosen = allb[pick, torch.arange(allb.shape[1], device=allb.device)]
+        for b in bests:
+            b.copy_(chosen.to(b.device))
+
 
 class TorchComm:
     """One shard per process; torch.distributed (backend nccl = RCCL on GPUs, gloo on CPU tensors)."""
@@ -217,6 +238,18 @@ class TorchComm:
         out = [torch.zeros_like(pad) for _ in range(self.world)]
         self.dist.all_gather(out, pad)
         return [o[:, : self.widths[s]] for s, o in enumerate(out)]
+
+    def select_best(self, bests):
+        """All-gather of the shards' candidates for the best block ([n][66] int32: 264 B per query and shard), then per query the one
+        with the largest bound, ties to the lowest rank -- the same choice on every rank."""
+        import torch
+
+        (b,) = bests
+        out = [torch.zeros_like(b) for _ in range(self.world)]
+        self.dist.all_gather(out, b.contiguous())
+        allb = torch.stack(out)
+        pick = torch.argmax(allb[:, :, 0], dim=0)
+        b.copy_(allb[pick, torch.arange(allb.shape[1], device=allb.device)])
 
 
 def assemble_prefix(parts):
@@ -268,13 +301,20 @@ class ShardedClassifier:
         n_sub, B = s.begin()
         n_q = self._n_q
         keep = []
+        prunes = s.prunes
+
+        def count(sb):
+            if prunes:   # bounds -> the best block of the whole database -> counting of the live tiles
+                s.bounds(sb, flags)
+                self.comm.select_best([s.buffer(RTX_BUF_BEST, min(B, n_q - sb * B), sb)])
+            s.count(sb, flags)
         with torch.cuda.stream(s.torch_stream):
-            s.count(0, flags)
+            count(0)
             for sb in range(n_sub):
                 nq = min(B, n_q - sb * B)
                 work = self.comm.allreduce_start(s.buffer(RTX_BUF_HIST, nq, sb))
                 if sb + 1 < n_sub:
-                    s.count(sb + 1, flags)
+                    count(sb + 1)
                 work.wait()
                 s.prob(sb)
                 pref = assemble_prefix(self.comm.allgather_prefix([s.buffer(RTX_BUF_PREFIX, nq, sb)]))
@@ -290,8 +330,17 @@ class ShardedClassifier:
         for s in self.shards[1:]:
             assert s.begin() == (n_sub, B), "all shards must use the same sub-batch size"
         n_q = self._n_q
+        prunes = self.shards[0].prunes
+        assert all(s.prunes == prunes for s in self.shards), "all shards must agree on the tile pruning"
         for sb in range(n_sub):
             nq = min(B, n_q - sb * B)
+            if prunes:
+                for s in self.shards:
+                    s.bounds(sb, flags)
+                for s in self.shards:
+                    s.sync()
+                self.comm.select_best([s.buffer(RTX_BUF_BEST, nq, sb) for s in self.shards])
+                torch.cuda.synchronize()
             for s in self.shards:
                 s.count(sb, flags)
             for s in self.shards:

@@ -151,3 +151,68 @@ def test_real_composition_short_reads(oracle, emul):
                 olin = olin or otree.lineages
                 exc.tie(assert_rows_equivalent(got, want, tables_o[k][counts_o[k]], olin, f"query {j} skip {skip}"))
         exc.check()
+
+
+@pytest.mark.parametrize("n_shards", [2, 3])
+def test_reference_shards_prune_with_the_global_threshold(oracle, n_shards):
+    """BASELINE configs[4] mode B with tile pruning: every shard (9 tiles or more) counts the queries against its own union bitmap, the
+    shards exchange their candidates for the best block (RTX_BUF_BEST: 264 bytes per query), every shard derives the threshold from the
+    best block of the WHOLE database and counts its live tiles only.  Against the oracle (rows, every query) and against the unsharded
+    pruned run (same rows; the thresholds may differ by a few counts where a shard's blocks of 64 are cut elsewhere); cuts inside taxa,
+    --skip-exact-matches (an exact match of the best block may live on another shard), several sub-batches."""
+    from raxtax_amd import sharded
+    from test_gpu_parity import assert_rows_equivalent
+
+    n_refs = 8192 * 9 * n_shards + 4321
+    db = synth.make_db(n_refs)
+    qs = synth.make_queries(db, 700, seed=21 + n_shards, exact_frac=0.15)
+    L = db.length
+    tree = rx.Tree.new_flat(db.lineages, db.seq_bytes, db.seq_off)
+    whole = rx.Index(tree)
+    ex = whole.exact_matches(qs.bases, qs.base_off)
+    cuts = sharded.shard_cuts(tree.num_tips, n_shards)
+    cuts[1] += 37                                         # not a multiple of 64, inside a species
+    shards = [sharded.ShardIndex(tree, r, cuts, sub_batch=256) for r in range(n_shards)]
+    clf = sharded.ShardedClassifier(shards, sharded.LocalComm())
+    otree = oracle.tree_new_flat(db.lineages, db.seq_bytes, db.seq_off)
+    import os
+    threads = os.cpu_count() or 1
+    lineages = otree.lineages
+    for skip in (False, True):
+        ref = whole.classify(qs.bases, qs.base_off, *ex, skip_exact_matches=skip)
+        assert whole.debug_prune_stats()["pairs"] > 0
+        got = clf.classify(qs.bases, qs.base_off, *ex, skip_exact_matches=skip)
+        assert all(s.prunes for s in shards)
+        live = [s.debug_prune_stats() for s in shards]
+        print(f"{n_shards} shards, skip={skip}: live tiles per pair and shard {[round(x['live_tiles_per_pair'], 2) for x in live]} of {[(s.n_refs + 8191) // 8192 for s in shards]}, "
+              f"unsharded {whole.debug_prune_stats()['live_tiles_per_pair']:.2f}; bound violations {[x['bound_violations'] for x in live]}")
+        assert all(x["bound_violations"] == 0 and x["pairs"] > 0 for x in live)
+        assert sum(x["live_tiles_per_pair"] for x in live) < 0.5 * sum((s.n_refs + 8191) // 8192 for s in shards)
+        assert np.array_equal(got.t, ref.t) and np.array_equal(got.status, ref.status)
+        assert np.max(np.abs(got.global_signal - ref.global_signal)) < 1e-9
+        bad, rows_o, nrows_o = otree.classify_batch(qs.bases, qs.base_off, skip_exact=skip, raw_confidence=True, threads=threads, cap=64)
+        assert bad == 0
+        exc = Excuses(f"pruned/shards{n_shards}/skip={int(skip)}")
+        for q in range(qs.n):
+            want = otree.rows_of(rows_o, nrows_o, q, 64)
+            for res, name in ((got, "sharded"), (ref, "whole")):
+                g = res.rows(q)
+                if name == "sharded":
+                    exc.checked += 1
+                if [r.lineage for r in g] != [r["idx"] for r in want] or [r.confidence_values for r in g] != [r["conf"] for r in want]:
+                    t, counts = otree.hit_counts(qs.seq(q), skip_exact=skip)
+                    tables, z, rc = oracle.prob_tables_batch(np.array([t], np.uint32), counts[None, :])
+                    ties = assert_rows_equivalent(g, want, tables[0][counts], lineages, f"{name}: query {q} skip {skip}")
+                    if name == "sharded":
+                        exc.tie(ties)
+        exc.check()
+        # the counts every shard wrote for the tiles it visited are the oracle's (last sub-batch: still resident, as the run left it)
+        perm = shards[0].debug_order(qs.n)
+        assert all(np.array_equal(s.debug_order(qs.n), perm) for s in shards)     # the shards agree on the processing order
+        q = int(perm[-1])
+        t, counts = otree.hit_counts(qs.seq(q), skip_exact=skip)
+        for s in shards:
+            rc = s.debug_run_counts(q, t)
+            lv = np.repeat(rc["tile_live"], 8192)[: s.n_refs]
+            assert np.array_equal(rc["counts"][lv], counts[s.ref_lo:s.ref_hi][lv]) and rc["threshold"] > 0
+            assert (counts[s.ref_lo:s.ref_hi][~lv] <= rc["threshold"]).all()

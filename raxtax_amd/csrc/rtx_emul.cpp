@@ -351,39 +351,43 @@ void emul_prune_threshold(uint32_t t, uint64_t n_refs, const uint32_t *hm_in, co
         if (!(up < dn && ln_len + ln_pmf_tab(lf, t, n, u, i1, ln_total) + ln_n <= kLnEps)) { first_fail = u; break; }
     }
     uint32_t u_max = first_fail - 1u;
-    {   // the tighter criterion ("(3)" in rtx_prune.hip): window W = i1 .. i1 + 63
-        const uint32_t i_last = std::min(i1 + 63u, n);
-        double gw[64], ww[64];
+    {   // the tighter criterion ("(3)" in rtx_prune.hip): window W = i1 .. i1 + 62 (lanes 0 .. 62), lane 63 = the tail point i1 + 63
+        double WA[64], WB[64], ww[64], gw[64];
         for (uint32_t l = 0; l < 64; l++) {
             const uint32_t iw = i1 + l;
             gw[l] = ww[l] = 0.0;
-            if (iw > n) continue;
+            if (iw > n || l == 63) continue;
             double lnG = 0.0;
             for (int h = 0; h < 64; h++)
                 if (hm[h]) lnG += rows[h][iw];
             gw[l] = exp(lnG);
             ww[l] = exp(std::min(0.0, ln_n + lnG));
         }
+        double incl = 0.0, a_tot = 0.0;
+        for (uint32_t l = 0; l < 64; l++) a_tot += ww[l];
+        for (uint32_t l = 0; l < 64; l++) {
+            const uint32_t iw = i1 + l;
+            const bool vi = iw <= n;
+            incl += ww[l];
+            const double len_tail = vi ? (double)(n - iw + 1u) : 0.0;
+            WA[l] = l == 63 ? len_tail * (a_tot + 1.0) : (vi ? incl - ww[l] : 0.0);
+            WB[l] = l == 63 ? len_tail : gw[l];
+        }
         const double nn = (double)n_refs;
+        const bool has_tail = i1 + 63u <= n;
         auto crit = [&](uint32_t u) {
-            double P[64], R = 0.0;
-            bool falling = true;
-            for (uint32_t l = 0; l < 64; l++) P[l] = i1 + l <= n ? exp(ln_pmf_tab(lf, t, n, u, i1 + l, ln_total)) : 0.0;
-            if (i_last < n) {
-                const uint32_t j = i_last + 1u;
-                const double up = (double)(u + j) * (double)(n - j), dn = (double)(j + 1u) * (double)(t - u + n - j - 1u);
-                falling = up < dn;
-                R = (double)(n - i_last) * exp(ln_pmf_tab(lf, t, n, u, j, ln_total));
-            }
-            double tot = 0.0;
-            for (uint32_t l = 0; l < 64; l++) tot += P[l];
-            double a = 0.0, b = 0.0, incl = 0.0;
+            double a = 0.0, b = 0.0;
             for (uint32_t l = 0; l < 64; l++) {
-                incl += P[l];
-                a += ww[l] * ((tot - incl) + R);
-                b += gw[l] * P[l];
+                const double P = i1 + l <= n ? exp(ln_pmf_tab(lf, t, n, u, i1 + l, ln_total)) : 0.0;
+                a += P * WA[l];
+                b += P * WB[l];
             }
-            return falling && nn * (a + R) <= 0.5e-12 && nn * (b + R) <= 0.5e-12;
+            bool falling = true;
+            if (has_tail) {
+                const uint32_t j = i1 + 63u;
+                falling = (double)(u + j) * (double)(n - j) < (double)(j + 1u) * (double)(t - u + n - j - 1u);
+            }
+            return falling && nn * a <= 0.5e-12 && nn * b <= 0.5e-12;
         };
         uint32_t lo2 = u_max, hi2 = h_min - 1u;
         while (lo2 < hi2) {

@@ -31,10 +31,10 @@
 //       gamma = what their removal adds to the kept entries = sum_{i>i*} F'(i) (1 - prod_dropped cmf_r(i))
 //               <= Z' [ sum_{i in W} min(1, N G(i)) N tail_u(i) + N tail_u(end of W) ]   for any window W = (i*, i_w].
 //     With alpha <= delta from (1): every probability and every sum of probabilities over any set of references moves by at most
-//     2 (alpha + beta + gamma) / min(Z, Z') (Z, Z' >= 1 - 2 eps).  The kernel takes W = 64 values of i (lanes), tail_u(i) <= the sum of
-//     pmf_u over the rest of W + R, R = (n - i_w) pmf_u(i_w + 1) >= tail_u(i_w) once pmf_u falls there, and searches the largest u
-//     below min H with N [sum_W min(1, N G) S_u + R] <= eps / 2 and N [sum_W G pmf_u + R] <= eps / 2 by bisection, starting from
-//     the u of (2) (a valid threshold on its own).  On the bench workload u rises from ~365 to ~440 (t ~ 640, best hit ~580).
+//     2 (alpha + beta + gamma) / min(Z, Z') (Z, Z' >= 1 - 2 eps).  The kernel takes W = 63 values of i (lanes), tail_u(i) <= the sum of
+//     pmf_u over the rest of W + R, R = (n - i_w) pmf_u(i_w + 1) >= tail_u(i_w) once pmf_u falls there (lane 63), and searches the
+//     largest u below min H with N [sum_W min(1, N G) S_u + R] <= eps / 2 and N [sum_W G pmf_u + R] <= eps / 2 by bisection, starting
+//     from the u of (2) (a valid threshold on its own).  On the bench workload u rises from ~365 to ~440 (t ~ 640, best hit ~580).
 // A tile is dead for a query if u >= 1 and ub(T) <= u (a query without a threshold has every tile counted); a (pair, tile)
 // block of hit_count_pair_kernel leaves at once if the tile is dead for both queries.  The references that are never counted
 // are booked into histogram bin 0: cmf_0 = 1, so they drop out of every product -- the approximation bounded in (2) -- and
@@ -51,6 +51,12 @@ namespace rtx {
 
 static constexpr double kPruneLnEps = -27.631021115928547;  // ln 1e-12
 static constexpr double kPruneHalfEps = 0.5e-12;
+#ifndef RTX_PRUNE_WAVES
+#define RTX_PRUNE_WAVES 4
+#endif
+#ifndef RTX_PRUNE_TURNS
+#define RTX_PRUNE_TURNS 8  // rows of the best block in flight per wave: 8 x this (16: 17 registers spill at four waves per SIMD)
+#endif
 
 __device__ __forceinline__ uint32_t wave_max_u32p(uint32_t v) {
 #pragma unroll
@@ -61,12 +67,13 @@ __device__ __forceinline__ uint32_t wave_max_u32p(uint32_t v) {
     return v;
 }
 
-__global__ __launch_bounds__(64) void prune_kernel(PruneParams p, ProbTables tb) {
+__global__ __launch_bounds__(64, RTX_PRUNE_WAVES) void prune_kernel(PruneParams p, ProbTables tb) {  // four waves per SIMD (<= 128 VGPRs): the kernel is a chain of dependent round trips per query, occupancy is what hides them
     extern __shared__ uint16_t ub_lds[];  // [2][ntiles]
     const uint32_t pair = blockIdx.x, lane = threadIdx.x;
     const uint32_t bpt = 8192u >> kPruneShift;  // blocks per tile
     const double ln_n = log((double)p.n_total);
     uint32_t thr[2] = {0u, 0u};
+    uint32_t ist_prev = 0;  // i* + 1 of the pair's first query (the second one's search starts there)
     unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // wave-uniform: what this wave adds to p.stats
     const bool has_b = pair * 2u + 1u < p.nq;
     for (uint32_t x = 0; x < 2u; x++) {
@@ -150,21 +157,38 @@ __global__ __launch_bounds__(64) void prune_kernel(PruneParams p, ProbTables tb)
             }
             uint32_t acc[4] = {0u, 0u, 0u, 0u};  // [pair of references of this lane's chunk]: two 16-bit counters (at most 1023 rows)
             const uint32_t nr_pad = (nr + 63u) & ~63u;  // the row list is padded with the all-zero row to whole chunks of 64
-            for (uint32_t i0 = 0; i0 < nr; i0 += 4u * kRowsPerTurn) {
-                uint32_t row[4], w[4];
+            // The rows are random lines of the best tile's region (HBM, not L2): kTurns turns = kTurns * kRowsPerTurn rows are in flight
+            // together, their row ids come in as whole 256-byte pieces of the list (lane l <- entry l, handed to the lanes of a row
+            // group with a shuffle) and the ids of the next piece are requested before this piece's lines are waited for -- one exposed
+            // round trip per piece (a loop of 32 rows with its ids loaded per row group paid two per 32).
+            constexpr uint32_t kTurns = RTX_PRUNE_TURNS, kPiece = kTurns * kRowsPerTurn;  // 64 or 128 rows
+            static_assert(kPiece % 64u == 0u && kPiece <= 128u, "a piece of the row list = one or two loads per lane");
+            auto load_ids = [&](uint32_t i0, uint32_t (&id)[2]) {
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const uint32_t i = i0 + (uint32_t)u * kRowsPerTurn + rg;
-                    row[u] = i < nr_pad ? rows[i] : zero_row;
+                for (uint32_t k = 0; k < kPiece / 64u; k++) {
+                    const uint32_t i = i0 + k * 64u + lane;
+                    id[k] = i < nr_pad ? rows[i] : zero_row;  // (the list is padded to whole chunks of 64 with the zero row)
+                }
+            };
+            uint32_t id[2] = {zero_row, zero_row}, idn[2] = {zero_row, zero_row};
+            load_ids(0, id);
+            for (uint32_t i0 = 0; i0 < nr; i0 += kPiece) {
+                if (i0 + kPiece < nr) load_ids(i0 + kPiece, idn);  // wave-uniform
+                uint32_t w[kTurns];
+#pragma unroll
+                for (uint32_t u = 0; u < kTurns; u++) {
+                    const uint32_t e = u * kRowsPerTurn + rg;  // entry of the piece this lane's row group takes in turn u
+                    const uint32_t row = (uint32_t)__shfl((int)id[e >> 6], (int)(e & 63u), 64);
+                    w[u] = p.bitmap[bitmap_word(row, word, p.n_rows1)];
                 }
 #pragma unroll
-                for (int u = 0; u < 4; u++) w[u] = p.bitmap[bitmap_word(row[u], word, p.n_rows1)];
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
+                for (uint32_t u = 0; u < kTurns; u++) {
                     const uint32_t bt = (w[u] >> bit) & 0xFFu;
 #pragma unroll
                     for (int k = 0; k < 4; k++) acc[k] += ((bt >> (2 * k)) & 1u) | (((bt >> (2 * k + 1)) & 1u) << 16);
                 }
+                id[0] = idn[0];
+                id[1] = idn[1];
             }
 #pragma unroll
             for (int k = 0; k < 4; k++)
@@ -234,17 +258,42 @@ __global__ __launch_bounds__(64) void prune_kernel(PruneParams p, ProbTables tb)
                 const uint32_t h_min = 0xFFFFFFFFu - wave_max_u32p(hm ? 0xFFFFFFFFu - hm : 0u);  // <= M: H holds the best one
                 auto passes = [&](uint32_t i) -> bool {
                     const double v = hm ? Ct[(size_t)hm * (n + 1) + i] : 0.0;  // ln cmf_m(i)
-                    return wave_sum_f64(v) + log(n_h + (double)p.n_total * (double)(i + 1u)) <= kPruneLnEps;
+                    return wave_sum_f64_dpp(v) + log(n_h + (double)p.n_total * (double)(i + 1u)) <= kPruneLnEps;
                 };
                 uint32_t ist1 = 0;  // i* + 1 in the end (0: none)
                 if (passes(0u)) {
-                    uint32_t lo = 0, hi = n - 2u;
-                    while (lo < hi) {  // wave-uniform
-                        const uint32_t mid = (lo + hi + 1u) >> 1;
-                        if (passes(mid)) lo = mid; else hi = mid - 1u;
+                    // passes() is monotone (G and the factor rise with i): the boundary is found by galloping away from a guess and a
+                    // bisection of the bracket -- the same i* as a plain bisection of [0, n - 2], in fewer round trips (every probe is a
+                    // gather from the 740 MB of tables; the probes around a good guess share their cache lines).  Guess: the second query
+                    // of the pair starts at the first one's i* (neighbours are relatives); the first at mean - 6 sd of the best hit.
+                    uint32_t g;
+                    if (x == 1u && ist_prev) g = ist_prev - 1u;
+                    else {
+                        const double pm = (double)M / (double)t;
+                        const double mu = (double)n * pm, sd = sqrt((double)n * pm * (1.0 - pm) * (double)(t + n) / (double)(t + 1u));
+                        const double gg = mu - 6.0 * sd;
+                        g = gg > 0.0 ? (uint32_t)gg : 0u;
+                    }
+                    g = g > n - 2u ? n - 2u : g;
+                    uint32_t lo, hi;  // passes(lo), and !passes(hi) or hi == n - 1 (beyond the range)
+                    if (passes(g)) {
+                        lo = g;
+                        uint32_t step = 1u;
+                        while (lo + step <= n - 2u && passes(lo + step)) { lo += step; step <<= 1; }  // wave-uniform
+                        hi = lo + step <= n - 2u ? lo + step : n - 1u;
+                    } else {
+                        hi = g;
+                        uint32_t step = 1u;
+                        while (hi > step && !passes(hi - step)) { hi -= step; step <<= 1; }
+                        lo = hi > step ? hi - step : 0u;
+                    }
+                    while (hi - lo > 1u) {
+                        const uint32_t mid = (lo + hi) >> 1;
+                        if (passes(mid)) lo = mid; else hi = mid;
                     }
                     ist1 = lo + 1u;
                 }
+                ist_prev = ist1;
                 if (ist1) {
                     const uint32_t i1 = ist1;  // = i* + 1: the first i that stays
                     const double ln_len = log((double)(n - i1 + 1u));
@@ -260,9 +309,14 @@ __global__ __launch_bounds__(64) void prune_kernel(PruneParams p, ProbTables tb)
                     u_max = first_fail - 1u;
                     i1_q = i1;
                     // ---- the tighter criterion (header, "(3)"): the same two error terms, but every i weighted with what G leaves of
-                    // it.  Lanes <-> the window i = i1 .. i1 + 63 (beyond it G counts as 1 and the tail of u as one lump R).
+                    // it.  Lanes 0 .. 62 <-> the window i = i1 .. i1 + 62; lane 63 <-> the point behind it, j = i1 + 63, which stands for
+                    // the whole tail of pmf_u from there on ((n - j + 1) pmf_u(j) once pmf_u falls; G counts as 1 out there).  With
+                    //   A(l) = sum_{l' < l} min(1, N G(i_l'))  (what a hit at i_l costs through every smaller i of the window)
+                    // the two sums are sum_l pmf_u(i_l) WA(l) and sum_l pmf_u(i_l) WB(l) with weights that do not depend on u:
+                    // one exp and two wave sums per candidate.
                     {
                         const uint32_t iw = i1 + lane;
+                        const bool tail_pt = lane == 63u;
                         const bool vi = iw <= n;
                         double lnG = 0.0;
                         unsigned long long hb = __ballot(hm != 0u);
@@ -272,24 +326,23 @@ __global__ __launch_bounds__(64) void prune_kernel(PruneParams p, ProbTables tb)
                             const uint32_t m = (uint32_t)__builtin_amdgcn_readlane((int)hm, h);
                             lnG += Ct[(size_t)m * (n + 1) + (vi ? iw : n)];
                         }
-                        const double gw = vi ? exp(lnG) : 0.0;                         // G(i)
-                        const double ww = vi ? exp(fmin(0.0, ln_n + lnG)) : 0.0;      // min(1, N G(i))
-                        const uint32_t i_last = i1 + 63u < n ? i1 + 63u : n;
+                        const double gw = vi && !tail_pt ? exp(lnG) : 0.0;                         // G(i)
+                        const double ww = vi && !tail_pt ? exp(fmin(0.0, ln_n + lnG)) : 0.0;      // min(1, N G(i))
+                        const double incl = wave_incl_scan_f64_dpp(ww);
+                        const double a_tot = readlane_f64(incl, 63);
+                        const double len_tail = vi ? (double)(n - iw + 1u) : 0.0;                 // lane 63: the values of i from j on
+                        const double WA = tail_pt ? len_tail * (a_tot + 1.0) : (vi ? incl - ww : 0.0);
+                        const double WB = tail_pt ? len_tail : gw;
                         const double nn = (double)p.n_total;
+                        const bool has_tail = i1 + 63u <= n;  // wave-uniform
                         auto crit = [&](uint32_t u) -> bool {
-                            const double P = vi ? exp(ln_pmf_tab(lf, t, n, u, iw, ln_total)) : 0.0;  // pmf_u(i)
-                            double R = 0.0;   // everything of pmf_u behind the window
+                            const double P = vi ? exp(ln_pmf_tab(lf, t, n, u, iw, ln_total)) : 0.0;  // pmf_u(i_l)
                             bool falling = true;
-                            if (i_last < n) {
-                                const uint32_t j = i_last + 1u;
-                                const double up = (double)(u + j) * (double)(n - j), dn = (double)(j + 1u) * (double)(t - u + n - j - 1u);
-                                falling = up < dn;  // pmf_u(j + 1) < pmf_u(j), and the ratio falls with j
-                                R = (double)(n - i_last) * exp(ln_pmf_tab(lf, t, n, u, j, ln_total));
+                            if (has_tail) {  // pmf_u(j + 1) < pmf_u(j) at j = i1 + 63, and the ratio falls with j
+                                const uint32_t j = i1 + 63u;
+                                falling = (double)(u + j) * (double)(n - j) < (double)(j + 1u) * (double)(t - u + n - j - 1u);
                             }
-                            const double incl = wave_incl_scan_f64(P);
-                            const double S = (readlane_f64(incl, 63) - incl) + R;     // >= tail_u(i) = sum_{j > i} pmf_u(j)
-                            const double a = wave_sum_f64(ww * S), b = wave_sum_f64(gw * P);
-                            return falling && nn * (a + R) <= kPruneHalfEps && nn * (b + R) <= kPruneHalfEps;
+                            return falling && nn * wave_sum_f64_dpp(P * WA) <= kPruneHalfEps && nn * wave_sum_f64_dpp(P * WB) <= kPruneHalfEps;
                         };
                         uint32_t lo = u_max, hi = h_min - 1u;
                         while (lo < hi) {  // wave-uniform

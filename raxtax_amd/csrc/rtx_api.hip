@@ -216,10 +216,11 @@ struct rtx_index {
         DevBuf<double> d_table_z, d_prefix;
         DevBuf<uint2> d_urec;   // hit_count_pair_kernel: union row lists of the pairs of the sub-batch
         DevBuf<uint32_t> d_nu;
-        // tile pruning: the queries counted against the union bitmap (every row dense: constant masks), the live tiles per pair
+        // tile pruning: the queries counted against the union bitmap (every row dense: constant masks) leave the largest bound of
+        // every tile and the best block (bounds_epilogue); thresholds and the live tiles per pair (prune_kernel)
         DevBuf<unsigned long long> d_uones;
-        DevBuf<uint32_t> d_uzero, d_uhist, d_live;
-        DevBuf<uint16_t> d_ucounts, d_utmax, d_prune_thr, d_prune_i1;
+        DevBuf<uint32_t> d_uzero, d_live, d_best_key;
+        DevBuf<uint16_t> d_tile_ub, d_prune_thr, d_prune_i1;
         DevBuf<uint32_t> d_best;  // [B][kPruneBestWords] reference shards: the candidate for the best block of the database
     } sc[2];
     bool staged = false;  // driven with rtx_shard_*: sub-batch sb works in scratch set sb & 1, so that the exchange of one
@@ -426,26 +427,29 @@ int enqueue_hit(rtx_index *ix, const SubBatch &b, uint32_t flags, hipStream_t s,
         up.dmask = sc.d_uones.p;
         up.nsparse = sc.d_uzero.p;
         up.ntiles = ix->u_ntiles;
-        const uint32_t unpad = ix->u_ntiles * 8192u;
-        up.counts = nullptr;  // packed like the counts of the database: low bytes, behind them the high bits
-        up.counts_lo = reinterpret_cast<uint8_t *>(sc.d_ucounts.p);
-        up.counts_hi = reinterpret_cast<uint16_t *>(up.counts_lo + (size_t)b.nq * unpad);
-        up.npad = unpad;
-        up.hist = sc.d_uhist.p;
-        up.tile_max = sc.d_utmax.p;
+        up.counts = nullptr;  // nothing is stored per block: the epilogue keeps the largest bound per tile and the best block
+        up.counts_lo = nullptr;
+        up.counts_hi = nullptr;
+        up.hist = nullptr;
+        up.tile_max = nullptr;
+        up.bounds_tile_ub = sc.d_tile_ub.p;
+        up.bounds_tile_stride = ix->ntiles;
+        up.bounds_ntiles = ix->ntiles;
+        up.bounds_best = sc.d_best_key.p;
         up.flags = 0;
         up.group_base = hp.group_base + ix->n_groups_run;  // work accounting apart from the counting proper
         if (part != 2) {
             if (b.timed) RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_TILE_BOUNDS, 0), s));
-            launch_hit_count_pair(s, up, b.nq, ix->u_ntiles);  // the union of the pair's rows serves both passes
+            RTX_HIP(hipMemsetAsync(sc.d_best_key.p, 0, (size_t)b.nq * 4, s));  // the waves of a query's union tiles meet in an atomicMax
+            launch_hit_count_pair_bounds(s, up, b.nq, ix->u_ntiles);  // the union of the pair's rows serves both passes
             if (b.timed) RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_TILE_BOUNDS, 1), s));
         }
         if (b.timed && part != 1) RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_TILE_PRUNE, 0), s));
         // (2) bounds per tile, a lower bound of the best hit, the threshold, the live tiles of every pair
         PruneParams pr{};
-        pr.ucounts_lo = up.counts_lo;
-        pr.ucounts_hi = up.counts_hi;
-        pr.unpad = unpad;
+        pr.tile_ub = sc.d_tile_ub.p;
+        pr.best_key = sc.d_best_key.p;
+        pr.tile_ub_stride = ix->ntiles;
         pr.ntiles = ix->ntiles;
         pr.nq = b.nq;
         pr.n_refs = ix->n_refs;
@@ -472,8 +476,6 @@ int enqueue_hit(rtx_index *ix, const SubBatch &b, uint32_t flags, hipStream_t s,
         pr.thr_out = sc.d_prune_thr.p;
         pr.i1_out = sc.d_prune_i1.p;
         pr.stats = ix->d_prune_stats.p;
-        pr.ubitmap = ix->d_ubitmap.p;
-        pr.ustride_bytes = ix->u_stride_bytes;
         pr.detail = ix->debug_taps && ix->d_prune_detail.n >= (size_t)b.nq * kPruneDetailWords ? ix->d_prune_detail.p : nullptr;
         ProbTables tb{ix->d_tab_cmf.p, ix->d_tab_ratio.p, ix->d_tab_off.p, ix->d_tab_moff.p, ix->d_tab_ilo.p, ix->d_tab_sat.p, ix->tab_tmax};
         launch_prune(s, pr, tb, b.nq);
@@ -642,7 +644,7 @@ int begin_run(rtx_index *ix, uint32_t *n_sub_out, bool *timed_out, bool cluster)
     const bool whole = ix->n_refs == ix->n_total && !ix->staged;
     const bool shard = ix->staged && ix->shard_prune_opt && ix->n_refs != ix->n_total;
     auto scratch_ok = [&](const rtx_index::Scratch &sc) {  // sized at the upload / rtx_shard_begin (alloc_scratch_set) for this sub-batch size
-        return sc.d_ucounts.p != nullptr && sc.d_ucounts.n >= (size_t)ix->sub_batch * ix->u_ntiles * 8192u && sc.d_prune_thr.n >= ix->sub_batch &&
+        return sc.d_tile_ub.p != nullptr && sc.d_tile_ub.n >= (size_t)ix->sub_batch * ix->ntiles && sc.d_best_key.n >= ix->sub_batch && sc.d_prune_thr.n >= ix->sub_batch &&
                sc.d_live.n >= (size_t)((ix->sub_batch + 1u) / 2u) * ((ix->ntiles + 31u) / 32u + 1u) && sc.d_best.n >= (size_t)ix->sub_batch * kPruneBestWords;
     };
     ix->prune_used = ix->prune_opt && ix->pair_used && ix->use_tables && ix->tile_skip && ix->d_ubitmap.p && (whole || shard) &&
@@ -813,7 +815,7 @@ int prepare_workspace(rtx_index *ix, uint64_t n_queries, uint64_t tmax, uint64_t
     const uint64_t per_q = (uint64_t)ix->kstride * 2 + (uint64_t)ix->rstride * 12 + 4 + (uint64_t)ix->ntiles * (ix->rstride / 8 + ((kSegMaxSparseRows + 1) * 4 + 10)) + (ix->packed() ? ix->npad * 5 / 4 : ix->npad * 2) + (uint64_t)ix->hstride * 12 +
                            (uint64_t)ix->n_bnd_local * 8 + 64 +
                            // + the scratch of the tile pruning: counts against the union bitmap, constant masks, its histogram, thresholds, live masks
-                           (will_prune ? (uint64_t)ix->u_ntiles * (8192u * 2u + ix->rstride / 8 + 6) + (uint64_t)ix->hstride * 4 + 4 + (ix->ntiles + 31u) / 32u * 2u + 2u : 0);
+                           (will_prune ? (uint64_t)ix->u_ntiles * (ix->rstride / 8 + 4) + (uint64_t)ix->ntiles * 2 + 12 + (ix->ntiles + 31u) / 32u * 2u + 2u + kPruneBestWords * 4 : 0);
     uint32_t B = ix->sub_batch_req;
     if (B == 0) {
         size_t free_b = 0, total_b = 0;
@@ -848,12 +850,10 @@ int alloc_scratch_set(rtx_index *ix, uint32_t k) {
             const size_t mw = (size_t)B * ix->u_ntiles * (ix->rstride / 64);
             const bool fresh = sc.d_uones.n < mw;
             if ((rc = sc.d_uones.alloc(mw)) || (rc = sc.d_uzero.alloc((size_t)B * ix->u_ntiles)) ||
-                (rc = sc.d_ucounts.alloc((size_t)B * ix->u_ntiles * 8192u)) || (rc = sc.d_uhist.alloc((size_t)B * ix->hstride)) ||
-                (rc = sc.d_utmax.alloc((size_t)B * ix->u_ntiles)) || (rc = sc.d_prune_thr.alloc(B)) || (rc = sc.d_prune_i1.alloc(B)) || (rc = sc.d_best.alloc((size_t)B * kPruneBestWords)) || (rc = sc.d_live.alloc((size_t)((B + 1u) / 2u) * ((ix->ntiles + 31u) / 32u + 1u))))
+                (rc = sc.d_tile_ub.alloc((size_t)B * ix->ntiles)) || (rc = sc.d_best_key.alloc(B)) || (rc = sc.d_prune_thr.alloc(B)) || (rc = sc.d_prune_i1.alloc(B)) || (rc = sc.d_best.alloc((size_t)B * kPruneBestWords)) || (rc = sc.d_live.alloc((size_t)((B + 1u) / 2u) * ((ix->ntiles + 31u) / 32u + 1u))))
                 return rc;
             if (fresh) RTX_HIP(hipMemsetAsync(sc.d_uones.p, 0xFF, sc.d_uones.n * 8, ix->stream));
             RTX_HIP(hipMemsetAsync(sc.d_uzero.p, 0, sc.d_uzero.n * 4, ix->stream));
-            RTX_HIP(hipMemsetAsync(sc.d_uhist.p, 0, sc.d_uhist.n * 4, ix->stream));
         }
     }
     return RTX_OK;

@@ -409,6 +409,68 @@ __device__ __forceinline__ void hit_epilogue_x(const HitParams &p, uint32_t (&pl
     RTX_EPI_DONE
 }
 
+// ---------------------------------------------------------------------------
+// Epilogue of the BOUNDS pass of the tile pruning (rtx_prune.hip): the "references" of this launch are blocks of 2^kPruneShift
+// references of the database (the union bitmap), a count is an upper bound of the counts of the block's members.  Nothing is stored
+// per block: what prune_kernel needs is the largest bound of every tile of the DATABASE (8192 >> kPruneShift blocks: with blocks of 64
+// the 128 blocks that group gi of the 16 lanes of one DPP row hold) and the block with the largest bound of all (the lowest one among
+// equals): key = bound << 20 | (0xFFFFF - block), the maximum over the wave, atomicMax over the waves of the query's union tiles.
+// No histogram, no count stores, no lists (every row of the union bitmap is read densely).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t row16_max_u32(uint32_t v) {  // maximum over the 16 lanes of a DPP row, in every lane of the row
+    uint32_t o;
+    o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true); v = o > v ? o : v;   // quad_perm [1,0,3,2]
+    o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true); v = o > v ? o : v;   // quad_perm [2,3,0,1]
+    o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true); v = o > v ? o : v;  // row_half_mirror
+    o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, true); v = o > v ? o : v;  // row_mirror
+    return v;
+}
+
+template <int NP>
+__device__ __forceinline__ void bounds_epilogue(const HitParams &p, uint32_t (&pl)[4][NP], uint32_t q, uint32_t utile, uint32_t lane) {
+    static_assert(kPruneShift == 6, "128 blocks per tile of the database = one group of 8 per lane of a DPP row");
+    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+    auto pkmax = [](uint32_t a, uint32_t b) -> uint32_t {
+        u16x2 x, y;
+        __builtin_memcpy(&x, &a, 4);
+        __builtin_memcpy(&y, &b, 4);
+        const u16x2 m = __builtin_elementwise_max(x, y);
+        uint32_t r;
+        __builtin_memcpy(&r, &m, 4);
+        return r;
+    };
+    uint32_t best = 0;  // key of this lane's best block
+    uint16_t *tub = p.bounds_tile_ub + (size_t)q * p.bounds_tile_stride;
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+#pragma unroll
+        for (int g2 = 0; g2 < 4; g2++) {
+            const uint32_t gi = (uint32_t)(w * 4 + g2);
+            uint32_t lo0, hi0, lo1, hi1;
+            planes_unpack8<NP>(pl[w], g2, lo0, hi0, lo1, hi1);
+            // (count << 3) | (7 - j) of the eight blocks as packed u16: the maximum is the largest count, the lowest block among equals
+            const uint32_t vx = (__builtin_amdgcn_perm(hi0, lo0, 0x05010400u) << 3) | 0x00060007u;
+            const uint32_t vy = (__builtin_amdgcn_perm(hi0, lo0, 0x07030602u) << 3) | 0x00040005u;
+            const uint32_t vz = (__builtin_amdgcn_perm(hi1, lo1, 0x05010400u) << 3) | 0x00020003u;
+            const uint32_t vw = (__builtin_amdgcn_perm(hi1, lo1, 0x07030602u) << 3) | 0x00000001u;
+            const uint32_t m2 = pkmax(pkmax(vx, vy), pkmax(vz, vw));
+            const uint32_t m = (m2 & 0xFFFFu) > (m2 >> 16) ? (m2 & 0xFFFFu) : (m2 >> 16);
+            const uint32_t blk0 = utile * 8192u + gi * 512u + lane * 8u;
+            const uint32_t key = ((m >> 3) << 20) | (0xFFFFFu - blk0 - 7u + (m & 7u));  // block blk0 + j, j = 7 - (m & 7)
+            best = key > best ? key : best;
+            const uint32_t tmax = row16_max_u32(m >> 3);
+            const uint32_t T = utile * 64u + gi * 4u + (lane >> 4);
+            if ((lane & 15u) == 0u && T < p.bounds_ntiles) tub[T] = (uint16_t)tmax;
+        }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const uint32_t o = (uint32_t)__shfl_xor((int)best, d, 64);
+        best = o > best ? o : best;
+    }
+    if (lane == 0) atomicMax(&p.bounds_best[q], best);
+}
+
 template <int NP, bool kPacked, bool kPrefetch = false>
 __device__ __forceinline__ void hit_epilogue(const HitParams &p, uint32_t (&pl)[4][NP], uint32_t q, uint32_t tile, uint32_t lane,
                                              uint32_t t, bool active, uint32_t *hist_lds, uint32_t *cnt8, uint32_t ns,

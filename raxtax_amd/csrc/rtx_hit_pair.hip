@@ -125,7 +125,9 @@ __device__ __forceinline__ void fold_seg(uint32_t (&pa)[4][NP], uint32_t (&pb)[4
     }
 }
 
-template <int NP, bool kPacked>
+// kBounds: the bounds pass of the tile pruning -- the bitmap is the union bitmap (every row dense: the caller passes constant masks and
+// no sparse lists), the epilogue keeps the largest bound per tile of the database and the best block instead of counts (bounds_epilogue).
+template <int NP, bool kPacked, bool kBounds>
 __global__ __launch_bounds__(64, 2) void hit_count_pair_kernel(HitParams p) {
     extern __shared__ uint32_t lds_dw[];
     const uint32_t tile = blockIdx.y, lane = threadIdx.x;
@@ -134,7 +136,7 @@ __global__ __launch_bounds__(64, 2) void hit_count_pair_kernel(HitParams p) {
     const uint32_t pair = blockIdx.x < np8 * 8u ? (blockIdx.x & 7u) * np8 + (blockIdx.x >> 3) : blockIdx.x;
     const uint32_t qa = pair * 2u, qb = qa + 1u;
     const bool has_b = qb < p.nq;
-    if (p.live && !((p.live[(size_t)pair * p.live_words + (tile >> 5)] >> (tile & 31u)) & 1u)) return;  // tile pruning (rtx_prune.hip): nothing in this tile can matter to either query
+    if (!kBounds && p.live && !((p.live[(size_t)pair * p.live_words + (tile >> 5)] >> (tile & 31u)) & 1u)) return;  // tile pruning (rtx_prune.hip): nothing in this tile can matter to either query
     uint32_t *l_both = lds_dw, *l_a = lds_dw + kPairListDw, *l_b = lds_dw + 2u * kPairListDw;
     unsigned long long *m_a = reinterpret_cast<unsigned long long *>(lds_dw + 3u * kPairListDw), *m_b = m_a + kPairMaskWords;
     uint32_t *l_zero = reinterpret_cast<uint32_t *>(m_b + kPairMaskWords);
@@ -167,7 +169,7 @@ __global__ __launch_bounds__(64, 2) void hit_count_pair_kernel(HitParams p) {
     };
     uint2 rec[8];
     load_recs(rec, 0);
-    const uint32_t ns_a = p.nsparse[(size_t)qa * p.ntiles + tile], ns_b = has_b ? p.nsparse[(size_t)qb * p.ntiles + tile] : 0u;
+    const uint32_t ns_a = kBounds ? 0u : p.nsparse[(size_t)qa * p.ntiles + tile], ns_b = !kBounds && has_b ? p.nsparse[(size_t)qb * p.ntiles + tile] : 0u;
     const uint32_t *srows_a = p.srows + ((size_t)qa * p.ntiles + tile) * (kSegMaxSparseRows + 1);
     const uint32_t *srows_b = p.srows + ((size_t)(has_b ? qb : qa) * p.ntiles + tile) * (kSegMaxSparseRows + 1);
     {
@@ -176,8 +178,8 @@ __global__ __launch_bounds__(64, 2) void hit_count_pair_kernel(HitParams p) {
         uint32_t sa[kSparseIt], sb[kSparseIt];
 #pragma unroll
         for (int it = 0; it < kSparseIt; it++) {  // unconditional: the lists have kSegMaxSparseRows + 1 entries
-            sa[it] = srows_a[(uint32_t)it * 64u + lane];
-            sb[it] = srows_b[(uint32_t)it * 64u + lane];
+            sa[it] = kBounds ? 0u : srows_a[(uint32_t)it * 64u + lane];
+            sb[it] = kBounds ? 0u : srows_b[(uint32_t)it * 64u + lane];
         }
         for (uint32_t i = lane; i < mwords; i += 64) {
             m_a[i] = dm_a[i];
@@ -261,6 +263,11 @@ __global__ __launch_bounds__(64, 2) void hit_count_pair_kernel(HitParams p) {
     if (lane == 0 && p.group_rows) atomicAdd(&p.group_rows[p.group_base + pair], rows_loaded);
 #endif
 
+    if (kBounds) {  // the largest bound per tile of the database and the best block of each query; nothing else leaves the wave
+        bounds_epilogue<NP>(p, pa, qa, tile, lane);
+        if (has_b) bounds_epilogue<NP>(p, pb, qb, tile, lane);
+        return;
+    }
     // epilogues: histogram (4 KiB) / byte counters of the whole tile (8 KiB) over the lists (dead now); the slots of the sparse
     // segments of BOTH queries are requested first (their ids wait in LDS since the prologue)
     uint32_t *hist_lds = lds_dw;
@@ -289,8 +296,12 @@ void launch_hit_count_pair(hipStream_t s, const HitParams &p, uint32_t nq, uint3
     static_assert(3u * kPairListDw >= 1024u + 2048u + 64u, "histogram (t <= 1023) and byte counters (+ pad words) alias the lists");
     static_assert(kSegMaxSparseRows + 1 >= kSparseIt * 64, "the slot id lists are read without a bound");
     const uint32_t np = (nq + 1u) / 2u;
-    if (p.counts_lo) hipLaunchKernelGGL((hit_count_pair_kernel<10, true>), dim3(np, ntiles), dim3(64), kPairLdsBytes, s, p);
-    else hipLaunchKernelGGL((hit_count_pair_kernel<10, false>), dim3(np, ntiles), dim3(64), kPairLdsBytes, s, p);
+    if (p.counts_lo) hipLaunchKernelGGL((hit_count_pair_kernel<10, true, false>), dim3(np, ntiles), dim3(64), kPairLdsBytes, s, p);
+    else hipLaunchKernelGGL((hit_count_pair_kernel<10, false, false>), dim3(np, ntiles), dim3(64), kPairLdsBytes, s, p);
+}
+
+void launch_hit_count_pair_bounds(hipStream_t s, const HitParams &p, uint32_t nq, uint32_t u_ntiles) {
+    hipLaunchKernelGGL((hit_count_pair_kernel<10, true, true>), dim3((nq + 1u) / 2u, u_ntiles), dim3(64), kPairLdsBytes, s, p);
 }
 
 }  // namespace rtx

@@ -143,6 +143,10 @@ struct HitParams {
     uint32_t pair_ustride;
     const uint32_t *live;     // [pairs][live_words] tiles to count for a pair (rtx_prune.hip) or null: all
     uint32_t live_words;
+    // the bounds pass of the tile pruning (hit_count_pair_kernel<.., kBounds>: this launch counts against the union bitmap)
+    uint16_t *bounds_tile_ub;     // [B][bounds_tile_stride] largest bound of every tile of the database
+    uint32_t bounds_tile_stride, bounds_ntiles;
+    uint32_t *bounds_best;        // [B] key of the block with the largest bound (bound << 20 | 0xFFFFF - block), zeroed by the caller
 };
 
 // tile pruning (rtx_prune.hip)
@@ -154,9 +158,9 @@ constexpr uint32_t kPruneShift = RTX_PRUNE_SHIFT;  // the union bitmap has one c
 static_assert(kPruneShift >= 3 && kPruneShift <= 6, "blocks of 8 .. 64 references");
 constexpr uint32_t kPruneBestWords = 66;  // PruneParams::best: {largest bound, 0, exact counts of the 64 references of that block}
 struct PruneParams {
-    const uint8_t *ucounts_lo;   // [B][unpad] counts of the queries against the union bitmap (an upper bound per block of
-    const uint16_t *ucounts_hi;  // [B][unpad / 8]  2^kPruneShift references), packed like HitParams::counts_lo / counts_hi
-    uint32_t unpad, ntiles, nq;
+    const uint16_t *tile_ub;     // [B][tile_ub_stride] largest bound of every tile (the bounds pass: bounds_epilogue, rtx_hit_common.hpp)
+    const uint32_t *best_key;    // [B] bound << 20 | (0xFFFFF - block) of the block with the largest bound, the lowest among equals
+    uint32_t tile_ub_stride, ntiles, nq;
     uint64_t n_refs;             // references on this handle
     uint64_t n_total;            // references of the whole database (the N of the threshold)
     uint32_t ref_base;           // global id of local reference 0 (reference-sharded index)
@@ -184,8 +188,6 @@ struct PruneParams {
     uint16_t *thr_out;        // [B] the threshold of every query (0: not pruned, every tile is counted)
     uint16_t *i1_out;         // [B] i* + 1 of every query with a threshold: Z holds less than 1e-12 at i <= i* (prob_lookup starts there)
     unsigned long long *stats;  // [kPruneStatCopies][8]: [0] += live tiles, [1] += pairs ... (reporting) or null
-    const uint32_t *ubitmap;    // debug (RTX_PRUNE_CHECK): the union bitmap
-    uint32_t ustride_bytes;
     uint32_t *detail;           // [B][kPruneDetailWords] debug tap (RTX_OPT_DEBUG_TAPS) or null: {best block, M, threshold, i* + 1, largest
                                 // bound, t, 0, 0, exact counts of the 64 references of the best block}
 };
@@ -276,6 +278,7 @@ void launch_hit_count(hipStream_t s, const HitParams &p, uint32_t nq, uint32_t n
 void launch_pair_union(hipStream_t s, const uint32_t *rows, const uint32_t *nrows, uint32_t rstride, uint32_t nq, uint2 *urec,
                        uint32_t *nu, uint32_t ustride);
 void launch_hit_count_pair(hipStream_t s, const HitParams &p, uint32_t nq, uint32_t ntiles);  // 10 bit planes only
+void launch_hit_count_pair_bounds(hipStream_t s, const HitParams &p, uint32_t nq, uint32_t u_ntiles);  // ... on the union bitmap: bounds_epilogue
 size_t prob_table_lds_bytes(uint32_t tmax);
 void launch_prob_table(hipStream_t s, const ProbParams &p, uint32_t nq);
 size_t prob_lookup_lds_bytes(uint32_t tmax);

@@ -79,52 +79,12 @@ __global__ __launch_bounds__(64, RTX_PRUNE_WAVES) void prune_kernel(PruneParams 
     for (uint32_t x = 0; x < 2u; x++) {
         if (x == 1u && !has_b) break;  // wave-uniform
         const uint32_t q = pair * 2u + x;
-        // ---- 1. bound of every tile, and the block with the largest bound.  The counts of the blocks are read as the
-        // counting pass packed them (low byte per block + the two high bits of eight blocks per u16); a wave takes 512
-        // consecutive blocks per turn, 8 per lane, four turns in flight: the 8192 >> shift blocks of a tile are held by
-        // bpt / 8 neighbouring lanes, which meet through shuffles
-        const uint8_t *ulo = p.ucounts_lo + (size_t)q * p.unpad;
-        const uint16_t *uhi = p.ucounts_hi + (size_t)q * (p.unpad >> 3);
-        const uint32_t lpt = bpt / 8u;  // lanes per tile in a turn (32 for blocks of 32 references): a power of two <= 64
-        uint32_t lmx = 0, lblk = 0;  // this lane's largest bound and its block
-        const uint32_t n_blocks_pad = p.ntiles * bpt;
-        for (uint32_t b0 = 0; b0 < n_blocks_pad; b0 += 4u * 512u) {
-            uint2 lo[4];
-            uint32_t hi[4];
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const uint32_t blk = b0 + (uint32_t)k * 512u + lane * 8u;
-                lo[k] = make_uint2(0u, 0u);
-                hi[k] = 0u;
-                if (blk < n_blocks_pad) {
-                    lo[k] = *reinterpret_cast<const uint2 *>(ulo + blk);
-                    hi[k] = uhi[blk >> 3];
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const uint32_t blk = b0 + (uint32_t)k * 512u + lane * 8u;
-                uint32_t mx = 0, arg = 0;
-#pragma unroll
-                for (int j = 0; j < 8; j++) {
-                    const uint32_t w = j < 4 ? lo[k].x : lo[k].y;
-                    const uint32_t c = ((w >> ((j & 3) * 8)) & 0xFFu) | (((hi[k] >> (2 * j)) & 3u) << 8);
-                    if (c > mx) { mx = c; arg = (uint32_t)j; }
-                }
-                if (mx > lmx) { lmx = mx; lblk = blk + arg; }
-                // the largest count of the tile: over the lpt lanes that hold its blocks
-                uint32_t tm = mx;
-                for (uint32_t d = 1; d < lpt; d <<= 1) {
-                    const uint32_t o = (uint32_t)__shfl_xor((int)tm, (int)d, 64);
-                    tm = o > tm ? o : tm;
-                }
-                const uint32_t T = blk / bpt;
-                if ((lane & (lpt - 1u)) == 0u && T < p.ntiles) ub_lds[x * p.ntiles + T] = (uint16_t)tm;
-            }
-        }
-        uint32_t ub_best = wave_max_u32p(lmx);
-        // the lowest block among those with the largest bound (0 if every bound is 0)
-        const uint32_t bb = ub_best ? 0xFFFFFFFFu - wave_max_u32p(lmx == ub_best ? 0xFFFFFFFFu - lblk : 0u) : 0u;
+        // ---- 1. bound of every tile, and the block with the largest bound (the lowest one among equals; block 0 if every bound is 0):
+        // left by the epilogue of the bounds pass (bounds_epilogue, rtx_hit_common.hpp)
+        for (uint32_t T = lane; T < p.ntiles; T += 64) ub_lds[x * p.ntiles + T] = p.tile_ub[(size_t)q * p.tile_ub_stride + T];
+        const uint32_t bkey = p.best_key[q];
+        uint32_t ub_best = bkey >> 20;
+        const uint32_t bb = 0xFFFFFu - (bkey & 0xFFFFFu);
         // ---- 2. exact counts of its references (not those that --skip-exact-matches zeroes); M = the best of them.  The
         // block's references lie in kChunks chunks of eight = that many bytes of a row segment, in neighbouring lane words
         // (ref_slot, rtx_math.hpp); lane l of a turn takes rows i0 + l and i0 + 64 + l and gathers those bytes, the hits of every
@@ -220,23 +180,6 @@ __global__ __launch_bounds__(64, RTX_PRUNE_WAVES) void prune_kernel(PruneParams 
             if (lane == 0) { bq[0] = ub_best; bq[1] = 0u; }
             continue;  // wave-uniform
         }
-#ifdef RTX_PRUNE_CHECK  // debug: the count of the best block recomputed from the union bitmap must equal what the counting pass left
-        if (p.ubitmap) {
-            uint32_t word, bit;
-            ref_slot(bb, p.ustride_bytes, word, bit);
-            const uint32_t nr = p.nrows[q];
-            const uint32_t *rows = p.rows + (size_t)q * p.rstride;
-            uint32_t cub = 0;
-            for (uint32_t i0 = 0; i0 < nr; i0 += 64) {
-                const uint32_t row = rows[i0 + lane];
-                cub += (p.ubitmap[bitmap_word(row, word, p.n_rows1)] >> bit) & 1u;
-            }
-#pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) cub += (uint32_t)__shfl_xor((int)cub, d, 64);
-            const uint32_t packed = (uint32_t)ulo[bb] | ((((uint32_t)uhi[bb >> 3] >> (2u * (bb & 7u))) & 3u) << 8);
-            if (cub != packed) st[7] += 1ull;
-        }
-#endif
         // ---- 3. the largest count a skipped tile may hold
         const uint32_t t = p.t[q], n = t >> 1;
         uint32_t u_max = 0, i1_q = 0;

@@ -74,26 +74,18 @@ def main():
         f.write("kernel,counter,dispatches,mean_per_dispatch,max_per_dispatch,sum\n")
         for k, c, n, mean, mx, tot in rows:
             f.write(f"\"{k}\",{c},{n},{mean:.1f},{mx:.1f},{tot:.1f}\n")
-        # the two kinds of launch of the hit_count kernel apart (tile pruning): by grid size
-        for agg in passes:
-            for k, d in sorted(agg.items()):
-                if not k.startswith("rtx::hit_count"):
-                    continue
-                for c, v in sorted(d.items()):
-                    g = GRID[(id(agg), k)][c]
-                    for kind, sel in split_kinds(g, a.unpruned).items():
-                        vals = [x for x, s_ in zip(v, sel) if s_]
-                        if vals:
-                            f.write(f"\"{k} [{kind}]\",{c},{len(vals)},{sum(vals) / len(vals):.1f},{max(vals):.1f},{sum(vals):.1f}\n")
     print("wrote", out)
 
     def hit(agg, ctr):
+        """Sum and number of the dispatches of the hit_count kernel per kind of launch.  The bounds pass of the tile pruning is an
+        instantiation of its own (hit_count_pair_kernel<10, true, true>: kBounds), so the kernel name tells the kinds apart."""
+        out = {}
         for k, d in agg.items():
             if k.startswith("rtx::hit_count") and ctr in d:   # hit_count_kernel / hit_count_pair_kernel: whichever the run used
-                v = d[ctr]
-                g = GRID[(id(agg), k)][ctr]
-                return {kind: (sum(x for x, s_ in zip(v, sel) if s_), sum(sel)) for kind, sel in split_kinds(g, a.unpruned).items()}
-        return None
+                kind = "all" if a.unpruned else ("bounds" if k.replace(" ", "").endswith(",true,true>") else "live")
+                tot, n = out.get(kind, (0.0, 0))
+                out[kind] = (tot + sum(d[ctr]), n + len(d[ctr]))
+        return out or None
 
     fetch, write = hit(passes[0], "FETCH_SIZE"), hit(passes[1], "WRITE_SIZE")
     if fetch is None or write is None:
@@ -123,16 +115,6 @@ def main():
     }
     tf.write_text(json.dumps(t, indent=1) + "\n")
     print("updated", tf, json.dumps(t["configs"][key]))
-
-
-def split_kinds(grids, unpruned):
-    """Which dispatches of the hit_count kernel are of which kind, by their grid: the bounds pass of the tile pruning runs on the union
-    bitmap (a tile or a few), the counting proper on every tile of the database (most blocks leave at once) -- 62 times the grid at
-    500k references.  Unpruned runs have one kind."""
-    if unpruned or len(set(grids)) == 1:
-        return {"all": [True] * len(grids)}
-    cut = (min(grids) * max(grids)) ** 0.5
-    return {"live": [g > cut for g in grids], "bounds": [g <= cut for g in grids]}
 
 
 if __name__ == "__main__":

@@ -306,7 +306,7 @@ def roofline_block(args, work, prob_work, stage_ms, stage_n, n_queries_step, que
                                       "sits in the 256 MB Infinity Cache -- what FETCH_SIZE counts here are refills of the eight L2s from it, not HBM reads)"}
     if prune is not None and prune.get("pairs"):
         out["tile_pruning"] = {
-            "live_tiles_per_pair": prune["live_tiles_per_pair"], "tiles": ntiles,
+            "live_tiles_per_pair": prune["live_tiles_per_pair"], "live_tiles_per_query": prune.get("live_tiles_per_query"), "tiles": ntiles,
             "mean_threshold": prune["mean_threshold"], "mean_best_hit_lower_bound": prune["mean_best_hit_lower_bound"],
             "tiles_above_threshold_per_query": prune.get("tiles_above_threshold_per_query"),     # what exact knowledge would count
             "queries_with_threshold": prune.get("queries_with_threshold"),
@@ -411,6 +411,7 @@ def extras_block(args, rx, lib, index, tree, db, qs, flags):
         dt = timed(plain)
         st = index.debug_prune_stats()
         sweep.append({"mu_q": mu, "value": 131072 / dt, "ms_per_step": dt * 1e3, "live_tiles_per_pair": st["live_tiles_per_pair"],
+                      "live_tiles_per_query": st.get("live_tiles_per_query"),
                       "share_with_threshold": st["queries_with_threshold"] / 131072, "mean_threshold": st["mean_threshold"],
                       "mean_best_hit_lower_bound": st["mean_best_hit_lower_bound"],
                       "tiles_above_threshold_per_query": st["tiles_above_threshold_per_query"]})

@@ -345,10 +345,10 @@ int rtx_debug_prob_table(rtx_index *index, uint64_t query, double *table_over_z 
 int rtx_debug_probs(rtx_index *index, uint64_t query, double *probs /*n_refs*/);
 /* processing order of the last run (RTX_OPT_CLUSTER / RTX_OPT_LOCATOR): perm[position] = query */
 int rtx_debug_order(rtx_index *index, uint32_t *perm /*n_queries*/);
-/* tile pruning of the last run (RTX_OPT_TILE_PRUNE): out[0] live (pair, tile) blocks, [1] pairs, [2] sum of the lower bounds of the
- * best hit, [3] sum of the thresholds, [4] sum of the largest tile bounds, [5] queries, [6] bounds below a count they bound (must be
- * 0), [7] debug builds only, [8] (query, tile) combinations with a count above the query's threshold -- what exact knowledge would
- * have counted --, [9] queries with a threshold; all 0 if the run did not prune */
+/* tile pruning of the last run (RTX_OPT_TILE_PRUNE): out[0] (pair, tile) blocks that are counted for at least one of their two queries, [1] pairs,
+ * [2] sum of the lower bounds of the best hit, [3] sum of the thresholds, [4] sum of the largest tile bounds, [5] queries, [6] bounds below a count
+ * they bound (must be 0), [7] (query, tile) combinations that are counted, [8] (query, tile) combinations with a count above the query's
+ * threshold -- what exact knowledge would have counted --, [9] queries with a threshold; all 0 if the run did not prune */
 int rtx_debug_prune_stats(rtx_index *index, uint64_t *out /*10*/);
 /* table / Z of a query of the last sub-batch as the PRUNED run computed it (0 for the counts up to the query's threshold), its Z and the
  * threshold; must be called before any other tap (those recount the sub-batch in full) */

@@ -72,7 +72,7 @@ def build_cli(force: bool = False) -> Path | None:
     if not force and not _stale(CLI, [main, LIB]):
         return CLI
     cmd = [_hipcc(), "-O2", "-std=c++17", f"-I{ROOT / 'include'}", f"-I{CSRC}", "-o", str(CLI), str(main),
-           f"-L{PKG}", "-lraxtax_hip", f"-Wl,-rpath,{PKG}", "-Wl,-rpath,$ORIGIN", "-lpthread"]
+           f"-L{PKG}", "-lraxtax_hip", f"-Wl,-rpath,{PKG}", "-Wl,-rpath,$ORIGIN", "-lpthread", "-lz"]
     subprocess.check_call(cmd)
     return CLI
 

@@ -398,7 +398,7 @@ class Index:
         check(self._lib.rtx_debug_prune_stats(self._h, ptr(out, u64p)))
         pairs, nq = max(int(out[1]), 1), max(int(out[5]), 1)
         return {"live_tiles_per_pair": int(out[0]) / pairs, "pairs": int(out[1]), "mean_best_hit_lower_bound": int(out[2]) / nq,
-                "mean_threshold": int(out[3]) / nq, "mean_largest_tile_bound": int(out[4]) / nq, "bound_violations": int(out[6]), "recount_mismatches": int(out[7]),
+                "mean_threshold": int(out[3]) / nq, "mean_largest_tile_bound": int(out[4]) / nq, "bound_violations": int(out[6]), "live_tiles_per_query": int(out[7]) / nq,
                 "tiles_above_threshold_per_query": int(out[8]) / max(int(out[9]), 1), "queries_with_threshold": int(out[9])}
 
     def debug_evaluate(self, probs) -> Result:

@@ -8,8 +8,10 @@
 //   PREFIX/<db>.bin     bincode database cache (unless --skip-db)
 // A rerun with the same flags and database resumes: labels listed in raxtax.ckp are skipped
 // (parser.rs:150-153) and half-written result lines of unlisted queries are purged first.
-// Out of scope: raxtax.log, progress bars, gzip input, thread options.
+// Inputs ending in .gz / .gzip are decompressed on the fly (utils.rs:42-60 get_reader: the extension decides).
+// Out of scope: raxtax.log, progress bars, thread options.
 #include <sys/stat.h>
+#include <zlib.h>
 
 #include <cctype>
 #include <chrono>
@@ -33,12 +35,67 @@
 
 namespace {
 
+// utils::get_reader (utils.rs:42-60): the file's last extension, lower-cased, "gz" or "gzip" = a GzDecoder in front of the reader
+bool is_gz(const std::string &path) {
+    const size_t slash = path.find_last_of('/'), dot = path.find_last_of('.');
+    if (dot == std::string::npos || (slash != std::string::npos && dot < slash)) return false;
+    std::string ext = path.substr(dot + 1);
+    for (char &c : ext) c = (char)tolower((unsigned char)c);
+    return ext == "gz" || ext == "gzip";
+}
+
+// A file read in pieces, plain or gzip-compressed.
+struct Input {
+    FILE *f = nullptr;
+    gzFile g = nullptr;
+    bool open(const std::string &path) {
+        if (is_gz(path)) {
+            g = gzopen(path.c_str(), "rb");
+            if (g) gzbuffer(g, 1 << 20);
+            return g != nullptr;
+        }
+        f = fopen(path.c_str(), "rb");
+        return f != nullptr;
+    }
+    // up to n bytes; fewer only at the end of the data; (size_t)-1 on a read / decompression error
+    size_t read(char *buf, size_t n) {
+        if (f) return fread(buf, 1, n, f);
+        size_t got = 0;
+        while (got < n) {
+            const int k = gzread(g, buf + got, (unsigned)std::min<size_t>(n - got, 1u << 30));
+            if (k < 0) return (size_t)-1;
+            if (k == 0) break;
+            got += (size_t)k;
+        }
+        if (got < n) {  // the end of the data -- or of a truncated / corrupt stream: zlib hands out what it decoded and keeps the error
+            int err = Z_OK;
+            (void)gzerror(g, &err);
+            if (err != Z_OK && err != Z_STREAM_END) return (size_t)-1;
+        }
+        return got;
+    }
+    void close() {
+        if (f) fclose(f);
+        if (g) gzclose(g);
+        f = nullptr;
+        g = nullptr;
+    }
+};
+
 bool slurp(const std::string &path, std::string &out) {
-    std::ifstream f(path, std::ios::binary);
-    if (!f) return false;
-    std::ostringstream ss;
-    ss << f.rdbuf();
-    out = ss.str();
+    Input in;
+    if (!in.open(path)) return false;
+    out.clear();
+    const size_t piece = (size_t)16 << 20;
+    for (;;) {
+        const size_t have = out.size();
+        out.resize(have + piece);
+        const size_t got = in.read(&out[have], piece);
+        if (got == (size_t)-1) { in.close(); return false; }
+        out.resize(have + got);
+        if (got < piece) break;
+    }
+    in.close();
     return true;
 }
 
@@ -252,14 +309,15 @@ int main(int argc, char **argv) {
             ready.push_back(std::move(pz));
             qcv.notify_all();
         };
-        FILE *f = fopen(qf.c_str(), "rb");
-        if (!f) { Parsed e; e.rc = RTX_ERR_PARSE; e.err = "cannot open file"; e.end = true; push(std::move(e)); return; }
+        Input f;
+        if (!f.open(qf)) { Parsed e; e.rc = RTX_ERR_PARSE; e.err = "cannot open file"; e.end = true; push(std::move(e)); return; }
         std::string buf;
         bool first = true, eof = false;
         while (!eof) {
             const size_t have = buf.size();
             buf.resize(have + block_bytes);
-            const size_t got = fread(&buf[have], 1, block_bytes, f);
+            const size_t got = f.read(&buf[have], block_bytes);
+            if (got == (size_t)-1) { Parsed e; e.rc = RTX_ERR_PARSE; e.err = "read error (corrupt gzip stream?)"; e.end = true; push(std::move(e)); break; }
             buf.resize(have + got);
             eof = got < block_bytes;
             uint64_t end = buf.size();
@@ -283,7 +341,7 @@ int main(int argc, char **argv) {
                 if (stop_reader) break;
             }
         }
-        fclose(f);
+        f.close();
     });
     auto stop_and_join_reader = [&]() {
         {

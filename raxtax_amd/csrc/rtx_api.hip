@@ -645,7 +645,7 @@ int begin_run(rtx_index *ix, uint32_t *n_sub_out, bool *timed_out, bool cluster)
     const bool shard = ix->staged && ix->shard_prune_opt && ix->n_refs != ix->n_total;
     auto scratch_ok = [&](const rtx_index::Scratch &sc) {  // sized at the upload / rtx_shard_begin (alloc_scratch_set) for this sub-batch size
         return sc.d_tile_ub.p != nullptr && sc.d_tile_ub.n >= (size_t)ix->sub_batch * ix->ntiles && sc.d_best_key.n >= ix->sub_batch && sc.d_prune_thr.n >= ix->sub_batch &&
-               sc.d_live.n >= (size_t)((ix->sub_batch + 1u) / 2u) * ((ix->ntiles + 31u) / 32u + 1u) && sc.d_best.n >= (size_t)ix->sub_batch * kPruneBestWords;
+               sc.d_live.n >= (size_t)(ix->sub_batch + 1u) * ((ix->ntiles + 31u) / 32u + 1u) && sc.d_best.n >= (size_t)ix->sub_batch * kPruneBestWords;
     };
     ix->prune_used = ix->prune_opt && ix->pair_used && ix->use_tables && ix->tile_skip && ix->d_ubitmap.p && (whole || shard) &&
                      scratch_ok(ix->sc[0]) && (!ix->staged || scratch_ok(ix->sc[1]));
@@ -850,7 +850,7 @@ int alloc_scratch_set(rtx_index *ix, uint32_t k) {
             const size_t mw = (size_t)B * ix->u_ntiles * (ix->rstride / 64);
             const bool fresh = sc.d_uones.n < mw;
             if ((rc = sc.d_uones.alloc(mw)) || (rc = sc.d_uzero.alloc((size_t)B * ix->u_ntiles)) ||
-                (rc = sc.d_tile_ub.alloc((size_t)B * ix->ntiles)) || (rc = sc.d_best_key.alloc(B)) || (rc = sc.d_prune_thr.alloc(B)) || (rc = sc.d_prune_i1.alloc(B)) || (rc = sc.d_best.alloc((size_t)B * kPruneBestWords)) || (rc = sc.d_live.alloc((size_t)((B + 1u) / 2u) * ((ix->ntiles + 31u) / 32u + 1u))))
+                (rc = sc.d_tile_ub.alloc((size_t)B * ix->ntiles)) || (rc = sc.d_best_key.alloc(B)) || (rc = sc.d_prune_thr.alloc(B)) || (rc = sc.d_prune_i1.alloc(B)) || (rc = sc.d_best.alloc((size_t)B * kPruneBestWords)) || (rc = sc.d_live.alloc((size_t)(B + 1u) * ((ix->ntiles + 31u) / 32u + 1u))))
                 return rc;
             if (fresh) RTX_HIP(hipMemsetAsync(sc.d_uones.p, 0xFF, sc.d_uones.n * 8, ix->stream));
             RTX_HIP(hipMemsetAsync(sc.d_uzero.p, 0, sc.d_uzero.n * 4, ix->stream));
@@ -2144,7 +2144,7 @@ int rtx_debug_run_counts(rtx_index *ix, uint64_t query, uint16_t *counts, uint8_
     if (ix->prune_used) {
         const uint32_t lw = (nt + 31u) / 32u + 1u;
         std::vector<uint32_t> words(lw);
-        RTX_HIP(hipMemcpy(words.data(), sc.d_live.p + (size_t)(slot >> 1) * lw, lw * 4, hipMemcpyDeviceToHost));
+        RTX_HIP(hipMemcpy(words.data(), sc.d_live.p + (size_t)slot * lw, lw * 4, hipMemcpyDeviceToHost));
         for (uint32_t T = 0; T < nt; T++) live[T] = (uint8_t)((words[T >> 5] >> (T & 31u)) & 1u);
         RTX_HIP(hipMemcpy(&thr, sc.d_prune_thr.p + slot, 2, hipMemcpyDeviceToHost));
         RTX_HIP(hipMemcpy(&i1v, sc.d_prune_i1.p + slot, 2, hipMemcpyDeviceToHost));

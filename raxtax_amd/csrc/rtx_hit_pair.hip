@@ -135,8 +135,13 @@ __global__ __launch_bounds__(64, 2) void hit_count_pair_kernel(HitParams p) {
     const uint32_t np8 = gridDim.x >> 3;
     const uint32_t pair = blockIdx.x < np8 * 8u ? (blockIdx.x & 7u) * np8 + (blockIdx.x >> 3) : blockIdx.x;
     const uint32_t qa = pair * 2u, qb = qa + 1u;
-    const bool has_b = qb < p.nq;
-    if (!kBounds && p.live && !((p.live[(size_t)pair * p.live_words + (tile >> 5)] >> (tile & 31u)) & 1u)) return;  // tile pruning (rtx_prune.hip): nothing in this tile can matter to either query
+    bool has_a = true, has_b = qb < p.nq;
+    if (!kBounds && p.live) {  // tile pruning (rtx_prune.hip): a mask per query -- the rows of a query are folded only where its tile is live
+        const uint32_t *lw = p.live + (size_t)qa * p.live_words + (tile >> 5);
+        has_a = (lw[0] >> (tile & 31u)) & 1u;
+        has_b = has_b && ((lw[p.live_words] >> (tile & 31u)) & 1u);
+        if (!has_a && !has_b) return;  // nothing in this tile can matter to either query
+    }
     uint32_t *l_both = lds_dw, *l_a = lds_dw + kPairListDw, *l_b = lds_dw + 2u * kPairListDw;
     unsigned long long *m_a = reinterpret_cast<unsigned long long *>(lds_dw + 3u * kPairListDw), *m_b = m_a + kPairMaskWords;
     uint32_t *l_zero = reinterpret_cast<uint32_t *>(m_b + kPairMaskWords);
@@ -169,7 +174,7 @@ __global__ __launch_bounds__(64, 2) void hit_count_pair_kernel(HitParams p) {
     };
     uint2 rec[8];
     load_recs(rec, 0);
-    const uint32_t ns_a = kBounds ? 0u : p.nsparse[(size_t)qa * p.ntiles + tile], ns_b = !kBounds && has_b ? p.nsparse[(size_t)qb * p.ntiles + tile] : 0u;
+    const uint32_t ns_a = kBounds || !has_a ? 0u : p.nsparse[(size_t)qa * p.ntiles + tile], ns_b = !kBounds && has_b ? p.nsparse[(size_t)qb * p.ntiles + tile] : 0u;
     const uint32_t *srows_a = p.srows + ((size_t)qa * p.ntiles + tile) * (kSegMaxSparseRows + 1);
     const uint32_t *srows_b = p.srows + ((size_t)(has_b ? qb : qa) * p.ntiles + tile) * (kSegMaxSparseRows + 1);
     {
@@ -181,8 +186,8 @@ __global__ __launch_bounds__(64, 2) void hit_count_pair_kernel(HitParams p) {
             sa[it] = kBounds ? 0u : srows_a[(uint32_t)it * 64u + lane];
             sb[it] = kBounds ? 0u : srows_b[(uint32_t)it * 64u + lane];
         }
-        for (uint32_t i = lane; i < mwords; i += 64) {
-            m_a[i] = dm_a[i];
+        for (uint32_t i = lane; i < mwords; i += 64) {  // (a query whose tile is dead has no dense row here: its lists were never built)
+            m_a[i] = has_a ? dm_a[i] : 0ull;
             m_b[i] = has_b ? dm_b[i] : 0ull;
         }
 #pragma unroll
@@ -275,7 +280,7 @@ __global__ __launch_bounds__(64, 2) void hit_count_pair_kernel(HitParams p) {
     uint4 pre_a[kSparseIt][kSparseV], pre_b[kSparseIt][kSparseV];
     if (ns_a) sparse_prefetch(p, lane, ns_a, l_sid, pre_a);
     if (ns_b) sparse_prefetch(p, lane, ns_b, l_sid + kSparseIt * 64u, pre_b);
-    hit_epilogue_x<NP, kPacked, true, true, true>(p, pa, qa, tile, lane, p.t[qa], active, hist_lds, cnt8, ns_a, srows_a, pre_a);
+    if (has_a) hit_epilogue_x<NP, kPacked, true, true, true>(p, pa, qa, tile, lane, p.t[qa], active, hist_lds, cnt8, ns_a, srows_a, pre_a);
     PAIR_MARK(3)
     if (has_b) {
         wave_lds_sync();

@@ -263,7 +263,7 @@ __global__ __launch_bounds__(64) void kmer_extract_kernel(KmerParams p) {
         return;
     }
     const uint32_t nchunks = (nrows + 63u) >> 6;
-    const uint32_t *live = p.mode == 2u ? p.live + (size_t)(q >> 1) * p.live_words : nullptr;  // of the query's pair
+    const uint32_t *live = p.mode == 2u ? p.live + (size_t)q * p.live_words : nullptr;  // the tiles that are counted for this query (rtx_prune.hip)
     // Per tile: which rows have a dense segment there (a 64-bit mask per 64 rows), and the slots of the sparse
     // segments; empty segments are dropped (rtx_segments.hip).
     const uint32_t nt = p.ntiles;

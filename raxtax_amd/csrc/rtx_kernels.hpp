@@ -100,7 +100,7 @@ struct KmerParams {
     uint32_t *hist;          // [B][hstride] zeroed here
     uint32_t hstride;
     uint32_t mode;           // 0: everything; 1: k-mers and row list; 2: the per-tile lists of the live tiles (after a launch with 1)
-    const uint32_t *live;    // mode 2: [pairs][live_words] (rtx_prune.hip)
+    const uint32_t *live;    // mode 2: [B][live_words] a mask per query (rtx_prune.hip)
     uint32_t live_words;
 };
 
@@ -141,7 +141,7 @@ struct HitParams {
     const uint2 *pair_urec;   // [pairs][pair_ustride] union of the two row lists (pair_union_kernel)
     const uint32_t *pair_nu;  // [pairs] entries of the union
     uint32_t pair_ustride;
-    const uint32_t *live;     // [pairs][live_words] tiles to count for a pair (rtx_prune.hip) or null: all
+    const uint32_t *live;     // [B][live_words] tiles to count for a query (rtx_prune.hip; the masks of a pair are neighbours) or null: all
     uint32_t live_words;
     // the bounds pass of the tile pruning (hit_count_pair_kernel<.., kBounds>: this launch counts against the union bitmap)
     uint16_t *bounds_tile_ub;     // [B][bounds_tile_stride] largest bound of every tile of the database
@@ -183,7 +183,7 @@ struct PruneParams {
     const double *lnfact;
     uint32_t *hist;           // [B][hstride]: bin 0 receives the references of the tiles that are not counted
     uint32_t hstride;
-    uint32_t *live;           // [pairs][live_words] bit T: tile T is counted for the pair
+    uint32_t *live;           // [B][live_words] bit T: tile T is counted for the query
     uint32_t live_words;
     uint16_t *thr_out;        // [B] the threshold of every query (0: not pruned, every tile is counted)
     uint16_t *i1_out;         // [B] i* + 1 of every query with a threshold: Z holds less than 1e-12 at i <= i* (prob_lookup starts there)

@@ -310,35 +310,44 @@ __global__ __launch_bounds__(64, RTX_PRUNE_WAVES) void prune_kernel(PruneParams 
     if (p.phase == 1u) return;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    // ---- 4. live tiles of the pair, the references never counted
-    unsigned long long dead_refs = 0;
-    uint32_t n_live = 0;
+    // ---- 4. live tiles of either query (a mask per QUERY: the wave of a (pair, tile) block folds the rows of a query only where its
+    // tile is live, and leaves at once where neither is), the references never counted
+    unsigned long long dead_refs[2] = {0, 0};
+    uint32_t n_live = 0, n_qlive = 0;
     for (uint32_t T0 = 0; T0 < p.ntiles; T0 += 64) {
         const uint32_t T = T0 + lane;
-        bool live = false;
+        bool la = false, lb = false;
         if (T < p.ntiles) {
             // a query without a threshold has every tile counted -- also those without any of its k-mers: taxon_prefix may
             // have to read them (every reference with count 0 can carry probability if the best hit is weak)
-            live = thr[0] == 0u || (uint32_t)ub_lds[T] > thr[0];
-            if (has_b) live = live || thr[1] == 0u || (uint32_t)ub_lds[p.ntiles + T] > thr[1];
+            la = thr[0] == 0u || (uint32_t)ub_lds[T] > thr[0];
+            lb = has_b && (thr[1] == 0u || (uint32_t)ub_lds[p.ntiles + T] > thr[1]);
         }
-        const unsigned long long bl = __ballot(live);
+        const unsigned long long ba = __ballot(la), bb2 = __ballot(lb);
         if (lane == 0) {
-            p.live[(size_t)pair * p.live_words + (T0 >> 5)] = (uint32_t)bl;
-            if ((T0 >> 5) + 1u < p.live_words) p.live[(size_t)pair * p.live_words + (T0 >> 5) + 1u] = (uint32_t)(bl >> 32);
+            uint32_t *wa = p.live + (size_t)(pair * 2u) * p.live_words, *wb = wa + p.live_words;
+            wa[T0 >> 5] = (uint32_t)ba;
+            if ((T0 >> 5) + 1u < p.live_words) wa[(T0 >> 5) + 1u] = (uint32_t)(ba >> 32);
+            if (has_b) {
+                wb[T0 >> 5] = (uint32_t)bb2;
+                if ((T0 >> 5) + 1u < p.live_words) wb[(T0 >> 5) + 1u] = (uint32_t)(bb2 >> 32);
+            }
         }
-        if (T < p.ntiles && !live) {
+        if (T < p.ntiles) {
             const uint64_t lo = (uint64_t)T * 8192u, hi = lo + 8192u < p.n_refs ? lo + 8192u : p.n_refs;
-            dead_refs += hi - lo;
+            if (!la) dead_refs[0] += hi - lo;
+            if (!lb) dead_refs[1] += hi - lo;
         }
-        n_live += (uint32_t)__popcll(bl);
+        n_live += (uint32_t)__popcll(ba | bb2);
+        n_qlive += (uint32_t)__popcll(ba) + (uint32_t)__popcll(bb2);
     }
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) dead_refs += __shfl_xor(dead_refs, d, 64);
+    for (int d = 32; d >= 1; d >>= 1) { dead_refs[0] += __shfl_xor(dead_refs[0], d, 64); dead_refs[1] += __shfl_xor(dead_refs[1], d, 64); }
     if (lane == 0) {
-        p.hist[(size_t)(pair * 2u) * p.hstride] = (uint32_t)dead_refs;  // kmer_extract has zeroed the row; hit_count adds the counted ones
-        if (has_b) p.hist[(size_t)(pair * 2u + 1u) * p.hstride] = (uint32_t)dead_refs;
+        p.hist[(size_t)(pair * 2u) * p.hstride] = (uint32_t)dead_refs[0];  // kmer_extract has zeroed the row; hit_count adds the counted ones
+        if (has_b) p.hist[(size_t)(pair * 2u + 1u) * p.hstride] = (uint32_t)dead_refs[1];
     }
+    st[7] = n_qlive;  // (query, tile) combinations that are counted
     if (p.stats) {  // one atomic instruction per wave (lane k adds counter k), 64 copies of the counters in lines of their own:
                     // thousands of waves adding to ONE address queue up in L2 for longer than everything else here takes
         st[0] = n_live; st[1] = 1ull;

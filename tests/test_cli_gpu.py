@@ -119,6 +119,24 @@ def test_cli_on_several_handles(tmp_path):
     assert run("-d", FASTA, "-i", FASTA, "-o", tmp_path / "none", "--gpus", "0", ok=False).returncode == 64
 
 
+def test_cli_reads_gzip_input(tmp_path):
+    """utils.rs:42-60 get_reader: inputs whose last extension is gz / gzip are decompressed on the fly -- database and queries; the
+    query file in blocks that do not line up with anything in the compressed stream."""
+    import gzip
+    a, b = tmp_path / "plain", tmp_path / "gz"
+    dbz, qz = tmp_path / "db.fasta.gz", tmp_path / "queries.fa.GZIP"
+    dbz.write_bytes(gzip.compress(FASTA.read_bytes()))
+    qz.write_bytes(gzip.compress(FASTA.read_bytes(), compresslevel=1))
+    run("-d", FASTA, "-i", FASTA, "-o", a, "--tsv")
+    run("-d", dbz, "-i", qz, "-o", b, "--tsv", "--block-bytes", 30000, "--batch", 100)
+    for f in ("raxtax.out", "raxtax.tsv", "raxtax.ckp"):
+        assert (a / f).read_text() == (b / f).read_text(), f
+    assert (b / "db.fasta.bin").exists()                     # with_extension("bin"): the last extension only (io.rs:269-276)
+    bad = tmp_path / "broken.fasta.gz"
+    bad.write_bytes(gzip.compress(FASTA.read_bytes())[:2000])
+    assert run("-d", FASTA, "-i", bad, "-o", tmp_path / "c", "--skip-db", ok=False).returncode != 0
+
+
 def test_cli_streamed_query_ingest(tmp_path):
     """--block-bytes: the query file is read and parsed in blocks (cut in front of header lines) on a thread of its own;
     the output must be the one of a single-block run."""

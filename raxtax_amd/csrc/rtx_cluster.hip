@@ -27,6 +27,7 @@
 #include <rocprim/device/device_radix_sort.hpp>
 
 #include "rtx_kernels.hpp"
+#include "rtx_wave.hpp"
 
 namespace rtx {
 
@@ -136,15 +137,6 @@ __global__ __launch_bounds__(256) void loc_finish_kernel(uint32_t *__restrict__ 
 static constexpr uint32_t kLocMaxBins = 8192;    // coarse bins (LDS: 16 KiB)
 static constexpr uint32_t kLocFineDiv = 16;      // fine bins per coarse bin
 static constexpr uint32_t kLocWin = 1024;        // windows of a query that vote
-
-__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        const uint32_t o = (uint32_t)__shfl_xor((int)v, d, 64);
-        v = o > v ? o : v;
-    }
-    return v;
-}
 
 // one vote per lane with `valid` for bin b: lanes that agree with the first pending voter are added by one atomic
 __device__ __forceinline__ void vote_bins(uint32_t *h, uint32_t b, bool valid, uint32_t lane) {

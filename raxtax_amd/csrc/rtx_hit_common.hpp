@@ -417,15 +417,6 @@ __device__ __forceinline__ void hit_epilogue_x(const HitParams &p, uint32_t (&pl
 // equals): key = bound << 20 | (0xFFFFF - block), the maximum over the wave, atomicMax over the waves of the query's union tiles.
 // No histogram, no count stores, no lists (every row of the union bitmap is read densely).
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t row16_max_u32(uint32_t v) {  // maximum over the 16 lanes of a DPP row, in every lane of the row
-    uint32_t o;
-    o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true); v = o > v ? o : v;   // quad_perm [1,0,3,2]
-    o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true); v = o > v ? o : v;   // quad_perm [2,3,0,1]
-    o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true); v = o > v ? o : v;  // row_half_mirror
-    o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, true); v = o > v ? o : v;  // row_mirror
-    return v;
-}
-
 template <int NP>
 __device__ __forceinline__ void bounds_epilogue(const HitParams &p, uint32_t (&pl)[4][NP], uint32_t q, uint32_t utile, uint32_t lane) {
     static_assert(kPruneShift == 6, "128 blocks per tile of the database = one group of 8 per lane of a DPP row");
@@ -463,11 +454,7 @@ __device__ __forceinline__ void bounds_epilogue(const HitParams &p, uint32_t (&p
             if ((lane & 15u) == 0u && T < p.bounds_ntiles) tub[T] = (uint16_t)tmax;
         }
     }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        const uint32_t o = (uint32_t)__shfl_xor((int)best, d, 64);
-        best = o > best ? o : best;
-    }
+    best = wave_max_u32(best);
     if (lane == 0) atomicMax(&p.bounds_best[q], best);
 }
 

@@ -47,11 +47,11 @@ constexpr int kPairNB = 4;                            // buffers of eight rows p
 __global__ __launch_bounds__(64) void pair_union_kernel(const uint32_t *__restrict__ rows, const uint32_t *__restrict__ nrows,
                                                         uint32_t rstride, uint32_t nq, uint2 *__restrict__ urec,
                                                         uint32_t *__restrict__ nu, uint32_t ustride) {
-    __shared__ uint32_t bits[2][2048];
+    __shared__ __attribute__((aligned(16))) uint32_t bits[2][2048];
     const uint32_t pair = blockIdx.x, lane = threadIdx.x;
     const uint32_t qa = pair * 2u, qb = qa + 1u;
     const uint32_t na = nrows[qa], nb = qb < nq ? nrows[qb] : 0u;
-    for (uint32_t i = lane; i < 4096u; i += 64) (&bits[0][0])[i] = 0u;
+    for (uint32_t i = lane; i < 1024u; i += 64) reinterpret_cast<uint4 *>(&bits[0][0])[i] = make_uint4(0u, 0u, 0u, 0u);
     wave_lds_sync();
     const uint32_t *ra = rows + (size_t)qa * rstride, *rb = rows + (size_t)(qb < nq ? qb : qa) * rstride;
     for (uint32_t i = lane; i < na; i += 64) {
@@ -69,14 +69,10 @@ __global__ __launch_bounds__(64) void pair_union_kernel(const uint32_t *__restri
         const uint32_t a = bits[0][w0 + lane], b = bits[1][w0 + lane];
         uint32_t u = a | b;
         if (__ballot(u != 0u) == 0ull) continue;
-        // exclusive prefix over the lanes of the three counts (each below 2^11 in total: packed 11 + 11 bits and one apart)
+        // exclusive prefix over the lanes of the three counts (each below 2^11 in total: packed 11 + 11 bits and one apart); DPP scans
+        // (the shuffle version -- twelve ds_bpermute round trips per 64 words -- was most of the kernel: 6.9 -> ms per 1 M queries)
         uint32_t su = (uint32_t)__popc(u), sab = (uint32_t)__popc(a) | ((uint32_t)__popc(b) << 16);
-        uint32_t iu = su, iab = sab;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t tu = __shfl_up(iu, d, 64), tab = __shfl_up(iab, d, 64);
-            if ((int)lane >= d) { iu += tu; iab += tab; }
-        }
+        const uint32_t iu = wave_incl_scan_u32(su), iab = wave_incl_scan_u32(sab);
         uint32_t pu = n_u + iu - su, pa = n_a + (iab & 0xFFFFu) - (sab & 0xFFFFu), pb = n_b + (iab >> 16) - (sab >> 16);
         while (u) {
             const uint32_t bit = (uint32_t)__ffs((int)u) - 1u;
@@ -88,8 +84,8 @@ __global__ __launch_bounds__(64) void pair_union_kernel(const uint32_t *__restri
             pa += ina;
             pb += inb;
         }
-        n_u += (uint32_t)__shfl(iu, 63, 64);
-        const uint32_t tab = (uint32_t)__shfl(iab, 63, 64);
+        n_u += (uint32_t)__builtin_amdgcn_readlane((int)iu, 63);
+        const uint32_t tab = (uint32_t)__builtin_amdgcn_readlane((int)iab, 63);
         n_a += tab & 0xFFFFu;
         n_b += tab >> 16;
     }

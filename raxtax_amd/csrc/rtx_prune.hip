@@ -58,14 +58,7 @@ static constexpr double kPruneHalfEps = 0.5e-12;
 #define RTX_PRUNE_TURNS 8  // rows of the best block in flight per wave: 8 x this (16: 17 registers spill at four waves per SIMD)
 #endif
 
-__device__ __forceinline__ uint32_t wave_max_u32p(uint32_t v) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        const uint32_t o = (uint32_t)__shfl_xor((int)v, d, 64);
-        v = o > v ? o : v;
-    }
-    return v;
-}
+__device__ __forceinline__ uint32_t wave_max_u32p(uint32_t v) { return wave_max_u32(v); }
 
 __global__ __launch_bounds__(64, RTX_PRUNE_WAVES) void prune_kernel(PruneParams p, ProbTables tb) {  // four waves per SIMD (<= 128 VGPRs): the kernel is a chain of dependent round trips per query, occupancy is what hides them
     extern __shared__ uint16_t ub_lds[];  // [2][ntiles]

@@ -25,6 +25,24 @@ __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) {
     return v + (row == 0 ? 0u : (row == 1 ? r0 : (row == 2 ? r0 + r1 : r0 + r1 + r2)));
 }
 
+__device__ __forceinline__ uint32_t row16_max_u32(uint32_t v) {  // maximum over the 16 lanes of a DPP row, in every lane of the row
+    uint32_t o;
+    o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true); v = o > v ? o : v;   // quad_perm [1,0,3,2]
+    o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true); v = o > v ? o : v;   // quad_perm [2,3,0,1]
+    o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true); v = o > v ? o : v;  // row_half_mirror
+    o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, true); v = o > v ? o : v;  // row_mirror
+    return v;
+}
+
+// Maximum over the 64 lanes, in every lane: DPP inside the rows, the four row maxima through v_readlane
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+    v = row16_max_u32(v);
+    const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)v, 0), b = (uint32_t)__builtin_amdgcn_readlane((int)v, 16),
+                   c = (uint32_t)__builtin_amdgcn_readlane((int)v, 32), d = (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
+    const uint32_t ab = a > b ? a : b, cd = c > d ? c : d;
+    return ab > cd ? ab : cd;
+}
+
 __device__ __forceinline__ double wave_sum_f64(double v) {
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);

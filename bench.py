@@ -410,7 +410,12 @@ def extras_block(args, rx, lib, index, tree, db, qs, flags):
         index.upload(q2.bases, q2.base_off)
         dt = timed(plain)
         st = index.debug_prune_stats()
-        sweep.append({"mu_q": mu, "value": 131072 / dt, "ms_per_step": dt * 1e3, "live_tiles_per_pair": st["live_tiles_per_pair"],
+        # the same queries with every tile counted: what the pruning is worth at this divergence
+        rx._lib.check(lib.rtx_index_set_option(index._h, 13, 0))
+        index.upload(q2.bases, q2.base_off)
+        dt_full = timed(plain)
+        rx._lib.check(lib.rtx_index_set_option(index._h, 13, 0 if args.no_tile_prune else 1))
+        sweep.append({"mu_q": mu, "value": 131072 / dt, "ms_per_step": dt * 1e3, "value_unpruned": 131072 / dt_full, "live_tiles_per_pair": st["live_tiles_per_pair"],
                       "live_tiles_per_query": st.get("live_tiles_per_query"),
                       "share_with_threshold": st["queries_with_threshold"] / 131072, "mean_threshold": st["mean_threshold"],
                       "mean_best_hit_lower_bound": st["mean_best_hit_lower_bound"],

@@ -919,7 +919,7 @@ def test_randomised_configurations(oracle, seed):
                     raise
                 n_boundary += 1
                 exc.boundary()
-    if seed in (101, 202, 303, 404):       # the seeds of the suite have committed expectations; extra seeds (RTX_FUZZ_SEEDS) only the bounds below
+    if seed in (101, 202, 303, 404, 505, 606, 707):       # the seeds of the suite have committed expectations; extra seeds (RTX_FUZZ_SEEDS) only the bounds below
         exc.check()
     assert n_boundary <= 20, n_boundary
     # exact ties between sibling taxa (accepted above only if the confidences agree to 1e-9) belong to degenerate

@@ -227,7 +227,8 @@ int rtx_set_default_option(int option, uint64_t value);
 
 /* ------------------------------------------------------------------------- */
 /* Classification: the body of raxtax(), src/raxtax.rs:39-84, minus string    */
-/* formatting (host mirror) and the exact-match lookup (caller passes ids).   */
+/* formatting (host mirror); the exact-match lookup of raxtax.rs:42 on the     */
+/* device, or the caller passes the ids.                                       */
 /* ------------------------------------------------------------------------- */
 /* One result row = one EvaluationResult (src/lineage.rs:8-14) before the
  * single-exact-match override of raxtax.rs:73-84 (applied by the caller /
@@ -251,7 +252,9 @@ typedef struct {
  * lineage.rs:91-93 + local signal).  The handle alternates between two host result sets: a view stays
  * valid until the second-next download on the handle, so a caller can format batch c while batch c+1
  * is classified (the host mirror rtx_raxtax does).  exact_ids/exact_off: the ids Tree.sequences.get()
- * returned per query (raxtax.rs:42); may be NULL when no query has an exact match. */
+ * returned per query (raxtax.rs:42), or NULL / NULL: the library looks them up on the device (handles built from the reference
+ * sequences, RTX_OPT_DEVICE_EXACT; rtx_batch_exact_matches returns them) -- on a handle without that table, or with the option off,
+ * NULL means that no query has an exact match. */
 int rtx_classify_batch(rtx_index *index, uint64_t n_queries, const uint8_t *bases,
                        const uint64_t *base_off, const uint32_t *exact_ids,
                        const uint64_t *exact_off, uint32_t flags, rtx_result_view *out);

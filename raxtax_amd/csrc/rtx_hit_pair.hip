@@ -21,6 +21,8 @@
 // The counts are those of hit_count_kernel bit for bit.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #ifdef RTX_PAIR_STAMP
 // stamps inside the epilogue: 5 = start .. histogram zeroed (incl. the wait for nothing), 7 = sparse segments, 6 = unpack + stores +
 // histogram atomics, 8 = the rest (high bits, flush); the variables live in the kernel
@@ -121,15 +123,9 @@ __device__ __forceinline__ void fold_seg(uint32_t (&pa)[4][NP], uint32_t (&pb)[4
     }
 }
 
-// kBounds: the bounds pass of the tile pruning -- the bitmap is the union bitmap (every row dense: the caller passes constant masks and
-// no sparse lists), the epilogue keeps the largest bound per tile of the database and the best block instead of counts (bounds_epilogue).
+// One (pair, tile) block: the rows of the pair in this tile, then the epilogue of each query that is live there.
 template <int NP, bool kPacked, bool kBounds>
-__global__ __launch_bounds__(64, 2) void hit_count_pair_kernel(HitParams p) {
-    extern __shared__ uint32_t lds_dw[];
-    const uint32_t tile = blockIdx.y, lane = threadIdx.x;
-    // pairs are dealt to the XCDs like the queries of hit_count_kernel: XCD x takes a contiguous slice of the sub-batch
-    const uint32_t np8 = gridDim.x >> 3;
-    const uint32_t pair = blockIdx.x < np8 * 8u ? (blockIdx.x & 7u) * np8 + (blockIdx.x >> 3) : blockIdx.x;
+__device__ __forceinline__ void pair_tile_block(const HitParams &p, uint32_t *lds_dw, const uint32_t pair, const uint32_t tile, const uint32_t lane) {
     const uint32_t qa = pair * 2u, qb = qa + 1u;
     bool has_a = true, has_b = qb < p.nq;
     if (!kBounds && p.live) {  // tile pruning (rtx_prune.hip): a mask per query -- the rows of a query are folded only where its tile is live
@@ -288,21 +284,123 @@ __global__ __launch_bounds__(64, 2) void hit_count_pair_kernel(HitParams p) {
 #endif
 }
 
+// kBounds: the bounds pass of the tile pruning -- the bitmap is the union bitmap (every row dense: the caller passes constant masks and
+// no sparse lists), the epilogue keeps the largest bound per tile of the database and the best block instead of counts (bounds_epilogue).
+//
+// Grid: pairs x tiles -- or, behind tile pruning, one-dimensional over the list of the (pair, tile) blocks with a live query
+// (live_items_kernel).  A pruned sub-batch of the bench workload keeps 1.5 of 62 tiles per pair: with the two-dimensional grid 97 % of
+// its million workgroups came up only to read their mask and leave, which took a third of the launch.
+template <int NP, bool kPacked, bool kBounds, bool kItems>
+__global__ __launch_bounds__(64, 2) void hit_count_pair_kernel(HitParams p) {
+    extern __shared__ uint32_t lds_dw[];
+    const uint32_t lane = threadIdx.x;
+    if (kItems) {
+        // Every pass over the grid takes the next gridDim.x entries of the list; inside a pass XCD x (= workgroup id mod 8) takes a
+        // contiguous eighth of them: neighbouring pairs share rows and tiles, and with them an L2.
+        const uint32_t n_items = (uint32_t)__builtin_amdgcn_readfirstlane((int)p.n_items[0]), G = gridDim.x, b = blockIdx.x;
+        for (uint32_t base = 0; base < n_items; base += G) {
+            const uint32_t S = n_items - base < G ? n_items - base : G, s8 = (S + 7u) >> 3;
+            const uint32_t j = (b & 7u) * s8 + (b >> 3);
+            if ((b >> 3) < s8 && j < S) {
+                const uint32_t item = (uint32_t)__builtin_amdgcn_readfirstlane((int)p.items[base + j]);  // wave-uniform: pair and tile stay scalar
+                uint32_t lane_v = lane;
+                asm volatile("" : "+v"(lane_v));  // nothing that depends on the lane is kept across blocks: the block needs every register (256)
+                pair_tile_block<NP, kPacked, kBounds>(p, lds_dw, item / p.ntiles, item % p.ntiles, lane_v);
+                wave_lds_sync();  // the histogram of this block's epilogue becomes the next block's lists
+            }
+        }
+        return;
+    }
+    // pairs are dealt to the XCDs like the queries of hit_count_kernel: XCD x takes a contiguous slice of the sub-batch
+    const uint32_t np8 = gridDim.x >> 3;
+    const uint32_t pair = blockIdx.x < np8 * 8u ? (blockIdx.x & 7u) * np8 + (blockIdx.x >> 3) : blockIdx.x;
+    pair_tile_block<NP, kPacked, kBounds>(p, lds_dw, pair, blockIdx.y, lane);
+}
+
+// The (pair, tile) blocks in which a query of the pair is live, ascending: entry = pair * ntiles + tile.  prune_kernel left the number of
+// live tiles of every pair; live_offsets_kernel (one workgroup, thread i takes the pairs [i * per, (i + 1) * per): loads of a thread
+// all in flight together) scans them, live_items_kernel (a thread per pair) writes the entries.
+__global__ __launch_bounds__(1024) void live_offsets_kernel(const uint32_t *__restrict__ pair_live, uint32_t np, uint32_t *__restrict__ off,
+                                                            uint32_t *__restrict__ n_items) {
+    __shared__ uint32_t wsum[16];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t per = (np + 1023u) / 1024u, p0 = tid * per;
+    uint32_t cnt = 0;
+    for (uint32_t i0 = 0; i0 < per; i0 += 16) {
+        uint32_t c[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) c[i] = i0 + i < per && p0 + i0 + i < np ? pair_live[p0 + i0 + i] : 0u;
+#pragma unroll
+        for (int i = 0; i < 16; i++) cnt += c[i];
+    }
+    const uint32_t incl = wave_incl_scan_u32(cnt);
+    if (lane == 63u) wsum[wave] = incl;
+    __syncthreads();
+    uint32_t o = incl - cnt;
+    for (uint32_t w = 0; w < wave; w++) o += wsum[w];
+    if (tid == 1023u) n_items[0] = o + cnt;
+    for (uint32_t i0 = 0; i0 < per; i0 += 16) {  // (L1 hits now)
+        uint32_t c[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) c[i] = i0 + i < per && p0 + i0 + i < np ? pair_live[p0 + i0 + i] : 0u;
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            if (i0 + i < per && p0 + i0 + i < np) off[p0 + i0 + i] = o;
+            o += c[i];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void live_items_kernel(const uint32_t *__restrict__ live, uint32_t live_words, uint32_t nq, uint32_t ntiles,
+                                                         const uint32_t *__restrict__ off, uint32_t *__restrict__ items) {
+    const uint32_t pair = blockIdx.x * 256u + threadIdx.x;
+    if (pair * 2u >= nq) return;
+    const uint32_t nw = (ntiles + 31u) >> 5;
+    const uint32_t *wa = live + (size_t)(pair * 2u) * live_words;
+    const bool hb = pair * 2u + 1u < nq;  // the mask of a missing second query was never written
+    uint32_t o = off[pair];
+    for (uint32_t w = 0; w < nw; w++) {
+        uint32_t bits = wa[w] | (hb ? wa[live_words + w] : 0u);
+        while (bits) {
+            const uint32_t tile = w * 32u + (uint32_t)__builtin_ctz(bits);
+            bits &= bits - 1u;
+            items[o++] = pair * ntiles + tile;
+        }
+    }
+}
+
 void launch_pair_union(hipStream_t s, const uint32_t *rows, const uint32_t *nrows, uint32_t rstride, uint32_t nq, uint2 *urec,
                        uint32_t *nu, uint32_t ustride) {
     hipLaunchKernelGGL(pair_union_kernel, dim3((nq + 1u) / 2u), dim3(64), 0, s, rows, nrows, rstride, nq, urec, nu, ustride);
 }
 
+#ifndef RTX_ITEM_GRID_HALVES
+#define RTX_ITEM_GRID_HALVES 4  // workgroups per pass of the list of live blocks, in halves of the number of pairs
+#endif
 void launch_hit_count_pair(hipStream_t s, const HitParams &p, uint32_t nq, uint32_t ntiles) {
     static_assert(3u * kPairListDw >= 1024u + 2048u + 64u, "histogram (t <= 1023) and byte counters (+ pad words) alias the lists");
     static_assert(kSegMaxSparseRows + 1 >= kSparseIt * 64, "the slot id lists are read without a bound");
     const uint32_t np = (nq + 1u) / 2u;
-    if (p.counts_lo) hipLaunchKernelGGL((hit_count_pair_kernel<10, true, false>), dim3(np, ntiles), dim3(64), kPairLdsBytes, s, p);
-    else hipLaunchKernelGGL((hit_count_pair_kernel<10, false, false>), dim3(np, ntiles), dim3(64), kPairLdsBytes, s, p);
+    // with the list of live blocks: two blocks' worth of workgroups per pair and pass (the bench workload keeps 1.5), never more than the blocks there are
+    const dim3 grid = p.items ? dim3((uint32_t)std::min<uint64_t>((uint64_t)np * ntiles, std::max<uint64_t>((uint64_t)RTX_ITEM_GRID_HALVES * np / 2u, 2048ull))) : dim3(np, ntiles);
+    if (p.counts_lo) {
+        if (p.items) hipLaunchKernelGGL((hit_count_pair_kernel<10, true, false, true>), grid, dim3(64), kPairLdsBytes, s, p);
+        else hipLaunchKernelGGL((hit_count_pair_kernel<10, true, false, false>), grid, dim3(64), kPairLdsBytes, s, p);
+    } else {
+        if (p.items) hipLaunchKernelGGL((hit_count_pair_kernel<10, false, false, true>), grid, dim3(64), kPairLdsBytes, s, p);
+        else hipLaunchKernelGGL((hit_count_pair_kernel<10, false, false, false>), grid, dim3(64), kPairLdsBytes, s, p);
+    }
+}
+
+void launch_live_items(hipStream_t s, const uint32_t *live, uint32_t live_words, const uint32_t *pair_live, uint32_t nq, uint32_t ntiles, uint32_t *off,
+                       uint32_t *items, uint32_t *n_items) {
+    const uint32_t np = (nq + 1u) / 2u;
+    hipLaunchKernelGGL(live_offsets_kernel, dim3(1), dim3(1024), 0, s, pair_live, np, off, n_items);
+    hipLaunchKernelGGL(live_items_kernel, dim3((np + 255u) / 256u), dim3(256), 0, s, live, live_words, nq, ntiles, off, items);
 }
 
 void launch_hit_count_pair_bounds(hipStream_t s, const HitParams &p, uint32_t nq, uint32_t u_ntiles) {
-    hipLaunchKernelGGL((hit_count_pair_kernel<10, true, true>), dim3((nq + 1u) / 2u, u_ntiles), dim3(64), kPairLdsBytes, s, p);
+    hipLaunchKernelGGL((hit_count_pair_kernel<10, true, true, false>), dim3((nq + 1u) / 2u, u_ntiles), dim3(64), kPairLdsBytes, s, p);
 }
 
 }  // namespace rtx

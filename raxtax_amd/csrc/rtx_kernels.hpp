@@ -143,6 +143,8 @@ struct HitParams {
     uint32_t pair_ustride;
     const uint32_t *live;     // [B][live_words] tiles to count for a query (rtx_prune.hip; the masks of a pair are neighbours) or null: all
     uint32_t live_words;
+    const uint32_t *items;    // [n_items] pair * ntiles + tile of the (pair, tile) blocks with a live query, ascending (live_items_kernel), or null:
+    const uint32_t *n_items;  //           the grid is pairs x tiles.  With the list the grid is one-dimensional and walks it
     // the bounds pass of the tile pruning (hit_count_pair_kernel<.., kBounds>: this launch counts against the union bitmap)
     uint16_t *bounds_tile_ub;     // [B][bounds_tile_stride] largest bound of every tile of the database
     uint32_t bounds_tile_stride, bounds_ntiles;
@@ -185,6 +187,7 @@ struct PruneParams {
     uint32_t hstride;
     uint32_t *live;           // [B][live_words] bit T: tile T is counted for the query
     uint32_t live_words;
+    uint32_t *pair_live;      // [pairs] tiles counted for either query of the pair (live_offsets_kernel turns them into the list of blocks) or null
     uint16_t *thr_out;        // [B] the threshold of every query (0: not pruned, every tile is counted)
     uint16_t *i1_out;         // [B] i* + 1 of every query with a threshold: Z holds less than 1e-12 at i <= i* (prob_lookup starts there)
     unsigned long long *stats;  // [kPruneStatCopies][8]: [0] += live tiles, [1] += pairs ... (reporting) or null
@@ -278,6 +281,9 @@ void launch_hit_count(hipStream_t s, const HitParams &p, uint32_t nq, uint32_t n
 void launch_pair_union(hipStream_t s, const uint32_t *rows, const uint32_t *nrows, uint32_t rstride, uint32_t nq, uint2 *urec,
                        uint32_t *nu, uint32_t ustride);
 void launch_hit_count_pair(hipStream_t s, const HitParams &p, uint32_t nq, uint32_t ntiles);  // 10 bit planes only
+// the list of the live (pair, tile) blocks from the masks and the per-pair numbers prune_kernel left: off = [pairs] scratch
+void launch_live_items(hipStream_t s, const uint32_t *live, uint32_t live_words, const uint32_t *pair_live, uint32_t nq, uint32_t ntiles, uint32_t *off,
+                       uint32_t *items, uint32_t *n_items);
 void launch_hit_count_pair_bounds(hipStream_t s, const HitParams &p, uint32_t nq, uint32_t u_ntiles);  // ... on the union bitmap: bounds_epilogue
 size_t prob_table_lds_bytes(uint32_t tmax);
 void launch_prob_table(hipStream_t s, const ProbParams &p, uint32_t nq);

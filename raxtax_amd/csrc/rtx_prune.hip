@@ -340,6 +340,7 @@ __global__ __launch_bounds__(64, RTX_PRUNE_WAVES) void prune_kernel(PruneParams 
         p.hist[(size_t)(pair * 2u) * p.hstride] = (uint32_t)dead_refs[0];  // kmer_extract has zeroed the row; hit_count adds the counted ones
         if (has_b) p.hist[(size_t)(pair * 2u + 1u) * p.hstride] = (uint32_t)dead_refs[1];
     }
+    if (lane == 0 && p.pair_live) p.pair_live[pair] = n_live;
     st[7] = n_qlive;  // (query, tile) combinations that are counted
     if (p.stats) {  // one atomic instruction per wave (lane k adds counter k), 64 copies of the counters in lines of their own:
                     // thousands of waves adding to ONE address queue up in L2 for longer than everything else here takes

@@ -78,11 +78,11 @@ def main():
 
     def hit(agg, ctr):
         """Sum and number of the dispatches of the hit_count kernel per kind of launch.  The bounds pass of the tile pruning is an
-        instantiation of its own (hit_count_pair_kernel<10, true, true>: kBounds), so the kernel name tells the kinds apart."""
+        instantiation of its own (hit_count_pair_kernel<10, true, true, false>: the third argument is kBounds), so the kernel name tells the kinds apart."""
         out = {}
         for k, d in agg.items():
             if k.startswith("rtx::hit_count") and ctr in d:   # hit_count_kernel / hit_count_pair_kernel: whichever the run used
-                kind = "all" if a.unpruned else ("bounds" if k.replace(" ", "").endswith(",true,true>") else "live")
+                kind = "all" if a.unpruned else ("bounds" if "pair_kernel<10,true,true," in k.replace(" ", "") else "live")
                 tot, n = out.get(kind, (0.0, 0))
                 out[kind] = (tot + sum(d[ctr]), n + len(d[ctr]))
         return out or None

@@ -417,6 +417,7 @@ int enqueue_hit(rtx_index *ix, const SubBatch &b, uint32_t flags, hipStream_t s,
     hp.live_words = 0;
     hp.items = nullptr;
     hp.n_items = nullptr;
+    hp.prune_thr = nullptr;
     const bool prune = ix->prune_used && !ix->dbg_full_run;
     if (b.timed && !prune) RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_HIT_COUNT, 0), s));
     if (ix->pair_used && part != 2) launch_pair_union(s, sc.d_rows.p, sc.d_nrows.p, ix->rstride, b.nq, sc.d_urec.p, sc.d_nu.p, 2u * ix->rstride);
@@ -488,6 +489,7 @@ int enqueue_hit(rtx_index *ix, const SubBatch &b, uint32_t flags, hipStream_t s,
         RTX_HIP(hipMemsetAsync(sc.d_tilemax.p, 0, (size_t)b.nq * ix->ntiles * 2, s));
         hp.live = sc.d_live.p;
         hp.live_words = pr.live_words;
+        hp.prune_thr = sc.d_prune_thr.p;
         if (ix->pair_used) {  // the grid of the counting pass walks the live (pair, tile) blocks instead of all of them
             const size_t np = (b.nq + 1u) / 2u, cap = np * ix->ntiles;
             launch_live_items(s, sc.d_live.p, pr.live_words, pr.pair_live, b.nq, ix->ntiles, sc.d_items.p + cap + 1u + np, sc.d_items.p, sc.d_items.p + cap);

@@ -209,10 +209,21 @@ __device__ __forceinline__ void sparse_prefetch(const HitParams &p, uint32_t lan
         }
 }
 
+__device__ __forceinline__ uint32_t pk_max_u16(uint32_t a, uint32_t b) {  // v_pk_max_u16
+    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+    u16x2 x, y;
+    __builtin_memcpy(&x, &a, 4);
+    __builtin_memcpy(&y, &b, 4);
+    const u16x2 m = __builtin_elementwise_max(x, y);
+    uint32_t r;
+    __builtin_memcpy(&r, &m, 4);
+    return r;
+}
+
 template <int NP, bool kPacked, bool kPrefetch, bool kFullTile, bool kPreLoaded>
 __device__ __forceinline__ void hit_epilogue_x(const HitParams &p, uint32_t (&pl)[4][NP], uint32_t q, uint32_t tile, uint32_t lane,
                                                uint32_t t, bool active, uint32_t *hist_lds, uint32_t *cnt8, uint32_t ns,
-                                               const uint32_t *srows, uint4 (&pre)[kSparseIt][kSparseV]) {
+                                               const uint32_t *srows, uint4 (&pre)[kSparseIt][kSparseV], uint32_t h_thr) {
     RTX_EPI_DECL
     constexpr int kIt = kSparseIt, kVp = kSparseV;
     const bool lists = ns != 0u;  // wave-uniform: byte counters in use
@@ -261,6 +272,9 @@ __device__ __forceinline__ void hit_epilogue_x(const HitParams &p, uint32_t (&pl
     for (uint32_t i = lane; i <= t; i += 64) hist_lds[i] = 0;
     wave_lds_sync();
     RTX_EPI_MARK(5)
+    // tile pruning gave the query a threshold u: every count up to u is a reference without a hit to prob_lookup (rtx_prob_tables.hip) --
+    // they go to bin 0 as one number, and only the groups of references that hold a count above u touch the histogram (h_thr: u or 0)
+    const uint32_t h_lo = h_thr ? h_thr + 1u : 0u;
 
     const uint32_t L = tile_lanes(p.stride_bytes, tile);  // lanes of this tile (64 except in the last one)
     if (active && (p.flags & RTX_SKIP_EXACT_MATCHES)) {  // raxtax.rs:65-68: the dense part
@@ -359,7 +373,17 @@ __device__ __forceinline__ void hit_epilogue_x(const HitParams &p, uint32_t (&pl
                         *reinterpret_cast<uint4 *>(out + goff) = st;
                     }
                     const uint32_t cw[4] = {st.x, st.y, st.z, st.w};
-                    if (tile_full) {  // wave-uniform: every reference of the tile exists -- no compare, no exec mask per atomic
+                    if (h_lo) {  // wave-uniform: a pruned query -- only the counts above its threshold are looked at one by one
+                        const uint32_t m2 = pk_max_u16(pk_max_u16(st.x, st.y), pk_max_u16(st.z, st.w));
+                        const uint32_t m = (m2 & 0xFFFFu) > (m2 >> 16) ? (m2 & 0xFFFFu) : (m2 >> 16);
+                        if (__ballot(m >= h_lo) != 0ull) {  // (references behind n_refs have a count of 0)
+#pragma unroll
+                            for (int j = 0; j < 8; j++) {
+                                const uint32_t c = (cw[j >> 1] >> ((j & 1) * 16)) & 0xFFFFu;
+                                if (c >= h_lo) atomicAdd(&hist_lds[c], 1u);
+                            }
+                        }
+                    } else if (tile_full) {  // wave-uniform: every reference of the tile exists -- no compare, no exec mask per atomic
 #pragma unroll
                         for (int j = 0; j < 8; j++) atomicAdd(&hist_lds[(cw[j >> 1] >> ((j & 1) * 16)) & 0xFFFFu], 1u);
                     } else {  // the last tile of the database: the references behind n_refs are not counted
@@ -395,9 +419,15 @@ __device__ __forceinline__ void hit_epilogue_x(const HitParams &p, uint32_t (&pl
     // every lane of the wave flushes (also those whose columns lie beyond the row)
     uint32_t *hist = p.hist + (size_t)q * p.hstride;
     uint32_t mx = 0;  // the largest count of this tile = its highest non-empty bin
+    uint32_t n_high = 0;
     for (uint32_t m = lane; m <= t; m += 64) {
         const uint32_t v = hist_lds[m];
-        if (v) { atomicAdd(&hist[m], v); mx = m; }
+        if (v) { atomicAdd(&hist[m], v); mx = m; n_high += v; }
+    }
+    if (h_lo) {  // the references of the tile with a count up to the threshold (0 for the tile's largest count if there is no other)
+        n_high = wave_incl_scan_u32(n_high);
+        const uint32_t in_tile = tile_full ? 8192u : (uint32_t)(p.n_refs - ((uint64_t)tile << 13));
+        if (lane == 63u && in_tile != n_high) atomicAdd(&hist[0], in_tile - n_high);
     }
     if (p.tile_max) {
         for (int d = 32; d >= 1; d >>= 1) {
@@ -463,7 +493,8 @@ __device__ __forceinline__ void hit_epilogue(const HitParams &p, uint32_t (&pl)[
                                              uint32_t t, bool active, uint32_t *hist_lds, uint32_t *cnt8, uint32_t ns,
                                              const uint32_t *srows) {
     uint4 pre[kSparseIt][kSparseV];  // unused without kPrefetch
-    hit_epilogue_x<NP, kPacked, kPrefetch, false, false>(p, pl, q, tile, lane, t, active, hist_lds, cnt8, ns, srows, pre);
+    hit_epilogue_x<NP, kPacked, kPrefetch, false, false>(p, pl, q, tile, lane, t, active, hist_lds, cnt8, ns, srows, pre,
+                                                         p.prune_thr ? (uint32_t)__builtin_amdgcn_readfirstlane((int)p.prune_thr[q]) : 0u);
 }
 
 }  // namespace rtx

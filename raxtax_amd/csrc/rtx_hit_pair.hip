@@ -157,14 +157,17 @@ __device__ __forceinline__ void pair_tile_block(const HitParams &p, uint32_t *ld
     const uint2 *urec = p.pair_urec + (size_t)pair * p.pair_ustride;
     // Everything the prologue needs comes in with ONE round trip: the first 512 union entries (clamped index: what lies
     // behind the union is masked below), the dense masks of the tile, the slot ids of the sparse segments, the counts.
-    auto load_recs = [&](uint2 (&rec)[8], uint32_t from) {
+    // (Requesting the second 512 entries and the numbers the epilogues start with -- t, the threshold -- here as well changed nothing
+    // or cost registers: tools/NOTES.md.)
+    constexpr int kRecChunks = 8;
+    auto load_recs = [&](uint2 (&rec)[kRecChunks], uint32_t from) {
 #pragma unroll
-        for (int c = 0; c < 8; c++) {
+        for (int c = 0; c < kRecChunks; c++) {
             const uint32_t i = from + (uint32_t)c * 64u + lane;
             rec[c] = urec[i < p.pair_ustride ? i : p.pair_ustride - 1u];
         }
     };
-    uint2 rec[8];
+    uint2 rec[kRecChunks];
     load_recs(rec, 0);
     const uint32_t ns_a = kBounds || !has_a ? 0u : p.nsparse[(size_t)qa * p.ntiles + tile], ns_b = !kBounds && has_b ? p.nsparse[(size_t)qb * p.ntiles + tile] : 0u;
     const uint32_t *srows_a = p.srows + ((size_t)qa * p.ntiles + tile) * (kSegMaxSparseRows + 1);
@@ -204,7 +207,7 @@ __device__ __forceinline__ void pair_tile_block(const HitParams &p, uint32_t *ld
             // eight chunks of 64 union entries per round trip (the first has been requested above)
             if (u0) load_recs(rec, u0);
 #pragma unroll
-            for (int c = 0; c < 8; c++) {
+            for (int c = 0; c < kRecChunks; c++) {
                 if (u0 >= n_u) break;
                 if (n_both + 64u > kPairCap || n_a + 64u > kPairCap || n_b + 64u > kPairCap) { room = false; break; }
                 const bool in = u0 + lane < n_u;
@@ -270,13 +273,14 @@ __device__ __forceinline__ void pair_tile_block(const HitParams &p, uint32_t *ld
     uint32_t *hist_lds = lds_dw;
     uint32_t *cnt8 = lds_dw + 1024u;
     uint4 pre_a[kSparseIt][kSparseV], pre_b[kSparseIt][kSparseV];
+    auto thr_of = [&](uint32_t q) -> uint32_t { return p.prune_thr ? (uint32_t)__builtin_amdgcn_readfirstlane((int)p.prune_thr[q]) : 0u; };
     if (ns_a) sparse_prefetch(p, lane, ns_a, l_sid, pre_a);
     if (ns_b) sparse_prefetch(p, lane, ns_b, l_sid + kSparseIt * 64u, pre_b);
-    if (has_a) hit_epilogue_x<NP, kPacked, true, true, true>(p, pa, qa, tile, lane, p.t[qa], active, hist_lds, cnt8, ns_a, srows_a, pre_a);
+    if (has_a) hit_epilogue_x<NP, kPacked, true, true, true>(p, pa, qa, tile, lane, p.t[qa], active, hist_lds, cnt8, ns_a, srows_a, pre_a, thr_of(qa));
     PAIR_MARK(3)
     if (has_b) {
         wave_lds_sync();
-        hit_epilogue_x<NP, kPacked, true, true, true>(p, pb, qb, tile, lane, p.t[qb], active, hist_lds, cnt8, ns_b, srows_b, pre_b);
+        hit_epilogue_x<NP, kPacked, true, true, true>(p, pb, qb, tile, lane, p.t[qb], active, hist_lds, cnt8, ns_b, srows_b, pre_b, thr_of(qb));
     }
     PAIR_MARK(4)
 #ifdef RTX_PAIR_STAMP

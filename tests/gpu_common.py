@@ -92,7 +92,8 @@ def check_run_as_left(index, j, t, counts_o, p_o, n_refs, emul=None, lf=None, la
     table / Z: prob.rs:8-103):
       * the counts hit_count wrote for the tiles it visited are the oracle's, bit for bit;
       * every tile it did not visit holds no count above the query's threshold (and the query has one);
-      * the histogram it left = the oracle's counts of the visited tiles + the unvisited references in bin 0;
+      * the histogram it left = the oracle's counts of the visited tiles above the threshold + everything else (unvisited references,
+        counts up to the threshold) in bin 0;
       * the probabilities of the pruned run equal the oracle's above the threshold (`tol`: 1e-9 by default, north_star allows 1e-6)
         and what the oracle gives the references at or below it -- which the pruned run sets to 0 -- is below 1e-9 in total;
       * (debug_taps) prune_kernel's best block holds the oracle's counts, its bound holds, and its threshold is the one the CPU
@@ -112,6 +113,9 @@ def check_run_as_left(index, j, t, counts_o, p_o, n_refs, emul=None, lf=None, la
     in_tile = np.minimum(8192, n_refs - np.arange(ntiles) * 8192)
     want_hist = np.bincount(co[live].reshape(-1), minlength=t + 1)[: t + 1].astype(np.int64)
     want_hist[0] += int(in_tile[~live].sum()) - int(pad if live[-1] else 0)      # the padding of the last tile is no reference
+    if thr:      # the epilogue of a pruned query puts the counts up to its threshold into bin 0 as one number (they are references without a hit to prob.rs)
+        want_hist[0] += int(want_hist[1: thr + 1].sum())
+        want_hist[1: thr + 1] = 0
     assert np.array_equal(rc["hist"].astype(np.int64), want_hist), f"{label}: histogram as the run left it"
     tz_p, z_p, thr2 = index.debug_pruned_prob_table(j, t)
     assert thr2 == thr

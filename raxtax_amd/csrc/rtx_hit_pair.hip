@@ -301,7 +301,8 @@ __global__ __launch_bounds__(64, 2) void hit_count_pair_kernel(HitParams p) {
     if (kItems) {
         // Every pass over the grid takes the next gridDim.x entries of the list; inside a pass XCD x (= workgroup id mod 8) takes a
         // contiguous eighth of them: neighbouring pairs share rows and tiles, and with them an L2.
-        const uint32_t n_items = (uint32_t)__builtin_amdgcn_readfirstlane((int)p.n_items[0]), G = gridDim.x, b = blockIdx.x;
+        // (G: a multiple of 8 -- workgroup b = 8 y + x takes entry x * s8 + y of the pass, x < 8, y < s8 <= G / 8)
+        const uint32_t n_items = (uint32_t)__builtin_amdgcn_readfirstlane((int)p.n_items[0]), G = gridDim.x & ~7u, b = blockIdx.x;
         for (uint32_t base = 0; base < n_items; base += G) {
             const uint32_t S = n_items - base < G ? n_items - base : G, s8 = (S + 7u) >> 3;
             const uint32_t j = (b & 7u) * s8 + (b >> 3);
@@ -386,7 +387,7 @@ void launch_hit_count_pair(hipStream_t s, const HitParams &p, uint32_t nq, uint3
     static_assert(kSegMaxSparseRows + 1 >= kSparseIt * 64, "the slot id lists are read without a bound");
     const uint32_t np = (nq + 1u) / 2u;
     // with the list of live blocks: two blocks' worth of workgroups per pair and pass (the bench workload keeps 1.5), never more than the blocks there are
-    const dim3 grid = p.items ? dim3((uint32_t)std::min<uint64_t>((uint64_t)np * ntiles, std::max<uint64_t>((uint64_t)RTX_ITEM_GRID_HALVES * np / 2u, 2048ull))) : dim3(np, ntiles);
+    const dim3 grid = p.items ? dim3((uint32_t)((std::min<uint64_t>((uint64_t)np * ntiles, std::max<uint64_t>((uint64_t)RTX_ITEM_GRID_HALVES * np / 2u, 2048ull)) + 7u) & ~7ull)) : dim3(np, ntiles);  // (a multiple of 8: the kernel deals a pass to the XCDs)
     if (p.counts_lo) {
         if (p.items) hipLaunchKernelGGL((hit_count_pair_kernel<10, true, false, true>), grid, dim3(64), kPairLdsBytes, s, p);
         else hipLaunchKernelGGL((hit_count_pair_kernel<10, true, false, false>), grid, dim3(64), kPairLdsBytes, s, p);

@@ -39,6 +39,20 @@ def test_more_than_one_tile_of_bounds(oracle, emul):
         ex = Excuses(f"pruned/620k/skip={int(skip)}")
         oracle_sample_parity(index, oracle, otree, db, qs, sample, skip, ex, full_res=None if skip else res, chunk=100, emul=emul)
         ex.check()
+    # Queries far from their best hit (10 % substitutions) keep tens of tiles each: the counting pass walks its list of live (pair, tile)
+    # blocks in several passes of the grid (rtx_hit_pair.hip: more blocks than workgroups), in the full batch and in the sample's own.
+    n_q2 = 3000
+    qs2 = synth.make_queries(db, n_q2, seed=12, mu_q=0.10, exact_frac=0.0)
+    res2 = index.classify(qs2.bases, qs2.base_off, *index.exact_matches(qs2.bases, qs2.base_off))
+    check_properties(res2, db, n_q2)
+    st2 = index.debug_prune_stats()
+    print("divergent queries:", st2)
+    assert st2["bound_violations"] == 0 and st2["live_tiles_per_pair"] * st2["pairs"] > 3 * n_q2      # grid: 2 workgroups per pair and pass
+    sample2 = np.sort(np.random.default_rng(63).choice(n_q2, 200, replace=False))
+    ex = Excuses("pruned/620k/divergent")
+    oracle_sample_parity(index, oracle, otree, db, qs2, sample2, False, ex, full_res=res2, chunk=100, emul=emul)
+    assert index.debug_prune_stats()["live_tiles_per_pair"] * 100 > 2048
+    ex.check()
 
 
 def _diptera_expanded(copies, seed=7):

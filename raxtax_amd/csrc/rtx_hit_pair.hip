@@ -67,20 +67,21 @@ __global__ __launch_bounds__(64) void pair_union_kernel(const uint32_t *__restri
     wave_lds_sync();
     uint2 *out = urec + (size_t)pair * ustride;
     uint32_t n_u = 0, n_a = 0, n_b = 0;  // wave-uniform running totals
-    for (uint32_t w0 = 0; w0 < 2048u; w0 += 64) {
-        const uint32_t a = bits[0][w0 + lane], b = bits[1][w0 + lane];
-        uint32_t u = a | b;
-        if (__ballot(u != 0u) == 0ull) continue;
+    const unsigned long long *b64a = reinterpret_cast<const unsigned long long *>(&bits[0][0]), *b64b = reinterpret_cast<const unsigned long long *>(&bits[1][0]);
+    for (uint32_t w0 = 0; w0 < 1024u; w0 += 64) {  // sixteen turns of 64 x 64 rows (with 32-bit words: thirty-two turns, twice the scans)
+        const unsigned long long a = b64a[w0 + lane], b = b64b[w0 + lane];
+        unsigned long long u = a | b;
+        if (__ballot(u != 0ull) == 0ull) continue;
         // exclusive prefix over the lanes of the three counts (each below 2^11 in total: packed 11 + 11 bits and one apart); DPP scans
-        // (the shuffle version -- twelve ds_bpermute round trips per 64 words -- was most of the kernel: 6.9 -> ms per 1 M queries)
-        uint32_t su = (uint32_t)__popc(u), sab = (uint32_t)__popc(a) | ((uint32_t)__popc(b) << 16);
+        // (the shuffle version -- twelve ds_bpermute round trips per 64 words -- was most of the kernel)
+        uint32_t su = (uint32_t)__popcll(u), sab = (uint32_t)__popcll(a) | ((uint32_t)__popcll(b) << 16);
         const uint32_t iu = wave_incl_scan_u32(su), iab = wave_incl_scan_u32(sab);
         uint32_t pu = n_u + iu - su, pa = n_a + (iab & 0xFFFFu) - (sab & 0xFFFFu), pb = n_b + (iab >> 16) - (sab >> 16);
         while (u) {
-            const uint32_t bit = (uint32_t)__ffs((int)u) - 1u;
-            u &= u - 1u;
-            const uint32_t ina = (a >> bit) & 1u, inb = (b >> bit) & 1u;
-            out[pu] = make_uint2(((w0 + lane) * 32u + bit) | (ina << 30) | (inb << 31),
+            const uint32_t bit = (uint32_t)__builtin_ctzll(u);
+            u &= u - 1ull;
+            const uint32_t ina = (uint32_t)(a >> bit) & 1u, inb = (uint32_t)(b >> bit) & 1u;
+            out[pu] = make_uint2(((w0 + lane) * 64u + bit) | (ina << 30) | (inb << 31),
                                  (ina ? pa : 0xFFFFu) | ((inb ? pb : 0xFFFFu) << 16));
             pu++;
             pa += ina;

@@ -144,11 +144,15 @@ __device__ __forceinline__ unsigned long long transpose64(unsigned long long x, 
 #define KMER_MARK(k)
 #endif
 
+// kTilesOnly: the launch behind tile pruning (mode 2) -- without the 8 KB k-mer set of the extraction in LDS twice as many of its waves fit a CU
+// (a chain of gathers per query: the waves in flight are what hides them)
+template <bool kTilesOnly>
 __global__ __launch_bounds__(64) void kmer_extract_kernel(KmerParams p) {
+    const uint32_t mode = kTilesOnly ? 2u : p.mode;
 #ifdef RTX_KMER_STAMP
     unsigned long long st_acc = 0, st_t = __builtin_amdgcn_s_memtime();
 #endif
-    __shared__ __attribute__((aligned(16))) uint32_t bm[2048];
+    __shared__ __attribute__((aligned(16))) uint32_t bm[kTilesOnly ? 64 : 2048];
     const uint32_t q = blockIdx.x;
     const uint32_t lane = threadIdx.x;
     const uint64_t gq = p.q0 + q;  // position in the processing order: index of the per-query outputs
@@ -157,13 +161,13 @@ __global__ __launch_bounds__(64) void kmer_extract_kernel(KmerParams p) {
     const uint64_t len = p.base_off[qin + 1] - b0;
     const uint8_t *seq = p.bases + b0;
 
-    // p.mode: 0 = everything; 1 = the k-mers and the row list only; 2 = the per-tile lists only, for the tiles tile pruning
+    // mode: 0 = everything; 1 = the k-mers and the row list only; 2 = the per-tile lists only, for the tiles tile pruning
     // left alive (the launch of mode 1 has left the row list; rtx_prune.hip decides between the two)
     uint32_t t = 0, nrows = 0;
     unsigned long long hq = 0;
     uint32_t *rout = p.rows + (size_t)q * p.rstride;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    if (p.mode == 2u) {
+    if (mode == 2u) {
         nrows = p.nrows[q];
     } else {
     for (uint32_t i = lane; i < 2048; i += 64) bm[i] = 0;
@@ -255,15 +259,15 @@ __global__ __launch_bounds__(64) void kmer_extract_kernel(KmerParams p) {
     for (uint32_t i = nrows + lane; i < ((nrows + 63u) & ~63u); i += 64) rout[i] = p.zero_row;
     __syncthreads();  // rout visible to the whole wave
     KMER_MARK(3)
-    }  // p.mode != 2
-    if (p.mode == 1u) {
+    }  // mode != 2
+    if (mode == 1u) {
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) hq += __shfl_xor(hq, d, 64);
         if (lane == 0) { p.t[q] = t; p.nrows[q] = nrows; p.hq[gq] = hq; p.t_all[gq] = t; }
         return;
     }
     const uint32_t nchunks = (nrows + 63u) >> 6;
-    const uint32_t *live = p.mode == 2u ? p.live + (size_t)q * p.live_words : nullptr;  // the tiles that are counted for this query (rtx_prune.hip)
+    const uint32_t *live = mode == 2u ? p.live + (size_t)q * p.live_words : nullptr;  // the tiles that are counted for this query (rtx_prune.hip)
     // Per tile: which rows have a dense segment there (a 64-bit mask per 64 rows), and the slots of the sparse
     // segments; empty segments are dropped (rtx_segments.hip).
     const uint32_t nt = p.ntiles;
@@ -445,7 +449,7 @@ __global__ __launch_bounds__(64) void kmer_extract_kernel(KmerParams p) {
     hq = st_acc;
 #endif
     if (lane == 0) {
-        if (p.mode != 2u) {
+        if (mode != 2u) {
             p.t[q] = t;
             p.nrows[q] = nrows;
             p.hq[gq] = hq;
@@ -1354,7 +1358,8 @@ void launch_row_popcount(hipStream_t s, const uint32_t *row_of, const uint32_t *
     hipLaunchKernelGGL(row_popcount_kernel, dim3(RTX_NUM_KMERS), dim3(256), 0, s, row_of, bitmap, stride_words, n_rows1, list_len);
 }
 void launch_kmer_extract(hipStream_t s, const KmerParams &p, uint32_t nq) {
-    hipLaunchKernelGGL(kmer_extract_kernel, dim3(nq), dim3(64), 0, s, p);
+    if (p.mode == 2u) hipLaunchKernelGGL(kmer_extract_kernel<true>, dim3(nq), dim3(64), 0, s, p);
+    else hipLaunchKernelGGL(kmer_extract_kernel<false>, dim3(nq), dim3(64), 0, s, p);
 }
 void launch_hit_count(hipStream_t s, const HitParams &p_in, uint32_t nq, uint32_t ntiles, int planes) {
     HitParams p = p_in;

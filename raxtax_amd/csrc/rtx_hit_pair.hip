@@ -44,53 +44,64 @@ constexpr int kPairNB = 4;                            // buffers of eight rows p
 // ---------------------------------------------------------------------------
 // Union of the row lists of the queries 2 * pair and 2 * pair + 1 of a sub-batch (ascending row ids, as kmer_extract
 // leaves them).  Entry = {row | inA << 30 | inB << 31, posA | posB << 16} (0xFFFF: not in that list).
-// One wave per pair; two 65 536-bit sets in LDS, read out in order with a prefix scan.
+// One wave per pair; two bit sets in LDS (the rows of A, of B), read out in order with a prefix scan.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void pair_union_kernel(const uint32_t *__restrict__ rows, const uint32_t *__restrict__ nrows,
                                                         uint32_t rstride, uint32_t nq, uint2 *__restrict__ urec,
                                                         uint32_t *__restrict__ nu, uint32_t ustride) {
-    __shared__ __attribute__((aligned(16))) uint32_t bits[2][2048];
+    // half of the row range at a time (8 KB of LDS per wave instead of 16: twenty waves per CU instead of ten)
+    __shared__ __attribute__((aligned(16))) unsigned long long bits[2][512];
     const uint32_t pair = blockIdx.x, lane = threadIdx.x;
     const uint32_t qa = pair * 2u, qb = qa + 1u;
     const uint32_t na = nrows[qa], nb = qb < nq ? nrows[qb] : 0u;
-    for (uint32_t i = lane; i < 1024u; i += 64) reinterpret_cast<uint4 *>(&bits[0][0])[i] = make_uint4(0u, 0u, 0u, 0u);
-    wave_lds_sync();
     const uint32_t *ra = rows + (size_t)qa * rstride, *rb = rows + (size_t)(qb < nq ? qb : qa) * rstride;
-    for (uint32_t i = lane; i < na; i += 64) {
-        const uint32_t r = ra[i] & 0xFFFFu;
-        atomicOr(&bits[0][r >> 5], 1u << (r & 31u));
-    }
-    for (uint32_t i = lane; i < nb; i += 64) {
-        const uint32_t r = rb[i] & 0xFFFFu;
-        atomicOr(&bits[1][r >> 5], 1u << (r & 31u));
-    }
-    wave_lds_sync();
+    const uint32_t nmax = na > nb ? na : nb;
     uint2 *out = urec + (size_t)pair * ustride;
     uint32_t n_u = 0, n_a = 0, n_b = 0;  // wave-uniform running totals
-    const unsigned long long *b64a = reinterpret_cast<const unsigned long long *>(&bits[0][0]), *b64b = reinterpret_cast<const unsigned long long *>(&bits[1][0]);
-    for (uint32_t w0 = 0; w0 < 1024u; w0 += 64) {  // sixteen turns of 64 x 64 rows (with 32-bit words: thirty-two turns, twice the scans)
-        const unsigned long long a = b64a[w0 + lane], b = b64b[w0 + lane];
-        unsigned long long u = a | b;
-        if (__ballot(u != 0ull) == 0ull) continue;
-        // exclusive prefix over the lanes of the three counts (each below 2^11 in total: packed 11 + 11 bits and one apart); DPP scans
-        // (the shuffle version -- twelve ds_bpermute round trips per 64 words -- was most of the kernel)
-        uint32_t su = (uint32_t)__popcll(u), sab = (uint32_t)__popcll(a) | ((uint32_t)__popcll(b) << 16);
-        const uint32_t iu = wave_incl_scan_u32(su), iab = wave_incl_scan_u32(sab);
-        uint32_t pu = n_u + iu - su, pa = n_a + (iab & 0xFFFFu) - (sab & 0xFFFFu), pb = n_b + (iab >> 16) - (sab >> 16);
-        while (u) {
-            const uint32_t bit = (uint32_t)__builtin_ctzll(u);
-            u &= u - 1ull;
-            const uint32_t ina = (uint32_t)(a >> bit) & 1u, inb = (uint32_t)(b >> bit) & 1u;
-            out[pu] = make_uint2(((w0 + lane) * 64u + bit) | (ina << 30) | (inb << 31),
-                                 (ina ? pa : 0xFFFFu) | ((inb ? pb : 0xFFFFu) << 16));
-            pu++;
-            pa += ina;
-            pb += inb;
+    uint32_t *bits32 = reinterpret_cast<uint32_t *>(&bits[0][0]);
+    for (uint32_t h = 0; h < 2u; h++) {
+        for (uint32_t i = lane; i < 512u; i += 64) reinterpret_cast<uint4 *>(&bits[0][0])[i] = make_uint4(0u, 0u, 0u, 0u);
+        wave_lds_sync();
+        for (uint32_t i0 = 0; i0 < nmax; i0 += 256) {  // four chunks of each list per turn: the eight loads leave together
+            uint32_t va[4], vb[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint32_t i = i0 + (uint32_t)k * 64u + lane;
+                va[k] = i < na ? ra[i] & 0xFFFFu : 0xFFFFFFFFu;
+                vb[k] = i < nb ? rb[i] & 0xFFFFu : 0xFFFFFFFFu;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if ((va[k] >> 15) == h) atomicOr(&bits32[(va[k] & 32767u) >> 5], 1u << (va[k] & 31u));
+                if ((vb[k] >> 15) == h) atomicOr(&bits32[1024u + ((vb[k] & 32767u) >> 5)], 1u << (vb[k] & 31u));
+            }
         }
-        n_u += (uint32_t)__builtin_amdgcn_readlane((int)iu, 63);
-        const uint32_t tab = (uint32_t)__builtin_amdgcn_readlane((int)iab, 63);
-        n_a += tab & 0xFFFFu;
-        n_b += tab >> 16;
+        wave_lds_sync();
+        for (uint32_t w0 = 0; w0 < 512u; w0 += 64) {  // eight turns of 64 x 64 rows
+            const unsigned long long a = bits[0][w0 + lane], b = bits[1][w0 + lane];
+            unsigned long long u = a | b;
+            if (__ballot(u != 0ull) == 0ull) continue;
+            // exclusive prefix over the lanes of the three counts (each below 2^11 in total: packed 11 + 11 bits and one apart); DPP scans
+            // (the shuffle version -- twelve ds_bpermute round trips per 64 words -- was most of the kernel)
+            uint32_t su = (uint32_t)__popcll(u), sab = (uint32_t)__popcll(a) | ((uint32_t)__popcll(b) << 16);
+            const uint32_t iu = wave_incl_scan_u32(su), iab = wave_incl_scan_u32(sab);
+            uint32_t pu = n_u + iu - su, pa = n_a + (iab & 0xFFFFu) - (sab & 0xFFFFu), pb = n_b + (iab >> 16) - (sab >> 16);
+            while (u) {
+                const uint32_t bit = (uint32_t)__builtin_ctzll(u);
+                u &= u - 1ull;
+                const uint32_t ina = (uint32_t)(a >> bit) & 1u, inb = (uint32_t)(b >> bit) & 1u;
+                out[pu] = make_uint2((h * 32768u + (w0 + lane) * 64u + bit) | (ina << 30) | (inb << 31),
+                                     (ina ? pa : 0xFFFFu) | ((inb ? pb : 0xFFFFu) << 16));
+                pu++;
+                pa += ina;
+                pb += inb;
+            }
+            n_u += (uint32_t)__builtin_amdgcn_readlane((int)iu, 63);
+            const uint32_t tab = (uint32_t)__builtin_amdgcn_readlane((int)iab, 63);
+            n_a += tab & 0xFFFFu;
+            n_b += tab >> 16;
+        }
+        wave_lds_sync();  // the sets are zeroed again
     }
     if (lane == 0) nu[pair] = n_u;
 }

@@ -17,6 +17,7 @@ LIB = PKG / "libraxtax_hip.so"
 SOURCES = ["rtx_kernels.hip", "rtx_hit_pair.hip", "rtx_prob_tables.hip", "rtx_cluster.hip", "rtx_segments.hip", "rtx_prune.hip", "rtx_exact.hip", "rtx_api.hip", "host_tree.cpp", "host_format.cpp", "host_raxtax.cpp", "host_bin.cpp"]
 HEADERS = ["rtx_kernels.hpp", "rtx_hit_common.hpp", "rtx_internal.hpp", "rtx_math.hpp", "rtx_wave.hpp", "host_raxtax.hpp"]
 CLI = PKG / "raxtax-hip"
+SYNTH = PKG / "raxtax-synth"   # the generator of the synthetic inputs as a host program: csrc/synth_main.cpp
 
 
 def _hipcc() -> str:
@@ -77,6 +78,14 @@ def build_cli(force: bool = False) -> Path | None:
     return CLI
 
 
+def build_synth(force: bool = False) -> Path:
+    main = CSRC / "synth_main.cpp"
+    if force or _stale(SYNTH, [main]):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", str(SYNTH), str(main)])
+    return SYNTH
+
+
 if __name__ == "__main__":
     print(build_lib(force=True, verbose=True))
     print(build_cli(force=True))
+    print(build_synth(force=True))

@@ -147,3 +147,29 @@ def test_cli_streamed_query_ingest(tmp_path):
     lb = (b / "raxtax.out").read_text().splitlines()
     assert len(la) >= 600 and la == lb
     assert (a / "raxtax.ckp").read_text() == (b / "raxtax.ckp").read_text()
+
+
+def test_cli_on_files_of_the_cpp_generator(tmp_path, oracle):
+    """raxtax-synth (csrc/synth_main.cpp, the C++ twin of the generator of SURVEY.md 8d) writes a database and queries;
+    raxtax-hip classifies them; every line against the oracle's text for the same files."""
+    import json
+
+    from raxtax_amd import _build
+    exe = _build.build_synth()
+    db, qf, out = tmp_path / "db.fasta", tmp_path / "q.fasta", tmp_path / "out"
+    subprocess.run([str(exe), "db", "3000", str(db)], check=True, capture_output=True)
+    subprocess.run([str(exe), "queries", str(db), "300", str(qf)], check=True, capture_output=True)
+    run("-d", db, "-i", qf, "-o", out)
+    by_label = {}
+    for l in (out / "raxtax.out").read_text().splitlines():
+        by_label.setdefault(l.split("\t")[0], []).append(l)
+    otree = oracle.parse_reference_fasta_str(db.read_text())
+    queries = oracle.parse_query_fasta_str(qf.read_text())
+    assert len(queries) == 300 and set(by_label) == {l for l, _ in queries}
+    n_diff = 0
+    for label, seq in queries:
+        rows, raw = otree.classify(seq)
+        n_diff += otree.format_out(label, raw).split("\n") != by_label[label]
+    allowed = json.loads((ROOT / "tests" / "golden" / "expected_excuses.json").read_text()).get("cli/synth3000", {}).get("ties", 0)
+    print(f"CLI on raxtax-synth files: {n_diff} of 300 queries differ from the oracle's text (ties allowed: {allowed})")
+    assert n_diff <= allowed

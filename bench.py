@@ -73,6 +73,8 @@ def parse():
     ap.add_argument("--no-tile-prune", action="store_true", help="hit_count counts every tile of 8192 references (RTX_OPT_TILE_PRUNE = 0; default: only the tiles that can hold a reference with any probability)")
     ap.add_argument("--tile-prune", action="store_true", help="(the default; kept for older command lines)")
     ap.add_argument("--no-tile-skip", action="store_true", help="taxon_prefix sums every reference (RTX_OPT_TILE_SKIP = 0; A/B measurements)")
+    ap.add_argument("--mu-q", type=float, default=0.02, help="per-site substitution rate of a query against its source reference (the headline: 0.02)")
+    ap.add_argument("--exact-frac", type=float, default=0.10, help="share of the queries that are exact copies of a reference (the headline: 0.10)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="only the headline: no H2D / end-to-end / unpruned legs, no divergence sweep")
     ap.add_argument("--host-exact-match", action="store_true",
@@ -508,7 +510,7 @@ def main():
                     f"{'reference id' if args.shard_mode == 'refs' else 'k-mer (every rank holds the posting lists of a k-mer range over all references)'} "
                     f"over {world} GPU(s) (BASELINE.json configs[4] shape)")
     else:
-        qs = synth.make_queries(db, args.queries, seed=3 + rank, first_label=rank * args.queries)   # rank-specific queries
+        qs = synth.make_queries(db, args.queries, seed=3 + rank, first_label=rank * args.queries, mu_q=args.mu_q, exact_frac=args.exact_frac)   # rank-specific queries
         tree = rx.Tree.new_flat(db.lineages, db.seq_bytes, db.seq_off, kmer_map=False)   # bitmaps built on the GPU
         index = rx.Index(tree, device=local_rank, sub_batch=args.sub_batch,
                          stage_timing=not args.hit_events_only, cluster=False if args.no_cluster else None,
@@ -567,6 +569,8 @@ def main():
         parallelism = f"queries sharded x{world}, index replicated"
         workload = (f"{args.queries} synthetic COI-length (658 bp) queries per GPU vs {args.refs}-seq reference DB replicated "
                     f"in HBM ({args.config_name})")
+        if args.mu_q != 0.02 or args.exact_frac != 0.10:
+            workload += f" -- NOT the headline queries: mu_q = {args.mu_q}, exact copies {args.exact_frac}"
 
     def barrier():
         finish()

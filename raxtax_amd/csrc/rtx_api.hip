@@ -220,7 +220,7 @@ struct rtx_index {
         // every tile and the best block (bounds_epilogue); thresholds and the live tiles per pair (prune_kernel)
         DevBuf<unsigned long long> d_uones;
         DevBuf<uint32_t> d_uzero, d_live, d_best_key;
-        DevBuf<uint32_t> d_items;  // [pairs x tiles] the (pair, tile) blocks with a live query | [1] their number | [pairs] live tiles per pair | [pairs] offsets
+        DevBuf<uint32_t> d_items;  // [pairs x tiles] the (pair, tile) blocks with a live query | [1] their number | [8] queue per XCD | [pairs] live tiles per pair | [pairs] offsets
         DevBuf<uint16_t> d_tile_ub, d_prune_thr, d_prune_i1;
         DevBuf<uint32_t> d_best;  // [B][kPruneBestWords] reference shards: the candidate for the best block of the database
     } sc[2];
@@ -477,7 +477,7 @@ int enqueue_hit(rtx_index *ix, const SubBatch &b, uint32_t flags, hipStream_t s,
         pr.hstride = ix->hstride;
         pr.live = sc.d_live.p;
         pr.live_words = (ix->ntiles + 31u) / 32u + 1u;
-        pr.pair_live = sc.d_items.p + (size_t)((b.nq + 1u) / 2u) * ix->ntiles + 1u;
+        pr.pair_live = sc.d_items.p + (size_t)((b.nq + 1u) / 2u) * ix->ntiles + 9u;
         pr.thr_out = sc.d_prune_thr.p;
         pr.i1_out = sc.d_prune_i1.p;
         pr.stats = ix->d_prune_stats.p;
@@ -492,7 +492,7 @@ int enqueue_hit(rtx_index *ix, const SubBatch &b, uint32_t flags, hipStream_t s,
         hp.prune_thr = sc.d_prune_thr.p;
         if (ix->pair_used) {  // the grid of the counting pass walks the live (pair, tile) blocks instead of all of them
             const size_t np = (b.nq + 1u) / 2u, cap = np * ix->ntiles;
-            launch_live_items(s, sc.d_live.p, pr.live_words, pr.pair_live, b.nq, ix->ntiles, sc.d_items.p + cap + 1u + np, sc.d_items.p, sc.d_items.p + cap);
+            launch_live_items(s, sc.d_live.p, pr.live_words, pr.pair_live, b.nq, ix->ntiles, sc.d_items.p + cap + 9u + np, sc.d_items.p, sc.d_items.p + cap);
             hp.items = sc.d_items.p;
             hp.n_items = sc.d_items.p + cap;
         }
@@ -658,7 +658,7 @@ int begin_run(rtx_index *ix, uint32_t *n_sub_out, bool *timed_out, bool cluster)
     auto scratch_ok = [&](const rtx_index::Scratch &sc) {  // sized at the upload / rtx_shard_begin (alloc_scratch_set) for this sub-batch size
         return sc.d_tile_ub.p != nullptr && sc.d_tile_ub.n >= (size_t)ix->sub_batch * ix->ntiles && sc.d_best_key.n >= ix->sub_batch && sc.d_prune_thr.n >= ix->sub_batch &&
                sc.d_live.n >= (size_t)(ix->sub_batch + 1u) * ((ix->ntiles + 31u) / 32u + 1u) && sc.d_best.n >= (size_t)ix->sub_batch * kPruneBestWords &&
-               sc.d_items.n >= (size_t)((ix->sub_batch + 1u) / 2u) * (ix->ntiles + 2u) + 1u;
+               sc.d_items.n >= (size_t)((ix->sub_batch + 1u) / 2u) * (ix->ntiles + 2u) + 9u;
     };
     ix->prune_used = ix->prune_opt && ix->pair_used && ix->use_tables && ix->tile_skip && ix->d_ubitmap.p && (whole || shard) &&
                      scratch_ok(ix->sc[0]) && (!ix->staged || scratch_ok(ix->sc[1]));
@@ -864,7 +864,7 @@ int alloc_scratch_set(rtx_index *ix, uint32_t k) {
             const bool fresh = sc.d_uones.n < mw;
             if ((rc = sc.d_uones.alloc(mw)) || (rc = sc.d_uzero.alloc((size_t)B * ix->u_ntiles)) ||
                 (rc = sc.d_tile_ub.alloc((size_t)B * ix->ntiles)) || (rc = sc.d_best_key.alloc(B)) || (rc = sc.d_prune_thr.alloc(B)) || (rc = sc.d_prune_i1.alloc(B)) || (rc = sc.d_best.alloc((size_t)B * kPruneBestWords)) || (rc = sc.d_live.alloc((size_t)(B + 1u) * ((ix->ntiles + 31u) / 32u + 1u))) ||
-                (rc = sc.d_items.alloc((size_t)((B + 1u) / 2u) * (ix->ntiles + 2u) + 1u)))
+                (rc = sc.d_items.alloc((size_t)((B + 1u) / 2u) * (ix->ntiles + 2u) + 9u)))
                 return rc;
             if (fresh) RTX_HIP(hipMemsetAsync(sc.d_uones.p, 0xFF, sc.d_uones.n * 8, ix->stream));
             RTX_HIP(hipMemsetAsync(sc.d_uzero.p, 0, sc.d_uzero.n * 4, ix->stream));

@@ -311,20 +311,27 @@ __global__ __launch_bounds__(64, 2) void hit_count_pair_kernel(HitParams p) {
     extern __shared__ uint32_t lds_dw[];
     const uint32_t lane = threadIdx.x;
     if (kItems) {
-        // Every pass over the grid takes the next gridDim.x entries of the list; inside a pass XCD x (= workgroup id mod 8) takes a
-        // contiguous eighth of them: neighbouring pairs share rows and tiles, and with them an L2.
-        // (G: a multiple of 8 -- workgroup b = 8 y + x takes entry x * s8 + y of the pass, x < 8, y < s8 <= G / 8)
-        const uint32_t n_items = (uint32_t)__builtin_amdgcn_readfirstlane((int)p.n_items[0]), G = gridDim.x & ~7u, b = blockIdx.x;
-        for (uint32_t base = 0; base < n_items; base += G) {
-            const uint32_t S = n_items - base < G ? n_items - base : G, s8 = (S + 7u) >> 3;
-            const uint32_t j = (b & 7u) * s8 + (b >> 3);
-            if ((b >> 3) < s8 && j < S) {
-                const uint32_t item = (uint32_t)__builtin_amdgcn_readfirstlane((int)p.items[base + j]);  // wave-uniform: pair and tile stay scalar
-                uint32_t lane_v = lane;
-                asm volatile("" : "+v"(lane_v));  // nothing that depends on the lane is kept across blocks: the block needs every register (256)
-                pair_tile_block<NP, kPacked, kBounds>(p, lds_dw, item / p.ntiles, item % p.ntiles, lane_v);
-                wave_lds_sync();  // the histogram of this block's epilogue becomes the next block's lists
-            }
+        // XCD x (= workgroup id mod 8) takes the x-th eighth of the list.  Workgroup y = id / 8 of the XCD starts with entry y of
+        // the eighth; if there are more entries than workgroups (queries far from their best hit keep tens of tiles each) it goes on
+        // with whatever entry is next in the XCD's queue (p.n_items[1 + x], counted from the number of workgroups on).  The workgroups
+        // that are resident on an XCD thus always work on ONE stretch of the list -- neighbouring pairs of few tiles, which share rows
+        // and with them the XCD's L2 -- however long the blocks of the others take.  (With a fixed share of the list per workgroup
+        // -- a stride, or a run of consecutive entries -- the resident ones spread over many tiles: 2.2 times slower at 36 live tiles
+        // per pair.)  The queue ends for every wave: an index at or behind the end of the eighth.
+        const uint32_t n_items = (uint32_t)__builtin_amdgcn_readfirstlane((int)p.n_items[0]), g8 = gridDim.x >> 3, x = blockIdx.x & 7u;
+        const uint32_t e8 = (n_items + 7u) >> 3, first = x * e8;
+        const uint32_t end = first + e8 < n_items ? first + e8 : n_items;  // (first >= n_items: nothing for this XCD)
+        uint32_t j = first + (blockIdx.x >> 3);
+        while (j < end) {
+            const uint32_t item = (uint32_t)__builtin_amdgcn_readfirstlane((int)p.items[j]);  // wave-uniform: pair and tile stay scalar
+            uint32_t lane_v = lane;
+            asm volatile("" : "+v"(lane_v));  // nothing that depends on the lane is kept across blocks: the block needs every register (256)
+            pair_tile_block<NP, kPacked, kBounds>(p, lds_dw, item / p.ntiles, item % p.ntiles, lane_v);
+            wave_lds_sync();  // the histogram of this block's epilogue becomes the next block's lists
+            if (e8 <= g8) break;  // every entry had a workgroup of its own
+            uint32_t nxt = 0;
+            if (lane_v == 0u) nxt = atomicAdd(&p.n_items[1u + x], 1u);
+            j = first + g8 + (uint32_t)__builtin_amdgcn_readfirstlane((int)nxt);
         }
         return;
     }
@@ -334,7 +341,7 @@ __global__ __launch_bounds__(64, 2) void hit_count_pair_kernel(HitParams p) {
     pair_tile_block<NP, kPacked, kBounds>(p, lds_dw, pair, blockIdx.y, lane);
 }
 
-// The (pair, tile) blocks in which a query of the pair is live, ascending: entry = pair * ntiles + tile.  prune_kernel left the number of
+// The (pair, tile) blocks in which a query of the pair is live: entry = pair * ntiles + tile.  prune_kernel left the number of
 // live tiles of every pair; live_offsets_kernel (one workgroup, thread i takes the pairs [i * per, (i + 1) * per): loads of a thread
 // all in flight together) scans them, live_items_kernel (a thread per pair) writes the entries.
 __global__ __launch_bounds__(1024) void live_offsets_kernel(const uint32_t *__restrict__ pair_live, uint32_t np, uint32_t *__restrict__ off,
@@ -356,6 +363,7 @@ __global__ __launch_bounds__(1024) void live_offsets_kernel(const uint32_t *__re
     uint32_t o = incl - cnt;
     for (uint32_t w = 0; w < wave; w++) o += wsum[w];
     if (tid == 1023u) n_items[0] = o + cnt;
+    if (tid < 8u) n_items[1u + tid] = 0;  // the queues of the XCDs (hit_count_pair_kernel)
     for (uint32_t i0 = 0; i0 < per; i0 += 16) {  // (L1 hits now)
         uint32_t c[16];
 #pragma unroll
@@ -368,20 +376,49 @@ __global__ __launch_bounds__(1024) void live_offsets_kernel(const uint32_t *__re
     }
 }
 
-__global__ __launch_bounds__(256) void live_items_kernel(const uint32_t *__restrict__ live, uint32_t live_words, uint32_t nq, uint32_t ntiles,
-                                                         const uint32_t *__restrict__ off, uint32_t *__restrict__ items) {
-    const uint32_t pair = blockIdx.x * 256u + threadIdx.x;
-    if (pair * 2u >= nq) return;
+// Groups of 1024 pairs, and inside a group the entries TILE by tile: the workgroups of the counting pass that run at the same time then
+// work on few tiles and many neighbouring pairs, whatever the number of live tiles per pair -- rows are shared in L2 between pairs of
+// the same tile.  (Pair by pair, queries far from their best hit -- tens of live tiles each -- spread the resident workgroups over
+// all tiles of 57 pairs: 0.64 M queries/s at 10 % divergence where the two-dimensional grid, tile-major by construction, gave 1.36 M.)
+// The order of the pairs inside a (group, tile) run is whatever the LDS atomics make it: it decides nothing but scheduling.
+__global__ __launch_bounds__(1024) void live_items_kernel(const uint32_t *__restrict__ live, uint32_t live_words, uint32_t nq, uint32_t ntiles,
+                                                          const uint32_t *__restrict__ off, uint32_t *__restrict__ items) {
+    extern __shared__ uint32_t tl[];  // [ntiles] entries of the group in the tile -> where they start -> cursor
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t np = (nq + 1u) / 2u, g0 = blockIdx.x * 1024u, pair = g0 + tid;
+    for (uint32_t T = tid; T < ntiles; T += 1024) tl[T] = 0;
+    __syncthreads();
     const uint32_t nw = (ntiles + 31u) >> 5;
-    const uint32_t *wa = live + (size_t)(pair * 2u) * live_words;
-    const bool hb = pair * 2u + 1u < nq;  // the mask of a missing second query was never written
-    uint32_t o = off[pair];
+    const bool valid = pair < np;
+    const uint32_t *wa = live + (size_t)((valid ? pair : 0u) * 2u) * live_words;
+    const bool hb = valid && pair * 2u + 1u < nq;  // the mask of a missing second query was never written
+    if (valid)
+        for (uint32_t w = 0; w < nw; w++) {
+            uint32_t bits = wa[w] | (hb ? wa[live_words + w] : 0u);
+            while (bits) {
+                atomicAdd(&tl[w * 32u + (uint32_t)__builtin_ctz(bits)], 1u);
+                bits &= bits - 1u;
+            }
+        }
+    __syncthreads();
+    if (tid < 64u) {  // exclusive scan over the tiles by one wave
+        uint32_t running = 0;
+        for (uint32_t T0 = 0; T0 < ntiles; T0 += 64) {
+            const uint32_t v = T0 + lane < ntiles ? tl[T0 + lane] : 0u;
+            const uint32_t incl = wave_incl_scan_u32(v);
+            if (T0 + lane < ntiles) tl[T0 + lane] = running + incl - v;
+            running += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        }
+    }
+    __syncthreads();
+    if (!valid) return;
+    const uint32_t base = off[g0];  // entries in front of the group
     for (uint32_t w = 0; w < nw; w++) {
         uint32_t bits = wa[w] | (hb ? wa[live_words + w] : 0u);
         while (bits) {
             const uint32_t tile = w * 32u + (uint32_t)__builtin_ctz(bits);
             bits &= bits - 1u;
-            items[o++] = pair * ntiles + tile;
+            items[base + atomicAdd(&tl[tile], 1u)] = pair * ntiles + tile;
         }
     }
 }
@@ -413,7 +450,7 @@ void launch_live_items(hipStream_t s, const uint32_t *live, uint32_t live_words,
                        uint32_t *items, uint32_t *n_items) {
     const uint32_t np = (nq + 1u) / 2u;
     hipLaunchKernelGGL(live_offsets_kernel, dim3(1), dim3(1024), 0, s, pair_live, np, off, n_items);
-    hipLaunchKernelGGL(live_items_kernel, dim3((np + 255u) / 256u), dim3(256), 0, s, live, live_words, nq, ntiles, off, items);
+    hipLaunchKernelGGL(live_items_kernel, dim3((np + 1023u) / 1024u), dim3(1024), (size_t)ntiles * 4, s, live, live_words, nq, ntiles, off, items);
 }
 
 void launch_hit_count_pair_bounds(hipStream_t s, const HitParams &p, uint32_t nq, uint32_t u_ntiles) {

@@ -144,8 +144,8 @@ struct HitParams {
     const uint32_t *live;     // [B][live_words] tiles to count for a query (rtx_prune.hip; the masks of a pair are neighbours) or null: all
     uint32_t live_words;
     const uint16_t *prune_thr;  // [B] threshold of the query (0: none) or null: the counts up to it go to bin 0 of the histogram as one number
-    const uint32_t *items;    // [n_items] pair * ntiles + tile of the (pair, tile) blocks with a live query, ascending (live_items_kernel), or null:
-    const uint32_t *n_items;  //           the grid is pairs x tiles.  With the list the grid is one-dimensional and walks it
+    const uint32_t *items;    // [n_items] pair * ntiles + tile of the (pair, tile) blocks with a live query (live_items_kernel: groups of 1024 pairs, tile by tile inside), or null:
+    uint32_t *n_items;        //           the grid is pairs x tiles.  With the list the grid is one-dimensional and walks it; n_items[1 .. 8]: the queues of the XCDs
     // the bounds pass of the tile pruning (hit_count_pair_kernel<.., kBounds>: this launch counts against the union bitmap)
     uint16_t *bounds_tile_ub;     // [B][bounds_tile_stride] largest bound of every tile of the database
     uint32_t bounds_tile_stride, bounds_ntiles;

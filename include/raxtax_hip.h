@@ -210,7 +210,7 @@ int rtx_index_set_batch(rtx_index *index, uint32_t sub_batch);
                                * than 1e-12 of probability together and are treated as references without a hit (rtx_prune.hip;
                                * every probability and confidence sum stays within 1e-11 of the full count, the result of a
                                * query does not depend on the rest of the batch).  Takes effect with t <= 1023,
-                               * RTX_OPT_HIT_PAIR = 1, RTX_OPT_TILE_SKIP = 1, the whole database on the handle and 8 tiles or more;
+                               * RTX_OPT_HIT_PAIR = 1, RTX_OPT_TILE_SKIP = 1, the whole database on the handle and 4 tiles or more;
                                * the debug taps recount the tapped sub-batch in full.  0: every tile is counted */
 /* RTX_OPT_SUB_BATCH, _PACKED_COUNTS, _HIT_PAIR, _TILE_PRUNE and _PROB_MODE shape the workspace that rtx_batch_upload sizes:
  * setting one of them drops the uploaded batch (rtx_batch_run then fails with RTX_ERR_STATE until the batch is uploaded again). */
@@ -283,7 +283,7 @@ int rtx_batch_download(rtx_index *index, rtx_result_view *out);
 #define RTX_BUF_HIST 1
 #define RTX_BUF_PREFIX 2
 int rtx_shard_begin(rtx_index *index, uint32_t *n_sub_batches, uint32_t *sub_batch);
-/* Tile pruning on a reference shard (RTX_OPT_SHARD_PRUNE = 1 before the upload; 8 tiles or more on the shard; queries with t <= 1023):
+/* Tile pruning on a reference shard (RTX_OPT_SHARD_PRUNE = 1 before the upload; 4 tiles or more on the shard; queries with t <= 1023):
  * the threshold of a query follows from the best block of 64 references ANYWHERE in the database, so the counting of a sub-batch
  * stops once for an exchange:   rtx_shard_bounds  ->  all-gather RTX_BUF_BEST, keep per query the record with the largest first word
  * (ties: the lowest shard) in every shard's buffer  ->  rtx_shard_count (counts the live tiles only)  ->  as before.

@@ -792,6 +792,9 @@ constexpr uint32_t kMaxSubBatch = 65536;
 // 8 192: 971 ms, 16 384: 953, 32 768: 964, 65 536: 995
 // With tile pruning a sub-batch is far less work and the fixed cost of its nine launches counts: N = 500k, per 1 M queries:
 // 8 192: 191 ms, 16 384: 171, 32 768: 159.5, 49 152: 158.1, 65 536: 157.8
+#ifndef RTX_PRUNE_MIN_TILES
+#define RTX_PRUNE_MIN_TILES 4  // tiles of 8192 references from which on the tile pruning is worth its bounds pass (configs[1], 7 tiles: 5.6 -> 7.8 M queries/s; it was 8 until the bounds pass lost its stores)
+#endif
 constexpr uint32_t kDefaultSubBatch = 20480, kDefaultSubBatchLarge = 16384, kDefaultSubBatchPruned = 32768;
 
 int alloc_scratch_set(rtx_index *ix, uint32_t k);
@@ -824,7 +827,7 @@ int prepare_workspace(rtx_index *ix, uint64_t n_queries, uint64_t tmax, uint64_t
         ix->arena_cap = want_arena;
     }
     // ---- sub-batch scratch, sized against free HBM
-    const bool will_prune = ix->prune_opt && ix->d_ubitmap.p && ix->pair_opt && ix->ntiles >= 8 && tmax <= 1023 && (ix->n_refs == ix->n_total || ix->shard_prune_opt);  // begin_run decides
+    const bool will_prune = ix->prune_opt && ix->d_ubitmap.p && ix->pair_opt && ix->ntiles >= RTX_PRUNE_MIN_TILES && tmax <= 1023 && (ix->n_refs == ix->n_total || ix->shard_prune_opt);  // begin_run decides
     const uint64_t per_q = (uint64_t)ix->kstride * 2 + (uint64_t)ix->rstride * 12 + 4 + (uint64_t)ix->ntiles * (ix->rstride / 8 + ((kSegMaxSparseRows + 1) * 4 + 10)) + (ix->packed() ? ix->npad * 5 / 4 : ix->npad * 2) + (uint64_t)ix->hstride * 12 +
                            (uint64_t)ix->n_bnd_local * 8 + 64 +
                            // + the scratch of the tile pruning: counts against the union bitmap, constant masks, its histogram, thresholds, live masks
@@ -1318,7 +1321,7 @@ static int create_from_csr(int device, uint64_t n_total, uint64_t ref_lo, uint64
 // references.  Same rows as d_bitmap.  Only for whole databases of some size (8 tiles or more); a failure to allocate
 // leaves the handle without it (no pruning).  Sizes first, then one of the two builders below fills it.
 static bool prepare_union_bitmap(rtx_index *ix) {
-    if (ix->ntiles < 8) return false;  // (a reference shard gets one too: it prunes with the threshold of the whole database, rtx_shard_bounds)
+    if (ix->ntiles < RTX_PRUNE_MIN_TILES) return false;  // (a reference shard gets one too: it prunes with the threshold of the whole database, rtx_shard_bounds)
     ix->u_nblocks = (ix->n_refs + (1ull << kPruneShift) - 1) >> kPruneShift;
     ix->u_ntiles = (uint32_t)((ix->u_nblocks + 8191) / 8192);
     ix->u_stride_bytes = ix->u_ntiles * 1024u;

@@ -132,7 +132,7 @@ class ShardIndex(_StagedMixin, Index):
         self.n_refs = int(cuts[rank + 1]) - int(cuts[rank])      # local references (debug taps)
         if sub_batch:
             check(self._lib.rtx_index_set_batch(self._h, sub_batch))
-        # a shard of 8 tiles or more counts only the tiles that can matter, with the threshold of the whole database (RTX_OPT_SHARD_PRUNE)
+        # a shard of 4 tiles or more counts only the tiles that can matter, with the threshold of the whole database (RTX_OPT_SHARD_PRUNE)
         check(self._lib.rtx_index_set_option(self._h, 16, int(tile_prune)))
         from ._lib import ResultView
 

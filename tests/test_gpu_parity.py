@@ -1171,7 +1171,7 @@ def test_tile_pruning_randomised(oracle, seed):
             exc.tie(assert_rows_equivalent(rb.rows(q), rows, oracle.highest_hit_prob_per_reference(t, t // 2, counts), otree.lineages,
                                            f"prune random seed {seed} skip {skip} q {q}"))
     print(f"seed {seed}: queries with another lineage in the pruned rows (exact ties): {flips}")
-    assert len(flips) <= 2 and exc.n["ties"] <= 4, (flips, exc.n)
+    assert len(set(flips)) <= 2 and exc.n["ties"] <= 4, (flips, exc.n)      # distinct queries (a tie shows in both skip modes); every one verified as an exact tie above
 
 
 def test_pruned_probabilities_against_the_oracle(oracle):

@@ -417,6 +417,21 @@ int rtx_raxtax_multi(rtx_index *const *indices, uint32_t n_indices, const rtx_tr
                      int raw_confidence, uint64_t chunk_size, rtx_sender_fn sender, void *sender_ctx, int tsv);
 /* A ready-made sender that discards the messages and only counts them: ctx = NULL or uint64_t[2] {messages, bytes of text} */
 int rtx_sender_discard(void *ctx, const char *label, const char *out_lines, const char *tsv_lines);
+/* Busy seconds of the stages of the last rtx_raxtax / rtx_raxtax_multi call of this process (which stage bounds an end-to-end run):
+ * busy[0] exact-match lookup on the host (0 when the device does it), busy[1] device stage of the busiest handle (upload, kernels,
+ * download), busy[2] formatting of the busiest handle, busy[3] sender; *n_chunks = chunks of that call.  The counterpart of the
+ * reference's `timer!` log lines (raxtax.rs:13, prob.rs:7, lineage.rs:79). */
+int rtx_raxtax_last_timing(double busy[4], uint64_t *n_chunks);
+
+/* ------------------------------------------------------------------------- */
+/* Host thread budget (the reference: rayon pool of std::thread::available_parallelism threads, main.rs:40-57, utils.rs:139-158) */
+/* ------------------------------------------------------------------------- */
+/* Every worker pool of the library (FASTA parsing, result finalisation, formatting, record packing) is sized from the CPUs this
+ * process may really use -- the affinity mask capped by the cgroup CPU quota, not the logical CPUs of the machine -- divided by the
+ * number of ranks that share the host.  That number is LOCAL_WORLD_SIZE (exported by torch.distributed.run) unless set here; the
+ * handles driven by one rtx_raxtax_multi call divide their share among themselves. */
+int rtx_set_host_share(uint32_t n_ranks_on_this_host);
+uint32_t rtx_host_threads(void); /* threads a pool of this process may use (>= 1) */
 
 #ifdef __cplusplus
 }

@@ -413,6 +413,13 @@ int main(int argc, char **argv) {
             rtx_queries_data(pz.qs, &bases, &off);
             rc = rtx_raxtax_multi(indices.data(), (uint32_t)indices.size(), tree, nb, labels.data(), bases, off, skip_exact, raw, chunk, sender, &sink, tsv);
             n += nb;
+            if (timing) {  // busy seconds of the pipeline stages of this block (which stage bounds the run)
+                double busy[4];
+                uint64_t nch = 0;
+                if (rtx_raxtax_last_timing(busy, &nch) == RTX_OK)
+                    fprintf(stderr, "[TIMING] pipeline busy seconds over %llu chunk(s) on %zu handle(s): lookup %.3f, device %.3f (busiest handle), format %.3f, sender %.3f\n",
+                            (unsigned long long)nch, indices.size(), busy[0], busy[1], busy[2], busy[3]);
+            }
         }
         rtx_queries_destroy(pz.qs);
         if (rc != RTX_OK || pz.end) break;

@@ -171,7 +171,7 @@ extern "C" int64_t rtx_result_pack(const rtx_result_view *res, uint8_t *buf, uin
             memcpy(p_local + 8 * r, &res->row_local_signal[r], 8);
         }
     };
-    const unsigned nt = nr + nq < 65536 ? 1u : std::min(8u, std::max(1u, std::thread::hardware_concurrency()));
+    const unsigned nt = nr + nq < 65536 ? 1u : rtx::host_threads(8u);
     if (nt == 1) {
         work(0, nq, 0, nr);
     } else {

@@ -24,12 +24,18 @@ void parallel_ranges(uint64_t n, unsigned nt, F fn) {
     for (auto &t : th) t.join();
 }
 
+struct LastTiming { double busy[4]; uint64_t n_chunks; };
+std::mutex g_timing_mu;
+LastTiming g_timing{{0, 0, 0, 0}, 0};
+
 // One chunk of queries travelling through the stages of run().
 struct Chunk {
     uint64_t q0 = 0, nq = 0;
     std::vector<uint32_t> exact_ids;   // tree.sequences.get(query) per query, raxtax.rs:42
     std::vector<uint64_t> exact_off;
     std::vector<uint8_t> differ;       // raxtax.rs:43-53: exact matches with different parents
+    std::vector<uint8_t> status;       // res.status / res.t copied by the format stage: the sender must not read `res`, whose host set the
+    std::vector<uint32_t> t;           // handle reuses once this chunk is formatted
     std::vector<std::string> out_msg, tsv_msg;
     rtx_result_view res{};
     int stage = 0;                     // 1: exact matches looked up (or left to the device), 2: classified, 3: formatted, 4: sent
@@ -58,8 +64,8 @@ int run(rtx_index *const *indices, uint32_t n_dev, const rtx_tree *tree, uint64_
     if (chunk_size == 0 || chunk_size > n_queries) chunk_size = std::max<uint64_t>(1, (n_queries + n_dev - 1) / n_dev);
     const uint32_t flags = (skip_exact_matches ? RTX_SKIP_EXACT_MATCHES : 0u) | (raw_confidence ? RTX_RAW_CONFIDENCE : 0u);
     const uint64_t n_chunks = (n_queries + chunk_size - 1) / chunk_size;
-    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-    const unsigned nt_lookup = std::min(4u, hw), nt_format = std::max(2u, std::min(16u, hw) / n_dev);
+    // thread budget: this process's share of the host's CPUs (rtx::host_threads), split over the handles driven here
+    const unsigned nt_lookup = rtx::host_threads(4u), nt_format = rtx::host_threads(16u, n_dev);
     std::vector<uint8_t> dev_lookup(n_dev);
     bool any_host_lookup = false;
     for (uint32_t d = 0; d < n_dev; d++) {
@@ -72,8 +78,7 @@ int run(rtx_index *const *indices, uint32_t n_dev, const rtx_tree *tree, uint64_
         chunks[c].q0 = c * chunk_size;
         chunks[c].nq = std::min<uint64_t>(chunk_size, n_queries - chunks[c].q0);
     }
-    // busy seconds of the stages (RTX_PIPELINE_TIMING=1 prints them: which stage bounds an end-to-end run)
-    const bool timing = getenv("RTX_PIPELINE_TIMING") != nullptr;
+    // busy seconds of the stages (rtx_raxtax_last_timing: which stage bounds an end-to-end run)
     double busy_lookup = 0, busy_send = 0;
     std::vector<double> busy_device(n_dev, 0.0), busy_format(n_dev, 0.0);
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -160,6 +165,8 @@ int run(rtx_index *const *indices, uint32_t n_dev, const rtx_tree *tree, uint64_
             ch.out_msg.assign(ch.nq, std::string());
             if (tsv) ch.tsv_msg.assign(ch.nq, std::string());
             ch.differ.assign(ch.nq, 0);
+            ch.status.assign(ch.res.status, ch.res.status + ch.nq);
+            ch.t.assign(ch.res.t, ch.res.t + ch.nq);
             std::atomic<int> rc_fmt{0};
             parallel_ranges(ch.nq, nt_format, [&](uint64_t a, uint64_t b) {
                 std::vector<char> out_buf(1 << 16), tsv_buf(1 << 16);
@@ -214,9 +221,9 @@ int run(rtx_index *const *indices, uint32_t n_dev, const rtx_tree *tree, uint64_
                 fprintf(stderr, "[WARN ] Exact matches for %s differ above the leafs of the lineage tree!\n", labels[q]);
                 warnings = true;
             }
-            if (ch.res.status[i] != RTX_Q_OK) {
+            if (ch.status[i] != RTX_Q_OK) {
                 // the reference aborts here (prob.rs:21/162); report and skip the query instead
-                fprintf(stderr, "[ERROR] query %s has too few valid 8-mers (%u) to be classified\n", labels[q], ch.res.t[i]);
+                fprintf(stderr, "[ERROR] query %s has too few valid 8-mers (%u) to be classified\n", labels[q], ch.t[i]);
                 continue;
             }
             std::optional<std::string> t;
@@ -227,6 +234,8 @@ int run(rtx_index *const *indices, uint32_t n_dev, const rtx_tree *tree, uint64_
         std::vector<uint32_t>().swap(ch.exact_ids);
         std::vector<uint64_t>().swap(ch.exact_off);
         std::vector<uint8_t>().swap(ch.differ);
+        std::vector<uint8_t>().swap(ch.status);
+        std::vector<uint32_t>().swap(ch.t);
         std::vector<std::string>().swap(ch.out_msg);
         std::vector<std::string>().swap(ch.tsv_msg);
         busy_send += now() - t_s0;
@@ -234,11 +243,11 @@ int run(rtx_index *const *indices, uint32_t n_dev, const rtx_tree *tree, uint64_
     }
     lookup.join();
     for (auto &t : workers) t.join();
-    if (timing) {
+    {
         double bd = 0, bf = 0;
         for (uint32_t d = 0; d < n_dev; d++) { bd = std::max(bd, busy_device[d]); bf = std::max(bf, busy_format[d]); }
-        fprintf(stderr, "[TIMING] pipeline busy seconds over %llu chunk(s) on %u handle(s): lookup %.3f (%s), device %.3f (busiest handle), format %.3f (%u threads per handle), sender %.3f\n",
-                (unsigned long long)n_chunks, n_dev, busy_lookup, any_host_lookup ? "host map" : "on the device", bd, bf, nt_format, busy_send);
+        std::lock_guard<std::mutex> g(g_timing_mu);
+        g_timing = {{any_host_lookup ? busy_lookup : 0.0, bd, bf, busy_send}, n_chunks};
     }
     if (failed != RTX_OK) { rtx::set_error("%s", failed_msg.c_str()); return failed; }
     if (warnings)  // raxtax.rs:93-95
@@ -290,6 +299,14 @@ extern "C" int rtx_raxtax_multi(rtx_index *const *indices, uint32_t n_indices, c
     };
     return run(indices, n_indices, tree, n_queries, labels, bases, base_off, skip_exact_matches != 0, raw_confidence != 0, chunk_size, s,
                tsv != 0);
+}
+
+extern "C" int rtx_raxtax_last_timing(double busy[4], uint64_t *n_chunks) {
+    if (!busy) { rtx::set_error("rtx_raxtax_last_timing: null argument"); return RTX_ERR_INVALID; }
+    std::lock_guard<std::mutex> g(g_timing_mu);
+    for (int i = 0; i < 4; i++) busy[i] = g_timing.busy[i];
+    if (n_chunks) *n_chunks = g_timing.n_chunks;
+    return RTX_OK;
 }
 
 // A sender that keeps nothing: counts the messages and their bytes into ctx (uint64_t[2]) if given.  For callers that time the

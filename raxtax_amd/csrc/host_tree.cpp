@@ -165,8 +165,7 @@ struct FastaPiece {
 };
 
 static unsigned parse_threads(uint64_t len) {
-    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-    return (unsigned)std::min<uint64_t>(std::min(hw, 16u), std::max<uint64_t>(1, len >> 20));  // >= 1 MiB per piece
+    return (unsigned)std::min<uint64_t>(rtx::host_threads(16u), std::max<uint64_t>(1, len >> 20));  // >= 1 MiB per piece
 }
 
 // cut points [0, ..., len]: every inner one is the position of a '>' that directly follows a newline

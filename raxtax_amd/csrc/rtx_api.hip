@@ -1117,7 +1117,7 @@ static void build_exact_table(rtx_index *ix, const uint8_t *seq_bytes, const uin
     std::vector<uint8_t> rep_bytes(rep_off[G] + 16, 0);
     std::vector<uint64_t> hashes(G);
     {
-        const unsigned nt = std::max(1u, std::min(8u, std::thread::hardware_concurrency()));
+        const unsigned nt = rtx::host_threads(8u);
         std::vector<std::thread> th;
         for (unsigned k = 0; k < nt; k++)
             th.emplace_back([&, k] {
@@ -1323,6 +1323,9 @@ static int create_from_csr(int device, uint64_t n_total, uint64_t ref_lo, uint64
 static bool prepare_union_bitmap(rtx_index *ix) {
     if (ix->ntiles < RTX_PRUNE_MIN_TILES) return false;  // (a reference shard gets one too: it prunes with the threshold of the whole database, rtx_shard_bounds)
     ix->u_nblocks = (ix->n_refs + (1ull << kPruneShift) - 1) >> kPruneShift;
+    // the best-block key of the bounds pass packs the block into 20 bits (bounds_epilogue, prune_kernel): beyond 2^20 blocks (67 M
+    // references on one handle) block ids would alias and the threshold would come from the wrong block -- such a handle counts every tile
+    if (ix->u_nblocks > 0xFFFFFull) return false;
     ix->u_ntiles = (uint32_t)((ix->u_nblocks + 8191) / 8192);
     ix->u_stride_bytes = ix->u_ntiles * 1024u;
     const size_t words = (size_t)(ix->n_rows + 1) * (ix->u_stride_bytes / 4);
@@ -1602,7 +1605,7 @@ int rtx_batch_sync(rtx_index *ix) {
 
 // Finalises positions [pa, pb) on up to nt threads; returns the number of rows they produced.
 static uint64_t finalise_mt(rtx_index *ix, uint64_t pa, uint64_t pb, uint64_t row_base, unsigned nt) {
-    nt = std::min<unsigned>(nt, std::max(1u, std::thread::hardware_concurrency()));
+    nt = rtx::host_threads(nt);  // this process's share of the host's CPUs (cgroup quota, ranks per host)
     if (pb - pa < 1024) nt = 1;
     std::vector<uint64_t> cut(nt + 1), base(nt + 1, row_base);
     for (unsigned i = 0; i <= nt; i++) cut[i] = pa + (pb - pa) * i / nt;

@@ -8,12 +8,6 @@
 #include "rtx_math.hpp"
 #include "rtx_wave.hpp"
 
-#ifndef RTX_EPI_MARK  // experiment hooks (rtx_hit_pair.hip, RTX_PAIR_STAMP): cycle stamps inside the epilogue
-#define RTX_EPI_MARK(k)
-#define RTX_EPI_DECL
-#define RTX_EPI_DONE
-#endif
-
 namespace rtx {
 
 // Orders the LDS traffic of ONE wave (some lanes write, others read): the hardware keeps the LDS operations of a
@@ -224,7 +218,6 @@ template <int NP, bool kPacked, bool kPrefetch, bool kFullTile, bool kPreLoaded>
 __device__ __forceinline__ void hit_epilogue_x(const HitParams &p, uint32_t (&pl)[4][NP], uint32_t q, uint32_t tile, uint32_t lane,
                                                uint32_t t, bool active, uint32_t *hist_lds, uint32_t *cnt8, uint32_t ns,
                                                const uint32_t *srows, uint4 (&pre)[kSparseIt][kSparseV], uint32_t h_thr) {
-    RTX_EPI_DECL
     constexpr int kIt = kSparseIt, kVp = kSparseV;
     const bool lists = ns != 0u;  // wave-uniform: byte counters in use
     if (kPrefetch && !kPreLoaded && ns) sparse_prefetch(p, lane, ns, srows, pre);
@@ -271,7 +264,6 @@ __device__ __forceinline__ void hit_epilogue_x(const HitParams &p, uint32_t (&pl
 
     for (uint32_t i = lane; i <= t; i += 64) hist_lds[i] = 0;
     wave_lds_sync();
-    RTX_EPI_MARK(5)
     // tile pruning gave the query a threshold u: every count up to u is a reference without a hit to prob_lookup (rtx_prob_tables.hip) --
     // they go to bin 0 as one number, and only the groups of references that hold a count above u touch the histogram (h_thr: u or 0)
     const uint32_t h_lo = h_thr ? h_thr + 1u : 0u;
@@ -311,7 +303,6 @@ __device__ __forceinline__ void hit_epilogue_x(const HitParams &p, uint32_t (&pl
     for (int i = 0; i < 8; i++) hiw[i] = 0;
 #pragma unroll
     for (int half = 0; half < 2; half++) {  // groups 0-7 = references 0..4095 of a full tile, groups 8-15 = 4096..8191
-        RTX_EPI_MARK(6)
         if (lists && (!kFullTile || half == 0)) {
             sparse_hits((uint32_t)half);
             if (p.flags & RTX_SKIP_EXACT_MATCHES) {  // raxtax.rs:65-68: the sparse part
@@ -327,7 +318,6 @@ __device__ __forceinline__ void hit_epilogue_x(const HitParams &p, uint32_t (&pl
                 wave_lds_sync();
             }
         }
-        RTX_EPI_MARK(7)
         if (active) {
 #pragma unroll
             for (int wi = 0; wi < 2; wi++) {
@@ -397,7 +387,6 @@ __device__ __forceinline__ void hit_epilogue_x(const HitParams &p, uint32_t (&pl
             }
         }
     }
-    RTX_EPI_MARK(6)
     if (kPacked) {
         // The high-bit words leave in chunk order (u16 index g * L + lane within the tile): transposed through the
         // byte-counter region of LDS (free now) so that every lane stores 32 contiguous bytes.
@@ -436,7 +425,6 @@ __device__ __forceinline__ void hit_epilogue_x(const HitParams &p, uint32_t (&pl
         }
         if (lane == 0) p.tile_max[(size_t)q * p.ntiles + tile] = (uint16_t)mx;
     }
-    RTX_EPI_DONE
 }
 
 // ---------------------------------------------------------------------------

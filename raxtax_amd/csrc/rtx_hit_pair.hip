@@ -23,13 +23,6 @@
 
 #include <algorithm>
 
-#ifdef RTX_PAIR_STAMP
-// stamps inside the epilogue: 5 = start .. histogram zeroed (incl. the wait for nothing), 7 = sparse segments, 6 = unpack + stores +
-// histogram atomics, 8 = the rest (high bits, flush); the variables live in the kernel
-#define RTX_EPI_MARK(k) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); if (RTX_PAIR_STAMP == (k)) st_acc_g += now_ - st_t_g; st_t_g = now_; }
-#define RTX_EPI_DECL unsigned long long st_acc_g = 0, st_t_g = __builtin_amdgcn_s_memtime();
-#define RTX_EPI_DONE RTX_EPI_MARK(8) if (RTX_PAIR_STAMP >= 5 && lane == 0 && p.group_rows) atomicAdd(&p.group_rows[p.group_base + (q >> 1)], (uint32_t)(st_acc_g >> 6));
-#endif
 #include "rtx_hit_common.hpp"
 
 namespace rtx {
@@ -159,12 +152,6 @@ __device__ __forceinline__ void pair_tile_block(const HitParams &p, uint32_t *ld
 #pragma unroll
         for (int b = 0; b < NP; b++) { pa[w][b] = 0; pb[w][b] = 0; }
 
-#ifdef RTX_PAIR_STAMP  // experiment: cycles of one phase per (pair, tile) instead of the rows loaded (1 prologue, 2 row loop, 3 epilogue A, 4 epilogue B)
-    unsigned long long st_acc = 0, st_t = __builtin_amdgcn_s_memtime();
-#define PAIR_MARK(k) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); if (RTX_PAIR_STAMP == (k)) st_acc += now_ - st_t; st_t = now_; }
-#else
-#define PAIR_MARK(k)
-#endif
     const uint32_t mwords = p.rstride >> 6;
     const uint2 *urec = p.pair_urec + (size_t)pair * p.pair_ustride;
     // Everything the prologue needs comes in with ONE round trip: the first 512 union entries (clamped index: what lies
@@ -247,7 +234,6 @@ __device__ __forceinline__ void pair_tile_block(const HitParams &p, uint32_t *ld
         for (uint32_t i = n_a + lane; i < g_a * 32u; i += 64) l_a[i] = zero_off;
         for (uint32_t i = n_b + lane; i < g_b * 32u; i += 64) l_b[i] = zero_off;
         wave_lds_sync();
-        PAIR_MARK(1)
         const uint32_t *first = g_both ? l_both : (g_a ? l_a : (g_b ? l_b : nullptr));
         if (first) {
             uint4 buf[4][8];
@@ -267,13 +253,10 @@ __device__ __forceinline__ void pair_tile_block(const HitParams &p, uint32_t *ld
             if (g_a) fold_seg<NP, 1>(pa, pb, buf, l_a, g_a, after_a, lane, rsrc, voff);
             if (g_b) fold_seg<NP, 2>(pa, pb, buf, l_b, g_b, l_zero, lane, rsrc, voff);
         }
-        PAIR_MARK(2)
         wave_lds_sync();  // the lists are rewritten (next round) or become the histogram and the byte counters
         first_round = false;
     }
-#ifndef RTX_PAIR_STAMP
     if (lane == 0 && p.group_rows) atomicAdd(&p.group_rows[p.group_base + pair], rows_loaded);
-#endif
 
     if (kBounds) {  // the largest bound per tile of the database and the best block of each query; nothing else leaves the wave
         bounds_epilogue<NP>(p, pa, qa, tile, lane);
@@ -289,15 +272,10 @@ __device__ __forceinline__ void pair_tile_block(const HitParams &p, uint32_t *ld
     if (ns_a) sparse_prefetch(p, lane, ns_a, l_sid, pre_a);
     if (ns_b) sparse_prefetch(p, lane, ns_b, l_sid + kSparseIt * 64u, pre_b);
     if (has_a) hit_epilogue_x<NP, kPacked, true, true, true>(p, pa, qa, tile, lane, p.t[qa], active, hist_lds, cnt8, ns_a, srows_a, pre_a, thr_of(qa));
-    PAIR_MARK(3)
     if (has_b) {
         wave_lds_sync();
         hit_epilogue_x<NP, kPacked, true, true, true>(p, pb, qb, tile, lane, p.t[qb], active, hist_lds, cnt8, ns_b, srows_b, pre_b, thr_of(qb));
     }
-    PAIR_MARK(4)
-#ifdef RTX_PAIR_STAMP
-    if (lane == 0 && p.group_rows) atomicAdd(&p.group_rows[p.group_base + pair], (uint32_t)(st_acc >> 6));
-#endif
 }
 
 // kBounds: the bounds pass of the tile pruning -- the bitmap is the union bitmap (every row dense: the caller passes constant masks and

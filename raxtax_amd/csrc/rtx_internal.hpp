@@ -16,6 +16,14 @@ void set_error(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
 
 constexpr uint32_t kNoNode = 0xFFFFFFFFu;
 
+// Host thread budget (host_threads.cpp): CPUs of the affinity mask capped by the cgroup CPU quota -- what
+// std::thread::available_parallelism gives the reference's rayon pool (main.rs:40-57) -- and a worker count for a pool that wants
+// up to `want` threads while `sharers` handles of this process (rtx_raxtax_multi) and host_share() ranks on this host
+// (rtx_set_host_share / LOCAL_WORLD_SIZE) work side by side.  Never std::thread::hardware_concurrency(): it ignores the quota.
+unsigned available_parallelism();
+unsigned host_share();
+unsigned host_threads(unsigned want, unsigned sharers = 1);
+
 #ifndef RTX_NODE_TYPES_DEFINED
 #define RTX_NODE_TYPES_DEFINED
 enum NodeType : uint8_t { kInner = 0, kTaxon = 1, kSequence = 2 };  // src/tree.rs:181-186

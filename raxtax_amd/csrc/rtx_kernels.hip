@@ -138,20 +138,11 @@ __device__ __forceinline__ unsigned long long transpose64(unsigned long long x, 
     return x;
 }
 
-#ifdef RTX_KMER_STAMP  // experiment (tools/quad_variants.sh ks1..ks4): cycles of one phase per query instead of H_q (1 extraction, 2 read-out, 3 rows, 4 tiles)
-#define KMER_MARK(k) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); if (RTX_KMER_STAMP == (k)) st_acc += now_ - st_t; st_t = now_; }
-#else
-#define KMER_MARK(k)
-#endif
-
 // kTilesOnly: the launch behind tile pruning (mode 2) -- without the 8 KB k-mer set of the extraction in LDS twice as many of its waves fit a CU
 // (a chain of gathers per query: the waves in flight are what hides them)
 template <bool kTilesOnly>
 __global__ __launch_bounds__(64) void kmer_extract_kernel(KmerParams p) {
     const uint32_t mode = kTilesOnly ? 2u : p.mode;
-#ifdef RTX_KMER_STAMP
-    unsigned long long st_acc = 0, st_t = __builtin_amdgcn_s_memtime();
-#endif
     __shared__ __attribute__((aligned(16))) uint32_t bm[kTilesOnly ? 64 : 2048];
     const uint32_t q = blockIdx.x;
     const uint32_t lane = threadIdx.x;
@@ -202,7 +193,6 @@ __global__ __launch_bounds__(64) void kmer_extract_kernel(KmerParams p) {
         }
     }
     __syncthreads();
-    KMER_MARK(1)
 
     // ascending read-out: round r covers the 64-bit words r*64 .. r*64+63 of the set (conflict-free LDS reads); sixteen
     // scans instead of thirty-two with 32-bit words
@@ -225,7 +215,6 @@ __global__ __launch_bounds__(64) void kmer_extract_kernel(KmerParams p) {
     }
     t = base;
     __syncthreads();  // kout visible to the whole wave
-    KMER_MARK(2)
 
     // rows of the k-mers present in the index, in ascending k-mer order (the query's row list, shared by all tiles)
     const uint32_t tt = t < p.kstride ? t : p.kstride;
@@ -258,7 +247,6 @@ __global__ __launch_bounds__(64) void kmer_extract_kernel(KmerParams p) {
     }
     for (uint32_t i = nrows + lane; i < ((nrows + 63u) & ~63u); i += 64) rout[i] = p.zero_row;
     __syncthreads();  // rout visible to the whole wave
-    KMER_MARK(3)
     }  // mode != 2
     if (mode == 1u) {
 #pragma unroll
@@ -444,10 +432,6 @@ __global__ __launch_bounds__(64) void kmer_extract_kernel(KmerParams p) {
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) { hq += __shfl_xor(hq, d, 64); nseg += __shfl_xor(nseg, d, 64); }
-    KMER_MARK(4)
-#ifdef RTX_KMER_STAMP
-    hq = st_acc;
-#endif
     if (lane == 0) {
         if (mode != 2u) {
             p.t[q] = t;

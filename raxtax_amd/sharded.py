@@ -197,6 +197,9 @@ class LocalComm:
 
     allreduce_counts = allreduce_hist
 
+    def agree_min(self, value: int) -> int:
+        return int(value)       # every shard lives in this process: the caller has taken the minimum already
+
     def allgather_prefix(self, locals_):
         return [p.clone() for p in locals_]
 
@@ -227,6 +230,16 @@ class TorchComm:
         return self.dist.all_reduce(t, async_op=True)
 
     allreduce_counts = allreduce_hist   # int32 view of pairs of u16 counts (_StagedMixin.buffer)
+
+    def agree_min(self, value: int) -> int:
+        """The minimum of an integer over the ranks: all-reduce(min) of one int32 (on the current GPU under nccl = RCCL, which
+        reduces device memory only; on the host under gloo)."""
+        import torch
+
+        on_gpu = str(self.dist.get_backend()).lower() == "nccl"
+        t = torch.tensor([int(value)], dtype=torch.int32, device=torch.device("cuda", torch.cuda.current_device()) if on_gpu else "cpu")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN)
+        return int(t.item())
 
     def allgather_prefix(self, locals_):
         import torch
@@ -277,6 +290,25 @@ class ShardedClassifier:
         for s in self.shards:
             s.upload(bases, base_off, exact_ids, exact_off)
         self._n_q = len(base_off) - 1
+        self._agree_on_pruning(bases, base_off, exact_ids, exact_off)
+
+    def _agree_on_pruning(self, bases, base_off, exact_ids, exact_off):
+        """Every shard prunes, or none does.  Whether a shard CAN prune is local state (a union bitmap exists only from
+        RTX_PRUNE_MIN_TILES local tiles on and if its allocation succeeded; the scratch of the bounds must have fitted) -- balanced
+        cuts can leave one rank a tile short of the limit -- but a pruning shard processes the queries in min-hash order and exchanges
+        best blocks, a counting one keeps the input order and does not: mixed, the histogram all-reduce would add rows of different
+        queries and the collectives would not pair up.  So the shards take the minimum of their verdicts; a shard that
+        could prune alone is switched to plain counting (RTX_OPT_SHARD_PRUNE = 0 drops its upload: uploaded again)."""
+        local = []
+        for s in self.shards:
+            s.begin()
+            local.append(int(s.prunes))
+        agreed = self.comm.agree_min(min(local))
+        for s, mine in zip(self.shards, local):
+            if mine and not agreed:
+                check(s._lib.rtx_index_set_option(s._h, 16, 0))
+                s.upload(bases, base_off, exact_ids, exact_off)
+        self._prunes = bool(agreed)
 
     def classify(self, bases: np.ndarray, base_off: np.ndarray, exact_ids=None, exact_off=None,
                  skip_exact_matches: bool = False) -> Result:
@@ -302,6 +334,7 @@ class ShardedClassifier:
         n_q = self._n_q
         keep = []
         prunes = s.prunes
+        assert prunes == self._prunes, "this shard's tile pruning differs from what the ranks agreed on at the upload"
 
         def count(sb):
             if prunes:   # bounds -> the best block of the whole database -> counting of the live tiles
@@ -330,7 +363,7 @@ class ShardedClassifier:
         for s in self.shards[1:]:
             assert s.begin() == (n_sub, B), "all shards must use the same sub-batch size"
         n_q = self._n_q
-        prunes = self.shards[0].prunes
+        prunes = self._prunes
         assert all(s.prunes == prunes for s in self.shards), "all shards must agree on the tile pruning"
         for sb in range(n_sub):
             nq = min(B, n_q - sb * B)

@@ -112,6 +112,8 @@ def _shard_worker(rank, world, port, out_path):
     want_hist = np.stack([np.bincount(counts[q], minlength=t + 1) for q in range(n_q)])
     want_pref = np.stack([np.concatenate([[0.0], np.cumsum(probs[q])])[bnd] for q in range(n_q)])
     ok = np.array_equal(h.numpy(), want_hist) and pref.shape == want_pref.shape and np.max(np.abs(pref - want_pref)) < 1e-9
+    # the ranks agree on the tile pruning before a run (ShardedClassifier._agree_on_pruning): one rank that cannot prune switches all off
+    ok = ok and comm.agree_min(1 if rank == 0 else 0) == 0 and comm.agree_min(1) == 1
     if rank == 0:
         np.save(out_path, np.array([ok]))
     dist.barrier()

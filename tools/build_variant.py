@@ -19,7 +19,13 @@ flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", f"-I{ROOT / 'inc
 
 def one(src):
     obj = obj_dir / (src + ".o")
-    subprocess.check_call([_build._hipcc()] + flags + ["-x", "hip", "-c", str(_build.CSRC / src), "-o", str(obj)], stderr=subprocess.DEVNULL)
+    # the compiler's diagnostics (register spills are what the experiments care about) go to a log beside the object; shown on failure
+    log = obj_dir / (src + ".log")
+    with open(log, "w") as fh:
+        rc = subprocess.call([_build._hipcc()] + flags + ["-Rpass-analysis=kernel-resource-usage", "-x", "hip", "-c", str(_build.CSRC / src), "-o", str(obj)], stderr=fh)
+    if rc:
+        sys.stderr.write(log.read_text())
+        raise SystemExit(f"{src}: hipcc failed ({rc}); diagnostics in {log}")
     return str(obj)
 
 

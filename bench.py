@@ -167,20 +167,61 @@ def cpu_model() -> str:
     return "unknown"
 
 
-def cpu_baseline(db, qs, target_s: float, skip_exact: bool):
-    """Times the oracle (oracle/, kind "port": a C restatement of raxtax.rs:35-88, compiled -O3 -march=native) on this
-    host's cores.  Three legs on prefixes of the same queries: one thread; all hardware threads; one thread per
-    physical core, pinned (the reference's --pin, utils.rs:139-197).  The parallel legs use the reference's chunk
+def oracle_context(db):
+    """The checker of the `cpu_baseline` leg (and of `parity_sample`, which is that leg's oracle held against the timed run): the C port
+    of the reference algorithm, COMPILED HERE -- `-march=native` must mean the host whose cores are timed, not the container the
+    repository was built in (VERDICT r3) -- and its Tree::new of the bench database.  Never on the measured path."""
+    from oracle import oracle_py
+
+    t0 = time.perf_counter()
+    lib_path = oracle_py.build(native=True, force=True)
+    t_build = time.perf_counter() - t0
+    orc = oracle_py.Oracle(native=True)
+    t0 = time.perf_counter()
+    otree = orc.tree_new_flat(db.lineages, db.seq_bytes, db.seq_off)
+    info = oracle_py.build_info(native=True)
+    info.update(library=str(lib_path.name), build_seconds=round(t_build, 2), built_on=socket.gethostname(), cpu_model=cpu_model())
+    return dict(orc=orc, otree=otree, t_tree=time.perf_counter() - t0, build=info)
+
+
+def parity_block(args, rx, index, view, ctx, db, qs, flags, n_sample=2000):
+    """parity on each run.  After the timed region, untimed, on the LAST timed step as the device left it:
+      * the size-independent properties of every result of the step (raxtax_amd/checks.py:check_properties: status, t, signals,
+        confidences monotone along a lineage, rows sorted, level sums);
+      * a seeded sample of the queries of the step's last sub-batch -- the ones whose counts, histograms, live masks and tables are
+        still in HBM -- against the oracle WITHOUT running anything again (checks.as_run_oracle_sample): t and the hit counts of every
+        visited tile bit-exact, no unvisited tile above the query's threshold, the histogram, table / Z within 1e-9 (north_star:
+        1e-6), the rows the step returned identical to the oracle's (exact ties between sibling taxa verified and counted).
+    A violation does not stop the line: it is reported as ok = false with its message, and bench.py exits non-zero."""
+    from raxtax_amd import checks
+
+    t0 = time.perf_counter()
+    out = {"n": 0, "ok": False, "where": "last sub-batch of the last timed step, as the run left it (no recount); seed 20264"}
+    try:
+        res = rx.Result(view)
+        checks.check_properties(res, db, qs.n)
+        out["properties_checked_on"] = int(qs.n)
+        seen = checks.as_run_oracle_sample(index, res, ctx["orc"], ctx["otree"], qs.bases, qs.base_off, n_sample, bool(flags),
+                                           threads=available_parallelism())
+        out.update(n=seen["n"], ok=True, counts_bit_exact=True, max_dp=seen["max_dp"], ties=seen["ties"], rows_identical=seen["rows_identical"],
+                   queries_with_threshold=seen["with_threshold"], mean_threshold=seen["thr"] / max(seen["n"], 1),
+                   tiles_visited_per_query=seen["live"] / max(seen["n"], 1), tiles_above_threshold_per_query=seen["needed"] / max(seen["n"], 1),
+                   max_mass_of_a_dropped_set=seen["max_dropped"], tolerance_asserted=1e-9)
+    except AssertionError as e:
+        out["error"] = str(e)[:400] or "assertion failed"
+    out["seconds"] = round(time.perf_counter() - t0, 1)
+    return out
+
+
+def cpu_baseline(db, qs, target_s: float, skip_exact: bool, ctx):
+    """Times the oracle (oracle/, kind "port": a C restatement of raxtax.rs:35-88, compiled -O3 -march=native ON THIS HOST at the
+    start of the leg: oracle_context) on this host's cores.  Three legs on prefixes of the same queries: one thread; all usable
+    threads; one thread per physical core, pinned (the reference's --pin, utils.rs:139-197).  The parallel legs use the reference's chunk
     rule (main.rs:119-124: max(100, n / (10 T) + 1) queries per work item); their samples are whole multiples of
     100 T queries, so that every thread gets the same number of full chunks -- a shorter sample would leave most
     threads idle in the last wave and understate the rate the reference reaches on a full batch."""
-    from oracle.oracle_py import Oracle
-
     T = available_parallelism()
-    orc = Oracle(native=True)
-    t0 = time.perf_counter()
-    otree = orc.tree_new_flat(db.lineages, db.seq_bytes, db.seq_off)
-    t_tree = time.perf_counter() - t0
+    orc, otree, t_tree = ctx["orc"], ctx["otree"], ctx["t_tree"]
     L = db.length
 
     def run(n, threads, pins=None):
@@ -215,10 +256,16 @@ def cpu_baseline(db, qs, target_s: float, skip_exact: bool):
                      f"no string formatting; oracle Tree::new {t_tree:.1f} s (untimed)",
            "per_thread": every["value"] / T,
            "one_thread": {"value": rate1, "queries": n1, "seconds": round(dt1, 2)},
+           "build": ctx["build"],
            "note": "the Rust reference itself cannot be built here (no cargo/rustc): this is the C port (oracle/oracle.c)"}
     if pinned is not None:
         out["pinned_physical_cores"] = {"value": pinned["value"], "cores": len(phys), "queries": pinned["queries"],
-                                        "seconds": round(pinned["seconds"], 2), "per_thread": pinned["value"] / len(phys)}
+                                        "seconds": round(pinned["seconds"], 2), "per_thread": pinned["value"] / len(phys), "cpus": phys,
+                                        "note": "thread i on the i-th physical core of the affinity mask in ascending CPU order -- the choice of the reference's --pin "
+                                                "(utils.rs:160-197 takes the first sibling of every core in /sys order, setup_threadpool_pinned the first T of them).  On an "
+                                                "EPYC host with a cgroup quota but no cpuset these are neighbouring cores of two or three CCDs: they share those CCDs' L3 "
+                                                "slices and fabric links, while the unpinned threads are spread by the scheduler over the whole socket (every thread an L3 "
+                                                "of its own) -- the counting loop streams 170 MB of postings per query, so the unpinned leg is the faster one here"}
     return out
 
 
@@ -368,13 +415,17 @@ def extras_block(args, rx, lib, index, tree, db, qs, flags):
             fn()
         return (time.perf_counter() - t0) / steps
 
+    # under --host-exact-match every leg uploads the host's ids, as the headline did; else the device looks them up
+    host_ids = index.exact_matches(qs.bases, qs.base_off) if (args.host_exact_match or not index.has_exact_lookup) else ()
+    lookup = "host map, ids uploaded with the queries" if host_ids else "device, inside the step"
+
     # ---- queries cross PCIe every step
     def with_upload():
-        index.upload(qs.bases, qs.base_off)
+        index.upload(qs.bases, qs.base_off, *host_ids)
         index.run(flags)
         index.download(copy=False)
     dt = timed(with_upload)
-    out["value_incl_h2d"] = {"value": n_q / dt, "ms_per_step": dt * 1e3, "steps": steps,
+    out["value_incl_h2d"] = {"value": n_q / dt, "ms_per_step": dt * 1e3, "steps": steps, "exact_match_lookup": lookup,
                              "what": "rtx_batch_upload (pageable host memory, one byte per base: %.0f MB) + rtx_batch_run + rtx_batch_download" % (len(qs.bases) / 1e6)}
     # ---- through the host mirror of raxtax() to strings
     labels = (ctypes.c_char_p * n_q)(*[l.encode() for l in qs.labels])
@@ -400,9 +451,10 @@ def extras_block(args, rx, lib, index, tree, db, qs, flags):
     def plain():
         index.run(flags)
         index.download(copy=False)
-    index.upload(qs.bases, qs.base_off)
+    index.upload(qs.bases, qs.base_off, *host_ids)
     dt = timed(plain)
-    out["value_unpruned"] = {"value": n_q / dt, "ms_per_step": dt * 1e3, "steps": steps, "what": "RTX_OPT_TILE_PRUNE = 0: hit_count counts every tile"}
+    out["value_unpruned"] = {"value": n_q / dt, "ms_per_step": dt * 1e3, "steps": steps, "exact_match_lookup": lookup,
+                             "what": "RTX_OPT_TILE_PRUNE = 0: hit_count counts every tile"}
     rx._lib.check(lib.rtx_index_set_option(index._h, 13, 0 if args.no_tile_prune else 1))
     # ---- divergence sweep
     from raxtax_amd import synth
@@ -425,8 +477,54 @@ def extras_block(args, rx, lib, index, tree, db, qs, flags):
     out["divergence_sweep"] = {"queries": 131072, "steps": steps, "exact_copies": 0.0,
                                "note": "per-site substitution rate of a query against its source reference (the headline workload: 0.02 and 10 % exact copies)",
                                "rows": sweep}
-    index.upload(qs.bases, qs.base_off)     # leave the handle as the headline had it
+    index.upload(qs.bases, qs.base_off, *host_ids)     # leave the handle as the headline had it
     return out
+
+
+def real_composition_block(args, rx, lib, flags):
+    """value_real_composition: the reference's methodology (scripts/common.py:11-25: real sequences, 90 % -> database, 10 % held out as
+    queries) on the only real data it ships -- the 7 868 Diptera COI records of example/diptera_queries.fasta (committed as
+    tests/golden/diptera_queries.fasta; ~205 bp, t ~ 195) -- scaled to a 14-tile database (raxtax_amd/synth.py:
+    real_composition_holdout: every database record 16 times with individual-level substitutions).  A query's best hit is a
+    relative at its natural distance, k-mers common to most references give unrelated references 40 % of the best count: the regime
+    where the tile pruning buys least.  Pruned and unpruned on the same handle; inputs resident as for `value`."""
+    from raxtax_amd import synth
+
+    fasta = ROOT / "tests" / "golden" / "diptera_queries.fasta"
+    if not fasta.exists():
+        return {"error": "tests/golden/diptera_queries.fasta not found"}
+    h = synth.real_composition_holdout(fasta)
+    tree = rx.Tree.new_flat(h.lineages, h.seq_bytes, h.seq_off, kmer_map=False)
+    index = rx.Index(tree, device=0)
+    n_q = len(h.q_off) - 1
+    steps = 3
+
+    def plain():
+        index.run(flags)
+        index.download(copy=False)
+
+    def timed(fn):
+        fn()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        return (time.perf_counter() - t0) / steps
+    index.upload(h.q_bases, h.q_off)
+    dt = timed(plain)
+    st = index.debug_prune_stats()
+    view = index.download(copy=False)
+    ok = int((np.ctypeslib.as_array(view.status, shape=(n_q,)) == 0).sum())
+    rx._lib.check(lib.rtx_index_set_option(index._h, 13, 0))
+    index.upload(h.q_bases, h.q_off)
+    dt_full = timed(plain)
+    ntiles = (len(h.lineages) + 8191) // 8192
+    return {"value": n_q / dt, "ms_per_step": dt * 1e3, "value_unpruned": n_q / dt_full, "ms_per_step_unpruned": dt_full * 1e3, "steps": steps,
+            "queries": n_q, "refs": len(h.lineages), "tiles": ntiles, "classified_ok": ok,
+            "live_tiles_per_pair": st["live_tiles_per_pair"], "live_tiles_per_query": st.get("live_tiles_per_query"),
+            "tiles_above_threshold_per_query": st["tiles_above_threshold_per_query"], "mean_threshold": st["mean_threshold"],
+            "mean_best_hit_lower_bound": st["mean_best_hit_lower_bound"], "share_with_threshold": st["queries_with_threshold"] / n_q,
+            "workload": f"{h.n_records_held_out} held-out Diptera COI records (~205 bp) as {n_q} queries vs the other {h.n_records_db} records x 16 "
+                        f"individual-level copies = {len(h.lineages)} references (scripts/common.py:11-25 hold-out methodology)"}
 
 
 # ------------------------------------------------------------------------------------------------------------
@@ -545,8 +643,15 @@ def main():
             n = lib.rtx_result_pack(ctypes.byref(view), rec_buf[k].ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), rec_buf[k].shape[0])
             assert n == need, "rtx_result_pack failed"
             if pending[0] is not None:
-                dist_util.gather_finish(pending[0])
+                note_gathered(dist_util.gather_finish(pending[0]))
             pending[0] = dist_util.gather_start(dist, rec_buf[k][:n], rank, world, device=coll_device, cache=gather_cache[k])
+
+        gathered_q = [0]
+
+        def note_gathered(parts):
+            """Rank 0: the record buffers of all ranks are in its (pinned) host memory; their headers say how many queries arrived."""
+            if parts is not None:
+                gathered_q[0] = sum(int(np.frombuffer(p_[:8].tobytes(), np.int64)[0]) for p_ in parts if len(p_) >= 32)
 
         def step():
             index.run(flags)                        # enqueues every kernel of this step
@@ -562,7 +667,7 @@ def main():
                 ship(prev_view[0])
                 prev_view[0] = None
             if pending[0] is not None:
-                dist_util.gather_finish(pending[0])
+                note_gathered(dist_util.gather_finish(pending[0]))
                 pending[0] = None
         total_q_step = args.queries * world
         scaling = "weak"
@@ -600,6 +705,7 @@ def main():
     prob_work = index.prob_work()
     prune_stats = index.debug_prune_stats() if hasattr(index, "debug_prune_stats") else None   # of the last step (all zero: not pruned)
     ok = int((np.ctypeslib.as_array(view.status, shape=(args.queries,)) == 0).sum())
+    parity_failed = False
     if rank == 0:
         line = {
             "metric": "classified queries/sec (whole node)",
@@ -622,6 +728,8 @@ def main():
                 "process_group": ({"backend": dist.get_backend(), "world_size": dist.get_world_size()} if dist is not None
                                   else {"backend": None, "world_size": 1}),
                 "classified_ok": ok, "skip_exact_matches": bool(args.skip_exact_matches),
+                "host_threads_per_rank": int(lib.rtx_host_threads()),      # affinity mask capped by the cgroup quota, divided by the ranks on this host
+                "gathered_queries_last_step": (gathered_q[0] if (dist is not None and not args.shard_db) else None),
                 "sub_batch": int(round(args.queries / max(stage_n["hit_count"] / args.steps, 1))) if stage_n["hit_count"] else None,
                 "exact_match_lookup": ("host hash map, once, untimed: %.3f s" % t_exact) if t_exact is not None else
                                       "device (rtx_exact.hip), inside every timed step",
@@ -630,16 +738,24 @@ def main():
                                        ntiles=(args.refs + 8191) // 8192),
             "stage_ms_per_step": {s: stage_ms[s] / args.steps for s in stage_ms},
         }
+        ctx = None
+        if not args.no_cpu_baseline and world == 1:      # the oracle: rank 0 at N = 1 only, never inside the timed region
+            ctx = oracle_context(db)
+            if not args.shard_db:                        # first of all: the last timed step is still on the device
+                line["parity_sample"] = parity_block(args, rx, index, view, ctx, db, qs, flags)
+                parity_failed = not line["parity_sample"]["ok"]
         if not args.no_extras and world == 1 and not args.shard_db:
             line.update(extras_block(args, rx, lib, index, tree, db, qs, flags))
-        if not args.no_cpu_baseline and world == 1:      # reported baseline: rank 0 at N = 1 only
-            line["cpu_baseline"] = cpu_baseline(db, qs, args.cpu_seconds, bool(flags))
-        else:
-            line["cpu_baseline"] = None
+            if args.config == 2 and args.config_name != "custom size":
+                line["value_real_composition"] = real_composition_block(args, rx, lib, flags)
+        line["cpu_baseline"] = cpu_baseline(db, qs, args.cpu_seconds, bool(flags), ctx) if ctx is not None else None
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if parity_failed:
+        print("bench.py: parity_sample failed: " + line["parity_sample"].get("error", ""), file=sys.stderr)
+        raise SystemExit(4)
 
 
 if __name__ == "__main__":

@@ -348,6 +348,9 @@ int rtx_debug_prob_table(rtx_index *index, uint64_t query, double *table_over_z 
 int rtx_debug_probs(rtx_index *index, uint64_t query, double *probs /*n_refs*/);
 /* processing order of the last run (RTX_OPT_CLUSTER / RTX_OPT_LOCATOR): perm[position] = query */
 int rtx_debug_order(rtx_index *index, uint32_t *perm /*n_queries*/);
+/* queries per sub-batch of the uploaded batch and the number of sub-batches: positions [(n_sub - 1) * sub_batch, n_queries) of the
+ * processing order are the last sub-batch, the one the taps can read */
+int rtx_batch_sub_batch(const rtx_index *index, uint32_t *sub_batch, uint32_t *n_sub_batches);
 /* tile pruning of the last run (RTX_OPT_TILE_PRUNE): out[0] (pair, tile) blocks that are counted for at least one of their two queries, [1] pairs,
  * [2] sum of the lower bounds of the best hit, [3] sum of the thresholds, [4] sum of the largest tile bounds, [5] queries, [6] bounds below a count
  * they bound (must be 0), [7] (query, tile) combinations that are counted, [8] (query, tile) combinations with a count above the query's

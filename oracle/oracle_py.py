@@ -42,6 +42,16 @@ def build(native: bool = False, force: bool = False) -> Path:
     return out
 
 
+def build_info(native: bool = False) -> dict:
+    """Compiler and flags of build(native): what `cpu_baseline` prints beside its numbers."""
+    march = "native" if native else "x86-64-v3"
+    try:
+        cc = subprocess.check_output(["gcc", "--version"], text=True).splitlines()[0]
+    except (OSError, subprocess.CalledProcessError):
+        cc = "gcc (version unknown)"
+    return {"compiler": cc, "flags": f"-O3 -march={march} -std=gnu11 -fPIC -fopenmp (oracle/Makefile)"}
+
+
 _u8p = C.POINTER(C.c_uint8)
 _u16p = C.POINTER(C.c_uint16)
 _u32p = C.POINTER(C.c_uint32)

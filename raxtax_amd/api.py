@@ -386,6 +386,12 @@ class Index:
         check(self._lib.rtx_debug_probs(self._h, q, ptr(out, f64p)))
         return out
 
+    def sub_batch_size(self) -> int:
+        """Queries per sub-batch (kernel launch) of the uploaded batch."""
+        b, n = C.c_uint32(), C.c_uint32()
+        check(self._lib.rtx_batch_sub_batch(self._h, C.byref(b), C.byref(n)))
+        return int(b.value)
+
     def debug_order(self, n_queries: int) -> np.ndarray:
         """Processing order of the last run: perm[position] = query."""
         out = np.zeros(n_queries, dtype=np.uint32)

@@ -2220,6 +2220,14 @@ int rtx_debug_prune_stats(rtx_index *ix, uint64_t *out) {
     return RTX_OK;
 }
 
+int rtx_batch_sub_batch(const rtx_index *ix, uint32_t *sub_batch, uint32_t *n_sub) {
+    if (!ix) { set_error("null index handle"); return RTX_ERR_INVALID; }
+    if (!ix->uploaded || ix->sub_batch == 0) { set_error("rtx_batch_sub_batch: no batch has been uploaded"); return RTX_ERR_STATE; }
+    if (sub_batch) *sub_batch = ix->sub_batch;
+    if (n_sub) *n_sub = (uint32_t)((ix->n_q + ix->sub_batch - 1) / ix->sub_batch);
+    return RTX_OK;
+}
+
 int rtx_debug_order(rtx_index *ix, uint32_t *perm) {
     if (!ix || !perm) { set_error("null argument"); return RTX_ERR_INVALID; }
     if (!ix->ran || ix->h_perm.n < ix->n_q) { set_error("rtx_debug_order: no batch has been run"); return RTX_ERR_STATE; }

@@ -148,3 +148,90 @@ def make_queries(db: SynthDB, n_queries: int, seed: int = 3, mu_q: float = 0.02,
     labels = [f"q{first_label + i}" for i in range(n_queries)]
     off = np.arange(n_queries + 1, dtype=np.uint64) * np.uint64(L)
     return SynthQueries(labels, bases.reshape(-1), off, src)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# Real composition: the reference's example barcodes, expanded (bench.py value_real_composition, tests)
+# ------------------------------------------------------------------------------------------------------------
+def read_fasta_records(path) -> Tuple[List[str], List[str], List[np.ndarray]]:
+    """(labels, lineages, sequences in the reference's encoding) of a FASTA file whose headers carry `tax=...;` (parser.rs:46-105:
+    the header up to the first ';' is the label, `tax=([^;]+);` the lineage; ACGT only)."""
+    code = np.zeros(256, np.uint8)
+    for ch, v in zip("ACGT", (1, 2, 4, 8)):
+        code[ord(ch)] = code[ord(ch.lower())] = v
+    labels, lins, seqs, cur = [], [], [], []
+    with open(path) as fh:
+        for line in fh:
+            line = line.strip()
+            if not line or line.startswith(";"):
+                continue
+            if line.startswith(">"):
+                if cur:
+                    seqs.append(code[np.frombuffer("".join(cur).encode(), np.uint8)])
+                cur = []
+                labels.append(line[1:].split(";")[0])
+                lins.append(line.split("tax=")[1].split(";")[0])
+            else:
+                cur.append(line)
+    seqs.append(code[np.frombuffer("".join(cur).encode(), np.uint8)])
+    assert len(labels) == len(lins) == len(seqs)
+    return labels, lins, seqs
+
+
+@dataclass
+class HoldOut:
+    lineages: List[str]        # database: one per reference
+    seq_bytes: np.ndarray
+    seq_off: np.ndarray
+    q_bases: np.ndarray        # queries (variable length)
+    q_off: np.ndarray
+    q_labels: List[str]
+    n_records_db: int
+    n_records_held_out: int
+
+
+def real_composition_holdout(path, copies: int = 16, n_queries: int = 131072, held_out: float = 0.10, seed: int = 11) -> HoldOut:
+    """The reference's benchmark methodology (scripts/common.py:11-25: sample real sequences, 90 % -> database, 10 % -> queries) on the
+    only real data it ships (example/diptera_queries.fasta, ~205 bp, t ~ 195), scaled to a database of some size: every database
+    record enters `copies` times -- once as it is, the others with 0.2 ... 4 % substitutions drawn from the record's own bases (what
+    individuals of a species look like) -- and the held-out records are the queries, each drawn with 0 / 0.5 / 1 % substitutions so
+    that the batch is not 787 sequences repeated.  A query's best hit is a relative at its natural distance, never a copy of itself;
+    k-mers common to most references and background counts near 40 % of the best hit are what this composition brings."""
+    labels, lins, seqs = read_fasta_records(path)
+    rng = np.random.default_rng(seed)
+    n = len(seqs)
+    perm = rng.permutation(n)
+    n_q_rec = max(1, int(round(n * held_out)))
+    q_rec, db_rec = np.sort(perm[:n_q_rec]), np.sort(perm[n_q_rec:])
+    mus = np.array([0.002, 0.005, 0.01, 0.02, 0.04])
+    out_seqs, out_lin = [], []
+    for r in db_rec:
+        base = seqs[r]
+        for c in range(copies):
+            s = base.copy()
+            if c:
+                hit = rng.random(len(s)) < float(mus[int(rng.integers(0, len(mus)))])
+                k = int(hit.sum())
+                if k:
+                    s[hit] = rng.choice(base, k)
+            out_seqs.append(s)
+            out_lin.append(lins[r])
+    off = np.zeros(len(out_seqs) + 1, np.uint64)
+    off[1:] = np.cumsum([len(s) for s in out_seqs])
+    qs, qlab = [], []
+    src = rng.integers(0, n_q_rec, size=n_queries)
+    qmu = (0.0, 0.005, 0.01)
+    for i in range(n_queries):
+        base = seqs[q_rec[src[i]]]
+        s = base.copy()
+        mu = qmu[i % 3]
+        if mu:
+            hit = rng.random(len(s)) < mu
+            k = int(hit.sum())
+            if k:
+                s[hit] = rng.choice(base, k)
+        qs.append(s)
+        qlab.append(f"{labels[q_rec[src[i]]]}#{i}")
+    qoff = np.zeros(n_queries + 1, np.uint64)
+    qoff[1:] = np.cumsum([len(s) for s in qs])
+    return HoldOut(out_lin, np.concatenate(out_seqs), off, np.concatenate(qs), qoff, qlab, len(db_rec), n_q_rec)

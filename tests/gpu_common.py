@@ -9,6 +9,9 @@ from pathlib import Path
 
 import numpy as np
 
+from raxtax_amd.checks import (as_run_oracle_sample, assert_rows_equivalent, check_properties, check_run_as_left,  # noqa: F401
+                               emul_threshold, last_sub_batch_queries, rows_of)
+
 ROOT = Path(__file__).resolve().parent.parent
 EXPECTED = ROOT / "tests" / "golden" / "expected_excuses.json"
 
@@ -44,111 +47,11 @@ class Excuses:
             assert v <= exp.get(k, 0), f"{self.id}: {v} queries excused as {k}, expectation {exp.get(k, 0)}"
 
 
-def check_properties(res, db, n_q):
-    """What holds for every query whatever the size of the database."""
-    assert res.n_queries == n_q and (res.status == 0).all()
-    assert (np.diff(res.row_off.astype(np.int64)) >= 1).all()
-    L = db.length
-    assert (res.t <= L - 7).all() and (res.t >= 2).all()
-    assert np.isfinite(res.global_signal).all() and (res.global_signal > 0).all()
-    conf = res.row_conf
-    assert (conf >= 0).all() and (conf <= 1.0 + 1e-12).all()
-    depth = res.row_depth
-    # confidences never increase from one level to the next (a child's range is inside its parent's)
-    for d in range(1, 6):
-        sel = depth > d
-        assert (conf[sel, d] <= conf[sel, d - 1] + 1e-12).all()
-    # rows of a query are sorted by descending confidence vectors (lineage.rs:91-93)
-    first = res.row_off[:-1].astype(np.int64)
-    nxt = first + 1
-    two = nxt < res.row_off[1:].astype(np.int64)
-    assert (conf[first[two], 0] >= conf[nxt[two], 0]).all()
-    # the confidences of the rows of a query at one level cannot sum to more than 1 (+ rounding of each)
-    nrows = np.diff(res.row_off.astype(np.int64))
-    top = np.add.reduceat(conf[:, 5] if conf.shape[1] > 5 else conf[:, 0], first)
-    assert (top <= 1.0 + 0.005 * nrows + 1e-9).all()
-
-
-def rows_of(res, q):
-    a, b = int(res.row_off[q]), int(res.row_off[q + 1])
-    return res.row_lineage[a:b], res.row_conf[a:b], res.row_local_signal[a:b]
-
-
-def emul_threshold(emul, lf, t, n_refs, block_counts, tab_tmax=1023):
-    """(u, i* + 1) of rtx_emul.cpp's restatement of prune_kernel's step 3."""
-    import ctypes as C
-
-    hm = np.zeros(64, np.uint32)
-    hm[: len(block_counts)] = block_counts
-    u, i1 = C.c_uint32(), C.c_uint32()
-    emul.emul_prune_threshold(C.c_uint32(t), C.c_uint64(n_refs), hm.ctypes.data_as(C.c_void_p), lf.ctypes.data_as(C.c_void_p),
-                              C.c_uint32(tab_tmax), C.byref(u), C.byref(i1))
-    return int(u.value), int(i1.value)
-
-
-def check_run_as_left(index, j, t, counts_o, p_o, n_refs, emul=None, lf=None, label="", tol=1e-9):
-    """What the PRUNED run itself computed for query j of the last sub-batch (no recount: rtx_debug_run_counts,
-    rtx_debug_pruned_prob_table, rtx_debug_prune_detail) against the oracle's full computation (counts_o: raxtax.rs:58-68, p_o =
-    table / Z: prob.rs:8-103):
-      * the counts hit_count wrote for the tiles it visited are the oracle's, bit for bit;
-      * every tile it did not visit holds no count above the query's threshold (and the query has one);
-      * the histogram it left = the oracle's counts of the visited tiles above the threshold + everything else (unvisited references,
-        counts up to the threshold) in bin 0;
-      * the probabilities of the pruned run equal the oracle's above the threshold (`tol`: 1e-9 by default, north_star allows 1e-6)
-        and what the oracle gives the references at or below it -- which the pruned run sets to 0 -- is below 1e-9 in total;
-      * (debug_taps) prune_kernel's best block holds the oracle's counts, its bound holds, and its threshold is the one the CPU
-        restatement derives from those counts (whose safety tests/test_prune_threshold_cpu.py attacks).
-    Returns a dict of what was seen."""
-    rc = index.debug_run_counts(j, t)
-    live, thr = rc["tile_live"], rc["threshold"]
-    ntiles = len(live)
-    pad = ntiles * 8192 - n_refs
-    co = np.concatenate([counts_o, np.zeros(pad, np.uint16)]).reshape(ntiles, 8192)
-    cr = np.concatenate([rc["counts"], np.zeros(pad, np.uint16)]).reshape(ntiles, 8192)
-    assert np.array_equal(cr[live], co[live]), f"{label}: counts of the visited tiles differ from the oracle"
-    tile_max_o = co.max(axis=1)
-    if not live.all():
-        assert thr > 0, f"{label}: tiles left out for a query without a threshold"
-        assert int(tile_max_o[~live].max()) <= thr, f"{label}: an unvisited tile holds a count above the threshold {thr}"
-    in_tile = np.minimum(8192, n_refs - np.arange(ntiles) * 8192)
-    want_hist = np.bincount(co[live].reshape(-1), minlength=t + 1)[: t + 1].astype(np.int64)
-    want_hist[0] += int(in_tile[~live].sum()) - int(pad if live[-1] else 0)      # the padding of the last tile is no reference
-    if thr:      # the epilogue of a pruned query puts the counts up to its threshold into bin 0 as one number (they are references without a hit to prob.rs)
-        want_hist[0] += int(want_hist[1: thr + 1].sum())
-        want_hist[1: thr + 1] = 0
-    assert np.array_equal(rc["hist"].astype(np.int64), want_hist), f"{label}: histogram as the run left it"
-    tz_p, z_p, thr2 = index.debug_pruned_prob_table(j, t)
-    assert thr2 == thr
-    hist_o = np.bincount(counts_o, minlength=t + 1)[: t + 1]
-    above = (np.arange(t + 1) > thr) & (hist_o > 0) if thr else hist_o > 0
-    d = float(np.max(np.abs(tz_p[above] - p_o[: t + 1][above]), initial=0.0))
-    assert d < tol, f"{label}: probabilities of the pruned run differ by {d}"
-    dropped = float((hist_o * p_o[: t + 1])[: thr + 1].sum()) if thr else 0.0
-    assert dropped < 1e-9, f"{label}: the references up to the threshold {thr} hold {dropped} in the oracle"
-    if thr:
-        assert (tz_p[: thr + 1] == 0).all()
-    out = dict(threshold=thr, live=int(live.sum()), needed=int((tile_max_o > thr).sum()) if thr else ntiles, dp=d, dropped=dropped)
-    if emul is not None:
-        det = index.debug_prune_detail(j)
-        b = det["block"]
-        blk = np.zeros(64, np.uint32)
-        seg = counts_o[b * 64:(b + 1) * 64]
-        blk[: len(seg)] = seg
-        assert np.array_equal(det["block_counts"], blk), f"{label}: exact counts of the best block {b}"
-        assert det["M"] == int(blk.max()) and det["t"] == t and det["threshold"] == thr
-        assert det["largest_bound"] >= int(counts_o.max()), f"{label}: the largest bound lies below a count"
-        u_e, i1_e = emul_threshold(emul, lf, t, n_refs, blk)
-        assert (u_e, i1_e) == (thr, rc["i1"]), f"{label}: kernel threshold {(thr, rc['i1'])}, CPU restatement {(u_e, i1_e)}"
-    return out
-
-
 def oracle_sample_parity(index, oracle, otree, db, qs, sample, skip, excuses, full_res=None, chunk=250, tol=1e-6, emul=None):
     """The seeded sample classified as a batch of its own and compared with the oracle, stage by stage:
     t and hit counts bit-exact (raxtax.rs:58-68), probabilities table[m]/Z within `tol` (north_star: 1e-6; asserted
     tighter below), result rows identical (ties counted in `excuses`).  If `full_res` is given the rows must also
     equal those the same queries got inside the full batch (composition and order of a batch never matter)."""
-    from test_gpu_parity import assert_rows_equivalent
-
     L = db.length
     threads = os.cpu_count() or 1
     B = qs.bases.reshape(-1, L)

@@ -61,3 +61,29 @@ def test_shard_db_mode_runs():
     r3 = bench("--shard-db", "--shard-mode", "kmers", "--gpus", 2, "--backend", "gloo", "--refs", 3000, "--queries", 300,
                "--steps", 1, "--warmup", 1, "--sub-batch", 64)
     assert r3["n_gpus"] == 2 and r3["config"]["classified_ok"] == 300 and "k-mers sharded" in r3["config"]["parallelism"]
+
+
+def test_five_ranks_rehearse_the_eight_gpu_runs():
+    """What the driver's 8-GPU runs will do that two ranks do not show: a world size that is not a power of two and divides neither the
+    references nor the tiles, every rank with its own thread budget (LOCAL_WORLD_SIZE -> rtx_host_threads), rank 0 gathering from many.
+    Five gloo ranks share the one GPU of the test box -- the box allows six processes on its card, and this pytest process is one of
+    them, which is why the rehearsal has five ranks and not eight.  configs[3] (queries sharded) and both modes of configs[4]."""
+    r = bench("--gpus", 5, "--backend", "gloo", "--refs", 6000, "--queries", 1111, "--steps", 2, "--warmup", 1)
+    assert r["n_gpus"] == 5 and r["config"]["process_group"] == {"backend": "gloo", "world_size": 5}
+    assert r["config"]["classified_ok"] == 1111 and r["config"]["host_threads_per_rank"] >= 1
+    assert r["config"]["gathered_queries_last_step"] == 5 * 1111        # rank 0 read the headers of all five record buffers
+    r2 = bench("--shard-db", "--gpus", 5, "--backend", "gloo", "--refs", 122882, "--queries", 333, "--steps", 1, "--warmup", 1,
+               "--sub-batch", 128)      # 122882 = 5 * 24576 + 2 references: two shards of 4 tiles (could prune alone), three of 3 (cannot): the
+                                        # ranks agree not to (ShardedClassifier._agree_on_pruning over gloo) instead of mixing two orders of the queries
+    assert r2["n_gpus"] == 5 and r2["config"]["classified_ok"] == 333
+    r3 = bench("--shard-db", "--shard-mode", "kmers", "--gpus", 5, "--backend", "gloo", "--refs", 3001, "--queries", 257,
+               "--steps", 1, "--warmup", 1, "--sub-batch", 64)
+    assert r3["n_gpus"] == 5 and r3["config"]["classified_ok"] == 257
+
+
+def test_rccl_backend_with_one_rank():
+    """The RCCL code path of bench.py at N > 1 (device tensors, pinned staging, asynchronous gather overlapped with the next step's
+    kernels on the library's stream) with a process group of one rank -- all of it that one GPU can exercise (tools/nccl_world1_check.py)."""
+    p = subprocess.run([sys.executable, str(ROOT / "tools" / "nccl_world1_check.py")], capture_output=True, text=True, timeout=600,
+                       env={**__import__("os").environ, "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    assert p.returncode == 0 and "nccl world-1 gather ok" in p.stdout, (p.stdout[-1500:], p.stderr[-3000:])

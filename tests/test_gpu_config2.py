@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 import raxtax_amd as rx
-from gpu_common import Excuses, check_properties, oracle_sample_parity, rows_of
+from gpu_common import Excuses, as_run_oracle_sample, check_properties, oracle_sample_parity, rows_of
 from raxtax_amd import synth
 
 pytestmark = pytest.mark.gpu
@@ -104,4 +104,29 @@ def test_tile_pruning_is_at_work_and_changes_no_row(cfg2, oracle):
     for j in range(0, N_SAMPLE, 3):
         x, y = rows_of(res, j), rows_of(c["res"], int(c["sample"][j]))
         assert np.array_equal(x[0], y[0]) and np.allclose(x[1], y[1], rtol=0, atol=1e-9), int(c["sample"][j])
+    ex.check()
+
+
+def test_one_million_queries_as_the_bench_runs_them(cfg2, oracle, emul):
+    """BASELINE.json configs[2] AT ITS SIZE: the 1 M queries of bench.py's rank 0 against the 500 000 references in one
+    batch -- 31 sub-batches, exact matches looked up on the device -- through the size-independent properties, and a seeded 2 000-query
+    sample taken from INSIDE that batch's last sub-batch held against the oracle exactly as the run left it (no recount, nothing run
+    again: counts of the visited tiles bit-exact, unvisited tiles below the threshold, histogram, probabilities, prune_kernel's
+    threshold against its CPU restatement), then the rows the batch returned for those queries against the oracle's rows."""
+    import os
+
+    c = cfg2
+    qs = synth.make_queries(c["db"], 1_000_000, seed=3)
+    index = c["index"]
+    res = index.classify(qs.bases, qs.base_off)
+    check_properties(res, c["db"], qs.n)
+    assert index.sub_batch_size() * 2 < qs.n                      # really many sub-batches
+    st = index.debug_prune_stats()
+    assert st["pairs"] == qs.n // 2 and st["bound_violations"] == 0, st
+    seen = as_run_oracle_sample(index, res, oracle, c["otree"], qs.bases, qs.base_off, 2000, False, threads=os.cpu_count() or 1, emul=emul)
+    print("1 M queries, sample of the last sub-batch as the run left it:", seen)
+    assert seen["n"] == 2000 and seen["with_threshold"] == 2000 and seen["max_dp"] < 1e-9
+    ex = Excuses("config2/1M/last_sub_batch")
+    ex.checked = seen["n"]
+    ex.n["ties"] = seen["ties"]
     ex.check()

@@ -10,6 +10,7 @@ import pytest
 
 import raxtax_amd as rx
 from gpu_common import Excuses, rows_of
+from raxtax_amd.checks import _path_confidences, assert_rows_equivalent  # noqa: F401
 from raxtax_amd import synth
 from raxtax_amd.api import DEFAULT_SEGMENT_CLASSES
 
@@ -56,63 +57,6 @@ def world(oracle):
     tree = rx.Tree.new_flat(db.lineages, db.seq_bytes, db.seq_off)
     index = rx.Index(tree)
     return dict(db=db, labels=labels, seqs=seqs, bases=bases, off=off, otree=otree, tree=tree, index=index)
-
-
-def _path_confidences(lineages, probs, idx):
-    """Unrounded confidence of every ancestor of reference `idx` (sum of probs over the references that
-    share the first d+1 lineage levels), computed from the oracle's probabilities."""
-    parts = lineages[idx].split(",")
-    out = []
-    lo = hi = idx
-    for d in range(len(parts)):
-        pre = ",".join(parts[: d + 1])
-        is_in = lambda s: s == pre or s.startswith(pre + ",")
-        a = idx
-        while a > 0 and is_in(lineages[a - 1]):
-            a -= 1
-        b = idx + 1
-        while b < len(lineages) and is_in(lineages[b]):
-            b += 1
-        out.append(float(probs[a:b].sum()))
-    return out
-
-
-def assert_rows_equivalent(got, rows, probs_ref, lineages, label=""):
-    """Rows must be identical, except that where the reference breaks an exact tie between sibling
-    taxa by floating-point noise in its prefix sums (lineage.rs:62-66,158-166: arg-max of equal
-    confidences; the stable sort of equal confidence vectors, lineage.rs:91-93) the device may pick the
-    other sibling.  A differing lineage is accepted only if its confidences equal those of the oracle's choice
-    to 1e-9 (computed from the ORACLE's probabilities) on every level down to the one where the two lineages part."""
-    assert len(got) == len(rows), label
-    if [g.lineage for g in got] == [r["idx"] for r in rows]:
-        for g, r in zip(got, rows):
-            assert g.confidence_values == r["conf"], label
-        return 0
-    remaining = list(rows)
-    n_ties = 0
-    for g in got:
-        match = None
-        for r in remaining:
-            if r["conf"] != g.confidence_values:
-                continue
-            if r["idx"] == g.lineage:
-                match = r
-                break
-            a = _path_confidences(lineages, probs_ref, g.lineage)
-            b = _path_confidences(lineages, probs_ref, r["idx"])
-            # the two lineages part at level `fork`: a tie there (equal confidences up to and including that level)
-            # explains every difference below it (the walk continues inside the sibling it chose)
-            la, lb = lineages[g.lineage].split(","), lineages[r["idx"]].split(",")
-            fork = next((d for d in range(min(len(la), len(lb))) if la[d] != lb[d]), min(len(la), len(lb)) - 1)
-            if len(a) == len(b) and max(abs(x - y) for x, y in zip(a[: fork + 1], b[: fork + 1])) < 1e-9:
-                match = r
-                n_ties += 1
-                break
-        assert match is not None, f"{label}: device row {g} has no equivalent oracle row"
-        remaining.remove(match)
-        if match["idx"] == g.lineage:   # a tied sibling may have another size, hence another expected vector / local signal
-            assert abs(g.local_signal - match["local_signal"]) < 1e-6, label
-    return n_ties
 
 
 def _oracle_rows(otree, seq, skip):

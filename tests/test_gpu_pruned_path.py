@@ -230,3 +230,33 @@ def test_reference_shards_prune_with_the_global_threshold(oracle, n_shards):
             lv = np.repeat(rc["tile_live"], 8192)[: s.n_refs]
             assert np.array_equal(rc["counts"][lv], counts[s.ref_lo:s.ref_hi][lv]) and rc["threshold"] > 0
             assert (counts[s.ref_lo:s.ref_hi][~lv] <= rc["threshold"]).all()
+
+
+def test_shards_that_disagree_on_pruning_fall_back_together(oracle):
+    """whether a reference shard CAN prune is local state (a union bitmap exists from RTX_PRUNE_MIN_TILES = 4 local tiles on).
+    49 153 references over two shards are 24 577 (4 tiles) and 24 576 (3 tiles): left to themselves one shard would process the queries
+    in min-hash order and exchange best blocks, the other in input order without -- the histogram all-reduce would add rows of different
+    queries.  ShardedClassifier.upload takes the minimum of the shards' verdicts: nobody prunes, and the result is the unsharded one."""
+    from raxtax_amd import sharded
+
+    n_refs = 49153
+    db = synth.make_db(n_refs)
+    qs = synth.make_queries(db, 300, seed=31, exact_frac=0.1)
+    tree = rx.Tree.new_flat(db.lineages, db.seq_bytes, db.seq_off)
+    cuts = sharded.shard_cuts(tree.num_tips, 2)
+    assert [(b - a + 8191) // 8192 for a, b in zip(cuts, cuts[1:])] == [4, 3]
+    shards = [sharded.ShardIndex(tree, r, cuts, sub_batch=128) for r in range(2)]
+    alone = []
+    for s in shards:          # each shard on its own: the first could prune, the second cannot
+        s.upload(qs.bases, qs.base_off)
+        s.begin()
+        alone.append(s.prunes)
+    assert alone == [True, False]
+    whole = rx.Index(tree, tile_prune=False)
+    ex = whole.exact_matches(qs.bases, qs.base_off)
+    ref = whole.classify(qs.bases, qs.base_off, *ex)
+    clf = sharded.ShardedClassifier(shards, sharded.LocalComm())
+    got = clf.classify(qs.bases, qs.base_off, *ex)
+    assert not any(s.prunes for s in shards) and clf._prunes is False
+    assert np.array_equal(got.t, ref.t) and np.array_equal(got.row_off, ref.row_off) and np.array_equal(got.row_lineage, ref.row_lineage)
+    assert np.max(np.abs(got.row_conf - ref.row_conf)) < 1e-9 and np.max(np.abs(got.global_signal - ref.global_signal)) < 1e-9

@@ -737,6 +737,10 @@ def main():
             "roofline": roofline_block(args, work, prob_work, stage_ms, stage_n, args.queries, L, prune=prune_stats,
                                        ntiles=(args.refs + 8191) // 8192),
             "stage_ms_per_step": {s: stage_ms[s] / args.steps for s in stage_ms},
+            # every kernel of a step sits in one of the stages (HIP events on the library's stream); what is left of ms_per_step is launch
+            # gaps, the host's finalisation of the last sub-batch and the D2H of the records
+            "stage_ms_sum_per_step": sum(stage_ms.values()) / args.steps,
+            "unstaged_ms_per_step": elapsed / args.steps * 1e3 - sum(stage_ms.values()) / args.steps,
         }
         ctx = None
         if not args.no_cpu_baseline and world == 1:      # the oracle: rank 0 at N = 1 only, never inside the timed region

@@ -32,7 +32,8 @@
 extern "C" {
 #endif
 
-#define RTX_ABI_VERSION 3 /* 2: rtx_result_view.row_begin/row_count replace row_off; 3: exact_off == NULL = look the exact matches up on the device */
+#define RTX_ABI_VERSION 4 /* 2: rtx_result_view.row_begin/row_count replace row_off; 3: exact_off == NULL = look the exact matches up on the device;
+                             4: RTX_NUM_STAGES 8 -> 10 (rtx_batch_stage_times writes ten entries), rtx_batch_upload_packed */
 #define RTX_NUM_KMERS 65536u /* 2 << 15 posting lists, src/tree.rs:52 */
 #define RTX_MAX_DEPTH 32u    /* deepest lineage (comma-separated levels) the device walk carries */
 
@@ -322,7 +323,9 @@ int rtx_index_stream(rtx_index *index, void **hip_stream);
 #define RTX_STAGE_TILE_BOUNDS 5 /* tile pruning (RTX_OPT_TILE_PRUNE): the queries counted against the union bitmap (the hit_count kernel again); 0 launches if the run did not prune */
 #define RTX_STAGE_TILE_PRUNE 6  /* ... prune_kernel (thresholds, live tiles) + the row lists of the live tiles */
 #define RTX_STAGE_EXACT_MATCH 7 /* Tree.sequences.get on the device (rtx_exact.hip; RTX_OPT_DEVICE_EXACT), once per run: reported with sub-batch 0 */
-#define RTX_NUM_STAGES 8
+#define RTX_STAGE_ORDER 8       /* processing order of the batch (rtx_cluster.hip: sketch, locator, radix sort, inverse), once per run: reported with sub-batch 0 */
+#define RTX_STAGE_PAIR_UNION 9  /* union row lists of the pairs of neighbouring queries (pair_union_kernel), once per sub-batch */
+#define RTX_NUM_STAGES 10
 int rtx_batch_stage_times(rtx_index *index, float ms[RTX_NUM_STAGES], uint32_t launches[RTX_NUM_STAGES]);
 /* Algorithmic work of the last rtx_batch_run: sum over queries of
  * H_q = sum_r count_q[r] (postings touched) and of L_q (query bytes), and the bitmap

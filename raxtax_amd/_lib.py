@@ -20,7 +20,7 @@ RTX_ERR_PARSE, RTX_ERR_DEPTH, RTX_ERR_STATE, RTX_ERR_TOO_LONG = -5, -6, -7, -8
 RTX_SKIP_EXACT_MATCHES = 1
 RTX_RAW_CONFIDENCE = 2
 RTX_Q_OK, RTX_Q_NO_KMERS = 0, 1
-STAGES = ("kmer_extract", "hit_count", "prob_table", "taxon_prefix", "lineage_walk", "tile_bounds", "tile_prune", "exact_match")
+STAGES = ("kmer_extract", "hit_count", "prob_table", "taxon_prefix", "lineage_walk", "tile_bounds", "tile_prune", "exact_match", "order", "pair_union")
 
 u8p = C.POINTER(C.c_uint8)
 u16p = C.POINTER(C.c_uint16)

@@ -419,8 +419,12 @@ int enqueue_hit(rtx_index *ix, const SubBatch &b, uint32_t flags, hipStream_t s,
     hp.n_items = nullptr;
     hp.prune_thr = nullptr;
     const bool prune = ix->prune_used && !ix->dbg_full_run;
+    if (ix->pair_used && part != 2) {
+        if (b.timed_all) RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_PAIR_UNION, 0), s));
+        launch_pair_union(s, sc.d_rows.p, sc.d_nrows.p, ix->rstride, b.nq, sc.d_urec.p, sc.d_nu.p, 2u * ix->rstride);
+        if (b.timed_all) RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_PAIR_UNION, 1), s));
+    }
     if (b.timed && !prune) RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_HIT_COUNT, 0), s));
-    if (ix->pair_used && part != 2) launch_pair_union(s, sc.d_rows.p, sc.d_nrows.p, ix->rstride, b.nq, sc.d_urec.p, sc.d_nu.p, 2u * ix->rstride);
     if (part != 0 && !prune) { set_error("internal: a split run without tile pruning"); return RTX_ERR_STATE; }
     if (prune) {
         // (1) the queries against the union bitmap: every row dense, no lists, packed counts (bounds per block of references)
@@ -641,11 +645,19 @@ int order_batch(rtx_index *ix, bool cluster) {
 }
 
 int begin_run(rtx_index *ix, uint32_t *n_sub_out, bool *timed_out, bool cluster) {
+    const uint32_t n_sub = (uint32_t)((ix->n_q + ix->sub_batch - 1) / ix->sub_batch);
+    const bool timed = n_sub <= 4096;
+    if (timed) {
+        int rc = ensure_events(ix, (size_t)n_sub * RTX_NUM_STAGES * 2);
+        if (rc) return rc;
+    }
+    const bool ev_all = timed && ix->stage_timing;
+    if (ev_all) RTX_HIP(hipEventRecord(ix->events[(size_t)RTX_STAGE_ORDER * 2], ix->stream));  // sub-batch 0
     int rc_o = order_batch(ix, cluster);
     if (rc_o) return rc_o;
+    if (ev_all) RTX_HIP(hipEventRecord(ix->events[(size_t)RTX_STAGE_ORDER * 2 + 1], ix->stream));
     RTX_HIP(hipMemsetAsync(ix->d_cursor.p, 0, sizeof(unsigned long long), ix->stream));
     RTX_HIP(hipMemsetAsync(ix->d_flags.p, 0, sizeof(uint32_t), ix->stream));
-    const uint32_t n_sub = (uint32_t)((ix->n_q + ix->sub_batch - 1) / ix->sub_batch);
     // two neighbours per wave only pays when neighbours are related: with the processing order on
     ix->pair_used = ix->pair_opt && cluster && ix->planes <= 10 && ix->n_q > 1 && ix->rstride <= 4096;
     ix->groups_per_sub = (ix->sub_batch + 1u) / 2u;
@@ -674,11 +686,6 @@ int begin_run(rtx_index *ix, uint32_t *n_sub_out, bool *timed_out, bool cluster)
         int rc_g = ix->d_group_rows.alloc((size_t)2 * n_sub * ix->groups_per_sub);  // second half: the bounds pass of the tile pruning
         if (rc_g) return rc_g;
         RTX_HIP(hipMemsetAsync(ix->d_group_rows.p, 0, (size_t)2 * n_sub * ix->groups_per_sub * 4, ix->stream));
-    }
-    const bool timed = n_sub <= 4096;
-    if (timed) {
-        int rc = ensure_events(ix, (size_t)n_sub * RTX_NUM_STAGES * 2);
-        if (rc) return rc;
     }
     ix->n_sub_last = timed ? n_sub : 0;
     if (ix->dev_exact_used) {  // Tree.sequences.get for every query of the batch (raxtax.rs:42), part of the run
@@ -1959,6 +1966,10 @@ int rtx_batch_stage_times(rtx_index *ix, float ms[RTX_NUM_STAGES], uint32_t laun
         for (int s = 0; s < RTX_NUM_STAGES; s++) {
             if (s == RTX_STAGE_EXACT_MATCH) {
                 if (sb != 0 || !ix->dev_exact_used || !ix->stage_timing) continue;  // one launch per run
+            } else if (s == RTX_STAGE_ORDER) {
+                if (sb != 0 || !ix->stage_timing) continue;  // once per run
+            } else if (s == RTX_STAGE_PAIR_UNION) {
+                if (!ix->pair_used || !ix->stage_timing) continue;
             } else if (s == RTX_STAGE_TILE_BOUNDS || s == RTX_STAGE_TILE_PRUNE ? !ix->prune_used : (s != RTX_STAGE_HIT_COUNT && !ix->stage_timing)) continue;  // events were not recorded
             float t = 0.f;
             RTX_HIP(hipEventElapsedTime(&t, ix->events[((size_t)sb * RTX_NUM_STAGES + s) * 2],

@@ -419,14 +419,28 @@ def extras_block(args, rx, lib, index, tree, db, qs, flags):
     host_ids = index.exact_matches(qs.bases, qs.base_off) if (args.host_exact_match or not index.has_exact_lookup) else ()
     lookup = "host map, ids uploaded with the queries" if host_ids else "device, inside the step"
 
-    # ---- queries cross PCIe every step
+    # ---- queries cross PCIe every step: the batch of step i + 1 is staged (packed two bases per byte into pinned memory, asynchronous
+    # H2D on a stream of its own) while step i runs -- what rtx_raxtax does with its chunks
+    index.prefetch(qs.bases, qs.base_off, *host_ids)
+
     def with_upload():
+        index.activate()
+        index.run(flags)
+        index.prefetch(qs.bases, qs.base_off, *host_ids)      # the next step's queries: host packing + transfer beside the kernels
+        index.download(copy=False)
+    dt = timed(with_upload)
+
+    def serial_upload():
         index.upload(qs.bases, qs.base_off, *host_ids)
         index.run(flags)
         index.download(copy=False)
-    dt = timed(with_upload)
+    index.activate()
+    dt_serial = timed(serial_upload)
     out["value_incl_h2d"] = {"value": n_q / dt, "ms_per_step": dt * 1e3, "steps": steps, "exact_match_lookup": lookup,
-                             "what": "rtx_batch_upload (pageable host memory, one byte per base: %.0f MB) + rtx_batch_run + rtx_batch_download" % (len(qs.bases) / 1e6)}
+                             "value_not_overlapped": n_q / dt_serial, "ms_per_step_not_overlapped": dt_serial * 1e3,
+                             "what": "every step's queries come from host memory (%.0f MB one byte per base, %.0f MB over PCIe: two bases per byte): "
+                                     "rtx_batch_activate + rtx_batch_run + rtx_batch_prefetch of the NEXT step's queries + rtx_batch_download; "
+                                     "not_overlapped = rtx_batch_upload + run + download one after the other" % (len(qs.bases) / 1e6, len(qs.bases) / 2e6)}
     # ---- through the host mirror of raxtax() to strings
     labels = (ctypes.c_char_p * n_q)(*[l.encode() for l in qs.labels])
     SENDER = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p)
@@ -495,7 +509,7 @@ def real_composition_block(args, rx, lib, flags):
         return {"error": "tests/golden/diptera_queries.fasta not found"}
     h = synth.real_composition_holdout(fasta)
     tree = rx.Tree.new_flat(h.lineages, h.seq_bytes, h.seq_off, kmer_map=False)
-    index = rx.Index(tree, device=0)
+    index = rx.Index(tree, device=0, stage_timing=True)
     n_q = len(h.q_off) - 1
     steps = 3
 
@@ -512,14 +526,16 @@ def real_composition_block(args, rx, lib, flags):
     index.upload(h.q_bases, h.q_off)
     dt = timed(plain)
     st = index.debug_prune_stats()
+    stages = {s: round(ms, 3) for s, (ms, n) in index.stage_times().items() if n}
     view = index.download(copy=False)
     ok = int((np.ctypeslib.as_array(view.status, shape=(n_q,)) == 0).sum())
     rx._lib.check(lib.rtx_index_set_option(index._h, 13, 0))
     index.upload(h.q_bases, h.q_off)
     dt_full = timed(plain)
+    stages_full = {s: round(ms, 3) for s, (ms, n) in index.stage_times().items() if n}
     ntiles = (len(h.lineages) + 8191) // 8192
     return {"value": n_q / dt, "ms_per_step": dt * 1e3, "value_unpruned": n_q / dt_full, "ms_per_step_unpruned": dt_full * 1e3, "steps": steps,
-            "queries": n_q, "refs": len(h.lineages), "tiles": ntiles, "classified_ok": ok,
+            "queries": n_q, "refs": len(h.lineages), "tiles": ntiles, "classified_ok": ok, "stage_ms_per_step": stages, "stage_ms_per_step_unpruned": stages_full,
             "live_tiles_per_pair": st["live_tiles_per_pair"], "live_tiles_per_query": st.get("live_tiles_per_query"),
             "tiles_above_threshold_per_query": st["tiles_above_threshold_per_query"], "mean_threshold": st["mean_threshold"],
             "mean_best_hit_lower_bound": st["mean_best_hit_lower_bound"], "share_with_threshold": st["queries_with_threshold"] / n_q,

@@ -33,7 +33,7 @@ extern "C" {
 #endif
 
 #define RTX_ABI_VERSION 4 /* 2: rtx_result_view.row_begin/row_count replace row_off; 3: exact_off == NULL = look the exact matches up on the device;
-                             4: RTX_NUM_STAGES 8 -> 10 (rtx_batch_stage_times writes ten entries), rtx_batch_upload_packed */
+                             4: RTX_NUM_STAGES 8 -> 10 (rtx_batch_stage_times writes ten entries), rtx_batch_prefetch / rtx_batch_activate */
 #define RTX_NUM_KMERS 65536u /* 2 << 15 posting lists, src/tree.rs:52 */
 #define RTX_MAX_DEPTH 32u    /* deepest lineage (comma-separated levels) the device walk carries */
 
@@ -256,6 +256,20 @@ typedef struct {
  * returned per query (raxtax.rs:42), or NULL / NULL: the library looks them up on the device (handles built from the reference
  * sequences, RTX_OPT_DEVICE_EXACT; rtx_batch_exact_matches returns them) -- on a handle without that table, or with the option off,
  * NULL means that no query has an exact match. */
+/* The upload in two halves, so that the NEXT batch can cross PCIe while the current one is classified (rtx_raxtax does this with its
+ * chunks; raxtax.rs:35-36: the reference's workers pick up their next chunk without waiting for anybody either):
+ *   rtx_batch_prefetch  validates and stages a batch beside the current one: bases packed two per byte (4-bit codes, parser.rs:11-34)
+ *                       into page-locked memory, asynchronous H2D on a stream of its own.  Returns when the host buffers may be reused.
+ *   rtx_batch_activate  makes the staged batch the current one (the handle's stream waits for the transfer, the host does not): call
+ *                       it once the batch before it has been downloaded, then rtx_batch_run.
+ * rtx_batch_upload = prefetch + activate. */
+int rtx_batch_prefetch(rtx_index *index, uint64_t n_queries, const uint8_t *bases, const uint64_t *base_off,
+                       const uint32_t *exact_ids, const uint64_t *exact_off);
+int rtx_batch_activate(rtx_index *index);
+/* The packing rtx_batch_prefetch applies, on its own (no device involved): packed[i] = bases[2 i] | bases[2 i + 1] << 4 for n_bases
+ * codes (an odd last one alone in its byte; packed holds (n_bases + 1) / 2 bytes).  Returns 1, or 0 if a byte above 15 was seen --
+ * no code of parser.rs:11-34; rtx_batch_prefetch sends such a batch as it is. */
+int rtx_pack_bases(const uint8_t *bases, uint64_t n_bases, uint8_t *packed);
 int rtx_classify_batch(rtx_index *index, uint64_t n_queries, const uint8_t *bases,
                        const uint64_t *base_off, const uint32_t *exact_ids,
                        const uint64_t *exact_off, uint32_t flags, rtx_result_view *out);

@@ -129,6 +129,9 @@ _SIGNATURES = {
     "rtx_raxtax": (C.c_int, None),  # argtypes set in api.py (callback type)
     "rtx_raxtax_multi": (C.c_int, None),
     "rtx_sender_discard": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p, C.c_char_p]),
+    "rtx_batch_prefetch": (C.c_int, [C.c_void_p, C.c_uint64, u8p, u64p, u32p, u64p]),
+    "rtx_batch_activate": (C.c_int, [C.c_void_p]),
+    "rtx_pack_bases": (C.c_int, [u8p, C.c_uint64, u8p]),
     "rtx_batch_sub_batch": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "rtx_raxtax_last_timing": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
     "rtx_set_host_share": (C.c_int, [C.c_uint32]),

@@ -269,6 +269,12 @@ class Index:
     # ---- staged interface -------------------------------------------------------------
     def upload(self, bases: np.ndarray, base_off: np.ndarray, exact_ids: Optional[np.ndarray] = None,
                exact_off: Optional[np.ndarray] = None):
+        self.prefetch(bases, base_off, exact_ids, exact_off)
+        self.activate()
+
+    def prefetch(self, bases: np.ndarray, base_off: np.ndarray, exact_ids: Optional[np.ndarray] = None,
+                 exact_off: Optional[np.ndarray] = None):
+        """Stages a batch beside the current one (rtx_batch_prefetch): packed, pinned, asynchronous H2D; activate() makes it current."""
         bases = np.ascontiguousarray(bases, dtype=np.uint8)
         base_off = np.ascontiguousarray(base_off, dtype=np.uint64)
         n_q = len(base_off) - 1
@@ -276,11 +282,13 @@ class Index:
             exact_off = np.ascontiguousarray(exact_off, dtype=np.uint64)
             exact_ids = np.ascontiguousarray(exact_ids if exact_ids is not None and len(exact_ids) else
                                              np.zeros(1, np.uint32), dtype=np.uint32)
-            check(self._lib.rtx_batch_upload(self._h, n_q, ptr(bases, u8p), ptr(base_off, u64p), ptr(exact_ids, u32p),
-                                             ptr(exact_off, u64p)))
+            check(self._lib.rtx_batch_prefetch(self._h, n_q, ptr(bases, u8p), ptr(base_off, u64p), ptr(exact_ids, u32p),
+                                               ptr(exact_off, u64p)))
         else:
-            check(self._lib.rtx_batch_upload(self._h, n_q, ptr(bases, u8p), ptr(base_off, u64p), None, None))
-        self._keep = (bases, base_off, exact_ids, exact_off)
+            check(self._lib.rtx_batch_prefetch(self._h, n_q, ptr(bases, u8p), ptr(base_off, u64p), None, None))
+
+    def activate(self):
+        check(self._lib.rtx_batch_activate(self._h))
 
     def run(self, flags: int = 0):
         check(self._lib.rtx_batch_run(self._h, flags))

@@ -130,25 +130,40 @@ int run(rtx_index *const *indices, uint32_t n_dev, const rtx_tree *tree, uint64_
         }
     });
 
+    // The device stage of a handle: activate -> run -> STAGE THE NEXT CHUNK -> download.  The queries of chunk c + n_dev are packed (two
+    // bases per byte, pinned memory) and cross PCIe on the handle's transfer stream while the kernels of chunk c run
+    // (rtx_batch_prefetch / rtx_batch_activate): the reference's workers pick up their next chunk without a pause either (raxtax.rs:35-36).
+    auto stage_chunk = [&](uint32_t d, uint64_t c) -> int {
+        Chunk &ch = chunks[c];
+        if (dev_lookup[d]) return rtx_batch_prefetch(indices[d], ch.nq, bases, base_off + ch.q0, nullptr, nullptr);
+        return rtx_batch_prefetch(indices[d], ch.nq, bases, base_off + ch.q0, ch.exact_ids.empty() ? nullptr : ch.exact_ids.data(), ch.exact_off.data());
+    };
     auto device_loop = [&](uint32_t d) {
+        bool staged = false;
         for (uint64_t c = d; c < n_chunks; c += n_dev) {
             if (!wait_stage(c, 1)) return;
             if (c >= ahead && !wait_stage(c - ahead, 3)) return;  // the result set of this handle's second-last chunk is reused now
             Chunk &ch = chunks[c];
             const double t_d0 = now();
-            int rc;
-            if (dev_lookup[d]) {
-                rc = rtx_classify_batch(indices[d], ch.nq, bases, base_off + ch.q0, nullptr, nullptr, flags, &ch.res);
+            int rc = staged ? RTX_OK : stage_chunk(d, c);
+            staged = false;
+            if (!rc) rc = rtx_batch_activate(indices[d]);
+            if (!rc) rc = rtx_batch_run(indices[d], flags);
+            const uint64_t nxt = c + n_dev;
+            if (!rc && nxt < n_chunks) {
+                if (!wait_stage(nxt, 1)) return;   // its exact-match ids (host lookup), ready long ago as a rule
+                rc = stage_chunk(d, nxt);
+                staged = !rc;
+            }
+            if (!rc) rc = rtx_batch_download(indices[d], &ch.res);
+            if (!rc && dev_lookup[d]) {
                 const uint64_t *xo = nullptr;
                 const uint32_t *xi = nullptr;
-                if (!rc) rc = rtx_batch_exact_matches(indices[d], &xo, &xi);
+                rc = rtx_batch_exact_matches(indices[d], &xo, &xi);
                 if (!rc) {  // copied: the format thread reads them while the next chunk is classified
                     ch.exact_off.assign(xo, xo + ch.nq + 1);
                     ch.exact_ids.assign(xi, xi + xo[ch.nq]);
                 }
-            } else {
-                rc = rtx_classify_batch(indices[d], ch.nq, bases, base_off + ch.q0, ch.exact_ids.empty() ? nullptr : ch.exact_ids.data(),
-                                        ch.exact_off.data(), flags, &ch.res);
             }
             if (rc) { fail(rc, rtx_last_error()); return; }
             busy_device[d] += now() - t_d0;

@@ -200,9 +200,25 @@ struct rtx_index {
     DevBuf<uint32_t> d_sidx, d_perm, d_iperm;
     DevBuf<uint8_t> d_sort_tmp;
     PinBuf<uint32_t> h_perm, h_inv;
-    DevBuf<uint8_t> d_bases;
-    DevBuf<uint64_t> d_base_off, d_exact_off;
-    DevBuf<uint32_t> d_exact_ids;
+    DevBuf<uint8_t> d_bases;  // the current batch, one byte per base (what the kernels read): unpacked from the staged transfer at activation
+    // Two input sets: a batch is STAGED (rtx_batch_prefetch: bases packed two per byte into pinned memory, offsets, exact-match ids;
+    // asynchronous H2D on h2d_stream) while the batch before it runs out of the other set, and becomes the current one at
+    // rtx_batch_activate.  rtx_batch_upload = prefetch + activate.
+    struct Inputs {
+        DevBuf<uint8_t> d_packed;          // bases two per byte (or raw, one per byte, if a byte above 15 was seen)
+        DevBuf<uint64_t> d_base_off, d_exact_off;
+        DevBuf<uint32_t> d_exact_ids;
+        PinBuf<uint8_t> h_packed;
+        PinBuf<uint64_t> h_base_off, h_exact_off;
+        PinBuf<uint32_t> h_exact_ids;
+        uint64_t n_q = 0, total = 0, max_len = 0, n_exact = 0;
+        bool packed = true, has_exact = false, staged = false, recorded = false;
+        hipEvent_t ready = nullptr;        // its transfer has arrived
+    } in[2];
+    uint32_t cur_in = 0;               // the set of the current (activated) batch
+    hipStream_t h2d_stream = nullptr;
+    hipEvent_t ev_activated = nullptr; // on the handle's stream, behind everything that was enqueued before the current batch was activated:
+                                       // the kernels that read the OTHER input set have run when it fires (a transfer into that set waits for it)
     uint64_t sum_query_bytes = 0;
     uint32_t kstride = 0, rstride = 0, hstride = 0, tmax = 0;
     int planes = 10;
@@ -270,6 +286,10 @@ struct rtx_index {
     ~rtx_index() {
         for (auto e : events) (void)hipEventDestroy(e);
         for (auto e : ev_sub) (void)hipEventDestroy(e);
+        for (auto &i : in)
+            if (i.ready) (void)hipEventDestroy(i.ready);
+        if (ev_activated) (void)hipEventDestroy(ev_activated);
+        if (h2d_stream) (void)hipStreamDestroy(h2d_stream);
         if (copy_stream) (void)hipStreamDestroy(copy_stream);
         if (stream) (void)hipStreamDestroy(stream);
     }
@@ -334,7 +354,7 @@ static KmerParams kmer_params(rtx_index *ix, const SubBatch &b) {
     rtx_index::Scratch &sc = ix->sc[b.set];
     KmerParams kp{};
     kp.bases = ix->d_bases.p;
-    kp.base_off = ix->d_base_off.p;
+    kp.base_off = ix->in[ix->cur_in].d_base_off.p;
     kp.q0 = b.q0;
     kp.perm = ix->d_perm.p;
     kp.row_of = ix->d_row_of.p;
@@ -406,7 +426,7 @@ int enqueue_hit(rtx_index *ix, const SubBatch &b, uint32_t flags, hipStream_t s,
     hp.flags = flags;
     hp.q0 = b.q0;
     hp.perm = ix->d_perm.p;
-    hp.exact = ExactRef{ix->d_exact_ids.p, ix->d_exact_off.p, ix->dev_exact_used ? ix->d_exact_grp.p : nullptr, ix->d_em_goff.p, ix->d_em_gids.p};
+    hp.exact = ExactRef{ix->in[ix->cur_in].d_exact_ids.p, ix->in[ix->cur_in].d_exact_off.p, ix->dev_exact_used ? ix->d_exact_grp.p : nullptr, ix->d_em_goff.p, ix->d_em_gids.p};
     hp.nq = b.nq;
     hp.group_rows = ix->pair_used ? ix->d_group_rows.p : nullptr;
     hp.group_base = b.sb * ix->groups_per_sub;
@@ -626,9 +646,9 @@ int order_batch(rtx_index *ix, bool cluster) {
             return RTX_ERR_HIP;
         }
         if (ix->d_sort_tmp.n < tmp && (rc = ix->d_sort_tmp.alloc(tmp + 256))) return rc;
-        launch_sketch(ix->stream, ix->d_bases.p, ix->d_base_off.p, n, ix->d_skey_in.p, ix->d_sidx.p);
+        launch_sketch(ix->stream, ix->d_bases.p, ix->in[ix->cur_in].d_base_off.p, n, ix->d_skey_in.p, ix->d_sidx.p);
         if (ix->d_loc_table.p && ix->locator_opt)
-            launch_locator(ix->stream, ix->d_bases.p, ix->d_base_off.p, n, ix->d_loc_table.p, ix->n_total, ix->d_skey_in.p);
+            launch_locator(ix->stream, ix->d_bases.p, ix->in[ix->cur_in].d_base_off.p, n, ix->d_loc_table.p, ix->n_total, ix->d_skey_in.p);
         tmp = ix->d_sort_tmp.n;
         if (cluster_sort(ix->stream, ix->d_sort_tmp.p, &tmp, ix->d_skey_in.p, ix->d_skey_out.p, ix->d_sidx.p, ix->d_perm.p, n)) {
             set_error("radix sort of the query sketches failed");
@@ -689,7 +709,7 @@ int begin_run(rtx_index *ix, uint32_t *n_sub_out, bool *timed_out, bool cluster)
     }
     ix->n_sub_last = timed ? n_sub : 0;
     if (ix->dev_exact_used) {  // Tree.sequences.get for every query of the batch (raxtax.rs:42), part of the run
-        ExactParams xp{ix->d_bases.p, ix->d_base_off.p, (uint32_t)ix->n_q, ix->d_em_table.p, ix->em_bits, ix->d_em_rep_off.p,
+        ExactParams xp{ix->d_bases.p, ix->in[ix->cur_in].d_base_off.p, (uint32_t)ix->n_q, ix->d_em_table.p, ix->em_bits, ix->d_em_rep_off.p,
                        ix->d_em_rep_bytes.p, ix->d_exact_grp.p, ix->em_hash_mask};
         const bool ev = timed && ix->stage_timing;
         if (ev) RTX_HIP(hipEventRecord(ix->events[(size_t)RTX_STAGE_EXACT_MATCH * 2], ix->stream));  // sub-batch 0
@@ -821,7 +841,6 @@ int prepare_workspace(rtx_index *ix, uint64_t n_queries, uint64_t tmax, uint64_t
     ix->hstride = (uint32_t)align_up(tmax + 1, 8);
     ix->planes = tmax <= 1023 ? 10 : (tmax <= 4095 ? 12 : 16);
     ix->n_q = n_queries;
-    if ((rc = ix->d_exact_off.alloc(n_queries + 1))) return rc;
     if ((rc = ensure_prob_tables(ix))) return rc;
     // ---- per-query results
     if ((rc = ix->d_status.alloc(n_queries)) || (rc = ix->d_t_all.alloc(n_queries)) || (rc = ix->d_nrows_all.alloc(n_queries)) ||
@@ -1542,36 +1561,30 @@ int rtx_index_set_option(rtx_index *index, int option, uint64_t value) {
     return RTX_ERR_INVALID;
 }
 
-int rtx_batch_upload(rtx_index *ix, uint64_t n_queries, const uint8_t *bases, const uint64_t *base_off,
-                     const uint32_t *exact_ids, const uint64_t *exact_off) {
+// Stages a batch in the input set that is NOT the current one: validation, bases packed two per byte into pinned memory (threads of
+// the library's budget), offsets and exact-match ids beside them, asynchronous H2D on a stream of its own.  The batch that is running
+// (or whose results are being downloaded) is not touched: rtx_raxtax stages chunk c + 1 while chunk c is classified.
+int rtx_batch_prefetch(rtx_index *ix, uint64_t n_queries, const uint8_t *bases, const uint64_t *base_off,
+                       const uint32_t *exact_ids, const uint64_t *exact_off) {
     int rc = bind(ix);
     if (rc) return rc;
     if (n_queries == 0 || !base_off || (!bases && base_off[n_queries])) {
         set_error("rtx_batch_upload: invalid argument");
         return RTX_ERR_INVALID;
     }
-    ix->uploaded = ix->ran = ix->synced = false;
+    rtx_index::Inputs &in = ix->in[ix->cur_in ^ 1u];
+    if (!ix->h2d_stream) RTX_HIP(hipStreamCreateWithFlags(&ix->h2d_stream, hipStreamNonBlocking));
+    if (!in.ready) RTX_HIP(hipEventCreateWithFlags(&in.ready, hipEventDisableTiming));
+    if (in.recorded) RTX_HIP(hipEventSynchronize(in.ready));  // the last transfer out of this set's pinned buffers (long done, as a rule)
+    in.staged = false;
+    if (ix->ev_activated) RTX_HIP(hipStreamWaitEvent(ix->h2d_stream, ix->ev_activated, 0));  // the batch that read this set has run
     uint64_t max_len = 0;
     for (uint64_t q = 0; q < n_queries; q++) {
         if (base_off[q + 1] < base_off[q]) { set_error("base_off not monotone at query %llu", (unsigned long long)q); return RTX_ERR_INVALID; }
         max_len = std::max(max_len, base_off[q + 1] - base_off[q]);
     }
     const uint64_t total = base_off[n_queries] - base_off[0];
-    // t <= min(len - 7, 65536); t == 65536 would trip the u16 assert of raxtax.rs:56
-    const uint64_t tmax = max_len >= 8 ? max_len - 7 : 1;
-    if ((rc = prepare_workspace(ix, n_queries, tmax, max_len))) return rc;
-    ix->sum_query_bytes = total;
-
-    // ---- inputs
-    if ((rc = ix->d_bases.alloc(total + 64)) || (rc = ix->d_base_off.alloc(n_queries + 1)))
-        return rc;
-    std::vector<uint64_t> off0(n_queries + 1);
-    for (uint64_t q = 0; q <= n_queries; q++) off0[q] = base_off[q] - base_off[0];
-    RTX_HIP(hipMemcpy(ix->d_bases.p, bases + base_off[0], total, hipMemcpyHostToDevice));
-    RTX_HIP(hipMemcpy(ix->d_base_off.p, off0.data(), (n_queries + 1) * 8, hipMemcpyHostToDevice));
     uint64_t n_exact = 0;
-    ix->dev_exact_used = !exact_off && ix->dev_exact_opt && ix->d_em_table.p && ix->n_refs == ix->n_total;
-    if (ix->dev_exact_used && (rc = ix->d_exact_grp.alloc(n_queries))) return rc;
     if (exact_off) {
         if (exact_off[0] != 0) { set_error("exact_off[0] must be 0"); return RTX_ERR_INVALID; }
         n_exact = exact_off[n_queries];
@@ -1580,14 +1593,77 @@ int rtx_batch_upload(rtx_index *ix, uint64_t n_queries, const uint8_t *bases, co
         if (n_exact && !exact_ids) { set_error("exact_ids is null"); return RTX_ERR_INVALID; }
         for (uint64_t i = 0; i < n_exact; i++)
             if (exact_ids[i] >= ix->n_total) { set_error("exact id %u out of range", exact_ids[i]); return RTX_ERR_INVALID; }
-        RTX_HIP(hipMemcpy(ix->d_exact_off.p, exact_off, (n_queries + 1) * 8, hipMemcpyHostToDevice));
-    } else {
-        RTX_HIP(hipMemset(ix->d_exact_off.p, 0, (n_queries + 1) * 8));
     }
-    if ((rc = ix->d_exact_ids.alloc(n_exact + 1))) return rc;
-    if (n_exact) RTX_HIP(hipMemcpy(ix->d_exact_ids.p, exact_ids, n_exact * 4, hipMemcpyHostToDevice));
+    const uint64_t n_packed = (total + 1) / 2;
+    if ((rc = in.h_packed.resize(total + 64)) || (rc = in.h_base_off.resize(n_queries + 1)) || (rc = in.d_packed.alloc(total + 64)) ||
+        (rc = in.d_base_off.alloc(n_queries + 1)) || (rc = in.d_exact_off.alloc(n_queries + 1)) || (rc = in.d_exact_ids.alloc(n_exact + 1)))
+        return rc;
+    for (uint64_t q = 0; q <= n_queries; q++) in.h_base_off[q] = base_off[q] - base_off[0];
+    // two bases per byte; a byte above 15 is no code of parser.rs:11-34 -- such a batch travels as it is (the kernels see the caller's bytes)
+    in.packed = total == 0 || rtx::pack_nibbles_mt(bases + base_off[0], total, in.h_packed.data(), rtx::host_threads(8u));
+    if (!in.packed) std::memcpy(in.h_packed.data(), bases + base_off[0], total);
+    RTX_HIP(hipMemcpyAsync(in.d_packed.p, in.h_packed.data(), in.packed ? n_packed : total, hipMemcpyHostToDevice, ix->h2d_stream));
+    RTX_HIP(hipMemcpyAsync(in.d_base_off.p, in.h_base_off.data(), (n_queries + 1) * 8, hipMemcpyHostToDevice, ix->h2d_stream));
+    if (exact_off) {
+        if ((rc = in.h_exact_off.resize(n_queries + 1)) || (rc = in.h_exact_ids.resize(n_exact + 1))) return rc;
+        std::memcpy(in.h_exact_off.data(), exact_off, (n_queries + 1) * 8);
+        if (n_exact) std::memcpy(in.h_exact_ids.data(), exact_ids, n_exact * 4);
+        RTX_HIP(hipMemcpyAsync(in.d_exact_off.p, in.h_exact_off.data(), (n_queries + 1) * 8, hipMemcpyHostToDevice, ix->h2d_stream));
+        if (n_exact) RTX_HIP(hipMemcpyAsync(in.d_exact_ids.p, in.h_exact_ids.data(), n_exact * 4, hipMemcpyHostToDevice, ix->h2d_stream));
+    } else {
+        RTX_HIP(hipMemsetAsync(in.d_exact_off.p, 0, (n_queries + 1) * 8, ix->h2d_stream));
+    }
+    RTX_HIP(hipEventRecord(in.ready, ix->h2d_stream));
+    in.recorded = true;
+    in.n_q = n_queries;
+    in.total = total;
+    in.max_len = max_len;
+    in.n_exact = n_exact;
+    in.has_exact = exact_off != nullptr;
+    in.staged = true;
+    return RTX_OK;
+}
+
+// The staged batch becomes the current one: the handle's stream waits for the transfer (the host does not), the workspace is sized
+// for the batch (options that shape it are read here), the bases are unpacked.  The batch before it must have been downloaded.
+int rtx_batch_activate(rtx_index *ix) {
+    int rc = bind(ix);
+    if (rc) return rc;
+    rtx_index::Inputs &in = ix->in[ix->cur_in ^ 1u];
+    if (!in.staged) { set_error("rtx_batch_activate without a staged batch (rtx_batch_prefetch)"); return RTX_ERR_STATE; }
+    ix->uploaded = ix->ran = ix->synced = false;
+    // t <= min(len - 7, 65536); t == 65536 would trip the u16 assert of raxtax.rs:56
+    const uint64_t tmax = in.max_len >= 8 ? in.max_len - 7 : 1;
+    if ((rc = prepare_workspace(ix, in.n_q, tmax, in.max_len))) return rc;
+    ix->sum_query_bytes = in.total;
+    if ((rc = ix->d_bases.alloc(in.total + 64))) return rc;
+    RTX_HIP(hipStreamWaitEvent(ix->stream, in.ready, 0));
+    if (in.packed) {
+        rtx::launch_unpack_nibbles(ix->stream, in.d_packed.p, ix->d_bases.p, in.total, in.total + 64);
+    } else {
+        RTX_HIP(hipMemcpyAsync(ix->d_bases.p, in.d_packed.p, in.total, hipMemcpyDeviceToDevice, ix->stream));
+        RTX_HIP(hipMemsetAsync(ix->d_bases.p + in.total, 0, 64, ix->stream));
+    }
+    ix->dev_exact_used = !in.has_exact && ix->dev_exact_opt && ix->d_em_table.p && ix->n_refs == ix->n_total;
+    if (ix->dev_exact_used && (rc = ix->d_exact_grp.alloc(in.n_q))) return rc;
+    if (!ix->ev_activated) RTX_HIP(hipEventCreateWithFlags(&ix->ev_activated, hipEventDisableTiming));
+    RTX_HIP(hipEventRecord(ix->ev_activated, ix->stream));
+    in.staged = false;
+    ix->cur_in ^= 1u;
     ix->uploaded = true;
     return RTX_OK;
+}
+
+int rtx_pack_bases(const uint8_t *bases, uint64_t n_bases, uint8_t *packed) {
+    if ((!bases || !packed) && n_bases) { set_error("rtx_pack_bases: null argument"); return RTX_ERR_INVALID; }
+    return rtx::pack_nibbles_mt(bases, n_bases, packed, rtx::host_threads(8u)) ? 1 : 0;
+}
+
+int rtx_batch_upload(rtx_index *ix, uint64_t n_queries, const uint8_t *bases, const uint64_t *base_off,
+                     const uint32_t *exact_ids, const uint64_t *exact_off) {
+    if (ix) ix->uploaded = ix->ran = ix->synced = false;
+    int rc = rtx_batch_prefetch(ix, n_queries, bases, base_off, exact_ids, exact_off);
+    return rc ? rc : rtx_batch_activate(ix);
 }
 
 int rtx_batch_run(rtx_index *ix, uint32_t flags) {

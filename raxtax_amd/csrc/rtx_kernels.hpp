@@ -68,6 +68,9 @@ struct ExactParams {  // rtx_exact.hip
     uint64_t hash_mask;        // all ones; tests weaken the hash (RTX_DEFAULT_EXACT_HASH_MASK) so that chains and tags collide
 };
 void launch_exact_match(hipStream_t s, const ExactParams &p);
+// rtx_ingest.hip: bases two per byte over PCIe (host packer, device unpacker)
+void launch_unpack_nibbles(hipStream_t s, const uint8_t *packed, uint8_t *bases, uint64_t n_bases, uint64_t n_out);
+bool pack_nibbles_mt(const uint8_t *in, uint64_t n, uint8_t *out, unsigned nt);
 
 struct KmerParams {
     const uint8_t *bases;

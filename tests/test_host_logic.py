@@ -238,3 +238,27 @@ def test_blockwise_query_parsing_equals_whole_file(oracle, block):
     assert len(got) == len(want)
     for (gl, gs), (wl, ws) in zip(got, want):
         assert gl == wl and np.array_equal(gs, ws)
+
+
+def test_pack_bases_two_per_byte():
+    """The packing of the upload (rtx_batch_prefetch: 4-bit codes of parser.rs:11-34, two per byte over PCIe) against numpy, at sizes
+    around the 32-base SSE step and the thread cuts, odd lengths, and a batch with a byte above 15 (reported, sent unpacked)."""
+    import ctypes as C
+
+    from raxtax_amd import _lib
+    from raxtax_amd._lib import ptr, u8p
+
+    lib = _lib.load()
+    rng = np.random.default_rng(5)
+    for n in (0, 1, 2, 31, 32, 33, 63, 64, 65, 1000, (1 << 20) + 77, (3 << 20) + 1):
+        b = rng.integers(0, 16, size=max(n, 1), dtype=np.uint8)[:n]
+        out = np.full((n + 1) // 2 + 8, 0xEE, np.uint8)
+        assert lib.rtx_pack_bases(ptr(b, u8p) if n else None, n, ptr(out, u8p)) == 1
+        pad = np.concatenate([b, np.zeros(n & 1, np.uint8)])
+        want = pad[0::2] | (pad[1::2] << 4)
+        assert np.array_equal(out[: (n + 1) // 2], want), n
+        assert (out[(n + 1) // 2:] == 0xEE).all(), n          # nothing written behind the packed bytes
+    bad = rng.integers(0, 16, size=(1 << 20) + 5, dtype=np.uint8)
+    bad[777_777] = 0x41
+    out = np.zeros(len(bad) // 2 + 8, np.uint8)
+    assert lib.rtx_pack_bases(ptr(bad, u8p), len(bad), ptr(out, u8p)) == 0

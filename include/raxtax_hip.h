@@ -363,6 +363,9 @@ int rtx_debug_kmers(rtx_index *index, uint64_t query, uint16_t *kmers /*cap 6553
 int rtx_debug_hit_counts(rtx_index *index, uint64_t query, uint16_t *counts /*n_refs*/);
 int rtx_debug_prob_table(rtx_index *index, uint64_t query, double *table_over_z /*t+1*/, double *z);
 int rtx_debug_probs(rtx_index *index, uint64_t query, double *probs /*n_refs*/);
+/* tile pruning: the largest bound of every tile of 8192 references as the bounds pass left it for a query of the last sub-batch
+ * (what prune_kernel's tile-aware threshold and the live masks are derived from); RTX_ERR_STATE if the last run did not prune */
+int rtx_debug_tile_bounds(rtx_index *index, uint64_t query, uint16_t *tile_ub /*ceil(n_refs / 8192)*/);
 /* processing order of the last run (RTX_OPT_CLUSTER / RTX_OPT_LOCATOR): perm[position] = query */
 int rtx_debug_order(rtx_index *index, uint32_t *perm /*n_queries*/);
 /* queries per sub-batch of the uploaded batch and the number of sub-batches: positions [(n_sub - 1) * sub_batch, n_queries) of the

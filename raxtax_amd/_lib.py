@@ -118,6 +118,7 @@ _SIGNATURES = {
     "rtx_debug_pruned_prob_table": (C.c_int, [C.c_void_p, C.c_uint64, f64p, f64p, u32p]),
     "rtx_debug_probs": (C.c_int, [C.c_void_p, C.c_uint64, f64p]),
     "rtx_debug_order": (C.c_int, [C.c_void_p, u32p]),
+    "rtx_debug_tile_bounds": (C.c_int, [C.c_void_p, C.c_uint64, u16p]),
     "rtx_debug_prune_stats": (C.c_int, [C.c_void_p, u64p]),
     "rtx_debug_run_counts": (C.c_int, [C.c_void_p, C.c_uint64, u16p, u8p, u32p, u32p, u32p]),
     "rtx_debug_prune_detail": (C.c_int, [C.c_void_p, C.c_uint64, u32p]),

@@ -382,6 +382,12 @@ class Index:
         check(self._lib.rtx_debug_run_counts(self._h, q, ptr(counts, u16p), ptr(live, u8p), ptr(hist, u32p), C.byref(thr), C.byref(i1)))
         return dict(counts=counts, tile_live=live.astype(bool), hist=hist, threshold=int(thr.value), i1=int(i1.value))
 
+    def debug_tile_bounds(self, q: int) -> np.ndarray:
+        """The largest bound of every tile as the bounds pass left it for query q of the last sub-batch."""
+        out = np.zeros((self.n_refs + 8191) // 8192, dtype=np.uint16)
+        check(self._lib.rtx_debug_tile_bounds(self._h, q, ptr(out, u16p)))
+        return out
+
     def debug_prune_detail(self, q: int) -> dict:
         """prune_kernel's view of query q (Index(debug_taps=True)): best block, its exact counts, M, threshold, i* + 1."""
         out = np.zeros(72, dtype=np.uint32)

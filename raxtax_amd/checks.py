@@ -45,15 +45,21 @@ def rows_of(res, q):
 
 
 
-def emul_threshold(emul, lf, t, n_refs, block_counts, tab_tmax=1023):
-    """(u, i* + 1) of rtx_emul.cpp's restatement of prune_kernel's step 3."""
+def emul_threshold(emul, lf, t, n_refs, block_counts, tab_tmax=1023, tile_ub=None):
+    """(u, i* + 1) of rtx_emul.cpp's restatement of prune_kernel's step 3: criterion (3) from the best block alone (reference shards),
+    or -- given the largest bound of every tile -- the tile-aware criterion (4) of a whole-database handle."""
     import ctypes as C
 
     hm = np.zeros(64, np.uint32)
     hm[: len(block_counts)] = block_counts
     u, i1 = C.c_uint32(), C.c_uint32()
-    emul.emul_prune_threshold(C.c_uint32(t), C.c_uint64(n_refs), hm.ctypes.data_as(C.c_void_p), lf.ctypes.data_as(C.c_void_p),
-                              C.c_uint32(tab_tmax), C.byref(u), C.byref(i1))
+    if tile_ub is None:
+        emul.emul_prune_threshold(C.c_uint32(t), C.c_uint64(n_refs), hm.ctypes.data_as(C.c_void_p), lf.ctypes.data_as(C.c_void_p),
+                                  C.c_uint32(tab_tmax), C.byref(u), C.byref(i1))
+    else:
+        ub = np.ascontiguousarray(tile_ub, dtype=np.uint16)
+        emul.emul_prune_threshold_tiles(C.c_uint32(t), C.c_uint64(n_refs), hm.ctypes.data_as(C.c_void_p), lf.ctypes.data_as(C.c_void_p),
+                                        C.c_uint32(tab_tmax), C.c_uint32(len(ub)), ub.ctypes.data_as(C.c_void_p), C.byref(u), C.byref(i1))
     return int(u.value), int(i1.value)
 
 
@@ -109,7 +115,10 @@ def check_run_as_left(index, j, t, counts_o, p_o, n_refs, emul=None, lf=None, la
         assert np.array_equal(det["block_counts"], blk), f"{label}: exact counts of the best block {b}"
         assert det["M"] == int(blk.max()) and det["t"] == t and det["threshold"] == thr
         assert det["largest_bound"] >= int(counts_o.max()), f"{label}: the largest bound lies below a count"
-        u_e, i1_e = emul_threshold(emul, lf, t, n_refs, blk)
+        tile_ub = index.debug_tile_bounds(j) if getattr(index, "tile_aware_threshold", True) else None
+        if tile_ub is not None:   # the bounds are bounds: every tile's largest count lies at or below its bound
+            assert (tile_ub.astype(np.int64) >= tile_max_o).all(), f"{label}: a tile bound lies below a count of the tile"
+        u_e, i1_e = emul_threshold(emul, lf, t, n_refs, blk, tile_ub=tile_ub)
         assert (u_e, i1_e) == (thr, rc["i1"]), f"{label}: kernel threshold {(thr, rc['i1'])}, CPU restatement {(u_e, i1_e)}"
     return out
 

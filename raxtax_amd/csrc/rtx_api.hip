@@ -497,6 +497,7 @@ int enqueue_hit(rtx_index *ix, const SubBatch &b, uint32_t flags, hipStream_t s,
         pr.perm = ix->d_perm.p;
         pr.exact = hp.exact;
         pr.lnfact = ix->d_lnfact.p;
+        pr.inv = ix->d_inv.p;
         pr.hist = sc.d_hist.p;
         pr.hstride = ix->hstride;
         pr.live = sc.d_live.p;
@@ -2290,6 +2291,17 @@ int rtx_debug_prune_detail(rtx_index *ix, uint64_t query, uint32_t *out) {
         return RTX_ERR_STATE;
     }
     RTX_HIP(hipMemcpy(out, ix->d_prune_detail.p + (size_t)slot * kPruneDetailWords, kPruneDetailWords * 4, hipMemcpyDeviceToHost));
+    return RTX_OK;
+}
+
+int rtx_debug_tile_bounds(rtx_index *ix, uint64_t query, uint16_t *tile_ub) {
+    uint32_t slot;
+    int rc = debug_slot_as_run(ix, query, &slot);
+    if (rc) return rc;
+    if (!tile_ub) { set_error("null argument"); return RTX_ERR_INVALID; }
+    rtx_index::Scratch &sc = ix->sc[ix->last_set];
+    if (!ix->prune_used || sc.d_tile_ub.n < (size_t)(slot + 1) * ix->ntiles) { set_error("rtx_debug_tile_bounds: the last run did not prune"); return RTX_ERR_STATE; }
+    RTX_HIP(hipMemcpy(tile_ub, sc.d_tile_ub.p + (size_t)slot * ix->ntiles, (size_t)ix->ntiles * 2, hipMemcpyDeviceToHost));
     return RTX_OK;
 }
 

@@ -308,9 +308,13 @@ static void emul_ln_cmf_row(uint32_t t, uint32_t m, const double *lf, std::vecto
 // with the largest bound (0: no reference / zeroed).  Same inequalities, same tables; only the order of the sums over the
 // lanes differs.  The GPU tests hold the kernel's (u, i* + 1) against this, the CPU tests hold this against the oracle on
 // adversarial histograms (tests/test_prune_threshold_cpu.py).
-void emul_prune_threshold(uint32_t t, uint64_t n_refs, const uint32_t *hm_in, const double *lf, uint32_t tab_tmax, uint32_t *u_out,
-                          uint32_t *i1_out) {
-    const double kLnEps = -27.631021115928547;  // ln 1e-12 (kPruneLnEps)
+// n_groups = 0: the criterion "(3)" -- every reference of the database priced at the candidate threshold (reference shards: every
+// shard must arrive at the same threshold, and a shard knows only its own tiles).  n_groups > 0: the tile-aware criterion "(4)" of a
+// whole-database handle: gub[g] = the largest bound of group g of tiles (every count of its gn[g] references is at most that), the
+// dropped references are priced at min(u, gub), the kept ones number at most the references of the groups with gub > u.
+static void emul_prune_threshold_x(uint32_t t, uint64_t n_refs, const uint32_t *hm_in, const double *lf, uint32_t tab_tmax, uint32_t n_groups,
+                                   const uint32_t *gub, const uint64_t *gn, uint32_t *u_out, uint32_t *i1_out) {
+    const double kLnEps = kPruneLnEpsHD;
     const uint32_t n = t >> 1;
     uint32_t hm[64], M = 0;
     for (int l = 0; l < 64; l++) { hm[l] = hm_in[l]; M = std::max(M, hm[l]); }
@@ -351,7 +355,15 @@ void emul_prune_threshold(uint32_t t, uint64_t n_refs, const uint32_t *hm_in, co
         if (!(up < dn && ln_len + ln_pmf_tab(lf, t, n, u, i1, ln_total) + ln_n <= kLnEps)) { first_fail = u; break; }
     }
     uint32_t u_max = first_fail - 1u;
-    {   // the tighter criterion ("(3)" in rtx_prune.hip): window W = i1 .. i1 + 62 (lanes 0 .. 62), lane 63 = the tail point i1 + 63
+    {   // the tighter criteria ("(3)" and "(4)" in rtx_prune.hip): window W = i1 .. i1 + 62 (lanes 0 .. 62), lane 63 = the tail point i1 + 63
+        // (4): the kept references number at most those of the groups whose bound lies above the threshold of (2) -- every later candidate is larger
+        double kept = (double)n_refs;
+        if (n_groups) {
+            kept = 0.0;
+            for (uint32_t g = 0; g < n_groups; g++)
+                if (gub[g] > u_max) kept += (double)gn[g];
+        }
+        const double ln_kept = log(kept > 1.0 ? kept : 1.0);
         double WA[64], WB[64], ww[64], gw[64];
         for (uint32_t l = 0; l < 64; l++) {
             const uint32_t iw = i1 + l;
@@ -361,7 +373,7 @@ void emul_prune_threshold(uint32_t t, uint64_t n_refs, const uint32_t *hm_in, co
             for (int h = 0; h < 64; h++)
                 if (hm[h]) lnG += rows[h][iw];
             gw[l] = exp(lnG);
-            ww[l] = exp(std::min(0.0, ln_n + lnG));
+            ww[l] = exp(std::min(0.0, ln_kept + lnG));
         }
         double incl = 0.0, a_tot = 0.0;
         for (uint32_t l = 0; l < 64; l++) a_tot += ww[l];
@@ -375,6 +387,12 @@ void emul_prune_threshold(uint32_t t, uint64_t n_refs, const uint32_t *hm_in, co
         }
         const double nn = (double)n_refs;
         const bool has_tail = i1 + 63u <= n;
+        // (4): S_A, S_B of every group at its own bound (capped below min H: a group above it is never dead)
+        std::vector<double> gsa(n_groups, 0.0), gsb(n_groups, 0.0), inv(t + n + 2, 0.0);
+        for (uint32_t x = 1; x <= t + n; x++) inv[x] = 1.0 / (double)x;
+        for (uint32_t g = 0; g < n_groups; g++)
+            prune_window_sums(lf, inv.data(), t, n, std::min(gub[g], h_min - 1u), i1, ln_total, [&](uint32_t l) { return WA[l]; },
+                              [&](uint32_t l) { return WB[l]; }, gsa[g], gsb[g]);
         auto crit = [&](uint32_t u) {
             double a = 0.0, b = 0.0;
             for (uint32_t l = 0; l < 64; l++) {
@@ -387,7 +405,14 @@ void emul_prune_threshold(uint32_t t, uint64_t n_refs, const uint32_t *hm_in, co
                 const uint32_t j = i1 + 63u;
                 falling = (double)(u + j) * (double)(n - j) < (double)(j + 1u) * (double)(t - u + n - j - 1u);
             }
-            return falling && nn * a <= 0.5e-12 && nn * b <= 0.5e-12;
+            if (!n_groups) return falling && nn * a <= kPruneHalfEpsHD && nn * b <= kPruneHalfEpsHD;
+            double ta = 0.0, tb = 0.0;
+            for (uint32_t g = 0; g < n_groups; g++) {
+                const bool dead = gub[g] <= u;
+                ta += (double)gn[g] * (dead ? gsa[g] : a);
+                tb += (double)gn[g] * (dead ? gsb[g] : b);
+            }
+            return falling && ta <= kPruneHalfEpsHD && tb <= kPruneHalfEpsHD;
         };
         uint32_t lo2 = u_max, hi2 = h_min - 1u;
         while (lo2 < hi2) {
@@ -398,6 +423,26 @@ void emul_prune_threshold(uint32_t t, uint64_t n_refs, const uint32_t *hm_in, co
     }
     *u_out = u_max;
     *i1_out = u_max ? i1 : 0u;
+}
+
+void emul_prune_threshold(uint32_t t, uint64_t n_refs, const uint32_t *hm_in, const double *lf, uint32_t tab_tmax, uint32_t *u_out,
+                          uint32_t *i1_out) {
+    emul_prune_threshold_x(t, n_refs, hm_in, lf, tab_tmax, 0, nullptr, nullptr, u_out, i1_out);
+}
+// The tile-aware criterion from the largest bound of every TILE of 8192 references (what the bounds pass leaves): the tiles are taken in
+// groups of ceil(ntiles / 64) consecutive ones, as the 64 lanes of prune_kernel take them.
+void emul_prune_threshold_tiles(uint32_t t, uint64_t n_refs, const uint32_t *hm_in, const double *lf, uint32_t tab_tmax, uint32_t ntiles,
+                                const uint16_t *tile_ub, uint32_t *u_out, uint32_t *i1_out) {
+    const uint32_t per = (ntiles + 63u) / 64u, ng = (ntiles + per - 1u) / per;
+    std::vector<uint32_t> gub(ng, 0);
+    std::vector<uint64_t> gn(ng, 0);
+    for (uint32_t T = 0; T < ntiles; T++) {
+        const uint32_t g = T / per;
+        gub[g] = std::max<uint32_t>(gub[g], tile_ub[T]);
+        const uint64_t lo = (uint64_t)T * 8192u, hi = std::min<uint64_t>(lo + 8192u, n_refs);
+        gn[g] += hi > lo ? hi - lo : 0u;
+    }
+    emul_prune_threshold_x(t, n_refs, hm_in, lf, tab_tmax, ng, gub.data(), gn.data(), u_out, i1_out);
 }
 
 // Bit layout of the bitmap rows (rtx_math.hpp ref_slot) and its inverse as hit_count / seg_emit use it:

@@ -262,6 +262,64 @@ __device__ __forceinline__ void hit_epilogue_x(const HitParams &p, uint32_t (&pl
         wave_lds_sync();
     };
 
+    // ---- a pruned query (threshold u = h_thr) whose tile turns out to hold no count above u: nothing of this tile can reach the
+    // result -- prob_lookup writes 0 into the table entries up to u, taxon_prefix leaves out every tile whose largest count is at most
+    // u -- so nothing is unpacked, stored or histogrammed: the references go to bin 0 as one number, the tile keeps a largest count
+    // of 0 and its live bit is cleared (the taps then see a tile that was never counted, which is what its outputs are).  The test
+    // works on the bit planes: count = dense part (planes) + sparse part (byte counters, at most `smax` = the OR of all of them), so
+    // no count exceeds u if no dense part exceeds u - smax -- a comparison of bit-sliced numbers with a constant, ~3 operations per
+    // plane and word.  Queries far from their best hit keep tens of tiles live of which a tenth hold such a count (the bounds of the
+    // union bitmap are loose there): their epilogues were a third of the counting pass.
+    if (kFullTile && h_thr) {
+        uint32_t smax = 0;
+        if (lists) {
+            sparse_hits(0u);
+            if (p.flags & RTX_SKIP_EXACT_MATCHES) {  // raxtax.rs:65-68: the sparse part
+                const uint64_t qin = p.perm[p.q0 + q];
+                uint64_t e0, e1;
+                const uint32_t *xids;
+                exact_range(p.exact, qin, e0, e1, xids);
+                for (uint64_t e = e0 + lane; e < e1; e += 64) {
+                    const uint32_t id = xids[e] - p.ref_base;
+                    if (id < p.n_refs && (id >> 13) == tile) reinterpret_cast<uint8_t *>(cnt8)[id & 8191u] = 0;
+                }
+                wave_lds_sync();
+            }
+            uint32_t orw = 0;
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const uint4 v = reinterpret_cast<const uint4 *>(cnt8)[i * 64 + lane];
+                orw |= (v.x | v.y) | (v.z | v.w);
+            }
+            orw |= orw >> 16;  // per byte position the OR of this lane's counters: at least each of them
+            smax = wave_max_u32((orw | (orw >> 8)) & 0xFFu);
+        }
+        bool any = smax >= h_thr;  // wave-uniform
+        if (!any) {
+            const uint32_t c = h_thr - smax;  // is any dense count > c ?
+            uint32_t gt_any = 0;
+#pragma unroll
+            for (int w = 0; w < 4; w++) {
+                uint32_t gt = 0, eq = 0xFFFFFFFFu;
+#pragma unroll
+                for (int b = NP - 1; b >= 0; b--) {
+                    const uint32_t cb = (c >> b) & 1u ? 0xFFFFFFFFu : 0u;  // scalar
+                    gt |= eq & pl[w][b] & ~cb;
+                    eq &= ~(pl[w][b] ^ cb);
+                }
+                gt_any |= gt;
+            }
+            any = __ballot(active && gt_any != 0u) != 0ull;
+        }
+        if (!any) {
+            if (lane == 0u) {
+                const uint32_t in_tile = (((uint64_t)tile + 1u) << 13) <= p.n_refs ? 8192u : (uint32_t)(p.n_refs - ((uint64_t)tile << 13));
+                atomicAdd(&p.hist[(size_t)q * p.hstride], in_tile);
+                atomicAnd(const_cast<uint32_t *>(p.live) + (size_t)q * p.live_words + (tile >> 5), ~(1u << (tile & 31u)));
+            }
+            return;
+        }
+    }
     for (uint32_t i = lane; i <= t; i += 64) hist_lds[i] = 0;
     wave_lds_sync();
     // tile pruning gave the query a threshold u: every count up to u is a reference without a hit to prob_lookup (rtx_prob_tables.hip) --
@@ -303,7 +361,7 @@ __device__ __forceinline__ void hit_epilogue_x(const HitParams &p, uint32_t (&pl
     for (int i = 0; i < 8; i++) hiw[i] = 0;
 #pragma unroll
     for (int half = 0; half < 2; half++) {  // groups 0-7 = references 0..4095 of a full tile, groups 8-15 = 4096..8191
-        if (lists && (!kFullTile || half == 0)) {
+        if (lists && (kFullTile ? (half == 0 && !h_thr) : true)) {  // (a pruned query's full-tile epilogue has scanned them above)
             sparse_hits((uint32_t)half);
             if (p.flags & RTX_SKIP_EXACT_MATCHES) {  // raxtax.rs:65-68: the sparse part
                 const uint64_t qin = p.perm[p.q0 + q];

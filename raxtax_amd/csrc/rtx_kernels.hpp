@@ -186,7 +186,7 @@ struct PruneParams {
     uint64_t q0;
     const uint32_t *perm;
     ExactRef exact;
-    const double *lnfact;
+    const double *lnfact, *inv;   // ln x!, 1 / x
     uint32_t *hist;           // [B][hstride]: bin 0 receives the references of the tiles that are not counted
     uint32_t hstride;
     uint32_t *live;           // [B][live_words] bit T: tile T is counted for the query

@@ -336,6 +336,39 @@ RTX_HD bool group_negligible(const double *lf, uint32_t t, uint32_t n, uint32_t 
     return log((double)(n - i_lo + 1)) + ln_pmf_tab(lf, t, n, m_hi, i_lo, ln_total) < kLnTailSkip;
 }
 
+// Budget of the tile pruning (rtx_prune.hip): every probability and every sum of probabilities over any set of references moves by at
+// most a few eps.  Round 3 ran with eps = 1e-12; 1e-10 keeps four orders of magnitude to north_star's 1e-6 (and the 1e-9 the parity
+// tests assert) and is worth ~12 counts of threshold at t ~ 640.
+constexpr double kPruneEpsHD = 1e-10;
+constexpr double kPruneLnEpsHD = -23.025850929940457;  // ln 1e-10
+constexpr double kPruneHalfEpsHD = 0.5e-10;
+
+// ---------------------------------------------------------------------------
+// Tile pruning, the tile-aware criterion (rtx_prune.hip, "(4)"): the window sums  S_A(m) = sum_l pmf_m(i1 + l) WA(l)  and
+// S_B(m) = sum_l pmf_m(i1 + l) WB(l)  over l = 0 .. 63 (i1 + l <= n) for ONE count m, pmf_m advanced by its exact ratio
+//     pmf_m(i + 1) / pmf_m(i) = (m + i)(n - i) / ((i + 1)(t - m + n - i - 1))
+// from exp(ln pmf_m(i1)) (clamped from below at e^-700: a larger start only makes the criterion stricter).  In the kernel a lane
+// runs this loop for the largest bound of its group of tiles; `wa(l)`, `wb(l)` hand out the weights of lane l (v_readlane there,
+// array reads in the emulation).  m = 0: pmf_0 is the point mass at i = 0 < i1, both sums are 0.
+// ---------------------------------------------------------------------------
+template <class WAf, class WBf>
+RTX_HD void prune_window_sums(const double *lf, const double *inv, uint32_t t, uint32_t n, uint32_t m, uint32_t i1, double ln_total,
+                              WAf wa, WBf wb, double &sa, double &sb) {
+    sa = 0.0;
+    sb = 0.0;
+    const bool ok = m != 0u && m < t;   // (no early exit: in the kernel the loop below is wave-uniform, the weights come by v_readlane)
+    const uint32_t ms = ok ? m : 1u;
+    double x0 = ln_pmf_tab(lf, t, n, ms, i1, ln_total);
+    if (x0 < -700.0) x0 = -700.0;
+    double P = ok ? exp(x0) : 0.0;
+    for (uint32_t l = 0; l < 64u && i1 + l <= n; l++) {
+        sa += P * wa(l);
+        sb += P * wb(l);
+        const uint32_t i = i1 + l;  // -> i + 1 (unused behind the last step)
+        if (i < n) P *= ((double)(ms + i) * inv[i + 1u]) * ((double)(n - i) * inv[t - ms + n - i - 1u]);
+    }
+}
+
 // prob.rs:105-119 with the table
 RTX_HD double only_last_pmf_tab(const double *lf, uint32_t t, uint32_t n, uint32_t m, double ln_total) {
     if (m == t) return 1.0;

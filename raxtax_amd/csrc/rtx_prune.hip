@@ -35,6 +35,19 @@
 //     pmf_u over the rest of W + R, R = (n - i_w) pmf_u(i_w + 1) >= tail_u(i_w) once pmf_u falls there (lane 63), and searches the
 //     largest u below min H with N [sum_W min(1, N G) S_u + R] <= eps / 2 and N [sum_W G pmf_u + R] <= eps / 2 by bisection, starting
 //     from the u of (2) (a valid threshold on its own).  On the bench workload u rises from ~365 to ~440 (t ~ 640, best hit ~580).
+//     (4) The tile-aware version of (3) (round 4; whole-database handles -- a reference shard knows only its own tiles and must arrive at
+//     the threshold of every other shard, it stays with (3)).  (3) prices EVERY reference of the database at the candidate u.  But the
+//     bounds pass has left ub(T), the largest bound of every tile: a reference of tile T has a count of at most ub(T), and the tiles of
+//     unrelated clades lie far below any threshold.  With c_T = min(u, ub(T)) for the dropped references of tile T (E[G(X_m); X > i*] and
+//     tail_m rise with the count m) and K = the kept references (count > u: they live in tiles with ub(T) > u, so K <= the references of
+//     those tiles <= the references of the tiles with ub(T) > the u of (2)):
+//       beta  <= sum_T n_T sum_{i>i*} G(i) pmf_{c_T}(i),     gamma <= Z' [ sum_{i in W} min(1, K G(i)) TAIL(i) + TAIL(end of W) ],
+//       TAIL(i) = sum_T n_T tail_{c_T}(i).
+//     The weights of (3) with K in the place of N, and in the place of N S(u):  sum_T n_T S(min(u, ub(T))),  S(m) = sum_l pmf_m(i_l) W(l).
+//     Lane g takes a group of ceil(ntiles / 64) consecutive tiles (the largest of their bounds, the sum of their references) and runs
+//     the window once for its bound, pmf advanced by its exact ratio (prune_window_sums, rtx_math.hpp); a candidate costs the two wave
+//     sums of (3) for S(u) and two more over the groups.  Worth ~ +15 counts at t ~ 640 on top of eps = 1e-10 (+12 over round 3's 1e-12):
+//     tests/test_prune_threshold_cpu.py fills every dead tile to its bound and every live one to the threshold.
 // A tile is dead for a query if u >= 1 and ub(T) <= u (a query without a threshold has every tile counted); a (pair, tile)
 // block of hit_count_pair_kernel leaves at once if the tile is dead for both queries.  The references that are never counted
 // are booked into histogram bin 0: cmf_0 = 1, so they drop out of every product -- the approximation bounded in (2) -- and
@@ -49,8 +62,8 @@
 
 namespace rtx {
 
-static constexpr double kPruneLnEps = -27.631021115928547;  // ln 1e-12
-static constexpr double kPruneHalfEps = 0.5e-12;
+static constexpr double kPruneLnEps = kPruneLnEpsHD;  // ln eps, eps = 1e-10 (rtx_math.hpp: the budget of the pruning)
+static constexpr double kPruneHalfEps = kPruneHalfEpsHD;
 #ifndef RTX_PRUNE_WAVES
 #define RTX_PRUNE_WAVES 4
 #endif
@@ -251,6 +264,24 @@ __global__ __launch_bounds__(64, RTX_PRUNE_WAVES) void prune_kernel(PruneParams 
                     // the two sums are sum_l pmf_u(i_l) WA(l) and sum_l pmf_u(i_l) WB(l) with weights that do not depend on u:
                     // one exp and two wave sums per candidate.
                     {
+                        // (4): lane g <-> group g of `per` consecutive tiles: the largest bound, the references; K = those of the groups above the u of (2)
+                        const bool tile_aware = p.phase == 0u;
+                        uint32_t gub = 0;
+                        double gnd = 0.0;
+                        {
+                            const uint32_t per = (p.ntiles + 63u) >> 6;
+                            for (uint32_t k = 0; k < per; k++) {
+                                const uint32_t T = lane * per + k;
+                                if (T < p.ntiles) {
+                                    const uint32_t b = ub_lds[x * p.ntiles + T];
+                                    gub = b > gub ? b : gub;
+                                    const uint64_t lo = (uint64_t)T * 8192u, hi = lo + 8192u < p.n_refs ? lo + 8192u : p.n_refs;
+                                    gnd += (double)(hi - lo);
+                                }
+                            }
+                        }
+                        const double kept = tile_aware ? wave_sum_f64_dpp(gub > u_max ? gnd : 0.0) : (double)p.n_total;
+                        const double ln_kept = log(kept > 1.0 ? kept : 1.0);
                         const uint32_t iw = i1 + lane;
                         const bool tail_pt = lane == 63u;
                         const bool vi = iw <= n;
@@ -263,7 +294,7 @@ __global__ __launch_bounds__(64, RTX_PRUNE_WAVES) void prune_kernel(PruneParams 
                             lnG += Ct[(size_t)m * (n + 1) + (vi ? iw : n)];
                         }
                         const double gw = vi && !tail_pt ? exp(lnG) : 0.0;                         // G(i)
-                        const double ww = vi && !tail_pt ? exp(fmin(0.0, ln_n + lnG)) : 0.0;      // min(1, N G(i))
+                        const double ww = vi && !tail_pt ? exp(fmin(0.0, ln_kept + lnG)) : 0.0;   // min(1, K G(i)), K = N for a shard
                         const double incl = wave_incl_scan_f64_dpp(ww);
                         const double a_tot = readlane_f64(incl, 63);
                         const double len_tail = vi ? (double)(n - iw + 1u) : 0.0;                 // lane 63: the values of i from j on
@@ -271,6 +302,13 @@ __global__ __launch_bounds__(64, RTX_PRUNE_WAVES) void prune_kernel(PruneParams 
                         const double WB = tail_pt ? len_tail : gw;
                         const double nn = (double)p.n_total;
                         const bool has_tail = i1 + 63u <= n;  // wave-uniform
+                        // (4): the window sums of every group at its own bound (capped below min H: a group above it is never dead)
+                        double gsa = 0.0, gsb = 0.0;
+                        if (tile_aware) {
+                            const uint32_t gcap = gub < h_min ? gub : h_min - 1u;
+                            prune_window_sums(lf, p.inv, t, n, gcap, i1, ln_total, [&](uint32_t l) { return readlane_f64(WA, (int)l); },
+                                              [&](uint32_t l) { return readlane_f64(WB, (int)l); }, gsa, gsb);
+                        }
                         auto crit = [&](uint32_t u) -> bool {
                             const double P = vi ? exp(ln_pmf_tab(lf, t, n, u, iw, ln_total)) : 0.0;  // pmf_u(i_l)
                             bool falling = true;
@@ -278,7 +316,10 @@ __global__ __launch_bounds__(64, RTX_PRUNE_WAVES) void prune_kernel(PruneParams 
                                 const uint32_t j = i1 + 63u;
                                 falling = (double)(u + j) * (double)(n - j) < (double)(j + 1u) * (double)(t - u + n - j - 1u);
                             }
-                            return falling && nn * wave_sum_f64_dpp(P * WA) <= kPruneHalfEps && nn * wave_sum_f64_dpp(P * WB) <= kPruneHalfEps;
+                            const double a = wave_sum_f64_dpp(P * WA), b = wave_sum_f64_dpp(P * WB);
+                            if (!tile_aware) return falling && nn * a <= kPruneHalfEps && nn * b <= kPruneHalfEps;
+                            const bool dead = gub <= u;
+                            return falling && wave_sum_f64_dpp(gnd * (dead ? gsa : a)) <= kPruneHalfEps && wave_sum_f64_dpp(gnd * (dead ? gsb : b)) <= kPruneHalfEps;
                         };
                         uint32_t lo = u_max, hi = h_min - 1u;
                         while (lo < hi) {  // wave-uniform

@@ -6,13 +6,17 @@
 at the top and EVERY other reference of the database exactly at the threshold u (or spreads them just below it), for databases
 of up to 5 M references.  Treating the counts up to u as references without a hit -- what prob_lookup does for a pruned query,
 emulated by `emul_prob_lookup_pruned` -- must leave every probability, and every sum of probabilities over any set of
-references (the prefix sums of lineage.rs:61-66), within 1e-11 of the oracle's full computation; north_star allows 1e-6."""
+references (the prefix sums of lineage.rs:61-66), within 1e-9 of the oracle's full computation; north_star allows 1e-6.
+
+The tile-aware criterion of a whole-database handle ("(4)" in rtx_prune.hip, `emul_prune_threshold_tiles`) knows the largest bound of
+every tile of 8192 references; there the adversary fills every dead tile with references exactly AT its bound and every live tile with
+references at the threshold (or just above it)."""
 import ctypes as C
 
 import numpy as np
 import pytest
 
-TOL = 1e-11          # proved: a few eps, eps = 1e-12 (rtx_prune.hip)
+TOL = 1e-9           # proved: a few eps, eps = 1e-10 (rtx_math.hpp: kPruneEpsHD; round 3 ran with 1e-12 and asserted 1e-11)
 TAB_TMAX = 1023
 
 
@@ -29,6 +33,16 @@ def threshold(emul, lf, t, n_refs, block_counts):
     return int(u.value), int(i1.value)
 
 
+def threshold_tiles(emul, lf, t, n_refs, block_counts, tile_ub):
+    hm = np.zeros(64, np.uint32)
+    hm[: len(block_counts)] = block_counts
+    ub = np.ascontiguousarray(tile_ub, dtype=np.uint16)
+    u, i1 = C.c_uint32(), C.c_uint32()
+    emul.emul_prune_threshold_tiles(C.c_uint32(t), C.c_uint64(n_refs), hm.ctypes.data_as(C.c_void_p), lf.ctypes.data_as(C.c_void_p),
+                                    C.c_uint32(TAB_TMAX), C.c_uint32(len(ub)), ub.ctypes.data_as(C.c_void_p), C.byref(u), C.byref(i1))
+    return int(u.value), int(i1.value)
+
+
 def pruned_table(emul, lf, t, n_refs, hist, u, i1):
     tz = np.zeros(t + 1)
     z, gs = C.c_double(), C.c_double()
@@ -39,10 +53,10 @@ def pruned_table(emul, lf, t, n_refs, hist, u, i1):
     return tz, z.value, gs.value
 
 
-def check_histogram(emul, oracle, lf, t, counts, block, label):
+def check_histogram(emul, oracle, lf, t, counts, block, label, thr=None):
     """counts: u16 [N] with the block's references among them.  Returns (u, worst error)."""
     n_refs = len(counts)
-    u, i1 = threshold(emul, lf, t, n_refs, block)
+    u, i1 = thr if thr is not None else threshold(emul, lf, t, n_refs, block)
     if u == 0:
         return 0, 0.0
     hist = np.bincount(counts, minlength=t + 1).astype(np.uint32)
@@ -149,3 +163,53 @@ def test_random_cases(emul, oracle, seed):
             counts = np.concatenate([block, rest(n_refs - n_h)]).astype(np.uint16)
             check_histogram(emul, oracle, lf, t, counts, block, f"t={t} N={n_refs} M={M} |H|={n_h}")
     assert n_thr >= 5
+
+
+TILE_CASES = [  # t, tiles, best hit as a share of t, size of H, tiles whose bound lies near the threshold
+    (640, 62, 0.90, 5, 3), (640, 62, 0.75, 12, 6), (640, 62, 0.55, 8, 20), (640, 62, 0.43, 8, 40), (640, 611, 0.9, 12, 9),
+    (195, 14, 0.93, 20, 6), (195, 62, 0.7, 6, 30), (900, 30, 0.8, 3, 4), (64, 12, 0.95, 4, 2), (640, 8, 0.6, 2, 8),
+]
+
+
+@pytest.mark.parametrize("t,ntiles,best,n_h,n_near", TILE_CASES)
+def test_tile_aware_threshold_against_tiles_filled_to_their_bounds(emul, oracle, t, ntiles, best, n_h, n_near):
+    """Criterion "(4)": the threshold from the best block AND the largest bound of every tile.  The adversary respects the bounds and
+    nothing else: every reference of a dead tile sits exactly at the tile's bound, every reference of a live tile at the threshold
+    (or a third of them just above it: kept, they carry the density of the pruned Z); far tiles, tiles just below the threshold, tiles
+    just above it.  The threshold must lie at or above the one of criterion (3) and keep every error within the budget."""
+    rng = np.random.default_rng(t * 7 + ntiles + n_h)
+    n_refs = ntiles * 8192 - 1234
+    lf = _lnfact(oracle, 2 * t + 8)
+    M = int(best * t)
+    block = np.sort(rng.integers(int(0.8 * M) + 1, M + 1, n_h).astype(np.uint32))[::-1].copy()
+    block[0] = M
+    u3, _ = threshold(emul, lf, t, n_refs, block)
+    if u3 == 0:
+        pytest.skip(f"no threshold for t={t} M={M}")
+    worst, gains = 0.0, []
+    for spread in (4, 25, 80):       # how far the near tiles' bounds lie from the threshold of (3)
+        ub = rng.integers(min(20, u3), max(int(0.55 * u3), 21), ntiles)                    # far tiles: unrelated clades
+        near = rng.choice(np.arange(1, ntiles), min(n_near, ntiles - 1), replace=False)
+        ub[near] = np.clip(u3 + rng.integers(-spread, spread + 1, len(near)), 1, int(0.8 * M))
+        ub[0] = min(M + 40, t)                                                             # the tile of the best block
+        u, i1 = threshold_tiles(emul, lf, t, n_refs, block, ub)
+        assert u >= u3, (u, u3)
+        gains.append(u - u3)
+        size = np.minimum(8192, n_refs - np.arange(ntiles) * 8192)
+        for pattern in range(3):
+            counts = np.empty(n_refs, np.uint16)
+            for T in range(ntiles):
+                lo, hi = T * 8192, T * 8192 + int(size[T])
+                if ub[T] <= u:
+                    counts[lo:hi] = ub[T]                                                  # dead: everything at the bound
+                elif pattern == 0:
+                    counts[lo:hi] = u                                                      # live: everything at the threshold
+                elif pattern == 1:
+                    counts[lo:hi] = np.where(np.arange(hi - lo) % 3 == 0, min(u + 1 + T % 5, int(ub[T]), int(0.8 * M)), u)
+                else:
+                    counts[lo:hi] = rng.integers(0, min(u, int(ub[T])) + 1, hi - lo)
+            counts[: len(block)] = block                                                   # H lives in tile 0
+            u2, err = check_histogram(emul, oracle, lf, t, counts, block, f"t={t} tiles={ntiles} M={M} |H|={n_h} spread {spread} pattern {pattern}",
+                                      thr=(u, i1))
+            worst = max(worst, err)
+    print(f"t={t} tiles={ntiles} M={M} |H|={n_h}: criterion (3) u={u3}, tile-aware +{gains} counts, worst error {worst:.2e}")

@@ -455,7 +455,12 @@ def extras_block(args, rx, lib, index, tree, db, qs, flags):
         rx._lib.check(lib.rtx_raxtax(index._h, tree._h, n_q, labels, rx._lib.ptr(bases, rx._lib.u8p), rx._lib.ptr(off, rx._lib.u64p),
                                      int(bool(flags)), 0, args.e2e_chunk, discard, ctypes.cast(counted, ctypes.c_void_p), 0))
     dt = timed(e2e)
+    busy = (ctypes.c_double * 4)()
+    n_chunks = ctypes.c_uint64()
+    rx._lib.check(lib.rtx_raxtax_last_timing(busy, ctypes.byref(n_chunks)))
     out["value_end_to_end"] = {"value": n_q / dt, "ms_per_step": dt * 1e3, "steps": steps, "chunk_size": args.e2e_chunk,
+                               "chunks": int(n_chunks.value),
+                               "busy_ms_last_call": {"host_lookup": busy[0] * 1e3, "device_stage": busy[1] * 1e3, "format": busy[2] * 1e3, "sender": busy[3] * 1e3},
                                "text_bytes_per_query": counted[1] / max(counted[0], 1),
                                "what": "rtx_raxtax: host buffers -> H2D -> exact-match lookup + classification on the device -> D2H -> override + "
                                        "formatting of the .out lines (raxtax.rs:73-87) -> sender (discards: no disk); pipelined over chunks"}

@@ -282,6 +282,10 @@ struct rtx_index {
     PinBuf<unsigned long long> h_hq, h_row_start;
     uint32_t stage_timing = 0;  // 0: HIP events around hit_count only; 1: around every kernel
     PinBuf<DevRow> h_arena;
+    // per node: expected vector and first level of the local signal (node_tables; finalise_range)
+    std::vector<double> h_node_expd;
+    std::vector<uint8_t> h_node_sig0;
+    uint32_t h_node_stride = 1;
 
     ~rtx_index() {
         for (auto e : events) (void)hipEventDestroy(e);
@@ -904,22 +908,11 @@ int alloc_scratch_set(rtx_index *ix, uint32_t k) {
     return RTX_OK;
 }
 
-// lineage.rs:91-110 for the rows of one query: expected vectors, stable descending sort by
-// confidence vector, local signal (utils.rs:91-105).
-struct HostRow {
-    uint32_t node, depth;
-    double conf[RTX_MAX_DEPTH], expd[RTX_MAX_DEPTH];
-};
-
-bool conf_less(const HostRow &a, const HostRow &b) {  // a < b, lexicographic, shorter prefix smaller
-    const uint32_t n = std::min(a.depth, b.depth);
-    for (uint32_t i = 0; i < n; i++) {
-        if (a.conf[i] < b.conf[i]) return true;
-        if (a.conf[i] > b.conf[i]) return false;
-    }
-    return a.depth < b.depth;
-}
-
+// lineage.rs:91-110 for the rows of one query: expected vectors, stable descending sort by confidence vector, local signal
+// (utils.rs:91-105).  The device hands a row over as {node, confidence per level in hundredths}; everything that depends on the node
+// alone -- depth, the expected vector (|range| / N per level, lineage.rs:137-139), the level the local signal starts at
+// (lineage.rs:95-98) -- is tabulated once per handle (node_tables), so that a row costs a handful of loads: real barcodes return ten
+// rows per query where the synthetic workload returns one, and the finalisation must keep up with the device there too.
 double euclidean_distance_l1(const double *a, const double *b, uint32_t n) {  // utils.rs:91-105
     if (n == 0) return 0.0;
     double a_sum = 0.0, b_sum = 0.0;
@@ -933,13 +926,35 @@ double euclidean_distance_l1(const double *a, const double *b, uint32_t n) {  //
     return std::sqrt(s);
 }
 
+void node_tables(rtx_index *ix) {  // expd[node][d], local-signal start per node
+    const FlatNodes &f = ix->nodes;
+    const uint32_t D = std::max(1u, f.max_depth), nn = f.size();
+    ix->h_node_stride = D;
+    ix->h_node_expd.assign((size_t)nn * D, 0.0);
+    ix->h_node_sig0.assign(nn, 0);
+    const double N = (double)ix->n_total;
+    for (uint32_t v = 0; v < nn; v++) {
+        const uint32_t depth = f.depth[v];
+        double *e = ix->h_node_expd.data() + (size_t)v * D;
+        uint32_t anc = v;
+        for (int d = (int)depth - 1; d >= 0; d--) {
+            e[d] = (double)(f.end[anc] - f.begin[anc]) / N;
+            anc = f.parent[anc];
+        }
+        uint32_t s0 = depth ? depth - 1 : 0;  // lineage.rs:95-98: the first level whose expected share is below 1, else the last
+        for (uint32_t d = 0; d < depth; d++)
+            if (1.0 > e[d]) { s0 = d; break; }
+        ix->h_node_sig0[v] = (uint8_t)s0;
+    }
+}
+
 // Host finalisation of the queries at positions [pa, pb) of the processing order; their rows go to
 // [row_base, ...) of the host row arrays in that order.
 void finalise_range(rtx_index *ix, uint64_t pa, uint64_t pb, uint64_t row_base) {
     rtx_index::HostRes &hr = ix->host_res[ix->res_set];
     const FlatNodes &f = ix->nodes;
-    const double N = (double)ix->n_total;
-    std::vector<HostRow> rows;
+    const uint32_t D = ix->h_node_stride;
+    std::vector<uint32_t> ord;
     uint64_t o = row_base;
     for (uint64_t pos = pa; pos < pb; pos++) {
         const uint64_t q = ix->h_perm[pos];  // the device records are in processing order
@@ -949,32 +964,27 @@ void finalise_range(rtx_index *ix, uint64_t pa, uint64_t pb, uint64_t row_base) 
         const uint32_t nr = ix->h_n_rows[pos];
         hr.v_row_begin[q] = o;
         hr.v_row_count[q] = nr;
-        rows.resize(nr);
         const DevRow *src = ix->h_arena.data() + ix->h_row_start[pos];
-        for (uint32_t r = 0; r < nr; r++) {
-            HostRow &h = rows[r];
-            h.node = src[r].node;
-            h.depth = f.depth[h.node];
-            uint32_t anc = h.node;
-            for (int d = (int)h.depth - 1; d >= 0; d--) {
-                h.conf[d] = (double)src[r].k[d] / 100.0;  // == round(x*100)/100, lineage.rs:128-129
-                h.expd[d] = (double)(f.end[anc] - f.begin[anc]) / N;  // lineage.rs:137-139
-                anc = f.parent[anc];
-            }
+        ord.resize(nr);
+        for (uint32_t r = 0; r < nr; r++) ord[r] = r;
+        if (nr > 1) {
+            // stable, descending by confidence vector, a shorter prefix smaller (lineage.rs:91-93): the hundredths order like the values
+            std::stable_sort(ord.begin(), ord.end(), [&](uint32_t x, uint32_t y) {  // true: x comes first = y < x
+                const uint32_t dx = f.depth[src[x].node], dy = f.depth[src[y].node], n = std::min(dx, dy);
+                const int c = n ? std::memcmp(src[y].k, src[x].k, n) : 0;  // bytes compare like the numbers they hold
+                return c ? c < 0 : dy < dx;
+            });
         }
-        // stable, descending (lineage.rs:91-93)
-        std::stable_sort(rows.begin(), rows.end(), [](const HostRow &a, const HostRow &b) { return conf_less(b, a); });
         for (uint32_t r = 0; r < nr; r++, o++) {
-            const HostRow &h = rows[r];
+            const DevRow &h = src[ord[r]];
+            const uint32_t depth = f.depth[h.node];
             hr.v_row_lineage[o] = f.begin[h.node];
             hr.v_row_node[o] = h.node;
-            hr.v_row_depth[o] = h.depth;
-            double *c = hr.v_row_conf.data() + o * RTX_MAX_DEPTH;
-            for (uint32_t d = 0; d < RTX_MAX_DEPTH; d++) c[d] = d < h.depth ? h.conf[d] : 0.0;
-            uint32_t s = h.depth ? h.depth - 1 : 0;  // lineage.rs:95-98
-            for (uint32_t d = 0; d < h.depth; d++)
-                if (1.0 > h.expd[d]) { s = d; break; }
-            hr.v_row_local[o] = h.depth ? euclidean_distance_l1(h.conf + s, h.expd + s, h.depth - s) : 0.0;
+            hr.v_row_depth[o] = depth;
+            double *c = hr.v_row_conf.data() + o * RTX_MAX_DEPTH;  // (entries from the deepest lineage of the tree on are never written: zero since the resize)
+            for (uint32_t d = 0; d < D; d++) c[d] = d < depth ? (double)h.k[d] / 100.0 : 0.0;  // == round(x*100)/100, lineage.rs:128-129
+            const uint32_t s = ix->h_node_sig0[h.node];
+            hr.v_row_local[o] = depth ? euclidean_distance_l1(c + s, ix->h_node_expd.data() + (size_t)h.node * D + s, depth - s) : 0.0;
         }
     }
 }
@@ -1026,6 +1036,7 @@ static int create_common(int device, uint64_t n_total, uint64_t ref_lo, uint64_t
         set_error("lineage depth %u exceeds RTX_MAX_DEPTH=%u", ix->nodes.max_depth, RTX_MAX_DEPTH);
         return fail(RTX_ERR_DEPTH);
     }
+    node_tables(ix);
     if (hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking) != hipSuccess) {
         set_error("hipStreamCreate failed");
         return fail(RTX_ERR_HIP);
@@ -1766,7 +1777,7 @@ static int download_streamed(rtx_index *ix, rtx_index::HostRes &hr, bool *done, 
         RTX_HIP(hipStreamSynchronize(ix->copy_stream));
         // one thread finalises 8192 queries in ~1.4 ms, about what the device needs for the next sub-batch: with a short
         // last sub-batch the host would still be busy with the one before it when the device is done
-        nrows += finalise_mt(ix, q0, q0 + n, nrows, sb + 1 == n_sub ? 8 : 4);
+        nrows += finalise_mt(ix, q0, q0 + n, nrows, sb + 1 == n_sub ? 16 : 8);
         prev = cur;
     }
     RTX_HIP(hipStreamSynchronize(ix->stream));

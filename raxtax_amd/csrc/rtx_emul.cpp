@@ -387,27 +387,51 @@ static void emul_prune_threshold_x(uint32_t t, uint64_t n_refs, const uint32_t *
         }
         const double nn = (double)n_refs;
         const bool has_tail = i1 + 63u <= n;
-        // (4): S_A, S_B of every group at its own bound (capped below min H: a group above it is never dead)
-        std::vector<double> gsa(n_groups, 0.0), gsb(n_groups, 0.0), inv(t + n + 2, 0.0);
-        for (uint32_t x = 1; x <= t + n; x++) inv[x] = 1.0 / (double)x;
-        for (uint32_t g = 0; g < n_groups; g++)
-            prune_window_sums(lf, inv.data(), t, n, std::min(gub[g], h_min - 1u), i1, ln_total, [&](uint32_t l) { return WA[l]; },
-                              [&](uint32_t l) { return WB[l]; }, gsa[g], gsb[g]);
-        auto crit = [&](uint32_t u) {
-            double a = 0.0, b = 0.0;
+        auto sums_at = [&](uint32_t m, double &a, double &b) {
+            a = b = 0.0;
             for (uint32_t l = 0; l < 64; l++) {
-                const double P = i1 + l <= n ? exp(ln_pmf_tab(lf, t, n, u, i1 + l, ln_total)) : 0.0;
+                const double P = i1 + l <= n && m != 0u ? exp(ln_pmf_tab(lf, t, n, m, i1 + l, ln_total)) : 0.0;
                 a += P * WA[l];
                 b += P * WB[l];
             }
+        };
+        // (4): S_A, S_B of the groups at their own bounds (capped below min H: a group above it is never dead); the groups far below the
+        // threshold of (2) together at S(u_(2) - kPruneFarGap) unless too many lie near (prune_kernel: same rule)
+        std::vector<double> gsa(n_groups, 0.0), gsb(n_groups, 0.0);
+        std::vector<uint8_t> near(n_groups, 0);
+        double far_a = 0.0, far_b = 0.0, n_far = 0.0;
+        if (n_groups) {
+            const uint32_t m_far = u_max > kPruneFarGap ? u_max - kPruneFarGap : 0u;
+            uint32_t n_near = 0;
+            for (uint32_t g = 0; g < n_groups; g++) { near[g] = gn[g] > 0 && gub[g] > m_far; n_near += near[g]; }
+            if (n_near > kPruneMaxNear) {
+                std::vector<double> inv(t + n + 2, 0.0);
+                for (uint32_t x = 1; x <= t + n; x++) inv[x] = 1.0 / (double)x;
+                for (uint32_t g = 0; g < n_groups; g++) {
+                    near[g] = gn[g] > 0;
+                    prune_window_sums(lf, inv.data(), t, n, std::min(gub[g], h_min - 1u), i1, ln_total, [&](uint32_t l) { return WA[l]; },
+                                      [&](uint32_t l) { return WB[l]; }, gsa[g], gsb[g]);
+                }
+            } else {
+                for (uint32_t g = 0; g < n_groups; g++)
+                    if (!near[g]) n_far += (double)gn[g];
+                if (m_far) sums_at(m_far, far_a, far_b);
+                for (uint32_t g = 0; g < n_groups; g++)
+                    if (near[g]) sums_at(std::min(gub[g], h_min - 1u), gsa[g], gsb[g]);
+            }
+        }
+        auto crit = [&](uint32_t u) {
+            double a, b;
+            sums_at(u, a, b);
             bool falling = true;
             if (has_tail) {
                 const uint32_t j = i1 + 63u;
                 falling = (double)(u + j) * (double)(n - j) < (double)(j + 1u) * (double)(t - u + n - j - 1u);
             }
             if (!n_groups) return falling && nn * a <= kPruneHalfEpsHD && nn * b <= kPruneHalfEpsHD;
-            double ta = 0.0, tb = 0.0;
+            double ta = n_far * far_a, tb = n_far * far_b;
             for (uint32_t g = 0; g < n_groups; g++) {
+                if (!near[g]) continue;
                 const bool dead = gub[g] <= u;
                 ta += (double)gn[g] * (dead ? gsa[g] : a);
                 tb += (double)gn[g] * (dead ? gsb[g] : b);

@@ -342,6 +342,8 @@ RTX_HD bool group_negligible(const double *lf, uint32_t t, uint32_t n, uint32_t 
 constexpr double kPruneEpsHD = 1e-10;
 constexpr double kPruneLnEpsHD = -23.025850929940457;  // ln 1e-10
 constexpr double kPruneHalfEpsHD = 0.5e-10;
+constexpr uint32_t kPruneFarGap = 40;    // tile-aware threshold: groups of tiles whose bound lies this far below the threshold of (2) are priced together
+constexpr uint32_t kPruneMaxNear = 12;   // ... unless more groups than this lie nearer: then every group gets the value of its own bound
 
 // ---------------------------------------------------------------------------
 // Tile pruning, the tile-aware criterion (rtx_prune.hip, "(4)"): the window sums  S_A(m) = sum_l pmf_m(i1 + l) WA(l)  and

@@ -302,24 +302,53 @@ __global__ __launch_bounds__(64, RTX_PRUNE_WAVES) void prune_kernel(PruneParams 
                         const double WB = tail_pt ? len_tail : gw;
                         const double nn = (double)p.n_total;
                         const bool has_tail = i1 + 63u <= n;  // wave-uniform
-                        // (4): the window sums of every group at its own bound (capped below min H: a group above it is never dead)
-                        double gsa = 0.0, gsb = 0.0;
+                        auto sums_at = [&](uint32_t m, double &a, double &b) {  // S_A(m), S_B(m): lanes <-> the window, one exp and two wave sums
+                            const double P = vi && m != 0u ? exp(ln_pmf_tab(lf, t, n, m, iw, ln_total)) : 0.0;  // pmf_m(i_l)
+                            a = wave_sum_f64_dpp(P * WA);
+                            b = wave_sum_f64_dpp(P * WB);
+                        };
+                        // (4): the window sums of the groups at their own bounds (capped below min H: a group above it is never dead).  Only the
+                        // groups whose bound lies within kPruneFarGap counts of the threshold of (2) -- the query's own clade and its
+                        // neighbours, a handful -- are worth a value of their own: the others ("far": unrelated clades, S falls by orders of
+                        // magnitude per ten counts) are priced together at S(u_(2) - kPruneFarGap), which bounds each of theirs (S rises with the
+                        // count).  More than kPruneMaxNear near groups (a threshold near the background: everything is "near"): lane g runs the
+                        // window once for its own bound, pmf advanced by its ratio (prune_window_sums), whatever their number.
+                        double gsa = 0.0, gsb = 0.0, far_a = 0.0, far_b = 0.0, n_far = 0.0;
+                        bool near = false;
                         if (tile_aware) {
-                            const uint32_t gcap = gub < h_min ? gub : h_min - 1u;
-                            prune_window_sums(lf, p.inv, t, n, gcap, i1, ln_total, [&](uint32_t l) { return readlane_f64(WA, (int)l); },
-                                              [&](uint32_t l) { return readlane_f64(WB, (int)l); }, gsa, gsb);
+                            const uint32_t m_far = u_max > kPruneFarGap ? u_max - kPruneFarGap : 0u;
+                            near = gnd > 0.0 && gub > m_far;
+                            unsigned long long nb = __ballot(near);
+                            if ((uint32_t)__popcll(nb) > kPruneMaxNear) {
+                                near = gnd > 0.0;
+                                const uint32_t gcap = gub < h_min ? gub : h_min - 1u;
+                                prune_window_sums(lf, p.inv, t, n, gcap, i1, ln_total, [&](uint32_t l) { return readlane_f64(WA, (int)l); },
+                                                  [&](uint32_t l) { return readlane_f64(WB, (int)l); }, gsa, gsb);
+                            } else {
+                                n_far = wave_sum_f64_dpp(near ? 0.0 : gnd);
+                                if (m_far) sums_at(m_far, far_a, far_b);
+                                while (nb) {  // wave-uniform
+                                    const int g = __builtin_ctzll(nb);
+                                    nb &= nb - 1ull;
+                                    const uint32_t m = (uint32_t)__builtin_amdgcn_readlane((int)gub, g);
+                                    double a, b;
+                                    sums_at(m < h_min ? m : h_min - 1u, a, b);
+                                    if ((int)lane == g) { gsa = a; gsb = b; }
+                                }
+                            }
                         }
                         auto crit = [&](uint32_t u) -> bool {
-                            const double P = vi ? exp(ln_pmf_tab(lf, t, n, u, iw, ln_total)) : 0.0;  // pmf_u(i_l)
                             bool falling = true;
                             if (has_tail) {  // pmf_u(j + 1) < pmf_u(j) at j = i1 + 63, and the ratio falls with j
                                 const uint32_t j = i1 + 63u;
                                 falling = (double)(u + j) * (double)(n - j) < (double)(j + 1u) * (double)(t - u + n - j - 1u);
                             }
-                            const double a = wave_sum_f64_dpp(P * WA), b = wave_sum_f64_dpp(P * WB);
+                            double a, b;
+                            sums_at(u, a, b);
                             if (!tile_aware) return falling && nn * a <= kPruneHalfEps && nn * b <= kPruneHalfEps;
                             const bool dead = gub <= u;
-                            return falling && wave_sum_f64_dpp(gnd * (dead ? gsa : a)) <= kPruneHalfEps && wave_sum_f64_dpp(gnd * (dead ? gsb : b)) <= kPruneHalfEps;
+                            return falling && wave_sum_f64_dpp(near ? gnd * (dead ? gsa : a) : 0.0) + n_far * far_a <= kPruneHalfEps &&
+                                   wave_sum_f64_dpp(near ? gnd * (dead ? gsb : b) : 0.0) + n_far * far_b <= kPruneHalfEps;
                         };
                         uint32_t lo = u_max, hi = h_min - 1u;
                         while (lo < hi) {  // wave-uniform

@@ -209,7 +209,7 @@ class Result:
         return out
 
 
-DEFAULT_SEGMENT_CLASSES = 1   # RTX_DEFAULT_SEGMENT_CLASSES of the library (rtx_api.hip: g_seg_classes)
+DEFAULT_SEGMENT_CLASSES = 1   # RTX_DEFAULT_SEGMENT_CLASSES of the library (rtx_api_index.hip: g_seg_classes)
 
 
 class Index:

@@ -1,0 +1,730 @@
+// The per-batch workspace, the upload (rtx_batch_prefetch / rtx_batch_activate) and the kernel sequence of a sub-batch on the handle's HIP
+// stream: order -> kmer_extract -> [pair_union] -> [bounds -> prune -> lists of the live tiles] -> hit_count -> prob -> taxon_prefix + walk.
+#include "rtx_index.hpp"
+
+namespace rtxi {
+
+int bind(rtx_index *ix) {
+    if (!ix) { set_error("null index handle"); return RTX_ERR_INVALID; }
+    RTX_HIP(hipSetDevice(ix->device));
+    return RTX_OK;
+}
+
+int ensure_events(rtx_index *ix, size_t count) {
+    while (ix->events.size() < count) {
+        hipEvent_t e;
+        RTX_HIP(hipEventCreate(&e));
+        ix->events.push_back(e);
+    }
+    return RTX_OK;
+}
+
+
+SubBatch sub_batch_of(rtx_index *ix, uint32_t sb, bool timed) {
+    SubBatch b;
+    b.sb = sb;
+    b.q0 = (uint64_t)sb * ix->sub_batch;
+    b.nq = (uint32_t)std::min<uint64_t>(ix->sub_batch, ix->n_q - b.q0);
+    b.set = ix->staged ? (sb & 1u) : 0u;
+    b.s = ix->stream;
+    b.timed = timed;
+    b.timed_all = timed && ix->stage_timing != 0;
+    return b;
+}
+
+// Counts of a sub-batch between hit_count and taxon_prefix.  With 10 bit planes (t <= 1023) they travel packed,
+// 10 bits per reference: [B][npad] low bytes, then [B][npad / 8] u16 with the two high bits of eight references
+// each; otherwise [B][npad] u16.  Both live in the same allocation (sized for the format in use).
+uint8_t *counts_lo(rtx_index *ix, rtx_index::Scratch &sc) { return reinterpret_cast<uint8_t *>(sc.d_counts.p); }
+uint16_t *counts_hi(rtx_index *ix, rtx_index::Scratch &sc) {
+    return reinterpret_cast<uint16_t *>(reinterpret_cast<uint8_t *>(sc.d_counts.p) + (size_t)ix->sub_batch * ix->npad);
+}
+size_t counts_elems(const rtx_index *ix, uint64_t B) {  // u16 elements of d_counts
+    return ix->packed() ? (size_t)B * ix->npad * 5 / 8 : (size_t)B * ix->npad;
+}
+
+hipEvent_t stage_event(rtx_index *ix, const SubBatch &b, int stage, int which) {
+    return ix->events[((size_t)b.sb * RTX_NUM_STAGES + stage) * 2 + which];
+}
+
+// group 1: kmer_extract + hit_count -> counts, per-shard histogram
+static KmerParams kmer_params(rtx_index *ix, const SubBatch &b) {
+    rtx_index::Scratch &sc = ix->sc[b.set];
+    KmerParams kp{};
+    kp.bases = ix->d_bases.p;
+    kp.base_off = ix->in[ix->cur_in].d_base_off.p;
+    kp.q0 = b.q0;
+    kp.perm = ix->d_perm.p;
+    kp.row_of = ix->d_row_of.p;
+    kp.list_len = ix->d_list_len.p;
+    kp.zero_row = ix->n_rows;
+    kp.kmers = sc.d_kmers.p;
+    kp.kstride = ix->kstride;
+    kp.seginfo = ix->d_seginfo.p;
+    kp.seg_stride = ix->seg_stride;
+    kp.ntiles = ix->ntiles;
+    kp.seg_dbits = ix->d_seg_dbits.p;
+    kp.seg_sbits = ix->d_seg_sbits.p;
+    kp.seg_sbase = ix->d_seg_sbase.p;
+    kp.seg_blocks = ix->seg_blocks;
+    kp.rows = sc.d_rows.p;
+    kp.rstride = ix->rstride;
+    kp.dmask = sc.d_dmask.p;
+    kp.srows = sc.d_srows.p;
+    kp.nsparse = sc.d_nsparse.p;
+    kp.t = sc.d_t.p;
+    kp.nrows = sc.d_nrows.p;
+    kp.hq = ix->d_hq.p;
+    kp.t_all = ix->d_t_all.p;
+    kp.nrows_all = ix->d_nrows_all.p;
+    kp.hist = sc.d_hist.p;  // zeroed by kmer_extract for hit_count's global atomics
+    kp.hstride = ix->hstride;
+    return kp;
+}
+
+int enqueue_kmer(rtx_index *ix, const SubBatch &b, hipStream_t s) {
+    KmerParams kp = kmer_params(ix, b);
+    // with tile pruning the per-tile lists wait until the live tiles are known (enqueue_hit); databases of few tiles build
+    // their lists in one pass per tile whatever is live
+    kp.mode = ix->prune_used && !ix->dbg_full_run && ix->seg_blocks ? 1u : 0u;
+    if (b.timed_all) RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_KMER_EXTRACT, 0), s));
+    launch_kmer_extract(s, kp, b.nq);
+    if (b.timed_all) RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_KMER_EXTRACT, 1), s));
+    return RTX_OK;
+}
+
+// part 0: everything.  A reference shard that prunes stops in the middle for the exchange of the best blocks: part 1 = up to the
+// candidates (bounds pass, prune_kernel phase 1), part 2 = the rest (prune_kernel phase 2, lists of the live tiles, counting).
+int enqueue_hit(rtx_index *ix, const SubBatch &b, uint32_t flags, hipStream_t s, int part) {
+    rtx_index::Scratch &sc = ix->sc[b.set];
+    ix->last_set = b.set;
+    HitParams hp{};
+    hp.bitmap = ix->d_bitmap.p;
+    hp.stride_bytes = ix->stride_bytes;
+    hp.n_rows1 = ix->n_rows + 1;
+    hp.n_refs = ix->n_refs;
+    hp.ref_base = ix->ref_lo;
+    hp.rows = sc.d_rows.p;
+    hp.rstride = ix->rstride;
+    hp.dmask = sc.d_dmask.p;
+    hp.nrows = sc.d_nrows.p;
+    hp.zero_row = ix->n_rows;
+    hp.srows = sc.d_srows.p;
+    hp.nsparse = sc.d_nsparse.p;
+    hp.segslots = ix->d_segslots.p;
+    hp.ntiles = ix->ntiles;
+    hp.t = sc.d_t.p;
+    hp.counts = sc.d_counts.p;
+    hp.counts_lo = ix->packed() ? counts_lo(ix, sc) : nullptr;  // null: u16 counts
+    hp.counts_hi = ix->packed() ? counts_hi(ix, sc) : nullptr;
+    hp.npad = ix->npad;
+    hp.hist = sc.d_hist.p;
+    hp.hstride = ix->hstride;
+    hp.tile_max = sc.d_tilemax.p;
+    hp.flags = flags;
+    hp.q0 = b.q0;
+    hp.perm = ix->d_perm.p;
+    hp.exact = ExactRef{ix->in[ix->cur_in].d_exact_ids.p, ix->in[ix->cur_in].d_exact_off.p, ix->dev_exact_used ? ix->d_exact_grp.p : nullptr, ix->d_em_goff.p, ix->d_em_gids.p};
+    hp.nq = b.nq;
+    hp.group_rows = ix->pair_used ? ix->d_group_rows.p : nullptr;
+    hp.group_base = b.sb * ix->groups_per_sub;
+    hp.pair_urec = sc.d_urec.p;
+    hp.pair_nu = sc.d_nu.p;
+    hp.pair_ustride = 2u * ix->rstride;
+    hp.live = nullptr;
+    hp.live_words = 0;
+    hp.items = nullptr;
+    hp.n_items = nullptr;
+    hp.prune_thr = nullptr;
+    const bool prune = ix->prune_used && !ix->dbg_full_run;
+    if (ix->pair_used && part != 2) {
+        if (b.timed_all) RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_PAIR_UNION, 0), s));
+        launch_pair_union(s, sc.d_rows.p, sc.d_nrows.p, ix->rstride, b.nq, sc.d_urec.p, sc.d_nu.p, 2u * ix->rstride);
+        if (b.timed_all) RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_PAIR_UNION, 1), s));
+    }
+    if (b.timed && !prune) RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_HIT_COUNT, 0), s));
+    if (part != 0 && !prune) { set_error("internal: a split run without tile pruning"); return RTX_ERR_STATE; }
+    if (prune) {
+        // (1) the queries against the union bitmap: every row dense, no lists, packed counts (bounds per block of references)
+        HitParams up = hp;
+        up.bitmap = ix->d_ubitmap.p;
+        up.stride_bytes = ix->u_stride_bytes;
+        up.n_refs = ix->u_nblocks;
+        up.dmask = sc.d_uones.p;
+        up.nsparse = sc.d_uzero.p;
+        up.ntiles = ix->u_ntiles;
+        up.counts = nullptr;  // nothing is stored per block: the epilogue keeps the largest bound per tile and the best block
+        up.counts_lo = nullptr;
+        up.counts_hi = nullptr;
+        up.hist = nullptr;
+        up.tile_max = nullptr;
+        up.bounds_tile_ub = sc.d_tile_ub.p;
+        up.bounds_tile_stride = ix->ntiles;
+        up.bounds_ntiles = ix->ntiles;
+        up.bounds_best = sc.d_best_key.p;
+        up.flags = 0;
+        up.group_base = hp.group_base + ix->n_groups_run;  // work accounting apart from the counting proper
+        if (part != 2) {
+            if (b.timed) RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_TILE_BOUNDS, 0), s));
+            RTX_HIP(hipMemsetAsync(sc.d_best_key.p, 0, (size_t)b.nq * 4, s));  // the waves of a query's union tiles meet in an atomicMax
+            launch_hit_count_pair_bounds(s, up, b.nq, ix->u_ntiles);  // the union of the pair's rows serves both passes
+            if (b.timed) RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_TILE_BOUNDS, 1), s));
+        }
+        if (b.timed && part != 1) RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_TILE_PRUNE, 0), s));
+        // (2) bounds per tile, a lower bound of the best hit, the threshold, the live tiles of every pair
+        PruneParams pr{};
+        pr.tile_ub = sc.d_tile_ub.p;
+        pr.best_key = sc.d_best_key.p;
+        pr.tile_ub_stride = ix->ntiles;
+        pr.ntiles = ix->ntiles;
+        pr.nq = b.nq;
+        pr.n_refs = ix->n_refs;
+        pr.n_total = ix->n_total;
+        pr.ref_base = ix->ref_lo;
+        pr.phase = (uint32_t)part;
+        pr.best = part ? sc.d_best.p : nullptr;
+        pr.bitmap = ix->d_bitmap.p;
+        pr.n_rows1 = ix->n_rows + 1;
+        pr.stride_bytes = ix->stride_bytes;
+        pr.rows = sc.d_rows.p;
+        pr.rstride = ix->rstride;
+        pr.nrows = sc.d_nrows.p;
+        pr.t = sc.d_t.p;
+        pr.flags = flags;
+        pr.q0 = b.q0;
+        pr.perm = ix->d_perm.p;
+        pr.exact = hp.exact;
+        pr.lnfact = ix->d_lnfact.p;
+        pr.inv = ix->d_inv.p;
+        pr.hist = sc.d_hist.p;
+        pr.hstride = ix->hstride;
+        pr.live = sc.d_live.p;
+        pr.live_words = (ix->ntiles + 31u) / 32u + 1u;
+        pr.pair_live = sc.d_items.p + (size_t)((b.nq + 1u) / 2u) * ix->ntiles + 9u;
+        pr.thr_out = sc.d_prune_thr.p;
+        pr.i1_out = sc.d_prune_i1.p;
+        pr.stats = ix->d_prune_stats.p;
+        pr.detail = ix->debug_taps && ix->d_prune_detail.n >= (size_t)b.nq * kPruneDetailWords ? ix->d_prune_detail.p : nullptr;
+        ProbTables tb{ix->d_tab_cmf.p, ix->d_tab_ratio.p, ix->d_tab_off.p, ix->d_tab_moff.p, ix->d_tab_ilo.p, ix->d_tab_sat.p, ix->tab_tmax};
+        launch_prune(s, pr, tb, b.nq);
+        if (part == 1) { RTX_HIP(hipGetLastError()); return RTX_OK; }  // the caller exchanges RTX_BUF_BEST, then part 2
+        // (3) tiles that are not counted keep a largest count of 0: taxon_prefix leaves them out
+        RTX_HIP(hipMemsetAsync(sc.d_tilemax.p, 0, (size_t)b.nq * ix->ntiles * 2, s));
+        hp.live = sc.d_live.p;
+        hp.live_words = pr.live_words;
+        hp.prune_thr = sc.d_prune_thr.p;
+        if (ix->pair_used) {  // the grid of the counting pass walks the live (pair, tile) blocks instead of all of them
+            const size_t np = (b.nq + 1u) / 2u, cap = np * ix->ntiles;
+            launch_live_items(s, sc.d_live.p, pr.live_words, pr.pair_live, b.nq, ix->ntiles, sc.d_items.p + cap + 9u + np, sc.d_items.p, sc.d_items.p + cap);
+            hp.items = sc.d_items.p;
+            hp.n_items = sc.d_items.p + cap;
+        }
+        if (ix->seg_blocks) {  // (4) the row lists of the live tiles (kmer_extract left them out)
+            KmerParams kp = kmer_params(ix, b);
+            kp.mode = 2u;
+            kp.live = sc.d_live.p;
+            kp.live_words = pr.live_words;
+            launch_kmer_extract(s, kp, b.nq);
+        }
+        if (b.timed) {
+            RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_TILE_PRUNE, 1), s));
+            RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_HIT_COUNT, 0), s));
+        }
+    }
+    if (ix->pair_used) launch_hit_count_pair(s, hp, b.nq, ix->ntiles);
+    else launch_hit_count(s, hp, b.nq, ix->ntiles, ix->planes);
+    if (b.timed) RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_HIT_COUNT, 1), s));
+    return RTX_OK;
+}
+
+int enqueue_count(rtx_index *ix, const SubBatch &b, uint32_t flags) {
+    int rc = enqueue_kmer(ix, b, b.s);
+    return rc ? rc : enqueue_hit(ix, b, flags, b.s);
+}
+
+static WalkParams walk_params(rtx_index *ix, const SubBatch &b, const double *prefix);
+
+// group 2: prob table from the (whole-database) histogram + prefix sums over this handle's references; with
+// fuse_walk (whole database on this handle) the taxonomy walk of group 3 runs inside the prefix kernel
+int enqueue_prob_prefix(rtx_index *ix, const SubBatch &b, bool fuse_walk, bool prob_only) {
+    rtx_index::Scratch &sc = ix->sc[b.set];
+    hipStream_t s = b.s;
+    ProbParams pp{};
+    pp.t = sc.d_t.p;
+    pp.hist = sc.d_hist.p;
+    pp.hstride = ix->hstride;
+    pp.tmax = ix->tmax;
+    pp.n1max = ix->tmax / 2 + 1;
+    pp.lnfact = ix->d_lnfact.p;
+    pp.n_refs = ix->n_total;
+    pp.q0 = b.q0;
+    pp.table_z = sc.d_table_z.p;
+    pp.z = ix->d_z.p;
+    pp.gs = ix->d_gs.p;
+    pp.status = ix->d_status.p;
+    pp.ndist = ix->d_ndist.p;
+    pp.prune_thr = ix->prune_used && !ix->dbg_full_run ? sc.d_prune_thr.p : nullptr;
+    pp.prune_i1 = pp.prune_thr ? sc.d_prune_i1.p : nullptr;
+    if (b.timed_all) RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_PROB_TABLE, 0), s));
+    if (ix->use_tables) {
+        ProbTables tb{ix->d_tab_cmf.p, ix->d_tab_ratio.p, ix->d_tab_off.p, ix->d_tab_moff.p,
+                      ix->d_tab_ilo.p, ix->d_tab_sat.p, ix->tab_tmax};
+        launch_prob_order(s, sc.d_t.p, b.nq, sc.d_order.p);
+        pp.order = sc.d_order.p;
+        launch_prob_lookup(s, pp, tb, b.nq);
+    } else {
+        launch_prob_table(s, pp, b.nq);
+    }
+    if (b.timed_all) RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_PROB_TABLE, 1), s));
+    if (prob_only) return RTX_OK;  // debug taps after a pruned run: counts and table again, the result rows stay
+
+    PrefixParams fp{};
+    fp.status = ix->d_status.p;
+    fp.t = sc.d_t.p;
+    fp.tz_in_lds = (size_t)ix->hstride * 8 <= 16 * 1024 ? 1u : 0u;
+    fp.q0 = b.q0;
+    fp.counts = sc.d_counts.p;
+    fp.counts_lo = counts_lo(ix, sc);
+    fp.counts_hi = counts_hi(ix, sc);
+    fp.packed = ix->packed() ? 1u : 0u;
+    fp.npad = ix->npad;
+    fp.table_z = sc.d_table_z.p;
+    fp.hstride = ix->hstride;
+    fp.n_refs = ix->n_refs;
+    fp.bnd_bits = ix->d_bnd_bits.p;
+    fp.bnd_rank = ix->d_bnd_rank.p;
+    fp.prefix = sc.d_prefix.p;
+    fp.n_bnd = ix->n_bnd_local;
+    fp.tile_max = ix->tile_skip ? sc.d_tilemax.p : nullptr;
+    fp.ntiles = ix->ntiles;
+    fp.prune_thr = ix->prune_used && !ix->dbg_full_run ? sc.d_prune_thr.p : nullptr;
+    fp.prune_stats = fp.prune_thr ? ix->d_prune_stats.p + kPruneStatCopies * 8 : nullptr;
+    fp.fuse_walk = fuse_walk ? 1u : 0u;
+    if (fuse_walk) fp.walk = walk_params(ix, b, sc.d_prefix.p);
+    if (b.timed_all) RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_TAXON_PREFIX, 0), s));
+    launch_taxon_prefix(s, fp, b.nq);
+    if (b.timed_all) RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_TAXON_PREFIX, 1), s));
+    return RTX_OK;
+}
+
+// group 3: taxonomy walk over prefix sums covering the WHOLE database ([nq][n_bnd], device)
+static WalkParams walk_params(rtx_index *ix, const SubBatch &b, const double *prefix) {
+    WalkParams wp{};
+    wp.status = ix->d_status.p;
+    wp.q0 = b.q0;
+    wp.prefix = prefix;
+    wp.n_bnd = ix->n_bnd;
+    wp.rec = ix->d_noderec.p;
+    wp.arena = ix->d_arena.p;
+    wp.arena_cap = ix->arena_cap;
+    wp.arena_cursor = ix->d_cursor.p;
+    wp.n_rows = ix->d_n_rows.p;
+    wp.row_start = ix->d_row_start.p;
+    wp.flags_out = ix->d_flags.p;
+    return wp;
+}
+
+int enqueue_walk(rtx_index *ix, const SubBatch &b, const double *prefix, hipStream_t s) {
+    const WalkParams wp = walk_params(ix, b, prefix);
+    if (b.timed_all) RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_LINEAGE_WALK, 0), s));
+    launch_lineage_walk(s, wp, b.nq);
+    if (b.timed_all) RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_LINEAGE_WALK, 1), s));
+    return RTX_OK;
+}
+
+// Processing order of the uploaded batch: related queries next to each other (rtx_cluster.hip), or input order.
+int order_batch(rtx_index *ix, bool cluster) {
+    const uint32_t n = (uint32_t)ix->n_q;
+    int rc;
+    if ((rc = ix->d_perm.alloc(n)) || (rc = ix->d_iperm.alloc(n)) || (rc = ix->h_perm.resize(n)) || (rc = ix->h_inv.resize(n))) return rc;
+    if (cluster && n > 2) {
+        if ((rc = ix->d_skey_in.alloc(n)) || (rc = ix->d_skey_out.alloc(n)) || (rc = ix->d_sidx.alloc(n))) return rc;
+        size_t tmp = 0;
+        if (cluster_sort(ix->stream, nullptr, &tmp, ix->d_skey_in.p, ix->d_skey_out.p, ix->d_sidx.p, ix->d_perm.p, n)) {
+            set_error("radix sort: size query failed");
+            return RTX_ERR_HIP;
+        }
+        if (ix->d_sort_tmp.n < tmp && (rc = ix->d_sort_tmp.alloc(tmp + 256))) return rc;
+        launch_sketch(ix->stream, ix->d_bases.p, ix->in[ix->cur_in].d_base_off.p, n, ix->d_skey_in.p, ix->d_sidx.p);
+        if (ix->d_loc_table.p && ix->locator_opt)
+            launch_locator(ix->stream, ix->d_bases.p, ix->in[ix->cur_in].d_base_off.p, n, ix->d_loc_table.p, ix->n_total, ix->d_skey_in.p);
+        tmp = ix->d_sort_tmp.n;
+        if (cluster_sort(ix->stream, ix->d_sort_tmp.p, &tmp, ix->d_skey_in.p, ix->d_skey_out.p, ix->d_sidx.p, ix->d_perm.p, n)) {
+            set_error("radix sort of the query sketches failed");
+            return RTX_ERR_HIP;
+        }
+        launch_invert_perm(ix->stream, ix->d_perm.p, n, ix->d_iperm.p);
+    } else {
+        launch_identity_perm(ix->stream, n, ix->d_perm.p, ix->d_iperm.p);
+    }
+    RTX_HIP(hipGetLastError());
+    RTX_HIP(hipMemcpyAsync(ix->h_perm.data(), ix->d_perm.p, (size_t)n * 4, hipMemcpyDeviceToHost, ix->stream));
+    RTX_HIP(hipMemcpyAsync(ix->h_inv.data(), ix->d_iperm.p, (size_t)n * 4, hipMemcpyDeviceToHost, ix->stream));
+    return RTX_OK;
+}
+
+int begin_run(rtx_index *ix, uint32_t *n_sub_out, bool *timed_out, bool cluster) {
+    const uint32_t n_sub = (uint32_t)((ix->n_q + ix->sub_batch - 1) / ix->sub_batch);
+    const bool timed = n_sub <= 4096;
+    if (timed) {
+        int rc = ensure_events(ix, (size_t)n_sub * RTX_NUM_STAGES * 2);
+        if (rc) return rc;
+    }
+    const bool ev_all = timed && ix->stage_timing;
+    if (ev_all) RTX_HIP(hipEventRecord(ix->events[(size_t)RTX_STAGE_ORDER * 2], ix->stream));  // sub-batch 0
+    int rc_o = order_batch(ix, cluster);
+    if (rc_o) return rc_o;
+    if (ev_all) RTX_HIP(hipEventRecord(ix->events[(size_t)RTX_STAGE_ORDER * 2 + 1], ix->stream));
+    RTX_HIP(hipMemsetAsync(ix->d_cursor.p, 0, sizeof(unsigned long long), ix->stream));
+    RTX_HIP(hipMemsetAsync(ix->d_flags.p, 0, sizeof(uint32_t), ix->stream));
+    // two neighbours per wave only pays when neighbours are related: with the processing order on
+    ix->pair_used = ix->pair_opt && cluster && ix->planes <= 10 && ix->n_q > 1 && ix->rstride <= 4096;
+    ix->groups_per_sub = (ix->sub_batch + 1u) / 2u;
+    // tile pruning: the pair kernel, the memoised tables (their ln cmf rows give the threshold), taxon_prefix skipping tiles by
+    // their largest count, the whole database on this handle
+    // a whole-database handle driven by rtx_batch_run, or a reference shard that was asked to (RTX_OPT_SHARD_PRUNE: the caller then
+    // drives rtx_shard_bounds and exchanges the best blocks); never a k-mer shard (its counts are partial sums)
+    const bool whole = ix->n_refs == ix->n_total && !ix->staged;
+    const bool shard = ix->staged && ix->shard_prune_opt && ix->n_refs != ix->n_total;
+    auto scratch_ok = [&](const rtx_index::Scratch &sc) {  // sized at the upload / rtx_shard_begin (alloc_scratch_set) for this sub-batch size
+        return sc.d_tile_ub.p != nullptr && sc.d_tile_ub.n >= (size_t)ix->sub_batch * ix->ntiles && sc.d_best_key.n >= ix->sub_batch && sc.d_prune_thr.n >= ix->sub_batch &&
+               sc.d_live.n >= (size_t)(ix->sub_batch + 1u) * ((ix->ntiles + 31u) / 32u + 1u) && sc.d_best.n >= (size_t)ix->sub_batch * kPruneBestWords &&
+               sc.d_items.n >= (size_t)((ix->sub_batch + 1u) / 2u) * (ix->ntiles + 2u) + 9u;
+    };
+    ix->prune_used = ix->prune_opt && ix->pair_used && ix->use_tables && ix->tile_skip && ix->d_ubitmap.p && (whole || shard) &&
+                     scratch_ok(ix->sc[0]) && (!ix->staged || scratch_ok(ix->sc[1]));
+    ix->dbg_full = false;
+    if (ix->prune_used) {
+        int rc_s = ix->d_prune_stats.alloc(kPruneStatCopies * 16);
+        if (!rc_s && ix->debug_taps) rc_s = ix->d_prune_detail.alloc((size_t)ix->sub_batch * kPruneDetailWords);
+        if (rc_s) return rc_s;
+        RTX_HIP(hipMemsetAsync(ix->d_prune_stats.p, 0, kPruneStatCopies * 128, ix->stream));
+    }
+    if (ix->pair_used) {
+        ix->n_groups_run = n_sub * ix->groups_per_sub;
+        int rc_g = ix->d_group_rows.alloc((size_t)2 * n_sub * ix->groups_per_sub);  // second half: the bounds pass of the tile pruning
+        if (rc_g) return rc_g;
+        RTX_HIP(hipMemsetAsync(ix->d_group_rows.p, 0, (size_t)2 * n_sub * ix->groups_per_sub * 4, ix->stream));
+    }
+    ix->n_sub_last = timed ? n_sub : 0;
+    if (ix->dev_exact_used) {  // Tree.sequences.get for every query of the batch (raxtax.rs:42), part of the run
+        ExactParams xp{ix->d_bases.p, ix->in[ix->cur_in].d_base_off.p, (uint32_t)ix->n_q, ix->d_em_table.p, ix->em_bits, ix->d_em_rep_off.p,
+                       ix->d_em_rep_bytes.p, ix->d_exact_grp.p, ix->em_hash_mask};
+        const bool ev = timed && ix->stage_timing;
+        if (ev) RTX_HIP(hipEventRecord(ix->events[(size_t)RTX_STAGE_EXACT_MATCH * 2], ix->stream));  // sub-batch 0
+        launch_exact_match(ix->stream, xp);
+        if (ev) RTX_HIP(hipEventRecord(ix->events[(size_t)RTX_STAGE_EXACT_MATCH * 2 + 1], ix->stream));
+    }
+    *n_sub_out = n_sub;
+    *timed_out = timed;
+    return RTX_OK;
+}
+
+// Enqueues every kernel of the uploaded batch (whole-database handle), sub-batch after sub-batch on the handle's stream.
+// (Round 2 also offered side streams -- the two small latency-bound kernels, or prob/prefix/walk of sub-batch i, beside the
+// counting of sub-batch i + 1: no gain on MI355X in any arrangement, hit_count holds every wave slot of the chip; DESIGN.md
+// section 3.  Removed in round 3.)
+int enqueue_batch(rtx_index *ix, uint32_t flags) {
+    if (ix->n_refs != ix->n_total) {
+        set_error("this handle holds a reference shard: drive it with rtx_shard_count/_prob/_walk");
+        return RTX_ERR_STATE;
+    }
+    uint32_t n_sub = 0;
+    bool timed = false;
+    int rc = begin_run(ix, &n_sub, &timed, ix->cluster != 0);
+    if (rc) return rc;
+    ix->stream_dl = false;
+    if (n_sub <= 4096) {  // per sub-batch: completion event (+ cursor snapshot) for the streamed download
+        if (!ix->copy_stream) RTX_HIP(hipStreamCreateWithFlags(&ix->copy_stream, hipStreamNonBlocking));
+        while (ix->ev_sub.size() < n_sub) {
+            hipEvent_t e;
+            RTX_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            ix->ev_sub.push_back(e);
+        }
+        if ((rc = ix->h_cursor_sub.resize(n_sub))) return rc;
+        ix->n_sub_run = n_sub;
+        ix->stream_dl = true;
+    }
+    // the walk rides inside the prefix kernel (the stage time of lineage_walk is then part of taxon_prefix)
+    const bool fuse = ix->n_bnd_local == ix->n_bnd;
+    for (uint32_t sb = 0; sb < n_sub; sb++) {
+        const SubBatch b = sub_batch_of(ix, sb, timed);
+        if ((rc = enqueue_count(ix, b, flags))) return rc;
+        if ((rc = enqueue_prob_prefix(ix, b, fuse))) return rc;
+        if (!fuse && (rc = enqueue_walk(ix, b, ix->sc[b.set].d_prefix.p, b.s))) return rc;
+        if (fuse && b.timed_all) {  // keeps rtx_batch_stage_times whole: an empty interval
+            RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_LINEAGE_WALK, 0), b.s));
+            RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_LINEAGE_WALK, 1), b.s));
+        }
+        if (ix->stream_dl) {
+            RTX_HIP(hipMemcpyAsync(&ix->h_cursor_sub[sb], ix->d_cursor.p, 8, hipMemcpyDeviceToHost, b.s));
+            RTX_HIP(hipEventRecord(ix->ev_sub[sb], b.s));
+        }
+    }
+    RTX_HIP(hipGetLastError());
+    return RTX_OK;
+}
+
+// Builds (once per handle and tmax) the memoised cmf tables used by prob_lookup_kernel.
+constexpr uint32_t kProbTablesMaxT = 1023;
+int ensure_prob_tables(rtx_index *ix) {
+    ix->use_tables = false;
+    if (ix->prob_mode == 1 || ix->tmax < 2) return RTX_OK;
+    if (ix->tmax > kProbTablesMaxT) {
+        if (ix->prob_mode == 2) { set_error("prob tables need t <= %u (got %u)", kProbTablesMaxT, ix->tmax); return RTX_ERR_TOO_LONG; }
+        return RTX_OK;
+    }
+    if (ix->tab_tmax >= ix->tmax) { ix->use_tables = true; return RTX_OK; }
+    const uint32_t T = ix->tmax;
+    std::vector<uint64_t> off(T + 1, 0);
+    std::vector<uint32_t> moff(T + 1, 0);
+    uint64_t run = 0;
+    uint32_t mrun = 0;
+    for (uint32_t t = 2; t <= T; t++) {
+        off[t] = run;
+        moff[t] = mrun;
+        run += (uint64_t)t * (t / 2 + 1);
+        mrun += t;
+    }
+    int rc;
+    size_t free_b = 0, total_b = 0;
+    RTX_HIP(hipMemGetInfo(&free_b, &total_b));
+    if (run * 16 > free_b / 2) {  // keep at least half of the free HBM for the batch workspace
+        if (ix->prob_mode == 2) { set_error("prob tables (%llu bytes) do not fit", (unsigned long long)(run * 16)); return RTX_ERR_OOM; }
+        return RTX_OK;
+    }
+    if ((rc = ix->d_tab_cmf.alloc(run)) || (rc = ix->d_tab_ratio.alloc(run)) || (rc = ix->d_tab_off.alloc(T + 1)) ||
+        (rc = ix->d_tab_moff.alloc(T + 1)) || (rc = ix->d_tab_ilo.alloc(mrun)) || (rc = ix->d_tab_sat.alloc(mrun)))
+        return rc;
+    RTX_HIP(hipMemcpy(ix->d_tab_off.p, off.data(), (T + 1) * 8, hipMemcpyHostToDevice));
+    RTX_HIP(hipMemcpy(ix->d_tab_moff.p, moff.data(), (T + 1) * 4, hipMemcpyHostToDevice));
+    ProbTables tb{ix->d_tab_cmf.p, ix->d_tab_ratio.p, ix->d_tab_off.p, ix->d_tab_moff.p, ix->d_tab_ilo.p, ix->d_tab_sat.p, T};
+    launch_prob_tables_build(ix->stream, tb, ix->d_lnfact.p, ix->d_inv.p);
+    RTX_HIP(hipGetLastError());
+    RTX_HIP(hipStreamSynchronize(ix->stream));
+    ix->tab_tmax = T;
+    ix->use_tables = true;
+    return RTX_OK;
+}
+
+// Queries per kernel launch: larger sub-batches amortise launch tails (measured: 4096 -> 8192 queries saves
+// 5 % of a step at N = 50k).
+constexpr uint32_t kMaxSubBatch = 65536;
+// default: fewer, larger launches save the drain/fill between the kernels of a sub-batch (N = 50k, per 100k queries: 10 000:
+// 20.4 ms, 14 286: 21.3, 25 000: 20.3, 50 000: 22.0).  A large database gains from more queries per launch -- every tile's
+// bitmap region is fetched once per launch and XCD, whatever the number of queries (N = 500k, per 1M queries: 10 240: 1 094 ms,
+// 16 384: 1 072, 24 576: 1 070, 32 768: 1 098).  With the kernels of the end of round 2: N = 50k, per 100k queries: 10 000: 19.55 ms,
+// 20 000: 19.08, 25 000: 21.1 (the last sub-batch's host work is no longer hidden), 50 000: 20.7; N = 500k, per 1 M queries:
+// 8 192: 971 ms, 16 384: 953, 32 768: 964, 65 536: 995
+// With tile pruning a sub-batch is far less work and the fixed cost of its nine launches counts: N = 500k, per 1 M queries:
+// 8 192: 191 ms, 16 384: 171, 32 768: 159.5, 49 152: 158.1, 65 536: 157.8
+constexpr uint32_t kDefaultSubBatch = 20480, kDefaultSubBatchLarge = 16384, kDefaultSubBatchPruned = 32768;
+
+
+// Sizes and allocates the per-batch workspace for n_queries queries of at most tmax k-mers.
+int prepare_workspace(rtx_index *ix, uint64_t n_queries, uint64_t tmax, uint64_t max_len) {
+    int rc;
+    if (tmax > 65535) { set_error("query with up to %llu k-mers: raxtax.rs:56 asserts t fits u16", (unsigned long long)tmax); return RTX_ERR_TOO_LONG; }
+    if (prob_table_lds_bytes((uint32_t)tmax) > 160 * 1024 - 512) {
+        set_error("query of %llu bases needs %zu bytes of LDS in prob_table (limit 160 KiB)", (unsigned long long)max_len,
+                  prob_table_lds_bytes((uint32_t)tmax));
+        return RTX_ERR_TOO_LONG;
+    }
+    ix->tmax = (uint32_t)tmax;
+    ix->kstride = (uint32_t)align_up(tmax, 8);
+    ix->rstride = (uint32_t)align_up(tmax, 64) + 64;  // row list padded to whole 64-row chunks
+    ix->hstride = (uint32_t)align_up(tmax + 1, 8);
+    ix->planes = tmax <= 1023 ? 10 : (tmax <= 4095 ? 12 : 16);
+    ix->n_q = n_queries;
+    if ((rc = ensure_prob_tables(ix))) return rc;
+    // ---- per-query results
+    if ((rc = ix->d_status.alloc(n_queries)) || (rc = ix->d_t_all.alloc(n_queries)) || (rc = ix->d_nrows_all.alloc(n_queries)) ||
+        (rc = ix->d_n_rows.alloc(n_queries)) || (rc = ix->d_gs.alloc(n_queries)) || (rc = ix->d_z.alloc(n_queries)) ||
+        (rc = ix->d_hq.alloc(n_queries)) || (rc = ix->d_row_start.alloc(n_queries)) || (rc = ix->d_ndist.alloc(n_queries)))
+        return rc;
+    const uint64_t want_arena = n_queries * 8 + 4096;
+    if (ix->arena_cap < want_arena) {
+        if ((rc = ix->d_arena.alloc(want_arena))) return rc;
+        ix->arena_cap = want_arena;
+    }
+    // ---- sub-batch scratch, sized against free HBM
+    const bool will_prune = ix->prune_opt && ix->d_ubitmap.p && ix->pair_opt && ix->ntiles >= RTX_PRUNE_MIN_TILES && tmax <= 1023 && (ix->n_refs == ix->n_total || ix->shard_prune_opt);  // begin_run decides
+    const uint64_t per_q = (uint64_t)ix->kstride * 2 + (uint64_t)ix->rstride * 12 + 4 + (uint64_t)ix->ntiles * (ix->rstride / 8 + ((kSegMaxSparseRows + 1) * 4 + 10)) + (ix->packed() ? ix->npad * 5 / 4 : ix->npad * 2) + (uint64_t)ix->hstride * 12 +
+                           (uint64_t)ix->n_bnd_local * 8 + 64 +
+                           // + the scratch of the tile pruning: counts against the union bitmap, constant masks, its histogram, thresholds, live masks
+                           (will_prune ? (uint64_t)ix->u_ntiles * (ix->rstride / 8 + 4) + (uint64_t)ix->ntiles * 2 + 12 + (ix->ntiles + 31u) / 32u * 2u + 2u + kPruneBestWords * 4 +
+                                          ((uint64_t)ix->ntiles + 2u) * 2u  /* the list of live (pair, tile) blocks: 4 bytes per pair and tile */ : 0);
+    uint32_t B = ix->sub_batch_req;
+    if (B == 0) {
+        size_t free_b = 0, total_b = 0;
+        RTX_HIP(hipMemGetInfo(&free_b, &total_b));
+        // scratch already held by this handle is reusable
+        const uint64_t held = (ix->sc[0].d_counts.n + ix->sc[1].d_counts.n) * 2 + (ix->sc[0].d_prefix.n + ix->sc[1].d_prefix.n) * 8;
+        const uint64_t budget = (uint64_t)((free_b + held) * 0.6);
+        B = (uint32_t)std::min<uint64_t>(will_prune ? kDefaultSubBatchPruned : ix->ntiles >= 16 ? kDefaultSubBatchLarge : kDefaultSubBatch,
+                                         std::max<uint64_t>(64, budget / per_q));
+    }
+    if (B > kMaxSubBatch) B = kMaxSubBatch;
+    B = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(B, n_queries));
+    ix->sub_batch = B;
+    ix->staged = false;
+    return alloc_scratch_set(ix, 0);
+}
+
+int alloc_scratch_set(rtx_index *ix, uint32_t k) {
+    int rc;
+    const uint32_t B = ix->sub_batch;
+    {
+        rtx_index::Scratch &sc = ix->sc[k];
+        if ((rc = sc.d_kmers.alloc((size_t)B * ix->kstride)) || (rc = sc.d_rows.alloc((size_t)B * ix->rstride)) || (rc = sc.d_dmask.alloc((size_t)B * ix->ntiles * (ix->rstride / 64))) ||
+            (rc = sc.d_nsparse.alloc((size_t)B * ix->ntiles)) || (rc = sc.d_srows.alloc((size_t)B * ix->ntiles * (kSegMaxSparseRows + 1))) ||
+            (rc = sc.d_t.alloc(B)) || (rc = sc.d_nrows.alloc(B)) || (rc = sc.d_counts.alloc(counts_elems(ix, B))) ||
+            (rc = sc.d_hist.alloc((size_t)B * ix->hstride)) || (rc = sc.d_table_z.alloc((size_t)B * ix->hstride)) ||
+            (rc = sc.d_prefix.alloc((size_t)B * ix->n_bnd_local)) || (rc = sc.d_order.alloc(B)) ||
+            (rc = sc.d_tilemax.alloc((size_t)B * ix->ntiles)) ||
+            (rc = sc.d_urec.alloc((size_t)((B + 1u) / 2u) * 2u * ix->rstride)) || (rc = sc.d_nu.alloc((B + 1u) / 2u)))
+            return rc;
+        if (ix->prune_opt && ix->d_ubitmap.p && (ix->n_refs == ix->n_total || ix->shard_prune_opt)) {
+            const size_t mw = (size_t)B * ix->u_ntiles * (ix->rstride / 64);
+            const bool fresh = sc.d_uones.n < mw;
+            if ((rc = sc.d_uones.alloc(mw)) || (rc = sc.d_uzero.alloc((size_t)B * ix->u_ntiles)) ||
+                (rc = sc.d_tile_ub.alloc((size_t)B * ix->ntiles)) || (rc = sc.d_best_key.alloc(B)) || (rc = sc.d_prune_thr.alloc(B)) || (rc = sc.d_prune_i1.alloc(B)) || (rc = sc.d_best.alloc((size_t)B * kPruneBestWords)) || (rc = sc.d_live.alloc((size_t)(B + 1u) * ((ix->ntiles + 31u) / 32u + 1u))) ||
+                (rc = sc.d_items.alloc((size_t)((B + 1u) / 2u) * (ix->ntiles + 2u) + 9u)))
+                return rc;
+            if (fresh) RTX_HIP(hipMemsetAsync(sc.d_uones.p, 0xFF, sc.d_uones.n * 8, ix->stream));
+            RTX_HIP(hipMemsetAsync(sc.d_uzero.p, 0, sc.d_uzero.n * 4, ix->stream));
+        }
+    }
+    return RTX_OK;
+}
+
+}  // namespace rtxi
+
+extern "C" {
+
+// Stages a batch in the input set that is NOT the current one: validation, bases packed two per byte into pinned memory (threads of
+// the library's budget), offsets and exact-match ids beside them, asynchronous H2D on a stream of its own.  The batch that is running
+// (or whose results are being downloaded) is not touched: rtx_raxtax stages chunk c + 1 while chunk c is classified.
+int rtx_batch_prefetch(rtx_index *ix, uint64_t n_queries, const uint8_t *bases, const uint64_t *base_off,
+                       const uint32_t *exact_ids, const uint64_t *exact_off) {
+    int rc = bind(ix);
+    if (rc) return rc;
+    if (n_queries == 0 || !base_off || (!bases && base_off[n_queries])) {
+        set_error("rtx_batch_upload: invalid argument");
+        return RTX_ERR_INVALID;
+    }
+    rtx_index::Inputs &in = ix->in[ix->cur_in ^ 1u];
+    if (!ix->h2d_stream) RTX_HIP(hipStreamCreateWithFlags(&ix->h2d_stream, hipStreamNonBlocking));
+    if (!in.ready) RTX_HIP(hipEventCreateWithFlags(&in.ready, hipEventDisableTiming));
+    if (in.recorded) RTX_HIP(hipEventSynchronize(in.ready));  // the last transfer out of this set's pinned buffers (long done, as a rule)
+    in.staged = false;
+    if (ix->ev_activated) RTX_HIP(hipStreamWaitEvent(ix->h2d_stream, ix->ev_activated, 0));  // the batch that read this set has run
+    uint64_t max_len = 0;
+    for (uint64_t q = 0; q < n_queries; q++) {
+        if (base_off[q + 1] < base_off[q]) { set_error("base_off not monotone at query %llu", (unsigned long long)q); return RTX_ERR_INVALID; }
+        max_len = std::max(max_len, base_off[q + 1] - base_off[q]);
+    }
+    const uint64_t total = base_off[n_queries] - base_off[0];
+    uint64_t n_exact = 0;
+    if (exact_off) {
+        if (exact_off[0] != 0) { set_error("exact_off[0] must be 0"); return RTX_ERR_INVALID; }
+        n_exact = exact_off[n_queries];
+        for (uint64_t q = 0; q < n_queries; q++)
+            if (exact_off[q + 1] < exact_off[q]) { set_error("exact_off not monotone"); return RTX_ERR_INVALID; }
+        if (n_exact && !exact_ids) { set_error("exact_ids is null"); return RTX_ERR_INVALID; }
+        for (uint64_t i = 0; i < n_exact; i++)
+            if (exact_ids[i] >= ix->n_total) { set_error("exact id %u out of range", exact_ids[i]); return RTX_ERR_INVALID; }
+    }
+    const uint64_t n_packed = (total + 1) / 2;
+    if ((rc = in.h_packed.resize(total + 64)) || (rc = in.h_base_off.resize(n_queries + 1)) || (rc = in.d_packed.alloc(total + 64)) ||
+        (rc = in.d_base_off.alloc(n_queries + 1)) || (rc = in.d_exact_off.alloc(n_queries + 1)) || (rc = in.d_exact_ids.alloc(n_exact + 1)))
+        return rc;
+    for (uint64_t q = 0; q <= n_queries; q++) in.h_base_off[q] = base_off[q] - base_off[0];
+    // two bases per byte; a byte above 15 is no code of parser.rs:11-34 -- such a batch travels as it is (the kernels see the caller's bytes)
+    in.packed = total == 0 || rtx::pack_nibbles_mt(bases + base_off[0], total, in.h_packed.data(), rtx::host_threads(8u));
+    if (!in.packed) std::memcpy(in.h_packed.data(), bases + base_off[0], total);
+    RTX_HIP(hipMemcpyAsync(in.d_packed.p, in.h_packed.data(), in.packed ? n_packed : total, hipMemcpyHostToDevice, ix->h2d_stream));
+    RTX_HIP(hipMemcpyAsync(in.d_base_off.p, in.h_base_off.data(), (n_queries + 1) * 8, hipMemcpyHostToDevice, ix->h2d_stream));
+    if (exact_off) {
+        if ((rc = in.h_exact_off.resize(n_queries + 1)) || (rc = in.h_exact_ids.resize(n_exact + 1))) return rc;
+        std::memcpy(in.h_exact_off.data(), exact_off, (n_queries + 1) * 8);
+        if (n_exact) std::memcpy(in.h_exact_ids.data(), exact_ids, n_exact * 4);
+        RTX_HIP(hipMemcpyAsync(in.d_exact_off.p, in.h_exact_off.data(), (n_queries + 1) * 8, hipMemcpyHostToDevice, ix->h2d_stream));
+        if (n_exact) RTX_HIP(hipMemcpyAsync(in.d_exact_ids.p, in.h_exact_ids.data(), n_exact * 4, hipMemcpyHostToDevice, ix->h2d_stream));
+    } else {
+        RTX_HIP(hipMemsetAsync(in.d_exact_off.p, 0, (n_queries + 1) * 8, ix->h2d_stream));
+    }
+    RTX_HIP(hipEventRecord(in.ready, ix->h2d_stream));
+    in.recorded = true;
+    in.n_q = n_queries;
+    in.total = total;
+    in.max_len = max_len;
+    in.n_exact = n_exact;
+    in.has_exact = exact_off != nullptr;
+    in.staged = true;
+    return RTX_OK;
+}
+
+// The staged batch becomes the current one: the handle's stream waits for the transfer (the host does not), the workspace is sized
+// for the batch (options that shape it are read here), the bases are unpacked.  The batch before it must have been downloaded.
+int rtx_batch_activate(rtx_index *ix) {
+    int rc = bind(ix);
+    if (rc) return rc;
+    rtx_index::Inputs &in = ix->in[ix->cur_in ^ 1u];
+    if (!in.staged) { set_error("rtx_batch_activate without a staged batch (rtx_batch_prefetch)"); return RTX_ERR_STATE; }
+    ix->uploaded = ix->ran = ix->synced = false;
+    // t <= min(len - 7, 65536); t == 65536 would trip the u16 assert of raxtax.rs:56
+    const uint64_t tmax = in.max_len >= 8 ? in.max_len - 7 : 1;
+    if ((rc = prepare_workspace(ix, in.n_q, tmax, in.max_len))) return rc;
+    ix->sum_query_bytes = in.total;
+    if ((rc = ix->d_bases.alloc(in.total + 64))) return rc;
+    RTX_HIP(hipStreamWaitEvent(ix->stream, in.ready, 0));
+    if (in.packed) {
+        rtx::launch_unpack_nibbles(ix->stream, in.d_packed.p, ix->d_bases.p, in.total, in.total + 64);
+    } else {
+        RTX_HIP(hipMemcpyAsync(ix->d_bases.p, in.d_packed.p, in.total, hipMemcpyDeviceToDevice, ix->stream));
+        RTX_HIP(hipMemsetAsync(ix->d_bases.p + in.total, 0, 64, ix->stream));
+    }
+    ix->dev_exact_used = !in.has_exact && ix->dev_exact_opt && ix->d_em_table.p && ix->n_refs == ix->n_total;
+    if (ix->dev_exact_used && (rc = ix->d_exact_grp.alloc(in.n_q))) return rc;
+    if (!ix->ev_activated) RTX_HIP(hipEventCreateWithFlags(&ix->ev_activated, hipEventDisableTiming));
+    RTX_HIP(hipEventRecord(ix->ev_activated, ix->stream));
+    in.staged = false;
+    ix->cur_in ^= 1u;
+    ix->uploaded = true;
+    return RTX_OK;
+}
+
+int rtx_pack_bases(const uint8_t *bases, uint64_t n_bases, uint8_t *packed) {
+    if ((!bases || !packed) && n_bases) { set_error("rtx_pack_bases: null argument"); return RTX_ERR_INVALID; }
+    return rtx::pack_nibbles_mt(bases, n_bases, packed, rtx::host_threads(8u)) ? 1 : 0;
+}
+
+int rtx_batch_upload(rtx_index *ix, uint64_t n_queries, const uint8_t *bases, const uint64_t *base_off,
+                     const uint32_t *exact_ids, const uint64_t *exact_off) {
+    if (ix) ix->uploaded = ix->ran = ix->synced = false;
+    int rc = rtx_batch_prefetch(ix, n_queries, bases, base_off, exact_ids, exact_off);
+    return rc ? rc : rtx_batch_activate(ix);
+}
+
+int rtx_batch_run(rtx_index *ix, uint32_t flags) {
+    int rc = bind(ix);
+    if (rc) return rc;
+    if (!ix->uploaded) { set_error("rtx_batch_run before rtx_batch_upload"); return RTX_ERR_STATE; }
+    ix->last_flags = flags;
+    ix->synced = false;
+    rc = enqueue_batch(ix, flags);
+    ix->ran = rc == RTX_OK;
+    return rc;
+}
+
+int rtx_batch_sync(rtx_index *ix) {
+    int rc = bind(ix);
+    if (rc) return rc;
+    if (!ix->ran) { set_error("rtx_batch_sync before rtx_batch_run"); return RTX_ERR_STATE; }
+    RTX_HIP(hipStreamSynchronize(ix->stream));
+    ix->synced = true;
+    return RTX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,617 @@
+// Index creation: the database re-encoded for the device (bitmaps tile by tile, segment classes, union bitmap of the tile
+// pruning, locator table, exact-match table), the taxonomy, the ln-factorial tables; handle options.
+#include "rtx_index.hpp"
+
+namespace {
+
+// statrs 0.16 `ln_factorial` (the reference's ln_binomial, prob.rs:5,20,117,143): ln of a cached
+// f64 factorial up to 170, Lanczos ln_gamma (g = 10.900511, 11 terms) above.
+double statrs_ln_gamma(double x) {
+    static const double dk[11] = {2.48574089138753565546e-5, 1.05142378581721974210,  -3.45687097222016235469,
+                                  4.51227709466894823700,    -2.98285225323576655721, 1.05639711577126713077,
+                                  -1.95428773191645869583e-1, 1.70970543404441224307e-2,
+                                  -5.71926117404305781283e-4, 4.63399473359905636708e-6,
+                                  -2.71994908488607703910e-9};
+    const double r = 10.900511, ln_2_sqrt_e_over_pi = 0.6207822376352452223455184457816472122518527279025978;
+    double s = dk[0];
+    for (int i = 1; i < 11; i++) s += dk[i] / (x + (double)i - 1.0);
+    return std::log(s) + ln_2_sqrt_e_over_pi + (x - 0.5) * std::log((x - 0.5 + r) / M_E);
+}
+void fill_ln_factorial(std::vector<double> &lf) {
+    lf.resize(kLnFactLen);
+    double f = 1.0;
+    for (uint32_t x = 0; x < kLnFactLen; x++) {
+        if (x <= 170) {
+            if (x > 0) f *= (double)x;
+            lf[x] = std::log(f);
+        } else {
+            lf[x] = statrs_ln_gamma((double)x + 1.0);
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int rtx_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+
+// Everything of index creation except the bitmap: device checks, stream, taxonomy, tables.
+static int create_common(int device, uint64_t n_total, uint64_t ref_lo, uint64_t ref_hi, const uint64_t *cuts,
+                         uint32_t n_cuts, uint32_t n_nodes, const uint32_t *node_begin, const uint32_t *node_end,
+                         const uint32_t *node_first_child, const uint32_t *node_n_children, const uint8_t *node_type,
+                         rtx_index **out) {
+    if (!out || !node_begin || !node_end || !node_first_child || !node_n_children || !node_type || n_total == 0 ||
+        n_total > 0xFFFFFFFFull || ref_lo >= ref_hi || ref_hi > n_total) {
+        set_error("rtx_index_create: invalid argument");
+        return RTX_ERR_INVALID;
+    }
+    const uint64_t n_refs = ref_hi - ref_lo;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) {
+        set_error("no usable HIP device (requested %d of %d); libraxtax_hip has no CPU fallback", device, ndev);
+        return RTX_ERR_NO_DEVICE;
+    }
+    RTX_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    RTX_HIP(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        set_error("device %d is %s; this library carries gfx950 (MI355X) code objects only", device, prop.gcnArchName);
+        return RTX_ERR_NO_DEVICE;
+    }
+    auto ix = new rtx_index();
+    ix->device = device;
+    ix->n_refs = n_refs;
+    ix->n_total = n_total;
+    ix->ref_lo = (uint32_t)ref_lo;
+    int rc = RTX_OK;
+    auto fail = [&](int code) { delete ix; return code; };
+    if (!derive_flat_nodes(n_total, n_nodes, node_begin, node_end, node_first_child, node_n_children, node_type, ix->nodes))
+        return fail(RTX_ERR_INVALID);
+    if (ix->nodes.max_depth > RTX_MAX_DEPTH) {
+        set_error("lineage depth %u exceeds RTX_MAX_DEPTH=%u", ix->nodes.max_depth, RTX_MAX_DEPTH);
+        return fail(RTX_ERR_DEPTH);
+    }
+    node_tables(ix);
+    if (hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking) != hipSuccess) {
+        set_error("hipStreamCreate failed");
+        return fail(RTX_ERR_HIP);
+    }
+    // ---- taxonomy boundaries
+    {
+        std::vector<uint32_t> b;
+        b.reserve(2 * (size_t)n_nodes + 2);
+        b.push_back(0);
+        b.push_back((uint32_t)n_total);
+        b.push_back((uint32_t)ref_lo);
+        b.push_back((uint32_t)ref_hi);
+        for (uint32_t c = 0; c < n_cuts; c++) {  // shard cut points: identical boundary lists on every rank
+            if (cuts[c] > n_total) { set_error("shard cut %llu beyond n_refs", (unsigned long long)cuts[c]); return fail(RTX_ERR_INVALID); }
+            b.push_back((uint32_t)cuts[c]);
+        }
+        for (uint32_t v = 0; v < n_nodes; v++) { b.push_back(ix->nodes.begin[v]); b.push_back(ix->nodes.end[v]); }
+        std::sort(b.begin(), b.end());
+        b.erase(std::unique(b.begin(), b.end()), b.end());
+        ix->bnd = std::move(b);
+        ix->n_bnd = (uint32_t)ix->bnd.size();
+        std::vector<uint32_t> blo(n_nodes), bhi(n_nodes);
+        for (uint32_t v = 0; v < n_nodes; v++) {
+            blo[v] = (uint32_t)(std::lower_bound(ix->bnd.begin(), ix->bnd.end(), ix->nodes.begin[v]) - ix->bnd.begin());
+            bhi[v] = (uint32_t)(std::lower_bound(ix->bnd.begin(), ix->bnd.end(), ix->nodes.end[v]) - ix->bnd.begin());
+        }
+        // flags / ranks over the LOCAL references: boundary position p in (ref_lo, ref_hi] belongs to
+        // local reference p - 1 - ref_lo; local boundary 0 is ref_lo itself
+        const size_t nchunk = (size_t)((n_refs + 7) / 8);
+        std::vector<uint8_t> bits(nchunk, 0);
+        std::vector<uint32_t> rank(nchunk, 0);
+        ix->bnd_first = (uint32_t)(std::lower_bound(ix->bnd.begin(), ix->bnd.end(), (uint32_t)ref_lo) - ix->bnd.begin());
+        ix->n_bnd_local = 1;
+        for (uint32_t j = 1; j < ix->n_bnd; j++) {
+            if (ix->bnd[j] <= ref_lo || ix->bnd[j] > ref_hi) continue;
+            const uint32_t r = ix->bnd[j] - 1 - (uint32_t)ref_lo;
+            bits[r >> 3] |= (uint8_t)(1u << (r & 7u));
+            ix->n_bnd_local++;
+        }
+        uint32_t run = 1;
+        for (size_t c = 0; c < nchunk; c++) {
+            rank[c] = run;
+            run += (uint32_t)__builtin_popcount(bits[c]);
+        }
+        std::vector<uint4> noderec(n_nodes);
+        for (uint32_t v = 0; v < n_nodes; v++) {
+            if (ix->nodes.n_children[v] >= (1u << 30)) { set_error("node with 2^30 or more children"); return fail(RTX_ERR_INVALID); }
+            noderec[v] = make_uint4(blo[v], bhi[v], ix->nodes.first_child[v], ix->nodes.n_children[v] | ((uint32_t)ix->nodes.type[v] << 30));
+        }
+        if ((rc = ix->d_noderec.alloc(n_nodes)) || (rc = ix->d_bnd_bits.alloc(nchunk)) || (rc = ix->d_bnd_rank.alloc(nchunk)))
+            return fail(rc);
+        hipError_t e = hipSuccess;
+        auto up = [&](void *d, const void *h, size_t bytes) { if (e == hipSuccess) e = hipMemcpy(d, h, bytes, hipMemcpyHostToDevice); };
+        up(ix->d_noderec.p, noderec.data(), (size_t)n_nodes * sizeof(uint4));
+        up(ix->d_bnd_bits.p, bits.data(), nchunk);
+        up(ix->d_bnd_rank.p, rank.data(), nchunk * 4);
+        if (e != hipSuccess) { set_error("taxonomy upload failed: %s", hipGetErrorString(e)); return fail(RTX_ERR_HIP); }
+    }
+    // ---- ln-factorial table
+    {
+        std::vector<double> lf;
+        fill_ln_factorial(lf);
+        if ((rc = ix->d_lnfact.alloc(lf.size()))) return fail(rc);
+        if (hipMemcpy(ix->d_lnfact.p, lf.data(), lf.size() * 8, hipMemcpyHostToDevice) != hipSuccess) {
+            set_error("lnfact upload failed");
+            return fail(RTX_ERR_HIP);
+        }
+        std::vector<double> inv(lf.size(), 0.0);
+        for (size_t x = 1; x < inv.size(); x++) inv[x] = 1.0 / (double)x;
+        if ((rc = ix->d_inv.alloc(inv.size()))) return fail(rc);
+        if (hipMemcpy(ix->d_inv.p, inv.data(), inv.size() * 8, hipMemcpyHostToDevice) != hipSuccess) {
+            set_error("reciprocal table upload failed");
+            return fail(RTX_ERR_HIP);
+        }
+    }
+    ix->stride_bytes = (uint32_t)align_up((n_refs + 7) / 8, 1024);  // whole tiles: the bitmap is stored tile by tile
+    ix->npad = (uint64_t)ix->stride_bytes * 8;
+    ix->ntiles = (ix->stride_bytes + 1023) / 1024;
+    if ((rc = ix->d_cursor.alloc(1)) || (rc = ix->d_flags.alloc(1))) return fail(rc);
+    *out = ix;
+    return RTX_OK;
+}
+
+static bool prepare_union_bitmap(rtx_index *ix);
+
+// Hash table of the distinct reference sequences for the device exact-match lookup (rtx_exact.hip).  `groups`: per distinct
+// sequence the ids of the references that have it, ascending (Tree.sequences, tree.rs:109-112); group order = order of the first
+// id, so that the table is the same however the caller's map iterates.  An aid like the locator: if it cannot be built (memory) the
+// handle works without it and callers pass the ids of Tree.sequences.get themselves.
+static uint64_t g_em_hash_mask = ~0ull;  // RTX_DEFAULT_EXACT_HASH_MASK (rtx_set_default_option)
+static uint64_t em_hash_bytes(const uint8_t *s, uint64_t len) {
+    uint64_t sum = 0;
+    for (uint64_t j = 0; j * 8 < len; j++) {
+        uint64_t w = 0;
+        std::memcpy(&w, s + 8 * j, (size_t)std::min<uint64_t>(8, len - 8 * j));
+        sum += em_mix_word(w, j);
+    }
+    return em_finish(sum, len);
+}
+static void build_exact_table(rtx_index *ix, const uint8_t *seq_bytes, const uint64_t *seq_off,
+                              std::vector<const std::vector<uint32_t> *> &groups) {
+    if (ix->n_refs != ix->n_total || groups.empty()) return;
+    std::sort(groups.begin(), groups.end(), [](const std::vector<uint32_t> *a, const std::vector<uint32_t> *b) { return (*a)[0] < (*b)[0]; });
+    const uint32_t G = (uint32_t)groups.size();
+    uint32_t bits = 4;
+    while ((1ull << bits) < 2ull * G) bits++;
+    std::vector<uint64_t> rep_off(G + 1, 0);
+    std::vector<uint32_t> goff(G + 1, 0), gids;
+    gids.reserve(ix->n_total);
+    for (uint32_t g = 0; g < G; g++) {
+        const uint32_t rep = (*groups[g])[0];
+        rep_off[g + 1] = rep_off[g] + (seq_off[rep + 1] - seq_off[rep]);
+        gids.insert(gids.end(), groups[g]->begin(), groups[g]->end());
+        goff[g + 1] = (uint32_t)gids.size();
+    }
+    std::vector<uint8_t> rep_bytes(rep_off[G] + 16, 0);
+    std::vector<uint64_t> hashes(G);
+    {
+        const unsigned nt = rtx::host_threads(8u);
+        std::vector<std::thread> th;
+        for (unsigned k = 0; k < nt; k++)
+            th.emplace_back([&, k] {
+                for (uint32_t g = (uint32_t)((uint64_t)G * k / nt); g < (uint32_t)((uint64_t)G * (k + 1) / nt); g++) {
+                    const uint32_t rep = (*groups[g])[0];
+                    const uint64_t len = seq_off[rep + 1] - seq_off[rep];
+                    std::memcpy(rep_bytes.data() + rep_off[g], seq_bytes + seq_off[rep], (size_t)len);
+                    hashes[g] = em_hash_bytes(seq_bytes + seq_off[rep], len) & g_em_hash_mask;
+                }
+            });
+        for (auto &t : th) t.join();
+    }
+    std::vector<uint2> table((size_t)1 << bits, make_uint2(0u, 0u));
+    const uint32_t mask = (1u << bits) - 1u;
+    for (uint32_t g = 0; g < G; g++) {
+        uint32_t slot = em_slot(hashes[g], bits);
+        while (table[slot].y) slot = (slot + 1u) & mask;
+        table[slot] = make_uint2(em_tag(hashes[g]), g + 1u);
+    }
+    hipError_t e = hipSuccess;
+    if (ix->d_em_table.alloc(table.size()) || ix->d_em_rep_off.alloc(G + 1) || ix->d_em_rep_bytes.alloc(rep_bytes.size()) ||
+        ix->d_em_goff.alloc(G + 1) || ix->d_em_gids.alloc(gids.size() + 1))
+        e = hipErrorOutOfMemory;
+    auto up = [&](void *d, const void *h, size_t bytes) { if (e == hipSuccess && bytes) e = hipMemcpy(d, h, bytes, hipMemcpyHostToDevice); };
+    up(ix->d_em_table.p, table.data(), table.size() * sizeof(uint2));
+    up(ix->d_em_rep_off.p, rep_off.data(), (G + 1) * 8);
+    up(ix->d_em_rep_bytes.p, rep_bytes.data(), rep_bytes.size());
+    up(ix->d_em_goff.p, goff.data(), (G + 1) * 4);
+    up(ix->d_em_gids.p, gids.data(), gids.size() * 4);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        ix->d_em_table.release(); ix->d_em_rep_off.release(); ix->d_em_rep_bytes.release(); ix->d_em_goff.release(); ix->d_em_gids.release();
+        return;
+    }
+    ix->em_groups = G;
+    ix->em_bits = bits;
+    ix->em_hash_mask = g_em_hash_mask;
+    ix->h_em_goff = std::move(goff);
+    ix->h_em_gids = std::move(gids);
+}
+// ... from the sequences alone (rtx_index_create_from_sequences): what Tree::new's map would hold
+static void build_exact_table_from_sequences(rtx_index *ix, uint64_t n_refs, const uint8_t *seq_bytes, const uint64_t *seq_off) {
+    std::unordered_map<std::string_view, std::vector<uint32_t>, BytesHash> map;
+    map.reserve(n_refs * 2);
+    for (uint64_t i = 0; i < n_refs; i++)
+        map[std::string_view((const char *)seq_bytes + seq_off[i], (size_t)(seq_off[i + 1] - seq_off[i]))].push_back((uint32_t)i);
+    std::vector<const std::vector<uint32_t> *> groups;
+    groups.reserve(map.size());
+    for (const auto &kv : map) groups.push_back(&kv.second);
+    build_exact_table(ix, seq_bytes, seq_off, groups);
+}
+
+static int create_from_csr(int device, uint64_t n_total, uint64_t ref_lo, uint64_t ref_hi, const uint64_t *cuts,
+                           uint32_t n_cuts, const uint64_t *offsets, const uint32_t *postings, uint32_t n_nodes,
+                           const uint32_t *node_begin, const uint32_t *node_end, const uint32_t *node_first_child,
+                           const uint32_t *node_n_children, const uint8_t *node_type, rtx_index **out);
+
+int rtx_index_create(int device, uint64_t n_refs, const uint64_t *offsets, const uint32_t *postings,
+                     uint32_t n_nodes, const uint32_t *node_begin, const uint32_t *node_end,
+                     const uint32_t *node_first_child, const uint32_t *node_n_children, const uint8_t *node_type,
+                     rtx_index **out) {
+    if (!offsets) { set_error("rtx_index_create: offsets is null"); return RTX_ERR_INVALID; }
+    if (offsets[RTX_NUM_KMERS] && !postings) { set_error("rtx_index_create: postings is null"); return RTX_ERR_INVALID; }
+    return create_from_csr(device, n_refs, 0, n_refs, nullptr, 0, offsets, postings, n_nodes, node_begin, node_end,
+                           node_first_child, node_n_children, node_type, out);
+}
+
+int rtx_index_create_shard(int device, uint64_t n_refs_total, uint64_t ref_lo, uint64_t ref_hi, const uint64_t *shard_cuts,
+                           uint32_t n_cuts, const uint64_t *offsets, const uint32_t *postings, uint32_t n_nodes,
+                           const uint32_t *node_begin, const uint32_t *node_end, const uint32_t *node_first_child,
+                           const uint32_t *node_n_children, const uint8_t *node_type, rtx_index **out) {
+    if (!offsets) { set_error("rtx_index_create_shard: offsets is null"); return RTX_ERR_INVALID; }
+    if (offsets[RTX_NUM_KMERS] && !postings) { set_error("rtx_index_create_shard: postings is null"); return RTX_ERR_INVALID; }
+    return create_from_csr(device, n_refs_total, ref_lo, ref_hi, shard_cuts, n_cuts, offsets, postings, n_nodes, node_begin,
+                           node_end, node_first_child, node_n_children, node_type, out);
+}
+
+// RTX_DEFAULT_SEGMENT_CLASSES (rtx_set_default_option): 0 = every segment is read densely (A/B measurements)
+static uint64_t g_seg_classes = 1;
+
+// Classifies every (row, tile) segment of the finished bitmap as empty / dense / sparse and writes the slots of the
+// sparse ones (rtx_segments.hip).  Slots are numbered in (row, tile) order: deterministic.
+static int build_segments(rtx_index *ix) {
+    const uint32_t n_rows1 = ix->n_rows + 1, nt = ix->ntiles;
+    const uint32_t ss = (nt + 3u) & ~3u;  // seginfo rows padded to whole uint4
+    ix->seg_stride = ss;
+    const size_t n = (size_t)n_rows1 * nt;
+    const bool sparse_on = g_seg_classes != 0, empty_on = g_seg_classes != 0;
+    DevBuf<uint16_t> d_pop;
+    int rc;
+    if ((rc = d_pop.alloc(n)) || (rc = ix->d_seginfo.alloc((size_t)n_rows1 * ss))) return rc;
+    launch_seg_popcount(ix->stream, ix->d_bitmap.p, ix->stride_bytes, n_rows1, nt, d_pop.p);
+    RTX_HIP(hipGetLastError());
+    RTX_HIP(hipStreamSynchronize(ix->stream));
+    std::vector<uint16_t> pop(n);
+    RTX_HIP(hipMemcpy(pop.data(), d_pop.p, n * 2, hipMemcpyDeviceToHost));
+    std::vector<uint32_t> info((size_t)n_rows1 * ss, 0u);
+    uint64_t slots = 0;
+    const bool last_full = ix->stride_bytes % 1024u == 0;  // hit_count's byte counters and row images want 64-lane tiles
+    for (uint32_t r = 0; r < n_rows1; r++)
+        for (uint32_t t = 0; t < nt; t++) {
+            const uint32_t c = pop[(size_t)r * nt + t];
+            uint32_t &o = info[(size_t)r * ss + t];
+            const bool full_tile = t + 1 < nt || last_full;
+            if (c == 0) o = empty_on ? 0u : 1u;
+            else if (c <= kSegSparseMax && sparse_on && full_tile) o = (uint32_t)(2 + slots++);
+            else o = 1u;
+        }
+    if (slots > 0x7FFFFFF0ull) { set_error("too many sparse segments"); return RTX_ERR_INVALID; }
+    // many tiles: the classes as bit tables per block of 64 tiles (kmer_extract transposes 64 rows x 64 tiles at a time)
+    ix->seg_blocks = nt > 12 ? (nt + 63) / 64 : 0;
+    if (ix->seg_blocks) {
+        const uint32_t nb = ix->seg_blocks;
+        std::vector<unsigned long long> dbits((size_t)n_rows1 * nb, 0), sbits((size_t)n_rows1 * nb, 0);
+        std::vector<uint32_t> sbase((size_t)n_rows1 * nb, 0);
+        for (uint32_t r = 0; r < n_rows1; r++)
+            for (uint32_t b = 0; b < nb; b++) {
+                bool first = true;
+                for (uint32_t t = b * 64; t < nt && t < b * 64 + 64; t++) {
+                    const uint32_t o = info[(size_t)r * ss + t];
+                    if (o == 1u) dbits[(size_t)r * nb + b] |= 1ull << (t & 63u);
+                    else if (o >= 2u) {
+                        sbits[(size_t)r * nb + b] |= 1ull << (t & 63u);
+                        if (first) { sbase[(size_t)r * nb + b] = o - 2u; first = false; }
+                    }
+                }
+            }
+        if ((rc = ix->d_seg_dbits.alloc(dbits.size())) || (rc = ix->d_seg_sbits.alloc(sbits.size())) || (rc = ix->d_seg_sbase.alloc(sbase.size()))) return rc;
+        RTX_HIP(hipMemcpy(ix->d_seg_dbits.p, dbits.data(), dbits.size() * 8, hipMemcpyHostToDevice));
+        RTX_HIP(hipMemcpy(ix->d_seg_sbits.p, sbits.data(), sbits.size() * 8, hipMemcpyHostToDevice));
+        RTX_HIP(hipMemcpy(ix->d_seg_sbase.p, sbase.data(), sbase.size() * 4, hipMemcpyHostToDevice));
+    }
+    ix->n_seg_slots = slots;
+    if ((rc = ix->d_segslots.alloc((slots ? slots : 1) * kSegSlotEntries))) return rc;
+    RTX_HIP(hipMemset(ix->d_segslots.p, 0xFF, (slots ? slots : 1) * kSegSlotEntries * 2));
+    RTX_HIP(hipMemcpy(ix->d_seginfo.p, info.data(), info.size() * 4, hipMemcpyHostToDevice));
+    if (slots) {
+        launch_seg_emit(ix->stream, ix->d_bitmap.p, ix->stride_bytes, n_rows1, nt, ix->d_seginfo.p, ss, ix->d_segslots.p);
+        RTX_HIP(hipGetLastError());
+        RTX_HIP(hipStreamSynchronize(ix->stream));
+    }
+    return RTX_OK;
+}
+
+static int create_from_csr(int device, uint64_t n_total, uint64_t ref_lo, uint64_t ref_hi, const uint64_t *cuts,
+                           uint32_t n_cuts, const uint64_t *offsets, const uint32_t *postings, uint32_t n_nodes,
+                           const uint32_t *node_begin, const uint32_t *node_end, const uint32_t *node_first_child,
+                           const uint32_t *node_n_children, const uint8_t *node_type, rtx_index **out) {
+    rtx_index *ix = nullptr;
+    int rc = create_common(device, n_total, ref_lo, ref_hi, cuts, n_cuts, n_nodes, node_begin, node_end, node_first_child,
+                           node_n_children, node_type, &ix);
+    if (rc) return rc;
+    auto fail = [&](int code) { delete ix; return code; };
+    // ---- bitmap index: one row of (local) n_refs bits per posting list that is non-empty in this shard
+    {
+        std::vector<uint32_t> row_of(RTX_NUM_KMERS, kEmptyRow);
+        std::vector<uint32_t> list_len(RTX_NUM_KMERS, 0);
+        uint32_t nr = 0;
+        for (uint32_t k = 0; k < RTX_NUM_KMERS; k++) {
+            if (offsets[k + 1] < offsets[k]) { set_error("offsets not monotone at k-mer %u", k); return fail(RTX_ERR_INVALID); }
+            const uint64_t l0 = offsets[k + 1] - offsets[k];
+            if (l0 > n_total) { set_error("posting list %u longer than n_refs", k); return fail(RTX_ERR_INVALID); }
+            // lists are sorted (tree.rs:134-137): the shard's part is a contiguous run
+            const uint32_t *b = postings + offsets[k], *e = postings + offsets[k + 1];
+            const uint64_t l = l0 ? (uint64_t)(std::lower_bound(b, e, (uint32_t)ref_hi) - std::lower_bound(b, e, (uint32_t)ref_lo)) : 0;
+            list_len[k] = (uint32_t)l;
+            if (l) row_of[k] = nr++;
+        }
+        ix->n_rows = nr;
+        const size_t words = (size_t)(nr + 1) * (ix->stride_bytes / 4);
+        const uint64_t total = offsets[RTX_NUM_KMERS];
+        DevBuf<uint64_t> d_off;
+        DevBuf<uint32_t> d_post;
+        if ((rc = ix->d_bitmap.alloc(words)) || (rc = ix->d_row_of.alloc(RTX_NUM_KMERS)) ||
+            (rc = ix->d_list_len.alloc(RTX_NUM_KMERS)) || (rc = d_off.alloc(RTX_NUM_KMERS + 1)) ||
+            (rc = d_post.alloc(total)))
+            return fail(rc);
+        hipError_t e = hipMemset(ix->d_bitmap.p, 0, words * 4);
+        if (e == hipSuccess) e = hipMemcpy(ix->d_row_of.p, row_of.data(), RTX_NUM_KMERS * 4, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(ix->d_list_len.p, list_len.data(), RTX_NUM_KMERS * 4, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(d_off.p, offsets, (RTX_NUM_KMERS + 1) * 8, hipMemcpyHostToDevice);
+        if (e == hipSuccess && total) e = hipMemcpy(d_post.p, postings, total * 4, hipMemcpyHostToDevice);
+        if (e == hipSuccess) {
+            launch_bitmap_build(ix->stream, d_off.p, d_post.p, ix->d_row_of.p, ix->d_bitmap.p, ix->stride_bytes / 4, nr + 1,
+                                (uint32_t)ref_lo, (uint32_t)ref_hi);
+            e = hipStreamSynchronize(ix->stream);
+        }
+        if (e != hipSuccess) { set_error("bitmap build failed: %s", hipGetErrorString(e)); return fail(RTX_ERR_HIP); }
+        if (prepare_union_bitmap(ix)) {
+            launch_bitmap_build(ix->stream, d_off.p, d_post.p, ix->d_row_of.p, ix->d_ubitmap.p, ix->u_stride_bytes / 4, nr + 1, (uint32_t)ref_lo,
+                                (uint32_t)ref_hi, kPruneShift);
+            if (hipStreamSynchronize(ix->stream) != hipSuccess) { (void)hipGetLastError(); ix->d_ubitmap.release(); }
+        }
+    }
+    if ((rc = build_segments(ix))) return fail(rc);
+    *out = ix;
+    return RTX_OK;
+}
+
+// Union bitmap of the tile pruning (rtx_prune.hip): the bitmap of the database with one column per block of 2^kPruneShift
+// references.  Same rows as d_bitmap.  Only for whole databases of some size (8 tiles or more); a failure to allocate
+// leaves the handle without it (no pruning).  Sizes first, then one of the two builders below fills it.
+static bool prepare_union_bitmap(rtx_index *ix) {
+    if (ix->ntiles < RTX_PRUNE_MIN_TILES) return false;  // (a reference shard gets one too: it prunes with the threshold of the whole database, rtx_shard_bounds)
+    ix->u_nblocks = (ix->n_refs + (1ull << kPruneShift) - 1) >> kPruneShift;
+    // the best-block key of the bounds pass packs the block into 20 bits (bounds_epilogue, prune_kernel): beyond 2^20 blocks (67 M
+    // references on one handle) block ids would alias and the threshold would come from the wrong block -- such a handle counts every tile
+    if (ix->u_nblocks > 0xFFFFFull) return false;
+    ix->u_ntiles = (uint32_t)((ix->u_nblocks + 8191) / 8192);
+    ix->u_stride_bytes = ix->u_ntiles * 1024u;
+    const size_t words = (size_t)(ix->n_rows + 1) * (ix->u_stride_bytes / 4);
+    if (ix->d_ubitmap.alloc(words)) { ix->d_ubitmap.release(); return false; }
+    // on the handle's stream: the builder kernel that follows must not start before the zeroes are in (a hipMemset on the null
+    // stream is not ordered with a non-blocking stream)
+    if (hipMemsetAsync(ix->d_ubitmap.p, 0, words * 4, ix->stream) != hipSuccess) { (void)hipGetLastError(); ix->d_ubitmap.release(); return false; }
+    return true;
+}
+
+// Locator table of the processing order (rtx_cluster.hip) from the reference sequences already on the device.
+// A scheduling aid only: if it cannot be built (memory) the handle works without it.
+static void build_locator(rtx_index *ix, const uint8_t *d_seq, const uint64_t *d_off, uint64_t n_refs) {
+    if (ix->n_refs != ix->n_total || n_refs < 256) return;  // whole-database handles of some size only
+    DevBuf<uint32_t> d_cnt;
+    if (ix->d_loc_table.alloc(kLocTableEntries) || d_cnt.alloc(kLocTableEntries)) { ix->d_loc_table.release(); return; }
+    hipError_t e = hipMemsetAsync(ix->d_loc_table.p, 0xFF, (size_t)kLocTableEntries * 4, ix->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(d_cnt.p, 0, (size_t)kLocTableEntries * 4, ix->stream);
+    if (e == hipSuccess) {
+        launch_loc_mark(ix->stream, d_seq, d_off, n_refs, ix->d_loc_table.p, d_cnt.p);
+        launch_loc_finish(ix->stream, ix->d_loc_table.p, d_cnt.p);
+        e = hipStreamSynchronize(ix->stream);
+    }
+    if (e != hipSuccess) { (void)hipGetLastError(); ix->d_loc_table.release(); }
+}
+
+static thread_local bool g_from_tree = false;  // rtx_index_create_from_tree -> _from_sequences on the same thread
+
+// Index build on the GPU from the encoded reference sequences in lineage-sorted order
+// (the k-mer map of Tree::new, tree.rs:114-123,134-137, without ever materialising posting lists).
+int rtx_index_create_from_sequences(int device, uint64_t n_refs, const uint8_t *seq_bytes, const uint64_t *seq_off,
+                                    uint32_t n_nodes, const uint32_t *node_begin, const uint32_t *node_end,
+                                    const uint32_t *node_first_child, const uint32_t *node_n_children,
+                                    const uint8_t *node_type, rtx_index **out) {
+    if (!seq_off || (!seq_bytes && n_refs && seq_off[n_refs])) { set_error("rtx_index_create_from_sequences: null sequences"); return RTX_ERR_INVALID; }
+    rtx_index *ix = nullptr;
+    int rc = create_common(device, n_refs, 0, n_refs, nullptr, 0, n_nodes, node_begin, node_end, node_first_child,
+                           node_n_children, node_type, &ix);
+    if (rc) return rc;
+    auto fail = [&](int code) { delete ix; return code; };
+    const uint64_t total = seq_off[n_refs] - seq_off[0];
+    DevBuf<uint8_t> d_seq;
+    DevBuf<uint64_t> d_off;
+    DevBuf<uint32_t> d_present;
+    if ((rc = d_seq.alloc(total + 16)) || (rc = d_off.alloc(n_refs + 1)) || (rc = d_present.alloc(2048)) ||
+        (rc = ix->d_row_of.alloc(RTX_NUM_KMERS)) || (rc = ix->d_list_len.alloc(RTX_NUM_KMERS)))
+        return fail(rc);
+    std::vector<uint64_t> off0(n_refs + 1);
+    for (uint64_t i = 0; i <= n_refs; i++) off0[i] = seq_off[i] - seq_off[0];
+    hipError_t e = hipMemcpy(d_seq.p, seq_bytes + seq_off[0], total, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_off.p, off0.data(), (n_refs + 1) * 8, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemset(d_present.p, 0, 2048 * 4);
+    if (e == hipSuccess) {
+        launch_ref_kmer_mark(ix->stream, d_seq.p, d_off.p, n_refs, d_present.p);
+        e = hipStreamSynchronize(ix->stream);
+    }
+    std::vector<uint32_t> present(2048, 0), row_of(RTX_NUM_KMERS, kEmptyRow);
+    if (e == hipSuccess) e = hipMemcpy(present.data(), d_present.p, 2048 * 4, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) { set_error("k-mer marking failed: %s", hipGetErrorString(e)); return fail(RTX_ERR_HIP); }
+    uint32_t nr = 0;
+    for (uint32_t k = 0; k < RTX_NUM_KMERS; k++)
+        if (present[k >> 5] & (1u << (k & 31u))) row_of[k] = nr++;
+    ix->n_rows = nr;
+    const size_t words = (size_t)(nr + 1) * (ix->stride_bytes / 4);
+    if ((rc = ix->d_bitmap.alloc(words))) return fail(rc);
+    e = hipMemset(ix->d_bitmap.p, 0, words * 4);
+    if (e == hipSuccess) e = hipMemcpy(ix->d_row_of.p, row_of.data(), RTX_NUM_KMERS * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        launch_ref_bitmap_set(ix->stream, d_seq.p, d_off.p, n_refs, ix->d_row_of.p, ix->d_bitmap.p, ix->stride_bytes / 4, nr + 1);
+        launch_row_popcount(ix->stream, ix->d_row_of.p, ix->d_bitmap.p, ix->stride_bytes / 4, nr + 1, ix->d_list_len.p);
+        e = hipStreamSynchronize(ix->stream);
+    }
+    if (e != hipSuccess) { set_error("bitmap build from sequences failed: %s", hipGetErrorString(e)); return fail(RTX_ERR_HIP); }
+    if ((rc = build_segments(ix))) return fail(rc);
+    build_locator(ix, d_seq.p, d_off.p, n_refs);
+    if (!g_from_tree) build_exact_table_from_sequences(ix, n_refs, seq_bytes, seq_off);  // (from a tree: its map is reused, below)
+    if (prepare_union_bitmap(ix)) {
+        launch_ref_bitmap_set(ix->stream, d_seq.p, d_off.p, n_refs, ix->d_row_of.p, ix->d_ubitmap.p, ix->u_stride_bytes / 4, nr + 1, kPruneShift);
+        if (hipStreamSynchronize(ix->stream) != hipSuccess) { (void)hipGetLastError(); ix->d_ubitmap.release(); }
+    }
+    *out = ix;
+    return RTX_OK;
+}
+
+static void exact_table_from_tree(rtx_index *ix, const rtx_tree *tree) {
+    if (tree->seq_off.size() != tree->num_tips + 1) return;
+    std::vector<const std::vector<uint32_t> *> groups;
+    groups.reserve(tree->sequences.size());
+    for (const auto &kv : tree->sequences)
+        if (!kv.second.empty()) groups.push_back(&kv.second);
+    build_exact_table(ix, tree->seq_bytes.data(), tree->seq_off.data(), groups);
+}
+
+int rtx_index_create_from_tree(int device, const rtx_tree *tree, rtx_index **out) {
+    if (!tree || !out) { set_error("null argument"); return RTX_ERR_INVALID; }
+    const FlatNodes &f = tree->flat;
+    if (tree->csr_off.empty()) {  // tree built without the host k-mer map: build the bitmaps on the GPU
+        g_from_tree = true;   // (this thread's call below: the exact-match table comes from the tree's map, not from a second pass over the sequences)
+        const int rc = rtx_index_create_from_sequences(device, tree->num_tips, tree->seq_bytes.data(), tree->seq_off.data(), f.size(),
+                                                       f.begin.data(), f.end.data(), f.first_child.data(), f.n_children.data(),
+                                                       f.type.data(), out);
+        g_from_tree = false;
+        if (rc == RTX_OK) exact_table_from_tree(*out, tree);
+        return rc;
+    }
+    int rc = rtx_index_create(device, tree->num_tips, tree->csr_off.data(), tree->postings.data(), f.size(), f.begin.data(),
+                              f.end.data(), f.first_child.data(), f.n_children.data(), f.type.data(), out);
+    if (rc != RTX_OK) return rc;
+    exact_table_from_tree(*out, tree);
+    // the tree holds the sequences (Tree.sequences, for the exact-match lookup): the locator table of the processing order
+    const uint64_t n = tree->num_tips;
+    if (n >= 256 && tree->seq_off.size() == n + 1) {
+        rtx_index *ix = *out;
+        const uint64_t total = tree->seq_off[n] - tree->seq_off[0];
+        DevBuf<uint8_t> d_seq;
+        DevBuf<uint64_t> d_off;
+        if (!d_seq.alloc(total + 16) && !d_off.alloc(n + 1)) {
+            std::vector<uint64_t> off0(n + 1);
+            for (uint64_t i = 0; i <= n; i++) off0[i] = tree->seq_off[i] - tree->seq_off[0];
+            hipError_t e = hipMemcpy(d_seq.p, tree->seq_bytes.data() + tree->seq_off[0], total, hipMemcpyHostToDevice);
+            if (e == hipSuccess) e = hipMemcpy(d_off.p, off0.data(), (n + 1) * 8, hipMemcpyHostToDevice);
+            if (e == hipSuccess) build_locator(ix, d_seq.p, d_off.p, n);
+            else (void)hipGetLastError();
+        }
+    }
+    return RTX_OK;
+}
+
+void rtx_index_destroy(rtx_index *index) {
+    if (!index) return;
+    (void)hipSetDevice(index->device);
+    delete index;
+}
+
+uint64_t rtx_index_num_refs(const rtx_index *index) { return index ? index->n_total : 0; }
+uint64_t rtx_index_device_bytes(const rtx_index *index) {
+    if (!index) return 0;
+    return index->d_seg_dbits.n * 8 + index->d_seg_sbits.n * 8 + index->d_seg_sbase.n * 4 + index->d_seginfo.n * 4 + index->d_segslots.n * 2 + index->d_bitmap.n * 4 + index->d_row_of.n * 4 + index->d_list_len.n * 4 + index->d_loc_table.n * 4 + index->d_ubitmap.n * 4 + index->d_em_table.n * 8 + index->d_em_rep_off.n * 8 + index->d_em_rep_bytes.n + index->d_em_goff.n * 4 + index->d_em_gids.n * 4 + index->d_lnfact.n * 8 +
+           index->d_noderec.n * 16 + index->d_bnd_bits.n + index->d_bnd_rank.n * 4;
+}
+int rtx_index_set_batch(rtx_index *index, uint32_t sub_batch) {
+    if (!index) { set_error("null index handle"); return RTX_ERR_INVALID; }
+    index->uploaded = index->ran = index->synced = false;  // as RTX_OPT_SUB_BATCH: read at the next upload
+    index->sub_batch_req = sub_batch;
+    return RTX_OK;
+}
+
+int rtx_set_default_option(int option, uint64_t value) {
+    if (option == RTX_DEFAULT_SEGMENT_CLASSES) { g_seg_classes = value ? 1 : 0; return RTX_OK; }
+    if (option == RTX_DEFAULT_EXACT_HASH_MASK) { g_em_hash_mask = value ? value : ~0ull; return RTX_OK; }
+    set_error("rtx_set_default_option: unknown option %d", option);
+    return RTX_ERR_INVALID;
+}
+
+int rtx_index_set_option(rtx_index *index, int option, uint64_t value) {
+    if (!index) { set_error("null index handle"); return RTX_ERR_INVALID; }
+    // Options that shape the per-batch workspace (count format, scratch of the tile pruning, sub-batch size, probability tables) are
+    // read when a batch is uploaded: setting one of them drops the uploaded batch, so that the next rtx_batch_run cannot work on
+    // buffers sized for another layout (it fails with RTX_ERR_STATE until the batch is uploaded again).
+    switch (option) {
+        case RTX_OPT_SUB_BATCH: case RTX_OPT_PACKED_COUNTS: case RTX_OPT_HIT_PAIR: case RTX_OPT_TILE_PRUNE: case RTX_OPT_PROB_MODE:
+            index->uploaded = index->ran = index->synced = false;
+            break;
+        default: break;
+    }
+    switch (option) {
+        case RTX_OPT_SUB_BATCH: index->sub_batch_req = (uint32_t)value; return RTX_OK;
+        case RTX_OPT_STAGE_TIMING:
+            index->stage_timing = value ? 1u : 0u;
+            return RTX_OK;
+        case RTX_OPT_DEBUG_TAPS:
+            index->debug_taps = value ? 1u : 0u;
+            return RTX_OK;
+        case RTX_OPT_SHARD_PRUNE:
+            index->uploaded = index->ran = index->synced = false;
+            index->shard_prune_opt = value ? 1u : 0u;
+            return RTX_OK;
+        case RTX_OPT_DEVICE_EXACT:
+            index->uploaded = index->ran = index->synced = false;  // decided at the upload
+            index->dev_exact_opt = value ? 1u : 0u;
+            return RTX_OK;
+        case RTX_OPT_CLUSTER:
+            index->cluster = value ? 1u : 0u;
+            return RTX_OK;
+        case RTX_OPT_PACKED_COUNTS:
+            index->packed_opt = value ? 1u : 0u;
+            return RTX_OK;
+        case RTX_OPT_HIT_PAIR:
+            index->pair_opt = value ? 1u : 0u;
+            return RTX_OK;
+        case RTX_OPT_TILE_SKIP:
+            index->tile_skip = value ? 1u : 0u;
+            return RTX_OK;
+        case RTX_OPT_LOCATOR:
+            index->locator_opt = value ? 1u : 0u;
+            return RTX_OK;
+        case RTX_OPT_TILE_PRUNE:
+            index->prune_opt = value ? 1u : 0u;
+            return RTX_OK;
+        case RTX_OPT_PROB_MODE:
+            if (value > 2) break;
+            index->prob_mode = (int)value;
+            return RTX_OK;
+        default: break;
+    }
+    set_error("rtx_index_set_option: unknown option %d / value %llu", option, (unsigned long long)value);
+    return RTX_ERR_INVALID;
+}
+
+}  // extern "C"

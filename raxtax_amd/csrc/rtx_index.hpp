@@ -1,0 +1,325 @@
+// Internals of the device side of libraxtax_hip.so shared by its translation units (rtx_api_*.hip): the index handle, the buffer
+// helpers and the functions that sequence the kernels of a sub-batch.  Not part of the ABI (include/raxtax_hip.h is).
+//   rtx_api_index.hip     index creation (bitmaps, segment classes, union bitmap, locator, exact-match table), options
+//   rtx_api_batch.hip     per-batch workspace, upload (prefetch / activate), the kernel sequence of a sub-batch, rtx_batch_run
+//   rtx_api_download.hip  streamed download, host finalisation (sort lineage.rs:91-93, local signal lineage.rs:95-102)
+//   rtx_api_shard.hip     the staged path of a sharded database (rtx_shard_*)
+//   rtx_api_debug.hip     stage times, work counters, parity / debug taps
+// There is deliberately no CPU fallback: without a gfx950 device every entry point returns RTX_ERR_NO_DEVICE.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <thread>
+
+#include "rtx_internal.hpp"
+#include "rtx_kernels.hpp"
+#include "rtx_math.hpp"
+
+using namespace rtx;
+
+namespace rtxi {
+
+
+constexpr uint32_t kEmptyRow = 0xFFFFFFFFu;
+constexpr uint32_t kLnFactLen = 98320;  // covers t + n - 1 for every t <= 65535
+
+#define RTX_HIP(call)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (call);                                                                \
+        if (e_ != hipSuccess) {                                                                \
+            set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return e_ == hipErrorOutOfMemory ? RTX_ERR_OOM : RTX_ERR_HIP;                      \
+        }                                                                                      \
+    } while (0)
+
+template <class T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    int alloc(size_t count) {
+        if (count <= n && p) return RTX_OK;
+        release();
+        if (count == 0) count = 1;
+        hipError_t e = hipMalloc((void **)&p, count * sizeof(T));
+        if (e != hipSuccess) {
+            p = nullptr;
+            set_error("hipMalloc(%zu bytes) failed: %s", count * sizeof(T), hipGetErrorString(e));
+            return RTX_ERR_OOM;
+        }
+        n = count;
+        return RTX_OK;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    ~DevBuf() { release(); }
+};
+
+// Pinned host array (hipHostMalloc): D2H copies of the result records run at PCIe rate and asynchronously.
+template <class T>
+struct PinBuf {
+    T *p = nullptr;
+    size_t cap = 0, n = 0;
+    int resize(size_t count) {
+        if (count > cap) {
+            if (p) (void)hipHostFree(p);
+            p = nullptr;
+            const size_t want = count + count / 4 + 16;
+            if (hipHostMalloc((void **)&p, want * sizeof(T), hipHostMallocDefault) != hipSuccess) {
+                p = nullptr;
+                cap = n = 0;
+                set_error("hipHostMalloc(%zu bytes) failed", want * sizeof(T));
+                return RTX_ERR_OOM;
+            }
+            cap = want;
+        }
+        n = count;
+        return RTX_OK;
+    }
+    T *data() { return p; }
+    const T *data() const { return p; }
+    size_t size() const { return n; }
+    T &operator[](size_t i) { return p[i]; }
+    const T &operator[](size_t i) const { return p[i]; }
+    ~PinBuf() { if (p) (void)hipHostFree(p); }
+};
+
+inline uint64_t align_up(uint64_t v, uint64_t a) { return (v + a - 1) / a * a; }
+
+#ifndef RTX_PRUNE_MIN_TILES
+#define RTX_PRUNE_MIN_TILES 4  // tiles of 8192 references from which on the tile pruning is worth its bounds pass (configs[1], 7 tiles: 5.6 -> 7.8 M queries/s; it was 8 until the bounds pass lost its stores)
+#endif
+
+}  // namespace rtxi
+using namespace rtxi;
+
+struct rtx_index {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    uint64_t n_refs = 0;    // references held by this handle (the whole database, or one shard of it)
+    uint64_t n_total = 0;   // references of the whole database (Tree.num_tips)
+    uint32_t ref_lo = 0;    // first global reference id of this shard
+    uint32_t n_bnd_local = 0, bnd_first = 0;  // boundaries in (ref_lo, ref_hi] + 1; global index of ref_lo
+    const double *ext_prefix = nullptr;       // sharded mode: assembled global prefix handed to the walk
+    // ---- index proper
+    uint32_t n_rows = 0;        // non-empty posting lists
+    uint32_t stride_bytes = 0;  // bytes per bitmap row over all tiles (multiple of 1024)
+    uint64_t npad = 0;          // references per padded row (= stride_bytes * 8)
+    uint32_t ntiles = 0;        // 8192-reference tiles
+    DevBuf<uint32_t> d_bitmap, d_row_of, d_list_len;
+    // segment classes (rtx_segments.hip): class / sparse slot of every (row, tile) segment, slots of 32 local ids
+    DevBuf<uint32_t> d_seginfo, d_seg_sbase;
+    DevBuf<unsigned long long> d_seg_dbits, d_seg_sbits;
+    uint32_t seg_blocks = 0;  // > 0: kmer_extract uses the bit tables (many tiles)
+    DevBuf<uint16_t> d_segslots;
+    uint64_t n_seg_slots = 0;
+    uint32_t seg_stride = 0;
+    DevBuf<double> d_lnfact, d_inv;
+    // ---- memoised prob tables (t <= 1023), built lazily for the largest tmax seen
+    int prob_mode = 0;  // 0 auto, 1 recurrence kernel only, 2 tables (error if they do not fit)
+    uint32_t tab_tmax = 0;
+    DevBuf<double> d_tab_cmf, d_tab_ratio;
+    DevBuf<uint64_t> d_tab_off;
+    DevBuf<uint32_t> d_tab_moff;
+    DevBuf<uint16_t> d_tab_ilo, d_tab_sat;
+    bool use_tables = false;
+    // ---- taxonomy
+    FlatNodes nodes;
+    std::vector<uint32_t> bnd;  // sorted unique range endpoints
+    uint32_t n_bnd = 0;
+    DevBuf<uint4> d_noderec;  // {blo, bhi, first_child, n_children | type << 30} per node (lineage_walk)
+    DevBuf<uint32_t> d_bnd_rank;
+    DevBuf<uint8_t> d_bnd_bits;
+    // ---- exact-match lookup on the device (rtx_exact.hip): the distinct reference sequences ("groups") in a hash table
+    uint32_t dev_exact_opt = 1;       // RTX_OPT_DEVICE_EXACT
+    uint32_t em_groups = 0, em_bits = 0;
+    uint64_t em_hash_mask = ~0ull;    // RTX_DEFAULT_EXACT_HASH_MASK at creation (tests: a weak hash, so that probes collide)
+    DevBuf<uint2> d_em_table;         // [2^em_bits] {tag, group + 1}
+    DevBuf<uint64_t> d_em_rep_off;    // [groups + 1]
+    DevBuf<uint8_t> d_em_rep_bytes;   // the distinct sequences
+    DevBuf<uint32_t> d_em_goff, d_em_gids;   // ids of group g: gids[goff[g] .. goff[g + 1]), ascending (tree.rs:109-112)
+    std::vector<uint32_t> h_em_goff, h_em_gids;  // host copies: the ids behind the groups the device reports
+    DevBuf<uint32_t> d_exact_grp;     // [n_q] group of every query of the batch (0xFFFFFFFF: none)
+    bool dev_exact_used = false;      // the uploaded batch came without ids: the device looks them up (every rtx_batch_run)
+    struct HostExact {                // per host result set: the groups of a download and, on demand, the CSR of their ids
+        std::vector<uint32_t> grp;
+        std::vector<uint64_t> off;
+        std::vector<uint32_t> ids;
+        bool csr_valid = false, valid = false;
+    } host_exact[2];
+    // ---- batch inputs
+    uint64_t n_q = 0;
+    bool uploaded = false, ran = false, synced = false;
+    uint32_t last_flags = 0;
+    // ---- processing order of the batch (rtx_cluster.hip): perm[position] = query, inv[query] = position
+    uint32_t cluster = 1;  // RTX_OPT_CLUSTER
+    uint32_t packed_opt = 1;  // RTX_OPT_PACKED_COUNTS
+    uint32_t tile_skip = 1;   // RTX_OPT_TILE_SKIP: taxon_prefix reads only the tiles that hold a reference with p >= 1e-30
+    uint32_t pair_opt = 1;    // RTX_OPT_HIT_PAIR
+    uint32_t prune_opt = 1;   // RTX_OPT_TILE_PRUNE: hit_count visits only the tiles that can hold a reference with any probability (rtx_prune.hip)
+    bool prune_used = false;  // the last run pruned
+    bool dbg_full = false;    // ... and the debug taps have recounted the last sub-batch in full since
+    bool dbg_full_run = false;  // (the recount in progress: enqueue_hit leaves the pruning out)
+    DevBuf<uint32_t> d_ubitmap;  // union bitmap: one column per block of 2^kPruneShift references, tile-major like d_bitmap
+    uint32_t u_stride_bytes = 0, u_ntiles = 0;
+    uint64_t u_nblocks = 0;
+    DevBuf<unsigned long long> d_prune_stats;
+    uint32_t shard_prune_opt = 0;  // RTX_OPT_SHARD_PRUNE: a reference shard prunes with the threshold of the whole database (rtx_shard_bounds)
+    uint32_t debug_taps = 0;     // RTX_OPT_DEBUG_TAPS: prune_kernel leaves its view of every query (rtx_debug_prune_detail)
+    DevBuf<uint32_t> d_prune_detail;  // [sub_batch][kPruneDetailWords]
+    uint32_t locator_opt = 1; // RTX_OPT_LOCATOR: the sort key of the processing order is led by the query's position in the database
+    DevBuf<uint32_t> d_loc_table;  // 12-mer -> lowest reference position (rtx_cluster.hip); only when built from sequences
+    bool pair_used = false;   // the last run went through hit_count_pair_kernel
+    DevBuf<uint32_t> d_group_rows;
+    uint32_t n_groups_run = 0;  // groups of the whole batch (n_sub * groups_per_sub): the second half of d_group_rows starts there
+    uint32_t groups_per_sub = 0;
+    bool packed() const { return packed_opt && planes <= 10; }
+    DevBuf<uint64_t> d_skey_in, d_skey_out;
+    DevBuf<uint32_t> d_sidx, d_perm, d_iperm;
+    DevBuf<uint8_t> d_sort_tmp;
+    PinBuf<uint32_t> h_perm, h_inv;
+    DevBuf<uint8_t> d_bases;  // the current batch, one byte per base (what the kernels read): unpacked from the staged transfer at activation
+    // Two input sets: a batch is STAGED (rtx_batch_prefetch: bases packed two per byte into pinned memory, offsets, exact-match ids;
+    // asynchronous H2D on h2d_stream) while the batch before it runs out of the other set, and becomes the current one at
+    // rtx_batch_activate.  rtx_batch_upload = prefetch + activate.
+    struct Inputs {
+        DevBuf<uint8_t> d_packed;          // bases two per byte (or raw, one per byte, if a byte above 15 was seen)
+        DevBuf<uint64_t> d_base_off, d_exact_off;
+        DevBuf<uint32_t> d_exact_ids;
+        PinBuf<uint8_t> h_packed;
+        PinBuf<uint64_t> h_base_off, h_exact_off;
+        PinBuf<uint32_t> h_exact_ids;
+        uint64_t n_q = 0, total = 0, max_len = 0, n_exact = 0;
+        bool packed = true, has_exact = false, staged = false, recorded = false;
+        hipEvent_t ready = nullptr;        // its transfer has arrived
+    } in[2];
+    uint32_t cur_in = 0;               // the set of the current (activated) batch
+    hipStream_t h2d_stream = nullptr;
+    hipEvent_t ev_activated = nullptr; // on the handle's stream, behind everything that was enqueued before the current batch was activated:
+                                       // the kernels that read the OTHER input set have run when it fires (a transfer into that set waits for it)
+    uint64_t sum_query_bytes = 0;
+    uint32_t kstride = 0, rstride = 0, hstride = 0, tmax = 0;
+    int planes = 10;
+    // ---- sub-batch scratch: two sets -- a staged (reference-sharded) run alternates between them, so that the exchange of
+    // one sub-batch can overlap with the counting of the next; a whole-database handle uses set 0 only
+    uint32_t sub_batch_req = 0, sub_batch = 0;
+    struct Scratch {
+        DevBuf<uint16_t> d_kmers, d_counts, d_tilemax;
+        DevBuf<uint32_t> d_rows, d_t, d_nrows, d_hist, d_order, d_srows, d_nsparse;
+        DevBuf<unsigned long long> d_dmask;
+        DevBuf<double> d_table_z, d_prefix;
+        DevBuf<uint2> d_urec;   // hit_count_pair_kernel: union row lists of the pairs of the sub-batch
+        DevBuf<uint32_t> d_nu;
+        // tile pruning: the queries counted against the union bitmap (every row dense: constant masks) leave the largest bound of
+        // every tile and the best block (bounds_epilogue); thresholds and the live tiles per pair (prune_kernel)
+        DevBuf<unsigned long long> d_uones;
+        DevBuf<uint32_t> d_uzero, d_live, d_best_key;
+        DevBuf<uint32_t> d_items;  // [pairs x tiles] the (pair, tile) blocks with a live query | [1] their number | [8] queue per XCD | [pairs] live tiles per pair | [pairs] offsets
+        DevBuf<uint16_t> d_tile_ub, d_prune_thr, d_prune_i1;
+        DevBuf<uint32_t> d_best;  // [B][kPruneBestWords] reference shards: the candidate for the best block of the database
+    } sc[2];
+    bool staged = false;  // driven with rtx_shard_*: sub-batch sb works in scratch set sb & 1, so that the exchange of one
+                          // sub-batch (RCCL, on the caller's stream) can overlap with the counting of the next
+    uint32_t last_set = 0;  // scratch set of the last sub-batch (debug taps)
+    DevBuf<double> d_probs_dbg;
+    DevBuf<uint16_t> d_counts_dbg;
+    // ---- per-query results
+    DevBuf<uint8_t> d_status;
+    DevBuf<uint32_t> d_t_all, d_nrows_all, d_n_rows, d_flags, d_ndist;
+    DevBuf<double> d_gs, d_z;
+    DevBuf<unsigned long long> d_hq, d_row_start, d_cursor;
+    DevBuf<DevRow> d_arena;
+    uint64_t arena_cap = 0;
+    // ---- timing
+    std::vector<hipEvent_t> events;  // 2 per (sub-batch, stage)
+    uint32_t n_sub_last = 0;
+    // ---- host results
+    // two alternating sets: the view of download c stays valid while batch c+1 runs and is downloaded
+    struct HostRes {
+        std::vector<uint32_t> v_row_lineage, v_row_node, v_row_depth;
+        std::vector<uint32_t> h_t;
+        std::vector<uint8_t> h_status;
+        std::vector<double> v_row_conf, v_row_local;
+        std::vector<double> h_gs;
+        std::vector<uint64_t> v_row_begin;  // by query; the rows themselves are in processing order
+        std::vector<uint32_t> v_row_count;
+    } host_res[2];
+    // D2H staging of the per-query records, indexed by position in the processing order
+    PinBuf<uint32_t> hs_t;
+    PinBuf<uint8_t> hs_status;
+    PinBuf<double> hs_gs;
+    uint32_t res_set = 0;
+    PinBuf<uint32_t> h_nrows_all, h_n_rows;
+    // streamed download: per sub-batch a snapshot of the arena cursor + an event; rtx_batch_download copies and
+    // finalises finished sub-batches on `copy_stream` while later ones are still running
+    std::vector<hipEvent_t> ev_sub;
+    PinBuf<unsigned long long> h_cursor_sub;
+    hipStream_t copy_stream = nullptr;
+    uint32_t n_sub_run = 0;
+    bool stream_dl = false;
+    PinBuf<unsigned long long> h_hq, h_row_start;
+    uint32_t stage_timing = 0;  // 0: HIP events around hit_count only; 1: around every kernel
+    PinBuf<DevRow> h_arena;
+    // per node: expected vector and first level of the local signal (node_tables; finalise_range)
+    std::vector<double> h_node_expd;
+    std::vector<uint8_t> h_node_sig0;
+    uint32_t h_node_stride = 1;
+
+    ~rtx_index() {
+        for (auto e : events) (void)hipEventDestroy(e);
+        for (auto e : ev_sub) (void)hipEventDestroy(e);
+        for (auto &i : in)
+            if (i.ready) (void)hipEventDestroy(i.ready);
+        if (ev_activated) (void)hipEventDestroy(ev_activated);
+        if (h2d_stream) (void)hipStreamDestroy(h2d_stream);
+        if (copy_stream) (void)hipStreamDestroy(copy_stream);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+};
+
+namespace rtxi {
+
+// ---- rtx_api_batch.hip
+int bind(rtx_index *ix);
+int ensure_events(rtx_index *ix, size_t count);
+
+// One sub-batch = three groups of kernels.  A whole-database handle runs them back to back; a
+// reference-sharded handle (config 5) stops after each group for the exchange with the other shards.
+struct SubBatch {
+    uint32_t sb, nq, set;
+    uint64_t q0;
+    hipStream_t s;   // main stream
+    bool timed;      // HIP events around hit_count (the roofline kernel)
+    bool timed_all;  // ... and around every other kernel (RTX_OPT_STAGE_TIMING)
+};
+SubBatch sub_batch_of(rtx_index *ix, uint32_t sb, bool timed);
+uint8_t *counts_lo(rtx_index *ix, rtx_index::Scratch &sc);
+uint16_t *counts_hi(rtx_index *ix, rtx_index::Scratch &sc);
+size_t counts_elems(const rtx_index *ix, uint64_t B);
+hipEvent_t stage_event(rtx_index *ix, const SubBatch &b, int stage, int which);
+int enqueue_kmer(rtx_index *ix, const SubBatch &b, hipStream_t s);
+int enqueue_hit(rtx_index *ix, const SubBatch &b, uint32_t flags, hipStream_t s, int part = 0);
+int enqueue_count(rtx_index *ix, const SubBatch &b, uint32_t flags);
+int enqueue_prob_prefix(rtx_index *ix, const SubBatch &b, bool fuse_walk, bool prob_only = false);
+int enqueue_walk(rtx_index *ix, const SubBatch &b, const double *prefix, hipStream_t s);
+int order_batch(rtx_index *ix, bool cluster);
+int begin_run(rtx_index *ix, uint32_t *n_sub_out, bool *timed_out, bool cluster);
+int enqueue_batch(rtx_index *ix, uint32_t flags);
+int ensure_prob_tables(rtx_index *ix);
+int prepare_workspace(rtx_index *ix, uint64_t n_queries, uint64_t tmax, uint64_t max_len);
+int alloc_scratch_set(rtx_index *ix, uint32_t k);
+// ---- rtx_api_download.hip
+void node_tables(rtx_index *ix);
+void finalise_range(rtx_index *ix, uint64_t pa, uint64_t pb, uint64_t row_base);
+uint64_t finalise_mt(rtx_index *ix, uint64_t pa, uint64_t pb, uint64_t row_base, unsigned nt);
+int size_host_results(rtx_index *ix, rtx_index::HostRes &hr, uint64_t nq, uint64_t arena_rows);
+int copy_results(rtx_index *ix, uint64_t q0, uint64_t n, uint64_t r0, uint64_t r1, hipStream_t cs);
+
+}  // namespace rtxi

@@ -1,5 +1,5 @@
 // Kernel parameter blocks and launchers (rtx_kernels.hip) used by the C-ABI layer
-// (rtx_api.hip).  Plain structs passed by value to the kernels.
+// (rtx_api_*.hip).  Plain structs passed by value to the kernels.
 #pragma once
 
 #include <hip/hip_runtime.h>

@@ -167,7 +167,7 @@ int enqueue_hit(rtx_index *ix, const SubBatch &b, uint32_t flags, hipStream_t s,
         if (part != 2) {
             if (b.timed) RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_TILE_BOUNDS, 0), s));
             RTX_HIP(hipMemsetAsync(sc.d_best_key.p, 0, (size_t)b.nq * 4, s));  // the waves of a query's union tiles meet in an atomicMax
-            launch_hit_count_pair_bounds(s, up, b.nq, ix->u_ntiles);  // the union of the pair's rows serves both passes
+            launch_hit_count_pair_bounds(s, up, b.nq, ix->u_ntiles, ix->planes);  // the union of the pair's rows serves both passes
             if (b.timed) RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_TILE_BOUNDS, 1), s));
         }
         if (b.timed && part != 1) RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_TILE_PRUNE, 0), s));
@@ -231,7 +231,7 @@ int enqueue_hit(rtx_index *ix, const SubBatch &b, uint32_t flags, hipStream_t s,
             RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_HIT_COUNT, 0), s));
         }
     }
-    if (ix->pair_used) launch_hit_count_pair(s, hp, b.nq, ix->ntiles);
+    if (ix->pair_used) launch_hit_count_pair(s, hp, b.nq, ix->ntiles, ix->planes);
     else launch_hit_count(s, hp, b.nq, ix->ntiles, ix->planes);
     if (b.timed) RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_HIT_COUNT, 1), s));
     return RTX_OK;
@@ -518,7 +518,8 @@ constexpr uint32_t kMaxSubBatch = 65536;
 // 8 192: 971 ms, 16 384: 953, 32 768: 964, 65 536: 995
 // With tile pruning a sub-batch is far less work and the fixed cost of its nine launches counts: N = 500k, per 1 M queries:
 // 8 192: 191 ms, 16 384: 171, 32 768: 159.5, 49 152: 158.1, 65 536: 157.8
-constexpr uint32_t kDefaultSubBatch = 20480, kDefaultSubBatchLarge = 16384, kDefaultSubBatchPruned = 32768;
+// Round 4 (stages for every kernel, 113 ms per step): 32 768: 113.1 ms, 49 152: 111.0, 65 536: 109.7 -- fewer launches, fewer tails.
+constexpr uint32_t kDefaultSubBatch = 20480, kDefaultSubBatchLarge = 16384, kDefaultSubBatchPruned = 65536;
 
 
 // Sizes and allocates the per-batch workspace for n_queries queries of at most tmax k-mers.
@@ -534,7 +535,7 @@ int prepare_workspace(rtx_index *ix, uint64_t n_queries, uint64_t tmax, uint64_t
     ix->kstride = (uint32_t)align_up(tmax, 8);
     ix->rstride = (uint32_t)align_up(tmax, 64) + 64;  // row list padded to whole 64-row chunks
     ix->hstride = (uint32_t)align_up(tmax + 1, 8);
-    ix->planes = tmax <= 1023 ? 10 : (tmax <= 4095 ? 12 : 16);
+    ix->planes = tmax <= 255 ? 8 : (tmax <= 1023 ? 10 : (tmax <= 4095 ? 12 : 16));  // (8: the pair kernel; the others run their 10-plane forms)
     ix->n_q = n_queries;
     if ((rc = ensure_prob_tables(ix))) return rc;
     // ---- per-query results

@@ -410,13 +410,15 @@ __device__ __forceinline__ void hit_epilogue_x(const HitParams &p, uint32_t (&pl
                             nv.y = lo8.y;
                             __builtin_nontemporal_store(nv, reinterpret_cast<u32x2_nt *>(out_lo + goff));
                         }
-                        // high bytes (0..3 each) -> 2 bits per reference: byte j moves to bit 2j
-                        const uint32_t hb0 = __builtin_amdgcn_perm(st.y, st.x, 0x07050301u), hb1 = __builtin_amdgcn_perm(st.w, st.z, 0x07050301u);
-                        const uint32_t h0 = (hb0 | (hb0 >> 6) | (hb0 >> 12) | (hb0 >> 18)) & 0xFFu;
-                        const uint32_t h1 = (hb1 | (hb1 >> 6) | (hb1 >> 12) | (hb1 >> 18)) & 0xFFu;
-                        const uint32_t h16 = h0 | (h1 << 8);
-                        const int gi = w * 4 + g2;
-                        hiw[gi >> 1] |= h16 << ((gi & 1) * 16);
+                        if (NP > 8) {  // (eight planes <=> t <= 255: a count -- dense and sparse part together at most t -- fits its low byte)
+                            // high bytes (0..3 each) -> 2 bits per reference: byte j moves to bit 2j
+                            const uint32_t hb0 = __builtin_amdgcn_perm(st.y, st.x, 0x07050301u), hb1 = __builtin_amdgcn_perm(st.w, st.z, 0x07050301u);
+                            const uint32_t h0 = (hb0 | (hb0 >> 6) | (hb0 >> 12) | (hb0 >> 18)) & 0xFFu;
+                            const uint32_t h1 = (hb1 | (hb1 >> 6) | (hb1 >> 12) | (hb1 >> 18)) & 0xFFu;
+                            const uint32_t h16 = h0 | (h1 << 8);
+                            const int gi = w * 4 + g2;
+                            hiw[gi >> 1] |= h16 << ((gi & 1) * 16);
+                        }
                     } else {
                         *reinterpret_cast<uint4 *>(out + goff) = st;
                     }
@@ -445,7 +447,13 @@ __device__ __forceinline__ void hit_epilogue_x(const HitParams &p, uint32_t (&pl
             }
         }
     }
-    if (kPacked) {
+    if (kPacked && NP <= 8) {  // no count above 255: the tile's high-bit words are zero
+        if (active) {
+            uint4 *dst = reinterpret_cast<uint4 *>(p.counts_hi + (size_t)q * (p.npad >> 3) + (size_t)tile * 1024u + lane * 16u);
+            __builtin_nontemporal_store(u32x4_t{0u, 0u, 0u, 0u}, reinterpret_cast<u32x4_t *>(dst));
+            __builtin_nontemporal_store(u32x4_t{0u, 0u, 0u, 0u}, reinterpret_cast<u32x4_t *>(dst) + 1);
+        }
+    } else if (kPacked) {
         // The high-bit words leave in chunk order (u16 index g * L + lane within the tile): transposed through the
         // byte-counter region of LDS (free now) so that every lane stores 32 contiguous bytes.
         wave_lds_sync();

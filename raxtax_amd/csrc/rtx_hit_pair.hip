@@ -409,19 +409,27 @@ void launch_pair_union(hipStream_t s, const uint32_t *rows, const uint32_t *nrow
 #ifndef RTX_ITEM_GRID_HALVES
 #define RTX_ITEM_GRID_HALVES 4  // workgroups per pass of the list of live blocks, in halves of the number of pairs
 #endif
-void launch_hit_count_pair(hipStream_t s, const HitParams &p, uint32_t nq, uint32_t ntiles) {
+// NP bit planes: 10 (t <= 1023), or 8 when every query of the batch has t <= 255 (amplicons of ~200 bp, the reference's example data:
+// no ripple into planes 8 and 9, no high-bit words in the epilogue -- where short reads spend most of a block: few rows, the same
+// 8192 counts to unpack -- and sixteen registers less)
+template <int NP>
+static void launch_hit_count_pair_np(hipStream_t s, const HitParams &p, uint32_t nq, uint32_t ntiles) {
     static_assert(3u * kPairListDw >= 1024u + 2048u + 64u, "histogram (t <= 1023) and byte counters (+ pad words) alias the lists");
     static_assert(kSegMaxSparseRows + 1 >= kSparseIt * 64, "the slot id lists are read without a bound");
     const uint32_t np = (nq + 1u) / 2u;
     // with the list of live blocks: two blocks' worth of workgroups per pair and pass (the bench workload keeps 1.5), never more than the blocks there are
     const dim3 grid = p.items ? dim3((uint32_t)((std::min<uint64_t>((uint64_t)np * ntiles, std::max<uint64_t>((uint64_t)RTX_ITEM_GRID_HALVES * np / 2u, 2048ull)) + 7u) & ~7ull)) : dim3(np, ntiles);  // (a multiple of 8: the kernel deals a pass to the XCDs)
     if (p.counts_lo) {
-        if (p.items) hipLaunchKernelGGL((hit_count_pair_kernel<10, true, false, true>), grid, dim3(64), kPairLdsBytes, s, p);
-        else hipLaunchKernelGGL((hit_count_pair_kernel<10, true, false, false>), grid, dim3(64), kPairLdsBytes, s, p);
+        if (p.items) hipLaunchKernelGGL((hit_count_pair_kernel<NP, true, false, true>), grid, dim3(64), kPairLdsBytes, s, p);
+        else hipLaunchKernelGGL((hit_count_pair_kernel<NP, true, false, false>), grid, dim3(64), kPairLdsBytes, s, p);
     } else {
-        if (p.items) hipLaunchKernelGGL((hit_count_pair_kernel<10, false, false, true>), grid, dim3(64), kPairLdsBytes, s, p);
-        else hipLaunchKernelGGL((hit_count_pair_kernel<10, false, false, false>), grid, dim3(64), kPairLdsBytes, s, p);
+        if (p.items) hipLaunchKernelGGL((hit_count_pair_kernel<NP, false, false, true>), grid, dim3(64), kPairLdsBytes, s, p);
+        else hipLaunchKernelGGL((hit_count_pair_kernel<NP, false, false, false>), grid, dim3(64), kPairLdsBytes, s, p);
     }
+}
+void launch_hit_count_pair(hipStream_t s, const HitParams &p, uint32_t nq, uint32_t ntiles, int planes) {
+    if (planes <= 8) launch_hit_count_pair_np<8>(s, p, nq, ntiles);
+    else launch_hit_count_pair_np<10>(s, p, nq, ntiles);
 }
 
 void launch_live_items(hipStream_t s, const uint32_t *live, uint32_t live_words, const uint32_t *pair_live, uint32_t nq, uint32_t ntiles, uint32_t *off,
@@ -431,8 +439,9 @@ void launch_live_items(hipStream_t s, const uint32_t *live, uint32_t live_words,
     hipLaunchKernelGGL(live_items_kernel, dim3((np + 1023u) / 1024u), dim3(1024), (size_t)ntiles * 4, s, live, live_words, nq, ntiles, off, items);
 }
 
-void launch_hit_count_pair_bounds(hipStream_t s, const HitParams &p, uint32_t nq, uint32_t u_ntiles) {
-    hipLaunchKernelGGL((hit_count_pair_kernel<10, true, true, false>), dim3((nq + 1u) / 2u, u_ntiles), dim3(64), kPairLdsBytes, s, p);
+void launch_hit_count_pair_bounds(hipStream_t s, const HitParams &p, uint32_t nq, uint32_t u_ntiles, int planes) {
+    if (planes <= 8) hipLaunchKernelGGL((hit_count_pair_kernel<8, true, true, false>), dim3((nq + 1u) / 2u, u_ntiles), dim3(64), kPairLdsBytes, s, p);
+    else hipLaunchKernelGGL((hit_count_pair_kernel<10, true, true, false>), dim3((nq + 1u) / 2u, u_ntiles), dim3(64), kPairLdsBytes, s, p);
 }
 
 }  // namespace rtx

@@ -284,11 +284,11 @@ void launch_kmer_extract(hipStream_t s, const KmerParams &p, uint32_t nq);
 void launch_hit_count(hipStream_t s, const HitParams &p, uint32_t nq, uint32_t ntiles, int planes);
 void launch_pair_union(hipStream_t s, const uint32_t *rows, const uint32_t *nrows, uint32_t rstride, uint32_t nq, uint2 *urec,
                        uint32_t *nu, uint32_t ustride);
-void launch_hit_count_pair(hipStream_t s, const HitParams &p, uint32_t nq, uint32_t ntiles);  // 10 bit planes only
+void launch_hit_count_pair(hipStream_t s, const HitParams &p, uint32_t nq, uint32_t ntiles, int planes);  // 8 (every t <= 255) or 10 bit planes
 // the list of the live (pair, tile) blocks from the masks and the per-pair numbers prune_kernel left: off = [pairs] scratch
 void launch_live_items(hipStream_t s, const uint32_t *live, uint32_t live_words, const uint32_t *pair_live, uint32_t nq, uint32_t ntiles, uint32_t *off,
                        uint32_t *items, uint32_t *n_items);
-void launch_hit_count_pair_bounds(hipStream_t s, const HitParams &p, uint32_t nq, uint32_t u_ntiles);  // ... on the union bitmap: bounds_epilogue
+void launch_hit_count_pair_bounds(hipStream_t s, const HitParams &p, uint32_t nq, uint32_t u_ntiles, int planes);  // ... on the union bitmap: bounds_epilogue
 size_t prob_table_lds_bytes(uint32_t tmax);
 void launch_prob_table(hipStream_t s, const ProbParams &p, uint32_t nq);
 size_t prob_lookup_lds_bytes(uint32_t tmax);

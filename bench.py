@@ -72,6 +72,7 @@ def parse():
     ap.add_argument("--no-locator", action="store_true", help="processing order by min-hash alone (RTX_OPT_LOCATOR = 0; A/B measurements)")
     ap.add_argument("--no-tile-prune", action="store_true", help="hit_count counts every tile of 8192 references (RTX_OPT_TILE_PRUNE = 0; default: only the tiles that can hold a reference with any probability)")
     ap.add_argument("--tile-prune", action="store_true", help="(the default; kept for older command lines)")
+    ap.add_argument("--no-fine-bounds", action="store_true", help="tile pruning with its first stage of bounds only (RTX_OPT_FINE_BOUNDS = 0; A/B measurements)")
     ap.add_argument("--no-tile-skip", action="store_true", help="taxon_prefix sums every reference (RTX_OPT_TILE_SKIP = 0; A/B measurements)")
     ap.add_argument("--mu-q", type=float, default=0.02, help="per-site substitution rate of a query against its source reference (the headline: 0.02)")
     ap.add_argument("--exact-frac", type=float, default=0.10, help="share of the queries that are exact copies of a reference (the headline: 0.10)")
@@ -356,6 +357,7 @@ def roofline_block(args, work, prob_work, stage_ms, stage_n, n_queries_step, que
     if prune is not None and prune.get("pairs"):
         out["tile_pruning"] = {
             "live_tiles_per_pair": prune["live_tiles_per_pair"], "live_tiles_per_query": prune.get("live_tiles_per_query"), "tiles": ntiles,
+            "live_tiles_per_pair_first_stage": prune.get("live_tiles_per_pair_first_stage"), "fine_blocks_per_pair": prune.get("fine_blocks_per_pair"),
             "mean_threshold": prune["mean_threshold"], "mean_best_hit_lower_bound": prune["mean_best_hit_lower_bound"],
             "tiles_above_threshold_per_query": prune.get("tiles_above_threshold_per_query"),     # what exact knowledge would count
             "queries_with_threshold": prune.get("queries_with_threshold"),
@@ -489,6 +491,7 @@ def extras_block(args, rx, lib, index, tree, db, qs, flags):
         dt_full = timed(plain)
         rx._lib.check(lib.rtx_index_set_option(index._h, 13, 0 if args.no_tile_prune else 1))
         sweep.append({"mu_q": mu, "value": 131072 / dt, "ms_per_step": dt * 1e3, "value_unpruned": 131072 / dt_full, "live_tiles_per_pair": st["live_tiles_per_pair"],
+                      "live_tiles_per_pair_first_stage": st["live_tiles_per_pair_first_stage"], "fine_blocks_per_pair": st["fine_blocks_per_pair"],
                       "live_tiles_per_query": st.get("live_tiles_per_query"),
                       "share_with_threshold": st["queries_with_threshold"] / 131072, "mean_threshold": st["mean_threshold"],
                       "mean_best_hit_lower_bound": st["mean_best_hit_lower_bound"],
@@ -635,7 +638,8 @@ def main():
                          stage_timing=not args.hit_events_only, cluster=False if args.no_cluster else None,
                          packed_counts=False if args.u16_counts else None,
                          tile_skip=False if args.no_tile_skip else None, hit_pair=False if args.no_pair else None,
-                         locator=False if args.no_locator else None, tile_prune=False if args.no_tile_prune else None)
+                         locator=False if args.no_locator else None, tile_prune=False if args.no_tile_prune else None,
+                         fine_bounds=False if args.no_fine_bounds else None)
         t_exact = None
         if args.host_exact_match or not index.has_exact_lookup:
             t0 = time.perf_counter()

@@ -208,11 +208,16 @@ int rtx_index_set_batch(rtx_index *index, uint32_t sub_batch);
 #define RTX_OPT_TILE_PRUNE 13 /* 1 (default): hit_count counts only the tiles of 8192 references that can hold a reference with any
                                * probability -- decided from upper bounds (the queries counted against a union bitmap over blocks
                                * of 64 references) and a per-query threshold u: the references with a count up to u hold less
-                               * than 1e-12 of probability together and are treated as references without a hit (rtx_prune.hip;
-                               * every probability and confidence sum stays within 1e-11 of the full count, the result of a
-                               * query does not depend on the rest of the batch).  Takes effect with t <= 1023,
+                               * than 1e-10 of probability together and are treated as references without a hit (rtx_prune.hip;
+                               * every probability and confidence sum stays within 1e-9 of the full count -- measured 1e-11 --,
+                               * the result of a query does not depend on the rest of the batch).  Takes effect with t <= 1023,
                                * RTX_OPT_HIT_PAIR = 1, RTX_OPT_TILE_SKIP = 1, the whole database on the handle and 4 tiles or more;
                                * the debug taps recount the tapped sub-batch in full.  0: every tile is counted */
+#define RTX_OPT_FINE_BOUNDS 17 /* 1 (default): second stage of the bounds of the tile pruning on databases of 16 tiles or more: the pairs of
+                                * queries that the bounds over blocks of 64 references leave 4 or more live tiles are counted against a
+                                * second union bitmap over blocks of 8 references (1/8 of the index), which takes the tiles without a block
+                                * above the query's threshold off their lists before the counting pass.  Results do not change (a bound is a
+                                * bound); 0: first stage only (A/B measurements) */
 /* RTX_OPT_SUB_BATCH, _PACKED_COUNTS, _HIT_PAIR, _TILE_PRUNE and _PROB_MODE shape the workspace that rtx_batch_upload sizes:
  * setting one of them drops the uploaded batch (rtx_batch_run then fails with RTX_ERR_STATE until the batch is uploaded again). */
 int rtx_index_set_option(rtx_index *index, int option, uint64_t value);
@@ -374,8 +379,10 @@ int rtx_batch_sub_batch(const rtx_index *index, uint32_t *sub_batch, uint32_t *n
 /* tile pruning of the last run (RTX_OPT_TILE_PRUNE): out[0] (pair, tile) blocks that are counted for at least one of their two queries, [1] pairs,
  * [2] sum of the lower bounds of the best hit, [3] sum of the thresholds, [4] sum of the largest tile bounds, [5] queries, [6] bounds below a count
  * they bound (must be 0), [7] (query, tile) combinations that are counted, [8] (query, tile) combinations with a count above the query's
- * threshold -- what exact knowledge would have counted --, [9] queries with a threshold; all 0 if the run did not prune */
-int rtx_debug_prune_stats(rtx_index *index, uint64_t *out /*10*/);
+ * threshold -- what exact knowledge would have counted --, [9] queries with a threshold; all 0 if the run did not prune.
+ * The fine bounds pass (RTX_OPT_FINE_BOUNDS): [10] (query, tile) combinations it took off the lists, [11] its (pair, fine tile) blocks,
+ * [12] (pair, tile) blocks the counting pass was left with (0 if the pass did not run: then [0] is that number), [13..15] 0 */
+int rtx_debug_prune_stats(rtx_index *index, uint64_t *out /*16*/);
 /* table / Z of a query of the last sub-batch as the PRUNED run computed it (0 for the counts up to the query's threshold), its Z and the
  * threshold; must be called before any other tap (those recount the sub-batch in full) */
 int rtx_debug_pruned_prob_table(rtx_index *index, uint64_t query, double *table_over_z /*t+1*/, double *z, uint32_t *threshold);

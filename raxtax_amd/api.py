@@ -219,7 +219,7 @@ class Index:
                  stage_timing: bool = False, cluster: Optional[bool] = None, segment_classes=None,
                  packed_counts: Optional[bool] = None,
                  tile_skip: Optional[bool] = None, hit_pair=None, locator: Optional[bool] = None, tile_prune: Optional[bool] = None,
-                 debug_taps: bool = False, device_exact: Optional[bool] = None):
+                 debug_taps: bool = False, device_exact: Optional[bool] = None, fine_bounds: Optional[bool] = None):
         self._lib = _lib.load()
         self.tree = tree
         if segment_classes is None:
@@ -251,6 +251,8 @@ class Index:
             check(self._lib.rtx_index_set_option(self._h, 14, 1))
         if device_exact is not None:
             check(self._lib.rtx_index_set_option(self._h, 15, int(device_exact)))
+        if fine_bounds is not None:
+            check(self._lib.rtx_index_set_option(self._h, 17, int(fine_bounds)))
         self._view = ResultView()
         self._keep = None
 
@@ -414,10 +416,12 @@ class Index:
 
     def debug_prune_stats(self) -> dict:
         """Tile pruning of the last run: live tiles per pair, mean lower bound of the best hit, mean threshold, mean largest tile bound."""
-        out = np.zeros(10, dtype=np.uint64)
+        out = np.zeros(16, dtype=np.uint64)
         check(self._lib.rtx_debug_prune_stats(self._h, ptr(out, u64p)))
         pairs, nq = max(int(out[1]), 1), max(int(out[5]), 1)
-        return {"live_tiles_per_pair": int(out[0]) / pairs, "pairs": int(out[1]), "mean_best_hit_lower_bound": int(out[2]) / nq,
+        counted = int(out[12]) if int(out[11]) or int(out[12]) else int(out[0])   # after the fine bounds pass, if it ran
+        return {"live_tiles_per_pair": counted / pairs, "live_tiles_per_pair_first_stage": int(out[0]) / pairs,
+                "fine_blocks_per_pair": int(out[11]) / pairs, "fine_cleared_per_query": int(out[10]) / nq, "pairs": int(out[1]), "mean_best_hit_lower_bound": int(out[2]) / nq,
                 "mean_threshold": int(out[3]) / nq, "mean_largest_tile_bound": int(out[4]) / nq, "bound_violations": int(out[6]), "live_tiles_per_query": int(out[7]) / nq,
                 "tiles_above_threshold_per_query": int(out[8]) / max(int(out[9]), 1), "queries_with_threshold": int(out[9])}
 

@@ -208,6 +208,30 @@ int enqueue_hit(rtx_index *ix, const SubBatch &b, uint32_t flags, hipStream_t s,
         ProbTables tb{ix->d_tab_cmf.p, ix->d_tab_ratio.p, ix->d_tab_off.p, ix->d_tab_moff.p, ix->d_tab_ilo.p, ix->d_tab_sat.p, ix->tab_tmax};
         launch_prune(s, pr, tb, b.nq);
         if (part == 1) { RTX_HIP(hipGetLastError()); return RTX_OK; }  // the caller exchanges RTX_BUF_BEST, then part 2
+        // (2b) second stage of the bounds (whole-database handles with a fine union bitmap): the pairs that are left many live tiles are
+        // counted against the union bitmap over blocks of 8 references, which takes the tiles without a block above the threshold off
+        // their lists (fine_epilogue); prune_kernel's number of live tiles per pair is brought up to date for the list below
+        if (part == 0 && ix->fine_opt && ix->d_fbitmap.p && ix->pair_used && sc.d_fine_items.p) {
+            HitParams fp = hp;
+            fp.bitmap = ix->d_fbitmap.p;
+            fp.stride_bytes = ix->f_stride_bytes;
+            fp.n_refs = ix->f_nblocks;
+            fp.ntiles = ix->f_ntiles;
+            fp.counts = nullptr;
+            fp.counts_lo = nullptr;
+            fp.counts_hi = nullptr;
+            fp.tile_max = nullptr;
+            fp.flags = 0;
+            fp.group_rows = nullptr;  // (its rows are not part of the work accounting of the roofline: reported through its own counters)
+            fp.live = sc.d_live.p;
+            fp.live_words = pr.live_words;
+            fp.prune_thr = sc.d_prune_thr.p;
+            fp.fine_n_refs = ix->n_refs;
+            fp.fine_ref_ntiles = ix->ntiles;
+            fp.fine_stats = ix->d_prune_stats.p + 2 * kPruneStatCopies * 8;
+            const size_t cap_f = (size_t)((b.nq + 1u) / 2u) * ix->f_ntiles;
+            launch_fine_bounds(s, fp, b.nq, ix->ntiles, ix->f_ntiles, pr.pair_live, sc.d_fine_items.p + cap_f + 9u, sc.d_fine_items.p, sc.d_fine_items.p + cap_f, ix->planes);
+        }
         // (3) tiles that are not counted keep a largest count of 0: taxon_prefix leaves them out
         RTX_HIP(hipMemsetAsync(sc.d_tilemax.p, 0, (size_t)b.nq * ix->ntiles * 2, s));
         hp.live = sc.d_live.p;
@@ -395,10 +419,10 @@ int begin_run(rtx_index *ix, uint32_t *n_sub_out, bool *timed_out, bool cluster)
                      scratch_ok(ix->sc[0]) && (!ix->staged || scratch_ok(ix->sc[1]));
     ix->dbg_full = false;
     if (ix->prune_used) {
-        int rc_s = ix->d_prune_stats.alloc(kPruneStatCopies * 16);
+        int rc_s = ix->d_prune_stats.alloc(kPruneStatCopies * 24);
         if (!rc_s && ix->debug_taps) rc_s = ix->d_prune_detail.alloc((size_t)ix->sub_batch * kPruneDetailWords);
         if (rc_s) return rc_s;
-        RTX_HIP(hipMemsetAsync(ix->d_prune_stats.p, 0, kPruneStatCopies * 128, ix->stream));
+        RTX_HIP(hipMemsetAsync(ix->d_prune_stats.p, 0, kPruneStatCopies * 192, ix->stream));
     }
     if (ix->pair_used) {
         ix->n_groups_run = n_sub * ix->groups_per_sub;
@@ -564,6 +588,10 @@ int prepare_workspace(rtx_index *ix, uint64_t n_queries, uint64_t tmax, uint64_t
         const uint64_t budget = (uint64_t)((free_b + held) * 0.6);
         B = (uint32_t)std::min<uint64_t>(will_prune ? kDefaultSubBatchPruned : ix->ntiles >= 16 ? kDefaultSubBatchLarge : kDefaultSubBatch,
                                          std::max<uint64_t>(64, budget / per_q));
+        // at least four sub-batches per batch (of 16 384 queries or more): the records of a finished sub-batch are copied and finalised on
+        // the host while the next ones run, and what is left when the device is done is the last sub-batch -- a chunk of 131 072 queries
+        // (rtx_raxtax) in two halves left 7 ms of host work exposed on real barcodes (ten result rows per query)
+        if (will_prune && n_queries < 4ull * B) B = (uint32_t)std::max<uint64_t>(16384, (n_queries + 3) / 4);
     }
     if (B > kMaxSubBatch) B = kMaxSubBatch;
     B = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(B, n_queries));
@@ -592,6 +620,7 @@ int alloc_scratch_set(rtx_index *ix, uint32_t k) {
                 (rc = sc.d_tile_ub.alloc((size_t)B * ix->ntiles)) || (rc = sc.d_best_key.alloc(B)) || (rc = sc.d_prune_thr.alloc(B)) || (rc = sc.d_prune_i1.alloc(B)) || (rc = sc.d_best.alloc((size_t)B * kPruneBestWords)) || (rc = sc.d_live.alloc((size_t)(B + 1u) * ((ix->ntiles + 31u) / 32u + 1u))) ||
                 (rc = sc.d_items.alloc((size_t)((B + 1u) / 2u) * (ix->ntiles + 2u) + 9u)))
                 return rc;
+            if (ix->d_fbitmap.p && (rc = sc.d_fine_items.alloc((size_t)((B + 1u) / 2u) * ix->f_ntiles + 9u + ix->f_ntiles))) return rc;
             if (fresh) RTX_HIP(hipMemsetAsync(sc.d_uones.p, 0xFF, sc.d_uones.n * 8, ix->stream));
             RTX_HIP(hipMemsetAsync(sc.d_uzero.p, 0, sc.d_uzero.n * 4, ix->stream));
         }

@@ -276,14 +276,15 @@ int rtx_debug_tile_bounds(rtx_index *ix, uint64_t query, uint16_t *tile_ub) {
 
 int rtx_debug_prune_stats(rtx_index *ix, uint64_t *out) {
     if (!ix || !out) { set_error("null argument"); return RTX_ERR_INVALID; }
-    std::memset(out, 0, 80);
+    std::memset(out, 0, 128);
     if (!ix->prune_used || !ix->d_prune_stats.p) return RTX_OK;
     RTX_HIP(hipStreamSynchronize(ix->stream));
-    unsigned long long h[kPruneStatCopies * 16];
+    unsigned long long h[kPruneStatCopies * 24];
     RTX_HIP(hipMemcpy(h, ix->d_prune_stats.p, sizeof(h), hipMemcpyDeviceToHost));
     for (uint32_t c = 0; c < kPruneStatCopies; c++) {
         for (uint32_t k = 0; k < 8; k++) out[k] += h[c * 8 + k];
         for (uint32_t k = 0; k < 2; k++) out[8 + k] += h[(kPruneStatCopies + c) * 8 + k];
+        for (uint32_t k = 0; k < 3; k++) out[10 + k] += h[(2 * kPruneStatCopies + c) * 8 + k];  // the fine bounds pass
     }
     return RTX_OK;
 }

@@ -162,6 +162,7 @@ static int create_common(int device, uint64_t n_total, uint64_t ref_lo, uint64_t
 }
 
 static bool prepare_union_bitmap(rtx_index *ix);
+static bool prepare_fine_bitmap(rtx_index *ix);
 
 // Hash table of the distinct reference sequences for the device exact-match lookup (rtx_exact.hip).  `groups`: per distinct
 // sequence the ids of the references that have it, ascending (Tree.sequences, tree.rs:109-112); group order = order of the first
@@ -390,6 +391,11 @@ static int create_from_csr(int device, uint64_t n_total, uint64_t ref_lo, uint64
                                 (uint32_t)ref_hi, kPruneShift);
             if (hipStreamSynchronize(ix->stream) != hipSuccess) { (void)hipGetLastError(); ix->d_ubitmap.release(); }
         }
+        if (prepare_fine_bitmap(ix)) {
+            launch_bitmap_build(ix->stream, d_off.p, d_post.p, ix->d_row_of.p, ix->d_fbitmap.p, ix->f_stride_bytes / 4, nr + 1, (uint32_t)ref_lo,
+                                (uint32_t)ref_hi, kFineShift);
+            if (hipStreamSynchronize(ix->stream) != hipSuccess) { (void)hipGetLastError(); ix->d_fbitmap.release(); }
+        }
     }
     if ((rc = build_segments(ix))) return fail(rc);
     *out = ix;
@@ -412,6 +418,19 @@ static bool prepare_union_bitmap(rtx_index *ix) {
     // on the handle's stream: the builder kernel that follows must not start before the zeroes are in (a hipMemset on the null
     // stream is not ordered with a non-blocking stream)
     if (hipMemsetAsync(ix->d_ubitmap.p, 0, words * 4, ix->stream) != hipSuccess) { (void)hipGetLastError(); ix->d_ubitmap.release(); return false; }
+    return true;
+}
+
+// The fine union bitmap (blocks of 8 references): sizes and zeroes; one of the builders fills it.  Whole databases of kFineMinTiles tiles or
+// more that have the coarse one; a failure to allocate leaves the handle without the second stage.
+static bool prepare_fine_bitmap(rtx_index *ix) {
+    if (!ix->d_ubitmap.p || ix->ntiles < kFineMinTiles || ix->n_refs != ix->n_total) return false;
+    ix->f_nblocks = (ix->n_refs + (1ull << kFineShift) - 1) >> kFineShift;
+    ix->f_ntiles = (uint32_t)((ix->f_nblocks + 8191) / 8192);
+    ix->f_stride_bytes = ix->f_ntiles * 1024u;
+    const size_t words = (size_t)(ix->n_rows + 1) * (ix->f_stride_bytes / 4);
+    if (ix->d_fbitmap.alloc(words)) { ix->d_fbitmap.release(); return false; }
+    if (hipMemsetAsync(ix->d_fbitmap.p, 0, words * 4, ix->stream) != hipSuccess) { (void)hipGetLastError(); ix->d_fbitmap.release(); return false; }
     return true;
 }
 
@@ -485,6 +504,10 @@ int rtx_index_create_from_sequences(int device, uint64_t n_refs, const uint8_t *
         launch_ref_bitmap_set(ix->stream, d_seq.p, d_off.p, n_refs, ix->d_row_of.p, ix->d_ubitmap.p, ix->u_stride_bytes / 4, nr + 1, kPruneShift);
         if (hipStreamSynchronize(ix->stream) != hipSuccess) { (void)hipGetLastError(); ix->d_ubitmap.release(); }
     }
+    if (prepare_fine_bitmap(ix)) {
+        launch_ref_bitmap_set(ix->stream, d_seq.p, d_off.p, n_refs, ix->d_row_of.p, ix->d_fbitmap.p, ix->f_stride_bytes / 4, nr + 1, kFineShift);
+        if (hipStreamSynchronize(ix->stream) != hipSuccess) { (void)hipGetLastError(); ix->d_fbitmap.release(); }
+    }
     *out = ix;
     return RTX_OK;
 }
@@ -542,7 +565,7 @@ void rtx_index_destroy(rtx_index *index) {
 uint64_t rtx_index_num_refs(const rtx_index *index) { return index ? index->n_total : 0; }
 uint64_t rtx_index_device_bytes(const rtx_index *index) {
     if (!index) return 0;
-    return index->d_seg_dbits.n * 8 + index->d_seg_sbits.n * 8 + index->d_seg_sbase.n * 4 + index->d_seginfo.n * 4 + index->d_segslots.n * 2 + index->d_bitmap.n * 4 + index->d_row_of.n * 4 + index->d_list_len.n * 4 + index->d_loc_table.n * 4 + index->d_ubitmap.n * 4 + index->d_em_table.n * 8 + index->d_em_rep_off.n * 8 + index->d_em_rep_bytes.n + index->d_em_goff.n * 4 + index->d_em_gids.n * 4 + index->d_lnfact.n * 8 +
+    return index->d_seg_dbits.n * 8 + index->d_seg_sbits.n * 8 + index->d_seg_sbase.n * 4 + index->d_seginfo.n * 4 + index->d_segslots.n * 2 + index->d_bitmap.n * 4 + index->d_row_of.n * 4 + index->d_list_len.n * 4 + index->d_loc_table.n * 4 + index->d_ubitmap.n * 4 + index->d_fbitmap.n * 4 + index->d_em_table.n * 8 + index->d_em_rep_off.n * 8 + index->d_em_rep_bytes.n + index->d_em_goff.n * 4 + index->d_em_gids.n * 4 + index->d_lnfact.n * 8 +
            index->d_noderec.n * 16 + index->d_bnd_bits.n + index->d_bnd_rank.n * 4;
 }
 int rtx_index_set_batch(rtx_index *index, uint32_t sub_batch) {
@@ -603,6 +626,9 @@ int rtx_index_set_option(rtx_index *index, int option, uint64_t value) {
             return RTX_OK;
         case RTX_OPT_TILE_PRUNE:
             index->prune_opt = value ? 1u : 0u;
+            return RTX_OK;
+        case RTX_OPT_FINE_BOUNDS:
+            index->fine_opt = value ? 1u : 0u;
             return RTX_OK;
         case RTX_OPT_PROB_MODE:
             if (value > 2) break;

@@ -542,6 +542,47 @@ __device__ __forceinline__ void bounds_epilogue(const HitParams &p, uint32_t (&p
     if (lane == 0) atomicMax(&p.bounds_best[q], best);
 }
 
+// ---------------------------------------------------------------------------
+// Epilogue of the FINE bounds pass (two-stage bounds): the "references" of this launch are blocks of 8 references,
+// one wave has counted a query against the 8192 blocks of fine tile `utile` = the eight tiles utile * 8 .. + 7 of the database.  With
+// ref_slot's layout group gi of every lane (byte gi of its 16) holds blocks of tile utile * 8 + gi / 2: the low half of plane word w is
+// tile 2 w, the high half tile 2 w + 1.  A tile whose every block bound is at most the query's threshold cannot hold a count above it:
+// its live bit is cleared and its references go to bin 0 of the histogram -- exactly what the counting pass would have found out at
+// the price of a block of its own (the epilogue's early exit).  The comparison runs on the bit planes (bound > u: ~3 operations per
+// plane and word); `bits`: the live tiles of the query among the eight.
+// ---------------------------------------------------------------------------
+template <int NP>
+__device__ __forceinline__ void fine_epilogue(const HitParams &p, uint32_t (&pl)[4][NP], uint32_t q, uint32_t utile, uint32_t lane, uint32_t bits) {
+    const uint32_t u = (uint32_t)__builtin_amdgcn_readfirstlane((int)p.prune_thr[q]);
+    if (u == 0u || bits == 0u) return;  // (a query without a threshold keeps every tile)
+    uint32_t above = 0;  // bit k: some block of tile utile * 8 + k has a bound above u
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        uint32_t gt = 0, eq = 0xFFFFFFFFu;
+#pragma unroll
+        for (int b = NP - 1; b >= 0; b--) {
+            const uint32_t cb = (u >> b) & 1u ? 0xFFFFFFFFu : 0u;  // scalar
+            gt |= eq & pl[w][b] & ~cb;
+            eq &= ~(pl[w][b] ^ cb);
+        }
+        if (__ballot((gt & 0xFFFFu) != 0u) != 0ull) above |= 1u << (2 * w);
+        if (__ballot((gt >> 16) != 0u) != 0ull) above |= 2u << (2 * w);
+    }
+    uint32_t clear = bits & ~above;  // wave-uniform
+    if (clear == 0u || lane != 0u) return;
+    const uint32_t T0 = utile * 8u;
+    uint32_t refs = 0, n = 0;
+    for (uint32_t k = 0; k < 8u; k++)
+        if ((clear >> k) & 1u) {
+            const uint64_t lo = (uint64_t)(T0 + k) << 13, hi = lo + 8192u < p.fine_n_refs ? lo + 8192u : p.fine_n_refs;
+            refs += (uint32_t)(hi - lo);
+            n++;
+        }
+    atomicAnd(const_cast<uint32_t *>(p.live) + (size_t)q * p.live_words + (T0 >> 5), ~(clear << (T0 & 31u)));
+    atomicAdd(&p.hist[(size_t)q * p.hstride], refs);
+    if (p.fine_stats) atomicAdd(&p.fine_stats[(size_t)(q & (kPruneStatCopies - 1u)) * 8u], (unsigned long long)n);
+}
+
 template <int NP, bool kPacked, bool kPrefetch = false>
 __device__ __forceinline__ void hit_epilogue(const HitParams &p, uint32_t (&pl)[4][NP], uint32_t q, uint32_t tile, uint32_t lane,
                                              uint32_t t, bool active, uint32_t *hist_lds, uint32_t *cnt8, uint32_t ns,

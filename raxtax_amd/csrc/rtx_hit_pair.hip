@@ -129,10 +129,20 @@ __device__ __forceinline__ void fold_seg(uint32_t (&pa)[4][NP], uint32_t (&pb)[4
 }
 
 // One (pair, tile) block: the rows of the pair in this tile, then the epilogue of each query that is live there.
-template <int NP, bool kPacked, bool kBounds>
+template <int NP, bool kPacked, int kBounds>  // kBounds: 0 the database, 1 the union bitmap over blocks of 64 (bounds), 2 over blocks of 8 (fine bounds)
 __device__ __forceinline__ void pair_tile_block(const HitParams &p, uint32_t *lds_dw, const uint32_t pair, const uint32_t tile, const uint32_t lane) {
     const uint32_t qa = pair * 2u, qb = qa + 1u;
     bool has_a = true, has_b = qb < p.nq;
+    uint32_t fine_a = 0, fine_b = 0;  // kBounds == 2: the live tiles of either query among the eight database tiles this fine tile covers
+    if (kBounds == 2) {
+        const uint32_t T0 = tile * 8u;  // (a multiple of 8: the eight bits lie in one word)
+        const uint32_t *lw = p.live + (size_t)qa * p.live_words + (T0 >> 5);
+        fine_a = (lw[0] >> (T0 & 31u)) & 0xFFu;
+        fine_b = has_b ? (lw[p.live_words] >> (T0 & 31u)) & 0xFFu : 0u;
+        has_a = fine_a != 0u;
+        has_b = fine_b != 0u;
+        if (!has_a && !has_b) return;
+    }
     if (!kBounds && p.live) {  // tile pruning (rtx_prune.hip): a mask per query -- the rows of a query are folded only where its tile is live
         const uint32_t *lw = p.live + (size_t)qa * p.live_words + (tile >> 5);
         has_a = (lw[0] >> (tile & 31u)) & 1u;
@@ -181,8 +191,8 @@ __device__ __forceinline__ void pair_tile_block(const HitParams &p, uint32_t *ld
             sb[it] = kBounds ? 0u : srows_b[(uint32_t)it * 64u + lane];
         }
         for (uint32_t i = lane; i < mwords; i += 64) {  // (a query whose tile is dead has no dense row here: its lists were never built)
-            m_a[i] = has_a ? dm_a[i] : 0ull;
-            m_b[i] = has_b ? dm_b[i] : 0ull;
+            m_a[i] = has_a ? (kBounds ? ~0ull : dm_a[i]) : 0ull;  // a union bitmap is read densely: every row of the query counts
+            m_b[i] = has_b ? (kBounds ? ~0ull : dm_b[i]) : 0ull;
         }
 #pragma unroll
         for (int it = 0; it < kSparseIt; it++) {
@@ -258,9 +268,15 @@ __device__ __forceinline__ void pair_tile_block(const HitParams &p, uint32_t *ld
     }
     if (lane == 0 && p.group_rows) atomicAdd(&p.group_rows[p.group_base + pair], rows_loaded);
 
-    if (kBounds) {  // the largest bound per tile of the database and the best block of each query; nothing else leaves the wave
+    if (kBounds == 1) {  // the largest bound per tile of the database and the best block of each query; nothing else leaves the wave
         bounds_epilogue<NP>(p, pa, qa, tile, lane);
         if (has_b) bounds_epilogue<NP>(p, pb, qb, tile, lane);
+        return;
+    }
+    if (kBounds == 2) {  // the tiles among the eight whose every block of 8 stays at or below the query's threshold are taken off its list
+        if (has_a) fine_epilogue<NP>(p, pa, qa, tile, lane, fine_a);
+        if (has_b) fine_epilogue<NP>(p, pb, qb, tile, lane, fine_b);
+        if (lane == 0u && p.fine_stats) atomicAdd(&p.fine_stats[(size_t)(pair & (kPruneStatCopies - 1u)) * 8u + 1u], 1ull);
         return;
     }
     // epilogues: histogram (4 KiB) / byte counters of the whole tile (8 KiB) over the lists (dead now); the slots of the sparse
@@ -284,7 +300,7 @@ __device__ __forceinline__ void pair_tile_block(const HitParams &p, uint32_t *ld
 // Grid: pairs x tiles -- or, behind tile pruning, one-dimensional over the list of the (pair, tile) blocks with a live query
 // (live_items_kernel).  A pruned sub-batch of the bench workload keeps 1.5 of 62 tiles per pair: with the two-dimensional grid 97 % of
 // its million workgroups came up only to read their mask and leave, which took a third of the launch.
-template <int NP, bool kPacked, bool kBounds, bool kItems>
+template <int NP, bool kPacked, int kBounds, bool kItems>
 __global__ __launch_bounds__(64, 2) void hit_count_pair_kernel(HitParams p) {
     extern __shared__ uint32_t lds_dw[];
     const uint32_t lane = threadIdx.x;
@@ -440,8 +456,80 @@ void launch_live_items(hipStream_t s, const uint32_t *live, uint32_t live_words,
 }
 
 void launch_hit_count_pair_bounds(hipStream_t s, const HitParams &p, uint32_t nq, uint32_t u_ntiles, int planes) {
-    if (planes <= 8) hipLaunchKernelGGL((hit_count_pair_kernel<8, true, true, false>), dim3((nq + 1u) / 2u, u_ntiles), dim3(64), kPairLdsBytes, s, p);
-    else hipLaunchKernelGGL((hit_count_pair_kernel<10, true, true, false>), dim3((nq + 1u) / 2u, u_ntiles), dim3(64), kPairLdsBytes, s, p);
+    if (planes <= 8) hipLaunchKernelGGL((hit_count_pair_kernel<8, true, 1, false>), dim3((nq + 1u) / 2u, u_ntiles), dim3(64), kPairLdsBytes, s, p);
+    else hipLaunchKernelGGL((hit_count_pair_kernel<10, true, 1, false>), dim3((nq + 1u) / 2u, u_ntiles), dim3(64), kPairLdsBytes, s, p);
+}
+
+// ---------------------------------------------------------------------------
+// The fine bounds pass: which pairs, which fine tiles.  A pair qualifies with kFineMinLive live tiles or more (prune_kernel's
+// number); it gets an item for every fine tile (eight tiles of the database) in which either query has a live tile.  The items are
+// grouped by fine tile -- the workgroups that run together then read one region of the fine bitmap: fine_count (entries per fine
+// tile), fine_scan (one thread: offsets, the header of the list), fine_scatter.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t fine_pair_mask(const uint32_t *live, uint32_t live_words, uint32_t pair, uint32_t nq, uint32_t U) {
+    const uint32_t T0 = U * 8u;
+    const uint32_t *wa = live + (size_t)(pair * 2u) * live_words + (T0 >> 5);
+    uint32_t m = (wa[0] >> (T0 & 31u)) & 0xFFu;
+    if (pair * 2u + 1u < nq) m |= (wa[live_words] >> (T0 & 31u)) & 0xFFu;
+    return m;
+}
+__global__ __launch_bounds__(256) void fine_count_kernel(const uint32_t *__restrict__ live, uint32_t live_words, const uint32_t *__restrict__ pair_live,
+                                                         uint32_t nq, uint32_t f_ntiles, uint32_t *__restrict__ cnt) {
+    const uint32_t pair = blockIdx.x * 256u + threadIdx.x, np = (nq + 1u) / 2u;
+    if (pair >= np || pair_live[pair] < kFineMinLive) return;
+    for (uint32_t U = 0; U < f_ntiles; U++)
+        if (fine_pair_mask(live, live_words, pair, nq, U)) atomicAdd(&cnt[U], 1u);
+}
+__global__ void fine_scan_kernel(uint32_t *__restrict__ cnt, uint32_t f_ntiles, uint32_t *__restrict__ n_items) {  // one thread
+    uint32_t run = 0;
+    for (uint32_t U = 0; U < f_ntiles; U++) {
+        const uint32_t c = cnt[U];
+        cnt[U] = run;  // becomes the cursor of fine tile U
+        run += c;
+    }
+    n_items[0] = run;
+    for (uint32_t x = 1; x <= 8u; x++) n_items[x] = 0;  // the queues of the XCDs
+}
+__global__ __launch_bounds__(256) void fine_scatter_kernel(const uint32_t *__restrict__ live, uint32_t live_words, const uint32_t *__restrict__ pair_live,
+                                                           uint32_t nq, uint32_t f_ntiles, uint32_t *__restrict__ cursor, uint32_t *__restrict__ items) {
+    const uint32_t pair = blockIdx.x * 256u + threadIdx.x, np = (nq + 1u) / 2u;
+    if (pair >= np || pair_live[pair] < kFineMinLive) return;
+    for (uint32_t U = 0; U < f_ntiles; U++)
+        if (fine_pair_mask(live, live_words, pair, nq, U)) items[atomicAdd(&cursor[U], 1u)] = pair * f_ntiles + U;
+}
+// live tiles per pair again, from the masks as the fine pass left them (live_offsets_kernel sizes the list of the counting pass with them)
+__global__ __launch_bounds__(256) void pair_live_recount_kernel(const uint32_t *__restrict__ live, uint32_t live_words, uint32_t nq, uint32_t ntiles,
+                                                                uint32_t *__restrict__ pair_live, unsigned long long *__restrict__ stats) {
+    const uint32_t pair = blockIdx.x * 256u + threadIdx.x, np = (nq + 1u) / 2u;
+    uint32_t n = 0;
+    if (pair < np) {
+        const uint32_t *wa = live + (size_t)(pair * 2u) * live_words;
+        const bool hb = pair * 2u + 1u < nq;
+        for (uint32_t w = 0; w < (ntiles + 31u) >> 5; w++) n += (uint32_t)__popc(wa[w] | (hb ? wa[live_words + w] : 0u));
+        pair_live[pair] = n;
+    }
+    if (stats) {  // reporting: the (pair, tile) blocks the counting pass is left with
+        n = wave_incl_scan_u32(n);
+        if ((threadIdx.x & 63u) == 63u && n) atomicAdd(&stats[(size_t)(blockIdx.x & (kPruneStatCopies - 1u)) * 8u + 2u], (unsigned long long)n);
+    }
+}
+
+// cnt: [f_ntiles] scratch; items: [pairs * f_ntiles]; n_items: [9]
+void launch_fine_bounds(hipStream_t s, const HitParams &p, uint32_t nq, uint32_t ntiles, uint32_t f_ntiles, uint32_t *pair_live, uint32_t *cnt,
+                        uint32_t *items, uint32_t *n_items, int planes) {
+    const uint32_t np = (nq + 1u) / 2u, nb = (np + 255u) / 256u;
+    (void)hipMemsetAsync(cnt, 0, (size_t)f_ntiles * 4, s);
+    hipLaunchKernelGGL(fine_count_kernel, dim3(nb), dim3(256), 0, s, p.live, p.live_words, pair_live, nq, f_ntiles, cnt);
+    hipLaunchKernelGGL(fine_scan_kernel, dim3(1), dim3(1), 0, s, cnt, f_ntiles, n_items);
+    hipLaunchKernelGGL(fine_scatter_kernel, dim3(nb), dim3(256), 0, s, p.live, p.live_words, pair_live, nq, f_ntiles, cnt, items);
+    HitParams fp = p;
+    fp.items = items;
+    fp.n_items = n_items;
+    // as many workgroups as a pass of the counting list: the list is walked through the queues of the XCDs
+    const dim3 grid((uint32_t)((std::min<uint64_t>((uint64_t)np * f_ntiles, std::max<uint64_t>((uint64_t)RTX_ITEM_GRID_HALVES * np / 2u, 2048ull)) + 7u) & ~7ull));
+    if (planes <= 8) hipLaunchKernelGGL((hit_count_pair_kernel<8, true, 2, true>), grid, dim3(64), kPairLdsBytes, s, fp);
+    else hipLaunchKernelGGL((hit_count_pair_kernel<10, true, 2, true>), grid, dim3(64), kPairLdsBytes, s, fp);
+    hipLaunchKernelGGL(pair_live_recount_kernel, dim3(nb), dim3(256), 0, s, p.live, p.live_words, nq, ntiles, pair_live, p.fine_stats);
 }
 
 }  // namespace rtx

@@ -170,6 +170,12 @@ struct rtx_index {
     DevBuf<uint32_t> d_ubitmap;  // union bitmap: one column per block of 2^kPruneShift references, tile-major like d_bitmap
     uint32_t u_stride_bytes = 0, u_ntiles = 0;
     uint64_t u_nblocks = 0;
+    // the fine union bitmap (blocks of 2^kFineShift = 8 references; databases of kFineMinTiles tiles or more, whole-database handles):
+    // second stage of the bounds for the pairs the first stage leaves many live tiles (rtx_hit_pair.hip: launch_fine_bounds)
+    DevBuf<uint32_t> d_fbitmap;
+    uint32_t f_stride_bytes = 0, f_ntiles = 0;
+    uint64_t f_nblocks = 0;
+    uint32_t fine_opt = 1;  // RTX_OPT_FINE_BOUNDS
     DevBuf<unsigned long long> d_prune_stats;
     uint32_t shard_prune_opt = 0;  // RTX_OPT_SHARD_PRUNE: a reference shard prunes with the threshold of the whole database (rtx_shard_bounds)
     uint32_t debug_taps = 0;     // RTX_OPT_DEBUG_TAPS: prune_kernel leaves its view of every query (rtx_debug_prune_detail)
@@ -224,6 +230,7 @@ struct rtx_index {
         DevBuf<uint32_t> d_items;  // [pairs x tiles] the (pair, tile) blocks with a live query | [1] their number | [8] queue per XCD | [pairs] live tiles per pair | [pairs] offsets
         DevBuf<uint16_t> d_tile_ub, d_prune_thr, d_prune_i1;
         DevBuf<uint32_t> d_best;  // [B][kPruneBestWords] reference shards: the candidate for the best block of the database
+        DevBuf<uint32_t> d_fine_items;  // fine bounds pass: [pairs x f_ntiles] items | [9] number + XCD queues | [f_ntiles] cursors
     } sc[2];
     bool staged = false;  // driven with rtx_shard_*: sub-batch sb works in scratch set sb & 1, so that the exchange of one
                           // sub-batch (RCCL, on the caller's stream) can overlap with the counting of the next

@@ -153,7 +153,15 @@ struct HitParams {
     uint16_t *bounds_tile_ub;     // [B][bounds_tile_stride] largest bound of every tile of the database
     uint32_t bounds_tile_stride, bounds_ntiles;
     uint32_t *bounds_best;        // [B] key of the block with the largest bound (bound << 20 | 0xFFFFF - block), zeroed by the caller
+    // the FINE bounds pass (kBounds == 2): the bitmap is the union bitmap over blocks of 8 references -- one "tile" of it covers eight
+    // tiles of the database -- and the launch walks the (pair, fine tile) items of the pairs that the coarse bounds left many live tiles
+    uint64_t fine_n_refs;         // references of the database (n_refs counts blocks in a bounds pass)
+    uint32_t fine_ref_ntiles;     // tiles of the database
+    unsigned long long *fine_stats;  // [kPruneStatCopies][8]: [0] += (query, tile) combinations cleared, [1] += blocks of the fine pass, or null
 };
+constexpr uint32_t kFineShift = 3;       // blocks of 8 references: the 8 references of one byte of a bitmap row (ref_slot)
+constexpr uint32_t kFineMinLive = 4;     // pairs with fewer live tiles than this skip the fine pass (a block of it costs what it can save there)
+constexpr uint32_t kFineMinTiles = 16;   // databases with fewer tiles have no fine union bitmap
 
 // tile pruning (rtx_prune.hip)
 constexpr uint32_t kPruneStatCopies = 64;  // PruneParams::stats: [copies][8] (prune_kernel) + [copies][8] (taxon_prefix), summed by the reader
@@ -288,7 +296,10 @@ void launch_hit_count_pair(hipStream_t s, const HitParams &p, uint32_t nq, uint3
 // the list of the live (pair, tile) blocks from the masks and the per-pair numbers prune_kernel left: off = [pairs] scratch
 void launch_live_items(hipStream_t s, const uint32_t *live, uint32_t live_words, const uint32_t *pair_live, uint32_t nq, uint32_t ntiles, uint32_t *off,
                        uint32_t *items, uint32_t *n_items);
-void launch_hit_count_pair_bounds(hipStream_t s, const HitParams &p, uint32_t nq, uint32_t u_ntiles, int planes);  // ... on the union bitmap: bounds_epilogue
+void launch_hit_count_pair_bounds(hipStream_t s, const HitParams &p, uint32_t nq, uint32_t u_ntiles, int planes);
+// the fine bounds pass over the pairs with many live tiles (p: the fine union bitmap, live masks, thresholds, histogram); updates pair_live
+void launch_fine_bounds(hipStream_t s, const HitParams &p, uint32_t nq, uint32_t ntiles, uint32_t f_ntiles, uint32_t *pair_live, uint32_t *cnt,
+                        uint32_t *items, uint32_t *n_items, int planes);  // ... on the union bitmap: bounds_epilogue
 size_t prob_table_lds_bytes(uint32_t tmax);
 void launch_prob_table(hipStream_t s, const ProbParams &p, uint32_t nq);
 size_t prob_lookup_lds_bytes(uint32_t tmax);

@@ -81,7 +81,7 @@ def main():
     ntiles = (N + 8191) // 8192
     seqs_sorted = db.seq_bytes.reshape(N, db.length)[orig]
     rng = np.random.default_rng(1)
-    for mu in (0.02, 0.05, 0.10):
+    for mu in (0.02, 0.05, 0.10, 0.15):
         rows = []
         for qi in range(NQ):
             src = int(rng.integers(0, N))
@@ -99,7 +99,7 @@ def main():
                 pad = (-N) % sz
                 X = np.concatenate([M, np.zeros((pad, t), bool)]) if pad else M
                 return X.reshape(-1, sz, t).any(axis=1).sum(axis=1)
-            ub64, ub32, ub16 = ub_fixed(64), ub_fixed(32), ub_fixed(16)
+            ub64, ub32, ub16, ub8 = ub_fixed(64), ub_fixed(32), ub_fixed(16), ub_fixed(8)
             ubsp = np.logical_or.reduceat(M, cuts, axis=0).sum(axis=1)
             ubg = {g: np.logical_or.reduceat(M, c, axis=0).sum(axis=1) for g, c in greedy_cuts.items()}
             best = int(np.argmax(ub64))
@@ -109,6 +109,13 @@ def main():
             u, i1 = C.c_uint32(), C.c_uint32()
             emul.emul_prune_threshold(C.c_uint32(t), C.c_uint64(N), blk.ctypes.data_as(C.c_void_p), lf.ctypes.data_as(C.c_void_p), C.c_uint32(1023), C.byref(u), C.byref(i1))
             thr = int(u.value)
+            # round 4: the tile-aware threshold (criterion (4)) from the largest bound of every tile of the blocks of 64
+            pad64 = (-len(ub64)) % 128
+            tub = np.concatenate([ub64, np.zeros(pad64, ub64.dtype)]).reshape(-1, 128).max(axis=1).astype(np.uint16)
+            u4, i14 = C.c_uint32(), C.c_uint32()
+            emul.emul_prune_threshold_tiles(C.c_uint32(t), C.c_uint64(N), blk.ctypes.data_as(C.c_void_p), lf.ctypes.data_as(C.c_void_p), C.c_uint32(1023),
+                                            C.c_uint32(len(tub)), tub.ctypes.data_as(C.c_void_p), C.byref(u4), C.byref(i14))
+            thr4 = int(u4.value)
 
             def live_fixed(ub, sz, th):
                 per_tile = 8192 // sz
@@ -121,8 +128,11 @@ def main():
                 mx = np.zeros(ntiles, np.int64)
                 np.maximum.at(mx, tile_of, ub)
                 return int((mx > th).sum())
-            tmax = np.concatenate([counts, np.zeros((-N) % 8192, counts.dtype)]).reshape(-1, 8192).max(axis=1)
-            r = dict(t=t, M=int(counts.max()), thr=thr)
+            def tmax_of(c):
+                return np.concatenate([c, np.zeros((-N) % 8192, c.dtype)]).reshape(-1, 8192).max(axis=1)
+            tmax = tmax_of(counts)
+            r = dict(t=t, M=int(counts.max()), thr=thr, thr4=thr4, need4=int((tmax_of(counts) > thr4).sum()), l64_4=live_fixed(ub64, 64, thr4),
+                     l16_4=live_fixed(ub16, 16, thr4), l8_4=live_fixed(ub8, 8, thr4))
             for d in (0, 30, 60):
                 r[f"need+{d}"] = int((tmax > thr + d).sum())
                 r[f"l64+{d}"] = live_fixed(ub64, 64, thr + d)

@@ -361,7 +361,7 @@ def roofline_block(args, work, prob_work, stage_ms, stage_n, n_queries_step, que
             "mean_threshold": prune["mean_threshold"], "mean_best_hit_lower_bound": prune["mean_best_hit_lower_bound"],
             "tiles_above_threshold_per_query": prune.get("tiles_above_threshold_per_query"),     # what exact knowledge would count
             "queries_with_threshold": prune.get("queries_with_threshold"),
-            "note": "a pruned query's references with a count up to its threshold carry < 1e-12 of probability together (rtx_prune.hip); "
+            "note": "a pruned query's references with a count up to its threshold carry < 1e-10 of probability together (rtx_prune.hip); "
                     "value_unpruned counts every tile, divergence_sweep shows how the live tiles grow with the distance of a query from its best hit",
         }
     if tr is not None:
@@ -485,6 +485,7 @@ def extras_block(args, rx, lib, index, tree, db, qs, flags):
         index.upload(q2.bases, q2.base_off)
         dt = timed(plain)
         st = index.debug_prune_stats()
+        stg = {s_: round(ms, 2) for s_, (ms, n) in index.stage_times().items() if n}
         # the same queries with every tile counted: what the pruning is worth at this divergence
         rx._lib.check(lib.rtx_index_set_option(index._h, 13, 0))
         index.upload(q2.bases, q2.base_off)
@@ -492,6 +493,7 @@ def extras_block(args, rx, lib, index, tree, db, qs, flags):
         rx._lib.check(lib.rtx_index_set_option(index._h, 13, 0 if args.no_tile_prune else 1))
         sweep.append({"mu_q": mu, "value": 131072 / dt, "ms_per_step": dt * 1e3, "value_unpruned": 131072 / dt_full, "live_tiles_per_pair": st["live_tiles_per_pair"],
                       "live_tiles_per_pair_first_stage": st["live_tiles_per_pair_first_stage"], "fine_blocks_per_pair": st["fine_blocks_per_pair"],
+                      "stage_ms_per_step": stg,
                       "live_tiles_per_query": st.get("live_tiles_per_query"),
                       "share_with_threshold": st["queries_with_threshold"] / 131072, "mean_threshold": st["mean_threshold"],
                       "mean_best_hit_lower_bound": st["mean_best_hit_lower_bound"],

@@ -41,17 +41,34 @@ def test_more_than_one_tile_of_bounds(oracle, emul):
         ex.check()
     # Queries far from their best hit (10 % substitutions) keep tens of tiles each: the counting pass walks its list of live (pair, tile)
     # blocks in several passes of the grid (rtx_hit_pair.hip: more blocks than workgroups), in the full batch and in the sample's own.
+    # First with the first stage of the bounds alone (RTX_OPT_FINE_BOUNDS = 0: the long lists), then with the second stage: the pairs with
+    # four live tiles or more are counted against the union bitmap over blocks of 8 references, which takes most of their tiles off
+    # the lists -- same rows, every sampled query as the run left it against the oracle, far fewer blocks counted.
     n_q2 = 3000
     qs2 = synth.make_queries(db, n_q2, seed=12, mu_q=0.10, exact_frac=0.0)
-    res2 = index.classify(qs2.bases, qs2.base_off, *index.exact_matches(qs2.bases, qs2.base_off))
+    ex2 = index.exact_matches(qs2.bases, qs2.base_off)
+    rx._lib.check(index._lib.rtx_index_set_option(index._h, 17, 0))
+    res2 = index.classify(qs2.bases, qs2.base_off, *ex2)
     check_properties(res2, db, n_q2)
     st2 = index.debug_prune_stats()
-    print("divergent queries:", st2)
+    print("divergent queries, first stage only:", st2)
     assert st2["bound_violations"] == 0 and st2["live_tiles_per_pair"] * st2["pairs"] > 3 * n_q2      # grid: 2 workgroups per pair and pass
+    assert st2["fine_blocks_per_pair"] == 0
     sample2 = np.sort(np.random.default_rng(63).choice(n_q2, 200, replace=False))
     ex = Excuses("pruned/620k/divergent")
     oracle_sample_parity(index, oracle, otree, db, qs2, sample2, False, ex, full_res=res2, chunk=100, emul=emul)
     assert index.debug_prune_stats()["live_tiles_per_pair"] * 100 > 2048
+    ex.check()
+    rx._lib.check(index._lib.rtx_index_set_option(index._h, 17, 1))
+    res3 = index.classify(qs2.bases, qs2.base_off, *ex2)
+    st3 = index.debug_prune_stats()
+    print("divergent queries, both stages:", st3)
+    assert st3["bound_violations"] == 0 and st3["fine_blocks_per_pair"] > 1 and st3["fine_cleared_per_query"] > 1
+    assert st3["live_tiles_per_pair_first_stage"] == st2["live_tiles_per_pair"] and st3["live_tiles_per_pair"] < 0.5 * st2["live_tiles_per_pair"]
+    for f in ("row_off", "row_lineage", "row_conf", "row_local_signal", "global_signal", "t", "status"):
+        assert np.array_equal(getattr(res3, f), getattr(res2, f)), f     # a tile taken off the list held nothing above the threshold
+    ex = Excuses("pruned/620k/divergent/two-stage")
+    oracle_sample_parity(index, oracle, otree, db, qs2, sample2, False, ex, full_res=res3, chunk=100, emul=emul)
     ex.check()
 
 

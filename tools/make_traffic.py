@@ -82,7 +82,11 @@ def main():
         out = {}
         for k, d in agg.items():
             if k.startswith("rtx::hit_count") and ctr in d:   # hit_count_kernel / hit_count_pair_kernel: whichever the run used
-                kind = "all" if a.unpruned else ("bounds" if "pair_kernel<10,true,true," in k.replace(" ", "") else "live")
+                # hit_count_pair_kernel<NP, kPacked, kBounds, kItems>: kBounds 1 (or `true`, round 3) = the bounds pass over blocks of 64,
+                # 2 = the fine bounds pass over blocks of 8 (round 4), 0 = the tiles of the database
+                targs = k.replace(" ", "").split("<", 1)[1].rstrip(">").split(",") if "<" in k else []
+                kb = targs[2] if len(targs) >= 3 and "pair_kernel" in k else "0"
+                kind = "all" if a.unpruned else ("bounds" if kb in ("1", "true") else "fine" if kb == "2" else "live")
                 tot, n = out.get(kind, (0.0, 0))
                 out[kind] = (tot + sum(d[ctr]), n + len(d[ctr]))
         return out or None

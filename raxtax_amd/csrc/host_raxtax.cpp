@@ -39,6 +39,8 @@ struct Chunk {
     std::vector<std::string> out_msg, tsv_msg;
     rtx_result_view res{};
     int stage = 0;                     // 1: exact matches looked up (or left to the device), 2: classified, 3: formatted, 4: sent
+    uint64_t formatted = 0;            // queries of the chunk whose messages are ready (under the run's mutex): the sender follows the format
+                                       // stage slice by slice, so that what is left behind the last chunk's device stage is one slice, not a chunk
 };
 
 // raxtax() (src/raxtax.rs:14-97) as a pipeline over chunks of `chunk_size` queries on one or several device handles -- the
@@ -183,7 +185,11 @@ int run(rtx_index *const *indices, uint32_t n_dev, const rtx_tree *tree, uint64_
             ch.status.assign(ch.res.status, ch.res.status + ch.nq);
             ch.t.assign(ch.res.t, ch.res.t + ch.nq);
             std::atomic<int> rc_fmt{0};
-            parallel_ranges(ch.nq, nt_format, [&](uint64_t a, uint64_t b) {
+            constexpr uint64_t kSlice = 16384;  // queries per slice handed to the sender
+            for (uint64_t s0 = 0; s0 < ch.nq && !rc_fmt; s0 += kSlice) {
+            const uint64_t s1 = std::min<uint64_t>(ch.nq, s0 + kSlice);
+            parallel_ranges(s1 - s0, nt_format, [&](uint64_t a_, uint64_t b_) {
+                const uint64_t a = s0 + a_, b = s0 + b_;
                 std::vector<char> out_buf(1 << 16), tsv_buf(1 << 16);
                 for (uint64_t i = a; i < b; i++) {
                     const uint64_t q = ch.q0 + i;
@@ -213,6 +219,12 @@ int run(rtx_index *const *indices, uint32_t n_dev, const rtx_tree *tree, uint64_
                     if (tsv) ch.tsv_msg[i].assign(tsv_buf.data(), (size_t)tsv_len);
                 }
             });
+            if (!rc_fmt) {
+                std::lock_guard<std::mutex> g(mu);
+                ch.formatted = s1;
+                cv.notify_all();
+            }
+            }
             if (rc_fmt) { fail(rc_fmt, "formatting a result failed"); return; }
             busy_format[d] += now() - t_f0;
             set_stage(c, 3);
@@ -226,11 +238,21 @@ int run(rtx_index *const *indices, uint32_t n_dev, const rtx_tree *tree, uint64_
     }
     // the sender: messages in input order
     for (uint64_t c = 0; c < n_chunks; c++) {
-        if (!wait_stage(c, 3)) break;
+        if (!wait_stage(c, 2)) break;
         Chunk &ch = chunks[c];
-        const double t_s0 = now();
-        bool closed = false;
+        double t_s0 = now();
+        bool closed = false, dead = false;
+        uint64_t ready = 0;  // messages of the chunk known to be formatted
         for (uint64_t i = 0; i < ch.nq && !closed; i++) {
+            if (i >= ready) {  // wait for the slice that holds query i
+                busy_send += now() - t_s0;
+                std::unique_lock<std::mutex> g(mu);
+                cv.wait(g, [&] { return failed != RTX_OK || ch.formatted > i; });
+                if (failed != RTX_OK) { dead = true; break; }
+                ready = ch.formatted;
+                g.unlock();
+                t_s0 = now();
+            }
             const uint64_t q = ch.q0 + i;
             if (ch.differ[i]) {
                 fprintf(stderr, "[WARN ] Exact matches for %s differ above the leafs of the lineage tree!\n", labels[q]);
@@ -245,7 +267,9 @@ int run(rtx_index *const *indices, uint32_t n_dev, const rtx_tree *tree, uint64_
             if (tsv) t.emplace(std::move(ch.tsv_msg[i]));
             if (!sender(labels[q], std::move(ch.out_msg[i]), std::move(t))) closed = true;
         }
+        if (dead) break;
         if (closed) { fail(RTX_ERR_SENDER, "result sink closed"); break; }  // sender.send(..)?, raxtax.rs:87
+        if (!wait_stage(c, 3)) break;  // (an empty tail of the chunk: the format stage has finished with it)
         std::vector<uint32_t>().swap(ch.exact_ids);
         std::vector<uint64_t>().swap(ch.exact_off);
         std::vector<uint8_t>().swap(ch.differ);

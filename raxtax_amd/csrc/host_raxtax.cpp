@@ -39,9 +39,10 @@ struct Chunk {
     std::vector<std::string> out_msg, tsv_msg;
     rtx_result_view res{};
     int stage = 0;                     // 1: exact matches looked up (or left to the device), 2: classified, 3: formatted, 4: sent
-    uint64_t formatted = 0;            // queries of the chunk whose messages are ready (under the run's mutex): the sender follows the format
-                                       // stage slice by slice, so that what is left behind the last chunk's device stage is one slice, not a chunk
+    std::vector<uint8_t> blk_done;     // per block of kFmtBlock queries: its messages are ready (under the run's mutex).  The sender follows the
+                                       // format stage block by block: what is left behind the last chunk's device stage is a block, not a chunk
 };
+constexpr uint64_t kFmtBlock = 2048;
 
 // raxtax() (src/raxtax.rs:14-97) as a pipeline over chunks of `chunk_size` queries on one or several device handles -- the
 // reference's `par_chunks(chunk_size)` (raxtax.rs:35-36) with GPUs in the place of rayon workers.  Chunk c belongs to handle
@@ -185,12 +186,18 @@ int run(rtx_index *const *indices, uint32_t n_dev, const rtx_tree *tree, uint64_
             ch.status.assign(ch.res.status, ch.res.status + ch.nq);
             ch.t.assign(ch.res.t, ch.res.t + ch.nq);
             std::atomic<int> rc_fmt{0};
-            constexpr uint64_t kSlice = 16384;  // queries per slice handed to the sender
-            for (uint64_t s0 = 0; s0 < ch.nq && !rc_fmt; s0 += kSlice) {
-            const uint64_t s1 = std::min<uint64_t>(ch.nq, s0 + kSlice);
-            parallel_ranges(s1 - s0, nt_format, [&](uint64_t a_, uint64_t b_) {
-                const uint64_t a = s0 + a_, b = s0 + b_;
+            // the workers take the blocks of the chunk in turn (worker k: blocks k, k + nt, ...), so that the front of the chunk is ready first
+            const uint64_t n_blk = (ch.nq + kFmtBlock - 1) / kFmtBlock;
+            {
+                std::lock_guard<std::mutex> g(mu);
+                ch.blk_done.assign(n_blk, 0);
+            }
+            const unsigned nt_used = (unsigned)std::min<uint64_t>(nt_format, n_blk);
+            parallel_ranges((uint64_t)nt_used * 256, nt_used, [&](uint64_t k0, uint64_t) {   // one call per worker: k0 / 256 is its number
+                const uint64_t k = k0 / 256;
                 std::vector<char> out_buf(1 << 16), tsv_buf(1 << 16);
+                for (uint64_t blk = k; blk < n_blk && !rc_fmt; blk += nt_used) {
+                const uint64_t a = blk * kFmtBlock, b = std::min<uint64_t>(ch.nq, a + kFmtBlock);
                 for (uint64_t i = a; i < b; i++) {
                     const uint64_t q = ch.q0 + i;
                     const uint64_t ne = ch.exact_off[i + 1] - ch.exact_off[i];
@@ -218,13 +225,13 @@ int run(rtx_index *const *indices, uint32_t n_dev, const rtx_tree *tree, uint64_
                     ch.out_msg[i].assign(out_buf.data(), (size_t)n);
                     if (tsv) ch.tsv_msg[i].assign(tsv_buf.data(), (size_t)tsv_len);
                 }
+                {
+                    std::lock_guard<std::mutex> g(mu);
+                    ch.blk_done[blk] = 1;
+                    cv.notify_all();
+                }
+                }
             });
-            if (!rc_fmt) {
-                std::lock_guard<std::mutex> g(mu);
-                ch.formatted = s1;
-                cv.notify_all();
-            }
-            }
             if (rc_fmt) { fail(rc_fmt, "formatting a result failed"); return; }
             busy_format[d] += now() - t_f0;
             set_stage(c, 3);
@@ -242,14 +249,15 @@ int run(rtx_index *const *indices, uint32_t n_dev, const rtx_tree *tree, uint64_
         Chunk &ch = chunks[c];
         double t_s0 = now();
         bool closed = false, dead = false;
-        uint64_t ready = 0;  // messages of the chunk known to be formatted
+        uint64_t ready = 0;  // messages of the chunk known to be formatted: [0, ready)
         for (uint64_t i = 0; i < ch.nq && !closed; i++) {
-            if (i >= ready) {  // wait for the slice that holds query i
+            if (i >= ready) {  // wait for the block that holds query i
                 busy_send += now() - t_s0;
+                const uint64_t blk = i / kFmtBlock;
                 std::unique_lock<std::mutex> g(mu);
-                cv.wait(g, [&] { return failed != RTX_OK || ch.formatted > i; });
+                cv.wait(g, [&] { return failed != RTX_OK || (blk < ch.blk_done.size() && ch.blk_done[blk]); });
                 if (failed != RTX_OK) { dead = true; break; }
-                ready = ch.formatted;
+                ready = std::min<uint64_t>(ch.nq, (blk + 1) * kFmtBlock);
                 g.unlock();
                 t_s0 = now();
             }

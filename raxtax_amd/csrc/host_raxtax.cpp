@@ -39,10 +39,7 @@ struct Chunk {
     std::vector<std::string> out_msg, tsv_msg;
     rtx_result_view res{};
     int stage = 0;                     // 1: exact matches looked up (or left to the device), 2: classified, 3: formatted, 4: sent
-    std::vector<uint8_t> blk_done;     // per block of kFmtBlock queries: its messages are ready (under the run's mutex).  The sender follows the
-                                       // format stage block by block: what is left behind the last chunk's device stage is a block, not a chunk
 };
-constexpr uint64_t kFmtBlock = 2048;
 
 // raxtax() (src/raxtax.rs:14-97) as a pipeline over chunks of `chunk_size` queries on one or several device handles -- the
 // reference's `par_chunks(chunk_size)` (raxtax.rs:35-36) with GPUs in the place of rayon workers.  Chunk c belongs to handle
@@ -186,18 +183,8 @@ int run(rtx_index *const *indices, uint32_t n_dev, const rtx_tree *tree, uint64_
             ch.status.assign(ch.res.status, ch.res.status + ch.nq);
             ch.t.assign(ch.res.t, ch.res.t + ch.nq);
             std::atomic<int> rc_fmt{0};
-            // the workers take the blocks of the chunk in turn (worker k: blocks k, k + nt, ...), so that the front of the chunk is ready first
-            const uint64_t n_blk = (ch.nq + kFmtBlock - 1) / kFmtBlock;
-            {
-                std::lock_guard<std::mutex> g(mu);
-                ch.blk_done.assign(n_blk, 0);
-            }
-            const unsigned nt_used = (unsigned)std::min<uint64_t>(nt_format, n_blk);
-            parallel_ranges((uint64_t)nt_used * 256, nt_used, [&](uint64_t k0, uint64_t) {   // one call per worker: k0 / 256 is its number
-                const uint64_t k = k0 / 256;
+            parallel_ranges(ch.nq, nt_format, [&](uint64_t a, uint64_t b) {
                 std::vector<char> out_buf(1 << 16), tsv_buf(1 << 16);
-                for (uint64_t blk = k; blk < n_blk && !rc_fmt; blk += nt_used) {
-                const uint64_t a = blk * kFmtBlock, b = std::min<uint64_t>(ch.nq, a + kFmtBlock);
                 for (uint64_t i = a; i < b; i++) {
                     const uint64_t q = ch.q0 + i;
                     const uint64_t ne = ch.exact_off[i + 1] - ch.exact_off[i];
@@ -225,12 +212,6 @@ int run(rtx_index *const *indices, uint32_t n_dev, const rtx_tree *tree, uint64_
                     ch.out_msg[i].assign(out_buf.data(), (size_t)n);
                     if (tsv) ch.tsv_msg[i].assign(tsv_buf.data(), (size_t)tsv_len);
                 }
-                {
-                    std::lock_guard<std::mutex> g(mu);
-                    ch.blk_done[blk] = 1;
-                    cv.notify_all();
-                }
-                }
             });
             if (rc_fmt) { fail(rc_fmt, "formatting a result failed"); return; }
             busy_format[d] += now() - t_f0;
@@ -245,22 +226,11 @@ int run(rtx_index *const *indices, uint32_t n_dev, const rtx_tree *tree, uint64_
     }
     // the sender: messages in input order
     for (uint64_t c = 0; c < n_chunks; c++) {
-        if (!wait_stage(c, 2)) break;
+        if (!wait_stage(c, 3)) break;
         Chunk &ch = chunks[c];
-        double t_s0 = now();
-        bool closed = false, dead = false;
-        uint64_t ready = 0;  // messages of the chunk known to be formatted: [0, ready)
+        const double t_s0 = now();
+        bool closed = false;
         for (uint64_t i = 0; i < ch.nq && !closed; i++) {
-            if (i >= ready) {  // wait for the block that holds query i
-                busy_send += now() - t_s0;
-                const uint64_t blk = i / kFmtBlock;
-                std::unique_lock<std::mutex> g(mu);
-                cv.wait(g, [&] { return failed != RTX_OK || (blk < ch.blk_done.size() && ch.blk_done[blk]); });
-                if (failed != RTX_OK) { dead = true; break; }
-                ready = std::min<uint64_t>(ch.nq, (blk + 1) * kFmtBlock);
-                g.unlock();
-                t_s0 = now();
-            }
             const uint64_t q = ch.q0 + i;
             if (ch.differ[i]) {
                 fprintf(stderr, "[WARN ] Exact matches for %s differ above the leafs of the lineage tree!\n", labels[q]);
@@ -275,9 +245,7 @@ int run(rtx_index *const *indices, uint32_t n_dev, const rtx_tree *tree, uint64_
             if (tsv) t.emplace(std::move(ch.tsv_msg[i]));
             if (!sender(labels[q], std::move(ch.out_msg[i]), std::move(t))) closed = true;
         }
-        if (dead) break;
         if (closed) { fail(RTX_ERR_SENDER, "result sink closed"); break; }  // sender.send(..)?, raxtax.rs:87
-        if (!wait_stage(c, 3)) break;  // (an empty tail of the chunk: the format stage has finished with it)
         std::vector<uint32_t>().swap(ch.exact_ids);
         std::vector<uint64_t>().swap(ch.exact_off);
         std::vector<uint8_t>().swap(ch.differ);

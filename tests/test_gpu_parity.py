@@ -1060,12 +1060,12 @@ _PRUNE_FUZZ = [int(x) for x in os.environ.get("RTX_PRUNE_FUZZ_SEEDS", "").split(
 
 @pytest.mark.parametrize("seed", [11, 12, 13] + _PRUNE_FUZZ)
 def test_tile_pruning_randomised(oracle, seed):
-    """Seeded databases of 8 ... 14 tiles with other roots, sequence lengths (t from 300 to 900) and query divergences; pruned
-    against full count: status, t, rows and lineages identical, confidences within 1e-9, no bound below a count it bounds; the
-    pruned rows of a few queries against the oracle."""
+    """Seeded databases of 8 ... 22 tiles (from 16 tiles on the second stage of the bounds is at work) with other roots, sequence lengths
+    (t from 190 -- eight bit planes -- to 900) and query divergences; pruned against full count: status, t, rows and lineages identical,
+    confidences within 1e-9, no bound below a count it bounds; the pruned rows of a few queries against the oracle."""
     rng = np.random.default_rng(seed)
-    n_refs = int(rng.integers(8 * 8192 + 1, 14 * 8192))
-    L = int(rng.choice([320, 658, 900]))
+    n_refs = int(rng.integers(8 * 8192 + 1, 22 * 8192))
+    L = int(rng.choice([200, 320, 658, 900]))
     db = synth.make_db(n_refs, length=L, seed_root=100 + seed, seed_db=200 + seed)
     parts = [synth.make_queries(db, 150, seed=seed, mu_q=0.02, exact_frac=0.1),
              synth.make_queries(db, 80, seed=seed + 1, mu_q=float(rng.choice([0.06, 0.1, 0.15])), exact_frac=0.0),
@@ -1090,7 +1090,7 @@ def test_tile_pruning_randomised(oracle, seed):
         assert st["pairs"] > 0 and st["bound_violations"] == 0 and a.debug_prune_stats()["pairs"] == 0
         for f in ("row_off", "t", "status"):
             assert np.array_equal(getattr(ra, f), getattr(rb, f)), (seed, skip, f)
-        assert np.allclose(ra.global_signal, rb.global_signal, rtol=0, atol=1e-12)
+        assert np.allclose(ra.global_signal, rb.global_signal, rtol=0, atol=1e-9)      # (proved: a few eps = 1e-10; measured 1e-13)
         for q in range(len(seqs)):
             xa, xb = rows_of(ra, q), rows_of(rb, q)
             if np.array_equal(xa[0], xb[0]):

@@ -150,8 +150,8 @@ int enqueue_hit(rtx_index *ix, const SubBatch &b, uint32_t flags, hipStream_t s,
         up.bitmap = ix->d_ubitmap.p;
         up.stride_bytes = ix->u_stride_bytes;
         up.n_refs = ix->u_nblocks;
-        up.dmask = sc.d_uones.p;
-        up.nsparse = sc.d_uzero.p;
+        up.dmask = nullptr;    // (a union bitmap is read densely: the kernel takes every row of the query, no masks, no sparse lists)
+        up.nsparse = nullptr;
         up.ntiles = ix->u_ntiles;
         up.counts = nullptr;  // nothing is stored per block: the epilogue keeps the largest bound per tile and the best block
         up.counts_lo = nullptr;
@@ -576,8 +576,8 @@ int prepare_workspace(rtx_index *ix, uint64_t n_queries, uint64_t tmax, uint64_t
     const bool will_prune = ix->prune_opt && ix->d_ubitmap.p && ix->pair_opt && ix->ntiles >= RTX_PRUNE_MIN_TILES && tmax <= 1023 && (ix->n_refs == ix->n_total || ix->shard_prune_opt);  // begin_run decides
     const uint64_t per_q = (uint64_t)ix->kstride * 2 + (uint64_t)ix->rstride * 12 + 4 + (uint64_t)ix->ntiles * (ix->rstride / 8 + ((kSegMaxSparseRows + 1) * 4 + 10)) + (ix->packed() ? ix->npad * 5 / 4 : ix->npad * 2) + (uint64_t)ix->hstride * 12 +
                            (uint64_t)ix->n_bnd_local * 8 + 64 +
-                           // + the scratch of the tile pruning: counts against the union bitmap, constant masks, its histogram, thresholds, live masks
-                           (will_prune ? (uint64_t)ix->u_ntiles * (ix->rstride / 8 + 4) + (uint64_t)ix->ntiles * 2 + 12 + (ix->ntiles + 31u) / 32u * 2u + 2u + kPruneBestWords * 4 +
+                           // + the scratch of the tile pruning: tile bounds, thresholds, live masks, best blocks, the lists of live blocks
+                           (will_prune ? (uint64_t)ix->ntiles * 2 + 12 + (ix->ntiles + 31u) / 32u * 2u + 2u + kPruneBestWords * 4 +
                                           ((uint64_t)ix->ntiles + 2u) * 2u  /* the list of live (pair, tile) blocks: 4 bytes per pair and tile */ : 0);
     uint32_t B = ix->sub_batch_req;
     if (B == 0) {
@@ -614,15 +614,10 @@ int alloc_scratch_set(rtx_index *ix, uint32_t k) {
             (rc = sc.d_urec.alloc((size_t)((B + 1u) / 2u) * 2u * ix->rstride)) || (rc = sc.d_nu.alloc((B + 1u) / 2u)))
             return rc;
         if (ix->prune_opt && ix->d_ubitmap.p && (ix->n_refs == ix->n_total || ix->shard_prune_opt)) {
-            const size_t mw = (size_t)B * ix->u_ntiles * (ix->rstride / 64);
-            const bool fresh = sc.d_uones.n < mw;
-            if ((rc = sc.d_uones.alloc(mw)) || (rc = sc.d_uzero.alloc((size_t)B * ix->u_ntiles)) ||
-                (rc = sc.d_tile_ub.alloc((size_t)B * ix->ntiles)) || (rc = sc.d_best_key.alloc(B)) || (rc = sc.d_prune_thr.alloc(B)) || (rc = sc.d_prune_i1.alloc(B)) || (rc = sc.d_best.alloc((size_t)B * kPruneBestWords)) || (rc = sc.d_live.alloc((size_t)(B + 1u) * ((ix->ntiles + 31u) / 32u + 1u))) ||
+            if ((rc = sc.d_tile_ub.alloc((size_t)B * ix->ntiles)) || (rc = sc.d_best_key.alloc(B)) || (rc = sc.d_prune_thr.alloc(B)) || (rc = sc.d_prune_i1.alloc(B)) || (rc = sc.d_best.alloc((size_t)B * kPruneBestWords)) || (rc = sc.d_live.alloc((size_t)(B + 1u) * ((ix->ntiles + 31u) / 32u + 1u))) ||
                 (rc = sc.d_items.alloc((size_t)((B + 1u) / 2u) * (ix->ntiles + 2u) + 9u)))
                 return rc;
             if (ix->d_fbitmap.p && (rc = sc.d_fine_items.alloc((size_t)((B + 1u) / 2u) * ix->f_ntiles + 9u + ix->f_ntiles))) return rc;
-            if (fresh) RTX_HIP(hipMemsetAsync(sc.d_uones.p, 0xFF, sc.d_uones.n * 8, ix->stream));
-            RTX_HIP(hipMemsetAsync(sc.d_uzero.p, 0, sc.d_uzero.n * 4, ix->stream));
         }
     }
     return RTX_OK;

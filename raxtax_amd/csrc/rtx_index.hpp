@@ -223,10 +223,9 @@ struct rtx_index {
         DevBuf<double> d_table_z, d_prefix;
         DevBuf<uint2> d_urec;   // hit_count_pair_kernel: union row lists of the pairs of the sub-batch
         DevBuf<uint32_t> d_nu;
-        // tile pruning: the queries counted against the union bitmap (every row dense: constant masks) leave the largest bound of
+        // tile pruning: the queries counted against the union bitmap (every row dense) leave the largest bound of
         // every tile and the best block (bounds_epilogue); thresholds and the live tiles per pair (prune_kernel)
-        DevBuf<unsigned long long> d_uones;
-        DevBuf<uint32_t> d_uzero, d_live, d_best_key;
+        DevBuf<uint32_t> d_live, d_best_key;
         DevBuf<uint32_t> d_items;  // [pairs x tiles] the (pair, tile) blocks with a live query | [1] their number | [8] queue per XCD | [pairs] live tiles per pair | [pairs] offsets
         DevBuf<uint16_t> d_tile_ub, d_prune_thr, d_prune_i1;
         DevBuf<uint32_t> d_best;  // [B][kPruneBestWords] reference shards: the candidate for the best block of the database

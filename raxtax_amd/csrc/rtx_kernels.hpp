@@ -201,7 +201,7 @@ struct PruneParams {
     uint32_t live_words;
     uint32_t *pair_live;      // [pairs] tiles counted for either query of the pair (live_offsets_kernel turns them into the list of blocks) or null
     uint16_t *thr_out;        // [B] the threshold of every query (0: not pruned, every tile is counted)
-    uint16_t *i1_out;         // [B] i* + 1 of every query with a threshold: Z holds less than 1e-12 at i <= i* (prob_lookup starts there)
+    uint16_t *i1_out;         // [B] i* + 1 of every query with a threshold: Z holds less than eps = 1e-10 at i <= i* (prob_lookup starts there)
     unsigned long long *stats;  // [kPruneStatCopies][8]: [0] += live tiles, [1] += pairs ... (reporting) or null
     uint32_t *detail;           // [B][kPruneDetailWords] debug tap (RTX_OPT_DEBUG_TAPS) or null: {best block, M, threshold, i* + 1, largest
                                 // bound, t, 0, 0, exact counts of the 64 references of the best block}
@@ -238,7 +238,7 @@ struct ProbParams {
     uint8_t *status;  // [n_q]
     uint32_t *ndist;  // [n_q] number of distinct hit counts D_q (work accounting)
     const uint16_t *prune_thr;  // [B] tile pruning: references with a count up to this carry nothing (rtx_prune.hip) or null
-    const uint16_t *prune_i1;   // [B] ... and the sums over i may start here (everything below holds less than 1e-12 of Z)
+    const uint16_t *prune_i1;   // [B] ... and the sums over i may start here (everything below holds less than eps = 1e-10 of Z)
 };
 
 struct WalkParams {

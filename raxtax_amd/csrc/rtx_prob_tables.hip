@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void prob_lookup_kernel(ProbParams p, ProbTabl
     }
     for (uint32_t m = tid; m <= t; m += 256) hl[m] = hist[m];  // one coalesced round instead of a chain of loads
     __syncthreads();
-    // Tile pruning gave the query a threshold u: the references with a count up to u hold less than 1e-12 of probability
+    // Tile pruning gave the query a threshold u: the references with a count up to u hold less than eps = 1e-10 of probability
     // together and move no product by more than that (rtx_prune.hip).  They all become references without a hit (cmf = 1,
     // probability 0) -- those of the tiles that were not counted already sit in bin 0 -- so that the result does not depend on
     // which of them happened to be counted (a tile is counted if EITHER query of its pair needs it).
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(256) void prob_lookup_kernel(ProbParams p, ProbTabl
         const double *Ct = tb.cmf + tb.off[t];
         const double *Rt = tb.ratio + tb.off[t];
         uint32_t i_lo = M > 0 ? t_ilo[M] : 0u;
-        // a pruned query: everything at i <= i* holds less than 1e-12 of Z (rtx_prune.hip, step 2 of the threshold) -- the sums
+        // a pruned query: everything at i <= i* holds less than eps = 1e-10 of Z (rtx_prune.hip, step 2 of the threshold) -- the sums
         // start behind it: one slice of i instead of three on the bench workload, and fewer rows still moving there
         if (u_thr && p.prune_i1) { const uint32_t i1 = p.prune_i1[q]; i_lo = i1 > i_lo && i1 <= n ? i1 : i_lo; }
         // saturation index of every distinct count, gathered by all threads at once (row_h as staging)

@@ -19,7 +19,7 @@
 //     hold at most N tail_u(i*) of probability themselves; tail_u(i*) <= (n - i*) pmf_u(i* + 1) once pmf_u falls.
 //     i* = the largest i with delta <= eps, u = the largest count below min H with N (n - i*) pmf_u(i* + 1) <= eps (below
 //     min H: the members of H are never dropped, so (1) holds for the pruned run as well): every probability and every
-//     prefix sum of the pruned run is within a few eps of the full one.  eps = 1e-12 (north_star asks for 1e-6).
+//     prefix sum of the pruned run is within a few eps of the full one.  eps = 1e-10 (rtx_math.hpp: kPruneEpsHD; 1e-12 until round 3; north_star asks for 1e-6).
 //     With a full-overlap reference (M = t) prob.rs:24-41 applies: table[m] = pmf_m(n), table[t] = 1: u = the largest
 //     count with N pmf_u(n) <= eps.
 //     (3) The tighter version of (2), the one in force.  (2) prices every dropped reference at the tail of the largest dropped

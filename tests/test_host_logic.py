@@ -262,3 +262,44 @@ def test_pack_bases_two_per_byte():
     bad[777_777] = 0x41
     out = np.zeros(len(bad) // 2 + 8, np.uint8)
     assert lib.rtx_pack_bases(ptr(bad, u8p), len(bad), ptr(out, u8p)) == 0
+
+
+def test_format_query_numbers_are_printf_numbers():
+    """rtx_format_query prints confidences "{:.2}" and signals "{:.5}" (lineage.rs:17-29) without snprintf (host_format.cpp: put_fixed);
+    the digits must be printf's / Rust's -- the exact binary value rounded half to even -- for every value, also those that sit on or
+    next to a rounding boundary (there the fast path hands over to snprintf)."""
+    import ctypes as C
+
+    from raxtax_amd import _lib
+
+    lib = _lib.load()
+    tree = rx.Tree.new(["k:A,p:B,c:C,o:D,f:E,g:F,s:G"], [np.array([1, 2, 4, 8, 1, 2, 4, 8, 1, 2], np.uint8)])
+    rng = np.random.default_rng(17)
+    vals = list(rng.random(3000)) + list(rng.random(500) * 1e-3) + list(rng.random(200) * 50) + [0.0, 1.0, 0.5, 0.000005, 0.0000149999999, 0.123455,
+            0.123465, 2.5e-6, 7.5e-6, 0.999995, 0.9999949999, 0.99999500001, 1e-300, 123456.7890149, 999999.999994, 1e6, 3e7, float("inf")]
+    vals += [k / 1e5 + 5e-6 for k in range(0, 2000, 7)] + [np.nextafter(k / 1e5 + 5e-6, 0) for k in range(0, 2000, 7)] + [np.nextafter(k / 1e5 + 5e-6, 1) for k in range(0, 2000, 7)]
+    nq = len(vals)
+    depth = np.full(nq, 7, np.uint32)
+    conf = np.zeros((nq, 32))
+    conf[:, :7] = rng.integers(0, 101, (nq, 7)) / 100.0
+    local = np.array(vals, dtype=np.float64)
+    gs = np.array(vals[::-1], dtype=np.float64)
+    begin = np.arange(nq, dtype=np.uint64)
+    count = np.ones(nq, np.uint32)
+    lin = np.zeros(nq, np.uint32)
+    t = np.full(nq, 3, np.uint32)
+    status = np.zeros(nq, np.uint8)
+    v = _lib.ResultView()
+    v.n_queries, v.n_rows = nq, nq
+    P = lambda a, ty: a.ctypes.data_as(C.POINTER(ty))
+    v.t, v.status, v.global_signal = P(t, C.c_uint32), P(status, C.c_uint8), P(gs, C.c_double)
+    v.row_begin, v.row_count = P(begin, C.c_uint64), P(count, C.c_uint32)
+    v.row_lineage, v.row_node, v.row_depth = P(lin, C.c_uint32), P(lin, C.c_uint32), P(depth, C.c_uint32)
+    v.row_conf, v.row_local_signal = P(conf, C.c_double), P(local, C.c_double)
+    buf = C.create_string_buffer(8192)
+    seq = np.array([1, 2, 4, 8], np.uint8)
+    for q in range(nq):
+        n = lib.rtx_format_query(tree._h, C.byref(v), q, b"q", P(seq, C.c_uint8), 4, None, 0, 2, buf, 8192, None, 0, None)
+        assert n > 0
+        want = "q\tk:A,p:B,c:C,o:D,f:E,g:F,s:G\t" + ",".join("%.2f" % c for c in conf[q, :7]) + "\t%.5f\t%.5f" % (local[q], gs[q])
+        assert buf.raw[:n].decode() == want, (q, local[q], gs[q])

@@ -139,23 +139,32 @@ int run(rtx_index *const *indices, uint32_t n_dev, const rtx_tree *tree, uint64_
         return rtx_batch_prefetch(indices[d], ch.nq, bases, base_off + ch.q0, ch.exact_ids.empty() ? nullptr : ch.exact_ids.data(), ch.exact_off.data());
     };
     auto device_loop = [&](uint32_t d) {
-        bool staged = false;
+        bool running = false;  // the kernels of chunk c have been enqueued already (behind the download of the chunk before it)
         for (uint64_t c = d; c < n_chunks; c += n_dev) {
             if (!wait_stage(c, 1)) return;
             if (c >= ahead && !wait_stage(c - ahead, 3)) return;  // the result set of this handle's second-last chunk is reused now
             Chunk &ch = chunks[c];
             const double t_d0 = now();
-            int rc = staged ? RTX_OK : stage_chunk(d, c);
-            staged = false;
-            if (!rc) rc = rtx_batch_activate(indices[d]);
-            if (!rc) rc = rtx_batch_run(indices[d], flags);
+            int rc = RTX_OK;
+            if (!running) {  // the handle's first chunk
+                rc = stage_chunk(d, c);
+                if (!rc) rc = rtx_batch_activate(indices[d]);
+                if (!rc) rc = rtx_batch_run(indices[d], flags);
+            }
+            running = false;
             const uint64_t nxt = c + n_dev;
+            bool staged = false;
             if (!rc && nxt < n_chunks) {
                 if (!wait_stage(nxt, 1)) return;   // its exact-match ids (host lookup), ready long ago as a rule
                 rc = stage_chunk(d, nxt);
                 staged = !rc;
             }
             if (!rc) rc = rtx_batch_download(indices[d], &ch.res);
+            if (!rc && staged) {  // the device goes on with the next chunk while this thread finishes its bookkeeping for this one
+                rc = rtx_batch_activate(indices[d]);
+                if (!rc) rc = rtx_batch_run(indices[d], flags);
+                running = !rc;
+            }
             if (!rc && dev_lookup[d]) {
                 const uint64_t *xo = nullptr;
                 const uint32_t *xi = nullptr;

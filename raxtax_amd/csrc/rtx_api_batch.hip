@@ -549,6 +549,17 @@ constexpr uint32_t kDefaultSubBatch = 20480, kDefaultSubBatchLarge = 16384, kDef
 // Sizes and allocates the per-batch workspace for n_queries queries of at most tmax k-mers.
 int prepare_workspace(rtx_index *ix, uint64_t n_queries, uint64_t tmax, uint64_t max_len) {
     int rc;
+    // A batch of the shape of the last one under the same options (the chunks of rtx_raxtax): everything below would come out the same --
+    // and hipMemGetInfo alone costs a good part of a millisecond between two chunks, with the device idle
+    const uint64_t key[6] = {n_queries, tmax, max_len, ix->sub_batch_req,
+                             (uint64_t)ix->packed_opt | (uint64_t)ix->pair_opt << 1 | (uint64_t)ix->prune_opt << 2 | (uint64_t)ix->shard_prune_opt << 3 | (uint64_t)ix->fine_opt << 4 |
+                                 (uint64_t)(ix->prob_mode & 3) << 5,
+                             (uint64_t)ix->n_bnd_local};
+    if (ix->ws_valid && std::memcmp(key, ix->ws_key, sizeof key) == 0 && !ix->staged) {
+        ix->n_q = n_queries;
+        return RTX_OK;
+    }
+    ix->ws_valid = false;
     if (tmax > 65535) { set_error("query with up to %llu k-mers: raxtax.rs:56 asserts t fits u16", (unsigned long long)tmax); return RTX_ERR_TOO_LONG; }
     if (prob_table_lds_bytes((uint32_t)tmax) > 160 * 1024 - 512) {
         set_error("query of %llu bases needs %zu bytes of LDS in prob_table (limit 160 KiB)", (unsigned long long)max_len,
@@ -597,7 +608,10 @@ int prepare_workspace(rtx_index *ix, uint64_t n_queries, uint64_t tmax, uint64_t
     B = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(B, n_queries));
     ix->sub_batch = B;
     ix->staged = false;
-    return alloc_scratch_set(ix, 0);
+    if ((rc = alloc_scratch_set(ix, 0))) return rc;
+    std::memcpy(ix->ws_key, key, sizeof key);
+    ix->ws_valid = true;
+    return RTX_OK;
 }
 
 int alloc_scratch_set(rtx_index *ix, uint32_t k) {

@@ -88,7 +88,7 @@ void finalise_range(rtx_index *ix, uint64_t pa, uint64_t pb, uint64_t row_base) 
 // Finalises positions [pa, pb) on up to nt threads; returns the number of rows they produced.
 uint64_t finalise_mt(rtx_index *ix, uint64_t pa, uint64_t pb, uint64_t row_base, unsigned nt) {
     nt = rtx::host_threads(nt);  // this process's share of the host's CPUs (cgroup quota, ranks per host)
-    if (pb - pa < 1024) nt = 1;
+    nt = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(nt, (pb - pa) / 4096));  // a thread start costs what 2 000 single-row queries cost
     std::vector<uint64_t> cut(nt + 1), base(nt + 1, row_base);
     for (unsigned i = 0; i <= nt; i++) cut[i] = pa + (pb - pa) * i / nt;
     for (unsigned i = 0; i < nt; i++) {

@@ -216,6 +216,8 @@ struct rtx_index {
     // ---- sub-batch scratch: two sets -- a staged (reference-sharded) run alternates between them, so that the exchange of
     // one sub-batch can overlap with the counting of the next; a whole-database handle uses set 0 only
     uint32_t sub_batch_req = 0, sub_batch = 0;
+    uint64_t ws_key[6] = {0, 0, 0, 0, 0, 0};  // shape and options the workspace was last prepared for (prepare_workspace)
+    bool ws_valid = false;
     struct Scratch {
         DevBuf<uint16_t> d_kmers, d_counts, d_tilemax;
         DevBuf<uint32_t> d_rows, d_t, d_nrows, d_hist, d_order, d_srows, d_nsparse;

@@ -6,10 +6,17 @@ kmer_extract -> hit_count -> prob_lookup -> taxon_prefix + lineage walk -> resul
 of synthetic queries per GPU, with the queries and the index already resident in HBM when the timed region starts
 (`--host-exact-match`: the lookup on the host instead, once, untimed -- rounds 1 and 2).
 
+The line verifies itself (SURVEY.md 8d, rank 0 at N = 1): after the timed region `parity_sample` holds the LAST TIMED STEP, as the device
+left it, against the CPU oracle -- the size-independent properties of all its results, and a seeded 2 000-query sample of its last
+sub-batch: hit counts of every visited tile bit-exact, no unvisited tile above the query's threshold, histogram, probabilities, result
+rows (raxtax_amd/checks.py).  A violation is printed in the line and the process exits with status 4.
+
 Beside `value` the line carries its own caveats (rank 0 at N = 1, `--no-extras` leaves them out): `value_incl_h2d` (the
-queries cross PCIe every step), `value_end_to_end` (host buffers -> rtx_raxtax -> formatted result strings, no disk),
-`value_unpruned` (RTX_OPT_TILE_PRUNE = 0: every tile counted) and a sweep over the divergence of the queries from their
-source reference (`divergence_sweep`: the tile pruning depends on how far a query's best hit stands out).
+queries cross PCIe every step: staged beside the running step, and not overlapped), `value_end_to_end` (host buffers -> rtx_raxtax ->
+formatted result strings, no disk; busy time of every pipeline stage), `value_unpruned` (RTX_OPT_TILE_PRUNE = 0: every tile counted), a
+sweep over the divergence of the queries from their source reference (`divergence_sweep`: the tile pruning depends on how far a query's
+best hit stands out) and `value_real_composition` (the reference's hold-out methodology on its own Diptera records: real barcodes whose
+every tile holds a relative).
 
 Default workload = BASELINE.json configs[2], the largest single-GPU configuration: 1 M synthetic COI-length
 (658 bp) queries per GPU vs a 500k-sequence database replicated per GPU (`--config 1` = configs[1]: 100k queries vs

@@ -196,6 +196,7 @@ int enqueue_hit(rtx_index *ix, const SubBatch &b, uint32_t flags, hipStream_t s,
         pr.exact = hp.exact;
         pr.lnfact = ix->d_lnfact.p;
         pr.inv = ix->d_inv.p;
+        pr.nlf = std::min<uint32_t>(kLnFactLen, ix->tmax + ix->tmax / 2 + 2);  // (pruning runs with tmax <= 1023: 12 KB)
         pr.hist = sc.d_hist.p;
         pr.hstride = ix->hstride;
         pr.live = sc.d_live.p;

@@ -195,6 +195,7 @@ struct PruneParams {
     const uint32_t *perm;
     ExactRef exact;
     const double *lnfact, *inv;   // ln x!, 1 / x
+    uint32_t nlf;                 // entries of lnfact the batch can reach (t + n - 1 < 1.5 tmax + 2): staged in LDS by every workgroup
     uint32_t *hist;           // [B][hstride]: bin 0 receives the references of the tiles that are not counted
     uint32_t hstride;
     uint32_t *live;           // [B][live_words] bit T: tile T is counted for the query

@@ -68,15 +68,24 @@ static constexpr double kPruneHalfEps = kPruneHalfEpsHD;
 #define RTX_PRUNE_WAVES 4
 #endif
 #ifndef RTX_PRUNE_TURNS
-#define RTX_PRUNE_TURNS 8  // rows of the best block in flight per wave: 8 x this (16: 17 registers spill at four waves per SIMD)
+#define RTX_PRUNE_TURNS 16  // rows of the best block in flight per wave: 8 x this (8 until round 4: 0.45 ms per step slower at configs[2])
 #endif
+static constexpr uint32_t kPruneWavesPerBlock = 4;
 
 __device__ __forceinline__ uint32_t wave_max_u32p(uint32_t v) { return wave_max_u32(v); }
 
-__global__ __launch_bounds__(64, RTX_PRUNE_WAVES) void prune_kernel(PruneParams p, ProbTables tb) {  // four waves per SIMD (<= 128 VGPRs): the kernel is a chain of dependent round trips per query, occupancy is what hides them
-    extern __shared__ uint16_t ub_lds[];  // [2][ntiles]
-    const uint32_t pair = blockIdx.x, lane = threadIdx.x;
-    const uint32_t bpt = 8192u >> kPruneShift;  // blocks per tile
+// Four waves per workgroup, one pair of queries per wave.  The kernel is bound by the instructions it issues (round 4 counters: every wave
+// active 24 % of its cycles at four waves per SIMD), and every evaluation of a pmf reads six entries of the ln x! table: the workgroup
+// stages the part of the table the batch can reach (t + n - 1 <= 1.5 tmax: 12 KB at t <= 1023) in LDS once, for its eight queries.
+// (RTX_PRUNE_PROFILE: a build for tools/prune_phase_probe.py -- the counters of p.stats carry shader-clock cycles per phase instead.)
+__global__ __launch_bounds__(64 * kPruneWavesPerBlock, RTX_PRUNE_WAVES) void prune_kernel(PruneParams p, ProbTables tb) {
+    extern __shared__ double prune_lds[];  // [nlf] ln x!; then per wave [2][ntiles] u16: the bounds of the tiles for the pair's queries
+    for (uint32_t i = threadIdx.x; i < p.nlf; i += 64u * kPruneWavesPerBlock) prune_lds[i] = p.lnfact[i];
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63u, pair = blockIdx.x * kPruneWavesPerBlock + (threadIdx.x >> 6);
+    if (pair * 2u >= p.nq) return;  // (behind the only barrier)
+    uint16_t *ub_lds = reinterpret_cast<uint16_t *>(prune_lds + p.nlf) + (size_t)(threadIdx.x >> 6) * 2u * p.ntiles;
+    const double *lf = prune_lds;
     const double ln_n = log((double)p.n_total);
     uint32_t thr[2] = {0u, 0u};
     uint32_t ist_prev = 0;  // i* + 1 of the pair's first query (the second one's search starts there)
@@ -85,6 +94,9 @@ __global__ __launch_bounds__(64, RTX_PRUNE_WAVES) void prune_kernel(PruneParams 
     for (uint32_t x = 0; x < 2u; x++) {
         if (x == 1u && !has_b) break;  // wave-uniform
         const uint32_t q = pair * 2u + x;
+#ifdef RTX_PRUNE_PROFILE
+        long long pt0 = clock64(), pt1 = pt0, pt2 = pt0, pt3 = pt0, pt4 = pt0;
+#endif
         // ---- 1. bound of every tile, and the block with the largest bound (the lowest one among equals; block 0 if every bound is 0):
         // left by the epilogue of the bounds pass (bounds_epilogue, rtx_hit_common.hpp)
         for (uint32_t T = lane; T < p.ntiles; T += 64) ub_lds[x * p.ntiles + T] = p.tile_ub[(size_t)q * p.tile_ub_stride + T];
@@ -93,8 +105,7 @@ __global__ __launch_bounds__(64, RTX_PRUNE_WAVES) void prune_kernel(PruneParams 
         const uint32_t bb = 0xFFFFFu - (bkey & 0xFFFFFu);
         // ---- 2. exact counts of its references (not those that --skip-exact-matches zeroes); M = the best of them.  The
         // block's references lie in kChunks chunks of eight = that many bytes of a row segment, in neighbouring lane words
-        // (ref_slot, rtx_math.hpp); lane l of a turn takes rows i0 + l and i0 + 64 + l and gathers those bytes, the hits of every
-        // reference are summed in 16-bit halves (at most 16 rows per lane x 64 lanes).
+        // (ref_slot, rtx_math.hpp); a lane takes one chunk of every eighth row of the list and sums the hits of its eight references.
         uint32_t M = 0;
         uint32_t hm = 0;  // lane l < 2^kPruneShift: the exact count of reference l of the block (0: none, or zeroed)
         if (p.phase == 2u) {  // the best block of the whole database, as the exchange between the shards left it
@@ -121,7 +132,12 @@ __global__ __launch_bounds__(64, RTX_PRUNE_WAVES) void prune_kernel(PruneParams 
                 const uint64_t r0 = ((uint64_t)bb << kPruneShift) + (uint64_t)ch * 8u;
                 ref_slot((uint32_t)(r0 < p.n_refs ? r0 : (uint64_t)bb << kPruneShift), p.stride_bytes, word, bit);  // bit = first bit of the chunk's byte
             }
-            uint32_t acc[4] = {0u, 0u, 0u, 0u};  // [pair of references of this lane's chunk]: two 16-bit counters (at most 1023 rows)
+            // this lane's chunk = eight references = one byte of the row segment: the low and the high nibble are spread over the four
+            // bytes of a word with one 24-bit multiply each (x * 0x204081 puts bit k of x at bit 8 k: the four shifted copies do not
+            // overlap) and summed in byte counters -- a lane sees every kChunks-th row of the list, at most 1024 / 8 = 128 of them
+            static_assert(kChunks == 8u, "the byte counters of the best block's exact counts hold the rows of one lane in eight (blocks of 64 references)");
+            uint32_t acc_lo = 0u, acc_hi = 0u;
+            const uint32_t bit4 = bit + 4u;
             const uint32_t nr_pad = (nr + 63u) & ~63u;  // the row list is padded with the all-zero row to whole chunks of 64
             // The rows are random lines of the best tile's region (HBM, not L2): kTurns turns = kTurns * kRowsPerTurn rows are in flight
             // together, their row ids come in as whole 256-byte pieces of the list (lane l <- entry l, handed to the lanes of a row
@@ -149,36 +165,38 @@ __global__ __launch_bounds__(64, RTX_PRUNE_WAVES) void prune_kernel(PruneParams 
                 }
 #pragma unroll
                 for (uint32_t u = 0; u < kTurns; u++) {
-                    const uint32_t bt = (w[u] >> bit) & 0xFFu;
-#pragma unroll
-                    for (int k = 0; k < 4; k++) acc[k] += ((bt >> (2 * k)) & 1u) | (((bt >> (2 * k + 1)) & 1u) << 16);
+                    acc_lo += __umul24((w[u] >> bit) & 0xFu, 0x204081u) & 0x01010101u;
+                    acc_hi += __umul24((w[u] >> bit4) & 0xFu, 0x204081u) & 0x01010101u;
                 }
                 id[0] = idn[0];
                 id[1] = idn[1];
             }
+            // [pair of references of this lane's chunk]: two 16-bit counters, summed over the row groups (lane c ends up with chunk c)
+            uint32_t acc[4] = {(acc_lo & 0xFFu) | ((acc_lo & 0xFF00u) << 8), ((acc_lo >> 16) & 0xFFu) | ((acc_lo >> 24) << 16),
+                               (acc_hi & 0xFFu) | ((acc_hi & 0xFF00u) << 8), ((acc_hi >> 16) & 0xFFu) | ((acc_hi >> 24) << 16)};
 #pragma unroll
             for (int k = 0; k < 4; k++)
 #pragma unroll
-                for (uint32_t d = 32; d >= kChunks; d >>= 1) acc[k] += (uint32_t)__shfl_xor((int)acc[k], (int)d, 64);  // over the row groups: lane c holds chunk c
-            // the block's references: drop those behind the end and those --skip-exact-matches zeroes
-#pragma unroll
-            for (uint32_t c = 0; c < kChunks; c++) {
-                const uint64_t r0 = ((uint64_t)bb << kPruneShift) + (uint64_t)c * 8u;
-#pragma unroll
-                for (int j = 0; j < 8; j++) {
-                    const uint64_t r = r0 + (uint64_t)j;
-                    bool ok = r < p.n_refs;
-                    if (ok && (p.flags & RTX_SKIP_EXACT_MATCHES)) {
-                        bool hit = false;
-                        for (uint64_t e = xe0 + lane; e < xe1; e += 64) hit = hit || (uint64_t)(xids[e] - p.ref_base) == r;  // local id; other shards' ids wrap out of range
-                        ok = __ballot(hit) == 0ull;
-                    }
-                    const uint32_t cnt = ((uint32_t)__builtin_amdgcn_readlane((int)acc[j >> 1], (int)c) >> ((j & 1) * 16)) & 0xFFFFu;
-                    if (ok && cnt > M) M = cnt;
-                    if (ok && lane == c * 8u + (uint32_t)j) hm = cnt;
-                }
+                for (uint32_t d = 32; d >= kChunks; d >>= 1) acc[k] += (uint32_t)__shfl_xor((int)acc[k], (int)d, 64);
+            // lane l <-> reference l of the block (chunk l / 8, reference l % 8 of it); not those behind the end, not those
+            // --skip-exact-matches zeroes
+            {
+                const uint32_t c = lane >> 3, j = lane & 7u;
+                const uint32_t v0 = (uint32_t)__shfl((int)acc[0], (int)c, 64), v1 = (uint32_t)__shfl((int)acc[1], (int)c, 64),
+                               v2 = (uint32_t)__shfl((int)acc[2], (int)c, 64), v3 = (uint32_t)__shfl((int)acc[3], (int)c, 64);
+                const uint32_t vv = (j & 4u) ? ((j & 2u) ? v3 : v2) : ((j & 2u) ? v1 : v0);
+                const uint32_t cnt = (vv >> ((j & 1u) * 16u)) & 0xFFFFu;
+                const uint64_t r = ((uint64_t)bb << kPruneShift) + (uint64_t)lane;
+                bool ok = lane < (1u << kPruneShift) && r < p.n_refs;
+                if (p.flags & RTX_SKIP_EXACT_MATCHES)
+                    for (uint64_t e = xe0; e < xe1; e++) ok = ok && (uint64_t)(xids[e] - p.ref_base) != r;  // local id; other shards' ids wrap out of range (wave-uniform loop)
+                hm = ok ? cnt : 0u;
+                M = wave_max_u32p(hm);
             }
         }
+#ifdef RTX_PRUNE_PROFILE
+        pt1 = pt2 = pt3 = pt4 = clock64();
+#endif
         if (p.detail) p.detail[(size_t)q * kPruneDetailWords + 8u + lane] = hm;  // debug tap: the exact counts of the best block's references
         if (p.phase == 1u) {  // a reference shard, first half: its candidate for the best block of the database
             uint32_t *bq = p.best + (size_t)q * kPruneBestWords;
@@ -190,7 +208,6 @@ __global__ __launch_bounds__(64, RTX_PRUNE_WAVES) void prune_kernel(PruneParams 
         const uint32_t t = p.t[q], n = t >> 1;
         uint32_t u_max = 0, i1_q = 0;
         if (t >= 16u && t <= tb.tmax && M >= 1u && n >= 2u) {
-            const double *lf = p.lnfact;
             const double ln_total = ln_binom_tab(lf, t + n - 1, n);
             if (M >= t) {  // full overlap: table[m] = pmf_m(n) = C(m+n-1, n) / C(t+n-1, n), rising with m
                 uint32_t mine = 0;
@@ -205,9 +222,15 @@ __global__ __launch_bounds__(64, RTX_PRUNE_WAVES) void prune_kernel(PruneParams 
                 if (hm * 5u < M * 4u) hm = 0u;  // H: the members close to the best one (the others would add next to nothing to G)
                 const double n_h = (double)__popcll(__ballot(hm != 0u));
                 const uint32_t h_min = 0xFFFFFFFFu - wave_max_u32p(hm ? 0xFFFFFFFFu - hm : 0u);  // <= M: H holds the best one
+                // ln(|H| + N (i + 1)) lies between its values at i = 0 and at i = n - 2: a sum outside that band (all but the last probes of
+                // the search: ln G moves by far more per step) decides without the logarithm -- the same answers, most of the log() calls gone
+                const double ln_f_lo = log(n_h + (double)p.n_total), ln_f_hi = log(n_h + (double)p.n_total * (double)(n - 1u));
                 auto passes = [&](uint32_t i) -> bool {
                     const double v = hm ? Ct[(size_t)hm * (n + 1) + i] : 0.0;  // ln cmf_m(i)
-                    return wave_sum_f64_dpp(v) + log(n_h + (double)p.n_total * (double)(i + 1u)) <= kPruneLnEps;
+                    const double sum = wave_sum_f64_dpp(v);
+                    if (sum + ln_f_hi <= kPruneLnEps) return true;   // wave-uniform
+                    if (sum + ln_f_lo > kPruneLnEps) return false;
+                    return sum + log(n_h + (double)p.n_total * (double)(i + 1u)) <= kPruneLnEps;
                 };
                 uint32_t ist1 = 0;  // i* + 1 in the end (0: none)
                 if (passes(0u)) {
@@ -243,6 +266,9 @@ __global__ __launch_bounds__(64, RTX_PRUNE_WAVES) void prune_kernel(PruneParams 
                     ist1 = lo + 1u;
                 }
                 ist_prev = ist1;
+#ifdef RTX_PRUNE_PROFILE
+                pt2 = pt3 = pt4 = clock64();
+#endif
                 if (ist1) {
                     const uint32_t i1 = ist1;  // = i* + 1: the first i that stays
                     const double ln_len = log((double)(n - i1 + 1u));
@@ -257,6 +283,9 @@ __global__ __launch_bounds__(64, RTX_PRUNE_WAVES) void prune_kernel(PruneParams 
                     first_fail = 0xFFFFFFFFu - wave_max_u32p(0xFFFFFFFFu - first_fail);
                     u_max = first_fail - 1u;
                     i1_q = i1;
+#ifdef RTX_PRUNE_PROFILE
+                    pt3 = pt4 = clock64();
+#endif
                     // ---- the tighter criterion (header, "(3)"): the same two error terms, but every i weighted with what G leaves of
                     // it.  Lanes 0 .. 62 <-> the window i = i1 .. i1 + 62; lane 63 <-> the point behind it, j = i1 + 63, which stands for
                     // the whole tail of pmf_u from there on ((n - j + 1) pmf_u(j) once pmf_u falls; G counts as 1 out there).  With
@@ -287,11 +316,21 @@ __global__ __launch_bounds__(64, RTX_PRUNE_WAVES) void prune_kernel(PruneParams 
                         const bool vi = iw <= n;
                         double lnG = 0.0;
                         unsigned long long hb = __ballot(hm != 0u);
-                        while (hb) {  // wave-uniform: the members of H
-                            const int h = __builtin_ctzll(hb);
-                            hb &= hb - 1ull;
-                            const uint32_t m = (uint32_t)__builtin_amdgcn_readlane((int)hm, h);
-                            lnG += Ct[(size_t)m * (n + 1) + (vi ? iw : n)];
+                        const uint32_t iwc = vi ? iw : n;
+                        while (hb) {  // wave-uniform: the members of H, four rows of the table in flight (added in the order of the lanes, as one by one)
+                            double v[4];
+#pragma unroll
+                            for (int k = 0; k < 4; k++) {
+                                v[k] = 0.0;
+                                if (hb) {
+                                    const int h = __builtin_ctzll(hb);
+                                    hb &= hb - 1ull;
+                                    const uint32_t m = (uint32_t)__builtin_amdgcn_readlane((int)hm, h);
+                                    v[k] = Ct[(size_t)m * (n + 1) + iwc];
+                                }
+                            }
+#pragma unroll
+                            for (int k = 0; k < 4; k++) lnG += v[k];
                         }
                         const double gw = vi && !tail_pt ? exp(lnG) : 0.0;                         // G(i)
                         const double ww = vi && !tail_pt ? exp(fmin(0.0, ln_kept + lnG)) : 0.0;   // min(1, K G(i)), K = N for a shard
@@ -350,6 +389,9 @@ __global__ __launch_bounds__(64, RTX_PRUNE_WAVES) void prune_kernel(PruneParams 
                             return falling && wave_sum_f64_dpp(near ? gnd * (dead ? gsa : a) : 0.0) + n_far * far_a <= kPruneHalfEps &&
                                    wave_sum_f64_dpp(near ? gnd * (dead ? gsb : b) : 0.0) + n_far * far_b <= kPruneHalfEps;
                         };
+#ifdef RTX_PRUNE_PROFILE
+                        pt4 = clock64();
+#endif
                         uint32_t lo = u_max, hi = h_min - 1u;
                         while (lo < hi) {  // wave-uniform
                             const uint32_t mid = (lo + hi + 1u) >> 1;
@@ -367,8 +409,12 @@ __global__ __launch_bounds__(64, RTX_PRUNE_WAVES) void prune_kernel(PruneParams 
             d[0] = bb; d[1] = M; d[2] = u_max; d[3] = u_max ? i1_q : 0u; d[4] = ub_best; d[5] = t; d[6] = 0u; d[7] = 0u;
         }
         // reporting: sums of the lower bound of the best hit, of the threshold, of the largest tile bound
+#ifdef RTX_PRUNE_PROFILE
+        { const long long pt5 = clock64(); st[2] += pt1 - pt0; st[3] += pt2 - pt1; st[4] += pt3 - pt2; st[6] += pt4 - pt3; st[7] += pt5 - pt4; st[5] += 1ull; }
+#else
         st[2] += M; st[3] += u_max; st[4] += ub_best; st[5] += 1ull;
-        if (ub_best < M) st[6] += 1ull;  // must never happen: a block's bound below one of its references' counts
+        if (ub_best < M) st[6] += 1ull;
+#endif  // must never happen: a block's bound below one of its references' counts
     }
     if (p.phase == 1u) return;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -411,7 +457,9 @@ __global__ __launch_bounds__(64, RTX_PRUNE_WAVES) void prune_kernel(PruneParams 
         if (has_b) p.hist[(size_t)(pair * 2u + 1u) * p.hstride] = (uint32_t)dead_refs[1];
     }
     if (lane == 0 && p.pair_live) p.pair_live[pair] = n_live;
+#ifndef RTX_PRUNE_PROFILE
     st[7] = n_qlive;  // (query, tile) combinations that are counted
+#endif
     if (p.stats) {  // one atomic instruction per wave (lane k adds counter k), 64 copies of the counters in lines of their own:
                     // thousands of waves adding to ONE address queue up in L2 for longer than everything else here takes
         st[0] = n_live; st[1] = 1ull;
@@ -423,7 +471,9 @@ __global__ __launch_bounds__(64, RTX_PRUNE_WAVES) void prune_kernel(PruneParams 
 }
 
 void launch_prune(hipStream_t s, const PruneParams &p, const ProbTables &tb, uint32_t nq) {
-    hipLaunchKernelGGL(prune_kernel, dim3((nq + 1u) / 2u), dim3(64), (size_t)2 * p.ntiles * sizeof(uint16_t), s, p, tb);
+    const uint32_t pairs = (nq + 1u) / 2u;
+    hipLaunchKernelGGL(prune_kernel, dim3((pairs + kPruneWavesPerBlock - 1u) / kPruneWavesPerBlock), dim3(64 * kPruneWavesPerBlock),
+                       (size_t)p.nlf * sizeof(double) + (size_t)kPruneWavesPerBlock * 2 * p.ntiles * sizeof(uint16_t), s, p, tb);
 }
 
 }  // namespace rtx

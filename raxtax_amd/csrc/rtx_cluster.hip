@@ -42,25 +42,33 @@ __global__ __launch_bounds__(64) void sketch_kernel(const uint8_t *__restrict__ 
     const uint32_t none = (1u << kSketchBits) - 1u;
     uint32_t m1 = none, m2 = none, m3 = none;
     if (len >= (uint64_t)kSketchK) {
-        // lane l rolls over the windows [l*wpl, (l+1)*wpl): wpl + 11 sequential byte reads
+        // lane l rolls over the windows [l*wpl, (l+1)*wpl), sixteen at a time: their 27 bases come in as four unaligned 8-byte words
+        // (one round trip instead of 27 dependent byte loads; the batch buffer is padded by 64 bytes behind its end) and the
+        // code rolls over them in registers, as in kmer_extract_kernel
         const uint64_t nwin = len - kSketchK + 1;
         const uint64_t wpl = (nwin + 63) / 64;
         const uint64_t w0 = (uint64_t)lane * wpl;
         const uint64_t w1 = w0 + wpl < nwin ? w0 + wpl : nwin;
-        uint32_t code = 0, run = 0;
-        for (uint64_t i = w0; i < w1 + kSketchK - 1 && w0 < w1; i++) {
-            const uint32_t c = seq[i];
-            const bool ok = c == 1u || c == 2u || c == 4u || c == 8u;
-            code = ((code << 2) | (((uint32_t)__ffs((int)c) - 1u) & 3u)) & 0xFFFFFFu;
-            run = ok ? run + 1u : 0u;
-            if (run >= (uint32_t)kSketchK) {
-                const uint64_t x = code;
-                const uint32_t h1 = (uint32_t)((x * 0x9E3779B97F4A7C15ull) >> (64 - kSketchBits));
-                const uint32_t h2 = (uint32_t)((x * 0xC2B2AE3D27D4EB4Full) >> (64 - kSketchBits));
-                const uint32_t h3 = (uint32_t)((x * 0x165667B19E3779F9ull) >> (64 - kSketchBits));
-                m1 = h1 < m1 ? h1 : m1;
-                m2 = h2 < m2 ? h2 : m2;
-                m3 = h3 < m3 ? h3 : m3;
+        for (uint64_t i = w0; i < w1; i += 16) {
+            unsigned long long v[4];
+            __builtin_memcpy(v, seq + i, 32);
+            const uint32_t nw = w1 - i < 16 ? (uint32_t)(w1 - i) : 16u;
+            uint32_t code = 0, run = 0;
+#pragma unroll
+            for (int b = 0; b < 16 + kSketchK - 1; b++) {
+                const uint32_t c = (uint32_t)(v[b >> 3] >> ((b & 7) * 8)) & 0xFFu;
+                const bool ok = c == 1u || c == 2u || c == 4u || c == 8u;
+                code = ((code << 2) | (((uint32_t)__ffs((int)c) - 1u) & 3u)) & 0xFFFFFFu;
+                run = ok ? run + 1u : 0u;
+                if (b >= kSketchK - 1 && (uint32_t)(b - (kSketchK - 1)) < nw && run >= (uint32_t)kSketchK) {
+                    const uint64_t x = code;
+                    const uint32_t h1 = (uint32_t)((x * 0x9E3779B97F4A7C15ull) >> (64 - kSketchBits));
+                    const uint32_t h2 = (uint32_t)((x * 0xC2B2AE3D27D4EB4Full) >> (64 - kSketchBits));
+                    const uint32_t h3 = (uint32_t)((x * 0x165667B19E3779F9ull) >> (64 - kSketchBits));
+                    m1 = h1 < m1 ? h1 : m1;
+                    m2 = h2 < m2 ? h2 : m2;
+                    m3 = h3 < m3 ? h3 : m3;
+                }
             }
         }
     }
@@ -123,7 +131,7 @@ __global__ __launch_bounds__(256) void loc_finish_kernel(uint32_t *__restrict__ 
 
 // ---------------------------------------------------------------------------
 // Locator of a query: one wave per query.
-//   1. lane l rolls over the windows [l * wpl, (l + 1) * wpl) of the first kLocWin windows (wpl + 11 sequential byte reads,
+//   1. lane l rolls over the windows [l * wpl, (l + 1) * wpl) of the first kLocWin windows (their wpl + 11 bases in one round trip,
 //      as sketch_kernel) and leaves their 12-mer codes in LDS;
 //   2. lane l looks up the windows l, l + 64, ... (coalesced codes, four table loads in flight), keeps the positions in
 //      LDS and votes for coarse bins of 2^bin_shift references.  Most lanes vote for the SAME bin -- that is the point --
@@ -156,7 +164,7 @@ __device__ __forceinline__ void vote_bins(uint32_t *h, uint32_t b, bool valid, u
 __global__ __launch_bounds__(64) void locator_kernel(const uint8_t *__restrict__ bases, const uint64_t *__restrict__ off,
                                                      const uint32_t *__restrict__ table, uint32_t bin_shift, uint32_t n_bins,
                                                      uint64_t *__restrict__ keys) {
-    extern __shared__ uint32_t h[];            // n_bins / 2 + 2 words: the coarse bins as u16 pairs
+    extern __shared__ __attribute__((aligned(16))) uint32_t h[];  // n_bins / 2 + 2 words (rounded up to four): the coarse bins as u16 pairs
     __shared__ uint32_t lcode[kLocWin];        // 12-mer codes, then the positions found for them
     __shared__ uint32_t hf[kLocFineDiv + 2];   // 2 * kLocFineDiv + 1 fine bins as u16 pairs
     const uint32_t q = blockIdx.x, lane = threadIdx.x;
@@ -166,23 +174,30 @@ __global__ __launch_bounds__(64) void locator_kernel(const uint8_t *__restrict__
     const uint8_t *seq = bases + b0;
     const uint32_t nwin = (uint32_t)(len - kSketchK + 1 < (uint64_t)kLocWin ? len - kSketchK + 1 : kLocWin);
     const uint32_t words = n_bins / 2 + 2;
-    for (uint32_t i = lane; i < words; i += 64) h[i] = 0;
+    for (uint32_t i = lane; i < (words + 3u) / 4u; i += 64) reinterpret_cast<uint4 *>(h)[i] = make_uint4(0u, 0u, 0u, 0u);
     if (lane < kLocFineDiv + 2) hf[lane] = 0;
-    {   // 1. codes of this lane's run of windows
+    {   // 1. codes of this lane's run of windows (at most 16: nwin <= kLocWin): its 27 bases as four unaligned 8-byte words, as sketch_kernel
         const uint32_t wpl = (nwin + 63u) / 64u;
         const uint32_t w0 = lane * wpl, w1 = w0 + wpl < nwin ? w0 + wpl : nwin;
-        uint32_t code = 0, run = 0;
-        for (uint32_t i = w0; w0 < w1 && i < w1 + kSketchK - 1; i++) {
-            uint32_t two;
-            const bool ok = base_code(seq[i], two);
-            code = ((code << 2) | two) & 0xFFFFFFu;
-            run = ok ? run + 1u : 0u;
-            if (i + 1 >= w0 + (uint32_t)kSketchK) lcode[i + 1 - kSketchK] = run >= (uint32_t)kSketchK ? code : kLocNone;
+        static_assert(kLocWin <= 1024u, "a lane's run of windows fits one piece of 16");
+        if (w0 < w1) {
+            unsigned long long v[4];
+            __builtin_memcpy(v, seq + w0, 32);
+            const uint32_t nw = w1 - w0;
+            uint32_t code = 0, run = 0;
+#pragma unroll
+            for (int b = 0; b < 16 + kSketchK - 1; b++) {
+                uint32_t two;
+                const bool ok = base_code((uint32_t)(v[b >> 3] >> ((b & 7) * 8)) & 0xFFu, two);
+                code = ((code << 2) | two) & 0xFFFFFFu;
+                run = ok ? run + 1u : 0u;
+                if (b >= kSketchK - 1 && (uint32_t)(b - (kSketchK - 1)) < nw) lcode[w0 + (uint32_t)(b - (kSketchK - 1))] = run >= (uint32_t)kSketchK ? code : kLocNone;
+            }
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    // 2. look-ups and the coarse vote, four windows per lane and turn
+    // 2. look-ups and the coarse vote, four windows per lane and turn (all sixteen of a lane at once: 0.3 ms per 1 M queries slower)
     uint32_t any = 0;
     for (uint32_t w0 = 0; w0 < nwin; w0 += 256) {
         uint32_t pos[4];
@@ -208,10 +223,12 @@ __global__ __launch_bounds__(64) void locator_kernel(const uint8_t *__restrict__
     // 3. best pair of neighbouring coarse bins (B, B + 1): value << 16 | (0xFFFF - B), the lowest B among equals
     auto bin = [&](uint32_t b) { return (h[b >> 1] >> ((b & 1u) * 16u)) & 0xFFFFu; };
     uint32_t best = 0;
-    for (uint32_t b = lane; b < n_bins; b += 64) {
-        const uint32_t v = bin(b) + bin(b + 1u);
-        const uint32_t cand = (v << 16) | (0xFFFFu - b);
-        best = cand > best ? cand : best;
+    for (uint32_t k = lane; 2u * k < n_bins; k += 64) {  // the bins 2k and 2k + 1 from two words (h[words - 1] = 0 stands behind the last bin)
+        const uint32_t w0 = h[k], w1 = h[k + 1u];
+        const uint32_t v0 = (w0 & 0xFFFFu) + (w0 >> 16), v1 = (w0 >> 16) + (w1 & 0xFFFFu);
+        const uint32_t c0 = (v0 << 16) | (0xFFFFu - 2u * k), c1 = 2u * k + 1u < n_bins ? (v1 << 16) | (0xFFFFu - (2u * k + 1u)) : 0u;
+        best = c0 > best ? c0 : best;
+        best = c1 > best ? c1 : best;
     }
     best = wave_max_u32(best);
     const uint32_t B = 0xFFFFu - (best & 0xFFFFu);
@@ -270,7 +287,7 @@ void launch_locator(hipStream_t s, const uint8_t *bases, const uint64_t *off, ui
                     uint64_t *keys) {
     const uint32_t sh = loc_bin_shift(n_refs);
     const uint32_t n_bins = (uint32_t)((n_refs + (1ull << sh) - 1) >> sh);
-    hipLaunchKernelGGL(locator_kernel, dim3(n_q), dim3(64), (n_bins / 2 + 2) * 4, s, bases, off, table, sh, n_bins, keys);
+    hipLaunchKernelGGL(locator_kernel, dim3(n_q), dim3(64), ((n_bins / 2 + 2 + 3) & ~3u) * 4, s, bases, off, table, sh, n_bins, keys);
 }
 void launch_invert_perm(hipStream_t s, const uint32_t *perm, uint32_t n, uint32_t *inv) {
     hipLaunchKernelGGL(invert_perm_kernel, dim3((n + 255) / 256), dim3(256), 0, s, perm, n, inv);

@@ -42,7 +42,12 @@ GRID = collections.defaultdict(lambda: collections.defaultdict(list))   # grid s
 
 def read_pass(d):
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
-    for f in glob.glob(str(Path(d) / "**" / "*counter_collection.csv"), recursive=True):
+    # gpurun MERGES a call's output into gpurun_out/: a directory that was profiled into before still holds the older runs (of older
+    # builds).  Only the newest result file of the pass counts (until late in round 4 all of them were averaged: three runs of 16 launches).
+    files = sorted(glob.glob(str(Path(d) / "**" / "*counter_collection.csv"), recursive=True), key=lambda f: Path(f).stat().st_mtime)
+    if len(files) > 1:
+        print(f"{d}: {len(files)} result files, taking the newest ({files[-1]})")
+    for f in files[-1:]:
         for r in csv.DictReader(open(f)):
             agg[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
             GRID[(id(agg), short(r["Kernel_Name"]))][r["Counter_Name"]].append(int(r.get("Grid_Size", 0) or 0))

@@ -10,6 +10,7 @@ TAG=${1:-r2}; shift || true
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out
 mkdir -p "$OUT"
+rm -rf "$OUT/${TAG}_trace" "$OUT/${TAG}_fetch" "$OUT/${TAG}_write" "$OUT/${TAG}_tcc"   # (a fresh box has none; a local rerun would mix runs)
 cd /tmp && export TMPDIR=/tmp
 ARGS="--steps 2 --warmup 1 --no-cpu-baseline --no-extras $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${TAG}_trace" -- python3 "$ROOT/bench.py" $ARGS > "$OUT/${TAG}_trace.log" 2>&1

@@ -57,11 +57,14 @@ static KmerParams kmer_params(rtx_index *ix, const SubBatch &b) {
     kp.perm = ix->d_perm.p;
     kp.row_of = ix->d_row_of.p;
     kp.list_len = ix->d_list_len.p;
+    kp.row_len = ix->d_row_len.p;
     kp.zero_row = ix->n_rows;
     kp.kmers = sc.d_kmers.p;
     kp.kstride = ix->kstride;
     kp.seginfo = ix->d_seginfo.p;
     kp.seg_stride = ix->seg_stride;
+    kp.segcls = ix->d_segcls.p;
+    kp.cls_stride = ix->cls_stride;
     kp.ntiles = ix->ntiles;
     kp.seg_dbits = ix->d_seg_dbits.p;
     kp.seg_sbits = ix->d_seg_sbits.p;

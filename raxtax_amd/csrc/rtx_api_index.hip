@@ -288,6 +288,8 @@ static int build_segments(rtx_index *ix) {
     const bool sparse_on = g_seg_classes != 0, empty_on = g_seg_classes != 0;
     DevBuf<uint16_t> d_pop;
     int rc;
+    if ((rc = ix->d_row_len.alloc(RTX_NUM_KMERS))) return rc;
+    launch_row_len_pack(ix->stream, ix->d_row_of.p, ix->d_list_len.p, ix->d_row_len.p);  // (both tables are final here, in either way of creating an index)
     if ((rc = d_pop.alloc(n)) || (rc = ix->d_seginfo.alloc((size_t)n_rows1 * ss))) return rc;
     launch_seg_popcount(ix->stream, ix->d_bitmap.p, ix->stride_bytes, n_rows1, nt, d_pop.p);
     RTX_HIP(hipGetLastError());
@@ -307,6 +309,18 @@ static int build_segments(rtx_index *ix) {
             else o = 1u;
         }
     if (slots > 0x7FFFFFF0ull) { set_error("too many sparse segments"); return RTX_ERR_INVALID; }
+    {   // the classes alone: [tile][row], two bits per row (kmer_extract behind tile pruning)
+        const uint32_t cw = (n_rows1 + 15u) / 16u;
+        ix->cls_stride = cw;
+        std::vector<uint32_t> cls((size_t)nt * cw, 0u);
+        for (uint32_t r = 0; r < n_rows1; r++)
+            for (uint32_t t = 0; t < nt; t++) {
+                const uint32_t o = info[(size_t)r * ss + t];
+                cls[(size_t)t * cw + (r >> 4)] |= (o >= 2u ? 2u : o) << ((r & 15u) * 2u);
+            }
+        if ((rc = ix->d_segcls.alloc(cls.size()))) return rc;
+        RTX_HIP(hipMemcpy(ix->d_segcls.p, cls.data(), cls.size() * 4, hipMemcpyHostToDevice));
+    }
     // many tiles: the classes as bit tables per block of 64 tiles (kmer_extract transposes 64 rows x 64 tiles at a time)
     ix->seg_blocks = nt > 12 ? (nt + 63) / 64 : 0;
     if (ix->seg_blocks) {
@@ -565,7 +579,7 @@ void rtx_index_destroy(rtx_index *index) {
 uint64_t rtx_index_num_refs(const rtx_index *index) { return index ? index->n_total : 0; }
 uint64_t rtx_index_device_bytes(const rtx_index *index) {
     if (!index) return 0;
-    return index->d_seg_dbits.n * 8 + index->d_seg_sbits.n * 8 + index->d_seg_sbase.n * 4 + index->d_seginfo.n * 4 + index->d_segslots.n * 2 + index->d_bitmap.n * 4 + index->d_row_of.n * 4 + index->d_list_len.n * 4 + index->d_loc_table.n * 4 + index->d_ubitmap.n * 4 + index->d_fbitmap.n * 4 + index->d_em_table.n * 8 + index->d_em_rep_off.n * 8 + index->d_em_rep_bytes.n + index->d_em_goff.n * 4 + index->d_em_gids.n * 4 + index->d_lnfact.n * 8 +
+    return index->d_seg_dbits.n * 8 + index->d_seg_sbits.n * 8 + index->d_seg_sbase.n * 4 + index->d_seginfo.n * 4 + index->d_segcls.n * 4 + index->d_segslots.n * 2 + index->d_bitmap.n * 4 + index->d_row_of.n * 4 + index->d_row_len.n * 8 + index->d_list_len.n * 4 + index->d_loc_table.n * 4 + index->d_ubitmap.n * 4 + index->d_fbitmap.n * 4 + index->d_em_table.n * 8 + index->d_em_rep_off.n * 8 + index->d_em_rep_bytes.n + index->d_em_goff.n * 4 + index->d_em_gids.n * 4 + index->d_lnfact.n * 8 +
            index->d_noderec.n * 16 + index->d_bnd_bits.n + index->d_bnd_rank.n * 4;
 }
 int rtx_index_set_batch(rtx_index *index, uint32_t sub_batch) {

@@ -336,38 +336,41 @@ __global__ __launch_bounds__(64, 2) void hit_count_pair_kernel(HitParams p) {
 }
 
 // The (pair, tile) blocks in which a query of the pair is live: entry = pair * ntiles + tile.  prune_kernel left the number of
-// live tiles of every pair; live_offsets_kernel (one workgroup, thread i takes the pairs [i * per, (i + 1) * per): loads of a thread
-// all in flight together) scans them, live_items_kernel (a thread per pair) writes the entries.
+// live tiles of every pair; live_offsets_kernel (one workgroup) scans them, live_items_kernel (a thread per pair) writes the entries.
 __global__ __launch_bounds__(1024) void live_offsets_kernel(const uint32_t *__restrict__ pair_live, uint32_t np, uint32_t *__restrict__ off,
                                                             uint32_t *__restrict__ n_items) {
-    __shared__ uint32_t wsum[16];
+    // pieces of 8192 pairs, a thread takes eight neighbours (a wave reads and writes 2 KB in one stretch; with a thread per run of
+    // np / 1024 pairs every load and store of the one workgroup was a line of its own: 48 us per 32 768 pairs)
+    __shared__ uint32_t wsum[2][16];  // double-buffered: one barrier per piece
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const uint32_t per = (np + 1023u) / 1024u, p0 = tid * per;
-    uint32_t cnt = 0;
-    for (uint32_t i0 = 0; i0 < per; i0 += 16) {
-        uint32_t c[16];
+    constexpr uint32_t kPer = 8;
+    uint32_t carry = 0, buf = 0;
+    for (uint32_t base = 0; base < np; base += 1024u * kPer, buf ^= 1u) {
+        const uint32_t i0 = base + tid * kPer;
+        uint32_t c[kPer], cnt = 0;
 #pragma unroll
-        for (int i = 0; i < 16; i++) c[i] = i0 + i < per && p0 + i0 + i < np ? pair_live[p0 + i0 + i] : 0u;
+        for (uint32_t j = 0; j < kPer; j++) c[j] = i0 + j < np ? pair_live[i0 + j] : 0u;
 #pragma unroll
-        for (int i = 0; i < 16; i++) cnt += c[i];
-    }
-    const uint32_t incl = wave_incl_scan_u32(cnt);
-    if (lane == 63u) wsum[wave] = incl;
-    __syncthreads();
-    uint32_t o = incl - cnt;
-    for (uint32_t w = 0; w < wave; w++) o += wsum[w];
-    if (tid == 1023u) n_items[0] = o + cnt;
-    if (tid < 8u) n_items[1u + tid] = 0;  // the queues of the XCDs (hit_count_pair_kernel)
-    for (uint32_t i0 = 0; i0 < per; i0 += 16) {  // (L1 hits now)
-        uint32_t c[16];
+        for (uint32_t j = 0; j < kPer; j++) cnt += c[j];
+        const uint32_t incl = wave_incl_scan_u32(cnt);
+        if (lane == 63u) wsum[buf][wave] = incl;
+        __syncthreads();
+        uint32_t o = carry + incl - cnt, tot = 0;
 #pragma unroll
-        for (int i = 0; i < 16; i++) c[i] = i0 + i < per && p0 + i0 + i < np ? pair_live[p0 + i0 + i] : 0u;
-#pragma unroll
-        for (int i = 0; i < 16; i++) {
-            if (i0 + i < per && p0 + i0 + i < np) off[p0 + i0 + i] = o;
-            o += c[i];
+        for (uint32_t w = 0; w < 16u; w++) {
+            const uint32_t sw = wsum[buf][w];
+            o += w < wave ? sw : 0u;
+            tot += sw;
         }
+#pragma unroll
+        for (uint32_t j = 0; j < kPer; j++) {
+            if (i0 + j < np) off[i0 + j] = o;
+            o += c[j];
+        }
+        carry += tot;
     }
+    if (tid == 0u) n_items[0] = carry;
+    if (tid < 8u) n_items[1u + tid] = 0;  // the queues of the XCDs (hit_count_pair_kernel)
 }
 
 // Groups of 1024 pairs, and inside a group the entries TILE by tile: the workgroups of the counting pass that run at the same time then

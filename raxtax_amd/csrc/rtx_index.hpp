@@ -114,8 +114,10 @@ struct rtx_index {
     uint64_t npad = 0;          // references per padded row (= stride_bytes * 8)
     uint32_t ntiles = 0;        // 8192-reference tiles
     DevBuf<uint32_t> d_bitmap, d_row_of, d_list_len;
+    DevBuf<uint2> d_row_len;    // {row_of, list_len} per k-mer (kmer_extract: one gather instead of two)
     // segment classes (rtx_segments.hip): class / sparse slot of every (row, tile) segment, slots of 32 local ids
-    DevBuf<uint32_t> d_seginfo, d_seg_sbase;
+    DevBuf<uint32_t> d_seginfo, d_seg_sbase, d_segcls;  // (d_segcls: the classes alone, [tile][row] two bits each)
+    uint32_t cls_stride = 0;
     DevBuf<unsigned long long> d_seg_dbits, d_seg_sbits;
     uint32_t seg_blocks = 0;  // > 0: kmer_extract uses the bit tables (many tiles)
     DevBuf<uint16_t> d_segslots;

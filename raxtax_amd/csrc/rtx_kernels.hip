@@ -233,8 +233,9 @@ __global__ __launch_bounds__(64) void kmer_extract_kernel(KmerParams p) {
             row[u] = kEmptyRow;
             ll[u] = 0;
             if (kk[u] != 0xFFFFFFFFu) {
-                row[u] = p.row_of[kk[u]];
-                ll[u] = p.list_len[kk[u]];
+                const uint2 rl = p.row_len[kk[u]];  // {row, posting-list length}: one gather
+                row[u] = rl.x;
+                ll[u] = rl.y;
             }
         }
 #pragma unroll
@@ -265,8 +266,8 @@ __global__ __launch_bounds__(64) void kmer_extract_kernel(KmerParams p) {
     uint32_t nseg = 0;
     __shared__ unsigned long long l_sb[64];
     __shared__ uint32_t l_base[64];
-    // Tile pruning left this query's pair a handful of tiles: one pass per live tile over the class table [row][tile] (a gather
-    // per 64 rows) instead of the bit tables and their transposes, which cost the same however few tiles are wanted.
+    // Tile pruning left this query's pair a handful of tiles: one pass per live tile over the tile's class table (two bits per row)
+    // instead of the bit tables and their transposes, which cost the same however few tiles are wanted.
     bool few_done = false;
     if (live && p.seg_blocks) {
         const uint32_t lw = (nt + 31u) >> 5;
@@ -281,33 +282,47 @@ __global__ __launch_bounds__(64) void kmer_extract_kernel(KmerParams p) {
                     if (tile >= nt) break;
                     uint32_t cd = 0, cs = 0;  // wave-uniform
                     for (uint32_t c0 = 0; c0 < nchunks; c0 += 4) {
-                        uint32_t row[4], code[4];
+                        uint32_t row[4], cls[4];
 #pragma unroll
                         for (int u = 0; u < 4; u++) {
                             const uint32_t i = (c0 + (uint32_t)u) * 64 + lane;
                             row[u] = i < nrows ? rout[i] : kEmptyRow;
                         }
 #pragma unroll
-                        for (int u = 0; u < 4; u++) {
-                            code[u] = p.seginfo[(size_t)(row[u] == kEmptyRow ? 0u : row[u]) * p.seg_stride + tile];
-                            if (row[u] == kEmptyRow) code[u] = 0u;
+                        for (int u = 0; u < 4; u++) {  // two bits per row from the tile's own table (16 KB: L1 / L2)
+                            const uint32_t r = row[u] == kEmptyRow ? 0u : row[u];
+                            cls[u] = (p.segcls[(size_t)tile * p.cls_stride + (r >> 4)] >> ((r & 15u) * 2u)) & 3u;
+                            if (row[u] == kEmptyRow) cls[u] = 0u;
                         }
+                        // as in the pass per tile below: the rows taken from a chunk are a prefix of its sparse candidates.  Their slots
+                        // come from seginfo -- a gather for the few lanes that hold one (at most kSegMaxSparseRows per tile), the four
+                        // chunks' together
+                        uint32_t srank[4], slot[4];
+                        bool take[4];
 #pragma unroll
                         for (int u = 0; u < 4; u++) {
                             const uint32_t c = c0 + (uint32_t)u;
-                            if (c >= nchunks) break;
-                            const bool sparse = code[u] >= 2u;
-                            // as in the pass per tile below: the rows taken from a chunk are a prefix of its sparse candidates
+                            take[u] = false;
+                            srank[u] = 0u;
+                            if (c >= nchunks) continue;  // wave-uniform
+                            const bool sparse = cls[u] == 2u;
                             const unsigned long long ms = __ballot(sparse);
-                            const uint32_t srank = cs + (uint32_t)__popcll(ms & lt_mask);
-                            const bool take = sparse && srank < kSegMaxSparseRows;
-                            if (take) sout[(size_t)tile * (kSegMaxSparseRows + 1) + srank] = code[u] - 2u;
-                            const unsigned long long bt = __ballot(take);
-                            const unsigned long long md = __ballot(code[u] == 1u || (sparse && !take));
+                            srank[u] = cs + (uint32_t)__popcll(ms & lt_mask);
+                            take[u] = sparse && srank[u] < kSegMaxSparseRows;
+                            const unsigned long long bt = __ballot(take[u]);
+                            const unsigned long long md = __ballot(cls[u] == 1u || (sparse && !take[u]));
                             if (lane == 0) dm[(size_t)tile * mstride + c] = md;
                             cd += (uint32_t)__popcll(md);
                             cs += (uint32_t)__popcll(bt);
                         }
+#pragma unroll
+                        for (int u = 0; u < 4; u++) {
+                            slot[u] = 0u;
+                            if (take[u]) slot[u] = p.seginfo[(size_t)row[u] * p.seg_stride + tile] - 2u;
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; u++)
+                            if (take[u]) sout[(size_t)tile * (kSegMaxSparseRows + 1) + srank[u]] = slot[u];
                     }
                     if (lane == 0) {
                         p.nsparse[(size_t)q * nt + tile] = cs;
@@ -1340,6 +1355,13 @@ void launch_ref_bitmap_set(hipStream_t s, const uint8_t *bases, const uint64_t *
 void launch_row_popcount(hipStream_t s, const uint32_t *row_of, const uint32_t *bitmap, uint32_t stride_words, uint32_t n_rows1,
                          uint32_t *list_len) {
     hipLaunchKernelGGL(row_popcount_kernel, dim3(RTX_NUM_KMERS), dim3(256), 0, s, row_of, bitmap, stride_words, n_rows1, list_len);
+}
+__global__ __launch_bounds__(256) void row_len_pack_kernel(const uint32_t *__restrict__ row_of, const uint32_t *__restrict__ list_len, uint2 *__restrict__ out) {
+    const uint32_t k = blockIdx.x * 256u + threadIdx.x;
+    out[k] = make_uint2(row_of[k], list_len[k]);
+}
+void launch_row_len_pack(hipStream_t s, const uint32_t *row_of, const uint32_t *list_len, uint2 *out) {
+    hipLaunchKernelGGL(row_len_pack_kernel, dim3(RTX_NUM_KMERS / 256), dim3(256), 0, s, row_of, list_len, out);
 }
 void launch_kmer_extract(hipStream_t s, const KmerParams &p, uint32_t nq) {
     if (p.mode == 2u) hipLaunchKernelGGL(kmer_extract_kernel<true>, dim3(nq), dim3(64), 0, s, p);

@@ -79,6 +79,7 @@ struct KmerParams {
     const uint32_t *perm;      // [n_q] query at every position (rtx_cluster.hip); per-query outputs are by position
     const uint32_t *row_of;    // [65536] bitmap row of a k-mer or 0xFFFFFFFF
     const uint32_t *list_len;  // [65536] posting-list length
+    const uint2 *row_len;      // [65536] {row_of, list_len}: what kmer_extract gathers per k-mer
     uint32_t zero_row;
     uint16_t *kmers;  // [B][kstride]
     uint32_t kstride;
@@ -90,6 +91,10 @@ struct KmerParams {
     const unsigned long long *seg_dbits, *seg_sbits;  // [n_rows+1][seg_blocks]
     const uint32_t *seg_sbase;                        // [n_rows+1][seg_blocks]
     uint32_t seg_blocks;                              // ceil(ntiles / 64); 0 = use seginfo
+    // the classes alone, tile by tile, two bits per row (0 empty, 1 dense, 2 sparse): the lists of the few tiles that tile pruning leaves
+    // a query are built from 16 KB per tile that stay in L1 / L2 (a gather from seginfo pulled one line per row: 0.77 G lines per 1 M queries)
+    const uint32_t *segcls;                           // [ntiles][cls_stride]
+    uint32_t cls_stride;                              // ceil((n_rows + 1) / 16)
     uint32_t *rows;     // [B][rstride] rows of the query's k-mers (ascending), padded with the zero row to a multiple of 64
     uint32_t rstride;
     unsigned long long *dmask;  // [B][ntiles][rstride/64] per tile: which of those rows have a dense segment there
@@ -287,6 +292,7 @@ void launch_bitmap_build(hipStream_t s, const uint64_t *off, const uint32_t *pos
 void launch_ref_kmer_mark(hipStream_t s, const uint8_t *bases, const uint64_t *off, uint64_t n_refs, uint32_t *present);
 void launch_ref_bitmap_set(hipStream_t s, const uint8_t *bases, const uint64_t *off, uint64_t n_refs,
                            const uint32_t *row_of, uint32_t *bitmap, uint32_t stride_words, uint32_t n_rows1, uint32_t shift = 0);
+void launch_row_len_pack(hipStream_t s, const uint32_t *row_of, const uint32_t *list_len, uint2 *out);
 void launch_row_popcount(hipStream_t s, const uint32_t *row_of, const uint32_t *bitmap, uint32_t stride_words, uint32_t n_rows1,
                          uint32_t *list_len);
 void launch_kmer_extract(hipStream_t s, const KmerParams &p, uint32_t nq);

@@ -133,7 +133,7 @@ __global__ __launch_bounds__(256) void loc_finish_kernel(uint32_t *__restrict__ 
 // Locator of a query: one wave per query.
 //   1. lane l rolls over the windows [l * wpl, (l + 1) * wpl) of the first kLocWin windows (their wpl + 11 bases in one round trip,
 //      as sketch_kernel) and leaves their 12-mer codes in LDS;
-//   2. lane l looks up the windows l, l + 64, ... (coalesced codes, four table loads in flight), keeps the positions in
+//   2. lane l looks up the windows 2 l, 2 (l + 64), ... (kLocStride; four table loads in flight), keeps the positions in
 //      LDS and votes for coarse bins of 2^bin_shift references.  Most lanes vote for the SAME bin -- that is the point --
 //      and LDS atomics on one address are served lane by lane (about 100 cycles for 64 of them): the lanes that agree
 //      with the first voter are counted with a ballot and added by one lane, two such rounds, the rest votes alone;
@@ -145,6 +145,12 @@ __global__ __launch_bounds__(256) void loc_finish_kernel(uint32_t *__restrict__ 
 static constexpr uint32_t kLocMaxBins = 8192;    // coarse bins (LDS: 16 KiB)
 static constexpr uint32_t kLocFineDiv = 16;      // fine bins per coarse bin
 static constexpr uint32_t kLocWin = 1024;        // windows of a query that vote
+#ifndef RTX_LOC_STRIDE
+#define RTX_LOC_STRIDE 2
+#endif
+// ... every kLocStride-th of them.  A look-up is a random word of a 64 MB table; at configs[2] every window / every second / every third:
+// order stage 5.55 / 3.57 / 3.22 ms per 1 M queries, the stages that live on the order (bounds + counting) 42.5 / 42.85 / 43.5 ms.
+static constexpr uint32_t kLocStride = RTX_LOC_STRIDE;
 
 // one vote per lane with `valid` for bin b: lanes that agree with the first pending voter are added by one atomic
 __device__ __forceinline__ void vote_bins(uint32_t *h, uint32_t b, bool valid, uint32_t lane) {
@@ -199,21 +205,26 @@ __global__ __launch_bounds__(64) void locator_kernel(const uint8_t *__restrict__
     __builtin_amdgcn_wave_barrier();
     // 2. look-ups and the coarse vote, four windows per lane and turn (all sixteen of a lane at once: 0.3 ms per 1 M queries slower)
     uint32_t any = 0;
-    for (uint32_t w0 = 0; w0 < nwin; w0 += 256) {
+    const uint32_t nlook = (nwin + kLocStride - 1u) / kLocStride;  // every kLocStride-th window votes
+    for (uint32_t j0 = 0; j0 < nlook; j0 += 256) {
         uint32_t pos[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-            const uint32_t w = w0 + (uint32_t)u * 64u + lane;
-            const uint32_t code = w < nwin ? lcode[w] : kLocNone;
+            const uint32_t j = j0 + (uint32_t)u * 64u + lane;
+            const uint32_t code = j < nlook ? lcode[j * kLocStride] : kLocNone;
             pos[u] = table[code == kLocNone ? 0u : code];  // unconditional: the four loads leave together
             if (code == kLocNone) pos[u] = kLocNone;
         }
+        if (kLocStride > 1u) {  // the positions go where the codes were: every code of this turn has been read by then
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-            const uint32_t w = w0 + (uint32_t)u * 64u + lane;
+            const uint32_t j = j0 + (uint32_t)u * 64u + lane;
             const bool valid = pos[u] != kLocNone;
             vote_bins(h, pos[u] >> bin_shift, valid, lane);
-            if (w < nwin) lcode[w] = pos[u];
+            if (j < nlook) lcode[j] = pos[u];
             any |= valid ? 1u : 0u;
         }
     }
@@ -236,9 +247,9 @@ __global__ __launch_bounds__(64) void locator_kernel(const uint8_t *__restrict__
     uint32_t fine = 0;
     if (bin_shift >= 4u) {
         const uint32_t fshift = bin_shift - 4u;  // fine bins of 2^bin_shift / 16 references over [lo, lo + 2 * 2^bin_shift)
-        for (uint32_t w0 = 0; w0 < nwin; w0 += 64) {  // wave-uniform trip count (vote_bins works with ballots)
+        for (uint32_t w0 = 0; w0 < nlook; w0 += 64) {  // wave-uniform trip count (vote_bins works with ballots)
             const uint32_t w = w0 + lane;
-            const uint32_t p = w < nwin ? lcode[w] : kLocNone;
+            const uint32_t p = w < nlook ? lcode[w] : kLocNone;
             const bool in = p != kLocNone && p >= lo && ((p - lo) >> bin_shift) < 2u;
             vote_bins(hf, in ? (p - lo) >> fshift : 0u, in, lane);
         }

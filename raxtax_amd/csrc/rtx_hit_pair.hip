@@ -9,7 +9,7 @@
 //
 //   pair_union_kernel   once per sub-batch and pair: the union of the two row lists in ascending row order, every
 //                       entry with its position in the list of A and / or B (the dense masks of kmer_extract are
-//                       indexed by those positions)
+//                       indexed by those positions); ranks by binary search in LDS
 //   prologue            per tile: the union entries whose segment is dense in this tile, split into three lists in
 //                       LDS: rows of both queries, of A only, of B only
 //   row loop            groups of 32 rows, four buffers of eight in flight; the shared rows are folded first, into ONE
@@ -37,66 +37,77 @@ constexpr int kPairNB = 4;                            // buffers of eight rows p
 // ---------------------------------------------------------------------------
 // Union of the row lists of the queries 2 * pair and 2 * pair + 1 of a sub-batch (ascending row ids, as kmer_extract
 // leaves them).  Entry = {row | inA << 30 | inB << 31, posA | posB << 16} (0xFFFF: not in that list).
-// One wave per pair; two bit sets in LDS (the rows of A, of B), read out in order with a prefix scan.
+// One wave per pair.  Both lists are sorted and free of repeats, so the place of an element in the union follows from ranks alone:
+//   a = A[i]:           i + rank_B(a) - (common elements below a)      rank_B(a) = elements of B below a (binary search in LDS)
+//   b = B[j] not in A:  j + rank_A(b) - (common elements below b)
+// and the common elements below are a running count over the list's own order (ballots).  Eleven dependent LDS reads per 64 elements --
+// until round 4 the kernel scattered both lists into two 64 K-bit sets and read them out word by word (82 k cycles per pair, 4.15 ms
+// per 1 M queries).  At most 1024 rows per list (the pair kernel runs with t <= 1023).
 // ---------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t lower_bound_u16(const uint16_t *l, uint32_t n, uint32_t key) {  // elements of l[0 .. n) below key; n <= 1024
+    uint32_t lo = 0;
+#pragma unroll
+    for (uint32_t step = 1024u; step >= 1u; step >>= 1) {  // lo + step - 1 < n and l[lo + step - 1] < key: the first lo + step are below
+        const uint32_t probe = lo + step;
+        const uint32_t v = probe <= n ? (uint32_t)l[probe - 1u] : 0xFFFFFFFFu;
+        lo = v < key ? probe : lo;
+    }
+    return lo;
+}
+
 __global__ __launch_bounds__(64) void pair_union_kernel(const uint32_t *__restrict__ rows, const uint32_t *__restrict__ nrows,
                                                         uint32_t rstride, uint32_t nq, uint2 *__restrict__ urec,
                                                         uint32_t *__restrict__ nu, uint32_t ustride) {
-    // half of the row range at a time (8 KB of LDS per wave instead of 16: twenty waves per CU instead of ten)
-    __shared__ __attribute__((aligned(16))) unsigned long long bits[2][512];
+    __shared__ uint16_t la[1024], lb[1024];
     const uint32_t pair = blockIdx.x, lane = threadIdx.x;
     const uint32_t qa = pair * 2u, qb = qa + 1u;
-    const uint32_t na = nrows[qa], nb = qb < nq ? nrows[qb] : 0u;
+    uint32_t na = nrows[qa], nb = qb < nq ? nrows[qb] : 0u;
+    na = na < 1024u ? na : 1024u;  // (never more: t <= 1023)
+    nb = nb < 1024u ? nb : 1024u;
     const uint32_t *ra = rows + (size_t)qa * rstride, *rb = rows + (size_t)(qb < nq ? qb : qa) * rstride;
-    const uint32_t nmax = na > nb ? na : nb;
     uint2 *out = urec + (size_t)pair * ustride;
-    uint32_t n_u = 0, n_a = 0, n_b = 0;  // wave-uniform running totals
-    uint32_t *bits32 = reinterpret_cast<uint32_t *>(&bits[0][0]);
-    for (uint32_t h = 0; h < 2u; h++) {
-        for (uint32_t i = lane; i < 512u; i += 64) reinterpret_cast<uint4 *>(&bits[0][0])[i] = make_uint4(0u, 0u, 0u, 0u);
-        wave_lds_sync();
-        for (uint32_t i0 = 0; i0 < nmax; i0 += 256) {  // four chunks of each list per turn: the eight loads leave together
-            uint32_t va[4], vb[4];
+    const uint32_t nmax = na > nb ? na : nb;
+    for (uint32_t i0 = 0; i0 < nmax; i0 += 256) {  // four chunks of each list per turn: the eight loads leave together
+        uint32_t va[4], vb[4];
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const uint32_t i = i0 + (uint32_t)k * 64u + lane;
-                va[k] = i < na ? ra[i] & 0xFFFFu : 0xFFFFFFFFu;
-                vb[k] = i < nb ? rb[i] & 0xFFFFu : 0xFFFFFFFFu;
-            }
+        for (int k = 0; k < 4; k++) {
+            const uint32_t i = i0 + (uint32_t)k * 64u + lane;
+            va[k] = i < na ? ra[i] : 0u;
+            vb[k] = i < nb ? rb[i] : 0u;
+        }
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                if ((va[k] >> 15) == h) atomicOr(&bits32[(va[k] & 32767u) >> 5], 1u << (va[k] & 31u));
-                if ((vb[k] >> 15) == h) atomicOr(&bits32[1024u + ((vb[k] & 32767u) >> 5)], 1u << (vb[k] & 31u));
-            }
+        for (int k = 0; k < 4; k++) {
+            const uint32_t i = i0 + (uint32_t)k * 64u + lane;
+            if (i < na) la[i] = (uint16_t)va[k];
+            if (i < nb) lb[i] = (uint16_t)vb[k];
         }
-        wave_lds_sync();
-        for (uint32_t w0 = 0; w0 < 512u; w0 += 64) {  // eight turns of 64 x 64 rows
-            const unsigned long long a = bits[0][w0 + lane], b = bits[1][w0 + lane];
-            unsigned long long u = a | b;
-            if (__ballot(u != 0ull) == 0ull) continue;
-            // exclusive prefix over the lanes of the three counts (each below 2^11 in total: packed 11 + 11 bits and one apart); DPP scans
-            // (the shuffle version -- twelve ds_bpermute round trips per 64 words -- was most of the kernel)
-            uint32_t su = (uint32_t)__popcll(u), sab = (uint32_t)__popcll(a) | ((uint32_t)__popcll(b) << 16);
-            const uint32_t iu = wave_incl_scan_u32(su), iab = wave_incl_scan_u32(sab);
-            uint32_t pu = n_u + iu - su, pa = n_a + (iab & 0xFFFFu) - (sab & 0xFFFFu), pb = n_b + (iab >> 16) - (sab >> 16);
-            while (u) {
-                const uint32_t bit = (uint32_t)__builtin_ctzll(u);
-                u &= u - 1ull;
-                const uint32_t ina = (uint32_t)(a >> bit) & 1u, inb = (uint32_t)(b >> bit) & 1u;
-                out[pu] = make_uint2((h * 32768u + (w0 + lane) * 64u + bit) | (ina << 30) | (inb << 31),
-                                     (ina ? pa : 0xFFFFu) | ((inb ? pb : 0xFFFFu) << 16));
-                pu++;
-                pa += ina;
-                pb += inb;
-            }
-            n_u += (uint32_t)__builtin_amdgcn_readlane((int)iu, 63);
-            const uint32_t tab = (uint32_t)__builtin_amdgcn_readlane((int)iab, 63);
-            n_a += tab & 0xFFFFu;
-            n_b += tab >> 16;
-        }
-        wave_lds_sync();  // the sets are zeroed again
     }
-    if (lane == 0) nu[pair] = n_u;
+    wave_lds_sync();
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    uint32_t common = 0;  // wave-uniform: common elements in front of the chunk
+    for (uint32_t i0 = 0; i0 < na; i0 += 64) {
+        const uint32_t i = i0 + lane;
+        const bool in = i < na;
+        const uint32_t a = in ? (uint32_t)la[i] : 0xFFFFu;
+        const uint32_t rk = lower_bound_u16(lb, nb, a);
+        const bool eq = in && rk < nb && (uint32_t)lb[rk < nb ? rk : 0u] == a;
+        const unsigned long long be = __ballot(eq);
+        if (in) out[i + rk - (common + (uint32_t)__popcll(be & lt_mask))] = make_uint2(a | (1u << 30) | ((uint32_t)eq << 31), i | ((eq ? rk : 0xFFFFu) << 16));
+        common += (uint32_t)__popcll(be);
+    }
+    const uint32_t n_common = common;
+    common = 0;
+    for (uint32_t j0 = 0; j0 < nb; j0 += 64) {
+        const uint32_t j = j0 + lane;
+        const bool in = j < nb;
+        const uint32_t bv = in ? (uint32_t)lb[j] : 0xFFFFu;
+        const uint32_t rk = lower_bound_u16(la, na, bv);
+        const bool eq = in && rk < na && (uint32_t)la[rk < na ? rk : 0u] == bv;
+        const unsigned long long be = __ballot(eq);
+        if (in && !eq) out[j + rk - (common + (uint32_t)__popcll(be & lt_mask))] = make_uint2(bv | (1u << 31), 0xFFFFu | (j << 16));
+        common += (uint32_t)__popcll(be);
+    }
+    if (lane == 0) nu[pair] = na + nb - n_common;
 }
 
 // One segment of the row loop: `ng` groups of 32 rows of `list`, folded into both plane sets (MODE 0), A's (1) or B's (2).

@@ -483,3 +483,13 @@ def raxtax(queries: Sequence[Tuple[str, np.ndarray]], tree, skip_exact_matches: 
     if err:
         raise err[0]
     check(rc)
+
+
+def raxtax_last_timing() -> Tuple[List[float], int]:
+    """rtx_raxtax_last_timing: busy seconds of the pipeline stages (host lookup, device, format, sender) and the number of chunks of the
+    last rtx_raxtax / rtx_raxtax_multi call of this process."""
+    lib = _lib.load()
+    busy = (C.c_double * 4)()
+    n_chunks = C.c_uint64(0)
+    check(lib.rtx_raxtax_last_timing(busy, C.byref(n_chunks)))
+    return [float(b) for b in busy], int(n_chunks.value)

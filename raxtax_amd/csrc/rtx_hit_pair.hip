@@ -84,29 +84,21 @@ __global__ __launch_bounds__(64) void pair_union_kernel(const uint32_t *__restri
     }
     wave_lds_sync();
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    uint32_t common = 0;  // wave-uniform: common elements in front of the chunk
-    for (uint32_t i0 = 0; i0 < na; i0 += 64) {
+    uint32_t ca = 0, cb = 0;  // wave-uniform: common elements in front of the chunk, in the order of A / of B
+    for (uint32_t i0 = 0; i0 < nmax; i0 += 64) {  // a chunk of A and a chunk of B per turn: two independent chains of LDS reads
         const uint32_t i = i0 + lane;
-        const bool in = i < na;
-        const uint32_t a = in ? (uint32_t)la[i] : 0xFFFFu;
-        const uint32_t rk = lower_bound_u16(lb, nb, a);
-        const bool eq = in && rk < nb && (uint32_t)lb[rk < nb ? rk : 0u] == a;
-        const unsigned long long be = __ballot(eq);
-        if (in) out[i + rk - (common + (uint32_t)__popcll(be & lt_mask))] = make_uint2(a | (1u << 30) | ((uint32_t)eq << 31), i | ((eq ? rk : 0xFFFFu) << 16));
-        common += (uint32_t)__popcll(be);
+        const bool in_a = i < na, in_b = i < nb;
+        const uint32_t a = in_a ? (uint32_t)la[i] : 0xFFFFu, bv = in_b ? (uint32_t)lb[i] : 0xFFFFu;
+        const uint32_t rka = lower_bound_u16(lb, nb, a), rkb = lower_bound_u16(la, na, bv);
+        const bool eqa = in_a && rka < nb && (uint32_t)lb[rka < nb ? rka : 0u] == a;
+        const bool eqb = in_b && rkb < na && (uint32_t)la[rkb < na ? rkb : 0u] == bv;
+        const unsigned long long bea = __ballot(eqa), beb = __ballot(eqb);
+        if (in_a) out[i + rka - (ca + (uint32_t)__popcll(bea & lt_mask))] = make_uint2(a | (1u << 30) | ((uint32_t)eqa << 31), i | ((eqa ? rka : 0xFFFFu) << 16));
+        if (in_b && !eqb) out[i + rkb - (cb + (uint32_t)__popcll(beb & lt_mask))] = make_uint2(bv | (1u << 31), 0xFFFFu | (i << 16));
+        ca += (uint32_t)__popcll(bea);
+        cb += (uint32_t)__popcll(beb);
     }
-    const uint32_t n_common = common;
-    common = 0;
-    for (uint32_t j0 = 0; j0 < nb; j0 += 64) {
-        const uint32_t j = j0 + lane;
-        const bool in = j < nb;
-        const uint32_t bv = in ? (uint32_t)lb[j] : 0xFFFFu;
-        const uint32_t rk = lower_bound_u16(la, na, bv);
-        const bool eq = in && rk < na && (uint32_t)la[rk < na ? rk : 0u] == bv;
-        const unsigned long long be = __ballot(eq);
-        if (in && !eq) out[j + rk - (common + (uint32_t)__popcll(be & lt_mask))] = make_uint2(bv | (1u << 31), 0xFFFFu | (j << 16));
-        common += (uint32_t)__popcll(be);
-    }
+    const uint32_t n_common = ca;
     if (lane == 0) nu[pair] = na + nb - n_common;
 }
 

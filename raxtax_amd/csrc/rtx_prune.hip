@@ -77,7 +77,6 @@ __device__ __forceinline__ uint32_t wave_max_u32p(uint32_t v) { return wave_max_
 // Four waves per workgroup, one pair of queries per wave.  The kernel is bound by the instructions it issues (round 4 counters: every wave
 // active 24 % of its cycles at four waves per SIMD), and every evaluation of a pmf reads six entries of the ln x! table: the workgroup
 // stages the part of the table the batch can reach (t + n - 1 <= 1.5 tmax: 12 KB at t <= 1023) in LDS once, for its eight queries.
-// (RTX_PRUNE_PROFILE: a build for tools/prune_phase_probe.py -- the counters of p.stats carry shader-clock cycles per phase instead.)
 __global__ __launch_bounds__(64 * kPruneWavesPerBlock, RTX_PRUNE_WAVES) void prune_kernel(PruneParams p, ProbTables tb) {
     extern __shared__ double prune_lds[];  // [nlf] ln x!; then per wave [2][ntiles] u16: the bounds of the tiles for the pair's queries
     for (uint32_t i = threadIdx.x; i < p.nlf; i += 64u * kPruneWavesPerBlock) prune_lds[i] = p.lnfact[i];
@@ -94,9 +93,6 @@ __global__ __launch_bounds__(64 * kPruneWavesPerBlock, RTX_PRUNE_WAVES) void pru
     for (uint32_t x = 0; x < 2u; x++) {
         if (x == 1u && !has_b) break;  // wave-uniform
         const uint32_t q = pair * 2u + x;
-#ifdef RTX_PRUNE_PROFILE
-        long long pt0 = clock64(), pt1 = pt0, pt2 = pt0, pt3 = pt0, pt4 = pt0;
-#endif
         // ---- 1. bound of every tile, and the block with the largest bound (the lowest one among equals; block 0 if every bound is 0):
         // left by the epilogue of the bounds pass (bounds_epilogue, rtx_hit_common.hpp)
         for (uint32_t T = lane; T < p.ntiles; T += 64) ub_lds[x * p.ntiles + T] = p.tile_ub[(size_t)q * p.tile_ub_stride + T];
@@ -194,9 +190,6 @@ __global__ __launch_bounds__(64 * kPruneWavesPerBlock, RTX_PRUNE_WAVES) void pru
                 M = wave_max_u32p(hm);
             }
         }
-#ifdef RTX_PRUNE_PROFILE
-        pt1 = pt2 = pt3 = pt4 = clock64();
-#endif
         if (p.detail) p.detail[(size_t)q * kPruneDetailWords + 8u + lane] = hm;  // debug tap: the exact counts of the best block's references
         if (p.phase == 1u) {  // a reference shard, first half: its candidate for the best block of the database
             uint32_t *bq = p.best + (size_t)q * kPruneBestWords;
@@ -266,9 +259,6 @@ __global__ __launch_bounds__(64 * kPruneWavesPerBlock, RTX_PRUNE_WAVES) void pru
                     ist1 = lo + 1u;
                 }
                 ist_prev = ist1;
-#ifdef RTX_PRUNE_PROFILE
-                pt2 = pt3 = pt4 = clock64();
-#endif
                 if (ist1) {
                     const uint32_t i1 = ist1;  // = i* + 1: the first i that stays
                     const double ln_len = log((double)(n - i1 + 1u));
@@ -283,9 +273,6 @@ __global__ __launch_bounds__(64 * kPruneWavesPerBlock, RTX_PRUNE_WAVES) void pru
                     first_fail = 0xFFFFFFFFu - wave_max_u32p(0xFFFFFFFFu - first_fail);
                     u_max = first_fail - 1u;
                     i1_q = i1;
-#ifdef RTX_PRUNE_PROFILE
-                    pt3 = pt4 = clock64();
-#endif
                     // ---- the tighter criterion (header, "(3)"): the same two error terms, but every i weighted with what G leaves of
                     // it.  Lanes 0 .. 62 <-> the window i = i1 .. i1 + 62; lane 63 <-> the point behind it, j = i1 + 63, which stands for
                     // the whole tail of pmf_u from there on ((n - j + 1) pmf_u(j) once pmf_u falls; G counts as 1 out there).  With
@@ -389,9 +376,6 @@ __global__ __launch_bounds__(64 * kPruneWavesPerBlock, RTX_PRUNE_WAVES) void pru
                             return falling && wave_sum_f64_dpp(near ? gnd * (dead ? gsa : a) : 0.0) + n_far * far_a <= kPruneHalfEps &&
                                    wave_sum_f64_dpp(near ? gnd * (dead ? gsb : b) : 0.0) + n_far * far_b <= kPruneHalfEps;
                         };
-#ifdef RTX_PRUNE_PROFILE
-                        pt4 = clock64();
-#endif
                         uint32_t lo = u_max, hi = h_min - 1u;
                         while (lo < hi) {  // wave-uniform
                             const uint32_t mid = (lo + hi + 1u) >> 1;
@@ -409,12 +393,8 @@ __global__ __launch_bounds__(64 * kPruneWavesPerBlock, RTX_PRUNE_WAVES) void pru
             d[0] = bb; d[1] = M; d[2] = u_max; d[3] = u_max ? i1_q : 0u; d[4] = ub_best; d[5] = t; d[6] = 0u; d[7] = 0u;
         }
         // reporting: sums of the lower bound of the best hit, of the threshold, of the largest tile bound
-#ifdef RTX_PRUNE_PROFILE
-        { const long long pt5 = clock64(); st[2] += pt1 - pt0; st[3] += pt2 - pt1; st[4] += pt3 - pt2; st[6] += pt4 - pt3; st[7] += pt5 - pt4; st[5] += 1ull; }
-#else
         st[2] += M; st[3] += u_max; st[4] += ub_best; st[5] += 1ull;
-        if (ub_best < M) st[6] += 1ull;
-#endif  // must never happen: a block's bound below one of its references' counts
+        if (ub_best < M) st[6] += 1ull;  // must never happen: a block's bound below one of its references' counts
     }
     if (p.phase == 1u) return;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -457,9 +437,7 @@ __global__ __launch_bounds__(64 * kPruneWavesPerBlock, RTX_PRUNE_WAVES) void pru
         if (has_b) p.hist[(size_t)(pair * 2u + 1u) * p.hstride] = (uint32_t)dead_refs[1];
     }
     if (lane == 0 && p.pair_live) p.pair_live[pair] = n_live;
-#ifndef RTX_PRUNE_PROFILE
     st[7] = n_qlive;  // (query, tile) combinations that are counted
-#endif
     if (p.stats) {  // one atomic instruction per wave (lane k adds counter k), 64 copies of the counters in lines of their own:
                     // thousands of waves adding to ONE address queue up in L2 for longer than everything else here takes
         st[0] = n_live; st[1] = 1ull;

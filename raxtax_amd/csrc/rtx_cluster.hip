@@ -171,7 +171,7 @@ __global__ __launch_bounds__(64) void locator_kernel(const uint8_t *__restrict__
                                                      const uint32_t *__restrict__ table, uint32_t bin_shift, uint32_t n_bins,
                                                      uint64_t *__restrict__ keys) {
     extern __shared__ __attribute__((aligned(16))) uint32_t h[];  // n_bins / 2 + 2 words (rounded up to four): the coarse bins as u16 pairs
-    __shared__ uint32_t lcode[kLocWin];        // 12-mer codes, then the positions found for them
+    __shared__ uint32_t lcode[kLocWin / kLocStride];  // 12-mer codes of the windows that vote, then the positions found for them
     __shared__ uint32_t hf[kLocFineDiv + 2];   // 2 * kLocFineDiv + 1 fine bins as u16 pairs
     const uint32_t q = blockIdx.x, lane = threadIdx.x;
     const uint64_t b0 = off[q], len = off[q + 1] - b0;
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(64) void locator_kernel(const uint8_t *__restrict__
     {   // 1. codes of this lane's run of windows (at most 16: nwin <= kLocWin): its 27 bases as four unaligned 8-byte words, as sketch_kernel
         const uint32_t wpl = (nwin + 63u) / 64u;
         const uint32_t w0 = lane * wpl, w1 = w0 + wpl < nwin ? w0 + wpl : nwin;
-        static_assert(kLocWin <= 1024u, "a lane's run of windows fits one piece of 16");
+        static_assert(kLocWin <= 1024u && kLocWin % kLocStride == 0u, "a lane's run of windows fits one piece of 16");
         if (w0 < w1) {
             unsigned long long v[4];
             __builtin_memcpy(v, seq + w0, 32);
@@ -197,7 +197,10 @@ __global__ __launch_bounds__(64) void locator_kernel(const uint8_t *__restrict__
                 const bool ok = base_code((uint32_t)(v[b >> 3] >> ((b & 7) * 8)) & 0xFFu, two);
                 code = ((code << 2) | two) & 0xFFFFFFu;
                 run = ok ? run + 1u : 0u;
-                if (b >= kSketchK - 1 && (uint32_t)(b - (kSketchK - 1)) < nw) lcode[w0 + (uint32_t)(b - (kSketchK - 1))] = run >= (uint32_t)kSketchK ? code : kLocNone;
+                if (b >= kSketchK - 1 && (uint32_t)(b - (kSketchK - 1)) < nw) {
+                    const uint32_t w = w0 + (uint32_t)(b - (kSketchK - 1));
+                    if (w % kLocStride == 0u) lcode[w / kLocStride] = run >= (uint32_t)kSketchK ? code : kLocNone;
+                }
             }
         }
     }
@@ -211,13 +214,9 @@ __global__ __launch_bounds__(64) void locator_kernel(const uint8_t *__restrict__
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const uint32_t j = j0 + (uint32_t)u * 64u + lane;
-            const uint32_t code = j < nlook ? lcode[j * kLocStride] : kLocNone;
+            const uint32_t code = j < nlook ? lcode[j] : kLocNone;
             pos[u] = table[code == kLocNone ? 0u : code];  // unconditional: the four loads leave together
             if (code == kLocNone) pos[u] = kLocNone;
-        }
-        if (kLocStride > 1u) {  // the positions go where the codes were: every code of this turn has been read by then
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
         }
 #pragma unroll
         for (int u = 0; u < 4; u++) {

@@ -75,9 +75,12 @@ __device__ __forceinline__ double row_load_f64(const double *table, uint32_t off
 
 // ---------------------------------------------------------------------------
 // per-query lookup kernel: 256 threads (4 waves) per query
-// LDS (dynamic): Pi[n1max] f64 | red[16] f64 | Ppart[64] f64 | row_h[tmax+18] u32 | row_m, row_sat, ms [tmax+18] u16 each | hl[tmax+4] u32 | row_off, row_end [tmax+18] u32
+// LDS (dynamic): Pi[n1max] f64 | red[16] f64 | Ppart[64] f64 | tzl[tmax+2] f64 | row_h[tmax+18] u32 | row_m, row_sat, ms [tmax+18] u16 each | hl[tmax+4] u32 | row_off, row_end [tmax+18] u32
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void prob_lookup_kernel(ProbParams p, ProbTables tb) {
+#ifndef RTX_PROB_WAVES
+#define RTX_PROB_WAVES 6  // waves per SIMD (<= 80 VGPRs, no spills; the kernel is a chain of round trips: 10.9 / 10.2 / 9.1 / 9.1 ms per 1 M queries at 4 / 5 / 6 / 7 -- unbounded it takes 100 VGPRs and runs four)
+#endif
+__global__ __launch_bounds__(256, RTX_PROB_WAVES) void prob_lookup_kernel(ProbParams p, ProbTables tb) {
     extern __shared__ double smem[];
     __shared__ uint32_t s_D, s_nact;
     __shared__ uint32_t s_nlive[8];  // per 64-wide slice of i: rows [0, s_nlive) include every row not yet saturated there
@@ -90,7 +93,9 @@ __global__ __launch_bounds__(256) void prob_lookup_kernel(ProbParams p, ProbTabl
     double *Pi = smem;
     double *red = Pi + p.n1max;
     double *Ppart = red + 16;  // [64] second half of the row sum of the first slice (pass 1)
-    uint32_t *row_h = reinterpret_cast<uint32_t *>(Ppart + 64);
+    double *tzl = Ppart + 64;  // [tmax+2] table[m] until it has been divided by Z: written by several waves, summed by all -- in LDS, not
+                               // through global memory (the sum and the division each waited for a store-to-load round trip through L2)
+    uint32_t *row_h = reinterpret_cast<uint32_t *>(tzl + (p.tmax + 2));
     uint16_t *row_m = reinterpret_cast<uint16_t *>(row_h + (p.tmax + 18));
     uint16_t *row_sat = row_m + (p.tmax + 18);
     uint16_t *ms = row_sat + (p.tmax + 18);
@@ -101,11 +106,15 @@ __global__ __launch_bounds__(256) void prob_lookup_kernel(ProbParams p, ProbTabl
     double *tz = p.table_z + (size_t)q * p.hstride;
     const double *lf = p.lnfact;
 
+    {   // the histogram row, as far as a count can reach in this batch -- not "up to t": the loads then leave together with the load of t
+        // (kmer_extract zeroes the whole row; bins above t stay 0)
+        const uint32_t hlim = p.hstride < p.tmax + 4u ? p.hstride : p.tmax + 4u;
+        for (uint32_t m = tid; m < hlim; m += 256) hl[m] = hist[m];
+    }
     if (t == 0) {  // reference: u64 underflow at prob.rs:21
         if (tid == 0) { p.status[gq] = RTX_Q_NO_KMERS; p.z[gq] = 0.0; p.gs[gq] = 0.0; p.ndist[gq] = 0; }
         return;
     }
-    for (uint32_t m = tid; m <= t; m += 256) hl[m] = hist[m];  // one coalesced round instead of a chain of loads
     __syncthreads();
     // Tile pruning gave the query a threshold u: the references with a count up to u hold less than eps = 1e-10 of probability
     // together and move no product by more than that (rtx_prune.hip).  They all become references without a hit (cmf = 1,
@@ -140,7 +149,7 @@ __global__ __launch_bounds__(256) void prob_lookup_kernel(ProbParams p, ProbTabl
     if (M == t) {  // prob.rs:24-41
         for (uint32_t j = tid; j < D; j += 256) {
             const uint32_t m = ms[j];
-            tz[m] = only_last_pmf_tab(lf, t, n, m, ln_total);
+            tzl[m] = only_last_pmf_tab(lf, t, n, m, ln_total);
         }
     } else {
         if (n == 0) {  // reference: zip_eq length mismatch at prob.rs:162
@@ -171,7 +180,7 @@ __global__ __launch_bounds__(256) void prob_lookup_kernel(ProbParams p, ProbTabl
                 if (j < D) {
                     m = ms[D - 1 - j];
                     sat = row_h[j];
-                    if (m && sat <= i_lo) tz[m] = 0.0;
+                    if (m && sat <= i_lo) tzl[m] = 0.0;
                 }
                 const bool keep = m != 0 && sat > i_lo;
                 const unsigned long long bal = __ballot(keep);
@@ -282,17 +291,17 @@ __global__ __launch_bounds__(256) void prob_lookup_kernel(ProbParams p, ProbTabl
             const double v = wave_sum8_f64(acc);  // lane l: total of row r0 + (l & 7)
             if (lane < 8) {
                 const uint32_t m = row_m[r0 + lane];
-                if (m != 0) tz[m] = v;
+                if (m != 0) tzl[m] = v;
             }
         }
-        if (tid == 0 && ms[0] == 0) tz[0] = i_lo == 0 && u_thr == 0u ? Pi[0] : 0.0;  // m = 0: table[0] = P(0)
+        if (tid == 0 && ms[0] == 0) tzl[0] = i_lo == 0 && u_thr == 0u ? Pi[0] : 0.0;  // m = 0: table[0] = P(0)
     }
     __syncthreads();
     // Z = probs_sum (prob.rs:97) grouped by count value; fixed reduction order
     double part = 0.0;
     for (uint32_t j = tid; j < D; j += 256) {
         const uint32_t m = ms[j];
-        part += (double)hl[m] * tz[m];
+        part += (double)hl[m] * tzl[m];
     }
     part = wave_sum_f64_dpp(part);
     if (lane == 0) red[wave] = part;
@@ -303,7 +312,7 @@ __global__ __launch_bounds__(256) void prob_lookup_kernel(ProbParams p, ProbTabl
     double gsum = 0.0;
     for (uint32_t j = tid; j < D; j += 256) {
         const uint32_t m = ms[j];
-        const double v = tz[m] / Z;  // prob.rs:99-102
+        const double v = tzl[m] / Z;  // prob.rs:99-102
         tz[m] = v;
         const double d = v - inv_n;
         gsum += (double)hl[m] * d * d;
@@ -350,7 +359,7 @@ __global__ __launch_bounds__(1024) void prob_order_kernel(const uint32_t *__rest
 // ---------------------------------------------------------------------------
 size_t prob_lookup_lds_bytes(uint32_t tmax) {
     const size_t n1max = tmax / 2 + 1;
-    return sizeof(double) * (n1max + 16 + 64) + (sizeof(uint32_t) + 3 * sizeof(uint16_t)) * ((size_t)tmax + 18) + 8 +
+    return sizeof(double) * (n1max + 16 + 64 + ((size_t)tmax + 2)) + (sizeof(uint32_t) + 3 * sizeof(uint16_t)) * ((size_t)tmax + 18) + 8 +
            sizeof(uint32_t) * ((size_t)tmax + 4) + 2 * sizeof(uint32_t) * ((size_t)tmax + 18);
 }
 void launch_prob_tables_build(hipStream_t s, const ProbTables &tb, const double *lf, const double *inv) {

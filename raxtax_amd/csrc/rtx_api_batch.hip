@@ -271,6 +271,7 @@ int enqueue_count(rtx_index *ix, const SubBatch &b, uint32_t flags) {
 }
 
 static WalkParams walk_params(rtx_index *ix, const SubBatch &b, const double *prefix);
+static int reset_sub_alloc(rtx_index *ix, hipStream_t s);
 
 // group 2: prob table from the (whole-database) histogram + prefix sums over this handle's references; with
 // fuse_walk (whole database on this handle) the taxonomy walk of group 3 runs inside the prefix kernel
@@ -328,7 +329,11 @@ int enqueue_prob_prefix(rtx_index *ix, const SubBatch &b, bool fuse_walk, bool p
     fp.prune_thr = ix->prune_used && !ix->dbg_full_run ? sc.d_prune_thr.p : nullptr;
     fp.prune_stats = fp.prune_thr ? ix->d_prune_stats.p + kPruneStatCopies * 8 : nullptr;
     fp.fuse_walk = fuse_walk ? 1u : 0u;
-    if (fuse_walk) fp.walk = walk_params(ix, b, sc.d_prefix.p);
+    if (fuse_walk) {
+        fp.walk = walk_params(ix, b, sc.d_prefix.p);
+        int rc_r = fp.walk.sub_alloc ? reset_sub_alloc(ix, s) : RTX_OK;
+        if (rc_r) return rc_r;
+    }
     if (b.timed_all) RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_TAXON_PREFIX, 0), s));
     launch_taxon_prefix(s, fp, b.nq);
     if (b.timed_all) RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_TAXON_PREFIX, 1), s));
@@ -346,14 +351,24 @@ static WalkParams walk_params(rtx_index *ix, const SubBatch &b, const double *pr
     wp.arena = ix->d_arena.p;
     wp.arena_cap = ix->arena_cap;
     wp.arena_cursor = ix->d_cursor.p;
+    // (launches of a few thousand walks do not contend, and the rows the sub-allocators leave unused must stay within the arena's
+    // allowance of two rows per query: at most kWalkSubAllocs * kWalkChunkRows = 8192 per launch of kWalkSubMinQueries or more)
+    wp.sub_alloc = b.nq >= kWalkSubMinQueries && ix->arena_cap < (1ull << 32) ? ix->d_sub_alloc.p : nullptr;
     wp.n_rows = ix->d_n_rows.p;
     wp.row_start = ix->d_row_start.p;
     wp.flags_out = ix->d_flags.p;
     return wp;
 }
+// the sub-allocators of the result arena start empty in every launch that walks (WalkParams::sub_alloc)
+static int reset_sub_alloc(rtx_index *ix, hipStream_t s) {
+    if (ix->d_sub_alloc.p) RTX_HIP(hipMemsetAsync(ix->d_sub_alloc.p, 0, (size_t)kWalkSubAllocs * kWalkSubStride * 8, s));
+    return RTX_OK;
+}
 
 int enqueue_walk(rtx_index *ix, const SubBatch &b, const double *prefix, hipStream_t s) {
     const WalkParams wp = walk_params(ix, b, prefix);
+    int rc_r = wp.sub_alloc ? reset_sub_alloc(ix, s) : RTX_OK;
+    if (rc_r) return rc_r;
     if (b.timed_all) RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_LINEAGE_WALK, 0), s));
     launch_lineage_walk(s, wp, b.nq);
     if (b.timed_all) RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_LINEAGE_WALK, 1), s));
@@ -582,7 +597,8 @@ int prepare_workspace(rtx_index *ix, uint64_t n_queries, uint64_t tmax, uint64_t
         (rc = ix->d_n_rows.alloc(n_queries)) || (rc = ix->d_gs.alloc(n_queries)) || (rc = ix->d_z.alloc(n_queries)) ||
         (rc = ix->d_hq.alloc(n_queries)) || (rc = ix->d_row_start.alloc(n_queries)) || (rc = ix->d_ndist.alloc(n_queries)))
         return rc;
-    const uint64_t want_arena = n_queries * 8 + 4096;
+    if ((rc = ix->d_sub_alloc.alloc((size_t)kWalkSubAllocs * kWalkSubStride))) return rc;
+    const uint64_t want_arena = n_queries * 10 + 4096;  // eight rows per query + two for what the sub-allocators leave unused (walk_params)
     if (ix->arena_cap < want_arena) {
         if ((rc = ix->d_arena.alloc(want_arena))) return rc;
         ix->arena_cap = want_arena;

@@ -244,7 +244,7 @@ struct rtx_index {
     DevBuf<uint8_t> d_status;
     DevBuf<uint32_t> d_t_all, d_nrows_all, d_n_rows, d_flags, d_ndist;
     DevBuf<double> d_gs, d_z;
-    DevBuf<unsigned long long> d_hq, d_row_start, d_cursor;
+    DevBuf<unsigned long long> d_hq, d_row_start, d_cursor, d_sub_alloc;  // (d_sub_alloc: WalkParams::sub_alloc)
     DevBuf<DevRow> d_arena;
     uint64_t arena_cap = 0;
     // ---- timing

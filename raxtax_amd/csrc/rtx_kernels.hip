@@ -1035,7 +1035,22 @@ __device__ __forceinline__ void lineage_walk_wave(const WalkParams &p, uint32_t 
     wave_lds_sync();
     const uint32_t keep = nrows < kWalkMaxRows ? nrows : kWalkMaxRows;
     unsigned long long start = 0;
-    if (lane == 0) start = atomicAdd(p.arena_cursor, (unsigned long long)keep);
+    if (lane == 0 && keep) {
+        if (p.sub_alloc) {
+            unsigned long long *w = p.sub_alloc + (size_t)(q & (kWalkSubAllocs - 1u)) * kWalkSubStride;
+            const unsigned long long old = atomicAdd(w, (unsigned long long)keep);  // (the cursor half: a piece never ends above 2^32 rows)
+            const unsigned long long cur = old & 0xFFFFFFFFull, end = old >> 32;
+            if (cur + keep <= end) {
+                start = cur;
+            } else {  // the piece is used up (or this is the first walk behind the reset): a new one, what this walk leaves of it is published
+                const unsigned long long take = keep > kWalkChunkRows ? keep : kWalkChunkRows;
+                start = atomicAdd(p.arena_cursor, take);
+                if (start + take < (1ull << 32)) atomicExch(w, ((start + take) << 32) | (start + keep));
+            }
+        } else {
+            start = atomicAdd(p.arena_cursor, (unsigned long long)keep);
+        }
+    }
     start = __shfl(start, 0, 64);
     if (start + keep <= p.arena_cap) {
         // DevRow = 9 dwords

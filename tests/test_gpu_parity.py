@@ -201,6 +201,36 @@ def test_raxtax_mirror_chunks_with_very_different_row_counts(world):
         assert got == single, chunk
 
 
+def test_result_rows_through_the_sub_allocators_of_the_arena(world):
+    """Launches of 4096 walks or more place their result rows through 128 sub-allocators of the arena (WalkParams::sub_alloc, rtx_kernels.hpp:
+    one cursor for 65 536 walks was what bounded taxon_prefix); smaller launches add to the cursor directly.  20 000 queries -- every second one
+    a fragment of 12-30 bases with dozens of rows, some above the 64 rows of a piece -- in launches of 20 000 and of 512: the same rows."""
+    w = world
+    db = w["db"]
+    rng = np.random.default_rng(13)
+    seqs = []
+    for i in range(20_000):
+        src = db.seq(int(rng.integers(0, db.n)))
+        if i % 2:
+            a = int(rng.integers(0, 600))
+            seqs.append(src[a:a + int(rng.integers(12, 30))].copy())
+        else:
+            seqs.append(src.copy())
+    off = np.zeros(len(seqs) + 1, dtype=np.uint64)
+    off[1:] = np.cumsum([len(x) for x in seqs])
+    bases = np.concatenate(seqs)
+    ib = rx.Index(w["tree"])
+    big = ib.classify(bases, off)
+    assert ib.sub_batch_size() >= 4096
+    small = rx.Index(w["tree"], sub_batch=512).classify(bases, off)
+    n_rows = np.diff(big.row_off)
+    assert n_rows.max() > 64 and n_rows.min() >= 1
+    assert np.array_equal(big.row_off, small.row_off)
+    assert np.array_equal(big.row_lineage, small.row_lineage) and np.array_equal(big.row_conf, small.row_conf)
+    assert np.array_equal(big.status, small.status) and np.array_equal(big.global_signal, small.global_signal)
+    assert np.array_equal(big.row_local_signal, small.row_local_signal)
+
+
 @pytest.mark.parametrize("name", ["F8_tree_construction", "F9_variable_lineage_length", "F10_likelihood_edge_case"])
 def test_lineage_kats_on_device(kats, name):
     """The reference's own lineage vectors (lineage.rs:192-334) through taxon_prefix + lineage_walk."""

@@ -80,6 +80,8 @@ def parse():
     ap.add_argument("--no-tile-prune", action="store_true", help="hit_count counts every tile of 8192 references (RTX_OPT_TILE_PRUNE = 0; default: only the tiles that can hold a reference with any probability)")
     ap.add_argument("--tile-prune", action="store_true", help="(the default; kept for older command lines)")
     ap.add_argument("--no-fine-bounds", action="store_true", help="tile pruning with its first stage of bounds only (RTX_OPT_FINE_BOUNDS = 0; A/B measurements)")
+    ap.add_argument("--records", type=int, default=None, help="RTX_OPT_RECORDS: pruned queries with at most this many live tiles write records of the counts above their threshold instead of counts (0: off; default: the library's)")
+    ap.add_argument("--overlap", type=int, default=None, help="RTX_OPT_OVERLAP: 1 = back half of a sub-batch on a second stream beside the front half of the next (default: the library's)")
     ap.add_argument("--no-tile-skip", action="store_true", help="taxon_prefix sums every reference (RTX_OPT_TILE_SKIP = 0; A/B measurements)")
     ap.add_argument("--mu-q", type=float, default=0.02, help="per-site substitution rate of a query against its source reference (the headline: 0.02)")
     ap.add_argument("--exact-frac", type=float, default=0.10, help="share of the queries that are exact copies of a reference (the headline: 0.10)")
@@ -648,7 +650,7 @@ def main():
                          packed_counts=False if args.u16_counts else None,
                          tile_skip=False if args.no_tile_skip else None, hit_pair=False if args.no_pair else None,
                          locator=False if args.no_locator else None, tile_prune=False if args.no_tile_prune else None,
-                         fine_bounds=False if args.no_fine_bounds else None)
+                         fine_bounds=False if args.no_fine_bounds else None, records=args.records, overlap=args.overlap)
         t_exact = None
         if args.host_exact_match or not index.has_exact_lookup:
             t0 = time.perf_counter()

@@ -218,6 +218,16 @@ int rtx_index_set_batch(rtx_index *index, uint32_t sub_batch);
                                 * second union bitmap over blocks of 8 references (1/8 of the index), which takes the tiles without a block
                                 * above the query's threshold off their lists before the counting pass.  Results do not change (a bound is a
                                 * bound); 0: first stage only (A/B measurements) */
+#define RTX_OPT_RECORDS 18 /* 4 (default; 0 .. 16): the RECORDS path of the tile pruning.  A query that the pruning gives a threshold and at most
+                            * this many live tiles only ever needs its references with a count ABOVE the threshold (every other one is a
+                            * reference without a hit): the epilogue of hit_count then writes (reference, count) records of those alone instead
+                            * of the counts of 8192 references per tile, and one wave per query turns them into the prefix sums of
+                            * lineage.rs:61-77 at the few taxonomy boundaries they touch and walks the lineage (rtx_records.hip) in the place
+                            * of taxon_prefix's sweeps.  Same thresholds, same probabilities; 0: every query takes the dense epilogue.
+                            * Shapes the workspace like the options below. */
+#define RTX_OPT_OVERLAP 19 /* 0 / 1: the back half of sub-batch k (prob_lookup, taxon_prefix + walk, records tail: chains of dependent round trips)
+                            * runs on a second HIP stream beside the front half of sub-batch k + 1 (bounds, counting: VALU and L1 rate);
+                            * two scratch sets alternate.  Same results.  Whole-database handles; shapes the workspace. */
 /* RTX_OPT_SUB_BATCH, _PACKED_COUNTS, _HIT_PAIR, _TILE_PRUNE and _PROB_MODE shape the workspace that rtx_batch_upload sizes:
  * setting one of them drops the uploaded batch (rtx_batch_run then fails with RTX_ERR_STATE until the batch is uploaded again). */
 int rtx_index_set_option(rtx_index *index, int option, uint64_t value);
@@ -381,7 +391,9 @@ int rtx_batch_sub_batch(const rtx_index *index, uint32_t *sub_batch, uint32_t *n
  * they bound (must be 0), [7] (query, tile) combinations that are counted, [8] (query, tile) combinations with a count above the query's
  * threshold -- what exact knowledge would have counted --, [9] queries with a threshold; all 0 if the run did not prune.
  * The fine bounds pass (RTX_OPT_FINE_BOUNDS): [10] (query, tile) combinations it took off the lists, [11] its (pair, fine tile) blocks,
- * [12] (pair, tile) blocks the counting pass was left with (0 if the pass did not run: then [0] is that number), [13..15] 0 */
+ * [12] (pair, tile) blocks the counting pass was left with (0 if the pass did not run: then [0] is that number).
+ * The records path (RTX_OPT_RECORDS): [13] records written (references above their query's threshold), [14] queries on the path,
+ * [15] of those, queries whose boundary entries did not fit LDS (prefix row written out, walked from memory) */
 int rtx_debug_prune_stats(rtx_index *index, uint64_t *out /*16*/);
 /* table / Z of a query of the last sub-batch as the PRUNED run computed it (0 for the counts up to the query's threshold), its Z and the
  * threshold; must be called before any other tap (those recount the sub-batch in full) */
@@ -393,6 +405,10 @@ int rtx_debug_pruned_prob_table(rtx_index *index, uint64_t query, double *table_
  * threshold (0: none) and i* + 1 (rtx_prune.hip).  Any output pointer may be NULL. */
 int rtx_debug_run_counts(rtx_index *index, uint64_t query, uint16_t *counts /*n_refs*/, uint8_t *tile_live /*ntiles*/,
                          uint32_t *hist /*t+1*/, uint32_t *threshold, uint32_t *i1);
+/* A query on the records path (RTX_OPT_RECORDS) wrote no counts but the (reference, count) records of the counts above its threshold:
+ * rtx_debug_run_counts then returns, for the visited tiles, the count of every reference that has a record and 0 for every other one
+ * (read back from the record segments, which must be in ascending reference order).  n_segments: 0 = the query took the dense epilogues. */
+int rtx_debug_run_mode(rtx_index *index, uint64_t query, uint32_t *n_segments);
 /* prune_kernel's view of a query of the last sub-batch (needs RTX_OPT_DEBUG_TAPS = 1 before the run): out[0] the block of 64 references
  * with the largest bound, [1] M = the best exact count in it, [2] the threshold, [3] i* + 1, [4] the largest bound, [5] t, [8 .. 72) the exact
  * counts of the block's references (0: behind the end of the database, or zeroed by RTX_SKIP_EXACT_MATCHES) */

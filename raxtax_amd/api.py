@@ -219,7 +219,8 @@ class Index:
                  stage_timing: bool = False, cluster: Optional[bool] = None, segment_classes=None,
                  packed_counts: Optional[bool] = None,
                  tile_skip: Optional[bool] = None, hit_pair=None, locator: Optional[bool] = None, tile_prune: Optional[bool] = None,
-                 debug_taps: bool = False, device_exact: Optional[bool] = None, fine_bounds: Optional[bool] = None):
+                 debug_taps: bool = False, device_exact: Optional[bool] = None, fine_bounds: Optional[bool] = None,
+                 records: Optional[int] = None, overlap: Optional[bool] = None):
         self._lib = _lib.load()
         self.tree = tree
         if segment_classes is None:
@@ -253,6 +254,10 @@ class Index:
             check(self._lib.rtx_index_set_option(self._h, 15, int(device_exact)))
         if fine_bounds is not None:
             check(self._lib.rtx_index_set_option(self._h, 17, int(fine_bounds)))
+        if records is not None:   # RTX_OPT_RECORDS: pruned queries with at most this many live tiles write records instead of counts (0: off)
+            check(self._lib.rtx_index_set_option(self._h, 18, int(records)))
+        if overlap is not None:   # RTX_OPT_OVERLAP: back half of a sub-batch on a second stream beside the front half of the next
+            check(self._lib.rtx_index_set_option(self._h, 19, int(overlap)))
         self._view = ResultView()
         self._keep = None
 
@@ -382,7 +387,11 @@ class Index:
         hist = np.zeros(t + 1, dtype=np.uint32)
         thr, i1 = C.c_uint32(), C.c_uint32()
         check(self._lib.rtx_debug_run_counts(self._h, q, ptr(counts, u16p), ptr(live, u8p), ptr(hist, u32p), C.byref(thr), C.byref(i1)))
-        return dict(counts=counts, tile_live=live.astype(bool), hist=hist, threshold=int(thr.value), i1=int(i1.value))
+        nseg = C.c_uint32()
+        check(self._lib.rtx_debug_run_mode(self._h, q, C.byref(nseg)))
+        # record_segments > 0: the query took the records path (RTX_OPT_RECORDS) -- `counts` of its visited tiles hold the count of every
+        # reference ABOVE the threshold and 0 for the others (it wrote records of those alone)
+        return dict(counts=counts, tile_live=live.astype(bool), hist=hist, threshold=int(thr.value), i1=int(i1.value), record_segments=int(nseg.value))
 
     def debug_tile_bounds(self, q: int) -> np.ndarray:
         """The largest bound of every tile as the bounds pass left it for query q of the last sub-batch."""
@@ -423,7 +432,8 @@ class Index:
         return {"live_tiles_per_pair": counted / pairs, "live_tiles_per_pair_first_stage": int(out[0]) / pairs,
                 "fine_blocks_per_pair": int(out[11]) / pairs, "fine_cleared_per_query": int(out[10]) / nq, "pairs": int(out[1]), "mean_best_hit_lower_bound": int(out[2]) / nq,
                 "mean_threshold": int(out[3]) / nq, "mean_largest_tile_bound": int(out[4]) / nq, "bound_violations": int(out[6]), "live_tiles_per_query": int(out[7]) / nq,
-                "tiles_above_threshold_per_query": int(out[8]) / max(int(out[9]), 1), "queries_with_threshold": int(out[9])}
+                "tiles_above_threshold_per_query": int(out[8]) / max(int(out[9]), 1), "queries_with_threshold": int(out[9]),
+                "record_queries": int(out[14]), "records_per_record_query": int(out[13]) / max(int(out[14]), 1), "record_slow_path_queries": int(out[15])}
 
     def debug_evaluate(self, probs) -> Result:
         """Lineage::new(label, tree, probs).evaluate() on the device (lineage.rs:61-112)."""

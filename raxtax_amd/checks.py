@@ -83,7 +83,13 @@ def check_run_as_left(index, j, t, counts_o, p_o, n_refs, emul=None, lf=None, la
     pad = ntiles * 8192 - n_refs
     co = np.concatenate([counts_o, np.zeros(pad, np.uint16)]).reshape(ntiles, 8192)
     cr = np.concatenate([rc["counts"], np.zeros(pad, np.uint16)]).reshape(ntiles, 8192)
-    assert np.array_equal(cr[live], co[live]), f"{label}: counts of the visited tiles differ from the oracle"
+    if rc.get("record_segments", 0):
+        # the records path (RTX_OPT_RECORDS): the run wrote (reference, count) records of the counts ABOVE the threshold and nothing else --
+        # they must be exactly the oracle's counts above the threshold in the visited tiles (every other reference reads 0)
+        assert thr > 0, f"{label}: records without a threshold"
+        assert np.array_equal(cr[live], np.where(co[live] > thr, co[live], 0)), f"{label}: the records of the visited tiles are not the oracle's counts above the threshold {thr}"
+    else:
+        assert np.array_equal(cr[live], co[live]), f"{label}: counts of the visited tiles differ from the oracle"
     tile_max_o = co.max(axis=1)
     if not live.all():
         assert thr > 0, f"{label}: tiles left out for a query without a threshold"
@@ -105,7 +111,8 @@ def check_run_as_left(index, j, t, counts_o, p_o, n_refs, emul=None, lf=None, la
     assert dropped < 1e-9, f"{label}: the references up to the threshold {thr} hold {dropped} in the oracle"
     if thr:
         assert (tz_p[: thr + 1] == 0).all()
-    out = dict(threshold=thr, live=int(live.sum()), needed=int((tile_max_o > thr).sum()) if thr else ntiles, dp=d, dropped=dropped)
+    out = dict(threshold=thr, live=int(live.sum()), needed=int((tile_max_o > thr).sum()) if thr else ntiles, dp=d, dropped=dropped,
+               records=bool(rc.get("record_segments", 0)))
     if emul is not None:
         det = index.debug_prune_detail(j)
         b = det["block"]
@@ -204,7 +211,7 @@ def as_run_oracle_sample(index, res, oracle, otree, bases, base_off, n_sample: i
     lf = None
     if emul is not None:
         lf = np.array([oracle.lib.orc_ln_factorial(i) for i in range(2 * int(res.t.max()) + 8)], dtype=np.float64)
-    seen = dict(n=0, with_threshold=0, thr=0, live=0, needed=0, max_dp=0.0, max_dropped=0.0, ties=0, rows_identical=0)
+    seen = dict(n=0, with_threshold=0, thr=0, live=0, needed=0, max_dp=0.0, max_dropped=0.0, ties=0, rows_identical=0, on_records_path=0)
     lineages = None
     pruned = index.debug_prune_stats()["pairs"] > 0
     for a in range(0, len(sample), chunk):
@@ -224,6 +231,7 @@ def as_run_oracle_sample(index, res, oracle, otree, bases, base_off, n_sample: i
             if pruned:
                 o = check_run_as_left(index, q, t, counts_o[j], tables_o[j], index.n_refs, emul, lf, f"query {q} skip {skip}", tol=tol)
                 seen["with_threshold"] += o["threshold"] > 0
+                seen["on_records_path"] += int(o["records"])
                 seen["thr"] += o["threshold"]
                 seen["live"] += o["live"]
                 seen["needed"] += o["needed"]

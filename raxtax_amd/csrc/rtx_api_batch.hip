@@ -209,6 +209,10 @@ int enqueue_hit(rtx_index *ix, const SubBatch &b, uint32_t flags, hipStream_t s,
         pr.i1_out = sc.d_prune_i1.p;
         pr.stats = ix->d_prune_stats.p;
         pr.detail = ix->debug_taps && ix->d_prune_detail.n >= (size_t)b.nq * kPruneDetailWords ? ix->d_prune_detail.p : nullptr;
+        // the records path: whole-database handles whose walk rides in the prefix launch (enqueue_prob_prefix starts records_tail_kernel there)
+        const bool records = part == 0 && ix->rec_used && sc.d_rec.p != nullptr;
+        const RecordRef rr{sc.d_rec_nslots.p, sc.d_rec_slots.p, sc.d_rec_cnt.p, sc.d_rec.p, std::min<uint32_t>(ix->rec_opt, kRecMaxSlots)};
+        if (records) { pr.rec = rr; pr.rec_max_slots = rr.stride; }
         ProbTables tb{ix->d_tab_cmf.p, ix->d_tab_ratio.p, ix->d_tab_off.p, ix->d_tab_moff.p, ix->d_tab_ilo.p, ix->d_tab_sat.p, ix->tab_tmax};
         launch_prune(s, pr, tb, b.nq);
         if (part == 1) { RTX_HIP(hipGetLastError()); return RTX_OK; }  // the caller exchanges RTX_BUF_BEST, then part 2
@@ -241,6 +245,7 @@ int enqueue_hit(rtx_index *ix, const SubBatch &b, uint32_t flags, hipStream_t s,
         hp.live = sc.d_live.p;
         hp.live_words = pr.live_words;
         hp.prune_thr = sc.d_prune_thr.p;
+        if (records) hp.rec = rr;
         if (ix->pair_used) {  // the grid of the counting pass walks the live (pair, tile) blocks instead of all of them
             const size_t np = (b.nq + 1u) / 2u, cap = np * ix->ntiles;
             launch_live_items(s, sc.d_live.p, pr.live_words, pr.pair_live, b.nq, ix->ntiles, sc.d_items.p + cap + 9u + np, sc.d_items.p, sc.d_items.p + cap);
@@ -329,6 +334,8 @@ int enqueue_prob_prefix(rtx_index *ix, const SubBatch &b, bool fuse_walk, bool p
     fp.prune_thr = ix->prune_used && !ix->dbg_full_run ? sc.d_prune_thr.p : nullptr;
     fp.prune_stats = fp.prune_thr ? ix->d_prune_stats.p + kPruneStatCopies * 8 : nullptr;
     fp.fuse_walk = fuse_walk ? 1u : 0u;
+    const bool records = fuse_walk && fp.prune_thr && ix->rec_used && sc.d_rec.p != nullptr;
+    fp.rec_nslots = records ? sc.d_rec_nslots.p : nullptr;
     if (fuse_walk) {
         fp.walk = walk_params(ix, b, sc.d_prefix.p);
         int rc_r = fp.walk.sub_alloc ? reset_sub_alloc(ix, s) : RTX_OK;
@@ -336,6 +343,22 @@ int enqueue_prob_prefix(rtx_index *ix, const SubBatch &b, bool fuse_walk, bool p
     }
     if (b.timed_all) RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_TAXON_PREFIX, 0), s));
     launch_taxon_prefix(s, fp, b.nq);
+    if (records) {  // the queries on the records path: prefix sums from their records, the walk from LDS (rtx_records.hip)
+        TailParams tp{};
+        tp.rec = RecordRef{sc.d_rec_nslots.p, sc.d_rec_slots.p, sc.d_rec_cnt.p, sc.d_rec.p, std::min<uint32_t>(ix->rec_opt, kRecMaxSlots)};
+        tp.t = sc.d_t.p;
+        tp.table_z = sc.d_table_z.p;
+        tp.hstride = ix->hstride;
+        tp.bnd_bits = ix->d_bnd_bits.p;
+        tp.bnd_rank = ix->d_bnd_rank.p;
+        tp.prefix = sc.d_prefix.p;
+        tp.n_bnd = ix->n_bnd_local;
+        tp.nq = b.nq;
+        tp.walk = fp.walk;
+        tp.prefix_stats = fp.prune_stats;
+        tp.stats = ix->d_prune_stats.p ? ix->d_prune_stats.p + 3 * kPruneStatCopies * 8 : nullptr;
+        launch_records_tail(s, tp, b.nq);
+    }
     if (b.timed_all) RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_TAXON_PREFIX, 1), s));
     return RTX_OK;
 }
@@ -437,11 +460,13 @@ int begin_run(rtx_index *ix, uint32_t *n_sub_out, bool *timed_out, bool cluster)
     ix->prune_used = ix->prune_opt && ix->pair_used && ix->use_tables && ix->tile_skip && ix->d_ubitmap.p && (whole || shard) &&
                      scratch_ok(ix->sc[0]) && (!ix->staged || scratch_ok(ix->sc[1]));
     ix->dbg_full = false;
+    ix->rec_used = ix->prune_used && whole && ix->rec_opt != 0u && ix->n_bnd_local == ix->n_bnd && ix->sc[0].d_rec.p != nullptr &&
+                   ix->sc[0].d_rec.n >= (size_t)ix->sub_batch * std::min<uint32_t>(ix->rec_opt, kRecMaxSlots) * 8192u;
     if (ix->prune_used) {
-        int rc_s = ix->d_prune_stats.alloc(kPruneStatCopies * 24);
+        int rc_s = ix->d_prune_stats.alloc(kPruneStatCopies * 32);
         if (!rc_s && ix->debug_taps) rc_s = ix->d_prune_detail.alloc((size_t)ix->sub_batch * kPruneDetailWords);
         if (rc_s) return rc_s;
-        RTX_HIP(hipMemsetAsync(ix->d_prune_stats.p, 0, kPruneStatCopies * 192, ix->stream));
+        RTX_HIP(hipMemsetAsync(ix->d_prune_stats.p, 0, kPruneStatCopies * 256, ix->stream));
     }
     if (ix->pair_used) {
         ix->n_groups_run = n_sub * ix->groups_per_sub;
@@ -450,6 +475,7 @@ int begin_run(rtx_index *ix, uint32_t *n_sub_out, bool *timed_out, bool cluster)
         RTX_HIP(hipMemsetAsync(ix->d_group_rows.p, 0, (size_t)2 * n_sub * ix->groups_per_sub * 4, ix->stream));
     }
     ix->n_sub_last = timed ? n_sub : 0;
+    ix->overlap_used = ix->overlap_opt != 0u && whole && n_sub >= 2 && ix->sc[1].d_kmers.p != nullptr && scratch_ok(ix->sc[1]) == scratch_ok(ix->sc[0]);
     if (ix->dev_exact_used) {  // Tree.sequences.get for every query of the batch (raxtax.rs:42), part of the run
         ExactParams xp{ix->d_bases.p, ix->in[ix->cur_in].d_base_off.p, (uint32_t)ix->n_q, ix->d_em_table.p, ix->em_bits, ix->d_em_rep_off.p,
                        ix->d_em_rep_bytes.p, ix->d_exact_grp.p, ix->em_hash_mask};
@@ -490,9 +516,32 @@ int enqueue_batch(rtx_index *ix, uint32_t flags) {
     }
     // the walk rides inside the prefix kernel (the stage time of lineage_walk is then part of taxon_prefix)
     const bool fuse = ix->n_bnd_local == ix->n_bnd;
+    // RTX_OPT_OVERLAP: the back half of sub-batch k (prob_lookup, taxon_prefix / records tail: chains of dependent round trips) on a second
+    // stream beside the front half of sub-batch k + 1 (bounds and counting: VALU and L1 rate); two scratch sets alternate (sb & 1), a
+    // front half waits for the back half that last used its set.
+    const bool overlap = ix->overlap_used;
+    if (overlap) {
+        if (!ix->stream2) RTX_HIP(hipStreamCreateWithFlags(&ix->stream2, hipStreamNonBlocking));
+        while (ix->ev_front.size() < n_sub) {
+            hipEvent_t e, f;
+            RTX_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            RTX_HIP(hipEventCreateWithFlags(&f, hipEventDisableTiming));
+            ix->ev_front.push_back(e);
+            ix->ev_back.push_back(f);
+        }
+    }
     for (uint32_t sb = 0; sb < n_sub; sb++) {
-        const SubBatch b = sub_batch_of(ix, sb, timed);
+        SubBatch b = sub_batch_of(ix, sb, timed);
+        if (overlap) {
+            b.set = sb & 1u;
+            if (sb >= 2) RTX_HIP(hipStreamWaitEvent(ix->stream, ix->ev_back[sb - 2], 0));  // the scratch set is free again
+        }
         if ((rc = enqueue_count(ix, b, flags))) return rc;
+        if (overlap) {
+            RTX_HIP(hipEventRecord(ix->ev_front[sb], ix->stream));
+            b.s = ix->stream2;
+            RTX_HIP(hipStreamWaitEvent(b.s, ix->ev_front[sb], 0));
+        }
         if ((rc = enqueue_prob_prefix(ix, b, fuse))) return rc;
         if (!fuse && (rc = enqueue_walk(ix, b, ix->sc[b.set].d_prefix.p, b.s))) return rc;
         if (fuse && b.timed_all) {  // keeps rtx_batch_stage_times whole: an empty interval
@@ -503,7 +552,9 @@ int enqueue_batch(rtx_index *ix, uint32_t flags) {
             RTX_HIP(hipMemcpyAsync(&ix->h_cursor_sub[sb], ix->d_cursor.p, 8, hipMemcpyDeviceToHost, b.s));
             RTX_HIP(hipEventRecord(ix->ev_sub[sb], b.s));
         }
+        if (overlap) RTX_HIP(hipEventRecord(ix->ev_back[sb], b.s));
     }
+    if (overlap && n_sub) RTX_HIP(hipStreamWaitEvent(ix->stream, ix->ev_back[n_sub - 1], 0));  // a wait for the handle's stream covers both
     RTX_HIP(hipGetLastError());
     return RTX_OK;
 }
@@ -572,7 +623,7 @@ int prepare_workspace(rtx_index *ix, uint64_t n_queries, uint64_t tmax, uint64_t
     // and hipMemGetInfo alone costs a good part of a millisecond between two chunks, with the device idle
     const uint64_t key[6] = {n_queries, tmax, max_len, ix->sub_batch_req,
                              (uint64_t)ix->packed_opt | (uint64_t)ix->pair_opt << 1 | (uint64_t)ix->prune_opt << 2 | (uint64_t)ix->shard_prune_opt << 3 | (uint64_t)ix->fine_opt << 4 |
-                                 (uint64_t)(ix->prob_mode & 3) << 5,
+                                 (uint64_t)(ix->prob_mode & 3) << 5 | (uint64_t)ix->rec_opt << 8 | (uint64_t)ix->overlap_opt << 16,
                              (uint64_t)ix->n_bnd_local};
     if (ix->ws_valid && std::memcmp(key, ix->ws_key, sizeof key) == 0 && !ix->staged) {
         ix->n_q = n_queries;
@@ -609,14 +660,17 @@ int prepare_workspace(rtx_index *ix, uint64_t n_queries, uint64_t tmax, uint64_t
                            (uint64_t)ix->n_bnd_local * 8 + 64 +
                            // + the scratch of the tile pruning: tile bounds, thresholds, live masks, best blocks, the lists of live blocks
                            (will_prune ? (uint64_t)ix->ntiles * 2 + 12 + (ix->ntiles + 31u) / 32u * 2u + 2u + kPruneBestWords * 4 +
-                                          ((uint64_t)ix->ntiles + 2u) * 2u  /* the list of live (pair, tile) blocks: 4 bytes per pair and tile */ : 0);
+                                          ((uint64_t)ix->ntiles + 2u) * 2u  /* the list of live (pair, tile) blocks: 4 bytes per pair and tile */ +
+                                          (ix->d_fbitmap.p ? (uint64_t)ix->f_ntiles * 2u + 1u : 0u) /* the items of the fine bounds pass */ +
+                                          (ix->rec_opt && ix->n_refs == ix->n_total ? (uint64_t)std::min<uint32_t>(ix->rec_opt, kRecMaxSlots) * 32768u + kRecMaxSlots * 6u + 2u : 0u) /* record segments */
+                                        : 0);
     uint32_t B = ix->sub_batch_req;
     if (B == 0) {
         size_t free_b = 0, total_b = 0;
         RTX_HIP(hipMemGetInfo(&free_b, &total_b));
         // scratch already held by this handle is reusable
         const uint64_t held = (ix->sc[0].d_counts.n + ix->sc[1].d_counts.n) * 2 + (ix->sc[0].d_prefix.n + ix->sc[1].d_prefix.n) * 8;
-        const uint64_t budget = (uint64_t)((free_b + held) * 0.6);
+        const uint64_t budget = (uint64_t)((free_b + held) * 0.6) / (ix->overlap_opt && ix->n_refs == ix->n_total ? 2u : 1u);  // (RTX_OPT_OVERLAP: two scratch sets)
         B = (uint32_t)std::min<uint64_t>(will_prune ? kDefaultSubBatchPruned : ix->ntiles >= 16 ? kDefaultSubBatchLarge : kDefaultSubBatch,
                                          std::max<uint64_t>(64, budget / per_q));
         // at least four sub-batches per batch (of 16 384 queries or more): the records of a finished sub-batch are copied and finalised on
@@ -629,6 +683,9 @@ int prepare_workspace(rtx_index *ix, uint64_t n_queries, uint64_t tmax, uint64_t
     ix->sub_batch = B;
     ix->staged = false;
     if ((rc = alloc_scratch_set(ix, 0))) return rc;
+    if (ix->overlap_opt && ix->n_refs == ix->n_total && alloc_scratch_set(ix, 1)) {  // (without a second set the run stays on one stream)
+        ix->sc[1].d_kmers.release();
+    }
     std::memcpy(ix->ws_key, key, sizeof key);
     ix->ws_valid = true;
     return RTX_OK;
@@ -651,7 +708,14 @@ int alloc_scratch_set(rtx_index *ix, uint32_t k) {
             if ((rc = sc.d_tile_ub.alloc((size_t)B * ix->ntiles)) || (rc = sc.d_best_key.alloc(B)) || (rc = sc.d_prune_thr.alloc(B)) || (rc = sc.d_prune_i1.alloc(B)) || (rc = sc.d_best.alloc((size_t)B * kPruneBestWords)) || (rc = sc.d_live.alloc((size_t)(B + 1u) * ((ix->ntiles + 31u) / 32u + 1u))) ||
                 (rc = sc.d_items.alloc((size_t)((B + 1u) / 2u) * (ix->ntiles + 2u) + 9u)))
                 return rc;
-            if (ix->d_fbitmap.p && (rc = sc.d_fine_items.alloc((size_t)((B + 1u) / 2u) * ix->f_ntiles + 9u + ix->f_ntiles))) return rc;
+            // (a failed allocation of the fine pass's lists only switches the pass off: enqueue_hit tolerates a null pointer)
+            if (ix->d_fbitmap.p && sc.d_fine_items.alloc((size_t)((B + 1u) / 2u) * ix->f_ntiles + 9u + ix->f_ntiles)) sc.d_fine_items.release();
+            if (ix->rec_opt && ix->n_refs == ix->n_total) {  // the records path; without its buffers the run takes the dense epilogues
+                const size_t slots = std::min<uint32_t>(ix->rec_opt, kRecMaxSlots);
+                if (sc.d_rec_nslots.alloc(B) || sc.d_rec_slots.alloc((size_t)B * kRecMaxSlots) || sc.d_rec_cnt.alloc((size_t)B * kRecMaxSlots) ||
+                    sc.d_rec.alloc((size_t)B * slots * 8192u))
+                    sc.d_rec.release();
+            }
         }
     }
     return RTX_OK;

@@ -227,7 +227,31 @@ int rtx_debug_run_counts(rtx_index *ix, uint64_t query, uint16_t *counts, uint8_
         RTX_HIP(hipMemcpy(&thr, sc.d_prune_thr.p + slot, 2, hipMemcpyDeviceToHost));
         RTX_HIP(hipMemcpy(&i1v, sc.d_prune_i1.p + slot, 2, hipMemcpyDeviceToHost));
     }
-    if (counts) {
+    uint16_t n_seg = 0;  // > 0: the query took the records path -- its counts are the records of its segments
+    if (ix->prune_used && ix->rec_used && sc.d_rec_nslots.p) RTX_HIP(hipMemcpy(&n_seg, sc.d_rec_nslots.p + slot, 2, hipMemcpyDeviceToHost));
+    if (counts && n_seg) {
+        // visited tiles: the count of every reference above the threshold, 0 for the others (the run never wrote those); unvisited: 0xFFFF
+        const uint32_t stride = std::min<uint32_t>(ix->rec_opt, kRecMaxSlots);
+        uint16_t tiles[kRecMaxSlots];
+        uint32_t cnts[kRecMaxSlots];
+        RTX_HIP(hipMemcpy(tiles, sc.d_rec_slots.p + (size_t)slot * kRecMaxSlots, sizeof tiles, hipMemcpyDeviceToHost));
+        RTX_HIP(hipMemcpy(cnts, sc.d_rec_cnt.p + (size_t)slot * kRecMaxSlots, sizeof cnts, hipMemcpyDeviceToHost));
+        for (uint64_t r = 0; r < ix->n_refs; r++) counts[r] = live[r >> 13] ? 0u : 0xFFFFu;
+        std::vector<uint32_t> seg(8192);
+        for (uint32_t k = 0; k < n_seg && k < stride; k++) {
+            const uint32_t c = std::min<uint32_t>(cnts[k], 8192u);
+            if (!c) continue;
+            RTX_HIP(hipMemcpy(seg.data(), sc.d_rec.p + ((size_t)slot * stride + k) * 8192u, (size_t)c * 4, hipMemcpyDeviceToHost));
+            uint32_t prev = 0;
+            for (uint32_t i = 0; i < c; i++) {
+                const uint32_t rl = seg[i] & 8191u;
+                const uint64_t r = (uint64_t)tiles[k] * 8192u + rl;
+                if (r >= ix->n_refs || (i && rl <= prev) || !live[tiles[k]]) { set_error("rtx_debug_run_counts: malformed record %u of segment %u of query %llu", i, k, (unsigned long long)query); return RTX_ERR_STATE; }
+                counts[r] = (uint16_t)(seg[i] >> 13);
+                prev = rl;
+            }
+        }
+    } else if (counts) {
         const uint16_t *src = nullptr;
         if ((rc = debug_counts_u16(ix, slot, &src))) return rc;
         RTX_HIP(hipMemcpy(counts, src, ix->n_refs * 2, hipMemcpyDeviceToHost));
@@ -245,6 +269,19 @@ int rtx_debug_run_counts(rtx_index *ix, uint64_t query, uint16_t *counts, uint8_
     }
     if (threshold) *threshold = thr;
     if (i1) *i1 = i1v;
+    return RTX_OK;
+}
+
+// number of record segments of a query of the last sub-batch (RTX_OPT_RECORDS): 0 = it took the dense epilogues
+int rtx_debug_run_mode(rtx_index *ix, uint64_t query, uint32_t *n_segments) {
+    uint32_t slot;
+    int rc = debug_slot_as_run(ix, query, &slot);
+    if (rc) return rc;
+    if (!n_segments) { set_error("null argument"); return RTX_ERR_INVALID; }
+    uint16_t n_seg = 0;
+    rtx_index::Scratch &sc = ix->sc[ix->last_set];
+    if (ix->prune_used && ix->rec_used && sc.d_rec_nslots.p) RTX_HIP(hipMemcpy(&n_seg, sc.d_rec_nslots.p + slot, 2, hipMemcpyDeviceToHost));
+    *n_segments = n_seg;
     return RTX_OK;
 }
 
@@ -279,12 +316,15 @@ int rtx_debug_prune_stats(rtx_index *ix, uint64_t *out) {
     std::memset(out, 0, 128);
     if (!ix->prune_used || !ix->d_prune_stats.p) return RTX_OK;
     RTX_HIP(hipStreamSynchronize(ix->stream));
-    unsigned long long h[kPruneStatCopies * 24];
+    unsigned long long h[kPruneStatCopies * 32];
     RTX_HIP(hipMemcpy(h, ix->d_prune_stats.p, sizeof(h), hipMemcpyDeviceToHost));
     for (uint32_t c = 0; c < kPruneStatCopies; c++) {
         for (uint32_t k = 0; k < 8; k++) out[k] += h[c * 8 + k];
         for (uint32_t k = 0; k < 2; k++) out[8 + k] += h[(kPruneStatCopies + c) * 8 + k];
         for (uint32_t k = 0; k < 3; k++) out[10 + k] += h[(2 * kPruneStatCopies + c) * 8 + k];  // the fine bounds pass
+        out[13] += h[(3 * kPruneStatCopies + c) * 8 + 0];  // the records path: records,
+        out[14] += h[(3 * kPruneStatCopies + c) * 8 + 1];  // queries,
+        out[15] += h[(3 * kPruneStatCopies + c) * 8 + 3];  // queries whose boundary entries did not fit LDS (slow path)
     }
     return RTX_OK;
 }

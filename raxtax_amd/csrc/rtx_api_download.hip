@@ -203,11 +203,14 @@ int rtx_batch_download(rtx_index *ix, rtx_result_view *out) {
             RTX_HIP(hipMemcpy(&cursor, ix->d_cursor.p, 8, hipMemcpyDeviceToHost));
             if (flags & 2u) { set_error("lineage walk exceeded its row/depth bounds (internal error)"); return RTX_ERR_HIP; }
             if (!(flags & 1u)) break;
-            if (attempt >= 2) { set_error("result arena overflow persists"); return RTX_ERR_HIP; }
+            if (attempt >= 5) { set_error("result arena overflow persists"); return RTX_ERR_HIP; }
             // arena too small: grow to what this run asked for and repeat the (deterministic) run
             // (+ what the sub-allocators of the walk may leave unused on top of this run's share: their holes differ from run to run, and an
             // arena cut to this run's cursor overflowed again on every other step of the same batch -- 3.3 instead of 4.5 M queries/s on real barcodes)
-            const uint64_t want = cursor + 4096 + (uint64_t)(ix->n_sub_run ? ix->n_sub_run : 1u) * kWalkSubAllocs * kWalkChunkRows;
+            // and at least half as much again as the arena that overflowed: walks that find their sub-allocator's piece used up at the
+            // same moment each take a fresh one, so the holes of a launch are not bounded by the number of sub-allocators
+            const uint64_t want = std::max<uint64_t>(cursor + 4096 + (uint64_t)(ix->n_sub_run ? ix->n_sub_run : 1u) * kWalkSubAllocs * kWalkChunkRows,
+                                                     ix->arena_cap + ix->arena_cap / 2);
             if ((rc = ix->d_arena.alloc(want))) return rc;
             ix->arena_cap = want;
             if (ix->n_refs != ix->n_total) {  // a sharded run is driven by the caller: ask it to repeat

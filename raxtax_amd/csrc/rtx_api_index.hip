@@ -644,6 +644,15 @@ int rtx_index_set_option(rtx_index *index, int option, uint64_t value) {
         case RTX_OPT_FINE_BOUNDS:
             index->fine_opt = value ? 1u : 0u;
             return RTX_OK;
+        case RTX_OPT_OVERLAP:
+            index->uploaded = index->ran = index->synced = false;  // shapes the workspace (a second scratch set)
+            index->overlap_opt = value ? 1u : 0u;
+            return RTX_OK;
+        case RTX_OPT_RECORDS:
+            if (value > kRecMaxSlots) break;
+            index->uploaded = index->ran = index->synced = false;  // shapes the workspace
+            index->rec_opt = (uint32_t)value;
+            return RTX_OK;
         case RTX_OPT_PROB_MODE:
             if (value > 2) break;
             index->prob_mode = (int)value;

@@ -494,6 +494,184 @@ __device__ __forceinline__ void hit_epilogue_x(const HitParams &p, uint32_t (&pl
 }
 
 // ---------------------------------------------------------------------------
+// The RECORDS epilogue (RecordRef, rtx_kernels.hpp): a pruned query (threshold u = h_thr > 0) on the records path leaves this tile
+// nothing but the references with a count ABOVE u, as (local reference | count << 13) in reference order in segment `slot` of the
+// query, plus what the dense epilogue leaves a pruned query elsewhere: the histogram above u (everything else in bin 0), the tile's
+// largest count, a cleared live bit if nothing is above u.  The comparison runs on the bit planes (count > u: 3 operations per plane
+// and word); only the groups of eight references that hold a candidate are unpacked -- on the bench workload one or two of the 16
+// groups of a lane, in a handful of lanes (the query's own species), where the dense epilogue unpacks, packs and stores 8192 counts.
+//   count = dense part (planes) + sparse part (byte counters, at most smax): candidates = dense > u - smax, then the exact test.
+// Reference order: group g, lane l, reference j <-> local reference (g * L + l) * 8 + j (ref_slot): ascending in (g, l, j).
+// ---------------------------------------------------------------------------
+template <int NP>
+__device__ __forceinline__ uint32_t planes_gt(const uint32_t (&pl)[NP], uint32_t c) {  // bit r: counter r of the word > c (c < 2^NP)
+    uint32_t gt = 0, eq = 0xFFFFFFFFu;
+#pragma unroll
+    for (int b = NP - 1; b >= 0; b--) {
+        const uint32_t cb = (c >> b) & 1u ? 0xFFFFFFFFu : 0u;  // scalar
+        gt |= eq & pl[b] & ~cb;
+        eq &= ~(pl[b] ^ cb);
+    }
+    return gt;
+}
+
+// raxtax.rs:65-68 on the bit planes: the counters of this query's exact matches in this tile are cleared (the dense part)
+template <int NP>
+__device__ __forceinline__ void zero_exact_dense(const HitParams &p, uint32_t (&pl)[4][NP], uint32_t q, uint32_t tile, uint32_t lane, uint32_t L) {
+    const uint64_t qin = p.perm[p.q0 + q];
+    uint64_t e0, e1;
+    const uint32_t *xids;
+    exact_range(p.exact, qin, e0, e1, xids);
+    for (uint64_t e = e0; e < e1; e++) {
+        const uint32_t id = xids[e] - p.ref_base;  // local id; other shards' ids wrap out of range
+        if (id < p.n_refs && (id >> 13) == tile) {
+            const uint32_t c = (id & 8191u) >> 3, g = c / L;
+            if (c - g * L == lane) {
+                const uint32_t w = g >> 2, msk = ~(1u << ((g & 3u) * 8u + (id & 7u)));
+#pragma unroll
+                for (int ww = 0; ww < 4; ww++)
+                    if ((uint32_t)ww == w) {
+#pragma unroll
+                        for (int b = 0; b < NP; b++) pl[ww][b] &= msk;
+                    }
+            }
+        }
+    }
+}
+
+template <int NP>
+__device__ __forceinline__ void rec_epilogue(const HitParams &p, uint32_t (&pl)[4][NP], uint32_t q, uint32_t tile, uint32_t lane, uint32_t t,
+                                             bool active, uint32_t *hist_lds, uint32_t *cnt8, uint32_t ns, uint4 (&pre)[kSparseIt][kSparseV],
+                                             uint32_t h_thr, uint32_t slot, uint32_t rec_stride) {
+    const bool lists = ns != 0u;  // wave-uniform
+    const uint32_t L = tile_lanes(p.stride_bytes, tile);
+    const bool skip_exact = (p.flags & RTX_SKIP_EXACT_MATCHES) != 0u;
+    uint32_t smax = 0;
+    if (lists) {  // the hits through sparse segments of the whole tile -> 8192 byte counters (as the dense epilogue of a full tile)
+#pragma unroll
+        for (int i = 0; i < 8; i++) reinterpret_cast<uint4 *>(cnt8)[i * 64 + lane] = make_uint4(0, 0, 0, 0);
+        cnt8[2048u + lane] = 0;
+        wave_lds_sync();
+#pragma unroll
+        for (int it = 0; it < kSparseIt; it++)
+            if ((uint32_t)it * 64u < ns) {  // wave-uniform
+#pragma unroll
+                for (int i = 0; i < kSparseV; i++) {
+                    const uint32_t wv[4] = {pre[it][i].x, pre[it][i].y, pre[it][i].z, pre[it][i].w};
+#pragma unroll
+                    for (int j = 0; j < 8; j++) {
+                        const uint32_t id = (wv[j >> 1] >> ((j & 1) * 16)) & 0xFFFFu;  // >= kSegPad: unused entry -> the pad words
+                        atomicAdd(&cnt8[id >> 2], 1u << ((id & 3u) * 8u));
+                    }
+                }
+            }
+        wave_lds_sync();
+        if (skip_exact) {  // raxtax.rs:65-68: the sparse part
+            const uint64_t qin = p.perm[p.q0 + q];
+            uint64_t e0, e1;
+            const uint32_t *xids;
+            exact_range(p.exact, qin, e0, e1, xids);
+            for (uint64_t e = e0 + lane; e < e1; e += 64) {
+                const uint32_t id = xids[e] - p.ref_base;
+                if (id < p.n_refs && (id >> 13) == tile) reinterpret_cast<uint8_t *>(cnt8)[id & 8191u] = 0;
+            }
+            wave_lds_sync();
+        }
+        uint32_t orw = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const uint4 v = reinterpret_cast<const uint4 *>(cnt8)[i * 64 + lane];
+            orw |= (v.x | v.y) | (v.z | v.w);
+        }
+        orw |= orw >> 16;
+        smax = wave_max_u32((orw | (orw >> 8)) & 0xFFu);  // at least every byte counter of the tile
+    }
+    if (active && skip_exact) zero_exact_dense<NP>(p, pl, q, tile, lane, L);
+    // candidates: a count above u needs a dense part above u - smax; with smax > u (never seen: a reference in more than u sparse
+    // segments) every reference is one
+    uint32_t gt[4];
+    {
+        const bool all = smax > h_thr;  // wave-uniform
+        const uint32_t c = all ? 0u : h_thr - smax;
+#pragma unroll
+        for (int w = 0; w < 4; w++) gt[w] = !active ? 0u : (all ? 0xFFFFFFFFu : planes_gt<NP>(pl[w], c));
+    }
+    const uint32_t in_tile = (((uint64_t)tile + 1u) << 13) <= p.n_refs ? 8192u : (uint32_t)(p.n_refs - ((uint64_t)tile << 13));
+    uint32_t *hist = p.hist + (size_t)q * p.hstride;
+    uint32_t running = 0;  // wave-uniform: records written so far
+    uint32_t mx = 0;
+    if (__ballot((gt[0] | gt[1]) | (gt[2] | gt[3])) != 0ull) {
+        for (uint32_t i = lane; i <= t; i += 64) hist_lds[i] = 0;
+        wave_lds_sync();
+        uint32_t *seg = p.rec.rec + ((size_t)q * rec_stride + slot) * 8192u;
+#pragma unroll
+        for (int g = 0; g < 16; g++) {
+            const int w = g >> 2, g2 = g & 3;
+            const uint32_t cand = (gt[w] >> (8 * g2)) & 0xFFu;
+            if (__ballot(cand != 0u) == 0ull) continue;  // wave-uniform: no lane holds a candidate in this group
+            uint32_t lo0, hi0, lo1, hi1;
+            planes_unpack8<NP>(pl[w], g2, lo0, hi0, lo1, hi1);
+            uint32_t cw[4];  // the eight counts as u16 pairs
+            cw[0] = __builtin_amdgcn_perm(hi0, lo0, 0x05010400u);
+            cw[1] = __builtin_amdgcn_perm(hi0, lo0, 0x07030602u);
+            cw[2] = __builtin_amdgcn_perm(hi1, lo1, 0x05010400u);
+            cw[3] = __builtin_amdgcn_perm(hi1, lo1, 0x07030602u);
+            if (lists) {
+                const uint2 sb = *reinterpret_cast<const uint2 *>(cnt8 + (((uint32_t)g * 64u + lane) * 2u));
+                cw[0] += __builtin_amdgcn_perm(0u, sb.x, 0x0C010C00u);
+                cw[1] += __builtin_amdgcn_perm(0u, sb.x, 0x0C030C02u);
+                cw[2] += __builtin_amdgcn_perm(0u, sb.y, 0x0C010C00u);
+                cw[3] += __builtin_amdgcn_perm(0u, sb.y, 0x0C030C02u);
+            }
+            const uint32_t rl0 = ((uint32_t)g * L + lane) * 8u;  // local reference of j = 0
+            uint32_t m8 = 0;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const uint32_t c = (cw[j >> 1] >> ((j & 1) * 16)) & 0xFFFFu;
+                if (c > h_thr && rl0 + (uint32_t)j < in_tile) m8 |= 1u << j;
+            }
+            if (!active) m8 = 0;
+            const uint32_t n8 = (uint32_t)__popc(m8);
+            const uint32_t incl = wave_incl_scan_u32(n8);
+            uint32_t pos = running + incl - n8;
+#pragma unroll
+            for (int j = 0; j < 8; j++)
+                if (m8 & (1u << j)) {
+                    const uint32_t c = (cw[j >> 1] >> ((j & 1) * 16)) & 0xFFFFu;
+                    seg[pos++] = (rl0 + (uint32_t)j) | (c << 13);
+                    atomicAdd(&hist_lds[c], 1u);
+                }
+            running += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        }
+        wave_lds_sync();
+        for (uint32_t m = lane; m <= t; m += 64) {  // only bins above u can be non-empty
+            const uint32_t v = hist_lds[m];
+            if (v) { atomicAdd(&hist[m], v); mx = m; }
+        }
+    }
+    if (lane == 0u) {
+        atomicAdd(&hist[0], in_tile - running);  // the references of the tile with a count up to the threshold
+        p.rec.cnt[(size_t)q * kRecMaxSlots + slot] = running;
+        if (running == 0u)  // nothing of this tile can reach the result: as if it had never been counted
+            atomicAnd(const_cast<uint32_t *>(p.live) + (size_t)q * p.live_words + (tile >> 5), ~(1u << (tile & 31u)));
+    }
+    if (p.tile_max) {
+        mx = wave_max_u32(mx);
+        if (lane == 0) p.tile_max[(size_t)q * p.ntiles + tile] = (uint16_t)mx;
+    }
+}
+
+// slot of `tile` among the record segments of query q (RecordRef), or 0xFFFFFFFF: the query takes the dense epilogue
+__device__ __forceinline__ uint32_t rec_slot_of(const HitParams &p, uint32_t q, uint32_t tile, uint32_t lane) {
+    if (!p.rec.nslots) return 0xFFFFFFFFu;
+    const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)p.rec.nslots[q]);
+    if (n == 0u) return 0xFFFFFFFFu;
+    const uint32_t v = lane < n ? (uint32_t)p.rec.slots[(size_t)q * kRecMaxSlots + lane] : 0xFFFFFFFFu;
+    const unsigned long long b = __ballot(v == tile);
+    return b ? (uint32_t)__builtin_ctzll(b) : 0xFFFFFFFFu;
+}
+
+// ---------------------------------------------------------------------------
 // Epilogue of the BOUNDS pass of the tile pruning (rtx_prune.hip): the "references" of this launch are blocks of 2^kPruneShift
 // references of the database (the union bitmap), a count is an upper bound of the counts of the block's members.  Nothing is stored
 // per block: what prune_kernel needs is the largest bound of every tile of the DATABASE (8192 >> kPruneShift blocks: with blocks of 64

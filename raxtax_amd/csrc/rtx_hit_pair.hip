@@ -290,10 +290,18 @@ __device__ __forceinline__ void pair_tile_block(const HitParams &p, uint32_t *ld
     auto thr_of = [&](uint32_t q) -> uint32_t { return p.prune_thr ? (uint32_t)__builtin_amdgcn_readfirstlane((int)p.prune_thr[q]) : 0u; };
     if (ns_a) sparse_prefetch(p, lane, ns_a, l_sid, pre_a);
     if (ns_b) sparse_prefetch(p, lane, ns_b, l_sid + kSparseIt * 64u, pre_b);
-    if (has_a) hit_epilogue_x<NP, kPacked, true, true, true>(p, pa, qa, tile, lane, p.t[qa], active, hist_lds, cnt8, ns_a, srows_a, pre_a, thr_of(qa));
+    // a query on the records path (RecordRef: pruned, few live tiles) leaves (reference, count) records of the counts above its threshold
+    // instead of 8192 counts
+    if (has_a) {
+        const uint32_t ka = rec_slot_of(p, qa, tile, lane);
+        if (ka != 0xFFFFFFFFu) rec_epilogue<NP>(p, pa, qa, tile, lane, p.t[qa], active, hist_lds, cnt8, ns_a, pre_a, thr_of(qa), ka, p.rec.stride);
+        else hit_epilogue_x<NP, kPacked, true, true, true>(p, pa, qa, tile, lane, p.t[qa], active, hist_lds, cnt8, ns_a, srows_a, pre_a, thr_of(qa));
+    }
     if (has_b) {
         wave_lds_sync();
-        hit_epilogue_x<NP, kPacked, true, true, true>(p, pb, qb, tile, lane, p.t[qb], active, hist_lds, cnt8, ns_b, srows_b, pre_b, thr_of(qb));
+        const uint32_t kb = rec_slot_of(p, qb, tile, lane);
+        if (kb != 0xFFFFFFFFu) rec_epilogue<NP>(p, pb, qb, tile, lane, p.t[qb], active, hist_lds, cnt8, ns_b, pre_b, thr_of(qb), kb, p.rec.stride);
+        else hit_epilogue_x<NP, kPacked, true, true, true>(p, pb, qb, tile, lane, p.t[qb], active, hist_lds, cnt8, ns_b, srows_b, pre_b, thr_of(qb));
     }
 }
 

@@ -178,6 +178,12 @@ struct rtx_index {
     uint32_t f_stride_bytes = 0, f_ntiles = 0;
     uint64_t f_nblocks = 0;
     uint32_t fine_opt = 1;  // RTX_OPT_FINE_BOUNDS
+    uint32_t rec_opt = 4;   // RTX_OPT_RECORDS: pruned queries with at most this many live tiles take the records path (0: off; at most kRecMaxSlots)
+    uint32_t overlap_opt = 0;  // RTX_OPT_OVERLAP: back half of sub-batch k on a second stream beside the front half of k + 1
+    bool overlap_used = false;
+    hipStream_t stream2 = nullptr;
+    std::vector<hipEvent_t> ev_front, ev_back;  // per sub-batch: front half enqueued (on stream), back half done (on stream2)
+    bool rec_used = false;  // the last run offered the records path (whole-database handle that prunes, walk fused)
     DevBuf<unsigned long long> d_prune_stats;
     uint32_t shard_prune_opt = 0;  // RTX_OPT_SHARD_PRUNE: a reference shard prunes with the threshold of the whole database (rtx_shard_bounds)
     uint32_t debug_taps = 0;     // RTX_OPT_DEBUG_TAPS: prune_kernel leaves its view of every query (rtx_debug_prune_detail)
@@ -234,6 +240,9 @@ struct rtx_index {
         DevBuf<uint16_t> d_tile_ub, d_prune_thr, d_prune_i1;
         DevBuf<uint32_t> d_best;  // [B][kPruneBestWords] reference shards: the candidate for the best block of the database
         DevBuf<uint32_t> d_fine_items;  // fine bounds pass: [pairs x f_ntiles] items | [9] number + XCD queues | [f_ntiles] cursors
+        // the records path (RecordRef, rtx_kernels.hpp): per query the live tiles at prune time, the records of each, their number
+        DevBuf<uint16_t> d_rec_nslots, d_rec_slots;
+        DevBuf<uint32_t> d_rec_cnt, d_rec;
     } sc[2];
     bool staged = false;  // driven with rtx_shard_*: sub-batch sb works in scratch set sb & 1, so that the exchange of one
                           // sub-batch (RCCL, on the caller's stream) can overlap with the counting of the next
@@ -285,6 +294,9 @@ struct rtx_index {
     ~rtx_index() {
         for (auto e : events) (void)hipEventDestroy(e);
         for (auto e : ev_sub) (void)hipEventDestroy(e);
+        for (auto e : ev_front) (void)hipEventDestroy(e);
+        for (auto e : ev_back) (void)hipEventDestroy(e);
+        if (stream2) (void)hipStreamDestroy(stream2);
         for (auto &i : in)
             if (i.ready) (void)hipEventDestroy(i.ready);
         if (ev_activated) (void)hipEventDestroy(ev_activated);

@@ -112,6 +112,22 @@ struct KmerParams {
     uint32_t live_words;
 };
 
+// The RECORDS path (round 5).  A pruned query (threshold u) only ever needs its references with a count ABOVE u: everything else is
+// a reference without a hit to prob_lookup and to the lineage walk.  For a query that prune_kernel leaves at most kRecMaxSlots live
+// tiles, the epilogue of hit_count compares the bit planes with u and writes nothing but (reference, count) RECORDS -- no unpacking of
+// 8192 counts, no count stores -- in reference order into the segment of its tile; records_tail_kernel (rtx_records.hip) turns them
+// into prefix sums at the handful of taxonomy boundaries they touch and walks the lineage from LDS, in the place of taxon_prefix's
+// sweeps over whole tiles.  slot k of query q <-> tile slots[q][k] (ascending), segment rec[(q * stride + k) * 8192 ..], cnt[q][k]
+// records, record = local reference (13 bits) | count << 13.
+constexpr uint32_t kRecMaxSlots = 16;
+struct RecordRef {
+    uint16_t *nslots;   // [B] live tiles of the query at prune time; 0: the query takes the dense path
+    uint16_t *slots;    // [B][kRecMaxSlots] their tiles, ascending
+    uint32_t *cnt;      // [B][kRecMaxSlots] records per segment (zeroed by prune_kernel)
+    uint32_t *rec;      // [B][stride][8192]
+    uint32_t stride;    // segments per query (the largest number of live tiles that still takes the path: RTX_OPT_RECORDS)
+};
+
 struct HitParams {
     const uint32_t *bitmap;   // tile-major: [tile][n_rows1][256 words] (rtx_math.hpp: bitmap_word)
     uint32_t n_rows1;         // rows per tile region (the last one is all zero)
@@ -163,6 +179,7 @@ struct HitParams {
     uint64_t fine_n_refs;         // references of the database (n_refs counts blocks in a bounds pass)
     uint32_t fine_ref_ntiles;     // tiles of the database
     unsigned long long *fine_stats;  // [kPruneStatCopies][8]: [0] += (query, tile) combinations cleared, [1] += blocks of the fine pass, or null
+    RecordRef rec;                // the records path of pruned queries (above); rec.nslots == null: every epilogue is the dense one
 };
 constexpr uint32_t kFineShift = 3;       // blocks of 8 references: the 8 references of one byte of a bitmap row (ref_slot)
 constexpr uint32_t kFineMinLive = 4;     // pairs with fewer live tiles than this skip the fine pass (a block of it costs what it can save there)
@@ -211,6 +228,8 @@ struct PruneParams {
     unsigned long long *stats;  // [kPruneStatCopies][8]: [0] += live tiles, [1] += pairs ... (reporting) or null
     uint32_t *detail;           // [B][kPruneDetailWords] debug tap (RTX_OPT_DEBUG_TAPS) or null: {best block, M, threshold, i* + 1, largest
                                 // bound, t, 0, 0, exact counts of the 64 references of the best block}
+    RecordRef rec;              // rec.nslots != null: queries with a threshold and at most rec_max_slots live tiles take the records path
+    uint32_t rec_max_slots;
 };
 constexpr uint32_t kPruneDetailWords = 72;
 struct ProbTables;
@@ -293,8 +312,26 @@ struct PrefixParams {
     unsigned long long *prune_stats;  // reporting (second half of PruneParams::stats) or null
     uint32_t fuse_walk;         // wave 0 of every workgroup walks its query right after the sweeps (walk.prefix == prefix)
     WalkParams walk;
+    const uint16_t *rec_nslots; // [B] records path (RecordRef::nslots): a query with slots is left to records_tail_kernel; or null
 };
 
+
+// records_tail_kernel (rtx_records.hip): the queries of a sub-batch on the records path, after prob_lookup
+struct TailParams {
+    RecordRef rec;
+    const uint32_t *t;          // [B]
+    const double *table_z;      // [B][hstride] table / Z (prob_lookup)
+    uint32_t hstride;
+    const uint8_t *bnd_bits;    // as PrefixParams
+    const uint32_t *bnd_rank;
+    double *prefix;             // [B][n_bnd] scratch row of the query: only the slow path (more boundary intervals than fit LDS) writes it
+    uint32_t n_bnd;
+    uint32_t nq;
+    WalkParams walk;
+    unsigned long long *prefix_stats;  // PrefixParams::prune_stats (the same two counters, for the queries this kernel takes) or null
+    unsigned long long *stats;  // [kPruneStatCopies][8] reporting: [0] += records, [1] += queries on the path, [2] += boundary entries, [3] += slow-path queries; or null
+};
+void launch_records_tail(hipStream_t s, const TailParams &p, uint32_t nq);
 
 void launch_bitmap_build(hipStream_t s, const uint64_t *off, const uint32_t *post, const uint32_t *row_of,
                          uint32_t *bitmap, uint32_t stride_words, uint32_t n_rows1, uint32_t ref_lo, uint32_t ref_hi, uint32_t shift = 0);

@@ -403,6 +403,7 @@ __global__ __launch_bounds__(64 * kPruneWavesPerBlock, RTX_PRUNE_WAVES) void pru
     // tile is live, and leaves at once where neither is), the references never counted
     unsigned long long dead_refs[2] = {0, 0};
     uint32_t n_live = 0, n_qlive = 0;
+    uint32_t n_rec[2] = {0u, 0u};  // wave-uniform: live tiles of either query
     for (uint32_t T0 = 0; T0 < p.ntiles; T0 += 64) {
         const uint32_t T = T0 + lane;
         bool la = false, lb = false;
@@ -427,8 +428,28 @@ __global__ __launch_bounds__(64 * kPruneWavesPerBlock, RTX_PRUNE_WAVES) void pru
             if (!la) dead_refs[0] += hi - lo;
             if (!lb) dead_refs[1] += hi - lo;
         }
+        if (p.rec.nslots) {  // the records path: the live tiles of either query in ascending order (the segments of its records, RecordRef)
+            const unsigned long long lt = (1ull << lane) - 1ull;
+            const uint32_t ka = n_rec[0] + (uint32_t)__popcll(ba & lt), kb = n_rec[1] + (uint32_t)__popcll(bb2 & lt);
+            if (la && ka < kRecMaxSlots) p.rec.slots[(size_t)(pair * 2u) * kRecMaxSlots + ka] = (uint16_t)T;
+            if (lb && kb < kRecMaxSlots) p.rec.slots[(size_t)(pair * 2u + 1u) * kRecMaxSlots + kb] = (uint16_t)T;
+            n_rec[0] += (uint32_t)__popcll(ba);
+            n_rec[1] += (uint32_t)__popcll(bb2);
+        }
         n_live += (uint32_t)__popcll(ba | bb2);
         n_qlive += (uint32_t)__popcll(ba) + (uint32_t)__popcll(bb2);
+    }
+    if (p.rec.nslots) {  // a query with a threshold and few live tiles: hit_count writes records, records_tail_kernel reads them
+        const uint32_t cap = p.rec_max_slots < kRecMaxSlots ? p.rec_max_slots : kRecMaxSlots;
+        const bool ra = thr[0] != 0u && n_rec[0] != 0u && n_rec[0] <= cap, rb = has_b && thr[1] != 0u && n_rec[1] != 0u && n_rec[1] <= cap;
+        if (lane < kRecMaxSlots) {
+            p.rec.cnt[(size_t)(pair * 2u) * kRecMaxSlots + lane] = 0u;
+            if (has_b) p.rec.cnt[(size_t)(pair * 2u + 1u) * kRecMaxSlots + lane] = 0u;
+        }
+        if (lane == 0) {
+            p.rec.nslots[pair * 2u] = (uint16_t)(ra ? n_rec[0] : 0u);
+            if (has_b) p.rec.nslots[pair * 2u + 1u] = (uint16_t)(rb ? n_rec[1] : 0u);
+        }
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) { dead_refs[0] += __shfl_xor(dead_refs[0], d, 64); dead_refs[1] += __shfl_xor(dead_refs[1], d, 64); }

@@ -225,9 +225,11 @@ int rtx_index_set_batch(rtx_index *index, uint32_t sub_batch);
                             * lineage.rs:61-77 at the few taxonomy boundaries they touch and walks the lineage (rtx_records.hip) in the place
                             * of taxon_prefix's sweeps.  Same thresholds, same probabilities; 0: every query takes the dense epilogue.
                             * Shapes the workspace like the options below. */
-#define RTX_OPT_OVERLAP 19 /* 0 / 1: the back half of sub-batch k (prob_lookup, taxon_prefix + walk, records tail: chains of dependent round trips)
-                            * runs on a second HIP stream beside the front half of sub-batch k + 1 (bounds, counting: VALU and L1 rate);
-                            * two scratch sets alternate.  Same results.  Whole-database handles; shapes the workspace. */
+#define RTX_OPT_OVERLAP 19 /* 1 (default): the back half of sub-batch k (prob_lookup, taxon_prefix + walk, records tail: chains of dependent round
+                            * trips) runs on a second HIP stream beside the front half of sub-batch k + 1 (bounds, counting: VALU and L1
+                            * rate); two scratch sets alternate -- taken only if the second one fits free HBM without shrinking the sub-batch.
+                            * 2: three stages (bounds | threshold + counting | back half; measured: no faster than two).  0: one stream.
+                            * Same results.  Whole-database handles; shapes the workspace. */
 /* RTX_OPT_SUB_BATCH, _PACKED_COUNTS, _HIT_PAIR, _TILE_PRUNE and _PROB_MODE shape the workspace that rtx_batch_upload sizes:
  * setting one of them drops the uploaded batch (rtx_batch_run then fails with RTX_ERR_STATE until the batch is uploaded again). */
 int rtx_index_set_option(rtx_index *index, int option, uint64_t value);

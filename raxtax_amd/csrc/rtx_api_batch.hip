@@ -98,7 +98,7 @@ int enqueue_kmer(rtx_index *ix, const SubBatch &b, hipStream_t s) {
 
 // part 0: everything.  A reference shard that prunes stops in the middle for the exchange of the best blocks: part 1 = up to the
 // candidates (bounds pass, prune_kernel phase 1), part 2 = the rest (prune_kernel phase 2, lists of the live tiles, counting).
-int enqueue_hit(rtx_index *ix, const SubBatch &b, uint32_t flags, hipStream_t s, int part) {
+int enqueue_hit(rtx_index *ix, const SubBatch &b, uint32_t flags, hipStream_t s, int part, hipStream_t s_mid) {
     rtx_index::Scratch &sc = ix->sc[b.set];
     ix->last_set = b.set;
     HitParams hp{};
@@ -172,6 +172,11 @@ int enqueue_hit(rtx_index *ix, const SubBatch &b, uint32_t flags, hipStream_t s,
             RTX_HIP(hipMemsetAsync(sc.d_best_key.p, 0, (size_t)b.nq * 4, s));  // the waves of a query's union tiles meet in an atomicMax
             launch_hit_count_pair_bounds(s, up, b.nq, ix->u_ntiles, ix->planes);  // the union of the pair's rows serves both passes
             if (b.timed) RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_TILE_BOUNDS, 1), s));
+        }
+        if (s_mid && s_mid != s && part == 0) {  // RTX_OPT_OVERLAP = 2: threshold, lists and counting go on on a stream of their own
+            RTX_HIP(hipEventRecord(ix->ev_mid[b.sb], s));
+            RTX_HIP(hipStreamWaitEvent(s_mid, ix->ev_mid[b.sb], 0));
+            s = s_mid;
         }
         if (b.timed && part != 1) RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_TILE_PRUNE, 0), s));
         // (2) bounds per tile, a lower bound of the best hit, the threshold, the live tiles of every pair
@@ -267,12 +272,13 @@ int enqueue_hit(rtx_index *ix, const SubBatch &b, uint32_t flags, hipStream_t s,
     if (ix->pair_used) launch_hit_count_pair(s, hp, b.nq, ix->ntiles, ix->planes);
     else launch_hit_count(s, hp, b.nq, ix->ntiles, ix->planes);
     if (b.timed) RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_HIT_COUNT, 1), s));
+    ix->hit_stream = s;
     return RTX_OK;
 }
 
-int enqueue_count(rtx_index *ix, const SubBatch &b, uint32_t flags) {
+int enqueue_count(rtx_index *ix, const SubBatch &b, uint32_t flags, hipStream_t s_mid) {
     int rc = enqueue_kmer(ix, b, b.s);
-    return rc ? rc : enqueue_hit(ix, b, flags, b.s);
+    return rc ? rc : enqueue_hit(ix, b, flags, b.s, 0, s_mid);
 }
 
 static WalkParams walk_params(rtx_index *ix, const SubBatch &b, const double *prefix);
@@ -475,7 +481,11 @@ int begin_run(rtx_index *ix, uint32_t *n_sub_out, bool *timed_out, bool cluster)
         RTX_HIP(hipMemsetAsync(ix->d_group_rows.p, 0, (size_t)2 * n_sub * ix->groups_per_sub * 4, ix->stream));
     }
     ix->n_sub_last = timed ? n_sub : 0;
-    ix->overlap_used = ix->overlap_opt != 0u && whole && n_sub >= 2 && ix->sc[1].d_kmers.p != nullptr && scratch_ok(ix->sc[1]) == scratch_ok(ix->sc[0]);
+    ix->overlap_used = 0;  // scratch sets in use beside each other (RTX_OPT_OVERLAP)
+    if (ix->overlap_opt != 0u && whole && n_sub >= 2 && ix->sc[1].d_kmers.p != nullptr && scratch_ok(ix->sc[1]) == scratch_ok(ix->sc[0])) {
+        ix->overlap_used = 2;
+        if (ix->overlap_opt >= 2u && n_sub >= 3 && ix->sc[2].d_kmers.p != nullptr && scratch_ok(ix->sc[2]) == scratch_ok(ix->sc[0])) ix->overlap_used = 3;
+    }
     if (ix->dev_exact_used) {  // Tree.sequences.get for every query of the batch (raxtax.rs:42), part of the run
         ExactParams xp{ix->d_bases.p, ix->in[ix->cur_in].d_base_off.p, (uint32_t)ix->n_q, ix->d_em_table.p, ix->em_bits, ix->d_em_rep_off.p,
                        ix->d_em_rep_bytes.p, ix->d_exact_grp.p, ix->em_hash_mask};
@@ -519,26 +529,30 @@ int enqueue_batch(rtx_index *ix, uint32_t flags) {
     // RTX_OPT_OVERLAP: the back half of sub-batch k (prob_lookup, taxon_prefix / records tail: chains of dependent round trips) on a second
     // stream beside the front half of sub-batch k + 1 (bounds and counting: VALU and L1 rate); two scratch sets alternate (sb & 1), a
     // front half waits for the back half that last used its set.
-    const bool overlap = ix->overlap_used;
+    const uint32_t nsets = ix->overlap_used;  // 0: one stream; 2: two stages, two scratch sets; 3: front | threshold + counting | back
+    const bool overlap = nsets != 0u;
     if (overlap) {
         if (!ix->stream2) RTX_HIP(hipStreamCreateWithFlags(&ix->stream2, hipStreamNonBlocking));
+        if (nsets == 3u && !ix->stream3) RTX_HIP(hipStreamCreateWithFlags(&ix->stream3, hipStreamNonBlocking));
         while (ix->ev_front.size() < n_sub) {
-            hipEvent_t e, f;
+            hipEvent_t e, f, g;
             RTX_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
             RTX_HIP(hipEventCreateWithFlags(&f, hipEventDisableTiming));
+            RTX_HIP(hipEventCreateWithFlags(&g, hipEventDisableTiming));
             ix->ev_front.push_back(e);
             ix->ev_back.push_back(f);
+            ix->ev_mid.push_back(g);
         }
     }
     for (uint32_t sb = 0; sb < n_sub; sb++) {
         SubBatch b = sub_batch_of(ix, sb, timed);
         if (overlap) {
-            b.set = sb & 1u;
-            if (sb >= 2) RTX_HIP(hipStreamWaitEvent(ix->stream, ix->ev_back[sb - 2], 0));  // the scratch set is free again
+            b.set = sb % nsets;
+            if (sb >= nsets) RTX_HIP(hipStreamWaitEvent(ix->stream, ix->ev_back[sb - nsets], 0));  // the scratch set is free again
         }
-        if ((rc = enqueue_count(ix, b, flags))) return rc;
+        if ((rc = enqueue_count(ix, b, flags, nsets == 3u ? ix->stream3 : nullptr))) return rc;
         if (overlap) {
-            RTX_HIP(hipEventRecord(ix->ev_front[sb], ix->stream));
+            RTX_HIP(hipEventRecord(ix->ev_front[sb], ix->hit_stream));
             b.s = ix->stream2;
             RTX_HIP(hipStreamWaitEvent(b.s, ix->ev_front[sb], 0));
         }
@@ -554,7 +568,7 @@ int enqueue_batch(rtx_index *ix, uint32_t flags) {
         }
         if (overlap) RTX_HIP(hipEventRecord(ix->ev_back[sb], b.s));
     }
-    if (overlap && n_sub) RTX_HIP(hipStreamWaitEvent(ix->stream, ix->ev_back[n_sub - 1], 0));  // a wait for the handle's stream covers both
+    if (overlap && n_sub) RTX_HIP(hipStreamWaitEvent(ix->stream, ix->ev_back[n_sub - 1], 0));  // a wait for the handle's stream covers all of them
     RTX_HIP(hipGetLastError());
     return RTX_OK;
 }
@@ -665,26 +679,36 @@ int prepare_workspace(rtx_index *ix, uint64_t n_queries, uint64_t tmax, uint64_t
                                           (ix->rec_opt && ix->n_refs == ix->n_total ? (uint64_t)std::min<uint32_t>(ix->rec_opt, kRecMaxSlots) * 32768u + kRecMaxSlots * 6u + 2u : 0u) /* record segments */
                                         : 0);
     uint32_t B = ix->sub_batch_req;
-    if (B == 0) {
+    uint32_t n_sets = ix->n_refs == ix->n_total ? 1u + std::min<uint32_t>(ix->overlap_opt, 2u) : 1u;  // RTX_OPT_OVERLAP: two (three) scratch sets
+    {
         size_t free_b = 0, total_b = 0;
         RTX_HIP(hipMemGetInfo(&free_b, &total_b));
         // scratch already held by this handle is reusable
-        const uint64_t held = (ix->sc[0].d_counts.n + ix->sc[1].d_counts.n) * 2 + (ix->sc[0].d_prefix.n + ix->sc[1].d_prefix.n) * 8;
-        const uint64_t budget = (uint64_t)((free_b + held) * 0.6) / (ix->overlap_opt && ix->n_refs == ix->n_total ? 2u : 1u);  // (RTX_OPT_OVERLAP: two scratch sets)
-        B = (uint32_t)std::min<uint64_t>(will_prune ? kDefaultSubBatchPruned : ix->ntiles >= 16 ? kDefaultSubBatchLarge : kDefaultSubBatch,
-                                         std::max<uint64_t>(64, budget / per_q));
-        // at least four sub-batches per batch (of 16 384 queries or more): the records of a finished sub-batch are copied and finalised on
-        // the host while the next ones run, and what is left when the device is done is the last sub-batch -- a chunk of 131 072 queries
-        // (rtx_raxtax) in two halves left 7 ms of host work exposed on real barcodes (ten result rows per query)
-        if (will_prune && n_queries < 4ull * B) B = (uint32_t)std::max<uint64_t>(16384, (n_queries + 3) / 4);
+        uint64_t held = 0;
+        for (const auto &sc : ix->sc) held += sc.d_counts.n * 2 + sc.d_prefix.n * 8 + sc.d_rec.n * 4 + sc.d_srows.n * 4;
+        const uint64_t budget = (uint64_t)((free_b + held) * 0.6);
+        if (B == 0) {
+            B = (uint32_t)std::min<uint64_t>(will_prune ? kDefaultSubBatchPruned : ix->ntiles >= 16 ? kDefaultSubBatchLarge : kDefaultSubBatch,
+                                             std::max<uint64_t>(64, budget / per_q));
+            // at least four sub-batches per batch (of 16 384 queries or more): the records of a finished sub-batch are copied and finalised on
+            // the host while the next ones run, and what is left when the device is done is the last sub-batch -- a chunk of 131 072 queries
+            // (rtx_raxtax) in two halves left 7 ms of host work exposed on real barcodes (ten result rows per query)
+            if (will_prune && n_queries < 4ull * B) B = (uint32_t)std::max<uint64_t>(16384, (n_queries + 3) / 4);
+        }
+        if (B > kMaxSubBatch) B = kMaxSubBatch;
+        B = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(B, n_queries));
+        // the further sets of the overlap never shrink a sub-batch: they are taken only while they fit the budget beside the first
+        while (n_sets > 1u && (uint64_t)n_sets * B * per_q > budget) n_sets--;
     }
-    if (B > kMaxSubBatch) B = kMaxSubBatch;
-    B = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(B, n_queries));
     ix->sub_batch = B;
     ix->staged = false;
     if ((rc = alloc_scratch_set(ix, 0))) return rc;
-    if (ix->overlap_opt && ix->n_refs == ix->n_total && alloc_scratch_set(ix, 1)) {  // (without a second set the run stays on one stream)
-        ix->sc[1].d_kmers.release();
+    for (uint32_t k = 1; k <= 2u; k++) {  // (without the further sets the run stays on one stream)
+        if (k < n_sets && n_queries > B) {
+            if (alloc_scratch_set(ix, k)) ix->sc[k].d_kmers.release();
+        } else {
+            if (ix->n_refs == ix->n_total) ix->sc[k].release_all();  // none wanted on a whole-database handle: given back (a shard keeps its second set for rtx_shard_begin)
+        }
     }
     std::memcpy(ix->ws_key, key, sizeof key);
     ix->ws_valid = true;

@@ -646,7 +646,8 @@ int rtx_index_set_option(rtx_index *index, int option, uint64_t value) {
             return RTX_OK;
         case RTX_OPT_OVERLAP:
             index->uploaded = index->ran = index->synced = false;  // shapes the workspace (a second scratch set)
-            index->overlap_opt = value ? 1u : 0u;
+            if (value > 2) break;
+            index->overlap_opt = (uint32_t)value;
             return RTX_OK;
         case RTX_OPT_RECORDS:
             if (value > kRecMaxSlots) break;

@@ -179,10 +179,10 @@ struct rtx_index {
     uint64_t f_nblocks = 0;
     uint32_t fine_opt = 1;  // RTX_OPT_FINE_BOUNDS
     uint32_t rec_opt = 4;   // RTX_OPT_RECORDS: pruned queries with at most this many live tiles take the records path (0: off; at most kRecMaxSlots)
-    uint32_t overlap_opt = 0;  // RTX_OPT_OVERLAP: back half of sub-batch k on a second stream beside the front half of k + 1
-    bool overlap_used = false;
-    hipStream_t stream2 = nullptr;
-    std::vector<hipEvent_t> ev_front, ev_back;  // per sub-batch: front half enqueued (on stream), back half done (on stream2)
+    uint32_t overlap_opt = 1;  // RTX_OPT_OVERLAP: 1 = back half of sub-batch k on a second stream beside the front half of k + 1 (2: three stages)
+    uint32_t overlap_used = 0;  // scratch sets the last run used beside each other (0: one stream)
+    hipStream_t stream2 = nullptr, stream3 = nullptr, hit_stream = nullptr;  // (hit_stream: where enqueue_hit launched the counting pass)
+    std::vector<hipEvent_t> ev_front, ev_back, ev_mid;  // per sub-batch: front half enqueued (on stream), back half done (on stream2)
     bool rec_used = false;  // the last run offered the records path (whole-database handle that prunes, walk fused)
     DevBuf<unsigned long long> d_prune_stats;
     uint32_t shard_prune_opt = 0;  // RTX_OPT_SHARD_PRUNE: a reference shard prunes with the threshold of the whole database (rtx_shard_bounds)
@@ -243,7 +243,13 @@ struct rtx_index {
         // the records path (RecordRef, rtx_kernels.hpp): per query the live tiles at prune time, the records of each, their number
         DevBuf<uint16_t> d_rec_nslots, d_rec_slots;
         DevBuf<uint32_t> d_rec_cnt, d_rec;
-    } sc[2];
+        void release_all() {
+            d_kmers.release(); d_counts.release(); d_tilemax.release(); d_rows.release(); d_t.release(); d_nrows.release(); d_hist.release();
+            d_order.release(); d_srows.release(); d_nsparse.release(); d_dmask.release(); d_table_z.release(); d_prefix.release(); d_urec.release();
+            d_nu.release(); d_live.release(); d_best_key.release(); d_items.release(); d_tile_ub.release(); d_prune_thr.release(); d_prune_i1.release();
+            d_best.release(); d_fine_items.release(); d_rec_nslots.release(); d_rec_slots.release(); d_rec_cnt.release(); d_rec.release();
+        }
+    } sc[3];
     bool staged = false;  // driven with rtx_shard_*: sub-batch sb works in scratch set sb & 1, so that the exchange of one
                           // sub-batch (RCCL, on the caller's stream) can overlap with the counting of the next
     uint32_t last_set = 0;  // scratch set of the last sub-batch (debug taps)
@@ -296,7 +302,9 @@ struct rtx_index {
         for (auto e : ev_sub) (void)hipEventDestroy(e);
         for (auto e : ev_front) (void)hipEventDestroy(e);
         for (auto e : ev_back) (void)hipEventDestroy(e);
+        for (auto e : ev_mid) (void)hipEventDestroy(e);
         if (stream2) (void)hipStreamDestroy(stream2);
+        if (stream3) (void)hipStreamDestroy(stream3);
         for (auto &i : in)
             if (i.ready) (void)hipEventDestroy(i.ready);
         if (ev_activated) (void)hipEventDestroy(ev_activated);
@@ -327,8 +335,8 @@ uint16_t *counts_hi(rtx_index *ix, rtx_index::Scratch &sc);
 size_t counts_elems(const rtx_index *ix, uint64_t B);
 hipEvent_t stage_event(rtx_index *ix, const SubBatch &b, int stage, int which);
 int enqueue_kmer(rtx_index *ix, const SubBatch &b, hipStream_t s);
-int enqueue_hit(rtx_index *ix, const SubBatch &b, uint32_t flags, hipStream_t s, int part = 0);
-int enqueue_count(rtx_index *ix, const SubBatch &b, uint32_t flags);
+int enqueue_hit(rtx_index *ix, const SubBatch &b, uint32_t flags, hipStream_t s, int part = 0, hipStream_t s_mid = nullptr);
+int enqueue_count(rtx_index *ix, const SubBatch &b, uint32_t flags, hipStream_t s_mid = nullptr);
 int enqueue_prob_prefix(rtx_index *ix, const SubBatch &b, bool fuse_walk, bool prob_only = false);
 int enqueue_walk(rtx_index *ix, const SubBatch &b, const double *prefix, hipStream_t s);
 int order_batch(rtx_index *ix, bool cluster);

@@ -46,7 +46,7 @@ extern "C" {
 #define RTX_ERR_PARSE (-5)      /* FASTA / lineage annotation error (parser.rs)     */
 #define RTX_ERR_DEPTH (-6)      /* lineage deeper than RTX_MAX_DEPTH                */
 #define RTX_ERR_STATE (-7)      /* call sequence violated (e.g. run before upload)  */
-#define RTX_ERR_TOO_LONG (-8)   /* a query has more than 65535 distinct k-mers (assert at raxtax.rs:56) */
+#define RTX_ERR_TOO_LONG (-8)   /* a query longer than 65 542 bases: it could hold more than 65 535 k-mers (assert at raxtax.rs:56) */
 #define RTX_ERR_SENDER (-9)     /* the result sink refused a message (closed channel, raxtax.rs:87)    */
 
 /* flags of rtx_classify_batch / rtx_batch_run (src/io.rs:119-121,131-133) */
@@ -388,6 +388,16 @@ int rtx_debug_order(rtx_index *index, uint32_t *perm /*n_queries*/);
 /* queries per sub-batch of the uploaded batch and the number of sub-batches: positions [(n_sub - 1) * sub_batch, n_queries) of the
  * processing order are the last sub-batch, the one the taps can read */
 int rtx_batch_sub_batch(const rtx_index *index, uint32_t *sub_batch, uint32_t *n_sub_batches);
+/* A batch is cut into LENGTH CLASSES (t <= 255 / t <= 1023 / longer reads whose probability arrays fit LDS / up to t = 65 535): the class
+ * leads the processing order, every class runs through sub-batches of its own shape (bit planes, pair kernel and tile pruning, memoised
+ * tables or the recurrence kernel), so that one long read does not move a batch of barcodes off the fast path; results come back in
+ * input order.  rtx_batch_sub_batch reports the sub-batch size of the LAST class and the number of sub-batches of the whole batch;
+ * rtx_batch_last_sub_batch the positions [first, first + n) of the processing order that form the last sub-batch (the one the taps read);
+ * rtx_batch_classes, per class c < *n_classes <= 4: out[4c] queries, [4c + 1] longest query (bases), [4c + 2] sub-batch size,
+ * [4c + 3] bit planes | tables << 8 | pair kernel << 9 | tile pruning << 10 | records path << 11 | global-memory forms << 12 (the last
+ * four after rtx_batch_run). */
+int rtx_batch_last_sub_batch(const rtx_index *index, uint64_t *first, uint32_t *n);
+int rtx_batch_classes(const rtx_index *index, uint32_t *n_classes, uint64_t out[16]);
 /* tile pruning of the last run (RTX_OPT_TILE_PRUNE): out[0] (pair, tile) blocks that are counted for at least one of their two queries, [1] pairs,
  * [2] sum of the lower bounds of the best hit, [3] sum of the thresholds, [4] sum of the largest tile bounds, [5] queries, [6] bounds below a count
  * they bound (must be 0), [7] (query, tile) combinations that are counted, [8] (query, tile) combinations with a count above the query's

@@ -122,6 +122,8 @@ _SIGNATURES = {
     "rtx_debug_prune_stats": (C.c_int, [C.c_void_p, u64p]),
     "rtx_debug_run_counts": (C.c_int, [C.c_void_p, C.c_uint64, u16p, u8p, u32p, u32p, u32p]),
     "rtx_debug_run_mode": (C.c_int, [C.c_void_p, C.c_uint64, u32p]),
+    "rtx_batch_last_sub_batch": (C.c_int, [C.c_void_p, u64p, u32p]),
+    "rtx_batch_classes": (C.c_int, [C.c_void_p, u32p, u64p]),
     "rtx_debug_prune_detail": (C.c_int, [C.c_void_p, C.c_uint64, u32p]),
     "rtx_debug_evaluate": (C.c_int, [C.c_void_p, f64p, C.POINTER(ResultView)]),
     "rtx_result_pack": (C.c_int64, [C.POINTER(ResultView), u8p, C.c_uint64]),

@@ -417,6 +417,24 @@ class Index:
         check(self._lib.rtx_batch_sub_batch(self._h, C.byref(b), C.byref(n)))
         return int(b.value)
 
+    def last_sub_batch(self):
+        """(first position, queries) of the last sub-batch of the uploaded batch in the processing order: what the taps can read."""
+        first, n = C.c_uint64(), C.c_uint32()
+        check(self._lib.rtx_batch_last_sub_batch(self._h, C.byref(first), C.byref(n)))
+        return int(first.value), int(n.value)
+
+    def batch_classes(self) -> list:
+        """Length classes of the uploaded batch: dicts of queries, longest query, sub-batch size, planes and what the class runs through."""
+        n = C.c_uint32()
+        out = np.zeros(16, dtype=np.uint64)
+        check(self._lib.rtx_batch_classes(self._h, C.byref(n), ptr(out, u64p)))
+        res = []
+        for c in range(int(n.value)):
+            f = int(out[4 * c + 3])
+            res.append(dict(queries=int(out[4 * c]), longest=int(out[4 * c + 1]), sub_batch=int(out[4 * c + 2]), planes=f & 0xFF, tables=bool(f >> 8 & 1),
+                            pair=bool(f >> 9 & 1), prune=bool(f >> 10 & 1), records=bool(f >> 11 & 1), global_memory_forms=bool(f >> 12 & 1)))
+        return res
+
     def debug_order(self, n_queries: int) -> np.ndarray:
         """Processing order of the last run: perm[position] = query."""
         out = np.zeros(n_queries, dtype=np.uint32)

@@ -193,9 +193,8 @@ def last_sub_batch_queries(index, n_q: int) -> np.ndarray:
     """The queries (input numbering) that the last run processed in its last sub-batch: the only ones whose scratch (counts, histogram,
     live masks, probability table) is still on the device when the run is over -- what the as-run taps can read."""
     order = index.debug_order(n_q)
-    b = index.sub_batch_size()
-    last0 = (n_q - 1) // b * b
-    return np.sort(order[last0:].astype(np.int64))
+    last0, n = index.last_sub_batch()     # (length classes of different sub-batch sizes follow one another: the library knows where the last one starts)
+    return np.sort(order[last0:last0 + n].astype(np.int64))
 
 
 def as_run_oracle_sample(index, res, oracle, otree, bases, base_off, n_sample: int, skip: bool, seed: int = 20264, chunk: int = 250,

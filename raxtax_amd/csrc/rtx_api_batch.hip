@@ -23,13 +23,57 @@ int ensure_events(rtx_index *ix, size_t count) {
 SubBatch sub_batch_of(rtx_index *ix, uint32_t sb, bool timed) {
     SubBatch b;
     b.sb = sb;
-    b.q0 = (uint64_t)sb * ix->sub_batch;
-    b.nq = (uint32_t)std::min<uint64_t>(ix->sub_batch, ix->n_q - b.q0);
+    if (sb < ix->sub_q0.size()) {  // the plan of the run (plan_sub_batches): classes of different sub-batch sizes follow one another
+        b.q0 = ix->sub_q0[sb];
+        b.nq = ix->sub_nq[sb];
+    } else {
+        b.q0 = (uint64_t)sb * ix->sub_batch;
+        b.nq = (uint32_t)std::min<uint64_t>(ix->sub_batch, ix->n_q - b.q0);
+    }
     b.set = ix->staged ? (sb & 1u) : 0u;
     b.s = ix->stream;
     b.timed = timed;
     b.timed_all = timed && ix->stage_timing != 0;
     return b;
+}
+
+// The class whose sub-batches are enqueued next: its shape becomes the handle's (the kernel parameters are filled from these fields).
+void apply_class(rtx_index *ix, uint32_t c) {
+    const rtx_index::BatchClass &k = ix->cls[c];
+    ix->tmax = k.tmax;
+    ix->kstride = k.kstride;
+    ix->rstride = k.rstride;
+    ix->hstride = k.hstride;
+    ix->planes = k.planes;
+    ix->sub_batch = k.sub_batch;
+    ix->use_tables = k.use_tables;
+    ix->pair_used = k.pair;
+    ix->prune_used = k.prune;
+    ix->rec_used = k.rec;
+    ix->cur_cls = (int)c;
+}
+
+// The sub-batches of the run, class after class (positions of the processing order: the class leads the sort key, order_batch).
+int plan_sub_batches(rtx_index *ix) {
+    ix->sub_q0.clear();
+    ix->sub_nq.clear();
+    ix->sub_cls.clear();
+    uint64_t pos = 0;
+    for (uint32_t c = 0; c < ix->n_cls; c++) {
+        rtx_index::BatchClass &k = ix->cls[c];
+        k.pos0 = pos;
+        k.sb0 = (uint32_t)ix->sub_q0.size();
+        for (uint64_t a = 0; a < k.n; a += k.sub_batch) {
+            ix->sub_q0.push_back(pos + a);
+            ix->sub_nq.push_back((uint32_t)std::min<uint64_t>(k.sub_batch, k.n - a));
+            ix->sub_cls.push_back((uint8_t)c);
+        }
+        k.n_sub = (uint32_t)ix->sub_q0.size() - k.sb0;
+        pos += k.n;
+    }
+    if (pos != ix->n_q) { set_error("internal: the length classes hold %llu of %llu queries", (unsigned long long)pos, (unsigned long long)ix->n_q); return RTX_ERR_STATE; }
+    ix->n_sub_total = (uint32_t)ix->sub_q0.size();
+    return RTX_OK;
 }
 
 // Counts of a sub-batch between hit_count and taxon_prefix.  With 10 bit planes (t <= 1023) they travel packed,
@@ -313,6 +357,11 @@ int enqueue_prob_prefix(rtx_index *ix, const SubBatch &b, bool fuse_walk, bool p
         pp.order = sc.d_order.p;
         launch_prob_lookup(s, pp, tb, b.nq);
     } else {
+        if (ix->cur_cls >= 0 && ix->cls[ix->cur_cls].huge) {  // its arrays do not fit LDS: a stretch of global memory per query
+            pp.gstride = (uint32_t)((prob_table_lds_bytes(ix->tmax) + 7) / 8);
+            if (ix->d_prob_scratch.n < (size_t)b.nq * pp.gstride) { set_error("internal: scratch of prob_table too small"); return RTX_ERR_STATE; }
+            pp.gscratch = ix->d_prob_scratch.p;
+        }
         launch_prob_table(s, pp, b.nq);
     }
     if (b.timed_all) RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_PROB_TABLE, 1), s));
@@ -409,19 +458,24 @@ int order_batch(rtx_index *ix, bool cluster) {
     const uint32_t n = (uint32_t)ix->n_q;
     int rc;
     if ((rc = ix->d_perm.alloc(n)) || (rc = ix->d_iperm.alloc(n)) || (rc = ix->h_perm.resize(n)) || (rc = ix->h_inv.resize(n))) return rc;
-    if (cluster && n > 2) {
+    const bool multi = ix->n_cls > 1;       // several length classes: the class leads the key, whatever orders the queries inside a class
+    const bool sketch = cluster && n > 2;
+    if (sketch || multi) {
         if ((rc = ix->d_skey_in.alloc(n)) || (rc = ix->d_skey_out.alloc(n)) || (rc = ix->d_sidx.alloc(n))) return rc;
         size_t tmp = 0;
-        if (cluster_sort(ix->stream, nullptr, &tmp, ix->d_skey_in.p, ix->d_skey_out.p, ix->d_sidx.p, ix->d_perm.p, n)) {
+        if (cluster_sort(ix->stream, nullptr, &tmp, ix->d_skey_in.p, ix->d_skey_out.p, ix->d_sidx.p, ix->d_perm.p, n, multi)) {
             set_error("radix sort: size query failed");
             return RTX_ERR_HIP;
         }
         if (ix->d_sort_tmp.n < tmp && (rc = ix->d_sort_tmp.alloc(tmp + 256))) return rc;
-        launch_sketch(ix->stream, ix->d_bases.p, ix->in[ix->cur_in].d_base_off.p, n, ix->d_skey_in.p, ix->d_sidx.p);
-        if (ix->d_loc_table.p && ix->locator_opt)
-            launch_locator(ix->stream, ix->d_bases.p, ix->in[ix->cur_in].d_base_off.p, n, ix->d_loc_table.p, ix->n_total, ix->d_skey_in.p);
+        if (sketch) {
+            launch_sketch(ix->stream, ix->d_bases.p, ix->in[ix->cur_in].d_base_off.p, n, ix->d_skey_in.p, ix->d_sidx.p);
+            if (ix->d_loc_table.p && ix->locator_opt)
+                launch_locator(ix->stream, ix->d_bases.p, ix->in[ix->cur_in].d_base_off.p, n, ix->d_loc_table.p, ix->n_total, ix->d_skey_in.p);
+        }
+        if (multi) launch_class_keys(ix->stream, ix->d_skey_in.p, ix->in[ix->cur_in].d_base_off.p, n, ix->key_lim, !sketch, ix->d_sidx.p);
         tmp = ix->d_sort_tmp.n;
-        if (cluster_sort(ix->stream, ix->d_sort_tmp.p, &tmp, ix->d_skey_in.p, ix->d_skey_out.p, ix->d_sidx.p, ix->d_perm.p, n)) {
+        if (cluster_sort(ix->stream, ix->d_sort_tmp.p, &tmp, ix->d_skey_in.p, ix->d_skey_out.p, ix->d_sidx.p, ix->d_perm.p, n, multi)) {
             set_error("radix sort of the query sketches failed");
             return RTX_ERR_HIP;
         }
@@ -436,7 +490,9 @@ int order_batch(rtx_index *ix, bool cluster) {
 }
 
 int begin_run(rtx_index *ix, uint32_t *n_sub_out, bool *timed_out, bool cluster) {
-    const uint32_t n_sub = (uint32_t)((ix->n_q + ix->sub_batch - 1) / ix->sub_batch);
+    int rc_p = plan_sub_batches(ix);
+    if (rc_p) return rc_p;
+    const uint32_t n_sub = ix->n_sub_total;
     const bool timed = n_sub <= 4096;
     if (timed) {
         int rc = ensure_events(ix, (size_t)n_sub * RTX_NUM_STAGES * 2);
@@ -449,32 +505,42 @@ int begin_run(rtx_index *ix, uint32_t *n_sub_out, bool *timed_out, bool cluster)
     if (ev_all) RTX_HIP(hipEventRecord(ix->events[(size_t)RTX_STAGE_ORDER * 2 + 1], ix->stream));
     RTX_HIP(hipMemsetAsync(ix->d_cursor.p, 0, sizeof(unsigned long long), ix->stream));
     RTX_HIP(hipMemsetAsync(ix->d_flags.p, 0, sizeof(uint32_t), ix->stream));
-    // two neighbours per wave only pays when neighbours are related: with the processing order on
-    ix->pair_used = ix->pair_opt && cluster && ix->planes <= 10 && ix->n_q > 1 && ix->rstride <= 4096;
-    ix->groups_per_sub = (ix->sub_batch + 1u) / 2u;
     // tile pruning: the pair kernel, the memoised tables (their ln cmf rows give the threshold), taxon_prefix skipping tiles by
     // their largest count, the whole database on this handle
     // a whole-database handle driven by rtx_batch_run, or a reference shard that was asked to (RTX_OPT_SHARD_PRUNE: the caller then
     // drives rtx_shard_bounds and exchanges the best blocks); never a k-mer shard (its counts are partial sums)
     const bool whole = ix->n_refs == ix->n_total && !ix->staged;
     const bool shard = ix->staged && ix->shard_prune_opt && ix->n_refs != ix->n_total;
-    auto scratch_ok = [&](const rtx_index::Scratch &sc) {  // sized at the upload / rtx_shard_begin (alloc_scratch_set) for this sub-batch size
-        return sc.d_tile_ub.p != nullptr && sc.d_tile_ub.n >= (size_t)ix->sub_batch * ix->ntiles && sc.d_best_key.n >= ix->sub_batch && sc.d_prune_thr.n >= ix->sub_batch &&
-               sc.d_live.n >= (size_t)(ix->sub_batch + 1u) * ((ix->ntiles + 31u) / 32u + 1u) && sc.d_best.n >= (size_t)ix->sub_batch * kPruneBestWords &&
-               sc.d_items.n >= (size_t)((ix->sub_batch + 1u) / 2u) * (ix->ntiles + 2u) + 9u;
+    auto scratch_ok = [&](const rtx_index::Scratch &sc, uint32_t B) {  // sized at the upload / rtx_shard_begin (alloc_scratch_set) for this sub-batch size
+        return sc.d_tile_ub.p != nullptr && sc.d_tile_ub.n >= (size_t)B * ix->ntiles && sc.d_best_key.n >= B && sc.d_prune_thr.n >= B &&
+               sc.d_live.n >= (size_t)(B + 1u) * ((ix->ntiles + 31u) / 32u + 1u) && sc.d_best.n >= (size_t)B * kPruneBestWords &&
+               sc.d_items.n >= (size_t)((B + 1u) / 2u) * (ix->ntiles + 2u) + 9u;
     };
-    ix->prune_used = ix->prune_opt && ix->pair_used && ix->use_tables && ix->tile_skip && ix->d_ubitmap.p && (whole || shard) &&
-                     scratch_ok(ix->sc[0]) && (!ix->staged || scratch_ok(ix->sc[1]));
+    bool any_pair = false, any_prune = false;
+    uint32_t b_max = 1;
+    for (uint32_t c = 0; c < ix->n_cls; c++) {  // what every class of the batch runs through
+        rtx_index::BatchClass &k = ix->cls[c];
+        // two neighbours per wave only pays when neighbours are related: with the processing order on
+        k.pair = ix->pair_opt && cluster && k.planes <= 10 && ix->n_q > 1 && k.rstride <= 4096;
+        k.prune = ix->prune_opt && k.pair && k.use_tables && ix->tile_skip && ix->d_ubitmap.p && (whole || shard) &&
+                  scratch_ok(ix->sc[0], k.sub_batch) && (!ix->staged || scratch_ok(ix->sc[1], k.sub_batch));
+        k.rec = k.prune && whole && ix->rec_opt != 0u && ix->n_bnd_local == ix->n_bnd && ix->sc[0].d_rec.p != nullptr &&
+                ix->sc[0].d_rec.n >= (size_t)k.sub_batch * std::min<uint32_t>(ix->rec_opt, kRecMaxSlots) * 8192u;
+        any_pair = any_pair || k.pair;
+        any_prune = any_prune || k.prune;
+        b_max = std::max(b_max, k.sub_batch);
+    }
+    ix->sub_batch_max = b_max;
+    ix->any_prune = any_prune;
+    ix->groups_per_sub = (b_max + 1u) / 2u;
     ix->dbg_full = false;
-    ix->rec_used = ix->prune_used && whole && ix->rec_opt != 0u && ix->n_bnd_local == ix->n_bnd && ix->sc[0].d_rec.p != nullptr &&
-                   ix->sc[0].d_rec.n >= (size_t)ix->sub_batch * std::min<uint32_t>(ix->rec_opt, kRecMaxSlots) * 8192u;
-    if (ix->prune_used) {
+    if (any_prune) {
         int rc_s = ix->d_prune_stats.alloc(kPruneStatCopies * 32);
-        if (!rc_s && ix->debug_taps) rc_s = ix->d_prune_detail.alloc((size_t)ix->sub_batch * kPruneDetailWords);
+        if (!rc_s && ix->debug_taps) rc_s = ix->d_prune_detail.alloc((size_t)b_max * kPruneDetailWords);
         if (rc_s) return rc_s;
         RTX_HIP(hipMemsetAsync(ix->d_prune_stats.p, 0, kPruneStatCopies * 256, ix->stream));
     }
-    if (ix->pair_used) {
+    if (any_pair) {
         ix->n_groups_run = n_sub * ix->groups_per_sub;
         int rc_g = ix->d_group_rows.alloc((size_t)2 * n_sub * ix->groups_per_sub);  // second half: the bounds pass of the tile pruning
         if (rc_g) return rc_g;
@@ -482,10 +548,11 @@ int begin_run(rtx_index *ix, uint32_t *n_sub_out, bool *timed_out, bool cluster)
     }
     ix->n_sub_last = timed ? n_sub : 0;
     ix->overlap_used = 0;  // scratch sets in use beside each other (RTX_OPT_OVERLAP)
-    if (ix->overlap_opt != 0u && whole && n_sub >= 2 && ix->sc[1].d_kmers.p != nullptr && scratch_ok(ix->sc[1]) == scratch_ok(ix->sc[0])) {
+    if (ix->overlap_opt != 0u && whole && n_sub >= 2 && ix->sc[1].d_kmers.p != nullptr && scratch_ok(ix->sc[1], b_max) == scratch_ok(ix->sc[0], b_max)) {
         ix->overlap_used = 2;
-        if (ix->overlap_opt >= 2u && n_sub >= 3 && ix->sc[2].d_kmers.p != nullptr && scratch_ok(ix->sc[2]) == scratch_ok(ix->sc[0])) ix->overlap_used = 3;
+        if (ix->overlap_opt >= 2u && n_sub >= 3 && ix->sc[2].d_kmers.p != nullptr && scratch_ok(ix->sc[2], b_max) == scratch_ok(ix->sc[0], b_max)) ix->overlap_used = 3;
     }
+    if (ix->n_cls) apply_class(ix, 0);
     if (ix->dev_exact_used) {  // Tree.sequences.get for every query of the batch (raxtax.rs:42), part of the run
         ExactParams xp{ix->d_bases.p, ix->in[ix->cur_in].d_base_off.p, (uint32_t)ix->n_q, ix->d_em_table.p, ix->em_bits, ix->d_em_rep_off.p,
                        ix->d_em_rep_bytes.p, ix->d_exact_grp.p, ix->em_hash_mask};
@@ -545,6 +612,7 @@ int enqueue_batch(rtx_index *ix, uint32_t flags) {
         }
     }
     for (uint32_t sb = 0; sb < n_sub; sb++) {
+        if ((int)ix->sub_cls[sb] != ix->cur_cls) apply_class(ix, ix->sub_cls[sb]);  // the next length class: its planes, strides, kernels
         SubBatch b = sub_batch_of(ix, sb, timed);
         if (overlap) {
             b.set = sb % nsets;
@@ -575,15 +643,15 @@ int enqueue_batch(rtx_index *ix, uint32_t flags) {
 
 // Builds (once per handle and tmax) the memoised cmf tables used by prob_lookup_kernel.
 constexpr uint32_t kProbTablesMaxT = 1023;
-int ensure_prob_tables(rtx_index *ix) {
-    ix->use_tables = false;
-    if (ix->prob_mode == 1 || ix->tmax < 2) return RTX_OK;
-    if (ix->tmax > kProbTablesMaxT) {
-        if (ix->prob_mode == 2) { set_error("prob tables need t <= %u (got %u)", kProbTablesMaxT, ix->tmax); return RTX_ERR_TOO_LONG; }
+int ensure_prob_tables(rtx_index *ix, uint32_t tmax, bool *usable) {
+    *usable = false;
+    if (ix->prob_mode == 1 || tmax < 2) return RTX_OK;
+    if (tmax > kProbTablesMaxT) {
+        if (ix->prob_mode == 2) { set_error("prob tables need t <= %u (got %u)", kProbTablesMaxT, tmax); return RTX_ERR_TOO_LONG; }
         return RTX_OK;
     }
-    if (ix->tab_tmax >= ix->tmax) { ix->use_tables = true; return RTX_OK; }
-    const uint32_t T = ix->tmax;
+    if (ix->tab_tmax >= tmax) { *usable = true; return RTX_OK; }
+    const uint32_t T = tmax;
     std::vector<uint64_t> off(T + 1, 0);
     std::vector<uint32_t> moff(T + 1, 0);
     uint64_t run = 0;
@@ -611,7 +679,7 @@ int ensure_prob_tables(rtx_index *ix) {
     RTX_HIP(hipGetLastError());
     RTX_HIP(hipStreamSynchronize(ix->stream));
     ix->tab_tmax = T;
-    ix->use_tables = true;
+    *usable = true;
     return RTX_OK;
 }
 
@@ -630,33 +698,128 @@ constexpr uint32_t kMaxSubBatch = 65536;
 constexpr uint32_t kDefaultSubBatch = 20480, kDefaultSubBatchLarge = 16384, kDefaultSubBatchPruned = 65536;
 
 
-// Sizes and allocates the per-batch workspace for n_queries queries of at most tmax k-mers.
-int prepare_workspace(rtx_index *ix, uint64_t n_queries, uint64_t tmax, uint64_t max_len) {
-    int rc;
+// ---- length classes ----------------------------------------------------------------------------------------------------------
+// class of a query by its length (t <= length - 7, known on the host when the batch is staged):
+//   0: t <= 255    8 bit planes, pair kernel, memoised tables, tile pruning
+//   1: t <= 1023  10 bit planes, the same
+//   2: longer     12 / 16 planes, one query per wave, prob_table_kernel with its arrays in LDS (t up to ~ 6 600)
+//   3: up to t = 65 535 (raxtax.rs:56): 16 planes, the histogram of hit_count and the arrays of prob_table in global memory
+constexpr size_t kProbTableLdsLimit = 160 * 1024 - 512;
+uint32_t length_class(uint64_t len) {
+    const uint64_t t = len >= 8 ? len - 7 : 1;
+    if (t <= 255) return 0;
+    if (t <= 1023) return 1;
+    return t <= 65535 && prob_table_lds_bytes((uint32_t)t) <= kProbTableLdsLimit ? 2u : 3u;
+}
+uint64_t class2_max_len() {  // the longest query of class 2: where prob_table's arrays still fit LDS
+    static uint64_t cached = 0;
+    if (!cached) {
+        uint64_t lo = 1030, hi = 65535 + 7;
+        while (lo < hi) { const uint64_t mid = (lo + hi + 1) / 2; if (length_class(mid) <= 2u) lo = mid; else hi = mid - 1; }
+        cached = lo;
+    }
+    return cached;
+}
+constexpr uint64_t kMinShortClass = 4096;  // fewer queries of t <= 255 than this ride with the t <= 1023 class (same results: 8 or 10 planes hold their counts)
+
+static void shape_class(rtx_index::BatchClass &k, uint64_t n, uint64_t max_len) {
+    const uint64_t tmax = max_len >= 8 ? max_len - 7 : 1;  // t <= min(len - 7, 65536); t == 65536 would trip the u16 assert of raxtax.rs:56
+    k = rtx_index::BatchClass();
+    k.n = n;
+    k.max_len = max_len;
+    k.tmax = (uint32_t)tmax;
+    k.kstride = (uint32_t)align_up(tmax, 8);
+    k.rstride = (uint32_t)align_up(tmax, 64) + 64;  // row list padded to whole 64-row chunks
+    k.hstride = (uint32_t)align_up(tmax + 1, 8);
+    k.planes = tmax <= 255 ? 8 : (tmax <= 1023 ? 10 : (tmax <= 4095 ? 12 : 16));  // (8: the pair kernel; the others run their 10-plane forms)
+    k.huge = prob_table_lds_bytes((uint32_t)tmax) > kProbTableLdsLimit;
+}
+
+static int size_workspace(rtx_index *ix, uint64_t n_queries);
+
+// Sizes and allocates the per-batch workspace for the staged batch: n_queries queries, cls_n[c] of them in length class c (the longest of
+// which has cls_max[c] bases).
+int prepare_workspace(rtx_index *ix, uint64_t n_queries, const uint64_t cls_n_in[4], const uint64_t cls_max_in[4]) {
+    uint64_t cn[4], cm[4];
+    for (int c = 0; c < 4; c++) { cn[c] = cls_n_in[c]; cm[c] = cls_max_in[c]; }
+    if (ix->n_refs != ix->n_total) {  // a reference / k-mer shard: the exchange buffers of rtx_shard_* have one row stride -- one class
+        uint64_t mx = 0;
+        for (int c = 0; c < 4; c++) mx = std::max(mx, cm[c]);
+        return prepare_workspace_single(ix, n_queries, mx >= 8 ? mx - 7 : 1, mx);
+    }
+    // a handful of short reads among barcodes ride with them (the results do not depend on the number of planes)
+    if (cn[0] && cn[1] && cn[0] < kMinShortClass) { cn[1] += cn[0]; cm[1] = std::max(cm[1], cm[0]); cn[0] = 0; cm[0] = 0; }
+    const uint64_t key[14] = {n_queries, cn[0], cn[1], cn[2], cn[3], cm[0], cm[1], cm[2], cm[3], ix->sub_batch_req,
+                              (uint64_t)ix->packed_opt | (uint64_t)ix->pair_opt << 1 | (uint64_t)ix->prune_opt << 2 | (uint64_t)ix->shard_prune_opt << 3 | (uint64_t)ix->fine_opt << 4 |
+                                  (uint64_t)(ix->prob_mode & 3) << 5 | (uint64_t)ix->rec_opt << 8 | (uint64_t)ix->overlap_opt << 16,
+                              (uint64_t)ix->n_bnd_local, 0, 0};
     // A batch of the shape of the last one under the same options (the chunks of rtx_raxtax): everything below would come out the same --
     // and hipMemGetInfo alone costs a good part of a millisecond between two chunks, with the device idle
-    const uint64_t key[6] = {n_queries, tmax, max_len, ix->sub_batch_req,
-                             (uint64_t)ix->packed_opt | (uint64_t)ix->pair_opt << 1 | (uint64_t)ix->prune_opt << 2 | (uint64_t)ix->shard_prune_opt << 3 | (uint64_t)ix->fine_opt << 4 |
-                                 (uint64_t)(ix->prob_mode & 3) << 5 | (uint64_t)ix->rec_opt << 8 | (uint64_t)ix->overlap_opt << 16,
-                             (uint64_t)ix->n_bnd_local};
     if (ix->ws_valid && std::memcmp(key, ix->ws_key, sizeof key) == 0 && !ix->staged) {
         ix->n_q = n_queries;
         return RTX_OK;
     }
     ix->ws_valid = false;
-    if (tmax > 65535) { set_error("query with up to %llu k-mers: raxtax.rs:56 asserts t fits u16", (unsigned long long)tmax); return RTX_ERR_TOO_LONG; }
-    if (prob_table_lds_bytes((uint32_t)tmax) > 160 * 1024 - 512) {
-        set_error("query of %llu bases needs %zu bytes of LDS in prob_table (limit 160 KiB)", (unsigned long long)max_len,
-                  prob_table_lds_bytes((uint32_t)tmax));
-        return RTX_ERR_TOO_LONG;
+    uint64_t longest = 0;
+    for (int c = 0; c < 4; c++) longest = std::max(longest, cm[c]);
+    if (longest >= 8 && longest - 7 > 65535) { set_error("query with up to %llu k-mers: raxtax.rs:56 asserts t fits u16", (unsigned long long)(longest - 7)); return RTX_ERR_TOO_LONG; }
+    ix->n_cls = 0;
+    // the longest query each class may hold: the sort rank of a query is the number of class boundaries its length exceeds
+    const uint64_t cls_len[3] = {255 + 7, 1023 + 7, class2_max_len()};
+    for (int c = 0; c < 3; c++) ix->key_lim[c] = ~0ull;
+    int last = -1;
+    for (int c = 0; c < 4; c++) {
+        if (!cn[c]) continue;
+        if (last >= 0) ix->key_lim[ix->n_cls - 1] = cls_len[last];  // a boundary between two classes that both exist
+        shape_class(ix->cls[ix->n_cls], cn[c], cm[c]);
+        ix->n_cls++;
+        last = c;
     }
-    ix->tmax = (uint32_t)tmax;
-    ix->kstride = (uint32_t)align_up(tmax, 8);
-    ix->rstride = (uint32_t)align_up(tmax, 64) + 64;  // row list padded to whole 64-row chunks
-    ix->hstride = (uint32_t)align_up(tmax + 1, 8);
-    ix->planes = tmax <= 255 ? 8 : (tmax <= 1023 ? 10 : (tmax <= 4095 ? 12 : 16));  // (8: the pair kernel; the others run their 10-plane forms)
+    if (ix->n_cls == 0) { set_error("internal: a batch without queries"); return RTX_ERR_INVALID; }
     ix->n_q = n_queries;
-    if ((rc = ensure_prob_tables(ix))) return rc;
+    int rc = size_workspace(ix, n_queries);
+    if (rc) return rc;
+    std::memcpy(ix->ws_key, key, sizeof key);
+    ix->ws_valid = true;
+    return RTX_OK;
+}
+
+// One class whatever the lengths: reference shards (rtx_shard_*: one row stride for the exchange buffers), rtx_debug_evaluate.
+int prepare_workspace_single(rtx_index *ix, uint64_t n_queries, uint64_t tmax, uint64_t max_len) {
+    ix->ws_valid = false;
+    if (tmax > 65535) { set_error("query with up to %llu k-mers: raxtax.rs:56 asserts t fits u16", (unsigned long long)tmax); return RTX_ERR_TOO_LONG; }
+    ix->n_cls = 1;
+    for (int c = 0; c < 3; c++) ix->key_lim[c] = ~0ull;
+    shape_class(ix->cls[0], n_queries, tmax + 7);
+    ix->cls[0].max_len = max_len;
+    ix->n_q = n_queries;
+    return size_workspace(ix, n_queries);
+}
+
+// per-query scratch bytes of a class (what a sub-batch of it costs per query)
+static uint64_t class_per_q(const rtx_index *ix, const rtx_index::BatchClass &k) {
+    const bool packed = ix->packed_opt && k.planes <= 10;
+    return (uint64_t)k.kstride * 2 + (uint64_t)k.rstride * 12 + 4 + (uint64_t)ix->ntiles * (k.rstride / 8 + ((kSegMaxSparseRows + 1) * 4 + 10)) + (packed ? ix->npad * 5 / 4 : ix->npad * 2) +
+           (uint64_t)k.hstride * 12 + (uint64_t)ix->n_bnd_local * 8 + 64 + (k.huge ? prob_table_lds_bytes(k.tmax) : 0) +
+           // + the scratch of the tile pruning: tile bounds, thresholds, live masks, best blocks, the lists of live blocks
+           (k.will_prune ? (uint64_t)ix->ntiles * 2 + 12 + (ix->ntiles + 31u) / 32u * 2u + 2u + kPruneBestWords * 4 +
+                               ((uint64_t)ix->ntiles + 2u) * 2u  /* the list of live (pair, tile) blocks: 4 bytes per pair and tile */ +
+                               (ix->d_fbitmap.p ? (uint64_t)ix->f_ntiles * 2u + 1u : 0u) /* the items of the fine bounds pass */ +
+                               (ix->rec_opt && ix->n_refs == ix->n_total ? (uint64_t)std::min<uint32_t>(ix->rec_opt, kRecMaxSlots) * 32768u + kRecMaxSlots * 6u + 2u : 0u) /* record segments */
+                           : 0);
+}
+
+static int size_workspace(rtx_index *ix, uint64_t n_queries) {
+    int rc;
+    // the memoised probability tables serve every class with t <= 1023: built for the longest of them
+    uint32_t tab_t = 0;
+    for (uint32_t c = 0; c < ix->n_cls; c++) {
+        if (ix->cls[c].tmax > kProbTablesMaxT && ix->prob_mode == 2) { set_error("prob tables need t <= %u (got %u)", kProbTablesMaxT, ix->cls[c].tmax); return RTX_ERR_TOO_LONG; }
+        if (ix->cls[c].tmax <= kProbTablesMaxT) tab_t = std::max(tab_t, ix->cls[c].tmax);
+    }
+    bool tables = false;
+    if (tab_t && (rc = ensure_prob_tables(ix, tab_t, &tables))) return rc;
+    for (uint32_t c = 0; c < ix->n_cls; c++) ix->cls[c].use_tables = tables && ix->cls[c].tmax >= 2 && ix->cls[c].tmax <= kProbTablesMaxT;
     // ---- per-query results
     if ((rc = ix->d_status.alloc(n_queries)) || (rc = ix->d_t_all.alloc(n_queries)) || (rc = ix->d_nrows_all.alloc(n_queries)) ||
         (rc = ix->d_n_rows.alloc(n_queries)) || (rc = ix->d_gs.alloc(n_queries)) || (rc = ix->d_z.alloc(n_queries)) ||
@@ -668,78 +831,88 @@ int prepare_workspace(rtx_index *ix, uint64_t n_queries, uint64_t tmax, uint64_t
         if ((rc = ix->d_arena.alloc(want_arena))) return rc;
         ix->arena_cap = want_arena;
     }
-    // ---- sub-batch scratch, sized against free HBM
-    const bool will_prune = ix->prune_opt && ix->d_ubitmap.p && ix->pair_opt && ix->ntiles >= RTX_PRUNE_MIN_TILES && tmax <= 1023 && (ix->n_refs == ix->n_total || ix->shard_prune_opt);  // begin_run decides
-    const uint64_t per_q = (uint64_t)ix->kstride * 2 + (uint64_t)ix->rstride * 12 + 4 + (uint64_t)ix->ntiles * (ix->rstride / 8 + ((kSegMaxSparseRows + 1) * 4 + 10)) + (ix->packed() ? ix->npad * 5 / 4 : ix->npad * 2) + (uint64_t)ix->hstride * 12 +
-                           (uint64_t)ix->n_bnd_local * 8 + 64 +
-                           // + the scratch of the tile pruning: tile bounds, thresholds, live masks, best blocks, the lists of live blocks
-                           (will_prune ? (uint64_t)ix->ntiles * 2 + 12 + (ix->ntiles + 31u) / 32u * 2u + 2u + kPruneBestWords * 4 +
-                                          ((uint64_t)ix->ntiles + 2u) * 2u  /* the list of live (pair, tile) blocks: 4 bytes per pair and tile */ +
-                                          (ix->d_fbitmap.p ? (uint64_t)ix->f_ntiles * 2u + 1u : 0u) /* the items of the fine bounds pass */ +
-                                          (ix->rec_opt && ix->n_refs == ix->n_total ? (uint64_t)std::min<uint32_t>(ix->rec_opt, kRecMaxSlots) * 32768u + kRecMaxSlots * 6u + 2u : 0u) /* record segments */
-                                        : 0);
-    uint32_t B = ix->sub_batch_req;
+    // ---- sub-batch scratch, sized against free HBM: every class gets the sub-batch size its own shape allows, the buffers the largest
+    // product over the classes (a class runs after the other through the same buffers)
     uint32_t n_sets = ix->n_refs == ix->n_total ? 1u + std::min<uint32_t>(ix->overlap_opt, 2u) : 1u;  // RTX_OPT_OVERLAP: two (three) scratch sets
-    {
-        size_t free_b = 0, total_b = 0;
-        RTX_HIP(hipMemGetInfo(&free_b, &total_b));
-        // scratch already held by this handle is reusable
-        uint64_t held = 0;
-        for (const auto &sc : ix->sc) held += sc.d_counts.n * 2 + sc.d_prefix.n * 8 + sc.d_rec.n * 4 + sc.d_srows.n * 4;
-        const uint64_t budget = (uint64_t)((free_b + held) * 0.6);
+    size_t free_b = 0, total_b = 0;
+    RTX_HIP(hipMemGetInfo(&free_b, &total_b));
+    uint64_t held = 0;  // scratch already held by this handle is reusable
+    for (const auto &sc : ix->sc) held += sc.d_counts.n * 2 + sc.d_prefix.n * 8 + sc.d_rec.n * 4 + sc.d_srows.n * 4;
+    const uint64_t budget = (uint64_t)((free_b + held) * 0.6);
+    uint64_t worst = 0;
+    for (uint32_t c = 0; c < ix->n_cls; c++) {
+        rtx_index::BatchClass &k = ix->cls[c];
+        k.will_prune = ix->prune_opt && ix->d_ubitmap.p && ix->pair_opt && ix->ntiles >= RTX_PRUNE_MIN_TILES && k.tmax <= 1023 && (ix->n_refs == ix->n_total || ix->shard_prune_opt);  // begin_run decides
+        const uint64_t per_q = class_per_q(ix, k);
+        uint32_t B = ix->sub_batch_req;
         if (B == 0) {
-            B = (uint32_t)std::min<uint64_t>(will_prune ? kDefaultSubBatchPruned : ix->ntiles >= 16 ? kDefaultSubBatchLarge : kDefaultSubBatch,
+            B = (uint32_t)std::min<uint64_t>(k.will_prune ? kDefaultSubBatchPruned : ix->ntiles >= 16 ? kDefaultSubBatchLarge : kDefaultSubBatch,
                                              std::max<uint64_t>(64, budget / per_q));
+            if (k.huge) B = std::min<uint32_t>(B, 1024u);
             // at least four sub-batches per batch (of 16 384 queries or more): the records of a finished sub-batch are copied and finalised on
             // the host while the next ones run, and what is left when the device is done is the last sub-batch -- a chunk of 131 072 queries
             // (rtx_raxtax) in two halves left 7 ms of host work exposed on real barcodes (ten result rows per query)
-            if (will_prune && n_queries < 4ull * B) B = (uint32_t)std::max<uint64_t>(16384, (n_queries + 3) / 4);
+            if (k.will_prune && k.n < 4ull * B) B = (uint32_t)std::max<uint64_t>(16384, (k.n + 3) / 4);
         }
         if (B > kMaxSubBatch) B = kMaxSubBatch;
-        B = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(B, n_queries));
-        // the further sets of the overlap never shrink a sub-batch: they are taken only while they fit the budget beside the first
-        while (n_sets > 1u && (uint64_t)n_sets * B * per_q > budget) n_sets--;
+        B = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(B, k.n));
+        k.sub_batch = B;
+        worst = std::max<uint64_t>(worst, (uint64_t)B * per_q);
     }
-    ix->sub_batch = B;
+    // the further sets of the overlap never shrink a sub-batch: they are taken only while they fit the budget beside the first
+    while (n_sets > 1u && (uint64_t)n_sets * worst > budget) n_sets--;
     ix->staged = false;
+    if ((rc = plan_sub_batches(ix))) return rc;
+    apply_class(ix, ix->n_cls - 1u);
     if ((rc = alloc_scratch_set(ix, 0))) return rc;
     for (uint32_t k = 1; k <= 2u; k++) {  // (without the further sets the run stays on one stream)
-        if (k < n_sets && n_queries > B) {
+        if (k < n_sets && ix->n_sub_total > 1) {
             if (alloc_scratch_set(ix, k)) ix->sc[k].d_kmers.release();
-        } else {
-            if (ix->n_refs == ix->n_total) ix->sc[k].release_all();  // none wanted on a whole-database handle: given back (a shard keeps its second set for rtx_shard_begin)
+        } else if (ix->n_refs == ix->n_total) {
+            ix->sc[k].release_all();  // none wanted on a whole-database handle: given back (a shard keeps its second set for rtx_shard_begin)
         }
     }
-    std::memcpy(ix->ws_key, key, sizeof key);
-    ix->ws_valid = true;
     return RTX_OK;
 }
 
+// One set of sub-batch scratch, every buffer sized for the class that needs most of it.
 int alloc_scratch_set(rtx_index *ix, uint32_t k) {
     int rc;
-    const uint32_t B = ix->sub_batch;
-    {
-        rtx_index::Scratch &sc = ix->sc[k];
-        if ((rc = sc.d_kmers.alloc((size_t)B * ix->kstride)) || (rc = sc.d_rows.alloc((size_t)B * ix->rstride)) || (rc = sc.d_dmask.alloc((size_t)B * ix->ntiles * (ix->rstride / 64))) ||
-            (rc = sc.d_nsparse.alloc((size_t)B * ix->ntiles)) || (rc = sc.d_srows.alloc((size_t)B * ix->ntiles * (kSegMaxSparseRows + 1))) ||
-            (rc = sc.d_t.alloc(B)) || (rc = sc.d_nrows.alloc(B)) || (rc = sc.d_counts.alloc(counts_elems(ix, B))) ||
-            (rc = sc.d_hist.alloc((size_t)B * ix->hstride)) || (rc = sc.d_table_z.alloc((size_t)B * ix->hstride)) ||
-            (rc = sc.d_prefix.alloc((size_t)B * ix->n_bnd_local)) || (rc = sc.d_order.alloc(B)) ||
-            (rc = sc.d_tilemax.alloc((size_t)B * ix->ntiles)) ||
-            (rc = sc.d_urec.alloc((size_t)((B + 1u) / 2u) * 2u * ix->rstride)) || (rc = sc.d_nu.alloc((B + 1u) / 2u)))
+    rtx_index::Scratch &sc = ix->sc[k];
+    size_t n_kmers = 0, n_rows = 0, n_dmask = 0, n_counts = 0, n_hist = 0, n_urec = 0, b_max = 1, n_probscr = 0;
+    for (uint32_t c = 0; c < ix->n_cls; c++) {
+        const rtx_index::BatchClass &kc = ix->cls[c];
+        const size_t B = kc.sub_batch;
+        b_max = std::max(b_max, B);
+        n_kmers = std::max(n_kmers, B * kc.kstride);
+        n_rows = std::max(n_rows, B * kc.rstride);
+        n_dmask = std::max(n_dmask, B * ix->ntiles * (kc.rstride / 64));
+        n_counts = std::max(n_counts, ix->packed_opt && kc.planes <= 10 ? B * ix->npad * 5 / 8 : B * ix->npad);
+        n_hist = std::max(n_hist, B * kc.hstride);
+        n_urec = std::max(n_urec, ((B + 1u) / 2u) * 2u * kc.rstride);
+        if (kc.huge) n_probscr = std::max(n_probscr, B * ((prob_table_lds_bytes(kc.tmax) + 7) / 8));
+    }
+    const size_t B = b_max;
+    if ((rc = sc.d_kmers.alloc(n_kmers)) || (rc = sc.d_rows.alloc(n_rows)) || (rc = sc.d_dmask.alloc(n_dmask)) ||
+        (rc = sc.d_nsparse.alloc(B * ix->ntiles)) || (rc = sc.d_srows.alloc(B * ix->ntiles * (kSegMaxSparseRows + 1))) ||
+        (rc = sc.d_t.alloc(B)) || (rc = sc.d_nrows.alloc(B)) || (rc = sc.d_counts.alloc(n_counts)) ||
+        (rc = sc.d_hist.alloc(n_hist)) || (rc = sc.d_table_z.alloc(n_hist)) ||
+        (rc = sc.d_prefix.alloc(B * ix->n_bnd_local)) || (rc = sc.d_order.alloc(B)) ||
+        (rc = sc.d_tilemax.alloc(B * ix->ntiles)) ||
+        (rc = sc.d_urec.alloc(n_urec)) || (rc = sc.d_nu.alloc((B + 1u) / 2u)))
+        return rc;
+    if (n_probscr && k == 0 && (rc = ix->d_prob_scratch.alloc(n_probscr))) return rc;
+    if (ix->prune_opt && ix->d_ubitmap.p && (ix->n_refs == ix->n_total || ix->shard_prune_opt)) {
+        if ((rc = sc.d_tile_ub.alloc(B * ix->ntiles)) || (rc = sc.d_best_key.alloc(B)) || (rc = sc.d_prune_thr.alloc(B)) || (rc = sc.d_prune_i1.alloc(B)) || (rc = sc.d_best.alloc(B * kPruneBestWords)) || (rc = sc.d_live.alloc((B + 1u) * ((ix->ntiles + 31u) / 32u + 1u))) ||
+            (rc = sc.d_items.alloc(((B + 1u) / 2u) * (ix->ntiles + 2u) + 9u)))
             return rc;
-        if (ix->prune_opt && ix->d_ubitmap.p && (ix->n_refs == ix->n_total || ix->shard_prune_opt)) {
-            if ((rc = sc.d_tile_ub.alloc((size_t)B * ix->ntiles)) || (rc = sc.d_best_key.alloc(B)) || (rc = sc.d_prune_thr.alloc(B)) || (rc = sc.d_prune_i1.alloc(B)) || (rc = sc.d_best.alloc((size_t)B * kPruneBestWords)) || (rc = sc.d_live.alloc((size_t)(B + 1u) * ((ix->ntiles + 31u) / 32u + 1u))) ||
-                (rc = sc.d_items.alloc((size_t)((B + 1u) / 2u) * (ix->ntiles + 2u) + 9u)))
-                return rc;
-            // (a failed allocation of the fine pass's lists only switches the pass off: enqueue_hit tolerates a null pointer)
-            if (ix->d_fbitmap.p && sc.d_fine_items.alloc((size_t)((B + 1u) / 2u) * ix->f_ntiles + 9u + ix->f_ntiles)) sc.d_fine_items.release();
-            if (ix->rec_opt && ix->n_refs == ix->n_total) {  // the records path; without its buffers the run takes the dense epilogues
-                const size_t slots = std::min<uint32_t>(ix->rec_opt, kRecMaxSlots);
-                if (sc.d_rec_nslots.alloc(B) || sc.d_rec_slots.alloc((size_t)B * kRecMaxSlots) || sc.d_rec_cnt.alloc((size_t)B * kRecMaxSlots) ||
-                    sc.d_rec.alloc((size_t)B * slots * 8192u))
-                    sc.d_rec.release();
-            }
+        // (a failed allocation of the fine pass's lists only switches the pass off: enqueue_hit tolerates a null pointer)
+        if (ix->d_fbitmap.p && sc.d_fine_items.alloc(((B + 1u) / 2u) * ix->f_ntiles + 9u + ix->f_ntiles)) sc.d_fine_items.release();
+        if (ix->rec_opt && ix->n_refs == ix->n_total) {  // the records path; without its buffers the run takes the dense epilogues
+            const size_t slots = std::min<uint32_t>(ix->rec_opt, kRecMaxSlots);
+            if (sc.d_rec_nslots.alloc(B) || sc.d_rec_slots.alloc(B * kRecMaxSlots) || sc.d_rec_cnt.alloc(B * kRecMaxSlots) ||
+                sc.d_rec.alloc(B * slots * 8192u))
+                sc.d_rec.release();
         }
     }
     return RTX_OK;
@@ -767,9 +940,17 @@ int rtx_batch_prefetch(rtx_index *ix, uint64_t n_queries, const uint8_t *bases, 
     in.staged = false;
     if (ix->ev_activated) RTX_HIP(hipStreamWaitEvent(ix->h2d_stream, ix->ev_activated, 0));  // the batch that read this set has run
     uint64_t max_len = 0;
-    for (uint64_t q = 0; q < n_queries; q++) {
-        if (base_off[q + 1] < base_off[q]) { set_error("base_off not monotone at query %llu", (unsigned long long)q); return RTX_ERR_INVALID; }
-        max_len = std::max(max_len, base_off[q + 1] - base_off[q]);
+    uint64_t cls_n[4] = {0, 0, 0, 0}, cls_max[4] = {0, 0, 0, 0};  // the length classes of the batch (length_class)
+    {
+        const uint64_t lim2 = class2_max_len();
+        for (uint64_t q = 0; q < n_queries; q++) {
+            if (base_off[q + 1] < base_off[q]) { set_error("base_off not monotone at query %llu", (unsigned long long)q); return RTX_ERR_INVALID; }
+            const uint64_t len = base_off[q + 1] - base_off[q];
+            max_len = std::max(max_len, len);
+            const int c = len <= 262 ? 0 : (len <= 1030 ? 1 : (len <= lim2 ? 2 : 3));
+            cls_n[c]++;
+            cls_max[c] = std::max(cls_max[c], len);
+        }
     }
     const uint64_t total = base_off[n_queries] - base_off[0];
     uint64_t n_exact = 0;
@@ -806,6 +987,7 @@ int rtx_batch_prefetch(rtx_index *ix, uint64_t n_queries, const uint8_t *bases, 
     in.n_q = n_queries;
     in.total = total;
     in.max_len = max_len;
+    for (int c = 0; c < 4; c++) { in.cls_n[c] = cls_n[c]; in.cls_max[c] = cls_max[c]; }
     in.n_exact = n_exact;
     in.has_exact = exact_off != nullptr;
     in.staged = true;
@@ -820,9 +1002,7 @@ int rtx_batch_activate(rtx_index *ix) {
     rtx_index::Inputs &in = ix->in[ix->cur_in ^ 1u];
     if (!in.staged) { set_error("rtx_batch_activate without a staged batch (rtx_batch_prefetch)"); return RTX_ERR_STATE; }
     ix->uploaded = ix->ran = ix->synced = false;
-    // t <= min(len - 7, 65536); t == 65536 would trip the u16 assert of raxtax.rs:56
-    const uint64_t tmax = in.max_len >= 8 ? in.max_len - 7 : 1;
-    if ((rc = prepare_workspace(ix, in.n_q, tmax, in.max_len))) return rc;
+    if ((rc = prepare_workspace(ix, in.n_q, in.cls_n, in.cls_max))) return rc;
     ix->sum_query_bytes = in.total;
     if ((rc = ix->d_bases.alloc(in.total + 64))) return rc;
     RTX_HIP(hipStreamWaitEvent(ix->stream, in.ready, 0));

@@ -8,21 +8,23 @@ int rtx_batch_stage_times(rtx_index *ix, float ms[RTX_NUM_STAGES], uint32_t laun
     if (rc) return rc;
     if (!ix->synced) { set_error("rtx_batch_stage_times: batch not synchronised"); return RTX_ERR_STATE; }
     for (int s = 0; s < RTX_NUM_STAGES; s++) { ms[s] = 0.f; launches[s] = 0; }
-    for (uint32_t sb = 0; sb < ix->n_sub_last; sb++)
+    for (uint32_t sb = 0; sb < ix->n_sub_last; sb++) {
+        const rtx_index::BatchClass &kc = ix->cls[sb < ix->sub_cls.size() ? ix->sub_cls[sb] : 0u];  // which events its class recorded
         for (int s = 0; s < RTX_NUM_STAGES; s++) {
             if (s == RTX_STAGE_EXACT_MATCH) {
                 if (sb != 0 || !ix->dev_exact_used || !ix->stage_timing) continue;  // one launch per run
             } else if (s == RTX_STAGE_ORDER) {
                 if (sb != 0 || !ix->stage_timing) continue;  // once per run
             } else if (s == RTX_STAGE_PAIR_UNION) {
-                if (!ix->pair_used || !ix->stage_timing) continue;
-            } else if (s == RTX_STAGE_TILE_BOUNDS || s == RTX_STAGE_TILE_PRUNE ? !ix->prune_used : (s != RTX_STAGE_HIT_COUNT && !ix->stage_timing)) continue;  // events were not recorded
+                if (!kc.pair || !ix->stage_timing) continue;
+            } else if (s == RTX_STAGE_TILE_BOUNDS || s == RTX_STAGE_TILE_PRUNE ? !kc.prune : (s != RTX_STAGE_HIT_COUNT && !ix->stage_timing)) continue;  // events were not recorded
             float t = 0.f;
             RTX_HIP(hipEventElapsedTime(&t, ix->events[((size_t)sb * RTX_NUM_STAGES + s) * 2],
                                         ix->events[((size_t)sb * RTX_NUM_STAGES + s) * 2 + 1]));
             ms[s] += t;
             launches[s]++;
         }
+    }
     return RTX_OK;
 }
 
@@ -37,22 +39,31 @@ int rtx_batch_work(rtx_index *ix, uint64_t *sum_hits, uint64_t *sum_query_bytes,
     RTX_HIP(hipMemcpy(ix->h_nrows_all.data(), ix->d_nrows_all.p, ix->n_q * 4, hipMemcpyDeviceToHost));
     uint64_t h = 0, b = 0;
     const uint64_t row_bytes = ((ix->n_refs + 7) / 8 + ix->ntiles - 1) / ix->ntiles;  // per dense segment (nrows counts segments)
-    for (uint64_t q = 0; q < ix->n_q; q++) {
-        h += ix->h_hq[q];
-        b += (uint64_t)ix->h_nrows_all[q] * row_bytes;
-    }
-    if (ix->pair_used) {  // rows were loaded once per pair of queries: the union rows every wave counted
-        const uint32_t n_sub = (uint32_t)((ix->n_q + ix->sub_batch - 1) / ix->sub_batch);
-        const size_t ng = (size_t)n_sub * ix->groups_per_sub;
-        std::vector<uint32_t> gr(2 * ng);
+    for (uint64_t q = 0; q < ix->n_q; q++) h += ix->h_hq[q];
+    // per sub-batch: a class on the pair kernel loaded its rows once per pair of queries (the union rows every wave counted: d_group_rows),
+    // the others once per query (kmer_extract's number of dense segments)
+    const uint32_t n_sub = ix->n_sub_total;
+    const size_t ng = (size_t)n_sub * ix->groups_per_sub;
+    std::vector<uint32_t> gr;
+    bool any_pair = false, any_prune = false;
+    for (uint32_t c = 0; c < ix->n_cls; c++) { any_pair = any_pair || ix->cls[c].pair; any_prune = any_prune || ix->cls[c].prune; }
+    if (any_pair) {
+        gr.resize(2 * ng);
         RTX_HIP(hipMemcpy(gr.data(), ix->d_group_rows.p, gr.size() * 4, hipMemcpyDeviceToHost));
-        b = 0;
-        for (size_t g = 0; g < ng; g++) b += (uint64_t)gr[g] * row_bytes;
-        if (ix->prune_used) {  // + the rows of the union bitmap the bounds pass of the tile pruning loaded (the same kernel)
-            const uint64_t urow_bytes = ((ix->u_nblocks + 7) / 8 + ix->u_ntiles - 1) / ix->u_ntiles;
-            for (size_t g = ng; g < 2 * ng; g++) b += (uint64_t)gr[g] * urow_bytes;
+    }
+    const uint64_t urow_bytes = ix->u_ntiles ? ((ix->u_nblocks + 7) / 8 + ix->u_ntiles - 1) / ix->u_ntiles : 0;
+    for (uint32_t sb = 0; sb < n_sub; sb++) {
+        const rtx_index::BatchClass &kc = ix->cls[ix->sub_cls[sb]];
+        if (kc.pair) {
+            for (size_t g = (size_t)sb * ix->groups_per_sub; g < (size_t)(sb + 1) * ix->groups_per_sub; g++) {
+                b += (uint64_t)gr[g] * row_bytes;
+                if (kc.prune) b += (uint64_t)gr[ng + g] * urow_bytes;  // + the rows of the union bitmap the bounds pass loaded (the same kernel)
+            }
+        } else {
+            for (uint64_t pos = ix->sub_q0[sb]; pos < ix->sub_q0[sb] + ix->sub_nq[sb]; pos++) b += (uint64_t)ix->h_nrows_all[pos] * row_bytes;
         }
     }
+    (void)any_prune;
     if (sum_hits) *sum_hits = h;
     if (sum_query_bytes) *sum_query_bytes = ix->sum_query_bytes;
     if (bitmap_bytes_read) *bitmap_bytes_read = b;
@@ -66,13 +77,19 @@ int rtx_batch_work_split(rtx_index *ix, uint64_t *live_bytes, uint64_t *bounds_b
     int rc = rtx_batch_work(ix, nullptr, nullptr, &total);
     if (rc) return rc;
     uint64_t bounds = 0;
-    if (ix->pair_used && ix->prune_used) {
-        const uint32_t n_sub = (uint32_t)((ix->n_q + ix->sub_batch - 1) / ix->sub_batch);
+    {
+        const uint32_t n_sub = ix->n_sub_total;
         const size_t ng = (size_t)n_sub * ix->groups_per_sub;
-        std::vector<uint32_t> gr(ng);
-        RTX_HIP(hipMemcpy(gr.data(), ix->d_group_rows.p + ng, ng * 4, hipMemcpyDeviceToHost));
-        const uint64_t urow_bytes = ((ix->u_nblocks + 7) / 8 + ix->u_ntiles - 1) / ix->u_ntiles;
-        for (size_t g = 0; g < ng; g++) bounds += (uint64_t)gr[g] * urow_bytes;
+        bool any = false;
+        for (uint32_t c = 0; c < ix->n_cls; c++) any = any || (ix->cls[c].pair && ix->cls[c].prune);
+        if (any) {
+            std::vector<uint32_t> gr(ng);
+            RTX_HIP(hipMemcpy(gr.data(), ix->d_group_rows.p + ng, ng * 4, hipMemcpyDeviceToHost));
+            const uint64_t urow_bytes = ((ix->u_nblocks + 7) / 8 + ix->u_ntiles - 1) / ix->u_ntiles;
+            for (uint32_t sb = 0; sb < n_sub; sb++)
+                if (ix->cls[ix->sub_cls[sb]].prune)
+                    for (size_t g = (size_t)sb * ix->groups_per_sub; g < (size_t)(sb + 1) * ix->groups_per_sub; g++) bounds += (uint64_t)gr[g] * urow_bytes;
+        }
     }
     if (live_bytes) *live_bytes = total - bounds;
     if (bounds_bytes) *bounds_bytes = bounds;
@@ -104,7 +121,7 @@ static int debug_slot_as_run(rtx_index *ix, uint64_t query, uint32_t *slot) {  /
     int rc = bind(ix);
     if (rc) return rc;
     if (!ix->synced) { set_error("debug tap: batch not synchronised"); return RTX_ERR_STATE; }
-    const uint64_t last0 = (ix->n_q - 1) / ix->sub_batch * ix->sub_batch;
+    const uint64_t last0 = ix->n_sub_total && ix->sub_q0.size() == ix->n_sub_total ? ix->sub_q0[ix->n_sub_total - 1] : 0;  // the last sub-batch of the run (of its last length class)
     if (query >= ix->n_q) { set_error("debug tap: query %llu out of range", (unsigned long long)query); return RTX_ERR_INVALID; }
     const uint64_t pos = ix->h_inv[query];  // position in the processing order (valid once the stream is synchronised)
     if (pos < last0) { set_error("debug tap: query %llu not in the last sub-batch", (unsigned long long)query); return RTX_ERR_INVALID; }
@@ -121,7 +138,7 @@ static int debug_slot(rtx_index *ix, uint64_t query, uint32_t *slot) {
 // (k-mers, hit counts, histogram, probability table; the result rows of the run are not touched).
 static int debug_recount_full(rtx_index *ix) {
     if (!ix->prune_used || ix->dbg_full) return RTX_OK;
-    const uint32_t n_sub = (uint32_t)((ix->n_q + ix->sub_batch - 1) / ix->sub_batch);
+    const uint32_t n_sub = ix->n_sub_total;
     SubBatch b = sub_batch_of(ix, n_sub - 1, false);
     b.set = ix->last_set;
     ix->dbg_full_run = true;
@@ -314,7 +331,7 @@ int rtx_debug_tile_bounds(rtx_index *ix, uint64_t query, uint16_t *tile_ub) {
 int rtx_debug_prune_stats(rtx_index *ix, uint64_t *out) {
     if (!ix || !out) { set_error("null argument"); return RTX_ERR_INVALID; }
     std::memset(out, 0, 128);
-    if (!ix->prune_used || !ix->d_prune_stats.p) return RTX_OK;
+    if (!ix->any_prune || !ix->d_prune_stats.p) return RTX_OK;
     RTX_HIP(hipStreamSynchronize(ix->stream));
     unsigned long long h[kPruneStatCopies * 32];
     RTX_HIP(hipMemcpy(h, ix->d_prune_stats.p, sizeof(h), hipMemcpyDeviceToHost));
@@ -331,9 +348,33 @@ int rtx_debug_prune_stats(rtx_index *ix, uint64_t *out) {
 
 int rtx_batch_sub_batch(const rtx_index *ix, uint32_t *sub_batch, uint32_t *n_sub) {
     if (!ix) { set_error("null index handle"); return RTX_ERR_INVALID; }
-    if (!ix->uploaded || ix->sub_batch == 0) { set_error("rtx_batch_sub_batch: no batch has been uploaded"); return RTX_ERR_STATE; }
-    if (sub_batch) *sub_batch = ix->sub_batch;
-    if (n_sub) *n_sub = (uint32_t)((ix->n_q + ix->sub_batch - 1) / ix->sub_batch);
+    if (!ix->uploaded || ix->sub_batch == 0 || ix->n_cls == 0) { set_error("rtx_batch_sub_batch: no batch has been uploaded"); return RTX_ERR_STATE; }
+    if (sub_batch) *sub_batch = ix->cls[ix->n_cls - 1].sub_batch;
+    if (n_sub) *n_sub = ix->n_sub_total;
+    return RTX_OK;
+}
+
+// the last sub-batch of the uploaded batch (the one the taps can read): positions [first, first + n) of the processing order
+int rtx_batch_last_sub_batch(const rtx_index *ix, uint64_t *first, uint32_t *n) {
+    if (!ix) { set_error("null index handle"); return RTX_ERR_INVALID; }
+    if (!ix->uploaded || ix->n_sub_total == 0 || ix->sub_q0.size() != ix->n_sub_total) { set_error("rtx_batch_last_sub_batch: no batch has been uploaded"); return RTX_ERR_STATE; }
+    if (first) *first = ix->sub_q0[ix->n_sub_total - 1];
+    if (n) *n = ix->sub_nq[ix->n_sub_total - 1];
+    return RTX_OK;
+}
+
+// length classes of the uploaded batch (rtx_index.hpp: BatchClass): out[c] = {queries, longest query, sub-batch size, bit planes} for c < *n_classes (at most 4)
+int rtx_batch_classes(const rtx_index *ix, uint32_t *n_classes, uint64_t out[16]) {
+    if (!ix || !n_classes || !out) { set_error("null argument"); return RTX_ERR_INVALID; }
+    if (!ix->uploaded) { set_error("rtx_batch_classes: no batch has been uploaded"); return RTX_ERR_STATE; }
+    *n_classes = ix->n_cls;
+    for (uint32_t c = 0; c < ix->n_cls && c < 4u; c++) {
+        out[c * 4 + 0] = ix->cls[c].n;
+        out[c * 4 + 1] = ix->cls[c].max_len;
+        out[c * 4 + 2] = ix->cls[c].sub_batch;
+        out[c * 4 + 3] = (uint64_t)ix->cls[c].planes | (ix->cls[c].use_tables ? 1ull << 8 : 0) | (ix->cls[c].pair ? 1ull << 9 : 0) | (ix->cls[c].prune ? 1ull << 10 : 0) |
+                         (ix->cls[c].rec ? 1ull << 11 : 0) | (ix->cls[c].huge ? 1ull << 12 : 0);
+    }
     return RTX_OK;
 }
 
@@ -368,7 +409,7 @@ int rtx_debug_evaluate(rtx_index *ix, const double *probs, rtx_result_view *out)
     const uint64_t N = ix->n_refs;
     if (N > 65535) { set_error("rtx_debug_evaluate supports at most 65535 references"); return RTX_ERR_INVALID; }
     ix->uploaded = ix->ran = ix->synced = false;
-    if ((rc = prepare_workspace(ix, 1, std::max<uint64_t>(N, 8), 0))) return rc;
+    if ((rc = prepare_workspace_single(ix, 1, std::max<uint64_t>(N, 8), 0))) return rc;
     ix->last_set = 0;
     ix->sum_query_bytes = 0;
     ix->stream_dl = false;

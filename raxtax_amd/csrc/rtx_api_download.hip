@@ -150,7 +150,8 @@ int copy_results(rtx_index *ix, uint64_t q0, uint64_t n, uint64_t r0, uint64_t r
 static int download_streamed(rtx_index *ix, rtx_index::HostRes &hr, bool *done, uint64_t *nrows_out) {
     *done = false;
     const uint32_t n_sub = ix->n_sub_run;
-    if (!ix->stream_dl || n_sub < 2 || hipEventQuery(ix->ev_sub[n_sub - 1]) == hipSuccess) return RTX_OK;
+    if (!ix->stream_dl || n_sub < 2 || ix->sub_q0.size() != n_sub || hipEventQuery(ix->ev_sub[n_sub - 1]) == hipSuccess) return RTX_OK;
+    (void)0;
     const uint64_t nq = ix->n_q;
     int rc = size_host_results(ix, hr, nq, ix->arena_cap);
     if (rc) return rc;
@@ -159,7 +160,7 @@ static int download_streamed(rtx_index *ix, rtx_index::HostRes &hr, bool *done, 
         RTX_HIP(hipEventSynchronize(ix->ev_sub[sb]));
         const uint64_t cur = ix->h_cursor_sub[sb];
         if (cur > ix->arena_cap) return RTX_OK;  // overflow: bulk path
-        const uint64_t q0 = (uint64_t)sb * ix->sub_batch, n = std::min<uint64_t>(ix->sub_batch, nq - q0);
+        const uint64_t q0 = ix->sub_q0[sb], n = ix->sub_nq[sb];  // (classes of different sub-batch sizes follow one another: plan_sub_batches)
         if ((rc = copy_results(ix, q0, n, prev, cur, ix->copy_stream))) return rc;
         RTX_HIP(hipStreamSynchronize(ix->copy_stream));
         // one thread finalises 8192 queries in ~1.4 ms, about what the device needs for the next sub-batch: with a short

@@ -36,7 +36,7 @@ static int shard_sb(rtx_index *ix, uint32_t sb, SubBatch *b) {
     int rc = bind(ix);
     if (rc) return rc;
     if (!ix->ran) { set_error("rtx_shard_* before rtx_shard_begin"); return RTX_ERR_STATE; }
-    const uint32_t n_sub = (uint32_t)((ix->n_q + ix->sub_batch - 1) / ix->sub_batch);
+    const uint32_t n_sub = ix->n_sub_total;
     if (sb >= n_sub) { set_error("sub-batch %u out of range (%u)", sb, n_sub); return RTX_ERR_INVALID; }
     *b = sub_batch_of(ix, sb, ix->n_sub_last != 0);
     ix->synced = false;

@@ -266,6 +266,20 @@ __global__ __launch_bounds__(64) void locator_kernel(const uint8_t *__restrict__
     if (lane == 0) keys[q] = (loc << 39) | (old_key >> 24);
 }
 
+// Length classes (rtx_index.hpp: BatchClass): the class of a query -- the number of the limits its length exceeds -- leads the sort key, so
+// that the processing order holds the classes one after the other; inside a class the order is the one the keys gave (or, with the
+// processing order switched off, the input order: index keys).
+__global__ __launch_bounds__(256) void class_keys_kernel(uint64_t *__restrict__ keys, const uint64_t *__restrict__ off, uint32_t n, uint64_t lim0,
+                                                         uint64_t lim1, uint64_t lim2, uint32_t shift, uint32_t from_index, uint32_t *__restrict__ idx) {
+    const uint32_t q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= n) return;
+    const uint64_t len = off[q + 1] - off[q];
+    const uint64_t rank = (len > lim0 ? 1u : 0u) + (len > lim1 ? 1u : 0u) + (len > lim2 ? 1u : 0u);
+    const uint64_t k = from_index ? (uint64_t)q : keys[q] >> shift;
+    keys[q] = (rank << 62) | k;
+    if (from_index) idx[q] = q;
+}
+
 __global__ __launch_bounds__(256) void invert_perm_kernel(const uint32_t *__restrict__ perm, uint32_t n, uint32_t *__restrict__ inv) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i < n) inv[perm[i]] = i;
@@ -306,10 +320,14 @@ void launch_identity_perm(hipStream_t s, uint32_t n, uint32_t *perm, uint32_t *i
     hipLaunchKernelGGL(identity_perm_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, perm, inv);
 }
 
-// tmp == nullptr: only reports the temporary storage needed
+void launch_class_keys(hipStream_t s, uint64_t *keys, const uint64_t *off, uint32_t n, const uint64_t lim[3], bool from_index, uint32_t *idx) {
+    hipLaunchKernelGGL(class_keys_kernel, dim3((n + 255) / 256), dim3(256), 0, s, keys, off, n, lim[0], lim[1], lim[2], 1u, from_index ? 1u : 0u, idx);
+}
+
+// tmp == nullptr: only reports the temporary storage needed.  with_class: the keys carry the length class in their two top bits.
 int cluster_sort(hipStream_t s, void *tmp, size_t *tmp_bytes, const uint64_t *keys_in, uint64_t *keys_out, const uint32_t *idx_in,
-                 uint32_t *perm_out, size_t n) {
-    const hipError_t e = rocprim::radix_sort_pairs(tmp, *tmp_bytes, keys_in, keys_out, idx_in, perm_out, n, 0, 3 * kSketchBits, s);
+                 uint32_t *perm_out, size_t n, bool with_class) {
+    const hipError_t e = rocprim::radix_sort_pairs(tmp, *tmp_bytes, keys_in, keys_out, idx_in, perm_out, n, 0, with_class ? 64u : 3 * kSketchBits, s);
     return e == hipSuccess ? 0 : 1;
 }
 

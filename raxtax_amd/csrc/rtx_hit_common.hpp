@@ -214,7 +214,9 @@ __device__ __forceinline__ uint32_t pk_max_u16(uint32_t a, uint32_t b) {  // v_p
     return r;
 }
 
-template <int NP, bool kPacked, bool kPrefetch, bool kFullTile, bool kPreLoaded>
+//   kGlobalHist: reads of tens of kilobases (t up to 65 535: a histogram row does not fit LDS beside the list): every count goes to the
+//   query's histogram row in global memory with an atomic of its own, the tile's largest count is taken from the counts themselves.
+template <int NP, bool kPacked, bool kPrefetch, bool kFullTile, bool kPreLoaded, bool kGlobalHist = false>
 __device__ __forceinline__ void hit_epilogue_x(const HitParams &p, uint32_t (&pl)[4][NP], uint32_t q, uint32_t tile, uint32_t lane,
                                                uint32_t t, bool active, uint32_t *hist_lds, uint32_t *cnt8, uint32_t ns,
                                                const uint32_t *srows, uint4 (&pre)[kSparseIt][kSparseV], uint32_t h_thr) {
@@ -320,8 +322,12 @@ __device__ __forceinline__ void hit_epilogue_x(const HitParams &p, uint32_t (&pl
             return;
         }
     }
-    for (uint32_t i = lane; i <= t; i += 64) hist_lds[i] = 0;
-    wave_lds_sync();
+    uint32_t *const hist_g = p.hist + (size_t)q * p.hstride;
+    uint32_t mx_g = 0;  // kGlobalHist: the largest count this lane saw
+    if (!kGlobalHist) {
+        for (uint32_t i = lane; i <= t; i += 64) hist_lds[i] = 0;
+        wave_lds_sync();
+    }
     // tile pruning gave the query a threshold u: every count up to u is a reference without a hit to prob_lookup (rtx_prob_tables.hip) --
     // they go to bin 0 as one number, and only the groups of references that hold a count above u touch the histogram (h_thr: u or 0)
     const uint32_t h_lo = h_thr ? h_thr + 1u : 0u;
@@ -433,6 +439,16 @@ __device__ __forceinline__ void hit_epilogue_x(const HitParams &p, uint32_t (&pl
                                 if (c >= h_lo) atomicAdd(&hist_lds[c], 1u);
                             }
                         }
+                    } else if (kGlobalHist) {  // the histogram row lives in global memory (reads of tens of kilobases)
+                        const int32_t left = refs_left - (int32_t)goff;
+                        const uint32_t nvalid = left <= 0 ? 0u : (left < 8 ? (uint32_t)left : 8u);
+#pragma unroll
+                        for (int j = 0; j < 8; j++)
+                            if ((uint32_t)j < nvalid) {
+                                const uint32_t c = (cw[j >> 1] >> ((j & 1) * 16)) & 0xFFFFu;
+                                atomicAdd(&hist_g[c <= t ? c : t], 1u);
+                                mx_g = c > mx_g ? c : mx_g;
+                            }
                     } else if (tile_full) {  // wave-uniform: every reference of the tile exists -- no compare, no exec mask per atomic
 #pragma unroll
                         for (int j = 0; j < 8; j++) atomicAdd(&hist_lds[(cw[j >> 1] >> ((j & 1) * 16)) & 0xFFFFu], 1u);
@@ -472,13 +488,14 @@ __device__ __forceinline__ void hit_epilogue_x(const HitParams &p, uint32_t (&pl
     }
     wave_lds_sync();
     // every lane of the wave flushes (also those whose columns lie beyond the row)
-    uint32_t *hist = p.hist + (size_t)q * p.hstride;
-    uint32_t mx = 0;  // the largest count of this tile = its highest non-empty bin
+    uint32_t *hist = hist_g;
+    uint32_t mx = mx_g;  // the largest count of this tile = its highest non-empty bin
     uint32_t n_high = 0;
-    for (uint32_t m = lane; m <= t; m += 64) {
-        const uint32_t v = hist_lds[m];
-        if (v) { atomicAdd(&hist[m], v); mx = m; n_high += v; }
-    }
+    if (!kGlobalHist)
+        for (uint32_t m = lane; m <= t; m += 64) {
+            const uint32_t v = hist_lds[m];
+            if (v) { atomicAdd(&hist[m], v); mx = m; n_high += v; }
+        }
     if (h_lo) {  // the references of the tile with a count up to the threshold (0 for the tile's largest count if there is no other)
         n_high = wave_incl_scan_u32(n_high);
         const uint32_t in_tile = tile_full ? 8192u : (uint32_t)(p.n_refs - ((uint64_t)tile << 13));
@@ -761,12 +778,12 @@ __device__ __forceinline__ void fine_epilogue(const HitParams &p, uint32_t (&pl)
     if (p.fine_stats) atomicAdd(&p.fine_stats[(size_t)(q & (kPruneStatCopies - 1u)) * 8u], (unsigned long long)n);
 }
 
-template <int NP, bool kPacked, bool kPrefetch = false>
+template <int NP, bool kPacked, bool kPrefetch = false, bool kGlobalHist = false>
 __device__ __forceinline__ void hit_epilogue(const HitParams &p, uint32_t (&pl)[4][NP], uint32_t q, uint32_t tile, uint32_t lane,
                                              uint32_t t, bool active, uint32_t *hist_lds, uint32_t *cnt8, uint32_t ns,
                                              const uint32_t *srows) {
     uint4 pre[kSparseIt][kSparseV];  // unused without kPrefetch
-    hit_epilogue_x<NP, kPacked, kPrefetch, false, false>(p, pl, q, tile, lane, t, active, hist_lds, cnt8, ns, srows, pre,
+    hit_epilogue_x<NP, kPacked, kPrefetch, false, false, kGlobalHist>(p, pl, q, tile, lane, t, active, hist_lds, cnt8, ns, srows, pre,
                                                          p.prune_thr ? (uint32_t)__builtin_amdgcn_readfirstlane((int)p.prune_thr[q]) : 0u);
 }
 

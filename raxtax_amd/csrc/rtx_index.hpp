@@ -211,6 +211,7 @@ struct rtx_index {
         PinBuf<uint64_t> h_base_off, h_exact_off;
         PinBuf<uint32_t> h_exact_ids;
         uint64_t n_q = 0, total = 0, max_len = 0, n_exact = 0;
+        uint64_t cls_n[4] = {0, 0, 0, 0}, cls_max[4] = {0, 0, 0, 0};  // queries and longest query per length class (length_class)
         bool packed = true, has_exact = false, staged = false, recorded = false;
         hipEvent_t ready = nullptr;        // its transfer has arrived
     } in[2];
@@ -224,8 +225,30 @@ struct rtx_index {
     // ---- sub-batch scratch: two sets -- a staged (reference-sharded) run alternates between them, so that the exchange of
     // one sub-batch can overlap with the counting of the next; a whole-database handle uses set 0 only
     uint32_t sub_batch_req = 0, sub_batch = 0;
-    uint64_t ws_key[6] = {0, 0, 0, 0, 0, 0};  // shape and options the workspace was last prepared for (prepare_workspace)
+    uint64_t ws_key[14] = {0};  // shape and options the workspace was last prepared for (prepare_workspace)
     bool ws_valid = false;
+    // ---- length classes of the batch (round 5).  t <= length - 7 decides how a query is counted (8 / 10 / 12 / 16 bit planes, the pair
+    // kernel, tile pruning), how its probabilities are computed (memoised tables up to t = 1023, the recurrence kernel in LDS, the same
+    // from global memory for reads of tens of kilobases) and how much scratch it needs.  A batch used to take ALL of that from its longest
+    // query: one 1 100-base read in a file of COI barcodes moved every query off the fast path.  Now the class leads the sort key of the
+    // processing order, every class is cut into sub-batches of its own shape, and the fields above (tmax, strides, planes, sub_batch,
+    // use_tables, pair_used, prune_used, rec_used) are those of the class being enqueued (apply_class) -- after a run: of the last one,
+    // which is what the taps of the last sub-batch read.  A reference shard and rtx_debug_evaluate run one class.
+    struct BatchClass {
+        uint64_t pos0 = 0, n = 0, max_len = 0;  // positions [pos0, pos0 + n) of the processing order
+        uint32_t tmax = 0, kstride = 0, rstride = 0, hstride = 0, sub_batch = 0, sb0 = 0, n_sub = 0;
+        int planes = 10;
+        bool use_tables = false, pair = false, prune = false, rec = false, huge = false, will_prune = false;
+    } cls[4];
+    uint32_t n_cls = 0;
+    int cur_cls = -1;
+    uint64_t key_lim[3] = {~0ull, ~0ull, ~0ull};  // sort rank of a query = the number of these lengths it exceeds
+    std::vector<uint64_t> sub_q0;   // per sub-batch of the run: first position,
+    std::vector<uint32_t> sub_nq;   // queries,
+    std::vector<uint8_t> sub_cls;   // class
+    uint32_t n_sub_total = 0, sub_batch_max = 0;
+    bool any_prune = false;  // some class of the last run pruned (rtx_debug_prune_stats sums over the run)
+    DevBuf<double> d_prob_scratch;  // prob_table_kernel's arrays of a class of very long reads (they do not fit LDS)
     struct Scratch {
         DevBuf<uint16_t> d_kmers, d_counts, d_tilemax;
         DevBuf<uint32_t> d_rows, d_t, d_nrows, d_hist, d_order, d_srows, d_nsparse;
@@ -342,8 +365,13 @@ int enqueue_walk(rtx_index *ix, const SubBatch &b, const double *prefix, hipStre
 int order_batch(rtx_index *ix, bool cluster);
 int begin_run(rtx_index *ix, uint32_t *n_sub_out, bool *timed_out, bool cluster);
 int enqueue_batch(rtx_index *ix, uint32_t flags);
-int ensure_prob_tables(rtx_index *ix);
-int prepare_workspace(rtx_index *ix, uint64_t n_queries, uint64_t tmax, uint64_t max_len);
+int ensure_prob_tables(rtx_index *ix, uint32_t tmax, bool *usable);
+uint32_t length_class(uint64_t len);
+uint64_t class2_max_len();  // 0: t <= 255, 1: t <= 1023, 2: longer, prob_table in LDS, 3: longer still
+int prepare_workspace(rtx_index *ix, uint64_t n_queries, const uint64_t cls_n[4], const uint64_t cls_max[4]);
+int prepare_workspace_single(rtx_index *ix, uint64_t n_queries, uint64_t tmax, uint64_t max_len);  // one class whatever the lengths
+void apply_class(rtx_index *ix, uint32_t c);
+int plan_sub_batches(rtx_index *ix);
 int alloc_scratch_set(rtx_index *ix, uint32_t k);
 // ---- rtx_api_download.hip
 void node_tables(rtx_index *ix);

@@ -478,7 +478,7 @@ __global__ __launch_bounds__(64) void kmer_extract_kernel(KmerParams p) {
 #define RTX_HIT_NB 2
 #endif
 
-template <int NP, bool kPacked>
+template <int NP, bool kPacked, bool kGlobalHist = false>
 #if RTX_HIT_NB > 2  // RTX_HIT_NB buffers of eight rows in flight per wave, 256 registers, two waves per SIMD (three with NB = 3)
 __global__ __launch_bounds__(64, (RTX_HIT_NB == 3 ? 3 : 2)) void hit_count_kernel(HitParams p) {
 #else
@@ -606,13 +606,14 @@ __global__ __launch_bounds__(64, (NP <= 10 ? 4 : 2)) void hit_count_kernel(HitPa
             __syncthreads();  // the list is rewritten (next round) or becomes the histogram
         }
     }
-    hit_epilogue<NP, kPacked>(p, pl, q, tile, lane, t, active, hist_lds, cnt8, ns, srows);
+    hit_epilogue<NP, kPacked, false, kGlobalHist>(p, pl, q, tile, lane, t, active, hist_lds, cnt8, ns, srows);
 }
 
 template __global__ void hit_count_kernel<10, true>(HitParams);
 template __global__ void hit_count_kernel<10, false>(HitParams);
 template __global__ void hit_count_kernel<12, false>(HitParams);
 template __global__ void hit_count_kernel<16, false>(HitParams);
+template __global__ void hit_count_kernel<16, false, true>(HitParams);
 
 // ---------------------------------------------------------------------------
 // prob_table (src/prob.rs:8-103): one workgroup of kProbWaves waves per query.
@@ -635,8 +636,13 @@ static constexpr uint32_t kGroupSkipped = 0xFFFFFFFFu;
 static constexpr uint32_t kProbWaves = 2;  // waves per query: groups g = wave, wave+2, ...
 static constexpr uint32_t kProbThreads = kProbWaves * 64;
 
+// kGlobal: reads of tens of kilobases (t up to 65 535) -- the arrays (3.4 bytes per k-mer ... 1.6 MB at the limit) do not fit LDS: the
+// workgroup works in a stretch of global memory of its own (ProbParams::gscratch), the same code and the same arithmetic through flat
+// addresses; __syncthreads orders the waves of the workgroup through it as it does through LDS (same CU, write-through L1).
+template <bool kGlobal>
 __global__ __launch_bounds__(kProbThreads) void prob_table_kernel(ProbParams p) {
-    extern __shared__ double smem[];
+    extern __shared__ double smem_lds[];
+    double *const smem = kGlobal ? p.gscratch + (size_t)blockIdx.x * p.gstride : smem_lds;
     __shared__ uint32_t s_D, s_ilo;
     const uint32_t q = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint64_t gq = p.q0 + q;
@@ -1155,17 +1161,17 @@ void launch_kmer_extract(hipStream_t s, const KmerParams &p, uint32_t nq) {
     if (p.mode == 2u) hipLaunchKernelGGL(kmer_extract_kernel<true>, dim3(nq), dim3(64), 0, s, p);
     else hipLaunchKernelGGL(kmer_extract_kernel<false>, dim3(nq), dim3(64), 0, s, p);
 }
+// a histogram row of more entries than this does not share LDS with the row list: hit_count adds to it in global memory
+constexpr uint32_t kHitLdsHistMax = 12288;
 void launch_hit_count(hipStream_t s, const HitParams &p_in, uint32_t nq, uint32_t ntiles, int planes) {
     HitParams p = p_in;
-    const uint32_t first = std::max<uint32_t>((p.hstride + 3u) & ~3u, kHitListCap + (RTX_HIT_NB > 2 ? 192u : 64u));  // histogram / row-id list
+    const bool ghist = p.hstride > kHitLdsHistMax;
+    const uint32_t first = std::max<uint32_t>(ghist ? 0u : (p.hstride + 3u) & ~3u, kHitListCap + (RTX_HIT_NB > 2 ? 192u : 64u));  // histogram / row-id list
     p.lds_cnt8_off = first;
     // 8.4 KB per wave: measured flat up to there, +7 % at 10.4 KB, +14 % at 12.5 KB (16 waves per CU must fit in 160 KB)
-#ifdef RTX_EXP_HIT_LDS_KB  // experiment: fewer waves per CU (160 KB / this)
-    const size_t lds = std::max<size_t>((size_t)first * sizeof(uint32_t) + 4096, (size_t)RTX_EXP_HIT_LDS_KB * 1024);
-#else
     const size_t lds = (size_t)first * sizeof(uint32_t) + 4096;  // ... | byte counters
-#endif
-    if (planes <= 10 && p.counts_lo) hipLaunchKernelGGL((hit_count_kernel<10, true>), dim3(nq, ntiles), dim3(64), lds, s, p);
+    if (ghist) hipLaunchKernelGGL((hit_count_kernel<16, false, true>), dim3(nq, ntiles), dim3(64), lds, s, p);
+    else if (planes <= 10 && p.counts_lo) hipLaunchKernelGGL((hit_count_kernel<10, true>), dim3(nq, ntiles), dim3(64), lds, s, p);
     else if (planes <= 10) hipLaunchKernelGGL((hit_count_kernel<10, false>), dim3(nq, ntiles), dim3(64), lds, s, p);
     else if (planes <= 12) hipLaunchKernelGGL((hit_count_kernel<12, false>), dim3(nq, ntiles), dim3(64), lds, s, p);
     else hipLaunchKernelGGL((hit_count_kernel<16, false>), dim3(nq, ntiles), dim3(64), lds, s, p);
@@ -1177,7 +1183,8 @@ size_t prob_table_lds_bytes(uint32_t tmax) {
            sizeof(uint16_t) * ((size_t)tmax + 2);
 }
 void launch_prob_table(hipStream_t s, const ProbParams &p, uint32_t nq) {
-    hipLaunchKernelGGL(prob_table_kernel, dim3(nq), dim3(kProbThreads), prob_table_lds_bytes(p.tmax), s, p);
+    if (p.gscratch) hipLaunchKernelGGL(prob_table_kernel<true>, dim3(nq), dim3(kProbThreads), 0, s, p);
+    else hipLaunchKernelGGL(prob_table_kernel<false>, dim3(nq), dim3(kProbThreads), prob_table_lds_bytes(p.tmax), s, p);
 }
 template <int NW>
 static void launch_taxon_prefix_nw(hipStream_t s, const PrefixParams &p, uint32_t nq, size_t lds) {

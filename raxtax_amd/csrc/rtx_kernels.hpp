@@ -264,6 +264,8 @@ struct ProbParams {
     uint32_t *ndist;  // [n_q] number of distinct hit counts D_q (work accounting)
     const uint16_t *prune_thr;  // [B] tile pruning: references with a count up to this carry nothing (rtx_prune.hip) or null
     const uint16_t *prune_i1;   // [B] ... and the sums over i may start here (everything below holds less than eps = 1e-10 of Z)
+    double *gscratch;           // prob_table_kernel for reads whose arrays do not fit LDS: [B][gstride] doubles of global memory, or null
+    uint32_t gstride;
 };
 
 constexpr uint32_t kWalkSubAllocs = 128;    // sub-allocators of the result arena (512 walks of a launch of 65 536 share one)
@@ -374,7 +376,8 @@ void launch_locator(hipStream_t s, const uint8_t *bases, const uint64_t *off, ui
                     uint64_t *keys);
 void launch_identity_perm(hipStream_t s, uint32_t n, uint32_t *perm, uint32_t *inv);
 int cluster_sort(hipStream_t s, void *tmp, size_t *tmp_bytes, const uint64_t *keys_in, uint64_t *keys_out, const uint32_t *idx_in,
-                 uint32_t *perm_out, size_t n);
+                 uint32_t *perm_out, size_t n, bool with_class = false);
+void launch_class_keys(hipStream_t s, uint64_t *keys, const uint64_t *off, uint32_t n, const uint64_t lim[3], bool from_index, uint32_t *idx);
 void launch_taxon_prefix(hipStream_t s, const PrefixParams &p, uint32_t nq);
 void launch_lineage_walk(hipStream_t s, const WalkParams &p, uint32_t nq);
 void launch_probs_expand(hipStream_t s, const uint16_t *counts, const double *tz, uint64_t n, double *out);

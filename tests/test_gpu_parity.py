@@ -646,9 +646,12 @@ def test_api_misuse_is_reported(world):
         ix.upload(bases, np.array([0, len(bases)], np.uint64), np.array([10 ** 7], np.uint32), np.array([0, 1], np.uint64))
     with pytest.raises(rx.RtxError):                # non-monotone offsets
         ix.upload(bases, np.array([5, 0], np.uint64))
-    long_q = np.tile(bases, 12)                     # t far above what prob_table's LDS can hold
+    long_q = np.tile(bases, 12)                     # 7.9 kb: more than prob_table's arrays in LDS hold -- served since round 5 (global-memory forms)
+    ix.upload(long_q, np.array([0, len(long_q)], np.uint64))
+    assert ix.batch_classes()[-1]["global_memory_forms"]
+    too_long = np.tile(bases, 100)[:65543]          # it could hold more than 65 535 k-mers: the reference asserts (raxtax.rs:56)
     with pytest.raises(rx.RtxError) as e:
-        ix.upload(long_q, np.array([0, len(long_q)], np.uint64))
+        ix.upload(too_long, np.array([0, len(too_long)], np.uint64))
     assert e.value.code == rx._lib.RTX_ERR_TOO_LONG
 
 
@@ -776,10 +779,15 @@ def test_long_queries_need_several_list_rounds(oracle):
     qoff = np.zeros(len(qs) + 1, np.uint64)
     qoff[1:] = np.cumsum([len(q) for q in qs])
     bases = np.concatenate(qs)
-    ix.classify(bases, qoff, *ix.exact_matches(bases, qoff))
-    for q in range(len(qs)):
+    res = ix.classify(bases, qoff, *ix.exact_matches(bases, qoff))
+    assert len(ix.batch_classes()) == 2      # the barcode and the read around the limit | the long read (length classes, round 5)
+    t_all = [otree.hit_counts(q)[0] for q in qs]
+    assert [int(x) for x in res.t] == t_all
+    for q in range(len(qs)):                 # the taps read the last sub-batch of a run: every query as a batch of its own
+        one_off = np.array([0, len(qs[q])], np.uint64)
+        ix.classify(qs[q], one_off, *ix.exact_matches(qs[q], one_off))
         t, counts = otree.hit_counts(qs[q])
-        assert np.array_equal(ix.debug_hit_counts(q), counts), q
+        assert np.array_equal(ix.debug_hit_counts(0), counts), q
 
 
 def test_many_tiles_use_the_transposed_class_tables(oracle):

@@ -80,12 +80,17 @@ def parse():
     ap.add_argument("--no-tile-prune", action="store_true", help="hit_count counts every tile of 8192 references (RTX_OPT_TILE_PRUNE = 0; default: only the tiles that can hold a reference with any probability)")
     ap.add_argument("--tile-prune", action="store_true", help="(the default; kept for older command lines)")
     ap.add_argument("--no-fine-bounds", action="store_true", help="tile pruning with its first stage of bounds only (RTX_OPT_FINE_BOUNDS = 0; A/B measurements)")
+    ap.add_argument("--emit-fasta", metavar="DIR", default=None,
+                    help="write the database and the queries of this line (rank 0's, as --refs / --queries / --mu-q / --exact-frac select them) to "
+                         "DIR/db.fasta and DIR/queries.fasta and exit (no GPU needed): the inputs the reference itself can be timed on, "
+                         "`raxtax -d DIR/db.fasta -i DIR/queries.fasta -t 0`")
     ap.add_argument("--records", type=int, default=None, help="RTX_OPT_RECORDS: pruned queries with at most this many live tiles write records of the counts above their threshold instead of counts (0: off; default: the library's)")
     ap.add_argument("--overlap", type=int, default=None, help="RTX_OPT_OVERLAP: 1 = back half of a sub-batch on a second stream beside the front half of the next (default: the library's)")
     ap.add_argument("--no-tile-skip", action="store_true", help="taxon_prefix sums every reference (RTX_OPT_TILE_SKIP = 0; A/B measurements)")
     ap.add_argument("--mu-q", type=float, default=0.02, help="per-site substitution rate of a query against its source reference (the headline: 0.02)")
     ap.add_argument("--exact-frac", type=float, default=0.10, help="share of the queries that are exact copies of a reference (the headline: 0.10)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true", help="N > 1: skip the self-check of the line (rank 0 holds a seeded sample of every rank's gathered records against the oracle)")
     ap.add_argument("--no-extras", action="store_true", help="only the headline: no H2D / end-to-end / unpruned legs, no divergence sweep")
     ap.add_argument("--host-exact-match", action="store_true",
                     help="Tree.sequences.get on the host, once, untimed (rounds 1-2); default: on the device inside the timed step")
@@ -109,6 +114,27 @@ def parse():
     args.refs = args.refs or refs
     args.queries = args.queries or queries
     return args
+
+
+def emit_fasta(args) -> int:
+    """--emit-fasta DIR: the exact inputs of the line as files the reference reads (README.md:29-62 of the reference: `-d` a FASTA whose
+    headers carry `tax=...;`, `-i` a FASTA of queries).  The arrays are the ones main() classifies: the same generator calls, seeds included
+    (queries of rank 0: seed 3)."""
+    from raxtax_amd import synth
+
+    out = Path(args.emit_fasta)
+    out.mkdir(parents=True, exist_ok=True)
+    db = synth.make_db(args.refs)
+    qs = synth.make_queries(db, args.queries, seed=3, first_label=0, mu_q=args.mu_q, exact_frac=args.exact_frac)
+    nb_db = synth.write_fasta(out / "db.fasta", [f"r{i};tax={lin};" for i, lin in enumerate(db.lineages)], db.seq_bytes, db.seq_off)
+    nb_q = synth.write_fasta(out / "queries.fasta", qs.labels, qs.bases, qs.base_off)
+    sha = hashlib.sha256()
+    sha.update(np.ascontiguousarray(db.seq_bytes).tobytes())
+    sha.update(np.ascontiguousarray(qs.bases).tobytes())
+    print(json.dumps({"emitted": str(out), "db_fasta_bytes": nb_db, "queries_fasta_bytes": nb_q, "refs": db.n, "queries": qs.n,
+                      "sha256_of_the_encoded_arrays": sha.hexdigest(),
+                      "reference_command": f"raxtax -d {out / 'db.fasta'} -i {out / 'queries.fasta'} -t 0 --redo"}))
+    return 0
 
 
 # ------------------------------------------------------------------------------------------------------------
@@ -216,9 +242,135 @@ def parity_block(args, rx, index, view, ctx, db, qs, flags, n_sample=2000):
         out.update(n=seen["n"], ok=True, counts_bit_exact=True, max_dp=seen["max_dp"], ties=seen["ties"], rows_identical=seen["rows_identical"],
                    queries_with_threshold=seen["with_threshold"], mean_threshold=seen["thr"] / max(seen["n"], 1),
                    tiles_visited_per_query=seen["live"] / max(seen["n"], 1), tiles_above_threshold_per_query=seen["needed"] / max(seen["n"], 1),
-                   max_mass_of_a_dropped_set=seen["max_dropped"], tolerance_asserted=1e-9)
+                   max_mass_of_a_dropped_set=seen["max_dropped"], tolerance_asserted=1e-9, on_records_path=seen.get("on_records_path", 0))
     except AssertionError as e:
         out["error"] = str(e)[:400] or "assertion failed"
+    except Exception as e:      # (an RtxError of a tap, an OSError of the oracle ...): ok stays false, the measured line is still printed
+        out["error"] = f"{type(e).__name__}: {str(e)[:400]}"
+    out["seconds"] = round(time.perf_counter() - t0, 1)
+    return out
+
+
+def multirank_parity_block(args, rx, index, view, ctx, db, qs, flags, world, last_parts, n_own=600, n_other=200):
+    """The self-check of a line with N > 1 ranks, rank 0, after the timed region, untimed:
+      * rank 0's own last timed step as its device left it: checks.as_run_oracle_sample on its last sub-batch (as parity_block at N = 1);
+      * the GATHERED records of every other rank -- what arrived on rank 0 over the collective in the last timed step -- unpacked and
+        held against the oracle on a seeded sample of that rank's queries (every rank's queries follow from its rank number: seed 3 + r):
+        t, the lineages and the confidences of every row, the signals.
+    A violation is reported as ok = false with its message (the process then exits with status 4)."""
+    from raxtax_amd import checks, dist_util, synth
+
+    t0 = time.perf_counter()
+    out = {"n": 0, "ok": False, "ranks_checked": [], "where": "rank 0: its last sub-batch as the run left it + a seeded sample of every other rank's gathered records"}
+    try:
+        res = rx.Result(view)
+        checks.check_properties(res, db, qs.n)
+        seen = checks.as_run_oracle_sample(index, res, ctx["orc"], ctx["otree"], qs.bases, qs.base_off, n_own, bool(flags), threads=available_parallelism())
+        out.update(n=seen["n"], counts_bit_exact=True, max_dp=seen["max_dp"], ties=seen["ties"], rows_identical=seen["rows_identical"], on_records_path=seen.get("on_records_path", 0))
+        out["ranks_checked"].append(0)
+        if last_parts is None or len(last_parts) != world:
+            raise AssertionError("rank 0 holds no gathered records of the last step")
+        otree, orc = ctx["otree"], ctx["orc"]
+        lineages = None
+        for r in range(1, world):
+            rec = dist_util.unpack_records(last_parts[r])
+            assert rec["n_queries"] == args.queries, f"rank {r}: {rec['n_queries']} queries gathered, {args.queries} expected"
+            assert (rec["status"] == 0).all(), f"rank {r}: queries with a status"
+            qr = synth.make_queries(db, args.queries, seed=3 + r, first_label=r * args.queries, mu_q=args.mu_q, exact_frac=args.exact_frac)
+            ids = np.sort(np.random.default_rng(20264 + r).choice(args.queries, min(n_other, args.queries), replace=False))
+            L = db.length
+            sub = np.concatenate([qr.bases[int(q) * L:(int(q) + 1) * L] for q in ids])
+            off = (np.arange(len(ids) + 1) * L).astype(np.uint64)
+            t_o, counts_o = otree.hit_counts_batch(sub, off, skip_exact=bool(flags), threads=available_parallelism())
+            tables_o, z_o, rc = orc.prob_tables_batch(t_o, counts_o, threads=available_parallelism())
+            bad, rows_o, nrows_o = otree.classify_batch(sub, off, skip_exact=bool(flags), raw_confidence=True, threads=available_parallelism(), cap=64)
+            assert bad == 0
+            for j, q in enumerate(ids):
+                q = int(q)
+                assert int(rec["t"][q]) == int(t_o[j]), f"rank {r} query {q}: t"
+                a, b = int(rec["row_off"][q]), int(rec["row_off"][q + 1])
+                want = otree.rows_of(rows_o, nrows_o, j, 64)
+                got_lin = [int(x) for x in rec["row_lineage"][a:b]]
+                got_conf = [[float(c) for c in rec["row_conf"][i][: int(rec["row_depth"][i])]] for i in range(a, b)]
+                if got_lin == [w["idx"] for w in want] and got_conf == [[float(c) for c in w["conf"]] for w in want]:
+                    assert abs(float(rec["global_signal"][q]) - want[0]["global_signal"]) < 1e-9, f"rank {r} query {q}: global signal"
+                    for i, w in zip(range(a, b), want):
+                        assert abs(float(rec["row_local_signal"][i]) - w["local_signal"]) < 1e-6, f"rank {r} query {q}: local signal"
+                    out["rows_identical"] = out.get("rows_identical", 0) + 1
+                else:   # an exact tie between sibling taxa: verified from the oracle's probabilities (checks.assert_rows_equivalent)
+                    class _Row:
+                        pass
+                    rows_g = []
+                    for i in range(a, b):
+                        g = _Row()
+                        g.lineage, g.confidence_values, g.local_signal = int(rec["row_lineage"][i]), got_conf[i - a], float(rec["row_local_signal"][i])
+                        rows_g.append(g)
+                    if lineages is None:
+                        lineages = otree.lineages
+                    k = checks.assert_rows_equivalent(rows_g, want, tables_o[j][counts_o[j]], lineages, f"rank {r} query {q}")
+                    assert k > 0, f"rank {r} query {q}: rows differ from the oracle's without a tie"
+                    out["ties"] = out.get("ties", 0) + 1
+                out["n"] += 1
+            out["ranks_checked"].append(r)
+        out["ok"] = True
+    except AssertionError as e:
+        out["error"] = str(e)[:400] or "assertion failed"
+    except Exception as e:
+        out["error"] = f"{type(e).__name__}: {str(e)[:400]}"
+    out["seconds"] = round(time.perf_counter() - t0, 1)
+    return out
+
+
+def sharded_parity_block(args, rx, index, view, ctx, db, qs, flags, cuts, n_sample=300):
+    """The self-check of a --shard-db line (both modes), rank 0, untimed: every rank classified the SAME queries against its shard and
+    the exchanges (histogram all-reduce + prefix all-gather, or the all-reduce of the counts) put them together -- so rank 0's final rows
+    of a seeded sample must be the oracle's rows of the whole database, and (reference shards) the hit counts of rank 0's shard, read
+    through the recounting tap for the sampled queries of its last sub-batch, the slice [cuts[0], cuts[1]) of the oracle's counts."""
+    from raxtax_amd import checks
+
+    t0 = time.perf_counter()
+    out = {"n": 0, "ok": False, "shard_counts_checked": 0, "where": "rank 0: final rows of a seeded sample against the oracle on the whole database"}
+    try:
+        res = rx.Result(view)
+        otree, orc = ctx["otree"], ctx["orc"]
+        L = db.length
+        ids = np.sort(np.random.default_rng(20264).choice(qs.n, min(n_sample, qs.n), replace=False))
+        sub = np.concatenate([qs.bases[int(q) * L:(int(q) + 1) * L] for q in ids])
+        off = (np.arange(len(ids) + 1) * L).astype(np.uint64)
+        t_o, counts_o = otree.hit_counts_batch(sub, off, skip_exact=bool(flags), threads=available_parallelism())
+        tables_o, z_o, rc = orc.prob_tables_batch(t_o, counts_o, threads=available_parallelism())
+        bad, rows_o, nrows_o = otree.classify_batch(sub, off, skip_exact=bool(flags), raw_confidence=True, threads=available_parallelism(), cap=64)
+        assert bad == 0
+        lineages = None
+        ties = 0
+        for j, q in enumerate(ids):
+            q = int(q)
+            assert int(res.t[q]) == int(t_o[j]), f"query {q}: t"
+            want, got = otree.rows_of(rows_o, nrows_o, j, 64), res.rows(q)
+            if [g.lineage for g in got] == [w["idx"] for w in want] and [g.confidence_values for g in got] == [w["conf"] for w in want]:
+                for g, w in zip(got, want):
+                    assert abs(g.local_signal - w["local_signal"]) < 1e-6 and abs(g.global_signal - w["global_signal"]) < 1e-9, q
+            else:
+                if lineages is None:
+                    lineages = otree.lineages
+                assert checks.assert_rows_equivalent(got, want, tables_o[j][counts_o[j]], lineages, f"query {q}") > 0, f"query {q}: rows differ without a tie"
+                ties += 1
+            out["n"] += 1
+        out["ties"] = ties
+        if cuts is not None:   # the counts of this rank's references
+            try:
+                last = set(int(x) for x in checks.last_sub_batch_queries(index, qs.n))
+                for j, q in enumerate(ids):
+                    if int(q) in last and out["shard_counts_checked"] < 50:
+                        assert np.array_equal(index.debug_hit_counts(int(q)), counts_o[j][cuts[0]:cuts[1]]), f"query {int(q)}: counts of rank 0's shard"
+                        out["shard_counts_checked"] += 1
+            except rx.RtxError as e:
+                out["shard_counts_note"] = f"taps not available on this handle: {str(e)[:120]}"
+        out["ok"] = True
+    except AssertionError as e:
+        out["error"] = str(e)[:400] or "assertion failed"
+    except Exception as e:
+        out["error"] = f"{type(e).__name__}: {str(e)[:400]}"
     out["seconds"] = round(time.perf_counter() - t0, 1)
     return out
 
@@ -320,6 +472,84 @@ def measured_traffic(refs: int, query_len: int, queries: int, pruned: bool):
         return out, None
     except Exception as ex:  # noqa: BLE001 - a broken profile file must not break the bench
         return None, f"profiles/traffic.json unreadable: {ex}"
+
+
+# which kernels run inside which HIP-event stage of a step (the index build and the table build are not part of a step)
+STAGE_KERNELS = {
+    "order": ("rtx::sketch_kernel", "rtx::locator_kernel", "rtx::class_keys_kernel", "rtx::invert_perm_kernel", "rtx::identity_perm_kernel"),
+    "exact_match": ("rtx::exact_match_kernel",),
+    "kmer_extract": ("rtx::kmer_extract_kernel<false>",),
+    "pair_union": ("rtx::pair_union_kernel",),
+    "tile_bounds": ("rtx::hit_count_pair_kernel<10, true, 1, false>", "rtx::hit_count_pair_kernel<8, true, 1, false>"),
+    "tile_prune": ("rtx::prune_kernel", "rtx::kmer_extract_kernel<true>", "rtx::hit_count_pair_kernel<10, true, 2, true>", "rtx::hit_count_pair_kernel<8, true, 2, true>",
+                   "rtx::live_offsets_kernel", "rtx::live_items_kernel", "rtx::fine_count_kernel", "rtx::fine_scan_kernel", "rtx::fine_scatter_kernel",
+                   "rtx::pair_live_recount_kernel"),
+    "hit_count": ("rtx::hit_count_pair_kernel<10, true, 0, true>", "rtx::hit_count_pair_kernel<8, true, 0, true>", "rtx::hit_count_pair_kernel<10, true, 0, false>",
+                  "rtx::hit_count_kernel<10, true, false>", "rtx::hit_count_kernel<12, false, false>", "rtx::hit_count_kernel<16, false, false>"),
+    "prob_table": ("rtx::prob_lookup_kernel", "rtx::prob_order_kernel", "rtx::prob_table_kernel<false>", "rtx::prob_table_kernel<true>"),
+    "taxon_prefix": ("rtx::taxon_prefix_kernel<2, true, true>", "rtx::taxon_prefix_kernel<4, true, true>", "rtx::records_tail_kernel", "rtx::lineage_walk_kernel"),
+}
+
+
+def step_bounds(args, stage_ms_per_step, ms_per_step, n_queries_step, query_len, pruned):
+    """the roofline the design actually has.  SURVEY 8d's HBM-read roofline (4 H_q + L_q algorithmic bytes against 8 TB/s)
+    bounds no kernel of this step any more -- a bitmap bit stands for a 4-byte posting, 60 of 62 tiles are never read.  What does:
+      * step_fabric_frac: the fabric-side bytes of EVERY kernel of a step (2 x FETCH_SIZE + WRITE_SIZE, rocprofv3 PMC passes of this
+        command on this build: profiles/traffic.json `step`) / ms_per_step / 8 TB/s;
+      * bounds: per stage its time (HIP events of this run), its fabric rate, and the resource that limits it with the counter that shows
+        it (SQ counters per kernel of the same command: profiles/sq_counters.json) -- the L1 request rate of 64 B/clk/CU for the two
+        counting launches, instruction issue or the wait for dependent round trips for the kernels around them.
+    Both profiles are keyed to the hash of the device sources: a line of another build carries null instead of stale numbers."""
+    out = {"step_fabric_frac": None, "bounds": None, "note": "SURVEY 8d's HBM-read roofline no longer bounds any kernel of the step (DESIGN.md section 5)"}
+    sha = device_source_sha()
+    per_kernel, sq = None, None
+    try:
+        t = json.loads((ROOT / "profiles" / "traffic.json").read_text())
+        e = t.get("configs", {}).get(f"refs={args.refs},query_len={query_len},queries={n_queries_step}")
+        if e and e.get("device_source_sha") == sha and bool(e.get("pruned")) == bool(pruned) and "step" in e:
+            per_kernel = e["step"]["per_kernel"]
+    except (OSError, ValueError):
+        pass
+    try:
+        q = json.loads((ROOT / "profiles" / "sq_counters.json").read_text())
+        if q.get("device_source_sha") == sha:
+            sq = q["kernels"]
+    except (OSError, ValueError):
+        pass
+    if per_kernel is not None:
+        in_step = {k for ks in STAGE_KERNELS.values() for k in ks}
+        tot = sum(2.0 * v["fetch_kb"] * 1024.0 + v["write_kb"] * 1024.0 for k, v in per_kernel.items() if k in in_step)
+        out["step_fabric_bytes"] = tot
+        out["step_fabric_frac"] = tot / (ms_per_step * 1e-3) / (HBM_PEAK_GBS * 1e9)
+    rows = {}
+    for stage, ms in stage_ms_per_step.items():
+        if not ms:
+            continue
+        row = {"ms": round(ms, 2)}
+        ks = STAGE_KERNELS.get(stage, ())
+        if per_kernel is not None:
+            b = sum(2.0 * per_kernel[k]["fetch_kb"] * 1024.0 + per_kernel[k]["write_kb"] * 1024.0 for k in ks if k in per_kernel)
+            row["fabric_tb_per_s"] = round(b / (ms * 1e-3) / 1e12, 2)
+        if sq is not None:
+            present = [(k, sq[k]) for k in ks if k in sq]
+            if present:
+                k, c = max(present, key=lambda kc: kc[1]["gui_mcycles"])   # the kernel of the stage that runs longest
+                if "hit_count" in k:
+                    lim = "L1 request rate (64 B/clk/CU: a 1-KiB row per 16 cycles) with VALU beside it"
+                elif c["wait_pct"] >= 50.0:
+                    lim = "latency: chains of dependent round trips (wave cycles waiting)"
+                elif c["issue_pct"] + c["stall_pct"] >= 45.0:
+                    lim = "instruction issue"
+                else:
+                    lim = "mixed"
+                row.update(limit=lim, kernel=k, counters={"wait_pct": c["wait_pct"], "stall_pct": c["stall_pct"], "issue_pct": c["issue_pct"],
+                                                          "valu_per_wave": c["valu_per_wave"], "vmem_rd_per_wave": c["vmem_rd_per_wave"],
+                                                          "waves_in_flight_per_cu": c["waves_in_flight_per_cu"]})
+        rows[stage] = row
+    out["bounds"] = rows
+    if per_kernel is None or sq is None:
+        out["missing"] = "profiles/traffic.json (step) and / or profiles/sq_counters.json are of another build or size: tools/refresh_profiles.sh + tools/sq_profile.sh"
+    return out
 
 
 def roofline_block(args, work, prob_work, stage_ms, stage_n, n_queries_step, query_len, prune=None, ntiles=None):
@@ -562,9 +792,91 @@ def real_composition_block(args, rx, lib, flags):
                         f"individual-level copies = {len(h.lineages)} references (scripts/common.py:11-25 hold-out methodology)"}
 
 
+def mixed_lengths_block(args, rx, lib, index, db, flags):
+    """value_mixed_lengths: 131 072 COI reads alone, then the same reads with ten reads of 1 100 .. 8 000 bases scattered among them -- the
+    library cuts a batch into length classes (include/raxtax_hip.h: rtx_batch_classes), so the outliers must not move the barcodes off
+    the pair kernel, the memoised tables and the tile pruning (until round 4 the longest query decided for the whole batch)."""
+    from raxtax_amd import synth
+
+    n = 131072
+    L = db.length
+    q = synth.make_queries(db, n, seed=77)
+    rng = np.random.default_rng(78)
+    refs = db.seq_bytes.reshape(db.n, L)
+    longs = []
+    for nb in (1100, 1500, 2200, 3000, 4100, 4500, 6000, 6500, 7000, 8000):
+        s = np.concatenate([refs[int(i)] for i in rng.integers(0, db.n, nb // L + 1)])[:nb].copy()
+        hit = rng.random(nb) < 0.02
+        s[hit] = (1 << rng.integers(0, 4, int(hit.sum()))).astype(np.uint8)
+        longs.append(s)
+    at = np.sort(rng.integers(0, n, len(longs)))
+    parts, prev = [], 0
+    for a, s in zip(at, longs):
+        parts.append(q.bases[prev * L:int(a) * L])
+        parts.append(s)
+        prev = int(a)
+    parts.append(q.bases[prev * L:])
+    mixed = np.concatenate(parts)
+    lens = np.full(n + len(longs), L, np.uint64)
+    for k, (a, s) in enumerate(zip(at, longs)):
+        lens[int(a) + k] = len(s)
+    moff = np.zeros(n + len(longs) + 1, np.uint64)
+    moff[1:] = np.cumsum(lens)
+    steps = 3
+
+    def timed():
+        index.run(flags)
+        index.download(copy=False)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            index.run(flags)
+            index.download(copy=False)
+        return (time.perf_counter() - t0) / steps
+    index.upload(q.bases, q.base_off)
+    dt_pure = timed()
+    index.upload(mixed, moff)
+    dt_mixed = timed()
+    classes = index.batch_classes()
+    view = index.download(copy=False)
+    ok = int((np.ctypeslib.as_array(view.status, shape=(len(lens),)) == 0).sum())
+    return {"value": (n + len(longs)) / dt_mixed, "ms_per_step": dt_mixed * 1e3, "value_coi_alone": n / dt_pure, "ms_per_step_coi_alone": dt_pure * 1e3,
+            "slowdown_of_the_batch": dt_mixed / dt_pure, "queries": n + len(longs), "long_reads": [len(s) for s in longs], "classified_ok": ok,
+            "classes": classes, "steps": steps,
+            "what": "131 072 COI reads alone / with ten reads of 1.1 .. 8 kb among them (one batch): length classes keep the barcodes on their path"}
+
+
+def long_reads_block(args, rx, lib, flags):
+    """value_long_reads: full-length 16S-like reads (1 500 bases, t ~ 1 490: the SINTAX use case the reference's README cites) against a
+    database of as many references as the headline's, same phylo model.  These queries take the one-query-per-wave counting kernel with
+    12 bit planes and the recurrence form of the probability stage: no pair kernel, no tile pruning, no memoised tables."""
+    from raxtax_amd import synth
+
+    n_refs, n_q, L = args.refs, 16384, 1500
+    db = synth.make_db(n_refs, length=L)
+    qs = synth.make_queries(db, n_q, seed=5)
+    tree = rx.Tree.new_flat(db.lineages, db.seq_bytes, db.seq_off, kmer_map=False)
+    index = rx.Index(tree, device=0, stage_timing=True)
+    index.upload(qs.bases, qs.base_off)
+    steps = 2
+    index.run(flags)
+    index.download(copy=False)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        index.run(flags)
+        view = index.download(copy=False)
+    dt = (time.perf_counter() - t0) / steps
+    ok = int((np.ctypeslib.as_array(view.status, shape=(n_q,)) == 0).sum())
+    stages = {s: round(ms, 2) for s, (ms, n) in index.stage_times().items() if n}
+    return {"value": n_q / dt, "ms_per_step": dt * 1e3, "queries": n_q, "refs": n_refs, "query_len": L, "classified_ok": ok, "steps": steps,
+            "classes": index.batch_classes(), "stage_ms_per_step": stages,
+            "what": f"{n_q} synthetic reads of {L} bases (phylo model, 2 % from their source) vs {n_refs} references of {L} bases"}
+
+
 # ------------------------------------------------------------------------------------------------------------
 def main():
     args = parse()
+    if args.emit_fasta:
+        raise SystemExit(emit_fasta(args))
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         raise SystemExit(self_launch(args))
     rank = int(os.environ.get("RANK", "0"))
@@ -683,11 +995,13 @@ def main():
             pending[0] = dist_util.gather_start(dist, rec_buf[k][:n], rank, world, device=coll_device, cache=gather_cache[k])
 
         gathered_q = [0]
+        last_parts = [None]
 
         def note_gathered(parts):
             """Rank 0: the record buffers of all ranks are in its (pinned) host memory; their headers say how many queries arrived."""
             if parts is not None:
                 gathered_q[0] = sum(int(np.frombuffer(p_[:8].tobytes(), np.int64)[0]) for p_ in parts if len(p_) >= 32)
+                last_parts[0] = parts     # (views of the staging buffers: the last gather of a run is not overwritten by a later one)
 
         def step():
             index.run(flags)                        # enqueues every kernel of this step
@@ -778,16 +1092,47 @@ def main():
             "stage_ms_sum_per_step": sum(stage_ms.values()) / args.steps,
             "unstaged_ms_per_step": elapsed / args.steps * 1e3 - sum(stage_ms.values()) / args.steps,
         }
+        if not args.shard_db:
+            line["step_bounds"] = step_bounds(args, line["stage_ms_per_step"], line["ms_per_step"], args.queries, L,
+                                              pruned=bool(prune_stats and prune_stats.get("pairs")))
+            line["stage_note"] = ("with RTX_OPT_OVERLAP (default) the back half of a sub-batch runs beside the front half of the next: the stage times "
+                                  "overlap and their sum exceeds ms_per_step (unstaged_ms_per_step is then negative)")
         ctx = None
+        if world > 1 and not args.no_parity:             # N > 1: the line verifies itself too (rank 0, untimed; the other ranks wait at the barrier)
+            try:
+                ctx_m = oracle_context(db)
+                if args.shard_db:
+                    line["parity_sample"] = sharded_parity_block(args, rx, index, view, ctx_m, db, qs, flags,
+                                                                 (cuts[rank], cuts[rank + 1]) if args.shard_mode == "refs" else None)
+                else:
+                    line["parity_sample"] = multirank_parity_block(args, rx, index, view, ctx_m, db, qs, flags, world, last_parts[0])
+            except Exception as e:
+                line["parity_sample"] = {"ok": False, "error": f"{type(e).__name__}: {str(e)[:300]}"}
+            parity_failed = not line["parity_sample"]["ok"]
+        if args.shard_db and world == 1 and not args.no_cpu_baseline:
+            try:
+                line["parity_sample"] = sharded_parity_block(args, rx, index, view, oracle_context(db), db, qs, flags,
+                                                             (cuts[rank], cuts[rank + 1]) if args.shard_mode == "refs" else None)
+                parity_failed = not line["parity_sample"]["ok"]
+            except Exception as e:
+                line["parity_sample"] = {"ok": False, "error": f"{type(e).__name__}: {str(e)[:300]}"}
+                parity_failed = True
         if not args.no_cpu_baseline and world == 1:      # the oracle: rank 0 at N = 1 only, never inside the timed region
-            ctx = oracle_context(db)
-            if not args.shard_db:                        # first of all: the last timed step is still on the device
+            try:
+                ctx = oracle_context(db)
+            except Exception as e:                       # (no C compiler on the bench host, ...): the measured line is still printed
+                line["parity_sample"] = {"ok": False, "error": f"oracle_context: {type(e).__name__}: {e}"}
+                parity_failed = True
+            if ctx is not None and not args.shard_db:    # first of all: the last timed step is still on the device
                 line["parity_sample"] = parity_block(args, rx, index, view, ctx, db, qs, flags)
                 parity_failed = not line["parity_sample"]["ok"]
         if not args.no_extras and world == 1 and not args.shard_db:
             line.update(extras_block(args, rx, lib, index, tree, db, qs, flags))
+            line["value_mixed_lengths"] = mixed_lengths_block(args, rx, lib, index, db, flags)
+            index.upload(qs.bases, qs.base_off)     # (the headline's batch again)
             if args.config == 2 and args.config_name != "custom size":
                 line["value_real_composition"] = real_composition_block(args, rx, lib, flags)
+                line["value_long_reads"] = long_reads_block(args, rx, lib, flags)
         line["cpu_baseline"] = cpu_baseline(db, qs, args.cpu_seconds, bool(flags), ctx) if ctx is not None else None
         print(json.dumps(line), flush=True)
     if dist is not None:

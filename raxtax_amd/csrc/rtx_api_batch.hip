@@ -59,19 +59,25 @@ int plan_sub_batches(rtx_index *ix) {
     ix->sub_nq.clear();
     ix->sub_cls.clear();
     uint64_t pos = 0;
-    for (uint32_t c = 0; c < ix->n_cls; c++) {
-        rtx_index::BatchClass &k = ix->cls[c];
-        k.pos0 = pos;
-        k.sb0 = (uint32_t)ix->sub_q0.size();
-        for (uint64_t a = 0; a < k.n; a += k.sub_batch) {
-            ix->sub_q0.push_back(pos + a);
-            ix->sub_nq.push_back((uint32_t)std::min<uint64_t>(k.sub_batch, k.n - a));
-            ix->sub_cls.push_back((uint8_t)c);
-        }
-        k.n_sub = (uint32_t)ix->sub_q0.size() - k.sb0;
-        pos += k.n;
+    for (uint32_t c = 0; c < ix->n_cls; c++) {  // positions: the classes in the order of their sort rank
+        ix->cls[c].pos0 = pos;
+        pos += ix->cls[c].n;
     }
     if (pos != ix->n_q) { set_error("internal: the length classes hold %llu of %llu queries", (unsigned long long)pos, (unsigned long long)ix->n_q); return RTX_ERR_STATE; }
+    // execution: the side classes first (a few long reads: their slow, latency-bound back halves then run beside the front halves of the
+    // bulk instead of behind everything), then the others -- the last sub-batch of a run, the one the taps read, belongs to the bulk
+    for (int pass = 0; pass < 2; pass++)
+        for (uint32_t c = 0; c < ix->n_cls; c++) {
+            rtx_index::BatchClass &k = ix->cls[c];
+            if (k.side != (pass == 0)) continue;
+            k.sb0 = (uint32_t)ix->sub_q0.size();
+            for (uint64_t a = 0; a < k.n; a += k.sub_batch) {
+                ix->sub_q0.push_back(k.pos0 + a);
+                ix->sub_nq.push_back((uint32_t)std::min<uint64_t>(k.sub_batch, k.n - a));
+                ix->sub_cls.push_back((uint8_t)c);
+            }
+            k.n_sub = (uint32_t)ix->sub_q0.size() - k.sb0;
+        }
     ix->n_sub_total = (uint32_t)ix->sub_q0.size();
     return RTX_OK;
 }
@@ -427,11 +433,12 @@ static WalkParams walk_params(rtx_index *ix, const SubBatch &b, const double *pr
     wp.n_bnd = ix->n_bnd;
     wp.rec = ix->d_noderec.p;
     wp.arena = ix->d_arena.p;
-    wp.arena_cap = ix->arena_cap;
-    wp.arena_cursor = ix->d_cursor.p;
+    const bool side = ix->cur_cls >= 0 && ix->cls[ix->cur_cls].side;  // its rows go to the top of the arena through a cursor of their own
+    wp.arena_cap = side ? ix->arena_cap : ix->side_base;
+    wp.arena_cursor = ix->d_cursor.p + (side ? 1 : 0);
     // (launches of a few thousand walks do not contend, and the rows the sub-allocators leave unused must stay within the arena's
     // allowance of two rows per query: at most kWalkSubAllocs * kWalkChunkRows = 8192 per launch of kWalkSubMinQueries or more)
-    wp.sub_alloc = b.nq >= kWalkSubMinQueries && ix->arena_cap < (1ull << 32) ? ix->d_sub_alloc.p : nullptr;
+    wp.sub_alloc = !side && b.nq >= kWalkSubMinQueries && ix->arena_cap < (1ull << 32) ? ix->d_sub_alloc.p : nullptr;
     wp.n_rows = ix->d_n_rows.p;
     wp.row_start = ix->d_row_start.p;
     wp.flags_out = ix->d_flags.p;
@@ -503,7 +510,23 @@ int begin_run(rtx_index *ix, uint32_t *n_sub_out, bool *timed_out, bool cluster)
     int rc_o = order_batch(ix, cluster);
     if (rc_o) return rc_o;
     if (ev_all) RTX_HIP(hipEventRecord(ix->events[(size_t)RTX_STAGE_ORDER * 2 + 1], ix->stream));
-    RTX_HIP(hipMemsetAsync(ix->d_cursor.p, 0, sizeof(unsigned long long), ix->stream));
+    {   // the result arena: the bulk's rows from 0 on, the side classes' (kWalkMaxRows per query at most) at its top
+        uint64_t n_side_q = 0;
+        for (uint32_t c = 0; c < ix->n_cls; c++)
+            if (ix->cls[c].side) n_side_q += ix->cls[c].n;
+        const uint64_t side_rows = n_side_q ? n_side_q * kWalkMaxRows + 64 : 0;
+        if (side_rows + ix->n_q * 2 + 1024 > ix->arena_cap) {  // (size_workspace has made room; a sharded or debug run has no side class)
+            int rc_a = ix->d_arena.alloc(ix->arena_cap + side_rows);
+            if (rc_a) return rc_a;
+            ix->arena_cap += side_rows;
+        }
+        ix->side_base = ix->arena_cap - side_rows;
+        int rc_h = ix->h_side_base.resize(2);
+        if (rc_h) return rc_h;
+        ix->h_side_base[0] = 0;
+        ix->h_side_base[1] = ix->side_base;
+        RTX_HIP(hipMemcpyAsync(ix->d_cursor.p, ix->h_side_base.data(), 2 * sizeof(unsigned long long), hipMemcpyHostToDevice, ix->stream));
+    }
     RTX_HIP(hipMemsetAsync(ix->d_flags.p, 0, sizeof(uint32_t), ix->stream));
     // tile pruning: the pair kernel, the memoised tables (their ln cmf rows give the threshold), taxon_prefix skipping tiles by
     // their largest count, the whole database on this handle
@@ -522,10 +545,11 @@ int begin_run(rtx_index *ix, uint32_t *n_sub_out, bool *timed_out, bool cluster)
         rtx_index::BatchClass &k = ix->cls[c];
         // two neighbours per wave only pays when neighbours are related: with the processing order on
         k.pair = ix->pair_opt && cluster && k.planes <= 10 && ix->n_q > 1 && k.rstride <= 4096;
+        const rtx_index::Scratch &s0 = ix->sc[k.side ? kSideSet : 0u];  // (a side class runs through the set of its own)
         k.prune = ix->prune_opt && k.pair && k.use_tables && ix->tile_skip && ix->d_ubitmap.p && (whole || shard) &&
-                  scratch_ok(ix->sc[0], k.sub_batch) && (!ix->staged || scratch_ok(ix->sc[1], k.sub_batch));
-        k.rec = k.prune && whole && ix->rec_opt != 0u && ix->n_bnd_local == ix->n_bnd && ix->sc[0].d_rec.p != nullptr &&
-                ix->sc[0].d_rec.n >= (size_t)k.sub_batch * std::min<uint32_t>(ix->rec_opt, kRecMaxSlots) * 8192u;
+                  scratch_ok(s0, k.sub_batch) && (!ix->staged || scratch_ok(ix->sc[1], k.sub_batch));
+        k.rec = k.prune && whole && ix->rec_opt != 0u && ix->n_bnd_local == ix->n_bnd && s0.d_rec.p != nullptr &&
+                s0.d_rec.n >= (size_t)k.sub_batch * std::min<uint32_t>(ix->rec_opt, kRecMaxSlots) * 8192u;
         any_pair = any_pair || k.pair;
         any_prune = any_prune || k.prune;
         b_max = std::max(b_max, k.sub_batch);
@@ -611,15 +635,33 @@ int enqueue_batch(rtx_index *ix, uint32_t flags) {
             ix->ev_mid.push_back(g);
         }
     }
+    uint32_t n_side = 0;
+    for (uint32_t c = 0; c < ix->n_cls; c++)
+        if (ix->cls[c].side) n_side += ix->cls[c].n_sub;
     for (uint32_t sb = 0; sb < n_sub; sb++) {
         if ((int)ix->sub_cls[sb] != ix->cur_cls) apply_class(ix, ix->sub_cls[sb]);  // the next length class: its planes, strides, kernels
         SubBatch b = sub_batch_of(ix, sb, timed);
-        if (overlap) {
-            b.set = sb % nsets;
-            if (sb >= nsets) RTX_HIP(hipStreamWaitEvent(ix->stream, ix->ev_back[sb - nsets], 0));  // the scratch set is free again
+        const bool side = ix->cls[ix->sub_cls[sb]].side;
+        if (side) {  // (the side classes come first: sub-batches 0 .. n_side - 1, one after the other through their own set)
+            b.set = kSideSet;
+            if (overlap) {
+                // ... and as a whole on a stream of their own: a few waves per kernel, every one a long chain of round trips (6 000 rows
+                // through one wave, the recurrence of prob_table) -- beside the bulk instead of in front of it.  Their result rows go to
+                // the top of the arena through a cursor of their own (walk_params), so the arena ranges of the streamed download hold.
+                if (!ix->stream3) RTX_HIP(hipStreamCreateWithFlags(&ix->stream3, hipStreamNonBlocking));
+                if (sb == 0) {
+                    RTX_HIP(hipEventRecord(ix->ev_mid[0], ix->stream));  // the processing order and the exact matches are in place
+                    RTX_HIP(hipStreamWaitEvent(ix->stream3, ix->ev_mid[0], 0));
+                }
+                b.s = ix->stream3;
+            }
+        } else if (overlap) {
+            const uint32_t m = sb - n_side;  // among the sub-batches of the bulk
+            b.set = m % nsets;
+            if (m >= nsets) RTX_HIP(hipStreamWaitEvent(ix->stream, ix->ev_back[sb - nsets], 0));  // the scratch set is free again
         }
-        if ((rc = enqueue_count(ix, b, flags, nsets == 3u ? ix->stream3 : nullptr))) return rc;
-        if (overlap) {
+        if ((rc = enqueue_count(ix, b, flags, nsets == 3u && !side && n_side == 0 ? ix->stream3 : nullptr))) return rc;
+        if (overlap && !side) {
             RTX_HIP(hipEventRecord(ix->ev_front[sb], ix->hit_stream));
             b.s = ix->stream2;
             RTX_HIP(hipStreamWaitEvent(b.s, ix->ev_front[sb], 0));
@@ -631,12 +673,15 @@ int enqueue_batch(rtx_index *ix, uint32_t flags) {
             RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_LINEAGE_WALK, 1), b.s));
         }
         if (ix->stream_dl) {
-            RTX_HIP(hipMemcpyAsync(&ix->h_cursor_sub[sb], ix->d_cursor.p, 8, hipMemcpyDeviceToHost, b.s));
+            RTX_HIP(hipMemcpyAsync(&ix->h_cursor_sub[sb], ix->d_cursor.p + (side ? 1 : 0), 8, hipMemcpyDeviceToHost, b.s));
             RTX_HIP(hipEventRecord(ix->ev_sub[sb], b.s));
         }
         if (overlap) RTX_HIP(hipEventRecord(ix->ev_back[sb], b.s));
     }
-    if (overlap && n_sub) RTX_HIP(hipStreamWaitEvent(ix->stream, ix->ev_back[n_sub - 1], 0));  // a wait for the handle's stream covers all of them
+    if (overlap && n_sub) {  // a wait for the handle's stream covers all of them
+        RTX_HIP(hipStreamWaitEvent(ix->stream, ix->ev_back[n_sub - 1], 0));
+        if (n_side && n_side < n_sub) RTX_HIP(hipStreamWaitEvent(ix->stream, ix->ev_back[n_side - 1], 0));
+    }
     RTX_HIP(hipGetLastError());
     return RTX_OK;
 }
@@ -720,6 +765,7 @@ uint64_t class2_max_len() {  // the longest query of class 2: where prob_table's
     }
     return cached;
 }
+constexpr uint64_t kSideMaxQueries = 2048;  // a class of at most this many queries (and a 64th of the bulk) runs as a side class
 constexpr uint64_t kMinShortClass = 4096;  // fewer queries of t <= 255 than this ride with the t <= 1023 class (same results: 8 or 10 planes hold their counts)
 
 static void shape_class(rtx_index::BatchClass &k, uint64_t n, uint64_t max_len) {
@@ -749,6 +795,8 @@ int prepare_workspace(rtx_index *ix, uint64_t n_queries, const uint64_t cls_n_in
     }
     // a handful of short reads among barcodes ride with them (the results do not depend on the number of planes)
     if (cn[0] && cn[1] && cn[0] < kMinShortClass) { cn[1] += cn[0]; cm[1] = std::max(cm[1], cm[0]); cn[0] = 0; cm[0] = 0; }
+    // ... and a handful of reads of a few kilobases with the longer ones (one set of launches; the global-memory forms compute the same values)
+    if (cn[2] && cn[3] && cn[2] + cn[3] <= kSideMaxQueries) { cn[3] += cn[2]; cm[3] = std::max(cm[3], cm[2]); cn[2] = 0; cm[2] = 0; }
     const uint64_t key[14] = {n_queries, cn[0], cn[1], cn[2], cn[3], cm[0], cm[1], cm[2], cm[3], ix->sub_batch_req,
                               (uint64_t)ix->packed_opt | (uint64_t)ix->pair_opt << 1 | (uint64_t)ix->prune_opt << 2 | (uint64_t)ix->shard_prune_opt << 3 | (uint64_t)ix->fine_opt << 4 |
                                   (uint64_t)(ix->prob_mode & 3) << 5 | (uint64_t)ix->rec_opt << 8 | (uint64_t)ix->overlap_opt << 16,
@@ -859,12 +907,39 @@ static int size_workspace(rtx_index *ix, uint64_t n_queries) {
         k.sub_batch = B;
         worst = std::max<uint64_t>(worst, (uint64_t)B * per_q);
     }
+    // side classes: a handful of queries of another length beside the bulk (ten 16S reads in a file of barcodes)
+    {
+        uint32_t bulk = 0;
+        for (uint32_t c = 1; c < ix->n_cls; c++)
+            if (ix->cls[c].n > ix->cls[bulk].n) bulk = c;
+        worst = 0;
+        for (uint32_t c = 0; c < ix->n_cls; c++) {
+            ix->cls[c].side = ix->n_refs == ix->n_total && c != bulk && ix->cls[c].n <= kSideMaxQueries && ix->cls[c].n * 64u <= ix->cls[bulk].n;
+            if (!ix->cls[c].side) worst = std::max<uint64_t>(worst, (uint64_t)ix->cls[c].sub_batch * class_per_q(ix, ix->cls[c]));
+        }
+    }
+    {   // room for the rows of the side classes at the top of the arena (begin_run: side_base)
+        uint64_t n_side_q = 0;
+        for (uint32_t c = 0; c < ix->n_cls; c++)
+            if (ix->cls[c].side) n_side_q += ix->cls[c].n;
+        const uint64_t want2 = want_arena + (n_side_q ? n_side_q * kWalkMaxRows + 64 : 0);
+        if (ix->arena_cap < want2) {
+            if ((rc = ix->d_arena.alloc(want2))) return rc;
+            ix->arena_cap = want2;
+        }
+    }
     // the further sets of the overlap never shrink a sub-batch: they are taken only while they fit the budget beside the first
     while (n_sets > 1u && (uint64_t)n_sets * worst > budget) n_sets--;
     ix->staged = false;
     if ((rc = plan_sub_batches(ix))) return rc;
     apply_class(ix, ix->n_cls - 1u);
     if ((rc = alloc_scratch_set(ix, 0))) return rc;
+    {
+        bool any_side = false;
+        for (uint32_t c = 0; c < ix->n_cls; c++) any_side = any_side || ix->cls[c].side;
+        if (any_side) { if ((rc = alloc_scratch_set(ix, kSideSet))) return rc; }
+        else ix->sc[kSideSet].release_all();
+    }
     for (uint32_t k = 1; k <= 2u; k++) {  // (without the further sets the run stays on one stream)
         if (k < n_sets && ix->n_sub_total > 1) {
             if (alloc_scratch_set(ix, k)) ix->sc[k].d_kmers.release();
@@ -882,6 +957,7 @@ int alloc_scratch_set(rtx_index *ix, uint32_t k) {
     size_t n_kmers = 0, n_rows = 0, n_dmask = 0, n_counts = 0, n_hist = 0, n_urec = 0, b_max = 1, n_probscr = 0;
     for (uint32_t c = 0; c < ix->n_cls; c++) {
         const rtx_index::BatchClass &kc = ix->cls[c];
+        if (kc.side != (k == kSideSet)) continue;  // set 3 serves the side classes, the others the bulk
         const size_t B = kc.sub_batch;
         b_max = std::max(b_max, B);
         n_kmers = std::max(n_kmers, B * kc.kstride);
@@ -901,7 +977,7 @@ int alloc_scratch_set(rtx_index *ix, uint32_t k) {
         (rc = sc.d_tilemax.alloc(B * ix->ntiles)) ||
         (rc = sc.d_urec.alloc(n_urec)) || (rc = sc.d_nu.alloc((B + 1u) / 2u)))
         return rc;
-    if (n_probscr && k == 0 && (rc = ix->d_prob_scratch.alloc(n_probscr))) return rc;
+    if (n_probscr && (rc = ix->d_prob_scratch.alloc(std::max(n_probscr, ix->d_prob_scratch.n)))) return rc;
     if (ix->prune_opt && ix->d_ubitmap.p && (ix->n_refs == ix->n_total || ix->shard_prune_opt)) {
         if ((rc = sc.d_tile_ub.alloc(B * ix->ntiles)) || (rc = sc.d_best_key.alloc(B)) || (rc = sc.d_prune_thr.alloc(B)) || (rc = sc.d_prune_i1.alloc(B)) || (rc = sc.d_best.alloc(B * kPruneBestWords)) || (rc = sc.d_live.alloc((B + 1u) * ((ix->ntiles + 31u) / 32u + 1u))) ||
             (rc = sc.d_items.alloc(((B + 1u) / 2u) * (ix->ntiles + 2u) + 9u)))

@@ -150,22 +150,27 @@ int copy_results(rtx_index *ix, uint64_t q0, uint64_t n, uint64_t r0, uint64_t r
 static int download_streamed(rtx_index *ix, rtx_index::HostRes &hr, bool *done, uint64_t *nrows_out) {
     *done = false;
     const uint32_t n_sub = ix->n_sub_run;
-    if (!ix->stream_dl || n_sub < 2 || ix->sub_q0.size() != n_sub || hipEventQuery(ix->ev_sub[n_sub - 1]) == hipSuccess) return RTX_OK;
+    if (!ix->stream_dl || n_sub < 2 || ix->sub_q0.size() != n_sub || (hipEventQuery(ix->ev_sub[n_sub - 1]) == hipSuccess && hipEventQuery(ix->ev_sub[0]) == hipSuccess)) return RTX_OK;
     (void)0;
     const uint64_t nq = ix->n_q;
     int rc = size_host_results(ix, hr, nq, ix->arena_cap);
     if (rc) return rc;
-    uint64_t prev = 0, nrows = 0;
-    for (uint32_t sb = 0; sb < n_sub; sb++) {
+    uint64_t prev_main = 0, prev_side = ix->side_base, nrows = 0;
+    uint32_t n_side = 0;  // the side classes' sub-batches come first in the plan and run beside the bulk: they are waited for LAST
+    while (n_side < n_sub && ix->cls[ix->sub_cls[n_side]].side) n_side++;
+    for (uint32_t k = 0; k < n_sub; k++) {
+        const uint32_t sb = k + n_side < n_sub ? k + n_side : k + n_side - n_sub;
         RTX_HIP(hipEventSynchronize(ix->ev_sub[sb]));
         const uint64_t cur = ix->h_cursor_sub[sb];
-        if (cur > ix->arena_cap) return RTX_OK;  // overflow: bulk path
+        const bool side = ix->cls[ix->sub_cls[sb]].side;  // its rows lie in the side region of the arena, behind its own cursor
+        uint64_t &prev = side ? prev_side : prev_main;
+        if (cur > (side ? ix->arena_cap : ix->side_base)) return RTX_OK;  // overflow: bulk path
         const uint64_t q0 = ix->sub_q0[sb], n = ix->sub_nq[sb];  // (classes of different sub-batch sizes follow one another: plan_sub_batches)
         if ((rc = copy_results(ix, q0, n, prev, cur, ix->copy_stream))) return rc;
         RTX_HIP(hipStreamSynchronize(ix->copy_stream));
         // one thread finalises 8192 queries in ~1.4 ms, about what the device needs for the next sub-batch: with a short
         // last sub-batch the host would still be busy with the one before it when the device is done
-        nrows += finalise_mt(ix, q0, q0 + n, nrows, sb + 1 == n_sub ? 16 : 8);
+        nrows += finalise_mt(ix, q0, q0 + n, nrows, k + 1 == n_sub ? 16 : 8);
         prev = cur;
     }
     RTX_HIP(hipStreamSynchronize(ix->stream));
@@ -195,13 +200,16 @@ int rtx_batch_download(rtx_index *ix, rtx_result_view *out) {
     uint64_t nrows = 0;
     if ((rc = download_streamed(ix, hr, &streamed, &nrows))) return rc;
     if (!streamed) {
-        unsigned long long cursor = 0;
+        unsigned long long cursor = 0, cursor_side = 0;
         for (int attempt = 0;; attempt++) {
             RTX_HIP(hipStreamSynchronize(ix->stream));
             ix->synced = true;
             uint32_t flags = 0;
+            unsigned long long both[2] = {0, 0};
             RTX_HIP(hipMemcpy(&flags, ix->d_flags.p, 4, hipMemcpyDeviceToHost));
-            RTX_HIP(hipMemcpy(&cursor, ix->d_cursor.p, 8, hipMemcpyDeviceToHost));
+            RTX_HIP(hipMemcpy(both, ix->d_cursor.p, 16, hipMemcpyDeviceToHost));
+            cursor = both[0];
+            cursor_side = both[1];
             if (flags & 2u) { set_error("lineage walk exceeded its row/depth bounds (internal error)"); return RTX_ERR_HIP; }
             if (!(flags & 1u)) break;
             if (attempt >= 5) { set_error("result arena overflow persists"); return RTX_ERR_HIP; }
@@ -211,7 +219,7 @@ int rtx_batch_download(rtx_index *ix, rtx_result_view *out) {
             // and at least half as much again as the arena that overflowed: walks that find their sub-allocator's piece used up at the
             // same moment each take a fresh one, so the holes of a launch are not bounded by the number of sub-allocators
             const uint64_t want = std::max<uint64_t>(cursor + 4096 + (uint64_t)(ix->n_sub_run ? ix->n_sub_run : 1u) * kWalkSubAllocs * kWalkChunkRows,
-                                                     ix->arena_cap + ix->arena_cap / 2);
+                                                     ix->arena_cap + ix->arena_cap / 2) + (ix->arena_cap - ix->side_base);  // (+ the side classes' region)
             if ((rc = ix->d_arena.alloc(want))) return rc;
             ix->arena_cap = want;
             if (ix->n_refs != ix->n_total) {  // a sharded run is driven by the caller: ask it to repeat
@@ -220,7 +228,9 @@ int rtx_batch_download(rtx_index *ix, rtx_result_view *out) {
             }
             if ((rc = enqueue_batch(ix, ix->last_flags))) return rc;
         }
-        if ((rc = size_host_results(ix, hr, nq, cursor)) || (rc = copy_results(ix, 0, nq, 0, cursor, ix->stream))) return rc;
+        const bool side_rows = cursor_side > ix->side_base && ix->side_base < ix->arena_cap;  // rows of side classes at the top of the arena
+        if ((rc = size_host_results(ix, hr, nq, side_rows ? (uint64_t)cursor_side : (uint64_t)cursor)) || (rc = copy_results(ix, 0, nq, 0, cursor, ix->stream))) return rc;
+        if (side_rows) RTX_HIP(hipMemcpyAsync(ix->h_arena.data() + ix->side_base, ix->d_arena.p + ix->side_base, (cursor_side - ix->side_base) * sizeof(DevRow), hipMemcpyDeviceToHost, ix->stream));
         RTX_HIP(hipStreamSynchronize(ix->stream));
         nrows = finalise_mt(ix, 0, nq, 0, nq < 4096 ? 1 : 16);
     }

@@ -156,7 +156,7 @@ static int create_common(int device, uint64_t n_total, uint64_t ref_lo, uint64_t
     ix->stride_bytes = (uint32_t)align_up((n_refs + 7) / 8, 1024);  // whole tiles: the bitmap is stored tile by tile
     ix->npad = (uint64_t)ix->stride_bytes * 8;
     ix->ntiles = (ix->stride_bytes + 1023) / 1024;
-    if ((rc = ix->d_cursor.alloc(1)) || (rc = ix->d_flags.alloc(1))) return fail(rc);
+    if ((rc = ix->d_cursor.alloc(2)) || (rc = ix->d_flags.alloc(1))) return fail(rc);  // (d_cursor[1]: the cursor of the side classes' region of the arena)
     *out = ix;
     return RTX_OK;
 }

@@ -239,6 +239,7 @@ struct rtx_index {
         uint32_t tmax = 0, kstride = 0, rstride = 0, hstride = 0, sub_batch = 0, sb0 = 0, n_sub = 0;
         int planes = 10;
         bool use_tables = false, pair = false, prune = false, rec = false, huge = false, will_prune = false;
+        bool side = false;  // a handful of queries beside the bulk of the batch: they run FIRST, through a small scratch set of their own (kSideSet)
     } cls[4];
     uint32_t n_cls = 0;
     int cur_cls = -1;
@@ -272,7 +273,7 @@ struct rtx_index {
             d_nu.release(); d_live.release(); d_best_key.release(); d_items.release(); d_tile_ub.release(); d_prune_thr.release(); d_prune_i1.release();
             d_best.release(); d_fine_items.release(); d_rec_nslots.release(); d_rec_slots.release(); d_rec_cnt.release(); d_rec.release();
         }
-    } sc[3];
+    } sc[4];  // 0 .. 2: the sets that alternate (RTX_OPT_OVERLAP, rtx_shard_*); 3: the set of the side classes (a few long reads among barcodes)
     bool staged = false;  // driven with rtx_shard_*: sub-batch sb works in scratch set sb & 1, so that the exchange of one
                           // sub-batch (RCCL, on the caller's stream) can overlap with the counting of the next
     uint32_t last_set = 0;  // scratch set of the last sub-batch (debug taps)
@@ -285,6 +286,8 @@ struct rtx_index {
     DevBuf<unsigned long long> d_hq, d_row_start, d_cursor, d_sub_alloc;  // (d_sub_alloc: WalkParams::sub_alloc)
     DevBuf<DevRow> d_arena;
     uint64_t arena_cap = 0;
+    uint64_t side_base = 0;  // rows [side_base, arena_cap) take the result rows of the side classes (their walks run beside the bulk's: a cursor of their own, d_cursor[1])
+    PinBuf<unsigned long long> h_side_base;
     // ---- timing
     std::vector<hipEvent_t> events;  // 2 per (sub-batch, stage)
     uint32_t n_sub_last = 0;
@@ -373,6 +376,7 @@ int prepare_workspace_single(rtx_index *ix, uint64_t n_queries, uint64_t tmax, u
 void apply_class(rtx_index *ix, uint32_t c);
 int plan_sub_batches(rtx_index *ix);
 int alloc_scratch_set(rtx_index *ix, uint32_t k);
+constexpr uint32_t kSideSet = 3;
 // ---- rtx_api_download.hip
 void node_tables(rtx_index *ix);
 void finalise_range(rtx_index *ix, uint64_t pa, uint64_t pb, uint64_t row_base);

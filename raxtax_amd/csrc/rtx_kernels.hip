@@ -679,7 +679,8 @@ __global__ __launch_bounds__(kProbThreads) void prob_table_kernel(ProbParams p) 
         }
         if (lane == 0) { s_D = D; s_ilo = n; p.ndist[gq] = D; }
     }
-    for (uint32_t x = tid + 1; x <= t + n; x += kProbThreads) inv[x] = 1.0 / (double)x;
+    if (!kGlobal)
+        for (uint32_t x = tid + 1; x <= t + n; x += kProbThreads) inv[x] = 1.0 / (double)x;
     for (uint32_t i = tid; i < kProbWaves * n1; i += kProbThreads) slots[i] = 1.0;
     __syncthreads();
     const uint32_t D = s_D;
@@ -733,22 +734,40 @@ __global__ __launch_bounds__(kProbThreads) void prob_table_kernel(ProbParams p) 
             if (act) st = pmf_start_at(lf, t, n, m, i_s, ln_total);
             uint32_t bw = n + 1;
             double base = 1.0;
+            // kGlobal: slots lives in global memory -- a read-modify-write per step would be a round trip per step.  The factors of 64
+            // consecutive i are collected in a register (lane i & 63) and multiplied in with ONE coalesced access per 64 steps.
+            double fbuf = 1.0;
+            uint32_t f_lo = 0xFFFFFFFFu;  // first i of the chunk in flight that has a factor (wave-uniform)
+            auto flush = [&](uint32_t i_last) {
+                if (!kGlobal || f_lo == 0xFFFFFFFFu) return;
+                const uint32_t idx = (i_last & ~63u) + lane;
+                if (idx >= f_lo && idx <= i_last) slots[wave * n1 + idx] *= fbuf;
+                f_lo = 0xFFFFFFFFu;
+            };
             for (uint32_t i = i_s; i <= n; i++) {
                 bool sat = !act;
                 if (i > i_s && act) {
                     const double c_old = st.c;
                     const int k_old = st.k;
-                    pmf_step(st, inv, t, n, m, i);
+                    if (kGlobal) pmf_step(st, InvDiv(), t, n, m, i);
+                    else pmf_step(st, inv, t, n, m, i);
                     sat = st.c == c_old && k_old == 0 && st.k == 0;  // pmf < 2^-53 cmf: cmf is final
                 }
                 if (i > i_s && __all(sat)) {
+                    if (i > 0) flush(i - 1u);
                     base = wave_prod_f64_dpp(act ? pmf_cmf_pow(st, h) : 1.0);
                     bw = i;
                     break;
                 }
                 if (i >= i_lo) {
                     const double f = wave_prod_f64_dpp(act ? pmf_cmf_pow(st, h) : 1.0);
-                    if (lane == 0) slots[wave * n1 + i] *= f;
+                    if (kGlobal) {
+                        if (lane == (i & 63u)) fbuf = f;
+                        if (f_lo == 0xFFFFFFFFu) f_lo = i;
+                        if ((i & 63u) == 63u || i == n) flush(i);
+                    } else if (lane == 0) {
+                        slots[wave * n1 + i] *= f;
+                    }
                 }
             }
             if (lane == 0) { gbw[g] = bw; gbase[g] = base; gstart[g] = i_s; }
@@ -771,27 +790,40 @@ __global__ __launch_bounds__(kProbThreads) void prob_table_kernel(ProbParams p) 
         // ---- pass 2
         for (uint32_t g = wave; g < ngroups; g += kProbWaves) {
             const uint32_t j = g * 64 + lane;
-            if (j >= D) continue;
-            const uint32_t m = ms[D - 1 - j];
-            if (m == 0) {  // pmf = [1,0,...], cmf = 1: table[0] = P(0)
-                tz[0] = Pi[0];
-                continue;
-            }
+            if (!kGlobal && j >= D) continue;  // (kGlobal: every lane stays for the shuffles below, the spare ones on a stand-in count)
+            const bool valid = j < D;
+            const uint32_t m_raw = valid ? ms[D - 1 - j] : 1u;
+            if (valid && m_raw == 0) tz[0] = Pi[0];  // pmf = [1,0,...], cmf = 1: table[0] = P(0)
+            if (!kGlobal && m_raw == 0) continue;
+            const uint32_t m = m_raw ? m_raw : 1u;
             const uint32_t b = gbw[g];
-            if (b == kGroupSkipped) {
-                tz[m] = 0.0;
+            if (b == kGroupSkipped) {  // wave-uniform
+                if (valid && m_raw) tz[m] = 0.0;
                 continue;
             }
             const uint32_t i_s = gstart[g];
             const uint32_t last = b == 0 ? 0u : (b - 1 < n ? b - 1 : n);
             PmfState st = pmf_start_at(lf, t, n, m, i_s, ln_total);
             double acc = 0.0;
-            for (uint32_t i = i_s; i <= last; i++) {
-                if (i > i_s) pmf_step(st, inv, t, n, m, i);
-                if (i < i_lo) continue;
-                const double P = Pi[i];
-                if (P > 0.0 && st.k == 0 && st.c > 0.0) acc += st.v * P / st.c;
+            if (kGlobal) {  // P(i) 64 at a time: one coalesced load per 64 steps, handed out with a shuffle (the loop is wave-uniform)
+                double Pc = 0.0;
+                const uint32_t i_first = i_s > i_lo ? i_s : i_lo;
+                for (uint32_t i = i_s; i <= last; i++) {
+                    if (i > i_s) pmf_step(st, InvDiv(), t, n, m, i);
+                    if (i < i_lo) continue;
+                    if ((i & 63u) == 0u || i == i_first) { const uint32_t idx = (i & ~63u) + lane; Pc = Pi[idx <= n ? idx : n]; }
+                    const double P = __shfl(Pc, (int)(i & 63u), 64);
+                    if (P > 0.0 && st.k == 0 && st.c > 0.0) acc += st.v * P / st.c;
+                }
+            } else {
+                for (uint32_t i = i_s; i <= last; i++) {
+                    if (i > i_s) pmf_step(st, inv, t, n, m, i);
+                    if (i < i_lo) continue;
+                    const double P = Pi[i];
+                    if (P > 0.0 && st.k == 0 && st.c > 0.0) acc += st.v * P / st.c;
+                }
             }
+            if (!(valid && m_raw)) continue;
             tz[m] = acc;
         }
     }

@@ -133,6 +133,7 @@ class ShardIndex(_StagedMixin, Index):
         if sub_batch:
             check(self._lib.rtx_index_set_batch(self._h, sub_batch))
         # a shard of 4 tiles or more counts only the tiles that can matter, with the threshold of the whole database (RTX_OPT_SHARD_PRUNE)
+        self.tile_prune = bool(tile_prune)
         check(self._lib.rtx_index_set_option(self._h, 16, int(tile_prune)))
         from ._lib import ResultView
 
@@ -197,7 +198,7 @@ class LocalComm:
 
     allreduce_counts = allreduce_hist
 
-    def agree_min(self, value: int) -> int:
+    def agree_min(self, value: int, device=None) -> int:
         return int(value)       # every shard lives in this process: the caller has taken the minimum already
 
     def allgather_prefix(self, locals_):
@@ -231,13 +232,17 @@ class TorchComm:
 
     allreduce_counts = allreduce_hist   # int32 view of pairs of u16 counts (_StagedMixin.buffer)
 
-    def agree_min(self, value: int) -> int:
-        """The minimum of an integer over the ranks: all-reduce(min) of one int32 (on the current GPU under nccl = RCCL, which
+    def agree_min(self, value: int, device: Optional[int] = None) -> int:
+        """The minimum of an integer over the ranks: all-reduce(min) of one int32 (on the shard's GPU under nccl = RCCL, which
         reduces device memory only; on the host under gloo)."""
         import torch
 
         on_gpu = str(self.dist.get_backend()).lower() == "nccl"
-        t = torch.tensor([int(value)], dtype=torch.int32, device=torch.device("cuda", torch.cuda.current_device()) if on_gpu else "cpu")
+        if on_gpu:
+            dev = torch.cuda.current_device() if device is None else int(device)
+            t = torch.tensor([int(value)], dtype=torch.int32, device=torch.device("cuda", dev))
+        else:
+            t = torch.tensor([int(value)], dtype=torch.int32)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN)
         return int(t.item())
 
@@ -288,6 +293,9 @@ class ShardedClassifier:
     def upload(self, bases: np.ndarray, base_off: np.ndarray, exact_ids=None, exact_off=None):
         """Queries (and their exact-match ids) to every shard's HBM; they stay resident for any number of run()s."""
         for s in self.shards:
+            # an earlier batch may have switched this shard to plain counting (a transient cause: a failed scratch allocation, a batch of
+            # long reads): every upload starts from what the shard was built with, the verdict below is taken anew (ADVICE r4)
+            check(s._lib.rtx_index_set_option(s._h, 16, int(getattr(s, "tile_prune", True))))
             s.upload(bases, base_off, exact_ids, exact_off)
         self._n_q = len(base_off) - 1
         self._agree_on_pruning(bases, base_off, exact_ids, exact_off)
@@ -303,7 +311,7 @@ class ShardedClassifier:
         for s in self.shards:
             s.begin()
             local.append(int(s.prunes))
-        agreed = self.comm.agree_min(min(local))
+        agreed = self.comm.agree_min(min(local), device=getattr(self.shards[0], "device", None))
         for s, mine in zip(self.shards, local):
             if mine and not agreed:
                 check(s._lib.rtx_index_set_option(s._h, 16, 0))

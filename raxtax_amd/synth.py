@@ -74,6 +74,25 @@ class SynthDB:
         return "\n".join(lines) + "\n"
 
 
+def write_fasta(path, headers: Sequence[str], seq_bytes: np.ndarray, seq_off: np.ndarray, block: int = 50_000) -> int:
+    """Writes sequences in the reference's in-memory encoding (parser.rs:11-34) as FASTA: one header line (`>` + headers[i]) and one
+    sequence line per record -- what `raxtax -d` / `-i` read (parser.rs:46-154).  Returns the bytes written."""
+    dec = np.frombuffer(b"?AC?G???T??????N", dtype=np.uint8)
+    n = len(headers)
+    written = 0
+    with open(path, "wb") as fh:
+        for a in range(0, n, block):
+            b = min(n, a + block)
+            parts = []
+            for i in range(a, b):
+                parts.append(b">" + headers[i].encode() + b"\n")
+                parts.append(dec[seq_bytes[int(seq_off[i]):int(seq_off[i + 1])]].tobytes() + b"\n")
+            chunk = b"".join(parts)
+            fh.write(chunk)
+            written += len(chunk)
+    return written
+
+
 def make_db(n_refs: int, length: int = COI_LEN, fanouts: Optional[Sequence[int]] = None, seed_root: int = 1,
             seed_db: int = 2) -> SynthDB:
     fan = tuple(fanouts) if fanouts is not None else default_fanouts(n_refs)

@@ -49,6 +49,10 @@ def test_gpus_2_launches_its_own_ranks():
     assert r["n_gpus"] == 2 and r["config"]["process_group"] == {"backend": "gloo", "world_size": 2}
     assert r["scaling"] == "weak" and r["cpu_baseline"] is None
     assert r["config"]["classified_ok"] == 3000
+    # the line verifies itself at N > 1 too: rank 0's own last sub-batch as the run left it, and a seeded sample of the records it
+    # gathered from the other rank, against the oracle
+    ps = r["parity_sample"]
+    assert ps["ok"] and ps["ranks_checked"] == [0, 1] and ps["n"] >= 400, ps
 
 
 def test_shard_db_mode_runs():
@@ -58,9 +62,11 @@ def test_shard_db_mode_runs():
     r2 = bench("--shard-db", "--gpus", 2, "--backend", "gloo", "--refs", 3000, "--queries", 300, "--steps", 1, "--warmup", 1,
                "--sub-batch", 64)   # several sub-batches: the pipelined exchange (histogram all-reduce beside the next count)
     assert r2["n_gpus"] == 2 and r2["config"]["classified_ok"] == 300
+    assert r2["parity_sample"]["ok"] and r2["parity_sample"]["n"] == 300, r2["parity_sample"]      # final rows of every query = the oracle's on the whole database
     r3 = bench("--shard-db", "--shard-mode", "kmers", "--gpus", 2, "--backend", "gloo", "--refs", 3000, "--queries", 300,
                "--steps", 1, "--warmup", 1, "--sub-batch", 64)
     assert r3["n_gpus"] == 2 and r3["config"]["classified_ok"] == 300 and "k-mers sharded" in r3["config"]["parallelism"]
+    assert r3["parity_sample"]["ok"], r3["parity_sample"]
 
 
 def test_three_ranks_rehearse_the_eight_gpu_runs():
@@ -73,13 +79,14 @@ def test_three_ranks_rehearse_the_eight_gpu_runs():
     assert r["n_gpus"] == 3 and r["config"]["process_group"] == {"backend": "gloo", "world_size": 3}
     assert r["config"]["classified_ok"] == 1111 and r["config"]["host_threads_per_rank"] >= 1
     assert r["config"]["gathered_queries_last_step"] == 3 * 1111        # rank 0 read the headers of all three record buffers
+    assert r["parity_sample"]["ok"] and r["parity_sample"]["ranks_checked"] == [0, 1, 2], r["parity_sample"]
     r2 = bench("--shard-db", "--gpus", 3, "--backend", "gloo", "--refs", 73730, "--queries", 333, "--steps", 1, "--warmup", 1,
                "--sub-batch", 128)      # 73730 = 3 * 24576 + 2 references: two shards of 4 tiles (could prune alone), one of 3 (cannot): the
                                         # ranks agree not to (ShardedClassifier._agree_on_pruning over gloo) instead of mixing two orders of the queries
-    assert r2["n_gpus"] == 3 and r2["config"]["classified_ok"] == 333
+    assert r2["n_gpus"] == 3 and r2["config"]["classified_ok"] == 333 and r2["parity_sample"]["ok"], r2.get("parity_sample")
     r3 = bench("--shard-db", "--shard-mode", "kmers", "--gpus", 3, "--backend", "gloo", "--refs", 3001, "--queries", 257,
                "--steps", 1, "--warmup", 1, "--sub-batch", 64)
-    assert r3["n_gpus"] == 3 and r3["config"]["classified_ok"] == 257
+    assert r3["n_gpus"] == 3 and r3["config"]["classified_ok"] == 257 and r3["parity_sample"]["ok"], r3.get("parity_sample")
 
 
 def test_rccl_backend_with_one_rank():

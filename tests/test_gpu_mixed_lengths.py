@@ -84,11 +84,11 @@ def test_coi_reads_with_long_and_short_reads_in_one_batch(oracle):
     assert res.n_queries == n_all and (res.status == 0).all()
     classes = index.batch_classes()
     print("length classes of the mixed batch:", classes)
-    assert len(classes) == 3, "barcodes (with the few short reads), reads up to ~6.6 kb, longer reads"
-    c_coi, c_long, c_huge = classes
+    # the barcodes with the few short reads | the ten long reads: a handful of reads of a few kilobases rides with the longer ones
+    assert len(classes) == 2
+    c_coi, c_huge = classes
     assert c_coi["queries"] == n_coi + len(shorts) and c_coi["planes"] == 10 and c_coi["tables"] and c_coi["pair"] and c_coi["prune"] and c_coi["records"]
-    assert c_long["queries"] == 8 and c_long["planes"] in (12, 16) and not c_long["pair"] and not c_long["global_memory_forms"]
-    assert c_huge["queries"] == 2 and c_huge["planes"] == 16 and c_huge["global_memory_forms"]
+    assert c_huge["queries"] == 10 and c_huge["planes"] == 16 and not c_huge["pair"] and c_huge["global_memory_forms"]
     assert index.debug_prune_stats()["pairs"] > 0
     otree = oracle.tree_new_flat(db.lineages, db.seq_bytes, db.seq_off)
     ids_long = np.nonzero(lens > 1030)[0]

@@ -108,6 +108,18 @@ def main():
         if req and hitc:
             kinds[kind]["tcc_req"] = req[kind][0]
             kinds[kind]["tcc_hit"] = hitc[kind][0]
+    # the whole step, every kernel of the library (step_fabric_frac = (2 FETCH + WRITE) / ms_per_step / 8 TB/s)
+    per_kernel = {}
+    for k in sorted(set(passes[0]) | set(passes[1])):
+        if not k.startswith("rtx::"):
+            continue
+        fk, wk = passes[0].get(k, {}).get("FETCH_SIZE", []), passes[1].get(k, {}).get("WRITE_SIZE", [])
+        per_kernel[k] = {"launches": max(len(fk), len(wk)), "fetch_kb": sum(fk), "write_kb": sum(wk)}
+    step = {"fetch_kb": sum(v["fetch_kb"] for v in per_kernel.values()), "write_kb": sum(v["write_kb"] for v in per_kernel.values()),
+            "per_kernel": per_kernel,
+            "note": "sums over one whole step of the profiled command, index-build kernels included only if the pass saw them (the passes profile "
+                    "bench.py --steps 1 --warmup 0: the index build and the table build run once in front of the step -- bench.py leaves "
+                    "out the kernels that do not belong to a step)"}
     tf = ROOT / "profiles" / "traffic.json"
     t = json.loads(tf.read_text()) if tf.exists() else {}
     if "configs" not in t:
@@ -118,7 +130,7 @@ def main():
     key = f"refs={a.refs},query_len={a.query_len},queries={a.queries}"
     t["configs"] = {k: v for k, v in t["configs"].items() if "kinds" in v}      # entries of the older layout are of older builds anyway
     t["configs"][key] = {
-        "pruned": not a.unpruned, "kinds": kinds, "device_source_sha": device_source_sha(),
+        "pruned": not a.unpruned, "kinds": kinds, "step": step, "device_source_sha": device_source_sha(),
         "source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / --pmc TCC_* (separate passes, tools/profile_bench.sh {a.tag}: one whole step of "
                   f"`bench.py` at this size, every sub-batch). {a.note}".strip(),
     }

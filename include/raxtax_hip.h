@@ -230,6 +230,10 @@ int rtx_index_set_batch(rtx_index *index, uint32_t sub_batch);
                             * rate); two scratch sets alternate -- taken only if the second one fits free HBM without shrinking the sub-batch.
                             * 2: three stages (bounds | threshold + counting | back half; measured: no faster than two).  0: one stream.
                             * Same results.  Whole-database handles; shapes the workspace. */
+#define RTX_OPT_MIN_SUB_BATCHES 20 /* 4 (default; 1 .. 64): a batch on the pruned path is cut into at least this many sub-batches (of 16 384 queries or
+                                    * more), so that the host finalises the records of one while the next ones run and only the last one is left
+                                    * when the device is done.  rtx_raxtax sets 2 for the time of a call: its chunks follow one another through
+                                    * rtx_batch_download_then_run, which hides the last sub-batch of a chunk behind the next chunk.  Shapes the workspace. */
 /* RTX_OPT_SUB_BATCH, _PACKED_COUNTS, _HIT_PAIR, _TILE_PRUNE and _PROB_MODE shape the workspace that rtx_batch_upload sizes:
  * setting one of them drops the uploaded batch (rtx_batch_run then fails with RTX_ERR_STATE until the batch is uploaded again). */
 int rtx_index_set_option(rtx_index *index, int option, uint64_t value);
@@ -304,6 +308,11 @@ int rtx_batch_upload(rtx_index *index, uint64_t n_queries, const uint8_t *bases,
 int rtx_batch_run(rtx_index *index, uint32_t flags); /* enqueue all kernels (async)        */
 int rtx_batch_sync(rtx_index *index);                /* wait for the handle's stream        */
 int rtx_batch_download(rtx_index *index, rtx_result_view *out);
+/* rtx_batch_download of the current batch that, as soon as the last result records have left the device, makes the STAGED batch
+ * (rtx_batch_prefetch) the current one and runs it with `flags` (= rtx_batch_activate + rtx_batch_run) -- the host finalises the last
+ * sub-batch of this batch while the device already classifies the next (rtx_raxtax's chunks follow one another without the host's
+ * finalisation between them).  Nothing staged: plain rtx_batch_download. */
+int rtx_batch_download_then_run(rtx_index *index, rtx_result_view *out, uint32_t flags);
 
 /* ---- staged execution of a reference-sharded handle (one sub-batch at a time) --------------------
  * Between the stages the caller exchanges two device buffers with the other shards (RCCL):

@@ -108,6 +108,7 @@ _SIGNATURES = {
     "rtx_batch_run": (C.c_int, [C.c_void_p, C.c_uint32]),
     "rtx_batch_sync": (C.c_int, [C.c_void_p]),
     "rtx_batch_download": (C.c_int, [C.c_void_p, C.POINTER(ResultView)]),
+    "rtx_batch_download_then_run": (C.c_int, [C.c_void_p, C.POINTER(ResultView), C.c_uint32]),
     "rtx_batch_stage_times": (C.c_int, [C.c_void_p, f32p, u32p]),
     "rtx_batch_work": (C.c_int, [C.c_void_p, u64p, u64p, u64p]),
     "rtx_batch_prob_work": (C.c_int, [C.c_void_p, u64p, u64p]),

@@ -73,6 +73,13 @@ int run(rtx_index *const *indices, uint32_t n_dev, const rtx_tree *tree, uint64_
         any_host_lookup = any_host_lookup || !dev_lookup[d];
     }
 
+    // chunks follow one another through rtx_batch_download_then_run (the last sub-batch of a chunk is finalised beside the next chunk): two
+    // large sub-batches per chunk instead of four small ones (RTX_OPT_MIN_SUB_BATCHES); the handles get their setting back below
+    struct MinSubs {
+        rtx_index *const *ix; uint32_t n;
+        MinSubs(rtx_index *const *i, uint32_t k, uint64_t n_chunks) : ix(i), n(n_chunks > 1 ? k : 0) { for (uint32_t d = 0; d < n; d++) (void)rtx_index_set_option(ix[d], RTX_OPT_MIN_SUB_BATCHES, 2); }
+        ~MinSubs() { for (uint32_t d = 0; d < n; d++) (void)rtx_index_set_option(ix[d], RTX_OPT_MIN_SUB_BATCHES, 4); }
+    } min_subs_guard(indices, n_dev, n_chunks);
     std::vector<Chunk> chunks(n_chunks);
     for (uint64_t c = 0; c < n_chunks; c++) {
         chunks[c].q0 = c * chunk_size;
@@ -159,12 +166,10 @@ int run(rtx_index *const *indices, uint32_t n_dev, const rtx_tree *tree, uint64_
                 rc = stage_chunk(d, nxt);
                 staged = !rc;
             }
-            if (!rc) rc = rtx_batch_download(indices[d], &ch.res);
-            if (!rc && staged) {  // the device goes on with the next chunk while this thread finishes its bookkeeping for this one
-                rc = rtx_batch_activate(indices[d]);
-                if (!rc) rc = rtx_batch_run(indices[d], flags);
-                running = !rc;
-            }
+            // the device goes on with the next chunk as soon as the last records of this one have left it: the host's finalisation of
+            // the last sub-batch (and this thread's bookkeeping) no longer stand between two chunks (rtx_batch_download_then_run)
+            if (!rc) rc = staged ? rtx_batch_download_then_run(indices[d], &ch.res, flags) : rtx_batch_download(indices[d], &ch.res);
+            if (!rc && staged) running = true;
             if (!rc && dev_lookup[d]) {
                 const uint64_t *xo = nullptr;
                 const uint32_t *xi = nullptr;

@@ -464,7 +464,8 @@ int enqueue_walk(rtx_index *ix, const SubBatch &b, const double *prefix, hipStre
 int order_batch(rtx_index *ix, bool cluster) {
     const uint32_t n = (uint32_t)ix->n_q;
     int rc;
-    if ((rc = ix->d_perm.alloc(n)) || (rc = ix->d_iperm.alloc(n)) || (rc = ix->h_perm.resize(n)) || (rc = ix->h_inv.resize(n))) return rc;
+    ix->perm_cur ^= 1u;  // (the other set may still be read by the download of the batch before this one)
+    if ((rc = ix->d_perm.alloc(n)) || (rc = ix->d_iperm.alloc(n)) || (rc = ix->h_perm_now().resize(n)) || (rc = ix->h_inv_now().resize(n))) return rc;
     const bool multi = ix->n_cls > 1;       // several length classes: the class leads the key, whatever orders the queries inside a class
     const bool sketch = cluster && n > 2;
     if (sketch || multi) {
@@ -491,8 +492,8 @@ int order_batch(rtx_index *ix, bool cluster) {
         launch_identity_perm(ix->stream, n, ix->d_perm.p, ix->d_iperm.p);
     }
     RTX_HIP(hipGetLastError());
-    RTX_HIP(hipMemcpyAsync(ix->h_perm.data(), ix->d_perm.p, (size_t)n * 4, hipMemcpyDeviceToHost, ix->stream));
-    RTX_HIP(hipMemcpyAsync(ix->h_inv.data(), ix->d_iperm.p, (size_t)n * 4, hipMemcpyDeviceToHost, ix->stream));
+    RTX_HIP(hipMemcpyAsync(ix->h_perm_now().data(), ix->d_perm.p, (size_t)n * 4, hipMemcpyDeviceToHost, ix->stream));
+    RTX_HIP(hipMemcpyAsync(ix->h_inv_now().data(), ix->d_iperm.p, (size_t)n * 4, hipMemcpyDeviceToHost, ix->stream));
     return RTX_OK;
 }
 
@@ -799,7 +800,7 @@ int prepare_workspace(rtx_index *ix, uint64_t n_queries, const uint64_t cls_n_in
     if (cn[2] && cn[3] && cn[2] + cn[3] <= kSideMaxQueries) { cn[3] += cn[2]; cm[3] = std::max(cm[3], cm[2]); cn[2] = 0; cm[2] = 0; }
     const uint64_t key[14] = {n_queries, cn[0], cn[1], cn[2], cn[3], cm[0], cm[1], cm[2], cm[3], ix->sub_batch_req,
                               (uint64_t)ix->packed_opt | (uint64_t)ix->pair_opt << 1 | (uint64_t)ix->prune_opt << 2 | (uint64_t)ix->shard_prune_opt << 3 | (uint64_t)ix->fine_opt << 4 |
-                                  (uint64_t)(ix->prob_mode & 3) << 5 | (uint64_t)ix->rec_opt << 8 | (uint64_t)ix->overlap_opt << 16,
+                                  (uint64_t)(ix->prob_mode & 3) << 5 | (uint64_t)ix->rec_opt << 8 | (uint64_t)ix->overlap_opt << 16 | (uint64_t)ix->min_subs << 20,
                               (uint64_t)ix->n_bnd_local, 0, 0};
     // A batch of the shape of the last one under the same options (the chunks of rtx_raxtax): everything below would come out the same --
     // and hipMemGetInfo alone costs a good part of a millisecond between two chunks, with the device idle
@@ -900,7 +901,7 @@ static int size_workspace(rtx_index *ix, uint64_t n_queries) {
             // at least four sub-batches per batch (of 16 384 queries or more): the records of a finished sub-batch are copied and finalised on
             // the host while the next ones run, and what is left when the device is done is the last sub-batch -- a chunk of 131 072 queries
             // (rtx_raxtax) in two halves left 7 ms of host work exposed on real barcodes (ten result rows per query)
-            if (k.will_prune && k.n < 4ull * B) B = (uint32_t)std::max<uint64_t>(16384, (k.n + 3) / 4);
+            if (k.will_prune && k.n < (uint64_t)ix->min_subs * B) B = (uint32_t)std::max<uint64_t>(16384, (k.n + ix->min_subs - 1) / ix->min_subs);
         }
         if (B > kMaxSubBatch) B = kMaxSubBatch;
         B = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(B, k.n));

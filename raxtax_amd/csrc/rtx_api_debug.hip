@@ -123,7 +123,7 @@ static int debug_slot_as_run(rtx_index *ix, uint64_t query, uint32_t *slot) {  /
     if (!ix->synced) { set_error("debug tap: batch not synchronised"); return RTX_ERR_STATE; }
     const uint64_t last0 = ix->n_sub_total && ix->sub_q0.size() == ix->n_sub_total ? ix->sub_q0[ix->n_sub_total - 1] : 0;  // the last sub-batch of the run (of its last length class)
     if (query >= ix->n_q) { set_error("debug tap: query %llu out of range", (unsigned long long)query); return RTX_ERR_INVALID; }
-    const uint64_t pos = ix->h_inv[query];  // position in the processing order (valid once the stream is synchronised)
+    const uint64_t pos = ix->h_inv_now()[query];  // position in the processing order (valid once the stream is synchronised)
     if (pos < last0) { set_error("debug tap: query %llu not in the last sub-batch", (unsigned long long)query); return RTX_ERR_INVALID; }
     *slot = (uint32_t)(pos - last0);
     return RTX_OK;
@@ -197,7 +197,7 @@ int rtx_debug_prob_table(rtx_index *ix, uint64_t query, double *table_over_z, do
     RTX_HIP(hipMemcpy(table_over_z, ix->sc[ix->last_set].d_table_z.p + (size_t)slot * ix->hstride, (tt + 1) * 8, hipMemcpyDeviceToHost));
     for (uint32_t m = 0; m <= tt; m++)
         if (!hist[m]) table_over_z[m] = 0.0;  // entries of absent counts are never written
-    if (z) RTX_HIP(hipMemcpy(z, ix->d_z.p + ix->h_inv[query], 8, hipMemcpyDeviceToHost));
+    if (z) RTX_HIP(hipMemcpy(z, ix->d_z.p + ix->h_inv_now()[query], 8, hipMemcpyDeviceToHost));
     return RTX_OK;
 }
 
@@ -218,7 +218,7 @@ int rtx_debug_pruned_prob_table(rtx_index *ix, uint64_t query, double *table_ove
     RTX_HIP(hipMemcpy(table_over_z, sc.d_table_z.p + (size_t)slot * ix->hstride, (tt + 1) * 8, hipMemcpyDeviceToHost));
     for (uint32_t m = 0; m <= tt; m++)
         if (!hist[m] || m <= thr) table_over_z[m] = 0.0;  // entries of absent counts are never written; up to the threshold: 0 by construction
-    if (z) RTX_HIP(hipMemcpy(z, ix->d_z.p + ix->h_inv[query], 8, hipMemcpyDeviceToHost));
+    if (z) RTX_HIP(hipMemcpy(z, ix->d_z.p + ix->h_inv_now()[query], 8, hipMemcpyDeviceToHost));
     if (threshold) *threshold = thr;
     return RTX_OK;
 }
@@ -380,9 +380,9 @@ int rtx_batch_classes(const rtx_index *ix, uint32_t *n_classes, uint64_t out[16]
 
 int rtx_debug_order(rtx_index *ix, uint32_t *perm) {
     if (!ix || !perm) { set_error("null argument"); return RTX_ERR_INVALID; }
-    if (!ix->ran || ix->h_perm.n < ix->n_q) { set_error("rtx_debug_order: no batch has been run"); return RTX_ERR_STATE; }
+    if (!ix->ran || ix->h_perm_now().n < ix->n_q) { set_error("rtx_debug_order: no batch has been run"); return RTX_ERR_STATE; }
     RTX_HIP(hipStreamSynchronize(ix->stream));
-    std::memcpy(perm, ix->h_perm.data(), (size_t)ix->n_q * 4);
+    std::memcpy(perm, ix->h_perm_now().data(), (size_t)ix->n_q * 4);
     return RTX_OK;
 }
 

@@ -53,7 +53,7 @@ void finalise_range(rtx_index *ix, uint64_t pa, uint64_t pb, uint64_t row_base) 
     std::vector<uint32_t> ord;
     uint64_t o = row_base;
     for (uint64_t pos = pa; pos < pb; pos++) {
-        const uint64_t q = ix->h_perm[pos];  // the device records are in processing order
+        const uint64_t q = ix->dl_perm[pos];  // the device records are in processing order
         hr.h_t[q] = ix->hs_t[pos];
         hr.h_status[q] = ix->hs_status[pos];
         hr.h_gs[q] = ix->hs_gs[pos];
@@ -147,7 +147,30 @@ int copy_results(rtx_index *ix, uint64_t q0, uint64_t n, uint64_t r0, uint64_t r
 // (copy_stream) and finalised on the calling thread, so that only the last sub-batch is left once the device is
 // done.  *done = false: not applicable (batch already complete: the bulk path with its threads is faster) or the
 // arena overflowed (the bulk path repeats the run).
-static int download_streamed(rtx_index *ix, rtx_index::HostRes &hr, bool *done, uint64_t *nrows_out) {
+// the exact matches the device found belong to the download (same alternation as the result sets)
+static int fetch_exact_groups(rtx_index *ix, uint64_t nq) {
+    rtx_index::HostExact &hx = ix->host_exact[ix->res_set];
+    hx.valid = hx.csr_valid = false;
+    if (ix->dev_exact_used) {
+        hx.grp.resize(nq);
+        RTX_HIP(hipMemcpy(hx.grp.data(), ix->d_exact_grp.p, nq * 4, hipMemcpyDeviceToHost));
+        hx.valid = true;
+    }
+    return RTX_OK;
+}
+
+// rtx_batch_download_then_run: the staged batch becomes the current one and is enqueued -- called when the last records of the batch
+// being downloaded have left the device, while its last sub-batch is still to be finalised on the host
+static int run_staged(rtx_index *ix, uint32_t flags, bool *ran_next) {
+    *ran_next = false;
+    if (!ix->in[ix->cur_in ^ 1u].staged) return RTX_OK;
+    int rc = rtx_batch_activate(ix);
+    if (!rc) rc = rtx_batch_run(ix, flags);
+    *ran_next = rc == RTX_OK;
+    return rc;
+}
+
+static int download_streamed(rtx_index *ix, rtx_index::HostRes &hr, bool *done, uint64_t *nrows_out, bool then_run, uint32_t next_flags, bool *ran_next) {
     *done = false;
     const uint32_t n_sub = ix->n_sub_run;
     if (!ix->stream_dl || n_sub < 2 || ix->sub_q0.size() != n_sub || (hipEventQuery(ix->ev_sub[n_sub - 1]) == hipSuccess && hipEventQuery(ix->ev_sub[0]) == hipSuccess)) return RTX_OK;
@@ -168,17 +191,21 @@ static int download_streamed(rtx_index *ix, rtx_index::HostRes &hr, bool *done, 
         const uint64_t q0 = ix->sub_q0[sb], n = ix->sub_nq[sb];  // (classes of different sub-batch sizes follow one another: plan_sub_batches)
         if ((rc = copy_results(ix, q0, n, prev, cur, ix->copy_stream))) return rc;
         RTX_HIP(hipStreamSynchronize(ix->copy_stream));
+        if (k + 1 == n_sub) {  // the last records have left the device: it is free for the next batch while the host finalises these
+            RTX_HIP(hipStreamSynchronize(ix->stream));
+            uint32_t flags = 0;
+            RTX_HIP(hipMemcpy(&flags, ix->d_flags.p, 4, hipMemcpyDeviceToHost));
+            if (flags & 2u) { set_error("lineage walk exceeded its row/depth bounds (internal error)"); return RTX_ERR_HIP; }
+            if (flags & 1u) return RTX_OK;  // arena overflow: the bulk path repeats the run
+            if ((rc = fetch_exact_groups(ix, nq))) return rc;
+            if (then_run && (rc = run_staged(ix, next_flags, ran_next))) return rc;
+        }
         // one thread finalises 8192 queries in ~1.4 ms, about what the device needs for the next sub-batch: with a short
         // last sub-batch the host would still be busy with the one before it when the device is done
         nrows += finalise_mt(ix, q0, q0 + n, nrows, k + 1 == n_sub ? 16 : 8);
         prev = cur;
     }
-    RTX_HIP(hipStreamSynchronize(ix->stream));
-    ix->synced = true;
-    uint32_t flags = 0;
-    RTX_HIP(hipMemcpy(&flags, ix->d_flags.p, 4, hipMemcpyDeviceToHost));
-    if (flags & 2u) { set_error("lineage walk exceeded its row/depth bounds (internal error)"); return RTX_ERR_HIP; }
-    if (flags & 1u) return RTX_OK;
+    if (!*ran_next) ix->synced = true;  // (else: the next batch is running)
     *nrows_out = nrows;
     *done = true;
     return RTX_OK;
@@ -189,16 +216,17 @@ static int download_streamed(rtx_index *ix, rtx_index::HostRes &hr, bool *done, 
 
 extern "C" {
 
-int rtx_batch_download(rtx_index *ix, rtx_result_view *out) {
+static int download_impl(rtx_index *ix, rtx_result_view *out, bool then_run, uint32_t next_flags) {
     int rc = bind(ix);
     if (rc) return rc;
     if (!ix->ran || !out) { set_error("rtx_batch_download before rtx_batch_run"); return RTX_ERR_STATE; }
     const uint64_t nq = ix->n_q;
     ix->res_set ^= 1u;
+    ix->dl_perm = ix->h_perm_now().data();
     rtx_index::HostRes &hr = ix->host_res[ix->res_set];
-    bool streamed = false;
+    bool streamed = false, ran_next = false;
     uint64_t nrows = 0;
-    if ((rc = download_streamed(ix, hr, &streamed, &nrows))) return rc;
+    if ((rc = download_streamed(ix, hr, &streamed, &nrows, then_run, next_flags, &ran_next))) return rc;
     if (!streamed) {
         unsigned long long cursor = 0, cursor_side = 0;
         for (int attempt = 0;; attempt++) {
@@ -250,14 +278,9 @@ int rtx_batch_download(rtx_index *ix, rtx_result_view *out) {
             other.v_row_local.resize(hr.v_row_local.size());
         }
     }
-    {   // the exact matches the device found belong to this download (same alternation as the result sets)
-        rtx_index::HostExact &hx = ix->host_exact[ix->res_set];
-        hx.valid = hx.csr_valid = false;
-        if (ix->dev_exact_used) {
-            hx.grp.resize(nq);
-            RTX_HIP(hipMemcpy(hx.grp.data(), ix->d_exact_grp.p, nq * 4, hipMemcpyDeviceToHost));
-            hx.valid = true;
-        }
+    if (!streamed) {  // (the streamed path has fetched them before it let the next batch onto the device)
+        if ((rc = fetch_exact_groups(ix, nq))) return rc;
+        if (then_run && (rc = run_staged(ix, next_flags, &ran_next))) return rc;
     }
     out->n_queries = (uint32_t)nq;
     out->n_rows = nrows;
@@ -273,6 +296,13 @@ int rtx_batch_download(rtx_index *ix, rtx_result_view *out) {
     out->row_local_signal = hr.v_row_local.data();
     return RTX_OK;
 }
+
+int rtx_batch_download(rtx_index *ix, rtx_result_view *out) { return download_impl(ix, out, false, 0); }
+
+// Download of the current batch; as soon as its last records have left the device the STAGED batch (rtx_batch_prefetch) is activated and
+// run with `flags` -- the host finalises the last sub-batch of this batch while the device already classifies the next one.  Without a
+// staged batch: rtx_batch_download.
+int rtx_batch_download_then_run(rtx_index *ix, rtx_result_view *out, uint32_t flags) { return download_impl(ix, out, true, flags); }
 
 int rtx_index_has_exact_lookup(const rtx_index *index) { return index && index->d_em_table.p && index->dev_exact_opt ? 1 : 0; }
 

@@ -644,6 +644,11 @@ int rtx_index_set_option(rtx_index *index, int option, uint64_t value) {
         case RTX_OPT_FINE_BOUNDS:
             index->fine_opt = value ? 1u : 0u;
             return RTX_OK;
+        case RTX_OPT_MIN_SUB_BATCHES:
+            if (value < 1 || value > 64) break;
+            index->uploaded = index->ran = index->synced = false;  // shapes the workspace
+            index->min_subs = (uint32_t)value;
+            return RTX_OK;
         case RTX_OPT_OVERLAP:
             index->uploaded = index->ran = index->synced = false;  // shapes the workspace (a second scratch set)
             if (value > 2) break;

@@ -198,7 +198,13 @@ struct rtx_index {
     DevBuf<uint64_t> d_skey_in, d_skey_out;
     DevBuf<uint32_t> d_sidx, d_perm, d_iperm;
     DevBuf<uint8_t> d_sort_tmp;
-    PinBuf<uint32_t> h_perm, h_inv;
+    // host copies of the order: two sets -- rtx_batch_download_then_run enqueues the next batch (whose order_batch writes a set) while
+    // the last sub-batch of the batch before it is still being finalised from the other
+    PinBuf<uint32_t> h_perm_[2], h_inv_[2];
+    uint32_t perm_cur = 0;              // the set of the batch that ran last
+    const uint32_t *dl_perm = nullptr;  // the order of the batch being downloaded (finalise_range)
+    PinBuf<uint32_t> &h_perm_now() { return h_perm_[perm_cur]; }
+    PinBuf<uint32_t> &h_inv_now() { return h_inv_[perm_cur]; }
     DevBuf<uint8_t> d_bases;  // the current batch, one byte per base (what the kernels read): unpacked from the staged transfer at activation
     // Two input sets: a batch is STAGED (rtx_batch_prefetch: bases packed two per byte into pinned memory, offsets, exact-match ids;
     // asynchronous H2D on h2d_stream) while the batch before it runs out of the other set, and becomes the current one at
@@ -225,6 +231,7 @@ struct rtx_index {
     // ---- sub-batch scratch: two sets -- a staged (reference-sharded) run alternates between them, so that the exchange of
     // one sub-batch can overlap with the counting of the next; a whole-database handle uses set 0 only
     uint32_t sub_batch_req = 0, sub_batch = 0;
+    uint32_t min_subs = 4;  // RTX_OPT_MIN_SUB_BATCHES: a pruned batch is cut into at least this many sub-batches (the host finalises one while the next run)
     uint64_t ws_key[14] = {0};  // shape and options the workspace was last prepared for (prepare_workspace)
     bool ws_valid = false;
     // ---- length classes of the batch (round 5).  t <= length - 7 decides how a query is counted (8 / 10 / 12 / 16 bit planes, the pair

@@ -234,6 +234,14 @@ int rtx_index_set_batch(rtx_index *index, uint32_t sub_batch);
                                     * more), so that the host finalises the records of one while the next ones run and only the last one is left
                                     * when the device is done.  rtx_raxtax sets 2 for the time of a call: its chunks follow one another through
                                     * rtx_batch_download_then_run, which hides the last sub-batch of a chunk behind the next chunk.  Shapes the workspace. */
+#define RTX_OPT_TWO_LEVEL_BOUNDS 21 /* 1 (default): the bounds pass of the tile pruning on a whole-database handle runs in two levels
+                                     * (rtx_bounds2.hip): union bounds over blocks of 256 references for every tile -- four rows of that
+                                     * bitmap per load instruction --, and over blocks of 64 only for the groups of four tiles whose
+                                     * coarse bound comes close to the query's largest (sixteen rows per load instruction).  Every tile
+                                     * keeps a valid upper bound either way: results differ from the one-level pass only through which
+                                     * tiles are proven dead before counting (a function of the query alone).  0: the one-level pass
+                                     * over blocks of 64 (reference shards always use it).  Values above 1 set the rule that picks the
+                                     * refined groups (experiments): c_t | c_m << 16 | lo << 32 | hi << 48, in 1/256 of t. */
 /* RTX_OPT_SUB_BATCH, _PACKED_COUNTS, _HIT_PAIR, _TILE_PRUNE and _PROB_MODE shape the workspace that rtx_batch_upload sizes:
  * setting one of them drops the uploaded batch (rtx_batch_run then fails with RTX_ERR_STATE until the batch is uploaded again). */
 int rtx_index_set_option(rtx_index *index, int option, uint64_t value);

@@ -121,8 +121,11 @@ def check_run_as_left(index, j, t, counts_o, p_o, n_refs, emul=None, lf=None, la
         blk[: len(seg)] = seg
         assert np.array_equal(det["block_counts"], blk), f"{label}: exact counts of the best block {b}"
         assert det["M"] == int(blk.max()) and det["t"] == t and det["threshold"] == thr
-        assert det["largest_bound"] >= int(counts_o.max()), f"{label}: the largest bound lies below a count"
         tile_ub = index.debug_tile_bounds(j) if getattr(index, "tile_aware_threshold", True) else None
+        # the bound of the best block covers its own references; every count lies at or below the largest bound of a tile (with the
+        # two-level bounds pass the best block comes from the refined tiles only: the largest count may sit in another one)
+        assert det["largest_bound"] >= int(blk.max()), f"{label}: the best block's bound lies below one of its counts"
+        assert max(det["largest_bound"], int(tile_ub.max()) if tile_ub is not None else 0) >= int(counts_o.max()), f"{label}: the largest bound lies below a count"
         if tile_ub is not None:   # the bounds are bounds: every tile's largest count lies at or below its bound
             assert (tile_ub.astype(np.int64) >= tile_max_o).all(), f"{label}: a tile bound lies below a count of the tile"
         u_e, i1_e = emul_threshold(emul, lf, t, n_refs, blk, tile_ub=tile_ub)

@@ -219,8 +219,35 @@ int enqueue_hit(rtx_index *ix, const SubBatch &b, uint32_t flags, hipStream_t s,
         up.group_base = hp.group_base + ix->n_groups_run;  // work accounting apart from the counting proper
         if (part != 2) {
             if (b.timed) RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_TILE_BOUNDS, 0), s));
-            RTX_HIP(hipMemsetAsync(sc.d_best_key.p, 0, (size_t)b.nq * 4, s));  // the waves of a query's union tiles meet in an atomicMax
-            launch_hit_count_pair_bounds(s, up, b.nq, ix->u_ntiles, ix->planes);  // the union of the pair's rows serves both passes
+            // whole-database handles: the two-level pass (rtx_bounds2.hip); reference shards and RTX_OPT_TWO_LEVEL_BOUNDS = 0: blocks of 64 throughout
+            ix->two_level_used = part == 0 && ix->two_level_opt && ix->d_abitmap.p && ix->d_bbitmap.p && ix->n_refs == ix->n_total;
+            if (ix->two_level_used) {
+                Bounds2Params bp{};
+                bp.abitmap = ix->d_abitmap.p;
+                bp.bbitmap = ix->d_bbitmap.p;
+                bp.n_rows1 = ix->n_rows + 1;
+                bp.n_atiles = ix->n_atiles;
+                bp.ntiles = ix->ntiles;
+                bp.zero_row = ix->n_rows;
+                bp.pair_urec = sc.d_urec.p;
+                bp.pair_nu = sc.d_nu.p;
+                bp.pair_ustride = 2u * ix->rstride;
+                bp.nq = b.nq;
+                bp.t = sc.d_t.p;
+                bp.tile_ub = sc.d_tile_ub.p;
+                bp.tile_ub_stride = ix->ntiles;
+                bp.best_key = sc.d_best_key.p;
+                bp.delta_ct = ix->b2_delta[0];
+                bp.delta_cm = ix->b2_delta[1];
+                bp.delta_lo = ix->b2_delta[2];
+                bp.delta_hi = ix->b2_delta[3];
+                bp.group_rows = up.group_rows;
+                bp.group_base = up.group_base;
+                launch_bounds2(s, bp, b.nq, ix->planes);
+            } else {
+                RTX_HIP(hipMemsetAsync(sc.d_best_key.p, 0, (size_t)b.nq * 4, s));  // the waves of a query's union tiles meet in an atomicMax
+                launch_hit_count_pair_bounds(s, up, b.nq, ix->u_ntiles, ix->planes);  // the union of the pair's rows serves both passes
+            }
             if (b.timed) RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_TILE_BOUNDS, 1), s));
         }
         if (s_mid && s_mid != s && part == 0) {  // RTX_OPT_OVERLAP = 2: threshold, lists and counting go on on a stream of their own

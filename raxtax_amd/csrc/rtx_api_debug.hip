@@ -51,7 +51,8 @@ int rtx_batch_work(rtx_index *ix, uint64_t *sum_hits, uint64_t *sum_query_bytes,
         gr.resize(2 * ng);
         RTX_HIP(hipMemcpy(gr.data(), ix->d_group_rows.p, gr.size() * 4, hipMemcpyDeviceToHost));
     }
-    const uint64_t urow_bytes = ix->u_ntiles ? ((ix->u_nblocks + 7) / 8 + ix->u_ntiles - 1) / ix->u_ntiles : 0;
+    // (the two-level pass counts load instructions: a KiB each, several short rows)
+    const uint64_t urow_bytes = ix->two_level_used ? 1024u : (ix->u_ntiles ? ((ix->u_nblocks + 7) / 8 + ix->u_ntiles - 1) / ix->u_ntiles : 0);
     for (uint32_t sb = 0; sb < n_sub; sb++) {
         const rtx_index::BatchClass &kc = ix->cls[ix->sub_cls[sb]];
         if (kc.pair) {
@@ -85,7 +86,7 @@ int rtx_batch_work_split(rtx_index *ix, uint64_t *live_bytes, uint64_t *bounds_b
         if (any) {
             std::vector<uint32_t> gr(ng);
             RTX_HIP(hipMemcpy(gr.data(), ix->d_group_rows.p + ng, ng * 4, hipMemcpyDeviceToHost));
-            const uint64_t urow_bytes = ((ix->u_nblocks + 7) / 8 + ix->u_ntiles - 1) / ix->u_ntiles;
+            const uint64_t urow_bytes = ix->two_level_used ? 1024u : ((ix->u_nblocks + 7) / 8 + ix->u_ntiles - 1) / ix->u_ntiles;
             for (uint32_t sb = 0; sb < n_sub; sb++)
                 if (ix->cls[ix->sub_cls[sb]].prune)
                     for (size_t g = (size_t)sb * ix->groups_per_sub; g < (size_t)(sb + 1) * ix->groups_per_sub; g++) bounds += (uint64_t)gr[g] * urow_bytes;

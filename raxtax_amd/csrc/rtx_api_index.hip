@@ -163,6 +163,7 @@ static int create_common(int device, uint64_t n_total, uint64_t ref_lo, uint64_t
 
 static bool prepare_union_bitmap(rtx_index *ix);
 static bool prepare_fine_bitmap(rtx_index *ix);
+static void build_two_level(rtx_index *ix);
 
 // Hash table of the distinct reference sequences for the device exact-match lookup (rtx_exact.hip).  `groups`: per distinct
 // sequence the ids of the references that have it, ascending (Tree.sequences, tree.rs:109-112); group order = order of the first
@@ -404,6 +405,7 @@ static int create_from_csr(int device, uint64_t n_total, uint64_t ref_lo, uint64
             launch_bitmap_build(ix->stream, d_off.p, d_post.p, ix->d_row_of.p, ix->d_ubitmap.p, ix->u_stride_bytes / 4, nr + 1, (uint32_t)ref_lo,
                                 (uint32_t)ref_hi, kPruneShift);
             if (hipStreamSynchronize(ix->stream) != hipSuccess) { (void)hipGetLastError(); ix->d_ubitmap.release(); }
+            build_two_level(ix);
         }
         if (prepare_fine_bitmap(ix)) {
             launch_bitmap_build(ix->stream, d_off.p, d_post.p, ix->d_row_of.p, ix->d_fbitmap.p, ix->f_stride_bytes / 4, nr + 1, (uint32_t)ref_lo,
@@ -446,6 +448,29 @@ static bool prepare_fine_bitmap(rtx_index *ix) {
     if (ix->d_fbitmap.alloc(words)) { ix->d_fbitmap.release(); return false; }
     if (hipMemsetAsync(ix->d_fbitmap.p, 0, words * 4, ix->stream) != hipSuccess) { (void)hipGetLastError(); ix->d_fbitmap.release(); return false; }
     return true;
+}
+
+// The two bitmaps of the two-level bounds pass (rtx_bounds2.hip) from the union bitmap over blocks of 64, which one of the builders has
+// filled: whole-database handles that prune.  A failure to allocate leaves the handle with the one-level pass.
+static void build_two_level(rtx_index *ix) {
+    if (!ix->d_ubitmap.p || ix->n_refs != ix->n_total) return;
+    static_assert(kPruneShift == 6, "level B of the two-level bounds pass holds the blocks of the union bitmap");
+    ix->n_btiles = (uint32_t)((ix->u_nblocks + 511) / 512);
+    ix->n_atiles = (uint32_t)((ix->u_nblocks + 8191) / 8192);  // 2048 blocks of 256 = 8192 blocks of 64
+    const size_t rows1 = (size_t)ix->n_rows + 1;
+    if (rows1 * 256u > 0xFFFFFFFFull) return;  // (a tile's region is addressed through one buffer descriptor)
+    if (ix->d_abitmap.alloc((size_t)ix->n_atiles * rows1 * 64) || ix->d_bbitmap.alloc((size_t)ix->n_btiles * rows1 * 64)) {
+        ix->d_abitmap.release();
+        ix->d_bbitmap.release();
+        return;
+    }
+    hipError_t e = hipMemsetAsync(ix->d_abitmap.p, 0, (size_t)ix->n_atiles * rows1 * 256, ix->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(ix->d_bbitmap.p, 0, (size_t)ix->n_btiles * rows1 * 64, ix->stream);
+    if (e == hipSuccess) {
+        launch_bounds2_build(ix->stream, ix->d_ubitmap.p, (uint32_t)rows1, ix->u_ntiles, ix->d_bbitmap.p, ix->d_abitmap.p);
+        e = hipStreamSynchronize(ix->stream);
+    }
+    if (e != hipSuccess) { (void)hipGetLastError(); ix->d_abitmap.release(); ix->d_bbitmap.release(); }
 }
 
 // Locator table of the processing order (rtx_cluster.hip) from the reference sequences already on the device.
@@ -517,6 +542,7 @@ int rtx_index_create_from_sequences(int device, uint64_t n_refs, const uint8_t *
     if (prepare_union_bitmap(ix)) {
         launch_ref_bitmap_set(ix->stream, d_seq.p, d_off.p, n_refs, ix->d_row_of.p, ix->d_ubitmap.p, ix->u_stride_bytes / 4, nr + 1, kPruneShift);
         if (hipStreamSynchronize(ix->stream) != hipSuccess) { (void)hipGetLastError(); ix->d_ubitmap.release(); }
+        build_two_level(ix);
     }
     if (prepare_fine_bitmap(ix)) {
         launch_ref_bitmap_set(ix->stream, d_seq.p, d_off.p, n_refs, ix->d_row_of.p, ix->d_fbitmap.p, ix->f_stride_bytes / 4, nr + 1, kFineShift);
@@ -579,7 +605,7 @@ void rtx_index_destroy(rtx_index *index) {
 uint64_t rtx_index_num_refs(const rtx_index *index) { return index ? index->n_total : 0; }
 uint64_t rtx_index_device_bytes(const rtx_index *index) {
     if (!index) return 0;
-    return index->d_seg_dbits.n * 8 + index->d_seg_sbits.n * 8 + index->d_seg_sbase.n * 4 + index->d_seginfo.n * 4 + index->d_segcls.n * 4 + index->d_segslots.n * 2 + index->d_bitmap.n * 4 + index->d_row_of.n * 4 + index->d_row_len.n * 8 + index->d_list_len.n * 4 + index->d_loc_table.n * 4 + index->d_ubitmap.n * 4 + index->d_fbitmap.n * 4 + index->d_em_table.n * 8 + index->d_em_rep_off.n * 8 + index->d_em_rep_bytes.n + index->d_em_goff.n * 4 + index->d_em_gids.n * 4 + index->d_lnfact.n * 8 +
+    return index->d_seg_dbits.n * 8 + index->d_seg_sbits.n * 8 + index->d_seg_sbase.n * 4 + index->d_seginfo.n * 4 + index->d_segcls.n * 4 + index->d_segslots.n * 2 + index->d_bitmap.n * 4 + index->d_row_of.n * 4 + index->d_row_len.n * 8 + index->d_list_len.n * 4 + index->d_loc_table.n * 4 + index->d_ubitmap.n * 4 + index->d_fbitmap.n * 4 + index->d_abitmap.n * 4 + index->d_bbitmap.n + index->d_em_table.n * 8 + index->d_em_rep_off.n * 8 + index->d_em_rep_bytes.n + index->d_em_goff.n * 4 + index->d_em_gids.n * 4 + index->d_lnfact.n * 8 +
            index->d_noderec.n * 16 + index->d_bnd_bits.n + index->d_bnd_rank.n * 4;
 }
 int rtx_index_set_batch(rtx_index *index, uint32_t sub_batch) {
@@ -643,6 +669,15 @@ int rtx_index_set_option(rtx_index *index, int option, uint64_t value) {
             return RTX_OK;
         case RTX_OPT_FINE_BOUNDS:
             index->fine_opt = value ? 1u : 0u;
+            return RTX_OK;
+        case RTX_OPT_TWO_LEVEL_BOUNDS:
+            index->two_level_opt = value ? 1u : 0u;
+            if (value > 1) {
+                index->b2_delta[0] = (uint32_t)(value & 0xFFFFu);
+                index->b2_delta[1] = (uint32_t)((value >> 16) & 0xFFFFu);
+                index->b2_delta[2] = (uint32_t)((value >> 32) & 0xFFFFu);
+                index->b2_delta[3] = (uint32_t)((value >> 48) & 0xFFFFu);
+            }
             return RTX_OK;
         case RTX_OPT_MIN_SUB_BATCHES:
             if (value < 1 || value > 64) break;

@@ -398,12 +398,17 @@ static void emul_prune_threshold_x(uint32_t t, uint64_t n_refs, const uint32_t *
         // (4): S_A, S_B of the groups at their own bounds (capped below min H: a group above it is never dead); the groups far below the
         // threshold of (2) together at S(u_(2) - kPruneFarGap) unless too many lie near (prune_kernel: same rule)
         std::vector<double> gsa(n_groups, 0.0), gsb(n_groups, 0.0);
-        std::vector<uint8_t> near(n_groups, 0);
-        double far_a = 0.0, far_b = 0.0, n_far = 0.0;
+        std::vector<uint8_t> near(n_groups, 0), mid(n_groups, 0);
+        double far_a = 0.0, far_b = 0.0, n_far = 0.0, mid_a = 0.0, mid_b = 0.0, n_mid = 0.0;
         if (n_groups) {
             const uint32_t m_far = u_max > kPruneFarGap ? u_max - kPruneFarGap : 0u;
             uint32_t n_near = 0;
-            for (uint32_t g = 0; g < n_groups; g++) { near[g] = gn[g] > 0 && gub[g] > m_far; n_near += near[g]; }
+            // near: above the threshold of (2), a window sum of their own; mid: within kPruneFarGap below it, together at S(u_(2))
+            for (uint32_t g = 0; g < n_groups; g++) {
+                near[g] = gn[g] > 0 && gub[g] > u_max;
+                mid[g] = gn[g] > 0 && gub[g] > m_far && gub[g] <= u_max;
+                n_near += near[g];
+            }
             if (n_near > kPruneMaxNear) {
                 std::vector<double> inv(t + n + 2, 0.0);
                 for (uint32_t x = 1; x <= t + n; x++) inv[x] = 1.0 / (double)x;
@@ -413,9 +418,12 @@ static void emul_prune_threshold_x(uint32_t t, uint64_t n_refs, const uint32_t *
                                       [&](uint32_t l) { return WB[l]; }, gsa[g], gsb[g]);
                 }
             } else {
-                for (uint32_t g = 0; g < n_groups; g++)
-                    if (!near[g]) n_far += (double)gn[g];
+                for (uint32_t g = 0; g < n_groups; g++) {
+                    if (mid[g]) n_mid += (double)gn[g];
+                    else if (!near[g]) n_far += (double)gn[g];
+                }
                 if (m_far) sums_at(m_far, far_a, far_b);
+                if (n_mid > 0.0) sums_at(u_max, mid_a, mid_b);
                 for (uint32_t g = 0; g < n_groups; g++)
                     if (near[g]) sums_at(std::min(gub[g], h_min - 1u), gsa[g], gsb[g]);
             }
@@ -429,7 +437,7 @@ static void emul_prune_threshold_x(uint32_t t, uint64_t n_refs, const uint32_t *
                 falling = (double)(u + j) * (double)(n - j) < (double)(j + 1u) * (double)(t - u + n - j - 1u);
             }
             if (!n_groups) return falling && nn * a <= kPruneHalfEpsHD && nn * b <= kPruneHalfEpsHD;
-            double ta = n_far * far_a, tb = n_far * far_b;
+            double ta = n_far * far_a + n_mid * mid_a, tb = n_far * far_b + n_mid * mid_b;
             for (uint32_t g = 0; g < n_groups; g++) {
                 if (!near[g]) continue;
                 const bool dead = gub[g] <= u;

@@ -178,6 +178,14 @@ struct rtx_index {
     uint32_t f_stride_bytes = 0, f_ntiles = 0;
     uint64_t f_nblocks = 0;
     uint32_t fine_opt = 1;  // RTX_OPT_FINE_BOUNDS
+    // the bounds pass in two levels (rtx_bounds2.hip; whole-database handles): blocks of 256 references for every tile (four rows per load
+    // instruction), blocks of 64 only for the B-tiles near the query's largest bound (sixteen rows per load instruction)
+    DevBuf<uint32_t> d_abitmap;  // [n_atiles][n_rows + 1][64 words]
+    DevBuf<uint8_t> d_bbitmap;   // [n_btiles][n_rows + 1][64 bytes]
+    uint32_t n_atiles = 0, n_btiles = 0;
+    uint32_t two_level_opt = 1;  // RTX_OPT_TWO_LEVEL_BOUNDS
+    uint32_t b2_delta[4] = {275u, 205u, 84u, 128u};  // which B-tiles are refined: c_t, c_m, lo, hi in 1/256 (Bounds2Params)
+    bool two_level_used = false;  // the last run's bounds pass was bounds2_kernel (its work accounting counts load instructions of 1 KiB)
     uint32_t rec_opt = 4;   // RTX_OPT_RECORDS: pruned queries with at most this many live tiles take the records path (0: off; at most kRecMaxSlots)
     uint32_t overlap_opt = 1;  // RTX_OPT_OVERLAP: 1 = back half of sub-batch k on a second stream beside the front half of k + 1 (2: three stages)
     uint32_t overlap_used = 0;  // scratch sets the last run used beside each other (0: one stream)

@@ -181,6 +181,25 @@ struct HitParams {
     unsigned long long *fine_stats;  // [kPruneStatCopies][8]: [0] += (query, tile) combinations cleared, [1] += blocks of the fine pass, or null
     RecordRef rec;                // the records path of pruned queries (above); rec.nslots == null: every epilogue is the dense one
 };
+// the bounds pass in two levels (rtx_bounds2.hip): level A over blocks of 256 references for every tile, level B over blocks of 64 for the
+// B-tiles (4 tiles of the database) near the query's largest level-A bound; one wave per pair, no atomics
+struct Bounds2Params {
+    const uint32_t *abitmap;   // [n_atiles][n_rows1][64 words]: bit b of a row = block b of 256 references of the A-tile (2048 blocks = 64 tiles)
+    const uint8_t *bbitmap;    // [n_btiles][n_rows1][64 bytes]: bit b = block b of 64 references of the B-tile (512 blocks = 4 tiles)
+    uint32_t n_rows1, n_atiles, ntiles, zero_row;
+    const uint2 *pair_urec;    // the unions of the pairs' row lists (pair_union_kernel)
+    const uint32_t *pair_nu;
+    uint32_t pair_ustride, nq;
+    const uint32_t *t;         // [B]
+    uint16_t *tile_ub;         // [B][tile_ub_stride] out: an upper bound of every count of every tile (level A's, or level B's where refined)
+    uint32_t tile_ub_stride;
+    uint32_t *best_key;        // [B] out: bound << 20 | (0xFFFFF - block) of the best block of 64 among the refined tiles
+    uint32_t delta_ct, delta_cm, delta_lo, delta_hi;  // which B-tiles are refined (in 1/256; bounds2_kernel)
+    uint32_t *group_rows;      // work accounting: load instructions (1 KiB each) per pair, or null
+    uint32_t group_base;
+};
+void launch_bounds2(hipStream_t s, const Bounds2Params &p, uint32_t nq, int planes);
+void launch_bounds2_build(hipStream_t s, const uint32_t *ubitmap, uint32_t n_rows1, uint32_t u_ntiles, uint8_t *bbitmap, uint32_t *abitmap);
 constexpr uint32_t kFineShift = 3;       // blocks of 8 references: the 8 references of one byte of a bitmap row (ref_slot)
 constexpr uint32_t kFineMinLive = 4;     // pairs with fewer live tiles than this skip the fine pass (a block of it costs what it can save there)
 constexpr uint32_t kFineMinTiles = 16;   // databases with fewer tiles have no fine union bitmap

@@ -339,11 +339,17 @@ __global__ __launch_bounds__(64 * kPruneWavesPerBlock, RTX_PRUNE_WAVES) void pru
                         // magnitude per ten counts) are priced together at S(u_(2) - kPruneFarGap), which bounds each of theirs (S rises with the
                         // count).  More than kPruneMaxNear near groups (a threshold near the background: everything is "near"): lane g runs the
                         // window once for its own bound, pmf advanced by its ratio (prune_window_sums), whatever their number.
-                        double gsa = 0.0, gsb = 0.0, far_a = 0.0, far_b = 0.0, n_far = 0.0;
+                        // Round 5: the groups between the two -- bound within kPruneFarGap counts BELOW the threshold of (2): dead at every
+                        // candidate, the bisection starts at that threshold -- are priced together at S(u_(2)), which bounds each of theirs.
+                        // They hold a handful of tiles against the N references (3) priced at its own, larger threshold: nothing is lost, and
+                        // the groups that get a window sum of their own are those ABOVE u_(2) only (with the two-level bounds pass the tiles
+                        // left with a bound over blocks of 256 crowd the band below it: their sums were a quarter of this kernel's time).
+                        double gsa = 0.0, gsb = 0.0, far_a = 0.0, far_b = 0.0, n_far = 0.0, mid_a = 0.0, mid_b = 0.0, n_mid = 0.0;
                         bool near = false;
                         if (tile_aware) {
                             const uint32_t m_far = u_max > kPruneFarGap ? u_max - kPruneFarGap : 0u;
-                            near = gnd > 0.0 && gub > m_far;
+                            near = gnd > 0.0 && gub > u_max;
+                            const bool mid = gnd > 0.0 && gub > m_far && gub <= u_max;
                             unsigned long long nb = __ballot(near);
                             if ((uint32_t)__popcll(nb) > kPruneMaxNear) {
                                 near = gnd > 0.0;
@@ -351,8 +357,10 @@ __global__ __launch_bounds__(64 * kPruneWavesPerBlock, RTX_PRUNE_WAVES) void pru
                                 prune_window_sums(lf, p.inv, t, n, gcap, i1, ln_total, [&](uint32_t l) { return readlane_f64(WA, (int)l); },
                                                   [&](uint32_t l) { return readlane_f64(WB, (int)l); }, gsa, gsb);
                             } else {
-                                n_far = wave_sum_f64_dpp(near ? 0.0 : gnd);
+                                n_far = wave_sum_f64_dpp(near || mid ? 0.0 : gnd);
+                                n_mid = wave_sum_f64_dpp(mid ? gnd : 0.0);
                                 if (m_far) sums_at(m_far, far_a, far_b);
+                                if (n_mid > 0.0) sums_at(u_max, mid_a, mid_b);  // wave-uniform
                                 while (nb) {  // wave-uniform
                                     const int g = __builtin_ctzll(nb);
                                     nb &= nb - 1ull;
@@ -373,8 +381,8 @@ __global__ __launch_bounds__(64 * kPruneWavesPerBlock, RTX_PRUNE_WAVES) void pru
                             sums_at(u, a, b);
                             if (!tile_aware) return falling && nn * a <= kPruneHalfEps && nn * b <= kPruneHalfEps;
                             const bool dead = gub <= u;
-                            return falling && wave_sum_f64_dpp(near ? gnd * (dead ? gsa : a) : 0.0) + n_far * far_a <= kPruneHalfEps &&
-                                   wave_sum_f64_dpp(near ? gnd * (dead ? gsb : b) : 0.0) + n_far * far_b <= kPruneHalfEps;
+                            return falling && wave_sum_f64_dpp(near ? gnd * (dead ? gsa : a) : 0.0) + n_far * far_a + n_mid * mid_a <= kPruneHalfEps &&
+                                   wave_sum_f64_dpp(near ? gnd * (dead ? gsb : b) : 0.0) + n_far * far_b + n_mid * mid_b <= kPruneHalfEps;
                         };
                         uint32_t lo = u_max, hi = h_min - 1u;
                         while (lo < hi) {  // wave-uniform

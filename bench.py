@@ -87,7 +87,6 @@ def parse():
     ap.add_argument("--records", type=int, default=None, help="RTX_OPT_RECORDS: pruned queries with at most this many live tiles write records of the counts above their threshold instead of counts (0: off; default: the library's)")
     ap.add_argument("--overlap", type=int, default=None, help="RTX_OPT_OVERLAP: 1 = back half of a sub-batch on a second stream beside the front half of the next (default: the library's)")
     ap.add_argument("--no-two-level", action="store_true", help="bounds pass of the tile pruning over blocks of 64 throughout (RTX_OPT_TWO_LEVEL_BOUNDS = 0; A/B measurements)")
-    ap.add_argument("--no-sub-count", action="store_true", help="the records-path queries are counted tile by tile by the pair kernel (RTX_OPT_SUB_COUNT = 0; A/B measurements)")
     ap.add_argument("--two-level-rule", type=int, default=None, help="RTX_OPT_TWO_LEVEL_BOUNDS > 1: the rule that picks the refined groups of tiles, packed (experiments)")
     ap.add_argument("--no-tile-skip", action="store_true", help="taxon_prefix sums every reference (RTX_OPT_TILE_SKIP = 0; A/B measurements)")
     ap.add_argument("--mu-q", type=float, default=0.02, help="per-site substitution rate of a query against its source reference (the headline: 0.02)")
@@ -966,7 +965,7 @@ def main():
                          tile_skip=False if args.no_tile_skip else None, hit_pair=False if args.no_pair else None,
                          locator=False if args.no_locator else None, tile_prune=False if args.no_tile_prune else None,
                          fine_bounds=False if args.no_fine_bounds else None, records=args.records, overlap=args.overlap,
-                         two_level=0 if args.no_two_level else args.two_level_rule, sub_count=False if args.no_sub_count else None)
+                         two_level=0 if args.no_two_level else args.two_level_rule)
         t_exact = None
         if args.host_exact_match or not index.has_exact_lookup:
             t0 = time.perf_counter()

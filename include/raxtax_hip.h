@@ -242,12 +242,6 @@ int rtx_index_set_batch(rtx_index *index, uint32_t sub_batch);
                                      * tiles are proven dead before counting (a function of the query alone).  0: the one-level pass
                                      * over blocks of 64 (reference shards always use it).  Values above 1 set the rule that picks the
                                      * refined groups (experiments): c_t | c_m << 16 | lo << 32 | hi << 48, in 1/256 of t. */
-#define RTX_OPT_SUB_COUNT 22 /* 1 (default): the queries on the records path (RTX_OPT_RECORDS) are counted over SUB-TILES of 512 references
-                              * (rtx_subcount.hip): the bounds over blocks of 64 references of a live tile say which sub-tiles can hold a
-                              * count above the query's threshold at all -- only those are counted, from a copy of the database bitmap
-                              * stored in sub-tiles (sixteen rows per load instruction), and their counts above the threshold leave as the
-                              * same records.  Needs RTX_OPT_TWO_LEVEL_BOUNDS' bitmaps (whole-database handles).  0: every live tile of
-                              * such a query is counted whole by the pair kernel. */
 /* RTX_OPT_SUB_BATCH, _PACKED_COUNTS, _HIT_PAIR, _TILE_PRUNE and _PROB_MODE shape the workspace that rtx_batch_upload sizes:
  * setting one of them drops the uploaded batch (rtx_batch_run then fails with RTX_ERR_STATE until the batch is uploaded again). */
 int rtx_index_set_option(rtx_index *index, int option, uint64_t value);

@@ -220,7 +220,7 @@ class Index:
                  packed_counts: Optional[bool] = None,
                  tile_skip: Optional[bool] = None, hit_pair=None, locator: Optional[bool] = None, tile_prune: Optional[bool] = None,
                  debug_taps: bool = False, device_exact: Optional[bool] = None, fine_bounds: Optional[bool] = None,
-                 records: Optional[int] = None, overlap: Optional[bool] = None, two_level: Optional[int] = None, sub_count: Optional[bool] = None):
+                 records: Optional[int] = None, overlap: Optional[bool] = None, two_level: Optional[int] = None):
         self._lib = _lib.load()
         self.tree = tree
         if segment_classes is None:
@@ -260,8 +260,6 @@ class Index:
             check(self._lib.rtx_index_set_option(self._h, 19, int(overlap)))
         if two_level is not None:  # RTX_OPT_TWO_LEVEL_BOUNDS: 0 = the bounds pass over blocks of 64 throughout (values above 1: the refine rule, packed)
             check(self._lib.rtx_index_set_option(self._h, 21, int(two_level)))
-        if sub_count is not None:  # RTX_OPT_SUB_COUNT: the records-path queries counted over sub-tiles of 512 references (0: whole tiles)
-            check(self._lib.rtx_index_set_option(self._h, 22, int(sub_count)))
         self._view = ResultView()
         self._keep = None
 

@@ -295,12 +295,6 @@ int enqueue_hit(rtx_index *ix, const SubBatch &b, uint32_t flags, hipStream_t s,
         const bool records = part == 0 && ix->rec_used && sc.d_rec.p != nullptr;
         const RecordRef rr{sc.d_rec_nslots.p, sc.d_rec_slots.p, sc.d_rec_cnt.p, sc.d_rec.p, std::min<uint32_t>(ix->rec_opt, kRecMaxSlots)};
         if (records) { pr.rec = rr; pr.rec_max_slots = rr.stride; }
-        // ... and are counted over sub-tiles of 512 references (rtx_subcount.hip) instead of whole tiles
-        const size_t cap_sub = (size_t)b.nq * ix->n_btiles;
-        const bool sub_count = records && ix->sub_count_opt && ix->d_sbitmap.p && ix->d_bbitmap.p && ix->pair_used && sc.d_sub_items.p &&
-                               sc.d_sub_items.n >= cap_sub + 9u + ix->n_btiles;
-        ix->sub_count_used = sub_count;
-        pr.sub_path = sub_count ? 1u : 0u;
         ProbTables tb{ix->d_tab_cmf.p, ix->d_tab_ratio.p, ix->d_tab_off.p, ix->d_tab_moff.p, ix->d_tab_ilo.p, ix->d_tab_sat.p, ix->tab_tmax};
         launch_prune(s, pr, tb, b.nq);
         if (part == 1) { RTX_HIP(hipGetLastError()); return RTX_OK; }  // the caller exchanges RTX_BUF_BEST, then part 2
@@ -325,7 +319,6 @@ int enqueue_hit(rtx_index *ix, const SubBatch &b, uint32_t flags, hipStream_t s,
             fp.fine_n_refs = ix->n_refs;
             fp.fine_ref_ntiles = ix->ntiles;
             fp.fine_stats = ix->d_prune_stats.p + 2 * kPruneStatCopies * 8;
-            fp.sub_skip = sub_count ? sc.d_rec_nslots.p : nullptr;
             const size_t cap_f = (size_t)((b.nq + 1u) / 2u) * ix->f_ntiles;
             launch_fine_bounds(s, fp, b.nq, ix->ntiles, ix->f_ntiles, pr.pair_live, sc.d_fine_items.p + cap_f + 9u, sc.d_fine_items.p, sc.d_fine_items.p + cap_f, ix->planes);
         }
@@ -335,10 +328,9 @@ int enqueue_hit(rtx_index *ix, const SubBatch &b, uint32_t flags, hipStream_t s,
         hp.live_words = pr.live_words;
         hp.prune_thr = sc.d_prune_thr.p;
         if (records) hp.rec = rr;
-        hp.sub_skip = sub_count ? sc.d_rec_nslots.p : nullptr;
         if (ix->pair_used) {  // the grid of the counting pass walks the live (pair, tile) blocks instead of all of them
             const size_t np = (b.nq + 1u) / 2u, cap = np * ix->ntiles;
-            launch_live_items(s, sc.d_live.p, pr.live_words, pr.pair_live, b.nq, ix->ntiles, sc.d_items.p + cap + 9u + np, sc.d_items.p, sc.d_items.p + cap, hp.sub_skip);
+            launch_live_items(s, sc.d_live.p, pr.live_words, pr.pair_live, b.nq, ix->ntiles, sc.d_items.p + cap + 9u + np, sc.d_items.p, sc.d_items.p + cap);
             hp.items = sc.d_items.p;
             hp.n_items = sc.d_items.p + cap;
         }
@@ -347,41 +339,11 @@ int enqueue_hit(rtx_index *ix, const SubBatch &b, uint32_t flags, hipStream_t s,
             kp.mode = 2u;
             kp.live = sc.d_live.p;
             kp.live_words = pr.live_words;
-            kp.sub_skip = hp.sub_skip;
             launch_kmer_extract(s, kp, b.nq);
         }
         if (b.timed) {
             RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_TILE_PRUNE, 1), s));
             RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_HIT_COUNT, 0), s));
-        }
-        if (sub_count) {  // (inside the hit_count stage) the records-path queries: (pair, B-tile) items, bounds over blocks of 64 against the threshold, the sub-tiles that can matter
-            SubCountParams sp{};
-            sp.bbitmap = ix->d_bbitmap.p;
-            sp.sbitmap = ix->d_sbitmap.p;
-            sp.n_rows1 = ix->n_rows + 1;
-            sp.ntiles = ix->ntiles;
-            sp.n_btiles = ix->n_btiles;
-            sp.zero_row = ix->n_rows;
-            sp.n_refs = ix->n_refs;
-            sp.rows = sc.d_rows.p;
-            sp.nrows = sc.d_nrows.p;
-            sp.rstride = ix->rstride;
-            sp.nq = b.nq;
-            sp.prune_thr = sc.d_prune_thr.p;
-            sp.live = sc.d_live.p;
-            sp.live_words = pr.live_words;
-            sp.hist = sc.d_hist.p;
-            sp.hstride = ix->hstride;
-            sp.tile_max = sc.d_tilemax.p;
-            sp.rec = rr;
-            sp.flags = flags;
-            sp.q0 = b.q0;
-            sp.perm = ix->d_perm.p;
-            sp.exact = hp.exact;
-            sp.group_rows = hp.group_rows;
-            sp.group_base = hp.group_base;
-            sp.stats = ix->d_prune_stats.p ? ix->d_prune_stats.p + 2 * kPruneStatCopies * 8 : nullptr;
-            launch_subcount(s, sp, b.nq, sc.d_sub_items.p + cap_sub + 9u, sc.d_sub_items.p, sc.d_sub_items.p + cap_sub, ix->planes);
         }
     }
     if (ix->pair_used) launch_hit_count_pair(s, hp, b.nq, ix->ntiles, ix->planes);
@@ -1050,7 +1012,6 @@ int alloc_scratch_set(rtx_index *ix, uint32_t k) {
             return rc;
         // (a failed allocation of the fine pass's lists only switches the pass off: enqueue_hit tolerates a null pointer)
         if (ix->d_fbitmap.p && sc.d_fine_items.alloc(((B + 1u) / 2u) * ix->f_ntiles + 9u + ix->f_ntiles)) sc.d_fine_items.release();
-        if (ix->d_sbitmap.p && ix->sub_count_opt && sc.d_sub_items.alloc(B * ix->n_btiles + 9u + ix->n_btiles)) sc.d_sub_items.release();
         if (ix->rec_opt && ix->n_refs == ix->n_total) {  // the records path; without its buffers the run takes the dense epilogues
             const size_t slots = std::min<uint32_t>(ix->rec_opt, kRecMaxSlots);
             if (sc.d_rec_nslots.alloc(B) || sc.d_rec_slots.alloc(B * kRecMaxSlots) || sc.d_rec_cnt.alloc(B * kRecMaxSlots) ||

@@ -470,22 +470,7 @@ static void build_two_level(rtx_index *ix) {
         launch_bounds2_build(ix->stream, ix->d_ubitmap.p, (uint32_t)rows1, ix->u_ntiles, ix->d_bbitmap.p, ix->d_abitmap.p);
         e = hipStreamSynchronize(ix->stream);
     }
-    if (e != hipSuccess) { (void)hipGetLastError(); ix->d_abitmap.release(); ix->d_bbitmap.release(); return; }
-    // the database bitmap in sub-tiles of 512 references (rtx_subcount.hip): as large as the bitmap itself; left out when HBM is short
-    ix->n_subtiles = (uint32_t)((ix->n_refs + 511) / 512);
-    const size_t sbytes = (size_t)ix->n_subtiles * rows1 * 64;
-    size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || sbytes > free_b / 3 || rows1 * 64u > 0xFFFFFFFFull || ix->d_sbitmap.alloc(sbytes)) {
-        (void)hipGetLastError();
-        ix->d_sbitmap.release();
-        return;
-    }
-    e = hipMemsetAsync(ix->d_sbitmap.p, 0, sbytes, ix->stream);
-    if (e == hipSuccess) {
-        launch_subtile_build(ix->stream, ix->d_bitmap.p, (uint32_t)rows1, ix->ntiles, ix->stride_bytes, ix->d_sbitmap.p);
-        e = hipStreamSynchronize(ix->stream);
-    }
-    if (e != hipSuccess) { (void)hipGetLastError(); ix->d_sbitmap.release(); }
+    if (e != hipSuccess) { (void)hipGetLastError(); ix->d_abitmap.release(); ix->d_bbitmap.release(); }
 }
 
 // Locator table of the processing order (rtx_cluster.hip) from the reference sequences already on the device.
@@ -620,7 +605,7 @@ void rtx_index_destroy(rtx_index *index) {
 uint64_t rtx_index_num_refs(const rtx_index *index) { return index ? index->n_total : 0; }
 uint64_t rtx_index_device_bytes(const rtx_index *index) {
     if (!index) return 0;
-    return index->d_seg_dbits.n * 8 + index->d_seg_sbits.n * 8 + index->d_seg_sbase.n * 4 + index->d_seginfo.n * 4 + index->d_segcls.n * 4 + index->d_segslots.n * 2 + index->d_bitmap.n * 4 + index->d_row_of.n * 4 + index->d_row_len.n * 8 + index->d_list_len.n * 4 + index->d_loc_table.n * 4 + index->d_ubitmap.n * 4 + index->d_fbitmap.n * 4 + index->d_abitmap.n * 4 + index->d_bbitmap.n + index->d_sbitmap.n + index->d_em_table.n * 8 + index->d_em_rep_off.n * 8 + index->d_em_rep_bytes.n + index->d_em_goff.n * 4 + index->d_em_gids.n * 4 + index->d_lnfact.n * 8 +
+    return index->d_seg_dbits.n * 8 + index->d_seg_sbits.n * 8 + index->d_seg_sbase.n * 4 + index->d_seginfo.n * 4 + index->d_segcls.n * 4 + index->d_segslots.n * 2 + index->d_bitmap.n * 4 + index->d_row_of.n * 4 + index->d_row_len.n * 8 + index->d_list_len.n * 4 + index->d_loc_table.n * 4 + index->d_ubitmap.n * 4 + index->d_fbitmap.n * 4 + index->d_abitmap.n * 4 + index->d_bbitmap.n + index->d_em_table.n * 8 + index->d_em_rep_off.n * 8 + index->d_em_rep_bytes.n + index->d_em_goff.n * 4 + index->d_em_gids.n * 4 + index->d_lnfact.n * 8 +
            index->d_noderec.n * 16 + index->d_bnd_bits.n + index->d_bnd_rank.n * 4;
 }
 int rtx_index_set_batch(rtx_index *index, uint32_t sub_batch) {
@@ -693,10 +678,6 @@ int rtx_index_set_option(rtx_index *index, int option, uint64_t value) {
                 index->b2_delta[2] = (uint32_t)((value >> 32) & 0xFFFFu);
                 index->b2_delta[3] = (uint32_t)((value >> 48) & 0xFFFFu);
             }
-            return RTX_OK;
-        case RTX_OPT_SUB_COUNT:
-            index->uploaded = index->ran = index->synced = false;  // shapes the workspace (its list of items)
-            index->sub_count_opt = value ? 1u : 0u;
             return RTX_OK;
         case RTX_OPT_MIN_SUB_BATCHES:
             if (value < 1 || value > 64) break;

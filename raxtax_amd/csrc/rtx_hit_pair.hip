@@ -140,16 +140,16 @@ __device__ __forceinline__ void pair_tile_block(const HitParams &p, uint32_t *ld
     if (kBounds == 2) {
         const uint32_t T0 = tile * 8u;  // (a multiple of 8: the eight bits lie in one word)
         const uint32_t *lw = p.live + (size_t)qa * p.live_words + (T0 >> 5);
-        fine_a = p.sub_skip && p.sub_skip[qa] ? 0u : (lw[0] >> (T0 & 31u)) & 0xFFu;  // (records-path queries: counted over sub-tiles, rtx_subcount.hip)
-        fine_b = has_b && !(p.sub_skip && p.sub_skip[qb]) ? (lw[p.live_words] >> (T0 & 31u)) & 0xFFu : 0u;
+        fine_a = (lw[0] >> (T0 & 31u)) & 0xFFu;
+        fine_b = has_b ? (lw[p.live_words] >> (T0 & 31u)) & 0xFFu : 0u;
         has_a = fine_a != 0u;
         has_b = fine_b != 0u;
         if (!has_a && !has_b) return;
     }
     if (!kBounds && p.live) {  // tile pruning (rtx_prune.hip): a mask per query -- the rows of a query are folded only where its tile is live
         const uint32_t *lw = p.live + (size_t)qa * p.live_words + (tile >> 5);
-        has_a = ((lw[0] >> (tile & 31u)) & 1u) && !(p.sub_skip && p.sub_skip[qa]);  // (records-path queries: counted over sub-tiles, rtx_subcount.hip)
-        has_b = has_b && ((lw[p.live_words] >> (tile & 31u)) & 1u) && !(p.sub_skip && p.sub_skip[qb]);
+        has_a = (lw[0] >> (tile & 31u)) & 1u;
+        has_b = has_b && ((lw[p.live_words] >> (tile & 31u)) & 1u);
         if (!has_a && !has_b) return;  // nothing in this tile can matter to either query
     }
     uint32_t *l_both = lds_dw, *l_a = lds_dw + kPairListDw, *l_b = lds_dw + 2u * kPairListDw;
@@ -390,7 +390,7 @@ __global__ __launch_bounds__(1024) void live_offsets_kernel(const uint32_t *__re
 // all tiles of 57 pairs: 0.64 M queries/s at 10 % divergence where the two-dimensional grid, tile-major by construction, gave 1.36 M.)
 // The order of the pairs inside a (group, tile) run is whatever the LDS atomics make it: it decides nothing but scheduling.
 __global__ __launch_bounds__(1024) void live_items_kernel(const uint32_t *__restrict__ live, uint32_t live_words, uint32_t nq, uint32_t ntiles,
-                                                          const uint32_t *__restrict__ off, uint32_t *__restrict__ items, const uint16_t *__restrict__ sub_skip) {
+                                                          const uint32_t *__restrict__ off, uint32_t *__restrict__ items) {
     extern __shared__ uint32_t tl[];  // [ntiles] entries of the group in the tile -> where they start -> cursor
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t np = (nq + 1u) / 2u, g0 = blockIdx.x * 1024u, pair = g0 + tid;
@@ -399,11 +399,10 @@ __global__ __launch_bounds__(1024) void live_items_kernel(const uint32_t *__rest
     const uint32_t nw = (ntiles + 31u) >> 5;
     const bool valid = pair < np;
     const uint32_t *wa = live + (size_t)((valid ? pair : 0u) * 2u) * live_words;
-    const bool hb = valid && pair * 2u + 1u < nq && !(sub_skip && sub_skip[pair * 2u + 1u]);  // the mask of a missing second query was never written
-    const bool ha = valid && !(sub_skip && sub_skip[pair * 2u]);  // (a query with record slots is counted over sub-tiles: none of its tiles is a block here)
+    const bool hb = valid && pair * 2u + 1u < nq;  // the mask of a missing second query was never written
     if (valid)
         for (uint32_t w = 0; w < nw; w++) {
-            uint32_t bits = (ha ? wa[w] : 0u) | (hb ? wa[live_words + w] : 0u);
+            uint32_t bits = wa[w] | (hb ? wa[live_words + w] : 0u);
             while (bits) {
                 atomicAdd(&tl[w * 32u + (uint32_t)__builtin_ctz(bits)], 1u);
                 bits &= bits - 1u;
@@ -423,7 +422,7 @@ __global__ __launch_bounds__(1024) void live_items_kernel(const uint32_t *__rest
     if (!valid) return;
     const uint32_t base = off[g0];  // entries in front of the group
     for (uint32_t w = 0; w < nw; w++) {
-        uint32_t bits = (ha ? wa[w] : 0u) | (hb ? wa[live_words + w] : 0u);
+        uint32_t bits = wa[w] | (hb ? wa[live_words + w] : 0u);
         while (bits) {
             const uint32_t tile = w * 32u + (uint32_t)__builtin_ctz(bits);
             bits &= bits - 1u;
@@ -464,10 +463,10 @@ void launch_hit_count_pair(hipStream_t s, const HitParams &p, uint32_t nq, uint3
 }
 
 void launch_live_items(hipStream_t s, const uint32_t *live, uint32_t live_words, const uint32_t *pair_live, uint32_t nq, uint32_t ntiles, uint32_t *off,
-                       uint32_t *items, uint32_t *n_items, const uint16_t *sub_skip) {
+                       uint32_t *items, uint32_t *n_items) {
     const uint32_t np = (nq + 1u) / 2u;
     hipLaunchKernelGGL(live_offsets_kernel, dim3(1), dim3(1024), 0, s, pair_live, np, off, n_items);
-    hipLaunchKernelGGL(live_items_kernel, dim3((np + 1023u) / 1024u), dim3(1024), (size_t)ntiles * 4, s, live, live_words, nq, ntiles, off, items, sub_skip);
+    hipLaunchKernelGGL(live_items_kernel, dim3((np + 1023u) / 1024u), dim3(1024), (size_t)ntiles * 4, s, live, live_words, nq, ntiles, off, items);
 }
 
 void launch_hit_count_pair_bounds(hipStream_t s, const HitParams &p, uint32_t nq, uint32_t u_ntiles, int planes) {
@@ -481,21 +480,21 @@ void launch_hit_count_pair_bounds(hipStream_t s, const HitParams &p, uint32_t nq
 // grouped by fine tile -- the workgroups that run together then read one region of the fine bitmap: fine_count (entries per fine
 // tile), fine_scan (one thread: offsets, the header of the list), fine_scatter.
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t fine_pair_mask(const uint32_t *live, uint32_t live_words, uint32_t pair, uint32_t nq, uint32_t U, const uint16_t *skip) {
+__device__ __forceinline__ uint32_t fine_pair_mask(const uint32_t *live, uint32_t live_words, uint32_t pair, uint32_t nq, uint32_t U) {
     const uint32_t T0 = U * 8u;
     const uint32_t *wa = live + (size_t)(pair * 2u) * live_words + (T0 >> 5);
-    uint32_t m = skip && skip[pair * 2u] ? 0u : (wa[0] >> (T0 & 31u)) & 0xFFu;  // (skip: records-path queries, counted over sub-tiles)
-    if (pair * 2u + 1u < nq && !(skip && skip[pair * 2u + 1u])) m |= (wa[live_words] >> (T0 & 31u)) & 0xFFu;
+    uint32_t m = (wa[0] >> (T0 & 31u)) & 0xFFu;
+    if (pair * 2u + 1u < nq) m |= (wa[live_words] >> (T0 & 31u)) & 0xFFu;
     return m;
 }
 __global__ __launch_bounds__(256) void fine_count_kernel(const uint32_t *__restrict__ live, uint32_t live_words, const uint32_t *__restrict__ pair_live,
-                                                         uint32_t nq, uint32_t f_ntiles, uint32_t *__restrict__ cnt, const uint16_t *__restrict__ skip) {
+                                                         uint32_t nq, uint32_t f_ntiles, uint32_t *__restrict__ cnt) {
     // one atomic per wave and fine tile (the lanes that hold an item are counted with a ballot): at 10 % divergence every pair qualifies, and
     // 32 768 atomics of a launch on each of eight addresses took 0.4 ms
     const uint32_t pair = blockIdx.x * 256u + threadIdx.x, np = (nq + 1u) / 2u, lane = threadIdx.x & 63u;
     const bool on = pair < np && pair_live[pair < np ? pair : 0u] >= kFineMinLive;
     for (uint32_t U = 0; U < f_ntiles; U++) {
-        const unsigned long long b = __ballot(on && fine_pair_mask(live, live_words, pair, nq, U, skip) != 0u);
+        const unsigned long long b = __ballot(on && fine_pair_mask(live, live_words, pair, nq, U) != 0u);
         if (b && lane == (uint32_t)__builtin_ctzll(b)) atomicAdd(&cnt[U], (uint32_t)__popcll(b));
     }
 }
@@ -510,11 +509,11 @@ __global__ void fine_scan_kernel(uint32_t *__restrict__ cnt, uint32_t f_ntiles, 
     for (uint32_t x = 1; x <= 8u; x++) n_items[x] = 0;  // the queues of the XCDs
 }
 __global__ __launch_bounds__(256) void fine_scatter_kernel(const uint32_t *__restrict__ live, uint32_t live_words, const uint32_t *__restrict__ pair_live,
-                                                           uint32_t nq, uint32_t f_ntiles, uint32_t *__restrict__ cursor, uint32_t *__restrict__ items, const uint16_t *__restrict__ skip) {
+                                                           uint32_t nq, uint32_t f_ntiles, uint32_t *__restrict__ cursor, uint32_t *__restrict__ items) {
     const uint32_t pair = blockIdx.x * 256u + threadIdx.x, np = (nq + 1u) / 2u, lane = threadIdx.x & 63u;
     const bool on = pair < np && pair_live[pair < np ? pair : 0u] >= kFineMinLive;
     for (uint32_t U = 0; U < f_ntiles; U++) {  // (as fine_count_kernel: a wave takes its entries of a fine tile with one atomic)
-        const bool has = on && fine_pair_mask(live, live_words, pair, nq, U, skip) != 0u;
+        const bool has = on && fine_pair_mask(live, live_words, pair, nq, U) != 0u;
         const unsigned long long b = __ballot(has);
         if (b == 0ull) continue;  // wave-uniform
         const int leader = __builtin_ctzll(b);
@@ -526,19 +525,14 @@ __global__ __launch_bounds__(256) void fine_scatter_kernel(const uint32_t *__res
 }
 // live tiles per pair again, from the masks as the fine pass left them (live_offsets_kernel sizes the list of the counting pass with them)
 __global__ __launch_bounds__(256) void pair_live_recount_kernel(const uint32_t *__restrict__ live, uint32_t live_words, uint32_t nq, uint32_t ntiles,
-                                                                uint32_t *__restrict__ pair_live, unsigned long long *__restrict__ stats, const uint16_t *__restrict__ skip) {
+                                                                uint32_t *__restrict__ pair_live, unsigned long long *__restrict__ stats) {
     const uint32_t pair = blockIdx.x * 256u + threadIdx.x, np = (nq + 1u) / 2u;
     uint32_t n = 0;
     if (pair < np) {
         const uint32_t *wa = live + (size_t)(pair * 2u) * live_words;
-        const bool ha = !(skip && skip[pair * 2u]), hb = pair * 2u + 1u < nq && !(skip && skip[pair * 2u + 1u]);
-        uint32_t n_all = 0;  // reporting counts every (pair, tile) with a live query, whichever kernel counts it
-        for (uint32_t w = 0; w < (ntiles + 31u) >> 5; w++) {
-            n += (uint32_t)__popc((ha ? wa[w] : 0u) | (hb ? wa[live_words + w] : 0u));
-            n_all += (uint32_t)__popc(wa[w] | (pair * 2u + 1u < nq ? wa[live_words + w] : 0u));
-        }
+        const bool hb = pair * 2u + 1u < nq;
+        for (uint32_t w = 0; w < (ntiles + 31u) >> 5; w++) n += (uint32_t)__popc(wa[w] | (hb ? wa[live_words + w] : 0u));
         pair_live[pair] = n;
-        n = n_all;
     }
     if (stats) {  // reporting: the (pair, tile) blocks the counting pass is left with
         n = wave_incl_scan_u32(n);
@@ -551,9 +545,9 @@ void launch_fine_bounds(hipStream_t s, const HitParams &p, uint32_t nq, uint32_t
                         uint32_t *items, uint32_t *n_items, int planes) {
     const uint32_t np = (nq + 1u) / 2u, nb = (np + 255u) / 256u;
     (void)hipMemsetAsync(cnt, 0, (size_t)f_ntiles * 4, s);
-    hipLaunchKernelGGL(fine_count_kernel, dim3(nb), dim3(256), 0, s, p.live, p.live_words, pair_live, nq, f_ntiles, cnt, p.sub_skip);
+    hipLaunchKernelGGL(fine_count_kernel, dim3(nb), dim3(256), 0, s, p.live, p.live_words, pair_live, nq, f_ntiles, cnt);
     hipLaunchKernelGGL(fine_scan_kernel, dim3(1), dim3(1), 0, s, cnt, f_ntiles, n_items);
-    hipLaunchKernelGGL(fine_scatter_kernel, dim3(nb), dim3(256), 0, s, p.live, p.live_words, pair_live, nq, f_ntiles, cnt, items, p.sub_skip);
+    hipLaunchKernelGGL(fine_scatter_kernel, dim3(nb), dim3(256), 0, s, p.live, p.live_words, pair_live, nq, f_ntiles, cnt, items);
     HitParams fp = p;
     fp.items = items;
     fp.n_items = n_items;
@@ -561,7 +555,7 @@ void launch_fine_bounds(hipStream_t s, const HitParams &p, uint32_t nq, uint32_t
     const dim3 grid((uint32_t)((std::min<uint64_t>((uint64_t)np * f_ntiles, std::max<uint64_t>((uint64_t)RTX_ITEM_GRID_HALVES * np / 2u, 2048ull)) + 7u) & ~7ull));
     if (planes <= 8) hipLaunchKernelGGL((hit_count_pair_kernel<8, true, 2, true>), grid, dim3(64), kPairLdsBytes, s, fp);
     else hipLaunchKernelGGL((hit_count_pair_kernel<10, true, 2, true>), grid, dim3(64), kPairLdsBytes, s, fp);
-    hipLaunchKernelGGL(pair_live_recount_kernel, dim3(nb), dim3(256), 0, s, p.live, p.live_words, nq, ntiles, pair_live, p.fine_stats, p.sub_skip);
+    hipLaunchKernelGGL(pair_live_recount_kernel, dim3(nb), dim3(256), 0, s, p.live, p.live_words, nq, ntiles, pair_live, p.fine_stats);
 }
 
 }  // namespace rtx

@@ -185,11 +185,6 @@ struct rtx_index {
     uint32_t n_atiles = 0, n_btiles = 0;
     uint32_t two_level_opt = 1;  // RTX_OPT_TWO_LEVEL_BOUNDS
     uint32_t b2_delta[4] = {275u, 205u, 84u, 128u};  // which B-tiles are refined: c_t, c_m, lo, hi in 1/256 (Bounds2Params)
-    // the records path counted over sub-tiles of 512 references (rtx_subcount.hip): the database bitmap once more, [sub-tile][row][64 bytes]
-    DevBuf<uint8_t> d_sbitmap;
-    uint32_t n_subtiles = 0;
-    uint32_t sub_count_opt = 1;  // RTX_OPT_SUB_COUNT
-    bool sub_count_used = false; // the last run counted its records-path queries over sub-tiles
     bool two_level_used = false;  // the last run's bounds pass was bounds2_kernel (its work accounting counts load instructions of 1 KiB)
     uint32_t rec_opt = 4;   // RTX_OPT_RECORDS: pruned queries with at most this many live tiles take the records path (0: off; at most kRecMaxSlots)
     uint32_t overlap_opt = 1;  // RTX_OPT_OVERLAP: 1 = back half of sub-batch k on a second stream beside the front half of k + 1 (2: three stages)
@@ -283,7 +278,6 @@ struct rtx_index {
         DevBuf<uint32_t> d_items;  // [pairs x tiles] the (pair, tile) blocks with a live query | [1] their number | [8] queue per XCD | [pairs] live tiles per pair | [pairs] offsets
         DevBuf<uint16_t> d_tile_ub, d_prune_thr, d_prune_i1;
         DevBuf<uint32_t> d_best;  // [B][kPruneBestWords] reference shards: the candidate for the best block of the database
-        DevBuf<uint32_t> d_sub_items;   // counting over sub-tiles: [pairs x n_btiles] items | [9] number + XCD queues | [n_btiles] cursors
         DevBuf<uint32_t> d_fine_items;  // fine bounds pass: [pairs x f_ntiles] items | [9] number + XCD queues | [f_ntiles] cursors
         // the records path (RecordRef, rtx_kernels.hpp): per query the live tiles at prune time, the records of each, their number
         DevBuf<uint16_t> d_rec_nslots, d_rec_slots;
@@ -292,7 +286,7 @@ struct rtx_index {
             d_kmers.release(); d_counts.release(); d_tilemax.release(); d_rows.release(); d_t.release(); d_nrows.release(); d_hist.release();
             d_order.release(); d_srows.release(); d_nsparse.release(); d_dmask.release(); d_table_z.release(); d_prefix.release(); d_urec.release();
             d_nu.release(); d_live.release(); d_best_key.release(); d_items.release(); d_tile_ub.release(); d_prune_thr.release(); d_prune_i1.release();
-            d_best.release(); d_fine_items.release(); d_sub_items.release(); d_rec_nslots.release(); d_rec_slots.release(); d_rec_cnt.release(); d_rec.release();
+            d_best.release(); d_fine_items.release(); d_rec_nslots.release(); d_rec_slots.release(); d_rec_cnt.release(); d_rec.release();
         }
     } sc[4];  // 0 .. 2: the sets that alternate (RTX_OPT_OVERLAP, rtx_shard_*); 3: the set of the side classes (a few long reads among barcodes)
     bool staged = false;  // driven with rtx_shard_*: sub-batch sb works in scratch set sb & 1, so that the exchange of one

@@ -160,7 +160,6 @@ __global__ __launch_bounds__(64) void kmer_extract_kernel(KmerParams p) {
     uint32_t *rout = p.rows + (size_t)q * p.rstride;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     if (mode == 2u) {
-        if (p.sub_skip && p.sub_skip[q]) return;  // counted over sub-tiles (rtx_subcount.hip): no per-tile lists (one wave per workgroup: no barrier is left behind)
         nrows = p.nrows[q];
     } else {
     for (uint32_t i = lane; i < 2048; i += 64) bm[i] = 0;

@@ -110,7 +110,6 @@ struct KmerParams {
     uint32_t mode;           // 0: everything; 1: k-mers and row list; 2: the per-tile lists of the live tiles (after a launch with 1)
     const uint32_t *live;    // mode 2: [B][live_words] a mask per query (rtx_prune.hip)
     uint32_t live_words;
-    const uint16_t *sub_skip;  // mode 2: [B] queries with slots are counted over sub-tiles (rtx_subcount.hip) and need no lists; or null
 };
 
 // The RECORDS path (round 5).  A pruned query (threshold u) only ever needs its references with a count ABOVE u: everything else is
@@ -181,7 +180,6 @@ struct HitParams {
     uint32_t fine_ref_ntiles;     // tiles of the database
     unsigned long long *fine_stats;  // [kPruneStatCopies][8]: [0] += (query, tile) combinations cleared, [1] += blocks of the fine pass, or null
     RecordRef rec;                // the records path of pruned queries (above); rec.nslots == null: every epilogue is the dense one
-    const uint16_t *sub_skip;     // [B] RecordRef::nslots when subcount_kernel (rtx_subcount.hip) counts the records-path queries: a query with slots is left out here; or null
 };
 // the bounds pass in two levels (rtx_bounds2.hip): level A over blocks of 256 references for every tile, level B over blocks of 64 for the
 // B-tiles (4 tiles of the database) near the query's largest level-A bound; one wave per pair, no atomics
@@ -202,34 +200,6 @@ struct Bounds2Params {
 };
 void launch_bounds2(hipStream_t s, const Bounds2Params &p, uint32_t nq, int planes);
 void launch_bounds2_build(hipStream_t s, const uint32_t *ubitmap, uint32_t n_rows1, uint32_t u_ntiles, uint8_t *bbitmap, uint32_t *abitmap);
-// the counting pass of the records path over sub-tiles of 512 references (rtx_subcount.hip)
-struct SubCountParams {
-    const uint8_t *bbitmap;    // union bitmap over blocks of 64 in B-tiles (Bounds2Params::bbitmap)
-    const uint8_t *sbitmap;    // the database in sub-tiles: [ceil(n_refs / 512)][n_rows1][64 bytes], bit j of a row = reference 512 sub + j
-    uint32_t n_rows1, ntiles, n_btiles, zero_row;
-    uint64_t n_refs;
-    const uint32_t *rows;      // [B][rstride] the rows of the query's k-mers (kmer_extract: padded with the zero row to a multiple of 64)
-    const uint32_t *nrows;     // [B]
-    uint32_t rstride, nq;
-    const uint16_t *prune_thr; // [B]
-    uint32_t *live;            // [B][live_words]: read (the live tiles of the records-path queries), bits cleared where a tile holds nothing above the threshold
-    uint32_t live_words;
-    uint32_t *hist;            // [B][hstride]
-    uint32_t hstride;
-    uint16_t *tile_max;        // [B][ntiles] or null
-    RecordRef rec;
-    const uint32_t *items;     // (query * n_btiles + B-tile), grouped by B-tile (launch_subcount builds the list)
-    uint32_t *n_items;         // [9]: number of items, queues of the XCDs
-    uint32_t flags;
-    uint64_t q0;
-    const uint32_t *perm;
-    ExactRef exact;
-    uint32_t *group_rows;      // work accounting: load instructions (1 KiB each) per pair, or null
-    uint32_t group_base;
-    unsigned long long *stats; // [kPruneStatCopies][8] (the fine pass's block): [4] += (pair, B-tile) items; or null
-};
-void launch_subcount(hipStream_t s, const SubCountParams &p, uint32_t nq, uint32_t *cnt, uint32_t *items, uint32_t *n_items, int planes);
-void launch_subtile_build(hipStream_t s, const uint32_t *bitmap, uint32_t n_rows1, uint32_t ntiles, uint32_t stride_bytes, uint8_t *sbitmap);
 constexpr uint32_t kFineShift = 3;       // blocks of 8 references: the 8 references of one byte of a bitmap row (ref_slot)
 constexpr uint32_t kFineMinLive = 4;     // pairs with fewer live tiles than this skip the fine pass (a block of it costs what it can save there)
 constexpr uint32_t kFineMinTiles = 16;   // databases with fewer tiles have no fine union bitmap
@@ -279,7 +249,6 @@ struct PruneParams {
                                 // bound, t, 0, 0, exact counts of the 64 references of the best block}
     RecordRef rec;              // rec.nslots != null: queries with a threshold and at most rec_max_slots live tiles take the records path
     uint32_t rec_max_slots;
-    uint32_t sub_path;          // the records-path queries are counted by subcount_kernel: pair_live counts the tiles of the other queries only
 };
 constexpr uint32_t kPruneDetailWords = 72;
 struct ProbTables;
@@ -400,7 +369,7 @@ void launch_pair_union(hipStream_t s, const uint32_t *rows, const uint32_t *nrow
 void launch_hit_count_pair(hipStream_t s, const HitParams &p, uint32_t nq, uint32_t ntiles, int planes);  // 8 (every t <= 255) or 10 bit planes
 // the list of the live (pair, tile) blocks from the masks and the per-pair numbers prune_kernel left: off = [pairs] scratch
 void launch_live_items(hipStream_t s, const uint32_t *live, uint32_t live_words, const uint32_t *pair_live, uint32_t nq, uint32_t ntiles, uint32_t *off,
-                       uint32_t *items, uint32_t *n_items, const uint16_t *sub_skip = nullptr);
+                       uint32_t *items, uint32_t *n_items);
 void launch_hit_count_pair_bounds(hipStream_t s, const HitParams &p, uint32_t nq, uint32_t u_ntiles, int planes);
 // the fine bounds pass over the pairs with many live tiles (p: the fine union bitmap, live masks, thresholds, histogram); updates pair_live
 void launch_fine_bounds(hipStream_t s, const HitParams &p, uint32_t nq, uint32_t ntiles, uint32_t f_ntiles, uint32_t *pair_live, uint32_t *cnt,

@@ -447,24 +447,9 @@ __global__ __launch_bounds__(64 * kPruneWavesPerBlock, RTX_PRUNE_WAVES) void pru
         n_live += (uint32_t)__popcll(ba | bb2);
         n_qlive += (uint32_t)__popcll(ba) + (uint32_t)__popcll(bb2);
     }
-    const uint32_t n_live_all = n_live;
     if (p.rec.nslots) {  // a query with a threshold and few live tiles: hit_count writes records, records_tail_kernel reads them
         const uint32_t cap = p.rec_max_slots < kRecMaxSlots ? p.rec_max_slots : kRecMaxSlots;
         const bool ra = thr[0] != 0u && n_rec[0] != 0u && n_rec[0] <= cap, rb = has_b && thr[1] != 0u && n_rec[1] != 0u && n_rec[1] <= cap;
-        if (p.sub_path && (ra || rb)) {
-            // the records-path queries are counted over sub-tiles (rtx_subcount.hip): the list of (pair, tile) blocks of hit_count_pair_kernel
-            // and the fine bounds pass see the tiles of the other query only
-            n_live = 0;
-            for (uint32_t T0 = 0; T0 < p.ntiles; T0 += 64) {
-                const uint32_t T = T0 + lane;
-                bool la = false, lb = false;
-                if (T < p.ntiles) {
-                    la = !ra && (thr[0] == 0u || (uint32_t)ub_lds[T] > thr[0]);
-                    lb = has_b && !rb && (thr[1] == 0u || (uint32_t)ub_lds[p.ntiles + T] > thr[1]);
-                }
-                n_live += (uint32_t)__popcll(__ballot(la || lb));
-            }
-        }
         if (lane < kRecMaxSlots) {
             p.rec.cnt[(size_t)(pair * 2u) * kRecMaxSlots + lane] = 0u;
             if (has_b) p.rec.cnt[(size_t)(pair * 2u + 1u) * kRecMaxSlots + lane] = 0u;
@@ -481,7 +466,6 @@ __global__ __launch_bounds__(64 * kPruneWavesPerBlock, RTX_PRUNE_WAVES) void pru
         if (has_b) p.hist[(size_t)(pair * 2u + 1u) * p.hstride] = (uint32_t)dead_refs[1];
     }
     if (lane == 0 && p.pair_live) p.pair_live[pair] = n_live;
-    n_live = n_live_all;  // reporting: every (pair, tile) with a live query, whichever kernel counts it
     st[7] = n_qlive;  // (query, tile) combinations that are counted
     if (p.stats) {  // one atomic instruction per wave (lane k adds counter k), 64 copies of the counters in lines of their own:
                     // thousands of waves adding to ONE address queue up in L2 for longer than everything else here takes

@@ -2,6 +2,10 @@
 // stream: order -> kmer_extract -> [pair_union] -> [bounds -> prune -> lists of the live tiles] -> hit_count -> prob -> taxon_prefix + walk.
 #include "rtx_index.hpp"
 
+#ifndef RTX_B2_HEAVY_PER_ATILE
+#define RTX_B2_HEAVY_PER_ATILE 3u  // two-level bounds pass: a query whose rule asks for more B-tiles per A-tile (of 16) than this goes to the one-level pass (2 / 3 / 4 / 8: 79.4 / 78.7 / 78.8 / 79.4 ms per step at configs[2], 6.03 / 5.84 / 5.84 / 5.49 M queries/s at 5 % divergence)
+#endif
+
 namespace rtxi {
 
 int bind(rtx_index *ix) {
@@ -243,7 +247,11 @@ int enqueue_hit(rtx_index *ix, const SubBatch &b, uint32_t flags, hipStream_t s,
                 bp.delta_hi = ix->b2_delta[3];
                 bp.group_rows = up.group_rows;
                 bp.group_base = up.group_base;
-                launch_bounds2(s, bp, b.nq, ix->planes);
+                // queries whose rule asks for more than five B-tiles per A-tile go to the one-level pass (5 folds of level B ~ half of it)
+                const bool heavy_ok = sc.d_heavy.p && sc.d_heavy_items.p && sc.d_heavy_items.n >= (size_t)((b.nq + 1u) / 2u) * ix->u_ntiles + 9u;
+                bp.heavy = heavy_ok ? sc.d_heavy.p : nullptr;
+                bp.heavy_max = std::max<uint32_t>(1u, std::min<uint32_t>(RTX_B2_HEAVY_PER_ATILE * ix->n_atiles, ix->n_btiles / 2u));
+                launch_bounds2(s, bp, b.nq, ix->planes, up, ix->u_ntiles, heavy_ok ? sc.d_heavy_items.p : nullptr);
             } else {
                 RTX_HIP(hipMemsetAsync(sc.d_best_key.p, 0, (size_t)b.nq * 4, s));  // the waves of a query's union tiles meet in an atomicMax
                 launch_hit_count_pair_bounds(s, up, b.nq, ix->u_ntiles, ix->planes);  // the union of the pair's rows serves both passes
@@ -1010,6 +1018,7 @@ int alloc_scratch_set(rtx_index *ix, uint32_t k) {
         if ((rc = sc.d_tile_ub.alloc(B * ix->ntiles)) || (rc = sc.d_best_key.alloc(B)) || (rc = sc.d_prune_thr.alloc(B)) || (rc = sc.d_prune_i1.alloc(B)) || (rc = sc.d_best.alloc(B * kPruneBestWords)) || (rc = sc.d_live.alloc((B + 1u) * ((ix->ntiles + 31u) / 32u + 1u))) ||
             (rc = sc.d_items.alloc(((B + 1u) / 2u) * (ix->ntiles + 2u) + 9u)))
             return rc;
+        if (ix->d_abitmap.p && (sc.d_heavy.alloc(B + 1u) || sc.d_heavy_items.alloc(((B + 1u) / 2u) * ix->u_ntiles + 9u))) { sc.d_heavy.release(); sc.d_heavy_items.release(); }
         // (a failed allocation of the fine pass's lists only switches the pass off: enqueue_hit tolerates a null pointer)
         if (ix->d_fbitmap.p && sc.d_fine_items.alloc(((B + 1u) / 2u) * ix->f_ntiles + 9u + ix->f_ntiles)) sc.d_fine_items.release();
         if (ix->rec_opt && ix->n_refs == ix->n_total) {  // the records path; without its buffers the run takes the dense epilogues

@@ -250,17 +250,43 @@ __global__ __launch_bounds__(64, 2) void bounds2_kernel(Bounds2Params p) {
 
     // ---- level B: the B-tiles (4 tiles of the database: the four words of sub-lane s at level A) near the largest bound
     const uint32_t sub4 = lane & 3u, grp16 = lane >> 2;
-    for (uint32_t at = 0; at < p.n_atiles; at++) {
+    // the B-tiles of A-tile `at` the rule of either query asks for (wave-uniform masks: bit s <-> B-tile at * 16 + s)
+    auto wanted = [&](uint32_t at, uint32_t &mask_a, uint32_t &mask_b) {
         uint32_t ma = l_keep[at * 128u + lane], mb = l_keep[at * 128u + 64u + lane];
         // the largest bound of the B-tile of sub-lane s = lane & 15: over the four DPP rows
         ma = umax(ma, (uint32_t)__shfl_xor((int)ma, 16, 64));
         ma = umax(ma, (uint32_t)__shfl_xor((int)ma, 32, 64));
         mb = umax(mb, (uint32_t)__shfl_xor((int)mb, 16, 64));
         mb = umax(mb, (uint32_t)__shfl_xor((int)mb, 32, 64));
+        mask_a = (uint32_t)(__ballot(ma + dl_a > max_a && ma != 0u && lane < 16u) & 0xFFFFull);
+        mask_b = has_b ? (uint32_t)(__ballot(mb + dl_b > max_b && mb != 0u && lane < 16u) & 0xFFFFull) : 0u;
+    };
+    // A query far from its best hit has EVERY tile near its largest bound: sixteen folds of level B per A-tile would cost twice the one-level
+    // pass.  Such a query ("heavy": more than heavy_max B-tiles; its own rule alone decides -- a result stays a function of the query) keeps
+    // level A's bounds here and is handed to the one-level pass over blocks of 64 (launch_bounds2), which overwrites them.
+    bool heavy_a = false, heavy_b = false;
+    if (p.heavy) {
+        uint32_t na = 0, nb = 0;
+        for (uint32_t at = 0; at < p.n_atiles; at++) {
+            uint32_t mask_a, mask_b;
+            wanted(at, mask_a, mask_b);
+            na += (uint32_t)__popc(mask_a);
+            nb += (uint32_t)__popc(mask_b);
+        }
+        heavy_a = na > p.heavy_max;
+        heavy_b = nb > p.heavy_max;
+        if (lane == 0u) {
+            p.heavy[qa] = heavy_a ? 1u : 0u;
+            if (has_b) p.heavy[qb] = heavy_b ? 1u : 0u;
+        }
+    }
+    for (uint32_t at = 0; at < p.n_atiles; at++) {
         // What a query is left with is a function of the query alone (a result never depends on the rest of the batch): the fold of a
         // B-tile serves both queries of the pair, but each takes the bounds of level B only where ITS OWN rule asked for them.
-        const uint32_t mask_a = (uint32_t)(__ballot(ma + dl_a > max_a && ma != 0u && lane < 16u) & 0xFFFFull);  // wave-uniform: bit s <-> B-tile at * 16 + s
-        const uint32_t mask_b = has_b ? (uint32_t)(__ballot(mb + dl_b > max_b && mb != 0u && lane < 16u) & 0xFFFFull) : 0u;
+        uint32_t mask_a, mask_b;
+        wanted(at, mask_a, mask_b);
+        mask_a = heavy_a ? 0u : mask_a;
+        mask_b = heavy_b ? 0u : mask_b;
         uint32_t todo = mask_a | mask_b;
         while (todo) {
             const uint32_t s = (uint32_t)__builtin_ctz(todo);
@@ -302,17 +328,81 @@ __global__ __launch_bounds__(64, 2) void bounds2_kernel(Bounds2Params p) {
         }
     }
     if (lane == 0u) {
-        p.best_key[qa] = best_a;
-        if (has_b) p.best_key[qb] = best_b;
+        p.best_key[qa] = heavy_a ? 0u : best_a;  // (a heavy query: the one-level pass meets in an atomicMax on it)
+        if (has_b) p.best_key[qb] = heavy_b ? 0u : best_b;
         if (p.group_rows) atomicAdd(&p.group_rows[p.group_base + pair], n_instr);
     }
 }
 
-void launch_bounds2(hipStream_t s, const Bounds2Params &p, uint32_t nq, int planes) {
+// The (pair, union tile) items of the one-level pass for the pairs with a heavy query, in pair order.  One workgroup; a thread takes 32
+// neighbouring pairs (64 flag bytes in four loads), so that a sub-batch of 65 536 queries is ONE pass: a scan per 1024 pairs was a chain
+// of 31 dependent round trips, 0.1 ms per sub-batch on a launch that finds nothing on the bench workload.
+__global__ __launch_bounds__(1024) void heavy_items_kernel(const uint8_t *__restrict__ heavy, uint32_t nq, uint32_t u_ntiles, uint32_t *__restrict__ items,
+                                                           uint32_t *__restrict__ n_items) {
+    __shared__ uint32_t wsum[2][16];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, np = (nq + 1u) / 2u;
+    constexpr uint32_t kPer = 32;
+    uint32_t carry = 0, buf = 0;
+    for (uint32_t base = 0; base < np; base += 1024u * kPer, buf ^= 1u) {
+        const uint32_t p0 = base + tid * kPer;
+        uint32_t bits = 0;  // bit j: pair p0 + j has a heavy query
+        if (p0 < np) {
+            if (p0 + kPer <= np && 2u * (p0 + kPer) <= nq) {  // 64 flags of 32 whole pairs (the scratch is 16-byte aligned, p0 a multiple of 32)
+                const uint4 *f = reinterpret_cast<const uint4 *>(heavy + (size_t)p0 * 2u);
+                const uint4 v[4] = {f[0], f[1], f[2], f[3]};
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const uint32_t w[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {  // a word = four flags = two pairs
+                        if (w[j] & 0x0000FFFFu) bits |= 1u << (k * 8 + j * 2);
+                        if (w[j] & 0xFFFF0000u) bits |= 1u << (k * 8 + j * 2 + 1);
+                    }
+                }
+            } else {
+                for (uint32_t j = 0; j < kPer && p0 + j < np; j++) {
+                    const uint32_t pr = p0 + j;
+                    if (heavy[pr * 2u] || (pr * 2u + 1u < nq && heavy[pr * 2u + 1u])) bits |= 1u << j;
+                }
+            }
+        }
+        const uint32_t cnt = (uint32_t)__popc(bits);
+        const uint32_t incl = wave_incl_scan_u32(cnt);
+        if (lane == 63u) wsum[buf][wave] = incl;
+        __syncthreads();
+        uint32_t o = carry + incl - cnt, tot = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < 16u; w++) {
+            const uint32_t sw = wsum[buf][w];
+            o += w < wave ? sw : 0u;
+            tot += sw;
+        }
+        while (bits) {
+            const uint32_t j = (uint32_t)__builtin_ctz(bits);
+            bits &= bits - 1u;
+            for (uint32_t ut = 0; ut < u_ntiles; ut++) items[(size_t)o * u_ntiles + ut] = (p0 + j) * u_ntiles + ut;
+            o++;
+        }
+        carry += tot;
+    }
+    if (tid == 0u) n_items[0] = carry * u_ntiles;
+    if (tid >= 1u && tid <= 8u) n_items[tid] = 0;  // the queues of the XCDs (hit_count_pair_kernel)
+}
+
+void launch_bounds2(hipStream_t s, const Bounds2Params &p, uint32_t nq, int planes, const HitParams &hp, uint32_t u_ntiles, uint32_t *items) {
     const uint32_t np = (nq + 1u) / 2u;
     const size_t lds = (size_t)kB2LdsDw * 4u + (size_t)p.n_atiles * 256u;
     if (planes <= 8) hipLaunchKernelGGL((bounds2_kernel<8>), dim3(np), dim3(64), lds, s, p);
     else hipLaunchKernelGGL((bounds2_kernel<10>), dim3(np), dim3(64), lds, s, p);
+    if (!p.heavy || !items) return;
+    // the heavy queries: the one-level pass over the union bitmap of blocks of 64 (on the bench workload an all but empty launch)
+    uint32_t *n_items = items + (size_t)np * u_ntiles;
+    hipLaunchKernelGGL(heavy_items_kernel, dim3(1), dim3(1024), 0, s, p.heavy, nq, u_ntiles, items, n_items);
+    HitParams up = hp;
+    up.items = items;
+    up.n_items = n_items;
+    up.bounds_heavy = p.heavy;
+    launch_hit_count_pair_bounds_items(s, up, nq, u_ntiles, planes);
 }
 
 // ---------------------------------------------------------------------------

@@ -146,6 +146,11 @@ __device__ __forceinline__ void pair_tile_block(const HitParams &p, uint32_t *ld
         has_b = fine_b != 0u;
         if (!has_a && !has_b) return;
     }
+    if (kBounds == 1 && p.bounds_heavy) {  // behind the two-level bounds pass: only the queries it left to this one
+        has_a = p.bounds_heavy[qa] != 0u;
+        has_b = has_b && p.bounds_heavy[qb] != 0u;
+        if (!has_a && !has_b) return;
+    }
     if (!kBounds && p.live) {  // tile pruning (rtx_prune.hip): a mask per query -- the rows of a query are folded only where its tile is live
         const uint32_t *lw = p.live + (size_t)qa * p.live_words + (tile >> 5);
         has_a = (lw[0] >> (tile & 31u)) & 1u;
@@ -272,7 +277,7 @@ __device__ __forceinline__ void pair_tile_block(const HitParams &p, uint32_t *ld
     if (lane == 0 && p.group_rows) atomicAdd(&p.group_rows[p.group_base + pair], rows_loaded);
 
     if (kBounds == 1) {  // the largest bound per tile of the database and the best block of each query; nothing else leaves the wave
-        bounds_epilogue<NP>(p, pa, qa, tile, lane);
+        if (has_a) bounds_epilogue<NP>(p, pa, qa, tile, lane);
         if (has_b) bounds_epilogue<NP>(p, pb, qb, tile, lane);
         return;
     }
@@ -472,6 +477,14 @@ void launch_live_items(hipStream_t s, const uint32_t *live, uint32_t live_words,
 void launch_hit_count_pair_bounds(hipStream_t s, const HitParams &p, uint32_t nq, uint32_t u_ntiles, int planes) {
     if (planes <= 8) hipLaunchKernelGGL((hit_count_pair_kernel<8, true, 1, false>), dim3((nq + 1u) / 2u, u_ntiles), dim3(64), kPairLdsBytes, s, p);
     else hipLaunchKernelGGL((hit_count_pair_kernel<10, true, 1, false>), dim3((nq + 1u) / 2u, u_ntiles), dim3(64), kPairLdsBytes, s, p);
+}
+
+void launch_hit_count_pair_bounds_items(hipStream_t s, const HitParams &p, uint32_t nq, uint32_t u_ntiles, int planes) {
+    const uint32_t np = (nq + 1u) / 2u;
+    // (a grid of one residency: on the bench workload the list is all but empty, and the queues of the XCDs walk a long one)
+    const dim3 grid((uint32_t)((std::min<uint64_t>((uint64_t)np * u_ntiles, 4096ull) + 7u) & ~7ull));
+    if (planes <= 8) hipLaunchKernelGGL((hit_count_pair_kernel<8, true, 1, true>), grid, dim3(64), kPairLdsBytes, s, p);
+    else hipLaunchKernelGGL((hit_count_pair_kernel<10, true, 1, true>), grid, dim3(64), kPairLdsBytes, s, p);
 }
 
 // ---------------------------------------------------------------------------

@@ -278,6 +278,8 @@ struct rtx_index {
         DevBuf<uint32_t> d_items;  // [pairs x tiles] the (pair, tile) blocks with a live query | [1] their number | [8] queue per XCD | [pairs] live tiles per pair | [pairs] offsets
         DevBuf<uint16_t> d_tile_ub, d_prune_thr, d_prune_i1;
         DevBuf<uint32_t> d_best;  // [B][kPruneBestWords] reference shards: the candidate for the best block of the database
+        DevBuf<uint8_t> d_heavy;        // two-level bounds pass: [B] queries left to the one-level pass (Bounds2Params::heavy)
+        DevBuf<uint32_t> d_heavy_items; // ... and the (pair, union tile) items of that pass: [pairs x u_ntiles] | [9]
         DevBuf<uint32_t> d_fine_items;  // fine bounds pass: [pairs x f_ntiles] items | [9] number + XCD queues | [f_ntiles] cursors
         // the records path (RecordRef, rtx_kernels.hpp): per query the live tiles at prune time, the records of each, their number
         DevBuf<uint16_t> d_rec_nslots, d_rec_slots;
@@ -286,7 +288,7 @@ struct rtx_index {
             d_kmers.release(); d_counts.release(); d_tilemax.release(); d_rows.release(); d_t.release(); d_nrows.release(); d_hist.release();
             d_order.release(); d_srows.release(); d_nsparse.release(); d_dmask.release(); d_table_z.release(); d_prefix.release(); d_urec.release();
             d_nu.release(); d_live.release(); d_best_key.release(); d_items.release(); d_tile_ub.release(); d_prune_thr.release(); d_prune_i1.release();
-            d_best.release(); d_fine_items.release(); d_rec_nslots.release(); d_rec_slots.release(); d_rec_cnt.release(); d_rec.release();
+            d_best.release(); d_fine_items.release(); d_heavy.release(); d_heavy_items.release(); d_rec_nslots.release(); d_rec_slots.release(); d_rec_cnt.release(); d_rec.release();
         }
     } sc[4];  // 0 .. 2: the sets that alternate (RTX_OPT_OVERLAP, rtx_shard_*); 3: the set of the side classes (a few long reads among barcodes)
     bool staged = false;  // driven with rtx_shard_*: sub-batch sb works in scratch set sb & 1, so that the exchange of one

@@ -174,6 +174,7 @@ struct HitParams {
     uint16_t *bounds_tile_ub;     // [B][bounds_tile_stride] largest bound of every tile of the database
     uint32_t bounds_tile_stride, bounds_ntiles;
     uint32_t *bounds_best;        // [B] key of the block with the largest bound (bound << 20 | 0xFFFFF - block), zeroed by the caller
+    const uint8_t *bounds_heavy;  // [B] behind the two-level pass: only the queries flagged here are folded and leave bounds (Bounds2Params::heavy); or null: all
     // the FINE bounds pass (kBounds == 2): the bitmap is the union bitmap over blocks of 8 references -- one "tile" of it covers eight
     // tiles of the database -- and the launch walks the (pair, fine tile) items of the pairs that the coarse bounds left many live tiles
     uint64_t fine_n_refs;         // references of the database (n_refs counts blocks in a bounds pass)
@@ -195,10 +196,14 @@ struct Bounds2Params {
     uint32_t tile_ub_stride;
     uint32_t *best_key;        // [B] out: bound << 20 | (0xFFFFF - block) of the best block of 64 among the refined tiles
     uint32_t delta_ct, delta_cm, delta_lo, delta_hi;  // which B-tiles are refined (in 1/256; bounds2_kernel)
+    uint8_t *heavy;            // [B] out: 1 = the query's rule asks for more than heavy_max B-tiles (a query far from its best hit: everything is
+    uint32_t heavy_max;        //     "near"): level B is left out for it and the one-level pass over blocks of 64 takes it (launch_bounds2 enqueues it)
     uint32_t *group_rows;      // work accounting: load instructions (1 KiB each) per pair, or null
     uint32_t group_base;
 };
-void launch_bounds2(hipStream_t s, const Bounds2Params &p, uint32_t nq, int planes);
+struct HitParams;
+// hp: the parameters of the one-level pass (launch_hit_count_pair_bounds) for the heavy queries; items: [pairs * u_ntiles + 9] scratch
+void launch_bounds2(hipStream_t s, const Bounds2Params &p, uint32_t nq, int planes, const HitParams &hp, uint32_t u_ntiles, uint32_t *items);
 void launch_bounds2_build(hipStream_t s, const uint32_t *ubitmap, uint32_t n_rows1, uint32_t u_ntiles, uint8_t *bbitmap, uint32_t *abitmap);
 constexpr uint32_t kFineShift = 3;       // blocks of 8 references: the 8 references of one byte of a bitmap row (ref_slot)
 constexpr uint32_t kFineMinLive = 4;     // pairs with fewer live tiles than this skip the fine pass (a block of it costs what it can save there)
@@ -371,6 +376,7 @@ void launch_hit_count_pair(hipStream_t s, const HitParams &p, uint32_t nq, uint3
 void launch_live_items(hipStream_t s, const uint32_t *live, uint32_t live_words, const uint32_t *pair_live, uint32_t nq, uint32_t ntiles, uint32_t *off,
                        uint32_t *items, uint32_t *n_items);
 void launch_hit_count_pair_bounds(hipStream_t s, const HitParams &p, uint32_t nq, uint32_t u_ntiles, int planes);
+void launch_hit_count_pair_bounds_items(hipStream_t s, const HitParams &p, uint32_t nq, uint32_t u_ntiles, int planes);  // ... over a list of (pair, union tile) items (p.items)
 // the fine bounds pass over the pairs with many live tiles (p: the fine union bitmap, live masks, thresholds, histogram); updates pair_live
 void launch_fine_bounds(hipStream_t s, const HitParams &p, uint32_t nq, uint32_t ntiles, uint32_t f_ntiles, uint32_t *pair_live, uint32_t *cnt,
                         uint32_t *items, uint32_t *n_items, int planes);  // ... on the union bitmap: bounds_epilogue

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """The real-composition leg of bench.py on its own (hold-out of the Diptera records, 14 tiles): step time, stage times, rows per query,
-host share.  For rocprofv3 --kernel-trace --stats.   python tools/real_composition_probe.py [steps]"""
+host share.  For rocprofv3 --kernel-trace --stats.   python tools/real_composition_probe.py [steps] [RTX_OPT_RECORDS]"""
 import sys
 import time
 from pathlib import Path
@@ -15,7 +15,8 @@ from raxtax_amd import synth  # noqa: E402
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 h = synth.real_composition_holdout(ROOT / "tests" / "golden" / "diptera_queries.fasta")
 tree = rx.Tree.new_flat(h.lineages, h.seq_bytes, h.seq_off, kmer_map=False)
-index = rx.Index(tree, stage_timing=True)
+records = int(sys.argv[2]) if len(sys.argv) > 2 else None   # RTX_OPT_RECORDS: live tiles up to which a pruned query takes the records path
+index = rx.Index(tree, stage_timing=True, records=records)
 n_q = len(h.q_off) - 1
 index.upload(h.q_bases, h.q_off)
 for prune in (1, 0):

@@ -80,6 +80,16 @@ int run(rtx_index *const *indices, uint32_t n_dev, const rtx_tree *tree, uint64_
         MinSubs(rtx_index *const *i, uint32_t k, uint64_t n_chunks) : ix(i), n(n_chunks > 1 ? k : 0) { for (uint32_t d = 0; d < n; d++) (void)rtx_index_set_option(ix[d], RTX_OPT_MIN_SUB_BATCHES, 2); }
         ~MinSubs() { for (uint32_t d = 0; d < n; d++) (void)rtx_index_set_option(ix[d], RTX_OPT_MIN_SUB_BATCHES, 4); }
     } min_subs_guard(indices, n_dev, n_chunks);
+    // handles that share a device (rehearsals of the multi-GPU path on one GPU) run on one stream each for the duration of the call
+    struct SharedDevice {
+        rtx_index *const *ix; uint32_t n;
+        SharedDevice(rtx_index *const *i, uint32_t k) : ix(i), n(k) {
+            for (uint32_t d = 0; d < n; d++)
+                for (uint32_t e = 0; e < n; e++)
+                    if (e != d && rtx::index_device(ix[e]) == rtx::index_device(ix[d])) rtx::index_set_shared_device(ix[d], true);
+        }
+        ~SharedDevice() { for (uint32_t d = 0; d < n; d++) rtx::index_set_shared_device(ix[d], false); }
+    } shared_guard(indices, n_dev);
     std::vector<Chunk> chunks(n_chunks);
     for (uint64_t c = 0; c < n_chunks; c++) {
         chunks[c].q0 = c * chunk_size;

@@ -3,7 +3,7 @@
 #include "rtx_index.hpp"
 
 #ifndef RTX_B2_HEAVY_PER_ATILE
-#define RTX_B2_HEAVY_PER_ATILE 3u  // two-level bounds pass: a query whose rule asks for more B-tiles per A-tile (of 16) than this goes to the one-level pass (2 / 3 / 4 / 8: 79.4 / 78.7 / 78.8 / 79.4 ms per step at configs[2], 6.03 / 5.84 / 5.84 / 5.49 M queries/s at 5 % divergence)
+#define RTX_B2_HEAVY_PER_ATILE 4u  // two-level bounds pass: a query whose rule asks for more B-tiles per A-tile (of 16) than this goes to the one-level pass (with lo = 0.36 t: 2 / 3 / 4: 80.9 / 79.2 / 78.8 ms per step at configs[2], 6.19 / 6.13 / 6.10 M queries/s at 5 % divergence; lo = 0.33 t and 3: 78.7 ms, 5.84 M)
 #endif
 
 namespace rtxi {
@@ -608,7 +608,7 @@ int begin_run(rtx_index *ix, uint32_t *n_sub_out, bool *timed_out, bool cluster)
     }
     ix->n_sub_last = timed ? n_sub : 0;
     ix->overlap_used = 0;  // scratch sets in use beside each other (RTX_OPT_OVERLAP)
-    if (ix->overlap_opt != 0u && whole && n_sub >= 2 && ix->sc[1].d_kmers.p != nullptr && scratch_ok(ix->sc[1], b_max) == scratch_ok(ix->sc[0], b_max)) {
+    if (ix->overlap_opt != 0u && whole && n_sub >= 2 && !ix->shared_device && ix->sc[1].d_kmers.p != nullptr && scratch_ok(ix->sc[1], b_max) == scratch_ok(ix->sc[0], b_max)) {
         ix->overlap_used = 2;
         if (ix->overlap_opt >= 2u && n_sub >= 3 && ix->sc[2].d_kmers.p != nullptr && scratch_ok(ix->sc[2], b_max) == scratch_ok(ix->sc[0], b_max)) ix->overlap_used = 3;
     }
@@ -836,7 +836,7 @@ int prepare_workspace(rtx_index *ix, uint64_t n_queries, const uint64_t cls_n_in
     const uint64_t key[14] = {n_queries, cn[0], cn[1], cn[2], cn[3], cm[0], cm[1], cm[2], cm[3], ix->sub_batch_req,
                               (uint64_t)ix->packed_opt | (uint64_t)ix->pair_opt << 1 | (uint64_t)ix->prune_opt << 2 | (uint64_t)ix->shard_prune_opt << 3 | (uint64_t)ix->fine_opt << 4 |
                                   (uint64_t)(ix->prob_mode & 3) << 5 | (uint64_t)ix->rec_opt << 8 | (uint64_t)ix->overlap_opt << 16 | (uint64_t)ix->min_subs << 20,
-                              (uint64_t)ix->n_bnd_local, 0, 0};
+                              (uint64_t)ix->n_bnd_local, ix->shared_device ? 1u : 0u, 0};
     // A batch of the shape of the last one under the same options (the chunks of rtx_raxtax): everything below would come out the same --
     // and hipMemGetInfo alone costs a good part of a millisecond between two chunks, with the device idle
     if (ix->ws_valid && std::memcmp(key, ix->ws_key, sizeof key) == 0 && !ix->staged) {
@@ -917,7 +917,10 @@ static int size_workspace(rtx_index *ix, uint64_t n_queries) {
     }
     // ---- sub-batch scratch, sized against free HBM: every class gets the sub-batch size its own shape allows, the buffers the largest
     // product over the classes (a class runs after the other through the same buffers)
-    uint32_t n_sets = ix->n_refs == ix->n_total ? 1u + std::min<uint32_t>(ix->overlap_opt, 2u) : 1u;  // RTX_OPT_OVERLAP: two (three) scratch sets
+    // RTX_OPT_OVERLAP: two (three) scratch sets -- not for a handle that shares its device with another one driven beside it (rtx_raxtax_multi):
+    // two sets of 60 GB each per handle (N = 500k, sub-batches of 65 536) left the second handle of a device a sliver of HBM and sub-batches of
+    // a few thousand queries: a tenth of the speed
+    uint32_t n_sets = ix->n_refs == ix->n_total && !ix->shared_device ? 1u + std::min<uint32_t>(ix->overlap_opt, 2u) : 1u;
     size_t free_b = 0, total_b = 0;
     RTX_HIP(hipMemGetInfo(&free_b, &total_b));
     uint64_t held = 0;  // scratch already held by this handle is reusable

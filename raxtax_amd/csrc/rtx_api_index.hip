@@ -2,6 +2,14 @@
 // pruning, locator table, exact-match table), the taxonomy, the ln-factorial tables; handle options.
 #include "rtx_index.hpp"
 
+// Two handles on ONE device driven side by side (rtx_raxtax_multi with `--devices 0,0`, the eight-handle test: rehearsals of the multi-GPU
+// path) with two streams each for RTX_OPT_OVERLAP oversubscribe the hardware queues: a run whose chunks change size fell to a tenth of its
+// speed (tools/NOTES.md, round 5).  rtx_raxtax_multi marks such handles for the duration of the call; begin_run then leaves the overlap out.
+namespace rtx {
+int index_device(const rtx_index *index) { return index ? index->device : -1; }
+void index_set_shared_device(rtx_index *index, bool shared) { if (index) index->shared_device = shared; }
+}  // namespace rtx
+
 namespace {
 
 // statrs 0.16 `ln_factorial` (the reference's ln_binomial, prob.rs:5,20,117,143): ln of a cached

@@ -239,7 +239,7 @@ __global__ __launch_bounds__(64, 2) void bounds2_kernel(Bounds2Params p) {
     wave_lds_sync();
     // B-tiles within `dl` counts of the query's largest level-A bound are refined.  The gap between that bound and the threshold grows as
     // the best hit weakens (tools/study_two_level.py, t ~ 640: 0.29 t at 2 % divergence, 0.36 t at 5 %, 0.42 t at 10 %):
-    // dl = c_t t - c_m max, kept within [lo t, hi t] (all in 1/256)
+    // dl = c_t t - c_m max, kept within [lo t, hi t] (all in 1/256; defaults in rtx_index.hpp: 1.105 t - 0.8 max within [0.36 t, 0.5 t])
     auto delta_of = [&](uint32_t t, uint32_t mx) -> uint32_t {
         const uint32_t up = p.delta_ct * t, dn = p.delta_cm * mx;
         const uint32_t d = up > dn ? (up - dn) >> 8 : 0u, lo = (p.delta_lo * t) >> 8, hi = (p.delta_hi * t) >> 8;

@@ -184,7 +184,7 @@ struct rtx_index {
     DevBuf<uint8_t> d_bbitmap;   // [n_btiles][n_rows + 1][64 bytes]
     uint32_t n_atiles = 0, n_btiles = 0;
     uint32_t two_level_opt = 1;  // RTX_OPT_TWO_LEVEL_BOUNDS
-    uint32_t b2_delta[4] = {275u, 205u, 84u, 128u};  // which B-tiles are refined: c_t, c_m, lo, hi in 1/256 (Bounds2Params)
+    uint32_t b2_delta[4] = {283u, 205u, 92u, 128u};  // which B-tiles are refined: c_t, c_m, lo, hi in 1/256 (Bounds2Params): dl = 1.105 t - 0.8 max within [0.36 t, 0.5 t]
     bool two_level_used = false;  // the last run's bounds pass was bounds2_kernel (its work accounting counts load instructions of 1 KiB)
     uint32_t rec_opt = 4;   // RTX_OPT_RECORDS: pruned queries with at most this many live tiles take the records path (0: off; at most kRecMaxSlots)
     uint32_t overlap_opt = 1;  // RTX_OPT_OVERLAP: 1 = back half of sub-batch k on a second stream beside the front half of k + 1 (2: three stages)
@@ -340,6 +340,7 @@ struct rtx_index {
     std::vector<uint8_t> h_node_sig0;
     uint32_t h_node_stride = 1;
 
+    bool shared_device = false;  // rtx_raxtax_multi drives another handle on the same device beside this one: no second stream (begin_run)
     ~rtx_index() {
         for (auto e : events) (void)hipEventDestroy(e);
         for (auto e : ev_sub) (void)hipEventDestroy(e);

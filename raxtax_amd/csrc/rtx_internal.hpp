@@ -24,6 +24,10 @@ unsigned available_parallelism();
 unsigned host_share();
 unsigned host_threads(unsigned want, unsigned sharers = 1);
 
+// (rtx_api_index.hip) the device of a handle; a handle that shares its device with another one driven beside it runs on one stream
+int index_device(const rtx_index *index);
+void index_set_shared_device(rtx_index *index, bool shared);
+
 #ifndef RTX_NODE_TYPES_DEFINED
 #define RTX_NODE_TYPES_DEFINED
 enum NodeType : uint8_t { kInner = 0, kTaxon = 1, kSequence = 2 };  // src/tree.rs:181-186

@@ -697,11 +697,20 @@ def extras_block(args, rx, lib, index, tree, db, qs, flags):
     def e2e():
         rx._lib.check(lib.rtx_raxtax(index._h, tree._h, n_q, labels, rx._lib.ptr(bases, rx._lib.u8p), rx._lib.ptr(off, rx._lib.u64p),
                                      int(bool(flags)), 0, args.e2e_chunk, discard, ctypes.cast(counted, ctypes.c_void_p), 0))
-    dt = timed(e2e)
+    # the host side of this leg (sixteen formatting threads, the sender) shares the granted CPUs with whatever else the host runs: the
+    # median of five calls, with the spread beside it
+    e2e()
+    e2e_ms = []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        e2e()
+        e2e_ms.append((time.perf_counter() - t0) * 1e3)
+    dt = float(np.median(e2e_ms)) / 1e3
     busy = (ctypes.c_double * 4)()
     n_chunks = ctypes.c_uint64()
     rx._lib.check(lib.rtx_raxtax_last_timing(busy, ctypes.byref(n_chunks)))
-    out["value_end_to_end"] = {"value": n_q / dt, "ms_per_step": dt * 1e3, "steps": steps, "chunk_size": args.e2e_chunk,
+    out["value_end_to_end"] = {"value": n_q / dt, "ms_per_step": dt * 1e3, "steps": 5, "statistic": "median of the calls", "ms_per_call": [round(x, 1) for x in e2e_ms],
+                               "chunk_size": args.e2e_chunk,
                                "chunks": int(n_chunks.value),
                                "busy_ms_last_call": {"host_lookup": busy[0] * 1e3, "device_stage": busy[1] * 1e3, "format": busy[2] * 1e3, "sender": busy[3] * 1e3},
                                "text_bytes_per_query": counted[1] / max(counted[0], 1),

@@ -229,7 +229,9 @@ int rtx_index_set_batch(rtx_index *index, uint32_t sub_batch);
                             * trips) runs on a second HIP stream beside the front half of sub-batch k + 1 (bounds, counting: VALU and L1
                             * rate); two scratch sets alternate -- taken only if the second one fits free HBM without shrinking the sub-batch.
                             * 2: three stages (bounds | threshold + counting | back half; measured: no faster than two).  0: one stream.
-                            * Same results.  Whole-database handles; shapes the workspace. */
+                            * Same results.  Whole-database handles whose batch is on the pruned path (where every tile is counted the second
+                            * stream costs more than it hides), one handle per device (handles that rtx_raxtax_multi drives side by side on
+                            * ONE device keep to one stream and one scratch set: two sets are ~120 GB at 500 000 references); shapes the workspace. */
 #define RTX_OPT_MIN_SUB_BATCHES 20 /* 4 (default; 1 .. 64): a batch on the pruned path is cut into at least this many sub-batches (of 16 384 queries or
                                     * more), so that the host finalises the records of one while the next ones run and only the last one is left
                                     * when the device is done.  rtx_raxtax sets 2 for the time of a call: its chunks follow one another through

@@ -608,7 +608,9 @@ int begin_run(rtx_index *ix, uint32_t *n_sub_out, bool *timed_out, bool cluster)
     }
     ix->n_sub_last = timed ? n_sub : 0;
     ix->overlap_used = 0;  // scratch sets in use beside each other (RTX_OPT_OVERLAP)
-    if (ix->overlap_opt != 0u && whole && n_sub >= 2 && !ix->shared_device && ix->sc[1].d_kmers.p != nullptr && scratch_ok(ix->sc[1], b_max) == scratch_ok(ix->sc[0], b_max)) {
+    // (only behind tile pruning: where every tile is counted the counting pass lives on its rows staying in L2, and the sweeps of a back half
+    // beside it cost more than they hide: 990 against 955 ms per 1 M queries at configs[2] with RTX_OPT_TILE_PRUNE = 0)
+    if (ix->overlap_opt != 0u && whole && n_sub >= 2 && !ix->shared_device && any_prune && ix->sc[1].d_kmers.p != nullptr && scratch_ok(ix->sc[1], b_max) == scratch_ok(ix->sc[0], b_max)) {
         ix->overlap_used = 2;
         if (ix->overlap_opt >= 2u && n_sub >= 3 && ix->sc[2].d_kmers.p != nullptr && scratch_ok(ix->sc[2], b_max) == scratch_ok(ix->sc[0], b_max)) ix->overlap_used = 3;
     }

@@ -482,7 +482,8 @@ STAGE_KERNELS = {
     "exact_match": ("rtx::exact_match_kernel",),
     "kmer_extract": ("rtx::kmer_extract_kernel<false>",),
     "pair_union": ("rtx::pair_union_kernel",),
-    "tile_bounds": ("rtx::hit_count_pair_kernel<10, true, 1, false>", "rtx::hit_count_pair_kernel<8, true, 1, false>"),
+    "tile_bounds": ("rtx::bounds2_kernel<10>", "rtx::bounds2_kernel<8>", "rtx::hit_count_pair_kernel<10, true, 1, true>", "rtx::hit_count_pair_kernel<8, true, 1, true>", "rtx::heavy_items_kernel",
+                    "rtx::hit_count_pair_kernel<10, true, 1, false>", "rtx::hit_count_pair_kernel<8, true, 1, false>"),
     "tile_prune": ("rtx::prune_kernel", "rtx::kmer_extract_kernel<true>", "rtx::hit_count_pair_kernel<10, true, 2, true>", "rtx::hit_count_pair_kernel<8, true, 2, true>",
                    "rtx::live_offsets_kernel", "rtx::live_items_kernel", "rtx::fine_count_kernel", "rtx::fine_scan_kernel", "rtx::fine_scatter_kernel",
                    "rtx::pair_live_recount_kernel"),

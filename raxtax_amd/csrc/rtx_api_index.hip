@@ -461,7 +461,9 @@ static bool prepare_fine_bitmap(rtx_index *ix) {
 // The two bitmaps of the two-level bounds pass (rtx_bounds2.hip) from the union bitmap over blocks of 64, which one of the builders has
 // filled: whole-database handles that prune.  A failure to allocate leaves the handle with the one-level pass.
 static void build_two_level(rtx_index *ix) {
-    if (!ix->d_ubitmap.p || ix->n_refs != ix->n_total) return;
+    // from 16 tiles on: below that the one-level pass reads a mostly empty coarse tile and is cheap, and the all-live databases of a few tiles
+    // (real short barcodes: every B-tile is wanted, every query "heavy") would pay level A for nothing (14 tiles: 30.5 against 28.7 ms per 131 072 queries)
+    if (!ix->d_ubitmap.p || ix->n_refs != ix->n_total || ix->ntiles < kTwoLevelMinTiles) return;
     static_assert(kPruneShift == 6, "level B of the two-level bounds pass holds the blocks of the union bitmap");
     ix->n_btiles = (uint32_t)((ix->u_nblocks + 511) / 512);
     ix->n_atiles = (uint32_t)((ix->u_nblocks + 8191) / 8192);  // 2048 blocks of 256 = 8192 blocks of 64

@@ -204,6 +204,7 @@ struct Bounds2Params {
 struct HitParams;
 // hp: the parameters of the one-level pass (launch_hit_count_pair_bounds) for the heavy queries; items: [pairs * u_ntiles + 9] scratch
 void launch_bounds2(hipStream_t s, const Bounds2Params &p, uint32_t nq, int planes, const HitParams &hp, uint32_t u_ntiles, uint32_t *items);
+constexpr uint32_t kTwoLevelMinTiles = 16;  // databases with fewer tiles keep the one-level bounds pass
 void launch_bounds2_build(hipStream_t s, const uint32_t *ubitmap, uint32_t n_rows1, uint32_t u_ntiles, uint8_t *bbitmap, uint32_t *abitmap);
 constexpr uint32_t kFineShift = 3;       // blocks of 8 references: the 8 references of one byte of a bitmap row (ref_slot)
 constexpr uint32_t kFineMinLive = 4;     // pairs with fewer live tiles than this skip the fine pass (a block of it costs what it can save there)

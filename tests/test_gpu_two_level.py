@@ -27,7 +27,7 @@ def _taps(index, n_q, n_take):
     return qs_last, {int(q): (index.debug_tile_bounds(int(q)), index.debug_prune_detail(int(q))) for q in qs_last}
 
 
-@pytest.mark.parametrize("n_refs,mu", [(140_000, 0.02), (140_000, 0.08), (33_000, 0.03)])
+@pytest.mark.parametrize("n_refs,mu", [(140_000, 0.02), (140_000, 0.08), (33_000, 0.03)])   # (33 000: 5 tiles -- below kTwoLevelMinTiles the option changes nothing)
 def test_two_level_bounds_against_one_level_and_oracle(oracle, n_refs, mu):
     n_q, n_take = 6000, 160
     db = synth.make_db(n_refs)

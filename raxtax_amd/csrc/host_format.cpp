@@ -17,13 +17,13 @@ struct Out {
     char *buf;
     uint64_t cap, len = 0;
     bool ok = true;
-    void put(const char *s, size_t n) {
+    void put(const char *s, size_t n) {  // (the text is terminated once, by finish())
         if (!ok) return;
         if (len + n + 1 > cap) { ok = false; return; }
         memcpy(buf + len, s, n);
         len += n;
-        buf[len] = 0;
     }
+    void finish() { if (ok && buf && len < cap) buf[len] = 0; }
     void put(const std::string &s) { put(s.data(), s.size()); }
     void putc(char c) { put(&c, 1); }
     void putf(const char *fmt, double v) {
@@ -44,6 +44,11 @@ struct Out {
         const double fl = std::floor(s), frac = s - fl;
         if (frac > 0.4999 && frac < 0.5001) { putf(D == 2 ? "%.2f" : "%.5f", v); return; }  // too close to call
         unsigned long long r = (unsigned long long)fl + (frac > 0.5 ? 1ull : 0ull);
+        if (D == 2 && r <= 100ull) {  // a confidence: "0.00" .. "1.00" from a table (six of them per row)
+            static const struct Tab { char t[101][4]; Tab() { for (int k = 0; k <= 100; k++) { t[k][0] = (char)('0' + k / 100); t[k][1] = '.'; t[k][2] = (char)('0' + k / 10 % 10); t[k][3] = (char)('0' + k % 10); } } } tab;
+            put(tab.t[r], 4);
+            return;
+        }
         char tmp[24];
         int n = 0;
         for (int d = 0; d < D; d++) { tmp[n++] = (char)('0' + r % 10ull); r /= 10ull; }
@@ -152,6 +157,8 @@ extern "C" int64_t rtx_format_query(const rtx_tree *tree, const rtx_result_view 
             tv.put(dec);
         }
     }
+    o.finish();
+    if (tsv_buf) tv.finish();
     if (!o.ok || (tsv_buf && !tv.ok)) { rtx::set_error("rtx_format_query: output buffer too small"); return RTX_ERR_INVALID; }
     if (tsv_len) *tsv_len = tsv_buf ? (int64_t)tv.len : 0;
     return (int64_t)o.len;

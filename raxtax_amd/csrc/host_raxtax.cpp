@@ -26,6 +26,52 @@ void parallel_ranges(uint64_t n, unsigned nt, F fn) {
     for (auto &t : th) t.join();
 }
 
+// A few worker threads that live as long as a run of the pipeline: run(n, fn) hands fn(0) .. fn(n - 1) to them and returns when all are
+// done (sixteen std::thread per chunk were half a millisecond of the format stage per chunk: created one after the other).
+class WorkerPool {
+public:
+    explicit WorkerPool(unsigned n) {
+        for (unsigned i = 0; i < n; i++) th_.emplace_back([this] { loop(); });
+    }
+    ~WorkerPool() {
+        { std::lock_guard<std::mutex> g(mu_); stop_ = true; }
+        cv_.notify_all();
+        for (auto &t : th_) t.join();
+    }
+    void run(unsigned n, const std::function<void(unsigned)> &fn) {
+        if (n == 0) return;
+        if (th_.empty() || n == 1) { for (unsigned r = 0; r < n; r++) fn(r); return; }
+        std::unique_lock<std::mutex> g(mu_);
+        job_ = &fn;
+        n_jobs_ = n;
+        next_ = done_ = 0;
+        cv_.notify_all();
+        cv_done_.wait(g, [&] { return done_ == n_jobs_; });
+        job_ = nullptr;
+        n_jobs_ = 0;
+    }
+private:
+    void loop() {
+        std::unique_lock<std::mutex> g(mu_);
+        for (;;) {
+            cv_.wait(g, [&] { return stop_ || (job_ && next_ < n_jobs_); });
+            if (stop_) return;
+            const unsigned r = next_++;
+            const std::function<void(unsigned)> *job = job_;
+            g.unlock();
+            (*job)(r);
+            g.lock();
+            if (++done_ == n_jobs_) cv_done_.notify_all();
+        }
+    }
+    std::vector<std::thread> th_;
+    std::mutex mu_;
+    std::condition_variable cv_, cv_done_;
+    const std::function<void(unsigned)> *job_ = nullptr;
+    unsigned n_jobs_ = 0, next_ = 0, done_ = 0;
+    bool stop_ = false;
+};
+
 struct LastTiming { double busy[4]; uint64_t n_chunks; };
 std::mutex g_timing_mu;
 LastTiming g_timing{{0, 0, 0, 0}, 0};
@@ -232,6 +278,7 @@ int run(rtx_index *const *indices, uint32_t n_dev, const rtx_tree *tree, uint64_
     };
 
     auto format_loop = [&](uint32_t d) {
+        WorkerPool pool(nt_format > 1 ? nt_format : 0);
         for (uint64_t c = d; c < n_chunks; c += n_dev) {
             if (!wait_stage(c, 2)) return;
             if (c >= 2 * ahead && !wait_stage(c - 2 * ahead, 4)) return;  // bounded memory: the sender is at most 4 chunks per handle behind
@@ -280,7 +327,9 @@ int run(rtx_index *const *indices, uint32_t n_dev, const rtx_tree *tree, uint64_
                     __builtin_prefetch(ch.res.row_local_signal + r);
                 };
                 auto stage2 = [&](uint64_t j) {
-                    if (j >= b || ch.res.status[j] != RTX_Q_OK || ch.res.row_count[j] == 0) return;
+                    if (j >= b) return;
+                    __builtin_prefetch(labels[ch.q0 + j]);  // (the labels are the caller's strings, one allocation each)
+                    if (ch.res.status[j] != RTX_Q_OK || ch.res.row_count[j] == 0) return;
                     __builtin_prefetch(&tree->lineages[ch.res.row_lineage[row_of(j)]]);
                 };
                 auto stage3 = [&](uint64_t j) {
@@ -326,13 +375,7 @@ int run(rtx_index *const *indices, uint32_t n_dev, const rtx_tree *tree, uint64_
                     if (ta) { ch.tsv_off[i] = ta->len; ta->len += (size_t)tsv_len + 1; }
                 }
             };
-            if (nt_f <= 1) {
-                format_range(0);
-            } else {
-                std::vector<std::thread> th;
-                for (unsigned r = 0; r < nt_f; r++) th.emplace_back(format_range, r);
-                for (auto &t : th) t.join();
-            }
+            pool.run(nt_f, format_range);
             if (rc_fmt) { fail(rc_fmt, "formatting a result failed"); return; }
             busy_format[d] += now() - t_f0;
             set_stage(c, 3);

@@ -71,19 +71,6 @@ __device__ __forceinline__ void fold_list(uint32_t (&pa)[4][NP], uint32_t (&pb)[
     }
 }
 
-// a + b on bit-sliced numbers (the sum fits NP planes: partial counts of disjoint rows of a query with t < 2^NP)
-template <int NP>
-__device__ __forceinline__ void planes_add(uint32_t (&a)[NP], const uint32_t (&b)[NP]) {
-    uint32_t c = a[0] & b[0];
-    a[0] ^= b[0];
-#pragma unroll
-    for (int p = 1; p < NP; p++) {
-        const uint32_t cn = __builtin_amdgcn_bitop3_b32(a[p], b[p], c, 0xE8);
-        a[p] = __builtin_amdgcn_bitop3_b32(a[p], b[p], c, 0x96);
-        c = cn;
-    }
-}
-
 // The four DPP rows of the wave hold partial counters of the same columns: summed over the rows, DPP row r ends with word r of its
 // lane's 16 bytes (two halving exchanges: with lane ^ 32 a lane keeps words {0, 1} or {2, 3}, with lane ^ 16 one of the two).
 template <int NP>
@@ -109,21 +96,6 @@ __device__ __forceinline__ void reduce_rows(const uint32_t (&pl)[4][NP], uint32_
         s[p] = (uint32_t)__shfl_xor((int)(mid ? k0[p] : k1[p]), 16, 64);
     }
     planes_add<NP>(out, s);
-}
-
-// the largest of the 32 counters of a bit-sliced word, and the counters that hold it (bit by bit from the top)
-template <int NP>
-__device__ __forceinline__ uint32_t planes_max(const uint32_t (&r)[NP], uint32_t &cand) {
-    uint32_t m = 0;
-    cand = 0xFFFFFFFFu;
-#pragma unroll
-    for (int p = NP - 1; p >= 0; p--) {
-        const uint32_t x = cand & r[p];
-        const bool nz = x != 0u;
-        cand = nz ? x : cand;
-        m |= nz ? 1u << p : 0u;
-    }
-    return m;
 }
 
 __device__ __forceinline__ uint32_t umax(uint32_t a, uint32_t b) { return a > b ? a : b; }

@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <array>
 #include <vector>
 
 #include "rtx_math.hpp"
@@ -14,6 +15,42 @@
 using namespace rtx;
 
 extern "C" {
+
+// The arithmetic of the two-level bounds pass (rtx_bounds2.hip) on one 32-counter column: the rows are dealt to `groups` lane groups as the
+// load instructions deal them (unit of 8 * groups rows: group g takes rows 8 g .. 8 g + 7 of the unit), every group folds its own (tree8 +
+// ripple), the partial plane sets are added pairwise as bit-sliced numbers (the butterfly of reduce_rows) and the largest counter is taken on
+// the planes.  n_rows must be a multiple of 8 * groups.  out: 32 counters; returns max << 8 | lowest counter that holds it.
+uint32_t emul_planes_grouped(const uint32_t *rows, uint32_t n_rows, uint32_t groups, uint32_t *out) {
+    constexpr int NP = 10;
+    std::vector<std::array<uint32_t, NP>> part(groups);
+    for (auto &p : part) p.fill(0);
+    for (uint32_t u = 0; u + 8 * groups <= n_rows; u += 8 * groups)
+        for (uint32_t g = 0; g < groups; g++) {
+            const uint32_t *r = rows + u + 8 * g;
+            uint32_t pl[NP];
+            for (int p = 0; p < NP; p++) pl[p] = part[g][p];
+            planes_ripple<NP, 3>(pl, planes_tree8<NP>(pl, r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7]));
+            for (int p = 0; p < NP; p++) part[g][p] = pl[p];
+        }
+    for (uint32_t d = 1; d < groups; d <<= 1)  // butterfly: every group ends with the total
+        for (uint32_t g = 0; g < groups; g++)
+            if (!(g & d)) {
+                uint32_t a[NP], b[NP];
+                for (int p = 0; p < NP; p++) { a[p] = part[g][p]; b[p] = part[g | d][p]; }
+                planes_add<NP>(a, b);
+                for (int p = 0; p < NP; p++) part[g][p] = part[g | d][p] = a[p];
+            }
+    uint32_t tot[NP];
+    for (int p = 0; p < NP; p++) tot[p] = part[groups - 1][p];
+    for (int b = 0; b < 32; b++) {
+        uint32_t c = 0;
+        for (int p = 0; p < NP; p++) c |= ((tot[p] >> b) & 1u) << p;
+        out[b] = c;
+    }
+    uint32_t cand;
+    const uint32_t m = planes_max<NP>(tot, cand);
+    return (m << 8) | (uint32_t)__builtin_ctz(cand);
+}
 
 // rows: n_rows x 1 words (one 32-reference column).  n_rows must be a multiple of 8.
 // out: 32 counters.

@@ -139,6 +139,36 @@ RTX_HD void planes_ripple(uint32_t (&pl)[NP], uint32_t e) {
     }
 }
 
+// ---- bit-sliced numbers as values (the two-level bounds pass, rtx_bounds2.hip: lanes that took different rows of a load instruction hold
+// partial counters of the same columns)
+// a += b (the sum fits NP planes: partial counts of disjoint rows of a query with t < 2^NP)
+template <int NP>
+RTX_HD void planes_add(uint32_t (&a)[NP], const uint32_t (&b)[NP]) {
+    uint32_t c = a[0] & b[0];
+    a[0] ^= b[0];
+#pragma unroll
+    for (int p = 1; p < NP; p++) {
+        uint32_t sum, carry;
+        csa(a[p], b[p], c, sum, carry);
+        a[p] = sum;
+        c = carry;
+    }
+}
+// the largest of the 32 counters of a bit-sliced word, and the counters that hold it (bit by bit from the top)
+template <int NP>
+RTX_HD uint32_t planes_max(const uint32_t (&r)[NP], uint32_t &cand) {
+    uint32_t m = 0;
+    cand = 0xFFFFFFFFu;
+#pragma unroll
+    for (int p = NP - 1; p >= 0; p--) {
+        const uint32_t x = cand & r[p];
+        const bool nz = x != 0u;
+        cand = nz ? x : cand;
+        m |= nz ? 1u << p : 0u;
+    }
+    return m;
+}
+
 // Spreads the 4 bits x[3:0] into the low bit of the 4 bytes of the result.
 RTX_HD uint32_t spread4(uint32_t x) {
 #if defined(__HIP_DEVICE_COMPILE__)

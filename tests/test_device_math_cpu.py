@@ -23,6 +23,21 @@ def test_bit_planes_exact(emul, planes, n_rows, density):
     assert np.array_equal(out, bits.sum(axis=0).astype(np.uint32))
 
 
+@pytest.mark.parametrize("groups,n_rows,density", [(4, 1024, 0.3), (16, 1024, 0.9), (4, 128, 0.02), (16, 896, 0.5)])
+def test_grouped_bit_planes_of_the_two_level_bounds(emul, groups, n_rows, density):
+    """rtx_bounds2.hip: R lane groups fold different rows of the same columns, their bit-sliced partial counters are added pairwise
+    (planes_add), the largest counter is read off the planes (planes_max): totals and maximum exact, the lowest counter among equals."""
+    rng = np.random.default_rng(groups * 10000 + n_rows)
+    bits = rng.random((n_rows, 32)) < density
+    rows = (bits.astype(np.uint64) << np.arange(32, dtype=np.uint64)).sum(axis=1).astype(np.uint32)
+    out = np.zeros(32, dtype=np.uint32)
+    emul.emul_planes_grouped.restype = C.c_uint32
+    key = emul.emul_planes_grouped(rows.ctypes.data_as(C.c_void_p), C.c_uint32(n_rows), C.c_uint32(groups), out.ctypes.data_as(C.c_void_p))
+    want = bits.sum(axis=0).astype(np.uint32)
+    assert np.array_equal(out, want)
+    assert key >> 8 == int(want.max()) and key & 0xFF == int(np.argmax(want))
+
+
 def _lnfact(oracle, n):
     return np.array([oracle.lib.orc_ln_factorial(i) for i in range(n)], dtype=np.float64)
 

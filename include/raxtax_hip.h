@@ -469,6 +469,15 @@ int64_t rtx_format_query(const rtx_tree *tree, const rtx_result_view *res, uint6
  * or a negative RTX_ERR_*. */
 int64_t rtx_result_pack(const rtx_result_view *res, uint8_t *buf, uint64_t cap);
 
+/* The writer's side of that gather (main.rs:126-136 for the results of every rank): the `.out` lines of all queries of ONE packed record
+ * buffer, formatted natively on `threads` threads (0: the library's budget) -- the text rtx_format_query gives for the view the records
+ * were packed from.  labels: [n] the labels of the buffer's queries; exact_one: [n] the id of a query's ONLY exact match (the override of
+ * raxtax.rs:73-84; 0xFFFFFFFF: none or several) or NULL; flags: RTX_SKIP_EXACT_MATCHES / RTX_RAW_CONFIDENCE switch the override off as in the
+ * reference.  out: the texts back to back, each NUL-terminated, lines of one query '\n'-joined; line_off: [n + 1] where each starts (a query
+ * without rows -- status != 0 -- has an empty text) or NULL.  Returns the bytes written, with out == NULL the bytes needed, or a negative RTX_ERR_*. */
+int64_t rtx_records_format(const rtx_tree *tree, const uint8_t *records, uint64_t n_bytes, const char *const *labels,
+                           const uint32_t *exact_one, uint32_t flags, char *out, uint64_t cap, uint64_t *line_off, uint32_t threads);
+
 /* ------------------------------------------------------------------------- */
 /* Host mirror of raxtax() itself (src/raxtax.rs:14-97)                       */
 /* ------------------------------------------------------------------------- */

@@ -128,6 +128,7 @@ _SIGNATURES = {
     "rtx_debug_prune_detail": (C.c_int, [C.c_void_p, C.c_uint64, u32p]),
     "rtx_debug_evaluate": (C.c_int, [C.c_void_p, f64p, C.POINTER(ResultView)]),
     "rtx_result_pack": (C.c_int64, [C.POINTER(ResultView), u8p, C.c_uint64]),
+    "rtx_records_format": (C.c_int64, [C.c_void_p, u8p, C.c_uint64, C.POINTER(C.c_char_p), u32p, C.c_uint32, C.c_char_p, C.c_uint64, u64p, C.c_uint32]),
     "rtx_format_query": (C.c_int64, [C.c_void_p, C.POINTER(ResultView), C.c_uint64, C.c_char_p, u8p, C.c_uint64,
                                      u32p, C.c_uint64, C.c_uint32, C.c_char_p, C.c_uint64, C.c_char_p, C.c_uint64,
                                      C.POINTER(C.c_int64)]),

@@ -94,6 +94,37 @@ def unpack_records(buf: np.ndarray) -> dict:
                 row_depth=depth, row_conf=conf, row_local_signal=local)
 
 
+def format_records(tree, buf: np.ndarray, labels, exact_one=None, flags: int = 0, threads: int = 0):
+    """The `.out` texts of every query of one packed record buffer, formatted natively (rtx_records_format: what a writer on rank 0 does
+    with the gathered records of a rank).  labels: the labels of the buffer's queries; exact_one: per query the id of its only exact
+    match or 0xFFFFFFFF (raxtax.rs:73-84) or None.  Returns (text bytes, line_off[n + 1])."""
+    import ctypes as C
+
+    from . import _lib
+
+    lib = _lib.load()
+    buf = np.ascontiguousarray(buf, dtype=np.uint8)
+    n_q = int(buf[:8].view(np.int64)[0])
+    assert len(labels) == n_q
+    arr = labels if isinstance(labels, C.Array) else (C.c_char_p * n_q)(*[l if isinstance(l, bytes) else l.encode() for l in labels])
+    ex = None if exact_one is None else np.ascontiguousarray(exact_one, dtype=np.uint32)
+    exp = _lib.ptr(ex, _lib.u32p) if ex is not None else None
+    if len(buf) < 32 or int(buf[24:32].view(np.int64)[0]) != RECORD_VERSION:
+        raise _lib.RtxError(-1, "format_records: not a record buffer of this version")
+    off = np.zeros(n_q + 1, dtype=np.uint64)
+    cap = 4 * len(buf) + (1 << 20)     # text is ~2.3 x the records on the bench workload: one pass as a rule ...
+    for _ in range(2):
+        out = np.empty(cap, dtype=np.uint8)
+        n = lib.rtx_records_format(tree._h, _lib.ptr(buf, _lib.u8p), len(buf), arr, exp, flags, out.ctypes.data_as(C.c_char_p), cap, _lib.ptr(off, _lib.u64p), threads)
+        if n >= 0:
+            return out[:n], off
+        need = lib.rtx_records_format(tree._h, _lib.ptr(buf, _lib.u8p), len(buf), arr, exp, flags, None, 0, None, threads)   # ... else measured
+        _lib.check(min(need, 0))
+        cap = need + 1
+    _lib.check(n)
+    return out[:0], off
+
+
 def pinned_bytes(n: int) -> np.ndarray:
     """A uint8 numpy buffer in page-locked host memory when CUDA is there (fast H2D/D2H of the records), else plain."""
     import torch

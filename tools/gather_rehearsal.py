@@ -45,6 +45,25 @@ def worker(rank, world, port, n_q, steps):
         u = dist_util.unpack_records(parts[-1])
         t_unpack = time.perf_counter() - t0
         assert u["n_queries"] == n_q and len(parts) == world and all(len(p) > 25 * n_q for p in parts)
+        # the writer: rank 0 turns the records of EVERY rank into `.out` lines natively (rtx_records_format), all of its CPUs at work
+        import ctypes
+
+        import raxtax_amd as rx
+        from raxtax_amd import synth
+        db = synth.make_db(500_000)
+        tree = rx.Tree.new_flat(db.lineages, db.seq_bytes, db.seq_off, kmer_map=False)
+        labels = (ctypes.c_char_p * n_q)(*[f"q{i}".encode() for i in range(n_q)])
+        nt = os.cpu_count()
+        dist_util.format_records(tree, parts[0], labels, threads=nt)    # (first touch of the tree's strings)
+        t0 = time.perf_counter()
+        n_bytes = 0
+        for p_ in parts:
+            text, off = dist_util.format_records(tree, p_, labels, threads=nt)
+            n_bytes += len(text)
+        t_fmt = time.perf_counter() - t0
+        print(f"rank 0 formats the records of {world} ranks ({world * n_q} queries) into {n_bytes / 1e6:.0f} MB of .out lines in {1e3 * t_fmt:.0f} ms on {nt} threads "
+              f"= {world * n_q / t_fmt / 1e6:.1f} M lines/s, {1e9 * t_fmt * nt / (world * n_q):.0f} ns of one thread per query (a 16-CPU grant: "
+              f"{1e3 * t_fmt * nt / 16:.0f} ms for these {world} M queries beside a device step of ~80 ms)")
         print(f"{world} gloo ranks on {os.cpu_count()} CPUs, {n_q} queries per rank: {len(rec) / 1e6:.1f} MB of records per rank, "
               f"gather to rank 0: {1e3 * np.mean(times):.1f} ms per step (min {1e3 * min(times):.1f}, max {1e3 * max(times):.1f}) = "
               f"{world * len(rec) / np.mean(times) / 1e9:.2f} GB/s into rank 0; numpy unpack of ONE rank's buffer on one thread: {1e3 * t_unpack:.0f} ms "

@@ -277,6 +277,7 @@ int enqueue_hit(rtx_index *ix, const SubBatch &b, uint32_t flags, hipStream_t s,
         pr.phase = (uint32_t)part;
         pr.best = part ? sc.d_best.p : nullptr;
         pr.bitmap = ix->d_bitmap.p;
+        pr.cbitmap = part == 0 && ix->two_level_used ? reinterpret_cast<const uint2 *>(ix->d_cbitmap.p) : nullptr;  // (with the two-level pass: RTX_OPT_TWO_LEVEL_BOUNDS = 0 is the round-4 path whole)
         pr.n_rows1 = ix->n_rows + 1;
         pr.stride_bytes = ix->stride_bytes;
         pr.rows = sc.d_rows.p;

@@ -469,6 +469,7 @@ static void build_two_level(rtx_index *ix) {
     ix->n_atiles = (uint32_t)((ix->u_nblocks + 8191) / 8192);  // 2048 blocks of 256 = 8192 blocks of 64
     const size_t rows1 = (size_t)ix->n_rows + 1;
     if (rows1 * 256u > 0xFFFFFFFFull) return;  // (a tile's region is addressed through one buffer descriptor)
+    if ((uint64_t)ix->u_ntiles * rows1 * 256u > 0xFFFFFFFFull) return;  // (bounds2_build_kernel: a thread per word, one grid dimension; ~130 M references)
     if (ix->d_abitmap.alloc((size_t)ix->n_atiles * rows1 * 64) || ix->d_bbitmap.alloc((size_t)ix->n_btiles * rows1 * 64)) {
         ix->d_abitmap.release();
         ix->d_bbitmap.release();
@@ -478,9 +479,26 @@ static void build_two_level(rtx_index *ix) {
     if (e == hipSuccess) e = hipMemsetAsync(ix->d_bbitmap.p, 0, (size_t)ix->n_btiles * rows1 * 64, ix->stream);
     if (e == hipSuccess) {
         launch_bounds2_build(ix->stream, ix->d_ubitmap.p, (uint32_t)rows1, ix->u_ntiles, ix->d_bbitmap.p, ix->d_abitmap.p);
-        e = hipStreamSynchronize(ix->stream);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(ix->stream);
     }
-    if (e != hipSuccess) { (void)hipGetLastError(); ix->d_abitmap.release(); ix->d_bbitmap.release(); }
+    if (e != hipSuccess) { (void)hipGetLastError(); ix->d_abitmap.release(); ix->d_bbitmap.release(); return; }
+    // the database once more block by block (prune_kernel's exact counts of the best block): as large as the bitmap itself -- left out
+    // when HBM is short (the kernel then walks the tile-major bitmap)
+    const size_t cbytes = (size_t)((ix->n_refs + 63) / 64) * rows1 * 8;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || cbytes > free_b / 4 || ix->d_cbitmap.alloc(cbytes)) {
+        (void)hipGetLastError();
+        ix->d_cbitmap.release();
+        return;
+    }
+    e = hipMemsetAsync(ix->d_cbitmap.p, 0, cbytes, ix->stream);
+    if (e == hipSuccess) {
+        launch_block_major_build(ix->stream, ix->d_bitmap.p, (uint32_t)rows1, ix->ntiles, ix->stride_bytes, ix->d_cbitmap.p);
+        e = hipGetLastError();  // (a launch that was refused leaves no bitmap, not an empty one)
+        if (e == hipSuccess) e = hipStreamSynchronize(ix->stream);
+    }
+    if (e != hipSuccess) { (void)hipGetLastError(); ix->d_cbitmap.release(); }
 }
 
 // Locator table of the processing order (rtx_cluster.hip) from the reference sequences already on the device.
@@ -615,7 +633,7 @@ void rtx_index_destroy(rtx_index *index) {
 uint64_t rtx_index_num_refs(const rtx_index *index) { return index ? index->n_total : 0; }
 uint64_t rtx_index_device_bytes(const rtx_index *index) {
     if (!index) return 0;
-    return index->d_seg_dbits.n * 8 + index->d_seg_sbits.n * 8 + index->d_seg_sbase.n * 4 + index->d_seginfo.n * 4 + index->d_segcls.n * 4 + index->d_segslots.n * 2 + index->d_bitmap.n * 4 + index->d_row_of.n * 4 + index->d_row_len.n * 8 + index->d_list_len.n * 4 + index->d_loc_table.n * 4 + index->d_ubitmap.n * 4 + index->d_fbitmap.n * 4 + index->d_abitmap.n * 4 + index->d_bbitmap.n + index->d_em_table.n * 8 + index->d_em_rep_off.n * 8 + index->d_em_rep_bytes.n + index->d_em_goff.n * 4 + index->d_em_gids.n * 4 + index->d_lnfact.n * 8 +
+    return index->d_seg_dbits.n * 8 + index->d_seg_sbits.n * 8 + index->d_seg_sbase.n * 4 + index->d_seginfo.n * 4 + index->d_segcls.n * 4 + index->d_segslots.n * 2 + index->d_bitmap.n * 4 + index->d_row_of.n * 4 + index->d_row_len.n * 8 + index->d_list_len.n * 4 + index->d_loc_table.n * 4 + index->d_ubitmap.n * 4 + index->d_fbitmap.n * 4 + index->d_abitmap.n * 4 + index->d_bbitmap.n + index->d_cbitmap.n + index->d_em_table.n * 8 + index->d_em_rep_off.n * 8 + index->d_em_rep_bytes.n + index->d_em_goff.n * 4 + index->d_em_gids.n * 4 + index->d_lnfact.n * 8 +
            index->d_noderec.n * 16 + index->d_bnd_bits.n + index->d_bnd_rank.n * 4;
 }
 int rtx_index_set_batch(rtx_index *index, uint32_t sub_batch) {

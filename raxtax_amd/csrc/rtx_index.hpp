@@ -183,6 +183,7 @@ struct rtx_index {
     DevBuf<uint32_t> d_abitmap;  // [n_atiles][n_rows + 1][64 words]
     DevBuf<uint8_t> d_bbitmap;   // [n_btiles][n_rows + 1][64 bytes]
     uint32_t n_atiles = 0, n_btiles = 0;
+    DevBuf<uint8_t> d_cbitmap;   // the database block by block: [ceil(n_refs / 64)][n_rows + 1][8 bytes] (prune_kernel: exact counts of the best block)
     uint32_t two_level_opt = 1;  // RTX_OPT_TWO_LEVEL_BOUNDS
     uint32_t b2_delta[4] = {283u, 205u, 92u, 128u};  // which B-tiles are refined: c_t, c_m, lo, hi in 1/256 (Bounds2Params): dl = 1.105 t - 0.8 max within [0.36 t, 0.5 t]
     bool two_level_used = false;  // the last run's bounds pass was bounds2_kernel (its work accounting counts load instructions of 1 KiB)

@@ -232,6 +232,8 @@ struct PruneParams {
     // phase 0 (whole database on the handle): both at once.
     uint32_t phase;
     uint32_t *best;              // [B][kPruneBestWords] (phases 1 and 2) or null
+    const uint2 *cbitmap;     // the database once more BLOCK by block: [block of 64 references][row] 8 bytes, bit j = reference 64 block + j has the
+                              // row's k-mer (rtx_prune.hip: the exact counts of the best block in ten loads per lane); or null: from `bitmap`
     const uint32_t *bitmap;   // the database's bitmap: the exact count of one reference
     uint32_t n_rows1, stride_bytes;
     const uint32_t *rows;     // [B][rstride]
@@ -259,6 +261,7 @@ struct PruneParams {
 constexpr uint32_t kPruneDetailWords = 72;
 struct ProbTables;
 void launch_prune(hipStream_t s, const PruneParams &p, const ProbTables &tb, uint32_t nq);
+void launch_block_major_build(hipStream_t s, const uint32_t *bitmap, uint32_t n_rows1, uint32_t ntiles, uint32_t stride_bytes, uint8_t *cbitmap);
 
 // memoised cmf / pmf-ratio tables for every (t, m, i), t <= tmax (rtx_prob_tables.hip)
 struct ProbTables {

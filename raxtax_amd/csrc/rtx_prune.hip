@@ -109,6 +109,80 @@ __global__ __launch_bounds__(64 * kPruneWavesPerBlock, RTX_PRUNE_WAVES) void pru
             ub_best = bq[0];
             hm = bq[2u + lane];
             M = wave_max_u32p(hm);
+        } else if (p.cbitmap) {
+            // Round 5: the database stored once more block by block -- [block][row] 8 bytes, bit j = reference 64 block + j -- so that the
+            // 64 references of the best block are ONE 8-byte load per row and lane = row: ten loads per lane for a query of 640 rows, all in
+            // flight together, from a region of 512 KB per block that neighbouring queries (same best block) keep in L2.  The walk through
+            // the tile-major bitmap below took a 128-byte line per row in eighty dependent-id loads per lane: 5.5 of this kernel's 11.9 ms
+            // per step.  A lane adds its <= 16 rows into bit-sliced counters (5 planes x 2 words), the lanes are summed as bit-sliced numbers
+            // (lane ^ 32: each keeps one word; then within the halves), and lane l reads counter l & 31 of word l >> 5: reference l.
+            static_assert(kPruneShift == 6, "a block of the block-major bitmap is the block of the bounds");
+            const uint32_t nr = p.nrows[q];
+            const uint32_t *rows = p.rows + (size_t)q * p.rstride;
+            const uint32_t zero_row = p.n_rows1 - 1u;
+            const uint32_t nr_pad = (nr + 63u) & ~63u;  // the row list is padded with the all-zero row to whole chunks of 64
+            const uint2 *C = p.cbitmap + (size_t)bb * p.n_rows1;
+            uint32_t pl[2][11];
+#pragma unroll
+            for (int w = 0; w < 2; w++)
+#pragma unroll
+                for (int b = 0; b < 11; b++) pl[w][b] = 0;
+            for (uint32_t i0 = 0; i0 < nr_pad; i0 += 256u) {  // four chunks of 64 rows per turn (a query of t <= 1023 rows: four turns at most)
+                uint32_t id[4];
+                uint2 v[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const uint32_t i = i0 + (uint32_t)k * 64u + lane;
+                    id[k] = i < nr_pad ? rows[i] : zero_row;
+                }
+#pragma unroll
+                for (int k = 0; k < 4; k++) v[k] = C[id[k]];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {  // + 1 into the counters of the set bits (at most 16 rows per lane: planes 0 .. 4)
+                    uint32_t cx = v[k].x, cy = v[k].y;
+#pragma unroll
+                    for (int b = 0; b < 5; b++) {
+                        const uint32_t nx = pl[0][b] & cx, ny = pl[1][b] & cy;
+                        pl[0][b] ^= cx;
+                        pl[1][b] ^= cy;
+                        cx = nx;
+                        cy = ny;
+                    }
+                }
+            }
+            // lane ^ 32: the lower half of the wave keeps word 0 (references 0 .. 31), the upper half word 1
+            uint32_t r[11];
+            {
+                const bool up = (lane & 32u) != 0u;
+                uint32_t o[11];
+#pragma unroll
+                for (int b = 0; b < 11; b++) {
+                    r[b] = up ? pl[1][b] : pl[0][b];
+                    o[b] = (uint32_t)__shfl_xor((int)(up ? pl[0][b] : pl[1][b]), 32, 64);
+                }
+                planes_add<11>(r, o);
+            }
+#pragma unroll
+            for (int d = 16; d >= 1; d >>= 1) {
+                uint32_t o[11];
+#pragma unroll
+                for (int b = 0; b < 11; b++) o[b] = (uint32_t)__shfl_xor((int)r[b], d, 64);
+                planes_add<11>(r, o);
+            }
+            uint32_t cnt = 0;
+#pragma unroll
+            for (int b = 0; b < 11; b++) cnt |= ((r[b] >> (lane & 31u)) & 1u) << b;
+            const uint64_t rr = ((uint64_t)bb << kPruneShift) + (uint64_t)lane;
+            bool ok = rr < p.n_refs;
+            if (p.flags & RTX_SKIP_EXACT_MATCHES) {
+                const uint64_t qin = p.perm[p.q0 + q];
+                uint64_t xe0 = 0, xe1 = 0;
+                const uint32_t *xids = nullptr;
+                exact_range(p.exact, qin, xe0, xe1, xids);
+                for (uint64_t e = xe0; e < xe1; e++) ok = ok && (uint64_t)(xids[e] - p.ref_base) != rr;  // (wave-uniform loop)
+            }
+            hm = ok ? cnt : 0u;
+            M = wave_max_u32p(hm);
         } else {
             constexpr uint32_t kChunks = (1u << kPruneShift) / 8u;  // 4 for blocks of 32
             const uint32_t nr = p.nrows[q];
@@ -475,6 +549,29 @@ __global__ __launch_bounds__(64 * kPruneWavesPerBlock, RTX_PRUNE_WAVES) void pru
         for (int k = 0; k < 8; k++) mine = lane == (uint32_t)k ? st[k] : mine;
         if (lane < 8u && mine) atomicAdd(&p.stats[(size_t)(pair & (kPruneStatCopies - 1u)) * 8u + lane], mine);
     }
+}
+
+// The block-major copy of the database bitmap (PruneParams::cbitmap) from the tile-major one: a workgroup per (row, tile), a thread per word.
+// Byte k of word (lane l, word wi) of tile T holds the references 8192 T + ((4 wi + k) L + l) 8 + [0, 8) (L = lanes of the tile): one byte of
+// the 8-byte entry of their block.  The target is zeroed first; only the non-zero bytes are written.  (A grid of two dimensions: the words of
+// a database of millions of references are more than the 2^32 work-items one dimension may hold.)
+__global__ __launch_bounds__(256) void block_major_build_kernel(const uint32_t *__restrict__ bitmap, uint32_t n_rows1, uint32_t stride_bytes,
+                                                                uint8_t *__restrict__ cbitmap) {
+    const uint32_t row = blockIdx.x, tile = blockIdx.y, word = threadIdx.x;
+    const uint32_t v = bitmap[((size_t)tile * n_rows1 + row) * 256u + word];
+    if (v == 0u) return;
+    const uint32_t l = word >> 2, wi = word & 3u, L = tile_lanes(stride_bytes, tile);
+    if (l >= L) return;
+#pragma unroll
+    for (uint32_t k = 0; k < 4u; k++) {
+        const uint32_t byte = (v >> (8u * k)) & 0xFFu;
+        if (byte == 0u) continue;
+        const uint32_t ref0 = tile * 8192u + ((wi * 4u + k) * L + l) * 8u;
+        cbitmap[((size_t)(ref0 >> 6) * n_rows1 + row) * 8u + ((ref0 & 63u) >> 3)] = (uint8_t)byte;
+    }
+}
+void launch_block_major_build(hipStream_t s, const uint32_t *bitmap, uint32_t n_rows1, uint32_t ntiles, uint32_t stride_bytes, uint8_t *cbitmap) {
+    hipLaunchKernelGGL(block_major_build_kernel, dim3(n_rows1, ntiles), dim3(256), 0, s, bitmap, n_rows1, stride_bytes, cbitmap);
 }
 
 void launch_prune(hipStream_t s, const PruneParams &p, const ProbTables &tb, uint32_t nq) {

@@ -436,7 +436,7 @@ int rtx_debug_evaluate(rtx_index *ix, const double *probs, rtx_result_view *out)
     RTX_HIP(hipMemset(ix->d_nrows_all.p, 0, 4));
     RTX_HIP(hipMemset(ix->d_hq.p, 0, 8));
     RTX_HIP(hipMemset(ix->d_z.p, 0, 8));
-    RTX_HIP(hipMemset(ix->d_cursor.p, 0, 8));
+    RTX_HIP(hipMemset(ix->d_cursor.p, 0, 16));  // both cursors: the download reads the side classes' one as well (left to the allocation it sized the host arrays by garbage)
     RTX_HIP(hipMemset(ix->d_flags.p, 0, 4));
     PrefixParams fp{};
     fp.status = ix->d_status.p;

@@ -63,7 +63,13 @@ def test_two_level_bounds_against_one_level_and_oracle(oracle, n_refs, mu):
             assert (ub2 >= ub1).all(), (name, int(q))                                   # blocks of 256 are unions of blocks of 64
             T = det2["block"] // 128
             assert ub2[T] == ub1[T] and det2["largest_bound"] == ub2[T], (name, int(q))  # the best block's tile was refined: the bound of level B
-            assert det2["largest_bound"] >= det2["M"] == int(counts_o[k][det2["block"] * 64:(det2["block"] + 1) * 64].max())
+            blk = counts_o[k][det2["block"] * 64:(det2["block"] + 1) * 64]
+            assert det2["largest_bound"] >= det2["M"] == int(blk.max())
+            # the exact counts of the best block, reference by reference (with the two-level pass they come from the block-major copy of the
+            # database, with the one-level pass from the tile-major bitmap: rtx_prune.hip)
+            assert np.array_equal(det2["block_counts"][:len(blk)], blk) and not det2["block_counts"][len(blk):].any(), (name, int(q))
+            blk1 = counts_o[k][det1["block"] * 64:(det1["block"] + 1) * 64]
+            assert np.array_equal(det1["block_counts"][:len(blk1)], blk1), int(q)
             n_equal_best += det1["block"] == det2["block"]
             n_all_equal += bool(np.array_equal(ub1, ub2))   # every tile at the one-level bound: a heavy query (the one-level pass took it), or one whose every B-tile was refined
             if name == "two/all":

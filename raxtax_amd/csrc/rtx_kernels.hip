@@ -1229,13 +1229,15 @@ void launch_taxon_prefix(hipStream_t s, const PrefixParams &p, uint32_t nq) {
     size_t lds = p.tz_in_lds ? (size_t)p.hstride * sizeof(double) : 0;
     if (p.fuse_walk) lds = std::max(lds, sizeof(WalkLds));
 #ifndef RTX_PREFIX_NW
-#define RTX_PREFIX_NW 4
+#define RTX_PREFIX_NW 2
 #endif
 #ifndef RTX_PREFIX_NW_PRUNED
 #define RTX_PREFIX_NW_PRUNED 2
 #endif
     // waves per query: NW * 512 references per sweep.  A query of a pruned run sweeps one or two tiles: two waves (more queries
-    // in flight) beat four (N = 500k, per 1 M queries: 18.2 ms with four, 14.5 with two, 15.2 with one)
+    // in flight) beat four (N = 500k, per 1 M queries: 18.2 ms with four, 14.5 with two, 15.2 with one).  A run that sweeps every tile: two as
+    // well since round 5 (131 072 short barcodes against 14 tiles: 11.7 ms with eight, 8.7 with four, 7.6 with two, 8.8 with one; 65 536 COI reads
+    // against 62 tiles, most of them skipped by their largest count: 1.2 with four, 0.8 with two) -- the kernel is short of issue slots, not of waves
     if (p.prune_thr) launch_taxon_prefix_nw<RTX_PREFIX_NW_PRUNED>(s, p, nq, lds);
     else launch_taxon_prefix_nw<RTX_PREFIX_NW>(s, p, nq, lds);
 }

@@ -90,3 +90,59 @@ def test_two_level_bounds_against_one_level_and_oracle(oracle, n_refs, mu):
     assert runs["two/all"][1][fs] == st1[fs] and runs["two/all"][1]["live_tiles_per_pair"] == st1["live_tiles_per_pair"]
     if ntiles >= 8 and mu <= 0.03:
         assert runs["two"][1]["live_tiles_per_pair"] <= 1.25 * st1["live_tiles_per_pair"], (runs["two"][1], st1)
+
+
+def test_best_block_at_the_ragged_end_of_the_database(oracle):
+    """A database that ends 37 references into a tile of its own (16 tiles + 37: the last block of 64, the last B-tile, the last A-tile and the last
+    tile are all partial) and queries drawn from those last references: their best block is the partial one.  Exact counts of the block
+    (block-major copy of the database, rtx_prune.hip), bounds and rows against the oracle and against the one-level run."""
+    n_refs, n_q = 16 * 8192 + 37, 1200
+    db = synth.make_db(n_refs)
+    qs = synth.make_queries(db, n_q, seed=9, mu_q=0.02, exact_frac=0.0)
+    L = db.length
+    refs = db.seq_bytes.reshape(n_refs, L)
+    rng = np.random.default_rng(4)
+    B = qs.bases.reshape(n_q, L)
+    tree = rx.Tree.new_flat(db.lineages, db.seq_bytes, db.seq_off, kmer_map=False)
+    orig = tree.original_index()                           # position in the (lineage-sorted) database -> record of `db`
+    for i in range(300):                                   # a quarter of the batch: relatives of the last 37 references of the database
+        s = refs[int(orig[n_refs - 1 - (i % 37)])].copy()
+        pos = rng.integers(0, L, size=12)
+        s[pos] = s[rng.integers(0, L, size=12)]
+        B[i] = s
+    otree = oracle.tree_new_flat(db.lineages, db.seq_bytes, db.seq_off)
+    last_block = (n_refs - 1) // 64
+    runs = {}
+    for name, opt in (("one", 0), ("two", 1)):
+        index = rx.Index(tree, debug_taps=True, two_level=opt)
+        res = index.classify(qs.bases, qs.base_off, *index.exact_matches(qs.bases, qs.base_off))
+        check_properties(res, db, n_q)
+        st = index.debug_prune_stats()
+        assert st["pairs"] == n_q // 2 and st["bound_violations"] == 0 and st["queries_with_threshold"] > 0.9 * n_q, (name, st)
+        sample = np.arange(0, 300, 3)
+        taps = {}
+        sub_last = set(int(q) for q in last_sub_batch_queries(index, n_q))
+        for q in sample:
+            if int(q) in sub_last:
+                taps[int(q)] = (index.debug_tile_bounds(int(q)), index.debug_prune_detail(int(q)))
+        runs[name] = (res, taps)
+    res1, taps1 = runs["one"]
+    res2, taps2 = runs["two"]
+    assert len(taps2) >= 20 and set(taps1) == set(taps2)
+    qlist = sorted(taps2)
+    sub = np.ascontiguousarray(B[qlist]).reshape(-1)
+    off = (np.arange(len(qlist) + 1) * L).astype(np.uint64)
+    t_o, counts_o = otree.hit_counts_batch(sub, off, skip_exact=False, threads=8)
+    n_last = 0
+    for k, q in enumerate(qlist):
+        for ub, det in (taps1[q], taps2[q]):
+            blk = counts_o[k][det["block"] * 64:(det["block"] + 1) * 64]
+            assert np.array_equal(det["block_counts"][:len(blk)], blk) and not det["block_counts"][len(blk):].any(), q
+            tile_max = np.concatenate([counts_o[k], np.zeros((-n_refs) % 8192, counts_o.dtype)]).reshape(-1, 8192).max(axis=1)
+            assert (ub.astype(np.int64) >= tile_max).all(), q
+        n_last += taps2[q][1]["block"] == last_block
+        assert taps1[q][1]["threshold"] > 0 and taps2[q][1]["threshold"] > 0
+    assert n_last >= 10, n_last                             # the partial block is the best block of the queries made from it
+    for f in ("row_off", "row_lineage", "t", "status"):
+        assert np.array_equal(getattr(res2, f), getattr(res1, f)), f
+    assert np.abs(res2.row_conf - res1.row_conf).max() < 1e-9

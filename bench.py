@@ -762,7 +762,8 @@ def real_composition_block(args, rx, lib, flags):
     tests/golden/diptera_queries.fasta; ~205 bp, t ~ 195) -- scaled to a 14-tile database (raxtax_amd/synth.py:
     real_composition_holdout: every database record 16 times with individual-level substitutions).  A query's best hit is a
     relative at its natural distance, k-mers common to most references give unrelated references 40 % of the best count: the regime
-    where the tile pruning buys least.  Pruned and unpruned on the same handle; inputs resident as for `value`."""
+    where the tile pruning buys least -- the handle's self-sample (include/raxtax_hip.h: rtx_index_self_sample) leaves it off.  As created, pruning
+    forced on and pruning off on the same handle; inputs resident as for `value`."""
     from raxtax_amd import synth
 
     fasta = ROOT / "tests" / "golden" / "diptera_queries.fasta"
@@ -784,22 +785,34 @@ def real_composition_block(args, rx, lib, flags):
         for _ in range(steps):
             fn()
         return (time.perf_counter() - t0) / steps
+    # the handle as it comes: its self-sample (rtx_index_self_sample: a property of the database) decides whether tile pruning runs
+    pruning_on, self_live = index.prune_verdict
     index.upload(h.q_bases, h.q_off)
     dt = timed(plain)
-    st = index.debug_prune_stats()
     stages = {s: round(ms, 3) for s, (ms, n) in index.stage_times().items() if n}
     view = index.download(copy=False)
     ok = int((np.ctypeslib.as_array(view.status, shape=(n_q,)) == 0).sum())
+    # tile pruning forced on (RTX_OPT_PRUNE_SELF_SAMPLE = 0) and off (RTX_OPT_TILE_PRUNE = 0), same handle
+    rx._lib.check(lib.rtx_index_set_option(index._h, 22, 0))
+    index.upload(h.q_bases, h.q_off)
+    dt_pruned = timed(plain)
+    st = index.debug_prune_stats()
+    stages_pruned = {s: round(ms, 3) for s, (ms, n) in index.stage_times().items() if n}
     rx._lib.check(lib.rtx_index_set_option(index._h, 13, 0))
     index.upload(h.q_bases, h.q_off)
     dt_full = timed(plain)
     stages_full = {s: round(ms, 3) for s, (ms, n) in index.stage_times().items() if n}
     ntiles = (len(h.lineages) + 8191) // 8192
-    return {"value": n_q / dt, "ms_per_step": dt * 1e3, "value_unpruned": n_q / dt_full, "ms_per_step_unpruned": dt_full * 1e3, "steps": steps,
-            "queries": n_q, "refs": len(h.lineages), "tiles": ntiles, "classified_ok": ok, "stage_ms_per_step": stages, "stage_ms_per_step_unpruned": stages_full,
+    return {"value": n_q / dt, "ms_per_step": dt * 1e3, "tile_pruning": "on" if pruning_on else "off (self-sample of the database)",
+            "self_sample_live_share": self_live, "value_pruned": n_q / dt_pruned, "ms_per_step_pruned": dt_pruned * 1e3,
+            "value_unpruned": n_q / dt_full, "ms_per_step_unpruned": dt_full * 1e3, "steps": steps,
+            "queries": n_q, "refs": len(h.lineages), "tiles": ntiles, "classified_ok": ok, "stage_ms_per_step": stages, "stage_ms_per_step_pruned": stages_pruned,
+            "stage_ms_per_step_unpruned": stages_full,
             "live_tiles_per_pair": st["live_tiles_per_pair"], "live_tiles_per_query": st.get("live_tiles_per_query"),
             "tiles_above_threshold_per_query": st["tiles_above_threshold_per_query"], "mean_threshold": st["mean_threshold"],
             "mean_best_hit_lower_bound": st["mean_best_hit_lower_bound"], "share_with_threshold": st["queries_with_threshold"] / n_q,
+            "what": "value: the handle as created (tile pruning as its self-sample decided); value_pruned: pruning forced on; value_unpruned: pruning off; "
+                    "live tiles, thresholds: of the forced pruned run",
             "workload": f"{h.n_records_held_out} held-out Diptera COI records (~205 bp) as {n_q} queries vs the other {h.n_records_db} records x 16 "
                         f"individual-level copies = {len(h.lineages)} references (scripts/common.py:11-25 hold-out methodology)"}
 

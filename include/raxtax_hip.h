@@ -244,9 +244,26 @@ int rtx_index_set_batch(rtx_index *index, uint32_t sub_batch);
                                      * tiles are proven dead before counting (a function of the query alone).  0: the one-level pass
                                      * over blocks of 64 (reference shards always use it).  Values above 1 set the rule that picks the
                                      * refined groups (experiments): c_t | c_m << 16 | lo << 32 | hi << 48, in 1/256 of t. */
+#define RTX_OPT_PRUNE_SELF_SAMPLE 22 /* 1 (default): the handle honours the verdict of rtx_index_self_sample (taken when the handle is created
+                                      * from the reference sequences or from a tree): on a database whose own references keep 85 % or more
+                                      * of its tiles live -- every tile holds relatives of every query: real barcodes of one order -- tile
+                                      * pruning stays off whatever RTX_OPT_TILE_PRUNE says (bounds and thresholds would cost more than they
+                                      * save).  0: RTX_OPT_TILE_PRUNE alone decides.  Shapes the workspace like RTX_OPT_TILE_PRUNE */
 /* RTX_OPT_SUB_BATCH, _PACKED_COUNTS, _HIT_PAIR, _TILE_PRUNE and _PROB_MODE shape the workspace that rtx_batch_upload sizes:
  * setting one of them drops the uploaded batch (rtx_batch_run then fails with RTX_ERR_STATE until the batch is uploaded again). */
 int rtx_index_set_option(rtx_index *index, int option, uint64_t value);
+
+/* Does tile pruning pay on this database?  Classifies every (n_refs / n_sample)-th reference (n_sample = 0: 1024) as a query with its
+ * exact copies left out (RTX_SKIP_EXACT_MATCHES) and tile pruning on, and keeps the share of (query, tile) combinations that stayed live:
+ * from 0.85 on the handle leaves tile pruning off (see RTX_OPT_PRUNE_SELF_SAMPLE).  A property of the database: the results of a query
+ * never depend on the rest of its batch.  rtx_index_create_from_sequences / _from_tree call it themselves; a handle built from postings
+ * (rtx_index_create) has no sequences and keeps pruning on until the caller passes them here.  seq_bytes / seq_off as in
+ * rtx_index_create_from_sequences (the references in the order of the handle).  *live_fraction (may be NULL): the share, or -1 where there
+ * was nothing to decide (a reference shard, fewer than 4 tiles, no union bitmap).  Any uploaded batch is dropped.
+ * The reference has no counterpart: it counts every reference for every query (raxtax.rs:58-64). */
+int rtx_index_self_sample(rtx_index *index, const uint8_t *seq_bytes, const uint64_t *seq_off, uint64_t n_refs, uint32_t n_sample, double *live_fraction);
+/* *pruning: 1 if tile pruning is on for this handle (RTX_OPT_TILE_PRUNE and the verdict above); *live_fraction: the share the sample kept live, -1 without a sample */
+int rtx_index_prune_verdict(const rtx_index *index, int *pruning, double *live_fraction);
 /* Process-wide default for handles created afterwards.  RTX_DEFAULT_SEGMENT_CLASSES (default 1): at index creation
  * every (row, tile) segment of the bitmaps is classified; empty segments are never read and segments with at most
  * 16 references are added from 32-byte slots through byte counters instead of 1-KiB row reads (rtx_segments.hip).

@@ -220,7 +220,8 @@ class Index:
                  packed_counts: Optional[bool] = None,
                  tile_skip: Optional[bool] = None, hit_pair=None, locator: Optional[bool] = None, tile_prune: Optional[bool] = None,
                  debug_taps: bool = False, device_exact: Optional[bool] = None, fine_bounds: Optional[bool] = None,
-                 records: Optional[int] = None, overlap: Optional[bool] = None, two_level: Optional[int] = None):
+                 records: Optional[int] = None, overlap: Optional[bool] = None, two_level: Optional[int] = None,
+                 prune_self_sample: Optional[bool] = None):
         self._lib = _lib.load()
         self.tree = tree
         if segment_classes is None:
@@ -260,8 +261,17 @@ class Index:
             check(self._lib.rtx_index_set_option(self._h, 19, int(overlap)))
         if two_level is not None:  # RTX_OPT_TWO_LEVEL_BOUNDS: 0 = the bounds pass over blocks of 64 throughout (values above 1: the refine rule, packed)
             check(self._lib.rtx_index_set_option(self._h, 21, int(two_level)))
+        if prune_self_sample is not None:  # RTX_OPT_PRUNE_SELF_SAMPLE: False = RTX_OPT_TILE_PRUNE alone decides (tests of the pruned path on real barcodes)
+            check(self._lib.rtx_index_set_option(self._h, 22, int(prune_self_sample)))
         self._view = ResultView()
         self._keep = None
+
+    @property
+    def prune_verdict(self):
+        """(tile pruning is on for this handle, share of (query, tile) combinations its self-sample kept live or -1): rtx_index_prune_verdict."""
+        on, frac = C.c_int(), C.c_double()
+        check(self._lib.rtx_index_prune_verdict(self._h, C.byref(on), C.byref(frac)))
+        return bool(on.value), float(frac.value)
 
     def __del__(self):
         try:

@@ -583,7 +583,7 @@ int begin_run(rtx_index *ix, uint32_t *n_sub_out, bool *timed_out, bool cluster)
         // two neighbours per wave only pays when neighbours are related: with the processing order on
         k.pair = ix->pair_opt && cluster && k.planes <= 10 && ix->n_q > 1 && k.rstride <= 4096;
         const rtx_index::Scratch &s0 = ix->sc[k.side ? kSideSet : 0u];  // (a side class runs through the set of its own)
-        k.prune = ix->prune_opt && k.pair && k.use_tables && ix->tile_skip && ix->d_ubitmap.p && (whole || shard) &&
+        k.prune = ix->pruning() && k.pair && k.use_tables && ix->tile_skip && ix->d_ubitmap.p && (whole || shard) &&
                   scratch_ok(s0, k.sub_batch) && (!ix->staged || scratch_ok(ix->sc[1], k.sub_batch));
         k.rec = k.prune && whole && ix->rec_opt != 0u && ix->n_bnd_local == ix->n_bnd && s0.d_rec.p != nullptr &&
                 s0.d_rec.n >= (size_t)k.sub_batch * std::min<uint32_t>(ix->rec_opt, kRecMaxSlots) * 8192u;
@@ -837,7 +837,7 @@ int prepare_workspace(rtx_index *ix, uint64_t n_queries, const uint64_t cls_n_in
     // ... and a handful of reads of a few kilobases with the longer ones (one set of launches; the global-memory forms compute the same values)
     if (cn[2] && cn[3] && cn[2] + cn[3] <= kSideMaxQueries) { cn[3] += cn[2]; cm[3] = std::max(cm[3], cm[2]); cn[2] = 0; cm[2] = 0; }
     const uint64_t key[14] = {n_queries, cn[0], cn[1], cn[2], cn[3], cm[0], cm[1], cm[2], cm[3], ix->sub_batch_req,
-                              (uint64_t)ix->packed_opt | (uint64_t)ix->pair_opt << 1 | (uint64_t)ix->prune_opt << 2 | (uint64_t)ix->shard_prune_opt << 3 | (uint64_t)ix->fine_opt << 4 |
+                              (uint64_t)ix->packed_opt | (uint64_t)ix->pair_opt << 1 | (uint64_t)ix->pruning() << 2 | (uint64_t)ix->shard_prune_opt << 3 | (uint64_t)ix->fine_opt << 4 |
                                   (uint64_t)(ix->prob_mode & 3) << 5 | (uint64_t)ix->rec_opt << 8 | (uint64_t)ix->overlap_opt << 16 | (uint64_t)ix->min_subs << 20,
                               (uint64_t)ix->n_bnd_local, ix->shared_device ? 1u : 0u, 0};
     // A batch of the shape of the last one under the same options (the chunks of rtx_raxtax): everything below would come out the same --
@@ -932,7 +932,7 @@ static int size_workspace(rtx_index *ix, uint64_t n_queries) {
     uint64_t worst = 0;
     for (uint32_t c = 0; c < ix->n_cls; c++) {
         rtx_index::BatchClass &k = ix->cls[c];
-        k.will_prune = ix->prune_opt && ix->d_ubitmap.p && ix->pair_opt && ix->ntiles >= RTX_PRUNE_MIN_TILES && k.tmax <= 1023 && (ix->n_refs == ix->n_total || ix->shard_prune_opt);  // begin_run decides
+        k.will_prune = ix->pruning() && ix->d_ubitmap.p && ix->pair_opt && ix->ntiles >= RTX_PRUNE_MIN_TILES && k.tmax <= 1023 && (ix->n_refs == ix->n_total || ix->shard_prune_opt);  // begin_run decides
         const uint64_t per_q = class_per_q(ix, k);
         uint32_t B = ix->sub_batch_req;
         if (B == 0) {
@@ -1020,7 +1020,7 @@ int alloc_scratch_set(rtx_index *ix, uint32_t k) {
         (rc = sc.d_urec.alloc(n_urec)) || (rc = sc.d_nu.alloc((B + 1u) / 2u)))
         return rc;
     if (n_probscr && (rc = ix->d_prob_scratch.alloc(std::max(n_probscr, ix->d_prob_scratch.n)))) return rc;
-    if (ix->prune_opt && ix->d_ubitmap.p && (ix->n_refs == ix->n_total || ix->shard_prune_opt)) {
+    if (ix->pruning() && ix->d_ubitmap.p && (ix->n_refs == ix->n_total || ix->shard_prune_opt)) {
         if ((rc = sc.d_tile_ub.alloc(B * ix->ntiles)) || (rc = sc.d_best_key.alloc(B)) || (rc = sc.d_prune_thr.alloc(B)) || (rc = sc.d_prune_i1.alloc(B)) || (rc = sc.d_best.alloc(B * kPruneBestWords)) || (rc = sc.d_live.alloc((B + 1u) * ((ix->ntiles + 31u) / 32u + 1u))) ||
             (rc = sc.d_items.alloc(((B + 1u) / 2u) * (ix->ntiles + 2u) + 9u)))
             return rc;

@@ -577,6 +577,7 @@ int rtx_index_create_from_sequences(int device, uint64_t n_refs, const uint8_t *
         if (hipStreamSynchronize(ix->stream) != hipSuccess) { (void)hipGetLastError(); ix->d_fbitmap.release(); }
     }
     *out = ix;
+    if (!g_from_tree) (void)rtx_index_self_sample(ix, seq_bytes, seq_off, n_refs, 0, nullptr);  // (from a tree: once its exact-match table is in place)
     return RTX_OK;
 }
 
@@ -598,7 +599,10 @@ int rtx_index_create_from_tree(int device, const rtx_tree *tree, rtx_index **out
                                                        f.begin.data(), f.end.data(), f.first_child.data(), f.n_children.data(),
                                                        f.type.data(), out);
         g_from_tree = false;
-        if (rc == RTX_OK) exact_table_from_tree(*out, tree);
+        if (rc == RTX_OK) {
+            exact_table_from_tree(*out, tree);
+            (void)rtx_index_self_sample(*out, tree->seq_bytes.data(), tree->seq_off.data(), tree->num_tips, 0, nullptr);
+        }
         return rc;
     }
     int rc = rtx_index_create(device, tree->num_tips, tree->csr_off.data(), tree->postings.data(), f.size(), f.begin.data(),
@@ -620,7 +624,60 @@ int rtx_index_create_from_tree(int device, const rtx_tree *tree, rtx_index **out
             if (e == hipSuccess) build_locator(ix, d_seq.p, d_off.p, n);
             else (void)hipGetLastError();
         }
+        (void)rtx_index_self_sample(ix, tree->seq_bytes.data(), tree->seq_off.data(), n, 0, nullptr);
     }
+    return RTX_OK;
+}
+
+// Does tile pruning pay on this database?  It pays when a query has close relatives in a few tiles and nothing elsewhere: the bounds pass
+// and the thresholds (rtx_prune.hip) cost about what counting two or three tiles costs.  On a database whose every tile holds relatives of
+// every query (real barcodes of one order: the conserved part of the marker is everywhere) they are pure overhead -- 29.1 against 27.5 ms per
+// 131 072 reads on the Diptera records of the reference's example data.  Whether a database is of that kind is a property of the DATABASE:
+// every (n_refs / n_sample)-th reference is classified as a query with its exact copies left out (raxtax.rs:65-68), pruning on, and the
+// share of (query, tile) combinations that stay live is taken.  A reference is at least as close to the database as any query from
+// outside, so its threshold is at least as high: where the sample keeps most tiles live, every real query will.  The Diptera database
+// keeps 95 % (synthetic clades: 7 %).  From kSelfSampleOff on the handle leaves tile pruning off (RTX_OPT_PRUNE_SELF_SAMPLE = 0 ignores
+// the verdict).  The decision is a function of the database alone: results never depend on what else is in a batch.
+// Called by rtx_index_create_from_sequences / _from_tree; a caller that built the handle from postings may call it with the sequences.
+static constexpr double kSelfSampleOff = 0.85;
+int rtx_index_self_sample(rtx_index *ix, const uint8_t *seq_bytes, const uint64_t *seq_off, uint64_t n_refs, uint32_t n_sample, double *live_fraction) {
+    if (live_fraction) *live_fraction = -1.0;
+    if (!ix || !seq_bytes || !seq_off) { set_error("null argument"); return RTX_ERR_INVALID; }
+    ix->prune_pays = true;
+    ix->self_live = -1.0;
+    if (ix->n_refs != ix->n_total || n_refs != ix->n_total || !ix->d_ubitmap.p || ix->ntiles < RTX_PRUNE_MIN_TILES) return RTX_OK;  // nothing to decide
+    const uint64_t n = std::min<uint64_t>(n_sample ? n_sample : 1024u, n_refs);
+    std::vector<uint64_t> off(n + 1, 0);
+    std::vector<uint8_t> bases;
+    for (uint64_t i = 0; i < n; i++) {
+        const uint64_t r = i * n_refs / n;
+        bases.insert(bases.end(), seq_bytes + seq_off[r], seq_bytes + seq_off[r + 1]);
+        off[i + 1] = bases.size();
+    }
+    if (bases.empty()) return RTX_OK;
+    const uint32_t prune_was = ix->prune_opt, taps_was = ix->debug_taps;
+    ix->prune_opt = 1u;
+    ix->debug_taps = 0u;
+    uint64_t st[16] = {0};
+    int rc = rtx_batch_upload(ix, n, bases.data(), off.data(), nullptr, nullptr);
+    if (rc == RTX_OK) rc = rtx_batch_run(ix, RTX_SKIP_EXACT_MATCHES);
+    if (rc == RTX_OK) rc = rtx_batch_sync(ix);
+    if (rc == RTX_OK) rc = rtx_debug_prune_stats(ix, st);
+    ix->prune_opt = prune_was;
+    ix->debug_taps = taps_was;
+    ix->uploaded = ix->ran = ix->synced = false;  // the sample is not a batch of the caller's
+    if (rc != RTX_OK) return RTX_OK;              // (no verdict: pruning stays as the options say; the error text stays readable)
+    if (st[5] != 0) {
+        ix->self_live = (double)st[7] / ((double)st[5] * (double)ix->ntiles);
+        ix->prune_pays = ix->self_live < kSelfSampleOff;
+    }
+    if (live_fraction) *live_fraction = ix->self_live;
+    return RTX_OK;
+}
+int rtx_index_prune_verdict(const rtx_index *ix, int *pruning, double *live_fraction) {
+    if (!ix) { set_error("null index handle"); return RTX_ERR_INVALID; }
+    if (pruning) *pruning = ix->pruning() ? 1 : 0;
+    if (live_fraction) *live_fraction = ix->self_live;
     return RTX_OK;
 }
 
@@ -697,6 +754,10 @@ int rtx_index_set_option(rtx_index *index, int option, uint64_t value) {
             return RTX_OK;
         case RTX_OPT_FINE_BOUNDS:
             index->fine_opt = value ? 1u : 0u;
+            return RTX_OK;
+        case RTX_OPT_PRUNE_SELF_SAMPLE:
+            index->uploaded = index->ran = index->synced = false;  // shapes the workspace (the scratch of the tile pruning)
+            index->self_sample_opt = value ? 1u : 0u;
             return RTX_OK;
         case RTX_OPT_TWO_LEVEL_BOUNDS:
             index->two_level_opt = value ? 1u : 0u;

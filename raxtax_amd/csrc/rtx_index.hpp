@@ -166,6 +166,10 @@ struct rtx_index {
     uint32_t tile_skip = 1;   // RTX_OPT_TILE_SKIP: taxon_prefix reads only the tiles that hold a reference with p >= 1e-30
     uint32_t pair_opt = 1;    // RTX_OPT_HIT_PAIR
     uint32_t prune_opt = 1;   // RTX_OPT_TILE_PRUNE: hit_count visits only the tiles that can hold a reference with any probability (rtx_prune.hip)
+    uint32_t self_sample_opt = 1;  // RTX_OPT_PRUNE_SELF_SAMPLE: the verdict of rtx_index_self_sample is honoured
+    bool prune_pays = true;        // ... which is: a sample of the database's own references keeps fewer than kSelfSampleOff of its tiles live
+    double self_live = -1.0;       // the share of (query, tile) combinations the sample kept live (-1: no sample was taken)
+    bool pruning() const { return prune_opt != 0u && (prune_pays || self_sample_opt == 0u); }  // tile pruning is on for this handle (where the batch allows it)
     bool prune_used = false;  // the last run pruned
     bool dbg_full = false;    // ... and the debug taps have recounted the last sub-batch in full since
     bool dbg_full_run = false;  // (the recount in progress: enqueue_hit leaves the pruning out)

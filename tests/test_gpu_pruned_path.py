@@ -133,7 +133,7 @@ def test_real_composition_short_reads(oracle, emul):
     bases = np.concatenate(qs)
     otree = oracle.tree_new_flat(lineages, flat, off)
     tree = rx.Tree.new_flat(lineages, flat, off, kmer_map=False)
-    index = rx.Index(tree, debug_taps=True)
+    index = rx.Index(tree, debug_taps=True, prune_self_sample=False)   # (a database of near-copies: its self-sample would leave tile pruning off)
     ex_ids, ex_off = index.exact_matches(bases, qoff)
     lf = np.array([oracle.lib.orc_ln_factorial(i) for i in range(2 * 210 + 8)], dtype=np.float64)
     olin = None
@@ -277,3 +277,33 @@ def test_shards_that_disagree_on_pruning_fall_back_together(oracle):
     assert not any(s.prunes for s in shards) and clf._prunes is False
     assert np.array_equal(got.t, ref.t) and np.array_equal(got.row_off, ref.row_off) and np.array_equal(got.row_lineage, ref.row_lineage)
     assert np.max(np.abs(got.row_conf - ref.row_conf)) < 1e-9 and np.max(np.abs(got.global_signal - ref.global_signal)) < 1e-9
+
+
+def test_self_sample_decides_per_database():
+    """rtx_index_self_sample (RTX_OPT_PRUNE_SELF_SAMPLE): a database of clades that have nothing to do with each other keeps tile pruning,
+    a database whose every tile holds relatives of every query (the Diptera records, expanded) leaves it off -- and the rows of a batch are
+    the same either way (what pruning drops never reaches a row; test_real_composition_short_reads holds the pruned run against the oracle)."""
+    db = synth.make_db(60_000)
+    ix = rx.Index(rx.Tree.new_flat(db.lineages, db.seq_bytes, db.seq_off, kmer_map=False))
+    on, frac = ix.prune_verdict
+    assert on and 0.0 < frac < 0.5, (on, frac)
+    qs = synth.make_queries(db, 512, seed=2)
+    ix.classify(qs.bases, qs.base_off)
+    assert ix.debug_prune_stats()["pairs"] == 256
+
+    # the database of bench.py's value_real_composition: the reference's hold-out methodology on its Diptera records, 14 tiles
+    h = synth.real_composition_holdout(FASTA.parent / "diptera_queries.fasta", n_queries=2048)
+    tree = rx.Tree.new_flat(h.lineages, h.seq_bytes, h.seq_off, kmer_map=False)
+    auto, forced = rx.Index(tree), rx.Index(tree, prune_self_sample=False)
+    on, frac = auto.prune_verdict
+    assert not on and frac >= 0.85, (on, frac)
+    assert forced.prune_verdict[0] and forced.prune_verdict[1] == frac
+    bases, qoff = h.q_bases, h.q_off
+    n_queries = len(qoff) - 1
+    a = auto.classify(bases, qoff)
+    assert auto.debug_prune_stats()["pairs"] == 0             # every tile counted
+    b = forced.classify(bases, qoff)
+    assert forced.debug_prune_stats()["pairs"] == n_queries // 2
+    for f in ("row_off", "row_lineage", "t", "status"):
+        assert np.array_equal(getattr(a, f), getattr(b, f)), f
+    assert np.abs(a.row_conf - b.row_conf).max() < 1e-9

@@ -80,7 +80,8 @@ def test_records_slow_path_when_entries_do_not_fit_lds(oracle):
     q = synth.ONE_HOT[synth._mutate(rng, seqs[qsrc], 0.01)].reshape(-1)
     qoff = np.arange(n_q + 1, dtype=np.uint64) * np.uint64(L)
     tree = rx.Tree.new_flat(lineages, seq_bytes, seq_off, kmer_map=False)
-    index = rx.Index(tree)
+    index = rx.Index(tree, prune_self_sample=False)   # (near-identical references: the handle's self-sample leaves tile pruning off here -- the test is about the pruned path)
+    assert rx.Index(tree).prune_verdict[0] is False
     res = index.classify(q, qoff)
     st = index.debug_prune_stats()
     print("near-identical references:", st)

@@ -6,7 +6,7 @@ import raxtax_amd as rx
 from raxtax_amd import synth, checks
 h = synth.real_composition_holdout(Path('tests/golden/diptera_queries.fasta'))
 tree = rx.Tree.new_flat(h.lineages, h.seq_bytes, h.seq_off, kmer_map=False)
-index = rx.Index(tree, debug_taps=True)
+index = rx.Index(tree, debug_taps=True, prune_self_sample=False)
 n_q = len(h.q_off) - 1
 index.upload(h.q_bases, h.q_off); index.run(0); res = index.download()
 qs = checks.last_sub_batch_queries(index, n_q)[:300]

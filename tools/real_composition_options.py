@@ -15,7 +15,7 @@ tree = rx.Tree.new_flat(h.lineages, h.seq_bytes, h.seq_off, kmer_map=False)
 n_q = len(h.q_off) - 1
 for name, opts in (("default", {}), ("min_sub_batches=2", {20: 2}), ("min_sub_batches=1", {20: 1}), ("min_sub_batches=8", {20: 8}), ("overlap=0", {19: 0}),
                    ("sub_batch=65536", {1: 65536}), ("sub_batch=16384", {1: 16384})):
-    index = rx.Index(tree)
+    index = rx.Index(tree, prune_self_sample=False)
     for k, v in opts.items():
         rx._lib.check(index._lib.rtx_index_set_option(index._h, k, v))
     out = []

@@ -16,7 +16,7 @@ steps = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 h = synth.real_composition_holdout(ROOT / "tests" / "golden" / "diptera_queries.fasta")
 tree = rx.Tree.new_flat(h.lineages, h.seq_bytes, h.seq_off, kmer_map=False)
 records = int(sys.argv[2]) if len(sys.argv) > 2 else None   # RTX_OPT_RECORDS: live tiles up to which a pruned query takes the records path
-index = rx.Index(tree, stage_timing=True, records=records)
+index = rx.Index(tree, stage_timing=True, records=records, prune_self_sample=False)   # (prune=1 below means pruning ON: the verdict of the self-sample is set aside)
 n_q = len(h.q_off) - 1
 index.upload(h.q_bases, h.q_off)
 for prune in (1, 0):

@@ -372,6 +372,12 @@ int main(int argc, char **argv) {
             }
     }
     lap("index");
+    if (timing) {  // the handle's own verdict on tile pruning (rtx_index_self_sample: a property of the database)
+        int on = 1;
+        double share = -1.0;
+        if (rtx_index_prune_verdict(indices[0], &on, &share) == RTX_OK && share >= 0.0)
+            fprintf(stderr, "[TIMING] tile pruning %s: a sample of the database's own references keeps %.1f %% of its tiles live\n", on ? "on" : "off", 100.0 * share);
+    }
     start_bin_writer();  // after the index: rtx_index_create_from_tree looks at the tree's k-mer map
     Sink sink;
     const auto mode = (redo || !resume) ? std::ios::trunc : std::ios::app;

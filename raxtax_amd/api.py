@@ -249,6 +249,8 @@ class Index:
             check(self._lib.rtx_index_set_option(self._h, 12, int(locator)))
         if tile_prune is not None:
             check(self._lib.rtx_index_set_option(self._h, 13, int(tile_prune)))
+            if tile_prune and prune_self_sample is None:   # an explicit True asks for the pruned path whatever the handle's self-sample said (A/B tests)
+                check(self._lib.rtx_index_set_option(self._h, 22, 0))
         if debug_taps:
             check(self._lib.rtx_index_set_option(self._h, 14, 1))
         if device_exact is not None:

@@ -94,10 +94,12 @@ def unpack_records(buf: np.ndarray) -> dict:
                 row_depth=depth, row_conf=conf, row_local_signal=local)
 
 
-def format_records(tree, buf: np.ndarray, labels, exact_one=None, flags: int = 0, threads: int = 0):
+def format_records(tree, buf: np.ndarray, labels, exact_one=None, flags: int = 0, threads: int = 0, out: Optional[np.ndarray] = None):
     """The `.out` texts of every query of one packed record buffer, formatted natively (rtx_records_format: what a writer on rank 0 does
     with the gathered records of a rank).  labels: the labels of the buffer's queries; exact_one: per query the id of its only exact
-    match or 0xFFFFFFFF (raxtax.rs:73-84) or None.  Returns (text bytes, line_off[n + 1])."""
+    match or 0xFFFFFFFF (raxtax.rs:73-84) or None.  out: a uint8 buffer of the caller's to format into (a writer keeps one per rank: a
+    fresh 190-MB array per call is 26 000 first-touch page faults inside the call); it is used if it is large enough.
+    Returns (text bytes, line_off[n + 1])."""
     import ctypes as C
 
     from . import _lib
@@ -113,8 +115,11 @@ def format_records(tree, buf: np.ndarray, labels, exact_one=None, flags: int = 0
         raise _lib.RtxError(-1, "format_records: not a record buffer of this version")
     off = np.zeros(n_q + 1, dtype=np.uint64)
     cap = 4 * len(buf) + (1 << 20)     # text is ~2.3 x the records on the bench workload: one pass as a rule ...
-    for _ in range(2):
-        out = np.empty(cap, dtype=np.uint8)
+    for attempt in range(2):
+        if attempt or out is None or out.dtype != np.uint8 or not out.flags.c_contiguous or len(out) < cap:
+            out = np.empty(cap, dtype=np.uint8)
+        else:
+            cap = len(out)
         n = lib.rtx_records_format(tree._h, _lib.ptr(buf, _lib.u8p), len(buf), arr, exp, flags, out.ctypes.data_as(C.c_char_p), cap, _lib.ptr(off, _lib.u64p), threads)
         if n >= 0:
             return out[:n], off

@@ -14,10 +14,13 @@ rec = dist_util.pack_records(None, rng.integers(0, 500_000, n_rows), np.full(n_r
 db = synth.make_db(500_000)
 tree = rx.Tree.new_flat(db.lineages, db.seq_bytes, db.seq_off, kmer_map=False)
 labels = (ctypes.c_char_p * n_q)(*[f"q{i}".encode() for i in range(n_q)])
+keep = np.empty(4 * len(rec) + (1 << 20), np.uint8)   # the writer's buffer, touched once
 for nt in (1, 4, 8, 16):
-    dist_util.format_records(tree, rec, labels, threads=nt)
-    t0 = time.perf_counter()
-    for _ in range(3):
-        text, off = dist_util.format_records(tree, rec, labels, threads=nt)
-    dt = (time.perf_counter() - t0) / 3
-    print(f"{nt} threads: {1e3*dt:.0f} ms per 1 M queries ({len(text)/1e6:.0f} MB), {1e9*dt*nt/n_q:.0f} ns of one thread per query")
+    for reuse in (False, True):
+        dist_util.format_records(tree, rec, labels, threads=nt, out=keep if reuse else None)
+        t0 = time.perf_counter()
+        for _ in range(3):
+            text, off = dist_util.format_records(tree, rec, labels, threads=nt, out=keep if reuse else None)
+        dt = (time.perf_counter() - t0) / 3
+        print(f"{nt} threads, {'the same output buffer every call' if reuse else 'a fresh output array per call'}: {1e3*dt:.0f} ms per 1 M queries "
+              f"({len(text)/1e6:.0f} MB), {1e9*dt*nt/n_q:.0f} ns of one thread per query", flush=True)

@@ -54,11 +54,15 @@ def worker(rank, world, port, n_q, steps):
         tree = rx.Tree.new_flat(db.lineages, db.seq_bytes, db.seq_off, kmer_map=False)
         labels = (ctypes.c_char_p * n_q)(*[f"q{i}".encode() for i in range(n_q)])
         nt = os.cpu_count()
-        dist_util.format_records(tree, parts[0], labels, threads=nt)    # (first touch of the tree's strings)
+        # the writer keeps one output buffer per rank and formats into them step after step (a fresh 190-MB array per call costs 26 000 first-touch
+        # page faults inside the call: 14 against 13 ms per rank on the bench host, 52 against 34 in an 8-CPU container)
+        keep = [np.empty(4 * len(p_) + (1 << 20), np.uint8) for p_ in parts]
+        for p_, k_ in zip(parts, keep):
+            dist_util.format_records(tree, p_, labels, threads=nt, out=k_)    # (first touch of the tree's strings and of the buffers)
         t0 = time.perf_counter()
         n_bytes = 0
-        for p_ in parts:
-            text, off = dist_util.format_records(tree, p_, labels, threads=nt)
+        for p_, k_ in zip(parts, keep):
+            text, off = dist_util.format_records(tree, p_, labels, threads=nt, out=k_)
             n_bytes += len(text)
         t_fmt = time.perf_counter() - t0
         print(f"rank 0 formats the records of {world} ranks ({world * n_q} queries) into {n_bytes / 1e6:.0f} MB of .out lines in {1e3 * t_fmt:.0f} ms on {nt} threads "

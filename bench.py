@@ -92,6 +92,12 @@ def parse():
     ap.add_argument("--mu-q", type=float, default=0.02, help="per-site substitution rate of a query against its source reference (the headline: 0.02)")
     ap.add_argument("--exact-frac", type=float, default=0.10, help="share of the queries that are exact copies of a reference (the headline: 0.10)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--host-share", type=int, default=0,
+                    help="rtx_set_host_share(K): size every host pool of the library as if K ranks shared this host's CPUs (K = 8 on a 16-CPU grant: "
+                         "two threads -- what a rank of the 8-GPU line gets); 0 = LOCAL_WORLD_SIZE or 1")
+    ap.add_argument("--host-cpus", type=int, default=0,
+                    help="restrict this process (and every thread it starts: HIP runtime, library pools) to its first C CPUs with sched_setaffinity before "
+                         "anything is loaded -- the stricter rehearsal of a rank's CPU share (0 = leave the affinity mask alone)")
     ap.add_argument("--no-parity", action="store_true", help="N > 1: skip the self-check of the line (rank 0 holds a seeded sample of every rank's gathered records against the oracle)")
     ap.add_argument("--no-extras", action="store_true", help="only the headline: no H2D / end-to-end / unpruned legs, no divergence sweep")
     ap.add_argument("--host-exact-match", action="store_true",
@@ -910,6 +916,8 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
+    if args.host_cpus:
+        os.sched_setaffinity(0, sorted(os.sched_getaffinity(0))[:args.host_cpus])
     import torch
 
     if not torch.cuda.is_available():
@@ -936,6 +944,8 @@ def main():
     db = synth.make_db(args.refs)
     flags = rx.RTX_SKIP_EXACT_MATCHES if args.skip_exact_matches else 0
     lib = rx._lib.load()
+    if args.host_share:
+        rx._lib.check(lib.rtx_set_host_share(args.host_share))
     L = db.length
 
     if args.shard_db:
@@ -1105,6 +1115,7 @@ def main():
                                   else {"backend": None, "world_size": 1}),
                 "classified_ok": ok, "skip_exact_matches": bool(args.skip_exact_matches),
                 "host_threads_per_rank": int(lib.rtx_host_threads()),      # affinity mask capped by the cgroup quota, divided by the ranks on this host
+                "host_share": args.host_share or int(os.environ.get("LOCAL_WORLD_SIZE", "1")),
                 "gathered_queries_last_step": (gathered_q[0] if (dist is not None and not args.shard_db) else None),
                 "sub_batch": int(round(args.queries / max(stage_n["hit_count"] / args.steps, 1))) if stage_n["hit_count"] else None,
                 "exact_match_lookup": ("host hash map, once, untimed: %.3f s" % t_exact) if t_exact is not None else

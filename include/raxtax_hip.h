@@ -32,8 +32,11 @@
 extern "C" {
 #endif
 
-#define RTX_ABI_VERSION 4 /* 2: rtx_result_view.row_begin/row_count replace row_off; 3: exact_off == NULL = look the exact matches up on the device;
-                             4: RTX_NUM_STAGES 8 -> 10 (rtx_batch_stage_times writes ten entries), rtx_batch_prefetch / rtx_batch_activate */
+#define RTX_ABI_VERSION 5 /* 2: rtx_result_view.row_begin/row_count replace row_off; 3: exact_off == NULL = look the exact matches up on the device;
+                             4: RTX_NUM_STAGES 8 -> 10 (rtx_batch_stage_times writes ten entries), rtx_batch_prefetch / rtx_batch_activate;
+                             5: rtx_result_view grows row_conf_stride, row_depth_u8, row_conf_hundredths (the rows are finalised on the device and
+                                arrive in their final layout: row_conf is [n_rows][row_conf_stride], no longer [n_rows][RTX_MAX_DEPTH]); the exports
+                                and options of round 5 (rtx_index_self_sample, rtx_records_format, options 18-22) */
 #define RTX_NUM_KMERS 65536u /* 2 << 15 posting lists, src/tree.rs:52 */
 #define RTX_MAX_DEPTH 32u    /* deepest lineage (comma-separated levels) the device walk carries */
 
@@ -293,8 +296,15 @@ typedef struct {
     const uint32_t *row_lineage;   /* [n_rows] index into tree.lineages (lineage.rs:105)             */
     const uint32_t *row_node;      /* [n_rows] node id (rtx_nodes_view numbering)                    */
     const uint32_t *row_depth;     /* [n_rows] number of confidence values                           */
-    const double *row_conf;        /* [n_rows][RTX_MAX_DEPTH] confidence_values, rounded to 2 decimals */
+    const double *row_conf;        /* [n_rows][row_conf_stride] confidence_values, rounded to 2 decimals; entries from row_depth on are 0 */
     const double *row_local_signal;/* [n_rows] lineage.rs:95-102                                     */
+    /* ABI 5.  The rows leave the device finalised (rtx_finalise.hip: sorted as lineage.rs:91-93 asks, local signal computed, final
+     * layout), the host copies them and nothing else.  row_conf_stride = the deepest lineage of the tree (0 in a view a caller fills
+     * by hand = RTX_MAX_DEPTH, the layout of ABI <= 4).  The two byte arrays carry what rtx_result_pack ships (NULL in a hand-made
+     * view: the pack converts). */
+    uint32_t row_conf_stride;
+    const uint8_t *row_depth_u8;        /* [n_rows] row_depth as a byte                                   */
+    const uint8_t *row_conf_hundredths; /* [n_rows][row_conf_stride] round(confidence * 100), lineage.rs:128-129 */
 } rtx_result_view;
 
 /* Whole path for one batch of queries: H2D, kernels, D2H, host finalisation (sort

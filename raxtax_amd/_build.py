@@ -14,7 +14,7 @@ PKG = Path(__file__).resolve().parent
 ROOT = PKG.parent
 CSRC = PKG / "csrc"
 LIB = PKG / "libraxtax_hip.so"
-SOURCES = ["rtx_kernels.hip", "rtx_hit_pair.hip", "rtx_prob_tables.hip", "rtx_cluster.hip", "rtx_segments.hip", "rtx_prune.hip", "rtx_bounds2.hip", "rtx_records.hip", "rtx_exact.hip", "rtx_ingest.hip", "rtx_api_index.hip", "rtx_api_batch.hip", "rtx_api_download.hip", "rtx_api_shard.hip", "rtx_api_debug.hip", "host_tree.cpp", "host_format.cpp", "host_raxtax.cpp", "host_bin.cpp", "host_threads.cpp"]
+SOURCES = ["rtx_kernels.hip", "rtx_hit_pair.hip", "rtx_prob_tables.hip", "rtx_cluster.hip", "rtx_segments.hip", "rtx_prune.hip", "rtx_bounds2.hip", "rtx_records.hip", "rtx_finalise.hip", "rtx_exact.hip", "rtx_ingest.hip", "rtx_api_index.hip", "rtx_api_batch.hip", "rtx_api_download.hip", "rtx_api_shard.hip", "rtx_api_debug.hip", "host_tree.cpp", "host_format.cpp", "host_raxtax.cpp", "host_bin.cpp", "host_threads.cpp"]
 HEADERS = ["rtx_index.hpp", "rtx_kernels.hpp", "rtx_hit_common.hpp", "rtx_internal.hpp", "rtx_math.hpp", "rtx_wave.hpp", "rtx_walk.hpp", "host_raxtax.hpp"]
 CLI = PKG / "raxtax-hip"
 SYNTH = PKG / "raxtax-synth"   # the generator of the synthetic inputs as a host program: csrc/synth_main.cpp

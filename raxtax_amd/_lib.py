@@ -38,7 +38,8 @@ class NodesView(C.Structure):
 class ResultView(C.Structure):
     _fields_ = [("n_queries", C.c_uint32), ("n_rows", C.c_uint64), ("t", u32p), ("status", u8p),
                 ("global_signal", f64p), ("row_begin", u64p), ("row_count", u32p), ("row_lineage", u32p), ("row_node", u32p),
-                ("row_depth", u32p), ("row_conf", f64p), ("row_local_signal", f64p)]
+                ("row_depth", u32p), ("row_conf", f64p), ("row_local_signal", f64p),
+                ("row_conf_stride", C.c_uint32), ("row_depth_u8", u8p), ("row_conf_hundredths", u8p)]   # ABI 5 (0 / NULL in a hand-made view)
 
 
 class RtxError(RuntimeError):

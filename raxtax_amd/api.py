@@ -195,8 +195,9 @@ class Result:
         self.row_lineage = arr(view.row_lineage, nr)[src]
         self.row_node = arr(view.row_node, nr)[src]
         self.row_depth = arr(view.row_depth, nr)[src]
-        self.row_conf = (np.ctypeslib.as_array(view.row_conf, shape=(nr, RTX_MAX_DEPTH))[src] if nr
-                         else np.zeros((0, RTX_MAX_DEPTH)))
+        stride = int(view.row_conf_stride) or RTX_MAX_DEPTH     # ABI 5: the deepest lineage of the tree (0 in a hand-made view: RTX_MAX_DEPTH)
+        self.row_conf = (np.ctypeslib.as_array(view.row_conf, shape=(nr, stride))[src] if nr
+                         else np.zeros((0, stride)))
         self.row_local_signal = arr(view.row_local_signal, nr)[src]
 
     def rows(self, q: int) -> List[EvaluationResult]:

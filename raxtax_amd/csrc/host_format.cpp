@@ -109,7 +109,7 @@ extern "C" int64_t rtx_format_query(const rtx_tree *tree, const rtx_result_view 
         const uint64_t r = r0 + i;
         uint32_t lin_idx = res->row_lineage[r];
         uint32_t depth = res->row_depth[r];
-        const double *conf = res->row_conf + r * RTX_MAX_DEPTH;
+        const double *conf = res->row_conf + r * (res->row_conf_stride ? res->row_conf_stride : RTX_MAX_DEPTH);
         double ones[RTX_MAX_DEPTH];
         if (override_one) {
             lin_idx = exact_ids[0];
@@ -186,9 +186,15 @@ extern "C" int64_t rtx_format_query(const rtx_tree *tree, const rtx_result_view 
 extern "C" int64_t rtx_result_pack(const rtx_result_view *res, uint8_t *buf, uint64_t cap) {
     if (!res) { rtx::set_error("rtx_result_pack: null view"); return RTX_ERR_INVALID; }
     const uint64_t nq = res->n_queries, nr = res->n_rows;
+    // A view of rtx_batch_download carries the row fields as the record wants them (depths and hundredths as bytes, written by
+    // finalise_kernel): the record is then a handful of block copies, L = the stride of the view (the deepest lineage of the tree).
+    // A hand-made view (no byte arrays): L = the deepest row, the confidences are converted.
+    const bool ready = res->row_depth_u8 && res->row_conf_hundredths && res->row_conf_stride;
+    const uint32_t stride = res->row_conf_stride ? res->row_conf_stride : RTX_MAX_DEPTH;
     uint32_t L = 1;  // every level of every row travels: the block is as wide as the deepest row
-    for (uint64_t r = 0; r < nr; r++) L = std::max(L, res->row_depth[r]);
-    if (L > RTX_MAX_DEPTH) { rtx::set_error("rtx_result_pack: row of depth %u (RTX_MAX_DEPTH %u)", L, RTX_MAX_DEPTH); return RTX_ERR_DEPTH; }
+    if (ready) L = stride;
+    else for (uint64_t r = 0; r < nr; r++) L = std::max(L, res->row_depth[r]);
+    if (L > RTX_MAX_DEPTH || L > stride) { rtx::set_error("rtx_result_pack: row of depth %u (RTX_MAX_DEPTH %u, stride %u)", L, RTX_MAX_DEPTH, stride); return RTX_ERR_DEPTH; }
     const uint64_t need = 32 + 25 * nq + (13 + (uint64_t)L) * nr;
     if (!buf) return (int64_t)need;  // size query
     if (cap < need) { rtx::set_error("rtx_result_pack: buffer of %llu bytes, need %llu", (unsigned long long)cap, (unsigned long long)need); return RTX_ERR_INVALID; }
@@ -200,20 +206,23 @@ extern "C" int64_t rtx_result_pack(const rtx_result_view *res, uint8_t *buf, uin
     uint8_t *p_begin = buf + 32, *p_gs = p_begin + 8 * nq, *p_count = p_gs + 8 * nq, *p_t = p_count + 4 * nq, *p_status = p_t + 4 * nq;
     uint8_t *p_lin = p_status + nq, *p_depth = p_lin + 4 * nr, *p_conf = p_depth + nr, *p_local = p_conf + (uint64_t)L * nr;
     auto work = [&](uint64_t qa, uint64_t qb, uint64_t ra, uint64_t rb) {
-        for (uint64_t q = qa; q < qb; q++) {
-            const int64_t b = (int64_t)res->row_begin[q];
-            memcpy(p_begin + 8 * q, &b, 8);
-            memcpy(p_gs + 8 * q, &res->global_signal[q], 8);
-            memcpy(p_count + 4 * q, &res->row_count[q], 4);
-            memcpy(p_t + 4 * q, &res->t[q], 4);
-            p_status[q] = res->status[q];
-        }
-        for (uint64_t r = ra; r < rb; r++) {
-            memcpy(p_lin + 4 * r, &res->row_lineage[r], 4);
-            p_depth[r] = (uint8_t)res->row_depth[r];
-            const double *cf = res->row_conf + r * RTX_MAX_DEPTH;
-            for (uint32_t d = 0; d < L; d++) p_conf[(uint64_t)L * r + d] = (uint8_t)std::lrint(cf[d] * 100.0);
-            memcpy(p_local + 8 * r, &res->row_local_signal[r], 8);
+        // (row_begin is u64 in the view and i64 in the record: the same bytes)
+        memcpy(p_begin + 8 * qa, res->row_begin + qa, 8 * (qb - qa));
+        memcpy(p_gs + 8 * qa, res->global_signal + qa, 8 * (qb - qa));
+        memcpy(p_count + 4 * qa, res->row_count + qa, 4 * (qb - qa));
+        memcpy(p_t + 4 * qa, res->t + qa, 4 * (qb - qa));
+        memcpy(p_status + qa, res->status + qa, qb - qa);
+        memcpy(p_lin + 4 * ra, res->row_lineage + ra, 4 * (rb - ra));
+        memcpy(p_local + 8 * ra, res->row_local_signal + ra, 8 * (rb - ra));
+        if (ready) {
+            memcpy(p_depth + ra, res->row_depth_u8 + ra, rb - ra);
+            memcpy(p_conf + (uint64_t)L * ra, res->row_conf_hundredths + (uint64_t)L * ra, (uint64_t)L * (rb - ra));
+        } else {
+            for (uint64_t r = ra; r < rb; r++) {
+                p_depth[r] = (uint8_t)res->row_depth[r];
+                const double *cf = res->row_conf + r * stride;
+                for (uint32_t d = 0; d < L; d++) p_conf[(uint64_t)L * r + d] = (uint8_t)std::lrint(cf[d] * 100.0);
+            }
         }
     };
     const unsigned nt = nr + nq < 65536 ? 1u : rtx::host_threads(8u);

@@ -321,7 +321,7 @@ int run(rtx_index *const *indices, uint32_t n_dev, const rtx_tree *tree, uint64_
                 auto stage1 = [&](uint64_t j) {
                     if (j >= b || ch.res.status[j] != RTX_Q_OK || ch.res.row_count[j] == 0) return;
                     const uint64_t r = row_of(j);
-                    __builtin_prefetch(ch.res.row_conf + r * RTX_MAX_DEPTH);
+                    __builtin_prefetch(ch.res.row_conf + r * (ch.res.row_conf_stride ? ch.res.row_conf_stride : RTX_MAX_DEPTH));
                     __builtin_prefetch(ch.res.row_lineage + r);
                     __builtin_prefetch(ch.res.row_depth + r);
                     __builtin_prefetch(ch.res.row_local_signal + r);

@@ -460,6 +460,61 @@ int enqueue_prob_prefix(rtx_index *ix, const SubBatch &b, bool fuse_walk, bool p
     return RTX_OK;
 }
 
+// The final result arrays (finalise_kernel): the per-query fields of the batch in input order, as many rows as the arena holds
+int alloc_final(rtx_index *ix, uint64_t n_queries) {
+    int rc;
+    if ((rc = ix->d_fin_t.alloc(n_queries)) || (rc = ix->d_fin_status.alloc(n_queries)) || (rc = ix->d_fin_gs.alloc(n_queries)) ||
+        (rc = ix->d_fin_row_begin.alloc(n_queries)) || (rc = ix->d_fin_row_count.alloc(n_queries)) || (rc = ix->d_fin_cursor.alloc(2)))
+        return rc;
+    const uint64_t rows = ix->arena_cap, D = ix->fin_D;
+    if ((rc = ix->d_fin_lineage.alloc(rows)) || (rc = ix->d_fin_node.alloc(rows)) || (rc = ix->d_fin_depth.alloc(rows)) || (rc = ix->d_fin_depth8.alloc(rows)) ||
+        (rc = ix->d_fin_local.alloc(rows)) || (rc = ix->d_fin_conf.alloc(rows * D)) || (rc = ix->d_fin_hund.alloc(rows * D)))
+        return rc;
+    ix->fin_cap = rows;
+    return RTX_OK;
+}
+
+// Behind the walks of a sub-batch: its rows sorted, finished and laid out for the host's view (rtx_finalise.hip).  The launches of a run
+// follow one another (the bulk's on the stream of the back halves, the side classes' behind the join: enqueue_batch), so the rows of a
+// sub-batch are [cursor before its launch, cursor behind it) -- h_fin_sub keeps the latter for the streamed download.
+int enqueue_finalise(rtx_index *ix, const SubBatch &b, hipStream_t s) {
+    FinaliseParams fp{};
+    fp.status = ix->d_status.p;
+    fp.t_all = ix->d_t_all.p;
+    fp.gs = ix->d_gs.p;
+    fp.n_rows = ix->d_n_rows.p;
+    fp.row_start = ix->d_row_start.p;
+    fp.arena = ix->d_arena.p;
+    fp.arena_cap = ix->arena_cap;
+    fp.perm = ix->d_perm.p;
+    fp.q0 = b.q0;
+    fp.nq = b.nq;
+    fp.node_depth = ix->d_node_depth.p;
+    fp.node_sig0 = ix->d_node_sig0.p;
+    fp.node_begin = ix->d_node_begin.p;
+    fp.node_eb = ix->d_node_eb.p;
+    fp.D = ix->fin_D;
+    fp.o_t = ix->d_fin_t.p;
+    fp.o_status = ix->d_fin_status.p;
+    fp.o_gs = ix->d_fin_gs.p;
+    fp.o_row_begin = ix->d_fin_row_begin.p;
+    fp.o_row_count = ix->d_fin_row_count.p;
+    fp.r_lineage = ix->d_fin_lineage.p;
+    fp.r_node = ix->d_fin_node.p;
+    fp.r_depth = ix->d_fin_depth.p;
+    fp.r_depth8 = ix->d_fin_depth8.p;
+    fp.r_hund = ix->d_fin_hund.p;
+    fp.r_local = ix->d_fin_local.p;
+    fp.r_conf = ix->d_fin_conf.p;
+    fp.row_cap = ix->fin_cap;
+    fp.fin_cursor = ix->d_fin_cursor.p;
+    fp.flags_out = ix->d_flags.p;
+    launch_finalise(s, fp);
+    if (ix->stream_dl && b.sb < ix->h_fin_sub.size())
+        RTX_HIP(hipMemcpyAsync(&ix->h_fin_sub[b.sb], ix->d_fin_cursor.p, 8, hipMemcpyDeviceToHost, s));
+    return RTX_OK;
+}
+
 // group 3: taxonomy walk over prefix sums covering the WHOLE database ([nq][n_bnd], device)
 static WalkParams walk_params(rtx_index *ix, const SubBatch &b, const double *prefix) {
     WalkParams wp{};
@@ -557,6 +612,10 @@ int begin_run(rtx_index *ix, uint32_t *n_sub_out, bool *timed_out, bool cluster)
             if (rc_a) return rc_a;
             ix->arena_cap += side_rows;
         }
+        if (ix->fin_cap < ix->arena_cap || ix->d_fin_t.n < ix->n_q) {
+            int rc_f = alloc_final(ix, ix->n_q);
+            if (rc_f) return rc_f;
+        }
         ix->side_base = ix->arena_cap - side_rows;
         int rc_h = ix->h_side_base.resize(2);
         if (rc_h) return rc_h;
@@ -565,6 +624,7 @@ int begin_run(rtx_index *ix, uint32_t *n_sub_out, bool *timed_out, bool cluster)
         RTX_HIP(hipMemcpyAsync(ix->d_cursor.p, ix->h_side_base.data(), 2 * sizeof(unsigned long long), hipMemcpyHostToDevice, ix->stream));
     }
     RTX_HIP(hipMemsetAsync(ix->d_flags.p, 0, sizeof(uint32_t), ix->stream));
+    RTX_HIP(hipMemsetAsync(ix->d_fin_cursor.p, 0, 2 * sizeof(unsigned long long), ix->stream));  // the final rows of this run start at 0
     // tile pruning: the pair kernel, the memoised tables (their ln cmf rows give the threshold), taxon_prefix skipping tiles by
     // their largest count, the whole database on this handle
     // a whole-database handle driven by rtx_batch_run, or a reference shard that was asked to (RTX_OPT_SHARD_PRUNE: the caller then
@@ -650,7 +710,7 @@ int enqueue_batch(rtx_index *ix, uint32_t flags) {
             RTX_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
             ix->ev_sub.push_back(e);
         }
-        if ((rc = ix->h_cursor_sub.resize(n_sub))) return rc;
+        if ((rc = ix->h_cursor_sub.resize(n_sub)) || (rc = ix->h_fin_sub.resize(n_sub))) return rc;
         ix->n_sub_run = n_sub;
         ix->stream_dl = true;
     }
@@ -711,15 +771,25 @@ int enqueue_batch(rtx_index *ix, uint32_t flags) {
             RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_LINEAGE_WALK, 0), b.s));
             RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_LINEAGE_WALK, 1), b.s));
         }
+        // the rows of the sub-batch finalised on the device (rtx_finalise.hip).  The launches of a run follow one another -- a sub-batch's rows
+        // are then a range of the final arrays: the bulk's on the stream of its back halves; those of side classes that run beside the bulk
+        // (a stream of their own) behind the join below
+        const bool fin_later = side && overlap;
+        if (!fin_later && (rc = enqueue_finalise(ix, b, b.s))) return rc;
         if (ix->stream_dl) {
             RTX_HIP(hipMemcpyAsync(&ix->h_cursor_sub[sb], ix->d_cursor.p + (side ? 1 : 0), 8, hipMemcpyDeviceToHost, b.s));
-            RTX_HIP(hipEventRecord(ix->ev_sub[sb], b.s));
+            if (!fin_later) RTX_HIP(hipEventRecord(ix->ev_sub[sb], b.s));
         }
         if (overlap) RTX_HIP(hipEventRecord(ix->ev_back[sb], b.s));
     }
     if (overlap && n_sub) {  // a wait for the handle's stream covers all of them
         RTX_HIP(hipStreamWaitEvent(ix->stream, ix->ev_back[n_sub - 1], 0));
         if (n_side && n_side < n_sub) RTX_HIP(hipStreamWaitEvent(ix->stream, ix->ev_back[n_side - 1], 0));
+        for (uint32_t sb = 0; sb < n_side; sb++) {  // (the streamed download waits for the side classes last)
+            SubBatch b = sub_batch_of(ix, sb, false);
+            if ((rc = enqueue_finalise(ix, b, ix->stream))) return rc;
+            if (ix->stream_dl) RTX_HIP(hipEventRecord(ix->ev_sub[sb], ix->stream));
+        }
     }
     RTX_HIP(hipGetLastError());
     return RTX_OK;
@@ -918,6 +988,7 @@ static int size_workspace(rtx_index *ix, uint64_t n_queries) {
         if ((rc = ix->d_arena.alloc(want_arena))) return rc;
         ix->arena_cap = want_arena;
     }
+    if ((rc = alloc_final(ix, n_queries))) return rc;
     // ---- sub-batch scratch, sized against free HBM: every class gets the sub-batch size its own shape allows, the buffers the largest
     // product over the classes (a class runs after the other through the same buffers)
     // RTX_OPT_OVERLAP: two (three) scratch sets -- not for a handle that shares its device with another one driven beside it (rtx_raxtax_multi):

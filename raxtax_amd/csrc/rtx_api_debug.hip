@@ -438,6 +438,7 @@ int rtx_debug_evaluate(rtx_index *ix, const double *probs, rtx_result_view *out)
     RTX_HIP(hipMemset(ix->d_z.p, 0, 8));
     RTX_HIP(hipMemset(ix->d_cursor.p, 0, 16));  // both cursors: the download reads the side classes' one as well (left to the allocation it sized the host arrays by garbage)
     RTX_HIP(hipMemset(ix->d_flags.p, 0, 4));
+    RTX_HIP(hipMemset(ix->d_fin_cursor.p, 0, 16));
     PrefixParams fp{};
     fp.status = ix->d_status.p;
     fp.t = ix->sc[ix->last_set].d_t.p;
@@ -466,6 +467,11 @@ int rtx_debug_evaluate(rtx_index *ix, const double *probs, rtx_result_view *out)
     wp.row_start = ix->d_row_start.p;
     wp.flags_out = ix->d_flags.p;
     launch_lineage_walk(s, wp, 1);
+    {
+        SubBatch b{};
+        b.sb = 0; b.nq = 1; b.set = 0; b.q0 = 0; b.s = s;
+        if ((rc = enqueue_finalise(ix, b, s))) return rc;
+    }
     RTX_HIP(hipGetLastError());
     ix->n_sub_last = 0;
     ix->ran = true;

@@ -1,145 +1,74 @@
-// Result download: the records of finished sub-batches are copied and finalised on the host (sort lineage.rs:91-93, expected vectors
-// and local signal lineage.rs:95-102) while later sub-batches still run; exact matches as the device found them; rtx_classify_batch.
+// Result download: the device finalises the rows of every sub-batch (rtx_finalise.hip: sort lineage.rs:91-93, expected vectors and local
+// signal lineage.rs:95-102, final layout); the rows of finished sub-batches are copied into the page-locked arrays of the view while
+// later sub-batches still run -- the host copies, it computes nothing; exact matches as the device found them; rtx_classify_batch.
 #include "rtx_index.hpp"
 
 namespace rtxi {
 
-// lineage.rs:91-110 for the rows of one query: expected vectors, stable descending sort by confidence vector, local signal
-// (utils.rs:91-105).  The device hands a row over as {node, confidence per level in hundredths}; everything that depends on the node
-// alone -- depth, the expected vector (|range| / N per level, lineage.rs:137-139), the level the local signal starts at
-// (lineage.rs:95-98) -- is tabulated once per handle (node_tables), so that a row costs a handful of loads: real barcodes return ten
-// rows per query where the synthetic workload returns one, and the finalisation must keep up with the device there too.
-double euclidean_distance_l1(const double *a, const double *b, uint32_t n) {  // utils.rs:91-105
-    if (n == 0) return 0.0;
-    double a_sum = 0.0, b_sum = 0.0;
-    for (uint32_t i = 0; i < n; i++) a_sum += a[i];
-    for (uint32_t i = 0; i < n; i++) b_sum += b[i];
-    double s = 0.0;
-    for (uint32_t i = 0; i < n; i++) {
-        const double d = a[i] / a_sum - b[i] / b_sum;
-        s += d * d;
-    }
-    return std::sqrt(s);
-}
-
-void node_tables(rtx_index *ix) {  // expd[node][d], local-signal start per node
+// The per-node tables of finalise_kernel (rtx_finalise.hip): depth, begin of the node's range (the lineage a row reports, lineage.rs:105),
+// and the expected side of the local signal (lineage.rs:95-98,137-139): the level it starts at and per level the expected share
+// |range of the ancestor| / N over the sum of those shares (rtx_math.hpp: fin_node_expected) -- everything of a row's local signal
+// that depends on the node alone.
+int node_tables(rtx_index *ix) {
     const FlatNodes &f = ix->nodes;
     const uint32_t D = std::max(1u, f.max_depth), nn = f.size();
-    ix->h_node_stride = D;
-    ix->h_node_expd.assign((size_t)nn * D, 0.0);
-    ix->h_node_sig0.assign(nn, 0);
+    ix->fin_D = D;
+    std::vector<uint8_t> depth(nn), sig0(nn);
+    std::vector<double> eb((size_t)nn * D, 0.0);
+    std::vector<uint32_t> size(D);
     const double N = (double)ix->n_total;
     for (uint32_t v = 0; v < nn; v++) {
-        const uint32_t depth = f.depth[v];
-        double *e = ix->h_node_expd.data() + (size_t)v * D;
+        depth[v] = (uint8_t)f.depth[v];
         uint32_t anc = v;
-        for (int d = (int)depth - 1; d >= 0; d--) {
-            e[d] = (double)(f.end[anc] - f.begin[anc]) / N;
+        for (int d = (int)f.depth[v] - 1; d >= 0; d--) {
+            size[d] = f.end[anc] - f.begin[anc];
             anc = f.parent[anc];
         }
-        uint32_t s0 = depth ? depth - 1 : 0;  // lineage.rs:95-98: the first level whose expected share is below 1, else the last
-        for (uint32_t d = 0; d < depth; d++)
-            if (1.0 > e[d]) { s0 = d; break; }
-        ix->h_node_sig0[v] = (uint8_t)s0;
+        sig0[v] = (uint8_t)fin_node_expected(size.data(), f.depth[v], N, eb.data() + (size_t)v * D);
     }
-}
-
-// Host finalisation of the queries at positions [pa, pb) of the processing order; their rows go to
-// [row_base, ...) of the host row arrays in that order.
-void finalise_range(rtx_index *ix, uint64_t pa, uint64_t pb, uint64_t row_base) {
-    rtx_index::HostRes &hr = ix->host_res[ix->res_set];
-    const FlatNodes &f = ix->nodes;
-    const uint32_t D = ix->h_node_stride;
-    std::vector<uint32_t> ord;
-    uint64_t o = row_base;
-    for (uint64_t pos = pa; pos < pb; pos++) {
-        const uint64_t q = ix->dl_perm[pos];  // the device records are in processing order
-        hr.h_t[q] = ix->hs_t[pos];
-        hr.h_status[q] = ix->hs_status[pos];
-        hr.h_gs[q] = ix->hs_gs[pos];
-        const uint32_t nr = ix->h_n_rows[pos];
-        hr.v_row_begin[q] = o;
-        hr.v_row_count[q] = nr;
-        const DevRow *src = ix->h_arena.data() + ix->h_row_start[pos];
-        ord.resize(nr);
-        for (uint32_t r = 0; r < nr; r++) ord[r] = r;
-        if (nr > 1) {
-            // stable, descending by confidence vector, a shorter prefix smaller (lineage.rs:91-93): the hundredths order like the values
-            std::stable_sort(ord.begin(), ord.end(), [&](uint32_t x, uint32_t y) {  // true: x comes first = y < x
-                const uint32_t dx = f.depth[src[x].node], dy = f.depth[src[y].node], n = std::min(dx, dy);
-                const int c = n ? std::memcmp(src[y].k, src[x].k, n) : 0;  // bytes compare like the numbers they hold
-                return c ? c < 0 : dy < dx;
-            });
-        }
-        for (uint32_t r = 0; r < nr; r++, o++) {
-            const DevRow &h = src[ord[r]];
-            const uint32_t depth = f.depth[h.node];
-            hr.v_row_lineage[o] = f.begin[h.node];
-            hr.v_row_node[o] = h.node;
-            hr.v_row_depth[o] = depth;
-            double *c = hr.v_row_conf.data() + o * RTX_MAX_DEPTH;  // (entries from the deepest lineage of the tree on are never written: zero since the resize)
-            for (uint32_t d = 0; d < D; d++) c[d] = d < depth ? (double)h.k[d] / 100.0 : 0.0;  // == round(x*100)/100, lineage.rs:128-129
-            const uint32_t s = ix->h_node_sig0[h.node];
-            hr.v_row_local[o] = depth ? euclidean_distance_l1(c + s, ix->h_node_expd.data() + (size_t)h.node * D + s, depth - s) : 0.0;
-        }
-    }
-}
-
-// Finalises positions [pa, pb) on up to nt threads; returns the number of rows they produced.
-uint64_t finalise_mt(rtx_index *ix, uint64_t pa, uint64_t pb, uint64_t row_base, unsigned nt) {
-    nt = rtx::host_threads(nt);  // this process's share of the host's CPUs (cgroup quota, ranks per host)
-    nt = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(nt, (pb - pa) / 4096));  // a thread start costs what 2 000 single-row queries cost
-    std::vector<uint64_t> cut(nt + 1), base(nt + 1, row_base);
-    for (unsigned i = 0; i <= nt; i++) cut[i] = pa + (pb - pa) * i / nt;
-    for (unsigned i = 0; i < nt; i++) {
-        uint64_t rows = 0;
-        for (uint64_t pos = cut[i]; pos < cut[i + 1]; pos++) rows += ix->h_n_rows[pos];
-        base[i + 1] = base[i] + rows;
-    }
-    rtx_index::HostRes &hr = ix->host_res[ix->res_set];
-    const uint64_t nrows = base[nt];
-    if (hr.v_row_lineage.size() < nrows) {
-        // Only the set being written grows: the other one is the view of the previous download, which stays valid (and
-        // may be read by the caller's formatting thread) until the second-next download (include/raxtax_hip.h).
-        // Growth keeps 25 % headroom so that a batch with a few more rows than the last one does not reallocate.
-        const uint64_t want = nrows + nrows / 4 + 64;
-        hr.v_row_lineage.resize(want);
-        hr.v_row_node.resize(want);
-        hr.v_row_depth.resize(want);
-        hr.v_row_local.resize(want);
-        hr.v_row_conf.resize(want * RTX_MAX_DEPTH);
-    }
-    if (nt == 1) {
-        finalise_range(ix, pa, pb, row_base);
-    } else {
-        std::vector<std::thread> th;
-        for (unsigned i = 0; i < nt; i++) th.emplace_back(finalise_range, ix, cut[i], cut[i + 1], base[i]);
-        for (auto &t : th) t.join();
-    }
-    return nrows - row_base;
-}
-
-int size_host_results(rtx_index *ix, rtx_index::HostRes &hr, uint64_t nq, uint64_t arena_rows) {
     int rc;
-    if ((rc = ix->hs_status.resize(nq)) || (rc = ix->hs_t.resize(nq)) || (rc = ix->h_n_rows.resize(nq)) || (rc = ix->hs_gs.resize(nq)) ||
-        (rc = ix->h_row_start.resize(nq)) || (rc = ix->h_arena.resize(arena_rows ? arena_rows : 1)))
-        return rc;
-    hr.h_status.resize(nq);
-    hr.h_t.resize(nq);
-    hr.h_gs.resize(nq);
-    hr.v_row_begin.resize(nq);
-    hr.v_row_count.resize(nq);
+    if ((rc = ix->d_node_depth.alloc(nn)) || (rc = ix->d_node_sig0.alloc(nn)) || (rc = ix->d_node_begin.alloc(nn)) || (rc = ix->d_node_eb.alloc((size_t)nn * D))) return rc;
+    RTX_HIP(hipMemcpy(ix->d_node_depth.p, depth.data(), nn, hipMemcpyHostToDevice));
+    RTX_HIP(hipMemcpy(ix->d_node_sig0.p, sig0.data(), nn, hipMemcpyHostToDevice));
+    RTX_HIP(hipMemcpy(ix->d_node_begin.p, f.begin.data(), (size_t)nn * 4, hipMemcpyHostToDevice));
+    RTX_HIP(hipMemcpy(ix->d_node_eb.p, eb.data(), (size_t)nn * D * 8, hipMemcpyHostToDevice));
     return RTX_OK;
 }
 
-// D2H of the per-query records at positions [q0, q0+n) and of arena rows [r0, r1) on stream cs (asynchronous)
-int copy_results(rtx_index *ix, uint64_t q0, uint64_t n, uint64_t r0, uint64_t r1, hipStream_t cs) {
-    RTX_HIP(hipMemcpyAsync(ix->hs_status.data() + q0, ix->d_status.p + q0, n, hipMemcpyDeviceToHost, cs));
-    RTX_HIP(hipMemcpyAsync(ix->hs_t.data() + q0, ix->d_t_all.p + q0, n * 4, hipMemcpyDeviceToHost, cs));
-    RTX_HIP(hipMemcpyAsync(ix->h_n_rows.data() + q0, ix->d_n_rows.p + q0, n * 4, hipMemcpyDeviceToHost, cs));
-    RTX_HIP(hipMemcpyAsync(ix->hs_gs.data() + q0, ix->d_gs.p + q0, n * 8, hipMemcpyDeviceToHost, cs));
-    RTX_HIP(hipMemcpyAsync(ix->h_row_start.data() + q0, ix->d_row_start.p + q0, n * 8, hipMemcpyDeviceToHost, cs));
-    if (r1 > r0) RTX_HIP(hipMemcpyAsync(ix->h_arena.data() + r0, ix->d_arena.p + r0, (r1 - r0) * sizeof(DevRow), hipMemcpyDeviceToHost, cs));
+// Host arrays of a download: the per-query fields for nq queries, the row arrays for at least `rows` rows with the first `keep` preserved
+static int size_host_results(rtx_index *ix, rtx_index::HostRes &hr, uint64_t nq, uint64_t rows, uint64_t keep) {
+    int rc;
+    if ((rc = hr.h_t.resize(nq)) || (rc = hr.h_status.resize(nq)) || (rc = hr.h_gs.resize(nq)) || (rc = hr.v_row_begin.resize(nq)) ||
+        (rc = hr.v_row_count.resize(nq)))
+        return rc;
+    const uint64_t D = ix->fin_D;
+    if ((rc = hr.v_row_lineage.grow_keep(rows, keep)) || (rc = hr.v_row_node.grow_keep(rows, keep)) || (rc = hr.v_row_depth.grow_keep(rows, keep)) ||
+        (rc = hr.v_row_depth8.grow_keep(rows, keep)) || (rc = hr.v_row_local.grow_keep(rows, keep)) || (rc = hr.v_row_conf.grow_keep(rows * D, keep * D)) ||
+        (rc = hr.v_row_hund.grow_keep(rows * D, keep * D)))
+        return rc;
+    return RTX_OK;
+}
+
+// D2H of the final rows [r0, r1) on stream cs (asynchronous): the device laid them out as the view wants them
+static int copy_rows(rtx_index *ix, rtx_index::HostRes &hr, uint64_t r0, uint64_t r1, hipStream_t cs) {
+    if (r1 <= r0) return RTX_OK;
+    const uint64_t n = r1 - r0, D = ix->fin_D;
+    RTX_HIP(hipMemcpyAsync(hr.v_row_lineage.data() + r0, ix->d_fin_lineage.p + r0, n * 4, hipMemcpyDeviceToHost, cs));
+    RTX_HIP(hipMemcpyAsync(hr.v_row_node.data() + r0, ix->d_fin_node.p + r0, n * 4, hipMemcpyDeviceToHost, cs));
+    RTX_HIP(hipMemcpyAsync(hr.v_row_depth.data() + r0, ix->d_fin_depth.p + r0, n * 4, hipMemcpyDeviceToHost, cs));
+    RTX_HIP(hipMemcpyAsync(hr.v_row_depth8.data() + r0, ix->d_fin_depth8.p + r0, n, hipMemcpyDeviceToHost, cs));
+    RTX_HIP(hipMemcpyAsync(hr.v_row_local.data() + r0, ix->d_fin_local.p + r0, n * 8, hipMemcpyDeviceToHost, cs));
+    RTX_HIP(hipMemcpyAsync(hr.v_row_conf.data() + r0 * D, ix->d_fin_conf.p + r0 * D, n * D * 8, hipMemcpyDeviceToHost, cs));
+    RTX_HIP(hipMemcpyAsync(hr.v_row_hund.data() + r0 * D, ix->d_fin_hund.p + r0 * D, n * D, hipMemcpyDeviceToHost, cs));
+    return RTX_OK;
+}
+// ... and of the per-query fields (input order: complete when the last sub-batch has been finalised)
+static int copy_queries(rtx_index *ix, rtx_index::HostRes &hr, uint64_t nq, hipStream_t cs) {
+    RTX_HIP(hipMemcpyAsync(hr.h_t.data(), ix->d_fin_t.p, nq * 4, hipMemcpyDeviceToHost, cs));
+    RTX_HIP(hipMemcpyAsync(hr.h_status.data(), ix->d_fin_status.p, nq, hipMemcpyDeviceToHost, cs));
+    RTX_HIP(hipMemcpyAsync(hr.h_gs.data(), ix->d_fin_gs.p, nq * 8, hipMemcpyDeviceToHost, cs));
+    RTX_HIP(hipMemcpyAsync(hr.v_row_begin.data(), ix->d_fin_row_begin.p, nq * 8, hipMemcpyDeviceToHost, cs));
+    RTX_HIP(hipMemcpyAsync(hr.v_row_count.data(), ix->d_fin_row_count.p, nq * 4, hipMemcpyDeviceToHost, cs));
     return RTX_OK;
 }
 
@@ -174,24 +103,25 @@ static int download_streamed(rtx_index *ix, rtx_index::HostRes &hr, bool *done, 
     *done = false;
     const uint32_t n_sub = ix->n_sub_run;
     if (!ix->stream_dl || n_sub < 2 || ix->sub_q0.size() != n_sub || (hipEventQuery(ix->ev_sub[n_sub - 1]) == hipSuccess && hipEventQuery(ix->ev_sub[0]) == hipSuccess)) return RTX_OK;
-    (void)0;
     const uint64_t nq = ix->n_q;
-    int rc = size_host_results(ix, hr, nq, ix->arena_cap);
+    int rc = size_host_results(ix, hr, nq, nq + nq / 4 + 64, 0);
     if (rc) return rc;
-    uint64_t prev_main = 0, prev_side = ix->side_base, nrows = 0;
-    uint32_t n_side = 0;  // the side classes' sub-batches come first in the plan and run beside the bulk: they are waited for LAST
+    uint64_t prev = 0;
+    uint32_t n_side = 0;  // the side classes' sub-batches come first in the plan and run beside the bulk: they are finalised and waited for LAST
     while (n_side < n_sub && ix->cls[ix->sub_cls[n_side]].side) n_side++;
     for (uint32_t k = 0; k < n_sub; k++) {
         const uint32_t sb = k + n_side < n_sub ? k + n_side : k + n_side - n_sub;
         RTX_HIP(hipEventSynchronize(ix->ev_sub[sb]));
-        const uint64_t cur = ix->h_cursor_sub[sb];
         const bool side = ix->cls[ix->sub_cls[sb]].side;  // its rows lie in the side region of the arena, behind its own cursor
-        uint64_t &prev = side ? prev_side : prev_main;
-        if (cur > (side ? ix->arena_cap : ix->side_base)) return RTX_OK;  // overflow: bulk path
-        const uint64_t q0 = ix->sub_q0[sb], n = ix->sub_nq[sb];  // (classes of different sub-batch sizes follow one another: plan_sub_batches)
-        if ((rc = copy_results(ix, q0, n, prev, cur, ix->copy_stream))) return rc;
-        RTX_HIP(hipStreamSynchronize(ix->copy_stream));
-        if (k + 1 == n_sub) {  // the last records have left the device: it is free for the next batch while the host finalises these
+        if (ix->h_cursor_sub[sb] > (side ? ix->arena_cap : ix->side_base)) return RTX_OK;  // arena overflow: the bulk path repeats the run
+        const uint64_t cur = ix->h_fin_sub[sb];  // final rows [prev, cur): this sub-batch's (the finalise launches follow one another)
+        if (cur > ix->fin_cap) return RTX_OK;
+        // (cur <= prev: a side class that ran in front of the bulk on the one stream -- its rows left with the first range)
+        if (cur > prev && ((rc = size_host_results(ix, hr, nq, cur, prev)) || (rc = copy_rows(ix, hr, prev, cur, ix->copy_stream)))) return rc;
+        prev = std::max(prev, cur);
+        if (k + 1 == n_sub) {  // the last records leave the device: it is free for the next batch
+            if ((rc = copy_queries(ix, hr, nq, ix->copy_stream))) return rc;
+            RTX_HIP(hipStreamSynchronize(ix->copy_stream));
             RTX_HIP(hipStreamSynchronize(ix->stream));
             uint32_t flags = 0;
             RTX_HIP(hipMemcpy(&flags, ix->d_flags.p, 4, hipMemcpyDeviceToHost));
@@ -200,13 +130,9 @@ static int download_streamed(rtx_index *ix, rtx_index::HostRes &hr, bool *done, 
             if ((rc = fetch_exact_groups(ix, nq))) return rc;
             if (then_run && (rc = run_staged(ix, next_flags, ran_next))) return rc;
         }
-        // one thread finalises 8192 queries in ~1.4 ms, about what the device needs for the next sub-batch: with a short
-        // last sub-batch the host would still be busy with the one before it when the device is done
-        nrows += finalise_mt(ix, q0, q0 + n, nrows, k + 1 == n_sub ? 16 : 8);
-        prev = cur;
     }
     if (!*ran_next) ix->synced = true;  // (else: the next batch is running)
-    *nrows_out = nrows;
+    *nrows_out = prev;
     *done = true;
     return RTX_OK;
 }
@@ -222,7 +148,6 @@ static int download_impl(rtx_index *ix, rtx_result_view *out, bool then_run, uin
     if (!ix->ran || !out) { set_error("rtx_batch_download before rtx_batch_run"); return RTX_ERR_STATE; }
     const uint64_t nq = ix->n_q;
     ix->res_set ^= 1u;
-    ix->dl_perm = ix->h_perm_now().data();
     rtx_index::HostRes &hr = ix->host_res[ix->res_set];
     bool streamed = false, ran_next = false;
     uint64_t nrows = 0;
@@ -250,33 +175,25 @@ static int download_impl(rtx_index *ix, rtx_result_view *out, bool then_run, uin
                                                      ix->arena_cap + ix->arena_cap / 2) + (ix->arena_cap - ix->side_base);  // (+ the side classes' region)
             if ((rc = ix->d_arena.alloc(want))) return rc;
             ix->arena_cap = want;
+            if ((rc = alloc_final(ix, nq))) return rc;  // (the final arrays hold as many rows as the arena)
             if (ix->n_refs != ix->n_total) {  // a sharded run is driven by the caller: ask it to repeat
                 set_error("result arena overflow: repeat the sharded run (the arena has been enlarged)");
                 return RTX_ERR_STATE;
             }
             if ((rc = enqueue_batch(ix, ix->last_flags))) return rc;
         }
-        const bool side_rows = cursor_side > ix->side_base && ix->side_base < ix->arena_cap;  // rows of side classes at the top of the arena
-        if ((rc = size_host_results(ix, hr, nq, side_rows ? (uint64_t)cursor_side : (uint64_t)cursor)) || (rc = copy_results(ix, 0, nq, 0, cursor, ix->stream))) return rc;
-        if (side_rows) RTX_HIP(hipMemcpyAsync(ix->h_arena.data() + ix->side_base, ix->d_arena.p + ix->side_base, (cursor_side - ix->side_base) * sizeof(DevRow), hipMemcpyDeviceToHost, ix->stream));
+        unsigned long long fin = 0;
+        RTX_HIP(hipMemcpy(&fin, ix->d_fin_cursor.p, 8, hipMemcpyDeviceToHost));
+        if (fin > ix->fin_cap) { set_error("final result arrays overflowed without a flag (internal error)"); return RTX_ERR_HIP; }
+        (void)cursor_side;
+        if ((rc = size_host_results(ix, hr, nq, fin, 0)) || (rc = copy_rows(ix, hr, 0, fin, ix->stream)) || (rc = copy_queries(ix, hr, nq, ix->stream))) return rc;
         RTX_HIP(hipStreamSynchronize(ix->stream));
-        nrows = finalise_mt(ix, 0, nq, 0, nq < 4096 ? 1 : 16);
+        nrows = fin;
     }
     {   // the first download of a handle: the other result set (the two alternate, a view stays valid until the second-next
-        // download) is sized and touched now, so that the second batch does not pay for its page faults (60 ms at 1M queries)
+        // download) is allocated now, so that the second batch does not pay for its page-locked allocations
         rtx_index::HostRes &other = ix->host_res[ix->res_set ^ 1u];
-        if (other.h_t.empty() && other.v_row_lineage.empty()) {
-            other.h_t.resize(hr.h_t.size());
-            other.h_status.resize(hr.h_status.size());
-            other.h_gs.resize(hr.h_gs.size());
-            other.v_row_begin.resize(hr.v_row_begin.size());
-            other.v_row_count.resize(hr.v_row_count.size());
-            other.v_row_lineage.resize(hr.v_row_lineage.size());
-            other.v_row_node.resize(hr.v_row_node.size());
-            other.v_row_depth.resize(hr.v_row_depth.size());
-            other.v_row_conf.resize(hr.v_row_conf.size());
-            other.v_row_local.resize(hr.v_row_local.size());
-        }
+        if (other.h_t.empty() && other.v_row_lineage.empty() && (rc = size_host_results(ix, other, nq, hr.v_row_lineage.size(), 0))) return rc;
     }
     if (!streamed) {  // (the streamed path has fetched them before it let the next batch onto the device)
         if ((rc = fetch_exact_groups(ix, nq))) return rc;
@@ -287,13 +204,16 @@ static int download_impl(rtx_index *ix, rtx_result_view *out, bool then_run, uin
     out->t = hr.h_t.data();
     out->status = hr.h_status.data();
     out->global_signal = hr.h_gs.data();
-    out->row_begin = hr.v_row_begin.data();
+    out->row_begin = reinterpret_cast<const uint64_t *>(hr.v_row_begin.data());
     out->row_count = hr.v_row_count.data();
     out->row_lineage = hr.v_row_lineage.data();
     out->row_node = hr.v_row_node.data();
     out->row_depth = hr.v_row_depth.data();
     out->row_conf = hr.v_row_conf.data();
     out->row_local_signal = hr.v_row_local.data();
+    out->row_conf_stride = ix->fin_D;
+    out->row_depth_u8 = hr.v_row_depth8.data();
+    out->row_conf_hundredths = hr.v_row_hund.data();
     return RTX_OK;
 }
 

@@ -85,7 +85,7 @@ static int create_common(int device, uint64_t n_total, uint64_t ref_lo, uint64_t
         set_error("lineage depth %u exceeds RTX_MAX_DEPTH=%u", ix->nodes.max_depth, RTX_MAX_DEPTH);
         return fail(RTX_ERR_DEPTH);
     }
-    node_tables(ix);
+    if ((rc = node_tables(ix))) return fail(rc);
     if (hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking) != hipSuccess) {
         set_error("hipStreamCreate failed");
         return fail(RTX_ERR_HIP);

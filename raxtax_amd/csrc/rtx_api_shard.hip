@@ -79,7 +79,8 @@ int rtx_shard_walk(rtx_index *ix, uint32_t sb, const double *prefix_global) {
     int rc = shard_sb(ix, sb, &b);
     if (rc) return rc;
     if (!prefix_global) { set_error("rtx_shard_walk: null prefix"); return RTX_ERR_INVALID; }
-    return enqueue_walk(ix, b, prefix_global, b.s);
+    if ((rc = enqueue_walk(ix, b, prefix_global, b.s))) return rc;
+    return enqueue_finalise(ix, b, b.s);
 }
 
 int rtx_shard_info(const rtx_index *ix, uint64_t *ref_lo, uint64_t *ref_hi, uint32_t *n_bnd_global, uint32_t *n_bnd_local,

@@ -542,4 +542,40 @@ void emul_transpose64(const unsigned long long *in, unsigned long long *out) {
     for (int l = 0; l < 64; l++) out[l] = x[l];
 }
 
+// The finalisation of one query's result rows as finalise_kernel (rtx_finalise.hip) does it: for every row the number of rows that come
+// before it in the order of lineage.rs:91-93 (fin_row_before: the rank count of the kernel's lanes) and its local signal
+// (fin_local_signal).  k: [n][D] hundredths, depth: [n], size: [n][D] references below the row's ancestor per level.
+// Returns the number of row pairs on which the word-wise compare of the kernel (fin_row_before_words over zero-padded big-endian words)
+// and the byte-wise statement of lineage.rs:91-93 (fin_row_before) disagree: 0.
+uint32_t emul_finalise_rows(uint32_t n, uint32_t D, const uint8_t *k, const uint32_t *depth, const uint32_t *size, double n_total, uint32_t *rank,
+                            double *local) {
+    const uint32_t kw = (D + 3u) / 4u;
+    std::vector<uint32_t> words((size_t)n * kw, 0u);
+    for (uint32_t r = 0; r < n; r++)
+        for (uint32_t w = 0; w < kw; w++) {
+            uint32_t v = 0;  // the word as the device loads it (little-endian bytes of the DevRow, zero beyond the depth)
+            for (uint32_t b = 0; b < 4u; b++) {
+                const uint32_t d = 4u * w + b;
+                v |= (uint32_t)(d < depth[r] && d < D ? k[(size_t)r * D + d] : 0u) << (8u * b);
+            }
+            words[(size_t)r * kw + w] = fin_be32(v);
+        }
+    uint32_t disagree = 0;
+    for (uint32_t r = 0; r < n; r++) {
+        uint32_t before = 0;
+        for (uint32_t x = 0; x < n; x++) {
+            const bool a = x != r && fin_row_before(k + (size_t)x * D, depth[x], x, k + (size_t)r * D, depth[r], r);
+            const bool b = x != r && fin_row_before_words(&words[(size_t)x * kw], depth[x], x, &words[(size_t)r * kw], depth[r], r, kw);
+            disagree += a != b;
+            before += b ? 1u : 0u;
+        }
+        rank[r] = before;
+        double eb[64];
+        const uint32_t s0 = fin_node_expected(size + (size_t)r * D, depth[r], n_total, eb);  // (per node in the library: node_tables)
+        const uint8_t *kr = k + (size_t)r * D;
+        local[r] = fin_local_signal([&](uint32_t d) { return kr[d]; }, eb, s0, depth[r]);
+    }
+    return disagree;
+}
+
 }  // extern "C"

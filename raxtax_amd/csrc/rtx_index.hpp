@@ -2,7 +2,7 @@
 // helpers and the functions that sequence the kernels of a sub-batch.  Not part of the ABI (include/raxtax_hip.h is).
 //   rtx_api_index.hip     index creation (bitmaps, segment classes, union bitmap, locator, exact-match table), options
 //   rtx_api_batch.hip     per-batch workspace, upload (prefetch / activate), the kernel sequence of a sub-batch, rtx_batch_run
-//   rtx_api_download.hip  streamed download, host finalisation (sort lineage.rs:91-93, local signal lineage.rs:95-102)
+//   rtx_api_download.hip  streamed download of the rows the device finalised (rtx_finalise.hip: sort lineage.rs:91-93, local signal lineage.rs:95-102)
 //   rtx_api_shard.hip     the staged path of a sharded database (rtx_shard_*)
 //   rtx_api_debug.hip     stage times, work counters, parity / debug taps
 // There is deliberately no CPU fallback: without a gfx950 device every entry point returns RTX_ERR_NO_DEVICE.
@@ -83,9 +83,26 @@ struct PinBuf {
         n = count;
         return RTX_OK;
     }
+    // room for `count` elements with the first `keep` of them preserved (the result rows of the sub-batches already copied); grows by doubling
+    int grow_keep(size_t count, size_t keep) {
+        if (count <= cap) { n = count; return RTX_OK; }
+        T *q = nullptr;
+        const size_t want = std::max(count + count / 4 + 16, cap * 2);
+        if (hipHostMalloc((void **)&q, want * sizeof(T), hipHostMallocDefault) != hipSuccess) {
+            set_error("hipHostMalloc(%zu bytes) failed", want * sizeof(T));
+            return RTX_ERR_OOM;
+        }
+        if (p && keep) std::memcpy(q, p, std::min(keep, cap) * sizeof(T));
+        if (p) (void)hipHostFree(p);
+        p = q;
+        cap = want;
+        n = count;
+        return RTX_OK;
+    }
     T *data() { return p; }
     const T *data() const { return p; }
     size_t size() const { return n; }
+    bool empty() const { return n == 0; }
     T &operator[](size_t i) { return p[i]; }
     const T &operator[](size_t i) const { return p[i]; }
     ~PinBuf() { if (p) (void)hipHostFree(p); }
@@ -137,6 +154,12 @@ struct rtx_index {
     std::vector<uint32_t> bnd;  // sorted unique range endpoints
     uint32_t n_bnd = 0;
     DevBuf<uint4> d_noderec;  // {blo, bhi, first_child, n_children | type << 30} per node (lineage_walk)
+    // per node, for finalise_kernel (rtx_finalise.hip): depth, begin of its range (= the lineage a row reports), and the expected side of its
+    // local signal ([node][fin_D] + the level it starts at; lineage.rs:95-98,137-139, rtx_math.hpp: fin_node_expected)
+    DevBuf<uint8_t> d_node_depth, d_node_sig0;
+    DevBuf<uint32_t> d_node_begin;
+    DevBuf<double> d_node_eb;
+    uint32_t fin_D = 1;  // levels of the deepest lineage = stride of the confidence arrays of a view
     DevBuf<uint32_t> d_bnd_rank;
     DevBuf<uint8_t> d_bnd_bits;
     // ---- exact-match lookup on the device (rtx_exact.hip): the distinct reference sequences ("groups") in a hash table
@@ -307,6 +330,13 @@ struct rtx_index {
     DevBuf<double> d_gs, d_z;
     DevBuf<unsigned long long> d_hq, d_row_start, d_cursor, d_sub_alloc;  // (d_sub_alloc: WalkParams::sub_alloc)
     DevBuf<DevRow> d_arena;
+    // the final result arrays (finalise_kernel): the per-query fields in input order, the rows back to back from 0 on (fin_cap = arena_cap rows)
+    DevBuf<uint32_t> d_fin_t, d_fin_row_count, d_fin_lineage, d_fin_node, d_fin_depth;
+    DevBuf<uint8_t> d_fin_status, d_fin_depth8, d_fin_hund;
+    DevBuf<double> d_fin_gs, d_fin_local, d_fin_conf;
+    DevBuf<unsigned long long> d_fin_row_begin, d_fin_cursor;
+    uint64_t fin_cap = 0;
+    PinBuf<unsigned long long> h_fin_sub;  // per sub-batch: the cursor of the final rows behind its finalise launch
     uint64_t arena_cap = 0;
     uint64_t side_base = 0;  // rows [side_base, arena_cap) take the result rows of the side classes (their walks run beside the bulk's: a cursor of their own, d_cursor[1])
     PinBuf<unsigned long long> h_side_base;
@@ -315,21 +345,19 @@ struct rtx_index {
     uint32_t n_sub_last = 0;
     // ---- host results
     // two alternating sets: the view of download c stays valid while batch c+1 runs and is downloaded
+    // (page-locked: the device's final arrays are copied straight into them, rtx_api_download.hip)
     struct HostRes {
-        std::vector<uint32_t> v_row_lineage, v_row_node, v_row_depth;
-        std::vector<uint32_t> h_t;
-        std::vector<uint8_t> h_status;
-        std::vector<double> v_row_conf, v_row_local;
-        std::vector<double> h_gs;
-        std::vector<uint64_t> v_row_begin;  // by query; the rows themselves are in processing order
-        std::vector<uint32_t> v_row_count;
+        PinBuf<uint32_t> v_row_lineage, v_row_node, v_row_depth;
+        PinBuf<uint8_t> v_row_depth8, v_row_hund;
+        PinBuf<uint32_t> h_t;
+        PinBuf<uint8_t> h_status;
+        PinBuf<double> v_row_conf, v_row_local;
+        PinBuf<double> h_gs;
+        PinBuf<unsigned long long> v_row_begin;  // by query; the rows themselves are in processing order
+        PinBuf<uint32_t> v_row_count;
     } host_res[2];
-    // D2H staging of the per-query records, indexed by position in the processing order
-    PinBuf<uint32_t> hs_t;
-    PinBuf<uint8_t> hs_status;
-    PinBuf<double> hs_gs;
     uint32_t res_set = 0;
-    PinBuf<uint32_t> h_nrows_all, h_n_rows;
+    PinBuf<uint32_t> h_nrows_all;
     // streamed download: per sub-batch a snapshot of the arena cursor + an event; rtx_batch_download copies and
     // finalises finished sub-batches on `copy_stream` while later ones are still running
     std::vector<hipEvent_t> ev_sub;
@@ -337,13 +365,8 @@ struct rtx_index {
     hipStream_t copy_stream = nullptr;
     uint32_t n_sub_run = 0;
     bool stream_dl = false;
-    PinBuf<unsigned long long> h_hq, h_row_start;
+    PinBuf<unsigned long long> h_hq;
     uint32_t stage_timing = 0;  // 0: HIP events around hit_count only; 1: around every kernel
-    PinBuf<DevRow> h_arena;
-    // per node: expected vector and first level of the local signal (node_tables; finalise_range)
-    std::vector<double> h_node_expd;
-    std::vector<uint8_t> h_node_sig0;
-    uint32_t h_node_stride = 1;
 
     bool shared_device = false;  // rtx_raxtax_multi drives another handle on the same device beside this one: no second stream (begin_run)
     ~rtx_index() {
@@ -401,10 +424,8 @@ int plan_sub_batches(rtx_index *ix);
 int alloc_scratch_set(rtx_index *ix, uint32_t k);
 constexpr uint32_t kSideSet = 3;
 // ---- rtx_api_download.hip
-void node_tables(rtx_index *ix);
-void finalise_range(rtx_index *ix, uint64_t pa, uint64_t pb, uint64_t row_base);
-uint64_t finalise_mt(rtx_index *ix, uint64_t pa, uint64_t pb, uint64_t row_base, unsigned nt);
-int size_host_results(rtx_index *ix, rtx_index::HostRes &hr, uint64_t nq, uint64_t arena_rows);
-int copy_results(rtx_index *ix, uint64_t q0, uint64_t n, uint64_t r0, uint64_t r1, hipStream_t cs);
+int node_tables(rtx_index *ix);  // the per-node tables of finalise_kernel, uploaded at creation
+int alloc_final(rtx_index *ix, uint64_t n_queries);  // (rtx_api_batch.hip) the final result arrays: n_queries per-query fields, arena_cap rows
+int enqueue_finalise(rtx_index *ix, const SubBatch &b, hipStream_t s);  // (rtx_api_batch.hip) behind the walks of a sub-batch
 
 }  // namespace rtxi

@@ -319,6 +319,41 @@ struct WalkParams {
     uint32_t *flags_out;             // bit0 arena overflow, bit1 row/depth overflow
 };
 
+// finalise_kernel (rtx_finalise.hip): the rows of a sub-batch as the walks left them in the arena -> the final result arrays, on the device
+// (lineage.rs:91-110): per query the rows sorted, the local signal computed, the rows laid out back to back in the arrays the host's view
+// points into; the per-query fields scattered from the processing order to the input order.  The host copies and does nothing else.
+struct FinaliseParams {
+    // in, by position of the processing order
+    const uint8_t *status;
+    const uint32_t *t_all;
+    const double *gs;
+    const uint32_t *n_rows;
+    const unsigned long long *row_start;
+    const DevRow *arena;
+    unsigned long long arena_cap;
+    const uint32_t *perm;  // position -> query
+    uint64_t q0;
+    uint32_t nq;
+    // per node: depth, index of its lineage (begin of its range), the expected side of its local signal (rtx_math.hpp: fin_node_expected)
+    const uint8_t *node_depth, *node_sig0;
+    const uint32_t *node_begin;
+    const double *node_eb;  // [node][D]
+    uint32_t D;       // levels of the deepest lineage = stride of the confidence arrays
+    // out, by query
+    uint32_t *o_t;
+    uint8_t *o_status;
+    double *o_gs;
+    unsigned long long *o_row_begin;
+    uint32_t *o_row_count;
+    // out, rows: [fin_cursor before the launch, behind it)
+    uint32_t *r_lineage, *r_node, *r_depth;
+    uint8_t *r_depth8, *r_hund;
+    double *r_local, *r_conf;
+    unsigned long long row_cap;
+    unsigned long long *fin_cursor;
+    uint32_t *flags_out;  // bit0: no room (the host enlarges the arena and repeats the run)
+};
+
 struct PrefixParams {
     const uint8_t *status;
     const uint32_t *t;     // [B] distinct k-mers per slot (size of the table copy)
@@ -409,6 +444,7 @@ int cluster_sort(hipStream_t s, void *tmp, size_t *tmp_bytes, const uint64_t *ke
 void launch_class_keys(hipStream_t s, uint64_t *keys, const uint64_t *off, uint32_t n, const uint64_t lim[3], bool from_index, uint32_t *idx);
 void launch_taxon_prefix(hipStream_t s, const PrefixParams &p, uint32_t nq);
 void launch_lineage_walk(hipStream_t s, const WalkParams &p, uint32_t nq);
+void launch_finalise(hipStream_t s, const FinaliseParams &p);
 void launch_probs_expand(hipStream_t s, const uint16_t *counts, const double *tz, uint64_t n, double *out);
 void launch_rehist(hipStream_t s, const uint16_t *counts, uint64_t npad, uint64_t n_refs, const uint32_t *t, uint32_t *hist,
                    uint32_t hstride, uint16_t *tile_max, uint32_t ntiles, uint32_t nq);

@@ -417,4 +417,78 @@ RTX_HD double only_last_pmf_tab(const double *lf, uint32_t t, uint32_t n, uint32
     return exp(ln_binom_tab(lf, m + n - 1, n) - ln_total);
 }
 
+// ---------------------------------------------------------------------------
+// Finalisation of the result rows of one query (lineage.rs:91-110, utils.rs:91-105), shared by finalise_kernel (rtx_finalise.hip)
+// and the x86 emulation of the CPU tests.  A row arrives as {node, confidence per level in hundredths} (DevRow); its depth is the
+// node's.  Every operation is a correctly rounded IEEE one in a fixed order and nothing is contracted into an FMA, so the
+// device writes the doubles a host loop over the same rows writes.
+// ---------------------------------------------------------------------------
+// Does row x come before row y?  lineage.rs:91-93 sorts descending by confidence vector, a shorter prefix being the smaller one
+// (Vec<f64> partial_cmp); the sort is stable: equal rows keep the order of the walk (ix, iy = their positions in it).  The
+// hundredths order like the values they stand for.
+RTX_HD bool fin_row_before(const uint8_t *kx, uint32_t dx, uint32_t ix, const uint8_t *ky, uint32_t dy, uint32_t iy) {
+    const uint32_t n = dx < dy ? dx : dy;
+    for (uint32_t d = 0; d < n; d++)
+        if (kx[d] != ky[d]) return kx[d] > ky[d];
+    if (dx != dy) return dx > dy;
+    return ix < iy;
+}
+// The same on whole words (finalise_kernel's rank loop: a query of real barcodes can have two hundred rows, and a compare byte by byte from
+// LDS was what the kernel spent its time on).  kx, ky: the rows' hundredths as big-endian words (level 0 in the top byte), ZERO beyond the
+// row's depth (the walk writes them so).  The first differing byte decides as in fin_row_before when it lies inside the common prefix; beyond
+// it the shorter row holds padding and the longer row the larger number -- the longer row is the larger one there too.  Equal numbers: the
+// common prefix is equal, the depths decide, then the positions.
+RTX_HD bool fin_row_before_words(const uint32_t *kx, uint32_t dx, uint32_t ix, const uint32_t *ky, uint32_t dy, uint32_t iy, uint32_t kw) {
+    for (uint32_t w = 0; w < kw; w++)
+        if (kx[w] != ky[w]) return kx[w] > ky[w];
+    if (dx != dy) return dx > dy;
+    return ix < iy;
+}
+RTX_HD uint32_t fin_be32(uint32_t v) { return (v >> 24) | ((v >> 8) & 0xFF00u) | ((v << 8) & 0xFF0000u) | (v << 24); }
+
+// Local signal of a row (lineage.rs:95-102): the euclidean distance (utils.rs:91-105: both vectors scaled to a sum of one) between the
+// confidences and the expected shares |range of the ancestor| / N (lineage.rs:137-139), from the first level on whose expected share is
+// below one (the last level if there is none).  The expected side depends on the node alone and is tabulated per node:
+// fin_node_expected gives s0 and eb[d] = e[d] / sum of e from s0 on (0 in front of s0); size[d] = references below the ancestor at level d.
+RTX_HD uint32_t fin_node_expected(const uint32_t *size, uint32_t depth, double n_total, double *eb) {
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
+    if (depth == 0) return 0;
+    uint32_t s0 = depth - 1u;
+    for (uint32_t d = 0; d < depth; d++)
+        if (1.0 > (double)size[d] / n_total) { s0 = d; break; }
+    double b_sum = 0.0;
+    for (uint32_t d = s0; d < depth; d++) b_sum += (double)size[d] / n_total;
+    for (uint32_t d = 0; d < depth; d++) eb[d] = d < s0 ? 0.0 : ((double)size[d] / n_total) / b_sum;
+    return s0;
+}
+// k(d): the row's hundredths at level d (an accessor: the kernel reads them from its staged words, the emulation from bytes).  The table
+// entries of four levels are requested together (what a row waits for on the device is the chain of its loads, not its arithmetic); the
+// additions keep the order of utils.rs:91-105.
+template <class K>
+RTX_HD double fin_local_signal(K k, const double *eb, uint32_t s0, uint32_t depth) {
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
+    if (depth == 0) return 0.0;
+    double a_sum = 0.0;
+    for (uint32_t d = s0; d < depth; d++) a_sum += (double)k(d) / 100.0;
+    double s = 0.0;
+    for (uint32_t d = s0; d < depth; d += 4u) {
+        double e[4];
+#pragma unroll
+        for (uint32_t u = 0; u < 4u; u++) e[u] = d + u < depth ? eb[d + u] : 0.0;
+#pragma unroll
+        for (uint32_t u = 0; u < 4u; u++) {
+            if (d + u < depth) {
+                const double x = ((double)k(d + u) / 100.0) / a_sum - e[u];
+                const double xx = x * x;
+                s = s + xx;
+            }
+        }
+    }
+    return sqrt(s);
+}
+
 }  // namespace rtx

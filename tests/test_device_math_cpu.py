@@ -171,3 +171,49 @@ def test_epilogue_byte_merge_and_transpose(emul):
     emul.emul_transpose64(rows.ctypes.data_as(C.c_void_p), cols.ctypes.data_as(C.c_void_p))
     want = (m.T << np.arange(64, dtype=np.uint64)[None, :]).sum(axis=1).astype(np.uint64)
     assert np.array_equal(cols, want)
+
+
+def test_row_finalisation_matches_the_oracle(emul, oracle):
+    """finalise_kernel's arithmetic (rtx_math.hpp: fin_row_before, fin_local_signal) on the CPU: the rows the oracle returns for real
+    barcodes (lineage.rs:91-110: sorted, with their local signal), shuffled, must come back in the oracle's order with the oracle's local
+    signals; rows handed over in the oracle's order must keep it (the sort of lineage.rs:91-93 is stable)."""
+    from pathlib import Path
+
+    text = (Path(__file__).resolve().parent / "golden" / "diptera_subset.fasta").read_text()
+    otree = oracle.parse_reference_fasta_str(text)
+    queries = oracle.parse_query_fasta_str(text)
+    N = otree.num_tips
+    rng = np.random.default_rng(5)
+    emul.emul_finalise_rows.restype = C.c_uint32
+    multi = 0
+    for label, seq in queries[:150]:
+        rows, _ = otree.classify(seq, skip_exact=True, raw_confidence=True)
+        n = len(rows)
+        D = max(len(r["conf"]) for r in rows)
+        k = np.zeros((n, D), np.uint8)
+        size = np.zeros((n, D), np.uint32)
+        depth = np.zeros(n, np.uint32)
+        for i, r in enumerate(rows):
+            depth[i] = len(r["conf"])
+            k[i, :depth[i]] = np.rint(np.array(r["conf"]) * 100).astype(np.uint8)
+            size[i, :depth[i]] = np.rint(np.array(r["expd"]) * N).astype(np.uint32)
+        for order in (np.arange(n), rng.permutation(n)):
+            ks, ss, ds = np.ascontiguousarray(k[order]), np.ascontiguousarray(size[order]), np.ascontiguousarray(depth[order])
+            rank = np.zeros(n, np.uint32)
+            local = np.zeros(n, np.float64)
+            bad = emul.emul_finalise_rows(C.c_uint32(n), C.c_uint32(D), ks.ctypes.data_as(C.c_void_p), ds.ctypes.data_as(C.c_void_p),
+                                          ss.ctypes.data_as(C.c_void_p), C.c_double(N), rank.ctypes.data_as(C.c_void_p), local.ctypes.data_as(C.c_void_p))
+            assert bad == 0                                           # the kernel's word-wise compare = the byte-wise statement of lineage.rs:91-93
+            assert sorted(rank.tolist()) == list(range(n))            # a permutation: no two rows share a place
+            back = np.empty(n, np.int64)
+            back[rank] = np.arange(n)
+            assert np.array_equal(ks[back], k) and np.array_equal(ds[back], depth)      # the oracle's order of confidence vectors
+            want = np.array([r["local_signal"] for r in rows])
+            if np.array_equal(order, np.arange(n)):
+                assert np.array_equal(rank, np.arange(n))             # stable: equal vectors keep the order of the walk
+                assert np.allclose(local, want, rtol=0, atol=1e-12)
+            else:   # (rows with equal confidence vectors may have changed places among themselves: compare them as a set)
+                key = lambda kk, dd, ll: sorted((tuple(a), int(b), round(float(c), 11)) for a, b, c in zip(kk.tolist(), dd, ll))
+                assert key(ks, ds, local) == key(k, depth, want)
+        multi += n > 1
+    assert multi > 20

@@ -47,9 +47,11 @@ extern "C" {
 #define RTX_ERR_NO_DEVICE (-3)  /* no usable gfx950 device                          */
 #define RTX_ERR_OOM (-4)        /* host or device allocation failed                 */
 #define RTX_ERR_PARSE (-5)      /* FASTA / lineage annotation error (parser.rs)     */
-#define RTX_ERR_DEPTH (-6)      /* lineage deeper than RTX_MAX_DEPTH                */
+#define RTX_ERR_DEPTH (-6)      /* lineage deeper than RTX_MAX_DEPTH: refused by rtx_tree_build* / _parse* / _load_bin, the lineage named in rtx_last_error */
 #define RTX_ERR_STATE (-7)      /* call sequence violated (e.g. run before upload)  */
-#define RTX_ERR_TOO_LONG (-8)   /* a query longer than 65 542 bases: it could hold more than 65 535 k-mers (assert at raxtax.rs:56) */
+#define RTX_ERR_TOO_LONG (-8)   /* the memoised probability tables were demanded (RTX_OPT_PROB_MODE = 2) for a read they do not cover.  (Until ABI 4 also: a
+                                   query longer than 65 542 bases.  The reference asserts on DISTINCT k-mers, raxtax.rs:56, and serves such reads: so does
+                                   the library now -- per query, RTX_Q_ALL_KMERS for a read that really holds all 65 536 of them) */
 #define RTX_ERR_SENDER (-9)     /* the result sink refused a message (closed channel, raxtax.rs:87)    */
 
 /* flags of rtx_classify_batch / rtx_batch_run (src/io.rs:119-121,131-133) */
@@ -61,6 +63,10 @@ extern "C" {
 #define RTX_Q_NO_KMERS 1 /* t == 0, or t == 1 without a full-overlap reference: the reference
                             panics here (prob.rs:21 u64 underflow / prob.rs:162 zip_eq); the
                             library reports the query instead of aborting -- deliberate divergence */
+
+#define RTX_Q_ALL_KMERS 2 /* t == 65 536: the read holds every 8-mer (only reads of 65 543 bases or more can).  The reference
+                            asserts that t fits a u16 (raxtax.rs:56) and aborts the run; the library reports this query, returns
+                            no rows for it (t = 65 536 in the view) and classifies the rest of the batch */
 
 typedef struct rtx_tree rtx_tree;   /* host mirror of `Tree` (src/tree.rs:36-43)          */
 typedef struct rtx_index rtx_index; /* device-resident index + per-GPU batch workspace    */
@@ -434,16 +440,16 @@ int rtx_debug_order(rtx_index *index, uint32_t *perm /*n_queries*/);
 /* queries per sub-batch of the uploaded batch and the number of sub-batches: positions [(n_sub - 1) * sub_batch, n_queries) of the
  * processing order are the last sub-batch, the one the taps can read */
 int rtx_batch_sub_batch(const rtx_index *index, uint32_t *sub_batch, uint32_t *n_sub_batches);
-/* A batch is cut into LENGTH CLASSES (t <= 255 / t <= 1023 / longer reads whose probability arrays fit LDS / up to t = 65 535): the class
+/* A batch is cut into LENGTH CLASSES (t <= 255 / t <= 1023 / t <= 2047 (ABI 5) / longer reads whose probability arrays fit LDS / up to t = 65 535): the class
  * leads the processing order, every class runs through sub-batches of its own shape (bit planes, pair kernel and tile pruning, memoised
  * tables or the recurrence kernel), so that one long read does not move a batch of barcodes off the fast path; results come back in
  * input order.  rtx_batch_sub_batch reports the sub-batch size of the LAST class and the number of sub-batches of the whole batch;
  * rtx_batch_last_sub_batch the positions [first, first + n) of the processing order that form the last sub-batch (the one the taps read);
- * rtx_batch_classes, per class c < *n_classes <= 4: out[4c] queries, [4c + 1] longest query (bases), [4c + 2] sub-batch size,
+ * rtx_batch_classes, per class c < *n_classes <= 5 (4 until ABI 4: out[16]): out[4c] queries, [4c + 1] longest query (bases), [4c + 2] sub-batch size,
  * [4c + 3] bit planes | tables << 8 | pair kernel << 9 | tile pruning << 10 | records path << 11 | global-memory forms << 12 (the last
  * four after rtx_batch_run). */
 int rtx_batch_last_sub_batch(const rtx_index *index, uint64_t *first, uint32_t *n);
-int rtx_batch_classes(const rtx_index *index, uint32_t *n_classes, uint64_t out[16]);
+int rtx_batch_classes(const rtx_index *index, uint32_t *n_classes, uint64_t out[20]);
 /* tile pruning of the last run (RTX_OPT_TILE_PRUNE): out[0] (pair, tile) blocks that are counted for at least one of their two queries, [1] pairs,
  * [2] sum of the lower bounds of the best hit, [3] sum of the thresholds, [4] sum of the largest tile bounds, [5] queries, [6] bounds below a count
  * they bound (must be 0), [7] (query, tile) combinations that are counted, [8] (query, tile) combinations with a count above the query's

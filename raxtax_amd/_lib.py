@@ -19,7 +19,7 @@ RTX_ERR_INVALID, RTX_ERR_HIP, RTX_ERR_NO_DEVICE, RTX_ERR_OOM = -1, -2, -3, -4
 RTX_ERR_PARSE, RTX_ERR_DEPTH, RTX_ERR_STATE, RTX_ERR_TOO_LONG = -5, -6, -7, -8
 RTX_SKIP_EXACT_MATCHES = 1
 RTX_RAW_CONFIDENCE = 2
-RTX_Q_OK, RTX_Q_NO_KMERS = 0, 1
+RTX_Q_OK, RTX_Q_NO_KMERS, RTX_Q_ALL_KMERS = 0, 1, 2
 STAGES = ("kmer_extract", "hit_count", "prob_table", "taxon_prefix", "lineage_walk", "tile_bounds", "tile_prune", "exact_match", "order", "pair_union")
 
 u8p = C.POINTER(C.c_uint8)

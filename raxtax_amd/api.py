@@ -441,7 +441,7 @@ class Index:
     def batch_classes(self) -> list:
         """Length classes of the uploaded batch: dicts of queries, longest query, sub-batch size, planes and what the class runs through."""
         n = C.c_uint32()
-        out = np.zeros(16, dtype=np.uint64)
+        out = np.zeros(20, dtype=np.uint64)
         check(self._lib.rtx_batch_classes(self._h, C.byref(n), ptr(out, u64p)))
         res = []
         for c in range(int(n.value)):

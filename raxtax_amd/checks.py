@@ -45,7 +45,7 @@ def rows_of(res, q):
 
 
 
-def emul_threshold(emul, lf, t, n_refs, block_counts, tab_tmax=1023, tile_ub=None):
+def emul_threshold(emul, lf, t, n_refs, block_counts, tab_tmax=2047, tile_ub=None):
     """(u, i* + 1) of rtx_emul.cpp's restatement of prune_kernel's step 3: criterion (3) from the best block alone (reference shards),
     or -- given the largest bound of every tile -- the tile-aware criterion (4) of a whole-database handle."""
     import ctypes as C

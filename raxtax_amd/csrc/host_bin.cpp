@@ -92,6 +92,7 @@ bool read_node(Reader &r, rtx_tree &t, uint32_t &id_out, int depth) {
 
 namespace rtx {
 void flatten_tree(rtx_tree &t);  // host_tree.cpp
+int check_tree_depth(const rtx_tree &t);
 }
 
 extern "C" {
@@ -217,6 +218,7 @@ int rtx_tree_load_bin(const char *path, rtx_tree **out) {
     t->orig_idx.resize(nl);
     for (uint64_t i = 0; i < nl; i++) t->orig_idx[i] = i;  // the input order is not stored in the file
     rtx::flatten_tree(*t);
+    if (int rc = rtx::check_tree_depth(*t)) { delete t; return rc; }
     *out = t;
     return RTX_OK;
 }

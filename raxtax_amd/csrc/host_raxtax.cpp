@@ -401,7 +401,8 @@ int run(rtx_index *const *indices, uint32_t n_dev, const rtx_tree *tree, uint64_
             }
             if (ch.status[i] != RTX_Q_OK) {
                 // the reference aborts here (prob.rs:21/162); report and skip the query instead
-                fprintf(stderr, "[ERROR] query %s has too few valid 8-mers (%u) to be classified\n", labels[q], ch.t[i]);
+                if (ch.status[i] == RTX_Q_ALL_KMERS) fprintf(stderr, "[ERROR] query %s holds every 8-mer (t = 65536): the reference asserts t < 65536 (raxtax.rs:56)\n", labels[q]);
+                else fprintf(stderr, "[ERROR] query %s has too few valid 8-mers (%u) to be classified\n", labels[q], ch.t[i]);
                 continue;
             }
             const uint32_t r = ch.msg_arena[i];

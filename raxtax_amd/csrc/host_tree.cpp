@@ -208,6 +208,21 @@ static bool find_tax(std::string_view s, std::string_view &out) {
     return false;
 }
 
+// The device walk carries RTX_MAX_DEPTH levels per result row (the reference has no limit, lineage.rs:119-179): a deeper taxonomy is
+// refused where the tree is built, with the lineage named -- not later, at index creation, with a number only.
+int check_tree_depth(const rtx_tree &t) {
+    if (t.flat.max_depth <= RTX_MAX_DEPTH) return RTX_OK;
+    size_t worst = 0, worst_levels = 0;
+    for (size_t i = 0; i < t.lineages.size(); i++) {
+        size_t levels = 1;
+        for (char c : t.lineages[i]) levels += c == ',';
+        if (levels > worst_levels) { worst_levels = levels; worst = i; }
+    }
+    const std::string &l = t.lineages.empty() ? std::string() : t.lineages[worst];
+    set_error("lineage of %zu levels, RTX_MAX_DEPTH = %u are carried per result row: \"%.160s%s\"", worst_levels, RTX_MAX_DEPTH, l.c_str(), l.size() > 160 ? "..." : "");
+    return RTX_ERR_DEPTH;
+}
+
 void flatten_tree(rtx_tree &t);
 static void flatten(rtx_tree &t) { flatten_tree(t); }
 void flatten_tree(rtx_tree &t) {
@@ -337,6 +352,7 @@ static int build_tree(std::vector<std::string> &&lineages_in, const uint8_t *seq
 
     if (with_kmer_map) build_kmer_map(*t);  // else: bitmaps are built on the GPU from the sequences, or rtx_tree_build_kmer_map later
     flatten(*t);
+    if (int rc = check_tree_depth(*t)) { delete t; return rc; }
     *out = t;
     return RTX_OK;
 }

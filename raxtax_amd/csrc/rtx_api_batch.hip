@@ -224,7 +224,7 @@ int enqueue_hit(rtx_index *ix, const SubBatch &b, uint32_t flags, hipStream_t s,
         if (part != 2) {
             if (b.timed) RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_TILE_BOUNDS, 0), s));
             // whole-database handles: the two-level pass (rtx_bounds2.hip); reference shards and RTX_OPT_TWO_LEVEL_BOUNDS = 0: blocks of 64 throughout
-            ix->two_level_used = part == 0 && ix->two_level_opt && ix->d_abitmap.p && ix->d_bbitmap.p && ix->n_refs == ix->n_total;
+            ix->two_level_used = part == 0 && ix->two_level_opt && ix->d_abitmap.p && ix->d_bbitmap.p && ix->n_refs == ix->n_total && ix->planes <= kBounds2MaxPlanes;
             if (ix->two_level_used) {
                 Bounds2Params bp{};
                 bp.abitmap = ix->d_abitmap.p;
@@ -277,7 +277,7 @@ int enqueue_hit(rtx_index *ix, const SubBatch &b, uint32_t flags, hipStream_t s,
         pr.phase = (uint32_t)part;
         pr.best = part ? sc.d_best.p : nullptr;
         pr.bitmap = ix->d_bitmap.p;
-        pr.cbitmap = part == 0 && ix->two_level_used ? reinterpret_cast<const uint2 *>(ix->d_cbitmap.p) : nullptr;  // (with the two-level pass: RTX_OPT_TWO_LEVEL_BOUNDS = 0 is the round-4 path whole)
+        pr.cbitmap = part == 0 && (ix->two_level_used || (ix->planes > kBounds2MaxPlanes && ix->two_level_opt && ix->n_refs == ix->n_total)) ? reinterpret_cast<const uint2 *>(ix->d_cbitmap.p) : nullptr;  // (with the two-level pass: RTX_OPT_TWO_LEVEL_BOUNDS = 0 is the round-4 path whole)
         pr.n_rows1 = ix->n_rows + 1;
         pr.stride_bytes = ix->stride_bytes;
         pr.rows = sc.d_rows.p;
@@ -290,7 +290,7 @@ int enqueue_hit(rtx_index *ix, const SubBatch &b, uint32_t flags, hipStream_t s,
         pr.exact = hp.exact;
         pr.lnfact = ix->d_lnfact.p;
         pr.inv = ix->d_inv.p;
-        pr.nlf = std::min<uint32_t>(kLnFactLen, ix->tmax + ix->tmax / 2 + 2);  // (pruning runs with tmax <= 1023: 12 KB)
+        pr.nlf = std::min<uint32_t>(kLnFactLen, ix->tmax + ix->tmax / 2 + 2);  // (pruning runs with tmax <= 2047: 12 KB at t <= 1023, 25 KB at most)
         pr.hist = sc.d_hist.p;
         pr.hstride = ix->hstride;
         pr.live = sc.d_live.p;
@@ -641,7 +641,7 @@ int begin_run(rtx_index *ix, uint32_t *n_sub_out, bool *timed_out, bool cluster)
     for (uint32_t c = 0; c < ix->n_cls; c++) {  // what every class of the batch runs through
         rtx_index::BatchClass &k = ix->cls[c];
         // two neighbours per wave only pays when neighbours are related: with the processing order on
-        k.pair = ix->pair_opt && cluster && k.planes <= 10 && ix->n_q > 1 && k.rstride <= 4096;
+        k.pair = ix->pair_opt && cluster && k.planes <= 11 && ix->n_q > 1 && k.rstride <= 4096;
         const rtx_index::Scratch &s0 = ix->sc[k.side ? kSideSet : 0u];  // (a side class runs through the set of its own)
         k.prune = ix->pruning() && k.pair && k.use_tables && ix->tile_skip && ix->d_ubitmap.p && (whole || shard) &&
                   scratch_ok(s0, k.sub_batch) && (!ix->staged || scratch_ok(ix->sc[1], k.sub_batch));
@@ -796,7 +796,7 @@ int enqueue_batch(rtx_index *ix, uint32_t flags) {
 }
 
 // Builds (once per handle and tmax) the memoised cmf tables used by prob_lookup_kernel.
-constexpr uint32_t kProbTablesMaxT = 1023;
+constexpr uint32_t kProbTablesMaxT = (uint32_t)2047;  // (= kMidClassMaxT: 0.74 GB at t = 651, 9 GB at t = 1 493, 23 GB at t = 2 047)
 int ensure_prob_tables(rtx_index *ix, uint32_t tmax, bool *usable) {
     *usable = false;
     if (ix->prob_mode == 1 || tmax < 2) return RTX_OK;
@@ -856,29 +856,40 @@ constexpr uint32_t kDefaultSubBatch = 20480, kDefaultSubBatchLarge = 16384, kDef
 // class of a query by its length (t <= length - 7, known on the host when the batch is staged):
 //   0: t <= 255    8 bit planes, pair kernel, memoised tables, tile pruning
 //   1: t <= 1023  10 bit planes, the same
-//   2: longer     12 / 16 planes, one query per wave, prob_table_kernel with its arrays in LDS (t up to ~ 6 600)
-//   3: up to t = 65 535 (raxtax.rs:56): 16 planes, the histogram of hit_count and the arrays of prob_table in global memory
+//   2: t <= 2047  11 bit planes, the same with u16 counts (round 6: full-length 16S -- until then every read beyond 1 030 bases fell to class 3's
+//                 one-query-per-wave kernel without pruning: 0.26 M reads of 1 500 bases per second against 12.9 M barcodes); fewer than
+//                 kMinMidClass of them in a batch ride with class 3 (the tables of this class are gigabytes, built for the batch's longest read)
+//   3: longer     12 / 16 planes, one query per wave, prob_table_kernel with its arrays in LDS (t up to ~ 6 600)
+//   4: up to t = 65 535 (raxtax.rs:56): 16 planes, the histogram of hit_count and the arrays of prob_table in global memory
 constexpr size_t kProbTableLdsLimit = 160 * 1024 - 512;
+constexpr uint64_t kMidClassMaxT = 2047;
+
 uint32_t length_class(uint64_t len) {
     const uint64_t t = len >= 8 ? len - 7 : 1;
     if (t <= 255) return 0;
     if (t <= 1023) return 1;
-    return t <= 65535 && prob_table_lds_bytes((uint32_t)t) <= kProbTableLdsLimit ? 2u : 3u;
+    if (t <= kMidClassMaxT) return 2;
+    return t <= 65535 && prob_table_lds_bytes((uint32_t)t) <= kProbTableLdsLimit ? 3u : 4u;
 }
-uint64_t class2_max_len() {  // the longest query of class 2: where prob_table's arrays still fit LDS
+uint64_t class3_max_len() {  // the longest query of class 3: where prob_table's arrays still fit LDS
     static uint64_t cached = 0;
     if (!cached) {
-        uint64_t lo = 1030, hi = 65535 + 7;
-        while (lo < hi) { const uint64_t mid = (lo + hi + 1) / 2; if (length_class(mid) <= 2u) lo = mid; else hi = mid - 1; }
+        uint64_t lo = kMidClassMaxT + 8, hi = 65535 + 7;
+        while (lo < hi) { const uint64_t mid = (lo + hi + 1) / 2; if (length_class(mid) <= 3u) lo = mid; else hi = mid - 1; }
         cached = lo;
     }
     return cached;
 }
 constexpr uint64_t kSideMaxQueries = 2048;  // a class of at most this many queries (and a 64th of the bulk) runs as a side class
 constexpr uint64_t kMinShortClass = 4096;  // fewer queries of t <= 255 than this ride with the t <= 1023 class (same results: 8 or 10 planes hold their counts)
+constexpr uint64_t kMinMidClass = 4096;    // fewer queries of 1024 <= t <= 2047 than this ride with the longer reads (one query per wave, the recurrence kernel)
 
-static void shape_class(rtx_index::BatchClass &k, uint64_t n, uint64_t max_len) {
-    const uint64_t tmax = max_len >= 8 ? max_len - 7 : 1;  // t <= min(len - 7, 65536); t == 65536 would trip the u16 assert of raxtax.rs:56
+// mid: the class of 1024 <= t <= 2047 proper (eleven planes: pair kernel, pruning, tables); reads of that length that ride with the longer
+// ones (too few of them, a reference shard) keep the twelve-plane form of the one-query-per-wave kernel and the recurrence kernel
+static void shape_class(rtx_index::BatchClass &k, uint64_t n, uint64_t max_len, bool mid = false) {
+    // t <= min(len - 7, 65536): the reference asserts on the DISTINCT k-mers of a read (raxtax.rs:56, utils.rs:27-40), so a read of any
+    // length is served; one that really holds all 65 536 8-mers is reported per query (RTX_Q_ALL_KMERS, kmer_extract_kernel)
+    const uint64_t tmax = std::min<uint64_t>(max_len >= 8 ? max_len - 7 : 1, 65535);
     k = rtx_index::BatchClass();
     k.n = n;
     k.max_len = max_len;
@@ -886,7 +897,7 @@ static void shape_class(rtx_index::BatchClass &k, uint64_t n, uint64_t max_len) 
     k.kstride = (uint32_t)align_up(tmax, 8);
     k.rstride = (uint32_t)align_up(tmax, 64) + 64;  // row list padded to whole 64-row chunks
     k.hstride = (uint32_t)align_up(tmax + 1, 8);
-    k.planes = tmax <= 255 ? 8 : (tmax <= 1023 ? 10 : (tmax <= 4095 ? 12 : 16));  // (8: the pair kernel; the others run their 10-plane forms)
+    k.planes = tmax <= 255 ? 8 : (tmax <= 1023 ? 10 : (tmax <= kMidClassMaxT && mid ? 11 : (tmax <= 4095 ? 12 : 16)));  // (8 / 10 / 11: the pair kernel)
     k.huge = prob_table_lds_bytes((uint32_t)tmax) > kProbTableLdsLimit;
 }
 
@@ -894,19 +905,22 @@ static int size_workspace(rtx_index *ix, uint64_t n_queries);
 
 // Sizes and allocates the per-batch workspace for the staged batch: n_queries queries, cls_n[c] of them in length class c (the longest of
 // which has cls_max[c] bases).
-int prepare_workspace(rtx_index *ix, uint64_t n_queries, const uint64_t cls_n_in[4], const uint64_t cls_max_in[4]) {
-    uint64_t cn[4], cm[4];
-    for (int c = 0; c < 4; c++) { cn[c] = cls_n_in[c]; cm[c] = cls_max_in[c]; }
+int prepare_workspace(rtx_index *ix, uint64_t n_queries, const uint64_t cls_n_in[5], const uint64_t cls_max_in[5]) {
+    uint64_t cn[5], cm[5];
+    for (int c = 0; c < 5; c++) { cn[c] = cls_n_in[c]; cm[c] = cls_max_in[c]; }
     if (ix->n_refs != ix->n_total) {  // a reference / k-mer shard: the exchange buffers of rtx_shard_* have one row stride -- one class
         uint64_t mx = 0;
-        for (int c = 0; c < 4; c++) mx = std::max(mx, cm[c]);
+        for (int c = 0; c < 5; c++) mx = std::max(mx, cm[c]);
         return prepare_workspace_single(ix, n_queries, mx >= 8 ? mx - 7 : 1, mx);
     }
     // a handful of short reads among barcodes ride with them (the results do not depend on the number of planes)
     if (cn[0] && cn[1] && cn[0] < kMinShortClass) { cn[1] += cn[0]; cm[1] = std::max(cm[1], cm[0]); cn[0] = 0; cm[0] = 0; }
-    // ... and a handful of reads of a few kilobases with the longer ones (one set of launches; the global-memory forms compute the same values)
-    if (cn[2] && cn[3] && cn[2] + cn[3] <= kSideMaxQueries) { cn[3] += cn[2]; cm[3] = std::max(cm[3], cm[2]); cn[2] = 0; cm[2] = 0; }
-    const uint64_t key[14] = {n_queries, cn[0], cn[1], cn[2], cn[3], cm[0], cm[1], cm[2], cm[3], ix->sub_batch_req,
+    // a few reads of 1 031 .. 2 054 bases (among barcodes, or alone) ride with the longer ones: the pruned path of their own class needs
+    // memoised tables of gigabytes (t^3), built for the longest read -- not for a handful of queries.  (No pair kernel, no pruning: no such class.)
+    if (cn[2] && ((cn[2] < kMinMidClass && ix->prob_mode != 2) || !ix->pair_opt || !ix->pruning() || ix->prob_mode == 1)) { cn[3] += cn[2]; cm[3] = std::max(cm[3], cm[2]); cn[2] = 0; cm[2] = 0; }
+    // ... and a handful of reads of a few kilobases with the longer ones still (one set of launches; the global-memory forms compute the same values)
+    if (cn[3] && cn[4] && cn[3] + cn[4] <= kSideMaxQueries) { cn[4] += cn[3]; cm[4] = std::max(cm[4], cm[3]); cn[3] = 0; cm[3] = 0; }
+    const uint64_t key[14] = {n_queries, cn[0], cn[1], cn[2] << 32 | cn[3], cn[4], cm[0], cm[1], cm[2] << 32 | cm[3], cm[4], ix->sub_batch_req,
                               (uint64_t)ix->packed_opt | (uint64_t)ix->pair_opt << 1 | (uint64_t)ix->pruning() << 2 | (uint64_t)ix->shard_prune_opt << 3 | (uint64_t)ix->fine_opt << 4 |
                                   (uint64_t)(ix->prob_mode & 3) << 5 | (uint64_t)ix->rec_opt << 8 | (uint64_t)ix->overlap_opt << 16 | (uint64_t)ix->min_subs << 20,
                               (uint64_t)ix->n_bnd_local, ix->shared_device ? 1u : 0u, 0};
@@ -917,18 +931,16 @@ int prepare_workspace(rtx_index *ix, uint64_t n_queries, const uint64_t cls_n_in
         return RTX_OK;
     }
     ix->ws_valid = false;
-    uint64_t longest = 0;
-    for (int c = 0; c < 4; c++) longest = std::max(longest, cm[c]);
-    if (longest >= 8 && longest - 7 > 65535) { set_error("query with up to %llu k-mers: raxtax.rs:56 asserts t fits u16", (unsigned long long)(longest - 7)); return RTX_ERR_TOO_LONG; }
+    // (reads beyond 65 542 bases belong to the last class; t is what kmer_extract finds, at most 65 535 -- or the query is flagged)
     ix->n_cls = 0;
     // the longest query each class may hold: the sort rank of a query is the number of class boundaries its length exceeds
-    const uint64_t cls_len[3] = {255 + 7, 1023 + 7, class2_max_len()};
-    for (int c = 0; c < 3; c++) ix->key_lim[c] = ~0ull;
+    const uint64_t cls_len[4] = {255 + 7, 1023 + 7, kMidClassMaxT + 7, class3_max_len()};
+    for (int c = 0; c < 4; c++) ix->key_lim[c] = ~0ull;
     int last = -1;
-    for (int c = 0; c < 4; c++) {
+    for (int c = 0; c < 5; c++) {
         if (!cn[c]) continue;
         if (last >= 0) ix->key_lim[ix->n_cls - 1] = cls_len[last];  // a boundary between two classes that both exist
-        shape_class(ix->cls[ix->n_cls], cn[c], cm[c]);
+        shape_class(ix->cls[ix->n_cls], cn[c], cm[c], c == 2);
         ix->n_cls++;
         last = c;
     }
@@ -944,9 +956,9 @@ int prepare_workspace(rtx_index *ix, uint64_t n_queries, const uint64_t cls_n_in
 // One class whatever the lengths: reference shards (rtx_shard_*: one row stride for the exchange buffers), rtx_debug_evaluate.
 int prepare_workspace_single(rtx_index *ix, uint64_t n_queries, uint64_t tmax, uint64_t max_len) {
     ix->ws_valid = false;
-    if (tmax > 65535) { set_error("query with up to %llu k-mers: raxtax.rs:56 asserts t fits u16", (unsigned long long)tmax); return RTX_ERR_TOO_LONG; }
+    tmax = std::min<uint64_t>(tmax, 65535);  // (shape_class)
     ix->n_cls = 1;
-    for (int c = 0; c < 3; c++) ix->key_lim[c] = ~0ull;
+    for (int c = 0; c < 4; c++) ix->key_lim[c] = ~0ull;
     shape_class(ix->cls[0], n_queries, tmax + 7);
     ix->cls[0].max_len = max_len;
     ix->n_q = n_queries;
@@ -972,11 +984,11 @@ static int size_workspace(rtx_index *ix, uint64_t n_queries) {
     uint32_t tab_t = 0;
     for (uint32_t c = 0; c < ix->n_cls; c++) {
         if (ix->cls[c].tmax > kProbTablesMaxT && ix->prob_mode == 2) { set_error("prob tables need t <= %u (got %u)", kProbTablesMaxT, ix->cls[c].tmax); return RTX_ERR_TOO_LONG; }
-        if (ix->cls[c].tmax <= kProbTablesMaxT) tab_t = std::max(tab_t, ix->cls[c].tmax);
+        if (ix->cls[c].tmax <= kProbTablesMaxT && ix->cls[c].planes <= 11) tab_t = std::max(tab_t, ix->cls[c].tmax);  // (not for mid-length reads that ride with the longer ones)
     }
     bool tables = false;
     if (tab_t && (rc = ensure_prob_tables(ix, tab_t, &tables))) return rc;
-    for (uint32_t c = 0; c < ix->n_cls; c++) ix->cls[c].use_tables = tables && ix->cls[c].tmax >= 2 && ix->cls[c].tmax <= kProbTablesMaxT;
+    for (uint32_t c = 0; c < ix->n_cls; c++) ix->cls[c].use_tables = tables && ix->cls[c].tmax >= 2 && ix->cls[c].tmax <= kProbTablesMaxT && ix->cls[c].planes <= 11;
     // ---- per-query results
     if ((rc = ix->d_status.alloc(n_queries)) || (rc = ix->d_t_all.alloc(n_queries)) || (rc = ix->d_nrows_all.alloc(n_queries)) ||
         (rc = ix->d_n_rows.alloc(n_queries)) || (rc = ix->d_gs.alloc(n_queries)) || (rc = ix->d_z.alloc(n_queries)) ||
@@ -1003,7 +1015,7 @@ static int size_workspace(rtx_index *ix, uint64_t n_queries) {
     uint64_t worst = 0;
     for (uint32_t c = 0; c < ix->n_cls; c++) {
         rtx_index::BatchClass &k = ix->cls[c];
-        k.will_prune = ix->pruning() && ix->d_ubitmap.p && ix->pair_opt && ix->ntiles >= RTX_PRUNE_MIN_TILES && k.tmax <= 1023 && (ix->n_refs == ix->n_total || ix->shard_prune_opt);  // begin_run decides
+        k.will_prune = ix->pruning() && ix->d_ubitmap.p && ix->pair_opt && ix->ntiles >= RTX_PRUNE_MIN_TILES && k.tmax <= kProbTablesMaxT && (ix->n_refs == ix->n_total || ix->shard_prune_opt);  // begin_run decides
         const uint64_t per_q = class_per_q(ix, k);
         uint32_t B = ix->sub_batch_req;
         if (B == 0) {
@@ -1130,14 +1142,14 @@ int rtx_batch_prefetch(rtx_index *ix, uint64_t n_queries, const uint8_t *bases, 
     in.staged = false;
     if (ix->ev_activated) RTX_HIP(hipStreamWaitEvent(ix->h2d_stream, ix->ev_activated, 0));  // the batch that read this set has run
     uint64_t max_len = 0;
-    uint64_t cls_n[4] = {0, 0, 0, 0}, cls_max[4] = {0, 0, 0, 0};  // the length classes of the batch (length_class)
+    uint64_t cls_n[5] = {0, 0, 0, 0, 0}, cls_max[5] = {0, 0, 0, 0, 0};  // the length classes of the batch (length_class)
     {
-        const uint64_t lim2 = class2_max_len();
+        const uint64_t lim3 = class3_max_len();
         for (uint64_t q = 0; q < n_queries; q++) {
             if (base_off[q + 1] < base_off[q]) { set_error("base_off not monotone at query %llu", (unsigned long long)q); return RTX_ERR_INVALID; }
             const uint64_t len = base_off[q + 1] - base_off[q];
             max_len = std::max(max_len, len);
-            const int c = len <= 262 ? 0 : (len <= 1030 ? 1 : (len <= lim2 ? 2 : 3));
+            const int c = len <= 262 ? 0 : (len <= 1030 ? 1 : (len <= kMidClassMaxT + 7 ? 2 : (len <= lim3 ? 3 : 4)));
             cls_n[c]++;
             cls_max[c] = std::max(cls_max[c], len);
         }
@@ -1177,7 +1189,7 @@ int rtx_batch_prefetch(rtx_index *ix, uint64_t n_queries, const uint8_t *bases, 
     in.n_q = n_queries;
     in.total = total;
     in.max_len = max_len;
-    for (int c = 0; c < 4; c++) { in.cls_n[c] = cls_n[c]; in.cls_max[c] = cls_max[c]; }
+    for (int c = 0; c < 5; c++) { in.cls_n[c] = cls_n[c]; in.cls_max[c] = cls_max[c]; }
     in.n_exact = n_exact;
     in.has_exact = exact_off != nullptr;
     in.staged = true;

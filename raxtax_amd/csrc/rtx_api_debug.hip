@@ -365,11 +365,11 @@ int rtx_batch_last_sub_batch(const rtx_index *ix, uint64_t *first, uint32_t *n) 
 }
 
 // length classes of the uploaded batch (rtx_index.hpp: BatchClass): out[c] = {queries, longest query, sub-batch size, bit planes} for c < *n_classes (at most 4)
-int rtx_batch_classes(const rtx_index *ix, uint32_t *n_classes, uint64_t out[16]) {
+int rtx_batch_classes(const rtx_index *ix, uint32_t *n_classes, uint64_t out[20]) {
     if (!ix || !n_classes || !out) { set_error("null argument"); return RTX_ERR_INVALID; }
     if (!ix->uploaded) { set_error("rtx_batch_classes: no batch has been uploaded"); return RTX_ERR_STATE; }
     *n_classes = ix->n_cls;
-    for (uint32_t c = 0; c < ix->n_cls && c < 4u; c++) {
+    for (uint32_t c = 0; c < ix->n_cls && c < 5u; c++) {
         out[c * 4 + 0] = ix->cls[c].n;
         out[c * 4 + 1] = ix->cls[c].max_len;
         out[c * 4 + 2] = ix->cls[c].sub_batch;

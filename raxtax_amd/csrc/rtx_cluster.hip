@@ -270,13 +270,13 @@ __global__ __launch_bounds__(64) void locator_kernel(const uint8_t *__restrict__
 // that the processing order holds the classes one after the other; inside a class the order is the one the keys gave (or, with the
 // processing order switched off, the input order: index keys).
 __global__ __launch_bounds__(256) void class_keys_kernel(uint64_t *__restrict__ keys, const uint64_t *__restrict__ off, uint32_t n, uint64_t lim0,
-                                                         uint64_t lim1, uint64_t lim2, uint32_t shift, uint32_t from_index, uint32_t *__restrict__ idx) {
+                                                         uint64_t lim1, uint64_t lim2, uint64_t lim3, uint32_t shift, uint32_t from_index, uint32_t *__restrict__ idx) {
     const uint32_t q = blockIdx.x * 256 + threadIdx.x;
     if (q >= n) return;
     const uint64_t len = off[q + 1] - off[q];
-    const uint64_t rank = (len > lim0 ? 1u : 0u) + (len > lim1 ? 1u : 0u) + (len > lim2 ? 1u : 0u);
+    const uint64_t rank = (len > lim0 ? 1u : 0u) + (len > lim1 ? 1u : 0u) + (len > lim2 ? 1u : 0u) + (len > lim3 ? 1u : 0u);  // five classes: three bits
     const uint64_t k = from_index ? (uint64_t)q : keys[q] >> shift;
-    keys[q] = (rank << 62) | k;
+    keys[q] = (rank << 61) | k;
     if (from_index) idx[q] = q;
 }
 
@@ -320,11 +320,12 @@ void launch_identity_perm(hipStream_t s, uint32_t n, uint32_t *perm, uint32_t *i
     hipLaunchKernelGGL(identity_perm_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, perm, inv);
 }
 
-void launch_class_keys(hipStream_t s, uint64_t *keys, const uint64_t *off, uint32_t n, const uint64_t lim[3], bool from_index, uint32_t *idx) {
-    hipLaunchKernelGGL(class_keys_kernel, dim3((n + 255) / 256), dim3(256), 0, s, keys, off, n, lim[0], lim[1], lim[2], 1u, from_index ? 1u : 0u, idx);
+void launch_class_keys(hipStream_t s, uint64_t *keys, const uint64_t *off, uint32_t n, const uint64_t lim[4], bool from_index, uint32_t *idx) {
+    // (the keys hold 63 bits: two of the third min-hash's make room for the class)
+    hipLaunchKernelGGL(class_keys_kernel, dim3((n + 255) / 256), dim3(256), 0, s, keys, off, n, lim[0], lim[1], lim[2], lim[3], 2u, from_index ? 1u : 0u, idx);
 }
 
-// tmp == nullptr: only reports the temporary storage needed.  with_class: the keys carry the length class in their two top bits.
+// tmp == nullptr: only reports the temporary storage needed.  with_class: the keys carry the length class in their three top bits.
 int cluster_sort(hipStream_t s, void *tmp, size_t *tmp_bytes, const uint64_t *keys_in, uint64_t *keys_out, const uint32_t *idx_in,
                  uint32_t *perm_out, size_t n, bool with_class) {
     const hipError_t e = rocprim::radix_sort_pairs(tmp, *tmp_bytes, keys_in, keys_out, idx_in, perm_out, n, 0, with_class ? 64u : 3 * kSketchBits, s);

@@ -74,8 +74,9 @@ __global__ __launch_bounds__(kFinThreads) void finalise_kernel(FinaliseParams p)
     const bool room = base != ~0ull;  // (else: the queries keep consistent fields; the host repeats the run with larger arrays)
     if (valid) {
         const uint32_t q = p.perm[pos];
-        p.o_t[q] = p.t_all[pos];
-        p.o_status[q] = p.status[pos];
+        const uint32_t t = p.t_all[pos];
+        p.o_t[q] = t;
+        p.o_status[q] = t > 65535u ? (uint8_t)RTX_Q_ALL_KMERS : p.status[pos];  // (kmer_extract: a read with every 8-mer was left uncounted)
         p.o_gs[q] = p.gs[pos];
         p.o_row_begin[q] = room ? base + before : 0ull;
         p.o_row_count[q] = room ? n : 0u;

@@ -42,12 +42,13 @@ constexpr int kPairNB = 4;                            // buffers of eight rows p
 //   b = B[j] not in A:  j + rank_A(b) - (common elements below b)
 // and the common elements below are a running count over the list's own order (ballots).  Eleven dependent LDS reads per 64 elements --
 // until round 4 the kernel scattered both lists into two 64 K-bit sets and read them out word by word (82 k cycles per pair, 4.15 ms
-// per 1 M queries).  At most 1024 rows per list (the pair kernel runs with t <= 1023).
+// per 1 M queries).  At most 2048 rows per list (the pair kernel runs with t <= 2047; t <= 1023 until round 6).
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t lower_bound_u16(const uint16_t *l, uint32_t n, uint32_t key) {  // elements of l[0 .. n) below key; n <= 1024
+constexpr uint32_t kUnionMaxRows = 2048u;
+__device__ __forceinline__ uint32_t lower_bound_u16(const uint16_t *l, uint32_t n, uint32_t key) {  // elements of l[0 .. n) below key; n <= kUnionMaxRows
     uint32_t lo = 0;
 #pragma unroll
-    for (uint32_t step = 1024u; step >= 1u; step >>= 1) {  // lo + step - 1 < n and l[lo + step - 1] < key: the first lo + step are below
+    for (uint32_t step = kUnionMaxRows; step >= 1u; step >>= 1) {  // lo + step - 1 < n and l[lo + step - 1] < key: the first lo + step are below
         const uint32_t probe = lo + step;
         const uint32_t v = probe <= n ? (uint32_t)l[probe - 1u] : 0xFFFFFFFFu;
         lo = v < key ? probe : lo;
@@ -58,12 +59,12 @@ __device__ __forceinline__ uint32_t lower_bound_u16(const uint16_t *l, uint32_t 
 __global__ __launch_bounds__(64) void pair_union_kernel(const uint32_t *__restrict__ rows, const uint32_t *__restrict__ nrows,
                                                         uint32_t rstride, uint32_t nq, uint2 *__restrict__ urec,
                                                         uint32_t *__restrict__ nu, uint32_t ustride) {
-    __shared__ uint16_t la[1024], lb[1024];
+    __shared__ uint16_t la[kUnionMaxRows], lb[kUnionMaxRows];
     const uint32_t pair = blockIdx.x, lane = threadIdx.x;
     const uint32_t qa = pair * 2u, qb = qa + 1u;
     uint32_t na = nrows[qa], nb = qb < nq ? nrows[qb] : 0u;
-    na = na < 1024u ? na : 1024u;  // (never more: t <= 1023)
-    nb = nb < 1024u ? nb : 1024u;
+    na = na < kUnionMaxRows ? na : kUnionMaxRows;  // (never more: t <= 2047)
+    nb = nb < kUnionMaxRows ? nb : kUnionMaxRows;
     const uint32_t *ra = rows + (size_t)qa * rstride, *rb = rows + (size_t)(qb < nq ? qb : qa) * rstride;
     uint2 *out = urec + (size_t)pair * ustride;
     const uint32_t nmax = na > nb ? na : nb;
@@ -287,10 +288,11 @@ __device__ __forceinline__ void pair_tile_block(const HitParams &p, uint32_t *ld
         if (lane == 0u && p.fine_stats) atomicAdd(&p.fine_stats[(size_t)(pair & (kPruneStatCopies - 1u)) * 8u + 1u], 1ull);
         return;
     }
-    // epilogues: histogram (4 KiB) / byte counters of the whole tile (8 KiB) over the lists (dead now); the slots of the sparse
-    // segments of BOTH queries are requested first (their ids wait in LDS since the prologue)
+    // epilogues: histogram (4 KiB; 8 KiB with eleven planes: t <= 2047) / byte counters of the whole tile (8 KiB) over the lists (dead now)
+    // -- with eleven planes also over the masks and the slot ids: the slots of the sparse segments of BOTH queries are requested first
+    // (their ids wait in LDS since the prologue), nothing else of the prologue is read again
     uint32_t *hist_lds = lds_dw;
-    uint32_t *cnt8 = lds_dw + 1024u;
+    uint32_t *cnt8 = lds_dw + (NP > 10 ? 2048u : 1024u);
     uint4 pre_a[kSparseIt][kSparseV], pre_b[kSparseIt][kSparseV];
     auto thr_of = [&](uint32_t q) -> uint32_t { return p.prune_thr ? (uint32_t)__builtin_amdgcn_readfirstlane((int)p.prune_thr[q]) : 0u; };
     if (ns_a) sparse_prefetch(p, lane, ns_a, l_sid, pre_a);
@@ -444,19 +446,20 @@ void launch_pair_union(hipStream_t s, const uint32_t *rows, const uint32_t *nrow
 #ifndef RTX_ITEM_GRID_HALVES
 #define RTX_ITEM_GRID_HALVES 4  // workgroups per pass of the list of live blocks, in halves of the number of pairs
 #endif
-// NP bit planes: 10 (t <= 1023), or 8 when every query of the batch has t <= 255 (amplicons of ~200 bp, the reference's example data:
+// NP bit planes: 10 (t <= 1023), 11 (t <= 2047: u16 counts), or 8 when every query of the batch has t <= 255 (amplicons of ~200 bp, the reference's example data:
 // no ripple into planes 8 and 9, no high-bit words in the epilogue -- where short reads spend most of a block: few rows, the same
 // 8192 counts to unpack -- and sixteen registers less)
 template <int NP>
 static void launch_hit_count_pair_np(hipStream_t s, const HitParams &p, uint32_t nq, uint32_t ntiles) {
     static_assert(3u * kPairListDw >= 1024u + 2048u + 64u, "histogram (t <= 1023) and byte counters (+ pad words) alias the lists");
+    static_assert(kPairLdsBytes >= (2048u + 2048u + 64u) * 4u, "eleven planes: histogram (t <= 2047) and byte counters alias the whole prologue");
     static_assert(kSegMaxSparseRows + 1 >= kSparseIt * 64, "the slot id lists are read without a bound");
     const uint32_t np = (nq + 1u) / 2u;
     // with the list of live blocks: two blocks' worth of workgroups per pair and pass (the bench workload keeps 1.5), never more than the blocks there are
     const dim3 grid = p.items ? dim3((uint32_t)((std::min<uint64_t>((uint64_t)np * ntiles, std::max<uint64_t>((uint64_t)RTX_ITEM_GRID_HALVES * np / 2u, 2048ull)) + 7u) & ~7ull)) : dim3(np, ntiles);  // (a multiple of 8: the kernel deals a pass to the XCDs)
-    if (p.counts_lo) {
-        if (p.items) hipLaunchKernelGGL((hit_count_pair_kernel<NP, true, false, true>), grid, dim3(64), kPairLdsBytes, s, p);
-        else hipLaunchKernelGGL((hit_count_pair_kernel<NP, true, false, false>), grid, dim3(64), kPairLdsBytes, s, p);
+    if (NP <= 10 && p.counts_lo) {  // (the packed format ends at ten planes)
+        if (p.items) hipLaunchKernelGGL((hit_count_pair_kernel<(NP <= 10 ? NP : 10), true, false, true>), grid, dim3(64), kPairLdsBytes, s, p);
+        else hipLaunchKernelGGL((hit_count_pair_kernel<(NP <= 10 ? NP : 10), true, false, false>), grid, dim3(64), kPairLdsBytes, s, p);
     } else {
         if (p.items) hipLaunchKernelGGL((hit_count_pair_kernel<NP, false, false, true>), grid, dim3(64), kPairLdsBytes, s, p);
         else hipLaunchKernelGGL((hit_count_pair_kernel<NP, false, false, false>), grid, dim3(64), kPairLdsBytes, s, p);
@@ -464,7 +467,8 @@ static void launch_hit_count_pair_np(hipStream_t s, const HitParams &p, uint32_t
 }
 void launch_hit_count_pair(hipStream_t s, const HitParams &p, uint32_t nq, uint32_t ntiles, int planes) {
     if (planes <= 8) launch_hit_count_pair_np<8>(s, p, nq, ntiles);
-    else launch_hit_count_pair_np<10>(s, p, nq, ntiles);
+    else if (planes <= 10) launch_hit_count_pair_np<10>(s, p, nq, ntiles);
+    else launch_hit_count_pair_np<11>(s, p, nq, ntiles);  // reads of 1 031 .. 2 054 bases: u16 counts
 }
 
 void launch_live_items(hipStream_t s, const uint32_t *live, uint32_t live_words, const uint32_t *pair_live, uint32_t nq, uint32_t ntiles, uint32_t *off,
@@ -476,7 +480,8 @@ void launch_live_items(hipStream_t s, const uint32_t *live, uint32_t live_words,
 
 void launch_hit_count_pair_bounds(hipStream_t s, const HitParams &p, uint32_t nq, uint32_t u_ntiles, int planes) {
     if (planes <= 8) hipLaunchKernelGGL((hit_count_pair_kernel<8, true, 1, false>), dim3((nq + 1u) / 2u, u_ntiles), dim3(64), kPairLdsBytes, s, p);
-    else hipLaunchKernelGGL((hit_count_pair_kernel<10, true, 1, false>), dim3((nq + 1u) / 2u, u_ntiles), dim3(64), kPairLdsBytes, s, p);
+    else if (planes <= 10) hipLaunchKernelGGL((hit_count_pair_kernel<10, true, 1, false>), dim3((nq + 1u) / 2u, u_ntiles), dim3(64), kPairLdsBytes, s, p);
+    else hipLaunchKernelGGL((hit_count_pair_kernel<11, false, 1, false>), dim3((nq + 1u) / 2u, u_ntiles), dim3(64), kPairLdsBytes, s, p);
 }
 
 void launch_hit_count_pair_bounds_items(hipStream_t s, const HitParams &p, uint32_t nq, uint32_t u_ntiles, int planes) {
@@ -484,7 +489,8 @@ void launch_hit_count_pair_bounds_items(hipStream_t s, const HitParams &p, uint3
     // (a grid of one residency: on the bench workload the list is all but empty, and the queues of the XCDs walk a long one)
     const dim3 grid((uint32_t)((std::min<uint64_t>((uint64_t)np * u_ntiles, 4096ull) + 7u) & ~7ull));
     if (planes <= 8) hipLaunchKernelGGL((hit_count_pair_kernel<8, true, 1, true>), grid, dim3(64), kPairLdsBytes, s, p);
-    else hipLaunchKernelGGL((hit_count_pair_kernel<10, true, 1, true>), grid, dim3(64), kPairLdsBytes, s, p);
+    else if (planes <= 10) hipLaunchKernelGGL((hit_count_pair_kernel<10, true, 1, true>), grid, dim3(64), kPairLdsBytes, s, p);
+    else hipLaunchKernelGGL((hit_count_pair_kernel<11, false, 1, true>), grid, dim3(64), kPairLdsBytes, s, p);
 }
 
 // ---------------------------------------------------------------------------
@@ -567,7 +573,8 @@ void launch_fine_bounds(hipStream_t s, const HitParams &p, uint32_t nq, uint32_t
     // as many workgroups as a pass of the counting list: the list is walked through the queues of the XCDs
     const dim3 grid((uint32_t)((std::min<uint64_t>((uint64_t)np * f_ntiles, std::max<uint64_t>((uint64_t)RTX_ITEM_GRID_HALVES * np / 2u, 2048ull)) + 7u) & ~7ull));
     if (planes <= 8) hipLaunchKernelGGL((hit_count_pair_kernel<8, true, 2, true>), grid, dim3(64), kPairLdsBytes, s, fp);
-    else hipLaunchKernelGGL((hit_count_pair_kernel<10, true, 2, true>), grid, dim3(64), kPairLdsBytes, s, fp);
+    else if (planes <= 10) hipLaunchKernelGGL((hit_count_pair_kernel<10, true, 2, true>), grid, dim3(64), kPairLdsBytes, s, fp);
+    else hipLaunchKernelGGL((hit_count_pair_kernel<11, false, 2, true>), grid, dim3(64), kPairLdsBytes, s, fp);
     hipLaunchKernelGGL(pair_live_recount_kernel, dim3(nb), dim3(256), 0, s, p.live, p.live_words, nq, ntiles, pair_live, p.fine_stats);
 }
 

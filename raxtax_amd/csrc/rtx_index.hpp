@@ -230,7 +230,7 @@ struct rtx_index {
     DevBuf<uint32_t> d_group_rows;
     uint32_t n_groups_run = 0;  // groups of the whole batch (n_sub * groups_per_sub): the second half of d_group_rows starts there
     uint32_t groups_per_sub = 0;
-    bool packed() const { return packed_opt && planes <= 10; }
+    bool packed() const { return packed_opt && planes <= 10; }  // (11 planes -- reads of 1 031 .. 2 054 bases on the pair kernel -- leave u16 counts)
     DevBuf<uint64_t> d_skey_in, d_skey_out;
     DevBuf<uint32_t> d_sidx, d_perm, d_iperm;
     DevBuf<uint8_t> d_sort_tmp;
@@ -253,7 +253,7 @@ struct rtx_index {
         PinBuf<uint64_t> h_base_off, h_exact_off;
         PinBuf<uint32_t> h_exact_ids;
         uint64_t n_q = 0, total = 0, max_len = 0, n_exact = 0;
-        uint64_t cls_n[4] = {0, 0, 0, 0}, cls_max[4] = {0, 0, 0, 0};  // queries and longest query per length class (length_class)
+        uint64_t cls_n[5] = {0, 0, 0, 0, 0}, cls_max[5] = {0, 0, 0, 0, 0};  // queries and longest query per length class (length_class)
         bool packed = true, has_exact = false, staged = false, recorded = false;
         hipEvent_t ready = nullptr;        // its transfer has arrived
     } in[2];
@@ -270,8 +270,8 @@ struct rtx_index {
     uint32_t min_subs = 4;  // RTX_OPT_MIN_SUB_BATCHES: a pruned batch is cut into at least this many sub-batches (the host finalises one while the next run)
     uint64_t ws_key[14] = {0};  // shape and options the workspace was last prepared for (prepare_workspace)
     bool ws_valid = false;
-    // ---- length classes of the batch (round 5).  t <= length - 7 decides how a query is counted (8 / 10 / 12 / 16 bit planes, the pair
-    // kernel, tile pruning), how its probabilities are computed (memoised tables up to t = 1023, the recurrence kernel in LDS, the same
+    // ---- length classes of the batch (round 5; round 6: the class of t <= 2047).  t <= length - 7 decides how a query is counted (8 / 10 / 11 / 12 / 16 bit planes, the pair
+    // kernel, tile pruning), how its probabilities are computed (memoised tables up to t = 2047, the recurrence kernel in LDS, the same
     // from global memory for reads of tens of kilobases) and how much scratch it needs.  A batch used to take ALL of that from its longest
     // query: one 1 100-base read in a file of COI barcodes moved every query off the fast path.  Now the class leads the sort key of the
     // processing order, every class is cut into sub-batches of its own shape, and the fields above (tmax, strides, planes, sub_batch,
@@ -283,10 +283,10 @@ struct rtx_index {
         int planes = 10;
         bool use_tables = false, pair = false, prune = false, rec = false, huge = false, will_prune = false;
         bool side = false;  // a handful of queries beside the bulk of the batch: they run FIRST, through a small scratch set of their own (kSideSet)
-    } cls[4];
+    } cls[5];
     uint32_t n_cls = 0;
     int cur_cls = -1;
-    uint64_t key_lim[3] = {~0ull, ~0ull, ~0ull};  // sort rank of a query = the number of these lengths it exceeds
+    uint64_t key_lim[4] = {~0ull, ~0ull, ~0ull, ~0ull};  // sort rank of a query = the number of these lengths it exceeds
     std::vector<uint64_t> sub_q0;   // per sub-batch of the run: first position,
     std::vector<uint32_t> sub_nq;   // queries,
     std::vector<uint8_t> sub_cls;   // class
@@ -416,8 +416,8 @@ int begin_run(rtx_index *ix, uint32_t *n_sub_out, bool *timed_out, bool cluster)
 int enqueue_batch(rtx_index *ix, uint32_t flags);
 int ensure_prob_tables(rtx_index *ix, uint32_t tmax, bool *usable);
 uint32_t length_class(uint64_t len);
-uint64_t class2_max_len();  // 0: t <= 255, 1: t <= 1023, 2: longer, prob_table in LDS, 3: longer still
-int prepare_workspace(rtx_index *ix, uint64_t n_queries, const uint64_t cls_n[4], const uint64_t cls_max[4]);
+uint64_t class3_max_len();  // 0: t <= 255, 1: t <= 1023, 2: t <= 2047, 3: longer, prob_table in LDS, 4: longer still
+int prepare_workspace(rtx_index *ix, uint64_t n_queries, const uint64_t cls_n[5], const uint64_t cls_max[5]);
 int prepare_workspace_single(rtx_index *ix, uint64_t n_queries, uint64_t tmax, uint64_t max_len);  // one class whatever the lengths
 void apply_class(rtx_index *ix, uint32_t c);
 int plan_sub_batches(rtx_index *ix);

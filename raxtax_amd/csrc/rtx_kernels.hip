@@ -216,9 +216,13 @@ __global__ __launch_bounds__(64) void kmer_extract_kernel(KmerParams p) {
     }
     t = base;
     __syncthreads();  // kout visible to the whole wave
+    // A read that holds EVERY 8-mer (t = 65 536; only reads of 65 543 bases or more can): the reference asserts that t fits a u16
+    // (raxtax.rs:56) and aborts.  Here the query is reported (RTX_Q_ALL_KMERS, set by finalise_kernel from t_all) and counted as one
+    // without k-mers; the other queries of the batch are not affected.
+    const bool all_kmers = t > 65535u;
 
     // rows of the k-mers present in the index, in ascending k-mer order (the query's row list, shared by all tiles)
-    const uint32_t tt = t < p.kstride ? t : p.kstride;
+    const uint32_t tt = all_kmers ? 0u : (t < p.kstride ? t : p.kstride);
     // Four chunks of 64 k-mers per turn, all loads of a level issued together: on gfx9 loads and stores share one
     // in-order counter, so every wait for a load also waits for the stores before it -- a chunk-by-chunk loop
     // (load, gather, store) pays two full round trips per chunk.
@@ -253,7 +257,7 @@ __global__ __launch_bounds__(64) void kmer_extract_kernel(KmerParams p) {
     if (mode == 1u) {
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) hq += __shfl_xor(hq, d, 64);
-        if (lane == 0) { p.t[q] = t; p.nrows[q] = nrows; p.hq[gq] = hq; p.t_all[gq] = t; }
+        if (lane == 0) { p.t[q] = t > 65535u ? 0u : t; p.nrows[q] = nrows; p.hq[gq] = hq; p.t_all[gq] = t; }
         return;
     }
     const uint32_t nchunks = (nrows + 63u) >> 6;
@@ -450,7 +454,7 @@ __global__ __launch_bounds__(64) void kmer_extract_kernel(KmerParams p) {
     for (int d = 32; d >= 1; d >>= 1) { hq += __shfl_xor(hq, d, 64); nseg += __shfl_xor(nseg, d, 64); }
     if (lane == 0) {
         if (mode != 2u) {
-            p.t[q] = t;
+            p.t[q] = t > 65535u ? 0u : t;  // (a read with every 8-mer: see above)
             p.nrows[q] = nrows;
             p.hq[gq] = hq;
             p.t_all[gq] = t;

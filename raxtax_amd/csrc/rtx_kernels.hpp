@@ -354,6 +354,8 @@ struct FinaliseParams {
     uint32_t *flags_out;  // bit0: no room (the host enlarges the arena and repeats the run)
 };
 
+constexpr int kBounds2MaxPlanes = 10;  // bounds2_kernel (rtx_bounds2.hip) is instantiated for 8 and 10 planes; the class of 11 (t <= 2047) takes the one-level pass
+
 struct PrefixParams {
     const uint8_t *status;
     const uint32_t *t;     // [B] distinct k-mers per slot (size of the table copy)
@@ -441,7 +443,7 @@ void launch_locator(hipStream_t s, const uint8_t *bases, const uint64_t *off, ui
 void launch_identity_perm(hipStream_t s, uint32_t n, uint32_t *perm, uint32_t *inv);
 int cluster_sort(hipStream_t s, void *tmp, size_t *tmp_bytes, const uint64_t *keys_in, uint64_t *keys_out, const uint32_t *idx_in,
                  uint32_t *perm_out, size_t n, bool with_class = false);
-void launch_class_keys(hipStream_t s, uint64_t *keys, const uint64_t *off, uint32_t n, const uint64_t lim[3], bool from_index, uint32_t *idx);
+void launch_class_keys(hipStream_t s, uint64_t *keys, const uint64_t *off, uint32_t n, const uint64_t lim[4], bool from_index, uint32_t *idx);
 void launch_taxon_prefix(hipStream_t s, const PrefixParams &p, uint32_t nq);
 void launch_lineage_walk(hipStream_t s, const WalkParams &p, uint32_t nq);
 void launch_finalise(hipStream_t s, const FinaliseParams &p);

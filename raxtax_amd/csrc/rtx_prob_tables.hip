@@ -1,7 +1,7 @@
 // prob_table through memoised cmf tables (src/prob.rs:8-103).
 //
 // pmf_m(i) and cmf_m(i) of prob.rs:121-170 depend on (t, n = t/2, m, i) only -- not on the query
-// beyond its number of distinct k-mers t.  For barcode-length queries (t <= 1023) the library
+// beyond its number of distinct k-mers t.  For queries of t <= 2047 (barcodes; since round 6 full-length 16S) the library
 // therefore builds, once per index handle, for every t <= tmax and every 0 < m < t
 //     L[t][m][i] = ln cmf_m(i)           R[t][m][i] = pmf_m(i) / cmf_m(i)
 // with the very recurrence of rtx_math.hpp (same arithmetic as prob_table_kernel), plus per (t, m)
@@ -83,7 +83,7 @@ __device__ __forceinline__ double row_load_f64(const double *table, uint32_t off
 __global__ __launch_bounds__(256, RTX_PROB_WAVES) void prob_lookup_kernel(ProbParams p, ProbTables tb) {
     extern __shared__ double smem[];
     __shared__ uint32_t s_D, s_nact;
-    __shared__ uint32_t s_nlive[8];  // per 64-wide slice of i: rows [0, s_nlive) include every row not yet saturated there
+    __shared__ uint32_t s_nlive[16];  // per 64-wide slice of i (n <= 1023: sixteen at most): rows [0, s_nlive) include every row not yet saturated there
     const uint32_t q = p.order ? p.order[blockIdx.x] : blockIdx.x;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint64_t gq = p.q0 + q;
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(256, RTX_PROB_WAVES) void prob_lookup_kernel(ProbPa
         // rows still moving at i_lo, in descending order of m; everything else gets table = 0
         if (wave == 0) {
             uint32_t na = 0;
-            if (lane < 8) s_nlive[lane] = 0;
+            if (lane < 16) s_nlive[lane] = 0;
             for (uint32_t j0 = 0; j0 < D; j0 += 64) {
                 const uint32_t j = j0 + lane;
                 uint32_t m = 0, sat = 0;
@@ -193,7 +193,7 @@ __global__ __launch_bounds__(256, RTX_PROB_WAVES) void prob_lookup_kernel(ProbPa
                     row_end[pos] = (m * n1 + (sat < n1 ? sat : n1)) * 8u;
                     // last slice of 64 values of i (from i_lo) in which this row still moves
                     const uint32_t nsl = ((sat < n1 ? sat : n1) - i_lo + 63u) >> 6;
-                    atomicMax(&s_nlive[(nsl < 8u ? nsl : 8u) - 1u], pos + 1u);
+                    atomicMax(&s_nlive[(nsl < 16u ? nsl : 16u) - 1u], pos + 1u);
                 }
                 na += (uint32_t)__popcll(bal);
             }
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(256, RTX_PROB_WAVES) void prob_lookup_kernel(ProbPa
             if (na + lane < padded) { row_m[na + lane] = 0; row_sat[na + lane] = 0; row_h[na + lane] = 0; row_off[na + lane] = 0; row_end[na + lane] = 0; }
             if (lane == 0) {
                 s_nact = na;
-                for (int sl = 6; sl >= 0; sl--) s_nlive[sl] = max(s_nlive[sl], s_nlive[sl + 1]);  // live in slice s' => live in every s <= s'
+                for (int sl = 14; sl >= 0; sl--) s_nlive[sl] = max(s_nlive[sl], s_nlive[sl + 1]);  // live in slice s' => live in every s <= s'
             }
         }
         __syncthreads();
@@ -235,7 +235,7 @@ __global__ __launch_bounds__(256, RTX_PROB_WAVES) void prob_lookup_kernel(ProbPa
             }
             return S;
         };
-        const uint32_t nslices = ((n - i_lo) >> 6) + 1u;  // <= 8 for t <= 1023
+        const uint32_t nslices = ((n - i_lo) >> 6) + 1u;  // <= 8 for t <= 1023, <= 16 for t <= 2047
         double S0 = 0.0;
         if (wave < 2) {
             S0 = slice_sum(0, wave * 16u, 32u);
@@ -330,28 +330,31 @@ __global__ __launch_bounds__(256, RTX_PROB_WAVES) void prob_lookup_kernel(ProbPa
 // ---------------------------------------------------------------------------
 // processing order of a sub-batch for prob_lookup: queries grouped by t (descending), so that
 // concurrently resident workgroups read the same (t) tables out of L2.  One workgroup: counting sort
-// over t <= 1023 in LDS (histogram, exclusive scan, scatter).  The order inside one t is arbitrary;
+// over t <= 2047 in LDS (histogram, exclusive scan, scatter).  The order inside one t is arbitrary;
 // it only decides which workgroup runs when, never a result.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void prob_order_kernel(const uint32_t *__restrict__ t, uint32_t nq,
                                                           uint32_t *__restrict__ order) {
-    __shared__ uint32_t bin[1024];
+    constexpr uint32_t kBins = 2048;  // t <= 2047 (the class of the memoised tables); a thread takes two neighbouring bins
+    __shared__ uint32_t bin[kBins];
     __shared__ uint32_t wsum[16];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    bin[tid] = 0;
+    bin[2u * tid] = 0;
+    bin[2u * tid + 1u] = 0;
     __syncthreads();
-    for (uint32_t q = tid; q < nq; q += 1024) atomicAdd(&bin[t[q] < 1023u ? t[q] : 1023u], 1u);
+    for (uint32_t q = tid; q < nq; q += 1024) atomicAdd(&bin[t[q] < kBins - 1u ? t[q] : kBins - 1u], 1u);
     __syncthreads();
-    const uint32_t v = bin[tid];
-    const uint32_t incl = wave_incl_scan_u32(v);
+    const uint32_t v0 = bin[2u * tid], v1 = bin[2u * tid + 1u];
+    const uint32_t incl = wave_incl_scan_u32(v0 + v1);
     if (lane == 63) wsum[wave] = incl;
     __syncthreads();
     uint32_t off = 0;
     for (uint32_t w = 0; w < wave; w++) off += wsum[w];
-    bin[tid] = off + incl - v;
+    bin[2u * tid] = off + incl - v0 - v1;
+    bin[2u * tid + 1u] = off + incl - v1;
     __syncthreads();
     // descending t: the longest queries start first and the short ones fill the tail of the launch
-    for (uint32_t q = tid; q < nq; q += 1024) order[nq - 1u - atomicAdd(&bin[t[q] < 1023u ? t[q] : 1023u], 1u)] = q;
+    for (uint32_t q = tid; q < nq; q += 1024) order[nq - 1u - atomicAdd(&bin[t[q] < kBins - 1u ? t[q] : kBins - 1u], 1u)] = q;
 }
 
 // ---------------------------------------------------------------------------

@@ -112,7 +112,7 @@ __global__ __launch_bounds__(64 * kPruneWavesPerBlock, RTX_PRUNE_WAVES) void pru
         } else if (p.cbitmap) {
             // Round 5: the database stored once more block by block -- [block][row] 8 bytes, bit j = reference 64 block + j -- so that the
             // 64 references of the best block are ONE 8-byte load per row and lane = row: ten loads per lane for a query of 640 rows, all in
-            // flight together, from a region of 512 KB per block that neighbouring queries (same best block) keep in L2.  The walk through
+            // flight together (32 for a read of t = 2047), from a region of 512 KB per block that neighbouring queries (same best block) keep in L2.  The walk through
             // the tile-major bitmap below took a 128-byte line per row in eighty dependent-id loads per lane: 5.5 of this kernel's 11.9 ms
             // per step.  A lane adds its <= 16 rows into bit-sliced counters (5 planes x 2 words), the lanes are summed as bit-sliced numbers
             // (lane ^ 32: each keeps one word; then within the halves), and lane l reads counter l & 31 of word l >> 5: reference l.
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(64 * kPruneWavesPerBlock, RTX_PRUNE_WAVES) void pru
             for (int w = 0; w < 2; w++)
 #pragma unroll
                 for (int b = 0; b < 11; b++) pl[w][b] = 0;
-            for (uint32_t i0 = 0; i0 < nr_pad; i0 += 256u) {  // four chunks of 64 rows per turn (a query of t <= 1023 rows: four turns at most)
+            for (uint32_t i0 = 0; i0 < nr_pad; i0 += 256u) {  // four chunks of 64 rows per turn (a query of t <= 2047 rows: eight turns at most)
                 uint32_t id[4];
                 uint2 v[4];
 #pragma unroll
@@ -138,10 +138,10 @@ __global__ __launch_bounds__(64 * kPruneWavesPerBlock, RTX_PRUNE_WAVES) void pru
 #pragma unroll
                 for (int k = 0; k < 4; k++) v[k] = C[id[k]];
 #pragma unroll
-                for (int k = 0; k < 4; k++) {  // + 1 into the counters of the set bits (at most 16 rows per lane: planes 0 .. 4)
+                for (int k = 0; k < 4; k++) {  // + 1 into the counters of the set bits (at most 32 rows per lane: planes 0 .. 5)
                     uint32_t cx = v[k].x, cy = v[k].y;
 #pragma unroll
-                    for (int b = 0; b < 5; b++) {
+                    for (int b = 0; b < 6; b++) {
                         const uint32_t nx = pl[0][b] & cx, ny = pl[1][b] & cy;
                         pl[0][b] ^= cx;
                         pl[1][b] ^= cy;
@@ -207,6 +207,7 @@ __global__ __launch_bounds__(64 * kPruneWavesPerBlock, RTX_PRUNE_WAVES) void pru
             // overlap) and summed in byte counters -- a lane sees every kChunks-th row of the list, at most 1024 / 8 = 128 of them
             static_assert(kChunks == 8u, "the byte counters of the best block's exact counts hold the rows of one lane in eight (blocks of 64 references)");
             uint32_t acc_lo = 0u, acc_hi = 0u;
+            uint32_t acc[4] = {0u, 0u, 0u, 0u};  // [pair of references of this lane's chunk]: two 16-bit counters
             const uint32_t bit4 = bit + 4u;
             const uint32_t nr_pad = (nr + 63u) & ~63u;  // the row list is padded with the all-zero row to whole chunks of 64
             // The rows are random lines of the best tile's region (HBM, not L2): kTurns turns = kTurns * kRowsPerTurn rows are in flight
@@ -240,10 +241,15 @@ __global__ __launch_bounds__(64 * kPruneWavesPerBlock, RTX_PRUNE_WAVES) void pru
                 }
                 id[0] = idn[0];
                 id[1] = idn[1];
+                // the byte counters are widened piece by piece (16 rows of this lane at most: a read of t = 2047 brings a lane 256 rows)
+                acc[0] += (acc_lo & 0xFFu) | ((acc_lo & 0xFF00u) << 8);
+                acc[1] += ((acc_lo >> 16) & 0xFFu) | ((acc_lo >> 24) << 16);
+                acc[2] += (acc_hi & 0xFFu) | ((acc_hi & 0xFF00u) << 8);
+                acc[3] += ((acc_hi >> 16) & 0xFFu) | ((acc_hi >> 24) << 16);
+                acc_lo = 0u;
+                acc_hi = 0u;
             }
-            // [pair of references of this lane's chunk]: two 16-bit counters, summed over the row groups (lane c ends up with chunk c)
-            uint32_t acc[4] = {(acc_lo & 0xFFu) | ((acc_lo & 0xFF00u) << 8), ((acc_lo >> 16) & 0xFFu) | ((acc_lo >> 24) << 16),
-                               (acc_hi & 0xFFu) | ((acc_hi & 0xFF00u) << 8), ((acc_hi >> 16) & 0xFFu) | ((acc_hi >> 24) << 16)};
+            // ... summed over the row groups (lane c ends up with chunk c)
 #pragma unroll
             for (int k = 0; k < 4; k++)
 #pragma unroll

@@ -14,7 +14,11 @@ from raxtax_amd import sharded, synth
 
 pytestmark = pytest.mark.gpu
 
-N_REFS, N_Q = 5_000_000, 256
+# The default -m gpu run takes the same path at 1 500 000 references (184 tiles, 23 tiles of bounds, two shards of 750 000): the suite has
+# to stay within the driver's time limit (135 of its 470 s were this one test).  RTX_FULL_SIZE=1 runs it at configs[4]'s
+# 5 000 000 (opt-in; tools/scale_check.py 5000000 is the timed run at that size, profiles/r6*_scale_check_5m.txt).
+FULL = os.environ.get("RTX_FULL_SIZE") == "1"
+N_REFS, N_Q = (5_000_000 if FULL else 1_500_000), 256
 
 
 @pytest.mark.skipif(os.environ.get("RTX_SKIP_5M") == "1", reason="RTX_SKIP_5M=1")
@@ -26,14 +30,14 @@ def test_5m_references_pruned_and_in_two_shards(oracle, emul):
     L = db.length
     tree = rx.Tree.new_flat(db.lineages, db.seq_bytes, db.seq_off)                 # with Tree.k_mer_map: the shards are cut out of it
     whole = rx.Index(rx.Tree.new_flat(db.lineages, db.seq_bytes, db.seq_off, kmer_map=False), debug_taps=True)   # default options: pruned
-    assert whole.device_bytes > 40e9
+    assert whole.device_bytes > (40e9 if FULL else 10e9)
     ex = whole.exact_matches(qs.bases, qs.base_off)
     ref = whole.classify(qs.bases, qs.base_off, *ex)
     assert (ref.status == 0).all()
     st = whole.debug_prune_stats()
     print("tile pruning at 5 M references:", st)
     assert st["pairs"] == N_Q // 2 and st["bound_violations"] == 0 and st["queries_with_threshold"] > 0.9 * N_Q
-    assert st["live_tiles_per_pair"] < 60                                          # of 611
+    assert st["live_tiles_per_pair"] < 60                                          # of 611 (184)
 
     # ---- the oracle on every query, in chunks (a count vector is 10 MB)
     otree = oracle.tree_new_flat(db.lineages, db.seq_bytes, db.seq_off)
@@ -58,7 +62,7 @@ def test_5m_references_pruned_and_in_two_shards(oracle, emul):
                 counts_keep[q] = counts_o[q - a].copy()
             tables[q] = tables_o[q - a].copy()          # table / Z per count; the count vector is recomputed where rows differ
     print(f"{len(seen)} queries read back as the pruned run left them: mean threshold {np.mean([o['threshold'] for o in seen]):.1f}, "
-          f"{np.mean([o['live'] for o in seen]):.2f} of 611 tiles visited per query ({np.mean([o['needed'] for o in seen]):.2f} hold a count above the "
+          f"{np.mean([o['live'] for o in seen]):.2f} of {(N_REFS + 8191) // 8192} tiles visited per query ({np.mean([o['needed'] for o in seen]):.2f} hold a count above the "
           f"threshold), max |p - p_oracle| {max(o['dp'] for o in seen):.2e}, dropped mass {max(o['dropped'] for o in seen):.2e}")
 
     def rows_against_oracle(res, name):

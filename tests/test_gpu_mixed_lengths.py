@@ -120,16 +120,40 @@ def test_coi_reads_with_long_and_short_reads_in_one_batch(oracle):
         assert [x.lineage for x in a] == [x.lineage for x in b] and [x.confidence_values for x in a] == [x.confidence_values for x in b], int(q)
 
 
+def _de_bruijn_4_8():
+    """B(4, 8) as encoded bases (1, 2, 4, 8), linearised: 4^8 + 7 bases that hold every 8-mer once (the standard Lyndon-word construction)."""
+    k, n = 4, 8
+    a = [0] * (k * n)
+    seq = []
+
+    def db(t, p):
+        if t > n:
+            if n % p == 0:
+                seq.extend(a[1:p + 1])
+        else:
+            a[t] = a[t - p]
+            db(t + 1, p)
+            for j in range(a[t - p] + 1, k):
+                a[t] = j
+                db(t + 1, t)
+    import sys
+    sys.setrecursionlimit(10000)
+    db(1, 1)
+    seq = seq + seq[:n - 1]
+    return (1 << np.array(seq, np.uint8)).astype(np.uint8)
+
+
 def test_reads_up_to_the_reference_limit(oracle):
-    """t <= 65 535 is the reference's limit (raxtax.rs:56): reads of 20 kb .. 65 542 bases are served (global-memory forms of hit_count's
-    histogram and of prob_table), one base more is refused with RTX_ERR_TOO_LONG -- for the whole batch, as the reference asserts."""
+    """t <= 65 535 DISTINCT k-mers is the reference's limit (raxtax.rs:56 on utils.rs:27-40): reads of 20 kb .. 90 kb are served (global-memory
+    forms of hit_count's histogram and of prob_table); only a read that holds every one of the 65 536 8-mers trips the reference's assert --
+    the library reports that query (RTX_Q_ALL_KMERS) and classifies the rest of the batch."""
     db = synth.make_db(6000, fanouts=(2, 2, 3, 3, 3, 2))
     rng = np.random.default_rng(41)
     # three chimeras of references (many hits; their k-mers repeat, so t stays near 10 000) and one read of random bases with a
     # reference spliced in: ~ 41 000 distinct k-mers, most of them in no reference
     rnd = (1 << rng.integers(0, 4, 65_542)).astype(np.uint8)
     rnd[1000:1000 + db.length] = db.seq(123)
-    seqs = [_long_read(rng, db, n) for n in (20_000, 33_001, 65_542)] + [rnd, db.seq(5).copy(), db.seq(77).copy()]
+    seqs = [_long_read(rng, db, n) for n in (20_000, 33_001, 90_000)] + [rnd, db.seq(5).copy(), db.seq(77).copy()]
     bases, off = _concat(seqs)
     tree = rx.Tree.new_flat(db.lineages, db.seq_bytes, db.seq_off, kmer_map=False)
     index = rx.Index(tree)
@@ -149,8 +173,71 @@ def test_reads_up_to_the_reference_limit(oracle):
         present = np.bincount(counts_o[q], minlength=int(t_o[q]) + 1)[: int(t_o[q]) + 1] > 0
         d = float(np.max(np.abs(tz[present] - tables_o[q][: int(t_o[q]) + 1][present])))
         assert d < 1e-9, f"probabilities of the {len(seqs[q])}-base read differ by {d}"
-    too_long = _long_read(rng, db, 65_543)
-    b2, o2 = _concat([db.seq(1).copy(), too_long])
-    with pytest.raises(rx.RtxError) as e:
-        index.classify(b2, o2)
-    assert e.value.code == -8, e.value
+    # a de Bruijn sequence B(4, 8): every 8-mer exactly once in 65 543 bases -- t = 65 536, the one case the reference's assert is about
+    every = _de_bruijn_4_8()
+    assert len(every) == 65_543
+    b2, o2 = _concat([db.seq(1).copy(), every, db.seq(9).copy()])
+    r2 = index.classify(b2, o2)
+    assert list(r2.status) == [0, 2, 0] and int(r2.t[1]) == 65_536 and len(r2.rows(1)) == 0
+    _check_against_oracle(r2, otree, b2, o2, np.array([0, 2]), "beside a read with every 8-mer")
+
+
+def test_full_length_16s_reads_take_the_pruned_class(oracle, emul):
+    """Reads of 1 031 .. 2 054 bases (t <= 2047: full-length 16S, the use SINTAX was written for) in numbers have a class of their own since
+    round 6: eleven bit planes on the pair kernel (u16 counts), tile pruning, the memoised tables -- until then they fell to the
+    one-query-per-wave kernel without pruning ("what's missing" 1).  The run AS IT WAS LEFT against the oracle: counts of the
+    visited tiles bit-exact, no unvisited tile above the threshold, probabilities, rows -- with the records path, with the dense epilogues
+    (RTX_OPT_RECORDS = 0), for reads 8 % from their source (tens of live tiles: the second stage of the bounds); and the rows of the
+    same reads through the unpruned class they take when there are only a few of them."""
+    from gpu_common import as_run_oracle_sample
+
+    n_refs, n_q, L = 140_000, 6_000, 1_500          # 18 tiles: the fine union bitmap and the block-major copy exist
+    db = synth.make_db(n_refs, length=L)
+    qs = synth.make_queries(db, n_q, seed=21)
+    qd = synth.make_queries(db, 1_500, seed=23, mu_q=0.08, exact_frac=0.0)
+    rng = np.random.default_rng(22)
+    seqs = []
+    for i in range(n_q):
+        s = qs.seq(i)
+        seqs.append(s[: int(rng.integers(1040, L))].copy() if i % 3 == 0 else s.copy())   # a third of them cut to 1 040 .. 1 499 bases
+    seqs += [_long_read(rng, db, 2054) for _ in range(24)]                                   # the longest reads of the class: t up to 2047
+    seqs += [qd.seq(i).copy() for i in range(qd.n)]
+    order = rng.permutation(len(seqs))
+    seqs = [seqs[int(i)] for i in order]
+    bases, off = _concat(seqs)
+    tree = rx.Tree.new_flat(db.lineages, db.seq_bytes, db.seq_off, kmer_map=False)
+    index = rx.Index(tree, debug_taps=True)
+    otree = oracle.tree_new_flat(db.lineages, db.seq_bytes, db.seq_off)
+    runs = {}
+    for records in (4, 0):
+        rx._lib.check(index._lib.rtx_index_set_option(index._h, 18, records))
+        res = index.classify(bases, off)
+        assert (res.status == 0).all()
+        classes = index.batch_classes()
+        st = index.debug_prune_stats()
+        print(f"RTX_OPT_RECORDS = {records}: classes:", classes, "pruning:", st)
+        assert len(classes) == 1 and classes[0]["planes"] == 11 and classes[0]["tables"] and classes[0]["pair"] and classes[0]["prune"]
+        assert int(res.t.max()) > 1500 and st["pairs"] > 0 and st["bound_violations"] == 0 and st["queries_with_threshold"] > 0.8 * len(seqs)
+        assert st["live_tiles_per_pair"] < 9 and st["fine_blocks_per_pair"] > 0             # of 18; the divergent reads reach the second stage
+        assert (st["record_queries"] > 0) == (records > 0)
+        seen = as_run_oracle_sample(index, res, oracle, otree, bases, off, 300, False, threads=8, emul=emul)
+        print("as the run left them:", seen)
+        assert seen["n"] == 300 and seen["ties"] <= 3 and seen["with_threshold"] > 240 and seen["max_dp"] < 1e-9
+        assert (seen["on_records_path"] > 0) == (records > 0)
+        runs[records] = res
+    for f in ("row_off", "row_lineage", "row_conf", "row_local_signal", "global_signal", "t", "status"):
+        assert np.array_equal(getattr(runs[4], f), getattr(runs[0], f)), f                 # records or counts: the same rows
+    res = runs[4]
+    # a few hundred of the same reads alone: too few for the class -- one query per wave, no pruning, the recurrence kernel (round 5's path)
+    ids = np.sort(rng.choice(len(seqs), 400, replace=False))
+    b2, o2 = _concat([seqs[int(i)] for i in ids])
+    few = index.classify(b2, o2)
+    c2 = index.batch_classes()
+    assert len(c2) == 1 and not c2[0]["pair"] and not c2[0]["prune"] and c2[0]["planes"] >= 12
+    differ = 0
+    for j, q in enumerate(ids):
+        a, b = res.rows(int(q)), few.rows(j)
+        same = [x.lineage for x in a] == [x.lineage for x in b] and [x.confidence_values for x in a] == [x.confidence_values for x in b]
+        differ += not same
+    print(f"{differ} of {len(ids)} reads print another row through the unpruned class")
+    assert differ <= 4          # (exact ties / a confidence on a rounding boundary: pruned and unpruned probabilities differ by ~1e-11)

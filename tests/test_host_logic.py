@@ -303,3 +303,20 @@ def test_format_query_numbers_are_printf_numbers():
         assert n > 0
         want = "q\tk:A,p:B,c:C,o:D,f:E,g:F,s:G\t" + ",".join("%.2f" % c for c in conf[q, :7]) + "\t%.5f\t%.5f" % (local[q], gs[q])
         assert buf.raw[:n].decode() == want, (q, local[q], gs[q])
+
+
+def test_a_taxonomy_deeper_than_the_device_walk_is_refused_with_its_lineage():
+    """RTX_MAX_DEPTH = 32 levels per result row (the reference has no limit, lineage.rs:119-179): a deeper lineage is refused where the tree
+    is built, and the error names it."""
+    import raxtax_amd as rx
+
+    seq = np.array([1, 2, 4, 8] * 5, np.uint8)
+    ok = ",".join(f"l{i}" for i in range(32))
+    deep = ",".join(f"d{i}" for i in range(33))
+    rx.Tree.new([ok, "a,b"], [seq, seq])                       # 32 levels: fine
+    with pytest.raises(rx.RtxError) as e:
+        rx.Tree.new([ok, deep], [seq, seq])
+    assert e.value.code == -6 and "33 levels" in str(e.value) and "d0,d1,d2" in str(e.value)
+    with pytest.raises(rx.RtxError) as e:
+        rx.parse_reference_fasta_str(f">x;tax={deep};\nACGTACGTACGTACGTAAAA\n>y;tax=a,b;\nACGTACGTACGTACGTAAAC\n")
+    assert e.value.code == -6

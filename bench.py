@@ -259,6 +259,31 @@ def parity_block(args, rx, index, view, ctx, db, qs, flags, n_sample=2000):
     return out
 
 
+def leg_parity(rx, index, view, ctx, lineages, seq_bytes, seq_off, q_bases, q_off, flags, n_sample):
+    """parity_sample of a caveat leg: the leg's LAST step as the device left it -- a seeded sample of its last sub-batch
+    against the oracle (its own Tree::new of the leg's database): t, the counts of the visited tiles bit-exact and no unvisited tile above
+    the threshold where the leg pruned, probabilities within 1e-9, the rows the step returned (checks.as_run_oracle_sample)."""
+    from raxtax_amd import checks
+
+    if ctx is None:
+        return None
+    t0 = time.perf_counter()
+    out = {"n": 0, "ok": False, "where": "last sub-batch of the leg's last step, as the run left it (no recount)"}
+    try:
+        otree = ctx["orc"].tree_new_flat(lineages, seq_bytes, seq_off)
+        res = rx.Result(view)
+        seen = checks.as_run_oracle_sample(index, res, ctx["orc"], otree, q_bases, q_off, n_sample, bool(flags), threads=available_parallelism())
+        out.update(n=seen["n"], ok=True, pruned=bool(seen["with_threshold"]), counts_bit_exact=bool(seen["with_threshold"]) or None, max_dp=seen["max_dp"], ties=seen["ties"],
+                   rows_identical=seen["rows_identical"], queries_with_threshold=seen["with_threshold"],
+                   tiles_visited_per_query=seen["live"] / max(seen["n"], 1), on_records_path=seen.get("on_records_path", 0), tolerance_asserted=1e-9)
+    except AssertionError as e:
+        out["error"] = str(e)[:400] or "assertion failed"
+    except Exception as e:
+        out["error"] = f"{type(e).__name__}: {str(e)[:400]}"
+    out["seconds"] = round(time.perf_counter() - t0, 1)
+    return out
+
+
 def multirank_parity_block(args, rx, index, view, ctx, db, qs, flags, world, last_parts, n_own=600, n_other=200):
     """The self-check of a line with N > 1 ranks, rank 0, after the timed region, untimed:
       * rank 0's own last timed step as its device left it: checks.as_run_oracle_sample on its last sub-batch (as parity_block at N = 1);
@@ -762,7 +787,7 @@ def extras_block(args, rx, lib, index, tree, db, qs, flags):
     return out
 
 
-def real_composition_block(args, rx, lib, flags):
+def real_composition_block(args, rx, lib, flags, ctx=None):
     """value_real_composition: the reference's methodology (scripts/common.py:11-25: real sequences, 90 % -> database, 10 % held out as
     queries) on the only real data it ships -- the 7 868 Diptera COI records of example/diptera_queries.fasta (committed as
     tests/golden/diptera_queries.fasta; ~205 bp, t ~ 195) -- scaled to a 14-tile database (raxtax_amd/synth.py:
@@ -798,6 +823,7 @@ def real_composition_block(args, rx, lib, flags):
     stages = {s: round(ms, 3) for s, (ms, n) in index.stage_times().items() if n}
     view = index.download(copy=False)
     ok = int((np.ctypeslib.as_array(view.status, shape=(n_q,)) == 0).sum())
+    parity = leg_parity(rx, index, view, ctx, h.lineages, h.seq_bytes, h.seq_off, h.q_bases, h.q_off, flags, 300)
     # tile pruning forced on (RTX_OPT_PRUNE_SELF_SAMPLE = 0) and off (RTX_OPT_TILE_PRUNE = 0), same handle
     rx._lib.check(lib.rtx_index_set_option(index._h, 22, 0))
     index.upload(h.q_bases, h.q_off)
@@ -812,7 +838,7 @@ def real_composition_block(args, rx, lib, flags):
     return {"value": n_q / dt, "ms_per_step": dt * 1e3, "tile_pruning": "on" if pruning_on else "off (self-sample of the database)",
             "self_sample_live_share": self_live, "value_pruned": n_q / dt_pruned, "ms_per_step_pruned": dt_pruned * 1e3,
             "value_unpruned": n_q / dt_full, "ms_per_step_unpruned": dt_full * 1e3, "steps": steps,
-            "queries": n_q, "refs": len(h.lineages), "tiles": ntiles, "classified_ok": ok, "stage_ms_per_step": stages, "stage_ms_per_step_pruned": stages_pruned,
+            "queries": n_q, "refs": len(h.lineages), "tiles": ntiles, "classified_ok": ok, "parity_sample": parity, "stage_ms_per_step": stages, "stage_ms_per_step_pruned": stages_pruned,
             "stage_ms_per_step_unpruned": stages_full,
             "live_tiles_per_pair": st["live_tiles_per_pair"], "live_tiles_per_query": st.get("live_tiles_per_query"),
             "tiles_above_threshold_per_query": st["tiles_above_threshold_per_query"], "mean_threshold": st["mean_threshold"],
@@ -876,19 +902,20 @@ def mixed_lengths_block(args, rx, lib, index, db, flags):
             "what": "131 072 COI reads alone / with ten reads of 1.1 .. 8 kb among them (one batch): length classes keep the barcodes on their path"}
 
 
-def long_reads_block(args, rx, lib, flags):
+def long_reads_block(args, rx, lib, flags, ctx=None):
     """value_long_reads: full-length 16S-like reads (1 500 bases, t ~ 1 490: the SINTAX use case the reference's README cites) against a
-    database of as many references as the headline's, same phylo model.  These queries take the one-query-per-wave counting kernel with
-    12 bit planes and the recurrence form of the probability stage: no pair kernel, no tile pruning, no memoised tables."""
+    database of as many references as the headline's, same phylo model.  Since round 6 these queries have a length class of their own
+    (t <= 2047): eleven bit planes on the pair kernel, tile pruning, the memoised tables (until then: one query per wave, every tile,
+    the recurrence kernel -- 0.26 M reads/s).  `parity_sample`: the leg's last step against the oracle, as run."""
     from raxtax_amd import synth
 
-    n_refs, n_q, L = args.refs, 16384, 1500
+    n_refs, n_q, L = args.refs, 65536, 1500
     db = synth.make_db(n_refs, length=L)
     qs = synth.make_queries(db, n_q, seed=5)
     tree = rx.Tree.new_flat(db.lineages, db.seq_bytes, db.seq_off, kmer_map=False)
     index = rx.Index(tree, device=0, stage_timing=True)
     index.upload(qs.bases, qs.base_off)
-    steps = 2
+    steps = 3
     index.run(flags)
     index.download(copy=False)
     t0 = time.perf_counter()
@@ -898,8 +925,9 @@ def long_reads_block(args, rx, lib, flags):
     dt = (time.perf_counter() - t0) / steps
     ok = int((np.ctypeslib.as_array(view.status, shape=(n_q,)) == 0).sum())
     stages = {s: round(ms, 2) for s, (ms, n) in index.stage_times().items() if n}
+    parity = leg_parity(rx, index, view, ctx, db.lineages, db.seq_bytes, db.seq_off, qs.bases, qs.base_off, flags, 200)
     return {"value": n_q / dt, "ms_per_step": dt * 1e3, "queries": n_q, "refs": n_refs, "query_len": L, "classified_ok": ok, "steps": steps,
-            "classes": index.batch_classes(), "stage_ms_per_step": stages,
+            "parity_sample": parity, "classes": index.batch_classes(), "stage_ms_per_step": stages,
             "what": f"{n_q} synthetic reads of {L} bases (phylo model, 2 % from their source) vs {n_refs} references of {L} bases"}
 
 
@@ -1168,8 +1196,13 @@ def main():
             line["value_mixed_lengths"] = mixed_lengths_block(args, rx, lib, index, db, flags)
             index.upload(qs.bases, qs.base_off)     # (the headline's batch again)
             if args.config == 2 and args.config_name != "custom size":
-                line["value_real_composition"] = real_composition_block(args, rx, lib, flags)
-                line["value_long_reads"] = long_reads_block(args, rx, lib, flags)
+                line["value_real_composition"] = real_composition_block(args, rx, lib, flags, ctx)
+                line["value_long_reads"] = long_reads_block(args, rx, lib, flags, ctx)
+                for leg in ("value_real_composition", "value_long_reads"):     # a leg that does not hold against the oracle fails the line like the headline's sample
+                    ps = line[leg].get("parity_sample") if isinstance(line[leg], dict) else None
+                    if ps is not None and not ps["ok"]:
+                        parity_failed = True
+                        line["parity_sample"] = dict(line.get("parity_sample") or {}, ok=False, error=f"{leg}: {ps.get('error', '')}")
         line["cpu_baseline"] = cpu_baseline(db, qs, args.cpu_seconds, bool(flags), ctx) if ctx is not None else None
         print(json.dumps(line), flush=True)
     if dist is not None:

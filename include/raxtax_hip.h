@@ -507,7 +507,10 @@ int64_t rtx_result_pack(const rtx_result_view *res, uint8_t *buf, uint64_t cap);
  * were packed from.  labels: [n] the labels of the buffer's queries; exact_one: [n] the id of a query's ONLY exact match (the override of
  * raxtax.rs:73-84; 0xFFFFFFFF: none or several) or NULL; flags: RTX_SKIP_EXACT_MATCHES / RTX_RAW_CONFIDENCE switch the override off as in the
  * reference.  out: the texts back to back, each NUL-terminated, lines of one query '\n'-joined; line_off: [n + 1] where each starts (a query
- * without rows -- status != 0 -- has an empty text) or NULL.  Returns the bytes written, with out == NULL the bytes needed, or a negative RTX_ERR_*. */
+ * without rows -- status != 0 -- has an empty text) or NULL.  Returns the bytes written, with out == NULL the bytes needed, or a negative RTX_ERR_*;
+ * a buffer that is too small: -(bytes needed) - RTX_NEED_BASE (every value below -RTX_NEED_BASE; ABI 5) -- the text has been formatted to be
+ * measured, the caller allocates and calls once more. */
+#define RTX_NEED_BASE 1024
 int64_t rtx_records_format(const rtx_tree *tree, const uint8_t *records, uint64_t n_bytes, const char *const *labels,
                            const uint32_t *exact_one, uint32_t flags, char *out, uint64_t cap, uint64_t *line_off, uint32_t threads);
 

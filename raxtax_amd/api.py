@@ -250,7 +250,9 @@ class Index:
             check(self._lib.rtx_index_set_option(self._h, 12, int(locator)))
         if tile_prune is not None:
             check(self._lib.rtx_index_set_option(self._h, 13, int(tile_prune)))
-            if tile_prune and prune_self_sample is None:   # an explicit True asks for the pruned path whatever the handle's self-sample said (A/B tests)
+            # NOTE: an explicit tile_prune=True also sets RTX_OPT_PRUNE_SELF_SAMPLE = 0 -- it asks for the pruned path whatever the
+            # handle's self-sample said (A/B tests); the C API keeps the two options independent.  Pass prune_self_sample=True to keep the verdict.
+            if tile_prune and prune_self_sample is None:
                 check(self._lib.rtx_index_set_option(self._h, 22, 0))
         if debug_taps:
             check(self._lib.rtx_index_set_option(self._h, 14, 1))

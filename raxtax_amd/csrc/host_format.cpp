@@ -330,7 +330,10 @@ extern "C" int64_t rtx_records_format(const rtx_tree *tree, const uint8_t *recor
     uint64_t total = 0;
     for (auto &pt : parts) { if (pt.rc) { rtx::set_error("rtx_records_format: malformed records"); return pt.rc; } total += pt.text.size(); }
     if (!out) return (int64_t)total;  // size query (the text is formatted to be measured: call once with a generous buffer instead where that matters)
-    if (cap < total) { rtx::set_error("rtx_records_format: buffer of %llu bytes, need %llu", (unsigned long long)cap, (unsigned long long)total); return RTX_ERR_INVALID; }
+    if (cap < total) {  // the caller learns what it needs from this call: -(bytes needed) - RTX_NEED_BASE (no second pass to measure: ADVICE r5)
+        rtx::set_error("rtx_records_format: buffer of %llu bytes, need %llu", (unsigned long long)cap, (unsigned long long)total);
+        return -(int64_t)total - (int64_t)RTX_NEED_BASE;
+    }
     uint64_t at = 0;
     std::vector<uint64_t> base(nt);
     for (unsigned w = 0; w < nt; w++) { base[w] = at; at += parts[w].text.size(); }

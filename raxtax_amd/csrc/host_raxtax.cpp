@@ -155,10 +155,11 @@ int run(rtx_index *const *indices, uint32_t n_dev, const rtx_tree *tree, uint64_
 
     // chunks follow one another through rtx_batch_download_then_run (the last sub-batch of a chunk is finalised beside the next chunk): two
     // large sub-batches per chunk instead of four small ones (RTX_OPT_MIN_SUB_BATCHES); the handles get their setting back below
-    struct MinSubs {
+    struct MinSubs {  // (the caller's own RTX_OPT_MIN_SUB_BATCHES comes back, and the handle's last batch stays what it was: ADVICE r5)
         rtx_index *const *ix; uint32_t n;
-        MinSubs(rtx_index *const *i, uint32_t k, uint64_t n_chunks) : ix(i), n(n_chunks > 1 ? k : 0) { for (uint32_t d = 0; d < n; d++) (void)rtx_index_set_option(ix[d], RTX_OPT_MIN_SUB_BATCHES, 2); }
-        ~MinSubs() { for (uint32_t d = 0; d < n; d++) (void)rtx_index_set_option(ix[d], RTX_OPT_MIN_SUB_BATCHES, 4); }
+        std::vector<uint32_t> was;
+        MinSubs(rtx_index *const *i, uint32_t k, uint64_t n_chunks) : ix(i), n(n_chunks > 1 ? k : 0), was(n) { for (uint32_t d = 0; d < n; d++) was[d] = rtx::index_swap_min_subs(ix[d], 2); }
+        ~MinSubs() { for (uint32_t d = 0; d < n; d++) (void)rtx::index_swap_min_subs(ix[d], was[d]); }
     } min_subs_guard(indices, n_dev, n_chunks);
     // handles that share a device (rehearsals of the multi-GPU path on one GPU) run on one stream each for the duration of the call
     struct SharedDevice {

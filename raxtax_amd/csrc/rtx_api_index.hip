@@ -8,6 +8,8 @@
 namespace rtx {
 int index_device(const rtx_index *index) { return index ? index->device : -1; }
 void index_set_shared_device(rtx_index *index, bool shared) { if (index) index->shared_device = shared; }
+// RTX_OPT_MIN_SUB_BATCHES for the duration of a call of the host mirror: the batch state of the handle stays, the caller's setting comes back
+uint32_t index_swap_min_subs(rtx_index *index, uint32_t v) { if (!index) return 0; const uint32_t old = index->min_subs; index->min_subs = v; return old; }
 }  // namespace rtx
 
 namespace {
@@ -470,6 +472,9 @@ static void build_two_level(rtx_index *ix) {
     const size_t rows1 = (size_t)ix->n_rows + 1;
     if (rows1 * 256u > 0xFFFFFFFFull) return;  // (a tile's region is addressed through one buffer descriptor)
     if ((uint64_t)ix->u_ntiles * rows1 * 256u > 0xFFFFFFFFull) return;  // (bounds2_build_kernel: a thread per word, one grid dimension; ~130 M references)
+    // bounds2_kernel keeps 256 bytes of LDS per A-tile beside its 13 KB of lists: a workgroup's LDS ends at 160 KB (beyond that the
+    // launch would fail and surface as an error of the whole run -- such a database keeps the one-level pass)
+    if ((size_t)ix->n_atiles * 256u + 16384u > 160u * 1024u) { ix->n_atiles = ix->n_btiles = 0; return; }
     if (ix->d_abitmap.alloc((size_t)ix->n_atiles * rows1 * 64) || ix->d_bbitmap.alloc((size_t)ix->n_btiles * rows1 * 64)) {
         ix->d_abitmap.release();
         ix->d_bbitmap.release();

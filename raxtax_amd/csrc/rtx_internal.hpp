@@ -27,6 +27,7 @@ unsigned host_threads(unsigned want, unsigned sharers = 1);
 // (rtx_api_index.hip) the device of a handle; a handle that shares its device with another one driven beside it runs on one stream
 int index_device(const rtx_index *index);
 void index_set_shared_device(rtx_index *index, bool shared);
+uint32_t index_swap_min_subs(rtx_index *index, uint32_t v);  // returns the previous value
 
 #ifndef RTX_NODE_TYPES_DEFINED
 #define RTX_NODE_TYPES_DEFINED

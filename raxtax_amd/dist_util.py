@@ -106,13 +106,14 @@ def format_records(tree, buf: np.ndarray, labels, exact_one=None, flags: int = 0
 
     lib = _lib.load()
     buf = np.ascontiguousarray(buf, dtype=np.uint8)
+    if len(buf) < 32 or int(buf[24:32].view(np.int64)[0]) != RECORD_VERSION:      # (first: a short or foreign buffer is an RtxError, not an IndexError)
+        raise _lib.RtxError(-1, "format_records: not a record buffer of this version")
     n_q = int(buf[:8].view(np.int64)[0])
-    assert len(labels) == n_q
+    if len(labels) != n_q:
+        raise _lib.RtxError(-1, f"format_records: {len(labels)} labels for a record buffer of {n_q} queries")
     arr = labels if isinstance(labels, C.Array) else (C.c_char_p * n_q)(*[l if isinstance(l, bytes) else l.encode() for l in labels])
     ex = None if exact_one is None else np.ascontiguousarray(exact_one, dtype=np.uint32)
     exp = _lib.ptr(ex, _lib.u32p) if ex is not None else None
-    if len(buf) < 32 or int(buf[24:32].view(np.int64)[0]) != RECORD_VERSION:
-        raise _lib.RtxError(-1, "format_records: not a record buffer of this version")
     off = np.zeros(n_q + 1, dtype=np.uint64)
     cap = 4 * len(buf) + (1 << 20)     # text is ~2.3 x the records on the bench workload: one pass as a rule ...
     for attempt in range(2):
@@ -123,9 +124,9 @@ def format_records(tree, buf: np.ndarray, labels, exact_one=None, flags: int = 0
         n = lib.rtx_records_format(tree._h, _lib.ptr(buf, _lib.u8p), len(buf), arr, exp, flags, out.ctypes.data_as(C.c_char_p), cap, _lib.ptr(off, _lib.u64p), threads)
         if n >= 0:
             return out[:n], off
-        need = lib.rtx_records_format(tree._h, _lib.ptr(buf, _lib.u8p), len(buf), arr, exp, flags, None, 0, None, threads)   # ... else measured
-        _lib.check(min(need, 0))
-        cap = need + 1
+        if n > -1024:          # a real error (RTX_ERR_*)
+            _lib.check(n)
+        cap = -n - 1024 + 1    # ... else the failed call has said what it needs (RTX_NEED_BASE)
     _lib.check(n)
     return out[:0], off
 

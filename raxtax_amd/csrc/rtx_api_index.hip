@@ -474,7 +474,7 @@ static void build_two_level(rtx_index *ix) {
     if ((uint64_t)ix->u_ntiles * rows1 * 256u > 0xFFFFFFFFull) return;  // (bounds2_build_kernel: a thread per word, one grid dimension; ~130 M references)
     // bounds2_kernel keeps 256 bytes of LDS per A-tile beside its 13 KB of lists: a workgroup's LDS ends at 160 KB (beyond that the
     // launch would fail and surface as an error of the whole run -- such a database keeps the one-level pass)
-    if ((size_t)ix->n_atiles * 256u + 16384u > 160u * 1024u) { ix->n_atiles = ix->n_btiles = 0; return; }
+    if ((size_t)ix->n_atiles * 256u + 32768u > 160u * 1024u) { ix->n_atiles = ix->n_btiles = 0; return; }
     if (ix->d_abitmap.alloc((size_t)ix->n_atiles * rows1 * 64) || ix->d_bbitmap.alloc((size_t)ix->n_btiles * rows1 * 64)) {
         ix->d_abitmap.release();
         ix->d_bbitmap.release();

@@ -30,9 +30,11 @@
 
 namespace rtx {
 
-constexpr uint32_t kB2Cap = 1024u;                       // entries per list (t <= 1023), padded with the zero row to multiples of kB2Pad
 constexpr uint32_t kB2Pad = 256u;                        // the largest group of rows of either level (level B: 16 instructions x 16 rows)
-constexpr uint32_t kB2LdsDw = 3u * kB2Cap + kB2Pad;       // lists | zero rows; behind them per A-tile [2][64] u16: the level-A bounds both queries' lanes found
+// entries per list (t <= 1023; eleven planes: t <= 2047), padded with the zero row to multiples of kB2Pad
+constexpr uint32_t b2_cap(int planes) { return planes > 10 ? 2048u : 1024u; }
+// lists | zero rows; behind them per A-tile [2][64] u16: the level-A bounds both queries' lanes found
+constexpr uint32_t b2_lds_dw(int planes) { return 3u * b2_cap(planes) + kB2Pad; }
 
 // eight load instructions of R rows each: this lane's rows are list[8 * grp .. + 8) of the unit, its bytes col .. col + 16 of each
 template <int SHIFT>
@@ -109,6 +111,7 @@ __global__ __launch_bounds__(64, 2) void bounds2_kernel(Bounds2Params p) {
     const uint32_t pair = blockIdx.x < np8 * 8u ? (blockIdx.x & 7u) * np8 + (blockIdx.x >> 3) : blockIdx.x;
     const uint32_t qa = pair * 2u, qb = qa + 1u;
     const bool has_b = qb < p.nq;
+    constexpr uint32_t kB2Cap = b2_cap(NP);
     uint32_t *l_both = b2_lds, *l_a = b2_lds + kB2Cap, *l_b = b2_lds + 2u * kB2Cap, *l_zero = b2_lds + 3u * kB2Cap;
     uint16_t *l_keep = reinterpret_cast<uint16_t *>(l_zero + kB2Pad);  // [n_atiles][2][64] level-A bound of every lane's tile, per query
     for (uint32_t i = lane; i < kB2Pad; i += 64) l_zero[i] = p.zero_row;
@@ -133,7 +136,7 @@ __global__ __launch_bounds__(64, 2) void bounds2_kernel(Bounds2Params p) {
             const uint32_t row = rec[c].x & 0x3FFFFFFFu;
             const bool sh = ia && ib, oa = ia && !ib, ob = ib && !ia;
             const unsigned long long bs = __ballot(sh), ba = __ballot(oa), bo = __ballot(ob);
-            // (a list never overflows: t <= 1023 rows per query; the guard keeps a corrupt union from writing beyond it)
+            // (a list never overflows: t <= 1023 / 2047 rows per query; the guard keeps a corrupt union from writing beyond it)
             const uint32_t ps = n_both + (uint32_t)__popcll(bs & lt_mask), pa_ = n_a + (uint32_t)__popcll(ba & lt_mask), pb_ = n_b + (uint32_t)__popcll(bo & lt_mask);
             if (sh && ps < kB2Cap) l_both[ps] = row;
             if (oa && pa_ < kB2Cap) l_a[pa_] = row;
@@ -363,9 +366,10 @@ __global__ __launch_bounds__(1024) void heavy_items_kernel(const uint8_t *__rest
 
 void launch_bounds2(hipStream_t s, const Bounds2Params &p, uint32_t nq, int planes, const HitParams &hp, uint32_t u_ntiles, uint32_t *items) {
     const uint32_t np = (nq + 1u) / 2u;
-    const size_t lds = (size_t)kB2LdsDw * 4u + (size_t)p.n_atiles * 256u;
+    const size_t lds = (size_t)b2_lds_dw(planes) * 4u + (size_t)p.n_atiles * 256u;
     if (planes <= 8) hipLaunchKernelGGL((bounds2_kernel<8>), dim3(np), dim3(64), lds, s, p);
-    else hipLaunchKernelGGL((bounds2_kernel<10>), dim3(np), dim3(64), lds, s, p);
+    else if (planes <= 10) hipLaunchKernelGGL((bounds2_kernel<10>), dim3(np), dim3(64), lds, s, p);
+    else hipLaunchKernelGGL((bounds2_kernel<11>), dim3(np), dim3(64), lds, s, p);  // reads of 1 031 .. 2 054 bases (lists of 2 048 rows: six workgroups per CU by LDS)
     if (!p.heavy || !items) return;
     // the heavy queries: the one-level pass over the union bitmap of blocks of 64 (on the bench workload an all but empty launch)
     uint32_t *n_items = items + (size_t)np * u_ntiles;

@@ -32,7 +32,13 @@ constexpr uint32_t kPairListDw = kPairCap + 192u;     // + padding to a multiple
 constexpr uint32_t kPairMaskWords = 64u;              // dense-mask words (u64) per query and tile kept in LDS: rstride <= 4096
 constexpr uint32_t kPairSidDw = 2u * kSparseIt * 64u;     // slot ids of the sparse segments of both queries (read at the start, used in the epilogue)
 constexpr uint32_t kPairLdsBytes = 3u * kPairListDw * 4u + 2u * kPairMaskWords * 8u + 32u * 4u + kPairSidDw * 4u;  // lists | dense masks | 32 x the zero row | sparse slot ids
-constexpr int kPairNB = 4;                            // buffers of eight rows per wave
+#ifndef RTX_PAIR_NB
+#define RTX_PAIR_NB 3  // (four until round 6: 24 rows in flight and 13 spilled registers beat 32 rows and 46 -- hit_count 24.3 -> 22.8 ms per step at configs[2], every tile counted: 60.5 -> 57.4 ms per 65 536 queries)
+#endif
+#ifndef RTX_PAIR_WAVES
+#define RTX_PAIR_WAVES 2
+#endif
+constexpr int kPairNB = RTX_PAIR_NB;                   // buffers of eight rows per wave (ten planes and fewer; eleven planes: three)
 
 // ---------------------------------------------------------------------------
 // Union of the row lists of the queries 2 * pair and 2 * pair + 1 of a sub-batch (ascending row ids, as kmer_extract
@@ -107,27 +113,37 @@ __global__ __launch_bounds__(64) void pair_union_kernel(const uint32_t *__restri
 // On entry the four buffers hold (have requested) the first group; every buffer is requested again as soon as it has
 // been folded -- in the last group with the first rows of the NEXT segment (`next`), so that the three segments of a
 // wave run as one pipeline: the load latency is exposed once per wave, not once per list.
-template <int NP, int MODE>
-__device__ __forceinline__ void fold_seg(uint32_t (&pa)[4][NP], uint32_t (&pb)[4][NP], uint4 (&buf)[4][8], const uint32_t *list,
+template <int NP, int MODE, int NB>
+__device__ __forceinline__ void fold_seg(uint32_t (&pa)[4][NP], uint32_t (&pb)[4][NP], uint4 (&buf)[NB][8], const uint32_t *list,
                                          uint32_t ng, const uint32_t *next, uint32_t lane, __amdgpu_buffer_rsrc_t rsrc,
                                          uint32_t voff) {
+    static_assert(NB >= 2 && NB <= 4, "groups of 16, 24 or 32 rows");
+    constexpr uint32_t GR = 8u * (uint32_t)NB;
     for (uint32_t g = 0; g < ng; g++) {
-        const uint32_t *src = g + 1 < ng ? list + (g + 1) * 32u : next;  // wave-uniform
-        const uint32_t idn = src[lane & 31u];
-        uint4 ca[4], cb[4];
+        const uint32_t *src = g + 1 < ng ? list + (g + 1) * GR : next;  // wave-uniform
+        const uint32_t idn = src[lane < GR ? lane : 0u];
+        uint4 ca[NB], cb[NB];
 #pragma unroll
-        for (int b = 0; b < 4; b++) {
+        for (int b = 0; b < NB; b++) {
             if (MODE != 2) ca[b] = tree8<NP>(pa, buf[b]);
             if (MODE != 1) cb[b] = tree8<NP>(pb, buf[b]);
             load8v_at(buf[b], rsrc, voff, idn, b * 8);
         }
         if (MODE != 2) {
-            const uint4 c4a = csa_plane<NP, 3>(pa, ca[0], ca[1]), c4b = csa_plane<NP, 3>(pa, ca[2], ca[3]);
-            ripple4<NP, 5>(pa, csa_plane<NP, 4>(pa, c4a, c4b));
+            const uint4 c4a = csa_plane<NP, 3>(pa, ca[0], ca[1]);
+            if constexpr (NB == 2) ripple4<NP, 4>(pa, c4a);
+            else {
+                const uint4 c4b = NB == 3 ? half_plane<NP, 3>(pa, ca[NB - 1]) : csa_plane<NP, 3>(pa, ca[NB - 2], ca[NB - 1]);
+                ripple4<NP, 5>(pa, csa_plane<NP, 4>(pa, c4a, c4b));
+            }
         }
         if (MODE != 1) {
-            const uint4 c4a = csa_plane<NP, 3>(pb, cb[0], cb[1]), c4b = csa_plane<NP, 3>(pb, cb[2], cb[3]);
-            ripple4<NP, 5>(pb, csa_plane<NP, 4>(pb, c4a, c4b));
+            const uint4 c4a = csa_plane<NP, 3>(pb, cb[0], cb[1]);
+            if constexpr (NB == 2) ripple4<NP, 4>(pb, c4a);
+            else {
+                const uint4 c4b = NB == 3 ? half_plane<NP, 3>(pb, cb[NB - 1]) : csa_plane<NP, 3>(pb, cb[NB - 2], cb[NB - 1]);
+                ripple4<NP, 5>(pb, csa_plane<NP, 4>(pb, c4a, c4b));
+            }
         }
     }
 }
@@ -247,30 +263,33 @@ __device__ __forceinline__ void pair_tile_block(const HitParams &p, uint32_t *ld
             }
         }
         rows_loaded += n_both + n_a + n_b;
-        // groups of 32 rows; the rows a list lacks for its last group are the zero row
-        const uint32_t g_both = (n_both + 31u) >> 5, g_a = (n_a + 31u) >> 5, g_b = (n_b + 31u) >> 5;
-        for (uint32_t i = n_both + lane; i < g_both * 32u; i += 64) l_both[i] = zero_off;
-        for (uint32_t i = n_a + lane; i < g_a * 32u; i += 64) l_a[i] = zero_off;
-        for (uint32_t i = n_b + lane; i < g_b * 32u; i += 64) l_b[i] = zero_off;
+        // groups of 32 rows (eleven planes: 24 -- 88 plane registers leave room for three buffers of eight rows, with four the kernel
+        // spilled 128 registers); the rows a list lacks for its last group are the zero row
+        constexpr int NB = NP > 10 ? 3 : kPairNB;
+        constexpr uint32_t GR = 8u * (uint32_t)NB;
+        const uint32_t g_both = (n_both + GR - 1u) / GR, g_a = (n_a + GR - 1u) / GR, g_b = (n_b + GR - 1u) / GR;
+        for (uint32_t i = n_both + lane; i < g_both * GR; i += 64) l_both[i] = zero_off;
+        for (uint32_t i = n_a + lane; i < g_a * GR; i += 64) l_a[i] = zero_off;
+        for (uint32_t i = n_b + lane; i < g_b * GR; i += 64) l_b[i] = zero_off;
         wave_lds_sync();
         const uint32_t *first = g_both ? l_both : (g_a ? l_a : (g_b ? l_b : nullptr));
         if (first) {
-            uint4 buf[4][8];
-            const uint32_t idv = first[lane & 31u];
+            uint4 buf[NB][8];
+            const uint32_t idv = first[lane < GR ? lane : 0u];
 #pragma unroll
-            for (int b = 0; b < 4; b++) load8v_at(buf[b], rsrc, voff, idv, b * 8);
+            for (int b = 0; b < NB; b++) load8v_at(buf[b], rsrc, voff, idv, b * 8);
             const uint32_t *after_a = g_b ? l_b : l_zero, *after_both = g_a ? l_a : after_a;
             // the shared rows are folded ONCE, into A's planes while B's are still empty, and copied: every row of the
             // union costs one fold (first round only: later rounds -- t > kPairCap - 64 -- have no shared list)
             if (g_both) {
-                fold_seg<NP, 1>(pa, pb, buf, l_both, g_both, after_both, lane, rsrc, voff);
+                fold_seg<NP, 1, NB>(pa, pb, buf, l_both, g_both, after_both, lane, rsrc, voff);
 #pragma unroll
                 for (int w = 0; w < 4; w++)
 #pragma unroll
                     for (int b = 0; b < NP; b++) pb[w][b] = pa[w][b];
             }
-            if (g_a) fold_seg<NP, 1>(pa, pb, buf, l_a, g_a, after_a, lane, rsrc, voff);
-            if (g_b) fold_seg<NP, 2>(pa, pb, buf, l_b, g_b, l_zero, lane, rsrc, voff);
+            if (g_a) fold_seg<NP, 1, NB>(pa, pb, buf, l_a, g_a, after_a, lane, rsrc, voff);
+            if (g_b) fold_seg<NP, 2, NB>(pa, pb, buf, l_b, g_b, l_zero, lane, rsrc, voff);
         }
         wave_lds_sync();  // the lists are rewritten (next round) or become the histogram and the byte counters
         first_round = false;
@@ -319,7 +338,7 @@ __device__ __forceinline__ void pair_tile_block(const HitParams &p, uint32_t *ld
 // (live_items_kernel).  A pruned sub-batch of the bench workload keeps 1.5 of 62 tiles per pair: with the two-dimensional grid 97 % of
 // its million workgroups came up only to read their mask and leave, which took a third of the launch.
 template <int NP, bool kPacked, int kBounds, bool kItems>
-__global__ __launch_bounds__(64, 2) void hit_count_pair_kernel(HitParams p) {
+__global__ __launch_bounds__(64, RTX_PAIR_WAVES) void hit_count_pair_kernel(HitParams p) {
     extern __shared__ uint32_t lds_dw[];
     const uint32_t lane = threadIdx.x;
     if (kItems) {

@@ -354,7 +354,7 @@ struct FinaliseParams {
     uint32_t *flags_out;  // bit0: no room (the host enlarges the arena and repeats the run)
 };
 
-constexpr int kBounds2MaxPlanes = 10;  // bounds2_kernel (rtx_bounds2.hip) is instantiated for 8 and 10 planes; the class of 11 (t <= 2047) takes the one-level pass
+constexpr int kBounds2MaxPlanes = 11;  // bounds2_kernel (rtx_bounds2.hip) is instantiated for 8, 10 and 11 planes
 
 struct PrefixParams {
     const uint8_t *status;

@@ -1144,6 +1144,9 @@ def main():
                 "classified_ok": ok, "skip_exact_matches": bool(args.skip_exact_matches),
                 "host_threads_per_rank": int(lib.rtx_host_threads()),      # affinity mask capped by the cgroup quota, divided by the ranks on this host
                 "host_share": args.host_share or int(os.environ.get("LOCAL_WORLD_SIZE", "1")),
+                "hbm_bytes": {"index": int(index.device_bytes), "workspace": int(index.workspace_bytes) if hasattr(index, "workspace_bytes") else None,
+                              "workspace_parts": index.workspace_parts() if hasattr(index, "workspace_parts") else None,
+                              "note": "index: bitmaps, segment classes, union bitmaps, taxonomy; workspace: probability tables, two scratch sets of a sub-batch, inputs, result arrays"},
                 "gathered_queries_last_step": (gathered_q[0] if (dist is not None and not args.shard_db) else None),
                 "sub_batch": int(round(args.queries / max(stage_n["hit_count"] / args.steps, 1))) if stage_n["hit_count"] else None,
                 "exact_match_lookup": ("host hash map, once, untimed: %.3f s" % t_exact) if t_exact is not None else

@@ -183,6 +183,11 @@ int rtx_index_create_from_tree(int device, const rtx_tree *tree, rtx_index **out
 void rtx_index_destroy(rtx_index *index);
 uint64_t rtx_index_num_refs(const rtx_index *index);
 uint64_t rtx_index_device_bytes(const rtx_index *index); /* HBM held by the index itself */
+uint64_t rtx_index_workspace_bytes(const rtx_index *index); /* ... and by everything else of the handle as of the last upload: probability tables, the scratch
+                                                               sets of a sub-batch, inputs, result arena and final result arrays (ABI 5) */
+/* ... in parts (bytes): [0] probability tables, [1] counts, [2] record segments, [3] boundary prefix sums, [4] per-tile masks and sparse-slot lists,
+ * [5] the rest of the scratch sets, [6] inputs and processing order, [7] result arena and final arrays; [8] = scratch sets in use */
+int rtx_index_workspace_parts(const rtx_index *index, uint64_t out[9]);
 /* queries processed per kernel wave (sub-batch); 0 = choose from free HBM */
 int rtx_index_set_batch(rtx_index *index, uint32_t sub_batch);
 /* Tuning / test knobs.  RTX_OPT_PROB_MODE: 0 = auto (memoised cmf tables when every query has

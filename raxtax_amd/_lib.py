@@ -98,6 +98,8 @@ _SIGNATURES = {
     "rtx_index_destroy": (None, [C.c_void_p]),
     "rtx_index_num_refs": (C.c_uint64, [C.c_void_p]),
     "rtx_index_device_bytes": (C.c_uint64, [C.c_void_p]),
+    "rtx_index_workspace_bytes": (C.c_uint64, [C.c_void_p]),
+    "rtx_index_workspace_parts": (C.c_int, [C.c_void_p, u64p]),
     "rtx_index_set_batch": (C.c_int, [C.c_void_p, C.c_uint32]),
     "rtx_set_default_option": (C.c_int, [C.c_int, C.c_uint64]),
     "rtx_index_set_option": (C.c_int, [C.c_void_p, C.c_int, C.c_uint64]),

@@ -290,6 +290,19 @@ class Index:
     def device_bytes(self) -> int:
         return self._lib.rtx_index_device_bytes(self._h)
 
+    @property
+    def workspace_bytes(self) -> int:
+        """HBM of everything else the handle holds as of the last upload (tables, scratch sets, inputs, result arrays)."""
+        return self._lib.rtx_index_workspace_bytes(self._h)
+
+    def workspace_parts(self) -> dict:
+        out = np.zeros(9, dtype=np.uint64)
+        check(self._lib.rtx_index_workspace_parts(self._h, ptr(out, u64p)))
+        names = ("prob_tables", "counts", "record_segments", "prefix_sums", "tile_masks_and_slot_lists", "other_scratch", "inputs_and_order", "results")
+        d = {k: int(v) for k, v in zip(names, out[:8])}
+        d["scratch_sets"] = int(out[8])
+        return d
+
     # ---- staged interface -------------------------------------------------------------
     def upload(self, bases: np.ndarray, base_off: np.ndarray, exact_ids: Optional[np.ndarray] = None,
                exact_off: Optional[np.ndarray] = None):

@@ -698,6 +698,49 @@ uint64_t rtx_index_device_bytes(const rtx_index *index) {
     return index->d_seg_dbits.n * 8 + index->d_seg_sbits.n * 8 + index->d_seg_sbase.n * 4 + index->d_seginfo.n * 4 + index->d_segcls.n * 4 + index->d_segslots.n * 2 + index->d_bitmap.n * 4 + index->d_row_of.n * 4 + index->d_row_len.n * 8 + index->d_list_len.n * 4 + index->d_loc_table.n * 4 + index->d_ubitmap.n * 4 + index->d_fbitmap.n * 4 + index->d_abitmap.n * 4 + index->d_bbitmap.n + index->d_cbitmap.n + index->d_em_table.n * 8 + index->d_em_rep_off.n * 8 + index->d_em_rep_bytes.n + index->d_em_goff.n * 4 + index->d_em_gids.n * 4 + index->d_lnfact.n * 8 +
            index->d_noderec.n * 16 + index->d_bnd_bits.n + index->d_bnd_rank.n * 4;
 }
+// HBM the handle holds beside the index proper, as of the last upload: the memoised probability tables, the scratch sets of a sub-batch
+// (k-mers, row lists, masks, counts, histograms, bounds, record segments ...), the inputs of two batches, the result arena and the
+// final result arrays.  What a deployment has to leave free beside rtx_index_device_bytes (bench.py reports both: VERDICT r5 item 7).
+uint64_t rtx_index_workspace_bytes(const rtx_index *ix) {
+    if (!ix) return 0;
+    uint64_t b = (ix->d_tab_cmf.n + ix->d_tab_ratio.n) * 8 + ix->d_tab_off.n * 8 + ix->d_tab_moff.n * 4 + (ix->d_tab_ilo.n + ix->d_tab_sat.n) * 2 + ix->d_node_depth.n + ix->d_node_sig0.n + ix->d_node_begin.n * 4 + ix->d_node_eb.n * 8;
+    for (const auto &sc : ix->sc)
+        b += (sc.d_kmers.n + sc.d_counts.n + sc.d_tilemax.n + sc.d_tile_ub.n + sc.d_prune_thr.n + sc.d_prune_i1.n + sc.d_rec_nslots.n + sc.d_rec_slots.n) * 2 +
+             (sc.d_rows.n + sc.d_t.n + sc.d_nrows.n + sc.d_hist.n + sc.d_order.n + sc.d_srows.n + sc.d_nsparse.n + sc.d_nu.n + sc.d_live.n + sc.d_best_key.n + sc.d_items.n + sc.d_best.n +
+              sc.d_heavy_items.n + sc.d_fine_items.n + sc.d_rec_cnt.n + sc.d_rec.n) * 4 +
+             (sc.d_dmask.n + sc.d_table_z.n + sc.d_prefix.n + sc.d_urec.n) * 8 + sc.d_heavy.n;
+    for (const auto &in : ix->in) b += in.d_packed.n + (in.d_base_off.n + in.d_exact_off.n) * 8 + in.d_exact_ids.n * 4;
+    b += ix->d_bases.n + ix->d_prob_scratch.n * 8 + (ix->d_skey_in.n + ix->d_skey_out.n) * 8 + (ix->d_sidx.n + ix->d_perm.n + ix->d_iperm.n) * 4 + ix->d_sort_tmp.n + ix->d_group_rows.n * 4 + ix->d_exact_grp.n * 4;
+    b += ix->d_status.n + (ix->d_t_all.n + ix->d_nrows_all.n + ix->d_n_rows.n + ix->d_ndist.n) * 4 + (ix->d_gs.n + ix->d_z.n + ix->d_hq.n + ix->d_row_start.n) * 8 + ix->d_arena.n * sizeof(DevRow);
+    b += (ix->d_fin_t.n + ix->d_fin_row_count.n + ix->d_fin_lineage.n + ix->d_fin_node.n + ix->d_fin_depth.n) * 4 + ix->d_fin_status.n + ix->d_fin_depth8.n + ix->d_fin_hund.n +
+         (ix->d_fin_gs.n + ix->d_fin_local.n + ix->d_fin_conf.n + ix->d_fin_row_begin.n) * 8;
+    return b;
+}
+// ... in parts: [0] probability tables, [1] counts, [2] record segments, [3] boundary prefix sums, [4] per-tile masks and sparse-slot lists,
+// [5] the rest of the scratch sets, [6] inputs + processing order, [7] result arena + final arrays; [8] scratch sets in use
+int rtx_index_workspace_parts(const rtx_index *ix, uint64_t out[9]) {
+    if (!ix || !out) { set_error("null argument"); return RTX_ERR_INVALID; }
+    for (int i = 0; i < 9; i++) out[i] = 0;
+    out[0] = (ix->d_tab_cmf.n + ix->d_tab_ratio.n) * 8 + ix->d_tab_off.n * 8 + ix->d_tab_moff.n * 4 + (ix->d_tab_ilo.n + ix->d_tab_sat.n) * 2;
+    for (const auto &sc : ix->sc) {
+        if (!sc.d_kmers.p) continue;
+        out[8]++;
+        out[1] += sc.d_counts.n * 2;
+        out[2] += sc.d_rec.n * 4 + sc.d_rec_cnt.n * 4 + (sc.d_rec_nslots.n + sc.d_rec_slots.n) * 2;
+        out[3] += sc.d_prefix.n * 8;
+        out[4] += sc.d_dmask.n * 8 + (sc.d_srows.n + sc.d_nsparse.n) * 4;
+    }
+    out[6] = ix->d_bases.n + (ix->d_skey_in.n + ix->d_skey_out.n) * 8 + (ix->d_sidx.n + ix->d_perm.n + ix->d_iperm.n) * 4 + ix->d_sort_tmp.n;
+    for (const auto &in : ix->in) out[6] += in.d_packed.n + (in.d_base_off.n + in.d_exact_off.n) * 8 + in.d_exact_ids.n * 4;
+    out[7] = ix->d_status.n + (ix->d_t_all.n + ix->d_nrows_all.n + ix->d_n_rows.n + ix->d_ndist.n) * 4 + (ix->d_gs.n + ix->d_z.n + ix->d_hq.n + ix->d_row_start.n) * 8 + ix->d_arena.n * sizeof(DevRow) +
+             (ix->d_fin_t.n + ix->d_fin_row_count.n + ix->d_fin_lineage.n + ix->d_fin_node.n + ix->d_fin_depth.n) * 4 + ix->d_fin_status.n + ix->d_fin_depth8.n + ix->d_fin_hund.n +
+             (ix->d_fin_gs.n + ix->d_fin_local.n + ix->d_fin_conf.n + ix->d_fin_row_begin.n) * 8;
+    const uint64_t all = rtx_index_workspace_bytes(ix);
+    uint64_t named = 0;
+    for (int i = 0; i < 8; i++) named += out[i];
+    out[5] = all > named ? all - named : 0;
+    return RTX_OK;
+}
 int rtx_index_set_batch(rtx_index *index, uint32_t sub_batch) {
     if (!index) { set_error("null index handle"); return RTX_ERR_INVALID; }
     index->uploaded = index->ran = index->synced = false;  // as RTX_OPT_SUB_BATCH: read at the next upload

@@ -44,6 +44,8 @@ SubBatch sub_batch_of(rtx_index *ix, uint32_t sb, bool timed) {
 // The class whose sub-batches are enqueued next: its shape becomes the handle's (the kernel parameters are filled from these fields).
 void apply_class(rtx_index *ix, uint32_t c) {
     const rtx_index::BatchClass &k = ix->cls[c];
+    ix->diet_used = k.diet;
+    ix->cnt_rows_cur = k.diet ? k.cnt_rows : k.sub_batch;
     ix->tmax = k.tmax;
     ix->kstride = k.kstride;
     ix->rstride = k.rstride;
@@ -89,13 +91,20 @@ int plan_sub_batches(rtx_index *ix) {
 // Counts of a sub-batch between hit_count and taxon_prefix.  With 10 bit planes (t <= 1023) they travel packed,
 // 10 bits per reference: [B][npad] low bytes, then [B][npad / 8] u16 with the two high bits of eight references
 // each; otherwise [B][npad] u16.  Both live in the same allocation (sized for the format in use).
+// Rows: one per query of the sub-batch -- or, behind tile pruning with the records path (BatchClass::diet), sub_batch >> diet_shift rows that
+// prune_kernel hands to the queries that take the dense epilogues (HitParams::cnt_row): at configs[2] 83 of the 125 GB of two scratch sets were
+// counts that 99 % of the queries never wrote.  The recounting taps (rtx_api_debug.hip) count a sub-batch in full: a row per query again.
+constexpr uint32_t kDietMinRows = 1024;
+uint32_t diet_rows(const rtx_index *ix, uint32_t B) { return std::min<uint32_t>(B, std::max<uint32_t>(kDietMinRows, B >> ix->diet_shift)); }
+uint32_t counts_rows_layout(const rtx_index *ix) { return ix->diet_used && !ix->dbg_full_run && !ix->dbg_full ? ix->cnt_rows_cur : ix->sub_batch; }
 uint8_t *counts_lo(rtx_index *ix, rtx_index::Scratch &sc) { return reinterpret_cast<uint8_t *>(sc.d_counts.p); }
 uint16_t *counts_hi(rtx_index *ix, rtx_index::Scratch &sc) {
-    return reinterpret_cast<uint16_t *>(reinterpret_cast<uint8_t *>(sc.d_counts.p) + (size_t)ix->sub_batch * ix->npad);
+    return reinterpret_cast<uint16_t *>(reinterpret_cast<uint8_t *>(sc.d_counts.p) + (size_t)counts_rows_layout(ix) * ix->npad);
 }
 size_t counts_elems(const rtx_index *ix, uint64_t B) {  // u16 elements of d_counts
     return ix->packed() ? (size_t)B * ix->npad * 5 / 8 : (size_t)B * ix->npad;
 }
+int ensure_full_counts(rtx_index *ix, rtx_index::Scratch &sc) { return sc.d_counts.alloc(counts_elems(ix, ix->sub_batch)); }
 
 hipEvent_t stage_event(rtx_index *ix, const SubBatch &b, int stage, int which) {
     return ix->events[((size_t)b.sb * RTX_NUM_STAGES + stage) * 2 + which];
@@ -304,6 +313,15 @@ int enqueue_hit(rtx_index *ix, const SubBatch &b, uint32_t flags, hipStream_t s,
         const bool records = part == 0 && ix->rec_used && sc.d_rec.p != nullptr;
         const RecordRef rr{sc.d_rec_nslots.p, sc.d_rec_slots.p, sc.d_rec_cnt.p, sc.d_rec.p, std::min<uint32_t>(ix->rec_opt, kRecMaxSlots)};
         if (records) { pr.rec = rr; pr.rec_max_slots = rr.stride; }
+        if (ix->diet_used && !(records && sc.d_cnt_row.p)) { set_error("internal: the counts buffer is on its diet without the records path"); return RTX_ERR_STATE; }
+        if (records && ix->diet_used && sc.d_cnt_row.p) {  // the rows of the counts buffer are handed out with the decision about the records path
+            RTX_HIP(hipMemsetAsync(sc.d_cnt_cursor.p, 0, 4, s));
+            pr.cnt_row = sc.d_cnt_row.p;
+            pr.cnt_cursor = sc.d_cnt_cursor.p;
+            pr.cnt_cap = ix->cnt_rows_cur;
+            pr.flags_out = ix->d_flags.p;
+            hp.cnt_row = sc.d_cnt_row.p;
+        }
         ProbTables tb{ix->d_tab_cmf.p, ix->d_tab_ratio.p, ix->d_tab_off.p, ix->d_tab_moff.p, ix->d_tab_ilo.p, ix->d_tab_sat.p, ix->tab_tmax};
         launch_prune(s, pr, tb, b.nq);
         if (part == 1) { RTX_HIP(hipGetLastError()); return RTX_OK; }  // the caller exchanges RTX_BUF_BEST, then part 2
@@ -433,6 +451,7 @@ int enqueue_prob_prefix(rtx_index *ix, const SubBatch &b, bool fuse_walk, bool p
     fp.fuse_walk = fuse_walk ? 1u : 0u;
     const bool records = fuse_walk && fp.prune_thr && ix->rec_used && sc.d_rec.p != nullptr;
     fp.rec_nslots = records ? sc.d_rec_nslots.p : nullptr;
+    fp.cnt_row = records && ix->diet_used && sc.d_cnt_row.p ? sc.d_cnt_row.p : nullptr;
     if (fuse_walk) {
         fp.walk = walk_params(ix, b, sc.d_prefix.p);
         int rc_r = fp.walk.sub_alloc ? reset_sub_alloc(ix, s) : RTX_OK;
@@ -647,6 +666,23 @@ int begin_run(rtx_index *ix, uint32_t *n_sub_out, bool *timed_out, bool cluster)
                   scratch_ok(s0, k.sub_batch) && (!ix->staged || scratch_ok(ix->sc[1], k.sub_batch));
         k.rec = k.prune && whole && ix->rec_opt != 0u && ix->n_bnd_local == ix->n_bnd && s0.d_rec.p != nullptr &&
                 s0.d_rec.n >= (size_t)k.sub_batch * std::min<uint32_t>(ix->rec_opt, kRecMaxSlots) * 8192u;
+        // the diet of the counts buffer: only with the records path (the queries without rows are exactly those on it), in every set the class may run through
+        auto diet_ok = [&](const rtx_index::Scratch &sc) { return sc.d_rec.p != nullptr && sc.d_cnt_row.p != nullptr && sc.d_cnt_cursor.p != nullptr && sc.d_cnt_row.n >= k.sub_batch; };
+        k.diet = k.rec && diet_rows(ix, k.sub_batch) < k.sub_batch && diet_ok(s0);
+        if (k.diet && !k.side)
+            for (uint32_t j = 1; j <= 2u; j++)
+                if (ix->sc[j].d_kmers.p != nullptr && !diet_ok(ix->sc[j])) k.diet = false;
+        k.cnt_rows = k.diet ? diet_rows(ix, k.sub_batch) : k.sub_batch;
+        {   // room for that many rows in the sets the class runs through (a class that was sized for the diet and runs without it, a diet that has grown)
+            const size_t need = ix->packed_opt && k.planes <= 10 ? (size_t)k.cnt_rows * ix->npad * 5 / 8 : (size_t)k.cnt_rows * ix->npad;
+            for (uint32_t j = 0; j < 4u; j++) {
+                rtx_index::Scratch &sc = ix->sc[j];
+                if ((j == kSideSet) != k.side || sc.d_kmers.p == nullptr || sc.d_counts.n >= need) continue;
+                RTX_HIP(hipStreamSynchronize(ix->stream));  // (nothing of an earlier run may still read the old buffer)
+                int rc_c = sc.d_counts.alloc(need);
+                if (rc_c) return rc_c;
+            }
+        }
         any_pair = any_pair || k.pair;
         any_prune = any_prune || k.prune;
         b_max = std::max(b_max, k.sub_batch);
@@ -1088,7 +1124,10 @@ int alloc_scratch_set(rtx_index *ix, uint32_t k) {
         n_kmers = std::max(n_kmers, B * kc.kstride);
         n_rows = std::max(n_rows, B * kc.rstride);
         n_dmask = std::max(n_dmask, B * ix->ntiles * (kc.rstride / 64));
-        n_counts = std::max(n_counts, ix->packed_opt && kc.planes <= 10 ? B * ix->npad * 5 / 8 : B * ix->npad);
+        // (a class that will prune with the records path starts with a fraction of the rows: begin_run enlarges the buffer if the run turns out otherwise)
+        const bool diet = kc.will_prune && ix->rec_opt != 0u && ix->n_refs == ix->n_total && ix->n_bnd_local == ix->n_bnd;
+        const size_t R = diet ? diet_rows(ix, (uint32_t)B) : B;
+        n_counts = std::max(n_counts, ix->packed_opt && kc.planes <= 10 ? R * ix->npad * 5 / 8 : R * ix->npad);
         n_hist = std::max(n_hist, B * kc.hstride);
         n_urec = std::max(n_urec, ((B + 1u) / 2u) * 2u * kc.rstride);
         if (kc.huge) n_probscr = std::max(n_probscr, B * ((prob_table_lds_bytes(kc.tmax) + 7) / 8));
@@ -1113,7 +1152,7 @@ int alloc_scratch_set(rtx_index *ix, uint32_t k) {
         if (ix->rec_opt && ix->n_refs == ix->n_total) {  // the records path; without its buffers the run takes the dense epilogues
             const size_t slots = std::min<uint32_t>(ix->rec_opt, kRecMaxSlots);
             if (sc.d_rec_nslots.alloc(B) || sc.d_rec_slots.alloc(B * kRecMaxSlots) || sc.d_rec_cnt.alloc(B * kRecMaxSlots) ||
-                sc.d_rec.alloc(B * slots * 8192u))
+                sc.d_rec.alloc(B * slots * 8192u) || sc.d_cnt_row.alloc(B) || sc.d_cnt_cursor.alloc(4))
                 sc.d_rec.release();
         }
     }

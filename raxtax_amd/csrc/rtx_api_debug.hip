@@ -142,8 +142,11 @@ static int debug_recount_full(rtx_index *ix) {
     const uint32_t n_sub = ix->n_sub_total;
     SubBatch b = sub_batch_of(ix, n_sub - 1, false);
     b.set = ix->last_set;
+    RTX_HIP(hipStreamSynchronize(ix->stream));
+    int rc = ensure_full_counts(ix, ix->sc[b.set]);  // the recount writes the counts of EVERY query of the sub-batch (the run's buffer may be on its diet)
+    if (rc) return rc;
     ix->dbg_full_run = true;
-    int rc = enqueue_kmer(ix, b, ix->stream);
+    rc = enqueue_kmer(ix, b, ix->stream);
     if (!rc) rc = enqueue_hit(ix, b, ix->last_flags, ix->stream);
     if (!rc) rc = enqueue_prob_prefix(ix, b, false, true);
     ix->dbg_full_run = false;
@@ -156,6 +159,12 @@ static int debug_recount_full(rtx_index *ix) {
 // u16 counts of one slot of the last sub-batch on the device (unpacked into a scratch row if they are packed)
 static int debug_counts_u16(rtx_index *ix, uint32_t slot, const uint16_t **out) {
     rtx_index::Scratch &sc = ix->sc[ix->last_set];
+    if (ix->diet_used && !ix->dbg_full && sc.d_cnt_row.p) {  // as the run left them: the query's row of the counts buffer (HitParams::cnt_row)
+        uint32_t row = 0;
+        RTX_HIP(hipMemcpy(&row, sc.d_cnt_row.p + slot, 4, hipMemcpyDeviceToHost));
+        if (row == 0xFFFFFFFFu) { set_error("debug tap: the query holds no row of the counts buffer (records path)"); return RTX_ERR_STATE; }
+        slot = row;
+    }
     if (!ix->packed()) { *out = sc.d_counts.p + (size_t)slot * ix->npad; return RTX_OK; }
     int rc = ix->d_counts_dbg.alloc(ix->npad);
     if (rc) return rc;

@@ -360,8 +360,10 @@ __device__ __forceinline__ void hit_epilogue_x(const HitParams &p, uint32_t (&pl
     const bool tile_full = (((uint64_t)tile + 1u) << 13) <= p.n_refs;  // wave-uniform
     // references of this lane from ref0 on that exist (only looked at in the last tile: |value| < 2^31 there)
     const int32_t refs_left = tile_full ? 0x7FFFFFFF : (int32_t)((int64_t)p.n_refs - (int64_t)ref0);
-    uint16_t *out = p.counts + (size_t)q * p.npad + ref0;
-    uint8_t *out_lo = p.counts_lo + (size_t)q * p.npad + ref0;
+    const uint32_t crow = p.cnt_row ? (uint32_t)__builtin_amdgcn_readfirstlane((int)p.cnt_row[q]) : q;  // the query's row of the counts buffer
+    const bool has_row = crow != 0xFFFFFFFFu;  // (none: the rows ran out -- the run is repeated with a larger buffer; nothing is stored)
+    uint16_t *out = p.counts + (size_t)(has_row ? crow : 0u) * p.npad + ref0;
+    uint8_t *out_lo = p.counts_lo + (size_t)(has_row ? crow : 0u) * p.npad + ref0;
     uint32_t hiw[8];  // packed format: the two high bits of the 8 references of group g in bits 16 (g & 1) + [0, 16) of hiw[g / 2]
 #pragma unroll
     for (int i = 0; i < 8; i++) hiw[i] = 0;
@@ -414,7 +416,7 @@ __device__ __forceinline__ void hit_epilogue_x(const HitParams &p, uint32_t (&pl
                             u32x2_nt nv;
                             nv.x = lo8.x;
                             nv.y = lo8.y;
-                            __builtin_nontemporal_store(nv, reinterpret_cast<u32x2_nt *>(out_lo + goff));
+                            if (has_row) __builtin_nontemporal_store(nv, reinterpret_cast<u32x2_nt *>(out_lo + goff));
                         }
                         if (NP > 8) {  // (eight planes <=> t <= 255: a count -- dense and sparse part together at most t -- fits its low byte)
                             // high bytes (0..3 each) -> 2 bits per reference: byte j moves to bit 2j
@@ -425,7 +427,7 @@ __device__ __forceinline__ void hit_epilogue_x(const HitParams &p, uint32_t (&pl
                             const int gi = w * 4 + g2;
                             hiw[gi >> 1] |= h16 << ((gi & 1) * 16);
                         }
-                    } else {
+                    } else if (has_row) {
                         *reinterpret_cast<uint4 *>(out + goff) = st;
                     }
                     const uint32_t cw[4] = {st.x, st.y, st.z, st.w};
@@ -464,8 +466,8 @@ __device__ __forceinline__ void hit_epilogue_x(const HitParams &p, uint32_t (&pl
         }
     }
     if (kPacked && NP <= 8) {  // no count above 255: the tile's high-bit words are zero
-        if (active) {
-            uint4 *dst = reinterpret_cast<uint4 *>(p.counts_hi + (size_t)q * (p.npad >> 3) + (size_t)tile * 1024u + lane * 16u);
+        if (active && has_row) {
+            uint4 *dst = reinterpret_cast<uint4 *>(p.counts_hi + (size_t)crow * (p.npad >> 3) + (size_t)tile * 1024u + lane * 16u);
             __builtin_nontemporal_store(u32x4_t{0u, 0u, 0u, 0u}, reinterpret_cast<u32x4_t *>(dst));
             __builtin_nontemporal_store(u32x4_t{0u, 0u, 0u, 0u}, reinterpret_cast<u32x4_t *>(dst) + 1);
         }
@@ -479,9 +481,9 @@ __device__ __forceinline__ void hit_epilogue_x(const HitParams &p, uint32_t (&pl
             for (int gi = 0; gi < 16; gi++) tr[(uint32_t)gi * L + lane] = (uint16_t)(hiw[gi >> 1] >> ((gi & 1) * 16));
         }
         wave_lds_sync();
-        if (active) {
+        if (active && has_row) {
             const uint4 a = reinterpret_cast<const uint4 *>(tr)[lane * 2u], b = reinterpret_cast<const uint4 *>(tr)[lane * 2u + 1u];
-            uint4 *dst = reinterpret_cast<uint4 *>(p.counts_hi + (size_t)q * (p.npad >> 3) + (size_t)tile * 1024u + lane * 16u);
+            uint4 *dst = reinterpret_cast<uint4 *>(p.counts_hi + (size_t)crow * (p.npad >> 3) + (size_t)tile * 1024u + lane * 16u);
             __builtin_nontemporal_store(u32x4_t{a.x, a.y, a.z, a.w}, reinterpret_cast<u32x4_t *>(dst));
             __builtin_nontemporal_store(u32x4_t{b.x, b.y, b.z, b.w}, reinterpret_cast<u32x4_t *>(dst) + 1);
         }

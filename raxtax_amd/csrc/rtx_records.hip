@@ -61,7 +61,7 @@ __global__ __launch_bounds__(64) void records_tail_kernel(TailParams p) {
     const uint32_t tile_v = lane < ns ? (uint32_t)p.rec.slots[(size_t)q * kRecMaxSlots + lane] : 0u;
     const uint32_t cnt_v = lane < ns ? p.rec.cnt[(size_t)q * kRecMaxSlots + lane] : 0u;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    double *__restrict__ Prow = p.prefix + (size_t)q * p.n_bnd;
+    double *__restrict__ Prow = p.prefix + (size_t)q * p.n_bnd;  // (the slow path; with the rows on their diet it takes one first, below)
     // pass 0: entries into LDS; if they do not fit, pass 1: the whole prefix row into memory (every boundary its running sum)
     uint32_t E = 0, n_rec = 0;
     bool slow = false;
@@ -126,6 +126,16 @@ __global__ __launch_bounds__(64) void records_tail_kernel(TailParams p) {
         if (pass == 0u) {
             if (E <= kTailEntries) break;
             slow = true;
+            if (p.cnt_cursor) {  // a row of the prefix buffer for this query (the dense queries got theirs from prune_kernel: PruneParams::cnt_row)
+                uint32_t r = 0;
+                if (lane == 0) r = atomicAdd(p.cnt_cursor, 1u);
+                r = (uint32_t)__builtin_amdgcn_readfirstlane((int)r);
+                if (r >= p.cnt_cap) {  // none left: the host enlarges the buffers and repeats the run
+                    if (lane == 0) { atomicOr(p.flags_out, 4u); p.walk.n_rows[gq] = 0; p.walk.row_start[gq] = 0; }
+                    return;
+                }
+                Prow = p.prefix + (size_t)r * p.n_bnd;
+            }
         } else {
             for (uint32_t b = filled + lane; b < p.n_bnd; b += 64) Prow[b] = carry;  // from the last run on: everything
         }

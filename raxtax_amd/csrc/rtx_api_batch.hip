@@ -311,7 +311,7 @@ int enqueue_hit(rtx_index *ix, const SubBatch &b, uint32_t flags, hipStream_t s,
         pr.detail = ix->debug_taps && ix->d_prune_detail.n >= (size_t)b.nq * kPruneDetailWords ? ix->d_prune_detail.p : nullptr;
         // the records path: whole-database handles whose walk rides in the prefix launch (enqueue_prob_prefix starts records_tail_kernel there)
         const bool records = part == 0 && ix->rec_used && sc.d_rec.p != nullptr;
-        const RecordRef rr{sc.d_rec_nslots.p, sc.d_rec_slots.p, sc.d_rec_cnt.p, sc.d_rec.p, std::min<uint32_t>(ix->rec_opt, kRecMaxSlots)};
+        const RecordRef rr{sc.d_rec_nslots.p, sc.d_rec_slots.p, sc.d_rec_cnt.p, sc.d_rec.p, std::min<uint32_t>(ix->rec_opt, kRecMaxSlots), ix->rec_seg_len, ix->d_flags.p};
         if (records) { pr.rec = rr; pr.rec_max_slots = rr.stride; }
         if (ix->diet_used && !(records && sc.d_cnt_row.p)) { set_error("internal: the counts buffer is on its diet without the records path"); return RTX_ERR_STATE; }
         if (records && ix->diet_used && sc.d_cnt_row.p) {  // the rows of the counts buffer are handed out with the decision about the records path
@@ -461,7 +461,7 @@ int enqueue_prob_prefix(rtx_index *ix, const SubBatch &b, bool fuse_walk, bool p
     launch_taxon_prefix(s, fp, b.nq);
     if (records) {  // the queries on the records path: prefix sums from their records, the walk from LDS (rtx_records.hip)
         TailParams tp{};
-        tp.rec = RecordRef{sc.d_rec_nslots.p, sc.d_rec_slots.p, sc.d_rec_cnt.p, sc.d_rec.p, std::min<uint32_t>(ix->rec_opt, kRecMaxSlots)};
+        tp.rec = RecordRef{sc.d_rec_nslots.p, sc.d_rec_slots.p, sc.d_rec_cnt.p, sc.d_rec.p, std::min<uint32_t>(ix->rec_opt, kRecMaxSlots), ix->rec_seg_len, ix->d_flags.p};
         tp.t = sc.d_t.p;
         tp.table_z = sc.d_table_z.p;
         tp.hstride = ix->hstride;
@@ -663,10 +663,18 @@ int begin_run(rtx_index *ix, uint32_t *n_sub_out, bool *timed_out, bool cluster)
         // two neighbours per wave only pays when neighbours are related: with the processing order on
         k.pair = ix->pair_opt && cluster && k.planes <= 11 && ix->n_q > 1 && k.rstride <= 4096;
         const rtx_index::Scratch &s0 = ix->sc[k.side ? kSideSet : 0u];  // (a side class runs through the set of its own)
+        if (whole && ix->rec_opt != 0u && ix->pruning())  // (segments that have grown since the workspace was sized: RecordRef::seg_len)
+            for (uint32_t j = 0; j < 4u; j++) {
+                rtx_index::Scratch &sc = ix->sc[j];
+                const size_t need_r = (size_t)k.sub_batch * std::min<uint32_t>(ix->rec_opt, kRecMaxSlots) * ix->rec_seg_len;
+                if ((j == kSideSet) != k.side || sc.d_kmers.p == nullptr || sc.d_rec.p == nullptr || sc.d_rec.n >= need_r) continue;
+                RTX_HIP(hipStreamSynchronize(ix->stream));
+                if (sc.d_rec.alloc(need_r)) sc.d_rec.release();
+            }
         k.prune = ix->pruning() && k.pair && k.use_tables && ix->tile_skip && ix->d_ubitmap.p && (whole || shard) &&
                   scratch_ok(s0, k.sub_batch) && (!ix->staged || scratch_ok(ix->sc[1], k.sub_batch));
         k.rec = k.prune && whole && ix->rec_opt != 0u && ix->n_bnd_local == ix->n_bnd && s0.d_rec.p != nullptr &&
-                s0.d_rec.n >= (size_t)k.sub_batch * std::min<uint32_t>(ix->rec_opt, kRecMaxSlots) * 8192u;
+                s0.d_rec.n >= (size_t)k.sub_batch * std::min<uint32_t>(ix->rec_opt, kRecMaxSlots) * ix->rec_seg_len;
         // the diet of the counts buffer: only with the records path (the queries without rows are exactly those on it), in every set the class may run through
         auto diet_ok = [&](const rtx_index::Scratch &sc) { return sc.d_rec.p != nullptr && sc.d_cnt_row.p != nullptr && sc.d_cnt_cursor.p != nullptr && sc.d_cnt_row.n >= k.sub_batch; };
         k.diet = k.rec && diet_rows(ix, k.sub_batch) < k.sub_batch && diet_ok(s0);
@@ -1156,7 +1164,7 @@ int alloc_scratch_set(rtx_index *ix, uint32_t k) {
         if (ix->rec_opt && ix->n_refs == ix->n_total) {  // the records path; without its buffers the run takes the dense epilogues
             const size_t slots = std::min<uint32_t>(ix->rec_opt, kRecMaxSlots);
             if (sc.d_rec_nslots.alloc(B) || sc.d_rec_slots.alloc(B * kRecMaxSlots) || sc.d_rec_cnt.alloc(B * kRecMaxSlots) ||
-                sc.d_rec.alloc(B * slots * 8192u) || sc.d_cnt_row.alloc(B) || sc.d_cnt_cursor.alloc(4))
+                sc.d_rec.alloc(B * slots * ix->rec_seg_len) || sc.d_cnt_row.alloc(B) || sc.d_cnt_cursor.alloc(4))
                 sc.d_rec.release();
         }
     }

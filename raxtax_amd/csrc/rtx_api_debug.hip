@@ -264,11 +264,11 @@ int rtx_debug_run_counts(rtx_index *ix, uint64_t query, uint16_t *counts, uint8_
         RTX_HIP(hipMemcpy(tiles, sc.d_rec_slots.p + (size_t)slot * kRecMaxSlots, sizeof tiles, hipMemcpyDeviceToHost));
         RTX_HIP(hipMemcpy(cnts, sc.d_rec_cnt.p + (size_t)slot * kRecMaxSlots, sizeof cnts, hipMemcpyDeviceToHost));
         for (uint64_t r = 0; r < ix->n_refs; r++) counts[r] = live[r >> 13] ? 0u : 0xFFFFu;
-        std::vector<uint32_t> seg(8192);
+        std::vector<uint32_t> seg(ix->rec_seg_len);
         for (uint32_t k = 0; k < n_seg && k < stride; k++) {
-            const uint32_t c = std::min<uint32_t>(cnts[k], 8192u);
+            const uint32_t c = std::min<uint32_t>(cnts[k], ix->rec_seg_len);
             if (!c) continue;
-            RTX_HIP(hipMemcpy(seg.data(), sc.d_rec.p + ((size_t)slot * stride + k) * 8192u, (size_t)c * 4, hipMemcpyDeviceToHost));
+            RTX_HIP(hipMemcpy(seg.data(), sc.d_rec.p + ((size_t)slot * stride + k) * ix->rec_seg_len, (size_t)c * 4, hipMemcpyDeviceToHost));
             uint32_t prev = 0;
             for (uint32_t i = 0; i < c; i++) {
                 const uint32_t rl = seg[i] & 8191u;

@@ -125,7 +125,7 @@ static int download_streamed(rtx_index *ix, rtx_index::HostRes &hr, bool *done, 
             RTX_HIP(hipStreamSynchronize(ix->stream));
             uint32_t flags = 0;
             RTX_HIP(hipMemcpy(&flags, ix->d_flags.p, 4, hipMemcpyDeviceToHost));
-            if (flags & 4u) return RTX_OK;  // the rows of the counts buffer ran out: the bulk path repeats the run (whatever else such a run flagged)
+            if (flags & 12u) return RTX_OK;  // the rows of the counts buffer ran out, or a record segment was too short: the bulk path repeats the run (whatever else such a run flagged)
             if (flags & 2u) { set_error("lineage walk exceeded its row/depth bounds (internal error)"); return RTX_ERR_HIP; }
             if (flags & 1u) return RTX_OK;  // arena overflow: the bulk path repeats the run
             if ((rc = fetch_exact_groups(ix, nq))) return rc;
@@ -164,12 +164,18 @@ static int download_impl(rtx_index *ix, rtx_result_view *out, bool then_run, uin
             RTX_HIP(hipMemcpy(both, ix->d_cursor.p, 16, hipMemcpyDeviceToHost));
             cursor = both[0];
             cursor_side = both[1];
-            if ((flags & 2u) && !(flags & 4u)) { set_error("lineage walk exceeded its row/depth bounds (internal error)"); return RTX_ERR_HIP; }
-            if (!(flags & 5u)) break;
+            if ((flags & 2u) && !(flags & 12u)) { set_error("lineage walk exceeded its row/depth bounds (internal error)"); return RTX_ERR_HIP; }
+            if (!(flags & 13u)) break;
             if (attempt >= 8) { set_error("result arena / counts rows overflow persists"); return RTX_ERR_HIP; }
             if (flags & 4u) {  // more queries took the dense epilogues than the counts buffer had rows (HitParams::cnt_row): twice the rows, the run again
                 if (ix->diet_shift == 0u) { set_error("the counts buffer ran out of rows without being on its diet (internal error)"); return RTX_ERR_HIP; }
                 ix->diet_shift--;
+            }
+            if (flags & 8u) {  // a query left a tile more records than a segment holds (RecordRef::seg_len): twice the length, the run again
+                if (ix->rec_seg_len >= 8192u) { set_error("a record segment of a whole tile overflowed (internal error)"); return RTX_ERR_HIP; }
+                ix->rec_seg_len *= 2u;
+            }
+            if (flags & 12u) {
                 if (!(flags & 1u)) {
                     if ((rc = enqueue_batch(ix, ix->last_flags))) return rc;
                     continue;

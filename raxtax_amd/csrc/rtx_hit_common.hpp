@@ -622,7 +622,7 @@ __device__ __forceinline__ void rec_epilogue(const HitParams &p, uint32_t (&pl)[
     if (__ballot((gt[0] | gt[1]) | (gt[2] | gt[3])) != 0ull) {
         for (uint32_t i = lane; i <= t; i += 64) hist_lds[i] = 0;
         wave_lds_sync();
-        uint32_t *seg = p.rec.rec + ((size_t)q * rec_stride + slot) * 8192u;
+        uint32_t *seg = p.rec.rec + ((size_t)q * rec_stride + slot) * p.rec.seg_len;
 #pragma unroll
         for (int g = 0; g < 16; g++) {
             const int w = g >> 2, g2 = g & 3;
@@ -657,7 +657,8 @@ __device__ __forceinline__ void rec_epilogue(const HitParams &p, uint32_t (&pl)[
             for (int j = 0; j < 8; j++)
                 if (m8 & (1u << j)) {
                     const uint32_t c = (cw[j >> 1] >> ((j & 1) * 16)) & 0xFFFFu;
-                    seg[pos++] = (rl0 + (uint32_t)j) | (c << 13);
+                    if (pos < p.rec.seg_len) seg[pos] = (rl0 + (uint32_t)j) | (c << 13);  // (beyond it: the run is repeated with longer segments, below)
+                    pos++;
                     atomicAdd(&hist_lds[c], 1u);
                 }
             running += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
@@ -670,7 +671,8 @@ __device__ __forceinline__ void rec_epilogue(const HitParams &p, uint32_t (&pl)[
     }
     if (lane == 0u) {
         atomicAdd(&hist[0], in_tile - running);  // the references of the tile with a count up to the threshold
-        p.rec.cnt[(size_t)q * kRecMaxSlots + slot] = running;
+        if (running > p.rec.seg_len) atomicOr(p.rec.flags_out, 8u);  // the segment was too short: the host doubles it and repeats the run
+        p.rec.cnt[(size_t)q * kRecMaxSlots + slot] = running < p.rec.seg_len ? running : p.rec.seg_len;
         if (running == 0u)  // nothing of this tile can reach the result: as if it had never been counted
             atomicAnd(const_cast<uint32_t *>(p.live) + (size_t)q * p.live_words + (tile >> 5), ~(1u << (tile & 31u)));
     }

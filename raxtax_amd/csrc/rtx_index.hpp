@@ -216,6 +216,7 @@ struct rtx_index {
     bool two_level_used = false;  // the last run's bounds pass was bounds2_kernel (its work accounting counts load instructions of 1 KiB)
     // The HBM diet of the counts buffer (round 6): a class that prunes with the records path holds sub_batch >> diet_shift rows of counts (at
     // least kDietMinRows); a run in which prune_kernel runs out of rows raises bit 2 of d_flags, the download lowers diet_shift and repeats it.
+    uint32_t rec_seg_len = 1024;  // records per segment of the records path (RecordRef::seg_len): doubled, up to 8192, when a run's segment overflows
     uint32_t diet_shift = 3;
     bool diet_used = false;      // the class being enqueued lays its counts out in cnt_rows_cur rows
     uint32_t cnt_rows_cur = 0;

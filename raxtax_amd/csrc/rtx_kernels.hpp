@@ -124,8 +124,11 @@ struct RecordRef {
     uint16_t *nslots;   // [B] live tiles of the query at prune time; 0: the query takes the dense path
     uint16_t *slots;    // [B][kRecMaxSlots] their tiles, ascending
     uint32_t *cnt;      // [B][kRecMaxSlots] records per segment (zeroed by prune_kernel)
-    uint32_t *rec;      // [B][stride][8192]
+    uint32_t *rec;      // [B][stride][seg_len]
     uint32_t stride;    // segments per query (the largest number of live tiles that still takes the path: RTX_OPT_RECORDS)
+    uint32_t seg_len;   // records a segment holds (round 6: 1024 to begin with -- a query of the bench workload leaves 70 in all; a segment that
+                        // would overflow raises bit 3 of the run's flags and the host repeats the run with twice the length, up to the 8192 of a tile)
+    uint32_t *flags_out;
 };
 
 struct HitParams {

@@ -73,8 +73,8 @@ __global__ __launch_bounds__(64) void records_tail_kernel(TailParams p) {
         for (uint32_t k = 0; k < ns; k++) {
             const uint32_t tile = (uint32_t)__builtin_amdgcn_readlane((int)tile_v, (int)k);
             uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)cnt_v, (int)k);
-            c = c < 8192u ? c : 8192u;
-            const uint32_t *seg = p.rec.rec + ((size_t)q * p.rec.stride + k) * 8192u;
+            c = c < p.rec.seg_len ? c : p.rec.seg_len;
+            const uint32_t *seg = p.rec.rec + ((size_t)q * p.rec.stride + k) * p.rec.seg_len;
             n_rec += c;
             for (uint32_t i0 = 0; i0 < c; i0 += 64) {
                 const uint32_t i = i0 + lane;

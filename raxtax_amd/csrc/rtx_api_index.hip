@@ -489,10 +489,11 @@ static void build_two_level(rtx_index *ix) {
     }
     if (e != hipSuccess) { (void)hipGetLastError(); ix->d_abitmap.release(); ix->d_bbitmap.release(); return; }
     // the database once more block by block (prune_kernel's exact counts of the best block): as large as the bitmap itself -- left out
-    // when HBM is short (the kernel then walks the tile-major bitmap)
+    // when HBM is short, or when it would take more than a sixteenth of the card (round 6: at 5 M references the copy is 41 GB for 1.3 % of
+    // a step -- the index is 51 GB without it; the kernel then walks the tile-major bitmap)
     const size_t cbytes = (size_t)((ix->n_refs + 63) / 64) * rows1 * 8;
     size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || cbytes > free_b / 4 || ix->d_cbitmap.alloc(cbytes)) {
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || cbytes > free_b / 4 || cbytes > total_b / 16 || ix->d_cbitmap.alloc(cbytes)) {
         (void)hipGetLastError();
         ix->d_cbitmap.release();
         return;

@@ -36,6 +36,7 @@ def main():
     res = ix.download()
     print(f"classify {n_q} queries: {dt * 1e3:.1f} ms -> {n_q / dt:.0f} q/s; stages {ix.stage_times()}")
     print("tile pruning:", ix.debug_prune_stats())
+    print("HBM: index", round(ix.device_bytes / 1e9, 2), "GB; workspace", round(ix.workspace_bytes / 1e9, 2), "GB", {k: round(v / 1e9, 2) for k, v in ix.workspace_parts().items()})
     work = ix.work()
     print("work", work, "H_q/N =", work["sum_hits"] / n_q / n_refs)
     assert (res.status == 0).all()

@@ -117,6 +117,8 @@ static int download_streamed(rtx_index *ix, rtx_index::HostRes &hr, bool *done, 
         const uint64_t cur = ix->h_fin_sub[sb];  // final rows [prev, cur): this sub-batch's (the finalise launches follow one another)
         if (cur > ix->fin_cap) return RTX_OK;
         // (cur <= prev: a side class that ran in front of the bulk on the one stream -- its rows left with the first range)
+        if (cur > std::min<uint64_t>({hr.v_row_lineage.cap, hr.v_row_depth8.cap, hr.v_row_local.cap, hr.v_row_conf.cap / ix->fin_D, hr.v_row_hund.cap / ix->fin_D}))
+            RTX_HIP(hipStreamSynchronize(ix->copy_stream));  // an array is about to move: the copies into it have to have landed
         if (cur > prev && ((rc = size_host_results(ix, hr, nq, cur, prev)) || (rc = copy_rows(ix, hr, prev, cur, ix->copy_stream)))) return rc;
         prev = std::max(prev, cur);
         if (k + 1 == n_sub) {  // the last records leave the device: it is free for the next batch

@@ -1,6 +1,6 @@
 """BASELINE.json configs[2] on the GPU: 500 000 references (the database size of the headline and of the 8-GPU
 configs[3]), 100 000 of the synthetic queries of the bench through the size-independent properties, and a seeded
-2 000-query sample against the CPU oracle in both exact-match modes -- hit counts bit-exact, probabilities within
+1 000-query sample against the CPU oracle in both exact-match modes -- hit counts bit-exact, probabilities within
 1e-6, result rows identical (the reference's own methodology samples databases of this size,
 scripts/runtime_memory.py:42-43)."""
 import numpy as np
@@ -12,7 +12,7 @@ from raxtax_amd import synth
 
 pytestmark = pytest.mark.gpu
 
-N_REFS, N_Q, N_SAMPLE = 500_000, 100_000, 2_000
+N_REFS, N_Q, N_SAMPLE = 500_000, 100_000, 1_000   # (2 000 until round 6: the suite has to stay well inside the driver's time limit; every bench line checks 2 000 of its own)
 
 
 @pytest.fixture(scope="module")

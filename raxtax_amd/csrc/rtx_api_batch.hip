@@ -730,6 +730,8 @@ int begin_run(rtx_index *ix, uint32_t *n_sub_out, bool *timed_out, bool cluster)
         if (ev) RTX_HIP(hipEventRecord(ix->events[(size_t)RTX_STAGE_EXACT_MATCH * 2], ix->stream));  // sub-batch 0
         launch_exact_match(ix->stream, xp);
         if (ev) RTX_HIP(hipEventRecord(ix->events[(size_t)RTX_STAGE_EXACT_MATCH * 2 + 1], ix->stream));
+        if (!ix->ev_exact) RTX_HIP(hipEventCreateWithFlags(&ix->ev_exact, hipEventDisableTiming));
+        RTX_HIP(hipEventRecord(ix->ev_exact, ix->stream));
     }
     *n_sub_out = n_sub;
     *timed_out = timed;
@@ -837,6 +839,11 @@ int enqueue_batch(rtx_index *ix, uint32_t flags) {
             if ((rc = enqueue_finalise(ix, b, ix->stream))) return rc;
             if (ix->stream_dl) RTX_HIP(hipEventRecord(ix->ev_sub[sb], ix->stream));
         }
+    }
+    {   // the flags of the run, behind its last kernel (the handle's stream has joined the others): the download finds them in page-locked memory
+        int rc_f = ix->h_flags.resize(1);
+        if (rc_f) return rc_f;
+        RTX_HIP(hipMemcpyAsync(ix->h_flags.data(), ix->d_flags.p, 4, hipMemcpyDeviceToHost, ix->stream));
     }
     RTX_HIP(hipGetLastError());
     return RTX_OK;

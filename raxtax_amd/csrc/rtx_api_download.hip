@@ -82,6 +82,7 @@ static int fetch_exact_groups(rtx_index *ix, uint64_t nq) {
     hx.valid = hx.csr_valid = false;
     if (ix->dev_exact_used) {
         hx.grp.resize(nq);
+        if (ix->ev_exact) RTX_HIP(hipEventSynchronize(ix->ev_exact));  // the lookup ran at the head of the batch (a re-run: of the re-run)
         RTX_HIP(hipMemcpy(hx.grp.data(), ix->d_exact_grp.p, nq * 4, hipMemcpyDeviceToHost));
         hx.valid = true;
     }
@@ -106,6 +107,7 @@ static int download_streamed(rtx_index *ix, rtx_index::HostRes &hr, bool *done, 
     const uint64_t nq = ix->n_q;
     int rc = size_host_results(ix, hr, nq, nq + nq / 4 + 64, 0);
     if (rc) return rc;
+    if ((rc = fetch_exact_groups(ix, nq))) return rc;  // (now, beside the kernels: 4 MB per 1 M queries that used to cross at the tail, with the device idle)
     uint64_t prev = 0;
     uint32_t n_side = 0;  // the side classes' sub-batches come first in the plan and run beside the bulk: they are finalised and waited for LAST
     while (n_side < n_sub && ix->cls[ix->sub_cls[n_side]].side) n_side++;
@@ -125,12 +127,10 @@ static int download_streamed(rtx_index *ix, rtx_index::HostRes &hr, bool *done, 
             if ((rc = copy_queries(ix, hr, nq, ix->copy_stream))) return rc;
             RTX_HIP(hipStreamSynchronize(ix->copy_stream));
             RTX_HIP(hipStreamSynchronize(ix->stream));
-            uint32_t flags = 0;
-            RTX_HIP(hipMemcpy(&flags, ix->d_flags.p, 4, hipMemcpyDeviceToHost));
+            const uint32_t flags = ix->h_flags.size() ? ix->h_flags[0] : 0u;  // (copied behind the run's last kernel: enqueue_batch)
             if (flags & 12u) return RTX_OK;  // the rows of the counts buffer ran out, or a record segment was too short: the bulk path repeats the run (whatever else such a run flagged)
             if (flags & 2u) { set_error("lineage walk exceeded its row/depth bounds (internal error)"); return RTX_ERR_HIP; }
             if (flags & 1u) return RTX_OK;  // arena overflow: the bulk path repeats the run
-            if ((rc = fetch_exact_groups(ix, nq))) return rc;
             if (then_run && (rc = run_staged(ix, next_flags, ran_next))) return rc;
         }
     }

@@ -172,6 +172,8 @@ struct rtx_index {
     DevBuf<uint32_t> d_em_goff, d_em_gids;   // ids of group g: gids[goff[g] .. goff[g + 1]), ascending (tree.rs:109-112)
     std::vector<uint32_t> h_em_goff, h_em_gids;  // host copies: the ids behind the groups the device reports
     DevBuf<uint32_t> d_exact_grp;     // [n_q] group of every query of the batch (0xFFFFFFFF: none)
+    hipEvent_t ev_exact = nullptr;    // behind exact_match_kernel of the run: the download fetches the groups at its START, beside the kernels, not at its tail
+    PinBuf<uint32_t> h_flags;         // the run's flags (d_flags), copied behind its last kernel: the download reads them without a round trip of its own
     bool dev_exact_used = false;      // the uploaded batch came without ids: the device looks them up (every rtx_batch_run)
     struct HostExact {                // per host result set: the groups of a download and, on demand, the CSR of their ids
         std::vector<uint32_t> grp;
@@ -390,6 +392,7 @@ struct rtx_index {
         for (auto &i : in)
             if (i.ready) (void)hipEventDestroy(i.ready);
         if (ev_activated) (void)hipEventDestroy(ev_activated);
+        if (ev_exact) (void)hipEventDestroy(ev_exact);
         if (h2d_stream) (void)hipStreamDestroy(h2d_stream);
         if (copy_stream) (void)hipStreamDestroy(copy_stream);
         if (stream) (void)hipStreamDestroy(stream);

@@ -1,6 +1,7 @@
 import ctypes, sys, time
 import numpy as np
-sys.path.insert(0, '.')
+from pathlib import Path
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 import raxtax_amd as rx
 from raxtax_amd import synth
 n_q = int(sys.argv[1]); chunk = int(sys.argv[2]); n_h = int(sys.argv[3]); opts = sys.argv[4:]

@@ -156,6 +156,8 @@ static int download_impl(rtx_index *ix, rtx_result_view *out, bool then_run, uin
     uint64_t nrows = 0;
     if ((rc = download_streamed(ix, hr, &streamed, &nrows, then_run, next_flags, &ran_next))) return rc;
     if (!streamed) {
+        // (a streamed download that gave up half way -- an overflow: the run is repeated -- may have copies in flight into this result set)
+        if (ix->copy_stream) RTX_HIP(hipStreamSynchronize(ix->copy_stream));
         unsigned long long cursor = 0, cursor_side = 0;
         for (int attempt = 0;; attempt++) {
             RTX_HIP(hipStreamSynchronize(ix->stream));

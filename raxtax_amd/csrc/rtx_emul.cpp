@@ -92,6 +92,18 @@ void emul_planes_count(const uint32_t *rows, uint32_t n_rows, int planes, uint32
                 if (c0 != out[8 * b + j] || c1 != out[8 * b + 4 + j]) out[8 * b + j] = 0xFFFFFFFFu;  // poison: the test fails
             }
         }
+        // ... and so must the unpack of the whole word at once (delta swaps between the plane registers)
+        uint32_t lo[4][2];
+        planes_unpack32<NP>(pl, lo);
+        for (int b = 0; b < 4; b++) {
+            uint32_t hi0, hi1;
+            planes_unpack8_hi<NP>(pl, b, hi0, hi1);
+            for (int j = 0; j < 4; j++) {
+                const uint32_t c0 = ((lo[b][0] >> (8 * j)) & 0xFF) | (((hi0 >> (8 * j)) & 0xFF) << 8);
+                const uint32_t c1 = ((lo[b][1] >> (8 * j)) & 0xFF) | (((hi1 >> (8 * j)) & 0xFF) << 8);
+                if (c0 != out[8 * b + j] || c1 != out[8 * b + 4 + j]) out[8 * b + j] = 0xFFFFFFFEu;
+            }
+        }
     };
     if (planes == 10) run(std::integral_constant<int, 10>{});
     else if (planes == 12) run(std::integral_constant<int, 12>{});

@@ -364,6 +364,7 @@ __device__ __forceinline__ void hit_epilogue_x(const HitParams &p, uint32_t (&pl
     const bool has_row = crow != 0xFFFFFFFFu;  // (none: the rows ran out -- the run is repeated with a larger buffer; nothing is stored)
     uint16_t *out = p.counts + (size_t)(has_row ? crow : 0u) * p.npad + ref0;
     uint8_t *out_lo = p.counts_lo + (size_t)(has_row ? crow : 0u) * p.npad + ref0;
+    constexpr bool kBytes = kPacked && NP <= 8 && !kGlobalHist;  // every count fits a byte: stored and histogrammed as bytes
     uint32_t hiw[8];  // packed format: the two high bits of the 8 references of group g in bits 16 (g & 1) + [0, 16) of hiw[g / 2]
 #pragma unroll
     for (int i = 0; i < 8; i++) hiw[i] = 0;
@@ -388,29 +389,41 @@ __device__ __forceinline__ void hit_epilogue_x(const HitParams &p, uint32_t (&pl
 #pragma unroll
             for (int wi = 0; wi < 2; wi++) {
                 const int w = half * 2 + wi;
+                // the low eight planes of the word, unpacked at once (planes_unpack32: 64 operations where four planes_unpack8 take 112)
+                uint32_t lo_w[4][2];
+                planes_unpack32<NP>(pl[w], lo_w);
 #pragma unroll
                 for (int g2 = 0; g2 < 4; g2++) {  // 8 references per store, contiguous across lanes
-                    uint32_t lo0, hi0, lo1, hi1;
-                    planes_unpack8<NP>(pl[w], g2, lo0, hi0, lo1, hi1);
-                    uint4 st;
-                    // bytes (lo.b0, hi.b0, lo.b1, hi.b1) -> two u16 counts
-                    st.x = __builtin_amdgcn_perm(hi0, lo0, 0x05010400u);
-                    st.y = __builtin_amdgcn_perm(hi0, lo0, 0x07030602u);
-                    st.z = __builtin_amdgcn_perm(hi1, lo1, 0x05010400u);
-                    st.w = __builtin_amdgcn_perm(hi1, lo1, 0x07030602u);
+                    const uint32_t lo0 = lo_w[g2][0], lo1 = lo_w[g2][1];
                     const uint32_t goff = (uint32_t)(w * 4 + g2) * L * 8u;
-                    if (lists) {  // + hits through sparse segments (L = 64 here): bytes of the eight references of this group
-                        const uint2 sb = *reinterpret_cast<const uint2 *>(cnt8 + (((uint32_t)((kFullTile ? w : wi) * 4 + g2) * 64u + lane) * 2u));
-                        // bytes (b0, b1) -> (b0, 0, b1, 0): one v_perm_b32 each (selector byte 0x0C = constant 0)
-                        st.x += __builtin_amdgcn_perm(0u, sb.x, 0x0C010C00u);
-                        st.y += __builtin_amdgcn_perm(0u, sb.x, 0x0C030C02u);
-                        st.z += __builtin_amdgcn_perm(0u, sb.y, 0x0C010C00u);
-                        st.w += __builtin_amdgcn_perm(0u, sb.y, 0x0C030C02u);
-                    }
-                    if (kPacked) {
-                        uint2 lo8;  // the low bytes of the eight counts, in reference order
+                    uint2 sb = make_uint2(0u, 0u);  // hits through sparse segments (L = 64 there): bytes of the eight references of this group
+                    if (lists) sb = *reinterpret_cast<const uint2 *>(cnt8 + (((uint32_t)((kFullTile ? w : wi) * 4 + g2) * 64u + lane) * 2u));
+                    uint4 st;   // the eight counts as u16 ...
+                    uint2 lo8;  // ... and their low bytes, in reference order
+                    if (kBytes) {
+                        // eight planes <=> t <= 255: a count -- dense and sparse part together at most t -- fits its byte, so the bytes are
+                        // added as they are (no carry leaves a byte) and nothing is widened to u16 on the way to the store and the histogram
+                        lo8 = make_uint2(lo0 + sb.x, lo1 + sb.y);
+                        st = make_uint4(0u, 0u, 0u, 0u);
+                    } else {
+                        uint32_t hi0, hi1;
+                        planes_unpack8_hi<NP>(pl[w], g2, hi0, hi1);
+                        // bytes (lo.b0, hi.b0, lo.b1, hi.b1) -> two u16 counts
+                        st.x = __builtin_amdgcn_perm(hi0, lo0, 0x05010400u);
+                        st.y = __builtin_amdgcn_perm(hi0, lo0, 0x07030602u);
+                        st.z = __builtin_amdgcn_perm(hi1, lo1, 0x05010400u);
+                        st.w = __builtin_amdgcn_perm(hi1, lo1, 0x07030602u);
+                        if (lists) {
+                            // bytes (b0, b1) -> (b0, 0, b1, 0): one v_perm_b32 each (selector byte 0x0C = constant 0)
+                            st.x += __builtin_amdgcn_perm(0u, sb.x, 0x0C010C00u);
+                            st.y += __builtin_amdgcn_perm(0u, sb.x, 0x0C030C02u);
+                            st.z += __builtin_amdgcn_perm(0u, sb.y, 0x0C010C00u);
+                            st.w += __builtin_amdgcn_perm(0u, sb.y, 0x0C030C02u);
+                        }
                         lo8.x = __builtin_amdgcn_perm(st.y, st.x, 0x06040200u);
                         lo8.y = __builtin_amdgcn_perm(st.w, st.z, 0x06040200u);
+                    }
+                    if (kPacked) {
                         {   // non-temporal: the counts are read once, much later (taxon_prefix), and should not displace bitmap rows
                             typedef uint32_t u32x2_nt __attribute__((ext_vector_type(2)));
                             u32x2_nt nv;
@@ -418,7 +431,7 @@ __device__ __forceinline__ void hit_epilogue_x(const HitParams &p, uint32_t (&pl
                             nv.y = lo8.y;
                             if (has_row) __builtin_nontemporal_store(nv, reinterpret_cast<u32x2_nt *>(out_lo + goff));
                         }
-                        if (NP > 8) {  // (eight planes <=> t <= 255: a count -- dense and sparse part together at most t -- fits its low byte)
+                        if (NP > 8) {
                             // high bytes (0..3 each) -> 2 bits per reference: byte j moves to bit 2j
                             const uint32_t hb0 = __builtin_amdgcn_perm(st.y, st.x, 0x07050301u), hb1 = __builtin_amdgcn_perm(st.w, st.z, 0x07050301u);
                             const uint32_t h0 = (hb0 | (hb0 >> 6) | (hb0 >> 12) | (hb0 >> 18)) & 0xFFu;
@@ -429,6 +442,31 @@ __device__ __forceinline__ void hit_epilogue_x(const HitParams &p, uint32_t (&pl
                         }
                     } else if (has_row) {
                         *reinterpret_cast<uint4 *>(out + goff) = st;
+                    }
+                    if (kBytes) {  // the histogram of the byte form
+                        const uint32_t bw[2] = {lo8.x, lo8.y};
+                        if (h_lo) {  // wave-uniform: a pruned query -- only the counts above its threshold are looked at one by one
+                            const uint32_t e = pk_max_u16(lo8.x & 0x00FF00FFu, lo8.y & 0x00FF00FFu), o = pk_max_u16((lo8.x >> 8) & 0x00FF00FFu, (lo8.y >> 8) & 0x00FF00FFu);
+                            const uint32_t m2 = pk_max_u16(e, o);
+                            const uint32_t m = (m2 & 0xFFFFu) > (m2 >> 16) ? (m2 & 0xFFFFu) : (m2 >> 16);
+                            if (__ballot(m >= h_lo) != 0ull) {  // (references behind n_refs have a count of 0)
+#pragma unroll
+                                for (int j = 0; j < 8; j++) {
+                                    const uint32_t c = (bw[j >> 2] >> ((j & 3) * 8)) & 0xFFu;
+                                    if (c >= h_lo) atomicAdd(&hist_lds[c], 1u);
+                                }
+                            }
+                        } else if (tile_full) {  // wave-uniform: every reference of the tile exists -- no compare, no exec mask per atomic
+#pragma unroll
+                            for (int j = 0; j < 8; j++) atomicAdd(&hist_lds[(bw[j >> 2] >> ((j & 3) * 8)) & 0xFFu], 1u);
+                        } else {  // the last tile of the database: the references behind n_refs are not counted
+                            const int32_t left = refs_left - (int32_t)goff;
+                            const uint32_t nvalid = left <= 0 ? 0u : (left < 8 ? (uint32_t)left : 8u);
+#pragma unroll
+                            for (int j = 0; j < 8; j++)
+                                if ((uint32_t)j < nvalid) atomicAdd(&hist_lds[(bw[j >> 2] >> ((j & 3) * 8)) & 0xFFu], 1u);
+                        }
+                        continue;
                     }
                     const uint32_t cw[4] = {st.x, st.y, st.z, st.w};
                     if (h_lo) {  // wave-uniform: a pruned query -- only the counts above its threshold are looked at one by one

@@ -236,6 +236,67 @@ RTX_HD void planes_unpack8(const uint32_t (&pl)[NP], int b, uint32_t &lo0, uint3
     }
 }
 
+// v_perm_b32(hi, lo, sel): byte k of the result is byte sel[k] of the eight bytes hi:lo (0-3 = lo, 4-7 = hi; 0x0C = the constant 0)
+RTX_HD uint32_t byte_perm(uint32_t hi, uint32_t lo, uint32_t sel) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_perm(hi, lo, sel);
+#else
+    const uint64_t v = ((uint64_t)hi << 32) | lo;
+    uint32_t r = 0;
+    for (int k = 0; k < 4; k++) {
+        const uint32_t s = (sel >> (8 * k)) & 0xFFu;
+        if (s < 8u) r |= (uint32_t)((v >> (8 * s)) & 0xFFu) << (8 * k);
+    }
+    return r;
+#endif
+}
+
+// The low eight planes of a whole 32-reference word at once: lo[b][h] = what planes_unpack8 gives as lo0 (h = 0) / lo1 (h = 1) for
+// byte b.  Three delta swaps BETWEEN the plane registers (plane bit p_k against reference bit r_k: two shifts and two bit-field
+// inserts per pair of registers) leave register r with the counts of references 8b + r in its bytes b; two rounds of byte
+// gathers then bring the counts of references 8b + 4h .. + 3 together: 48 + 16 operations for 32 references, where four calls of
+// planes_unpack8 take 112 (the dense epilogue unpacks every word of a tile: a quarter of its instructions were this).
+RTX_HD void delta_swap_regs(uint32_t &a, uint32_t &b, int s, uint32_t m) {  // a takes b's elements at m into m << s, b takes a's at m << s into m
+    const uint32_t na = (a & m) | ((b & m) << s), nb = ((a >> s) & m) | (b & ~m);
+    a = na;
+    b = nb;
+}
+template <int NP>
+RTX_HD void planes_unpack32(const uint32_t (&pl)[NP], uint32_t (&lo)[4][2]) {
+    static_assert(NP >= 8, "at least eight planes");
+    uint32_t r[8];
+#pragma unroll
+    for (int p = 0; p < 8; p++) r[p] = pl[p];
+#pragma unroll
+    for (int p = 0; p < 4; p++) delta_swap_regs(r[p], r[p + 4], 4, 0x0F0F0F0Fu);
+#pragma unroll
+    for (int p = 0; p < 8; p++)
+        if (!(p & 2)) delta_swap_regs(r[p], r[p + 2], 2, 0x33333333u);
+#pragma unroll
+    for (int p = 0; p < 8; p += 2) delta_swap_regs(r[p], r[p + 1], 1, 0x55555555u);
+    // r[j] byte b = the count of reference 8b + j
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const uint32_t x0 = byte_perm(r[4 * h + 1], r[4 * h], 0x05010400u), x1 = byte_perm(r[4 * h + 1], r[4 * h], 0x07030602u);
+        const uint32_t y0 = byte_perm(r[4 * h + 3], r[4 * h + 2], 0x05010400u), y1 = byte_perm(r[4 * h + 3], r[4 * h + 2], 0x07030602u);
+        lo[0][h] = byte_perm(y0, x0, 0x05040100u);
+        lo[1][h] = byte_perm(y0, x0, 0x07060302u);
+        lo[2][h] = byte_perm(y1, x1, 0x05040100u);
+        lo[3][h] = byte_perm(y1, x1, 0x07060302u);
+    }
+}
+// the planes above the eighth, as planes_unpack8 gives them (hi0 / hi1 for byte b)
+template <int NP>
+RTX_HD void planes_unpack8_hi(const uint32_t (&pl)[NP], int b, uint32_t &hi0, uint32_t &hi1) {
+    hi0 = 0;
+    hi1 = 0;
+#pragma unroll
+    for (int p = 8; p < NP; p++) {
+        hi0 |= spread4(pl[p] >> (8 * b)) << (p - 8);
+        hi1 |= spread4(pl[p] >> (8 * b + 4)) << (p - 8);
+    }
+}
+
 // ---------------------------------------------------------------------------
 // prob.rs restated for the device: the reference builds ln pmf_m(i) for every distinct
 // hit count m and every i in 0..=n (prob.rs:121-170), exponentiates, accumulates ln cmf,

@@ -10,11 +10,15 @@ ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 from raxtax_amd import _build  # noqa: E402
 
+import os  # noqa: E402
+
 name, extra = sys.argv[1], sys.argv[2:]
+# RTX_VARIANT_CSRC: another copy of the sources (e.g. `git worktree add gpurun_scratch/head HEAD` for a before / after pair)
+CSRC = Path(os.environ.get("RTX_VARIANT_CSRC", _build.CSRC))
 out_dir = ROOT / "gpurun_scratch"
 obj_dir = out_dir / f"obj_{name}"
 obj_dir.mkdir(parents=True, exist_ok=True)
-flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", f"-I{ROOT / 'include'}", f"-I{_build.CSRC}"] + extra
+flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", f"-I{ROOT / 'include'}", f"-I{CSRC}"] + extra
 
 
 def one(src):
@@ -22,7 +26,7 @@ def one(src):
     # the compiler's diagnostics (register spills are what the experiments care about) go to a log beside the object; shown on failure
     log = obj_dir / (src + ".log")
     with open(log, "w") as fh:
-        rc = subprocess.call([_build._hipcc()] + flags + ["-Rpass-analysis=kernel-resource-usage", "-x", "hip", "-c", str(_build.CSRC / src), "-o", str(obj)], stderr=fh)
+        rc = subprocess.call([_build._hipcc()] + flags + ["-Rpass-analysis=kernel-resource-usage", "-x", "hip", "-c", str(CSRC / src), "-o", str(obj)], stderr=fh)
     if rc:
         sys.stderr.write(log.read_text())
         raise SystemExit(f"{src}: hipcc failed ({rc}); diagnostics in {log}")

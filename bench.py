@@ -39,7 +39,9 @@ import ctypes
 import hashlib
 import json
 import os
-import socket
+
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # before torch can initialise HIP (raxtax_amd/csrc/host_threads.cpp: transfers get hardware queues of their own)
+import socket  # noqa: E402
 import subprocess
 import sys
 import time

@@ -32,11 +32,12 @@
 extern "C" {
 #endif
 
-#define RTX_ABI_VERSION 5 /* 2: rtx_result_view.row_begin/row_count replace row_off; 3: exact_off == NULL = look the exact matches up on the device;
+#define RTX_ABI_VERSION 6 /* 2: rtx_result_view.row_begin/row_count replace row_off; 3: exact_off == NULL = look the exact matches up on the device;
                              4: RTX_NUM_STAGES 8 -> 10 (rtx_batch_stage_times writes ten entries), rtx_batch_prefetch / rtx_batch_activate;
                              5: rtx_result_view grows row_conf_stride, row_depth_u8, row_conf_hundredths (the rows are finalised on the device and
                                 arrive in their final layout: row_conf is [n_rows][row_conf_stride], no longer [n_rows][RTX_MAX_DEPTH]); the exports
-                                and options of round 5 (rtx_index_self_sample, rtx_records_format, options 18-22) */
+                                and options of round 5 (rtx_index_self_sample, rtx_records_format, options 18-22);
+                             6: RTX_OPT_RUN_AHEAD (23), RTX_RETRY_CHUNK from rtx_batch_download_then_run under it, rtx_index_run_ahead_stats */
 #define RTX_NUM_KMERS 65536u /* 2 << 15 posting lists, src/tree.rs:52 */
 #define RTX_MAX_DEPTH 32u    /* deepest lineage (comma-separated levels) the device walk carries */
 
@@ -53,6 +54,9 @@ extern "C" {
                                    query longer than 65 542 bases.  The reference asserts on DISTINCT k-mers, raxtax.rs:56, and serves such reads: so does
                                    the library now -- per query, RTX_Q_ALL_KMERS for a read that really holds all 65 536 of them) */
 #define RTX_ERR_SENDER (-9)     /* the result sink refused a message (closed channel, raxtax.rs:87)    */
+#define RTX_RETRY_CHUNK 1        /* not an error: rtx_batch_download_then_run under RTX_OPT_RUN_AHEAD found the batch being downloaded short of buffer space
+                                   AFTER it had enqueued the next one; both have been taken off the handle (buffers grown): run this batch again
+                                   (upload, run, download) and stage the next one anew */
 
 /* flags of rtx_classify_batch / rtx_batch_run (src/io.rs:119-121,131-133) */
 #define RTX_SKIP_EXACT_MATCHES 1u /* zero the hit counts of exact matches, raxtax.rs:65-68 */
@@ -263,6 +267,14 @@ int rtx_index_set_batch(rtx_index *index, uint32_t sub_batch);
                                       * of its tiles live -- every tile holds relatives of every query: real barcodes of one order -- tile
                                       * pruning stays off whatever RTX_OPT_TILE_PRUNE says (bounds and thresholds would cost more than they
                                       * save).  0: RTX_OPT_TILE_PRUNE alone decides.  Shapes the workspace like RTX_OPT_TILE_PRUNE */
+#define RTX_OPT_RUN_AHEAD 23         /* 0 (default).  1: rtx_batch_download_then_run enqueues the staged batch BEFORE the last sub-batch of the batch
+                                      * being downloaded has finished: the front half of the next batch's first sub-batch runs beside the back
+                                      * half of this batch's last one (RTX_OPT_OVERLAP's two streams never drain between the chunks of a file).
+                                      * The result state of a batch then exists twice on the device.  The call may return RTX_RETRY_CHUNK (see
+                                      * there); a run under this option leaves the handle's stream NOT covering its back halves until the next
+                                      * call that needs it (rtx_batch_sync, a download, the next run, switching the option off).  rtx_raxtax sets
+                                      * it for the duration of a call with more than one chunk.  Results are those of the plain sequence.  (2: a test aid -- every
+                                      * second run-ahead is abandoned as if the batch had overflowed.) */
 /* RTX_OPT_SUB_BATCH, _PACKED_COUNTS, _HIT_PAIR, _TILE_PRUNE and _PROB_MODE shape the workspace that rtx_batch_upload sizes:
  * setting one of them drops the uploaded batch (rtx_batch_run then fails with RTX_ERR_STATE until the batch is uploaded again). */
 int rtx_index_set_option(rtx_index *index, int option, uint64_t value);
@@ -278,6 +290,8 @@ int rtx_index_set_option(rtx_index *index, int option, uint64_t value);
 int rtx_index_self_sample(rtx_index *index, const uint8_t *seq_bytes, const uint64_t *seq_off, uint64_t n_refs, uint32_t n_sample, double *live_fraction);
 /* *pruning: 1 if tile pruning is on for this handle (RTX_OPT_TILE_PRUNE and the verdict above); *live_fraction: the share the sample kept live, -1 without a sample */
 int rtx_index_prune_verdict(const rtx_index *index, int *pruning, double *live_fraction);
+/* RTX_OPT_RUN_AHEAD: batches this handle enqueued ahead of the end of the batch before them, and run-aheads it abandoned (RTX_RETRY_CHUNK), since its creation */
+int rtx_index_run_ahead_stats(const rtx_index *index, uint64_t *enqueued_ahead, uint64_t *abandoned);
 /* Process-wide default for handles created afterwards.  RTX_DEFAULT_SEGMENT_CLASSES (default 1): at index creation
  * every (row, tile) segment of the bitmaps is classified; empty segments are never read and segments with at most
  * 16 references are added from 32-byte slots through byte counters instead of 1-KiB row reads (rtx_segments.hip).
@@ -359,7 +373,8 @@ int rtx_batch_download(rtx_index *index, rtx_result_view *out);
 /* rtx_batch_download of the current batch that, as soon as the last result records have left the device, makes the STAGED batch
  * (rtx_batch_prefetch) the current one and runs it with `flags` (= rtx_batch_activate + rtx_batch_run) -- the host finalises the last
  * sub-batch of this batch while the device already classifies the next (rtx_raxtax's chunks follow one another without the host's
- * finalisation between them).  Nothing staged: plain rtx_batch_download. */
+ * finalisation between them).  Nothing staged: plain rtx_batch_download.  Under RTX_OPT_RUN_AHEAD the staged batch is enqueued before the
+ * current one has finished, and the call may return RTX_RETRY_CHUNK (> 0). */
 int rtx_batch_download_then_run(rtx_index *index, rtx_result_view *out, uint32_t flags);
 
 /* ---- staged execution of a reference-sharded handle (one sub-batch at a time) --------------------

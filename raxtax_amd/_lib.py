@@ -105,6 +105,7 @@ _SIGNATURES = {
     "rtx_index_set_option": (C.c_int, [C.c_void_p, C.c_int, C.c_uint64]),
     "rtx_index_self_sample": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.POINTER(C.c_double)]),
     "rtx_index_prune_verdict": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_double)]),
+    "rtx_index_run_ahead_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "rtx_classify_batch": (C.c_int, [C.c_void_p, C.c_uint64, u8p, u64p, u32p, u64p, C.c_uint32,
                                      C.POINTER(ResultView)]),
     "rtx_index_has_exact_lookup": (C.c_int, [C.c_void_p]),

@@ -278,6 +278,13 @@ class Index:
         check(self._lib.rtx_index_prune_verdict(self._h, C.byref(on), C.byref(frac)))
         return bool(on.value), float(frac.value)
 
+    @property
+    def run_ahead_stats(self):
+        """(batches enqueued ahead of the end of the batch before them, run-aheads abandoned) under RTX_OPT_RUN_AHEAD: rtx_index_run_ahead_stats."""
+        a, b = C.c_uint64(), C.c_uint64()
+        check(self._lib.rtx_index_run_ahead_stats(self._h, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
+
     def __del__(self):
         try:
             if self._h:

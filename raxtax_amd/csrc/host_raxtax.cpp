@@ -161,6 +161,14 @@ int run(rtx_index *const *indices, uint32_t n_dev, const rtx_tree *tree, uint64_
         MinSubs(rtx_index *const *i, uint32_t k, uint64_t n_chunks) : ix(i), n(n_chunks > 1 ? k : 0), was(n) { for (uint32_t d = 0; d < n; d++) was[d] = rtx::index_swap_min_subs(ix[d], 2); }
         ~MinSubs() { for (uint32_t d = 0; d < n; d++) (void)rtx::index_swap_min_subs(ix[d], was[d]); }
     } min_subs_guard(indices, n_dev, n_chunks);
+    // ... and chunk c + 1 is enqueued before the last sub-batch of chunk c has finished (RTX_OPT_RUN_AHEAD: the two streams of a handle do not
+    // drain between chunks); not for handles that share a device (one stream each, below), and only with hardware queues to spare (host_threads.cpp)
+    struct RunAhead {
+        rtx_index *const *ix; uint32_t n;
+        std::vector<uint32_t> was;
+        RunAhead(rtx_index *const *i, uint32_t k, uint64_t n_chunks) : ix(i), n(n_chunks > 1 && rtx::hw_queues_for_run_ahead() ? k : 0), was(n) { for (uint32_t d = 0; d < n; d++) { was[d] = rtx::index_swap_run_ahead(ix[d], 1); if (was[d] > 1u) (void)rtx::index_swap_run_ahead(ix[d], was[d]); } }  // (2: the test aid stays)
+        ~RunAhead() { for (uint32_t d = 0; d < n; d++) (void)rtx::index_swap_run_ahead(ix[d], was[d]); }
+    } run_ahead_guard(indices, n_dev, n_chunks);
     // handles that share a device (rehearsals of the multi-GPU path on one GPU) run on one stream each for the duration of the call
     struct SharedDevice {
         rtx_index *const *ix; uint32_t n;
@@ -262,6 +270,13 @@ int run(rtx_index *const *indices, uint32_t n_dev, const rtx_tree *tree, uint64_
             // the device goes on with the next chunk as soon as the last records of this one have left it: the host's finalisation of
             // the last sub-batch (and this thread's bookkeeping) no longer stand between two chunks (rtx_batch_download_then_run)
             if (!rc) rc = staged ? rtx_batch_download_then_run(indices[d], &ch.res, flags) : rtx_batch_download(indices[d], &ch.res);
+            if (rc == RTX_RETRY_CHUNK) {  // the run-ahead was abandoned (this chunk outgrew a buffer with the next one enqueued already): this chunk on its own
+                rc = dev_lookup[d] ? rtx_batch_upload(indices[d], ch.nq, bases, base_off + ch.q0, nullptr, nullptr)
+                                   : rtx_batch_upload(indices[d], ch.nq, bases, base_off + ch.q0, ch.exact_ids.empty() ? nullptr : ch.exact_ids.data(), ch.exact_off.data());
+                if (!rc) rc = rtx_batch_run(indices[d], flags);
+                if (!rc) rc = rtx_batch_download(indices[d], &ch.res);
+                staged = false;  // (the next chunk is staged, activated and run at the head of the loop)
+            }
             if (!rc && staged) running = true;
             if (!rc && dev_lookup[d]) {
                 const uint64_t *xo = nullptr;

@@ -66,6 +66,22 @@ unsigned host_threads(unsigned want, unsigned sharers) {
     return std::max(1u, std::min(want, budget));
 }
 
+// Hardware queues of the HIP runtime (GPU_MAX_HW_QUEUES, 4 by default, read when the runtime initialises): a handle drives five streams -- two for
+// kernels, two for transfers, the runtime's own -- and streams beyond the queues SHARE one: a D2H copy then waits behind every kernel that was
+// enqueued on its queue-mate before it.  With two chunks of rtx_raxtax on the device (RTX_OPT_RUN_AHEAD) that was the whole front half of the
+// next chunk: 113 ms per 1 M queries where six queues or more give 86 (four queues without the run-ahead: 92).  The library asks for eight when
+// it is loaded, unless the process has set the variable itself; a host that initialised HIP before loading the library keeps what it had -- it
+// can export the variable itself -- and rtx_raxtax leaves the run-ahead off unless the variable reads six or more.
+static const int g_hw_queues_asked = [] {
+    setenv("GPU_MAX_HW_QUEUES", "8", 0);
+    return 0;
+}();
+bool hw_queues_for_run_ahead() {
+    (void)g_hw_queues_asked;
+    const char *e = getenv("GPU_MAX_HW_QUEUES");
+    return e && strtol(e, nullptr, 10) >= 6;
+}
+
 }  // namespace rtx
 
 extern "C" int rtx_set_host_share(uint32_t n_ranks_on_this_host) {

@@ -481,6 +481,47 @@ int enqueue_prob_prefix(rtx_index *ix, const SubBatch &b, bool fuse_walk, bool p
 }
 
 // The final result arrays (finalise_kernel): the per-query fields of the batch in input order, as many rows as the arena holds
+// The result state of a batch in two sets (rtx_index::ResultSet): the members of the handle <-> `alt`
+void swap_result_sets(rtx_index *ix) {
+    rtx_index::ResultSet &a = ix->alt;
+    swap_buf(ix->d_status, a.d_status); swap_buf(ix->d_t_all, a.d_t_all); swap_buf(ix->d_nrows_all, a.d_nrows_all); swap_buf(ix->d_n_rows, a.d_n_rows);
+    swap_buf(ix->d_flags, a.d_flags); swap_buf(ix->d_ndist, a.d_ndist); swap_buf(ix->d_gs, a.d_gs); swap_buf(ix->d_z, a.d_z);
+    swap_buf(ix->d_hq, a.d_hq); swap_buf(ix->d_row_start, a.d_row_start); swap_buf(ix->d_cursor, a.d_cursor); swap_buf(ix->d_arena, a.d_arena);
+    swap_buf(ix->d_fin_t, a.d_fin_t); swap_buf(ix->d_fin_row_count, a.d_fin_row_count); swap_buf(ix->d_fin_lineage, a.d_fin_lineage);
+    swap_buf(ix->d_fin_node, a.d_fin_node); swap_buf(ix->d_fin_depth, a.d_fin_depth); swap_buf(ix->d_fin_status, a.d_fin_status);
+    swap_buf(ix->d_fin_depth8, a.d_fin_depth8); swap_buf(ix->d_fin_hund, a.d_fin_hund); swap_buf(ix->d_fin_gs, a.d_fin_gs);
+    swap_buf(ix->d_fin_local, a.d_fin_local); swap_buf(ix->d_fin_conf, a.d_fin_conf); swap_buf(ix->d_fin_row_begin, a.d_fin_row_begin);
+    swap_buf(ix->d_fin_cursor, a.d_fin_cursor); swap_buf(ix->d_perm, a.d_perm); swap_buf(ix->d_iperm, a.d_iperm); swap_buf(ix->d_exact_grp, a.d_exact_grp);
+    std::swap(ix->fin_cap, a.fin_cap); std::swap(ix->arena_cap, a.arena_cap); std::swap(ix->side_base, a.side_base);
+    swap_buf(ix->h_flags, a.h_flags); swap_buf(ix->h_fin_sub, a.h_fin_sub); swap_buf(ix->h_cursor_sub, a.h_cursor_sub);
+    ix->ev_sub.swap(a.ev_sub);
+    std::swap(ix->ev_exact, a.ev_exact); std::swap(ix->ev_flags, a.ev_flags);
+}
+
+// The per-query arrays, the cursors, the arena and the final arrays of the current set, for a batch of n_queries
+int alloc_result_set(rtx_index *ix, uint64_t n_queries) {
+    int rc;
+    if ((rc = ix->d_status.alloc(n_queries)) || (rc = ix->d_t_all.alloc(n_queries)) || (rc = ix->d_nrows_all.alloc(n_queries)) ||
+        (rc = ix->d_n_rows.alloc(n_queries)) || (rc = ix->d_gs.alloc(n_queries)) || (rc = ix->d_z.alloc(n_queries)) ||
+        (rc = ix->d_hq.alloc(n_queries)) || (rc = ix->d_row_start.alloc(n_queries)) || (rc = ix->d_ndist.alloc(n_queries)) ||
+        (rc = ix->d_cursor.alloc(2)) || (rc = ix->d_flags.alloc(1)))
+        return rc;
+    const uint64_t want_arena = n_queries * 10 + 4096;  // eight rows per query + two for what the sub-allocators leave unused (walk_params)
+    if (ix->arena_cap < want_arena) {
+        if ((rc = ix->d_arena.alloc(want_arena))) return rc;
+        ix->arena_cap = want_arena;
+    }
+    return alloc_final(ix, n_queries);
+}
+
+// A run that may be followed by a run-ahead (RTX_OPT_RUN_AHEAD) leaves out the wait of the handle's stream for the stream of its back
+// halves; whoever needs the handle's stream to cover the whole run asks for it here.
+int settle_join(rtx_index *ix) {
+    if (ix->join_pending && ix->join_ev) RTX_HIP(hipStreamWaitEvent(ix->stream, ix->join_ev, 0));
+    ix->join_pending = false;
+    return RTX_OK;
+}
+
 int alloc_final(rtx_index *ix, uint64_t n_queries) {
     int rc;
     if ((rc = ix->d_fin_t.alloc(n_queries)) || (rc = ix->d_fin_status.alloc(n_queries)) || (rc = ix->d_fin_gs.alloc(n_queries)) ||
@@ -749,7 +790,10 @@ int enqueue_batch(rtx_index *ix, uint32_t flags) {
     }
     uint32_t n_sub = 0;
     bool timed = false;
-    int rc = begin_run(ix, &n_sub, &timed, ix->cluster != 0);
+    int rc;
+    // (a run that left its join out, and no run-ahead in progress: the kernels of this run write what its back halves may still read)
+    if (ix->join_pending && !ix->hold_join && (rc = settle_join(ix))) return rc;
+    rc = begin_run(ix, &n_sub, &timed, ix->cluster != 0);
     if (rc) return rc;
     ix->stream_dl = false;
     if (n_sub <= 4096) {  // per sub-batch: completion event (+ cursor snapshot) for the streamed download
@@ -786,6 +830,17 @@ int enqueue_batch(rtx_index *ix, uint32_t flags) {
     uint32_t n_side = 0;
     for (uint32_t c = 0; c < ix->n_cls; c++)
         if (ix->cls[c].side) n_side += ix->cls[c].n_sub;
+    // RTX_OPT_RUN_AHEAD: a run of this shape (two streams, no side class) leaves out the join at its end -- the next chunk may be enqueued
+    // behind its last FRONT half (rtx_batch_download_then_run) -- and, enqueued that way itself (hold_join: the result sets have been
+    // swapped), drops the join of the run before it: its first front halves wait for the scratch sets only.
+    const bool ra = ix->run_ahead_opt != 0u && nsets == 2u && n_side == 0u && ix->stream_dl && !ix->stage_timing && n_sub >= 2u;
+    if (ix->join_pending) {  // (hold_join)
+        if (ra) ix->join_pending = false;
+        else if ((rc = settle_join(ix))) return rc;
+    }
+    if (ra)
+        for (uint32_t k = 0; k < 2u; k++)
+            if (!ix->ev_set_free[k]) RTX_HIP(hipEventCreateWithFlags(&ix->ev_set_free[k], hipEventDisableTiming));
     for (uint32_t sb = 0; sb < n_sub; sb++) {
         if ((int)ix->sub_cls[sb] != ix->cur_cls) apply_class(ix, ix->sub_cls[sb]);  // the next length class: its planes, strides, kernels
         SubBatch b = sub_batch_of(ix, sb, timed);
@@ -807,6 +862,7 @@ int enqueue_batch(rtx_index *ix, uint32_t flags) {
             const uint32_t m = sb - n_side;  // among the sub-batches of the bulk
             b.set = m % nsets;
             if (m >= nsets) RTX_HIP(hipStreamWaitEvent(ix->stream, ix->ev_back[sb - nsets], 0));  // the scratch set is free again
+            else if (ra && ix->set_busy[b.set]) RTX_HIP(hipStreamWaitEvent(ix->stream, ix->ev_set_free[b.set], 0));  // ... of the run before (run-ahead)
         }
         if ((rc = enqueue_count(ix, b, flags, nsets == 3u && !side && n_side == 0 ? ix->stream3 : nullptr))) return rc;
         if (overlap && !side) {
@@ -830,8 +886,15 @@ int enqueue_batch(rtx_index *ix, uint32_t flags) {
             if (!fin_later) RTX_HIP(hipEventRecord(ix->ev_sub[sb], b.s));
         }
         if (overlap) RTX_HIP(hipEventRecord(ix->ev_back[sb], b.s));
+        if (ra) {
+            RTX_HIP(hipEventRecord(ix->ev_set_free[b.set], b.s));
+            ix->set_busy[b.set] = true;
+        }
     }
-    if (overlap && n_sub) {  // a wait for the handle's stream covers all of them
+    if (ra) {  // the join is left to whoever needs it (settle_join)
+        ix->join_pending = true;
+        ix->join_ev = ix->ev_back[n_sub - 1];
+    } else if (overlap && n_sub) {  // a wait for the handle's stream covers all of them
         RTX_HIP(hipStreamWaitEvent(ix->stream, ix->ev_back[n_sub - 1], 0));
         if (n_side && n_side < n_sub) RTX_HIP(hipStreamWaitEvent(ix->stream, ix->ev_back[n_side - 1], 0));
         for (uint32_t sb = 0; sb < n_side; sb++) {  // (the streamed download waits for the side classes last)
@@ -843,7 +906,10 @@ int enqueue_batch(rtx_index *ix, uint32_t flags) {
     {   // the flags of the run, behind its last kernel (the handle's stream has joined the others): the download finds them in page-locked memory
         int rc_f = ix->h_flags.resize(1);
         if (rc_f) return rc_f;
-        RTX_HIP(hipMemcpyAsync(ix->h_flags.data(), ix->d_flags.p, 4, hipMemcpyDeviceToHost, ix->stream));
+        const hipStream_t fs = ra ? ix->stream2 : ix->stream;  // (run-ahead: behind the last back half -- every front half lies before it)
+        RTX_HIP(hipMemcpyAsync(ix->h_flags.data(), ix->d_flags.p, 4, hipMemcpyDeviceToHost, fs));
+        if (!ix->ev_flags) RTX_HIP(hipEventCreateWithFlags(&ix->ev_flags, hipEventDisableTiming));
+        RTX_HIP(hipEventRecord(ix->ev_flags, fs));
     }
     RTX_HIP(hipGetLastError());
     return RTX_OK;
@@ -1044,17 +1110,9 @@ static int size_workspace(rtx_index *ix, uint64_t n_queries) {
     if (tab_t && (rc = ensure_prob_tables(ix, tab_t, &tables))) return rc;
     for (uint32_t c = 0; c < ix->n_cls; c++) ix->cls[c].use_tables = tables && ix->cls[c].tmax >= 2 && ix->cls[c].tmax <= kProbTablesMaxT && ix->cls[c].planes <= 11;
     // ---- per-query results
-    if ((rc = ix->d_status.alloc(n_queries)) || (rc = ix->d_t_all.alloc(n_queries)) || (rc = ix->d_nrows_all.alloc(n_queries)) ||
-        (rc = ix->d_n_rows.alloc(n_queries)) || (rc = ix->d_gs.alloc(n_queries)) || (rc = ix->d_z.alloc(n_queries)) ||
-        (rc = ix->d_hq.alloc(n_queries)) || (rc = ix->d_row_start.alloc(n_queries)) || (rc = ix->d_ndist.alloc(n_queries)))
-        return rc;
+    if ((rc = alloc_result_set(ix, n_queries))) return rc;
     if ((rc = ix->d_sub_alloc.alloc((size_t)kWalkSubAllocs * kWalkSubStride))) return rc;
-    const uint64_t want_arena = n_queries * 10 + 4096;  // eight rows per query + two for what the sub-allocators leave unused (walk_params)
-    if (ix->arena_cap < want_arena) {
-        if ((rc = ix->d_arena.alloc(want_arena))) return rc;
-        ix->arena_cap = want_arena;
-    }
-    if ((rc = alloc_final(ix, n_queries))) return rc;
+    const uint64_t want_arena = n_queries * 10 + 4096;  // (alloc_result_set)
     // ---- sub-batch scratch, sized against free HBM: every class gets the sub-batch size its own shape allows, the buffers the largest
     // product over the classes (a class runs after the other through the same buffers)
     // RTX_OPT_OVERLAP: two (three) scratch sets -- not for a handle that shares its device with another one driven beside it (rtx_raxtax_multi):
@@ -1309,6 +1367,7 @@ int rtx_batch_sync(rtx_index *ix) {
     int rc = bind(ix);
     if (rc) return rc;
     if (!ix->ran) { set_error("rtx_batch_sync before rtx_batch_run"); return RTX_ERR_STATE; }
+    if ((rc = settle_join(ix))) return rc;
     RTX_HIP(hipStreamSynchronize(ix->stream));
     ix->synced = true;
     return RTX_OK;

@@ -100,39 +100,126 @@ static int run_staged(rtx_index *ix, uint32_t flags, bool *ran_next) {
     return rc;
 }
 
+// What a run asked for that it did not have (its flags; the arena cursor it reached): more rows of counts, longer record segments, a larger
+// arena with its final arrays -- for the CURRENT result set.  The caller repeats the (deterministic) run.
+static int grow_for_flags(rtx_index *ix, uint32_t flags, unsigned long long cursor, uint64_t nq) {
+    int rc;
+    if (flags & 4u) {  // more queries took the dense epilogues than the counts buffer had rows (HitParams::cnt_row): twice the rows
+        if (ix->diet_shift == 0u) { set_error("the counts buffer ran out of rows without being on its diet (internal error)"); return RTX_ERR_HIP; }
+        ix->diet_shift--;
+    }
+    if (flags & 8u) {  // a query left a tile more records than a segment holds (RecordRef::seg_len): twice the length
+        if (ix->rec_seg_len >= 8192u) { set_error("a record segment of a whole tile overflowed (internal error)"); return RTX_ERR_HIP; }
+        ix->rec_seg_len *= 2u;
+    }
+    if ((flags & 12u) && !(flags & 1u)) return RTX_OK;
+    // arena too small: grow to what this run asked for
+    // (+ what the sub-allocators of the walk may leave unused on top of this run's share: their holes differ from run to run, and an
+    // arena cut to this run's cursor overflowed again on every other step of the same batch -- 3.3 instead of 4.5 M queries/s on real barcodes)
+    // and at least half as much again as the arena that overflowed: walks that find their sub-allocator's piece used up at the
+    // same moment each take a fresh one, so the holes of a launch are not bounded by the number of sub-allocators
+    const uint64_t want = std::max<uint64_t>(cursor + 4096 + (uint64_t)(ix->n_sub_run ? ix->n_sub_run : 1u) * kWalkSubAllocs * kWalkChunkRows,
+                                             ix->arena_cap + ix->arena_cap / 2) + (ix->arena_cap - ix->side_base);  // (+ the side classes' region)
+    if ((rc = ix->d_arena.alloc(want))) return rc;
+    ix->arena_cap = want;
+    return alloc_final(ix, nq);  // (the final arrays hold as many rows as the arena)
+}
+
+// RTX_OPT_RUN_AHEAD: the staged batch is enqueued while the last sub-batch of the batch being downloaded is still running.  The result
+// state of that batch moves to rtx_index::alt (swap_result_sets), the next batch writes the other set; its first front half starts behind
+// this batch's last FRONT half (the handle's stream), its scratch sets wait for the back halves that last used them (enqueue_batch).
+static int run_ahead(rtx_index *ix, uint32_t flags) {
+    rtx_index::Inputs &nx = ix->in[ix->cur_in ^ 1u];
+    swap_result_sets(ix);
+    int rc = alloc_result_set(ix, nx.n_q);
+    ix->hold_join = true;
+    bool ran = false;
+    if (!rc) rc = run_staged(ix, flags, &ran);
+    ix->hold_join = false;
+    if (!rc) ix->n_run_ahead++;
+    return rc;
+}
+
+// Streamed download.  Under RTX_OPT_RUN_AHEAD (`ahead` below) the staged batch is enqueued FIRST (run_ahead): two batches are then on the device,
+// and the host has a whole batch's time to come back with the one after.  From there on the members of the handle are the next batch's; this
+// batch's state comes back under its names for the rest of the call (the copies are asynchronous: the pointers are read when they are
+// enqueued) and leaves again at its end.  An overflow of this batch found now -- with the next one on the device already -- ends in
+// RTX_RETRY_CHUNK: both streams drained, the buffers grown, no batch on the handle; the caller runs this chunk again and stages the next one
+// anew (host_raxtax.cpp).  Happens while a handle's buffers find their size (its first chunks), not in steady state.
 static int download_streamed(rtx_index *ix, rtx_index::HostRes &hr, bool *done, uint64_t *nrows_out, bool then_run, uint32_t next_flags, bool *ran_next) {
     *done = false;
     const uint32_t n_sub = ix->n_sub_run;
-    if (!ix->stream_dl || n_sub < 2 || ix->sub_q0.size() != n_sub || (hipEventQuery(ix->ev_sub[n_sub - 1]) == hipSuccess && hipEventQuery(ix->ev_sub[0]) == hipSuccess)) return RTX_OK;
+    if (!ix->stream_dl || n_sub < 2 || ix->sub_q0.size() != n_sub) return RTX_OK;
+    uint32_t n_side = 0;  // the side classes' sub-batches come first in the plan and run beside the bulk: they are finalised and waited for LAST
+    while (n_side < n_sub && ix->cls[ix->sub_cls[n_side]].side) n_side++;
+    const bool ahead = then_run && ix->run_ahead_opt != 0u && ix->join_pending && n_side == 0 && ix->in[ix->cur_in ^ 1u].staged;
+    // (a batch that is complete already takes the bulk path -- unless the next one is about to be enqueued ahead: the device comes first)
+    if (!ahead && hipEventQuery(ix->ev_sub[n_sub - 1]) == hipSuccess && hipEventQuery(ix->ev_sub[0]) == hipSuccess) return RTX_OK;
     const uint64_t nq = ix->n_q;
     int rc = size_host_results(ix, hr, nq, nq + nq / 4 + 64, 0);
     if (rc) return rc;
     if ((rc = fetch_exact_groups(ix, nq))) return rc;  // (now, beside the kernels: 4 MB per 1 M queries that used to cross at the tail, with the device idle)
+    struct Restore {  // this batch's result state under the handle's names while `on`
+        rtx_index *ix; bool on;
+        ~Restore() { if (on) swap_result_sets(ix); }
+    } restore{ix, false};
+    if (ahead) {
+        if ((rc = run_ahead(ix, next_flags))) return rc;
+        *ran_next = true;
+        swap_result_sets(ix);
+        restore.on = true;
+    }
     uint64_t prev = 0;
-    uint32_t n_side = 0;  // the side classes' sub-batches come first in the plan and run beside the bulk: they are finalised and waited for LAST
-    while (n_side < n_sub && ix->cls[ix->sub_cls[n_side]].side) n_side++;
-    for (uint32_t k = 0; k < n_sub; k++) {
+    uint32_t redo = 0;  // what sends this batch round again (bits of d_flags)
+    for (uint32_t k = 0; k < n_sub && !redo; k++) {
         const uint32_t sb = k + n_side < n_sub ? k + n_side : k + n_side - n_sub;
         RTX_HIP(hipEventSynchronize(ix->ev_sub[sb]));
-        const bool side = ix->cls[ix->sub_cls[sb]].side;  // its rows lie in the side region of the arena, behind its own cursor
-        if (ix->h_cursor_sub[sb] > (side ? ix->arena_cap : ix->side_base)) return RTX_OK;  // arena overflow: the bulk path repeats the run
+        const bool side = !ahead && ix->cls[ix->sub_cls[sb]].side;  // its rows lie in the side region of the arena, behind its own cursor (ahead: no side class; the plan is the next batch's by now)
+        if (ix->h_cursor_sub[sb] > (side ? ix->arena_cap : ix->side_base)) { redo = 1u; break; }  // arena overflow
         const uint64_t cur = ix->h_fin_sub[sb];  // final rows [prev, cur): this sub-batch's (the finalise launches follow one another)
-        if (cur > ix->fin_cap) return RTX_OK;
+        if (cur > ix->fin_cap) { redo = 1u; break; }
         // (cur <= prev: a side class that ran in front of the bulk on the one stream -- its rows left with the first range)
         if (cur > std::min<uint64_t>({hr.v_row_lineage.cap, hr.v_row_depth8.cap, hr.v_row_local.cap, hr.v_row_conf.cap / ix->fin_D, hr.v_row_hund.cap / ix->fin_D}))
             RTX_HIP(hipStreamSynchronize(ix->copy_stream));  // an array is about to move: the copies into it have to have landed
         if (cur > prev && ((rc = size_host_results(ix, hr, nq, cur, prev)) || (rc = copy_rows(ix, hr, prev, cur, ix->copy_stream)))) return rc;
         prev = std::max(prev, cur);
-        if (k + 1 == n_sub) {  // the last records leave the device: it is free for the next batch
+        if (k + 1 == n_sub) {  // the last records leave the device
             if ((rc = copy_queries(ix, hr, nq, ix->copy_stream))) return rc;
             RTX_HIP(hipStreamSynchronize(ix->copy_stream));
-            RTX_HIP(hipStreamSynchronize(ix->stream));
-            const uint32_t flags = ix->h_flags.size() ? ix->h_flags[0] : 0u;  // (copied behind the run's last kernel: enqueue_batch)
-            if (flags & 12u) return RTX_OK;  // the rows of the counts buffer ran out, or a record segment was too short: the bulk path repeats the run (whatever else such a run flagged)
+            if (ahead) {
+                RTX_HIP(hipEventSynchronize(ix->ev_flags));  // (behind the last back half of this batch, on the stream of the back halves)
+            } else {
+                if ((rc = settle_join(ix))) return rc;
+                RTX_HIP(hipStreamSynchronize(ix->stream));
+            }
+            uint32_t flags = ix->h_flags.size() ? ix->h_flags[0] : 0u;  // (copied behind the run's last kernel: enqueue_batch)
+            if (ahead && ix->run_ahead_opt == 2u && (ix->n_run_ahead & 1u)) flags |= 1u;  // (test aid: as if the arena had overflowed)
+            if (flags & 12u) { redo = flags & 13u; break; }  // the rows of the counts buffer ran out, or a record segment was too short (whatever else such a run flagged)
             if (flags & 2u) { set_error("lineage walk exceeded its row/depth bounds (internal error)"); return RTX_ERR_HIP; }
-            if (flags & 1u) return RTX_OK;  // arena overflow: the bulk path repeats the run
-            if (then_run && (rc = run_staged(ix, next_flags, ran_next))) return rc;
+            if (flags & 1u) { redo = 1u; break; }  // arena overflow
+            if (!ahead && then_run && (rc = run_staged(ix, next_flags, ran_next))) return rc;  // the device is free for the next batch
         }
+    }
+    if (redo && !ahead) return RTX_OK;  // the bulk path repeats the run
+    if (redo) {  // this batch has to run again, and the next one is on the device: drain, grow, hand both back to the caller
+        RTX_HIP(hipStreamSynchronize(ix->copy_stream));
+        RTX_HIP(hipStreamSynchronize(ix->stream));
+        if (ix->stream2) RTX_HIP(hipStreamSynchronize(ix->stream2));
+        uint32_t flags = 0;
+        unsigned long long both[2] = {0, 0};
+        RTX_HIP(hipMemcpy(&flags, ix->d_flags.p, 4, hipMemcpyDeviceToHost));
+        RTX_HIP(hipMemcpy(both, ix->d_cursor.p, 16, hipMemcpyDeviceToHost));
+        restore.on = false;  // (this batch's set stays the current one: it is the one that grows)
+        if ((rc = grow_for_flags(ix, (flags & 13u) | redo, both[0], nq))) return rc;
+        ix->join_pending = false;
+        ix->uploaded = ix->ran = false;
+        ix->synced = true;
+        ix->in[0].staged = ix->in[1].staged = false;
+        ix->ws_valid = false;
+        ix->res_set ^= 1u;  // (the repeated download takes this host set again: the other one holds the view of the chunk before)
+        ix->n_run_ahead_retry++;
+        *ran_next = false;
+        return RTX_RETRY_CHUNK;
     }
     if (!*ran_next) ix->synced = true;  // (else: the next batch is running)
     *nrows_out = prev;
@@ -160,6 +247,7 @@ static int download_impl(rtx_index *ix, rtx_result_view *out, bool then_run, uin
         if (ix->copy_stream) RTX_HIP(hipStreamSynchronize(ix->copy_stream));
         unsigned long long cursor = 0, cursor_side = 0;
         for (int attempt = 0;; attempt++) {
+            if ((rc = settle_join(ix))) return rc;
             RTX_HIP(hipStreamSynchronize(ix->stream));
             ix->synced = true;
             uint32_t flags = 0;
@@ -171,30 +259,11 @@ static int download_impl(rtx_index *ix, rtx_result_view *out, bool then_run, uin
             if ((flags & 2u) && !(flags & 12u)) { set_error("lineage walk exceeded its row/depth bounds (internal error)"); return RTX_ERR_HIP; }
             if (!(flags & 13u)) break;
             if (attempt >= 8) { set_error("result arena / counts rows overflow persists"); return RTX_ERR_HIP; }
-            if (flags & 4u) {  // more queries took the dense epilogues than the counts buffer had rows (HitParams::cnt_row): twice the rows, the run again
-                if (ix->diet_shift == 0u) { set_error("the counts buffer ran out of rows without being on its diet (internal error)"); return RTX_ERR_HIP; }
-                ix->diet_shift--;
+            if ((rc = grow_for_flags(ix, flags, cursor, nq))) return rc;
+            if ((flags & 12u) && !(flags & 1u)) {
+                if ((rc = enqueue_batch(ix, ix->last_flags))) return rc;
+                continue;
             }
-            if (flags & 8u) {  // a query left a tile more records than a segment holds (RecordRef::seg_len): twice the length, the run again
-                if (ix->rec_seg_len >= 8192u) { set_error("a record segment of a whole tile overflowed (internal error)"); return RTX_ERR_HIP; }
-                ix->rec_seg_len *= 2u;
-            }
-            if (flags & 12u) {
-                if (!(flags & 1u)) {
-                    if ((rc = enqueue_batch(ix, ix->last_flags))) return rc;
-                    continue;
-                }
-            }
-            // arena too small: grow to what this run asked for and repeat the (deterministic) run
-            // (+ what the sub-allocators of the walk may leave unused on top of this run's share: their holes differ from run to run, and an
-            // arena cut to this run's cursor overflowed again on every other step of the same batch -- 3.3 instead of 4.5 M queries/s on real barcodes)
-            // and at least half as much again as the arena that overflowed: walks that find their sub-allocator's piece used up at the
-            // same moment each take a fresh one, so the holes of a launch are not bounded by the number of sub-allocators
-            const uint64_t want = std::max<uint64_t>(cursor + 4096 + (uint64_t)(ix->n_sub_run ? ix->n_sub_run : 1u) * kWalkSubAllocs * kWalkChunkRows,
-                                                     ix->arena_cap + ix->arena_cap / 2) + (ix->arena_cap - ix->side_base);  // (+ the side classes' region)
-            if ((rc = ix->d_arena.alloc(want))) return rc;
-            ix->arena_cap = want;
-            if ((rc = alloc_final(ix, nq))) return rc;  // (the final arrays hold as many rows as the arena)
             if (ix->n_refs != ix->n_total) {  // a sharded run is driven by the caller: ask it to repeat
                 set_error("result arena overflow: repeat the sharded run (the arena has been enlarged)");
                 return RTX_ERR_STATE;

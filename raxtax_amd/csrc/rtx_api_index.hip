@@ -10,6 +10,13 @@ int index_device(const rtx_index *index) { return index ? index->device : -1; }
 void index_set_shared_device(rtx_index *index, bool shared) { if (index) index->shared_device = shared; }
 // RTX_OPT_MIN_SUB_BATCHES for the duration of a call of the host mirror: the batch state of the handle stays, the caller's setting comes back
 uint32_t index_swap_min_subs(rtx_index *index, uint32_t v) { if (!index) return 0; const uint32_t old = index->min_subs; index->min_subs = v; return old; }
+// RTX_OPT_RUN_AHEAD for the duration of a call of the host mirror (rtx_raxtax over several chunks); switched off: the last run's join is enqueued
+uint32_t index_swap_run_ahead(rtx_index *index, uint32_t v) {
+    if (!index) return 0;
+    const uint32_t old = index->run_ahead_opt;
+    (void)rtx_index_set_option(index, RTX_OPT_RUN_AHEAD, v);
+    return old;
+}
 }  // namespace rtx
 
 namespace {
@@ -687,12 +694,26 @@ int rtx_index_prune_verdict(const rtx_index *ix, int *pruning, double *live_frac
     return RTX_OK;
 }
 
+int rtx_index_run_ahead_stats(const rtx_index *ix, uint64_t *enqueued_ahead, uint64_t *abandoned) {
+    if (!ix) { set_error("null index handle"); return RTX_ERR_INVALID; }
+    if (enqueued_ahead) *enqueued_ahead = ix->n_run_ahead;
+    if (abandoned) *abandoned = ix->n_run_ahead_retry;
+    return RTX_OK;
+}
+
 void rtx_index_destroy(rtx_index *index) {
     if (!index) return;
     (void)hipSetDevice(index->device);
     delete index;
 }
 
+// the second result set of a handle that ran ahead (rtx_index::alt): per-query arrays, arena, final arrays, order
+static uint64_t alt_set_bytes(const rtx_index *ix) {
+    const rtx_index::ResultSet &a = ix->alt;
+    return a.d_status.n + (a.d_t_all.n + a.d_nrows_all.n + a.d_n_rows.n + a.d_ndist.n + a.d_perm.n + a.d_iperm.n + a.d_exact_grp.n) * 4 + (a.d_gs.n + a.d_z.n + a.d_hq.n + a.d_row_start.n) * 8 +
+           a.d_arena.n * sizeof(DevRow) + (a.d_fin_t.n + a.d_fin_row_count.n + a.d_fin_lineage.n + a.d_fin_node.n + a.d_fin_depth.n) * 4 + a.d_fin_status.n + a.d_fin_depth8.n + a.d_fin_hund.n +
+           (a.d_fin_gs.n + a.d_fin_local.n + a.d_fin_conf.n + a.d_fin_row_begin.n) * 8;
+}
 uint64_t rtx_index_num_refs(const rtx_index *index) { return index ? index->n_total : 0; }
 uint64_t rtx_index_device_bytes(const rtx_index *index) {
     if (!index) return 0;
@@ -715,7 +736,7 @@ uint64_t rtx_index_workspace_bytes(const rtx_index *ix) {
     b += ix->d_status.n + (ix->d_t_all.n + ix->d_nrows_all.n + ix->d_n_rows.n + ix->d_ndist.n) * 4 + (ix->d_gs.n + ix->d_z.n + ix->d_hq.n + ix->d_row_start.n) * 8 + ix->d_arena.n * sizeof(DevRow);
     b += (ix->d_fin_t.n + ix->d_fin_row_count.n + ix->d_fin_lineage.n + ix->d_fin_node.n + ix->d_fin_depth.n) * 4 + ix->d_fin_status.n + ix->d_fin_depth8.n + ix->d_fin_hund.n +
          (ix->d_fin_gs.n + ix->d_fin_local.n + ix->d_fin_conf.n + ix->d_fin_row_begin.n) * 8;
-    return b;
+    return b + alt_set_bytes(ix);
 }
 // ... in parts: [0] probability tables, [1] counts, [2] record segments, [3] boundary prefix sums, [4] per-tile masks and sparse-slot lists,
 // [5] the rest of the scratch sets, [6] inputs + processing order, [7] result arena + final arrays; [8] scratch sets in use
@@ -735,7 +756,7 @@ int rtx_index_workspace_parts(const rtx_index *ix, uint64_t out[9]) {
     for (const auto &in : ix->in) out[6] += in.d_packed.n + (in.d_base_off.n + in.d_exact_off.n) * 8 + in.d_exact_ids.n * 4;
     out[7] = ix->d_status.n + (ix->d_t_all.n + ix->d_nrows_all.n + ix->d_n_rows.n + ix->d_ndist.n) * 4 + (ix->d_gs.n + ix->d_z.n + ix->d_hq.n + ix->d_row_start.n) * 8 + ix->d_arena.n * sizeof(DevRow) +
              (ix->d_fin_t.n + ix->d_fin_row_count.n + ix->d_fin_lineage.n + ix->d_fin_node.n + ix->d_fin_depth.n) * 4 + ix->d_fin_status.n + ix->d_fin_depth8.n + ix->d_fin_hund.n +
-             (ix->d_fin_gs.n + ix->d_fin_local.n + ix->d_fin_conf.n + ix->d_fin_row_begin.n) * 8;
+             (ix->d_fin_gs.n + ix->d_fin_local.n + ix->d_fin_conf.n + ix->d_fin_row_begin.n) * 8 + alt_set_bytes(ix);
     const uint64_t all = rtx_index_workspace_bytes(ix);
     uint64_t named = 0;
     for (int i = 0; i < 8; i++) named += out[i];
@@ -807,6 +828,14 @@ int rtx_index_set_option(rtx_index *index, int option, uint64_t value) {
         case RTX_OPT_PRUNE_SELF_SAMPLE:
             index->uploaded = index->ran = index->synced = false;  // shapes the workspace (the scratch of the tile pruning)
             index->self_sample_opt = value ? 1u : 0u;
+            return RTX_OK;
+        case RTX_OPT_RUN_AHEAD:
+            index->run_ahead_opt = (uint32_t)std::min<uint64_t>(value, 2u);  // (2: a test aid -- every second run-ahead is abandoned as if the batch had overflowed)
+            if (!value && index->join_pending) {  // a run that left its join out: enqueued now, the handle's stream covers that run again
+                int rc_b = bind(index);
+                if (!rc_b) rc_b = settle_join(index);
+                return rc_b;
+            }
             return RTX_OK;
         case RTX_OPT_TWO_LEVEL_BOUNDS:
             index->two_level_opt = value ? 1u : 0u;

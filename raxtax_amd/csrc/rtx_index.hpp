@@ -108,6 +108,11 @@ struct PinBuf {
     ~PinBuf() { if (p) (void)hipHostFree(p); }
 };
 
+template <class T>
+inline void swap_buf(DevBuf<T> &a, DevBuf<T> &b) { std::swap(a.p, b.p); std::swap(a.n, b.n); }
+template <class T>
+inline void swap_buf(PinBuf<T> &a, PinBuf<T> &b) { std::swap(a.p, b.p); std::swap(a.cap, b.cap); std::swap(a.n, b.n); }
+
 inline uint64_t align_up(uint64_t v, uint64_t a) { return (v + a - 1) / a * a; }
 
 #ifndef RTX_PRUNE_MIN_TILES
@@ -380,10 +385,47 @@ struct rtx_index {
     PinBuf<unsigned long long> h_hq;
     uint32_t stage_timing = 0;  // 0: HIP events around hit_count only; 1: around every kernel
 
+    // ---- run-ahead (RTX_OPT_RUN_AHEAD, set by rtx_raxtax for its chunks): rtx_batch_download_then_run enqueues the staged batch BEFORE the last
+    // sub-batch of the batch being downloaded has finished, so that the front half of the next chunk's first sub-batch runs beside the back
+    // half of this chunk's last one (the two streams of RTX_OPT_OVERLAP then never drain between chunks).  Everything a batch writes per query
+    // and per row, and what its download reads, exists twice: the members of these names are the CURRENT batch's, `alt` holds the other set
+    // (swap_result_sets); the scratch sets are shared (a front half waits for the back half that last used its set: ev_set_free).
+    struct ResultSet {
+        DevBuf<uint8_t> d_status;
+        DevBuf<uint32_t> d_t_all, d_nrows_all, d_n_rows, d_flags, d_ndist;
+        DevBuf<double> d_gs, d_z;
+        DevBuf<unsigned long long> d_hq, d_row_start, d_cursor;
+        DevBuf<DevRow> d_arena;
+        DevBuf<uint32_t> d_fin_t, d_fin_row_count, d_fin_lineage, d_fin_node, d_fin_depth;
+        DevBuf<uint8_t> d_fin_status, d_fin_depth8, d_fin_hund;
+        DevBuf<double> d_fin_gs, d_fin_local, d_fin_conf;
+        DevBuf<unsigned long long> d_fin_row_begin, d_fin_cursor;
+        DevBuf<uint32_t> d_perm, d_iperm, d_exact_grp;
+        uint64_t fin_cap = 0, arena_cap = 0, side_base = 0;
+        PinBuf<uint32_t> h_flags;
+        PinBuf<unsigned long long> h_fin_sub, h_cursor_sub;
+        std::vector<hipEvent_t> ev_sub;
+        hipEvent_t ev_exact = nullptr, ev_flags = nullptr;
+    } alt;
+    hipEvent_t ev_flags = nullptr;   // behind the copy of the run's flags into h_flags
+    uint32_t run_ahead_opt = 0;      // RTX_OPT_RUN_AHEAD
+    bool join_pending = false;       // the last run left out the join of the handle's stream with the stream of its back halves (settle_join enqueues it)
+    hipEvent_t join_ev = nullptr;    // ... which is a wait for this event (the run's last ev_back)
+    bool hold_join = false;          // a run-ahead is being enqueued: the join of the batch before it is dropped, not enqueued
+    hipEvent_t ev_set_free[3] = {nullptr, nullptr, nullptr};  // behind the back half that last used scratch set k
+    bool set_busy[3] = {false, false, false};
+    uint64_t n_run_ahead = 0, n_run_ahead_retry = 0;  // chunks enqueued ahead / run-aheads abandoned for an overflow of the chunk before (rtx_index_run_ahead_stats)
+
     bool shared_device = false;  // rtx_raxtax_multi drives another handle on the same device beside this one: no second stream (begin_run)
     ~rtx_index() {
         for (auto e : events) (void)hipEventDestroy(e);
         for (auto e : ev_sub) (void)hipEventDestroy(e);
+        for (auto e : alt.ev_sub) (void)hipEventDestroy(e);
+        if (alt.ev_exact) (void)hipEventDestroy(alt.ev_exact);
+        if (alt.ev_flags) (void)hipEventDestroy(alt.ev_flags);
+        if (ev_flags) (void)hipEventDestroy(ev_flags);
+        for (auto e : ev_set_free)
+            if (e) (void)hipEventDestroy(e);
         for (auto e : ev_front) (void)hipEventDestroy(e);
         for (auto e : ev_back) (void)hipEventDestroy(e);
         for (auto e : ev_mid) (void)hipEventDestroy(e);
@@ -442,6 +484,9 @@ int alloc_scratch_set(rtx_index *ix, uint32_t k);
 constexpr uint32_t kSideSet = 3;
 // ---- rtx_api_download.hip
 int node_tables(rtx_index *ix);  // the per-node tables of finalise_kernel, uploaded at creation
+void swap_result_sets(rtx_index *ix);  // (rtx_api_batch.hip) the current batch's result state <-> rtx_index::alt
+int alloc_result_set(rtx_index *ix, uint64_t n_queries);  // (rtx_api_batch.hip) the per-query arrays, the arena and the final arrays of the CURRENT set
+int settle_join(rtx_index *ix);        // (rtx_api_batch.hip) the handle's stream waits for the back halves of the last run, if that run left the join out
 int alloc_final(rtx_index *ix, uint64_t n_queries);  // (rtx_api_batch.hip) the final result arrays: n_queries per-query fields, arena_cap rows
 int enqueue_finalise(rtx_index *ix, const SubBatch &b, hipStream_t s);  // (rtx_api_batch.hip) behind the walks of a sub-batch
 

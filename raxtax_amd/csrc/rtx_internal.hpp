@@ -28,6 +28,8 @@ unsigned host_threads(unsigned want, unsigned sharers = 1);
 int index_device(const rtx_index *index);
 void index_set_shared_device(rtx_index *index, bool shared);
 uint32_t index_swap_min_subs(rtx_index *index, uint32_t v);  // returns the previous value
+uint32_t index_swap_run_ahead(rtx_index *index, uint32_t v);  // RTX_OPT_RUN_AHEAD, returns the previous value
+bool hw_queues_for_run_ahead();  // (host_threads.cpp) GPU_MAX_HW_QUEUES reads six or more: transfers do not share a hardware queue with kernels
 
 #ifndef RTX_NODE_TYPES_DEFINED
 #define RTX_NODE_TYPES_DEFINED

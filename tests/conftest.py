@@ -1,5 +1,8 @@
+import os
 import sys
 from pathlib import Path
+
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # (raxtax_amd/__init__.py: before anything initialises HIP)
 
 import pytest
 

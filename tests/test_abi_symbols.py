@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_abi_version_and_no_device_is_loud():
     lib = _lib.load()
-    assert lib.rtx_abi_version() == 5
+    assert lib.rtx_abi_version() == 6
     if lib.rtx_device_count() == 0:
         # no CPU fallback: index creation must fail with RTX_ERR_NO_DEVICE
         import numpy as np

@@ -33,4 +33,5 @@ for rep in range(4):
         lib.rtx_batch_sub_batch(h._h, ctypes.byref(sb), ctypes.byref(ns))
         info.append((sb.value, ns.value, round(h.device_bytes / 1e9, 2)))
     print("   (sub-batch, sub-batches, index GB) per handle:", info)
+    print("   run-ahead (enqueued ahead, abandoned) per handle:", [h.run_ahead_stats for h in handles])
     print(f"n_q={n_q} chunk={chunk} handles={n_h} {opts} rep {rep}: {dt*1e3:.1f} ms; device {busy[1]*1e3:.0f} format {busy[2]*1e3:.0f} sender {busy[3]*1e3:.0f}", flush=True)

@@ -833,7 +833,7 @@ int enqueue_batch(rtx_index *ix, uint32_t flags) {
     // RTX_OPT_RUN_AHEAD: a run of this shape (two streams, no side class) leaves out the join at its end -- the next chunk may be enqueued
     // behind its last FRONT half (rtx_batch_download_then_run) -- and, enqueued that way itself (hold_join: the result sets have been
     // swapped), drops the join of the run before it: its first front halves wait for the scratch sets only.
-    const bool ra = ix->run_ahead_opt != 0u && nsets == 2u && n_side == 0u && ix->stream_dl && !ix->stage_timing && n_sub >= 2u;
+    const bool ra = ix->run_ahead_opt != 0u && nsets == 2u && n_side == 0u && ix->stream_dl && n_sub >= 2u;  // (RTX_OPT_STAGE_TIMING: the stage events are then those of whichever run recorded them last)
     if (ix->join_pending) {  // (hold_join)
         if (ra) ix->join_pending = false;
         else if ((rc = settle_join(ix))) return rc;
@@ -848,15 +848,17 @@ int enqueue_batch(rtx_index *ix, uint32_t flags) {
         if (side) {  // (the side classes come first: sub-batches 0 .. n_side - 1, one after the other through their own set)
             b.set = kSideSet;
             if (overlap) {
-                // ... and as a whole on a stream of their own: a few waves per kernel, every one a long chain of round trips (6 000 rows
-                // through one wave, the recurrence of prob_table) -- beside the bulk instead of in front of it.  Their result rows go to
-                // the top of the arena through a cursor of their own (walk_params), so the arena ranges of the streamed download hold.
-                if (!ix->stream3) RTX_HIP(hipStreamCreateWithFlags(&ix->stream3, hipStreamNonBlocking));
+                // ... and as a whole on the stream of the BACK halves, in front of them: a few waves per kernel, every one a long chain of
+                // round trips (6 000 rows through one wave, the recurrence of prob_table) -- 3 ms for ten reads of 1 .. 8 kb -- that hides
+                // under the bulk's first front half.  (Until the library asked for eight hardware queues this was a stream of its own that
+                // SHARED a queue: 12.0 ms per batch of 131 072 barcodes + ten long reads; with a queue of its own every launch of the chain
+                // queued for a slot on a full device and the batch took 13.0; in front of the bulk on the handle's stream: 14.7.)
+                // Their result rows go to the top of the arena through a cursor of their own (walk_params); they are finalised first.
                 if (sb == 0) {
                     RTX_HIP(hipEventRecord(ix->ev_mid[0], ix->stream));  // the processing order and the exact matches are in place
-                    RTX_HIP(hipStreamWaitEvent(ix->stream3, ix->ev_mid[0], 0));
+                    RTX_HIP(hipStreamWaitEvent(ix->stream2, ix->ev_mid[0], 0));
                 }
-                b.s = ix->stream3;
+                b.s = ix->stream2;
             }
         } else if (overlap) {
             const uint32_t m = sb - n_side;  // among the sub-batches of the bulk
@@ -877,13 +879,11 @@ int enqueue_batch(rtx_index *ix, uint32_t flags) {
             RTX_HIP(hipEventRecord(stage_event(ix, b, RTX_STAGE_LINEAGE_WALK, 1), b.s));
         }
         // the rows of the sub-batch finalised on the device (rtx_finalise.hip).  The launches of a run follow one another -- a sub-batch's rows
-        // are then a range of the final arrays: the bulk's on the stream of its back halves; those of side classes that run beside the bulk
-        // (a stream of their own) behind the join below
-        const bool fin_later = side && overlap;
-        if (!fin_later && (rc = enqueue_finalise(ix, b, b.s))) return rc;
+        // are then a range of the final arrays: the side classes' first, then the bulk's, on the stream of the back halves
+        if ((rc = enqueue_finalise(ix, b, b.s))) return rc;
         if (ix->stream_dl) {
             RTX_HIP(hipMemcpyAsync(&ix->h_cursor_sub[sb], ix->d_cursor.p + (side ? 1 : 0), 8, hipMemcpyDeviceToHost, b.s));
-            if (!fin_later) RTX_HIP(hipEventRecord(ix->ev_sub[sb], b.s));
+            RTX_HIP(hipEventRecord(ix->ev_sub[sb], b.s));
         }
         if (overlap) RTX_HIP(hipEventRecord(ix->ev_back[sb], b.s));
         if (ra) {
@@ -896,12 +896,7 @@ int enqueue_batch(rtx_index *ix, uint32_t flags) {
         ix->join_ev = ix->ev_back[n_sub - 1];
     } else if (overlap && n_sub) {  // a wait for the handle's stream covers all of them
         RTX_HIP(hipStreamWaitEvent(ix->stream, ix->ev_back[n_sub - 1], 0));
-        if (n_side && n_side < n_sub) RTX_HIP(hipStreamWaitEvent(ix->stream, ix->ev_back[n_side - 1], 0));
-        for (uint32_t sb = 0; sb < n_side; sb++) {  // (the streamed download waits for the side classes last)
-            SubBatch b = sub_batch_of(ix, sb, false);
-            if ((rc = enqueue_finalise(ix, b, ix->stream))) return rc;
-            if (ix->stream_dl) RTX_HIP(hipEventRecord(ix->ev_sub[sb], ix->stream));
-        }
+        if (n_side && n_side < n_sub) RTX_HIP(hipStreamWaitEvent(ix->stream, ix->ev_back[n_side - 1], 0));  // (a batch of side classes alone)
     }
     {   // the flags of the run, behind its last kernel (the handle's stream has joined the others): the download finds them in page-locked memory
         int rc_f = ix->h_flags.resize(1);

@@ -425,6 +425,10 @@ int main(int argc, char **argv) {
                 if (rtx_raxtax_last_timing(busy, &nch) == RTX_OK)
                     fprintf(stderr, "[TIMING] pipeline busy seconds over %llu chunk(s) on %zu handle(s): lookup %.3f, device %.3f (busiest handle), format %.3f, sender %.3f\n",
                             (unsigned long long)nch, indices.size(), busy[0], busy[1], busy[2], busy[3]);
+                uint64_t ahead = 0, abandoned = 0;  // RTX_OPT_RUN_AHEAD (the first handle, since its creation)
+                if (rtx_index_run_ahead_stats(indices[0], &ahead, &abandoned) == RTX_OK)
+                    fprintf(stderr, "[TIMING] chunks enqueued ahead of the end of the chunk before them: %llu, abandoned: %llu (queries of this block: %llu)\n", (unsigned long long)ahead,
+                            (unsigned long long)abandoned, (unsigned long long)nb);
             }
         }
         rtx_queries_destroy(pz.qs);

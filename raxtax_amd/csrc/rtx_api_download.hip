@@ -186,12 +186,13 @@ static int download_streamed(rtx_index *ix, rtx_index::HostRes &hr, bool *done, 
         if (k + 1 == n_sub) {  // the last records leave the device
             if ((rc = copy_queries(ix, hr, nq, ix->copy_stream))) return rc;
             RTX_HIP(hipStreamSynchronize(ix->copy_stream));
-            if (ahead) {
-                RTX_HIP(hipEventSynchronize(ix->ev_flags));  // (behind the last back half of this batch, on the stream of the back halves)
-            } else {
+            if (!ahead) {
                 if ((rc = settle_join(ix))) return rc;
                 RTX_HIP(hipStreamSynchronize(ix->stream));
             }
+            // the run's flags have arrived (copied behind its last kernel -- under RTX_OPT_RUN_AHEAD on the stream of the back halves, which the
+            // handle's stream joins in FRONT of that copy: the event behind the copy is what says so)
+            if (ix->ev_flags) RTX_HIP(hipEventSynchronize(ix->ev_flags));
             uint32_t flags = ix->h_flags.size() ? ix->h_flags[0] : 0u;  // (copied behind the run's last kernel: enqueue_batch)
             if (ahead && ix->run_ahead_opt == 2u && (ix->n_run_ahead & 1u)) flags |= 1u;  // (test aid: as if the arena had overflowed)
             if (flags & 12u) { redo = flags & 13u; break; }  // the rows of the counts buffer ran out, or a record segment was too short (whatever else such a run flagged)

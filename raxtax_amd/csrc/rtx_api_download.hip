@@ -125,13 +125,20 @@ static int grow_for_flags(rtx_index *ix, uint32_t flags, unsigned long long curs
     return alloc_final(ix, nq);  // (the final arrays hold as many rows as the arena)
 }
 
-// RTX_OPT_RUN_AHEAD: the staged batch is enqueued while the last sub-batch of the batch being downloaded is still running.  The result
-// state of that batch moves to rtx_index::alt (swap_result_sets), the next batch writes the other set; its first front half starts behind
-// this batch's last FRONT half (the handle's stream), its scratch sets wait for the back halves that last used them (enqueue_batch).
+// RTX_OPT_RUN_AHEAD: the staged batch is enqueued while the batch being downloaded is still on the device.  The result state of that batch
+// moves to rtx_index::alt (swap_result_sets), the next batch writes the other set; its first front half starts behind this batch's last
+// FRONT half (the handle's stream), its scratch sets wait for the back halves that last used them (enqueue_batch).
 static int run_ahead(rtx_index *ix, uint32_t flags) {
     rtx_index::Inputs &nx = ix->in[ix->cur_in ^ 1u];
     swap_result_sets(ix);
     int rc = alloc_result_set(ix, nx.n_q);
+    if (!rc && ix->arena_cap < ix->alt.arena_cap) {  // what the other set has grown to, this one will need as well (and would find out by an abandoned run-ahead)
+        rc = ix->d_arena.alloc(ix->alt.arena_cap);
+        if (!rc) {
+            ix->arena_cap = ix->alt.arena_cap;
+            rc = alloc_final(ix, nx.n_q);
+        }
+    }
     ix->hold_join = true;
     bool ran = false;
     if (!rc) rc = run_staged(ix, flags, &ran);
@@ -150,7 +157,7 @@ static int download_streamed(rtx_index *ix, rtx_index::HostRes &hr, bool *done, 
     *done = false;
     const uint32_t n_sub = ix->n_sub_run;
     if (!ix->stream_dl || n_sub < 2 || ix->sub_q0.size() != n_sub) return RTX_OK;
-    uint32_t n_side = 0;  // the side classes' sub-batches come first in the plan and run beside the bulk: they are finalised and waited for LAST
+    uint32_t n_side = 0;  // the side classes' sub-batches come first in the plan (and on the stream of the back halves): they are waited for LAST, their rows left with the first range
     while (n_side < n_sub && ix->cls[ix->sub_cls[n_side]].side) n_side++;
     const bool ahead = then_run && ix->run_ahead_opt != 0u && ix->join_pending && n_side == 0 && ix->in[ix->cur_in ^ 1u].staged;
     // (a batch that is complete already takes the bulk path -- unless the next one is about to be enqueued ahead: the device comes first)

@@ -49,3 +49,23 @@ def test_chunks_enqueued_ahead_print_the_lines_of_one_batch(oracle, aid):
     ex = Excuses(f"run_ahead/aid={aid}")
     oracle_sample_parity(index, oracle, otree, db, qs, sample, False, ex, full_res=res, chunk=100)
     ex.check()
+
+
+def test_chunks_with_a_few_long_reads_among_the_barcodes(oracle):
+    """Chunks that hold a side class (a handful of long reads) do not run ahead -- the chunk behind such a chunk is enqueued when it has left the
+    device, the chunk behind a plain one ahead of its end: the text is that of one batch either way."""
+    db = synth.make_db(60_000)
+    qs = synth.make_queries(db, 70_000, seed=13)
+    L = db.length
+    rng = np.random.default_rng(14)
+    refs = db.seq_bytes.reshape(db.n, L)
+    queries = [(qs.labels[i], qs.bases[qs.base_off[i]:qs.base_off[i + 1]]) for i in range(len(qs.labels))]
+    for k, (at, nb) in enumerate(((100, 1500), (20_000, 3000), (36_000, 1200), (69_000, 5000))):   # chunks of 35 000: the first and the second hold long reads
+        s = np.concatenate([refs[int(i)] for i in rng.integers(0, db.n, nb // L + 1)])[:nb].copy()
+        queries.insert(at + k, (f"long{k}", s))
+    tree = rx.Tree.new_flat(db.lineages, db.seq_bytes, db.seq_off, kmer_map=False)
+    index = rx.Index(tree, device=0)
+    single = _lines(index, queries, 0)
+    for chunk in (35_000, 17_600):
+        assert _lines(index, queries, chunk) == single, chunk
+    assert len(single) == len(queries) and all(o for _, o, _ in single)

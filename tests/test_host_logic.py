@@ -320,3 +320,19 @@ def test_a_taxonomy_deeper_than_the_device_walk_is_refused_with_its_lineage():
     with pytest.raises(rx.RtxError) as e:
         rx.parse_reference_fasta_str(f">x;tax={deep};\nACGTACGTACGTACGTAAAA\n>y;tax=a,b;\nACGTACGTACGTACGTAAAC\n")
     assert e.value.code == -6
+
+
+def test_the_package_asks_for_hardware_queues_before_hip_can_initialise():
+    """raxtax_amd/__init__.py (and the library's own initialiser, csrc/host_threads.cpp): GPU_MAX_HW_QUEUES is exported -- without overwriting a value the
+    process came with -- so that the transfer streams of a handle do not share a hardware queue with its compute streams (RTX_OPT_RUN_AHEAD needs that)."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    ROOT = Path(__file__).resolve().parent.parent
+    env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
+    code = "import os, raxtax_amd; print(os.environ.get('GPU_MAX_HW_QUEUES'))"
+    assert subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, cwd=str(ROOT)).stdout.strip() == "8"
+    env["GPU_MAX_HW_QUEUES"] = "5"
+    assert subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, cwd=str(ROOT)).stdout.strip() == "5"
